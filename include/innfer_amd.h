@@ -1,0 +1,165 @@
+/*
+ * innfer_amd.h -- flat C ABI of the MI355X (gfx950) hot path for victorca25/iNNfer.
+ *
+ * Scope: generator forward (ESRGAN RRDBNet / SRResNet) +
+ * chop_forward tile extraction and overlap blend + uint8<->float pre/post.
+ * The reference has no FFI; each entry point below names the reference
+ * interface (file:line in victorca25/iNNfer) it replaces.  INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (INNFER_OK) or a negative innfer_status; no C++
+ *     exception crosses the boundary; innfer_last_error() gives the thread's
+ *     last message.
+ *   - pointers named d_* are device (HBM) pointers owned by the caller (e.g.
+ *     torch storages); h_* are host pointers.  `stream` is a hipStream_t passed
+ *     as void* (NULL = default stream).  Nothing synchronises the stream.
+ *   - activations inside the library are fp16 NHWC channel slabs, accumulated
+ *     in fp32 on MFMA; tensors at the boundary are NCHW like the reference's
+ *     torch tensors.
+ *   - handles are immutable after the last innfer_net_set_conv(); forward is
+ *     re-entrant across streams given distinct workspaces.
+ */
+#ifndef INNFER_AMD_H
+#define INNFER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    INNFER_OK = 0,
+    INNFER_ERR_INVALID = -1,     /* bad argument (the reference raises ValueError/AssertionError) */
+    INNFER_ERR_HIP = -2,         /* HIP runtime error */
+    INNFER_ERR_UNSUPPORTED = -3, /* valid for the reference, not built here (NotImplementedError) */
+    INNFER_ERR_NOMEM = -4,
+    INNFER_ERR_WORKSPACE = -5    /* workspace too small */
+} innfer_status;
+
+typedef enum { INNFER_F16 = 0, INNFER_F32 = 1 } innfer_dtype;
+
+typedef struct innfer_net* innfer_net_t;
+
+int innfer_version(void);
+const char* innfer_last_error(void);
+
+/* ------------------------------------------------------------------ networks
+ * Replaces architectures.get_network(opt_net) + nn.Module.forward
+ * (architectures/__init__.py:5-40, RRDBNet_arch.py:16-62, SRResNet_arch.py:15-91).
+ */
+
+/* RRDBNet (old-arch ESRGAN).  gc is the dense growth (32 in the reference,
+ * RRDBNet_arch.py:27); scale in {1,2,4,8}.  plus (ESRGAN+) -> UNSUPPORTED. */
+int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
+                          int gc, int scale, int plus);
+
+/* SRResNet / SRGAN with the reference defaults (norm none, ReLU, CNA,
+ * pixelshuffle, res_scale 1: utils/defaults.py:53-67). */
+int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale);
+
+void innfer_net_destroy(innfer_net_t net);
+
+/* Convolutions in forward order.  key is the state-dict prefix in the
+ * reference's naming ("model.1.sub.0.RDB1.conv1.0"); weights are
+ * key+".weight" [K,C,3,3] and key+".bias" [K]. */
+int innfer_net_num_convs(innfer_net_t net);
+int innfer_net_conv_info(innfer_net_t net, int idx, char* key, size_t key_cap, int* K, int* C);
+
+/* Replaces net.load_state_dict for one conv (run.py:93): host fp32 OIHW
+ * weights + bias are packed into the MFMA panel layout and uploaded.
+ * Synchronous (load time, not forward time). */
+int innfer_net_set_conv(innfer_net_t net, int idx, const float* h_weight_oihw, const float* h_bias);
+
+int innfer_net_scale(innfer_net_t net);
+size_t innfer_net_workspace_bytes(innfer_net_t net, int N, int H, int W);
+
+/* nn.Module.forward(x): d_in [N,in_nc,H,W] -> d_out [N,out_nc,s*H,s*W], NCHW,
+ * dtypes per innfer_dtype.  Replaces `self.model(data)` (run.py:187-189,217-219). */
+int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                       int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Scheduling knob: 0 = one launch per layer over the whole frame; R>0 = skewed
+ * row bands of R rows through the RRDB trunk (working set kept Infinity-Cache
+ * resident; identical results). */
+int innfer_net_set_band_rows(innfer_net_t net, int rows);
+
+/* Algorithmic FLOPs of one forward (2*MAC of every conv). */
+double innfer_net_flops(innfer_net_t net, int N, int H, int W);
+
+/* -------------------------------------------------- single fused convolution
+ * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution
+ * over an fp16 NHWC channel slab (conv_block, block.py:213-254).
+ *   out[.., out_ch_off + k] = epilogue(conv(in[.., 0:C]))
+ *   epilogue: +bias -> act -> (*res1_scale + res1) -> (*res2_scale + res2)
+ * act: 0 none, 1 LeakyReLU(0.2) (block.py:89-90), 2 ReLU.
+ * upsample2x: input is read through nearest-2x upsampling (block.py:321-322,358),
+ *   i.e. d_in is [N,H/2,W/2,*] while H,W are the conv's (output) size.
+ * d_packed comes from innfer_pack_conv3x3().  C % 32 == 0, K % 16 == 0, K <= 64.
+ */
+typedef struct {
+    const void* d_in;  int in_stride;   /* elements per pixel of the input slab */
+    int C;
+    const void* d_packed; const float* d_bias;
+    void* d_out; int out_stride; int out_ch_off; int K;
+    int N, H, W;
+    int act; int upsample2x;
+    const void* d_res1; int res1_stride; float res1_scale;
+    const void* d_res2; int res2_stride; float res2_scale;
+    int row_begin, row_end;             /* rows of the output to compute; 0,0 = all */
+} innfer_conv_args;
+
+size_t innfer_conv3x3_packed_bytes(int K, int C);
+int innfer_pack_conv3x3(const float* h_weight_oihw, int K, int C, void* h_packed);
+int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream);
+
+/* NCHW (f16/f32) <-> NHWC-slab f16 helpers used by tests of the single conv. */
+int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int slab_stride, int ch_off,
+                        int N, int C, int H, int W, void* stream);
+int innfer_slab_to_nchw(const void* d_slab, int slab_stride, int ch_off, void* d_dst, int dst_dtype,
+                        int N, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------ chop / blend
+ * Replaces extract_patches_2d / recompose_tensor (utils/utils.py:318-369,
+ * 372-445) as used by Model.chop_forward (run.py:167-202).
+ */
+
+/* Geometry only (host).  ps = min(H,W,patch); origins are the row-major tile
+ * lattice of stride int(ps*step) plus one ragged row/column anchored at H-ps /
+ * W-ps.  ys/xs may be NULL to query counts.  Capacity: nh<=H, nw<=W. */
+int innfer_chop_plan(int H, int W, int patch, double step, int* ps, int* nh, int* nw,
+                     int* ys, int* xs);
+
+/* d_img [B,C,H,W] -> d_tiles [nh*nw*?..]: tiles[(b? see below)]
+ * Output order matches extract_patches_2d(batch_first=True).squeeze(0) for B=1:
+ * d_tiles [n, C, ps, ps], n = nh*nw row-major.  tile_begin/tile_count select a
+ * contiguous sub-range (multi-GPU sharding). */
+int innfer_extract_tiles(const void* d_img, int dtype, int C, int H, int W, int patch, double step,
+                         int tile_begin, int tile_count, void* d_tiles, void* stream);
+
+/* 1-D blending profile (utils.py:396,413-416), host, fp32, length P. */
+int innfer_blend_profile(int P, double step, int scale, float* h_profile);
+
+/* recompose_tensor: d_tiles [n,C,P,P] (HR tiles, row-major over the tile
+ * lattice) -> d_out [1,C,scale*height,scale*width].  Accumulates in fp32 in
+ * the reference's (h,w) order: with fp32 tiles the result is bit-identical to
+ * the reference's fp32 path. */
+int innfer_recompose(const void* d_tiles, int dtype, int n, int C, int P, int height, int width,
+                     double step, int scale, void* d_out, int out_dtype, void* stream);
+
+/* --------------------------------------------------------------- pre / post
+ * np2tensor / tensor2np (utils/utils.py:164-194,197-248, colors.py:5-26):
+ * uint8 HWC BGR(A) <-> float NCHW RGB(A), /255, optional [-1,1] (de)normalise,
+ * clip*255 and round-half-to-even on the way back.
+ */
+int innfer_u8hwc_to_nchw(const uint8_t* d_img, int H, int W, int C, int normalize,
+                         void* d_out, int out_dtype, void* stream);
+int innfer_nchw_to_u8hwc(const void* d_in, int in_dtype, int H, int W, int C, int denormalize,
+                         uint8_t* d_img, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INNFER_AMD_H */

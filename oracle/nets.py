@@ -1,0 +1,133 @@
+"""Oracle network forwards (test infrastructure; see oracle/__init__.py).
+
+Functional restatements over a plain {key: tensor} state dict with the
+reference's key names.  All NCHW, computed in the dtype of the inputs
+(fp32 for parity; the reference's `-cpu` mode is always fp32, run.py:345).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _conv3(sd, key, x):
+    # conv_block -> nn.Conv2d(k=3, s=1, zero padding 1, bias)  (block.py:213-236,163-166)
+    return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=1, padding=1)
+
+
+def _lrelu(x):
+    # act('leakyrelu') -> nn.LeakyReLU(0.2)  (block.py:81-90)
+    return F.leaky_relu(x, 0.2)
+
+
+def rdb_forward(sd, prefix, x, plus=False):
+    """ResidualDenseBlock_5C.forward (RRDBNet_arch.py:152-165)."""
+    x1 = _lrelu(_conv3(sd, prefix + "conv1.0", x))
+    x2 = _lrelu(_conv3(sd, prefix + "conv2.0", torch.cat((x, x1), 1)))
+    if plus:
+        x2 = x2 + F.conv2d(x, sd[prefix + "conv1x1.weight"])          # :155-156
+    x3 = _lrelu(_conv3(sd, prefix + "conv3.0", torch.cat((x, x1, x2), 1)))
+    x4 = _lrelu(_conv3(sd, prefix + "conv4.0", torch.cat((x, x1, x2, x3), 1)))
+    if plus:
+        x4 = x4 + x2                                                   # :159-160
+    x5 = _conv3(sd, prefix + "conv5.0", torch.cat((x, x1, x2, x3, x4), 1))
+    return x5 * 0.2 + x                                                # :165
+
+
+def rrdb_forward(sd, prefix, x, plus=False):
+    """RRDB.forward (RRDBNet_arch.py:91-98)."""
+    out = x
+    for r in (1, 2, 3):
+        out = rdb_forward(sd, f"{prefix}RDB{r}.", out, plus)
+    return out * 0.2 + x
+
+
+def _n_upscale(scale):
+    # RRDBNet_arch.py:21-23 / SRResNet_arch.py:20-22
+    return 1 if scale == 3 else int(math.log(scale, 2))
+
+
+def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None):
+    """RRDBNet.forward with the flat Sequential of RRDBNet_arch.py:25-48.
+
+    taps: optional dict filled with named intermediates (golden G3 stages).
+    """
+    fea = _conv3(sd, "model.0", x)
+    if taps is not None:
+        taps["conv_first"] = fea
+    t = fea
+    for b in range(nb):
+        t = rrdb_forward(sd, f"model.1.sub.{b}.", t, plus)
+        if taps is not None and b == 0:
+            taps["rrdb0"] = t
+    t = _conv3(sd, f"model.1.sub.{nb}", t)
+    t = fea + t                                   # ShortcutBlock (block.py:189-191)
+    if taps is not None:
+        taps["trunk"] = t
+    idx = 2
+    for u in range(_n_upscale(scale)):
+        f = 3 if scale == 3 else 2
+        t = F.interpolate(t, scale_factor=float(f), mode="nearest")   # block.py:321-322,358
+        t = _lrelu(_conv3(sd, f"model.{idx + 1}", t))
+        if taps is not None:
+            taps[f"up{u}"] = t
+        idx += 3
+    t = _lrelu(_conv3(sd, f"model.{idx}", t))     # HR_conv0
+    return _conv3(sd, f"model.{idx + 2}", t)      # HR_conv1
+
+
+def srresnet_forward(sd, x, nb=16, scale=4):
+    """SRResNet.forward with defaults norm=None, act=relu, mode=CNA,
+    pixelshuffle, res_scale=1 (SRResNet_arch.py:15-91, defaults.py:53-67)."""
+    fea = _conv3(sd, "model.0", x)
+    t = fea
+    for b in range(nb):
+        r = F.relu(_conv3(sd, f"model.1.sub.{b}.res.0", t))
+        r = _conv3(sd, f"model.1.sub.{b}.res.2", r)
+        t = t + r * 1                              # :88-91 (res_scale = 1)
+    t = fea + _conv3(sd, f"model.1.sub.{nb}", t)
+    idx = 2
+    for _ in range(_n_upscale(scale)):
+        f = 3 if scale == 3 else 2
+        t = F.relu(F.pixel_shuffle(_conv3(sd, f"model.{idx}", t), f))  # block.py:333-346
+        idx += 3
+    t = F.relu(_conv3(sd, f"model.{idx}", t))
+    return _conv3(sd, f"model.{idx + 2}", t)
+
+
+def unet_forward(sd, x, num_downs=8, eps=1e-5):
+    """UnetGenerator(norm=batch, deconv).forward with BatchNorm in TRAINING mode
+    (batch statistics), as run.py runs pix2pix (meval=False, run.py:299-303).
+    UNet_arch.py:107-161.  x: [N,3,256,256]; BN statistics are over the batch
+    given (callers loop batch-1 for the per-image semantics of SURVEY D6)."""
+
+    def bn(t, key):
+        return F.batch_norm(t, None, None, sd[key + ".weight"], sd[key + ".bias"],
+                            training=True, momentum=0.0, eps=eps)
+
+    def block(t, prefix, depth):
+        outermost = depth == 0
+        innermost = depth == num_downs - 1
+        if outermost:
+            d = F.conv2d(t, sd[prefix + "model.0.weight"], None, stride=2, padding=1)
+            m = block(d, prefix + "model.1.", depth + 1)
+            u = F.conv_transpose2d(F.relu(m), sd[prefix + "model.3.weight"],
+                                   sd[prefix + "model.3.bias"], stride=2, padding=1)
+            return torch.tanh(u)
+        # nn.LeakyReLU(0.2, inplace=True) is the block's first layer (UNet_arch.py:109,
+        # 135,148): it rewrites the block input in place, so the skip branch of
+        # torch.cat([x, model(x)]) (:160-161) carries lrelu(x), not x.
+        t = F.leaky_relu(t, 0.2)
+        if innermost:
+            d = F.conv2d(t, sd[prefix + "model.1.weight"], None, stride=2, padding=1)
+            u = F.conv_transpose2d(F.relu(d), sd[prefix + "model.3.weight"], None, stride=2, padding=1)
+            u = bn(u, prefix + "model.4")
+            return torch.cat([t, u], 1)
+        d = F.conv2d(t, sd[prefix + "model.1.weight"], None, stride=2, padding=1)
+        d = bn(d, prefix + "model.2")
+        m = block(d, prefix + "model.3.", depth + 1)
+        u = F.conv_transpose2d(F.relu(m), sd[prefix + "model.5.weight"], None, stride=2, padding=1)
+        u = bn(u, prefix + "model.6")
+        return torch.cat([t, u], 1)
+
+    return block(x, "model.", 0)

@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the REFERENCE (victorca25/iNNfer) itself.
+
+Runs only in the build container, where /root/reference is mounted; the GPU box
+never sees the reference.  `cv2` is absent, so an empty stub module is injected
+before `utils.utils` is imported -- no cv2-dependent function is
+called.  Weights/images come from innfer_amd.synth (integer hash), loaded into
+the reference's own nn.Modules with load_state_dict(strict=True).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Fixtures hold inputs' seeds/shapes and expected OUTPUTS only (data, not code).
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("INNFER_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+
+from innfer_amd import synth  # noqa: E402
+import run as ref_run  # noqa: E402  (reference run.py)
+from utils import utils as ref_utils  # noqa: E402
+from utils import colors as ref_colors  # noqa: E402
+from utils.defaults import get_network_G_config  # noqa: E402
+from architectures import get_network  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def t_sd(sd_np):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def ref_net(kind, scale, **kw):
+    d = dict(type=kind, **kw)
+    return get_network(get_network_G_config(d, scale))
+
+
+def rrdb_ref(nb, scale, seed=0, plus=False):
+    sd = synth.fill_state_dict(synth.rrdbnet_shapes(nb=nb, scale=scale, plus=plus), seed)
+    net = ref_net("esrgan", scale, nb=nb, plus=plus)
+    net.load_state_dict(t_sd(sd), strict=True)
+    return net.eval(), sd
+
+
+# ---------------------------------------------------------------- G1 geometry
+def g1():
+    out = {}
+    for (h, w) in [(128, 128), (200, 200), (250, 330), (1080, 1920), (2160, 3840),
+                   (4320, 7680), (201, 640), (150, 250), (540, 960), (400, 400)]:
+        ps = min(h, w, 200)
+        yy = torch.arange(h, dtype=torch.int16)[:, None].expand(h, w)
+        xx = torch.arange(w, dtype=torch.int16)[None, :].expand(h, w)
+        img = torch.stack([yy, xx], 0)[None].contiguous()
+        p = ref_utils.extract_patches_2d(img, (ps, ps), [0.5, 0.5], batch_first=True).squeeze(0)
+        org = p[:, :, 0, 0].numpy().astype(np.int32)          # [n, 2] (y, x)
+        assert int(p[0].shape[-1]) == ps
+        out[f"org_{h}x{w}"] = org
+    save("g1_geometry", **out)
+
+
+# ------------------------------------------------------------------- G2 blend
+def g2():
+    out = {}
+    for P, scale in [(800, 4), (200, 1), (512, 2), (400, 2), (600, 4), (150, 1)]:
+        step = 0.5
+        overlap = scale * int(round((1.0 - step) * (P / scale)))
+        prof = torch.cat([torch.linspace(0.1, 1.0, overlap), torch.ones(P - 2 * overlap),
+                          torch.linspace(1.0, 0.1, overlap)], 0)
+        out[f"profile_P{P}_s{scale}"] = prof.numpy()
+    for scale in (1, 2, 4):
+        h, w = 250, 330
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), 100 + scale))
+        p = ref_utils.extract_patches_2d(x, (200, 200), [0.5, 0.5], batch_first=True).squeeze(0)
+        up = torch.nn.functional.interpolate(p, scale_factor=float(scale), mode="nearest") if scale > 1 else p
+        # perturb tiles so that the blend is not an identity: tile k scaled by (1 + k/16)
+        k = torch.arange(up.shape[0], dtype=torch.float32)[:, None, None, None]
+        tiles = up * (1.0 + k / 16.0)
+        r = ref_utils.recompose_tensor(tiles, h, w, step=0.5, scale=scale)
+        out[f"blend_s{scale}_sub"] = r[0, :, ::7, ::5].numpy()
+        out[f"blend_s{scale}_sum"] = np.float64(r.double().sum().item())
+        r_id = ref_utils.recompose_tensor(up, h, w, step=0.5, scale=scale)
+        ref_id = torch.nn.functional.interpolate(x, scale_factor=float(scale), mode="nearest") if scale > 1 else x
+        out[f"ident_s{scale}_maxerr"] = np.float64((r_id - ref_id).abs().max().item())
+    # small-image case (patch = min(H,W) < 200, even)
+    h, w = 150, 250
+    x = torch.from_numpy(synth.uniform((1, 3, h, w), 77))
+    p = ref_utils.extract_patches_2d(x, (150, 150), [0.5, 0.5], batch_first=True).squeeze(0)
+    k = torch.arange(p.shape[0], dtype=torch.float32)[:, None, None, None]
+    r = ref_utils.recompose_tensor(p * (1.0 + k / 16.0), h, w, step=0.5, scale=1)
+    out["blend_150x250"] = r[0].numpy()
+    save("g2_blend", **out)
+
+
+# ------------------------------------------------------- G3/G11 RRDBNet-23 4x
+def g3():
+    net, _ = rrdb_ref(23, 4)
+    x = torch.from_numpy(synth.uniform((1, 3, 32, 32), 3))
+    with torch.no_grad():
+        y = net(x)
+    out = {"out_32": y.numpy()}
+    x16 = torch.from_numpy(synth.uniform((1, 3, 16, 16), 4))
+    taps = {}
+    m = net.model
+    hooks = [m[0].register_forward_hook(lambda _m, _i, o: taps.__setitem__("conv_first", o.detach().numpy())),
+             m[1].sub[0].register_forward_hook(lambda _m, _i, o: taps.__setitem__("rrdb0", o.detach().numpy())),
+             m[1].sub[0].RDB1.register_forward_hook(lambda _m, _i, o: taps.__setitem__("rdb0", o.detach().numpy())),
+             m[1].register_forward_hook(lambda _m, _i, o: taps.__setitem__("trunk", o.detach().numpy())),
+             m[4].register_forward_hook(lambda _m, _i, o: taps.__setitem__("up0", o.detach().numpy())),
+             m[7].register_forward_hook(lambda _m, _i, o: taps.__setitem__("up1", o.detach().numpy()))]
+    with torch.no_grad():
+        y16 = net(x16)
+    for h in hooks:
+        h.remove()
+    out["out_16"] = y16.numpy()
+    for k, v in taps.items():
+        out["tap16_" + k] = v
+    save("g3_rrdbnet23_x4", **out)
+    # G11: the reference's fp16 mode restated on CPU (net.half(), input.half())
+    neth = net.half()
+    with torch.no_grad():
+        yh = neth(x.half())
+        yh16 = neth(x16.half())
+    save("g11_rrdbnet23_x4_fp16", out_32=yh.float().numpy(), out_16=yh16.float().numpy())
+
+
+# ------------------------------------------- G4 chop through Model.__call__
+def g4():
+    tmp = tempfile.mkdtemp()
+    out = {}
+    for (nb, scale, h, w, tag) in [(2, 4, 250, 330, "x4_250x330"), (1, 2, 201, 640, "x2_201x640"),
+                                   (1, 1, 150, 250, "x1_150x250")]:
+        sd = synth.fill_state_dict(synth.rrdbnet_shapes(nb=nb, scale=scale), 0)
+        path = os.path.join(tmp, f"{scale}x_synth_{tag}.pth")
+        torch.save(t_sd(sd), path)
+        mdl = ref_run.Model(path, arch="infer", scale=None, device="cpu", chop=True)
+        assert mdl.scale == scale and mdl.arch == "esrgan"
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), 40 + scale))
+        y = mdl(x)
+        out[f"chop_{tag}_sub"] = y[0, :, ::8, ::8].numpy()
+        out[f"chop_{tag}_sum"] = np.float64(y.double().sum().item())
+        # crops across seams (tile origins are multiples of 100*scale / ragged)
+        s = scale
+        out[f"chop_{tag}_crop_a"] = y[0, :, 100 * s - 16:100 * s + 16, 100 * s - 16:100 * s + 16].numpy() \
+            if h > 216 else y[0, :, :32, :32].numpy()
+        out[f"chop_{tag}_crop_b"] = y[0, :, -32:, -32:].numpy()
+        mdl2 = ref_run.Model(path, arch="infer", scale=None, device="cpu", chop=False)
+        y2 = mdl2(x)
+        out[f"nochop_{tag}_sub"] = y2[0, :, ::8, ::8].numpy()
+    save("g4_chop", **out)
+
+
+# --------------------------------------------------------- G5 scale variants
+def g5():
+    out = {}
+    x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 5))
+    for scale in (1, 2, 8):
+        net, _ = rrdb_ref(1, scale)
+        with torch.no_grad():
+            out[f"out_x{scale}"] = net(x).numpy()
+    net, _ = rrdb_ref(1, 4, plus=True)
+    with torch.no_grad():
+        out["out_x4_plus"] = net(x).numpy()
+    save("g5_scales", **out)
+
+
+# ------------------------------------------------------------------ G6 SRGAN
+def g6():
+    sd = synth.fill_state_dict(synth.srresnet_shapes(nb=16, scale=4), 0)
+    net = ref_net("srgan", 4)
+    net.load_state_dict(t_sd(sd), strict=True)
+    net.eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 24, 24), 6))
+    with torch.no_grad():
+        y = net(x)
+    ps_in = torch.arange(1 * 8 * 3 * 5, dtype=torch.float32).reshape(1, 8, 3, 5)
+    save("g6_srgan", out_24=y.numpy(), ps_in=ps_in.numpy(),
+         ps_out=torch.nn.PixelShuffle(2)(ps_in).numpy())
+
+
+# ------------------------------------------------------------------- G7 UNet
+def g7():
+    net = ref_net("unet_256", 1)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, 0)
+    net.load_state_dict(t_sd(sd), strict=True)
+    net.train()                                          # meval=False (run.py:299-303,98-99)
+    xa = torch.from_numpy(synth.uniform((1, 3, 256, 256), 7, -1.0, 1.0))
+    with torch.no_grad():
+        ya = net(xa)
+    keys = np.array(sorted(shapes.keys()))
+    save("g7_unet256", out_a=ya.numpy().astype(np.float16), out_a_sub=ya[0, :, ::4, ::4].numpy(),
+         keys=keys, shapes=np.array([str(shapes[k]) for k in keys]))
+
+
+# ---------------------------------------------------------------- G9 convert
+def g9():
+    ramp = (np.arange(5 * 7 * 3) * 37 % 256).astype(np.uint8).reshape(5, 7, 3)
+    t0 = ref_utils.np2tensor(ramp, normalize=False)
+    t1 = ref_utils.np2tensor(ramp, normalize=True)
+    # values that land exactly on .5 after *255 (0.5/255 -> 0, 1.5/255 -> 2, ...)
+    halves = torch.tensor([(k + 0.5) / 255.0 for k in range(0, 12)] + [-0.1, 1.2, 0.999, 0.5],
+                          dtype=torch.float32)
+    th = halves.reshape(1, 1, 4, 4).repeat(1, 3, 1, 1).contiguous()
+    th[0, 1] += 1.0 / 1024
+    th[0, 2] -= 1.0 / 1024
+    u0 = ref_utils.tensor2np(th, denormalize=False)
+    u1 = ref_utils.tensor2np(th * 2 - 1, denormalize=True)
+    big = torch.from_numpy(synth.uniform((1, 3, 33, 47), 9, -0.2, 1.2))
+    lin = ref_colors.srgb2linear(np.arange(256, dtype=np.uint8))
+    back = ref_colors.linear2srgb(np.linspace(-0.1, 1.1, 1001, dtype=np.float32))
+    save("g9_convert", ramp=ramp, np2t=t0.numpy(), np2t_norm=t1.numpy(), t2np_in=th.numpy(),
+         t2np=u0, t2np_denorm=u1, big_in=big.numpy(), big_u8=ref_utils.tensor2np(big),
+         srgb2linear=lin, linear2srgb=back)
+
+
+# ----------------------------------------------------------------- G10 loader
+def g10():
+    tmp = tempfile.mkdtemp()
+    rows = []
+
+    def probe(sd, name):
+        path = os.path.join(tmp, name)
+        torch.save(t_sd(sd), path)
+        m = ref_run.Model(path, arch="infer", scale=None, device="cpu", chop=False)
+        net = m.model
+        first = net.model[0]
+        nb = len(net.model[1].sub) - 1
+        rows.append((name, m.arch, m.scale, first.out_channels, nb, m.in_nc, m.out_nc,
+                     sorted(net.state_dict().keys())))
+
+    for scale in (1, 2, 4, 8):
+        probe(synth.fill_state_dict(synth.rrdbnet_shapes(nb=2, scale=scale, nf=48, in_nc=3, out_nc=3), 0),
+              f"{scale}x_old.pth")
+    probe(synth.fill_state_dict(synth.rrdbnet_shapes(nb=1, scale=4, in_nc=1, out_nc=1), 0), "4x_gray.pth")
+    probe(synth.fill_state_dict(synth.rrdbnet_shapes(nb=1, scale=4, plus=True), 0), "4x_plus.pth")
+    probe(synth.fill_state_dict(synth.srresnet_shapes(nb=3, scale=4), 0), "4x_srgan.pth")
+    # new-arch (MRRDBNet key names) 23-block model -> mod2normal -> old arch
+    old = synth.fill_state_dict(synth.rrdbnet_shapes(nb=23, scale=4, nf=16), 0)
+    new = ref_utils.normal2mod(dict(old))
+    probe(new, "4x_newarch.pth")
+    new_keys = sorted(new.keys())
+    # SWA-wrapped
+    swa = {"n_averaged": np.asarray(3, dtype=np.int64)}
+    small = synth.fill_state_dict(synth.rrdbnet_shapes(nb=1, scale=2), 0)
+    for k, v in small.items():
+        swa["module.module." + k] = v
+    probe(swa, "2x_swa.pth")
+    save("g10_loader",
+         names=np.array([r[0] for r in rows]), arch=np.array([r[1] for r in rows]),
+         scale=np.array([r[2] for r in rows]), nf=np.array([r[3] for r in rows]),
+         nb=np.array([r[4] for r in rows]), in_nc=np.array([r[5] for r in rows]),
+         out_nc=np.array([r[6] for r in rows]),
+         keys=np.array(["|".join(r[7]) for r in rows]),
+         newarch_keys=np.array(new_keys))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10"]
+    for g in which:
+        globals()[g]()

@@ -1,0 +1,136 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import tiles as otiles
+from innfer_amd import synth
+
+
+def _sd(shapes, seed=0):
+    return {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed).items()}
+
+
+def test_g1_geometry(golden):
+    g = golden("g1_geometry")
+    for key in g.files:
+        h, w = map(int, key[4:].split("x"))
+        ps, ys, xs = oracle.chop_geometry(h, w)
+        org = np.array([(y, x) for y in ys for x in xs], dtype=np.int32)
+        assert np.array_equal(org, g[key]), key
+    ps, ys, xs = oracle.chop_geometry(250, 330)
+    assert [(y, x) for y in ys for x in xs] == [(0, 0), (0, 100), (0, 130), (50, 0), (50, 100), (50, 130)]
+    for (h, w, n) in [(1080, 1920, 190), (2160, 3840, 798), (4320, 7680, 3268), (128, 128, 1)]:
+        _, ys, xs = oracle.chop_geometry(h, w)
+        assert len(ys) * len(xs) == n
+
+
+def test_g2_blend(golden):
+    g = golden("g2_blend")
+    for key in g.files:
+        if key.startswith("profile_"):
+            P, s = key[8:].split("_")
+            prof = oracle.blend_profile(int(P[1:]), 0.5, int(s[1:]))
+            assert np.array_equal(prof.numpy(), g[key]), key
+    for scale in (1, 2, 4):
+        h, w = 250, 330
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), 100 + scale))
+        p = oracle.extract_patches_2d(x, (200, 200), [0.5, 0.5], batch_first=True).squeeze(0)
+        up = torch.nn.functional.interpolate(p, scale_factor=float(scale), mode="nearest") if scale > 1 else p
+        k = torch.arange(up.shape[0], dtype=torch.float32)[:, None, None, None]
+        r = oracle.recompose_tensor(up * (1.0 + k / 16.0), h, w, step=0.5, scale=scale)
+        assert np.array_equal(r[0, :, ::7, ::5].numpy(), g[f"blend_s{scale}_sub"])      # bit-exact
+        assert r.double().sum().item() == g[f"blend_s{scale}_sum"]
+        r_id = oracle.recompose_tensor(up, h, w, step=0.5, scale=scale)
+        ref = torch.nn.functional.interpolate(x, scale_factor=float(scale), mode="nearest") if scale > 1 else x
+        assert (r_id - ref).abs().max().item() <= 3e-7
+    x = torch.from_numpy(synth.uniform((1, 3, 150, 250), 77))
+    p = oracle.extract_patches_2d(x, (150, 150), [0.5, 0.5], batch_first=True).squeeze(0)
+    k = torch.arange(p.shape[0], dtype=torch.float32)[:, None, None, None]
+    r = oracle.recompose_tensor(p * (1.0 + k / 16.0), 150, 250, step=0.5, scale=1)
+    assert np.array_equal(r[0].numpy(), g["blend_150x250"])
+
+
+def test_g3_rrdbnet23(golden):
+    g = golden("g3_rrdbnet23_x4")
+    sd = _sd(synth.rrdbnet_shapes(nb=23, scale=4))
+    with torch.no_grad():
+        x16 = torch.from_numpy(synth.uniform((1, 3, 16, 16), 4))
+        taps = {}
+        y16 = oracle.rrdbnet_forward(sd, x16, nb=23, scale=4, taps=taps)
+        np.testing.assert_allclose(y16.numpy(), g["out_16"], atol=2e-6, rtol=0)
+        for k in ("conv_first", "rrdb0", "trunk", "up0", "up1"):
+            np.testing.assert_allclose(taps[k].numpy(), g["tap16_" + k], atol=2e-6, rtol=0, err_msg=k)
+        x = torch.from_numpy(synth.uniform((1, 3, 32, 32), 3))
+        y = oracle.rrdbnet_forward(sd, x, nb=23, scale=4)
+        np.testing.assert_allclose(y.numpy(), g["out_32"], atol=2e-6, rtol=0)
+        rdb = oracle.rdb_forward(sd, "model.1.sub.0.RDB1.", taps["conv_first"])
+        np.testing.assert_allclose(rdb.numpy(), g["tap16_rdb0"], atol=2e-6, rtol=0)
+
+
+def test_g4_chop(golden):
+    g = golden("g4_chop")
+    for (nb, scale, h, w, tag) in [(2, 4, 250, 330, "x4_250x330"), (1, 2, 201, 640, "x2_201x640"),
+                                   (1, 1, 150, 250, "x1_150x250")]:
+        sd = _sd(synth.rrdbnet_shapes(nb=nb, scale=scale))
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), 40 + scale))
+        with torch.no_grad():
+            fn = lambda t: oracle.rrdbnet_forward(sd, t, nb=nb, scale=scale)
+            y = oracle.chop_forward(fn, x, scale)
+            y2 = fn(x)
+        np.testing.assert_allclose(y[0, :, ::8, ::8].numpy(), g[f"chop_{tag}_sub"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(y[0, :, -32:, -32:].numpy(), g[f"chop_{tag}_crop_b"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(y2[0, :, ::8, ::8].numpy(), g[f"nochop_{tag}_sub"], atol=2e-6, rtol=0)
+        assert abs(y.double().sum().item() - g[f"chop_{tag}_sum"]) < 1e-2 * max(1, abs(g[f"chop_{tag}_sum"]) * 1e-4)
+
+
+def test_g5_scales(golden):
+    g = golden("g5_scales")
+    x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 5))
+    with torch.no_grad():
+        for scale in (1, 2, 8):
+            sd = _sd(synth.rrdbnet_shapes(nb=1, scale=scale))
+            y = oracle.rrdbnet_forward(sd, x, nb=1, scale=scale)
+            np.testing.assert_allclose(y.numpy(), g[f"out_x{scale}"], atol=2e-6, rtol=0)
+        sd = _sd(synth.rrdbnet_shapes(nb=1, scale=4, plus=True))
+        y = oracle.rrdbnet_forward(sd, x, nb=1, scale=4, plus=True)
+        np.testing.assert_allclose(y.numpy(), g["out_x4_plus"], atol=2e-6, rtol=0)
+
+
+def test_g6_srgan(golden):
+    g = golden("g6_srgan")
+    sd = _sd(synth.srresnet_shapes(nb=16, scale=4))
+    x = torch.from_numpy(synth.uniform((1, 3, 24, 24), 6))
+    with torch.no_grad():
+        y = oracle.srresnet_forward(sd, x, nb=16, scale=4)
+    np.testing.assert_allclose(y.numpy(), g["out_24"], atol=2e-6, rtol=0)
+    ps = torch.nn.functional.pixel_shuffle(torch.from_numpy(g["ps_in"]), 2)
+    assert np.array_equal(ps.numpy(), g["ps_out"])
+
+
+def test_g7_unet(golden):
+    g = golden("g7_unet256")
+    import ast
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = _sd(shapes)
+    x = torch.from_numpy(synth.uniform((1, 3, 256, 256), 7, -1.0, 1.0))
+    with torch.no_grad():
+        y = oracle.unet_forward(sd, x)
+    np.testing.assert_allclose(y[0, :, ::4, ::4].numpy(), g["out_a_sub"], atol=2e-5, rtol=0)
+
+
+def test_g9_convert(golden):
+    g = golden("g9_convert")
+    assert np.array_equal(oracle.np2tensor(g["ramp"]).numpy(), g["np2t"])
+    assert np.array_equal(oracle.np2tensor(g["ramp"], normalize=True).numpy(), g["np2t_norm"])
+    th = torch.from_numpy(g["t2np_in"])
+    assert np.array_equal(oracle.tensor2np(th), g["t2np"])
+    assert np.array_equal(oracle.tensor2np(th * 2 - 1, denormalize=True), g["t2np_denorm"])
+    assert np.array_equal(oracle.tensor2np(torch.from_numpy(g["big_in"])), g["big_u8"])
+    assert np.array_equal(oracle.srgb2linear(np.arange(256, dtype=np.uint8)), g["srgb2linear"])
+    assert np.array_equal(oracle.linear2srgb(np.linspace(-0.1, 1.1, 1001, dtype=np.float32)), g["linear2srgb"])
+    # round trip is exact for uint8
+    img = synth.image_u8(33, 47, 3, 1)
+    assert np.array_equal(oracle.tensor2np(oracle.np2tensor(img)), img)
