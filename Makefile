@@ -1,0 +1,23 @@
+# Build the gfx950 HIP library in-tree (the .so travels to the GPU box with the snapshot).
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+SRC   := innfer_amd/csrc/conv3x3.hip innfer_amd/csrc/conv_first.hip innfer_amd/csrc/tiles.hip innfer_amd/csrc/net.hip
+OBJ   := $(SRC:.hip=.o)
+LIB   := innfer_amd/lib/libinnfer_amd.so
+FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function
+
+all: $(LIB)
+
+innfer_amd/csrc/tiles.o: FLAGS += -ffp-contract=off
+
+%.o: %.hip innfer_amd/csrc/common.h include/innfer_amd.h
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+$(LIB): $(OBJ)
+	@mkdir -p innfer_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+
+clean:
+	rm -f $(OBJ) $(LIB)
+
+.PHONY: all clean

@@ -81,6 +81,14 @@ size_t innfer_net_workspace_bytes(innfer_net_t net, int N, int H, int W);
 int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                        int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Same forward with a HIP-event pair around every kernel launch (on `stream`), then a
+ * stream synchronise.  Fills up to `cap` entries: elapsed ms, algorithmic FLOPs and kernel
+ * kind (0 = first conv on VALU; 16*NT + out_mode = conv3x3_mfma instantiation with NT
+ * 16-channel output tiles).  Used by bench.py for the roofline object. */
+int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                             int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream,
+                             int cap, float* h_ms, double* h_flops, int* h_kind, int* n_launches);
+
 /* Scheduling knob: 0 = one launch per layer over the whole frame; R>0 = skewed
  * row bands of R rows through the RRDB trunk (working set kept Infinity-Cache
  * resident; identical results). */

@@ -1,0 +1,22 @@
+"""Generator factory: string -> nn.Module, mirror of the reference's
+architectures.get_network (architectures/__init__.py:5-40) for the hot-path
+families.  Modules are imported lazily so that `architectures.keys` stays
+importable without torch or the HIP library."""
+
+
+def get_network(opt_net):
+    """Instantiate a generator from a config dict made by
+    utils.defaults.get_network_G_config (same contract as the reference:
+    'type' is popped, the rest are constructor keyword arguments)."""
+    kind = opt_net.pop('type').lower()
+    if kind == 'rrdb_net':
+        from .RRDBNet_arch import RRDBNet as net
+    elif kind == 'sr_resnet':
+        from .SRResNet_arch import SRResNet as net
+    elif kind in ('mrrdb_net', 'ppon', 'pan_net', 'unet_net', 'resnet_net', 'wbcunet_net'):
+        raise NotImplementedError(
+            f'Model [{kind}] exists in the reference but is outside the MI355X hot path built so far '
+            '(SURVEY.md section 8: ESRGAN RRDBNet and SRResNet first)')
+    else:
+        raise NotImplementedError('Model [{:s}] not recognized'.format(kind))
+    return net(**opt_net)

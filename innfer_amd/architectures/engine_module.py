@@ -1,0 +1,108 @@
+"""nn.Module shell whose parameters carry the reference's state-dict keys and whose
+forward runs entirely in libinnfer_amd.so (HIP, gfx950).
+
+PyTorch here is plumbing: parameter storage, load_state_dict(strict=True), device
+memory for input / output / workspace and the current HIP stream.  No arithmetic
+of the forward pass is executed by torch.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import lib as L
+
+
+class _Node(nn.Module):
+    """Anonymous container used to spell dotted key paths ("model.1.sub.0...")."""
+
+
+class EngineModule(nn.Module):
+    def __init__(self, shapes):
+        super().__init__()
+        for key, shape in shapes.items():
+            *path, leaf = key.split('.')
+            node = self
+            for name in path:
+                if name not in node._modules:
+                    node.add_module(name, _Node())
+                node = node._modules[name]
+            node.register_parameter(leaf, nn.Parameter(torch.zeros(*shape), requires_grad=False))
+        self._handle = None
+        self._uploaded_version = None
+        self._ws = None
+        self.band_rows = 0
+
+    # ---- subclasses provide the C handle ------------------------------------
+    def _create_handle(self):
+        raise NotImplementedError
+
+    # ---- weight upload (load time, not forward time) -------------------------
+    def _weights_version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _ensure_engine(self):
+        ver = self._weights_version()
+        if self._handle is not None and ver == self._uploaded_version:
+            return
+        if self._handle is None:
+            self._handle = self._create_handle()
+        sd = self.state_dict()
+        n = L.lib.innfer_net_num_convs(self._handle)
+        key = C.create_string_buffer(128)
+        K, Cc = C.c_int(), C.c_int()
+        for i in range(n):
+            L.check(L.lib.innfer_net_conv_info(self._handle, i, key, 128, C.byref(K), C.byref(Cc)))
+            k = key.value.decode()
+            w = np.ascontiguousarray(sd[k + '.weight'].detach().float().cpu().numpy())
+            if w.shape[:2] != (K.value, Cc.value):
+                raise RuntimeError(f'size mismatch for {k}.weight: {tuple(w.shape)} vs engine ({K.value},{Cc.value},3,3)')
+            b = sd.get(k + '.bias')
+            bp = None
+            if b is not None:
+                b = np.ascontiguousarray(b.detach().float().cpu().numpy())
+                bp = b.ctypes.data
+            L.check(L.lib.innfer_net_set_conv(self._handle, i, w.ctypes.data, bp))
+        self._uploaded_version = ver
+
+    def __del__(self):
+        h = getattr(self, '_handle', None)
+        if h is not None:
+            try:
+                L.lib.innfer_net_destroy(h)
+            except Exception:
+                pass
+
+    # ---- forward ---------------------------------------------------------------
+    def forward(self, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise ValueError('expected a 4D [N,C,H,W] tensor')
+        if not x.is_cuda:
+            raise RuntimeError(
+                'innfer_amd runs its forward on an MI355X only: there is no CPU path '
+                '(the CPU restatement lives in oracle/ and is test infrastructure).')
+        if x.dtype not in (torch.float16, torch.float32):
+            raise TypeError(f'unsupported dtype {x.dtype}')
+        self._ensure_engine()
+        L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        s = L.lib.innfer_net_scale(self._handle)
+        out = torch.empty((N, self.out_nc, H * s, W * s), dtype=x.dtype, device=x.device)
+        need = L.lib.innfer_net_workspace_bytes(self._handle, N, H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        dt = L.F16 if x.dtype == torch.float16 else L.F32
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        L.check(L.lib.innfer_net_forward(self._handle, x.data_ptr(), dt, out.data_ptr(), dt, N, H, W,
+                                         self._ws.data_ptr(), self._ws.numel(), stream))
+        return out
+
+    def release_workspace(self):
+        self._ws = None
+
+    def flops(self, N, H, W):
+        self._ensure_engine()
+        return L.lib.innfer_net_flops(self._handle, N, H, W)

@@ -1,0 +1,59 @@
+"""State-dict key -> shape tables of the reference generators (host logic, no torch).
+
+The nn.Module shells in this package are built FROM these tables, so their
+state_dict() keys are the reference's by construction and model-database .pth
+files load with strict=True.
+"""
+
+
+def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False):
+    """State-dict key -> shape of the reference's old-arch ESRGAN
+    (reference RRDBNet_arch.py:16-48; key layout SURVEY.md 3.3)."""
+    import math
+    s = {"model.0.weight": (nf, in_nc, 3, 3), "model.0.bias": (nf,)}
+    for b in range(nb):
+        for r in (1, 2, 3):
+            p = f"model.1.sub.{b}.RDB{r}."
+            if plus:
+                s[p + "conv1x1.weight"] = (gc, nf, 1, 1)
+            for i in range(1, 6):
+                cin = nf + (i - 1) * gc
+                cout = gc if i < 5 else nf
+                s[p + f"conv{i}.0.weight"] = (cout, cin, 3, 3)
+                s[p + f"conv{i}.0.bias"] = (cout,)
+    s[f"model.1.sub.{nb}.weight"] = (nf, nf, 3, 3)
+    s[f"model.1.sub.{nb}.bias"] = (nf,)
+    n_up = 1 if scale == 3 else int(math.log(scale, 2))
+    idx = 2
+    for _ in range(n_up):
+        s[f"model.{idx + 1}.weight"] = (nf, nf, 3, 3)
+        s[f"model.{idx + 1}.bias"] = (nf,)
+        idx += 3
+    s[f"model.{idx}.weight"] = (nf, nf, 3, 3)
+    s[f"model.{idx}.bias"] = (nf,)
+    s[f"model.{idx + 2}.weight"] = (out_nc, nf, 3, 3)
+    s[f"model.{idx + 2}.bias"] = (out_nc,)
+    return s
+
+
+def srresnet_shapes(in_nc=3, out_nc=3, nf=64, nb=16, scale=4):
+    """SRGAN/SRResNet keys (reference SRResNet_arch.py:15-46, defaults.py:53-67)."""
+    import math
+    s = {"model.0.weight": (nf, in_nc, 3, 3), "model.0.bias": (nf,)}
+    for b in range(nb):
+        for j in (0, 2):
+            s[f"model.1.sub.{b}.res.{j}.weight"] = (nf, nf, 3, 3)
+            s[f"model.1.sub.{b}.res.{j}.bias"] = (nf,)
+    s[f"model.1.sub.{nb}.weight"] = (nf, nf, 3, 3)
+    s[f"model.1.sub.{nb}.bias"] = (nf,)
+    n_up = 1 if scale == 3 else int(math.log(scale, 2))
+    idx = 2
+    for _ in range(n_up):
+        s[f"model.{idx}.weight"] = (nf * 4, nf, 3, 3)
+        s[f"model.{idx}.bias"] = (nf * 4,)
+        idx += 3
+    s[f"model.{idx}.weight"] = (nf, nf, 3, 3)
+    s[f"model.{idx}.bias"] = (nf,)
+    s[f"model.{idx + 2}.weight"] = (out_nc, nf, 3, 3)
+    s[f"model.{idx + 2}.bias"] = (out_nc,)
+    return s

@@ -1,0 +1,66 @@
+// Shared declarations of the innfer_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/innfer_amd.h"
+
+namespace innfer {
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int set_error(int code, const char* fmt, ...);
+
+#define INNFER_HIP(expr)                                                              \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess)                                                         \
+            return innfer::set_error(INNFER_ERR_HIP, "%s failed: %s (%s:%d)", #expr,  \
+                                     hipGetErrorString(_e), __FILE__, __LINE__);      \
+    } while (0)
+
+// ---- 3x3 convolution on fp16 NHWC slabs (conv3x3.hip) -----------------------
+enum OutMode { OUT_SLAB = 0, OUT_NCHW = 1, OUT_SHUFFLE2 = 2 };
+
+struct ConvLaunch {
+    const f16* in; int in_stride; int C;          // C % 32 == 0
+    const f16* wpk; const float* bias;            // packed panels for KG*16*NT channels
+    void* out; int out_stride;                    // OUT_SLAB: f16 slab (channel offset folded in)
+    int K;                                        // valid output channels
+    int N, H, W;                                  // conv (output) size
+    int act; int up;                              // act: 0/1/2 ; up: input read through nearest 2x
+    const f16* res1; int res1_stride; float s1;
+    const f16* res2; int res2_stride; float s2;
+    int y0, y1;                                   // output rows [y0,y1)
+    int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
+    void* out2; int out2_stride;                  // optional second slab destination (OUT_SLAB)
+};
+
+// Panel geometry of packed weights.
+int conv_nt_for(int K);                           // 16-channel tiles per group: 1, 2 or 4
+size_t conv_packed_bytes(int K, int C);
+void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
+int conv_launch(const ConvLaunch& L, hipStream_t s);
+
+// ---- first conv: few input channels, NCHW input (conv_first.hip) -------------
+struct FirstConvLaunch {
+    const void* in; int in_f32; int Cin;          // NCHW planar input
+    const float* w;                               // [Cin*9][K] fp32 (k-major), device
+    const float* bias;
+    f16* out; int out_stride; f16* out2; int out2_stride;
+    int K; int N, H, W; int act;
+};
+int first_conv_launch(const FirstConvLaunch& L, hipStream_t s);
+
+// ---- layout / tiles / blend / pre-post (tiles.hip) ---------------------------
+int nchw_to_slab(const void* src, int src_f32, f16* slab, int stride, int N, int C, int H, int W, hipStream_t s);
+int slab_to_nchw(const f16* slab, int stride, void* dst, int dst_f32, int N, int C, int H, int W, hipStream_t s);
+
+}  // namespace innfer

@@ -1,0 +1,354 @@
+// 3x3 stride-1 zero-pad-1 convolution as implicit GEMM on CDNA4 MFMA (gfx950).
+//
+// Replaces the reference's conv_block -> nn.Conv2d [+ LeakyReLU/ReLU] [+ torch.cat]
+// [+ x*0.2 + residual] [+ nearest-2x Upsample in front] [+ PixelShuffle behind]
+// (architectures/block.py:213-254,333-361; RRDBNet_arch.py:152-165,91-98).
+//
+// Data layout in HBM: activations are fp16 NHWC "channel slabs": a pixel's
+// channels are contiguous, pixel stride = slab width (192 for an RDB: x|x1|x2|x3|x4),
+// so the dense concat of the reference is a channel offset, never a copy.
+//
+// GEMM view per tap (r,s) and 32-channel chunk:  D[oc][px] += W[oc][c] * X[px+tap][c]
+//   MFMA v_mfma_f32_16x16x32_f16, A = weights (rows = 16 out channels),
+//   B = pixels (cols = 16 consecutive pixels of one image row), fp32 accumulate.
+//   Output channels are permuted inside a panel so that one lane ends up holding
+//   4*NT CONSECUTIVE channels of one pixel -> 8/16/32-byte vector stores into NHWC.
+//
+// Workgroup = 256 threads = 4 waves, tile = (4*RPW rows) x 32 px, all 16*NT output
+// channels of one channel group.  Wave w owns rows [w*RPW, (w+1)*RPW).
+// Per 32-channel chunk the halo tile ((4*RPW+2) x 34 px x 64 B) and the weight
+// panel (9 x 16*NT x 64 B) are staged with LDS-DMA (global_load_lds_dwordx4);
+// LDS rows are 40 px so every row base is a multiple of 8 px, which makes the
+// 16-B-slot XOR swizzle (slot ^= 2*bit2(pixel)) a pure function of (lane, s):
+// all ds_read_b128 are base+immediate and bank-conflict free.
+// A pixel fragment B(row, seg, s) is read once and used by the up to three
+// (row-in-wave, r) pairs that need it.
+#include "common.h"
+
+namespace innfer {
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+namespace {
+
+constexpr int TW = 32;        // tile width (pixels)
+constexpr int LWP = 40;       // LDS row pitch (pixels), multiple of 8
+constexpr int LVALID = TW + 2;
+
+struct KP {
+    const f16* in; long in_img_stride; int in_stride; int nchunks;
+    const f16* wpk; const float* bias;
+    void* out; long out_img_stride; int out_stride;
+    int K, KG;
+    int H, W, Hs, Ws;
+    int act, up;
+    const f16* res1; int res1_stride; float s1;
+    const f16* res2; int res2_stride; float s2;
+    int y0, y1;
+    int tiles_x, tiles_y;
+    int out_f32;
+};
+
+__device__ __forceinline__ void dma16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int RPW, int NT, int OUTMODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
+    constexpr int TH = 4 * RPW;
+    constexpr int LH = TH + 2;
+    constexpr int NPX = LH * LWP;
+    constexpr int NQ = NPX / 16;                 // input DMA wave-instructions per chunk
+    constexpr int KQ = (NQ + 3) / 4;
+    constexpr int IN_BYTES = NQ * 1024;
+    constexpr int WROWS = NT * 16;
+    constexpr int W_BYTES = 9 * WROWS * 64;
+    constexpr int WQ = W_BYTES / 1024;           // 9*NT
+    constexpr int KW = (WQ + 3) / 4;
+    constexpr int MT = RPW * 2;
+    static_assert(NPX % 16 == 0, "tile must be a whole number of DMA pieces");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_in = smem;
+    char* lds_w = smem + IN_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- block -> (channel group, tile): XCD-aware bijective remap ------------
+    // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
+    // contiguous run of tiles so neighbouring halos and the next layer's reads
+    // of the same region meet in one L2.  Speed only, never correctness.
+    int lid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int kg = lid % p.KG;
+    int tile = lid / p.KG;
+    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty = tile % p.tiles_y;
+    const int n = tile / p.tiles_y;
+    const int ty0 = p.y0 + ty * TH;
+    const int tx0 = tx * TW;
+
+    // ---- per-lane DMA source offsets (chunk independent) ----------------------
+    const int sy_base = (ty0 > 0 ? ty0 - 1 : 0) >> p.up;
+    const char* in_base = (const char*)(p.in + (long)n * p.in_img_stride +
+                                        (long)sy_base * p.Ws * p.in_stride);
+    int in_off[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int q = wave + 4 * k;
+        const int px = q * 16 + (lane >> 2);
+        const int ly = px / LWP, lx = px - ly * LWP;
+        const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
+        const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
+        const bool ok = (q < NQ) && (lx < LVALID) && (Y >= 0) && (Y < p.H) && (X >= 0) && (X < p.W);
+        const int sy = (Y >> p.up) - sy_base, sx = X >> p.up;
+        in_off[k] = ok ? ((sy * p.Ws + sx) * p.in_stride + slot * 8) * 2 : -1;
+    }
+    const char* w_base = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES + lane * 16;
+
+    // ---- per-lane LDS read bases ------------------------------------------------
+    const int li = lane & 15, lg = lane >> 4;
+    const char* bbase[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int pb = wave * RPW * LWP + li + s;
+        bbase[s] = lds_in + pb * 64 + ((lg ^ ((((li + s) >> 2) & 1) << 1)) << 4);
+    }
+    const char* abase = lds_w + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+
+    // ---- accumulators start at the bias ----------------------------------------
+    const int cbase = kg * WROWS + 4 * NT * lg;     // first of this lane's 4*NT channels
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 b = *(const f32x4*)(p.bias + cbase + 4 * t);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[t][m] = b;
+    }
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        // stage chunk c: halo tile + weight panel, straight into LDS
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int q = wave + 4 * k;
+            if (q < NQ) {
+                const char* src = in_off[k] >= 0 ? in_base + in_off[k] + c * 64
+                                                 : (const char*)g_zero_page;
+                dma16(src, lds_in + q * 1024);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int j = wave + 4 * k;
+            if (j < WQ) dma16(w_base + (long)c * W_BYTES + j * 1024, lds_w + j * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            f16x8 a[3][NT];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    a[r][t] = *(const f16x8*)(abase + ((r * 3 + s) * WROWS + t * 16) * 64);
+#pragma unroll
+            for (int rr = 0; rr < RPW + 2; ++rr) {
+#pragma unroll
+                for (int seg = 0; seg < 2; ++seg) {
+                    const f16x8 b = *(const f16x8*)(bbase[s] + (rr * LWP + seg * 16) * 64);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int rw = rr - r;
+                        if (rw >= 0 && rw < RPW) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                acc[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                    a[r][t], b, acc[t][rw * 2 + seg], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: act -> residuals -> store -----------------------------------
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = ty0 + wave * RPW + (m >> 1);
+        const int x = tx0 + (m & 1) * 16 + li;
+        if (y >= p.y1 || x >= p.W) continue;
+        const long pix = ((long)n * p.H + y) * p.W + x;
+        float v[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = acc[t][m][j];
+                if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                v[t][j] = f;
+            }
+        if (p.res1) {
+            const f16* rp = p.res1 + pix * p.res1_stride + cbase;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[t][j] = v[t][j] * p.s1 + (float)r4[j];
+            }
+        }
+        if (p.res2) {
+            const f16* rp = p.res2 + pix * p.res2_stride + cbase;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[t][j] = v[t][j] * p.s2 + (float)r4[j];
+            }
+        }
+        if constexpr (OUTMODE == OUT_SLAB) {
+            f16* op = (f16*)p.out + pix * p.out_stride + cbase;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f16x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (f16)v[t][j];
+                *(f16x4*)(op + 4 * t) = h;
+            }
+        } else if constexpr (OUTMODE == OUT_NCHW) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = cbase + 4 * t + j;
+                    if (ch < p.K) {
+                        const long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
+                        if (p.out_f32) ((float*)p.out)[o] = v[t][j];
+                        else ((f16*)p.out)[o] = (f16)v[t][j];
+                    }
+                }
+        } else {   // OUT_SHUFFLE2: nn.PixelShuffle(2): out[c][2y+a][2x+b] = in[4c+2a+b][y][x]
+            // this lane's conv channels cbase+4t+j  <->  c = cbase/4 + t, (a,b) = (j>>1, j&1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long opix = ((long)n * 2 * p.H + 2 * y + (j >> 1)) * (2 * p.W) + 2 * x + (j & 1);
+                f16* op = (f16*)p.out + opix * p.out_stride + cbase / 4;
+                if constexpr (NT == 4) {
+                    f16x4 h;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) h[t] = (f16)v[t][j];
+                    *(f16x4*)op = h;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) op[t] = (f16)v[t][j];
+                }
+            }
+        }
+    }
+}
+
+template <int RPW, int NT, int OUTMODE>
+int launch_t(const KP& kp, int N, hipStream_t s) {
+    constexpr int TH = 4 * RPW;
+    constexpr int LDS = ((TH + 2) * LWP / 16) * 1024 + 9 * NT * 16 * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma<RPW, NT, OUTMODE>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    KP k = kp;
+    k.tiles_x = (k.W + TW - 1) / TW;
+    k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
+    const long grid = (long)N * k.tiles_x * k.tiles_y * k.KG;
+    if (grid <= 0) return INNFER_OK;
+    if (grid > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
+    hipLaunchKernelGGL((conv3x3_mfma<RPW, NT, OUTMODE>), dim3((unsigned)grid), dim3(256), LDS, s, k);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+}  // namespace
+
+int conv_nt_for(int K) { return K >= 64 ? 4 : (K >= 32 ? 2 : 1); }
+
+static int conv_groups(int K) {
+    const int per = 16 * conv_nt_for(K);
+    return (K + per - 1) / per;
+}
+
+size_t conv_packed_bytes(int K, int C) {
+    const int nt = conv_nt_for(K);
+    return (size_t)conv_groups(K) * (C / 32) * 9 * nt * 16 * 64;
+}
+
+// Host: OIHW fp32 -> [group][chunk][tap][row R][slot][8 ch] fp16, the exact LDS image.
+// Row R = t*16 + rho of a group holds out channel  group*16*NT + (4*NT)*(rho>>2) + 4*t + (rho&3);
+// slot sigma holds input channels chunk*32 + 8*(sigma ^ 2*bit2(R)) .. +7.
+void conv_pack(const float* w, int K, int C, void* packed) {
+    const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
+    f16* dst = (f16*)packed;
+    for (int g = 0; g < groups; ++g)
+        for (int c = 0; c < nch; ++c)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int R = 0; R < rows; ++R) {
+                    const int t = R >> 4, rho = R & 15;
+                    const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
+                    for (int sg = 0; sg < 4; ++sg) {
+                        const int cg = sg ^ (((R >> 2) & 1) << 1);
+                        for (int e = 0; e < 8; ++e) {
+                            const int ic = c * 32 + cg * 8 + e;
+                            const float v = oc < K ? w[((size_t)oc * C + ic) * 9 + tap] : 0.f;
+                            *dst++ = (f16)v;
+                        }
+                    }
+                }
+}
+
+int conv_launch(const ConvLaunch& L, hipStream_t s) {
+    if (L.C <= 0 || L.C % 32) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: C=%d must be a multiple of 32", L.C);
+    if (L.up && ((L.H | L.W) & 1)) return set_error(INNFER_ERR_INVALID, "conv3x3: upsampled size must be even");
+    KP k{};
+    k.up = L.up ? 1 : 0;
+    k.H = L.H; k.W = L.W; k.Hs = L.H >> k.up; k.Ws = L.W >> k.up;
+    k.in = L.in; k.in_stride = L.in_stride; k.in_img_stride = (long)k.Hs * k.Ws * L.in_stride;
+    k.nchunks = L.C / 32;
+    k.wpk = L.wpk; k.bias = L.bias;
+    k.out = L.out; k.out_stride = L.out_stride;
+    k.K = L.K; k.KG = conv_groups(L.K);
+    k.act = L.act;
+    k.res1 = L.res1; k.res1_stride = L.res1_stride; k.s1 = L.s1;
+    k.res2 = L.res2; k.res2_stride = L.res2_stride; k.s2 = L.s2;
+    k.y0 = L.y0; k.y1 = L.y1 > 0 ? L.y1 : L.H;
+    if (k.y0 < 0 || k.y1 > L.H || k.y0 >= k.y1) return set_error(INNFER_ERR_INVALID, "conv3x3: bad row range [%d,%d)", k.y0, k.y1);
+    k.out_f32 = L.out_f32;
+    const int nt = conv_nt_for(L.K);
+    if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
+    switch (L.out_mode) {
+        case OUT_SLAB:
+            if (nt == 4) return launch_t<2, 4, OUT_SLAB>(k, L.N, s);
+            if (nt == 2) return launch_t<4, 2, OUT_SLAB>(k, L.N, s);
+            return launch_t<4, 1, OUT_SLAB>(k, L.N, s);
+        case OUT_NCHW:
+            if (nt == 4) return launch_t<2, 4, OUT_NCHW>(k, L.N, s);
+            if (nt == 2) return launch_t<4, 2, OUT_NCHW>(k, L.N, s);
+            return launch_t<4, 1, OUT_NCHW>(k, L.N, s);
+        case OUT_SHUFFLE2:
+            if (nt == 4) return launch_t<2, 4, OUT_SHUFFLE2>(k, L.N, s);
+            return set_error(INNFER_ERR_UNSUPPORTED, "pixelshuffle conv needs K %% 64 == 0");
+    }
+    return set_error(INNFER_ERR_INVALID, "conv3x3: bad out_mode");
+}
+
+}  // namespace innfer

@@ -1,0 +1,510 @@
+// Network engine: RRDBNet (ESRGAN) and SRResNet (SRGAN) forward as a sequence of
+// fused conv launches over fp16 NHWC channel slabs in a caller-provided workspace.
+//
+// Replaces the nn.Sequential graph of RRDBNet_arch.py:16-62 / SRResNet_arch.py:15-91:
+//   torch.cat            -> channel offsets inside a 192-wide slab (x|x1|x2|x3|x4)
+//   LeakyReLU / ReLU     -> conv epilogue
+//   x5*0.2 + x, RRDB out*0.2 + x, ShortcutBlock x + sub(x) -> conv epilogue
+//   Upsample(nearest 2x) -> folded into the next conv's input addressing
+//   PixelShuffle(2)      -> folded into the conv's store
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace innfer {
+
+static thread_local std::string g_err;
+
+int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+}  // namespace innfer
+
+using namespace innfer;
+
+struct ConvSlot {
+    std::string key;
+    int K = 0, C = 0;
+    bool first = false;          // small-Cin VALU conv (fp32 [C*9][K] weights)
+    void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
+    float* d_b = nullptr;        // bias padded to the panel width
+    bool loaded = false;
+};
+
+struct innfer_net {
+    int kind = 0;                // 0 rrdbnet, 1 srresnet
+    int in_nc = 3, out_nc = 3, nf = 64, nb = 23, gc = 32, scale = 4, n_up = 2;
+    int band_rows = 0;
+    std::vector<ConvSlot> convs;
+};
+
+static int n_upscale(int scale) {
+    int n = 0;
+    while ((1 << n) < scale) ++n;
+    return n;
+}
+
+static void add_conv(innfer_net* net, const std::string& key, int K, int C, bool first = false) {
+    ConvSlot s;
+    s.key = key; s.K = K; s.C = C; s.first = first;
+    net->convs.push_back(s);
+}
+
+extern "C" int innfer_version(void) { return 100; }
+extern "C" const char* innfer_last_error(void) { return g_err.c_str(); }
+
+extern "C" int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
+                                     int gc, int scale, int plus) {
+    if (!out) return set_error(INNFER_ERR_INVALID, "rrdbnet_create: null out");
+    if (plus) return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: ESRGAN+ (plus/conv1x1) is not built yet");
+    if (scale != 1 && scale != 2 && scale != 4 && scale != 8 && scale != 16)
+        return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: scale %d (only powers of two)", scale);
+    if (nf % 32 || gc % 32 || nf <= 0 || gc <= 0 || nf > 64)
+        return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: nf=%d gc=%d (need nf in {32,64}, gc %% 32 == 0)", nf, gc);
+    if (in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 16 || nb < 1)
+        return set_error(INNFER_ERR_INVALID, "rrdbnet_create: in_nc=%d out_nc=%d nb=%d", in_nc, out_nc, nb);
+    innfer_net* net = new innfer_net();
+    net->kind = 0; net->in_nc = in_nc; net->out_nc = out_nc; net->nf = nf; net->nb = nb;
+    net->gc = gc; net->scale = scale; net->n_up = n_upscale(scale);
+    add_conv(net, "model.0", nf, in_nc, true);
+    for (int b = 0; b < nb; ++b)
+        for (int r = 1; r <= 3; ++r)
+            for (int i = 1; i <= 5; ++i) {
+                char key[96];
+                snprintf(key, sizeof key, "model.1.sub.%d.RDB%d.conv%d.0", b, r, i);
+                add_conv(net, key, i < 5 ? gc : nf, nf + (i - 1) * gc);
+            }
+    add_conv(net, "model.1.sub." + std::to_string(nb), nf, nf);
+    int idx = 2;
+    for (int u = 0; u < net->n_up; ++u) { add_conv(net, "model." + std::to_string(idx + 1), nf, nf); idx += 3; }
+    add_conv(net, "model." + std::to_string(idx), nf, nf);
+    add_conv(net, "model." + std::to_string(idx + 2), out_nc, nf);
+    *out = net;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale) {
+    if (!out) return set_error(INNFER_ERR_INVALID, "srresnet_create: null out");
+    if (scale != 1 && scale != 2 && scale != 4 && scale != 8)
+        return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: scale %d (only powers of two)", scale);
+    if (nf != 64 && nf != 32) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: nf=%d", nf);
+    if (scale > 1 && nf != 64) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: pixelshuffle path needs nf=64");
+    if (in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 16 || nb < 1)
+        return set_error(INNFER_ERR_INVALID, "srresnet_create: in_nc=%d out_nc=%d nb=%d", in_nc, out_nc, nb);
+    innfer_net* net = new innfer_net();
+    net->kind = 1; net->in_nc = in_nc; net->out_nc = out_nc; net->nf = nf; net->nb = nb;
+    net->gc = 0; net->scale = scale; net->n_up = n_upscale(scale);
+    add_conv(net, "model.0", nf, in_nc, true);
+    for (int b = 0; b < nb; ++b) {
+        add_conv(net, "model.1.sub." + std::to_string(b) + ".res.0", nf, nf);
+        add_conv(net, "model.1.sub." + std::to_string(b) + ".res.2", nf, nf);
+    }
+    add_conv(net, "model.1.sub." + std::to_string(nb), nf, nf);
+    int idx = 2;
+    for (int u = 0; u < net->n_up; ++u) { add_conv(net, "model." + std::to_string(idx), nf * 4, nf); idx += 3; }
+    add_conv(net, "model." + std::to_string(idx), nf, nf);
+    add_conv(net, "model." + std::to_string(idx + 2), out_nc, nf);
+    *out = net;
+    return INNFER_OK;
+}
+
+extern "C" void innfer_net_destroy(innfer_net_t net) {
+    if (!net) return;
+    for (auto& c : net->convs) {
+        if (c.d_w) (void)hipFree(c.d_w);
+        if (c.d_b) (void)hipFree(c.d_b);
+    }
+    delete net;
+}
+
+extern "C" int innfer_net_num_convs(innfer_net_t net) { return net ? (int)net->convs.size() : INNFER_ERR_INVALID; }
+extern "C" int innfer_net_scale(innfer_net_t net) { return net ? net->scale : INNFER_ERR_INVALID; }
+
+extern "C" int innfer_net_conv_info(innfer_net_t net, int idx, char* key, size_t key_cap, int* K, int* C) {
+    if (!net || idx < 0 || idx >= (int)net->convs.size()) return set_error(INNFER_ERR_INVALID, "conv_info: bad index %d", idx);
+    const ConvSlot& c = net->convs[idx];
+    if (key && key_cap) { strncpy(key, c.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
+    if (K) *K = c.K;
+    if (C) *C = c.C;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, const float* b) {
+    if (!net || idx < 0 || idx >= (int)net->convs.size() || !w) return set_error(INNFER_ERR_INVALID, "set_conv: bad arguments");
+    ConvSlot& c = net->convs[idx];
+    std::vector<char> host;
+    size_t bias_n;
+    if (c.first) {
+        host.resize((size_t)c.C * 9 * c.K * sizeof(float));
+        float* d = (float*)host.data();
+        for (int ci = 0; ci < c.C; ++ci)
+            for (int t = 0; t < 9; ++t)
+                for (int k = 0; k < c.K; ++k) d[((size_t)ci * 9 + t) * c.K + k] = w[((size_t)k * c.C + ci) * 9 + t];
+        bias_n = c.K;
+    } else {
+        host.resize(conv_packed_bytes(c.K, c.C));
+        conv_pack(w, c.K, c.C, host.data());
+        const int per = 16 * conv_nt_for(c.K);
+        bias_n = (size_t)((c.K + per - 1) / per) * per;
+    }
+    std::vector<float> bias(bias_n, 0.f);
+    if (b) for (int k = 0; k < c.K; ++k) bias[k] = b[k];
+    if (!c.d_w) INNFER_HIP(hipMalloc(&c.d_w, host.size()));
+    if (!c.d_b) INNFER_HIP(hipMalloc((void**)&c.d_b, bias_n * sizeof(float)));
+    INNFER_HIP(hipMemcpy(c.d_w, host.data(), host.size(), hipMemcpyHostToDevice));
+    INNFER_HIP(hipMemcpy(c.d_b, bias.data(), bias_n * sizeof(float), hipMemcpyHostToDevice));
+    c.loaded = true;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_set_band_rows(innfer_net_t net, int rows) {
+    if (!net || rows < 0) return set_error(INNFER_ERR_INVALID, "set_band_rows: bad arguments");
+    net->band_rows = rows;
+    return INNFER_OK;
+}
+
+extern "C" double innfer_net_flops(innfer_net_t net, int N, int H, int W) {
+    if (!net) return 0.0;
+    double px = (double)N * H * W, f = 0.0;
+    const int nconv = (int)net->convs.size();
+    // resolution multiplier per conv: trunk at 1x, up-conv u at 4^(u+1) (RRDB: conv runs AFTER the
+    // upsample; SRGAN: conv runs BEFORE the shuffle, i.e. at 4^u), tail convs at scale^2.
+    for (int i = 0; i < nconv; ++i) {
+        const ConvSlot& c = net->convs[i];
+        double mult = 1.0;
+        const int tail0 = nconv - 2 - net->n_up;          // first up conv
+        if (i >= tail0) {
+            const int u = i - tail0;
+            if (u < net->n_up) mult = std::pow(4.0, net->kind == 0 ? u + 1 : u);
+            else mult = std::pow(4.0, net->n_up);
+        }
+        f += 2.0 * 9.0 * c.K * c.C * px * mult;
+    }
+    return f;
+}
+
+// Workspace carve (all fp16 NHWC):
+//   fea        [N,H,W,nf]               conv_first output, kept for the trunk shortcut
+//   slab[3]    [N,H,W,nf+4gc]           rotating RDB slabs (RRDB) / ping-pong features (SRGAN)
+//   trunk      [N,H,W,nf]
+//   up[u]      [N,2^(u+1)H,2^(u+1)W,nf] after each upsample stage
+//   hr         [N,sH,sW,nf]             HR_conv0 output
+struct Carve {
+    size_t fea, slab[3], trunk, up[5], hr, total;
+    int slab_w;
+};
+
+static Carve carve(const innfer_net* net, int N, int H, int W) {
+    Carve c{};
+    const size_t px = (size_t)N * H * W;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    c.slab_w = net->kind == 0 ? net->nf + 4 * net->gc : net->nf;
+    size_t off = 0;
+    c.fea = off; off += al(px * net->nf * 2);
+    for (int i = 0; i < 3; ++i) { c.slab[i] = off; off += al(px * c.slab_w * 2); }
+    c.trunk = off; off += al(px * net->nf * 2);
+    size_t m = 1;
+    for (int u = 0; u < net->n_up; ++u) { m *= 4; c.up[u] = off; off += al(px * m * net->nf * 2); }
+    c.hr = off; off += al(px * m * net->nf * 2);
+    c.total = off;
+    return c;
+}
+
+extern "C" size_t innfer_net_workspace_bytes(innfer_net_t net, int N, int H, int W) {
+    if (!net || N <= 0 || H <= 0 || W <= 0) return 0;
+    return carve(net, N, H, W).total;
+}
+
+namespace {
+
+// Optional per-launch timing (innfer_net_forward_timed): HIP events on the launch stream
+// bracket every kernel of one forward.
+struct LaunchTimer {
+    std::vector<hipEvent_t> ev;      // 2 per launch
+    std::vector<double> flops;
+    std::vector<int> kind;           // 0 first conv (VALU); 16*NT + out_mode for conv3x3_mfma
+};
+thread_local LaunchTimer* g_timer = nullptr;
+
+int timed_begin(hipStream_t s) {
+    if (!g_timer) return INNFER_OK;
+    hipEvent_t e;
+    INNFER_HIP(hipEventCreate(&e));
+    INNFER_HIP(hipEventRecord(e, s));
+    g_timer->ev.push_back(e);
+    return INNFER_OK;
+}
+
+int timed_end(hipStream_t s, double flops, int kind) {
+    if (!g_timer) return INNFER_OK;
+    hipEvent_t e;
+    INNFER_HIP(hipEventCreate(&e));
+    INNFER_HIP(hipEventRecord(e, s));
+    g_timer->ev.push_back(e);
+    g_timer->flops.push_back(flops);
+    g_timer->kind.push_back(kind);
+    return INNFER_OK;
+}
+
+// INNFER_DEBUG=1: print every launch and synchronise after it (fault localisation only).
+bool debug_sync() {
+    static const bool on = getenv("INNFER_DEBUG") != nullptr;
+    return on;
+}
+
+int debug_after(const char* what, hipStream_t s) {
+    if (!debug_sync()) return INNFER_OK;
+    fprintf(stderr, "[innfer] %s ... ", what); fflush(stderr);
+    hipError_t e = hipStreamSynchronize(s);
+    fprintf(stderr, "%s\n", hipGetErrorString(e)); fflush(stderr);
+    return e == hipSuccess ? INNFER_OK : set_error(INNFER_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+}
+
+int do_conv(const ConvLaunch& L, hipStream_t s) {
+    int rc = timed_begin(s);
+    if (rc) return rc;
+    if (debug_sync())
+        fprintf(stderr, "[innfer] conv C=%d K=%d N=%d H=%d W=%d up=%d act=%d mode=%d rows=[%d,%d) in_stride=%d out_stride=%d\n",
+                L.C, L.K, L.N, L.H, L.W, L.up, L.act, L.out_mode, L.y0, L.y1, L.in_stride, L.out_stride);
+    rc = conv_launch(L, s);
+    if (rc) return rc;
+    rc = debug_after("conv3x3", s);
+    if (rc) return rc;
+    const int y1 = L.y1 > 0 ? L.y1 : L.H;
+    return timed_end(s, 2.0 * 9.0 * L.K * L.C * (double)L.N * (y1 - L.y0) * L.W,
+                     16 * conv_nt_for(L.K) + L.out_mode);
+}
+
+int do_first(const FirstConvLaunch& F, hipStream_t s) {
+    int rc = timed_begin(s);
+    if (rc) return rc;
+    rc = first_conv_launch(F, s);
+    if (rc) return rc;
+    rc = debug_after("first_conv", s);
+    if (rc) return rc;
+    return timed_end(s, 2.0 * 9.0 * F.K * F.Cin * (double)F.N * F.H * F.W, 0);
+}
+
+struct Plan {                    // one MFMA conv in the launch list
+    ConvLaunch L;
+};
+
+ConvLaunch mk(const ConvSlot& cs, const f16* in, int in_stride, void* out, int out_stride,
+              int N, int H, int W, int act) {
+    ConvLaunch L{};
+    L.in = in; L.in_stride = in_stride; L.C = cs.C;
+    L.wpk = (const f16*)cs.d_w; L.bias = cs.d_b;
+    L.out = out; L.out_stride = out_stride; L.K = cs.K;
+    L.N = N; L.H = H; L.W = W; L.act = act;
+    L.s1 = 1.f; L.s2 = 1.f;
+    L.y0 = 0; L.y1 = H;
+    L.out_mode = OUT_SLAB;
+    return L;
+}
+
+// Launch a dependent chain of same-resolution convs.  band_rows == 0: one launch per
+// layer over the whole frame.  band_rows > 0: skewed row bands -- layer l of band b
+// covers rows [b*R - l, (b+1)*R - l), so every row a layer reads from its predecessor
+// (its own rows +-1) has already been produced, nothing is recomputed, and the ~R-row
+// working set of consecutive layers stays resident in the 256 MiB Infinity Cache
+// instead of streaming 1664 B/pixel/RDB from HBM.
+int run_chain(std::vector<ConvLaunch>& chain, int band_rows, hipStream_t s) {
+    if (chain.empty()) return INNFER_OK;
+    const int H = chain[0].H, L = (int)chain.size();
+    if (band_rows <= 0 || band_rows >= H) {
+        for (auto& c : chain) { int rc = do_conv(c, s); if (rc) return rc; }
+        return INNFER_OK;
+    }
+    const int nbands = (H + (L - 1) + band_rows - 1) / band_rows;
+    for (int b = 0; b < nbands; ++b)
+        for (int l = 0; l < L; ++l) {
+            int y0 = b * band_rows - l, y1 = y0 + band_rows;
+            if (y0 < 0) y0 = 0;
+            if (y1 > H) y1 = H;
+            if (b == nbands - 1) y1 = H;
+            if (y0 >= y1) continue;
+            ConvLaunch c = chain[l];
+            c.y0 = y0; c.y1 = y1;
+            int rc = do_conv(c, s);
+            if (rc) return rc;
+        }
+    return INNFER_OK;
+}
+
+}  // namespace
+
+extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                                  int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!net || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "forward: null argument");
+    if (N <= 0 || H <= 0 || W <= 0) return set_error(INNFER_ERR_INVALID, "forward: bad shape %dx%dx%d", N, H, W);
+    if ((in_dtype != INNFER_F16 && in_dtype != INNFER_F32) || (out_dtype != INNFER_F16 && out_dtype != INNFER_F32))
+        return set_error(INNFER_ERR_INVALID, "forward: bad dtype");
+    for (auto& c : net->convs)
+        if (!c.loaded) return set_error(INNFER_ERR_INVALID, "forward: weights of '%s' were never set", c.key.c_str());
+    const Carve cv = carve(net, N, H, W);
+    if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    const int nf = net->nf, gc = net->gc, SW = cv.slab_w;
+    f16* fea = (f16*)(ws + cv.fea);
+    f16* slab[3] = {(f16*)(ws + cv.slab[0]), (f16*)(ws + cv.slab[1]), (f16*)(ws + cv.slab[2])};
+    f16* trunk = (f16*)(ws + cv.trunk);
+    int ci = 0;
+
+    {   // conv_first: NCHW input -> fea (+ slab[0][0:nf))
+        const ConvSlot& c0 = net->convs[ci++];
+        FirstConvLaunch F{};
+        F.in = d_in; F.in_f32 = in_dtype == INNFER_F32; F.Cin = c0.C; F.w = (const float*)c0.d_w; F.bias = c0.d_b;
+        F.out = fea; F.out_stride = nf; F.out2 = slab[0]; F.out2_stride = SW;
+        F.K = nf; F.N = N; F.H = H; F.W = W; F.act = 0;
+        int rc = do_first(F, s);
+        if (rc) return rc;
+    }
+
+    std::vector<ConvLaunch> chain;
+    int cur = 0;
+    if (net->kind == 0) {
+        for (int b = 0; b < net->nb; ++b) {
+            const int in_slab = cur;
+            int f1 = (cur + 1) % 3, f2 = (cur + 2) % 3;
+            const int work[3] = {in_slab, f1, f2};
+            const int dest[3] = {f1, f2, f1};
+            for (int r = 0; r < 3; ++r) {
+                f16* S = slab[work[r]];
+                for (int i = 0; i < 4; ++i) {
+                    const ConvSlot& cs = net->convs[ci++];
+                    chain.push_back(mk(cs, S, SW, S + nf + i * gc, SW, N, H, W, 1));
+                }
+                const ConvSlot& cs = net->convs[ci++];
+                ConvLaunch L = mk(cs, S, SW, slab[dest[r]], SW, N, H, W, 0);
+                L.res1 = S; L.res1_stride = SW; L.s1 = 0.2f;                      // x5*0.2 + x
+                if (r == 2) { L.res2 = slab[in_slab]; L.res2_stride = SW; L.s2 = 0.2f; }   // RRDB: out*0.2 + x
+                chain.push_back(L);
+            }
+            cur = f1;
+        }
+    } else {
+        // SRGAN residual blocks: t = t + conv(relu(conv(t))) on nf-wide slabs
+        for (int b = 0; b < net->nb; ++b) {
+            const int a = cur, m = (cur + 1) % 3, o = (cur + 2) % 3;
+            const ConvSlot& c0 = net->convs[ci++];
+            chain.push_back(mk(c0, slab[a], SW, slab[m], SW, N, H, W, 2));
+            const ConvSlot& c1 = net->convs[ci++];
+            ConvLaunch L = mk(c1, slab[m], SW, slab[o], SW, N, H, W, 0);
+            L.res1 = slab[a]; L.res1_stride = SW; L.s1 = 1.f;
+            chain.push_back(L);
+            cur = o;
+        }
+    }
+    {   // trunk conv + ShortcutBlock: fea + conv(t)
+        const ConvSlot& cs = net->convs[ci++];
+        ConvLaunch L = mk(cs, slab[cur], SW, trunk, nf, N, H, W, 0);
+        L.res1 = fea; L.res1_stride = nf; L.s1 = 1.f;
+        chain.push_back(L);
+    }
+    int rc = run_chain(chain, net->band_rows, s);
+    if (rc) return rc;
+
+    const f16* t = trunk;
+    int h = H, w = W;
+    for (int u = 0; u < net->n_up; ++u) {
+        const ConvSlot& cs = net->convs[ci++];
+        f16* dst = (f16*)(ws + cv.up[u]);
+        if (net->kind == 0) {        // Upsample(nearest 2x) -> conv -> LeakyReLU
+            ConvLaunch L = mk(cs, t, nf, dst, nf, N, 2 * h, 2 * w, 1);
+            L.up = 1;
+            rc = do_conv(L, s);
+        } else {                     // conv nf->4nf -> PixelShuffle(2) -> ReLU
+            ConvLaunch L = mk(cs, t, nf, dst, nf, N, h, w, 2);
+            L.out_mode = OUT_SHUFFLE2;
+            rc = do_conv(L, s);
+        }
+        if (rc) return rc;
+        t = dst; h *= 2; w *= 2;
+    }
+    {
+        const ConvSlot& cs = net->convs[ci++];
+        ConvLaunch L = mk(cs, t, nf, ws + cv.hr, nf, N, h, w, net->kind == 0 ? 1 : 2);
+        rc = do_conv(L, s);
+        if (rc) return rc;
+    }
+    {
+        const ConvSlot& cs = net->convs[ci++];
+        ConvLaunch L = mk(cs, (const f16*)(ws + cv.hr), nf, d_out, 0, N, h, w, 0);
+        L.out_mode = OUT_NCHW; L.out_f32 = out_dtype == INNFER_F32;
+        rc = do_conv(L, s);
+        if (rc) return rc;
+    }
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                                        int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream,
+                                        int cap, float* h_ms, double* h_flops, int* h_kind, int* n_launches) {
+    LaunchTimer t;
+    g_timer = &t;
+    int rc = innfer_net_forward(net, d_in, in_dtype, d_out, out_dtype, N, H, W, d_ws, ws_bytes, stream);
+    g_timer = nullptr;
+    if (rc == INNFER_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        rc = set_error(INNFER_ERR_HIP, "forward_timed: stream synchronize failed");
+    const int n = (int)t.flops.size();
+    if (rc == INNFER_OK) {
+        if (n_launches) *n_launches = n;
+        for (int i = 0; i < n && i < cap; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]);
+            if (h_ms) h_ms[i] = ms;
+            if (h_flops) h_flops[i] = t.flops[i];
+            if (h_kind) h_kind[i] = t.kind[i];
+        }
+    }
+    for (auto e : t.ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+// ---------------------------------------------------------------- single conv
+extern "C" size_t innfer_conv3x3_packed_bytes(int K, int C) {
+    if (K <= 0 || C <= 0 || C % 32) return 0;
+    return conv_packed_bytes(K, C);
+}
+
+extern "C" int innfer_pack_conv3x3(const float* w, int K, int C, void* h_packed) {
+    if (!w || !h_packed || K <= 0 || C <= 0 || C % 32)
+        return set_error(INNFER_ERR_INVALID, "pack_conv3x3: K=%d C=%d (C must be a multiple of 32)", K, C);
+    conv_pack(w, K, C, h_packed);
+    return INNFER_OK;
+}
+
+extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
+    if (!a || !a->d_in || !a->d_packed || !a->d_bias || !a->d_out) return set_error(INNFER_ERR_INVALID, "conv3x3: null argument");
+    if (a->K <= 0 || a->K % 16 || a->K > 64) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d (need K %% 16 == 0, K <= 64)", a->K);
+    ConvLaunch L{};
+    L.in = (const f16*)a->d_in; L.in_stride = a->in_stride; L.C = a->C;
+    L.wpk = (const f16*)a->d_packed; L.bias = a->d_bias;
+    L.out = (f16*)a->d_out + a->out_ch_off; L.out_stride = a->out_stride; L.K = a->K;
+    L.N = a->N; L.H = a->H; L.W = a->W; L.act = a->act; L.up = a->upsample2x;
+    L.res1 = (const f16*)a->d_res1; L.res1_stride = a->res1_stride; L.s1 = a->res1_scale;
+    L.res2 = (const f16*)a->d_res2; L.res2_stride = a->res2_stride; L.s2 = a->res2_scale;
+    L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
+    L.out_mode = OUT_SLAB;
+    return conv_launch(L, (hipStream_t)stream);
+}
+
+extern "C" int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int slab_stride, int ch_off,
+                                   int N, int C, int H, int W, void* stream) {
+    return nchw_to_slab(d_src, src_dtype == INNFER_F32, (f16*)d_slab + ch_off, slab_stride, N, C, H, W, (hipStream_t)stream);
+}
+
+extern "C" int innfer_slab_to_nchw(const void* d_slab, int slab_stride, int ch_off, void* d_dst, int dst_dtype,
+                                   int N, int C, int H, int W, void* stream) {
+    return slab_to_nchw((const f16*)d_slab + ch_off, slab_stride, d_dst, dst_dtype == INNFER_F32, N, C, H, W, (hipStream_t)stream);
+}

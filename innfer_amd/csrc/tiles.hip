@@ -1,0 +1,292 @@
+// HBM-bound pointwise / gather kernels around the conv stack:
+//   - NCHW <-> fp16 NHWC slab (test helpers of the single-conv entry point)
+//   - chop_forward tile extraction  (utils/utils.py:318-369 as used by run.py:178-181)
+//   - overlap blend / recompose     (utils/utils.py:372-445)
+//   - uint8 HWC BGR <-> float NCHW RGB pre/post (utils/utils.py:164-194,197-248)
+// All of them are one read + one write per element; the blend is written as a
+// GATHER (one thread per output pixel walks the <=3x3 tiles covering it in the
+// reference's (h,w) order) so there are no atomics, no read-modify-write of the
+// 3.2 GB output and the fp32 result is bit-identical to the reference's
+// scatter loop.
+#include "common.h"
+
+// Bit-exact parity with the reference's separate torch ops (mul, then +=, then /) needs every
+// rounding kept: hipcc defaults to -ffp-contract=fast, which would fuse a*w + num into one FMA.
+#pragma clang fp contract(off)
+
+namespace innfer {
+namespace {
+
+__global__ void k_nchw_to_slab(const void* src, int f32, f16* slab, int stride, int C, long hw, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over N*C*H*W, pixel fastest
+    if (i >= total) return;
+    const long px = i % hw;
+    const int c = (int)((i / hw) % C);
+    const long n = i / (hw * C);
+    const float v = f32 ? ((const float*)src)[i] : (float)((const f16*)src)[i];
+    slab[(n * hw + px) * stride + c] = (f16)v;
+}
+
+__global__ void k_slab_to_nchw(const f16* slab, int stride, void* dst, int f32, int C, long hw, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long px = i % hw;
+    const int c = (int)((i / hw) % C);
+    const long n = i / (hw * C);
+    const f16 v = slab[(n * hw + px) * stride + c];
+    if (f32) ((float*)dst)[i] = (float)v; else ((f16*)dst)[i] = v;
+}
+
+template <typename T>
+__global__ void k_extract(const T* img, T* tiles, int C, int H, int W, int ps, int step_int,
+                          int nw, int tile_begin, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over count*C*ps*ps
+    if (i >= total) return;
+    const int x = (int)(i % ps);
+    const int y = (int)((i / ps) % ps);
+    const int c = (int)((i / ((long)ps * ps)) % C);
+    const int k = (int)(i / ((long)ps * ps * C)) + tile_begin;
+    const int th = k / nw, tw = k % nw;
+    int oy = th * step_int; if (oy > H - ps) oy = H - ps;      // ragged last row anchored at H-ps
+    int ox = tw * step_int; if (ox > W - ps) ox = W - ps;
+    tiles[i] = img[((long)c * H + oy + y) * W + ox + x];
+}
+
+// torch.linspace(start, end, steps)[i] in fp32 = one fused multiply-add per element,
+// counted from the nearer end (ATen RangeFactories; verified against golden G2).
+__device__ __forceinline__ float lin(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = __fdiv_rn(__fsub_rn(end, start), (float)(steps - 1));
+    return i < steps / 2 ? __fmaf_rn(step, (float)i, start)
+                         : __fmaf_rn(-step, (float)(steps - i - 1), end);
+}
+
+__device__ __forceinline__ float profile(int i, int P, int ov) {
+    if (i < ov) return lin(0.1f, 1.0f, ov, i);
+    if (i < P - ov) return 1.0f;
+    return lin(1.0f, 0.1f, ov, i - (P - ov));
+}
+
+template <typename TI, typename TO>
+__global__ void k_recompose(const TI* tiles, TO* out, int C, int P, int FH, int FW, int eff,
+                            int nh, int nw, int ov) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Y = blockIdx.y;
+    const int b = blockIdx.z;
+    if (X >= FW) return;
+    float num[4] = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    // first lattice tile whose span [h*eff, h*eff+P) can reach Y (clamped origins only move up)
+    const int h0 = max(0, (Y - P + eff) / eff), w0 = max(0, (X - P + eff) / eff);
+    for (int cb = 0; cb < C; cb += 4) {
+        den = 0.f;
+        num[0] = num[1] = num[2] = num[3] = 0.f;
+        for (int h = h0; h < nh; ++h) {
+            const int oy = min(h * eff, FH - P);
+            if (oy > Y) break;
+            if (Y - oy >= P) continue;
+            const float wy = profile(Y - oy, P, ov);
+            for (int w = w0; w < nw; ++w) {
+                const int ox = min(w * eff, FW - P);
+                if (ox > X) break;
+                if (X - ox >= P) continue;
+                const float wgt = __fmul_rn(profile(X - ox, P, ov), wy);
+                den = __fadd_rn(den, wgt);
+                const long k = ((long)b * nh + h) * nw + w;
+                const TI* tp = tiles + ((k * C + cb) * P + (Y - oy)) * (long)P + (X - ox);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (cb + c < C)
+                        num[c] = __fadd_rn(num[c], __fmul_rn((float)tp[(long)c * P * P], wgt));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cb + c < C)
+                out[(((long)b * C + cb + c) * FH + Y) * FW + X] = (TO)__fdiv_rn(num[c], den);
+    }
+}
+
+// np2tensor: float32(u8)/255 -> HWC->CHW -> BGR->RGB flip (C%3==0: full flip; C==4: [2,1,0,3])
+// -> optional ((x-0.5)*2).clamp(-1,1).  One thread per pixel, all channels.
+template <typename TO>
+__global__ void k_u8_to_nchw(const uint8_t* img, TO* out, long hw, int C, int normalize) {
+    const long px = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= hw) return;
+    for (int c = 0; c < C; ++c) {
+        int sc = c;
+        if (C % 3 == 0) sc = C - 1 - c; else if (C == 4 && c < 3) sc = 2 - c;
+        float v = __fdiv_rn((float)img[px * C + sc], 255.0f);
+        if (normalize) {
+            v = __fmul_rn(__fsub_rn(v, 0.5f), 2.0f);
+            v = fminf(fmaxf(v, -1.0f), 1.0f);
+        }
+        out[(long)c * hw + px] = (TO)v;
+    }
+}
+
+// tensor2np: .float() -> RGB->BGR flip -> CHW->HWC -> optional denorm ((x+1)/2).clip(0,1)
+// -> clip(255*x, 0, 255).round() (half to even) -> uint8.
+template <typename TI>
+__global__ void k_nchw_to_u8(const TI* in, uint8_t* img, long hw, int C, int denormalize) {
+    const long px = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= hw) return;
+    for (int c = 0; c < C; ++c) {
+        int sc = c;
+        if (C == 3) sc = 2 - c; else if (C == 4 && c < 3) sc = 2 - c;
+        float v = (float)in[(long)sc * hw + px];
+        if (denormalize) {
+            v = __fdiv_rn(__fsub_rn(v, -1.0f), 2.0f);
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+        v = __fmul_rn(255.0f, v);
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        img[px * C + c] = (uint8_t)__float2int_rn(v);          // round half to even
+    }
+}
+
+inline unsigned blocks(long total, int bs) { return (unsigned)((total + bs - 1) / bs); }
+
+}  // namespace
+
+int nchw_to_slab(const void* src, int f32, f16* slab, int stride, int N, int C, int H, int W, hipStream_t s) {
+    const long hw = (long)H * W, total = hw * C * N;
+    if (total == 0) return INNFER_OK;
+    hipLaunchKernelGGL(k_nchw_to_slab, dim3(blocks(total, 256)), dim3(256), 0, s, src, f32, slab, stride, C, hw, total);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+int slab_to_nchw(const f16* slab, int stride, void* dst, int f32, int N, int C, int H, int W, hipStream_t s) {
+    const long hw = (long)H * W, total = hw * C * N;
+    if (total == 0) return INNFER_OK;
+    hipLaunchKernelGGL(k_slab_to_nchw, dim3(blocks(total, 256)), dim3(256), 0, s, slab, stride, dst, f32, C, hw, total);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+}  // namespace innfer
+
+using namespace innfer;
+
+// ------------------------------------------------------------------ C ABI part
+static int axis_plan(int size, int ps, int step_int, int* org) {
+    int n = (size - ps) / step_int + 1;
+    if (org) for (int i = 0; i < n; ++i) org[i] = i * step_int;
+    if ((size - ps) % step_int != 0) { if (org) org[n] = size - ps; ++n; }
+    return n;
+}
+
+extern "C" int innfer_chop_plan(int H, int W, int patch, double step, int* ps_out, int* nh, int* nw,
+                                int* ys, int* xs) {
+    if (H <= 0 || W <= 0 || patch <= 0 || !(step > 0.0))
+        return set_error(INNFER_ERR_INVALID, "chop_plan: bad arguments H=%d W=%d patch=%d step=%g", H, W, patch, step);
+    int ps = patch; if (H < ps) ps = H; if (W < ps) ps = W;          // run.py:176
+    const int step_int = (int)(ps * step);                             // utils.py:351-352
+    if (step_int <= 0) return set_error(INNFER_ERR_INVALID, "chop_plan: step too small");
+    const int a = axis_plan(H, ps, step_int, ys), b = axis_plan(W, ps, step_int, xs);
+    if (ps_out) *ps_out = ps;
+    if (nh) *nh = a;
+    if (nw) *nw = b;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_extract_tiles(const void* d_img, int dtype, int C, int H, int W, int patch, double step,
+                                    int tile_begin, int tile_count, void* d_tiles, void* stream) {
+    int ps, nh, nw;
+    int rc = innfer_chop_plan(H, W, patch, step, &ps, &nh, &nw, nullptr, nullptr);
+    if (rc) return rc;
+    if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > nh * nw)
+        return set_error(INNFER_ERR_INVALID, "extract_tiles: range [%d,+%d) outside %d tiles", tile_begin, tile_count, nh * nw);
+    const long total = (long)tile_count * C * ps * ps;
+    if (total == 0) return INNFER_OK;
+    const int step_int = (int)(ps * step);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == INNFER_F16)
+        hipLaunchKernelGGL(k_extract<f16>, dim3(blocks(total, 256)), dim3(256), 0, s, (const f16*)d_img, (f16*)d_tiles,
+                           C, H, W, ps, step_int, nw, tile_begin, total);
+    else if (dtype == INNFER_F32)
+        hipLaunchKernelGGL(k_extract<float>, dim3(blocks(total, 256)), dim3(256), 0, s, (const float*)d_img, (float*)d_tiles,
+                           C, H, W, ps, step_int, nw, tile_begin, total);
+    else return set_error(INNFER_ERR_INVALID, "extract_tiles: bad dtype %d", dtype);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+// overlap = scale * int(round((1-step) * (P/scale)))  with Python's round-half-to-even (utils.py:396)
+static int blend_overlap(int P, double step, int scale) {
+    const double v = (1.0 - step) * ((double)P / scale);
+    double r = __builtin_rint(v);                                     // FE_TONEAREST = half to even
+    return scale * (int)r;
+}
+
+static float lin_host(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return i < steps / 2 ? __builtin_fmaf(step, (float)i, start)
+                         : __builtin_fmaf(-step, (float)(steps - i - 1), end);
+}
+
+extern "C" int innfer_blend_profile(int P, double step, int scale, float* h_profile) {
+    if (P <= 0 || scale <= 0 || step < 0.5 || step > 1.0 || !h_profile)
+        return set_error(INNFER_ERR_INVALID, "blend_profile: bad arguments");
+    const int ov = blend_overlap(P, step, scale);
+    if (P - 2 * ov < 0)
+        return set_error(INNFER_ERR_INVALID, "blend_profile: overlap %d exceeds half of patch %d "
+                         "(the reference raises here: torch.ones(negative), utils.py:415)", ov, P);
+    for (int i = 0; i < P; ++i)
+        h_profile[i] = i < ov ? lin_host(0.1f, 1.0f, ov, i)
+                     : (i < P - ov ? 1.0f : lin_host(1.0f, 0.1f, ov, i - (P - ov)));
+    return INNFER_OK;
+}
+
+extern "C" int innfer_recompose(const void* d_tiles, int dtype, int n, int C, int P, int height, int width,
+                                double step, int scale, void* d_out, int out_dtype, void* stream) {
+    if (step < 0.5 || step > 1.0) return set_error(INNFER_ERR_INVALID, "recompose: step must be in [0.5,1]");
+    if (n <= 0 || C <= 0 || P <= 0 || scale <= 0) return set_error(INNFER_ERR_INVALID, "recompose: bad sizes");
+    const int FH = scale * height, FW = scale * width;
+    if (FH < P || FW < P) return set_error(INNFER_ERR_INVALID, "recompose: patch %d larger than output %dx%d", P, FH, FW);
+    const int ov = blend_overlap(P, step, scale);
+    if (P - 2 * ov < 0)
+        return set_error(INNFER_ERR_INVALID, "recompose: overlap %d exceeds half of patch %d (reference raises too)", ov, P);
+    const int eff = (int)(step * P), step_int = (int)(P * step);
+    const int nh = 1 + (FH - P) / step_int + ((FH - P) % step_int != 0);
+    const int nw = 1 + (FW - P) / step_int + ((FW - P) % step_int != 0);
+    if (n % (nh * nw)) return set_error(INNFER_ERR_INVALID, "recompose: %d tiles is not a multiple of %dx%d", n, nh, nw);
+    const int nb = n / (nh * nw);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((FW + 255) / 256, FH, nb), block(256);
+#define RC(TI, TO) hipLaunchKernelGGL((k_recompose<TI, TO>), grid, block, 0, s, (const TI*)d_tiles, (TO*)d_out, C, P, FH, FW, eff, nh, nw, ov)
+    if (dtype == INNFER_F16 && out_dtype == INNFER_F16) RC(f16, f16);
+    else if (dtype == INNFER_F16 && out_dtype == INNFER_F32) RC(f16, float);
+    else if (dtype == INNFER_F32 && out_dtype == INNFER_F32) RC(float, float);
+    else if (dtype == INNFER_F32 && out_dtype == INNFER_F16) RC(float, f16);
+    else return set_error(INNFER_ERR_INVALID, "recompose: bad dtype");
+#undef RC
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_u8hwc_to_nchw(const uint8_t* d_img, int H, int W, int C, int normalize,
+                                    void* d_out, int out_dtype, void* stream) {
+    const long hw = (long)H * W;
+    if (hw <= 0 || C <= 0) return set_error(INNFER_ERR_INVALID, "u8hwc_to_nchw: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == INNFER_F16) hipLaunchKernelGGL(k_u8_to_nchw<f16>, dim3(blocks(hw, 256)), dim3(256), 0, s, d_img, (f16*)d_out, hw, C, normalize);
+    else if (out_dtype == INNFER_F32) hipLaunchKernelGGL(k_u8_to_nchw<float>, dim3(blocks(hw, 256)), dim3(256), 0, s, d_img, (float*)d_out, hw, C, normalize);
+    else return set_error(INNFER_ERR_INVALID, "u8hwc_to_nchw: bad dtype");
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_nchw_to_u8hwc(const void* d_in, int in_dtype, int H, int W, int C, int denormalize,
+                                    uint8_t* d_img, void* stream) {
+    const long hw = (long)H * W;
+    if (hw <= 0 || C <= 0) return set_error(INNFER_ERR_INVALID, "nchw_to_u8hwc: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == INNFER_F16) hipLaunchKernelGGL(k_nchw_to_u8<f16>, dim3(blocks(hw, 256)), dim3(256), 0, s, (const f16*)d_in, d_img, hw, C, denormalize);
+    else if (in_dtype == INNFER_F32) hipLaunchKernelGGL(k_nchw_to_u8<float>, dim3(blocks(hw, 256)), dim3(256), 0, s, (const float*)d_in, d_img, hw, C, denormalize);
+    else return set_error(INNFER_ERR_INVALID, "nchw_to_u8hwc: bad dtype");
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}

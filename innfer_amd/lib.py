@@ -1,0 +1,127 @@
+"""ctypes binding of libinnfer_amd.so (the C ABI declared in include/innfer_amd.h).
+
+The library is the product: there is NO fallback.  If the shared object is
+missing the import of this module raises; if a call fails the Python side
+raises the exception class the reference would have raised for the same
+condition (ValueError / NotImplementedError / RuntimeError).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libinnfer_amd.so")
+
+F16, F32 = 0, 1
+OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM, ERR_WORKSPACE = 0, -1, -2, -3, -4, -5
+
+
+class InnferError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "innfer_amd has no CPU or PyTorch fallback for its hot path.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; it must be the ONE HIP runtime of the
+    # process (device pointers, streams and events are shared with torch), so torch is imported
+    # first and libinnfer_amd.so's NEEDED libamdhip64.so.7 binds to the copy already loaded.
+    import torch  # noqa: F401
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load()
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("d_in", C.c_void_p), ("in_stride", C.c_int), ("C", C.c_int),
+        ("d_packed", C.c_void_p), ("d_bias", C.c_void_p),
+        ("d_out", C.c_void_p), ("out_stride", C.c_int), ("out_ch_off", C.c_int), ("K", C.c_int),
+        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("act", C.c_int), ("upsample2x", C.c_int),
+        ("d_res1", C.c_void_p), ("res1_stride", C.c_int), ("res1_scale", C.c_float),
+        ("d_res2", C.c_void_p), ("res2_stride", C.c_int), ("res2_scale", C.c_float),
+        ("row_begin", C.c_int), ("row_end", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/innfer_amd.h
+SIGNATURES = {
+    "innfer_version": (C.c_int, []),
+    "innfer_last_error": (C.c_char_p, []),
+    "innfer_rrdbnet_create": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 7),
+    "innfer_srresnet_create": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 5),
+    "innfer_net_destroy": (None, [C.c_void_p]),
+    "innfer_net_num_convs": (C.c_int, [C.c_void_p]),
+    "innfer_net_conv_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_net_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "innfer_net_scale": (C.c_int, [C.c_void_p]),
+    "innfer_net_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "innfer_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "innfer_net_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                           C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_net_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "innfer_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "innfer_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "innfer_conv3x3_f16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "innfer_nchw_to_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "innfer_slab_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "innfer_chop_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
+    "innfer_extract_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "innfer_blend_profile": (C.c_int, [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_float)]),
+    "innfer_recompose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "innfer_u8hwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "innfer_nchw_to_u8hwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_lib, _name)          # AttributeError here = header/library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+lib = _lib
+
+
+def last_error():
+    return _lib.innfer_last_error().decode(errors="replace")
+
+
+def check(rc):
+    """Map a status code to the exception the reference raises for that condition."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise InnferError(f"innfer_amd status {rc}: {msg}")
+
+
+def chop_plan(H, W, patch=200, step=0.5):
+    """(ps, ys, xs): host-side tile geometry."""
+    ps, nh, nw = C.c_int(), C.c_int(), C.c_int()
+    check(_lib.innfer_chop_plan(H, W, patch, step, C.byref(ps), C.byref(nh), C.byref(nw), None, None))
+    ys, xs = (C.c_int * nh.value)(), (C.c_int * nw.value)()
+    check(_lib.innfer_chop_plan(H, W, patch, step, C.byref(ps), C.byref(nh), C.byref(nw), ys, xs))
+    return ps.value, list(ys), list(xs)
+
+
+def blend_profile(P, step=0.5, scale=1):
+    import numpy as np
+    buf = (C.c_float * P)()
+    check(_lib.innfer_blend_profile(P, step, scale, buf))
+    return np.frombuffer(buf, dtype=np.float32).copy()

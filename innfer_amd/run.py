@@ -1,0 +1,140 @@
+"""Mirror of the reference's `Model` wrapper (run.py:23-225): .pth loading with
+architecture / scale inference, and `Model.__call__` -> chop_forward.
+
+Differences that are the point of this build:
+  * the network forward, tile extraction and blend run in HIP (libinnfer_amd.so);
+  * chop tiles are pushed through the network in BATCHES (the reference loops
+    batch-1 and calls empty_cache() per tile, run.py:186-197); per-tile results
+    are identical because tiles are independent;
+  * with torch.distributed initialised, tiles can be sharded over ranks and
+    gathered on rank 0 (parallel.py).
+There is no CPU execution path: device must be a GPU.
+"""
+import torch
+
+from .architectures import get_network
+from .utils.defaults import get_network_G_config
+from .utils.utils import extract_patches_2d, mod2normal, recompose_tensor, swa2normal
+
+# families the HIP engine implements; the other branches of the reference's key
+# sniffing are recognised and refused explicitly
+_SNIFF = (
+    ('SCPA_trunk.0.conv1_a.weight', 'pan'),
+    ('model.1.sub.0.res.0.weight', 'srgan'),
+    ('conv_first.weight', 'mesrgan'),
+    ('model.0.weight', 'esrgan'),
+    ('CFEM.0.weight', 'ppon'),
+    ('conv_9.weight', 'wbcunet'),
+)
+
+
+def infer_from_state_dict(state_dict):
+    """Architecture, scale and hyper-parameters from a checkpoint's key names and
+    shapes -- host logic of Model.load_model / infer_params (run.py:44-72,103-165).
+    Returns dict(arch, scale, in_nc, out_nc, nf, nb, plus, net_params, state_dict)
+    where state_dict has been SWA-unwrapped / converted to old-arch keys."""
+    if 'n_averaged' in state_dict:
+        state_dict = swa2normal(state_dict)
+    for probe, arch in _SNIFF:
+        if probe in state_dict:
+            break
+    else:
+        raise Exception("Could not infer model parameters.")
+    if arch == 'mesrgan':                    # new-arch checkpoints run as old-arch (run.py:57-61)
+        state_dict = mod2normal(state_dict)
+        arch = 'esrgan'
+    if arch not in ('esrgan', 'srgan'):
+        raise NotImplementedError(f"'{arch}' checkpoints are recognised but not on the HIP path yet")
+    top = {}                                 # N -> out channels of 'model.N.weight|bias'
+    nb = None
+    n_2x = 0
+    for key, val in state_dict.items():
+        parts = key.split('.')
+        if len(parts) == 5 and parts[2] == 'sub':
+            nb = int(parts[3])               # the trunk conv sits right after the last block
+        elif len(parts) == 3:
+            n = int(parts[1])
+            top.setdefault(n, val.shape[0])
+            if n > 6 and parts[0] == 'model' and parts[2] == 'weight':
+                n_2x += 1                    # every top-level conv past index 6 = one 2x stage
+    w0 = state_dict['model.0.weight']
+    info = dict(arch=arch, scale=2 ** n_2x, in_nc=int(w0.shape[1]), out_nc=int(top[max(top)]),
+                nf=int(w0.shape[0]), nb=nb, plus=False, state_dict=state_dict)
+    cfg = {'type': arch, 'in_nc': info['in_nc'], 'out_nc': info['out_nc'], 'nf': info['nf'], 'nb': nb}
+    if arch == 'esrgan':
+        info['plus'] = any('conv1x1' in k for k in state_dict)
+        cfg['plus'] = info['plus']
+    info['net_params'] = get_network_G_config(cfg, info['scale'])
+    return info
+
+
+class Model:
+    def __init__(self, model_path, arch=None, scale=None, in_nc=3, out_nc=3, device='cuda',
+                 meval=True, strict=True, chop=True, tile_batch=32, state_dict=None):
+        self.model_path = model_path
+        self.arch = arch
+        self.scale = scale
+        self.in_nc = in_nc
+        self.out_nc = out_nc
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError("innfer_amd.Model needs device='cuda' (MI355X); the reference's -cpu mode "
+                               "is not accelerated here and is not silently emulated")
+        self.model = None
+        self.eval = meval
+        self.strict = strict
+        self.chop = chop
+        self.tile_batch = tile_batch
+        self.load_model(state_dict)
+
+    # ------------------------------------------------------------- loading
+    def load_model(self, state_dict=None):
+        if self.arch == 'ts':
+            raise NotImplementedError('TorchScript models are opaque graphs and cannot run on the HIP engine')
+        if state_dict is None:
+            state_dict = torch.load(self.model_path, map_location='cpu')
+        if self.arch == 'infer':
+            info = infer_from_state_dict(state_dict)
+            state_dict = info['state_dict']
+            self.arch, self.scale = info['arch'], info['scale']
+            self.in_nc, self.out_nc = info['in_nc'], info['out_nc']
+            net_params = info['net_params']
+        else:
+            if 'n_averaged' in state_dict:
+                state_dict = swa2normal(state_dict)
+            if not self.scale:
+                self.scale = 1
+            net_params = get_network_G_config({'type': self.arch}, self.scale)
+        net = get_network(net_params)
+        net.load_state_dict(state_dict, strict=self.strict)
+        for p in net.parameters():
+            p.requires_grad = False
+        if self.eval:
+            net.eval()
+        self.model = net.to(self.device)
+
+    def infer_params(self, state_dict):
+        return infer_from_state_dict(state_dict)['net_params']
+
+    # ------------------------------------------------------------- forward
+    def chop_forward(self, data, patch_size=200, step=1.0, tile_range=None):
+        """Tile, run, blend (run.py:167-202).  tile_range=(begin,count) runs a
+        sub-range of tiles and returns the raw HR tiles instead of the blend."""
+        _, _, H, W = data.shape
+        patch_size = min(H, W, patch_size)
+        tiles = extract_patches_2d(data, (patch_size, patch_size), [step, step], batch_first=True,
+                                   tile_range=tile_range).squeeze(0)
+        outs = []
+        with torch.no_grad():
+            for i in range(0, tiles.shape[0], self.tile_batch):
+                outs.append(self.model(tiles[i:i + self.tile_batch]))
+        hr = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
+        if tile_range is not None:
+            return hr
+        return recompose_tensor(hr, H, W, step=step, scale=self.scale)
+
+    def __call__(self, data):
+        if self.chop:
+            return self.chop_forward(data, patch_size=200, step=0.5)
+        with torch.no_grad():
+            return self.model(data)

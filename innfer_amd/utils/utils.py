@@ -1,0 +1,162 @@
+"""Mirror of the hot-path functions of the reference's utils/utils.py, backed by
+HIP kernels (csrc/tiles.hip) through the C ABI:
+
+    extract_patches_2d / recompose_tensor   utils/utils.py:318-369 / 372-445
+    np2tensor / tensor2np                   utils/utils.py:164-194 / 197-248
+    mod2normal / swa2normal                 utils/utils.py:666-698 / 701-720 (host, key renaming)
+
+Same names, argument meaning and error behaviour.  Tensors must live on the
+GPU; there is no CPU fallback.
+"""
+import numpy as np
+import torch
+
+from .. import lib as L
+
+
+def _dt(t):
+    if t.dtype == torch.float16:
+        return L.F16
+    if t.dtype == torch.float32:
+        return L.F32
+    raise TypeError(f'unsupported dtype {t.dtype}')
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f'{what}: tensor must be on the GPU (innfer_amd has no CPU path)')
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def extract_patches_2d(img, patch_shape, step=None, batch_first=False, tile_range=None):
+    """[1,C,H,W] -> [n,1,C,ph,pw] ([1,n,C,ph,pw] when batch_first): sliding tiles
+    with stride int(patch*step) plus a ragged last row/column (utils.py:318-369).
+    tile_range=(begin,count) extracts a contiguous sub-range (multi-GPU sharding)."""
+    if step is None:
+        step = [1.0, 1.0]
+    _need_cuda(img, 'extract_patches_2d')
+    B, C, H, W = img.shape
+    ph, pw = patch_shape
+    if B != 1:
+        raise NotImplementedError('extract_patches_2d: batch > 1 (run.py only ever passes batch 1)')
+    if ph != pw or step[0] != step[1] or not isinstance(step[0], float):
+        raise NotImplementedError('extract_patches_2d: square patches with one fractional step only (chop_forward usage)')
+    if H < ph or W < pw:
+        # the reference's pad branch dereferences an undefined name `nn` (utils.py:341,346)
+        raise NameError("name 'nn' is not defined")
+    ps, ys, xs = L.chop_plan(H, W, ph, step[0])
+    n = len(ys) * len(xs)
+    begin, count = tile_range if tile_range is not None else (0, n)
+    img = img.contiguous()
+    tiles = torch.empty((count, C, ps, ps), dtype=img.dtype, device=img.device)
+    L.check(L.lib.innfer_extract_tiles(img.data_ptr(), _dt(img), C, H, W, ph, step[0], begin, count,
+                                       tiles.data_ptr(), _stream(img)))
+    out = tiles.unsqueeze(1)                       # [n, B=1, C, ph, pw]
+    return out.permute(1, 0, 2, 3, 4) if batch_first else out
+
+
+def recompose_tensor(patches, height, width, step=None, scale=1, out_dtype=None):
+    """Weighted overlap blend of [n,C,P,P] tiles into [n/(nh*nw),C,scale*H,scale*W]
+    (utils.py:372-445).  fp32 accumulation in the reference's tile order."""
+    if step is None:
+        step = [1.0, 1.0]
+    assert isinstance(step, float) and step >= 0.5 and step <= 1.0
+    _need_cuda(patches, 'recompose_tensor')
+    patches = patches.contiguous()
+    n, C, P, P2 = patches.shape
+    assert P == P2
+    FH, FW = scale * height, scale * width
+    eff = int(P * step)
+    nh = 1 + (max(FH, P) - P) // eff + (1 if (max(FH, P) - P) % eff else 0)
+    nw = 1 + (max(FW, P) - P) // eff + (1 if (max(FW, P) - P) % eff else 0)
+    nb = n // (nh * nw)
+    dtype = out_dtype or patches.dtype
+    out = torch.empty((nb, C, FH, FW), dtype=dtype, device=patches.device)
+    odt = L.F16 if dtype == torch.float16 else L.F32
+    L.check(L.lib.innfer_recompose(patches.data_ptr(), _dt(patches), n, C, P, height, width, float(step), scale,
+                                   out.data_ptr(), odt, _stream(patches)))
+    return out
+
+
+def np2tensor(img, bgr2rgb=True, data_range=1., normalize=False, change_range=True, add_batch=True,
+              device='cuda', dtype=torch.float32):
+    """uint8 HWC BGR(A) image -> [1,C,H,W] RGB(A) float tensor ON THE GPU
+    (utils.py:164-194): the uint8 image crosses PCIe (4x fewer bytes than fp32) and
+    /255, HWC->CHW, channel flip and optional [-1,1] norm run in one HIP kernel."""
+    if not isinstance(img, np.ndarray):
+        raise TypeError("Got unexpected object type, expected np.ndarray")
+    if img.dtype != np.uint8 or img.ndim != 3 or not (bgr2rgb and change_range and add_batch):
+        raise NotImplementedError('np2tensor: only uint8 HWC images with the default flags are built')
+    H, W, Cc = img.shape
+    d_img = torch.from_numpy(np.ascontiguousarray(img)).to(device)
+    out = torch.empty((1, Cc, H, W), dtype=dtype, device=d_img.device)
+    L.check(L.lib.innfer_u8hwc_to_nchw(d_img.data_ptr(), H, W, Cc, int(bool(normalize)), out.data_ptr(),
+                                       _dt(out), _stream(out)))
+    return out
+
+
+def tensor2np(img, rgb2bgr=True, remove_batch=True, data_range=255, denormalize=False,
+              change_range=True, imtype=np.uint8):
+    """[1,C,H,W] RGB float GPU tensor -> HWC BGR uint8 numpy (utils.py:197-248);
+    clip*255 and round-half-to-even on the GPU, one uint8 D2H copy."""
+    if not isinstance(img, torch.Tensor):
+        raise TypeError("Got unexpected object type, expected torch.Tensor")
+    if img.dim() != 4 or img.shape[0] != 1:
+        raise TypeError(f'Only 4D [1,C,H,W] tensors are built. But received with dimension: {img.dim():d}')
+    if not (rgb2bgr and remove_batch and change_range) or data_range != 255 or imtype != np.uint8:
+        raise NotImplementedError('tensor2np: only the default flags are built')
+    _need_cuda(img, 'tensor2np')
+    img = img.contiguous()
+    _, Cc, H, W = img.shape
+    out = torch.empty((H, W, Cc), dtype=torch.uint8, device=img.device)
+    L.check(L.lib.innfer_nchw_to_u8hwc(img.data_ptr(), _dt(img), H, W, Cc, int(bool(denormalize)),
+                                       out.data_ptr(), _stream(img)))
+    return out.cpu().numpy()
+
+
+# --------------------------------------------------------------- key converters
+_NEW2OLD_FIXED = (('conv_first', 'model.0'), ('trunk_conv', 'model.1.sub.23'), ('upconv1', 'model.3'),
+                  ('upconv2', 'model.6'), ('HRconv', 'model.8'), ('conv_last', 'model.10'))
+
+
+def mod2normal(state_dict):
+    """New-arch ESRGAN keys (conv_first / RRDB_trunk.N.RDBk.convj / trunk_conv /
+    upconv1,2 / HRconv / conv_last) -> old-arch keys (utils.py:666-698).  Like the
+    reference this assumes the 23-block 4x layout ('model.1.sub.23', 'model.3' ...)."""
+    if 'conv_first.weight' not in state_dict:
+        return state_dict
+    print('Converting and loading a modified RRDB model to normal RRDB')
+    out = {}
+    for new, old in _NEW2OLD_FIXED[:1]:
+        for p in ('weight', 'bias'):
+            out[f'{old}.{p}'] = state_dict[f'{new}.{p}']
+    for k, v in state_dict.items():
+        if 'RDB' in k:
+            k2 = k.replace('RRDB_trunk.', 'model.1.sub.')
+            if '.weight' in k:
+                k2 = k2.replace('.weight', '.0.weight')
+            elif '.bias' in k:
+                k2 = k2.replace('.bias', '.0.bias')
+            out[k2] = v
+    for new, old in _NEW2OLD_FIXED[1:]:
+        for p in ('weight', 'bias'):
+            out[f'{old}.{p}'] = state_dict[f'{new}.{p}']
+    return out
+
+
+def swa2normal(state_dict):
+    """Unwrap a torch.optim.swa_utils.AveragedModel checkpoint: keep only
+    'module.module.*' entries, stripped of that prefix (utils.py:701-720)."""
+    if 'n_averaged' not in state_dict:
+        return state_dict
+    print('Attempting to convert a SWA model to a regular model\n')
+    out = {}
+    for k, v in state_dict.items():
+        if 'n_averaged' in k:
+            print('n_averaged: {}'.format(v))
+        elif 'module.module.' in k:
+            out[k.replace('module.module.', '')] = v
+    return out

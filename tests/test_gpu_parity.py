@@ -1,0 +1,346 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden
+vectors generated from the reference.  Needs an MI355X: `pytest -m gpu`.
+
+Tolerances:
+  fp16 HIP path vs fp32 oracle / golden .......... max-abs <= 1e-2 on O(1) outputs
+  fp16 HIP path vs the reference's own fp16 mode . max-abs <= 4e-3 (golden G11)
+  tiles, blend (fp32), uint8 pre/post, geometry .. bit-exact
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _sd(shapes, seed=0):
+    from innfer_amd import synth
+    return {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed).items()}
+
+
+# ------------------------------------------------------------------ single conv
+def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0,
+              in_extra=0, out_stride=None, out_off=0, rows=None):
+    """x [N,C,Hs,Ws] fp16 (cpu), w [K,C,3,3] fp32, returns NCHW fp32 (cpu) of the HIP conv."""
+    import innfer_amd.lib as L
+    N, Cc, Hs, Ws = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up else (Hs, Ws)
+    in_stride = Cc + in_extra
+    out_stride = out_stride or K
+    slab = torch.full((N, Hs, Ws, in_stride), 7.0, dtype=torch.float16, device=dev)   # junk in unused channels
+    L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), in_stride, 0,
+                                      N, Cc, Hs, Ws, None))
+    nbytes = L.lib.innfer_conv3x3_packed_bytes(K, Cc)
+    packed = np.zeros(nbytes, dtype=np.uint8)
+    wc = np.ascontiguousarray(w.numpy())
+    L.check(L.lib.innfer_pack_conv3x3(wc.ctypes.data, K, Cc, packed.ctypes.data))
+    d_packed = torch.from_numpy(packed).to(dev)
+    d_bias = b.float().to(dev)
+    out = torch.full((N, H, W, out_stride), -3.0, dtype=torch.float16, device=dev)
+    a = L.ConvArgs()
+    a.d_in, a.in_stride, a.C = slab.data_ptr(), in_stride, Cc
+    a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
+    a.d_out, a.out_stride, a.out_ch_off, a.K = out.data_ptr(), out_stride, out_off, K
+    a.N, a.H, a.W, a.act, a.upsample2x = N, H, W, act, int(up)
+    keep = [slab, d_packed, d_bias]
+    for name, r, sc in (("1", res1, s1), ("2", res2, s2)):
+        if r is not None:
+            rs = torch.empty((N, H, W, K), dtype=torch.float16, device=dev)
+            L.check(L.lib.innfer_nchw_to_slab(r.to(dev).contiguous().data_ptr(), L.F16, rs.data_ptr(), K, 0, N, K, H, W, None))
+            setattr(a, f"d_res{name}", rs.data_ptr()); setattr(a, f"res{name}_stride", K); setattr(a, f"res{name}_scale", sc)
+            keep.append(rs)
+    if rows:
+        a.row_begin, a.row_end = rows
+    L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
+    torch.cuda.synchronize()
+    res = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
+    L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), out_stride, out_off, res.data_ptr(), L.F32, N, K, H, W, None))
+    torch.cuda.synchronize()
+    return res.cpu(), out.cpu()
+
+
+def _ref_conv(x, w, b, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0):
+    xx = x.float()
+    if up:
+        xx = F.interpolate(xx, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xx, w.half().float(), b.float(), padding=1)
+    if act == 1:
+        y = F.leaky_relu(y, 0.2)
+    elif act == 2:
+        y = F.relu(y)
+    if res1 is not None:
+        y = y * s1 + res1.float()
+    if res2 is not None:
+        y = y * s2 + res2.float()
+    return y
+
+
+@pytest.mark.parametrize("Cc,K,H,W,N", [
+    (64, 32, 16, 32, 1), (96, 32, 37, 45, 2), (128, 32, 8, 70, 1), (160, 32, 33, 33, 1),
+    (192, 64, 21, 50, 2), (64, 64, 16, 16, 1), (64, 16, 19, 40, 1), (32, 32, 5, 3, 1), (64, 64, 1, 1, 1),
+])
+def test_conv_shapes(dev, Cc, K, H, W, N):
+    from innfer_amd import synth
+    x = torch.from_numpy(synth.uniform((N, Cc, H, W), 1, -1, 1)).half()
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 2, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.from_numpy(synth.uniform((K,), 3, -1, 1))
+    got, _ = _run_conv(dev, x, w, b, K, act=1, in_extra=32)
+    ref = _ref_conv(x, w, b, act=1)
+    assert (got - ref).abs().max().item() < 4e-3
+
+
+def test_conv_epilogues_and_slab_offsets(dev):
+    from innfer_amd import synth
+    N, Cc, K, H, W = 1, 192, 64, 20, 36
+    x = torch.from_numpy(synth.uniform((N, Cc, H, W), 4, -1, 1)).half()
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 5, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.from_numpy(synth.uniform((K,), 6, -1, 1))
+    r1 = torch.from_numpy(synth.uniform((N, K, H, W), 7, -1, 1)).half()
+    r2 = torch.from_numpy(synth.uniform((N, K, H, W), 8, -1, 1)).half()
+    got, raw = _run_conv(dev, x, w, b, K, act=0, res1=r1, s1=0.2, res2=r2, s2=0.2, out_stride=192, out_off=64)
+    ref = _ref_conv(x, w, b, act=0, res1=r1, s1=0.2, res2=r2, s2=0.2)
+    assert (got - ref).abs().max().item() < 4e-3
+    # channels outside [64,128) of the output slab are untouched (dense concat = channel offset)
+    assert torch.all(raw[..., :64] == -3.0) and torch.all(raw[..., 128:] == -3.0)
+    got, _ = _run_conv(dev, x, w, b, K, act=2)
+    assert (got - _ref_conv(x, w, b, act=2)).abs().max().item() < 4e-3
+
+
+def test_conv_nearest_upsample_fused(dev):
+    from innfer_amd import synth
+    N, Cc, K, Hs, Ws = 1, 64, 64, 13, 21
+    x = torch.from_numpy(synth.uniform((N, Cc, Hs, Ws), 9, -1, 1)).half()
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 10, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.from_numpy(synth.uniform((K,), 11, -1, 1))
+    got, _ = _run_conv(dev, x, w, b, K, act=1, up=True)
+    assert (got - _ref_conv(x, w, b, act=1, up=True)).abs().max().item() < 4e-3
+
+
+def test_conv_row_range(dev):
+    from innfer_amd import synth
+    N, Cc, K, H, W = 1, 64, 32, 50, 40
+    x = torch.from_numpy(synth.uniform((N, Cc, H, W), 12, -1, 1)).half()
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 13, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.zeros(K)
+    full, _ = _run_conv(dev, x, w, b, K)
+    part, raw = _run_conv(dev, x, w, b, K, rows=(7, 29))
+    assert torch.equal(part[:, :, 7:29], full[:, :, 7:29])
+    assert torch.all(raw[:, :7] == -3.0) and torch.all(raw[:, 29:] == -3.0)
+
+
+def test_conv_error_codes(dev):
+    import innfer_amd.lib as L
+    a = L.ConvArgs()
+    assert L.lib.innfer_conv3x3_f16(C.byref(a), None) == L.ERR_INVALID
+    with pytest.raises(ValueError):
+        L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
+    assert L.lib.innfer_conv3x3_packed_bytes(32, 48) == 0
+
+
+# -------------------------------------------------------------------- networks
+def _rrdb(dev, nb, scale, seed=0):
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    sd = _sd(synth.rrdbnet_shapes(nb=nb, scale=scale), seed)
+    net = RRDBNet(3, 3, 64, nb, upscale=scale)
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev).eval(), sd
+
+
+def test_rrdbnet23_x4_golden(dev, golden):
+    from innfer_amd import synth
+    g3, g11 = golden("g3_rrdbnet23_x4"), golden("g11_rrdbnet23_x4_fp16")
+    net, _ = _rrdb(dev, 23, 4)
+    for tag, shape, seed in (("out_32", (1, 3, 32, 32), 3), ("out_16", (1, 3, 16, 16), 4)):
+        x = torch.from_numpy(synth.uniform(shape, seed)).to(dev)
+        y = net(x.half()).float().cpu().numpy()
+        assert np.isfinite(y).all()
+        e32 = np.abs(y - g3[tag]).max()
+        e16 = np.abs(y - g11[tag]).max()
+        assert e32 < 1e-2, f"{tag}: vs fp32 reference {e32}"
+        assert e16 < 4e-3, f"{tag}: vs the reference's fp16 mode {e16}"
+        # and at least as close to the fp32 truth as the reference's own fp16 mode is (x1.5 slack)
+        assert e32 <= 1.5 * np.abs(g11[tag] - g3[tag]).max() + 1e-4
+        y32 = net(x).float().cpu().numpy()          # fp32 I/O, fp16 internals
+        assert np.abs(y32 - g3[tag]).max() < 1e-2
+
+
+def test_rrdbnet_scales_golden(dev, golden):
+    from innfer_amd import synth
+    g = golden("g5_scales")
+    x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 5)).to(dev).half()
+    for scale in (1, 2, 8):
+        net, _ = _rrdb(dev, 1, scale)
+        y = net(x).float().cpu().numpy()
+        assert y.shape == g[f"out_x{scale}"].shape
+        assert np.abs(y - g[f"out_x{scale}"]).max() < 5e-3, scale
+
+
+def test_rrdbnet_batch_and_ragged_sizes(dev):
+    import oracle
+    from innfer_amd import synth
+    net, sd = _rrdb(dev, 2, 4)
+    x = torch.from_numpy(synth.uniform((3, 3, 37, 53), 21))
+    y = net(x.to(dev).half()).float().cpu()
+    with torch.no_grad():
+        ref = oracle.rrdbnet_forward(sd, x, nb=2, scale=4)
+    assert (y - ref).abs().max().item() < 1e-2
+    y0 = net(x[1:2].to(dev).half()).float().cpu()
+    assert torch.equal(y0, y[1:2])                 # batching does not change a tile's result
+
+
+def test_forward_does_not_depend_on_workspace_contents(dev):
+    """Every byte the kernels read was written by an earlier launch of the same forward:
+    poisoning the workspace (NaN patterns) must not change the result."""
+    from innfer_amd import synth
+    net, _ = _rrdb(dev, 1, 4)
+    x = torch.from_numpy(synth.uniform((2, 3, 21, 45), 23)).to(dev).half()
+    y = net(x)
+    assert torch.isfinite(y).all()
+    net._ws.fill_(0xFF)
+    y2 = net(x)
+    assert torch.equal(y, y2)
+
+
+def test_rrdbnet_banded_schedule_is_identical(dev):
+    from innfer_amd import synth
+    net, _ = _rrdb(dev, 2, 2)
+    x = torch.from_numpy(synth.uniform((1, 3, 150, 70), 22)).to(dev).half()
+    y = net(x)
+    for rows in (16, 37, 64):
+        net.band_rows = rows
+        assert torch.equal(net(x), y), rows
+    net.band_rows = 0
+
+
+def test_srresnet_golden(dev, golden):
+    from innfer_amd import synth
+    from innfer_amd.architectures.SRResNet_arch import SRResNet
+    g = golden("g6_srgan")
+    sd = _sd(synth.srresnet_shapes(nb=16, scale=4))
+    net = SRResNet(3, 3, 64, 16, upscale=4, norm_type=None, act_type='relu', mode='CNA',
+                   upsample_mode='pixelshuffle')
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 24, 24), 6)).to(dev).half()
+    y = net(x).float().cpu().numpy()
+    assert np.abs(y - g["out_24"]).max() < 1e-2
+
+
+def test_missing_weights_and_cpu_are_loud(dev):
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    net = RRDBNet(3, 3, 64, 1, upscale=2)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 8, 8))               # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        RRDBNet(3, 3, 64, 1, plus=True)
+
+
+# ---------------------------------------------------------- tiles / blend / io
+def test_extract_and_blend_bit_exact(dev, golden):
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.utils import utils as U
+    g = golden("g2_blend")
+    for scale in (1, 2, 4):
+        h, w = 250, 330
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), 100 + scale))
+        tiles = U.extract_patches_2d(x.to(dev), (200, 200), [0.5, 0.5], batch_first=True).squeeze(0)
+        assert torch.equal(tiles.cpu(), oracle.extract_patches_2d(x, (200, 200), [0.5, 0.5], batch_first=True).squeeze(0))
+        up = F.interpolate(tiles, scale_factor=float(scale), mode="nearest") if scale > 1 else tiles
+        k = torch.arange(up.shape[0], dtype=torch.float32, device=dev)[:, None, None, None]
+        r = U.recompose_tensor(up * (1.0 + k / 16.0), h, w, step=0.5, scale=scale).cpu()
+        assert np.array_equal(r[0, :, ::7, ::5].numpy(), g[f"blend_s{scale}_sub"])
+        assert r.double().sum().item() == g[f"blend_s{scale}_sum"]
+    x = torch.from_numpy(synth.uniform((1, 3, 150, 250), 77))
+    p = U.extract_patches_2d(x.to(dev), (150, 150), [0.5, 0.5], batch_first=True).squeeze(0)
+    k = torch.arange(p.shape[0], dtype=torch.float32, device=dev)[:, None, None, None]
+    r = U.recompose_tensor(p * (1.0 + k / 16.0), 150, 250, step=0.5, scale=1).cpu()
+    assert np.array_equal(r[0].numpy(), g["blend_150x250"])
+    # odd small patch: the reference raises (torch.ones(negative)); so do we
+    with pytest.raises(ValueError):
+        U.recompose_tensor(torch.zeros(2, 3, 151, 151, device=dev), 151, 250, step=0.5, scale=1)
+
+
+def test_blend_identity_at_full_size(dev):
+    """Size-independent property at the 8K-input tile count (3268 tiles of 200x200, scale 1):
+    recompose(extract(x)) == x up to fp32 rounding."""
+    from innfer_amd.utils import utils as U
+    h, w = 4320, 7680
+    x = torch.rand((1, 3, h, w), device=dev)
+    tiles = U.extract_patches_2d(x, (200, 200), [0.5, 0.5], batch_first=True).squeeze(0)
+    assert tiles.shape[0] == 3268
+    r = U.recompose_tensor(tiles, h, w, step=0.5, scale=1)
+    assert (r - x).abs().max().item() <= 3e-7
+
+
+def test_pre_post_bit_exact(dev, golden):
+    from innfer_amd import synth
+    from innfer_amd.utils import utils as U
+    g = golden("g9_convert")
+    assert np.array_equal(U.np2tensor(g["ramp"]).cpu().numpy(), g["np2t"])
+    assert np.array_equal(U.np2tensor(g["ramp"], normalize=True).cpu().numpy(), g["np2t_norm"])
+    th = torch.from_numpy(g["t2np_in"]).to(dev)
+    assert np.array_equal(U.tensor2np(th), g["t2np"])
+    assert np.array_equal(U.tensor2np(th * 2 - 1, denormalize=True), g["t2np_denorm"])
+    assert np.array_equal(U.tensor2np(torch.from_numpy(g["big_in"]).to(dev)), g["big_u8"])
+    img = synth.image_u8(270, 481, 3, 5)
+    assert np.array_equal(U.tensor2np(U.np2tensor(img)), img)               # exact uint8 round trip
+    assert np.array_equal(U.tensor2np(U.np2tensor(img, dtype=torch.float16)), img)
+    img4 = synth.image_u8(17, 9, 4, 6)
+    t4 = U.np2tensor(img4).cpu().numpy()[0]
+    assert np.array_equal(t4, (img4.astype(np.float32) / 255).transpose(2, 0, 1)[[2, 1, 0, 3]])
+
+
+# ---------------------------------------------------------------- Model / chop
+def test_model_chop_golden(dev, golden, tmp_path):
+    from innfer_amd import synth
+    from innfer_amd.run import Model
+    g = golden("g4_chop")
+    for (nb, scale, h, w, tag) in [(2, 4, 250, 330, "x4_250x330"), (1, 2, 201, 640, "x2_201x640"),
+                                   (1, 1, 150, 250, "x1_150x250")]:
+        sd = _sd(synth.rrdbnet_shapes(nb=nb, scale=scale))
+        path = str(tmp_path / f"{scale}x_{tag}.pth")
+        torch.save(sd, path)
+        m = Model(path, arch="infer", scale=None, device="cuda", chop=True, tile_batch=4)
+        assert (m.arch, m.scale) == ("esrgan", scale)
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), 40 + scale)).to(dev).half()
+        y = m(x).float().cpu()
+        assert tuple(y.shape) == (1, 3, h * scale, w * scale)
+        assert np.abs(y[0, :, ::8, ::8].numpy() - g[f"chop_{tag}_sub"]).max() < 1e-2
+        assert np.abs(y[0, :, -32:, -32:].numpy() - g[f"chop_{tag}_crop_b"]).max() < 1e-2
+        m2 = Model(path, arch="infer", device="cuda", chop=False)
+        y2 = m2(x).float().cpu()
+        assert np.abs(y2[0, :, ::8, ::8].numpy() - g[f"nochop_{tag}_sub"]).max() < 1e-2
+
+
+def test_full_frame_1080p_translation_property(dev):
+    """BASELINE config 2 size (1x3x1080x1920 -> 1x3x4320x7680, RRDBNet-23 4x fp16): an
+    interior window of the full-frame result equals the forward of a crop that
+    contains the window plus the network's receptive radius (stride-1 convs are
+    translation equivariant).  Also: banded schedule == plain schedule at full size."""
+    from innfer_amd import synth
+    net, _ = _rrdb(dev, 23, 4)
+    x = torch.from_numpy(synth.uniform((1, 3, 1080, 1920), 31)).to(dev).half()
+    y = net(x)
+    assert tuple(y.shape) == (1, 3, 4320, 7680)
+    assert torch.isfinite(y).all()
+    R = 23 * 15 + 6                                   # 3x3 convs on the LR grid: 1 + 345 + 1 (+2 HR-side, <1 LR px each)
+    cy, cx, hw = 540, 960, 16
+    y0, y1, x0, x1 = cy - hw - R, cy + hw + R, cx - hw - R, cx + hw + R
+    yc = net(x[:, :, y0:y1, x0:x1].contiguous())
+    a = y[:, :, 4 * (cy - hw):4 * (cy + hw), 4 * (cx - hw):4 * (cx + hw)]
+    b = yc[:, :, 4 * (cy - hw - y0):4 * (cy + hw - y0), 4 * (cx - hw - x0):4 * (cx + hw - x0)]
+    assert torch.equal(a, b)
+    net.band_rows = 128
+    assert torch.equal(net(x), y)
+    net.band_rows = 0
