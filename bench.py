@@ -94,6 +94,18 @@ def roofline_from_launches(launches):
             "per_kernel": per_kernel}
 
 
+def per_layer_table(launches, npix_lr):
+    """stderr table: per distinct (kind, flops) launch class -> avg ms, TFLOP/s (diagnostics)."""
+    rows = {}
+    for k, ms, fl in launches:
+        r = rows.setdefault((k, fl), [0.0, 0])
+        r[0] += ms; r[1] += 1
+    out = []
+    for (k, fl), (ms, n) in sorted(rows.items()):
+        out.append(f"  {kind_name(k):34s} n={n:3d} GFLOP={fl / 1e9:9.1f} avg_ms={ms / n:8.4f} TFLOP/s={fl / (ms / n * 1e-3) / 1e12:8.1f}")
+    return "\n".join(out)
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -254,7 +266,9 @@ def main():
         if not args.no_roofline and args.workload.startswith("frame"):
             log('per-launch timing')
             timed_forward(net, x)
-            line["roofline"] = roofline_from_launches(timed_forward(net, x))
+            launches = timed_forward(net, x)
+            line["roofline"] = roofline_from_launches(launches)
+            log("per-layer classes:\n" + per_layer_table(launches, H * W))
         net.release_workspace()
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline')
