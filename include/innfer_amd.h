@@ -14,7 +14,7 @@
  *   - pointers named d_* are device (HBM) pointers owned by the caller (e.g.
  *     torch storages); h_* are host pointers.  `stream` is a hipStream_t passed
  *     as void* (NULL = default stream).  Nothing synchronises the stream.
- *   - activations inside the library are fp16 NHWC channel slabs, accumulated
+ *   - activations inside the library are fp16 blocked-NHWC channel slabs, accumulated
  *     in fp32 on MFMA; tensors at the boundary are NCHW like the reference's
  *     torch tensors.
  *   - handles are immutable after the last innfer_net_set_conv(); forward is
@@ -99,7 +99,11 @@ double innfer_net_flops(innfer_net_t net, int N, int H, int W);
 
 /* -------------------------------------------------- single fused convolution
  * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution
- * over an fp16 NHWC channel slab (conv_block, block.py:213-254).
+ * over an fp16 "blocked NHWC" channel slab (conv_block, block.py:213-254).
+ * Slab layout: channels in groups of 32; element (n,y,x,c) lives at
+ *   base + (c/32)*group_stride + ((n*H + y)*W + x)*32 + c%32   (elements; group_stride >= N*H*W*32)
+ * so a 32-channel chunk of consecutive pixels is a contiguous run of full 128-byte lines and the
+ * reference's torch.cat is a group offset.
  *   out[.., out_ch_off + k] = epilogue(conv(in[.., 0:C]))
  *   epilogue: +bias -> act -> (*res1_scale + res1) -> (*res2_scale + res2)
  * act: 0 none, 1 LeakyReLU(0.2) (block.py:89-90), 2 ReLU.
@@ -108,14 +112,14 @@ double innfer_net_flops(innfer_net_t net, int N, int H, int W);
  * d_packed comes from innfer_pack_conv3x3().  C % 32 == 0, K % 16 == 0, K <= 64.
  */
 typedef struct {
-    const void* d_in;  int in_stride;   /* elements per pixel of the input slab */
+    const void* d_in;  int64_t in_group_stride;  /* elements between 32-channel groups of the input slab */
     int C;
     const void* d_packed; const float* d_bias;
-    void* d_out; int out_stride; int out_ch_off; int K;
+    void* d_out; int64_t out_group_stride; int out_ch_off; int K;
     int N, H, W;
     int act; int upsample2x;
-    const void* d_res1; int res1_stride; float res1_scale;
-    const void* d_res2; int res2_stride; float res2_scale;
+    const void* d_res1; int64_t res1_group_stride; float res1_scale;
+    const void* d_res2; int64_t res2_group_stride; float res2_scale;
     int row_begin, row_end;             /* rows of the output to compute; 0,0 = all */
 } innfer_conv_args;
 
@@ -123,10 +127,10 @@ size_t innfer_conv3x3_packed_bytes(int K, int C);
 int innfer_pack_conv3x3(const float* h_weight_oihw, int K, int C, void* h_packed);
 int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream);
 
-/* NCHW (f16/f32) <-> NHWC-slab f16 helpers used by tests of the single conv. */
-int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int slab_stride, int ch_off,
+/* NCHW (f16/f32) <-> blocked-NHWC f16 slab helpers used by tests of the single conv. */
+int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int64_t group_stride, int ch_off,
                         int N, int C, int H, int W, void* stream);
-int innfer_slab_to_nchw(const void* d_slab, int slab_stride, int ch_off, void* d_dst, int dst_dtype,
+int innfer_slab_to_nchw(const void* d_slab, int64_t group_stride, int ch_off, void* d_dst, int dst_dtype,
                         int N, int C, int H, int W, void* stream);
 
 /* ------------------------------------------------------------ chop / blend

@@ -29,18 +29,21 @@ int set_error(int code, const char* fmt, ...);
 // ---- 3x3 convolution on fp16 NHWC slabs (conv3x3.hip) -----------------------
 enum OutMode { OUT_SLAB = 0, OUT_NCHW = 1, OUT_SHUFFLE2 = 2 };
 
+// Slab layout ("blocked NHWC"): channels in groups of 32; element (n,y,x,c) of a slab lives at
+//   base + (c/32)*gstride + ((n*H + y)*W + x)*32 + c%32        (gstride in elements, >= N*H*W*32)
+// so a 32-channel chunk of consecutive pixels is one contiguous run of full 128-B lines.
 struct ConvLaunch {
-    const f16* in; int in_stride; int C;          // C % 32 == 0
+    const f16* in; long in_gstride; int C;        // C % 32 == 0
     const f16* wpk; const float* bias;            // packed panels for KG*16*NT channels
-    void* out; int out_stride;                    // OUT_SLAB: f16 slab (channel offset folded in)
+    void* out; long out_gstride;                  // OUT_SLAB: pointer to the group holding channel 0 of the output
+    int out_coff;                                 // channel offset inside that group (0 or 16)
     int K;                                        // valid output channels
     int N, H, W;                                  // conv (output) size
     int act; int up;                              // act: 0/1/2 ; up: input read through nearest 2x
-    const f16* res1; int res1_stride; float s1;
-    const f16* res2; int res2_stride; float s2;
+    const f16* res1; long res1_gstride; float s1;
+    const f16* res2; long res2_gstride; float s2;
     int y0, y1;                                   // output rows [y0,y1)
     int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
-    void* out2; int out2_stride;                  // optional second slab destination (OUT_SLAB)
 };
 
 // Panel geometry of packed weights.
@@ -54,13 +57,13 @@ struct FirstConvLaunch {
     const void* in; int in_f32; int Cin;          // NCHW planar input
     const float* w;                               // [Cin*9][K] fp32 (k-major), device
     const float* bias;
-    f16* out; int out_stride; f16* out2; int out2_stride;
+    f16* out; long out_gstride; f16* out2; long out2_gstride;
     int K; int N, H, W; int act;
 };
 int first_conv_launch(const FirstConvLaunch& L, hipStream_t s);
 
 // ---- layout / tiles / blend / pre-post (tiles.hip) ---------------------------
-int nchw_to_slab(const void* src, int src_f32, f16* slab, int stride, int N, int C, int H, int W, hipStream_t s);
-int slab_to_nchw(const f16* slab, int stride, void* dst, int dst_f32, int N, int C, int H, int W, hipStream_t s);
+int nchw_to_slab(const void* src, int src_f32, f16* slab, long gstride, int ch_off, int N, int C, int H, int W, hipStream_t s);
+int slab_to_nchw(const f16* slab, long gstride, int ch_off, void* dst, int dst_f32, int N, int C, int H, int W, hipStream_t s);
 
 }  // namespace innfer

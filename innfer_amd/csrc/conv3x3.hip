@@ -25,6 +25,8 @@
 // (row-in-wave, r) pairs that need it.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace innfer {
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
@@ -36,17 +38,18 @@ constexpr int LWP = 40;       // LDS row pitch (pixels), multiple of 8
 constexpr int LVALID = TW + 2;
 
 struct KP {
-    const f16* in; long in_img_stride; int in_stride; int nchunks;
+    const f16* in; long in_img_stride; long in_gbytes; int nchunks;   // gbytes: bytes between channel groups
     const f16* wpk; const float* bias;
-    void* out; long out_img_stride; int out_stride;
+    void* out; long out_gstride; int out_coff;
     int K, KG;
     int H, W, Hs, Ws;
     int act, up;
-    const f16* res1; int res1_stride; float s1;
-    const f16* res2; int res2_stride; float s2;
+    const f16* res1; long res1_gstride; float s1;
+    const f16* res2; long res2_gstride; float s2;
     int y0, y1;
     int tiles_x, tiles_y;
     int out_f32;
+    int N;
 };
 
 __device__ __forceinline__ void dma16(const void* g, void* lds) {
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
     // ---- per-lane DMA source offsets (chunk independent) ----------------------
     const int sy_base = (ty0 > 0 ? ty0 - 1 : 0) >> p.up;
     const char* in_base = (const char*)(p.in + (long)n * p.in_img_stride +
-                                        (long)sy_base * p.Ws * p.in_stride);
+                                        (long)sy_base * p.Ws * 32);
     int in_off[KQ];
 #pragma unroll
     for (int k = 0; k < KQ; ++k) {
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
         const bool ok = (q < NQ) && (lx < LVALID) && (Y >= 0) && (Y < p.H) && (X >= 0) && (X < p.W);
         const int sy = (Y >> p.up) - sy_base, sx = X >> p.up;
-        in_off[k] = ok ? ((sy * p.Ws + sx) * p.in_stride + slot * 8) * 2 : -1;
+        in_off[k] = ok ? ((sy * p.Ws + sx) * 32 + slot * 8) * 2 : -1;
     }
     const char* w_base = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES + lane * 16;
 
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         for (int k = 0; k < KQ; ++k) {
             const int q = wave + 4 * k;
             if (q < NQ) {
-                const char* src = in_off[k] >= 0 ? in_base + in_off[k] + c * 64
+                const char* src = in_off[k] >= 0 ? in_base + in_off[k] + c * p.in_gbytes
                                                  : (const char*)g_zero_page;
                 dma16(src, lds_in + q * 1024);
             }
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
                 v[t][j] = f;
             }
         if (p.res1) {
-            const f16* rp = p.res1 + pix * p.res1_stride + cbase;
+            const f16* rp = p.res1 + (cbase >> 5) * p.res1_gstride + pix * 32 + (cbase & 31);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
             }
         }
         if (p.res2) {
-            const f16* rp = p.res2 + pix * p.res2_stride + cbase;
+            const f16* rp = p.res2 + (cbase >> 5) * p.res2_gstride + pix * 32 + (cbase & 31);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
             }
         }
         if constexpr (OUTMODE == OUT_SLAB) {
-            f16* op = (f16*)p.out + pix * p.out_stride + cbase;
+            const int oc0 = cbase + p.out_coff;
+                f16* op = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix * 32 + (oc0 & 31);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f16x4 h;
@@ -242,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long opix = ((long)n * 2 * p.H + 2 * y + (j >> 1)) * (2 * p.W) + 2 * x + (j & 1);
-                f16* op = (f16*)p.out + opix * p.out_stride + cbase / 4;
+                const int oc0 = cbase / 4;
+                    f16* op = (f16*)p.out + (oc0 >> 5) * p.out_gstride + opix * 32 + (oc0 & 31);
                 if constexpr (NT == 4) {
                     f16x4 h;
 #pragma unroll
@@ -255,6 +260,308 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// v2: persistent, double-buffered variant (the default).
+//   * one 512-thread workgroup (8 waves, 2 per SIMD) per CU, grid = #CUs; every workgroup
+//     walks a strided list of tiles of "its" XCD's contiguous tile range;
+//   * two LDS stages of PPW*8 KiB: while the MFMAs of chunk c read stage c&1, the LDS-DMA
+//     of chunk c+1 -- or of the NEXT tile's first chunk -- lands in the other stage.  Waits
+//     are counted (s_waitcnt vmcnt(PPW): everything but the PPW pieces just issued), barriers
+//     are raw s_barrier: __syncthreads() would drain the in-flight DMA (vmcnt(0));
+//   * every wave issues exactly PPW DMA pieces per chunk (input pieces, then weight pieces,
+//     then dummies that read the zero page) so that the counted wait is a literal.
+// Tile = (8*RPW rows) x 32 px; wave w owns rows [w*RPW, (w+1)*RPW).
+// ---------------------------------------------------------------------------------------
+struct TileCoord { int n, ty0, tx0, kg; };
+
+template <int RPW, int NT, int OUTMODE>
+__global__ __launch_bounds__(512, 2) void conv3x3_mfma_p(const KP p) {
+    constexpr int NW = 8;
+    constexpr int TH = NW * RPW;
+    constexpr int LH = TH + 2;
+    constexpr int NPX = LH * LWP;
+    constexpr int NQ = NPX / 16;
+    constexpr int WROWS = NT * 16;
+    constexpr int W_BYTES = 9 * WROWS * 64;
+    constexpr int WQ = W_BYTES / 1024;
+    constexpr int NP = NQ + WQ;
+    constexpr int PPW = (NP + NW - 1) / NW;
+    constexpr int STAGE = PPW * NW * 1024;
+    constexpr int MT = RPW * 2;
+    static_assert(NPX % 16 == 0, "tile must be a whole number of DMA pieces");
+    static_assert(PPW <= 63, "vmcnt immediate");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+
+    // ---- work list: XCD x (= blockIdx & 7 under round-robin dispatch; speed only) owns a
+    // contiguous range of items; its workgroups take them round-robin.
+    const int items = p.N * p.tiles_y * p.tiles_x * p.KG;
+    int item, item_end, item_stride;
+    {
+        const int G = gridDim.x, b = blockIdx.x;
+        const int x = b & 7, slot = b >> 3;
+        const int q = items >> 3, r = items & 7;
+        const int lo = x * q + (x < r ? x : r);
+        const int cnt = q + (x < r ? 1 : 0);
+        item_stride = (G - x + 7) >> 3;
+        item = lo + slot;
+        item_end = lo + cnt;
+    }
+    if (item >= item_end) return;
+
+    auto decode = [&](int it) {
+        TileCoord t;
+        t.kg = it % p.KG;
+        int tile = it / p.KG;
+        const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+        const int ty = tile % p.tiles_y;
+        t.n = tile / p.tiles_y;
+        t.ty0 = p.y0 + ty * TH;
+        t.tx0 = tx * TW;
+        return t;
+    };
+
+    // per-lane source offsets of this wave's PPW pieces for the tile being staged
+    int off[PPW];
+    const char* in_base = nullptr;
+    const char* w_base = nullptr;
+    auto setup = [&](const TileCoord& t) {
+        const int sy_base = (t.ty0 > 0 ? t.ty0 - 1 : 0) >> p.up;
+        in_base = (const char*)(p.in + (long)t.n * p.in_img_stride + (long)sy_base * p.Ws * 32);
+        w_base = (const char*)p.wpk + (long)t.kg * p.nchunks * W_BYTES;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int pc = wave + NW * k;
+            if (pc < NQ) {
+                const int px = pc * 16 + (lane >> 2);
+                const int ly = px / LWP, lx = px - ly * LWP;
+                const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
+                const int Y = t.ty0 - 1 + ly, X = t.tx0 - 1 + lx;
+                const bool ok = (lx < LVALID) && (Y >= 0) && (Y < p.H) && (X >= 0) && (X < p.W);
+                const int sy = (Y >> p.up) - sy_base, sx = X >> p.up;
+                off[k] = ok ? ((sy * p.Ws + sx) * 32 + slot * 8) * 2 : -1;
+            } else {
+                off[k] = pc < NP ? (pc - NQ) * 1024 + lane * 16 : -1;
+            }
+        }
+    };
+    auto issue = [&](int c, int stage) {
+        char* dst = smem + stage * STAGE;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int pc = wave + NW * k;
+            const char* src;
+            if (pc < NQ) src = in_base + off[k] + c * p.in_gbytes;
+            else src = w_base + (long)c * W_BYTES + off[k];
+            if (off[k] < 0) src = (const char*)g_zero_page;
+            dma16(src, dst + pc * 1024);
+        }
+    };
+
+    // stage-relative LDS read offsets
+    int boff[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int pb = wave * RPW * LWP + li + s;
+        boff[s] = pb * 64 + ((lg ^ ((((li + s) >> 2) & 1) << 1)) << 4);
+    }
+    const int aoff = NQ * 1024 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+
+    TileCoord cur = decode(item);
+    setup(cur);
+    issue(0, 0);
+    int stage = 0;
+
+    while (true) {
+        const int cbase = cur.kg * WROWS + 4 * NT * lg;
+        f32x4 acc[NT][MT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 b = *(const f32x4*)(p.bias + cbase + 4 * t);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[t][m] = b;
+        }
+        const int next_item = item + item_stride;
+        const bool has_next = next_item < item_end;
+        TileCoord nxt = cur;
+
+        for (int c = 0; c < p.nchunks; ++c) {
+            bool issued = true;
+            if (c + 1 < p.nchunks) {
+                issue(c + 1, stage ^ 1);
+            } else if (has_next) {
+                nxt = decode(next_item);
+                setup(nxt);
+                issue(0, stage ^ 1);
+            } else {
+                issued = false;
+            }
+            if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+
+            const char* sb = smem + stage * STAGE;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                f16x8 a[3][NT];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        a[r][t] = *(const f16x8*)(sb + aoff + ((r * 3 + s) * WROWS + t * 16) * 64);
+#pragma unroll
+                for (int rr = 0; rr < RPW + 2; ++rr) {
+#pragma unroll
+                    for (int seg = 0; seg < 2; ++seg) {
+                        const f16x8 b = *(const f16x8*)(sb + boff[s] + (rr * LWP + seg * 16) * 64);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const int rw = rr - r;
+                            if (rw >= 0 && rw < RPW) {
+#pragma unroll
+                                for (int t = 0; t < NT; ++t)
+                                    acc[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                        a[r][t], b, acc[t][rw * 2 + seg], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            asm volatile("s_barrier" ::: "memory");
+            stage ^= 1;
+        }
+
+        // ---- epilogue of tile `cur` (the next tile's first chunk is already in flight) ----
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int y = cur.ty0 + wave * RPW + (m >> 1);
+            const int x = cur.tx0 + (m & 1) * 16 + li;
+            if (y >= p.y1 || x >= p.W) continue;
+            const long pix = ((long)cur.n * p.H + y) * p.W + x;
+            float v[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = acc[t][m][j];
+                    if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                    else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                    v[t][j] = f;
+                }
+            if (p.res1) {
+                const f16* rp = p.res1 + (cbase >> 5) * p.res1_gstride + pix * 32 + (cbase & 31);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[t][j] = v[t][j] * p.s1 + (float)r4[j];
+                }
+            }
+            if (p.res2) {
+                const f16* rp = p.res2 + (cbase >> 5) * p.res2_gstride + pix * 32 + (cbase & 31);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[t][j] = v[t][j] * p.s2 + (float)r4[j];
+                }
+            }
+            if constexpr (OUTMODE == OUT_SLAB) {
+                const int oc0 = cbase + p.out_coff;
+                f16* op = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix * 32 + (oc0 & 31);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f16x4 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = (f16)v[t][j];
+                    *(f16x4*)(op + 4 * t) = h;
+                }
+            } else if constexpr (OUTMODE == OUT_NCHW) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ch = cbase + 4 * t + j;
+                        if (ch < p.K) {
+                            const long o = (((long)cur.n * p.K + ch) * p.H + y) * p.W + x;
+                            if (p.out_f32) ((float*)p.out)[o] = v[t][j];
+                            else ((f16*)p.out)[o] = (f16)v[t][j];
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long opix = ((long)cur.n * 2 * p.H + 2 * y + (j >> 1)) * (2 * p.W) + 2 * x + (j & 1);
+                    const int oc0 = cbase / 4;
+                    f16* op = (f16*)p.out + (oc0 >> 5) * p.out_gstride + opix * 32 + (oc0 & 31);
+                    if constexpr (NT == 4) {
+                        f16x4 h;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) h[t] = (f16)v[t][j];
+                        *(f16x4*)op = h;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) op[t] = (f16)v[t][j];
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        item = next_item;
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+template <int RPW, int NT, int OUTMODE>
+int launch_p(const KP& kp, int N, hipStream_t s) {
+    constexpr int TH = 8 * RPW;
+    constexpr int NP = (TH + 2) * LWP / 16 + 9 * NT;
+    constexpr int LDS = 2 * ((NP + 7) / 8) * 8 * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_p<RPW, NT, OUTMODE>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    KP k = kp;
+    k.N = N;
+    k.tiles_x = (k.W + TW - 1) / TW;
+    k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
+    const long items = (long)N * k.tiles_x * k.tiles_y * k.KG;
+    if (items <= 0) return INNFER_OK;
+    if (items > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
+    const int grid = (int)(items < num_cus() ? items : num_cus());
+    hipLaunchKernelGGL((conv3x3_mfma_p<RPW, NT, OUTMODE>), dim3(grid), dim3(512), LDS, s, k);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+int conv_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("INNFER_CONV_VARIANT");
+        v = e ? atoi(e) : 2;
+    }
+    return v;
 }
 
 template <int RPW, int NT, int OUTMODE>
@@ -321,20 +628,36 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     KP k{};
     k.up = L.up ? 1 : 0;
     k.H = L.H; k.W = L.W; k.Hs = L.H >> k.up; k.Ws = L.W >> k.up;
-    k.in = L.in; k.in_stride = L.in_stride; k.in_img_stride = (long)k.Hs * k.Ws * L.in_stride;
+    k.in = L.in; k.in_gbytes = L.in_gstride * 2; k.in_img_stride = (long)k.Hs * k.Ws * 32;
     k.nchunks = L.C / 32;
     k.wpk = L.wpk; k.bias = L.bias;
-    k.out = L.out; k.out_stride = L.out_stride;
+    k.out = L.out; k.out_gstride = L.out_gstride; k.out_coff = L.out_coff;
     k.K = L.K; k.KG = conv_groups(L.K);
     k.act = L.act;
-    k.res1 = L.res1; k.res1_stride = L.res1_stride; k.s1 = L.s1;
-    k.res2 = L.res2; k.res2_stride = L.res2_stride; k.s2 = L.s2;
+    k.res1 = L.res1; k.res1_gstride = L.res1_gstride; k.s1 = L.s1;
+    k.res2 = L.res2; k.res2_gstride = L.res2_gstride; k.s2 = L.s2;
     k.y0 = L.y0; k.y1 = L.y1 > 0 ? L.y1 : L.H;
     if (k.y0 < 0 || k.y1 > L.H || k.y0 >= k.y1) return set_error(INNFER_ERR_INVALID, "conv3x3: bad row range [%d,%d)", k.y0, k.y1);
     k.out_f32 = L.out_f32;
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
+    if (conv_variant() == 2) {
+        switch (L.out_mode) {
+            case OUT_SLAB:
+                if (nt == 4) return launch_p<1, 4, OUT_SLAB>(k, L.N, s);
+                if (nt == 2) return launch_p<2, 2, OUT_SLAB>(k, L.N, s);
+                return launch_p<2, 1, OUT_SLAB>(k, L.N, s);
+            case OUT_NCHW:
+                if (nt == 4) return launch_p<1, 4, OUT_NCHW>(k, L.N, s);
+                if (nt == 2) return launch_p<2, 2, OUT_NCHW>(k, L.N, s);
+                return launch_p<2, 1, OUT_NCHW>(k, L.N, s);
+            case OUT_SHUFFLE2:
+                if (nt == 4) return launch_p<1, 4, OUT_SHUFFLE2>(k, L.N, s);
+                return set_error(INNFER_ERR_UNSUPPORTED, "pixelshuffle conv needs K %% 64 == 0");
+        }
+        return set_error(INNFER_ERR_INVALID, "conv3x3: bad out_mode");
+    }
     switch (L.out_mode) {
         case OUT_SLAB:
             if (nt == 4) return launch_t<2, 4, OUT_SLAB>(k, L.N, s);

@@ -1,5 +1,5 @@
 // First convolution of a generator: few input channels (1..4), NCHW planar input
-// straight from the caller's tensor, fp16 NHWC slab output.
+// straight from the caller's tensor, fp16 blocked-NHWC slab output.
 // Replaces `fea_conv = conv_block(in_nc, nf, 3)` (RRDBNet_arch.py:25, SRResNet_arch.py:24).
 //
 // 1728 MAC per pixel for 3->64: 0.01 % of an RRDBNet-23 forward, so this is a plain
@@ -14,7 +14,7 @@ namespace {
 struct FP {
     const void* in; int in_f32; int Cin;
     const float* w; const float* bias;
-    f16* out; int out_stride; f16* out2; int out2_stride;
+    f16* out; long out_gstride; f16* out2; long out2_gstride;
     int K; long npix; int H, W; int act;
 };
 
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
         else if (p.act == 2) f = f > 0.f ? f : 0.f;
         h[e] = (f16)f;
     }
-    *(f16x8*)(p.out + pix * p.out_stride + cg) = h;
-    if (p.out2) *(f16x8*)(p.out2 + pix * p.out2_stride + cg) = h;
+    *(f16x8*)(p.out + (cg >> 5) * p.out_gstride + pix * 32 + (cg & 31)) = h;
+    if (p.out2) *(f16x8*)(p.out2 + (cg >> 5) * p.out2_gstride + pix * 32 + (cg & 31)) = h;
 }
 
 }  // namespace
@@ -73,7 +73,7 @@ int first_conv_launch(const FirstConvLaunch& L, hipStream_t s) {
     if (L.K % 8 || L.K > 256 || L.K <= 0)
         return set_error(INNFER_ERR_UNSUPPORTED, "first conv: nf=%d must be a multiple of 8, <= 256", L.K);
     if (L.Cin < 1 || L.Cin > 8) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: in_nc=%d unsupported", L.Cin);
-    FP p{L.in, L.in_f32, L.Cin, L.w, L.bias, L.out, L.out_stride, L.out2, L.out2_stride,
+    FP p{L.in, L.in_f32, L.Cin, L.w, L.bias, L.out, L.out_gstride, L.out2, L.out2_gstride,
          L.K, (long)L.N * L.H * L.W, L.H, L.W, L.act};
     const int ppb = 256 / (L.K / 8);
     const long grid = (p.npix + ppb - 1) / ppb;

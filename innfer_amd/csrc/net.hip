@@ -1,8 +1,8 @@
 // Network engine: RRDBNet (ESRGAN) and SRResNet (SRGAN) forward as a sequence of
-// fused conv launches over fp16 NHWC channel slabs in a caller-provided workspace.
+// fused conv launches over fp16 blocked-NHWC channel slabs ([C/32][N*H*W][32]) in a caller-provided workspace.
 //
 // Replaces the nn.Sequential graph of RRDBNet_arch.py:16-62 / SRResNet_arch.py:15-91:
-//   torch.cat            -> channel offsets inside a 192-wide slab (x|x1|x2|x3|x4)
+//   torch.cat            -> channel-group offsets inside a 6-group slab (x|x|x1|x2|x3|x4)
 //   LeakyReLU / ReLU     -> conv epilogue
 //   x5*0.2 + x, RRDB out*0.2 + x, ShortcutBlock x + sub(x) -> conv epilogue
 //   Upsample(nearest 2x) -> folded into the next conv's input addressing
@@ -273,8 +273,8 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
     int rc = timed_begin(s);
     if (rc) return rc;
     if (debug_sync())
-        fprintf(stderr, "[innfer] conv C=%d K=%d N=%d H=%d W=%d up=%d act=%d mode=%d rows=[%d,%d) in_stride=%d out_stride=%d\n",
-                L.C, L.K, L.N, L.H, L.W, L.up, L.act, L.out_mode, L.y0, L.y1, L.in_stride, L.out_stride);
+        fprintf(stderr, "[innfer] conv C=%d K=%d N=%d H=%d W=%d up=%d act=%d mode=%d rows=[%d,%d) in_g=%ld out_g=%ld\n",
+                L.C, L.K, L.N, L.H, L.W, L.up, L.act, L.out_mode, L.y0, L.y1, L.in_gstride, L.out_gstride);
     rc = conv_launch(L, s);
     if (rc) return rc;
     rc = debug_after("conv3x3", s);
@@ -298,12 +298,13 @@ struct Plan {                    // one MFMA conv in the launch list
     ConvLaunch L;
 };
 
-ConvLaunch mk(const ConvSlot& cs, const f16* in, int in_stride, void* out, int out_stride,
+// in/out point at channel 0 of the tensors; *_g are their group strides (elements).
+ConvLaunch mk(const ConvSlot& cs, const f16* in, long in_g, void* out, long out_g,
               int N, int H, int W, int act) {
     ConvLaunch L{};
-    L.in = in; L.in_stride = in_stride; L.C = cs.C;
+    L.in = in; L.in_gstride = in_g; L.C = cs.C;
     L.wpk = (const f16*)cs.d_w; L.bias = cs.d_b;
-    L.out = out; L.out_stride = out_stride; L.K = cs.K;
+    L.out = out; L.out_gstride = out_g; L.out_coff = 0; L.K = cs.K;
     L.N = N; L.H = H; L.W = W; L.act = act;
     L.s1 = 1.f; L.s2 = 1.f;
     L.y0 = 0; L.y1 = H;
@@ -354,7 +355,8 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)d_ws;
-    const int nf = net->nf, gc = net->gc, SW = cv.slab_w;
+    const int nf = net->nf, gc = net->gc;
+    const long G = (long)N * H * W * 32;          // group stride of every LR-resolution slab
     f16* fea = (f16*)(ws + cv.fea);
     f16* slab[3] = {(f16*)(ws + cv.slab[0]), (f16*)(ws + cv.slab[1]), (f16*)(ws + cv.slab[2])};
     f16* trunk = (f16*)(ws + cv.trunk);
@@ -364,7 +366,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         const ConvSlot& c0 = net->convs[ci++];
         FirstConvLaunch F{};
         F.in = d_in; F.in_f32 = in_dtype == INNFER_F32; F.Cin = c0.C; F.w = (const float*)c0.d_w; F.bias = c0.d_b;
-        F.out = fea; F.out_stride = nf; F.out2 = slab[0]; F.out2_stride = SW;
+        F.out = fea; F.out_gstride = G; F.out2 = slab[0]; F.out2_gstride = G;
         F.K = nf; F.N = N; F.H = H; F.W = W; F.act = 0;
         int rc = do_first(F, s);
         if (rc) return rc;
@@ -382,12 +384,12 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
                 f16* S = slab[work[r]];
                 for (int i = 0; i < 4; ++i) {
                     const ConvSlot& cs = net->convs[ci++];
-                    chain.push_back(mk(cs, S, SW, S + nf + i * gc, SW, N, H, W, 1));
+                    chain.push_back(mk(cs, S, G, S + (long)((nf + i * gc) / 32) * G, G, N, H, W, 1));
                 }
                 const ConvSlot& cs = net->convs[ci++];
-                ConvLaunch L = mk(cs, S, SW, slab[dest[r]], SW, N, H, W, 0);
-                L.res1 = S; L.res1_stride = SW; L.s1 = 0.2f;                      // x5*0.2 + x
-                if (r == 2) { L.res2 = slab[in_slab]; L.res2_stride = SW; L.s2 = 0.2f; }   // RRDB: out*0.2 + x
+                ConvLaunch L = mk(cs, S, G, slab[dest[r]], G, N, H, W, 0);
+                L.res1 = S; L.res1_gstride = G; L.s1 = 0.2f;                      // x5*0.2 + x
+                if (r == 2) { L.res2 = slab[in_slab]; L.res2_gstride = G; L.s2 = 0.2f; }   // RRDB: out*0.2 + x
                 chain.push_back(L);
             }
             cur = f1;
@@ -397,18 +399,18 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         for (int b = 0; b < net->nb; ++b) {
             const int a = cur, m = (cur + 1) % 3, o = (cur + 2) % 3;
             const ConvSlot& c0 = net->convs[ci++];
-            chain.push_back(mk(c0, slab[a], SW, slab[m], SW, N, H, W, 2));
+            chain.push_back(mk(c0, slab[a], G, slab[m], G, N, H, W, 2));
             const ConvSlot& c1 = net->convs[ci++];
-            ConvLaunch L = mk(c1, slab[m], SW, slab[o], SW, N, H, W, 0);
-            L.res1 = slab[a]; L.res1_stride = SW; L.s1 = 1.f;
+            ConvLaunch L = mk(c1, slab[m], G, slab[o], G, N, H, W, 0);
+            L.res1 = slab[a]; L.res1_gstride = G; L.s1 = 1.f;
             chain.push_back(L);
             cur = o;
         }
     }
     {   // trunk conv + ShortcutBlock: fea + conv(t)
         const ConvSlot& cs = net->convs[ci++];
-        ConvLaunch L = mk(cs, slab[cur], SW, trunk, nf, N, H, W, 0);
-        L.res1 = fea; L.res1_stride = nf; L.s1 = 1.f;
+        ConvLaunch L = mk(cs, slab[cur], G, trunk, G, N, H, W, 0);
+        L.res1 = fea; L.res1_gstride = G; L.s1 = 1.f;
         chain.push_back(L);
     }
     int rc = run_chain(chain, net->band_rows, s);
@@ -419,12 +421,13 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     for (int u = 0; u < net->n_up; ++u) {
         const ConvSlot& cs = net->convs[ci++];
         f16* dst = (f16*)(ws + cv.up[u]);
+        const long gi = (long)N * h * w * 32, go = gi * 4;
         if (net->kind == 0) {        // Upsample(nearest 2x) -> conv -> LeakyReLU
-            ConvLaunch L = mk(cs, t, nf, dst, nf, N, 2 * h, 2 * w, 1);
+            ConvLaunch L = mk(cs, t, gi, dst, go, N, 2 * h, 2 * w, 1);
             L.up = 1;
             rc = do_conv(L, s);
         } else {                     // conv nf->4nf -> PixelShuffle(2) -> ReLU
-            ConvLaunch L = mk(cs, t, nf, dst, nf, N, h, w, 2);
+            ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, 2);
             L.out_mode = OUT_SHUFFLE2;
             rc = do_conv(L, s);
         }
@@ -433,13 +436,14 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     }
     {
         const ConvSlot& cs = net->convs[ci++];
-        ConvLaunch L = mk(cs, t, nf, ws + cv.hr, nf, N, h, w, net->kind == 0 ? 1 : 2);
+        const long gh = (long)N * h * w * 32;
+        ConvLaunch L = mk(cs, t, gh, ws + cv.hr, gh, N, h, w, net->kind == 0 ? 1 : 2);
         rc = do_conv(L, s);
         if (rc) return rc;
     }
     {
         const ConvSlot& cs = net->convs[ci++];
-        ConvLaunch L = mk(cs, (const f16*)(ws + cv.hr), nf, d_out, 0, N, h, w, 0);
+        ConvLaunch L = mk(cs, (const f16*)(ws + cv.hr), (long)N * h * w * 32, d_out, 0, N, h, w, 0);
         L.out_mode = OUT_NCHW; L.out_f32 = out_dtype == INNFER_F32;
         rc = do_conv(L, s);
         if (rc) return rc;
@@ -488,23 +492,26 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     if (!a || !a->d_in || !a->d_packed || !a->d_bias || !a->d_out) return set_error(INNFER_ERR_INVALID, "conv3x3: null argument");
     if (a->K <= 0 || a->K % 16 || a->K > 64) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d (need K %% 16 == 0, K <= 64)", a->K);
     ConvLaunch L{};
-    L.in = (const f16*)a->d_in; L.in_stride = a->in_stride; L.C = a->C;
+    if (a->out_ch_off % 16 || (a->out_ch_off % 32 && a->K > 16))
+        return set_error(INNFER_ERR_INVALID, "conv3x3: out_ch_off=%d must keep the %d output channels inside 32-channel groups", a->out_ch_off, a->K);
+    L.in = (const f16*)a->d_in; L.in_gstride = a->in_group_stride; L.C = a->C;
     L.wpk = (const f16*)a->d_packed; L.bias = a->d_bias;
-    L.out = (f16*)a->d_out + a->out_ch_off; L.out_stride = a->out_stride; L.K = a->K;
+    L.out = (f16*)a->d_out + (long)(a->out_ch_off / 32) * a->out_group_stride; L.out_gstride = a->out_group_stride;
+    L.out_coff = a->out_ch_off % 32; L.K = a->K;
     L.N = a->N; L.H = a->H; L.W = a->W; L.act = a->act; L.up = a->upsample2x;
-    L.res1 = (const f16*)a->d_res1; L.res1_stride = a->res1_stride; L.s1 = a->res1_scale;
-    L.res2 = (const f16*)a->d_res2; L.res2_stride = a->res2_stride; L.s2 = a->res2_scale;
+    L.res1 = (const f16*)a->d_res1; L.res1_gstride = a->res1_group_stride; L.s1 = a->res1_scale;
+    L.res2 = (const f16*)a->d_res2; L.res2_gstride = a->res2_group_stride; L.s2 = a->res2_scale;
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
     L.out_mode = OUT_SLAB;
     return conv_launch(L, (hipStream_t)stream);
 }
 
-extern "C" int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int slab_stride, int ch_off,
+extern "C" int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int64_t group_stride, int ch_off,
                                    int N, int C, int H, int W, void* stream) {
-    return nchw_to_slab(d_src, src_dtype == INNFER_F32, (f16*)d_slab + ch_off, slab_stride, N, C, H, W, (hipStream_t)stream);
+    return nchw_to_slab(d_src, src_dtype == INNFER_F32, (f16*)d_slab, group_stride, ch_off, N, C, H, W, (hipStream_t)stream);
 }
 
-extern "C" int innfer_slab_to_nchw(const void* d_slab, int slab_stride, int ch_off, void* d_dst, int dst_dtype,
+extern "C" int innfer_slab_to_nchw(const void* d_slab, int64_t group_stride, int ch_off, void* d_dst, int dst_dtype,
                                    int N, int C, int H, int W, void* stream) {
-    return slab_to_nchw((const f16*)d_slab + ch_off, slab_stride, d_dst, dst_dtype == INNFER_F32, N, C, H, W, (hipStream_t)stream);
+    return slab_to_nchw((const f16*)d_slab, group_stride, ch_off, d_dst, dst_dtype == INNFER_F32, N, C, H, W, (hipStream_t)stream);
 }

@@ -1,5 +1,5 @@
 // HBM-bound pointwise / gather kernels around the conv stack:
-//   - NCHW <-> fp16 NHWC slab (test helpers of the single-conv entry point)
+//   - NCHW <-> fp16 blocked-NHWC slab (test helpers of the single-conv entry point)
 //   - chop_forward tile extraction  (utils/utils.py:318-369 as used by run.py:178-181)
 //   - overlap blend / recompose     (utils/utils.py:372-445)
 //   - uint8 HWC BGR <-> float NCHW RGB pre/post (utils/utils.py:164-194,197-248)
@@ -17,23 +17,25 @@
 namespace innfer {
 namespace {
 
-__global__ void k_nchw_to_slab(const void* src, int f32, f16* slab, int stride, int C, long hw, long total) {
+__global__ void k_nchw_to_slab(const void* src, int f32, f16* slab, long gstride, int ch_off, int C, long hw, long total) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over N*C*H*W, pixel fastest
     if (i >= total) return;
     const long px = i % hw;
     const int c = (int)((i / hw) % C);
     const long n = i / (hw * C);
     const float v = f32 ? ((const float*)src)[i] : (float)((const f16*)src)[i];
-    slab[(n * hw + px) * stride + c] = (f16)v;
+    const int ch = ch_off + c;
+    slab[(ch >> 5) * gstride + (n * hw + px) * 32 + (ch & 31)] = (f16)v;
 }
 
-__global__ void k_slab_to_nchw(const f16* slab, int stride, void* dst, int f32, int C, long hw, long total) {
+__global__ void k_slab_to_nchw(const f16* slab, long gstride, int ch_off, void* dst, int f32, int C, long hw, long total) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const long px = i % hw;
     const int c = (int)((i / hw) % C);
     const long n = i / (hw * C);
-    const f16 v = slab[(n * hw + px) * stride + c];
+    const int ch = ch_off + c;
+    const f16 v = slab[(ch >> 5) * gstride + (n * hw + px) * 32 + (ch & 31)];
     if (f32) ((float*)dst)[i] = (float)v; else ((f16*)dst)[i] = v;
 }
 
@@ -149,18 +151,18 @@ inline unsigned blocks(long total, int bs) { return (unsigned)((total + bs - 1) 
 
 }  // namespace
 
-int nchw_to_slab(const void* src, int f32, f16* slab, int stride, int N, int C, int H, int W, hipStream_t s) {
+int nchw_to_slab(const void* src, int f32, f16* slab, long gstride, int ch_off, int N, int C, int H, int W, hipStream_t s) {
     const long hw = (long)H * W, total = hw * C * N;
     if (total == 0) return INNFER_OK;
-    hipLaunchKernelGGL(k_nchw_to_slab, dim3(blocks(total, 256)), dim3(256), 0, s, src, f32, slab, stride, C, hw, total);
+    hipLaunchKernelGGL(k_nchw_to_slab, dim3(blocks(total, 256)), dim3(256), 0, s, src, f32, slab, gstride, ch_off, C, hw, total);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
 
-int slab_to_nchw(const f16* slab, int stride, void* dst, int f32, int N, int C, int H, int W, hipStream_t s) {
+int slab_to_nchw(const f16* slab, long gstride, int ch_off, void* dst, int f32, int N, int C, int H, int W, hipStream_t s) {
     const long hw = (long)H * W, total = hw * C * N;
     if (total == 0) return INNFER_OK;
-    hipLaunchKernelGGL(k_slab_to_nchw, dim3(blocks(total, 256)), dim3(256), 0, s, slab, stride, dst, f32, C, hw, total);
+    hipLaunchKernelGGL(k_slab_to_nchw, dim3(blocks(total, 256)), dim3(256), 0, s, slab, gstride, ch_off, dst, f32, C, hw, total);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }

@@ -36,13 +36,13 @@ _lib = _load()
 
 class ConvArgs(C.Structure):
     _fields_ = [
-        ("d_in", C.c_void_p), ("in_stride", C.c_int), ("C", C.c_int),
+        ("d_in", C.c_void_p), ("in_group_stride", C.c_int64), ("C", C.c_int),
         ("d_packed", C.c_void_p), ("d_bias", C.c_void_p),
-        ("d_out", C.c_void_p), ("out_stride", C.c_int), ("out_ch_off", C.c_int), ("K", C.c_int),
+        ("d_out", C.c_void_p), ("out_group_stride", C.c_int64), ("out_ch_off", C.c_int), ("K", C.c_int),
         ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
         ("act", C.c_int), ("upsample2x", C.c_int),
-        ("d_res1", C.c_void_p), ("res1_stride", C.c_int), ("res1_scale", C.c_float),
-        ("d_res2", C.c_void_p), ("res2_stride", C.c_int), ("res2_scale", C.c_float),
+        ("d_res1", C.c_void_p), ("res1_group_stride", C.c_int64), ("res1_scale", C.c_float),
+        ("d_res2", C.c_void_p), ("res2_group_stride", C.c_int64), ("res2_scale", C.c_float),
         ("row_begin", C.c_int), ("row_end", C.c_int),
     ]
 
@@ -71,9 +71,9 @@ SIGNATURES = {
     "innfer_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv3x3_f16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
-    "innfer_nchw_to_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+    "innfer_nchw_to_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "innfer_slab_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+    "innfer_slab_to_nchw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "innfer_chop_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),

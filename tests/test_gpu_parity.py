@@ -29,15 +29,16 @@ def _sd(shapes, seed=0):
 
 # ------------------------------------------------------------------ single conv
 def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0,
-              in_extra=0, out_stride=None, out_off=0, rows=None):
-    """x [N,C,Hs,Ws] fp16 (cpu), w [K,C,3,3] fp32, returns NCHW fp32 (cpu) of the HIP conv."""
+              in_extra=0, out_channels=None, out_off=0, rows=None):
+    """x [N,C,Hs,Ws] fp16 (cpu), w [K,C,3,3] fp32.  Runs the HIP conv on blocked-NHWC slabs
+    ([C/32][N*H*W][32]) and returns (NCHW fp32 result, raw output slab [groups,N,H,W,32]) on the cpu."""
     import innfer_amd.lib as L
     N, Cc, Hs, Ws = x.shape
     H, W = (2 * Hs, 2 * Ws) if up else (Hs, Ws)
-    in_stride = Cc + in_extra
-    out_stride = out_stride or K
-    slab = torch.full((N, Hs, Ws, in_stride), 7.0, dtype=torch.float16, device=dev)   # junk in unused channels
-    L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), in_stride, 0,
+    in_groups = (Cc + in_extra) // 32
+    g_in = N * Hs * Ws * 32
+    slab = torch.full((in_groups, N, Hs, Ws, 32), 7.0, dtype=torch.float16, device=dev)   # junk in unused groups
+    L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), g_in, 0,
                                       N, Cc, Hs, Ws, None))
     nbytes = L.lib.innfer_conv3x3_packed_bytes(K, Cc)
     packed = np.zeros(nbytes, dtype=np.uint8)
@@ -45,25 +46,27 @@ def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2
     L.check(L.lib.innfer_pack_conv3x3(wc.ctypes.data, K, Cc, packed.ctypes.data))
     d_packed = torch.from_numpy(packed).to(dev)
     d_bias = b.float().to(dev)
-    out = torch.full((N, H, W, out_stride), -3.0, dtype=torch.float16, device=dev)
+    out_channels = out_channels or max(K, 32)
+    g_out = N * H * W * 32
+    out = torch.full((out_channels // 32, N, H, W, 32), -3.0, dtype=torch.float16, device=dev)
     a = L.ConvArgs()
-    a.d_in, a.in_stride, a.C = slab.data_ptr(), in_stride, Cc
+    a.d_in, a.in_group_stride, a.C = slab.data_ptr(), g_in, Cc
     a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
-    a.d_out, a.out_stride, a.out_ch_off, a.K = out.data_ptr(), out_stride, out_off, K
+    a.d_out, a.out_group_stride, a.out_ch_off, a.K = out.data_ptr(), g_out, out_off, K
     a.N, a.H, a.W, a.act, a.upsample2x = N, H, W, act, int(up)
     keep = [slab, d_packed, d_bias]
     for name, r, sc in (("1", res1, s1), ("2", res2, s2)):
         if r is not None:
-            rs = torch.empty((N, H, W, K), dtype=torch.float16, device=dev)
-            L.check(L.lib.innfer_nchw_to_slab(r.to(dev).contiguous().data_ptr(), L.F16, rs.data_ptr(), K, 0, N, K, H, W, None))
-            setattr(a, f"d_res{name}", rs.data_ptr()); setattr(a, f"res{name}_stride", K); setattr(a, f"res{name}_scale", sc)
+            rs = torch.empty((max(K, 32) // 32, N, H, W, 32), dtype=torch.float16, device=dev)
+            L.check(L.lib.innfer_nchw_to_slab(r.to(dev).contiguous().data_ptr(), L.F16, rs.data_ptr(), g_out, 0, N, K, H, W, None))
+            setattr(a, f"d_res{name}", rs.data_ptr()); setattr(a, f"res{name}_group_stride", g_out); setattr(a, f"res{name}_scale", sc)
             keep.append(rs)
     if rows:
         a.row_begin, a.row_end = rows
     L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
     torch.cuda.synchronize()
     res = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
-    L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), out_stride, out_off, res.data_ptr(), L.F32, N, K, H, W, None))
+    L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), g_out, out_off, res.data_ptr(), L.F32, N, K, H, W, None))
     torch.cuda.synchronize()
     return res.cpu(), out.cpu()
 
@@ -106,11 +109,11 @@ def test_conv_epilogues_and_slab_offsets(dev):
     b = torch.from_numpy(synth.uniform((K,), 6, -1, 1))
     r1 = torch.from_numpy(synth.uniform((N, K, H, W), 7, -1, 1)).half()
     r2 = torch.from_numpy(synth.uniform((N, K, H, W), 8, -1, 1)).half()
-    got, raw = _run_conv(dev, x, w, b, K, act=0, res1=r1, s1=0.2, res2=r2, s2=0.2, out_stride=192, out_off=64)
+    got, raw = _run_conv(dev, x, w, b, K, act=0, res1=r1, s1=0.2, res2=r2, s2=0.2, out_channels=192, out_off=64)
     ref = _ref_conv(x, w, b, act=0, res1=r1, s1=0.2, res2=r2, s2=0.2)
     assert (got - ref).abs().max().item() < 4e-3
-    # channels outside [64,128) of the output slab are untouched (dense concat = channel offset)
-    assert torch.all(raw[..., :64] == -3.0) and torch.all(raw[..., 128:] == -3.0)
+    # channel groups outside [64,128) of the output slab are untouched (dense concat = group offset)
+    assert torch.all(raw[:2] == -3.0) and torch.all(raw[4:] == -3.0)
     got, _ = _run_conv(dev, x, w, b, K, act=2)
     assert (got - _ref_conv(x, w, b, act=2)).abs().max().item() < 4e-3
 
@@ -134,7 +137,7 @@ def test_conv_row_range(dev):
     full, _ = _run_conv(dev, x, w, b, K)
     part, raw = _run_conv(dev, x, w, b, K, rows=(7, 29))
     assert torch.equal(part[:, :, 7:29], full[:, :, 7:29])
-    assert torch.all(raw[:, :7] == -3.0) and torch.all(raw[:, 29:] == -3.0)
+    assert torch.all(raw[:, :, :7] == -3.0) and torch.all(raw[:, :, 29:] == -3.0)
 
 
 def test_conv_error_codes(dev):
