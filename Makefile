@@ -17,7 +17,12 @@ $(LIB): $(OBJ)
 	@mkdir -p innfer_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
 
+# diagnostic library with in-kernel s_memtime stamps (never shipped, never benchmarked)
+stamps:
+	@mkdir -p build/stamps
+	$(HIPCC) $(FLAGS) -DINNFER_STAMPS -shared -o innfer_amd/lib/libinnfer_amd_stamps.so $(SRC)
+
 clean:
 	rm -f $(OBJ) $(LIB)
 
-.PHONY: all clean
+.PHONY: all clean stamps

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libinnfer_amd.so")
+LIB_PATH = os.environ.get("INNFER_LIB") or os.path.join(_HERE, "lib", "libinnfer_amd.so")
 
 F16, F32 = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM, ERR_WORKSPACE = 0, -1, -2, -3, -4, -5

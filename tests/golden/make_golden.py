@@ -270,7 +270,21 @@ def g10():
          newarch_keys=np.array(new_keys))
 
 
+# ------------------------------------------------------- G12 default configs
+def g12():
+    import json
+    rows = {}
+    for kind, scale, extra in [("esrgan", 4, {}), ("esrgan", 1, {}), ("rrdb_net", 2, {"nb": 5}), ("esrgan-lite", 4, {}),
+                               ("srgan", 4, {}), ("sr_resnet", 2, {"nf": 32, "nb": 3}), ("srresnet", 8, {}),
+                               ("esrgan", 4, {"in_nc": 1, "out_nc": 1, "nf": 48, "nb": 2, "plus": True})]:
+        d = dict(type=kind, **extra)
+        rows[f"{kind}|{scale}|{json.dumps(extra, sort_keys=True)}"] = get_network_G_config(d, scale)
+    rows["str:esrgan|4"] = get_network_G_config("esrgan", 4)
+    rows["which_model_G:srgan|4"] = get_network_G_config({"which_model_G": "srgan"}, 4)
+    save("g12_defaults", table=np.array(json.dumps(rows, sort_keys=True)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "g12"]
     for g in which:
         globals()[g]()

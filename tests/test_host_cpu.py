@@ -1,0 +1,202 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host-side logic
+(tile geometry, blend profile, weight panels, loader, default configs, tile sharding) matches the
+golden vectors generated from the reference, and nothing silently falls back to the CPU."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import innfer_amd.lib as L
+from innfer_amd import synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "innfer_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(innfer_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 24
+    for n in sorted(names):
+        assert hasattr(L.lib, n), f"libinnfer_amd.so does not export {n}"
+        assert n in L.SIGNATURES, f"{n} has no ctypes signature in innfer_amd/lib.py"
+    assert set(L.SIGNATURES) <= names, "lib.py binds symbols the header does not declare"
+    assert L.lib.innfer_version() >= 100
+
+
+def test_chop_plan_matches_reference_geometry(golden):
+    g = golden("g1_geometry")
+    for key in g.files:
+        h, w = map(int, key[4:].split("x"))
+        ps, ys, xs = L.chop_plan(h, w)
+        assert ps == min(h, w, 200)
+        org = np.array([(y, x) for y in ys for x in xs], dtype=np.int32)
+        assert np.array_equal(org, g[key]), key
+    for (h, w, n) in [(1080, 1920, 190), (2160, 3840, 798), (4320, 7680, 3268), (128, 128, 1)]:
+        _, ys, xs = L.chop_plan(h, w)
+        assert len(ys) * len(xs) == n
+    with pytest.raises(ValueError):
+        L.chop_plan(0, 10)
+
+
+def test_blend_profile_is_torch_linspace_bit_exact(golden):
+    g = golden("g2_blend")
+    for key in g.files:
+        if key.startswith("profile_"):
+            P, s = key[8:].split("_")
+            assert np.array_equal(L.blend_profile(int(P[1:]), 0.5, int(s[1:])), g[key]), key
+    with pytest.raises(ValueError):          # odd small patch: the reference raises too (utils.py:415)
+        L.blend_profile(151, 0.5, 1)
+
+
+def _pack_reference(w, K, Cc):
+    """numpy restatement of the documented panel layout (csrc/conv3x3.hip conv_pack)."""
+    nt = 4 if K >= 64 else (2 if K >= 32 else 1)
+    rows = 16 * nt
+    groups = (K + rows - 1) // rows
+    out = np.zeros((groups, Cc // 32, 9, rows, 4, 8), dtype=np.float16)
+    for g in range(groups):
+        for R in range(rows):
+            t, rho = R >> 4, R & 15
+            oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3)
+            if oc >= K:
+                continue
+            for sg in range(4):
+                cg = sg ^ (((R >> 2) & 1) << 1)
+                for c in range(Cc // 32):
+                    ic = c * 32 + cg * 8
+                    out[g, c, :, R, sg, :] = w[oc, ic:ic + 8].reshape(8, 9).T
+    return out
+
+
+@pytest.mark.parametrize("K,Cc", [(32, 64), (64, 96), (16, 32), (3, 64), (256, 64)])
+def test_weight_panel_layout(K, Cc):
+    w = synth.uniform((K, Cc, 3, 3), 7, -1, 1)
+    n = L.lib.innfer_conv3x3_packed_bytes(K, Cc)
+    buf = np.zeros(n, dtype=np.uint8)
+    L.check(L.lib.innfer_pack_conv3x3(w.ctypes.data, K, Cc, buf.ctypes.data))
+    ref = _pack_reference(w, K, Cc)
+    assert n == ref.nbytes
+    assert np.array_equal(buf.view(np.float16), ref.reshape(-1))
+    assert L.lib.innfer_conv3x3_packed_bytes(32, 48) == 0
+    assert L.lib.innfer_pack_conv3x3(w.ctypes.data, K, 48, buf.ctypes.data) == L.ERR_INVALID
+
+
+def _new_arch(sd_old):
+    fixed = {"model.0": "conv_first", "model.1.sub.23": "trunk_conv", "model.3": "upconv1", "model.6": "upconv2",
+             "model.8": "HRconv", "model.10": "conv_last"}
+    out = {}
+    for k, v in sd_old.items():
+        base, leaf = k.rsplit(".", 1)
+        if base in fixed:
+            out[f"{fixed[base]}.{leaf}"] = v
+        else:
+            out[base.replace("model.1.sub.", "RRDB_trunk.")[:-2] + "." + leaf] = v
+    return out
+
+
+def test_loader_inference_matches_reference(golden):
+    from innfer_amd.run import infer_from_state_dict
+    g = golden("g10_loader")
+    cases = {}
+    for scale in (1, 2, 4, 8):
+        cases[f"{scale}x_old.pth"] = synth.fill_state_dict(synth.rrdbnet_shapes(nb=2, scale=scale, nf=48), 0)
+    cases["4x_gray.pth"] = synth.fill_state_dict(synth.rrdbnet_shapes(nb=1, scale=4, in_nc=1, out_nc=1), 0)
+    cases["4x_plus.pth"] = synth.fill_state_dict(synth.rrdbnet_shapes(nb=1, scale=4, plus=True), 0)
+    cases["4x_srgan.pth"] = synth.fill_state_dict(synth.srresnet_shapes(nb=3, scale=4), 0)
+    old = synth.fill_state_dict(synth.rrdbnet_shapes(nb=23, scale=4, nf=16), 0)
+    cases["4x_newarch.pth"] = _new_arch(old)
+    assert sorted(cases["4x_newarch.pth"]) == list(g["newarch_keys"])
+    swa = {"n_averaged": np.asarray(3)}
+    swa.update({"module.module." + k: v for k, v in synth.fill_state_dict(synth.rrdbnet_shapes(nb=1, scale=2), 0).items()})
+    cases["2x_swa.pth"] = swa
+    for i, name in enumerate(g["names"]):
+        info = infer_from_state_dict(dict(cases[str(name)]))
+        assert info["arch"] == str(g["arch"][i]), name
+        assert info["scale"] == int(g["scale"][i]), name
+        assert (info["nf"], info["nb"], info["in_nc"], info["out_nc"]) == \
+            (int(g["nf"][i]), int(g["nb"][i]), int(g["in_nc"][i]), int(g["out_nc"][i])), name
+        assert "|".join(sorted(info["state_dict"].keys())) == str(g["keys"][i]), name
+        assert info["plus"] == (str(name) == "4x_plus.pth")
+    with pytest.raises(Exception, match="Could not infer"):
+        infer_from_state_dict({"foo.weight": np.zeros(1)})
+    with pytest.raises(NotImplementedError):
+        infer_from_state_dict({"SCPA_trunk.0.conv1_a.weight": np.zeros(1)})
+
+
+def test_default_configs_match_reference(golden):
+    from innfer_amd.utils.defaults import get_network_G_config
+    table = json.loads(str(golden("g12_defaults")["table"]))
+    for key, ref in table.items():
+        if key.startswith("str:"):
+            kind, scale = key[4:].split("|")
+            got = get_network_G_config(kind, int(scale))
+        elif key.startswith("which_model_G:"):
+            kind, scale = key[len("which_model_G:"):].split("|")
+            got = get_network_G_config({"which_model_G": kind}, int(scale))
+        else:
+            kind, scale, extra = key.split("|", 2)
+            got = get_network_G_config(dict(type=kind, **json.loads(extra)), int(scale))
+        assert got == ref, key
+    with pytest.raises(NotImplementedError):
+        get_network_G_config("nope", 4)
+
+
+def test_module_shells_carry_reference_keys_and_refuse_cpu():
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config({"type": "esrgan", "nb": 2}, 4))
+    shapes = synth.rrdbnet_shapes(nb=2, scale=4)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}, strict=True)
+    bad = dict(sd); bad.pop("model.0.bias")
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad, strict=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net(torch.zeros(1, 3, 8, 8))
+    srg = get_network(get_network_G_config({"type": "srgan", "nb": 2}, 4))
+    assert list(srg.state_dict().keys()) == list(synth.srresnet_shapes(nb=2, scale=4).keys())
+    with pytest.raises(NotImplementedError):
+        get_network(get_network_G_config({"type": "esrgan", "plus": True}, 4))
+    with pytest.raises(NotImplementedError):
+        get_network({"type": "pan_net"})
+    from innfer_amd.run import Model
+    with pytest.raises(RuntimeError):
+        Model("nowhere.pth", arch="infer", device="cpu")
+
+
+def test_entry_points_report_errors_without_a_gpu():
+    a = L.ConvArgs()
+    assert L.lib.innfer_conv3x3_f16(C.byref(a), None) == L.ERR_INVALID
+    assert "null" in L.last_error()
+    h = C.c_void_p()
+    assert L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 3, 0) == L.ERR_UNSUPPORTED      # scale 3
+    assert L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 4, 1) == L.ERR_UNSUPPORTED      # ESRGAN+
+    L.check(L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 23, 32, 4, 0))
+    assert L.lib.innfer_net_num_convs(h) == 351                                                      # 351 convs
+    key = C.create_string_buffer(128); K = C.c_int(); Cc = C.c_int()
+    L.check(L.lib.innfer_net_conv_info(h, 5, key, 128, C.byref(K), C.byref(Cc)))
+    assert (key.value.decode(), K.value, Cc.value) == ("model.1.sub.0.RDB1.conv5.0", 64, 192)
+    # 35 853 696 FLOP per input pixel
+    assert L.lib.innfer_net_flops(h, 1, 1080, 1920) == pytest.approx(35853696.0 * 1080 * 1920, rel=1e-12)
+    assert L.lib.innfer_net_workspace_bytes(h, 1, 1080, 1920) > 0
+    assert L.lib.innfer_net_forward(h, None, 0, None, 0, 1, 8, 8, None, 0, None) == L.ERR_INVALID
+    L.lib.innfer_net_destroy(h)
+
+
+def test_tile_row_sharding():
+    from innfer_amd.parallel import shard_tile_rows
+    for rows, cols, world in [(43, 76, 8), (21, 38, 8), (10, 19, 4), (3, 5, 8), (1, 1, 2)]:
+        spans = [shard_tile_rows(rows, cols, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == rows * cols
+        for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+            assert f0 + c0 == f1
+        counts = [c // cols for _, c in spans]
+        assert max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
+    assert [shard_tile_rows(43, 76, 8, r)[1] // 76 for r in range(8)] == [6, 6, 6, 5, 5, 5, 5, 5]
