@@ -74,6 +74,18 @@ def timed_forward(net, x):
     return [(kd[i], ms[i], fl[i]) for i in range(min(n.value, cap))]
 
 
+def pmc_traffic(kind):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by scripts/profile.sh + summarize_prof.py), or None."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        nt, mode = kind // 16, kind % 16
+        rpw = {1: 4, 2: 4, 4: 2}[nt]
+        return t[f"conv3x3_mfma<{rpw},{nt},{mode}>"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def roofline_from_launches(launches):
     agg = {}
     for k, ms, fl in launches:
@@ -89,7 +101,9 @@ def roofline_from_launches(launches):
     return {"bound": "mfma", "kernel": kind_name(dom), "launches": cnt,
             "avg_launch_ms": round(t_ms / cnt, 5), "flops_per_launch": flops / cnt,
             "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": pmc_traffic(dom),
+            "traffic_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB averaged over the kernel's "
+                            "dispatches, separate rocprofv3 --pmc passes (profiles/traffic.json)",
             "all_kernels_tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 2),
             "per_kernel": per_kernel}
 
