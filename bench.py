@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="frame1080", choices=["frame1080", "frame540", "chop8k", "chop4k"])
     ap.add_argument("--band-rows", type=int, default=int(os.environ.get("INNFER_BAND_ROWS", "0")))
+    ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -230,7 +231,7 @@ def main():
         from innfer_amd import parallel
         H, W = (4320, 7680) if args.workload == "chop8k" else (2160, 3840)
         x = torch.from_numpy(synth.uniform((1, 3, H, W), 2)).to(dev).half()
-        runner = parallel.ChopRunner(net, scale=4, tile_batch=38 if args.workload == "chop4k" else 76)
+        runner = parallel.ChopRunner(net, scale=4, tile_batch=args.tile_batch or 16)
         out_pix_per_rank = 16 * H * W / world       # unique output pixels of the ONE shared frame
 
         def step():

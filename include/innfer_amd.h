@@ -171,6 +171,12 @@ int innfer_u8hwc_to_nchw(const uint8_t* d_img, int H, int W, int C, int normaliz
 int innfer_nchw_to_u8hwc(const void* d_in, int in_dtype, int H, int W, int C, int denormalize,
                          uint8_t* d_img, void* stream);
 
+/* srgb2linear / linear2srgb (utils/colors.py:29-46, 49-60), the pointwise halves of the `-cf` colour
+ * fix: uint8 sRGB -> float32 linear, and float32 linear -> uint8 sRGB (clip, gamma, *255, TRUNCATING
+ * cast like astype(np.uint8)).  n = number of elements (any layout). */
+int innfer_srgb_to_linear(const uint8_t* d_in, float* d_out, size_t n, void* stream);
+int innfer_linear_to_srgb(const float* d_in, uint8_t* d_out, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,6 +147,24 @@ __global__ void k_nchw_to_u8(const TI* in, uint8_t* img, long hw, int C, int den
     }
 }
 
+// colors.py:29-46: linear = float32(srgb)/255; linear <= 0.04045 ? linear/12.92 : ((linear+0.055)/1.055)^2.4
+__global__ void k_srgb2linear(const uint8_t* in, float* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float l = __fdiv_rn((float)in[i], 255.0f);
+    out[i] = l <= 0.04045f ? __fdiv_rn(l, 12.92f) : powf(__fdiv_rn(__fadd_rn(l, 0.055f), 1.055f), 2.4f);
+}
+
+// colors.py:49-60: clip to [0,1]; s <= 0.0031308 ? s*12.92 : 1.055*s^(1/2.4) - 0.055; clip(s*255, 0, 255) TRUNCATED to uint8
+__global__ void k_linear2srgb(const float* in, uint8_t* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = fminf(fmaxf(in[i], 0.0f), 1.0f);
+    s = s <= 0.0031308f ? __fmul_rn(s, 12.92f) : __fsub_rn(__fmul_rn(1.055f, powf(s, (float)(1.0 / 2.4))), 0.055f);
+    s = fminf(fmaxf(__fmul_rn(s, 255.0f), 0.0f), 255.0f);
+    out[i] = (uint8_t)(int)s;                                   // astype(np.uint8): truncation
+}
+
 inline unsigned blocks(long total, int bs) { return (unsigned)((total + bs - 1) / bs); }
 
 }  // namespace
@@ -289,6 +307,22 @@ extern "C" int innfer_nchw_to_u8hwc(const void* d_in, int in_dtype, int H, int W
     if (in_dtype == INNFER_F16) hipLaunchKernelGGL(k_nchw_to_u8<f16>, dim3(blocks(hw, 256)), dim3(256), 0, s, (const f16*)d_in, d_img, hw, C, denormalize);
     else if (in_dtype == INNFER_F32) hipLaunchKernelGGL(k_nchw_to_u8<float>, dim3(blocks(hw, 256)), dim3(256), 0, s, (const float*)d_in, d_img, hw, C, denormalize);
     else return set_error(INNFER_ERR_INVALID, "nchw_to_u8hwc: bad dtype");
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_srgb_to_linear(const uint8_t* d_in, float* d_out, size_t n, void* stream) {
+    if (!d_in || !d_out) return set_error(INNFER_ERR_INVALID, "srgb_to_linear: null argument");
+    if (n == 0) return INNFER_OK;
+    hipLaunchKernelGGL(k_srgb2linear, dim3(blocks((long)n, 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, (long)n);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_linear_to_srgb(const float* d_in, uint8_t* d_out, size_t n, void* stream) {
+    if (!d_in || !d_out) return set_error(INNFER_ERR_INVALID, "linear_to_srgb: null argument");
+    if (n == 0) return INNFER_OK;
+    hipLaunchKernelGGL(k_linear2srgb, dim3(blocks((long)n, 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, (long)n);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }

@@ -70,7 +70,7 @@ def infer_from_state_dict(state_dict):
 
 class Model:
     def __init__(self, model_path, arch=None, scale=None, in_nc=3, out_nc=3, device='cuda',
-                 meval=True, strict=True, chop=True, tile_batch=32, state_dict=None):
+                 meval=True, strict=True, chop=True, tile_batch=16, state_dict=None):
         self.model_path = model_path
         self.arch = arch
         self.scale = scale

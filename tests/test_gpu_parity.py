@@ -304,6 +304,38 @@ def test_pre_post_bit_exact(dev, golden):
     assert np.array_equal(t4, (img4.astype(np.float32) / 255).transpose(2, 0, 1)[[2, 1, 0, 3]])
 
 
+def test_srgb_helpers(dev, golden):
+    """colors.py srgb2linear / linear2srgb.  powf differs from numpy's by an ulp or so: float results
+    within 2e-6; the truncating uint8 cast may flip one code exactly at a boundary."""
+    from innfer_amd.utils import colors as Cc
+    g = golden("g9_convert")
+    lin = Cc.srgb2linear(np.arange(256, dtype=np.uint8))
+    assert lin.dtype == np.float32 and np.abs(lin - g["srgb2linear"]).max() < 2e-6
+    back = Cc.linear2srgb(np.linspace(-0.1, 1.1, 1001, dtype=np.float32))
+    d = np.abs(back.astype(int) - g["linear2srgb"].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() < 0.005
+    img = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    rt = Cc.linear2srgb(Cc.srgb2linear(img))
+    assert np.abs(rt.astype(int) - img.astype(int)).max() <= 1
+
+
+def test_esrgan_lite_and_gray_shapes(dev):
+    """nf=32 (esrgan-lite, defaults.py:25-27) and 1-channel models run through the same kernels."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    for (in_nc, out_nc, nf, nb, scale) in [(3, 3, 32, 2, 4), (1, 1, 64, 1, 2), (4, 4, 64, 1, 1)]:
+        sd = _sd(synth.rrdbnet_shapes(in_nc=in_nc, out_nc=out_nc, nf=nf, nb=nb, scale=scale))
+        net = RRDBNet(in_nc, out_nc, nf, nb, upscale=scale)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((2, in_nc, 29, 41), 50 + nf))
+        y = net(x.to(dev).half()).float().cpu()
+        with torch.no_grad():
+            ref = oracle.rrdbnet_forward(sd, x, nb=nb, scale=scale)
+        assert (y - ref).abs().max().item() < 1e-2, (in_nc, nf, scale)
+
+
 # ---------------------------------------------------------------- Model / chop
 def test_model_chop_golden(dev, golden, tmp_path):
     from innfer_amd import synth
