@@ -4,9 +4,10 @@
 // [+ x*0.2 + residual] [+ nearest-2x Upsample in front] [+ PixelShuffle behind]
 // (architectures/block.py:213-254,333-361; RRDBNet_arch.py:152-165,91-98).
 //
-// Data layout in HBM: activations are fp16 NHWC "channel slabs": a pixel's
-// channels are contiguous, pixel stride = slab width (192 for an RDB: x|x1|x2|x3|x4),
-// so the dense concat of the reference is a channel offset, never a copy.
+// Data layout in HBM: activations are fp16 "blocked NHWC" channel slabs: channels in groups of
+// 32, element (n,y,x,c) at base + (c/32)*group_stride + ((n*H+y)*W+x)*32 + c%32, so a 32-channel
+// chunk of consecutive pixels is a contiguous run of full 128-B lines and the dense concat of the
+// reference (x|x1|x2|x3|x4) is a group offset, never a copy.
 //
 // GEMM view per tap (r,s) and 32-channel chunk:  D[oc][px] += W[oc][c] * X[px+tap][c]
 //   MFMA v_mfma_f32_16x16x32_f16, A = weights (rows = 16 out channels),
@@ -17,7 +18,8 @@
 // Workgroup = 256 threads = 4 waves, tile = (4*RPW rows) x 32 px, all 16*NT output
 // channels of one channel group.  Wave w owns rows [w*RPW, (w+1)*RPW).
 // Per 32-channel chunk the halo tile ((4*RPW+2) x 34 px x 64 B) and the weight
-// panel (9 x 16*NT x 64 B) are staged with LDS-DMA (global_load_lds_dwordx4);
+// panel (9 x 16*NT x 64 B) are staged with LDS-DMA (buffer_load_dwordx4 ... lds; out-of-image
+// lanes are zero-filled by the buffer range check = the conv's zero padding);
 // LDS rows are 40 px so every row base is a multiple of 8 px, which makes the
 // 16-B-slot XOR swizzle (slot ^= 2*bit2(pixel)) a pure function of (lane, s):
 // all ds_read_b128 are base+immediate and bank-conflict free.
@@ -130,8 +132,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         const int sy = (Y >> p.up) - sy_base, sx = X >> p.up;
         in_off[k] = ok ? ((sy * p.Ws + sx) * 32 + slot * 8) * 2 : -1;
     }
-    const char* w_base = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES + lane * 16;
-
     // ---- per-lane LDS read bases ------------------------------------------------
     const int li = lane & 15, lg = lane >> 4;
     const char* bbase[3];
@@ -153,22 +153,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
     }
 
     STAMP(1);
+    // Issue path: every piece is ONE `buffer_load_dwordx4 ... offen lds` with a per-chunk SGPR
+    // descriptor and a per-lane byte offset computed once per workgroup -- no VALU, no select.
+    // Lanes whose pixel lies outside the image (the conv's zero padding) or in the LDS row pad carry
+    // an offset beyond num_records: the buffer range check then writes ZEROS to LDS (verified on
+    // gfx950 by the border cases of tests/test_gpu_parity.py).
+    int voff[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) voff[k] = in_off[k] >= 0 ? in_off[k] : (int)0x80000000;
+    const int wvoff = lane * 16;
+    const char* w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
+
     for (int c = 0; c < p.nchunks; ++c) {
         // stage chunk c: halo tile + weight panel, straight into LDS
+#if defined(__HIP_DEVICE_COMPILE__)      // the LDS buffer-load builtin only exists in the device pass
+        {
+            const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(in_base + c * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(w_tile + (long)c * W_BYTES), 0, W_BYTES, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) {
-            const int q = wave + 4 * k;
-            if (q < NQ) {
-                const char* src = in_off[k] >= 0 ? in_base + in_off[k] + c * p.in_gbytes
-                                                 : (const char*)g_zero_page;
-                dma16(src, lds_in + q * 1024);
+            for (int k = 0; k < KQ; ++k) {
+                const int q = wave + 4 * k;
+                if (q < NQ)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        ri, (__attribute__((address_space(3))) void*)(lds_in + q * 1024), 16, voff[k], 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int j = wave + 4 * k;
+                if (j < WQ)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rw, (__attribute__((address_space(3))) void*)(lds_w + j * 1024), 16, wvoff, j * 1024, 0, 0);
             }
         }
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            const int j = wave + 4 * k;
-            if (j < WQ) dma16(w_base + (long)c * W_BYTES + j * 1024, lds_w + j * 1024);
-        }
+#else
+        (void)voff; (void)wvoff; (void)w_tile; (void)in_base; (void)KW;
+#endif
         if (c < 3) STAMP(2 + 3 * c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
