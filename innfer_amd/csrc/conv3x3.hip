@@ -67,6 +67,7 @@ struct KP {
     int out_f32;
     int N;
     unsigned tx_magic;       // ceil(2^32 / tiles_x): tile / tiles_x == (tile * tx_magic) >> 32
+    int pf;                  // L2 prefetch of the next chunk's input lines
 };
 
 __device__ __forceinline__ void dma16(const void* g, void* lds) {
@@ -164,6 +165,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
     const int wvoff = lane * 16;
     const char* w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
 
+    // L2 prefetch plan (p.pf): LDS-DMA streams ~3x faster from L2 than from HBM and a workgroup can
+    // only keep one chunk of LDS-DMA in flight, so while chunk c is landing / being computed every
+    // thread touches one dword in (up to) two 128-B lines of chunk c+1's halo tile: ordinary loads,
+    // results discarded, nothing waits for them until a whole compute phase later.
+    constexpr int LPR = (LVALID * 64 + 127) / 128 + 1;        // 128-B lines per tile row (18)
+    constexpr int NLINES = LH * LPR;
+    int pfo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i;
+        const int r = id / LPR, l = id - r * LPR;
+        const int Y = ty0 - 1 + r;
+        const int xs = tx0 > 0 ? tx0 - 1 : 0;
+        const bool ok = p.pf && !p.up && id < NLINES && Y >= 0 && Y < p.H && ((xs * 64) & ~127) + l * 128 < p.W * 64;
+        pfo[i] = ok ? (((Y - sy_base) * p.Ws * 64 + ((xs * 64) & ~127) + l * 128)) : (int)0x80000000;
+    }
+    char* lds_pf = smem + IN_BYTES + W_BYTES + wave * 512;    // 2 KiB scratch nobody reads
+
     for (int c = 0; c < p.nchunks; ++c) {
         // stage chunk c: halo tile + weight panel, straight into LDS
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS buffer-load builtin only exists in the device pass
@@ -187,12 +206,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
                         rw, (__attribute__((address_space(3))) void*)(lds_w + j * 1024), 16, wvoff, j * 1024, 0, 0);
             }
         }
+        asm volatile("" ::: "memory");                      // keep the prefetch loads BEHIND the DMA pieces
+        const bool do_pf = p.pf && !p.up && c + 1 < p.nchunks;
+        if (do_pf) {
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(in_base + (c + 1) * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void*)lds_pf, 4, pfo[0], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void*)(lds_pf + 256), 4, pfo[1], 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the DMA pieces, not the two prefetch loads
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
 #else
-        (void)voff; (void)wvoff; (void)w_tile; (void)in_base; (void)KW;
+        (void)voff; (void)wvoff; (void)w_tile; (void)in_base; (void)KW; (void)pfo; (void)lds_pf;
 #endif
         if (c < 3) STAMP(2 + 3 * c);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_barrier" ::: "memory");             // raw: __syncthreads() would drain vmcnt to 0
         if (c < 3) STAMP(3 + 3 * c);
 
 #pragma unroll
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
                 }
             }
         }
-        __syncthreads();
+        asm volatile("s_barrier" ::: "memory");
         if (c < 3) STAMP(4 + 3 * c);
     }
     STAMP(11);
@@ -671,7 +700,7 @@ int conv_variant() {
 template <int RPW, int NT, int OUTMODE>
 int launch_t(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 4 * RPW;
-    constexpr int LDS = ((TH + 2) * LWP / 16) * 1024 + 9 * NT * 16 * 64;
+    constexpr int LDS = ((TH + 2) * LWP / 16) * 1024 + 9 * NT * 16 * 64 + 2048;   // + prefetch scratch
     static bool attr_done = false;
     if (!attr_done) {
         INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma<RPW, NT, OUTMODE>,
@@ -681,6 +710,10 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
+    {
+        static const int pf = getenv("INNFER_PREFETCH") ? atoi(getenv("INNFER_PREFETCH")) : 1;
+        k.pf = pf;
+    }
     const long grid = (long)N * k.tiles_x * k.tiles_y * k.KG;
     if (grid <= 0) return INNFER_OK;
     if (grid > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
