@@ -20,16 +20,16 @@ class RRDBNet(EngineModule):
         if upsample_mode != 'upconv': unsupported.append(f'upsample_mode={upsample_mode}')
         if convtype != 'Conv2D': unsupported.append(f'convtype={convtype}')
         if finalact: unsupported.append(f'finalact={finalact}')
-        if plus: unsupported.append('plus=True (ESRGAN+)')
         if upscale == 3: unsupported.append('upscale=3')
         if unsupported:
             raise NotImplementedError('RRDBNet option(s) not built on the HIP path yet: ' + ', '.join(unsupported))
         # gaussian_noise: GaussianNoise is the identity in eval mode (block.py:382-388)
         super().__init__(rrdbnet_shapes(in_nc, out_nc, nf, nb, 32, upscale, plus))
         self.in_nc, self.out_nc, self.nf, self.nb, self.gc, self.upscale = in_nc, out_nc, nf, nb, 32, upscale
+        self.plus = bool(plus)
 
     def _create_handle(self):
         h = C.c_void_p()
         L.check(L.lib.innfer_rrdbnet_create(C.byref(h), self.in_nc, self.out_nc, self.nf, self.nb,
-                                            self.gc, self.upscale, 0))
+                                            self.gc, self.upscale, int(self.plus)))
         return h

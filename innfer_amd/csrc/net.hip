@@ -35,6 +35,7 @@ struct ConvSlot {
     std::string key;
     int K = 0, C = 0;
     bool first = false;          // small-Cin VALU conv (fp32 [C*9][K] weights)
+    int ksize = 3;               // 1: a 1x1 conv, packed as the centre tap of a 3x3 panel
     void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
     float* d_b = nullptr;        // bias padded to the panel width
     bool loaded = false;
@@ -44,6 +45,7 @@ struct innfer_net {
     int kind = 0;                // 0 rrdbnet, 1 srresnet
     int in_nc = 3, out_nc = 3, nf = 64, nb = 23, gc = 32, scale = 4, n_up = 2;
     int band_rows = 0;
+    bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
     std::vector<ConvSlot> convs;
 };
 
@@ -53,9 +55,9 @@ static int n_upscale(int scale) {
     return n;
 }
 
-static void add_conv(innfer_net* net, const std::string& key, int K, int C, bool first = false) {
+static void add_conv(innfer_net* net, const std::string& key, int K, int C, bool first = false, int ksize = 3) {
     ConvSlot s;
-    s.key = key; s.K = K; s.C = C; s.first = first;
+    s.key = key; s.K = K; s.C = C; s.first = first; s.ksize = ksize;
     net->convs.push_back(s);
 }
 
@@ -65,7 +67,6 @@ extern "C" const char* innfer_last_error(void) { return g_err.c_str(); }
 extern "C" int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
                                      int gc, int scale, int plus) {
     if (!out) return set_error(INNFER_ERR_INVALID, "rrdbnet_create: null out");
-    if (plus) return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: ESRGAN+ (plus/conv1x1) is not built yet");
     if (scale != 1 && scale != 2 && scale != 4 && scale != 8 && scale != 16)
         return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: scale %d (only powers of two)", scale);
     if (nf % 32 || gc % 32 || nf <= 0 || gc <= 0 || nf > 64)
@@ -74,15 +75,21 @@ extern "C" int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, i
         return set_error(INNFER_ERR_INVALID, "rrdbnet_create: in_nc=%d out_nc=%d nb=%d", in_nc, out_nc, nb);
     innfer_net* net = new innfer_net();
     net->kind = 0; net->in_nc = in_nc; net->out_nc = out_nc; net->nf = nf; net->nb = nb;
-    net->gc = gc; net->scale = scale; net->n_up = n_upscale(scale);
+    net->gc = gc; net->scale = scale; net->n_up = n_upscale(scale); net->plus = plus != 0;
     add_conv(net, "model.0", nf, in_nc, true);
     for (int b = 0; b < nb; ++b)
-        for (int r = 1; r <= 3; ++r)
+        for (int r = 1; r <= 3; ++r) {
+            if (plus) {          // conv1x1(nf -> gc, no bias), added to x2 (RRDBNet_arch.py:131,155-156)
+                char key[96];
+                snprintf(key, sizeof key, "model.1.sub.%d.RDB%d.conv1x1", b, r);
+                add_conv(net, key, gc, nf, false, 1);
+            }
             for (int i = 1; i <= 5; ++i) {
                 char key[96];
                 snprintf(key, sizeof key, "model.1.sub.%d.RDB%d.conv%d.0", b, r, i);
                 add_conv(net, key, i < 5 ? gc : nf, nf + (i - 1) * gc);
             }
+        }
     add_conv(net, "model.1.sub." + std::to_string(nb), nf, nf);
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) { add_conv(net, "model." + std::to_string(idx + 1), nf, nf); idx += 3; }
@@ -152,7 +159,13 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
         bias_n = c.K;
     } else {
         host.resize(conv_packed_bytes(c.K, c.C));
-        conv_pack(w, c.K, c.C, host.data());
+        if (c.ksize == 1) {          // [K,C,1,1] -> centre tap of a [K,C,3,3] panel
+            std::vector<float> w3((size_t)c.K * c.C * 9, 0.f);
+            for (size_t i = 0; i < (size_t)c.K * c.C; ++i) w3[i * 9 + 4] = w[i];
+            conv_pack(w3.data(), c.K, c.C, host.data());
+        } else {
+            conv_pack(w, c.K, c.C, host.data());
+        }
         const int per = 16 * conv_nt_for(c.K);
         bias_n = (size_t)((c.K + per - 1) / per) * per;
     }
@@ -187,7 +200,7 @@ extern "C" double innfer_net_flops(innfer_net_t net, int N, int H, int W) {
             if (u < net->n_up) mult = std::pow(4.0, net->kind == 0 ? u + 1 : u);
             else mult = std::pow(4.0, net->n_up);
         }
-        f += 2.0 * 9.0 * c.K * c.C * px * mult;
+        f += 2.0 * c.ksize * c.ksize * c.K * c.C * px * mult;
     }
     return f;
 }
@@ -199,7 +212,7 @@ extern "C" double innfer_net_flops(innfer_net_t net, int N, int H, int W) {
 //   up[u]      [N,2^(u+1)H,2^(u+1)W,nf] after each upsample stage
 //   hr         [N,sH,sW,nf]             HR_conv0 output
 struct Carve {
-    size_t fea, slab[3], trunk, up[5], hr, total;
+    size_t fea, slab[3], trunk, up[5], hr, tmp, total;
     int slab_w;
 };
 
@@ -212,6 +225,7 @@ static Carve carve(const innfer_net* net, int N, int H, int W) {
     c.fea = off; off += al(px * net->nf * 2);
     for (int i = 0; i < 3; ++i) { c.slab[i] = off; off += al(px * c.slab_w * 2); }
     c.trunk = off; off += al(px * net->nf * 2);
+    c.tmp = off; if (net->plus) off += al(px * net->gc * 2);          // conv1x1(x) of the current RDB
     size_t m = 1;
     for (int u = 0; u < net->n_up; ++u) { m *= 4; c.up[u] = off; off += al(px * m * net->nf * 2); }
     c.hr = off; off += al(px * m * net->nf * 2);
@@ -382,9 +396,19 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             const int dest[3] = {f1, f2, f1};
             for (int r = 0; r < 3; ++r) {
                 f16* S = slab[work[r]];
+                f16* t1x1 = (f16*)(ws + cv.tmp);
+                if (net->plus) {                 // t = conv1x1(x): no bias, no activation
+                    const ConvSlot& cs = net->convs[ci++];
+                    chain.push_back(mk(cs, S, G, t1x1, G, N, H, W, 0));
+                }
                 for (int i = 0; i < 4; ++i) {
                     const ConvSlot& cs = net->convs[ci++];
-                    chain.push_back(mk(cs, S, G, S + (long)((nf + i * gc) / 32) * G, G, N, H, W, 1));
+                    ConvLaunch L = mk(cs, S, G, S + (long)((nf + i * gc) / 32) * G, G, N, H, W, 1);
+                    if (net->plus && i == 1) { L.res1 = t1x1; L.res1_gstride = G; L.s1 = 1.f; }          // x2 += conv1x1(x)
+                    if (net->plus && i == 3) {                                                             // x4 += x2
+                        L.res1 = S + (long)((nf + gc) / 32) * G; L.res1_gstride = G; L.s1 = 1.f;
+                    }
+                    chain.push_back(L);
                 }
                 const ConvSlot& cs = net->convs[ci++];
                 ConvLaunch L = mk(cs, S, G, slab[dest[r]], G, N, H, W, 0);

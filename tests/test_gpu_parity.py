@@ -188,6 +188,20 @@ def test_rrdbnet_scales_golden(dev, golden):
         assert np.abs(y - g[f"out_x{scale}"]).max() < 5e-3, scale
 
 
+def test_esrgan_plus_golden(dev, golden):
+    """ESRGAN+ residual paths (x2 += conv1x1(x), x4 += x2) against the reference (golden G5)."""
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    g = golden("g5_scales")
+    sd = _sd(synth.rrdbnet_shapes(nb=1, scale=4, plus=True))
+    net = RRDBNet(3, 3, 64, 1, upscale=4, plus=True)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 5)).to(dev).half()
+    y = net(x).float().cpu().numpy()
+    assert np.abs(y - g["out_x4_plus"]).max() < 5e-3
+
+
 def test_rrdbnet_batch_and_ragged_sizes(dev):
     import oracle
     from innfer_amd import synth
@@ -245,7 +259,7 @@ def test_missing_weights_and_cpu_are_loud(dev):
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 8, 8))               # CPU tensor: no fallback
     with pytest.raises(NotImplementedError):
-        RRDBNet(3, 3, 64, 1, plus=True)
+        RRDBNet(3, 3, 64, 1, upscale=3)
 
 
 # ---------------------------------------------------------- tiles / blend / io

@@ -162,8 +162,8 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
         net(torch.zeros(1, 3, 8, 8))
     srg = get_network(get_network_G_config({"type": "srgan", "nb": 2}, 4))
     assert list(srg.state_dict().keys()) == list(synth.srresnet_shapes(nb=2, scale=4).keys())
-    with pytest.raises(NotImplementedError):
-        get_network(get_network_G_config({"type": "esrgan", "plus": True}, 4))
+    plus = get_network(get_network_G_config({"type": "esrgan", "plus": True, "nb": 1}, 4))
+    assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
     with pytest.raises(NotImplementedError):
         get_network({"type": "pan_net"})
     from innfer_amd.run import Model
@@ -177,7 +177,9 @@ def test_entry_points_report_errors_without_a_gpu():
     assert "null" in L.last_error()
     h = C.c_void_p()
     assert L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 3, 0) == L.ERR_UNSUPPORTED      # scale 3
-    assert L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 4, 1) == L.ERR_UNSUPPORTED      # ESRGAN+
+    L.check(L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 4, 1))                           # ESRGAN+
+    assert L.lib.innfer_net_num_convs(h) == 1 + 3 * 6 + 1 + 2 + 2
+    L.lib.innfer_net_destroy(h)
     L.check(L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 23, 32, 4, 0))
     assert L.lib.innfer_net_num_convs(h) == 351                                                      # 351 convs
     key = C.create_string_buffer(128); K = C.c_int(); Cc = C.c_int()
