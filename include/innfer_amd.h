@@ -98,6 +98,26 @@ int innfer_net_set_band_rows(innfer_net_t net, int rows);
 /* Algorithmic FLOPs of one forward (2*MAC of every conv). */
 double innfer_net_flops(innfer_net_t net, int N, int H, int W);
 
+/* ------------------------------------------------------------- pix2pix UNet
+ * Replaces UnetGenerator(norm=batch, upsample_mode=deconv).forward (architectures/UNet_arch.py:11-161)
+ * as run.py runs it for `-a p2p_256 / unet_256` (meval=False: BatchNorm uses the statistics of the
+ * current image, run.py:299-303).  A batch is N independent batch-1 forwards (per-image statistics).
+ * Parameters are addressed by their state-dict key ("model.model.1.model.2.weight" ...): conv /
+ * conv-transpose weights in PyTorch layout, BatchNorm weight and bias; running statistics are listed
+ * (so that strict loading sees every key) but not used.
+ */
+typedef struct innfer_unet* innfer_unet_t;
+int innfer_unet_create(innfer_unet_t* out, int in_nc, int out_nc, int num_downs, int ngf);
+void innfer_unet_destroy(innfer_unet_t u);
+int innfer_unet_num_params(innfer_unet_t u);
+int innfer_unet_param_info(innfer_unet_t u, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
+int innfer_unet_set_param(innfer_unet_t u, int idx, const float* h_data);
+size_t innfer_unet_workspace_bytes(innfer_unet_t u, int N, int H, int W);
+double innfer_unet_flops(innfer_unet_t u, int N, int H, int W);
+/* d_in [N,in_nc,H,W] -> d_out [N,out_nc,H,W] (tanh range), NCHW f16/f32; H, W multiples of 2^num_downs. */
+int innfer_unet_forward(innfer_unet_t u, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                        int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* -------------------------------------------------- single fused convolution
  * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution
  * over an fp16 "blocked NHWC" channel slab (conv_block, block.py:213-254).

@@ -13,7 +13,9 @@ def get_network(opt_net):
         from .RRDBNet_arch import RRDBNet as net
     elif kind == 'sr_resnet':
         from .SRResNet_arch import SRResNet as net
-    elif kind in ('mrrdb_net', 'ppon', 'pan_net', 'unet_net', 'resnet_net', 'wbcunet_net'):
+    elif kind == 'unet_net':
+        from .UNet_arch import UnetGenerator as net
+    elif kind in ('mrrdb_net', 'ppon', 'pan_net', 'resnet_net', 'wbcunet_net'):
         raise NotImplementedError(
             f'Model [{kind}] exists in the reference but is outside the MI355X hot path built so far '
             '(SURVEY.md section 8: ESRGAN RRDBNet and SRResNet first)')

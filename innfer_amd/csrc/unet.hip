@@ -1,0 +1,526 @@
+// pix2pix UNet generator (UnetGenerator, norm=batch, deconv) on gfx950 -- BASELINE config 5.
+//
+// Replaces UNet_arch.py:11-161 as run.py runs it (meval=False: BatchNorm normalises with the
+// statistics of the CURRENT image, run.py:299-303,98-99; SURVEY.md D6: a batch is N independent
+// batch-1 forwards, so statistics are per image).
+//
+//   4x4 stride-2 pad-1 conv           -> gather-GEMM on MFMA: 16 taps x Cin/32 chunks
+//   4x4 stride-2 pad-1 ConvTranspose  -> four output phases (oy&1, ox&1), each a 2x2-tap gather-GEMM
+//   BatchNorm2d (training mode)       -> per-(image, channel) mean / biased variance over H*W in fp32
+//                                        on the fp32 conv output (two passes), eps 1e-5
+//   LeakyReLU(0.2, inplace) / ReLU / torch.cat / Tanh -> the "post" kernel writes every consumer's
+//       view of a tensor directly: the in-place LeakyReLU at the head of each block also rewrites the
+//       skip branch (UNet_arch.py:109,160), and the parent's in-place ReLU acts on the concatenation,
+//       so a down-path tensor t is consumed as lrelu(t) by the next down conv and as
+//       relu(lrelu(t)) = relu(t) by the up conv: two fp16 slabs, no activation on load.
+//
+// Correctness-first kernels (this path is 774 GFLOP for 64 images against 74 TFLOP per ESRGAN
+// frame): one 64-pixel x 64-channel tile per workgroup, operands staged through LDS with plain
+// loads, single-buffered.  Activations are blocked-NHWC fp16 like the SR path; conv outputs stay
+// fp32 until normalised.
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace innfer;
+
+namespace {
+
+struct GP {
+    const f16* in; long in_g; int nchunks; int N, Hin, Win;
+    const f16* wpk;                       // [cot][tap][chunk][64 rows][64 B], the LDS image of the A operand
+    float* out; int cout_pad;             // raw fp32 [N*Hfull*Wfull][cout_pad]
+    int Ho, Wo, stride;                   // this launch's output grid; in = out*stride + d
+    int ntaps; int dy[16], dx[16];
+    int Hfull, Wfull, os, ooy, oox;       // out pixel = (oy*os + ooy, ox*os + oox)
+};
+
+__global__ __launch_bounds__(256) void gemm_gather(const GP p) {
+    __shared__ __attribute__((aligned(16))) char lds[8192];
+    char* lds_b = lds;                    // 64 pixels x 64 B
+    char* lds_a = lds + 4096;             // 64 out channels x 64 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const long M = (long)p.N * p.Ho * p.Wo;
+    const long m0 = (long)blockIdx.x * 64;
+    const int cot = blockIdx.y;
+
+    // staging role of this thread: pixel row (tid>>2), 16-byte slot (tid&3)
+    const int srow = tid >> 2, sslot = tid & 3;
+    const long sm = m0 + srow;
+    int sn = 0, soy = 0, sox = 0;
+    const bool sm_ok = sm < M;
+    if (sm_ok) {
+        sox = (int)(sm % p.Wo);
+        soy = (int)((sm / p.Wo) % p.Ho);
+        sn = (int)(sm / ((long)p.Wo * p.Ho));
+    }
+    const int cslot = sslot ^ (((srow >> 2) & 1) << 1);           // channel slot stored at LDS slot sslot
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wbase = (const char*)p.wpk + (long)cot * p.ntaps * p.nchunks * 4096 + tid * 16;
+    const int brow = wave * 16 + li;
+    const int boff = brow * 64 + ((lg ^ (((brow >> 2) & 1) << 1)) << 4);
+    const int aoff = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+
+    for (int t = 0; t < p.ntaps; ++t) {
+        const int iy = soy * p.stride + p.dy[t], ix = sox * p.stride + p.dx[t];
+        const bool ok = sm_ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        const f16* src = p.in + (((long)sn * p.Hin + iy) * p.Win + ix) * 32 + cslot * 8;
+        for (int c = 0; c < p.nchunks; ++c) {
+            u32x4 vb = u32x4{0u, 0u, 0u, 0u};
+            if (ok) vb = *(const u32x4*)(src + (long)c * p.in_g);
+            const u32x4 va = *(const u32x4*)(wbase + ((long)t * p.nchunks + c) * 4096);
+            __syncthreads();
+            *(u32x4*)(lds_b + tid * 16) = vb;
+            *(u32x4*)(lds_a + tid * 16) = va;
+            __syncthreads();
+            const f16x8 b = *(const f16x8*)(lds_b + boff);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f16x8 a = *(const f16x8*)(lds_a + q * 1024 + aoff);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[q], 0, 0, 0);
+            }
+        }
+    }
+    // D rows = out channels (16*lg + 4*q + j after the panel permutation), cols = pixels
+    const long m = m0 + wave * 16 + li;
+    if (m < M) {
+        const int ox = (int)(m % p.Wo);
+        const int oy = (int)((m / p.Wo) % p.Ho);
+        const long n = m / ((long)p.Wo * p.Ho);
+        const long opix = (n * p.Hfull + (long)oy * p.os + p.ooy) * p.Wfull + (long)ox * p.os + p.oox;
+        float* op = p.out + opix * p.cout_pad + cot * 64 + 16 * lg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(op + 4 * q) = acc[q];
+    }
+}
+
+// per-(image, channel) mean and 1/sqrt(var_biased + eps) of raw[N][HW][cpad]
+__global__ __launch_bounds__(256) void bn_stats(const float* raw, int cpad, long HW, float eps, float* mean, float* rstd, int C) {
+    __shared__ float red[256];
+    const int n = blockIdx.y, cb = blockIdx.x * 32;
+    const int c = cb + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+    const float* base = raw + (long)n * HW * cpad + c;
+    float s = 0.f;
+    for (long px = pl; px < HW; px += 8) s += base[px * cpad];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += red[(threadIdx.x & 31) + 32 * i];
+    const float mu = tot / (float)HW;
+    __syncthreads();
+    float v = 0.f;
+    for (long px = pl; px < HW; px += 8) { const float d = base[px * cpad] - mu; v += d * d; }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        float vt = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vt += red[(threadIdx.x & 31) + 32 * i];
+        mean[(long)n * C + c] = mu;
+        rstd[(long)n * C + c] = 1.0f / sqrtf(vt / (float)HW + eps);
+    }
+}
+
+struct PostDst { f16* p; long g; int coff; int act; };      // act: 1 lrelu(0.2), 2 relu
+
+// raw fp32 -> (BatchNorm) -> activation -> up to two fp16 blocked-NHWC destinations; 8 channels per thread
+__global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, PostDst d0, PostDst d1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C / 8;
+    if (i >= (long)N * HW * c8) return;
+    const int c = (int)(i % c8) * 8;
+    const long pix = i / c8;                                  // n*HW + px
+    const long n = pix / HW;
+    const float* rp = raw + pix * cpad + c;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float x = rp[e];
+        if (mean) x = (x - mean[n * C + c + e]) * rstd[n * C + c + e] * gamma[c + e] + beta[c + e];
+        v[e] = x;
+    }
+    const PostDst ds[2] = {d0, d1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!ds[k].p) continue;
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (f16)(ds[k].act == 1 ? fmaxf(v[e], 0.2f * v[e]) : fmaxf(v[e], 0.f));
+        const int ch = ds[k].coff + c;
+        *(f16x8*)(ds[k].p + (ch >> 5) * ds[k].g + pix * 32 + (ch & 31)) = h;
+    }
+}
+
+// outermost: raw[.., 0:C] + bias -> tanh -> NCHW
+__global__ void unet_final(const float* raw, int cpad, int C, long HW, int N, const float* bias, void* out, int out_f32) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const long n = i / HW, px = i % HW;
+    for (int c = 0; c < C; ++c) {
+        const float y = tanhf(raw[i * cpad + c] + bias[c]);
+        const long o = (n * C + c) * HW + px;
+        if (out_f32) ((float*)out)[o] = y; else ((f16*)out)[o] = (f16)y;
+    }
+}
+
+__global__ void unet_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {    // NCHW -> one zero-padded group
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const long n = i / HW, px = i % HW;
+    f16 h[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) h[c] = (f16)0.f;
+    for (int c = 0; c < C; ++c) {
+        const long o = (n * C + c) * HW + px;
+        h[c] = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f16x8*)(slab + i * 32 + 8 * q) = *(const f16x8*)(h + 8 * q);
+}
+
+// ---- host: weight panels -----------------------------------------------------------------------
+// row R = q*16 + rho of a 64-channel tile holds out channel cot*64 + 16*(rho>>2) + 4*q + (rho&3);
+// LDS slot s of that row holds input channels chunk*32 + 8*(s ^ 2*bit2(R)) .. +7
+template <typename W>
+void pack_panels(std::vector<f16>& dst, int cout, int cin, int cin_pad, int ntaps, W weight_of) {
+    const int cots = (cout + 63) / 64, nch = cin_pad / 32;
+    dst.assign((size_t)cots * ntaps * nch * 64 * 32, (f16)0.f);
+    size_t o = 0;
+    for (int cot = 0; cot < cots; ++cot)
+        for (int t = 0; t < ntaps; ++t)
+            for (int c = 0; c < nch; ++c)
+                for (int R = 0; R < 64; ++R) {
+                    const int q = R >> 4, rho = R & 15;
+                    const int co = cot * 64 + 16 * (rho >> 2) + 4 * q + (rho & 3);
+                    for (int s = 0; s < 4; ++s) {
+                        const int cg = s ^ (((R >> 2) & 1) << 1);
+                        for (int e = 0; e < 8; ++e, ++o) {
+                            const int ci = c * 32 + cg * 8 + e;
+                            if (co < cout && ci < cin) dst[o] = (f16)weight_of(co, ci, t);
+                        }
+                    }
+                }
+}
+
+struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
+
+struct Layer {            // one conv / conv-transpose
+    bool transposed = false;
+    int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0;
+    int w = -1, bias = -1, gamma = -1, beta = -1;          // indices into params
+    f16* d_w[4] = {nullptr, nullptr, nullptr, nullptr};    // conv: [0]; convT: one panel set per phase
+    float *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
+};
+
+}  // namespace
+
+struct innfer_unet {
+    int in_nc = 3, out_nc = 3, num_downs = 8, ngf = 64;
+    std::vector<Param> params;
+    std::vector<Layer> down, up;       // down[k], up[k] for level k = 0 .. num_downs-1
+    std::vector<int> dc;               // down-path channels per level
+    bool uploaded = false;
+};
+
+static int add_param(innfer_unet* u, const std::string& key, std::vector<int> shape) {
+    Param p; p.key = key; p.shape = shape;
+    u->params.push_back(p);
+    return (int)u->params.size() - 1;
+}
+
+extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int num_downs, int ngf) {
+    if (!out) return set_error(INNFER_ERR_INVALID, "unet_create: null out");
+    if (num_downs < 5 || num_downs > 9 || ngf % 32 || ngf <= 0 || in_nc < 1 || in_nc > 32 || out_nc < 1 || out_nc > 32)
+        return set_error(INNFER_ERR_UNSUPPORTED, "unet_create: in_nc=%d out_nc=%d num_downs=%d ngf=%d", in_nc, out_nc, num_downs, ngf);
+    innfer_unet* u = new innfer_unet();
+    u->in_nc = in_nc; u->out_nc = out_nc; u->num_downs = num_downs; u->ngf = ngf;
+    const int L = num_downs;
+    u->dc.resize(L);
+    for (int k = 0; k < L; ++k) u->dc[k] = ngf * (k < 3 ? (1 << k) : 8);      // 64,128,256,512,512,...
+    u->down.resize(L); u->up.resize(L);
+    std::string blk = "model.model.";                       // children of the block at level k
+    for (int k = 0; k < L; ++k) {
+        Layer& d = u->down[k]; Layer& p = u->up[k];
+        const bool outer = k == 0, inner = k == L - 1;
+        d.cin = outer ? in_nc : u->dc[k - 1]; d.cout = u->dc[k];
+        p.transposed = true;
+        p.cin = inner ? u->dc[k] : 2 * u->dc[k]; p.cout = outer ? out_nc : u->dc[k - 1];
+        if (outer) {
+            d.w = add_param(u, blk + "0.weight", {d.cout, d.cin, 4, 4});
+        } else {
+            d.w = add_param(u, blk + "1.weight", {d.cout, d.cin, 4, 4});
+            if (!inner) {
+                d.gamma = add_param(u, blk + "2.weight", {d.cout});
+                d.beta = add_param(u, blk + "2.bias", {d.cout});
+                add_param(u, blk + "2.running_mean", {d.cout});
+                add_param(u, blk + "2.running_var", {d.cout});
+                add_param(u, blk + "2.num_batches_tracked", {});
+            }
+        }
+        const std::string next = blk + (outer ? "1.model." : "3.model.");
+        // (the up-path parameters of level k follow its submodule in module order)
+        if (k + 1 < L) {
+            // recurse textually: deeper levels are appended first, so defer the up params
+        }
+        d.cin_pad = (d.cin + 31) / 32 * 32; d.cout_pad = (d.cout + 63) / 64 * 64;
+        p.cin_pad = (p.cin + 31) / 32 * 32; p.cout_pad = (p.cout + 63) / 64 * 64;
+        blk = next;
+    }
+    // up params, innermost first (= module order after the submodule)
+    for (int k = L - 1; k >= 0; --k) {
+        std::string b = "model.model.";
+        for (int j = 0; j < k; ++j) b += (j == 0 ? "1.model." : "3.model.");
+        Layer& p = u->up[k];
+        const bool outer = k == 0, inner = k == L - 1;
+        const std::string wi = outer ? "3" : (inner ? "3" : "5"), ni = inner ? "4" : "6";
+        p.w = add_param(u, b + wi + ".weight", {p.cin, p.cout, 4, 4});
+        if (outer) {
+            p.bias = add_param(u, b + wi + ".bias", {p.cout});
+        } else {
+            p.gamma = add_param(u, b + ni + ".weight", {p.cout});
+            p.beta = add_param(u, b + ni + ".bias", {p.cout});
+            add_param(u, b + ni + ".running_mean", {p.cout});
+            add_param(u, b + ni + ".running_var", {p.cout});
+            add_param(u, b + ni + ".num_batches_tracked", {});
+        }
+    }
+    *out = u;
+    return INNFER_OK;
+}
+
+extern "C" void innfer_unet_destroy(innfer_unet* u) {
+    if (!u) return;
+    for (auto* v : {&u->down, &u->up})
+        for (auto& l : *v) {
+            for (auto& w : l.d_w) if (w) (void)hipFree(w);
+            if (l.d_bias) (void)hipFree(l.d_bias);
+            if (l.d_gamma) (void)hipFree(l.d_gamma);
+            if (l.d_beta) (void)hipFree(l.d_beta);
+        }
+    delete u;
+}
+
+extern "C" int innfer_unet_num_params(innfer_unet* u) { return u ? (int)u->params.size() : INNFER_ERR_INVALID; }
+
+extern "C" int innfer_unet_param_info(innfer_unet* u, int idx, char* key, size_t key_cap, int* ndim, int* shape4) {
+    if (!u || idx < 0 || idx >= (int)u->params.size()) return set_error(INNFER_ERR_INVALID, "unet_param_info: bad index");
+    const Param& p = u->params[idx];
+    if (key && key_cap) { strncpy(key, p.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_unet_set_param(innfer_unet* u, int idx, const float* h_data) {
+    if (!u || idx < 0 || idx >= (int)u->params.size() || !h_data) return set_error(INNFER_ERR_INVALID, "unet_set_param: bad arguments");
+    Param& p = u->params[idx];
+    size_t n = 1;
+    for (int s : p.shape) n *= (size_t)s;
+    p.host.assign(h_data, h_data + n);
+    p.set = true;
+    u->uploaded = false;
+    return INNFER_OK;
+}
+
+static int upload_f32(float** dst, const std::vector<float>& v) {
+    if (!*dst) INNFER_HIP(hipMalloc((void**)dst, v.size() * sizeof(float)));
+    INNFER_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return INNFER_OK;
+}
+
+static int upload_f16(f16** dst, const std::vector<f16>& v) {
+    if (!*dst) INNFER_HIP(hipMalloc((void**)dst, v.size() * sizeof(f16)));
+    INNFER_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(f16), hipMemcpyHostToDevice));
+    return INNFER_OK;
+}
+
+// taps of output phase (a, b) of ConvTranspose2d(k=4, s=2, p=1): oy = 2*iy - 1 + ky
+static void phase_taps(int a, int b, int ky[4], int kx[4], int dy[4], int dx[4]) {
+    const int kys[2] = {a == 0 ? 1 : 0, a == 0 ? 3 : 2}, dys[2] = {a == 0 ? 0 : 1, a == 0 ? -1 : 0};
+    const int kxs[2] = {b == 0 ? 1 : 0, b == 0 ? 3 : 2}, dxs[2] = {b == 0 ? 0 : 1, b == 0 ? -1 : 0};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) { ky[i * 2 + j] = kys[i]; dy[i * 2 + j] = dys[i]; kx[i * 2 + j] = kxs[j]; dx[i * 2 + j] = dxs[j]; }
+}
+
+static int upload_all(innfer_unet* u) {
+    for (auto& p : u->params)
+        if (!p.set && p.key.find("running_") == std::string::npos && p.key.find("num_batches") == std::string::npos)
+            return set_error(INNFER_ERR_INVALID, "unet: parameter '%s' was never set", p.key.c_str());
+    std::vector<f16> panel;
+    for (auto* v : {&u->down, &u->up})
+        for (auto& l : *v) {
+            const std::vector<float>& w = u->params[l.w].host;
+            if (!l.transposed) {
+                pack_panels(panel, l.cout, l.cin, l.cin_pad, 16,
+                            [&](int co, int ci, int t) { return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
+                int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
+            } else {
+                for (int ph = 0; ph < 4; ++ph) {
+                    int ky[4], kx[4], dy[4], dx[4];
+                    phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
+                    pack_panels(panel, l.cout, l.cin, l.cin_pad, 4,
+                                [&](int co, int ci, int t) { return w[(((size_t)ci * l.cout + co) * 4 + ky[t]) * 4 + kx[t]]; });
+                    int rc = upload_f16(&l.d_w[ph], panel); if (rc) return rc;
+                }
+            }
+            if (l.bias >= 0) { int rc = upload_f32(&l.d_bias, u->params[l.bias].host); if (rc) return rc; }
+            if (l.gamma >= 0) { int rc = upload_f32(&l.d_gamma, u->params[l.gamma].host); if (rc) return rc; }
+            if (l.beta >= 0) { int rc = upload_f32(&l.d_beta, u->params[l.beta].host); if (rc) return rc; }
+        }
+    u->uploaded = true;
+    return INNFER_OK;
+}
+
+namespace {
+struct UCarve { size_t x0, raw, mean, rstd, r_inner, total; std::vector<size_t> D, CAT; };
+
+UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
+    UCarve c;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int L = u->num_downs;
+    size_t off = 0;
+    c.x0 = off; off += al((size_t)N * H * W * 32 * 2);
+    size_t raw = (size_t)N * H * W * 64 * 4;                                       // outermost up conv (64-padded)
+    for (int k = 0; k < L; ++k) raw = std::max(raw, (size_t)N * (H >> (k + 1)) * (W >> (k + 1)) * (size_t)((u->dc[k] + 63) / 64 * 64) * 4);
+    c.raw = off; off += al(raw);
+    c.mean = off; off += al((size_t)N * 1024 * 4);
+    c.rstd = off; off += al((size_t)N * 1024 * 4);
+    c.D.resize(L); c.CAT.resize(L);
+    for (int k = 0; k < L - 1; ++k) {
+        const size_t px = (size_t)N * (H >> (k + 1)) * (W >> (k + 1));
+        c.D[k] = off; off += al(px * u->dc[k] * 2);
+        c.CAT[k] = off; off += al(px * 2 * u->dc[k] * 2);
+    }
+    c.r_inner = off; off += al((size_t)N * (H >> L) * (W >> L) * u->dc[L - 1] * 2);
+    c.total = off;
+    return c;
+}
+
+int run_gemm(const Layer& l, const f16* wpk, const f16* in, long in_g, int N, int Hin, int Win, float* raw,
+             int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx, int Hfull, int Wfull,
+             int os, int ooy, int oox, hipStream_t s) {
+    GP g{};
+    g.in = in; g.in_g = in_g; g.nchunks = l.cin_pad / 32; g.N = N; g.Hin = Hin; g.Win = Win;
+    g.wpk = wpk; g.out = raw; g.cout_pad = l.cout_pad;
+    g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps;
+    for (int t = 0; t < ntaps; ++t) { g.dy[t] = dy[t]; g.dx[t] = dx[t]; }
+    g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox;
+    const long M = (long)N * Ho * Wo;
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)(l.cout_pad / 64));
+    hipLaunchKernelGGL(gemm_gather, grid, dim3(256), 0, s, g);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+}  // namespace
+
+extern "C" size_t innfer_unet_workspace_bytes(innfer_unet* u, int N, int H, int W) {
+    if (!u || N <= 0 || H <= 0 || W <= 0) return 0;
+    return ucarve(u, N, H, W).total;
+}
+
+extern "C" double innfer_unet_flops(innfer_unet* u, int N, int H, int W) {
+    if (!u) return 0.0;
+    double f = 0.0;
+    for (int k = 0; k < u->num_downs; ++k) {
+        const double px = (double)N * (H >> (k + 1)) * (W >> (k + 1));           // down output = up input grid
+        f += 2.0 * 16.0 * u->down[k].cin * u->down[k].cout * px;
+        f += 2.0 * 16.0 * u->up[k].cin * u->up[k].cout * px;
+    }
+    return f;
+}
+
+extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                                   int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!u || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "unet_forward: null argument");
+    const int L = u->num_downs;
+    if (N <= 0 || H <= 0 || W <= 0 || (H & ((1 << L) - 1)) || (W & ((1 << L) - 1)))
+        return set_error(INNFER_ERR_INVALID, "unet_forward: %dx%d must be a multiple of %d", H, W, 1 << L);
+    if ((H >> (L - 1)) * (W >> (L - 1)) < 2)
+        return set_error(INNFER_ERR_INVALID, "unet_forward: BatchNorm needs more than one value per channel");
+    if (!u->uploaded) { int rc = upload_all(u); if (rc) return rc; }
+    const UCarve cv = ucarve(u, N, H, W);
+    if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "unet_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    float* raw = (float*)(ws + cv.raw);
+    float* mean = (float*)(ws + cv.mean);
+    float* rstd = (float*)(ws + cv.rstd);
+    int dy16[16], dx16[16];
+    for (int t = 0; t < 16; ++t) { dy16[t] = (t >> 2) - 1; dx16[t] = (t & 3) - 1; }
+
+    auto post = [&](const Layer& l, long HW, bool bn, PostDst d0, PostDst d1) -> int {
+        if (bn) {
+            hipLaunchKernelGGL(bn_stats, dim3((l.cout + 31) / 32, N), dim3(256), 0, s, raw, l.cout_pad, HW, 1e-5f, mean, rstd, l.cout);
+            INNFER_HIP(hipGetLastError());
+        }
+        const long total = (long)N * HW * (l.cout / 8);
+        hipLaunchKernelGGL(unet_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
+                           bn ? mean : nullptr, bn ? rstd : nullptr, l.d_gamma, l.d_beta, d0, d1);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
+
+    {   // NCHW input -> one zero-padded 32-channel group
+        const long HW = (long)H * W;
+        hipLaunchKernelGGL(unet_pre, dim3((unsigned)((N * HW + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, u->in_nc, HW, N, (f16*)(ws + cv.x0));
+        INNFER_HIP(hipGetLastError());
+    }
+    // ---- down path ----
+    const f16* cur = (const f16*)(ws + cv.x0);
+    long cur_g = (long)N * H * W * 32;
+    int h = H, w = W;
+    for (int k = 0; k < L; ++k) {
+        const Layer& l = u->down[k];
+        const int ho = h / 2, wo = w / 2;
+        int rc = run_gemm(l, l.d_w[0], cur, cur_g, N, h, w, raw, ho, wo, 2, 16, dy16, dx16, ho, wo, 1, 0, 0, s);
+        if (rc) return rc;
+        const long HW = (long)ho * wo, G = (long)N * HW * 32;
+        if (k < L - 1) {
+            PostDst dl{(f16*)(ws + cv.D[k]), G, 0, 1};              // lrelu(t): next down conv (and the skip's stored form)
+            PostDst dr{(f16*)(ws + cv.CAT[k]), G, 0, 2};            // relu(t): first half of the up conv's concatenation
+            rc = post(l, HW, k > 0, dl, dr);
+            cur = dl.p; cur_g = G;
+        } else {
+            PostDst dr{(f16*)(ws + cv.r_inner), G, 0, 2};           // innermost: only relu(conv) is consumed
+            rc = post(l, HW, false, dr, PostDst{nullptr, 0, 0, 0});
+        }
+        if (rc) return rc;
+        h = ho; w = wo;
+    }
+    // ---- up path ----
+    for (int k = L - 1; k >= 0; --k) {
+        const Layer& l = u->up[k];
+        const f16* in = k == L - 1 ? (const f16*)(ws + cv.r_inner) : (const f16*)(ws + cv.CAT[k]);
+        const long in_g = (long)N * h * w * 32;
+        const int hf = 2 * h, wf = 2 * w;
+        for (int ph = 0; ph < 4; ++ph) {
+            int ky[4], kx[4], dy[4], dx[4];
+            phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
+            int rc = run_gemm(l, l.d_w[ph], in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, ph >> 1, ph & 1, s);
+            if (rc) return rc;
+        }
+        const long HW = (long)hf * wf;
+        if (k > 0) {
+            const long G = (long)N * HW * 32;
+            PostDst dr{(f16*)(ws + cv.CAT[k - 1]), G, u->dc[k - 1], 2};     // second half of the parent's concatenation
+            int rc = post(l, HW, true, dr, PostDst{nullptr, 0, 0, 0});
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(unet_final, dim3((unsigned)((N * HW + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
+                               l.d_bias, d_out, out_dtype == INNFER_F32);
+            INNFER_HIP(hipGetLastError());
+        }
+        h = hf; w = wf;
+    }
+    return INNFER_OK;
+}

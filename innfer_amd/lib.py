@@ -68,6 +68,15 @@ SIGNATURES = {
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "innfer_unet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "innfer_unet_destroy": (None, [C.c_void_p]),
+    "innfer_unet_num_params": (C.c_int, [C.c_void_p]),
+    "innfer_unet_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_unet_set_param": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "innfer_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "innfer_unet_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "innfer_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv3x3_f16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),

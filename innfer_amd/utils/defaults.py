@@ -55,8 +55,17 @@ def get_network_G_config(network_G, scale):
         cfg['convtype'] = _pick(opts, 'convtype', 'Conv2D')
         cfg['finalact'] = _pick(opts, 'finalact', None)
         cfg['res_scale'] = _pick(opts, 'res_scale', 1)
+    elif 'wbcunet' not in kind and ('unet' in kind or 'p2p' in kind):
+        cfg['type'] = 'unet_net'
+        cfg['input_nc'] = _pick(opts, 'in_nc', 3)
+        cfg['output_nc'] = _pick(opts, 'out_nc', 3)
+        cfg['num_downs'] = _pick(opts, 'num_downs', 7 if kind in ('unet_128', 'p2p_128') else 8)
+        cfg['ngf'] = _pick(opts, 'ngf', 64)
+        cfg['norm_type'] = _pick(opts, 'norm_type', 'batch')
+        cfg['use_dropout'] = _pick(opts, 'use_dropout', False)
+        cfg['upsample_mode'] = _pick(opts, 'upsample_mode', 'deconv')
     elif (kind in ('mrrdb_net', 'mesrgan') or 'ppon' in kind or kind in ('pan_net', 'pan')
-          or 'wbcunet' in kind or 'unet' in kind or 'p2p' in kind or 'resnet' in kind or 'cg' in kind):
+          or 'wbcunet' in kind or 'resnet' in kind or 'cg' in kind):
         raise NotImplementedError(
             f'Generator model [{kind}] is a reference architecture outside the MI355X hot path built so far')
     else:

@@ -279,6 +279,8 @@ def g12():
                                ("esrgan", 4, {"in_nc": 1, "out_nc": 1, "nf": 48, "nb": 2, "plus": True})]:
         d = dict(type=kind, **extra)
         rows[f"{kind}|{scale}|{json.dumps(extra, sort_keys=True)}"] = get_network_G_config(d, scale)
+    for kind in ("p2p_256", "unet_256", "unet_128", "p2p_128", "unet_512"):
+        rows[f"str:{kind}|1"] = get_network_G_config(kind, 1)
     rows["str:esrgan|4"] = get_network_G_config("esrgan", 4)
     rows["which_model_G:srgan|4"] = get_network_G_config({"which_model_G": "srgan"}, 4)
     save("g12_defaults", table=np.array(json.dumps(rows, sort_keys=True)))

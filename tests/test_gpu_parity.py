@@ -262,6 +262,37 @@ def test_missing_weights_and_cpu_are_loud(dev):
         RRDBNet(3, 3, 64, 1, upscale=3)
 
 
+def test_unet256_golden(dev, golden):
+    """pix2pix UNet_256 (BASELINE config 5) with per-image train-mode BatchNorm against the reference
+    (golden G7).  fp16 activations through 15 BatchNorms (down to 2x2 statistics): tolerance 3e-2 on the
+    tanh output, mean error an order of magnitude below."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    g = golden("g7_unet256")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = _sd(shapes)
+    net = get_network(get_network_G_config("p2p_256", 1))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    net.train()                                                     # meval=False (run.py:299-303)
+    xa = torch.from_numpy(synth.uniform((1, 3, 256, 256), 7, -1.0, 1.0)).to(dev)
+    ya = net(xa.half()).float().cpu().numpy()
+    ref = g["out_a"].astype(np.float32)
+    err = np.abs(ya - ref)
+    assert np.isfinite(ya).all() and np.abs(ya).max() <= 1.0
+    assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max(), err.mean())
+    assert np.abs(ya[0, :, ::4, ::4] - g["out_a_sub"]).max() < 3e-2
+    # batch = independent batch-1 forwards (per-image statistics, SURVEY.md D6)
+    xb = torch.from_numpy(synth.uniform((1, 3, 256, 256), 8, -1.0, 1.0)).to(dev)
+    yab = net(torch.cat([xa, xb], 0).half()).float().cpu().numpy()
+    assert np.array_equal(yab[0:1], ya)
+    assert np.array_equal(yab[1:2], net(xb.half()).float().cpu().numpy())
+    y32 = net(xa).float().cpu().numpy()                             # fp32 I/O
+    assert np.abs(y32 - ref).max() < 3e-2
+
+
 # ---------------------------------------------------------- tiles / blend / io
 def test_extract_and_blend_bit_exact(dev, golden):
     import oracle

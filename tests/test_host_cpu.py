@@ -166,6 +166,10 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
     with pytest.raises(NotImplementedError):
         get_network({"type": "pan_net"})
+    unet = get_network(get_network_G_config("p2p_256", 1))
+    assert len(unet.state_dict()) == 82 and "model.model.1.model.2.running_mean" in unet.state_dict()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        unet(torch.zeros(1, 3, 256, 256))
     from innfer_amd.run import Model
     with pytest.raises(RuntimeError):
         Model("nowhere.pth", arch="infer", device="cpu")
