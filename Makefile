@@ -1,7 +1,7 @@
 # Build the gfx950 HIP library in-tree (the .so travels to the GPU box with the snapshot).
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
-SRC   := innfer_amd/csrc/conv3x3.hip innfer_amd/csrc/conv_first.hip innfer_amd/csrc/tiles.hip innfer_amd/csrc/net.hip innfer_amd/csrc/unet.hip
+SRC   := innfer_amd/csrc/conv3x3.hip innfer_amd/csrc/conv_first.hip innfer_amd/csrc/tiles.hip innfer_amd/csrc/net.hip innfer_amd/csrc/unet.hip innfer_amd/csrc/pan.hip
 OBJ   := $(SRC:.hip=.o)
 LIB   := innfer_amd/lib/libinnfer_amd.so
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function
@@ -10,7 +10,7 @@ all: $(LIB)
 
 innfer_amd/csrc/tiles.o: FLAGS += -ffp-contract=off
 
-%.o: %.hip innfer_amd/csrc/common.h include/innfer_amd.h
+%.o: %.hip innfer_amd/csrc/common.h innfer_amd/csrc/gather_gemm.h include/innfer_amd.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJ)

@@ -118,6 +118,25 @@ double innfer_unet_flops(innfer_unet_t u, int N, int H, int W);
 int innfer_unet_forward(innfer_unet_t u, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                         int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* --------------------------------------------------------------------- PAN
+ * Replaces PAN.forward (architectures/PAN_arch.py:163-222) with its SCPA blocks (PAN_arch.py:47-106),
+ * PAConv (PAN_arch.py:24-45), the FSA SelfAttentionBlock on a 4x max-pooled map (block.py:398-473,
+ * bicubic re-expansion) and the nearest pixel-attention up-blocks (block.py pa_upconv_block), as
+ * utils/defaults.py:78-89 configures them: nf 40, unf 24, nb 16, scale 1/2/4, self_attention=True,
+ * double_scpa=False, ups_inter_mode='nearest'.  Parameters are addressed by state-dict key
+ * ("SCPA_trunk.3.PACnv.k2.weight" ...), PyTorch layout, fp32 host data.
+ */
+typedef struct innfer_pan* innfer_pan_t;
+int innfer_pan_create(innfer_pan_t* out, int in_nc, int out_nc, int nf, int unf, int nb, int scale);
+void innfer_pan_destroy(innfer_pan_t p);
+int innfer_pan_num_params(innfer_pan_t p);
+int innfer_pan_param_info(innfer_pan_t p, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
+int innfer_pan_set_param(innfer_pan_t p, int idx, const float* h_data);
+size_t innfer_pan_workspace_bytes(innfer_pan_t p, int N, int H, int W);
+/* d_in [N,in_nc,H,W] -> d_out [N,out_nc,scale*H,scale*W], NCHW f16/f32; H, W >= 4. */
+int innfer_pan_forward(innfer_pan_t p, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                       int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* -------------------------------------------------- single fused convolution
  * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution
  * over an fp16 "blocked NHWC" channel slab (conv_block, block.py:213-254).

@@ -1,0 +1,21 @@
+"""PAN shell (reference PAN_arch.py:109-222): parameters carry the reference's state-dict keys
+(conv_first, SCPA_trunk.<b>.{conv1_a,conv1_b,k1.0,PACnv.k2,PACnv.k3,PACnv.k4,conv3}, trunk_conv,
+FSA.{gamma,conv_f,conv_g,conv_h}, upsample.<i>, conv_last), forward runs in libinnfer_amd.so
+(csrc/pan.hip).  Built: the configuration utils/defaults.py:78-89 produces (self-attention on,
+single SCPA, nearest up-blocks)."""
+from .param_module import ParamEngineModule
+
+
+class PAN(ParamEngineModule):
+    _api = 'pan'
+
+    def __init__(self, in_nc=3, out_nc=3, nf=40, unf=24, nb=16, scale=4, self_attention=True,
+                 double_scpa=False, ups_inter_mode='nearest'):
+        super().__init__()
+        if not self_attention or double_scpa or ups_inter_mode != 'nearest':
+            raise NotImplementedError('PAN: only self_attention=True, double_scpa=False, nearest up-blocks are built')
+        self.in_nc, self.out_nc, self.nf, self.unf, self.nb, self.scale = in_nc, out_nc, nf, unf, nb, scale
+        self._init_engine(in_nc, out_nc, nf, unf, nb, scale)
+
+    def _out_shape(self, N, H, W):
+        return (N, self.out_nc, H * self.scale, W * self.scale)

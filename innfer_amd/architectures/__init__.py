@@ -15,10 +15,12 @@ def get_network(opt_net):
         from .SRResNet_arch import SRResNet as net
     elif kind == 'unet_net':
         from .UNet_arch import UnetGenerator as net
-    elif kind in ('mrrdb_net', 'ppon', 'pan_net', 'resnet_net', 'wbcunet_net'):
+    elif kind == 'pan_net':
+        from .PAN_arch import PAN as net
+    elif kind in ('mrrdb_net', 'ppon', 'resnet_net', 'wbcunet_net'):
         raise NotImplementedError(
             f'Model [{kind}] exists in the reference but is outside the MI355X hot path built so far '
-            '(SURVEY.md section 8: ESRGAN RRDBNet and SRResNet first)')
+            '(SURVEY.md section 8)')
     else:
         raise NotImplementedError('Model [{:s}] not recognized'.format(kind))
     return net(**opt_net)

@@ -1,0 +1,89 @@
+"""Shell for the engines whose C API addresses parameters by state-dict key
+(innfer_unet_*, innfer_pan_*): the module tree is built from the keys the engine
+reports, so load_state_dict(strict=True) sees exactly the reference's names, and
+forward hands device pointers to libinnfer_amd.so.  torch is plumbing only."""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import lib as L
+from .engine_module import _Node
+
+
+class ParamEngineModule(nn.Module):
+    _api = None                      # 'unet' | 'pan' -> innfer_<api>_* entry points
+
+    def _fn(self, name):
+        return getattr(L.lib, f'innfer_{self._api}_{name}')
+
+    def _init_engine(self, *create_args):
+        h = C.c_void_p()
+        L.check(self._fn('create')(C.byref(h), *create_args))
+        self._handle = h
+        self._keys = []
+        key, nd, shp = C.create_string_buffer(256), C.c_int(), (C.c_int * 4)()
+        for i in range(self._fn('num_params')(h)):
+            L.check(self._fn('param_info')(h, i, key, 256, C.byref(nd), shp))
+            k = key.value.decode()
+            shape = tuple(shp[j] for j in range(nd.value))
+            *path, leaf = k.split('.')
+            node = self
+            for name in path:
+                if name not in node._modules:
+                    node.add_module(name, _Node())
+                node = node._modules[name]
+            if leaf == 'num_batches_tracked':
+                node.register_buffer(leaf, torch.zeros(shape, dtype=torch.long))
+            elif leaf.startswith('running_'):
+                node.register_buffer(leaf, torch.ones(shape) if leaf == 'running_var' else torch.zeros(shape))
+            else:
+                node.register_parameter(leaf, nn.Parameter(torch.zeros(*shape), requires_grad=False))
+            self._keys.append(k)
+        self._version = None
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, '_handle', None)
+        if h is not None:
+            try:
+                self._fn('destroy')(h)
+            except Exception:
+                pass
+
+    def _upload(self):
+        ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if ver == self._version:
+            return
+        sd = self.state_dict()
+        for i, k in enumerate(self._keys):
+            if 'running_' in k or 'num_batches' in k:
+                continue
+            a = np.ascontiguousarray(sd[k].detach().float().cpu().numpy())
+            L.check(self._fn('set_param')(self._handle, i, a.ctypes.data))
+        self._version = ver
+
+    def _out_shape(self, N, H, W):
+        raise NotImplementedError
+
+    def forward(self, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise ValueError('expected a 4D [N,C,H,W] tensor')
+        if not x.is_cuda:
+            raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
+        if x.dtype not in (torch.float16, torch.float32):
+            raise TypeError(f'unsupported dtype {x.dtype}')
+        self._upload()
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        out = torch.empty(self._out_shape(N, H, W), dtype=x.dtype, device=x.device)
+        need = self._fn('workspace_bytes')(self._handle, N, H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        dt = L.F16 if x.dtype == torch.float16 else L.F32
+        L.check(self._fn('forward')(self._handle, x.data_ptr(), dt, out.data_ptr(), dt, N, H, W,
+                                    self._ws.data_ptr(), self._ws.numel(),
+                                    torch.cuda.current_stream(x.device).cuda_stream))
+        return out

@@ -1,0 +1,496 @@
+// PAN (Efficient Image Super-Resolution Using Pixel Attention) forward on gfx950.
+// Replaces architectures/PAN_arch.py:11-222 (defaults utils/defaults.py:78-89: nf 40, unf 24,
+// nb 16, self attention on, nearest up-blocks) and SelfAttentionBlock (block.py:398-473).
+//
+//   every conv (1x1 and 3x3, 3..40 channels)   gather-GEMM on MFMA (gather_gemm.h), channels padded
+//                                              to 32/64 in blocked-NHWC fp16 slabs whose pad
+//                                              channels are kept zero; fp32 outputs
+//   conv1_a | conv1_b                          ONE 40->40 1x1 GEMM (rows 0..19 = a, 20..39 = b)
+//   PACnv: k3(x) * sigmoid(k2(x))              ONE 3x3 GEMM whose rows 0..19 are k2 (centre tap only)
+//                                              and rows 20..39 are k3; the post kernel gates
+//   torch.cat([a, b])                          channel offsets 0 / 20 inside one slab
+//   channel slices (b = channels 20..39)       weights packed at the slice's positions, zeros elsewhere
+//   LeakyReLU / sigmoid gates / residual adds  pan_post
+//   FSA: MaxPool2d(4) -> f,g,h 1x1 -> softmax(f^T g) -> h att^T -> bicubic up -> gamma*out + in
+//                                              pan_maxpool, one 40->50 GEMM, pan_attention (one
+//                                              workgroup per query, streaming two-pass softmax, no
+//                                              N x N matrix in memory), pan_fsa_combine (ATen's
+//                                              bicubic, A = -0.75, align_corners=False)
+//   nearest-2x Upsample in the up-blocks       folded into the GEMM's gather (GP.up)
+//   + bilinear(x, align_corners=True)          pan_final, NCHW output
+// Reference quirk kept: B.sequential() flattens with children(), which yields the shared LeakyReLU
+// of pa_upconv_block once, so NO activation follows HRconv (golden G8 confirms).
+#include "common.h"
+#include "gather_gemm.h"
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+using namespace innfer;
+
+namespace {
+
+enum { MODE_LIN = 0, MODE_GATE = 1, MODE_PA = 2 };
+
+struct PP {
+    const float* raw; int C; const float* bias; int mode; int act;       // act: 1 = LeakyReLU(0.2)
+    const f16* res; long res_g; int res_off;                              // MODE_LIN: + res ; MODE_PA: * v
+    f16* dst; long dst_g; int dst_off;
+    long npix;
+};
+
+__device__ __forceinline__ float slab_get(const f16* s, long g, long pix, int ch) {
+    return (float)s[(ch >> 5) * g + pix * 32 + (ch & 31)];
+}
+
+__global__ void pan_post(const PP p) {
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= p.npix) return;
+    const float* r = p.raw + pix * 64;
+    for (int c = 0; c < p.C; ++c) {
+        float y;
+        if (p.mode == MODE_GATE) {
+            const float gate = 1.0f / (1.0f + expf(-(r[c] + p.bias[c])));
+            y = r[p.C + c] * gate;
+        } else if (p.mode == MODE_PA) {
+            const float gate = 1.0f / (1.0f + expf(-(r[c] + p.bias[c])));
+            y = slab_get(p.res, p.res_g, pix, p.res_off + c) * gate;
+        } else {
+            y = r[c] + (p.bias ? p.bias[c] : 0.f);
+        }
+        if (p.act == 1) y = fmaxf(y, 0.2f * y);
+        if (p.mode == MODE_LIN && p.res) y += slab_get(p.res, p.res_g, pix, p.res_off + c);
+        const int ch = p.dst_off + c;
+        p.dst[(ch >> 5) * p.dst_g + pix * 32 + (ch & 31)] = (f16)y;
+    }
+}
+
+__global__ void pan_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const long n = i / HW, px = i % HW;
+    for (int c = 0; c < C; ++c) {
+        const long o = (n * C + c) * HW + px;
+        slab[i * 32 + c] = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+    }
+}
+
+__global__ void pan_maxpool(const f16* in, long in_g, int C, int N, int H, int W, int hp, int wp, f16* out, long out_g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * hp * wp) return;
+    const int x = (int)(i % wp), y = (int)((i / wp) % hp);
+    const long n = i / ((long)wp * hp);
+    for (int c = 0; c < C; ++c) {
+        float m = -INFINITY;
+        for (int dy = 0; dy < 4; ++dy)
+            for (int dx = 0; dx < 4; ++dx)
+                m = fmaxf(m, slab_get(in, in_g, (n * H + 4 * y + dy) * W + 4 * x + dx, c));
+        out[(c >> 5) * out_g + i * 32 + (c & 31)] = (f16)m;
+    }
+}
+
+// fgh: fp32 [N*Np][64] = [f(5) | g(5) | h(40)] without bias.  One workgroup per query pixel:
+// att_j = softmax_j(f_i . g_j); out_i[c] = sum_j h_j[c] att_j.
+__global__ __launch_bounds__(256) void pan_attention(const float* fgh, const float* bf, const float* bg, const float* bh,
+                                                     int Np, int Cq, int C, float* out) {
+    __shared__ float red[256];
+    __shared__ float redc[4][64];
+    const int i = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const float* base = fgh + (long)n * Np * 64;
+    float fi[8];
+    for (int c = 0; c < Cq; ++c) fi[c] = base[(long)i * 64 + c] + bf[c];
+    auto score = [&](int j) {
+        float s = 0.f;
+        for (int c = 0; c < Cq; ++c) s += fi[c] * (base[(long)j * 64 + Cq + c] + bg[c]);
+        return s;
+    };
+    float m = -INFINITY;
+    for (int j = tid; j < Np; j += 256) m = fmaxf(m, score(j));
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    m = red[0];
+    __syncthreads();
+    float acc[40];
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    float sum = 0.f;
+    for (int j = tid; j < Np; j += 256) {
+        const float e = expf(score(j) - m);
+        sum += e;
+        const float* hj = base + (long)j * 64 + 2 * Cq;
+        for (int c = 0; c < C; ++c) acc[c] += (hj[c] + bh[c]) * e;
+    }
+    red[tid] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    sum = red[0];
+    // reduce the C partial outputs over the 256 threads: wave shuffle, then 4 waves through LDS
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c = 0; c < C; ++c) {
+        float v = acc[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) redc[wave][c] = v;
+    }
+    __syncthreads();
+    if (tid < C) out[((long)n * Np + i) * C + tid] = (redc[0][tid] + redc[1][tid] + redc[2][tid] + redc[3][tid]) / sum;
+}
+
+__device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+// t = gamma * bicubic(att, size=(H,W), align_corners=False) + inp      (ATen upsample_bicubic2d)
+__global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f16* inp, long g, int N, int H, int W,
+                                const float* gamma, f16* dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * H * W) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const long n = i / ((long)W * H);
+    const float A = -0.75f;
+    const float sy = (float)hp / (float)H, sx = (float)wp / (float)W;
+    const float ry = sy * ((float)Y + 0.5f) - 0.5f, rx = sx * ((float)X + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+    const float ty = ry - (float)iy, tx = rx - (float)ix;
+    const float wy[4] = {cc2(ty + 1.f, A), cc1(ty, A), cc1(1.f - ty, A), cc2(2.f - ty, A)};
+    const float wx[4] = {cc2(tx + 1.f, A), cc1(tx, A), cc1(1.f - tx, A), cc2(2.f - tx, A)};
+    const float gm = gamma[0];
+    const float* an = att + n * (long)hp * wp * C;
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), hp - 1);
+            float row = 0.f;
+            for (int b = 0; b < 4; ++b) {
+                const int xx = min(max(ix - 1 + b, 0), wp - 1);
+                row += an[((long)yy * wp + xx) * C + c] * wx[b];
+            }
+            v += row * wy[a];
+        }
+        const float y = gm * v + slab_get(inp, g, i, c);
+        dst[(c >> 5) * g + i * 32 + (c & 31)] = (f16)y;
+    }
+}
+
+// out = conv_last + bias + bilinear(x, align_corners=True) -> NCHW
+__global__ void pan_final(const float* raw, const float* bias, int C, const void* x, int x_f32, int N, int H, int W,
+                          int scale, void* out, int out_f32) {
+    const int FH = H * scale, FW = W * scale;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * FH * FW) return;
+    const int X = (int)(i % FW), Y = (int)((i / FW) % FH);
+    const long n = i / ((long)FW * FH);
+    const float sy = FH > 1 ? (float)(H - 1) / (float)(FH - 1) : 0.f, sx = FW > 1 ? (float)(W - 1) / (float)(FW - 1) : 0.f;
+    const float fy = sy * (float)Y, fx = sx * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    for (int c = 0; c < C; ++c) {
+        const long pl = (n * C + c) * (long)H * W;
+        auto at = [&](int yy, int xx) {
+            const long o = pl + (long)yy * W + xx;
+            return x_f32 ? ((const float*)x)[o] : (float)((const f16*)x)[o];
+        };
+        float il;
+        if (scale > 1)
+            il = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
+        else
+            il = at(Y, X);
+        const float v = raw[i * 64 + c] + bias[c] + il;
+        const long o = ((n * C + c) * FH + Y) * (long)FW + X;
+        if (out_f32) ((float*)out)[o] = v; else ((f16*)out)[o] = (f16)v;
+    }
+}
+
+struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
+
+struct Gemm {                       // one packed GEMM
+    int cin_pad = 32, cout = 0, ntaps = 1;
+    f16* d_w = nullptr;
+    std::function<float(int, int, int)> weight;        // (co, ci over the padded slab channels, tap) -> value
+    int cin_used = 0;                                   // channels of the slab that may carry weights
+};
+
+}  // namespace
+
+struct innfer_pan {
+    int in_nc = 3, out_nc = 3, nf = 40, unf = 24, nb = 16, scale = 4, n_up = 2;
+    std::vector<Param> params;
+    std::vector<Gemm> gemms;
+    std::vector<float*> d_vecs;      // device copies of bias vectors / gamma, by param index (nullptr if unused)
+    bool uploaded = false;
+};
+
+static int P(innfer_pan* p, const std::string& key, std::vector<int> shape) {
+    Param q; q.key = key; q.shape = shape;
+    p->params.push_back(q);
+    return (int)p->params.size() - 1;
+}
+
+extern "C" int innfer_pan_create(innfer_pan** out, int in_nc, int out_nc, int nf, int unf, int nb, int scale) {
+    if (!out) return set_error(INNFER_ERR_INVALID, "pan_create: null out");
+    if (nf != 40 || unf != 24 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || nb < 1 ||
+        (scale != 1 && scale != 2 && scale != 4))
+        return set_error(INNFER_ERR_UNSUPPORTED, "pan_create: nf=%d unf=%d scale=%d (built: nf 40, unf 24, scale 1/2/4)", nf, unf, scale);
+    innfer_pan* p = new innfer_pan();
+    p->in_nc = in_nc; p->out_nc = out_nc; p->nf = nf; p->unf = scale == 1 ? nf : unf; p->nb = nb; p->scale = scale;
+    p->n_up = scale == 4 ? 2 : (scale == 2 ? 1 : 0);
+    const int gw = nf / 2, UF = p->unf;
+    P(p, "conv_first.weight", {nf, in_nc, 3, 3}); P(p, "conv_first.bias", {nf});
+    for (int b = 0; b < nb; ++b) {
+        const std::string s = "SCPA_trunk." + std::to_string(b) + ".";
+        P(p, s + "conv1_a.weight", {gw, nf, 1, 1}); P(p, s + "conv1_b.weight", {gw, nf, 1, 1});
+        P(p, s + "k1.0.weight", {gw, gw, 3, 3});
+        P(p, s + "PACnv.k2.weight", {gw, gw, 1, 1}); P(p, s + "PACnv.k2.bias", {gw});
+        P(p, s + "PACnv.k3.weight", {gw, gw, 3, 3}); P(p, s + "PACnv.k4.weight", {gw, gw, 3, 3});
+        P(p, s + "conv3.weight", {nf, nf, 1, 1});
+    }
+    P(p, "trunk_conv.weight", {nf, nf, 3, 3}); P(p, "trunk_conv.bias", {nf});
+    P(p, "FSA.gamma", {1});
+    P(p, "FSA.conv_f.weight", {nf / 8, nf, 1}); P(p, "FSA.conv_f.bias", {nf / 8});
+    P(p, "FSA.conv_g.weight", {nf / 8, nf, 1}); P(p, "FSA.conv_g.bias", {nf / 8});
+    P(p, "FSA.conv_h.weight", {nf, nf, 1}); P(p, "FSA.conv_h.bias", {nf});
+    for (int u = 0; u < p->n_up; ++u) {
+        const int i = 5 * u, ci = u == 0 ? nf : UF;
+        const std::string s = "upsample.";
+        P(p, s + std::to_string(i + 1) + ".weight", {UF, ci, 3, 3}); P(p, s + std::to_string(i + 1) + ".bias", {UF});
+        P(p, s + std::to_string(i + 2) + ".conv.weight", {UF, UF, 1, 1}); P(p, s + std::to_string(i + 2) + ".conv.bias", {UF});
+        P(p, s + std::to_string(i + 4) + ".weight", {UF, UF, 3, 3}); P(p, s + std::to_string(i + 4) + ".bias", {UF});
+    }
+    P(p, "conv_last.weight", {out_nc, UF, 3, 3}); P(p, "conv_last.bias", {out_nc});
+    *out = p;
+    return INNFER_OK;
+}
+
+extern "C" void innfer_pan_destroy(innfer_pan* p) {
+    if (!p) return;
+    for (auto& g : p->gemms) if (g.d_w) (void)hipFree(g.d_w);
+    for (auto v : p->d_vecs) if (v) (void)hipFree(v);
+    delete p;
+}
+
+extern "C" int innfer_pan_num_params(innfer_pan* p) { return p ? (int)p->params.size() : INNFER_ERR_INVALID; }
+
+extern "C" int innfer_pan_param_info(innfer_pan* p, int idx, char* key, size_t key_cap, int* ndim, int* shape4) {
+    if (!p || idx < 0 || idx >= (int)p->params.size()) return set_error(INNFER_ERR_INVALID, "pan_param_info: bad index");
+    const Param& q = p->params[idx];
+    if (key && key_cap) { strncpy(key, q.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
+    if (ndim) *ndim = (int)q.shape.size();
+    if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < q.shape.size() ? q.shape[i] : 1;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_pan_set_param(innfer_pan* p, int idx, const float* h_data) {
+    if (!p || idx < 0 || idx >= (int)p->params.size() || !h_data) return set_error(INNFER_ERR_INVALID, "pan_set_param: bad arguments");
+    Param& q = p->params[idx];
+    size_t n = 1;
+    for (int s : q.shape) n *= (size_t)s;
+    q.host.assign(h_data, h_data + n);
+    q.set = true;
+    p->uploaded = false;
+    return INNFER_OK;
+}
+
+namespace {
+
+int find(const innfer_pan* p, const std::string& key) {
+    for (size_t i = 0; i < p->params.size(); ++i) if (p->params[i].key == key) return (int)i;
+    return -1;
+}
+
+// GEMM list in forward order; weights are looked up in the host copies when packing
+int build_gemms(innfer_pan* p) {
+    p->gemms.clear();
+    const int nf = p->nf, gw = nf / 2, UF = p->unf;
+    auto W = [p](const std::string& key) -> const std::vector<float>& { return p->params[find(p, key)].host; };
+    auto add = [&](int cin_pad, int cout, int ntaps, std::function<float(int, int, int)> f) {
+        Gemm g; g.cin_pad = cin_pad; g.cout = cout; g.ntaps = ntaps; g.weight = f;
+        p->gemms.push_back(g);
+    };
+    {   const auto& w = W("conv_first.weight"); const int ci_n = p->in_nc;
+        add(32, nf, 9, [&w, ci_n](int co, int ci, int t) { return ci < ci_n ? w[((size_t)co * ci_n + ci) * 9 + t] : 0.f; }); }
+    for (int b = 0; b < p->nb; ++b) {
+        const std::string s = "SCPA_trunk." + std::to_string(b) + ".";
+        const auto &wa = W(s + "conv1_a.weight"), &wb = W(s + "conv1_b.weight"), &k1 = W(s + "k1.0.weight"),
+                   &k2 = W(s + "PACnv.k2.weight"), &k3 = W(s + "PACnv.k3.weight"), &k4 = W(s + "PACnv.k4.weight"),
+                   &c3 = W(s + "conv3.weight");
+        add(64, nf, 1, [&wa, &wb, nf, gw](int co, int ci, int) {
+            if (ci >= nf) return 0.f;
+            return co < gw ? wa[(size_t)co * nf + ci] : wb[(size_t)(co - gw) * nf + ci]; });
+        add(32, gw, 9, [&k1, gw](int co, int ci, int t) { return ci < gw ? k1[((size_t)co * gw + ci) * 9 + t] : 0.f; });
+        add(64, nf, 9, [&k2, &k3, gw](int co, int ci, int t) {          // rows 0..gw-1: k2 (1x1 = centre tap), gw..: k3
+            if (ci < gw || ci >= 2 * gw) return 0.f;
+            if (co < gw) return t == 4 ? k2[(size_t)co * gw + (ci - gw)] : 0.f;
+            return k3[((size_t)(co - gw) * gw + (ci - gw)) * 9 + t]; });
+        add(32, gw, 9, [&k4, gw](int co, int ci, int t) { return ci < gw ? k4[((size_t)co * gw + ci) * 9 + t] : 0.f; });
+        add(64, nf, 1, [&c3, nf](int co, int ci, int) { return ci < nf ? c3[(size_t)co * nf + ci] : 0.f; });
+    }
+    {   const auto& w = W("trunk_conv.weight");
+        add(64, nf, 9, [&w, nf](int co, int ci, int t) { return ci < nf ? w[((size_t)co * nf + ci) * 9 + t] : 0.f; }); }
+    {   const auto &wf = W("FSA.conv_f.weight"), &wg = W("FSA.conv_g.weight"), &wh = W("FSA.conv_h.weight");
+        const int cq = nf / 8;
+        add(64, 2 * cq + nf, 1, [&wf, &wg, &wh, nf, cq](int co, int ci, int) {
+            if (ci >= nf) return 0.f;
+            if (co < cq) return wf[(size_t)co * nf + ci];
+            if (co < 2 * cq) return wg[(size_t)(co - cq) * nf + ci];
+            return wh[(size_t)(co - 2 * cq) * nf + ci]; }); }
+    for (int u = 0; u < p->n_up; ++u) {
+        const int i = 5 * u, cin = u == 0 ? nf : UF;
+        const auto &w1 = W("upsample." + std::to_string(i + 1) + ".weight"), &wp = W("upsample." + std::to_string(i + 2) + ".conv.weight"),
+                   &w4 = W("upsample." + std::to_string(i + 4) + ".weight");
+        add(u == 0 ? 64 : 32, UF, 9, [&w1, cin](int co, int ci, int t) { return ci < cin ? w1[((size_t)co * cin + ci) * 9 + t] : 0.f; });
+        add(32, UF, 1, [&wp, UF](int co, int ci, int) { return ci < UF ? wp[(size_t)co * UF + ci] : 0.f; });
+        add(32, UF, 9, [&w4, UF](int co, int ci, int t) { return ci < UF ? w4[((size_t)co * UF + ci) * 9 + t] : 0.f; });
+    }
+    {   const auto& w = W("conv_last.weight");
+        add(p->n_up ? 32 : 64, p->out_nc, 9, [&w, UF](int co, int ci, int t) { return ci < UF ? w[((size_t)co * UF + ci) * 9 + t] : 0.f; }); }
+    return INNFER_OK;
+}
+
+int upload(innfer_pan* p) {
+    for (auto& q : p->params) if (!q.set) return set_error(INNFER_ERR_INVALID, "pan: parameter '%s' was never set", q.key.c_str());
+    for (auto& g : p->gemms) if (g.d_w) { (void)hipFree(g.d_w); g.d_w = nullptr; }
+    build_gemms(p);
+    std::vector<f16> panel;
+    for (auto& g : p->gemms) {
+        gg::pack_panels(panel, g.cout, g.cin_pad, g.cin_pad, g.ntaps, g.weight);
+        INNFER_HIP(hipMalloc((void**)&g.d_w, panel.size() * sizeof(f16)));
+        INNFER_HIP(hipMemcpy(g.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
+    }
+    for (auto v : p->d_vecs) if (v) (void)hipFree(v);
+    p->d_vecs.assign(p->params.size(), nullptr);
+    for (size_t i = 0; i < p->params.size(); ++i) {
+        const Param& q = p->params[i];
+        if (q.shape.size() != 1) continue;
+        INNFER_HIP(hipMalloc((void**)&p->d_vecs[i], q.host.size() * sizeof(float)));
+        INNFER_HIP(hipMemcpy(p->d_vecs[i], q.host.data(), q.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    p->uploaded = true;
+    return INNFER_OK;
+}
+
+struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, inp, t, pool, fgh, att, raw, hr[2][3], total, slab_end; };
+
+PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
+    PCarve c{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t px = (size_t)N * H * W, hp = H / 4, wp = W / 4, np = (size_t)N * hp * wp;
+    size_t off = 0;
+    auto slab = [&](size_t pixels, int groups) { size_t o = off; off += al(pixels * 32 * 2 * groups); return o; };
+    c.x0 = slab(px, 1); c.fea = slab(px, 2); c.xa = slab(px, 2); c.xb = slab(px, 2); c.ab = slab(px, 2);
+    c.ab2 = slab(px, 2); c.k3y = slab(px, 1); c.inp = slab(px, 2); c.t = slab(px, 2); c.pool = slab(np ? np : 1, 2);
+    size_t m = 1;
+    for (int u = 0; u < p->n_up; ++u) { m *= 4; for (int k = 0; k < 3; ++k) c.hr[u][k] = slab(px * m, 1); }
+    c.slab_end = off;
+    c.fgh = off; off += al((np ? np : 1) * 64 * 4);
+    c.att = off; off += al((np ? np : 1) * p->nf * 4);
+    c.raw = off; off += al(px * m * 64 * 4);
+    c.total = off;
+    return c;
+}
+
+}  // namespace
+
+extern "C" size_t innfer_pan_workspace_bytes(innfer_pan* p, int N, int H, int W) {
+    if (!p || N <= 0 || H <= 0 || W <= 0) return 0;
+    return pcarve(p, N, H, W).total;
+}
+
+extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                                  int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!p || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "pan_forward: null argument");
+    if (N <= 0 || H < 4 || W < 4) return set_error(INNFER_ERR_INVALID, "pan_forward: input must be at least 4x4 (MaxPool2d(4))");
+    if (!p->uploaded) { int rc = upload(p); if (rc) return rc; }
+    const PCarve cv = pcarve(p, N, H, W);
+    if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "pan_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    INNFER_HIP(hipMemsetAsync(ws, 0, cv.slab_end, s));            // pad channels of every slab must read as zero
+    const long px = (long)N * H * W, G = px * 32;
+    const int nf = p->nf, gw = nf / 2, UF = p->unf;
+    float* raw = (float*)(ws + cv.raw);
+    int dy9[9], dx9[9], d0[1] = {0};
+    for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
+    int gi = 0;
+    auto vec = [&](const std::string& key) { return p->d_vecs[find(p, key)]; };
+    auto gemm = [&](const f16* in, long in_g, int Hin, int Win, int Ho, int Wo, int up) -> int {
+        const Gemm& g = p->gemms[gi++];
+        return gg::launch(g.d_w, g.cin_pad, 64, in, in_g, N, Hin, Win, raw, Ho, Wo, 1, g.ntaps,
+                          g.ntaps == 9 ? dy9 : d0, g.ntaps == 9 ? dx9 : d0, Ho, Wo, 1, 0, 0, up, s);
+    };
+    auto post = [&](long npix, int C, const float* bias, int mode, int act, const f16* res, long res_g, int res_off,
+                    f16* dst, long dst_g, int dst_off) -> int {
+        PP q{raw, C, bias, mode, act, res, res_g, res_off, dst, dst_g, dst_off, npix};
+        hipLaunchKernelGGL(pan_post, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, q);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    f16 *X0 = (f16*)(ws + cv.x0), *FEA = (f16*)(ws + cv.fea), *XA = (f16*)(ws + cv.xa), *XB = (f16*)(ws + cv.xb),
+        *AB = (f16*)(ws + cv.ab), *AB2 = (f16*)(ws + cv.ab2), *K3Y = (f16*)(ws + cv.k3y), *INP = (f16*)(ws + cv.inp),
+        *T = (f16*)(ws + cv.t), *POOL = (f16*)(ws + cv.pool);
+
+    hipLaunchKernelGGL(pan_pre, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, p->in_nc, (long)H * W, N, X0);
+    INNFER_HIP(hipGetLastError());
+    CK(gemm(X0, G, H, W, H, W, 0));                                                   // conv_first
+    CK(post(px, nf, vec("conv_first.bias"), MODE_LIN, 0, nullptr, 0, 0, FEA, G, 0));
+    const f16* x = FEA;
+    for (int b = 0; b < p->nb; ++b) {
+        const std::string sk = "SCPA_trunk." + std::to_string(b) + ".";
+        f16* xn = (b & 1) ? XB : XA;
+        CK(gemm(x, G, H, W, H, W, 0));                                                // [conv1_a | conv1_b]
+        CK(post(px, nf, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB, G, 0));
+        CK(gemm(AB, G, H, W, H, W, 0));                                               // k1(a)
+        CK(post(px, gw, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB2, G, 0));
+        CK(gemm(AB, G, H, W, H, W, 0));                                               // [k2(b) | k3(b)]
+        CK(post(px, gw, vec(sk + "PACnv.k2.bias"), MODE_GATE, 0, nullptr, 0, 0, K3Y, G, 0));
+        CK(gemm(K3Y, G, H, W, H, W, 0));                                              // k4
+        CK(post(px, gw, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB2, G, gw));
+        CK(gemm(AB2, G, H, W, H, W, 0));                                              // conv3(cat[a,b]) + x
+        CK(post(px, nf, nullptr, MODE_LIN, 0, x, G, 0, xn, G, 0));
+        x = xn;
+    }
+    CK(gemm(x, G, H, W, H, W, 0));                                                    // trunk_conv; inp = fea + trunk
+    CK(post(px, nf, vec("trunk_conv.bias"), MODE_LIN, 0, FEA, G, 0, INP, G, 0));
+    {   // FSA
+        const int hp = H / 4, wp = W / 4;
+        const long np = (long)N * hp * wp, Gp = np * 32;
+        hipLaunchKernelGGL(pan_maxpool, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, INP, G, nf, N, H, W, hp, wp, POOL, Gp);
+        INNFER_HIP(hipGetLastError());
+        float* save = raw;
+        raw = (float*)(ws + cv.fgh);
+        CK(gemm(POOL, Gp, hp, wp, hp, wp, 0));                                        // [f | g | h]
+        raw = save;
+        hipLaunchKernelGGL(pan_attention, dim3(hp * wp, N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
+                           vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, nf / 8, nf, (float*)(ws + cv.att));
+        INNFER_HIP(hipGetLastError());
+        hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
+                           INP, G, N, H, W, vec("FSA.gamma"), T);
+        INNFER_HIP(hipGetLastError());
+    }
+    const f16* cur = T;
+    long cur_g = G;
+    int h = H, w = W;
+    for (int u = 0; u < p->n_up; ++u) {
+        const int i = 5 * u, hh = 2 * h, ww = 2 * w;
+        const long hpx = (long)N * hh * ww, HG = hpx * 32;
+        f16 *V = (f16*)(ws + cv.hr[u][0]), *PA = (f16*)(ws + cv.hr[u][1]), *HRC = (f16*)(ws + cv.hr[u][2]);
+        CK(gemm(cur, cur_g, h, w, hh, ww, 1));                                        // conv(nearest2x(t))
+        CK(post(hpx, UF, vec("upsample." + std::to_string(i + 1) + ".bias"), MODE_LIN, 0, nullptr, 0, 0, V, HG, 0));
+        CK(gemm(V, HG, hh, ww, hh, ww, 0));                                           // PA: v * sigmoid(conv1x1(v)), then lrelu
+        CK(post(hpx, UF, vec("upsample." + std::to_string(i + 2) + ".conv.bias"), MODE_PA, 1, V, HG, 0, PA, HG, 0));
+        CK(gemm(PA, HG, hh, ww, hh, ww, 0));                                          // HRconv (no activation follows)
+        CK(post(hpx, UF, vec("upsample." + std::to_string(i + 4) + ".bias"), MODE_LIN, 0, nullptr, 0, 0, HRC, HG, 0));
+        cur = HRC; cur_g = HG; h = hh; w = ww;
+    }
+    CK(gemm(cur, cur_g, h, w, h, w, 0));                                              // conv_last
+    {
+        const long fpx = (long)N * h * w;
+        hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, raw, vec("conv_last.bias"), p->out_nc,
+                           d_in, in_dtype == INNFER_F32, N, H, W, p->scale, d_out, out_dtype == INNFER_F32);
+        INNFER_HIP(hipGetLastError());
+    }
+#undef CK
+    return INNFER_OK;
+}

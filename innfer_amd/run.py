@@ -28,7 +28,7 @@ _SNIFF = (
 )
 
 
-def infer_from_state_dict(state_dict):
+def infer_from_state_dict(state_dict, scale=None, in_nc=3, out_nc=3):
     """Architecture, scale and hyper-parameters from a checkpoint's key names and
     shapes -- host logic of Model.load_model / infer_params (run.py:44-72,103-165).
     Returns dict(arch, scale, in_nc, out_nc, nf, nb, plus, net_params, state_dict)
@@ -43,6 +43,8 @@ def infer_from_state_dict(state_dict):
     if arch == 'mesrgan':                    # new-arch checkpoints run as old-arch (run.py:57-61)
         state_dict = mod2normal(state_dict)
         arch = 'esrgan'
+    if arch == 'pan':
+        return _infer_pan(state_dict, scale, in_nc, out_nc)
     if arch not in ('esrgan', 'srgan'):
         raise NotImplementedError(f"'{arch}' checkpoints are recognised but not on the HIP path yet")
     top = {}                                 # N -> out channels of 'model.N.weight|bias'
@@ -66,6 +68,18 @@ def infer_from_state_dict(state_dict):
         cfg['plus'] = info['plus']
     info['net_params'] = get_network_G_config(cfg, info['scale'])
     return info
+
+
+def _infer_pan(state_dict, scale, in_nc, out_nc):
+    """PAN checkpoints: the reference leaves "custom params inference TBD" and builds the defaults
+    with the caller's scale / in_nc / out_nc (run.py:157-163).  Same here when a scale is given;
+    without one (the reference would fail in PAN.__init__) it is read off the up-block keys."""
+    if not scale:
+        ups = {int(k.split('.')[1]) for k in state_dict if k.startswith('upsample.')}
+        scale = 2 ** sum(1 for i in ups if i % 5 == 1)
+    cfg = {'type': 'pan', 'in_nc': in_nc, 'out_nc': out_nc}
+    return dict(arch='pan', scale=int(scale), in_nc=in_nc, out_nc=out_nc, nf=40, nb=16, plus=False,
+                state_dict=state_dict, net_params=get_network_G_config(cfg, int(scale)))
 
 
 class Model:
@@ -94,7 +108,7 @@ class Model:
         if state_dict is None:
             state_dict = torch.load(self.model_path, map_location='cpu')
         if self.arch == 'infer':
-            info = infer_from_state_dict(state_dict)
+            info = infer_from_state_dict(state_dict, self.scale, self.in_nc, self.out_nc)
             state_dict = info['state_dict']
             self.arch, self.scale = info['arch'], info['scale']
             self.in_nc, self.out_nc = info['in_nc'], info['out_nc']

@@ -64,7 +64,18 @@ def get_network_G_config(network_G, scale):
         cfg['norm_type'] = _pick(opts, 'norm_type', 'batch')
         cfg['use_dropout'] = _pick(opts, 'use_dropout', False)
         cfg['upsample_mode'] = _pick(opts, 'upsample_mode', 'deconv')
-    elif (kind in ('mrrdb_net', 'mesrgan') or 'ppon' in kind or kind in ('pan_net', 'pan')
+    elif kind in ('pan_net', 'pan'):
+        cfg['type'] = 'pan_net'
+        cfg['in_nc'] = _pick(opts, 'in_nc', 3)
+        cfg['out_nc'] = _pick(opts, 'out_nc', 3)
+        cfg['nf'] = _pick(opts, 'nf', 40)
+        cfg['unf'] = _pick(opts, 'unf', 24)
+        cfg['nb'] = _pick(opts, 'nb', 16)
+        cfg['scale'] = _pick(opts, 'scale', scale)
+        cfg['self_attention'] = _pick(opts, 'self_attention', True)
+        cfg['double_scpa'] = _pick(opts, 'double_scpa', False)
+        cfg['ups_inter_mode'] = _pick(opts, 'ups_inter_mode', 'nearest')
+    elif (kind in ('mrrdb_net', 'mesrgan') or 'ppon' in kind
           or 'wbcunet' in kind or 'resnet' in kind or 'cg' in kind):
         raise NotImplementedError(
             f'Generator model [{kind}] is a reference architecture outside the MI355X hot path built so far')

@@ -131,3 +131,52 @@ def unet_forward(sd, x, num_downs=8, eps=1e-5):
         return torch.cat([t, u], 1)
 
     return block(x, "model.", 0)
+
+
+def pan_forward(sd, x, nb=16, scale=4):
+    """PAN.forward (PAN_arch.py:178-222) with the defaults of defaults.py:78-89 (nf 40, unf 24,
+    self_attention, nearest up-blocks): SCPA blocks (PAN_arch.py:56-99), PA / PACnv pixel attention
+    (:21-55), max-pooled SAGAN self attention (block.py:398-473), bilinear(align_corners) global skip."""
+    def conv(t, key, pad=0):
+        return F.conv2d(t, sd[key + ".weight"], sd.get(key + ".bias"), padding=pad)
+
+    fea = conv(x, "conv_first", 1)
+    t = fea
+    for b in range(nb):
+        p = f"SCPA_trunk.{b}."
+        a = F.leaky_relu(conv(t, p + "conv1_a"), 0.2)
+        bb = F.leaky_relu(conv(t, p + "conv1_b"), 0.2)
+        a = F.leaky_relu(conv(a, p + "k1.0", 1), 0.2)
+        y = torch.sigmoid(conv(bb, p + "PACnv.k2"))
+        bb = conv(conv(bb, p + "PACnv.k3", 1) * y, p + "PACnv.k4", 1)
+        bb = F.leaky_relu(bb, 0.2)
+        t = conv(torch.cat([a, bb], 1), p + "conv3") + t
+    trunk = conv(t, "trunk_conv", 1)
+    # FSA(fea + trunk)
+    inp = fea + trunk
+    xp = F.max_pool2d(inp, 4, 4)
+    B, C, h, w = xp.shape
+    xv = xp.reshape(B, C, h * w)
+    f = F.conv1d(xv, sd["FSA.conv_f.weight"], sd["FSA.conv_f.bias"])
+    g = F.conv1d(xv, sd["FSA.conv_g.weight"], sd["FSA.conv_g.bias"])
+    hh = F.conv1d(xv, sd["FSA.conv_h.weight"], sd["FSA.conv_h.bias"])
+    att = torch.softmax(torch.bmm(f.permute(0, 2, 1), g), dim=-1)
+    out = torch.bmm(hh, att.permute(0, 2, 1)).reshape(B, C, h, w)
+    out = F.interpolate(out, size=(inp.shape[2], inp.shape[3]), mode="bicubic", align_corners=False)
+    t = sd["FSA.gamma"] * out + inp
+    n_up = 1 if scale == 3 else int(math.log(scale, 2))
+    for u in range(n_up):
+        # pa_upconv_block builds sequential(upsample, upconv, att, a, HRconv, a) with ONE LeakyReLU
+        # instance `a` (PAN_arch.py:11-19); B.sequential flattens with children(), which yields each
+        # module once, so a block is 5 modules (indices 5u..5u+4) and nothing follows HRconv.
+        i = 5 * u
+        t = F.interpolate(t, scale_factor=2.0 if scale != 3 else 3.0, mode="nearest")
+        t = conv(t, f"upsample.{i + 1}", 1)
+        t = F.leaky_relu(t * torch.sigmoid(conv(t, f"upsample.{i + 2}.conv")), 0.2)
+        t = conv(t, f"upsample.{i + 4}", 1)
+    out = conv(t, "conv_last", 1)
+    if scale > 1:
+        out = out + F.interpolate(x, scale_factor=float(scale), mode="bilinear", align_corners=True)
+    else:
+        out = out + x
+    return out

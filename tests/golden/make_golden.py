@@ -208,6 +208,21 @@ def g7():
          keys=keys, shapes=np.array([str(shapes[k]) for k in keys]))
 
 
+# -------------------------------------------------------------------- G8 PAN
+def g8():
+    net = ref_net("pan", 4)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, 0)
+    net.load_state_dict(t_sd(sd), strict=True)
+    net.eval()
+    out = {"keys": np.array(list(shapes.keys())), "shapes": np.array([str(shapes[k]) for k in shapes])}
+    for (h, w, seed) in [(48, 48, 8), (50, 70, 9)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed))
+        with torch.no_grad():
+            out[f"out_{h}x{w}"] = net(x).numpy()
+    save("g8_pan", **out)
+
+
 # ---------------------------------------------------------------- G9 convert
 def g9():
     ramp = (np.arange(5 * 7 * 3) * 37 % 256).astype(np.uint8).reshape(5, 7, 3)
@@ -287,6 +302,6 @@ def g12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12"]
     for g in which:
         globals()[g]()

@@ -293,6 +293,61 @@ def test_unet256_golden(dev, golden):
     assert np.abs(y32 - ref).max() < 3e-2
 
 
+def test_pan_golden(dev, golden):
+    """PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA self attention) against the
+    reference (golden G8).  fp16 slabs between the GEMMs, fp32 accumulation / gates / softmax /
+    bicubic: tolerance 1e-2 on outputs of O(1), mean error an order of magnitude below."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    g = golden("g8_pan")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = _sd(shapes)
+    net = get_network(get_network_G_config("pan", 4))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    outs = {}
+    for (h, w, seed) in [(48, 48, 8), (50, 70, 9)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed)).to(dev)
+        ref = g[f"out_{h}x{w}"].astype(np.float32)
+        for xin in (x, x.half()):
+            y = net(xin).float().cpu().numpy()
+            err = np.abs(y - ref)
+            assert y.shape == ref.shape and np.isfinite(y).all()
+            assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (h, w, err.max(), err.mean())
+        outs[(h, w)] = net(x).float().cpu().numpy()
+    # a batch is independent images (attention and pooling are per image)
+    xa = torch.from_numpy(synth.uniform((1, 3, 48, 48), 8)).to(dev)
+    xb = torch.from_numpy(synth.uniform((1, 3, 48, 48), 21)).to(dev)
+    yab = net(torch.cat([xa, xb], 0)).float().cpu().numpy()
+    assert np.array_equal(yab[0:1], outs[(48, 48)])
+    assert np.array_equal(yab[1:2], net(xb).float().cpu().numpy())
+
+
+def test_pan_scales_vs_oracle(dev):
+    """scale 2 and 1 (one / no up-block, unf = nf at scale 1), grayscale, ragged sizes, 3 blocks."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    for scale, in_nc, h, w in [(2, 3, 37, 21), (1, 1, 24, 33), (4, 1, 9, 5)]:
+        net = get_network(get_network_G_config({"type": "pan", "nb": 3, "in_nc": in_nc, "out_nc": in_nc}, scale))
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = _sd(shapes)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev)
+        x = torch.from_numpy(synth.uniform((2, in_nc, h, w), 30 + scale))
+        with torch.no_grad():
+            ref = oracle.pan_forward(sd, x, nb=3, scale=scale).numpy()
+        y = net(x.to(dev)).float().cpu().numpy()
+        err = np.abs(y - ref)
+        assert y.shape == ref.shape
+        assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (scale, err.max(), err.mean())
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 1, 3, 8, device=dev))                        # MaxPool2d(4) needs >= 4x4
+
+
 # ---------------------------------------------------------- tiles / blend / io
 def test_extract_and_blend_bit_exact(dev, golden):
     import oracle

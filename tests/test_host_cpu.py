@@ -124,8 +124,12 @@ def test_loader_inference_matches_reference(golden):
         assert info["plus"] == (str(name) == "4x_plus.pth")
     with pytest.raises(Exception, match="Could not infer"):
         infer_from_state_dict({"foo.weight": np.zeros(1)})
+    pan = infer_from_state_dict({"SCPA_trunk.0.conv1_a.weight": np.zeros(1), "upsample.1.weight": np.zeros(1),
+                                 "upsample.6.weight": np.zeros(1)})
+    assert pan["arch"] == "pan" and pan["scale"] == 4 and pan["net_params"]["type"] == "pan_net"
+    assert infer_from_state_dict({"SCPA_trunk.0.conv1_a.weight": np.zeros(1)}, scale=2)["net_params"]["scale"] == 2
     with pytest.raises(NotImplementedError):
-        infer_from_state_dict({"SCPA_trunk.0.conv1_a.weight": np.zeros(1)})
+        infer_from_state_dict({"CFEM.0.weight": np.zeros(1)})
 
 
 def test_default_configs_match_reference(golden):
@@ -165,7 +169,16 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     plus = get_network(get_network_G_config({"type": "esrgan", "plus": True, "nb": 1}, 4))
     assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
     with pytest.raises(NotImplementedError):
-        get_network({"type": "pan_net"})
+        get_network({"type": "ppon"})
+    import ast
+    g8 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_pan.npz"))
+    pan = get_network(get_network_G_config("pan", 4))
+    psd = pan.state_dict()
+    assert {k: tuple(v.shape) for k, v in psd.items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g8["keys"], g8["shapes"])}
+    with pytest.raises(NotImplementedError):
+        get_network(get_network_G_config({"type": "pan", "self_attention": False}, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pan(torch.zeros(1, 3, 8, 8))
     unet = get_network(get_network_G_config("p2p_256", 1))
     assert len(unet.state_dict()) == 82 and "model.model.1.model.2.running_mean" in unet.state_dict()
     with pytest.raises(RuntimeError, match="no CPU path"):

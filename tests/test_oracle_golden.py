@@ -121,6 +121,18 @@ def test_g7_unet(golden):
     np.testing.assert_allclose(y[0, :, ::4, ::4].numpy(), g["out_a_sub"], atol=2e-5, rtol=0)
 
 
+def test_g8_pan(golden):
+    g = golden("g8_pan")
+    import ast
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = _sd(shapes)
+    for (h, w, seed) in [(48, 48, 8), (50, 70, 9)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed))
+        with torch.no_grad():
+            y = oracle.pan_forward(sd, x, nb=16, scale=4)
+        np.testing.assert_allclose(y.numpy(), g[f"out_{h}x{w}"], atol=3e-6, rtol=0)
+
+
 def test_g9_convert(golden):
     g = golden("g9_convert")
     assert np.array_equal(oracle.np2tensor(g["ramp"]).numpy(), g["np2t"])
