@@ -22,7 +22,11 @@ stamps:
 	@mkdir -p build/stamps
 	$(HIPCC) $(FLAGS) -DINNFER_STAMPS -shared -o innfer_amd/lib/libinnfer_amd_stamps.so $(SRC)
 
+# diagnostic library whose conv kernel can skip its stores / DMA / MFMA phase (INNFER_ABL bits; never shipped)
+ablate:
+	$(HIPCC) $(FLAGS) -DINNFER_ABLATE -shared -o innfer_amd/lib/libinnfer_amd_ablate.so $(SRC)
+
 clean:
 	rm -f $(OBJ) $(LIB)
 
-.PHONY: all clean stamps
+.PHONY: all clean stamps ablate

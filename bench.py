@@ -34,14 +34,15 @@ sys.path.insert(0, REPO)
 
 PEAK_F16_TFLOPS = 2516.6      # MI355X dense fp16/bf16 MFMA: 256 CU x 4096 FLOP/clk x 2.4 GHz
 KIND_NAMES = {0: "first_conv_kernel"}
+# rows per wave of the instantiation conv_launch picks for NT 16-channel tiles (csrc/conv3x3.hip), slab / NCHW output
+RPW_OF_NT = {1: 4, 2: int(os.environ.get("INNFER_RPW32", "5")), 4: int(os.environ.get("INNFER_RPW64", "3"))}
 
 
 def kind_name(k):
     if k == 0:
         return "first_conv_kernel"
     nt, mode = k // 16, k % 16
-    rpw = {1: 4, 2: 4, 4: 2}[nt]
-    return f"conv3x3_mfma<RPW={rpw},NT={nt},OUT={mode}>"
+    return f"conv3x3_mfma<RPW={RPW_OF_NT[nt]},NT={nt},OUT={mode}>"
 
 
 def build_net(dev, nb=23, scale=4):
@@ -80,8 +81,7 @@ def pmc_traffic(kind):
     try:
         t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
         nt, mode = kind // 16, kind % 16
-        rpw = {1: 4, 2: 4, 4: 2}[nt]
-        return t[f"conv3x3_mfma<{rpw},{nt},{mode}>"]["hbm_bytes_per_launch"]
+        return t[f"conv3x3_mfma<{RPW_OF_NT[nt]},{nt},{mode}>"]["hbm_bytes_per_launch"]
     except Exception:
         return None
 

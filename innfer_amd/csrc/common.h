@@ -45,6 +45,7 @@ struct ConvLaunch {
     const f16* res2; long res2_gstride; float s2;
     int y0, y1;                                   // output rows [y0,y1)
     int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
+    int rev;                                      // traverse the tiles in reverse order (speed only: see conv3x3.hip)
 };
 
 // Panel geometry of packed weights.

@@ -49,6 +49,11 @@ __device__ unsigned long long g_stamps[8192 * NSTAMP];
 
 namespace {
 
+#ifdef INNFER_ABLATE
+#define ABL_AND(x) && (x)
+#else
+#define ABL_AND(x)
+#endif
 constexpr int TW = 32;        // tile width (pixels)
 constexpr int LWP = 40;       // LDS row pitch (pixels), multiple of 8
 constexpr int LVALID = TW + 2;
@@ -68,6 +73,12 @@ struct KP {
     int N;
     unsigned tx_magic;       // ceil(2^32 / tiles_x): tile / tiles_x == (tile * tx_magic) >> 32
     int pf;                  // L2 prefetch of the next chunk's input lines
+    int rev;                 // each XCD walks its run of tiles backwards
+    int blk;                 // tiles are enumerated in blk x blk super-blocks (0: row-major)
+    int st;                  // cache policy of the slab stores
+#ifdef INNFER_ABLATE
+    int abl;                 // diagnostic build only: 1 no stores, 2 no weight DMA, 4 no input DMA, 8 no MFMA phase
+#endif
 };
 
 __device__ __forceinline__ void dma16(const void* g, void* lds) {
@@ -107,13 +118,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        // rev: consecutive layers walk the frame in opposite directions, so a layer starts on the
+        // region its predecessor touched last -- the part of the activations that is still in the
+        // 256 MiB Infinity Cache (a cyclic sweep of a larger working set would never hit).
+        lid = start + (p.rev ? len - 1 - (bid >> 3) : (bid >> 3));
     }
     const int kg = lid % p.KG;
     int tile = lid / p.KG;
-    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
-    const int ty = tile % p.tiles_y;
-    const int n = tile / p.tiles_y;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int n = tile / per_img;
+    tile -= n * per_img;
+    int tx, ty;
+    if (p.blk > 0) {
+        // super-block order: the ~64 workgroups an XCD runs at a time form a blk x blk patch of
+        // tiles, so their halos meet in that XCD's L2 instead of being fetched again a tile row later
+        const int B = p.blk;
+        const int br = tile / (B * p.tiles_x);
+        int rem = tile - br * B * p.tiles_x;
+        const int hb = min(B, p.tiles_y - B * br);
+        const int bc = rem / (hb * B);
+        rem -= bc * hb * B;
+        const int wb = min(B, p.tiles_x - B * bc);
+        const int ly = rem / wb;
+        ty = B * br + ly;
+        tx = B * bc + (rem - ly * wb);
+    } else {
+        ty = tile / p.tiles_x;
+        tx = tile - ty * p.tiles_x;
+    }
     const int ty0 = p.y0 + ty * TH;
     const int tx0 = tx * TW;
 
@@ -194,14 +228,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
 #pragma unroll
             for (int k = 0; k < KQ; ++k) {
                 const int q = wave + 4 * k;
-                if (q < NQ)
+                if (q < NQ ABL_AND(!(p.abl & 4)))
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         ri, (__attribute__((address_space(3))) void*)(lds_in + q * 1024), 16, voff[k], 0, 0, 0);
             }
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
                 const int j = wave + 4 * k;
-                if (j < WQ)
+                if (j < WQ ABL_AND(!(p.abl & 2)))
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         rw, (__attribute__((address_space(3))) void*)(lds_w + j * 1024), 16, wvoff, j * 1024, 0, 0);
             }
@@ -224,6 +258,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         asm volatile("s_barrier" ::: "memory");             // raw: __syncthreads() would drain vmcnt to 0
         if (c < 3) STAMP(3 + 3 * c);
 
+#ifdef INNFER_ABLATE
+        if (!(p.abl & 8))
+#endif
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             f16x8 a[3][NT];
@@ -261,7 +298,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         const int y = ty0 + wave * RPW + (m >> 1);
         const int x = tx0 + (m & 1) * 16 + li;
         if (y >= p.y1 || x >= p.W) continue;
+#ifdef INNFER_ABLATE
+        if ((p.abl & 1) && acc[0][m][0] != 12345.678f) continue;
+#endif
+#ifdef INNFER_ABLATE
+        // bit 16: every workgroup stores into a private 64-KiB window (cache resident, no HBM writes)
+        const long pix = (p.abl & 16) ? (long)(blockIdx.x & 511) * 1024 + (wave * RPW + (m >> 1)) * 32 + (m & 1) * 16 + li
+                                      : ((long)n * p.H + y) * p.W + x;
+#else
         const long pix = ((long)n * p.H + y) * p.W + x;
+#endif
         float v[NT][4];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -293,12 +339,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         if constexpr (OUTMODE == OUT_SLAB) {
             const int oc0 = cbase + p.out_coff;
                 f16* op = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix * 32 + (oc0 & 31);
+            if constexpr (NT >= 2) {
+                // 16-byte stores; p.st picks the cache policy (speed only): 1 = sc1, 2 = sc0 sc1, 3 = nt
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+                for (int t = 0; t < NT; t += 2) {
+                    f16x8 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { h[j] = (f16)v[t][j]; h[4 + j] = (f16)v[t + 1][j]; }
+                    f16* o8 = op + 4 * t;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if (p.st == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(o8), "v"(h) : "memory");
+                    else if (p.st == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o8), "v"(h) : "memory");
+                    else if (p.st == 3) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(o8), "v"(h) : "memory");
+                    else
+#endif
+                        *(f16x8*)o8 = h;
+                }
+            } else {
                 f16x4 h;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (f16)v[t][j];
-                *(f16x4*)(op + 4 * t) = h;
+                for (int j = 0; j < 4; ++j) h[j] = (f16)v[0][j];
+                *(f16x4*)op = h;
             }
         } else if constexpr (OUTMODE == OUT_NCHW) {
 #pragma unroll
@@ -712,7 +773,14 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
     {
         static const int pf = getenv("INNFER_PREFETCH") ? atoi(getenv("INNFER_PREFETCH")) : 1;
+        static const int blk = getenv("INNFER_TILE_BLOCK") ? atoi(getenv("INNFER_TILE_BLOCK")) : 0;
+        static const int st = getenv("INNFER_STORE") ? atoi(getenv("INNFER_STORE")) : 0;
         k.pf = pf;
+        k.blk = blk;
+        k.st = st;
+#ifdef INNFER_ABLATE
+        k.abl = getenv("INNFER_ABL") ? atoi(getenv("INNFER_ABL")) : 0;
+#endif
     }
     const long grid = (long)N * k.tiles_x * k.tiles_y * k.KG;
     if (grid <= 0) return INNFER_OK;
@@ -787,6 +855,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.y0 = L.y0; k.y1 = L.y1 > 0 ? L.y1 : L.H;
     if (k.y0 < 0 || k.y1 > L.H || k.y0 >= k.y1) return set_error(INNFER_ERR_INVALID, "conv3x3: bad row range [%d,%d)", k.y0, k.y1);
     k.out_f32 = L.out_f32;
+    k.rev = L.rev ? 1 : 0;
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
@@ -806,10 +875,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         }
         return set_error(INNFER_ERR_INVALID, "conv3x3: bad out_mode");
     }
+    static const int rpw64 = getenv("INNFER_RPW64") ? atoi(getenv("INNFER_RPW64")) : 3;
+    static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
     switch (L.out_mode) {
         case OUT_SLAB:
-            if (nt == 4) return launch_t<2, 4, OUT_SLAB>(k, L.N, s);
-            if (nt == 2) return launch_t<4, 2, OUT_SLAB>(k, L.N, s);
+            if (nt == 4) return rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);
+            if (nt == 2) return rpw32 == 5 ? launch_t<5, 2, OUT_SLAB>(k, L.N, s) : launch_t<4, 2, OUT_SLAB>(k, L.N, s);
             return launch_t<4, 1, OUT_SLAB>(k, L.N, s);
         case OUT_NCHW:
             if (nt == 4) return launch_t<2, 4, OUT_NCHW>(k, L.N, s);

@@ -289,7 +289,15 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
     if (debug_sync())
         fprintf(stderr, "[innfer] conv C=%d K=%d N=%d H=%d W=%d up=%d act=%d mode=%d rows=[%d,%d) in_g=%ld out_g=%ld\n",
                 L.C, L.K, L.N, L.H, L.W, L.up, L.act, L.out_mode, L.y0, L.y1, L.in_gstride, L.out_gstride);
-    rc = conv_launch(L, s);
+    {
+        // whole-frame launches alternate their traversal direction (Infinity Cache reuse between layers)
+        static const bool alt = !getenv("INNFER_TILE_REV") || atoi(getenv("INNFER_TILE_REV")) != 0;
+        thread_local unsigned parity = 0;
+        ConvLaunch R = L;
+        const int y1 = L.y1 > 0 ? L.y1 : L.H;
+        R.rev = (alt && L.y0 == 0 && y1 == L.H) ? (int)(parity++ & 1) : 0;
+        rc = conv_launch(R, s);
+    }
     if (rc) return rc;
     rc = debug_after("conv3x3", s);
     if (rc) return rc;
