@@ -20,7 +20,7 @@ $(LIB): $(OBJ)
 # diagnostic library with in-kernel s_memtime stamps (never shipped, never benchmarked)
 stamps:
 	@mkdir -p build/stamps
-	$(HIPCC) $(FLAGS) -DINNFER_STAMPS -shared -o innfer_amd/lib/libinnfer_amd_stamps.so $(SRC)
+	$(HIPCC) $(FLAGS) -DINNFER_STAMPS -DINNFER_ABLATE -shared -o innfer_amd/lib/libinnfer_amd_stamps.so $(SRC)
 
 # diagnostic library whose conv kernel can skip its stores / DMA / MFMA phase (INNFER_ABL bits; never shipped)
 ablate:

@@ -29,6 +29,17 @@
 
 #include <cstdlib>
 
+// Pins a value as a rounded fp32 number in a VGPR: the backend cannot fold the fp16 conversion that
+// follows into the fma that produced it (v_fma_mixlo_f16 rounds ONCE, fma + convert rounds twice).
+#define FP32_VALUE(x) asm("" : "+v"(x))
+
+// No implicit floating-point contraction in this file.  With contraction allowed the backend may fold
+// "round to fp16 of (a*b + c)" into v_fma_mixlo_f16 (ONE rounding) for some unrolled copies of the
+// epilogue and keep fma + convert (TWO roundings) for others, which makes a pixel's value depend on
+// where in a tile it was computed (1 fp16 ulp, seen as banded != plain schedule).  The residual adds
+// below are explicit fmaf() calls, pinned with FP32_VALUE before the conversion.
+#pragma clang fp contract(off)
+
 namespace innfer {
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
@@ -74,8 +85,7 @@ struct KP {
     unsigned tx_magic;       // ceil(2^32 / tiles_x): tile / tiles_x == (tile * tx_magic) >> 32
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
-    int blk;                 // tiles are enumerated in blk x blk super-blocks (0: row-major)
-    int st;                  // cache policy of the slab stores
+    int total;               // tiles x channel groups of this launch
 #ifdef INNFER_ABLATE
     int abl;                 // diagnostic build only: 1 no stores, 2 no weight DMA, 4 no input DMA, 8 no MFMA phase
 #endif
@@ -84,6 +94,70 @@ struct KP {
 __device__ __forceinline__ void dma16(const void* g, void* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// Slab epilogue, specialised on (activation, residual 1, residual 2) so that the unrolled loop over the
+// wave's pixel tiles is straight-line code: residual loads for all tiles first (their latencies
+// overlap), then act -> *s1 + res1 -> *s2 + res2 -> fp16 -> one 8*NT-byte store per pixel tile.
+// (The generic runtime-flag version of this loop took ~15 k cycles per workgroup, a third of the
+// lifetime of a 64->32 workgroup: profiles/r1/wg_timeline_r1c.txt.)
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST>
+__device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
+                                              int wave, int li, int cbase) {
+    constexpr int MT = 2 * RPW;
+    const int oc0 = cbase + p.out_coff;
+    const int yw = ty0 + wave * RPW, xl = tx0 + li;
+    const long pix0 = ((long)n * p.H + yw) * p.W + xl;
+    const long rowstep = (long)p.W * 32;
+    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix0 * 32 + (oc0 & 31);
+    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + pix0 * 32 + (cbase & 31) : nullptr;
+    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + pix0 * 32 + (cbase & 31) : nullptr;
+    bool ok[MT];
+    f16x4 r1[R1 ? MT : 1][NT], r2[R2 ? MT : 1][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        ok[m] = (yw + (m >> 1) < p.y1) && (xl + (m & 1) * 16 < p.W);
+        const long o = (m >> 1) * rowstep + (m & 1) * 16 * 32;
+        if (HOIST && R1 && ok[m]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + 4 * t);
+        }
+        if (HOIST && R2 && ok[m]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + o + 4 * t);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (!ok[m]) continue;
+#ifdef INNFER_ABLATE
+        if (p.abl & 1) continue;
+#endif
+        f16* op = ob + (m >> 1) * rowstep + (m & 1) * 16 * 32;
+        if (!HOIST) {
+            const long o = (m >> 1) * rowstep + (m & 1) * 16 * 32;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (R1) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + 4 * t);
+                if (R2) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + o + 4 * t);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = acc[t][m][j];
+                if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
+                if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
+                FP32_VALUE(f);
+                h[j] = (f16)f;
+            }
+            *(f16x4*)(op + 4 * t) = h;
+        }
+    }
 }
 
 template <int RPW, int NT, int OUTMODE>
@@ -109,66 +183,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     STAMP(0);
-
-    // ---- block -> (channel group, tile): XCD-aware bijective remap ------------
-    // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
-    // contiguous run of tiles so neighbouring halos and the next layer's reads
-    // of the same region meet in one L2.  Speed only, never correctness.
-    int lid;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int len = q + (xcd < r ? 1 : 0);
-        // rev: consecutive layers walk the frame in opposite directions, so a layer starts on the
-        // region its predecessor touched last -- the part of the activations that is still in the
-        // 256 MiB Infinity Cache (a cyclic sweep of a larger working set would never hit).
-        lid = start + (p.rev ? len - 1 - (bid >> 3) : (bid >> 3));
-    }
-    const int kg = lid % p.KG;
-    int tile = lid / p.KG;
+    // ---- workgroup -> tiles ---------------------------------------------------------
+    // Blocks b and b+8 share an XCD (round-robin dispatch): each XCD gets a contiguous run of the
+    // tile list, so neighbouring halos and the next layer's reads of the same region meet in one L2,
+    // and its workgroups walk that run round-robin.  With fewer workgroups than tiles (the default:
+    // two per CU) a workgroup is PERSISTENT: it goes on to its next tile while the stores of the last
+    // one drain, instead of holding its LDS and wave slots idle until they are acknowledged
+    // (s_endpgm waits for them; profiles/r1/ablation_conv.txt).  Speed only, never correctness.
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int run_q = p.total >> 3, run_r = p.total & 7;
+    const int run_start = xcd < run_r ? xcd * (run_q + 1) : run_r * (run_q + 1) + (xcd - run_r) * run_q;
+    const int run_len = run_q + (xcd < run_r ? 1 : 0);
+    const int slots = ((int)gridDim.x + 7 - xcd) >> 3;            // this launch's workgroups on this XCD
     const int per_img = p.tiles_x * p.tiles_y;
-    const int n = tile / per_img;
-    tile -= n * per_img;
-    int tx, ty;
-    if (p.blk > 0) {
-        // super-block order: the ~64 workgroups an XCD runs at a time form a blk x blk patch of
-        // tiles, so their halos meet in that XCD's L2 instead of being fetched again a tile row later
-        const int B = p.blk;
-        const int br = tile / (B * p.tiles_x);
-        int rem = tile - br * B * p.tiles_x;
-        const int hb = min(B, p.tiles_y - B * br);
-        const int bc = rem / (hb * B);
-        rem -= bc * hb * B;
-        const int wb = min(B, p.tiles_x - B * bc);
-        const int ly = rem / wb;
-        ty = B * br + ly;
-        tx = B * bc + (rem - ly * wb);
-    } else {
-        ty = tile / p.tiles_x;
-        tx = tile - ty * p.tiles_x;
-    }
-    const int ty0 = p.y0 + ty * TH;
-    const int tx0 = tx * TW;
-
-    // ---- per-lane DMA source offsets (chunk independent) ----------------------
-    const int sy_base = (ty0 > 0 ? ty0 - 1 : 0) >> p.up;
-    const char* in_base = (const char*)(p.in + (long)n * p.in_img_stride +
-                                        (long)sy_base * p.Ws * 32);
-    int in_off[KQ];
-#pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-        const int q = wave + 4 * k;
-        const int px = q * 16 + (lane >> 2);
-        const int ly = px / LWP, lx = px - ly * LWP;
-        const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
-        const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
-        const bool ok = (q < NQ) && (lx < LVALID) && (Y >= 0) && (Y < p.H) && (X >= 0) && (X < p.W);
-        const int sy = (Y >> p.up) - sy_base, sx = X >> p.up;
-        in_off[k] = ok ? ((sy * p.Ws + sx) * 32 + slot * 8) * 2 : -1;
-    }
-    // ---- per-lane LDS read bases ------------------------------------------------
     const int li = lane & 15, lg = lane >> 4;
+    constexpr int OOB = (int)0x80000000;
+
+    // ---- per-lane constants: computed ONCE per (persistent) workgroup ---------------------------
+    // Issue path: every DMA piece is ONE `buffer_load_dwordx4 ... offen lds` with a per-chunk SGPR
+    // descriptor based at the tile's first halo pixel and a per-lane byte offset that does not depend
+    // on the tile.  Lanes in the LDS row pad, and (border tiles only) lanes whose pixel lies outside
+    // the image -- the conv's zero padding -- carry an offset beyond num_records: the buffer range
+    // check then writes ZEROS to LDS (verified on gfx950 by the border cases of the parity tests).
+    int loff[KQ];
+    {
+        const int ypar = p.up ? ((p.y0 - 1) & 1) : 0;           // parity of the first halo row (tile rows are even)
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int q = wave + 4 * k;
+            const int px = q * 16 + (lane >> 2);
+            const int ly = px / LWP, lx = px - ly * LWP;
+            const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
+            const int ry = p.up ? (ly + ypar) >> 1 : ly;        // source row / column relative to the base pixel
+            const int rx = p.up ? (lx + 1) >> 1 : lx;
+            loff[k] = (q < NQ && lx < LVALID) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
+        }
+    }
     const char* bbase[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -176,53 +226,100 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         bbase[s] = lds_in + pb * 64 + ((lg ^ ((((li + s) >> 2) & 1) << 1)) << 4);
     }
     const char* abase = lds_w + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
-
-    // ---- accumulators start at the bias ----------------------------------------
-    const int cbase = kg * WROWS + 4 * NT * lg;     // first of this lane's 4*NT channels
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const f32x4 b = *(const f32x4*)(p.bias + cbase + 4 * t);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[t][m] = b;
-    }
-
-    STAMP(1);
-    // Issue path: every piece is ONE `buffer_load_dwordx4 ... offen lds` with a per-chunk SGPR
-    // descriptor and a per-lane byte offset computed once per workgroup -- no VALU, no select.
-    // Lanes whose pixel lies outside the image (the conv's zero padding) or in the LDS row pad carry
-    // an offset beyond num_records: the buffer range check then writes ZEROS to LDS (verified on
-    // gfx950 by the border cases of tests/test_gpu_parity.py).
-    int voff[KQ];
-#pragma unroll
-    for (int k = 0; k < KQ; ++k) voff[k] = in_off[k] >= 0 ? in_off[k] : (int)0x80000000;
     const int wvoff = lane * 16;
-    const char* w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
-
-    // L2 prefetch plan (p.pf): LDS-DMA streams ~3x faster from L2 than from HBM and a workgroup can
-    // only keep one chunk of LDS-DMA in flight, so while chunk c is landing / being computed every
-    // thread touches one dword in (up to) two 128-B lines of chunk c+1's halo tile: ordinary loads,
-    // results discarded, nothing waits for them until a whole compute phase later.
+    // L2 prefetch plan (p.pf): LDS-DMA streams several times faster from L2 than from HBM and a
+    // workgroup keeps only one chunk of LDS-DMA in flight, so while chunk c is landing / being computed
+    // every thread touches one dword in (up to) two 128-B lines of the NEXT stage's halo tile -- chunk
+    // c+1 of this tile, or chunk 0 of the workgroup's next tile: results discarded (2 KiB LDS scratch),
+    // nothing waits for them until a whole compute phase later.
     constexpr int LPR = (LVALID * 64 + 127) / 128 + 1;        // 128-B lines per tile row (18)
     constexpr int NLINES = LH * LPR;
-    int pfo[2];
+    int pfl[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int id = tid + 256 * i;
         const int r = id / LPR, l = id - r * LPR;
-        const int Y = ty0 - 1 + r;
-        const int xs = tx0 > 0 ? tx0 - 1 : 0;
-        const bool ok = p.pf && !p.up && id < NLINES && Y >= 0 && Y < p.H && ((xs * 64) & ~127) + l * 128 < p.W * 64;
-        pfo[i] = ok ? (((Y - sy_base) * p.Ws * 64 + ((xs * 64) & ~127) + l * 128)) : (int)0x80000000;
+        pfl[i] = (p.pf && !p.up && id < NLINES) ? r * p.Ws * 64 + (l - 1) * 128 : OOB;   // relative to (row ty0-1, col tx0)
     }
-    char* lds_pf = smem + IN_BYTES + W_BYTES + wave * 512;    // 2 KiB scratch nobody reads
+    char* lds_pf = smem + IN_BYTES + W_BYTES + wave * 512;
+    f32x4 bias_r[NT];
+    int bias_kg = -1;
+
+    auto decode = [&](int jj, int& kg_, int& n_, int& ty0_, int& tx0_) {
+        // rev: consecutive layers walk the frame in opposite directions, so a layer starts on the region
+        // its predecessor touched last -- the part of the activations that is still in the 256 MiB
+        // Infinity Cache (a cyclic sweep of a larger working set would never hit).
+        const int lid = run_start + (p.rev ? run_len - 1 - jj : jj);
+        kg_ = lid % p.KG;
+        int tile = lid / p.KG;
+        n_ = tile / per_img;
+        tile -= n_ * per_img;
+        const int ty = tile / p.tiles_x;
+        ty0_ = p.y0 + ty * TH;
+        tx0_ = (tile - ty * p.tiles_x) * TW;
+    };
+    auto is_edge = [&](int ty0_, int tx0_) {
+        return ty0_ == 0 || ty0_ + TH + 1 > p.H || tx0_ == 0 || tx0_ + TW + 1 > p.W;
+    };
+
+    for (int j = bid >> 3; j < run_len; j += slots) {
+    STAMP(0);
+    int kg, n, ty0, tx0;
+    decode(j, kg, n, ty0, tx0);
+    const bool edge = is_edge(ty0, tx0);
+    const char* img = (const char*)(p.in + (long)n * p.in_img_stride);
+    const char* in_tile = img + ((long)((ty0 - 1) >> p.up) * p.Ws + ((tx0 >> p.up) - 1)) * 64;
+    const char* pf_tile = img + ((long)(ty0 - 1) * p.Ws + tx0) * 64;         // prefetch only runs with up == 0
+    int voff[KQ], pfo[2];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
+    pfo[0] = pfl[0]; pfo[1] = pfl[1];
+    if (edge) {
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {                   // border tiles only: recomputed, not kept in registers
+            const int px = (wave + 4 * k) * 16 + (lane >> 2);
+            const int ly = px / LWP, lx = px - ly * LWP;
+            const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
+            if (Y < 0 || Y >= p.H || X < 0 || X >= p.W) voff[k] = OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / LPR, l = id - r * LPR;
+            const int Y = ty0 - 1 + r, lb = tx0 * 64 + (l - 1) * 128;
+            if (Y < 0 || Y >= p.H || lb < 0 || lb >= p.W * 64) pfo[i] = OOB;
+        }
+    }
+    // the workgroup's next tile, for the cross-tile prefetch (border tiles are not prefetched)
+    const char* pf_next = nullptr;
+    if (p.pf >= 2 && !p.up && j + slots < run_len) {
+        int kg2, n2, ty2, tx2;
+        decode(j + slots, kg2, n2, ty2, tx2);
+        if (!is_edge(ty2, tx2))
+            pf_next = (const char*)(p.in + (long)n2 * p.in_img_stride) + ((long)(ty2 - 1) * p.Ws + tx2) * 64;
+    }
+
+    // ---- accumulators start at the bias ----------------------------------------
+    const int cbase = kg * WROWS + 4 * NT * lg;     // first of this lane's 4*NT channels
+    if (kg != bias_kg) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bias_r[t] = *(const f32x4*)(p.bias + cbase + 4 * t);
+        bias_kg = kg;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[t][m] = bias_r[t];
+    const char* w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
+    STAMP(1);
 
     for (int c = 0; c < p.nchunks; ++c) {
         // stage chunk c: halo tile + weight panel, straight into LDS
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS buffer-load builtin only exists in the device pass
         {
             const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(in_base + c * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
+                (void*)(in_tile + c * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(w_tile + (long)c * W_BYTES), 0, W_BYTES, 0x00020000);
 #pragma unroll
@@ -241,18 +338,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
             }
         }
         asm volatile("" ::: "memory");                      // keep the prefetch loads BEHIND the DMA pieces
-        const bool do_pf = p.pf && !p.up && c + 1 < p.nchunks;
+        const bool last = c + 1 == p.nchunks;
+        const bool do_pf = p.pf && !p.up && (!last || pf_next != nullptr);
         if (do_pf) {
             const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(in_base + (c + 1) * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void*)lds_pf, 4, pfo[0], 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void*)(lds_pf + 256), 4, pfo[1], 0, 0, 0);
+                (void*)(last ? pf_next : pf_tile + (c + 1) * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void*)lds_pf, 4, last ? pfl[0] : pfo[0], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void*)(lds_pf + 256), 4, last ? pfl[1] : pfo[1], 0, 0, 0);
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the DMA pieces, not the two prefetch loads
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #else
-        (void)voff; (void)wvoff; (void)w_tile; (void)in_base; (void)KW; (void)pfo; (void)lds_pf;
+        (void)voff; (void)wvoff; (void)w_tile; (void)in_tile; (void)pf_tile; (void)pf_next; (void)KW; (void)pfo; (void)lds_pf;
 #endif
         if (c < 3) STAMP(2 + 3 * c);
         asm volatile("s_barrier" ::: "memory");             // raw: __syncthreads() would drain vmcnt to 0
@@ -293,21 +391,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
     STAMP(11);
 
     // ---- epilogue: act -> residuals -> store -----------------------------------
+    if constexpr (OUTMODE == OUT_SLAB) {
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C)>(p, acc, n, ty0, tx0, wave, li, cbase)
+        if (!p.res1) {
+            if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
+        } else if (!p.res2) {
+            if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
+        } else {
+            if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
+        }
+#undef EPI
+    } else
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int y = ty0 + wave * RPW + (m >> 1);
         const int x = tx0 + (m & 1) * 16 + li;
         if (y >= p.y1 || x >= p.W) continue;
-#ifdef INNFER_ABLATE
-        if ((p.abl & 1) && acc[0][m][0] != 12345.678f) continue;
-#endif
-#ifdef INNFER_ABLATE
-        // bit 16: every workgroup stores into a private 64-KiB window (cache resident, no HBM writes)
-        const long pix = (p.abl & 16) ? (long)(blockIdx.x & 511) * 1024 + (wave * RPW + (m >> 1)) * 32 + (m & 1) * 16 + li
-                                      : ((long)n * p.H + y) * p.W + x;
-#else
         const long pix = ((long)n * p.H + y) * p.W + x;
-#endif
         float v[NT][4];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -324,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
             for (int t = 0; t < NT; ++t) {
                 const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[t][j] = v[t][j] * p.s1 + (float)r4[j];
+                for (int j = 0; j < 4; ++j) v[t][j] = __builtin_fmaf(v[t][j], p.s1, (float)r4[j]);
             }
         }
         if (p.res2) {
@@ -333,35 +433,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
             for (int t = 0; t < NT; ++t) {
                 const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[t][j] = v[t][j] * p.s2 + (float)r4[j];
+                for (int j = 0; j < 4; ++j) v[t][j] = __builtin_fmaf(v[t][j], p.s2, (float)r4[j]);
             }
         }
-        if constexpr (OUTMODE == OUT_SLAB) {
-            const int oc0 = cbase + p.out_coff;
-                f16* op = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix * 32 + (oc0 & 31);
-            if constexpr (NT >= 2) {
-                // 16-byte stores; p.st picks the cache policy (speed only): 1 = sc1, 2 = sc0 sc1, 3 = nt
 #pragma unroll
-                for (int t = 0; t < NT; t += 2) {
-                    f16x8 h;
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { h[j] = (f16)v[t][j]; h[4 + j] = (f16)v[t + 1][j]; }
-                    f16* o8 = op + 4 * t;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    if (p.st == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(o8), "v"(h) : "memory");
-                    else if (p.st == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o8), "v"(h) : "memory");
-                    else if (p.st == 3) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(o8), "v"(h) : "memory");
-                    else
-#endif
-                        *(f16x8*)o8 = h;
-                }
-            } else {
-                f16x4 h;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (f16)v[0][j];
-                *(f16x4*)op = h;
-            }
-        } else if constexpr (OUTMODE == OUT_NCHW) {
+            for (int j = 0; j < 4; ++j) FP32_VALUE(v[t][j]);
+        if constexpr (OUTMODE == OUT_NCHW) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -393,9 +472,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         }
     }
 #ifdef INNFER_STAMPS
+    STAMP(13);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(12);
 #endif
+    }   // tiles of this workgroup
 }
 
 
@@ -659,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_t(const KP p) {
                     for (int t = 0; t < NT; ++t) {
                         const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[t][j] = v[t][j] * p.s1 + (float)r4[j];
+                        for (int j = 0; j < 4; ++j) v[t][j] = __builtin_fmaf(v[t][j], p.s1, (float)r4[j]);
                     }
                 }
                 if (p.res2) {
@@ -668,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_t(const KP p) {
                     for (int t = 0; t < NT; ++t) {
                         const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[t][j] = v[t][j] * p.s2 + (float)r4[j];
+                        for (int j = 0; j < 4; ++j) v[t][j] = __builtin_fmaf(v[t][j], p.s2, (float)r4[j]);
                     }
                 }
                 if constexpr (OUTMODE == OUT_SLAB) {
@@ -772,19 +853,19 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
     {
-        static const int pf = getenv("INNFER_PREFETCH") ? atoi(getenv("INNFER_PREFETCH")) : 1;
-        static const int blk = getenv("INNFER_TILE_BLOCK") ? atoi(getenv("INNFER_TILE_BLOCK")) : 0;
-        static const int st = getenv("INNFER_STORE") ? atoi(getenv("INNFER_STORE")) : 0;
+        static const int pf = getenv("INNFER_PREFETCH") ? atoi(getenv("INNFER_PREFETCH")) : 0;   // 1: next chunk, 2: + next tile
         k.pf = pf;
-        k.blk = blk;
-        k.st = st;
 #ifdef INNFER_ABLATE
         k.abl = getenv("INNFER_ABL") ? atoi(getenv("INNFER_ABL")) : 0;
 #endif
     }
-    const long grid = (long)N * k.tiles_x * k.tiles_y * k.KG;
-    if (grid <= 0) return INNFER_OK;
-    if (grid > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
+    const long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
+    if (total <= 0) return INNFER_OK;
+    if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
+    k.total = (int)total;
+    static const int persist = getenv("INNFER_PERSIST") ? atoi(getenv("INNFER_PERSIST")) : 2;   // workgroups per CU, 0 = one per tile
+    const long slots = (long)persist * num_cus();
+    const long grid = (persist > 0 && total > slots) ? slots : total;
     hipLaunchKernelGGL((conv3x3_mfma<RPW, NT, OUTMODE>), dim3((unsigned)grid), dim3(256), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
