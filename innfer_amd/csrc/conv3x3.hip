@@ -264,6 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
 
     for (int j = bid >> 3; j < run_len; j += slots) {
     STAMP(0);
+#ifdef INNFER_STAMPS
+    if (blockIdx.x < 8192 && threadIdx.x == 0) g_stamps[blockIdx.x * NSTAMP + 14] = (unsigned long long)wall_clock64();
+#endif
     int kg, n, ty0, tx0;
     decode(j, kg, n, ty0, tx0);
     const bool edge = is_edge(ty0, tx0);
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
     STAMP(13);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(12);
+    if (blockIdx.x < 8192 && threadIdx.x == 0) g_stamps[blockIdx.x * NSTAMP + 15] = (unsigned long long)wall_clock64();   // 100 MHz
 #endif
     }   // tiles of this workgroup
 }

@@ -30,5 +30,7 @@ for (Cc, K) in [(64, 32), (160, 32), (192, 64)][:int(os.environ.get('STAMPS_CASE
     med = np.median(rel, axis=0)
     for i in valid:
         print(f"  {names[i]:12s} median {med[i]:9.0f} ticks   p10 {np.percentile(rel[:, i], 10):9.0f}  p90 {np.percentile(rel[:, i], 90):9.0f}")
+    wall = (st[:, 15] - st[:, 14]) / 100.0          # us (s_memrealtime, 100 MHz)
+    print(f"  shader clock while this tile ran: median {np.median(rel[:, 12] / wall) / 1e3:.3f} GHz  (tile wall time {np.median(wall):.2f} us)")
     life = rel[:, 12]
     print(f"  WG lifetime median {np.median(life):.0f} ticks; start times: first {0:.0f}, median {np.median(st[:, 0] - t0):.0f}, last {(st[:, 0] - t0).max():.0f}")
