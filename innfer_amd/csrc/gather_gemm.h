@@ -1,6 +1,6 @@
 // Gather-GEMM on MFMA shared by the UNet and PAN engines: out[pixel][co] = sum over taps and input
-// channels of in[pixel displaced by the tap][ci] * W[tap][ci][co].  One 64-pixel x 64-channel tile per
-// workgroup, operands staged through LDS with plain loads (correctness-first; the SR hot path uses
+// channels of in[pixel displaced by the tap][ci] * W[tap][ci][co].  One 128-pixel x 64-channel tile per
+// workgroup, operands staged through LDS with register-prefetched loads (the SR hot path uses
 // conv3x3.hip).  Input: blocked-NHWC fp16 slab; output: fp32 [pixel][cout_pad].
 #pragma once
 #include "common.h"
@@ -20,69 +20,110 @@ struct GP {
     int up;                               // input is read through nearest-2x upsampling (Hin, Win = source size)
 };
 
+// 128 pixels x 64 output channels per workgroup (4 waves x (32 px x 64 co) = 8 MFMAs per wave and 32-channel
+// k-step).  Operands go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 12 one-KiB pieces per step)
+// through a ring of GG_STAGES stages, issued GG_STAGES-1 steps ahead: a wave waits only for its own pieces
+// of the current step (counted vmcnt), one raw barrier per step publishes them and frees the stage consumed
+// last.  Out-of-image taps (the conv's zero padding / the transposed conv's missing taps) and pixels beyond
+// M carry an offset beyond num_records: the buffer range check writes zeros to LDS.
+constexpr int GG_STAGES = 4;
+constexpr int GG_STAGE_BYTES = 12288;                                 // 128 px x 64 B | 64 co x 64 B
+
 static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
-    __shared__ __attribute__((aligned(16))) char lds[8192];
-    char* lds_b = lds;                    // 64 pixels x 64 B
-    char* lds_a = lds + 4096;             // 64 out channels x 64 B
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) char lds[GG_STAGES * GG_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const long M = (long)p.N * p.Ho * p.Wo;
-    const long m0 = (long)blockIdx.x * 64;
+    const long m0 = (long)blockIdx.x * 128;
     const int cot = blockIdx.y;
 
-    // staging role of this thread: pixel row (tid>>2), 16-byte slot (tid&3)
-    const int srow = tid >> 2, sslot = tid & 3;
-    const long sm = m0 + srow;
-    int sn = 0, soy = 0, sox = 0;
-    const bool sm_ok = sm < M;
-    if (sm_ok) {
-        sox = (int)(sm % p.Wo);
-        soy = (int)((sm / p.Wo) % p.Ho);
-        sn = (int)(sm / ((long)p.Wo * p.Ho));
+    // staging role: pixel rows (tid>>2) and 64 + (tid>>2), 16-byte slot (tid&3); weight row (tid>>2)
+    const int sslot = tid & 3;
+    int spix[2], soy[2], sox[2], cso[2]; bool sok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int srow = (tid >> 2) + 64 * h;
+        const long sm = m0 + srow;
+        sok[h] = sm < M;
+        int n = 0;
+        soy[h] = sox[h] = 0;
+        if (sok[h]) {
+            sox[h] = (int)(sm % p.Wo);
+            soy[h] = (int)((sm / p.Wo) % p.Ho);
+            n = (int)(sm / ((long)p.Wo * p.Ho));
+        }
+        spix[h] = n * p.Hin * p.Win;                                  // first pixel of the image (launch checks 32-bit range)
+        cso[h] = (sslot ^ (((srow >> 2) & 1) << 1)) * 16;             // byte offset of the channel slot stored at LDS slot sslot
     }
-    const int cslot = sslot ^ (((srow >> 2) & 1) << 1);           // channel slot stored at LDS slot sslot
+    const char* wtile = (const char*)p.wpk + (long)cot * p.ntaps * p.nchunks * 4096;
+    const int nsteps = p.ntaps * p.nchunks;
 
-    f32x4 acc[4];
+    auto issue = [&](int step) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int t = step / p.nchunks, c = step - t * p.nchunks;
+        char* st = lds + (step % GG_STAGES) * GG_STAGE_BYTES;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)c * p.in_g), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + (long)step * 4096), 0, 4096, 0x00020000);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < 2; ++h) {
+            int iy = soy[h] * p.stride + p.dy[t], ix = sox[h] * p.stride + p.dx[t];
+            bool ok = sok[h] && iy >= 0 && ix >= 0;
+            if (p.up) { ok = ok && iy < 2 * p.Hin && ix < 2 * p.Win; iy >>= 1; ix >>= 1; }
+            else ok = ok && iy < p.Hin && ix < p.Win;
+            const int voff = ok ? (spix[h] + iy * p.Win + ix) * 64 + cso[h] : (int)0x80000000;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(st + (wave + 4 * h) * 1024), 16, voff, 0, 0, 0);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + 8192 + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+#else
+        (void)step; (void)wtile; (void)spix; (void)cso;
+#endif
+    };
 
-    const char* wbase = (const char*)p.wpk + (long)cot * p.ntaps * p.nchunks * 4096 + tid * 16;
-    const int brow = wave * 16 + li;
-    const int boff = brow * 64 + ((lg ^ (((brow >> 2) & 1) << 1)) << 4);
-    const int aoff = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
-
-    for (int t = 0; t < p.ntaps; ++t) {
-        int iy = soy * p.stride + p.dy[t], ix = sox * p.stride + p.dx[t];
-        bool ok = sm_ok && iy >= 0 && ix >= 0;
-        if (p.up) { ok = ok && iy < 2 * p.Hin && ix < 2 * p.Win; iy >>= 1; ix >>= 1; }
-        else ok = ok && iy < p.Hin && ix < p.Win;
-        const f16* src = p.in + (((long)sn * p.Hin + iy) * p.Win + ix) * 32 + cslot * 8;
-        for (int c = 0; c < p.nchunks; ++c) {
-            u32x4 vb = u32x4{0u, 0u, 0u, 0u};
-            if (ok) vb = *(const u32x4*)(src + (long)c * p.in_g);
-            const u32x4 va = *(const u32x4*)(wbase + ((long)t * p.nchunks + c) * 4096);
-            __syncthreads();
-            *(u32x4*)(lds_b + tid * 16) = vb;
-            *(u32x4*)(lds_a + tid * 16) = va;
-            __syncthreads();
-            const f16x8 b = *(const f16x8*)(lds_b + boff);
+    f32x4 acc[2][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f16x8 a = *(const f16x8*)(lds_a + q * 1024 + aoff);
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[q], 0, 0, 0);
-            }
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int boff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int brow = wave * 32 + 16 * h + li;
+        boff[h] = brow * 64 + ((lg ^ (((brow >> 2) & 1) << 1)) << 4);
+    }
+    const int aoff = 8192 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+
+    for (int s0 = 0; s0 < GG_STAGES - 1 && s0 < nsteps; ++s0) issue(s0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int ahead = nsteps - 1 - step;                          // steps issued after this one, capped by the ring
+        if (ahead >= GG_STAGES - 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (step + GG_STAGES - 1 < nsteps) issue(step + GG_STAGES - 1);
+        const char* b = lds + (step % GG_STAGES) * GG_STAGE_BYTES;
+        const f16x8 b0 = *(const f16x8*)(b + boff[0]);
+        const f16x8 b1 = *(const f16x8*)(b + boff[1]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f16x8 a = *(const f16x8*)(b + q * 1024 + aoff);
+            acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc[0][q], 0, 0, 0);
+            acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc[1][q], 0, 0, 0);
         }
     }
     // D rows = out channels (16*lg + 4*q + j after the panel permutation), cols = pixels
-    const long m = m0 + wave * 16 + li;
-    if (m < M) {
-        const int ox = (int)(m % p.Wo);
-        const int oy = (int)((m / p.Wo) % p.Ho);
-        const long n = m / ((long)p.Wo * p.Ho);
-        const long opix = (n * p.Hfull + (long)oy * p.os + p.ooy) * p.Wfull + (long)ox * p.os + p.oox;
-        float* op = p.out + opix * p.cout_pad + cot * 64 + 16 * lg;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(f32x4*)(op + 4 * q) = acc[q];
+    for (int h = 0; h < 2; ++h) {
+        const long m = m0 + wave * 32 + 16 * h + li;
+        if (m < M) {
+            const int ox = (int)(m % p.Wo);
+            const int oy = (int)((m / p.Wo) % p.Ho);
+            const long n = m / ((long)p.Wo * p.Ho);
+            const long opix = (n * p.Hfull + (long)oy * p.os + p.ooy) * p.Wfull + (long)ox * p.os + p.oox;
+            float* op = p.out + opix * p.cout_pad + cot * 64 + 16 * lg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(op + 4 * q) = acc[h][q];
+        }
     }
 }
 
@@ -124,7 +165,8 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up;
     const long M = (long)N * Ho * Wo;
     if (M <= 0) return INNFER_OK;
-    dim3 grid((unsigned)((M + 63) / 64), (unsigned)(cout_pad / 64));
+    if ((long)N * Hin * Win * 64 >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "gather GEMM: input of %d x %d x %d pixels exceeds the 2 GiB buffer window", N, Hin, Win);
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64));
     hipLaunchKernelGGL(gemm_gather, grid, dim3(256), 0, s, g);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;

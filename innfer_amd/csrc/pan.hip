@@ -46,26 +46,46 @@ __device__ __forceinline__ float slab_get(const f16* s, long g, long pix, int ch
     return (float)s[(ch >> 5) * g + pix * 32 + (ch & 31)];
 }
 
+// One thread per (pixel, 4 consecutive channels): 16-byte reads of the fp32 GEMM rows, 8-byte reads /
+// writes of the fp16 slabs.  Every channel count (20, 24, 40) and channel offset (0, 20) on this
+// path is a multiple of 4, and a 4-channel run never straddles a 32-channel group.
 __global__ void pan_post(const PP p) {
-    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= p.npix) return;
+    const int c4 = p.C >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.npix * c4) return;
+    const long pix = i / c4;
+    const int c = (int)(i - pix * c4) * 4;
     const float* r = p.raw + pix * 64;
-    for (int c = 0; c < p.C; ++c) {
-        float y;
-        if (p.mode == MODE_GATE) {
-            const float gate = 1.0f / (1.0f + expf(-(r[c] + p.bias[c])));
-            y = r[p.C + c] * gate;
-        } else if (p.mode == MODE_PA) {
-            const float gate = 1.0f / (1.0f + expf(-(r[c] + p.bias[c])));
-            y = slab_get(p.res, p.res_g, pix, p.res_off + c) * gate;
-        } else {
-            y = r[c] + (p.bias ? p.bias[c] : 0.f);
-        }
-        if (p.act == 1) y = fmaxf(y, 0.2f * y);
-        if (p.mode == MODE_LIN && p.res) y += slab_get(p.res, p.res_g, pix, p.res_off + c);
-        const int ch = p.dst_off + c;
-        p.dst[(ch >> 5) * p.dst_g + pix * 32 + (ch & 31)] = (f16)y;
+    const f32x4 a = *(const f32x4*)(r + c);
+    float y[4];
+    if (p.mode == MODE_GATE) {
+        const f32x4 v = *(const f32x4*)(r + p.C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = v[e] * (1.0f / (1.0f + expf(-(a[e] + p.bias[c + e]))));
+    } else if (p.mode == MODE_PA) {
+        const int ch = p.res_off + c;
+        const f16x4 v = *(const f16x4*)(p.res + (ch >> 5) * p.res_g + pix * 32 + (ch & 31));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (float)v[e] * (1.0f / (1.0f + expf(-(a[e] + p.bias[c + e]))));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = a[e] + (p.bias ? p.bias[c + e] : 0.f);
     }
+    if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.2f * y[e]);
+    }
+    if (p.mode == MODE_LIN && p.res) {
+        const int ch = p.res_off + c;
+        const f16x4 v = *(const f16x4*)(p.res + (ch >> 5) * p.res_g + pix * 32 + (ch & 31));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] += (float)v[e];
+    }
+    const int ch = p.dst_off + c;
+    f16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (f16)y[e];
+    *(f16x4*)(p.dst + (ch >> 5) * p.dst_g + pix * 32 + (ch & 31)) = h;
 }
 
 __global__ void pan_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {
@@ -422,7 +442,9 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     auto post = [&](long npix, int C, const float* bias, int mode, int act, const f16* res, long res_g, int res_off,
                     f16* dst, long dst_g, int dst_off) -> int {
         PP q{raw, C, bias, mode, act, res, res_g, res_off, dst, dst_g, dst_off, npix};
-        hipLaunchKernelGGL(pan_post, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, q);
+        if (C & 3) return set_error(INNFER_ERR_UNSUPPORTED, "pan_post: channel count %d is not a multiple of 4", C);
+        const long nthr = npix * (C >> 2);
+        hipLaunchKernelGGL(pan_post, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, q);
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     };

@@ -30,31 +30,42 @@ using namespace innfer;
 
 namespace {
 
-// per-(image, channel) mean and 1/sqrt(var_biased + eps) of raw[N][HW][cpad]
-__global__ __launch_bounds__(256) void bn_stats(const float* raw, int cpad, long HW, float eps, float* mean, float* rstd, int C) {
-    __shared__ float red[256];
+// per-(image, channel) mean and 1/sqrt(var_biased + eps) of raw[N][HW][cpad]: two passes in fp32 (mean, then
+// the sum of squared deviations), 32 channels x 32 pixel lanes per workgroup, 4 loads in flight per thread
+__global__ __launch_bounds__(1024) void bn_stats(const float* raw, int cpad, long HW, float eps, float* mean, float* rstd, int C) {
+    __shared__ float red[1024];
     const int n = blockIdx.y, cb = blockIdx.x * 32;
-    const int c = cb + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = cb + cl;
     const float* base = raw + (long)n * HW * cpad + c;
-    float s = 0.f;
-    for (long px = pl; px < HW; px += 8) s += base[px * cpad];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    float tot = 0.f;
+    auto reduce32 = [&](float v) {                 // sum over the 32 pixel lanes of one channel, result in every lane
+        red[threadIdx.x] = v;
+        __syncthreads();
+        float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tot += red[(threadIdx.x & 31) + 32 * i];
-    const float mu = tot / (float)HW;
-    __syncthreads();
-    float v = 0.f;
-    for (long px = pl; px < HW; px += 8) { const float d = base[px * cpad] - mu; v += d * d; }
-    red[threadIdx.x] = v;
-    __syncthreads();
+        for (int i = 0; i < 32; ++i) t += red[cl + 32 * i];
+        __syncthreads();
+        return t;
+    };
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long px = pl;
+    for (; px + 96 < HW; px += 128) {
+        s0 += base[px * cpad]; s1 += base[(px + 32) * cpad]; s2 += base[(px + 64) * cpad]; s3 += base[(px + 96) * cpad];
+    }
+    for (; px < HW; px += 32) s0 += base[px * cpad];
+    const float mu = reduce32((s0 + s1) + (s2 + s3)) / (float)HW;
+    s0 = s1 = s2 = s3 = 0.f;
+    px = pl;
+    for (; px + 96 < HW; px += 128) {
+        const float d0 = base[px * cpad] - mu, d1 = base[(px + 32) * cpad] - mu, d2 = base[(px + 64) * cpad] - mu,
+                    d3 = base[(px + 96) * cpad] - mu;
+        s0 += d0 * d0; s1 += d1 * d1; s2 += d2 * d2; s3 += d3 * d3;
+    }
+    for (; px < HW; px += 32) { const float d = base[px * cpad] - mu; s0 += d * d; }
+    const float var = reduce32((s0 + s1) + (s2 + s3)) / (float)HW;
     if (pl == 0 && c < C) {
-        float vt = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vt += red[(threadIdx.x & 31) + 32 * i];
         mean[(long)n * C + c] = mu;
-        rstd[(long)n * C + c] = 1.0f / sqrtf(vt / (float)HW + eps);
+        rstd[(long)n * C + c] = 1.0f / sqrtf(var + eps);
     }
 }
 
@@ -355,7 +366,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
 
     auto post = [&](const Layer& l, long HW, bool bn, PostDst d0, PostDst d1) -> int {
         if (bn) {
-            hipLaunchKernelGGL(bn_stats, dim3((l.cout + 31) / 32, N), dim3(256), 0, s, raw, l.cout_pad, HW, 1e-5f, mean, rstd, l.cout);
+            hipLaunchKernelGGL(bn_stats, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, raw, l.cout_pad, HW, 1e-5f, mean, rstd, l.cout);
             INNFER_HIP(hipGetLastError());
         }
         const long total = (long)N * HW * (l.cout / 8);
