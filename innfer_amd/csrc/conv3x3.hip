@@ -161,7 +161,7 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
 }
 
 template <int RPW, int NT, int OUTMODE>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
+__global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mfma(const KP p) {
     constexpr int TH = 4 * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const KP p) {
         const int r = id / LPR, l = id - r * LPR;
         pfl[i] = (p.pf && !p.up && id < NLINES) ? r * p.Ws * 64 + (l - 1) * 128 : OOB;   // relative to (row ty0-1, col tx0)
     }
-    char* lds_pf = smem + IN_BYTES + W_BYTES + wave * 512;
+    // 3-per-CU shape: no scratch (prefetch must stay off for it)
+    char* lds_pf = smem + IN_BYTES + W_BYTES + ((RPW == 3 && NT == 2) ? 0 : wave * 512);
     f32x4 bias_r[NT];
     int bias_kg = -1;
 
@@ -846,7 +847,7 @@ int conv_variant() {
 template <int RPW, int NT, int OUTMODE>
 int launch_t(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 4 * RPW;
-    constexpr int LDS = ((TH + 2) * LWP / 16) * 1024 + 9 * NT * 16 * 64 + 2048;   // + prefetch scratch
+    constexpr int LDS = ((TH + 2) * LWP / 16) * 1024 + 9 * NT * 16 * 64 + ((RPW == 3 && NT == 2) ? 0 : 2048);   // + prefetch scratch
     static bool attr_done = false;
     if (!attr_done) {
         INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma<RPW, NT, OUTMODE>,
@@ -858,7 +859,7 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
     {
         static const int pf = getenv("INNFER_PREFETCH") ? atoi(getenv("INNFER_PREFETCH")) : 0;   // 1: next chunk, 2: + next tile
-        k.pf = pf;
+        k.pf = (RPW == 3 && NT == 2) ? 0 : pf;
 #ifdef INNFER_ABLATE
         k.abl = getenv("INNFER_ABL") ? atoi(getenv("INNFER_ABL")) : 0;
 #endif
@@ -868,7 +869,7 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     static const int persist = getenv("INNFER_PERSIST") ? atoi(getenv("INNFER_PERSIST")) : 2;   // workgroups per CU, 0 = one per tile
-    const long slots = (long)persist * num_cus();
+    const long slots = (long)((persist == 2 && RPW == 3 && NT == 2) ? 3 : persist) * num_cus();   // = workgroups resident per CU
     const long grid = (persist > 0 && total > slots) ? slots : total;
     hipLaunchKernelGGL((conv3x3_mfma<RPW, NT, OUTMODE>), dim3((unsigned)grid), dim3(256), LDS, s, k);
     INNFER_HIP(hipGetLastError());
@@ -965,7 +966,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     switch (L.out_mode) {
         case OUT_SLAB:
             if (nt == 4) return rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);
-            if (nt == 2) return rpw32 == 5 ? launch_t<5, 2, OUT_SLAB>(k, L.N, s) : launch_t<4, 2, OUT_SLAB>(k, L.N, s);
+            if (nt == 2) return rpw32 == 5 ? launch_t<5, 2, OUT_SLAB>(k, L.N, s) : rpw32 == 3 ? launch_t<3, 2, OUT_SLAB>(k, L.N, s) : launch_t<4, 2, OUT_SLAB>(k, L.N, s);
             return launch_t<4, 1, OUT_SLAB>(k, L.N, s);
         case OUT_NCHW:
             if (nt == 4) return launch_t<2, 4, OUT_NCHW>(k, L.N, s);
