@@ -5,6 +5,7 @@
 #pragma once
 #include "common.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace innfer {
@@ -13,11 +14,14 @@ namespace gg {
 struct GP {
     const f16* in; long in_g; int nchunks; int N, Hin, Win;
     const f16* wpk;                       // [cot][tap][chunk][64 rows][64 B], the LDS image of the A operand
-    float* out; int cout_pad;             // raw fp32 [N*Hfull*Wfull][cout_pad]
+    float* out; int cout_pad;             // raw fp32 [N*Hfull*Wfull][raw_stride]; cout_pad/64 channel tiles are computed
+    int raw_stride;                       // floats per pixel of the raw buffer (<= cout_pad, multiple of 4): channels beyond it are not stored
     int Ho, Wo, stride;                   // this launch's output grid; in = out*stride + d
     int ntaps; int dy[16], dx[16];
     int Hfull, Wfull, os, ooy, oox;       // out pixel = (oy*os + ooy, ox*os + oox)
     int up;                               // input is read through nearest-2x upsampling (Hin, Win = source size)
+    int seg;                              // k-steps per accumulation segment: result = ((seg0 + seg1) + seg2) ...
+    int ksplit; long split_elems;         // ksplit > 1: blockIdx.z computes segment z and writes out + z*split_elems
 };
 
 // 128 pixels x 64 output channels per workgroup (4 waves x (32 px x 64 co) = 8 MFMAs per wave and 32-channel
@@ -57,12 +61,16 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
         cso[h] = (sslot ^ (((srow >> 2) & 1) << 1)) * 16;             // byte offset of the channel slot stored at LDS slot sslot
     }
     const char* wtile = (const char*)p.wpk + (long)cot * p.ntaps * p.nchunks * 4096;
-    const int nsteps = p.ntaps * p.nchunks;
+    const int total_steps = p.ntaps * p.nchunks;
+    // split-K: one accumulation segment per blockIdx.z; otherwise all segments, added up in the same order
+    const int step0 = p.ksplit > 1 ? blockIdx.z * p.seg : 0;
+    const int nsteps = p.ksplit > 1 ? min(p.seg, total_steps - step0) : total_steps;
 
-    auto issue = [&](int step) {
+    auto issue = [&](int rel) {
+        const int step = step0 + rel;
 #if defined(__HIP_DEVICE_COMPILE__)
         const int t = step / p.nchunks, c = step - t * p.nchunks;
-        char* st = lds + (step % GG_STAGES) * GG_STAGE_BYTES;
+        char* st = lds + (rel % GG_STAGES) * GG_STAGE_BYTES;
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)c * p.in_g), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + (long)step * 4096), 0, 4096, 0x00020000);
 #pragma unroll
@@ -76,15 +84,16 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + 8192 + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
 #else
-        (void)step; (void)wtile; (void)spix; (void)cso;
+        (void)step; (void)rel; (void)wtile; (void)spix; (void)cso;
 #endif
     };
 
-    f32x4 acc[2][4];
+    f32x4 acc[2][4], tot[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) { acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[h][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    int seg_left = p.seg;
     int boff[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -110,6 +119,17 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc[0][q], 0, 0, 0);
             acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc[1][q], 0, 0, 0);
         }
+        if (--seg_left == 0 || step + 1 == nsteps) {                  // close the segment: tot += acc (tot starts at 0)
+            seg_left = p.seg;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tot[h][q][j] += acc[h][q][j];
+                    acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
     }
     // D rows = out channels (16*lg + 4*q + j after the panel permutation), cols = pixels
 #pragma unroll
@@ -120,9 +140,11 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             const int oy = (int)((m / p.Wo) % p.Ho);
             const long n = m / ((long)p.Wo * p.Ho);
             const long opix = (n * p.Hfull + (long)oy * p.os + p.ooy) * p.Wfull + (long)ox * p.os + p.oox;
-            float* op = p.out + opix * p.cout_pad + cot * 64 + 16 * lg;
+            const int ch0 = cot * 64 + 16 * lg;
+            float* op = p.out + (long)blockIdx.z * p.split_elems + opix * p.raw_stride + ch0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *(f32x4*)(op + 4 * q) = acc[h][q];
+            for (int q = 0; q < 4; ++q)
+                if (ch0 + 4 * q < p.raw_stride) *(f32x4*)(op + 4 * q) = tot[h][q];
         }
     }
 }
@@ -153,22 +175,66 @@ inline void pack_panels(std::vector<f16>& dst, int cout, int cin, int cin_pad, i
 }
 
 
+// raw[pixel][0:cout_pad] = sum over the ksplit partial results, in split order (deterministic)
+static __global__ void splitk_reduce(const float* part, long split_elems, int ksplit, float* raw, int cout_pad,
+                                     int N, int Ho, int Wo, int Hfull, int Wfull, int os, int ooy, int oox) {
+    const int c4 = cout_pad >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long M = (long)N * Ho * Wo;
+    if (i >= M * c4) return;
+    const long m = i / c4;
+    const int c = (int)(i - m * c4) * 4;
+    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+    const long n = m / ((long)Wo * Ho);
+    const long o = ((n * Hfull + (long)oy * os + ooy) * Wfull + (long)ox * os + oox) * cout_pad + c;
+    f32x4 a = *(const f32x4*)(part + o);
+    for (int z = 1; z < ksplit; ++z) {
+        const f32x4 b = *(const f32x4*)(part + z * split_elems + o);
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    *(f32x4*)(raw + o) = a;
+}
+
 // One launch.  dy/dx: ntaps displacements; stride: input step per output pixel (2 for the 4x4 s2 conv).
+// scratch (optional): when the launch would not fill the chip (deep UNet layers: few pixels, a K loop of up
+// to 256 steps) the K range is split over blockIdx.z into partial results that splitk_reduce adds up.
 inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long in_g, int N, int Hin, int Win,
                   float* raw, int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx,
-                  int Hfull, int Wfull, int os, int ooy, int oox, int up, hipStream_t s) {
+                  int Hfull, int Wfull, int os, int ooy, int oox, int up, hipStream_t s,
+                  float* scratch = nullptr, size_t scratch_bytes = 0, int raw_stride = 0) {
     GP g{};
     g.in = in; g.in_g = in_g; g.nchunks = cin_pad / 32; g.N = N; g.Hin = Hin; g.Win = Win;
     g.wpk = wpk; g.out = raw; g.cout_pad = cout_pad;
+    g.raw_stride = raw_stride > 0 ? raw_stride : cout_pad;
+    if (g.raw_stride > cout_pad || (g.raw_stride & 3)) return set_error(INNFER_ERR_INVALID, "gather GEMM: bad raw stride %d", g.raw_stride);
     g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps;
     for (int t = 0; t < ntaps; ++t) { g.dy[t] = dy[t]; g.dx[t] = dx[t]; }
     g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up;
     const long M = (long)N * Ho * Wo;
     if (M <= 0) return INNFER_OK;
     if ((long)N * Hin * Win * 64 >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "gather GEMM: input of %d x %d x %d pixels exceeds the 2 GiB buffer window", N, Hin, Win);
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64));
+    const long wgs = ((M + 127) / 128) * (cout_pad / 64);
+    const int nsteps = ntaps * g.nchunks;
+    const size_t full = (size_t)N * Hfull * Wfull * g.raw_stride * sizeof(float);
+    // Accumulation is segmented the same way whether or not the K range is split over workgroups, so the
+    // result does not depend on the batch size (a batch must equal the independent batch-1 forwards).
+    const int nseg = nsteps >= 32 ? 8 : 1;
+    g.seg = (nsteps + nseg - 1) / nseg;
+    const int segs = (nsteps + g.seg - 1) / g.seg;
+    int ks = 1;
+    if (scratch && wgs < 1024 && segs > 1 && (size_t)segs * full <= scratch_bytes) ks = segs;
+    g.ksplit = ks;
+    g.split_elems = ks > 1 ? (long)(full / sizeof(float)) : 0;
+    if (ks > 1) g.out = scratch;
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64), (unsigned)ks);
     hipLaunchKernelGGL(gemm_gather, grid, dim3(256), 0, s, g);
     INNFER_HIP(hipGetLastError());
+    if (ks > 1) {
+        const long nthr = M * (g.raw_stride / 4);
+        hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)scratch, g.split_elems, ks,
+                           raw, g.raw_stride, N, Ho, Wo, Hfull, Wfull, os, ooy, oox);
+        INNFER_HIP(hipGetLastError());
+    }
     return INNFER_OK;
 }
 

@@ -297,7 +297,8 @@ static int upload_all(innfer_unet* u) {
 }
 
 namespace {
-struct UCarve { size_t x0, raw, mean, rstd, r_inner, total; std::vector<size_t> D, CAT; };
+struct UCarve { size_t x0, raw, mean, rstd, r_inner, splitk, total; std::vector<size_t> D, CAT; };
+constexpr size_t SPLITK_BYTES = 128u << 20;      // partial results of the split-K deep layers
 
 UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
     UCarve c;
@@ -317,15 +318,16 @@ UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
         c.CAT[k] = off; off += al(px * 2 * u->dc[k] * 2);
     }
     c.r_inner = off; off += al((size_t)N * (H >> L) * (W >> L) * u->dc[L - 1] * 2);
+    c.splitk = off; off += SPLITK_BYTES;
     c.total = off;
     return c;
 }
 
 int run_gemm(const Layer& l, const f16* wpk, const f16* in, long in_g, int N, int Hin, int Win, float* raw,
              int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx, int Hfull, int Wfull,
-             int os, int ooy, int oox, hipStream_t s) {
+             int os, int ooy, int oox, hipStream_t s, float* scratch, int raw_stride = 0) {
     return gg::launch(wpk, l.cin_pad, l.cout_pad, in, in_g, N, Hin, Win, raw, Ho, Wo, stride, ntaps, dy, dx,
-                      Hfull, Wfull, os, ooy, oox, 0, s);
+                      Hfull, Wfull, os, ooy, oox, 0, s, scratch, SPLITK_BYTES, raw_stride);
 }
 }  // namespace
 
@@ -359,6 +361,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)d_ws;
     float* raw = (float*)(ws + cv.raw);
+    float* splitk = (float*)(ws + cv.splitk);
     float* mean = (float*)(ws + cv.mean);
     float* rstd = (float*)(ws + cv.rstd);
     int dy16[16], dx16[16];
@@ -388,7 +391,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     for (int k = 0; k < L; ++k) {
         const Layer& l = u->down[k];
         const int ho = h / 2, wo = w / 2;
-        int rc = run_gemm(l, l.d_w[0], cur, cur_g, N, h, w, raw, ho, wo, 2, 16, dy16, dx16, ho, wo, 1, 0, 0, s);
+        int rc = run_gemm(l, l.d_w[0], cur, cur_g, N, h, w, raw, ho, wo, 2, 16, dy16, dx16, ho, wo, 1, 0, 0, s, splitk);
         if (rc) return rc;
         const long HW = (long)ho * wo, G = (long)N * HW * 32;
         if (k < L - 1) {
@@ -412,7 +415,9 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         for (int ph = 0; ph < 4; ++ph) {
             int ky[4], kx[4], dy[4], dx[4];
             phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
-            int rc = run_gemm(l, l.d_w[ph], in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, ph >> 1, ph & 1, s);
+            // the outermost layer has out_nc (3) channels: its raw rows are 4..8 floats, not a 64-channel tile
+            const int rs = k == 0 ? (l.cout + 3) / 4 * 4 : 0;
+            int rc = run_gemm(l, l.d_w[ph], in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, ph >> 1, ph & 1, s, splitk, rs);
             if (rc) return rc;
         }
         const long HW = (long)hf * wf;
@@ -422,7 +427,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             int rc = post(l, HW, true, dr, PostDst{nullptr, 0, 0, 0});
             if (rc) return rc;
         } else {
-            hipLaunchKernelGGL(unet_final, dim3((unsigned)((N * HW + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
+            hipLaunchKernelGGL(unet_final, dim3((unsigned)((N * HW + 255) / 256)), dim3(256), 0, s, raw, (l.cout + 3) / 4 * 4, l.cout, HW, N,
                                l.d_bias, d_out, out_dtype == INNFER_F32);
             INNFER_HIP(hipGetLastError());
         }
