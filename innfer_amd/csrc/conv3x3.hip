@@ -66,7 +66,7 @@ namespace {
 #define ABL_AND(x)
 #endif
 constexpr int TW = 32;        // tile width (pixels)
-constexpr int LWP = 40;       // LDS row pitch (pixels), multiple of 8
+constexpr int LWP = 36;       // LDS row pitch (pixels): 36 px = 2304 B = 9 x 256 B, so every row starts on bank 0
 constexpr int LVALID = TW + 2;
 
 struct KP {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
     constexpr int TH = 4 * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
-    constexpr int NQ = NPX / 16;                 // input DMA wave-instructions per chunk
+    constexpr int NQ = (NPX + 15) / 16;          // input DMA wave-instructions per chunk (the last one may be partly unused)
     constexpr int KQ = (NQ + 3) / 4;
     constexpr int IN_BYTES = NQ * 1024;
     constexpr int WROWS = NT * 16;
@@ -173,7 +173,6 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
     constexpr int WQ = W_BYTES / 1024;           // 9*NT
     constexpr int KW = (WQ + 3) / 4;
     constexpr int MT = RPW * 2;
-    static_assert(NPX % 16 == 0, "tile must be a whole number of DMA pieces");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_in = smem;
@@ -216,15 +215,21 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
             const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
             const int ry = p.up ? (ly + ypar) >> 1 : ly;        // source row / column relative to the base pixel
             const int rx = p.up ? (lx + 1) >> 1 : lx;
-            loff[k] = (q < NQ && lx < LVALID) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
+            loff[k] = (px < NPX && lx < LVALID) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
         }
     }
-    const char* bbase[3];
+    // LDS read bases.  The 16-B-slot swizzle is slot ^= 2*bit2(pixel index in LDS); with a 36-px pitch
+    // bit2(row*36 + x) = bit2(x) ^ (row & 1), so there is one base per tap column s and row parity;
+    // all ds_read_b128 stay base + immediate and bank-conflict free.
+    const char* bbase[3][2];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int pb = wave * RPW * LWP + li + s;
-        bbase[s] = lds_in + pb * 64 + ((lg ^ ((((li + s) >> 2) & 1) << 1)) << 4);
-    }
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {                   // par: parity of rr (row inside the wave's strip)
+            const int pb = wave * RPW * LWP + li + s;
+            const int rowpar = ((wave * RPW) & 1) ^ par;
+            bbase[s][par] = lds_in + pb * 64 + ((lg ^ (((((li + s) >> 2) & 1) ^ rowpar) << 1)) << 4);
+        }
     const char* abase = lds_w + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
     const int wvoff = lane * 16;
     // L2 prefetch plan (p.pf): LDS-DMA streams several times faster from L2 than from HBM and a
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
             for (int rr = 0; rr < RPW + 2; ++rr) {
 #pragma unroll
                 for (int seg = 0; seg < 2; ++seg) {
-                    const f16x8 b = *(const f16x8*)(bbase[s] + (rr * LWP + seg * 16) * 64);
+                    const f16x8 b = *(const f16x8*)(bbase[s][rr & 1] + (rr * LWP + seg * 16) * 64);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         const int rw = rr - r;
@@ -847,7 +852,7 @@ int conv_variant() {
 template <int RPW, int NT, int OUTMODE>
 int launch_t(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 4 * RPW;
-    constexpr int LDS = ((TH + 2) * LWP / 16) * 1024 + 9 * NT * 16 * 64 + ((RPW == 3 && NT == 2) ? 0 : 2048);   // + prefetch scratch
+    constexpr int LDS = (((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64 + ((RPW == 3 && NT == 2) ? 0 : 2048);   // + prefetch scratch
     static bool attr_done = false;
     if (!attr_done) {
         INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma<RPW, NT, OUTMODE>,
@@ -965,8 +970,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
     switch (L.out_mode) {
         case OUT_SLAB:
-            if (nt == 4) return rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);
-            if (nt == 2) return rpw32 == 5 ? launch_t<5, 2, OUT_SLAB>(k, L.N, s) : rpw32 == 3 ? launch_t<3, 2, OUT_SLAB>(k, L.N, s) : launch_t<4, 2, OUT_SLAB>(k, L.N, s);
+            if (nt == 4) return rpw64 == 4 ? launch_t<4, 4, OUT_SLAB>(k, L.N, s) : rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);
+            if (nt == 2) return rpw32 == 6 ? launch_t<6, 2, OUT_SLAB>(k, L.N, s) : rpw32 == 5 ? launch_t<5, 2, OUT_SLAB>(k, L.N, s) : rpw32 == 3 ? launch_t<3, 2, OUT_SLAB>(k, L.N, s) : launch_t<4, 2, OUT_SLAB>(k, L.N, s);
             return launch_t<4, 1, OUT_SLAB>(k, L.N, s);
         case OUT_NCHW:
             if (nt == 4) return launch_t<2, 4, OUT_NCHW>(k, L.N, s);
