@@ -82,7 +82,6 @@ struct KP {
     int tiles_x, tiles_y;
     int out_f32;
     int N;
-    unsigned tx_magic;       // ceil(2^32 / tiles_x): tile / tiles_x == (tile * tx_magic) >> 32
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
     int total;               // tiles x channel groups of this launch
@@ -490,8 +489,6 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 }
 
 
-struct TileCoord { int n, ty0, tx0, kg; };
-
 int num_cus() {
     static int n = 0;
     if (!n) {
@@ -503,351 +500,6 @@ int num_cus() {
     return n;
 }
 
-// ---------------------------------------------------------------------------------------
-// v3 (INNFER_CONV_VARIANT=3): persistent single-stage kernel, 2 workgroups of 4 waves per CU.
-// What the in-kernel stamps of v1 showed (profiles/r1/v1_wg_timeline.txt): a workgroup spent
-// 15 % of its life in the prologue, 29 % in the epilogue, 21 % issuing LDS-DMA pieces
-// (~150 cycles per 1-KiB piece, a third to a half of them weights) and only 22 % in MFMAs.
-//   * persistent: grid = 2 x #CUs, every workgroup walks tiles of its XCD's contiguous range;
-//     kernel-argument load, decode divisions and LDS-address setup happen once, not per tile;
-//   * the next tile's first chunk is issued BEFORE the current tile's epilogue, so its DMA
-//     flight (and the partner workgroup's MFMAs) cover the store tail;
-//   * tile = 16 rows x 32 px for every NT: the 64-output convs re-stage their 36 KiB weight
-//     panel half as often as with 8-row tiles;
-//   * LDS rows are the 34 valid pixels, not padded to 40 (-13 % DMA pieces).  Row bases are
-//     then only multiples of 2 px, so the swizzle bit (bit 2 of the LDS pixel index) depends
-//     on e = (2*row + s) mod 8: eight per-lane base registers + immediates instead of three;
-//   * bias is added in the epilogue (no global-load wait in front of the first MFMA).
-// ---------------------------------------------------------------------------------------
-template <int NT, int OUTMODE>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_t(const KP p) {
-    constexpr int RPW = 4, NW = 4;
-    constexpr int TH = NW * RPW;                 // 16
-    constexpr int LH = TH + 2, LW = LVALID;      // 18 x 34
-    constexpr int NPX = LH * LW;                 // 612
-    constexpr int NQ = (NPX + 15) / 16;          // 39 input pieces
-    constexpr int KQ = (NQ + NW - 1) / NW;       // 10
-    constexpr int IN_BYTES = NQ * 1024;
-    constexpr int WROWS = NT * 16;
-    constexpr int W_BYTES = 9 * WROWS * 64;
-    constexpr int WQ = W_BYTES / 1024;
-    constexpr int KW = (WQ + NW - 1) / NW;
-    constexpr int MT = RPW * 2;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_in = smem;
-    char* lds_w = smem + IN_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-
-    const int tiles_per_img = p.tiles_x * p.tiles_y;
-    const int items = p.N * tiles_per_img * p.KG;
-    int item, item_end, item_stride;
-    {
-        const int G = gridDim.x, b = blockIdx.x;
-        const int x = b & 7, slot = b >> 3;
-        const int q = items >> 3, r = items & 7;
-        const int lo = x * q + (x < r ? x : r);
-        const int cnt = q + (x < r ? 1 : 0);
-        item_stride = (G - x + 7) >> 3;
-        item = lo + slot;
-        item_end = lo + cnt;
-    }
-    if (item >= item_end) return;
-
-    auto decode = [&](int it) {
-        TileCoord t;
-        int tile = it;
-        t.kg = 0;
-        if (p.KG > 1) { t.kg = it % p.KG; tile = it / p.KG; }
-        t.n = 0;
-        if (p.N > 1) { t.n = tile / tiles_per_img; tile -= t.n * tiles_per_img; }
-        const int ty = p.tiles_x == 1 ? tile
-                                      : (int)(((unsigned long long)(unsigned)tile * (unsigned)p.tx_magic) >> 32);
-        const int tx = tile - ty * p.tiles_x;
-        t.ty0 = p.y0 + ty * TH;
-        t.tx0 = tx * TW;
-        return t;
-    };
-
-    // ---- per-lane constants, computed ONCE per workgroup ---------------------------
-    // Tiles of one launch differ by a translation (ty0 = y0 + 16*ty, tx0 = 32*tx), so the source
-    // offset of every DMA lane relative to the tile's halo origin is tile independent -- also under
-    // nearest-2x upsampling, because the parity of (ty0-1, tx0-1) is the same for all tiles.
-    const int par_y = p.up ? ((p.y0 - 1) & 1) : 0;
-    const int par_x = p.up ? 1 : 0;                        // tx0 - 1 is odd
-    int loff[KQ];                                          // byte offset from the halo origin, -1 = never valid
-#pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-        const int q = wave + NW * k;
-        const int px = q * 16 + (lane >> 2);
-        const int ly = px / LW, lx = px - ly * LW;
-        const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
-        const int ry = p.up ? (par_y + ly) >> 1 : ly;
-        const int rx = p.up ? (par_x + lx) >> 1 : lx;
-        loff[k] = (q < NQ && px < NPX) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : -1;
-    }
-    const int woff = lane * 16;
-
-    int bo[8];                                             // LDS read offsets, one per e = (2*rr + s) & 7
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-        bo[e] = (wave * RPW * LW + li) * 64 + ((lg ^ ((((e + li) >> 2) & 1) << 1)) << 4);
-    const int ao = IN_BYTES + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
-
-    // ---- per-tile state ---------------------------------------------------------------
-    const char* t_base = nullptr;                          // address of the halo origin, chunk 0
-    const char* w_base = nullptr;
-    unsigned vmask = 0;                                    // bit k: this lane's piece k reads real data
-    auto setup = [&](const TileCoord& t) {
-        const int oy = (t.ty0 - 1) >> p.up, ox = (t.tx0 - 1) >> p.up;       // arithmetic shift = floor
-        t_base = (const char*)p.in + ((long)t.n * p.in_img_stride + ((long)oy * p.Ws + ox) * 32) * 2;
-        w_base = (const char*)p.wpk + (long)t.kg * p.nchunks * W_BYTES + woff;
-        const bool interior = t.ty0 >= 1 && t.ty0 + TH < p.H && t.tx0 >= 1 && t.tx0 + TW < p.W;
-        vmask = 0;
-        if (interior) {
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) vmask |= (loff[k] >= 0 ? 1u : 0u) << k;
-        } else {
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) {
-                const int px = (wave + NW * k) * 16 + (lane >> 2);
-                const int ly = px / LW, lx = px - ly * LW;
-                const int Y = t.ty0 - 1 + ly, X = t.tx0 - 1 + lx;
-                const bool ok = loff[k] >= 0 && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
-                vmask |= (ok ? 1u : 0u) << k;
-            }
-        }
-    };
-    auto issue = [&](int c) {
-        const char* cb = t_base + c * p.in_gbytes;
-#pragma unroll
-        for (int k = 0; k < KQ; ++k) {
-            const int q = wave + NW * k;
-            if (q < NQ) {
-                const char* src = (vmask >> k) & 1 ? cb + loff[k] : (const char*)g_zero_page;
-                dma16(src, lds_in + q * 1024);
-            }
-        }
-        const char* wb = w_base + (long)c * W_BYTES;
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            const int j = wave + NW * k;
-            if (j < WQ) dma16(wb + j * 1024, lds_w + j * 1024);
-        }
-    };
-
-    TileCoord cur = decode(item);
-    setup(cur);
-    issue(0);
-
-    // NT <= 2: the bias of this lane's channels lives in registers (accumulators start from it) and
-    // is reloaded only when the channel group changes; NT == 4 is register-bound (128 accumulators +
-    // 48 weight-fragment registers) and adds the bias in the epilogue instead.
-    constexpr bool BIAS_REGS = NT <= 2;
-    constexpr int NB = BIAS_REGS ? NT : 1;
-    int bias_kg = cur.kg;
-    f32x4 bias[NB];
-    if constexpr (BIAS_REGS) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bias[t] = *(const f32x4*)(p.bias + cur.kg * WROWS + 4 * NT * lg + 4 * t);
-    }
-
-    while (true) {
-        if constexpr (BIAS_REGS) {
-            if (p.KG > 1 && cur.kg != bias_kg) {
-                bias_kg = cur.kg;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bias[t] = *(const f32x4*)(p.bias + cur.kg * WROWS + 4 * NT * lg + 4 * t);
-            }
-        }
-        f32x4 acc[NT][MT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if constexpr (BIAS_REGS) acc[t][m] = bias[t];
-                else acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-
-        const int next_item = item + item_stride;
-        const bool has_next = next_item < item_end;
-        TileCoord nxt = cur;
-
-        for (int c = 0; c < p.nchunks; ++c) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                f16x8 a[3][NT];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        a[r][t] = *(const f16x8*)(smem + ao + ((r * 3 + s) * WROWS + t * 16) * 64);
-#pragma unroll
-                for (int rr = 0; rr < RPW + 2; ++rr) {
-#pragma unroll
-                    for (int seg = 0; seg < 2; ++seg) {
-                        const f16x8 b = *(const f16x8*)(smem + bo[(2 * rr + s) & 7] + (rr * LW + seg * 16 + s) * 64);
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            const int rw = rr - r;
-                            if (rw >= 0 && rw < RPW) {
-#pragma unroll
-                                for (int t = 0; t < NT; ++t)
-                                    acc[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                        a[r][t], b, acc[t][rw * 2 + seg], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // LDS is free again: stage the next chunk -- or the NEXT TILE's first chunk, whose
-            // flight then overlaps this tile's epilogue.
-            if (c + 1 < p.nchunks) {
-                issue(c + 1);
-            } else if (has_next) {
-                nxt = decode(next_item);
-                setup(nxt);
-                issue(0);
-            }
-        }
-
-        // ---- epilogue of tile `cur`: act -> residuals -> store ------------------------
-        {
-            const int cbase = cur.kg * WROWS + 4 * NT * lg;
-            const int y_w = cur.ty0 + wave * RPW;                      // first row of this wave
-            const long pix0 = ((long)cur.n * p.H + y_w) * p.W + cur.tx0 + li;
-            const bool full = (y_w + RPW <= p.y1) && (cur.tx0 + TW <= p.W);
-            f32x4 lbias[NT];
-            if constexpr (!BIAS_REGS) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) lbias[t] = *(const f32x4*)(p.bias + cbase + 4 * t);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if (!full) {
-                    if (y_w + (m >> 1) >= p.y1 || cur.tx0 + (m & 1) * 16 + li >= p.W) continue;
-                }
-                const long pix = pix0 + (long)(m >> 1) * p.W + (m & 1) * 16;
-                float v[NT][4];
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float f = acc[t][m][j];
-                        if constexpr (!BIAS_REGS) f += lbias[t][j];
-                        v[t][j] = p.act == 1 ? fmaxf(f, 0.2f * f) : (p.act == 2 ? fmaxf(f, 0.f) : f);
-                    }
-                if (p.res1) {
-                    const f16* rp = p.res1 + (cbase >> 5) * p.res1_gstride + pix * 32 + (cbase & 31);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[t][j] = __builtin_fmaf(v[t][j], p.s1, (float)r4[j]);
-                    }
-                }
-                if (p.res2) {
-                    const f16* rp = p.res2 + (cbase >> 5) * p.res2_gstride + pix * 32 + (cbase & 31);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const f16x4 r4 = *(const f16x4*)(rp + 4 * t);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[t][j] = __builtin_fmaf(v[t][j], p.s2, (float)r4[j]);
-                    }
-                }
-                if constexpr (OUTMODE == OUT_SLAB) {
-                    const int oc0 = cbase + p.out_coff;
-                    f16* op = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix * 32 + (oc0 & 31);
-                    f16 h[4 * NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) h[4 * t + j] = (f16)v[t][j];
-                    if constexpr (NT == 1) {
-                        *(f16x4*)op = *(const f16x4*)h;
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < NT / 2; ++u) *(f16x8*)(op + 8 * u) = *(const f16x8*)(h + 8 * u);
-                    }
-                } else if constexpr (OUTMODE == OUT_NCHW) {
-                    const int y = y_w + (m >> 1), x = cur.tx0 + (m & 1) * 16 + li;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int ch = cbase + 4 * t + j;
-                            if (ch < p.K) {
-                                const long o = (((long)cur.n * p.K + ch) * p.H + y) * p.W + x;
-                                if (p.out_f32) ((float*)p.out)[o] = v[t][j];
-                                else ((f16*)p.out)[o] = (f16)v[t][j];
-                            }
-                        }
-                } else {
-                    const int y = y_w + (m >> 1), x = cur.tx0 + (m & 1) * 16 + li;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const long opix = ((long)cur.n * 2 * p.H + 2 * y + (j >> 1)) * (2 * p.W) + 2 * x + (j & 1);
-                        const int oc0 = cbase / 4;
-                        f16* op = (f16*)p.out + (oc0 >> 5) * p.out_gstride + opix * 32 + (oc0 & 31);
-                        if constexpr (NT == 4) {
-                            f16x4 h;
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) h[t] = (f16)v[t][j];
-                            *(f16x4*)op = h;
-                        } else {
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) op[t] = (f16)v[t][j];
-                        }
-                    }
-                }
-            }
-        }
-        if (!has_next) break;
-        cur = nxt;
-        item = next_item;
-    }
-}
-
-template <int NT, int OUTMODE>
-int launch_v3(const KP& kp, int N, hipStream_t s) {
-    constexpr int LDS = ((18 * LVALID + 15) / 16) * 1024 + 9 * NT * 16 * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
-        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_t<NT, OUTMODE>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
-    KP k = kp;
-    k.N = N;
-    k.tiles_x = (k.W + TW - 1) / TW;
-    k.tiles_y = (k.y1 - k.y0 + 15) / 16;
-    k.tx_magic = k.tiles_x > 1 ? (unsigned)(0x100000000ULL / (unsigned)k.tiles_x + 1) : 0;   // exact for tile < 2^24
-    const long items = (long)N * k.tiles_x * k.tiles_y * k.KG;
-    if (items <= 0) return INNFER_OK;
-    if (items > 0x7fffffffL || (long)k.tiles_x * k.tiles_y >= (1L << 24))
-        return set_error(INNFER_ERR_INVALID, "conv grid too large");
-    const int slots = 2 * num_cus();
-    const int grid = (int)(items < slots ? items : slots);
-    hipLaunchKernelGGL((conv3x3_mfma_t<NT, OUTMODE>), dim3(grid), dim3(256), LDS, s, k);
-    INNFER_HIP(hipGetLastError());
-    return INNFER_OK;
-}
-
-int conv_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("INNFER_CONV_VARIANT");
-        v = e ? atoi(e) : 1;
-    }
-    return v;
-}
 
 template <int RPW, int NT, int OUTMODE>
 int launch_t(const KP& kp, int N, hipStream_t s) {
@@ -950,22 +602,6 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
-    if (conv_variant() == 3) {
-        switch (L.out_mode) {
-            case OUT_SLAB:
-                if (nt == 4) return launch_v3<4, OUT_SLAB>(k, L.N, s);
-                if (nt == 2) return launch_v3<2, OUT_SLAB>(k, L.N, s);
-                return launch_v3<1, OUT_SLAB>(k, L.N, s);
-            case OUT_NCHW:
-                if (nt == 4) return launch_v3<4, OUT_NCHW>(k, L.N, s);
-                if (nt == 2) return launch_v3<2, OUT_NCHW>(k, L.N, s);
-                return launch_v3<1, OUT_NCHW>(k, L.N, s);
-            case OUT_SHUFFLE2:
-                if (nt == 4) return launch_v3<4, OUT_SHUFFLE2>(k, L.N, s);
-                return set_error(INNFER_ERR_UNSUPPORTED, "pixelshuffle conv needs K %% 64 == 0");
-        }
-        return set_error(INNFER_ERR_INVALID, "conv3x3: bad out_mode");
-    }
     static const int rpw64 = getenv("INNFER_RPW64") ? atoi(getenv("INNFER_RPW64")) : 3;
     static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
     switch (L.out_mode) {
