@@ -296,6 +296,10 @@ def g12():
         rows[f"{kind}|{scale}|{json.dumps(extra, sort_keys=True)}"] = get_network_G_config(d, scale)
     for kind in ("p2p_256", "unet_256", "unet_128", "p2p_128", "unet_512"):
         rows[f"str:{kind}|1"] = get_network_G_config(kind, 1)
+    for kind, scale in (("pan", 4), ("pan_net", 2), ("pan", 1)):
+        rows[f"str:{kind}|{scale}"] = get_network_G_config(kind, scale)
+    rows["pan|4|" + json.dumps({"nb": 3, "in_nc": 1, "out_nc": 1}, sort_keys=True)] = get_network_G_config(
+        dict(type="pan", nb=3, in_nc=1, out_nc=1), 4)
     rows["str:esrgan|4"] = get_network_G_config("esrgan", 4)
     rows["which_model_G:srgan|4"] = get_network_G_config({"which_model_G": "srgan"}, 4)
     save("g12_defaults", table=np.array(json.dumps(rows, sort_keys=True)))
