@@ -489,6 +489,212 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Producer / consumer form of the same convolution (slab output).  One workgroup of 12 waves per CU:
+// waves 0..7 (two per SIMD) only read LDS, issue MFMAs and run the epilogue; waves 8..11 only issue
+// LDS-DMA.  LDS holds TWO stages of (halo tile + weight panel); while the consumers work on chunk g the
+// loaders stage chunk g+1 (of this tile or of the workgroup's next tile), then every wave meets at one
+// raw barrier per chunk.  Compared with two independent single-buffered workgroups per CU (the kernel
+// above) the weight panel is staged once per CU instead of twice, the tile is 8*RPW rows tall, the
+// consumers never stall on DMA issue and the staging of a chunk overlaps a full compute phase.
+template <int RPW, int NT>
+__global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
+    constexpr int NCW = 8;                       // consumer waves
+    constexpr int TH = NCW * RPW;
+    constexpr int LH = TH + 2;
+    constexpr int NPX = LH * LWP;
+    constexpr int NQ = (NPX + 15) / 16;
+    constexpr int KQ = (NQ + 3) / 4;
+    constexpr int IN_BYTES = NQ * 1024;
+    constexpr int WROWS = NT * 16;
+    constexpr int W_BYTES = 9 * WROWS * 64;
+    constexpr int WQ = W_BYTES / 1024;
+    constexpr int KW = (WQ + 3) / 4;
+    constexpr int MT = RPW * 2;
+    constexpr int STAGE = IN_BYTES + W_BYTES;
+    constexpr int OOB = (int)0x80000000;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int run_q = p.total >> 3, run_r = p.total & 7;
+    const int run_start = xcd < run_r ? xcd * (run_q + 1) : run_r * (run_q + 1) + (xcd - run_r) * run_q;
+    const int run_len = run_q + (xcd < run_r ? 1 : 0);
+    const int slots = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int j0 = bid >> 3;
+    if (j0 >= run_len) return;                                   // whole workgroup: no tiles
+    const int ntiles = (run_len - j0 + slots - 1) / slots;
+    const int G = ntiles * p.nchunks;                            // chunks this workgroup goes through
+
+    auto decode = [&](int jj, int& kg_, int& n_, int& ty0_, int& tx0_) {
+        const int lid = run_start + (p.rev ? run_len - 1 - jj : jj);
+        kg_ = lid % p.KG;
+        int tile = lid / p.KG;
+        n_ = tile / per_img;
+        tile -= n_ * per_img;
+        const int ty = tile / p.tiles_x;
+        ty0_ = p.y0 + ty * TH;
+        tx0_ = (tile - ty * p.tiles_x) * TW;
+    };
+
+    if (wave >= NCW) {
+        // ================================ loaders ================================
+        const int lw = wave - NCW;
+        int loff[KQ];
+        {
+            const int ypar = p.up ? ((p.y0 - 1) & 1) : 0;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) {
+                const int px = (lw + 4 * k) * 16 + (lane >> 2);
+                const int ly = px / LWP, lx = px - ly * LWP;
+                const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
+                const int ry = p.up ? (ly + ypar) >> 1 : ly;
+                const int rx = p.up ? (lx + 1) >> 1 : lx;
+                loff[k] = (px < NPX && lx < LVALID) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
+            }
+        }
+        const int wvoff = lane * 16;
+        int voff[KQ];
+        const char* in_tile = nullptr;
+        const char* w_tile = nullptr;
+        auto setup = [&](int jj) {
+            int kg, n, ty0, tx0;
+            decode(jj, kg, n, ty0, tx0);
+            in_tile = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)((ty0 - 1) >> p.up) * p.Ws + ((tx0 >> p.up) - 1)) * 64;
+            w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
+            if (ty0 == 0 || ty0 + TH + 1 > p.H || tx0 == 0 || tx0 + TW + 1 > p.W) {
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) {
+                    const int px = (lw + 4 * k) * 16 + (lane >> 2);
+                    const int ly = px / LWP, lx = px - ly * LWP;
+                    const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
+                    if (Y < 0 || Y >= p.H || X < 0 || X >= p.W) voff[k] = OOB;
+                }
+            }
+        };
+        auto issue = [&](int c, int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            char* st = smem + stage * STAGE;
+            const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)(in_tile + c * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(w_tile + (long)c * W_BYTES), 0, W_BYTES, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) {
+                const int q = lw + 4 * k;
+                if (q < NQ)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void*)(st + q * 1024), 16, voff[k], 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int jq = lw + 4 * k;
+                if (jq < WQ)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + IN_BYTES + jq * 1024), 16, wvoff, jq * 1024, 0, 0);
+            }
+#else
+            (void)c; (void)stage; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile;
+#endif
+        };
+        int jt = j0, c = 0;
+        setup(jt);
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) {
+                if (++c == p.nchunks) { c = 0; jt += slots; setup(jt); }
+                issue(c, (g + 1) & 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_barrier" ::: "memory");
+        }
+        return;
+    }
+
+    // ================================ consumers ================================
+    const int cw = wave;
+    int boffs[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int pb = cw * RPW * LWP + li + s;
+            const int rowpar = ((cw * RPW) & 1) ^ par;
+            boffs[s][par] = pb * 64 + ((lg ^ (((((li + s) >> 2) & 1) ^ rowpar) << 1)) << 4);
+        }
+    const int aoffs = IN_BYTES + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    f32x4 bias_r[NT];
+    int bias_kg = -1;
+    f32x4 acc[NT][MT];
+    int jt = j0, c = 0;
+    int kg = 0, n = 0, ty0 = 0, tx0 = 0, cbase = 0;
+    asm volatile("s_barrier" ::: "memory");                       // chunk 0 of the first tile has landed
+    for (int g = 0; g < G; ++g) {
+        if (c == 0) {
+            decode(jt, kg, n, ty0, tx0);
+            cbase = kg * WROWS + 4 * NT * lg;
+            if (kg != bias_kg) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bias_r[t] = *(const f32x4*)(p.bias + cbase + 4 * t);
+                bias_kg = kg;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[t][m] = bias_r[t];
+        }
+        const char* st = smem + (g & 1) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            f16x8 a[3][NT];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    a[r][t] = *(const f16x8*)(st + aoffs + ((r * 3 + s) * WROWS + t * 16) * 64);
+#pragma unroll
+            for (int rr = 0; rr < RPW + 2; ++rr) {
+#pragma unroll
+                for (int seg = 0; seg < 2; ++seg) {
+                    const f16x8 b = *(const f16x8*)(st + boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int rw = rr - r;
+                        if (rw >= 0 && rw < RPW) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                acc[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                    a[r][t], b, acc[t][rw * 2 + seg], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (++c == p.nchunks) {
+            c = 0;
+            jt += slots;
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C)>(p, acc, n, ty0, tx0, cw, li, cbase)
+            if (!p.res1) {
+                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
+            } else if (!p.res2) {
+                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
+            } else {
+                if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
+            }
+#undef EPI
+        }
+        asm volatile("s_barrier" ::: "memory");
+    }
+}
+
+template <int RPW, int NT>
+int launch_pc(const KP& kp, int N, hipStream_t s);
+
 int num_cus() {
     static int n = 0;
     if (!n) {
@@ -529,6 +735,29 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     const long slots = (long)((persist == 2 && RPW == 3 && NT == 2) ? 3 : persist) * num_cus();   // = workgroups resident per CU
     const long grid = (persist > 0 && total > slots) ? slots : total;
     hipLaunchKernelGGL((conv3x3_mfma<RPW, NT, OUTMODE>), dim3((unsigned)grid), dim3(256), LDS, s, k);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+template <int RPW, int NT>
+int launch_pc(const KP& kp, int N, hipStream_t s) {
+    constexpr int TH = 8 * RPW;
+    constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64);
+    static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_pc<RPW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    KP k = kp;
+    k.tiles_x = (k.W + TW - 1) / TW;
+    k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
+    const long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
+    if (total <= 0) return INNFER_OK;
+    if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
+    k.total = (int)total;
+    const long grid = total < num_cus() ? total : num_cus();
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT>), dim3((unsigned)grid), dim3(768), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -604,6 +833,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
     static const int rpw64 = getenv("INNFER_RPW64") ? atoi(getenv("INNFER_RPW64")) : 3;
     static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
+    static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 0;     // producer / consumer kernel for slab outputs
+    if (pc && L.out_mode == OUT_SLAB && nt == 2) return launch_pc<3, 2>(k, L.N, s);
+    if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4>(k, L.N, s);
     switch (L.out_mode) {
         case OUT_SLAB:
             if (nt == 4) return rpw64 == 4 ? launch_t<4, 4, OUT_SLAB>(k, L.N, s) : rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);
