@@ -36,13 +36,20 @@ PEAK_F16_TFLOPS = 2516.6      # MI355X dense fp16/bf16 MFMA: 256 CU x 4096 FLOP/
 KIND_NAMES = {0: "first_conv_kernel"}
 # rows per wave of the instantiation conv_launch picks for NT 16-channel tiles (csrc/conv3x3.hip), slab / NCHW output
 RPW_OF_NT = {1: 4, 2: int(os.environ.get("INNFER_RPW32", "5")), 4: int(os.environ.get("INNFER_RPW64", "3"))}
+PC = int(os.environ.get("INNFER_PC", "1"))      # slab-output convs run the producer / consumer kernel
+PC_SHAPE = {2: (3, 2, 8 if PC == 2 else 4), 4: (2, 4, 4)}
+
+
+def kernel_key(k):
+    """rocprof-style name of the instantiation conv_launch picks for launch kind k = 16*NT + out_mode."""
+    nt, mode = k // 16, k % 16
+    if PC and mode == 0 and nt in PC_SHAPE:
+        return "conv3x3_pc<%d,%d,%d>" % PC_SHAPE[nt]
+    return f"conv3x3_mfma<{RPW_OF_NT[nt]},{nt},{mode}>"
 
 
 def kind_name(k):
-    if k == 0:
-        return "first_conv_kernel"
-    nt, mode = k // 16, k % 16
-    return f"conv3x3_mfma<RPW={RPW_OF_NT[nt]},NT={nt},OUT={mode}>"
+    return "first_conv_kernel" if k == 0 else kernel_key(k)
 
 
 def build_net(dev, nb=23, scale=4):
@@ -80,8 +87,7 @@ def pmc_traffic(kind):
     (profiles/traffic.json, written by scripts/profile.sh + summarize_prof.py), or None."""
     try:
         t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        nt, mode = kind // 16, kind % 16
-        return t[f"conv3x3_mfma<{RPW_OF_NT[nt]},{nt},{mode}>"]["hbm_bytes_per_launch"]
+        return t[kernel_key(kind)]["hbm_bytes_per_launch"]
     except Exception:
         return None
 

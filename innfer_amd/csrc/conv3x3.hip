@@ -497,19 +497,26 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 // raw barrier per chunk.  Compared with two independent single-buffered workgroups per CU (the kernel
 // above) the weight panel is staged once per CU instead of twice, the tile is 8*RPW rows tall, the
 // consumers never stall on DMA issue and the staging of a chunk overlaps a full compute phase.
-template <int RPW, int NT>
-__global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
-    constexpr int NCW = 8;                       // consumer waves
+#ifdef INNFER_STAMPS
+#define PCT(var) const unsigned long long var = clock64()
+#define PCACC(slot, t1, t0) do { if (lane == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * NSTAMP + (slot)] += (t1) - (t0); } while (0)
+#else
+#define PCT(var) do { } while (0)
+#define PCACC(slot, t1, t0) do { } while (0)
+#endif
+template <int RPW, int NT, int NLW>
+__global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
+    constexpr int NCW = 8;                       // consumer waves; NLW loader waves
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
     constexpr int NQ = (NPX + 15) / 16;
-    constexpr int KQ = (NQ + 3) / 4;
+    constexpr int KQ = (NQ + NLW - 1) / NLW;
     constexpr int IN_BYTES = NQ * 1024;
     constexpr int WROWS = NT * 16;
     constexpr int W_BYTES = 9 * WROWS * 64;
     constexpr int WQ = W_BYTES / 1024;
-    constexpr int KW = (WQ + 3) / 4;
+    constexpr int KW = (WQ + NLW - 1) / NLW;
     constexpr int MT = RPW * 2;
     constexpr int STAGE = IN_BYTES + W_BYTES;
     constexpr int OOB = (int)0x80000000;
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
             const int ypar = p.up ? ((p.y0 - 1) & 1) : 0;
 #pragma unroll
             for (int k = 0; k < KQ; ++k) {
-                const int px = (lw + 4 * k) * 16 + (lane >> 2);
+                const int px = (lw + NLW * k) * 16 + (lane >> 2);
                 const int ly = px / LWP, lx = px - ly * LWP;
                 const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
                 const int ry = p.up ? (ly + ypar) >> 1 : ly;
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
             if (ty0 == 0 || ty0 + TH + 1 > p.H || tx0 == 0 || tx0 + TW + 1 > p.W) {
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
-                    const int px = (lw + 4 * k) * 16 + (lane >> 2);
+                    const int px = (lw + NLW * k) * 16 + (lane >> 2);
                     const int ly = px / LWP, lx = px - ly * LWP;
                     const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
                     if (Y < 0 || Y >= p.H || X < 0 || X >= p.W) voff[k] = OOB;
@@ -586,13 +593,13 @@ __global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(w_tile + (long)c * W_BYTES), 0, W_BYTES, 0x00020000);
 #pragma unroll
             for (int k = 0; k < KQ; ++k) {
-                const int q = lw + 4 * k;
+                const int q = lw + NLW * k;
                 if (q < NQ)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void*)(st + q * 1024), 16, voff[k], 0, 0, 0);
             }
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
-                const int jq = lw + 4 * k;
+                const int jq = lw + NLW * k;
                 if (jq < WQ)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + IN_BYTES + jq * 1024), 16, wvoff, jq * 1024, 0, 0);
             }
@@ -606,12 +613,19 @@ __global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         for (int g = 0; g < G; ++g) {
+            PCT(l0);
             if (g + 1 < G) {
                 if (++c == p.nchunks) { c = 0; jt += slots; setup(jt); }
                 issue(c, (g + 1) & 1);
+                PCT(l1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PCT(l2);
+                if (lw == 0) { PCACC(3, l1, l0); PCACC(4, l2, l1); }
             }
+            PCT(l3);
             asm volatile("s_barrier" ::: "memory");
+            PCT(l4);
+            if (lw == 0) PCACC(5, l4, l3);
         }
         return;
     }
@@ -649,6 +663,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
                 for (int m = 0; m < MT; ++m) acc[t][m] = bias_r[t];
         }
         const char* st = smem + (g & 1) * STAGE;
+        PCT(c0);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             f16x8 a[3][NT];
@@ -675,6 +690,8 @@ __global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
                 }
             }
         }
+        PCT(c1);
+        if (cw == 0) PCACC(0, c1, c0);
         if (++c == p.nchunks) {
             c = 0;
             jt += slots;
@@ -688,11 +705,14 @@ __global__ __launch_bounds__(768, 1) void conv3x3_pc(const KP p) {
             }
 #undef EPI
         }
+        PCT(c2);
         asm volatile("s_barrier" ::: "memory");
+        PCT(c3);
+        if (cw == 0) { PCACC(1, c2, c1); PCACC(2, c3, c2); PCACC(6, 1, 0); }
     }
 }
 
-template <int RPW, int NT>
+template <int RPW, int NT, int NLW>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 int num_cus() {
@@ -739,14 +759,14 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     return INNFER_OK;
 }
 
-template <int RPW, int NT>
+template <int RPW, int NT, int NLW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
     constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_pc<RPW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_pc<RPW, NT, NLW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
     }
     KP k = kp;
@@ -757,7 +777,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT>), dim3((unsigned)grid), dim3(768), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -765,6 +785,17 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
 }  // namespace
 
 }  // namespace innfer
+#ifdef INNFER_STAMPS
+namespace innfer { __global__ void k_clear_stamps() { for (int i = threadIdx.x; i < 8192 * NSTAMP; i += blockDim.x) g_stamps[i] = 0; } }
+#endif
+extern "C" int innfer_debug_clear_stamps() {
+#ifdef INNFER_STAMPS
+    hipLaunchKernelGGL(innfer::k_clear_stamps, dim3(1), dim3(1024), 0, 0);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+#else
+    return 0;
+#endif
+}
 extern "C" int innfer_debug_read_stamps(unsigned long long* h, int n_words) {
 #ifdef INNFER_STAMPS
     return hipMemcpyFromSymbol(h, HIP_SYMBOL(innfer::g_stamps), (size_t)n_words * 8) == hipSuccess ? NSTAMP : -2;
@@ -833,9 +864,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
     static const int rpw64 = getenv("INNFER_RPW64") ? atoi(getenv("INNFER_RPW64")) : 3;
     static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
-    static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 0;     // producer / consumer kernel for slab outputs
-    if (pc && L.out_mode == OUT_SLAB && nt == 2) return launch_pc<3, 2>(k, L.N, s);
-    if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4>(k, L.N, s);
+    static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 1;     // producer / consumer kernel for slab outputs
+    if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
+    if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
     switch (L.out_mode) {
         case OUT_SLAB:
             if (nt == 4) return rpw64 == 4 ? launch_t<4, 4, OUT_SLAB>(k, L.N, s) : rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);
