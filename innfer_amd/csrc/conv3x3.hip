@@ -648,6 +648,9 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     int jt = j0, c = 0;
     int kg = 0, n = 0, ty0 = 0, tx0 = 0, cbase = 0;
     asm volatile("s_barrier" ::: "memory");                       // chunk 0 of the first tile has landed
+#ifdef INNFER_STAMPS
+    const unsigned long long k_c0 = clock64(), k_w0 = wall_clock64();
+#endif
     for (int g = 0; g < G; ++g) {
         if (c == 0) {
             decode(jt, kg, n, ty0, tx0);
@@ -710,6 +713,9 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         PCT(c3);
         if (cw == 0) { PCACC(1, c2, c1); PCACC(2, c3, c2); PCACC(6, 1, 0); }
     }
+#ifdef INNFER_STAMPS
+    if (cw == 0) { PCACC(7, clock64(), k_c0); PCACC(8, wall_clock64(), k_w0); }
+#endif
 }
 
 template <int RPW, int NT, int NLW>

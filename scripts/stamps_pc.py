@@ -20,5 +20,6 @@ for (Cc, K) in [(64, 32), (160, 32), (192, 64)]:
     st = buf.reshape(8192, 16)[:256].astype(np.float64)
     chunks = st[:, 6].mean()
     print(f"--- C={Cc} K={K}: {chunks:.0f} chunks per workgroup (4 launches); cycles per chunk, mean over workgroups:")
+    print(f"  shader clock over the chunk loop: {st[:, 7].sum() / (st[:, 8].sum() / 100.0) / 1e3:.3f} GHz; loop wall time per launch {st[:, 8].mean() / 100.0 / 4:.1f} us")
     for i, nm in enumerate(names):
         print(f"  {nm:24s} {st[:, i].mean() / chunks:9.0f}")
