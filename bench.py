@@ -37,14 +37,14 @@ KIND_NAMES = {0: "first_conv_kernel"}
 # rows per wave of the instantiation conv_launch picks for NT 16-channel tiles (csrc/conv3x3.hip), slab / NCHW output
 RPW_OF_NT = {1: 4, 2: int(os.environ.get("INNFER_RPW32", "5")), 4: int(os.environ.get("INNFER_RPW64", "3"))}
 PC = int(os.environ.get("INNFER_PC", "1"))      # slab-output convs run the producer / consumer kernel
-PC_SHAPE = {2: (3, 2, 8 if PC == 2 else 4), 4: (2, 4, 4)}
+PC_SHAPE = {(2, 0): (3, 2, 8 if PC == 2 else 4, 0), (4, 0): (2, 4, 4, 0), (1, 1): (3, 1, 4, 1)}
 
 
 def kernel_key(k):
     """rocprof-style name of the instantiation conv_launch picks for launch kind k = 16*NT + out_mode."""
     nt, mode = k // 16, k % 16
-    if PC and mode == 0 and nt in PC_SHAPE:
-        return "conv3x3_pc<%d,%d,%d>" % PC_SHAPE[nt]
+    if PC and (nt, mode) in PC_SHAPE:
+        return "conv3x3_pc<%d,%d,%d,%d>" % PC_SHAPE[(nt, mode)]
     return f"conv3x3_mfma<{RPW_OF_NT[nt]},{nt},{mode}>"
 
 

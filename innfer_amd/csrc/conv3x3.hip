@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 #define PCT(var) do { } while (0)
 #define PCACC(slot, t1, t0) do { } while (0)
 #endif
-template <int RPW, int NT, int NLW>
+template <int RPW, int NT, int NLW, int OUTMODE>
 __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int NCW = 8;                       // consumer waves; NLW loader waves
     constexpr int TH = NCW * RPW;
@@ -698,6 +698,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         if (++c == p.nchunks) {
             c = 0;
             jt += slots;
+            if constexpr (OUTMODE == OUT_SLAB) {
 #define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C)>(p, acc, n, ty0, tx0, cw, li, cbase)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
@@ -707,6 +708,28 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                 if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
             }
 #undef EPI
+            } else {
+                // planar NCHW output (the network's last conv): activation only, K valid channels
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int y = ty0 + cw * RPW + (m >> 1);
+                    const int x = tx0 + (m & 1) * 16 + li;
+                    if (y >= p.y1 || x >= p.W) continue;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int ch = cbase + 4 * t + j;
+                            if (ch >= p.K) continue;
+                            float f = acc[t][m][j];
+                            if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                            else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                            const long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
+                            if (p.out_f32) ((float*)p.out)[o] = f;
+                            else ((f16*)p.out)[o] = (f16)f;
+                        }
+                }
+            }
         }
         PCT(c2);
         asm volatile("s_barrier" ::: "memory");
@@ -718,7 +741,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
 }
 
-template <int RPW, int NT, int NLW>
+template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 int num_cus() {
@@ -765,14 +788,14 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     return INNFER_OK;
 }
 
-template <int RPW, int NT, int NLW>
+template <int RPW, int NT, int NLW, int OUTMODE>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
     constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_pc<RPW, NT, NLW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_pc<RPW, NT, NLW, OUTMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
     }
     KP k = kp;
@@ -783,7 +806,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -873,6 +896,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 1;     // producer / consumer kernel for slab outputs
     if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
+    if (pc && L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2) return launch_pc<3, 1, 4, OUT_NCHW>(k, L.N, s);
     switch (L.out_mode) {
         case OUT_SLAB:
             if (nt == 4) return rpw64 == 4 ? launch_t<4, 4, OUT_SLAB>(k, L.N, s) : rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);
