@@ -15,16 +15,18 @@
 //   Output channels are permuted inside a panel so that one lane ends up holding
 //   4*NT CONSECUTIVE channels of one pixel -> 8/16/32-byte vector stores into NHWC.
 //
-// Workgroup = 256 threads = 4 waves, tile = (4*RPW rows) x 32 px, all 16*NT output
-// channels of one channel group.  Wave w owns rows [w*RPW, (w+1)*RPW).
-// Per 32-channel chunk the halo tile ((4*RPW+2) x 34 px x 64 B) and the weight
-// panel (9 x 16*NT x 64 B) are staged with LDS-DMA (buffer_load_dwordx4 ... lds; out-of-image
-// lanes are zero-filled by the buffer range check = the conv's zero padding);
-// LDS rows are 40 px so every row base is a multiple of 8 px, which makes the
-// 16-B-slot XOR swizzle (slot ^= 2*bit2(pixel)) a pure function of (lane, s):
-// all ds_read_b128 are base+immediate and bank-conflict free.
-// A pixel fragment B(row, seg, s) is read once and used by the up to three
-// (row-in-wave, r) pairs that need it.
+// Two kernels share the tile machinery below:
+//   conv3x3_pc<RPW,NT,NLW,OUT>   producer / consumer workgroup (8 MFMA waves + NLW LDS-DMA waves, one per CU,
+//                                tile = 8*RPW rows x 32 px, two LDS stages): every slab-output conv and the
+//                                planar last conv;
+//   conv3x3_mfma<RPW,NT,OUT>     two independent 4-wave workgroups per CU, tile = 4*RPW rows x 32 px, one LDS
+//                                stage each: PixelShuffle outputs, planar outputs with residuals, fallback.
+// Per 32-channel chunk the halo tile ((rows+2) x 34 px x 64 B) and the weight panel (9 x 16*NT x 64 B) are
+// staged with LDS-DMA (buffer_load_dwordx4 ... lds; out-of-image lanes are zero-filled by the buffer range
+// check = the conv's zero padding).  LDS rows are 36 px (2304 B = 9 x 256 B: every row starts on bank 0);
+// the 16-B-slot XOR swizzle (slot ^= 2*bit2(pixel index)) then depends on (lane, tap column, row parity)
+// only: all ds_read_b128 are base+immediate and bank-conflict free.  A pixel fragment B(row, seg, s) is
+// read once and used by the up to three (row-in-wave, r) pairs that need it.
 #include "common.h"
 
 #include <cstdlib>
@@ -41,8 +43,6 @@
 #pragma clang fp contract(off)
 
 namespace innfer {
-
-__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
 // Diagnostic build only (-DINNFER_STAMPS): s_memtime stamps of one wave per workgroup, written to a
 // buffer nothing else reads.  Never enabled in the shipped library; never quote its run time.
@@ -89,11 +89,6 @@ struct KP {
     int abl;                 // diagnostic build only: 1 no stores, 2 no weight DMA, 4 no input DMA, 8 no MFMA phase
 #endif
 };
-
-__device__ __forceinline__ void dma16(const void* g, void* lds) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
-}
 
 // Slab epilogue, specialised on (activation, residual 1, residual 2) so that the unrolled loop over the
 // wave's pixel tiles is straight-line code: residual loads for all tiles first (their latencies
