@@ -5,6 +5,7 @@ cache-resident window.  Results are wrong
 by construction; only the launch times mean anything."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("INNFER_PC", "0")      # these hooks live in the two-workgroup kernel (conv3x3_mfma)
 os.environ.setdefault("INNFER_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                  "innfer_amd", "lib", "libinnfer_amd_ablate.so"))
 from scripts.bench_conv import run

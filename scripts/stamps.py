@@ -7,6 +7,7 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("INNFER_PC", "0")      # these hooks live in the two-workgroup kernel (conv3x3_mfma)
 import innfer_amd.lib as L
 from scripts.bench_conv import run  # noqa
 
