@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="frame1080", choices=["frame1080", "frame540", "chop8k", "chop4k"])
+    ap.add_argument("--workload", default="frame1080", choices=["frame1080", "frame540", "chop8k", "chop4k", "chain4k"])
     ap.add_argument("--band-rows", type=int, default=int(os.environ.get("INNFER_BAND_ROWS", "0")))
     ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -235,14 +235,22 @@ def main():
                "parallelism": f"frame replicas x{world}" if world > 1 else "single GPU"}
     else:
         from innfer_amd import parallel
-        H, W = (4320, 7680) if args.workload == "chop8k" else (2160, 3840)
+        H, W = (4320, 7680) if args.workload == "chop8k" else (2160, 3840)       # chop4k and chain4k: 4K input
         x = torch.from_numpy(synth.uniform((1, 3, H, W), 2)).to(dev).half()
         runner = parallel.ChopRunner(net, scale=4, tile_batch=args.tile_batch or 16)
         out_pix_per_rank = 16 * H * W / world       # unique output pixels of the ONE shared frame
+        if args.workload == "chain4k":              # BASELINE config 4: model chain 1x + 4x (run.py:424-426)
+            net1, _ = build_net(dev, scale=1)
+            runner1 = parallel.ChopRunner(net1, scale=1, tile_batch=args.tile_batch or 16)
 
-        def step():
-            return runner(x)
-        cfg = {"workload": f"ESRGAN RRDBNet-23 4x fp16, {H}x{W} input through chop_forward (patch 200, step 0.5), "
+            def step():
+                return parallel.run_chain([runner1, runner], x)
+            what = "model chain RRDBNet-23 1x + RRDBNet-23 4x"
+        else:
+            def step():
+                return runner(x)
+            what = "ESRGAN RRDBNet-23 4x"
+        cfg = {"workload": f"{what} fp16, {H}x{W} input through chop_forward (patch 200, step 0.5), "
                            f"tiles sharded over {world} rank(s), HR tiles gathered + blended on rank 0",
                "band_rows": args.band_rows, "parallelism": f"tile-dp{world}"}
 
