@@ -12,9 +12,9 @@
 //   channel slices (b = channels 20..39)       weights packed at the slice's positions, zeros elsewhere
 //   LeakyReLU / sigmoid gates / residual adds  pan_post
 //   FSA: MaxPool2d(4) -> f,g,h 1x1 -> softmax(f^T g) -> h att^T -> bicubic up -> gamma*out + in
-//                                              pan_maxpool, one 40->50 GEMM, pan_attention (one
-//                                              workgroup per query, streaming two-pass softmax, no
-//                                              N x N matrix in memory), pan_fsa_combine (ATen's
+//                                              pan_maxpool, one 40->50 GEMM, pan_attention (a query
+//                                              per lane, keys split over 4 waves and tiled through LDS, two-pass
+//                                              softmax, no N x N matrix in memory), pan_fsa_combine (ATen's
 //                                              bicubic, A = -0.75, align_corners=False)
 //   nearest-2x Upsample in the up-blocks       folded into the GEMM's gather (GP.up)
 //   + bilinear(x, align_corners=True)          pan_final, NCHW output
@@ -112,50 +112,90 @@ __global__ void pan_maxpool(const f16* in, long in_g, int C, int N, int H, int W
     }
 }
 
-// fgh: fp32 [N*Np][64] = [f(5) | g(5) | h(40)] without bias.  One workgroup per query pixel:
-// att_j = softmax_j(f_i . g_j); out_i[c] = sum_j h_j[c] att_j.
+// fgh: fp32 [N*Np][64] = [f(5) | g(5) | h(40)] without bias.  att_j = softmax_j(f_i . g_j);
+// out_i[c] = sum_j h_j[c] att_j.  A workgroup owns 64 queries (a query per lane, 40 accumulators in
+// registers) and its 4 waves split the keys: wave w takes the key tiles t = w, w+4, ...; keys / values
+// go through a wave-private LDS tile of 64 and are read as broadcasts, so they are fetched once per 64
+// queries instead of once per query.  Two passes (max, then exp / accumulate); the four partial sums
+// are added in wave order: the result does not depend on the batch.
 __global__ __launch_bounds__(256) void pan_attention(const float* fgh, const float* bf, const float* bg, const float* bh,
-                                                     int Np, int Cq, int C, float* out) {
-    __shared__ float red[256];
-    __shared__ float redc[4][64];
-    const int i = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+                                                     int Np, float* out) {
+    constexpr int CQ = 5, C = 40, KT = 64, PITCH = 48;       // LDS row: g at 0..4, h at 8..47
+    __shared__ __attribute__((aligned(16))) float lds[4 * KT * PITCH];
+    __shared__ float redm[4][64], reds[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = blockIdx.y;
+    float* kt = lds + wave * KT * PITCH;
+    const int i = blockIdx.x * 64 + lane;
     const float* base = fgh + (long)n * Np * 64;
-    float fi[8];
-    for (int c = 0; c < Cq; ++c) fi[c] = base[(long)i * 64 + c] + bf[c];
-    auto score = [&](int j) {
+    float fi[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) fi[c] = i < Np ? base[(long)i * 64 + c] + bf[c] : 0.f;
+    const int ntiles = (Np + KT - 1) / KT, rounds = (ntiles + 3) / 4;
+    auto load_tile = [&](int t, bool with_h) {
+        const int j = t * KT + lane;                          // this lane stages key j
+        const float* row = base + (long)j * 64;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) kt[lane * PITCH + c] = j < Np ? row[CQ + c] + bg[c] : 0.f;
+        if (with_h) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) kt[lane * PITCH + 8 + c] = j < Np ? row[2 * CQ + c] + bh[c] : 0.f;
+        }
+    };
+    auto score = [&](int jj) {
         float s = 0.f;
-        for (int c = 0; c < Cq; ++c) s += fi[c] * (base[(long)j * 64 + Cq + c] + bg[c]);
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) s += fi[c] * kt[jj * PITCH + c];
         return s;
     };
     float m = -INFINITY;
-    for (int j = tid; j < Np; j += 256) m = fmaxf(m, score(j));
-    red[tid] = m;
+    for (int r = 0; r < rounds; ++r) {
+        const int t = 4 * r + wave;
+        __syncthreads();
+        load_tile(t, false);
+        __syncthreads();
+        const int cnt = min(KT, Np - t * KT);
+        for (int jj = 0; jj < cnt; ++jj) m = fmaxf(m, score(jj));
+    }
+    redm[wave][lane] = m;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
-    m = red[0];
-    __syncthreads();
-    float acc[40];
+    m = fmaxf(fmaxf(redm[0][lane], redm[1][lane]), fmaxf(redm[2][lane], redm[3][lane]));
+    float acc[C];
+#pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
     float sum = 0.f;
-    for (int j = tid; j < Np; j += 256) {
-        const float e = expf(score(j) - m);
-        sum += e;
-        const float* hj = base + (long)j * 64 + 2 * Cq;
-        for (int c = 0; c < C; ++c) acc[c] += (hj[c] + bh[c]) * e;
+    for (int r = 0; r < rounds; ++r) {
+        const int t = 4 * r + wave;
+        __syncthreads();
+        load_tile(t, true);
+        __syncthreads();
+        const int cnt = min(KT, Np - t * KT);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float e = expf(score(jj) - m);
+            sum += e;
+            const f32x4* hv = (const f32x4*)(kt + jj * PITCH + 8);
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q) {
+                const f32x4 h = hv[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[4 * q + k] += h[k] * e;
+            }
+        }
     }
-    red[tid] = sum;
+    // combine the four key partitions in wave order: partials go through the (now free) tile buffers
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    sum = red[0];
-    // reduce the C partial outputs over the 256 threads: wave shuffle, then 4 waves through LDS
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int c = 0; c < C; ++c) {
-        float v = acc[c];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if (lane == 0) redc[wave][c] = v;
+    reds[wave][lane] = sum;
+#pragma unroll
+    for (int c = 0; c < C; ++c) kt[c * 64 + lane] = acc[c];       // [wave][c][query]
+    __syncthreads();
+    if (i < Np) {
+        const float inv = 1.0f / (((reds[0][lane] + reds[1][lane]) + reds[2][lane]) + reds[3][lane]);
+        float* o = out + ((long)n * Np + i) * C;
+        for (int c = wave; c < C; c += 4) {
+            const float v = ((lds[(0 * KT * PITCH) + c * 64 + lane] + lds[(1 * KT * PITCH) + c * 64 + lane]) +
+                             lds[(2 * KT * PITCH) + c * 64 + lane]) + lds[(3 * KT * PITCH) + c * 64 + lane];
+            o[c] = v * inv;
+        }
     }
-    __syncthreads();
-    if (tid < C) out[((long)n * Np + i) * C + tid] = (redc[0][tid] + redc[1][tid] + redc[2][tid] + redc[3][tid]) / sum;
 }
 
 __device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
@@ -484,8 +524,8 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         raw = (float*)(ws + cv.fgh);
         CK(gemm(POOL, Gp, hp, wp, hp, wp, 0));                                        // [f | g | h]
         raw = save;
-        hipLaunchKernelGGL(pan_attention, dim3(hp * wp, N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
-                           vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, nf / 8, nf, (float*)(ws + cv.att));
+        hipLaunchKernelGGL(pan_attention, dim3((hp * wp + 63) / 64, N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
+                           vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, (float*)(ws + cv.att));
         INNFER_HIP(hipGetLastError());
         hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
                            INP, G, N, H, W, vec("FSA.gamma"), T);
