@@ -36,7 +36,7 @@ namespace {
 enum { MODE_LIN = 0, MODE_GATE = 1, MODE_PA = 2 };
 
 struct PP {
-    const float* raw; int C; const float* bias; int mode; int act;       // act: 1 = LeakyReLU(0.2)
+    const float* raw; int rs; int C; const float* bias; int mode; int act;   // rs: floats per raw row; act: 1 = LeakyReLU(0.2)
     const f16* res; long res_g; int res_off;                              // MODE_LIN: + res ; MODE_PA: * v
     f16* dst; long dst_g; int dst_off;
     long npix;
@@ -55,7 +55,7 @@ __global__ void pan_post(const PP p) {
     if (i >= p.npix * c4) return;
     const long pix = i / c4;
     const int c = (int)(i - pix * c4) * 4;
-    const float* r = p.raw + pix * 64;
+    const float* r = p.raw + pix * p.rs;
     const f32x4 a = *(const f32x4*)(r + c);
     float y[4];
     if (p.mode == MODE_GATE) {
@@ -234,7 +234,7 @@ __global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f
 }
 
 // out = conv_last + bias + bilinear(x, align_corners=True) -> NCHW
-__global__ void pan_final(const float* raw, const float* bias, int C, const void* x, int x_f32, int N, int H, int W,
+__global__ void pan_final(const float* raw, int rs, const float* bias, int C, const void* x, int x_f32, int N, int H, int W,
                           int scale, void* out, int out_f32) {
     const int FH = H * scale, FW = W * scale;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,7 +257,7 @@ __global__ void pan_final(const float* raw, const float* bias, int C, const void
             il = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
         else
             il = at(Y, X);
-        const float v = raw[i * 64 + c] + bias[c] + il;
+        const float v = raw[i * rs + c] + bias[c] + il;
         const long o = ((n * C + c) * FH + Y) * (long)FW + X;
         if (out_f32) ((float*)out)[o] = v; else ((f16*)out)[o] = (f16)v;
     }
@@ -474,14 +474,17 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
     int gi = 0;
     auto vec = [&](const std::string& key) { return p->d_vecs[find(p, key)]; };
-    auto gemm = [&](const f16* in, long in_g, int Hin, int Win, int Ho, int Wo, int up) -> int {
+    // raw GEMM rows hold only the layer's channels (rounded to 4), not the whole 64-channel tile
+    int raw_rs = 64;
+    auto gemm = [&](const f16* in, long in_g, int Hin, int Win, int Ho, int Wo, int up, bool full_rows = false) -> int {
         const Gemm& g = p->gemms[gi++];
+        raw_rs = full_rows ? 64 : (g.cout + 3) / 4 * 4;
         return gg::launch(g.d_w, g.cin_pad, 64, in, in_g, N, Hin, Win, raw, Ho, Wo, 1, g.ntaps,
-                          g.ntaps == 9 ? dy9 : d0, g.ntaps == 9 ? dx9 : d0, Ho, Wo, 1, 0, 0, up, s);
+                          g.ntaps == 9 ? dy9 : d0, g.ntaps == 9 ? dx9 : d0, Ho, Wo, 1, 0, 0, up, s, nullptr, 0, raw_rs);
     };
     auto post = [&](long npix, int C, const float* bias, int mode, int act, const f16* res, long res_g, int res_off,
                     f16* dst, long dst_g, int dst_off) -> int {
-        PP q{raw, C, bias, mode, act, res, res_g, res_off, dst, dst_g, dst_off, npix};
+        PP q{raw, raw_rs, C, bias, mode, act, res, res_g, res_off, dst, dst_g, dst_off, npix};
         if (C & 3) return set_error(INNFER_ERR_UNSUPPORTED, "pan_post: channel count %d is not a multiple of 4", C);
         const long nthr = npix * (C >> 2);
         hipLaunchKernelGGL(pan_post, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, q);
@@ -522,7 +525,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         INNFER_HIP(hipGetLastError());
         float* save = raw;
         raw = (float*)(ws + cv.fgh);
-        CK(gemm(POOL, Gp, hp, wp, hp, wp, 0));                                        // [f | g | h]
+        CK(gemm(POOL, Gp, hp, wp, hp, wp, 0, true));                                  // [f | g | h], 64-float rows for pan_attention
         raw = save;
         hipLaunchKernelGGL(pan_attention, dim3((hp * wp + 63) / 64, N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
                            vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, (float*)(ws + cv.att));
@@ -549,7 +552,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     CK(gemm(cur, cur_g, h, w, h, w, 0));                                              // conv_last
     {
         const long fpx = (long)N * h * w;
-        hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, raw, vec("conv_last.bias"), p->out_nc,
+        hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, raw, raw_rs, vec("conv_last.bias"), p->out_nc,
                            d_in, in_dtype == INNFER_F32, N, H, W, p->scale, d_out, out_dtype == INNFER_F32);
         INNFER_HIP(hipGetLastError());
     }
