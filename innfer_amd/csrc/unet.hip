@@ -30,9 +30,10 @@ using namespace innfer;
 
 namespace {
 
-// per-(image, channel) mean and 1/sqrt(var_biased + eps) of raw[N][HW][cpad]: two passes in fp32 (mean, then
+// per-(image, channel) BatchNorm transform (alpha, shift) from the mean and biased variance of raw[N][HW][cpad]: two passes in fp32 (mean, then
 // the sum of squared deviations), 32 channels x 32 pixel lanes per workgroup, 4 loads in flight per thread
-__global__ __launch_bounds__(1024) void bn_stats(const float* raw, int cpad, long HW, float eps, float* mean, float* rstd, int C) {
+__global__ __launch_bounds__(1024) void bn_stats(const float* raw, int cpad, long HW, float eps, const float* gamma, const float* beta,
+                                                 float* alpha, float* shift, int C) {
     __shared__ float red[1024];
     const int n = blockIdx.y, cb = blockIdx.x * 32;
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
@@ -64,16 +65,19 @@ __global__ __launch_bounds__(1024) void bn_stats(const float* raw, int cpad, lon
     for (; px < HW; px += 32) { const float d = base[px * cpad] - mu; s0 += d * d; }
     const float var = reduce32((s0 + s1) + (s2 + s3)) / (float)HW;
     if (pl == 0 && c < C) {
-        mean[(long)n * C + c] = mu;
-        rstd[(long)n * C + c] = 1.0f / sqrtf(var + eps);
+        // the transform ATen applies (batch_norm_cpu_transform_input): out = x * alpha + shift,
+        // alpha = invstd * weight, shift = bias - mean * alpha
+        const float a = (1.0f / sqrtf(var + eps)) * gamma[c];
+        alpha[(long)n * C + c] = a;
+        shift[(long)n * C + c] = beta[c] - mu * a;
     }
 }
 
 struct PostDst { f16* p; long g; int coff; int act; };      // act: 1 lrelu(0.2), 2 relu
 
 // raw fp32 -> (BatchNorm) -> activation -> up to two fp16 blocked-NHWC destinations; 8 channels per thread
-__global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, const float* mean, const float* rstd,
-                          const float* gamma, const float* beta, PostDst d0, PostDst d1) {
+__global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, const float* alpha, const float* shift,
+                          PostDst d0, PostDst d1) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c8 = C / 8;
     if (i >= (long)N * HW * c8) return;
@@ -82,11 +86,15 @@ __global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, con
     const long n = pix / HW;
     const float* rp = raw + pix * cpad + c;
     float v[8];
+    const f32x4 x0 = *(const f32x4*)rp, x1 = *(const f32x4*)(rp + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float x = rp[e];
-        if (mean) x = (x - mean[n * C + c + e]) * rstd[n * C + c + e] * gamma[c + e] + beta[c + e];
-        v[e] = x;
+    for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+    if (alpha) {
+        const float* ap = alpha + n * C + c;
+        const float* sp = shift + n * C + c;
+        const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4), s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v[e] * a0[e] + s0[e]; v[4 + e] = v[4 + e] * a1[e] + s1[e]; }
     }
     const PostDst ds[2] = {d0, d1};
 #pragma unroll
@@ -369,12 +377,12 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
 
     auto post = [&](const Layer& l, long HW, bool bn, PostDst d0, PostDst d1) -> int {
         if (bn) {
-            hipLaunchKernelGGL(bn_stats, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, raw, l.cout_pad, HW, 1e-5f, mean, rstd, l.cout);
+            hipLaunchKernelGGL(bn_stats, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, raw, l.cout_pad, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout);
             INNFER_HIP(hipGetLastError());
         }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(unet_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
-                           bn ? mean : nullptr, bn ? rstd : nullptr, l.d_gamma, l.d_beta, d0, d1);
+                           bn ? mean : nullptr, bn ? rstd : nullptr, d0, d1);
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     };
