@@ -6,6 +6,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace innfer {
@@ -20,7 +21,7 @@ struct GP {
     int ntaps; int dy[16], dx[16];
     int Hfull, Wfull, os, ooy, oox;       // out pixel = (oy*os + ooy, ox*os + oox)
     int up;                               // input is read through nearest-2x upsampling (Hin, Win = source size)
-    int seg;                              // k-steps per accumulation segment: result = ((seg0 + seg1) + seg2) ...
+    int seg;                              // k-steps per split-K segment
     int ksplit; long split_elems;         // ksplit > 1: blockIdx.z computes segment z and writes out + z*split_elems
 };
 
@@ -30,23 +31,34 @@ struct GP {
 // of the current step (counted vmcnt), one raw barrier per step publishes them and frees the stage consumed
 // last.  Out-of-image taps (the conv's zero padding / the transposed conv's missing taps) and pixels beyond
 // M carry an offset beyond num_records: the buffer range check writes zeros to LDS.
-constexpr int GG_STAGES = 4;
-constexpr int GG_STAGE_BYTES = 12288;                                 // 128 px x 64 B | 64 co x 64 B
+// Layers with at most this many output pixels per image (and >= 32 k-steps) are split over K.
+constexpr int SPLIT_MAX_PX = 256;
+inline long split_max_px() {
+    static const long v = getenv("INNFER_SPLIT_PX") ? atol(getenv("INNFER_SPLIT_PX")) : 64;
+    return v < SPLIT_MAX_PX ? v : SPLIT_MAX_PX;
+}
 
+// Tile shapes: <BP, Q, STAGES> = 16*BP pixels per wave x 64*Q output channels, 4 waves:
+//   <2,1,4>  128 px x  64 co, 12 KiB per stage   small / narrow layers and every split-K launch
+//   <4,2,3>  256 px x 128 co, 24 KiB per stage   big layers (twice the MFMAs per staged byte)
+template <int BP, int Q, int STAGES>
 static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
-    __shared__ __attribute__((aligned(16))) char lds[GG_STAGES * GG_STAGE_BYTES];
+    constexpr int PXT = 64 * BP;                                      // pixels per workgroup
+    constexpr int B_BYTES = PXT * 64, A_BYTES = Q * 4096, STAGE_BYTES = B_BYTES + A_BYTES;
+    constexpr int NPIECE = BP + Q;                                    // LDS-DMA pieces per wave and step
+    __shared__ __attribute__((aligned(16))) char lds[STAGES * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const long M = (long)p.N * p.Ho * p.Wo;
-    const long m0 = (long)blockIdx.x * 128;
-    const int cot = blockIdx.y;
+    const long m0 = (long)blockIdx.x * PXT;
+    const int cot = blockIdx.y * Q;                                   // first 64-channel panel of this workgroup
 
-    // staging role: pixel rows (tid>>2) and 64 + (tid>>2), 16-byte slot (tid&3); weight row (tid>>2)
+    // staging role: pixel rows (tid>>2) + 64*h, 16-byte slot (tid&3); weight row (tid>>2) of panel cot + j
     const int sslot = tid & 3;
-    int spix[2], soy[2], sox[2], cso[2]; bool sok[2];
+    int spix[BP], soy[BP], sox[BP], cso[BP]; bool sok[BP];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < BP; ++h) {
         const int srow = (tid >> 2) + 64 * h;
         const long sm = m0 + srow;
         sok[h] = sm < M;
@@ -60,9 +72,10 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
         spix[h] = n * p.Hin * p.Win;                                  // first pixel of the image (launch checks 32-bit range)
         cso[h] = (sslot ^ (((srow >> 2) & 1) << 1)) * 16;             // byte offset of the channel slot stored at LDS slot sslot
     }
-    const char* wtile = (const char*)p.wpk + (long)cot * p.ntaps * p.nchunks * 4096;
+    const long panel_bytes = (long)p.ntaps * p.nchunks * 4096;
+    const char* wtile = (const char*)p.wpk + (long)cot * panel_bytes;
     const int total_steps = p.ntaps * p.nchunks;
-    // split-K: one accumulation segment per blockIdx.z; otherwise all segments, added up in the same order
+    // split-K: blockIdx.z takes the k-steps [z*seg, (z+1)*seg) and writes a partial result
     const int step0 = p.ksplit > 1 ? blockIdx.z * p.seg : 0;
     const int nsteps = p.ksplit > 1 ? min(p.seg, total_steps - step0) : total_steps;
 
@@ -70,11 +83,10 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
         const int step = step0 + rel;
 #if defined(__HIP_DEVICE_COMPILE__)
         const int t = step / p.nchunks, c = step - t * p.nchunks;
-        char* st = lds + (rel % GG_STAGES) * GG_STAGE_BYTES;
+        char* st = lds + (rel % STAGES) * STAGE_BYTES;
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)c * p.in_g), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + (long)step * 4096), 0, 4096, 0x00020000);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BP; ++h) {
             int iy = soy[h] * p.stride + p.dy[t], ix = sox[h] * p.stride + p.dx[t];
             bool ok = sok[h] && iy >= 0 && ix >= 0;
             if (p.up) { ok = ok && iy < 2 * p.Hin && ix < 2 * p.Win; iy >>= 1; ix >>= 1; }
@@ -82,69 +94,64 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             const int voff = ok ? (spix[h] + iy * p.Win + ix) * 64 + cso[h] : (int)0x80000000;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(st + (wave + 4 * h) * 1024), 16, voff, 0, 0, 0);
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + 8192 + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + j * panel_bytes + (long)step * 4096), 0, 4096, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + B_BYTES + j * 4096 + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+        }
 #else
-        (void)step; (void)rel; (void)wtile; (void)spix; (void)cso;
+        (void)step; (void)rel; (void)wtile; (void)spix; (void)cso; (void)panel_bytes;
 #endif
     };
 
-    f32x4 acc[2][4], tot[2][4];
+    f32x4 acc[BP][4 * Q];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < BP; ++h)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[h][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    int seg_left = p.seg;
-    int boff[2];
+        for (int q = 0; q < 4 * Q; ++q) acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int boff[BP];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int brow = wave * 32 + 16 * h + li;
+    for (int h = 0; h < BP; ++h) {
+        const int brow = wave * 16 * BP + 16 * h + li;
         boff[h] = brow * 64 + ((lg ^ (((brow >> 2) & 1) << 1)) << 4);
     }
-    const int aoff = 8192 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    const int aoff = B_BYTES + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
 
-    for (int s0 = 0; s0 < GG_STAGES - 1 && s0 < nsteps; ++s0) issue(s0);
+    for (int s0 = 0; s0 < STAGES - 1 && s0 < nsteps; ++s0) issue(s0);
     for (int step = 0; step < nsteps; ++step) {
-        const int ahead = nsteps - 1 - step;                          // steps issued after this one, capped by the ring
-        if (ahead >= GG_STAGES - 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        // wait for this wave's own pieces of `step`: up to STAGES-2 later steps stay in flight
+        const int ahead = min(STAGES - 2, nsteps - 1 - step);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPIECE) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPIECE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        if (step + GG_STAGES - 1 < nsteps) issue(step + GG_STAGES - 1);
-        const char* b = lds + (step % GG_STAGES) * GG_STAGE_BYTES;
-        const f16x8 b0 = *(const f16x8*)(b + boff[0]);
-        const f16x8 b1 = *(const f16x8*)(b + boff[1]);
+        if (step + STAGES - 1 < nsteps) issue(step + STAGES - 1);
+        const char* b = lds + (step % STAGES) * STAGE_BYTES;
+        f16x8 bf[BP];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int h = 0; h < BP; ++h) bf[h] = *(const f16x8*)(b + boff[h]);
+#pragma unroll
+        for (int q = 0; q < 4 * Q; ++q) {
             const f16x8 a = *(const f16x8*)(b + q * 1024 + aoff);
-            acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc[0][q], 0, 0, 0);
-            acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc[1][q], 0, 0, 0);
-        }
-        if (--seg_left == 0 || step + 1 == nsteps) {                  // close the segment: tot += acc (tot starts at 0)
-            seg_left = p.seg;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) tot[h][q][j] += acc[h][q][j];
-                    acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+            for (int h = 0; h < BP; ++h) acc[h][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[h], acc[h][q], 0, 0, 0);
         }
     }
     // D rows = out channels (16*lg + 4*q + j after the panel permutation), cols = pixels
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const long m = m0 + wave * 32 + 16 * h + li;
+    for (int h = 0; h < BP; ++h) {
+        const long m = m0 + wave * 16 * BP + 16 * h + li;
         if (m < M) {
             const int ox = (int)(m % p.Wo);
             const int oy = (int)((m / p.Wo) % p.Ho);
             const long n = m / ((long)p.Wo * p.Ho);
             const long opix = (n * p.Hfull + (long)oy * p.os + p.ooy) * p.Wfull + (long)ox * p.os + p.oox;
-            const int ch0 = cot * 64 + 16 * lg;
-            float* op = p.out + (long)blockIdx.z * p.split_elems + opix * p.raw_stride + ch0;
+            float* op = p.out + (long)blockIdx.z * p.split_elems + opix * p.raw_stride;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (ch0 + 4 * q < p.raw_stride) *(f32x4*)(op + 4 * q) = tot[h][q];
+            for (int q = 0; q < 4 * Q; ++q) {
+                const int ch = (cot + (q >> 2)) * 64 + 16 * lg + 4 * (q & 3);
+                if (ch < p.raw_stride) *(f32x4*)(op + ch) = acc[h][q];
+            }
         }
     }
 }
@@ -213,21 +220,25 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     const long M = (long)N * Ho * Wo;
     if (M <= 0) return INNFER_OK;
     if ((long)N * Hin * Win * 64 >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "gather GEMM: input of %d x %d x %d pixels exceeds the 2 GiB buffer window", N, Hin, Win);
-    const long wgs = ((M + 127) / 128) * (cout_pad / 64);
     const int nsteps = ntaps * g.nchunks;
     const size_t full = (size_t)N * Hfull * Wfull * g.raw_stride * sizeof(float);
-    // Accumulation is segmented the same way whether or not the K range is split over workgroups, so the
-    // result does not depend on the batch size (a batch must equal the independent batch-1 forwards).
-    const int nseg = nsteps >= 32 ? 8 : 1;
-    g.seg = (nsteps + nseg - 1) / nseg;
+    // Split-K (deep UNet layers: a few pixels per image, a K loop of up to 256 steps): the decision depends on
+    // the layer only, never on the batch size, so a batch stays bit-identical to the batch-1 forwards.
+    g.seg = (nsteps + 7) / 8;
     const int segs = (nsteps + g.seg - 1) / g.seg;
     int ks = 1;
-    if (scratch && wgs < 1024 && segs > 1 && (size_t)segs * full <= scratch_bytes) ks = segs;
+    if (scratch && nsteps >= 32 && (long)Ho * Wo <= split_max_px() && (size_t)segs * full <= scratch_bytes) ks = segs;
     g.ksplit = ks;
     g.split_elems = ks > 1 ? (long)(full / sizeof(float)) : 0;
     if (ks > 1) g.out = scratch;
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64), (unsigned)ks);
-    hipLaunchKernelGGL(gemm_gather, grid, dim3(256), 0, s, g);
+    const bool big = ks == 1 && cout_pad % 128 == 0 && ((M + 255) / 256) * (cout_pad / 128) >= 256;
+    if (big) {
+        dim3 grid((unsigned)((M + 255) / 256), (unsigned)(cout_pad / 128), 1);
+        hipLaunchKernelGGL((gemm_gather<4, 2, 3>), grid, dim3(256), 0, s, g);
+    } else {
+        dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64), (unsigned)ks);
+        hipLaunchKernelGGL((gemm_gather<2, 1, 4>), grid, dim3(256), 0, s, g);
+    }
     INNFER_HIP(hipGetLastError());
     if (ks > 1) {
         const long nthr = M * (g.raw_stride / 4);

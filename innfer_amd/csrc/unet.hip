@@ -306,7 +306,9 @@ static int upload_all(innfer_unet* u) {
 
 namespace {
 struct UCarve { size_t x0, raw, mean, rstd, r_inner, splitk, total; std::vector<size_t> D, CAT; };
-constexpr size_t SPLITK_BYTES = 128u << 20;      // partial results of the split-K deep layers
+// partial results of the split-K deep layers: 8 segments x (<= GG_SPLIT_MAX_PX pixels x <= 1024 channels) fp32 per image,
+// so that whether a layer is split never depends on the batch size
+inline size_t splitk_bytes(int N) { return (size_t)N * 8 * gg::SPLIT_MAX_PX * 1024 * sizeof(float); }
 
 UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
     UCarve c;
@@ -326,7 +328,7 @@ UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
         c.CAT[k] = off; off += al(px * 2 * u->dc[k] * 2);
     }
     c.r_inner = off; off += al((size_t)N * (H >> L) * (W >> L) * u->dc[L - 1] * 2);
-    c.splitk = off; off += SPLITK_BYTES;
+    c.splitk = off; off += splitk_bytes(N);
     c.total = off;
     return c;
 }
@@ -335,7 +337,7 @@ int run_gemm(const Layer& l, const f16* wpk, const f16* in, long in_g, int N, in
              int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx, int Hfull, int Wfull,
              int os, int ooy, int oox, hipStream_t s, float* scratch, int raw_stride = 0) {
     return gg::launch(wpk, l.cin_pad, l.cout_pad, in, in_g, N, Hin, Win, raw, Ho, Wo, stride, ntaps, dy, dx,
-                      Hfull, Wfull, os, ooy, oox, 0, s, scratch, SPLITK_BYTES, raw_stride);
+                      Hfull, Wfull, os, ooy, oox, 0, s, scratch, splitk_bytes(N), raw_stride);
 }
 }  // namespace
 
