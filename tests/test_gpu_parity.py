@@ -293,6 +293,23 @@ def test_unet256_golden(dev, golden):
     assert np.abs(y32 - ref).max() < 3e-2
 
 
+def test_unet256_big_batch_uses_wide_tiles_and_stays_identical(dev):
+    """A batch of 16 makes the mid layers take the 256 px x 128 channel GEMM tiles and keeps the deep
+    layers on the split-K path; every image must still equal its own batch-1 forward bit for bit."""
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config("p2p_256", 1))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(_sd(shapes, seed=5), strict=True)
+    net = net.to(dev).train()
+    x = torch.from_numpy(synth.uniform((16, 3, 256, 256), 41, -1.0, 1.0)).to(dev).half()
+    y = net(x)
+    assert torch.isfinite(y).all()
+    for i in (0, 7, 15):
+        assert torch.equal(y[i:i + 1], net(x[i:i + 1])), i
+
+
 def test_pan_golden(dev, golden):
     """PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA self attention) against the
     reference (golden G8).  fp16 slabs between the GEMMs, fp32 accumulation / gates / softmax /
