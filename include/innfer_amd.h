@@ -217,6 +217,14 @@ int innfer_nchw_to_u8hwc(const void* d_in, int in_dtype, int H, int W, int C, in
 int innfer_srgb_to_linear(const uint8_t* d_in, float* d_out, size_t n, void* stream);
 int innfer_linear_to_srgb(const float* d_in, uint8_t* d_out, size_t n, void* stream);
 
+/* Colour fix (`-cf`): replaces color_fix (utils/utils.py:278-315).  d_lr / d_sr / d_out are uint8 HWC images
+ * on the device (any channel order, C <= 4); out = linear2srgb(resize(gauss3(lin(lr) - resize(lin(sr)))) + lin(sr)).
+ * The reference's cv2.resize(INTER_CUBIC) and cv2.GaussianBlur(3x3, sigma 0) are restated from OpenCV's
+ * published float32 algorithms (parity with OpenCV itself is unpinned: it is absent from the image). */
+size_t innfer_color_fix_workspace_bytes(int h_lr, int w_lr, int h_sr, int w_sr, int channels);
+int innfer_color_fix(const uint8_t* d_lr, int h_lr, int w_lr, const uint8_t* d_sr, int h_sr, int w_sr, int channels,
+                     uint8_t* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,133 @@
+// `-cf` colour fix on the GPU: replaces color_fix (utils/utils.py:278-315) with its srgb2linear /
+// linear2srgb (utils/colors.py:29-60) ends.  The reference calls OpenCV twice (cv2.resize INTER_CUBIC and
+// cv2.GaussianBlur 3x3, sigma 0); OpenCV is neither vendored nor installed here, so these kernels follow
+// the published float32 algorithms (oracle/colorfix.py states them) and parity with OpenCV itself is
+// UNPINNED.  All images are HWC, the two uint8 inputs and the uint8 output live on the device.
+//   1. lin_b = srgb2linear(B) (kept: it is needed again at the end); diff = srgb2linear(A) - cubic(lin_b -> size A)
+//   2. blur  = gauss3(diff)            rows, then columns, BORDER_REFLECT_101
+//   3. out   = linear2srgb(cubic(blur -> size B) + lin_b)
+// HBM-bound pointwise / gather work: one thread per output element, contraction off so that the float32
+// operation order is the one written down (and mirrored by the oracle).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+using namespace innfer;
+
+namespace {
+
+__device__ __forceinline__ float srgb2lin(uint8_t v) {
+    const float l = __fdiv_rn((float)v, 255.0f);
+    return l <= 0.04045f ? __fdiv_rn(l, 12.92f) : powf(__fdiv_rn(__fadd_rn(l, 0.055f), 1.055f), 2.4f);
+}
+
+__device__ __forceinline__ uint8_t lin2srgb(float x) {
+    float s = fminf(fmaxf(x, 0.0f), 1.0f);
+    s = s <= 0.0031308f ? __fmul_rn(s, 12.92f) : __fsub_rn(__fmul_rn(1.055f, powf(s, (float)(1.0 / 2.4))), 0.055f);
+    s = fminf(fmaxf(__fmul_rn(s, 255.0f), 0.0f), 255.0f);
+    return (uint8_t)(int)s;
+}
+
+// OpenCV's cubic taps for destination index d: first source index (s - 1) and the four weights
+__device__ __forceinline__ void cubic_taps(int d, float scale, int& s, float w[4]) {
+    const float A = -0.75f;
+    float f = ((float)d + 0.5f) * scale - 0.5f;
+    const float fl = floorf(f);
+    s = (int)fl;
+    const float t = f - fl;
+    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    w[3] = 1.f - w[0] - w[1] - w[2];
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// horizontal pass, then vertical pass, as cv2.resize does for float images
+__device__ __forceinline__ float cubic_sample(const float* src, int Hs, int Ws, int C, int c, int y, int x, float sy, float sx) {
+    int x0, y0;
+    float wx[4], wy[4];
+    cubic_taps(x, sx, x0, wx);
+    cubic_taps(y, sy, y0, wy);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* row = src + (long)clampi(y0 - 1 + j, 0, Hs - 1) * Ws * C + c;
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r = r + row[(long)clampi(x0 - 1 + i, 0, Ws - 1) * C] * wx[i];
+        acc = acc + r * wy[j];
+    }
+    return acc;
+}
+
+__global__ void k_lin(const uint8_t* in, float* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = srgb2lin(in[i]);
+}
+
+// diff = srgb2linear(A) - (scaling ? cubic(lin_b -> A's size) : lin_b)
+__global__ void k_diff(const uint8_t* a, const float* lin_b, int hA, int wA, int hB, int wB, int C, int scaling, float* diff) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)hA * wA * C) return;
+    const int c = (int)(i % C), x = (int)((i / C) % wA), y = (int)(i / ((long)C * wA));
+    const float b = scaling ? cubic_sample(lin_b, hB, wB, C, c, y, x, (float)hB / (float)hA, (float)wB / (float)wA) : lin_b[i];
+    diff[i] = srgb2lin(a[i]) - b;
+}
+
+// one pass of the [0.25, 0.5, 0.25] filter along x (dir 0) or y (dir 1), BORDER_REFLECT_101
+__global__ void k_gauss3(const float* in, int H, int W, int C, int dir, float* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)H * W * C) return;
+    const int c = (int)(i % C), x = (int)((i / C) % W), y = (int)(i / ((long)C * W));
+    const int n = dir ? H : W, p = dir ? y : x;
+    int lo = p - 1, hi = p + 1;
+    if (lo < 0) lo = n > 1 ? 1 : 0;
+    if (hi >= n) hi = n > 1 ? n - 2 : 0;
+    const long step = dir ? (long)W * C : C;
+    const float* base = in + i - (long)p * step;
+    (void)c;
+    out[i] = in[i] * 0.5f + (base[(long)lo * step] + base[(long)hi * step]) * 0.25f;
+}
+
+// out = linear2srgb((scaling ? cubic(blur -> B's size) : blur) + lin_b)
+__global__ void k_finish(const float* blur, const float* lin_b, int hA, int wA, int hB, int wB, int C, int scaling, uint8_t* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)hB * wB * C) return;
+    const int c = (int)(i % C), x = (int)((i / C) % wB), y = (int)(i / ((long)C * wB));
+    const float u = scaling ? cubic_sample(blur, hA, wA, C, c, y, x, (float)hA / (float)hB, (float)wA / (float)wB) : blur[i];
+    out[i] = lin2srgb(u + lin_b[i]);
+}
+
+inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t innfer_color_fix_workspace_bytes(int hA, int wA, int hB, int wB, int C) {
+    if (hA <= 0 || wA <= 0 || hB <= 0 || wB <= 0 || C <= 0) return 0;
+    return al((size_t)hB * wB * C * 4) + 2 * al((size_t)hA * wA * C * 4);
+}
+
+extern "C" int innfer_color_fix(const uint8_t* d_a, int hA, int wA, const uint8_t* d_b, int hB, int wB, int C, uint8_t* d_out,
+                                void* d_ws, size_t ws_bytes, void* stream) {
+    if (!d_a || !d_b || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "color_fix: null argument");
+    if (hA <= 0 || wA <= 0 || hB <= 0 || wB <= 0 || C <= 0 || C > 4) return set_error(INNFER_ERR_INVALID, "color_fix: bad shape");
+    const int scaling = hA < hB && wA < wB;
+    if (!scaling && (hA != hB || wA != wB))
+        return set_error(INNFER_ERR_INVALID, "color_fix: images of %dx%d and %dx%d cannot be subtracted (the reference raises too)", hA, wA, hB, wB);
+    if (ws_bytes < innfer_color_fix_workspace_bytes(hA, wA, hB, wB, C))
+        return set_error(INNFER_ERR_WORKSPACE, "color_fix: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long nA = (long)hA * wA * C, nB = (long)hB * wB * C;
+    float* lin_b = (float*)d_ws;
+    float* t0 = (float*)((char*)d_ws + al((size_t)nB * 4));
+    float* t1 = (float*)((char*)t0 + al((size_t)nA * 4));
+    hipLaunchKernelGGL(k_lin, dim3(nblk(nB)), dim3(256), 0, s, d_b, lin_b, nB);
+    hipLaunchKernelGGL(k_diff, dim3(nblk(nA)), dim3(256), 0, s, d_a, (const float*)lin_b, hA, wA, hB, wB, C, scaling, t0);
+    hipLaunchKernelGGL(k_gauss3, dim3(nblk(nA)), dim3(256), 0, s, (const float*)t0, hA, wA, C, 0, t1);
+    hipLaunchKernelGGL(k_gauss3, dim3(nblk(nA)), dim3(256), 0, s, (const float*)t1, hA, wA, C, 1, t0);
+    hipLaunchKernelGGL(k_finish, dim3(nblk(nB)), dim3(256), 0, s, (const float*)t0, (const float*)lin_b, hA, wA, hB, wB, C, scaling, d_out);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}

@@ -117,6 +117,28 @@ def tensor2np(img, rgb2bgr=True, remove_batch=True, data_range=255, denormalize=
     return out.cpu().numpy()
 
 
+def color_fix(imgA, imgB, device='cuda'):
+    """`-cf` (utils.py:278-315): add the low-frequency LR - SR difference (linear light) back to the SR
+    image.  imgA (LR) and imgB (SR) are uint8 HWC numpy images like the reference's; both cross PCIe as
+    uint8, everything else runs in libinnfer_amd.so (csrc/colorfix.hip); returns a uint8 HWC numpy image.
+    The reference's two OpenCV calls (bicubic resize, 3x3 Gaussian) follow OpenCV's published float32
+    algorithms -- OpenCV itself is not available here to compare with."""
+    for im in (imgA, imgB):
+        if not isinstance(im, np.ndarray) or im.dtype != np.uint8 or im.ndim != 3:
+            raise TypeError('color_fix: expected uint8 HWC numpy images')
+    if imgA.shape[2] != imgB.shape[2]:
+        raise ValueError('color_fix: channel counts differ')
+    hA, wA, Cc = imgA.shape
+    hB, wB, _ = imgB.shape
+    d_a = torch.from_numpy(np.ascontiguousarray(imgA)).to(device)
+    d_b = torch.from_numpy(np.ascontiguousarray(imgB)).to(device)
+    out = torch.empty((hB, wB, Cc), dtype=torch.uint8, device=d_a.device)
+    ws = torch.empty(L.lib.innfer_color_fix_workspace_bytes(hA, wA, hB, wB, Cc), dtype=torch.uint8, device=d_a.device)
+    L.check(L.lib.innfer_color_fix(d_a.data_ptr(), hA, wA, d_b.data_ptr(), hB, wB, Cc, out.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), _stream(out)))
+    return out.cpu().numpy()
+
+
 # --------------------------------------------------------------- key converters
 _NEW2OLD_FIXED = (('conv_first', 'model.0'), ('trunk_conv', 'model.1.sub.23'), ('upconv1', 'model.3'),
                   ('upconv2', 'model.6'), ('HRconv', 'model.8'), ('conv_last', 'model.10'))

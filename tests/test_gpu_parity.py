@@ -310,6 +310,29 @@ def test_unet256_big_batch_uses_wide_tiles_and_stays_identical(dev):
         assert torch.equal(y[i:i + 1], net(x[i:i + 1])), i
 
 
+def test_color_fix_vs_oracle(dev):
+    """`-cf` colour fix.  The oracle restates OpenCV's published bicubic resize and 3x3
+    Gaussian (parity with OpenCV itself is unpinned); the HIP kernels must agree with it to the uint8
+    code: the final cast truncates, so float32 rounding noise (powf) may move a value across an integer
+    boundary -- at most +-1 code, on at most 0.2 % of the values."""
+    import oracle
+    from oracle.colorfix import color_fix as ref_color_fix
+    from innfer_amd import synth
+    from innfer_amd.utils import utils as U
+    for (hA, wA, scale, Cc) in [(25, 37, 4, 3), (64, 48, 2, 3), (30, 30, 1, 3), (17, 9, 4, 1)]:
+        a = synth.image_u8(hA, wA, Cc, 3)
+        # SR image = the LR image blown up and perturbed, like a real model output
+        b = np.repeat(np.repeat(a, scale, 0), scale, 1).astype(np.int16) + (synth.image_u8(hA * scale, wA * scale, Cc, 4) % 25).astype(np.int16) - 12
+        b = np.clip(b, 0, 255).astype(np.uint8)
+        got = U.color_fix(a, b, device=dev)
+        ref = ref_color_fix(a, b)
+        assert got.shape == ref.shape and got.dtype == np.uint8
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() <= 2e-3, (hA, wA, scale, d.max(), (d > 0).mean())
+    with pytest.raises(ValueError):
+        U.color_fix(synth.image_u8(20, 20, 3, 1), synth.image_u8(10, 10, 3, 2), device=dev)      # LR larger than SR
+
+
 def test_pan_golden(dev, golden):
     """PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA self attention) against the
     reference (golden G8).  fp16 slabs between the GEMMs, fp32 accumulation / gates / softmax /
