@@ -333,6 +333,22 @@ def test_color_fix_vs_oracle(dev):
         U.color_fix(synth.image_u8(20, 20, 3, 1), synth.image_u8(10, 10, 3, 2), device=dev)      # LR larger than SR
 
 
+def test_frame_pipeline_equals_serial_loop(dev):
+    """The overlapped image loop (uint8 over PCIe on side streams) must return exactly what the serial
+    np2tensor -> model -> tensor2np loop returns, in order, with and without the colour fix."""
+    from innfer_amd import synth
+    from innfer_amd.pipeline import FramePipeline
+    from innfer_amd.utils import utils as U
+    net, _ = _rrdb(dev, 1, 2)
+    frames = [synth.image_u8(40, 56, 3, 60 + i) for i in range(7)]
+    serial = [U.tensor2np(net(U.np2tensor(f, device=dev).half())) for f in frames]
+    got = [o.copy() for o in FramePipeline(net, scale=2, device=dev, depth=3)(frames)]
+    assert len(got) == len(serial) and all(np.array_equal(a, b) for a, b in zip(got, serial))
+    fixed = [o.copy() for o in FramePipeline(net, scale=2, device=dev, depth=2, color_fix=True)(frames[:3])]
+    for f, sr, fx in zip(frames, serial, fixed):
+        assert np.array_equal(fx, U.color_fix(f, sr, device=dev))
+
+
 def test_pan_golden(dev, golden):
     """PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA self attention) against the
     reference (golden G8).  fp16 slabs between the GEMMs, fp32 accumulation / gates / softmax /
