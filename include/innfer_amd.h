@@ -137,6 +137,24 @@ size_t innfer_pan_workspace_bytes(innfer_pan_t p, int N, int H, int W);
 int innfer_pan_forward(innfer_pan_t p, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                        int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* -------------------------------------------------------------------- PPON
+ * Replaces PPON.forward with RRBlock_32 / _ResBlock_32 (architectures/PPON_arch.py:12-129): first conv,
+ * nb residual-in-residual blocks of eight dilated 3x3 convs (rates 1..8) each, the structure / perception
+ * branches and the three reconstruction heads, as utils/defaults.py:68-77 configures them (nf 64, nb 24,
+ * alpha 1).  Returns the three outputs of the reference (content, structure, perceptual); run.py keeps the
+ * last one (run.py:191-192).  Parameters are addressed by state-dict key ("CFEM.1.sub.3.RB2.d5.weight" ...).
+ */
+typedef struct innfer_ppon* innfer_ppon_t;
+int innfer_ppon_create(innfer_ppon_t* out, int in_nc, int out_nc, int nf, int nb, int scale, float alpha);
+void innfer_ppon_destroy(innfer_ppon_t p);
+int innfer_ppon_num_params(innfer_ppon_t p);
+int innfer_ppon_param_info(innfer_ppon_t p, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
+int innfer_ppon_set_param(innfer_ppon_t p, int idx, const float* h_data);
+size_t innfer_ppon_workspace_bytes(innfer_ppon_t p, int N, int H, int W);
+/* d_in [N,in_nc,H,W] -> d_out_{c,s,p} [N,out_nc,scale*H,scale*W], NCHW f16/f32; d_out_c / d_out_s may be NULL. */
+int innfer_ppon_forward(innfer_ppon_t p, const void* d_in, int in_dtype, void* d_out_c, void* d_out_s, void* d_out_p,
+                        int out_dtype, int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* -------------------------------------------------- single fused convolution
  * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution
  * over an fp16 "blocked NHWC" channel slab (conv_block, block.py:213-254).

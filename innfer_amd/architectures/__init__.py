@@ -17,7 +17,9 @@ def get_network(opt_net):
         from .UNet_arch import UnetGenerator as net
     elif kind == 'pan_net':
         from .PAN_arch import PAN as net
-    elif kind in ('mrrdb_net', 'ppon', 'resnet_net', 'wbcunet_net'):
+    elif kind == 'ppon':
+        from .PPON_arch import PPON as net
+    elif kind in ('mrrdb_net', 'resnet_net', 'wbcunet_net'):
         raise NotImplementedError(
             f'Model [{kind}] exists in the reference but is outside the MI355X hot path built so far '
             '(SURVEY.md section 8)')

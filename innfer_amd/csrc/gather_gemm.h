@@ -16,7 +16,8 @@ struct GP {
     const f16* in; long in_g; int nchunks; int N, Hin, Win;
     const f16* wpk;                       // [cot][tap][chunk][64 rows][64 B], the LDS image of the A operand
     float* out; int cout_pad;             // raw fp32 [N*Hfull*Wfull][raw_stride]; cout_pad/64 channel tiles are computed
-    int raw_stride;                       // floats per pixel of the raw buffer (<= cout_pad, multiple of 4): channels beyond it are not stored
+    int raw_stride;                       // floats per pixel of the raw buffer (multiple of 4): channels beyond it are not stored; a stride
+                                          // larger than cout_pad lets several GEMMs fill one row (out points at the first channel)
     int Ho, Wo, stride;                   // this launch's output grid; in = out*stride + d
     int ntaps; int dy[16], dx[16];
     int Hfull, Wfull, os, ooy, oox;       // out pixel = (oy*os + ooy, ox*os + oox)
@@ -213,7 +214,7 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     g.in = in; g.in_g = in_g; g.nchunks = cin_pad / 32; g.N = N; g.Hin = Hin; g.Win = Win;
     g.wpk = wpk; g.out = raw; g.cout_pad = cout_pad;
     g.raw_stride = raw_stride > 0 ? raw_stride : cout_pad;
-    if (g.raw_stride > cout_pad || (g.raw_stride & 3)) return set_error(INNFER_ERR_INVALID, "gather GEMM: bad raw stride %d", g.raw_stride);
+    if (g.raw_stride <= 0 || (g.raw_stride & 3)) return set_error(INNFER_ERR_INVALID, "gather GEMM: bad raw stride %d", g.raw_stride);
     g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps;
     for (int t = 0; t < ntaps; ++t) { g.dy[t] = dy[t]; g.dx[t] = dx[t]; }
     g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up;

@@ -1,0 +1,398 @@
+// PPON (Progressive Perception-Oriented Network) forward on gfx950 -- SURVEY.md section 8f row n3.
+// Replaces PPON.forward with RRBlock_32 / _ResBlock_32 (architectures/PPON_arch.py:12-129; defaults
+// utils/defaults.py:68-77: nf 64, nb 24, alpha 1, leakyrelu).
+//
+//   3x3 convs 64->64 (c1, LR_conv, up-convs, HR_conv0), 64->3 (HR_conv1)     conv3x3.hip (conv_launch): fused bias /
+//                                                                           LeakyReLU / nearest-2x / shortcut add
+//   first conv 3->64                                                        conv_first.hip
+//   eight dilated 3x3 convs 64->32, rates 1..8 (conv_layer(.., dilation))   gg::gemm_gather: 9 taps displaced by the
+//                                                                           rate, all eight into one fp32 row per pixel
+//   d1, d1+d2, ..., d1+..+d8 -> cat -> LeakyReLU                            ppon_comb: running sums, 256-ch fp16 slab
+//   c2 1x1 256->64, *0.2 + input (and the RRBlock's out*0.2 + input)        gg::gemm_gather (1 tap) + ppon_res
+//   out_s = SRM(..) + out_c, out_p = alpha * PRM(..) + out_s                ppon_axpy on the planar outputs
+// Activations are blocked-NHWC fp16 slabs like everywhere else; the three reconstruction heads reuse one
+// set of HR buffers.  Returns (out_c, out_s, out_p) like the reference; run.py keeps out_p.
+#include "common.h"
+#include "gather_gemm.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace innfer;
+
+namespace {
+
+// raw[px][288] fp32: eight 32-channel dilated conv results (+32 floats the last GEMM's zero channels land in)
+constexpr int RAW_ROW = 288;
+
+// comb[.., 32*r + c] = lrelu(sum_{i<=r} (raw[.., 32*i + c] + bias[32*i + c])): one thread per (pixel, 4 channels)
+__global__ void ppon_comb(const float* raw, const float* bias, long npix, f16* comb, long g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 8) return;
+    const long pix = i >> 3;
+    const int c = (int)(i & 7) * 4;
+    const float* r = raw + pix * RAW_ROW + c;
+    float run[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x4 v = *(const f32x4*)(r + 32 * k);
+        const f32x4 b = *(const f32x4*)(bias + 32 * k + c);
+        f16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            run[e] += v[e] + b[e];
+            h[e] = (f16)fmaxf(run[e], 0.2f * run[e]);
+        }
+        *(f16x4*)(comb + k * g + pix * 32 + c) = h;
+    }
+}
+
+// out = x + 0.2 * (raw2 + bias), optionally followed by the RRBlock's  out * 0.2 + rrb_in
+__global__ void ppon_res(const float* raw2, const float* bias, long npix, const f16* x, const f16* rrb_in, f16* out, long g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 16) return;
+    const long pix = i >> 4;
+    const int c = (int)(i & 15) * 4;
+    const f32x4 v = *(const f32x4*)(raw2 + pix * 64 + c);
+    const f32x4 b = *(const f32x4*)(bias + c);
+    const long o = (c >> 5) * g + pix * 32 + (c & 31);
+    const f16x4 xv = *(const f16x4*)(x + o);
+    f16x4 h;
+    if (rrb_in) {
+        const f16x4 rv = *(const f16x4*)(rrb_in + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (f16)(((float)xv[e] + (v[e] + b[e]) * 0.2f) * 0.2f + (float)rv[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (f16)((float)xv[e] + (v[e] + b[e]) * 0.2f);
+    }
+    *(f16x4*)(out + o) = h;
+}
+
+// planar outputs: dst = a * x + y   (x may alias dst)
+__global__ void ppon_axpy(const void* x, const void* y, void* dst, float a, long n, int f32) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (f32) ((float*)dst)[i] = a * ((const float*)x)[i] + ((const float*)y)[i];
+    else ((f16*)dst)[i] = (f16)(a * (float)((const f16*)x)[i] + (float)((const f16*)y)[i]);
+}
+
+struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
+
+struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr; };      // conv3x3.hip panels
+struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; f16* d_dw[8] = {}; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr; };
+struct Head { Conv3 up[2]; Conv3 hr0, hr1; };
+
+}  // namespace
+
+struct innfer_ppon {
+    int in_nc = 3, out_nc = 3, nf = 64, nb = 24, scale = 4, n_up = 2;
+    float alpha = 1.f;
+    std::vector<Param> params;
+    int fea_w = -1, fea_b = -1;
+    float* d_fea_w = nullptr; float* d_fea_b = nullptr;
+    std::vector<ResB> rbs;                   // (nb + 4) * 3 residual blocks: CFEM trunk, SFEM, PFEM
+    Conv3 lr;                                // CFEM.1.sub.<nb>
+    Head heads[3];                           // CRM, SRM, PRM
+    bool uploaded = false;
+};
+
+static int PP(innfer_ppon* p, const std::string& key, std::vector<int> shape) {
+    Param q; q.key = key; q.shape = shape;
+    p->params.push_back(q);
+    return (int)p->params.size() - 1;
+}
+
+static Conv3 add_conv3(innfer_ppon* p, const std::string& key, int K, int C) {
+    Conv3 c; c.K = K; c.C = C;
+    c.w = PP(p, key + ".weight", {K, C, 3, 3});
+    c.b = PP(p, key + ".bias", {K});
+    return c;
+}
+
+static void add_rrblock(innfer_ppon* p, const std::string& prefix) {
+    const int nf = p->nf;
+    for (int k = 1; k <= 3; ++k) {
+        const std::string b = prefix + "RB" + std::to_string(k) + ".";
+        ResB r;
+        r.c1 = add_conv3(p, b + "c1", nf, nf);
+        for (int d = 0; d < 8; ++d) {
+            r.d_w[d] = PP(p, b + "d" + std::to_string(d + 1) + ".weight", {nf / 2, nf, 3, 3});
+            r.d_b[d] = PP(p, b + "d" + std::to_string(d + 1) + ".bias", {nf / 2});
+        }
+        r.c2_w = PP(p, b + "c2.weight", {nf, nf * 4, 1, 1});
+        r.c2_b = PP(p, b + "c2.bias", {nf});
+        p->rbs.push_back(r);
+    }
+}
+
+extern "C" int innfer_ppon_create(innfer_ppon** out, int in_nc, int out_nc, int nf, int nb, int scale, float alpha) {
+    if (!out) return set_error(INNFER_ERR_INVALID, "ppon_create: null out");
+    if (nf != 64 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 16 || nb < 1 || (scale != 1 && scale != 2 && scale != 4 && scale != 8))
+        return set_error(INNFER_ERR_UNSUPPORTED, "ppon_create: nf=%d scale=%d (built: nf 64, scale 1/2/4/8)", nf, scale);
+    innfer_ppon* p = new innfer_ppon();
+    p->in_nc = in_nc; p->out_nc = out_nc; p->nf = nf; p->nb = nb; p->scale = scale; p->alpha = alpha;
+    p->n_up = scale == 8 ? 3 : (scale == 4 ? 2 : (scale == 2 ? 1 : 0));
+    p->fea_w = PP(p, "CFEM.0.weight", {nf, in_nc, 3, 3});
+    p->fea_b = PP(p, "CFEM.0.bias", {nf});
+    for (int b = 0; b < nb; ++b) add_rrblock(p, "CFEM.1.sub." + std::to_string(b) + ".");
+    p->lr = add_conv3(p, "CFEM.1.sub." + std::to_string(nb), nf, nf);
+    for (int b = 0; b < 2; ++b) add_rrblock(p, "SFEM." + std::to_string(b) + ".");
+    for (int b = 0; b < 2; ++b) add_rrblock(p, "PFEM." + std::to_string(b) + ".");
+    if (p->n_up > 2) { delete p; return set_error(INNFER_ERR_UNSUPPORTED, "ppon_create: scale 8 is not built"); }
+    const char* hn[3] = {"CRM.", "SRM.", "PRM."};
+    // the reference declares the heads in the order CRM, SRM, PRM; keys: <3u+1> up-convs, then <3n>, <3n+2>
+    for (int h = 0; h < 3; ++h) {
+        Head& H = p->heads[h];
+        for (int u = 0; u < p->n_up; ++u) H.up[u] = add_conv3(p, hn[h] + std::to_string(3 * u + 1), nf, nf);
+        H.hr0 = add_conv3(p, hn[h] + std::to_string(3 * p->n_up), nf, nf);
+        H.hr1 = add_conv3(p, hn[h] + std::to_string(3 * p->n_up + 2), out_nc, nf);
+    }
+    *out = p;
+    return INNFER_OK;
+}
+
+static void free_conv3(Conv3& c) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); c.d_w = nullptr; c.d_b = nullptr; }
+
+static void free_device(innfer_ppon* p) {
+    if (p->d_fea_w) (void)hipFree(p->d_fea_w);
+    if (p->d_fea_b) (void)hipFree(p->d_fea_b);
+    p->d_fea_w = p->d_fea_b = nullptr;
+    for (auto& r : p->rbs) {
+        free_conv3(r.c1);
+        for (int d = 0; d < 8; ++d) { if (r.d_dw[d]) (void)hipFree(r.d_dw[d]); r.d_dw[d] = nullptr; }
+        if (r.d_c2) (void)hipFree(r.d_c2);
+        if (r.d_dbias) (void)hipFree(r.d_dbias);
+        if (r.d_c2b) (void)hipFree(r.d_c2b);
+        r.d_c2 = nullptr; r.d_dbias = r.d_c2b = nullptr;
+    }
+    free_conv3(p->lr);
+    for (auto& H : p->heads) { for (auto& u : H.up) free_conv3(u); free_conv3(H.hr0); free_conv3(H.hr1); }
+}
+
+extern "C" void innfer_ppon_destroy(innfer_ppon* p) {
+    if (!p) return;
+    free_device(p);
+    delete p;
+}
+
+extern "C" int innfer_ppon_num_params(innfer_ppon* p) { return p ? (int)p->params.size() : INNFER_ERR_INVALID; }
+
+extern "C" int innfer_ppon_param_info(innfer_ppon* p, int idx, char* key, size_t key_cap, int* ndim, int* shape4) {
+    if (!p || idx < 0 || idx >= (int)p->params.size()) return set_error(INNFER_ERR_INVALID, "ppon_param_info: bad index");
+    const Param& q = p->params[idx];
+    if (key && key_cap) { strncpy(key, q.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
+    if (ndim) *ndim = (int)q.shape.size();
+    if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < q.shape.size() ? q.shape[i] : 1;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_ppon_set_param(innfer_ppon* p, int idx, const float* h_data) {
+    if (!p || idx < 0 || idx >= (int)p->params.size() || !h_data) return set_error(INNFER_ERR_INVALID, "ppon_set_param: bad arguments");
+    Param& q = p->params[idx];
+    size_t n = 1;
+    for (int s : q.shape) n *= (size_t)s;
+    q.host.assign(h_data, h_data + n);
+    q.set = true;
+    p->uploaded = false;
+    return INNFER_OK;
+}
+
+namespace {
+
+int upload_conv3(innfer_ppon* p, Conv3& c) {
+    const std::vector<float>& w = p->params[c.w].host;
+    const std::vector<float>& b = p->params[c.b].host;
+    std::vector<char> host(conv_packed_bytes(c.K, c.C));
+    conv_pack(w.data(), c.K, c.C, host.data());
+    const int per = 16 * conv_nt_for(c.K);
+    const size_t bias_n = (size_t)((c.K + per - 1) / per) * per;
+    std::vector<float> bias(bias_n, 0.f);
+    for (int k = 0; k < c.K; ++k) bias[k] = b[k];
+    INNFER_HIP(hipMalloc(&c.d_w, host.size()));
+    INNFER_HIP(hipMalloc((void**)&c.d_b, bias_n * sizeof(float)));
+    INNFER_HIP(hipMemcpy(c.d_w, host.data(), host.size(), hipMemcpyHostToDevice));
+    INNFER_HIP(hipMemcpy(c.d_b, bias.data(), bias_n * sizeof(float), hipMemcpyHostToDevice));
+    return INNFER_OK;
+}
+
+int upload(innfer_ppon* p) {
+    for (auto& q : p->params) if (!q.set) return set_error(INNFER_ERR_INVALID, "ppon: parameter '%s' was never set", q.key.c_str());
+    free_device(p);
+    const int nf = p->nf;
+    {   // first conv: [Cin*9][K] fp32, k-major (conv_first.hip)
+        const std::vector<float>& w = p->params[p->fea_w].host;
+        std::vector<float> t((size_t)p->in_nc * 9 * nf);
+        for (int ci = 0; ci < p->in_nc; ++ci)
+            for (int tp = 0; tp < 9; ++tp)
+                for (int k = 0; k < nf; ++k) t[((size_t)ci * 9 + tp) * nf + k] = w[((size_t)k * p->in_nc + ci) * 9 + tp];
+        INNFER_HIP(hipMalloc((void**)&p->d_fea_w, t.size() * sizeof(float)));
+        INNFER_HIP(hipMemcpy(p->d_fea_w, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        const std::vector<float>& b = p->params[p->fea_b].host;
+        INNFER_HIP(hipMalloc((void**)&p->d_fea_b, nf * sizeof(float)));
+        INNFER_HIP(hipMemcpy(p->d_fea_b, b.data(), nf * sizeof(float), hipMemcpyHostToDevice));
+    }
+    std::vector<f16> panel;
+    for (auto& r : p->rbs) {
+        int rc = upload_conv3(p, r.c1);
+        if (rc) return rc;
+        std::vector<float> dbias(256);
+        for (int d = 0; d < 8; ++d) {
+            const std::vector<float>& w = p->params[r.d_w[d]].host;
+            gg::pack_panels(panel, nf / 2, nf, nf, 9, [&](int co, int ci, int t) { return w[((size_t)co * nf + ci) * 9 + t]; });
+            INNFER_HIP(hipMalloc((void**)&r.d_dw[d], panel.size() * sizeof(f16)));
+            INNFER_HIP(hipMemcpy(r.d_dw[d], panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
+            const std::vector<float>& b = p->params[r.d_b[d]].host;
+            for (int k = 0; k < nf / 2; ++k) dbias[32 * d + k] = b[k];
+        }
+        INNFER_HIP(hipMalloc((void**)&r.d_dbias, 256 * sizeof(float)));
+        INNFER_HIP(hipMemcpy(r.d_dbias, dbias.data(), 256 * sizeof(float), hipMemcpyHostToDevice));
+        const std::vector<float>& w2 = p->params[r.c2_w].host;
+        gg::pack_panels(panel, nf, 4 * nf, 4 * nf, 1, [&](int co, int ci, int) { return w2[(size_t)co * 4 * nf + ci]; });
+        INNFER_HIP(hipMalloc((void**)&r.d_c2, panel.size() * sizeof(f16)));
+        INNFER_HIP(hipMemcpy(r.d_c2, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
+        INNFER_HIP(hipMalloc((void**)&r.d_c2b, nf * sizeof(float)));
+        INNFER_HIP(hipMemcpy(r.d_c2b, p->params[r.c2_b].host.data(), nf * sizeof(float), hipMemcpyHostToDevice));
+    }
+    int rc = upload_conv3(p, p->lr);
+    if (rc) return rc;
+    for (auto& H : p->heads) {
+        for (int u = 0; u < p->n_up; ++u) { rc = upload_conv3(p, H.up[u]); if (rc) return rc; }
+        rc = upload_conv3(p, H.hr0); if (rc) return rc;
+        rc = upload_conv3(p, H.hr1); if (rc) return rc;
+    }
+    p->uploaded = true;
+    return INNFER_OK;
+}
+
+struct QCarve { size_t fea, t[4], o1, comb, raw, raw2, cfem, sfem, up[2], hr, tmp_c, tmp_s, total; };
+
+QCarve qcarve(const innfer_ppon* p, int N, int H, int W, int out_elt) {
+    QCarve c{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t px = (size_t)N * H * W;
+    size_t off = 0;
+    auto slab = [&](size_t pixels, int ch) { size_t o = off; off += al(pixels * ch * 2); return o; };
+    c.fea = slab(px, 64);
+    for (int i = 0; i < 4; ++i) c.t[i] = slab(px, 64);
+    c.o1 = slab(px, 64);
+    c.comb = slab(px, 256);
+    c.raw = off; off += al(px * RAW_ROW * 4);
+    c.raw2 = off; off += al(px * 64 * 4);
+    c.cfem = slab(px, 64);
+    c.sfem = slab(px, 64);
+    size_t m = 1;
+    for (int u = 0; u < p->n_up; ++u) { m *= 4; c.up[u] = slab(px * m, 64); }
+    c.hr = slab(px * m, 64);
+    c.tmp_c = off; off += al(px * m * p->out_nc * out_elt);
+    c.tmp_s = off; off += al(px * m * p->out_nc * out_elt);
+    c.total = off;
+    return c;
+}
+
+}  // namespace
+
+extern "C" size_t innfer_ppon_workspace_bytes(innfer_ppon* p, int N, int H, int W) {
+    if (!p || N <= 0 || H <= 0 || W <= 0) return 0;
+    return qcarve(p, N, H, W, 4).total;
+}
+
+extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtype, void* d_out_c, void* d_out_s, void* d_out_p,
+                                   int out_dtype, int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!p || !d_in || !d_out_p || !d_ws) return set_error(INNFER_ERR_INVALID, "ppon_forward: null argument");
+    if (N <= 0 || H <= 0 || W <= 0) return set_error(INNFER_ERR_INVALID, "ppon_forward: bad shape");
+    if (!p->uploaded) { int rc = upload(p); if (rc) return rc; }
+    const QCarve cv = qcarve(p, N, H, W, 4);
+    if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "ppon_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    const long px = (long)N * H * W, G = px * 32;
+    const int f32o = out_dtype == INNFER_F32;
+    if (!d_out_c) d_out_c = ws + cv.tmp_c;
+    if (!d_out_s) d_out_s = ws + cv.tmp_s;
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    auto conv = [&](const Conv3& c, const f16* in, long in_g, void* out, long out_g, int h, int w, int act, int up,
+                    const f16* res, long res_g, int mode) -> int {
+        ConvLaunch L{};
+        L.in = in; L.in_gstride = in_g; L.C = c.C;
+        L.wpk = (const f16*)c.d_w; L.bias = c.d_b;
+        L.out = out; L.out_gstride = out_g; L.out_coff = 0; L.K = c.K;
+        L.N = N; L.H = h; L.W = w; L.act = act; L.up = up;
+        L.res1 = res; L.res1_gstride = res_g; L.s1 = 1.f; L.s2 = 1.f;
+        L.y0 = 0; L.y1 = h;
+        L.out_mode = mode; L.out_f32 = f32o;
+        return conv_launch(L, s);
+    };
+    f16 *FEA = (f16*)(ws + cv.fea), *O1 = (f16*)(ws + cv.o1), *COMB = (f16*)(ws + cv.comb), *CFEM = (f16*)(ws + cv.cfem),
+        *SFEM = (f16*)(ws + cv.sfem);
+    f16* T[4] = {(f16*)(ws + cv.t[0]), (f16*)(ws + cv.t[1]), (f16*)(ws + cv.t[2]), (f16*)(ws + cv.t[3])};
+    float* raw = (float*)(ws + cv.raw);
+    float* raw2 = (float*)(ws + cv.raw2);
+
+    {   // CFEM.0
+        FirstConvLaunch F{};
+        F.in = d_in; F.in_f32 = in_dtype == INNFER_F32; F.Cin = p->in_nc; F.w = p->d_fea_w; F.bias = p->d_fea_b;
+        F.out = FEA; F.out_gstride = G; F.out2 = nullptr; F.out2_gstride = 0;
+        F.K = p->nf; F.N = N; F.H = H; F.W = W; F.act = 0;
+        CK(first_conv_launch(F, s));
+    }
+    int dy[9], dx[9], d0[1] = {0};
+    size_t rbi = 0;
+    // one RRBlock: x -> RB1 -> RB2 -> RB3 -> *0.2 + x, written to `dst` (any slab but x and the two scratch slabs)
+    auto rrblock = [&](const f16* x, f16* dst, f16* sa, f16* sb) -> int {
+        const f16* cur = x;
+        for (int k = 0; k < 3; ++k) {
+            const ResB& r = p->rbs[rbi++];
+            f16* out = k == 2 ? dst : (k == 0 ? sa : sb);
+            CK(conv(r.c1, cur, G, O1, G, H, W, 1, 0, nullptr, 0, OUT_SLAB));
+            for (int d = 0; d < 8; ++d) {
+                for (int t = 0; t < 9; ++t) { dy[t] = (t / 3 - 1) * (d + 1); dx[t] = (t % 3 - 1) * (d + 1); }
+                CK(gg::launch(r.d_dw[d], 64, 64, O1, G, N, H, W, raw + 32 * d, H, W, 1, 9, dy, dx, H, W, 1, 0, 0, 0, s, nullptr, 0, RAW_ROW));
+            }
+            hipLaunchKernelGGL(ppon_comb, dim3((unsigned)((px * 8 + 255) / 256)), dim3(256), 0, s, (const float*)raw, (const float*)r.d_dbias, px, COMB, G);
+            CK(gg::launch(r.d_c2, 256, 64, COMB, G, N, H, W, raw2, H, W, 1, 1, d0, d0, H, W, 1, 0, 0, 0, s));
+            hipLaunchKernelGGL(ppon_res, dim3((unsigned)((px * 16 + 255) / 256)), dim3(256), 0, s, (const float*)raw2, (const float*)r.d_c2b, px,
+                               cur, k == 2 ? x : (const f16*)nullptr, out, G);
+            INNFER_HIP(hipGetLastError());
+            cur = out;
+        }
+        return INNFER_OK;
+    };
+    // CFEM trunk: nb RRBlocks rotating over T[0..3] (input, output and two scratch slabs are distinct), then LR_conv + shortcut
+    const f16* x = FEA;
+    for (int b = 0; b < p->nb; ++b) {
+        f16* dst = T[b % 4];
+        CK(rrblock(x, dst, T[(b + 1) % 4], T[(b + 2) % 4]));
+        x = dst;
+    }
+    CK(conv(p->lr, x, G, CFEM, G, H, W, 0, 0, FEA, G, OUT_SLAB));
+    auto recon = [&](const Head& Hd, const f16* feat, void* out) -> int {
+        const f16* t = feat;
+        long tg = G;
+        int h = H, w = W;
+        for (int u = 0; u < p->n_up; ++u) {
+            f16* dst = (f16*)(ws + cv.up[u]);
+            const long go = tg * 4;
+            CK(conv(Hd.up[u], t, tg, dst, go, 2 * h, 2 * w, 1, 1, nullptr, 0, OUT_SLAB));
+            t = dst; tg = go; h *= 2; w *= 2;
+        }
+        CK(conv(Hd.hr0, t, tg, ws + cv.hr, tg, h, w, 1, 0, nullptr, 0, OUT_SLAB));
+        CK(conv(Hd.hr1, (const f16*)(ws + cv.hr), tg, out, 0, h, w, 0, 0, nullptr, 0, OUT_NCHW));
+        return INNFER_OK;
+    };
+    const long nout = (long)N * p->out_nc * H * W * p->scale * p->scale;
+    CK(recon(p->heads[0], CFEM, d_out_c));                                           // out_c
+    CK(rrblock(CFEM, T[0], T[1], T[2]));                                             // SFEM
+    CK(rrblock(T[0], SFEM, T[1], T[2]));
+    CK(recon(p->heads[1], SFEM, d_out_s));                                           // out_s = SRM(sfem) + out_c
+    hipLaunchKernelGGL(ppon_axpy, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, (const void*)d_out_s, (const void*)d_out_c, d_out_s, 1.0f, nout, f32o);
+    CK(rrblock(SFEM, T[0], T[1], T[2]));                                             // PFEM
+    CK(rrblock(T[0], CFEM, T[1], T[2]));                                             // (CFEM's slab is free now)
+    CK(recon(p->heads[2], CFEM, d_out_p));                                           // out_p = alpha * PRM(pfem) + out_s
+    hipLaunchKernelGGL(ppon_axpy, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, (const void*)d_out_p, (const void*)d_out_s, d_out_p, p->alpha, nout, f32o);
+    INNFER_HIP(hipGetLastError());
+#undef CK
+    return INNFER_OK;
+}

@@ -45,6 +45,8 @@ def infer_from_state_dict(state_dict, scale=None, in_nc=3, out_nc=3):
         arch = 'esrgan'
     if arch == 'pan':
         return _infer_pan(state_dict, scale, in_nc, out_nc)
+    if arch == 'ppon':
+        return _infer_ppon(state_dict, scale, in_nc, out_nc)
     if arch not in ('esrgan', 'srgan'):
         raise NotImplementedError(f"'{arch}' checkpoints are recognised but not on the HIP path yet")
     top = {}                                 # N -> out channels of 'model.N.weight|bias'
@@ -79,6 +81,17 @@ def _infer_pan(state_dict, scale, in_nc, out_nc):
         scale = 2 ** sum(1 for i in ups if i % 5 == 1)
     cfg = {'type': 'pan', 'in_nc': in_nc, 'out_nc': out_nc}
     return dict(arch='pan', scale=int(scale), in_nc=in_nc, out_nc=out_nc, nf=40, nb=16, plus=False,
+                state_dict=state_dict, net_params=get_network_G_config(cfg, int(scale)))
+
+
+def _infer_ppon(state_dict, scale, in_nc, out_nc):
+    """PPON checkpoints: like PAN the reference builds the defaults with the caller's scale / in_nc / out_nc
+    (run.py:157-163); without a scale it is read off the reconstruction head (one up-conv per 2x)."""
+    if not scale:
+        idx = sorted(int(k.split('.')[1]) for k in state_dict if k.startswith('CRM.') and k.endswith('.weight'))
+        scale = 2 ** (len(idx) - 2)                      # the last two convs are HR_conv0 / HR_conv1
+    cfg = {'type': 'ppon', 'in_nc': in_nc, 'out_nc': out_nc}
+    return dict(arch='ppon', scale=int(scale), in_nc=in_nc, out_nc=out_nc, nf=64, nb=24, plus=False,
                 state_dict=state_dict, net_params=get_network_G_config(cfg, int(scale)))
 
 
@@ -141,14 +154,19 @@ class Model:
         outs = []
         with torch.no_grad():
             for i in range(0, tiles.shape[0], self.tile_batch):
-                outs.append(self.model(tiles[i:i + self.tile_batch]))
+                outs.append(self._predict(tiles[i:i + self.tile_batch]))
         hr = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
         if tile_range is not None:
             return hr
         return recompose_tensor(hr, H, W, step=step, scale=self.scale)
 
+    def _predict(self, x):
+        """self.model(x); PPON returns (content, structure, perceptual) and run.py keeps the last (run.py:191-192,220-221)."""
+        y = self.model(x)
+        return y[2] if self.arch == 'ppon' else y
+
     def __call__(self, data):
         if self.chop:
             return self.chop_forward(data, patch_size=200, step=0.5)
         with torch.no_grad():
-            return self.model(data)
+            return self._predict(data)

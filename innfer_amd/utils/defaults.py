@@ -75,7 +75,16 @@ def get_network_G_config(network_G, scale):
         cfg['self_attention'] = _pick(opts, 'self_attention', True)
         cfg['double_scpa'] = _pick(opts, 'double_scpa', False)
         cfg['ups_inter_mode'] = _pick(opts, 'ups_inter_mode', 'nearest')
-    elif (kind in ('mrrdb_net', 'mesrgan') or 'ppon' in kind
+    elif 'ppon' in kind:
+        cfg['type'] = 'ppon'
+        cfg['in_nc'] = _pick(opts, 'in_nc', 3)
+        cfg['out_nc'] = _pick(opts, 'out_nc', 3)
+        cfg['nf'] = _pick(opts, 'nf', 64)
+        cfg['nb'] = _pick(opts, 'nb', 24)
+        cfg['upscale'] = _pick(opts, 'scale', scale)
+        cfg['act_type'] = _pick(opts, 'net_act', None) or _pick(opts, 'act_type', 'leakyrelu')
+        cfg['alpha'] = _pick(opts, 'alpha', 1)
+    elif (kind in ('mrrdb_net', 'mesrgan')
           or 'wbcunet' in kind or 'resnet' in kind or 'cg' in kind):
         raise NotImplementedError(
             f'Generator model [{kind}] is a reference architecture outside the MI355X hot path built so far')

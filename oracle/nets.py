@@ -180,3 +180,54 @@ def pan_forward(sd, x, nb=16, scale=4):
     else:
         out = out + x
     return out
+
+
+def ppon_forward(sd, x, nb=24, scale=4, alpha=1.0):
+    """PPON.forward (PPON_arch.py:65-76) with RRBlock_32 / _ResBlock_32 (:79-129): every residual block is
+    c1 3x3 -> LeakyReLU(0.2) -> eight dilated 3x3 convs 64->32 (rates 1..8, :83-91) -> running sums
+    (:104-110) -> cat -> LeakyReLU -> 1x1 256->64 -> *0.2 + input.  Returns (out_c, out_s, out_p);
+    run.py keeps element [2] (run.py:191-192,220-221)."""
+    def conv(t, key, pad=1, dil=1):
+        return F.conv2d(t, sd[key + ".weight"], sd[key + ".bias"], padding=pad, dilation=dil)
+
+    def resblock(t, p):
+        o1 = F.leaky_relu(conv(t, p + "c1"), 0.2)
+        d = [conv(o1, p + f"d{r}", pad=r, dil=r) for r in range(1, 9)]
+        parts, run = [d[0]], d[0]
+        for r in range(1, 8):
+            run = run + d[r]
+            parts.append(run)
+        o2 = conv(F.leaky_relu(torch.cat(parts, 1), 0.2), p + "c2", pad=0)
+        return t + o2 * 0.2
+
+    def rrblock(t, p):
+        o = t
+        for k in (1, 2, 3):
+            o = resblock(o, p + f"RB{k}.")
+        return o * 0.2 + t
+
+    def recon(t, p):
+        n_up = 1 if scale == 3 else int(math.log(scale, 2))
+        i = 0
+        for _ in range(n_up):
+            t = F.interpolate(t, scale_factor=3.0 if scale == 3 else 2.0, mode="nearest")
+            t = F.leaky_relu(conv(t, p + f"{i + 1}"), 0.2)
+            i += 3
+        t = F.leaky_relu(conv(t, p + f"{i}"), 0.2)
+        return conv(t, p + f"{i + 2}")
+
+    fea = conv(x, "CFEM.0")
+    t = fea
+    for b in range(nb):
+        t = rrblock(t, f"CFEM.1.sub.{b}.")
+    cfem = fea + conv(t, f"CFEM.1.sub.{nb}")
+    out_c = recon(cfem, "CRM.")
+    sfem = cfem
+    for b in range(2):
+        sfem = rrblock(sfem, f"SFEM.{b}.")
+    out_s = recon(sfem, "SRM.") + out_c
+    pfem = sfem
+    for b in range(2):
+        pfem = rrblock(pfem, f"PFEM.{b}.")
+    out_p = alpha * recon(pfem, "PRM.") + out_s
+    return out_c, out_s, out_p

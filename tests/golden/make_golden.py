@@ -223,6 +223,22 @@ def g8():
     save("g8_pan", **out)
 
 
+# ---------------------------------------------------------------- G13 PPON
+def g13():
+    net = ref_net("ppon", 4)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, 0)
+    net.load_state_dict(t_sd(sd), strict=True)
+    net.eval()
+    out = {"keys": np.array(list(shapes.keys())), "shapes": np.array([str(shapes[k]) for k in shapes])}
+    for (h, w, seed) in [(24, 24, 13), (20, 28, 14)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed))
+        with torch.no_grad():
+            oc, os_, op = net(x)
+        out[f"out_c_{h}x{w}"], out[f"out_s_{h}x{w}"], out[f"out_p_{h}x{w}"] = oc.numpy(), os_.numpy(), op.numpy()
+    save("g13_ppon", **out)
+
+
 # ---------------------------------------------------------------- G9 convert
 def g9():
     ramp = (np.arange(5 * 7 * 3) * 37 % 256).astype(np.uint8).reshape(5, 7, 3)
@@ -296,6 +312,8 @@ def g12():
         rows[f"{kind}|{scale}|{json.dumps(extra, sort_keys=True)}"] = get_network_G_config(d, scale)
     for kind in ("p2p_256", "unet_256", "unet_128", "p2p_128", "unet_512"):
         rows[f"str:{kind}|1"] = get_network_G_config(kind, 1)
+    for kind, scale in (("ppon", 4), ("ppon", 2)):
+        rows[f"str:{kind}|{scale}"] = get_network_G_config(kind, scale)
     for kind, scale in (("pan", 4), ("pan_net", 2), ("pan", 1)):
         rows[f"str:{kind}|{scale}"] = get_network_G_config(kind, scale)
     rows["pan|4|" + json.dumps({"nb": 3, "in_nc": 1, "out_nc": 1}, sort_keys=True)] = get_network_G_config(
@@ -306,6 +324,6 @@ def g12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13"]
     for g in which:
         globals()[g]()

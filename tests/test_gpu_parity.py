@@ -349,6 +349,40 @@ def test_frame_pipeline_equals_serial_loop(dev):
         assert np.array_equal(fx, U.color_fix(f, sr, device=dev))
 
 
+def test_ppon_golden(dev, golden):
+    """PPON 4x (24 + 4 residual-in-residual blocks of eight dilated convs, three heads)
+    against the reference (golden G13), all three outputs.  fp16 slabs between the layers, fp32 sums:
+    tolerance 1e-2 relative to the output range (|out| up to 5.5 with the synthetic weights)."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    g = golden("g13_ppon")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    net = get_network(get_network_G_config("ppon", 4))
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    net.load_state_dict(_sd(shapes), strict=True)
+    net = net.to(dev).eval()
+    for (h, w, seed) in [(24, 24, 13), (20, 28, 14)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed)).to(dev)
+        for xin in (x, x.half()):
+            outs = net(xin)
+            assert len(outs) == 3
+            for name, y in zip("csp", outs):
+                ref = g[f"out_{name}_{h}x{w}"].astype(np.float32)
+                err = np.abs(y.float().cpu().numpy() - ref)
+                assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 2e-3 * max(1.0, np.abs(ref).max()), (name, h, w, err.max(), err.mean())
+    xb = torch.from_numpy(synth.uniform((2, 3, 24, 24), 13)).to(dev)
+    xb[1] = torch.from_numpy(synth.uniform((1, 3, 24, 24), 77)).to(dev)[0]
+    yb = net(xb)[2]
+    assert torch.equal(yb[0:1], net(xb[0:1])[2]) and torch.equal(yb[1:2], net(xb[1:2])[2])
+    # Model keeps the perceptual output (run.py:191-192)
+    from innfer_amd.run import Model
+    m = Model(None, arch="infer", device=str(dev), chop=False, state_dict=_sd(shapes))
+    assert m.arch == "ppon" and m.scale == 4
+    assert torch.equal(m(xb[0:1].half()), net(xb[0:1].half())[2])
+
+
 def test_pan_golden(dev, golden):
     """PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA self attention) against the
     reference (golden G8).  fp16 slabs between the GEMMs, fp32 accumulation / gates / softmax /

@@ -1,6 +1,7 @@
 """CPU-only tests: the C-ABI library loads and exports every declared symbol, host-side logic
 (tile geometry, blend profile, weight panels, loader, default configs, tile sharding) matches the
 golden vectors generated from the reference, and nothing silently falls back to the CPU."""
+import ast
 import ctypes as C
 import json
 import os
@@ -128,8 +129,10 @@ def test_loader_inference_matches_reference(golden):
                                  "upsample.6.weight": np.zeros(1)})
     assert pan["arch"] == "pan" and pan["scale"] == 4 and pan["net_params"]["type"] == "pan_net"
     assert infer_from_state_dict({"SCPA_trunk.0.conv1_a.weight": np.zeros(1)}, scale=2)["net_params"]["scale"] == 2
+    ppon = infer_from_state_dict({"CFEM.0.weight": np.zeros(1), "CRM.1.weight": 0, "CRM.4.weight": 0, "CRM.6.weight": 0, "CRM.8.weight": 0})
+    assert ppon["arch"] == "ppon" and ppon["scale"] == 4 and ppon["net_params"]["type"] == "ppon" and ppon["net_params"]["nb"] == 24
     with pytest.raises(NotImplementedError):
-        infer_from_state_dict({"CFEM.0.weight": np.zeros(1)})
+        infer_from_state_dict({"conv_9.weight": np.zeros(1)})
 
 
 def test_default_configs_match_reference(golden):
@@ -169,8 +172,10 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     plus = get_network(get_network_G_config({"type": "esrgan", "plus": True, "nb": 1}, 4))
     assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
     with pytest.raises(NotImplementedError):
-        get_network({"type": "ppon"})
-    import ast
+        get_network({"type": "resnet_net"})
+    g13 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_ppon.npz"))
+    ppon = get_network(get_network_G_config("ppon", 4))
+    assert {k: tuple(v.shape) for k, v in ppon.state_dict().items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g13["keys"], g13["shapes"])}
     g8 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_pan.npz"))
     pan = get_network(get_network_G_config("pan", 4))
     psd = pan.state_dict()

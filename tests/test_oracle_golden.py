@@ -133,6 +133,19 @@ def test_g8_pan(golden):
         np.testing.assert_allclose(y.numpy(), g[f"out_{h}x{w}"], atol=3e-6, rtol=0)
 
 
+def test_g13_ppon(golden):
+    g = golden("g13_ppon")
+    import ast
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = _sd(shapes)
+    for (h, w, seed) in [(24, 24, 13), (20, 28, 14)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed))
+        with torch.no_grad():
+            oc, os_, op = oracle.ppon_forward(sd, x, nb=24, scale=4)
+        for name, t in (("c", oc), ("s", os_), ("p", op)):
+            np.testing.assert_allclose(t.numpy(), g[f"out_{name}_{h}x{w}"], atol=5e-6, rtol=0)
+
+
 def test_g9_convert(golden):
     g = golden("g9_convert")
     assert np.array_equal(oracle.np2tensor(g["ramp"]).numpy(), g["np2t"])
