@@ -155,6 +155,22 @@ size_t innfer_ppon_workspace_bytes(innfer_ppon_t p, int N, int H, int W);
 int innfer_ppon_forward(innfer_ppon_t p, const void* d_in, int in_dtype, void* d_out_c, void* d_out_s, void* d_out_p,
                         int out_dtype, int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* -------------------------------------------------------- CycleGAN ResNet
+ * Replaces ResnetGenerator(norm=instance, padding=reflect, upsample=deconv).forward with ResnetBlock
+ * (architectures/ResNet_arch.py:19-151; `-a resnet_9blocks / cg_6 ...`, utils/defaults.py:124-140): reflection-padded
+ * 7x7 and 3x3 convs, two stride-2 convs, n_blocks residual blocks, two ConvTranspose2d(3,2,1,1), tanh; InstanceNorm2d
+ * without affine parameters, statistics of the instance.  H, W multiples of 4, >= 16.
+ */
+typedef struct innfer_resnet* innfer_resnet_t;
+int innfer_resnet_create(innfer_resnet_t* out, int in_nc, int out_nc, int ngf, int n_blocks);
+void innfer_resnet_destroy(innfer_resnet_t r);
+int innfer_resnet_num_params(innfer_resnet_t r);
+int innfer_resnet_param_info(innfer_resnet_t r, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
+int innfer_resnet_set_param(innfer_resnet_t r, int idx, const float* h_data);
+size_t innfer_resnet_workspace_bytes(innfer_resnet_t r, int N, int H, int W);
+int innfer_resnet_forward(innfer_resnet_t r, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                          int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* -------------------------------------------------- single fused convolution
  * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution
  * over an fp16 "blocked NHWC" channel slab (conv_block, block.py:213-254).

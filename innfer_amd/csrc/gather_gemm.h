@@ -19,7 +19,8 @@ struct GP {
     int raw_stride;                       // floats per pixel of the raw buffer (multiple of 4): channels beyond it are not stored; a stride
                                           // larger than cout_pad lets several GEMMs fill one row (out points at the first channel)
     int Ho, Wo, stride;                   // this launch's output grid; in = out*stride + d
-    int ntaps; int dy[16], dx[16];
+    int ntaps; int dy[49], dx[49];        // up to 7x7 taps
+    int reflect;                          // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d) instead of zero
     int Hfull, Wfull, os, ooy, oox;       // out pixel = (oy*os + ooy, ox*os + oox)
     int up;                               // input is read through nearest-2x upsampling (Hin, Win = source size)
     int seg;                              // k-steps per split-K segment
@@ -89,6 +90,10 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
 #pragma unroll
         for (int h = 0; h < BP; ++h) {
             int iy = soy[h] * p.stride + p.dy[t], ix = sox[h] * p.stride + p.dx[t];
+            if (p.reflect) {                                          // pad < size: one reflection is enough
+                iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
+                ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
+            }
             bool ok = sok[h] && iy >= 0 && ix >= 0;
             if (p.up) { ok = ok && iy < 2 * p.Hin && ix < 2 * p.Win; iy >>= 1; ix >>= 1; }
             else ok = ok && iy < p.Hin && ix < p.Win;
@@ -209,7 +214,7 @@ static __global__ void splitk_reduce(const float* part, long split_elems, int ks
 inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long in_g, int N, int Hin, int Win,
                   float* raw, int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx,
                   int Hfull, int Wfull, int os, int ooy, int oox, int up, hipStream_t s,
-                  float* scratch = nullptr, size_t scratch_bytes = 0, int raw_stride = 0) {
+                  float* scratch = nullptr, size_t scratch_bytes = 0, int raw_stride = 0, int reflect = 0) {
     GP g{};
     g.in = in; g.in_g = in_g; g.nchunks = cin_pad / 32; g.N = N; g.Hin = Hin; g.Win = Win;
     g.wpk = wpk; g.out = raw; g.cout_pad = cout_pad;
@@ -217,7 +222,8 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     if (g.raw_stride <= 0 || (g.raw_stride & 3)) return set_error(INNFER_ERR_INVALID, "gather GEMM: bad raw stride %d", g.raw_stride);
     g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps;
     for (int t = 0; t < ntaps; ++t) { g.dy[t] = dy[t]; g.dx[t] = dx[t]; }
-    g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up;
+    g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up; g.reflect = reflect;
+    if (ntaps < 1 || ntaps > 49) return set_error(INNFER_ERR_INVALID, "gather GEMM: %d taps", ntaps);
     const long M = (long)N * Ho * Wo;
     if (M <= 0) return INNFER_OK;
     if ((long)N * Hin * Win * 64 >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "gather GEMM: input of %d x %d x %d pixels exceeds the 2 GiB buffer window", N, Hin, Win);

@@ -1,0 +1,331 @@
+// CycleGAN ResnetGenerator forward on gfx950 -- SURVEY.md section 8f row n4.
+// Replaces ResnetGenerator(norm=instance, padding=reflect, upsample=deconv).forward with ResnetBlock
+// (architectures/ResNet_arch.py:19-151; defaults utils/defaults.py:124-140: ngf 64, 9 (or 6) blocks).
+//
+//   ReflectionPad2d(3) + 7x7 conv, ReflectionPad2d(1) + 3x3 conv      gg::gemm_gather, 49 / 9 taps, out-of-image taps
+//                                                                     read the mirrored pixel (GP.reflect)
+//   3x3 stride-2 zero-pad-1 convs                                     gg::gemm_gather (stride 2)
+//   ConvTranspose2d(3, stride 2, padding 1, output_padding 1)         four output phases (1, 2, 2, 4 taps) of the same GEMM
+//   InstanceNorm2d (no affine, statistics of the instance also under eval)   in_stats: per-(image, channel) mean / biased variance in
+//                                                                     fp32, two passes; the conv bias is folded into the shift
+//   ReLU / residual add / Tanh                                        rn_post, rn_final
+// Activations are blocked-NHWC fp16 slabs, GEMM results fp32 rows.  A batch is N independent images.
+#include "common.h"
+#include "gather_gemm.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace innfer;
+
+namespace {
+
+// out = x * alpha + shift with alpha = 1/sqrt(var + eps), shift = (bias - mean_of(x + bias)) * alpha = -mean(x) * alpha:
+// the conv bias cancels inside an instance norm, which is what this kernel computes (x = raw conv result without bias)
+__global__ __launch_bounds__(1024) void in_stats(const float* raw, int cpad, long HW, float eps, float* alpha, float* shift, int C) {
+    __shared__ float red[1024];
+    const int n = blockIdx.y, cb = blockIdx.x * 32;
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = cb + cl;
+    const float* base = raw + (long)n * HW * cpad + c;
+    auto reduce32 = [&](float v) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[cl + 32 * i];
+        __syncthreads();
+        return t;
+    };
+    float s = 0.f;
+    for (long px = pl; px < HW; px += 32) s += base[px * cpad];
+    const float mu = reduce32(s) / (float)HW;
+    s = 0.f;
+    for (long px = pl; px < HW; px += 32) { const float d = base[px * cpad] - mu; s += d * d; }
+    const float var = reduce32(s) / (float)HW;
+    if (pl == 0 && c < C) {
+        const float a = 1.0f / sqrtf(var + eps);
+        alpha[(long)n * C + c] = a;
+        shift[(long)n * C + c] = -mu * a;
+    }
+}
+
+// raw fp32 -> instance norm -> [ReLU] -> [+ residual] -> fp16 slab; one thread per (pixel, 8 channels)
+__global__ void rn_post(const float* raw, int cpad, int C, long HW, int N, const float* alpha, const float* shift, int relu,
+                        const f16* res, f16* dst, long g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C / 8;
+    if (i >= (long)N * HW * c8) return;
+    const int c = (int)(i % c8) * 8;
+    const long pix = i / c8;
+    const long n = pix / HW;
+    const float* rp = raw + pix * cpad + c;
+    const float* ap = alpha + n * C + c;
+    const float* sp = shift + n * C + c;
+    const long o = (c >> 5) * g + pix * 32 + (c & 31);
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = rp[e] * ap[e] + sp[e];
+        if (relu) v = fmaxf(v, 0.f);
+        if (res) v += (float)res[o + e];
+        h[e] = (f16)v;
+    }
+    *(f16x8*)(dst + o) = h;
+}
+
+__global__ void rn_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {     // NCHW -> one zero-padded group
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const long n = i / HW, px = i % HW;
+    f16 v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = (f16)0.f;
+    for (int c = 0; c < C; ++c) {
+        const long o = (n * C + c) * HW + px;
+        v[c] = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) slab[i * 32 + c] = v[c];
+}
+
+__global__ void rn_final(const float* raw, int rs, int C, long HW, int N, const float* bias, void* out, int out_f32) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const long n = i / HW, px = i % HW;
+    for (int c = 0; c < C; ++c) {
+        const float y = tanhf(raw[i * rs + c] + bias[c]);
+        const long o = (n * C + c) * HW + px;
+        if (out_f32) ((float*)out)[o] = y; else ((f16*)out)[o] = (f16)y;
+    }
+}
+
+struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
+struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; bool transposed = false; std::vector<f16*> d_w; float* d_b = nullptr; };
+
+}  // namespace
+
+struct innfer_resnet {
+    int in_nc = 3, out_nc = 3, ngf = 64, n_blocks = 9;
+    std::vector<Param> params;
+    std::vector<Layer> layers;       // first, down1, down2, 2*n_blocks block convs, up1, up2, last
+    bool uploaded = false;
+};
+
+static int RP(innfer_resnet* r, const std::string& key, std::vector<int> shape) {
+    Param q; q.key = key; q.shape = shape;
+    r->params.push_back(q);
+    return (int)r->params.size() - 1;
+}
+
+static void add_layer(innfer_resnet* r, const std::string& key, int cin, int cout, int k, bool transposed) {
+    Layer l; l.cin = cin; l.cout = cout; l.k = k; l.transposed = transposed;
+    l.w = RP(r, key + ".weight", transposed ? std::vector<int>{cin, cout, k, k} : std::vector<int>{cout, cin, k, k});
+    l.b = RP(r, key + ".bias", {cout});
+    r->layers.push_back(l);
+}
+
+extern "C" int innfer_resnet_create(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks) {
+    if (!out) return set_error(INNFER_ERR_INVALID, "resnet_create: null out");
+    if (ngf != 64 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || n_blocks < 0 || n_blocks > 64)
+        return set_error(INNFER_ERR_UNSUPPORTED, "resnet_create: ngf=%d n_blocks=%d (built: ngf 64)", ngf, n_blocks);
+    innfer_resnet* r = new innfer_resnet();
+    r->in_nc = in_nc; r->out_nc = out_nc; r->ngf = ngf; r->n_blocks = n_blocks;
+    add_layer(r, "model.1", in_nc, ngf, 7, false);
+    add_layer(r, "model.4", ngf, 2 * ngf, 3, false);
+    add_layer(r, "model.7", 2 * ngf, 4 * ngf, 3, false);
+    for (int i = 0; i < n_blocks; ++i) {
+        const std::string b = "model." + std::to_string(10 + i) + ".conv_block.";
+        add_layer(r, b + "1", 4 * ngf, 4 * ngf, 3, false);
+        add_layer(r, b + "5", 4 * ngf, 4 * ngf, 3, false);
+    }
+    const int i = 10 + n_blocks;
+    add_layer(r, "model." + std::to_string(i), 4 * ngf, 2 * ngf, 3, true);
+    add_layer(r, "model." + std::to_string(i + 3), 2 * ngf, ngf, 3, true);
+    add_layer(r, "model." + std::to_string(i + 7), ngf, out_nc, 7, false);
+    *out = r;
+    return INNFER_OK;
+}
+
+static void rn_free(innfer_resnet* r) {
+    for (auto& l : r->layers) {
+        for (auto w : l.d_w) if (w) (void)hipFree(w);
+        l.d_w.clear();
+        if (l.d_b) (void)hipFree(l.d_b);
+        l.d_b = nullptr;
+    }
+}
+
+extern "C" void innfer_resnet_destroy(innfer_resnet* r) {
+    if (!r) return;
+    rn_free(r);
+    delete r;
+}
+
+extern "C" int innfer_resnet_num_params(innfer_resnet* r) { return r ? (int)r->params.size() : INNFER_ERR_INVALID; }
+
+extern "C" int innfer_resnet_param_info(innfer_resnet* r, int idx, char* key, size_t key_cap, int* ndim, int* shape4) {
+    if (!r || idx < 0 || idx >= (int)r->params.size()) return set_error(INNFER_ERR_INVALID, "resnet_param_info: bad index");
+    const Param& q = r->params[idx];
+    if (key && key_cap) { strncpy(key, q.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
+    if (ndim) *ndim = (int)q.shape.size();
+    if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < q.shape.size() ? q.shape[i] : 1;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_resnet_set_param(innfer_resnet* r, int idx, const float* h_data) {
+    if (!r || idx < 0 || idx >= (int)r->params.size() || !h_data) return set_error(INNFER_ERR_INVALID, "resnet_set_param: bad arguments");
+    Param& q = r->params[idx];
+    size_t n = 1;
+    for (int s : q.shape) n *= (size_t)s;
+    q.host.assign(h_data, h_data + n);
+    q.set = true;
+    r->uploaded = false;
+    return INNFER_OK;
+}
+
+namespace {
+
+// ConvTranspose2d(3, s2, p1, op1): out[2i + a] takes in[i + d] * W[ky] for (a = 0: ky 1, d 0), (a = 1: ky 0, d +1; ky 2, d 0)
+int phase_taps1d(int a, int ky[2], int d[2]) {
+    if (a == 0) { ky[0] = 1; d[0] = 0; return 1; }
+    ky[0] = 0; d[0] = 1; ky[1] = 2; d[1] = 0;
+    return 2;
+}
+
+int rn_upload(innfer_resnet* r) {
+    for (auto& q : r->params) if (!q.set) return set_error(INNFER_ERR_INVALID, "resnet: parameter '%s' was never set", q.key.c_str());
+    rn_free(r);
+    std::vector<f16> panel;
+    for (auto& l : r->layers) {
+        const std::vector<float>& w = r->params[l.w].host;
+        const int cin_pad = (l.cin + 31) / 32 * 32, k = l.k;
+        auto put = [&](int ntaps, auto weight_of) -> int {
+            gg::pack_panels(panel, l.cout, l.cin, cin_pad, ntaps, weight_of);
+            f16* d = nullptr;
+            INNFER_HIP(hipMalloc((void**)&d, panel.size() * sizeof(f16)));
+            INNFER_HIP(hipMemcpy(d, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
+            l.d_w.push_back(d);
+            return INNFER_OK;
+        };
+        if (!l.transposed) {
+            int rc = put(k * k, [&](int co, int ci, int t) { return w[((size_t)co * l.cin + ci) * k * k + t]; });
+            if (rc) return rc;
+        } else {
+            for (int ph = 0; ph < 4; ++ph) {
+                int kyv[2], dyv[2], kxv[2], dxv[2];
+                const int ny = phase_taps1d(ph >> 1, kyv, dyv), nx = phase_taps1d(ph & 1, kxv, dxv);
+                int rc = put(ny * nx, [&](int co, int ci, int t) {
+                    const int ky = kyv[t / nx], kx = kxv[t % nx];
+                    return w[(((size_t)ci * l.cout + co) * 3 + ky) * 3 + kx];          // ConvTranspose2d weight is [in, out, kH, kW]
+                });
+                if (rc) return rc;
+            }
+        }
+        INNFER_HIP(hipMalloc((void**)&l.d_b, l.cout * sizeof(float)));
+        INNFER_HIP(hipMemcpy(l.d_b, r->params[l.b].host.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    r->uploaded = true;
+    return INNFER_OK;
+}
+
+struct RCarve { size_t x0, s1, s2, a, b, c, u1, u2, raw, alpha, shift, total; };
+
+RCarve rcarve(const innfer_resnet* r, int N, int H, int W) {
+    RCarve c{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t px = (size_t)N * H * W;
+    size_t off = 0;
+    auto slab = [&](size_t pixels, int ch) { size_t o = off; off += al(pixels * ch * 2); return o; };
+    c.x0 = slab(px, 32); c.s1 = slab(px, 64); c.s2 = slab(px / 4, 128);
+    c.a = slab(px / 16, 256); c.b = slab(px / 16, 256); c.c = slab(px / 16, 256);
+    c.u1 = slab(px / 4, 128); c.u2 = slab(px, 64);
+    c.raw = off; off += al(px * 64 * 4);               // the largest fp32 GEMM result: 64 channels at full resolution
+    c.alpha = off; off += al((size_t)N * 256 * 4);
+    c.shift = off; off += al((size_t)N * 256 * 4);
+    c.total = off;
+    (void)r;
+    return c;
+}
+
+}  // namespace
+
+extern "C" size_t innfer_resnet_workspace_bytes(innfer_resnet* r, int N, int H, int W) {
+    if (!r || N <= 0 || H <= 0 || W <= 0) return 0;
+    return rcarve(r, N, H, W).total;
+}
+
+extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                                     int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!r || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "resnet_forward: null argument");
+    if (N <= 0 || H < 16 || W < 16 || (H & 3) || (W & 3))
+        return set_error(INNFER_ERR_INVALID, "resnet_forward: H and W must be multiples of 4 and at least 16 (two stride-2 stages, reflection pads)");
+    if (!r->uploaded) { int rc = rn_upload(r); if (rc) return rc; }
+    const RCarve cv = rcarve(r, N, H, W);
+    if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "resnet_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    float* raw = (float*)(ws + cv.raw);
+    float* alpha = (float*)(ws + cv.alpha);
+    float* shift = (float*)(ws + cv.shift);
+    int dy49[49], dx49[49], dy9[9], dx9[9];
+    for (int t = 0; t < 49; ++t) { dy49[t] = t / 7 - 3; dx49[t] = t % 7 - 3; }
+    for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    // GEMM of layer l over (Hi, Wi) -> (Ho, Wo) + instance norm + [relu] [+ res] -> dst slab
+    auto norm_post = [&](const Layer& l, int Ho, int Wo, int relu, const f16* res, f16* dst) -> int {
+        const long HW = (long)Ho * Wo;
+        const int cpad = (l.cout + 63) / 64 * 64;
+        hipLaunchKernelGGL(in_stats, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, (const float*)raw, cpad, HW, 1e-5f, alpha, shift, l.cout);
+        const long total = (long)N * HW * (l.cout / 8);
+        hipLaunchKernelGGL(rn_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)raw, cpad, l.cout, HW, N,
+                           (const float*)alpha, (const float*)shift, relu, res, dst, (long)N * HW * 32);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
+    auto conv = [&](const Layer& l, const f16* in, int Hi, int Wi, int Ho, int Wo, int stride, int reflect) -> int {
+        const int cin_pad = (l.cin + 31) / 32 * 32, cout_pad = (l.cout + 63) / 64 * 64;
+        return gg::launch(l.d_w[0], cin_pad, cout_pad, in, (long)N * Hi * Wi * 32, N, Hi, Wi, raw, Ho, Wo, stride, l.k * l.k,
+                          l.k == 7 ? dy49 : dy9, l.k == 7 ? dx49 : dx9, Ho, Wo, 1, 0, 0, 0, s, nullptr, 0, 0, reflect);
+    };
+    auto deconv = [&](const Layer& l, const f16* in, int Hi, int Wi) -> int {
+        const int cin_pad = (l.cin + 31) / 32 * 32, cout_pad = (l.cout + 63) / 64 * 64;
+        for (int ph = 0; ph < 4; ++ph) {
+            int kyv[2], dyv[2], kxv[2], dxv[2], dy[4], dx[4];
+            const int ny = phase_taps1d(ph >> 1, kyv, dyv), nx = phase_taps1d(ph & 1, kxv, dxv);
+            for (int t = 0; t < ny * nx; ++t) { dy[t] = dyv[t / nx]; dx[t] = dxv[t % nx]; }
+            CK(gg::launch(l.d_w[ph], cin_pad, cout_pad, in, (long)N * Hi * Wi * 32, N, Hi, Wi, raw, Hi, Wi, 1, ny * nx, dy, dx,
+                          2 * Hi, 2 * Wi, 2, ph >> 1, ph & 1, 0, s));
+        }
+        return INNFER_OK;
+    };
+    f16 *X0 = (f16*)(ws + cv.x0), *S1 = (f16*)(ws + cv.s1), *S2 = (f16*)(ws + cv.s2), *A = (f16*)(ws + cv.a), *B = (f16*)(ws + cv.b),
+        *Cc = (f16*)(ws + cv.c), *U1 = (f16*)(ws + cv.u1), *U2 = (f16*)(ws + cv.u2);
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    size_t li = 0;
+    hipLaunchKernelGGL(rn_pre, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, r->in_nc, (long)H * W, N, X0);
+    CK(conv(r->layers[li], X0, H, W, H, W, 1, 1)); CK(norm_post(r->layers[li], H, W, 1, nullptr, S1)); ++li;          // c7s1-64
+    CK(conv(r->layers[li], S1, H, W, H2, W2, 2, 0)); CK(norm_post(r->layers[li], H2, W2, 1, nullptr, S2)); ++li;     // d128
+    CK(conv(r->layers[li], S2, H2, W2, H4, W4, 2, 0)); CK(norm_post(r->layers[li], H4, W4, 1, nullptr, A)); ++li;    // d256
+    f16* t = A;
+    f16* spare = B;
+    for (int b = 0; b < r->n_blocks; ++b) {                                                                             // R256 x n
+        CK(conv(r->layers[li], t, H4, W4, H4, W4, 1, 1)); CK(norm_post(r->layers[li], H4, W4, 1, nullptr, Cc)); ++li;
+        CK(conv(r->layers[li], Cc, H4, W4, H4, W4, 1, 1)); CK(norm_post(r->layers[li], H4, W4, 0, t, spare)); ++li;
+        f16* tmp = t; t = spare; spare = tmp;
+    }
+    CK(deconv(r->layers[li], t, H4, W4)); CK(norm_post(r->layers[li], H2, W2, 1, nullptr, U1)); ++li;                 // u128
+    CK(deconv(r->layers[li], U1, H2, W2)); CK(norm_post(r->layers[li], H, W, 1, nullptr, U2)); ++li;                  // u64
+    {   // c7s1-out + tanh
+        const Layer& l = r->layers[li];
+        const int rs = (l.cout + 3) / 4 * 4;
+        CK(gg::launch(l.d_w[0], 64, 64, U2, (long)N * H * W * 32, N, H, W, raw, H, W, 1, 49, dy49, dx49, H, W, 1, 0, 0, 0, s, nullptr, 0, rs, 1));
+        hipLaunchKernelGGL(rn_final, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, (const float*)raw, rs, l.cout, (long)H * W, N,
+                           (const float*)l.d_b, d_out, out_dtype == INNFER_F32);
+        INNFER_HIP(hipGetLastError());
+    }
+#undef CK
+    return INNFER_OK;
+}

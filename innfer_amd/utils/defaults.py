@@ -84,8 +84,17 @@ def get_network_G_config(network_G, scale):
         cfg['upscale'] = _pick(opts, 'scale', scale)
         cfg['act_type'] = _pick(opts, 'net_act', None) or _pick(opts, 'act_type', 'leakyrelu')
         cfg['alpha'] = _pick(opts, 'alpha', 1)
-    elif (kind in ('mrrdb_net', 'mesrgan')
-          or 'wbcunet' in kind or 'resnet' in kind or 'cg' in kind):
+    elif ('resnet' in kind and kind != 'sr_resnet') or 'cg' in kind:
+        cfg['type'] = 'resnet_net'
+        cfg['input_nc'] = _pick(opts, 'in_nc', 3)
+        cfg['output_nc'] = _pick(opts, 'out_nc', 3)
+        cfg['n_blocks'] = _pick(opts, 'n_blocks', 6 if kind in ('resnet_6blocks', 'resnet_6', 'cg_6') else 9)
+        cfg['ngf'] = _pick(opts, 'ngf', 64)
+        cfg['norm_type'] = _pick(opts, 'norm_type', 'instance')
+        cfg['use_dropout'] = _pick(opts, 'use_dropout', False)
+        cfg['upsample_mode'] = _pick(opts, 'upsample_mode', 'deconv')
+        cfg['padding_type'] = _pick(opts, 'padding_type', 'reflect')
+    elif kind in ('mrrdb_net', 'mesrgan') or 'wbcunet' in kind:
         raise NotImplementedError(
             f'Generator model [{kind}] is a reference architecture outside the MI355X hot path built so far')
     else:

@@ -231,3 +231,28 @@ def ppon_forward(sd, x, nb=24, scale=4, alpha=1.0):
         pfem = rrblock(pfem, f"PFEM.{b}.")
     out_p = alpha * recon(pfem, "PRM.") + out_s
     return out_c, out_s, out_p
+
+
+def resnet_forward(sd, x, n_blocks=9, eps=1e-5):
+    """ResnetGenerator(norm=instance, padding=reflect, upsample=deconv).forward (ResNet_arch.py:19-86) with
+    ResnetBlock (:89-151): c7s1-64, two stride-2 convs, n_blocks reflect-padded residual blocks, two
+    ConvTranspose2d(3, s2, p1, op1), c7s1-out, tanh.  InstanceNorm2d has no affine parameters and always
+    uses the statistics of the instance (track_running_stats=False), also under eval()."""
+    def conv(t, key, **kw):
+        return F.conv2d(t, sd[key + ".weight"], sd[key + ".bias"], **kw)
+
+    def inorm(t):
+        return F.instance_norm(t, eps=eps)
+
+    t = F.relu(inorm(conv(F.pad(x, (3, 3, 3, 3), mode="reflect"), "model.1")))
+    t = F.relu(inorm(conv(t, "model.4", stride=2, padding=1)))
+    t = F.relu(inorm(conv(t, "model.7", stride=2, padding=1)))
+    for i in range(10, 10 + n_blocks):
+        r = F.relu(inorm(conv(F.pad(t, (1, 1, 1, 1), mode="reflect"), f"model.{i}.conv_block.1")))
+        r = inorm(conv(F.pad(r, (1, 1, 1, 1), mode="reflect"), f"model.{i}.conv_block.5"))
+        t = t + r
+    i = 10 + n_blocks
+    for k in (i, i + 3):
+        t = F.conv_transpose2d(t, sd[f"model.{k}.weight"], sd[f"model.{k}.bias"], stride=2, padding=1, output_padding=1)
+        t = F.relu(inorm(t))
+    return torch.tanh(conv(F.pad(t, (3, 3, 3, 3), mode="reflect"), f"model.{i + 7}"))

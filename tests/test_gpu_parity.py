@@ -383,6 +383,36 @@ def test_ppon_golden(dev, golden):
     assert torch.equal(m(xb[0:1].half()), net(xb[0:1].half())[2])
 
 
+def test_cyclegan_resnet9_golden(dev, golden):
+    """CycleGAN ResnetGenerator, 9 blocks against the reference (golden G14): reflection
+    padding, stride-2 convs, instance norm over as few as 8x10 pixels, transposed convs, tanh.  fp16
+    activations through 23 instance norms: tolerance 3e-2 on the tanh output, mean error 10x below."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    g = golden("g14_resnet9")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    net = get_network(get_network_G_config("resnet_9blocks", 1))
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    net.load_state_dict(_sd(shapes), strict=True)
+    net = net.to(dev).eval()
+    for (h, w, seed) in [(32, 40, 15), (64, 64, 16)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0)).to(dev)
+        ref = g[f"out_{h}x{w}"].astype(np.float32)
+        for xin in (x, x.half()):
+            y = net(xin).float().cpu().numpy()
+            err = np.abs(y - ref)
+            assert np.isfinite(y).all() and np.abs(y).max() <= 1.0
+            assert err.max() < 3e-2 and err.mean() < 3e-3, (h, w, err.max(), err.mean())
+    xa = torch.from_numpy(synth.uniform((1, 3, 32, 40), 15, -1.0, 1.0)).to(dev).half()
+    xb = torch.from_numpy(synth.uniform((1, 3, 32, 40), 91, -1.0, 1.0)).to(dev).half()
+    yab = net(torch.cat([xa, xb], 0))
+    assert torch.equal(yab[0:1], net(xa)) and torch.equal(yab[1:2], net(xb))
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 30, 40, device=dev))                      # not a multiple of 4
+
+
 def test_pan_golden(dev, golden):
     """PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA self attention) against the
     reference (golden G8).  fp16 slabs between the GEMMs, fp32 accumulation / gates / softmax /

@@ -172,7 +172,12 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     plus = get_network(get_network_G_config({"type": "esrgan", "plus": True, "nb": 1}, 4))
     assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
     with pytest.raises(NotImplementedError):
-        get_network({"type": "resnet_net"})
+        get_network({"type": "wbcunet_net"})
+    g14 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g14_resnet9.npz"))
+    cg = get_network(get_network_G_config("resnet_9blocks", 1))
+    assert {k: tuple(v.shape) for k, v in cg.state_dict().items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g14["keys"], g14["shapes"])}
+    with pytest.raises(NotImplementedError):
+        get_network(get_network_G_config({"type": "resnet_9blocks", "norm_type": "batch"}, 1))
     g13 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_ppon.npz"))
     ppon = get_network(get_network_G_config("ppon", 4))
     assert {k: tuple(v.shape) for k, v in ppon.state_dict().items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g13["keys"], g13["shapes"])}

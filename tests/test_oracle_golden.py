@@ -146,6 +146,18 @@ def test_g13_ppon(golden):
             np.testing.assert_allclose(t.numpy(), g[f"out_{name}_{h}x{w}"], atol=5e-6, rtol=0)
 
 
+def test_g14_resnet9(golden):
+    g = golden("g14_resnet9")
+    import ast
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = _sd(shapes)
+    for (h, w, seed) in [(32, 40, 15), (64, 64, 16)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0))
+        with torch.no_grad():
+            y = oracle.resnet_forward(sd, x, n_blocks=9)
+        np.testing.assert_allclose(y.numpy(), g[f"out_{h}x{w}"], atol=1e-5, rtol=0)
+
+
 def test_g9_convert(golden):
     g = golden("g9_convert")
     assert np.array_equal(oracle.np2tensor(g["ramp"]).numpy(), g["np2t"])
