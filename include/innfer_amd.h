@@ -171,6 +171,25 @@ size_t innfer_resnet_workspace_bytes(innfer_resnet_t r, int N, int H, int W);
 int innfer_resnet_forward(innfer_resnet_t r, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                           int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------- WBC UNet + guided filter
+ * Replaces UnetGeneratorWBC(mode='pt').forward with ResBlock (architectures/WBCNet_arch.py:8-99; `-a wbcunet`) and
+ * guided_filter(x, y, r=1, eps) in 'regular' mode (utils/utils.py:548-626; run.py:427-429 applies it with eps 5e-3 to
+ * (input image, network output)).  H, W multiples of 4 (run.py modcrops to 4).
+ */
+typedef struct innfer_wbc* innfer_wbc_t;
+int innfer_wbc_create(innfer_wbc_t* out, int nf);
+void innfer_wbc_destroy(innfer_wbc_t u);
+int innfer_wbc_num_params(innfer_wbc_t u);
+int innfer_wbc_param_info(innfer_wbc_t u, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
+int innfer_wbc_set_param(innfer_wbc_t u, int idx, const float* h_data);
+size_t innfer_wbc_workspace_bytes(innfer_wbc_t u, int N, int H, int W);
+int innfer_wbc_forward(innfer_wbc_t u, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                       int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
+/* d_x (guidance), d_y (input), d_out: [N,C,H,W] tensors of one dtype (f16/f32); means over 3x3 windows, reflect padding. */
+size_t innfer_guided_filter_workspace_bytes(int N, int C, int H, int W);
+int innfer_guided_filter(const void* d_x, const void* d_y, int dtype, int N, int C, int H, int W, float eps, void* d_out,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* -------------------------------------------------- single fused convolution
  * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution
  * over an fp16 "blocked NHWC" channel slab (conv_block, block.py:213-254).

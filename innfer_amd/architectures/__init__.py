@@ -21,7 +21,9 @@ def get_network(opt_net):
         from .PPON_arch import PPON as net
     elif kind == 'resnet_net':
         from .ResNet_arch import ResnetGenerator as net
-    elif kind in ('mrrdb_net', 'wbcunet_net'):
+    elif kind == 'wbcunet_net':
+        from .WBCNet_arch import UnetGeneratorWBC as net
+    elif kind in ('mrrdb_net',):
         raise NotImplementedError(
             f'Model [{kind}] exists in the reference but is outside the MI355X hot path built so far '
             '(SURVEY.md section 8)')

@@ -1,0 +1,327 @@
+// White-box-Cartoonization UNet + guided filter on gfx950 -- SURVEY.md section 8f row n4 (second half).
+// Replaces UnetGeneratorWBC(mode='pt').forward with ResBlock (architectures/WBCNet_arch.py:8-99; `-a wbcunet`,
+// utils/defaults.py:90-97: nf 32) and guided_filter(x, y, r=1, eps) (utils/utils.py:548-626, run.py:427-429).
+//
+//   7x7 / 3x3 convs, stride 1 or 2, zero padding          gg::gemm_gather (49 / 9 taps, zero fill)
+//   bias, LeakyReLU(0.2), ResBlock skip                    wb_post
+//   bilinear 2x (align_corners=False) + skip addition      wb_upadd (ATen's source index / lambda arithmetic)
+//   guided filter, 3x3 box means, reflect padding          gf_ab (means, covariance, A, b) + gf_out (mean_A * x + mean_b)
+#include "common.h"
+#include "gather_gemm.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace innfer;
+
+namespace {
+
+// raw fp32 + bias -> [LeakyReLU] -> [+ residual] -> fp16 slab (or NCHW when nchw != nullptr); one thread per (pixel, 4 channels)
+__global__ void wb_post(const float* raw, int rs, int C, long npix, const float* bias, int act, const f16* res, f16* dst, long g,
+                        void* nchw, int nchw_f32, long HW) {
+    const int c4 = (C + 3) / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * c4) return;
+    const long pix = i / c4;
+    const int c = (int)(i - pix * c4) * 4;
+    const f32x4 v = *(const f32x4*)(raw + pix * rs + c);
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        y[e] = c + e < C ? v[e] + bias[c + e] : 0.f;
+        if (act) y[e] = fmaxf(y[e], 0.2f * y[e]);
+    }
+    if (nchw) {
+        const long n = pix / HW, px = pix % HW;
+        for (int e = 0; e < 4 && c + e < C; ++e) {
+            const long o = (n * C + c + e) * HW + px;
+            if (nchw_f32) ((float*)nchw)[o] = y[e]; else ((f16*)nchw)[o] = (f16)y[e];
+        }
+        return;
+    }
+    const long o = (c >> 5) * g + pix * 32 + (c & 31);
+    f16x4 h;
+    if (res) {
+        const f16x4 r = *(const f16x4*)(res + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] += (float)r[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (f16)y[e];
+    *(f16x4*)(dst + o) = h;
+}
+
+// dst[2H x 2W] = bilinear2x(src[H x W], align_corners=False) + skip; slabs of C channels; thread per (out pixel, 8 channels)
+__global__ void wb_upadd(const f16* src, long sg, const f16* skip, f16* dst, long dg, int C, int N, int H, int W) {
+    const int c8 = C / 8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ho = 2 * H, Wo = 2 * W;
+    if (i >= (long)N * Ho * Wo * c8) return;
+    const int c = (int)(i % c8) * 8;
+    const long opix = i / c8;
+    const int X = (int)(opix % Wo), Y = (int)((opix / Wo) % Ho);
+    const long n = opix / ((long)Wo * Ho);
+    // ATen area_pixel_compute_source_index (align_corners=False): src = max(0, (dst + 0.5) * 0.5 - 0.5)
+    const float fy = fmaxf(((float)Y + 0.5f) * 0.5f - 0.5f, 0.f), fx = fmaxf(((float)X + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const long so = (c >> 5) * sg + (c & 31);
+    auto at = [&](int yy, int xx) { return *(const f16x8*)(src + so + ((n * H + yy) * (long)W + xx) * 32); };
+    const f16x8 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
+    const long o = (c >> 5) * dg + opix * 32 + (c & 31);
+    const f16x8 sk = *(const f16x8*)(skip + o);
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float up = hy * (hx * (float)v00[e] + lx * (float)v01[e]) + ly * (hx * (float)v10[e] + lx * (float)v11[e]);
+        h[e] = (f16)((float)(f16)up + (float)sk[e]);          // the reference rounds the upsampled tensor to the storage type before the add
+    }
+    *(f16x8*)(dst + o) = h;
+}
+
+__global__ void wb_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const long n = i / HW, px = i % HW;
+    for (int c = 0; c < 32; ++c) {
+        f16 v = (f16)0.f;
+        if (c < C) { const long o = (n * C + c) * HW + px; v = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o]; }
+        slab[i * 32 + c] = v;
+    }
+}
+
+// ---- guided filter (r = 1) on NCHW planes --------------------------------------------------------
+__device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+__device__ __forceinline__ float ld(const void* p, long o, int f32) { return f32 ? ((const float*)p)[o] : (float)((const f16*)p)[o]; }
+
+// A = cov_xy / (var_x + eps), b = mean_y - A * mean_x  with 3x3 reflect box means (filter2D(., ones/9) / N, N = filter2D(ones))
+__global__ void gf_ab(const void* x, const void* y, int f32, long planes, int H, int W, float eps, float* A, float* B) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const long base = i - (long)Y * W - X;
+    const float k = 1.0f / 9.0f;
+    float sx = 0.f, sy = 0.f, sxy = 0.f, sxx = 0.f, sn = 0.f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const long o = base + (long)refl(Y + dy, H) * W + refl(X + dx, W);
+            const float xv = ld(x, o, f32), yv = ld(y, o, f32);
+            sx += xv * k; sy += yv * k; sxy += (xv * yv) * k; sxx += (xv * xv) * k; sn += k;
+        }
+    const float mx = sx / sn, my = sy / sn;
+    const float cov = sxy / sn - mx * my, var = sxx / sn - mx * mx;
+    const float a = cov / (var + eps);
+    A[i] = a;
+    B[i] = my - a * mx;
+}
+
+__global__ void gf_out(const float* A, const float* B, const void* x, int f32, long planes, int H, int W, void* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const long base = i - (long)Y * W - X;
+    const float k = 1.0f / 9.0f;
+    float sa = 0.f, sb = 0.f, sn = 0.f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const long o = base + (long)refl(Y + dy, H) * W + refl(X + dx, W);
+            sa += A[o] * k; sb += B[o] * k; sn += k;
+        }
+    const float v = (sa / sn) * ld(x, i, f32) + sb / sn;
+    if (f32) ((float*)out)[i] = v; else ((f16*)out)[i] = (f16)v;
+}
+
+struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
+struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; f16* d_w = nullptr; float* d_b = nullptr; };
+
+}  // namespace
+
+struct innfer_wbc {
+    int nf = 32;
+    std::vector<Param> params;
+    std::vector<Layer> layers;   // conv, conv_1..conv_4, block_0..3 (conv1, conv2), conv_5..conv_9
+    bool uploaded = false;
+};
+
+static void wb_add(innfer_wbc* u, const std::string& key, int cin, int cout, int k) {
+    Layer l; l.cin = cin; l.cout = cout; l.k = k;
+    Param pw; pw.key = key + ".weight"; pw.shape = {cout, cin, k, k}; u->params.push_back(pw); l.w = (int)u->params.size() - 1;
+    Param pb; pb.key = key + ".bias"; pb.shape = {cout}; u->params.push_back(pb); l.b = (int)u->params.size() - 1;
+    u->layers.push_back(l);
+}
+
+extern "C" int innfer_wbc_create(innfer_wbc** out, int nf) {
+    if (!out) return set_error(INNFER_ERR_INVALID, "wbc_create: null out");
+    if (nf != 32) return set_error(INNFER_ERR_UNSUPPORTED, "wbc_create: nf=%d (built: 32)", nf);
+    innfer_wbc* u = new innfer_wbc();
+    u->nf = nf;
+    wb_add(u, "conv", 3, nf, 7);
+    wb_add(u, "conv_1", nf, nf, 3); wb_add(u, "conv_2", nf, 2 * nf, 3);
+    wb_add(u, "conv_3", 2 * nf, 2 * nf, 3); wb_add(u, "conv_4", 2 * nf, 4 * nf, 3);
+    for (int b = 0; b < 4; ++b) {
+        wb_add(u, "block_" + std::to_string(b) + ".conv1", 4 * nf, 4 * nf, 3);
+        wb_add(u, "block_" + std::to_string(b) + ".conv2", 4 * nf, 4 * nf, 3);
+    }
+    wb_add(u, "conv_5", 4 * nf, 2 * nf, 3); wb_add(u, "conv_6", 2 * nf, 2 * nf, 3);
+    wb_add(u, "conv_7", 2 * nf, nf, 3); wb_add(u, "conv_8", nf, nf, 3); wb_add(u, "conv_9", nf, 3, 7);
+    *out = u;
+    return INNFER_OK;
+}
+
+static void wb_free(innfer_wbc* u) {
+    for (auto& l : u->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); l.d_w = nullptr; l.d_b = nullptr; }
+}
+
+extern "C" void innfer_wbc_destroy(innfer_wbc* u) { if (u) { wb_free(u); delete u; } }
+extern "C" int innfer_wbc_num_params(innfer_wbc* u) { return u ? (int)u->params.size() : INNFER_ERR_INVALID; }
+
+extern "C" int innfer_wbc_param_info(innfer_wbc* u, int idx, char* key, size_t key_cap, int* ndim, int* shape4) {
+    if (!u || idx < 0 || idx >= (int)u->params.size()) return set_error(INNFER_ERR_INVALID, "wbc_param_info: bad index");
+    const Param& q = u->params[idx];
+    if (key && key_cap) { strncpy(key, q.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
+    if (ndim) *ndim = (int)q.shape.size();
+    if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < q.shape.size() ? q.shape[i] : 1;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_wbc_set_param(innfer_wbc* u, int idx, const float* h_data) {
+    if (!u || idx < 0 || idx >= (int)u->params.size() || !h_data) return set_error(INNFER_ERR_INVALID, "wbc_set_param: bad arguments");
+    Param& q = u->params[idx];
+    size_t n = 1;
+    for (int s : q.shape) n *= (size_t)s;
+    q.host.assign(h_data, h_data + n);
+    q.set = true;
+    u->uploaded = false;
+    return INNFER_OK;
+}
+
+namespace {
+
+int wb_upload(innfer_wbc* u) {
+    for (auto& q : u->params) if (!q.set) return set_error(INNFER_ERR_INVALID, "wbc: parameter '%s' was never set", q.key.c_str());
+    wb_free(u);
+    std::vector<f16> panel;
+    for (auto& l : u->layers) {
+        const std::vector<float>& w = u->params[l.w].host;
+        const int cin_pad = (l.cin + 31) / 32 * 32, kk = l.k * l.k;
+        gg::pack_panels(panel, l.cout, l.cin, cin_pad, kk, [&](int co, int ci, int t) { return w[((size_t)co * l.cin + ci) * kk + t]; });
+        INNFER_HIP(hipMalloc((void**)&l.d_w, panel.size() * sizeof(f16)));
+        INNFER_HIP(hipMemcpy(l.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
+        INNFER_HIP(hipMalloc((void**)&l.d_b, l.cout * sizeof(float)));
+        INNFER_HIP(hipMemcpy(l.d_b, u->params[l.b].host.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    u->uploaded = true;
+    return INNFER_OK;
+}
+
+struct WCarve { size_t xin, x0, t1, x1, t2, a, b, c, u1, v1, u0, raw, total; };
+
+WCarve wcarve(int N, int H, int W) {
+    WCarve c{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t px = (size_t)N * H * W;
+    size_t off = 0;
+    auto slab = [&](size_t pixels, int ch) { size_t o = off; off += al(pixels * ch * 2); return o; };
+    c.xin = slab(px, 32); c.x0 = slab(px, 32);
+    c.t1 = slab(px / 4, 32); c.x1 = slab(px / 4, 64);
+    c.t2 = slab(px / 16, 64); c.a = slab(px / 16, 128); c.b = slab(px / 16, 128); c.c = slab(px / 16, 128);
+    c.u1 = slab(px / 4, 64); c.v1 = slab(px / 4, 64);
+    c.u0 = slab(px, 32);
+    c.raw = off; off += al(px * 64 * 4);
+    c.total = off;
+    return c;
+}
+
+}  // namespace
+
+extern "C" size_t innfer_wbc_workspace_bytes(innfer_wbc* u, int N, int H, int W) {
+    if (!u || N <= 0 || H <= 0 || W <= 0) return 0;
+    return wcarve(N, H, W).total;
+}
+
+extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype, void* d_out, int out_dtype,
+                                  int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!u || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "wbc_forward: null argument");
+    if (N <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3)) return set_error(INNFER_ERR_INVALID, "wbc_forward: H and W must be multiples of 4 (run.py applies modcrop(img, 4))");
+    if (!u->uploaded) { int rc = wb_upload(u); if (rc) return rc; }
+    const WCarve cv = wcarve(N, H, W);
+    if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "wbc_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    float* raw = (float*)(ws + cv.raw);
+    int dy49[49], dx49[49], dy9[9], dx9[9];
+    for (int t = 0; t < 49; ++t) { dy49[t] = t / 7 - 3; dx49[t] = t % 7 - 3; }
+    for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    size_t li = 0;
+    // conv of the next layer: in (Hi x Wi) -> (Ho x Wo), then bias / act / residual into dst (or NCHW output)
+    auto layer = [&](const f16* in, int Hi, int Wi, int stride, int act, const f16* res, f16* dst, void* nchw) -> int {
+        const Layer& l = u->layers[li++];
+        const int Ho = Hi / stride, Wo = Wi / stride;
+        const int cin_pad = (l.cin + 31) / 32 * 32, cout_pad = (l.cout + 63) / 64 * 64, rs = (l.cout + 3) / 4 * 4;
+        CK(gg::launch(l.d_w, cin_pad, cout_pad, in, (long)N * Hi * Wi * 32, N, Hi, Wi, raw, Ho, Wo, stride, l.k * l.k,
+                      l.k == 7 ? dy49 : dy9, l.k == 7 ? dx49 : dx9, Ho, Wo, 1, 0, 0, 0, s, nullptr, 0, rs));
+        const long npix = (long)N * Ho * Wo;
+        const long nthr = npix * ((l.cout + 3) / 4);
+        hipLaunchKernelGGL(wb_post, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)raw, rs, l.cout, npix, (const float*)l.d_b, act,
+                           res, dst, npix * 32, nchw, out_dtype == INNFER_F32, (long)Ho * Wo);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
+    auto upadd = [&](const f16* src, const f16* skip, f16* dst, int C, int h, int w) -> int {
+        const long nthr = (long)N * 4 * h * w * (C / 8);
+        hipLaunchKernelGGL(wb_upadd, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, src, (long)N * h * w * 32, skip, dst,
+                           (long)N * 4 * h * w * 32, C, N, h, w);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
+    f16 *XIN = (f16*)(ws + cv.xin), *X0 = (f16*)(ws + cv.x0), *T1 = (f16*)(ws + cv.t1), *X1 = (f16*)(ws + cv.x1), *T2 = (f16*)(ws + cv.t2),
+        *A = (f16*)(ws + cv.a), *B = (f16*)(ws + cv.b), *Cc = (f16*)(ws + cv.c), *U1 = (f16*)(ws + cv.u1), *V1 = (f16*)(ws + cv.v1), *U0 = (f16*)(ws + cv.u0);
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    hipLaunchKernelGGL(wb_pre, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, 3, (long)H * W, N, XIN);
+    CK(layer(XIN, H, W, 1, 1, nullptr, X0, nullptr));                      // conv
+    CK(layer(X0, H, W, 2, 1, nullptr, T1, nullptr));                       // conv_1 (stride 2)
+    CK(layer(T1, H2, W2, 1, 1, nullptr, X1, nullptr));                     // conv_2
+    CK(layer(X1, H2, W2, 2, 1, nullptr, T2, nullptr));                     // conv_3 (stride 2)
+    CK(layer(T2, H4, W4, 1, 1, nullptr, A, nullptr));                      // conv_4
+    f16* t = A;
+    f16* spare = B;
+    for (int b = 0; b < 4; ++b) {                                           // ResBlocks
+        CK(layer(t, H4, W4, 1, 1, nullptr, Cc, nullptr));
+        CK(layer(Cc, H4, W4, 1, 0, t, spare, nullptr));
+        f16* tmp = t; t = spare; spare = tmp;
+    }
+    CK(layer(t, H4, W4, 1, 1, nullptr, T2, nullptr));                      // conv_5 -> 64 ch (T2 is free)
+    CK(upadd(T2, X1, U1, 64, H4, W4));                                      // up(x2) + x1
+    CK(layer(U1, H2, W2, 1, 1, nullptr, V1, nullptr));                     // conv_6
+    CK(layer(V1, H2, W2, 1, 1, nullptr, T1, nullptr));                     // conv_7 -> 32 ch (T1 is free)
+    CK(upadd(T1, X0, U0, 32, H2, W2));                                      // up(x3) + x0
+    CK(layer(U0, H, W, 1, 1, nullptr, XIN, nullptr));                      // conv_8 (XIN is free)
+    CK(layer(XIN, H, W, 1, 0, nullptr, nullptr, d_out));                   // conv_9 -> NCHW
+#undef CK
+    return INNFER_OK;
+}
+
+extern "C" size_t innfer_guided_filter_workspace_bytes(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return 2 * (((size_t)N * C * H * W * 4 + 255) & ~(size_t)255);
+}
+
+extern "C" int innfer_guided_filter(const void* d_x, const void* d_y, int dtype, int N, int C, int H, int W, float eps, void* d_out,
+                                    void* d_ws, size_t ws_bytes, void* stream) {
+    if (!d_x || !d_y || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "guided_filter: null argument");
+    if (N <= 0 || C <= 0 || H < 2 || W < 2) return set_error(INNFER_ERR_INVALID, "guided_filter: bad shape (reflect padding needs >= 2 pixels)");
+    if (ws_bytes < innfer_guided_filter_workspace_bytes(N, C, H, W)) return set_error(INNFER_ERR_WORKSPACE, "guided_filter: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)N * C * H * W;
+    float* A = (float*)d_ws;
+    float* B = (float*)((char*)d_ws + (((size_t)n * 4 + 255) & ~(size_t)255));
+    const int f32 = dtype == INNFER_F32;
+    hipLaunchKernelGGL(gf_ab, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_x, d_y, f32, (long)N * C, H, W, eps, A, B);
+    hipLaunchKernelGGL(gf_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)A, (const float*)B, d_x, f32, (long)N * C, H, W, d_out);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}

@@ -101,6 +101,17 @@ SIGNATURES = {
     "innfer_resnet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_resnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "innfer_wbc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "innfer_wbc_destroy": (None, [C.c_void_p]),
+    "innfer_wbc_num_params": (C.c_int, [C.c_void_p]),
+    "innfer_wbc_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_wbc_set_param": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "innfer_wbc_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "innfer_wbc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "innfer_guided_filter_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "innfer_guided_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv3x3_f16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),

@@ -47,6 +47,10 @@ def infer_from_state_dict(state_dict, scale=None, in_nc=3, out_nc=3):
         return _infer_pan(state_dict, scale, in_nc, out_nc)
     if arch == 'ppon':
         return _infer_ppon(state_dict, scale, in_nc, out_nc)
+    if arch == 'wbcunet':                    # run.py:150-156: scale 1, mode 'pt', nf from the first conv
+        cfg = {'type': 'wbcunet', 'mode': 'pt', 'nf': int(state_dict['conv.weight'].shape[0])}
+        return dict(arch='wbcunet', scale=1, in_nc=3, out_nc=3, nf=cfg['nf'], nb=4, plus=False, state_dict=state_dict,
+                    net_params=get_network_G_config(cfg, 1))
     if arch not in ('esrgan', 'srgan'):
         raise NotImplementedError(f"'{arch}' checkpoints are recognised but not on the HIP path yet")
     top = {}                                 # N -> out channels of 'model.N.weight|bias'

@@ -55,7 +55,11 @@ def get_network_G_config(network_G, scale):
         cfg['convtype'] = _pick(opts, 'convtype', 'Conv2D')
         cfg['finalact'] = _pick(opts, 'finalact', None)
         cfg['res_scale'] = _pick(opts, 'res_scale', 1)
-    elif 'wbcunet' not in kind and ('unet' in kind or 'p2p' in kind):
+    elif 'wbcunet' in kind:
+        cfg['type'] = 'wbcunet_net'
+        cfg['nf'] = _pick(opts, 'nf', 32)
+        cfg['mode'] = 'tf' if 'tf' in kind else _pick(opts, 'mode', 'pt')
+    elif 'unet' in kind or 'p2p' in kind:
         cfg['type'] = 'unet_net'
         cfg['input_nc'] = _pick(opts, 'in_nc', 3)
         cfg['output_nc'] = _pick(opts, 'out_nc', 3)
@@ -94,7 +98,7 @@ def get_network_G_config(network_G, scale):
         cfg['use_dropout'] = _pick(opts, 'use_dropout', False)
         cfg['upsample_mode'] = _pick(opts, 'upsample_mode', 'deconv')
         cfg['padding_type'] = _pick(opts, 'padding_type', 'reflect')
-    elif kind in ('mrrdb_net', 'mesrgan') or 'wbcunet' in kind:
+    elif kind in ('mrrdb_net', 'mesrgan'):
         raise NotImplementedError(
             f'Generator model [{kind}] is a reference architecture outside the MI355X hot path built so far')
     else:

@@ -139,6 +139,30 @@ def color_fix(imgA, imgB, device='cuda'):
     return out.cpu().numpy()
 
 
+def guided_filter(x, y, x_HR=None, ks=None, r=None, eps=1e-2, box_kernel=None, mode='regular', conv_a=None):
+    """guided_filter (utils.py:548-626) in the form run.py uses after the WBC UNet (run.py:427-429):
+    'regular' mode, window radius 1 (3x3 box means, reflect padding); x guidance, y input, [B,C,H,W] GPU
+    tensors of one dtype.  Runs in libinnfer_amd.so (csrc/wbcunet.hip)."""
+    if mode != 'regular' or x_HR is not None or box_kernel is not None or conv_a is not None:
+        raise NotImplementedError("guided_filter: only mode='regular' without a precomputed kernel is built")
+    if ks is None:
+        if not r:
+            raise ValueError("Either kernel size (ks) or radius (r) for the window are required.")
+        ks = 2 * r + 1
+    if ks != 3:
+        raise NotImplementedError('guided_filter: only the 3x3 window (r=1) is built')
+    _need_cuda(x, 'guided_filter')
+    if x.shape != y.shape or x.dtype != y.dtype or x.dim() != 4:
+        raise ValueError('guided_filter: x and y must be [B,C,H,W] tensors of one shape and dtype')
+    x, y = x.contiguous(), y.contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    ws = torch.empty(L.lib.innfer_guided_filter_workspace_bytes(B, Cc, H, W), dtype=torch.uint8, device=x.device)
+    L.check(L.lib.innfer_guided_filter(x.data_ptr(), y.data_ptr(), _dt(x), B, Cc, H, W, float(eps), out.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream(x)))
+    return out
+
+
 # --------------------------------------------------------------- key converters
 _NEW2OLD_FIXED = (('conv_first', 'model.0'), ('trunk_conv', 'model.1.sub.23'), ('upconv1', 'model.3'),
                   ('upconv2', 'model.6'), ('HRconv', 'model.8'), ('conv_last', 'model.10'))

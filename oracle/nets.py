@@ -256,3 +256,21 @@ def resnet_forward(sd, x, n_blocks=9, eps=1e-5):
         t = F.conv_transpose2d(t, sd[f"model.{k}.weight"], sd[f"model.{k}.bias"], stride=2, padding=1, output_padding=1)
         t = F.relu(inorm(t))
     return torch.tanh(conv(F.pad(t, (3, 3, 3, 3), mode="reflect"), f"model.{i + 7}"))
+
+
+def wbcunet_forward(sd, x):
+    """UnetGeneratorWBC(mode='pt').forward (WBCNet_arch.py:22-99) with ResBlock (:8-20): no norm layers,
+    LeakyReLU(0.2), bilinear 2x upsampling (align_corners=False) + skip additions."""
+    def conv(t, key, stride=1, pad=1):
+        return F.conv2d(t, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=pad)
+    lr = lambda t: F.leaky_relu(t, 0.2)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+    x0 = lr(conv(x, "conv", pad=3))
+    x1 = lr(conv(lr(conv(x0, "conv_1", stride=2)), "conv_2"))
+    x2 = lr(conv(lr(conv(x1, "conv_3", stride=2)), "conv_4"))
+    for b in range(4):
+        x2 = conv(lr(conv(x2, f"block_{b}.conv1")), f"block_{b}.conv2") + x2
+    x2 = lr(conv(x2, "conv_5"))
+    x3 = lr(conv(lr(conv(up(x2) + x1, "conv_6")), "conv_7"))
+    x4 = lr(conv(up(x3) + x0, "conv_8"))
+    return conv(x4, "conv_9", pad=3)

@@ -254,6 +254,23 @@ def g14():
     save("g14_resnet9", **out)
 
 
+# ---------------------------------------------------------------- G15 WBC UNet + guided filter
+def g15():
+    net = ref_net("wbcunet", 1)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, 0)
+    net.load_state_dict(t_sd(sd), strict=True)
+    net.eval()
+    out = {"keys": np.array(list(shapes.keys())), "shapes": np.array([str(shapes[k]) for k in shapes])}
+    for (h, w, seed) in [(32, 40, 17), (64, 64, 18)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0))
+        with torch.no_grad():
+            y = net(x)
+            out[f"out_{h}x{w}"] = y.numpy()
+            out[f"gf_{h}x{w}"] = ref_utils.guided_filter(x, y, r=1, eps=5e-3).numpy()      # run.py:427-429
+    save("g15_wbcunet", **out)
+
+
 # ---------------------------------------------------------------- G9 convert
 def g9():
     ramp = (np.arange(5 * 7 * 3) * 37 % 256).astype(np.uint8).reshape(5, 7, 3)
@@ -327,6 +344,8 @@ def g12():
         rows[f"{kind}|{scale}|{json.dumps(extra, sort_keys=True)}"] = get_network_G_config(d, scale)
     for kind in ("p2p_256", "unet_256", "unet_128", "p2p_128", "unet_512"):
         rows[f"str:{kind}|1"] = get_network_G_config(kind, 1)
+    for kind in ("wbcunet", "wbcunet_tf"):
+        rows[f"str:{kind}|1"] = get_network_G_config(kind, 1)
     for kind in ("resnet_9blocks", "resnet_6blocks", "cg_6", "cg9"):
         rows[f"str:{kind}|1"] = get_network_G_config(kind, 1)
     for kind, scale in (("ppon", 4), ("ppon", 2)):
@@ -341,6 +360,6 @@ def g12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15"]
     for g in which:
         globals()[g]()

@@ -413,6 +413,39 @@ def test_cyclegan_resnet9_golden(dev, golden):
         net(torch.zeros(1, 3, 30, 40, device=dev))                      # not a multiple of 4
 
 
+def test_wbcunet_and_guided_filter_golden(dev, golden):
+    """White-box-Cartoonization UNet + the guided filter run.py applies to its output
+    against the reference (golden G15).  No norm layers: fp16 slabs, tolerance 5e-3 on outputs of O(0.2)."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    from innfer_amd.utils import utils as U
+    g = golden("g15_wbcunet")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    net = get_network(get_network_G_config("wbcunet", 1))
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    net.load_state_dict(_sd(shapes), strict=True)
+    net = net.to(dev).eval()
+    for (h, w, seed) in [(32, 40, 17), (64, 64, 18)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0)).to(dev)
+        ref, ref_gf = g[f"out_{h}x{w}"].astype(np.float32), g[f"gf_{h}x{w}"].astype(np.float32)
+        for xin in (x, x.half()):
+            y = net(xin)
+            err = np.abs(y.float().cpu().numpy() - ref)
+            assert err.max() < 5e-3 and err.mean() < 5e-4, (h, w, err.max(), err.mean())
+        # guided filter on the reference's own tensors (fp32): kernel vs reference
+        gf = U.guided_filter(x, torch.from_numpy(ref).to(dev), r=1, eps=5e-3).cpu().numpy()
+        assert np.abs(gf - ref_gf).max() < 2e-5
+        # and the run.py sequence end to end in fp16
+        y16 = net(x.half())
+        gf16 = U.guided_filter(x.half(), y16, r=1, eps=5e-3).float().cpu().numpy()
+        assert np.abs(gf16 - ref_gf).max() < 5e-3
+    xa = torch.from_numpy(synth.uniform((2, 3, 32, 40), 17, -1.0, 1.0)).to(dev).half()
+    yab = net(xa)
+    assert torch.equal(yab[0:1], net(xa[0:1])) and torch.equal(yab[1:2], net(xa[1:2]))
+
+
 def test_pan_golden(dev, golden):
     """PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA self attention) against the
     reference (golden G8).  fp16 slabs between the GEMMs, fp32 accumulation / gates / softmax /

@@ -131,8 +131,8 @@ def test_loader_inference_matches_reference(golden):
     assert infer_from_state_dict({"SCPA_trunk.0.conv1_a.weight": np.zeros(1)}, scale=2)["net_params"]["scale"] == 2
     ppon = infer_from_state_dict({"CFEM.0.weight": np.zeros(1), "CRM.1.weight": 0, "CRM.4.weight": 0, "CRM.6.weight": 0, "CRM.8.weight": 0})
     assert ppon["arch"] == "ppon" and ppon["scale"] == 4 and ppon["net_params"]["type"] == "ppon" and ppon["net_params"]["nb"] == 24
-    with pytest.raises(NotImplementedError):
-        infer_from_state_dict({"conv_9.weight": np.zeros(1)})
+    wbc = infer_from_state_dict({"conv_9.weight": np.zeros((3, 32, 7, 7)), "conv.weight": np.zeros((32, 3, 7, 7))})
+    assert wbc["arch"] == "wbcunet" and wbc["scale"] == 1 and wbc["net_params"] == {"type": "wbcunet_net", "nf": 32, "mode": "pt"}
 
 
 def test_default_configs_match_reference(golden):
@@ -172,7 +172,12 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     plus = get_network(get_network_G_config({"type": "esrgan", "plus": True, "nb": 1}, 4))
     assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
     with pytest.raises(NotImplementedError):
-        get_network({"type": "wbcunet_net"})
+        get_network({"type": "mrrdb_net"})
+    with pytest.raises(NotImplementedError):
+        get_network(get_network_G_config("wbcunet_tf", 1))             # TensorFlow-style padding / upsampling is not built
+    g15 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g15_wbcunet.npz"))
+    wb = get_network(get_network_G_config("wbcunet", 1))
+    assert {k: tuple(v.shape) for k, v in wb.state_dict().items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g15["keys"], g15["shapes"])}
     g14 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g14_resnet9.npz"))
     cg = get_network(get_network_G_config("resnet_9blocks", 1))
     assert {k: tuple(v.shape) for k, v in cg.state_dict().items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g14["keys"], g14["shapes"])}

@@ -158,6 +158,21 @@ def test_g14_resnet9(golden):
         np.testing.assert_allclose(y.numpy(), g[f"out_{h}x{w}"], atol=1e-5, rtol=0)
 
 
+def test_g15_wbcunet_and_guided_filter(golden):
+    from oracle.guided import guided_filter
+    g = golden("g15_wbcunet")
+    import ast
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = _sd(shapes)
+    for (h, w, seed) in [(32, 40, 17), (64, 64, 18)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0))
+        with torch.no_grad():
+            y = oracle.wbcunet_forward(sd, x)
+            gf = guided_filter(x, y, eps=5e-3)
+        np.testing.assert_allclose(y.numpy(), g[f"out_{h}x{w}"], atol=5e-6, rtol=0)
+        np.testing.assert_allclose(gf.numpy(), g[f"gf_{h}x{w}"], atol=2e-5, rtol=0)
+
+
 def test_g9_convert(golden):
     g = golden("g9_convert")
     assert np.array_equal(oracle.np2tensor(g["ramp"]).numpy(), g["np2t"])
