@@ -25,6 +25,9 @@ struct GP {
     int up;                               // input is read through nearest-2x upsampling (Hin, Win = source size)
     int seg;                              // k-steps per split-K segment
     int ksplit; long split_elems;         // ksplit > 1: blockIdx.z computes segment z and writes out + z*split_elems
+    int cout_store;                       // channels [0, cout_store) of the computed tile are written
+    int ngroup; long g_wbytes; long g_outoff; int g_tapmul;   // ngroup > 1: blockIdx.z / ksplit selects one of several convs of the SAME
+                                          // input: weights wpk + g*g_wbytes, taps * (1 + g*g_tapmul), output out + g*g_outoff
 };
 
 // 128 pixels x 64 output channels per workgroup (4 waves x (32 px x 64 co) = 8 MFMAs per wave and 32-channel
@@ -75,10 +78,12 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
         cso[h] = (sslot ^ (((srow >> 2) & 1) << 1)) * 16;             // byte offset of the channel slot stored at LDS slot sslot
     }
     const long panel_bytes = (long)p.ntaps * p.nchunks * 4096;
-    const char* wtile = (const char*)p.wpk + (long)cot * panel_bytes;
+    const int zg = p.ngroup > 1 ? (int)blockIdx.z / p.ksplit : 0, zs = (int)blockIdx.z - zg * p.ksplit;
+    const int tapmul = 1 + zg * p.g_tapmul;
+    const char* wtile = (const char*)p.wpk + zg * p.g_wbytes + (long)cot * panel_bytes;
     const int total_steps = p.ntaps * p.nchunks;
     // split-K: blockIdx.z takes the k-steps [z*seg, (z+1)*seg) and writes a partial result
-    const int step0 = p.ksplit > 1 ? blockIdx.z * p.seg : 0;
+    const int step0 = p.ksplit > 1 ? zs * p.seg : 0;
     const int nsteps = p.ksplit > 1 ? min(p.seg, total_steps - step0) : total_steps;
 
     auto issue = [&](int rel) {
@@ -89,7 +94,7 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)c * p.in_g), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int h = 0; h < BP; ++h) {
-            int iy = soy[h] * p.stride + p.dy[t], ix = sox[h] * p.stride + p.dx[t];
+            int iy = soy[h] * p.stride + p.dy[t] * tapmul, ix = sox[h] * p.stride + p.dx[t] * tapmul;
             if (p.reflect) {                                          // pad < size: one reflection is enough
                 iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
                 ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
@@ -106,7 +111,7 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + B_BYTES + j * 4096 + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
         }
 #else
-        (void)step; (void)rel; (void)wtile; (void)spix; (void)cso; (void)panel_bytes;
+        (void)step; (void)rel; (void)wtile; (void)spix; (void)cso; (void)panel_bytes; (void)tapmul;
 #endif
     };
 
@@ -152,11 +157,11 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             const int oy = (int)((m / p.Wo) % p.Ho);
             const long n = m / ((long)p.Wo * p.Ho);
             const long opix = (n * p.Hfull + (long)oy * p.os + p.ooy) * p.Wfull + (long)ox * p.os + p.oox;
-            float* op = p.out + (long)blockIdx.z * p.split_elems + opix * p.raw_stride;
+            float* op = p.out + (long)zs * p.split_elems + zg * p.g_outoff + opix * p.raw_stride;
 #pragma unroll
             for (int q = 0; q < 4 * Q; ++q) {
                 const int ch = (cot + (q >> 2)) * 64 + 16 * lg + 4 * (q & 3);
-                if (ch < p.raw_stride) *(f32x4*)(op + ch) = acc[h][q];
+                if (ch < p.cout_store) *(f32x4*)(op + ch) = acc[h][q];
             }
         }
     }
@@ -214,7 +219,8 @@ static __global__ void splitk_reduce(const float* part, long split_elems, int ks
 inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long in_g, int N, int Hin, int Win,
                   float* raw, int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx,
                   int Hfull, int Wfull, int os, int ooy, int oox, int up, hipStream_t s,
-                  float* scratch = nullptr, size_t scratch_bytes = 0, int raw_stride = 0, int reflect = 0) {
+                  float* scratch = nullptr, size_t scratch_bytes = 0, int raw_stride = 0, int reflect = 0,
+                  int ngroup = 1, long g_wbytes = 0, long g_outoff = 0, int g_tapmul = 0, int cout_store = 0) {
     GP g{};
     g.in = in; g.in_g = in_g; g.nchunks = cin_pad / 32; g.N = N; g.Hin = Hin; g.Win = Win;
     g.wpk = wpk; g.out = raw; g.cout_pad = cout_pad;
@@ -235,15 +241,18 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     const int segs = (nsteps + g.seg - 1) / g.seg;
     int ks = 1;
     if (scratch && nsteps >= 32 && (long)Ho * Wo <= split_max_px() && (size_t)segs * full <= scratch_bytes) ks = segs;
+    if (ngroup > 1) ks = 1;
     g.ksplit = ks;
+    g.cout_store = cout_store > 0 ? cout_store : (g.raw_stride < cout_pad ? g.raw_stride : cout_pad);
+    g.ngroup = ngroup; g.g_wbytes = g_wbytes; g.g_outoff = g_outoff; g.g_tapmul = g_tapmul;
     g.split_elems = ks > 1 ? (long)(full / sizeof(float)) : 0;
     if (ks > 1) g.out = scratch;
-    const bool big = ks == 1 && cout_pad % 128 == 0 && ((M + 255) / 256) * (cout_pad / 128) >= 256;
+    const bool big = ks == 1 && ngroup == 1 && cout_pad % 128 == 0 && ((M + 255) / 256) * (cout_pad / 128) >= 256;
     if (big) {
         dim3 grid((unsigned)((M + 255) / 256), (unsigned)(cout_pad / 128), 1);
         hipLaunchKernelGGL((gemm_gather<4, 2, 3>), grid, dim3(256), 0, s, g);
     } else {
-        dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64), (unsigned)ks);
+        dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64), (unsigned)(ks * ngroup));
         hipLaunchKernelGGL((gemm_gather<2, 1, 4>), grid, dim3(256), 0, s, g);
     }
     INNFER_HIP(hipGetLastError());

@@ -24,8 +24,8 @@ using namespace innfer;
 
 namespace {
 
-// raw[px][288] fp32: eight 32-channel dilated conv results (+32 floats the last GEMM's zero channels land in)
-constexpr int RAW_ROW = 288;
+// raw[px][256] fp32: the eight 32-channel dilated conv results of a residual block
+constexpr int RAW_ROW = 256;
 
 // comb[.., 32*r + c] = lrelu(sum_{i<=r} (raw[.., 32*i + c] + bias[32*i + c])): one thread per (pixel, 4 channels)
 __global__ void ppon_comb(const float* raw, const float* bias, long npix, f16* comb, long g) {
@@ -82,7 +82,7 @@ __global__ void ppon_axpy(const void* x, const void* y, void* dst, float a, long
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 
 struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr; };      // conv3x3.hip panels
-struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; f16* d_dw[8] = {}; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr; };
+struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr; };
 struct Head { Conv3 up[2]; Conv3 hr0, hr1; };
 
 }  // namespace
@@ -162,7 +162,8 @@ static void free_device(innfer_ppon* p) {
     p->d_fea_w = p->d_fea_b = nullptr;
     for (auto& r : p->rbs) {
         free_conv3(r.c1);
-        for (int d = 0; d < 8; ++d) { if (r.d_dw[d]) (void)hipFree(r.d_dw[d]); r.d_dw[d] = nullptr; }
+        if (r.d_dw) (void)hipFree(r.d_dw);
+        r.d_dw = nullptr;
         if (r.d_c2) (void)hipFree(r.d_c2);
         if (r.d_dbias) (void)hipFree(r.d_dbias);
         if (r.d_c2b) (void)hipFree(r.d_c2b);
@@ -239,14 +240,17 @@ int upload(innfer_ppon* p) {
         int rc = upload_conv3(p, r.c1);
         if (rc) return rc;
         std::vector<float> dbias(256);
+        std::vector<f16> all;                                     // the eight dilated convs' panels, back to back
         for (int d = 0; d < 8; ++d) {
             const std::vector<float>& w = p->params[r.d_w[d]].host;
             gg::pack_panels(panel, nf / 2, nf, nf, 9, [&](int co, int ci, int t) { return w[((size_t)co * nf + ci) * 9 + t]; });
-            INNFER_HIP(hipMalloc((void**)&r.d_dw[d], panel.size() * sizeof(f16)));
-            INNFER_HIP(hipMemcpy(r.d_dw[d], panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
+            r.dw_bytes = (long)(panel.size() * sizeof(f16));
+            all.insert(all.end(), panel.begin(), panel.end());
             const std::vector<float>& b = p->params[r.d_b[d]].host;
             for (int k = 0; k < nf / 2; ++k) dbias[32 * d + k] = b[k];
         }
+        INNFER_HIP(hipMalloc((void**)&r.d_dw, all.size() * sizeof(f16)));
+        INNFER_HIP(hipMemcpy(r.d_dw, all.data(), all.size() * sizeof(f16), hipMemcpyHostToDevice));
         INNFER_HIP(hipMalloc((void**)&r.d_dbias, 256 * sizeof(float)));
         INNFER_HIP(hipMemcpy(r.d_dbias, dbias.data(), 256 * sizeof(float), hipMemcpyHostToDevice));
         const std::vector<float>& w2 = p->params[r.c2_w].host;
@@ -347,10 +351,11 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
             const ResB& r = p->rbs[rbi++];
             f16* out = k == 2 ? dst : (k == 0 ? sa : sb);
             CK(conv(r.c1, cur, G, O1, G, H, W, 1, 0, nullptr, 0, OUT_SLAB));
-            for (int d = 0; d < 8; ++d) {
-                for (int t = 0; t < 9; ++t) { dy[t] = (t / 3 - 1) * (d + 1); dx[t] = (t % 3 - 1) * (d + 1); }
-                CK(gg::launch(r.d_dw[d], 64, 64, O1, G, N, H, W, raw + 32 * d, H, W, 1, 9, dy, dx, H, W, 1, 0, 0, 0, s, nullptr, 0, RAW_ROW));
-            }
+            // the eight dilated convs of the block in ONE launch: group g = rate g+1 (taps scaled by the rate),
+            // its own weight panel, its own 32-float column of the raw row
+            for (int t = 0; t < 9; ++t) { dy[t] = t / 3 - 1; dx[t] = t % 3 - 1; }
+            CK(gg::launch(r.d_dw, 64, 64, O1, G, N, H, W, raw, H, W, 1, 9, dy, dx, H, W, 1, 0, 0, 0, s, nullptr, 0, RAW_ROW, 0,
+                          8, r.dw_bytes, 32, 1, 32));
             hipLaunchKernelGGL(ppon_comb, dim3((unsigned)((px * 8 + 255) / 256)), dim3(256), 0, s, (const float*)raw, (const float*)r.d_dbias, px, COMB, G);
             CK(gg::launch(r.d_c2, 256, 64, COMB, G, N, H, W, raw2, H, W, 1, 1, d0, d0, H, W, 1, 0, 0, 0, s));
             hipLaunchKernelGGL(ppon_res, dim3((unsigned)((px * 16 + 255) / 256)), dim3(256), 0, s, (const float*)raw2, (const float*)r.d_c2b, px,
