@@ -172,12 +172,12 @@ int innfer_resnet_forward(innfer_resnet_t r, const void* d_in, int in_dtype, voi
                           int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------- WBC UNet + guided filter
- * Replaces UnetGeneratorWBC(mode='pt').forward with ResBlock (architectures/WBCNet_arch.py:8-99; `-a wbcunet`) and
+ * Replaces UnetGeneratorWBC(mode='pt' or 'tf').forward with ResBlock (architectures/WBCNet_arch.py:8-99; `-a wbcunet`) and
  * guided_filter(x, y, r=1, eps) in 'regular' mode (utils/utils.py:548-626; run.py:427-429 applies it with eps 5e-3 to
  * (input image, network output)).  H, W multiples of 4 (run.py modcrops to 4).
  */
 typedef struct innfer_wbc* innfer_wbc_t;
-int innfer_wbc_create(innfer_wbc_t* out, int nf);
+int innfer_wbc_create(innfer_wbc_t* out, int nf, int tf_mode);   /* tf_mode: tf_same_padding + tf_2xupsample_bilinear (WBCNet_arch.py:126-142) */
 void innfer_wbc_destroy(innfer_wbc_t u);
 int innfer_wbc_num_params(innfer_wbc_t u);
 int innfer_wbc_param_info(innfer_wbc_t u, int idx, char* key, size_t key_cap, int* ndim, int* shape4);

@@ -1,6 +1,7 @@
 """White-box-Cartoonization UNet shell (reference WBCNet_arch.py:22-99): parameters carry the reference's
 state-dict keys (conv, conv_1..conv_9, block_<b>.conv{1,2}), forward runs in libinnfer_amd.so
-(csrc/wbcunet.hip).  Built: mode='pt' (PyTorch padding / bilinear upsampling), nf 32, slope 0.2."""
+(csrc/wbcunet.hip).  Built: mode 'pt' (PyTorch padding / bilinear upsampling) and 'tf' (tf_same_padding,
+tf_2xupsample_bilinear), nf 32, slope 0.2."""
 from .param_module import ParamEngineModule
 
 
@@ -9,10 +10,10 @@ class UnetGeneratorWBC(ParamEngineModule):
 
     def __init__(self, nf=32, mode='pt', slope=0.2):
         super().__init__()
-        if mode != 'pt' or abs(slope - 0.2) > 1e-12:
-            raise NotImplementedError("UnetGeneratorWBC: only mode='pt' with slope 0.2 is built (the 'tf' mode pads and upsamples differently)")
+        if mode not in ('pt', 'tf') or abs(slope - 0.2) > 1e-12:
+            raise NotImplementedError("UnetGeneratorWBC: modes 'pt' / 'tf' with slope 0.2 are built")
         self.nf, self.mode = nf, mode
-        self._init_engine(nf)
+        self._init_engine(nf, 1 if mode == 'tf' else 0)
 
     def _out_shape(self, N, H, W):
         return (N, 3, H, W)

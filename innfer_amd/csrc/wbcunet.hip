@@ -1,5 +1,5 @@
 // White-box-Cartoonization UNet + guided filter on gfx950 -- SURVEY.md section 8f row n4 (second half).
-// Replaces UnetGeneratorWBC(mode='pt').forward with ResBlock (architectures/WBCNet_arch.py:8-99; `-a wbcunet`,
+// Replaces UnetGeneratorWBC(mode='pt' | 'tf').forward with ResBlock (architectures/WBCNet_arch.py:8-99; `-a wbcunet`,
 // utils/defaults.py:90-97: nf 32) and guided_filter(x, y, r=1, eps) (utils/utils.py:548-626, run.py:427-429).
 //
 //   7x7 / 3x3 convs, stride 1 or 2, zero padding          gg::gemm_gather (49 / 9 taps, zero fill)
@@ -54,7 +54,7 @@ __global__ void wb_post(const float* raw, int rs, int C, long npix, const float*
 }
 
 // dst[2H x 2W] = bilinear2x(src[H x W], align_corners=False) + skip; slabs of C channels; thread per (out pixel, 8 channels)
-__global__ void wb_upadd(const f16* src, long sg, const f16* skip, f16* dst, long dg, int C, int N, int H, int W) {
+__global__ void wb_upadd(const f16* src, long sg, const f16* skip, f16* dst, long dg, int C, int N, int H, int W, int tf) {
     const int c8 = C / 8;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Ho = 2 * H, Wo = 2 * W;
@@ -70,10 +70,24 @@ __global__ void wb_upadd(const f16* src, long sg, const f16* skip, f16* dst, lon
     const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
     const long so = (c >> 5) * sg + (c & 31);
     auto at = [&](int yy, int xx) { return *(const f16x8*)(src + so + ((n * H + yy) * (long)W + xx) * 32); };
-    const f16x8 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
     const long o = (c >> 5) * dg + opix * 32 + (c & 31);
     const f16x8 sk = *(const f16x8*)(skip + o);
     f16x8 h;
+    if (tf) {
+        // tf_2xupsample_bilinear (WBCNet_arch.py:126-137): even/even copies, the others average x[i,j] with its
+        // lower / right / lower-right (diagonal) neighbour, replicated at the border
+        const int i = Y >> 1, j = X >> 1;
+        const int i2 = (Y & 1) ? min(i + 1, H - 1) : i, j2 = (X & 1) ? min(j + 1, W - 1) : j;
+        const f16x8 a = at(i, j), b = at(i2, j2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float up = ((Y | X) & 1) ? ((float)a[e] + (float)b[e]) / 2.f : (float)a[e];
+            h[e] = (f16)((float)(f16)up + (float)sk[e]);
+        }
+        *(f16x8*)(dst + o) = h;
+        return;
+    }
+    const f16x8 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float up = hy * (hx * (float)v00[e] + lx * (float)v01[e]) + ly * (hx * (float)v10[e] + lx * (float)v11[e]);
@@ -140,7 +154,7 @@ struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; f16* d_w = nullptr;
 }  // namespace
 
 struct innfer_wbc {
-    int nf = 32;
+    int nf = 32; int tf = 0;
     std::vector<Param> params;
     std::vector<Layer> layers;   // conv, conv_1..conv_4, block_0..3 (conv1, conv2), conv_5..conv_9
     bool uploaded = false;
@@ -153,11 +167,11 @@ static void wb_add(innfer_wbc* u, const std::string& key, int cin, int cout, int
     u->layers.push_back(l);
 }
 
-extern "C" int innfer_wbc_create(innfer_wbc** out, int nf) {
+extern "C" int innfer_wbc_create(innfer_wbc** out, int nf, int tf_mode) {
     if (!out) return set_error(INNFER_ERR_INVALID, "wbc_create: null out");
     if (nf != 32) return set_error(INNFER_ERR_UNSUPPORTED, "wbc_create: nf=%d (built: 32)", nf);
     innfer_wbc* u = new innfer_wbc();
-    u->nf = nf;
+    u->nf = nf; u->tf = tf_mode ? 1 : 0;
     wb_add(u, "conv", 3, nf, 7);
     wb_add(u, "conv_1", nf, nf, 3); wb_add(u, "conv_2", nf, 2 * nf, 3);
     wb_add(u, "conv_3", 2 * nf, 2 * nf, 3); wb_add(u, "conv_4", 2 * nf, 4 * nf, 3);
@@ -254,7 +268,8 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
     float* raw = (float*)(ws + cv.raw);
     int dy49[49], dx49[49], dy9[9], dx9[9];
     for (int t = 0; t < 49; ++t) { dy49[t] = t / 7 - 3; dx49[t] = t % 7 - 3; }
-    for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
+    int dy9tf[9], dx9tf[9];                              // tf_same_padding: pad (0,1,0,1) in front of the stride-2 convs
+    for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; dy9tf[t] = t / 3; dx9tf[t] = t % 3; }
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
     size_t li = 0;
     // conv of the next layer: in (Hi x Wi) -> (Ho x Wo), then bias / act / residual into dst (or NCHW output)
@@ -263,7 +278,8 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
         const int Ho = Hi / stride, Wo = Wi / stride;
         const int cin_pad = (l.cin + 31) / 32 * 32, cout_pad = (l.cout + 63) / 64 * 64, rs = (l.cout + 3) / 4 * 4;
         CK(gg::launch(l.d_w, cin_pad, cout_pad, in, (long)N * Hi * Wi * 32, N, Hi, Wi, raw, Ho, Wo, stride, l.k * l.k,
-                      l.k == 7 ? dy49 : dy9, l.k == 7 ? dx49 : dx9, Ho, Wo, 1, 0, 0, 0, s, nullptr, 0, rs));
+                      l.k == 7 ? dy49 : (stride == 2 && u->tf ? dy9tf : dy9), l.k == 7 ? dx49 : (stride == 2 && u->tf ? dx9tf : dx9),
+                      Ho, Wo, 1, 0, 0, 0, s, nullptr, 0, rs));
         const long npix = (long)N * Ho * Wo;
         const long nthr = npix * ((l.cout + 3) / 4);
         hipLaunchKernelGGL(wb_post, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)raw, rs, l.cout, npix, (const float*)l.d_b, act,
@@ -274,7 +290,7 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
     auto upadd = [&](const f16* src, const f16* skip, f16* dst, int C, int h, int w) -> int {
         const long nthr = (long)N * 4 * h * w * (C / 8);
         hipLaunchKernelGGL(wb_upadd, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, src, (long)N * h * w * 32, skip, dst,
-                           (long)N * 4 * h * w * 32, C, N, h, w);
+                           (long)N * 4 * h * w * 32, C, N, h, w, u->tf);
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     };

@@ -101,7 +101,7 @@ SIGNATURES = {
     "innfer_resnet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_resnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "innfer_wbc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "innfer_wbc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "innfer_wbc_destroy": (None, [C.c_void_p]),
     "innfer_wbc_num_params": (C.c_int, [C.c_void_p]),
     "innfer_wbc_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -258,16 +258,34 @@ def resnet_forward(sd, x, n_blocks=9, eps=1e-5):
     return torch.tanh(conv(F.pad(t, (3, 3, 3, 3), mode="reflect"), f"model.{i + 7}"))
 
 
-def wbcunet_forward(sd, x):
-    """UnetGeneratorWBC(mode='pt').forward (WBCNet_arch.py:22-99) with ResBlock (:8-20): no norm layers,
-    LeakyReLU(0.2), bilinear 2x upsampling (align_corners=False) + skip additions."""
+def wbcunet_forward(sd, x, mode="pt"):
+    """UnetGeneratorWBC(mode).forward (WBCNet_arch.py:22-99) with ResBlock (:8-20): no norm layers,
+    LeakyReLU(0.2), 2x upsampling + skip additions.  mode 'pt': zero-padded stride-2 convs, F.interpolate
+    bilinear (align_corners=False); mode 'tf': tf_same_padding (:140-142) and tf_2xupsample_bilinear (:126-137)."""
     def conv(t, key, stride=1, pad=1):
         return F.conv2d(t, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=pad)
     lr = lambda t: F.leaky_relu(t, 0.2)
-    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+
+    def down(t, key):
+        if mode == "tf":
+            return conv(F.pad(t, (0, 1, 0, 1)), key, stride=2, pad=0)
+        return conv(t, key, stride=2)
+
+    def up(t):
+        if mode != "tf":
+            return F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+        b, c, h, w = t.shape
+        out = torch.zeros(b, c, h * 2, w * 2, dtype=t.dtype)
+        out[:, :, ::2, ::2] = t
+        p = F.pad(t, (0, 1, 0, 1), mode="replicate")
+        out[:, :, 1::2, ::2] = (p[:, :, :-1, :-1] + p[:, :, 1:, :-1]) / 2
+        out[:, :, ::2, 1::2] = (p[:, :, :-1, :-1] + p[:, :, :-1, 1:]) / 2
+        out[:, :, 1::2, 1::2] = (p[:, :, :-1, :-1] + p[:, :, 1:, 1:]) / 2
+        return out
+
     x0 = lr(conv(x, "conv", pad=3))
-    x1 = lr(conv(lr(conv(x0, "conv_1", stride=2)), "conv_2"))
-    x2 = lr(conv(lr(conv(x1, "conv_3", stride=2)), "conv_4"))
+    x1 = lr(conv(lr(down(x0, "conv_1")), "conv_2"))
+    x2 = lr(conv(lr(down(x1, "conv_3")), "conv_4"))
     for b in range(4):
         x2 = conv(lr(conv(x2, f"block_{b}.conv1")), f"block_{b}.conv2") + x2
     x2 = lr(conv(x2, "conv_5"))

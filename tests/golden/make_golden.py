@@ -268,6 +268,12 @@ def g15():
             y = net(x)
             out[f"out_{h}x{w}"] = y.numpy()
             out[f"gf_{h}x{w}"] = ref_utils.guided_filter(x, y, r=1, eps=5e-3).numpy()      # run.py:427-429
+    net_tf = ref_net("wbcunet_tf", 1)
+    net_tf.load_state_dict(t_sd(sd), strict=True)
+    net_tf.eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 17, -1.0, 1.0))
+    with torch.no_grad():
+        out["out_tf_32x40"] = net_tf(x).numpy()
     save("g15_wbcunet", **out)
 
 

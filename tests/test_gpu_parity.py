@@ -444,6 +444,13 @@ def test_wbcunet_and_guided_filter_golden(dev, golden):
     xa = torch.from_numpy(synth.uniform((2, 3, 32, 40), 17, -1.0, 1.0)).to(dev).half()
     yab = net(xa)
     assert torch.equal(yab[0:1], net(xa[0:1])) and torch.equal(yab[1:2], net(xa[1:2]))
+    # the TensorFlow-converted variant: tf_same_padding in front of the stride-2 convs, tf_2xupsample_bilinear
+    net_tf = get_network(get_network_G_config("wbcunet_tf", 1))
+    net_tf.load_state_dict(_sd(shapes), strict=True)
+    net_tf = net_tf.to(dev).eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 17, -1.0, 1.0)).to(dev)
+    err = np.abs(net_tf(x).float().cpu().numpy() - g["out_tf_32x40"])
+    assert err.max() < 5e-3 and err.mean() < 5e-4, (err.max(), err.mean())
 
 
 def test_pan_golden(dev, golden):

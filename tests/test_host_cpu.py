@@ -173,8 +173,7 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
     with pytest.raises(NotImplementedError):
         get_network({"type": "mrrdb_net"})
-    with pytest.raises(NotImplementedError):
-        get_network(get_network_G_config("wbcunet_tf", 1))             # TensorFlow-style padding / upsampling is not built
+    assert get_network(get_network_G_config("wbcunet_tf", 1)).mode == "tf"
     g15 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g15_wbcunet.npz"))
     wb = get_network(get_network_G_config("wbcunet", 1))
     assert {k: tuple(v.shape) for k, v in wb.state_dict().items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g15["keys"], g15["shapes"])}

@@ -171,6 +171,9 @@ def test_g15_wbcunet_and_guided_filter(golden):
             gf = guided_filter(x, y, eps=5e-3)
         np.testing.assert_allclose(y.numpy(), g[f"out_{h}x{w}"], atol=5e-6, rtol=0)
         np.testing.assert_allclose(gf.numpy(), g[f"gf_{h}x{w}"], atol=2e-5, rtol=0)
+    x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 17, -1.0, 1.0))
+    with torch.no_grad():
+        np.testing.assert_allclose(oracle.wbcunet_forward(sd, x, mode="tf").numpy(), g["out_tf_32x40"], atol=5e-6, rtol=0)
 
 
 def test_g9_convert(golden):
