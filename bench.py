@@ -237,11 +237,11 @@ def main():
         from innfer_amd import parallel
         H, W = (4320, 7680) if args.workload == "chop8k" else (2160, 3840)       # chop4k and chain4k: 4K input
         x = torch.from_numpy(synth.uniform((1, 3, H, W), 2)).to(dev).half()
-        runner = parallel.ChopRunner(net, scale=4, tile_batch=args.tile_batch or 16)
+        runner = parallel.ChopRunner(net, scale=4, tile_batch=args.tile_batch or 64)
         out_pix_per_rank = 16 * H * W / world       # unique output pixels of the ONE shared frame
         if args.workload == "chain4k":              # BASELINE config 4: model chain 1x + 4x (run.py:424-426)
             net1, _ = build_net(dev, scale=1)
-            runner1 = parallel.ChopRunner(net1, scale=1, tile_batch=args.tile_batch or 16)
+            runner1 = parallel.ChopRunner(net1, scale=1, tile_batch=args.tile_batch or 64)
 
             def step():
                 return parallel.run_chain([runner1, runner], x)

@@ -41,7 +41,7 @@ class ChopRunner:
     (all ranks get it with broadcast_result=True, used between chained models).
     """
 
-    def __init__(self, model_fn, scale, tile_batch=32, patch=200, step=0.5, group=None,
+    def __init__(self, model_fn, scale, tile_batch=64, patch=200, step=0.5, group=None,
                  extract_fn=None, recompose_fn=None, plan_fn=None):
         self.model_fn, self.scale, self.tile_batch = model_fn, scale, tile_batch
         self.patch, self.step, self.group = patch, step, group

@@ -101,7 +101,7 @@ def _infer_ppon(state_dict, scale, in_nc, out_nc):
 
 class Model:
     def __init__(self, model_path, arch=None, scale=None, in_nc=3, out_nc=3, device='cuda',
-                 meval=True, strict=True, chop=True, tile_batch=16, state_dict=None):
+                 meval=True, strict=True, chop=True, tile_batch=64, state_dict=None):
         self.model_path = model_path
         self.arch = arch
         self.scale = scale
