@@ -214,10 +214,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # INNFER_BENCH_DRYRUN=1: control-flow rehearsal of the N>1 path on a ONE-GPU box (every rank on cuda:0, gloo
+    # rendezvous); never a measurement.
+    dryrun = world > 1 and os.environ.get("INNFER_BENCH_DRYRUN") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dryrun:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from innfer_amd import synth
     net, _ = build_net(dev)
@@ -232,7 +240,7 @@ def main():
             return net(x)
         cfg = {"workload": f"ESRGAN RRDBNet-23 4x fp16, 1x3x{H}x{W} -> 1x3x{4 * H}x{4 * W}, un-tiled "
                            f"(Model(chop=False)), one frame per rank", "band_rows": args.band_rows,
-               "parallelism": f"frame replicas x{world}" if world > 1 else "single GPU"}
+               "parallelism": (f"frame replicas x{world}" if world > 1 else "single GPU") + (" (DRY RUN: all ranks on one GPU)" if dryrun else "")}
     else:
         from innfer_amd import parallel
         H, W = (4320, 7680) if args.workload == "chop8k" else (2160, 3840)       # chop4k and chain4k: 4K input
@@ -272,7 +280,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall], dtype=torch.float64, device="cpu" if dryrun else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = t.item()
