@@ -739,15 +739,32 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
+// Per-device state (a process may drive several GPUs): CU count, and which devices already carry a kernel's
+// dynamic-LDS attribute (function attributes belong to the device's copy of the code object).
+int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 ? dev : 0;
+}
+
 int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
+    static int n[64] = {};
+    const int dev = current_device() & 63;
+    if (!n[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev] = v;
     }
-    return n;
+    return n[dev];
+}
+
+template <typename F>
+int ensure_lds_attr(F* kernel, int lds_bytes, unsigned long long& done_mask) {
+    const unsigned long long bit = 1ull << (current_device() & 63);
+    if (!(done_mask & bit)) {
+        INNFER_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        done_mask |= bit;
+    }
+    return INNFER_OK;
 }
 
 
@@ -755,12 +772,8 @@ template <int RPW, int NT, int OUTMODE>
 int launch_t(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 4 * RPW;
     constexpr int LDS = (((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64 + ((RPW == 3 && NT == 2) ? 0 : 2048);   // + prefetch scratch
-    static bool attr_done = false;
-    if (!attr_done) {
-        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma<RPW, NT, OUTMODE>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = ensure_lds_attr(conv3x3_mfma<RPW, NT, OUTMODE>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
@@ -788,11 +801,8 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
     constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        INNFER_HIP(hipFuncSetAttribute((const void*)conv3x3_pc<RPW, NT, NLW, OUTMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;

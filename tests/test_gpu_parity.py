@@ -215,6 +215,23 @@ def test_rrdbnet_batch_and_ragged_sizes(dev):
     assert torch.equal(y0, y[1:2])                 # batching does not change a tile's result
 
 
+def test_rrdbnet_degenerate_sizes(dev):
+    """Edge sizes: a single pixel, one-pixel-wide rows / columns, sizes below one MFMA tile, a chop of an image smaller
+    than the patch.  (An empty batch is an argument error, as nn.Conv2d's 'non-zero batch' check is in the reference.)"""
+    import oracle
+    from innfer_amd import synth
+    net, sd = _rrdb(dev, 1, 4)
+    for i, (n, h, w) in enumerate([(1, 1, 1), (2, 1, 9), (1, 7, 1), (1, 2, 2), (1, 3, 33), (1, 25, 2)]):
+        x = torch.from_numpy(synth.uniform((n, 3, h, w), 70 + i))
+        y = net(x.to(dev).half()).float().cpu()
+        with torch.no_grad():
+            ref = oracle.rrdbnet_forward(sd, x, nb=1, scale=4)
+        assert y.shape == ref.shape == (n, 3, 4 * h, 4 * w)
+        assert (y - ref).abs().max().item() < 5e-3, (n, h, w)
+    with pytest.raises((RuntimeError, ValueError)):
+        net(torch.zeros(0, 3, 8, 8, device=dev, dtype=torch.float16))
+
+
 def test_forward_does_not_depend_on_workspace_contents(dev):
     """Every byte the kernels read was written by an earlier launch of the same forward:
     poisoning the workspace (NaN patterns) must not change the result."""
