@@ -5,7 +5,7 @@ import ctypes as C
 
 from .. import lib as L
 from .engine_module import EngineModule
-from .keys import rrdbnet_shapes
+from .keys import mrrdb_key_of, mrrdbnet_shapes, rrdbnet_shapes
 
 
 class RRDBNet(EngineModule):
@@ -33,3 +33,24 @@ class RRDBNet(EngineModule):
         L.check(L.lib.innfer_rrdbnet_create(C.byref(h), self.in_nc, self.out_nc, self.nf, self.nb,
                                             self.gc, self.upscale, int(self.plus)))
         return h
+
+
+
+class MRRDBNet(EngineModule):
+    """Modified ("new"-arch) ESRGAN (reference RRDBNet_arch.py:173-231): conv_first, RRDB_trunk.<b>.RDB<r>.conv<i>,
+    trunk_conv, upconv1/2 behind nearest 2x, HRconv, conv_last -- the 4x RRDBNet graph under other parameter names,
+    so it runs on the same engine (csrc/net.hip); only the state-dict keys differ."""
+
+    def __init__(self, in_nc, out_nc, nf, nb, gc=32):
+        super().__init__(mrrdbnet_shapes(in_nc, out_nc, nf, nb, 32))
+        if gc != 32:
+            raise NotImplementedError(f'MRRDBNet: gc={gc} is not built on the HIP path (gc=32 only)')
+        self.in_nc, self.out_nc, self.nf, self.nb, self.gc, self.upscale = in_nc, out_nc, nf, nb, 32, 4
+
+    def _create_handle(self):
+        h = C.c_void_p()
+        L.check(L.lib.innfer_rrdbnet_create(C.byref(h), self.in_nc, self.out_nc, self.nf, self.nb, self.gc, 4, 0))
+        return h
+
+    def _param_key(self, engine_key):
+        return mrrdb_key_of(engine_key, self.nb)

@@ -23,10 +23,8 @@ def get_network(opt_net):
         from .ResNet_arch import ResnetGenerator as net
     elif kind == 'wbcunet_net':
         from .WBCNet_arch import UnetGeneratorWBC as net
-    elif kind in ('mrrdb_net',):
-        raise NotImplementedError(
-            f'Model [{kind}] exists in the reference but is outside the MI355X hot path built so far '
-            '(SURVEY.md section 8)')
+    elif kind == 'mrrdb_net':
+        from .RRDBNet_arch import MRRDBNet as net
     else:
         raise NotImplementedError('Model [{:s}] not recognized'.format(kind))
     return net(**opt_net)

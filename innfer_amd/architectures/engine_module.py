@@ -38,6 +38,10 @@ class EngineModule(nn.Module):
     def _create_handle(self):
         raise NotImplementedError
 
+    def _param_key(self, engine_key):
+        """State-dict prefix of the conv the engine calls `engine_key` (old-arch names); identity by default."""
+        return engine_key
+
     # ---- weight upload (load time, not forward time) -------------------------
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -54,7 +58,7 @@ class EngineModule(nn.Module):
         K, Cc = C.c_int(), C.c_int()
         for i in range(n):
             L.check(L.lib.innfer_net_conv_info(self._handle, i, key, 128, C.byref(K), C.byref(Cc)))
-            k = key.value.decode()
+            k = self._param_key(key.value.decode())
             w = np.ascontiguousarray(sd[k + '.weight'].detach().float().cpu().numpy())
             if w.shape[:2] != (K.value, Cc.value):
                 raise RuntimeError(f'size mismatch for {k}.weight: {tuple(w.shape)} vs engine ({K.value},{Cc.value},3,3)')

@@ -36,6 +36,36 @@ def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False):
     return s
 
 
+def mrrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=24, gc=32):
+    """State-dict key -> shape of the modified ("new"-arch) ESRGAN, MRRDBNet (reference RRDBNet_arch.py:173-231):
+    the graph of the old-arch 4x RRDBNet under different names."""
+    s = {"conv_first.weight": (nf, in_nc, 3, 3), "conv_first.bias": (nf,)}
+    for b in range(nb):
+        for r in (1, 2, 3):
+            for i in range(1, 6):
+                cin = nf + (i - 1) * gc
+                cout = gc if i < 5 else nf
+                s[f"RRDB_trunk.{b}.RDB{r}.conv{i}.weight"] = (cout, cin, 3, 3)
+                s[f"RRDB_trunk.{b}.RDB{r}.conv{i}.bias"] = (cout,)
+    for name in ("trunk_conv", "upconv1", "upconv2", "HRconv"):
+        s[name + ".weight"] = (nf, nf, 3, 3)
+        s[name + ".bias"] = (nf,)
+    s["conv_last.weight"] = (out_nc, nf, 3, 3)
+    s["conv_last.bias"] = (out_nc,)
+    return s
+
+
+def mrrdb_key_of(old_key, nb):
+    """Old-arch conv key of the engine ('model.1.sub.3.RDB2.conv4.0') -> MRRDBNet's name for the same conv
+    (the inverse of mod2normal, utils.py:666-698, for any nb)."""
+    fixed = {"model.0": "conv_first", f"model.1.sub.{nb}": "trunk_conv", "model.3": "upconv1",
+             "model.6": "upconv2", "model.8": "HRconv", "model.10": "conv_last"}
+    if old_key in fixed:
+        return fixed[old_key]
+    assert old_key.startswith("model.1.sub.") and old_key.endswith(".0"), old_key
+    return "RRDB_trunk." + old_key[len("model.1.sub."):-2]
+
+
 def srresnet_shapes(in_nc=3, out_nc=3, nf=64, nb=16, scale=4):
     """SRGAN/SRResNet keys (reference SRResNet_arch.py:15-46, defaults.py:53-67)."""
     import math

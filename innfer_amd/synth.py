@@ -80,4 +80,4 @@ def fill_state_dict(shapes, seed=0, bias_scale=1.0):
     return out
 
 
-from .architectures.keys import rrdbnet_shapes, srresnet_shapes  # noqa: E402,F401
+from .architectures.keys import mrrdbnet_shapes, rrdbnet_shapes, srresnet_shapes  # noqa: E402,F401

@@ -98,9 +98,13 @@ def get_network_G_config(network_G, scale):
         cfg['use_dropout'] = _pick(opts, 'use_dropout', False)
         cfg['upsample_mode'] = _pick(opts, 'upsample_mode', 'deconv')
         cfg['padding_type'] = _pick(opts, 'padding_type', 'reflect')
-    elif kind in ('mrrdb_net', 'mesrgan'):
-        raise NotImplementedError(
-            f'Generator model [{kind}] is a reference architecture outside the MI355X hot path built so far')
+    elif kind in ('mrrdb_net', 'mesrgan'):                 # modified ("new"-arch) ESRGAN (defaults.py:45-52)
+        cfg['type'] = 'mrrdb_net'
+        cfg['in_nc'] = _pick(opts, 'in_nc', 3)
+        cfg['out_nc'] = _pick(opts, 'out_nc', 3)
+        cfg['nf'] = _pick(opts, 'nf', 64)
+        cfg['nb'] = _pick(opts, 'nb', 24)
+        cfg['gc'] = _pick(opts, 'gc', 32)
     else:
         raise NotImplementedError(f'Generator model [{kind:s}] not recognized')
 

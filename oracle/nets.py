@@ -76,6 +76,31 @@ def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None):
     return _conv3(sd, f"model.{idx + 2}", t)      # HR_conv1
 
 
+def mrrdbnet_forward(sd, x, nb=24):
+    """MRRDBNet.forward (RRDBNet_arch.py:173-199) with ResidualDenseBlock_5CM / RRDBM (:201-231): restated on its own
+    parameter names, not through the old-arch function, so that the key mapping of the product is checked too."""
+    def conv(key, t):
+        return F.conv2d(t, sd[key + ".weight"], sd[key + ".bias"], padding=1)
+    fea = conv("conv_first", x)
+    t = fea
+    for b in range(nb):
+        r_in = t
+        for r in (1, 2, 3):
+            p = f"RRDB_trunk.{b}.RDB{r}."
+            x0 = t
+            x1 = _lrelu(conv(p + "conv1", x0))
+            x2 = _lrelu(conv(p + "conv2", torch.cat((x0, x1), 1)))
+            x3 = _lrelu(conv(p + "conv3", torch.cat((x0, x1, x2), 1)))
+            x4 = _lrelu(conv(p + "conv4", torch.cat((x0, x1, x2, x3), 1)))
+            x5 = conv(p + "conv5", torch.cat((x0, x1, x2, x3, x4), 1))
+            t = x5 * 0.2 + x0
+        t = t * 0.2 + r_in
+    fea = fea + conv("trunk_conv", t)
+    fea = _lrelu(conv("upconv1", F.interpolate(fea, scale_factor=2, mode="nearest")))
+    fea = _lrelu(conv("upconv2", F.interpolate(fea, scale_factor=2, mode="nearest")))
+    return conv("conv_last", _lrelu(conv("HRconv", fea)))
+
+
 def srresnet_forward(sd, x, nb=16, scale=4):
     """SRResNet.forward with defaults norm=None, act=relu, mode=CNA,
     pixelshuffle, res_scale=1 (SRResNet_arch.py:15-91, defaults.py:53-67)."""

@@ -340,6 +340,20 @@ def g10():
 
 
 # ------------------------------------------------------- G12 default configs
+# ---------------------------------------------------------------- G16 MRRDBNet ("new"-arch ESRGAN built directly)
+def g16():
+    shapes = synth.mrrdbnet_shapes(nb=2)
+    sd = synth.fill_state_dict(shapes, 61)
+    net = ref_net("mrrdb_net", 4, nb=2)
+    assert list(net.state_dict().keys()) == list(shapes.keys())
+    net.load_state_dict(t_sd(sd), strict=True)
+    net.eval()
+    x = torch.from_numpy(synth.uniform((2, 3, 16, 20), 62))
+    with torch.no_grad():
+        y = net(x)
+    save("g16_mrrdb", out=y.numpy(), keys=np.array(list(shapes.keys())), shapes=np.array([str(tuple(v)) for v in shapes.values()]))
+
+
 def g12():
     import json
     rows = {}
@@ -361,11 +375,13 @@ def g12():
     rows["pan|4|" + json.dumps({"nb": 3, "in_nc": 1, "out_nc": 1}, sort_keys=True)] = get_network_G_config(
         dict(type="pan", nb=3, in_nc=1, out_nc=1), 4)
     rows["str:esrgan|4"] = get_network_G_config("esrgan", 4)
+    rows["str:mesrgan|4"] = get_network_G_config("mesrgan", 4)
+    rows["mrrdb_net|4|" + json.dumps({"nb": 2, "nf": 32}, sort_keys=True)] = get_network_G_config(dict(type="mrrdb_net", nb=2, nf=32), 4)
     rows["which_model_G:srgan|4"] = get_network_G_config({"which_model_G": "srgan"}, 4)
     save("g12_defaults", table=np.array(json.dumps(rows, sort_keys=True)))
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16"]
     for g in which:
         globals()[g]()

@@ -202,6 +202,29 @@ def test_esrgan_plus_golden(dev, golden):
     assert np.abs(y - g["out_x4_plus"]).max() < 5e-3
 
 
+def test_mrrdbnet_golden_and_same_engine(dev, golden):
+    """MRRDBNet built directly: golden G16 (reference MRRDBNet, nb 2), and bit-identical to the old-arch RRDBNet holding
+    the same weights under mod2normal's names (one engine, two key layouts)."""
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    g = golden("g16_mrrdb")
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(synth.mrrdbnet_shapes(nb=2), 61).items()}
+    net = get_network(get_network_G_config({"type": "mrrdb_net", "nb": 2}, 4))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x = torch.from_numpy(synth.uniform((2, 3, 16, 20), 62)).to(dev)
+    y = net(x)
+    err = np.abs(y.cpu().numpy() - g["out"])
+    assert err.max() < 5e-3, err.max()                                   # fp32 in/out, fp16 storage inside; golden is fp32
+    yh = net(x.half())
+    assert np.abs(yh.float().cpu().numpy() - g["out"]).max() < 5e-3
+    from innfer_amd.architectures.keys import mrrdb_key_of
+    old = get_network(get_network_G_config({"type": "esrgan", "nb": 2}, 4))
+    old.load_state_dict({k: sd[mrrdb_key_of(k.rsplit(".", 1)[0], 2) + "." + k.rsplit(".", 1)[1]] for k in old.state_dict()}, strict=True)
+    assert torch.equal(old.to(dev).eval()(x.half()), yh)
+
+
 def test_rrdbnet_batch_and_ragged_sizes(dev):
     import oracle
     from innfer_amd import synth

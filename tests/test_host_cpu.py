@@ -171,8 +171,12 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     assert list(srg.state_dict().keys()) == list(synth.srresnet_shapes(nb=2, scale=4).keys())
     plus = get_network(get_network_G_config({"type": "esrgan", "plus": True, "nb": 1}, 4))
     assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
-    with pytest.raises(NotImplementedError):
-        get_network({"type": "mrrdb_net"})
+    m = get_network(get_network_G_config({"type": "mesrgan", "nb": 2}, 4))          # new-arch ESRGAN built directly
+    assert list(m.state_dict().keys()) == list(synth.mrrdbnet_shapes(nb=2).keys())
+    from innfer_amd.architectures.keys import mrrdb_key_of
+    from innfer_amd.utils.utils import mod2normal
+    old = mod2normal({k: k for k in synth.mrrdbnet_shapes(nb=23)})            # the reference's own conversion (nb 23)
+    assert all(mrrdb_key_of(k_old.rsplit(".", 1)[0], 23) + "." + k_old.rsplit(".", 1)[1] == k_new for k_old, k_new in old.items())
     assert get_network(get_network_G_config("wbcunet_tf", 1)).mode == "tf"
     g15 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g15_wbcunet.npz"))
     wb = get_network(get_network_G_config("wbcunet", 1))

@@ -189,3 +189,15 @@ def test_g9_convert(golden):
     # round trip is exact for uint8
     img = synth.image_u8(33, 47, 3, 1)
     assert np.array_equal(oracle.tensor2np(oracle.np2tensor(img)), img)
+
+
+def test_g16_mrrdbnet(golden):
+    """MRRDBNet (new-arch ESRGAN built directly, RRDBNet_arch.py:173-231) on its own key names."""
+    g = golden("g16_mrrdb")
+    shapes = synth.mrrdbnet_shapes(nb=2)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]]
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 61).items()}
+    x = torch.from_numpy(synth.uniform((2, 3, 16, 20), 62))
+    with torch.no_grad():
+        y = oracle.mrrdbnet_forward(sd, x, nb=2)
+    np.testing.assert_allclose(y.numpy(), g["out"], atol=2e-6, rtol=0)
