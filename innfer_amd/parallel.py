@@ -79,7 +79,7 @@ class ChopRunner:
         # ---- gather the HR tiles on rank 0 (shares padded to the largest one) ----
         max_count = shard_tile_rows(n_rows, n_cols, world, 0)[1]
         dtype = outs[0].dtype if outs else data.dtype
-        out_c = outs[0].shape[1] if outs else C
+        out_c = outs[0].shape[1] if outs else getattr(self.model_fn, 'out_nc', C)    # a rank without tiles (more ranks than tile rows)
         send = torch.zeros((max_count, out_c, P, P), dtype=dtype, device=data.device)
         if count:
             send[:count] = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
