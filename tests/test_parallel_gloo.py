@@ -59,9 +59,8 @@ def _worker(rank, world, port, h, w, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h,w", [(250, 330)])
-def test_two_rank_chop_equals_single_process(h, w):
-    world = 2
+@pytest.mark.parametrize("h,w,world", [(250, 330, 2), (250, 330, 3)])      # 2 tile rows: with 3 ranks the last one has no tiles
+def test_sharded_chop_equals_single_process(h, w, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
