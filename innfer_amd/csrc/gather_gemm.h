@@ -28,6 +28,8 @@ struct GP {
     int cout_store;                       // channels [0, cout_store) of the computed tile are written
     int ngroup; long g_wbytes; long g_outoff; int g_tapmul;   // ngroup > 1: blockIdx.z / ksplit selects one of several convs of the SAME
                                           // input: weights wpk + g*g_wbytes, taps * (1 + g*g_tapmul), output out + g*g_outoff
+    int g_phase;                          // ngroup == 4 output phases of a stride-2 transposed conv: group g uses taps [g*ntaps, (g+1)*ntaps)
+                                          // of dy/dx and writes output pixel (oy*os + (g>>1), ox*os + (g&1))
 };
 
 // 128 pixels x 64 output channels per workgroup (4 waves x (32 px x 64 co) = 8 MFMAs per wave and 32-channel
@@ -80,6 +82,7 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
     const long panel_bytes = (long)p.ntaps * p.nchunks * 4096;
     const int zg = p.ngroup > 1 ? (int)blockIdx.z / p.ksplit : 0, zs = (int)blockIdx.z - zg * p.ksplit;
     const int tapmul = 1 + zg * p.g_tapmul;
+    const int tap0 = p.g_phase ? zg * p.ntaps : 0;
     const char* wtile = (const char*)p.wpk + zg * p.g_wbytes + (long)cot * panel_bytes;
     const int total_steps = p.ntaps * p.nchunks;
     // split-K: blockIdx.z takes the k-steps [z*seg, (z+1)*seg) and writes a partial result
@@ -94,7 +97,7 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)c * p.in_g), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int h = 0; h < BP; ++h) {
-            int iy = soy[h] * p.stride + p.dy[t] * tapmul, ix = sox[h] * p.stride + p.dx[t] * tapmul;
+            int iy = soy[h] * p.stride + p.dy[tap0 + t] * tapmul, ix = sox[h] * p.stride + p.dx[tap0 + t] * tapmul;
             if (p.reflect) {                                          // pad < size: one reflection is enough
                 iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
                 ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
@@ -111,7 +114,7 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + B_BYTES + j * 4096 + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
         }
 #else
-        (void)step; (void)rel; (void)wtile; (void)spix; (void)cso; (void)panel_bytes; (void)tapmul;
+        (void)step; (void)rel; (void)wtile; (void)spix; (void)cso; (void)panel_bytes; (void)tapmul; (void)tap0;
 #endif
     };
 
@@ -156,7 +159,8 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             const int ox = (int)(m % p.Wo);
             const int oy = (int)((m / p.Wo) % p.Ho);
             const long n = m / ((long)p.Wo * p.Ho);
-            const long opix = (n * p.Hfull + (long)oy * p.os + p.ooy) * p.Wfull + (long)ox * p.os + p.oox;
+            const int ooy = p.g_phase ? zg >> 1 : p.ooy, oox = p.g_phase ? zg & 1 : p.oox;
+            const long opix = (n * p.Hfull + (long)oy * p.os + ooy) * p.Wfull + (long)ox * p.os + oox;
             float* op = p.out + (long)zs * p.split_elems + zg * p.g_outoff + opix * p.raw_stride;
 #pragma unroll
             for (int q = 0; q < 4 * Q; ++q) {
@@ -220,14 +224,15 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
                   float* raw, int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx,
                   int Hfull, int Wfull, int os, int ooy, int oox, int up, hipStream_t s,
                   float* scratch = nullptr, size_t scratch_bytes = 0, int raw_stride = 0, int reflect = 0,
-                  int ngroup = 1, long g_wbytes = 0, long g_outoff = 0, int g_tapmul = 0, int cout_store = 0) {
+                  int ngroup = 1, long g_wbytes = 0, long g_outoff = 0, int g_tapmul = 0, int cout_store = 0, int g_phase = 0) {
     GP g{};
     g.in = in; g.in_g = in_g; g.nchunks = cin_pad / 32; g.N = N; g.Hin = Hin; g.Win = Win;
     g.wpk = wpk; g.out = raw; g.cout_pad = cout_pad;
     g.raw_stride = raw_stride > 0 ? raw_stride : cout_pad;
     if (g.raw_stride <= 0 || (g.raw_stride & 3)) return set_error(INNFER_ERR_INVALID, "gather GEMM: bad raw stride %d", g.raw_stride);
     g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps;
-    for (int t = 0; t < ntaps; ++t) { g.dy[t] = dy[t]; g.dx[t] = dx[t]; }
+    if (g_phase && (ngroup != 4 || ntaps * 4 > 49)) return set_error(INNFER_ERR_INVALID, "gather GEMM: phase groups need 4 groups of <= 12 taps");
+    for (int t = 0; t < ntaps * (g_phase ? 4 : 1); ++t) { g.dy[t] = dy[t]; g.dx[t] = dx[t]; }
     g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up; g.reflect = reflect;
     if (ntaps < 1 || ntaps > 49) return set_error(INNFER_ERR_INVALID, "gather GEMM: %d taps", ntaps);
     const long M = (long)N * Ho * Wo;
@@ -244,12 +249,12 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     if (ngroup > 1) ks = 1;
     g.ksplit = ks;
     g.cout_store = cout_store > 0 ? cout_store : (g.raw_stride < cout_pad ? g.raw_stride : cout_pad);
-    g.ngroup = ngroup; g.g_wbytes = g_wbytes; g.g_outoff = g_outoff; g.g_tapmul = g_tapmul;
+    g.ngroup = ngroup; g.g_wbytes = g_wbytes; g.g_outoff = g_outoff; g.g_tapmul = g_tapmul; g.g_phase = g_phase;
     g.split_elems = ks > 1 ? (long)(full / sizeof(float)) : 0;
     if (ks > 1) g.out = scratch;
-    const bool big = ks == 1 && ngroup == 1 && cout_pad % 128 == 0 && ((M + 255) / 256) * (cout_pad / 128) >= 256;
+    const bool big = ks == 1 && (ngroup == 1 || g_phase) && cout_pad % 128 == 0 && ((M + 255) / 256) * (cout_pad / 128) * ngroup >= 256;
     if (big) {
-        dim3 grid((unsigned)((M + 255) / 256), (unsigned)(cout_pad / 128), 1);
+        dim3 grid((unsigned)((M + 255) / 256), (unsigned)(cout_pad / 128), (unsigned)ngroup);
         hipLaunchKernelGGL((gemm_gather<4, 2, 3>), grid, dim3(256), 0, s, g);
     } else {
         dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64), (unsigned)(ks * ngroup));

@@ -30,15 +30,30 @@ using namespace innfer;
 
 namespace {
 
-// per-(image, channel) BatchNorm transform (alpha, shift) from the mean and biased variance of raw[N][HW][cpad]: two passes in fp32 (mean, then
-// the sum of squared deviations), 32 channels x 32 pixel lanes per workgroup, 4 loads in flight per thread
+// per-(image, channel) BatchNorm transform (alpha, shift) from the mean and biased variance of raw[N][HW][cpad], fp32, ONE read of raw:
+// a workgroup holds a segment of BN_SEG pixels x 32 channels in registers (32 pixel lanes x 32 values), takes the segment mean and
+// the sum of squared deviations from it (the two-pass form, on registers); segments are combined in index order with the
+// parallel-variance formula  M2 = sum M2_s + sum n_s (mean_s - mean)^2  -- deterministic, no atomics.
+constexpr int BN_SEG = 1024;
+
+__device__ __forceinline__ void bn_write(float mu, float var, float eps, const float* gamma, const float* beta, float* alpha, float* shift,
+                                         long n, int C, int c) {
+    // the transform ATen applies (batch_norm_cpu_transform_input): out = x * alpha + shift,
+    // alpha = invstd * weight, shift = bias - mean * alpha
+    const float a = (1.0f / sqrtf(var + eps)) * gamma[c];
+    alpha[n * C + c] = a;
+    shift[n * C + c] = beta[c] - mu * a;
+}
+
 __global__ __launch_bounds__(1024) void bn_stats(const float* raw, int cpad, long HW, float eps, const float* gamma, const float* beta,
-                                                 float* alpha, float* shift, int C) {
+                                                 float* alpha, float* shift, int C, float* part, int nseg) {
     __shared__ float red[1024];
-    const int n = blockIdx.y, cb = blockIdx.x * 32;
+    const int n = blockIdx.y, cb = blockIdx.x * 32, sg = blockIdx.z;
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = cb + cl;
-    const float* base = raw + (long)n * HW * cpad + c;
+    const long p0 = (long)sg * BN_SEG;
+    const int cnt = (int)min((long)BN_SEG, HW - p0);
+    const float* base = raw + ((long)n * HW + p0) * cpad + c;
     auto reduce32 = [&](float v) {                 // sum over the 32 pixel lanes of one channel, result in every lane
         red[threadIdx.x] = v;
         __syncthreads();
@@ -48,29 +63,49 @@ __global__ __launch_bounds__(1024) void bn_stats(const float* raw, int cpad, lon
         __syncthreads();
         return t;
     };
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    long px = pl;
-    for (; px + 96 < HW; px += 128) {
-        s0 += base[px * cpad]; s1 += base[(px + 32) * cpad]; s2 += base[(px + 64) * cpad]; s3 += base[(px + 96) * cpad];
+    float v[BN_SEG / 32];
+    const int iters = (cnt + 31) >> 5;             // uniform: deep layers have a handful of pixels per image
+#pragma unroll
+    for (int i = 0; i < BN_SEG / 32; ++i) {
+        v[i] = 0.f;
+        if (i < iters) {
+            const int px = pl + 32 * i;
+            if (px < cnt) v[i] = base[(long)px * cpad];
+        }
     }
-    for (; px < HW; px += 32) s0 += base[px * cpad];
-    const float mu = reduce32((s0 + s1) + (s2 + s3)) / (float)HW;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < BN_SEG / 32; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
+    const float mu = reduce32((s0 + s1) + (s2 + s3)) / (float)cnt;
     s0 = s1 = s2 = s3 = 0.f;
-    px = pl;
-    for (; px + 96 < HW; px += 128) {
-        const float d0 = base[px * cpad] - mu, d1 = base[(px + 32) * cpad] - mu, d2 = base[(px + 64) * cpad] - mu,
-                    d3 = base[(px + 96) * cpad] - mu;
+#pragma unroll
+    for (int i = 0; i < BN_SEG / 32; i += 4) {
+        const float d0 = pl + 32 * i < cnt ? v[i] - mu : 0.f, d1 = pl + 32 * (i + 1) < cnt ? v[i + 1] - mu : 0.f,
+                    d2 = pl + 32 * (i + 2) < cnt ? v[i + 2] - mu : 0.f, d3 = pl + 32 * (i + 3) < cnt ? v[i + 3] - mu : 0.f;
         s0 += d0 * d0; s1 += d1 * d1; s2 += d2 * d2; s3 += d3 * d3;
     }
-    for (; px < HW; px += 32) { const float d = base[px * cpad] - mu; s0 += d * d; }
-    const float var = reduce32((s0 + s1) + (s2 + s3)) / (float)HW;
+    const float m2 = reduce32((s0 + s1) + (s2 + s3));
     if (pl == 0 && c < C) {
-        // the transform ATen applies (batch_norm_cpu_transform_input): out = x * alpha + shift,
-        // alpha = invstd * weight, shift = bias - mean * alpha
-        const float a = (1.0f / sqrtf(var + eps)) * gamma[c];
-        alpha[(long)n * C + c] = a;
-        shift[(long)n * C + c] = beta[c] - mu * a;
+        if (nseg == 1) bn_write(mu, m2 / (float)HW, eps, gamma, beta, alpha, shift, n, C, c);
+        else { float* q = part + (((long)n * C + c) * nseg + sg) * 2; q[0] = mu; q[1] = m2; }
     }
+}
+
+// segments -> (alpha, shift): one thread per (image, channel), segments in index order
+__global__ void bn_combine(const float* part, int nseg, long HW, float eps, const float* gamma, const float* beta,
+                           float* alpha, float* shift, int C, int N) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * C) return;
+    const float* q = part + i * nseg * 2;
+    float sum = 0.f;
+    for (int g = 0; g < nseg; ++g) sum += q[2 * g] * (float)min((long)BN_SEG, HW - (long)g * BN_SEG);
+    const float mu = sum / (float)HW;
+    float m2 = 0.f;
+    for (int g = 0; g < nseg; ++g) {
+        const float d = q[2 * g] - mu;
+        m2 += q[2 * g + 1] + (float)min((long)BN_SEG, HW - (long)g * BN_SEG) * d * d;
+    }
+    bn_write(mu, m2 / (float)HW, eps, gamma, beta, alpha, shift, i / C, C, (int)(i % C));
 }
 
 struct PostDst { f16* p; long g; int coff; int act; };      // act: 1 lrelu(0.2), 2 relu
@@ -120,6 +155,21 @@ __global__ void unet_final(const float* raw, int cpad, int C, long HW, int N, co
     }
 }
 
+// outermost, phase-combined GEMM: raw[n][y][x][(2a+b)*C + c] is output pixel (2y+a, 2x+b); one thread per OUTPUT pixel
+__global__ void unet_final_phases(const float* raw, int cpad, int C, int h, int w, int N, const float* bias, void* out, int out_f32) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long HW = 4L * h * w;
+    if (i >= (long)N * HW) return;
+    const long n = i / HW, px = i % HW;
+    const int Y = (int)(px / (2 * w)), X = (int)(px % (2 * w));
+    const float* rp = raw + ((n * h + (Y >> 1)) * w + (X >> 1)) * cpad + ((Y & 1) * 2 + (X & 1)) * C;
+    for (int c = 0; c < C; ++c) {
+        const float y = tanhf(rp[c] + bias[c]);
+        const long o = (n * C + c) * HW + px;
+        if (out_f32) ((float*)out)[o] = y; else ((f16*)out)[o] = (f16)y;
+    }
+}
+
 __global__ void unet_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {    // NCHW -> one zero-padded group
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * HW) return;
@@ -135,13 +185,45 @@ __global__ void unet_pre(const void* in, int in_f32, int C, long HW, int N, f16*
     for (int q = 0; q < 4; ++q) *(f16x8*)(slab + i * 32 + 8 * q) = *(const f16x8*)(h + 8 * q);
 }
 
+// Outermost down conv with C <= 4 input channels: the 4x4 stride-2 window of an output pixel is only 16*C <= 64 values, so the
+// NCHW input is rewritten as a 64-channel "patch" slab at HALF resolution (channel j = (ky*4+kx)*C + c, zero outside the image and
+// beyond 16*C) and the conv becomes a 1-tap GEMM over 64 channels instead of 16 taps over a 32-channel group holding C values.
+// One thread per (output pixel, 32-channel group).
+__global__ void unet_pre_patch(const void* in, int in_f32, int C, int H, int W, int N, f16* slab, long g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ho = H >> 1, wo = W >> 1;
+    const long M = (long)N * ho * wo;
+    if (i >= 2 * M) return;
+    const int grp = (int)(i / M);
+    const long m = i - grp * M;
+    const int ox = (int)(m % wo), oy = (int)((m / wo) % ho);
+    const long n = m / ((long)wo * ho);
+    f16 hbuf[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const int j = grp * 32 + e, t = j / C, c = j - t * C;
+        const int iy = 2 * oy - 1 + (t >> 2), ix = 2 * ox - 1 + (t & 3);
+        f16 v = (f16)0.f;
+        if (t < 16 && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const long o = ((n * C + c) * H + iy) * W + ix;
+            v = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+        }
+        hbuf[e] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f16x8*)(slab + grp * g + m * 32 + 8 * q) = *(const f16x8*)(hbuf + 8 * q);
+}
+
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 
 struct Layer {            // one conv / conv-transpose
     bool transposed = false;
+    bool patch = false;                                    // outermost down conv as a 1-tap GEMM on the patch slab (unet_pre_patch)
+    bool phases = false;                                   // outermost up conv: the four output phases as 4*cout channels of ONE 3x3-tap GEMM
     int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0;
     int w = -1, bias = -1, gamma = -1, beta = -1;          // indices into params
-    f16* d_w[4] = {nullptr, nullptr, nullptr, nullptr};    // conv: [0]; convT: one panel set per phase
+    f16* d_w[4] = {nullptr, nullptr, nullptr, nullptr};    // conv: [0]; convT: one panel set per phase, [1..3] point into [0]'s allocation
+    long phase_elems = 0;
     float *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
 };
 
@@ -197,6 +279,8 @@ extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int 
         }
         d.cin_pad = (d.cin + 31) / 32 * 32; d.cout_pad = (d.cout + 63) / 64 * 64;
         p.cin_pad = (p.cin + 31) / 32 * 32; p.cout_pad = (p.cout + 63) / 64 * 64;
+        if (outer && d.cin <= 4) { d.patch = true; d.cin_pad = 64; }
+        if (outer && 4 * p.cout <= 64) p.phases = true;
         blk = next;
     }
     // up params, innermost first (= module order after the submodule)
@@ -225,7 +309,7 @@ extern "C" void innfer_unet_destroy(innfer_unet* u) {
     if (!u) return;
     for (auto* v : {&u->down, &u->up})
         for (auto& l : *v) {
-            for (auto& w : l.d_w) if (w) (void)hipFree(w);
+            if (l.d_w[0]) (void)hipFree(l.d_w[0]);
             if (l.d_bias) (void)hipFree(l.d_bias);
             if (l.d_gamma) (void)hipFree(l.d_gamma);
             if (l.d_beta) (void)hipFree(l.d_beta);
@@ -283,18 +367,36 @@ static int upload_all(innfer_unet* u) {
     for (auto* v : {&u->down, &u->up})
         for (auto& l : *v) {
             const std::vector<float>& w = u->params[l.w].host;
-            if (!l.transposed) {
+            if (l.patch) {
+                gg::pack_panels(panel, l.cout, 16 * l.cin, 64, 1,
+                            [&](int co, int j, int) { const int t = j / l.cin, ci = j - t * l.cin;
+                                                      return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
+                int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
+            } else if (l.phases) {
+                // output channel (2a+b)*cout + c of tap (dy,dx) in {-1,0,1}^2: phase a takes ky = 1 (dy 0), 3 (dy -1) when a == 0 and
+                // ky = 0 (dy +1), 2 (dy 0) when a == 1 (oy = 2*iy - 1 + ky); the other (phase, tap) pairs are structural zeros
+                auto kof = [](int a, int d) { return a == 0 ? (d == 0 ? 1 : (d == -1 ? 3 : -1)) : (d == 1 ? 0 : (d == 0 ? 2 : -1)); };
+                gg::pack_panels(panel, 4 * l.cout, l.cin, l.cin_pad, 9,
+                            [&](int co, int ci, int t) { const int ph = co / l.cout, c = co - ph * l.cout;
+                                                         const int ky = kof(ph >> 1, t / 3 - 1), kx = kof(ph & 1, t % 3 - 1);
+                                                         return ky < 0 || kx < 0 ? 0.f : w[(((size_t)ci * l.cout + c) * 4 + ky) * 4 + kx]; });
+                int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
+            } else if (!l.transposed) {
                 gg::pack_panels(panel, l.cout, l.cin, l.cin_pad, 16,
                             [&](int co, int ci, int t) { return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
                 int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
             } else {
+                std::vector<f16> all;                               // the four phase panels back to back: one grouped launch reads them
                 for (int ph = 0; ph < 4; ++ph) {
                     int ky[4], kx[4], dy[4], dx[4];
                     phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
                     gg::pack_panels(panel, l.cout, l.cin, l.cin_pad, 4,
                                 [&](int co, int ci, int t) { return w[(((size_t)ci * l.cout + co) * 4 + ky[t]) * 4 + kx[t]]; });
-                    int rc = upload_f16(&l.d_w[ph], panel); if (rc) return rc;
+                    all.insert(all.end(), panel.begin(), panel.end());
                 }
+                int rc = upload_f16(&l.d_w[0], all); if (rc) return rc;
+                l.phase_elems = (long)panel.size();
+                for (int ph = 1; ph < 4; ++ph) l.d_w[ph] = l.d_w[0] + ph * l.phase_elems;      // aliases, never freed
             }
             if (l.bias >= 0) { int rc = upload_f32(&l.d_bias, u->params[l.bias].host); if (rc) return rc; }
             if (l.gamma >= 0) { int rc = upload_f32(&l.d_gamma, u->params[l.gamma].host); if (rc) return rc; }
@@ -305,7 +407,7 @@ static int upload_all(innfer_unet* u) {
 }
 
 namespace {
-struct UCarve { size_t x0, raw, mean, rstd, r_inner, splitk, total; std::vector<size_t> D, CAT; };
+struct UCarve { size_t x0, raw, mean, rstd, bnpart, r_inner, splitk, total; std::vector<size_t> D, CAT; };
 // partial results of the split-K deep layers: 8 segments x (<= GG_SPLIT_MAX_PX pixels x <= 1024 channels) fp32 per image,
 // so that whether a layer is split never depends on the batch size
 inline size_t splitk_bytes(int N) { return (size_t)N * 8 * gg::SPLIT_MAX_PX * 1024 * sizeof(float); }
@@ -321,6 +423,13 @@ UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
     c.raw = off; off += al(raw);
     c.mean = off; off += al((size_t)N * 1024 * 4);
     c.rstd = off; off += al((size_t)N * 1024 * 4);
+    size_t part = 0;                                                               // (mean, M2) per BN segment of the widest layer
+    for (int k = 0; k < L; ++k) {
+        const size_t hw = (size_t)(H >> (k + 1)) * (W >> (k + 1)), hw2 = (size_t)(H >> k) * (W >> k);
+        part = std::max(part, (size_t)u->dc[k] * ((hw + BN_SEG - 1) / BN_SEG));
+        if (k > 0) part = std::max(part, (size_t)u->dc[k - 1] * ((hw2 + BN_SEG - 1) / BN_SEG));
+    }
+    c.bnpart = off; off += al((size_t)N * part * 2 * 4);
     c.D.resize(L); c.CAT.resize(L);
     for (int k = 0; k < L - 1; ++k) {
         const size_t px = (size_t)N * (H >> (k + 1)) * (W >> (k + 1));
@@ -374,13 +483,21 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     float* splitk = (float*)(ws + cv.splitk);
     float* mean = (float*)(ws + cv.mean);
     float* rstd = (float*)(ws + cv.rstd);
+    float* bnpart = (float*)(ws + cv.bnpart);
     int dy16[16], dx16[16];
     for (int t = 0; t < 16; ++t) { dy16[t] = (t >> 2) - 1; dx16[t] = (t & 3) - 1; }
 
     auto post = [&](const Layer& l, long HW, bool bn, PostDst d0, PostDst d1) -> int {
         if (bn) {
-            hipLaunchKernelGGL(bn_stats, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, raw, l.cout_pad, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout);
+            const int nseg = (int)((HW + BN_SEG - 1) / BN_SEG);
+            hipLaunchKernelGGL(bn_stats, dim3((l.cout + 31) / 32, N, nseg), dim3(1024), 0, s, raw, l.cout_pad, HW, 1e-5f, l.d_gamma, l.d_beta,
+                               mean, rstd, l.cout, bnpart, nseg);
             INNFER_HIP(hipGetLastError());
+            if (nseg > 1) {
+                hipLaunchKernelGGL(bn_combine, dim3((unsigned)(((long)N * l.cout + 255) / 256)), dim3(256), 0, s, (const float*)bnpart, nseg, HW, 1e-5f,
+                                   l.d_gamma, l.d_beta, mean, rstd, l.cout, N);
+                INNFER_HIP(hipGetLastError());
+            }
         }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(unet_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
@@ -389,7 +506,12 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         return INNFER_OK;
     };
 
-    {   // NCHW input -> one zero-padded 32-channel group
+    if (u->down[0].patch) {   // NCHW input -> 64-channel patch slab at half resolution
+        const long M = (long)N * (H / 2) * (W / 2);
+        hipLaunchKernelGGL(unet_pre_patch, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, u->in_nc, H, W, N,
+                           (f16*)(ws + cv.x0), M * 32);
+        INNFER_HIP(hipGetLastError());
+    } else {                  // NCHW input -> one zero-padded 32-channel group
         const long HW = (long)H * W;
         hipLaunchKernelGGL(unet_pre, dim3((unsigned)((N * HW + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, u->in_nc, HW, N, (f16*)(ws + cv.x0));
         INNFER_HIP(hipGetLastError());
@@ -401,7 +523,13 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     for (int k = 0; k < L; ++k) {
         const Layer& l = u->down[k];
         const int ho = h / 2, wo = w / 2;
-        int rc = run_gemm(l, l.d_w[0], cur, cur_g, N, h, w, raw, ho, wo, 2, 16, dy16, dx16, ho, wo, 1, 0, 0, s, splitk);
+        int rc;
+        if (l.patch) {
+            const int zero = 0;
+            rc = run_gemm(l, l.d_w[0], cur, (long)N * ho * wo * 32, N, ho, wo, raw, ho, wo, 1, 1, &zero, &zero, ho, wo, 1, 0, 0, s, splitk);
+        } else {
+            rc = run_gemm(l, l.d_w[0], cur, cur_g, N, h, w, raw, ho, wo, 2, 16, dy16, dx16, ho, wo, 1, 0, 0, s, splitk);
+        }
         if (rc) return rc;
         const long HW = (long)ho * wo, G = (long)N * HW * 32;
         if (k < L - 1) {
@@ -422,13 +550,34 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const f16* in = k == L - 1 ? (const f16*)(ws + cv.r_inner) : (const f16*)(ws + cv.CAT[k]);
         const long in_g = (long)N * h * w * 32;
         const int hf = 2 * h, wf = 2 * w;
-        for (int ph = 0; ph < 4; ++ph) {
-            int ky[4], kx[4], dy[4], dx[4];
-            phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
-            // the outermost layer has out_nc (3) channels: its raw rows are 4..8 floats, not a 64-channel tile
-            const int rs = k == 0 ? (l.cout + 3) / 4 * 4 : 0;
-            int rc = run_gemm(l, l.d_w[ph], in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, ph >> 1, ph & 1, s, splitk, rs);
+        if (l.phases) {
+            int dy9[9], dx9[9];
+            for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
+            const int rs = (4 * l.cout + 3) / 4 * 4;
+            int rc = run_gemm(l, l.d_w[0], in, in_g, N, h, w, raw, h, w, 1, 9, dy9, dx9, h, w, 1, 0, 0, s, splitk, rs);
             if (rc) return rc;
+            hipLaunchKernelGGL(unet_final_phases, dim3((unsigned)(((long)N * hf * wf + 255) / 256)), dim3(256), 0, s, raw, rs, l.cout, h, w, N,
+                               l.d_bias, d_out, out_dtype == INNFER_F32);
+            INNFER_HIP(hipGetLastError());
+            h = hf; w = wf;
+            continue;
+        }
+        // the outermost layer has out_nc (3) channels: its raw rows are 4..8 floats, not a 64-channel tile
+        const int rs = k == 0 ? (l.cout + 3) / 4 * 4 : 0;
+        const bool split = 4 * (l.cin_pad / 32) >= 32 && (long)h * w <= gg::split_max_px();       // gg::launch's split-K rule (batch independent)
+        if (!split) {       // the four output phases as ONE grouped launch: 4x the workgroups, wide tiles where the layer is big enough
+            int dy[16], dx[16];
+            for (int ph = 0; ph < 4; ++ph) { int ky[4], kx[4]; phase_taps(ph >> 1, ph & 1, ky, kx, dy + 4 * ph, dx + 4 * ph); }
+            int rc = gg::launch(l.d_w[0], l.cin_pad, l.cout_pad, in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, 0, 0, 0, s,
+                                nullptr, 0, rs, 0, 4, l.phase_elems * (long)sizeof(f16), 0, 0, 0, 1);
+            if (rc) return rc;
+        } else {
+            for (int ph = 0; ph < 4; ++ph) {
+                int ky[4], kx[4], dy[4], dx[4];
+                phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
+                int rc = run_gemm(l, l.d_w[ph], in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, ph >> 1, ph & 1, s, splitk, rs);
+                if (rc) return rc;
+            }
         }
         const long HW = (long)hf * wf;
         if (k > 0) {

@@ -11,7 +11,7 @@ net = get_network(get_network_G_config("p2p_256", 1))
 sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()}
 net.load_state_dict(sd, strict=True)
 net = net.to(dev)
-for N in (1, 8, 64):
+for N in ([int(os.environ['UNET_N'])] if os.environ.get('UNET_N') else (1, 8, 64)):
     x = torch.from_numpy(synth.uniform((N, 3, 256, 256), 3, -1, 1)).to(dev).half()
     for _ in range(2): y = net(x)
     torch.cuda.synchronize()
