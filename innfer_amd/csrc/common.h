@@ -40,12 +40,13 @@ struct ConvLaunch {
     int out_coff;                                 // channel offset inside that group (0 or 16)
     int K;                                        // valid output channels
     int N, H, W;                                  // conv (output) size
-    int act; int up;                              // act: 0/1/2 ; up: input read through nearest 2x
+    int act; int up;                              // act: 0 none / 1 LeakyReLU(0.2) / 2 ReLU / 3 tanh (OUT_NCHW only); up: input read through nearest 2x
     const f16* res1; long res1_gstride; float s1;
     const f16* res2; long res2_gstride; float s2;
     int y0, y1;                                   // output rows [y0,y1)
     int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
     int rev;                                      // traverse the tiles in reverse order (speed only: see conv3x3.hip)
+    int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)
 };
 
 // Panel geometry of packed weights.

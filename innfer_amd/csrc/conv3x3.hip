@@ -84,6 +84,7 @@ struct KP {
     int N;
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
+    int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
     int total;               // tiles x channel groups of this launch
 #ifdef INNFER_ABLATE
     int abl;                 // diagnostic build only: 1 no stores, 2 no weight DMA, 4 no input DMA, 8 no MFMA phase
@@ -719,7 +720,12 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                             float f = acc[t][m][j];
                             if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
                             else if (p.act == 2) f = f > 0.f ? f : 0.f;
-                            const long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
+                            else if (p.act == 3) f = tanhf(f);
+                            long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
+                            if (p.phase_c > 0) {
+                                const int ph = ch / p.phase_c, c = ch - ph * p.phase_c;
+                                o = (((long)n * p.phase_c + c) * (2 * p.H) + 2 * y + (ph >> 1)) * (2 * p.W) + 2 * x + (ph & 1);
+                            }
                             if (p.out_f32) ((float*)p.out)[o] = f;
                             else ((f16*)p.out)[o] = (f16)f;
                         }
@@ -886,6 +892,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.wpk = L.wpk; k.bias = L.bias;
     k.out = L.out; k.out_gstride = L.out_gstride; k.out_coff = L.out_coff;
     k.K = L.K; k.KG = conv_groups(L.K);
+    if (L.act < 0 || L.act > 3 || (L.phase_c > 0 && (L.K % L.phase_c || L.K / L.phase_c != 4)))
+        return set_error(INNFER_ERR_INVALID, "conv3x3: act=%d phase_c=%d K=%d", L.act, L.phase_c, L.K);
     k.act = L.act;
     k.res1 = L.res1; k.res1_gstride = L.res1_gstride; k.s1 = L.s1;
     k.res2 = L.res2; k.res2_gstride = L.res2_gstride; k.s2 = L.s2;
@@ -893,6 +901,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (k.y0 < 0 || k.y1 > L.H || k.y0 >= k.y1) return set_error(INNFER_ERR_INVALID, "conv3x3: bad row range [%d,%d)", k.y0, k.y1);
     k.out_f32 = L.out_f32;
     k.rev = L.rev ? 1 : 0;
+    k.phase_c = L.out_mode == OUT_NCHW ? L.phase_c : 0;
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
@@ -902,6 +911,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2) return launch_pc<3, 1, 4, OUT_NCHW>(k, L.N, s);
+    if (L.act == 3 || L.phase_c > 0)
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tanh / phase output exist only in the producer-consumer planar epilogue (K <= 16, no residual)");
     switch (L.out_mode) {
         case OUT_SLAB:
             if (nt == 4) return rpw64 == 4 ? launch_t<4, 4, OUT_SLAB>(k, L.N, s) : rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);

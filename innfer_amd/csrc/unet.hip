@@ -155,21 +155,6 @@ __global__ void unet_final(const float* raw, int cpad, int C, long HW, int N, co
     }
 }
 
-// outermost, phase-combined GEMM: raw[n][y][x][(2a+b)*C + c] is output pixel (2y+a, 2x+b); one thread per OUTPUT pixel
-__global__ void unet_final_phases(const float* raw, int cpad, int C, int h, int w, int N, const float* bias, void* out, int out_f32) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long HW = 4L * h * w;
-    if (i >= (long)N * HW) return;
-    const long n = i / HW, px = i % HW;
-    const int Y = (int)(px / (2 * w)), X = (int)(px % (2 * w));
-    const float* rp = raw + ((n * h + (Y >> 1)) * w + (X >> 1)) * cpad + ((Y & 1) * 2 + (X & 1)) * C;
-    for (int c = 0; c < C; ++c) {
-        const float y = tanhf(rp[c] + bias[c]);
-        const long o = (n * C + c) * HW + px;
-        if (out_f32) ((float*)out)[o] = y; else ((f16*)out)[o] = (f16)y;
-    }
-}
-
 __global__ void unet_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {    // NCHW -> one zero-padded group
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * HW) return;
@@ -224,6 +209,7 @@ struct Layer {            // one conv / conv-transpose
     int w = -1, bias = -1, gamma = -1, beta = -1;          // indices into params
     f16* d_w[4] = {nullptr, nullptr, nullptr, nullptr};    // conv: [0]; convT: one panel set per phase, [1..3] point into [0]'s allocation
     long phase_elems = 0;
+    void* d_w3 = nullptr; float* d_b3 = nullptr;           // `phases` layer: conv3x3.hip panels [4*cout][cin][3][3] and the bias repeated per phase
     float *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
 };
 
@@ -280,7 +266,7 @@ extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int 
         d.cin_pad = (d.cin + 31) / 32 * 32; d.cout_pad = (d.cout + 63) / 64 * 64;
         p.cin_pad = (p.cin + 31) / 32 * 32; p.cout_pad = (p.cout + 63) / 64 * 64;
         if (outer && d.cin <= 4) { d.patch = true; d.cin_pad = 64; }
-        if (outer && 4 * p.cout <= 64) p.phases = true;
+        if (outer && 4 * p.cout <= 16) p.phases = true;          // conv3x3.hip's planar epilogue: one 16-channel tile
         blk = next;
     }
     // up params, innermost first (= module order after the submodule)
@@ -310,6 +296,8 @@ extern "C" void innfer_unet_destroy(innfer_unet* u) {
     for (auto* v : {&u->down, &u->up})
         for (auto& l : *v) {
             if (l.d_w[0]) (void)hipFree(l.d_w[0]);
+            if (l.d_w3) (void)hipFree(l.d_w3);
+            if (l.d_b3) (void)hipFree(l.d_b3);
             if (l.d_bias) (void)hipFree(l.d_bias);
             if (l.d_gamma) (void)hipFree(l.d_gamma);
             if (l.d_beta) (void)hipFree(l.d_beta);
@@ -373,14 +361,27 @@ static int upload_all(innfer_unet* u) {
                                                       return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
                 int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
             } else if (l.phases) {
-                // output channel (2a+b)*cout + c of tap (dy,dx) in {-1,0,1}^2: phase a takes ky = 1 (dy 0), 3 (dy -1) when a == 0 and
-                // ky = 0 (dy +1), 2 (dy 0) when a == 1 (oy = 2*iy - 1 + ky); the other (phase, tap) pairs are structural zeros
+                // The four output phases of ConvTranspose2d(k4, s2, p1) as ONE 3x3 convolution with 4*cout output channels over the
+                // un-upsampled input (conv3x3.hip's halo-tile kernel reads each input pixel once instead of once per tap): output channel
+                // (2a+b)*cout + c at tap (dy,dx) in {-1,0,1}^2 is w[ci][c][ky][kx] with ky = 1 (dy 0), 3 (dy -1) for a == 0 and
+                // ky = 0 (dy +1), 2 (dy 0) for a == 1 (oy = 2*iy - 1 + ky); the other (phase, tap) pairs are structural zeros.
                 auto kof = [](int a, int d) { return a == 0 ? (d == 0 ? 1 : (d == -1 ? 3 : -1)) : (d == 1 ? 0 : (d == 0 ? 2 : -1)); };
-                gg::pack_panels(panel, 4 * l.cout, l.cin, l.cin_pad, 9,
-                            [&](int co, int ci, int t) { const int ph = co / l.cout, c = co - ph * l.cout;
-                                                         const int ky = kof(ph >> 1, t / 3 - 1), kx = kof(ph & 1, t % 3 - 1);
-                                                         return ky < 0 || kx < 0 ? 0.f : w[(((size_t)ci * l.cout + c) * 4 + ky) * 4 + kx]; });
-                int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
+                const int K3 = 4 * l.cout;
+                std::vector<float> w3((size_t)K3 * l.cin_pad * 9, 0.f), b3(16, 0.f);
+                for (int co = 0; co < K3; ++co) {
+                    const int ph = co / l.cout, c = co - ph * l.cout;
+                    for (int ci = 0; ci < l.cin; ++ci)
+                        for (int t = 0; t < 9; ++t) {
+                            const int ky = kof(ph >> 1, t / 3 - 1), kx = kof(ph & 1, t % 3 - 1);
+                            if (ky >= 0 && kx >= 0) w3[((size_t)co * l.cin_pad + ci) * 9 + t] = w[(((size_t)ci * l.cout + c) * 4 + ky) * 4 + kx];
+                        }
+                    b3[co] = u->params[l.bias].host[c];
+                }
+                std::vector<char> packed(conv_packed_bytes(K3, l.cin_pad));
+                conv_pack(w3.data(), K3, l.cin_pad, packed.data());
+                if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+                INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+                int rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
             } else if (!l.transposed) {
                 gg::pack_panels(panel, l.cout, l.cin, l.cin_pad, 16,
                             [&](int co, int ci, int t) { return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
@@ -550,15 +551,15 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const f16* in = k == L - 1 ? (const f16*)(ws + cv.r_inner) : (const f16*)(ws + cv.CAT[k]);
         const long in_g = (long)N * h * w * 32;
         const int hf = 2 * h, wf = 2 * w;
-        if (l.phases) {
-            int dy9[9], dx9[9];
-            for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
-            const int rs = (4 * l.cout + 3) / 4 * 4;
-            int rc = run_gemm(l, l.d_w[0], in, in_g, N, h, w, raw, h, w, 1, 9, dy9, dx9, h, w, 1, 0, 0, s, splitk, rs);
+        if (l.phases) {       // outermost: 3x3 conv with 4*cout phase channels, bias, tanh and the phase scatter in the epilogue
+            ConvLaunch Lc{};
+            Lc.in = in; Lc.in_gstride = in_g; Lc.C = l.cin_pad;
+            Lc.wpk = (const f16*)l.d_w3; Lc.bias = l.d_b3;
+            Lc.out = d_out; Lc.K = 4 * l.cout; Lc.N = N; Lc.H = h; Lc.W = w;
+            Lc.act = 3; Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = h;
+            Lc.out_mode = OUT_NCHW; Lc.out_f32 = out_dtype == INNFER_F32; Lc.phase_c = l.cout;
+            int rc = conv_launch(Lc, s);
             if (rc) return rc;
-            hipLaunchKernelGGL(unet_final_phases, dim3((unsigned)(((long)N * hf * wf + 255) / 256)), dim3(256), 0, s, raw, rs, l.cout, h, w, N,
-                               l.d_bias, d_out, out_dtype == INNFER_F32);
-            INNFER_HIP(hipGetLastError());
             h = hf; w = wf;
             continue;
         }
