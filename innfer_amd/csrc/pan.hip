@@ -234,6 +234,7 @@ __global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f
 }
 
 // out = conv_last + bias + bilinear(x, align_corners=True) -> NCHW
+// (rs == 0: raw is the planar fp32 [N][C][FH][FW] output of the halo-tile conv, bias already added)
 __global__ void pan_final(const float* raw, int rs, const float* bias, int C, const void* x, int x_f32, int N, int H, int W,
                           int scale, void* out, int out_f32) {
     const int FH = H * scale, FW = W * scale;
@@ -257,8 +258,8 @@ __global__ void pan_final(const float* raw, int rs, const float* bias, int C, co
             il = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
         else
             il = at(Y, X);
-        const float v = raw[i * rs + c] + bias[c] + il;
         const long o = ((n * C + c) * FH + Y) * (long)FW + X;
+        const float v = (rs ? raw[i * rs + c] + bias[c] : raw[o]) + il;
         if (out_f32) ((float*)out)[o] = v; else ((f16*)out)[o] = (f16)v;
     }
 }
@@ -270,6 +271,9 @@ struct Gemm {                       // one packed GEMM
     f16* d_w = nullptr;
     std::function<float(int, int, int)> weight;        // (co, ci over the padded slab channels, tap) -> value
     int cin_used = 0;                                   // channels of the slab that may carry weights
+    // plain 3x3 convs (bias, optional LeakyReLU / residual) run on the SR path's halo-tile kernel (conv3x3.hip) instead:
+    bool tile3 = false; std::string bias_key;           // its packed panels [K3][cin_pad][3][3] and the bias padded with zeros
+    void* d_w3 = nullptr; float* d_b3 = nullptr; int K3 = 0;
 };
 
 }  // namespace
@@ -325,7 +329,7 @@ extern "C" int innfer_pan_create(innfer_pan** out, int in_nc, int out_nc, int nf
 
 extern "C" void innfer_pan_destroy(innfer_pan* p) {
     if (!p) return;
-    for (auto& g : p->gemms) if (g.d_w) (void)hipFree(g.d_w);
+    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
     delete p;
 }
@@ -364,12 +368,13 @@ int build_gemms(innfer_pan* p) {
     p->gemms.clear();
     const int nf = p->nf, gw = nf / 2, UF = p->unf;
     auto W = [p](const std::string& key) -> const std::vector<float>& { return p->params[find(p, key)].host; };
-    auto add = [&](int cin_pad, int cout, int ntaps, std::function<float(int, int, int)> f) {
+    auto add = [&](int cin_pad, int cout, int ntaps, std::function<float(int, int, int)> f, const char* tile3_bias = nullptr) {
         Gemm g; g.cin_pad = cin_pad; g.cout = cout; g.ntaps = ntaps; g.weight = f;
+        if (tile3_bias) { g.tile3 = true; g.bias_key = tile3_bias; }
         p->gemms.push_back(g);
     };
     {   const auto& w = W("conv_first.weight"); const int ci_n = p->in_nc;
-        add(32, nf, 9, [&w, ci_n](int co, int ci, int t) { return ci < ci_n ? w[((size_t)co * ci_n + ci) * 9 + t] : 0.f; }); }
+        add(32, nf, 9, [&w, ci_n](int co, int ci, int t) { return ci < ci_n ? w[((size_t)co * ci_n + ci) * 9 + t] : 0.f; }, "conv_first.bias"); }
     for (int b = 0; b < p->nb; ++b) {
         const std::string s = "SCPA_trunk." + std::to_string(b) + ".";
         const auto &wa = W(s + "conv1_a.weight"), &wb = W(s + "conv1_b.weight"), &k1 = W(s + "k1.0.weight"),
@@ -387,7 +392,7 @@ int build_gemms(innfer_pan* p) {
         add(64, nf, 1, [&c3, nf](int co, int ci, int) { return ci < nf ? c3[(size_t)co * nf + ci] : 0.f; });
     }
     {   const auto& w = W("trunk_conv.weight");
-        add(64, nf, 9, [&w, nf](int co, int ci, int t) { return ci < nf ? w[((size_t)co * nf + ci) * 9 + t] : 0.f; }); }
+        add(64, nf, 9, [&w, nf](int co, int ci, int t) { return ci < nf ? w[((size_t)co * nf + ci) * 9 + t] : 0.f; }, "trunk_conv.bias"); }
     {   const auto &wf = W("FSA.conv_f.weight"), &wg = W("FSA.conv_g.weight"), &wh = W("FSA.conv_h.weight");
         const int cq = nf / 8;
         add(64, 2 * cq + nf, 1, [&wf, &wg, &wh, nf, cq](int co, int ci, int) {
@@ -399,21 +404,44 @@ int build_gemms(innfer_pan* p) {
         const int i = 5 * u, cin = u == 0 ? nf : UF;
         const auto &w1 = W("upsample." + std::to_string(i + 1) + ".weight"), &wp = W("upsample." + std::to_string(i + 2) + ".conv.weight"),
                    &w4 = W("upsample." + std::to_string(i + 4) + ".weight");
-        add(u == 0 ? 64 : 32, UF, 9, [&w1, cin](int co, int ci, int t) { return ci < cin ? w1[((size_t)co * cin + ci) * 9 + t] : 0.f; });
+        const std::string b1 = "upsample." + std::to_string(i + 1) + ".bias", b4 = "upsample." + std::to_string(i + 4) + ".bias";
+        add(u == 0 ? 64 : 32, UF, 9, [&w1, cin](int co, int ci, int t) { return ci < cin ? w1[((size_t)co * cin + ci) * 9 + t] : 0.f; }, b1.c_str());
         add(32, UF, 1, [&wp, UF](int co, int ci, int) { return ci < UF ? wp[(size_t)co * UF + ci] : 0.f; });
-        add(32, UF, 9, [&w4, UF](int co, int ci, int t) { return ci < UF ? w4[((size_t)co * UF + ci) * 9 + t] : 0.f; });
+        add(32, UF, 9, [&w4, UF](int co, int ci, int t) { return ci < UF ? w4[((size_t)co * UF + ci) * 9 + t] : 0.f; }, b4.c_str());
     }
     {   const auto& w = W("conv_last.weight");
-        add(p->n_up ? 32 : 64, p->out_nc, 9, [&w, UF](int co, int ci, int t) { return ci < UF ? w[((size_t)co * UF + ci) * 9 + t] : 0.f; }); }
+        add(p->n_up ? 32 : 64, p->out_nc, 9, [&w, UF](int co, int ci, int t) { return ci < UF ? w[((size_t)co * UF + ci) * 9 + t] : 0.f; }, "conv_last.bias"); }
     return INNFER_OK;
 }
 
 int upload(innfer_pan* p) {
     for (auto& q : p->params) if (!q.set) return set_error(INNFER_ERR_INVALID, "pan: parameter '%s' was never set", q.key.c_str());
-    for (auto& g : p->gemms) if (g.d_w) { (void)hipFree(g.d_w); g.d_w = nullptr; }
+    for (auto& g : p->gemms) {
+        if (g.d_w) { (void)hipFree(g.d_w); g.d_w = nullptr; }
+        if (g.d_w3) { (void)hipFree(g.d_w3); g.d_w3 = nullptr; }
+        if (g.d_b3) { (void)hipFree(g.d_b3); g.d_b3 = nullptr; }
+    }
     build_gemms(p);
     std::vector<f16> panel;
     for (auto& g : p->gemms) {
+        if (g.tile3) {
+            // slab outputs carry whole 32-channel groups (pad channels: zero weights and bias, so they stay zero); the planar last conv
+            // keeps its own channel count
+            g.K3 = g.cout <= 16 ? g.cout : (g.cout + 31) / 32 * 32;
+            std::vector<float> w3((size_t)g.K3 * g.cin_pad * 9, 0.f), b3((size_t)(g.K3 + 63) / 64 * 64, 0.f);
+            for (int co = 0; co < g.cout; ++co)
+                for (int ci = 0; ci < g.cin_pad; ++ci)
+                    for (int t = 0; t < 9; ++t) w3[((size_t)co * g.cin_pad + ci) * 9 + t] = g.weight(co, ci, t);
+            const std::vector<float>& hb = p->params[find(p, g.bias_key)].host;
+            for (int co = 0; co < g.cout; ++co) b3[co] = hb[co];
+            std::vector<char> packed(conv_packed_bytes(g.K3, g.cin_pad));
+            conv_pack(w3.data(), g.K3, g.cin_pad, packed.data());
+            INNFER_HIP(hipMalloc(&g.d_w3, packed.size()));
+            INNFER_HIP(hipMemcpy(g.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+            INNFER_HIP(hipMalloc((void**)&g.d_b3, b3.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(g.d_b3, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
+            continue;
+        }
         gg::pack_panels(panel, g.cout, g.cin_pad, g.cin_pad, g.ntaps, g.weight);
         INNFER_HIP(hipMalloc((void**)&g.d_w, panel.size() * sizeof(f16)));
         INNFER_HIP(hipMemcpy(g.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
@@ -491,6 +519,21 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     };
+    // plain 3x3 conv on conv3x3.hip: dst = act(conv(in) + bias) [+ res]; planar != nullptr: fp32 NCHW output instead of a slab
+    auto conv3 = [&](const f16* in, long in_g, int Ho, int Wo, int up, int act, const f16* res, long res_g, f16* dst, long dst_g,
+                     float* planar = nullptr) -> int {
+        const Gemm& g = p->gemms[gi++];
+        if (!g.tile3) return set_error(INNFER_ERR_INVALID, "pan: conv %d is not a halo-tile conv", gi - 1);
+        ConvLaunch L{};
+        L.in = in; L.in_gstride = in_g; L.C = g.cin_pad;
+        L.wpk = (const f16*)g.d_w3; L.bias = g.d_b3;
+        L.out = planar ? (void*)planar : (void*)dst; L.out_gstride = dst_g; L.K = g.K3;
+        L.N = N; L.H = Ho; L.W = Wo; L.act = act; L.up = up;
+        L.res1 = res; L.res1_gstride = res_g; L.s1 = 1.f; L.s2 = 1.f;
+        L.y0 = 0; L.y1 = Ho;
+        L.out_mode = planar ? OUT_NCHW : OUT_SLAB; L.out_f32 = planar ? 1 : 0;
+        return conv_launch(L, s);
+    };
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
     f16 *X0 = (f16*)(ws + cv.x0), *FEA = (f16*)(ws + cv.fea), *XA = (f16*)(ws + cv.xa), *XB = (f16*)(ws + cv.xb),
         *AB = (f16*)(ws + cv.ab), *AB2 = (f16*)(ws + cv.ab2), *K3Y = (f16*)(ws + cv.k3y), *INP = (f16*)(ws + cv.inp),
@@ -498,8 +541,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
 
     hipLaunchKernelGGL(pan_pre, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, p->in_nc, (long)H * W, N, X0);
     INNFER_HIP(hipGetLastError());
-    CK(gemm(X0, G, H, W, H, W, 0));                                                   // conv_first
-    CK(post(px, nf, vec("conv_first.bias"), MODE_LIN, 0, nullptr, 0, 0, FEA, G, 0));
+    CK(conv3(X0, G, H, W, 0, 0, nullptr, 0, FEA, G));                                  // conv_first
     const f16* x = FEA;
     for (int b = 0; b < p->nb; ++b) {
         const std::string sk = "SCPA_trunk." + std::to_string(b) + ".";
@@ -516,8 +558,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         CK(post(px, nf, nullptr, MODE_LIN, 0, x, G, 0, xn, G, 0));
         x = xn;
     }
-    CK(gemm(x, G, H, W, H, W, 0));                                                    // trunk_conv; inp = fea + trunk
-    CK(post(px, nf, vec("trunk_conv.bias"), MODE_LIN, 0, FEA, G, 0, INP, G, 0));
+    CK(conv3(x, G, H, W, 0, 0, FEA, G, INP, G));                                       // trunk_conv; inp = fea + trunk
     {   // FSA
         const int hp = H / 4, wp = W / 4;
         const long np = (long)N * hp * wp, Gp = np * 32;
@@ -541,18 +582,16 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         const int i = 5 * u, hh = 2 * h, ww = 2 * w;
         const long hpx = (long)N * hh * ww, HG = hpx * 32;
         f16 *V = (f16*)(ws + cv.hr[u][0]), *PA = (f16*)(ws + cv.hr[u][1]), *HRC = (f16*)(ws + cv.hr[u][2]);
-        CK(gemm(cur, cur_g, h, w, hh, ww, 1));                                        // conv(nearest2x(t))
-        CK(post(hpx, UF, vec("upsample." + std::to_string(i + 1) + ".bias"), MODE_LIN, 0, nullptr, 0, 0, V, HG, 0));
+        CK(conv3(cur, cur_g, hh, ww, 1, 0, nullptr, 0, V, HG));                        // conv(nearest2x(t))
         CK(gemm(V, HG, hh, ww, hh, ww, 0));                                           // PA: v * sigmoid(conv1x1(v)), then lrelu
         CK(post(hpx, UF, vec("upsample." + std::to_string(i + 2) + ".conv.bias"), MODE_PA, 1, V, HG, 0, PA, HG, 0));
-        CK(gemm(PA, HG, hh, ww, hh, ww, 0));                                          // HRconv (no activation follows)
-        CK(post(hpx, UF, vec("upsample." + std::to_string(i + 4) + ".bias"), MODE_LIN, 0, nullptr, 0, 0, HRC, HG, 0));
+        CK(conv3(PA, HG, hh, ww, 0, 0, nullptr, 0, HRC, HG));                          // HRconv (no activation follows)
         cur = HRC; cur_g = HG; h = hh; w = ww;
     }
-    CK(gemm(cur, cur_g, h, w, h, w, 0));                                              // conv_last
+    CK(conv3(cur, cur_g, h, w, 0, 0, nullptr, 0, nullptr, 0, raw));                    // conv_last -> planar fp32 (+ bias)
     {
         const long fpx = (long)N * h * w;
-        hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, raw, raw_rs, vec("conv_last.bias"), p->out_nc,
+        hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, raw, 0, vec("conv_last.bias"), p->out_nc,
                            d_in, in_dtype == INNFER_F32, N, H, W, p->scale, d_out, out_dtype == INNFER_F32);
         INNFER_HIP(hipGetLastError());
     }
