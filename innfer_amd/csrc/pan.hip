@@ -8,8 +8,8 @@
 //   conv1_a | conv1_b                          ONE 40->40 1x1 GEMM (rows 0..19 = a, 20..39 = b)
 //   PACnv: k3(x) * sigmoid(k2(x))              ONE 3x3 GEMM whose rows 0..19 are k2 (centre tap only)
 //                                              and rows 20..39 are k3; the post kernel gates
-//   torch.cat([a, b])                          channel offsets 0 / 20 inside one slab
-//   channel slices (b = channels 20..39)       weights packed at the slice's positions, zeros elsewhere
+//   torch.cat([a, b])                          channel groups 0 / 1 of one slab (a: channels 0..19, b: 32..51)
+//   branch b of an SCPA                        channel group 1 (channels 32..51): the GEMMs over b read that group only
 //   LeakyReLU / sigmoid gates / residual adds  pan_post
 //   FSA: MaxPool2d(4) -> f,g,h 1x1 -> softmax(f^T g) -> h att^T -> bicubic up -> gamma*out + in
 //                                              pan_maxpool, one 40->50 GEMM, pan_attention (a query
@@ -370,7 +370,7 @@ int build_gemms(innfer_pan* p) {
     auto W = [p](const std::string& key) -> const std::vector<float>& { return p->params[find(p, key)].host; };
     auto add = [&](int cin_pad, int cout, int ntaps, std::function<float(int, int, int)> f, const char* tile3_bias = nullptr) {
         Gemm g; g.cin_pad = cin_pad; g.cout = cout; g.ntaps = ntaps; g.weight = f;
-        if (tile3_bias) { g.tile3 = true; g.bias_key = tile3_bias; }
+        if (tile3_bias) { g.tile3 = true; g.bias_key = tile3_bias; }           // "" = a halo-tile conv without bias
         p->gemms.push_back(g);
     };
     {   const auto& w = W("conv_first.weight"); const int ci_n = p->in_nc;
@@ -380,16 +380,21 @@ int build_gemms(innfer_pan* p) {
         const auto &wa = W(s + "conv1_a.weight"), &wb = W(s + "conv1_b.weight"), &k1 = W(s + "k1.0.weight"),
                    &k2 = W(s + "PACnv.k2.weight"), &k3 = W(s + "PACnv.k3.weight"), &k4 = W(s + "PACnv.k4.weight"),
                    &c3 = W(s + "conv3.weight");
-        add(64, nf, 1, [&wa, &wb, nf, gw](int co, int ci, int) {
+        // branch a lives in channel group 0 (channels 0..gw-1), branch b in group 1 (32..32+gw-1): group-aligned halves let the
+        // 3x3 convs of either branch run on the halo-tile kernel, which writes whole 32-channel groups
+        add(64, 32 + gw, 1, [&wa, &wb, nf, gw](int co, int ci, int) {
             if (ci >= nf) return 0.f;
-            return co < gw ? wa[(size_t)co * nf + ci] : wb[(size_t)(co - gw) * nf + ci]; });
-        add(32, gw, 9, [&k1, gw](int co, int ci, int t) { return ci < gw ? k1[((size_t)co * gw + ci) * 9 + t] : 0.f; });
-        add(64, nf, 9, [&k2, &k3, gw](int co, int ci, int t) {          // rows 0..gw-1: k2 (1x1 = centre tap), gw..: k3
-            if (ci < gw || ci >= 2 * gw) return 0.f;
-            if (co < gw) return t == 4 ? k2[(size_t)co * gw + (ci - gw)] : 0.f;
-            return k3[((size_t)(co - gw) * gw + (ci - gw)) * 9 + t]; });
-        add(32, gw, 9, [&k4, gw](int co, int ci, int t) { return ci < gw ? k4[((size_t)co * gw + ci) * 9 + t] : 0.f; });
-        add(64, nf, 1, [&c3, nf](int co, int ci, int) { return ci < nf ? c3[(size_t)co * nf + ci] : 0.f; });
+            if (co < gw) return wa[(size_t)co * nf + ci];
+            return co >= 32 ? wb[(size_t)(co - 32) * nf + ci] : 0.f; });
+        add(32, gw, 9, [&k1, gw](int co, int ci, int t) { return ci < gw ? k1[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
+        add(32, nf, 9, [&k2, &k3, gw](int co, int ci, int t) {          // on group 1 (b): rows 0..gw-1: k2 (1x1 = centre tap), gw..: k3
+            if (ci >= gw) return 0.f;
+            if (co < gw) return t == 4 ? k2[(size_t)co * gw + ci] : 0.f;
+            return k3[((size_t)(co - gw) * gw + ci) * 9 + t]; });
+        add(32, gw, 9, [&k4, gw](int co, int ci, int t) { return ci < gw ? k4[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
+        add(64, nf, 1, [&c3, nf, gw](int co, int ci, int) {             // cat[a, b] = channels 0..gw-1 and 32..32+gw-1
+            if (ci < gw) return c3[(size_t)co * nf + ci];
+            return ci >= 32 && ci < 32 + gw ? c3[(size_t)co * nf + gw + (ci - 32)] : 0.f; });
     }
     {   const auto& w = W("trunk_conv.weight");
         add(64, nf, 9, [&w, nf](int co, int ci, int t) { return ci < nf ? w[((size_t)co * nf + ci) * 9 + t] : 0.f; }, "trunk_conv.bias"); }
@@ -432,8 +437,10 @@ int upload(innfer_pan* p) {
             for (int co = 0; co < g.cout; ++co)
                 for (int ci = 0; ci < g.cin_pad; ++ci)
                     for (int t = 0; t < 9; ++t) w3[((size_t)co * g.cin_pad + ci) * 9 + t] = g.weight(co, ci, t);
-            const std::vector<float>& hb = p->params[find(p, g.bias_key)].host;
-            for (int co = 0; co < g.cout; ++co) b3[co] = hb[co];
+            if (!g.bias_key.empty()) {
+                const std::vector<float>& hb = p->params[find(p, g.bias_key)].host;
+                for (int co = 0; co < g.cout; ++co) b3[co] = hb[co];
+            }
             std::vector<char> packed(conv_packed_bytes(g.K3, g.cin_pad));
             conv_pack(w3.data(), g.K3, g.cin_pad, packed.data());
             INNFER_HIP(hipMalloc(&g.d_w3, packed.size()));
@@ -546,14 +553,12 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     for (int b = 0; b < p->nb; ++b) {
         const std::string sk = "SCPA_trunk." + std::to_string(b) + ".";
         f16* xn = (b & 1) ? XB : XA;
-        CK(gemm(x, G, H, W, H, W, 0));                                                // [conv1_a | conv1_b]
-        CK(post(px, nf, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB, G, 0));
-        CK(gemm(AB, G, H, W, H, W, 0));                                               // k1(a)
-        CK(post(px, gw, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB2, G, 0));
-        CK(gemm(AB, G, H, W, H, W, 0));                                               // [k2(b) | k3(b)]
+        CK(gemm(x, G, H, W, H, W, 0));                                                // [conv1_a | . | conv1_b]: a -> group 0, b -> group 1
+        CK(post(px, 32 + gw, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB, G, 0));
+        CK(conv3(AB, G, H, W, 0, 1, nullptr, 0, AB2, G));                             // lrelu(k1(a)) -> cat group 0
+        CK(gemm(AB + G, G, H, W, H, W, 0));                                           // [k2(b) | k3(b)]
         CK(post(px, gw, vec(sk + "PACnv.k2.bias"), MODE_GATE, 0, nullptr, 0, 0, K3Y, G, 0));
-        CK(gemm(K3Y, G, H, W, H, W, 0));                                              // k4
-        CK(post(px, gw, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB2, G, gw));
+        CK(conv3(K3Y, G, H, W, 0, 1, nullptr, 0, AB2 + G, G));                        // lrelu(k4(.)) -> cat group 1
         CK(gemm(AB2, G, H, W, H, W, 0));                                              // conv3(cat[a,b]) + x
         CK(post(px, nf, nullptr, MODE_LIN, 0, x, G, 0, xn, G, 0));
         x = xn;
