@@ -6,8 +6,7 @@
 //                                              to 32/64 in blocked-NHWC fp16 slabs whose pad
 //                                              channels are kept zero; fp32 outputs
 //   conv1_a | conv1_b                          ONE 40->40 1x1 GEMM (rows 0..19 = a, 20..39 = b)
-//   PACnv: k3(x) * sigmoid(k2(x))              ONE 3x3 GEMM whose rows 0..19 are k2 (centre tap only)
-//                                              and rows 20..39 are k3; the post kernel gates
+//   PACnv: k3(x) * sigmoid(k2(x))              k3 on the halo-tile kernel (fp16 slab), k2 a 1x1 GEMM whose post kernel gates
 //   torch.cat([a, b])                          channel groups 0 / 1 of one slab (a: channels 0..19, b: 32..51)
 //   branch b of an SCPA                        channel group 1 (channels 32..51): the GEMMs over b read that group only
 //   LeakyReLU / sigmoid gates / residual adds  pan_post
@@ -33,7 +32,7 @@ using namespace innfer;
 
 namespace {
 
-enum { MODE_LIN = 0, MODE_GATE = 1, MODE_PA = 2 };
+enum { MODE_LIN = 0, MODE_PA = 2 };
 
 struct PP {
     const float* raw; int rs; int C; const float* bias; int mode; int act;   // rs: floats per raw row; act: 1 = LeakyReLU(0.2)
@@ -58,11 +57,7 @@ __global__ void pan_post(const PP p) {
     const float* r = p.raw + pix * p.rs;
     const f32x4 a = *(const f32x4*)(r + c);
     float y[4];
-    if (p.mode == MODE_GATE) {
-        const f32x4 v = *(const f32x4*)(r + p.C + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = v[e] * (1.0f / (1.0f + expf(-(a[e] + p.bias[c + e]))));
-    } else if (p.mode == MODE_PA) {
+    if (p.mode == MODE_PA) {
         const int ch = p.res_off + c;
         const f16x4 v = *(const f16x4*)(p.res + (ch >> 5) * p.res_g + pix * 32 + (ch & 31));
 #pragma unroll
@@ -387,10 +382,8 @@ int build_gemms(innfer_pan* p) {
             if (co < gw) return wa[(size_t)co * nf + ci];
             return co >= 32 ? wb[(size_t)(co - 32) * nf + ci] : 0.f; });
         add(32, gw, 9, [&k1, gw](int co, int ci, int t) { return ci < gw ? k1[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
-        add(32, nf, 9, [&k2, &k3, gw](int co, int ci, int t) {          // on group 1 (b): rows 0..gw-1: k2 (1x1 = centre tap), gw..: k3
-            if (ci >= gw) return 0.f;
-            if (co < gw) return t == 4 ? k2[(size_t)co * gw + ci] : 0.f;
-            return k3[((size_t)(co - gw) * gw + ci) * 9 + t]; });
+        add(32, gw, 9, [&k3, gw](int co, int ci, int t) { return ci < gw ? k3[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");   // k3(b), halo tile
+        add(32, gw, 1, [&k2, gw](int co, int ci, int) { return ci < gw ? k2[(size_t)co * gw + ci] : 0.f; });                    // k2(b), 1x1
         add(32, gw, 9, [&k4, gw](int co, int ci, int t) { return ci < gw ? k4[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
         add(64, nf, 1, [&c3, nf, gw](int co, int ci, int) {             // cat[a, b] = channels 0..gw-1 and 32..32+gw-1
             if (ci < gw) return c3[(size_t)co * nf + ci];
@@ -465,7 +458,7 @@ int upload(innfer_pan* p) {
     return INNFER_OK;
 }
 
-struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, inp, t, pool, fgh, att, raw, hr[2][3], total, slab_end; };
+struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, k3v, inp, t, pool, fgh, att, raw, hr[2][3], total, slab_end; };
 
 PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     PCarve c{};
@@ -474,7 +467,7 @@ PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     size_t off = 0;
     auto slab = [&](size_t pixels, int groups) { size_t o = off; off += al(pixels * 32 * 2 * groups); return o; };
     c.x0 = slab(px, 1); c.fea = slab(px, 2); c.xa = slab(px, 2); c.xb = slab(px, 2); c.ab = slab(px, 2);
-    c.ab2 = slab(px, 2); c.k3y = slab(px, 1); c.inp = slab(px, 2); c.t = slab(px, 2); c.pool = slab(np ? np : 1, 2);
+    c.ab2 = slab(px, 2); c.k3y = slab(px, 1); c.k3v = slab(px, 1); c.inp = slab(px, 2); c.t = slab(px, 2); c.pool = slab(np ? np : 1, 2);
     size_t m = 1;
     for (int u = 0; u < p->n_up; ++u) { m *= 4; for (int k = 0; k < 3; ++k) c.hr[u][k] = slab(px * m, 1); }
     c.slab_end = off;
@@ -543,7 +536,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     };
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
     f16 *X0 = (f16*)(ws + cv.x0), *FEA = (f16*)(ws + cv.fea), *XA = (f16*)(ws + cv.xa), *XB = (f16*)(ws + cv.xb),
-        *AB = (f16*)(ws + cv.ab), *AB2 = (f16*)(ws + cv.ab2), *K3Y = (f16*)(ws + cv.k3y), *INP = (f16*)(ws + cv.inp),
+        *AB = (f16*)(ws + cv.ab), *AB2 = (f16*)(ws + cv.ab2), *K3Y = (f16*)(ws + cv.k3y), *K3V = (f16*)(ws + cv.k3v), *INP = (f16*)(ws + cv.inp),
         *T = (f16*)(ws + cv.t), *POOL = (f16*)(ws + cv.pool);
 
     hipLaunchKernelGGL(pan_pre, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, p->in_nc, (long)H * W, N, X0);
@@ -556,8 +549,9 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         CK(gemm(x, G, H, W, H, W, 0));                                                // [conv1_a | . | conv1_b]: a -> group 0, b -> group 1
         CK(post(px, 32 + gw, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB, G, 0));
         CK(conv3(AB, G, H, W, 0, 1, nullptr, 0, AB2, G));                             // lrelu(k1(a)) -> cat group 0
-        CK(gemm(AB + G, G, H, W, H, W, 0));                                           // [k2(b) | k3(b)]
-        CK(post(px, gw, vec(sk + "PACnv.k2.bias"), MODE_GATE, 0, nullptr, 0, 0, K3Y, G, 0));
+        CK(conv3(AB + G, G, H, W, 0, 0, nullptr, 0, K3V, G));                         // k3(b)
+        CK(gemm(AB + G, G, H, W, H, W, 0));                                           // k2(b); y = k3(b) * sigmoid(k2(b) + bias)
+        CK(post(px, gw, vec(sk + "PACnv.k2.bias"), MODE_PA, 0, K3V, G, 0, K3Y, G, 0));
         CK(conv3(K3Y, G, H, W, 0, 1, nullptr, 0, AB2 + G, G));                        // lrelu(k4(.)) -> cat group 1
         CK(gemm(AB2, G, H, W, H, W, 0));                                              // conv3(cat[a,b]) + x
         CK(post(px, nf, nullptr, MODE_LIN, 0, x, G, 0, xn, G, 0));
