@@ -377,17 +377,20 @@ int build_gemms(innfer_pan* p) {
                    &c3 = W(s + "conv3.weight");
         // branch a lives in channel group 0 (channels 0..gw-1), branch b in group 1 (32..32+gw-1): group-aligned halves let the
         // 3x3 convs of either branch run on the halo-tile kernel, which writes whole 32-channel groups
-        add(64, 32 + gw, 1, [&wa, &wb, nf, gw](int co, int ci, int) {
-            if (ci >= nf) return 0.f;
+        // (the two 40-channel 1x1 convs of a block also run on the halo-tile kernel, as 3x3 convs with a centre tap only: the kernel is
+        //  bound by its loads and stores at these widths, and its epilogue writes the fp16 slab that a GEMM + post pair needs two passes for)
+        add(64, 32 + gw, 9, [&wa, &wb, nf, gw](int co, int ci, int t) {
+            if (ci >= nf || t != 4) return 0.f;
             if (co < gw) return wa[(size_t)co * nf + ci];
-            return co >= 32 ? wb[(size_t)(co - 32) * nf + ci] : 0.f; });
+            return co >= 32 ? wb[(size_t)(co - 32) * nf + ci] : 0.f; }, "");
         add(32, gw, 9, [&k1, gw](int co, int ci, int t) { return ci < gw ? k1[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
         add(32, gw, 9, [&k3, gw](int co, int ci, int t) { return ci < gw ? k3[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");   // k3(b), halo tile
         add(32, gw, 1, [&k2, gw](int co, int ci, int) { return ci < gw ? k2[(size_t)co * gw + ci] : 0.f; });                    // k2(b), 1x1
         add(32, gw, 9, [&k4, gw](int co, int ci, int t) { return ci < gw ? k4[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
-        add(64, nf, 1, [&c3, nf, gw](int co, int ci, int) {             // cat[a, b] = channels 0..gw-1 and 32..32+gw-1
+        add(64, nf, 9, [&c3, nf, gw](int co, int ci, int t) {           // cat[a, b] = channels 0..gw-1 and 32..32+gw-1
+            if (t != 4) return 0.f;
             if (ci < gw) return c3[(size_t)co * nf + ci];
-            return ci >= 32 && ci < 32 + gw ? c3[(size_t)co * nf + gw + (ci - 32)] : 0.f; });
+            return ci >= 32 && ci < 32 + gw ? c3[(size_t)co * nf + gw + (ci - 32)] : 0.f; }, "");
     }
     {   const auto& w = W("trunk_conv.weight");
         add(64, nf, 9, [&w, nf](int co, int ci, int t) { return ci < nf ? w[((size_t)co * nf + ci) * 9 + t] : 0.f; }, "trunk_conv.bias"); }
@@ -546,15 +549,13 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     for (int b = 0; b < p->nb; ++b) {
         const std::string sk = "SCPA_trunk." + std::to_string(b) + ".";
         f16* xn = (b & 1) ? XB : XA;
-        CK(gemm(x, G, H, W, H, W, 0));                                                // [conv1_a | . | conv1_b]: a -> group 0, b -> group 1
-        CK(post(px, 32 + gw, nullptr, MODE_LIN, 1, nullptr, 0, 0, AB, G, 0));
+        CK(conv3(x, G, H, W, 0, 1, nullptr, 0, AB, G));                               // lrelu([conv1_a | . | conv1_b]): a -> group 0, b -> group 1
         CK(conv3(AB, G, H, W, 0, 1, nullptr, 0, AB2, G));                             // lrelu(k1(a)) -> cat group 0
         CK(conv3(AB + G, G, H, W, 0, 0, nullptr, 0, K3V, G));                         // k3(b)
         CK(gemm(AB + G, G, H, W, H, W, 0));                                           // k2(b); y = k3(b) * sigmoid(k2(b) + bias)
         CK(post(px, gw, vec(sk + "PACnv.k2.bias"), MODE_PA, 0, K3V, G, 0, K3Y, G, 0));
         CK(conv3(K3Y, G, H, W, 0, 1, nullptr, 0, AB2 + G, G));                        // lrelu(k4(.)) -> cat group 1
-        CK(gemm(AB2, G, H, W, H, W, 0));                                              // conv3(cat[a,b]) + x
-        CK(post(px, nf, nullptr, MODE_LIN, 0, x, G, 0, xn, G, 0));
+        CK(conv3(AB2, G, H, W, 0, 0, x, G, xn, G));                                   // conv3(cat[a,b]) + x
         x = xn;
     }
     CK(conv3(x, G, H, W, 0, 0, FEA, G, INP, G));                                       // trunk_conv; inp = fea + trunk
