@@ -143,10 +143,15 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float f = acc[t][m][j];
-                if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
-                if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
+                if (ACT >= 4) {           // pixel-attention gate (PAN): res1 * sigmoid(conv), ACT 4: LeakyReLU(0.2) after it
+                    f = (float)r1[R1 ? m : 0][t][j] * (1.0f / (1.0f + expf(-f)));
+                    if (ACT == 4) f = fmaxf(f, 0.2f * f);
+                } else {
+                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
+                    if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
+                }
                 FP32_VALUE(f);
                 h[j] = (f16)f;
             }
@@ -699,7 +704,8 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
-                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
+                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else if (p.act == 4) EPI(4, true, false);
+                else if (p.act == 5) EPI(5, true, false); else EPI(0, true, false);
             } else {
                 if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
             }
@@ -892,7 +898,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.wpk = L.wpk; k.bias = L.bias;
     k.out = L.out; k.out_gstride = L.out_gstride; k.out_coff = L.out_coff;
     k.K = L.K; k.KG = conv_groups(L.K);
-    if (L.act < 0 || L.act > 3 || (L.phase_c > 0 && (L.K % L.phase_c || L.K / L.phase_c != 4)))
+    if (L.act >= 4 && (L.out_mode != OUT_SLAB || !L.res1 || L.res2))
+        return set_error(INNFER_ERR_INVALID, "conv3x3: the gate epilogue multiplies res1 (slab output, no second residual)");
+    if (L.act < 0 || L.act > 5 || (L.phase_c > 0 && (L.K % L.phase_c || L.K / L.phase_c != 4)))
         return set_error(INNFER_ERR_INVALID, "conv3x3: act=%d phase_c=%d K=%d", L.act, L.phase_c, L.K);
     k.act = L.act;
     k.res1 = L.res1; k.res1_gstride = L.res1_gstride; k.s1 = L.s1;
@@ -911,8 +919,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2) return launch_pc<3, 1, 4, OUT_NCHW>(k, L.N, s);
-    if (L.act == 3 || L.phase_c > 0)
-        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tanh / phase output exist only in the producer-consumer planar epilogue (K <= 16, no residual)");
+    if (L.act >= 3 || L.phase_c > 0)
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tanh / phase output / gate epilogues exist only in the producer-consumer kernel");
     switch (L.out_mode) {
         case OUT_SLAB:
             if (nt == 4) return rpw64 == 4 ? launch_t<4, 4, OUT_SLAB>(k, L.N, s) : rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);

@@ -2,20 +2,20 @@
 // Replaces architectures/PAN_arch.py:11-222 (defaults utils/defaults.py:78-89: nf 40, unf 24,
 // nb 16, self attention on, nearest up-blocks) and SelfAttentionBlock (block.py:398-473).
 //
-//   every conv (1x1 and 3x3, 3..40 channels)   gather-GEMM on MFMA (gather_gemm.h), channels padded
-//                                              to 32/64 in blocked-NHWC fp16 slabs whose pad
-//                                              channels are kept zero; fp32 outputs
-//   conv1_a | conv1_b                          ONE 40->40 1x1 GEMM (rows 0..19 = a, 20..39 = b)
-//   PACnv: k3(x) * sigmoid(k2(x))              k3 on the halo-tile kernel (fp16 slab), k2 a 1x1 GEMM whose post kernel gates
-//   torch.cat([a, b])                          channel groups 0 / 1 of one slab (a: channels 0..19, b: 32..51)
-//   branch b of an SCPA                        channel group 1 (channels 32..51): the GEMMs over b read that group only
-//   LeakyReLU / sigmoid gates / residual adds  pan_post
+//   every conv of the network (3..40 channels, 3x3 and 1x1) runs on the SR path's halo-tile MFMA kernel (conv3x3.hip,
+//   conv3x3_pc): channels padded to whole 32-channel groups of blocked-NHWC fp16 slabs whose pad channels are kept zero
+//   (zero weights and bias), a 1x1 conv = a 3x3 panel with a centre tap only (the kernel is bound by its loads and
+//   stores at these widths; its epilogue writes the fp16 slab directly); epilogues used: bias, LeakyReLU(0.2), + residual,
+//   nearest-2x input (`up`), res1 * sigmoid(conv) (pixel attention, with / without LeakyReLU), planar fp32 (conv_last)
+//   conv1_a | conv1_b                          ONE 40->52 conv: a -> channel group 0 (0..19), b -> group 1 (32..51)
+//   PACnv: k3(x) * sigmoid(k2(x))              k3 -> fp16 slab, then k2 with the gate epilogue multiplying it
+//   torch.cat([a, b])                          channel groups 0 / 1 of one slab; conv3 reads both
 //   FSA: MaxPool2d(4) -> f,g,h 1x1 -> softmax(f^T g) -> h att^T -> bicubic up -> gamma*out + in
-//                                              pan_maxpool, one 40->50 GEMM, pan_attention (a query
+//                                              pan_maxpool, one 40->50 gather GEMM (gather_gemm.h, fp32 rows), pan_attention (a query
 //                                              per lane, keys split over 4 waves and tiled through LDS, two-pass
 //                                              softmax, no N x N matrix in memory), pan_fsa_combine (ATen's
 //                                              bicubic, A = -0.75, align_corners=False)
-//   nearest-2x Upsample in the up-blocks       folded into the GEMM's gather (GP.up)
+//   nearest-2x Upsample in the up-blocks       folded into the conv's input addressing (ConvLaunch.up)
 //   + bilinear(x, align_corners=True)          pan_final, NCHW output
 // Reference quirk kept: B.sequential() flattens with children(), which yields the shared LeakyReLU
 // of pa_upconv_block once, so NO activation follows HRconv (golden G8 confirms).
@@ -32,55 +32,8 @@ using namespace innfer;
 
 namespace {
 
-enum { MODE_LIN = 0, MODE_PA = 2 };
-
-struct PP {
-    const float* raw; int rs; int C; const float* bias; int mode; int act;   // rs: floats per raw row; act: 1 = LeakyReLU(0.2)
-    const f16* res; long res_g; int res_off;                              // MODE_LIN: + res ; MODE_PA: * v
-    f16* dst; long dst_g; int dst_off;
-    long npix;
-};
-
 __device__ __forceinline__ float slab_get(const f16* s, long g, long pix, int ch) {
     return (float)s[(ch >> 5) * g + pix * 32 + (ch & 31)];
-}
-
-// One thread per (pixel, 4 consecutive channels): 16-byte reads of the fp32 GEMM rows, 8-byte reads /
-// writes of the fp16 slabs.  Every channel count (20, 24, 40) and channel offset (0, 20) on this
-// path is a multiple of 4, and a 4-channel run never straddles a 32-channel group.
-__global__ void pan_post(const PP p) {
-    const int c4 = p.C >> 2;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.npix * c4) return;
-    const long pix = i / c4;
-    const int c = (int)(i - pix * c4) * 4;
-    const float* r = p.raw + pix * p.rs;
-    const f32x4 a = *(const f32x4*)(r + c);
-    float y[4];
-    if (p.mode == MODE_PA) {
-        const int ch = p.res_off + c;
-        const f16x4 v = *(const f16x4*)(p.res + (ch >> 5) * p.res_g + pix * 32 + (ch & 31));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (float)v[e] * (1.0f / (1.0f + expf(-(a[e] + p.bias[c + e]))));
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = a[e] + (p.bias ? p.bias[c + e] : 0.f);
-    }
-    if (p.act == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.2f * y[e]);
-    }
-    if (p.mode == MODE_LIN && p.res) {
-        const int ch = p.res_off + c;
-        const f16x4 v = *(const f16x4*)(p.res + (ch >> 5) * p.res_g + pix * 32 + (ch & 31));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] += (float)v[e];
-    }
-    const int ch = p.dst_off + c;
-    f16x4 h;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = (f16)y[e];
-    *(f16x4*)(p.dst + (ch >> 5) * p.dst_g + pix * 32 + (ch & 31)) = h;
 }
 
 __global__ void pan_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {
@@ -385,7 +338,8 @@ int build_gemms(innfer_pan* p) {
             return co >= 32 ? wb[(size_t)(co - 32) * nf + ci] : 0.f; }, "");
         add(32, gw, 9, [&k1, gw](int co, int ci, int t) { return ci < gw ? k1[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
         add(32, gw, 9, [&k3, gw](int co, int ci, int t) { return ci < gw ? k3[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");   // k3(b), halo tile
-        add(32, gw, 1, [&k2, gw](int co, int ci, int) { return ci < gw ? k2[(size_t)co * gw + ci] : 0.f; });                    // k2(b), 1x1
+        const std::string kb = s + "PACnv.k2.bias";
+        add(32, gw, 9, [&k2, gw](int co, int ci, int t) { return ci < gw && t == 4 ? k2[(size_t)co * gw + ci] : 0.f; }, kb.c_str());   // k2(b), 1x1
         add(32, gw, 9, [&k4, gw](int co, int ci, int t) { return ci < gw ? k4[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
         add(64, nf, 9, [&c3, nf, gw](int co, int ci, int t) {           // cat[a, b] = channels 0..gw-1 and 32..32+gw-1
             if (t != 4) return 0.f;
@@ -407,7 +361,8 @@ int build_gemms(innfer_pan* p) {
                    &w4 = W("upsample." + std::to_string(i + 4) + ".weight");
         const std::string b1 = "upsample." + std::to_string(i + 1) + ".bias", b4 = "upsample." + std::to_string(i + 4) + ".bias";
         add(u == 0 ? 64 : 32, UF, 9, [&w1, cin](int co, int ci, int t) { return ci < cin ? w1[((size_t)co * cin + ci) * 9 + t] : 0.f; }, b1.c_str());
-        add(32, UF, 1, [&wp, UF](int co, int ci, int) { return ci < UF ? wp[(size_t)co * UF + ci] : 0.f; });
+        const std::string bp = "upsample." + std::to_string(i + 2) + ".conv.bias";
+        add(32, UF, 9, [&wp, UF](int co, int ci, int t) { return ci < UF && t == 4 ? wp[(size_t)co * UF + ci] : 0.f; }, bp.c_str());
         add(32, UF, 9, [&w4, UF](int co, int ci, int t) { return ci < UF ? w4[((size_t)co * UF + ci) * 9 + t] : 0.f; }, b4.c_str());
     }
     {   const auto& w = W("conv_last.weight");
@@ -499,7 +454,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     char* ws = (char*)d_ws;
     INNFER_HIP(hipMemsetAsync(ws, 0, cv.slab_end, s));            // pad channels of every slab must read as zero
     const long px = (long)N * H * W, G = px * 32;
-    const int nf = p->nf, gw = nf / 2, UF = p->unf;
+    const int nf = p->nf;
     float* raw = (float*)(ws + cv.raw);
     int dy9[9], dx9[9], d0[1] = {0};
     for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
@@ -512,15 +467,6 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         raw_rs = full_rows ? 64 : (g.cout + 3) / 4 * 4;
         return gg::launch(g.d_w, g.cin_pad, 64, in, in_g, N, Hin, Win, raw, Ho, Wo, 1, g.ntaps,
                           g.ntaps == 9 ? dy9 : d0, g.ntaps == 9 ? dx9 : d0, Ho, Wo, 1, 0, 0, up, s, nullptr, 0, raw_rs);
-    };
-    auto post = [&](long npix, int C, const float* bias, int mode, int act, const f16* res, long res_g, int res_off,
-                    f16* dst, long dst_g, int dst_off) -> int {
-        PP q{raw, raw_rs, C, bias, mode, act, res, res_g, res_off, dst, dst_g, dst_off, npix};
-        if (C & 3) return set_error(INNFER_ERR_UNSUPPORTED, "pan_post: channel count %d is not a multiple of 4", C);
-        const long nthr = npix * (C >> 2);
-        hipLaunchKernelGGL(pan_post, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, q);
-        INNFER_HIP(hipGetLastError());
-        return INNFER_OK;
     };
     // plain 3x3 conv on conv3x3.hip: dst = act(conv(in) + bias) [+ res]; planar != nullptr: fp32 NCHW output instead of a slab
     auto conv3 = [&](const f16* in, long in_g, int Ho, int Wo, int up, int act, const f16* res, long res_g, f16* dst, long dst_g,
@@ -552,8 +498,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         CK(conv3(x, G, H, W, 0, 1, nullptr, 0, AB, G));                               // lrelu([conv1_a | . | conv1_b]): a -> group 0, b -> group 1
         CK(conv3(AB, G, H, W, 0, 1, nullptr, 0, AB2, G));                             // lrelu(k1(a)) -> cat group 0
         CK(conv3(AB + G, G, H, W, 0, 0, nullptr, 0, K3V, G));                         // k3(b)
-        CK(gemm(AB + G, G, H, W, H, W, 0));                                           // k2(b); y = k3(b) * sigmoid(k2(b) + bias)
-        CK(post(px, gw, vec(sk + "PACnv.k2.bias"), MODE_PA, 0, K3V, G, 0, K3Y, G, 0));
+        CK(conv3(AB + G, G, H, W, 0, 5, K3V, G, K3Y, G));                             // y = k3(b) * sigmoid(k2(b) + bias): gate epilogue
         CK(conv3(K3Y, G, H, W, 0, 1, nullptr, 0, AB2 + G, G));                        // lrelu(k4(.)) -> cat group 1
         CK(conv3(AB2, G, H, W, 0, 0, x, G, xn, G));                                   // conv3(cat[a,b]) + x
         x = xn;
@@ -579,12 +524,11 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     long cur_g = G;
     int h = H, w = W;
     for (int u = 0; u < p->n_up; ++u) {
-        const int i = 5 * u, hh = 2 * h, ww = 2 * w;
+        const int hh = 2 * h, ww = 2 * w;
         const long hpx = (long)N * hh * ww, HG = hpx * 32;
         f16 *V = (f16*)(ws + cv.hr[u][0]), *PA = (f16*)(ws + cv.hr[u][1]), *HRC = (f16*)(ws + cv.hr[u][2]);
         CK(conv3(cur, cur_g, hh, ww, 1, 0, nullptr, 0, V, HG));                        // conv(nearest2x(t))
-        CK(gemm(V, HG, hh, ww, hh, ww, 0));                                           // PA: v * sigmoid(conv1x1(v)), then lrelu
-        CK(post(hpx, UF, vec("upsample." + std::to_string(i + 2) + ".conv.bias"), MODE_PA, 1, V, HG, 0, PA, HG, 0));
+        CK(conv3(V, HG, hh, ww, 0, 4, V, HG, PA, HG));                                 // PA: lrelu(v * sigmoid(conv1x1(v)))
         CK(conv3(PA, HG, hh, ww, 0, 0, nullptr, 0, HRC, HG));                          // HRconv (no activation follows)
         cur = HRC; cur_g = HG; h = hh; w = ww;
     }
