@@ -46,18 +46,27 @@ __global__ void pan_pre(const void* in, int in_f32, int C, long HW, int N, f16* 
     }
 }
 
+// MaxPool2d(4): one thread per (pooled pixel, 8 channels), 16-byte loads (C % 8 == 0)
 __global__ void pan_maxpool(const f16* in, long in_g, int C, int N, int H, int W, int hp, int wp, f16* out, long out_g) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * hp * wp) return;
+    const int c8 = C >> 3;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * hp * wp * c8) return;
+    const long i = t / c8;
+    const int c = (int)(t - i * c8) * 8;
     const int x = (int)(i % wp), y = (int)((i / wp) % hp);
     const long n = i / ((long)wp * hp);
-    for (int c = 0; c < C; ++c) {
-        float m = -INFINITY;
-        for (int dy = 0; dy < 4; ++dy)
-            for (int dx = 0; dx < 4; ++dx)
-                m = fmaxf(m, slab_get(in, in_g, (n * H + 4 * y + dy) * W + 4 * x + dx, c));
-        out[(c >> 5) * out_g + i * 32 + (c & 31)] = (f16)m;
-    }
+    const f16* base = in + (c >> 5) * in_g + (c & 31);
+    f16x8 m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = (f16)-INFINITY;
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const f16x8 v = *(const f16x8*)(base + ((n * H + 4 * y + dy) * W + 4 * x + dx) * 32);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+        }
+    *(f16x8*)(out + (c >> 5) * out_g + i * 32 + (c & 31)) = m;
 }
 
 // fgh: fp32 [N*Np][64] = [f(5) | g(5) | h(40)] without bias.  att_j = softmax_j(f_i . g_j);
@@ -152,8 +161,11 @@ __device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * 
 // t = gamma * bicubic(att, size=(H,W), align_corners=False) + inp      (ATen upsample_bicubic2d)
 __global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f16* inp, long g, int N, int H, int W,
                                 const float* gamma, f16* dst) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * H * W) return;
+    const int c8 = C >> 3;                           // one thread per (pixel, 8 channels); per channel the same sums in the same order
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * H * W * c8) return;
+    const long i = t / c8;
+    const int c0 = (int)(t - i * c8) * 8;
     const int X = (int)(i % W), Y = (int)((i / W) % H);
     const long n = i / ((long)W * H);
     const float A = -0.75f;
@@ -164,21 +176,28 @@ __global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f
     const float wy[4] = {cc2(ty + 1.f, A), cc1(ty, A), cc1(1.f - ty, A), cc2(2.f - ty, A)};
     const float wx[4] = {cc2(tx + 1.f, A), cc1(tx, A), cc1(1.f - tx, A), cc2(2.f - tx, A)};
     const float gm = gamma[0];
-    const float* an = att + n * (long)hp * wp * C;
-    for (int c = 0; c < C; ++c) {
-        float v = 0.f;
-        for (int a = 0; a < 4; ++a) {
-            const int yy = min(max(iy - 1 + a, 0), hp - 1);
-            float row = 0.f;
-            for (int b = 0; b < 4; ++b) {
-                const int xx = min(max(ix - 1 + b, 0), wp - 1);
-                row += an[((long)yy * wp + xx) * C + c] * wx[b];
-            }
-            v += row * wy[a];
+    const float* an = att + n * (long)hp * wp * C + c0;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), hp - 1);
+        float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xx = min(max(ix - 1 + b, 0), wp - 1);
+            const float* q = an + ((long)yy * wp + xx) * C;
+            const f32x4 q0 = *(const f32x4*)q, q1 = *(const f32x4*)(q + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { row[e] += q0[e] * wx[b]; row[4 + e] += q1[e] * wx[b]; }
         }
-        const float y = gm * v + slab_get(inp, g, i, c);
-        dst[(c >> 5) * g + i * 32 + (c & 31)] = (f16)y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += row[e] * wy[a];
     }
+    const long so = (c0 >> 5) * g + i * 32 + (c0 & 31);
+    const f16x8 in8 = *(const f16x8*)(inp + so);
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (f16)(gm * v[e] + (float)in8[e]);
+    *(f16x8*)(dst + so) = h;
 }
 
 // out = conv_last + bias + bilinear(x, align_corners=True) -> NCHW
@@ -507,7 +526,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     {   // FSA
         const int hp = H / 4, wp = W / 4;
         const long np = (long)N * hp * wp, Gp = np * 32;
-        hipLaunchKernelGGL(pan_maxpool, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, INP, G, nf, N, H, W, hp, wp, POOL, Gp);
+        hipLaunchKernelGGL(pan_maxpool, dim3((unsigned)((np * (nf / 8) + 255) / 256)), dim3(256), 0, s, INP, G, nf, N, H, W, hp, wp, POOL, Gp);
         INNFER_HIP(hipGetLastError());
         float* save = raw;
         raw = (float*)(ws + cv.fgh);
@@ -516,7 +535,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         hipLaunchKernelGGL(pan_attention, dim3((hp * wp + 63) / 64, N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
                            vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, (float*)(ws + cv.att));
         INNFER_HIP(hipGetLastError());
-        hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
+        hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px * (nf / 8) + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
                            INP, G, N, H, W, vec("FSA.gamma"), T);
         INNFER_HIP(hipGetLastError());
     }
