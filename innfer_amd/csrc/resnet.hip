@@ -6,12 +6,13 @@
 //                                                                     read the mirrored pixel (GP.reflect)
 //   3x3 stride-2 zero-pad-1 convs                                     gg::gemm_gather (stride 2)
 //   ConvTranspose2d(3, stride 2, padding 1, output_padding 1)         four output phases (1, 2, 2, 4 taps) of the same GEMM
-//   InstanceNorm2d (no affine, statistics of the instance also under eval)   in_stats: per-(image, channel) mean / biased variance in
+//   InstanceNorm2d (no affine, statistics of the instance also under eval)   norm_stats.h: per-(image, channel) mean / biased variance in
 //                                                                     fp32, two passes; the conv bias is folded into the shift
 //   ReLU / residual add / Tanh                                        rn_post, rn_final
 // Activations are blocked-NHWC fp16 slabs, GEMM results fp32 rows.  A batch is N independent images.
 #include "common.h"
 #include "gather_gemm.h"
+#include "norm_stats.h"
 
 #include <cmath>
 #include <cstring>
@@ -22,35 +23,8 @@ using namespace innfer;
 
 namespace {
 
-// out = x * alpha + shift with alpha = 1/sqrt(var + eps), shift = (bias - mean_of(x + bias)) * alpha = -mean(x) * alpha:
-// the conv bias cancels inside an instance norm, which is what this kernel computes (x = raw conv result without bias)
-__global__ __launch_bounds__(1024) void in_stats(const float* raw, int cpad, long HW, float eps, float* alpha, float* shift, int C) {
-    __shared__ float red[1024];
-    const int n = blockIdx.y, cb = blockIdx.x * 32;
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int c = cb + cl;
-    const float* base = raw + (long)n * HW * cpad + c;
-    auto reduce32 = [&](float v) {
-        red[threadIdx.x] = v;
-        __syncthreads();
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) t += red[cl + 32 * i];
-        __syncthreads();
-        return t;
-    };
-    float s = 0.f;
-    for (long px = pl; px < HW; px += 32) s += base[px * cpad];
-    const float mu = reduce32(s) / (float)HW;
-    s = 0.f;
-    for (long px = pl; px < HW; px += 32) { const float d = base[px * cpad] - mu; s += d * d; }
-    const float var = reduce32(s) / (float)HW;
-    if (pl == 0 && c < C) {
-        const float a = 1.0f / sqrtf(var + eps);
-        alpha[(long)n * C + c] = a;
-        shift[(long)n * C + c] = -mu * a;
-    }
-}
+// InstanceNorm statistics: norm_stats.h without affine parameters, i.e. alpha = 1/sqrt(var + eps), shift = (bias - mean_of(x + bias)) * alpha =
+// -mean(x) * alpha: the conv bias cancels inside an instance norm, which is why the GEMM result is normalised without it
 
 // raw fp32 -> instance norm -> [ReLU] -> [+ residual] -> fp16 slab; one thread per (pixel, 8 channels)
 __global__ void rn_post(const float* raw, int cpad, int C, long HW, int N, const float* alpha, const float* shift, int relu,
@@ -231,7 +205,7 @@ int rn_upload(innfer_resnet* r) {
     return INNFER_OK;
 }
 
-struct RCarve { size_t x0, s1, s2, a, b, c, u1, u2, raw, alpha, shift, total; };
+struct RCarve { size_t x0, s1, s2, a, b, c, u1, u2, raw, alpha, shift, part, total; };
 
 RCarve rcarve(const innfer_resnet* r, int N, int H, int W) {
     RCarve c{};
@@ -245,6 +219,8 @@ RCarve rcarve(const innfer_resnet* r, int N, int H, int W) {
     c.raw = off; off += al(px * 64 * 4);               // the largest fp32 GEMM result: 64 channels at full resolution
     c.alpha = off; off += al((size_t)N * 256 * 4);
     c.shift = off; off += al((size_t)N * 256 * 4);
+    // (mean, M2) per statistics segment: the widest case is 64 channels at full resolution or 256 at 1/16
+    c.part = off; off += al((size_t)N * std::max(norm::part_floats(64, (long)H * W), norm::part_floats(256, (long)H * W / 16)) * 4);
     c.total = off;
     (void)r;
     return c;
@@ -270,6 +246,7 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     float* raw = (float*)(ws + cv.raw);
     float* alpha = (float*)(ws + cv.alpha);
     float* shift = (float*)(ws + cv.shift);
+    float* part = (float*)(ws + cv.part);
     int dy49[49], dx49[49], dy9[9], dx9[9];
     for (int t = 0; t < 49; ++t) { dy49[t] = t / 7 - 3; dx49[t] = t % 7 - 3; }
     for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
@@ -278,7 +255,7 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     auto norm_post = [&](const Layer& l, int Ho, int Wo, int relu, const f16* res, f16* dst) -> int {
         const long HW = (long)Ho * Wo;
         const int cpad = (l.cout + 63) / 64 * 64;
-        hipLaunchKernelGGL(in_stats, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, (const float*)raw, cpad, HW, 1e-5f, alpha, shift, l.cout);
+        { int rc = norm::launch_stats(raw, cpad, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s); if (rc) return rc; }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(rn_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)raw, cpad, l.cout, HW, N,
                            (const float*)alpha, (const float*)shift, relu, res, dst, (long)N * HW * 32);

@@ -20,6 +20,7 @@
 // fp32 until normalised.
 #include "common.h"
 #include "gather_gemm.h"
+#include "norm_stats.h"
 
 #include <cmath>
 #include <cstring>
@@ -29,84 +30,6 @@
 using namespace innfer;
 
 namespace {
-
-// per-(image, channel) BatchNorm transform (alpha, shift) from the mean and biased variance of raw[N][HW][cpad], fp32, ONE read of raw:
-// a workgroup holds a segment of BN_SEG pixels x 32 channels in registers (32 pixel lanes x 32 values), takes the segment mean and
-// the sum of squared deviations from it (the two-pass form, on registers); segments are combined in index order with the
-// parallel-variance formula  M2 = sum M2_s + sum n_s (mean_s - mean)^2  -- deterministic, no atomics.
-constexpr int BN_SEG = 1024;
-
-__device__ __forceinline__ void bn_write(float mu, float var, float eps, const float* gamma, const float* beta, float* alpha, float* shift,
-                                         long n, int C, int c) {
-    // the transform ATen applies (batch_norm_cpu_transform_input): out = x * alpha + shift,
-    // alpha = invstd * weight, shift = bias - mean * alpha
-    const float a = (1.0f / sqrtf(var + eps)) * gamma[c];
-    alpha[n * C + c] = a;
-    shift[n * C + c] = beta[c] - mu * a;
-}
-
-__global__ __launch_bounds__(1024) void bn_stats(const float* raw, int cpad, long HW, float eps, const float* gamma, const float* beta,
-                                                 float* alpha, float* shift, int C, float* part, int nseg) {
-    __shared__ float red[1024];
-    const int n = blockIdx.y, cb = blockIdx.x * 32, sg = blockIdx.z;
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int c = cb + cl;
-    const long p0 = (long)sg * BN_SEG;
-    const int cnt = (int)min((long)BN_SEG, HW - p0);
-    const float* base = raw + ((long)n * HW + p0) * cpad + c;
-    auto reduce32 = [&](float v) {                 // sum over the 32 pixel lanes of one channel, result in every lane
-        red[threadIdx.x] = v;
-        __syncthreads();
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) t += red[cl + 32 * i];
-        __syncthreads();
-        return t;
-    };
-    float v[BN_SEG / 32];
-    const int iters = (cnt + 31) >> 5;             // uniform: deep layers have a handful of pixels per image
-#pragma unroll
-    for (int i = 0; i < BN_SEG / 32; ++i) {
-        v[i] = 0.f;
-        if (i < iters) {
-            const int px = pl + 32 * i;
-            if (px < cnt) v[i] = base[(long)px * cpad];
-        }
-    }
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int i = 0; i < BN_SEG / 32; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
-    const float mu = reduce32((s0 + s1) + (s2 + s3)) / (float)cnt;
-    s0 = s1 = s2 = s3 = 0.f;
-#pragma unroll
-    for (int i = 0; i < BN_SEG / 32; i += 4) {
-        const float d0 = pl + 32 * i < cnt ? v[i] - mu : 0.f, d1 = pl + 32 * (i + 1) < cnt ? v[i + 1] - mu : 0.f,
-                    d2 = pl + 32 * (i + 2) < cnt ? v[i + 2] - mu : 0.f, d3 = pl + 32 * (i + 3) < cnt ? v[i + 3] - mu : 0.f;
-        s0 += d0 * d0; s1 += d1 * d1; s2 += d2 * d2; s3 += d3 * d3;
-    }
-    const float m2 = reduce32((s0 + s1) + (s2 + s3));
-    if (pl == 0 && c < C) {
-        if (nseg == 1) bn_write(mu, m2 / (float)HW, eps, gamma, beta, alpha, shift, n, C, c);
-        else { float* q = part + (((long)n * C + c) * nseg + sg) * 2; q[0] = mu; q[1] = m2; }
-    }
-}
-
-// segments -> (alpha, shift): one thread per (image, channel), segments in index order
-__global__ void bn_combine(const float* part, int nseg, long HW, float eps, const float* gamma, const float* beta,
-                           float* alpha, float* shift, int C, int N) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * C) return;
-    const float* q = part + i * nseg * 2;
-    float sum = 0.f;
-    for (int g = 0; g < nseg; ++g) sum += q[2 * g] * (float)min((long)BN_SEG, HW - (long)g * BN_SEG);
-    const float mu = sum / (float)HW;
-    float m2 = 0.f;
-    for (int g = 0; g < nseg; ++g) {
-        const float d = q[2 * g] - mu;
-        m2 += q[2 * g + 1] + (float)min((long)BN_SEG, HW - (long)g * BN_SEG) * d * d;
-    }
-    bn_write(mu, m2 / (float)HW, eps, gamma, beta, alpha, shift, i / C, C, (int)(i % C));
-}
 
 struct PostDst { f16* p; long g; int coff; int act; };      // act: 1 lrelu(0.2), 2 relu
 
@@ -427,10 +350,10 @@ UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
     size_t part = 0;                                                               // (mean, M2) per BN segment of the widest layer
     for (int k = 0; k < L; ++k) {
         const size_t hw = (size_t)(H >> (k + 1)) * (W >> (k + 1)), hw2 = (size_t)(H >> k) * (W >> k);
-        part = std::max(part, (size_t)u->dc[k] * ((hw + BN_SEG - 1) / BN_SEG));
-        if (k > 0) part = std::max(part, (size_t)u->dc[k - 1] * ((hw2 + BN_SEG - 1) / BN_SEG));
+        part = std::max(part, norm::part_floats(u->dc[k], (long)hw));
+        if (k > 0) part = std::max(part, norm::part_floats(u->dc[k - 1], (long)hw2));
     }
-    c.bnpart = off; off += al((size_t)N * part * 2 * 4);
+    c.bnpart = off; off += al((size_t)N * part * 4);
     c.D.resize(L); c.CAT.resize(L);
     for (int k = 0; k < L - 1; ++k) {
         const size_t px = (size_t)N * (H >> (k + 1)) * (W >> (k + 1));
@@ -490,15 +413,8 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
 
     auto post = [&](const Layer& l, long HW, bool bn, PostDst d0, PostDst d1) -> int {
         if (bn) {
-            const int nseg = (int)((HW + BN_SEG - 1) / BN_SEG);
-            hipLaunchKernelGGL(bn_stats, dim3((l.cout + 31) / 32, N, nseg), dim3(1024), 0, s, raw, l.cout_pad, HW, 1e-5f, l.d_gamma, l.d_beta,
-                               mean, rstd, l.cout, bnpart, nseg);
-            INNFER_HIP(hipGetLastError());
-            if (nseg > 1) {
-                hipLaunchKernelGGL(bn_combine, dim3((unsigned)(((long)N * l.cout + 255) / 256)), dim3(256), 0, s, (const float*)bnpart, nseg, HW, 1e-5f,
-                                   l.d_gamma, l.d_beta, mean, rstd, l.cout, N);
-                INNFER_HIP(hipGetLastError());
-            }
+            int rc = norm::launch_stats(raw, l.cout_pad, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
+            if (rc) return rc;
         }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(unet_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
