@@ -199,7 +199,8 @@ int innfer_guided_filter(const void* d_x, const void* d_y, int dtype, int N, int
  * reference's torch.cat is a group offset.
  *   out[.., out_ch_off + k] = epilogue(conv(in[.., 0:C]))
  *   epilogue: +bias -> act -> (*res1_scale + res1) -> (*res2_scale + res2)
- * act: 0 none, 1 LeakyReLU(0.2) (block.py:89-90), 2 ReLU.
+ * act: 0 none, 1 LeakyReLU(0.2) (block.py:89-90), 2 ReLU; 4 / 5: the pixel-attention gate of PAN (PAN_arch.py PA, PAConv):
+ *   out = d_res1 * sigmoid(conv + bias), followed by LeakyReLU(0.2) for 4 (d_res1 required, no d_res2, scales unused).
  * upsample2x: input is read through nearest-2x upsampling (block.py:321-322,358),
  *   i.e. d_in is [N,H/2,W/2,*] while H,W are the conv's (output) size.
  * d_packed comes from innfer_pack_conv3x3().  C % 32 == 0, K % 16 == 0, K <= 64.

@@ -118,6 +118,21 @@ def test_conv_epilogues_and_slab_offsets(dev):
     assert (got - _ref_conv(x, w, b, act=2)).abs().max().item() < 4e-3
 
 
+def test_conv_pixel_attention_gate_epilogue(dev):
+    """act 4 / 5: res1 * sigmoid(conv + bias) [+ LeakyReLU] -- PAN's PA / PAConv gate (PAN_arch.py) as a conv epilogue."""
+    from innfer_amd import synth
+    N, Cc, K, H, W = 2, 32, 32, 19, 41
+    x = torch.from_numpy(synth.uniform((N, Cc, H, W), 31, -1, 1)).half()
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 32, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.from_numpy(synth.uniform((K,), 33, -1, 1))
+    v = torch.from_numpy(synth.uniform((N, K, H, W), 34, -2, 2)).half()
+    gate = v.float() * torch.sigmoid(F.conv2d(x.float(), w.half().float(), b.float(), padding=1))
+    got, _ = _run_conv(dev, x, w, b, K, act=5, res1=v)
+    assert (got - gate).abs().max().item() < 4e-3
+    got, _ = _run_conv(dev, x, w, b, K, act=4, res1=v)
+    assert (got - F.leaky_relu(gate, 0.2)).abs().max().item() < 4e-3
+
+
 def test_conv_nearest_upsample_fused(dev):
     from innfer_amd import synth
     N, Cc, K, Hs, Ws = 1, 64, 64, 13, 21
