@@ -52,7 +52,7 @@ const char* innfer_last_error(void);
  */
 
 /* RRDBNet (old-arch ESRGAN).  gc is the dense growth (32 in the reference,
- * RRDBNet_arch.py:27); scale in {1,2,4,8}.  plus != 0 adds the ESRGAN+ paths
+ * RRDBNet_arch.py:27); scale in {1,2,3,4,8,16} (3: one nearest-3x stage).  plus != 0 adds the ESRGAN+ paths
  * (x2 += conv1x1(x), x4 += x2: RRDBNet_arch.py:155-160; GaussianNoise is the identity in eval). */
 int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
                           int gc, int scale, int plus);

@@ -20,7 +20,6 @@ class RRDBNet(EngineModule):
         if upsample_mode != 'upconv': unsupported.append(f'upsample_mode={upsample_mode}')
         if convtype != 'Conv2D': unsupported.append(f'convtype={convtype}')
         if finalact: unsupported.append(f'finalact={finalact}')
-        if upscale == 3: unsupported.append('upscale=3')
         if unsupported:
             raise NotImplementedError('RRDBNet option(s) not built on the HIP path yet: ' + ', '.join(unsupported))
         # gaussian_noise: GaussianNoise is the identity in eval mode (block.py:382-388)

@@ -50,6 +50,7 @@ struct innfer_net {
 };
 
 static int n_upscale(int scale) {
+    if (scale == 3) return 1;             // one Upsample(scale_factor=3) stage (RRDBNet_arch.py:33-36)
     int n = 0;
     while ((1 << n) < scale) ++n;
     return n;
@@ -67,8 +68,8 @@ extern "C" const char* innfer_last_error(void) { return g_err.c_str(); }
 extern "C" int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
                                      int gc, int scale, int plus) {
     if (!out) return set_error(INNFER_ERR_INVALID, "rrdbnet_create: null out");
-    if (scale != 1 && scale != 2 && scale != 4 && scale != 8 && scale != 16)
-        return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: scale %d (only powers of two)", scale);
+    if (scale != 1 && scale != 2 && scale != 3 && scale != 4 && scale != 8 && scale != 16)
+        return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: scale %d (built: 1, 2, 3, 4, 8, 16)", scale);
     if (nf % 32 || gc % 32 || nf <= 0 || gc <= 0 || nf > 64)
         return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: nf=%d gc=%d (need nf in {32,64}, gc %% 32 == 0)", nf, gc);
     if (in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 16 || nb < 1)
@@ -197,8 +198,9 @@ extern "C" double innfer_net_flops(innfer_net_t net, int N, int H, int W) {
         const int tail0 = nconv - 2 - net->n_up;          // first up conv
         if (i >= tail0) {
             const int u = i - tail0;
-            if (u < net->n_up) mult = std::pow(4.0, net->kind == 0 ? u + 1 : u);
-            else mult = std::pow(4.0, net->n_up);
+            const double f2 = net->scale == 3 ? 9.0 : 4.0;     // pixels per input pixel after one upsample stage
+            if (u < net->n_up) mult = std::pow(f2, net->kind == 0 ? u + 1 : u);
+            else mult = std::pow(f2, net->n_up);
         }
         f += 2.0 * c.ksize * c.ksize * c.K * c.C * px * mult;
     }
@@ -227,7 +229,7 @@ static Carve carve(const innfer_net* net, int N, int H, int W) {
     c.trunk = off; off += al(px * net->nf * 2);
     c.tmp = off; if (net->plus) off += al(px * net->gc * 2);          // conv1x1(x) of the current RDB
     size_t m = 1;
-    for (int u = 0; u < net->n_up; ++u) { m *= 4; c.up[u] = off; off += al(px * m * net->nf * 2); }
+    for (int u = 0; u < net->n_up; ++u) { m *= net->scale == 3 ? 9 : 4; c.up[u] = off; off += al(px * m * net->nf * 2); }
     c.hr = off; off += al(px * m * net->nf * 2);
     c.total = off;
     return c;
@@ -304,6 +306,24 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
     const int y1 = L.y1 > 0 ? L.y1 : L.H;
     return timed_end(s, 2.0 * 9.0 * L.K * L.C * (double)L.N * (y1 - L.y0) * L.W,
                      16 * conv_nt_for(L.K) + L.out_mode);
+}
+
+// nearest-neighbour upsampling of a slab by an integer factor (src = dst / f, block.py:321-322).  The 2x case is folded into the conv's input
+// addressing; the 3x models (one stage, RRDBNet_arch.py:33-36) materialise the tensor: a tile's source columns are not a fixed function of
+// the column inside the tile when the tile width (32) is not a multiple of the factor.  One thread per (output pixel, 16-byte piece).
+__global__ void slab_upsample_nearest(const f16* src, long src_g, f16* dst, long dst_g, int groups, int N, int H, int W, int f) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int HO = H * f, WO = W * f;
+    const long M = (long)N * HO * WO;
+    if (i >= M * 4 * groups) return;
+    const int q = (int)(i & 3);
+    const long r = i >> 2;
+    const int g = (int)(r / M);
+    const long m = r - g * M;
+    const int X = (int)(m % WO), Y = (int)((m / WO) % HO);
+    const long n = m / ((long)WO * HO);
+    const long sp = (n * H + Y / f) * W + X / f;
+    *(f16x8*)(dst + g * dst_g + m * 32 + q * 8) = *(const f16x8*)(src + g * src_g + sp * 32 + q * 8);
 }
 
 int do_first(const FirstConvLaunch& F, hipStream_t s) {
@@ -454,6 +474,16 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         const ConvSlot& cs = net->convs[ci++];
         f16* dst = (f16*)(ws + cv.up[u]);
         const long gi = (long)N * h * w * 32, go = gi * 4;
+        if (net->kind == 0 && net->scale == 3) {      // Upsample(nearest 3x), materialised in the (still unused) HR slab -> conv -> LeakyReLU
+            f16* U = (f16*)(ws + cv.hr);
+            const long g3 = gi * 9, nthr = (long)N * 9 * h * w * 4 * (net->nf / 32);
+            hipLaunchKernelGGL(slab_upsample_nearest, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, t, gi, U, g3, net->nf / 32, N, h, w, 3);
+            INNFER_HIP(hipGetLastError());
+            rc = do_conv(mk(cs, U, g3, dst, g3, N, 3 * h, 3 * w, 1), s);
+            if (rc) return rc;
+            t = dst; h *= 3; w *= 3;
+            continue;
+        }
         if (net->kind == 0) {        // Upsample(nearest 2x) -> conv -> LeakyReLU
             ConvLaunch L = mk(cs, t, gi, dst, go, N, 2 * h, 2 * w, 1);
             L.up = 1;

@@ -169,7 +169,7 @@ def g4():
 def g5():
     out = {}
     x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 5))
-    for scale in (1, 2, 8):
+    for scale in (1, 2, 3, 8):
         net, _ = rrdb_ref(1, scale)
         with torch.no_grad():
             out[f"out_x{scale}"] = net(x).numpy()

@@ -196,7 +196,7 @@ def test_rrdbnet_scales_golden(dev, golden):
     from innfer_amd import synth
     g = golden("g5_scales")
     x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 5)).to(dev).half()
-    for scale in (1, 2, 8):
+    for scale in (1, 2, 3, 8):
         net, _ = _rrdb(dev, 1, scale)
         y = net(x).float().cpu().numpy()
         assert y.shape == g[f"out_x{scale}"].shape
@@ -314,7 +314,7 @@ def test_missing_weights_and_cpu_are_loud(dev):
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 8, 8))               # CPU tensor: no fallback
     with pytest.raises(NotImplementedError):
-        RRDBNet(3, 3, 64, 1, upscale=3)
+        RRDBNet(3, 3, 64, 1, upscale=4, upsample_mode='pixelshuffle')
 
 
 def test_unet256_golden(dev, golden):

@@ -211,7 +211,10 @@ def test_entry_points_report_errors_without_a_gpu():
     assert L.lib.innfer_conv3x3_f16(C.byref(a), None) == L.ERR_INVALID
     assert "null" in L.last_error()
     h = C.c_void_p()
-    assert L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 3, 0) == L.ERR_UNSUPPORTED      # scale 3
+    assert L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 5, 0) == L.ERR_UNSUPPORTED      # scale 5
+    L.check(L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 3, 0))                           # scale 3: ONE up stage (factor 3)
+    assert L.lib.innfer_net_num_convs(h) == 1 + 3 * 5 + 1 + 1 + 2 and L.lib.innfer_net_scale(h) == 3
+    L.lib.innfer_net_destroy(h)
     L.check(L.lib.innfer_rrdbnet_create(C.byref(h), 3, 3, 64, 1, 32, 4, 1))                           # ESRGAN+
     assert L.lib.innfer_net_num_convs(h) == 1 + 3 * 6 + 1 + 2 + 2
     L.lib.innfer_net_destroy(h)
