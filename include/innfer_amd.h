@@ -95,6 +95,10 @@ int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, v
  * resident; identical results). */
 int innfer_net_set_band_rows(innfer_net_t net, int rows);
 
+/* `finalact` of the reference constructors (RRDBNet_arch.py:45-48: an activation module after the last conv):
+ * 0 none (default), 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 6 sigmoid. */
+int innfer_net_set_final_act(innfer_net_t net, int act);
+
 /* Algorithmic FLOPs of one forward (2*MAC of every conv). */
 double innfer_net_flops(innfer_net_t net, int N, int H, int W);
 

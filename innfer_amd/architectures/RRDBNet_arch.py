@@ -8,6 +8,10 @@ from .engine_module import EngineModule
 from .keys import mrrdb_key_of, mrrdbnet_shapes, rrdbnet_shapes
 
 
+# `finalact` (block.py:81-101 act()) -> activation code of the last conv's epilogue
+_FINAL_ACT = {'relu': 2, 'leakyrelu': 1, 'lrelu': 1, 'tanh': 3, 'sigmoid': 6}
+
+
 class RRDBNet(EngineModule):
     def __init__(self, in_nc, out_nc, nf, nb, nr=3, gc=32, upscale=4, norm_type=None,
                  act_type='leakyrelu', mode='CNA', upsample_mode='upconv', convtype='Conv2D',
@@ -19,18 +23,20 @@ class RRDBNet(EngineModule):
         if mode != 'CNA': unsupported.append(f'mode={mode}')
         if upsample_mode != 'upconv': unsupported.append(f'upsample_mode={upsample_mode}')
         if convtype != 'Conv2D': unsupported.append(f'convtype={convtype}')
-        if finalact: unsupported.append(f'finalact={finalact}')
+        if finalact and finalact.lower() not in _FINAL_ACT: unsupported.append(f'finalact={finalact}')
         if unsupported:
             raise NotImplementedError('RRDBNet option(s) not built on the HIP path yet: ' + ', '.join(unsupported))
         # gaussian_noise: GaussianNoise is the identity in eval mode (block.py:382-388)
         super().__init__(rrdbnet_shapes(in_nc, out_nc, nf, nb, 32, upscale, plus))
         self.in_nc, self.out_nc, self.nf, self.nb, self.gc, self.upscale = in_nc, out_nc, nf, nb, 32, upscale
         self.plus = bool(plus)
+        self.final_act = _FINAL_ACT[finalact.lower()] if finalact else 0
 
     def _create_handle(self):
         h = C.c_void_p()
         L.check(L.lib.innfer_rrdbnet_create(C.byref(h), self.in_nc, self.out_nc, self.nf, self.nb,
                                             self.gc, self.upscale, int(self.plus)))
+        L.check(L.lib.innfer_net_set_final_act(h, self.final_act))
         return h
 
 

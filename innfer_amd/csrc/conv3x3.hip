@@ -727,6 +727,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                             if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
                             else if (p.act == 2) f = f > 0.f ? f : 0.f;
                             else if (p.act == 3) f = tanhf(f);
+                            else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
                             long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
                             if (p.phase_c > 0) {
                                 const int ph = ch / p.phase_c, c = ch - ph * p.phase_c;
@@ -898,9 +899,10 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.wpk = L.wpk; k.bias = L.bias;
     k.out = L.out; k.out_gstride = L.out_gstride; k.out_coff = L.out_coff;
     k.K = L.K; k.KG = conv_groups(L.K);
-    if (L.act >= 4 && (L.out_mode != OUT_SLAB || !L.res1 || L.res2))
+    if ((L.act == 4 || L.act == 5) && (L.out_mode != OUT_SLAB || !L.res1 || L.res2))
         return set_error(INNFER_ERR_INVALID, "conv3x3: the gate epilogue multiplies res1 (slab output, no second residual)");
-    if (L.act < 0 || L.act > 5 || (L.phase_c > 0 && (L.K % L.phase_c || L.K / L.phase_c != 4)))
+    if (L.act == 6 && L.out_mode != OUT_NCHW) return set_error(INNFER_ERR_INVALID, "conv3x3: sigmoid is a planar-output activation");
+    if (L.act < 0 || L.act > 6 || (L.phase_c > 0 && (L.K % L.phase_c || L.K / L.phase_c != 4)))
         return set_error(INNFER_ERR_INVALID, "conv3x3: act=%d phase_c=%d K=%d", L.act, L.phase_c, L.K);
     k.act = L.act;
     k.res1 = L.res1; k.res1_gstride = L.res1_gstride; k.s1 = L.s1;

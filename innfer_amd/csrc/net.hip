@@ -44,6 +44,7 @@ struct ConvSlot {
 struct innfer_net {
     int kind = 0;                // 0 rrdbnet, 1 srresnet
     int in_nc = 3, out_nc = 3, nf = 64, nb = 23, gc = 32, scale = 4, n_up = 2;
+    int final_act = 0;           // `finalact` of the reference constructors: activation after the last conv (ConvLaunch.act codes)
     int band_rows = 0;
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
     std::vector<ConvSlot> convs;
@@ -183,6 +184,13 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
 extern "C" int innfer_net_set_band_rows(innfer_net_t net, int rows) {
     if (!net || rows < 0) return set_error(INNFER_ERR_INVALID, "set_band_rows: bad arguments");
     net->band_rows = rows;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_set_final_act(innfer_net_t net, int act) {
+    if (!net || (act != 0 && act != 1 && act != 2 && act != 3 && act != 6))
+        return set_error(INNFER_ERR_INVALID, "set_final_act: act %d (0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 6 sigmoid)", act);
+    net->final_act = act;
     return INNFER_OK;
 }
 
@@ -505,7 +513,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     }
     {
         const ConvSlot& cs = net->convs[ci++];
-        ConvLaunch L = mk(cs, (const f16*)(ws + cv.hr), (long)N * h * w * 32, d_out, 0, N, h, w, 0);
+        ConvLaunch L = mk(cs, (const f16*)(ws + cv.hr), (long)N * h * w * 32, d_out, 0, N, h, w, net->final_act);
         L.out_mode = OUT_NCHW; L.out_f32 = out_dtype == INNFER_F32;
         rc = do_conv(L, s);
         if (rc) return rc;

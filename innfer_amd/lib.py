@@ -67,6 +67,7 @@ SIGNATURES = {
                                            C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_destroy": (None, [C.c_void_p]),

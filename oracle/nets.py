@@ -47,7 +47,7 @@ def _n_upscale(scale):
     return 1 if scale == 3 else int(math.log(scale, 2))
 
 
-def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None):
+def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None):
     """RRDBNet.forward with the flat Sequential of RRDBNet_arch.py:25-48.
 
     taps: optional dict filled with named intermediates (golden G3 stages).
@@ -73,7 +73,10 @@ def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None):
             taps[f"up{u}"] = t
         idx += 3
     t = _lrelu(_conv3(sd, f"model.{idx}", t))     # HR_conv0
-    return _conv3(sd, f"model.{idx + 2}", t)      # HR_conv1
+    y = _conv3(sd, f"model.{idx + 2}", t)         # HR_conv1
+    if finalact:                                  # outact (RRDBNet_arch.py:45-48; block.py:81-101)
+        y = {"relu": F.relu, "leakyrelu": _lrelu, "lrelu": _lrelu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[finalact.lower()](y)
+    return y
 
 
 def mrrdbnet_forward(sd, x, nb=24):

@@ -176,6 +176,11 @@ def g5():
     net, _ = rrdb_ref(1, 4, plus=True)
     with torch.no_grad():
         out["out_x4_plus"] = net(x).numpy()
+    for fa in ("tanh", "sigmoid"):
+        net = ref_net("esrgan", 4, nb=1, finalact=fa)
+        net.load_state_dict(t_sd(synth.fill_state_dict(synth.rrdbnet_shapes(nb=1, scale=4), 0)), strict=True)
+        with torch.no_grad():
+            out[f"out_x4_{fa}"] = net.eval()(x).numpy()
     save("g5_scales", **out)
 
 

@@ -201,6 +201,13 @@ def test_rrdbnet_scales_golden(dev, golden):
         y = net(x).float().cpu().numpy()
         assert y.shape == g[f"out_x{scale}"].shape
         assert np.abs(y - g[f"out_x{scale}"]).max() < 5e-3, scale
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    from innfer_amd import synth as _s
+    for fa in ("tanh", "sigmoid"):                       # finalact: activation in the last conv's epilogue
+        net = RRDBNet(3, 3, 64, 1, upscale=4, finalact=fa)
+        net.load_state_dict(_sd(_s.rrdbnet_shapes(nb=1, scale=4)), strict=True)
+        y = net.to(dev).eval()(x).float().cpu().numpy()
+        assert np.abs(y - g[f"out_x4_{fa}"]).max() < 5e-3, fa
 
 
 def test_esrgan_plus_golden(dev, golden):

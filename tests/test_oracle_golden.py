@@ -97,6 +97,10 @@ def test_g5_scales(golden):
         sd = _sd(synth.rrdbnet_shapes(nb=1, scale=4, plus=True))
         y = oracle.rrdbnet_forward(sd, x, nb=1, scale=4, plus=True)
         np.testing.assert_allclose(y.numpy(), g["out_x4_plus"], atol=2e-6, rtol=0)
+        sd = _sd(synth.rrdbnet_shapes(nb=1, scale=4))
+        for fa in ("tanh", "sigmoid"):
+            y = oracle.rrdbnet_forward(sd, x, nb=1, scale=4, finalact=fa)
+            np.testing.assert_allclose(y.numpy(), g[f"out_x4_{fa}"], atol=2e-6, rtol=0)
 
 
 def test_g6_srgan(golden):
