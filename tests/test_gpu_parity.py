@@ -313,6 +313,11 @@ def test_srresnet_golden(dev, golden):
     x = torch.from_numpy(synth.uniform((1, 3, 24, 24), 6)).to(dev).half()
     y = net(x).float().cpu().numpy()
     assert np.abs(y - g["out_24"]).max() < 1e-2
+    # finalact='tanh' (SRResNet_arch.py:41-44): the same graph with tanh after the last conv
+    nt = SRResNet(3, 3, 64, 16, upscale=4, norm_type=None, act_type='relu', mode='CNA', upsample_mode='pixelshuffle', finalact='tanh')
+    nt.load_state_dict(sd, strict=True)
+    yt = nt.to(dev).eval()(x).float().cpu().numpy()
+    assert np.abs(yt - np.tanh(g["out_24"])).max() < 1e-2
 
 
 def test_missing_weights_and_cpu_are_loud(dev):
