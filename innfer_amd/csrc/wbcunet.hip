@@ -149,7 +149,8 @@ __global__ void gf_out(const float* A, const float* B, const void* x, int f32, l
 }
 
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
-struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; f16* d_w = nullptr; float* d_b = nullptr; };
+struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; f16* d_w = nullptr; float* d_b = nullptr;
+               void* d_w3 = nullptr; float* d_b3 = nullptr; };     // 3x3 layers: conv3x3.hip panels + bias (the stride-1 ones run there)
 
 }  // namespace
 
@@ -186,7 +187,10 @@ extern "C" int innfer_wbc_create(innfer_wbc** out, int nf, int tf_mode) {
 }
 
 static void wb_free(innfer_wbc* u) {
-    for (auto& l : u->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); l.d_w = nullptr; l.d_b = nullptr; }
+    for (auto& l : u->layers) {
+        if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w3) (void)hipFree(l.d_w3); if (l.d_b3) (void)hipFree(l.d_b3);
+        l.d_w = nullptr; l.d_b = nullptr; l.d_w3 = nullptr; l.d_b3 = nullptr;
+    }
 }
 
 extern "C" void innfer_wbc_destroy(innfer_wbc* u) { if (u) { wb_free(u); delete u; } }
@@ -226,6 +230,16 @@ int wb_upload(innfer_wbc* u) {
         INNFER_HIP(hipMemcpy(l.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
         INNFER_HIP(hipMalloc((void**)&l.d_b, l.cout * sizeof(float)));
         INNFER_HIP(hipMemcpy(l.d_b, u->params[l.b].host.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+        if (l.k == 3 && l.cin % 32 == 0 && l.cout % 32 == 0) {       // halo-tile form for the stride-1 launches
+            std::vector<char> packed(conv_packed_bytes(l.cout, l.cin));
+            conv_pack(w.data(), l.cout, l.cin, packed.data());
+            std::vector<float> b3((size_t)(l.cout + 63) / 64 * 64, 0.f);
+            for (int c = 0; c < l.cout; ++c) b3[c] = u->params[l.b].host[c];
+            INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+            INNFER_HIP(hipMalloc((void**)&l.d_b3, b3.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(l.d_b3, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     u->uploaded = true;
     return INNFER_OK;
@@ -276,6 +290,16 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
     auto layer = [&](const f16* in, int Hi, int Wi, int stride, int act, const f16* res, f16* dst, void* nchw) -> int {
         const Layer& l = u->layers[li++];
         const int Ho = Hi / stride, Wo = Wi / stride;
+        if (l.d_w3 && stride == 1 && !nchw) {     // zero-padded stride-1 3x3 conv: the SR path's halo-tile kernel, epilogue = bias / LeakyReLU / + residual
+            ConvLaunch L{};
+            L.in = in; L.in_gstride = (long)N * Hi * Wi * 32; L.C = l.cin;
+            L.wpk = (const f16*)l.d_w3; L.bias = l.d_b3;
+            L.out = dst; L.out_gstride = (long)N * Ho * Wo * 32; L.K = l.cout;
+            L.N = N; L.H = Ho; L.W = Wo; L.act = act ? 1 : 0;
+            L.res1 = res; L.res1_gstride = L.out_gstride; L.s1 = 1.f; L.s2 = 1.f;
+            L.y0 = 0; L.y1 = Ho; L.out_mode = OUT_SLAB;
+            return conv_launch(L, s);
+        }
         const int cin_pad = (l.cin + 31) / 32 * 32, cout_pad = (l.cout + 63) / 64 * 64, rs = (l.cout + 3) / 4 * 4;
         CK(gg::launch(l.d_w, cin_pad, cout_pad, in, (long)N * Hi * Wi * 32, N, Hi, Wi, raw, Ho, Wo, stride, l.k * l.k,
                       l.k == 7 ? dy49 : (stride == 2 && u->tf ? dy9tf : dy9), l.k == 7 ? dx49 : (stride == 2 && u->tf ? dx9tf : dx9),
