@@ -96,15 +96,28 @@ __global__ void wb_upadd(const f16* src, long sg, const f16* skip, f16* dst, lon
     *(f16x8*)(dst + o) = h;
 }
 
-__global__ void wb_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {
+// NCHW input -> "row patch" slab for the first 7x7 conv: channel kx*C + c of pixel (y, x) holds in[c][y][x + kx - 3] (zero outside the
+// image and beyond 7*C <= 32 channels), so the 49-tap conv becomes 7 vertical taps over ONE 32-channel group: 7x less gather traffic than
+// 49 taps over a group holding C values.  One thread per pixel, 16-byte stores.
+__global__ void wb_pre(const void* in, int in_f32, int C, int H, int W, int N, f16* slab) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long HW = (long)H * W;
     if (i >= (long)N * HW) return;
     const long n = i / HW, px = i % HW;
-    for (int c = 0; c < 32; ++c) {
-        f16 v = (f16)0.f;
-        if (c < C) { const long o = (n * C + c) * HW + px; v = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o]; }
-        slab[i * 32 + c] = v;
+    const int x = (int)(px % W);
+    f16 v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int kx = j / C, c = j - kx * C, X = x + kx - 3;
+        f16 t = (f16)0.f;
+        if (kx < 7 && X >= 0 && X < W) {
+            const long o = (n * C + c) * HW + px + (kx - 3);
+            t = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+        }
+        v[j] = t;
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f16x8*)(slab + i * 32 + 8 * q) = *(const f16x8*)(v + 8 * q);
 }
 
 // ---- guided filter (r = 1) on NCHW planes --------------------------------------------------------
@@ -225,6 +238,11 @@ int wb_upload(innfer_wbc* u) {
     for (auto& l : u->layers) {
         const std::vector<float>& w = u->params[l.w].host;
         const int cin_pad = (l.cin + 31) / 32 * 32, kk = l.k * l.k;
+        if (l.k == 7 && 7 * l.cin <= 32)      // first conv on the row-patch slab (wb_pre): tap t = ky, channel kx*cin + c
+            gg::pack_panels(panel, l.cout, 7 * l.cin, 32, 7, [&](int co, int j, int ky) {
+                const int kx = j / l.cin, c = j - kx * l.cin;
+                return w[((size_t)co * l.cin + c) * 49 + ky * 7 + kx]; });
+        else
         gg::pack_panels(panel, l.cout, l.cin, cin_pad, kk, [&](int co, int ci, int t) { return w[((size_t)co * l.cin + ci) * kk + t]; });
         INNFER_HIP(hipMalloc((void**)&l.d_w, panel.size() * sizeof(f16)));
         INNFER_HIP(hipMemcpy(l.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
@@ -282,6 +300,8 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
     float* raw = (float*)(ws + cv.raw);
     int dy49[49], dx49[49], dy9[9], dx9[9];
     for (int t = 0; t < 49; ++t) { dy49[t] = t / 7 - 3; dx49[t] = t % 7 - 3; }
+    int dy7[7], dx7[7];                                  // first conv on the row-patch slab: vertical taps only
+    for (int t = 0; t < 7; ++t) { dy7[t] = t - 3; dx7[t] = 0; }
     int dy9tf[9], dx9tf[9];                              // tf_same_padding: pad (0,1,0,1) in front of the stride-2 convs
     for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; dy9tf[t] = t / 3; dx9tf[t] = t % 3; }
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
@@ -301,9 +321,13 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
             return conv_launch(L, s);
         }
         const int cin_pad = (l.cin + 31) / 32 * 32, cout_pad = (l.cout + 63) / 64 * 64, rs = (l.cout + 3) / 4 * 4;
-        CK(gg::launch(l.d_w, cin_pad, cout_pad, in, (long)N * Hi * Wi * 32, N, Hi, Wi, raw, Ho, Wo, stride, l.k * l.k,
-                      l.k == 7 ? dy49 : (stride == 2 && u->tf ? dy9tf : dy9), l.k == 7 ? dx49 : (stride == 2 && u->tf ? dx9tf : dx9),
-                      Ho, Wo, 1, 0, 0, 0, s, nullptr, 0, rs));
+        if (l.k == 7 && 7 * l.cin <= 32) {
+            CK(gg::launch(l.d_w, 32, cout_pad, in, (long)N * Hi * Wi * 32, N, Hi, Wi, raw, Ho, Wo, 1, 7, dy7, dx7, Ho, Wo, 1, 0, 0, 0, s, nullptr, 0, rs));
+        } else {
+            CK(gg::launch(l.d_w, cin_pad, cout_pad, in, (long)N * Hi * Wi * 32, N, Hi, Wi, raw, Ho, Wo, stride, l.k * l.k,
+                          l.k == 7 ? dy49 : (stride == 2 && u->tf ? dy9tf : dy9), l.k == 7 ? dx49 : (stride == 2 && u->tf ? dx9tf : dx9),
+                          Ho, Wo, 1, 0, 0, 0, s, nullptr, 0, rs));
+        }
         const long npix = (long)N * Ho * Wo;
         const long nthr = npix * ((l.cout + 3) / 4);
         hipLaunchKernelGGL(wb_post, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)raw, rs, l.cout, npix, (const float*)l.d_b, act,
@@ -321,7 +345,8 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
     f16 *XIN = (f16*)(ws + cv.xin), *X0 = (f16*)(ws + cv.x0), *T1 = (f16*)(ws + cv.t1), *X1 = (f16*)(ws + cv.x1), *T2 = (f16*)(ws + cv.t2),
         *A = (f16*)(ws + cv.a), *B = (f16*)(ws + cv.b), *Cc = (f16*)(ws + cv.c), *U1 = (f16*)(ws + cv.u1), *V1 = (f16*)(ws + cv.v1), *U0 = (f16*)(ws + cv.u0);
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
-    hipLaunchKernelGGL(wb_pre, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, 3, (long)H * W, N, XIN);
+    hipLaunchKernelGGL(wb_pre, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, 3, H, W, N, XIN);
+    INNFER_HIP(hipGetLastError());
     CK(layer(XIN, H, W, 1, 1, nullptr, X0, nullptr));                      // conv
     CK(layer(X0, H, W, 2, 1, nullptr, T1, nullptr));                       // conv_1 (stride 2)
     CK(layer(T1, H2, W2, 1, 1, nullptr, X1, nullptr));                     // conv_2
