@@ -50,19 +50,35 @@ __global__ void rn_post(const float* raw, int cpad, int C, long HW, int N, const
     *(f16x8*)(dst + o) = h;
 }
 
-__global__ void rn_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {     // NCHW -> one zero-padded group
+// NCHW input -> "row patch" slab of the reflection-padded first 7x7 conv: channel kx*C + c of pixel (y, x) holds in[c][y][reflect(x + kx - 3)]
+// (zero beyond 7*C <= 32 channels), so the 49-tap conv becomes 7 vertical taps (reflected by the GEMM's gather) over ONE 32-channel group.
+// C > 4: plain copy into a zero-padded group (49 taps).  One thread per pixel, 16-byte stores.
+__global__ void rn_pre(const void* in, int in_f32, int C, int H, int W, int N, f16* slab, int patch) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long HW = (long)H * W;
     if (i >= (long)N * HW) return;
     const long n = i / HW, px = i % HW;
+    const int x = (int)(px % W);
     f16 v[32];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) v[c] = (f16)0.f;
-    for (int c = 0; c < C; ++c) {
-        const long o = (n * C + c) * HW + px;
-        v[c] = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+    for (int j = 0; j < 32; ++j) {
+        f16 t = (f16)0.f;
+        if (patch) {
+            const int kx = j / C, c = j - kx * C;
+            int X = x + kx - 3;
+            X = X < 0 ? -X : (X >= W ? 2 * W - 2 - X : X);
+            if (kx < 7) {
+                const long o = (n * C + c) * HW + px + (X - x);
+                t = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+            }
+        } else if (j < C) {
+            const long o = (n * C + j) * HW + px;
+            t = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+        }
+        v[j] = t;
     }
 #pragma unroll
-    for (int c = 0; c < 32; ++c) slab[i * 32 + c] = v[c];
+    for (int q = 0; q < 4; ++q) *(f16x8*)(slab + i * 32 + 8 * q) = *(const f16x8*)(v + 8 * q);
 }
 
 __global__ void rn_final(const float* raw, int rs, int C, long HW, int N, const float* bias, void* out, int out_f32) {
@@ -184,7 +200,15 @@ int rn_upload(innfer_resnet* r) {
             l.d_w.push_back(d);
             return INNFER_OK;
         };
-        if (!l.transposed) {
+        if (!l.transposed && k == 7 && 7 * l.cin <= 32) {       // first conv on the row-patch slab (rn_pre): tap = ky, channel kx*cin + c
+            gg::pack_panels(panel, l.cout, 7 * l.cin, 32, 7, [&](int co, int j, int ky) {
+                const int kx = j / l.cin, c = j - kx * l.cin;
+                return w[((size_t)co * l.cin + c) * 49 + ky * 7 + kx]; });
+            f16* d = nullptr;
+            INNFER_HIP(hipMalloc((void**)&d, panel.size() * sizeof(f16)));
+            INNFER_HIP(hipMemcpy(d, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
+            l.d_w.push_back(d);
+        } else if (!l.transposed) {
             int rc = put(k * k, [&](int co, int ci, int t) { return w[((size_t)co * l.cin + ci) * k * k + t]; });
             if (rc) return rc;
         } else {
@@ -282,8 +306,16 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         *Cc = (f16*)(ws + cv.c), *U1 = (f16*)(ws + cv.u1), *U2 = (f16*)(ws + cv.u2);
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
     size_t li = 0;
-    hipLaunchKernelGGL(rn_pre, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, r->in_nc, (long)H * W, N, X0);
-    CK(conv(r->layers[li], X0, H, W, H, W, 1, 1)); CK(norm_post(r->layers[li], H, W, 1, nullptr, S1)); ++li;          // c7s1-64
+    const int patch = 7 * r->in_nc <= 32;
+    hipLaunchKernelGGL(rn_pre, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, r->in_nc, H, W, N, X0, patch);
+    INNFER_HIP(hipGetLastError());
+    if (patch) {
+        int dy7[7], dx7[7];
+        for (int t = 0; t < 7; ++t) { dy7[t] = t - 3; dx7[t] = 0; }
+        CK(gg::launch(r->layers[li].d_w[0], 32, 64, X0, (long)N * H * W * 32, N, H, W, raw, H, W, 1, 7, dy7, dx7, H, W, 1, 0, 0, 0, s, nullptr, 0, 0, 1));
+    } else
+    CK(conv(r->layers[li], X0, H, W, H, W, 1, 1));
+    CK(norm_post(r->layers[li], H, W, 1, nullptr, S1)); ++li;          // c7s1-64
     CK(conv(r->layers[li], S1, H, W, H2, W2, 2, 0)); CK(norm_post(r->layers[li], H2, W2, 1, nullptr, S2)); ++li;     // d128
     CK(conv(r->layers[li], S2, H2, W2, H4, W4, 2, 0)); CK(norm_post(r->layers[li], H4, W4, 1, nullptr, A)); ++li;    // d256
     f16* t = A;
