@@ -3,11 +3,12 @@
 // (architectures/ResNet_arch.py:19-151; defaults utils/defaults.py:124-140: ngf 64, 9 (or 6) blocks).
 //
 //   ReflectionPad2d(3) + 7x7 conv, ReflectionPad2d(1) + 3x3 conv      gg::gemm_gather, 49 / 9 taps, out-of-image taps
-//                                                                     read the mirrored pixel (GP.reflect)
+//                                                                     read the mirrored pixel (GP.reflect); the first conv (3 input
+//                                                                     channels) reads a row-patch slab: 7 vertical taps (rn_pre)
 //   3x3 stride-2 zero-pad-1 convs                                     gg::gemm_gather (stride 2)
 //   ConvTranspose2d(3, stride 2, padding 1, output_padding 1)         four output phases (1, 2, 2, 4 taps) of the same GEMM
 //   InstanceNorm2d (no affine, statistics of the instance also under eval)   norm_stats.h: per-(image, channel) mean / biased variance in
-//                                                                     fp32, two passes; the conv bias is folded into the shift
+//                                                                     fp32, one read; the conv bias cancels in the norm
 //   ReLU / residual add / Tanh                                        rn_post, rn_final
 // Activations are blocked-NHWC fp16 slabs, GEMM results fp32 rows.  A batch is N independent images.
 #include "common.h"

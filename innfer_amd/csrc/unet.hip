@@ -4,20 +4,21 @@
 // statistics of the CURRENT image, run.py:299-303,98-99; SURVEY.md D6: a batch is N independent
 // batch-1 forwards, so statistics are per image).
 //
-//   4x4 stride-2 pad-1 conv           -> gather-GEMM on MFMA: 16 taps x Cin/32 chunks
-//   4x4 stride-2 pad-1 ConvTranspose  -> four output phases (oy&1, ox&1), each a 2x2-tap gather-GEMM
-//   BatchNorm2d (training mode)       -> per-(image, channel) mean / biased variance over H*W in fp32
-//                                        on the fp32 conv output (two passes), eps 1e-5
+//   4x4 stride-2 pad-1 conv           -> gather GEMM on MFMA (gather_gemm.h): 16 taps x Cin/32 chunks; the outermost one (3 input
+//                                        channels) reads a 64-channel patch slab at half resolution instead (unet_pre_patch, 1 tap)
+//   4x4 stride-2 pad-1 ConvTranspose  -> four output phases (oy&1, ox&1) of 2x2 taps each, ONE grouped launch (GP.g_phase) unless the
+//                                        layer is split over K; the outermost one (128 -> 3, bias, tanh) is ONE 3x3 conv with 4*3 phase
+//                                        channels on the SR path's halo-tile kernel (conv3x3.hip, planar epilogue with the phase scatter)
+//   BatchNorm2d (training mode)       -> norm_stats.h: per-(image, channel) mean / biased variance over H*W in fp32 from one read of
+//                                        the fp32 conv output, eps 1e-5
 //   LeakyReLU(0.2, inplace) / ReLU / torch.cat / Tanh -> the "post" kernel writes every consumer's
 //       view of a tensor directly: the in-place LeakyReLU at the head of each block also rewrites the
 //       skip branch (UNet_arch.py:109,160), and the parent's in-place ReLU acts on the concatenation,
 //       so a down-path tensor t is consumed as lrelu(t) by the next down conv and as
 //       relu(lrelu(t)) = relu(t) by the up conv: two fp16 slabs, no activation on load.
 //
-// Correctness-first kernels (this path is 774 GFLOP for 64 images against 74 TFLOP per ESRGAN
-// frame): one 64-pixel x 64-channel tile per workgroup, operands staged through LDS with plain
-// loads, single-buffered.  Activations are blocked-NHWC fp16 like the SR path; conv outputs stay
-// fp32 until normalised.
+// Activations are blocked-NHWC fp16 like the SR path; GEMM outputs stay fp32 until normalised.  Deep layers (<= 64 output
+// pixels per image) are split over K; whether a layer is split never depends on the batch, so a batch equals its batch-1 forwards.
 #include "common.h"
 #include "gather_gemm.h"
 #include "norm_stats.h"

@@ -2,8 +2,9 @@
 // Replaces UnetGeneratorWBC(mode='pt' | 'tf').forward with ResBlock (architectures/WBCNet_arch.py:8-99; `-a wbcunet`,
 // utils/defaults.py:90-97: nf 32) and guided_filter(x, y, r=1, eps) (utils/utils.py:548-626, run.py:427-429).
 //
-//   7x7 / 3x3 convs, stride 1 or 2, zero padding          gg::gemm_gather (49 / 9 taps, zero fill)
-//   bias, LeakyReLU(0.2), ResBlock skip                    wb_post
+//   stride-1 3x3 convs, zero padding                      the SR path's halo-tile kernel (conv3x3.hip), epilogue bias / LeakyReLU / skip
+//   first 7x7 conv (3 input channels)                      gg::gemm_gather over a row-patch slab (wb_pre): 7 vertical taps
+//   stride-2 3x3 convs, last 7x7 conv                      gg::gemm_gather (9 / 49 taps, zero fill) + wb_post (bias, LeakyReLU, NCHW)
 //   bilinear 2x (align_corners=False) + skip addition      wb_upadd (ATen's source index / lambda arithmetic)
 //   guided filter, 3x3 box means, reflect padding          gf_ab (means, covariance, A, b) + gf_out (mean_A * x + mean_b)
 #include "common.h"
