@@ -2,7 +2,10 @@
 //
 // Replaces the reference's conv_block -> nn.Conv2d [+ LeakyReLU/ReLU] [+ torch.cat]
 // [+ x*0.2 + residual] [+ nearest-2x Upsample in front] [+ PixelShuffle behind]
-// (architectures/block.py:213-254,333-361; RRDBNet_arch.py:152-165,91-98).
+// (architectures/block.py:213-254,333-361; RRDBNet_arch.py:152-165,91-98).  The other generators reuse it for every
+// conv it can express -- PAN (all convs; a 1x1 conv is a panel with a centre tap only; pixel-attention gate epilogue
+// res1 * sigmoid(conv)), PPON, the WBC UNet, and the pix2pix UNet's outermost ConvTranspose (the four output phases as
+// 4*out_nc channels of one 3x3 conv, tanh + phase scatter in the planar epilogue).
 //
 // Data layout in HBM: activations are fp16 "blocked NHWC" channel slabs: channels in groups of
 // 32, element (n,y,x,c) at base + (c/32)*group_stride + ((n*H+y)*W+x)*32 + c%32, so a 32-channel

@@ -1,4 +1,5 @@
-// Gather-GEMM on MFMA shared by the UNet and PAN engines: out[pixel][co] = sum over taps and input
+// Gather-GEMM on MFMA for the convolutions the halo-tile kernel (conv3x3.hip) cannot express -- strided, transposed, dilated, 7x7,
+// reflection-padded (UNet, CycleGAN ResNet, PPON's dilated convs, WBC UNet, PAN's attention projections): out[pixel][co] = sum over taps and input
 // channels of in[pixel displaced by the tap][ci] * W[tap][ci][co].  One 128-pixel x 64-channel tile per
 // workgroup, operands staged through LDS with register-prefetched loads (the SR hot path uses
 // conv3x3.hip).  Input: blocked-NHWC fp16 slab; output: fp32 [pixel][cout_pad].
