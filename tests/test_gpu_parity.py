@@ -360,6 +360,28 @@ def test_unet256_golden(dev, golden):
     assert np.abs(y32 - ref).max() < 3e-2
 
 
+def test_unet_variants_vs_oracle(dev):
+    """Other UnetGenerator shapes through the same engine: unet_128 (7 levels) on a non-square image, and 1-channel input /
+    5-channel output (the patch-slab first conv and the phase-combined last ConvTranspose are taken only for <= 4 channels)."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.UNet_arch import UnetGenerator
+    for in_nc, out_nc, num_downs, h, w, seed in ((3, 3, 7, 128, 256, 40), (1, 5, 5, 64, 96, 41)):
+        net = UnetGenerator(in_nc, out_nc, num_downs, ngf=64)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = _sd(shapes, seed)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev)
+        net.train()
+        x = torch.from_numpy(synth.uniform((2, in_nc, h, w), seed + 1, -1.0, 1.0))
+        y = net(x.to(dev).half()).float().cpu()
+        with torch.no_grad():
+            ref = torch.cat([oracle.unet_forward(sd, x[i:i + 1], num_downs=num_downs) for i in range(2)], 0)
+        err = (y - ref).abs()
+        assert y.shape == ref.shape == (2, out_nc, h, w)
+        assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (in_nc, out_nc, num_downs, err.max().item(), err.mean().item())
+
+
 def test_unet256_big_batch_uses_wide_tiles_and_stays_identical(dev):
     """A batch of 16 makes the mid layers take the 256 px x 128 channel GEMM tiles and keeps the deep
     layers on the split-K path; every image must still equal its own batch-1 forward bit for bit."""
