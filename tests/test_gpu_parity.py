@@ -707,6 +707,29 @@ def test_model_chop_golden(dev, golden, tmp_path):
         assert np.abs(y2[0, :, ::8, ::8].numpy() - g[f"nochop_{tag}_sub"]).max() < 1e-2
 
 
+def test_model_chop_pan_vs_oracle(dev, tmp_path):
+    """A PAN checkpoint through Model.__call__(chop=True): loader inference (arch / scale from the keys), tile batches through the
+    halo-tile convs, blend -- against the oracle's chop_forward of the oracle's PAN on a 210x250 image (4 tiles)."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.run import Model
+    from innfer_amd.utils.defaults import get_network_G_config
+    shapes = {k: tuple(v.shape) for k, v in get_network(get_network_G_config("pan", 4)).state_dict().items()}
+    sd = _sd(shapes, 51)
+    path = str(tmp_path / "4x_pan.pth")
+    torch.save(sd, path)
+    m = Model(path, arch="infer", scale=None, device="cuda", chop=True, tile_batch=3)
+    assert (m.arch, m.scale) == ("pan", 4)
+    x = torch.from_numpy(synth.uniform((1, 3, 210, 250), 52))
+    y = m(x.to(dev).half()).float().cpu()
+    with torch.no_grad():
+        ref = oracle.chop_forward(lambda t: oracle.pan_forward(sd, t, nb=16, scale=4), x, 4)
+    assert tuple(y.shape) == tuple(ref.shape) == (1, 3, 840, 1000)
+    err = (y - ref).abs()
+    assert err.max().item() < 1e-2 and err.mean().item() < 1.5e-3, (err.max().item(), err.mean().item())
+
+
 def test_full_frame_1080p_translation_property(dev):
     """BASELINE config 2 size (1x3x1080x1920 -> 1x3x4320x7680, RRDBNet-23 4x fp16): an
     interior window of the full-frame result equals the forward of a crop that
