@@ -751,3 +751,23 @@ def test_full_frame_1080p_translation_property(dev):
     net.band_rows = 128
     assert torch.equal(net(x), y)
     net.band_rows = 0
+
+
+def test_4k_input_untiled_addresses_beyond_2gib(dev):
+    """A 2160x3840 frame un-tiled through a 1-block 4x RRDBNet: the HR slabs are 17 GB each (132.7 M pixels x 64 channels), far beyond
+    32-bit byte offsets.  A window at the bottom-right corner (the largest addresses) must equal the forward of a crop that
+    contains the window plus the receptive radius, bit for bit (stride-1 convs are translation equivariant; the crop keeps
+    the frame's bottom / right borders so the zero padding matches)."""
+    from innfer_amd import synth
+    net, _ = _rrdb(dev, 1, 4)
+    H, W = 2160, 3840
+    x = torch.from_numpy(synth.uniform((1, 3, H, W), 77)).to(dev).half()
+    y = net(x)
+    assert tuple(y.shape) == (1, 3, 4 * H, 4 * W) and torch.isfinite(y[:, :, -64:, -64:]).all()
+    R, hw = 1 * 15 + 6, 24
+    y0, x0 = H - hw - R, W - hw - R
+    yc = net(x[:, :, y0:, x0:].contiguous())
+    assert torch.equal(y[:, :, 4 * (H - hw):, 4 * (W - hw):], yc[:, :, 4 * R:, 4 * R:])
+    del y, yc
+    net.release_workspace()
+    torch.cuda.empty_cache()
