@@ -114,6 +114,52 @@ def roofline_from_launches(launches):
             "per_kernel": per_kernel}
 
 
+def power_probe(step, seconds=2.5):
+    """Package power and shader clock the GPU holds under THIS workload: `step` is enqueued back to back for ~`seconds`
+    while a thread samples `rocm-smi` (about one sample per 0.4 s; the first second is discarded so that the power manager has
+    settled).  Context for the roofline object only -- the peak in `roofline.peak` is the 2.4 GHz figure; never part of
+    the timed region.  Returns None when rocm-smi is not there."""
+    import re, shutil, subprocess, threading
+    import torch
+    if not shutil.which("rocm-smi"):
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        t0 = time.perf_counter()
+        while not stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            clk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            pw = re.search(r"Package Power \(W\): ([0-9.]+)", out)
+            if clk and pw and time.perf_counter() - t0 > 1.0:
+                samples.append((int(clk.group(1)), float(pw.group(1))))
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=15)
+    if not samples:
+        return None
+    cap = None
+    try:
+        m = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)",
+                      subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout)
+        cap = float(m.group(1)) if m else None
+    except Exception:
+        pass
+    sclk = sum(c for c, _ in samples) / len(samples)
+    return {"sclk_mhz": round(sclk, 0), "package_w": round(sum(w for _, w in samples) / len(samples), 0), "cap_w": cap,
+            "samples": len(samples), "peak_at_sclk_tflops": round(PEAK_F16_TFLOPS * sclk / 2400.0, 1)}
+
+
 def per_layer_table(launches, npix_lr):
     """stderr table: per distinct (kind, flops) launch class -> avg ms, TFLOP/s (diagnostics)."""
     rows = {}
@@ -199,6 +245,7 @@ def main():
     ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -305,6 +352,12 @@ def main():
             timed_forward(net, x)
             launches = timed_forward(net, x)
             line["roofline"] = roofline_from_launches(launches)
+            if world == 1 and not args.no_power_probe:
+                log('power probe')
+                pw = power_probe(step)
+                if pw:
+                    pw["frac_of_peak_at_sclk"] = round(line["roofline"]["achieved"] / pw["peak_at_sclk_tflops"], 4)
+                    line["roofline"]["power"] = pw
             log("per-layer classes:\n" + per_layer_table(launches, H * W))
         net.release_workspace()
         if world == 1 and not args.no_cpu_baseline:
