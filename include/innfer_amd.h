@@ -219,6 +219,8 @@ typedef struct {
     const void* d_res1; int64_t res1_group_stride; float res1_scale;
     const void* d_res2; int64_t res2_group_stride; float res2_scale;
     int row_begin, row_end;             /* rows of the output to compute; 0,0 = all */
+    int reflect_pad;                    /* != 0: nn.ReflectionPad2d(1) in front of the conv instead of zero padding (CycleGAN ResnetBlock,
+                                           ResNet_arch.py:103-140); not together with upsample2x */
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);

@@ -87,6 +87,7 @@ struct KP {
     int N;
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
+    int reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d(1)) instead of zero; not with `up`
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
     int total;               // tiles x channel groups of this launch
 #ifdef INNFER_ABLATE
@@ -586,7 +587,16 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                     const int px = (lw + NLW * k) * 16 + (lane >> 2);
                     const int ly = px / LWP, lx = px - ly * LWP;
                     const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
-                    if (Y < 0 || Y >= p.H || X < 0 || X >= p.W) voff[k] = OOB;
+                    if (Y < 0 || Y >= p.H || X < 0 || X >= p.W) {
+                        // reflection padding: the ring of pixels one step outside the image mirrors the pixel one step inside; farther
+                        // out (tile padding of a ragged frame) only feeds outputs that are never stored
+                        if (p.reflect && loff[k] != OOB && Y >= -1 && Y <= p.H && X >= -1 && X <= p.W) {
+                            const int Yr = Y < 0 ? 1 : (Y >= p.H ? p.H - 2 : Y), Xr = X < 0 ? 1 : (X >= p.W ? p.W - 2 : X);
+                            voff[k] = loff[k] + ((Yr - Y) * p.Ws + (Xr - X)) * 64;
+                        } else {
+                            voff[k] = OOB;
+                        }
+                    }
                 }
             }
         };
@@ -915,6 +925,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.out_f32 = L.out_f32;
     k.rev = L.rev ? 1 : 0;
     k.phase_c = L.out_mode == OUT_NCHW ? L.phase_c : 0;
+    k.reflect = L.reflect ? 1 : 0;
+    if (L.reflect && (L.up || L.H < 2 || L.W < 2)) return set_error(INNFER_ERR_INVALID, "conv3x3: reflection padding needs >= 2x2 pixels and no upsampled input");
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
@@ -924,8 +936,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2) return launch_pc<3, 1, 4, OUT_NCHW>(k, L.N, s);
-    if (L.act >= 3 || L.phase_c > 0)
-        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tanh / phase output / gate epilogues exist only in the producer-consumer kernel");
+    if (L.act >= 3 || L.phase_c > 0 || L.reflect)
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tanh / phase output / gate epilogues / reflection padding exist only in the producer-consumer kernel");
     switch (L.out_mode) {
         case OUT_SLAB:
             if (nt == 4) return rpw64 == 4 ? launch_t<4, 4, OUT_SLAB>(k, L.N, s) : rpw64 == 3 ? launch_t<3, 4, OUT_SLAB>(k, L.N, s) : launch_t<2, 4, OUT_SLAB>(k, L.N, s);

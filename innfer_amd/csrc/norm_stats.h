@@ -22,7 +22,9 @@ __device__ __forceinline__ void bn_write(float mu, float var, float eps, const f
     shift[n * C + c] = (beta ? beta[c] : 0.f) - mu * a;
 }
 
-static __global__ __launch_bounds__(1024) void stats_kernel(const float* raw, int cpad, long HW, float eps, const float* gamma, const float* beta,
+// SLAB: the source is an fp16 blocked-NHWC slab (raw = slab base, cpad = group stride in elements taken from `gs`)
+template <bool SLAB>
+static __global__ __launch_bounds__(1024) void stats_kernel(const void* src, long gs, int cpad, long HW, float eps, const float* gamma, const float* beta,
                                                  float* alpha, float* shift, int C, float* part, int nseg) {
     __shared__ float red[1024];
     const int n = blockIdx.y, cb = blockIdx.x * 32, sg = blockIdx.z;
@@ -30,7 +32,8 @@ static __global__ __launch_bounds__(1024) void stats_kernel(const float* raw, in
     const int c = cb + cl;
     const long p0 = (long)sg * SEG;
     const int cnt = (int)min((long)SEG, HW - p0);
-    const float* base = raw + ((long)n * HW + p0) * cpad + c;
+    const float* base = SLAB ? nullptr : (const float*)src + ((long)n * HW + p0) * cpad + c;
+    const f16* sbase = SLAB ? (const f16*)src + (c >> 5) * gs + ((long)n * HW + p0) * 32 + (c & 31) : nullptr;
     auto reduce32 = [&](float v) {                 // sum over the 32 pixel lanes of one channel, result in every lane
         red[threadIdx.x] = v;
         __syncthreads();
@@ -47,7 +50,7 @@ static __global__ __launch_bounds__(1024) void stats_kernel(const float* raw, in
         v[i] = 0.f;
         if (i < iters) {
             const int px = pl + 32 * i;
-            if (px < cnt) v[i] = base[(long)px * cpad];
+            if (px < cnt) v[i] = SLAB ? (float)sbase[(long)px * 32] : base[(long)px * cpad];
         }
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -91,7 +94,21 @@ inline size_t part_floats(int C, long HW) { return (size_t)C * (size_t)((HW + SE
 inline int launch_stats(const float* raw, int cpad, long HW, float eps, const float* gamma, const float* beta, float* alpha, float* shift,
                         int C, int N, float* part, hipStream_t s) {
     const int nseg = (int)((HW + SEG - 1) / SEG);
-    hipLaunchKernelGGL(stats_kernel, dim3((C + 31) / 32, N, nseg), dim3(1024), 0, s, raw, cpad, HW, eps, gamma, beta, alpha, shift, C, part, nseg);
+    hipLaunchKernelGGL(stats_kernel<false>, dim3((C + 31) / 32, N, nseg), dim3(1024), 0, s, (const void*)raw, 0L, cpad, HW, eps, gamma, beta, alpha, shift, C, part, nseg);
+    INNFER_HIP(hipGetLastError());
+    if (nseg > 1) {
+        hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(((long)N * C + 255) / 256)), dim3(256), 0, s, (const float*)part, nseg, HW, eps,
+                           gamma, beta, alpha, shift, C, N);
+        INNFER_HIP(hipGetLastError());
+    }
+    return INNFER_OK;
+}
+
+// the same statistics over an fp16 slab of C channels (group stride gs elements)
+inline int launch_stats_slab(const f16* slab, long gs, long HW, float eps, const float* gamma, const float* beta, float* alpha, float* shift,
+                             int C, int N, float* part, hipStream_t s) {
+    const int nseg = (int)((HW + SEG - 1) / SEG);
+    hipLaunchKernelGGL(stats_kernel<true>, dim3((C + 31) / 32, N, nseg), dim3(1024), 0, s, (const void*)slab, gs, 0, HW, eps, gamma, beta, alpha, shift, C, part, nseg);
     INNFER_HIP(hipGetLastError());
     if (nseg > 1) {
         hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(((long)N * C + 255) / 256)), dim3(256), 0, s, (const float*)part, nseg, HW, eps,

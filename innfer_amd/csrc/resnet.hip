@@ -2,9 +2,11 @@
 // Replaces ResnetGenerator(norm=instance, padding=reflect, upsample=deconv).forward with ResnetBlock
 // (architectures/ResNet_arch.py:19-151; defaults utils/defaults.py:124-140: ngf 64, 9 (or 6) blocks).
 //
-//   ReflectionPad2d(3) + 7x7 conv, ReflectionPad2d(1) + 3x3 conv      gg::gemm_gather, 49 / 9 taps, out-of-image taps
-//                                                                     read the mirrored pixel (GP.reflect); the first conv (3 input
-//                                                                     channels) reads a row-patch slab: 7 vertical taps (rn_pre)
+//   ReflectionPad2d(1) + 3x3 conv (the residual blocks)               the SR path's halo-tile kernel (conv3x3.hip, ConvLaunch.reflect):
+//                                                                     fp16 slab out, statistics / normalisation on that slab
+//   ReflectionPad2d(3) + 7x7 conv                                     gg::gemm_gather, out-of-image taps read the mirrored pixel
+//                                                                     (GP.reflect); the first one (3 input channels) reads a
+//                                                                     row-patch slab: 7 vertical taps (rn_pre), the last one 49 taps
 //   3x3 stride-2 zero-pad-1 convs                                     gg::gemm_gather (stride 2)
 //   ConvTranspose2d(3, stride 2, padding 1, output_padding 1)         four output phases (1, 2, 2, 4 taps) of the same GEMM
 //   InstanceNorm2d (no affine, statistics of the instance also under eval)   norm_stats.h: per-(image, channel) mean / biased variance in
@@ -46,6 +48,33 @@ __global__ void rn_post(const float* raw, int cpad, int C, long HW, int N, const
         float v = rp[e] * ap[e] + sp[e];
         if (relu) v = fmaxf(v, 0.f);
         if (res) v += (float)res[o + e];
+        h[e] = (f16)v;
+    }
+    *(f16x8*)(dst + o) = h;
+}
+
+// fp16 conv result (slab, bias included) -> instance norm -> [ReLU] -> [+ residual] -> fp16 slab (may be the source slab itself);
+// one thread per (pixel, 8 channels).  Used behind the halo-tile convs of the residual blocks.
+__global__ void rn_post_slab(const f16* src, int C, long HW, int N, const float* alpha, const float* shift, int relu,
+                             const f16* res, f16* dst, long g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C / 8;
+    if (i >= (long)N * HW * c8) return;
+    const int c = (int)(i % c8) * 8;
+    const long pix = i / c8;
+    const long n = pix / HW;
+    const float* ap = alpha + n * C + c;
+    const float* sp = shift + n * C + c;
+    const long o = (c >> 5) * g + pix * 32 + (c & 31);
+    const f16x8 x = *(const f16x8*)(src + o);
+    f16x8 r8;
+    if (res) r8 = *(const f16x8*)(res + o);
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = (float)x[e] * ap[e] + sp[e];
+        if (relu) v = fmaxf(v, 0.f);
+        if (res) v += (float)r8[e];
         h[e] = (f16)v;
     }
     *(f16x8*)(dst + o) = h;
@@ -94,7 +123,8 @@ __global__ void rn_final(const float* raw, int rs, int C, long HW, int N, const 
 }
 
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
-struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; bool transposed = false; std::vector<f16*> d_w; float* d_b = nullptr; };
+struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; bool transposed = false; std::vector<f16*> d_w; float* d_b = nullptr;
+               void* d_w3 = nullptr; };    // residual-block convs: conv3x3.hip panels (reflection padding in the halo-tile loader)
 
 }  // namespace
 
@@ -146,6 +176,8 @@ static void rn_free(innfer_resnet* r) {
         l.d_w.clear();
         if (l.d_b) (void)hipFree(l.d_b);
         l.d_b = nullptr;
+        if (l.d_w3) (void)hipFree(l.d_w3);
+        l.d_w3 = nullptr;
     }
 }
 
@@ -225,6 +257,12 @@ int rn_upload(innfer_resnet* r) {
         }
         INNFER_HIP(hipMalloc((void**)&l.d_b, l.cout * sizeof(float)));
         INNFER_HIP(hipMemcpy(l.d_b, r->params[l.b].host.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+        if (!l.transposed && k == 3 && l.cin == l.cout && l.cin % 64 == 0) {       // ResnetBlock convs (stride 1, reflection pad 1)
+            std::vector<char> packed(conv_packed_bytes(l.cout, l.cin));
+            conv_pack(w.data(), l.cout, l.cin, packed.data());
+            INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        }
     }
     r->uploaded = true;
     return INNFER_OK;
@@ -303,6 +341,26 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         }
         return INNFER_OK;
     };
+    // ResnetBlock conv: reflection-padded 3x3 on the halo-tile kernel (fp16 slab out, bias included), statistics and normalisation on
+    // that slab -- the conv output is rounded to fp16 before the instance norm, as in the reference's own fp16 mode
+    auto block_conv = [&](const Layer& l, const f16* in, int Hc, int Wc, int relu, const f16* res, f16* dst) -> int {
+        if (!l.d_w3) { CK(conv(l, in, Hc, Wc, Hc, Wc, 1, 1)); return norm_post(l, Hc, Wc, relu, res, dst); }
+        const long HW = (long)Hc * Wc, G = (long)N * HW * 32;
+        f16* Y = (f16*)raw;                                           // the fp32 GEMM buffer is free here
+        ConvLaunch L{};
+        L.in = in; L.in_gstride = G; L.C = l.cin;
+        L.wpk = (const f16*)l.d_w3; L.bias = l.d_b;
+        L.out = Y; L.out_gstride = G; L.K = l.cout;
+        L.N = N; L.H = Hc; L.W = Wc; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Hc;
+        L.out_mode = OUT_SLAB; L.reflect = 1;
+        CK(conv_launch(L, s));
+        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        const long total = (long)N * HW * (l.cout / 8);
+        hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
+                           (const float*)alpha, (const float*)shift, relu, res, dst, G);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
     f16 *X0 = (f16*)(ws + cv.x0), *S1 = (f16*)(ws + cv.s1), *S2 = (f16*)(ws + cv.s2), *A = (f16*)(ws + cv.a), *B = (f16*)(ws + cv.b),
         *Cc = (f16*)(ws + cv.c), *U1 = (f16*)(ws + cv.u1), *U2 = (f16*)(ws + cv.u2);
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
@@ -322,8 +380,8 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     f16* t = A;
     f16* spare = B;
     for (int b = 0; b < r->n_blocks; ++b) {                                                                             // R256 x n
-        CK(conv(r->layers[li], t, H4, W4, H4, W4, 1, 1)); CK(norm_post(r->layers[li], H4, W4, 1, nullptr, Cc)); ++li;
-        CK(conv(r->layers[li], Cc, H4, W4, H4, W4, 1, 1)); CK(norm_post(r->layers[li], H4, W4, 0, t, spare)); ++li;
+        CK(block_conv(r->layers[li], t, H4, W4, 1, nullptr, Cc)); ++li;
+        CK(block_conv(r->layers[li], Cc, H4, W4, 0, t, spare)); ++li;
         f16* tmp = t; t = spare; spare = tmp;
     }
     CK(deconv(r->layers[li], t, H4, W4)); CK(norm_post(r->layers[li], H2, W2, 1, nullptr, U1)); ++li;                 // u128

@@ -29,7 +29,7 @@ def _sd(shapes, seed=0):
 
 # ------------------------------------------------------------------ single conv
 def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0,
-              in_extra=0, out_channels=None, out_off=0, rows=None):
+              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False):
     """x [N,C,Hs,Ws] fp16 (cpu), w [K,C,3,3] fp32.  Runs the HIP conv on blocked-NHWC slabs
     ([C/32][N*H*W][32]) and returns (NCHW fp32 result, raw output slab [groups,N,H,W,32]) on the cpu."""
     import innfer_amd.lib as L
@@ -63,6 +63,7 @@ def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2
             keep.append(rs)
     if rows:
         a.row_begin, a.row_end = rows
+    a.reflect_pad = int(reflect)
     L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
     torch.cuda.synchronize()
     res = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
@@ -131,6 +132,18 @@ def test_conv_pixel_attention_gate_epilogue(dev):
     assert (got - gate).abs().max().item() < 4e-3
     got, _ = _run_conv(dev, x, w, b, K, act=4, res1=v)
     assert (got - F.leaky_relu(gate, 0.2)).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("N,Cc,K,H,W", [(1, 64, 64, 25, 33), (2, 32, 32, 2, 2), (1, 64, 32, 48, 64), (1, 32, 64, 24, 32)])
+def test_conv_reflection_padding(dev, N, Cc, K, H, W):
+    """nn.ReflectionPad2d(1) + conv (ResNet_arch.py:103-140) in the halo-tile loader: ragged, tile-aligned and minimal sizes."""
+    from innfer_amd import synth
+    x = torch.from_numpy(synth.uniform((N, Cc, H, W), 61, -1, 1)).half()
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 62, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.from_numpy(synth.uniform((K,), 63, -1, 1))
+    got, _ = _run_conv(dev, x, w, b, K, act=0, reflect=True)
+    ref = F.conv2d(F.pad(x.float(), (1, 1, 1, 1), mode="reflect"), w.half().float(), b.float())
+    assert (got - ref).abs().max().item() < 4e-3
 
 
 def test_conv_nearest_upsample_fused(dev):
