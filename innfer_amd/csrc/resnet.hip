@@ -42,12 +42,16 @@ __global__ void rn_post(const float* raw, int cpad, int C, long HW, int N, const
     const float* ap = alpha + n * C + c;
     const float* sp = shift + n * C + c;
     const long o = (c >> 5) * g + pix * 32 + (c & 31);
+    const f32x4 x0 = *(const f32x4*)rp, x1 = *(const f32x4*)(rp + 4), a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4),
+                s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+    f16x8 r8;
+    if (res) r8 = *(const f16x8*)(res + o);
     f16x8 h;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        float v = rp[e] * ap[e] + sp[e];
+        float v = (e < 4 ? x0[e & 3] : x1[e & 3]) * (e < 4 ? a0[e & 3] : a1[e & 3]) + (e < 4 ? s0[e & 3] : s1[e & 3]);
         if (relu) v = fmaxf(v, 0.f);
-        if (res) v += (float)res[o + e];
+        if (res) v += (float)r8[e];
         h[e] = (f16)v;
     }
     *(f16x8*)(dst + o) = h;
