@@ -36,19 +36,25 @@ __device__ __forceinline__ float slab_get(const f16* s, long g, long pix, int ch
     return (float)s[(ch >> 5) * g + pix * 32 + (ch & 31)];
 }
 
-__global__ void pan_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {
+__global__ void pan_pre(const void* in, int in_f32, int C, long HW, int N, f16* slab) {        // NCHW -> one zero-padded 32-channel group
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * HW) return;
     const long n = i / HW, px = i % HW;
-    for (int c = 0; c < C; ++c) {
-        const long o = (n * C + c) * HW + px;
-        slab[i * 32 + c] = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+    f16 v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        f16 t = (f16)0.f;
+        if (c < C) { const long o = (n * C + c) * HW + px; t = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o]; }
+        v[c] = t;
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f16x8*)(slab + i * 32 + 8 * q) = *(const f16x8*)(v + 8 * q);
 }
 
-// MaxPool2d(4): one thread per (pooled pixel, 8 channels), 16-byte loads (C % 8 == 0)
+// MaxPool2d(4): one thread per (pooled pixel, 8 channels), 16-byte loads (C % 8 == 0); the pad channels up to the next multiple of 32 are
+// written as zeros (the projections behind it read whole 32-channel groups)
 __global__ void pan_maxpool(const f16* in, long in_g, int C, int N, int H, int W, int hp, int wp, f16* out, long out_g) {
-    const int c8 = C >> 3;
+    const int c8 = ((C + 31) / 32 * 32) >> 3;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)N * hp * wp * c8) return;
     const long i = t / c8;
@@ -57,6 +63,12 @@ __global__ void pan_maxpool(const f16* in, long in_g, int C, int N, int H, int W
     const long n = i / ((long)wp * hp);
     const f16* base = in + (c >> 5) * in_g + (c & 31);
     f16x8 m;
+    if (c >= C) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (f16)0.f;
+        *(f16x8*)(out + (c >> 5) * out_g + i * 32 + (c & 31)) = m;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = (f16)-INFINITY;
     for (int dy = 0; dy < 4; ++dy)
@@ -161,11 +173,18 @@ __device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * 
 // t = gamma * bicubic(att, size=(H,W), align_corners=False) + inp      (ATen upsample_bicubic2d)
 __global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f16* inp, long g, int N, int H, int W,
                                 const float* gamma, f16* dst) {
-    const int c8 = C >> 3;                           // one thread per (pixel, 8 channels); per channel the same sums in the same order
+    const int c8 = ((C + 31) / 32 * 32) >> 3;        // one thread per (pixel, 8 channels); per channel the same sums in the same order
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)N * H * W * c8) return;
     const long i = t / c8;
     const int c0 = (int)(t - i * c8) * 8;
+    if (c0 >= C) {                                   // pad channels of the last group: zeros (the up conv reads whole groups)
+        f16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (f16)0.f;
+        *(f16x8*)(dst + (c0 >> 5) * g + i * 32 + (c0 & 31)) = z;
+        return;
+    }
     const int X = (int)(i % W), Y = (int)((i / W) % H);
     const long n = i / ((long)W * H);
     const float A = -0.75f;
@@ -471,7 +490,8 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "pan_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)d_ws;
-    INNFER_HIP(hipMemsetAsync(ws, 0, cv.slab_end, s));            // pad channels of every slab must read as zero
+    // pad channels of every slab read as zero: every producer (pre, convs with zero pad weights / bias, MaxPool, FSA combine) writes whole
+    // 32-channel groups, so the workspace needs no clearing
     const long px = (long)N * H * W, G = px * 32;
     const int nf = p->nf;
     float* raw = (float*)(ws + cv.raw);
@@ -512,7 +532,6 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     CK(conv3(X0, G, H, W, 0, 0, nullptr, 0, FEA, G));                                  // conv_first
     const f16* x = FEA;
     for (int b = 0; b < p->nb; ++b) {
-        const std::string sk = "SCPA_trunk." + std::to_string(b) + ".";
         f16* xn = (b & 1) ? XB : XA;
         CK(conv3(x, G, H, W, 0, 1, nullptr, 0, AB, G));                               // lrelu([conv1_a | . | conv1_b]): a -> group 0, b -> group 1
         CK(conv3(AB, G, H, W, 0, 1, nullptr, 0, AB2, G));                             // lrelu(k1(a)) -> cat group 0
@@ -526,7 +545,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     {   // FSA
         const int hp = H / 4, wp = W / 4;
         const long np = (long)N * hp * wp, Gp = np * 32;
-        hipLaunchKernelGGL(pan_maxpool, dim3((unsigned)((np * (nf / 8) + 255) / 256)), dim3(256), 0, s, INP, G, nf, N, H, W, hp, wp, POOL, Gp);
+        hipLaunchKernelGGL(pan_maxpool, dim3((unsigned)((np * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, INP, G, nf, N, H, W, hp, wp, POOL, Gp);
         INNFER_HIP(hipGetLastError());
         float* save = raw;
         raw = (float*)(ws + cv.fgh);
@@ -535,7 +554,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         hipLaunchKernelGGL(pan_attention, dim3((hp * wp + 63) / 64, N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
                            vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, (float*)(ws + cv.att));
         INNFER_HIP(hipGetLastError());
-        hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px * (nf / 8) + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
+        hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
                            INP, G, N, H, W, vec("FSA.gamma"), T);
         INNFER_HIP(hipGetLastError());
     }

@@ -606,6 +606,8 @@ def test_pan_scales_vs_oracle(dev):
         err = np.abs(y - ref)
         assert y.shape == ref.shape
         assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (scale, err.max(), err.mean())
+        net._ws.fill_(0xFF)                                             # every byte read was written by this forward: NaN-poisoned workspace
+        assert torch.equal(net(x.to(dev)).float().cpu(), torch.from_numpy(y))
     with pytest.raises(ValueError):
         net(torch.zeros(1, 1, 3, 8, device=dev))                        # MaxPool2d(4) needs >= 4x4
 
