@@ -786,3 +786,28 @@ def test_4k_input_untiled_addresses_beyond_2gib(dev):
     del y, yc
     net.release_workspace()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind,scale,shape", [("p2p_256", 1, (2, 3, 256, 256)), ("resnet_9blocks", 1, (2, 3, 32, 48)), ("wbcunet", 1, (1, 3, 40, 56)),
+                                              ("wbcunet_tf", 1, (1, 3, 40, 56)), ("ppon", 4, (2, 3, 24, 20)), ("pan", 4, (2, 3, 21, 37)),
+                                              ("srgan", 4, (1, 3, 19, 33))])
+def test_every_family_ignores_workspace_contents(dev, kind, scale, shape):
+    """Every byte a forward reads from its workspace was written by an earlier launch of the SAME forward: filling the
+    workspace with NaN patterns between two forwards must not change a single output bit (pad channels, halo rows, split-K
+    partials, statistics scratch ...)."""
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config(kind, scale))
+    net.load_state_dict(_sd({k: tuple(v.shape) for k, v in net.state_dict().items()}, 5), strict=True)
+    net = net.to(dev)
+    if kind.startswith("p2p"):
+        net.train()
+    else:
+        net.eval()
+    x = torch.from_numpy(synth.uniform(shape, 6, -1.0, 1.0)).to(dev).half()
+    out = lambda r: r[-1] if isinstance(r, (tuple, list)) else r
+    y = out(net(x)).clone()
+    assert torch.isfinite(y).all()
+    net._ws.fill_(0xFF)
+    assert torch.equal(out(net(x)), y)
