@@ -247,7 +247,7 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     const int segs = (nsteps + g.seg - 1) / g.seg;
     int ks = 1;
     if (scratch && nsteps >= 32 && (long)Ho * Wo <= split_max_px() && (size_t)segs * full <= scratch_bytes) ks = segs;
-    if (ngroup > 1) ks = 1;
+    if (ngroup > 1 && !g_phase) ks = 1;        // phase groups may be split over K: every segment buffer then holds the whole full-resolution grid
     g.ksplit = ks;
     g.cout_store = cout_store > 0 ? cout_store : (g.raw_stride < cout_pad ? g.raw_stride : cout_pad);
     g.ngroup = ngroup; g.g_wbytes = g_wbytes; g.g_outoff = g_outoff; g.g_tapmul = g_tapmul; g.g_phase = g_phase;
@@ -263,9 +263,11 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     }
     INNFER_HIP(hipGetLastError());
     if (ks > 1) {
-        const long nthr = M * (g.raw_stride / 4);
+        // (phase groups: the four launches' worth of partials interleave into the full grid, reduced in one pass)
+        const int rh = g_phase ? Hfull : Ho, rw = g_phase ? Wfull : Wo;
+        const long nthr = (long)N * rh * rw * (g.raw_stride / 4);
         hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)scratch, g.split_elems, ks,
-                           raw, g.raw_stride, N, Ho, Wo, Hfull, Wfull, os, ooy, oox);
+                           raw, g.raw_stride, N, rh, rw, Hfull, Wfull, g_phase ? 1 : os, g_phase ? 0 : ooy, g_phase ? 0 : oox);
         INNFER_HIP(hipGetLastError());
     }
     return INNFER_OK;

@@ -482,20 +482,13 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         }
         // the outermost layer has out_nc (3) channels: its raw rows are 4..8 floats, not a 64-channel tile
         const int rs = k == 0 ? (l.cout + 3) / 4 * 4 : 0;
-        const bool split = 4 * (l.cin_pad / 32) >= 32 && (long)h * w <= gg::split_max_px();       // gg::launch's split-K rule (batch independent)
-        if (!split) {       // the four output phases as ONE grouped launch: 4x the workgroups, wide tiles where the layer is big enough
+        {   // the four output phases as ONE grouped launch (4x the workgroups, wide tiles where the layer is big enough); deep layers are
+            // also split over K inside that launch and reduced over the full-resolution grid in one pass
             int dy[16], dx[16];
             for (int ph = 0; ph < 4; ++ph) { int ky[4], kx[4]; phase_taps(ph >> 1, ph & 1, ky, kx, dy + 4 * ph, dx + 4 * ph); }
             int rc = gg::launch(l.d_w[0], l.cin_pad, l.cout_pad, in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, 0, 0, 0, s,
-                                nullptr, 0, rs, 0, 4, l.phase_elems * (long)sizeof(f16), 0, 0, 0, 1);
+                                splitk, splitk_bytes(N), rs, 0, 4, l.phase_elems * (long)sizeof(f16), 0, 0, 0, 1);
             if (rc) return rc;
-        } else {
-            for (int ph = 0; ph < 4; ++ph) {
-                int ky[4], kx[4], dy[4], dx[4];
-                phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
-                int rc = run_gemm(l, l.d_w[ph], in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, ph >> 1, ph & 1, s, splitk, rs);
-                if (rc) return rc;
-            }
         }
         const long HW = (long)hf * wf;
         if (k > 0) {
