@@ -225,7 +225,9 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
                   float* raw, int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx,
                   int Hfull, int Wfull, int os, int ooy, int oox, int up, hipStream_t s,
                   float* scratch = nullptr, size_t scratch_bytes = 0, int raw_stride = 0, int reflect = 0,
-                  int ngroup = 1, long g_wbytes = 0, long g_outoff = 0, int g_tapmul = 0, int cout_store = 0, int g_phase = 0) {
+                  int ngroup = 1, long g_wbytes = 0, long g_outoff = 0, int g_tapmul = 0, int cout_store = 0, int g_phase = 0,
+                  int* ksplit_out = nullptr) {      // ksplit_out: the caller reduces the partial results itself (scratch, *ksplit_out segments of
+                                                     // N*Hfull*Wfull*raw_stride floats; 1 = not split, the result is in raw)
     GP g{};
     g.in = in; g.in_g = in_g; g.nchunks = cin_pad / 32; g.N = N; g.Hin = Hin; g.Win = Win;
     g.wpk = wpk; g.out = raw; g.cout_pad = cout_pad;
@@ -262,7 +264,8 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
         hipLaunchKernelGGL((gemm_gather<2, 1, 4>), grid, dim3(256), 0, s, g);
     }
     INNFER_HIP(hipGetLastError());
-    if (ks > 1) {
+    if (ksplit_out) *ksplit_out = ks;
+    if (ks > 1 && !ksplit_out) {
         // (phase groups: the four launches' worth of partials interleave into the full grid, reduced in one pass)
         const int rh = g_phase ? Hfull : Ho, rw = g_phase ? Wfull : Wo;
         const long nthr = (long)N * rh * rw * (g.raw_stride / 4);

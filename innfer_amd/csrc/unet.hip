@@ -67,6 +67,64 @@ __global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, con
     }
 }
 
+// Deep levels (at most DEEP_PX output pixels per image): split-K reduction + BatchNorm statistics + normalisation / activation in ONE
+// launch.  A workgroup owns 32 channels of one image: 32 channel lanes x 32 pixel lanes, every thread keeps its <= DEEP_PX/32 pixels in
+// registers; the partial results are added in segment order, the statistics are the two-pass form on registers (as norm_stats.h), the
+// result goes to up to two fp16 destinations like unet_post.  part: ks segments of split_elems floats (ks == 1: the GEMM result itself).
+constexpr int DEEP_PX = 64;
+__global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long split_elems, int ks, int cpad, int C, int HW, float eps,
+                                                       const float* gamma, const float* beta, PostDst d0, PostDst d1) {
+    __shared__ float red[1024];
+    const int n = blockIdx.y, cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    auto reduce32 = [&](float v) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[cl + 32 * i];
+        __syncthreads();
+        return t;
+    };
+    float v[DEEP_PX / 32];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEEP_PX / 32; ++i) {
+        const int px = pl + 32 * i;
+        float a = 0.f;
+        if (px < HW && c < C) {
+            const float* q = part + ((long)n * HW + px) * cpad + c;
+            a = q[0];
+            for (int z = 1; z < ks; ++z) a += q[z * split_elems];
+        }
+        v[i] = a;
+        sum += a;
+    }
+    float al = 1.f, sh = 0.f;
+    if (gamma) {                                     // train-mode BatchNorm of this image (uniform branch)
+        const float mu = reduce32(sum) / (float)HW;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < DEEP_PX / 32; ++i) { const float d = pl + 32 * i < HW ? v[i] - mu : 0.f; m2 += d * d; }
+        const float var = reduce32(m2) / (float)HW;
+        if (c < C) { al = (1.0f / sqrtf(var + eps)) * gamma[c]; sh = beta[c] - mu * al; }
+    }
+    if (c >= C) return;
+    const PostDst ds[2] = {d0, d1};
+#pragma unroll
+    for (int i = 0; i < DEEP_PX / 32; ++i) {
+        const int px = pl + 32 * i;
+        if (px >= HW) continue;
+        const float y = gamma ? v[i] * al + sh : v[i];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!ds[k].p) continue;
+            const int ch = ds[k].coff + c;
+            ds[k].p[(ch >> 5) * ds[k].g + ((long)n * HW + px) * 32 + (ch & 31)] = (f16)(ds[k].act == 1 ? fmaxf(y, 0.2f * y) : fmaxf(y, 0.f));
+        }
+    }
+}
+
 // outermost: raw[.., 0:C] + bias -> tanh -> NCHW
 __global__ void unet_final(const float* raw, int cpad, int C, long HW, int N, const float* bias, void* out, int out_f32) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,9 +427,9 @@ UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
 
 int run_gemm(const Layer& l, const f16* wpk, const f16* in, long in_g, int N, int Hin, int Win, float* raw,
              int Ho, int Wo, int stride, int ntaps, const int* dy, const int* dx, int Hfull, int Wfull,
-             int os, int ooy, int oox, hipStream_t s, float* scratch, int raw_stride = 0) {
+             int os, int ooy, int oox, hipStream_t s, float* scratch, int raw_stride = 0, int* ks_out = nullptr) {
     return gg::launch(wpk, l.cin_pad, l.cout_pad, in, in_g, N, Hin, Win, raw, Ho, Wo, stride, ntaps, dy, dx,
-                      Hfull, Wfull, os, ooy, oox, 0, s, scratch, splitk_bytes(N), raw_stride);
+                      Hfull, Wfull, os, ooy, oox, 0, s, scratch, splitk_bytes(N), raw_stride, 0, 1, 0, 0, 0, 0, 0, ks_out);
 }
 }  // namespace
 
@@ -412,7 +470,14 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     int dy16[16], dx16[16];
     for (int t = 0; t < 16; ++t) { dy16[t] = (t >> 2) - 1; dx16[t] = (t & 3) - 1; }
 
+    int ks_last = 1;                  // segments the last GEMM left in `splitk` (1: its result is in raw)
     auto post = [&](const Layer& l, long HW, bool bn, PostDst d0, PostDst d1) -> int {
+        if (HW <= DEEP_PX) {          // deep level: reduce + statistics + post in one launch
+            hipLaunchKernelGGL(unet_deep_post, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw,
+                               (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn ? l.d_gamma : nullptr, bn ? l.d_beta : nullptr, d0, d1);
+            INNFER_HIP(hipGetLastError());
+            return INNFER_OK;
+        }
         if (bn) {
             int rc = norm::launch_stats(raw, l.cout_pad, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
             if (rc) return rc;
@@ -446,7 +511,9 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             const int zero = 0;
             rc = run_gemm(l, l.d_w[0], cur, (long)N * ho * wo * 32, N, ho, wo, raw, ho, wo, 1, 1, &zero, &zero, ho, wo, 1, 0, 0, s, splitk);
         } else {
-            rc = run_gemm(l, l.d_w[0], cur, cur_g, N, h, w, raw, ho, wo, 2, 16, dy16, dx16, ho, wo, 1, 0, 0, s, splitk);
+            ks_last = 1;
+            rc = run_gemm(l, l.d_w[0], cur, cur_g, N, h, w, raw, ho, wo, 2, 16, dy16, dx16, ho, wo, 1, 0, 0, s, splitk, 0,
+                          (long)ho * wo <= DEEP_PX ? &ks_last : nullptr);
         }
         if (rc) return rc;
         const long HW = (long)ho * wo, G = (long)N * HW * 32;
@@ -486,8 +553,10 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             // also split over K inside that launch and reduced over the full-resolution grid in one pass
             int dy[16], dx[16];
             for (int ph = 0; ph < 4; ++ph) { int ky[4], kx[4]; phase_taps(ph >> 1, ph & 1, ky, kx, dy + 4 * ph, dx + 4 * ph); }
+            ks_last = 1;
             int rc = gg::launch(l.d_w[0], l.cin_pad, l.cout_pad, in, in_g, N, h, w, raw, h, w, 1, 4, dy, dx, hf, wf, 2, 0, 0, 0, s,
-                                splitk, splitk_bytes(N), rs, 0, 4, l.phase_elems * (long)sizeof(f16), 0, 0, 0, 1);
+                                splitk, splitk_bytes(N), rs, 0, 4, l.phase_elems * (long)sizeof(f16), 0, 0, 0, 1,
+                                (long)hf * wf <= DEEP_PX ? &ks_last : nullptr);
             if (rc) return rc;
         }
         const long HW = (long)hf * wf;
