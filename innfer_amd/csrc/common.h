@@ -46,6 +46,7 @@ struct ConvLaunch {
     int y0, y1;                                   // output rows [y0,y1)
     int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
     int rev;                                      // traverse the tiles in reverse order (speed only: see conv3x3.hip)
+    int conv7;                                    // 7x7 conv, padding 3 (zero or `reflect`), panels from conv_pack7x7: OUT_NCHW, K <= 16 only
     int reflect;                                  // ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel)
     int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)
 };
@@ -55,6 +56,8 @@ int conv_nt_for(int K);                           // 16-channel tiles per group:
 size_t conv_packed_bytes(int K, int C);
 void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
 int conv_launch(const ConvLaunch& L, hipStream_t s);
+size_t conv_packed_bytes7x7(int K, int C);
+void conv_pack7x7(const float* w_oihw, int K, int C, void* packed);   // host; C % 32 == 0
 
 // ---- first conv: few input channels, NCHW input (conv_first.hip) -------------
 struct FirstConvLaunch {

@@ -33,6 +33,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <vector>
 
 // Pins a value as a rounded fp32 number in a VGPR: the backend cannot fold the fp16 conversion that
 // follows into the fma that produced it (v_fma_mixlo_f16 rounds ONCE, fma + convert rounds twice).
@@ -87,6 +88,7 @@ struct KP {
     int N;
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
+    int ncg;                 // S9 kernels: real 32-channel groups of the input (nchunks = 9 * ncg virtual chunks)
     int reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d(1)) instead of zero; not with `up`
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
     int total;               // tiles x channel groups of this launch
@@ -509,7 +511,11 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 #define PCT(var) do { } while (0)
 #define PCACC(slot, t1, t0) do { } while (0)
 #endif
-template <int RPW, int NT, int NLW, int OUTMODE>
+// S9: a 7x7 convolution as nine 3x3 convolutions over displaced copies of the input -- virtual chunk c = (sub, group): the loader reads
+// channel group `group` displaced by (3*(sub/3 - 1), 3*(sub%3 - 1)) pixels and the weight panel of that chunk holds the 3x3 block
+// (sub/3, sub%3) of the 7x7 kernel zero-padded to 9x9; the consumers see 9x as many chunks of an ordinary 3x3 conv.  Each input pixel
+// is staged 9 times instead of 49 (gather GEMM).  Padding 3: zero, or mirrored (`reflect`).
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false>
 __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int NCW = 8;                       // consumer waves; NLW loader waves
     constexpr int TH = NCW * RPW;
@@ -558,6 +564,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         // ================================ loaders ================================
         const int lw = wave - NCW;
         int loff[KQ];
+        int s9_ty0 = 0, s9_tx0 = 0, s9_n = 0; bool s9_edge = false;          // S9: the current tile (edge tiles re-derive their offsets per chunk)
         {
             const int ypar = p.up ? ((p.y0 - 1) & 1) : 0;
 #pragma unroll
@@ -581,6 +588,11 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
             w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
 #pragma unroll
             for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
+            if constexpr (S9) {          // displaced reads reach 4 pixels beyond the tile: such tiles derive their offsets per chunk (issue)
+                s9_ty0 = ty0; s9_tx0 = tx0; s9_n = n;
+                s9_edge = ty0 < 4 || ty0 + TH + 4 > p.H || tx0 < 4 || tx0 + TW + 4 > p.W;
+                return;
+            }
             if (ty0 == 0 || ty0 + TH + 1 > p.H || tx0 == 0 || tx0 + TW + 1 > p.W) {
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
@@ -603,7 +615,31 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         auto issue = [&](int c, int stage) {
 #if defined(__HIP_DEVICE_COMPILE__)
             char* st = smem + stage * STAGE;
-            const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)(in_tile + c * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
+            const char* src = in_tile + c * p.in_gbytes;
+            if constexpr (S9) {
+                const int sub = c / p.ncg, cg = c - sub * p.ncg;
+                const int sy = 3 * (sub / 3 - 1), sx = 3 * (sub % 3 - 1);
+                if (!s9_edge) {
+                    src = in_tile + cg * p.in_gbytes + ((long)sy * p.Ws + sx) * 64;        // every displaced pixel is inside the image
+#pragma unroll
+                    for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
+                } else {                                                                  // offsets from the image origin, per lane
+                    src = (const char*)(p.in + (long)s9_n * p.in_img_stride) + cg * p.in_gbytes;
+#pragma unroll
+                    for (int k = 0; k < KQ; ++k) {
+                        const int px = (lw + NLW * k) * 16 + (lane >> 2);
+                        const int ly = px / LWP, lx = px - ly * LWP;
+                        int Y = s9_ty0 - 1 + ly + sy, X = s9_tx0 - 1 + lx + sx;
+                        if (p.reflect) {                                                  // ReflectionPad2d(3)
+                            Y = Y < 0 ? -Y : (Y >= p.H ? 2 * p.H - 2 - Y : Y);
+                            X = X < 0 ? -X : (X >= p.W ? 2 * p.W - 2 - X : X);
+                        }
+                        const bool ok = loff[k] != OOB && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+                        voff[k] = ok ? (Y * p.Ws + X) * 64 + (loff[k] - (ly * p.Ws + lx) * 64) : OOB;
+                    }
+                }
+            }
+            const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(w_tile + (long)c * W_BYTES), 0, W_BYTES, 0x00020000);
 #pragma unroll
             for (int k = 0; k < KQ; ++k) {
@@ -618,7 +654,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + IN_BYTES + jq * 1024), 16, wvoff, jq * 1024, 0, 0);
             }
 #else
-            (void)c; (void)stage; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile;
+            (void)c; (void)stage; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile; (void)s9_ty0; (void)s9_tx0; (void)s9_n; (void)s9_edge;
 #endif
         };
         int jt = j0, c = 0;
@@ -762,7 +798,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB>
+template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 // Per-device state (a process may drive several GPUs): CU count, and which devices already carry a kernel's
@@ -822,13 +858,13 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     return INNFER_OK;
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE>
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
     constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
     static unsigned long long attr_done = 0;
-    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE>, LDS, attr_done)) return rc;
+    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
@@ -837,7 +873,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -901,6 +937,22 @@ void conv_pack(const float* w, int K, int C, void* packed) {
                 }
 }
 
+// 7x7 weights [K][C][7][7] -> panels of the equivalent conv over 9*C virtual channels (conv3x3_pc<.., S9>): virtual channel sub*C + ci,
+// tap (r, s) holds w[k][ci][3*(sub/3) + r - 1][3*(sub%3) + s - 1] (zero outside the 7x7 kernel: the 9x9 padding ring)
+size_t conv_packed_bytes7x7(int K, int C) { return conv_packed_bytes(K, 9 * C); }
+void conv_pack7x7(const float* w, int K, int C, void* packed) {
+    std::vector<float> v((size_t)K * 9 * C * 9, 0.f);
+    for (int k = 0; k < K; ++k)
+        for (int sub = 0; sub < 9; ++sub)
+            for (int ci = 0; ci < C; ++ci)
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = 3 * (sub / 3) + t / 3 - 1, kx = 3 * (sub % 3) + t % 3 - 1;
+                    if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7)
+                        v[((size_t)k * 9 * C + sub * C + ci) * 9 + t] = w[(((size_t)k * C + ci) * 7 + ky) * 7 + kx];
+                }
+    conv_pack(v.data(), K, 9 * C, packed);
+}
+
 int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (L.C <= 0 || L.C % 32) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: C=%d must be a multiple of 32", L.C);
     if (L.up && ((L.H | L.W) & 1)) return set_error(INNFER_ERR_INVALID, "conv3x3: upsampled size must be even");
@@ -909,6 +961,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.H = L.H; k.W = L.W; k.Hs = L.H >> k.up; k.Ws = L.W >> k.up;
     k.in = L.in; k.in_gbytes = L.in_gstride * 2; k.in_img_stride = (long)k.Hs * k.Ws * 32;
     k.nchunks = L.C / 32;
+    k.ncg = L.C / 32;
     k.wpk = L.wpk; k.bias = L.bias;
     k.out = L.out; k.out_gstride = L.out_gstride; k.out_coff = L.out_coff;
     k.K = L.K; k.KG = conv_groups(L.K);
@@ -926,7 +979,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.rev = L.rev ? 1 : 0;
     k.phase_c = L.out_mode == OUT_NCHW ? L.phase_c : 0;
     k.reflect = L.reflect ? 1 : 0;
-    if (L.reflect && (L.up || L.H < 2 || L.W < 2)) return set_error(INNFER_ERR_INVALID, "conv3x3: reflection padding needs >= 2x2 pixels and no upsampled input");
+    if (L.reflect && (L.up || L.H < (L.conv7 ? 4 : 2) || L.W < (L.conv7 ? 4 : 2))) return set_error(INNFER_ERR_INVALID, "conv3x3: reflection padding needs >= 2x2 pixels and no upsampled input");
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
@@ -935,6 +988,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 1;     // producer / consumer kernel for slab outputs
     if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
+    if (L.conv7) {         // 7x7 (padding 3) as nine displaced 3x3 convs: planar output, <= 16 output channels, panels from conv_pack7x7
+        if (!pc || L.out_mode != OUT_NCHW || nt != 1 || L.res1 || L.res2 || L.up || (long)L.H * L.W * 64 >= 0x7fffffffL)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv7x7: planar output with K <= 16, no residual / upsampling, images below 33 M pixels");
+        k.nchunks = 9 * k.ncg;
+        return launch_pc<3, 1, 4, OUT_NCHW, true>(k, L.N, s);
+    }
     if (pc && L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2) return launch_pc<3, 1, 4, OUT_NCHW>(k, L.N, s);
     if (L.act >= 3 || L.phase_c > 0 || L.reflect)
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tanh / phase output / gate epilogues / reflection padding exist only in the producer-consumer kernel");

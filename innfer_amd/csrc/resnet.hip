@@ -6,7 +6,8 @@
 //                                                                     fp16 slab out, statistics / normalisation on that slab
 //   ReflectionPad2d(3) + 7x7 conv                                     gg::gemm_gather, out-of-image taps read the mirrored pixel
 //                                                                     (GP.reflect); the first one (3 input channels) reads a
-//                                                                     row-patch slab: 7 vertical taps (rn_pre), the last one 49 taps
+//                                                                     row-patch slab: 7 vertical taps (rn_pre); the last one (64 -> 3,
+//                                                                     tanh) is nine displaced 3x3 convs on the halo-tile kernel
 //   3x3 stride-2 zero-pad-1 convs                                     gg::gemm_gather (stride 2)
 //   ConvTranspose2d(3, stride 2, padding 1, output_padding 1)         four output phases (1, 2, 2, 4 taps) of the same GEMM
 //   InstanceNorm2d (no affine, statistics of the instance also under eval)   norm_stats.h: per-(image, channel) mean / biased variance in
@@ -261,6 +262,17 @@ int rn_upload(innfer_resnet* r) {
         }
         INNFER_HIP(hipMalloc((void**)&l.d_b, l.cout * sizeof(float)));
         INNFER_HIP(hipMemcpy(l.d_b, r->params[l.b].host.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+        if (!l.transposed && k == 7 && l.cin % 32 == 0 && l.cout <= 16) {          // c7s1-out: nine displaced 3x3 convs, ReflectionPad2d(3)
+            std::vector<char> packed(conv_packed_bytes7x7(l.cout, l.cin));
+            conv_pack7x7(w.data(), l.cout, l.cin, packed.data());
+            INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+            std::vector<float> b3(64, 0.f);
+            for (int c = 0; c < l.cout; ++c) b3[c] = r->params[l.b].host[c];
+            (void)hipFree(l.d_b); l.d_b = nullptr;
+            INNFER_HIP(hipMalloc((void**)&l.d_b, b3.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(l.d_b, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (!l.transposed && k == 3 && l.cin == l.cout && l.cin % 64 == 0) {       // ResnetBlock convs (stride 1, reflection pad 1)
             std::vector<char> packed(conv_packed_bytes(l.cout, l.cin));
             conv_pack(w.data(), l.cout, l.cin, packed.data());
@@ -392,6 +404,16 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     CK(deconv(r->layers[li], U1, H2, W2)); CK(norm_post(r->layers[li], H, W, 1, nullptr, U2)); ++li;                  // u64
     {   // c7s1-out + tanh
         const Layer& l = r->layers[li];
+        if (l.d_w3) {       // tanh(conv7x7(reflect3(x)) + bias) -> NCHW in the conv's planar epilogue
+            ConvLaunch L{};
+            L.in = U2; L.in_gstride = (long)N * H * W * 32; L.C = l.cin;
+            L.wpk = (const f16*)l.d_w3; L.bias = l.d_b;
+            L.out = d_out; L.K = l.cout; L.N = N; L.H = H; L.W = W; L.act = 3;
+            L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = H;
+            L.out_mode = OUT_NCHW; L.out_f32 = out_dtype == INNFER_F32; L.conv7 = 1; L.reflect = 1;
+            CK(conv_launch(L, s));
+            return INNFER_OK;
+        }
         const int rs = (l.cout + 3) / 4 * 4;
         CK(gg::launch(l.d_w[0], 64, 64, U2, (long)N * H * W * 32, N, H, W, raw, H, W, 1, 49, dy49, dx49, H, W, 1, 0, 0, 0, s, nullptr, 0, rs, 1));
         hipLaunchKernelGGL(rn_final, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, (const float*)raw, rs, l.cout, (long)H * W, N,

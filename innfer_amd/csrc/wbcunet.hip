@@ -4,7 +4,8 @@
 //
 //   stride-1 3x3 convs, zero padding                      the SR path's halo-tile kernel (conv3x3.hip), epilogue bias / LeakyReLU / skip
 //   first 7x7 conv (3 input channels)                      gg::gemm_gather over a row-patch slab (wb_pre): 7 vertical taps
-//   stride-2 3x3 convs, last 7x7 conv                      gg::gemm_gather (9 / 49 taps, zero fill) + wb_post (bias, LeakyReLU, NCHW)
+//   last 7x7 conv (32 -> 3)                                nine displaced 3x3 convs on the halo-tile kernel (conv3x3_pc<..,S9>), planar output
+//   stride-2 3x3 convs                                     gg::gemm_gather (9 taps, zero fill) + wb_post (bias, LeakyReLU)
 //   bilinear 2x (align_corners=False) + skip addition      wb_upadd (ATen's source index / lambda arithmetic)
 //   guided filter, 3x3 box means, reflect padding          gf_ab (means, covariance, A, b) + gf_out (mean_A * x + mean_b)
 #include "common.h"
@@ -249,6 +250,16 @@ int wb_upload(innfer_wbc* u) {
         INNFER_HIP(hipMemcpy(l.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
         INNFER_HIP(hipMalloc((void**)&l.d_b, l.cout * sizeof(float)));
         INNFER_HIP(hipMemcpy(l.d_b, u->params[l.b].host.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+        if (l.k == 7 && l.cin % 32 == 0 && l.cout <= 16) {          // last conv (32 -> 3): nine displaced 3x3 convs on the halo-tile kernel
+            std::vector<char> packed(conv_packed_bytes7x7(l.cout, l.cin));
+            conv_pack7x7(w.data(), l.cout, l.cin, packed.data());
+            std::vector<float> b3(64, 0.f);
+            for (int c = 0; c < l.cout; ++c) b3[c] = u->params[l.b].host[c];
+            INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+            INNFER_HIP(hipMalloc((void**)&l.d_b3, b3.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(l.d_b3, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (l.k == 3 && l.cin % 32 == 0 && l.cout % 32 == 0) {       // halo-tile form for the stride-1 launches
             std::vector<char> packed(conv_packed_bytes(l.cout, l.cin));
             conv_pack(w.data(), l.cout, l.cin, packed.data());
@@ -311,7 +322,16 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
     auto layer = [&](const f16* in, int Hi, int Wi, int stride, int act, const f16* res, f16* dst, void* nchw) -> int {
         const Layer& l = u->layers[li++];
         const int Ho = Hi / stride, Wo = Wi / stride;
-        if (l.d_w3 && stride == 1 && !nchw) {     // zero-padded stride-1 3x3 conv: the SR path's halo-tile kernel, epilogue = bias / LeakyReLU / + residual
+        if (l.d_w3 && l.k == 7 && stride == 1 && nchw) {     // 7x7, zero padding 3, planar output
+            ConvLaunch L{};
+            L.in = in; L.in_gstride = (long)N * Hi * Wi * 32; L.C = l.cin;
+            L.wpk = (const f16*)l.d_w3; L.bias = l.d_b3;
+            L.out = nchw; L.K = l.cout; L.N = N; L.H = Ho; L.W = Wo; L.act = act ? 1 : 0;
+            L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Ho;
+            L.out_mode = OUT_NCHW; L.out_f32 = out_dtype == INNFER_F32; L.conv7 = 1;
+            return conv_launch(L, s);
+        }
+        if (l.d_w3 && l.k == 3 && stride == 1 && !nchw) {     // zero-padded stride-1 3x3 conv: the SR path's halo-tile kernel, epilogue = bias / LeakyReLU / + residual
             ConvLaunch L{};
             L.in = in; L.in_gstride = (long)N * Hi * Wi * 32; L.C = l.cin;
             L.wpk = (const f16*)l.d_w3; L.bias = l.d_b3;

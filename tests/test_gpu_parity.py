@@ -811,3 +811,24 @@ def test_every_family_ignores_workspace_contents(dev, kind, scale, shape):
     assert torch.isfinite(y).all()
     net._ws.fill_(0xFF)
     assert torch.equal(out(net(x)), y)
+
+
+@pytest.mark.parametrize("kind", ["wbcunet", "resnet_9blocks"])
+def test_7x7_last_conv_interior_and_edge_tiles_vs_oracle(dev, kind):
+    """The last 7x7 conv of the WBC UNet (zero padding) and of the CycleGAN generator (ReflectionPad2d(3), tanh) runs as nine displaced
+    3x3 convs; tiles at least 4 pixels away from every border take the tile-relative path, the others derive per-lane offsets from
+    the image origin.  132x172 has both kinds (24x32 tiles) and ragged last tiles; compared with the oracle."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config(kind, 1))
+    sd = _sd({k: tuple(v.shape) for k, v in net.state_dict().items()}, 9)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 132, 172), 10, -1.0, 1.0))
+    y = net(x.to(dev).half()).float().cpu()
+    with torch.no_grad():
+        ref = oracle.wbcunet_forward(sd, x) if kind == "wbcunet" else oracle.resnet_forward(sd, x, n_blocks=9)
+    err = (y - ref).abs()
+    assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (kind, err.max().item(), err.mean().item())
