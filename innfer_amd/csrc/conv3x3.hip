@@ -5,7 +5,8 @@
 // (architectures/block.py:213-254,333-361; RRDBNet_arch.py:152-165,91-98).  The other generators reuse it for every
 // conv it can express -- PAN (all convs; a 1x1 conv is a panel with a centre tap only; pixel-attention gate epilogue
 // res1 * sigmoid(conv)), PPON, the WBC UNet, and the pix2pix UNet's outermost ConvTranspose (the four output phases as
-// 4*out_nc channels of one 3x3 conv, tanh + phase scatter in the planar epilogue).
+// 4*out_nc channels of one 3x3 conv, tanh + phase scatter in the planar epilogue), the CycleGAN residual blocks (reflection padding in
+// the loader) and the 7x7 convs with few outputs of the WBC UNet / CycleGAN (conv3x3_pc<..,S9>: nine displaced 3x3 convs).
 //
 // Data layout in HBM: activations are fp16 "blocked NHWC" channel slabs: channels in groups of
 // 32, element (n,y,x,c) at base + (c/32)*group_stride + ((n*H+y)*W+x)*32 + c%32, so a 32-channel
