@@ -342,6 +342,19 @@ static int upload_all(innfer_unet* u) {
                             [&](int co, int j, int) { const int t = j / l.cin, ci = j - t * l.cin;
                                                       return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
                 int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
+                if (l.cout % 64 == 0) {        // ... and as a centre-tap 3x3 panel for the halo-tile kernel, whose epilogue writes the fp16 slabs directly
+                    std::vector<float> w3((size_t)l.cout * 64 * 9, 0.f), b3((size_t)l.cout, 0.f);
+                    for (int co = 0; co < l.cout; ++co)
+                        for (int j = 0; j < 16 * l.cin; ++j) {
+                            const int t = j / l.cin, ci = j - t * l.cin;
+                            w3[((size_t)co * 64 + j) * 9 + 4] = w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)];
+                        }
+                    std::vector<char> packed(conv_packed_bytes(l.cout, 64));
+                    conv_pack(w3.data(), l.cout, 64, packed.data());
+                    if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+                    INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+                    rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
+                }
             } else if (l.phases) {
                 // The four output phases of ConvTranspose2d(k4, s2, p1) as ONE 3x3 convolution with 4*cout output channels over the
                 // un-upsampled input (conv3x3.hip's halo-tile kernel reads each input pixel once instead of once per tap): output channel
@@ -507,6 +520,24 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const Layer& l = u->down[k];
         const int ho = h / 2, wo = w / 2;
         int rc;
+        if (l.patch && l.d_w3 && k < L - 1) {
+            // no BatchNorm behind the outermost conv: the two views of its output (lrelu for the next conv, relu for the concatenation) come
+            // straight out of the conv epilogue, one launch each (HBM-bound launches; the GEMM + post pair makes three passes)
+            const long HWo = (long)ho * wo, Go = (long)N * HWo * 32;
+            f16* dsts[2] = {(f16*)(ws + cv.D[k]), (f16*)(ws + cv.CAT[k])};
+            for (int v = 0; v < 2; ++v) {
+                ConvLaunch Lc{};
+                Lc.in = cur; Lc.in_gstride = Go; Lc.C = 64;
+                Lc.wpk = (const f16*)l.d_w3; Lc.bias = l.d_b3;
+                Lc.out = dsts[v]; Lc.out_gstride = Go; Lc.K = l.cout; Lc.N = N; Lc.H = ho; Lc.W = wo; Lc.act = v == 0 ? 1 : 2;
+                Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = ho; Lc.out_mode = OUT_SLAB;
+                rc = conv_launch(Lc, s);
+                if (rc) return rc;
+            }
+            cur = dsts[0]; cur_g = Go;
+            h = ho; w = wo;
+            continue;
+        }
         if (l.patch) {
             const int zero = 0;
             rc = run_gemm(l, l.d_w[0], cur, (long)N * ho * wo * 32, N, ho, wo, raw, ho, wo, 1, 1, &zero, &zero, ho, wo, 1, 0, 0, s, splitk);
