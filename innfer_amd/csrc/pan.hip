@@ -469,7 +469,7 @@ PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     c.slab_end = off;
     c.fgh = off; off += al((np ? np : 1) * 64 * 4);
     c.att = off; off += al((np ? np : 1) * p->nf * 4);
-    c.raw = off; off += al(px * m * 64 * 4);
+    c.raw = off; off += al(px * m * (size_t)p->out_nc * 4);          // planar fp32 output of conv_last (every other conv writes fp16 slabs)
     c.total = off;
     return c;
 }
