@@ -89,7 +89,6 @@ struct KP {
     int N;
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
-    int os, oa, ob;          // OUT_SLAB: output pixel of conv pixel (y, x) is (y*os + oa, x*os + ob) in an (H*os) x (W*os) slab (transposed-conv phases)
     int ncg;                 // S9 kernels: real 32-channel groups of the input (nchunks = 9 * ncg virtual chunks)
     int reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d(1)) instead of zero; not with `up`
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
@@ -112,10 +111,7 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
     const int yw = ty0 + wave * RPW, xl = tx0 + li;
     const long pix0 = ((long)n * p.H + yw) * p.W + xl;
     const long rowstep = (long)p.W * 32;
-    // output side: the same pixel grid, or every os-th pixel of an os times larger one (one phase of a stride-os transposed conv)
-    const long opix0 = ((long)n * p.H * p.os + (long)yw * p.os + p.oa) * ((long)p.W * p.os) + (long)xl * p.os + p.ob;
-    const long orowstep = rowstep * p.os * p.os, ocolstep = 16L * 32 * p.os;
-    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + opix0 * 32 + (oc0 & 31);
+    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix0 * 32 + (oc0 & 31);
     const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + pix0 * 32 + (cbase & 31) : nullptr;
     const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + pix0 * 32 + (cbase & 31) : nullptr;
     bool ok[MT];
@@ -139,7 +135,7 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
 #ifdef INNFER_ABLATE
         if (p.abl & 1) continue;
 #endif
-        f16* op = ob + (m >> 1) * orowstep + (m & 1) * ocolstep;
+        f16* op = ob + (m >> 1) * rowstep + (m & 1) * 16 * 32;
         if (!HOIST) {
             const long o = (m >> 1) * rowstep + (m & 1) * 16 * 32;
 #pragma unroll
@@ -520,8 +516,7 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 // channel group `group` displaced by (3*(sub/3 - 1), 3*(sub%3 - 1)) pixels and the weight panel of that chunk holds the 3x3 block
 // (sub/3, sub%3) of the 7x7 kernel zero-padded to 9x9; the consumers see 9x as many chunks of an ordinary 3x3 conv.  Each input pixel
 // is staged 9 times instead of 49 (gather GEMM).  Padding 3: zero, or mirrored (`reflect`).
-// TM: tap mask (bit r*3 + s): the consumers skip the masked taps entirely -- the phases of a stride-2 transposed conv are 2x2-tap convs.
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, int TM = 0x1FF>
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false>
 __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int NCW = 8;                       // consumer waves; NLW loader waves
     constexpr int TH = NCW * RPW;
@@ -725,26 +720,21 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         PCT(c0);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            if (!((TM >> s) & 0x49)) continue;                     // no tap in this column (loop constants: folded at compile time)
             f16x8 a[3][NT];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if ((TM >> (r * 3 + s)) & 1) a[r][t] = *(const f16x8*)(st + aoffs + ((r * 3 + s) * WROWS + t * 16) * 64);
+                    a[r][t] = *(const f16x8*)(st + aoffs + ((r * 3 + s) * WROWS + t * 16) * 64);
 #pragma unroll
             for (int rr = 0; rr < RPW + 2; ++rr) {
-                bool need = false;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) need = need || (((TM >> (r * 3 + s)) & 1) && rr - r >= 0 && rr - r < RPW);
-                if (!need) continue;
 #pragma unroll
                 for (int seg = 0; seg < 2; ++seg) {
                     const f16x8 b = *(const f16x8*)(st + boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         const int rw = rr - r;
-                        if (((TM >> (r * 3 + s)) & 1) && rw >= 0 && rw < RPW) {
+                        if (rw >= 0 && rw < RPW) {
 #pragma unroll
                             for (int t = 0; t < NT; ++t)
                                 acc[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
@@ -809,7 +799,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, int TM = 0x1FF>
+template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 // Per-device state (a process may drive several GPUs): CU count, and which devices already carry a kernel's
@@ -869,13 +859,13 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     return INNFER_OK;
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9, int TM>
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
     constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
     static unsigned long long attr_done = 0;
-    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, TM>, LDS, attr_done)) return rc;
+    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
@@ -884,7 +874,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, TM>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -973,9 +963,6 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.in = L.in; k.in_gbytes = L.in_gstride * 2; k.in_img_stride = (long)k.Hs * k.Ws * 32;
     k.nchunks = L.C / 32;
     k.ncg = L.C / 32;
-    k.os = L.out_stride > 1 ? L.out_stride : 1; k.oa = L.out_oy; k.ob = L.out_ox;
-    if (k.os > 1 && (L.out_mode != OUT_SLAB || L.res1 || L.res2 || k.oa < 0 || k.oa >= k.os || k.ob < 0 || k.ob >= k.os))
-        return set_error(INNFER_ERR_INVALID, "conv3x3: strided output placement is a plain slab epilogue (no residuals)");
     k.wpk = L.wpk; k.bias = L.bias;
     k.out = L.out; k.out_gstride = L.out_gstride; k.out_coff = L.out_coff;
     k.K = L.K; k.KG = conv_groups(L.K);
@@ -1001,17 +988,6 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
     static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 1;     // producer / consumer kernel for slab outputs
     if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
-    if (L.tapmask && L.tapmask != 0x1FF) {       // 2x2-tap phases of a stride-2 transposed conv (masks of rows {a, a+1} x columns {b, b+1})
-        if (!pc || L.out_mode != OUT_SLAB || nt != 4)
-            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tap masks exist for 64-channel slab tiles of the producer-consumer kernel");
-        switch (L.tapmask) {
-            case 0x01B: return launch_pc<2, 4, 4, OUT_SLAB, false, 0x01B>(k, L.N, s);
-            case 0x036: return launch_pc<2, 4, 4, OUT_SLAB, false, 0x036>(k, L.N, s);
-            case 0x0D8: return launch_pc<2, 4, 4, OUT_SLAB, false, 0x0D8>(k, L.N, s);
-            case 0x1B0: return launch_pc<2, 4, 4, OUT_SLAB, false, 0x1B0>(k, L.N, s);
-            default: return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tap mask 0x%x", L.tapmask);
-        }
-    }
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
     if (L.conv7) {         // 7x7 (padding 3) as nine displaced 3x3 convs: planar output, <= 16 output channels, panels from conv_pack7x7
         if (!pc || L.out_mode != OUT_NCHW || nt != 1 || L.res1 || L.res2 || L.up || (long)L.H * L.W * 64 >= 0x7fffffffL)
