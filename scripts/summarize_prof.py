@@ -54,10 +54,11 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            m = re.search(r"(conv3x3_mfma|conv3x3_pc)<([0-9, ]+)>", r["Kernel_Name"])
+            # conv3x3_pc<RPW, NT, NLW, OUT[, S9]>: the key keeps the numeric shape (bench.py's kernel names); the 7x7 variant gets a suffix
+            m = re.search(r"(conv3x3_mfma|conv3x3_pc)<([0-9, ]+?)(?:, (false|true))?>", r["Kernel_Name"])
             if not m:
                 continue
-            key = m.group(1) + "<" + m.group(2).replace(" ", "") + ">"
+            key = m.group(1) + "<" + m.group(2).replace(" ", "") + ">" + ("+s9" if m.group(3) == "true" else "")
             t = traffic.setdefault(key, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
             t[counter][0] += float(r["Counter_Value"]); t[counter][1] += 1
 out = {}
