@@ -221,6 +221,8 @@ typedef struct {
     int row_begin, row_end;             /* rows of the output to compute; 0,0 = all */
     int reflect_pad;                    /* != 0: nn.ReflectionPad2d(1) in front of the conv instead of zero padding (CycleGAN ResnetBlock,
                                            ResNet_arch.py:103-140); not together with upsample2x */
+    int dilation;                       /* > 1: dilated 3x3 conv with zero padding = dilation (PPON's _ResBlock_32, PPON_arch.py:83-91); K == 32,
+                                           no residuals / upsampling / row range */
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);

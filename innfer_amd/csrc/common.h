@@ -46,6 +46,7 @@ struct ConvLaunch {
     int y0, y1;                                   // output rows [y0,y1)
     int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
     int rev;                                      // traverse the tiles in reverse order (speed only: see conv3x3.hip)
+    int dilation;                                 // > 1: dilated 3x3 conv, zero padding = dilation (PPON); 32-output slab convs only
     int conv7;                                    // 7x7 conv, padding 3 (zero or `reflect`), panels from conv_pack7x7: OUT_NCHW, K <= 16 only
     int reflect;                                  // ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel)
     int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)

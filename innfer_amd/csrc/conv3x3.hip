@@ -89,6 +89,7 @@ struct KP {
     int N;
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
+    int dil, fullH, fullW;   // POLY kernels: dilation d; H, W, N are those of the d*d polyphase sub-images (ceil(fullH/d) x ceil(fullW/d), N*d*d of them)
     int ncg;                 // S9 kernels: real 32-channel groups of the input (nchunks = 9 * ncg virtual chunks)
     int reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d(1)) instead of zero; not with `up`
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
@@ -103,14 +104,27 @@ struct KP {
 // overlap), then act -> *s1 + res1 -> *s2 + res2 -> fp16 -> one 8*NT-byte store per pixel tile.
 // (The generic runtime-flag version of this loop took ~15 k cycles per workgroup, a third of the
 // lifetime of a 64->32 workgroup: profiles/r1/wg_timeline_r1c.txt.)
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST>
+// POLY: (n, y, x) address a polyphase sub-image of a dilation-d conv: image n / d^2, phase (py, px) = (n % d^2) / d, % d, full-resolution
+// pixel (y*d + py, x*d + px); the sub-image ends where the full image does.  No residuals in that mode.
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase) {
     constexpr int MT = 2 * RPW;
     const int oc0 = cbase + p.out_coff;
     const int yw = ty0 + wave * RPW, xl = tx0 + li;
-    const long pix0 = ((long)n * p.H + yw) * p.W + xl;
-    const long rowstep = (long)p.W * 32;
+    long pix0 = ((long)n * p.H + yw) * p.W + xl;
+    long rowstep = (long)p.W * 32;
+    long colstep = 16 * 32;
+    int ylim = p.y1, xlim = p.W;
+    if constexpr (POLY) {
+        const int d = p.dil, dd = d * d;
+        const int nn = n / dd, ph = n - nn * dd, py = ph / d, px = ph - py * d;
+        pix0 = ((long)nn * p.fullH + (long)yw * d + py) * p.fullW + (long)xl * d + px;
+        rowstep = (long)p.fullW * 32 * d;
+        colstep = 16L * 32 * d;
+        ylim = (p.fullH - py + d - 1) / d;
+        xlim = (p.fullW - px + d - 1) / d;
+    }
     f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix0 * 32 + (oc0 & 31);
     const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + pix0 * 32 + (cbase & 31) : nullptr;
     const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + pix0 * 32 + (cbase & 31) : nullptr;
@@ -118,8 +132,8 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
     f16x4 r1[R1 ? MT : 1][NT], r2[R2 ? MT : 1][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        ok[m] = (yw + (m >> 1) < p.y1) && (xl + (m & 1) * 16 < p.W);
-        const long o = (m >> 1) * rowstep + (m & 1) * 16 * 32;
+        ok[m] = (yw + (m >> 1) < ylim) && (xl + (m & 1) * 16 < xlim);
+        const long o = (m >> 1) * rowstep + (m & 1) * colstep;
         if (HOIST && R1 && ok[m]) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + 4 * t);
@@ -135,9 +149,9 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
 #ifdef INNFER_ABLATE
         if (p.abl & 1) continue;
 #endif
-        f16* op = ob + (m >> 1) * rowstep + (m & 1) * 16 * 32;
+        f16* op = ob + (m >> 1) * rowstep + (m & 1) * colstep;
         if (!HOIST) {
-            const long o = (m >> 1) * rowstep + (m & 1) * 16 * 32;
+            const long o = (m >> 1) * rowstep + (m & 1) * colstep;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (R1) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + 4 * t);
@@ -516,7 +530,9 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 // channel group `group` displaced by (3*(sub/3 - 1), 3*(sub%3 - 1)) pixels and the weight panel of that chunk holds the 3x3 block
 // (sub/3, sub%3) of the 7x7 kernel zero-padded to 9x9; the consumers see 9x as many chunks of an ordinary 3x3 conv.  Each input pixel
 // is staged 9 times instead of 49 (gather GEMM).  Padding 3: zero, or mirrored (`reflect`).
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false>
+// POLY: a dilation-d 3x3 conv (zero padding d) as ordinary 3x3 convs on the d*d polyphase components of the image ("space to batch"
+// folded into the addressing): the loader's pixel steps and the epilogue's store steps are d pixels, everything else is unchanged.
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false>
 __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int NCW = 8;                       // consumer waves; NLW loader waves
     constexpr int TH = NCW * RPW;
@@ -576,6 +592,8 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                 const int ry = p.up ? (ly + ypar) >> 1 : ly;
                 const int rx = p.up ? (lx + 1) >> 1 : lx;
                 loff[k] = (px < NPX && lx < LVALID) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
+                if constexpr (POLY)
+                    loff[k] = (px < NPX && lx < LVALID) ? (ly * p.dil * p.fullW + lx * p.dil) * 64 + slot * 16 : OOB;
             }
         }
         const int wvoff = lane * 16;
@@ -589,6 +607,22 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
             w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
 #pragma unroll
             for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
+            if constexpr (POLY) {
+                const int d = p.dil, dd = d * d;
+                const int nn = n / dd, ph = n - nn * dd, py = ph / d, px = ph - py * d;
+                const int Hp = (p.fullH - py + d - 1) / d, Wp = (p.fullW - px + d - 1) / d;      // this component's extent
+                in_tile = (const char*)(p.in + (long)nn * p.in_img_stride) + (((long)(ty0 - 1) * d + py) * p.fullW + (long)(tx0 - 1) * d + px) * 64;
+                if (ty0 == 0 || ty0 + TH + 1 > Hp || tx0 == 0 || tx0 + TW + 1 > Wp) {
+#pragma unroll
+                    for (int k = 0; k < KQ; ++k) {
+                        const int pxi = (lw + NLW * k) * 16 + (lane >> 2);
+                        const int ly = pxi / LWP, lx = pxi - ly * LWP;
+                        const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
+                        if (Y < 0 || Y >= Hp || X < 0 || X >= Wp) voff[k] = OOB;
+                    }
+                }
+                return;
+            }
             if constexpr (S9) {          // displaced reads reach 4 pixels beyond the tile: such tiles derive their offsets per chunk (issue)
                 s9_ty0 = ty0; s9_tx0 = tx0; s9_n = n;
                 s9_edge = ty0 < 4 || ty0 + TH + 4 > p.H || tx0 < 4 || tx0 + TW + 4 > p.W;
@@ -750,7 +784,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
             c = 0;
             jt += slots;
             if constexpr (OUTMODE == OUT_SLAB) {
-#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C)>(p, acc, n, ty0, tx0, cw, li, cbase)
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY>(p, acc, n, ty0, tx0, cw, li, cbase)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
@@ -799,7 +833,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false>
+template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 // Per-device state (a process may drive several GPUs): CU count, and which devices already carry a kernel's
@@ -859,13 +893,13 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     return INNFER_OK;
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9>
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
     constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
     static unsigned long long attr_done = 0;
-    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9>, LDS, attr_done)) return rc;
+    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
@@ -874,7 +908,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -987,6 +1021,16 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     static const int rpw64 = getenv("INNFER_RPW64") ? atoi(getenv("INNFER_RPW64")) : 3;
     static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
     static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 1;     // producer / consumer kernel for slab outputs
+    if (L.dilation > 1) {  // dilated 3x3 conv (zero padding = dilation) on the polyphase components: 32-output slab tiles, plain epilogue
+        const int d = L.dilation;
+        if (!pc || L.out_mode != OUT_SLAB || nt != 2 || L.res1 || L.res2 || L.up || L.reflect || L.y0 != 0 || k.y1 != L.H ||
+            (long)L.H * L.W * 64 >= 0x7fffffffL || d > 64)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: dilated convs are 32-output slab convs without residual / upsampling, images below 33 M pixels");
+        k.dil = d; k.fullH = L.H; k.fullW = L.W;
+        k.H = (L.H + d - 1) / d; k.W = (L.W + d - 1) / d; k.Hs = k.H; k.Ws = k.W;
+        k.y0 = 0; k.y1 = k.H;
+        return launch_pc<3, 2, 4, OUT_SLAB, false, true>(k, L.N * d * d, s);
+    }
     if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
     if (L.conv7) {         // 7x7 (padding 3) as nine displaced 3x3 convs: planar output, <= 16 output channels, panels from conv_pack7x7

@@ -572,7 +572,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.res1 = (const f16*)a->d_res1; L.res1_gstride = a->res1_group_stride; L.s1 = a->res1_scale;
     L.res2 = (const f16*)a->d_res2; L.res2_gstride = a->res2_group_stride; L.s2 = a->res2_scale;
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
-    L.out_mode = OUT_SLAB; L.reflect = a->reflect_pad;
+    L.out_mode = OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation;
     return conv_launch(L, (hipStream_t)stream);
 }
 

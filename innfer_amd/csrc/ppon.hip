@@ -27,6 +27,30 @@ namespace {
 // raw[px][256] fp32: the eight 32-channel dilated conv results of a residual block
 constexpr int RAW_ROW = 256;
 
+// in place on the 256-channel slab of the eight dilated conv results d1..d8 (fp16, bias included): group r <- lrelu(d1 + .. + d(r+1)),
+// running sums in fp32; one thread per (pixel, 8 channels)
+__global__ void ppon_comb_slab(f16* comb, long g, long npix) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 4) return;
+    const long pix = i >> 2;
+    const int c = (int)(i & 3) * 8;
+    f16* q = comb + pix * 32 + c;
+    float run[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16x8 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *(const f16x8*)(q + k * g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            run[e] += (float)v[k][e];
+            h[e] = (f16)fmaxf(run[e], 0.2f * run[e]);
+        }
+        *(f16x8*)(q + k * g) = h;
+    }
+}
+
 // comb[.., 32*r + c] = lrelu(sum_{i<=r} (raw[.., 32*i + c] + bias[32*i + c])): one thread per (pixel, 4 channels)
 __global__ void ppon_comb(const float* raw, const float* bias, long npix, f16* comb, long g) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,7 +106,8 @@ __global__ void ppon_axpy(const void* x, const void* y, void* dst, float a, long
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 
 struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr; };      // conv3x3.hip panels
-struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr; };
+struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; void* d_dw3[8] = {}; float* d_db3 = nullptr;   // halo-tile panels / biases of the dilated convs
+              f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr; };
 struct Head { Conv3 up[2]; Conv3 hr0, hr1; };
 
 }  // namespace
@@ -164,6 +189,9 @@ static void free_device(innfer_ppon* p) {
         free_conv3(r.c1);
         if (r.d_dw) (void)hipFree(r.d_dw);
         r.d_dw = nullptr;
+        for (auto& w3 : r.d_dw3) { if (w3) (void)hipFree(w3); w3 = nullptr; }
+        if (r.d_db3) (void)hipFree(r.d_db3);
+        r.d_db3 = nullptr;
         if (r.d_c2) (void)hipFree(r.d_c2);
         if (r.d_dbias) (void)hipFree(r.d_dbias);
         if (r.d_c2b) (void)hipFree(r.d_c2b);
@@ -248,6 +276,18 @@ int upload(innfer_ppon* p) {
             all.insert(all.end(), panel.begin(), panel.end());
             const std::vector<float>& b = p->params[r.d_b[d]].host;
             for (int k = 0; k < nf / 2; ++k) dbias[32 * d + k] = b[k];
+        }
+        if (nf == 64) {          // the halo-tile kernel's polyphase form of the dilated convs (32-output slab tiles)
+            std::vector<float> db3(8 * 64, 0.f);
+            std::vector<char> packed(conv_packed_bytes(nf / 2, nf));
+            for (int d = 0; d < 8; ++d) {
+                conv_pack(p->params[r.d_w[d]].host.data(), nf / 2, nf, packed.data());
+                INNFER_HIP(hipMalloc(&r.d_dw3[d], packed.size()));
+                INNFER_HIP(hipMemcpy(r.d_dw3[d], packed.data(), packed.size(), hipMemcpyHostToDevice));
+                for (int k = 0; k < nf / 2; ++k) db3[64 * d + k] = p->params[r.d_b[d]].host[k];
+            }
+            INNFER_HIP(hipMalloc((void**)&r.d_db3, db3.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(r.d_db3, db3.data(), db3.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         INNFER_HIP(hipMalloc((void**)&r.d_dw, all.size() * sizeof(f16)));
         INNFER_HIP(hipMemcpy(r.d_dw, all.data(), all.size() * sizeof(f16), hipMemcpyHostToDevice));
@@ -344,6 +384,7 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
     }
     int dy[9], dx[9], d0[1] = {0};
     size_t rbi = 0;
+    static const bool poly = !getenv("INNFER_PPON_POLY") || atoi(getenv("INNFER_PPON_POLY")) != 0;   // 0: grouped gather GEMM (A/B)
     // one RRBlock: x -> RB1 -> RB2 -> RB3 -> *0.2 + x, written to `dst` (any slab but x and the two scratch slabs)
     auto rrblock = [&](const f16* x, f16* dst, f16* sa, f16* sb) -> int {
         const f16* cur = x;
@@ -353,10 +394,24 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
             CK(conv(r.c1, cur, G, O1, G, H, W, 1, 0, nullptr, 0, OUT_SLAB));
             // the eight dilated convs of the block in ONE launch: group g = rate g+1 (taps scaled by the rate),
             // its own weight panel, its own 32-float column of the raw row
+            if (r.d_db3 && poly) {
+                // each dilated conv = ordinary 3x3 convs on the rate^2 polyphase components of the tile (halo-tile kernel, conv3x3_pc<..,POLY>):
+                // every input pixel is staged once per rate instead of once per tap and rate; fp16 results d_r go to group r of COMB
+                for (int d = 0; d < 8; ++d) {
+                    ConvLaunch Ld{};
+                    Ld.in = O1; Ld.in_gstride = G; Ld.C = 64;
+                    Ld.wpk = (const f16*)r.d_dw3[d]; Ld.bias = r.d_db3 + 64 * d;
+                    Ld.out = COMB + d * G; Ld.out_gstride = G; Ld.K = 32; Ld.N = N; Ld.H = H; Ld.W = W; Ld.act = 0;
+                    Ld.s1 = Ld.s2 = 1.f; Ld.y0 = 0; Ld.y1 = H; Ld.out_mode = OUT_SLAB; Ld.dilation = d + 1;
+                    CK(conv_launch(Ld, s));
+                }
+                hipLaunchKernelGGL(ppon_comb_slab, dim3((unsigned)((px * 4 + 255) / 256)), dim3(256), 0, s, COMB, G, px);
+            } else {
             for (int t = 0; t < 9; ++t) { dy[t] = t / 3 - 1; dx[t] = t % 3 - 1; }
             CK(gg::launch(r.d_dw, 64, 64, O1, G, N, H, W, raw, H, W, 1, 9, dy, dx, H, W, 1, 0, 0, 0, s, nullptr, 0, RAW_ROW, 0,
                           8, r.dw_bytes, 32, 1, 32));
             hipLaunchKernelGGL(ppon_comb, dim3((unsigned)((px * 8 + 255) / 256)), dim3(256), 0, s, (const float*)raw, (const float*)r.d_dbias, px, COMB, G);
+            }
             CK(gg::launch(r.d_c2, 256, 64, COMB, G, N, H, W, raw2, H, W, 1, 1, d0, d0, H, W, 1, 0, 0, 0, s));
             hipLaunchKernelGGL(ppon_res, dim3((unsigned)((px * 16 + 255) / 256)), dim3(256), 0, s, (const float*)raw2, (const float*)r.d_c2b, px,
                                cur, k == 2 ? x : (const f16*)nullptr, out, G);

@@ -44,7 +44,7 @@ class ConvArgs(C.Structure):
         ("d_res1", C.c_void_p), ("res1_group_stride", C.c_int64), ("res1_scale", C.c_float),
         ("d_res2", C.c_void_p), ("res2_group_stride", C.c_int64), ("res2_scale", C.c_float),
         ("row_begin", C.c_int), ("row_end", C.c_int),
-        ("reflect_pad", C.c_int),
+        ("reflect_pad", C.c_int), ("dilation", C.c_int),
     ]
 
 

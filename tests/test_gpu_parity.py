@@ -29,7 +29,7 @@ def _sd(shapes, seed=0):
 
 # ------------------------------------------------------------------ single conv
 def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0,
-              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False):
+              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False, dilation=0):
     """x [N,C,Hs,Ws] fp16 (cpu), w [K,C,3,3] fp32.  Runs the HIP conv on blocked-NHWC slabs
     ([C/32][N*H*W][32]) and returns (NCHW fp32 result, raw output slab [groups,N,H,W,32]) on the cpu."""
     import innfer_amd.lib as L
@@ -64,6 +64,7 @@ def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2
     if rows:
         a.row_begin, a.row_end = rows
     a.reflect_pad = int(reflect)
+    a.dilation = int(dilation)
     L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
     torch.cuda.synchronize()
     res = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
@@ -144,6 +145,20 @@ def test_conv_reflection_padding(dev, N, Cc, K, H, W):
     got, _ = _run_conv(dev, x, w, b, K, act=0, reflect=True)
     ref = F.conv2d(F.pad(x.float(), (1, 1, 1, 1), mode="reflect"), w.half().float(), b.float())
     assert (got - ref).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("d", [2, 3, 4, 5, 6, 7, 8])
+def test_conv_dilated_polyphase(dev, d):
+    """Dilated 3x3 conv, zero padding d (PPON_arch.py:83-91), as ordinary 3x3 convs on the d*d polyphase components of the image:
+    ragged sizes (the components have different extents), a batch, sizes below the dilation."""
+    from innfer_amd import synth
+    for (N, H, W) in ((2, 37, 53), (1, 200, 200), (1, 5, 3)):
+        x = torch.from_numpy(synth.uniform((N, 64, H, W), 71 + d, -1, 1)).half()
+        w = torch.from_numpy(synth.uniform((32, 64, 3, 3), 72, -1, 1)) / np.sqrt(9 * 64)
+        b = torch.from_numpy(synth.uniform((32,), 73, -1, 1))
+        got, _ = _run_conv(dev, x, w, b, 32, act=0, dilation=d)
+        ref = F.conv2d(x.float(), w.half().float(), b.float(), padding=d, dilation=d)
+        assert (got - ref).abs().max().item() < 4e-3, (d, N, H, W)
 
 
 def test_conv_nearest_upsample_fused(dev):
