@@ -46,6 +46,8 @@ struct ConvLaunch {
     int y0, y1;                                   // output rows [y0,y1)
     int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
     int rev;                                      // traverse the tiles in reverse order (speed only: see conv3x3.hip)
+    int dilation_groups;                          // G > 0: K = 32*G, output channel group g is the conv of dilation g+1 (own 32-output panel, panels of
+                                                  // conv_pack(K=32) back to back, bias[32*G]): PPON's eight dilated convs in one launch
     int dilation;                                 // > 1: dilated 3x3 conv, zero padding = dilation (PPON); 32-output slab convs only
     int conv7;                                    // 7x7 conv, padding 3 (zero or `reflect`), panels from conv_pack7x7: OUT_NCHW, K <= 16 only
     int reflect;                                  // ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel)

@@ -6,7 +6,8 @@
 // conv it can express -- PAN (all convs; a 1x1 conv is a panel with a centre tap only; pixel-attention gate epilogue
 // res1 * sigmoid(conv)), PPON, the WBC UNet, and the pix2pix UNet's outermost ConvTranspose (the four output phases as
 // 4*out_nc channels of one 3x3 conv, tanh + phase scatter in the planar epilogue), the CycleGAN residual blocks (reflection padding in
-// the loader) and the 7x7 convs with few outputs of the WBC UNet / CycleGAN (conv3x3_pc<..,S9>: nine displaced 3x3 convs).
+// the loader), the 7x7 convs with few outputs of the WBC UNet / CycleGAN (conv3x3_pc<..,S9>: nine displaced 3x3 convs) and PPON's dilated
+// convs (conv3x3_pc<..,POLY>: ordinary 3x3 convs on the polyphase components of the image).
 //
 // Data layout in HBM: activations are fp16 "blocked NHWC" channel slabs: channels in groups of
 // 32, element (n,y,x,c) at base + (c/32)*group_stride + ((n*H+y)*W+x)*32 + c%32, so a 32-channel
@@ -89,6 +90,8 @@ struct KP {
     int N;
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
+    int nrate, rate_start[9];// POLY kernels with nrate > 0: output channel group g (32 channels) is a conv of dilation g + 1 over its own tile grid;
+                             // tiles [rate_start[g], rate_start[g+1]) of the launch belong to it (dil unused)
     int dil, fullH, fullW;   // POLY kernels: dilation d; H, W, N are those of the d*d polyphase sub-images (ceil(fullH/d) x ceil(fullW/d), N*d*d of them)
     int ncg;                 // S9 kernels: real 32-channel groups of the input (nchunks = 9 * ncg virtual chunks)
     int reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d(1)) instead of zero; not with `up`
@@ -108,7 +111,7 @@ struct KP {
 // pixel (y*d + py, x*d + px); the sub-image ends where the full image does.  No residuals in that mode.
 template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
-                                              int wave, int li, int cbase) {
+                                              int wave, int li, int cbase, int dil = 1) {
     constexpr int MT = 2 * RPW;
     const int oc0 = cbase + p.out_coff;
     const int yw = ty0 + wave * RPW, xl = tx0 + li;
@@ -117,7 +120,7 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
     long colstep = 16 * 32;
     int ylim = p.y1, xlim = p.W;
     if constexpr (POLY) {
-        const int d = p.dil, dd = d * d;
+        const int d = dil, dd = d * d;
         const int nn = n / dd, ph = n - nn * dd, py = ph / d, px = ph - py * d;
         pix0 = ((long)nn * p.fullH + (long)yw * d + py) * p.fullW + (long)xl * d + px;
         rowstep = (long)p.fullW * 32 * d;
@@ -576,11 +579,27 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         ty0_ = p.y0 + ty * TH;
         tx0_ = (tile - ty * p.tiles_x) * TW;
     };
+    // POLY: also the tile's dilation; with rate groups the channel group IS the rate and every rate has its own tile grid
+    auto decode_poly = [&](int jj, int& kg_, int& n_, int& ty0_, int& tx0_, int& d_) {
+        if (p.nrate == 0) { decode(jj, kg_, n_, ty0_, tx0_); d_ = p.dil; return; }
+        const int lid = run_start + (p.rev ? run_len - 1 - jj : jj);
+        int r = 0;
+        while (r + 1 < p.nrate && lid >= p.rate_start[r + 1]) ++r;
+        kg_ = r; d_ = r + 1;
+        int tile = lid - p.rate_start[r];
+        const int tx = ((p.fullW + d_ - 1) / d_ + TW - 1) / TW, ty = ((p.fullH + d_ - 1) / d_ + TH - 1) / TH;
+        n_ = tile / (tx * ty);
+        tile -= n_ * tx * ty;
+        const int row = tile / tx;
+        ty0_ = row * TH;
+        tx0_ = (tile - row * tx) * TW;
+    };
 
     if (wave >= NCW) {
         // ================================ loaders ================================
         const int lw = wave - NCW;
         int loff[KQ];
+        int lpix[POLY ? KQ : 1];
         int s9_ty0 = 0, s9_tx0 = 0, s9_n = 0; bool s9_edge = false;          // S9: the current tile (edge tiles re-derive their offsets per chunk)
         {
             const int ypar = p.up ? ((p.y0 - 1) & 1) : 0;
@@ -592,8 +611,10 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                 const int ry = p.up ? (ly + ypar) >> 1 : ly;
                 const int rx = p.up ? (lx + 1) >> 1 : lx;
                 loff[k] = (px < NPX && lx < LVALID) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
-                if constexpr (POLY)
-                    loff[k] = (px < NPX && lx < LVALID) ? (ly * p.dil * p.fullW + lx * p.dil) * 64 + slot * 16 : OOB;
+                if constexpr (POLY) {          // the tile's dilation scales the pixel part: voff = lpix * d + slot (setup)
+                    lpix[k] = (px < NPX && lx < LVALID) ? (ly * p.fullW + lx) * 64 : -1;
+                    loff[k] = slot * 16;
+                }
             }
         }
         const int wvoff = lane * 16;
@@ -601,25 +622,29 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         const char* in_tile = nullptr;
         const char* w_tile = nullptr;
         auto setup = [&](int jj) {
-            int kg, n, ty0, tx0;
-            decode(jj, kg, n, ty0, tx0);
+            int kg, n, ty0, tx0, dl = 1;
+            if constexpr (POLY) decode_poly(jj, kg, n, ty0, tx0, dl);
+            else decode(jj, kg, n, ty0, tx0);
             in_tile = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)((ty0 - 1) >> p.up) * p.Ws + ((tx0 >> p.up) - 1)) * 64;
             w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
 #pragma unroll
             for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
             if constexpr (POLY) {
-                const int d = p.dil, dd = d * d;
+                const int d = dl, dd = d * d;
                 const int nn = n / dd, ph = n - nn * dd, py = ph / d, px = ph - py * d;
                 const int Hp = (p.fullH - py + d - 1) / d, Wp = (p.fullW - px + d - 1) / d;      // this component's extent
                 in_tile = (const char*)(p.in + (long)nn * p.in_img_stride) + (((long)(ty0 - 1) * d + py) * p.fullW + (long)(tx0 - 1) * d + px) * 64;
-                if (ty0 == 0 || ty0 + TH + 1 > Hp || tx0 == 0 || tx0 + TW + 1 > Wp) {
+                const bool edge = ty0 == 0 || ty0 + TH + 1 > Hp || tx0 == 0 || tx0 + TW + 1 > Wp;
 #pragma unroll
-                    for (int k = 0; k < KQ; ++k) {
+                for (int k = 0; k < KQ; ++k) {
+                    bool ok = lpix[POLY ? k : 0] >= 0;
+                    if (edge) {
                         const int pxi = (lw + NLW * k) * 16 + (lane >> 2);
                         const int ly = pxi / LWP, lx = pxi - ly * LWP;
                         const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
-                        if (Y < 0 || Y >= Hp || X < 0 || X >= Wp) voff[k] = OOB;
+                        ok = ok && Y >= 0 && Y < Hp && X >= 0 && X < Wp;
                     }
+                    voff[k] = ok ? lpix[POLY ? k : 0] * d + loff[k] : OOB;
                 }
                 return;
             }
@@ -731,14 +756,15 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     int bias_kg = -1;
     f32x4 acc[NT][MT];
     int jt = j0, c = 0;
-    int kg = 0, n = 0, ty0 = 0, tx0 = 0, cbase = 0;
+    int kg = 0, n = 0, ty0 = 0, tx0 = 0, cbase = 0, dcur = 1;
     asm volatile("s_barrier" ::: "memory");                       // chunk 0 of the first tile has landed
 #ifdef INNFER_STAMPS
     const unsigned long long k_c0 = clock64(), k_w0 = wall_clock64();
 #endif
     for (int g = 0; g < G; ++g) {
         if (c == 0) {
-            decode(jt, kg, n, ty0, tx0);
+            if constexpr (POLY) decode_poly(jt, kg, n, ty0, tx0, dcur);
+            else decode(jt, kg, n, ty0, tx0);
             cbase = kg * WROWS + 4 * NT * lg;
             if (kg != bias_kg) {
 #pragma unroll
@@ -784,7 +810,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
             c = 0;
             jt += slots;
             if constexpr (OUTMODE == OUT_SLAB) {
-#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY>(p, acc, n, ty0, tx0, cw, li, cbase)
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
@@ -903,7 +929,16 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
-    const long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
+    long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
+    if (POLY && k.nrate > 0) {               // N = images here; rate g has N * g^2 sub-images with their own tile grid
+        total = 0;
+        for (int g = 0; g < k.nrate; ++g) {
+            const int d = g + 1;
+            k.rate_start[g] = (int)total;
+            total += (long)N * d * d * (((k.fullW + d - 1) / d + TW - 1) / TW) * (((k.fullH + d - 1) / d + TH - 1) / TH);
+        }
+        if (total <= 0x7fffffffL) k.rate_start[k.nrate] = (int)total;
+    }
     if (total <= 0) return INNFER_OK;
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
@@ -1021,6 +1056,14 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     static const int rpw64 = getenv("INNFER_RPW64") ? atoi(getenv("INNFER_RPW64")) : 3;
     static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
     static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 1;     // producer / consumer kernel for slab outputs
+    if (L.dilation_groups > 0) {   // K = 32 * groups: output channel group g (its own 32-output panel) is the conv of dilation g + 1
+        if (!pc || L.out_mode != OUT_SLAB || L.K != 32 * L.dilation_groups || L.dilation_groups > 8 || L.res1 || L.res2 || L.up || L.reflect ||
+            L.y0 != 0 || k.y1 != L.H || (long)L.H * L.W * 64 >= 0x7fffffffL)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: dilation groups are 32-output slab convs (K = 32 * groups <= 256), no residual / upsampling");
+        k.nrate = L.dilation_groups; k.KG = L.dilation_groups; k.dil = 1; k.fullH = L.H; k.fullW = L.W;
+        k.y0 = 0; k.y1 = L.H;
+        return launch_pc<3, 2, 4, OUT_SLAB, false, true>(k, L.N, s);
+    }
     if (L.dilation > 1) {  // dilated 3x3 conv (zero padding = dilation) on the polyphase components: 32-output slab tiles, plain epilogue
         const int d = L.dilation;
         if (!pc || L.out_mode != OUT_SLAB || nt != 2 || L.res1 || L.res2 || L.up || L.reflect || L.y0 != 0 || k.y1 != L.H ||

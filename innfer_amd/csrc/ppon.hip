@@ -5,9 +5,11 @@
 //   3x3 convs 64->64 (c1, LR_conv, up-convs, HR_conv0), 64->3 (HR_conv1)     conv3x3.hip (conv_launch): fused bias /
 //                                                                           LeakyReLU / nearest-2x / shortcut add
 //   first conv 3->64                                                        conv_first.hip
-//   eight dilated 3x3 convs 64->32, rates 1..8 (conv_layer(.., dilation))   gg::gemm_gather: 9 taps displaced by the
-//                                                                           rate, all eight into one fp32 row per pixel
-//   d1, d1+d2, ..., d1+..+d8 -> cat -> LeakyReLU                            ppon_comb: running sums, 256-ch fp16 slab
+//   eight dilated 3x3 convs 64->32, rates 1..8 (conv_layer(.., dilation))   ONE launch of the halo-tile kernel (conv3x3_pc<..,POLY>, dilation groups):
+//                                                                           a rate-d conv = ordinary 3x3 convs on the d*d polyphase components
+//                                                                           of the tile; fp16 results in the eight groups of one 256-ch slab
+//                                                                           (INNFER_PPON_POLY=0: the first version, one grouped gather GEMM)
+//   d1, d1+d2, ..., d1+..+d8 -> cat -> LeakyReLU                            ppon_comb_slab: running sums in fp32, in place on that slab
 //   c2 1x1 256->64, *0.2 + input (and the RRBlock's out*0.2 + input)        gg::gemm_gather (1 tap) + ppon_res
 //   out_s = SRM(..) + out_c, out_p = alpha * PRM(..) + out_s                ppon_axpy on the planar outputs
 // Activations are blocked-NHWC fp16 slabs like everywhere else; the three reconstruction heads reuse one
@@ -106,7 +108,7 @@ __global__ void ppon_axpy(const void* x, const void* y, void* dst, float a, long
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 
 struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr; };      // conv3x3.hip panels
-struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; void* d_dw3[8] = {}; float* d_db3 = nullptr;   // halo-tile panels / biases of the dilated convs
+struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; void* d_dw3[8] = {};   // [0]: halo-tile panels of the eight dilated convs, back to back
               f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr; };
 struct Head { Conv3 up[2]; Conv3 hr0, hr1; };
 
@@ -190,8 +192,6 @@ static void free_device(innfer_ppon* p) {
         if (r.d_dw) (void)hipFree(r.d_dw);
         r.d_dw = nullptr;
         for (auto& w3 : r.d_dw3) { if (w3) (void)hipFree(w3); w3 = nullptr; }
-        if (r.d_db3) (void)hipFree(r.d_db3);
-        r.d_db3 = nullptr;
         if (r.d_c2) (void)hipFree(r.d_c2);
         if (r.d_dbias) (void)hipFree(r.d_dbias);
         if (r.d_c2b) (void)hipFree(r.d_c2b);
@@ -277,17 +277,12 @@ int upload(innfer_ppon* p) {
             const std::vector<float>& b = p->params[r.d_b[d]].host;
             for (int k = 0; k < nf / 2; ++k) dbias[32 * d + k] = b[k];
         }
-        if (nf == 64) {          // the halo-tile kernel's polyphase form of the dilated convs (32-output slab tiles)
-            std::vector<float> db3(8 * 64, 0.f);
-            std::vector<char> packed(conv_packed_bytes(nf / 2, nf));
-            for (int d = 0; d < 8; ++d) {
-                conv_pack(p->params[r.d_w[d]].host.data(), nf / 2, nf, packed.data());
-                INNFER_HIP(hipMalloc(&r.d_dw3[d], packed.size()));
-                INNFER_HIP(hipMemcpy(r.d_dw3[d], packed.data(), packed.size(), hipMemcpyHostToDevice));
-                for (int k = 0; k < nf / 2; ++k) db3[64 * d + k] = p->params[r.d_b[d]].host[k];
-            }
-            INNFER_HIP(hipMalloc((void**)&r.d_db3, db3.size() * sizeof(float)));
-            INNFER_HIP(hipMemcpy(r.d_db3, db3.data(), db3.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (nf == 64) {          // the halo-tile kernel's polyphase form of the dilated convs: eight 32-output panels back to back (rate = channel group)
+            const size_t pb = conv_packed_bytes(nf / 2, nf);
+            std::vector<char> packed(8 * pb);
+            for (int d = 0; d < 8; ++d) conv_pack(p->params[r.d_w[d]].host.data(), nf / 2, nf, packed.data() + d * pb);
+            INNFER_HIP(hipMalloc(&r.d_dw3[0], packed.size()));
+            INNFER_HIP(hipMemcpy(r.d_dw3[0], packed.data(), packed.size(), hipMemcpyHostToDevice));
         }
         INNFER_HIP(hipMalloc((void**)&r.d_dw, all.size() * sizeof(f16)));
         INNFER_HIP(hipMemcpy(r.d_dw, all.data(), all.size() * sizeof(f16), hipMemcpyHostToDevice));
@@ -394,17 +389,16 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
             CK(conv(r.c1, cur, G, O1, G, H, W, 1, 0, nullptr, 0, OUT_SLAB));
             // the eight dilated convs of the block in ONE launch: group g = rate g+1 (taps scaled by the rate),
             // its own weight panel, its own 32-float column of the raw row
-            if (r.d_db3 && poly) {
-                // each dilated conv = ordinary 3x3 convs on the rate^2 polyphase components of the tile (halo-tile kernel, conv3x3_pc<..,POLY>):
-                // every input pixel is staged once per rate instead of once per tap and rate; fp16 results d_r go to group r of COMB
-                for (int d = 0; d < 8; ++d) {
-                    ConvLaunch Ld{};
-                    Ld.in = O1; Ld.in_gstride = G; Ld.C = 64;
-                    Ld.wpk = (const f16*)r.d_dw3[d]; Ld.bias = r.d_db3 + 64 * d;
-                    Ld.out = COMB + d * G; Ld.out_gstride = G; Ld.K = 32; Ld.N = N; Ld.H = H; Ld.W = W; Ld.act = 0;
-                    Ld.s1 = Ld.s2 = 1.f; Ld.y0 = 0; Ld.y1 = H; Ld.out_mode = OUT_SLAB; Ld.dilation = d + 1;
-                    CK(conv_launch(Ld, s));
-                }
+            if (r.d_dw3[0] && poly) {
+                // the eight dilated convs as ONE launch of the halo-tile kernel (conv3x3_pc<..,POLY>, dilation groups): rate g+1 = output channel
+                // group g; each is ordinary 3x3 convs on the rate^2 polyphase components of the tile, so every input pixel is staged once per
+                // rate instead of once per tap and rate; fp16 results d_r (bias included) land in group r of COMB
+                ConvLaunch Ld{};
+                Ld.in = O1; Ld.in_gstride = G; Ld.C = 64;
+                Ld.wpk = (const f16*)r.d_dw3[0]; Ld.bias = r.d_dbias;
+                Ld.out = COMB; Ld.out_gstride = G; Ld.K = 256; Ld.N = N; Ld.H = H; Ld.W = W; Ld.act = 0;
+                Ld.s1 = Ld.s2 = 1.f; Ld.y0 = 0; Ld.y1 = H; Ld.out_mode = OUT_SLAB; Ld.dilation_groups = 8;
+                CK(conv_launch(Ld, s));
                 hipLaunchKernelGGL(ppon_comb_slab, dim3((unsigned)((px * 4 + 255) / 256)), dim3(256), 0, s, COMB, G, px);
             } else {
             for (int t = 0; t < 9; ++t) { dy[t] = t / 3 - 1; dx[t] = t % 3 - 1; }
