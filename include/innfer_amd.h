@@ -43,6 +43,9 @@ typedef enum { INNFER_F16 = 0, INNFER_F32 = 1 } innfer_dtype;
 
 typedef struct innfer_net* innfer_net_t;
 
+/* ABI revision of this header (major*100 + minor).  101: innfer_conv_args grew reflect_pad / dilation (zero-initialise the struct),
+ * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 101
 int innfer_version(void);
 const char* innfer_last_error(void);
 

@@ -63,7 +63,7 @@ static void add_conv(innfer_net* net, const std::string& key, int K, int C, bool
     net->convs.push_back(s);
 }
 
-extern "C" int innfer_version(void) { return 100; }
+extern "C" int innfer_version(void) { return INNFER_ABI_VERSION; }
 extern "C" const char* innfer_last_error(void) { return g_err.c_str(); }
 
 extern "C" int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,

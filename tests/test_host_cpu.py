@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(L.lib, n), f"libinnfer_amd.so does not export {n}"
         assert n in L.SIGNATURES, f"{n} has no ctypes signature in innfer_amd/lib.py"
     assert set(L.SIGNATURES) <= names, "lib.py binds symbols the header does not declare"
-    assert L.lib.innfer_version() >= 100
+    assert L.lib.innfer_version() == L.ABI_VERSION == int(re.search(r"#define INNFER_ABI_VERSION (\d+)", open(os.path.join(REPO, "include", "innfer_amd.h")).read()).group(1))
 
 
 def test_chop_plan_matches_reference_geometry(golden):
