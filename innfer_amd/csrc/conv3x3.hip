@@ -23,7 +23,9 @@
 // Two kernels share the tile machinery below:
 //   conv3x3_pc<RPW,NT,NLW,OUT>   producer / consumer workgroup (8 MFMA waves + NLW LDS-DMA waves, one per CU,
 //                                tile = 8*RPW rows x 32 px, two LDS stages): every slab-output conv and the
-//                                planar last conv;
+//                                planar last conv; two more template flags change only the ADDRESSING of its loader /
+//                                epilogue: S9 (a 7x7 conv as nine displaced 3x3 convs) and POLY (a dilated conv as
+//                                ordinary convs on the polyphase components of the image);
 //   conv3x3_mfma<RPW,NT,OUT>     two independent 4-wave workgroups per CU, tile = 4*RPW rows x 32 px, one LDS
 //                                stage each: PixelShuffle outputs, planar outputs with residuals, fallback.
 // Per 32-channel chunk the halo tile ((rows+2) x 34 px x 64 B) and the weight panel (9 x 16*NT x 64 B) are
