@@ -43,9 +43,9 @@ typedef enum { INNFER_F16 = 0, INNFER_F32 = 1 } innfer_dtype;
 
 typedef struct innfer_net* innfer_net_t;
 
-/* ABI revision of this header (major*100 + minor).  101: innfer_conv_args grew reflect_pad / dilation (zero-initialise the struct),
+/* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 101
+#define INNFER_ABI_VERSION 102
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -226,6 +226,8 @@ typedef struct {
                                            ResNet_arch.py:103-140); not together with upsample2x */
     int dilation;                       /* > 1: dilated 3x3 conv with zero padding = dilation (PPON's _ResBlock_32, PPON_arch.py:83-91); K == 32,
                                            no residuals / upsampling / row range */
+    int dilation_groups;                /* G > 0 (<= 8): K = 32*G output channels, channel group g is the conv of dilation g+1 -- PPON's eight dilated
+                                           convs as ONE launch; d_packed = the G panels of innfer_pack_conv3x3(K = 32) back to back, d_bias[32*G] */
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);

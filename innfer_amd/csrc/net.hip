@@ -560,7 +560,8 @@ extern "C" int innfer_pack_conv3x3(const float* w, int K, int C, void* h_packed)
 
 extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     if (!a || !a->d_in || !a->d_packed || !a->d_bias || !a->d_out) return set_error(INNFER_ERR_INVALID, "conv3x3: null argument");
-    if (a->K <= 0 || a->K % 16 || a->K > 64) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d (need K %% 16 == 0, K <= 64)", a->K);
+    if (a->dilation_groups > 0 ? a->K != 32 * a->dilation_groups : (a->K <= 0 || a->K % 16 || a->K > 64))
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d (need K %% 16 == 0, K <= 64; K = 32 * dilation_groups)", a->K);
     ConvLaunch L{};
     if (a->out_ch_off % 16 || (a->out_ch_off % 32 && a->K > 16))
         return set_error(INNFER_ERR_INVALID, "conv3x3: out_ch_off=%d must keep the %d output channels inside 32-channel groups", a->out_ch_off, a->K);
@@ -572,7 +573,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.res1 = (const f16*)a->d_res1; L.res1_gstride = a->res1_group_stride; L.s1 = a->res1_scale;
     L.res2 = (const f16*)a->d_res2; L.res2_gstride = a->res2_group_stride; L.s2 = a->res2_scale;
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
-    L.out_mode = OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation;
+    L.out_mode = OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
     return conv_launch(L, (hipStream_t)stream);
 }
 

@@ -44,7 +44,7 @@ class ConvArgs(C.Structure):
         ("d_res1", C.c_void_p), ("res1_group_stride", C.c_int64), ("res1_scale", C.c_float),
         ("d_res2", C.c_void_p), ("res2_group_stride", C.c_int64), ("res2_scale", C.c_float),
         ("row_begin", C.c_int), ("row_end", C.c_int),
-        ("reflect_pad", C.c_int), ("dilation", C.c_int),
+        ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int),
     ]
 
 
@@ -145,7 +145,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 101          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 102          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

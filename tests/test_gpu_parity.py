@@ -161,6 +161,38 @@ def test_conv_dilated_polyphase(dev, d):
         assert (got - ref).abs().max().item() < 4e-3, (d, N, H, W)
 
 
+def test_conv_dilation_groups_one_launch(dev):
+    """PPON's eight dilated convs (64 -> 32 each, rates 1..8) as ONE launch: output channel group g = the conv of dilation g+1 with its
+    own panel and tile grid.  Against eight F.conv2d calls on a ragged batch."""
+    import innfer_amd.lib as L
+    from innfer_amd import synth
+    N, H, W, G = 2, 45, 70, 8
+    x = torch.from_numpy(synth.uniform((N, 64, H, W), 81, -1, 1)).half()
+    ws = [torch.from_numpy(synth.uniform((32, 64, 3, 3), 82 + g, -1, 1)) / 24 for g in range(G)]
+    b = torch.from_numpy(synth.uniform((32 * G,), 90, -1, 1))
+    g_in = N * H * W * 32
+    slab = torch.empty((2, N, H, W, 32), dtype=torch.float16, device=dev)
+    L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), g_in, 0, N, 64, H, W, None))
+    pb = L.lib.innfer_conv3x3_packed_bytes(32, 64)
+    packed = np.zeros(G * pb, dtype=np.uint8)
+    for g in range(G):
+        wc = np.ascontiguousarray(ws[g].numpy())
+        L.check(L.lib.innfer_pack_conv3x3(wc.ctypes.data, 32, 64, packed[g * pb:].ctypes.data))
+    d_packed, d_bias = torch.from_numpy(packed).to(dev), b.float().to(dev)
+    out = torch.full((G, N, H, W, 32), -3.0, dtype=torch.float16, device=dev)
+    a = L.ConvArgs()
+    a.d_in, a.in_group_stride, a.C = slab.data_ptr(), g_in, 64
+    a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
+    a.d_out, a.out_group_stride, a.out_ch_off, a.K = out.data_ptr(), g_in, 0, 32 * G
+    a.N, a.H, a.W, a.act, a.dilation_groups = N, H, W, 0, G
+    L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
+    res = torch.empty((N, 32 * G, H, W), dtype=torch.float32, device=dev)
+    L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), g_in, 0, res.data_ptr(), L.F32, N, 32 * G, H, W, None))
+    torch.cuda.synchronize()
+    ref = torch.cat([F.conv2d(x.float(), ws[g].half().float(), b[32 * g:32 * g + 32].float(), padding=g + 1, dilation=g + 1) for g in range(G)], 1)
+    assert (res.cpu() - ref).abs().max().item() < 4e-3
+
+
 def test_conv_nearest_upsample_fused(dev):
     from innfer_amd import synth
     N, Cc, K, Hs, Ws = 1, 64, 64, 13, 21
