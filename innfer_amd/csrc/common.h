@@ -46,6 +46,7 @@ struct ConvLaunch {
     int y0, y1;                                   // output rows [y0,y1)
     int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
     int rev;                                      // traverse the tiles in reverse order (speed only: see conv3x3.hip)
+    int conv1x1;                                  // 1x1 conv: the centre tap only is staged and multiplied (panels from conv_pack_1x1); slab outputs
     int dilation_groups;                          // G > 0: K = 32*G, output channel group g is the conv of dilation g+1 (own 32-output panel, panels of
                                                   // conv_pack(K=32) back to back, bias[32*G]): PPON's eight dilated convs in one launch
     int dilation;                                 // > 1: dilated 3x3 conv, zero padding = dilation (PPON); 32-output slab convs only
@@ -59,6 +60,8 @@ int conv_nt_for(int K);                           // 16-channel tiles per group:
 size_t conv_packed_bytes(int K, int C);
 void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
 int conv_launch(const ConvLaunch& L, hipStream_t s);
+size_t conv_packed_bytes_taps(int K, int C, int mask);
+void conv_pack_1x1(const float* w_oi, int K, int C, void* packed);    // host; w [K][C]
 size_t conv_packed_bytes7x7(int K, int C);
 void conv_pack7x7(const float* w_oihw, int K, int C, void* packed);   // host; C % 32 == 0
 

@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 // is staged 9 times instead of 49 (gather GEMM).  Padding 3: zero, or mirrored (`reflect`).
 // POLY: a dilation-d 3x3 conv (zero padding d) as ordinary 3x3 convs on the d*d polyphase components of the image ("space to batch"
 // folded into the addressing): the loader's pixel steps and the epilogue's store steps are d pixels, everything else is unchanged.
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false>
+// TM: tap mask (bit r*3 + s).  A 1x1 conv is the centre tap only (TM = 0x10): the weight panel then holds, the loaders stage and the consumers
+// multiply ONE tap instead of nine (panels from conv_pack_taps).
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TM = 0x1FF>
 __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int NCW = 8;                       // consumer waves; NLW loader waves
     constexpr int TH = NCW * RPW;
@@ -547,7 +549,8 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int KQ = (NQ + NLW - 1) / NLW;
     constexpr int IN_BYTES = NQ * 1024;
     constexpr int WROWS = NT * 16;
-    constexpr int W_BYTES = 9 * WROWS * 64;
+    constexpr int NTAP = __builtin_popcount(TM);                    // taps in the panel, in (r, s) order
+    constexpr int W_BYTES = NTAP * WROWS * 64;
     constexpr int WQ = W_BYTES / 1024;
     constexpr int KW = (WQ + NLW - 1) / NLW;
     constexpr int MT = RPW * 2;
@@ -782,21 +785,27 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         PCT(c0);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
+            if (!((TM >> s) & 0x49)) continue;                     // no tap in this column (loop constants: folded at compile time)
             f16x8 a[3][NT];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    a[r][t] = *(const f16x8*)(st + aoffs + ((r * 3 + s) * WROWS + t * 16) * 64);
+                    if ((TM >> (r * 3 + s)) & 1)                   // panel slot = rank of the tap among the mask's set bits
+                        a[r][t] = *(const f16x8*)(st + aoffs + (__builtin_popcount(TM & ((1 << (r * 3 + s)) - 1)) * WROWS + t * 16) * 64);
 #pragma unroll
             for (int rr = 0; rr < RPW + 2; ++rr) {
+                bool need = false;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) need = need || (((TM >> (r * 3 + s)) & 1) && rr - r >= 0 && rr - r < RPW);
+                if (!need) continue;
 #pragma unroll
                 for (int seg = 0; seg < 2; ++seg) {
                     const f16x8 b = *(const f16x8*)(st + boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         const int rw = rr - r;
-                        if (rw >= 0 && rw < RPW) {
+                        if (((TM >> (r * 3 + s)) & 1) && rw >= 0 && rw < RPW) {
 #pragma unroll
                             for (int t = 0; t < NT; ++t)
                                 acc[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false>
+template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false, int TM = 0x1FF>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 // Per-device state (a process may drive several GPUs): CU count, and which devices already carry a kernel's
@@ -921,13 +930,13 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     return INNFER_OK;
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY>
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
-    constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + 9 * NT * 16 * 64);
+    constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + __builtin_popcount(TM) * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
     static unsigned long long attr_done = 0;
-    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY>, LDS, attr_done)) return rc;
+    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
@@ -945,7 +954,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -1007,6 +1016,27 @@ void conv_pack(const float* w, int K, int C, void* packed) {
                         }
                     }
                 }
+}
+
+// Panels holding only the taps of `mask` (bit r*3+s), in (r, s) order: [group][chunk][tap rank][row R][slot][8 ch]; mask 0x10 = a 1x1 conv,
+// w then is [K][C] (one value per pair) -- the counterpart of conv3x3_pc<.., TM>
+size_t conv_packed_bytes_taps(int K, int C, int mask) { return conv_packed_bytes(K, C) / 9 * __builtin_popcount(mask & 0x1FF); }
+void conv_pack_1x1(const float* w, int K, int C, void* packed) {
+    const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
+    f16* dst = (f16*)packed;
+    for (int g = 0; g < groups; ++g)
+        for (int c = 0; c < nch; ++c)
+            for (int R = 0; R < rows; ++R) {
+                const int t = R >> 4, rho = R & 15;
+                const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
+                for (int sg = 0; sg < 4; ++sg) {
+                    const int cg = sg ^ (((R >> 2) & 1) << 1);
+                    for (int e = 0; e < 8; ++e) {
+                        const int ic = c * 32 + cg * 8 + e;
+                        *dst++ = (f16)(oc < K ? w[(size_t)oc * C + ic] : 0.f);
+                    }
+                }
+            }
 }
 
 // 7x7 weights [K][C][7][7] -> panels of the equivalent conv over 9*C virtual channels (conv3x3_pc<.., S9>): virtual channel sub*C + ci,
@@ -1075,6 +1105,11 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         k.H = (L.H + d - 1) / d; k.W = (L.W + d - 1) / d; k.Hs = k.H; k.Ws = k.W;
         k.y0 = 0; k.y1 = k.H;
         return launch_pc<3, 2, 4, OUT_SLAB, false, true>(k, L.N * d * d, s);
+    }
+    if (L.conv1x1) {        // centre tap only: panels from conv_pack_1x1
+        if (!pc || L.out_mode != OUT_SLAB || (nt != 2 && nt != 4))
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv1x1: slab outputs of 32- / 64-channel tiles on the producer-consumer kernel");
+        return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s) : launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);

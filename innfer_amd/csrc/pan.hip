@@ -260,6 +260,7 @@ struct Gemm {                       // one packed GEMM
     // plain 3x3 convs (bias, optional LeakyReLU / residual) run on the SR path's halo-tile kernel (conv3x3.hip) instead:
     bool tile3 = false; std::string bias_key;           // its packed panels [K3][cin_pad][3][3] and the bias padded with zeros
     void* d_w3 = nullptr; float* d_b3 = nullptr; int K3 = 0;
+    bool one_tap = false;                               // a 1x1 conv: single-tap panel (conv_pack_1x1), the kernel's one-tap instantiation
 };
 
 }  // namespace
@@ -430,8 +431,16 @@ int upload(innfer_pan* p) {
                 const std::vector<float>& hb = p->params[find(p, g.bias_key)].host;
                 for (int co = 0; co < g.cout; ++co) b3[co] = hb[co];
             }
-            std::vector<char> packed(conv_packed_bytes(g.K3, g.cin_pad));
-            conv_pack(w3.data(), g.K3, g.cin_pad, packed.data());
+            g.one_tap = g.K3 >= 32;                     // slab outputs only (the planar last conv keeps the 3x3 kernel)
+            for (size_t i = 0; i < w3.size() && g.one_tap; ++i) if (i % 9 != 4 && w3[i] != 0.f) g.one_tap = false;
+            std::vector<char> packed(g.one_tap ? conv_packed_bytes_taps(g.K3, g.cin_pad, 0x10) : conv_packed_bytes(g.K3, g.cin_pad));
+            if (g.one_tap) {
+                std::vector<float> w1((size_t)g.K3 * g.cin_pad);
+                for (size_t i = 0; i < w1.size(); ++i) w1[i] = w3[i * 9 + 4];
+                conv_pack_1x1(w1.data(), g.K3, g.cin_pad, packed.data());
+            } else {
+                conv_pack(w3.data(), g.K3, g.cin_pad, packed.data());
+            }
             INNFER_HIP(hipMalloc(&g.d_w3, packed.size()));
             INNFER_HIP(hipMemcpy(g.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
             INNFER_HIP(hipMalloc((void**)&g.d_b3, b3.size() * sizeof(float)));
@@ -520,6 +529,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         L.res1 = res; L.res1_gstride = res_g; L.s1 = 1.f; L.s2 = 1.f;
         L.y0 = 0; L.y1 = Ho;
         L.out_mode = planar ? OUT_NCHW : OUT_SLAB; L.out_f32 = planar ? 1 : 0;
+        L.conv1x1 = g.one_tap ? 1 : 0;
         return conv_launch(L, s);
     };
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)

@@ -10,7 +10,7 @@
 //                                                                           of the tile; fp16 results in the eight groups of one 256-ch slab
 //                                                                           (INNFER_PPON_POLY=0: the first version, one grouped gather GEMM)
 //   d1, d1+d2, ..., d1+..+d8 -> cat -> LeakyReLU                            ppon_comb_slab: running sums in fp32, in place on that slab
-//   c2 1x1 256->64, *0.2 + input (and the RRBlock's out*0.2 + input)        gg::gemm_gather (1 tap) + ppon_res
+//   c2 1x1 256->64, *0.2 + input (and the RRBlock's out*0.2 + input)        the halo-tile kernel's one-tap instantiation, both residual stages in its epilogue
 //   out_s = SRM(..) + out_c, out_p = alpha * PRM(..) + out_s                ppon_axpy on the planar outputs
 // Activations are blocked-NHWC fp16 slabs like everywhere else; the three reconstruction heads reuse one
 // set of HR buffers.  Returns (out_c, out_s, out_p) like the reference; run.py keeps out_p.
@@ -109,7 +109,8 @@ struct Param { std::string key; std::vector<int> shape; std::vector<float> host;
 
 struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr; };      // conv3x3.hip panels
 struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; void* d_dw3[8] = {};   // [0]: halo-tile panels of the eight dilated convs, back to back
-              f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr; };
+              f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr;
+              void* d_c2t = nullptr; };        // c2 as a centre-tap panel for the halo-tile kernel
 struct Head { Conv3 up[2]; Conv3 hr0, hr1; };
 
 }  // namespace
@@ -193,6 +194,8 @@ static void free_device(innfer_ppon* p) {
         r.d_dw = nullptr;
         for (auto& w3 : r.d_dw3) { if (w3) (void)hipFree(w3); w3 = nullptr; }
         if (r.d_c2) (void)hipFree(r.d_c2);
+        if (r.d_c2t) (void)hipFree(r.d_c2t);
+        r.d_c2t = nullptr;
         if (r.d_dbias) (void)hipFree(r.d_dbias);
         if (r.d_c2b) (void)hipFree(r.d_c2b);
         r.d_c2 = nullptr; r.d_dbias = r.d_c2b = nullptr;
@@ -292,6 +295,12 @@ int upload(innfer_ppon* p) {
         gg::pack_panels(panel, nf, 4 * nf, 4 * nf, 1, [&](int co, int ci, int) { return w2[(size_t)co * 4 * nf + ci]; });
         INNFER_HIP(hipMalloc((void**)&r.d_c2, panel.size() * sizeof(f16)));
         INNFER_HIP(hipMemcpy(r.d_c2, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
+        if (nf == 64) {
+            std::vector<char> pk(conv_packed_bytes_taps(nf, 4 * nf, 0x10));
+            conv_pack_1x1(w2.data(), nf, 4 * nf, pk.data());
+            INNFER_HIP(hipMalloc(&r.d_c2t, pk.size()));
+            INNFER_HIP(hipMemcpy(r.d_c2t, pk.data(), pk.size(), hipMemcpyHostToDevice));
+        }
         INNFER_HIP(hipMalloc((void**)&r.d_c2b, nf * sizeof(float)));
         INNFER_HIP(hipMemcpy(r.d_c2b, p->params[r.c2_b].host.data(), nf * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -406,10 +415,23 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
                           8, r.dw_bytes, 32, 1, 32));
             hipLaunchKernelGGL(ppon_comb, dim3((unsigned)((px * 8 + 255) / 256)), dim3(256), 0, s, (const float*)raw, (const float*)r.d_dbias, px, COMB, G);
             }
+            if (r.d_c2t && poly) {
+                // c2 (1x1, 256 -> 64) on the halo-tile kernel's one-tap instantiation; `(c2 + b) * 0.2 + input` and, at the end of the block of
+                // three, `* 0.2 + block input` are its two residual epilogue stages (the RRDB epilogue of the SR path)
+                ConvLaunch Lc{};
+                Lc.in = COMB; Lc.in_gstride = G; Lc.C = 256;
+                Lc.wpk = (const f16*)r.d_c2t; Lc.bias = r.d_c2b;
+                Lc.out = out; Lc.out_gstride = G; Lc.K = 64; Lc.N = N; Lc.H = H; Lc.W = W; Lc.act = 0;
+                Lc.res1 = cur; Lc.res1_gstride = G; Lc.s1 = 0.2f;
+                if (k == 2) { Lc.res2 = x; Lc.res2_gstride = G; }
+                Lc.s2 = 0.2f; Lc.y0 = 0; Lc.y1 = H; Lc.out_mode = OUT_SLAB; Lc.conv1x1 = 1;
+                CK(conv_launch(Lc, s));
+            } else {
             CK(gg::launch(r.d_c2, 256, 64, COMB, G, N, H, W, raw2, H, W, 1, 1, d0, d0, H, W, 1, 0, 0, 0, s));
             hipLaunchKernelGGL(ppon_res, dim3((unsigned)((px * 16 + 255) / 256)), dim3(256), 0, s, (const float*)raw2, (const float*)r.d_c2b, px,
                                cur, k == 2 ? x : (const f16*)nullptr, out, G);
             INNFER_HIP(hipGetLastError());
+            }
             cur = out;
         }
         return INNFER_OK;

@@ -342,15 +342,15 @@ static int upload_all(innfer_unet* u) {
                             [&](int co, int j, int) { const int t = j / l.cin, ci = j - t * l.cin;
                                                       return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
                 int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
-                if (l.cout % 64 == 0) {        // ... and as a centre-tap 3x3 panel for the halo-tile kernel, whose epilogue writes the fp16 slabs directly
-                    std::vector<float> w3((size_t)l.cout * 64 * 9, 0.f), b3((size_t)l.cout, 0.f);
+                if (l.cout % 64 == 0) {        // ... and as a one-tap panel for the halo-tile kernel, whose epilogue writes the fp16 slabs directly
+                    std::vector<float> w1((size_t)l.cout * 64, 0.f), b3((size_t)l.cout, 0.f);
                     for (int co = 0; co < l.cout; ++co)
                         for (int j = 0; j < 16 * l.cin; ++j) {
                             const int t = j / l.cin, ci = j - t * l.cin;
-                            w3[((size_t)co * 64 + j) * 9 + 4] = w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)];
+                            w1[(size_t)co * 64 + j] = w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)];
                         }
-                    std::vector<char> packed(conv_packed_bytes(l.cout, 64));
-                    conv_pack(w3.data(), l.cout, 64, packed.data());
+                    std::vector<char> packed(conv_packed_bytes_taps(l.cout, 64, 0x10));
+                    conv_pack_1x1(w1.data(), l.cout, 64, packed.data());
                     if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
                     INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
                     rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
@@ -530,7 +530,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
                 Lc.in = cur; Lc.in_gstride = Go; Lc.C = 64;
                 Lc.wpk = (const f16*)l.d_w3; Lc.bias = l.d_b3;
                 Lc.out = dsts[v]; Lc.out_gstride = Go; Lc.K = l.cout; Lc.N = N; Lc.H = ho; Lc.W = wo; Lc.act = v == 0 ? 1 : 2;
-                Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = ho; Lc.out_mode = OUT_SLAB;
+                Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = ho; Lc.out_mode = OUT_SLAB; Lc.conv1x1 = 1;
                 rc = conv_launch(Lc, s);
                 if (rc) return rc;
             }
