@@ -35,7 +35,7 @@ struct ConvSlot {
     std::string key;
     int K = 0, C = 0;
     bool first = false;          // small-Cin VALU conv (fp32 [C*9][K] weights)
-    int ksize = 3;               // 1: a 1x1 conv, packed as the centre tap of a 3x3 panel
+    int ksize = 3;               // 1: a 1x1 conv (one-tap panel, ConvLaunch.conv1x1)
     void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
     float* d_b = nullptr;        // bias padded to the panel width
     bool loaded = false;
@@ -160,12 +160,11 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
                 for (int k = 0; k < c.K; ++k) d[((size_t)ci * 9 + t) * c.K + k] = w[((size_t)k * c.C + ci) * 9 + t];
         bias_n = c.K;
     } else {
-        host.resize(conv_packed_bytes(c.K, c.C));
-        if (c.ksize == 1) {          // [K,C,1,1] -> centre tap of a [K,C,3,3] panel
-            std::vector<float> w3((size_t)c.K * c.C * 9, 0.f);
-            for (size_t i = 0; i < (size_t)c.K * c.C; ++i) w3[i * 9 + 4] = w[i];
-            conv_pack(w3.data(), c.K, c.C, host.data());
+        if (c.ksize == 1) {          // [K,C,1,1]: the one-tap panel of the kernel's 1x1 instantiation
+            host.resize(conv_packed_bytes_taps(c.K, c.C, 0x10));
+            conv_pack_1x1(w, c.K, c.C, host.data());
         } else {
+            host.resize(conv_packed_bytes(c.K, c.C));
             conv_pack(w, c.K, c.C, host.data());
         }
         const int per = 16 * conv_nt_for(c.K);
@@ -359,6 +358,7 @@ ConvLaunch mk(const ConvSlot& cs, const f16* in, long in_g, void* out, long out_
     L.s1 = 1.f; L.s2 = 1.f;
     L.y0 = 0; L.y1 = H;
     L.out_mode = OUT_SLAB;
+    L.conv1x1 = cs.ksize == 1;
     return L;
 }
 
