@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: output MPix/s of 4x ESRGAN RRDBNet-23 (fp16) on MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W        (N > 1: this process starts N fresh rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path (`Model.__call__(chop=False)` semantics: the whole
 generator forward through libinnfer_amd.so) over one synthetic frame that is already
-resident in HBM.  Workloads:
+resident in HBM.  Workloads (`--workload`):
     frame1080 (default)  1x3x1080x1920 -> 1x3x4320x7680, un-tiled   (BASELINE config 2)
     frame540             1x3x540x960   -> 1x3x2160x3840  (the "->4K" reading of the metric)
-    chop8k               4320x7680 input through chop_forward (3268 tiles of 200^2, blend)
-With N > 1 ranks every rank runs the same workload on its own frame (frame-level data
-parallel replicas: an un-tiled frame cannot be split without halo exchange over the
-~348-px receptive radius) -- weak scaling, no data-path collective; `chop8k` shards the
-tile list over ranks and gathers HR tiles on rank 0 (innfer_amd/parallel.py).
+    chop8k               4320x7680 input through chop_forward (3268 tiles of 200^2, blend)   (BASELINE config 3)
+    chop4k               2160x3840 input through chop_forward (798 tiles)
+    chain4k              model chain RRDBNet-23 1x + 4x on a 2160x3840 input, 798 tiles per stage   (BASELINE config 4)
+frame*: with N > 1 ranks every rank runs the workload on its own frame (frame-level replicas: an un-tiled
+frame cannot be split without halo exchange over the ~348-px receptive radius) -- weak scaling, no data-path
+collective.  chop* / chain*: ONE shared frame, its tile list sharded over the ranks, raw HR tiles sent to rank 0
+over RCCL and blended there (innfer_amd/parallel.py) -- strong scaling.
+Whatever the headline workload, the line also carries `tile_sharded`: BASELINE config 4 (chain4k) timed the same
+way (barrier + synchronise on both sides, max over ranks) on the SAME ranks, with the exchange bytes / ms of one
+profiled pass -- the north_star's "tiles partition across the GPUs, reassembled with an RCCL gather".
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     : dominant kernel (conv3x3_mfma, by summed time) -- algorithmic FLOPs per launch /
-                 its average launch duration, both from HIP events around every launch of one forward
+  roofline     : dominant kernel (by summed time) -- algorithmic FLOPs and bytes per launch / its average launch
+                 duration, from HIP events around every launch of one forward; BOTH roofs per kernel, `bound` = the larger floor
   cpu_baseline : the oracle (torch fp32 restatement of the reference) timed on the host cores on a
                  bounded sample (rank 0, N == 1 only).
 """
@@ -26,6 +31,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,19 +39,19 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F16_TFLOPS = 2516.6      # MI355X dense fp16/bf16 MFMA: 256 CU x 4096 FLOP/clk x 2.4 GHz
-KIND_NAMES = {0: "first_conv_kernel"}
-# rows per wave of the instantiation conv_launch picks for NT 16-channel tiles (csrc/conv3x3.hip), slab / NCHW output
-RPW_OF_NT = {1: 4, 2: int(os.environ.get("INNFER_RPW32", "5")), 4: int(os.environ.get("INNFER_RPW64", "3"))}
-PC = int(os.environ.get("INNFER_PC", "1"))      # slab-output convs run the producer / consumer kernel
-PC_SHAPE = {(2, 0): (3, 2, 8 if PC == 2 else 4, 0), (4, 0): (2, 4, 4, 0), (1, 1): (3, 1, 4, 1)}
+PEAK_HBM_GBS = 8000.0         # HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# instantiation conv_launch picks for NT 16-channel output tiles and the output mode (csrc/conv3x3.hip)
+PC_SHAPE = {(2, 0): (3, 2, 4, 0), (4, 0): (2, 4, 4, 0), (1, 1): (3, 1, 4, 1)}
+MFMA_SHAPE = {1: 4, 2: 4, 4: 2}
+WORKLOADS = ["frame1080", "frame540", "chop8k", "chop4k", "chain4k"]
 
 
 def kernel_key(k):
     """rocprof-style name of the instantiation conv_launch picks for launch kind k = 16*NT + out_mode."""
     nt, mode = k // 16, k % 16
-    if PC and (nt, mode) in PC_SHAPE:
+    if (nt, mode) in PC_SHAPE:
         return "conv3x3_pc<%d,%d,%d,%d>" % PC_SHAPE[(nt, mode)]
-    return f"conv3x3_mfma<{RPW_OF_NT[nt]},{nt},{mode}>"
+    return f"conv3x3_mfma<{MFMA_SHAPE[nt]},{nt},{mode}>"
 
 
 def kind_name(k):
@@ -63,7 +69,7 @@ def build_net(dev, nb=23, scale=4):
 
 
 def timed_forward(net, x):
-    """Per-launch HIP-event timing of one forward (plain schedule) through the C ABI."""
+    """Per-launch HIP-event timing of one forward (plain schedule) through the C ABI: [(kind, ms, flops, bytes)]."""
     import torch
     import innfer_amd.lib as L
     net._ensure_engine()
@@ -74,12 +80,12 @@ def timed_forward(net, x):
     if net._ws is None or net._ws.numel() < need:
         net._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     cap = 4096
-    ms, fl, kd, n = (C.c_float * cap)(), (C.c_double * cap)(), (C.c_int * cap)(), C.c_int()
+    ms, fl, by, kd, n = (C.c_float * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), (C.c_int * cap)(), C.c_int()
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(L.lib.innfer_net_set_band_rows(net._handle, int(net.band_rows)))
     L.check(L.lib.innfer_net_forward_timed(net._handle, x.data_ptr(), L.F16, out.data_ptr(), L.F16, N, H, W,
-                                           net._ws.data_ptr(), net._ws.numel(), stream, cap, ms, fl, kd, C.byref(n)))
-    return [(kd[i], ms[i], fl[i]) for i in range(min(n.value, cap))]
+                                           net._ws.data_ptr(), net._ws.numel(), stream, cap, ms, fl, by, kd, C.byref(n)))
+    return [(kd[i], ms[i], fl[i], by[i]) for i in range(min(n.value, cap))]
 
 
 def pmc_traffic(kind):
@@ -92,26 +98,45 @@ def pmc_traffic(kind):
         return None
 
 
+def two_roofs(flops, nbytes, ms):
+    """Both floors of a kernel (or a sum of launches): MFMA time at the dense fp16 peak, HBM time at 8 TB/s for the
+    ALGORITHMIC bytes; the binding roof is the larger floor."""
+    t = ms * 1e-3
+    t_mfma, t_hbm = flops / (PEAK_F16_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+    return {"tflops": round(flops / t / 1e12, 2), "gbs": round(nbytes / t / 1e9, 1),
+            "frac_mfma": round(t_mfma / t, 4), "frac_hbm": round(t_hbm / t, 4),
+            "bound": "mfma" if t_mfma >= t_hbm else "hbm", "flop_per_byte": round(flops / nbytes, 1)}
+
+
 def roofline_from_launches(launches):
     agg = {}
-    for k, ms, fl in launches:
-        a = agg.setdefault(k, [0.0, 0.0, 0])
-        a[0] += ms; a[1] += fl; a[2] += 1
+    for k, ms, fl, by in launches:
+        a = agg.setdefault(k, [0.0, 0.0, 0.0, 0])
+        a[0] += ms; a[1] += fl; a[2] += by; a[3] += 1
     dom = max(agg, key=lambda k: agg[k][0])
-    t_ms, flops, cnt = agg[dom]
-    achieved = flops / (t_ms * 1e-3) / 1e12
-    per_kernel = {kind_name(k): {"launches": v[2], "ms_total": round(v[0], 4), "avg_ms": round(v[0] / v[2], 5),
-                                 "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2)} for k, v in agg.items()}
+    t_ms, flops, nbytes, cnt = agg[dom]
+    r = two_roofs(flops, nbytes, t_ms)
+    per_kernel = {}
+    for k, v in agg.items():
+        e = {"launches": v[3], "ms_total": round(v[0], 4), "avg_ms": round(v[0] / v[3], 5)}
+        e.update(two_roofs(v[1], v[2], v[0]))
+        per_kernel[kind_name(k)] = e
     total_ms = sum(v[0] for v in agg.values())
     total_fl = sum(v[1] for v in agg.values())
-    return {"bound": "mfma", "kernel": kind_name(dom), "launches": cnt,
-            "avg_launch_ms": round(t_ms / cnt, 5), "flops_per_launch": flops / cnt,
-            "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": pmc_traffic(dom),
-            "traffic_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB averaged over the kernel's "
-                            "dispatches, separate rocprofv3 --pmc passes (profiles/traffic.json)",
-            "all_kernels_tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 2),
-            "per_kernel": per_kernel}
+    out = {"bound": r["bound"], "kernel": kind_name(dom), "launches": cnt, "avg_launch_ms": round(t_ms / cnt, 5),
+           "flops_per_launch": flops / cnt, "bytes_per_launch": nbytes / cnt}
+    if r["bound"] == "hbm":
+        out.update({"achieved": r["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": r["frac_hbm"]})
+    else:
+        out.update({"achieved": r["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": r["frac_mfma"]})
+    out.update({"frac_mfma": r["frac_mfma"], "frac_hbm": r["frac_hbm"], "tflops": r["tflops"], "gbs": r["gbs"],
+                "flop_per_byte": r["flop_per_byte"], "ridge_flop_per_byte": round(PEAK_F16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
+                "traffic": pmc_traffic(dom),
+                "traffic_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB averaged over the kernel's "
+                                "dispatches, separate rocprofv3 --pmc passes (profiles/traffic.json)",
+                "all_kernels_tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 2),
+                "per_kernel": per_kernel})
+    return out
 
 
 def power_probe(step, seconds=2.5):
@@ -119,7 +144,7 @@ def power_probe(step, seconds=2.5):
     while a thread samples `rocm-smi` (about one sample per 0.4 s; the first second is discarded so that the power manager has
     settled).  Context for the roofline object only -- the peak in `roofline.peak` is the 2.4 GHz figure; never part of
     the timed region.  Returns None when rocm-smi is not there."""
-    import re, shutil, subprocess, threading
+    import re, shutil, threading
     import torch
     if not shutil.which("rocm-smi"):
         return None
@@ -160,15 +185,17 @@ def power_probe(step, seconds=2.5):
             "samples": len(samples), "peak_at_sclk_tflops": round(PEAK_F16_TFLOPS * sclk / 2400.0, 1)}
 
 
-def per_layer_table(launches, npix_lr):
-    """stderr table: per distinct (kind, flops) launch class -> avg ms, TFLOP/s (diagnostics)."""
+def per_layer_table(launches):
+    """stderr table: per distinct (kind, flops) launch class -> avg ms, TFLOP/s, algorithmic GB/s (diagnostics)."""
     rows = {}
-    for k, ms, fl in launches:
-        r = rows.setdefault((k, fl), [0.0, 0])
+    for k, ms, fl, by in launches:
+        r = rows.setdefault((k, fl, by), [0.0, 0])
         r[0] += ms; r[1] += 1
     out = []
-    for (k, fl), (ms, n) in sorted(rows.items()):
-        out.append(f"  {kind_name(k):34s} n={n:3d} GFLOP={fl / 1e9:9.1f} avg_ms={ms / n:8.4f} TFLOP/s={fl / (ms / n * 1e-3) / 1e12:8.1f}")
+    for (k, fl, by), (ms, n) in sorted(rows.items()):
+        t = ms / n * 1e-3
+        out.append(f"  {kind_name(k):26s} n={n:3d} GFLOP={fl / 1e9:8.1f} MB={by / 1e6:8.1f} avg_ms={ms / n:8.4f} "
+                   f"TFLOP/s={fl / t / 1e12:7.1f} GB/s={by / t / 1e9:7.1f}")
     return "\n".join(out)
 
 
@@ -217,7 +244,6 @@ def cpu_baseline_child(budget_s=12.0):
 
 
 def cpu_baseline(timeout_s=120):
-    import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"],
                            capture_output=True, text=True, timeout=timeout_s)
@@ -235,14 +261,85 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent starts one fresh process per rank BEFORE anything touches the GPU
+# (never re-exec a process that has initialised HIP), relays rank 0's JSON line and fails if a rank fails.
+def spawn_ranks(args, argv):
+    import socket
+    n = args.gpus
+    dry = os.environ.get("INNFER_BENCH_DRYRUN") == "1" or os.environ.get("INNFER_BENCH_SELFTEST") == "1"
+    if not dry:
+        import torch                                    # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n:
+            log(f"--gpus {n} but only {have} GPU(s) visible (INNFER_BENCH_DRYRUN=1 rehearses the N > 1 control flow on one GPU)")
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")            # rank 0's stdout (the JSON line); the other ranks' stdout goes to stderr
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):      # a rank died: the others would wait in a collective for ever
+            time.sleep(2.0)
+            for i, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()                            # exactly the PIDs started above
+                    rcs[i] = p.wait()
+                else:
+                    rcs[i] = p.returncode
+            break
+        time.sleep(0.1)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    if any(rcs):
+        log(f"rank exit codes {rcs}")
+        return 1
+    return 0
+
+
+def timed_steps(step, steps, warmup, world, sync, barrier, max_over_ranks):
+    """The contract's timed region: W untimed steps, then exactly K steps bracketed by barrier + synchronise, MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if world > 1:
+        barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = step()
+    sync()
+    if world > 1:
+        barrier()
+    sync()
+    wall = time.perf_counter() - t0
+    del y
+    return max_over_ranks(wall)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="frame1080", choices=["frame1080", "frame540", "chop8k", "chop4k", "chain4k"])
-    ap.add_argument("--band-rows", type=int, default=int(os.environ.get("INNFER_BAND_ROWS", "0")))
+    ap.add_argument("--workload", default="frame1080", choices=WORKLOADS)
+    ap.add_argument("--band-rows", type=int, default=0)
     ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch")
+    ap.add_argument("--sharded-steps", type=int, default=2, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-power-probe", action="store_true")
@@ -250,6 +347,10 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -257,109 +358,183 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"--gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    # INNFER_BENCH_DRYRUN=1: control-flow rehearsal of the N>1 path on a ONE-GPU box (every rank on cuda:0, gloo
-    # rendezvous); never a measurement.
+    # INNFER_BENCH_SELFTEST=1: the N-rank control flow only (spawn, rendezvous, barriers, max over ranks, ONE line from rank 0)
+    #   with a sleep as the "step": runs without a GPU, covered by tests/test_bench_ranks_cpu.py.  Never a measurement.
+    # INNFER_BENCH_DRYRUN=1: the real HIP workload with every rank on cuda:0 and a gloo rendezvous -- a rehearsal of the
+    #   N > 1 path on a ONE-GPU box.  Never a measurement either.
+    selftest = os.environ.get("INNFER_BENCH_SELFTEST") == "1"
     dryrun = world > 1 and os.environ.get("INNFER_BENCH_DRYRUN") == "1"
+    if world > 1:
+        if selftest or dryrun:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        dist.barrier()
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if (selftest or dryrun) else torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    if selftest:
+        wall = timed_steps(lambda: time.sleep(0.002), args.steps, args.warmup, world, lambda: None, barrier, max_over_ranks)
+        seen = torch.tensor([1.0])
+        if world > 1:
+            dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"metric": "selftest", "value": round(world * args.steps / wall, 2), "unit": "steps/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 3),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                              "data": "selftest: no GPU work, control flow only", "ranks_seen": int(seen.item()),
+                              "config": {"workload": "selftest"}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if dryrun:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if dryrun:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from innfer_amd import synth
+    def sync():
+        torch.cuda.synchronize()
+
+    from innfer_amd import parallel, synth
     net, _ = build_net(dev)
     net.band_rows = args.band_rows
+    tag = " (DRY RUN: all ranks on one GPU, gloo)" if dryrun else ""
 
-    if args.workload.startswith("frame"):
+    def chop_setup(workload, profile=False):
+        """(step, H, W, description, runners) of a tile-sharded workload over the current ranks."""
+        H, W = (4320, 7680) if workload == "chop8k" else (2160, 3840)
+        x = torch.from_numpy(synth.uniform((1, 3, H, W), 2)).to(dev).half()
+        r4 = parallel.ChopRunner(net, scale=4, tile_batch=args.tile_batch or 64, profile=profile)
+        if workload == "chain4k":                   # BASELINE config 4: model chain 1x + 4x (run.py:424-426)
+            net1, _ = build_net(dev, scale=1)
+            r1 = parallel.ChopRunner(net1, scale=1, tile_batch=args.tile_batch or 64, profile=profile)
+            return (lambda: parallel.run_chain([r1, r4], x)), H, W, "model chain RRDBNet-23 1x + RRDBNet-23 4x", [r1, r4]
+        return (lambda: r4(x)), H, W, "ESRGAN RRDBNet-23 4x", [r4]
+
+    def chop_flops(runners, H, W):
+        """Algorithmic FLOPs of one pass: every tile of every stage counts (the reference's tiling is part of the contract)."""
+        import innfer_amd.lib as L
+        ps, ys, xs = L.chop_plan(H, W, 200, 0.5)
+        return sum(r.model_fn.flops(len(ys) * len(xs), ps, ps) for r in runners), len(ys) * len(xs)
+
+    frame = args.workload.startswith("frame")
+    if frame:
         H, W = (1080, 1920) if args.workload == "frame1080" else (540, 960)
         x = torch.from_numpy(synth.uniform((1, 3, H, W), 2 + rank)).to(dev).half()
-        out_pix_per_rank = 16 * H * W
+        out_pix = 16 * H * W * world                # every rank produces its own frame
 
         def step():
             return net(x)
         cfg = {"workload": f"ESRGAN RRDBNet-23 4x fp16, 1x3x{H}x{W} -> 1x3x{4 * H}x{4 * W}, un-tiled "
                            f"(Model(chop=False)), one frame per rank", "band_rows": args.band_rows,
-               "parallelism": (f"frame replicas x{world}" if world > 1 else "single GPU") + (" (DRY RUN: all ranks on one GPU)" if dryrun else "")}
+               "parallelism": (f"frame replicas x{world}" if world > 1 else "single GPU") + tag}
+        scaling = "weak"
+        metric = "output MPix/s, 4x ESRGAN RRDB-23 1080p->4K"
     else:
-        from innfer_amd import parallel
-        H, W = (4320, 7680) if args.workload == "chop8k" else (2160, 3840)       # chop4k and chain4k: 4K input
-        x = torch.from_numpy(synth.uniform((1, 3, H, W), 2)).to(dev).half()
-        runner = parallel.ChopRunner(net, scale=4, tile_batch=args.tile_batch or 64)
-        out_pix_per_rank = 16 * H * W / world       # unique output pixels of the ONE shared frame
-        if args.workload == "chain4k":              # BASELINE config 4: model chain 1x + 4x (run.py:424-426)
-            net1, _ = build_net(dev, scale=1)
-            runner1 = parallel.ChopRunner(net1, scale=1, tile_batch=args.tile_batch or 64)
-
-            def step():
-                return parallel.run_chain([runner1, runner], x)
-            what = "model chain RRDBNet-23 1x + RRDBNet-23 4x"
-        else:
-            def step():
-                return runner(x)
-            what = "ESRGAN RRDBNet-23 4x"
+        step, H, W, what, main_runners = chop_setup(args.workload)
+        out_pix = 16 * H * W                        # unique output pixels of the ONE shared frame
         cfg = {"workload": f"{what} fp16, {H}x{W} input through chop_forward (patch 200, step 0.5), "
-                           f"tiles sharded over {world} rank(s), HR tiles gathered + blended on rank 0",
-               "band_rows": args.band_rows, "parallelism": f"tile-dp{world}"}
+                           f"tile list sharded over {world} rank(s), raw HR tiles sent to rank 0 and blended there",
+               "band_rows": args.band_rows, "parallelism": f"tile-dp{world}" + tag}
+        scaling = "strong"
+        metric = {"chop8k": "output MPix/s, 4x ESRGAN RRDB-23, 8K input through chop_forward",
+                  "chop4k": "output MPix/s, 4x ESRGAN RRDB-23, 4K input through chop_forward",
+                  "chain4k": "output MPix/s, model chain 1x + 4x ESRGAN RRDB-23, 4K input through chop_forward"}[args.workload]
 
-    log('warmup')
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    log('warmup + timed region')
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        y = step()
+    n_done = [0]
+
+    def step_ev():                                  # HIP events around the K timed steps only (torch's current stream = the launch stream)
+        if n_done[0] == args.warmup:
+            e0.record()
+        n_done[0] += 1
+        return step()
+    wall = timed_steps(step_ev, args.steps, args.warmup, world, sync, barrier, max_over_ranks)
     e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    t = torch.tensor([wall], dtype=torch.float64, device="cpu" if dryrun else dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = t.item()
+    sync()
     log(f'timed {args.steps} steps in {wall:.3f} s')
     ev_ms = e0.elapsed_time(e1)
-    del y
 
+    line = None
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
-        value = out_pix_per_rank * world * args.steps / wall / 1e6
-        line = {"metric": "output MPix/s, 4x ESRGAN RRDB-23 1080p->4K", "value": round(value, 2),
+        line = {"metric": metric, "value": round(out_pix * args.steps / wall / 1e6, 2),
                 "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling,
                 "vs_baseline": None, "dtype": "f16", "data": "synthetic", "config": cfg,
                 "hip_event_ms_per_step": round(ev_ms / args.steps, 3)}
-        flops = net.flops(1, H, W) if args.workload.startswith("frame") else None
-        if flops:
+        if not frame:
+            flops, _ = chop_flops(main_runners, H, W)
+            line["model_tflops"] = round(flops * args.steps / wall / 1e12, 2)
+            line["frac_of_mfma_peak_all_gpus"] = round(flops * args.steps / wall / 1e12 / (PEAK_F16_TFLOPS * world), 4)
+        if frame:
+            flops = net.flops(1, H, W)
             line["model_tflops"] = round(flops * world * args.steps / wall / 1e12, 2)
             line["frac_of_mfma_peak"] = round(flops * args.steps / wall / 1e12 / PEAK_F16_TFLOPS, 4)
-        if not args.no_roofline and args.workload.startswith("frame"):
-            log('per-launch timing')
-            timed_forward(net, x)
-            launches = timed_forward(net, x)
-            line["roofline"] = roofline_from_launches(launches)
-            if world == 1 and not args.no_power_probe:
-                log('power probe')
-                pw = power_probe(step)
-                if pw:
-                    pw["frac_of_peak_at_sclk"] = round(line["roofline"]["achieved"] / pw["peak_at_sclk_tflops"], 4)
-                    line["roofline"]["power"] = pw
-            log("per-layer classes:\n" + per_layer_table(launches, H * W))
-        net.release_workspace()
+            if not args.no_roofline:
+                log('per-launch timing')
+                timed_forward(net, x)
+                launches = timed_forward(net, x)
+                line["roofline"] = roofline_from_launches(launches)
+                if world == 1 and not args.no_power_probe:
+                    log('power probe')
+                    pw = power_probe(step)
+                    if pw:
+                        pw["frac_of_peak_at_sclk"] = round(line["roofline"]["tflops"] / pw["peak_at_sclk_tflops"], 4)
+                        line["roofline"]["power"] = pw
+                log("per-layer classes:\n" + per_layer_table(launches))
+    if frame:
+        del x
+    net.release_workspace()
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE config 4 on the same ranks: chain 1x + 4x, 4K input, tile list sharded, RCCL exchange ----
+    if args.sharded_steps > 0 and args.workload != "chain4k":
+        log('tile-sharded chain4k')
+        cstep, cH, cW, cwhat, runners = chop_setup("chain4k", profile=False)
+        cwall = timed_steps(cstep, args.sharded_steps, 1, world, sync, barrier, max_over_ranks)
+        for r in runners:
+            r.profile = True                        # one more pass with a synchronise around every phase: where the time goes
+        cstep()
+        sync()
+        phases = [dict(r.last) for r in runners]
+        if world > 1:
+            barrier()
+        if rank == 0:
+            ms = cwall * 1e3 / args.sharded_steps
+            cfl, ntile = chop_flops(runners, cH, cW)            # SURVEY 8d: 1060 + 1144 TFLOP per frame
+            tf = cfl / 1e12
+            line["tile_sharded"] = {
+                "workload": f"{cwhat} fp16, {cH}x{cW} input, {ntile} tiles of 200^2 per stage (BASELINE config 4), tile list sharded "
+                            f"over {world} rank(s), raw HR tiles to rank 0, blend there, intermediate broadcast" + tag,
+                "parallelism": f"tile-dp{world}", "scaling": "strong", "steps": args.sharded_steps, "warmup": 1,
+                "ms_per_frame": round(ms, 2), "value": round(16 * cH * cW / (ms * 1e-3) / 1e6, 2), "unit": "MPix/s",
+                "model_tflops": round(tf / (ms * 1e-3), 1),
+                "frac_of_mfma_peak_all_gpus": round(tf / (ms * 1e-3) / (PEAK_F16_TFLOPS * world), 4),
+                "rank0_phases_ms": [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in p.items()} for p in phases],
+                "exchange_bytes_into_rank0": sum(p.get("exchange_bytes", 0) for p in phases),
+                "exchange_ms": round(sum(p.get("exchange_ms", 0.0) for p in phases), 2)}
+        del cstep, runners
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline')
             line["cpu_baseline"] = cpu_baseline()
@@ -367,7 +542,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

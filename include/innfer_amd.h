@@ -44,8 +44,8 @@ typedef enum { INNFER_F16 = 0, INNFER_F32 = 1 } innfer_dtype;
 typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
- * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 102
+ * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval.  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 103
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -86,12 +86,14 @@ int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dtype, void* d
                        int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Same forward with a HIP-event pair around every kernel launch (on `stream`), then a
- * stream synchronise.  Fills up to `cap` entries: elapsed ms, algorithmic FLOPs and kernel
- * kind (0 = first conv on VALU; 16*NT + out_mode = conv3x3_mfma instantiation with NT
- * 16-channel output tiles).  Used by bench.py for the roofline object. */
+ * stream synchronise.  Fills up to `cap` entries: elapsed ms, algorithmic FLOPs, algorithmic HBM
+ * bytes (every operand read once, every result written once: (C + K) * 2 B per output pixel,
+ * + K * 2 B per residual, + the weight panel) and kernel kind (0 = first conv on VALU; 16*NT +
+ * out_mode = the conv instantiation with NT 16-channel output tiles).  Used by bench.py for the
+ * roofline object (both roofs per kernel). */
 int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                              int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream,
-                             int cap, float* h_ms, double* h_flops, int* h_kind, int* n_launches);
+                             int cap, float* h_ms, double* h_flops, double* h_bytes, int* h_kind, int* n_launches);
 
 /* Scheduling knob: 0 = one launch per layer over the whole frame; R>0 = skewed
  * row bands of R rows through the RRDB trunk (working set kept Infinity-Cache
@@ -110,8 +112,8 @@ double innfer_net_flops(innfer_net_t net, int N, int H, int W);
  * as run.py runs it for `-a p2p_256 / unet_256` (meval=False: BatchNorm uses the statistics of the
  * current image, run.py:299-303).  A batch is N independent batch-1 forwards (per-image statistics).
  * Parameters are addressed by their state-dict key ("model.model.1.model.2.weight" ...): conv /
- * conv-transpose weights in PyTorch layout, BatchNorm weight and bias; running statistics are listed
- * (so that strict loading sees every key) but not used.
+ * conv-transpose weights in PyTorch layout, BatchNorm weight and bias, and the running statistics, which only
+ * innfer_unet_set_eval(u, 1) forwards read.
  */
 typedef struct innfer_unet* innfer_unet_t;
 int innfer_unet_create(innfer_unet_t* out, int in_nc, int out_nc, int num_downs, int ngf);
@@ -119,6 +121,10 @@ void innfer_unet_destroy(innfer_unet_t u);
 int innfer_unet_num_params(innfer_unet_t u);
 int innfer_unet_param_info(innfer_unet_t u, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
 int innfer_unet_set_param(innfer_unet_t u, int idx, const float* h_data);
+/* nn.Module.eval() / .train() (run.py:96-99): eval_mode != 0 normalises with the running statistics ("...running_mean" / "...running_var",
+ * set like any other parameter; unset = a fresh BatchNorm's 0 / 1) as ATen's eval-mode batch_norm does: alpha = weight / sqrt(running_var + eps),
+ * y = x * alpha + (bias - running_mean * alpha).  Default 0: statistics of the current image (how run.py runs pix2pix, meval=False). */
+int innfer_unet_set_eval(innfer_unet_t u, int eval_mode);
 size_t innfer_unet_workspace_bytes(innfer_unet_t u, int N, int H, int W);
 double innfer_unet_flops(innfer_unet_t u, int N, int H, int W);
 /* d_in [N,in_nc,H,W] -> d_out [N,out_nc,H,W] (tanh range), NCHW f16/f32; H, W multiples of 2^num_downs. */
@@ -210,7 +216,7 @@ int innfer_guided_filter(const void* d_x, const void* d_y, int dtype, int N, int
  *   out = d_res1 * sigmoid(conv + bias), followed by LeakyReLU(0.2) for 4 (d_res1 required, no d_res2, scales unused).
  * upsample2x: input is read through nearest-2x upsampling (block.py:321-322,358),
  *   i.e. d_in is [N,H/2,W/2,*] while H,W are the conv's (output) size.
- * d_packed comes from innfer_pack_conv3x3().  C % 32 == 0, K % 16 == 0, K <= 64.
+ * d_packed comes from innfer_pack_conv3x3().  C % 32 == 0, K % 16 == 0, K <= 64 (pixel_shuffle2: K % 64 == 0, any K).
  */
 typedef struct {
     const void* d_in;  int64_t in_group_stride;  /* elements between 32-channel groups of the input slab */
@@ -228,6 +234,9 @@ typedef struct {
                                            no residuals / upsampling / row range */
     int dilation_groups;                /* G > 0 (<= 8): K = 32*G output channels, channel group g is the conv of dilation g+1 -- PPON's eight dilated
                                            convs as ONE launch; d_packed = the G panels of innfer_pack_conv3x3(K = 32) back to back, d_bias[32*G] */
+    int pixel_shuffle2;                 /* != 0: nn.PixelShuffle(2) folded into the store (pixelshuffle_block, block.py:333-346): K % 64 == 0 conv channels,
+                                           d_out is the [N,2H,2W,K/4] slab, out[n, c, 2y+i, 2x+j] = act(conv)[n, 4c+2i+j, y, x] -- a pure index map,
+                                           bit-exact; act 0 / 1 / 2, residuals allowed, out_ch_off 0, no row range */
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);

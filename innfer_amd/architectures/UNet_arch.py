@@ -1,7 +1,8 @@
 """pix2pix UnetGenerator shell (reference UNet_arch.py:11-161): parameters and buffers carry the
 reference's state-dict keys (queried from the engine), forward runs in libinnfer_amd.so (csrc/unet.hip).
-BatchNorm always uses the statistics of the current image -- that is how run.py runs pix2pix
-(meval=False, run.py:299-303); an eval()-mode forward with running statistics is not built."""
+BatchNorm follows the module's mode like nn.BatchNorm2d does: train() (how run.py runs pix2pix: meval=False, run.py:299-303)
+normalises with the statistics of the current image, eval() (Model's default meval=True, run.py:96-97) with the running
+statistics of the checkpoint."""
 from .. import lib as L
 from .param_module import ParamEngineModule
 
@@ -19,6 +20,10 @@ class UnetGenerator(ParamEngineModule):
 
     def _out_shape(self, N, H, W):
         return (N, self.output_nc, H, W)
+
+    def forward(self, x):
+        L.check(L.lib.innfer_unet_set_eval(self._handle, int(not self.training)))
+        return super().forward(x)
 
     def flops(self, N, H, W):
         return L.lib.innfer_unet_flops(self._handle, N, H, W)

@@ -31,6 +31,7 @@ class EngineModule(nn.Module):
             node.register_parameter(leaf, nn.Parameter(torch.zeros(*shape), requires_grad=False))
         self._handle = None
         self._uploaded_version = None
+        self._weights_device = None          # GPU the engine's packed weights live on
         self._ws = None
         self.band_rows = 0
 
@@ -70,13 +71,17 @@ class EngineModule(nn.Module):
             L.check(L.lib.innfer_net_set_conv(self._handle, i, w.ctypes.data, bp))
         self._uploaded_version = ver
 
-    def __del__(self):
+    def _destroy_handle(self):
         h = getattr(self, '_handle', None)
         if h is not None:
             try:
                 L.lib.innfer_net_destroy(h)
             except Exception:
                 pass
+        self._handle, self._uploaded_version, self._ws = None, None, None
+
+    def __del__(self):
+        self._destroy_handle()
 
     # ---- forward ---------------------------------------------------------------
     def forward(self, x):
@@ -88,7 +93,16 @@ class EngineModule(nn.Module):
                 '(the CPU restatement lives in oracle/ and is test infrastructure).')
         if x.dtype not in (torch.float16, torch.float32):
             raise TypeError(f'unsupported dtype {x.dtype}')
+        # the library allocates and launches on the process's CURRENT HIP device: make that the input's for the whole call
+        # (weights packed for another GPU are re-uploaded)
+        with torch.cuda.device(x.device):
+            return self._forward_on_device(x)
+
+    def _forward_on_device(self, x):
+        if self._weights_device is not None and self._weights_device != x.device:
+            self._destroy_handle()
         self._ensure_engine()
+        self._weights_device = x.device
         L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
         x = x.contiguous()
         N, _, H, W = x.shape

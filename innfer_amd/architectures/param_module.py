@@ -42,6 +42,7 @@ class ParamEngineModule(nn.Module):
                 node.register_parameter(leaf, nn.Parameter(torch.zeros(*shape), requires_grad=False))
             self._keys.append(k)
         self._version = None
+        self._weights_device = None
         self._ws = None
 
     def __del__(self):
@@ -53,12 +54,13 @@ class ParamEngineModule(nn.Module):
                 pass
 
     def _upload(self):
-        ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # parameters AND buffers: the running statistics of a BatchNorm are part of an eval()-mode forward
+        ver = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
         if ver == self._version:
             return
         sd = self.state_dict()
         for i, k in enumerate(self._keys):
-            if 'running_' in k or 'num_batches' in k:
+            if 'num_batches' in k:
                 continue
             a = np.ascontiguousarray(sd[k].detach().float().cpu().numpy())
             L.check(self._fn('set_param')(self._handle, i, a.ctypes.data))
@@ -74,7 +76,14 @@ class ParamEngineModule(nn.Module):
             raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
         if x.dtype not in (torch.float16, torch.float32):
             raise TypeError(f'unsupported dtype {x.dtype}')
+        with torch.cuda.device(x.device):        # the library allocates and launches on the process's current HIP device
+            return self._forward_on_device(x)
+
+    def _forward_on_device(self, x):
+        if self._weights_device is not None and self._weights_device != x.device:
+            raise NotImplementedError('this engine was first used on %s; build a second module for %s' % (self._weights_device, x.device))
         self._upload()
+        self._weights_device = x.device
         x = x.contiguous()
         N, _, H, W = x.shape
         out = torch.empty(self._out_shape(N, H, W), dtype=x.dtype, device=x.device)

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 int set_error(int code, const char* fmt, ...);
+
+// A/B knobs of the kernel experiments kept under profiles/: an environment variable only in the diagnostic builds (`make ablate`,
+// `make stamps`); the shipped library compiles the measured-best value in as a constant, so the untaken branches (and the kernel
+// instantiations only they reach) are not even in the binary.  INNFER_DEBUG (net.hip) is the one run-time switch of the shipped library.
+#ifdef INNFER_ABLATE
+#define INNFER_KNOB(name, dflt) ([] { static const int v = getenv(name) ? atoi(getenv(name)) : (dflt); return v; }())
+#else
+#define INNFER_KNOB(name, dflt) (dflt)
+#endif
 
 #define INNFER_HIP(expr)                                                              \
     do {                                                                              \

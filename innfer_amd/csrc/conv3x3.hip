@@ -912,17 +912,17 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
     {
-        static const int pf = getenv("INNFER_PREFETCH") ? atoi(getenv("INNFER_PREFETCH")) : 0;   // 1: next chunk, 2: + next tile
+        const int pf = INNFER_KNOB("INNFER_PREFETCH", 0);   // 1: next chunk, 2: + next tile
         k.pf = (RPW == 3 && NT == 2) ? 0 : pf;
 #ifdef INNFER_ABLATE
-        k.abl = getenv("INNFER_ABL") ? atoi(getenv("INNFER_ABL")) : 0;
+        k.abl = INNFER_KNOB("INNFER_ABL", 0);
 #endif
     }
     const long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
     if (total <= 0) return INNFER_OK;
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
-    static const int persist = getenv("INNFER_PERSIST") ? atoi(getenv("INNFER_PERSIST")) : 2;   // workgroups per CU, 0 = one per tile
+    const int persist = INNFER_KNOB("INNFER_PERSIST", 2);   // workgroups per CU, 0 = one per tile
     const long slots = (long)((persist == 2 && RPW == 3 && NT == 2) ? 3 : persist) * num_cus();   // = workgroups resident per CU
     const long grid = (persist > 0 && total > slots) ? slots : total;
     hipLaunchKernelGGL((conv3x3_mfma<RPW, NT, OUTMODE>), dim3((unsigned)grid), dim3(256), LDS, s, k);
@@ -1085,9 +1085,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);
-    static const int rpw64 = getenv("INNFER_RPW64") ? atoi(getenv("INNFER_RPW64")) : 3;
-    static const int rpw32 = getenv("INNFER_RPW32") ? atoi(getenv("INNFER_RPW32")) : 5;
-    static const int pc = getenv("INNFER_PC") ? atoi(getenv("INNFER_PC")) : 1;     // producer / consumer kernel for slab outputs
+    const int rpw64 = INNFER_KNOB("INNFER_RPW64", 3);
+    const int rpw32 = INNFER_KNOB("INNFER_RPW32", 5);
+    const int pc = INNFER_KNOB("INNFER_PC", 1);     // producer / consumer kernel for slab outputs
     if (L.dilation_groups > 0) {   // K = 32 * groups: output channel group g (its own 32-output panel) is the conv of dilation g + 1
         if (!pc || L.out_mode != OUT_SLAB || L.K != 32 * L.dilation_groups || L.dilation_groups > 8 || L.res1 || L.res2 || L.up || L.reflect ||
             L.y0 != 0 || k.y1 != L.H || (long)L.H * L.W * 64 >= 0x7fffffffL)

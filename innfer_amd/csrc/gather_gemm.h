@@ -42,7 +42,7 @@ struct GP {
 // Layers with at most this many output pixels per image (and >= 32 k-steps) are split over K.
 constexpr int SPLIT_MAX_PX = 256;
 inline long split_max_px() {
-    static const long v = getenv("INNFER_SPLIT_PX") ? atol(getenv("INNFER_SPLIT_PX")) : 64;
+    const long v = INNFER_KNOB("INNFER_SPLIT_PX", 64);
     return v < SPLIT_MAX_PX ? v : SPLIT_MAX_PX;
 }
 

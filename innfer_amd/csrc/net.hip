@@ -254,6 +254,7 @@ namespace {
 struct LaunchTimer {
     std::vector<hipEvent_t> ev;      // 2 per launch
     std::vector<double> flops;
+    std::vector<double> bytes;       // algorithmic HBM bytes of the launch: every operand read once, every result written once
     std::vector<int> kind;           // 0 first conv (VALU); 16*NT + out_mode for conv3x3_mfma
 };
 thread_local LaunchTimer* g_timer = nullptr;
@@ -267,13 +268,14 @@ int timed_begin(hipStream_t s) {
     return INNFER_OK;
 }
 
-int timed_end(hipStream_t s, double flops, int kind) {
+int timed_end(hipStream_t s, double flops, double bytes, int kind) {
     if (!g_timer) return INNFER_OK;
     hipEvent_t e;
     INNFER_HIP(hipEventCreate(&e));
     INNFER_HIP(hipEventRecord(e, s));
     g_timer->ev.push_back(e);
     g_timer->flops.push_back(flops);
+    g_timer->bytes.push_back(bytes);
     g_timer->kind.push_back(kind);
     return INNFER_OK;
 }
@@ -300,7 +302,7 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
                 L.C, L.K, L.N, L.H, L.W, L.up, L.act, L.out_mode, L.y0, L.y1, L.in_gstride, L.out_gstride);
     {
         // whole-frame launches alternate their traversal direction (Infinity Cache reuse between layers)
-        static const bool alt = !getenv("INNFER_TILE_REV") || atoi(getenv("INNFER_TILE_REV")) != 0;
+        const bool alt = INNFER_KNOB("INNFER_TILE_REV", 1) != 0;
         thread_local unsigned parity = 0;
         ConvLaunch R = L;
         const int y1 = L.y1 > 0 ? L.y1 : L.H;
@@ -311,8 +313,13 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
     rc = debug_after("conv3x3", s);
     if (rc) return rc;
     const int y1 = L.y1 > 0 ? L.y1 : L.H;
-    return timed_end(s, 2.0 * 9.0 * L.K * L.C * (double)L.N * (y1 - L.y0) * L.W,
-                     16 * conv_nt_for(L.K) + L.out_mode);
+    const double px = (double)L.N * (y1 - L.y0) * L.W;
+    const int taps = L.conv1x1 ? 1 : 9;
+    // algorithmic bytes per output pixel: C input channels (a quarter of them per pixel behind the folded nearest-2x), K outputs, K per residual
+    const double obytes = L.out_mode == OUT_NCHW ? (L.out_f32 ? 4.0 : 2.0) : 2.0;
+    const double bytes = px * (L.C * 2.0 / (L.up ? 4.0 : 1.0) + L.K * obytes + (L.res1 ? L.K * 2.0 : 0.0) + (L.res2 ? L.K * 2.0 : 0.0))
+                         + (double)taps * L.K * L.C * 2.0;
+    return timed_end(s, 2.0 * taps * L.K * L.C * px, bytes, 16 * conv_nt_for(L.K) + L.out_mode);
 }
 
 // nearest-neighbour upsampling of a slab by an integer factor (src = dst / f, block.py:321-322).  The 2x case is folded into the conv's input
@@ -340,7 +347,8 @@ int do_first(const FirstConvLaunch& F, hipStream_t s) {
     if (rc) return rc;
     rc = debug_after("first_conv", s);
     if (rc) return rc;
-    return timed_end(s, 2.0 * 9.0 * F.K * F.Cin * (double)F.N * F.H * F.W, 0);
+    const double px = (double)F.N * F.H * F.W;
+    return timed_end(s, 2.0 * 9.0 * F.K * F.Cin * px, px * (F.Cin * (F.in_f32 ? 4.0 : 2.0) + F.K * 2.0 * (F.out2 ? 2 : 1)), 0);
 }
 
 struct Plan {                    // one MFMA conv in the launch list
@@ -523,7 +531,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
 
 extern "C" int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                                         int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream,
-                                        int cap, float* h_ms, double* h_flops, int* h_kind, int* n_launches) {
+                                        int cap, float* h_ms, double* h_flops, double* h_bytes, int* h_kind, int* n_launches) {
     LaunchTimer t;
     g_timer = &t;
     int rc = innfer_net_forward(net, d_in, in_dtype, d_out, out_dtype, N, H, W, d_ws, ws_bytes, stream);
@@ -538,6 +546,7 @@ extern "C" int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int 
             (void)hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]);
             if (h_ms) h_ms[i] = ms;
             if (h_flops) h_flops[i] = t.flops[i];
+            if (h_bytes) h_bytes[i] = t.bytes[i];
             if (h_kind) h_kind[i] = t.kind[i];
         }
     }
@@ -560,7 +569,10 @@ extern "C" int innfer_pack_conv3x3(const float* w, int K, int C, void* h_packed)
 
 extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     if (!a || !a->d_in || !a->d_packed || !a->d_bias || !a->d_out) return set_error(INNFER_ERR_INVALID, "conv3x3: null argument");
-    if (a->dilation_groups > 0 ? a->K != 32 * a->dilation_groups : (a->K <= 0 || a->K % 16 || a->K > 64))
+    if (a->pixel_shuffle2) {
+        if (a->K <= 0 || a->K % 64 || a->out_ch_off || a->row_begin || a->row_end || a->dilation > 1 || a->dilation_groups || a->reflect_pad || a->act < 0 || a->act > 2)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the PixelShuffle(2) store needs K %% 64 == 0 (K=%d), out_ch_off 0, act 0..2, all rows, plain zero padding", a->K);
+    } else if (a->dilation_groups > 0 ? a->K != 32 * a->dilation_groups : (a->K <= 0 || a->K % 16 || a->K > 64))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d (need K %% 16 == 0, K <= 64; K = 32 * dilation_groups)", a->K);
     ConvLaunch L{};
     if (a->out_ch_off % 16 || (a->out_ch_off % 32 && a->K > 16))
@@ -573,7 +585,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.res1 = (const f16*)a->d_res1; L.res1_gstride = a->res1_group_stride; L.s1 = a->res1_scale;
     L.res2 = (const f16*)a->d_res2; L.res2_gstride = a->res2_group_stride; L.s2 = a->res2_scale;
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
-    L.out_mode = OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
+    L.out_mode = a->pixel_shuffle2 ? OUT_SHUFFLE2 : OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
     return conv_launch(L, (hipStream_t)stream);
 }
 

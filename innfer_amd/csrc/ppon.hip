@@ -388,7 +388,7 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
     }
     int dy[9], dx[9], d0[1] = {0};
     size_t rbi = 0;
-    static const bool poly = !getenv("INNFER_PPON_POLY") || atoi(getenv("INNFER_PPON_POLY")) != 0;   // 0: grouped gather GEMM (A/B)
+    const bool poly = INNFER_KNOB("INNFER_PPON_POLY", 1) != 0;   // 0: grouped gather GEMM (A/B)
     // one RRBlock: x -> RB1 -> RB2 -> RB3 -> *0.2 + x, written to `dst` (any slab but x and the two scratch slabs)
     auto rrblock = [&](const f16* x, f16* dst, f16* sa, f16* sb) -> int {
         const f16* cur = x;

@@ -35,7 +35,8 @@ namespace {
 struct PostDst { f16* p; long g; int coff; int act; };      // act: 1 lrelu(0.2), 2 relu
 
 // raw fp32 -> (BatchNorm) -> activation -> up to two fp16 blocked-NHWC destinations; 8 channels per thread
-__global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, const float* alpha, const float* shift,
+// alpha / shift: [N][C] (train mode: statistics of each image, nstride = C) or [C] (eval mode: running statistics, nstride = 0)
+__global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, const float* alpha, const float* shift, int nstride,
                           PostDst d0, PostDst d1) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c8 = C / 8;
@@ -49,8 +50,8 @@ __global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, con
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
     if (alpha) {
-        const float* ap = alpha + n * C + c;
-        const float* sp = shift + n * C + c;
+        const float* ap = alpha + n * nstride + c;
+        const float* sp = shift + n * nstride + c;
         const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4), s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = v[e] * a0[e] + s0[e]; v[4 + e] = v[4 + e] * a1[e] + s1[e]; }
@@ -72,8 +73,10 @@ __global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, con
 // registers; the partial results are added in segment order, the statistics are the two-pass form on registers (as norm_stats.h), the
 // result goes to up to two fp16 destinations like unet_post.  part: ks segments of split_elems floats (ks == 1: the GEMM result itself).
 constexpr int DEEP_PX = 64;
+// ev_alpha / ev_shift != nullptr: eval-mode BatchNorm (the per-channel transform of the running statistics) instead of this image's.
 __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long split_elems, int ks, int cpad, int C, int HW, float eps,
-                                                       const float* gamma, const float* beta, PostDst d0, PostDst d1) {
+                                                       const float* gamma, const float* beta, const float* ev_alpha, const float* ev_shift,
+                                                       PostDst d0, PostDst d1) {
     __shared__ float red[1024];
     const int n = blockIdx.y, cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -101,7 +104,9 @@ __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long s
         sum += a;
     }
     float al = 1.f, sh = 0.f;
-    if (gamma) {                                     // train-mode BatchNorm of this image (uniform branch)
+    if (ev_alpha) {
+        if (c < C) { al = ev_alpha[c]; sh = ev_shift[c]; }
+    } else if (gamma) {                              // train-mode BatchNorm of this image (uniform branch)
         const float mu = reduce32(sum) / (float)HW;
         float m2 = 0.f;
 #pragma unroll
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long s
     for (int i = 0; i < DEEP_PX / 32; ++i) {
         const int px = pl + 32 * i;
         if (px >= HW) continue;
-        const float y = gamma ? v[i] * al + sh : v[i];
+        const float y = (gamma || ev_alpha) ? v[i] * al + sh : v[i];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (!ds[k].p) continue;
@@ -188,11 +193,12 @@ struct Layer {            // one conv / conv-transpose
     bool patch = false;                                    // outermost down conv as a 1-tap GEMM on the patch slab (unet_pre_patch)
     bool phases = false;                                   // outermost up conv: the four output phases as 4*cout channels of ONE 3x3-tap GEMM
     int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0;
-    int w = -1, bias = -1, gamma = -1, beta = -1;          // indices into params
+    int w = -1, bias = -1, gamma = -1, beta = -1, rmean = -1, rvar = -1;   // indices into params
     f16* d_w[4] = {nullptr, nullptr, nullptr, nullptr};    // conv: [0]; convT: one panel set per phase, [1..3] point into [0]'s allocation
     long phase_elems = 0;
     void* d_w3 = nullptr; float* d_b3 = nullptr;           // `phases` layer: conv3x3.hip panels [4*cout][cin][3][3] and the bias repeated per phase
     float *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
+    float *d_ev_alpha = nullptr, *d_ev_shift = nullptr;    // eval-mode BatchNorm: weight / sqrt(running_var + eps), bias - running_mean * that
 };
 
 }  // namespace
@@ -203,6 +209,7 @@ struct innfer_unet {
     std::vector<Layer> down, up;       // down[k], up[k] for level k = 0 .. num_downs-1
     std::vector<int> dc;               // down-path channels per level
     bool uploaded = false;
+    bool eval_mode = false;            // BatchNorm on running statistics (nn.Module.eval()) instead of the current image's
 };
 
 static int add_param(innfer_unet* u, const std::string& key, std::vector<int> shape) {
@@ -235,8 +242,8 @@ extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int 
             if (!inner) {
                 d.gamma = add_param(u, blk + "2.weight", {d.cout});
                 d.beta = add_param(u, blk + "2.bias", {d.cout});
-                add_param(u, blk + "2.running_mean", {d.cout});
-                add_param(u, blk + "2.running_var", {d.cout});
+                d.rmean = add_param(u, blk + "2.running_mean", {d.cout});
+                d.rvar = add_param(u, blk + "2.running_var", {d.cout});
                 add_param(u, blk + "2.num_batches_tracked", {});
             }
         }
@@ -264,8 +271,8 @@ extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int 
         } else {
             p.gamma = add_param(u, b + ni + ".weight", {p.cout});
             p.beta = add_param(u, b + ni + ".bias", {p.cout});
-            add_param(u, b + ni + ".running_mean", {p.cout});
-            add_param(u, b + ni + ".running_var", {p.cout});
+            p.rmean = add_param(u, b + ni + ".running_mean", {p.cout});
+            p.rvar = add_param(u, b + ni + ".running_var", {p.cout});
             add_param(u, b + ni + ".num_batches_tracked", {});
         }
     }
@@ -283,6 +290,8 @@ extern "C" void innfer_unet_destroy(innfer_unet* u) {
             if (l.d_bias) (void)hipFree(l.d_bias);
             if (l.d_gamma) (void)hipFree(l.d_gamma);
             if (l.d_beta) (void)hipFree(l.d_beta);
+            if (l.d_ev_alpha) (void)hipFree(l.d_ev_alpha);
+            if (l.d_ev_shift) (void)hipFree(l.d_ev_shift);
         }
     delete u;
 }
@@ -295,6 +304,12 @@ extern "C" int innfer_unet_param_info(innfer_unet* u, int idx, char* key, size_t
     if (key && key_cap) { strncpy(key, p.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
     if (ndim) *ndim = (int)p.shape.size();
     if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_unet_set_eval(innfer_unet* u, int eval_mode) {
+    if (!u) return set_error(INNFER_ERR_INVALID, "unet_set_eval: null handle");
+    u->eval_mode = eval_mode != 0;
     return INNFER_OK;
 }
 
@@ -397,6 +412,21 @@ static int upload_all(innfer_unet* u) {
             if (l.bias >= 0) { int rc = upload_f32(&l.d_bias, u->params[l.bias].host); if (rc) return rc; }
             if (l.gamma >= 0) { int rc = upload_f32(&l.d_gamma, u->params[l.gamma].host); if (rc) return rc; }
             if (l.beta >= 0) { int rc = upload_f32(&l.d_beta, u->params[l.beta].host); if (rc) return rc; }
+            if (l.gamma >= 0) {
+                // eval-mode transform as ATen forms it (batch_norm_cpu_transform_input: alpha = weight / sqrt(running_var + eps),
+                // beta = bias - running_mean * alpha); a checkpoint without running statistics means a fresh BatchNorm's (0, 1)
+                const int C = l.cout;
+                const std::vector<float>&g = u->params[l.gamma].host, &b = u->params[l.beta].host;
+                const Param &pm = u->params[l.rmean], &pv = u->params[l.rvar];
+                std::vector<float> al(C), sh(C);
+                for (int c = 0; c < C; ++c) {
+                    const float mean = pm.set ? pm.host[c] : 0.f, var = pv.set ? pv.host[c] : 1.f;
+                    al[c] = g[c] * (1.0f / std::sqrt(var + 1e-5f));
+                    sh[c] = b[c] - mean * al[c];
+                }
+                int rc = upload_f32(&l.d_ev_alpha, al); if (rc) return rc;
+                rc = upload_f32(&l.d_ev_shift, sh); if (rc) return rc;
+            }
         }
     u->uploaded = true;
     return INNFER_OK;
@@ -468,7 +498,8 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     const int L = u->num_downs;
     if (N <= 0 || H <= 0 || W <= 0 || (H & ((1 << L) - 1)) || (W & ((1 << L) - 1)))
         return set_error(INNFER_ERR_INVALID, "unet_forward: %dx%d must be a multiple of %d", H, W, 1 << L);
-    if ((H >> (L - 1)) * (W >> (L - 1)) < 2)
+    const bool ev = u->eval_mode;
+    if (!ev && (H >> (L - 1)) * (W >> (L - 1)) < 2)
         return set_error(INNFER_ERR_INVALID, "unet_forward: BatchNorm needs more than one value per channel");
     if (!u->uploaded) { int rc = upload_all(u); if (rc) return rc; }
     const UCarve cv = ucarve(u, N, H, W);
@@ -487,17 +518,18 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     auto post = [&](const Layer& l, long HW, bool bn, PostDst d0, PostDst d1) -> int {
         if (HW <= DEEP_PX) {          // deep level: reduce + statistics + post in one launch
             hipLaunchKernelGGL(unet_deep_post, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw,
-                               (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn ? l.d_gamma : nullptr, bn ? l.d_beta : nullptr, d0, d1);
+                               (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn && !ev ? l.d_gamma : nullptr, bn && !ev ? l.d_beta : nullptr,
+                               bn && ev ? l.d_ev_alpha : nullptr, bn && ev ? l.d_ev_shift : nullptr, d0, d1);
             INNFER_HIP(hipGetLastError());
             return INNFER_OK;
         }
-        if (bn) {
+        if (bn && !ev) {
             int rc = norm::launch_stats(raw, l.cout_pad, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
             if (rc) return rc;
         }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(unet_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
-                           bn ? mean : nullptr, bn ? rstd : nullptr, d0, d1);
+                           bn ? (ev ? l.d_ev_alpha : mean) : nullptr, bn ? (ev ? l.d_ev_shift : rstd) : nullptr, ev ? 0 : l.cout, d0, d1);
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     };

@@ -44,7 +44,7 @@ class ConvArgs(C.Structure):
         ("d_res1", C.c_void_p), ("res1_group_stride", C.c_int64), ("res1_scale", C.c_float),
         ("d_res2", C.c_void_p), ("res2_group_stride", C.c_int64), ("res2_scale", C.c_float),
         ("row_begin", C.c_int), ("row_end", C.c_int),
-        ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int),
+        ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int), ("pixel_shuffle2", C.c_int),
     ]
 
 
@@ -65,7 +65,7 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_net_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
-                                           C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                           C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
@@ -75,6 +75,7 @@ SIGNATURES = {
     "innfer_unet_num_params": (C.c_int, [C.c_void_p]),
     "innfer_unet_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "innfer_unet_set_param": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "innfer_unet_set_eval": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -145,7 +146,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 102          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 103          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

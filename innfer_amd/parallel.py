@@ -1,21 +1,31 @@
-"""Multi-GPU chop_forward: tiles sharded over ranks, HR tiles gathered on rank 0.
+"""Multi-GPU chop_forward: tiles sharded over ranks, HR tiles collected on rank 0.
 
 The reference is single-process; the only part of its hot path that shards is
 Model.chop_forward's tile list (run.py:186-197: every tile's forward is independent,
 the blend utils.py:436-443 is the single cross-tile step).  One process per GPU
-(torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests):
+(torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests and in the
+one-GPU rehearsal):
 
-  * every rank holds the (small) LR frame and cuts ITS contiguous range of whole tile
-    rows -- tiles are row-major, so the range is contiguous in the tile list and seams
-    between ranks are horizontal bands only;
+  * every rank holds the (small) LR frame and cuts ITS contiguous range of the row-major
+    tile list.  The split is even over TILES (798 tiles over 8 ranks -> 100,100,100,100,100,100,99,99:
+    99.7 % balanced); SURVEY 8e's whole-tile-row blocks (21 rows -> 3,3,3,3,3,2,2,2: 87.5 %)
+    stay available as shard='rows' -- they only matter for a design that blends per rank,
+    and this one ships raw tiles so that the blend keeps the reference's accumulation order
+    bit for bit;
   * each rank pushes its tiles through the network in batches;
-  * one gather of the raw HR tiles to rank 0 (padded to the largest share; RCCL lowers a
-    gather to direct peer sends, which suits the fully connected 7-link xGMI topology:
-    every peer pushes over its own link), then ONE blend kernel on rank 0;
+  * ONE grouped exchange of the raw HR tiles: every rank r > 0 sends exactly its tiles (no
+    padding) and rank 0 receives each share straight into its slot of the [n,C,P,P] tile
+    buffer the blend kernel reads (RCCL: grouped ncclSend / ncclRecv, every peer pushes over
+    its own xGMI link), then ONE blend kernel on rank 0.  The exchange is issued after the
+    rank's last batch on purpose: the conv kernels are persistent, one workgroup per CU with the
+    whole LDS, so an RCCL kernel spinning on a CU during the compute phase would stretch every
+    layer by a whole tile round (the exchange is <= 5 % of a stage);
   * model chains: the blended intermediate is broadcast before the next stage.
 
 No collective sits inside the per-tile compute.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -30,21 +40,44 @@ def shard_tile_rows(n_rows, n_cols, world, rank):
     return first * n_cols, rows * n_cols
 
 
+def shard_tiles(n_tiles, world, rank):
+    """Contiguous range of the row-major tile list for `rank`: (first_tile, n_tiles); earlier
+    ranks take the remainder (798 tiles over 8 ranks -> 100 x 6, 99 x 2)."""
+    base, rem = divmod(n_tiles, world)
+    return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+
+
+def _sync(t):
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+
+
 class ChopRunner:
     """chop_forward (run.py:167-202) over `world` ranks.
 
-    model_fn   : [n,C,ps,ps] -> [n,C,s*ps,s*ps] (an innfer_amd nn.Module on the GPU)
+    model_fn   : [n,C,ps,ps] -> [n,C',s*ps,s*ps] (an innfer_amd nn.Module on the GPU)
     extract_fn : (img, (ps,ps), [step,step], batch_first, tile_range) -> tiles, default HIP kernel
     recompose_fn: (tiles, H, W, step, scale) -> image, default HIP kernel
     plan_fn    : (H, W, patch, step) -> (ps, ys, xs), default the C ABI's innfer_chop_plan
-    Returns the blended [1,C,sH,sW] tensor on rank 0 and None elsewhere
+    out_channels / out_dtype: shape and dtype of model_fn's output; every rank must agree on them BEFORE the
+                 exchange (a rank may own no tile at all).  Defaults: model_fn.out_nc if it has one, else the
+                 input's channel count; the input's dtype.
+    shard      : 'tiles' (even split of the tile list) or 'rows' (whole tile rows)
+    Returns the blended [1,C',sH,sW] tensor on rank 0 and None elsewhere
     (all ranks get it with broadcast_result=True, used between chained models).
+    With profile=True every phase is bracketed by a device synchronise and `self.last` holds
+    {tiles, compute_ms, exchange_ms, exchange_bytes, blend_ms, bcast_ms} of the call (never in a timed region).
     """
 
     def __init__(self, model_fn, scale, tile_batch=64, patch=200, step=0.5, group=None,
-                 extract_fn=None, recompose_fn=None, plan_fn=None):
+                 extract_fn=None, recompose_fn=None, plan_fn=None, out_channels=None, out_dtype=None,
+                 shard='tiles', profile=False):
+        if shard not in ('tiles', 'rows'):
+            raise ValueError("shard must be 'tiles' or 'rows'")
         self.model_fn, self.scale, self.tile_batch = model_fn, scale, tile_batch
         self.patch, self.step, self.group = patch, step, group
+        self.out_channels, self.out_dtype, self.shard, self.profile = out_channels, out_dtype, shard, profile
+        self.last = {}
         if extract_fn is None or recompose_fn is None or plan_fn is None:
             from . import lib as L
             from .utils import utils as U
@@ -58,44 +91,100 @@ class ChopRunner:
             return dist.get_world_size(self.group), dist.get_rank(self.group)
         return 1, 0
 
+    def _peer(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _share(self, n_rows, n_cols, world, rank):
+        if self.shard == 'rows':
+            return shard_tile_rows(n_rows, n_cols, world, rank)
+        return shard_tiles(n_rows * n_cols, world, rank)
+
+    def _staged(self, t):
+        """gloo moves host memory only: the one-GPU rehearsal (all ranks on one device) stages through the host."""
+        return t.is_cuda and dist.get_backend(self.group) == 'gloo'
+
     def __call__(self, data, broadcast_result=False):
         world, rank = self._world()
+        prof = self.profile
         _, C, H, W = data.shape
         ps, ys, xs = self.plan_fn(H, W, self.patch, self.step)
         n_rows, n_cols = len(ys), len(xs)
-        first, count = shard_tile_rows(n_rows, n_cols, world, rank)
+        n = n_rows * n_cols
+        first, count = self._share(n_rows, n_cols, world, rank)
         P = ps * self.scale
-        outs = []
+        out_c = self.out_channels or getattr(self.model_fn, 'out_nc', None) or C
+        dtype = self.out_dtype or data.dtype
+        if prof:
+            _sync(data)
+            t0 = time.perf_counter()
+        # rank 0 owns the whole [n,C',P,P] buffer the blend reads, the others only their share; batches land in place
+        hr = torch.empty((n if rank == 0 else count, out_c, P, P), dtype=dtype, device=data.device)
         if count:
             tiles = self.extract_fn(data, (ps, ps), [self.step, self.step], batch_first=True,
                                     tile_range=(first, count)).squeeze(0)
+            base = first if rank == 0 else 0
             with torch.no_grad():
                 for i in range(0, count, self.tile_batch):
-                    outs.append(self.model_fn(tiles[i:i + self.tile_batch]))
-        if world == 1:
-            hr = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
-            return self.recompose_fn(hr, H, W, step=self.step, scale=self.scale)
-
-        # ---- gather the HR tiles on rank 0 (shares padded to the largest one) ----
-        max_count = shard_tile_rows(n_rows, n_cols, world, 0)[1]
-        dtype = outs[0].dtype if outs else data.dtype
-        out_c = outs[0].shape[1] if outs else getattr(self.model_fn, 'out_nc', C)    # a rank without tiles (more ranks than tile rows)
-        send = torch.zeros((max_count, out_c, P, P), dtype=dtype, device=data.device)
-        if count:
-            send[:count] = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
-        del outs
-        gathered = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-        dist.gather(send, gathered, dst=0, group=self.group)
+                    y = self.model_fn(tiles[i:i + self.tile_batch])
+                    if y.shape[1:] != hr.shape[1:] or y.dtype != hr.dtype:
+                        raise RuntimeError(f'ChopRunner: model_fn returned {tuple(y.shape[1:])} {y.dtype}, every rank was told '
+                                           f'{tuple(hr.shape[1:])} {hr.dtype} (set out_channels / out_dtype)')
+                    hr[base + i:base + i + y.shape[0]].copy_(y)
+                    del y
+            del tiles
+        if prof:
+            _sync(data)
+            t1 = time.perf_counter()
+        xbytes = 0
+        if world > 1:
+            # ---- grouped point-to-point exchange: real tiles only, received in place ----
+            ops, stage = [], []
+            if rank == 0:
+                for r in range(1, world):
+                    f, c = self._share(n_rows, n_cols, world, r)
+                    if not c:
+                        continue
+                    dst = hr[f:f + c]
+                    xbytes += dst.numel() * dst.element_size()
+                    if self._staged(dst):
+                        buf = torch.empty(dst.shape, dtype=dst.dtype, device='cpu')
+                        stage.append((dst, buf))
+                        dst = buf
+                    ops.append(dist.P2POp(dist.irecv, dst, self._peer(r), self.group))
+            elif count:
+                src = hr.cpu() if self._staged(hr) else hr
+                xbytes = hr.numel() * hr.element_size()
+                ops.append(dist.P2POp(dist.isend, src, self._peer(0), self.group))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for dst, buf in stage:
+                dst.copy_(buf)
+        if prof:
+            _sync(data)
+            t2 = time.perf_counter()
         result = None
         if rank == 0:
-            parts = [gathered[r][:shard_tile_rows(n_rows, n_cols, world, r)[1]] for r in range(world)]
-            hr = torch.cat(parts, 0)
-            del gathered, parts
             result = self.recompose_fn(hr, H, W, step=self.step, scale=self.scale)
-        if broadcast_result:
+        del hr
+        if prof:
+            _sync(data)
+            t3 = time.perf_counter()
+        if broadcast_result and world > 1:
             if rank != 0:
                 result = torch.empty((1, out_c, H * self.scale, W * self.scale), dtype=dtype, device=data.device)
-            dist.broadcast(result, src=0, group=self.group)
+            if self._staged(result):
+                buf = result.cpu() if rank == 0 else torch.empty(result.shape, dtype=dtype, device='cpu')
+                dist.broadcast(buf, src=self._peer(0), group=self.group)
+                if rank != 0:
+                    result.copy_(buf)
+            else:
+                dist.broadcast(result, src=self._peer(0), group=self.group)
+        if prof:
+            _sync(data)
+            t4 = time.perf_counter()
+            self.last = {'tiles': count, 'tiles_total': n, 'compute_ms': (t1 - t0) * 1e3, 'exchange_ms': (t2 - t1) * 1e3,
+                         'exchange_bytes': xbytes, 'blend_ms': (t3 - t2) * 1e3, 'bcast_ms': (t4 - t3) * 1e3}
         return result
 
 

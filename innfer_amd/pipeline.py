@@ -15,24 +15,27 @@ from .utils.utils import _dt
 
 class FramePipeline:
     """`for out in FramePipeline(model, scale)(frames)`: frames are uint8 HWC BGR numpy arrays of ONE
-    shape; yields uint8 HWC BGR numpy arrays (views of pinned buffers, valid until `depth` further frames
-    have been produced -- copy them if they must live longer)."""
+    shape; yields uint8 HWC BGR numpy arrays.  A yielded array is a view of a pinned buffer that stays untouched until the
+    NEXT frame has been yielded (the pipeline owns depth + 1 output buffers: `depth` in flight and the one lent out) -- copy it if
+    it must live longer than that."""
 
     def __init__(self, model, scale, device='cuda', half=True, normalize=False, depth=3, color_fix=False):
         self.model, self.scale, self.dev = model, scale, torch.device(device)
         self.half, self.normalize, self.depth, self.cf = half, normalize, max(2, depth), color_fix
         self.s_in, self.s_out = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
         self._slots = None
+        self._free_out, self._lent = [], None
 
     def _alloc(self, shape):
         H, W, C = shape
         s = self.scale
         self._slots = [dict(h_in=torch.empty((H, W, C), dtype=torch.uint8).pin_memory(),
                             d_in=torch.empty((H, W, C), dtype=torch.uint8, device=self.dev),
-                            d_out=torch.empty((H * s, W * s, C), dtype=torch.uint8, device=self.dev),
-                            h_out=torch.empty((H * s, W * s, C), dtype=torch.uint8).pin_memory(),
+                            d_out=torch.empty((H * s, W * s, C), dtype=torch.uint8, device=self.dev), h_out=None,
                             up=torch.cuda.Event(), done=torch.cuda.Event(), down=torch.cuda.Event(), busy=False)
                        for _ in range(self.depth)]
+        self._free_out = [torch.empty((H * s, W * s, C), dtype=torch.uint8).pin_memory() for _ in range(self.depth + 1)]
+        self._lent = None
         self._ws_cf = None
 
     def _compute(self, sl, shape):
@@ -72,6 +75,7 @@ class FramePipeline:
                 sl['d_in'].copy_(sl['h_in'], non_blocking=True)
                 sl['up'].record(self.s_in)
             self._compute(sl, img.shape)
+            sl['h_out'] = self._free_out.pop()         # never the buffer lent to the consumer: that one returns in _finish
             with torch.cuda.stream(self.s_out):
                 self.s_out.wait_event(sl['done'])
                 sl['h_out'].copy_(sl['d_out'], non_blocking=True)
@@ -82,8 +86,10 @@ class FramePipeline:
         while pending:
             yield self._finish(pending.pop(0))
 
-    @staticmethod
-    def _finish(sl):
+    def _finish(self, sl):
         sl['down'].synchronize()
         sl['busy'] = False
-        return sl['h_out'].numpy()
+        if self._lent is not None:                     # the consumer asked for another frame: the previous one's buffer is free again
+            self._free_out.append(self._lent)
+        self._lent, sl['h_out'] = sl['h_out'], None
+        return self._lent.numpy()

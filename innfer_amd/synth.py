@@ -80,4 +80,16 @@ def fill_state_dict(shapes, seed=0, bias_scale=1.0):
     return out
 
 
+def fill_running_stats(sd, seed=0):
+    """Non-trivial BatchNorm running statistics for a state dict made by fill_state_dict (which leaves a fresh BatchNorm's 0 / 1):
+    running_mean uniform in +-0.25, running_var in [0.5, 1.5).  Returns a new dict."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if k.endswith("running_mean"):
+            out[k] = uniform(v.shape, key_seed(k, seed), -0.25, 0.25)
+        elif k.endswith("running_var"):
+            out[k] = uniform(v.shape, key_seed(k, seed), 0.5, 1.5)
+    return out
+
+
 from .architectures.keys import mrrdbnet_shapes, rrdbnet_shapes, srresnet_shapes  # noqa: E402,F401

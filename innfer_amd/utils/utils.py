@@ -31,6 +31,11 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _on(t):
+    """The library launches on the process's current HIP device: make it the tensor's for the call."""
+    return torch.cuda.device(t.device)
+
+
 def extract_patches_2d(img, patch_shape, step=None, batch_first=False, tile_range=None):
     """[1,C,H,W] -> [n,1,C,ph,pw] ([1,n,C,ph,pw] when batch_first): sliding tiles
     with stride int(patch*step) plus a ragged last row/column (utils.py:318-369).
@@ -52,7 +57,8 @@ def extract_patches_2d(img, patch_shape, step=None, batch_first=False, tile_rang
     begin, count = tile_range if tile_range is not None else (0, n)
     img = img.contiguous()
     tiles = torch.empty((count, C, ps, ps), dtype=img.dtype, device=img.device)
-    L.check(L.lib.innfer_extract_tiles(img.data_ptr(), _dt(img), C, H, W, ph, step[0], begin, count,
+    with _on(img):
+        L.check(L.lib.innfer_extract_tiles(img.data_ptr(), _dt(img), C, H, W, ph, step[0], begin, count,
                                        tiles.data_ptr(), _stream(img)))
     out = tiles.unsqueeze(1)                       # [n, B=1, C, ph, pw]
     return out.permute(1, 0, 2, 3, 4) if batch_first else out
@@ -76,8 +82,9 @@ def recompose_tensor(patches, height, width, step=None, scale=1, out_dtype=None)
     dtype = out_dtype or patches.dtype
     out = torch.empty((nb, C, FH, FW), dtype=dtype, device=patches.device)
     odt = L.F16 if dtype == torch.float16 else L.F32
-    L.check(L.lib.innfer_recompose(patches.data_ptr(), _dt(patches), n, C, P, height, width, float(step), scale,
-                                   out.data_ptr(), odt, _stream(patches)))
+    with _on(patches):
+        L.check(L.lib.innfer_recompose(patches.data_ptr(), _dt(patches), n, C, P, height, width, float(step), scale,
+                                       out.data_ptr(), odt, _stream(patches)))
     return out
 
 
@@ -93,8 +100,9 @@ def np2tensor(img, bgr2rgb=True, data_range=1., normalize=False, change_range=Tr
     H, W, Cc = img.shape
     d_img = torch.from_numpy(np.ascontiguousarray(img)).to(device)
     out = torch.empty((1, Cc, H, W), dtype=dtype, device=d_img.device)
-    L.check(L.lib.innfer_u8hwc_to_nchw(d_img.data_ptr(), H, W, Cc, int(bool(normalize)), out.data_ptr(),
-                                       _dt(out), _stream(out)))
+    with _on(out):
+        L.check(L.lib.innfer_u8hwc_to_nchw(d_img.data_ptr(), H, W, Cc, int(bool(normalize)), out.data_ptr(),
+                                           _dt(out), _stream(out)))
     return out
 
 
@@ -112,8 +120,9 @@ def tensor2np(img, rgb2bgr=True, remove_batch=True, data_range=255, denormalize=
     img = img.contiguous()
     _, Cc, H, W = img.shape
     out = torch.empty((H, W, Cc), dtype=torch.uint8, device=img.device)
-    L.check(L.lib.innfer_nchw_to_u8hwc(img.data_ptr(), _dt(img), H, W, Cc, int(bool(denormalize)),
-                                       out.data_ptr(), _stream(img)))
+    with _on(img):
+        L.check(L.lib.innfer_nchw_to_u8hwc(img.data_ptr(), _dt(img), H, W, Cc, int(bool(denormalize)),
+                                           out.data_ptr(), _stream(img)))
     return out.cpu().numpy()
 
 
@@ -134,8 +143,9 @@ def color_fix(imgA, imgB, device='cuda'):
     d_b = torch.from_numpy(np.ascontiguousarray(imgB)).to(device)
     out = torch.empty((hB, wB, Cc), dtype=torch.uint8, device=d_a.device)
     ws = torch.empty(L.lib.innfer_color_fix_workspace_bytes(hA, wA, hB, wB, Cc), dtype=torch.uint8, device=d_a.device)
-    L.check(L.lib.innfer_color_fix(d_a.data_ptr(), hA, wA, d_b.data_ptr(), hB, wB, Cc, out.data_ptr(),
-                                   ws.data_ptr(), ws.numel(), _stream(out)))
+    with _on(out):
+        L.check(L.lib.innfer_color_fix(d_a.data_ptr(), hA, wA, d_b.data_ptr(), hB, wB, Cc, out.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream(out)))
     return out.cpu().numpy()
 
 
@@ -158,8 +168,9 @@ def guided_filter(x, y, x_HR=None, ks=None, r=None, eps=1e-2, box_kernel=None, m
     B, Cc, H, W = x.shape
     out = torch.empty_like(x)
     ws = torch.empty(L.lib.innfer_guided_filter_workspace_bytes(B, Cc, H, W), dtype=torch.uint8, device=x.device)
-    L.check(L.lib.innfer_guided_filter(x.data_ptr(), y.data_ptr(), _dt(x), B, Cc, H, W, float(eps), out.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), _stream(x)))
+    with _on(x):
+        L.check(L.lib.innfer_guided_filter(x.data_ptr(), y.data_ptr(), _dt(x), B, Cc, H, W, float(eps), out.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _stream(x)))
     return out
 
 

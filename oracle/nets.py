@@ -123,13 +123,17 @@ def srresnet_forward(sd, x, nb=16, scale=4):
     return _conv3(sd, f"model.{idx + 2}", t)
 
 
-def unet_forward(sd, x, num_downs=8, eps=1e-5):
-    """UnetGenerator(norm=batch, deconv).forward with BatchNorm in TRAINING mode
-    (batch statistics), as run.py runs pix2pix (meval=False, run.py:299-303).
-    UNet_arch.py:107-161.  x: [N,3,256,256]; BN statistics are over the batch
+def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True):
+    """UnetGenerator(norm=batch, deconv).forward.  training=True: BatchNorm in TRAINING mode
+    (batch statistics), as run.py runs pix2pix (meval=False, run.py:299-303); training=False:
+    eval mode on the checkpoint's running statistics (Model's default meval=True, run.py:96-97).
+    UNet_arch.py:107-161.  x: [N,3,256,256]; training-mode statistics are over the batch
     given (callers loop batch-1 for the per-image semantics of SURVEY D6)."""
 
     def bn(t, key):
+        if not training:
+            return F.batch_norm(t, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"],
+                                training=False, momentum=0.0, eps=eps)
         return F.batch_norm(t, None, None, sd[key + ".weight"], sd[key + ".bias"],
                             training=True, momentum=0.0, eps=eps)
 

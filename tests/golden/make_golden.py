@@ -386,7 +386,46 @@ def g12():
     save("g12_defaults", table=np.array(json.dumps(rows, sort_keys=True)))
 
 
+# ---------------------------------------------------------------- G17: the reference's own fp16 mode for the normalised generators
+def g17():
+    """(a) pix2pix UNet_256 and CycleGAN ResNet-9 in the reference's fp16 mode (`net.half()`, run.py:383) on the inputs of G7 / G14, run
+    on the CPU: separates "fp16 rounding of a network with BatchNorm / InstanceNorm + tanh" from "kernel bug" the way G11 does for RRDBNet;
+    (b) UNet_256 in EVAL mode (Model's default meval=True, run.py:96-97) on non-trivial running statistics, fp32."""
+    out = {}
+    net = ref_net("unet_256", 1)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, 0)
+    net.load_state_dict(t_sd(sd), strict=True)
+    net.train()
+    xa = torch.from_numpy(synth.uniform((1, 3, 256, 256), 7, -1.0, 1.0))
+    with torch.no_grad():
+        y32 = net(xa)
+        yh = net.half()(xa.half()).float()
+    out["unet_fp16_out_a"] = yh.numpy().astype(np.float16)
+    out["unet_fp16_err_vs_fp32"] = np.array([(yh - y32).abs().max().item(), (yh - y32).abs().mean().item()], np.float32)
+    net = ref_net("unet_256", 1)
+    sd_ev = synth.fill_running_stats(sd, 17)
+    net.load_state_dict(t_sd(sd_ev), strict=True)
+    net.eval()
+    with torch.no_grad():
+        yev = net(xa)
+    out["unet_eval_out_a"] = yev.numpy().astype(np.float16)
+    out["unet_eval_out_a_sub"] = yev[0, :, ::4, ::4].numpy()
+    net = ref_net("resnet_9blocks", 1)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(t_sd(synth.fill_state_dict(shapes, 0)), strict=True)
+    net.eval()
+    for (h, w, seed) in [(32, 40, 15), (64, 64, 16)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0))
+        with torch.no_grad():
+            y32 = net.float()(x)
+            yh = net.half()(x.half()).float()
+        out[f"resnet_fp16_out_{h}x{w}"] = yh.numpy()
+        out[f"resnet_fp16_err_vs_fp32_{h}x{w}"] = np.array([(yh - y32).abs().max().item(), (yh - y32).abs().mean().item()], np.float32)
+    save("g17_fp16_and_eval", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17"]
     for g in which:
         globals()[g]()

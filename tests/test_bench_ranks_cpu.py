@@ -1,0 +1,67 @@
+"""bench.py's N > 1 entry without a launcher (`python bench.py --gpus N`): the parent starts N fresh rank processes before
+anything touches a GPU, the ranks rendezvous, time the contract's region (barriers, max over ranks) and rank 0 prints ONE
+JSON line.  INNFER_BENCH_SELFTEST=1 replaces the HIP workload by a sleep so that this control flow runs on the CPU box;
+the same flow with the real kernels is tests/test_gpu_sharded.py::test_bench_two_ranks_dry_run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from innfer_amd.parallel import shard_tile_rows, shard_tiles
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=300):
+    env = dict(os.environ, INNFER_BENCH_SELFTEST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_gpus_flag_starts_n_ranks_and_prints_one_line(n):
+    r = _run(["--gpus", str(n), "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == n and line["ranks_seen"] == n
+    assert line["steps"] == 3 and line["warmup"] == 1
+    assert line["ms_per_step"] >= 2.0                    # the 2 ms sleep of every step is inside the timed region
+
+
+def test_launcher_env_wins_over_the_flag():
+    """Under torch.distributed.run the ranks already exist: bench.py must not spawn again (world size from the environment)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, INNFER_BENCH_SELFTEST="1", WORLD_SIZE="2", RANK=str(rank), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1000:] for o in outs]
+    assert json.loads(outs[0][0].strip().splitlines()[-1])["n_gpus"] == 2
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # only rank 0 prints the line (gloo itself chats on stdout)
+
+
+def test_a_failing_rank_fails_the_run():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "nonsense"])
+    assert r.returncode != 0
+
+
+def test_shard_tiles_is_an_even_contiguous_partition():
+    for n, world in [(798, 8), (3268, 8), (6, 4), (3, 7), (0, 2), (798, 1)]:
+        shares = [shard_tiles(n, world, r) for r in range(world)]
+        assert shares[0][0] == 0 and sum(c for _, c in shares) == n
+        for (f0, c0), (f1, _) in zip(shares, shares[1:]):
+            assert f1 == f0 + c0
+        counts = [c for _, c in shares]
+        assert max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
+    assert [shard_tiles(798, 8, r)[1] for r in range(8)] == [100] * 6 + [99] * 2
+    assert [shard_tile_rows(43, 76, 8, r)[1] // 76 for r in range(8)] == [6, 6, 6, 5, 5, 5, 5, 5]

@@ -33,7 +33,7 @@ def _plan(H, W, patch, step):
     return oracle.chop_geometry(H, W, patch, step)
 
 
-def _worker(rank, world, port, h, w, q):
+def _worker(rank, world, port, h, w, q, shard='tiles'):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -44,12 +44,18 @@ def _worker(rank, world, port, h, w, q):
         f1 = lambda t: oracle.rrdbnet_forward(sd1, t, nb=1, scale=1)
         f2 = lambda t: oracle.rrdbnet_forward(sd2, t, nb=1, scale=2)
         x = torch.from_numpy(synth.uniform((1, 3, h, w), 5))
-        kw = dict(extract_fn=_extract, recompose_fn=otiles.recompose_tensor, plan_fn=_plan, tile_batch=2)
+        kw = dict(extract_fn=_extract, recompose_fn=otiles.recompose_tensor, plan_fn=_plan, tile_batch=2, shard=shard, profile=True)
         r1 = ChopRunner(f1, 1, **kw)
         r2 = ChopRunner(f2, 2, **kw)
         with torch.no_grad():
             y = r2(x)                                   # single stage
             z = run_chain([r1, r2], x)                  # chain 1x + 2x
+        first, count = r2._share(*[len(v) for v in _plan(h, w, 200, 0.5)[1:]], world, rank)
+        assert r2.last['tiles'] == count and r2.last['tiles_total'] >= count
+        # real tiles only: a sender moves exactly its share, rank 0 receives everybody else's
+        tile_bytes = 3 * (400 ** 2) * 4
+        want = (r2.last['tiles_total'] - count if rank == 0 else count) * tile_bytes
+        assert r2.last['exchange_bytes'] == want, (r2.last, want)
         if rank == 0:
             q.put((y.numpy(), z.numpy()))
         else:
@@ -59,12 +65,14 @@ def _worker(rank, world, port, h, w, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h,w,world", [(250, 330, 2), (250, 330, 3)])      # 2 tile rows: with 3 ranks the last one has no tiles
-def test_sharded_chop_equals_single_process(h, w, world):
+# 250x330: 2 tile rows x 3 columns.  shard='rows' with 3 ranks leaves the last one without tiles; shard='tiles' with 4 ranks
+# gives 2,2,1,1 (ranges that split a tile row); 7 ranks: one rank has nothing to send
+@pytest.mark.parametrize("h,w,world,shard", [(250, 330, 2, 'tiles'), (250, 330, 3, 'rows'), (250, 330, 4, 'tiles'), (250, 330, 7, 'tiles')])
+def test_sharded_chop_equals_single_process(h, w, world, shard):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, q, shard)) for r in range(world)]
     for p in procs:
         p.start()
     y, z = q.get(timeout=240)
