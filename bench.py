@@ -338,7 +338,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="frame1080", choices=WORKLOADS)
     ap.add_argument("--band-rows", type=int, default=0)
-    ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch")
+    ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch (0 = innfer_amd.parallel.tile_batches: evenly sized launches of <= 272 tiles)")
     ap.add_argument("--sharded-steps", type=int, default=2, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -420,10 +420,10 @@ def main():
         """(step, H, W, description, runners) of a tile-sharded workload over the current ranks."""
         H, W = (4320, 7680) if workload == "chop8k" else (2160, 3840)
         x = torch.from_numpy(synth.uniform((1, 3, H, W), 2)).to(dev).half()
-        r4 = parallel.ChopRunner(net, scale=4, tile_batch=args.tile_batch or 64, profile=profile)
+        r4 = parallel.ChopRunner(net, scale=4, tile_batch=args.tile_batch or None, profile=profile)
         if workload == "chain4k":                   # BASELINE config 4: model chain 1x + 4x (run.py:424-426)
             net1, _ = build_net(dev, scale=1)
-            r1 = parallel.ChopRunner(net1, scale=1, tile_batch=args.tile_batch or 64, profile=profile)
+            r1 = parallel.ChopRunner(net1, scale=1, tile_batch=args.tile_batch or None, profile=profile)
             return (lambda: parallel.run_chain([r1, r4], x)), H, W, "model chain RRDBNet-23 1x + RRDBNet-23 4x", [r1, r4]
         return (lambda: r4(x)), H, W, "ESRGAN RRDBNet-23 4x", [r4]
 

@@ -99,6 +99,7 @@ struct KP {
     int reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d(1)) instead of zero; not with `up`
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
     int total;               // tiles x channel groups of this launch
+    int cv_gx, cv_gy, cv_h1, cv_w1;   // CV kernels (image canvas): the N images are the cells of a cv_gx x cv_gy grid, cell pitch (H + 1) x (W + 1)
 #ifdef INNFER_ABLATE
     int abl;                 // diagnostic build only: 1 no stores, 2 no weight DMA, 4 no input DMA, 8 no MFMA phase
 #endif
@@ -111,6 +112,63 @@ struct KP {
 // lifetime of a 64->32 workgroup: profiles/r1/wg_timeline_r1c.txt.)
 // POLY: (n, y, x) address a polyphase sub-image of a dilation-d conv: image n / d^2, phase (py, px) = (n % d^2) / d, % d, full-resolution
 // pixel (y*d + py, x*d + px); the sub-image ends where the full image does.  No residuals in that mode.
+// CV (image canvas, see conv3x3_pc): (ty0, tx0) are canvas coordinates; a pixel tile may lie in the cell below / right of the tile's first
+// cell, or on the one-pixel gutter between cells (not stored).  Same arithmetic, per-pixel-tile addresses.
+template <int RPW, int NT, int ACT, bool R1, bool R2>
+__device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2 * RPW], int ty0, int tx0, int wave, int li, int cbase) {
+    constexpr int MT = 2 * RPW;
+    const int oc0 = cbase + p.out_coff;
+    const int cyB = ty0 / p.cv_h1, yB = ty0 - cyB * p.cv_h1 + wave * RPW;        // wave-uniform
+    const int cxB = tx0 / p.cv_w1, xB = tx0 - cxB * p.cv_w1 + li;
+    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + (oc0 & 31);
+    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + (cbase & 31) : nullptr;
+    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + (cbase & 31) : nullptr;
+    bool ok[MT];
+    int off[MT];                                   // element offset of the pixel inside a channel group (< 2^31: checked by the host)
+    f16x4 r1[R1 ? MT : 1][NT], r2[R2 ? MT : 1][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        int y = yB + (m >> 1), cy = cyB;
+        if (y >= p.cv_h1) { y -= p.cv_h1; ++cy; }
+        int x = xB + (m & 1) * 16, cx = cxB;
+        if (x >= p.cv_w1) { x -= p.cv_w1; ++cx; }
+        const int n = cy * p.cv_gx + cx;
+        ok[m] = y < p.H && x < p.W && cy < p.cv_gy && cx < p.cv_gx && n < p.N;
+        off[m] = ((n * p.H + y) * p.W + x) * 32;
+        if (R1 && !R2 && ok[m]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + 4 * t);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (!ok[m]) continue;
+        f16* op = ob + off[m];
+        if (R2) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + 4 * t);
+                r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + off[m] + 4 * t);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = acc[t][m][j];
+                if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
+                if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
+                FP32_VALUE(f);
+                h[j] = (f16)f;
+            }
+            *(f16x4*)(op + 4 * t) = h;
+        }
+    }
+}
+
 template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase, int dil = 1) {
@@ -539,7 +597,13 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 // folded into the addressing): the loader's pixel steps and the epilogue's store steps are d pixels, everything else is unchanged.
 // TM: tap mask (bit r*3 + s).  A 1x1 conv is the centre tap only (TM = 0x10): the weight panel then holds, the loaders stage and the consumers
 // multiply ONE tap instead of nine (panels from conv_pack_taps).
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TM = 0x1FF>
+// CV: image canvas.  A batch of N equally sized images (the 200 x 200 tiles of chop_forward: 7 x 32 columns and 9 x 24 rows cover 224 x 216, 21 %
+// of the MFMA work on pixels that do not exist) is tiled as ONE canvas: the images are the cells of a cv_gx x cv_gy grid with a one-pixel gutter
+// to the right of and below every cell (cell pitch (H + 1) x (W + 1)), and the 32-pixel-wide tile lattice runs over the whole canvas.  A gutter
+// pixel is staged as zeros -- the zero padding of BOTH neighbouring images -- and never stored; a tile that straddles cells stages / stores each
+// pixel at its own image's address (per-lane offsets, derived once per tile; tiles inside one cell take the plain path).  64 tiles of 200 x 200:
+// 3417 canvas tiles instead of 4032.  Results are bit-identical to the per-image lattice: every output pixel sees the same operands in the same order.
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false>
 __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int NCW = 8;                       // consumer waves; NLW loader waves
     constexpr int TH = NCW * RPW;
@@ -650,6 +714,31 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                         ok = ok && Y >= 0 && Y < Hp && X >= 0 && X < Wp;
                     }
                     voff[k] = ok ? lpix[POLY ? k : 0] * d + loff[k] : OOB;
+                }
+                return;
+            }
+            if constexpr (CV) {
+                const int uy = ty0 - 1 + p.cv_h1, ux = tx0 - 1 + p.cv_w1;                 // first halo pixel, shifted by one cell so that it is >= 0
+                const int qy = uy / p.cv_h1, qx = ux / p.cv_w1;
+                const int cyA = qy - 1, yA = uy - qy * p.cv_h1, cxA = qx - 1, xA = ux - qx * p.cv_w1;
+                const int nA = cyA * p.cv_gx + cxA;
+                if (cyA >= 0 && cxA >= 0 && cxA < p.cv_gx && nA < p.N && yA + LH <= p.H && xA + LVALID <= p.W) {
+                    in_tile = (const char*)(p.in + (long)nA * p.in_img_stride) + ((long)yA * p.Ws + xA) * 64;       // inside one image: plain path
+                    return;
+                }
+                in_tile = (const char*)p.in;                                              // offsets from the first image's origin, per lane
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) {
+                    const int px = (lw + NLW * k) * 16 + (lane >> 2);
+                    const int ly = px / LWP, lx = px - ly * LWP;
+                    int y = yA + ly, cy = cyA;
+                    if (y >= p.cv_h1) { y -= p.cv_h1; ++cy; }
+                    int x = xA + lx, cx = cxA;
+                    if (x >= p.cv_w1) { x -= p.cv_w1; ++cx; }
+                    const int nn = cy * p.cv_gx + cx;
+                    const bool ok = loff[k] != OOB && y < p.H && x < p.W && cy >= 0 && cx >= 0 && cy < p.cv_gy && cx < p.cv_gx && nn < p.N;
+                    const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
+                    voff[k] = ok ? (((nn * p.H + y) * p.W + x) * 32 + slot * 8) * 2 : OOB;
                 }
                 return;
             }
@@ -820,7 +909,17 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
         if (++c == p.nchunks) {
             c = 0;
             jt += slots;
-            if constexpr (OUTMODE == OUT_SLAB) {
+            if constexpr (OUTMODE == OUT_SLAB && CV) {
+#define EPI(A, B, C) epilogue_slab_cv<RPW, NT, A, B, C>(p, acc, ty0, tx0, cw, li, cbase)
+            if (!p.res1) {
+                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
+            } else if (!p.res2) {
+                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
+            } else {
+                if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
+            }
+#undef EPI
+            } else if constexpr (OUTMODE == OUT_SLAB) {
 #define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
@@ -870,7 +969,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false, int TM = 0x1FF>
+template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 // Per-device state (a process may drive several GPUs): CU count, and which devices already carry a kernel's
@@ -930,17 +1029,50 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
     return INNFER_OK;
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM>
+// Image canvas for a batch (conv3x3_pc<.., CV>): the grid (columns x rows of cells) with the fewest tiles, or 0 columns when the per-image lattice
+// is at least as good (one image, images that already are whole tiles) or the form does not apply.
+template <int TH>
+int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
+    const long plain = (long)N * ((k.W + TW - 1) / TW) * ((k.H + TH - 1) / TH);
+    *tiles = plain; *gy = 0;
+    if (N < 2 || k.up || k.reflect || k.act >= 3 || k.y0 != 0 || k.y1 != k.H || k.H < TH + 2 || k.W < LVALID || k.nrate || k.dil > 1 ||
+        (long)N * k.H * k.W * 64 >= 0x7fffffffL)
+        return 0;
+    int best = 0;
+    for (int gx = 1; gx <= N; ++gx) {
+        const int g_y = (N + gx - 1) / gx;
+        const long t = (long)((gx * (k.W + 1) + TW - 1) / TW) * ((g_y * (k.H + 1) + TH - 1) / TH);
+        if (t < *tiles) { *tiles = t; best = gx; *gy = g_y; }
+    }
+    return *tiles * 100 <= plain * 98 ? best : 0;         // worth it from 2 % fewer tiles
+}
+
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
     constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + __builtin_popcount(TM) * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && TM == 0x1FF && !CV) {      // a batch of images whose size is not a whole number of tiles
+        int gy = 0; long t = 0;
+        const int gx = INNFER_KNOB("INNFER_CANVAS", 1) ? canvas_grid<TH>(kp, N, &gy, &t) : 0;
+        if (gx > 0) {
+            KP kc = kp;
+            kc.cv_gx = gx; kc.cv_gy = gy; kc.cv_h1 = kp.H + 1; kc.cv_w1 = kp.W + 1;
+            return launch_pc<RPW, NT, NLW, OUTMODE, false, false, 0x1FF, true>(kc, N, s);
+        }
+    }
     static unsigned long long attr_done = 0;
-    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM>, LDS, attr_done)) return rc;
+    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
+    k.N = N;
     long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
+    if constexpr (CV) {                       // one canvas instead of N images
+        k.tiles_x = (k.cv_gx * k.cv_w1 + TW - 1) / TW;
+        k.tiles_y = (k.cv_gy * k.cv_h1 + TH - 1) / TH;
+        total = (long)k.tiles_x * k.tiles_y * k.KG;
+    }
     if (POLY && k.nrate > 0) {               // N = images here; rate g has N * g^2 sub-images with their own tile grid
         total = 0;
         for (int g = 0; g < k.nrate; ++g) {
@@ -954,7 +1086,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }

@@ -47,6 +47,23 @@ def shard_tiles(n_tiles, world, rank):
     return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
 
 
+MAX_TILE_BATCH = 272
+
+
+def tile_batches(count, tile_batch=None):
+    """Sizes of the network launches for `count` tiles.  tile_batch=None: as few launches as fit `MAX_TILE_BATCH` tiles each, evenly sized
+    (798 tiles -> 3 x 266).  A launch tiles its whole batch as ONE canvas (csrc/conv3x3.hip, conv3x3_pc<.., CV>) whose tile count is then
+    rounded up to whole rounds of 256 workgroups: 64 tiles of 200^2 are 13.35 rounds (93 % useful), 266 are 54.8 (98 %); the workspace
+    of 272 tiles of 200^2 is 64 GB of the 288 GB.  A number: fixed-size launches (the last one takes the remainder)."""
+    if count <= 0:
+        return []
+    if tile_batch:
+        return [min(tile_batch, count - i) for i in range(0, count, tile_batch)]
+    nb = -(-count // MAX_TILE_BATCH)
+    base, rem = divmod(count, nb)
+    return [base + (1 if i < rem else 0) for i in range(nb)]
+
+
 def _sync(t):
     if t.is_cuda:
         torch.cuda.synchronize(t.device)
@@ -56,6 +73,7 @@ class ChopRunner:
     """chop_forward (run.py:167-202) over `world` ranks.
 
     model_fn   : [n,C,ps,ps] -> [n,C',s*ps,s*ps] (an innfer_amd nn.Module on the GPU)
+    tile_batch : tiles per network launch; None = evenly sized launches of at most MAX_TILE_BATCH tiles (tile_batches())
     extract_fn : (img, (ps,ps), [step,step], batch_first, tile_range) -> tiles, default HIP kernel
     recompose_fn: (tiles, H, W, step, scale) -> image, default HIP kernel
     plan_fn    : (H, W, patch, step) -> (ps, ys, xs), default the C ABI's innfer_chop_plan
@@ -69,7 +87,7 @@ class ChopRunner:
     {tiles, compute_ms, exchange_ms, exchange_bytes, blend_ms, bcast_ms} of the call (never in a timed region).
     """
 
-    def __init__(self, model_fn, scale, tile_batch=64, patch=200, step=0.5, group=None,
+    def __init__(self, model_fn, scale, tile_batch=None, patch=200, step=0.5, group=None,
                  extract_fn=None, recompose_fn=None, plan_fn=None, out_channels=None, out_dtype=None,
                  shard='tiles', profile=False):
         if shard not in ('tiles', 'rows'):
@@ -124,12 +142,14 @@ class ChopRunner:
                                     tile_range=(first, count)).squeeze(0)
             base = first if rank == 0 else 0
             with torch.no_grad():
-                for i in range(0, count, self.tile_batch):
-                    y = self.model_fn(tiles[i:i + self.tile_batch])
+                i = 0
+                for b in tile_batches(count, self.tile_batch):
+                    y = self.model_fn(tiles[i:i + b])
                     if y.shape[1:] != hr.shape[1:] or y.dtype != hr.dtype:
                         raise RuntimeError(f'ChopRunner: model_fn returned {tuple(y.shape[1:])} {y.dtype}, every rank was told '
                                            f'{tuple(hr.shape[1:])} {hr.dtype} (set out_channels / out_dtype)')
-                    hr[base + i:base + i + y.shape[0]].copy_(y)
+                    hr[base + i:base + i + b].copy_(y)
+                    i += b
                     del y
             del tiles
         if prof:

@@ -5,7 +5,8 @@ Differences that are the point of this build:
   * the network forward, tile extraction and blend run in HIP (libinnfer_amd.so);
   * chop tiles are pushed through the network in BATCHES (the reference loops
     batch-1 and calls empty_cache() per tile, run.py:186-197); per-tile results
-    are identical because tiles are independent;
+    are identical because tiles are independent.  tile_batch=None sizes the
+    batches for 288 GB of HBM (parallel.tile_batches: <= 272 tiles per launch);
   * with torch.distributed initialised, tiles can be sharded over ranks and
     gathered on rank 0 (parallel.py).
 There is no CPU execution path: device must be a GPU.
@@ -101,7 +102,7 @@ def _infer_ppon(state_dict, scale, in_nc, out_nc):
 
 class Model:
     def __init__(self, model_path, arch=None, scale=None, in_nc=3, out_nc=3, device='cuda',
-                 meval=True, strict=True, chop=True, tile_batch=64, state_dict=None):
+                 meval=True, strict=True, chop=True, tile_batch=None, state_dict=None):
         self.model_path = model_path
         self.arch = arch
         self.scale = scale
@@ -155,10 +156,12 @@ class Model:
         patch_size = min(H, W, patch_size)
         tiles = extract_patches_2d(data, (patch_size, patch_size), [step, step], batch_first=True,
                                    tile_range=tile_range).squeeze(0)
-        outs = []
+        from .parallel import tile_batches
+        outs, i = [], 0
         with torch.no_grad():
-            for i in range(0, tiles.shape[0], self.tile_batch):
-                outs.append(self._predict(tiles[i:i + self.tile_batch]))
+            for b in tile_batches(tiles.shape[0], self.tile_batch):
+                outs.append(self._predict(tiles[i:i + b]))
+                i += b
         hr = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
         if tile_range is not None:
             return hr

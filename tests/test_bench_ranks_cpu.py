@@ -65,3 +65,13 @@ def test_shard_tiles_is_an_even_contiguous_partition():
         assert max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
     assert [shard_tiles(798, 8, r)[1] for r in range(8)] == [100] * 6 + [99] * 2
     assert [shard_tile_rows(43, 76, 8, r)[1] // 76 for r in range(8)] == [6, 6, 6, 5, 5, 5, 5, 5]
+
+
+def test_tile_batches():
+    from innfer_amd.parallel import MAX_TILE_BATCH, tile_batches
+    assert tile_batches(798) == [266, 266, 266]
+    assert tile_batches(100) == [100] and tile_batches(0) == []
+    for n in (1, 63, 272, 273, 3268, 5000):
+        b = tile_batches(n)
+        assert sum(b) == n and max(b) <= MAX_TILE_BATCH and max(b) - min(b) <= 1 and len(b) == -(-n // MAX_TILE_BATCH)
+    assert tile_batches(10, 4) == [4, 4, 2] and tile_batches(8, 64) == [8]

@@ -461,8 +461,8 @@ def test_missing_weights_and_cpu_are_loud(dev):
 
 def test_unet256_golden(dev, golden):
     """pix2pix UNet_256 (BASELINE config 5) with per-image train-mode BatchNorm against the reference
-    (golden G7).  fp16 activations through 15 BatchNorms (down to 2x2 statistics): tolerance 3e-2 on the
-    tanh output, mean error an order of magnitude below."""
+    (golden G7).  fp16 activations through 15 BatchNorms (down to 2x2 statistics): SURVEY 8c's 1e-2 on the
+    tanh output, mean error an order of magnitude below, and no further from the fp32 truth than the reference's own fp16 mode."""
     import ast
     from innfer_amd import synth
     from innfer_amd.architectures import get_network
@@ -479,22 +479,22 @@ def test_unet256_golden(dev, golden):
     ref = g["out_a"].astype(np.float32)
     err = np.abs(ya - ref)
     assert np.isfinite(ya).all() and np.abs(ya).max() <= 1.0
-    assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max(), err.mean())
-    assert np.abs(ya[0, :, ::4, ::4] - g["out_a_sub"]).max() < 3e-2
+    assert err.max() < 1e-2 and err.mean() < 1e-3, (err.max(), err.mean())          # SURVEY 8c (measured 4.3e-3 / 4.1e-4)
+    assert np.abs(ya[0, :, ::4, ::4] - g["out_a_sub"]).max() < 1e-2
     # batch = independent batch-1 forwards (per-image statistics)
     xb = torch.from_numpy(synth.uniform((1, 3, 256, 256), 8, -1.0, 1.0)).to(dev)
     yab = net(torch.cat([xa, xb], 0).half()).float().cpu().numpy()
     assert np.array_equal(yab[0:1], ya)
     assert np.array_equal(yab[1:2], net(xb.half()).float().cpu().numpy())
     y32 = net(xa).float().cpu().numpy()                             # fp32 I/O
-    assert np.abs(y32 - ref).max() < 3e-2
+    assert np.abs(y32 - ref).max() < 1e-2
     # What fp16 costs on THIS network: the reference's own fp16 mode (net.half(), run.py:383, on the CPU: golden G17) is 6.9e-3 max /
-    # 6.7e-4 mean away from its fp32 output.  The HIP path (fp16 activations, fp32 accumulate and statistics) must be no further from
-    # the fp32 truth than twice that, and within the same distance of the reference's fp16 output.
+    # 6.7e-4 mean away from its fp32 output.  The HIP path (fp16 activations, fp32 accumulate and statistics; measured 4.3e-3 / 4.1e-4)
+    # must be no further from the fp32 truth than that, and within twice that of the reference's fp16 output (two roundings apart).
     g17 = golden("g17_fp16_and_eval")
     ref_max, ref_mean = [float(v) for v in g17["unet_fp16_err_vs_fp32"]]
     print(f"unet256 train-mode BN: HIP vs fp32 golden max {err.max():.2e} mean {err.mean():.2e}; reference fp16 mode {ref_max:.2e} / {ref_mean:.2e}")
-    assert err.max() <= 2.0 * ref_max and err.mean() <= 2.0 * ref_mean, (err.max(), err.mean(), ref_max, ref_mean)
+    assert err.max() <= 1.1 * ref_max and err.mean() <= 1.1 * ref_mean, (err.max(), err.mean(), ref_max, ref_mean)
     e16 = np.abs(ya - g17["unet_fp16_out_a"].astype(np.float32))
     print(f"unet256 train-mode BN: HIP vs the reference's fp16 mode max {e16.max():.2e} mean {e16.mean():.2e}")
     assert e16.max() <= 2.0 * ref_max + 1e-3 and e16.mean() <= 2.0 * ref_mean
@@ -524,7 +524,7 @@ def test_unet256_eval_mode_uses_running_statistics(dev, golden):
     assert np.abs(y_ev[0, :, ::4, ::4] - g17["unet_eval_out_a_sub"]).max() < 1e-2
     net.train()                                         # and back: the mode is read at every forward, not frozen at load time
     y_tr = net(xa.half()).float().cpu().numpy()
-    assert np.abs(y_tr - g["out_a"].astype(np.float32)).max() < 3e-2
+    assert np.abs(y_tr - g["out_a"].astype(np.float32)).max() < 1e-2
     assert np.abs(y_tr - y_ev).max() > 5e-2              # the two modes are different functions on this checkpoint
     net.eval()
     assert np.array_equal(net(xa.half()).float().cpu().numpy(), y_ev)
@@ -662,7 +662,7 @@ def test_ppon_golden(dev, golden):
 def test_cyclegan_resnet9_golden(dev, golden):
     """CycleGAN ResnetGenerator, 9 blocks against the reference (golden G14): reflection
     padding, stride-2 convs, instance norm over as few as 8x10 pixels, transposed convs, tanh.  fp16
-    activations through 23 instance norms: tolerance 3e-2 on the tanh output, mean error 10x below."""
+    activations through 23 instance norms: SURVEY 8c's 1e-2 on the tanh output, and bounded by the reference's own fp16 mode (G17)."""
     import ast
     from innfer_amd import synth
     from innfer_amd.architectures import get_network
@@ -680,14 +680,14 @@ def test_cyclegan_resnet9_golden(dev, golden):
             y = net(xin).float().cpu().numpy()
             err = np.abs(y - ref)
             assert np.isfinite(y).all() and np.abs(y).max() <= 1.0
-            assert err.max() < 3e-2 and err.mean() < 3e-3, (h, w, err.max(), err.mean())
+            assert err.max() < 1e-2 and err.mean() < 1e-3, (h, w, err.max(), err.mean())          # SURVEY 8c (measured 3.4e-3 / 6.4e-4)
             # the reference's own fp16 mode on this input (golden G17) is 4.1e-3..4.2e-3 max / 7e-4..8e-4 mean away from its fp32 output:
-            # the HIP path may be at most twice as far from the fp32 truth, and as close to the reference's fp16 output
+            # the HIP path must be no further from the fp32 truth than that, and within twice that of the reference's fp16 output
             ref_max, ref_mean = [float(v) for v in g17[f"resnet_fp16_err_vs_fp32_{h}x{w}"]]
             e16 = np.abs(y - g17[f"resnet_fp16_out_{h}x{w}"])
             print(f"resnet9 {h}x{w} in={xin.dtype}: HIP vs fp32 max {err.max():.2e} mean {err.mean():.2e}; vs ref fp16 max {e16.max():.2e} mean {e16.mean():.2e}; "
                   f"reference fp16 mode vs fp32 {ref_max:.2e} / {ref_mean:.2e}")
-            assert err.max() <= 2.0 * ref_max and err.mean() <= 2.0 * ref_mean, (h, w, err.max(), err.mean())
+            assert err.max() <= 1.1 * ref_max and err.mean() <= 1.1 * ref_mean, (h, w, err.max(), err.mean())
             assert e16.max() <= 2.0 * ref_max + 1e-3 and e16.mean() <= 2.0 * ref_mean
             assert _codes_within_one(dev, (y + 1) / 2, (ref + 1) / 2) >= 0.99
     xa = torch.from_numpy(synth.uniform((1, 3, 32, 40), 15, -1.0, 1.0)).to(dev).half()
