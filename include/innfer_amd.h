@@ -44,7 +44,8 @@ typedef enum { INNFER_F16 = 0, INNFER_F32 = 1 } innfer_dtype;
 typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
- * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 103
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -276,6 +277,34 @@ int innfer_blend_profile(int P, double step, int scale, float* h_profile);
  * the reference's fp32 path. */
 int innfer_recompose(const void* d_tiles, int dtype, int n, int C, int P, int height, int width,
                      double step, int scale, void* d_out, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------ multi-GPU chop (RCCL over xGMI)
+ * The reference is single-process; what shards is chop_forward's tile list (run.py:186-197: every tile's forward is independent) and the
+ * one exchange is "raw HR tiles -> rank 0" in front of recompose_tensor (utils/utils.py:372-445), plus the broadcast of the blended
+ * intermediate between the models of a chain (run.py:424-426).  One process per GPU; the calls below are collective over the ranks of a
+ * communicator.  RCCL (librccl.so.1) is bound at run time, on the first of these calls: single-GPU users never load it.
+ */
+#define INNFER_COMM_ID_BYTES 128
+typedef struct innfer_comm* innfer_comm_t;
+
+/* Host geometry: rank's contiguous share [first, first+count) of the row-major tile list, split as evenly as possible (earlier ranks take
+ * the remainder: 798 tiles over 8 ranks -> 100 x 6, 99 x 2).  Use it with innfer_extract_tiles(tile_begin, tile_count). */
+int innfer_shard_tiles(int n_tiles, int nranks, int rank, int* first, int* count);
+
+/* ncclGetUniqueId on ONE rank; the caller ships the INNFER_COMM_ID_BYTES to the other ranks by its own means (file, socket, MPI, torch store). */
+int innfer_comm_unique_id(void* h_id);
+/* ncclCommInitRank on the calling thread's current HIP device. */
+int innfer_comm_init(innfer_comm_t* out, const void* h_id, int rank, int nranks);
+void innfer_comm_destroy(innfer_comm_t c);
+int innfer_comm_rank(innfer_comm_t c);
+int innfer_comm_size(innfer_comm_t c);
+
+/* Collect every rank's tiles on rank 0, real tiles only.  Rank 0: d_tiles is the whole [n_tiles][tile_bytes] buffer the blend reads, with
+ * its own share already in place; rank r > 0: d_tiles is its own share [count][tile_bytes] (innfer_shard_tiles).  One group of ncclSend /
+ * ncclRecv enqueued on `stream`; the buffer may be read by work enqueued on `stream` after the call. */
+int innfer_gather_tiles(innfer_comm_t c, void* d_tiles, size_t tile_bytes, int n_tiles, void* stream);
+/* ncclBroadcast of `bytes` bytes from `root` (the blended intermediate of a model chain), in place. */
+int innfer_comm_broadcast(innfer_comm_t c, void* d_buf, size_t bytes, int root, void* stream);
 
 /* --------------------------------------------------------------- pre / post
  * np2tensor / tensor2np (utils/utils.py:164-194,197-248, colors.py:5-26):

@@ -176,6 +176,9 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
     const int oc0 = cbase + p.out_coff;
     const int yw = ty0 + wave * RPW, xl = tx0 + li;
     long pix0 = ((long)n * p.H + yw) * p.W + xl;
+#ifdef INNFER_ABLATE
+    if (p.abl & 16) pix0 = (long)blockIdx.x * 64 + wave * RPW * p.W + li;      // every tile of a workgroup stores to the same (cache-resident) lines
+#endif
     long rowstep = (long)p.W * 32;
     long colstep = 16 * 32;
     int ylim = p.y1, xlim = p.W;
@@ -603,7 +606,12 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 // pixel is staged as zeros -- the zero padding of BOTH neighbouring images -- and never stored; a tile that straddles cells stages / stores each
 // pixel at its own image's address (per-lane offsets, derived once per tile; tiles inside one cell take the plain path).  64 tiles of 200 x 200:
 // 3417 canvas tiles instead of 4032.  Results are bit-identical to the per-image lattice: every output pixel sees the same operands in the same order.
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false>
+// NSI: input stages in LDS.  2: halo tile + weight panel of a chunk are one stage, the loaders stage chunk g + 1 while the consumers work on chunk g
+// and then WAIT for it to land before the barrier -- for that wait (a third of the loaders' time in the 32-output layers) nothing new is in
+// flight.  3 (16-row tiles, 32-output layers): a ring of three input slots and two weight slots; during step g the loaders issue the weight
+// panel of chunk g + 1 and the halo tile of chunk g + 2 and wait (counted vmcnt) only for what was issued a whole step earlier, so the
+// request stream into HBM never pauses.
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false, int NSI = 2>
 __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int NCW = 8;                       // consumer waves; NLW loader waves
     constexpr int TH = NCW * RPW;
@@ -620,6 +628,11 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int MT = RPW * 2;
     constexpr int STAGE = IN_BYTES + W_BYTES;
     constexpr int OOB = (int)0x80000000;
+#ifdef INNFER_NO_PIPE
+    constexpr bool PIPE = false;                 // A/B build: the compiler's own placement of the fragment reads
+#else
+    constexpr bool PIPE = true;
+#endif
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -766,9 +779,9 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                 }
             }
         };
-        auto issue = [&](int c, int stage) {
+        // what: 1 input pieces, 2 weight pieces, 3 both; st_i / st_w: LDS destinations; wsrc: the chunk's weight panel
+        auto issue_to = [&](int c, char* st_i, char* st_w, const char* wsrc, int what) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            char* st = smem + stage * STAGE;
             const char* src = in_tile + c * p.in_gbytes;
             if constexpr (S9) {
                 const int sub = c / p.ncg, cg = c - sub * p.ncg;
@@ -794,23 +807,74 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                 }
             }
             const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(w_tile + (long)c * W_BYTES), 0, W_BYTES, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, W_BYTES, 0x00020000);
+#ifdef INNFER_ABLATE
+            if (p.abl & 2) what &= ~2;                                   // abl 2: no weight pieces, abl 4: no input pieces
+            if (p.abl & 4) what &= ~1;
+#endif
+            if (what & 2) {
 #pragma unroll
-            for (int k = 0; k < KQ; ++k) {
-                const int q = lw + NLW * k;
-                if (q < NQ)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void*)(st + q * 1024), 16, voff[k], 0, 0, 0);
+                for (int k = 0; k < KW; ++k) {
+                    const int jq = lw + NLW * k;
+                    if (jq < WQ)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st_w + jq * 1024), 16, wvoff, jq * 1024, 0, 0);
+                }
             }
+            if (what & 1) {
 #pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const int jq = lw + NLW * k;
-                if (jq < WQ)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + IN_BYTES + jq * 1024), 16, wvoff, jq * 1024, 0, 0);
+                for (int k = 0; k < KQ; ++k) {
+                    const int q = lw + NLW * k;
+                    if (q < NQ)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void*)(st_i + q * 1024), 16, voff[k], 0, 0, 0);
+                }
             }
 #else
-            (void)c; (void)stage; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile; (void)s9_ty0; (void)s9_tx0; (void)s9_n; (void)s9_edge;
+            (void)c; (void)st_i; (void)st_w; (void)wsrc; (void)what; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile; (void)s9_ty0; (void)s9_tx0; (void)s9_n; (void)s9_edge;
 #endif
         };
+        auto issue = [&](int c, int stage) {
+            issue_to(c, smem + stage * STAGE, smem + stage * STAGE + IN_BYTES, w_tile + (long)c * W_BYTES, 3);
+        };
+        if constexpr (NSI == 3) {
+            // ---- ring of three input slots + two weight slots: the input cursor runs two chunks ahead of the consumers, the weight cursor one ----
+            char* const wring = smem + 3 * IN_BYTES;
+            const int my_in = (NQ - lw + NLW - 1) / NLW;                 // input pieces THIS wave issues per chunk (KQ or KQ - 1)
+            auto wait_all_but_in = [&](bool pending) {                    // everything older than the youngest chunk's input pieces has landed
+                if (!pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (my_in == KQ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KQ) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KQ - 1) : "memory");
+            };
+            int jt_i = j0, c_i = 0;                                       // input cursor (setup() keeps its tile's offsets in voff / in_tile)
+            int jt_w = j0, c_w = 0, kg_w;                                 // weight cursor
+            { int n_, ty_, tx_; decode(jt_w, kg_w, n_, ty_, tx_); }
+            setup(jt_i);
+            issue_to(0, smem, wring, (const char*)p.wpk + (long)kg_w * p.nchunks * W_BYTES, 3);
+            bool pending = false;
+            if (G > 1) {
+                if (++c_i == p.nchunks) { c_i = 0; jt_i += slots; setup(jt_i); }
+                issue_to(c_i, smem + IN_BYTES, nullptr, nullptr, 1);
+                pending = true;
+            }
+            wait_all_but_in(pending);
+            asm volatile("s_barrier" ::: "memory");
+            int slot = 2;                                                 // (g + 2) % 3
+            for (int g = 0; g < G; ++g) {
+                pending = false;
+                if (g + 1 < G) {
+                    if (++c_w == p.nchunks) { c_w = 0; jt_w += slots; int n_, ty_, tx_; decode(jt_w, kg_w, n_, ty_, tx_); }
+                    issue_to(0, nullptr, wring + ((g + 1) & 1) * W_BYTES, (const char*)p.wpk + ((long)kg_w * p.nchunks + c_w) * W_BYTES, 2);
+                }
+                if (g + 2 < G) {
+                    if (++c_i == p.nchunks) { c_i = 0; jt_i += slots; setup(jt_i); }
+                    issue_to(c_i, smem + slot * IN_BYTES, nullptr, nullptr, 1);
+                    pending = true;
+                }
+                slot = slot == 2 ? 0 : slot + 1;
+                wait_all_but_in(pending);
+                asm volatile("s_barrier" ::: "memory");
+            }
+            return;
+        }
         int jt = j0, c = 0;
         setup(jt);
         issue(0, 0);
@@ -845,7 +909,8 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
             const int rowpar = ((cw * RPW) & 1) ^ par;
             boffs[s][par] = pb * 64 + ((lg ^ (((((li + s) >> 2) & 1) ^ rowpar) << 1)) << 4);
         }
-    const int aoffs = IN_BYTES + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    const int aoffs = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    int islot = 0;                                                // NSI == 3: g % 3
     f32x4 bias_r[NT];
     int bias_kg = -1;
     f32x4 acc[NT][MT];
@@ -870,8 +935,59 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[t][m] = bias_r[t];
         }
-        const char* st = smem + (g & 1) * STAGE;
+        const char* st = NSI == 3 ? smem + islot * IN_BYTES : smem + (g & 1) * STAGE;                       // halo tile
+        const char* sw = NSI == 3 ? smem + 3 * IN_BYTES + (g & 1) * W_BYTES : st + IN_BYTES;              // weight panel
+        if constexpr (NSI == 3) islot = islot == 2 ? 0 : islot + 1;
         PCT(c0);
+#ifdef INNFER_ABLATE
+        const bool abl_no_mfma = (p.abl & 8) != 0;
+#else
+        constexpr bool abl_no_mfma = false;
+#endif
+        if (abl_no_mfma) {
+        } else if constexpr (TM == 0x1FF && PIPE) {
+            // Software-pipelined fragment reads (the nine-tap kernels).  The B fragments of a chunk are walked in (s, rr, seg) order through
+            // a three-register ring, each read issued two MFMA groups (>= 8 MFMAs = 128 pipe cycles) ahead of its use; the weight fragments
+            // of tap column s + 1 overwrite those of column s as soon as their last MFMA has been issued (A(s,0,*) after row RPW - 1,
+            // A(s,1,*) after row RPW, A(s,2,*) at the end of the column, needed again from row 2 on).  sched_barrier pins the order: left to
+            // itself the scheduler sinks every ds_read to just in front of its first use and the MFMA pipe then waits out the LDS latency
+            // at each of them, both waves of the SIMD at the same points (they run in step between the chunk barriers).  Same MFMAs in the
+            // same order: results are unchanged.
+            constexpr int GPS = 2 * (RPW + 2);                     // B fragments (= MFMA groups) per tap column
+            constexpr int NB = 3 * GPS;
+            f16x8 a[3][NT];
+            f16x8 bq[3];
+            auto lda = [&](int sc, int r) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a[r][t] = *(const f16x8*)(sw + aoffs + ((r * 3 + sc) * WROWS + t * 16) * 64);
+            };
+            auto ldb = [&](int i) {
+                const int sc = i / GPS, j = i - sc * GPS, rr = j >> 1, seg = j & 1;
+                return *(const f16x8*)(st + boffs[sc][rr & 1] + (rr * LWP + seg * 16) * 64);
+            };
+            lda(0, 0); lda(0, 1); lda(0, 2);
+            bq[0] = ldb(0); bq[1] = ldb(1);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int sc = i / GPS, j = i - sc * GPS, rr = j >> 1, seg = j & 1;
+                if (i + 2 < NB) bq[(i + 2) % 3] = ldb(i + 2);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int rw = rr - r;
+                    if (rw >= 0 && rw < RPW) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[r][t], bq[i % 3], acc[t][rw * 2 + seg], 0, 0, 0);
+                    }
+                }
+                if (sc < 2 && seg == 1) {
+                    if (rr == RPW - 1) lda(sc + 1, 0);
+                    if (rr == RPW) lda(sc + 1, 1);
+                    if (rr == RPW + 1) lda(sc + 1, 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (!((TM >> s) & 0x49)) continue;                     // no tap in this column (loop constants: folded at compile time)
@@ -881,7 +997,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     if ((TM >> (r * 3 + s)) & 1)                   // panel slot = rank of the tap among the mask's set bits
-                        a[r][t] = *(const f16x8*)(st + aoffs + (__builtin_popcount(TM & ((1 << (r * 3 + s)) - 1)) * WROWS + t * 16) * 64);
+                        a[r][t] = *(const f16x8*)(sw + aoffs + (__builtin_popcount(TM & ((1 << (r * 3 + s)) - 1)) * WROWS + t * 16) * 64);
 #pragma unroll
             for (int rr = 0; rr < RPW + 2; ++rr) {
                 bool need = false;
@@ -903,6 +1019,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
                     }
                 }
             }
+        }
         }
         PCT(c1);
         if (cw == 0) PCACC(0, c1, c0);
@@ -969,7 +1086,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false>
+template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false, int NSI = 2>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 // Per-device state (a process may drive several GPUs): CU count, and which devices already carry a kernel's
@@ -1014,7 +1131,7 @@ int launch_t(const KP& kp, int N, hipStream_t s) {
         const int pf = INNFER_KNOB("INNFER_PREFETCH", 0);   // 1: next chunk, 2: + next tile
         k.pf = (RPW == 3 && NT == 2) ? 0 : pf;
 #ifdef INNFER_ABLATE
-        k.abl = INNFER_KNOB("INNFER_ABL", 0);
+        k.abl = getenv("INNFER_ABL") ? atoi(getenv("INNFER_ABL")) : 0;     // read per launch: scripts/ablate.py changes it between runs
 #endif
     }
     const long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
@@ -1047,26 +1164,30 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
     return *tiles * 100 <= plain * 98 ? best : 0;         // worth it from 2 % fewer tiles
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV>
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = 8 * RPW;
-    constexpr int LDS = 2 * ((((TH + 2) * LWP + 15) / 16) * 1024 + __builtin_popcount(TM) * NT * 16 * 64);
-    static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (__builtin_popcount(TM) * NT * 16 * 64);
+    static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
+    static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
     if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && TM == 0x1FF && !CV) {      // a batch of images whose size is not a whole number of tiles
         int gy = 0; long t = 0;
         const int gx = INNFER_KNOB("INNFER_CANVAS", 1) ? canvas_grid<TH>(kp, N, &gy, &t) : 0;
         if (gx > 0) {
             KP kc = kp;
             kc.cv_gx = gx; kc.cv_gy = gy; kc.cv_h1 = kp.H + 1; kc.cv_w1 = kp.W + 1;
-            return launch_pc<RPW, NT, NLW, OUTMODE, false, false, 0x1FF, true>(kc, N, s);
+            return launch_pc<RPW, NT, NLW, OUTMODE, false, false, 0x1FF, true, NSI>(kc, N, s);
         }
     }
     static unsigned long long attr_done = 0;
-    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV>, LDS, attr_done)) return rc;
+    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV, NSI>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
     k.N = N;
+#ifdef INNFER_ABLATE
+    k.abl = getenv("INNFER_ABL") ? atoi(getenv("INNFER_ABL")) : 0;     // read per launch: scripts/ablate.py changes it between runs
+#endif
     long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
     if constexpr (CV) {                       // one canvas instead of N images
         k.tiles_x = (k.cv_gx * k.cv_w1 + TW - 1) / TW;
@@ -1086,7 +1207,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV, NSI>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -1243,7 +1364,11 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
             return set_error(INNFER_ERR_UNSUPPORTED, "conv1x1: slab outputs of 32- / 64-channel tiles on the producer-consumer kernel");
         return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s) : launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s);
     }
-    if (pc && L.out_mode == OUT_SLAB && nt == 2) return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
+    if (pc && L.out_mode == OUT_SLAB && nt == 2) {
+        // 32-output layers: 16-row tiles on the three-slot input ring (continuous LDS-DMA issue); pc 4: the 24-row two-stage form (A/B)
+        if (pc == 1) return launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 3>(k, L.N, s);
+        return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
+    }
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
     if (L.conv7) {         // 7x7 (padding 3) as nine displaced 3x3 convs: planar output, <= 16 output channels, panels from conv_pack7x7
         if (!pc || L.out_mode != OUT_NCHW || nt != 1 || L.res1 || L.res2 || L.up || (long)L.H * L.W * 64 >= 0x7fffffffL)

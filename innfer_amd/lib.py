@@ -130,6 +130,14 @@ SIGNATURES = {
     "innfer_blend_profile": (C.c_int, [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_float)]),
     "innfer_recompose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "innfer_shard_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "innfer_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "innfer_comm_destroy": (None, [C.c_void_p]),
+    "innfer_comm_rank": (C.c_int, [C.c_void_p]),
+    "innfer_comm_size": (C.c_int, [C.c_void_p]),
+    "innfer_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "innfer_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "innfer_u8hwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "innfer_srgb_to_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_linear_to_srgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -165,6 +173,15 @@ def check(rc):
     if rc == ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
     raise InnferError(f"innfer_amd status {rc}: {msg}")
+
+
+COMM_ID_BYTES = 128
+
+
+def shard_tiles(n_tiles, nranks, rank):
+    first, count = C.c_int(), C.c_int()
+    check(_lib.innfer_shard_tiles(n_tiles, nranks, rank, C.byref(first), C.byref(count)))
+    return first.value, count.value
 
 
 def chop_plan(H, W, patch=200, step=0.5):

@@ -69,6 +69,45 @@ def _sync(t):
         torch.cuda.synchronize(t.device)
 
 
+class CabiComm:
+    """The C ABI's own RCCL communicator (include/innfer_amd.h: innfer_comm_init / innfer_gather_tiles / innfer_comm_broadcast) for the
+    ranks of a torch.distributed group: rank 0 draws the ncclUniqueId, the group's store ships its 128 bytes, every rank joins on its
+    current device.  What a C user of the library calls; ChopRunner(transport='cabi') routes its exchange through it."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import lib as L
+        self._L, self.group = L, group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [None]
+        if rank == 0:
+            buf = (C.c_char * L.COMM_ID_BYTES)()
+            L.check(L.lib.innfer_comm_unique_id(buf))
+            box[0] = bytes(buf)
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.handle = C.c_void_p()
+        L.check(L.lib.innfer_comm_init(C.byref(self.handle), box[0], rank, world))
+
+    def gather_tiles(self, t, n_tiles):
+        """t: rank 0 the whole [n_tiles, ...] buffer, other ranks their share (shard_tiles)."""
+        tile_bytes = t[0].numel() * t.element_size() if t.shape[0] else 0
+        if tile_bytes:
+            self._L.check(self._L.lib.innfer_gather_tiles(self.handle, t.data_ptr(), tile_bytes, n_tiles,
+                                                          torch.cuda.current_stream(t.device).cuda_stream))
+
+    def broadcast(self, t, root=0):
+        self._L.check(self._L.lib.innfer_comm_broadcast(self.handle, t.data_ptr(), t.numel() * t.element_size(), root,
+                                                        torch.cuda.current_stream(t.device).cuda_stream))
+
+    def __del__(self):
+        h = getattr(self, 'handle', None)
+        if h:
+            try:
+                self._L.lib.innfer_comm_destroy(h)
+            except Exception:
+                pass
+
+
 class ChopRunner:
     """chop_forward (run.py:167-202) over `world` ranks.
 
@@ -81,6 +120,8 @@ class ChopRunner:
                  exchange (a rank may own no tile at all).  Defaults: model_fn.out_nc if it has one, else the
                  input's channel count; the input's dtype.
     shard      : 'tiles' (even split of the tile list) or 'rows' (whole tile rows)
+    transport  : 'torch' (torch.distributed point-to-point ops: RCCL under the "nccl" backend, host staging under "gloo") or 'cabi' (the
+                 library's own RCCL communicator, the entry points a C user binds: GPU tensors, shard='tiles' only)
     Returns the blended [1,C',sH,sW] tensor on rank 0 and None elsewhere
     (all ranks get it with broadcast_result=True, used between chained models).
     With profile=True every phase is bracketed by a device synchronise and `self.last` holds
@@ -89,9 +130,12 @@ class ChopRunner:
 
     def __init__(self, model_fn, scale, tile_batch=None, patch=200, step=0.5, group=None,
                  extract_fn=None, recompose_fn=None, plan_fn=None, out_channels=None, out_dtype=None,
-                 shard='tiles', profile=False):
+                 shard='tiles', profile=False, transport='torch'):
         if shard not in ('tiles', 'rows'):
             raise ValueError("shard must be 'tiles' or 'rows'")
+        if transport not in ('torch', 'cabi') or (transport == 'cabi' and shard != 'tiles'):
+            raise ValueError("transport must be 'torch' or 'cabi' (the C ABI's partition is shard='tiles')")
+        self.transport, self._cabi = transport, None
         self.model_fn, self.scale, self.tile_batch = model_fn, scale, tile_batch
         self.patch, self.step, self.group = patch, step, group
         self.out_channels, self.out_dtype, self.shard, self.profile = out_channels, out_dtype, shard, profile
@@ -156,7 +200,13 @@ class ChopRunner:
             _sync(data)
             t1 = time.perf_counter()
         xbytes = 0
-        if world > 1:
+        if world > 1 and self.transport == 'cabi':
+            if self._cabi is None:
+                self._cabi = CabiComm(self.group)
+            self._cabi.gather_tiles(hr, n)
+            tb = out_c * P * P * hr.element_size()
+            xbytes = (n - count if rank == 0 else count) * tb
+        elif world > 1:
             # ---- grouped point-to-point exchange: real tiles only, received in place ----
             ops, stage = [], []
             if rank == 0:
@@ -193,7 +243,9 @@ class ChopRunner:
         if broadcast_result and world > 1:
             if rank != 0:
                 result = torch.empty((1, out_c, H * self.scale, W * self.scale), dtype=dtype, device=data.device)
-            if self._staged(result):
+            if self.transport == 'cabi':
+                self._cabi.broadcast(result, 0)
+            elif self._staged(result):
                 buf = result.cpu() if rank == 0 else torch.empty(result.shape, dtype=dtype, device='cpu')
                 dist.broadcast(buf, src=self._peer(0), group=self.group)
                 if rank != 0:

@@ -5,12 +5,12 @@ cache-resident window.  Results are wrong
 by construction; only the launch times mean anything."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("INNFER_PC", "0")      # these hooks live in the two-workgroup kernel (conv3x3_mfma)
+# INNFER_PC=0: the two-workgroup kernel (conv3x3_mfma); default: the producer / consumer kernels (bits 1, 2, 4, 8)
 os.environ.setdefault("INNFER_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                  "innfer_amd", "lib", "libinnfer_amd_ablate.so"))
 from scripts.bench_conv import run
 for (Cc, K) in [(64, 32), (160, 32), (192, 64)]:
-    for abl in (0, 1, 16, 6, 22, 7):
+    for abl in [int(v) for v in os.environ.get('ABLS', '0,1,8,9,6,7,14').split(',')]:
         os.environ["INNFER_ABL"] = str(abl)
         print(f"abl={abl:2d} ", end="")
         run(Cc, K, 1080, 1920, reps=20)

@@ -65,6 +65,9 @@ def test_shard_tiles_is_an_even_contiguous_partition():
         assert max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
     assert [shard_tiles(798, 8, r)[1] for r in range(8)] == [100] * 6 + [99] * 2
     assert [shard_tile_rows(43, 76, 8, r)[1] // 76 for r in range(8)] == [6, 6, 6, 5, 5, 5, 5, 5]
+    import innfer_amd.lib as L                                   # the C ABI's partition (innfer_shard_tiles, host code) is the same function
+    for n, world in [(798, 8), (3268, 8), (5, 7), (0, 3)]:
+        assert [L.shard_tiles(n, world, r) for r in range(world)] == [shard_tiles(n, world, r) for r in range(world)]
 
 
 def test_tile_batches():

@@ -214,3 +214,31 @@ def test_bench_two_ranks_dry_run(dev):
     rf = line["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == ("GB/s" if rf["bound"] == "hbm" else "TFLOP/s")
     assert 0 < rf["frac"] <= 1 and 0 < rf["frac_mfma"] <= 1 and 0 < rf["frac_hbm"] <= 1
+
+
+def test_cabi_comm_single_rank(dev):
+    """The C ABI's multi-GPU entry points (innfer_comm_*, innfer_gather_tiles) on the one GPU of this box: RCCL is bound at run time, a
+    one-rank communicator is created on the current device, gather / broadcast of a one-rank communicator leave the buffer alone, and the
+    host partition equals innfer_amd.parallel.shard_tiles.  (Two ranks need two GPUs: RCCL refuses two ranks on one device.)"""
+    import ctypes as C
+    import innfer_amd.lib as L
+    from innfer_amd.parallel import shard_tiles
+    for n, world in [(798, 8), (3268, 8), (5, 7), (0, 3)]:
+        assert [L.shard_tiles(n, world, r) for r in range(world)] == [shard_tiles(n, world, r) for r in range(world)]
+    torch.cuda.set_device(dev)
+    buf = (C.c_char * L.COMM_ID_BYTES)()
+    L.check(L.lib.innfer_comm_unique_id(buf))
+    assert any(bytes(buf))
+    h = C.c_void_p()
+    L.check(L.lib.innfer_comm_init(C.byref(h), buf, 0, 1))
+    assert L.lib.innfer_comm_rank(h) == 0 and L.lib.innfer_comm_size(h) == 1
+    t = torch.arange(6 * 3 * 8 * 8, dtype=torch.float16, device=dev).reshape(6, 3, 8, 8)
+    ref = t.clone()
+    s = torch.cuda.current_stream(dev).cuda_stream
+    L.check(L.lib.innfer_gather_tiles(h, t.data_ptr(), 3 * 8 * 8 * 2, 6, s))
+    L.check(L.lib.innfer_comm_broadcast(h, t.data_ptr(), t.numel() * 2, 0, s))
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref)
+    with pytest.raises(ValueError):
+        L.check(L.lib.innfer_comm_broadcast(h, t.data_ptr(), 16, 3, s))      # root outside the communicator
+    L.lib.innfer_comm_destroy(h)
