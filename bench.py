@@ -41,7 +41,7 @@ sys.path.insert(0, REPO)
 PEAK_F16_TFLOPS = 2516.6      # MI355X dense fp16/bf16 MFMA: 256 CU x 4096 FLOP/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0         # HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # instantiation conv_launch picks for NT 16-channel output tiles and the output mode (csrc/conv3x3.hip)
-PC_SHAPE = {(2, 0): (2, 2, 4, 0), (4, 0): (2, 4, 4, 0), (1, 1): (3, 1, 4, 1)}
+PC_SHAPE = {(2, 0): (3, 2, 4, 0), (4, 0): (2, 4, 4, 0), (1, 1): (3, 1, 4, 1)}
 MFMA_SHAPE = {1: 4, 2: 4, 4: 2}
 WORKLOADS = ["frame1080", "frame540", "chop8k", "chop4k", "chain4k"]
 

@@ -1365,8 +1365,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s) : launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 2) {
-        // 32-output layers: 16-row tiles on the three-slot input ring (continuous LDS-DMA issue); pc 4: the 24-row two-stage form (A/B)
-        if (pc == 1) return launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 3>(k, L.N, s);
+        // 32-output layers: 24-row tiles, two LDS stages.  pc 5 (diagnostic builds): 16-row tiles on the three-slot input ring (continuous LDS-DMA
+        // issue) -- measured within +-1 % of the default on the frame and on the chop path (profiles/r2/kernel_experiments.txt), so the simpler form ships
+        if (pc == 5) return launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 3>(k, L.N, s);
         return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);

@@ -23,3 +23,12 @@ for N in ([int(os.environ['UNET_N'])] if os.environ.get('UNET_N') else (1, 8, 64
     ms = e0.elapsed_time(e1) / reps
     fl = net.flops(N, 256, 256)
     print(f"UNet_256 N={N:2d}: {ms:8.3f} ms  {N / ms * 1e3:8.1f} img/s  {N * 65536 / ms / 1e3:7.2f} MPix/s  {fl / ms / 1e9:7.2f} TFLOP/s", flush=True)
+    if N == 64:          # BASELINE config 5: one JSON line with a roofline object (algorithmic FLOPs from the engine: 12.1 GFLOP per image)
+        import json
+        wbytes = sum(p.numel() for p in net.parameters()) * 2.0          # fp16 weight panels, read at least once per launch
+        print(json.dumps({"metric": "images/s, pix2pix UNet_256 (BASELINE config 5)", "value": round(N / ms * 1e3, 1), "unit": "img/s", "n_gpus": 1,
+                          "ms_per_step": round(ms, 4), "dtype": "f16", "data": "synthetic",
+                          "config": {"workload": "UnetGenerator(3,3,8,ngf 64, batch norm on the statistics of each image), 64x3x256x256 -> 64x3x256x256"},
+                          "roofline": {"bound": "mfma", "achieved": round(fl / ms / 1e9, 2), "peak": 2516.6, "unit": "TFLOP/s",
+                                       "frac": round(fl / ms / 1e9 / 2516.6, 4), "flops_per_forward": fl, "weight_bytes": wbytes,
+                                       "note": "whole forward (69 launches), not one kernel: the network is a chain of small GEMM-shaped layers"}}), flush=True)

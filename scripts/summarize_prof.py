@@ -54,11 +54,17 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            # conv3x3_pc<RPW, NT, NLW, OUT[, S9]>: the key keeps the numeric shape (bench.py's kernel names); the 7x7 variant gets a suffix
-            m = re.search(r"(conv3x3_mfma|conv3x3_pc)<([0-9, ]+?)(?:, (false|true))?>", r["Kernel_Name"])
+            # conv3x3_pc<RPW, NT, NLW, OUT, S9, POLY, TM, CV, NSI>: the key keeps the first four numbers (bench.py's kernel names); the 7x7 / polyphase /
+            # canvas variants get a suffix
+            m = re.search(r"(conv3x3_mfma|conv3x3_pc)<([^>]*)>", r["Kernel_Name"])
             if not m:
                 continue
-            key = m.group(1) + "<" + m.group(2).replace(" ", "") + ">" + ("+s9" if m.group(3) == "true" else "")
+            a = [v.strip() for v in m.group(2).split(",")]
+            nnum = 4 if m.group(1) == "conv3x3_pc" else 3
+            key = m.group(1) + "<" + ",".join(a[:nnum]) + ">"
+            if m.group(1) == "conv3x3_pc":
+                key += ("+s9" if len(a) > 4 and a[4] == "true" else "") + ("+poly" if len(a) > 5 and a[5] == "true" else "") + \
+                       ("+tm" + a[6] if len(a) > 6 and a[6] != "511" else "") + ("+cv" if len(a) > 7 and a[7] == "true" else "")
             t = traffic.setdefault(key, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
             t[counter][0] += float(r["Counter_Value"]); t[counter][1] += 1
 out = {}
