@@ -29,7 +29,7 @@ def _sd(shapes, seed=0):
 
 # ------------------------------------------------------------------ single conv
 def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0,
-              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False, dilation=0):
+              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False, dilation=0, res1_is_input=False):
     """x [N,C,Hs,Ws] fp16 (cpu), w [K,C,3,3] fp32.  Runs the HIP conv on blocked-NHWC slabs
     ([C/32][N*H*W][32]) and returns (NCHW fp32 result, raw output slab [groups,N,H,W,32]) on the cpu."""
     import innfer_amd.lib as L
@@ -55,6 +55,9 @@ def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2
     a.d_out, a.out_group_stride, a.out_ch_off, a.K = out.data_ptr(), g_out, out_off, K
     a.N, a.H, a.W, a.act, a.upsample2x = N, H, W, act, int(up)
     keep = [slab, d_packed, d_bias]
+    if res1_is_input:       # residual 1 = the first K channels of the conv's own input slab (x5 * 0.2 + x of an RDB)
+        a.d_res1, a.res1_group_stride, a.res1_scale = slab.data_ptr(), g_in, s1
+        res1 = None
     for name, r, sc in (("1", res1, s1), ("2", res2, s2)):
         if r is not None:
             rs = torch.empty((max(K, 32) // 32, N, H, W, 32), dtype=torch.float16, device=dev)
@@ -118,6 +121,23 @@ def test_conv_epilogues_and_slab_offsets(dev):
     assert torch.all(raw[:2] == -3.0) and torch.all(raw[4:] == -3.0)
     got, _ = _run_conv(dev, x, w, b, K, act=2)
     assert (got - _ref_conv(x, w, b, act=2)).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("N,H,W,with_res2", [(1, 37, 70, False), (1, 16, 32, True), (4, 40, 40, True), (3, 200, 200, False), (1, 1, 1, False)])
+def test_conv_rdb_residual_aliasing_the_input_slab(dev, N, H, W, with_res2):
+    """RRDBNet_arch.py:165 `x5 * 0.2 + x` exactly as the trunk issues it: residual 1 is channels 0..63 of the conv's OWN input slab (the pointer
+    aliases the input) -- plain lattice, image canvas (N > 1) and the RRDB's second residual; same result as with the residual in its own buffer."""
+    from innfer_amd import synth
+    Cc, K = 192, 64
+    x = torch.from_numpy(synth.uniform((N, Cc, H, W), 14, -1, 1)).half()
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 15, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.from_numpy(synth.uniform((K,), 16, -1, 1))
+    r2 = torch.from_numpy(synth.uniform((N, K, H, W), 17, -1, 1)).half() if with_res2 else None
+    got, _ = _run_conv(dev, x, w, b, K, act=0, s1=0.2, res2=r2, s2=0.2, res1_is_input=True)
+    ref = _ref_conv(x, w, b, act=0, res1=x[:, :K], s1=0.2, res2=r2, s2=0.2)
+    assert (got - ref).abs().max().item() < 4e-3
+    got2, _ = _run_conv(dev, x, w, b, K, act=0, res1=x[:, :K].contiguous(), s1=0.2, res2=r2, s2=0.2)
+    assert torch.equal(got, got2)
 
 
 def test_conv_pixel_attention_gate_epilogue(dev):
