@@ -48,6 +48,8 @@ WORKLOADS = ["frame1080", "frame540", "chop8k", "chop4k", "chain4k"]
 
 def kernel_key(k):
     """rocprof-style name of the instantiation conv_launch picks for launch kind k = 16*NT + out_mode."""
+    if k == 1000:
+        return "conv3x3_pair"
     nt, mode = k // 16, k % 16
     if (nt, mode) in PC_SHAPE:
         return "conv3x3_pc<%d,%d,%d,%d>" % PC_SHAPE[(nt, mode)]
@@ -83,6 +85,7 @@ def timed_forward(net, x):
     ms, fl, by, kd, n = (C.c_float * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), (C.c_int * cap)(), C.c_int()
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(L.lib.innfer_net_set_band_rows(net._handle, int(net.band_rows)))
+    L.check(L.lib.innfer_net_set_pair_convs(net._handle, int(net.pair_convs)))
     L.check(L.lib.innfer_net_forward_timed(net._handle, x.data_ptr(), L.F16, out.data_ptr(), L.F16, N, H, W,
                                            net._ws.data_ptr(), net._ws.numel(), stream, cap, ms, fl, by, kd, C.byref(n)))
     return [(kd[i], ms[i], fl[i], by[i]) for i in range(min(n.value, cap))]
@@ -338,6 +341,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="frame1080", choices=WORKLOADS)
     ap.add_argument("--band-rows", type=int, default=0)
+    ap.add_argument("--pair-convs", type=int, default=0, choices=[0, 1, 2],
+                    help="innfer_net_set_pair_convs: 0 one launch per layer (default), 1 fused conv pairs on single-image forwards, 2 always")
     ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch (0 = innfer_amd.parallel.tile_batches: evenly sized launches of <= 272 tiles)")
     ap.add_argument("--sharded-steps", type=int, default=2, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -414,6 +419,7 @@ def main():
     from innfer_amd import parallel, synth
     net, _ = build_net(dev)
     net.band_rows = args.band_rows
+    net.pair_convs = args.pair_convs
     tag = " (DRY RUN: all ranks on one GPU, gloo)" if dryrun else ""
 
     def chop_setup(workload, profile=False):

@@ -46,7 +46,7 @@ typedef struct innfer_net* innfer_net_t;
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
  * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 103
+#define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -100,6 +100,15 @@ int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, v
  * row bands of R rows through the RRDB trunk (working set kept Infinity-Cache
  * resident; identical results). */
 int innfer_net_set_band_rows(innfer_net_t net, int rows);
+
+/* Scheduling knob: how the 32-output convs of a residual dense block (RRDBNet_arch.py:152-160) are launched.
+ * 0 (default) = one launch per layer.  1 = (conv1, conv2) and (conv3, conv4) as fused pairs on single-image forwards
+ * (csrc/conv_pair.hip: conv_b runs on the tile conv_a has just produced, its other inputs come from L2 / Infinity Cache instead
+ * of HBM; 0.43 x the HBM bytes of the two layers for 1.16 x their MFMA work); batches keep one launch per layer.  2 = pairs for
+ * batches too.  Results are bit-identical either way (every output sees the same operands in the same order); on MI355X the
+ * package is power-bound, not HBM-bound, on this network and the pairs measure 3 % slower per frame
+ * (profiles/r2/kernel_experiments.txt), hence the default. */
+int innfer_net_set_pair_convs(innfer_net_t net, int mode);
 
 /* `finalact` of the reference constructors (RRDBNet_arch.py:45-48: an activation module after the last conv):
  * 0 none (default), 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 6 sigmoid. */

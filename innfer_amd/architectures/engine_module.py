@@ -34,6 +34,7 @@ class EngineModule(nn.Module):
         self._weights_device = None          # GPU the engine's packed weights live on
         self._ws = None
         self.band_rows = 0
+        self.pair_convs = 0          # innfer_net_set_pair_convs: 0 one launch per layer (default), 1 fused conv pairs on single-image forwards, 2 always
 
     # ---- subclasses provide the C handle ------------------------------------
     def _create_handle(self):
@@ -104,6 +105,7 @@ class EngineModule(nn.Module):
         self._ensure_engine()
         self._weights_device = x.device
         L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
+        L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
         x = x.contiguous()
         N, _, H, W = x.shape
         s = L.lib.innfer_net_scale(self._handle)

@@ -63,7 +63,21 @@ struct ConvLaunch {
     int conv7;                                    // 7x7 conv, padding 3 (zero or `reflect`), panels from conv_pack7x7: OUT_NCHW, K <= 16 only
     int reflect;                                  // ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel)
     int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)
+    const f16* pair_wpk; const float* pair_bias;  // net.hip only: non-null = this 32-output LeakyReLU conv AND the next one of the dense block (inputs: the same
+                                                  // C channels + this conv's output, output: the following channel group) as one conv_pair_launch
 };
+
+// conv_a (C -> 32) and conv_b (C + 32 -> 32) of a residual dense block in one tile visit (conv_pair.hip): LeakyReLU(0.2) after both, bias, no
+// residuals; x_a goes to the channel group `out` = in + (C / 32) * in_gstride (the dense concat), x_b to the group after it.
+struct ConvPairLaunch {
+    const f16* in; long in_gstride; int C;        // C % 32 == 0, C >= 64
+    const f16* wpk_a; const float* bias_a;        // conv_pack(K = 32, C)
+    const f16* wpk_b; const float* bias_b;        // conv_pack(K = 32, C + 32)
+    f16* out;
+    int N, H, W;
+    int rev;
+};
+int conv_pair_launch(const ConvPairLaunch& L, hipStream_t s);
 
 // Panel geometry of packed weights.
 int conv_nt_for(int K);                           // 16-channel tiles per group: 1, 2 or 4

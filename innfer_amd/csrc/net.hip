@@ -46,6 +46,7 @@ struct innfer_net {
     int in_nc = 3, out_nc = 3, nf = 64, nb = 23, gc = 32, scale = 4, n_up = 2;
     int final_act = 0;           // `finalact` of the reference constructors: activation after the last conv (ConvLaunch.act codes)
     int band_rows = 0;
+    int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
     std::vector<ConvSlot> convs;
 };
@@ -186,6 +187,12 @@ extern "C" int innfer_net_set_band_rows(innfer_net_t net, int rows) {
     return INNFER_OK;
 }
 
+extern "C" int innfer_net_set_pair_convs(innfer_net_t net, int mode) {
+    if (!net || mode < 0 || mode > 2) return set_error(INNFER_ERR_INVALID, "set_pair_convs: mode 0, 1 or 2");
+    net->pair_convs = mode;
+    return INNFER_OK;
+}
+
 extern "C" int innfer_net_set_final_act(innfer_net_t net, int act) {
     if (!net || (act != 0 && act != 1 && act != 2 && act != 3 && act != 6))
         return set_error(INNFER_ERR_INVALID, "set_final_act: act %d (0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 6 sigmoid)", act);
@@ -307,13 +314,23 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
         ConvLaunch R = L;
         const int y1 = L.y1 > 0 ? L.y1 : L.H;
         R.rev = (alt && L.y0 == 0 && y1 == L.H) ? (int)(parity++ & 1) : 0;
-        rc = conv_launch(R, s);
+        if (L.pair_wpk) {
+            ConvPairLaunch P{};
+            P.in = L.in; P.in_gstride = L.in_gstride; P.C = L.C;
+            P.wpk_a = L.wpk; P.bias_a = L.bias; P.wpk_b = L.pair_wpk; P.bias_b = L.pair_bias;
+            P.out = (f16*)L.out; P.N = L.N; P.H = L.H; P.W = L.W; P.rev = R.rev;
+            rc = conv_pair_launch(P, s);
+        } else {
+            rc = conv_launch(R, s);
+        }
     }
     if (rc) return rc;
     rc = debug_after("conv3x3", s);
     if (rc) return rc;
     const int y1 = L.y1 > 0 ? L.y1 : L.H;
     const double px = (double)L.N * (y1 - L.y0) * L.W;
+    if (L.pair_wpk)      // both layers' FLOPs; bytes of the FUSED schedule: C channels in, 64 out, both panels
+        return timed_end(s, 2.0 * 9.0 * 32.0 * (2.0 * L.C + 32.0) * px, px * (L.C * 2.0 + 64.0 * 2.0) + 9.0 * 32.0 * (2.0 * L.C + 32.0) * 2.0, 1000);
     const int taps = L.conv1x1 ? 1 : 9;
     // algorithmic bytes per output pixel: C input channels (a quarter of them per pixel behind the folded nearest-2x), K outputs, K per residual
     const double obytes = L.out_mode == OUT_NCHW ? (L.out_f32 ? 4.0 : 2.0) : 2.0;
@@ -445,9 +462,14 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
                     const ConvSlot& cs = net->convs[ci++];
                     chain.push_back(mk(cs, S, G, t1x1, G, N, H, W, 0));
                 }
+                // (conv1, conv2) and (conv3, conv4) as fused pairs (conv_pair.hip) on whole-frame launches of the plain dense block
+                const bool pairs = (net->pair_convs == 2 || (net->pair_convs == 1 && N == 1)) && !net->plus && gc == 32 && nf % 32 == 0 && nf >= 64 && net->band_rows == 0 &&
+                                   (long)N * H * W * 64 < 0x7fffffffL;
                 for (int i = 0; i < 4; ++i) {
                     const ConvSlot& cs = net->convs[ci++];
+                    if (pairs && (i & 1)) continue;               // launched with its predecessor
                     ConvLaunch L = mk(cs, S, G, S + (long)((nf + i * gc) / 32) * G, G, N, H, W, 1);
+                    if (pairs) { L.pair_wpk = (const f16*)net->convs[ci].d_w; L.pair_bias = net->convs[ci].d_b; }
                     if (net->plus && i == 1) { L.res1 = t1x1; L.res1_gstride = G; L.s1 = 1.f; }          // x2 += conv1x1(x)
                     if (net->plus && i == 3) {                                                             // x4 += x2
                         L.res1 = S + (long)((nf + gc) / 32) * G; L.res1_gstride = G; L.s1 = 1.f;

@@ -451,6 +451,23 @@ def test_rrdbnet_banded_schedule_is_identical(dev):
     net.band_rows = 0
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 150, 70), (1, 3, 23, 31), (1, 3, 44, 60), (1, 3, 45, 61), (1, 3, 1, 1), (2, 3, 50, 33)])
+def test_rrdbnet_fused_conv_pairs_are_bit_identical(dev, shape):
+    """conv_pair.hip: (conv1, conv2) / (conv3, conv4) of every dense block in one tile visit (22 x 30 owned pixels of a 24 x 32 region,
+    x_a read back from L2) against one launch per layer -- ragged sizes, sizes that are whole tiles, one pixel, a batch (mode 2)."""
+    from innfer_amd import synth
+    net, _ = _rrdb(dev, 2, 2)
+    x = torch.from_numpy(synth.uniform(shape, 23)).to(dev).half()
+    net.pair_convs = 0
+    y = net(x)
+    net.pair_convs = 2
+    if net._ws is not None:
+        net._ws.fill_(0x7B)                       # stale x_a from the run before must not leak into the result
+    assert torch.equal(net(x), y)
+    net.pair_convs = 1
+    assert torch.equal(net(x), y)
+
+
 def test_srresnet_golden(dev, golden):
     from innfer_amd import synth
     from innfer_amd.architectures.SRResNet_arch import SRResNet
