@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -60,6 +60,13 @@ const char* innfer_last_error(void);
  * (x2 += conv1x1(x), x4 += x2: RRDBNet_arch.py:155-160; GaussianNoise is the identity in eval). */
 int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
                           int gc, int scale, int plus);
+
+/* The same with the graph-changing constructor arguments of RRDBNet_arch.py:16-48: nr = dense blocks per RRDB (3: parameters
+ * `RDB1..RDB3`, else `RDBs.<i>`, RRDBNet_arch.py:73-88); act = `act_type` of every conv block (1 LeakyReLU(0.2), 2 ReLU);
+ * pixelshuffle_up != 0 = upsample_mode 'pixelshuffle' (conv nf -> 4 nf, PixelShuffle(2), act: block.py:333-346) instead of
+ * 'upconv'.  innfer_rrdbnet_create(...) = innfer_rrdbnet_create_ex(..., 3, 1, 0).  (104) */
+int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
+                             int gc, int scale, int plus, int nr, int act, int pixelshuffle_up);
 
 /* SRResNet / SRGAN with the reference defaults (norm none, ReLU, CNA,
  * pixelshuffle, res_scale 1: utils/defaults.py:53-67). */
@@ -151,6 +158,10 @@ int innfer_unet_forward(innfer_unet_t u, const void* d_in, int in_dtype, void* d
  */
 typedef struct innfer_pan* innfer_pan_t;
 int innfer_pan_create(innfer_pan_t* out, int in_nc, int out_nc, int nf, int unf, int nb, int scale);
+/* The same with PAN's graph-changing constructor arguments (PAN_arch.py:115-141): self_attention = 0 drops the FSA block (fea + trunk goes
+ * straight to the upsampler), double_scpa != 0 runs a second SCPA trunk + `trunk_conv2` behind the first.  innfer_pan_create(...) =
+ * innfer_pan_create_ex(..., 1, 0).  (104) */
+int innfer_pan_create_ex(innfer_pan_t* out, int in_nc, int out_nc, int nf, int unf, int nb, int scale, int self_attention, int double_scpa);
 void innfer_pan_destroy(innfer_pan_t p);
 int innfer_pan_num_params(innfer_pan_t p);
 int innfer_pan_param_info(innfer_pan_t p, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
@@ -324,6 +335,13 @@ int innfer_u8hwc_to_nchw(const uint8_t* d_img, int H, int W, int C, int normaliz
                          void* d_out, int out_dtype, void* stream);
 int innfer_nchw_to_u8hwc(const void* d_in, int in_dtype, int H, int W, int C, int denormalize,
                          uint8_t* d_img, void* stream);
+/* The same with the remaining arguments of np2tensor / tensor2np (104).  bits: 8 or 16 (uint8 / uint16 image, MAX_VALUES_BY_DTYPE
+ * utils.py:22-33); maxval: what the image is divided by (255, 65535; 1 = change_range False); bgr2rgb / rgb2bgr = 0 keeps the channel order.
+ * innfer_nchw_to_inthwc scales by the data_range that goes with the type (255 / 65535), clips and rounds half to even. */
+int innfer_inthwc_to_nchw(const void* d_img, int bits, int H, int W, int C, int bgr2rgb, int normalize, float maxval,
+                          void* d_out, int out_dtype, void* stream);
+int innfer_nchw_to_inthwc(const void* d_in, int in_dtype, int H, int W, int C, int rgb2bgr, int denormalize, int bits,
+                          void* d_img, void* stream);
 
 /* srgb2linear / linear2srgb (utils/colors.py:29-46, 49-60), the pointwise halves of the `-cf` colour
  * fix: uint8 sRGB -> float32 linear, and float32 linear -> uint8 sRGB (clip, gamma, *255, TRUNCATING

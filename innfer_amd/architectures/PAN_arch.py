@@ -12,10 +12,14 @@ class PAN(ParamEngineModule):
     def __init__(self, in_nc=3, out_nc=3, nf=40, unf=24, nb=16, scale=4, self_attention=True,
                  double_scpa=False, ups_inter_mode='nearest'):
         super().__init__()
-        if not self_attention or double_scpa or ups_inter_mode != 'nearest':
-            raise NotImplementedError('PAN: only self_attention=True, double_scpa=False, nearest up-blocks are built')
+        if ups_inter_mode != 'nearest':
+            raise NotImplementedError('PAN: only nearest up-blocks are built (ups_inter_mode)')
         self.in_nc, self.out_nc, self.nf, self.unf, self.nb, self.scale = in_nc, out_nc, nf, unf, nb, scale
-        self._init_engine(in_nc, out_nc, nf, unf, nb, scale)
+        self.self_attention, self.double_scpa = bool(self_attention), bool(double_scpa)
+        self._init_engine(in_nc, out_nc, nf, unf, nb, scale, int(self.self_attention), int(self.double_scpa))
+
+    def _fn(self, name):
+        return super()._fn('create_ex' if name == 'create' else name)
 
     def _out_shape(self, N, H, W):
         return (N, self.out_nc, H * self.scale, W * self.scale)

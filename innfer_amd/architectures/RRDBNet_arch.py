@@ -10,32 +10,40 @@ from .keys import mrrdb_key_of, mrrdbnet_shapes, rrdbnet_shapes
 
 # `finalact` (block.py:81-101 act()) -> activation code of the last conv's epilogue
 _FINAL_ACT = {'relu': 2, 'leakyrelu': 1, 'lrelu': 1, 'tanh': 3, 'sigmoid': 6}
+# `act_type` of every conv block (block.py:81-90: LeakyReLU slope 0.2) -> activation code of the conv epilogues
+_TRUNK_ACT = {'leakyrelu': 1, 'relu': 2}
 
 
 class RRDBNet(EngineModule):
     def __init__(self, in_nc, out_nc, nf, nb, nr=3, gc=32, upscale=4, norm_type=None,
                  act_type='leakyrelu', mode='CNA', upsample_mode='upconv', convtype='Conv2D',
                  finalact=None, gaussian_noise=False, plus=False):
+        if upsample_mode not in ('upconv', 'pixelshuffle'):      # the reference's own error (RRDBNet_arch.py:32-33)
+            raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
         unsupported = []
-        if nr != 3: unsupported.append(f'nr={nr}')
+        if not isinstance(nr, int) or nr < 1: unsupported.append(f'nr={nr}')
         if norm_type: unsupported.append(f'norm_type={norm_type}')
-        if act_type not in ('leakyrelu', 'lrelu'): unsupported.append(f'act_type={act_type}')
-        if mode != 'CNA': unsupported.append(f'mode={mode}')
-        if upsample_mode != 'upconv': unsupported.append(f'upsample_mode={upsample_mode}')
+        if act_type not in _TRUNK_ACT: unsupported.append(f'act_type={act_type}')
+        # mode: the dense blocks are built with mode='CNA' whatever is passed (RRDBNet_arch.py:27-29); only LR_conv takes it, and without
+        # a norm layer or an activation a 'NAC' / 'CNAC' conv_block is the bare conv (block.py:237-254)
+        if mode not in ('CNA', 'NAC', 'CNAC'): unsupported.append(f'mode={mode}')
+        if upsample_mode == 'pixelshuffle' and (upscale == 3 or nf != 64): unsupported.append(f'upsample_mode=pixelshuffle with upscale={upscale}, nf={nf}')
         if convtype != 'Conv2D': unsupported.append(f'convtype={convtype}')
         if finalact and finalact.lower() not in _FINAL_ACT: unsupported.append(f'finalact={finalact}')
         if unsupported:
             raise NotImplementedError('RRDBNet option(s) not built on the HIP path yet: ' + ', '.join(unsupported))
         # gaussian_noise: GaussianNoise is the identity in eval mode (block.py:382-388)
-        super().__init__(rrdbnet_shapes(in_nc, out_nc, nf, nb, 32, upscale, plus))
+        super().__init__(rrdbnet_shapes(in_nc, out_nc, nf, nb, 32, upscale, plus, nr, upsample_mode))
         self.in_nc, self.out_nc, self.nf, self.nb, self.gc, self.upscale = in_nc, out_nc, nf, nb, 32, upscale
-        self.plus = bool(plus)
+        self.plus, self.nr = bool(plus), nr
+        self.trunk_act = _TRUNK_ACT[act_type]
+        self.pixelshuffle_up = upsample_mode == 'pixelshuffle'
         self.final_act = _FINAL_ACT[finalact.lower()] if finalact else 0
 
     def _create_handle(self):
         h = C.c_void_p()
-        L.check(L.lib.innfer_rrdbnet_create(C.byref(h), self.in_nc, self.out_nc, self.nf, self.nb,
-                                            self.gc, self.upscale, int(self.plus)))
+        L.check(L.lib.innfer_rrdbnet_create_ex(C.byref(h), self.in_nc, self.out_nc, self.nf, self.nb, self.gc, self.upscale,
+                                               int(self.plus), self.nr, self.trunk_act, int(self.pixelshuffle_up)))
         L.check(L.lib.innfer_net_set_final_act(h, self.final_act))
         return h
 

@@ -82,7 +82,10 @@ class EngineModule(nn.Module):
         self._handle, self._uploaded_version, self._ws = None, None, None
 
     def __del__(self):
-        self._destroy_handle()
+        try:
+            self._destroy_handle()
+        except Exception:          # interpreter shutdown: torch's module machinery may already be torn down
+            pass
 
     # ---- forward ---------------------------------------------------------------
     def forward(self, x):

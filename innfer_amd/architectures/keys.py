@@ -6,14 +6,15 @@ files load with strict=True.
 """
 
 
-def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False):
+def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False, nr=3, upsample_mode='upconv'):
     """State-dict key -> shape of the reference's old-arch ESRGAN
-    (reference RRDBNet_arch.py:16-48; key layout SURVEY.md 3.3)."""
+    (reference RRDBNet_arch.py:16-48; key layout SURVEY.md 3.3).  nr != 3: the dense blocks are `RDBs.<i>` (RRDBNet_arch.py:84-88);
+    upsample_mode 'pixelshuffle': the stage's conv (nf -> 4 nf, 9 nf for scale 3) comes first (block.py:333-346)."""
     import math
     s = {"model.0.weight": (nf, in_nc, 3, 3), "model.0.bias": (nf,)}
     for b in range(nb):
-        for r in (1, 2, 3):
-            p = f"model.1.sub.{b}.RDB{r}."
+        for r in range(1, nr + 1):
+            p = f"model.1.sub.{b}.RDB{r}." if nr == 3 else f"model.1.sub.{b}.RDBs.{r - 1}."
             if plus:
                 s[p + "conv1x1.weight"] = (gc, nf, 1, 1)
             for i in range(1, 6):
@@ -26,8 +27,13 @@ def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False):
     n_up = 1 if scale == 3 else int(math.log(scale, 2))
     idx = 2
     for _ in range(n_up):
-        s[f"model.{idx + 1}.weight"] = (nf, nf, 3, 3)
-        s[f"model.{idx + 1}.bias"] = (nf,)
+        if upsample_mode == 'pixelshuffle':
+            f = 9 if scale == 3 else 4
+            s[f"model.{idx}.weight"] = (nf * f, nf, 3, 3)
+            s[f"model.{idx}.bias"] = (nf * f,)
+        else:
+            s[f"model.{idx + 1}.weight"] = (nf, nf, 3, 3)
+            s[f"model.{idx + 1}.bias"] = (nf,)
         idx += 3
     s[f"model.{idx}.weight"] = (nf, nf, 3, 3)
     s[f"model.{idx}.bias"] = (nf,)

@@ -46,6 +46,9 @@ struct innfer_net {
     int in_nc = 3, out_nc = 3, nf = 64, nb = 23, gc = 32, scale = 4, n_up = 2;
     int final_act = 0;           // `finalact` of the reference constructors: activation after the last conv (ConvLaunch.act codes)
     int band_rows = 0;
+    int nr = 3;                  // dense blocks per RRDB (RRDBNet_arch.py:73-88)
+    int trunk_act = 1;           // `act_type` of the constructors as a ConvLaunch.act code: 1 LeakyReLU(0.2), 2 ReLU
+    bool ps_up = false;          // RRDBNet(upsample_mode='pixelshuffle'): conv nf -> 4 nf, PixelShuffle(2), act instead of Upsample, conv, act
     int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
     std::vector<ConvSlot> convs;
@@ -69,7 +72,16 @@ extern "C" const char* innfer_last_error(void) { return g_err.c_str(); }
 
 extern "C" int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
                                      int gc, int scale, int plus) {
+    return innfer_rrdbnet_create_ex(out, in_nc, out_nc, nf, nb, gc, scale, plus, 3, 1, 0);
+}
+
+extern "C" int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
+                                        int gc, int scale, int plus, int nr, int act, int pixelshuffle_up) {
     if (!out) return set_error(INNFER_ERR_INVALID, "rrdbnet_create: null out");
+    if (nr < 1 || nr > 64 || (act != 1 && act != 2))
+        return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: nr=%d act=%d (built: nr >= 1; act 1 LeakyReLU(0.2), 2 ReLU)", nr, act);
+    if (pixelshuffle_up && (scale == 3 || nf != 64))
+        return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: the PixelShuffle upsampler is built for factor-2 stages of nf=64 (scale %d, nf %d)", scale, nf);
     if (scale != 1 && scale != 2 && scale != 3 && scale != 4 && scale != 8 && scale != 16)
         return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: scale %d (built: 1, 2, 3, 4, 8, 16)", scale);
     if (nf % 32 || gc % 32 || nf <= 0 || gc <= 0 || nf > 64)
@@ -79,23 +91,25 @@ extern "C" int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, i
     innfer_net* net = new innfer_net();
     net->kind = 0; net->in_nc = in_nc; net->out_nc = out_nc; net->nf = nf; net->nb = nb;
     net->gc = gc; net->scale = scale; net->n_up = n_upscale(scale); net->plus = plus != 0;
+    net->nr = nr; net->trunk_act = act; net->ps_up = pixelshuffle_up != 0;
     add_conv(net, "model.0", nf, in_nc, true);
     for (int b = 0; b < nb; ++b)
-        for (int r = 1; r <= 3; ++r) {
-            if (plus) {          // conv1x1(nf -> gc, no bias), added to x2 (RRDBNet_arch.py:131,155-156)
-                char key[96];
-                snprintf(key, sizeof key, "model.1.sub.%d.RDB%d.conv1x1", b, r);
-                add_conv(net, key, gc, nf, false, 1);
-            }
-            for (int i = 1; i <= 5; ++i) {
-                char key[96];
-                snprintf(key, sizeof key, "model.1.sub.%d.RDB%d.conv%d.0", b, r, i);
-                add_conv(net, key, i < 5 ? gc : nf, nf + (i - 1) * gc);
-            }
+        for (int r = 1; r <= nr; ++r) {
+            char rdb[96];        // nr == 3: attributes RDB1..RDB3, else nn.Sequential `RDBs` (RRDBNet_arch.py:73-88)
+            if (nr == 3) snprintf(rdb, sizeof rdb, "model.1.sub.%d.RDB%d", b, r);
+            else snprintf(rdb, sizeof rdb, "model.1.sub.%d.RDBs.%d", b, r - 1);
+            if (plus)            // conv1x1(nf -> gc, no bias), added to x2 (RRDBNet_arch.py:131,155-156)
+                add_conv(net, std::string(rdb) + ".conv1x1", gc, nf, false, 1);
+            for (int i = 1; i <= 5; ++i)
+                add_conv(net, std::string(rdb) + ".conv" + std::to_string(i) + ".0", i < 5 ? gc : nf, nf + (i - 1) * gc);
         }
     add_conv(net, "model.1.sub." + std::to_string(nb), nf, nf);
     int idx = 2;
-    for (int u = 0; u < net->n_up; ++u) { add_conv(net, "model." + std::to_string(idx + 1), nf, nf); idx += 3; }
+    for (int u = 0; u < net->n_up; ++u) {        // upconv_block: Upsample, conv, act -- pixelshuffle_block: conv, PixelShuffle, act (block.py:333-361)
+        if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * 4, nf);
+        else add_conv(net, "model." + std::to_string(idx + 1), nf, nf);
+        idx += 3;
+    }
     add_conv(net, "model." + std::to_string(idx), nf, nf);
     add_conv(net, "model." + std::to_string(idx + 2), out_nc, nf);
     *out = net;
@@ -213,7 +227,7 @@ extern "C" double innfer_net_flops(innfer_net_t net, int N, int H, int W) {
         if (i >= tail0) {
             const int u = i - tail0;
             const double f2 = net->scale == 3 ? 9.0 : 4.0;     // pixels per input pixel after one upsample stage
-            if (u < net->n_up) mult = std::pow(f2, net->kind == 0 ? u + 1 : u);
+            if (u < net->n_up) mult = std::pow(f2, (net->kind == 0 && !net->ps_up) ? u + 1 : u);
             else mult = std::pow(f2, net->n_up);
         }
         f += 2.0 * c.ksize * c.ksize * c.K * c.C * px * mult;
@@ -451,24 +465,27 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     int cur = 0;
     if (net->kind == 0) {
         for (int b = 0; b < net->nb; ++b) {
+            // three rotating slabs: the RRDB's input stays untouched (its x*0.2 + x residual) while the blocks ping-pong between the other two
             const int in_slab = cur;
-            int f1 = (cur + 1) % 3, f2 = (cur + 2) % 3;
-            const int work[3] = {in_slab, f1, f2};
-            const int dest[3] = {f1, f2, f1};
-            for (int r = 0; r < 3; ++r) {
-                f16* S = slab[work[r]];
+            const int f1 = (cur + 1) % 3, f2 = (cur + 2) % 3;
+            const int nr = net->nr;
+            int last = in_slab;
+            for (int r = 0; r < nr; ++r) {
+                const int work_r = last, dest_r = (r == 0 || last == f2) ? f1 : f2;
+                last = dest_r;
+                f16* S = slab[work_r];
                 f16* t1x1 = (f16*)(ws + cv.tmp);
                 if (net->plus) {                 // t = conv1x1(x): no bias, no activation
                     const ConvSlot& cs = net->convs[ci++];
                     chain.push_back(mk(cs, S, G, t1x1, G, N, H, W, 0));
                 }
                 // (conv1, conv2) and (conv3, conv4) as fused pairs (conv_pair.hip) on whole-frame launches of the plain dense block
-                const bool pairs = (net->pair_convs == 2 || (net->pair_convs == 1 && N == 1)) && !net->plus && gc == 32 && nf % 32 == 0 && nf >= 64 && net->band_rows == 0 &&
+                const bool pairs = (net->pair_convs == 2 || (net->pair_convs == 1 && N == 1)) && !net->plus && net->trunk_act == 1 && gc == 32 && nf % 32 == 0 && nf >= 64 && net->band_rows == 0 &&
                                    (long)N * H * W * 64 < 0x7fffffffL;
                 for (int i = 0; i < 4; ++i) {
                     const ConvSlot& cs = net->convs[ci++];
                     if (pairs && (i & 1)) continue;               // launched with its predecessor
-                    ConvLaunch L = mk(cs, S, G, S + (long)((nf + i * gc) / 32) * G, G, N, H, W, 1);
+                    ConvLaunch L = mk(cs, S, G, S + (long)((nf + i * gc) / 32) * G, G, N, H, W, net->trunk_act);
                     if (pairs) { L.pair_wpk = (const f16*)net->convs[ci].d_w; L.pair_bias = net->convs[ci].d_b; }
                     if (net->plus && i == 1) { L.res1 = t1x1; L.res1_gstride = G; L.s1 = 1.f; }          // x2 += conv1x1(x)
                     if (net->plus && i == 3) {                                                             // x4 += x2
@@ -477,12 +494,12 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
                     chain.push_back(L);
                 }
                 const ConvSlot& cs = net->convs[ci++];
-                ConvLaunch L = mk(cs, S, G, slab[dest[r]], G, N, H, W, 0);
+                ConvLaunch L = mk(cs, S, G, slab[dest_r], G, N, H, W, 0);
                 L.res1 = S; L.res1_gstride = G; L.s1 = 0.2f;                      // x5*0.2 + x
-                if (r == 2) { L.res2 = slab[in_slab]; L.res2_gstride = G; L.s2 = 0.2f; }   // RRDB: out*0.2 + x
+                if (r == nr - 1) { L.res2 = slab[in_slab]; L.res2_gstride = G; L.s2 = 0.2f; }   // RRDB: out*0.2 + x
                 chain.push_back(L);
             }
-            cur = f1;
+            cur = last;
         }
     } else {
         // SRGAN residual blocks: t = t + conv(relu(conv(t))) on nf-wide slabs
@@ -517,17 +534,17 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             const long g3 = gi * 9, nthr = (long)N * 9 * h * w * 4 * (net->nf / 32);
             hipLaunchKernelGGL(slab_upsample_nearest, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, t, gi, U, g3, net->nf / 32, N, h, w, 3);
             INNFER_HIP(hipGetLastError());
-            rc = do_conv(mk(cs, U, g3, dst, g3, N, 3 * h, 3 * w, 1), s);
+            rc = do_conv(mk(cs, U, g3, dst, g3, N, 3 * h, 3 * w, net->trunk_act), s);
             if (rc) return rc;
             t = dst; h *= 3; w *= 3;
             continue;
         }
-        if (net->kind == 0) {        // Upsample(nearest 2x) -> conv -> LeakyReLU
-            ConvLaunch L = mk(cs, t, gi, dst, go, N, 2 * h, 2 * w, 1);
+        if (net->kind == 0 && !net->ps_up) {        // Upsample(nearest 2x) -> conv -> act
+            ConvLaunch L = mk(cs, t, gi, dst, go, N, 2 * h, 2 * w, net->trunk_act);
             L.up = 1;
             rc = do_conv(L, s);
-        } else {                     // conv nf->4nf -> PixelShuffle(2) -> ReLU
-            ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, 2);
+        } else {                     // conv nf->4nf -> PixelShuffle(2) -> act (SRGAN: ReLU; RRDBNet(upsample_mode='pixelshuffle'): its act_type)
+            ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, net->kind == 0 ? net->trunk_act : 2);
             L.out_mode = OUT_SHUFFLE2;
             rc = do_conv(L, s);
         }
@@ -537,7 +554,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     {
         const ConvSlot& cs = net->convs[ci++];
         const long gh = (long)N * h * w * 32;
-        ConvLaunch L = mk(cs, t, gh, ws + cv.hr, gh, N, h, w, net->kind == 0 ? 1 : 2);
+        ConvLaunch L = mk(cs, t, gh, ws + cv.hr, gh, N, h, w, net->kind == 0 ? net->trunk_act : 2);
         rc = do_conv(L, s);
         if (rc) return rc;
     }

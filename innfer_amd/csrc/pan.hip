@@ -267,6 +267,8 @@ struct Gemm {                       // one packed GEMM
 
 struct innfer_pan {
     int in_nc = 3, out_nc = 3, nf = 40, unf = 24, nb = 16, scale = 4, n_up = 2;
+    bool self_attention = true;      // FSA after fea + trunk (PAN_arch.py:200-203)
+    bool double_scpa = false;        // a second SCPA trunk + trunk_conv2 behind the first (PAN_arch.py:139-141,195-196)
     std::vector<Param> params;
     std::vector<Gemm> gemms;
     std::vector<float*> d_vecs;      // device copies of bias vectors / gamma, by param index (nullptr if unused)
@@ -280,6 +282,10 @@ static int P(innfer_pan* p, const std::string& key, std::vector<int> shape) {
 }
 
 extern "C" int innfer_pan_create(innfer_pan** out, int in_nc, int out_nc, int nf, int unf, int nb, int scale) {
+    return innfer_pan_create_ex(out, in_nc, out_nc, nf, unf, nb, scale, 1, 0);
+}
+
+extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int nf, int unf, int nb, int scale, int self_attention, int double_scpa) {
     if (!out) return set_error(INNFER_ERR_INVALID, "pan_create: null out");
     if (nf != 40 || unf != 24 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || nb < 1 ||
         (scale != 1 && scale != 2 && scale != 4))
@@ -287,21 +293,27 @@ extern "C" int innfer_pan_create(innfer_pan** out, int in_nc, int out_nc, int nf
     innfer_pan* p = new innfer_pan();
     p->in_nc = in_nc; p->out_nc = out_nc; p->nf = nf; p->unf = scale == 1 ? nf : unf; p->nb = nb; p->scale = scale;
     p->n_up = scale == 4 ? 2 : (scale == 2 ? 1 : 0);
+    p->self_attention = self_attention != 0; p->double_scpa = double_scpa != 0;
     const int gw = nf / 2, UF = p->unf;
     P(p, "conv_first.weight", {nf, in_nc, 3, 3}); P(p, "conv_first.bias", {nf});
-    for (int b = 0; b < nb; ++b) {
-        const std::string s = "SCPA_trunk." + std::to_string(b) + ".";
-        P(p, s + "conv1_a.weight", {gw, nf, 1, 1}); P(p, s + "conv1_b.weight", {gw, nf, 1, 1});
-        P(p, s + "k1.0.weight", {gw, gw, 3, 3});
-        P(p, s + "PACnv.k2.weight", {gw, gw, 1, 1}); P(p, s + "PACnv.k2.bias", {gw});
-        P(p, s + "PACnv.k3.weight", {gw, gw, 3, 3}); P(p, s + "PACnv.k4.weight", {gw, gw, 3, 3});
-        P(p, s + "conv3.weight", {nf, nf, 1, 1});
+    for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {          // registration order of PAN.__init__ (PAN_arch.py:134-141)
+        const std::string sfx = k ? "2" : "";
+        for (int b = 0; b < nb; ++b) {
+            const std::string s = "SCPA_trunk" + sfx + "." + std::to_string(b) + ".";
+            P(p, s + "conv1_a.weight", {gw, nf, 1, 1}); P(p, s + "conv1_b.weight", {gw, nf, 1, 1});
+            P(p, s + "k1.0.weight", {gw, gw, 3, 3});
+            P(p, s + "PACnv.k2.weight", {gw, gw, 1, 1}); P(p, s + "PACnv.k2.bias", {gw});
+            P(p, s + "PACnv.k3.weight", {gw, gw, 3, 3}); P(p, s + "PACnv.k4.weight", {gw, gw, 3, 3});
+            P(p, s + "conv3.weight", {nf, nf, 1, 1});
+        }
+        P(p, "trunk_conv" + sfx + ".weight", {nf, nf, 3, 3}); P(p, "trunk_conv" + sfx + ".bias", {nf});
     }
-    P(p, "trunk_conv.weight", {nf, nf, 3, 3}); P(p, "trunk_conv.bias", {nf});
-    P(p, "FSA.gamma", {1});
-    P(p, "FSA.conv_f.weight", {nf / 8, nf, 1}); P(p, "FSA.conv_f.bias", {nf / 8});
-    P(p, "FSA.conv_g.weight", {nf / 8, nf, 1}); P(p, "FSA.conv_g.bias", {nf / 8});
-    P(p, "FSA.conv_h.weight", {nf, nf, 1}); P(p, "FSA.conv_h.bias", {nf});
+    if (p->self_attention) {
+        P(p, "FSA.gamma", {1});
+        P(p, "FSA.conv_f.weight", {nf / 8, nf, 1}); P(p, "FSA.conv_f.bias", {nf / 8});
+        P(p, "FSA.conv_g.weight", {nf / 8, nf, 1}); P(p, "FSA.conv_g.bias", {nf / 8});
+        P(p, "FSA.conv_h.weight", {nf, nf, 1}); P(p, "FSA.conv_h.bias", {nf});
+    }
     for (int u = 0; u < p->n_up; ++u) {
         const int i = 5 * u, ci = u == 0 ? nf : UF;
         const std::string s = "upsample.";
@@ -362,8 +374,10 @@ int build_gemms(innfer_pan* p) {
     };
     {   const auto& w = W("conv_first.weight"); const int ci_n = p->in_nc;
         add(32, nf, 9, [&w, ci_n](int co, int ci, int t) { return ci < ci_n ? w[((size_t)co * ci_n + ci) * 9 + t] : 0.f; }, "conv_first.bias"); }
+    for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {
+    const std::string sfx = k ? "2" : "";
     for (int b = 0; b < p->nb; ++b) {
-        const std::string s = "SCPA_trunk." + std::to_string(b) + ".";
+        const std::string s = "SCPA_trunk" + sfx + "." + std::to_string(b) + ".";
         const auto &wa = W(s + "conv1_a.weight"), &wb = W(s + "conv1_b.weight"), &k1 = W(s + "k1.0.weight"),
                    &k2 = W(s + "PACnv.k2.weight"), &k3 = W(s + "PACnv.k3.weight"), &k4 = W(s + "PACnv.k4.weight"),
                    &c3 = W(s + "conv3.weight");
@@ -385,9 +399,12 @@ int build_gemms(innfer_pan* p) {
             if (ci < gw) return c3[(size_t)co * nf + ci];
             return ci >= 32 && ci < 32 + gw ? c3[(size_t)co * nf + gw + (ci - 32)] : 0.f; }, "");
     }
-    {   const auto& w = W("trunk_conv.weight");
-        add(64, nf, 9, [&w, nf](int co, int ci, int t) { return ci < nf ? w[((size_t)co * nf + ci) * 9 + t] : 0.f; }, "trunk_conv.bias"); }
-    {   const auto &wf = W("FSA.conv_f.weight"), &wg = W("FSA.conv_g.weight"), &wh = W("FSA.conv_h.weight");
+    {   const auto& w = W("trunk_conv" + sfx + ".weight");
+        const std::string bk = "trunk_conv" + sfx + ".bias";
+        add(64, nf, 9, [&w, nf](int co, int ci, int t) { return ci < nf ? w[((size_t)co * nf + ci) * 9 + t] : 0.f; }, bk.c_str()); }
+    }
+    if (p->self_attention) {
+        const auto &wf = W("FSA.conv_f.weight"), &wg = W("FSA.conv_g.weight"), &wh = W("FSA.conv_h.weight");
         const int cq = nf / 8;
         add(64, 2 * cq + nf, 1, [&wf, &wg, &wh, nf, cq](int co, int ci, int) {
             if (ci >= nf) return 0.f;
@@ -493,7 +510,8 @@ extern "C" size_t innfer_pan_workspace_bytes(innfer_pan* p, int N, int H, int W)
 extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                                   int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
     if (!p || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "pan_forward: null argument");
-    if (N <= 0 || H < 4 || W < 4) return set_error(INNFER_ERR_INVALID, "pan_forward: input must be at least 4x4 (MaxPool2d(4))");
+    if (N <= 0 || H <= 0 || W <= 0 || (p->self_attention && (H < 4 || W < 4)))
+        return set_error(INNFER_ERR_INVALID, "pan_forward: input must be at least 4x4 (MaxPool2d(4))");
     if (!p->uploaded) { int rc = upload(p); if (rc) return rc; }
     const PCarve cv = pcarve(p, N, H, W);
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "pan_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
@@ -541,6 +559,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     INNFER_HIP(hipGetLastError());
     CK(conv3(X0, G, H, W, 0, 0, nullptr, 0, FEA, G));                                  // conv_first
     const f16* x = FEA;
+    for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {
     for (int b = 0; b < p->nb; ++b) {
         f16* xn = (b & 1) ? XB : XA;
         CK(conv3(x, G, H, W, 0, 1, nullptr, 0, AB, G));                               // lrelu([conv1_a | . | conv1_b]): a -> group 0, b -> group 1
@@ -551,8 +570,15 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         CK(conv3(AB2, G, H, W, 0, 0, x, G, xn, G));                                   // conv3(cat[a,b]) + x
         x = xn;
     }
-    CK(conv3(x, G, H, W, 0, 0, FEA, G, INP, G));                                       // trunk_conv; inp = fea + trunk
-    {   // FSA
+    if (p->double_scpa && k == 0) {
+        CK(conv3(x, G, H, W, 0, 0, nullptr, 0, INP, G));                               // trunk_conv; the second trunk starts from it
+        x = INP;
+    } else {
+        CK(conv3(x, G, H, W, 0, 0, FEA, G, p->double_scpa ? T : INP, G));              // last trunk conv; + fea (INP still feeds the second trunk's first block)
+    }
+    }
+    if (p->double_scpa) { f16* sw = INP; INP = T; T = sw; }                             // INP = fea + trunk from here on
+    if (p->self_attention) {   // FSA
         const int hp = H / 4, wp = W / 4;
         const long np = (long)N * hp * wp, Gp = np * 32;
         hipLaunchKernelGGL(pan_maxpool, dim3((unsigned)((np * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, INP, G, nf, N, H, W, hp, wp, POOL, Gp);
@@ -568,7 +594,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
                            INP, G, N, H, W, vec("FSA.gamma"), T);
         INNFER_HIP(hipGetLastError());
     }
-    const f16* cur = T;
+    const f16* cur = p->self_attention ? T : INP;
     long cur_g = G;
     int h = H, w = W;
     for (int u = 0; u < p->n_up; ++u) {
@@ -577,7 +603,10 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         f16 *V = (f16*)(ws + cv.hr[u][0]), *PA = (f16*)(ws + cv.hr[u][1]), *HRC = (f16*)(ws + cv.hr[u][2]);
         CK(conv3(cur, cur_g, hh, ww, 1, 0, nullptr, 0, V, HG));                        // conv(nearest2x(t))
         CK(conv3(V, HG, hh, ww, 0, 4, V, HG, PA, HG));                                 // PA: lrelu(v * sigmoid(conv1x1(v)))
-        CK(conv3(PA, HG, hh, ww, 0, 0, nullptr, 0, HRC, HG));                          // HRconv (no activation follows)
+        // HRconv.  Two stages (4x): PAN's outer B.sequential flattens the stages with children(), which yields the shared LeakyReLU once per
+        // stage -- nothing follows HRconv.  One stage (2x): the stage's own nn.Sequential is used as it is and holds the LeakyReLU in two slots,
+        // so HRconv IS followed by it (PAN_arch.py:11-19, block.py:197-210; golden G18)
+        CK(conv3(PA, HG, hh, ww, 0, p->n_up == 1 ? 1 : 0, nullptr, 0, HRC, HG));
         cur = HRC; cur_g = HG; h = hh; w = ww;
     }
     CK(conv3(cur, cur_g, h, w, 0, 0, nullptr, 0, nullptr, 0, raw));                    // conv_last -> planar fp32 (+ bias)

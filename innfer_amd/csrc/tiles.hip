@@ -111,14 +111,15 @@ __global__ void k_recompose(const TI* tiles, TO* out, int C, int P, int FH, int 
 
 // np2tensor: float32(u8)/255 -> HWC->CHW -> BGR->RGB flip (C%3==0: full flip; C==4: [2,1,0,3])
 // -> optional ((x-0.5)*2).clamp(-1,1).  One thread per pixel, all channels.
-template <typename TO>
-__global__ void k_u8_to_nchw(const uint8_t* img, TO* out, long hw, int C, int normalize) {
+// TI uint8_t / uint16_t, maxval = MAX_VALUES_BY_DTYPE (utils.py:22-33: 255 / 65535; 1 with change_range=False); flip 0: bgr2rgb=False
+template <typename TI, typename TO>
+__global__ void k_u8_to_nchw(const TI* img, TO* out, long hw, int C, int normalize, float maxval, int flip) {
     const long px = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (px >= hw) return;
     for (int c = 0; c < C; ++c) {
         int sc = c;
-        if (C % 3 == 0) sc = C - 1 - c; else if (C == 4 && c < 3) sc = 2 - c;
-        float v = __fdiv_rn((float)img[px * C + sc], 255.0f);
+        if (flip) { if (C % 3 == 0) sc = C - 1 - c; else if (C == 4 && c < 3) sc = 2 - c; }
+        float v = __fdiv_rn((float)img[px * C + sc], maxval);
         if (normalize) {
             v = __fmul_rn(__fsub_rn(v, 0.5f), 2.0f);
             v = fminf(fmaxf(v, -1.0f), 1.0f);
@@ -129,21 +130,22 @@ __global__ void k_u8_to_nchw(const uint8_t* img, TO* out, long hw, int C, int no
 
 // tensor2np: .float() -> RGB->BGR flip -> CHW->HWC -> optional denorm ((x+1)/2).clip(0,1)
 // -> clip(255*x, 0, 255).round() (half to even) -> uint8.
-template <typename TI>
-__global__ void k_nchw_to_u8(const TI* in, uint8_t* img, long hw, int C, int denormalize) {
+// TU uint8_t / uint16_t with data_range 255 / 65535 (tensor2np(data_range=, imtype=)); flip 0: rgb2bgr=False
+template <typename TI, typename TU>
+__global__ void k_nchw_to_u8(const TI* in, TU* img, long hw, int C, int denormalize, float range, int flip) {
     const long px = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (px >= hw) return;
     for (int c = 0; c < C; ++c) {
         int sc = c;
-        if (C == 3) sc = 2 - c; else if (C == 4 && c < 3) sc = 2 - c;
+        if (flip) { if (C == 3) sc = 2 - c; else if (C == 4 && c < 3) sc = 2 - c; }
         float v = (float)in[(long)sc * hw + px];
         if (denormalize) {
             v = __fdiv_rn(__fsub_rn(v, -1.0f), 2.0f);
             v = fminf(fmaxf(v, 0.0f), 1.0f);
         }
-        v = __fmul_rn(255.0f, v);
-        v = fminf(fmaxf(v, 0.0f), 255.0f);
-        img[px * C + c] = (uint8_t)__float2int_rn(v);          // round half to even
+        v = __fmul_rn(range, v);
+        v = fminf(fmaxf(v, 0.0f), range);
+        img[px * C + c] = (TU)__float2int_rn(v);               // round half to even
     }
 }
 
@@ -292,9 +294,43 @@ extern "C" int innfer_u8hwc_to_nchw(const uint8_t* d_img, int H, int W, int C, i
     const long hw = (long)H * W;
     if (hw <= 0 || C <= 0) return set_error(INNFER_ERR_INVALID, "u8hwc_to_nchw: bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    if (out_dtype == INNFER_F16) hipLaunchKernelGGL(k_u8_to_nchw<f16>, dim3(blocks(hw, 256)), dim3(256), 0, s, d_img, (f16*)d_out, hw, C, normalize);
-    else if (out_dtype == INNFER_F32) hipLaunchKernelGGL(k_u8_to_nchw<float>, dim3(blocks(hw, 256)), dim3(256), 0, s, d_img, (float*)d_out, hw, C, normalize);
+    if (out_dtype == INNFER_F16) hipLaunchKernelGGL((k_u8_to_nchw<uint8_t, f16>), dim3(blocks(hw, 256)), dim3(256), 0, s, d_img, (f16*)d_out, hw, C, normalize, 255.0f, 1);
+    else if (out_dtype == INNFER_F32) hipLaunchKernelGGL((k_u8_to_nchw<uint8_t, float>), dim3(blocks(hw, 256)), dim3(256), 0, s, d_img, (float*)d_out, hw, C, normalize, 255.0f, 1);
     else return set_error(INNFER_ERR_INVALID, "u8hwc_to_nchw: bad dtype");
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_inthwc_to_nchw(const void* d_img, int bits, int H, int W, int C, int bgr2rgb, int normalize, float maxval,
+                                     void* d_out, int out_dtype, void* stream) {
+    const long hw = (long)H * W;
+    if (!d_img || !d_out || hw <= 0 || C <= 0 || !(maxval > 0.f)) return set_error(INNFER_ERR_INVALID, "inthwc_to_nchw: bad arguments");
+    if ((bits != 8 && bits != 16) || (out_dtype != INNFER_F16 && out_dtype != INNFER_F32))
+        return set_error(INNFER_ERR_INVALID, "inthwc_to_nchw: bits %d (8, 16), dtype %d", bits, out_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(blocks(hw, 256)), b(256);
+    const int f = bgr2rgb ? 1 : 0;
+    if (bits == 8 && out_dtype == INNFER_F16) hipLaunchKernelGGL((k_u8_to_nchw<uint8_t, f16>), g, b, 0, s, (const uint8_t*)d_img, (f16*)d_out, hw, C, normalize, maxval, f);
+    else if (bits == 8) hipLaunchKernelGGL((k_u8_to_nchw<uint8_t, float>), g, b, 0, s, (const uint8_t*)d_img, (float*)d_out, hw, C, normalize, maxval, f);
+    else if (out_dtype == INNFER_F16) hipLaunchKernelGGL((k_u8_to_nchw<uint16_t, f16>), g, b, 0, s, (const uint16_t*)d_img, (f16*)d_out, hw, C, normalize, maxval, f);
+    else hipLaunchKernelGGL((k_u8_to_nchw<uint16_t, float>), g, b, 0, s, (const uint16_t*)d_img, (float*)d_out, hw, C, normalize, maxval, f);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_nchw_to_inthwc(const void* d_in, int in_dtype, int H, int W, int C, int rgb2bgr, int denormalize, int bits,
+                                     void* d_img, void* stream) {
+    const long hw = (long)H * W;
+    if (!d_in || !d_img || hw <= 0 || C <= 0) return set_error(INNFER_ERR_INVALID, "nchw_to_inthwc: bad arguments");
+    if ((bits != 8 && bits != 16) || (in_dtype != INNFER_F16 && in_dtype != INNFER_F32))
+        return set_error(INNFER_ERR_INVALID, "nchw_to_inthwc: bits %d (8, 16), dtype %d", bits, in_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(blocks(hw, 256)), b(256);
+    const int f = rgb2bgr ? 1 : 0;
+    if (bits == 8 && in_dtype == INNFER_F16) hipLaunchKernelGGL((k_nchw_to_u8<f16, uint8_t>), g, b, 0, s, (const f16*)d_in, (uint8_t*)d_img, hw, C, denormalize, 255.0f, f);
+    else if (bits == 8) hipLaunchKernelGGL((k_nchw_to_u8<float, uint8_t>), g, b, 0, s, (const float*)d_in, (uint8_t*)d_img, hw, C, denormalize, 255.0f, f);
+    else if (in_dtype == INNFER_F16) hipLaunchKernelGGL((k_nchw_to_u8<f16, uint16_t>), g, b, 0, s, (const f16*)d_in, (uint16_t*)d_img, hw, C, denormalize, 65535.0f, f);
+    else hipLaunchKernelGGL((k_nchw_to_u8<float, uint16_t>), g, b, 0, s, (const float*)d_in, (uint16_t*)d_img, hw, C, denormalize, 65535.0f, f);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -304,8 +340,8 @@ extern "C" int innfer_nchw_to_u8hwc(const void* d_in, int in_dtype, int H, int W
     const long hw = (long)H * W;
     if (hw <= 0 || C <= 0) return set_error(INNFER_ERR_INVALID, "nchw_to_u8hwc: bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    if (in_dtype == INNFER_F16) hipLaunchKernelGGL(k_nchw_to_u8<f16>, dim3(blocks(hw, 256)), dim3(256), 0, s, (const f16*)d_in, d_img, hw, C, denormalize);
-    else if (in_dtype == INNFER_F32) hipLaunchKernelGGL(k_nchw_to_u8<float>, dim3(blocks(hw, 256)), dim3(256), 0, s, (const float*)d_in, d_img, hw, C, denormalize);
+    if (in_dtype == INNFER_F16) hipLaunchKernelGGL((k_nchw_to_u8<f16, uint8_t>), dim3(blocks(hw, 256)), dim3(256), 0, s, (const f16*)d_in, d_img, hw, C, denormalize, 255.0f, 1);
+    else if (in_dtype == INNFER_F32) hipLaunchKernelGGL((k_nchw_to_u8<float, uint8_t>), dim3(blocks(hw, 256)), dim3(256), 0, s, (const float*)d_in, d_img, hw, C, denormalize, 255.0f, 1);
     else return set_error(INNFER_ERR_INVALID, "nchw_to_u8hwc: bad dtype");
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;

@@ -67,6 +67,7 @@ SIGNATURES = {
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                            C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_rrdbnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 10),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "innfer_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_pan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "innfer_pan_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 8),
     "innfer_pan_destroy": (None, [C.c_void_p]),
     "innfer_pan_num_params": (C.c_int, [C.c_void_p]),
     "innfer_pan_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -146,6 +148,8 @@ SIGNATURES = {
     "innfer_color_fix": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_nchw_to_u8hwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "innfer_inthwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "innfer_nchw_to_inthwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -13,6 +13,9 @@ import torch
 
 from .. import lib as L
 
+# what an integer image is divided by (utils.py:22-33; the image reader returns uint8 or uint16)
+MAX_VALUES_BY_DTYPE = {np.dtype("uint8"): 255, np.dtype("uint16"): 65535}
+
 
 def _dt(t):
     if t.dtype == torch.float16:
@@ -90,40 +93,54 @@ def recompose_tensor(patches, height, width, step=None, scale=1, out_dtype=None)
 
 def np2tensor(img, bgr2rgb=True, data_range=1., normalize=False, change_range=True, add_batch=True,
               device='cuda', dtype=torch.float32):
-    """uint8 HWC BGR(A) image -> [1,C,H,W] RGB(A) float tensor ON THE GPU
-    (utils.py:164-194): the uint8 image crosses PCIe (4x fewer bytes than fp32) and
-    /255, HWC->CHW, channel flip and optional [-1,1] norm run in one HIP kernel."""
+    """uint8 / uint16 HWC BGR(A) image -> [1,C,H,W] RGB(A) float tensor ON THE GPU
+    (utils.py:164-194): the integer image crosses PCIe (4x / 2x fewer bytes than fp32) and
+    /maxval (MAX_VALUES_BY_DTYPE, utils.py:22-33), HWC->CHW, channel flip and optional [-1,1] norm run in one HIP kernel.
+    bgr2rgb / change_range / add_batch as in the reference (`data_range` is unused there too)."""
     if not isinstance(img, np.ndarray):
         raise TypeError("Got unexpected object type, expected np.ndarray")
-    if img.dtype != np.uint8 or img.ndim != 3 or not (bgr2rgb and change_range and add_batch):
-        raise NotImplementedError('np2tensor: only uint8 HWC images with the default flags are built')
+    if img.dtype not in (np.uint8, np.uint16) or img.ndim != 3:
+        raise NotImplementedError('np2tensor: uint8 / uint16 HWC images are built (the reader, utils.py:36-133, produces nothing else)')
     H, W, Cc = img.shape
-    d_img = torch.from_numpy(np.ascontiguousarray(img)).to(device)
+    bits = 8 if img.dtype == np.uint8 else 16
+    maxval = float(MAX_VALUES_BY_DTYPE[img.dtype]) if change_range else 1.0
+    host = np.ascontiguousarray(img)
+    if bits == 16:                                   # torch has no uint16 arithmetic; the bytes are what crosses PCIe
+        host = host.view(np.int16)
+    d_img = torch.from_numpy(host).to(device)
     out = torch.empty((1, Cc, H, W), dtype=dtype, device=d_img.device)
     with _on(out):
-        L.check(L.lib.innfer_u8hwc_to_nchw(d_img.data_ptr(), H, W, Cc, int(bool(normalize)), out.data_ptr(),
-                                           _dt(out), _stream(out)))
-    return out
+        L.check(L.lib.innfer_inthwc_to_nchw(d_img.data_ptr(), bits, H, W, Cc, int(bool(bgr2rgb)), int(bool(normalize)), maxval,
+                                            out.data_ptr(), _dt(out), _stream(out)))
+    return out if add_batch else out.squeeze(0)
 
 
 def tensor2np(img, rgb2bgr=True, remove_batch=True, data_range=255, denormalize=False,
               change_range=True, imtype=np.uint8):
-    """[1,C,H,W] RGB float GPU tensor -> HWC BGR uint8 numpy (utils.py:197-248);
-    clip*255 and round-half-to-even on the GPU, one uint8 D2H copy."""
+    """[1,C,H,W] / [C,H,W] / [H,W] RGB float GPU tensor -> HWC BGR uint8 (or uint16) numpy (utils.py:197-248);
+    clip * data_range and round-half-to-even on the GPU, one integer D2H copy.  (data_range, imtype) = (255, np.uint8) or
+    (65535, np.uint16); rgb2bgr as in the reference (3- and 4-channel images only)."""
     if not isinstance(img, torch.Tensor):
         raise TypeError("Got unexpected object type, expected torch.Tensor")
-    if img.dim() != 4 or img.shape[0] != 1:
-        raise TypeError(f'Only 4D [1,C,H,W] tensors are built. But received with dimension: {img.dim():d}')
-    if not (rgb2bgr and remove_batch and change_range) or data_range != 255 or imtype != np.uint8:
-        raise NotImplementedError('tensor2np: only the default flags are built')
+    n_dim = img.dim()
+    if n_dim not in (2, 3, 4):
+        raise TypeError(f'Only support 4D, 3D and 2D tensor. But received with dimension: {n_dim:d}')
+    if n_dim == 4 and (img.shape[0] != 1 or not remove_batch):
+        raise NotImplementedError('tensor2np: a 4D tensor must be one image with remove_batch=True (the reference transposes a kept batch axis into the image)')
+    if not change_range or (data_range, np.dtype(imtype)) not in ((255, np.dtype(np.uint8)), (65535, np.dtype(np.uint16))):
+        raise NotImplementedError('tensor2np: built for (data_range, imtype) = (255, uint8) and (65535, uint16) with change_range=True')
     _need_cuda(img, 'tensor2np')
     img = img.contiguous()
-    _, Cc, H, W = img.shape
-    out = torch.empty((H, W, Cc), dtype=torch.uint8, device=img.device)
+    Cc, (H, W) = (1 if n_dim == 2 else img.shape[-3]), img.shape[-2:]
+    bits = 8 if np.dtype(imtype) == np.dtype(np.uint8) else 16
+    out = torch.empty((H, W, Cc), dtype=torch.uint8 if bits == 8 else torch.int16, device=img.device)
     with _on(img):
-        L.check(L.lib.innfer_nchw_to_u8hwc(img.data_ptr(), _dt(img), H, W, Cc, int(bool(denormalize)),
-                                           out.data_ptr(), _stream(img)))
-    return out.cpu().numpy()
+        L.check(L.lib.innfer_nchw_to_inthwc(img.data_ptr(), _dt(img), H, W, Cc, int(bool(rgb2bgr) and n_dim != 2), int(bool(denormalize)), bits,
+                                            out.data_ptr(), _stream(img)))
+    arr = out.cpu().numpy()
+    if bits == 16:
+        arr = arr.view(np.uint16)
+    return arr[:, :, 0] if n_dim == 2 else arr
 
 
 def color_fix(imgA, imgB, device='cuda'):

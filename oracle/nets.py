@@ -20,25 +20,25 @@ def _lrelu(x):
     return F.leaky_relu(x, 0.2)
 
 
-def rdb_forward(sd, prefix, x, plus=False):
-    """ResidualDenseBlock_5C.forward (RRDBNet_arch.py:152-165)."""
-    x1 = _lrelu(_conv3(sd, prefix + "conv1.0", x))
-    x2 = _lrelu(_conv3(sd, prefix + "conv2.0", torch.cat((x, x1), 1)))
+def rdb_forward(sd, prefix, x, plus=False, a=_lrelu):
+    """ResidualDenseBlock_5C.forward (RRDBNet_arch.py:152-165); a: the act_type of its conv blocks."""
+    x1 = a(_conv3(sd, prefix + "conv1.0", x))
+    x2 = a(_conv3(sd, prefix + "conv2.0", torch.cat((x, x1), 1)))
     if plus:
         x2 = x2 + F.conv2d(x, sd[prefix + "conv1x1.weight"])          # :155-156
-    x3 = _lrelu(_conv3(sd, prefix + "conv3.0", torch.cat((x, x1, x2), 1)))
-    x4 = _lrelu(_conv3(sd, prefix + "conv4.0", torch.cat((x, x1, x2, x3), 1)))
+    x3 = a(_conv3(sd, prefix + "conv3.0", torch.cat((x, x1, x2), 1)))
+    x4 = a(_conv3(sd, prefix + "conv4.0", torch.cat((x, x1, x2, x3), 1)))
     if plus:
         x4 = x4 + x2                                                   # :159-160
     x5 = _conv3(sd, prefix + "conv5.0", torch.cat((x, x1, x2, x3, x4), 1))
     return x5 * 0.2 + x                                                # :165
 
 
-def rrdb_forward(sd, prefix, x, plus=False):
-    """RRDB.forward (RRDBNet_arch.py:91-98)."""
+def rrdb_forward(sd, prefix, x, plus=False, nr=3, a=_lrelu):
+    """RRDB.forward (RRDBNet_arch.py:91-98): RDB1..RDB3, or the Sequential `RDBs` when nr != 3 (:84-88)."""
     out = x
-    for r in (1, 2, 3):
-        out = rdb_forward(sd, f"{prefix}RDB{r}.", out, plus)
+    for r in range(1, nr + 1):
+        out = rdb_forward(sd, f"{prefix}RDB{r}." if nr == 3 else f"{prefix}RDBs.{r - 1}.", out, plus, a)
     return out * 0.2 + x
 
 
@@ -47,17 +47,19 @@ def _n_upscale(scale):
     return 1 if scale == 3 else int(math.log(scale, 2))
 
 
-def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None):
+def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None, nr=3, act_type="leakyrelu", upsample_mode="upconv"):
     """RRDBNet.forward with the flat Sequential of RRDBNet_arch.py:25-48.
 
     taps: optional dict filled with named intermediates (golden G3 stages).
+    nr / act_type / upsample_mode: the constructor arguments of the same names (:16-18, :30-38).
     """
+    _act = {"leakyrelu": _lrelu, "relu": F.relu}[act_type]
     fea = _conv3(sd, "model.0", x)
     if taps is not None:
         taps["conv_first"] = fea
     t = fea
     for b in range(nb):
-        t = rrdb_forward(sd, f"model.1.sub.{b}.", t, plus)
+        t = rrdb_forward(sd, f"model.1.sub.{b}.", t, plus, nr, _act)
         if taps is not None and b == 0:
             taps["rrdb0"] = t
     t = _conv3(sd, f"model.1.sub.{nb}", t)
@@ -67,12 +69,15 @@ def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None)
     idx = 2
     for u in range(_n_upscale(scale)):
         f = 3 if scale == 3 else 2
-        t = F.interpolate(t, scale_factor=float(f), mode="nearest")   # block.py:321-322,358
-        t = _lrelu(_conv3(sd, f"model.{idx + 1}", t))
+        if upsample_mode == "pixelshuffle":                           # block.py:333-346: conv, PixelShuffle, act
+            t = _act(F.pixel_shuffle(_conv3(sd, f"model.{idx}", t), f))
+        else:
+            t = F.interpolate(t, scale_factor=float(f), mode="nearest")   # block.py:321-322,358
+            t = _act(_conv3(sd, f"model.{idx + 1}", t))
         if taps is not None:
             taps[f"up{u}"] = t
         idx += 3
-    t = _lrelu(_conv3(sd, f"model.{idx}", t))     # HR_conv0
+    t = _act(_conv3(sd, f"model.{idx}", t))       # HR_conv0
     y = _conv3(sd, f"model.{idx + 2}", t)         # HR_conv1
     if finalact:                                  # outact (RRDBNet_arch.py:45-48; block.py:81-101)
         y = {"relu": F.relu, "leakyrelu": _lrelu, "lrelu": _lrelu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[finalact.lower()](y)
@@ -165,47 +170,58 @@ def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True):
     return block(x, "model.", 0)
 
 
-def pan_forward(sd, x, nb=16, scale=4):
+def pan_forward(sd, x, nb=16, scale=4, self_attention=True, double_scpa=False):
     """PAN.forward (PAN_arch.py:178-222) with the defaults of defaults.py:78-89 (nf 40, unf 24,
     self_attention, nearest up-blocks): SCPA blocks (PAN_arch.py:56-99), PA / PACnv pixel attention
-    (:21-55), max-pooled SAGAN self attention (block.py:398-473), bilinear(align_corners) global skip."""
+    (:21-55), max-pooled SAGAN self attention (block.py:398-473), bilinear(align_corners) global skip.
+    self_attention / double_scpa: the constructor arguments of the same names (:115-141, :193-203)."""
     def conv(t, key, pad=0):
         return F.conv2d(t, sd[key + ".weight"], sd.get(key + ".bias"), padding=pad)
 
+    def scpa_trunk(t, name):
+        for b in range(nb):
+            p = f"{name}.{b}."
+            a = F.leaky_relu(conv(t, p + "conv1_a"), 0.2)
+            bb = F.leaky_relu(conv(t, p + "conv1_b"), 0.2)
+            a = F.leaky_relu(conv(a, p + "k1.0", 1), 0.2)
+            y = torch.sigmoid(conv(bb, p + "PACnv.k2"))
+            bb = conv(conv(bb, p + "PACnv.k3", 1) * y, p + "PACnv.k4", 1)
+            bb = F.leaky_relu(bb, 0.2)
+            t = conv(torch.cat([a, bb], 1), p + "conv3") + t
+        return t
+
     fea = conv(x, "conv_first", 1)
-    t = fea
-    for b in range(nb):
-        p = f"SCPA_trunk.{b}."
-        a = F.leaky_relu(conv(t, p + "conv1_a"), 0.2)
-        bb = F.leaky_relu(conv(t, p + "conv1_b"), 0.2)
-        a = F.leaky_relu(conv(a, p + "k1.0", 1), 0.2)
-        y = torch.sigmoid(conv(bb, p + "PACnv.k2"))
-        bb = conv(conv(bb, p + "PACnv.k3", 1) * y, p + "PACnv.k4", 1)
-        bb = F.leaky_relu(bb, 0.2)
-        t = conv(torch.cat([a, bb], 1), p + "conv3") + t
-    trunk = conv(t, "trunk_conv", 1)
-    # FSA(fea + trunk)
+    trunk = conv(scpa_trunk(fea, "SCPA_trunk"), "trunk_conv", 1)
+    if double_scpa:                                                   # :195-196
+        trunk = conv(scpa_trunk(trunk, "SCPA_trunk2"), "trunk_conv2", 1)
     inp = fea + trunk
-    xp = F.max_pool2d(inp, 4, 4)
-    B, C, h, w = xp.shape
-    xv = xp.reshape(B, C, h * w)
-    f = F.conv1d(xv, sd["FSA.conv_f.weight"], sd["FSA.conv_f.bias"])
-    g = F.conv1d(xv, sd["FSA.conv_g.weight"], sd["FSA.conv_g.bias"])
-    hh = F.conv1d(xv, sd["FSA.conv_h.weight"], sd["FSA.conv_h.bias"])
-    att = torch.softmax(torch.bmm(f.permute(0, 2, 1), g), dim=-1)
-    out = torch.bmm(hh, att.permute(0, 2, 1)).reshape(B, C, h, w)
-    out = F.interpolate(out, size=(inp.shape[2], inp.shape[3]), mode="bicubic", align_corners=False)
-    t = sd["FSA.gamma"] * out + inp
+    if self_attention:                                                # FSA(fea + trunk), :200-201
+        xp = F.max_pool2d(inp, 4, 4)
+        B, C, h, w = xp.shape
+        xv = xp.reshape(B, C, h * w)
+        f = F.conv1d(xv, sd["FSA.conv_f.weight"], sd["FSA.conv_f.bias"])
+        g = F.conv1d(xv, sd["FSA.conv_g.weight"], sd["FSA.conv_g.bias"])
+        hh = F.conv1d(xv, sd["FSA.conv_h.weight"], sd["FSA.conv_h.bias"])
+        att = torch.softmax(torch.bmm(f.permute(0, 2, 1), g), dim=-1)
+        out = torch.bmm(hh, att.permute(0, 2, 1)).reshape(B, C, h, w)
+        out = F.interpolate(out, size=(inp.shape[2], inp.shape[3]), mode="bicubic", align_corners=False)
+        t = sd["FSA.gamma"] * out + inp
+    else:
+        t = inp
     n_up = 1 if scale == 3 else int(math.log(scale, 2))
     for u in range(n_up):
         # pa_upconv_block builds sequential(upsample, upconv, att, a, HRconv, a) with ONE LeakyReLU
-        # instance `a` (PAN_arch.py:11-19); B.sequential flattens with children(), which yields each
-        # module once, so a block is 5 modules (indices 5u..5u+4) and nothing follows HRconv.
+        # instance `a` (PAN_arch.py:11-19).  With two stages (4x) PAN's outer B.sequential flattens them with children(), which
+        # yields each module once, so a block is 5 modules (indices 5u..5u+4) and nothing follows HRconv.  With ONE stage
+        # (2x, 3x) B.sequential returns the stage's own nn.Sequential untouched (block.py:197-210), whose six slots hold `a`
+        # twice: there HRconv IS followed by the LeakyReLU (pinned by golden G18 `double_noattn_x2`).
         i = 5 * u
         t = F.interpolate(t, scale_factor=2.0 if scale != 3 else 3.0, mode="nearest")
         t = conv(t, f"upsample.{i + 1}", 1)
         t = F.leaky_relu(t * torch.sigmoid(conv(t, f"upsample.{i + 2}.conv")), 0.2)
         t = conv(t, f"upsample.{i + 4}", 1)
+        if n_up == 1:
+            t = F.leaky_relu(t, 0.2)
     out = conv(t, "conv_last", 1)
     if scale > 1:
         out = out + F.interpolate(x, scale_factor=float(scale), mode="bilinear", align_corners=True)

@@ -303,6 +303,28 @@ def g9():
          srgb2linear=lin, linear2srgb=back)
 
 
+def g19():
+    """np2tensor / tensor2np beyond the defaults (utils.py:164-248): uint16 images (maxval 65535, utils.py:22-33), bgr2rgb / rgb2bgr off,
+    add_batch off, change_range off, (data_range, imtype) = (65535, uint16), 3-D and 2-D tensors."""
+    ramp16 = (np.arange(5 * 7 * 3) * 997 % 65536).astype(np.uint16).reshape(5, 7, 3)
+    ramp8 = (np.arange(5 * 7 * 3) * 37 % 256).astype(np.uint8).reshape(5, 7, 3)
+    ramp4 = (np.arange(4 * 6 * 4) * 1201 % 65536).astype(np.uint16).reshape(4, 6, 4)
+    halves = torch.tensor([(k + 0.5) / 65535.0 for k in range(0, 12)] + [-0.1, 1.2, 0.99999, 0.5], dtype=torch.float32)
+    th = halves.reshape(1, 1, 4, 4).repeat(1, 3, 1, 1).contiguous()
+    th[0, 1] += 1.0 / (1 << 18)
+    th[0, 2] -= 1.0 / (1 << 18)
+    big = torch.from_numpy(synth.uniform((1, 3, 21, 30), 19, -0.2, 1.2))
+    save("g19_convert_flags", ramp16=ramp16, ramp8=ramp8, ramp4=ramp4,
+         np2t16=ref_utils.np2tensor(ramp16).numpy(), np2t16_norm=ref_utils.np2tensor(ramp16, normalize=True).numpy(),
+         np2t4=ref_utils.np2tensor(ramp4).numpy(),
+         np2t8_noflip=ref_utils.np2tensor(ramp8, bgr2rgb=False).numpy(), np2t8_nobatch=ref_utils.np2tensor(ramp8, add_batch=False).numpy(),
+         np2t8_norange=ref_utils.np2tensor(ramp8, change_range=False).numpy(),
+         t2np_in=th.numpy(), t2np16=ref_utils.tensor2np(th, data_range=65535, imtype=np.uint16),
+         t2np16_denorm=ref_utils.tensor2np(th * 2 - 1, denormalize=True, data_range=65535, imtype=np.uint16),
+         big_in=big.numpy(), big_u16=ref_utils.tensor2np(big, data_range=65535, imtype=np.uint16),
+         big_noflip=ref_utils.tensor2np(big, rgb2bgr=False), big_3d=ref_utils.tensor2np(big[0]), big_2d=ref_utils.tensor2np(big[0, 1]))
+
+
 # ----------------------------------------------------------------- G10 loader
 def g10():
     tmp = tempfile.mkdtemp()
@@ -425,7 +447,45 @@ def g17():
     save("g17_fp16_and_eval", **out)
 
 
+def g18():
+    """Graph-changing constructor arguments of RRDBNet (RRDBNet_arch.py:16-48) built directly from the reference class: nr != 3 (`RDBs.<i>`),
+    act_type='relu', mode='NAC' (only LR_conv sees it), upsample_mode='pixelshuffle'.  Keys are stored too: they pin the parameter names."""
+    from architectures.RRDBNet_arch import RRDBNet as RefRRDBNet
+    out = {}
+    cases = {"ps4": (dict(nb=2, upscale=4, upsample_mode="pixelshuffle"), (1, 3, 12, 20)),
+             "ps2_relu": (dict(nb=1, upscale=2, upsample_mode="pixelshuffle", act_type="relu"), (1, 3, 16, 16)),
+             "nr2_relu_nac": (dict(nb=2, nr=2, upscale=2, act_type="relu", mode="NAC"), (1, 3, 16, 16)),
+             "nr4": (dict(nb=1, nr=4, upscale=1), (1, 3, 10, 14))}
+    for i, (tag, (kw, shape)) in enumerate(cases.items()):
+        net = RefRRDBNet(3, 3, 64, **kw).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        mine = synth.rrdbnet_shapes(nb=kw["nb"], scale=kw["upscale"], nr=kw.get("nr", 3), upsample_mode=kw.get("upsample_mode", "upconv"))
+        assert shapes == mine, (tag, set(shapes) ^ set(mine))
+        sd = synth.fill_state_dict(mine, 180 + i)
+        net.load_state_dict(t_sd(sd), strict=True)
+        x = torch.from_numpy(synth.uniform(shape, 190 + i))
+        with torch.no_grad():
+            out[tag] = net(x).numpy()
+        out[tag + "_keys"] = np.array(sorted(shapes))
+    save("g18_rrdb_variants", **out)
+    # PAN(self_attention=False), PAN(double_scpa=True) (PAN_arch.py:115-141,193-203)
+    from architectures.PAN_arch import PAN as RefPAN
+    out = {}
+    for i, (tag, kw) in enumerate({"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
+                                   "double_noattn_x2": dict(double_scpa=True, self_attention=False, scale=2)}.items()):
+        net = RefPAN(3, 3, 40, 24, 3, **kw).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = synth.fill_state_dict(shapes, 185 + i)
+        net.load_state_dict(t_sd(sd), strict=True)
+        x = torch.from_numpy(synth.uniform((1, 3, 20, 28), 195 + i))
+        with torch.no_grad():
+            out[tag] = net(x).numpy()
+        out[tag + "_keys"] = np.array(list(shapes.keys()))
+        out[tag + "_shapes"] = np.array([str(shapes[k]) for k in shapes])
+    save("g18_pan_variants", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     for g in which:
         globals()[g]()

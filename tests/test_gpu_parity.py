@@ -360,6 +360,25 @@ def test_rrdbnet_scales_golden(dev, golden):
         assert np.abs(y - g[f"out_x4_{fa}"]).max() < 5e-3, fa
 
 
+def test_rrdbnet_constructor_variants_golden(dev, golden):
+    """RRDBNet(nr=.., act_type='relu', mode='NAC', upsample_mode='pixelshuffle') (RRDBNet_arch.py:16-48) against the reference's outputs (G18)."""
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    from test_oracle_golden import G18_CASES
+    g = golden("g18_rrdb_variants")
+    for i, (tag, (kw, shape, xseed)) in enumerate(G18_CASES.items()):
+        ctor = dict(upscale=kw["scale"], nr=kw.get("nr", 3), upsample_mode=kw.get("upsample_mode", "upconv"), act_type=kw.get("act_type", "leakyrelu"),
+                    mode="NAC" if tag == "nr2_relu_nac" else "CNA")
+        net = RRDBNet(3, 3, 64, kw["nb"], **ctor)
+        assert sorted(net.state_dict()) == list(g[tag + "_keys"])
+        net.load_state_dict(_sd(synth.rrdbnet_shapes(nb=kw["nb"], scale=kw["scale"], nr=ctor["nr"], upsample_mode=ctor["upsample_mode"]), 180 + i), strict=True)
+        x = torch.from_numpy(synth.uniform(shape, xseed)).to(dev).half()
+        y = net.to(dev).eval()(x).float().cpu().numpy()
+        assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 5e-3, tag
+    with pytest.raises(NotImplementedError):
+        RRDBNet(3, 3, 64, 1, upsample_mode="deconv")
+
+
 def test_esrgan_plus_golden(dev, golden):
     """ESRGAN+ residual paths (x2 += conv1x1(x), x4 += x2) against the reference (golden G5)."""
     from innfer_amd import synth
@@ -493,7 +512,7 @@ def test_missing_weights_and_cpu_are_loud(dev):
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 8, 8))               # CPU tensor: no fallback
     with pytest.raises(NotImplementedError):
-        RRDBNet(3, 3, 64, 1, upscale=4, upsample_mode='pixelshuffle')
+        RRDBNet(3, 3, 64, 1, upscale=4, norm_type='batch')           # a norm layer inside every conv block: not built
 
 
 def test_unet256_golden(dev, golden):
@@ -807,6 +826,30 @@ def test_pan_golden(dev, golden):
     assert np.array_equal(yab[1:2], net(xb).float().cpu().numpy())
 
 
+def test_pan_constructor_variants_golden(dev, golden):
+    """PAN(self_attention=False), PAN(double_scpa=True) and both at 2x (PAN_arch.py:115-141,193-203) against the reference (G18): same
+    parameter names in the same order, outputs within the PAN tolerance."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures.PAN_arch import PAN
+    from test_oracle_golden import G18_PAN
+    g = golden("g18_pan_variants")
+    for i, (tag, kw) in enumerate(G18_PAN.items()):
+        shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[tag + "_keys"], g[tag + "_shapes"])}
+        net = PAN(3, 3, 40, 24, 3, **kw)
+        assert list(net.state_dict()) == [str(k) for k in g[tag + "_keys"]]
+        net.load_state_dict(_sd(shapes, 185 + i), strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((1, 3, 20, 28), 195 + i)).to(dev)
+        ref = g[tag].astype(np.float32)
+        for xin in (x, x.half()):
+            y = net(xin).float().cpu().numpy()
+            err = np.abs(y - ref)
+            assert y.shape == ref.shape and err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (tag, err.max(), err.mean())
+    with pytest.raises(NotImplementedError):
+        PAN(ups_inter_mode='bilinear')
+
+
 def test_pan_scales_vs_oracle(dev):
     """scale 2 and 1 (one / no up-block, unf = nf at scale 1), grayscale, ragged sizes, 3 blocks."""
     import oracle
@@ -886,6 +929,21 @@ def test_pre_post_bit_exact(dev, golden):
     img4 = synth.image_u8(17, 9, 4, 6)
     t4 = U.np2tensor(img4).cpu().numpy()[0]
     assert np.array_equal(t4, (img4.astype(np.float32) / 255).transpose(2, 0, 1)[[2, 1, 0, 3]])
+
+
+def test_pre_post_uint16_and_flags_bit_exact(dev, golden):
+    """np2tensor / tensor2np with uint16 images (maxval 65535, utils.py:22-33) and the non-default flags (bgr2rgb / rgb2bgr off, add_batch
+    off, change_range off, 3-D / 2-D tensors) against the reference (golden G19): bit-exact, like the uint8 defaults."""
+    from innfer_amd.utils import utils as U
+    from test_oracle_golden import _convert_flag_cases
+    g = golden("g19_convert_flags")
+    for name, got, want in _convert_flag_cases(g, U.np2tensor, U.tensor2np, to_t=lambda a: torch.from_numpy(a).to(dev)):
+        got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+        assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), name
+    img16 = (np.arange(64 * 48 * 3, dtype=np.uint32) * 2654435761 % 65536).astype(np.uint16).reshape(64, 48, 3)
+    assert np.array_equal(U.tensor2np(U.np2tensor(img16), data_range=65535, imtype=np.uint16), img16)      # exact uint16 round trip (fp32)
+    with pytest.raises(NotImplementedError):
+        U.np2tensor(img16.astype(np.float32))
 
 
 def test_srgb_helpers(dev, golden):

@@ -103,6 +103,42 @@ def test_g5_scales(golden):
             np.testing.assert_allclose(y.numpy(), g[f"out_x4_{fa}"], atol=2e-6, rtol=0)
 
 
+G18_CASES = {"ps4": (dict(nb=2, scale=4, upsample_mode="pixelshuffle"), (1, 3, 12, 20), 190),
+             "ps2_relu": (dict(nb=1, scale=2, upsample_mode="pixelshuffle", act_type="relu"), (1, 3, 16, 16), 191),
+             "nr2_relu_nac": (dict(nb=2, nr=2, scale=2, act_type="relu"), (1, 3, 16, 16), 192),
+             "nr4": (dict(nb=1, nr=4, scale=1), (1, 3, 10, 14), 193)}
+
+
+def test_g18_rrdbnet_constructor_variants(golden):
+    """nr != 3, act_type='relu', mode='NAC', upsample_mode='pixelshuffle' (RRDBNet_arch.py:16-48): key names and outputs of the reference."""
+    g = golden("g18_rrdb_variants")
+    for i, (tag, (kw, shape, xseed)) in enumerate(G18_CASES.items()):
+        shapes = synth.rrdbnet_shapes(nb=kw["nb"], scale=kw["scale"], nr=kw.get("nr", 3), upsample_mode=kw.get("upsample_mode", "upconv"))
+        assert sorted(shapes) == list(g[tag + "_keys"])
+        sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 180 + i).items()}
+        x = torch.from_numpy(synth.uniform(shape, xseed))
+        with torch.no_grad():
+            y = oracle.rrdbnet_forward(sd, x, **kw).numpy()
+        assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-6, tag
+
+
+G18_PAN = {"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
+           "double_noattn_x2": dict(double_scpa=True, self_attention=False, scale=2)}
+
+
+def test_g18_pan_constructor_variants(golden):
+    """PAN(self_attention=False / double_scpa=True) (PAN_arch.py:115-141,193-203) against the reference."""
+    import ast
+    g = golden("g18_pan_variants")
+    for i, (tag, kw) in enumerate(G18_PAN.items()):
+        shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[tag + "_keys"], g[tag + "_shapes"])}
+        sd = _sd(shapes, 185 + i)
+        x = torch.from_numpy(synth.uniform((1, 3, 20, 28), 195 + i))
+        with torch.no_grad():
+            y = oracle.pan_forward(sd, x, nb=3, **kw).numpy()
+        assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 5e-6, tag
+
+
 def test_g6_srgan(golden):
     g = golden("g6_srgan")
     sd = _sd(synth.srresnet_shapes(nb=16, scale=4))
@@ -207,6 +243,27 @@ def test_g9_convert(golden):
     # round trip is exact for uint8
     img = synth.image_u8(33, 47, 3, 1)
     assert np.array_equal(oracle.tensor2np(oracle.np2tensor(img)), img)
+
+
+def _convert_flag_cases(g, np2tensor, tensor2np, to_t=lambda a: torch.from_numpy(a)):
+    """(name, result, expected) of every G19 case for one implementation of np2tensor / tensor2np."""
+    th, big = to_t(g["t2np_in"]), to_t(g["big_in"])
+    return [("np2t16", np2tensor(g["ramp16"]), g["np2t16"]), ("np2t16_norm", np2tensor(g["ramp16"], normalize=True), g["np2t16_norm"]),
+            ("np2t4", np2tensor(g["ramp4"]), g["np2t4"]), ("np2t8_noflip", np2tensor(g["ramp8"], bgr2rgb=False), g["np2t8_noflip"]),
+            ("np2t8_nobatch", np2tensor(g["ramp8"], add_batch=False), g["np2t8_nobatch"]),
+            ("np2t8_norange", np2tensor(g["ramp8"], change_range=False), g["np2t8_norange"]),
+            ("t2np16", tensor2np(th, data_range=65535, imtype=np.uint16), g["t2np16"]),
+            ("t2np16_denorm", tensor2np(th * 2 - 1, denormalize=True, data_range=65535, imtype=np.uint16), g["t2np16_denorm"]),
+            ("big_u16", tensor2np(big, data_range=65535, imtype=np.uint16), g["big_u16"]),
+            ("big_noflip", tensor2np(big, rgb2bgr=False), g["big_noflip"]), ("big_3d", tensor2np(big[0]), g["big_3d"]),
+            ("big_2d", tensor2np(big[0, 1]), g["big_2d"])]
+
+
+def test_g19_convert_flags(golden):
+    """uint16 images and the non-default flags of np2tensor / tensor2np (utils.py:22-33,164-248) against the reference: bit-exact."""
+    for name, got, want in _convert_flag_cases(golden("g19_convert_flags"), oracle.np2tensor, oracle.tensor2np):
+        got = got.numpy() if isinstance(got, torch.Tensor) else got
+        assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), name
 
 
 def test_g16_mrrdbnet(golden):
