@@ -67,6 +67,99 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
     if (p.out2) *(f16x8*)(p.out2 + (cg >> 5) * p.out2_gstride + pix * 32 + (cg & 31)) = h;
 }
 
+// The same conv on the matrix cores (K = 32 or 64 outputs): the 9 * Cin taps of a pixel are the k dimension of a 16 x 16 x 32 MFMA
+// (27 of 32 for RGB; ceil(9 Cin / 32) steps), 16 consecutive pixels are its columns, 16 * NT output channels its rows.  A lane gathers
+// the 8 patch values of its (pixel, k-octet) straight from the planar input -- 8 loads per lane and 16 pixels instead of the VALU
+// kernel's 27 loads per lane and 8 pixels, no LDS -- and ends up with 4 * NT consecutive output channels of its pixel (rows permuted as in
+// conv_pack): one or two 16-byte stores per output slab.  fp32 weights and fp32 input are split into an fp16 head and an fp16 remainder
+// (w = wh + wl, x = xh + xl; wh*xh + wl*xh + wh*xl with fp32 accumulation), so the result keeps the fp32 VALU kernel's accuracy (product
+// terms below 2^-22 relative dropped) although the MFMA operands are fp16.  Bound by its two 128 B/pixel stores, as it should be.
+template <int NT, int STEPS>                                        // STEPS = ceil(9 Cin / 32): 1 for gray / RGB, 2 for 4..7 channels, 3 for 8
+__global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const int nk = p.Cin * 9;
+    // weight fragments, once per wave: row li of sub-tile t is output channel 4 NT (li >> 2) + 4 t + (li & 3); k octet lg of every step
+    f16x8 wh[STEPS][NT], wl[STEPS][NT];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int oc = 4 * NT * (li >> 2) + 4 * t + (li & 3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = st * 32 + lg * 8 + e;
+                const float w = kk < nk ? p.w[(long)kk * p.K + oc] : 0.f;
+                const f16 h = (f16)w;
+                wh[st][t][e] = h;
+                wl[st][t][e] = (f16)(w - (float)h);
+            }
+        }
+    const int cb = 4 * NT * lg;                                      // this lane's first output channel
+    f32x4 bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias[t] = *(const f32x4*)(p.bias + cb + 4 * t);
+    const long hw = (long)p.H * p.W;
+    const long ngroups = (p.npix + 15) >> 4;
+    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long g = wave_id; g < ngroups; g += nwaves) {
+        const long pix = g * 16 + li;
+        const bool live = pix < p.npix;
+        const long n = live ? pix / hw : 0;
+        const long rem = live ? pix - n * hw : 0;
+        const int y = (int)(rem / p.W), x = (int)(rem - (long)y * p.W);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = bias[t];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {             // compile-time index into the fragment arrays (a runtime one would send them to scratch)
+            f16x8 xh, xl;
+            bool any_lo = false;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = st * 32 + lg * 8 + e;
+                const int ci = kk / 9, tap = kk - ci * 9, r = tap / 3, s = tap - r * 3;
+                const int Y = y + r - 1, X = x + s - 1;
+                float v = 0.f;
+                if (live && kk < nk && Y >= 0 && Y < p.H && X >= 0 && X < p.W) {
+                    const long o = (n * p.Cin + ci) * hw + (long)Y * p.W + X;
+                    v = p.in_f32 ? ((const float*)p.in)[o] : (float)((const f16*)p.in)[o];
+                }
+                const f16 h = (f16)v;
+                xh[e] = h;
+                xl[e] = (f16)(v - (float)h);
+            }
+            any_lo = p.in_f32 != 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st][t], xh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[st][t], xh, acc[t], 0, 0, 0);
+                if (any_lo) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st][t], xl, acc[t], 0, 0, 0);
+            }
+        }
+        if (!live) continue;
+        f16 h[4 * NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = acc[t][j];
+                if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                h[4 * t + j] = (f16)f;
+            }
+        const long o1 = (cb >> 5) * p.out_gstride + pix * 32 + (cb & 31);
+        const long o2 = (cb >> 5) * p.out2_gstride + pix * 32 + (cb & 31);
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) {
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = h[8 * q + e];
+            *(f16x8*)(p.out + o1 + 8 * q) = v;
+            if (p.out2) *(f16x8*)(p.out2 + o2 + 8 * q) = v;
+        }
+    }
+}
+
 }  // namespace
 
 int first_conv_launch(const FirstConvLaunch& L, hipStream_t s) {
@@ -75,6 +168,17 @@ int first_conv_launch(const FirstConvLaunch& L, hipStream_t s) {
     if (L.Cin < 1 || L.Cin > 8) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: in_nc=%d unsupported", L.Cin);
     FP p{L.in, L.in_f32, L.Cin, L.w, L.bias, L.out, L.out_gstride, L.out2, L.out2_gstride,
          L.K, (long)L.N * L.H * L.W, L.H, L.W, L.act};
+    if ((L.K == 32 || L.K == 64) && INNFER_KNOB("INNFER_FIRST_MFMA", 1)) {
+        const long groups = (p.npix + 15) / 16, want = (groups + 3) / 4;
+        const long grid = want < 8192 ? want : 8192;                 // 32 waves' worth of pixel groups per CU in flight, the rest by striding
+        const int steps = (L.Cin * 9 + 31) / 32;
+#define FC(NT_, ST_) hipLaunchKernelGGL((first_conv_mfma<NT_, ST_>), dim3((unsigned)grid), dim3(256), 0, s, p)
+        if (L.K == 64) { if (steps == 1) FC(4, 1); else if (steps == 2) FC(4, 2); else FC(4, 3); }
+        else { if (steps == 1) FC(2, 1); else if (steps == 2) FC(2, 2); else FC(2, 3); }
+#undef FC
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    }
     const int ppb = 256 / (L.K / 8);
     const long grid = (p.npix + ppb - 1) / ppb;
     const size_t lds = (size_t)(L.Cin * 9 * L.K + L.K) * sizeof(float);
