@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -356,6 +356,12 @@ int innfer_linear_to_srgb(const float* d_in, uint8_t* d_out, size_t n, void* str
 size_t innfer_color_fix_workspace_bytes(int h_lr, int w_lr, int h_sr, int w_sr, int channels);
 int innfer_color_fix(const uint8_t* d_lr, int h_lr, int w_lr, const uint8_t* d_sr, int h_sr, int w_sr, int channels,
                      uint8_t* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* linear_resize (utils/utils.py:267-276, the pix2pix pre-step of run.py:413-414): uint8 HWC image -> srgb2linear -> bicubic resize to
+ * (oh, ow) (OpenCV INTER_CUBIC, a = -0.75, as in innfer_color_fix: parity with OpenCV itself unpinned) -> linear2srgb, uint8 HWC.
+ * Workspace: h * w * C floats.  (104) */
+int innfer_linear_resize(const uint8_t* d_img, int h, int w, int C, uint8_t* d_out, int oh, int ow,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

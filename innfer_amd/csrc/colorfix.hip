@@ -99,6 +99,14 @@ __global__ void k_finish(const float* blur, const float* lin_b, int hA, int wA, 
     out[i] = lin2srgb(u + lin_b[i]);
 }
 
+// linear_resize (utils.py:267-276): out = linear2srgb(cubic(srgb2linear(img) -> (oh, ow)))
+__global__ void k_resize_finish(const float* lin, int h, int w, int C, int oh, int ow, uint8_t* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)oh * ow * C) return;
+    const int c = (int)(i % C), x = (int)((i / C) % ow), y = (int)(i / ((long)C * ow));
+    out[i] = lin2srgb(cubic_sample(lin, h, w, C, c, y, x, (float)h / (float)oh, (float)w / (float)ow));
+}
+
 inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -107,6 +115,17 @@ inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t innfer_color_fix_workspace_bytes(int hA, int wA, int hB, int wB, int C) {
     if (hA <= 0 || wA <= 0 || hB <= 0 || wB <= 0 || C <= 0) return 0;
     return al((size_t)hB * wB * C * 4) + 2 * al((size_t)hA * wA * C * 4);
+}
+
+extern "C" int innfer_linear_resize(const uint8_t* d_img, int h, int w, int C, uint8_t* d_out, int oh, int ow, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!d_img || !d_out || !d_ws || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || C <= 0 || C > 4) return set_error(INNFER_ERR_INVALID, "linear_resize: bad arguments");
+    if (ws_bytes < (size_t)h * w * C * 4) return set_error(INNFER_ERR_WORKSPACE, "linear_resize: workspace %zu < %zu bytes", ws_bytes, (size_t)h * w * C * 4);
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)h * w * C, no = (long)oh * ow * C;
+    hipLaunchKernelGGL(k_lin, dim3(nblk(n)), dim3(256), 0, s, d_img, (float*)d_ws, n);
+    hipLaunchKernelGGL(k_resize_finish, dim3(nblk(no)), dim3(256), 0, s, (const float*)d_ws, h, w, C, oh, ow, d_out);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
 }
 
 extern "C" int innfer_color_fix(const uint8_t* d_a, int hA, int wA, const uint8_t* d_b, int hB, int wB, int C, uint8_t* d_out,

@@ -177,3 +177,142 @@ class Model:
             return self.chop_forward(data, patch_size=200, step=0.5)
         with torch.no_grad():
             return self._predict(data)
+
+
+# ------------------------------------------------------------------- command line (run.py:225-445)
+def parse_models(models_paths, scales_list=None):
+    """`a+b` / `a>b` model chains and the per-model scale guessed from the file name (run.py:227-250)."""
+    from .utils.utils import get_models_paths
+    model_chain = models_paths.split("+") if "+" in models_paths else models_paths.split(">")
+    try:
+        all_models = get_models_paths("./models")
+    except AssertionError:          # the reference insists on a ./models folder even for absolute paths; only the partial-name search needs it
+        all_models = []
+    full_chain = [check_model_path(m, all_models) for m in model_chain]
+    if not scales_list:
+        scales_list = [get_scale_name(m, None) for m in full_chain]
+    elif len(scales_list) != len(model_chain):
+        raise ValueError(f"The num. of scales {len(scales_list)} is != from number of models {len(model_chain)}")
+    return full_chain, scales_list
+
+
+def check_model_path(model_path, all_models=None):
+    """Absolute path, ./models/<name>, or a unique partial-name match in ./models (run.py:253-274)."""
+    import os.path as osp
+    if osp.isfile(model_path):
+        return model_path
+    model_path_a = osp.join("models", model_path)
+    if osp.isfile(model_path_a):
+        return model_path_a
+    if not all_models:
+        raise ValueError(f"Model {model_path} not found.")
+    m_list = [m for m in all_models if str(model_path.lower()) in str(m).lower()]
+    if len(m_list) > 1:
+        raise ValueError(f"Filter {model_path} returned multiple models: {m_list}.")
+    if not m_list:
+        raise ValueError(f"Model {model_path} not found.")
+    return m_list[0]
+
+
+def get_scale_name(model_path, scale=None):
+    """`4x_name.pth` -> 4 (run.py:277-293)."""
+    import os.path as osp
+    rlt_scale = None
+    scale_name = str(osp.basename(model_path)[0:2]).lower()
+    if 'x' in scale_name:
+        try:
+            rlt_scale = int(scale_name.replace('x', ''))
+        except ValueError:
+            rlt_scale = None
+    if scale:
+        if rlt_scale and (scale != rlt_scale):
+            print(f"Warning: possible model scale mismatch on {model_path}")
+        return scale
+    return rlt_scale
+
+
+pix2pix_extras = {'meval': False, 'strict': True, 'normalize': True}       # run.py:299-303
+cyglegan_extras = {'meval': True, 'strict': False, 'normalize': True}      # run.py:305-309
+default_extras = {'meval': True, 'strict': True, 'normalize': False}       # run.py:311-315
+
+
+def build_parser():
+    """The reference's flags, names and destinations (run.py:320-331)."""
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-models', '-m', type=str, required=True, help='Path to models.')
+    parser.add_argument('-arch', '-a', type=str, required=False, default='infer', help='Model architecture.')
+    parser.add_argument('-input', '-i', type=str, required=False, default='./input', help='Path to read input images.')
+    parser.add_argument('-output', '-o', type=str, required=False, default='./output', help='Path to save output images.')
+    parser.add_argument('-scale', '-s', type=str, required=False, default='-1', help='Model scaling factor.')
+    parser.add_argument('-cf', required=False, action='store_true', help='Use color correction if enabled.')
+    parser.add_argument('-comp', required=False, action='store_true', help='Save as comparison images if enabled.')
+    parser.add_argument('-no_gpu', '-cpu', required=False, action='store_false', help='Run in CPU if enabled.')
+    parser.add_argument('-no_fp16', required=False, action='store_false', help='Disable fp16 mode if needed.')
+    parser.add_argument('-norm', required=False, action='store_true', help='Normalizes images in range [-1,1] if set, else [0,1].')
+    return parser
+
+
+def main(argv=None):
+    """The image loop of the reference's command line (run.py:318-445) on the HIP engine: same flags, same per-architecture presets, same
+    sequence read -> [linear_resize | modcrop] -> np2tensor -> model chain [-> guided filter] -> tensor2np [-> color_fix] -> save.  The
+    uint8 image is what crosses PCIe in both directions; files go through OpenCV when it is installed and through PIL otherwise."""
+    import os
+    import os.path as osp
+    from .utils import utils as U
+    args = build_parser().parse_args(argv)
+    if not args.no_gpu:
+        raise RuntimeError("-cpu / -no_gpu: innfer_amd runs on an MI355X only; use the reference for a CPU run")
+    if args.arch == 'ts':
+        raise NotImplementedError('TorchScript models are opaque graphs and cannot run on the HIP engine')
+    fp16 = args.no_fp16
+    use_guided_filter = use_modcrop = False
+    if 'unet_' in args.arch or 'p2p_' in args.arch:
+        defaults, chop = pix2pix_extras, False
+        resize = 512 if '512' in args.arch else 256 if '256' in args.arch else 128 if '128' in args.arch else False
+    elif 'resnet_' in args.arch or 'cg_' in args.arch:
+        defaults, chop, resize = cyglegan_extras, True, False
+    elif 'wbc' in args.arch or 'wbc' in args.models:
+        args.arch = "wbcunet_tf" if ('tf' in args.arch or 'tf' in args.models) else "wbcunet"
+        defaults, chop, resize = pix2pix_extras, False, False
+        use_guided_filter = use_modcrop = True
+    else:
+        defaults, resize, chop = default_extras, False, True
+    meval, strict = defaults['meval'], defaults['strict']
+    normalize = defaults['normalize'] or args.norm
+    device = torch.device('cuda')
+    scale = args.scale if args.scale != -1 else None        # (sic) the string '-1' never equals -1: the flag's value is what parse_models ignores
+    del scale
+    model_chain, scale_chain = parse_models(args.models)
+    models = [Model(mc, args.arch, sc, device=device, meval=meval, strict=strict, chop=chop) for mc, sc in zip(model_chain, scale_chain)]
+    images = U.get_images_paths(args.input)
+    os.makedirs(args.output, exist_ok=True)
+    for image_path in images:
+        img_name = osp.splitext(osp.basename(image_path))[0]
+        img = U.read_img(image_path)
+        if img is None:
+            print(f'Error reading image {image_path}, skipping.')
+            continue
+        if resize:
+            img = U.linear_resize(img, resize)
+        if use_modcrop:
+            img = U.modcrop(img, 4)
+        t_img = U.np2tensor(img, normalize=normalize, device=device, dtype=torch.float16 if fp16 else torch.float32)
+        t_out = t_img
+        for mod in models:
+            t_out = mod(t_out)
+            if use_guided_filter:
+                t_out = U.guided_filter(t_img, t_out, r=1, eps=5e-3)
+        img_out = U.tensor2np(t_out.detach(), denormalize=normalize)
+        if args.cf:
+            img_out = U.color_fix(img, img_out)
+        save_img_path = osp.join(args.output, f'{img_name:s}.png')
+        if args.comp:
+            U.save_img_comp([img, img_out], save_img_path)
+        else:
+            U.save_img(img_out, save_img_path)
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())

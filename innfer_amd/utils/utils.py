@@ -8,10 +8,22 @@ HIP kernels (csrc/tiles.hip) through the C ABI:
 Same names, argument meaning and error behaviour.  Tensors must live on the
 GPU; there is no CPU fallback.
 """
+import os
+import os.path as osp
+
 import numpy as np
 import torch
 
 from .. import lib as L
+
+try:                                    # the reference reads / writes through OpenCV (utils.py:3-4,68-95); PIL is the stand-in where it is absent
+    import cv2
+    cv2_available = True
+except ImportError:
+    cv2_available = False
+
+IMG_EXTENSIONS = ['.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.webp', 'tga', '.tif', '.tiff', '.dng']       # utils.py:18-19 (sic: 'tga')
+MODEL_EXTENSIONS = ['.pth', '.pt']                                                                       # utils.py:16
 
 # what an integer image is divided by (utils.py:22-33; the image reader returns uint8 or uint16)
 MAX_VALUES_BY_DTYPE = {np.dtype("uint8"): 255, np.dtype("uint16"): 65535}
@@ -141,6 +153,129 @@ def tensor2np(img, rgb2bgr=True, remove_batch=True, data_range=255, denormalize=
     if bits == 16:
         arr = arr.view(np.uint16)
     return arr[:, :, 0] if n_dim == 2 else arr
+
+
+# ---------------------------------------------------------------- files (utils.py:36-133): the image loop's codec hand-off
+def is_ext_file(filename, extensions=IMG_EXTENSIONS):
+    return any(filename.endswith(extension) for extension in extensions)
+
+
+def scan_dir(path, extensions=IMG_EXTENSIONS):
+    if not osp.isdir(path):
+        raise AssertionError(f'{path:s} is not a valid directory')
+    files_list = []
+    for dirpath, _, fnames in sorted(os.walk(path)):
+        for fname in sorted(fnames):
+            if is_ext_file(fname, extensions):
+                files_list.append(osp.join(dirpath, fname))
+    return files_list
+
+
+def get_models_paths(path):
+    models = scan_dir(path, MODEL_EXTENSIONS)
+    if not models:
+        raise AssertionError(f'{path:s} has no valid model file')
+    return models
+
+
+def get_images_paths(path):
+    images = scan_dir(path, IMG_EXTENSIONS)
+    if not images:
+        raise AssertionError(f'{path:s} has no valid image file')
+    return images
+
+
+def read_img(path=None):
+    """cv2.imread(path, IMREAD_UNCHANGED) (utils.py:68-89): HWC BGR / BGRA (HW for gray), uint8 or uint16, None when the file cannot
+    be decoded.  Without OpenCV the file is decoded by PIL and put into OpenCV's channel order."""
+    if not path:
+        raise AssertionError("Empty path provided.")
+    if cv2_available:
+        return cv2.imread(path, cv2.IMREAD_UNCHANGED)
+    from PIL import Image
+    try:
+        with Image.open(path) as im:
+            if im.mode in ('P', 'CMYK', 'YCbCr', '1'):
+                im = im.convert('RGBA' if 'transparency' in im.info else 'RGB')
+            elif im.mode == 'LA':
+                im = im.convert('RGBA')
+            a = np.asarray(im)
+    except Exception:
+        return None
+    if a.dtype == np.int32:                  # PIL's 16-bit gray ('I') arrives as int32
+        a = a.astype(np.uint16)
+    if a.ndim == 3 and a.shape[2] == 3:
+        a = a[:, :, ::-1]
+    elif a.ndim == 3 and a.shape[2] == 4:
+        a = a[:, :, [2, 1, 0, 3]]
+    return np.ascontiguousarray(a)
+
+
+def _resize_nearest(img, h, w):
+    """cv2.resize(INTER_NEAREST): source index floor(dst * src / dst_size)."""
+    ys = np.minimum((np.arange(h) * (img.shape[0] / h)).astype(np.int64), img.shape[0] - 1)
+    xs = np.minimum((np.arange(w) * (img.shape[1] / w)).astype(np.int64), img.shape[1] - 1)
+    return img[ys][:, xs]
+
+
+def save_img(img, img_path, mode='RGB', scale=None):
+    """cv2.imwrite of a BGR(A) / gray image (utils.py:92-96), through PIL when OpenCV is absent."""
+    if scale:
+        img = _resize_nearest(img, int(round(img.shape[0] * scale)), int(round(img.shape[1] * scale)))
+    if cv2_available:
+        cv2.imwrite(img_path, img)
+        return
+    from PIL import Image
+    a = np.asarray(img)
+    if a.ndim == 3 and a.shape[2] == 3:
+        a = a[:, :, ::-1]
+    elif a.ndim == 3 and a.shape[2] == 4:
+        a = a[:, :, [2, 1, 0, 3]]
+    elif a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    Image.fromarray(np.ascontiguousarray(a)).save(img_path)
+
+
+def merge_imgs(img_list):
+    """Images side by side, the smaller ones enlarged (nearest) to the largest height / width (utils.py:99-124)."""
+    if isinstance(img_list, np.ndarray):
+        return img_list
+    if not isinstance(img_list, list):
+        raise NotImplementedError('To merge images img_list should be a list of cv2 images.')
+    img_h = max(im.shape[0] for im in img_list)
+    img_v = max(im.shape[1] for im in img_list)
+    return np.concatenate([im if im.shape[:2] == (img_h, img_v) else _resize_nearest(im, img_h, img_v) for im in img_list], axis=1)
+
+
+def save_img_comp(img_list, img_path, mode='RGB'):
+    save_img(img=merge_imgs(img_list), img_path=img_path, mode=mode)
+
+
+def modcrop(img_in, scale):
+    """utils.py:250-264."""
+    img = np.copy(img_in)
+    if img.ndim not in (2, 3):
+        raise ValueError('Wrong img ndim: [{:d}].'.format(img.ndim))
+    H, W = img.shape[:2]
+    return img[:H - H % scale, :W - W % scale]
+
+
+def linear_resize(img, st=256, device='cuda'):
+    """utils.py:267-276: enlarge to the next multiple of `st` in linear light (srgb2linear -> bicubic -> linear2srgb), on the GPU
+    (csrc/colorfix.hip; the bicubic follows OpenCV's INTER_CUBIC formulas -- parity with OpenCV itself is unpinned, as for color_fix)."""
+    h, w = img.shape[0:2]
+    if h % st == 0 and w % st == 0:
+        return img
+    if img.dtype != np.uint8 or img.ndim != 3:
+        raise TypeError('linear_resize: expected a uint8 HWC numpy image')
+    oh, ow = -(-h // st) * st, -(-w // st) * st
+    Cc = img.shape[2]
+    d_in = torch.from_numpy(np.ascontiguousarray(img)).to(device)
+    out = torch.empty((oh, ow, Cc), dtype=torch.uint8, device=d_in.device)
+    ws = torch.empty(h * w * Cc * 4, dtype=torch.uint8, device=d_in.device)
+    with _on(out):
+        L.check(L.lib.innfer_linear_resize(d_in.data_ptr(), h, w, Cc, out.data_ptr(), oh, ow, ws.data_ptr(), ws.numel(), _stream(out)))
+    return out.cpu().numpy()
 
 
 def color_fix(imgA, imgB, device='cuda'):

@@ -325,6 +325,29 @@ def g19():
          big_noflip=ref_utils.tensor2np(big, rgb2bgr=False), big_3d=ref_utils.tensor2np(big[0]), big_2d=ref_utils.tensor2np(big[0, 1]))
 
 
+def g20():
+    """Command-line helpers of run.py (:227-315): scale from the file name, model lookup, the per-architecture presets; modcrop (utils.py:250-264)."""
+    import json
+    names = ["4x_foo.pth", "/a/b/1x_JPEG.pth", "models/2X_up.pth", "16x.pth", "x4_bar.pth", "8x", "foo.pth", "3x_.pth", "xx.pth", "4xfoo+1x.pth"]
+    scales = [ref_run.get_scale_name(n) for n in names]
+    with_arg = [ref_run.get_scale_name("4x_foo.pth", 2), ref_run.get_scale_name("foo.pth", 2)]
+    extras = {"pix2pix": ref_run.pix2pix_extras, "cyclegan": ref_run.cyglegan_extras, "default": ref_run.default_extras}
+    crops = {f"{h}x{w}x{c}@{s}": list(ref_utils.modcrop(np.zeros((h, w, c) if c else (h, w), np.uint8), s).shape)
+             for (h, w, c, s) in [(13, 17, 3, 4), (16, 16, 3, 4), (7, 9, 0, 2), (5, 5, 4, 8)]}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "models", "sub"))
+    for f in ("4x_alpha.pth", "1x_beta.pth", os.path.join("sub", "2x_gamma.pth")):
+        open(os.path.join(tmp, "models", f), "wb").close()
+    os.chdir(tmp)
+    try:
+        chain = {q: [[os.path.relpath(p, tmp) for p in ref_run.parse_models(q)[0]], ref_run.parse_models(q)[1]]
+                 for q in ("4x_alpha.pth", "alpha", "4x_alpha.pth+1x_beta.pth", "beta>gamma", "models/1x_beta.pth")}
+    finally:
+        os.chdir(cwd)
+    save("g20_cli", table=np.array(json.dumps({"names": names, "scales": scales, "with_arg": with_arg, "extras": extras, "crops": crops, "chain": chain})))
+
+
 # ----------------------------------------------------------------- G10 loader
 def g10():
     tmp = tempfile.mkdtemp()
@@ -486,6 +509,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     for g in which:
         globals()[g]()

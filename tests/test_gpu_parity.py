@@ -657,6 +657,59 @@ def test_color_fix_vs_oracle(dev):
         U.color_fix(synth.image_u8(20, 20, 3, 1), synth.image_u8(10, 10, 3, 2), device=dev)      # LR larger than SR
 
 
+def test_command_line_image_loop(dev, tmp_path, monkeypatch):
+    """`run.py -m <chain> -i in -o out [-cf] [-comp]` (run.py:318-445) end to end on the HIP engine: files in, files out.  Two images (one
+    larger than a chop tile), a 1x + 2x model chain found by partial name in ./models; the PNGs must hold exactly what the library calls
+    return and lie within one uint8 code of the oracle's fp32 forward on >= 99 % of the values."""
+    import oracle
+    from innfer_amd import run as R, synth
+    from innfer_amd.utils import utils as U
+    (tmp_path / "models").mkdir(); (tmp_path / "in").mkdir()
+    sds = {}
+    for name, scale, seed in (("1x_clean.pth", 1, 31), ("2x_up.pth", 2, 32)):
+        sds[name] = _sd(synth.rrdbnet_shapes(nb=1, scale=scale), seed)
+        torch.save(sds[name], str(tmp_path / "models" / name))
+    imgs = {"small": synth.image_u8(37, 52, 3, 41), "large": synth.image_u8(210, 230, 3, 42)}
+    for k, im in imgs.items():
+        U.save_img(im, str(tmp_path / "in" / f"{k}.png"))
+    monkeypatch.chdir(tmp_path)
+    assert R.main(["-m", "clean+2x_up", "-i", "in", "-o", "out"]) == 0
+    assert R.main(["-m", "clean+2x_up", "-i", "in", "-o", "out_cf", "-cf", "-comp"]) == 0
+    m1 = R.Model(str(tmp_path / "models" / "1x_clean.pth"), "infer", 1)
+    m2 = R.Model(str(tmp_path / "models" / "2x_up.pth"), "infer", 2)
+    for k, im in imgs.items():
+        got = U.read_img(str(tmp_path / "out" / f"{k}.png"))
+        want = U.tensor2np(m2(m1(U.np2tensor(im, dtype=torch.float16))))
+        assert got.shape == (2 * im.shape[0], 2 * im.shape[1], 3) and np.array_equal(got, want), k
+        comp = U.read_img(str(tmp_path / "out_cf" / f"{k}.png"))
+        assert comp.shape == (2 * im.shape[0], 4 * im.shape[1], 3)
+        assert np.array_equal(comp[:, 2 * im.shape[1]:], U.color_fix(im, want)), k
+        if k == "small":                                   # below the tile size chop_forward is one tile: the plain forward
+            x = oracle.np2tensor(im)
+            with torch.no_grad():
+                ref = oracle.tensor2np(oracle.rrdbnet_forward(sds["2x_up.pth"], oracle.rrdbnet_forward(sds["1x_clean.pth"], x, nb=1, scale=1), nb=1, scale=2))
+            assert (np.abs(got.astype(np.int16) - ref.astype(np.int16)) <= 1).mean() >= 0.99
+
+
+def test_linear_resize_vs_oracle(dev):
+    """linear_resize (utils.py:267-276, the pix2pix pre-step): srgb2linear -> bicubic to the next multiple of `st` -> linear2srgb against the
+    oracle's restatement of OpenCV's INTER_CUBIC (unpinned against OpenCV itself, like color_fix); the truncating cast allows one code."""
+    import oracle
+    from oracle.colorfix import resize_cubic
+    from innfer_amd import synth
+    from innfer_amd.utils import utils as U
+    for (h, w, st) in [(100, 130, 64), (250, 256, 256), (64, 64, 64), (31, 7, 16)]:
+        img = synth.image_u8(h, w, 3, 51)
+        got = U.linear_resize(img, st, device=dev)
+        oh, ow = -(-h // st) * st, -(-w // st) * st
+        if (oh, ow) == (h, w):
+            assert got is img
+            continue
+        ref = oracle.linear2srgb(resize_cubic(oracle.srgb2linear(img).astype(np.float32), (ow, oh)))
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        assert got.shape == (oh, ow, 3) and d.max() <= 1 and (d > 0).mean() <= 2e-3, (h, w, st, d.max(), (d > 0).mean())
+
+
 def test_frame_pipeline_equals_serial_loop(dev):
     """The overlapped image loop (uint8 over PCIe on side streams) must return exactly what the serial
     np2tensor -> model -> tensor2np loop returns, in order, with and without the colour fix."""

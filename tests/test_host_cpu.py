@@ -242,3 +242,61 @@ def test_tile_row_sharding():
         counts = [c // cols for _, c in spans]
         assert max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
     assert [shard_tile_rows(43, 76, 8, r)[1] // 76 for r in range(8)] == [6, 6, 6, 5, 5, 5, 5, 5]
+
+
+def test_cli_helpers_match_reference(golden, tmp_path, monkeypatch):
+    """run.py:227-315 + utils.py:250-264 against the reference's own functions (golden G20): scale from the file name, model lookup in ./models
+    (exact, partial, chains with + and >), the per-architecture presets, modcrop; and the flag surface of the parser (run.py:320-331)."""
+    from innfer_amd import run as R
+    from innfer_amd.utils import utils as U
+    t = json.loads(str(golden("g20_cli")["table"]))
+    assert [R.get_scale_name(n) for n in t["names"]] == t["scales"]
+    assert [R.get_scale_name("4x_foo.pth", 2), R.get_scale_name("foo.pth", 2)] == t["with_arg"]
+    assert {"pix2pix": R.pix2pix_extras, "cyclegan": R.cyglegan_extras, "default": R.default_extras} == t["extras"]
+    for key, shape in t["crops"].items():
+        dims, s = key.split("@")
+        h, w, c = map(int, dims.split("x"))
+        assert list(U.modcrop(np.zeros((h, w, c) if c else (h, w), np.uint8), int(s)).shape) == shape, key
+    (tmp_path / "models" / "sub").mkdir(parents=True)
+    for f in ("4x_alpha.pth", "1x_beta.pth", os.path.join("sub", "2x_gamma.pth")):
+        (tmp_path / "models" / f).write_bytes(b"")
+    monkeypatch.chdir(tmp_path)
+    for q, (paths, scales) in t["chain"].items():
+        got_p, got_s = R.parse_models(q)
+        assert [os.path.relpath(p, tmp_path) for p in got_p] == paths and got_s == scales, q
+    with pytest.raises(ValueError):
+        R.parse_models("a")                       # 'a' matches alpha, beta and gamma
+    with pytest.raises(ValueError):
+        R.parse_models("nope.pth")
+    a = R.build_parser().parse_args(["-m", "4x.pth", "-a", "p2p_256", "-i", "in", "-o", "out", "-cf", "-comp", "-no_fp16", "-norm", "-s", "4"])
+    assert vars(a) == {"models": "4x.pth", "arch": "p2p_256", "input": "in", "output": "out", "scale": "4", "cf": True, "comp": True,
+                       "no_gpu": True, "no_fp16": False, "norm": True}
+    assert vars(R.build_parser().parse_args(["-models", "m.pth", "-cpu"]))["no_gpu"] is False
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        R.main(["-m", "m.pth", "-cpu"])            # no silent CPU path
+
+
+def test_image_files_round_trip_in_opencv_channel_order(tmp_path):
+    """read_img / save_img (utils.py:68-96) through PIL when OpenCV is absent: BGR, BGRA, gray, 16-bit gray come back bit for bit, an
+    unreadable file is None, merge_imgs enlarges the smaller image like cv2.resize(INTER_NEAREST)."""
+    from innfer_amd.utils import utils as U
+    bgr = synth.image_u8(9, 13, 3, 1)
+    bgra = synth.image_u8(7, 5, 4, 2)
+    gray = synth.image_u8(6, 8, 1, 3)[:, :, 0]
+    g16 = (synth.image_u8(6, 8, 1, 4)[:, :, 0].astype(np.uint16) * 257)
+    for name, im in (("a.png", bgr), ("b.png", bgra), ("c.png", gray), ("d.png", g16)):
+        p = str(tmp_path / name)
+        U.save_img(im, p)
+        back = U.read_img(p)
+        assert back.dtype == im.dtype and np.array_equal(back, im), name
+    if not U.cv2_available:
+        from PIL import Image
+        rgb = np.asarray(Image.open(str(tmp_path / "a.png")))
+        assert np.array_equal(rgb[:, :, ::-1], bgr)                  # the file holds RGB: what was saved was BGR
+    (tmp_path / "junk.png").write_bytes(b"not an image")
+    assert U.read_img(str(tmp_path / "junk.png")) is None
+    assert U.get_images_paths(str(tmp_path)) == sorted(str(tmp_path / n) for n in ("a.png", "b.png", "c.png", "d.png", "junk.png"))
+    with pytest.raises(AssertionError):
+        U.get_images_paths(str(tmp_path / "a.png"))
+    m = U.merge_imgs([bgr, np.repeat(np.repeat(bgr, 2, 0), 2, 1)])
+    assert m.shape == (18, 52, 3) and np.array_equal(m[:, :26], m[:, 26:])
