@@ -611,9 +611,10 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 // flight.  3 (16-row tiles, 32-output layers): a ring of three input slots and two weight slots; during step g the loaders issue the weight
 // panel of chunk g + 1 and the halo tile of chunk g + 2 and wait (counted vmcnt) only for what was issued a whole step earlier, so the
 // request stream into HBM never pauses.
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false, int NSI = 2>
-__global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
-    constexpr int NCW = 8;                       // consumer waves; NLW loader waves
+// NCW: consumer waves (8: two per SIMD; 4: one per SIMD with twice the rows each -- the same tile with 0.25 instead of 0.42 ds_read_b128 per MFMA,
+// 256 registers per wave).
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false, int NSI = 2, int NCW = 8>
+__global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -1086,7 +1087,7 @@ __global__ __launch_bounds__(64 * (8 + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false, int NSI = 2>
+template <int RPW, int NT, int NLW, int OUTMODE = OUT_SLAB, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false, int NSI = 2, int NCW = 8>
 int launch_pc(const KP& kp, int N, hipStream_t s);
 
 // Per-device state (a process may drive several GPUs): CU count, and which devices already carry a kernel's
@@ -1164,9 +1165,9 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
     return *tiles * 100 <= plain * 98 ? best : 0;         // worth it from 2 % fewer tiles
 }
 
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI>
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI, int NCW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
-    constexpr int TH = 8 * RPW;
+    constexpr int TH = NCW * RPW;
     constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (__builtin_popcount(TM) * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
@@ -1176,11 +1177,11 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
         if (gx > 0) {
             KP kc = kp;
             kc.cv_gx = gx; kc.cv_gy = gy; kc.cv_h1 = kp.H + 1; kc.cv_w1 = kp.W + 1;
-            return launch_pc<RPW, NT, NLW, OUTMODE, false, false, 0x1FF, true, NSI>(kc, N, s);
+            return launch_pc<RPW, NT, NLW, OUTMODE, false, false, 0x1FF, true, NSI, NCW>(kc, N, s);
         }
     }
     static unsigned long long attr_done = 0;
-    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV, NSI>, LDS, attr_done)) return rc;
+    if (int rc = ensure_lds_attr(conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV, NSI, NCW>, LDS, attr_done)) return rc;
     KP k = kp;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.tiles_y = (k.y1 - k.y0 + TH - 1) / TH;
@@ -1207,7 +1208,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "conv grid too large");
     k.total = (int)total;
     const long grid = total < num_cus() ? total : num_cus();
-    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV, NSI>), dim3((unsigned)grid), dim3(64 * (8 + NLW)), LDS, s, k);
+    hipLaunchKernelGGL((conv3x3_pc<RPW, NT, NLW, OUTMODE, S9, POLY, TM, CV, NSI, NCW>), dim3((unsigned)grid), dim3(64 * (NCW + NLW)), LDS, s, k);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -1368,9 +1369,14 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         // 32-output layers: 24-row tiles, two LDS stages.  pc 5 (diagnostic builds): 16-row tiles on the three-slot input ring (continuous LDS-DMA
         // issue) -- measured within +-1 % of the default on the frame and on the chop path (profiles/r2/kernel_experiments.txt), so the simpler form ships
         if (pc == 5) return launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 3>(k, L.N, s);
+        if (INNFER_KNOB("INNFER_FAT", 0) & 1) return launch_pc<6, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);
         return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     }
-    if (pc && L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4>(k, L.N, s);
+    if (pc && L.out_mode == OUT_SLAB && nt == 4) {
+        // diagnostic builds: four consumer waves of twice the rows (measured within +-1 %: profiles/r2/kernel_experiments.txt 10)
+        if (INNFER_KNOB("INNFER_FAT", 0) & 2) return launch_pc<4, 4, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);
+        return launch_pc<2, 4, 4>(k, L.N, s);
+    }
     if (L.conv7) {         // 7x7 (padding 3) as nine displaced 3x3 convs: planar output, <= 16 output channels, panels from conv_pack7x7
         if (!pc || L.out_mode != OUT_NCHW || nt != 1 || L.res1 || L.res2 || L.up || (long)L.H * L.W * 64 >= 0x7fffffffL)
             return set_error(INNFER_ERR_UNSUPPORTED, "conv7x7: planar output with K <= 16, no residual / upsampling, images below 33 M pixels");
