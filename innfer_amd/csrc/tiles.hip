@@ -39,6 +39,13 @@ __global__ void k_slab_to_nchw(const f16* slab, long gstride, int ch_off, void* 
     if (f32) ((float*)dst)[i] = (float)v; else ((f16*)dst)[i] = v;
 }
 
+// Four consecutive pixels per thread: when P, the tile step and the output width are multiples of 4 every tile origin is, so the four pixels lie
+// under the same tiles and every tile row is read with one 8- / 16-byte load and written with one store.  The ramp step of torch.linspace (one
+// IEEE division) is computed once per thread, not per weight.  Same products, sums and division per pixel in the same order as k_recompose
+// (bit-identical; the launcher picks this form whenever the geometry allows).
+template <typename TI, typename TO>
+__global__ void k_recompose_x4(const TI* tiles, TO* out, int C, int P, int FH, int FW, int eff, int nh, int nw, int ov);
+
 template <typename T>
 __global__ void k_extract(const T* img, T* tiles, int C, int H, int W, int ps, int step_int,
                           int nw, int tile_begin, long total) {
@@ -52,6 +59,23 @@ __global__ void k_extract(const T* img, T* tiles, int C, int H, int W, int ps, i
     int oy = th * step_int; if (oy > H - ps) oy = H - ps;      // ragged last row anchored at H-ps
     int ox = tw * step_int; if (ox > W - ps) ox = W - ps;
     tiles[i] = img[((long)c * H + oy + y) * W + ox + x];
+}
+
+// four consecutive pixels per thread (8- / 16-byte copies): patch size, tile step and image width multiples of 4
+template <typename T>
+__global__ void k_extract_x4(const T* img, T* tiles, int C, int H, int W, int ps, int step_int, int nw, int tile_begin, long total4) {
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over count*C*ps*(ps/4)
+    if (i >= total4) return;
+    const int q = ps >> 2;
+    const int x = (int)(i % q) * 4;
+    const int y = (int)((i / q) % ps);
+    const int c = (int)((i / ((long)q * ps)) % C);
+    const int k = (int)(i / ((long)q * ps * C)) + tile_begin;
+    const int th = k / nw, tw = k % nw;
+    int oy = th * step_int; if (oy > H - ps) oy = H - ps;
+    int ox = tw * step_int; if (ox > W - ps) ox = W - ps;
+    *(v4*)(tiles + i * 4) = *(const v4*)(img + ((long)c * H + oy + y) * W + ox + x);
 }
 
 // torch.linspace(start, end, steps)[i] in fp32 = one fused multiply-add per element,
@@ -106,6 +130,65 @@ __global__ void k_recompose(const TI* tiles, TO* out, int C, int P, int FH, int 
         for (int c = 0; c < 4; ++c)
             if (cb + c < C)
                 out[(((long)b * C + cb + c) * FH + Y) * FW + X] = (TO)__fdiv_rn(num[c], den);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void k_recompose_x4(const TI* tiles, TO* out, int C, int P, int FH, int FW, int eff, int nh, int nw, int ov) {
+    typedef TI vin __attribute__((ext_vector_type(4)));
+    typedef TO vout __attribute__((ext_vector_type(4)));
+    const int X = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int Y = blockIdx.y;
+    const int b = blockIdx.z;
+    if (X >= FW) return;
+    const float st = ov > 1 ? __fdiv_rn(__fsub_rn(1.0f, 0.1f), (float)(ov - 1)) : 0.f;     // linspace(0.1, 1, ov) step; the falling ramp's is -st exactly
+    auto prof = [&](int i) -> float {                       // == profile(i, P, ov)
+        if (i < ov) return ov == 1 ? 0.1f : (i < ov / 2 ? __fmaf_rn(st, (float)i, 0.1f) : __fmaf_rn(-st, (float)(ov - i - 1), 1.0f));
+        if (i < P - ov) return 1.0f;
+        const int k = i - (P - ov);
+        return ov == 1 ? 1.0f : (k < ov / 2 ? __fmaf_rn(-st, (float)k, 1.0f) : __fmaf_rn(st, (float)(ov - k - 1), 0.1f));
+    };
+    const int h0 = max(0, (Y - P + eff) / eff), w0 = max(0, (X - P + eff) / eff);
+    for (int cb = 0; cb < C; cb += 4) {                     // channels in groups of four: one set of weights per group
+        float num[4][4], den[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) num[c][j] = 0.f;
+        for (int h = h0; h < nh; ++h) {
+            const int oy = min(h * eff, FH - P);
+            if (oy > Y) break;
+            if (Y - oy >= P) continue;
+            const float wy = prof(Y - oy);
+            for (int w = w0; w < nw; ++w) {
+                const int ox = min(w * eff, FW - P);
+                if (ox > X) break;
+                if (X - ox >= P) continue;
+                const long k = ((long)b * nh + h) * nw + w;
+                float wgt[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wgt[j] = __fmul_rn(prof(X + j - ox), wy);
+                    den[j] = __fadd_rn(den[j], wgt[j]);
+                }
+                const TI* tp = tiles + ((k * C + cb) * P + (Y - oy)) * (long)P + (X - ox);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (cb + c < C) {
+                        const vin v = *(const vin*)(tp + (long)c * P * P);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) num[c][j] = __fadd_rn(num[c][j], __fmul_rn((float)v[j], wgt[j]));
+                    }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cb + c < C) {
+                vout o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (TO)__fdiv_rn(num[c][j], den[j]);
+                *(vout*)(out + (((long)b * C + cb + c) * FH + Y) * FW + X) = o;
+            }
     }
 }
 
@@ -224,7 +307,14 @@ extern "C" int innfer_extract_tiles(const void* d_img, int dtype, int C, int H, 
     if (total == 0) return INNFER_OK;
     const int step_int = (int)(ps * step);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == INNFER_F16)
+    const bool x4 = ps % 4 == 0 && step_int % 4 == 0 && W % 4 == 0;
+    if (x4 && dtype == INNFER_F16)
+        hipLaunchKernelGGL(k_extract_x4<f16>, dim3(blocks(total / 4, 256)), dim3(256), 0, s, (const f16*)d_img, (f16*)d_tiles,
+                           C, H, W, ps, step_int, nw, tile_begin, total / 4);
+    else if (x4 && dtype == INNFER_F32)
+        hipLaunchKernelGGL(k_extract_x4<float>, dim3(blocks(total / 4, 256)), dim3(256), 0, s, (const float*)d_img, (float*)d_tiles,
+                           C, H, W, ps, step_int, nw, tile_begin, total / 4);
+    else if (dtype == INNFER_F16)
         hipLaunchKernelGGL(k_extract<f16>, dim3(blocks(total, 256)), dim3(256), 0, s, (const f16*)d_img, (f16*)d_tiles,
                            C, H, W, ps, step_int, nw, tile_begin, total);
     else if (dtype == INNFER_F32)
@@ -277,8 +367,11 @@ extern "C" int innfer_recompose(const void* d_tiles, int dtype, int n, int C, in
     if (n % (nh * nw)) return set_error(INNFER_ERR_INVALID, "recompose: %d tiles is not a multiple of %dx%d", n, nh, nw);
     const int nb = n / (nh * nw);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((FW + 255) / 256, FH, nb), block(256);
-#define RC(TI, TO) hipLaunchKernelGGL((k_recompose<TI, TO>), grid, block, 0, s, (const TI*)d_tiles, (TO*)d_out, C, P, FH, FW, eff, nh, nw, ov)
+    // four pixels per thread when every tile origin (multiples of eff, or FW - P for the ragged last column) and the row pitch are multiples of 4
+    const bool x4 = P % 4 == 0 && eff % 4 == 0 && FW % 4 == 0;
+    dim3 grid(x4 ? (FW / 4 + 127) / 128 : (FW + 255) / 256, FH, nb), block(x4 ? 128 : 256);
+#define RC(TI, TO) do { if (x4) hipLaunchKernelGGL((k_recompose_x4<TI, TO>), grid, block, 0, s, (const TI*)d_tiles, (TO*)d_out, C, P, FH, FW, eff, nh, nw, ov); \
+                        else hipLaunchKernelGGL((k_recompose<TI, TO>), grid, block, 0, s, (const TI*)d_tiles, (TO*)d_out, C, P, FH, FW, eff, nh, nw, ov); } while (0)
     if (dtype == INNFER_F16 && out_dtype == INNFER_F16) RC(f16, f16);
     else if (dtype == INNFER_F16 && out_dtype == INNFER_F32) RC(f16, float);
     else if (dtype == INNFER_F32 && out_dtype == INNFER_F32) RC(float, float);
