@@ -39,13 +39,13 @@ typedef enum {
     INNFER_ERR_WORKSPACE = -5    /* workspace too small */
 } innfer_status;
 
-typedef enum { INNFER_F16 = 0, INNFER_F32 = 1 } innfer_dtype;
+typedef enum { INNFER_F16 = 0, INNFER_F32 = 1, INNFER_U8 = 2 /* uint8 HWC image: innfer_net_forward only */ } innfer_dtype;
 
 typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -106,6 +106,14 @@ int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, v
 /* Scheduling knob: 0 = one launch per layer over the whole frame; R>0 = skewed
  * row bands of R rows through the RRDB trunk (working set kept Infinity-Cache
  * resident; identical results). */
+/* uint8 images at the network boundary (104): innfer_net_forward accepts INNFER_U8 as in_dtype and / or out_dtype.  The input then is N
+ * uint8 HWC BGR(A) images back to back and np2tensor (utils/utils.py:164-194: /255, BGR->RGB, optional [-1,1] normalisation, `.half()` in fp16
+ * mode) runs as the first conv's prologue; the output is N uint8 HWC BGR(A) images and tensor2np (utils/utils.py:197-248: optional
+ * denormalisation, clip(255 x).round() half to even, RGB->BGR) runs as the last conv's epilogue.  Bit-identical to the separate passes
+ * innfer_u8hwc_to_nchw / innfer_nchw_to_u8hwc around a float forward.  normalize: the `normalize` / `denormalize` flag of both; fp16_mode != 0:
+ * values are rounded to fp16 where the reference's fp16 mode holds an fp16 tensor (default 1). */
+int innfer_net_set_u8_io(innfer_net_t net, int normalize, int fp16_mode);
+
 int innfer_net_set_band_rows(innfer_net_t net, int rows);
 
 /* Scheduling knob: how the 32-output convs of a residual dense block (RRDBNet_arch.py:152-160) are launched.
@@ -338,6 +346,14 @@ int innfer_nchw_to_u8hwc(const void* d_in, int in_dtype, int H, int W, int C, in
 /* The same with the remaining arguments of np2tensor / tensor2np (104).  bits: 8 or 16 (uint8 / uint16 image, MAX_VALUES_BY_DTYPE
  * utils.py:22-33); maxval: what the image is divided by (255, 65535; 1 = change_range False); bgr2rgb / rgb2bgr = 0 keeps the channel order.
  * innfer_nchw_to_inthwc scales by the data_range that goes with the type (255 / 65535), clips and rounds half to even. */
+/* The chop path with uint8 images at both ends (104): extract_patches_2d(np2tensor(img)) and tensor2np(recompose_tensor(tiles)) without the
+ * float image in between -- the tile gather converts (same /255, flip, normalisation, cast to the tile dtype), the blend stores uint8 HWC
+ * BGR(A) (the blended value is first rounded to via_dtype, the dtype recompose_tensor would have returned).  One image; same geometry and
+ * arithmetic as innfer_extract_tiles / innfer_recompose, bit-identical to the separate passes. */
+int innfer_extract_tiles_u8(const uint8_t* d_img, int C, int H, int W, int normalize, int patch, double step,
+                            int tile_begin, int tile_count, void* d_tiles, int tile_dtype, void* stream);
+int innfer_recompose_u8(const void* d_tiles, int dtype, int n_tiles, int C, int P, int height, int width, double step, int scale,
+                        int via_dtype, int denormalize, uint8_t* d_img, void* stream);
 int innfer_inthwc_to_nchw(const void* d_img, int bits, int H, int W, int C, int bgr2rgb, int normalize, float maxval,
                           void* d_out, int out_dtype, void* stream);
 int innfer_nchw_to_inthwc(const void* d_in, int in_dtype, int H, int W, int C, int rgb2bgr, int denormalize, int bits,

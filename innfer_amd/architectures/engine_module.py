@@ -123,6 +123,41 @@ class EngineModule(nn.Module):
                                          self._ws.data_ptr(), self._ws.numel(), stream))
         return out
 
+    def forward_u8(self, img, normalize=False, fp16=True, out=None):
+        """uint8 HWC BGR(A) image(s) on the GPU -> uint8 HWC BGR(A) image(s): np2tensor is the first conv's prologue and tensor2np the last conv's
+        epilogue (innfer_net_forward with INNFER_U8 at both ends).  Equals tensor2np(self(np2tensor(img)[.half()]), denormalize=normalize) bit for
+        bit.  img: [H,W,C] or [N,H,W,C] uint8 cuda tensor; returns the same rank."""
+        if not isinstance(img, torch.Tensor) or img.dtype != torch.uint8 or img.dim() not in (3, 4):
+            raise ValueError('forward_u8: expected a uint8 [H,W,C] or [N,H,W,C] tensor')
+        if not img.is_cuda:
+            raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
+        with torch.cuda.device(img.device):
+            if self._weights_device is not None and self._weights_device != img.device:
+                self._destroy_handle()
+            self._ensure_engine()
+            self._weights_device = img.device
+            L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
+            L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
+            L.check(L.lib.innfer_net_set_u8_io(self._handle, int(bool(normalize)), int(bool(fp16))))
+            x = img.contiguous()
+            batched = x.dim() == 4
+            N, (H, W, Cc) = (x.shape[0] if batched else 1), x.shape[-3:]
+            if Cc != self.in_nc:
+                raise ValueError(f'forward_u8: the image has {Cc} channels, the network takes {self.in_nc}')
+            s = L.lib.innfer_net_scale(self._handle)
+            shape = (N, H * s, W * s, self.out_nc) if batched else (H * s, W * s, self.out_nc)
+            if out is None:
+                out = torch.empty(shape, dtype=torch.uint8, device=x.device)
+            elif tuple(out.shape) != shape or out.dtype != torch.uint8 or not out.is_contiguous():
+                raise ValueError(f'forward_u8: out must be a contiguous uint8 tensor of shape {shape}')
+            need = L.lib.innfer_net_workspace_bytes(self._handle, N, H, W)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            L.check(L.lib.innfer_net_forward(self._handle, x.data_ptr(), L.U8, out.data_ptr(), L.U8, N, H, W,
+                                             self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
     def release_workspace(self):
         self._ws = None
 

@@ -63,6 +63,8 @@ struct ConvLaunch {
     int conv7;                                    // 7x7 conv, padding 3 (zero or `reflect`), panels from conv_pack7x7: OUT_NCHW, K <= 16 only
     int reflect;                                  // ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel)
     int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)
+    int out_u8, out_denorm, out_round16;          // OUT_NCHW with <= 4 channels: write a uint8 HWC BGR(A) image instead -- tensor2np as the conv's epilogue
+                                                  // (utils.py:197-248): [round to fp16,] optional denormalisation, clip(255 x).round() half to even, channel flip
     const f16* pair_wpk; const float* pair_bias;  // net.hip only: non-null = this 32-output LeakyReLU conv AND the next one of the dense block (inputs: the same
                                                   // C channels + this conv's output, output: the following channel group) as one conv_pair_launch
 };
@@ -92,6 +94,8 @@ void conv_pack7x7(const float* w_oihw, int K, int C, void* packed);   // host; C
 // ---- first conv: few input channels, NCHW input (conv_first.hip) -------------
 struct FirstConvLaunch {
     const void* in; int in_f32; int Cin;          // NCHW planar input
+    int in_u8, in_norm, in_round16;               // in_u8: `in` is a uint8 HWC BGR(A) image instead -- np2tensor as the conv's prologue (utils.py:164-194):
+                                                  // /255, channel flip, optional [-1,1] normalisation, optional rounding to fp16 (`.half()`, run.py:422)
     const float* w;                               // [Cin*9][K] fp32 (k-major), device
     const float* bias;
     f16* out; long out_gstride; f16* out2; long out2_gstride;

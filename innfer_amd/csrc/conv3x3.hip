@@ -89,6 +89,7 @@ struct KP {
     int y0, y1;
     int tiles_x, tiles_y;
     int out_f32;
+    int out_u8, out_denorm, out_round16;   // planar kernels with <= 4 channels: uint8 HWC BGR(A) image instead of planar floats (tensor2np as the epilogue)
     int N;
     int pf;                  // L2 prefetch of the next chunk's input lines
     int rev;                 // each XCD walks its run of tiles backwards
@@ -1071,6 +1072,16 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                                 const int ph = ch / p.phase_c, c = ch - ph * p.phase_c;
                                 o = (((long)n * p.phase_c + c) * (2 * p.H) + 2 * y + (ph >> 1)) * (2 * p.W) + 2 * x + (ph & 1);
                             }
+                            if (p.out_u8) {
+                                // tensor2np (utils.py:197-248) on the value the planar store would have held: [fp16 rounding,] denorm ((x + 1) / 2
+                                // clipped), clip(255 x, 0, 255).round() half to even, RGB -> BGR flip for 3 / 4 channels; HWC bytes
+                                float v = p.out_round16 ? (float)(f16)f : f;
+                                if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
+                                v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
+                                const int sc = (p.K == 3 || (p.K == 4 && ch < 3)) ? 2 - ch : ch;
+                                ((uint8_t*)p.out)[(((long)n * p.H + y) * p.W + x) * p.K + sc] = (uint8_t)__float2int_rn(v);
+                                continue;
+                            }
                             if (p.out_f32) ((float*)p.out)[o] = f;
                             else ((f16*)p.out)[o] = (f16)f;
                         }
@@ -1332,6 +1343,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.y0 = L.y0; k.y1 = L.y1 > 0 ? L.y1 : L.H;
     if (k.y0 < 0 || k.y1 > L.H || k.y0 >= k.y1) return set_error(INNFER_ERR_INVALID, "conv3x3: bad row range [%d,%d)", k.y0, k.y1);
     k.out_f32 = L.out_f32;
+    if (L.out_u8 && (L.out_mode != OUT_NCHW || L.K > 4 || L.phase_c > 0 || L.res1 || L.res2 || L.conv7))
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the uint8 image epilogue belongs to planar outputs of <= 4 channels");
+    k.out_u8 = L.out_u8; k.out_denorm = L.out_denorm; k.out_round16 = L.out_round16;
     k.rev = L.rev ? 1 : 0;
     k.phase_c = L.out_mode == OUT_NCHW ? L.phase_c : 0;
     k.reflect = L.reflect ? 1 : 0;

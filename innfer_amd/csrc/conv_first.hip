@@ -11,12 +11,31 @@
 namespace innfer {
 namespace {
 
+struct FP;
+__device__ __forceinline__ float first_conv_input(const FP& p, long n, int ci, int Y, int X, long hw);
+
 struct FP {
     const void* in; int in_f32; int Cin;
+    int in_u8, in_norm, in_round16;
     const float* w; const float* bias;
     f16* out; long out_gstride; f16* out2; long out2_gstride;
     int K; long npix; int H, W; int act;
 };
+
+// One input value of the first conv: planar fp16 / fp32, or np2tensor of a uint8 HWC image (float32(u8) / 255, BGR -> RGB flip as in
+// colors.py:5-21, optional ((x - 0.5) * 2).clamp(-1, 1), optional rounding to fp16) -- bit for bit what the separate pass produces.
+__device__ __forceinline__ float first_conv_input(const FP& p, long n, int ci, int Y, int X, long hw) {
+    if (p.in_u8) {
+        int sc = ci;
+        if (p.Cin % 3 == 0) sc = p.Cin - 1 - ci; else if (p.Cin == 4 && ci < 3) sc = 2 - ci;
+        float v = __fdiv_rn((float)((const uint8_t*)p.in)[(n * hw + (long)Y * p.W + X) * p.Cin + sc], 255.0f);
+        if (p.in_norm) v = fminf(fmaxf(__fmul_rn(__fsub_rn(v, 0.5f), 2.0f), -1.0f), 1.0f);
+        if (p.in_round16) v = (float)(f16)v;
+        return v;
+    }
+    const long o = (n * p.Cin + ci) * hw + (long)Y * p.W + X;
+    return p.in_f32 ? ((const float*)p.in)[o] : (float)((const f16*)p.in)[o];
+}
 
 __global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
     extern __shared__ __attribute__((aligned(16))) float sw[];
@@ -37,7 +56,6 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = sw[nw + cg + e];
     for (int ci = 0; ci < p.Cin; ++ci) {
-        const long plane = (n * p.Cin + ci) * (long)p.H * p.W;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int Y = y + r - 1;
@@ -45,10 +63,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
             for (int s = 0; s < 3; ++s) {
                 const int X = x + s - 1;
                 float v = 0.f;
-                if (Y >= 0 && Y < p.H && X >= 0 && X < p.W) {
-                    const long o = plane + (long)Y * p.W + X;
-                    v = p.in_f32 ? ((const float*)p.in)[o] : (float)((const f16*)p.in)[o];
-                }
+                if (Y >= 0 && Y < p.H && X >= 0 && X < p.W) v = first_conv_input(p, n, ci, Y, X, (long)p.H * p.W);
                 const float* wk = sw + (ci * 9 + r * 3 + s) * p.K + cg;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, wk[e], acc[e]);
@@ -120,15 +135,12 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
                 const int ci = kk / 9, tap = kk - ci * 9, r = tap / 3, s = tap - r * 3;
                 const int Y = y + r - 1, X = x + s - 1;
                 float v = 0.f;
-                if (live && kk < nk && Y >= 0 && Y < p.H && X >= 0 && X < p.W) {
-                    const long o = (n * p.Cin + ci) * hw + (long)Y * p.W + X;
-                    v = p.in_f32 ? ((const float*)p.in)[o] : (float)((const f16*)p.in)[o];
-                }
+                if (live && kk < nk && Y >= 0 && Y < p.H && X >= 0 && X < p.W) v = first_conv_input(p, n, ci, Y, X, hw);
                 const f16 h = (f16)v;
                 xh[e] = h;
                 xl[e] = (f16)(v - (float)h);
             }
-            any_lo = p.in_f32 != 0;
+            any_lo = p.in_f32 != 0 || (p.in_u8 && !p.in_round16);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st][t], xh, acc[t], 0, 0, 0);
@@ -166,7 +178,7 @@ int first_conv_launch(const FirstConvLaunch& L, hipStream_t s) {
     if (L.K % 8 || L.K > 256 || L.K <= 0)
         return set_error(INNFER_ERR_UNSUPPORTED, "first conv: nf=%d must be a multiple of 8, <= 256", L.K);
     if (L.Cin < 1 || L.Cin > 8) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: in_nc=%d unsupported", L.Cin);
-    FP p{L.in, L.in_f32, L.Cin, L.w, L.bias, L.out, L.out_gstride, L.out2, L.out2_gstride,
+    FP p{L.in, L.in_f32, L.Cin, L.in_u8, L.in_norm, L.in_round16, L.w, L.bias, L.out, L.out_gstride, L.out2, L.out2_gstride,
          L.K, (long)L.N * L.H * L.W, L.H, L.W, L.act};
     if ((L.K == 32 || L.K == 64) && INNFER_KNOB("INNFER_FIRST_MFMA", 1)) {
         const long groups = (p.npix + 15) / 16, want = (groups + 3) / 4;

@@ -49,6 +49,7 @@ struct innfer_net {
     int nr = 3;                  // dense blocks per RRDB (RRDBNet_arch.py:73-88)
     int trunk_act = 1;           // `act_type` of the constructors as a ConvLaunch.act code: 1 LeakyReLU(0.2), 2 ReLU
     bool ps_up = false;          // RRDBNet(upsample_mode='pixelshuffle'): conv nf -> 4 nf, PixelShuffle(2), act instead of Upsample, conv, act
+    int u8_normalize = 0, u8_round16 = 1;   // innfer_net_forward with INNFER_U8 images: normalize / denormalize flags of np2tensor / tensor2np, fp16 mode
     int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
     std::vector<ConvSlot> convs;
@@ -207,6 +208,13 @@ extern "C" int innfer_net_set_pair_convs(innfer_net_t net, int mode) {
     return INNFER_OK;
 }
 
+extern "C" int innfer_net_set_u8_io(innfer_net_t net, int normalize, int fp16_mode) {
+    if (!net) return set_error(INNFER_ERR_INVALID, "set_u8_io: null net");
+    net->u8_normalize = normalize != 0;
+    net->u8_round16 = fp16_mode != 0;
+    return INNFER_OK;
+}
+
 extern "C" int innfer_net_set_final_act(innfer_net_t net, int act) {
     if (!net || (act != 0 && act != 1 && act != 2 && act != 3 && act != 6))
         return set_error(INNFER_ERR_INVALID, "set_final_act: act %d (0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 6 sigmoid)", act);
@@ -347,7 +355,7 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
         return timed_end(s, 2.0 * 9.0 * 32.0 * (2.0 * L.C + 32.0) * px, px * (L.C * 2.0 + 64.0 * 2.0) + 9.0 * 32.0 * (2.0 * L.C + 32.0) * 2.0, 1000);
     const int taps = L.conv1x1 ? 1 : 9;
     // algorithmic bytes per output pixel: C input channels (a quarter of them per pixel behind the folded nearest-2x), K outputs, K per residual
-    const double obytes = L.out_mode == OUT_NCHW ? (L.out_f32 ? 4.0 : 2.0) : 2.0;
+    const double obytes = L.out_mode == OUT_NCHW ? (L.out_u8 ? 1.0 : L.out_f32 ? 4.0 : 2.0) : 2.0;
     const double bytes = px * (L.C * 2.0 / (L.up ? 4.0 : 1.0) + L.K * obytes + (L.res1 ? L.K * 2.0 : 0.0) + (L.res2 ? L.K * 2.0 : 0.0))
                          + (double)taps * L.K * L.C * 2.0;
     return timed_end(s, 2.0 * taps * L.K * L.C * px, bytes, 16 * conv_nt_for(L.K) + L.out_mode);
@@ -436,8 +444,9 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
                                   int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
     if (!net || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "forward: null argument");
     if (N <= 0 || H <= 0 || W <= 0) return set_error(INNFER_ERR_INVALID, "forward: bad shape %dx%dx%d", N, H, W);
-    if ((in_dtype != INNFER_F16 && in_dtype != INNFER_F32) || (out_dtype != INNFER_F16 && out_dtype != INNFER_F32))
-        return set_error(INNFER_ERR_INVALID, "forward: bad dtype");
+    auto dtype_ok = [](int d) { return d == INNFER_F16 || d == INNFER_F32 || d == INNFER_U8; };
+    if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return set_error(INNFER_ERR_INVALID, "forward: bad dtype");
+    if (out_dtype == INNFER_U8 && net->out_nc > 4) return set_error(INNFER_ERR_UNSUPPORTED, "forward: a uint8 image has at most 4 channels (out_nc %d)", net->out_nc);
     for (auto& c : net->convs)
         if (!c.loaded) return set_error(INNFER_ERR_INVALID, "forward: weights of '%s' were never set", c.key.c_str());
     const Carve cv = carve(net, N, H, W);
@@ -455,6 +464,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         const ConvSlot& c0 = net->convs[ci++];
         FirstConvLaunch F{};
         F.in = d_in; F.in_f32 = in_dtype == INNFER_F32; F.Cin = c0.C; F.w = (const float*)c0.d_w; F.bias = c0.d_b;
+        F.in_u8 = in_dtype == INNFER_U8; F.in_norm = net->u8_normalize; F.in_round16 = net->u8_round16;     // np2tensor as the conv's prologue
         F.out = fea; F.out_gstride = G; F.out2 = slab[0]; F.out2_gstride = G;
         F.K = nf; F.N = N; F.H = H; F.W = W; F.act = 0;
         int rc = do_first(F, s);
@@ -562,6 +572,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         const ConvSlot& cs = net->convs[ci++];
         ConvLaunch L = mk(cs, (const f16*)(ws + cv.hr), (long)N * h * w * 32, d_out, 0, N, h, w, net->final_act);
         L.out_mode = OUT_NCHW; L.out_f32 = out_dtype == INNFER_F32;
+        L.out_u8 = out_dtype == INNFER_U8; L.out_denorm = net->u8_normalize; L.out_round16 = net->u8_round16;     // tensor2np as the conv's epilogue
         rc = do_conv(L, s);
         if (rc) return rc;
     }

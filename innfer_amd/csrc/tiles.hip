@@ -78,6 +78,27 @@ __global__ void k_extract_x4(const T* img, T* tiles, int C, int H, int W, int ps
     *(v4*)(tiles + i * 4) = *(const v4*)(img + ((long)c * H + oy + y) * W + ox + x);
 }
 
+// extract_patches_2d of np2tensor(img) without the float image in between: tile element = float32(u8) / 255 [-> (x - 0.5) * 2 clamped]
+// [-> fp16], channels flipped BGR -> RGB (3n channels: full flip; 4: [2,1,0,3]) -- the values k_u8_to_nchw + k_extract produce
+template <typename TO>
+__global__ void k_extract_u8(const uint8_t* img, TO* tiles, int C, int H, int W, int ps, int step_int, int nw, int tile_begin, long total,
+                             int normalize) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over count*C*ps*ps
+    if (i >= total) return;
+    const int x = (int)(i % ps);
+    const int y = (int)((i / ps) % ps);
+    const int c = (int)((i / ((long)ps * ps)) % C);
+    const int k = (int)(i / ((long)ps * ps * C)) + tile_begin;
+    const int th = k / nw, tw = k % nw;
+    int oy = th * step_int; if (oy > H - ps) oy = H - ps;
+    int ox = tw * step_int; if (ox > W - ps) ox = W - ps;
+    int sc = c;
+    if (C % 3 == 0) sc = C - 1 - c; else if (C == 4 && c < 3) sc = 2 - c;
+    float v = __fdiv_rn((float)img[((long)(oy + y) * W + ox + x) * C + sc], 255.0f);
+    if (normalize) v = fminf(fmaxf(__fmul_rn(__fsub_rn(v, 0.5f), 2.0f), -1.0f), 1.0f);
+    tiles[i] = (TO)v;
+}
+
 // torch.linspace(start, end, steps)[i] in fp32 = one fused multiply-add per element,
 // counted from the nearer end (ATen RangeFactories; verified against golden G2).
 __device__ __forceinline__ float lin(float start, float end, int steps, int i) {
@@ -93,9 +114,11 @@ __device__ __forceinline__ float profile(int i, int P, int ov) {
     return lin(1.0f, 0.1f, ov, i - (P - ov));
 }
 
-template <typename TI, typename TO>
+// U8OUT: tensor2np of the blended image as the store -- the blended value is rounded to TO (the tensor recompose_tensor would have returned),
+// optionally denormalised, scaled, clipped, rounded half to even and written as a uint8 HWC BGR(A) pixel (`img`, batch 1).
+template <typename TI, typename TO, bool U8OUT = false>
 __global__ void k_recompose(const TI* tiles, TO* out, int C, int P, int FH, int FW, int eff,
-                            int nh, int nw, int ov) {
+                            int nh, int nw, int ov, uint8_t* img = nullptr, int denormalize = 0) {
     const int X = blockIdx.x * blockDim.x + threadIdx.x;
     const int Y = blockIdx.y;
     const int b = blockIdx.z;
@@ -128,8 +151,18 @@ __global__ void k_recompose(const TI* tiles, TO* out, int C, int P, int FH, int 
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (cb + c < C)
-                out[(((long)b * C + cb + c) * FH + Y) * FW + X] = (TO)__fdiv_rn(num[c], den);
+            if (cb + c < C) {
+                const TO r = (TO)__fdiv_rn(num[c], den);
+                if constexpr (U8OUT) {
+                    float v = (float)r;
+                    if (denormalize) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
+                    v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
+                    const int ch = cb + c, sc = (C == 3 || (C == 4 && ch < 3)) ? 2 - ch : ch;
+                    img[((long)Y * FW + X) * C + sc] = (uint8_t)__float2int_rn(v);
+                } else {
+                    out[(((long)b * C + cb + c) * FH + Y) * FW + X] = r;
+                }
+            }
     }
 }
 
@@ -378,6 +411,52 @@ extern "C" int innfer_recompose(const void* d_tiles, int dtype, int n, int C, in
     else if (dtype == INNFER_F32 && out_dtype == INNFER_F16) RC(float, f16);
     else return set_error(INNFER_ERR_INVALID, "recompose: bad dtype");
 #undef RC
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_extract_tiles_u8(const uint8_t* d_img, int C, int H, int W, int normalize, int patch, double step,
+                                       int tile_begin, int tile_count, void* d_tiles, int tile_dtype, void* stream) {
+    if (!d_img || !d_tiles || C <= 0) return set_error(INNFER_ERR_INVALID, "extract_tiles_u8: null argument / no channels");
+    int ps, nh, nw;
+    if (int rc = innfer_chop_plan(H, W, patch, step, &ps, &nh, &nw, nullptr, nullptr)) return rc;
+    const int step_int = (int)(ps * step);
+    if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > nh * nw)
+        return set_error(INNFER_ERR_INVALID, "extract_tiles_u8: tile range [%d,+%d) outside %d tiles", tile_begin, tile_count, nh * nw);
+    const long total = (long)tile_count * C * ps * ps;
+    if (total == 0) return INNFER_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (tile_dtype == INNFER_F16)
+        hipLaunchKernelGGL(k_extract_u8<f16>, dim3(blocks(total, 256)), dim3(256), 0, s, d_img, (f16*)d_tiles, C, H, W, ps, step_int, nw, tile_begin, total, normalize);
+    else if (tile_dtype == INNFER_F32)
+        hipLaunchKernelGGL(k_extract_u8<float>, dim3(blocks(total, 256)), dim3(256), 0, s, d_img, (float*)d_tiles, C, H, W, ps, step_int, nw, tile_begin, total, normalize);
+    else return set_error(INNFER_ERR_INVALID, "extract_tiles_u8: bad dtype %d", tile_dtype);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_recompose_u8(const void* d_tiles, int dtype, int n, int C, int P, int height, int width, double step, int scale,
+                                   int via_dtype, int denormalize, uint8_t* d_img, void* stream) {
+    if (!d_tiles || !d_img) return set_error(INNFER_ERR_INVALID, "recompose_u8: null argument");
+    if (step < 0.5 || step > 1.0) return set_error(INNFER_ERR_INVALID, "recompose_u8: step must be in [0.5,1]");
+    if (n <= 0 || C <= 0 || C > 4 || P <= 0 || scale <= 0) return set_error(INNFER_ERR_INVALID, "recompose_u8: bad sizes");
+    const int FH = scale * height, FW = scale * width;
+    if (FH < P || FW < P) return set_error(INNFER_ERR_INVALID, "recompose_u8: patch %d larger than output %dx%d", P, FH, FW);
+    const int ov = blend_overlap(P, step, scale);
+    if (P - 2 * ov < 0) return set_error(INNFER_ERR_INVALID, "recompose_u8: overlap %d exceeds half of patch %d (reference raises too)", ov, P);
+    const int eff = (int)(step * P), step_int = (int)(P * step);
+    const int nh = 1 + (FH - P) / step_int + ((FH - P) % step_int != 0);
+    const int nw = 1 + (FW - P) / step_int + ((FW - P) % step_int != 0);
+    if (n != nh * nw) return set_error(INNFER_ERR_INVALID, "recompose_u8: one image of %dx%d tiles expected, got %d tiles", nh, nw, n);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((FW + 255) / 256, FH, 1), block(256);
+#define RCU(TI, TO) hipLaunchKernelGGL((k_recompose<TI, TO, true>), grid, block, 0, s, (const TI*)d_tiles, (TO*)nullptr, C, P, FH, FW, eff, nh, nw, ov, d_img, denormalize)
+    if (dtype == INNFER_F16 && via_dtype == INNFER_F16) RCU(f16, f16);
+    else if (dtype == INNFER_F16 && via_dtype == INNFER_F32) RCU(f16, float);
+    else if (dtype == INNFER_F32 && via_dtype == INNFER_F32) RCU(float, float);
+    else if (dtype == INNFER_F32 && via_dtype == INNFER_F16) RCU(float, f16);
+    else return set_error(INNFER_ERR_INVALID, "recompose_u8: bad dtype");
+#undef RCU
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }

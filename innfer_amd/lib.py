@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INNFER_LIB") or os.path.join(_HERE, "lib", "libinnfer_amd.so")
 
-F16, F32 = 0, 1
+F16, F32, U8 = 0, 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM, ERR_WORKSPACE = 0, -1, -2, -3, -4, -5
 
 
@@ -149,6 +149,9 @@ SIGNATURES = {
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_nchw_to_u8hwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "innfer_linear_resize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "innfer_extract_tiles_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "innfer_recompose_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "innfer_net_set_u8_io": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "innfer_inthwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "innfer_nchw_to_inthwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }

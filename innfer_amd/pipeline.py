@@ -42,11 +42,16 @@ class FramePipeline:
         H, W, C = shape
         cur = torch.cuda.current_stream(self.dev)
         cur.wait_event(sl['up'])
-        x = torch.empty((1, C, H, W), dtype=torch.float16 if self.half else torch.float32, device=self.dev)
-        L.check(L.lib.innfer_u8hwc_to_nchw(sl['d_in'].data_ptr(), H, W, C, int(self.normalize), x.data_ptr(), _dt(x), cur.cuda_stream))
-        y = self.model(x)
         s = self.scale
-        L.check(L.lib.innfer_nchw_to_u8hwc(y.data_ptr(), _dt(y), H * s, W * s, C, int(self.normalize), sl['d_out'].data_ptr(), cur.cuda_stream))
+        if hasattr(self.model, 'run_u8'):            # run.Model: np2tensor / tensor2np fused into the tile gather / blend or the first / last conv
+            self.model.run_u8(sl['d_in'], normalize=self.normalize, fp16=self.half, out=sl['d_out'])
+        elif hasattr(self.model, 'forward_u8'):      # an RRDBNet / SRResNet module
+            self.model.forward_u8(sl['d_in'], normalize=self.normalize, fp16=self.half, out=sl['d_out'])
+        else:
+            x = torch.empty((1, C, H, W), dtype=torch.float16 if self.half else torch.float32, device=self.dev)
+            L.check(L.lib.innfer_u8hwc_to_nchw(sl['d_in'].data_ptr(), H, W, C, int(self.normalize), x.data_ptr(), _dt(x), cur.cuda_stream))
+            y = self.model(x)
+            L.check(L.lib.innfer_nchw_to_u8hwc(y.data_ptr(), _dt(y), H * s, W * s, C, int(self.normalize), sl['d_out'].data_ptr(), cur.cuda_stream))
         if self.cf:
             need = L.lib.innfer_color_fix_workspace_bytes(H, W, H * s, W * s, C)
             if self._ws_cf is None or self._ws_cf.numel() < need:

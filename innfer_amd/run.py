@@ -178,6 +178,54 @@ class Model:
         with torch.no_grad():
             return self._predict(data)
 
+    def run_u8(self, img, normalize=False, fp16=True, out=None):
+        """Image in, image out: tensor2np(self(np2tensor(img, normalize)[.half()]), denormalize=normalize) (run.py:421-431) with the two
+        conversions fused into the neighbouring kernels -- the tile gather / the blend on the chop path (innfer_extract_tiles_u8,
+        innfer_recompose_u8), the first / last conv otherwise (EngineModule.forward_u8).  Bit-identical to the separate passes.
+        img: uint8 HWC BGR(A), a numpy array (uploaded / downloaded as uint8) or a cuda tensor (stays on the GPU)."""
+        import numpy as np
+        from . import lib as L
+        from .architectures.engine_module import EngineModule
+        from .parallel import tile_batches
+        from .utils import utils as U
+        host = isinstance(img, np.ndarray)
+        d = torch.from_numpy(np.ascontiguousarray(img)).to(self.device) if host else img.contiguous()
+        if d.dtype != torch.uint8 or d.dim() != 3:
+            raise TypeError('run_u8: expected a uint8 HWC image')
+        H, W, Cc = d.shape
+        s = int(self.scale or 1)
+        dt = torch.float16 if fp16 else torch.float32
+        code = L.F16 if fp16 else L.F32
+        stream = torch.cuda.current_stream(d.device).cuda_stream
+        fused_net = isinstance(self.model, EngineModule) and self.arch != 'ppon'
+        with torch.no_grad(), torch.cuda.device(d.device):
+            if self.chop:
+                ps = min(H, W, 200)
+                _, ys, xs = L.chop_plan(H, W, ps, 0.5)
+                n = len(ys) * len(xs)
+                tiles = torch.empty((n, Cc, ps, ps), dtype=dt, device=d.device)
+                L.check(L.lib.innfer_extract_tiles_u8(d.data_ptr(), Cc, H, W, int(bool(normalize)), ps, 0.5, 0, n, tiles.data_ptr(), code, stream))
+                outs, i = [], 0
+                for b in tile_batches(n, self.tile_batch):
+                    outs.append(self._predict(tiles[i:i + b]))
+                    i += b
+                hr = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
+                Co, P = hr.shape[1], hr.shape[2]
+                if out is None:
+                    out = torch.empty((H * s, W * s, Co), dtype=torch.uint8, device=d.device)
+                L.check(L.lib.innfer_recompose_u8(hr.data_ptr(), U._dt(hr), n, Co, P, H, W, 0.5, s, U._dt(hr), int(bool(normalize)),
+                                                  out.data_ptr(), stream))
+            elif fused_net:
+                out = self.model.forward_u8(d, normalize=normalize, fp16=fp16, out=out)
+            else:
+                x = torch.empty((1, Cc, H, W), dtype=dt, device=d.device)
+                L.check(L.lib.innfer_u8hwc_to_nchw(d.data_ptr(), H, W, Cc, int(bool(normalize)), x.data_ptr(), code, stream))
+                y = self._predict(x).contiguous()
+                if out is None:
+                    out = torch.empty((y.shape[2], y.shape[3], y.shape[1]), dtype=torch.uint8, device=d.device)
+                L.check(L.lib.innfer_nchw_to_u8hwc(y.data_ptr(), U._dt(y), y.shape[2], y.shape[3], y.shape[1], int(bool(normalize)), out.data_ptr(), stream))
+        return out.cpu().numpy() if host else out
+
 
 # ------------------------------------------------------------------- command line (run.py:225-445)
 def parse_models(models_paths, scales_list=None):
@@ -259,6 +307,7 @@ def main(argv=None):
     uint8 image is what crosses PCIe in both directions; files go through OpenCV when it is installed and through PIL otherwise."""
     import os
     import os.path as osp
+    import numpy as np
     from .utils import utils as U
     args = build_parser().parse_args(argv)
     if not args.no_gpu:
@@ -297,13 +346,16 @@ def main(argv=None):
             img = U.linear_resize(img, resize)
         if use_modcrop:
             img = U.modcrop(img, 4)
-        t_img = U.np2tensor(img, normalize=normalize, device=device, dtype=torch.float16 if fp16 else torch.float32)
-        t_out = t_img
-        for mod in models:
-            t_out = mod(t_out)
-            if use_guided_filter:
-                t_out = U.guided_filter(t_img, t_out, r=1, eps=5e-3)
-        img_out = U.tensor2np(t_out.detach(), denormalize=normalize)
+        if len(models) == 1 and not use_guided_filter and img.dtype == np.uint8 and img.ndim == 3:
+            img_out = models[0].run_u8(img, normalize=normalize, fp16=fp16)          # conversions fused into the tile gather / blend / first and last conv
+        else:
+            t_img = U.np2tensor(img, normalize=normalize, device=device, dtype=torch.float16 if fp16 else torch.float32)
+            t_out = t_img
+            for mod in models:
+                t_out = mod(t_out)
+                if use_guided_filter:
+                    t_out = U.guided_filter(t_img, t_out, r=1, eps=5e-3)
+            img_out = U.tensor2np(t_out.detach(), denormalize=normalize)
         if args.cf:
             img_out = U.color_fix(img, img_out)
         save_img_path = osp.join(args.output, f'{img_name:s}.png')

@@ -691,6 +691,34 @@ def test_command_line_image_loop(dev, tmp_path, monkeypatch):
             assert (np.abs(got.astype(np.int16) - ref.astype(np.int16)) <= 1).mean() >= 0.99
 
 
+@pytest.mark.parametrize("chop", [True, False])
+def test_image_in_image_out_equals_the_separate_passes(dev, tmp_path, chop):
+    """Model.run_u8: np2tensor and tensor2np fused into the tile gather / blend (chop) or into the first / last conv (un-tiled) must return
+    exactly tensor2np(model(np2tensor(img)[.half()])) -- fp16 and fp32 mode, with and without [-1,1] normalisation, images smaller and larger
+    than a chop tile, gray models."""
+    from innfer_amd import run as R, synth
+    from innfer_amd.utils import utils as U
+    for in_nc, name in ((3, "2x_rgb.pth"), (1, "2x_gray.pth")):
+        torch.save(_sd(synth.rrdbnet_shapes(nb=1, scale=2, in_nc=in_nc, out_nc=in_nc), 60 + in_nc), str(tmp_path / name))
+        m = R.Model(str(tmp_path / name), "infer", 2, in_nc=in_nc, out_nc=in_nc, chop=chop)
+        for (h, w, seed) in [(37, 52, 61), (210, 230, 62), (200, 200, 63), (1, 1, 64)]:
+            if chop and min(h, w) < 2:
+                continue                      # a one-pixel patch has tile step 0: chop_forward raises, in the reference too
+            img = synth.image_u8(h, w, in_nc, seed)
+            for fp16 in (True, False):
+                for normalize in (False, True):
+                    want = U.tensor2np(m(U.np2tensor(img, normalize=normalize, dtype=torch.float16 if fp16 else torch.float32)), denormalize=normalize)
+                    got = m.run_u8(img, normalize=normalize, fp16=fp16)
+                    assert got.dtype == np.uint8 and got.shape == want.shape and np.array_equal(got, want), (in_nc, h, w, fp16, normalize)
+            d = torch.from_numpy(img).to(dev)
+            assert np.array_equal(m.run_u8(d).cpu().numpy(), m.run_u8(img))          # device image in, device image out
+    net = m.model
+    batch = torch.from_numpy(np.stack([synth.image_u8(20, 24, 1, 70 + i) for i in range(3)])).to(dev)
+    got = net.forward_u8(batch)
+    for i in range(3):
+        assert torch.equal(got[i], net.forward_u8(batch[i]))
+
+
 def test_linear_resize_vs_oracle(dev):
     """linear_resize (utils.py:267-276, the pix2pix pre-step): srgb2linear -> bicubic to the next multiple of `st` -> linear2srgb against the
     oracle's restatement of OpenCV's INTER_CUBIC (unpinned against OpenCV itself, like color_fix); the truncating cast allows one code."""
