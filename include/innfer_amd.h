@@ -231,6 +231,11 @@ int innfer_wbc_forward(innfer_wbc_t u, const void* d_in, int in_dtype, void* d_o
 size_t innfer_guided_filter_workspace_bytes(int N, int C, int H, int W);
 int innfer_guided_filter(const void* d_x, const void* d_y, int dtype, int N, int C, int H, int W, float eps, void* d_out,
                          void* d_workspace, size_t workspace_bytes, void* stream);
+/* guided_filter with a ks x ks window (ks = 2 r + 1, odd) and, when d_x_hr is not null, its 'fast' mode (utils/utils.py:548-626): A and b of
+ * the [N,C,H,W] pair are enlarged to [N,C,Hh,Wh] (bilinear, align_corners=True) and applied to the high-resolution guidance d_x_hr; d_out then is
+ * [N,C,Hh,Wh].  Same workspace as innfer_guided_filter.  (104) */
+int innfer_guided_filter_ex(const void* d_x, const void* d_y, int dtype, int N, int C, int H, int W, int ks, float eps,
+                            const void* d_x_hr, int Hh, int Wh, void* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* -------------------------------------------------- single fused convolution
  * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution

@@ -163,6 +163,60 @@ __global__ void gf_out(const float* A, const float* B, const void* x, int f32, l
     if (f32) ((float*)out)[i] = v; else ((f16*)out)[i] = (f16)v;
 }
 
+// The same with a (2r+1)^2 window (ks = 2r + 1 of guided_filter, utils.py:584-590; box value float32(1 / ks^2), get_box_kernel :536-545)
+__global__ void gf_ab_r(const void* x, const void* y, int f32, long planes, int H, int W, int r, float k, float eps, float* A, float* B) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const long base = i - (long)Y * W - X;
+    float sx = 0.f, sy = 0.f, sxy = 0.f, sxx = 0.f, sn = 0.f;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const long o = base + (long)refl(Y + dy, H) * W + refl(X + dx, W);
+            const float xv = ld(x, o, f32), yv = ld(y, o, f32);
+            sx += xv * k; sy += yv * k; sxy += (xv * yv) * k; sxx += (xv * xv) * k; sn += k;
+        }
+    const float mx = sx / sn, my = sy / sn;
+    const float cov = sxy / sn - mx * my, var = sxx / sn - mx * mx;
+    const float a = cov / (var + eps);
+    A[i] = a;
+    B[i] = my - a * mx;
+}
+
+__global__ void gf_out_r(const float* A, const float* B, const void* x, int f32, long planes, int H, int W, int r, float k, void* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const long base = i - (long)Y * W - X;
+    float sa = 0.f, sb = 0.f, sn = 0.f;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const long o = base + (long)refl(Y + dy, H) * W + refl(X + dx, W);
+            sa += A[o] * k; sb += B[o] * k; sn += k;
+        }
+    const float v = (sa / sn) * ld(x, i, f32) + sb / sn;
+    if (f32) ((float*)out)[i] = v; else ((f16*)out)[i] = (f16)v;
+}
+
+// 'fast' mode (utils.py:611-619): A and b of the low-resolution pair are enlarged to x_HR's size (bilinear, align_corners=True) and applied there
+__global__ void gf_out_fast(const float* A, const float* B, const void* xhr, int f32, long planes, int H, int W, int Hh, int Wh, void* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Hh * Wh) return;
+    const int X = (int)(i % Wh), Y = (int)((i / Wh) % Hh);
+    const long pl = i / ((long)Hh * Wh);
+    const float sy = Hh > 1 ? (float)(H - 1) / (float)(Hh - 1) : 0.f, sx = Wh > 1 ? (float)(W - 1) / (float)(Wh - 1) : 0.f;
+    const float fy = sy * (float)Y, fx = sx * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* a = A + pl * H * W;
+    const float* b = B + pl * H * W;
+    const float ma = hy * (hx * a[(long)y0 * W + x0] + lx * a[(long)y0 * W + x1]) + ly * (hx * a[(long)y1 * W + x0] + lx * a[(long)y1 * W + x1]);
+    const float mb = hy * (hx * b[(long)y0 * W + x0] + lx * b[(long)y0 * W + x1]) + ly * (hx * b[(long)y1 * W + x0] + lx * b[(long)y1 * W + x1]);
+    const float v = ma * ld(xhr, i, f32) + mb;
+    if (f32) ((float*)out)[i] = v; else ((f16*)out)[i] = (f16)v;
+}
+
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; f16* d_w = nullptr; float* d_b = nullptr;
                void* d_w3 = nullptr; float* d_b3 = nullptr; };     // 3x3 layers: conv3x3.hip panels + bias (the stride-1 ones run there)
@@ -408,6 +462,31 @@ extern "C" int innfer_guided_filter(const void* d_x, const void* d_y, int dtype,
     const int f32 = dtype == INNFER_F32;
     hipLaunchKernelGGL(gf_ab, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_x, d_y, f32, (long)N * C, H, W, eps, A, B);
     hipLaunchKernelGGL(gf_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)A, (const float*)B, d_x, f32, (long)N * C, H, W, d_out);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_guided_filter_ex(const void* d_x, const void* d_y, int dtype, int N, int C, int H, int W, int ks, float eps,
+                                       const void* d_x_hr, int Hh, int Wh, void* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!d_x || !d_y || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "guided_filter: null argument");
+    if (ks < 1 || !(ks & 1)) return set_error(INNFER_ERR_UNSUPPORTED, "guided_filter: window size %d (odd sizes are built: ks = 2 r + 1)", ks);
+    const int r = ks / 2;
+    if (N <= 0 || C <= 0 || H <= r || W <= r) return set_error(INNFER_ERR_INVALID, "guided_filter: %dx%d image, window radius %d (reflect padding needs radius < size)", H, W, r);
+    if (d_x_hr && (Hh <= 0 || Wh <= 0)) return set_error(INNFER_ERR_INVALID, "guided_filter: bad high-resolution size");
+    if (ws_bytes < innfer_guided_filter_workspace_bytes(N, C, H, W)) return set_error(INNFER_ERR_WORKSPACE, "guided_filter: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)N * C * H * W;
+    float* A = (float*)d_ws;
+    float* B = (float*)((char*)d_ws + (((size_t)n * 4 + 255) & ~(size_t)255));
+    const int f32 = dtype == INNFER_F32;
+    const float k = (float)(1.0 / ((double)ks * (double)ks));
+    hipLaunchKernelGGL(gf_ab_r, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_x, d_y, f32, (long)N * C, H, W, r, k, eps, A, B);
+    if (d_x_hr) {
+        const long nh = (long)N * C * Hh * Wh;
+        hipLaunchKernelGGL(gf_out_fast, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, (const float*)A, (const float*)B, d_x_hr, f32, (long)N * C, H, W, Hh, Wh, d_out);
+    } else {
+        hipLaunchKernelGGL(gf_out_r, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)A, (const float*)B, d_x, f32, (long)N * C, H, W, r, k, d_out);
+    }
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }

@@ -302,27 +302,36 @@ def color_fix(imgA, imgB, device='cuda'):
 
 
 def guided_filter(x, y, x_HR=None, ks=None, r=None, eps=1e-2, box_kernel=None, mode='regular', conv_a=None):
-    """guided_filter (utils.py:548-626) in the form run.py uses after the WBC UNet (run.py:427-429):
-    'regular' mode, window radius 1 (3x3 box means, reflect padding); x guidance, y input, [B,C,H,W] GPU
-    tensors of one dtype.  Runs in libinnfer_amd.so (csrc/wbcunet.hip)."""
-    if mode != 'regular' or x_HR is not None or box_kernel is not None or conv_a is not None:
-        raise NotImplementedError("guided_filter: only mode='regular' without a precomputed kernel is built")
-    if ks is None:
+    """guided_filter (utils.py:548-626): 'regular' mode (what run.py:427-429 applies after the WBC UNet with r=1) and 'fast' mode (A, b of the
+    low-resolution pair enlarged bilinearly to the high-resolution guidance x_HR), any odd window ks = 2 r + 1 (box means, reflect padding);
+    x guidance, y input, [B,C,H,W] GPU tensors of one dtype.  Runs in libinnfer_amd.so (csrc/wbcunet.hip).  Not built: 'conv' mode (a caller's
+    nn.Sequential computes A), a precomputed box_kernel tensor, even window sizes."""
+    if mode not in ('regular', 'fast') or box_kernel is not None or conv_a is not None:
+        raise NotImplementedError("guided_filter: modes 'regular' and 'fast' without a precomputed kernel are built")
+    if not ks:
         if not r:
             raise ValueError("Either kernel size (ks) or radius (r) for the window are required.")
         ks = 2 * r + 1
-    if ks != 3:
-        raise NotImplementedError('guided_filter: only the 3x3 window (r=1) is built')
+    if int(ks) != ks or int(ks) % 2 == 0:
+        raise NotImplementedError(f'guided_filter: window size {ks} (odd sizes ks = 2 r + 1 are built)')
+    if mode == 'fast' and not isinstance(x_HR, torch.Tensor):
+        raise ValueError("guided_filter: mode 'fast' needs the high-resolution guidance x_HR")
     _need_cuda(x, 'guided_filter')
     if x.shape != y.shape or x.dtype != y.dtype or x.dim() != 4:
         raise ValueError('guided_filter: x and y must be [B,C,H,W] tensors of one shape and dtype')
     x, y = x.contiguous(), y.contiguous()
     B, Cc, H, W = x.shape
-    out = torch.empty_like(x)
+    hr = None
+    if mode == 'fast':
+        hr = x_HR.contiguous()
+        if hr.dim() != 4 or hr.shape[:2] != x.shape[:2] or hr.dtype != x.dtype or hr.device != x.device:
+            raise ValueError('guided_filter: x_HR must be a [B,C,Hh,Wh] tensor with the batch, channels, dtype and device of x')
+    out = torch.empty_like(hr if hr is not None else x)
     ws = torch.empty(L.lib.innfer_guided_filter_workspace_bytes(B, Cc, H, W), dtype=torch.uint8, device=x.device)
     with _on(x):
-        L.check(L.lib.innfer_guided_filter(x.data_ptr(), y.data_ptr(), _dt(x), B, Cc, H, W, float(eps), out.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), _stream(x)))
+        L.check(L.lib.innfer_guided_filter_ex(x.data_ptr(), y.data_ptr(), _dt(x), B, Cc, H, W, int(ks), float(eps),
+                                              hr.data_ptr() if hr is not None else None, hr.shape[2] if hr is not None else 0,
+                                              hr.shape[3] if hr is not None else 0, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x)))
     return out
 
 

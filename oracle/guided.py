@@ -21,3 +21,24 @@ def guided_filter(x, y, eps=5e-3):
     a = cov_xy / (var_x + eps)
     b = mean_y - a * mean_x
     return (box3(a) / n) * x + box3(b) / n
+
+
+def box(t, ks):
+    """filter2D(t, ones(ks,ks)/ks^2) for odd ks (utils.py:484-545): depthwise conv over a reflect-padded tensor."""
+    c, r = t.shape[1], ks // 2
+    k = torch.full((c, 1, ks, ks), 1.0, dtype=torch.float64).div(float(ks) * float(ks)).to(t.dtype)
+    return F.conv2d(F.pad(t, (r, r, r, r), mode="reflect"), k, groups=c)
+
+
+def guided_filter_ex(x, y, ks=3, eps=1e-2, x_hr=None):
+    """guided_filter(x, y, x_HR, ks=ks, eps=eps, mode='regular' | 'fast') (utils.py:548-626)."""
+    n = box(torch.ones((1, 1, x.shape[-2], x.shape[-1]), dtype=x.dtype), ks)
+    mean_x, mean_y = box(x, ks) / n, box(y, ks) / n
+    cov_xy = box(x * y, ks) / n - mean_x * mean_y
+    var_x = box(x * x, ks) / n - mean_x * mean_x
+    a = cov_xy / (var_x + eps)
+    b = mean_y - a * mean_x
+    if x_hr is not None:                                   # 'fast' (:611-619)
+        size = (x_hr.shape[-2], x_hr.shape[-1])
+        return F.interpolate(a, size, mode="bilinear", align_corners=True) * x_hr + F.interpolate(b, size, mode="bilinear", align_corners=True)
+    return (box(a, ks) / n) * x + box(b, ks) / n

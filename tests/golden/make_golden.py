@@ -348,6 +348,16 @@ def g20():
     save("g20_cli", table=np.array(json.dumps({"names": names, "scales": scales, "with_arg": with_arg, "extras": extras, "crops": crops, "chain": chain})))
 
 
+def g21():
+    """guided_filter beyond r = 1 / 'regular' (utils.py:548-626): a 5x5 and a 7x7 window, and the 'fast' mode on a 2x guidance image."""
+    x = torch.from_numpy(synth.uniform((2, 3, 23, 31), 211))
+    y = torch.from_numpy(synth.uniform((2, 3, 23, 31), 212))
+    xh = torch.from_numpy(synth.uniform((2, 3, 46, 62), 213))
+    save("g21_guided", r2=ref_utils.guided_filter(x, y, r=2, eps=5e-3).numpy(), ks7=ref_utils.guided_filter(x, y, ks=7, eps=1e-2).numpy(),
+         fast=ref_utils.guided_filter(x, y, x_HR=xh, r=1, eps=5e-3, mode='fast').numpy(),
+         fast_r2=ref_utils.guided_filter(x, y, x_HR=xh, r=2, eps=1e-2, mode='fast').numpy())
+
+
 # ----------------------------------------------------------------- G10 loader
 def g10():
     tmp = tempfile.mkdtemp()
@@ -509,6 +519,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     for g in which:
         globals()[g]()

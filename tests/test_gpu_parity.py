@@ -719,6 +719,26 @@ def test_image_in_image_out_equals_the_separate_passes(dev, tmp_path, chop):
         assert torch.equal(got[i], net.forward_u8(batch[i]))
 
 
+def test_guided_filter_windows_and_fast_mode_golden(dev, golden):
+    """guided_filter(r=2), (ks=7) and mode='fast' with a 2x guidance image (utils.py:548-626) against the reference (golden G21)."""
+    from innfer_amd.utils import utils as U
+    from test_oracle_golden import _guided_cases
+    g = golden("g21_guided")
+    x, y, xh, cases = _guided_cases()
+    x, y, xh = x.to(dev), y.to(dev), xh.to(dev)
+    for tag, kw in cases.items():
+        args = dict(ks=kw["ks"], eps=kw["eps"])
+        if kw.get("hr"):
+            args.update(x_HR=xh, mode="fast")
+        got = U.guided_filter(x, y, **args).cpu().numpy()
+        assert got.shape == g[tag].shape and np.abs(got - g[tag]).max() < 5e-5, (tag, np.abs(got - g[tag]).max())
+    assert torch.equal(U.guided_filter(x, y, r=1, eps=5e-3), U.guided_filter(x, y, ks=3, eps=5e-3))
+    with pytest.raises(NotImplementedError):
+        U.guided_filter(x, y, ks=4)
+    with pytest.raises(ValueError):
+        U.guided_filter(x, y, r=1, mode="fast")
+
+
 def test_linear_resize_vs_oracle(dev):
     """linear_resize (utils.py:267-276, the pix2pix pre-step): srgb2linear -> bicubic to the next multiple of `st` -> linear2srgb against the
     oracle's restatement of OpenCV's INTER_CUBIC (unpinned against OpenCV itself, like color_fix); the truncating cast allows one code."""

@@ -266,6 +266,23 @@ def test_g19_convert_flags(golden):
         assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), name
 
 
+def _guided_cases():
+    x = torch.from_numpy(synth.uniform((2, 3, 23, 31), 211))
+    y = torch.from_numpy(synth.uniform((2, 3, 23, 31), 212))
+    xh = torch.from_numpy(synth.uniform((2, 3, 46, 62), 213))
+    return x, y, xh, {"r2": dict(ks=5, eps=5e-3), "ks7": dict(ks=7, eps=1e-2), "fast": dict(ks=3, eps=5e-3, hr=True), "fast_r2": dict(ks=5, eps=1e-2, hr=True)}
+
+
+def test_g21_guided_filter_windows_and_fast_mode(golden):
+    """guided_filter with 5x5 / 7x7 windows and in 'fast' mode (utils.py:548-626) against the reference."""
+    from oracle.guided import guided_filter_ex
+    g = golden("g21_guided")
+    x, y, xh, cases = _guided_cases()
+    for tag, kw in cases.items():
+        got = guided_filter_ex(x, y, ks=kw["ks"], eps=kw["eps"], x_hr=xh if kw.get("hr") else None).numpy()
+        assert got.shape == g[tag].shape and np.abs(got - g[tag]).max() < 2e-5, tag
+
+
 def test_g16_mrrdbnet(golden):
     """MRRDBNet (new-arch ESRGAN built directly, RRDBNet_arch.py:173-231) on its own key names."""
     g = golden("g16_mrrdb")
