@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_resnet_create_ex, innfer_guided_filter_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -205,6 +205,10 @@ int innfer_ppon_forward(innfer_ppon_t p, const void* d_in, int in_dtype, void* d
  */
 typedef struct innfer_resnet* innfer_resnet_t;
 int innfer_resnet_create(innfer_resnet_t* out, int in_nc, int out_nc, int ngf, int n_blocks);
+/* The same with ResnetBlock's constructor arguments (ResNet_arch.py:104-146): padding 0 reflect / 1 replicate / 2 zero (the pad layer in front of
+ * the two 3x3 convs of every block; the parameter indices inside `conv_block` follow), use_dropout != 0 = an nn.Dropout(0.5) behind the first
+ * conv + norm + ReLU (identity in eval mode -- how run.py runs these generators -- but it shifts the second conv's index).  (104) */
+int innfer_resnet_create_ex(innfer_resnet_t* out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout);
 void innfer_resnet_destroy(innfer_resnet_t r);
 int innfer_resnet_num_params(innfer_resnet_t r);
 int innfer_resnet_param_info(innfer_resnet_t r, int idx, char* key, size_t key_cap, int* ndim, int* shape4);

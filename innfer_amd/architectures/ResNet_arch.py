@@ -4,6 +4,8 @@ model.<17+n>), forward runs in libinnfer_amd.so (csrc/resnet.hip).  Built: the c
 utils/defaults.py:124-140 produces (instance norm, reflect padding, deconv upsampling, no dropout)."""
 from .param_module import ParamEngineModule
 
+_PADDING = {'reflect': 0, 'replicate': 1, 'zero': 2}          # innfer_resnet_create_ex codes
+
 
 class ResnetGenerator(ParamEngineModule):
     _api = 'resnet'
@@ -11,10 +13,21 @@ class ResnetGenerator(ParamEngineModule):
     def __init__(self, input_nc, output_nc, ngf=64, norm_type="instance", use_dropout=False, n_blocks=6,
                  padding_type='reflect', upsample_mode="deconv"):
         super().__init__()
-        if norm_type not in ('IN', 'instance') or use_dropout or padding_type != 'reflect' or upsample_mode != 'deconv':
-            raise NotImplementedError('ResnetGenerator: only norm=instance, padding=reflect, deconv, no dropout is built')
+        if padding_type not in _PADDING:                       # the reference's own error (ResNet_arch.py:128)
+            raise NotImplementedError('padding {} is not implemented'.format(padding_type))
+        if norm_type not in ('IN', 'instance') or upsample_mode != 'deconv':
+            raise NotImplementedError('ResnetGenerator: norm=instance and deconv upsampling are built')
         self.input_nc, self.output_nc, self.ngf, self.n_blocks = input_nc, output_nc, ngf, n_blocks
-        self._init_engine(input_nc, output_nc, ngf, n_blocks)
+        self.padding_type, self.use_dropout = padding_type, bool(use_dropout)
+        self._init_engine(input_nc, output_nc, ngf, n_blocks, _PADDING[padding_type], int(self.use_dropout))
+
+    def _fn(self, name):
+        return super()._fn('create_ex' if name == 'create' else name)
+
+    def forward(self, x):
+        if self.use_dropout and self.training:
+            raise NotImplementedError('ResnetGenerator(use_dropout=True) in train mode draws random masks; the engine runs the eval-mode graph (net.eval())')
+        return super().forward(x)
 
     def _out_shape(self, N, H, W):
         return (N, self.output_nc, H, W)

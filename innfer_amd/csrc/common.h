@@ -61,7 +61,8 @@ struct ConvLaunch {
                                                   // conv_pack(K=32) back to back, bias[32*G]): PPON's eight dilated convs in one launch
     int dilation;                                 // > 1: dilated 3x3 conv, zero padding = dilation (PPON); 32-output slab convs only
     int conv7;                                    // 7x7 conv, padding 3 (zero or `reflect`), panels from conv_pack7x7: OUT_NCHW, K <= 16 only
-    int reflect;                                  // ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel)
+    int reflect;                                  // 1: ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel);
+                                                  // 2: ReplicationPad2d(1) (3x3 slab convs)
     int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)
     int out_u8, out_denorm, out_round16;          // OUT_NCHW with <= 4 channels: write a uint8 HWC BGR(A) image instead -- tensor2np as the conv's epilogue
                                                   // (utils.py:197-248): [round to fp16,] optional denormalisation, clip(255 x).round() half to even, channel flip

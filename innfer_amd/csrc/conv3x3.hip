@@ -771,8 +771,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                     if (Y < 0 || Y >= p.H || X < 0 || X >= p.W) {
                         // reflection padding: the ring of pixels one step outside the image mirrors the pixel one step inside; farther
                         // out (tile padding of a ragged frame) only feeds outputs that are never stored
+                        // (reflect 2 = nn.ReplicationPad2d(1): the ring repeats the border pixel)
                         if (p.reflect && loff[k] != OOB && Y >= -1 && Y <= p.H && X >= -1 && X <= p.W) {
-                            const int Yr = Y < 0 ? 1 : (Y >= p.H ? p.H - 2 : Y), Xr = X < 0 ? 1 : (X >= p.W ? p.W - 2 : X);
+                            const int in1 = p.reflect == 2 ? 0 : 1, in2 = p.reflect == 2 ? 1 : 2;
+                            const int Yr = Y < 0 ? in1 : (Y >= p.H ? p.H - in2 : Y), Xr = X < 0 ? in1 : (X >= p.W ? p.W - in2 : X);
                             voff[k] = loff[k] + ((Yr - Y) * p.Ws + (Xr - X)) * 64;
                         } else {
                             voff[k] = OOB;
@@ -1348,8 +1350,10 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.out_u8 = L.out_u8; k.out_denorm = L.out_denorm; k.out_round16 = L.out_round16;
     k.rev = L.rev ? 1 : 0;
     k.phase_c = L.out_mode == OUT_NCHW ? L.phase_c : 0;
-    k.reflect = L.reflect ? 1 : 0;
-    if (L.reflect && (L.up || L.H < (L.conv7 ? 4 : 2) || L.W < (L.conv7 ? 4 : 2))) return set_error(INNFER_ERR_INVALID, "conv3x3: reflection padding needs >= 2x2 pixels and no upsampled input");
+    k.reflect = L.reflect == 2 ? 2 : (L.reflect ? 1 : 0);
+    if (L.reflect == 2 && (L.conv7 || L.out_mode != OUT_SLAB)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: replication padding is built for 3x3 slab convs");
+    if (L.reflect && (L.up || L.H < (L.conv7 ? 4 : (L.reflect == 2 ? 1 : 2)) || L.W < (L.conv7 ? 4 : (L.reflect == 2 ? 1 : 2))))
+        return set_error(INNFER_ERR_INVALID, "conv3x3: reflection padding needs >= 2x2 pixels and no upsampled input");
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: K=%d must be a multiple of %d for slab output", L.K, 16 * nt);

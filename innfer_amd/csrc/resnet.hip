@@ -135,6 +135,7 @@ struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; bool transposed = f
 
 struct innfer_resnet {
     int in_nc = 3, out_nc = 3, ngf = 64, n_blocks = 9;
+    int block_pad = 1;               // padding of the residual blocks' convs as a ConvLaunch.reflect code: 1 reflect, 2 replicate, 0 zero
     std::vector<Param> params;
     std::vector<Layer> layers;       // first, down1, down2, 2*n_blocks block convs, up1, up2, last
     bool uploaded = false;
@@ -154,18 +155,27 @@ static void add_layer(innfer_resnet* r, const std::string& key, int cin, int cou
 }
 
 extern "C" int innfer_resnet_create(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks) {
+    return innfer_resnet_create_ex(out, in_nc, out_nc, ngf, n_blocks, 0, 0);
+}
+
+extern "C" int innfer_resnet_create_ex(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout) {
     if (!out) return set_error(INNFER_ERR_INVALID, "resnet_create: null out");
+    if (padding < 0 || padding > 2) return set_error(INNFER_ERR_INVALID, "resnet_create: padding %d (0 reflect, 1 replicate, 2 zero)", padding);
     if (ngf != 64 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || n_blocks < 0 || n_blocks > 64)
         return set_error(INNFER_ERR_UNSUPPORTED, "resnet_create: ngf=%d n_blocks=%d (built: ngf 64)", ngf, n_blocks);
     innfer_resnet* r = new innfer_resnet();
     r->in_nc = in_nc; r->out_nc = out_nc; r->ngf = ngf; r->n_blocks = n_blocks;
+    r->block_pad = padding == 0 ? 1 : (padding == 1 ? 2 : 0);        // ConvLaunch.reflect code of the residual blocks' convs
+    // ResnetBlock.conv_block (ResNet_arch.py:118-146): [pad] conv norm relu [dropout] [pad] conv norm -- a pad layer for reflect / replicate only,
+    // nn.Dropout(0.5) (identity in eval mode, which is how run.py runs CycleGAN generators: cyglegan_extras) when use_dropout
+    const int c1 = padding == 2 ? 0 : 1, c2 = c1 + 3 + (use_dropout ? 1 : 0) + (padding == 2 ? 0 : 1);
     add_layer(r, "model.1", in_nc, ngf, 7, false);
     add_layer(r, "model.4", ngf, 2 * ngf, 3, false);
     add_layer(r, "model.7", 2 * ngf, 4 * ngf, 3, false);
     for (int i = 0; i < n_blocks; ++i) {
         const std::string b = "model." + std::to_string(10 + i) + ".conv_block.";
-        add_layer(r, b + "1", 4 * ngf, 4 * ngf, 3, false);
-        add_layer(r, b + "5", 4 * ngf, 4 * ngf, 3, false);
+        add_layer(r, b + std::to_string(c1), 4 * ngf, 4 * ngf, 3, false);
+        add_layer(r, b + std::to_string(c2), 4 * ngf, 4 * ngf, 3, false);
     }
     const int i = 10 + n_blocks;
     add_layer(r, "model." + std::to_string(i), 4 * ngf, 2 * ngf, 3, true);
@@ -360,7 +370,11 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     // ResnetBlock conv: reflection-padded 3x3 on the halo-tile kernel (fp16 slab out, bias included), statistics and normalisation on
     // that slab -- the conv output is rounded to fp16 before the instance norm, as in the reference's own fp16 mode
     auto block_conv = [&](const Layer& l, const f16* in, int Hc, int Wc, int relu, const f16* res, f16* dst) -> int {
-        if (!l.d_w3) { CK(conv(l, in, Hc, Wc, Hc, Wc, 1, 1)); return norm_post(l, Hc, Wc, relu, res, dst); }
+        if (!l.d_w3) {
+            if (r->block_pad == 2) return set_error(INNFER_ERR_UNSUPPORTED, "resnet: replication padding needs the halo-tile conv (channels %% 64 == 0)");
+            CK(conv(l, in, Hc, Wc, Hc, Wc, 1, r->block_pad));
+            return norm_post(l, Hc, Wc, relu, res, dst);
+        }
         const long HW = (long)Hc * Wc, G = (long)N * HW * 32;
         f16* Y = (f16*)raw;                                           // the fp32 GEMM buffer is free here
         ConvLaunch L{};
@@ -368,7 +382,7 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.wpk = (const f16*)l.d_w3; L.bias = l.d_b;
         L.out = Y; L.out_gstride = G; L.K = l.cout;
         L.N = N; L.H = Hc; L.W = Wc; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Hc;
-        L.out_mode = OUT_SLAB; L.reflect = 1;
+        L.out_mode = OUT_SLAB; L.reflect = r->block_pad;
         CK(conv_launch(L, s));
         CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
         const long total = (long)N * HW * (l.cout / 8);

@@ -281,7 +281,7 @@ def ppon_forward(sd, x, nb=24, scale=4, alpha=1.0):
     return out_c, out_s, out_p
 
 
-def resnet_forward(sd, x, n_blocks=9, eps=1e-5):
+def resnet_forward(sd, x, n_blocks=9, eps=1e-5, padding_type="reflect", use_dropout=False):
     """ResnetGenerator(norm=instance, padding=reflect, upsample=deconv).forward (ResNet_arch.py:19-86) with
     ResnetBlock (:89-151): c7s1-64, two stride-2 convs, n_blocks reflect-padded residual blocks, two
     ConvTranspose2d(3, s2, p1, op1), c7s1-out, tanh.  InstanceNorm2d has no affine parameters and always
@@ -295,9 +295,14 @@ def resnet_forward(sd, x, n_blocks=9, eps=1e-5):
     t = F.relu(inorm(conv(F.pad(x, (3, 3, 3, 3), mode="reflect"), "model.1")))
     t = F.relu(inorm(conv(t, "model.4", stride=2, padding=1)))
     t = F.relu(inorm(conv(t, "model.7", stride=2, padding=1)))
+    # ResnetBlock.conv_block (:118-146): [pad] conv norm relu [dropout: identity in eval mode] [pad] conv norm; 'zero' pads inside the conv
+    pad_layer = padding_type != "zero"
+    c1 = 1 if pad_layer else 0
+    c2 = c1 + 3 + (1 if use_dropout else 0) + (1 if pad_layer else 0)
+    mode = {"reflect": "reflect", "replicate": "replicate", "zero": "constant"}[padding_type]
     for i in range(10, 10 + n_blocks):
-        r = F.relu(inorm(conv(F.pad(t, (1, 1, 1, 1), mode="reflect"), f"model.{i}.conv_block.1")))
-        r = inorm(conv(F.pad(r, (1, 1, 1, 1), mode="reflect"), f"model.{i}.conv_block.5"))
+        r = F.relu(inorm(conv(F.pad(t, (1, 1, 1, 1), mode=mode), f"model.{i}.conv_block.{c1}")))
+        r = inorm(conv(F.pad(r, (1, 1, 1, 1), mode=mode), f"model.{i}.conv_block.{c2}"))
         t = t + r
     i = 10 + n_blocks
     for k in (i, i + 3):

@@ -358,6 +358,24 @@ def g21():
          fast_r2=ref_utils.guided_filter(x, y, x_HR=xh, r=2, eps=1e-2, mode='fast').numpy())
 
 
+def g22():
+    """ResnetGenerator(padding_type='zero' / 'replicate', use_dropout=True) in eval mode (ResNet_arch.py:20-146), 2 blocks, 32x40 input."""
+    from architectures.ResNet_arch import ResnetGenerator as RefResnet
+    out = {}
+    for i, (tag, kw) in enumerate({"zero": dict(padding_type="zero"), "replicate": dict(padding_type="replicate"),
+                                   "reflect_dropout": dict(padding_type="reflect", use_dropout=True),
+                                   "zero_dropout": dict(padding_type="zero", use_dropout=True)}.items()):
+        net = RefResnet(3, 3, 64, norm_type="instance", n_blocks=2, **kw).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict(t_sd(synth.fill_state_dict(shapes, 220 + i)), strict=True)
+        x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0))
+        with torch.no_grad():
+            out[tag] = net(x).numpy()
+        out[tag + "_keys"] = np.array(list(shapes.keys()))
+        out[tag + "_shapes"] = np.array([str(shapes[k]) for k in shapes])
+    save("g22_resnet_variants", **out)
+
+
 # ----------------------------------------------------------------- G10 loader
 def g10():
     tmp = tempfile.mkdtemp()
@@ -519,6 +537,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     for g in which:
         globals()[g]()

@@ -855,6 +855,31 @@ def test_cyclegan_resnet9_golden(dev, golden):
         net(torch.zeros(1, 3, 30, 40, device=dev))                      # not a multiple of 4
 
 
+def test_cyclegan_resnet_padding_and_dropout_variants_golden(dev, golden):
+    """ResnetGenerator(padding_type='zero' / 'replicate', use_dropout=True) in eval mode (ResNet_arch.py:104-146) against the reference (G22):
+    same parameter names (the conv indices inside `conv_block` move with the pad and dropout layers), outputs within the CycleGAN tolerance."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures.ResNet_arch import ResnetGenerator
+    from test_oracle_golden import G22_CASES
+    g = golden("g22_resnet_variants")
+    for i, (tag, kw) in enumerate(G22_CASES.items()):
+        shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[tag + "_keys"], g[tag + "_shapes"])}
+        net = ResnetGenerator(3, 3, 64, norm_type="instance", n_blocks=2, **kw)
+        assert list(net.state_dict()) == [str(k) for k in g[tag + "_keys"]]
+        net.load_state_dict(_sd(shapes, 220 + i), strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0)).to(dev)
+        for xin in (x, x.half()):
+            err = np.abs(net(xin).float().cpu().numpy() - g[tag])
+            assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
+    with pytest.raises(NotImplementedError):
+        ResnetGenerator(3, 3, 64, norm_type="instance", padding_type="circular")
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(x)                                   # use_dropout=True in train mode is random: refused
+
+
 def test_wbcunet_and_guided_filter_golden(dev, golden):
     """White-box-Cartoonization UNet + the guided filter run.py applies to its output
     against the reference (golden G15).  No norm layers: fp16 slabs, tolerance 5e-3 on outputs of O(0.2)."""

@@ -283,6 +283,22 @@ def test_g21_guided_filter_windows_and_fast_mode(golden):
         assert got.shape == g[tag].shape and np.abs(got - g[tag]).max() < 2e-5, tag
 
 
+G22_CASES = {"zero": dict(padding_type="zero"), "replicate": dict(padding_type="replicate"),
+             "reflect_dropout": dict(padding_type="reflect", use_dropout=True), "zero_dropout": dict(padding_type="zero", use_dropout=True)}
+
+
+def test_g22_resnet_padding_and_dropout_variants(golden):
+    """ResnetGenerator(padding_type=zero / replicate, use_dropout=True) in eval mode (ResNet_arch.py:104-146) against the reference."""
+    import ast
+    g = golden("g22_resnet_variants")
+    for i, (tag, kw) in enumerate(G22_CASES.items()):
+        shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[tag + "_keys"], g[tag + "_shapes"])}
+        x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0))
+        with torch.no_grad():
+            y = oracle.resnet_forward(_sd(shapes, 220 + i), x, n_blocks=2, **kw).numpy()
+        assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-5, tag
+
+
 def test_g16_mrrdbnet(golden):
     """MRRDBNet (new-arch ESRGAN built directly, RRDBNet_arch.py:173-231) on its own key names."""
     g = golden("g16_mrrdb")
