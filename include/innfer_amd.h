@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_resnet_create_ex, innfer_guided_filter_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_guided_filter_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -142,6 +142,10 @@ double innfer_net_flops(innfer_net_t net, int N, int H, int W);
  */
 typedef struct innfer_unet* innfer_unet_t;
 int innfer_unet_create(innfer_unet_t* out, int in_nc, int out_nc, int num_downs, int ngf);
+/* The same with norm_type 'instance' (UNet_arch.py:38-41,101-104): nn.InstanceNorm2d layers (no parameters, no running statistics: always the
+ * statistics of the image, train() and eval() alike) and a bias on every conv (it only matters where no norm follows: the outermost and the
+ * innermost down conv, the outermost up conv).  innfer_unet_create(...) = innfer_unet_create_ex(..., 0).  (104) */
+int innfer_unet_create_ex(innfer_unet_t* out, int in_nc, int out_nc, int num_downs, int ngf, int instance_norm);
 void innfer_unet_destroy(innfer_unet_t u);
 int innfer_unet_num_params(innfer_unet_t u);
 int innfer_unet_param_info(innfer_unet_t u, int idx, char* key, size_t key_cap, int* ndim, int* shape4);

@@ -13,15 +13,25 @@ class UnetGenerator(ParamEngineModule):
     def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm_type="batch", use_dropout=False,
                  upsample_mode="deconv"):
         super().__init__()
-        if norm_type not in ('BN', 'batch') or use_dropout or upsample_mode != 'deconv':
-            raise NotImplementedError('UnetGenerator: only norm=batch, no dropout, deconv is built on the HIP path')
+        if norm_type not in ('BN', 'batch', 'IN', 'instance'):           # the reference's own error (UNet_arch.py:42-43)
+            raise NameError("Unknown norm layer")
+        if upsample_mode != 'deconv':
+            raise NotImplementedError("UnetGenerator: upsample_mode='deconv' is built on the HIP path")
         self.input_nc, self.output_nc, self.num_downs, self.ngf = input_nc, output_nc, num_downs, ngf
-        self._init_engine(input_nc, output_nc, num_downs, ngf)
+        self.instance_norm = norm_type in ('IN', 'instance')
+        # use_dropout: nn.Dropout(0.5) at the end of the ngf*8 blocks (UNet_arch.py:153-154) -- no parameters; the identity under eval()
+        self.use_dropout = bool(use_dropout)
+        self._init_engine(input_nc, output_nc, num_downs, ngf, int(self.instance_norm))
+
+    def _fn(self, name):
+        return super()._fn('create_ex' if name == 'create' else name)
 
     def _out_shape(self, N, H, W):
         return (N, self.output_nc, H, W)
 
     def forward(self, x):
+        if self.use_dropout and self.training:
+            raise NotImplementedError('UnetGenerator(use_dropout=True) in train mode draws random masks; the engine runs the eval-mode graph (net.eval())')
         L.check(L.lib.innfer_unet_set_eval(self._handle, int(not self.training)))
         return super().forward(x)
 

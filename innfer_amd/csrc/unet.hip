@@ -199,6 +199,8 @@ struct Layer {            // one conv / conv-transpose
     void* d_w3 = nullptr; float* d_b3 = nullptr;           // `phases` layer: conv3x3.hip panels [4*cout][cin][3][3] and the bias repeated per phase
     float *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
     float *d_ev_alpha = nullptr, *d_ev_shift = nullptr;    // eval-mode BatchNorm: weight / sqrt(running_var + eps), bias - running_mean * that
+    float* d_ones = nullptr;                               // instance-norm nets: the unit scale beside d_bias of a conv that no norm layer follows
+    bool normed = false;                                   // a norm layer follows this conv
 };
 
 }  // namespace
@@ -210,6 +212,8 @@ struct innfer_unet {
     std::vector<int> dc;               // down-path channels per level
     bool uploaded = false;
     bool eval_mode = false;            // BatchNorm on running statistics (nn.Module.eval()) instead of the current image's
+    bool instance_norm = false;        // norm_type 'instance' (UNet_arch.py:38-41): nn.InstanceNorm2d -- no parameters, no running statistics, always the
+                                       // statistics of the image; every conv then has a bias (use_bias, :101-104), which only matters where no norm follows
 };
 
 static int add_param(innfer_unet* u, const std::string& key, std::vector<int> shape) {
@@ -219,11 +223,17 @@ static int add_param(innfer_unet* u, const std::string& key, std::vector<int> sh
 }
 
 extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int num_downs, int ngf) {
+    return innfer_unet_create_ex(out, in_nc, out_nc, num_downs, ngf, 0);
+}
+
+extern "C" int innfer_unet_create_ex(innfer_unet** out, int in_nc, int out_nc, int num_downs, int ngf, int instance_norm) {
     if (!out) return set_error(INNFER_ERR_INVALID, "unet_create: null out");
     if (num_downs < 5 || num_downs > 9 || ngf % 32 || ngf <= 0 || in_nc < 1 || in_nc > 32 || out_nc < 1 || out_nc > 32)
         return set_error(INNFER_ERR_UNSUPPORTED, "unet_create: in_nc=%d out_nc=%d num_downs=%d ngf=%d", in_nc, out_nc, num_downs, ngf);
     innfer_unet* u = new innfer_unet();
     u->in_nc = in_nc; u->out_nc = out_nc; u->num_downs = num_downs; u->ngf = ngf;
+    u->instance_norm = instance_norm != 0;
+    const bool in_ = u->instance_norm;
     const int L = num_downs;
     u->dc.resize(L);
     for (int k = 0; k < L; ++k) u->dc[k] = ngf * (k < 3 ? (1 << k) : 8);      // 64,128,256,512,512,...
@@ -235,11 +245,14 @@ extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int 
         d.cin = outer ? in_nc : u->dc[k - 1]; d.cout = u->dc[k];
         p.transposed = true;
         p.cin = inner ? u->dc[k] : 2 * u->dc[k]; p.cout = outer ? out_nc : u->dc[k - 1];
+        d.normed = !outer && !inner;
         if (outer) {
             d.w = add_param(u, blk + "0.weight", {d.cout, d.cin, 4, 4});
+            if (in_) d.bias = add_param(u, blk + "0.bias", {d.cout});
         } else {
             d.w = add_param(u, blk + "1.weight", {d.cout, d.cin, 4, 4});
-            if (!inner) {
+            if (in_) d.bias = add_param(u, blk + "1.bias", {d.cout});
+            if (!inner && !in_) {
                 d.gamma = add_param(u, blk + "2.weight", {d.cout});
                 d.beta = add_param(u, blk + "2.bias", {d.cout});
                 d.rmean = add_param(u, blk + "2.running_mean", {d.cout});
@@ -266,8 +279,11 @@ extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int 
         const bool outer = k == 0, inner = k == L - 1;
         const std::string wi = outer ? "3" : (inner ? "3" : "5"), ni = inner ? "4" : "6";
         p.w = add_param(u, b + wi + ".weight", {p.cin, p.cout, 4, 4});
+        p.normed = !outer;
         if (outer) {
             p.bias = add_param(u, b + wi + ".bias", {p.cout});
+        } else if (in_) {
+            p.bias = add_param(u, b + wi + ".bias", {p.cout});          // in front of an InstanceNorm2d: cancels in the mean subtraction, kept for the state dict
         } else {
             p.gamma = add_param(u, b + ni + ".weight", {p.cout});
             p.beta = add_param(u, b + ni + ".bias", {p.cout});
@@ -292,6 +308,7 @@ extern "C" void innfer_unet_destroy(innfer_unet* u) {
             if (l.d_beta) (void)hipFree(l.d_beta);
             if (l.d_ev_alpha) (void)hipFree(l.d_ev_alpha);
             if (l.d_ev_shift) (void)hipFree(l.d_ev_shift);
+            if (l.d_ones) (void)hipFree(l.d_ones);
         }
     delete u;
 }
@@ -359,6 +376,7 @@ static int upload_all(innfer_unet* u) {
                 int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
                 if (l.cout % 64 == 0) {        // ... and as a one-tap panel for the halo-tile kernel, whose epilogue writes the fp16 slabs directly
                     std::vector<float> w1((size_t)l.cout * 64, 0.f), b3((size_t)l.cout, 0.f);
+                    if (l.bias >= 0) b3 = u->params[l.bias].host;          // instance-norm nets: the outermost down conv has a bias and no norm
                     for (int co = 0; co < l.cout; ++co)
                         for (int j = 0; j < 16 * l.cin; ++j) {
                             const int t = j / l.cin, ci = j - t * l.cin;
@@ -412,6 +430,11 @@ static int upload_all(innfer_unet* u) {
             if (l.bias >= 0) { int rc = upload_f32(&l.d_bias, u->params[l.bias].host); if (rc) return rc; }
             if (l.gamma >= 0) { int rc = upload_f32(&l.d_gamma, u->params[l.gamma].host); if (rc) return rc; }
             if (l.beta >= 0) { int rc = upload_f32(&l.d_beta, u->params[l.beta].host); if (rc) return rc; }
+            if (u->instance_norm) {            // InstanceNorm2d(affine=False): unit scale, zero shift on the statistics of the image
+                const std::vector<float> ones((size_t)l.cout, 1.f), zeros((size_t)l.cout, 0.f);
+                int rc = upload_f32(&l.d_ones, ones); if (rc) return rc;
+                if (l.normed) { rc = upload_f32(&l.d_gamma, ones); if (rc) return rc; rc = upload_f32(&l.d_beta, zeros); if (rc) return rc; }
+            }
             if (l.gamma >= 0) {
                 // eval-mode transform as ATen forms it (batch_norm_cpu_transform_input: alpha = weight / sqrt(running_var + eps),
                 // beta = bias - running_mean * alpha); a checkpoint without running statistics means a fresh BatchNorm's (0, 1)
@@ -498,9 +521,9 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     const int L = u->num_downs;
     if (N <= 0 || H <= 0 || W <= 0 || (H & ((1 << L) - 1)) || (W & ((1 << L) - 1)))
         return set_error(INNFER_ERR_INVALID, "unet_forward: %dx%d must be a multiple of %d", H, W, 1 << L);
-    const bool ev = u->eval_mode;
+    const bool ev = u->eval_mode && !u->instance_norm;            // InstanceNorm2d keeps no running statistics: eval() changes nothing
     if (!ev && (H >> (L - 1)) * (W >> (L - 1)) < 2)
-        return set_error(INNFER_ERR_INVALID, "unet_forward: BatchNorm needs more than one value per channel");
+        return set_error(INNFER_ERR_INVALID, "unet_forward: the norm layers need more than one value per channel");
     if (!u->uploaded) { int rc = upload_all(u); if (rc) return rc; }
     const UCarve cv = ucarve(u, N, H, W);
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "unet_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
@@ -516,10 +539,12 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
 
     int ks_last = 1;                  // segments the last GEMM left in `splitk` (1: its result is in raw)
     auto post = [&](const Layer& l, long HW, bool bn, PostDst d0, PostDst d1) -> int {
+        // a conv that no norm layer follows but that has a bias (instance-norm nets: outermost / innermost down conv): y = 1 * x + bias
+        const bool nb = !bn && !l.transposed && l.d_bias && l.d_ones;
         if (HW <= DEEP_PX) {          // deep level: reduce + statistics + post in one launch
             hipLaunchKernelGGL(unet_deep_post, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw,
                                (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn && !ev ? l.d_gamma : nullptr, bn && !ev ? l.d_beta : nullptr,
-                               bn && ev ? l.d_ev_alpha : nullptr, bn && ev ? l.d_ev_shift : nullptr, d0, d1);
+                               bn && ev ? l.d_ev_alpha : (nb ? l.d_ones : nullptr), bn && ev ? l.d_ev_shift : (nb ? l.d_bias : nullptr), d0, d1);
             INNFER_HIP(hipGetLastError());
             return INNFER_OK;
         }
@@ -529,7 +554,8 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(unet_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
-                           bn ? (ev ? l.d_ev_alpha : mean) : nullptr, bn ? (ev ? l.d_ev_shift : rstd) : nullptr, ev ? 0 : l.cout, d0, d1);
+                           bn ? (ev ? l.d_ev_alpha : mean) : (nb ? l.d_ones : nullptr), bn ? (ev ? l.d_ev_shift : rstd) : (nb ? l.d_bias : nullptr),
+                           (bn && !ev) ? l.cout : 0, d0, d1);
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     };

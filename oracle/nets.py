@@ -128,14 +128,18 @@ def srresnet_forward(sd, x, nb=16, scale=4):
     return _conv3(sd, f"model.{idx + 2}", t)
 
 
-def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True):
+def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True, norm_type="batch"):
     """UnetGenerator(norm=batch, deconv).forward.  training=True: BatchNorm in TRAINING mode
     (batch statistics), as run.py runs pix2pix (meval=False, run.py:299-303); training=False:
     eval mode on the checkpoint's running statistics (Model's default meval=True, run.py:96-97).
     UNet_arch.py:107-161.  x: [N,3,256,256]; training-mode statistics are over the batch
     given (callers loop batch-1 for the per-image semantics of SURVEY D6)."""
 
+    # norm_type 'instance' (UNet_arch.py:38-41): nn.InstanceNorm2d -- no parameters, always the statistics of the image; the convs then have
+    # biases (use_bias, :101-104), read with sd.get below
     def bn(t, key):
+        if norm_type in ("IN", "instance"):
+            return F.instance_norm(t, eps=eps)
         if not training:
             return F.batch_norm(t, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"],
                                 training=False, momentum=0.0, eps=eps)
@@ -146,7 +150,7 @@ def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True):
         outermost = depth == 0
         innermost = depth == num_downs - 1
         if outermost:
-            d = F.conv2d(t, sd[prefix + "model.0.weight"], None, stride=2, padding=1)
+            d = F.conv2d(t, sd[prefix + "model.0.weight"], sd.get(prefix + "model.0.bias"), stride=2, padding=1)
             m = block(d, prefix + "model.1.", depth + 1)
             u = F.conv_transpose2d(F.relu(m), sd[prefix + "model.3.weight"],
                                    sd[prefix + "model.3.bias"], stride=2, padding=1)
@@ -156,14 +160,14 @@ def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True):
         # torch.cat([x, model(x)]) (:160-161) carries lrelu(x), not x.
         t = F.leaky_relu(t, 0.2)
         if innermost:
-            d = F.conv2d(t, sd[prefix + "model.1.weight"], None, stride=2, padding=1)
-            u = F.conv_transpose2d(F.relu(d), sd[prefix + "model.3.weight"], None, stride=2, padding=1)
+            d = F.conv2d(t, sd[prefix + "model.1.weight"], sd.get(prefix + "model.1.bias"), stride=2, padding=1)
+            u = F.conv_transpose2d(F.relu(d), sd[prefix + "model.3.weight"], sd.get(prefix + "model.3.bias"), stride=2, padding=1)
             u = bn(u, prefix + "model.4")
             return torch.cat([t, u], 1)
-        d = F.conv2d(t, sd[prefix + "model.1.weight"], None, stride=2, padding=1)
+        d = F.conv2d(t, sd[prefix + "model.1.weight"], sd.get(prefix + "model.1.bias"), stride=2, padding=1)
         d = bn(d, prefix + "model.2")
         m = block(d, prefix + "model.3.", depth + 1)
-        u = F.conv_transpose2d(F.relu(m), sd[prefix + "model.5.weight"], None, stride=2, padding=1)
+        u = F.conv_transpose2d(F.relu(m), sd[prefix + "model.5.weight"], sd.get(prefix + "model.5.bias"), stride=2, padding=1)
         u = bn(u, prefix + "model.6")
         return torch.cat([t, u], 1)
 

@@ -376,6 +376,25 @@ def g22():
     save("g22_resnet_variants", **out)
 
 
+def g23():
+    """UnetGenerator(norm_type='instance') and (use_dropout=True, eval) (UNet_arch.py:20-157): 5 downs, ngf 32, 64x64 and 64x96 inputs."""
+    from architectures.UNet_arch import UnetGenerator as RefUnet
+    out = {}
+    for i, (tag, kw, ev) in enumerate([("instance", dict(norm_type="instance"), False), ("instance_eval", dict(norm_type="instance"), True),
+                                       ("batch_dropout_eval", dict(norm_type="batch", use_dropout=True), True)]):
+        net = RefUnet(3, 3, 5, ngf=32, **kw)
+        net = net.eval() if ev else net.train()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = synth.fill_running_stats(synth.fill_state_dict(shapes, 230 + i), 235 + i) if "batch" in tag else synth.fill_state_dict(shapes, 230 + i)
+        net.load_state_dict(t_sd(sd), strict=True)
+        x = torch.from_numpy(synth.uniform((1, 3, 64, 96), 240 + i, -1.0, 1.0))
+        with torch.no_grad():
+            out[tag] = net(x).numpy()
+        out[tag + "_keys"] = np.array(list(shapes.keys()))
+        out[tag + "_shapes"] = np.array([str(shapes[k]) for k in shapes])
+    save("g23_unet_variants", **out)
+
+
 # ----------------------------------------------------------------- G10 loader
 def g10():
     tmp = tempfile.mkdtemp()
@@ -537,6 +556,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
     for g in which:
         globals()[g]()

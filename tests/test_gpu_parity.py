@@ -595,6 +595,30 @@ def test_unet256_eval_mode_uses_running_statistics(dev, golden):
     assert np.abs(net(xa.half()).float().cpu().numpy() - y_ev).max() > 1e-2
 
 
+def test_unet_instance_norm_and_dropout_variants_golden(dev, golden):
+    """UnetGenerator(norm_type='instance') in train and eval mode and (use_dropout=True) under eval() (UNet_arch.py:20-157) against the reference
+    (golden G23): the reference's parameter names (biases instead of norm parameters for instance norm), outputs within the UNet tolerance."""
+    from innfer_amd import synth
+    from innfer_amd.architectures.UNet_arch import UnetGenerator
+    from test_oracle_golden import G23_CASES, _g23_state
+    g = golden("g23_unet_variants")
+    for i, (tag, kw, ev) in enumerate(G23_CASES):
+        net = UnetGenerator(3, 3, 5, ngf=32, **kw)
+        assert list(net.state_dict()) == [str(k) for k in g[tag + "_keys"]]
+        net.load_state_dict(_g23_state(g, tag, i), strict=True)
+        net = net.to(dev)
+        net = net.eval() if ev else net.train()
+        x = torch.from_numpy(synth.uniform((1, 3, 64, 96), 240 + i, -1.0, 1.0)).to(dev)
+        for xin in (x, x.half()):
+            err = np.abs(net(xin).float().cpu().numpy() - g[tag])
+            assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(x)                                   # use_dropout=True in train mode is random: refused
+    with pytest.raises(NameError):
+        UnetGenerator(3, 3, 5, norm_type="group")
+
+
 def test_unet_variants_vs_oracle(dev):
     """Other UnetGenerator shapes through the same engine: unet_128 (7 levels) on a non-square image, and 1-channel input /
     5-channel output (the patch-slab first conv and the phase-combined last ConvTranspose are taken only for <= 4 channels)."""

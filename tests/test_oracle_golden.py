@@ -299,6 +299,29 @@ def test_g22_resnet_padding_and_dropout_variants(golden):
         assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-5, tag
 
 
+G23_CASES = [("instance", dict(norm_type="instance"), False), ("instance_eval", dict(norm_type="instance"), True),
+             ("batch_dropout_eval", dict(norm_type="batch", use_dropout=True), True)]
+
+
+def _g23_state(g, tag, i):
+    import ast
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[tag + "_keys"], g[tag + "_shapes"])}
+    sd = synth.fill_state_dict(shapes, 230 + i)
+    if "batch" in tag:
+        sd = synth.fill_running_stats(sd, 235 + i)
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def test_g23_unet_instance_norm_and_dropout_variants(golden):
+    """UnetGenerator(norm_type='instance') (train / eval: the same) and (use_dropout=True) under eval() (UNet_arch.py:20-157) against the reference."""
+    g = golden("g23_unet_variants")
+    for i, (tag, kw, ev) in enumerate(G23_CASES):
+        x = torch.from_numpy(synth.uniform((1, 3, 64, 96), 240 + i, -1.0, 1.0))
+        with torch.no_grad():
+            y = oracle.unet_forward(_g23_state(g, tag, i), x, num_downs=5, training=not ev, norm_type=kw["norm_type"]).numpy()
+        assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-5, tag
+
+
 def test_g16_mrrdbnet(golden):
     """MRRDBNet (new-arch ESRGAN built directly, RRDBNet_arch.py:173-231) on its own key names."""
     g = golden("g16_mrrdb")
