@@ -705,7 +705,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         int voff[KQ];
         const char* in_tile = nullptr;
         const char* w_tile = nullptr;
-        auto setup = [&](int jj) {
+        // (always_inline: a lambda left as a call keeps the per-lane offset arrays it captures in scratch memory -- the S9 instantiation, whose
+        //  issue path is the longest, ran 11 x slower that way: profiles/r2/kernel_experiments.txt 13)
+        auto setup = [&](int jj) __attribute__((always_inline)) {
             int kg, n, ty0, tx0, dl = 1;
             if constexpr (POLY) decode_poly(jj, kg, n, ty0, tx0, dl);
             else decode(jj, kg, n, ty0, tx0);
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
         };
         // what: 1 input pieces, 2 weight pieces, 3 both; st_i / st_w: LDS destinations; wsrc: the chunk's weight panel
-        auto issue_to = [&](int c, char* st_i, char* st_w, const char* wsrc, int what) {
+        auto issue_to = [&](int c, char* st_i, char* st_w, const char* wsrc, int what) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const char* src = in_tile + c * p.in_gbytes;
             if constexpr (S9) {
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             (void)c; (void)st_i; (void)st_w; (void)wsrc; (void)what; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile; (void)s9_ty0; (void)s9_tx0; (void)s9_n; (void)s9_edge;
 #endif
         };
-        auto issue = [&](int c, int stage) {
+        auto issue = [&](int c, int stage) __attribute__((always_inline)) {
             issue_to(c, smem + stage * STAGE, smem + stage * STAGE + IN_BYTES, w_tile + (long)c * W_BYTES, 3);
         };
         if constexpr (NSI == 3) {

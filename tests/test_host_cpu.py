@@ -300,3 +300,54 @@ def test_image_files_round_trip_in_opencv_channel_order(tmp_path):
         U.get_images_paths(str(tmp_path / "a.png"))
     m = U.merge_imgs([bgr, np.repeat(np.repeat(bgr, 2, 0), 2, 1)])
     assert m.shape == (18, 52, 3) and np.array_equal(m[:, :26], m[:, 26:])
+
+
+def _kernel_metadata(so_path):
+    """(kernel name, private_segment_fixed_size, vgpr_count, sgpr_spill, vgpr_spill) of every gfx950 kernel in the shared library: the
+    uncompressed clang offload bundles of its .hip_fatbin section -> the gfx950 ELF code objects -> the msgpack AMDGPU metadata note."""
+    import struct
+    import msgpack
+    blob = open(so_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out = []
+    for m in re.finditer(magic, blob):
+        base = m.start()
+        (n,) = struct.unpack_from("<Q", blob, base + 24)
+        p = base + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" not in triple or size == 0:
+                continue
+            elf = blob[base + off:base + off + size]
+            assert elf[:4] == b"\x7fELF"
+            shoff, = struct.unpack_from("<Q", elf, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+            for i in range(shnum):
+                sh = shoff + i * shentsize
+                sh_type, = struct.unpack_from("<I", elf, sh + 4)
+                sh_offset, sh_size = struct.unpack_from("<QQ", elf, sh + 0x18)
+                if sh_type != 7:                                  # SHT_NOTE
+                    continue
+                q, end = sh_offset, sh_offset + sh_size
+                while q + 12 <= end:
+                    namesz, descsz, ntype = struct.unpack_from("<III", elf, q)
+                    d0 = q + 12 + (namesz + 3) // 4 * 4
+                    if ntype == 32:                               # NT_AMDGPU_METADATA
+                        md = msgpack.unpackb(elf[d0:d0 + descsz], raw=False, strict_map_key=False)
+                        for k in md.get("amdhsa.kernels", []):
+                            out.append((k[".name"], k[".private_segment_fixed_size"], k[".vgpr_count"], k.get(".sgpr_spill_count", 0), k.get(".vgpr_spill_count", 0)))
+                    q = d0 + (descsz + 3) // 4 * 4
+    return out
+
+
+def test_no_shipped_kernel_uses_scratch_memory():
+    """A kernel whose per-lane arrays land in scratch memory stays correct and gets slow without a trace in any parity test (the 7x7 instantiation
+    of conv3x3_pc ran 11 x slower for a while because a loader lambda was no longer inlined).  Every kernel of the shipped library must have a
+    private segment of 0 bytes and no spilled vector registers; the one exception is a fallback instantiation no launch path selects."""
+    ks = _kernel_metadata(L.LIB_PATH)
+    assert len(ks) >= 60, len(ks)
+    allowed = ("conv3x3_mfmaILi4ELi4ELi0E",)          # 16-row x 64-channel two-workgroup form: diagnostic builds only (INNFER_PC=0, INNFER_RPW64=4)
+    bad = [(n, priv, vs) for (n, priv, _v, _ss, vs) in ks if (priv or vs) and not any(a in n for a in allowed)]
+    assert not bad, bad
