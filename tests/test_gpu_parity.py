@@ -106,6 +106,50 @@ def test_conv_shapes(dev, Cc, K, H, W, N):
     assert (got - ref).abs().max().item() < 4e-3
 
 
+def test_conv_random_shapes_fuzz(dev):
+    """Seeded sweep over what the trunk kernels are parameterised on -- input / output channel counts, image sizes around the tile sizes (24 x 32,
+    16 x 32), batches (N > 1 takes the image-canvas form when that saves tiles: cells, gutters, tiles that straddle images), activation, one
+    or two residuals, nearest-2x input, reflection / replication padding, output channel offsets -- against F.conv2d on the same fp16 operands."""
+    from innfer_amd import synth
+    rng = np.random.RandomState(20260101)
+    for case in range(48):
+        K = int(rng.choice([16, 32, 64]))
+        Cc = int(rng.choice([32, 64, 96, 128, 160, 192]))
+        N = int(rng.choice([1, 1, 2, 3, 5]))
+        H, W = int(rng.randint(1, 70)), int(rng.randint(1, 90))
+        if case % 6 == 0:
+            H, W = int(rng.choice([24, 48, 16, 32, 25, 47])), int(rng.choice([32, 64, 33, 63, 31]))      # whole tiles and one off
+        act = int(rng.choice([0, 1, 2]))
+        up = bool(rng.rand() < 0.15) and N == 1
+        pad = 0 if (up or K < 32) else int(rng.choice([0, 0, 0, 1, 2]))      # reflection / replication padding: the 32- / 64-output slab kernels
+        if pad == 1 and min(H, W) < 2:
+            pad = 0
+        use_r1 = K >= 32 and rng.rand() < 0.4
+        use_r2 = use_r1 and rng.rand() < 0.5
+        Hs, Ws = (H, W)
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        x = torch.from_numpy(synth.uniform((N, Cc, Hs, Ws), 1000 + case, -1, 1)).half()
+        w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 2000 + case, -1, 1)) / np.sqrt(9 * Cc)
+        b = torch.from_numpy(synth.uniform((K,), 3000 + case, -1, 1))
+        r1 = torch.from_numpy(synth.uniform((N, K, Ho, Wo), 4000 + case, -1, 1)).half() if use_r1 else None
+        r2 = torch.from_numpy(synth.uniform((N, K, Ho, Wo), 5000 + case, -1, 1)).half() if use_r2 else None
+        off = 0 if K == 64 else int(rng.choice([0, 16])) if K == 16 else 0
+        got, _ = _run_conv(dev, x, w, b, K, act=act, up=up, res1=r1, s1=0.2, res2=r2, s2=0.2, in_extra=int(rng.choice([0, 32])),
+                           out_channels=64, out_off=off, reflect=pad)
+        xx = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+        if pad:
+            y = F.conv2d(F.pad(xx, (1, 1, 1, 1), mode="reflect" if pad == 1 else "replicate"), w.half().float(), b.float())
+        else:
+            y = F.conv2d(xx, w.half().float(), b.float(), padding=1)
+        y = F.leaky_relu(y, 0.2) if act == 1 else F.relu(y) if act == 2 else y
+        if use_r1:
+            y = y * 0.2 + r1.float()
+        if use_r2:
+            y = y * 0.2 + r2.float()
+        err = (got - y).abs().max().item()
+        assert err < 4e-3, (case, N, Cc, K, H, W, act, up, pad, use_r1, use_r2, off, err)
+
+
 def test_conv_epilogues_and_slab_offsets(dev):
     from innfer_amd import synth
     N, Cc, K, H, W = 1, 192, 64, 20, 36

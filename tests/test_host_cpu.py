@@ -351,3 +351,27 @@ def test_no_shipped_kernel_uses_scratch_memory():
     allowed = ("conv3x3_mfmaILi4ELi4ELi0E",)          # 16-row x 64-channel two-workgroup form: diagnostic builds only (INNFER_PC=0, INNFER_RPW64=4)
     bad = [(n, priv, vs) for (n, priv, _v, _ss, vs) in ks if (priv or vs) and not any(a in n for a in allowed)]
     assert not bad, bad
+
+
+def test_chop_plan_equals_oracle_geometry_on_random_sizes():
+    """innfer_chop_plan (C, host) against the oracle's restatement of run.py:176-181 / utils.py:350-365 for 400 seeded image sizes, patch sizes and
+    steps -- the oracle itself is pinned on the reference's unfold geometry by golden G1."""
+    from oracle.tiles import chop_geometry
+    rng = np.random.RandomState(7)
+    for _ in range(400):
+        h, w = int(rng.randint(2, 1300)), int(rng.randint(2, 1300))
+        patch = int(rng.choice([200, 200, 200, 64, 150, 333, 17]))
+        step = float(rng.choice([0.5, 0.5, 0.75, 1.0]))
+        ps, ys, xs = chop_geometry(h, w, patch, step)
+        if int(ps * step) <= 0:
+            continue
+        assert L.chop_plan(h, w, patch, step) == (ps, ys, xs), (h, w, patch, step)
+        first, count = C.c_int(), C.c_int()
+        n, tot = len(ys) * len(xs), 0
+        for world in (1, 3, 8):
+            tot = 0
+            for r in range(world):
+                L.check(L.lib.innfer_shard_tiles(n, world, r, C.byref(first), C.byref(count)))
+                assert first.value == tot and 0 <= count.value <= -(-n // world)
+                tot += count.value
+            assert tot == n
