@@ -1172,6 +1172,30 @@ def test_esrgan_lite_and_gray_shapes(dev):
         assert (y - ref).abs().max().item() < 1e-2, (in_nc, nf, scale)
 
 
+def test_first_conv_on_the_matrix_cores_all_widths(dev):
+    """first_conv_mfma<NT, STEPS>: 1..8 input channels (one, two or three 32-deep k steps of 9 * in_nc taps), nf 32 / 64, fp16 and fp32 input,
+    ragged and one-pixel images -- through a one-block RRDBNet against the oracle.  With fp32 input the split fp16 operands must keep the first
+    conv at fp32 accuracy: fp32-in and fp16-in forwards of the same fp16-representable image agree bit for bit."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    for in_nc in (1, 2, 3, 4, 5, 7, 8):
+        for nf in (32, 64):
+            sd = _sd(synth.rrdbnet_shapes(in_nc=in_nc, out_nc=3, nf=nf, nb=1, scale=1), 300 + in_nc)
+            net = RRDBNet(in_nc, 3, nf, 1, upscale=1)
+            net.load_state_dict(sd, strict=True)
+            net = net.to(dev).eval()
+            for shape in ((1, in_nc, 17, 23), (2, in_nc, 1, 1), (1, in_nc, 33, 16)):
+                x = torch.from_numpy(synth.uniform(shape, 310 + in_nc)).half()
+                with torch.no_grad():
+                    ref = oracle.rrdbnet_forward(sd, x.float(), nb=1, scale=1)
+                y16 = net(x.to(dev)).float().cpu()
+                y32 = net(x.float().to(dev)).float().cpu()
+                assert (y16 - ref).abs().max().item() < 5e-3, (in_nc, nf, shape)
+                assert (y32 - ref).abs().max().item() < 5e-3, (in_nc, nf, shape)
+                assert torch.equal(net(x.float().to(dev)).half(), net(x.to(dev))), (in_nc, nf, shape)
+
+
 # ---------------------------------------------------------------- Model / chop
 def test_model_chop_golden(dev, golden, tmp_path):
     from innfer_amd import synth
