@@ -22,7 +22,8 @@ class RRDBNet(EngineModule):
             raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
         unsupported = []
         if not isinstance(nr, int) or nr < 1: unsupported.append(f'nr={nr}')
-        if norm_type: unsupported.append(f'norm_type={norm_type}')
+        if norm_type and (norm_type.lower() != 'batch' or mode != 'CNA'):
+            unsupported.append(f'norm_type={norm_type} with mode={mode}')          # built: BatchNorm2d behind the convs (CNA), folded at load
         if act_type not in _TRUNK_ACT: unsupported.append(f'act_type={act_type}')
         # mode: the dense blocks are built with mode='CNA' whatever is passed (RRDBNet_arch.py:27-29); only LR_conv takes it, and without
         # a norm layer or an activation a 'NAC' / 'CNAC' conv_block is the bare conv (block.py:237-254)
@@ -33,12 +34,45 @@ class RRDBNet(EngineModule):
         if unsupported:
             raise NotImplementedError('RRDBNet option(s) not built on the HIP path yet: ' + ', '.join(unsupported))
         # gaussian_noise: GaussianNoise is the identity in eval mode (block.py:382-388)
-        super().__init__(rrdbnet_shapes(in_nc, out_nc, nf, nb, 32, upscale, plus, nr, upsample_mode))
+        super().__init__(rrdbnet_shapes(in_nc, out_nc, nf, nb, 32, upscale, plus, nr, upsample_mode, bool(norm_type)))
+        self.norm = bool(norm_type)
         self.in_nc, self.out_nc, self.nf, self.nb, self.gc, self.upscale = in_nc, out_nc, nf, nb, 32, upscale
         self.plus, self.nr = bool(plus), nr
         self.trunk_act = _TRUNK_ACT[act_type]
         self.pixelshuffle_up = upsample_mode == 'pixelshuffle'
         self.final_act = _FINAL_ACT[finalact.lower()] if finalact else 0
+
+    # norm_type='batch' (RRDBNet_arch.py:27-29, block.py:244-246): every conv of the dense blocks and LR_conv is followed by a BatchNorm2d.  Under
+    # eval() -- Model's default (run.py:96-97) -- that is a per-channel affine map of the conv's output, so it is folded into the conv's weights and
+    # bias when they are uploaded (float64 arithmetic): y = (conv(x) + b - mean) * g / sqrt(var + eps) + beta.
+    def _bn_key(self, k):
+        if not self.norm:
+            return None
+        if k.endswith('.0') and '.conv' in k:
+            return k[:-2] + '.1'
+        return f'model.1.sub.{self.nb + 1}' if k == f'model.1.sub.{self.nb}' else None
+
+    def _conv_tensors(self, k, sd):
+        w, b = super()._conv_tensors(k, sd)
+        bk = self._bn_key(k)
+        if bk is None:
+            return w, b
+        import numpy as np
+        g, beta = sd[bk + '.weight'].double().cpu().numpy(), sd[bk + '.bias'].double().cpu().numpy()
+        mean, var = sd[bk + '.running_mean'].double().cpu().numpy(), sd[bk + '.running_var'].double().cpu().numpy()
+        a = g / np.sqrt(var + 1e-5)
+        w = (w.astype(np.float64) * a[:, None, None, None]).astype(np.float32)
+        b = ((0.0 if b is None else b.astype(np.float64)) - mean) * a + beta
+        return w, b.astype(np.float32)
+
+    def _weights_version(self):
+        ver = super()._weights_version()
+        return ver + tuple((t.data_ptr(), t._version) for t in self.buffers()) if self.norm else ver
+
+    def forward(self, x):
+        if self.norm and self.training:
+            raise NotImplementedError("RRDBNet(norm_type='batch') in train mode normalises with batch statistics; the engine folds the eval-mode BatchNorm (net.eval())")
+        return super().forward(x)
 
     def _create_handle(self):
         h = C.c_void_p()

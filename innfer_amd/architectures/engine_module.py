@@ -28,7 +28,12 @@ class EngineModule(nn.Module):
                 if name not in node._modules:
                     node.add_module(name, _Node())
                 node = node._modules[name]
-            node.register_parameter(leaf, nn.Parameter(torch.zeros(*shape), requires_grad=False))
+            if leaf == 'num_batches_tracked':               # BatchNorm2d state (RRDBNet(norm_type='batch')): buffers, as in nn.BatchNorm2d
+                node.register_buffer(leaf, torch.zeros(shape, dtype=torch.long))
+            elif leaf.startswith('running_'):
+                node.register_buffer(leaf, torch.ones(shape) if leaf == 'running_var' else torch.zeros(shape))
+            else:
+                node.register_parameter(leaf, nn.Parameter(torch.zeros(*shape), requires_grad=False))
         self._handle = None
         self._uploaded_version = None
         self._weights_device = None          # GPU the engine's packed weights live on
@@ -61,16 +66,22 @@ class EngineModule(nn.Module):
         for i in range(n):
             L.check(L.lib.innfer_net_conv_info(self._handle, i, key, 128, C.byref(K), C.byref(Cc)))
             k = self._param_key(key.value.decode())
-            w = np.ascontiguousarray(sd[k + '.weight'].detach().float().cpu().numpy())
+            w, b = self._conv_tensors(k, sd)
+            w = np.ascontiguousarray(w)
             if w.shape[:2] != (K.value, Cc.value):
                 raise RuntimeError(f'size mismatch for {k}.weight: {tuple(w.shape)} vs engine ({K.value},{Cc.value},3,3)')
-            b = sd.get(k + '.bias')
             bp = None
             if b is not None:
-                b = np.ascontiguousarray(b.detach().float().cpu().numpy())
+                b = np.ascontiguousarray(b)
                 bp = b.ctypes.data
             L.check(L.lib.innfer_net_set_conv(self._handle, i, w.ctypes.data, bp))
         self._uploaded_version = ver
+
+    def _conv_tensors(self, k, sd):
+        """fp32 (weight, bias or None) the engine's conv `k` is loaded with; subclasses fold what follows the conv into them."""
+        w = sd[k + '.weight'].detach().float().cpu().numpy()
+        b = sd.get(k + '.bias')
+        return w, (None if b is None else b.detach().float().cpu().numpy())
 
     def _destroy_handle(self):
         h = getattr(self, '_handle', None)

@@ -6,7 +6,12 @@ files load with strict=True.
 """
 
 
-def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False, nr=3, upsample_mode='upconv'):
+def _bn(s, key, c):
+    s[key + ".weight"] = (c,); s[key + ".bias"] = (c,)
+    s[key + ".running_mean"] = (c,); s[key + ".running_var"] = (c,); s[key + ".num_batches_tracked"] = ()
+
+
+def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False, nr=3, upsample_mode='upconv', norm=False):
     """State-dict key -> shape of the reference's old-arch ESRGAN
     (reference RRDBNet_arch.py:16-48; key layout SURVEY.md 3.3).  nr != 3: the dense blocks are `RDBs.<i>` (RRDBNet_arch.py:84-88);
     upsample_mode 'pixelshuffle': the stage's conv (nf -> 4 nf, 9 nf for scale 3) comes first (block.py:333-346)."""
@@ -22,8 +27,12 @@ def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False, 
                 cout = gc if i < 5 else nf
                 s[p + f"conv{i}.0.weight"] = (cout, cin, 3, 3)
                 s[p + f"conv{i}.0.bias"] = (cout,)
+                if norm:                        # conv_block(CNA) = conv, BatchNorm2d[, act] (block.py:244-246)
+                    _bn(s, p + f"conv{i}.1", cout)
     s[f"model.1.sub.{nb}.weight"] = (nf, nf, 3, 3)
     s[f"model.1.sub.{nb}.bias"] = (nf,)
+    if norm:                                    # LR_conv's norm layer is flattened into the trunk's Sequential behind its conv
+        _bn(s, f"model.1.sub.{nb + 1}", nf)
     n_up = 1 if scale == 3 else int(math.log(scale, 2))
     idx = 2
     for _ in range(n_up):

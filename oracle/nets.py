@@ -15,6 +15,16 @@ def _conv3(sd, key, x):
     return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=1, padding=1)
 
 
+def _conv3_bn(sd, key, x):
+    """conv_block(mode='CNA', norm_type='batch') of a dense block: conv `key`.0 then the eval-mode BatchNorm2d `key`.1 when the state dict has one
+    (block.py:244-246; RRDBNet(norm_type='batch'), RRDBNet_arch.py:27-29)."""
+    y = _conv3(sd, key + ".0", x)
+    bk = key + ".1"
+    if bk + ".running_mean" in sd:
+        y = F.batch_norm(y, sd[bk + ".running_mean"], sd[bk + ".running_var"], sd[bk + ".weight"], sd[bk + ".bias"], training=False, eps=1e-5)
+    return y
+
+
 def _lrelu(x):
     # act('leakyrelu') -> nn.LeakyReLU(0.2)  (block.py:81-90)
     return F.leaky_relu(x, 0.2)
@@ -22,15 +32,15 @@ def _lrelu(x):
 
 def rdb_forward(sd, prefix, x, plus=False, a=_lrelu):
     """ResidualDenseBlock_5C.forward (RRDBNet_arch.py:152-165); a: the act_type of its conv blocks."""
-    x1 = a(_conv3(sd, prefix + "conv1.0", x))
-    x2 = a(_conv3(sd, prefix + "conv2.0", torch.cat((x, x1), 1)))
+    x1 = a(_conv3_bn(sd, prefix + "conv1", x))
+    x2 = a(_conv3_bn(sd, prefix + "conv2", torch.cat((x, x1), 1)))
     if plus:
         x2 = x2 + F.conv2d(x, sd[prefix + "conv1x1.weight"])          # :155-156
-    x3 = a(_conv3(sd, prefix + "conv3.0", torch.cat((x, x1, x2), 1)))
-    x4 = a(_conv3(sd, prefix + "conv4.0", torch.cat((x, x1, x2, x3), 1)))
+    x3 = a(_conv3_bn(sd, prefix + "conv3", torch.cat((x, x1, x2), 1)))
+    x4 = a(_conv3_bn(sd, prefix + "conv4", torch.cat((x, x1, x2, x3), 1)))
     if plus:
         x4 = x4 + x2                                                   # :159-160
-    x5 = _conv3(sd, prefix + "conv5.0", torch.cat((x, x1, x2, x3, x4), 1))
+    x5 = _conv3_bn(sd, prefix + "conv5", torch.cat((x, x1, x2, x3, x4), 1))
     return x5 * 0.2 + x                                                # :165
 
 
@@ -63,6 +73,9 @@ def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None,
         if taps is not None and b == 0:
             taps["rrdb0"] = t
     t = _conv3(sd, f"model.1.sub.{nb}", t)
+    if f"model.1.sub.{nb + 1}.running_mean" in sd:           # LR_conv's BatchNorm2d (norm_type='batch'), flattened behind its conv
+        bk = f"model.1.sub.{nb + 1}"
+        t = F.batch_norm(t, sd[bk + ".running_mean"], sd[bk + ".running_var"], sd[bk + ".weight"], sd[bk + ".bias"], training=False, eps=1e-5)
     t = fea + t                                   # ShortcutBlock (block.py:189-191)
     if taps is not None:
         taps["trunk"] = t

@@ -537,6 +537,16 @@ def g18():
         with torch.no_grad():
             out[tag] = net(x).numpy()
         out[tag + "_keys"] = np.array(sorted(shapes))
+    # norm_type='batch' under eval(): BatchNorm2d behind every conv of the dense blocks and behind LR_conv
+    net = RefRRDBNet(3, 3, 64, 2, upscale=2, norm_type="batch").eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    mine = synth.rrdbnet_shapes(nb=2, scale=2, norm=True)
+    assert shapes == mine, set(shapes) ^ set(mine)
+    sd = synth.fill_running_stats(synth.fill_state_dict(mine, 184), 184)
+    net.load_state_dict(t_sd(sd), strict=True)
+    with torch.no_grad():
+        out["batchnorm"] = net(torch.from_numpy(synth.uniform((1, 3, 16, 16), 194))).numpy()
+    out["batchnorm_keys"] = np.array(sorted(shapes))
     save("g18_rrdb_variants", **out)
     # PAN(self_attention=False), PAN(double_scpa=True) (PAN_arch.py:115-141,193-203)
     from architectures.PAN_arch import PAN as RefPAN

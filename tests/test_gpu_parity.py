@@ -421,6 +421,20 @@ def test_rrdbnet_constructor_variants_golden(dev, golden):
         assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 5e-3, tag
     with pytest.raises(NotImplementedError):
         RRDBNet(3, 3, 64, 1, upsample_mode="deconv")
+    # norm_type='batch': the eval-mode BatchNorm2d layers are folded into the convs when the weights are uploaded
+    shapes = synth.rrdbnet_shapes(nb=2, scale=2, norm=True)
+    net = RRDBNet(3, 3, 64, 2, upscale=2, norm_type="batch")
+    assert sorted(net.state_dict()) == list(g["batchnorm_keys"])
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_running_stats(synth.fill_state_dict(shapes, 184), 184).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 194)).to(dev).half()
+    assert np.abs(net(x).float().cpu().numpy() - g["batchnorm"]).max() < 5e-3
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(x)                                    # batch statistics: not what the engine folds
+    with pytest.raises(NotImplementedError):
+        RRDBNet(3, 3, 64, 1, norm_type="instance")
 
 
 def test_esrgan_plus_golden(dev, golden):
@@ -556,7 +570,7 @@ def test_missing_weights_and_cpu_are_loud(dev):
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 8, 8))               # CPU tensor: no fallback
     with pytest.raises(NotImplementedError):
-        RRDBNet(3, 3, 64, 1, upscale=4, norm_type='batch')           # a norm layer inside every conv block: not built
+        RRDBNet(3, 3, 64, 1, upscale=4, norm_type='instance')        # instance statistics cannot be folded into the convs: not built
 
 
 def test_unet256_golden(dev, golden):

@@ -120,6 +120,13 @@ def test_g18_rrdbnet_constructor_variants(golden):
         with torch.no_grad():
             y = oracle.rrdbnet_forward(sd, x, **kw).numpy()
         assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-6, tag
+    # norm_type='batch' under eval(): the BatchNorm2d layers behind the dense blocks' convs and behind LR_conv
+    shapes = synth.rrdbnet_shapes(nb=2, scale=2, norm=True)
+    assert sorted(shapes) == list(g["batchnorm_keys"])
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_running_stats(synth.fill_state_dict(shapes, 184), 184).items()}
+    with torch.no_grad():
+        y = oracle.rrdbnet_forward(sd, torch.from_numpy(synth.uniform((1, 3, 16, 16), 194)), nb=2, scale=2).numpy()
+    assert np.abs(y - g["batchnorm"]).max() < 5e-6
 
 
 G18_PAN = {"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
