@@ -65,10 +65,6 @@ class RRDBNet(EngineModule):
         b = ((0.0 if b is None else b.astype(np.float64)) - mean) * a + beta
         return w, b.astype(np.float32)
 
-    def _weights_version(self):
-        ver = super()._weights_version()
-        return ver + tuple((t.data_ptr(), t._version) for t in self.buffers()) if self.norm else ver
-
     def forward(self, x):
         if self.norm and self.training:
             raise NotImplementedError("RRDBNet(norm_type='batch') in train mode normalises with batch statistics; the engine folds the eval-mode BatchNorm (net.eval())")

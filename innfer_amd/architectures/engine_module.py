@@ -51,7 +51,13 @@ class EngineModule(nn.Module):
 
     # ---- weight upload (load time, not forward time) -------------------------
     def _weights_version(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # (data pointer, in-place version) of every tensor the engine was loaded from.  The tensor OBJECTS never change (load_state_dict and
+        # .to() work in place on them), so the walk over the module tree -- ~700 parameters for RRDBNet-23 -- is done once, not per forward.
+        ts = self.__dict__.get('_version_tensors')
+        if ts is None:
+            ts = list(self.parameters()) + list(self.buffers())
+            self.__dict__['_version_tensors'] = ts
+        return tuple([(t.data_ptr(), t._version) for t in ts])
 
     def _ensure_engine(self):
         ver = self._weights_version()

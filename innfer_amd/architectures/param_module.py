@@ -55,7 +55,11 @@ class ParamEngineModule(nn.Module):
 
     def _upload(self):
         # parameters AND buffers: the running statistics of a BatchNorm are part of an eval()-mode forward
-        ver = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        ts = self.__dict__.get('_version_tensors')      # the tensor objects never change: walk the module tree once
+        if ts is None:
+            ts = list(self.parameters()) + list(self.buffers())
+            self.__dict__['_version_tensors'] = ts
+        ver = tuple([(t.data_ptr(), t._version) for t in ts])
         if ver == self._version:
             return
         sd = self.state_dict()
