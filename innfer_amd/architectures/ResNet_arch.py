@@ -15,11 +15,12 @@ class ResnetGenerator(ParamEngineModule):
         super().__init__()
         if padding_type not in _PADDING:                       # the reference's own error (ResNet_arch.py:128)
             raise NotImplementedError('padding {} is not implemented'.format(padding_type))
-        if norm_type not in ('IN', 'instance') or upsample_mode != 'deconv':
-            raise NotImplementedError('ResnetGenerator: norm=instance and deconv upsampling are built')
+        if norm_type not in ('IN', 'instance') or upsample_mode not in ('deconv', 'upconv'):
+            raise NotImplementedError('ResnetGenerator: norm=instance with deconv / upconv upsampling is built')
         self.input_nc, self.output_nc, self.ngf, self.n_blocks = input_nc, output_nc, ngf, n_blocks
         self.padding_type, self.use_dropout = padding_type, bool(use_dropout)
-        self._init_engine(input_nc, output_nc, ngf, n_blocks, _PADDING[padding_type], int(self.use_dropout))
+        self.upsample_mode = upsample_mode
+        self._init_engine(input_nc, output_nc, ngf, n_blocks, _PADDING[padding_type], int(self.use_dropout), int(upsample_mode == 'upconv'))
 
     def _fn(self, name):
         return super()._fn('create_ex' if name == 'create' else name)

@@ -129,7 +129,8 @@ __global__ void rn_final(const float* raw, int rs, int C, long HW, int N, const 
 
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; bool transposed = false; std::vector<f16*> d_w; float* d_b = nullptr;
-               void* d_w3 = nullptr; };    // residual-block convs: conv3x3.hip panels (reflection padding in the halo-tile loader)
+               void* d_w3 = nullptr;
+               bool up2 = false; };        // upsample_mode 'upconv': Upsample(nearest 2x) + 3x3 conv on the halo-tile kernel (nearest-2x in the loader)    // residual-block convs: conv3x3.hip panels (reflection padding in the halo-tile loader)
 
 }  // namespace
 
@@ -155,10 +156,10 @@ static void add_layer(innfer_resnet* r, const std::string& key, int cin, int cou
 }
 
 extern "C" int innfer_resnet_create(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks) {
-    return innfer_resnet_create_ex(out, in_nc, out_nc, ngf, n_blocks, 0, 0);
+    return innfer_resnet_create_ex(out, in_nc, out_nc, ngf, n_blocks, 0, 0, 0);
 }
 
-extern "C" int innfer_resnet_create_ex(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout) {
+extern "C" int innfer_resnet_create_ex(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout, int upconv) {
     if (!out) return set_error(INNFER_ERR_INVALID, "resnet_create: null out");
     if (padding < 0 || padding > 2) return set_error(INNFER_ERR_INVALID, "resnet_create: padding %d (0 reflect, 1 replicate, 2 zero)", padding);
     if (ngf != 64 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || n_blocks < 0 || n_blocks > 64)
@@ -178,8 +179,13 @@ extern "C" int innfer_resnet_create_ex(innfer_resnet** out, int in_nc, int out_n
         add_layer(r, b + std::to_string(c2), 4 * ngf, 4 * ngf, 3, false);
     }
     const int i = 10 + n_blocks;
-    add_layer(r, "model." + std::to_string(i), 4 * ngf, 2 * ngf, 3, true);
-    add_layer(r, "model." + std::to_string(i + 3), 2 * ngf, ngf, 3, true);
+    if (upconv) {        // upconv_block (block.py:348-361): sequential(Upsample, Conv2d) inside the model's Sequential -> `model.<i>.1`
+        add_layer(r, "model." + std::to_string(i) + ".1", 4 * ngf, 2 * ngf, 3, false); r->layers.back().up2 = true;
+        add_layer(r, "model." + std::to_string(i + 3) + ".1", 2 * ngf, ngf, 3, false); r->layers.back().up2 = true;
+    } else {
+        add_layer(r, "model." + std::to_string(i), 4 * ngf, 2 * ngf, 3, true);
+        add_layer(r, "model." + std::to_string(i + 3), 2 * ngf, ngf, 3, true);
+    }
     add_layer(r, "model." + std::to_string(i + 7), ngf, out_nc, 7, false);
     *out = r;
     return INNFER_OK;
@@ -283,7 +289,7 @@ int rn_upload(innfer_resnet* r) {
             INNFER_HIP(hipMalloc((void**)&l.d_b, b3.size() * sizeof(float)));
             INNFER_HIP(hipMemcpy(l.d_b, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
         }
-        if (!l.transposed && k == 3 && l.cin == l.cout && l.cin % 64 == 0) {       // ResnetBlock convs (stride 1, reflection pad 1)
+        if (l.up2 || (!l.transposed && k == 3 && l.cin == l.cout && l.cin % 64 == 0)) {       // ResnetBlock convs (stride 1, pad 1) and the upconv convs
             std::vector<char> packed(conv_packed_bytes(l.cout, l.cin));
             conv_pack(w.data(), l.cout, l.cin, packed.data());
             INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
@@ -414,8 +420,32 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         CK(block_conv(r->layers[li], Cc, H4, W4, 0, t, spare)); ++li;
         f16* tmp = t; t = spare; spare = tmp;
     }
+    // upsample_mode 'upconv': nearest-2x + 3x3 conv (zero padding) on the halo-tile kernel, instance norm + ReLU on its fp16 slab
+    auto up_conv = [&](const Layer& l, const f16* in, int Hi, int Wi, f16* dst) -> int {
+        const int Ho = 2 * Hi, Wo = 2 * Wi;
+        const long HW = (long)Ho * Wo, G = (long)N * HW * 32;
+        f16* Y = (f16*)raw;
+        ConvLaunch L{};
+        L.in = in; L.in_gstride = (long)N * Hi * Wi * 32; L.C = l.cin;
+        L.wpk = (const f16*)l.d_w3; L.bias = l.d_b;
+        L.out = Y; L.out_gstride = G; L.K = l.cout;
+        L.N = N; L.H = Ho; L.W = Wo; L.up = 1; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Ho;
+        L.out_mode = OUT_SLAB;
+        CK(conv_launch(L, s));
+        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        const long total = (long)N * HW * (l.cout / 8);
+        hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
+                           (const float*)alpha, (const float*)shift, 1, (const f16*)nullptr, dst, G);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
+    if (r->layers[li].up2) {
+        CK(up_conv(r->layers[li], t, H4, W4, U1)); ++li;                                                                // u128
+        CK(up_conv(r->layers[li], U1, H2, W2, U2)); ++li;                                                               // u64
+    } else {
     CK(deconv(r->layers[li], t, H4, W4)); CK(norm_post(r->layers[li], H2, W2, 1, nullptr, U1)); ++li;                 // u128
     CK(deconv(r->layers[li], U1, H2, W2)); CK(norm_post(r->layers[li], H, W, 1, nullptr, U2)); ++li;                  // u64
+    }
     {   // c7s1-out + tanh
         const Layer& l = r->layers[li];
         if (l.d_w3) {       // tanh(conv7x7(reflect3(x)) + bias) -> NCHW in the conv's planar epilogue

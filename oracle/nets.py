@@ -323,7 +323,10 @@ def resnet_forward(sd, x, n_blocks=9, eps=1e-5, padding_type="reflect", use_drop
         t = t + r
     i = 10 + n_blocks
     for k in (i, i + 3):
-        t = F.conv_transpose2d(t, sd[f"model.{k}.weight"], sd[f"model.{k}.bias"], stride=2, padding=1, output_padding=1)
+        if f"model.{k}.1.weight" in sd:             # upsample_mode 'upconv' (:70-73): upconv_block = Upsample(nearest 2x), Conv2d(3x3) (block.py:348-361)
+            t = conv(F.interpolate(t, scale_factor=2.0, mode="nearest"), f"model.{k}.1", padding=1)
+        else:
+            t = F.conv_transpose2d(t, sd[f"model.{k}.weight"], sd[f"model.{k}.bias"], stride=2, padding=1, output_padding=1)
         t = F.relu(inorm(t))
     return torch.tanh(conv(F.pad(t, (3, 3, 3, 3), mode="reflect"), f"model.{i + 7}"))
 

@@ -364,7 +364,8 @@ def g22():
     out = {}
     for i, (tag, kw) in enumerate({"zero": dict(padding_type="zero"), "replicate": dict(padding_type="replicate"),
                                    "reflect_dropout": dict(padding_type="reflect", use_dropout=True),
-                                   "zero_dropout": dict(padding_type="zero", use_dropout=True)}.items()):
+                                   "zero_dropout": dict(padding_type="zero", use_dropout=True),
+                                   "upconv": dict(upsample_mode="upconv")}.items()):
         net = RefResnet(3, 3, 64, norm_type="instance", n_blocks=2, **kw).eval()
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
         net.load_state_dict(t_sd(synth.fill_state_dict(shapes, 220 + i)), strict=True)

@@ -957,9 +957,9 @@ def test_cyclegan_resnet_padding_and_dropout_variants_golden(dev, golden):
             assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
     with pytest.raises(NotImplementedError):
         ResnetGenerator(3, 3, 64, norm_type="instance", padding_type="circular")
-    net.train()
+    drop = ResnetGenerator(3, 3, 64, norm_type="instance", n_blocks=1, use_dropout=True).to(dev).train()
     with pytest.raises(NotImplementedError):
-        net(x)                                   # use_dropout=True in train mode is random: refused
+        drop(x)                                  # use_dropout=True in train mode is random: refused
 
 
 def test_wbcunet_and_guided_filter_golden(dev, golden):
