@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_guided_filter_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -71,6 +71,9 @@ int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, i
 /* SRResNet / SRGAN with the reference defaults (norm none, ReLU, CNA,
  * pixelshuffle, res_scale 1: utils/defaults.py:53-67). */
 int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale);
+/* The same with the constructor arguments that keep the graph on the built kernels (SRResNet_arch.py:16-46,69-91): act = `act_type` (1 LeakyReLU(0.2),
+ * 2 ReLU), res_scale (x + res * res_scale), upconv_up != 0 = upsample_mode 'upconv' (Upsample, conv, act) instead of 'pixelshuffle'.  (104) */
+int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale, int act, float res_scale, int upconv_up);
 
 void innfer_net_destroy(innfer_net_t net);
 
@@ -128,6 +131,10 @@ int innfer_net_set_pair_convs(innfer_net_t net, int mode);
 /* `finalact` of the reference constructors (RRDBNet_arch.py:45-48: an activation module after the last conv):
  * 0 none (default), 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 6 sigmoid. */
 int innfer_net_set_final_act(innfer_net_t net, int act);
+
+/* `outm` of RRDBNet.forward / SRResNet.forward (RRDBNet_arch.py:50-62): a range limiter applied to the network's output, after `finalact`:
+ * 0 none (default), 1 'scaltanh' (tanh(x) + 1) / 2, 2 'tanh', 3 'sigmoid', 4 'clamp' to [0, 1] -- in the last conv's epilogue.  (104) */
+int innfer_net_set_outm(innfer_net_t net, int outm);
 
 /* Algorithmic FLOPs of one forward (2*MAC of every conv). */
 double innfer_net_flops(innfer_net_t net, int N, int H, int W);

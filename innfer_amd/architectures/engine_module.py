@@ -105,7 +105,11 @@ class EngineModule(nn.Module):
             pass
 
     # ---- forward ---------------------------------------------------------------
-    def forward(self, x):
+    _OUTM = {None: 0, 'scaltanh': 1, 'tanh': 2, 'sigmoid': 3, 'clamp': 4}
+
+    def forward(self, x, outm=None):
+        """outm: the range limiter of RRDBNet.forward / SRResNet.forward (RRDBNet_arch.py:50-62); any other value means none, as there."""
+        self._outm = self._OUTM.get(outm, 0)
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise ValueError('expected a 4D [N,C,H,W] tensor')
         if not x.is_cuda:
@@ -126,6 +130,7 @@ class EngineModule(nn.Module):
         self._weights_device = x.device
         L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
         L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
+        L.check(L.lib.innfer_net_set_outm(self._handle, int(getattr(self, '_outm', 0))))
         x = x.contiguous()
         N, _, H, W = x.shape
         s = L.lib.innfer_net_scale(self._handle)
@@ -156,6 +161,7 @@ class EngineModule(nn.Module):
             L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
             L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
             L.check(L.lib.innfer_net_set_u8_io(self._handle, int(bool(normalize)), int(bool(fp16))))
+            L.check(L.lib.innfer_net_set_outm(self._handle, 0))
             x = img.contiguous()
             batched = x.dim() == 4
             N, (H, W, Cc) = (x.shape[0] if batched else 1), x.shape[-3:]

@@ -81,8 +81,8 @@ def mrrdb_key_of(old_key, nb):
     return "RRDB_trunk." + old_key[len("model.1.sub."):-2]
 
 
-def srresnet_shapes(in_nc=3, out_nc=3, nf=64, nb=16, scale=4):
-    """SRGAN/SRResNet keys (reference SRResNet_arch.py:15-46, defaults.py:53-67)."""
+def srresnet_shapes(in_nc=3, out_nc=3, nf=64, nb=16, scale=4, upsample_mode='pixelshuffle'):
+    """SRGAN/SRResNet keys (reference SRResNet_arch.py:15-46, defaults.py:53-67); upsample_mode 'upconv': Upsample, conv, act per stage."""
     import math
     s = {"model.0.weight": (nf, in_nc, 3, 3), "model.0.bias": (nf,)}
     for b in range(nb):
@@ -94,8 +94,12 @@ def srresnet_shapes(in_nc=3, out_nc=3, nf=64, nb=16, scale=4):
     n_up = 1 if scale == 3 else int(math.log(scale, 2))
     idx = 2
     for _ in range(n_up):
-        s[f"model.{idx}.weight"] = (nf * 4, nf, 3, 3)
-        s[f"model.{idx}.bias"] = (nf * 4,)
+        if upsample_mode == 'upconv':
+            s[f"model.{idx + 1}.weight"] = (nf, nf, 3, 3)
+            s[f"model.{idx + 1}.bias"] = (nf,)
+        else:
+            s[f"model.{idx}.weight"] = (nf * 4, nf, 3, 3)
+            s[f"model.{idx}.bias"] = (nf * 4,)
         idx += 3
     s[f"model.{idx}.weight"] = (nf, nf, 3, 3)
     s[f"model.{idx}.bias"] = (nf,)

@@ -64,6 +64,7 @@ struct ConvLaunch {
     int reflect;                                  // 1: ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel);
                                                   // 2: ReplicationPad2d(1) (3x3 slab convs)
     int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)
+    int outm;                                     // OUT_NCHW: `outm` of RRDBNet / SRResNet.forward applied after `act`: 1 (tanh + 1) / 2, 2 tanh, 3 sigmoid, 4 clamp(0, 1)
     int out_u8, out_denorm, out_round16;          // OUT_NCHW with <= 4 channels: write a uint8 HWC BGR(A) image instead -- tensor2np as the conv's epilogue
                                                   // (utils.py:197-248): [round to fp16,] optional denormalisation, clip(255 x).round() half to even, channel flip
     const f16* pair_wpk; const float* pair_bias;  // net.hip only: non-null = this 32-output LeakyReLU conv AND the next one of the dense block (inputs: the same

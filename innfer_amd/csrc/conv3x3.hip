@@ -89,6 +89,7 @@ struct KP {
     int y0, y1;
     int tiles_x, tiles_y;
     int out_f32;
+    int outm;                // planar kernels: RRDBNet / SRResNet.forward(outm=...) after the activation
     int out_u8, out_denorm, out_round16;   // planar kernels with <= 4 channels: uint8 HWC BGR(A) image instead of planar floats (tensor2np as the epilogue)
     int N;
     int pf;                  // L2 prefetch of the next chunk's input lines
@@ -1071,6 +1072,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                             else if (p.act == 2) f = f > 0.f ? f : 0.f;
                             else if (p.act == 3) f = tanhf(f);
                             else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
+                            if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
+                            else if (p.outm == 2) f = tanhf(f);
+                            else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
+                            else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
                             long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
                             if (p.phase_c > 0) {
                                 const int ph = ch / p.phase_c, c = ch - ph * p.phase_c;
@@ -1350,6 +1355,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (L.out_u8 && (L.out_mode != OUT_NCHW || L.K > 4 || L.phase_c > 0 || L.res1 || L.res2 || L.conv7))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the uint8 image epilogue belongs to planar outputs of <= 4 channels");
     k.out_u8 = L.out_u8; k.out_denorm = L.out_denorm; k.out_round16 = L.out_round16;
+    k.outm = L.outm;
     k.rev = L.rev ? 1 : 0;
     k.phase_c = L.out_mode == OUT_NCHW ? L.phase_c : 0;
     k.reflect = L.reflect == 2 ? 2 : (L.reflect ? 1 : 0);
@@ -1362,6 +1368,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     const int rpw64 = INNFER_KNOB("INNFER_RPW64", 3);
     const int rpw32 = INNFER_KNOB("INNFER_RPW32", 5);
     const int pc = INNFER_KNOB("INNFER_PC", 1);     // producer / consumer kernel for slab outputs
+    if (L.outm && (L.out_mode != OUT_NCHW || !pc || nt != 1 || L.res1 || L.res2 || L.outm < 0 || L.outm > 4))
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: outm belongs to the planar last conv (<= 16 channels)");
     if (L.dilation_groups > 0) {   // K = 32 * groups: output channel group g (its own 32-output panel) is the conv of dilation g + 1
         if (!pc || L.out_mode != OUT_SLAB || L.K != 32 * L.dilation_groups || L.dilation_groups > 8 || L.res1 || L.res2 || L.up || L.reflect ||
             L.y0 != 0 || k.y1 != L.H || (long)L.H * L.W * 64 >= 0x7fffffffL)

@@ -49,6 +49,8 @@ struct innfer_net {
     int nr = 3;                  // dense blocks per RRDB (RRDBNet_arch.py:73-88)
     int trunk_act = 1;           // `act_type` of the constructors as a ConvLaunch.act code: 1 LeakyReLU(0.2), 2 ReLU
     bool ps_up = false;          // RRDBNet(upsample_mode='pixelshuffle'): conv nf -> 4 nf, PixelShuffle(2), act instead of Upsample, conv, act
+    float res_scale = 1.f;       // SRResNet: x + res * res_scale (SRResNet_arch.py:88-91)
+    int outm = 0;                // `outm` of RRDBNet / SRResNet.forward (RRDBNet_arch.py:50-62): 0 none, 1 scaltanh, 2 tanh, 3 sigmoid, 4 clamp
     int u8_normalize = 0, u8_round16 = 1;   // innfer_net_forward with INNFER_U8 images: normalize / denormalize flags of np2tensor / tensor2np, fp16 mode
     int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
@@ -118,16 +120,22 @@ extern "C" int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc
 }
 
 extern "C" int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale) {
+    return innfer_srresnet_create_ex(out, in_nc, out_nc, nf, nb, scale, 2, 1.0f, 0);
+}
+
+extern "C" int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale, int act, float res_scale, int upconv_up) {
     if (!out) return set_error(INNFER_ERR_INVALID, "srresnet_create: null out");
     if (scale != 1 && scale != 2 && scale != 4 && scale != 8)
         return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: scale %d (only powers of two)", scale);
     if (nf != 64 && nf != 32) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: nf=%d", nf);
-    if (scale > 1 && nf != 64) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: pixelshuffle path needs nf=64");
+    if (scale > 1 && nf != 64 && !upconv_up) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: pixelshuffle path needs nf=64");
+    if (act != 1 && act != 2) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: act %d (1 LeakyReLU(0.2), 2 ReLU)", act);
     if (in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 16 || nb < 1)
         return set_error(INNFER_ERR_INVALID, "srresnet_create: in_nc=%d out_nc=%d nb=%d", in_nc, out_nc, nb);
     innfer_net* net = new innfer_net();
     net->kind = 1; net->in_nc = in_nc; net->out_nc = out_nc; net->nf = nf; net->nb = nb;
     net->gc = 0; net->scale = scale; net->n_up = n_upscale(scale);
+    net->trunk_act = act; net->res_scale = res_scale; net->ps_up = !upconv_up;
     add_conv(net, "model.0", nf, in_nc, true);
     for (int b = 0; b < nb; ++b) {
         add_conv(net, "model.1.sub." + std::to_string(b) + ".res.0", nf, nf);
@@ -135,10 +143,20 @@ extern "C" int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, 
     }
     add_conv(net, "model.1.sub." + std::to_string(nb), nf, nf);
     int idx = 2;
-    for (int u = 0; u < net->n_up; ++u) { add_conv(net, "model." + std::to_string(idx), nf * 4, nf); idx += 3; }
+    for (int u = 0; u < net->n_up; ++u) {        // pixelshuffle_block: conv, PixelShuffle, act -- upconv_block: Upsample, conv, act (block.py:333-361)
+        if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * 4, nf);
+        else add_conv(net, "model." + std::to_string(idx + 1), nf, nf);
+        idx += 3;
+    }
     add_conv(net, "model." + std::to_string(idx), nf, nf);
     add_conv(net, "model." + std::to_string(idx + 2), out_nc, nf);
     *out = net;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_set_outm(innfer_net_t net, int outm) {
+    if (!net || outm < 0 || outm > 4) return set_error(INNFER_ERR_INVALID, "set_outm: 0 none, 1 scaltanh, 2 tanh, 3 sigmoid, 4 clamp");
+    net->outm = outm;
     return INNFER_OK;
 }
 
@@ -235,7 +253,7 @@ extern "C" double innfer_net_flops(innfer_net_t net, int N, int H, int W) {
         if (i >= tail0) {
             const int u = i - tail0;
             const double f2 = net->scale == 3 ? 9.0 : 4.0;     // pixels per input pixel after one upsample stage
-            if (u < net->n_up) mult = std::pow(f2, (net->kind == 0 && !net->ps_up) ? u + 1 : u);
+            if (u < net->n_up) mult = std::pow(f2, !net->ps_up ? u + 1 : u);
             else mult = std::pow(f2, net->n_up);
         }
         f += 2.0 * c.ksize * c.ksize * c.K * c.C * px * mult;
@@ -516,10 +534,10 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         for (int b = 0; b < net->nb; ++b) {
             const int a = cur, m = (cur + 1) % 3, o = (cur + 2) % 3;
             const ConvSlot& c0 = net->convs[ci++];
-            chain.push_back(mk(c0, slab[a], G, slab[m], G, N, H, W, 2));
+            chain.push_back(mk(c0, slab[a], G, slab[m], G, N, H, W, net->trunk_act));
             const ConvSlot& c1 = net->convs[ci++];
             ConvLaunch L = mk(c1, slab[m], G, slab[o], G, N, H, W, 0);
-            L.res1 = slab[a]; L.res1_gstride = G; L.s1 = 1.f;
+            L.res1 = slab[a]; L.res1_gstride = G; L.s1 = net->res_scale;          // x + res * res_scale
             chain.push_back(L);
             cur = o;
         }
@@ -549,12 +567,12 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             t = dst; h *= 3; w *= 3;
             continue;
         }
-        if (net->kind == 0 && !net->ps_up) {        // Upsample(nearest 2x) -> conv -> act
+        if (!net->ps_up) {           // Upsample(nearest 2x) -> conv -> act
             ConvLaunch L = mk(cs, t, gi, dst, go, N, 2 * h, 2 * w, net->trunk_act);
             L.up = 1;
             rc = do_conv(L, s);
         } else {                     // conv nf->4nf -> PixelShuffle(2) -> act (SRGAN: ReLU; RRDBNet(upsample_mode='pixelshuffle'): its act_type)
-            ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, net->kind == 0 ? net->trunk_act : 2);
+            ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, net->trunk_act);
             L.out_mode = OUT_SHUFFLE2;
             rc = do_conv(L, s);
         }
@@ -564,7 +582,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     {
         const ConvSlot& cs = net->convs[ci++];
         const long gh = (long)N * h * w * 32;
-        ConvLaunch L = mk(cs, t, gh, ws + cv.hr, gh, N, h, w, net->kind == 0 ? net->trunk_act : 2);
+        ConvLaunch L = mk(cs, t, gh, ws + cv.hr, gh, N, h, w, net->trunk_act);
         rc = do_conv(L, s);
         if (rc) return rc;
     }
@@ -572,6 +590,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         const ConvSlot& cs = net->convs[ci++];
         ConvLaunch L = mk(cs, (const f16*)(ws + cv.hr), (long)N * h * w * 32, d_out, 0, N, h, w, net->final_act);
         L.out_mode = OUT_NCHW; L.out_f32 = out_dtype == INNFER_F32;
+        L.outm = net->outm;
         L.out_u8 = out_dtype == INNFER_U8; L.out_denorm = net->u8_normalize; L.out_round16 = net->u8_round16;     // tensor2np as the conv's epilogue
         rc = do_conv(L, s);
         if (rc) return rc;

@@ -68,6 +68,8 @@ SIGNATURES = {
                                            C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "innfer_rrdbnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 10),
+    "innfer_srresnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 6 + [C.c_float, C.c_int]),
+    "innfer_net_set_outm": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),

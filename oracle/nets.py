@@ -57,7 +57,7 @@ def _n_upscale(scale):
     return 1 if scale == 3 else int(math.log(scale, 2))
 
 
-def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None, nr=3, act_type="leakyrelu", upsample_mode="upconv"):
+def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None, nr=3, act_type="leakyrelu", upsample_mode="upconv", outm=None):
     """RRDBNet.forward with the flat Sequential of RRDBNet_arch.py:25-48.
 
     taps: optional dict filled with named intermediates (golden G3 stages).
@@ -94,7 +94,7 @@ def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None,
     y = _conv3(sd, f"model.{idx + 2}", t)         # HR_conv1
     if finalact:                                  # outact (RRDBNet_arch.py:45-48; block.py:81-101)
         y = {"relu": F.relu, "leakyrelu": _lrelu, "lrelu": _lrelu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[finalact.lower()](y)
-    return y
+    return _outm(y, outm)
 
 
 def mrrdbnet_forward(sd, x, nb=24):
@@ -122,23 +122,39 @@ def mrrdbnet_forward(sd, x, nb=24):
     return conv("conv_last", _lrelu(conv("HRconv", fea)))
 
 
-def srresnet_forward(sd, x, nb=16, scale=4):
-    """SRResNet.forward with defaults norm=None, act=relu, mode=CNA,
-    pixelshuffle, res_scale=1 (SRResNet_arch.py:15-91, defaults.py:53-67)."""
+def _outm(y, outm):
+    """The range limiters of RRDBNet.forward / SRResNet.forward (RRDBNet_arch.py:50-62, SRResNet_arch.py:47-59)."""
+    if outm == "scaltanh":
+        return (torch.tanh(y) + 1.0) / 2.0
+    if outm == "tanh":
+        return torch.tanh(y)
+    if outm == "sigmoid":
+        return torch.sigmoid(y)
+    if outm == "clamp":
+        return torch.clamp(y, min=0.0, max=1.0)
+    return y
+
+
+def srresnet_forward(sd, x, nb=16, scale=4, act_type="relu", res_scale=1, upsample_mode="pixelshuffle", outm=None):
+    """SRResNet.forward with norm=None, mode=CNA (SRResNet_arch.py:15-91; defaults.py:53-67: relu, pixelshuffle, res_scale 1)."""
+    a = {"relu": F.relu, "leakyrelu": _lrelu}[act_type]
     fea = _conv3(sd, "model.0", x)
     t = fea
     for b in range(nb):
-        r = F.relu(_conv3(sd, f"model.1.sub.{b}.res.0", t))
+        r = a(_conv3(sd, f"model.1.sub.{b}.res.0", t))
         r = _conv3(sd, f"model.1.sub.{b}.res.2", r)
-        t = t + r * 1                              # :88-91 (res_scale = 1)
+        t = t + r * res_scale                      # :88-91
     t = fea + _conv3(sd, f"model.1.sub.{nb}", t)
     idx = 2
     for _ in range(_n_upscale(scale)):
         f = 3 if scale == 3 else 2
-        t = F.relu(F.pixel_shuffle(_conv3(sd, f"model.{idx}", t), f))  # block.py:333-346
+        if upsample_mode == "upconv":              # block.py:348-361
+            t = a(_conv3(sd, f"model.{idx + 1}", F.interpolate(t, scale_factor=float(f), mode="nearest")))
+        else:
+            t = a(F.pixel_shuffle(_conv3(sd, f"model.{idx}", t), f))  # block.py:333-346
         idx += 3
-    t = F.relu(_conv3(sd, f"model.{idx}", t))
-    return _conv3(sd, f"model.{idx + 2}", t)
+    t = a(_conv3(sd, f"model.{idx}", t))
+    return _outm(_conv3(sd, f"model.{idx + 2}", t), outm)
 
 
 def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True, norm_type="batch"):

@@ -548,6 +548,26 @@ def g18():
     with torch.no_grad():
         out["batchnorm"] = net(torch.from_numpy(synth.uniform((1, 3, 16, 16), 194))).numpy()
     out["batchnorm_keys"] = np.array(sorted(shapes))
+    # SRResNet(act_type / res_scale / upsample_mode='upconv') and the `outm` argument of both forwards
+    from architectures.SRResNet_arch import SRResNet as RefSRResNet
+    for j, (tag, kw) in enumerate({"sr_upconv_lrelu": dict(upscale=2, act_type="leakyrelu", upsample_mode="upconv", res_scale=0.5),
+                                   "sr_ps_scale": dict(upscale=4, act_type="relu", upsample_mode="pixelshuffle", res_scale=0.25)}.items()):
+        net = RefSRResNet(3, 3, 64, 2, norm_type=None, mode="CNA", **kw).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        mine = synth.srresnet_shapes(nb=2, scale=kw["upscale"], upsample_mode=kw["upsample_mode"])
+        assert shapes == mine, (tag, set(shapes) ^ set(mine))
+        net.load_state_dict(t_sd(synth.fill_state_dict(mine, 186 + j)), strict=True)
+        x = torch.from_numpy(synth.uniform((1, 3, 14, 18), 196 + j))
+        with torch.no_grad():
+            out[tag] = net(x).numpy()
+            for om in ("scaltanh", "tanh", "sigmoid", "clamp"):
+                out[f"{tag}_{om}"] = net(x, outm=om).numpy()
+        out[tag + "_keys"] = np.array(sorted(shapes))
+    net, _ = rrdb_ref(1, 2)
+    x = torch.from_numpy(synth.uniform((1, 3, 12, 12), 198))
+    with torch.no_grad():
+        for om in ("scaltanh", "clamp"):
+            out[f"rrdb_{om}"] = net(x, outm=om).numpy()
     save("g18_rrdb_variants", **out)
     # PAN(self_attention=False), PAN(double_scpa=True) (PAN_arch.py:115-141,193-203)
     from architectures.PAN_arch import PAN as RefPAN

@@ -437,6 +437,33 @@ def test_rrdbnet_constructor_variants_golden(dev, golden):
         RRDBNet(3, 3, 64, 1, norm_type="instance")
 
 
+def test_srresnet_variants_and_outm_golden(dev, golden):
+    """SRResNet(act_type='leakyrelu', res_scale, upsample_mode='upconv' / 'pixelshuffle') and forward(x, outm=...) of SRResNet / RRDBNet -- the
+    range limiter runs in the last conv's epilogue -- against the reference (golden G18)."""
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    from innfer_amd.architectures.SRResNet_arch import SRResNet
+    from test_oracle_golden import G18_SR, OUTMS
+    g = golden("g18_rrdb_variants")
+    for j, (tag, kw) in enumerate(G18_SR.items()):
+        net = SRResNet(3, 3, 64, 2, upscale=kw["scale"], norm_type=None, act_type=kw["act_type"], mode="CNA", res_scale=kw["res_scale"],
+                       upsample_mode=kw["upsample_mode"])
+        assert sorted(net.state_dict()) == list(g[tag + "_keys"])
+        net.load_state_dict(_sd(synth.srresnet_shapes(nb=2, scale=kw["scale"], upsample_mode=kw["upsample_mode"]), 186 + j), strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((1, 3, 14, 18), 196 + j)).to(dev).half()
+        for om in OUTMS:
+            y = (net(x, outm=om) if om else net(x)).float().cpu().numpy()
+            assert np.abs(y - g[tag + ("_" + om if om else "")]).max() < 5e-3, (tag, om)
+        assert torch.equal(net(x, outm="no such limiter"), net(x))              # anything else means none, as in the reference
+    net, _ = _rrdb(dev, 1, 2)
+    x = torch.from_numpy(synth.uniform((1, 3, 12, 12), 198)).to(dev).half()
+    for om in ("scaltanh", "clamp"):
+        assert np.abs(net(x, outm=om).float().cpu().numpy() - g["rrdb_" + om]).max() < 5e-3, om
+    plain = net(x)
+    assert not torch.equal(plain, net(x, outm="clamp")) and torch.equal(net(x), plain)          # outm does not stick to the module
+
+
 def test_esrgan_plus_golden(dev, golden):
     """ESRGAN+ residual paths (x2 += conv1x1(x), x4 += x2) against the reference (golden G5)."""
     from innfer_amd import synth

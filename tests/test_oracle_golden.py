@@ -129,6 +129,31 @@ def test_g18_rrdbnet_constructor_variants(golden):
     assert np.abs(y - g["batchnorm"]).max() < 5e-6
 
 
+G18_SR = {"sr_upconv_lrelu": dict(scale=2, act_type="leakyrelu", upsample_mode="upconv", res_scale=0.5),
+          "sr_ps_scale": dict(scale=4, act_type="relu", upsample_mode="pixelshuffle", res_scale=0.25)}
+OUTMS = (None, "scaltanh", "tanh", "sigmoid", "clamp")
+
+
+def test_g18_srresnet_variants_and_outm(golden):
+    """SRResNet(act_type, res_scale, upsample_mode='upconv') (SRResNet_arch.py:16-91) and the `outm` argument of SRResNet.forward /
+    RRDBNet.forward (RRDBNet_arch.py:50-62) against the reference."""
+    g = golden("g18_rrdb_variants")
+    for j, (tag, kw) in enumerate(G18_SR.items()):
+        shapes = synth.srresnet_shapes(nb=2, scale=kw["scale"], upsample_mode=kw["upsample_mode"])
+        assert sorted(shapes) == list(g[tag + "_keys"])
+        sd = _sd(shapes, 186 + j)
+        x = torch.from_numpy(synth.uniform((1, 3, 14, 18), 196 + j))
+        for om in OUTMS:
+            with torch.no_grad():
+                y = oracle.srresnet_forward(sd, x, nb=2, outm=om, **kw).numpy()
+            assert np.abs(y - g[tag + ("_" + om if om else "")]).max() < 2e-6, (tag, om)
+    sd = _sd(synth.rrdbnet_shapes(nb=1, scale=2))
+    x = torch.from_numpy(synth.uniform((1, 3, 12, 12), 198))
+    for om in ("scaltanh", "clamp"):
+        with torch.no_grad():
+            assert np.abs(oracle.rrdbnet_forward(sd, x, nb=1, scale=2, outm=om).numpy() - g["rrdb_" + om]).max() < 2e-6
+
+
 G18_PAN = {"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
            "double_noattn_x2": dict(double_scpa=True, self_attention=False, scale=2)}
 
