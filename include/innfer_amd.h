@@ -151,8 +151,10 @@ typedef struct innfer_unet* innfer_unet_t;
 int innfer_unet_create(innfer_unet_t* out, int in_nc, int out_nc, int num_downs, int ngf);
 /* The same with norm_type 'instance' (UNet_arch.py:38-41,101-104): nn.InstanceNorm2d layers (no parameters, no running statistics: always the
  * statistics of the image, train() and eval() alike) and a bias on every conv (it only matters where no norm follows: the outermost and the
- * innermost down conv, the outermost up conv).  innfer_unet_create(...) = innfer_unet_create_ex(..., 0).  (104) */
-int innfer_unet_create_ex(innfer_unet_t* out, int in_nc, int out_nc, int num_downs, int ngf, int instance_norm);
+ * innermost down conv, the outermost up conv).  upconv: upsample_mode 'upconv' (UNet_arch.py:119-122,131-134,143-146; block.py:348-361) -- every
+ * ConvTranspose2d(4, 2, 1) is Upsample(nearest 2x) + Conv2d(3x3, zero padding), keys `<i>.1.weight`.
+ * innfer_unet_create(...) = innfer_unet_create_ex(..., 0, 0).  (104) */
+int innfer_unet_create_ex(innfer_unet_t* out, int in_nc, int out_nc, int num_downs, int ngf, int instance_norm, int upconv);
 void innfer_unet_destroy(innfer_unet_t u);
 int innfer_unet_num_params(innfer_unet_t u);
 int innfer_unet_param_info(innfer_unet_t u, int idx, char* key, size_t key_cap, int* ndim, int* shape4);

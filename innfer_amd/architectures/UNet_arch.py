@@ -15,13 +15,15 @@ class UnetGenerator(ParamEngineModule):
         super().__init__()
         if norm_type not in ('BN', 'batch', 'IN', 'instance'):           # the reference's own error (UNet_arch.py:42-43)
             raise NameError("Unknown norm layer")
-        if upsample_mode != 'deconv':
-            raise NotImplementedError("UnetGenerator: upsample_mode='deconv' is built on the HIP path")
+        if upsample_mode not in ('deconv', 'upconv'):
+            # the reference documents 'pixelshuffle' (UNet_arch.py:94) but builds no layer for it: its constructor dies on an unbound `upconv`
+            raise NotImplementedError("UnetGenerator: upsample_mode is 'deconv' or 'upconv' (the reference builds no other)")
+        self.upsample_mode = upsample_mode
         self.input_nc, self.output_nc, self.num_downs, self.ngf = input_nc, output_nc, num_downs, ngf
         self.instance_norm = norm_type in ('IN', 'instance')
         # use_dropout: nn.Dropout(0.5) at the end of the ngf*8 blocks (UNet_arch.py:153-154) -- no parameters; the identity under eval()
         self.use_dropout = bool(use_dropout)
-        self._init_engine(input_nc, output_nc, num_downs, ngf, int(self.instance_norm))
+        self._init_engine(input_nc, output_nc, num_downs, ngf, int(self.instance_norm), int(upsample_mode == 'upconv'))
 
     def _fn(self, name):
         return super()._fn('create_ex' if name == 'create' else name)

@@ -68,6 +68,27 @@ __global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, con
     }
 }
 
+// The same behind a halo-tile conv (upsample_mode 'upconv'): fp16 conv result (slab) -> norm -> activation -> ONE fp16 destination at a channel offset
+__global__ void unet_post_slab(const f16* src, long sg, int C, long HW, int N, const float* alpha, const float* shift, int nstride, PostDst d) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C / 8;
+    if (i >= (long)N * HW * c8) return;
+    const int c = (int)(i % c8) * 8;
+    const long pix = i / c8;
+    const long n = pix / HW;
+    const f16x8 x = *(const f16x8*)(src + (c >> 5) * sg + pix * 32 + (c & 31));
+    const float* ap = alpha + n * nstride + c;
+    const float* sp = shift + n * nstride + c;
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = (float)x[e] * ap[e] + sp[e];
+        h[e] = (f16)(d.act == 1 ? fmaxf(v, 0.2f * v) : fmaxf(v, 0.f));
+    }
+    const int ch = d.coff + c;
+    *(f16x8*)(d.p + (ch >> 5) * d.g + pix * 32 + (ch & 31)) = h;
+}
+
 // Deep levels (at most DEEP_PX output pixels per image): split-K reduction + BatchNorm statistics + normalisation / activation in ONE
 // launch.  A workgroup owns 32 channels of one image: 32 channel lanes x 32 pixel lanes, every thread keeps its <= DEEP_PX/32 pixels in
 // registers; the partial results are added in segment order, the statistics are the two-pass form on registers (as norm_stats.h), the
@@ -201,6 +222,7 @@ struct Layer {            // one conv / conv-transpose
     float *d_ev_alpha = nullptr, *d_ev_shift = nullptr;    // eval-mode BatchNorm: weight / sqrt(running_var + eps), bias - running_mean * that
     float* d_ones = nullptr;                               // instance-norm nets: the unit scale beside d_bias of a conv that no norm layer follows
     bool normed = false;                                   // a norm layer follows this conv
+    bool upconv = false;                                   // upsample_mode 'upconv': Upsample(nearest 2x) + Conv2d(3x3) instead of ConvTranspose2d(4, 2, 1)
 };
 
 }  // namespace
@@ -212,6 +234,7 @@ struct innfer_unet {
     std::vector<int> dc;               // down-path channels per level
     bool uploaded = false;
     bool eval_mode = false;            // BatchNorm on running statistics (nn.Module.eval()) instead of the current image's
+    bool upconv = false;               // upsample_mode 'upconv' (UNet_arch.py:114-118,127-131,142-146; block.py:348-361)
     bool instance_norm = false;        // norm_type 'instance' (UNet_arch.py:38-41): nn.InstanceNorm2d -- no parameters, no running statistics, always the
                                        // statistics of the image; every conv then has a bias (use_bias, :101-104), which only matters where no norm follows
 };
@@ -223,16 +246,17 @@ static int add_param(innfer_unet* u, const std::string& key, std::vector<int> sh
 }
 
 extern "C" int innfer_unet_create(innfer_unet** out, int in_nc, int out_nc, int num_downs, int ngf) {
-    return innfer_unet_create_ex(out, in_nc, out_nc, num_downs, ngf, 0);
+    return innfer_unet_create_ex(out, in_nc, out_nc, num_downs, ngf, 0, 0);
 }
 
-extern "C" int innfer_unet_create_ex(innfer_unet** out, int in_nc, int out_nc, int num_downs, int ngf, int instance_norm) {
+extern "C" int innfer_unet_create_ex(innfer_unet** out, int in_nc, int out_nc, int num_downs, int ngf, int instance_norm, int upconv) {
     if (!out) return set_error(INNFER_ERR_INVALID, "unet_create: null out");
     if (num_downs < 5 || num_downs > 9 || ngf % 32 || ngf <= 0 || in_nc < 1 || in_nc > 32 || out_nc < 1 || out_nc > 32)
         return set_error(INNFER_ERR_UNSUPPORTED, "unet_create: in_nc=%d out_nc=%d num_downs=%d ngf=%d", in_nc, out_nc, num_downs, ngf);
     innfer_unet* u = new innfer_unet();
     u->in_nc = in_nc; u->out_nc = out_nc; u->num_downs = num_downs; u->ngf = ngf;
     u->instance_norm = instance_norm != 0;
+    u->upconv = upconv != 0;
     const bool in_ = u->instance_norm;
     const int L = num_downs;
     u->dc.resize(L);
@@ -268,7 +292,8 @@ extern "C" int innfer_unet_create_ex(innfer_unet** out, int in_nc, int out_nc, i
         d.cin_pad = (d.cin + 31) / 32 * 32; d.cout_pad = (d.cout + 63) / 64 * 64;
         p.cin_pad = (p.cin + 31) / 32 * 32; p.cout_pad = (p.cout + 63) / 64 * 64;
         if (outer && d.cin <= 4) { d.patch = true; d.cin_pad = 64; }
-        if (outer && 4 * p.cout <= 16) p.phases = true;          // conv3x3.hip's planar epilogue: one 16-channel tile
+        if (outer && 4 * p.cout <= 16 && !u->upconv) p.phases = true;          // conv3x3.hip's planar epilogue: one 16-channel tile
+        if (u->upconv) { p.upconv = true; p.transposed = false; }
         blk = next;
     }
     // up params, innermost first (= module order after the submodule)
@@ -277,8 +302,9 @@ extern "C" int innfer_unet_create_ex(innfer_unet** out, int in_nc, int out_nc, i
         for (int j = 0; j < k; ++j) b += (j == 0 ? "1.model." : "3.model.");
         Layer& p = u->up[k];
         const bool outer = k == 0, inner = k == L - 1;
-        const std::string wi = outer ? "3" : (inner ? "3" : "5"), ni = inner ? "4" : "6";
-        p.w = add_param(u, b + wi + ".weight", {p.cin, p.cout, 4, 4});
+        // upconv_block is a Sequential(Upsample, Conv2d) in the block's Sequential: its conv is `<i>.1`
+        const std::string wi = std::string(outer ? "3" : (inner ? "3" : "5")) + (u->upconv ? ".1" : ""), ni = inner ? "4" : "6";
+        p.w = u->upconv ? add_param(u, b + wi + ".weight", {p.cout, p.cin, 3, 3}) : add_param(u, b + wi + ".weight", {p.cin, p.cout, 4, 4});
         p.normed = !outer;
         if (outer) {
             p.bias = add_param(u, b + wi + ".bias", {p.cout});
@@ -410,6 +436,16 @@ static int upload_all(innfer_unet* u) {
                 if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
                 INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
                 int rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
+            } else if (l.upconv) {
+                // Upsample(nearest 2x) + Conv2d(3x3, zero padding): conv3x3.hip's halo-tile kernel with the upsampled read (`up`);
+                // the bias (outermost / instance-norm nets) rides in the conv epilogue
+                std::vector<char> packed(conv_packed_bytes(l.cout, l.cin));
+                conv_pack(w.data(), l.cout, l.cin, packed.data());
+                if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+                INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+                std::vector<float> b3((size_t)std::max(16, l.cout), 0.f);
+                if (l.bias >= 0) std::copy(u->params[l.bias].host.begin(), u->params[l.bias].host.end(), b3.begin());
+                int rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
             } else if (!l.transposed) {
                 gg::pack_panels(panel, l.cout, l.cin, l.cin_pad, 16,
                             [&](int co, int ci, int t) { return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
@@ -510,7 +546,7 @@ extern "C" double innfer_unet_flops(innfer_unet* u, int N, int H, int W) {
     for (int k = 0; k < u->num_downs; ++k) {
         const double px = (double)N * (H >> (k + 1)) * (W >> (k + 1));           // down output = up input grid
         f += 2.0 * 16.0 * u->down[k].cin * u->down[k].cout * px;
-        f += 2.0 * 16.0 * u->up[k].cin * u->up[k].cout * px;
+        f += 2.0 * (u->upconv ? 36.0 : 16.0) * u->up[k].cin * u->up[k].cout * px;          // upconv: 9 taps on the 2x grid
     }
     return f;
 }
@@ -624,6 +660,35 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const f16* in = k == L - 1 ? (const f16*)(ws + cv.r_inner) : (const f16*)(ws + cv.CAT[k]);
         const long in_g = (long)N * h * w * 32;
         const int hf = 2 * h, wf = 2 * w;
+        if (l.upconv) {       // nearest 2x + 3x3 conv on the halo-tile kernel; outermost: bias + tanh -> NCHW in its planar epilogue
+            ConvLaunch Lc{};
+            Lc.in = in; Lc.in_gstride = in_g; Lc.C = l.cin;
+            Lc.wpk = (const f16*)l.d_w3; Lc.bias = l.d_b3;
+            Lc.K = l.cout; Lc.N = N; Lc.H = hf; Lc.W = wf; Lc.up = 1;
+            Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = hf;
+            const long HW = (long)hf * wf, G = (long)N * HW * 32;
+            if (k == 0) {
+                Lc.out = d_out; Lc.act = 3; Lc.out_mode = OUT_NCHW; Lc.out_f32 = out_dtype == INNFER_F32;
+                int rc = conv_launch(Lc, s);
+                if (rc) return rc;
+            } else {
+                f16* Y = (f16*)raw;       // fp16 conv result; the norm statistics are taken from it (as behind resnet.hip's upconv layers)
+                Lc.out = Y; Lc.out_gstride = G; Lc.act = 0; Lc.out_mode = OUT_SLAB;
+                int rc = conv_launch(Lc, s);
+                if (rc) return rc;
+                if (!ev) {
+                    rc = norm::launch_stats_slab(Y, G, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
+                    if (rc) return rc;
+                }
+                const long total = (long)N * HW * (l.cout / 8);
+                PostDst dr{(f16*)(ws + cv.CAT[k - 1]), G, u->dc[k - 1], 2};
+                hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, G, l.cout, HW, N,
+                                   (const float*)(ev ? l.d_ev_alpha : mean), (const float*)(ev ? l.d_ev_shift : rstd), ev ? 0 : l.cout, dr);
+                INNFER_HIP(hipGetLastError());
+            }
+            h = hf; w = wf;
+            continue;
+        }
         if (l.phases) {       // outermost: 3x3 conv with 4*cout phase channels, bias, tanh and the phase scatter in the epilogue
             ConvLaunch Lc{};
             Lc.in = in; Lc.in_gstride = in_g; Lc.C = l.cin_pad;

@@ -75,7 +75,7 @@ SIGNATURES = {
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
-    "innfer_unet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 5),
+    "innfer_unet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 6),
     "innfer_unet_destroy": (None, [C.c_void_p]),
     "innfer_unet_num_params": (C.c_int, [C.c_void_p]),
     "innfer_unet_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -157,7 +157,7 @@ def srresnet_forward(sd, x, nb=16, scale=4, act_type="relu", res_scale=1, upsamp
     return _outm(_conv3(sd, f"model.{idx + 2}", t), outm)
 
 
-def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True, norm_type="batch"):
+def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True, norm_type="batch", upsample_mode="deconv"):
     """UnetGenerator(norm=batch, deconv).forward.  training=True: BatchNorm in TRAINING mode
     (batch statistics), as run.py runs pix2pix (meval=False, run.py:299-303); training=False:
     eval mode on the checkpoint's running statistics (Model's default meval=True, run.py:96-97).
@@ -175,29 +175,33 @@ def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True, norm_type="batch")
         return F.batch_norm(t, None, None, sd[key + ".weight"], sd[key + ".bias"],
                             training=True, momentum=0.0, eps=eps)
 
+    # upsample_mode 'upconv' (UNet_arch.py:119-122,131-134,143-146): upconv_block (block.py:348-361) = Sequential(Upsample(nearest 2x),
+    # Conv2d(3x3, zero padding)), so the conv's keys are `<i>.1.*`
+    def up(t, key):
+        if upsample_mode == "upconv":
+            t = F.interpolate(t, scale_factor=2, mode="nearest")
+            return F.conv2d(t, sd[key + ".1.weight"], sd.get(key + ".1.bias"), padding=1)
+        return F.conv_transpose2d(t, sd[key + ".weight"], sd.get(key + ".bias"), stride=2, padding=1)
+
     def block(t, prefix, depth):
         outermost = depth == 0
         innermost = depth == num_downs - 1
         if outermost:
             d = F.conv2d(t, sd[prefix + "model.0.weight"], sd.get(prefix + "model.0.bias"), stride=2, padding=1)
             m = block(d, prefix + "model.1.", depth + 1)
-            u = F.conv_transpose2d(F.relu(m), sd[prefix + "model.3.weight"],
-                                   sd[prefix + "model.3.bias"], stride=2, padding=1)
-            return torch.tanh(u)
+            return torch.tanh(up(F.relu(m), prefix + "model.3"))
         # nn.LeakyReLU(0.2, inplace=True) is the block's first layer (UNet_arch.py:109,
         # 135,148): it rewrites the block input in place, so the skip branch of
         # torch.cat([x, model(x)]) (:160-161) carries lrelu(x), not x.
         t = F.leaky_relu(t, 0.2)
         if innermost:
             d = F.conv2d(t, sd[prefix + "model.1.weight"], sd.get(prefix + "model.1.bias"), stride=2, padding=1)
-            u = F.conv_transpose2d(F.relu(d), sd[prefix + "model.3.weight"], sd.get(prefix + "model.3.bias"), stride=2, padding=1)
-            u = bn(u, prefix + "model.4")
+            u = bn(up(F.relu(d), prefix + "model.3"), prefix + "model.4")
             return torch.cat([t, u], 1)
         d = F.conv2d(t, sd[prefix + "model.1.weight"], sd.get(prefix + "model.1.bias"), stride=2, padding=1)
         d = bn(d, prefix + "model.2")
         m = block(d, prefix + "model.3.", depth + 1)
-        u = F.conv_transpose2d(F.relu(m), sd[prefix + "model.5.weight"], sd.get(prefix + "model.5.bias"), stride=2, padding=1)
-        u = bn(u, prefix + "model.6")
+        u = bn(up(F.relu(m), prefix + "model.5"), prefix + "model.6")
         return torch.cat([t, u], 1)
 
     return block(x, "model.", 0)

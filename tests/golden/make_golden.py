@@ -378,11 +378,14 @@ def g22():
 
 
 def g23():
-    """UnetGenerator(norm_type='instance') and (use_dropout=True, eval) (UNet_arch.py:20-157): 5 downs, ngf 32, 64x64 and 64x96 inputs."""
+    """UnetGenerator(norm_type='instance'), (use_dropout=True, eval) and (upsample_mode='upconv') (UNet_arch.py:20-157): 5 downs, ngf 32, 64x96 input."""
     from architectures.UNet_arch import UnetGenerator as RefUnet
     out = {}
     for i, (tag, kw, ev) in enumerate([("instance", dict(norm_type="instance"), False), ("instance_eval", dict(norm_type="instance"), True),
-                                       ("batch_dropout_eval", dict(norm_type="batch", use_dropout=True), True)]):
+                                       ("batch_dropout_eval", dict(norm_type="batch", use_dropout=True), True),
+                                       ("batch_upconv", dict(norm_type="batch", upsample_mode="upconv"), False),
+                                       ("batch_upconv_eval", dict(norm_type="batch", upsample_mode="upconv"), True),
+                                       ("instance_upconv", dict(norm_type="instance", upsample_mode="upconv"), False)]):
         net = RefUnet(3, 3, 5, ngf=32, **kw)
         net = net.eval() if ev else net.train()
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}

@@ -681,7 +681,7 @@ def test_unet256_eval_mode_uses_running_statistics(dev, golden):
 
 
 def test_unet_instance_norm_and_dropout_variants_golden(dev, golden):
-    """UnetGenerator(norm_type='instance') in train and eval mode and (use_dropout=True) under eval() (UNet_arch.py:20-157) against the reference
+    """UnetGenerator(norm_type='instance') in train and eval mode, (use_dropout=True) under eval() and upsample_mode='upconv' (UNet_arch.py:20-157) against the reference
     (golden G23): the reference's parameter names (biases instead of norm parameters for instance norm), outputs within the UNet tolerance."""
     from innfer_amd import synth
     from innfer_amd.architectures.UNet_arch import UnetGenerator
@@ -697,11 +697,14 @@ def test_unet_instance_norm_and_dropout_variants_golden(dev, golden):
         for xin in (x, x.half()):
             err = np.abs(net(xin).float().cpu().numpy() - g[tag])
             assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(x)                                   # use_dropout=True in train mode is random: refused
+        if kw.get("use_dropout"):
+            net.train()
+            with pytest.raises(NotImplementedError):
+                net(x)                               # use_dropout=True in train mode is random: refused
     with pytest.raises(NameError):
         UnetGenerator(3, 3, 5, norm_type="group")
+    with pytest.raises(NotImplementedError):
+        UnetGenerator(3, 3, 5, upsample_mode="pixelshuffle")   # documented by the reference, never built there either
 
 
 def test_unet_variants_vs_oracle(dev):
@@ -724,6 +727,27 @@ def test_unet_variants_vs_oracle(dev):
         err = (y - ref).abs()
         assert y.shape == ref.shape == (2, out_nc, h, w)
         assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (in_nc, out_nc, num_downs, err.max().item(), err.mean().item())
+
+
+def test_unet256_upconv_full_depth_vs_oracle(dev):
+    """upsample_mode='upconv' at unet_256's full depth (8 levels, 1x1 bottleneck -> the 3x3 conv runs on 2x2 .. 256x256 upsampled grids
+    with 512 .. 1024 input channels), batch 2, train-mode and eval-mode BatchNorm, against the oracle (itself pinned on the reference, G23)."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.UNet_arch import UnetGenerator
+    net = UnetGenerator(3, 3, 8, ngf=64, upsample_mode="upconv")
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_running_stats(synth.fill_state_dict(shapes, 77), 78).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    x = torch.from_numpy(synth.uniform((2, 3, 256, 256), 79, -1.0, 1.0))
+    for training in (True, False):
+        net.train(training)
+        y = net(x.to(dev).half()).float().cpu()
+        with torch.no_grad():
+            ref = torch.cat([oracle.unet_forward(sd, x[i:i + 1], num_downs=8, training=training, upsample_mode="upconv") for i in range(2)], 0)
+        err = (y - ref).abs()
+        assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (training, err.max().item(), err.mean().item())
 
 
 def test_unet256_big_batch_uses_wide_tiles_and_stays_identical(dev):

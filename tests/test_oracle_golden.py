@@ -333,7 +333,10 @@ def test_g22_resnet_padding_and_dropout_variants(golden):
 
 
 G23_CASES = [("instance", dict(norm_type="instance"), False), ("instance_eval", dict(norm_type="instance"), True),
-             ("batch_dropout_eval", dict(norm_type="batch", use_dropout=True), True)]
+             ("batch_dropout_eval", dict(norm_type="batch", use_dropout=True), True),
+             ("batch_upconv", dict(norm_type="batch", upsample_mode="upconv"), False),
+             ("batch_upconv_eval", dict(norm_type="batch", upsample_mode="upconv"), True),
+             ("instance_upconv", dict(norm_type="instance", upsample_mode="upconv"), False)]
 
 
 def _g23_state(g, tag, i):
@@ -351,7 +354,8 @@ def test_g23_unet_instance_norm_and_dropout_variants(golden):
     for i, (tag, kw, ev) in enumerate(G23_CASES):
         x = torch.from_numpy(synth.uniform((1, 3, 64, 96), 240 + i, -1.0, 1.0))
         with torch.no_grad():
-            y = oracle.unet_forward(_g23_state(g, tag, i), x, num_downs=5, training=not ev, norm_type=kw["norm_type"]).numpy()
+            y = oracle.unet_forward(_g23_state(g, tag, i), x, num_downs=5, training=not ev, norm_type=kw["norm_type"],
+                                    upsample_mode=kw.get("upsample_mode", "deconv")).numpy()
         assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-5, tag
 
 
