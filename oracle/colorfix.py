@@ -12,6 +12,8 @@ smooth: float32 path):
   * GaussianBlur ksize 3, sigma 0: the fixed kernel [0.25, 0.5, 0.25], separable (rows, then columns),
     BORDER_REFLECT_101 (x[-1] = x[1]).
 Everything else (srgb2linear / linear2srgb, the difference, the sums) follows the reference line by line.
+Cross-checked (tests/test_colorfix_cpu.py) against a second implementation of the same published scheme: ATen's upsample_bicubic2d
+(A = -0.75, half-pixel grid, clamped taps) to 5e-6 on up- and down-scales, and a reflect-padded conv2d for the blur -- still not OpenCV itself.
 """
 import numpy as np
 

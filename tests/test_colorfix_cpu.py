@@ -54,3 +54,31 @@ def test_color_fix_properties():
     err_fixed = np.abs(fixed.astype(float) - b.astype(float))[8:-8, 8:-8].mean((0, 1))
     err_cast = np.abs(cast.astype(float) - b.astype(float))[8:-8, 8:-8].mean((0, 1))
     assert err_fixed.max() < 1.5 and err_cast.max() > 8, (err_fixed, err_cast)
+
+
+def test_cubic_resize_agrees_with_aten_bicubic():
+    """A second, independent implementation of the same published algorithm: ATen's upsample_bicubic2d (align_corners=False, no antialias) is the
+    Keys kernel with A = -0.75 on the half-pixel grid with clamped taps -- the scheme OpenCV's INTER_CUBIC float path documents.  This does not pin
+    the oracle against OpenCV itself (absent here); it rules out a slip in the restatement (weights, tap order, source coordinate, border)."""
+    import torch
+    import torch.nn.functional as F
+    rs = np.random.RandomState(3)
+    for (h, w, hd, wd) in [(9, 13, 36, 52), (9, 13, 18, 39), (40, 36, 10, 9), (17, 5, 17, 20), (8, 8, 3, 29)]:
+        x = rs.rand(h, w, 3).astype(np.float32)
+        ours = resize_cubic(x, (wd, hd))
+        ref = F.interpolate(torch.from_numpy(x).permute(2, 0, 1)[None], size=(hd, wd), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert ours.shape == ref.shape == (hd, wd, 3)
+        assert np.abs(ours - ref).max() < 5e-6, (h, w, hd, wd, np.abs(ours - ref).max())
+
+
+def test_gauss3_agrees_with_a_reflect_padded_convolution():
+    """cv2.GaussianBlur(x, (3, 3), 0) = the fixed [1, 2, 1] / 4 kernel under BORDER_REFLECT_101, checked against torch's 'reflect' padding (the same
+    border rule: the edge pixel is not repeated) and a plain conv2d."""
+    import torch
+    import torch.nn.functional as F
+    x = np.random.RandomState(4).rand(11, 7, 3).astype(np.float32)
+    k = torch.tensor([0.25, 0.5, 0.25])
+    k2 = (k[:, None] * k[None, :])[None, None].repeat(3, 1, 1, 1)
+    t = F.pad(torch.from_numpy(x).permute(2, 0, 1)[None], (1, 1, 1, 1), mode="reflect")
+    ref = F.conv2d(t, k2, groups=3)[0].permute(1, 2, 0).numpy()
+    assert np.abs(gauss3(x) - ref).max() < 1e-6
