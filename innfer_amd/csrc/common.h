@@ -56,6 +56,8 @@ struct ConvLaunch {
     int y0, y1;                                   // output rows [y0,y1)
     int out_mode; int out_f32;                    // OUT_NCHW: planar, f16 or f32
     int rev;                                      // traverse the tiles in reverse order (speed only: see conv3x3.hip)
+    int deconv_phases;                            // ConvTranspose2d(4, 2, 1) as four 2x2-tap phase convs: K = 4 * phase_c (phase-major, phase_c % 64 == 0), panels from
+                                                  // conv_pack_taps(mask 0x1B), H x W = the INPUT grid, fp16 slab output of 2H x 2W pixels and phase_c channels
     int conv1x1;                                  // 1x1 conv: the centre tap only is staged and multiplied (panels from conv_pack_1x1); slab outputs
     int dilation_groups;                          // G > 0: K = 32*G, output channel group g is the conv of dilation g+1 (own 32-output panel, panels of
                                                   // conv_pack(K=32) back to back, bias[32*G]): PPON's eight dilated convs in one launch
@@ -90,6 +92,7 @@ void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
 int conv_launch(const ConvLaunch& L, hipStream_t s);
 size_t conv_packed_bytes_taps(int K, int C, int mask);
 void conv_pack_1x1(const float* w_oi, int K, int C, void* packed);    // host; w [K][C]
+void conv_pack_taps(const float* w, int K, int C, int mask, void* packed);   // host; w [K][C][9], only the taps of `mask` are packed (conv_packed_bytes_taps)
 size_t conv_packed_bytes7x7(int K, int C);
 void conv_pack7x7(const float* w_oihw, int K, int C, void* packed);   // host; C % 32 == 0
 

@@ -171,12 +171,14 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
     }
 }
 
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false>
+// DCV (conv3x3_pc<.., TM = 0x1B>: one output phase of ConvTranspose2d(4, 2, 1) per 16*NT-channel group): (ty0, tx0) are coordinates of the phase's
+// shifted lattice (see decode); virtual pixel (y', x') of phase (a, b) is output pixel (2y' - a, 2x' - b) of the 2H x 2W slab, channel ch % phase_c.
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase, int dil = 1) {
     constexpr int MT = 2 * RPW;
-    const int oc0 = cbase + p.out_coff;
-    const int yw = ty0 + wave * RPW, xl = tx0 + li;
+    int oc0 = cbase + p.out_coff;
+    int yw = ty0 + wave * RPW, xl = tx0 + li;
     long pix0 = ((long)n * p.H + yw) * p.W + xl;
 #ifdef INNFER_ABLATE
     if (p.abl & 16) pix0 = (long)blockIdx.x * 64 + wave * RPW * p.W + li;      // every tile of a workgroup stores to the same (cache-resident) lines
@@ -192,6 +194,15 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
         colstep = 16L * 32 * d;
         ylim = (p.fullH - py + d - 1) / d;
         xlim = (p.fullW - px + d - 1) / d;
+    }
+    if constexpr (DCV) {
+        const int ph = cbase / p.phase_c, a = ph >> 1, b = ph & 1;
+        oc0 -= ph * p.phase_c;
+        yw -= a; xl -= b;                               // source pixel of the virtual one (>= 0: the lattice starts at (a, b))
+        pix0 = ((long)n * 2 * p.H + 2 * yw + a) * (2 * p.W) + 2 * xl + b;
+        rowstep = (long)p.W * 32 * 4;
+        colstep = 16 * 32 * 2;
+        ylim = p.H;
     }
     f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix0 * 32 + (oc0 & 31);
     const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + pix0 * 32 + (cbase & 31) : nullptr;
@@ -663,6 +674,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         const int ty = tile / p.tiles_x;
         ty0_ = p.y0 + ty * TH;
         tx0_ = (tile - ty * p.tiles_x) * TW;
+        if constexpr (TM == 0x1B) {
+            // one phase of a 2x transposed conv per channel group: phase (a, b) of ConvTranspose2d(4, 2, 1) is the conv of taps (dy, dx) in
+            // {-1, 0}^2 taken at the virtual pixel (y + a, x + b) -- the same four-tap kernel on a tile lattice shifted by (a, b)
+            const int ph = kg_ * WROWS / p.phase_c;
+            ty0_ += ph >> 1; tx0_ += ph & 1;
+        }
     };
     // POLY: also the tile's dilation; with rate groups the channel group IS the rate and every rate has its own tile grid
     auto decode_poly = [&](int jj, int& kg_, int& n_, int& ty0_, int& tx0_, int& d_) {
@@ -1044,7 +1061,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
 #undef EPI
             } else if constexpr (OUTMODE == OUT_SLAB) {
-#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
@@ -1295,6 +1312,27 @@ void conv_pack(const float* w, int K, int C, void* packed) {
 // Panels holding only the taps of `mask` (bit r*3+s), in (r, s) order: [group][chunk][tap rank][row R][slot][8 ch]; mask 0x10 = a 1x1 conv,
 // w then is [K][C] (one value per pair) -- the counterpart of conv3x3_pc<.., TM>
 size_t conv_packed_bytes_taps(int K, int C, int mask) { return conv_packed_bytes(K, C) / 9 * __builtin_popcount(mask & 0x1FF); }
+// any mask: w is [K][C][9] (taps outside the mask are not read)
+void conv_pack_taps(const float* w, int K, int C, int mask, void* packed) {
+    const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
+    f16* dst = (f16*)packed;
+    for (int g = 0; g < groups; ++g)
+        for (int c = 0; c < nch; ++c)
+            for (int tap = 0; tap < 9; ++tap) {
+                if (!((mask >> tap) & 1)) continue;
+                for (int R = 0; R < rows; ++R) {
+                    const int t = R >> 4, rho = R & 15;
+                    const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
+                    for (int sg = 0; sg < 4; ++sg) {
+                        const int cg = sg ^ (((R >> 2) & 1) << 1);
+                        for (int e = 0; e < 8; ++e) {
+                            const int ic = c * 32 + cg * 8 + e;
+                            *dst++ = (f16)(oc < K ? w[((size_t)oc * C + ic) * 9 + tap] : 0.f);
+                        }
+                    }
+                }
+            }
+}
 void conv_pack_1x1(const float* w, int K, int C, void* packed) {
     const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
     f16* dst = (f16*)packed;
@@ -1357,7 +1395,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.out_u8 = L.out_u8; k.out_denorm = L.out_denorm; k.out_round16 = L.out_round16;
     k.outm = L.outm;
     k.rev = L.rev ? 1 : 0;
-    k.phase_c = L.out_mode == OUT_NCHW ? L.phase_c : 0;
+    k.phase_c = (L.out_mode == OUT_NCHW || L.deconv_phases) ? L.phase_c : 0;
     k.reflect = L.reflect == 2 ? 2 : (L.reflect ? 1 : 0);
     if (L.reflect == 2 && (L.conv7 || L.out_mode != OUT_SLAB)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: replication padding is built for 3x3 slab convs");
     if (L.reflect && (L.up || L.H < (L.conv7 ? 4 : (L.reflect == 2 ? 1 : 2)) || L.W < (L.conv7 ? 4 : (L.reflect == 2 ? 1 : 2))))
@@ -1387,6 +1425,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         k.H = (L.H + d - 1) / d; k.W = (L.W + d - 1) / d; k.Hs = k.H; k.Ws = k.W;
         k.y0 = 0; k.y1 = k.H;
         return launch_pc<3, 2, 4, OUT_SLAB, false, true>(k, L.N * d * d, s);
+    }
+    if (L.deconv_phases) {   // ConvTranspose2d(4, 2, 1): K = 4 * phase_c, group g = phase g / (phase_c / 64); H, W: the input grid; output slab 2H x 2W
+        if (!pc || L.out_mode != OUT_SLAB || nt != 4 || L.phase_c <= 0 || L.phase_c % 64 || L.K != 4 * L.phase_c || L.res1 || L.res2 || L.up || L.reflect ||
+            L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.dilation > 1 || L.dilation_groups)
+            return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: slab output, 64-channel phase groups, no residual / upsampling / padding modes");
+        return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B>(k, L.N, s);
     }
     if (L.conv1x1) {        // centre tap only: panels from conv_pack_1x1
         if (!pc || L.out_mode != OUT_SLAB || (nt != 2 && nt != 4))

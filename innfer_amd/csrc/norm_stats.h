@@ -71,6 +71,78 @@ static __global__ __launch_bounds__(1024) void stats_kernel(const void* src, lon
     }
 }
 
+// The slab form with 16-byte loads: a thread holds 8 channels of 4 pixels (lane = pixel lane * 4 + channel octet), sums over the wave's 16 pixel
+// lanes by a fixed xor butterfly, over the 16 waves in index order through LDS -- deterministic, same two-pass scheme as stats_kernel.
+// (stats_kernel<true> reads 2 bytes per lane: 1.8 TB/s on a 134 MB slab; this one reads the slab at the streaming rate.)
+static __global__ __launch_bounds__(1024) void stats_slab8_kernel(const f16* slab, long gs, long HW, float eps, const float* gamma, const float* beta,
+                                                                  float* alpha, float* shift, int C, float* part, int nseg) {
+    __shared__ float red[16][32];
+    __shared__ float tot[32];
+    const int n = blockIdx.y, cb = blockIdx.x * 32, sg = blockIdx.z;
+    const int t = threadIdx.x, q = t & 3, pl = t >> 2, wv = t >> 6, lane = t & 63;
+    const long p0 = (long)sg * SEG;
+    const int cnt = (int)min((long)SEG, HW - p0);
+    const f16* base = slab + (cb >> 5) * gs + ((long)n * HW + p0) * 32 + q * 8;
+    f16x8 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = pl + 256 * i;
+        if (px < cnt) v[i] = *(const f16x8*)(base + (long)px * 32);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = (f16)0.f;
+    }
+    auto reduce = [&](float (&s)[8]) {           // per-channel total over the workgroup, returned in s for this thread's 8 channels
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int m = 4; m < 64; m <<= 1) s[e] += __shfl_xor(s[e], m);
+        }
+        if (lane < 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wv][q * 8 + e] = s[e];
+        }
+        __syncthreads();
+        if (t < 32) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a += red[w][t];
+            tot[t] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = tot[q * 8 + e];
+        __syncthreads();
+    };
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = ((float)v[0][e] + (float)v[1][e]) + ((float)v[2][e] + (float)v[3][e]);
+    reduce(s);
+    float mu[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mu[e] = s[e] / (float)cnt;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = pl + 256 * i < cnt ? (float)v[i][e] - mu[e] : 0.f;
+            a += d * d;
+        }
+        s[e] = a;
+    }
+    reduce(s);
+    if (pl == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cb + q * 8 + e;
+            if (c >= C) continue;
+            if (nseg == 1) bn_write(mu[e], s[e] / (float)HW, eps, gamma, beta, alpha, shift, n, C, c);
+            else { float* o = part + (((long)n * C + c) * nseg + sg) * 2; o[0] = mu[e]; o[1] = s[e]; }
+        }
+    }
+}
+
 // segments -> (alpha, shift): one thread per (image, channel), segments in index order
 static __global__ void combine_kernel(const float* part, int nseg, long HW, float eps, const float* gamma, const float* beta,
                            float* alpha, float* shift, int C, int N) {
@@ -108,7 +180,7 @@ inline int launch_stats(const float* raw, int cpad, long HW, float eps, const fl
 inline int launch_stats_slab(const f16* slab, long gs, long HW, float eps, const float* gamma, const float* beta, float* alpha, float* shift,
                              int C, int N, float* part, hipStream_t s) {
     const int nseg = (int)((HW + SEG - 1) / SEG);
-    hipLaunchKernelGGL(stats_kernel<true>, dim3((C + 31) / 32, N, nseg), dim3(1024), 0, s, (const void*)slab, gs, 0, HW, eps, gamma, beta, alpha, shift, C, part, nseg);
+    hipLaunchKernelGGL(stats_slab8_kernel, dim3((C + 31) / 32, N, nseg), dim3(1024), 0, s, slab, gs, HW, eps, gamma, beta, alpha, shift, C, part, nseg);
     INNFER_HIP(hipGetLastError());
     if (nseg > 1) {
         hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(((long)N * C + 255) / 256)), dim3(256), 0, s, (const float*)part, nseg, HW, eps,

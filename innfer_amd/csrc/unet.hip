@@ -222,6 +222,7 @@ struct Layer {            // one conv / conv-transpose
     float *d_ev_alpha = nullptr, *d_ev_shift = nullptr;    // eval-mode BatchNorm: weight / sqrt(running_var + eps), bias - running_mean * that
     float* d_ones = nullptr;                               // instance-norm nets: the unit scale beside d_bias of a conv that no norm layer follows
     bool normed = false;                                   // a norm layer follows this conv
+    bool tile4 = false;                                    // ConvTranspose2d also packed as four 2x2-tap phase panels for conv3x3.hip's halo-tile kernel (d_w3)
     bool upconv = false;                                   // upsample_mode 'upconv': Upsample(nearest 2x) + Conv2d(3x3) instead of ConvTranspose2d(4, 2, 1)
 };
 
@@ -294,6 +295,9 @@ extern "C" int innfer_unet_create_ex(innfer_unet** out, int in_nc, int out_nc, i
         if (outer && d.cin <= 4) { d.patch = true; d.cin_pad = 64; }
         if (outer && 4 * p.cout <= 16 && !u->upconv) p.phases = true;          // conv3x3.hip's planar epilogue: one 16-channel tile
         if (u->upconv) { p.upconv = true; p.transposed = false; }
+        // levels whose input grid fills the halo-tile kernel's 16 x 32 tiles at the usual 256 x 256 (and larger) inputs; deeper ones stay on the
+        // gather GEMM (a 16 x 16 grid would pad every tile to twice its pixels)
+        if (p.transposed && !p.phases && k >= 1 && k <= 3 && p.cout % 64 == 0) p.tile4 = true;
         blk = next;
     }
     // up params, innermost first (= module order after the submodule)
@@ -451,6 +455,25 @@ static int upload_all(innfer_unet* u) {
                             [&](int co, int ci, int t) { return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
                 int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
             } else {
+                if (l.tile4) {
+                    // phase (a, b) of ConvTranspose2d(4, 2, 1) = taps (dy, dx) in {-1, 0}^2 at the virtual pixel (y + a, x + b) (conv3x3_pc<.., TM = 0x1B>):
+                    // tap (r, s) of the 3x3 lattice (r, s in {0, 1}) carries w[ci][c][3 - 2r - a][3 - 2s - b]  (oy = 2 iy - 1 + ky)
+                    const int K4 = 4 * l.cout;
+                    std::vector<float> w3((size_t)K4 * l.cin * 9, 0.f), b3((size_t)K4, 0.f);
+                    for (int co = 0; co < K4; ++co) {
+                        const int ph = co / l.cout, c = co - ph * l.cout, a = ph >> 1, b = ph & 1;
+                        for (int ci = 0; ci < l.cin; ++ci)
+                            for (int r = 0; r < 2; ++r)
+                                for (int sx = 0; sx < 2; ++sx)
+                                    w3[((size_t)co * l.cin + ci) * 9 + r * 3 + sx] = w[(((size_t)ci * l.cout + c) * 4 + (3 - 2 * r - a)) * 4 + (3 - 2 * sx - b)];
+                        if (l.bias >= 0) b3[co] = u->params[l.bias].host[c];
+                    }
+                    std::vector<char> packed(conv_packed_bytes_taps(K4, l.cin, 0x1B));
+                    conv_pack_taps(w3.data(), K4, l.cin, 0x1B, packed.data());
+                    if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+                    INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+                    int rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
+                }
                 std::vector<f16> all;                               // the four phase panels back to back: one grouped launch reads them
                 for (int ph = 0; ph < 4; ++ph) {
                     int ky[4], kx[4], dy[4], dx[4];
@@ -660,12 +683,15 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const f16* in = k == L - 1 ? (const f16*)(ws + cv.r_inner) : (const f16*)(ws + cv.CAT[k]);
         const long in_g = (long)N * h * w * 32;
         const int hf = 2 * h, wf = 2 * w;
-        if (l.upconv) {       // nearest 2x + 3x3 conv on the halo-tile kernel; outermost: bias + tanh -> NCHW in its planar epilogue
+        // a ConvTranspose whose input grid fills the 16 x 32 tiles (>= 70 % real pixels) runs as four 2x2-tap phase convs on the halo-tile kernel
+        const bool tile4 = l.tile4 && (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * ((w + 31) / 32 * 32) * 7;
+        if (l.upconv || tile4) {   // upconv: nearest 2x + 3x3 conv on the halo-tile kernel; outermost: bias + tanh -> NCHW in its planar epilogue
             ConvLaunch Lc{};
             Lc.in = in; Lc.in_gstride = in_g; Lc.C = l.cin;
             Lc.wpk = (const f16*)l.d_w3; Lc.bias = l.d_b3;
             Lc.K = l.cout; Lc.N = N; Lc.H = hf; Lc.W = wf; Lc.up = 1;
             Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = hf;
+            if (tile4) { Lc.K = 4 * l.cout; Lc.phase_c = l.cout; Lc.deconv_phases = 1; Lc.H = h; Lc.W = w; Lc.up = 0; Lc.y1 = h; }
             const long HW = (long)hf * wf, G = (long)N * HW * 32;
             if (k == 0) {
                 Lc.out = d_out; Lc.act = 3; Lc.out_mode = OUT_NCHW; Lc.out_f32 = out_dtype == INNFER_F32;
