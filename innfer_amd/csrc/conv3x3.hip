@@ -626,8 +626,14 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 // request stream into HBM never pauses.
 // NCW: consumer waves (8: two per SIMD; 4: one per SIMD with twice the rows each -- the same tile with 0.25 instead of 0.42 ds_read_b128 per MFMA,
 // 256 registers per wave).
-template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TM = 0x1FF, bool CV = false, int NSI = 2, int NCW = 8>
+template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TMF = 0x1FF, bool CV = false, int NSI = 2, int NCW = 8>
 __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
+    // TMF: tap mask (bits 0..8) + 0x200 = the stride-2 gather loader (S2): Conv2d(k 4, s 2, p 1) as the 2x2-tap conv of the space-to-depth input --
+    // chunk c is (phase (pa, pb) = c / ncg, channel group c % ncg); cell (cy, cx) of phase (pa, pb) is source pixel (2cy + pa - 1, 2cx + pb - 1)
+    // (the lattice of the image padded by one pixel), so output (y, x) reads cells y, y + 1 (taps r, s in {1, 2}: mask 0x1B0) and the padding
+    // is the loader's range check.  H, W: the OUTPUT grid; the source image is Hs x Ws = 2H x 2W.
+    constexpr int TM = TMF & 0x1FF;
+    constexpr bool S2 = (TMF & 0x200) != 0;
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -710,8 +716,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 const int px = (lw + NLW * k) * 16 + (lane >> 2);
                 const int ly = px / LWP, lx = px - ly * LWP;
                 const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
-                const int ry = p.up ? (ly + ypar) >> 1 : ly;
-                const int rx = p.up ? (lx + 1) >> 1 : lx;
+                const int ry = S2 ? 2 * ly : p.up ? (ly + ypar) >> 1 : ly;
+                const int rx = S2 ? 2 * lx : p.up ? (lx + 1) >> 1 : lx;
                 loff[k] = (px < NPX && lx < LVALID) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
                 if constexpr (POLY) {          // the tile's dilation scales the pixel part: voff = lpix * d + slot (setup)
                     lpix[k] = (px < NPX && lx < LVALID) ? (ly * p.fullW + lx) * 64 : -1;
@@ -782,6 +788,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 s9_edge = ty0 < 4 || ty0 + TH + 4 > p.H || tx0 < 4 || tx0 + TW + 4 > p.W;
                 return;
             }
+            if constexpr (S2) {          // cells (ty0 - 1 .. ty0 + TH) x (tx0 - 1 .. tx0 + TW) of both phases: source rows 2 ty0 - 3 .. 2 (ty0 + TH)
+                s9_ty0 = ty0; s9_tx0 = tx0; s9_n = n;
+                s9_edge = 2 * ty0 < 3 || 2 * (ty0 + TH) >= p.Hs || 2 * tx0 < 3 || 2 * (tx0 + TW) >= p.Ws;
+                in_tile = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)(2 * ty0 - 3) * p.Ws + (2 * tx0 - 3)) * 64;
+                return;
+            }
             if (ty0 == 0 || ty0 + TH + 1 > p.H || tx0 == 0 || tx0 + TW + 1 > p.W) {
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
@@ -827,6 +839,24 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                         }
                         const bool ok = loff[k] != OOB && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
                         voff[k] = ok ? (Y * p.Ws + X) * 64 + (loff[k] - (ly * p.Ws + lx) * 64) : OOB;
+                    }
+                }
+            }
+            if constexpr (S2) {
+                const int ph = c / p.ncg, cg = c - ph * p.ncg, pa = ph >> 1, pb = ph & 1;
+                if (!s9_edge) {
+                    src = in_tile + cg * p.in_gbytes + ((long)pa * p.Ws + pb) * 64;
+#pragma unroll
+                    for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
+                } else {                                                                  // offsets from the image origin, per lane
+                    src = (const char*)(p.in + (long)s9_n * p.in_img_stride) + cg * p.in_gbytes;
+#pragma unroll
+                    for (int k = 0; k < KQ; ++k) {
+                        const int px = (lw + NLW * k) * 16 + (lane >> 2);
+                        const int ly = px / LWP, lx = px - ly * LWP;
+                        const int Y = 2 * (s9_ty0 - 1 + ly) + pa - 1, X = 2 * (s9_tx0 - 1 + lx) + pb - 1;
+                        const bool ok = loff[k] != OOB && Y >= 0 && Y < p.Hs && X >= 0 && X < p.Ws;
+                        voff[k] = ok ? (Y * p.Ws + X) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64) : OOB;
                     }
                 }
             }
@@ -1205,7 +1235,7 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI, int NCW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = NCW * RPW;
-    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (__builtin_popcount(TM) * NT * 16 * 64);
+    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (__builtin_popcount(TM & 0x1FF) * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
     if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && TM == 0x1FF && !CV) {      // a batch of images whose size is not a whole number of tiles
@@ -1431,6 +1461,15 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
             L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.dilation > 1 || L.dilation_groups)
             return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: slab output, 64-channel phase groups, no residual / upsampling / padding modes");
         return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B>(k, L.N, s);
+    }
+    if (L.stride2) {         // Conv2d(k 4, s 2, p 1): H x W = the OUTPUT grid, source image 2H x 2W; panels from conv_pack_taps(K, 4C, 0x1B0), virtual channel
+                             // (2 pa + pb) * C + ci, tap (1 + dy, 1 + dx) = w[co][ci][2 dy + pa][2 dx + pb]
+        if (!pc || L.out_mode != OUT_SLAB || nt != 4 || L.res1 || L.res2 || L.up || L.reflect || L.act > 2 || L.y0 != 0 || k.y1 != L.H ||
+            L.dilation > 1 || L.dilation_groups || (long)L.H * L.W * 4 * 64 >= 0x7fffffffL)
+            return set_error(INNFER_ERR_UNSUPPORTED, "stride-2 conv: slab output of 64-channel tiles, no residual / upsampling / padding modes, sources below 33 M pixels");
+        k.Hs = 2 * L.H; k.Ws = 2 * L.W; k.in_img_stride = (long)k.Hs * k.Ws * 32;
+        k.nchunks = 4 * k.ncg;
+        return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
     }
     if (L.conv1x1) {        // centre tap only: panels from conv_pack_1x1
         if (!pc || L.out_mode != OUT_SLAB || (nt != 2 && nt != 4))

@@ -69,7 +69,7 @@ __global__ void unet_post(const float* raw, int cpad, int C, long HW, int N, con
 }
 
 // The same behind a halo-tile conv (upsample_mode 'upconv'): fp16 conv result (slab) -> norm -> activation -> ONE fp16 destination at a channel offset
-__global__ void unet_post_slab(const f16* src, long sg, int C, long HW, int N, const float* alpha, const float* shift, int nstride, PostDst d) {
+__global__ void unet_post_slab(const f16* src, long sg, int C, long HW, int N, const float* alpha, const float* shift, int nstride, PostDst d, PostDst d1) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c8 = C / 8;
     if (i >= (long)N * HW * c8) return;
@@ -79,14 +79,19 @@ __global__ void unet_post_slab(const f16* src, long sg, int C, long HW, int N, c
     const f16x8 x = *(const f16x8*)(src + (c >> 5) * sg + pix * 32 + (c & 31));
     const float* ap = alpha + n * nstride + c;
     const float* sp = shift + n * nstride + c;
-    f16x8 h;
+    f16x8 h, h1;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float v = (float)x[e] * ap[e] + sp[e];
         h[e] = (f16)(d.act == 1 ? fmaxf(v, 0.2f * v) : fmaxf(v, 0.f));
+        h1[e] = (f16)(d1.act == 1 ? fmaxf(v, 0.2f * v) : fmaxf(v, 0.f));
     }
     const int ch = d.coff + c;
     *(f16x8*)(d.p + (ch >> 5) * d.g + pix * 32 + (ch & 31)) = h;
+    if (d1.p) {
+        const int c1 = d1.coff + c;
+        *(f16x8*)(d1.p + (c1 >> 5) * d1.g + pix * 32 + (c1 & 31)) = h1;
+    }
 }
 
 // Deep levels (at most DEEP_PX output pixels per image): split-K reduction + BatchNorm statistics + normalisation / activation in ONE
@@ -207,6 +212,73 @@ __global__ void unet_pre_patch(const void* in, int in_f32, int C, int H, int W, 
     for (int q = 0; q < 4; ++q) *(f16x8*)(slab + grp * g + m * 32 + 8 * q) = *(const f16x8*)(hbuf + 8 * q);
 }
 
+// The same conv straight from the NCHW input, for 64 output channels: the 16 * C window values are the k dimension of v_mfma_f32_16x16x32_f16
+// (k = c * 16 + ky * 4 + kx, two k-steps), a wave takes 16 consecutive output pixels of a row, gathers their windows into the B fragments
+// (the input is 1/5 of the bytes this kernel writes and every value is re-read from L1 / L2), multiplies by the 64 x 64 weight panel it keeps in
+// registers and writes BOTH views of the result (no norm layer follows this conv): LeakyReLU(0.2) for the next down conv, ReLU for the
+// concatenation.  Replaces unet_pre_patch + two one-tap conv launches (178 -> ~60 us at 64 x 256^2): one pass, HBM-write bound.
+// wpk: [k-step][16-channel tile t][row rho][k-block lg][8], row rho of tile t = output channel 16 * (rho >> 2) + 4 * t + (rho & 3), so that lane
+// group lg ends up with channels 16 lg .. 16 lg + 15 of its pixel (32 contiguous bytes per view).
+__global__ __launch_bounds__(256) void unet_first_mfma(const void* in, int in_f32, int C, int H, int W, int N, const f16* wpk, const float* bias,
+                                                       f16* d0, f16* d1, long g) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const int ho = H >> 1, wo = W >> 1, spr = wo >> 4;
+    const long total = (long)N * ho * spr;
+    f16x8 a[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[ks][t] = *(const f16x8*)(wpk + ((ks * 4 + t) * 16 + li) * 32 + lg * 8);
+    f32x4 b4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[t][j] = bias ? bias[16 * lg + 4 * t + j] : 0.f;
+    const int ky0 = (lg & 1) * 2;
+    for (long seg = (long)blockIdx.x * 4 + (threadIdx.x >> 6); seg < total; seg += (long)gridDim.x * 4) {
+        const int sx = (int)(seg % spr);
+        const long r = seg / spr;
+        const int oy = (int)(r % ho);
+        const long n = r / ho;
+        const int ox = sx * 16 + li;
+        f16x8 bf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 2 + (lg >> 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int iy = 2 * oy - 1 + ky0 + (e >> 2), ix = 2 * ox - 1 + (e & 3);
+                f16 v = (f16)0.f;
+                if (c < C && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const long o = ((n * C + c) * H + iy) * W + ix;
+                    v = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+                }
+                bf[ks][e] = v;
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = b4[t];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][t], bf[ks], acc[t], 0, 0, 0);
+        const long m = (n * ho + oy) * wo + ox;
+        f16x8 h0[2], h1[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[t][j];
+                h0[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.2f * v);
+                h1[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.f);
+            }
+        const long o = (lg >> 1) * g + m * 32 + (lg & 1) * 16;
+        *(f16x8*)(d0 + o) = h0[0]; *(f16x8*)(d0 + o + 8) = h0[1];
+        *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + o + 8) = h1[1];
+    }
+}
+
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 
 struct Layer {            // one conv / conv-transpose
@@ -222,6 +294,7 @@ struct Layer {            // one conv / conv-transpose
     float *d_ev_alpha = nullptr, *d_ev_shift = nullptr;    // eval-mode BatchNorm: weight / sqrt(running_var + eps), bias - running_mean * that
     float* d_ones = nullptr;                               // instance-norm nets: the unit scale beside d_bias of a conv that no norm layer follows
     bool normed = false;                                   // a norm layer follows this conv
+    f16* d_wf = nullptr;                                   // patch layer with 64 outputs: the panel of unet_first_mfma
     bool tile4 = false;                                    // ConvTranspose2d also packed as four 2x2-tap phase panels for conv3x3.hip's halo-tile kernel (d_w3)
     bool upconv = false;                                   // upsample_mode 'upconv': Upsample(nearest 2x) + Conv2d(3x3) instead of ConvTranspose2d(4, 2, 1)
 };
@@ -298,6 +371,7 @@ extern "C" int innfer_unet_create_ex(innfer_unet** out, int in_nc, int out_nc, i
         // levels whose input grid fills the halo-tile kernel's 16 x 32 tiles at the usual 256 x 256 (and larger) inputs; deeper ones stay on the
         // gather GEMM (a 16 x 16 grid would pad every tile to twice its pixels)
         if (p.transposed && !p.phases && k >= 1 && k <= 3 && p.cout % 64 == 0) p.tile4 = true;
+        if (!d.patch && k >= 1 && k <= 3 && k < L - 1 && d.cout % 64 == 0 && d.cin % 32 == 0) d.tile4 = true;       // the 4x4 stride-2 convs of the same levels
         blk = next;
     }
     // up params, innermost first (= module order after the submodule)
@@ -332,6 +406,7 @@ extern "C" void innfer_unet_destroy(innfer_unet* u) {
         for (auto& l : *v) {
             if (l.d_w[0]) (void)hipFree(l.d_w[0]);
             if (l.d_w3) (void)hipFree(l.d_w3);
+            if (l.d_wf) (void)hipFree(l.d_wf);
             if (l.d_b3) (void)hipFree(l.d_b3);
             if (l.d_bias) (void)hipFree(l.d_bias);
             if (l.d_gamma) (void)hipFree(l.d_gamma);
@@ -418,6 +493,17 @@ static int upload_all(innfer_unet* u) {
                     INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
                     rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
                 }
+                if (l.cout == 64) {            // unet_first_mfma's panel: k = c * 16 + ky * 4 + kx
+                    std::vector<f16> wf(2 * 4 * 16 * 32);
+                    for (int ks = 0; ks < 2; ++ks)
+                        for (int t = 0; t < 4; ++t)
+                            for (int rho = 0; rho < 16; ++rho)
+                                for (int q = 0; q < 32; ++q) {
+                                    const int co = 16 * (rho >> 2) + 4 * t + (rho & 3), kk = ks * 32 + q, c = kk >> 4, tap = kk & 15;
+                                    wf[((ks * 4 + t) * 16 + rho) * 32 + q] = (f16)(c < l.cin ? w[(((size_t)co * l.cin + c) * 4 + (tap >> 2)) * 4 + (tap & 3)] : 0.f);
+                                }
+                    rc = upload_f16(&l.d_wf, wf); if (rc) return rc;
+                }
             } else if (l.phases) {
                 // The four output phases of ConvTranspose2d(k4, s2, p1) as ONE 3x3 convolution with 4*cout output channels over the
                 // un-upsampled input (conv3x3.hip's halo-tile kernel reads each input pixel once instead of once per tap): output channel
@@ -454,6 +540,25 @@ static int upload_all(innfer_unet* u) {
                 gg::pack_panels(panel, l.cout, l.cin, l.cin_pad, 16,
                             [&](int co, int ci, int t) { return w[(((size_t)co * l.cin + ci) * 4 + (t >> 2)) * 4 + (t & 3)]; });
                 int rc = upload_f16(&l.d_w[0], panel); if (rc) return rc;
+                if (l.tile4) {
+                    // Conv2d(4, 2, 1) = the 2x2-tap conv of the space-to-depth source (conv3x3_pc's stride-2 loader): virtual channel (2 pa + pb) * cin + ci,
+                    // tap (1 + dy, 1 + dx) of the 3x3 lattice carries w[co][ci][2 dy + pa][2 dx + pb]
+                    const int C4 = 4 * l.cin;
+                    std::vector<float> w3((size_t)l.cout * C4 * 9, 0.f), b3((size_t)l.cout, 0.f);
+                    for (int co = 0; co < l.cout; ++co)
+                        for (int ph = 0; ph < 4; ++ph)
+                            for (int ci = 0; ci < l.cin; ++ci)
+                                for (int dy = 0; dy < 2; ++dy)
+                                    for (int dx = 0; dx < 2; ++dx)
+                                        w3[((size_t)co * C4 + ph * l.cin + ci) * 9 + (1 + dy) * 3 + 1 + dx] =
+                                            w[(((size_t)co * l.cin + ci) * 4 + 2 * dy + (ph >> 1)) * 4 + 2 * dx + (ph & 1)];
+                    if (l.bias >= 0) b3 = u->params[l.bias].host;
+                    std::vector<char> packed(conv_packed_bytes_taps(l.cout, C4, 0x1B0));
+                    conv_pack_taps(w3.data(), l.cout, C4, 0x1B0, packed.data());
+                    if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+                    INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+                    rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
+                }
             } else {
                 if (l.tile4) {
                     // phase (a, b) of ConvTranspose2d(4, 2, 1) = taps (dy, dx) in {-1, 0}^2 at the virtual pixel (y + a, x + b) (conv3x3_pc<.., TM = 0x1B>):
@@ -619,7 +724,9 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         return INNFER_OK;
     };
 
-    if (u->down[0].patch) {   // NCHW input -> 64-channel patch slab at half resolution
+    const bool first_mfma = u->down[0].patch && u->down[0].d_wf && L > 1;
+    if (first_mfma) {          // the outermost down conv reads the NCHW input itself
+    } else if (u->down[0].patch) {   // NCHW input -> 64-channel patch slab at half resolution
         const long M = (long)N * (H / 2) * (W / 2);
         hipLaunchKernelGGL(unet_pre_patch, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, u->in_nc, H, W, N,
                            (f16*)(ws + cv.x0), M * 32);
@@ -637,6 +744,17 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const Layer& l = u->down[k];
         const int ho = h / 2, wo = w / 2;
         int rc;
+        if (k == 0 && first_mfma) {
+            const long HWo = (long)ho * wo, Go = (long)N * HWo * 32;
+            const long segs = (long)N * ho * (wo / 16);
+            const unsigned grid = (unsigned)std::min<long>((segs + 3) / 4, 256L * 8);
+            hipLaunchKernelGGL(unet_first_mfma, dim3(grid), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, u->in_nc, H, W, N, (const f16*)l.d_wf,
+                               (const float*)(l.bias >= 0 ? l.d_bias : nullptr), (f16*)(ws + cv.D[0]), (f16*)(ws + cv.CAT[0]), Go);
+            INNFER_HIP(hipGetLastError());
+            cur = (f16*)(ws + cv.D[0]); cur_g = Go;
+            h = ho; w = wo;
+            continue;
+        }
         if (l.patch && l.d_w3 && k < L - 1) {
             // no BatchNorm behind the outermost conv: the two views of its output (lrelu for the next conv, relu for the concatenation) come
             // straight out of the conv epilogue, one launch each (HBM-bound launches; the GEMM + post pair makes three passes)
@@ -652,6 +770,30 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
                 if (rc) return rc;
             }
             cur = dsts[0]; cur_g = Go;
+            h = ho; w = wo;
+            continue;
+        }
+        if (l.tile4 && k < L - 1 && (long)ho * wo * 10 >= (long)((ho + 15) / 16 * 16) * ((wo + 31) / 32 * 32) * 7) {
+            // output grid fills the 16 x 32 tiles: the halo-tile kernel with the stride-2 gather loader, fp16 slab out, statistics and the two views from it
+            const long HWo = (long)ho * wo, Go = (long)N * HWo * 32;
+            f16* Y = (f16*)raw;
+            ConvLaunch Lc{};
+            Lc.in = cur; Lc.in_gstride = cur_g; Lc.C = l.cin;
+            Lc.wpk = (const f16*)l.d_w3; Lc.bias = l.d_b3;
+            Lc.out = Y; Lc.out_gstride = Go; Lc.K = l.cout; Lc.N = N; Lc.H = ho; Lc.W = wo; Lc.act = 0;
+            Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = ho; Lc.out_mode = OUT_SLAB; Lc.stride2 = 1;
+            rc = conv_launch(Lc, s);
+            if (rc) return rc;
+            if (!ev) {
+                rc = norm::launch_stats_slab(Y, Go, HWo, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
+                if (rc) return rc;
+            }
+            const long total = (long)N * HWo * (l.cout / 8);
+            PostDst dl{(f16*)(ws + cv.D[k]), Go, 0, 1}, dr{(f16*)(ws + cv.CAT[k]), Go, 0, 2};
+            hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, Go, l.cout, HWo, N,
+                               (const float*)(ev ? l.d_ev_alpha : mean), (const float*)(ev ? l.d_ev_shift : rstd), ev ? 0 : l.cout, dl, dr);
+            INNFER_HIP(hipGetLastError());
+            cur = dl.p; cur_g = Go;
             h = ho; w = wo;
             continue;
         }
@@ -709,7 +851,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
                 const long total = (long)N * HW * (l.cout / 8);
                 PostDst dr{(f16*)(ws + cv.CAT[k - 1]), G, u->dc[k - 1], 2};
                 hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, G, l.cout, HW, N,
-                                   (const float*)(ev ? l.d_ev_alpha : mean), (const float*)(ev ? l.d_ev_shift : rstd), ev ? 0 : l.cout, dr);
+                                   (const float*)(ev ? l.d_ev_alpha : mean), (const float*)(ev ? l.d_ev_shift : rstd), ev ? 0 : l.cout, dr, PostDst{nullptr, 0, 0, 0});
                 INNFER_HIP(hipGetLastError());
             }
             h = hf; w = wf;
