@@ -246,14 +246,12 @@ __global__ __launch_bounds__(256) void unet_first_mfma(const void* in, int in_f3
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 2 + (lg >> 1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 8; ++e) {          // unconditional loads from a clamped address (independent, all in flight together), zeroed afterwards
                 const int iy = 2 * oy - 1 + ky0 + (e >> 2), ix = 2 * ox - 1 + (e & 3);
-                f16 v = (f16)0.f;
-                if (c < C && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                    const long o = ((n * C + c) * H + iy) * W + ix;
-                    v = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
-                }
-                bf[ks][e] = v;
+                const bool ok = c < C && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const long o = ok ? ((n * C + c) * H + iy) * W + ix : 0;
+                const f16 v = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
+                bf[ks][e] = ok ? v : (f16)0.f;
             }
         }
         f32x4 acc[4];
