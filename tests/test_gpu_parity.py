@@ -713,7 +713,8 @@ def test_unet_variants_vs_oracle(dev):
     import oracle
     from innfer_amd import synth
     from innfer_amd.architectures.UNet_arch import UnetGenerator
-    for in_nc, out_nc, num_downs, h, w, seed in ((3, 3, 7, 128, 256, 40), (1, 5, 5, 64, 96, 41)):
+    # (the 512 x 384 case puts four levels of either path on the halo-tile kernel -- stride-2 gather loader down, phase lattice up -- with ragged tile rows)
+    for in_nc, out_nc, num_downs, h, w, seed in ((3, 3, 7, 128, 256, 40), (1, 5, 5, 64, 96, 41), (3, 3, 6, 512, 384, 42)):
         net = UnetGenerator(in_nc, out_nc, num_downs, ngf=64)
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
         sd = _sd(shapes, seed)
