@@ -130,6 +130,7 @@ __global__ void rn_final(const float* raw, int rs, int C, long HW, int N, const 
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; bool transposed = false; std::vector<f16*> d_w; float* d_b = nullptr;
                void* d_w3 = nullptr;
+               float* d_b4 = nullptr;      // ConvTranspose layers on the halo-tile kernel: the bias once per output phase
                bool up2 = false; };        // upsample_mode 'upconv': Upsample(nearest 2x) + 3x3 conv on the halo-tile kernel (nearest-2x in the loader)    // residual-block convs: conv3x3.hip panels (reflection padding in the halo-tile loader)
 
 }  // namespace
@@ -199,6 +200,8 @@ static void rn_free(innfer_resnet* r) {
         l.d_b = nullptr;
         if (l.d_w3) (void)hipFree(l.d_w3);
         l.d_w3 = nullptr;
+        if (l.d_b4) (void)hipFree(l.d_b4);
+        l.d_b4 = nullptr;
     }
 }
 
@@ -288,6 +291,30 @@ int rn_upload(innfer_resnet* r) {
             (void)hipFree(l.d_b); l.d_b = nullptr;
             INNFER_HIP(hipMalloc((void**)&l.d_b, b3.size() * sizeof(float)));
             INNFER_HIP(hipMemcpy(l.d_b, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (l.transposed && k == 3 && l.cout % 64 == 0 && l.cin % 32 == 0) {
+            // ConvTranspose2d(3, stride 2, padding 1, output_padding 1) on the halo-tile kernel (conv3x3_pc<.., TM = 0x1B>, see unet.hip): output phase
+            // (a, b) at the virtual pixel (y + a, x + b) reads taps (dy, dx) in {-1, 0}^2 with ky = 1 - a - 2 dy (oy = 2 iy - 1 + ky); ky = 3 does not
+            // exist in a 3-tap kernel: a structural zero (9 of the 16 phase taps are real)
+            const int K4 = 4 * l.cout;
+            std::vector<float> w3((size_t)K4 * l.cin * 9, 0.f), b4((size_t)K4);
+            for (int co = 0; co < K4; ++co) {
+                const int ph = co / l.cout, c = co - ph * l.cout, a = ph >> 1, b = ph & 1;
+                for (int rr = 0; rr < 2; ++rr)
+                    for (int sx = 0; sx < 2; ++sx) {
+                        const int ky = 3 - 2 * rr - a, kx = 3 - 2 * sx - b;
+                        if (ky > 2 || kx > 2) continue;
+                        for (int ci = 0; ci < l.cin; ++ci)
+                            w3[((size_t)co * l.cin + ci) * 9 + rr * 3 + sx] = w[(((size_t)ci * l.cout + c) * 3 + ky) * 3 + kx];
+                    }
+                b4[co] = r->params[l.b].host[c];
+            }
+            std::vector<char> packed(conv_packed_bytes_taps(K4, l.cin, 0x1B));
+            conv_pack_taps(w3.data(), K4, l.cin, 0x1B, packed.data());
+            INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+            INNFER_HIP(hipMalloc((void**)&l.d_b4, b4.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(l.d_b4, b4.data(), b4.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         if (l.up2 || (!l.transposed && k == 3 && l.cin == l.cout && l.cin % 64 == 0)) {       // ResnetBlock convs (stride 1, pad 1) and the upconv convs
             std::vector<char> packed(conv_packed_bytes(l.cout, l.cin));
@@ -439,9 +466,32 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     };
+    // ConvTranspose whose input grid fills the 16 x 32 tiles: four phase convs in one launch of the halo-tile kernel, fp16 slab out, norm on the slab
+    auto deconv_tile = [&](const Layer& l, const f16* in, int Hi, int Wi, f16* dst) -> int {
+        const int Ho = 2 * Hi, Wo = 2 * Wi;
+        const long HW = (long)Ho * Wo, G = (long)N * HW * 32;
+        f16* Y = (f16*)raw;
+        ConvLaunch L{};
+        L.in = in; L.in_gstride = (long)N * Hi * Wi * 32; L.C = l.cin;
+        L.wpk = (const f16*)l.d_w3; L.bias = l.d_b4;
+        L.out = Y; L.out_gstride = G; L.K = 4 * l.cout; L.phase_c = l.cout; L.deconv_phases = 1;
+        L.N = N; L.H = Hi; L.W = Wi; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Hi;
+        L.out_mode = OUT_SLAB;
+        CK(conv_launch(L, s));
+        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        const long total = (long)N * HW * (l.cout / 8);
+        hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
+                           (const float*)alpha, (const float*)shift, 1, (const f16*)nullptr, dst, G);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
+    auto fills_tiles = [](int h, int w) { return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * ((w + 31) / 32 * 32) * 7; };
     if (r->layers[li].up2) {
         CK(up_conv(r->layers[li], t, H4, W4, U1)); ++li;                                                                // u128
         CK(up_conv(r->layers[li], U1, H2, W2, U2)); ++li;                                                               // u64
+    } else if (r->layers[li].transposed && r->layers[li].d_b4 && r->layers[li + 1].d_b4 && fills_tiles(H4, W4)) {
+        CK(deconv_tile(r->layers[li], t, H4, W4, U1)); ++li;                                                            // u128
+        CK(deconv_tile(r->layers[li], U1, H2, W2, U2)); ++li;                                                           // u64
     } else {
     CK(deconv(r->layers[li], t, H4, W4)); CK(norm_post(r->layers[li], H2, W2, 1, nullptr, U1)); ++li;                 // u128
     CK(deconv(r->layers[li], U1, H2, W2)); CK(norm_post(r->layers[li], H, W, 1, nullptr, U2)); ++li;                  // u64
