@@ -173,7 +173,7 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
 
 // DCV (conv3x3_pc<.., TM = 0x1B>: one output phase of ConvTranspose2d(4, 2, 1) per 16*NT-channel group): (ty0, tx0) are coordinates of the phase's
 // shifted lattice (see decode); virtual pixel (y', x') of phase (a, b) is output pixel (2y' - a, 2x' - b) of the 2H x 2W slab, channel ch % phase_c.
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false>
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, int NSEG = 2>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase, int dil = 1) {
     constexpr int MT = 2 * RPW;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
     f16x4 r1[R1 ? MT : 1][NT], r2[R2 ? MT : 1][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        ok[m] = (yw + (m >> 1) < ylim) && (xl + (m & 1) * 16 < xlim);
+        ok[m] = (NSEG == 2 || !(m & 1)) && (yw + (m >> 1) < ylim) && (xl + (m & 1) * 16 < xlim);
         const long o = (m >> 1) * rowstep + (m & 1) * colstep;
         if (HOIST && R1 && ok[m]) {
 #pragma unroll
@@ -632,8 +632,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // chunk c is (phase (pa, pb) = c / ncg, channel group c % ncg); cell (cy, cx) of phase (pa, pb) is source pixel (2cy + pa - 1, 2cx + pb - 1)
     // (the lattice of the image padded by one pixel), so output (y, x) reads cells y, y + 1 (taps r, s in {1, 2}: mask 0x1B0) and the padding
     // is the loader's range check.  H, W: the OUTPUT grid; the source image is Hs x Ws = 2H x 2W.
+    // + 0x400: images at most 16 pixels wide -- only the first 16-pixel segment of the tile row is multiplied and stored (the deep UNet levels)
     constexpr int TM = TMF & 0x1FF;
     constexpr bool S2 = (TMF & 0x200) != 0;
+    constexpr int NSEG = (TMF & 0x400) ? 1 : 2;
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 for (int r = 0; r < 3; ++r) need = need || (((TM >> (r * 3 + s)) & 1) && rr - r >= 0 && rr - r < RPW);
                 if (!need) continue;
 #pragma unroll
-                for (int seg = 0; seg < 2; ++seg) {
+                for (int seg = 0; seg < NSEG; ++seg) {
                     const f16x8 b = *(const f16x8*)(st + boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
@@ -1091,7 +1093,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
 #undef EPI
             } else if constexpr (OUTMODE == OUT_SLAB) {
-#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, NSEG>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
@@ -1460,7 +1462,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         if (!pc || L.out_mode != OUT_SLAB || nt != 4 || L.phase_c <= 0 || L.phase_c % 64 || L.K != 4 * L.phase_c || L.res1 || L.res2 || L.up || L.reflect ||
             L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.dilation > 1 || L.dilation_groups)
             return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: slab output, 64-channel phase groups, no residual / upsampling / padding modes");
-        return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B>(k, L.N, s);
+        return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x41B>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B>(k, L.N, s);
     }
     if (L.stride2) {         // Conv2d(k 4, s 2, p 1): H x W = the OUTPUT grid, source image 2H x 2W; panels from conv_pack_taps(K, 4C, 0x1B0), virtual channel
                              // (2 pa + pb) * C + ci, tap (1 + dy, 1 + dx) = w[co][ci][2 dy + pa][2 dx + pb]
@@ -1469,7 +1471,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
             return set_error(INNFER_ERR_UNSUPPORTED, "stride-2 conv: slab output of 64-channel tiles, no residual / upsampling / padding modes, sources below 33 M pixels");
         k.Hs = 2 * L.H; k.Ws = 2 * L.W; k.in_img_stride = (long)k.Hs * k.Ws * 32;
         k.nchunks = 4 * k.ncg;
-        return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
+        return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x7B0>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
     }
     if (L.conv1x1) {        // centre tap only: panels from conv_pack_1x1
         if (!pc || L.out_mode != OUT_SLAB || (nt != 2 && nt != 4))

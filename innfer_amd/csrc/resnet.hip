@@ -485,7 +485,7 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     };
-    auto fills_tiles = [](int h, int w) { return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * ((w + 31) / 32 * 32) * 7; };
+    auto fills_tiles = [](int h, int w) { return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * (w <= 16 ? 16 : (w + 31) / 32 * 32) * 7; };
     if (r->layers[li].up2) {
         CK(up_conv(r->layers[li], t, H4, W4, U1)); ++li;                                                                // u128
         CK(up_conv(r->layers[li], U1, H2, W2, U2)); ++li;                                                               // u64

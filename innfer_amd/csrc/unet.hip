@@ -216,14 +216,15 @@ __global__ void unet_pre_patch(const void* in, int in_f32, int C, int H, int W, 
 // (k = c * 16 + ky * 4 + kx, two k-steps), a wave takes 16 consecutive output pixels of a row, gathers their windows into the B fragments
 // (the input is 1/5 of the bytes this kernel writes and every value is re-read from L1 / L2), multiplies by the 64 x 64 weight panel it keeps in
 // registers and writes BOTH views of the result (no norm layer follows this conv): LeakyReLU(0.2) for the next down conv, ReLU for the
-// concatenation.  Replaces unet_pre_patch + two one-tap conv launches (178 -> ~60 us at 64 x 256^2): one pass, HBM-write bound.
+// concatenation.  Replaces unet_pre_patch + two one-tap conv launches (178 -> 98 us at 64 x 256^2): one pass.
 // wpk: [k-step][16-channel tile t][row rho][k-block lg][8], row rho of tile t = output channel 16 * (rho >> 2) + 4 * t + (rho & 3), so that lane
 // group lg ends up with channels 16 lg .. 16 lg + 15 of its pixel (32 contiguous bytes per view).
-__global__ __launch_bounds__(256) void unet_first_mfma(const void* in, int in_f32, int C, int H, int W, int N, const f16* wpk, const float* bias,
-                                                       f16* d0, f16* d1, long g) {
+template <typename TI>
+__global__ __launch_bounds__(256) void unet_first_mfma(const TI* in, int C, int H, int W, int N, const f16* wpk, const float* bias,
+                                                       f16* d0, f16* d1, long g, int abl) {
+    (void)abl;
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const int ho = H >> 1, wo = W >> 1, spr = wo >> 4;
-    const long total = (long)N * ho * spr;
     f16x8 a[2][4];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -235,45 +236,91 @@ __global__ __launch_bounds__(256) void unet_first_mfma(const void* in, int in_f3
 #pragma unroll
         for (int j = 0; j < 4; ++j) b4[t][j] = bias ? bias[16 * lg + 4 * t + j] : 0.f;
     const int ky0 = (lg & 1) * 2;
-    for (long seg = (long)blockIdx.x * 4 + (threadIdx.x >> 6); seg < total; seg += (long)gridDim.x * 4) {
-        const int sx = (int)(seg % spr);
-        const long r = seg / spr;
-        const int oy = (int)(r % ho);
-        const long n = r / ho;
-        const int ox = sx * 16 + li;
-        f16x8 bf[2];
+    // element offsets of this lane's 16 window values from the first value of its row pair in channel 0 (loop constants; one image < 2^31 elements)
+    int off[2][8];
+    bool cok[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int c = ks * 2 + (lg >> 1);
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 2 + (lg >> 1);
+        cok[ks] = c < C;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {          // unconditional loads from a clamped address (independent, all in flight together), zeroed afterwards
-                const int iy = 2 * oy - 1 + ky0 + (e >> 2), ix = 2 * ox - 1 + (e & 3);
-                const bool ok = c < C && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const long o = ok ? ((n * C + c) * H + iy) * W + ix : 0;
-                const f16 v = in_f32 ? (f16)((const float*)in)[o] : ((const f16*)in)[o];
-                bf[ks][e] = ok ? v : (f16)0.f;
+        for (int e = 0; e < 8; ++e) off[ks][e] = c * H * W + (e >> 2) * W + (e & 3) + 2 * li;
+    }
+    // a wave walks whole output rows (one division per row, none per segment)
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < N * ho; row += gridDim.x * 4) {
+        const int n = row / ho, oy = row - n * ho;
+        const int iy0 = 2 * oy - 1 + ky0;
+        const bool row_ok[2] = {iy0 >= 0, iy0 + 1 < H};                // (the other bounds hold by construction: oy < H / 2, ky0 <= 2)
+        const TI* rb = in + ((long)n * C * H + iy0) * W - 1;            // window origin of output pixel 0 of this row (wave-uniform)
+        const int safe = iy0 >= 0 ? 1 : W + 1;                           // offset of a real element (column 0 of the window's first real row)
+        const long m0 = (long)row * wo + li;
+        // The window of segment sx + 1 is requested before segment sx is multiplied and stored, and first touched at the top of the next iteration
+        // (two register sets used alternately: a single loop-carried set is copied at the loop edge, and the copy touches the data).
+        // Measured on the diagnostic build (scripts/unet_first_abl.py, 64 x 256^2): 98 us; without the stores 37, with every load from one address 61,
+        // with neither 26 -- what is left is the L1 request rate: the 2-byte gathers of a segment touch 64 cache lines, as many as its stores.
+        unsigned rawA[2][8], rawB[2][8];   // one full register per value (a 16-bit load leaves its upper half zero): packing pairs here would touch the data
+        auto request = [&](int sx, unsigned (&raw)[2][8]) __attribute__((always_inline)) {
+            const int ox = sx * 16 + li;
+            const bool col_ok[4] = {ox > 0, true, true, 2 * ox + 2 < W};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {      // unconditional loads from a clamped offset: independent, all in flight together
+                    const bool ok = cok[ks] && row_ok[e >> 2] && col_ok[e & 3];
+                    int o = ok ? off[ks][e] + sx * 32 : safe;
+#ifdef INNFER_ABLATE
+                    if (abl & 1) o = safe;          // diagnostic build: every load from one address
+#endif
+                    if constexpr (sizeof(TI) == 2) raw[ks][e] = ((const unsigned short*)rb)[o];
+                    else raw[ks][e] = ((const unsigned*)rb)[o];
+                }
+        };
+        auto segment = [&](int sx, unsigned (&cur)[2][8], unsigned (&nxt)[2][8]) __attribute__((always_inline)) {
+            f16x8 bf[2];
+            {
+                const int ox = sx * 16 + li;
+                const bool col_ok[4] = {ox > 0, true, true, 2 * ox + 2 < W};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f16 v;
+                        if constexpr (sizeof(TI) == 2) v = __builtin_bit_cast(f16, (unsigned short)cur[ks][e]);
+                        else v = (f16)__builtin_bit_cast(float, cur[ks][e]);
+                        bf[ks][e] = (cok[ks] && row_ok[e >> 2] && col_ok[e & 3]) ? v : (f16)0.f;
+                    }
             }
+            if (sx + 1 < spr) request(sx + 1, nxt);
+            f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = b4[t];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][t], bf[ks], acc[t], 0, 0, 0);
+            f16x8 h0[2], h1[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[t][j];
+                    h0[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.2f * v);
+                    h1[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.f);
+                }
+            const long o = (lg >> 1) * g + (m0 + sx * 16) * 32 + (lg & 1) * 16;
+#ifdef INNFER_ABLATE
+            if ((abl & 2) && h0[0][0] != (f16)12345.f) return;       // diagnostic build: no stores
+#endif
+            *(f16x8*)(d0 + o) = h0[0]; *(f16x8*)(d0 + o + 8) = h0[1];
+            *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + o + 8) = h1[1];
+        };
+        request(0, rawA);
+        int sx = 0;
+        for (; sx + 1 < spr; sx += 2) {
+            segment(sx, rawA, rawB);
+            segment(sx + 1, rawB, rawA);
         }
-        f32x4 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = b4[t];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][t], bf[ks], acc[t], 0, 0, 0);
-        const long m = (n * ho + oy) * wo + ox;
-        f16x8 h0[2], h1[2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = acc[t][j];
-                h0[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.2f * v);
-                h1[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.f);
-            }
-        const long o = (lg >> 1) * g + m * 32 + (lg & 1) * 16;
-        *(f16x8*)(d0 + o) = h0[0]; *(f16x8*)(d0 + o + 8) = h0[1];
-        *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + o + 8) = h1[1];
+        if (sx < spr) segment(sx, rawA, rawB);
     }
 }
 
@@ -661,6 +708,12 @@ int run_gemm(const Layer& l, const f16* wpk, const f16* in, long in_g, int N, in
 }
 }  // namespace
 
+// >= 70 % of the halo-tile kernel's pixels are real ones: 16-row tiles of 32 columns, or of 16 for grids at most 16 wide (conv3x3_pc's half-width form)
+static bool fills_tiles(int h, int w) {
+    const long tw = w <= 16 ? 16 : (w + 31) / 32 * 32;
+    return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * tw * 7;
+}
+
 extern "C" size_t innfer_unet_workspace_bytes(innfer_unet* u, int N, int H, int W) {
     if (!u || N <= 0 || H <= 0 || W <= 0) return 0;
     return ucarve(u, N, H, W).total;
@@ -744,10 +797,15 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         int rc;
         if (k == 0 && first_mfma) {
             const long HWo = (long)ho * wo, Go = (long)N * HWo * 32;
-            const long segs = (long)N * ho * (wo / 16);
-            const unsigned grid = (unsigned)std::min<long>((segs + 3) / 4, 256L * 8);
-            hipLaunchKernelGGL(unet_first_mfma, dim3(grid), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, u->in_nc, H, W, N, (const f16*)l.d_wf,
-                               (const float*)(l.bias >= 0 ? l.d_bias : nullptr), (f16*)(ws + cv.D[0]), (f16*)(ws + cv.CAT[0]), Go);
+            if ((long)u->in_nc * H * W >= 0x7fffffffL || (long)N * ho >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "unet_forward: image too large");
+            const unsigned grid = (unsigned)std::min<long>(((long)N * ho + 3) / 4, 256L * 8);
+            const int abl = INNFER_KNOB("INNFER_FIRST_ABL", 0);
+            if (in_dtype == INNFER_F32)
+                hipLaunchKernelGGL(unet_first_mfma<float>, dim3(grid), dim3(256), 0, s, (const float*)d_in, u->in_nc, H, W, N, (const f16*)l.d_wf,
+                                   (const float*)(l.bias >= 0 ? l.d_bias : nullptr), (f16*)(ws + cv.D[0]), (f16*)(ws + cv.CAT[0]), Go, abl);
+            else
+                hipLaunchKernelGGL(unet_first_mfma<f16>, dim3(grid), dim3(256), 0, s, (const f16*)d_in, u->in_nc, H, W, N, (const f16*)l.d_wf,
+                                   (const float*)(l.bias >= 0 ? l.d_bias : nullptr), (f16*)(ws + cv.D[0]), (f16*)(ws + cv.CAT[0]), Go, abl);
             INNFER_HIP(hipGetLastError());
             cur = (f16*)(ws + cv.D[0]); cur_g = Go;
             h = ho; w = wo;
@@ -771,7 +829,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             h = ho; w = wo;
             continue;
         }
-        if (l.tile4 && k < L - 1 && (long)ho * wo * 10 >= (long)((ho + 15) / 16 * 16) * ((wo + 31) / 32 * 32) * 7) {
+        if (l.tile4 && k < L - 1 && fills_tiles(ho, wo)) {
             // output grid fills the 16 x 32 tiles: the halo-tile kernel with the stride-2 gather loader, fp16 slab out, statistics and the two views from it
             const long HWo = (long)ho * wo, Go = (long)N * HWo * 32;
             f16* Y = (f16*)raw;
@@ -824,7 +882,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const long in_g = (long)N * h * w * 32;
         const int hf = 2 * h, wf = 2 * w;
         // a ConvTranspose whose input grid fills the 16 x 32 tiles (>= 70 % real pixels) runs as four 2x2-tap phase convs on the halo-tile kernel
-        const bool tile4 = l.tile4 && (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * ((w + 31) / 32 * 32) * 7;
+        const bool tile4 = l.tile4 && fills_tiles(h, w);
         if (l.upconv || tile4) {   // upconv: nearest 2x + 3x3 conv on the halo-tile kernel; outermost: bias + tanh -> NCHW in its planar epilogue
             ConvLaunch Lc{};
             Lc.in = in; Lc.in_gstride = in_g; Lc.C = l.cin;
