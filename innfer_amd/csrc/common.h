@@ -94,6 +94,10 @@ void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
 int conv_launch(const ConvLaunch& L, hipStream_t s);
 size_t conv_packed_bytes_taps(int K, int C, int mask);
 void conv_pack_1x1(const float* w_oi, int K, int C, void* packed);    // host; w [K][C]
+size_t conv_packed_bytes_s2k4(int K, int C);
+void conv_pack_s2k4(const float* w_oi44, int K, int C, void* packed);         // host; Conv2d(4, 2, 1) panels for ConvLaunch.stride2
+size_t conv_packed_bytes_deconv2x(int K, int C);
+void conv_pack_deconv2x(const float* w_io, int K, int C, int k, void* packed); // host; ConvTranspose2d(k = 3 | 4, 2, 1) panels for ConvLaunch.deconv_phases, w [C][K][k][k]
 void conv_pack_taps(const float* w, int K, int C, int mask, void* packed);   // host; w [K][C][9], only the taps of `mask` are packed (conv_packed_bytes_taps)
 size_t conv_packed_bytes7x7(int K, int C);
 void conv_pack7x7(const float* w_oihw, int K, int C, void* packed);   // host; C % 32 == 0

@@ -1385,6 +1385,41 @@ void conv_pack_1x1(const float* w, int K, int C, void* packed) {
 
 // 7x7 weights [K][C][7][7] -> panels of the equivalent conv over 9*C virtual channels (conv3x3_pc<.., S9>): virtual channel sub*C + ci,
 // tap (r, s) holds w[k][ci][3*(sub/3) + r - 1][3*(sub%3) + s - 1] (zero outside the 7x7 kernel: the 9x9 padding ring)
+// Conv2d(k 4, s 2, p 1) for the stride-2 gather loader (ConvLaunch.stride2): w [K][C][4][4] -> panels over 4 * C virtual channels, mask 0x1B0;
+// virtual channel (2 pa + pb) * C + ci, tap (1 + dy, 1 + dx) = w[co][ci][2 dy + pa][2 dx + pb]
+size_t conv_packed_bytes_s2k4(int K, int C) { return conv_packed_bytes_taps(K, 4 * C, 0x1B0); }
+void conv_pack_s2k4(const float* w, int K, int C, void* packed) {
+    const int C4 = 4 * C;
+    std::vector<float> w3((size_t)K * C4 * 9, 0.f);
+    for (int co = 0; co < K; ++co)
+        for (int ph = 0; ph < 4; ++ph)
+            for (int ci = 0; ci < C; ++ci)
+                for (int dy = 0; dy < 2; ++dy)
+                    for (int dx = 0; dx < 2; ++dx)
+                        w3[((size_t)co * C4 + ph * C + ci) * 9 + (1 + dy) * 3 + 1 + dx] = w[(((size_t)co * C + ci) * 4 + 2 * dy + (ph >> 1)) * 4 + 2 * dx + (ph & 1)];
+    conv_pack_taps(w3.data(), K, C4, 0x1B0, packed);
+}
+
+// ConvTranspose2d(k, stride 2, padding 1[, output_padding 1 for k == 3]) for ConvLaunch.deconv_phases: w [C][K][k][k] (torch's layout) -> panels of
+// 4 * K phase-major output channels, mask 0x1B.  Output phase (a, b) taken at the virtual pixel (y + a, x + b) reads taps (dy, dx) in {-1, 0}^2;
+// tap (r, s) of the 3x3 lattice (r, s in {0, 1}) carries w[ci][c][3 - 2r - a][3 - 2s - b] (oy = 2 iy - 1 + ky); a kernel index of 3 does not
+// exist for k == 3: a structural zero (9 of the 16 phase taps are real there)
+size_t conv_packed_bytes_deconv2x(int K, int C) { return conv_packed_bytes_taps(4 * K, C, 0x1B); }
+void conv_pack_deconv2x(const float* w, int K, int C, int k, void* packed) {
+    const int K4 = 4 * K;
+    std::vector<float> w3((size_t)K4 * C * 9, 0.f);
+    for (int co = 0; co < K4; ++co) {
+        const int ph = co / K, c = co - ph * K, a = ph >> 1, b = ph & 1;
+        for (int r = 0; r < 2; ++r)
+            for (int sx = 0; sx < 2; ++sx) {
+                const int ky = 3 - 2 * r - a, kx = 3 - 2 * sx - b;
+                if (ky >= k || kx >= k) continue;
+                for (int ci = 0; ci < C; ++ci) w3[((size_t)co * C + ci) * 9 + r * 3 + sx] = w[(((size_t)ci * K + c) * k + ky) * k + kx];
+            }
+    }
+    conv_pack_taps(w3.data(), K4, C, 0x1B, packed);
+}
+
 size_t conv_packed_bytes7x7(int K, int C) { return conv_packed_bytes(K, 9 * C); }
 void conv_pack7x7(const float* w, int K, int C, void* packed) {
     std::vector<float> v((size_t)K * 9 * C * 9, 0.f);

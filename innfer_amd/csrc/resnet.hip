@@ -296,21 +296,10 @@ int rn_upload(innfer_resnet* r) {
             // ConvTranspose2d(3, stride 2, padding 1, output_padding 1) on the halo-tile kernel (conv3x3_pc<.., TM = 0x1B>, see unet.hip): output phase
             // (a, b) at the virtual pixel (y + a, x + b) reads taps (dy, dx) in {-1, 0}^2 with ky = 1 - a - 2 dy (oy = 2 iy - 1 + ky); ky = 3 does not
             // exist in a 3-tap kernel: a structural zero (9 of the 16 phase taps are real)
-            const int K4 = 4 * l.cout;
-            std::vector<float> w3((size_t)K4 * l.cin * 9, 0.f), b4((size_t)K4);
-            for (int co = 0; co < K4; ++co) {
-                const int ph = co / l.cout, c = co - ph * l.cout, a = ph >> 1, b = ph & 1;
-                for (int rr = 0; rr < 2; ++rr)
-                    for (int sx = 0; sx < 2; ++sx) {
-                        const int ky = 3 - 2 * rr - a, kx = 3 - 2 * sx - b;
-                        if (ky > 2 || kx > 2) continue;
-                        for (int ci = 0; ci < l.cin; ++ci)
-                            w3[((size_t)co * l.cin + ci) * 9 + rr * 3 + sx] = w[(((size_t)ci * l.cout + c) * 3 + ky) * 3 + kx];
-                    }
-                b4[co] = r->params[l.b].host[c];
-            }
-            std::vector<char> packed(conv_packed_bytes_taps(K4, l.cin, 0x1B));
-            conv_pack_taps(w3.data(), K4, l.cin, 0x1B, packed.data());
+            std::vector<float> b4((size_t)4 * l.cout);
+            for (int co = 0; co < 4 * l.cout; ++co) b4[co] = r->params[l.b].host[co % l.cout];
+            std::vector<char> packed(conv_packed_bytes_deconv2x(l.cout, l.cin));
+            conv_pack_deconv2x(w.data(), l.cout, l.cin, 3, packed.data());
             INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
             INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
             INNFER_HIP(hipMalloc((void**)&l.d_b4, b4.size() * sizeof(float)));

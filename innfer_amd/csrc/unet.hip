@@ -588,18 +588,10 @@ static int upload_all(innfer_unet* u) {
                 if (l.tile4) {
                     // Conv2d(4, 2, 1) = the 2x2-tap conv of the space-to-depth source (conv3x3_pc's stride-2 loader): virtual channel (2 pa + pb) * cin + ci,
                     // tap (1 + dy, 1 + dx) of the 3x3 lattice carries w[co][ci][2 dy + pa][2 dx + pb]
-                    const int C4 = 4 * l.cin;
-                    std::vector<float> w3((size_t)l.cout * C4 * 9, 0.f), b3((size_t)l.cout, 0.f);
-                    for (int co = 0; co < l.cout; ++co)
-                        for (int ph = 0; ph < 4; ++ph)
-                            for (int ci = 0; ci < l.cin; ++ci)
-                                for (int dy = 0; dy < 2; ++dy)
-                                    for (int dx = 0; dx < 2; ++dx)
-                                        w3[((size_t)co * C4 + ph * l.cin + ci) * 9 + (1 + dy) * 3 + 1 + dx] =
-                                            w[(((size_t)co * l.cin + ci) * 4 + 2 * dy + (ph >> 1)) * 4 + 2 * dx + (ph & 1)];
+                    std::vector<float> b3((size_t)l.cout, 0.f);
                     if (l.bias >= 0) b3 = u->params[l.bias].host;
-                    std::vector<char> packed(conv_packed_bytes_taps(l.cout, C4, 0x1B0));
-                    conv_pack_taps(w3.data(), l.cout, C4, 0x1B0, packed.data());
+                    std::vector<char> packed(conv_packed_bytes_s2k4(l.cout, l.cin));
+                    conv_pack_s2k4(w.data(), l.cout, l.cin, packed.data());
                     if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
                     INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
                     rc = upload_f32(&l.d_b3, b3); if (rc) return rc;
@@ -608,18 +600,10 @@ static int upload_all(innfer_unet* u) {
                 if (l.tile4) {
                     // phase (a, b) of ConvTranspose2d(4, 2, 1) = taps (dy, dx) in {-1, 0}^2 at the virtual pixel (y + a, x + b) (conv3x3_pc<.., TM = 0x1B>):
                     // tap (r, s) of the 3x3 lattice (r, s in {0, 1}) carries w[ci][c][3 - 2r - a][3 - 2s - b]  (oy = 2 iy - 1 + ky)
-                    const int K4 = 4 * l.cout;
-                    std::vector<float> w3((size_t)K4 * l.cin * 9, 0.f), b3((size_t)K4, 0.f);
-                    for (int co = 0; co < K4; ++co) {
-                        const int ph = co / l.cout, c = co - ph * l.cout, a = ph >> 1, b = ph & 1;
-                        for (int ci = 0; ci < l.cin; ++ci)
-                            for (int r = 0; r < 2; ++r)
-                                for (int sx = 0; sx < 2; ++sx)
-                                    w3[((size_t)co * l.cin + ci) * 9 + r * 3 + sx] = w[(((size_t)ci * l.cout + c) * 4 + (3 - 2 * r - a)) * 4 + (3 - 2 * sx - b)];
-                        if (l.bias >= 0) b3[co] = u->params[l.bias].host[c];
-                    }
-                    std::vector<char> packed(conv_packed_bytes_taps(K4, l.cin, 0x1B));
-                    conv_pack_taps(w3.data(), K4, l.cin, 0x1B, packed.data());
+                    std::vector<float> b3((size_t)4 * l.cout, 0.f);
+                    if (l.bias >= 0) for (int co = 0; co < 4 * l.cout; ++co) b3[co] = u->params[l.bias].host[co % l.cout];
+                    std::vector<char> packed(conv_packed_bytes_deconv2x(l.cout, l.cin));
+                    conv_pack_deconv2x(w.data(), l.cout, l.cin, 4, packed.data());
                     if (!l.d_w3) INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
                     INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
                     int rc = upload_f32(&l.d_b3, b3); if (rc) return rc;

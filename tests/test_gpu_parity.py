@@ -730,6 +730,71 @@ def test_unet_variants_vs_oracle(dev):
         assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (in_nc, out_nc, num_downs, err.max().item(), err.mean().item())
 
 
+def _run_stride2(dev, x, w, b, K, kind, k=4, act=0):
+    """The stride-2 forms of the single-conv ABI: kind 'down' = Conv2d(4, 2, 1) (x [N,C,2H,2W] -> [N,K,H,W]), kind 'up' = ConvTranspose2d(k, 2, 1[, 1])
+    (x [N,C,H,W] -> [N,K,2H,2W]).  Returns the NCHW fp32 result on the cpu."""
+    import innfer_amd.lib as L
+    N, Cc, Hi, Wi = x.shape
+    Ho, Wo = (Hi // 2, Wi // 2) if kind == "down" else (2 * Hi, 2 * Wi)
+    g_in, g_out = N * Hi * Wi * 32, N * Ho * Wo * 32
+    slab = torch.full((Cc // 32, N, Hi, Wi, 32), 7.0, dtype=torch.float16, device=dev)
+    L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), g_in, 0, N, Cc, Hi, Wi, None))
+    wc = np.ascontiguousarray(w.numpy())
+    if kind == "down":
+        packed = np.zeros(L.lib.innfer_conv4x4s2_packed_bytes(K, Cc), dtype=np.uint8)
+        L.check(L.lib.innfer_pack_conv4x4s2(wc.ctypes.data, K, Cc, packed.ctypes.data))
+        d_bias = b.float().to(dev)
+    else:
+        packed = np.zeros(L.lib.innfer_convt2x_packed_bytes(K, Cc), dtype=np.uint8)
+        L.check(L.lib.innfer_pack_convt2x(wc.ctypes.data, K, Cc, k, packed.ctypes.data))
+        d_bias = b.float().repeat(4).to(dev)
+    d_packed = torch.from_numpy(packed).to(dev)
+    out = torch.full((K // 32, N, Ho, Wo, 32), -3.0, dtype=torch.float16, device=dev)
+    a = L.ConvArgs()
+    a.d_in, a.in_group_stride, a.C = slab.data_ptr(), g_in, Cc
+    a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
+    a.d_out, a.out_group_stride, a.K = out.data_ptr(), g_out, K
+    a.N, a.act = N, act
+    if kind == "down":
+        a.H, a.W, a.stride2_k4 = Ho, Wo, 1
+    else:
+        a.H, a.W, a.transposed2x = Hi, Wi, k
+    L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
+    res = torch.empty((N, K, Ho, Wo), dtype=torch.float32, device=dev)
+    L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), g_out, 0, res.data_ptr(), L.F32, N, K, Ho, Wo, None))
+    torch.cuda.synchronize()
+    return res.cpu()
+
+
+def test_stride2_conv_and_transposed_conv_vs_torch(dev):
+    """Conv2d(4, 2, 1) on the stride-2 gather loader and ConvTranspose2d(4, 2, 1) / (3, 2, 1, output_padding 1) on the phase lattice (conv3x3_pc
+    TMF 0x3B0 / 0x1B and their half-width forms) against torch in fp32 on the fp16-rounded operands, over seeded shapes: ragged tile rows and
+    columns, one- and two-tile-wide images, grids at most 16 wide (one 16-pixel segment), batches, 64 .. 192 output channels, activations.
+    Tolerance: fp16 rounding of the stored result plus fp32 accumulation order (<= 4e-3 for unit-scale outputs, as for the 3x3 conv)."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(11)
+    cases = [(1, 32, 64, 16, 32), (2, 64, 128, 24, 40), (1, 96, 64, 7, 9), (3, 32, 192, 16, 16), (1, 64, 64, 33, 65), (2, 32, 64, 5, 16), (1, 128, 128, 48, 17)]
+    for _ in range(6):
+        cases.append((int(rng.randint(1, 4)), 32 * int(rng.randint(1, 5)), 64 * int(rng.randint(1, 4)), int(rng.randint(1, 50)), int(rng.randint(1, 70))))
+    for i, (N, Cc, K, H, W) in enumerate(cases):
+        act = i % 3
+        post = (lambda t: t) if act == 0 else (lambda t: F.leaky_relu(t, 0.2)) if act == 1 else F.relu
+        b = torch.from_numpy(rng.uniform(-0.5, 0.5, K).astype(np.float32))
+        # down: output grid H x W from a 2H x 2W source
+        x = torch.from_numpy(rng.uniform(-1, 1, (N, Cc, 2 * H, 2 * W)).astype(np.float32)).half()
+        w = torch.from_numpy((rng.uniform(-1, 1, (K, Cc, 4, 4)) / np.sqrt(16 * Cc)).astype(np.float32)).half().float()
+        ref = post(F.conv2d(x.float(), w, b, stride=2, padding=1))
+        got = _run_stride2(dev, x, w, b, K, "down", act=act)
+        assert got.shape == ref.shape and (got - ref).abs().max().item() < 4e-3, ("down", N, Cc, K, H, W, (got - ref).abs().max().item())
+        # up: input grid H x W -> 2H x 2W
+        for k in (4, 3):
+            x = torch.from_numpy(rng.uniform(-1, 1, (N, Cc, H, W)).astype(np.float32)).half()
+            w = torch.from_numpy((rng.uniform(-1, 1, (Cc, K, k, k)) / np.sqrt(k * k * Cc / 4)).astype(np.float32)).half().float()
+            ref = post(F.conv_transpose2d(x.float(), w, b, stride=2, padding=1, output_padding=1 if k == 3 else 0))
+            got = _run_stride2(dev, x, w, b, K, "up", k=k, act=act)
+            assert got.shape == ref.shape and (got - ref).abs().max().item() < 4e-3, ("up", k, N, Cc, K, H, W, (got - ref).abs().max().item())
+
+
 def test_unet256_upconv_full_depth_vs_oracle(dev):
     """upsample_mode='upconv' at unet_256's full depth (8 levels, 1x1 bottleneck -> the 3x3 conv runs on 2x2 .. 256x256 upsampled grids
     with 512 .. 1024 input channels), batch 2, train-mode and eval-mode BatchNorm, against the oracle (itself pinned on the reference, G23)."""
