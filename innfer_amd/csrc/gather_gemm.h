@@ -49,10 +49,7 @@ inline long split_max_px() {
 // Tile shapes: <BP, Q, STAGES> = 16*BP pixels per wave x 64*Q output channels, 4 waves:
 //   <2,1,4>  128 px x  64 co, 12 KiB per stage   small / narrow layers and every split-K launch
 //   <4,2,3>  256 px x 128 co, 24 KiB per stage   big layers (twice the MFMAs per staged byte)
-// SEGACC: a layer whose rule says "split over K" on a batch that fills the chip without it: ONE workgroup walks all k-steps and folds its accumulators
-// into a running total at every segment boundary (total = p0, then + p1, + p2 ...) -- the additions splitk_reduce / unet_deep_post would do on the
-// partial results, in the same order, so the result is bit-identical to the split form and a batch still equals its batch-1 forwards.
-template <int BP, int Q, int STAGES, bool SEGACC = false>
+template <int BP, int Q, int STAGES>
 static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
     constexpr int PXT = 64 * BP;                                      // pixels per workgroup
     constexpr int B_BYTES = PXT * 64, A_BYTES = Q * 4096, STAGE_BYTES = B_BYTES + A_BYTES;
@@ -90,8 +87,8 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
     const char* wtile = (const char*)p.wpk + zg * p.g_wbytes + (long)cot * panel_bytes;
     const int total_steps = p.ntaps * p.nchunks;
     // split-K: blockIdx.z takes the k-steps [z*seg, (z+1)*seg) and writes a partial result
-    const int step0 = (!SEGACC && p.ksplit > 1) ? zs * p.seg : 0;
-    const int nsteps = (!SEGACC && p.ksplit > 1) ? min(p.seg, total_steps - step0) : total_steps;
+    const int step0 = p.ksplit > 1 ? zs * p.seg : 0;
+    const int nsteps = p.ksplit > 1 ? min(p.seg, total_steps - step0) : total_steps;
 
     auto issue = [&](int rel) {
         const int step = step0 + rel;
@@ -127,9 +124,6 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
     for (int h = 0; h < BP; ++h)
 #pragma unroll
         for (int q = 0; q < 4 * Q; ++q) acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 tot[SEGACC ? BP : 1][SEGACC ? 4 * Q : 1];
-    bool first_seg = true; int in_seg = 0;
-    (void)tot; (void)first_seg; (void)in_seg;
     int boff[BP];
 #pragma unroll
     for (int h = 0; h < BP; ++h) {
@@ -157,24 +151,6 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
 #pragma unroll
             for (int h = 0; h < BP; ++h) acc[h][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[h], acc[h][q], 0, 0, 0);
         }
-        if constexpr (SEGACC) {
-            if (++in_seg == p.seg || step + 1 == nsteps) {
-#pragma unroll
-                for (int h = 0; h < BP; ++h)
-#pragma unroll
-                    for (int q = 0; q < 4 * Q; ++q) {
-                        tot[h][q] = first_seg ? acc[h][q] : tot[h][q] + acc[h][q];
-                        acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                first_seg = false; in_seg = 0;
-            }
-        }
-    }
-    if constexpr (SEGACC) {
-#pragma unroll
-        for (int h = 0; h < BP; ++h)
-#pragma unroll
-            for (int q = 0; q < 4 * Q; ++q) acc[h][q] = tot[h][q];
     }
     // D rows = out channels (16*lg + 4*q + j after the panel permutation), cols = pixels
 #pragma unroll
@@ -274,22 +250,18 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     int ks = 1;
     if (scratch && nsteps >= 32 && (long)Ho * Wo <= split_max_px() && (size_t)segs * full <= scratch_bytes) ks = segs;
     if (ngroup > 1 && !g_phase) ks = 1;        // phase groups may be split over K: every segment buffer then holds the whole full-resolution grid
-    // ... and a batch that fills the chip unsplit folds the segments inside the workgroup instead (SEGACC: same bits).  From four 128 x 64 tiles
-    // per CU: a workgroup's k loop is latency-bound (one barrier per 8 MFMAs), so below that the split form's extra workgroups are what hides it
-    // (measured at 64 x 256^2: 256 tiles 108 -> 181 us, 1024 tiles 256 -> 218 us)
-    const bool segacc = ks > 1 && ((M + 127) / 128) * (cout_pad / 64) * ngroup >= 1024 && INNFER_KNOB("INNFER_SEGACC", 1);
-    if (segacc) ks = 1;
     g.ksplit = ks;
     g.cout_store = cout_store > 0 ? cout_store : (g.raw_stride < cout_pad ? g.raw_stride : cout_pad);
     g.ngroup = ngroup; g.g_wbytes = g_wbytes; g.g_outoff = g_outoff; g.g_tapmul = g_tapmul; g.g_phase = g_phase;
     g.split_elems = ks > 1 ? (long)(full / sizeof(float)) : 0;
     if (ks > 1) g.out = scratch;
-    const bool big = ks == 1 && (ngroup == 1 || g_phase) && cout_pad % 128 == 0 && ((M + 255) / 256) * (cout_pad / 128) * ngroup >= 256;
-    if (segacc) {
-        dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64), (unsigned)ngroup);
-        hipLaunchKernelGGL((gemm_gather<2, 1, 4, true>), grid, dim3(256), 0, s, g);
-    } else if (big) {
-        dim3 grid((unsigned)((M + 255) / 256), (unsigned)(cout_pad / 128), (unsigned)ngroup);
+    // (the tile shape never changes an element's accumulation order, so it may follow the batch size -- split launches included: 64 x 256^2
+    //  1.76 -> 1.72 ms.  Folding the segments inside one workgroup instead of splitting -- same bits -- was measured too: the k loop of a
+    //  workgroup is latency-bound, 108 -> 181 us on a 256-tile layer, and no gain beside the wide split tiles: not built)
+    const bool big = (ngroup == 1 || g_phase) && cout_pad % 128 == 0 &&
+                     ((M + 255) / 256) * (cout_pad / 128) * ngroup * ks >= 256;
+    if (big) {
+        dim3 grid((unsigned)((M + 255) / 256), (unsigned)(cout_pad / 128), (unsigned)(ks * ngroup));
         hipLaunchKernelGGL((gemm_gather<4, 2, 3>), grid, dim3(256), 0, s, g);
     } else {
         dim3 grid((unsigned)((M + 127) / 128), (unsigned)(cout_pad / 64), (unsigned)(ks * ngroup));
