@@ -1532,6 +1532,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         return launch_pc<3, 1, 4, OUT_NCHW, true>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2) return launch_pc<3, 1, 4, OUT_NCHW>(k, L.N, s);
+    if (pc && L.out_mode == OUT_NCHW && nt == 2 && !L.res1 && !L.res2 && !L.phase_c && !L.reflect && !L.out_u8) return launch_pc<3, 2, 4, OUT_NCHW>(k, L.N, s);
     if (L.act >= 3 || L.phase_c > 0 || L.reflect)
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: tanh / phase output / gate epilogues / reflection padding exist only in the producer-consumer kernel");
     switch (L.out_mode) {

@@ -85,6 +85,88 @@ __global__ void rn_post_slab(const f16* src, int C, long HW, int N, const float*
     *(f16x8*)(dst + o) = h;
 }
 
+// The last 7x7 conv (64 -> out_nc <= 3, ReflectionPad2d(3)) as ONE plain 3x3 conv with 9 * out_nc output channels + a 9-term gather: the 7x7
+// kernel, zero-padded to 9x9, is nine 3x3 sub-blocks (sr, sc); channel (co, sr, sc) of the 3x3 conv is
+//   Q[co, sr, sc][y'][x'] = sum_{r, s, ci} w9[co][ci][3 sr + r][3 sc + s] * pad(in)[ci][y' + r - 1][x' + s - 1]
+// and  out[co][y][x] = tanh(bias + sum_{sr, sc} Q[co, sr, sc][y + 3 (sr - 1)][x + 3 (sc - 1)]).
+// The sub-blocks sit in the MFMA's output rows (27 of 32 used) instead of being nine displaced passes over 3 of 16 rows (conv3x3_pc<.., S9>: 81 tap
+// positions, 312 us at 16 x 256^2).  Q is needed 3 pixels beyond the image, from the reflection-padded input: the producer of the conv's input
+// writes it as a (H + 8) x (W + 8) slab -- image at (4, 4), three mirrored rings, one outer ring of zeros that only meets the 9x9's zero border.
+// rn_post_slab with `padW > 0`: destination is that padded slab (g = its group stride); a border pixel is written up to four times.
+__device__ __forceinline__ int rn_mirror_targets(int y, int H, int* t) {       // padded rows that hold source row y (reflection of 3, offset 4)
+    int n = 0;
+    t[n++] = y + 4;
+    if (y >= 1 && y <= 3) t[n++] = 4 - y;
+    if (y >= H - 4 && y <= H - 2) t[n++] = 2 * (H - 1) - y + 4;
+    return n;
+}
+
+__global__ void rn_post_slab_pad(const f16* src, int C, int H, int W, int N, const float* alpha, const float* shift, int relu, f16* dst, long gsrc, long gdst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C / 8;
+    const long HW = (long)H * W;
+    if (i >= (long)N * HW * c8) return;
+    const int c = (int)(i % c8) * 8;
+    const long pix = i / c8;
+    const long n = pix / HW;
+    const int y = (int)((pix - n * HW) / W), x = (int)(pix - n * HW - (long)y * W);
+    const float* ap = alpha + n * C + c;
+    const float* sp = shift + n * C + c;
+    const f16x8 v = *(const f16x8*)(src + (c >> 5) * gsrc + pix * 32 + (c & 31));
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float f = (float)v[e] * ap[e] + sp[e];
+        if (relu) f = fmaxf(f, 0.f);
+        h[e] = (f16)f;
+    }
+    int ty[3], tx[3];
+    const int ny = rn_mirror_targets(y, H, ty), nx = rn_mirror_targets(x, W, tx);
+    const int Wp = W + 8;
+    f16* db = dst + (c >> 5) * gdst + n * (long)(H + 8) * Wp * 32 + (c & 31);
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) *(f16x8*)(db + ((long)ty[a] * Wp + tx[b]) * 32) = h;
+}
+
+// the outer ring of the padded slab (row / column 0 and H + 7 / W + 7): zeros
+__global__ void rn_zero_ring(f16* dst, int G, int H, int W, int N, long g) {
+    const int Hp = H + 8, Wp = W + 8, ring = 2 * Wp + 2 * (Hp - 2);
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * G * ring * 4) return;
+    const int q = (int)(i & 3);
+    long r = i >> 2;
+    const int k = (int)(r % ring); r /= ring;
+    const int grp = (int)(r % G);
+    const long n = r / G;
+    int y, x;
+    if (k < Wp) { y = 0; x = k; }
+    else if (k < 2 * Wp) { y = Hp - 1; x = k - Wp; }
+    else { const int j = k - 2 * Wp; y = 1 + (j >> 1); x = (j & 1) ? Wp - 1 : 0; }
+    f16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (f16)0.f;
+    *(f16x8*)(dst + grp * g + ((n * Hp + y) * (long)Wp + x) * 32 + q * 8) = z;
+}
+
+// out[n][co][y][x] = tanh(bias[co] + sum over the nine sub-blocks of Q[n][co * 9 + sr * 3 + sc][y + 3 sr + 1][x + 3 sc + 1]); Q: planar fp32 over the padded grid
+__global__ void rn_sum9_tanh(const float* Q, const float* bias, void* out, int out_f32, int K, int H, int W, int N) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long HW = (long)H * W;
+    if (i >= (long)N * K * HW) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int co = (int)((i / HW) % K);
+    const long n = i / (HW * K);
+    const int Hp = H + 8, Wp = W + 8;
+    const float* q = Q + ((n * 9 * K + co * 9) * Hp + (y + 1)) * (long)Wp + (x + 1);
+    float a = bias[co];
+#pragma unroll
+    for (int sr = 0; sr < 3; ++sr)
+#pragma unroll
+        for (int sc = 0; sc < 3; ++sc) a += q[((long)(sr * 3 + sc) * Hp + 3 * sr) * Wp + 3 * sc];
+    a = tanhf(a);
+    if (out_f32) ((float*)out)[i] = a; else ((f16*)out)[i] = (f16)a;
+}
+
 // NCHW input -> "row patch" slab of the reflection-padded first 7x7 conv: channel kx*C + c of pixel (y, x) holds in[c][y][reflect(x + kx - 3)]
 // (zero beyond 7*C <= 32 channels), so the 49-tap conv becomes 7 vertical taps (reflected by the GEMM's gather) over ONE 32-channel group.
 // C > 4: plain copy into a zero-padded group (49 taps).  One thread per pixel, 16-byte stores.
@@ -131,6 +213,7 @@ struct Param { std::string key; std::vector<int> shape; std::vector<float> host;
 struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; bool transposed = false; std::vector<f16*> d_w; float* d_b = nullptr;
                void* d_w3 = nullptr;
                float* d_b4 = nullptr;      // ConvTranspose layers on the halo-tile kernel: the bias once per output phase
+               void* d_w27 = nullptr; float* d_z32 = nullptr;   // last 7x7 conv as a 3x3 conv over nine sub-blocks (rn_sum9_tanh): panels [9 * cout][cin][3][3], zero bias
                bool up2 = false; };        // upsample_mode 'upconv': Upsample(nearest 2x) + 3x3 conv on the halo-tile kernel (nearest-2x in the loader)    // residual-block convs: conv3x3.hip panels (reflection padding in the halo-tile loader)
 
 }  // namespace
@@ -202,6 +285,10 @@ static void rn_free(innfer_resnet* r) {
         l.d_w3 = nullptr;
         if (l.d_b4) (void)hipFree(l.d_b4);
         l.d_b4 = nullptr;
+        if (l.d_w27) (void)hipFree(l.d_w27);
+        l.d_w27 = nullptr;
+        if (l.d_z32) (void)hipFree(l.d_z32);
+        l.d_z32 = nullptr;
     }
 }
 
@@ -292,6 +379,24 @@ int rn_upload(innfer_resnet* r) {
             INNFER_HIP(hipMalloc((void**)&l.d_b, b3.size() * sizeof(float)));
             INNFER_HIP(hipMemcpy(l.d_b, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        if (!l.transposed && k == 7 && l.cin % 32 == 0 && 9 * l.cout <= 32) {
+            const int K9 = 9 * l.cout;
+            std::vector<float> w27((size_t)K9 * l.cin * 9, 0.f), z32(32, 0.f);
+            for (int co = 0; co < l.cout; ++co)
+                for (int sb = 0; sb < 9; ++sb)
+                    for (int t = 0; t < 9; ++t) {
+                        const int ky = 3 * (sb / 3) + t / 3 - 1, kx = 3 * (sb % 3) + t % 3 - 1;          // index into the 7x7 (the 9x9 has a zero border)
+                        if (ky < 0 || ky > 6 || kx < 0 || kx > 6) continue;
+                        for (int ci = 0; ci < l.cin; ++ci)
+                            w27[((size_t)(co * 9 + sb) * l.cin + ci) * 9 + t] = w[(((size_t)co * l.cin + ci) * 7 + ky) * 7 + kx];
+                    }
+            std::vector<char> packed(conv_packed_bytes(K9, l.cin));
+            conv_pack(w27.data(), K9, l.cin, packed.data());
+            INNFER_HIP(hipMalloc(&l.d_w27, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_w27, packed.data(), packed.size(), hipMemcpyHostToDevice));
+            INNFER_HIP(hipMalloc((void**)&l.d_z32, z32.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(l.d_z32, z32.data(), z32.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (l.transposed && k == 3 && l.cout % 64 == 0 && l.cin % 32 == 0) {
             // ConvTranspose2d(3, stride 2, padding 1, output_padding 1) on the halo-tile kernel (conv3x3_pc<.., TM = 0x1B>, see unet.hip): output phase
             // (a, b) at the virtual pixel (y + a, x + b) reads taps (dy, dx) in {-1, 0}^2 with ky = 1 - a - 2 dy (oy = 2 iy - 1 + ky); ky = 3 does not
@@ -326,7 +431,7 @@ RCarve rcarve(const innfer_resnet* r, int N, int H, int W) {
     auto slab = [&](size_t pixels, int ch) { size_t o = off; off += al(pixels * ch * 2); return o; };
     c.x0 = slab(px, 32); c.s1 = slab(px, 64); c.s2 = slab(px / 4, 128);
     c.a = slab(px / 16, 256); c.b = slab(px / 16, 256); c.c = slab(px / 16, 256);
-    c.u1 = slab(px / 4, 128); c.u2 = slab(px, 64);
+    c.u1 = slab(px / 4, 128); c.u2 = slab((size_t)N * (H + 8) * (W + 8), 64);      // (room for the reflection-padded form the last conv may read)
     c.raw = off; off += al(px * 64 * 4);               // the largest fp32 GEMM result: 64 channels at full resolution
     c.alpha = off; off += al((size_t)N * 256 * 4);
     c.shift = off; off += al((size_t)N * 256 * 4);
@@ -437,7 +542,24 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         f16* tmp = t; t = spare; spare = tmp;
     }
     // upsample_mode 'upconv': nearest-2x + 3x3 conv (zero padding) on the halo-tile kernel, instance norm + ReLU on its fp16 slab
-    auto up_conv = [&](const Layer& l, const f16* in, int Hi, int Wi, f16* dst) -> int {
+    // norm + ReLU of an fp16 conv result; pad: into the reflection-padded (Ho + 8) x (Wo + 8) slab the sub-block form of the last conv reads
+    auto post_relu = [&](const Layer& l, const f16* Y, int Ho, int Wo, f16* dst, bool pad) -> int {
+        const long HW = (long)Ho * Wo, G = (long)N * HW * 32;
+        const long total = (long)N * HW * (l.cout / 8);
+        if (pad) {
+            const long Gp = (long)N * (Ho + 8) * (Wo + 8) * 32;
+            const long ring = (long)N * (l.cout / 32) * (2 * (Wo + 8) + 2 * (Ho + 6)) * 4;
+            hipLaunchKernelGGL(rn_zero_ring, dim3((unsigned)((ring + 255) / 256)), dim3(256), 0, s, dst, l.cout / 32, Ho, Wo, N, Gp);
+            hipLaunchKernelGGL(rn_post_slab_pad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Y, l.cout, Ho, Wo, N,
+                               (const float*)alpha, (const float*)shift, 1, dst, G, Gp);
+        } else {
+            hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Y, l.cout, HW, N,
+                               (const float*)alpha, (const float*)shift, 1, (const f16*)nullptr, dst, G);
+        }
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
+    auto up_conv = [&](const Layer& l, const f16* in, int Hi, int Wi, f16* dst, bool pad) -> int {
         const int Ho = 2 * Hi, Wo = 2 * Wi;
         const long HW = (long)Ho * Wo, G = (long)N * HW * 32;
         f16* Y = (f16*)raw;
@@ -449,14 +571,10 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out_mode = OUT_SLAB;
         CK(conv_launch(L, s));
         CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
-        const long total = (long)N * HW * (l.cout / 8);
-        hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
-                           (const float*)alpha, (const float*)shift, 1, (const f16*)nullptr, dst, G);
-        INNFER_HIP(hipGetLastError());
-        return INNFER_OK;
+        return post_relu(l, Y, Ho, Wo, dst, pad);
     };
     // ConvTranspose whose input grid fills the 16 x 32 tiles: four phase convs in one launch of the halo-tile kernel, fp16 slab out, norm on the slab
-    auto deconv_tile = [&](const Layer& l, const f16* in, int Hi, int Wi, f16* dst) -> int {
+    auto deconv_tile = [&](const Layer& l, const f16* in, int Hi, int Wi, f16* dst, bool pad) -> int {
         const int Ho = 2 * Hi, Wo = 2 * Wi;
         const long HW = (long)Ho * Wo, G = (long)N * HW * 32;
         f16* Y = (f16*)raw;
@@ -468,25 +586,41 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out_mode = OUT_SLAB;
         CK(conv_launch(L, s));
         CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
-        const long total = (long)N * HW * (l.cout / 8);
-        hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
-                           (const float*)alpha, (const float*)shift, 1, (const f16*)nullptr, dst, G);
-        INNFER_HIP(hipGetLastError());
-        return INNFER_OK;
+        return post_relu(l, Y, Ho, Wo, dst, pad);
     };
-    auto fills_tiles = [](int h, int w) { return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * (w <= 16 ? 16 : (w + 31) / 32 * 32) * 7; };
+    auto fills_tiles = [](int h, int w) { return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * (w <= 16 ? 16 : (w + 31) / 32 * 32) * 5; };
+    // the last conv's sub-block form needs its input reflection-padded (written so by the slab post pass) and Q in the fp32 buffer
+    const Layer& last = r->layers.back();
+    bool pad_last = last.d_w27 && H >= 8 && W >= 8 && (size_t)N * 9 * last.cout * (H + 8) * (W + 8) <= (size_t)N * H * W * 64 &&
+                    (long)(H + 8) * (W + 8) * 64 < 0x7fffffffL;
     if (r->layers[li].up2) {
-        CK(up_conv(r->layers[li], t, H4, W4, U1)); ++li;                                                                // u128
-        CK(up_conv(r->layers[li], U1, H2, W2, U2)); ++li;                                                               // u64
+        CK(up_conv(r->layers[li], t, H4, W4, U1, false)); ++li;                                                         // u128
+        CK(up_conv(r->layers[li], U1, H2, W2, U2, pad_last)); ++li;                                                     // u64
     } else if (r->layers[li].transposed && r->layers[li].d_b4 && r->layers[li + 1].d_b4 && fills_tiles(H4, W4)) {
-        CK(deconv_tile(r->layers[li], t, H4, W4, U1)); ++li;                                                            // u128
-        CK(deconv_tile(r->layers[li], U1, H2, W2, U2)); ++li;                                                           // u64
+        CK(deconv_tile(r->layers[li], t, H4, W4, U1, false)); ++li;                                                     // u128
+        CK(deconv_tile(r->layers[li], U1, H2, W2, U2, pad_last)); ++li;                                                 // u64
     } else {
+    pad_last = false;
     CK(deconv(r->layers[li], t, H4, W4)); CK(norm_post(r->layers[li], H2, W2, 1, nullptr, U1)); ++li;                 // u128
     CK(deconv(r->layers[li], U1, H2, W2)); CK(norm_post(r->layers[li], H, W, 1, nullptr, U2)); ++li;                  // u64
     }
     {   // c7s1-out + tanh
         const Layer& l = r->layers[li];
+        if (pad_last) {     // 3x3 conv with nine sub-block channels per output over the padded grid (fp32, planar), then the 9-term gather + bias + tanh
+            const int Hp = H + 8, Wp = W + 8;
+            ConvLaunch L{};
+            L.in = U2; L.in_gstride = (long)N * Hp * Wp * 32; L.C = l.cin;
+            L.wpk = (const f16*)l.d_w27; L.bias = l.d_z32;
+            L.out = raw; L.K = 9 * l.cout; L.N = N; L.H = Hp; L.W = Wp; L.act = 0;
+            L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Hp;
+            L.out_mode = OUT_NCHW; L.out_f32 = 1;
+            CK(conv_launch(L, s));
+            const long total = (long)N * l.cout * H * W;
+            hipLaunchKernelGGL(rn_sum9_tanh, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)raw, (const float*)l.d_b, d_out,
+                               out_dtype == INNFER_F32, l.cout, H, W, N);
+            INNFER_HIP(hipGetLastError());
+            return INNFER_OK;
+        }
         if (l.d_w3) {       // tanh(conv7x7(reflect3(x)) + bias) -> NCHW in the conv's planar epilogue
             ConvLaunch L{};
             L.in = U2; L.in_gstride = (long)N * H * W * 32; L.C = l.cin;

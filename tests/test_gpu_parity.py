@@ -1079,6 +1079,28 @@ def test_cyclegan_resnet_padding_and_dropout_variants_golden(dev, golden):
         drop(x)                                  # use_dropout=True in train mode is random: refused
 
 
+def test_cyclegan_resnet_chop_tile_shapes_vs_oracle(dev):
+    """ResnetGenerator on 200 x 200 chop tiles and a 120 x 200 image (ragged tile rows and columns at every level): the transposed convs on the
+    phase lattice of the halo-tile kernel and the last 7x7 conv in its nine-sub-block form over the reflection-padded slab, batch 2, against the
+    oracle (pinned on the reference by G14 / G22); every image equals its batch-1 forward bit for bit."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.ResNet_arch import ResnetGenerator
+    net = ResnetGenerator(3, 3, 64, norm_type="instance", n_blocks=2)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = _sd(shapes, 333)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    for (h, w, seed) in [(200, 200, 31), (120, 200, 32)]:
+        x = torch.from_numpy(synth.uniform((2, 3, h, w), seed, -1.0, 1.0))
+        y = net(x.to(dev).half())
+        with torch.no_grad():
+            ref = torch.cat([oracle.resnet_forward(sd, x[i:i + 1], n_blocks=2) for i in range(2)], 0)
+        err = (y.float().cpu() - ref).abs()
+        assert err.max().item() < 1e-2 and err.mean().item() < 1e-3, (h, w, err.max().item(), err.mean().item())
+        assert torch.equal(y[1:2], net(x[1:2].to(dev).half()))
+
+
 def test_wbcunet_and_guided_filter_golden(dev, golden):
     """White-box-Cartoonization UNet + the guided filter run.py applies to its output
     against the reference (golden G15).  No norm layers: fp16 slabs, tolerance 5e-3 on outputs of O(0.2)."""
