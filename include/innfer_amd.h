@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x with innfer_pack_conv4x4s2 / innfer_pack_convt2x.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -295,11 +295,17 @@ typedef struct {
     int transposed2x;                   /* 3 | 4: nn.ConvTranspose2d(C, K, kernel_size=k, stride=2, padding=1, output_padding = 1 for k 3 / 0 for k 4) (UNet_arch.py:116-142,
                                            ResNet_arch.py:66-72): d_in is the [N,H,W,C] slab, d_out the [N,2H,2W,K] slab; d_packed from innfer_pack_convt2x(); d_bias holds
                                            the K biases FOUR times (one run per output phase); K % 64 == 0 (any K), act 0 / 1 / 2, no residuals / row range / out_ch_off (104) */
+    int column7;                        /* != 0: nn.Conv2d(C, K, kernel_size=(7, 1), padding=(3, 0)) -- rows zero-padded, or reflected with reflect_pad (ReflectionPad2d rows):
+                                           the 7x7 first convs of ResnetGenerator / UnetGeneratorWBC (ResNet_arch.py:57-60, WBCNet_arch.py:31) over their row-patch slab
+                                           (channel kx * in_nc + c holds the horizontally displaced input); d_packed from innfer_pack_conv7x1(); K % 32 == 0, K <= 64,
+                                           act 0 / 1 / 2, no residuals / row range / out_ch_off (104) */
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);
 int innfer_pack_conv3x3(const float* h_weight_oihw, int K, int C, void* h_packed);
 /* Panels of the two stride-2 forms above: h_weight is torch's layout, [K][C][4][4] for the conv and [C][K][k][k] for the transposed conv (k = 3 | 4). (104) */
+size_t innfer_conv7x1_packed_bytes(int K, int C);
+int innfer_pack_conv7x1(const float* h_weight_oc7, int K, int C, void* h_packed);     /* h_weight [K][C][7] */
 size_t innfer_conv4x4s2_packed_bytes(int K, int C);
 int innfer_pack_conv4x4s2(const float* h_weight_oihw, int K, int C, void* h_packed);
 size_t innfer_convt2x_packed_bytes(int K, int C);

@@ -64,6 +64,8 @@ struct ConvLaunch {
     int dilation_groups;                          // G > 0: K = 32*G, output channel group g is the conv of dilation g+1 (own 32-output panel, panels of
                                                   // conv_pack(K=32) back to back, bias[32*G]): PPON's eight dilated convs in one launch
     int dilation;                                 // > 1: dilated 3x3 conv, zero padding = dilation (PPON); 32-output slab convs only
+    int conv7v;                                   // 7 x 1 column conv, padding 3 rows (zero or `reflect`), panels from conv_pack7v: slab output, K % 32 == 0 -- the 7x7 first
+                                                  // convs of the CycleGAN / WBC generators over their row-patch slab (channel kx * C + c holds the horizontally displaced input)
     int conv7;                                    // 7x7 conv, padding 3 (zero or `reflect`), panels from conv_pack7x7: OUT_NCHW, K <= 16 only
     int reflect;                                  // 1: ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel);
                                                   // 2: ReplicationPad2d(1) (3x3 slab convs)
@@ -94,6 +96,8 @@ void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
 int conv_launch(const ConvLaunch& L, hipStream_t s);
 size_t conv_packed_bytes_taps(int K, int C, int mask);
 void conv_pack_1x1(const float* w_oi, int K, int C, void* packed);    // host; w [K][C]
+size_t conv_packed_bytes7v(int K, int C);
+void conv_pack7v(const float* w_oc7, int K, int C, void* packed);             // host; w [K][C][7]
 size_t conv_packed_bytes_s2k4(int K, int C);
 void conv_pack_s2k4(const float* w_oi44, int K, int C, void* packed);         // host; Conv2d(4, 2, 1) panels for ConvLaunch.stride2
 size_t conv_packed_bytes_deconv2x(int K, int C);

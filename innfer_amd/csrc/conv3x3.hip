@@ -98,6 +98,7 @@ struct KP {
                              // tiles [rate_start[g], rate_start[g+1]) of the launch belong to it (dil unused)
     int dil, fullH, fullW;   // POLY kernels: dilation d; H, W, N are those of the d*d polyphase sub-images (ceil(fullH/d) x ceil(fullW/d), N*d*d of them)
     int ncg;                 // S9 kernels: real 32-channel groups of the input (nchunks = 9 * ncg virtual chunks)
+    int s9v;                 // S9 kernels: only the three VERTICAL displacements (a 7-tap column conv as three 3-tap blocks; nchunks = 3 * ncg)
     int reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d(1)) instead of zero; not with `up`
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
     int total;               // tiles x channel groups of this launch
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             const char* src = in_tile + c * p.in_gbytes;
             if constexpr (S9) {
                 const int sub = c / p.ncg, cg = c - sub * p.ncg;
-                const int sy = 3 * (sub / 3 - 1), sx = 3 * (sub % 3 - 1);
+                const int sy = p.s9v ? 3 * (sub - 1) : 3 * (sub / 3 - 1), sx = p.s9v ? 0 : 3 * (sub % 3 - 1);
                 if (!s9_edge) {
                     src = in_tile + cg * p.in_gbytes + ((long)sy * p.Ws + sx) * 64;        // every displaced pixel is inside the image
 #pragma unroll
@@ -1420,6 +1421,22 @@ void conv_pack_deconv2x(const float* w, int K, int C, int k, void* packed) {
     conv_pack_taps(w3.data(), K4, C, 0x1B, packed);
 }
 
+// 7 x 1 column conv (ConvLaunch.conv7v): w [K][C][7] -> three 3-tap blocks (the 7 taps zero-padded to 9: tap k9 = k7 + 1), virtual channel
+// block * C + ci, centre-column taps only (mask 0x92)
+size_t conv_packed_bytes7v(int K, int C) { return conv_packed_bytes_taps(K, 3 * C, 0x92); }
+void conv_pack7v(const float* w, int K, int C, void* packed) {
+    const int C3 = 3 * C;
+    std::vector<float> w3((size_t)K * C3 * 9, 0.f);
+    for (int co = 0; co < K; ++co)
+        for (int sb = 0; sb < 3; ++sb)
+            for (int r = 0; r < 3; ++r) {
+                const int ky = 3 * sb + r - 1;
+                if (ky < 0 || ky > 6) continue;
+                for (int ci = 0; ci < C; ++ci) w3[((size_t)co * C3 + sb * C + ci) * 9 + r * 3 + 1] = w[((size_t)co * C + ci) * 7 + ky];
+            }
+    conv_pack_taps(w3.data(), K, C3, 0x92, packed);
+}
+
 size_t conv_packed_bytes7x7(int K, int C) { return conv_packed_bytes(K, 9 * C); }
 void conv_pack7x7(const float* w, int K, int C, void* packed) {
     std::vector<float> v((size_t)K * 9 * C * 9, 0.f);
@@ -1465,7 +1482,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.phase_c = (L.out_mode == OUT_NCHW || L.deconv_phases) ? L.phase_c : 0;
     k.reflect = L.reflect == 2 ? 2 : (L.reflect ? 1 : 0);
     if (L.reflect == 2 && (L.conv7 || L.out_mode != OUT_SLAB)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: replication padding is built for 3x3 slab convs");
-    if (L.reflect && (L.up || L.H < (L.conv7 ? 4 : (L.reflect == 2 ? 1 : 2)) || L.W < (L.conv7 ? 4 : (L.reflect == 2 ? 1 : 2))))
+    if (L.reflect && (L.up || L.H < ((L.conv7 || L.conv7v) ? 4 : (L.reflect == 2 ? 1 : 2)) || L.W < (L.conv7 ? 4 : (L.reflect == 2 ? 1 : 2))))
         return set_error(INNFER_ERR_INVALID, "conv3x3: reflection padding needs >= 2x2 pixels and no upsampled input");
     const int nt = conv_nt_for(L.K);
     if (L.out_mode != OUT_NCHW && L.K % (16 * nt))
@@ -1507,6 +1524,13 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         k.Hs = 2 * L.H; k.Ws = 2 * L.W; k.in_img_stride = (long)k.Hs * k.Ws * 32;
         k.nchunks = 4 * k.ncg;
         return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x7B0>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
+    }
+    if (L.conv7v) {        // 7 x 1 column conv (padding 3 rows, zero or reflected) as three vertically displaced 3-tap blocks: panels from conv_pack7v, slab output
+        if (!pc || L.out_mode != OUT_SLAB || (nt != 2 && nt != 4) || L.res1 || L.res2 || L.up || L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.reflect == 2 ||
+            (long)L.H * L.W * 64 >= 0x7fffffffL)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv7x1: slab output of 32- / 64-channel tiles, no residual / upsampling, images below 33 M pixels");
+        k.nchunks = 3 * k.ncg; k.s9v = 1;
+        return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, true, false, 0x92>(k, L.N, s) : launch_pc<3, 2, 4, OUT_SLAB, true, false, 0x92>(k, L.N, s);
     }
     if (L.conv1x1) {        // centre tap only: panels from conv_pack_1x1
         if (!pc || L.out_mode != OUT_SLAB || (nt != 2 && nt != 4))

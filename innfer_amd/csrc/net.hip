@@ -636,6 +636,12 @@ extern "C" int innfer_pack_conv3x3(const float* w, int K, int C, void* h_packed)
     return INNFER_OK;
 }
 
+extern "C" size_t innfer_conv7x1_packed_bytes(int K, int C) { return (K > 0 && C > 0 && C % 32 == 0) ? conv_packed_bytes7v(K, C) : 0; }
+extern "C" int innfer_pack_conv7x1(const float* w, int K, int C, void* packed) {
+    if (!w || !packed || K <= 0 || K % 32 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv7x1: K=%d (%% 32) C=%d (%% 32)", K, C);
+    conv_pack7v(w, K, C, packed);
+    return INNFER_OK;
+}
 extern "C" size_t innfer_conv4x4s2_packed_bytes(int K, int C) { return (K > 0 && C > 0 && C % 32 == 0) ? conv_packed_bytes_s2k4(K, C) : 0; }
 extern "C" int innfer_pack_conv4x4s2(const float* w, int K, int C, void* packed) {
     if (!w || !packed || K <= 0 || K % 64 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv4x4s2: K=%d (%% 64) C=%d (%% 32)", K, C);
@@ -651,6 +657,18 @@ extern "C" int innfer_pack_convt2x(const float* w, int K, int C, int k, void* pa
 
 extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     if (!a || !a->d_in || !a->d_packed || !a->d_bias || !a->d_out) return set_error(INNFER_ERR_INVALID, "conv3x3: null argument");
+    if (a->column7) {
+        if (a->K <= 0 || a->K % 32 || a->K > 64 || a->out_ch_off || a->row_begin || a->row_end || a->dilation > 1 || a->dilation_groups || a->pixel_shuffle2 ||
+            a->upsample2x || a->d_res1 || a->d_res2 || a->stride2_k4 || a->transposed2x || a->act < 0 || a->act > 2)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv7x1: K %% 32 == 0, K <= 64 (K=%d), act 0..2, all rows, no residual / upsampling", a->K);
+        ConvLaunch L{};
+        L.in = (const f16*)a->d_in; L.in_gstride = a->in_group_stride; L.C = a->C;
+        L.wpk = (const f16*)a->d_packed; L.bias = a->d_bias;
+        L.out = a->d_out; L.out_gstride = a->out_group_stride; L.K = a->K;
+        L.N = a->N; L.H = a->H; L.W = a->W; L.act = a->act; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = a->H; L.out_mode = OUT_SLAB;
+        L.conv7v = 1; L.reflect = a->reflect_pad ? 1 : 0;
+        return conv_launch(L, (hipStream_t)stream);
+    }
     if (a->stride2_k4 || a->transposed2x) {
         if ((a->stride2_k4 && a->transposed2x) || (a->transposed2x && a->transposed2x != 3 && a->transposed2x != 4) || a->K <= 0 || a->K % 64 || a->out_ch_off ||
             a->row_begin || a->row_end || a->dilation > 1 || a->dilation_groups || a->reflect_pad || a->pixel_shuffle2 || a->upsample2x || a->d_res1 || a->d_res2 ||

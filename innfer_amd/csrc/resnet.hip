@@ -379,6 +379,19 @@ int rn_upload(innfer_resnet* r) {
             INNFER_HIP(hipMalloc((void**)&l.d_b, b3.size() * sizeof(float)));
             INNFER_HIP(hipMemcpy(l.d_b, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        if (!l.transposed && k == 7 && 7 * l.cin <= 32 && l.cout % 32 == 0) {
+            // first conv over the row-patch slab (rn_pre) as a 7 x 1 column conv on the halo-tile kernel (three vertically displaced 3-tap blocks,
+            // rows reflected by the loader): fp16 slab out, norm on the slab
+            std::vector<float> wv((size_t)l.cout * 32 * 7, 0.f);
+            for (int co = 0; co < l.cout; ++co)
+                for (int kx = 0; kx < 7; ++kx)
+                    for (int c = 0; c < l.cin; ++c)
+                        for (int ky = 0; ky < 7; ++ky) wv[((size_t)co * 32 + kx * l.cin + c) * 7 + ky] = w[((size_t)co * l.cin + c) * 49 + ky * 7 + kx];
+            std::vector<char> packed(conv_packed_bytes7v(l.cout, 32));
+            conv_pack7v(wv.data(), l.cout, 32, packed.data());
+            INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        }
         if (!l.transposed && k == 7 && l.cin % 32 == 0 && 9 * l.cout <= 32) {
             const int K9 = 9 * l.cout;
             std::vector<float> w27((size_t)K9 * l.cin * 9, 0.f), z32(32, 0.f);
@@ -525,6 +538,25 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     const int patch = 7 * r->in_nc <= 32;
     hipLaunchKernelGGL(rn_pre, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, r->in_nc, H, W, N, X0, patch);
     INNFER_HIP(hipGetLastError());
+    if (patch && r->layers[li].d_w3 && H >= 4 && (long)H * W * 64 < 0x7fffffffL) {
+        // c7s1-64 as a 7 x 1 column conv over the row-patch slab on the halo-tile kernel (rows reflected by its loader), fp16 slab out, norm on the slab
+        const Layer& l = r->layers[li];
+        const long HW = (long)H * W, G = (long)N * HW * 32;
+        f16* Y = (f16*)raw;
+        ConvLaunch L{};
+        L.in = X0; L.in_gstride = G; L.C = 32;
+        L.wpk = (const f16*)l.d_w3; L.bias = l.d_b;
+        L.out = Y; L.out_gstride = G; L.K = l.cout;
+        L.N = N; L.H = H; L.W = W; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = H;
+        L.out_mode = OUT_SLAB; L.conv7v = 1; L.reflect = 1;
+        CK(conv_launch(L, s));
+        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        const long total = (long)N * HW * (l.cout / 8);
+        hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
+                           (const float*)alpha, (const float*)shift, 1, (const f16*)nullptr, S1, G);
+        INNFER_HIP(hipGetLastError());
+        ++li;
+    } else {
     if (patch) {
         int dy7[7], dx7[7];
         for (int t = 0; t < 7; ++t) { dy7[t] = t - 3; dx7[t] = 0; }
@@ -532,6 +564,7 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     } else
     CK(conv(r->layers[li], X0, H, W, H, W, 1, 1));
     CK(norm_post(r->layers[li], H, W, 1, nullptr, S1)); ++li;          // c7s1-64
+    }
     CK(conv(r->layers[li], S1, H, W, H2, W2, 2, 0)); CK(norm_post(r->layers[li], H2, W2, 1, nullptr, S2)); ++li;     // d128
     CK(conv(r->layers[li], S2, H2, W2, H4, W4, 2, 0)); CK(norm_post(r->layers[li], H4, W4, 1, nullptr, A)); ++li;    // d256
     f16* t = A;

@@ -304,6 +304,23 @@ int wb_upload(innfer_wbc* u) {
         INNFER_HIP(hipMemcpy(l.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
         INNFER_HIP(hipMalloc((void**)&l.d_b, l.cout * sizeof(float)));
         INNFER_HIP(hipMemcpy(l.d_b, u->params[l.b].host.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+        if (l.k == 7 && 7 * l.cin <= 32 && l.cout % 32 == 0) {
+            // first conv over the row-patch slab as a 7 x 1 column conv on the halo-tile kernel (three vertically displaced 3-tap blocks, conv_pack7v):
+            // bias + LeakyReLU + the fp16 slab come out of its epilogue (gather GEMM -> 64-wide fp32 rows -> wb_post took 282 us at 1080p)
+            std::vector<float> wv((size_t)l.cout * 32 * 7, 0.f);
+            for (int co = 0; co < l.cout; ++co)
+                for (int kx = 0; kx < 7; ++kx)
+                    for (int c = 0; c < l.cin; ++c)
+                        for (int ky = 0; ky < 7; ++ky) wv[((size_t)co * 32 + kx * l.cin + c) * 7 + ky] = w[((size_t)co * l.cin + c) * 49 + ky * 7 + kx];
+            std::vector<char> packed(conv_packed_bytes7v(l.cout, 32));
+            conv_pack7v(wv.data(), l.cout, 32, packed.data());
+            std::vector<float> b3((size_t)(l.cout + 63) / 64 * 64, 0.f);
+            for (int c = 0; c < l.cout; ++c) b3[c] = u->params[l.b].host[c];
+            INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
+            INNFER_HIP(hipMalloc((void**)&l.d_b3, b3.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(l.d_b3, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (l.k == 7 && l.cin % 32 == 0 && l.cout <= 16) {          // last conv (32 -> 3): nine displaced 3x3 convs on the halo-tile kernel
             std::vector<char> packed(conv_packed_bytes7x7(l.cout, l.cin));
             conv_pack7x7(w.data(), l.cout, l.cin, packed.data());
@@ -383,6 +400,15 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
             L.out = nchw; L.K = l.cout; L.N = N; L.H = Ho; L.W = Wo; L.act = act ? 1 : 0;
             L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Ho;
             L.out_mode = OUT_NCHW; L.out_f32 = out_dtype == INNFER_F32; L.conv7 = 1;
+            return conv_launch(L, s);
+        }
+        if (l.d_w3 && l.k == 7 && 7 * l.cin <= 32 && stride == 1 && !nchw && !res) {     // first conv: 7 x 1 column conv over the row-patch slab
+            ConvLaunch L{};
+            L.in = in; L.in_gstride = (long)N * Hi * Wi * 32; L.C = 32;
+            L.wpk = (const f16*)l.d_w3; L.bias = l.d_b3;
+            L.out = dst; L.out_gstride = (long)N * Ho * Wo * 32; L.K = l.cout;
+            L.N = N; L.H = Ho; L.W = Wo; L.act = act ? 1 : 0; L.s1 = L.s2 = 1.f;
+            L.y0 = 0; L.y1 = Ho; L.out_mode = OUT_SLAB; L.conv7v = 1;
             return conv_launch(L, s);
         }
         if (l.d_w3 && l.k == 3 && stride == 1 && !nchw) {     // zero-padded stride-1 3x3 conv: the SR path's halo-tile kernel, epilogue = bias / LeakyReLU / + residual

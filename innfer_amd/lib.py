@@ -45,7 +45,7 @@ class ConvArgs(C.Structure):
         ("d_res2", C.c_void_p), ("res2_group_stride", C.c_int64), ("res2_scale", C.c_float),
         ("row_begin", C.c_int), ("row_end", C.c_int),
         ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int), ("pixel_shuffle2", C.c_int),
-        ("stride2_k4", C.c_int), ("transposed2x", C.c_int),
+        ("stride2_k4", C.c_int), ("transposed2x", C.c_int), ("column7", C.c_int),
     ]
 
 
@@ -126,6 +126,8 @@ SIGNATURES = {
     "innfer_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv3x3_f16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "innfer_conv7x1_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "innfer_pack_conv7x1": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv4x4s2_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv4x4s2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_convt2x_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -795,6 +795,42 @@ def test_stride2_conv_and_transposed_conv_vs_torch(dev):
             assert got.shape == ref.shape and (got - ref).abs().max().item() < 4e-3, ("up", k, N, Cc, K, H, W, (got - ref).abs().max().item())
 
 
+def test_column7_conv_vs_torch(dev):
+    """The 7 x 1 column conv of the single-conv ABI (three vertically displaced 3-tap blocks of the halo-tile kernel) against torch: zero-padded
+    and reflected rows, 32 / 64 outputs, 32 / 64 input channels, ragged and sub-tile sizes, batches."""
+    import torch.nn.functional as F
+    import innfer_amd.lib as L
+    rng = np.random.RandomState(5)
+    for i, (N, Cc, K, H, W, reflect) in enumerate([(1, 32, 32, 32, 40, 0), (1, 32, 64, 32, 40, 1), (2, 32, 64, 64, 64, 1), (1, 64, 32, 19, 70, 0),
+                                                   (2, 32, 32, 8, 33, 1), (1, 32, 64, 50, 50, 0), (1, 32, 64, 4, 9, 1)]):
+        act = i % 3
+        x = torch.from_numpy(rng.uniform(-1, 1, (N, Cc, H, W)).astype(np.float32)).half()
+        w = torch.from_numpy((rng.uniform(-1, 1, (K, Cc, 7)) / np.sqrt(7 * Cc)).astype(np.float32)).half().float()
+        b = torch.from_numpy(rng.uniform(-0.5, 0.5, K).astype(np.float32))
+        xp = F.pad(x.float(), (0, 0, 3, 3), mode="reflect") if reflect else F.pad(x.float(), (0, 0, 3, 3))
+        ref = F.conv2d(xp, w[:, :, :, None], b)
+        ref = ref if act == 0 else F.leaky_relu(ref, 0.2) if act == 1 else F.relu(ref)
+        g = N * H * W * 32
+        slab = torch.full((Cc // 32, N, H, W, 32), 7.0, dtype=torch.float16, device=dev)
+        L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), g, 0, N, Cc, H, W, None))
+        packed = np.zeros(L.lib.innfer_conv7x1_packed_bytes(K, Cc), dtype=np.uint8)
+        wc = np.ascontiguousarray(w.numpy())
+        L.check(L.lib.innfer_pack_conv7x1(wc.ctypes.data, K, Cc, packed.ctypes.data))
+        d_packed, d_bias = torch.from_numpy(packed).to(dev), torch.cat([b, torch.zeros(64 - K)]).to(dev)
+        out = torch.full((max(K, 32) // 32, N, H, W, 32), -3.0, dtype=torch.float16, device=dev)
+        a = L.ConvArgs()
+        a.d_in, a.in_group_stride, a.C = slab.data_ptr(), g, Cc
+        a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
+        a.d_out, a.out_group_stride, a.K = out.data_ptr(), g, K
+        a.N, a.H, a.W, a.act, a.column7, a.reflect_pad = N, H, W, act, 1, reflect
+        L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
+        res = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
+        L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), g, 0, res.data_ptr(), L.F32, N, K, H, W, None))
+        torch.cuda.synchronize()
+        err = (res.cpu() - ref).abs().max().item()
+        assert err < 4e-3, (N, Cc, K, H, W, reflect, err)
+
+
 def test_unet256_upconv_full_depth_vs_oracle(dev):
     """upsample_mode='upconv' at unet_256's full depth (8 levels, 1x1 bottleneck -> the 3x3 conv runs on 2x2 .. 256x256 upsampled grids
     with 512 .. 1024 input channels), batch 2, train-mode and eval-mode BatchNorm, against the oracle (itself pinned on the reference, G23)."""
