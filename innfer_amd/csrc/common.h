@@ -60,6 +60,7 @@ struct ConvLaunch {
                                                   // conv_pack_taps(mask 0x1B), H x W = the INPUT grid, fp16 slab output of 2H x 2W pixels and phase_c channels
     int stride2;                                  // Conv2d(k 4, s 2, p 1) as the 2x2-tap conv of the space-to-depth source (gathered by the loader): H x W = the OUTPUT grid,
                                                   // the source slab holds 2H x 2W pixels; panels from conv_pack_taps(K, 4 * C, 0x1B0)
+    int prefix_lrelu;                             // with conv1x1: the operand of input group k is LeakyReLU(0.2)(group 0 + .. + group k) (fp32 running sums): PPON's c2
     int conv1x1;                                  // 1x1 conv: the centre tap only is staged and multiplied (panels from conv_pack_1x1); slab outputs
     int dilation_groups;                          // G > 0: K = 32*G, output channel group g is the conv of dilation g+1 (own 32-output panel, panels of
                                                   // conv_pack(K=32) back to back, bias[32*G]): PPON's eight dilated convs in one launch

@@ -637,6 +637,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int TM = TMF & 0x1FF;
     constexpr bool S2 = (TMF & 0x200) != 0;
     constexpr int NSEG = (TMF & 0x400) ? 1 : 2;
+    // + 0x800 (one-tap kernels): the B operand of chunk k is LeakyReLU(0.2) of the running sum of chunks 0 .. k of the pixel -- PPON's
+    // cat(d1, d1 + d2, .., d1 + .. + d8) -> act -> c2 (PPON_arch.py:104-114) without the pass that materialises it: the consumer keeps the
+    // fp32 running sums of its own pixels in registers (same additions in the same order as that pass made: same bits)
+    constexpr bool PFX = (TMF & 0x800) != 0;
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -971,6 +975,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     f32x4 bias_r[NT];
     int bias_kg = -1;
     f32x4 acc[NT][MT];
+    float pfx[PFX ? MT : 1][8];
+    (void)pfx;
     int jt = j0, c = 0;
     int kg = 0, n = 0, ty0 = 0, tx0 = 0, cbase = 0, dcur = 1;
     asm volatile("s_barrier" ::: "memory");                       // chunk 0 of the first tile has landed
@@ -991,6 +997,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[t][m] = bias_r[t];
+            if constexpr (PFX) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pfx[m][e] = 0.f;
+            }
         }
         const char* st = NSI == 3 ? smem + islot * IN_BYTES : smem + (g & 1) * STAGE;                       // halo tile
         const char* sw = NSI == 3 ? smem + 3 * IN_BYTES + (g & 1) * W_BYTES : st + IN_BYTES;              // weight panel
@@ -1063,7 +1075,16 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 if (!need) continue;
 #pragma unroll
                 for (int seg = 0; seg < NSEG; ++seg) {
-                    const f16x8 b = *(const f16x8*)(st + boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64);
+                    f16x8 b = *(const f16x8*)(st + boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64);
+                    if constexpr (PFX) {           // (one tap: row rr feeds output row rr - 1 only)
+                        static_assert(!PFX || TM == 0x10, "the running-sum operand belongs to the one-tap kernels");
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float& run = pfx[PFX ? (rr - 1) * 2 + seg : 0][e];
+                            run += (float)b[e];
+                            b[e] = (f16)fmaxf(run, 0.2f * run);
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         const int rw = rr - r;
@@ -1535,6 +1556,10 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (L.conv1x1) {        // centre tap only: panels from conv_pack_1x1
         if (!pc || L.out_mode != OUT_SLAB || (nt != 2 && nt != 4))
             return set_error(INNFER_ERR_UNSUPPORTED, "conv1x1: slab outputs of 32- / 64-channel tiles on the producer-consumer kernel");
+        if (L.prefix_lrelu) {
+            if (nt != 4) return set_error(INNFER_ERR_UNSUPPORTED, "conv1x1: the running-sum operand is built for 64-channel tiles");
+            return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x810>(k, L.N, s);
+        }
         return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s) : launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 2) {

@@ -408,7 +408,8 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
                 Ld.out = COMB; Ld.out_gstride = G; Ld.K = 256; Ld.N = N; Ld.H = H; Ld.W = W; Ld.act = 0;
                 Ld.s1 = Ld.s2 = 1.f; Ld.y0 = 0; Ld.y1 = H; Ld.out_mode = OUT_SLAB; Ld.dilation_groups = 8;
                 CK(conv_launch(Ld, s));
-                hipLaunchKernelGGL(ppon_comb_slab, dim3((unsigned)((px * 4 + 255) / 256)), dim3(256), 0, s, COMB, G, px);
+                // (d1, d1 + d2, .., d1 + .. + d8 -> LeakyReLU is the operand transform of c2 below; without the one-tap c2 the pass that writes it)
+                if (!r.d_c2t) hipLaunchKernelGGL(ppon_comb_slab, dim3((unsigned)((px * 4 + 255) / 256)), dim3(256), 0, s, COMB, G, px);
             } else {
             for (int t = 0; t < 9; ++t) { dy[t] = t / 3 - 1; dx[t] = t % 3 - 1; }
             CK(gg::launch(r.d_dw, 64, 64, O1, G, N, H, W, raw, H, W, 1, 9, dy, dx, H, W, 1, 0, 0, 0, s, nullptr, 0, RAW_ROW, 0,
@@ -425,6 +426,7 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
                 Lc.res1 = cur; Lc.res1_gstride = G; Lc.s1 = 0.2f;
                 if (k == 2) { Lc.res2 = x; Lc.res2_gstride = G; }
                 Lc.s2 = 0.2f; Lc.y0 = 0; Lc.y1 = H; Lc.out_mode = OUT_SLAB; Lc.conv1x1 = 1;
+                Lc.prefix_lrelu = r.d_dw3[0] ? 1 : 0;          // COMB holds d1 .. d8 as the dilated convs wrote them
                 CK(conv_launch(Lc, s));
             } else {
             CK(gg::launch(r.d_c2, 256, 64, COMB, G, N, H, W, raw2, H, W, 1, 1, d0, d0, H, W, 1, 0, 0, 0, s));
