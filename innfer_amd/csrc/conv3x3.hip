@@ -725,7 +725,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
                 const int ry = S2 ? 2 * ly : p.up ? (ly + ypar) >> 1 : ly;
                 const int rx = S2 ? 2 * lx : p.up ? (lx + 1) >> 1 : lx;
-                loff[k] = (px < NPX && lx < LVALID) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
+                // only the halo rows / columns a tap of the mask reads are fetched (a 1x1 conv: none; the other lanes' pieces arrive as zeros
+                // without memory traffic)
+                constexpr int R0 = (TM & 0x007) ? 0 : (TM & 0x038) ? 1 : 2, R1 = (TM & 0x1C0) ? 2 : (TM & 0x038) ? 1 : 0;
+                constexpr int S0 = (TM & 0x049) ? 0 : (TM & 0x092) ? 1 : 2, S1 = (TM & 0x124) ? 2 : (TM & 0x092) ? 1 : 0;
+                const bool used = ly >= R0 && ly <= TH - 1 + R1 && lx >= S0 && lx <= TW - 1 + S1;
+                loff[k] = (px < NPX && lx < LVALID && used) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
                 if constexpr (POLY) {          // the tile's dilation scales the pixel part: voff = lpix * d + slot (setup)
                     lpix[k] = (px < NPX && lx < LVALID) ? (ly * p.fullW + lx) * 64 : -1;
                     loff[k] = slot * 16;
