@@ -180,9 +180,10 @@ int innfer_unet_forward(innfer_unet_t u, const void* d_in, int in_dtype, void* d
 typedef struct innfer_pan* innfer_pan_t;
 int innfer_pan_create(innfer_pan_t* out, int in_nc, int out_nc, int nf, int unf, int nb, int scale);
 /* The same with PAN's graph-changing constructor arguments (PAN_arch.py:115-141): self_attention = 0 drops the FSA block (fea + trunk goes
- * straight to the upsampler), double_scpa != 0 runs a second SCPA trunk + `trunk_conv2` behind the first.  innfer_pan_create(...) =
- * innfer_pan_create_ex(..., 1, 0).  (104) */
-int innfer_pan_create_ex(innfer_pan_t* out, int in_nc, int out_nc, int nf, int unf, int nb, int scale, int self_attention, int double_scpa);
+ * straight to the upsampler), double_scpa != 0 runs a second SCPA trunk + `trunk_conv2` behind the first, bilinear_up != 0 =
+ * ups_inter_mode 'bilinear' (the up-blocks' B.Upsample(2, mode), align_corners False: PAN_arch.py:11-19, block.py:286-323) instead of 'nearest'.
+ * innfer_pan_create(...) = innfer_pan_create_ex(..., 1, 0, 0).  (104) */
+int innfer_pan_create_ex(innfer_pan_t* out, int in_nc, int out_nc, int nf, int unf, int nb, int scale, int self_attention, int double_scpa, int bilinear_up);
 void innfer_pan_destroy(innfer_pan_t p);
 int innfer_pan_num_params(innfer_pan_t p);
 int innfer_pan_param_info(innfer_pan_t p, int idx, char* key, size_t key_cap, int* ndim, int* shape4);

@@ -2,7 +2,7 @@
 (conv_first, SCPA_trunk.<b>.{conv1_a,conv1_b,k1.0,PACnv.k2,PACnv.k3,PACnv.k4,conv3}, trunk_conv,
 FSA.{gamma,conv_f,conv_g,conv_h}, upsample.<i>, conv_last), forward runs in libinnfer_amd.so
 (csrc/pan.hip).  Built: the configuration utils/defaults.py:78-89 produces (self-attention on,
-single SCPA, nearest up-blocks)."""
+single SCPA, nearest up-blocks) and the constructor's other values (self_attention, double_scpa, ups_inter_mode 'bilinear')."""
 from .param_module import ParamEngineModule
 
 
@@ -12,11 +12,12 @@ class PAN(ParamEngineModule):
     def __init__(self, in_nc=3, out_nc=3, nf=40, unf=24, nb=16, scale=4, self_attention=True,
                  double_scpa=False, ups_inter_mode='nearest'):
         super().__init__()
-        if ups_inter_mode != 'nearest':
-            raise NotImplementedError('PAN: only nearest up-blocks are built (ups_inter_mode)')
+        if ups_inter_mode not in ('nearest', 'bilinear'):
+            raise NotImplementedError("PAN: ups_inter_mode 'nearest' and 'bilinear' are built")
+        self.ups_inter_mode = ups_inter_mode
         self.in_nc, self.out_nc, self.nf, self.unf, self.nb, self.scale = in_nc, out_nc, nf, unf, nb, scale
         self.self_attention, self.double_scpa = bool(self_attention), bool(double_scpa)
-        self._init_engine(in_nc, out_nc, nf, unf, nb, scale, int(self.self_attention), int(self.double_scpa))
+        self._init_engine(in_nc, out_nc, nf, unf, nb, scale, int(self.self_attention), int(self.double_scpa), int(ups_inter_mode == 'bilinear'))
 
     def _fn(self, name):
         return super()._fn('create_ex' if name == 'create' else name)

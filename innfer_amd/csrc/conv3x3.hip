@@ -980,8 +980,11 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     f32x4 bias_r[NT];
     int bias_kg = -1;
     f32x4 acc[NT][MT];
-    float pfx[PFX ? MT : 1][8];
-    (void)pfx;
+    float pfx[PFX ? MT : 1][8];          // (cleared after a tile's last chunk, in front of its epilogue: live sums there would cost the epilogue's registers)
+#pragma unroll
+    for (int m = 0; m < (PFX ? MT : 1); ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pfx[m][e] = 0.f;
     int jt = j0, c = 0;
     int kg = 0, n = 0, ty0 = 0, tx0 = 0, cbase = 0, dcur = 1;
     asm volatile("s_barrier" ::: "memory");                       // chunk 0 of the first tile has landed
@@ -1002,12 +1005,6 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[t][m] = bias_r[t];
-            if constexpr (PFX) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pfx[m][e] = 0.f;
-            }
         }
         const char* st = NSI == 3 ? smem + islot * IN_BYTES : smem + (g & 1) * STAGE;                       // halo tile
         const char* sw = NSI == 3 ? smem + 3 * IN_BYTES + (g & 1) * W_BYTES : st + IN_BYTES;              // weight panel
@@ -1109,6 +1106,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         if (++c == p.nchunks) {
             c = 0;
             jt += slots;
+            if constexpr (PFX) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pfx[m][e] = 0.f;
+            }
             if constexpr (OUTMODE == OUT_SLAB && CV) {
 #define EPI(A, B, C) epilogue_slab_cv<RPW, NT, A, B, C>(p, acc, ty0, tx0, cw, li, cbase)
             if (!p.res1) {

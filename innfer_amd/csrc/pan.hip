@@ -219,6 +219,34 @@ __global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f
     *(f16x8*)(dst + so) = h;
 }
 
+// F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False) on a blocked slab (ATen upsample_bilinear2d: source index
+// max(0, (dst + 0.5) / 2 - 0.5), the second tap clamped to the last pixel, fp32 arithmetic in ATen's association); one thread per
+// (output pixel, 8 channels) of `groups` 32-channel groups
+__global__ void pan_up_bilinear2x(const f16* src, long sg, f16* dst, long dg, int groups, int N, int h, int w) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int H2 = 2 * h, W2 = 2 * w;
+    const long total = (long)N * H2 * W2 * groups * 4;
+    if (i >= total) return;
+    const int q = (int)(i & 3);
+    long r = i >> 2;
+    const int grp = (int)(r % groups); r /= groups;
+    const int x = (int)(r % W2), y = (int)((r / W2) % H2);
+    const long n = r / ((long)W2 * H2);
+    const float sy = fmaxf(0.5f * ((float)y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const f16* b = src + grp * sg + n * (long)h * w * 32 + q * 8;
+    const f16x8 v00 = *(const f16x8*)(b + ((long)y0 * w + x0) * 32), v01 = *(const f16x8*)(b + ((long)y0 * w + x1) * 32);
+    const f16x8 v10 = *(const f16x8*)(b + ((long)y1 * w + x0) * 32), v11 = *(const f16x8*)(b + ((long)y1 * w + x1) * 32);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        o[e] = (f16)(hy * (hx * (float)v00[e] + lx * (float)v01[e]) + ly * (hx * (float)v10[e] + lx * (float)v11[e]));
+    *(f16x8*)(dst + grp * dg + ((n * H2 + y) * (long)W2 + x) * 32 + q * 8) = o;
+}
+
+
 // out = conv_last + bias + bilinear(x, align_corners=True) -> NCHW
 // (rs == 0: raw is the planar fp32 [N][C][FH][FW] output of the halo-tile conv, bias already added)
 __global__ void pan_final(const float* raw, int rs, const float* bias, int C, const void* x, int x_f32, int N, int H, int W,
@@ -267,6 +295,7 @@ struct Gemm {                       // one packed GEMM
 
 struct innfer_pan {
     int in_nc = 3, out_nc = 3, nf = 40, unf = 24, nb = 16, scale = 4, n_up = 2;
+    bool bilinear_up = false;              // ups_inter_mode 'bilinear': the up-blocks' Upsample(2) as its own pass (nearest rides in the conv's loader)
     bool self_attention = true;      // FSA after fea + trunk (PAN_arch.py:200-203)
     bool double_scpa = false;        // a second SCPA trunk + trunk_conv2 behind the first (PAN_arch.py:139-141,195-196)
     std::vector<Param> params;
@@ -282,10 +311,10 @@ static int P(innfer_pan* p, const std::string& key, std::vector<int> shape) {
 }
 
 extern "C" int innfer_pan_create(innfer_pan** out, int in_nc, int out_nc, int nf, int unf, int nb, int scale) {
-    return innfer_pan_create_ex(out, in_nc, out_nc, nf, unf, nb, scale, 1, 0);
+    return innfer_pan_create_ex(out, in_nc, out_nc, nf, unf, nb, scale, 1, 0, 0);
 }
 
-extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int nf, int unf, int nb, int scale, int self_attention, int double_scpa) {
+extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int nf, int unf, int nb, int scale, int self_attention, int double_scpa, int bilinear_up) {
     if (!out) return set_error(INNFER_ERR_INVALID, "pan_create: null out");
     if (nf != 40 || unf != 24 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || nb < 1 ||
         (scale != 1 && scale != 2 && scale != 4))
@@ -293,7 +322,7 @@ extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int
     innfer_pan* p = new innfer_pan();
     p->in_nc = in_nc; p->out_nc = out_nc; p->nf = nf; p->unf = scale == 1 ? nf : unf; p->nb = nb; p->scale = scale;
     p->n_up = scale == 4 ? 2 : (scale == 2 ? 1 : 0);
-    p->self_attention = self_attention != 0; p->double_scpa = double_scpa != 0;
+    p->self_attention = self_attention != 0; p->double_scpa = double_scpa != 0; p->bilinear_up = bilinear_up != 0;
     const int gw = nf / 2, UF = p->unf;
     P(p, "conv_first.weight", {nf, in_nc, 3, 3}); P(p, "conv_first.bias", {nf});
     for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {          // registration order of PAN.__init__ (PAN_arch.py:134-141)
@@ -480,7 +509,7 @@ int upload(innfer_pan* p) {
     return INNFER_OK;
 }
 
-struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, k3v, inp, t, pool, fgh, att, raw, hr[2][3], total, slab_end; };
+struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, k3v, inp, t, pool, fgh, att, raw, hr[2][3], ups, total, slab_end; };
 
 PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     PCarve c{};
@@ -492,6 +521,8 @@ PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     c.ab2 = slab(px, 2); c.k3y = slab(px, 1); c.k3v = slab(px, 1); c.inp = slab(px, 2); c.t = slab(px, 2); c.pool = slab(np ? np : 1, 2);
     size_t m = 1;
     for (int u = 0; u < p->n_up; ++u) { m *= 4; for (int k = 0; k < 3; ++k) c.hr[u][k] = slab(px * m, 1); }
+    // ups_inter_mode 'bilinear': the upsampled input of a stage (stage 0: 4 px of 2 groups; stage 1: 16 px of 1 group -- the larger of the two)
+    c.ups = (p->bilinear_up && p->n_up) ? (p->n_up == 2 ? slab(px * 16, 1) : slab(px * 4, 2)) : 0;
     c.slab_end = off;
     c.fgh = off; off += al((np ? np : 1) * 64 * 4);
     c.att = off; off += al((np ? np : 1) * p->nf * 4);
@@ -601,6 +632,14 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         const int hh = 2 * h, ww = 2 * w;
         const long hpx = (long)N * hh * ww, HG = hpx * 32;
         f16 *V = (f16*)(ws + cv.hr[u][0]), *PA = (f16*)(ws + cv.hr[u][1]), *HRC = (f16*)(ws + cv.hr[u][2]);
+        if (p->bilinear_up) {                                                          // conv(bilinear2x(t)): the upsampling as its own pass
+            f16* UPS = (f16*)(ws + cv.ups);
+            const int groups = u == 0 ? 2 : 1;                                         // nf = 40 / unf = 24 channels (pad channels stay zero: 0 interpolates to 0)
+            const long tot = hpx * groups * 4;
+            hipLaunchKernelGGL(pan_up_bilinear2x, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, cur, cur_g, UPS, HG, groups, N, h, w);
+            INNFER_HIP(hipGetLastError());
+            CK(conv3(UPS, HG, hh, ww, 0, 0, nullptr, 0, V, HG));
+        } else
         CK(conv3(cur, cur_g, hh, ww, 1, 0, nullptr, 0, V, HG));                        // conv(nearest2x(t))
         CK(conv3(V, HG, hh, ww, 0, 4, V, HG, PA, HG));                                 // PA: lrelu(v * sigmoid(conv1x1(v)))
         // HRconv.  Two stages (4x): PAN's outer B.sequential flattens the stages with children(), which yields the shared LeakyReLU once per

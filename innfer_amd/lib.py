@@ -87,7 +87,7 @@ SIGNATURES = {
     "innfer_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_pan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "innfer_pan_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 8),
+    "innfer_pan_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 9),
     "innfer_pan_destroy": (None, [C.c_void_p]),
     "innfer_pan_num_params": (C.c_int, [C.c_void_p]),
     "innfer_pan_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -207,7 +207,7 @@ def unet_forward(sd, x, num_downs=8, eps=1e-5, training=True, norm_type="batch",
     return block(x, "model.", 0)
 
 
-def pan_forward(sd, x, nb=16, scale=4, self_attention=True, double_scpa=False):
+def pan_forward(sd, x, nb=16, scale=4, self_attention=True, double_scpa=False, ups_inter_mode="nearest"):
     """PAN.forward (PAN_arch.py:178-222) with the defaults of defaults.py:78-89 (nf 40, unf 24,
     self_attention, nearest up-blocks): SCPA blocks (PAN_arch.py:56-99), PA / PACnv pixel attention
     (:21-55), max-pooled SAGAN self attention (block.py:398-473), bilinear(align_corners) global skip.
@@ -253,7 +253,8 @@ def pan_forward(sd, x, nb=16, scale=4, self_attention=True, double_scpa=False):
         # (2x, 3x) B.sequential returns the stage's own nn.Sequential untouched (block.py:197-210), whose six slots hold `a`
         # twice: there HRconv IS followed by the LeakyReLU (pinned by golden G18 `double_noattn_x2`).
         i = 5 * u
-        t = F.interpolate(t, scale_factor=2.0 if scale != 3 else 3.0, mode="nearest")
+        # B.Upsample(scale_factor, mode) (block.py:286-323): align_corners stays None, i.e. False for 'bilinear'
+        t = F.interpolate(t, scale_factor=2.0 if scale != 3 else 3.0, mode=ups_inter_mode)
         t = conv(t, f"upsample.{i + 1}", 1)
         t = F.leaky_relu(t * torch.sigmoid(conv(t, f"upsample.{i + 2}.conv")), 0.2)
         t = conv(t, f"upsample.{i + 4}", 1)

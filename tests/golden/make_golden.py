@@ -576,7 +576,9 @@ def g18():
     from architectures.PAN_arch import PAN as RefPAN
     out = {}
     for i, (tag, kw) in enumerate({"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
-                                   "double_noattn_x2": dict(double_scpa=True, self_attention=False, scale=2)}.items()):
+                                   "double_noattn_x2": dict(double_scpa=True, self_attention=False, scale=2),
+                                   "bilinear": dict(ups_inter_mode="bilinear"),
+                                   "bilinear_noattn_x2": dict(ups_inter_mode="bilinear", self_attention=False, scale=2)}.items()):
         net = RefPAN(3, 3, 40, 24, 3, **kw).eval()
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
         sd = synth.fill_state_dict(shapes, 185 + i)

@@ -1230,7 +1230,7 @@ def test_pan_constructor_variants_golden(dev, golden):
             err = np.abs(y - ref)
             assert y.shape == ref.shape and err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (tag, err.max(), err.mean())
     with pytest.raises(NotImplementedError):
-        PAN(ups_inter_mode='bilinear')
+        PAN(ups_inter_mode='bicubic')
 
 
 def test_pan_scales_vs_oracle(dev):

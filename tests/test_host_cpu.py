@@ -196,7 +196,7 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     noattn = get_network(get_network_G_config({"type": "pan", "self_attention": False}, 4))
     assert not any(k.startswith("FSA") for k in noattn.state_dict())
     with pytest.raises(NotImplementedError):
-        get_network(get_network_G_config({"type": "pan", "ups_inter_mode": "bilinear"}, 4))
+        get_network(get_network_G_config({"type": "pan", "ups_inter_mode": "bicubic"}, 4))
     with pytest.raises(RuntimeError, match="no CPU path"):
         pan(torch.zeros(1, 3, 8, 8))
     unet = get_network(get_network_G_config("p2p_256", 1))
