@@ -60,6 +60,8 @@ struct ConvLaunch {
                                                   // conv_pack_taps(mask 0x1B), H x W = the INPUT grid, fp16 slab output of 2H x 2W pixels and phase_c channels
     int stride2;                                  // Conv2d(k 4, s 2, p 1) as the 2x2-tap conv of the space-to-depth source (gathered by the loader): H x W = the OUTPUT grid,
                                                   // the source slab holds 2H x 2W pixels; panels from conv_pack_taps(K, 4 * C, 0x1B0)
+    float* stats_part;                            // != nullptr: the kernel also writes partial norm statistics of its result (count, mean, M2 per tile, consumer wave and
+                                                  // channel; conv_stats_nper records per image, merged by norm::launch_combine_parts): 64-channel slab kernels, act 0, no residual
     int prefix_lrelu;                             // with conv1x1: the operand of input group k is LeakyReLU(0.2)(group 0 + .. + group k) (fp32 running sums): PPON's c2
     int conv1x1;                                  // 1x1 conv: the centre tap only is staged and multiplied (panels from conv_pack_1x1); slab outputs
     int dilation_groups;                          // G > 0: K = 32*G, output channel group g is the conv of dilation g+1 (own 32-output panel, panels of
@@ -97,6 +99,7 @@ void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
 int conv_launch(const ConvLaunch& L, hipStream_t s);
 size_t conv_packed_bytes_taps(int K, int C, int mask);
 void conv_pack_1x1(const float* w_oi, int K, int C, void* packed);    // host; w [K][C]
+int conv_stats_nper(int H, int W, int phases);                              // host; see ConvLaunch.stats_part
 size_t conv_packed_bytes7v(int K, int C);
 void conv_pack7v(const float* w_oc7, int K, int C, void* packed);             // host; w [K][C][7]
 size_t conv_packed_bytes_s2k4(int K, int C);

@@ -98,6 +98,8 @@ struct KP {
                              // tiles [rate_start[g], rate_start[g+1]) of the launch belong to it (dil unused)
     int dil, fullH, fullW;   // POLY kernels: dilation d; H, W, N are those of the d*d polyphase sub-images (ceil(fullH/d) x ceil(fullW/d), N*d*d of them)
     int ncg;                 // S9 kernels: real 32-channel groups of the input (nchunks = 9 * ncg virtual chunks)
+    float* stats_part;       // STATS kernels (TMF | 0x1000): per-(tile[, phase], consumer wave, channel) partial statistics (count, mean, M2) of the conv result
+    int stats_cn;            //   channels of the output slab (K, or phase_c behind the phase lattice)
     int s9v;                 // S9 kernels: only the three VERTICAL displacements (a 7-tap column conv as three 3-tap blocks; nchunks = 3 * ncg)
     int reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d(1)) instead of zero; not with `up`
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
@@ -606,6 +608,67 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 #define PCT(var) do { } while (0)
 #define PCACC(slot, t1, t0) do { } while (0)
 #endif
+// Partial statistics of a norm layer that follows the conv, out of the accumulators (fp32, bias included, before the fp16 rounding): every consumer
+// wave reduces its RPW x 32 pixels per channel to (count, mean, M2 = sum of squared deviations from that mean) -- in-lane over its pixel tiles,
+// a fixed xor butterfly over the 16 pixel lanes -- and writes them to
+//   part[((slot * NCW + wave) * cn + channel) * 3],  slot = tile index over the batch (x 4 + phase behind the phase lattice).
+// norm::combine_parts merges an image's partials in index order (Chan's update): deterministic, no atomics, and the pass that re-read the conv
+// output for its statistics is gone.
+template <int RPW, int NT, bool DCV, int NSEG, int NCW>
+__device__ __forceinline__ void epilogue_stats(const KP& p, const f32x4 (&acc)[NT][2 * RPW], const f32x4 (&bias)[NT], int ty0, int tx0, int wave, int li,
+                                               int cbase, int tile) {
+    static_assert(NT == 4, "sixteen channels per lane: one per pixel lane after the transposing reduction");
+    constexpr int MT = 2 * RPW;
+    int yw = ty0 + wave * RPW, x0 = tx0, ylim = p.y1, c0 = cbase, slot = tile;
+    if constexpr (DCV) {
+        const int ph = cbase / p.phase_c;
+        yw -= ph >> 1; x0 -= ph & 1; ylim = p.H;
+        c0 -= ph * p.phase_c;
+        slot = tile * 4 + ph;
+    }
+    bool ok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ok[m] = (NSEG == 2 || !(m & 1)) && (yw + (m >> 1) < ylim) && (x0 + li + (m & 1) * 16 < p.W);
+    const int rows = min(max(ylim - yw, 0), RPW), cols = min(max(p.W - x0, 0), 16 * NSEG);
+    const float cnt = (float)(rows * cols);                        // valid pixels of this wave (uniform)
+    // sums of (x - bias) and of its square per channel: the conv response without its bias has a small mean, so M2 = s2 - s1^2 / n loses nothing
+    float s1[16], s2[16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { const float d = ok[m] ? acc[t][m][j] - bias[t][j] : 0.f; a += d; b += d * d; }
+            s1[4 * t + j] = a; s2[4 * t + j] = b;
+        }
+    // transposing reduction over the 16 pixel lanes: at the step of lane bit `bit` a lane keeps the half of its values whose channel index has
+    // that bit equal to its own and adds the partner's half -- 8 + 4 + 2 + 1 exchanges instead of 16 x 4; lane li ends with channel li's totals
+#define INNFER_TR_STEP(BIT, CNT)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < CNT; ++i) {                                                 \
+        const bool up = (li & BIT) != 0;                                                              \
+        const float k1 = up ? s1[i + CNT] : s1[i], g1 = up ? s1[i] : s1[i + CNT];                     \
+        const float k2 = up ? s2[i + CNT] : s2[i], g2 = up ? s2[i] : s2[i + CNT];                     \
+        s1[i] = k1 + __shfl_xor(g1, BIT);                                                             \
+        s2[i] = k2 + __shfl_xor(g2, BIT);                                                             \
+    }
+    INNFER_TR_STEP(8, 8)
+    INNFER_TR_STEP(4, 4)
+    INNFER_TR_STEP(2, 2)
+    INNFER_TR_STEP(1, 1)
+#undef INNFER_TR_STEP
+    // channel of lane li: bit 3 chose between values [0, 8) / [8, 16), bit 2 between the halves of that, ... = value index li = 4 t + j
+    float bl = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bl = (li == 4 * t + j) ? bias[t][j] : bl;
+    const float inv = cnt > 0.f ? 1.0f / cnt : 0.f;
+    const float mean = s1[0] * inv;
+    float* o = p.stats_part + ((long)(slot * NCW + wave) * p.stats_cn + c0 + li) * 3;
+    o[0] = cnt; o[1] = bl + mean; o[2] = fmaxf(s2[0] - s1[0] * mean, 0.f);
+}
+
 // S9: a 7x7 convolution as nine 3x3 convolutions over displaced copies of the input -- virtual chunk c = (sub, group): the loader reads
 // channel group `group` displaced by (3*(sub/3 - 1), 3*(sub%3 - 1)) pixels and the weight panel of that chunk holds the 3x3 block
 // (sub/3, sub%3) of the 7x7 kernel zero-padded to 9x9; the consumers see 9x as many chunks of an ordinary 3x3 conv.  Each input pixel
@@ -641,6 +704,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // cat(d1, d1 + d2, .., d1 + .. + d8) -> act -> c2 (PPON_arch.py:104-114) without the pass that materialises it: the consumer keeps the
     // fp32 running sums of its own pixels in registers (same additions in the same order as that pass made: same bits)
     constexpr bool PFX = (TMF & 0x800) != 0;
+    constexpr bool STATS = (TMF & 0x1000) != 0;          // + 0x1000: partial norm statistics out of the epilogue (epilogue_stats)
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -1123,6 +1187,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
 #undef EPI
             } else if constexpr (OUTMODE == OUT_SLAB) {
+            if constexpr (STATS) {
+                const int lid = run_start + (p.rev ? run_len - 1 - (jt - slots) : (jt - slots));         // (jt was advanced above)
+                epilogue_stats<RPW, NT, TM == 0x1B, NSEG, NCW>(p, acc, bias_r, ty0, tx0, cw, li, cbase, lid / p.KG);
+            }
 #define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, NSEG>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
@@ -1252,7 +1320,7 @@ template <int TH>
 int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
     const long plain = (long)N * ((k.W + TW - 1) / TW) * ((k.H + TH - 1) / TH);
     *tiles = plain; *gy = 0;
-    if (N < 2 || k.up || k.reflect || k.act >= 3 || k.y0 != 0 || k.y1 != k.H || k.H < TH + 2 || k.W < LVALID || k.nrate || k.dil > 1 ||
+    if (N < 2 || k.up || k.reflect || k.act >= 3 || k.y0 != 0 || k.y1 != k.H || k.H < TH + 2 || k.W < LVALID || k.nrate || k.dil > 1 || k.stats_part ||
         (long)N * k.H * k.W * 64 >= 0x7fffffffL)
         return 0;
     int best = 0;
@@ -1466,6 +1534,10 @@ void conv_pack7v(const float* w, int K, int C, void* packed) {
     conv_pack_taps(w3.data(), K, C3, 0x92, packed);
 }
 
+// partial-statistics records (3 floats each per channel) an image contributes with ConvLaunch.stats_part: tiles of 16 x 32 pixels over the kernel's
+// H x W grid (the INPUT grid behind the phase lattice, which has four phases per tile), 8 consumer waves per tile
+int conv_stats_nper(int H, int W, int phases) { return ((H + 15) / 16) * ((W + TW - 1) / TW) * phases * 8; }
+
 size_t conv_packed_bytes7x7(int K, int C) { return conv_packed_bytes(K, 9 * C); }
 void conv_pack7x7(const float* w, int K, int C, void* packed) {
     std::vector<float> v((size_t)K * 9 * C * 9, 0.f);
@@ -1509,6 +1581,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     k.outm = L.outm;
     k.rev = L.rev ? 1 : 0;
     k.phase_c = (L.out_mode == OUT_NCHW || L.deconv_phases) ? L.phase_c : 0;
+    k.stats_part = L.stats_part; k.stats_cn = L.deconv_phases ? L.phase_c : L.K;
+    if (L.stats_part && (L.out_mode != OUT_SLAB || conv_nt_for(L.K) != 4 || L.act || L.res1 || L.res2 || L.conv1x1 || L.dilation > 1 || L.dilation_groups))
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: epilogue statistics are built for the 64-channel slab kernels without activation / residual");
     k.reflect = L.reflect == 2 ? 2 : (L.reflect ? 1 : 0);
     if (L.reflect == 2 && (L.conv7 || L.out_mode != OUT_SLAB)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: replication padding is built for 3x3 slab convs");
     if (L.reflect && (L.up || L.H < ((L.conv7 || L.conv7v) ? 4 : (L.reflect == 2 ? 1 : 2)) || L.W < (L.conv7 ? 4 : (L.reflect == 2 ? 1 : 2))))
@@ -1543,6 +1618,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         if (!pc || L.out_mode != OUT_SLAB || nt != 4 || L.phase_c <= 0 || L.phase_c % 64 || L.K != 4 * L.phase_c || L.res1 || L.res2 || L.up || L.reflect ||
             L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.dilation > 1 || L.dilation_groups)
             return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: slab output, 64-channel phase groups, no residual / upsampling / padding modes");
+        if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x141B>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x101B>(k, L.N, s);
         return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x41B>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B>(k, L.N, s);
     }
     if (L.stride2) {         // Conv2d(k 4, s 2, p 1): H x W = the OUTPUT grid, source image 2H x 2W; panels from conv_pack_taps(K, 4C, 0x1B0), virtual channel
@@ -1552,6 +1628,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
             return set_error(INNFER_ERR_UNSUPPORTED, "stride-2 conv: slab output of 64-channel tiles, no residual / upsampling / padding modes, sources below 33 M pixels");
         k.Hs = 2 * L.H; k.Ws = 2 * L.W; k.in_img_stride = (long)k.Hs * k.Ws * 32;
         k.nchunks = 4 * k.ncg;
+        if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x17B0>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x13B0>(k, L.N, s);
         return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x7B0>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
     }
     if (L.conv7v) {        // 7 x 1 column conv (padding 3 rows, zero or reflected) as three vertically displaced 3-tap blocks: panels from conv_pack7v, slab output
@@ -1559,6 +1636,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
             (long)L.H * L.W * 64 >= 0x7fffffffL)
             return set_error(INNFER_ERR_UNSUPPORTED, "conv7x1: slab output of 32- / 64-channel tiles, no residual / upsampling, images below 33 M pixels");
         k.nchunks = 3 * k.ncg; k.s9v = 1;
+        if (L.stats_part) return launch_pc<2, 4, 4, OUT_SLAB, true, false, 0x1092>(k, L.N, s);
         return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, true, false, 0x92>(k, L.N, s) : launch_pc<3, 2, 4, OUT_SLAB, true, false, 0x92>(k, L.N, s);
     }
     if (L.conv1x1) {        // centre tap only: panels from conv_pack_1x1
@@ -1577,6 +1655,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         if (INNFER_KNOB("INNFER_FAT", 0) & 1) return launch_pc<6, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);
         return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     }
+    if (pc && L.out_mode == OUT_SLAB && nt == 4 && L.stats_part) return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x11FF>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) {
         // diagnostic builds: four consumer waves of twice the rows (measured within +-1 %: profiles/r2/kernel_experiments.txt 10)
         if (INNFER_KNOB("INNFER_FAT", 0) & 2) return launch_pc<4, 4, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);

@@ -160,6 +160,42 @@ static __global__ void combine_kernel(const float* part, int nseg, long HW, floa
     bn_write(mu, m2 / (float)HW, eps, gamma, beta, alpha, shift, i / C, C, (int)(i % C));
 }
 
+// Partials written by the conv epilogue (conv3x3.hip epilogue_stats: nper records of (count, mean, M2) per image and channel,
+// part[((n * nper + r) * C + c) * 3]) -> (alpha, shift).  A workgroup owns (image, 32 channels): lane pl of a channel merges records pl, pl + 32, ..
+// with Chan's update, then the 32 lanes' results are merged in lane order -- deterministic.
+__device__ __forceinline__ void chan_merge(float& n, float& mu, float& m2, float nb, float mub, float m2b) {
+    if (nb <= 0.f) return;
+    const float tot = n + nb, d = mub - mu;
+    mu += d * (nb / tot);
+    m2 += m2b + d * d * (n * nb / tot);
+    n = tot;
+}
+static __global__ __launch_bounds__(1024) void combine_parts_kernel(const float* part, int nper, long HW, float eps, const float* gamma, const float* beta,
+                                                                    float* alpha, float* shift, int C) {
+    __shared__ float sn[32][33], sm[32][33], sq[32][33];
+    const int n = blockIdx.y, cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float cnt = 0.f, mu = 0.f, m2 = 0.f;
+    if (c < C)
+        for (int r = pl; r < nper; r += 32) {
+            const float* q = part + (((long)n * nper + r) * C + c) * 3;
+            chan_merge(cnt, mu, m2, q[0], q[1], q[2]);
+        }
+    sn[pl][cl] = cnt; sm[pl][cl] = mu; sq[pl][cl] = m2;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int i = 1; i < 32; ++i) chan_merge(cnt, mu, m2, sn[i][cl], sm[i][cl], sq[i][cl]);
+        bn_write(mu, m2 / (float)HW, eps, gamma, beta, alpha, shift, n, C, c);
+    }
+}
+inline int launch_combine_parts(const float* part, int nper, long HW, float eps, const float* gamma, const float* beta, float* alpha, float* shift,
+                                int C, int N, hipStream_t s) {
+    hipLaunchKernelGGL(combine_parts_kernel, dim3((C + 31) / 32, N), dim3(1024), 0, s, part, nper, HW, eps, gamma, beta, alpha, shift, C);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+inline size_t parts_floats(int C, int nper) { return (size_t)C * nper * 3; }      // per image
+
 // floats of `part` scratch for a layer of C channels and HW pixels per image (per image)
 inline size_t part_floats(int C, long HW) { return (size_t)C * (size_t)((HW + SEG - 1) / SEG) * 2; }
 

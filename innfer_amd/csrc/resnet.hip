@@ -449,7 +449,13 @@ RCarve rcarve(const innfer_resnet* r, int N, int H, int W) {
     c.alpha = off; off += al((size_t)N * 256 * 4);
     c.shift = off; off += al((size_t)N * 256 * 4);
     // (mean, M2) per statistics segment: the widest case is 64 channels at full resolution or 256 at 1/16
-    c.part = off; off += al((size_t)N * std::max(norm::part_floats(64, (long)H * W), norm::part_floats(256, (long)H * W / 16)) * 4);
+    // ... or the conv epilogues' partial statistics (3 floats per 16 x 32 tile, consumer wave and channel; the phase-lattice convs count their input grid x 4)
+    size_t pf = std::max(norm::part_floats(64, (long)H * W), norm::part_floats(256, (long)H * W / 16));
+    pf = std::max(pf, norm::parts_floats(64, conv_stats_nper(H, W, 1)));
+    pf = std::max(pf, norm::parts_floats(64, conv_stats_nper(H / 2, W / 2, 4)));
+    pf = std::max(pf, norm::parts_floats(128, conv_stats_nper(H / 4, W / 4, 4)));
+    pf = std::max(pf, norm::parts_floats(256, conv_stats_nper(H / 4, W / 4, 1)));
+    c.part = off; off += al((size_t)N * pf * 4);
     c.total = off;
     (void)r;
     return c;
@@ -523,8 +529,14 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out = Y; L.out_gstride = G; L.K = l.cout;
         L.N = N; L.H = Hc; L.W = Wc; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Hc;
         L.out_mode = OUT_SLAB; L.reflect = r->block_pad;
+        if (l.cout % 64 == 0 && l.cout <= 256) {      // statistics as per-tile partials out of the conv epilogue: the slab is not read again for them
+            L.stats_part = part;
+            CK(conv_launch(L, s));
+            CK(norm::launch_combine_parts(part, conv_stats_nper(Hc, Wc, 1), HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, s));
+        } else {
         CK(conv_launch(L, s));
         CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
                            (const float*)alpha, (const float*)shift, relu, res, dst, G);
@@ -549,8 +561,14 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out = Y; L.out_gstride = G; L.K = l.cout;
         L.N = N; L.H = H; L.W = W; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = H;
         L.out_mode = OUT_SLAB; L.conv7v = 1; L.reflect = 1;
+        if (l.cout == 64) {
+            L.stats_part = part;
+            CK(conv_launch(L, s));
+            CK(norm::launch_combine_parts(part, conv_stats_nper(H, W, 1), HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, s));
+        } else {
         CK(conv_launch(L, s));
         CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
                            (const float*)alpha, (const float*)shift, 1, (const f16*)nullptr, S1, G);
@@ -602,8 +620,14 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out = Y; L.out_gstride = G; L.K = l.cout;
         L.N = N; L.H = Ho; L.W = Wo; L.up = 1; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Ho;
         L.out_mode = OUT_SLAB;
+        if (l.cout % 64 == 0 && l.cout <= 128) {
+            L.stats_part = part;
+            CK(conv_launch(L, s));
+            CK(norm::launch_combine_parts(part, conv_stats_nper(Ho, Wo, 1), HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, s));
+        } else {
         CK(conv_launch(L, s));
         CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        }
         return post_relu(l, Y, Ho, Wo, dst, pad);
     };
     // ConvTranspose whose input grid fills the 16 x 32 tiles: four phase convs in one launch of the halo-tile kernel, fp16 slab out, norm on the slab
@@ -617,8 +641,9 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out = Y; L.out_gstride = G; L.K = 4 * l.cout; L.phase_c = l.cout; L.deconv_phases = 1;
         L.N = N; L.H = Hi; L.W = Wi; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Hi;
         L.out_mode = OUT_SLAB;
+        L.stats_part = part;                      // (cout % 64 == 0 is this path's condition; 64 / 128 channels)
         CK(conv_launch(L, s));
-        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        CK(norm::launch_combine_parts(part, conv_stats_nper(Hi, Wi, 4), HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, s));
         return post_relu(l, Y, Ho, Wo, dst, pad);
     };
     auto fills_tiles = [](int h, int w) { return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * (w <= 16 ? 16 : (w + 31) / 32 * 32) * 5; };

@@ -670,6 +670,10 @@ UCarve ucarve(const innfer_unet* u, int N, int H, int W) {
         const size_t hw = (size_t)(H >> (k + 1)) * (W >> (k + 1)), hw2 = (size_t)(H >> k) * (W >> k);
         part = std::max(part, norm::part_floats(u->dc[k], (long)hw));
         if (k > 0) part = std::max(part, norm::part_floats(u->dc[k - 1], (long)hw2));
+        // ... or the partial statistics out of the halo-tile convs' epilogues (3 floats per 16 x 32 tile, consumer wave and channel)
+        const int hk = H >> (k + 1), wk = W >> (k + 1);
+        part = std::max(part, norm::parts_floats(u->dc[k], conv_stats_nper(hk, wk, 1)));
+        if (k > 0) part = std::max(part, norm::parts_floats(u->dc[k - 1], std::max(conv_stats_nper(hk, wk, 4), conv_stats_nper(2 * hk, 2 * wk, 1))));
     }
     c.bnpart = off; off += al((size_t)N * part * 4);
     c.D.resize(L); c.CAT.resize(L);
@@ -822,10 +826,11 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             Lc.wpk = (const f16*)l.d_w3; Lc.bias = l.d_b3;
             Lc.out = Y; Lc.out_gstride = Go; Lc.K = l.cout; Lc.N = N; Lc.H = ho; Lc.W = wo; Lc.act = 0;
             Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = ho; Lc.out_mode = OUT_SLAB; Lc.stride2 = 1;
+            if (!ev) Lc.stats_part = bnpart;              // statistics as per-tile partials out of the conv epilogue
             rc = conv_launch(Lc, s);
             if (rc) return rc;
             if (!ev) {
-                rc = norm::launch_stats_slab(Y, Go, HWo, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
+                rc = norm::launch_combine_parts(bnpart, conv_stats_nper(ho, wo, 1), HWo, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, s);
                 if (rc) return rc;
             }
             const long total = (long)N * HWo * (l.cout / 8);
@@ -882,9 +887,15 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             } else {
                 f16* Y = (f16*)raw;       // fp16 conv result; the norm statistics are taken from it (as behind resnet.hip's upconv layers)
                 Lc.out = Y; Lc.out_gstride = G; Lc.act = 0; Lc.out_mode = OUT_SLAB;
+                const bool epi_stats = !ev && l.cout % 64 == 0;          // statistics as per-tile partials out of the conv epilogue
+                if (epi_stats) Lc.stats_part = bnpart;
                 int rc = conv_launch(Lc, s);
                 if (rc) return rc;
-                if (!ev) {
+                if (epi_stats) {
+                    rc = norm::launch_combine_parts(bnpart, tile4 ? conv_stats_nper(h, w, 4) : conv_stats_nper(hf, wf, 1), HW, 1e-5f, l.d_gamma, l.d_beta,
+                                                    mean, rstd, l.cout, N, s);
+                    if (rc) return rc;
+                } else if (!ev) {
                     rc = norm::launch_stats_slab(Y, G, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
                     if (rc) return rc;
                 }
