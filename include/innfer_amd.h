@@ -222,8 +222,13 @@ int innfer_resnet_create(innfer_resnet_t* out, int in_nc, int out_nc, int ngf, i
 /* The same with ResnetBlock's constructor arguments (ResNet_arch.py:104-146): padding 0 reflect / 1 replicate / 2 zero (the pad layer in front of
  * the two 3x3 convs of every block; the parameter indices inside `conv_block` follow), use_dropout != 0 = an nn.Dropout(0.5) behind the first
  * conv + norm + ReLU (identity in eval mode -- how run.py runs these generators -- but it shifts the second conv's index); upconv != 0 =
- * upsample_mode 'upconv': the two ConvTranspose2d stages become Upsample(nearest 2x) + Conv2d(3x3) (block.py:348-361; parameters `model.<i>.1`).  (104) */
-int innfer_resnet_create_ex(innfer_resnet_t* out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout, int upconv);
+ * upsample_mode 'upconv': the two ConvTranspose2d stages become Upsample(nearest 2x) + Conv2d(3x3) (block.py:348-361; parameters `model.<i>.1`);
+ * batch_norm != 0 = norm_type 'batch' (the constructor's default, ResNet_arch.py:19,39-49): nn.BatchNorm2d behind every conv but the last (parameters
+ * and buffers `model.<i+1>.{weight,bias,running_mean,running_var,num_batches_tracked}`) and no bias on those convs.  (104) */
+int innfer_resnet_create_ex(innfer_resnet_t* out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout, int upconv, int batch_norm);
+/* BatchNorm mode of a batch_norm generator, as innfer_unet_set_eval: 0 (nn.Module.train()) the statistics of the image, != 0 (eval(), Model's default)
+ * the running statistics.  No effect on instance-norm generators.  (104) */
+int innfer_resnet_set_eval(innfer_resnet_t r, int eval_mode);
 void innfer_resnet_destroy(innfer_resnet_t r);
 int innfer_resnet_num_params(innfer_resnet_t r);
 int innfer_resnet_param_info(innfer_resnet_t r, int idx, char* key, size_t key_cap, int* ndim, int* shape4);

@@ -167,6 +167,13 @@ __global__ void rn_sum9_tanh(const float* Q, const float* bias, void* out, int o
     if (out_f32) ((float*)out)[i] = a; else ((f16*)out)[i] = (f16)a;
 }
 
+// eval-mode BatchNorm: the per-channel transform of the running statistics, once per image (the post kernels index alpha / shift by image)
+__global__ void rn_fill_ev(const float* ev_alpha, const float* ev_shift, float* alpha, float* shift, int C, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    alpha[i] = ev_alpha[i % C]; shift[i] = ev_shift[i % C];
+}
+
 // NCHW input -> "row patch" slab of the reflection-padded first 7x7 conv: channel kx*C + c of pixel (y, x) holds in[c][y][reflect(x + kx - 3)]
 // (zero beyond 7*C <= 32 channels), so the 49-tap conv becomes 7 vertical taps (reflected by the GEMM's gather) over ONE 32-channel group.
 // C > 4: plain copy into a zero-padded group (49 taps).  One thread per pixel, 16-byte stores.
@@ -213,6 +220,8 @@ struct Param { std::string key; std::vector<int> shape; std::vector<float> host;
 struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; bool transposed = false; std::vector<f16*> d_w; float* d_b = nullptr;
                void* d_w3 = nullptr;
                float* d_b4 = nullptr;      // ConvTranspose layers on the halo-tile kernel: the bias once per output phase
+               int g = -1, be = -1, rm = -1, rv = -1;          // norm_type 'batch': the BatchNorm2d behind this conv (weight, bias, running_mean, running_var)
+               float *d_gamma = nullptr, *d_beta = nullptr, *d_ev_alpha = nullptr, *d_ev_shift = nullptr;
                void* d_w27 = nullptr; float* d_z32 = nullptr;   // last 7x7 conv as a 3x3 conv over nine sub-blocks (rn_sum9_tanh): panels [9 * cout][cin][3][3], zero bias
                bool up2 = false; };        // upsample_mode 'upconv': Upsample(nearest 2x) + 3x3 conv on the halo-tile kernel (nearest-2x in the loader)    // residual-block convs: conv3x3.hip panels (reflection padding in the halo-tile loader)
 
@@ -224,6 +233,9 @@ struct innfer_resnet {
     std::vector<Param> params;
     std::vector<Layer> layers;       // first, down1, down2, 2*n_blocks block convs, up1, up2, last
     bool uploaded = false;
+    bool batch_norm = false;         // norm_type 'batch' (the constructor's default, ResNet_arch.py:19,39-49): nn.BatchNorm2d behind every conv but the last, and
+                                     // no bias on those convs (use_bias is True for InstanceNorm2d only)
+    bool eval_mode = false;          // BatchNorm on its running statistics (nn.Module.eval()); train(): the statistics of the image, like pix2pix's UNet
 };
 
 static int RP(innfer_resnet* r, const std::string& key, std::vector<int> shape) {
@@ -232,43 +244,58 @@ static int RP(innfer_resnet* r, const std::string& key, std::vector<int> shape) 
     return (int)r->params.size() - 1;
 }
 
-static void add_layer(innfer_resnet* r, const std::string& key, int cin, int cout, int k, bool transposed) {
+// norm: state-dict prefix of the norm layer that follows the conv ("" behind the last conv); with norm_type 'batch' the conv then has no bias and the
+// BatchNorm2d's parameters and buffers follow it in the state dict
+static void add_layer(innfer_resnet* r, const std::string& key, int cin, int cout, int k, bool transposed, const std::string& norm = "") {
     Layer l; l.cin = cin; l.cout = cout; l.k = k; l.transposed = transposed;
     l.w = RP(r, key + ".weight", transposed ? std::vector<int>{cin, cout, k, k} : std::vector<int>{cout, cin, k, k});
-    l.b = RP(r, key + ".bias", {cout});
+    const bool bn = r->batch_norm && !norm.empty();
+    if (!bn) l.b = RP(r, key + ".bias", {cout});
+    if (bn) {
+        l.g = RP(r, norm + ".weight", {cout}); l.be = RP(r, norm + ".bias", {cout});
+        l.rm = RP(r, norm + ".running_mean", {cout}); l.rv = RP(r, norm + ".running_var", {cout});
+        RP(r, norm + ".num_batches_tracked", {});
+    }
     r->layers.push_back(l);
 }
 
 extern "C" int innfer_resnet_create(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks) {
-    return innfer_resnet_create_ex(out, in_nc, out_nc, ngf, n_blocks, 0, 0, 0);
+    return innfer_resnet_create_ex(out, in_nc, out_nc, ngf, n_blocks, 0, 0, 0, 0);
 }
 
-extern "C" int innfer_resnet_create_ex(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout, int upconv) {
+extern "C" int innfer_resnet_set_eval(innfer_resnet* r, int eval_mode) {
+    if (!r) return set_error(INNFER_ERR_INVALID, "resnet_set_eval: null handle");
+    r->eval_mode = eval_mode != 0;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_resnet_create_ex(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout, int upconv, int batch_norm) {
     if (!out) return set_error(INNFER_ERR_INVALID, "resnet_create: null out");
     if (padding < 0 || padding > 2) return set_error(INNFER_ERR_INVALID, "resnet_create: padding %d (0 reflect, 1 replicate, 2 zero)", padding);
     if (ngf != 64 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || n_blocks < 0 || n_blocks > 64)
         return set_error(INNFER_ERR_UNSUPPORTED, "resnet_create: ngf=%d n_blocks=%d (built: ngf 64)", ngf, n_blocks);
     innfer_resnet* r = new innfer_resnet();
     r->in_nc = in_nc; r->out_nc = out_nc; r->ngf = ngf; r->n_blocks = n_blocks;
+    r->batch_norm = batch_norm != 0;
     r->block_pad = padding == 0 ? 1 : (padding == 1 ? 2 : 0);        // ConvLaunch.reflect code of the residual blocks' convs
     // ResnetBlock.conv_block (ResNet_arch.py:118-146): [pad] conv norm relu [dropout] [pad] conv norm -- a pad layer for reflect / replicate only,
     // nn.Dropout(0.5) (identity in eval mode, which is how run.py runs CycleGAN generators: cyglegan_extras) when use_dropout
     const int c1 = padding == 2 ? 0 : 1, c2 = c1 + 3 + (use_dropout ? 1 : 0) + (padding == 2 ? 0 : 1);
-    add_layer(r, "model.1", in_nc, ngf, 7, false);
-    add_layer(r, "model.4", ngf, 2 * ngf, 3, false);
-    add_layer(r, "model.7", 2 * ngf, 4 * ngf, 3, false);
+    add_layer(r, "model.1", in_nc, ngf, 7, false, "model.2");
+    add_layer(r, "model.4", ngf, 2 * ngf, 3, false, "model.5");
+    add_layer(r, "model.7", 2 * ngf, 4 * ngf, 3, false, "model.8");
     for (int i = 0; i < n_blocks; ++i) {
         const std::string b = "model." + std::to_string(10 + i) + ".conv_block.";
-        add_layer(r, b + std::to_string(c1), 4 * ngf, 4 * ngf, 3, false);
-        add_layer(r, b + std::to_string(c2), 4 * ngf, 4 * ngf, 3, false);
+        add_layer(r, b + std::to_string(c1), 4 * ngf, 4 * ngf, 3, false, b + std::to_string(c1 + 1));
+        add_layer(r, b + std::to_string(c2), 4 * ngf, 4 * ngf, 3, false, b + std::to_string(c2 + 1));
     }
     const int i = 10 + n_blocks;
     if (upconv) {        // upconv_block (block.py:348-361): sequential(Upsample, Conv2d) inside the model's Sequential -> `model.<i>.1`
-        add_layer(r, "model." + std::to_string(i) + ".1", 4 * ngf, 2 * ngf, 3, false); r->layers.back().up2 = true;
-        add_layer(r, "model." + std::to_string(i + 3) + ".1", 2 * ngf, ngf, 3, false); r->layers.back().up2 = true;
+        add_layer(r, "model." + std::to_string(i) + ".1", 4 * ngf, 2 * ngf, 3, false, "model." + std::to_string(i + 1)); r->layers.back().up2 = true;
+        add_layer(r, "model." + std::to_string(i + 3) + ".1", 2 * ngf, ngf, 3, false, "model." + std::to_string(i + 4)); r->layers.back().up2 = true;
     } else {
-        add_layer(r, "model." + std::to_string(i), 4 * ngf, 2 * ngf, 3, true);
-        add_layer(r, "model." + std::to_string(i + 3), 2 * ngf, ngf, 3, true);
+        add_layer(r, "model." + std::to_string(i), 4 * ngf, 2 * ngf, 3, true, "model." + std::to_string(i + 1));
+        add_layer(r, "model." + std::to_string(i + 3), 2 * ngf, ngf, 3, true, "model." + std::to_string(i + 4));
     }
     add_layer(r, "model." + std::to_string(i + 7), ngf, out_nc, 7, false);
     *out = r;
@@ -285,6 +312,7 @@ static void rn_free(innfer_resnet* r) {
         l.d_w3 = nullptr;
         if (l.d_b4) (void)hipFree(l.d_b4);
         l.d_b4 = nullptr;
+        for (float** q : {&l.d_gamma, &l.d_beta, &l.d_ev_alpha, &l.d_ev_shift}) { if (*q) (void)hipFree(*q); *q = nullptr; }
         if (l.d_w27) (void)hipFree(l.d_w27);
         l.d_w27 = nullptr;
         if (l.d_z32) (void)hipFree(l.d_z32);
@@ -330,11 +358,31 @@ int phase_taps1d(int a, int ky[2], int d[2]) {
 }
 
 int rn_upload(innfer_resnet* r) {
-    for (auto& q : r->params) if (!q.set) return set_error(INNFER_ERR_INVALID, "resnet: parameter '%s' was never set", q.key.c_str());
+    for (auto& q : r->params)
+        if (!q.set && q.key.find("running_") == std::string::npos && q.key.find("num_batches") == std::string::npos)
+            return set_error(INNFER_ERR_INVALID, "resnet: parameter '%s' was never set", q.key.c_str());
     rn_free(r);
     std::vector<f16> panel;
     for (auto& l : r->layers) {
         const std::vector<float>& w = r->params[l.w].host;
+        const std::vector<float> bias = l.b >= 0 ? r->params[l.b].host : std::vector<float>((size_t)l.cout, 0.f);     // no conv bias in front of a BatchNorm2d
+        if (l.g >= 0) {
+            // train(): gamma / beta beside the statistics of the image; eval(): ATen's transform of the running statistics (alpha = weight /
+            // sqrt(running_var + eps), shift = bias - running_mean * alpha; a checkpoint without them means a fresh BatchNorm's (0, 1))
+            const std::vector<float>&g = r->params[l.g].host, &b = r->params[l.be].host;
+            const Param &pm = r->params[l.rm], &pv = r->params[l.rv];
+            std::vector<float> al((size_t)l.cout), sh((size_t)l.cout);
+            for (int c = 0; c < l.cout; ++c) {
+                const float mean = pm.set ? pm.host[c] : 0.f, var = pv.set ? pv.host[c] : 1.f;
+                al[c] = g[c] * (1.0f / std::sqrt(var + 1e-5f));
+                sh[c] = b[c] - mean * al[c];
+            }
+            for (auto pr : {std::make_pair(&l.d_gamma, &g), std::make_pair(&l.d_beta, &b), std::make_pair(&l.d_ev_alpha, (const std::vector<float>*)&al),
+                            std::make_pair(&l.d_ev_shift, (const std::vector<float>*)&sh)}) {
+                INNFER_HIP(hipMalloc((void**)pr.first, l.cout * sizeof(float)));
+                INNFER_HIP(hipMemcpy(*pr.first, pr.second->data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+            }
+        }
         const int cin_pad = (l.cin + 31) / 32 * 32, k = l.k;
         auto put = [&](int ntaps, auto weight_of) -> int {
             gg::pack_panels(panel, l.cout, l.cin, cin_pad, ntaps, weight_of);
@@ -367,14 +415,14 @@ int rn_upload(innfer_resnet* r) {
             }
         }
         INNFER_HIP(hipMalloc((void**)&l.d_b, l.cout * sizeof(float)));
-        INNFER_HIP(hipMemcpy(l.d_b, r->params[l.b].host.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
+        INNFER_HIP(hipMemcpy(l.d_b, bias.data(), l.cout * sizeof(float), hipMemcpyHostToDevice));
         if (!l.transposed && k == 7 && l.cin % 32 == 0 && l.cout <= 16) {          // c7s1-out: nine displaced 3x3 convs, ReflectionPad2d(3)
             std::vector<char> packed(conv_packed_bytes7x7(l.cout, l.cin));
             conv_pack7x7(w.data(), l.cout, l.cin, packed.data());
             INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
             INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
             std::vector<float> b3(64, 0.f);
-            for (int c = 0; c < l.cout; ++c) b3[c] = r->params[l.b].host[c];
+            for (int c = 0; c < l.cout; ++c) b3[c] = bias[c];
             (void)hipFree(l.d_b); l.d_b = nullptr;
             INNFER_HIP(hipMalloc((void**)&l.d_b, b3.size() * sizeof(float)));
             INNFER_HIP(hipMemcpy(l.d_b, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -415,7 +463,7 @@ int rn_upload(innfer_resnet* r) {
             // (a, b) at the virtual pixel (y + a, x + b) reads taps (dy, dx) in {-1, 0}^2 with ky = 1 - a - 2 dy (oy = 2 iy - 1 + ky); ky = 3 does not
             // exist in a 3-tap kernel: a structural zero (9 of the 16 phase taps are real)
             std::vector<float> b4((size_t)4 * l.cout);
-            for (int co = 0; co < 4 * l.cout; ++co) b4[co] = r->params[l.b].host[co % l.cout];
+            for (int co = 0; co < 4 * l.cout; ++co) b4[co] = bias[co % l.cout];
             std::vector<char> packed(conv_packed_bytes_deconv2x(l.cout, l.cin));
             conv_pack_deconv2x(w.data(), l.cout, l.cin, 3, packed.data());
             INNFER_HIP(hipMalloc(&l.d_w3, packed.size()));
@@ -487,10 +535,19 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     for (int t = 0; t < 9; ++t) { dy9[t] = t / 3 - 1; dx9[t] = t % 3 - 1; }
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
     // GEMM of layer l over (Hi, Wi) -> (Ho, Wo) + instance norm + [relu] [+ res] -> dst slab
+    // BatchNorm under eval(): no statistics of the image -- (alpha, shift) are the layer's transform of its running statistics
+    const bool bn_eval = r->batch_norm && r->eval_mode;
+    auto fill_ev = [&](const Layer& l) -> int {
+        hipLaunchKernelGGL(rn_fill_ev, dim3((unsigned)((N * l.cout + 255) / 256)), dim3(256), 0, s, (const float*)l.d_ev_alpha, (const float*)l.d_ev_shift,
+                           alpha, shift, l.cout, N);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    };
     auto norm_post = [&](const Layer& l, int Ho, int Wo, int relu, const f16* res, f16* dst) -> int {
         const long HW = (long)Ho * Wo;
         const int cpad = (l.cout + 63) / 64 * 64;
-        { int rc = norm::launch_stats(raw, cpad, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s); if (rc) return rc; }
+        if (bn_eval) { int rc = fill_ev(l); if (rc) return rc; }
+        else { int rc = norm::launch_stats(raw, cpad, HW, 1e-5f, l.d_gamma, l.d_beta, alpha, shift, l.cout, N, part, s); if (rc) return rc; }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(rn_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)raw, cpad, l.cout, HW, N,
                            (const float*)alpha, (const float*)shift, relu, res, dst, (long)N * HW * 32);
@@ -529,13 +586,16 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out = Y; L.out_gstride = G; L.K = l.cout;
         L.N = N; L.H = Hc; L.W = Wc; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Hc;
         L.out_mode = OUT_SLAB; L.reflect = r->block_pad;
-        if (l.cout % 64 == 0 && l.cout <= 256) {      // statistics as per-tile partials out of the conv epilogue: the slab is not read again for them
+        if (bn_eval) {
+            CK(conv_launch(L, s));
+            CK(fill_ev(l));
+        } else if (l.cout % 64 == 0 && l.cout <= 256) {      // statistics as per-tile partials out of the conv epilogue: the slab is not read again for them
             L.stats_part = part;
             CK(conv_launch(L, s));
-            CK(norm::launch_combine_parts(part, conv_stats_nper(Hc, Wc, 1), HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, s));
+            CK(norm::launch_combine_parts(part, conv_stats_nper(Hc, Wc, 1), HW, 1e-5f, l.d_gamma, l.d_beta, alpha, shift, l.cout, N, s));
         } else {
         CK(conv_launch(L, s));
-        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, l.d_gamma, l.d_beta, alpha, shift, l.cout, N, part, s));
         }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
@@ -561,13 +621,16 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out = Y; L.out_gstride = G; L.K = l.cout;
         L.N = N; L.H = H; L.W = W; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = H;
         L.out_mode = OUT_SLAB; L.conv7v = 1; L.reflect = 1;
-        if (l.cout == 64) {
+        if (bn_eval) {
+            CK(conv_launch(L, s));
+            CK(fill_ev(l));
+        } else if (l.cout == 64) {
             L.stats_part = part;
             CK(conv_launch(L, s));
-            CK(norm::launch_combine_parts(part, conv_stats_nper(H, W, 1), HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, s));
+            CK(norm::launch_combine_parts(part, conv_stats_nper(H, W, 1), HW, 1e-5f, l.d_gamma, l.d_beta, alpha, shift, l.cout, N, s));
         } else {
         CK(conv_launch(L, s));
-        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, l.d_gamma, l.d_beta, alpha, shift, l.cout, N, part, s));
         }
         const long total = (long)N * HW * (l.cout / 8);
         hipLaunchKernelGGL(rn_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, l.cout, HW, N,
@@ -620,13 +683,16 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out = Y; L.out_gstride = G; L.K = l.cout;
         L.N = N; L.H = Ho; L.W = Wo; L.up = 1; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Ho;
         L.out_mode = OUT_SLAB;
-        if (l.cout % 64 == 0 && l.cout <= 128) {
+        if (bn_eval) {
+            CK(conv_launch(L, s));
+            CK(fill_ev(l));
+        } else if (l.cout % 64 == 0 && l.cout <= 128) {
             L.stats_part = part;
             CK(conv_launch(L, s));
-            CK(norm::launch_combine_parts(part, conv_stats_nper(Ho, Wo, 1), HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, s));
+            CK(norm::launch_combine_parts(part, conv_stats_nper(Ho, Wo, 1), HW, 1e-5f, l.d_gamma, l.d_beta, alpha, shift, l.cout, N, s));
         } else {
         CK(conv_launch(L, s));
-        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, part, s));
+        CK(norm::launch_stats_slab(Y, G, HW, 1e-5f, l.d_gamma, l.d_beta, alpha, shift, l.cout, N, part, s));
         }
         return post_relu(l, Y, Ho, Wo, dst, pad);
     };
@@ -641,9 +707,14 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
         L.out = Y; L.out_gstride = G; L.K = 4 * l.cout; L.phase_c = l.cout; L.deconv_phases = 1;
         L.N = N; L.H = Hi; L.W = Wi; L.act = 0; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = Hi;
         L.out_mode = OUT_SLAB;
+        if (bn_eval) {
+            CK(conv_launch(L, s));
+            CK(fill_ev(l));
+        } else {
         L.stats_part = part;                      // (cout % 64 == 0 is this path's condition; 64 / 128 channels)
         CK(conv_launch(L, s));
-        CK(norm::launch_combine_parts(part, conv_stats_nper(Hi, Wi, 4), HW, 1e-5f, nullptr, nullptr, alpha, shift, l.cout, N, s));
+        CK(norm::launch_combine_parts(part, conv_stats_nper(Hi, Wi, 4), HW, 1e-5f, l.d_gamma, l.d_beta, alpha, shift, l.cout, N, s));
+        }
         return post_relu(l, Y, Ho, Wo, dst, pad);
     };
     auto fills_tiles = [](int h, int w) { return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * (w <= 16 ? 16 : (w + 31) / 32 * 32) * 5; };

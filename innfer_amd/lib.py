@@ -104,7 +104,8 @@ SIGNATURES = {
     "innfer_ppon_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_resnet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
-    "innfer_resnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 7),
+    "innfer_resnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 8),
+    "innfer_resnet_set_eval": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_resnet_destroy": (None, [C.c_void_p]),
     "innfer_resnet_num_params": (C.c_int, [C.c_void_p]),
     "innfer_resnet_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

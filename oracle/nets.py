@@ -319,36 +319,42 @@ def ppon_forward(sd, x, nb=24, scale=4, alpha=1.0):
     return out_c, out_s, out_p
 
 
-def resnet_forward(sd, x, n_blocks=9, eps=1e-5, padding_type="reflect", use_dropout=False):
+def resnet_forward(sd, x, n_blocks=9, eps=1e-5, padding_type="reflect", use_dropout=False, norm_type="instance", training=False):
     """ResnetGenerator(norm=instance, padding=reflect, upsample=deconv).forward (ResNet_arch.py:19-86) with
     ResnetBlock (:89-151): c7s1-64, two stride-2 convs, n_blocks reflect-padded residual blocks, two
     ConvTranspose2d(3, s2, p1, op1), c7s1-out, tanh.  InstanceNorm2d has no affine parameters and always
     uses the statistics of the instance (track_running_stats=False), also under eval()."""
+    # norm_type 'batch' (the constructor's default, :39-49): nn.BatchNorm2d behind every conv but the last -- its parameters sit at the next index of
+    # the Sequential -- and no bias on those convs (use_bias is True for InstanceNorm2d only); training=True: statistics of the batch given
     def conv(t, key, **kw):
-        return F.conv2d(t, sd[key + ".weight"], sd[key + ".bias"], **kw)
+        return F.conv2d(t, sd[key + ".weight"], sd.get(key + ".bias"), **kw)
 
-    def inorm(t):
-        return F.instance_norm(t, eps=eps)
+    def inorm(t, key=None):
+        if norm_type in ("IN", "instance"):
+            return F.instance_norm(t, eps=eps)
+        if training:
+            return F.batch_norm(t, None, None, sd[key + ".weight"], sd[key + ".bias"], training=True, momentum=0.0, eps=eps)
+        return F.batch_norm(t, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"], training=False, momentum=0.0, eps=eps)
 
-    t = F.relu(inorm(conv(F.pad(x, (3, 3, 3, 3), mode="reflect"), "model.1")))
-    t = F.relu(inorm(conv(t, "model.4", stride=2, padding=1)))
-    t = F.relu(inorm(conv(t, "model.7", stride=2, padding=1)))
+    t = F.relu(inorm(conv(F.pad(x, (3, 3, 3, 3), mode="reflect"), "model.1"), "model.2"))
+    t = F.relu(inorm(conv(t, "model.4", stride=2, padding=1), "model.5"))
+    t = F.relu(inorm(conv(t, "model.7", stride=2, padding=1), "model.8"))
     # ResnetBlock.conv_block (:118-146): [pad] conv norm relu [dropout: identity in eval mode] [pad] conv norm; 'zero' pads inside the conv
     pad_layer = padding_type != "zero"
     c1 = 1 if pad_layer else 0
     c2 = c1 + 3 + (1 if use_dropout else 0) + (1 if pad_layer else 0)
     mode = {"reflect": "reflect", "replicate": "replicate", "zero": "constant"}[padding_type]
     for i in range(10, 10 + n_blocks):
-        r = F.relu(inorm(conv(F.pad(t, (1, 1, 1, 1), mode=mode), f"model.{i}.conv_block.{c1}")))
-        r = inorm(conv(F.pad(r, (1, 1, 1, 1), mode=mode), f"model.{i}.conv_block.{c2}"))
+        r = F.relu(inorm(conv(F.pad(t, (1, 1, 1, 1), mode=mode), f"model.{i}.conv_block.{c1}"), f"model.{i}.conv_block.{c1 + 1}"))
+        r = inorm(conv(F.pad(r, (1, 1, 1, 1), mode=mode), f"model.{i}.conv_block.{c2}"), f"model.{i}.conv_block.{c2 + 1}")
         t = t + r
     i = 10 + n_blocks
     for k in (i, i + 3):
         if f"model.{k}.1.weight" in sd:             # upsample_mode 'upconv' (:70-73): upconv_block = Upsample(nearest 2x), Conv2d(3x3) (block.py:348-361)
             t = conv(F.interpolate(t, scale_factor=2.0, mode="nearest"), f"model.{k}.1", padding=1)
         else:
-            t = F.conv_transpose2d(t, sd[f"model.{k}.weight"], sd[f"model.{k}.bias"], stride=2, padding=1, output_padding=1)
-        t = F.relu(inorm(t))
+            t = F.conv_transpose2d(t, sd[f"model.{k}.weight"], sd.get(f"model.{k}.bias"), stride=2, padding=1, output_padding=1)
+        t = F.relu(inorm(t, f"model.{k + 1}"))
     return torch.tanh(conv(F.pad(t, (3, 3, 3, 3), mode="reflect"), f"model.{i + 7}"))
 
 

@@ -365,10 +365,18 @@ def g22():
     for i, (tag, kw) in enumerate({"zero": dict(padding_type="zero"), "replicate": dict(padding_type="replicate"),
                                    "reflect_dropout": dict(padding_type="reflect", use_dropout=True),
                                    "zero_dropout": dict(padding_type="zero", use_dropout=True),
-                                   "upconv": dict(upsample_mode="upconv")}.items()):
-        net = RefResnet(3, 3, 64, norm_type="instance", n_blocks=2, **kw).eval()
+                                   "upconv": dict(upsample_mode="upconv"),
+                                   "batch_eval": dict(norm_type="batch"), "batch_train": dict(norm_type="batch", train=True),
+                                   "batch_zero_upconv_eval": dict(norm_type="batch", padding_type="zero", upsample_mode="upconv")}.items()):
+        kw = dict(kw)
+        train = kw.pop("train", False)
+        net = RefResnet(3, 3, 64, n_blocks=2, **{"norm_type": "instance", **kw})
+        net = net.train() if train else net.eval()
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-        net.load_state_dict(t_sd(synth.fill_state_dict(shapes, 220 + i)), strict=True)
+        sd = synth.fill_state_dict(shapes, 220 + i)
+        if kw.get("norm_type") == "batch":
+            sd = synth.fill_running_stats(sd, 228 + i)
+        net.load_state_dict(t_sd(sd), strict=True)
         x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0))
         with torch.no_grad():
             out[tag] = net(x).numpy()

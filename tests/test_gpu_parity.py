@@ -1096,20 +1096,26 @@ def test_cyclegan_resnet_padding_and_dropout_variants_golden(dev, golden):
     import ast
     from innfer_amd import synth
     from innfer_amd.architectures.ResNet_arch import ResnetGenerator
-    from test_oracle_golden import G22_CASES
+    from test_oracle_golden import G22_CASES, _g22_state
     g = golden("g22_resnet_variants")
     for i, (tag, kw) in enumerate(G22_CASES.items()):
         shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[tag + "_keys"], g[tag + "_shapes"])}
-        net = ResnetGenerator(3, 3, 64, norm_type="instance", n_blocks=2, **kw)
+        kw = dict(kw)
+        train = kw.pop("train", False)
+        net = ResnetGenerator(3, 3, 64, n_blocks=2, **{"norm_type": "instance", **kw})
         assert list(net.state_dict()) == [str(k) for k in g[tag + "_keys"]]
-        net.load_state_dict(_sd(shapes, 220 + i), strict=True)
-        net = net.to(dev).eval()
+        net.load_state_dict(_g22_state(shapes, kw, i), strict=True)
+        net = net.to(dev)
+        net = net.train() if train else net.eval()
         x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0)).to(dev)
         for xin in (x, x.half()):
             err = np.abs(net(xin).float().cpu().numpy() - g[tag])
             assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
     with pytest.raises(NotImplementedError):
         ResnetGenerator(3, 3, 64, norm_type="instance", padding_type="circular")
+    with pytest.raises(NameError):
+        ResnetGenerator(3, 3, 64, norm_type="group")              # the reference's own error
+    assert ResnetGenerator(3, 3).batch_norm                        # the constructor's default is norm_type='batch' (ResNet_arch.py:19)
     drop = ResnetGenerator(3, 3, 64, norm_type="instance", n_blocks=1, use_dropout=True).to(dev).train()
     with pytest.raises(NotImplementedError):
         drop(x)                                  # use_dropout=True in train mode is random: refused

@@ -184,8 +184,10 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
     g14 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g14_resnet9.npz"))
     cg = get_network(get_network_G_config("resnet_9blocks", 1))
     assert {k: tuple(v.shape) for k, v in cg.state_dict().items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g14["keys"], g14["shapes"])}
-    with pytest.raises(NotImplementedError):
-        get_network(get_network_G_config({"type": "resnet_9blocks", "norm_type": "batch"}, 1))
+    bn = get_network(get_network_G_config({"type": "resnet_9blocks", "norm_type": "batch"}, 1))        # BatchNorm2d: no conv biases, running statistics
+    assert "model.2.running_var" in bn.state_dict() and "model.1.bias" not in bn.state_dict() and "model.26.bias" in bn.state_dict()
+    with pytest.raises(NameError):
+        get_network(get_network_G_config({"type": "resnet_9blocks", "norm_type": "group"}, 1))
     g13 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_ppon.npz"))
     ppon = get_network(get_network_G_config("ppon", 4))
     assert {k: tuple(v.shape) for k, v in ppon.state_dict().items()} == {str(k): tuple(ast.literal_eval(str(v))) for k, v in zip(g13["keys"], g13["shapes"])}

@@ -318,7 +318,16 @@ def test_g21_guided_filter_windows_and_fast_mode(golden):
 
 G22_CASES = {"zero": dict(padding_type="zero"), "replicate": dict(padding_type="replicate"),
              "reflect_dropout": dict(padding_type="reflect", use_dropout=True), "zero_dropout": dict(padding_type="zero", use_dropout=True),
-             "upconv": dict(upsample_mode="upconv")}
+             "upconv": dict(upsample_mode="upconv"),
+             "batch_eval": dict(norm_type="batch"), "batch_train": dict(norm_type="batch", train=True),
+             "batch_zero_upconv_eval": dict(norm_type="batch", padding_type="zero", upsample_mode="upconv")}
+
+
+def _g22_state(shapes, kw, i):
+    sd = synth.fill_state_dict(shapes, 220 + i)
+    if kw.get("norm_type") == "batch":
+        sd = synth.fill_running_stats(sd, 228 + i)
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
 
 
 def test_g22_resnet_padding_and_dropout_variants(golden):
@@ -329,7 +338,8 @@ def test_g22_resnet_padding_and_dropout_variants(golden):
         shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[tag + "_keys"], g[tag + "_shapes"])}
         x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0))
         with torch.no_grad():
-            y = oracle.resnet_forward(_sd(shapes, 220 + i), x, n_blocks=2, **{k: v for k, v in kw.items() if k != "upsample_mode"}).numpy()
+            y = oracle.resnet_forward(_g22_state(shapes, kw, i), x, n_blocks=2, training=kw.get("train", False),
+                                      **{k: v for k, v in kw.items() if k not in ("upsample_mode", "train")}).numpy()
         assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-5, tag
 
 
