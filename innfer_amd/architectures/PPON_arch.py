@@ -11,7 +11,7 @@ from .param_module import ParamEngineModule
 class PPON(ParamEngineModule):
     _api = 'ppon'
 
-    def __init__(self, in_nc=3, nf=64, nb=24, out_nc=3, upscale=4, act_type='leakyrelu', alpha=1.0):
+    def __init__(self, in_nc=3, nf=64, nb=24, out_nc=3, upscale=4, act_type='lrelu', alpha=1.0):
         super().__init__()
         if str(act_type).lower() not in ('lrelu', 'leakyrelu'):
             raise NotImplementedError('PPON: only the LeakyReLU(0.2) activation is built')
