@@ -149,6 +149,11 @@ class Model:
         return infer_from_state_dict(state_dict)['net_params']
 
     # ------------------------------------------------------------- forward
+    def get_torch_ctx(self):
+        """The context a forward runs under (run.py:204-209): torch.no_grad() -- the TorchScript special case of the reference does not arise (no
+        'ts' architecture here)."""
+        return torch.no_grad()
+
     def chop_forward(self, data, patch_size=200, step=1.0, tile_range=None):
         """Tile, run, blend (run.py:167-202).  tile_range=(begin,count) runs a
         sub-range of tiles and returns the raw HR tiles instead of the blend."""

@@ -30,3 +30,25 @@ def linear2srgb(linear, gamma=2.4, th=0.0031308, device='cuda'):
     L.check(L.lib.innfer_linear_to_srgb(d_in.data_ptr(), d_out.data_ptr(), a.size,
                                         torch.cuda.current_stream(d_in.device).cuda_stream))
     return d_out.cpu().numpy()
+
+
+# Channel-order helpers of the reference (utils/colors.py:5-26): pure index plumbing on tensors of any device -- the image path itself flips
+# channels inside its fused pre / post kernels (np2tensor / tensor2np / forward_u8).
+def bgr_to_rgb(image):
+    """[.., C, H, W] -> the same with the channel axis reversed (utils/colors.py:5-11)."""
+    return image.flip(-3)
+
+
+def rgb_to_bgr(image):
+    """The same flip as bgr_to_rgb (utils/colors.py:14-16)."""
+    return bgr_to_rgb(image)
+
+
+def bgra_to_rgba(image):
+    """[4, H, W]: swap channels 0 and 2, keep alpha (utils/colors.py:19-21: it indexes the FIRST axis)."""
+    return image[[2, 1, 0, 3], :, :]
+
+
+def rgba_to_bgra(image):
+    """The same permutation as bgra_to_rgba (utils/colors.py:24-26)."""
+    return bgra_to_rgba(image)

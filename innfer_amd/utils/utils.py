@@ -335,6 +335,56 @@ def guided_filter(x, y, x_HR=None, ks=None, r=None, eps=1e-2, box_kernel=None, m
     return out
 
 
+# --------------------------------------------------------------- small helpers of the reference's utils (host math / elementwise plumbing)
+def denorm(x, min_max=(-1.0, 1.0)):
+    """[min, max] -> [0, 1], clamped (utils.py:136-150).  The image path applies it inside tensor2np / the uint8 epilogue; this is the free function."""
+    out = (x - min_max[0]) / (min_max[1] - min_max[0])
+    if isinstance(x, torch.Tensor):
+        return out.clamp(0, 1)
+    if isinstance(x, np.ndarray):
+        return np.clip(out, 0, 1)
+    raise TypeError("Got unexpected object type, expected torch.Tensor or np.ndarray")
+
+
+def norm(x):
+    """[0, 1] -> [-1, 1], clamped (utils.py:152-161)."""
+    out = (x - 0.5) * 2.0
+    if isinstance(x, torch.Tensor):
+        return out.clamp(-1, 1)
+    if isinstance(x, np.ndarray):
+        return np.clip(out, -1, 1)
+    raise TypeError("Got unexpected object type, expected torch.Tensor or np.ndarray")
+
+
+def get_box_kernel(kernel_size=5, dim=2):
+    """The mean filter of guided_filter as a tensor (utils.py:538-546): ones / (kx * ky)."""
+    if isinstance(kernel_size, (int, float)):
+        kernel_size = [kernel_size] * dim
+    kx, ky = int(kernel_size[0]), int(kernel_size[1])
+    return torch.full((kx, ky), 1.0 / (float(kx) * float(ky)), dtype=torch.float32)
+
+
+def normalize_kernel2d(x):
+    """L1-normalise the last two axes of a kernel (utils.py:448-454)."""
+    if x.dim() < 2:
+        raise TypeError("input should be at least 2D tensor. Got {}".format(x.size()))
+    return x / x.abs().sum(dim=(-1, -2), keepdim=True)
+
+
+def compute_padding(kernel_size):
+    """Padding that keeps the size under a kernel (utils.py:457-481): k // 2 for an int; for a tuple / list one (before, after) pair per axis,
+    last axis first, the 'before' side one less for even kernels."""
+    if isinstance(kernel_size, int):
+        return kernel_size // 2
+    ks = list(kernel_size)
+    half = [k // 2 for k in ks]
+    out = []
+    for i in range(len(ks)):
+        after = half[-(i + 1)]
+        out += [after - 1 if ks[i] % 2 == 0 else after, after]
+    return out
+
+
 # --------------------------------------------------------------- key converters
 _NEW2OLD_FIXED = (('conv_first', 'model.0'), ('trunk_conv', 'model.1.sub.23'), ('upconv1', 'model.3'),
                   ('upconv2', 'model.6'), ('HRconv', 'model.8'), ('conv_last', 'model.10'))
@@ -362,6 +412,29 @@ def mod2normal(state_dict):
     for new, old in _NEW2OLD_FIXED[1:]:
         for p in ('weight', 'bias'):
             out[f'{old}.{p}'] = state_dict[f'{new}.{p}']
+    return out
+
+
+def normal2mod(state_dict):
+    """Old-arch ESRGAN keys -> new-arch keys (utils.py:629-663), the inverse of mod2normal; like the reference it assumes the 23-block 4x layout."""
+    if 'model.0.weight' not in state_dict:
+        return state_dict
+    print('Converting and loading an RRDB model to modified RRDB')
+    out = {}
+    for new, old in _NEW2OLD_FIXED[:1]:
+        for p in ('weight', 'bias'):
+            out[f'{new}.{p}'] = state_dict[f'{old}.{p}']
+    for k, v in state_dict.items():
+        if 'RDB' in k:
+            k2 = k.replace('model.1.sub.', 'RRDB_trunk.')
+            if '.0.weight' in k:
+                k2 = k2.replace('.0.weight', '.weight')
+            elif '.0.bias' in k:
+                k2 = k2.replace('.0.bias', '.bias')
+            out[k2] = v
+    for new, old in _NEW2OLD_FIXED[1:]:
+        for p in ('weight', 'bias'):
+            out[f'{new}.{p}'] = state_dict[f'{old}.{p}']
     return out
 
 

@@ -348,6 +348,25 @@ def g20():
     save("g20_cli", table=np.array(json.dumps({"names": names, "scales": scales, "with_arg": with_arg, "extras": extras, "crops": crops, "chain": chain})))
 
 
+def g24():
+    """The small helpers of utils/utils.py and utils/colors.py that the image path inlines elsewhere: norm / denorm (:136-161), get_box_kernel /
+    normalize_kernel2d / compute_padding (:448-481, 538-546), the channel flips (colors.py:5-26), normal2mod (:629-663)."""
+    import json
+    x = synth.uniform((2, 3, 5, 7), 241, -1.5, 1.5)
+    t = torch.from_numpy(x)
+    k = torch.from_numpy(synth.uniform((2, 3, 5), 242, -1.0, 1.0))
+    rgba = torch.from_numpy(synth.uniform((4, 3, 5), 243))
+    pads = {str(ks): ref_utils.compute_padding(ks) for ks in (3, 4, 7, (3, 3), (4, 4), (3, 5), (4, 7), [2, 6], (3, 4, 5))}
+    shapes = synth.rrdbnet_shapes(nb=23, scale=4)
+    old = {kk: np.zeros((1,), np.float32) for kk in shapes}                      # key mapping only: old-arch keys -> new-arch keys and back
+    new_keys = list(ref_utils.normal2mod(dict(old)).keys())
+    save("g24_helpers", x=x, norm_t=ref_utils.norm(t).numpy(), norm_np=ref_utils.norm(x), denorm_t=ref_utils.denorm(t).numpy(),
+         denorm_np=ref_utils.denorm(x, (-0.5, 1.25)), box5=ref_utils.get_box_kernel(5).numpy(), box37=ref_utils.get_box_kernel([3, 7]).numpy(),
+         k=k.numpy(), k_norm=ref_utils.normalize_kernel2d(k).numpy(), rgba=rgba.numpy(), bgr2rgb=ref_colors.bgr_to_rgb(t).numpy(),
+         rgb2bgr=ref_colors.rgb_to_bgr(t[0]).numpy(), bgra2rgba=ref_colors.bgra_to_rgba(rgba).numpy(), rgba2bgra=ref_colors.rgba_to_bgra(rgba).numpy(),
+         table=np.array(json.dumps({"pads": pads, "old_keys": list(old.keys()), "new_keys": new_keys})))
+
+
 def g21():
     """guided_filter beyond r = 1 / 'regular' (utils.py:548-626): a 5x5 and a 7x7 window, and the 'fast' mode on a 2x guidance image."""
     x = torch.from_numpy(synth.uniform((2, 3, 23, 31), 211))

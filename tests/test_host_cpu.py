@@ -377,3 +377,29 @@ def test_chop_plan_equals_oracle_geometry_on_random_sizes():
                 assert first.value == tot and 0 <= count.value <= -(-n // world)
                 tot += count.value
             assert tot == n
+
+
+def test_small_helpers_golden():
+    """norm / denorm, the box-kernel helpers, the channel flips and normal2mod against the reference's own functions (golden G24)."""
+    import json
+    from innfer_amd.utils import utils as U
+    from innfer_amd.utils import colors as Cc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g24_helpers.npz"))
+    x, t = g["x"], torch.from_numpy(g["x"])
+    assert np.array_equal(U.norm(t).numpy(), g["norm_t"]) and np.array_equal(U.norm(x), g["norm_np"])
+    assert np.array_equal(U.denorm(t).numpy(), g["denorm_t"]) and np.array_equal(U.denorm(x, (-0.5, 1.25)), g["denorm_np"])
+    with pytest.raises(TypeError):
+        U.norm([0.5])
+    assert np.array_equal(U.get_box_kernel(5).numpy(), g["box5"]) and np.array_equal(U.get_box_kernel([3, 7]).numpy(), g["box37"])
+    assert np.allclose(U.normalize_kernel2d(torch.from_numpy(g["k"])).numpy(), g["k_norm"], atol=1e-7, rtol=0)
+    rgba = torch.from_numpy(g["rgba"])
+    assert np.array_equal(Cc.bgr_to_rgb(t).numpy(), g["bgr2rgb"]) and np.array_equal(Cc.rgb_to_bgr(t[0]).numpy(), g["rgb2bgr"])
+    assert np.array_equal(Cc.bgra_to_rgba(rgba).numpy(), g["bgra2rgba"]) and np.array_equal(Cc.rgba_to_bgra(rgba).numpy(), g["rgba2bgra"])
+    tab = json.loads(str(g["table"]))
+    for ks, want in tab["pads"].items():
+        assert U.compute_padding(eval(ks)) == want, ks
+    old = {k: np.zeros((1,), np.float32) for k in tab["old_keys"]}
+    new = U.normal2mod(dict(old))
+    assert list(new.keys()) == tab["new_keys"]
+    assert list(U.mod2normal(dict(new)).keys()) != [] and set(U.mod2normal(dict(new)).keys()) == set(old.keys())      # and back
+    assert U.normal2mod({"a": 1}) == {"a": 1}
