@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 104
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -260,6 +260,11 @@ int innfer_guided_filter(const void* d_x, const void* d_y, int dtype, int N, int
  * [N,C,Hh,Wh].  Same workspace as innfer_guided_filter.  (104) */
 int innfer_guided_filter_ex(const void* d_x, const void* d_y, int dtype, int N, int C, int H, int W, int ks, float eps,
                             const void* d_x_hr, int Hh, int Wh, void* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* filter2D (utils/utils.py:484-535): every [H,W] plane of d_x (planes = B*C, f16 / f32) cross-correlated with one kH x kW fp32 kernel in device memory
+ * behind F.pad(x, (pad_left, kW-1-pad_left, pad_top, kH-1-pad_top), mode); border 0 constant / 1 reflect / 2 replicate / 3 circular.  (104) */
+int innfer_filter2d(const void* d_x, int dtype, long planes, int H, int W, const float* d_kernel, int kH, int kW, int pad_left, int pad_top,
+                    int border, void* d_out, void* stream);
 
 /* -------------------------------------------------- single fused convolution
  * The building block, exposed for tests: 3x3 stride-1 zero-pad-1 convolution

@@ -492,6 +492,49 @@ extern "C" int innfer_guided_filter(const void* d_x, const void* d_y, int dtype,
     return INNFER_OK;
 }
 
+// filter2D (utils/utils.py:484-535): every plane of x [planes][H][W] cross-correlated with ONE kH x kW kernel after F.pad(x, (pl, pr, pt, pb), mode) --
+// the output keeps the plane's size (pl + pr = kW - 1, pt + pb = kH - 1).  One thread per output value; the kernel sits in device memory (fp32).
+// border: 0 constant (zeros), 1 reflect (no edge repeat), 2 replicate, 3 circular.
+__device__ __forceinline__ int f2d_src(int i, int n, int border) {
+    if (i >= 0 && i < n) return i;
+    if (border == 1) { i = i < 0 ? -i : 2 * n - 2 - i; return i; }
+    if (border == 2) return i < 0 ? 0 : n - 1;
+    if (border == 3) { i %= n; return i < 0 ? i + n : i; }
+    return -1;
+}
+__global__ void k_filter2d(const void* x, int f32, long planes, int H, int W, const float* k, int kH, int kW, int pl, int pt, int border, void* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const long base = i - (long)Y * W - X;
+    float acc = 0.f;
+    for (int a = 0; a < kH; ++a) {
+        const int sy = f2d_src(Y + a - pt, H, border);
+        for (int b = 0; b < kW; ++b) {
+            const int sx = f2d_src(X + b - pl, W, border);
+            const float v = (sy < 0 || sx < 0) ? 0.f : ld(x, base + (long)sy * W + sx, f32);
+            acc = fmaf(k[a * kW + b], v, acc);
+        }
+    }
+    if (f32) ((float*)out)[i] = acc; else ((f16*)out)[i] = (f16)acc;
+}
+
+extern "C" int innfer_filter2d(const void* d_x, int dtype, long planes, int H, int W, const float* d_kernel, int kH, int kW, int pad_left, int pad_top,
+                               int border, void* d_out, void* stream) {
+    if (!d_x || !d_kernel || !d_out || planes <= 0 || H <= 0 || W <= 0 || kH <= 0 || kW <= 0) return set_error(INNFER_ERR_INVALID, "filter2d: bad argument");
+    if (border < 0 || border > 3 || pad_left < 0 || pad_left >= kW || pad_top < 0 || pad_top >= kH)
+        return set_error(INNFER_ERR_INVALID, "filter2d: border %d (0 constant, 1 reflect, 2 replicate, 3 circular), pad (%d, %d) for a %d x %d kernel", border, pad_left, pad_top, kH, kW);
+    // F.pad's own limits: a reflection needs pad < size, a circular pad <= size
+    const int pmax_y = std::max(pad_top, kH - 1 - pad_top), pmax_x = std::max(pad_left, kW - 1 - pad_left);
+    if ((border == 1 && (pmax_y >= H || pmax_x >= W)) || (border == 3 && (pmax_y > H || pmax_x > W)))
+        return set_error(INNFER_ERR_INVALID, "filter2d: padding (%d, %d) exceeds what the %d x %d plane allows for this border mode", pmax_x, pmax_y, H, W);
+    const long n = planes * H * W;
+    hipLaunchKernelGGL(k_filter2d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, dtype == INNFER_F32, planes, H, W, d_kernel, kH, kW,
+                       pad_left, pad_top, border, d_out);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
 extern "C" int innfer_guided_filter_ex(const void* d_x, const void* d_y, int dtype, int N, int C, int H, int W, int ks, float eps,
                                        const void* d_x_hr, int Hh, int Wh, void* d_out, void* d_ws, size_t ws_bytes, void* stream) {
     if (!d_x || !d_y || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "guided_filter: null argument");

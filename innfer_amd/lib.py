@@ -127,6 +127,7 @@ SIGNATURES = {
     "innfer_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv3x3_f16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "innfer_filter2d": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "innfer_conv7x1_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv7x1": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv4x4s2_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -356,6 +356,35 @@ def norm(x):
     raise TypeError("Got unexpected object type, expected torch.Tensor or np.ndarray")
 
 
+def filter2D(x, kernel, border_type='reflect', dim=2, normalized=False):
+    """Every channel of x [B,C,H,W] convolved (cross-correlated) with one [1,kH,kW] kernel behind F.pad(x, compute_padding((kH, kW)), border_type):
+    the output keeps x's shape and dtype (utils.py:484-535).  HIP kernel (csrc/wbcunet.hip k_filter2d); dim 2 only."""
+    borders = ['constant', 'reflect', 'replicate', 'circular']
+    if border_type not in borders:
+        raise ValueError("Invalid border_type, we expect the following: {0}.Got: {1}".format(borders, border_type))
+    if dim != 2:
+        raise NotImplementedError("filter2D: 2-D tensors are built (the reference's only use)")
+    if not isinstance(x, torch.Tensor) or x.dim() != 4:
+        raise ValueError('expected a 4D [B,C,H,W] tensor')
+    if not x.is_cuda:
+        raise RuntimeError('innfer_amd runs filter2D on an MI355X only: there is no CPU path')
+    k = kernel.unsqueeze(0).to(x.device).to(x.dtype)
+    if normalized:
+        k = normalize_kernel2d(k)
+    kH, kW = int(k.shape[-2]), int(k.shape[-1])
+    pad = compute_padding((kH, kW))                                   # (left, right, top, bottom)
+    if pad[0] + pad[1] != kW - 1 or pad[2] + pad[3] != kH - 1:
+        raise NotImplementedError("filter2D: this kernel shape changes the output size in the reference (mixed even / odd sides)")
+    x = x.contiguous() if x.dtype in (torch.float16, torch.float32) else x.float().contiguous()
+    kd = k.reshape(kH, kW).float().contiguous()
+    out = torch.empty_like(x)
+    B, Cc, H, W = x.shape
+    with _on(x):
+        L.check(L.lib.innfer_filter2d(x.data_ptr(), _dt(x), B * Cc, H, W, kd.data_ptr(), kH, kW, int(pad[0]), int(pad[2]), borders.index(border_type),
+                                      out.data_ptr(), _stream(x)))
+    return out
+
+
 def get_box_kernel(kernel_size=5, dim=2):
     """The mean filter of guided_filter as a tensor (utils.py:538-546): ones / (kx * ky)."""
     if isinstance(kernel_size, (int, float)):

@@ -367,6 +367,22 @@ def g24():
          table=np.array(json.dumps({"pads": pads, "old_keys": list(old.keys()), "new_keys": new_keys})))
 
 
+def g25():
+    """filter2D (utils.py:484-535): the four border modes, odd / even kernels, a normalised random kernel."""
+    x = torch.from_numpy(synth.uniform((2, 3, 11, 13), 251, -1.0, 1.0))
+    out = {"x": x.numpy()}
+    k33 = torch.from_numpy(synth.uniform((1, 3, 3), 252, -1.0, 1.0))
+    k57 = torch.from_numpy(synth.uniform((1, 5, 7), 253, 0.0, 1.0))
+    k44 = torch.from_numpy(synth.uniform((1, 4, 4), 254, -1.0, 1.0))
+    out.update(k33=k33.numpy(), k57=k57.numpy(), k44=k44.numpy())
+    for b in ("constant", "reflect", "replicate", "circular"):
+        out["k33_" + b] = ref_utils.filter2D(x, k33, border_type=b).numpy()
+        out["k57n_" + b] = ref_utils.filter2D(x, k57, border_type=b, normalized=True).numpy()
+        out["k44_" + b] = ref_utils.filter2D(x, k44, border_type=b).numpy()
+    out["box5"] = ref_utils.filter2D(x, ref_utils.get_box_kernel(5).unsqueeze(0)).numpy()
+    save("g25_filter2d", **out)
+
+
 def g21():
     """guided_filter beyond r = 1 / 'regular' (utils.py:548-626): a 5x5 and a 7x7 window, and the 'fast' mode on a 2x guidance image."""
     x = torch.from_numpy(synth.uniform((2, 3, 23, 31), 211))

@@ -831,6 +831,27 @@ def test_column7_conv_vs_torch(dev):
         assert err < 4e-3, (N, Cc, K, H, W, reflect, err)
 
 
+def test_filter2d_golden(dev, golden):
+    """filter2D against the reference's own function (golden G25): four border modes, 3x3 / 5x7 (normalised) / 4x4 (even: asymmetric padding) kernels, the box
+    kernel of the guided filter; fp32 to 2e-6, fp16 input to fp16 rounding; the reference's errors."""
+    from innfer_amd.utils import utils as U
+    g = golden("g25_filter2d")
+    x = torch.from_numpy(g["x"]).to(dev)
+    for b in ("constant", "reflect", "replicate", "circular"):
+        for name, kw in (("k33", {}), ("k57n", dict(normalized=True)), ("k44", {})):
+            k = torch.from_numpy(g[name.rstrip("n")])
+            y = U.filter2D(x, k, border_type=b, **kw)
+            assert y.shape == x.shape and y.dtype == x.dtype
+            assert np.abs(y.cpu().numpy() - g[f"{name}_{b}"]).max() < 2e-6, (name, b)
+            yh = U.filter2D(x.half(), k, border_type=b, **kw)
+            assert yh.dtype == torch.float16 and np.abs(yh.float().cpu().numpy() - g[f"{name}_{b}"]).max() < 6e-3, (name, b)
+    assert np.abs(U.filter2D(x, U.get_box_kernel(5).unsqueeze(0)).cpu().numpy() - g["box5"]).max() < 2e-6
+    with pytest.raises(ValueError):
+        U.filter2D(x, torch.ones(1, 3, 3), border_type="wrap")
+    with pytest.raises(RuntimeError):
+        U.filter2D(x.cpu(), torch.ones(1, 3, 3))
+
+
 def test_unet256_upconv_full_depth_vs_oracle(dev):
     """upsample_mode='upconv' at unet_256's full depth (8 levels, 1x1 bottleneck -> the 3x3 conv runs on 2x2 .. 256x256 upsampled grids
     with 512 .. 1024 input channels), batch 2, train-mode and eval-mode BatchNorm, against the oracle (itself pinned on the reference, G23)."""
