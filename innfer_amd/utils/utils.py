@@ -304,16 +304,18 @@ def color_fix(imgA, imgB, device='cuda'):
 def guided_filter(x, y, x_HR=None, ks=None, r=None, eps=1e-2, box_kernel=None, mode='regular', conv_a=None):
     """guided_filter (utils.py:548-626): 'regular' mode (what run.py:427-429 applies after the WBC UNet with r=1) and 'fast' mode (A, b of the
     low-resolution pair enlarged bilinearly to the high-resolution guidance x_HR), any odd window ks = 2 r + 1 (box means, reflect padding);
-    x guidance, y input, [B,C,H,W] GPU tensors of one dtype.  Runs in libinnfer_amd.so (csrc/wbcunet.hip).  Not built: 'conv' mode (a caller's
-    nn.Sequential computes A), a precomputed box_kernel tensor, even window sizes."""
-    if mode not in ('regular', 'fast') or box_kernel is not None or conv_a is not None:
-        raise NotImplementedError("guided_filter: modes 'regular' and 'fast' without a precomputed kernel are built")
-    if not ks:
-        if not r:
-            raise ValueError("Either kernel size (ks) or radius (r) for the window are required.")
-        ks = 2 * r + 1
-    if int(ks) != ks or int(ks) % 2 == 0:
-        raise NotImplementedError(f'guided_filter: window size {ks} (odd sizes ks = 2 r + 1 are built)')
+    x guidance, y input, [B,C,H,W] GPU tensors of one dtype.  Runs in libinnfer_amd.so (csrc/wbcunet.hip: one fused pass per stage).  The remaining
+    forms -- 'conv' mode (the caller's nn.Sequential `conv_a` computes A from cat(cov_xy, var_x)), a precomputed box_kernel tensor, even window
+    sizes -- follow the reference's formula step by step on the HIP filter2D (its box means) with the caller's module in between."""
+    if mode not in ('regular', 'fast', 'conv'):
+        raise NotImplementedError("guided_filter: modes 'regular', 'fast' and 'conv'")
+    if not isinstance(box_kernel, torch.Tensor):
+        if not ks:
+            if not r:
+                raise ValueError("Either kernel size (ks) or radius (r) for the window are required.")
+            ks = 2 * r + 1
+    if mode == 'conv' or isinstance(box_kernel, torch.Tensor) or int(ks) != ks or int(ks) % 2 == 0:
+        return _guided_filter_stepwise(x, y, x_HR, box_kernel if isinstance(box_kernel, torch.Tensor) else get_box_kernel(kernel_size=ks), eps, mode, conv_a)
     if mode == 'fast' and not isinstance(x_HR, torch.Tensor):
         raise ValueError("guided_filter: mode 'fast' needs the high-resolution guidance x_HR")
     _need_cuda(x, 'guided_filter')
@@ -333,6 +335,28 @@ def guided_filter(x, y, x_HR=None, ks=None, r=None, eps=1e-2, box_kernel=None, m
                                               hr.data_ptr() if hr is not None else None, hr.shape[2] if hr is not None else 0,
                                               hr.shape[3] if hr is not None else 0, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x)))
     return out
+
+
+def _guided_filter_stepwise(x, y, x_HR, box_kernel, eps, mode, conv_a):
+    """utils.py:590-626 step by step: box means by the HIP filter2D, the products / quotients as tensor expressions, `conv_a` the caller's module."""
+    import torch.nn.functional as F
+    _need_cuda(x, 'guided_filter')
+    if mode in ('fast', 'conv') and not isinstance(x_HR, torch.Tensor):
+        raise ValueError(f"guided_filter: mode '{mode}' needs the high-resolution guidance x_HR")
+    if mode == 'conv' and conv_a is None:
+        raise ValueError("guided_filter: mode 'conv' needs conv_a")
+    box_kernel = box_kernel.to(x.device)
+    N = filter2D(torch.ones((1, 1, x.shape[-2], x.shape[-1]), device=x.device, dtype=x.dtype), box_kernel)
+    mean_x = filter2D(x, box_kernel) / N
+    mean_y = filter2D(y, box_kernel) / N
+    cov_xy = (filter2D(x * y, box_kernel) / N) - mean_x * mean_y
+    var_x = (filter2D(x * x, box_kernel) / N) - mean_x * mean_x
+    A = conv_a(torch.cat([cov_xy, var_x], dim=1)) if mode == 'conv' else cov_xy / (var_x + eps)
+    b = mean_y - A * mean_x
+    if mode in ('fast', 'conv'):
+        size = (x_HR.shape[-2], x_HR.shape[-1])
+        return F.interpolate(A, size, mode='bilinear', align_corners=True) * x_HR + F.interpolate(b, size, mode='bilinear', align_corners=True)
+    return (filter2D(A, box_kernel) / N) * x + filter2D(b, box_kernel) / N
 
 
 # --------------------------------------------------------------- small helpers of the reference's utils (host math / elementwise plumbing)

@@ -390,7 +390,24 @@ def g21():
     xh = torch.from_numpy(synth.uniform((2, 3, 46, 62), 213))
     save("g21_guided", r2=ref_utils.guided_filter(x, y, r=2, eps=5e-3).numpy(), ks7=ref_utils.guided_filter(x, y, ks=7, eps=1e-2).numpy(),
          fast=ref_utils.guided_filter(x, y, x_HR=xh, r=1, eps=5e-3, mode='fast').numpy(),
-         fast_r2=ref_utils.guided_filter(x, y, x_HR=xh, r=2, eps=1e-2, mode='fast').numpy())
+         fast_r2=ref_utils.guided_filter(x, y, x_HR=xh, r=2, eps=1e-2, mode='fast').numpy(),
+         # the forms beyond the fused kernels: a caller's conv_a ('conv' mode), an even window, a precomputed (here: non-uniform) box kernel
+         conv_w=_g21_conv_a()[1], conv_b=_g21_conv_a()[2], conv=ref_utils.guided_filter(x, y, x_HR=xh, r=1, mode='conv', conv_a=_g21_conv_a()[0]).detach().numpy(),
+         ks4=ref_utils.guided_filter(x, y, ks=4, eps=1e-2).numpy(),
+         bk=_g21_bk().numpy(), bk_out=ref_utils.guided_filter(x, y, box_kernel=_g21_bk(), eps=1e-2).numpy())
+
+
+def _g21_conv_a():
+    w, b = synth.uniform((3, 6, 1, 1), 214, -0.5, 0.5), synth.uniform((3,), 215, -0.1, 0.1)
+    m = torch.nn.Sequential(torch.nn.Conv2d(6, 3, 1))
+    with torch.no_grad():
+        m[0].weight.copy_(torch.from_numpy(w)); m[0].bias.copy_(torch.from_numpy(b))
+    return m, w, b
+
+
+def _g21_bk():
+    k = torch.from_numpy(synth.uniform((3, 5), 216, 0.5, 1.5))
+    return k / k.sum()
 
 
 def g22():

@@ -989,10 +989,20 @@ def test_guided_filter_windows_and_fast_mode_golden(dev, golden):
         got = U.guided_filter(x, y, **args).cpu().numpy()
         assert got.shape == g[tag].shape and np.abs(got - g[tag]).max() < 5e-5, (tag, np.abs(got - g[tag]).max())
     assert torch.equal(U.guided_filter(x, y, r=1, eps=5e-3), U.guided_filter(x, y, ks=3, eps=5e-3))
-    with pytest.raises(NotImplementedError):
-        U.guided_filter(x, y, ks=4)
+    # the forms that follow the reference's formula step by step on the HIP filter2D: a caller's conv_a, an even window, a precomputed kernel
+    conv_a = torch.nn.Sequential(torch.nn.Conv2d(6, 3, 1)).to(dev)
+    with torch.no_grad():
+        conv_a[0].weight.copy_(torch.from_numpy(g["conv_w"])); conv_a[0].bias.copy_(torch.from_numpy(g["conv_b"]))
+        got = U.guided_filter(x, y, x_HR=xh, r=1, mode="conv", conv_a=conv_a).cpu().numpy()
+    assert got.shape == g["conv"].shape and np.abs(got - g["conv"]).max() < 5e-5
+    assert np.abs(U.guided_filter(x, y, ks=4, eps=1e-2).cpu().numpy() - g["ks4"]).max() < 5e-5
+    assert np.abs(U.guided_filter(x, y, box_kernel=torch.from_numpy(g["bk"]), eps=1e-2).cpu().numpy() - g["bk_out"]).max() < 5e-5
+    # the stepwise form and the fused kernels agree where both apply
+    assert (U._guided_filter_stepwise(x, y, None, U.get_box_kernel(5), 5e-3, "regular", None) - U.guided_filter(x, y, r=2, eps=5e-3)).abs().max().item() < 5e-5
     with pytest.raises(ValueError):
         U.guided_filter(x, y, r=1, mode="fast")
+    with pytest.raises(ValueError):
+        U.guided_filter(x, y, x_HR=xh, r=1, mode="conv")
 
 
 def test_linear_resize_vs_oracle(dev):
