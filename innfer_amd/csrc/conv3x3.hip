@@ -1623,11 +1623,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     }
     if (L.stride2) {         // Conv2d(k 4, s 2, p 1): H x W = the OUTPUT grid, source image 2H x 2W; panels from conv_pack_taps(K, 4C, 0x1B0), virtual channel
                              // (2 pa + pb) * C + ci, tap (1 + dy, 1 + dx) = w[co][ci][2 dy + pa][2 dx + pb]
-        if (!pc || L.out_mode != OUT_SLAB || nt != 4 || L.res1 || L.res2 || L.up || L.reflect || L.act > 2 || L.y0 != 0 || k.y1 != L.H ||
-            L.dilation > 1 || L.dilation_groups || (long)L.H * L.W * 4 * 64 >= 0x7fffffffL)
-            return set_error(INNFER_ERR_UNSUPPORTED, "stride-2 conv: slab output of 64-channel tiles, no residual / upsampling / padding modes, sources below 33 M pixels");
+        if (!pc || L.out_mode != OUT_SLAB || (nt != 4 && nt != 2) || L.res1 || L.res2 || L.up || L.reflect || L.act > 2 || L.y0 != 0 || k.y1 != L.H ||
+            L.dilation > 1 || L.dilation_groups || (long)L.H * L.W * 4 * 64 >= 0x7fffffffL || (nt == 2 && L.stats_part))
+            return set_error(INNFER_ERR_UNSUPPORTED, "stride-2 conv: slab output of 32- / 64-channel tiles, no residual / upsampling / padding modes, sources below 33 M pixels");
         k.Hs = 2 * L.H; k.Ws = 2 * L.W; k.in_img_stride = (long)k.Hs * k.Ws * 32;
         k.nchunks = 4 * k.ncg;
+        if (nt == 2) return launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
         if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x17B0>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x13B0>(k, L.N, s);
         return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x7B0>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
     }

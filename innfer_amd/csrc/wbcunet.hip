@@ -219,7 +219,8 @@ __global__ void gf_out_fast(const float* A, const float* B, const void* xhr, int
 
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 struct Layer { int w = -1, b = -1, cin = 0, cout = 0, k = 3; f16* d_w = nullptr; float* d_b = nullptr;
-               void* d_w3 = nullptr; float* d_b3 = nullptr; };     // 3x3 layers: conv3x3.hip panels + bias (the stride-1 ones run there)
+               void* d_w3 = nullptr; float* d_b3 = nullptr;
+               void* d_ws2 = nullptr; };    // the two stride-2 3x3 convs: panels of the stride-2 gather loader (conv_pack_s2k4 over the kernel embedded in 4x4)     // 3x3 layers: conv3x3.hip panels + bias (the stride-1 ones run there)
 
 }  // namespace
 
@@ -258,7 +259,8 @@ extern "C" int innfer_wbc_create(innfer_wbc** out, int nf, int tf_mode) {
 static void wb_free(innfer_wbc* u) {
     for (auto& l : u->layers) {
         if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w3) (void)hipFree(l.d_w3); if (l.d_b3) (void)hipFree(l.d_b3);
-        l.d_w = nullptr; l.d_b = nullptr; l.d_w3 = nullptr; l.d_b3 = nullptr;
+        if (l.d_ws2) (void)hipFree(l.d_ws2);
+        l.d_w = nullptr; l.d_b = nullptr; l.d_w3 = nullptr; l.d_b3 = nullptr; l.d_ws2 = nullptr;
     }
 }
 
@@ -330,6 +332,22 @@ int wb_upload(innfer_wbc* u) {
             INNFER_HIP(hipMemcpy(l.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
             INNFER_HIP(hipMalloc((void**)&l.d_b3, b3.size() * sizeof(float)));
             INNFER_HIP(hipMemcpy(l.d_b3, b3.data(), b3.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        const size_t li_ = (size_t)(&l - &u->layers[0]);
+        if ((li_ == 1 || li_ == 3) && l.k == 3 && l.cin % 32 == 0 && l.cout % 32 == 0) {
+            // conv_1 / conv_3 (stride 2): Conv2d(3, 2, padding 1) reads rows 2y - 1 + ky -- the 4x4 / stride 2 / padding 1 lattice of the stride-2 gather
+            // loader with a zero fourth tap; tf_same_padding (pad (0, 1, 0, 1), rows 2y + ky) is the same lattice one tap later
+            const int o = u->tf ? 1 : 0;
+            std::vector<float> w4((size_t)l.cout * l.cin * 16, 0.f);
+            for (int co = 0; co < l.cout; ++co)
+                for (int ci = 0; ci < l.cin; ++ci)
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx)
+                            w4[(((size_t)co * l.cin + ci) * 4 + ky + o) * 4 + kx + o] = w[((size_t)co * l.cin + ci) * 9 + ky * 3 + kx];
+            std::vector<char> packed(conv_packed_bytes_s2k4(l.cout, l.cin));
+            conv_pack_s2k4(w4.data(), l.cout, l.cin, packed.data());
+            INNFER_HIP(hipMalloc(&l.d_ws2, packed.size()));
+            INNFER_HIP(hipMemcpy(l.d_ws2, packed.data(), packed.size(), hipMemcpyHostToDevice));
         }
         if (l.k == 3 && l.cin % 32 == 0 && l.cout % 32 == 0) {       // halo-tile form for the stride-1 launches
             std::vector<char> packed(conv_packed_bytes(l.cout, l.cin));
@@ -409,6 +427,15 @@ extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype,
             L.out = dst; L.out_gstride = (long)N * Ho * Wo * 32; L.K = l.cout;
             L.N = N; L.H = Ho; L.W = Wo; L.act = act ? 1 : 0; L.s1 = L.s2 = 1.f;
             L.y0 = 0; L.y1 = Ho; L.out_mode = OUT_SLAB; L.conv7v = 1;
+            return conv_launch(L, s);
+        }
+        if (l.d_ws2 && l.d_b3 && stride == 2 && !nchw && !res && (Hi % 2 == 0) && (Wi % 2 == 0)) {     // stride-2 3x3 conv on the stride-2 gather loader: bias + LeakyReLU + slab out
+            ConvLaunch L{};
+            L.in = in; L.in_gstride = (long)N * Hi * Wi * 32; L.C = l.cin;
+            L.wpk = (const f16*)l.d_ws2; L.bias = l.d_b3;
+            L.out = dst; L.out_gstride = (long)N * Ho * Wo * 32; L.K = l.cout;
+            L.N = N; L.H = Ho; L.W = Wo; L.act = act ? 1 : 0; L.s1 = L.s2 = 1.f;
+            L.y0 = 0; L.y1 = Ho; L.out_mode = OUT_SLAB; L.stride2 = 1;
             return conv_launch(L, s);
         }
         if (l.d_w3 && l.k == 3 && stride == 1 && !nchw) {     // zero-padded stride-1 3x3 conv: the SR path's halo-tile kernel, epilogue = bias / LeakyReLU / + residual
