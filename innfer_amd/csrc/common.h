@@ -50,7 +50,7 @@ struct ConvLaunch {
     int out_coff;                                 // channel offset inside that group (0 or 16)
     int K;                                        // valid output channels
     int N, H, W;                                  // conv (output) size
-    int act; int up;                              // act: 0 none / 1 LeakyReLU(0.2) / 2 ReLU / 3 tanh (OUT_NCHW only) / 4, 5 res1 * sigmoid(conv) with / without LeakyReLU (slab) / 6 sigmoid (OUT_NCHW only); up: input read through nearest 2x
+    int act; int up;                              // act: 0 none / 1 LeakyReLU(0.2) / 2 ReLU / 3 tanh (OUT_NCHW only) / 4, 5 res1 * sigmoid(conv) with / without LeakyReLU (slab) / 6 sigmoid (OUT_NCHW only) / 7 pair gate: 64 rows -> 32 outputs, row 16 lg + r (r < 8) times sigmoid(row 16 lg + r + 8) (slab, PAN's PAConv); up: input read through nearest 2x
     const f16* res1; long res1_gstride; float s1;
     const f16* res2; long res2_gstride; float s2;
     int y0, y1;                                   // output rows [y0,y1)

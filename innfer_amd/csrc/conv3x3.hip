@@ -122,7 +122,10 @@ struct KP {
 template <int RPW, int NT, int ACT, bool R1, bool R2>
 __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2 * RPW], int ty0, int tx0, int wave, int li, int cbase) {
     constexpr int MT = 2 * RPW;
-    const int oc0 = cbase + p.out_coff;
+    // ACT 7 (pair gate, PAN's PAConv): the lane's upper NT / 2 channel tiles are the gates of its lower ones -- out = conv_lo * sigmoid(conv_hi),
+    // half as many output channels (the launch's rows are ordered so that a value and its gate share a lane)
+    constexpr int NTS = ACT == 7 ? NT / 2 : NT;
+    const int oc0 = (ACT == 7 ? cbase >> 1 : cbase) + p.out_coff;
     const int cyB = ty0 / p.cv_h1, yB = ty0 - cyB * p.cv_h1 + wave * RPW;        // wave-uniform
     const int cxB = tx0 / p.cv_w1, xB = tx0 - cxB * p.cv_w1 + li;
     f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + (oc0 & 31);
@@ -157,12 +160,13 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
             }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NTS; ++t) {
             f16x4 h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float f = acc[t][m][j];
-                if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                if (ACT == 7) f = f * (1.0f / (1.0f + expf(-acc[t + NT / 2][m][j])));
+                else if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
                 else if (ACT == 2) f = f > 0.f ? f : 0.f;
                 if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
                 if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
@@ -180,7 +184,8 @@ template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = fa
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase, int dil = 1) {
     constexpr int MT = 2 * RPW;
-    int oc0 = cbase + p.out_coff;
+    constexpr int NTS = ACT == 7 ? NT / 2 : NT;              // ACT 7: pair gate (see epilogue_slab_cv)
+    int oc0 = (ACT == 7 ? cbase >> 1 : cbase) + p.out_coff;
     int yw = ty0 + wave * RPW, xl = tx0 + li;
     long pix0 = ((long)n * p.H + yw) * p.W + xl;
 #ifdef INNFER_ABLATE
@@ -241,12 +246,14 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
             }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NTS; ++t) {
             f16x4 h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float f = acc[t][m][j];
-                if (ACT >= 4) {           // pixel-attention gate (PAN): res1 * sigmoid(conv), ACT 4: LeakyReLU(0.2) after it
+                if (ACT == 7) {
+                    f = f * (1.0f / (1.0f + expf(-acc[t + NT / 2][m][j])));
+                } else if (ACT >= 4) {           // pixel-attention gate (PAN): res1 * sigmoid(conv), ACT 4: LeakyReLU(0.2) after it
                     f = (float)r1[R1 ? m : 0][t][j] * (1.0f / (1.0f + expf(-f)));
                     if (ACT == 4) f = fmaxf(f, 0.2f * f);
                 } else {
@@ -1179,7 +1186,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             if constexpr (OUTMODE == OUT_SLAB && CV) {
 #define EPI(A, B, C) epilogue_slab_cv<RPW, NT, A, B, C>(p, acc, ty0, tx0, cw, li, cbase)
             if (!p.res1) {
-                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
+                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
+                else if (NT == 4 && p.act == 7) EPI(NT == 4 ? 7 : 0, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
                 if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
             } else {
@@ -1193,7 +1201,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
 #define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, NSEG>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
-                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
+                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
+                else if (NT == 4 && TM == 0x1FF && !POLY && p.act == 7) EPI((NT == 4 && TM == 0x1FF && !POLY) ? 7 : 0, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
                 if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else if (p.act == 4) EPI(4, true, false);
                 else if (p.act == 5) EPI(5, true, false); else EPI(0, true, false);
@@ -1320,7 +1329,7 @@ template <int TH>
 int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
     const long plain = (long)N * ((k.W + TW - 1) / TW) * ((k.H + TH - 1) / TH);
     *tiles = plain; *gy = 0;
-    if (N < 2 || k.up || k.reflect || k.act >= 3 || k.y0 != 0 || k.y1 != k.H || k.H < TH + 2 || k.W < LVALID || k.nrate || k.dil > 1 || k.stats_part ||
+    if (N < 2 || k.up || k.reflect || (k.act >= 3 && k.act != 7) || k.y0 != 0 || k.y1 != k.H || k.H < TH + 2 || k.W < LVALID || k.nrate || k.dil > 1 || k.stats_part ||
         (long)N * k.H * k.W * 64 >= 0x7fffffffL)
         return 0;
     int best = 0;
@@ -1567,7 +1576,10 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if ((L.act == 4 || L.act == 5) && (L.out_mode != OUT_SLAB || !L.res1 || L.res2))
         return set_error(INNFER_ERR_INVALID, "conv3x3: the gate epilogue multiplies res1 (slab output, no second residual)");
     if (L.act == 6 && L.out_mode != OUT_NCHW) return set_error(INNFER_ERR_INVALID, "conv3x3: sigmoid is a planar-output activation");
-    if (L.act < 0 || L.act > 6 || (L.phase_c > 0 && (L.K % L.phase_c || L.K / L.phase_c != 4)))
+    if (L.act == 7 && (L.out_mode != OUT_SLAB || conv_nt_for(L.K) != 4 || L.K % 64 || L.res1 || L.res2 || L.conv1x1 || L.dilation > 1 || L.dilation_groups ||
+                       L.deconv_phases || L.stride2 || L.conv7v || L.stats_part))
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the pair gate is an epilogue of the plain 64-row slab conv (32 gated outputs per 64 rows)");
+    if (L.act < 0 || L.act > 7 || (L.phase_c > 0 && (L.K % L.phase_c || L.K / L.phase_c != 4)))
         return set_error(INNFER_ERR_INVALID, "conv3x3: act=%d phase_c=%d K=%d", L.act, L.phase_c, L.K);
     k.act = L.act;
     k.res1 = L.res1; k.res1_gstride = L.res1_gstride; k.s1 = L.s1;

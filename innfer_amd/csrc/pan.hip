@@ -288,6 +288,7 @@ struct Gemm {                       // one packed GEMM
     // plain 3x3 convs (bias, optional LeakyReLU / residual) run on the SR path's halo-tile kernel (conv3x3.hip) instead:
     bool tile3 = false; std::string bias_key;           // its packed panels [K3][cin_pad][3][3] and the bias padded with zeros
     void* d_w3 = nullptr; float* d_b3 = nullptr; int K3 = 0;
+    std::function<int(int)> bias_row;                   // optional: output row -> index into the bias parameter (-1: none); default: row == index
     bool one_tap = false;                               // a 1x1 conv: single-tap panel (conv_pack_1x1), the kernel's one-tap instantiation
 };
 
@@ -419,9 +420,16 @@ int build_gemms(innfer_pan* p) {
             if (co < gw) return wa[(size_t)co * nf + ci];
             return co >= 32 ? wb[(size_t)(co - 32) * nf + ci] : 0.f; }, "");
         add(32, gw, 9, [&k1, gw](int co, int ci, int t) { return ci < gw ? k1[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
-        add(32, gw, 9, [&k3, gw](int co, int ci, int t) { return ci < gw ? k3[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");   // k3(b), halo tile
+        // PAConv's k3(b) * sigmoid(k2(b) + bias) as ONE 64-row conv with the pair-gate epilogue (ConvLaunch.act 7): a lane of the MFMA result holds rows
+        // 16 lg + 4 t + j, its tiles t = 2, 3 gate its tiles t = 0, 1 -- so row 16 lg + r is k3's channel 8 lg + r for r < 8 and k2's channel
+        // 8 lg + r - 8 (a 1x1 conv: centre tap) for r >= 8; one read of b instead of two launches and a round trip of k3(b)
         const std::string kb = s + "PACnv.k2.bias";
-        add(32, gw, 9, [&k2, gw](int co, int ci, int t) { return ci < gw && t == 4 ? k2[(size_t)co * gw + ci] : 0.f; }, kb.c_str());   // k2(b), 1x1
+        add(32, 64, 9, [&k3, &k2, gw](int co, int ci, int t) {
+            const int lg = co >> 4, r = co & 15, c = 8 * lg + (r & 7);
+            if (ci >= gw || c >= gw) return 0.f;
+            if (r < 8) return k3[((size_t)c * gw + ci) * 9 + t];
+            return t == 4 ? k2[(size_t)c * gw + ci] : 0.f; }, kb.c_str());
+        p->gemms.back().bias_row = [gw](int co) { const int r = co & 15, c = 8 * (co >> 4) + (r & 7); return (r >= 8 && c < gw) ? c : -1; };
         add(32, gw, 9, [&k4, gw](int co, int ci, int t) { return ci < gw ? k4[((size_t)co * gw + ci) * 9 + t] : 0.f; }, "");
         add(64, nf, 9, [&c3, nf, gw](int co, int ci, int t) {           // cat[a, b] = channels 0..gw-1 and 32..32+gw-1
             if (t != 4) return 0.f;
@@ -475,7 +483,10 @@ int upload(innfer_pan* p) {
                     for (int t = 0; t < 9; ++t) w3[((size_t)co * g.cin_pad + ci) * 9 + t] = g.weight(co, ci, t);
             if (!g.bias_key.empty()) {
                 const std::vector<float>& hb = p->params[find(p, g.bias_key)].host;
-                for (int co = 0; co < g.cout; ++co) b3[co] = hb[co];
+                for (int co = 0; co < g.cout; ++co) {
+                    const int bi = g.bias_row ? g.bias_row(co) : co;
+                    if (bi >= 0) b3[co] = hb[bi];
+                }
             }
             g.one_tap = g.K3 >= 32;                     // slab outputs only (the planar last conv keeps the 3x3 kernel)
             for (size_t i = 0; i < w3.size() && g.one_tap; ++i) if (i % 9 != 4 && w3[i] != 0.f) g.one_tap = false;
@@ -509,7 +520,7 @@ int upload(innfer_pan* p) {
     return INNFER_OK;
 }
 
-struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, k3v, inp, t, pool, fgh, att, raw, hr[2][3], ups, total, slab_end; };
+struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, inp, t, pool, fgh, att, raw, hr[2][3], ups, total, slab_end; };
 
 PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     PCarve c{};
@@ -518,7 +529,7 @@ PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     size_t off = 0;
     auto slab = [&](size_t pixels, int groups) { size_t o = off; off += al(pixels * 32 * 2 * groups); return o; };
     c.x0 = slab(px, 1); c.fea = slab(px, 2); c.xa = slab(px, 2); c.xb = slab(px, 2); c.ab = slab(px, 2);
-    c.ab2 = slab(px, 2); c.k3y = slab(px, 1); c.k3v = slab(px, 1); c.inp = slab(px, 2); c.t = slab(px, 2); c.pool = slab(np ? np : 1, 2);
+    c.ab2 = slab(px, 2); c.k3y = slab(px, 1); c.inp = slab(px, 2); c.t = slab(px, 2); c.pool = slab(np ? np : 1, 2);
     size_t m = 1;
     for (int u = 0; u < p->n_up; ++u) { m *= 4; for (int k = 0; k < 3; ++k) c.hr[u][k] = slab(px * m, 1); }
     // ups_inter_mode 'bilinear': the upsampled input of a stage (stage 0: 4 px of 2 groups; stage 1: 16 px of 1 group -- the larger of the two)
@@ -583,7 +594,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     };
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
     f16 *X0 = (f16*)(ws + cv.x0), *FEA = (f16*)(ws + cv.fea), *XA = (f16*)(ws + cv.xa), *XB = (f16*)(ws + cv.xb),
-        *AB = (f16*)(ws + cv.ab), *AB2 = (f16*)(ws + cv.ab2), *K3Y = (f16*)(ws + cv.k3y), *K3V = (f16*)(ws + cv.k3v), *INP = (f16*)(ws + cv.inp),
+        *AB = (f16*)(ws + cv.ab), *AB2 = (f16*)(ws + cv.ab2), *K3Y = (f16*)(ws + cv.k3y), *INP = (f16*)(ws + cv.inp),
         *T = (f16*)(ws + cv.t), *POOL = (f16*)(ws + cv.pool);
 
     hipLaunchKernelGGL(pan_pre, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, p->in_nc, (long)H * W, N, X0);
@@ -595,8 +606,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         f16* xn = (b & 1) ? XB : XA;
         CK(conv3(x, G, H, W, 0, 1, nullptr, 0, AB, G));                               // lrelu([conv1_a | . | conv1_b]): a -> group 0, b -> group 1
         CK(conv3(AB, G, H, W, 0, 1, nullptr, 0, AB2, G));                             // lrelu(k1(a)) -> cat group 0
-        CK(conv3(AB + G, G, H, W, 0, 0, nullptr, 0, K3V, G));                         // k3(b)
-        CK(conv3(AB + G, G, H, W, 0, 5, K3V, G, K3Y, G));                             // y = k3(b) * sigmoid(k2(b) + bias): gate epilogue
+        CK(conv3(AB + G, G, H, W, 0, 7, nullptr, 0, K3Y, G));                         // y = k3(b) * sigmoid(k2(b) + bias): one conv, pair-gate epilogue
         CK(conv3(K3Y, G, H, W, 0, 1, nullptr, 0, AB2 + G, G));                        // lrelu(k4(.)) -> cat group 1
         CK(conv3(AB2, G, H, W, 0, 0, x, G, xn, G));                                   // conv3(cat[a,b]) + x
         x = xn;
