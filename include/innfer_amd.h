@@ -276,7 +276,10 @@ int innfer_filter2d(const void* d_x, int dtype, long planes, int H, int W, const
  *   out[.., out_ch_off + k] = epilogue(conv(in[.., 0:C]))
  *   epilogue: +bias -> act -> (*res1_scale + res1) -> (*res2_scale + res2)
  * act: 0 none, 1 LeakyReLU(0.2) (block.py:89-90), 2 ReLU; 4 / 5: the pixel-attention gate of PAN (PAN_arch.py PA, PAConv):
- *   out = d_res1 * sigmoid(conv + bias), followed by LeakyReLU(0.2) for 4 (d_res1 required, no d_res2, scales unused).
+ *   out = d_res1 * sigmoid(conv + bias), followed by LeakyReLU(0.2) for 4 (d_res1 required, no d_res2, scales unused);
+ *   7: the pair gate of PAN's PAConv (PAN_arch.py:36-55: k3(x) * sigmoid(k2(x))) as ONE conv of K = 64 g rows that writes 32 g channels:
+ *   row 16 q + r (r < 8) is value channel 8 q + r, row 16 q + 8 + r its gate -- out[8 q + r] = (conv + bias)[16 q + r] * sigmoid((conv + bias)[16 q + 8 + r])
+ *   (no residuals; d_out holds K / 2 channels).
  * upsample2x: input is read through nearest-2x upsampling (block.py:321-322,358),
  *   i.e. d_in is [N,H/2,W/2,*] while H,W are the conv's (output) size.
  * d_packed comes from innfer_pack_conv3x3().  C % 32 == 0, K % 16 == 0, K <= 64 (pixel_shuffle2: K % 64 == 0, any K).

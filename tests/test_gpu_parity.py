@@ -795,6 +795,44 @@ def test_stride2_conv_and_transposed_conv_vs_torch(dev):
             assert got.shape == ref.shape and (got - ref).abs().max().item() < 4e-3, ("up", k, N, Cc, K, H, W, (got - ref).abs().max().item())
 
 
+def test_pair_gate_epilogue_vs_torch(dev):
+    """act 7 of the single-conv ABI: 64 rows -> 32 channels, out[8 q + r] = conv[16 q + r] * sigmoid(conv[16 q + 8 + r]) -- two independent 3x3 convs
+    (value, gate) interleaved that way against torch; a batch of ragged images (the canvas form) and one image."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(9)
+    for (N, Cc, H, W) in [(1, 32, 40, 56), (5, 64, 30, 38), (2, 32, 16, 32)]:
+        x = torch.from_numpy(rng.uniform(-1, 1, (N, Cc, H, W)).astype(np.float32)).half()
+        wv = torch.from_numpy((rng.uniform(-1, 1, (32, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(np.float32)).half().float()
+        wg = torch.from_numpy((rng.uniform(-1, 1, (32, Cc, 3, 3)) / np.sqrt(9 * Cc) * 4).astype(np.float32)).half().float()
+        bv, bg = [torch.from_numpy(rng.uniform(-0.5, 0.5, 32).astype(np.float32)) for _ in range(2)]
+        w, b = torch.zeros(64, Cc, 3, 3), torch.zeros(64)
+        for c in range(32):
+            q, r = divmod(c, 8)
+            w[16 * q + r], b[16 * q + r] = wv[c], bv[c]
+            w[16 * q + 8 + r], b[16 * q + 8 + r] = wg[c], bg[c]
+        ref = F.conv2d(x.float(), wv, bv, padding=1) * torch.sigmoid(F.conv2d(x.float(), wg, bg, padding=1))
+        import innfer_amd.lib as L
+        g = N * H * W * 32
+        slab = torch.empty((Cc // 32, N, H, W, 32), dtype=torch.float16, device=dev)
+        L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), g, 0, N, Cc, H, W, None))
+        packed = np.zeros(L.lib.innfer_conv3x3_packed_bytes(64, Cc), dtype=np.uint8)
+        wc = np.ascontiguousarray(w.numpy())
+        L.check(L.lib.innfer_pack_conv3x3(wc.ctypes.data, 64, Cc, packed.ctypes.data))
+        d_packed, d_bias = torch.from_numpy(packed).to(dev), b.to(dev)
+        out = torch.full((1, N, H, W, 32), -3.0, dtype=torch.float16, device=dev)
+        a = L.ConvArgs()
+        a.d_in, a.in_group_stride, a.C = slab.data_ptr(), g, Cc
+        a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
+        a.d_out, a.out_group_stride, a.K = out.data_ptr(), g, 64
+        a.N, a.H, a.W, a.act = N, H, W, 7
+        L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
+        got = torch.empty((N, 32, H, W), dtype=torch.float32, device=dev)
+        L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), g, 0, got.data_ptr(), L.F32, N, 32, H, W, None))
+        torch.cuda.synchronize()
+        err = (got.cpu() - ref).abs().max().item()
+        assert err < 4e-3, (N, Cc, H, W, err)
+
+
 def test_column7_conv_vs_torch(dev):
     """The 7 x 1 column conv of the single-conv ABI (three vertically displaced 3-tap blocks of the halo-tile kernel) against torch: zero-padded
     and reflected rows, 32 / 64 outputs, 32 / 64 input channels, ragged and sub-tile sizes, batches."""
