@@ -1333,6 +1333,59 @@ def test_pan_scales_vs_oracle(dev):
         net(torch.zeros(1, 1, 3, 8, device=dev))                        # MaxPool2d(4) needs >= 4x4
 
 
+def test_small_generators_shape_fuzz_and_poisoned_workspace(dev):
+    """Seeded shapes for the pix2pix UNet, the CycleGAN ResNet and the WBC UNet against the oracle: every size decides anew which levels run on the
+    halo-tile kernel's stride-2 / phase-lattice / column / sub-block forms (ragged tile rows and columns, half-width grids, batches) and which on the
+    gather GEMM.  Each forward is repeated on a workspace filled with 0xFF bytes (NaN as fp16 / fp32): the result must not change, i.e. every byte a
+    kernel reads -- padded rings, statistics partials, split-K segments -- was written by this forward."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.UNet_arch import UnetGenerator
+    from innfer_amd.architectures.ResNet_arch import ResnetGenerator
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    rng = np.random.RandomState(77)
+
+    def check(net, x, ref, tol_max, tol_mean, tag):
+        y = net(x.to(dev).half()).float().cpu()
+        err = (y - ref).abs()
+        assert y.shape == ref.shape and err.max().item() < tol_max and err.mean().item() < tol_mean, (tag, tuple(x.shape), err.max().item(), err.mean().item())
+        net._ws.fill_(0xFF)
+        assert torch.equal(net(x.to(dev).half()).float().cpu(), y), (tag, tuple(x.shape), "reads unwritten workspace")
+
+    unet = UnetGenerator(3, 3, 5, ngf=64)
+    sd_u = _sd({k: tuple(v.shape) for k, v in unet.state_dict().items()}, 401)
+    unet.load_state_dict(sd_u, strict=True)
+    unet = unet.to(dev).train()
+    for _ in range(6):
+        n, h, w = int(rng.randint(1, 3)), 32 * int(rng.randint(2, 9)), 32 * int(rng.randint(2, 9))
+        x = torch.from_numpy(synth.uniform((n, 3, h, w), int(rng.randint(1 << 20)), -1.0, 1.0))
+        with torch.no_grad():
+            ref = torch.cat([oracle.unet_forward(sd_u, x[i:i + 1], num_downs=5) for i in range(n)], 0)
+        check(unet, x, ref, 3e-2, 3e-3, "unet")
+    res = ResnetGenerator(3, 3, 64, norm_type="instance", n_blocks=1)
+    sd_r = _sd({k: tuple(v.shape) for k, v in res.state_dict().items()}, 402)
+    res.load_state_dict(sd_r, strict=True)
+    res = res.to(dev).eval()
+    for _ in range(6):
+        n, h, w = int(rng.randint(1, 3)), 4 * int(rng.randint(4, 60)), 4 * int(rng.randint(4, 60))
+        x = torch.from_numpy(synth.uniform((n, 3, h, w), int(rng.randint(1 << 20)), -1.0, 1.0))
+        with torch.no_grad():
+            ref = torch.cat([oracle.resnet_forward(sd_r, x[i:i + 1], n_blocks=1) for i in range(n)], 0)
+        check(res, x, ref, 1e-2, 1.5e-3, "resnet")
+    for mode in ("wbcunet", "wbcunet_tf"):
+        wb = get_network(get_network_G_config(mode, 1))
+        sd_w = _sd({k: tuple(v.shape) for k, v in wb.state_dict().items()}, 403)
+        wb.load_state_dict(sd_w, strict=True)
+        wb = wb.to(dev).eval()
+        for _ in range(3):
+            n, h, w = int(rng.randint(1, 3)), 4 * int(rng.randint(4, 50)), 4 * int(rng.randint(4, 50))
+            x = torch.from_numpy(synth.uniform((n, 3, h, w), int(rng.randint(1 << 20)), -1.0, 1.0))
+            with torch.no_grad():
+                ref = oracle.wbcunet_forward(sd_w, x, mode="tf" if mode.endswith("tf") else "pt")
+            check(wb, x, ref, 8e-3, 1e-3, mode)
+
+
 # ---------------------------------------------------------- tiles / blend / io
 def test_extract_and_blend_bit_exact(dev, golden):
     import oracle
