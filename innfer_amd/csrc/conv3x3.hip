@@ -697,6 +697,13 @@ __device__ __forceinline__ void epilogue_stats(const KP& p, const f32x4 (&acc)[N
 // request stream into HBM never pauses.
 // NCW: consumer waves (8: two per SIMD; 4: one per SIMD with twice the rows each -- the same tile with 0.25 instead of 0.42 ds_read_b128 per MFMA,
 // 256 registers per wave).
+// TMF: bits 0..8 the tap mask of the 3x3 lattice (bit r * 3 + s; the weight panel holds the set taps in that order) + mode flags:
+//   0x1FF  3x3 conv (software-pipelined fragment reads)          0x010  1x1 conv                      0x092  column taps (S9: 7 x 1 conv as three blocks)
+//   0x01B  ConvTranspose2d(k, 2, 1): one output phase per channel group on a lattice shifted by the phase, scatter into the 2x slab
+//   0x1B0 | 0x200  Conv2d(4, 2, 1): the loader gathers the space-to-depth source (chunk = (phase, channel group))
+//   | 0x400  grids <= 16 wide: one 16-pixel segment per tile row      | 0x800  (1x1) operand = LeakyReLU(running sum over the chunks) (PPON's c2)
+//   | 0x1000 partial norm statistics out of the epilogue (epilogue_stats)
+// Every flag is compile-time: the instantiations of the SR path (0x1FF without flags) contain none of the other modes' code.
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TMF = 0x1FF, bool CV = false, int NSI = 2, int NCW = 8>
 __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // TMF: tap mask (bits 0..8) + 0x200 = the stride-2 gather loader (S2): Conv2d(k 4, s 2, p 1) as the 2x2-tap conv of the space-to-depth input --
