@@ -173,7 +173,7 @@ int innfer_unet_forward(innfer_unet_t u, const void* d_in, int in_dtype, void* d
  * Replaces PAN.forward (architectures/PAN_arch.py:163-222) with its SCPA blocks (PAN_arch.py:47-106),
  * PAConv (PAN_arch.py:24-45), the FSA SelfAttentionBlock on a 4x max-pooled map (block.py:398-473,
  * bicubic re-expansion) and the nearest pixel-attention up-blocks (block.py pa_upconv_block), as
- * utils/defaults.py:78-89 configures them: nf 40, unf 24, nb 16, scale 1/2/4, self_attention=True,
+ * utils/defaults.py:78-89 configures them: nf 40, unf 24, nb 16, scale 1/2/3/4, self_attention=True,
  * double_scpa=False, ups_inter_mode='nearest'.  Parameters are addressed by state-dict key
  * ("SCPA_trunk.3.PACnv.k2.weight" ...), PyTorch layout, fp32 host data.
  */

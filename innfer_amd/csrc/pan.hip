@@ -219,12 +219,12 @@ __global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f
     *(f16x8*)(dst + so) = h;
 }
 
-// F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False) on a blocked slab (ATen upsample_bilinear2d: source index
-// max(0, (dst + 0.5) / 2 - 0.5), the second tap clamped to the last pixel, fp32 arithmetic in ATen's association); one thread per
-// (output pixel, 8 channels) of `groups` 32-channel groups
-__global__ void pan_up_bilinear2x(const f16* src, long sg, f16* dst, long dg, int groups, int N, int h, int w) {
+// F.interpolate(t, scale_factor=f, mode) on a blocked slab, f = 2 | 3.  bilinear (align_corners=False, ATen upsample_bilinear2d): source index
+// max(0, (dst + 0.5) / f - 0.5), the second tap clamped to the last pixel, fp32 arithmetic in ATen's association; nearest: source dst / f.
+// One thread per (output pixel, 8 channels) of `groups` 32-channel groups.
+__global__ void pan_upsample(const f16* src, long sg, f16* dst, long dg, int groups, int N, int h, int w, int f, int bilinear) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int H2 = 2 * h, W2 = 2 * w;
+    const int H2 = f * h, W2 = f * w;
     const long total = (long)N * H2 * W2 * groups * 4;
     if (i >= total) return;
     const int q = (int)(i & 3);
@@ -232,20 +232,24 @@ __global__ void pan_up_bilinear2x(const f16* src, long sg, f16* dst, long dg, in
     const int grp = (int)(r % groups); r /= groups;
     const int x = (int)(r % W2), y = (int)((r / W2) % H2);
     const long n = r / ((long)W2 * H2);
-    const float sy = fmaxf(0.5f * ((float)y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)x + 0.5f) - 0.5f, 0.f);
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
     const f16* b = src + grp * sg + n * (long)h * w * 32 + q * 8;
-    const f16x8 v00 = *(const f16x8*)(b + ((long)y0 * w + x0) * 32), v01 = *(const f16x8*)(b + ((long)y0 * w + x1) * 32);
-    const f16x8 v10 = *(const f16x8*)(b + ((long)y1 * w + x0) * 32), v11 = *(const f16x8*)(b + ((long)y1 * w + x1) * 32);
     f16x8 o;
+    if (!bilinear) {
+        o = *(const f16x8*)(b + ((long)(y / f) * w + x / f) * 32);
+    } else {
+        const float inv = 1.0f / (float)f;
+        const float sy = fmaxf(inv * ((float)y + 0.5f) - 0.5f, 0.f), sx = fmaxf(inv * ((float)x + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const f16x8 v00 = *(const f16x8*)(b + ((long)y0 * w + x0) * 32), v01 = *(const f16x8*)(b + ((long)y0 * w + x1) * 32);
+        const f16x8 v10 = *(const f16x8*)(b + ((long)y1 * w + x0) * 32), v11 = *(const f16x8*)(b + ((long)y1 * w + x1) * 32);
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-        o[e] = (f16)(hy * (hx * (float)v00[e] + lx * (float)v01[e]) + ly * (hx * (float)v10[e] + lx * (float)v11[e]));
+        for (int e = 0; e < 8; ++e)
+            o[e] = (f16)(hy * (hx * (float)v00[e] + lx * (float)v01[e]) + ly * (hx * (float)v10[e] + lx * (float)v11[e]));
+    }
     *(f16x8*)(dst + grp * dg + ((n * H2 + y) * (long)W2 + x) * 32 + q * 8) = o;
 }
-
 
 // out = conv_last + bias + bilinear(x, align_corners=True) -> NCHW
 // (rs == 0: raw is the planar fp32 [N][C][FH][FW] output of the halo-tile conv, bias already added)
@@ -318,11 +322,11 @@ extern "C" int innfer_pan_create(innfer_pan** out, int in_nc, int out_nc, int nf
 extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int nf, int unf, int nb, int scale, int self_attention, int double_scpa, int bilinear_up) {
     if (!out) return set_error(INNFER_ERR_INVALID, "pan_create: null out");
     if (nf != 40 || unf != 24 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || nb < 1 ||
-        (scale != 1 && scale != 2 && scale != 4))
-        return set_error(INNFER_ERR_UNSUPPORTED, "pan_create: nf=%d unf=%d scale=%d (built: nf 40, unf 24, scale 1/2/4)", nf, unf, scale);
+        (scale != 1 && scale != 2 && scale != 3 && scale != 4))
+        return set_error(INNFER_ERR_UNSUPPORTED, "pan_create: nf=%d unf=%d scale=%d (built: nf 40, unf 24, scale 1/2/3/4)", nf, unf, scale);
     innfer_pan* p = new innfer_pan();
     p->in_nc = in_nc; p->out_nc = out_nc; p->nf = nf; p->unf = scale == 1 ? nf : unf; p->nb = nb; p->scale = scale;
-    p->n_up = scale == 4 ? 2 : (scale == 2 ? 1 : 0);
+    p->n_up = scale == 4 ? 2 : (scale == 1 ? 0 : 1);          // scale 3: ONE Upsample(scale_factor=3) stage (PAN_arch.py:112-114,164-166)
     p->self_attention = self_attention != 0; p->double_scpa = double_scpa != 0; p->bilinear_up = bilinear_up != 0;
     const int gw = nf / 2, UF = p->unf;
     P(p, "conv_first.weight", {nf, in_nc, 3, 3}); P(p, "conv_first.bias", {nf});
@@ -531,9 +535,10 @@ PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     c.x0 = slab(px, 1); c.fea = slab(px, 2); c.xa = slab(px, 2); c.xb = slab(px, 2); c.ab = slab(px, 2);
     c.ab2 = slab(px, 2); c.k3y = slab(px, 1); c.inp = slab(px, 2); c.t = slab(px, 2); c.pool = slab(np ? np : 1, 2);
     size_t m = 1;
-    for (int u = 0; u < p->n_up; ++u) { m *= 4; for (int k = 0; k < 3; ++k) c.hr[u][k] = slab(px * m, 1); }
+    for (int u = 0; u < p->n_up; ++u) { m *= p->scale == 3 ? 9 : 4; for (int k = 0; k < 3; ++k) c.hr[u][k] = slab(px * m, 1); }
     // ups_inter_mode 'bilinear': the upsampled input of a stage (stage 0: 4 px of 2 groups; stage 1: 16 px of 1 group -- the larger of the two)
-    c.ups = (p->bilinear_up && p->n_up) ? (p->n_up == 2 ? slab(px * 16, 1) : slab(px * 4, 2)) : 0;
+    // (nearest 3x has no place in the conv's loader either: it is materialised the same way)
+    c.ups = ((p->bilinear_up || p->scale == 3) && p->n_up) ? (p->n_up == 2 ? slab(px * 16, 1) : slab(px * (p->scale == 3 ? 9 : 4), 2)) : 0;
     c.slab_end = off;
     c.fgh = off; off += al((np ? np : 1) * 64 * 4);
     c.att = off; off += al((np ? np : 1) * p->nf * 4);
@@ -639,14 +644,15 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     long cur_g = G;
     int h = H, w = W;
     for (int u = 0; u < p->n_up; ++u) {
-        const int hh = 2 * h, ww = 2 * w;
+        const int uf = p->scale == 3 ? 3 : 2;
+        const int hh = uf * h, ww = uf * w;
         const long hpx = (long)N * hh * ww, HG = hpx * 32;
         f16 *V = (f16*)(ws + cv.hr[u][0]), *PA = (f16*)(ws + cv.hr[u][1]), *HRC = (f16*)(ws + cv.hr[u][2]);
-        if (p->bilinear_up) {                                                          // conv(bilinear2x(t)): the upsampling as its own pass
+        if (p->bilinear_up || uf == 3) {                                               // conv(upsampled(t)): the upsampling as its own pass
             f16* UPS = (f16*)(ws + cv.ups);
             const int groups = u == 0 ? 2 : 1;                                         // nf = 40 / unf = 24 channels (pad channels stay zero: 0 interpolates to 0)
             const long tot = hpx * groups * 4;
-            hipLaunchKernelGGL(pan_up_bilinear2x, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, cur, cur_g, UPS, HG, groups, N, h, w);
+            hipLaunchKernelGGL(pan_upsample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, cur, cur_g, UPS, HG, groups, N, h, w, uf, p->bilinear_up ? 1 : 0);
             INNFER_HIP(hipGetLastError());
             CK(conv3(UPS, HG, hh, ww, 0, 0, nullptr, 0, V, HG));
         } else

@@ -638,7 +638,8 @@ def g18():
     for i, (tag, kw) in enumerate({"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
                                    "double_noattn_x2": dict(double_scpa=True, self_attention=False, scale=2),
                                    "bilinear": dict(ups_inter_mode="bilinear"),
-                                   "bilinear_noattn_x2": dict(ups_inter_mode="bilinear", self_attention=False, scale=2)}.items()):
+                                   "bilinear_noattn_x2": dict(ups_inter_mode="bilinear", self_attention=False, scale=2),
+                                   "x3": dict(scale=3), "bilinear_x3": dict(ups_inter_mode="bilinear", scale=3, self_attention=False)}.items()):
         net = RefPAN(3, 3, 40, 24, 3, **kw).eval()
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
         sd = synth.fill_state_dict(shapes, 185 + i)

@@ -156,7 +156,8 @@ def test_g18_srresnet_variants_and_outm(golden):
 
 G18_PAN = {"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
            "double_noattn_x2": dict(double_scpa=True, self_attention=False, scale=2),
-           "bilinear": dict(ups_inter_mode="bilinear"), "bilinear_noattn_x2": dict(ups_inter_mode="bilinear", self_attention=False, scale=2)}
+           "bilinear": dict(ups_inter_mode="bilinear"), "bilinear_noattn_x2": dict(ups_inter_mode="bilinear", self_attention=False, scale=2),
+           "x3": dict(scale=3), "bilinear_x3": dict(ups_inter_mode="bilinear", scale=3, self_attention=False)}
 
 
 def test_g18_pan_constructor_variants(golden):
