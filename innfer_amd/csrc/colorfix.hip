@@ -16,16 +16,47 @@ using namespace innfer;
 
 namespace {
 
-__device__ __forceinline__ float srgb2lin(uint8_t v) {
+// The two transfer functions as written down (colors.py:29-60 on uint8 / on the float result)...
+__device__ __forceinline__ float srgb2lin_eval(uint8_t v) {
     const float l = __fdiv_rn((float)v, 255.0f);
     return l <= 0.04045f ? __fdiv_rn(l, 12.92f) : powf(__fdiv_rn(__fadd_rn(l, 0.055f), 1.055f), 2.4f);
 }
 
-__device__ __forceinline__ uint8_t lin2srgb(float x) {
+__device__ __forceinline__ uint8_t lin2srgb_eval(float x) {
     float s = fminf(fmaxf(x, 0.0f), 1.0f);
     s = s <= 0.0031308f ? __fmul_rn(s, 12.92f) : __fsub_rn(__fmul_rn(1.055f, powf(s, (float)(1.0 / 2.4))), 0.055f);
     s = fminf(fmaxf(__fmul_rn(s, 255.0f), 0.0f), 255.0f);
     return (uint8_t)(int)s;
+}
+
+// ... and as the image kernels apply them: both have only 256 outcomes, so the powf leaves the per-pixel path (it was what color_fix's time went to).
+// g_s2l[v] = srgb2lin_eval(v); g_thr[k] = the smallest float in [0, 1] that lin2srgb_eval maps to a code >= k (k = 1 .. 255; found by bisection over
+// the float bit patterns with lin2srgb_eval itself, once per device) -- linear2srgb(x) is then the number of thresholds <= clamp(x), eight compares.
+__device__ float g_s2l[256];
+__device__ float g_thr[256];
+
+__global__ void k_build_tables() {
+    const int k = threadIdx.x;
+    g_s2l[k] = srgb2lin_eval((uint8_t)k);
+    unsigned lo = 0u, hi = 0x3F800000u;                 // bit patterns of 0.0f and 1.0f: non-negative floats order like their bits
+    if (k == 0) { g_thr[0] = 0.0f; return; }
+    if (lin2srgb_eval(__uint_as_float(hi)) < k) { g_thr[k] = 2.0f; return; }       // (code 255 is reached at 1.0: never taken)
+    while (lo < hi) {                                   // invariant: eval(hi) >= k
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        if (lin2srgb_eval(__uint_as_float(mid)) >= k) hi = mid; else lo = mid + 1;
+    }
+    g_thr[k] = __uint_as_float(hi);
+}
+
+__device__ __forceinline__ float srgb2lin(uint8_t v) { return g_s2l[v]; }
+
+// thr: the 256 thresholds in LDS
+__device__ __forceinline__ uint8_t lin2srgb(float x, const float* thr) {
+    const float s = fminf(fmaxf(x, 0.0f), 1.0f);
+    int code = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) code += (thr[code + step] <= s) ? step : 0;
+    return (uint8_t)code;
 }
 
 // OpenCV's cubic taps for destination index d: first source index (s - 1) and the four weights
@@ -44,7 +75,11 @@ __device__ __forceinline__ void cubic_taps(int d, float scale, int& s, float w[4
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // horizontal pass, then vertical pass, as cv2.resize does for float images
-__device__ __forceinline__ float cubic_sample(const float* src, int Hs, int Ws, int C, int c, int y, int x, float sy, float sx) {
+// (SRC = uint8_t: the source is an sRGB image, linearised through the table as it is read)
+__device__ __forceinline__ float cs_load(const float* p, long o) { return p[o]; }
+__device__ __forceinline__ float cs_load(const uint8_t* p, long o) { return srgb2lin(p[o]); }
+template <typename SRC>
+__device__ __forceinline__ float cubic_sample(const SRC* src, int Hs, int Ws, int C, int c, int y, int x, float sy, float sx) {
     int x0, y0;
     float wx[4], wy[4];
     cubic_taps(x, sx, x0, wx);
@@ -52,10 +87,10 @@ __device__ __forceinline__ float cubic_sample(const float* src, int Hs, int Ws, 
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float* row = src + (long)clampi(y0 - 1 + j, 0, Hs - 1) * Ws * C + c;
+        const SRC* row = src + (long)clampi(y0 - 1 + j, 0, Hs - 1) * Ws * C + c;
         float r = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r = r + row[(long)clampi(x0 - 1 + i, 0, Ws - 1) * C] * wx[i];
+        for (int i = 0; i < 4; ++i) r = r + cs_load(row, (long)clampi(x0 - 1 + i, 0, Ws - 1) * C) * wx[i];
         acc = acc + r * wy[j];
     }
     return acc;
@@ -66,12 +101,12 @@ __global__ void k_lin(const uint8_t* in, float* out, long n) {
     if (i < n) out[i] = srgb2lin(in[i]);
 }
 
-// diff = srgb2linear(A) - (scaling ? cubic(lin_b -> A's size) : lin_b)
-__global__ void k_diff(const uint8_t* a, const float* lin_b, int hA, int wA, int hB, int wB, int C, int scaling, float* diff) {
+// diff = srgb2linear(A) - (scaling ? cubic(srgb2linear(B) -> A's size) : srgb2linear(B)); B is linearised through the table as it is read
+__global__ void k_diff(const uint8_t* a, const uint8_t* b8, int hA, int wA, int hB, int wB, int C, int scaling, float* diff) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)hA * wA * C) return;
     const int c = (int)(i % C), x = (int)((i / C) % wA), y = (int)(i / ((long)C * wA));
-    const float b = scaling ? cubic_sample(lin_b, hB, wB, C, c, y, x, (float)hB / (float)hA, (float)wB / (float)wA) : lin_b[i];
+    const float b = scaling ? cubic_sample(b8, hB, wB, C, c, y, x, (float)hB / (float)hA, (float)wB / (float)wA) : srgb2lin(b8[i]);
     diff[i] = srgb2lin(a[i]) - b;
 }
 
@@ -90,21 +125,62 @@ __global__ void k_gauss3(const float* in, int H, int W, int C, int dir, float* o
     out[i] = in[i] * 0.5f + (base[(long)lo * step] + base[(long)hi * step]) * 0.25f;
 }
 
-// out = linear2srgb((scaling ? cubic(blur -> B's size) : blur) + lin_b)
-__global__ void k_finish(const float* blur, const float* lin_b, int hA, int wA, int hB, int wB, int C, int scaling, uint8_t* out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)hB * wB * C) return;
-    const int c = (int)(i % C), x = (int)((i / C) % wB), y = (int)(i / ((long)C * wB));
-    const float u = scaling ? cubic_sample(blur, hA, wA, C, c, y, x, (float)hA / (float)hB, (float)wA / (float)wB) : blur[i];
-    out[i] = lin2srgb(u + lin_b[i]);
+// out = linear2srgb((scaling ? cubic(blur -> B's size) : blur) + srgb2linear(B))
+__global__ void k_finish(const float* blur, const uint8_t* b8, int hA, int wA, int hB, int wB, int C, int scaling, uint8_t* out) {
+    __shared__ float thr[256];
+    thr[threadIdx.x] = g_thr[threadIdx.x];
+    __syncthreads();
+    // one thread per pixel: the cubic taps and weights are the same for its C channels (same arithmetic per channel as cubic_sample)
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (long)hB * wB) return;
+    const int x = (int)(pix % wB), y = (int)(pix / wB);
+    if (!scaling) {
+        for (int c = 0; c < C; ++c) out[pix * C + c] = lin2srgb(blur[pix * C + c] + srgb2lin(b8[pix * C + c]), thr);
+        return;
+    }
+    int x0, y0;
+    float wx[4], wy[4];
+    cubic_taps(x, (float)wA / (float)wB, x0, wx);
+    cubic_taps(y, (float)hA / (float)hB, y0, wy);
+    long ro[4]; int co[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ro[j] = (long)clampi(y0 - 1 + j, 0, hA - 1) * wA * C; co[j] = clampi(x0 - 1 + j, 0, wA - 1) * C; }
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r = r + blur[ro[j] + co[i] + c] * wx[i];
+            acc = acc + r * wy[j];
+        }
+        out[pix * C + c] = lin2srgb(acc + srgb2lin(b8[pix * C + c]), thr);
+    }
 }
 
 // linear_resize (utils.py:267-276): out = linear2srgb(cubic(srgb2linear(img) -> (oh, ow)))
 __global__ void k_resize_finish(const float* lin, int h, int w, int C, int oh, int ow, uint8_t* out) {
+    __shared__ float thr[256];
+    thr[threadIdx.x] = g_thr[threadIdx.x];
+    __syncthreads();
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)oh * ow * C) return;
     const int c = (int)(i % C), x = (int)((i / C) % ow), y = (int)(i / ((long)C * ow));
-    out[i] = lin2srgb(cubic_sample(lin, h, w, C, c, y, x, (float)h / (float)oh, (float)w / (float)ow));
+    out[i] = lin2srgb(cubic_sample(lin, h, w, C, c, y, x, (float)h / (float)oh, (float)w / (float)ow), thr);
+}
+
+// the tables are built once per device (the first call waits for them: later calls may come on other streams)
+int ensure_tables(hipStream_t s) {
+    static bool built[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (!built[dev & 63]) {
+        hipLaunchKernelGGL(k_build_tables, dim3(1), dim3(256), 0, s);
+        INNFER_HIP(hipGetLastError());
+        INNFER_HIP(hipStreamSynchronize(s));
+        built[dev & 63] = true;
+    }
+    return INNFER_OK;
 }
 
 inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
@@ -114,13 +190,15 @@ inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" size_t innfer_color_fix_workspace_bytes(int hA, int wA, int hB, int wB, int C) {
     if (hA <= 0 || wA <= 0 || hB <= 0 || wB <= 0 || C <= 0) return 0;
-    return al((size_t)hB * wB * C * 4) + 2 * al((size_t)hA * wA * C * 4);
+    (void)hB; (void)wB;                                 // two fp32 planes of A's size (difference, blur); nothing of B's size is kept
+    return 2 * al((size_t)hA * wA * C * 4);
 }
 
 extern "C" int innfer_linear_resize(const uint8_t* d_img, int h, int w, int C, uint8_t* d_out, int oh, int ow, void* d_ws, size_t ws_bytes, void* stream) {
     if (!d_img || !d_out || !d_ws || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || C <= 0 || C > 4) return set_error(INNFER_ERR_INVALID, "linear_resize: bad arguments");
     if (ws_bytes < (size_t)h * w * C * 4) return set_error(INNFER_ERR_WORKSPACE, "linear_resize: workspace %zu < %zu bytes", ws_bytes, (size_t)h * w * C * 4);
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = ensure_tables(s)) return rc;
     const long n = (long)h * w * C, no = (long)oh * ow * C;
     hipLaunchKernelGGL(k_lin, dim3(nblk(n)), dim3(256), 0, s, d_img, (float*)d_ws, n);
     hipLaunchKernelGGL(k_resize_finish, dim3(nblk(no)), dim3(256), 0, s, (const float*)d_ws, h, w, C, oh, ow, d_out);
@@ -138,15 +216,15 @@ extern "C" int innfer_color_fix(const uint8_t* d_a, int hA, int wA, const uint8_
     if (ws_bytes < innfer_color_fix_workspace_bytes(hA, wA, hB, wB, C))
         return set_error(INNFER_ERR_WORKSPACE, "color_fix: workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = ensure_tables(s)) return rc;
     const long nA = (long)hA * wA * C, nB = (long)hB * wB * C;
-    float* lin_b = (float*)d_ws;
-    float* t0 = (float*)((char*)d_ws + al((size_t)nB * 4));
+    float* t0 = (float*)d_ws;                          // (the linear copy of B the first version kept is gone: B is linearised through the table where it is read)
     float* t1 = (float*)((char*)t0 + al((size_t)nA * 4));
-    hipLaunchKernelGGL(k_lin, dim3(nblk(nB)), dim3(256), 0, s, d_b, lin_b, nB);
-    hipLaunchKernelGGL(k_diff, dim3(nblk(nA)), dim3(256), 0, s, d_a, (const float*)lin_b, hA, wA, hB, wB, C, scaling, t0);
+    (void)nB;
+    hipLaunchKernelGGL(k_diff, dim3(nblk(nA)), dim3(256), 0, s, d_a, d_b, hA, wA, hB, wB, C, scaling, t0);
     hipLaunchKernelGGL(k_gauss3, dim3(nblk(nA)), dim3(256), 0, s, (const float*)t0, hA, wA, C, 0, t1);
     hipLaunchKernelGGL(k_gauss3, dim3(nblk(nA)), dim3(256), 0, s, (const float*)t1, hA, wA, C, 1, t0);
-    hipLaunchKernelGGL(k_finish, dim3(nblk(nB)), dim3(256), 0, s, (const float*)t0, (const float*)lin_b, hA, wA, hB, wB, C, scaling, d_out);
+    hipLaunchKernelGGL(k_finish, dim3(nblk((long)hB * wB)), dim3(256), 0, s, (const float*)t0, d_b, hA, wA, hB, wB, C, scaling, d_out);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
