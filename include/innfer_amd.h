@@ -215,7 +215,7 @@ int innfer_ppon_forward(innfer_ppon_t p, const void* d_in, int in_dtype, void* d
  * Replaces ResnetGenerator(norm=instance, padding=reflect, upsample=deconv).forward with ResnetBlock
  * (architectures/ResNet_arch.py:19-151; `-a resnet_9blocks / cg_6 ...`, utils/defaults.py:124-140): reflection-padded
  * 7x7 and 3x3 convs, two stride-2 convs, n_blocks residual blocks, two ConvTranspose2d(3,2,1,1), tanh; InstanceNorm2d
- * without affine parameters, statistics of the instance.  H, W multiples of 4, >= 16.
+ * without affine parameters, statistics of the instance.  H, W multiples of 4, >= 16; ngf 32 / 64 / 96 / 128 (the presets use 64).
  */
 typedef struct innfer_resnet* innfer_resnet_t;
 int innfer_resnet_create(innfer_resnet_t* out, int in_nc, int out_nc, int ngf, int n_blocks);

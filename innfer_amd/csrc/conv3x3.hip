@@ -1420,7 +1420,7 @@ extern "C" int innfer_debug_read_stamps(unsigned long long* h, int n_words) {
 }
 namespace innfer {
 
-int conv_nt_for(int K) { return K >= 64 ? 4 : (K >= 32 ? 2 : 1); }
+int conv_nt_for(int K) { return (K >= 64 && K % 64 == 0) ? 4 : (K >= 32 ? 2 : 1); }          // (96, 160 .. output channels: 32-channel groups)
 
 static int conv_groups(int K) {
     const int per = 16 * conv_nt_for(K);

@@ -272,8 +272,8 @@ extern "C" int innfer_resnet_set_eval(innfer_resnet* r, int eval_mode) {
 extern "C" int innfer_resnet_create_ex(innfer_resnet** out, int in_nc, int out_nc, int ngf, int n_blocks, int padding, int use_dropout, int upconv, int batch_norm) {
     if (!out) return set_error(INNFER_ERR_INVALID, "resnet_create: null out");
     if (padding < 0 || padding > 2) return set_error(INNFER_ERR_INVALID, "resnet_create: padding %d (0 reflect, 1 replicate, 2 zero)", padding);
-    if (ngf != 64 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || n_blocks < 0 || n_blocks > 64)
-        return set_error(INNFER_ERR_UNSUPPORTED, "resnet_create: ngf=%d n_blocks=%d (built: ngf 64)", ngf, n_blocks);
+    if (ngf < 32 || ngf > 128 || ngf % 32 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 8 || n_blocks < 0 || n_blocks > 64)
+        return set_error(INNFER_ERR_UNSUPPORTED, "resnet_create: ngf=%d n_blocks=%d (built: ngf 32, 64, 96, 128)", ngf, n_blocks);
     innfer_resnet* r = new innfer_resnet();
     r->in_nc = in_nc; r->out_nc = out_nc; r->ngf = ngf; r->n_blocks = n_blocks;
     r->batch_norm = batch_norm != 0;
@@ -490,19 +490,21 @@ RCarve rcarve(const innfer_resnet* r, int N, int H, int W) {
     const size_t px = (size_t)N * H * W;
     size_t off = 0;
     auto slab = [&](size_t pixels, int ch) { size_t o = off; off += al(pixels * ch * 2); return o; };
-    c.x0 = slab(px, 32); c.s1 = slab(px, 64); c.s2 = slab(px / 4, 128);
-    c.a = slab(px / 16, 256); c.b = slab(px / 16, 256); c.c = slab(px / 16, 256);
-    c.u1 = slab(px / 4, 128); c.u2 = slab((size_t)N * (H + 8) * (W + 8), 64);      // (room for the reflection-padded form the last conv may read)
-    c.raw = off; off += al(px * 64 * 4);               // the largest fp32 GEMM result: 64 channels at full resolution
-    c.alpha = off; off += al((size_t)N * 256 * 4);
-    c.shift = off; off += al((size_t)N * 256 * 4);
+    const int g1 = r->ngf, g2 = 2 * g1, g4 = 4 * g1, g1p = (g1 + 63) / 64 * 64;        // widths at full, half and quarter resolution; fp32 GEMM rows are 64-padded
+    c.x0 = slab(px, 32); c.s1 = slab(px, g1p); c.s2 = slab(px / 4, g2);
+    c.a = slab(px / 16, g4); c.b = slab(px / 16, g4); c.c = slab(px / 16, g4);
+    c.u1 = slab(px / 4, g2); c.u2 = slab((size_t)N * (H + 8) * (W + 8), g1p);      // (room for the reflection-padded form the last conv may read)
+    c.raw = off; off += al(px * g1p * 4);              // the largest fp32 GEMM result: the first / last level's channels at full resolution
+    c.alpha = off; off += al((size_t)N * g4 * 4);
+    c.shift = off; off += al((size_t)N * g4 * 4);
     // (mean, M2) per statistics segment: the widest case is 64 channels at full resolution or 256 at 1/16
     // ... or the conv epilogues' partial statistics (3 floats per 16 x 32 tile, consumer wave and channel; the phase-lattice convs count their input grid x 4)
-    size_t pf = std::max(norm::part_floats(64, (long)H * W), norm::part_floats(256, (long)H * W / 16));
-    pf = std::max(pf, norm::parts_floats(64, conv_stats_nper(H, W, 1)));
-    pf = std::max(pf, norm::parts_floats(64, conv_stats_nper(H / 2, W / 2, 4)));
-    pf = std::max(pf, norm::parts_floats(128, conv_stats_nper(H / 4, W / 4, 4)));
-    pf = std::max(pf, norm::parts_floats(256, conv_stats_nper(H / 4, W / 4, 1)));
+    size_t pf = std::max(norm::part_floats(g1p, (long)H * W), norm::part_floats(g4, (long)H * W / 16));
+    pf = std::max(pf, norm::part_floats(g2, (long)H * W / 4));
+    pf = std::max(pf, norm::parts_floats(g1p, conv_stats_nper(H, W, 1)));
+    pf = std::max(pf, norm::parts_floats(g1p, conv_stats_nper(H / 2, W / 2, 4)));
+    pf = std::max(pf, norm::parts_floats(g2, conv_stats_nper(H / 4, W / 4, 4)));
+    pf = std::max(pf, norm::parts_floats(g4, conv_stats_nper(H / 4, W / 4, 1)));
     c.part = off; off += al((size_t)N * pf * 4);
     c.total = off;
     (void)r;
@@ -641,7 +643,7 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     if (patch) {
         int dy7[7], dx7[7];
         for (int t = 0; t < 7; ++t) { dy7[t] = t - 3; dx7[t] = 0; }
-        CK(gg::launch(r->layers[li].d_w[0], 32, 64, X0, (long)N * H * W * 32, N, H, W, raw, H, W, 1, 7, dy7, dx7, H, W, 1, 0, 0, 0, s, nullptr, 0, 0, 1));
+        CK(gg::launch(r->layers[li].d_w[0], 32, (r->ngf + 63) / 64 * 64, X0, (long)N * H * W * 32, N, H, W, raw, H, W, 1, 7, dy7, dx7, H, W, 1, 0, 0, 0, s, nullptr, 0, 0, 1));
     } else
     CK(conv(r->layers[li], X0, H, W, H, W, 1, 1));
     CK(norm_post(r->layers[li], H, W, 1, nullptr, S1)); ++li;          // c7s1-64
@@ -761,7 +763,7 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
             return INNFER_OK;
         }
         const int rs = (l.cout + 3) / 4 * 4;
-        CK(gg::launch(l.d_w[0], 64, 64, U2, (long)N * H * W * 32, N, H, W, raw, H, W, 1, 49, dy49, dx49, H, W, 1, 0, 0, 0, s, nullptr, 0, rs, 1));
+        CK(gg::launch(l.d_w[0], (l.cin + 31) / 32 * 32, 64, U2, (long)N * H * W * 32, N, H, W, raw, H, W, 1, 49, dy49, dx49, H, W, 1, 0, 0, 0, s, nullptr, 0, rs, 1));
         hipLaunchKernelGGL(rn_final, dim3((unsigned)(((long)N * H * W + 255) / 256)), dim3(256), 0, s, (const float*)raw, rs, l.cout, (long)H * W, N,
                            (const float*)l.d_b, d_out, out_dtype == INNFER_F32);
         INNFER_HIP(hipGetLastError());

@@ -1373,6 +1373,16 @@ def test_small_generators_shape_fuzz_and_poisoned_workspace(dev):
         with torch.no_grad():
             ref = torch.cat([oracle.resnet_forward(sd_r, x[i:i + 1], n_blocks=1) for i in range(n)], 0)
         check(res, x, ref, 1e-2, 1.5e-3, "resnet")
+    for ngf in (32, 96, 128):                            # other widths than the presets' 64: some layers leave the 64-channel tile forms
+        rw = ResnetGenerator(3, 3, ngf, norm_type="instance", n_blocks=1)
+        sd_n = _sd({k: tuple(v.shape) for k, v in rw.state_dict().items()}, 404 + ngf)
+        rw.load_state_dict(sd_n, strict=True)
+        rw = rw.to(dev).eval()
+        for (h, w) in ((64, 64), (72, 104)):
+            x = torch.from_numpy(synth.uniform((2, 3, h, w), 500 + ngf + h, -1.0, 1.0))
+            with torch.no_grad():
+                ref = torch.cat([oracle.resnet_forward(sd_n, x[i:i + 1], n_blocks=1) for i in range(2)], 0)
+            check(rw, x, ref, 1e-2, 1.5e-3, f"resnet ngf {ngf}")
     for mode in ("wbcunet", "wbcunet_tf"):
         wb = get_network(get_network_G_config(mode, 1))
         sd_w = _sd({k: tuple(v.shape) for k, v in wb.state_dict().items()}, 403)
