@@ -1373,6 +1373,23 @@ def test_small_generators_shape_fuzz_and_poisoned_workspace(dev):
         with torch.no_grad():
             ref = torch.cat([oracle.resnet_forward(sd_r, x[i:i + 1], n_blocks=1) for i in range(n)], 0)
         check(res, x, ref, 1e-2, 1.5e-3, "resnet")
+    pp = get_network(get_network_G_config({"type": "ppon", "nb": 2}, 4))          # two residual-in-residual blocks per module: the dilated-conv launch, the
+    sd_p = _sd({k: tuple(v.shape) for k, v in pp.state_dict().items()}, 405)      # running-sum operand of c2 and the three heads on ragged sizes and batches
+    pp.load_state_dict(sd_p, strict=True)
+    pp = pp.to(dev).eval()
+    for _ in range(4):
+        n, h, w = int(rng.randint(1, 4)), int(rng.randint(9, 70)), int(rng.randint(9, 70))
+        x = torch.from_numpy(synth.uniform((n, 3, h, w), int(rng.randint(1 << 20))))
+        with torch.no_grad():
+            refs = oracle.ppon_forward(sd_p, x, nb=2, scale=4)
+        outs = pp(x.to(dev).half())
+        for name, y, ref in zip("csp", outs, refs):
+            err = (y.float().cpu() - ref).abs()
+            lim = max(1.0, ref.abs().max().item())
+            assert err.max().item() < 1e-2 * lim and err.mean().item() < 2e-3 * lim, ("ppon", name, n, h, w, err.max().item(), err.mean().item())
+        keep = [o.clone() for o in outs]
+        pp._ws.fill_(0xFF)
+        assert all(torch.equal(a, b) for a, b in zip(pp(x.to(dev).half()), keep)), ("ppon", n, h, w, "reads unwritten workspace")
     for ngf in (32, 96, 128):                            # other widths than the presets' 64: some layers leave the 64-channel tile forms
         rw = ResnetGenerator(3, 3, ngf, norm_type="instance", n_blocks=1)
         sd_n = _sd({k: tuple(v.shape) for k, v in rw.state_dict().items()}, 404 + ngf)
