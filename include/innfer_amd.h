@@ -45,8 +45,8 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 104
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3 ('upconv').  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 105
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -74,6 +74,11 @@ int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int
 /* The same with the constructor arguments that keep the graph on the built kernels (SRResNet_arch.py:16-46,69-91): act = `act_type` (1 LeakyReLU(0.2),
  * 2 ReLU), res_scale (x + res * res_scale), upconv_up != 0 = upsample_mode 'upconv' (Upsample, conv, act) instead of 'pixelshuffle'.  (104) */
 int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale, int act, float res_scale, int upconv_up);
+/* mode 'NAC' conv blocks (block.py:246-254: norm -> act -> conv; SRResNet's own default, SRResNet_arch.py:16-27): conv `idx` reads
+ * act(alpha[c] * x + shift[c]) instead of x -- the eval-mode BatchNorm2d of its input channels as a per-channel map (NULL alpha / shift: 1 / 0) and
+ * act (0 none, 1 LeakyReLU(0.2), 2 ReLU), one elementwise launch in front of the conv.  Built for the first conv of an SRResNet block and LR_conv
+ * (the norm in front of a block's second conv follows the first conv and is folded into its weights by the host).  All of NULL, NULL, 0 removes the map.  (105) */
+int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const float* h_alpha, const float* h_shift, int act);
 
 void innfer_net_destroy(innfer_net_t net);
 

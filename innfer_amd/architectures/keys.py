@@ -81,16 +81,42 @@ def mrrdb_key_of(old_key, nb):
     return "RRDB_trunk." + old_key[len("model.1.sub."):-2]
 
 
-def srresnet_shapes(in_nc=3, out_nc=3, nf=64, nb=16, scale=4, upsample_mode='pixelshuffle'):
-    """SRGAN/SRResNet keys (reference SRResNet_arch.py:15-46, defaults.py:53-67); upsample_mode 'upconv': Upsample, conv, act per stage."""
+def srresnet_layout(nb, norm=False, mode='CNA'):
+    """Positions of a ResNetBlock's / LR_conv's layers inside the flattened Sequentials (SRResNet_arch.py:23-27,68-86; block.py:242-254,
+    B.sequential flattens nested Sequentials): {engine key -> (conv key, BatchNorm in front of the conv or None, BatchNorm behind it or None)}.
+    Engine keys are the default graph's (norm none, CNA): `model.1.sub.<b>.res.0`, `.res.2`, `model.1.sub.<nb>`."""
+    lay = {}
+    for b in range(nb):
+        p = f"model.1.sub.{b}.res."
+        if mode == 'NAC':            # [norm,] act, conv, [norm,] act, conv
+            if norm: lay[p + "0"], lay[p + "2"] = (p + "2", p + "0", p + "3"), (p + "5", None, None)     # the 2nd block's norm follows conv0: folded there
+            else: lay[p + "0"], lay[p + "2"] = (p + "1", None, None), (p + "3", None, None)
+        elif mode == 'CNAC':         # conv, [norm,] act, conv
+            if norm: lay[p + "0"], lay[p + "2"] = (p + "0", None, p + "1"), (p + "3", None, None)
+            else: lay[p + "0"], lay[p + "2"] = (p + "0", None, None), (p + "2", None, None)
+        else:                        # conv, [norm,] act, conv[, norm]
+            if norm: lay[p + "0"], lay[p + "2"] = (p + "0", None, p + "1"), (p + "3", None, p + "4")
+            else: lay[p + "0"], lay[p + "2"] = (p + "0", None, None), (p + "2", None, None)
+    lr = f"model.1.sub.{nb}"
+    if not norm: lay[lr] = (lr, None, None)
+    elif mode == 'NAC': lay[lr] = (f"model.1.sub.{nb + 1}", lr, None)
+    else: lay[lr] = (lr, None, f"model.1.sub.{nb + 1}")
+    return lay
+
+
+def srresnet_shapes(in_nc=3, out_nc=3, nf=64, nb=16, scale=4, upsample_mode='pixelshuffle', norm=False, mode='CNA'):
+    """SRGAN/SRResNet keys (reference SRResNet_arch.py:15-46, defaults.py:53-67); upsample_mode 'upconv': Upsample, conv, act per stage;
+    norm / mode: BatchNorm2d layers and the layer order of the conv blocks (srresnet_layout)."""
     import math
     s = {"model.0.weight": (nf, in_nc, 3, 3), "model.0.bias": (nf,)}
-    for b in range(nb):
-        for j in (0, 2):
-            s[f"model.1.sub.{b}.res.{j}.weight"] = (nf, nf, 3, 3)
-            s[f"model.1.sub.{b}.res.{j}.bias"] = (nf,)
-    s[f"model.1.sub.{nb}.weight"] = (nf, nf, 3, 3)
-    s[f"model.1.sub.{nb}.bias"] = (nf,)
+    lay = srresnet_layout(nb, norm, mode)
+    ordered = [f"model.1.sub.{b}.res.{j}" for b in range(nb) for j in (0, 2)] + [f"model.1.sub.{nb}"]
+    for ek in ordered:
+        conv, pre, post = lay[ek]
+        if pre: _bn(s, pre, nf)
+        s[conv + ".weight"] = (nf, nf, 3, 3)
+        s[conv + ".bias"] = (nf,)
+        if post: _bn(s, post, nf)
     n_up = 1 if scale == 3 else int(math.log(scale, 2))
     idx = 2
     for _ in range(n_up):

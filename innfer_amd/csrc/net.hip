@@ -39,6 +39,10 @@ struct ConvSlot {
     void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
     float* d_b = nullptr;        // bias padded to the panel width
     bool loaded = false;
+    // mode 'NAC' conv blocks (block.py:246-254: norm -> act -> conv): the conv reads act(alpha[c] * x + shift[c]); an elementwise pass in front of it
+    bool map_ok = false;         // slot may carry an input map (first conv of an SRResNet block, LR_conv)
+    float* d_map = nullptr;      // alpha[C] then shift[C]
+    int map_act = 0;
 };
 
 struct innfer_net {
@@ -125,8 +129,8 @@ extern "C" int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, 
 
 extern "C" int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale, int act, float res_scale, int upconv_up) {
     if (!out) return set_error(INNFER_ERR_INVALID, "srresnet_create: null out");
-    if (scale != 1 && scale != 2 && scale != 4 && scale != 8)
-        return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: scale %d (only powers of two)", scale);
+    if (scale != 1 && scale != 2 && scale != 4 && scale != 8 && !(scale == 3 && upconv_up))
+        return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: scale %d (built: powers of two; 3 with upsample_mode 'upconv')", scale);
     if (nf != 64 && nf != 32) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: nf=%d", nf);
     if (scale > 1 && nf != 64 && !upconv_up) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: pixelshuffle path needs nf=64");
     if (act != 1 && act != 2) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: act %d (1 LeakyReLU(0.2), 2 ReLU)", act);
@@ -139,9 +143,11 @@ extern "C" int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_n
     add_conv(net, "model.0", nf, in_nc, true);
     for (int b = 0; b < nb; ++b) {
         add_conv(net, "model.1.sub." + std::to_string(b) + ".res.0", nf, nf);
+        net->convs.back().map_ok = true;
         add_conv(net, "model.1.sub." + std::to_string(b) + ".res.2", nf, nf);
     }
     add_conv(net, "model.1.sub." + std::to_string(nb), nf, nf);
+    net->convs.back().map_ok = true;
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) {        // pixelshuffle_block: conv, PixelShuffle, act -- upconv_block: Upsample, conv, act (block.py:333-361)
         if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * 4, nf);
@@ -165,6 +171,7 @@ extern "C" void innfer_net_destroy(innfer_net_t net) {
     for (auto& c : net->convs) {
         if (c.d_w) (void)hipFree(c.d_w);
         if (c.d_b) (void)hipFree(c.d_b);
+        if (c.d_map) (void)hipFree(c.d_map);
     }
     delete net;
 }
@@ -211,6 +218,24 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
     INNFER_HIP(hipMemcpy(c.d_w, host.data(), host.size(), hipMemcpyHostToDevice));
     INNFER_HIP(hipMemcpy(c.d_b, bias.data(), bias_n * sizeof(float), hipMemcpyHostToDevice));
     c.loaded = true;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const float* alpha, const float* shift, int act) {
+    if (!net || idx < 0 || idx >= (int)net->convs.size() || act < 0 || act > 2) return set_error(INNFER_ERR_INVALID, "set_conv_input_map: bad arguments");
+    ConvSlot& c = net->convs[idx];
+    if (!alpha && !shift && act == 0) {          // no map
+        if (c.d_map) { (void)hipFree(c.d_map); c.d_map = nullptr; }
+        c.map_act = 0;
+        return INNFER_OK;
+    }
+    if (!c.map_ok)
+        return set_error(INNFER_ERR_UNSUPPORTED, "set_conv_input_map: '%s' (built in front of the first conv of an SRResNet block and of LR_conv)", c.key.c_str());
+    std::vector<float> h(2 * (size_t)c.C);
+    for (int i = 0; i < c.C; ++i) { h[i] = alpha ? alpha[i] : 1.f; h[c.C + i] = shift ? shift[i] : 0.f; }
+    if (!c.d_map) INNFER_HIP(hipMalloc((void**)&c.d_map, h.size() * sizeof(float)));
+    INNFER_HIP(hipMemcpy(c.d_map, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    c.map_act = act;
     return INNFER_OK;
 }
 
@@ -397,6 +422,34 @@ __global__ void slab_upsample_nearest(const f16* src, long src_g, f16* dst, long
     *(f16x8*)(dst + g * dst_g + m * 32 + q * 8) = *(const f16x8*)(src + g * src_g + sp * 32 + q * 8);
 }
 
+// Input map of a 'NAC' conv block: dst = act(alpha[c] * src + shift[c]) on a slab (8 channels per thread)
+__global__ void slab_input_map(const f16* src, f16* dst, long g_elems, int groups, const float* map, int C, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = g_elems / 8;
+    if (i >= per * groups) return;
+    const int g = (int)(i / per);
+    const long r = i % per;
+    const int c = g * 32 + (int)(r & 3) * 8;
+    const f16x8 x = *(const f16x8*)(src + g * g_elems + r * 8);
+    f16x8 y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = c + e < C ? (float)x[e] * map[c + e] + map[C + c + e] : 0.f;
+        if (act == 1) v = fmaxf(v, 0.2f * v);
+        else if (act == 2) v = fmaxf(v, 0.f);
+        y[e] = (f16)v;
+    }
+    *(f16x8*)(dst + g * g_elems + r * 8) = y;
+}
+
+int do_input_map(const ConvSlot& cs, const f16* src, f16* dst, long G, hipStream_t s) {
+    const int groups = (cs.C + 31) / 32;
+    const long n = G / 8 * groups;
+    hipLaunchKernelGGL(slab_input_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, G, groups, (const float*)cs.d_map, cs.C, cs.map_act);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
 int do_first(const FirstConvLaunch& F, hipStream_t s) {
     int rc = timed_begin(s);
     if (rc) return rc;
@@ -534,7 +587,16 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         for (int b = 0; b < net->nb; ++b) {
             const int a = cur, m = (cur + 1) % 3, o = (cur + 2) % 3;
             const ConvSlot& c0 = net->convs[ci++];
-            chain.push_back(mk(c0, slab[a], G, slab[m], G, N, H, W, net->trunk_act));
+            const f16* in0 = slab[a];
+            if (c0.d_map) {          // mode 'NAC': norm -> act in front of the conv, into the (still unused) trunk slab; launches in order, whole frame
+                int rc = run_chain(chain, 0, s);
+                if (rc) return rc;
+                chain.clear();
+                rc = do_input_map(c0, slab[a], trunk, G, s);
+                if (rc) return rc;
+                in0 = trunk;
+            }
+            chain.push_back(mk(c0, in0, G, slab[m], G, N, H, W, net->trunk_act));
             const ConvSlot& c1 = net->convs[ci++];
             ConvLaunch L = mk(c1, slab[m], G, slab[o], G, N, H, W, 0);
             L.res1 = slab[a]; L.res1_gstride = G; L.s1 = net->res_scale;          // x + res * res_scale
@@ -544,11 +606,22 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     }
     {   // trunk conv + ShortcutBlock: fea + conv(t)
         const ConvSlot& cs = net->convs[ci++];
-        ConvLaunch L = mk(cs, slab[cur], G, trunk, G, N, H, W, 0);
+        const f16* in = slab[cur];
+        if (cs.d_map) {
+            int rc = run_chain(chain, 0, s);
+            if (rc) return rc;
+            chain.clear();
+            rc = do_input_map(cs, slab[cur], slab[(cur + 1) % 3], G, s);
+            if (rc) return rc;
+            in = slab[(cur + 1) % 3];
+        }
+        ConvLaunch L = mk(cs, in, G, trunk, G, N, H, W, 0);
         L.res1 = fea; L.res1_gstride = G; L.s1 = 1.f;
         chain.push_back(L);
     }
-    int rc = run_chain(chain, net->band_rows, s);
+    bool any_map = false;
+    for (auto& c : net->convs) any_map |= c.d_map != nullptr;
+    int rc = run_chain(chain, any_map ? 0 : net->band_rows, s);
     if (rc) return rc;
 
     const f16* t = trunk;
@@ -557,7 +630,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         const ConvSlot& cs = net->convs[ci++];
         f16* dst = (f16*)(ws + cv.up[u]);
         const long gi = (long)N * h * w * 32, go = gi * 4;
-        if (net->kind == 0 && net->scale == 3) {      // Upsample(nearest 3x), materialised in the (still unused) HR slab -> conv -> LeakyReLU
+        if (net->scale == 3) {      // Upsample(nearest 3x), materialised in the (still unused) HR slab -> conv -> LeakyReLU
             f16* U = (f16*)(ws + cv.hr);
             const long g3 = gi * 9, nthr = (long)N * 9 * h * w * 4 * (net->nf / 32);
             hipLaunchKernelGGL(slab_upsample_nearest, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, t, gi, U, g3, net->nf / 32, N, h, w, 3);

@@ -70,6 +70,7 @@ SIGNATURES = {
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "innfer_rrdbnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 10),
     "innfer_srresnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 6 + [C.c_float, C.c_int]),
+    "innfer_net_set_conv_input_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "innfer_net_set_outm": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
@@ -178,7 +179,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 104          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 105          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

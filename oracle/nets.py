@@ -135,16 +135,35 @@ def _outm(y, outm):
     return y
 
 
-def srresnet_forward(sd, x, nb=16, scale=4, act_type="relu", res_scale=1, upsample_mode="pixelshuffle", outm=None):
-    """SRResNet.forward with norm=None, mode=CNA (SRResNet_arch.py:15-91; defaults.py:53-67: relu, pixelshuffle, res_scale 1)."""
+def srresnet_forward(sd, x, nb=16, scale=4, act_type="relu", res_scale=1, upsample_mode="pixelshuffle", outm=None, norm_type=None, mode="CNA"):
+    """SRResNet.forward in eval mode (SRResNet_arch.py:15-91; defaults.py:53-67 builds it with norm none, CNA, relu, pixelshuffle, res_scale 1;
+    the class defaults are norm_type='batch', mode='NAC').  The conv blocks follow block.py:213-254: 'CNA' / 'CNAC' = conv[, norm][, act],
+    'NAC' = [norm,][act,] conv; a ResNetBlock (SRResNet_arch.py:68-91) drops the second block's act under 'CNA' and its norm + act under 'CNAC';
+    LR_conv has no act.  B.sequential flattens the blocks, so the layer indices count norm and act layers."""
     a = {"relu": F.relu, "leakyrelu": _lrelu}[act_type]
+
+    def bn(t, key):
+        return F.batch_norm(t, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"], training=False, eps=1e-5)
+
+    def block(t, p, layers):          # layers: sequence of 'n' / 'a' / 'c' in module order; indices are positions in the flattened Sequential
+        for i, kind in enumerate(layers):
+            t = bn(t, f"{p}{i}") if kind == "n" else a(t) if kind == "a" else _conv3(sd, f"{p}{i}", t)
+        return t
+
+    n = "n" if norm_type else ""
+    if mode == "NAC":
+        res_layers, lr_layers = n + "a" + "c" + n + "a" + "c", n + "c"
+    elif mode == "CNAC":
+        res_layers, lr_layers = "c" + n + "a" + "c", "c" + n
+    else:
+        res_layers, lr_layers = "c" + n + "a" + "c" + n, "c" + n
     fea = _conv3(sd, "model.0", x)
     t = fea
     for b in range(nb):
-        r = a(_conv3(sd, f"model.1.sub.{b}.res.0", t))
-        r = _conv3(sd, f"model.1.sub.{b}.res.2", r)
-        t = t + r * res_scale                      # :88-91
-    t = fea + _conv3(sd, f"model.1.sub.{nb}", t)
+        t = t + block(t, f"model.1.sub.{b}.res.", res_layers) * res_scale          # :88-91
+    for i, kind in enumerate(lr_layers):                                            # LR_conv's layers continue the trunk Sequential's numbering
+        t = bn(t, f"model.1.sub.{nb + i}") if kind == "n" else _conv3(sd, f"model.1.sub.{nb + i}", t)
+    t = fea + t
     idx = 2
     for _ in range(_n_upscale(scale)):
         f = 3 if scale == 3 else 2

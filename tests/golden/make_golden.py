@@ -383,6 +383,32 @@ def g25():
     save("g25_filter2d", **out)
 
 
+def g26():
+    """SRResNet(norm_type, mode) (SRResNet_arch.py:16-27,68-91; block.py:242-254) in eval mode -- the class's own defaults are norm_type='batch',
+    mode='NAC' -- and upscale=3 with 'upconv'.  Keys (in state-dict order) are stored too."""
+    from architectures.SRResNet_arch import SRResNet as RefSRResNet
+    out = {}
+    for j, (tag, kw) in enumerate(G26_SR.items()):
+        net = RefSRResNet(3, 3, 64, 2, upsample_mode="upconv", **kw).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        norm, mode, sc = bool(kw.get("norm_type", "batch")), kw.get("mode", "NAC"), kw.get("upscale", 4)
+        mine = synth.srresnet_shapes(nb=2, scale=sc, upsample_mode="upconv", norm=norm, mode=mode)
+        assert list(shapes.items()) == list(mine.items()), tag
+        sd = synth.fill_state_dict(mine, 300 + j)
+        if norm:
+            sd = synth.fill_running_stats(sd, 300 + j)
+        net.load_state_dict(t_sd(sd), strict=True)
+        x = torch.from_numpy(synth.uniform((1, 3, 14, 18), 310 + j))
+        with torch.no_grad():
+            out[tag] = net(x).numpy()
+        out[tag + "_keys"] = np.array(list(shapes))
+    save("g26_srresnet_modes", **out)
+
+
+G26_SR = {"nac_bn": dict(), "cna_bn": dict(mode="CNA"), "nac": dict(norm_type=None), "cnac_bn": dict(mode="CNAC"), "cnac": dict(norm_type=None, mode="CNAC"),
+          "x3_lrelu": dict(norm_type=None, mode="CNA", upscale=3, act_type="leakyrelu", res_scale=0.5), "nac_bn_x2_lrelu": dict(upscale=2, act_type="leakyrelu", res_scale=0.25)}
+
+
 def g21():
     """guided_filter beyond r = 1 / 'regular' (utils.py:548-626): a 5x5 and a 7x7 window, and the 'fast' mode on a 2x guidance image."""
     x = torch.from_numpy(synth.uniform((2, 3, 23, 31), 211))
@@ -653,6 +679,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26"]
     for g in which:
         globals()[g]()

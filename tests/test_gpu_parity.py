@@ -464,6 +464,36 @@ def test_srresnet_variants_and_outm_golden(dev, golden):
     assert not torch.equal(plain, net(x, outm="clamp")) and torch.equal(net(x), plain)          # outm does not stick to the module
 
 
+def test_srresnet_norm_and_mode_golden(dev, golden):
+    """SRResNet(norm_type='batch', mode='NAC') -- the class's own defaults (SRResNet_arch.py:16-17) -- and the other norm / mode combinations in eval
+    mode, upscale=3 with 'upconv': BatchNorm behind a conv is folded at upload, norm -> act in front of a conv whose input is the residual stream runs
+    as the engine's input map (innfer_net_set_conv_input_map).  Against the reference (golden G26); parameter names in state-dict order."""
+    from innfer_amd.architectures.SRResNet_arch import SRResNet
+    from test_oracle_golden import G26_SR, g26_case
+    g = golden("g26_srresnet_modes")
+    for j, tag in enumerate(G26_SR):
+        c, shapes, sd, x = g26_case(j, tag)
+        net = SRResNet(3, 3, 64, 2, upscale=c["scale"], norm_type="batch" if c["norm"] else None, act_type=c["act_type"], mode=c["mode"],
+                       res_scale=c["res_scale"], upsample_mode="upconv")
+        assert list(net.state_dict()) == list(g[tag + "_keys"]), tag
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        net = net.to(dev).eval()
+        xt = torch.from_numpy(x).to(dev)
+        y = net(xt.half()).float().cpu().numpy()
+        assert y.shape == g[tag].shape, tag
+        assert np.abs(y - g[tag]).max() < 1.5e-3, (tag, float(np.abs(y - g[tag]).max()))
+        y32 = net(xt).cpu().numpy()                      # fp32 at the boundary, fp16 slabs inside
+        assert np.abs(y32 - g[tag]).max() < 1.5e-3, tag
+        if c["norm"]:
+            with pytest.raises(NotImplementedError):
+                net.train()(xt)
+            net.eval()
+    with pytest.raises(NotImplementedError):
+        SRResNet(3, 3, 64, 2, norm_type="instance")
+    with pytest.raises(NotImplementedError):
+        SRResNet(3, 3, 64, 2, upscale=3, upsample_mode="pixelshuffle", norm_type=None, mode="CNA")
+
+
 def test_esrgan_plus_golden(dev, golden):
     """ESRGAN+ residual paths (x2 += conv1x1(x), x4 += x2) against the reference (golden G5)."""
     from innfer_amd import synth

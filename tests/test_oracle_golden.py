@@ -154,6 +154,35 @@ def test_g18_srresnet_variants_and_outm(golden):
             assert np.abs(oracle.rrdbnet_forward(sd, x, nb=1, scale=2, outm=om).numpy() - g["rrdb_" + om]).max() < 2e-6
 
 
+G26_SR = {"nac_bn": dict(), "cna_bn": dict(mode="CNA"), "nac": dict(norm_type=None), "cnac_bn": dict(mode="CNAC"), "cnac": dict(norm_type=None, mode="CNAC"),
+          "x3_lrelu": dict(norm_type=None, mode="CNA", upscale=3, act_type="leakyrelu", res_scale=0.5), "nac_bn_x2_lrelu": dict(upscale=2, act_type="leakyrelu", res_scale=0.25)}
+
+
+def g26_case(j, tag):
+    """(constructor kwargs, state dict as numpy, input) of golden G26's case `tag` -- as tests/golden/make_golden.py g26 builds them."""
+    kw = G26_SR[tag]
+    norm, mode, sc = bool(kw.get("norm_type", "batch")), kw.get("mode", "NAC"), kw.get("upscale", 4)
+    shapes = synth.srresnet_shapes(nb=2, scale=sc, upsample_mode="upconv", norm=norm, mode=mode)
+    sd = synth.fill_state_dict(shapes, 300 + j)
+    if norm:
+        sd = synth.fill_running_stats(sd, 300 + j)
+    return dict(norm=norm, mode=mode, scale=sc, act_type=kw.get("act_type", "relu"), res_scale=kw.get("res_scale", 1)), shapes, sd, synth.uniform((1, 3, 14, 18), 310 + j)
+
+
+def test_g26_srresnet_norm_and_mode(golden):
+    """SRResNet(norm_type='batch' / None, mode='NAC' / 'CNA' / 'CNAC') in eval mode and upscale=3 (SRResNet_arch.py:16-27,68-91; block.py:242-254)
+    against the reference; the parameter names in state-dict order too."""
+    g = golden("g26_srresnet_modes")
+    for j, tag in enumerate(G26_SR):
+        c, shapes, sd, x = g26_case(j, tag)
+        assert list(shapes) == list(g[tag + "_keys"]), tag
+        tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        with torch.no_grad():
+            y = oracle.srresnet_forward(tsd, torch.from_numpy(x), nb=2, scale=c["scale"], act_type=c["act_type"], res_scale=c["res_scale"],
+                                        upsample_mode="upconv", norm_type="batch" if c["norm"] else None, mode=c["mode"]).numpy()
+        assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-6, tag
+
+
 G18_PAN = {"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
            "double_noattn_x2": dict(double_scpa=True, self_attention=False, scale=2),
            "bilinear": dict(ups_inter_mode="bilinear"), "bilinear_noattn_x2": dict(ups_inter_mode="bilinear", self_attention=False, scale=2),
