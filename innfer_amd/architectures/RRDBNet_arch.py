@@ -22,8 +22,8 @@ class RRDBNet(EngineModule):
             raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
         unsupported = []
         if not isinstance(nr, int) or nr < 1: unsupported.append(f'nr={nr}')
-        if norm_type and (norm_type.lower() != 'batch' or mode != 'CNA'):
-            unsupported.append(f'norm_type={norm_type} with mode={mode}')          # built: BatchNorm2d behind the convs (CNA), folded at load
+        if norm_type and norm_type.lower() != 'batch':
+            unsupported.append(f'norm_type={norm_type}')          # built: BatchNorm2d behind the convs (folded at load); in front of LR_conv under 'NAC' (input map)
         if act_type not in _TRUNK_ACT: unsupported.append(f'act_type={act_type}')
         # mode: the dense blocks are built with mode='CNA' whatever is passed (RRDBNet_arch.py:27-29); only LR_conv takes it, and without
         # a norm layer or an activation a 'NAC' / 'CNAC' conv_block is the bare conv (block.py:237-254)
@@ -34,8 +34,9 @@ class RRDBNet(EngineModule):
         if unsupported:
             raise NotImplementedError('RRDBNet option(s) not built on the HIP path yet: ' + ', '.join(unsupported))
         # gaussian_noise: GaussianNoise is the identity in eval mode (block.py:382-388)
-        super().__init__(rrdbnet_shapes(in_nc, out_nc, nf, nb, 32, upscale, plus, nr, upsample_mode, bool(norm_type)))
+        super().__init__(rrdbnet_shapes(in_nc, out_nc, nf, nb, 32, upscale, plus, nr, upsample_mode, bool(norm_type), mode))
         self.norm = bool(norm_type)
+        self.lr_norm_first = bool(norm_type) and mode == 'NAC'          # LR_conv = BatchNorm2d, conv: the norm cannot be folded (the zero padding is not mapped)
         self.in_nc, self.out_nc, self.nf, self.nb, self.gc, self.upscale = in_nc, out_nc, nf, nb, 32, upscale
         self.plus, self.nr = bool(plus), nr
         self.trunk_act = _TRUNK_ACT[act_type]
@@ -50,7 +51,31 @@ class RRDBNet(EngineModule):
             return None
         if k.endswith('.0') and '.conv' in k:
             return k[:-2] + '.1'
-        return f'model.1.sub.{self.nb + 1}' if k == f'model.1.sub.{self.nb}' else None
+        return f'model.1.sub.{self.nb + 1}' if k == f'model.1.sub.{self.nb}' and not self.lr_norm_first else None
+
+    def _param_key(self, engine_key):
+        if self.lr_norm_first and engine_key == f'model.1.sub.{self.nb}':
+            return f'model.1.sub.{self.nb + 1}'
+        return engine_key
+
+    def _ensure_engine(self):
+        ver = self._weights_version()
+        if self._handle is not None and ver == self._uploaded_version:
+            return
+        super()._ensure_engine()
+        if not self.lr_norm_first:
+            return
+        import numpy as np
+        sd, bk = self.state_dict(), f'model.1.sub.{self.nb}'
+        a = sd[bk + '.weight'].double().cpu().numpy() / np.sqrt(sd[bk + '.running_var'].double().cpu().numpy() + 1e-5)
+        sh = sd[bk + '.bias'].double().cpu().numpy() - sd[bk + '.running_mean'].double().cpu().numpy() * a
+        a, sh = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(sh, np.float32)
+        key = C.create_string_buffer(128)
+        K, Cc = C.c_int(), C.c_int()
+        for i in range(L.lib.innfer_net_num_convs(self._handle)):
+            L.check(L.lib.innfer_net_conv_info(self._handle, i, key, 128, C.byref(K), C.byref(Cc)))
+            if key.value.decode() == bk:
+                L.check(L.lib.innfer_net_set_conv_input_map(self._handle, i, a.ctypes.data, sh.ctypes.data, 0))
 
     def _conv_tensors(self, k, sd):
         w, b = super()._conv_tensors(k, sd)

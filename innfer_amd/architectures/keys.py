@@ -11,7 +11,7 @@ def _bn(s, key, c):
     s[key + ".running_mean"] = (c,); s[key + ".running_var"] = (c,); s[key + ".num_batches_tracked"] = ()
 
 
-def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False, nr=3, upsample_mode='upconv', norm=False):
+def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False, nr=3, upsample_mode='upconv', norm=False, mode='CNA'):
     """State-dict key -> shape of the reference's old-arch ESRGAN
     (reference RRDBNet_arch.py:16-48; key layout SURVEY.md 3.3).  nr != 3: the dense blocks are `RDBs.<i>` (RRDBNet_arch.py:84-88);
     upsample_mode 'pixelshuffle': the stage's conv (nf -> 4 nf, 9 nf for scale 3) comes first (block.py:333-346)."""
@@ -29,9 +29,13 @@ def rrdbnet_shapes(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False, 
                 s[p + f"conv{i}.0.bias"] = (cout,)
                 if norm:                        # conv_block(CNA) = conv, BatchNorm2d[, act] (block.py:244-246)
                     _bn(s, p + f"conv{i}.1", cout)
-    s[f"model.1.sub.{nb}.weight"] = (nf, nf, 3, 3)
-    s[f"model.1.sub.{nb}.bias"] = (nf,)
-    if norm:                                    # LR_conv's norm layer is flattened into the trunk's Sequential behind its conv
+    lr = nb
+    if norm and mode == 'NAC':                  # LR_conv = norm, conv (block.py:246-254): the norm layer takes the conv's slot, the conv the next
+        _bn(s, f"model.1.sub.{nb}", nf)
+        lr = nb + 1
+    s[f"model.1.sub.{lr}.weight"] = (nf, nf, 3, 3)
+    s[f"model.1.sub.{lr}.bias"] = (nf,)
+    if norm and mode != 'NAC':                  # LR_conv's norm layer is flattened into the trunk's Sequential behind its conv
         _bn(s, f"model.1.sub.{nb + 1}", nf)
     n_up = 1 if scale == 3 else int(math.log(scale, 2))
     idx = 2

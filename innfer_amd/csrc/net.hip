@@ -111,6 +111,7 @@ extern "C" int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc
                 add_conv(net, std::string(rdb) + ".conv" + std::to_string(i) + ".0", i < 5 ? gc : nf, nf + (i - 1) * gc);
         }
     add_conv(net, "model.1.sub." + std::to_string(nb), nf, nf);
+    net->convs.back().map_ok = true;             // LR_conv under mode 'NAC' with a norm layer (RRDBNet_arch.py:29; block.py:246-254)
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) {        // upconv_block: Upsample, conv, act -- pixelshuffle_block: conv, PixelShuffle, act (block.py:333-361)
         if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * 4, nf);
@@ -230,7 +231,7 @@ extern "C" int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const fl
         return INNFER_OK;
     }
     if (!c.map_ok)
-        return set_error(INNFER_ERR_UNSUPPORTED, "set_conv_input_map: '%s' (built in front of the first conv of an SRResNet block and of LR_conv)", c.key.c_str());
+        return set_error(INNFER_ERR_UNSUPPORTED, "set_conv_input_map: '%s' (built in front of the first conv of an SRResNet block and of LR_conv of either network)", c.key.c_str());
     std::vector<float> h(2 * (size_t)c.C);
     for (int i = 0; i < c.C; ++i) { h[i] = alpha ? alpha[i] : 1.f; h[c.C + i] = shift ? shift[i] : 0.f; }
     if (!c.d_map) INNFER_HIP(hipMalloc((void**)&c.d_map, h.size() * sizeof(float)));

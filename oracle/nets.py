@@ -72,7 +72,12 @@ def rrdbnet_forward(sd, x, nb=23, scale=4, plus=False, taps=None, finalact=None,
         t = rrdb_forward(sd, f"model.1.sub.{b}.", t, plus, nr, _act)
         if taps is not None and b == 0:
             taps["rrdb0"] = t
-    t = _conv3(sd, f"model.1.sub.{nb}", t)
+    if f"model.1.sub.{nb}.running_mean" in sd:               # mode='NAC' with norm_type='batch': LR_conv = BatchNorm2d, conv (block.py:246-254)
+        bk = f"model.1.sub.{nb}"
+        t = F.batch_norm(t, sd[bk + ".running_mean"], sd[bk + ".running_var"], sd[bk + ".weight"], sd[bk + ".bias"], training=False, eps=1e-5)
+        t = _conv3(sd, f"model.1.sub.{nb + 1}", t)
+    else:
+        t = _conv3(sd, f"model.1.sub.{nb}", t)
     if f"model.1.sub.{nb + 1}.running_mean" in sd:           # LR_conv's BatchNorm2d (norm_type='batch'), flattened behind its conv
         bk = f"model.1.sub.{nb + 1}"
         t = F.batch_norm(t, sd[bk + ".running_mean"], sd[bk + ".running_var"], sd[bk + ".weight"], sd[bk + ".bias"], training=False, eps=1e-5)

@@ -402,6 +402,18 @@ def g26():
         with torch.no_grad():
             out[tag] = net(x).numpy()
         out[tag + "_keys"] = np.array(list(shapes))
+    # RRDBNet(norm_type='batch', mode='NAC' / 'CNAC'): only LR_conv sees the mode (RRDBNet_arch.py:27-29) -- 'NAC' puts its BatchNorm2d in front
+    from architectures.RRDBNet_arch import RRDBNet as RefRRDBNet
+    for j, mode in enumerate(("NAC", "CNAC")):
+        net = RefRRDBNet(3, 3, 64, 2, upscale=2, norm_type="batch", mode=mode).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        mine = synth.rrdbnet_shapes(nb=2, scale=2, norm=True, mode=mode)
+        assert list(shapes.items()) == list(mine.items()), mode
+        sd = synth.fill_running_stats(synth.fill_state_dict(mine, 320 + j), 320 + j)
+        net.load_state_dict(t_sd(sd), strict=True)
+        with torch.no_grad():
+            out["rrdb_bn_" + mode] = net(torch.from_numpy(synth.uniform((1, 3, 16, 16), 330 + j))).numpy()
+        out[f"rrdb_bn_{mode}_keys"] = np.array(list(shapes))
     save("g26_srresnet_modes", **out)
 
 

@@ -488,6 +488,16 @@ def test_srresnet_norm_and_mode_golden(dev, golden):
             with pytest.raises(NotImplementedError):
                 net.train()(xt)
             net.eval()
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    for j, mode in enumerate(("NAC", "CNAC")):              # RRDBNet(norm_type='batch', mode): LR_conv = norm, conv under 'NAC' (the input map), conv, norm else
+        net = RRDBNet(3, 3, 64, 2, upscale=2, norm_type="batch", mode=mode)
+        assert list(net.state_dict()) == list(g[f"rrdb_bn_{mode}_keys"])
+        sd = synth.fill_running_stats(synth.fill_state_dict(synth.rrdbnet_shapes(nb=2, scale=2, norm=True, mode=mode), 320 + j), 320 + j)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        net = net.to(dev).eval()
+        y = net(torch.from_numpy(synth.uniform((1, 3, 16, 16), 330 + j)).to(dev).half()).float().cpu().numpy()
+        assert np.abs(y - g["rrdb_bn_" + mode]).max() < 5e-3, (mode, float(np.abs(y - g["rrdb_bn_" + mode]).max()))
     with pytest.raises(NotImplementedError):
         SRResNet(3, 3, 64, 2, norm_type="instance")
     with pytest.raises(NotImplementedError):

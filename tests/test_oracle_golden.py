@@ -181,6 +181,14 @@ def test_g26_srresnet_norm_and_mode(golden):
             y = oracle.srresnet_forward(tsd, torch.from_numpy(x), nb=2, scale=c["scale"], act_type=c["act_type"], res_scale=c["res_scale"],
                                         upsample_mode="upconv", norm_type="batch" if c["norm"] else None, mode=c["mode"]).numpy()
         assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-6, tag
+    for j, mode in enumerate(("NAC", "CNAC")):              # RRDBNet(norm_type='batch', mode): LR_conv = norm, conv under 'NAC'
+        shapes = synth.rrdbnet_shapes(nb=2, scale=2, norm=True, mode=mode)
+        assert list(shapes) == list(g[f"rrdb_bn_{mode}_keys"])
+        sd = synth.fill_running_stats(synth.fill_state_dict(shapes, 320 + j), 320 + j)
+        tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        with torch.no_grad():
+            y = oracle.rrdbnet_forward(tsd, torch.from_numpy(synth.uniform((1, 3, 16, 16), 330 + j)), nb=2, scale=2).numpy()
+        assert np.abs(y - g["rrdb_bn_" + mode]).max() < 2e-6, mode
 
 
 G18_PAN = {"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
