@@ -111,7 +111,7 @@ struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b
 struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; void* d_dw3[8] = {};   // [0]: halo-tile panels of the eight dilated convs, back to back
               f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr;
               void* d_c2t = nullptr; };        // c2 as a centre-tap panel for the halo-tile kernel
-struct Head { Conv3 up[2]; Conv3 hr0, hr1; };
+struct Head { Conv3 up[3]; Conv3 hr0, hr1; };
 
 }  // namespace
 
@@ -158,18 +158,17 @@ static void add_rrblock(innfer_ppon* p, const std::string& prefix) {
 
 extern "C" int innfer_ppon_create(innfer_ppon** out, int in_nc, int out_nc, int nf, int nb, int scale, float alpha) {
     if (!out) return set_error(INNFER_ERR_INVALID, "ppon_create: null out");
-    if (nf != 64 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 16 || nb < 1 || (scale != 1 && scale != 2 && scale != 4 && scale != 8))
-        return set_error(INNFER_ERR_UNSUPPORTED, "ppon_create: nf=%d scale=%d (built: nf 64, scale 1/2/4/8)", nf, scale);
+    if (nf != 64 || in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 16 || nb < 1 || (scale != 1 && scale != 2 && scale != 3 && scale != 4 && scale != 8))
+        return set_error(INNFER_ERR_UNSUPPORTED, "ppon_create: nf=%d scale=%d (built: nf 64, scale 1/2/3/4/8)", nf, scale);
     innfer_ppon* p = new innfer_ppon();
     p->in_nc = in_nc; p->out_nc = out_nc; p->nf = nf; p->nb = nb; p->scale = scale; p->alpha = alpha;
-    p->n_up = scale == 8 ? 3 : (scale == 4 ? 2 : (scale == 2 ? 1 : 0));
+    p->n_up = scale == 8 ? 3 : (scale == 4 ? 2 : (scale == 2 || scale == 3 ? 1 : 0));          // upscale 3: ONE Upsample(3) stage (PPON_arch.py:20-22,33-36)
     p->fea_w = PP(p, "CFEM.0.weight", {nf, in_nc, 3, 3});
     p->fea_b = PP(p, "CFEM.0.bias", {nf});
     for (int b = 0; b < nb; ++b) add_rrblock(p, "CFEM.1.sub." + std::to_string(b) + ".");
     p->lr = add_conv3(p, "CFEM.1.sub." + std::to_string(nb), nf, nf);
     for (int b = 0; b < 2; ++b) add_rrblock(p, "SFEM." + std::to_string(b) + ".");
     for (int b = 0; b < 2; ++b) add_rrblock(p, "PFEM." + std::to_string(b) + ".");
-    if (p->n_up > 2) { delete p; return set_error(INNFER_ERR_UNSUPPORTED, "ppon_create: scale 8 is not built"); }
     const char* hn[3] = {"CRM.", "SRM.", "PRM."};
     // the reference declares the heads in the order CRM, SRM, PRM; keys: <3u+1> up-convs, then <3n>, <3n+2>
     for (int h = 0; h < 3; ++h) {
@@ -315,7 +314,23 @@ int upload(innfer_ppon* p) {
     return INNFER_OK;
 }
 
-struct QCarve { size_t fea, t[4], o1, comb, raw, raw2, cfem, sfem, up[2], hr, tmp_c, tmp_s, total; };
+// nearest 3x of a 64-channel slab (two groups), 8 channels per thread
+__global__ void ppon_upsample3(const f16* src, long src_g, f16* dst, long dst_g, int N, int H, int W) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int WO = 3 * W, HO = 3 * H;
+    const long per = (long)N * HO * WO * 4;
+    if (i >= per * 2) return;
+    const int g = (int)(i / per);
+    const long r = i % per;
+    const int q = (int)(r & 3);
+    const long m = r >> 2;
+    const int X = (int)(m % WO), Y = (int)((m / WO) % HO);
+    const long n = m / ((long)WO * HO);
+    const long sp = (n * H + Y / 3) * W + X / 3;
+    *(f16x8*)(dst + g * dst_g + m * 32 + q * 8) = *(const f16x8*)(src + g * src_g + sp * 32 + q * 8);
+}
+
+struct QCarve { size_t fea, t[4], o1, comb, raw, raw2, cfem, sfem, up[3], hr, tmp_c, tmp_s, total; };
 
 QCarve qcarve(const innfer_ppon* p, int N, int H, int W, int out_elt) {
     QCarve c{};
@@ -332,7 +347,7 @@ QCarve qcarve(const innfer_ppon* p, int N, int H, int W, int out_elt) {
     c.cfem = slab(px, 64);
     c.sfem = slab(px, 64);
     size_t m = 1;
-    for (int u = 0; u < p->n_up; ++u) { m *= 4; c.up[u] = slab(px * m, 64); }
+    for (int u = 0; u < p->n_up; ++u) { m *= p->scale == 3 ? 9 : 4; c.up[u] = slab(px * m, 64); }
     c.hr = slab(px * m, 64);
     c.tmp_c = off; off += al(px * m * p->out_nc * out_elt);
     c.tmp_s = off; off += al(px * m * p->out_nc * out_elt);
@@ -452,6 +467,15 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
         int h = H, w = W;
         for (int u = 0; u < p->n_up; ++u) {
             f16* dst = (f16*)(ws + cv.up[u]);
+            if (p->scale == 3) {          // Upsample(nearest 3x) materialised in the (still unused) HR slab, then conv -> LeakyReLU
+                f16* U = (f16*)(ws + cv.hr);
+                const long g3 = tg * 9, nthr = (long)N * 9 * h * w * 4 * 2;
+                hipLaunchKernelGGL(ppon_upsample3, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, t, tg, U, g3, N, h, w);
+                INNFER_HIP(hipGetLastError());
+                CK(conv(Hd.up[u], U, g3, dst, g3, 3 * h, 3 * w, 1, 0, nullptr, 0, OUT_SLAB));
+                t = dst; tg = g3; h *= 3; w *= 3;
+                continue;
+            }
             const long go = tg * 4;
             CK(conv(Hd.up[u], t, tg, dst, go, 2 * h, 2 * w, 1, 1, nullptr, 0, OUT_SLAB));
             t = dst; tg = go; h *= 2; w *= 2;

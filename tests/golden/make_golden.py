@@ -417,6 +417,22 @@ def g26():
     save("g26_srresnet_modes", **out)
 
 
+def g27():
+    """PPON with upscale 8 (three upconv stages) and 3 (one Upsample(3) stage) (PPON_arch.py:16-63), two-block trunk, all three outputs."""
+    from architectures.PPON_arch import PPON as RefPPON
+    out = {}
+    for j, sc in enumerate((8, 3, 2)):
+        net = RefPPON(3, 64, 2, 3, upscale=sc).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict(t_sd(synth.fill_state_dict(shapes, 340 + j)), strict=True)
+        x = torch.from_numpy(synth.uniform((1, 3, 10, 12), 350 + j))
+        with torch.no_grad():
+            oc, os_, op = net(x)
+        out[f"x{sc}_c"], out[f"x{sc}_s"], out[f"x{sc}_p"] = oc.numpy(), os_.numpy(), op.numpy()
+        out[f"x{sc}_keys"], out[f"x{sc}_shapes"] = np.array(list(shapes)), np.array([str(shapes[k]) for k in shapes])
+    save("g27_ppon_scales", **out)
+
+
 G26_SR = {"nac_bn": dict(), "cna_bn": dict(mode="CNA"), "nac": dict(norm_type=None), "cnac_bn": dict(mode="CNAC"), "cnac": dict(norm_type=None, mode="CNAC"),
           "x3_lrelu": dict(norm_type=None, mode="CNA", upscale=3, act_type="leakyrelu", res_scale=0.5), "nac_bn_x2_lrelu": dict(upscale=2, act_type="leakyrelu", res_scale=0.25)}
 
@@ -691,6 +707,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27"]
     for g in which:
         globals()[g]()

@@ -1126,6 +1126,28 @@ def test_frame_pipeline_equals_serial_loop(dev):
         assert np.array_equal(fx, U.color_fix(f, sr, device=dev))
 
 
+def test_ppon_scales_golden(dev, golden):
+    """PPON with upscale 8 (three upconv stages), 3 (one nearest-3x stage) and 2 against the reference (golden G27), all three outputs."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures.PPON_arch import PPON
+    g = golden("g27_ppon_scales")
+    for j, sc in enumerate((8, 3, 2)):
+        shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[f"x{sc}_keys"], g[f"x{sc}_shapes"])}
+        net = PPON(3, 64, 2, 3, upscale=sc)
+        assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+        net.load_state_dict(_sd(shapes, 340 + j), strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((1, 3, 10, 12), 350 + j)).to(dev)
+        for xin in (x, x.half()):
+            outs = net(xin)
+            for name, y in zip("csp", outs):
+                ref = g[f"x{sc}_{name}"].astype(np.float32)
+                assert tuple(y.shape) == ref.shape
+                err = np.abs(y.float().cpu().numpy() - ref)
+                assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()), (sc, name, err.max())
+
+
 def test_ppon_golden(dev, golden):
     """PPON 4x (24 + 4 residual-in-residual blocks of eight dilated convs, three heads)
     against the reference (golden G13), all three outputs.  fp16 slabs between the layers, fp32 sums:

@@ -271,6 +271,19 @@ def test_g13_ppon(golden):
             np.testing.assert_allclose(t.numpy(), g[f"out_{name}_{h}x{w}"], atol=5e-6, rtol=0)
 
 
+def test_g27_ppon_scales(golden):
+    """PPON with upscale 8 / 3 / 2 (PPON_arch.py:16-63: log2 upconv stages, ONE Upsample(3) stage for 3) against the reference."""
+    g = golden("g27_ppon_scales")
+    import ast
+    for j, sc in enumerate((8, 3, 2)):
+        shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g[f"x{sc}_keys"], g[f"x{sc}_shapes"])}
+        sd = _sd(shapes, 340 + j)
+        with torch.no_grad():
+            outs = oracle.ppon_forward(sd, torch.from_numpy(synth.uniform((1, 3, 10, 12), 350 + j)), nb=2, scale=sc)
+        for name, t in zip("csp", outs):
+            np.testing.assert_allclose(t.numpy(), g[f"x{sc}_{name}"], atol=5e-6, rtol=0)
+
+
 def test_g14_resnet9(golden):
     g = golden("g14_resnet9")
     import ast
