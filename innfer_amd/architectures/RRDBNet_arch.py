@@ -28,7 +28,7 @@ class RRDBNet(EngineModule):
         # mode: the dense blocks are built with mode='CNA' whatever is passed (RRDBNet_arch.py:27-29); only LR_conv takes it, and without
         # a norm layer or an activation a 'NAC' / 'CNAC' conv_block is the bare conv (block.py:237-254)
         if mode not in ('CNA', 'NAC', 'CNAC'): unsupported.append(f'mode={mode}')
-        if upsample_mode == 'pixelshuffle' and (upscale == 3 or nf != 64): unsupported.append(f'upsample_mode=pixelshuffle with upscale={upscale}, nf={nf}')
+        if upsample_mode == 'pixelshuffle' and upscale == 3 and nf != 64: unsupported.append(f'upsample_mode=pixelshuffle with upscale={upscale}, nf={nf}')
         if convtype != 'Conv2D': unsupported.append(f'convtype={convtype}')
         if finalact and finalact.lower() not in _FINAL_ACT: unsupported.append(f'finalact={finalact}')
         if unsupported:

@@ -21,7 +21,7 @@ class SRResNet(EngineModule):
         if mode not in ('CNA', 'NAC', 'CNAC'): unsupported.append(f'mode={mode}')
         if convtype != 'Conv2D': unsupported.append(f'convtype={convtype}')
         if finalact and finalact.lower() not in _FINAL_ACT: unsupported.append(f'finalact={finalact}')
-        if upscale == 3 and upsample_mode != 'upconv': unsupported.append('upscale=3 with upsample_mode=pixelshuffle')
+        if upscale == 3 and upsample_mode != 'upconv' and nf != 64: unsupported.append(f'upscale=3 with upsample_mode=pixelshuffle, nf={nf}')
         if unsupported:
             raise NotImplementedError('SRResNet option(s) not built on the HIP path yet: ' + ', '.join(unsupported))
         super().__init__(srresnet_shapes(in_nc, out_nc, nf, nb, upscale, upsample_mode, bool(norm_type), mode))

@@ -128,8 +128,8 @@ def srresnet_shapes(in_nc=3, out_nc=3, nf=64, nb=16, scale=4, upsample_mode='pix
             s[f"model.{idx + 1}.weight"] = (nf, nf, 3, 3)
             s[f"model.{idx + 1}.bias"] = (nf,)
         else:
-            s[f"model.{idx}.weight"] = (nf * 4, nf, 3, 3)
-            s[f"model.{idx}.bias"] = (nf * 4,)
+            s[f"model.{idx}.weight"] = (nf * (9 if scale == 3 else 4), nf, 3, 3)
+            s[f"model.{idx}.bias"] = (nf * (9 if scale == 3 else 4),)
         idx += 3
     s[f"model.{idx}.weight"] = (nf, nf, 3, 3)
     s[f"model.{idx}.bias"] = (nf,)

@@ -87,8 +87,8 @@ extern "C" int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc
     if (!out) return set_error(INNFER_ERR_INVALID, "rrdbnet_create: null out");
     if (nr < 1 || nr > 64 || (act != 1 && act != 2))
         return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: nr=%d act=%d (built: nr >= 1; act 1 LeakyReLU(0.2), 2 ReLU)", nr, act);
-    if (pixelshuffle_up && (scale == 3 || nf != 64))
-        return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: the PixelShuffle upsampler is built for factor-2 stages of nf=64 (scale %d, nf %d)", scale, nf);
+    if (pixelshuffle_up && scale == 3 && nf != 64)
+        return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: PixelShuffle(3) is built for nf=64 (nf %d: 9 nf is not a multiple of 64)", nf);
     if (scale != 1 && scale != 2 && scale != 3 && scale != 4 && scale != 8 && scale != 16)
         return set_error(INNFER_ERR_UNSUPPORTED, "rrdbnet_create: scale %d (built: 1, 2, 3, 4, 8, 16)", scale);
     if (nf % 32 || gc % 32 || nf <= 0 || gc <= 0 || nf > 64)
@@ -114,7 +114,7 @@ extern "C" int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc
     net->convs.back().map_ok = true;             // LR_conv under mode 'NAC' with a norm layer (RRDBNet_arch.py:29; block.py:246-254)
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) {        // upconv_block: Upsample, conv, act -- pixelshuffle_block: conv, PixelShuffle, act (block.py:333-361)
-        if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * 4, nf);
+        if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * (scale == 3 ? 9 : 4), nf);
         else add_conv(net, "model." + std::to_string(idx + 1), nf, nf);
         idx += 3;
     }
@@ -130,10 +130,10 @@ extern "C" int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, 
 
 extern "C" int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale, int act, float res_scale, int upconv_up) {
     if (!out) return set_error(INNFER_ERR_INVALID, "srresnet_create: null out");
-    if (scale != 1 && scale != 2 && scale != 4 && scale != 8 && !(scale == 3 && upconv_up))
-        return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: scale %d (built: powers of two; 3 with upsample_mode 'upconv')", scale);
+    if (scale != 1 && scale != 2 && scale != 3 && scale != 4 && scale != 8)
+        return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: scale %d (built: 1, 2, 3, 4, 8)", scale);
     if (nf != 64 && nf != 32) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: nf=%d", nf);
-    if (scale > 1 && nf != 64 && !upconv_up) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: pixelshuffle path needs nf=64");
+    if (scale == 3 && nf != 64 && !upconv_up) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: PixelShuffle(3) is built for nf=64 (9 nf must be a multiple of 64)");
     if (act != 1 && act != 2) return set_error(INNFER_ERR_UNSUPPORTED, "srresnet_create: act %d (1 LeakyReLU(0.2), 2 ReLU)", act);
     if (in_nc < 1 || in_nc > 8 || out_nc < 1 || out_nc > 16 || nb < 1)
         return set_error(INNFER_ERR_INVALID, "srresnet_create: in_nc=%d out_nc=%d nb=%d", in_nc, out_nc, nb);
@@ -151,7 +151,7 @@ extern "C" int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_n
     net->convs.back().map_ok = true;
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) {        // pixelshuffle_block: conv, PixelShuffle, act -- upconv_block: Upsample, conv, act (block.py:333-361)
-        if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * 4, nf);
+        if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * (scale == 3 ? 9 : 4), nf);
         else add_conv(net, "model." + std::to_string(idx + 1), nf, nf);
         idx += 3;
     }
@@ -443,6 +443,26 @@ __global__ void slab_input_map(const f16* src, f16* dst, long g_elems, int group
     *(f16x8*)(dst + g * g_elems + r * 8) = y;
 }
 
+// PixelShuffle(r) between slabs: out[n, y r + i, x r + j, c] = in[n, y, x, c r^2 + i r + j] (torch.nn.PixelShuffle); 8 output channels per thread
+__global__ void slab_pixel_shuffle(const f16* src, long src_g, f16* dst, long dst_g, int nf, int N, int H, int W, int r) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = nf / 8, WO = W * r, HO = H * r;
+    if (i >= (long)N * HO * WO * c8) return;
+    const int c = (int)(i % c8) * 8;
+    const long m = i / c8;
+    const int X = (int)(m % WO), Y = (int)((m / WO) % HO);
+    const long n = m / ((long)WO * HO);
+    const long sp = (n * H + Y / r) * W + X / r;
+    const int sub = (Y % r) * r + X % r;
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = (c + e) * r * r + sub;
+        v[e] = src[(long)(ch >> 5) * src_g + sp * 32 + (ch & 31)];
+    }
+    *(f16x8*)(dst + (long)(c >> 5) * dst_g + m * 32 + (c & 31)) = v;
+}
+
 int do_input_map(const ConvSlot& cs, const f16* src, f16* dst, long G, hipStream_t s) {
     const int groups = (cs.C + 31) / 32;
     const long n = G / 8 * groups;
@@ -631,6 +651,20 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         const ConvSlot& cs = net->convs[ci++];
         f16* dst = (f16*)(ws + cv.up[u]);
         const long gi = (long)N * h * w * 32, go = gi * 4;
+        if (net->ps_up && (net->scale == 3 || net->nf != 64)) {
+            // PixelShuffle(3), or factor 2 on 32 features: the conv (nf -> r^2 nf, act in its epilogue -- it commutes with the permutation) writes a
+            // slab in the (still unused) HR region, one gather pass rearranges it (block.py:333-346).  The 64-feature factor-2 stages shuffle in the
+            // conv's own store (OUT_SHUFFLE2) below.
+            const int r = net->scale == 3 ? 3 : 2;
+            f16* Y = (f16*)(ws + cv.hr);
+            rc = do_conv(mk(cs, t, gi, Y, gi, N, h, w, net->trunk_act), s);
+            if (rc) return rc;
+            const long gr = gi * r * r, nthr = (long)N * h * w * r * r * (net->nf / 8);
+            hipLaunchKernelGGL(slab_pixel_shuffle, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const f16*)Y, gi, dst, gr, net->nf, N, h, w, r);
+            INNFER_HIP(hipGetLastError());
+            t = dst; h *= r; w *= r;
+            continue;
+        }
         if (net->scale == 3) {      // Upsample(nearest 3x), materialised in the (still unused) HR slab -> conv -> LeakyReLU
             f16* U = (f16*)(ws + cv.hr);
             const long g3 = gi * 9, nthr = (long)N * 9 * h * w * 4 * (net->nf / 32);

@@ -414,6 +414,17 @@ def g26():
         with torch.no_grad():
             out["rrdb_bn_" + mode] = net(torch.from_numpy(synth.uniform((1, 3, 16, 16), 330 + j))).numpy()
         out[f"rrdb_bn_{mode}_keys"] = np.array(list(shapes))
+    # PixelShuffle(3) and PixelShuffle(2) on 32 features (block.py:333-346): SRResNet x3, SRResNet nf=32 x4, RRDBNet x3
+    for tag, (net, mine, seed) in {
+            "ps3_sr": (RefSRResNet(3, 3, 64, 2, upscale=3, norm_type=None, mode="CNA", upsample_mode="pixelshuffle"), synth.srresnet_shapes(nb=2, scale=3, upsample_mode="pixelshuffle"), 360),
+            "ps2_sr_nf32": (RefSRResNet(3, 3, 32, 2, upscale=4, norm_type=None, mode="CNA", upsample_mode="pixelshuffle"), synth.srresnet_shapes(nf=32, nb=2, scale=4, upsample_mode="pixelshuffle"), 361),
+            "ps3_rrdb": (RefRRDBNet(3, 3, 64, 1, upscale=3, upsample_mode="pixelshuffle"), synth.rrdbnet_shapes(nb=1, scale=3, upsample_mode="pixelshuffle"), 362)}.items():
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        assert list(shapes.items()) == list(mine.items()), tag
+        net.load_state_dict(t_sd(synth.fill_state_dict(mine, seed)), strict=True)
+        with torch.no_grad():
+            out[tag] = net.eval()(torch.from_numpy(synth.uniform((1, 3, 10, 12), seed + 10))).numpy()
+        out[tag + "_keys"] = np.array(list(shapes))
     save("g26_srresnet_modes", **out)
 
 

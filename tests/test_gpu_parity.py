@@ -498,10 +498,22 @@ def test_srresnet_norm_and_mode_golden(dev, golden):
         net = net.to(dev).eval()
         y = net(torch.from_numpy(synth.uniform((1, 3, 16, 16), 330 + j)).to(dev).half()).float().cpu().numpy()
         assert np.abs(y - g["rrdb_bn_" + mode]).max() < 5e-3, (mode, float(np.abs(y - g["rrdb_bn_" + mode]).max()))
+    # PixelShuffle(3), PixelShuffle(2) on 32 features: conv to a slab, one gather pass (slab_pixel_shuffle)
+    from test_oracle_golden import G26_PS
+    nets = {"ps3_sr": lambda: SRResNet(3, 3, 64, 2, upscale=3, norm_type=None, mode="CNA", upsample_mode="pixelshuffle"),
+            "ps2_sr_nf32": lambda: SRResNet(3, 3, 32, 2, upscale=4, norm_type=None, mode="CNA", upsample_mode="pixelshuffle"),
+            "ps3_rrdb": lambda: RRDBNet(3, 3, 64, 1, upscale=3, upsample_mode="pixelshuffle")}
+    for tag, (shapes, seed, _) in G26_PS.items():
+        net = nets[tag]()
+        assert list(net.state_dict()) == list(g[tag + "_keys"]), tag
+        net.load_state_dict(_sd(shapes(), seed), strict=True)
+        net = net.to(dev).eval()
+        y = net(torch.from_numpy(synth.uniform((1, 3, 10, 12), seed + 10)).to(dev).half()).float().cpu().numpy()
+        assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 5e-3, (tag, float(np.abs(y - g[tag]).max()))
     with pytest.raises(NotImplementedError):
         SRResNet(3, 3, 64, 2, norm_type="instance")
     with pytest.raises(NotImplementedError):
-        SRResNet(3, 3, 64, 2, upscale=3, upsample_mode="pixelshuffle", norm_type=None, mode="CNA")
+        SRResNet(3, 3, 32, 2, upscale=3, upsample_mode="pixelshuffle", norm_type=None, mode="CNA")          # 9 * 32 output channels: not a multiple of 64
 
 
 def test_esrgan_plus_golden(dev, golden):

@@ -189,6 +189,19 @@ def test_g26_srresnet_norm_and_mode(golden):
         with torch.no_grad():
             y = oracle.rrdbnet_forward(tsd, torch.from_numpy(synth.uniform((1, 3, 16, 16), 330 + j)), nb=2, scale=2).numpy()
         assert np.abs(y - g["rrdb_bn_" + mode]).max() < 2e-6, mode
+    for tag, (shapes, seed, fwd) in G26_PS.items():        # PixelShuffle(3), PixelShuffle(2) on 32 features
+        assert list(shapes()) == list(g[tag + "_keys"]), tag
+        with torch.no_grad():
+            y = fwd(_sd(shapes(), seed), torch.from_numpy(synth.uniform((1, 3, 10, 12), seed + 10))).numpy()
+        assert y.shape == g[tag].shape and np.abs(y - g[tag]).max() < 2e-6, tag
+
+
+G26_PS = {"ps3_sr": (lambda: synth.srresnet_shapes(nb=2, scale=3, upsample_mode="pixelshuffle"), 360,
+                     lambda sd, x: oracle.srresnet_forward(sd, x, nb=2, scale=3, upsample_mode="pixelshuffle")),
+          "ps2_sr_nf32": (lambda: synth.srresnet_shapes(nf=32, nb=2, scale=4, upsample_mode="pixelshuffle"), 361,
+                          lambda sd, x: oracle.srresnet_forward(sd, x, nb=2, scale=4, upsample_mode="pixelshuffle")),
+          "ps3_rrdb": (lambda: synth.rrdbnet_shapes(nb=1, scale=3, upsample_mode="pixelshuffle"), 362,
+                       lambda sd, x: oracle.rrdbnet_forward(sd, x, nb=1, scale=3, upsample_mode="pixelshuffle"))}
 
 
 G18_PAN = {"noattn": dict(self_attention=False), "double": dict(double_scpa=True),
