@@ -63,8 +63,8 @@ int innfer_rrdbnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int 
 
 /* The same with the graph-changing constructor arguments of RRDBNet_arch.py:16-48: nr = dense blocks per RRDB (3: parameters
  * `RDB1..RDB3`, else `RDBs.<i>`, RRDBNet_arch.py:73-88); act = `act_type` of every conv block (1 LeakyReLU(0.2), 2 ReLU);
- * pixelshuffle_up != 0 = upsample_mode 'pixelshuffle' (conv nf -> 4 nf, PixelShuffle(2), act: block.py:333-346) instead of
- * 'upconv'.  innfer_rrdbnet_create(...) = innfer_rrdbnet_create_ex(..., 3, 1, 0).  (104) */
+ * pixelshuffle_up != 0 = upsample_mode 'pixelshuffle' (conv nf -> 4 nf, PixelShuffle(2), act: block.py:333-346; scale 3: conv nf -> 9 nf,
+ * PixelShuffle(3), nf 64 only) instead of 'upconv'.  innfer_rrdbnet_create(...) = innfer_rrdbnet_create_ex(..., 3, 1, 0).  (104) */
 int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb,
                              int gc, int scale, int plus, int nr, int act, int pixelshuffle_up);
 
@@ -72,7 +72,8 @@ int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, i
  * pixelshuffle, res_scale 1: utils/defaults.py:53-67). */
 int innfer_srresnet_create(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale);
 /* The same with the constructor arguments that keep the graph on the built kernels (SRResNet_arch.py:16-46,69-91): act = `act_type` (1 LeakyReLU(0.2),
- * 2 ReLU), res_scale (x + res * res_scale), upconv_up != 0 = upsample_mode 'upconv' (Upsample, conv, act) instead of 'pixelshuffle'.  (104) */
+ * 2 ReLU), res_scale (x + res * res_scale), upconv_up != 0 = upsample_mode 'upconv' (Upsample, conv, act) instead of 'pixelshuffle';
+ * scale in {1,2,3,4,8} (3: one factor-3 stage; PixelShuffle(3) needs nf 64).  (104, 105) */
 int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, int nb, int scale, int act, float res_scale, int upconv_up);
 /* mode 'NAC' conv blocks (block.py:246-254: norm -> act -> conv; SRResNet's own default, SRResNet_arch.py:16-27): conv `idx` reads
  * act(alpha[c] * x + shift[c]) instead of x -- the eval-mode BatchNorm2d of its input channels as a per-channel map (NULL alpha / shift: 1 / 0) and
