@@ -11,7 +11,7 @@ from .keys import mrrdb_key_of, mrrdbnet_shapes, rrdbnet_shapes
 # `finalact` (block.py:81-101 act()) -> activation code of the last conv's epilogue
 _FINAL_ACT = {'relu': 2, 'leakyrelu': 1, 'lrelu': 1, 'tanh': 3, 'sigmoid': 6}
 # `act_type` of every conv block (block.py:81-90: LeakyReLU slope 0.2) -> activation code of the conv epilogues
-_TRUNK_ACT = {'leakyrelu': 1, 'relu': 2}
+_TRUNK_ACT = {'leakyrelu': 1, 'lrelu': 1, 'relu': 2}          # act() lower-cases its argument and takes both spellings (block.py:86-90)
 
 
 class RRDBNet(EngineModule):
@@ -24,7 +24,7 @@ class RRDBNet(EngineModule):
         if not isinstance(nr, int) or nr < 1: unsupported.append(f'nr={nr}')
         if norm_type and norm_type.lower() != 'batch':
             unsupported.append(f'norm_type={norm_type}')          # built: BatchNorm2d behind the convs (folded at load); in front of LR_conv under 'NAC' (input map)
-        if act_type not in _TRUNK_ACT: unsupported.append(f'act_type={act_type}')
+        if str(act_type).lower() not in _TRUNK_ACT: unsupported.append(f'act_type={act_type}')
         # mode: the dense blocks are built with mode='CNA' whatever is passed (RRDBNet_arch.py:27-29); only LR_conv takes it, and without
         # a norm layer or an activation a 'NAC' / 'CNAC' conv_block is the bare conv (block.py:237-254)
         if mode not in ('CNA', 'NAC', 'CNAC'): unsupported.append(f'mode={mode}')
@@ -39,7 +39,7 @@ class RRDBNet(EngineModule):
         self.lr_norm_first = bool(norm_type) and mode == 'NAC'          # LR_conv = BatchNorm2d, conv: the norm cannot be folded (the zero padding is not mapped)
         self.in_nc, self.out_nc, self.nf, self.nb, self.gc, self.upscale = in_nc, out_nc, nf, nb, 32, upscale
         self.plus, self.nr = bool(plus), nr
-        self.trunk_act = _TRUNK_ACT[act_type]
+        self.trunk_act = _TRUNK_ACT[str(act_type).lower()]
         self.pixelshuffle_up = upsample_mode == 'pixelshuffle'
         self.final_act = _FINAL_ACT[finalact.lower()] if finalact else 0
 

@@ -17,7 +17,7 @@ class SRResNet(EngineModule):
             raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
         unsupported = []
         if norm_type and norm_type.lower() != 'batch': unsupported.append(f'norm_type={norm_type}')
-        if act_type not in _TRUNK_ACT: unsupported.append(f'act_type={act_type}')
+        if str(act_type).lower() not in _TRUNK_ACT: unsupported.append(f'act_type={act_type}')
         if mode not in ('CNA', 'NAC', 'CNAC'): unsupported.append(f'mode={mode}')
         if convtype != 'Conv2D': unsupported.append(f'convtype={convtype}')
         if finalact and finalact.lower() not in _FINAL_ACT: unsupported.append(f'finalact={finalact}')
@@ -28,7 +28,7 @@ class SRResNet(EngineModule):
         self.norm, self.mode = bool(norm_type), mode
         self._layout = srresnet_layout(nb, self.norm, mode)          # engine key -> (conv key, BatchNorm in front, BatchNorm behind)
         self.in_nc, self.out_nc, self.nf, self.nb, self.upscale = in_nc, out_nc, nf, nb, upscale
-        self.trunk_act, self.res_scale, self.upconv_up = _TRUNK_ACT[act_type], float(res_scale), upsample_mode == 'upconv'
+        self.trunk_act, self.res_scale, self.upconv_up = _TRUNK_ACT[str(act_type).lower()], float(res_scale), upsample_mode == 'upconv'
         self.final_act = _FINAL_ACT[finalact.lower()] if finalact else 0
 
     # Eval-mode BatchNorm2d is a per-channel affine map.  BEHIND a conv (mode 'CNA' / 'CNAC'; and the norm in front of a NAC block's second conv, which

@@ -169,6 +169,11 @@ def test_module_shells_carry_reference_keys_and_refuse_cpu():
         net(torch.zeros(1, 3, 8, 8))
     srg = get_network(get_network_G_config({"type": "srgan", "nb": 2}, 4))
     assert list(srg.state_dict().keys()) == list(synth.srresnet_shapes(nb=2, scale=4).keys())
+    # the class's own defaults (norm_type='batch', mode='NAC': SRResNet_arch.py:16-17) and act() spellings (block.py:86-90), golden G26 pins the keys
+    from innfer_amd.architectures.SRResNet_arch import SRResNet
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    assert list(SRResNet(3, 3, 64, 2).state_dict()) == list(synth.srresnet_shapes(nb=2, scale=4, upsample_mode="upconv", norm=True, mode="NAC"))
+    assert SRResNet(3, 3, 64, 1, act_type="LRelu").trunk_act == RRDBNet(3, 3, 64, 1, act_type="lrelu").trunk_act == 1
     plus = get_network(get_network_G_config({"type": "esrgan", "plus": True, "nb": 1}, 4))
     assert list(plus.state_dict().keys()) == list(synth.rrdbnet_shapes(nb=1, scale=4, plus=True).keys())
     m = get_network(get_network_G_config({"type": "mesrgan", "nb": 2}, 4))          # new-arch ESRGAN built directly
