@@ -94,6 +94,61 @@ __global__ void unet_post_slab(const f16* src, long sg, int C, long HW, int N, c
     }
 }
 
+// The same with the statistics merge inside (as resnet.hip's rn_post_slab_parts): a workgroup = pxb pixels x 32 channels of one image; it merges that
+// image's per-tile records of its 32 channels itself (8 lanes per channel, Chan's update, lanes merged in order: every workgroup of the group
+// computes the same alpha / shift) and applies them -- the combine launch between conv and post is gone.
+__global__ __launch_bounds__(256) void unet_post_slab_parts(const f16* src, long sg, int C, long HW, const float* part, int nper, float eps,
+                                                            const float* gamma, const float* beta, PostDst d, PostDst d1, int pxb) {
+    __shared__ float sn[8][32], sm[8][32], sq[8][32], sal[32], ssh[32];
+    const int n = blockIdx.z, cb = blockIdx.y * 32, t = threadIdx.x;
+    {
+        const int cl = t & 31, lg = t >> 5, c = cb + cl;
+        float cnt = 0.f, mu = 0.f, m2 = 0.f;
+        for (int r = lg; r < nper; r += 8) {
+            const float* q = part + (((long)n * nper + r) * C + c) * 3;
+            norm::chan_merge(cnt, mu, m2, q[0], q[1], q[2]);
+        }
+        sn[lg][cl] = cnt; sm[lg][cl] = mu; sq[lg][cl] = m2;
+        __syncthreads();
+        if (lg == 0) {
+            for (int i = 1; i < 8; ++i) norm::chan_merge(cnt, mu, m2, sn[i][cl], sm[i][cl], sq[i][cl]);
+            const float a = (1.0f / sqrtf(m2 / (float)HW + eps)) * (gamma ? gamma[c] : 1.0f);
+            sal[cl] = a;
+            ssh[cl] = (beta ? beta[c] : 0.f) - mu * a;
+        }
+        __syncthreads();
+    }
+    const int q8 = (t & 3) * 8, pl = t >> 2;
+    float al[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { al[e] = sal[q8 + e]; sh[e] = ssh[q8 + e]; }
+    const int c0 = d.coff + cb + q8, c1 = d1.coff + cb + q8;
+#pragma unroll 4
+    for (int i = 0; i < pxb / 64; ++i) {
+        const long px = (long)blockIdx.x * pxb + pl + 64 * i;
+        if (px >= HW) break;
+        const long pix = (long)n * HW + px;
+        const f16x8 x = *(const f16x8*)(src + (cb >> 5) * sg + pix * 32 + q8);
+        f16x8 h, h1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (float)x[e] * al[e] + sh[e];
+            h[e] = (f16)(d.act == 1 ? fmaxf(v, 0.2f * v) : fmaxf(v, 0.f));
+            h1[e] = (f16)(d1.act == 1 ? fmaxf(v, 0.2f * v) : fmaxf(v, 0.f));
+        }
+        *(f16x8*)(d.p + (c0 >> 5) * d.g + pix * 32 + (c0 & 31)) = h;
+        if (d1.p) *(f16x8*)(d1.p + (c1 >> 5) * d1.g + pix * 32 + (c1 & 31)) = h1;
+    }
+}
+static int launch_post_slab_parts(const f16* src, long sg, int C, long HW, int N, const float* part, int nper, const float* gamma, const float* beta,
+                                  PostDst d, PostDst d1, hipStream_t s) {
+    const int pxb = ((HW + 1023) / 1024) * (C / 32) * N >= 256 ? 1024 : 256;
+    hipLaunchKernelGGL(unet_post_slab_parts, dim3((unsigned)((HW + pxb - 1) / pxb), C / 32, N), dim3(256), 0, s, src, sg, C, HW, part, nper, 1e-5f,
+                       gamma, beta, d, d1, pxb);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
 // Deep levels (at most DEEP_PX output pixels per image): split-K reduction + BatchNorm statistics + normalisation / activation in ONE
 // launch.  A workgroup owns 32 channels of one image: 32 channel lanes x 32 pixel lanes, every thread keeps its <= DEEP_PX/32 pixels in
 // registers; the partial results are added in segment order, the statistics are the two-pass form on registers (as norm_stats.h), the
@@ -829,15 +884,16 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             if (!ev) Lc.stats_part = bnpart;              // statistics as per-tile partials out of the conv epilogue
             rc = conv_launch(Lc, s);
             if (rc) return rc;
-            if (!ev) {
-                rc = norm::launch_combine_parts(bnpart, conv_stats_nper(ho, wo, 1), HWo, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, s);
-                if (rc) return rc;
-            }
             const long total = (long)N * HWo * (l.cout / 8);
             PostDst dl{(f16*)(ws + cv.D[k]), Go, 0, 1}, dr{(f16*)(ws + cv.CAT[k]), Go, 0, 2};
-            hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, Go, l.cout, HWo, N,
-                               (const float*)(ev ? l.d_ev_alpha : mean), (const float*)(ev ? l.d_ev_shift : rstd), ev ? 0 : l.cout, dl, dr);
-            INNFER_HIP(hipGetLastError());
+            if (!ev) {           // the records are merged inside the post pass
+                rc = launch_post_slab_parts((const f16*)Y, Go, l.cout, HWo, N, bnpart, conv_stats_nper(ho, wo, 1), l.d_gamma, l.d_beta, dl, dr, s);
+                if (rc) return rc;
+            } else {
+                hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, Go, l.cout, HWo, N,
+                                   (const float*)l.d_ev_alpha, (const float*)l.d_ev_shift, 0, dl, dr);
+                INNFER_HIP(hipGetLastError());
+            }
             cur = dl.p; cur_g = Go;
             h = ho; w = wo;
             continue;
@@ -891,19 +947,21 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
                 if (epi_stats) Lc.stats_part = bnpart;
                 int rc = conv_launch(Lc, s);
                 if (rc) return rc;
-                if (epi_stats) {
-                    rc = norm::launch_combine_parts(bnpart, tile4 ? conv_stats_nper(h, w, 4) : conv_stats_nper(hf, wf, 1), HW, 1e-5f, l.d_gamma, l.d_beta,
-                                                    mean, rstd, l.cout, N, s);
-                    if (rc) return rc;
-                } else if (!ev) {
-                    rc = norm::launch_stats_slab(Y, G, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
-                    if (rc) return rc;
-                }
-                const long total = (long)N * HW * (l.cout / 8);
                 PostDst dr{(f16*)(ws + cv.CAT[k - 1]), G, u->dc[k - 1], 2};
-                hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, G, l.cout, HW, N,
-                                   (const float*)(ev ? l.d_ev_alpha : mean), (const float*)(ev ? l.d_ev_shift : rstd), ev ? 0 : l.cout, dr, PostDst{nullptr, 0, 0, 0});
-                INNFER_HIP(hipGetLastError());
+                if (epi_stats) {           // the records are merged inside the post pass
+                    rc = launch_post_slab_parts((const f16*)Y, G, l.cout, HW, N, bnpart, tile4 ? conv_stats_nper(h, w, 4) : conv_stats_nper(hf, wf, 1),
+                                                l.d_gamma, l.d_beta, dr, PostDst{nullptr, 0, 0, 0}, s);
+                    if (rc) return rc;
+                } else {
+                    if (!ev) {
+                        rc = norm::launch_stats_slab(Y, G, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
+                        if (rc) return rc;
+                    }
+                    const long total = (long)N * HW * (l.cout / 8);
+                    hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, G, l.cout, HW, N,
+                                       (const float*)(ev ? l.d_ev_alpha : mean), (const float*)(ev ? l.d_ev_shift : rstd), ev ? 0 : l.cout, dr, PostDst{nullptr, 0, 0, 0});
+                    INNFER_HIP(hipGetLastError());
+                }
             }
             h = hf; w = wf;
             continue;
