@@ -1487,6 +1487,53 @@ def test_small_generators_shape_fuzz_and_poisoned_workspace(dev):
             check(wb, x, ref, 8e-3, 1e-3, mode)
 
 
+def test_sr_network_options_shape_fuzz_and_poisoned_workspace(dev):
+    """Seeded ragged shapes and batches for the SR shells' graph-changing options against the oracle: SRResNet's own defaults (BatchNorm, 'NAC': the
+    input map in front of every block and of LR_conv), RRDBNet(norm_type='batch', mode='NAC'), the PixelShuffle(3) stage and PixelShuffle(2) on 32
+    features (conv to a slab + gather pass), upscale 3 with 'upconv'.  Each forward is repeated on a workspace of 0xFF bytes: the result must not change."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    from innfer_amd.architectures.SRResNet_arch import SRResNet
+    rng = np.random.RandomState(91)
+
+    def np_sd(shapes, seed, bn):
+        sd = synth.fill_state_dict(shapes, seed)
+        return {k: torch.from_numpy(np.asarray(v)) for k, v in (synth.fill_running_stats(sd, seed) if bn else sd).items()}
+
+    cases = [
+        ("sr nac bn", SRResNet(3, 3, 64, 3), True,
+         lambda sd, x: oracle.srresnet_forward(sd, x, nb=3, scale=4, upsample_mode="upconv", norm_type="batch", mode="NAC")),
+        ("sr nac lrelu x2", SRResNet(3, 3, 64, 2, upscale=2, norm_type=None, act_type="leakyrelu", res_scale=0.5), False,
+         lambda sd, x: oracle.srresnet_forward(sd, x, nb=2, scale=2, act_type="leakyrelu", res_scale=0.5, upsample_mode="upconv", mode="NAC")),
+        ("sr ps3", SRResNet(3, 3, 64, 2, upscale=3, norm_type=None, mode="CNA", upsample_mode="pixelshuffle"), False,
+         lambda sd, x: oracle.srresnet_forward(sd, x, nb=2, scale=3, upsample_mode="pixelshuffle")),
+        ("sr nf32 ps2", SRResNet(3, 3, 32, 2, upscale=2, norm_type=None, mode="CNA", upsample_mode="pixelshuffle"), False,
+         lambda sd, x: oracle.srresnet_forward(sd, x, nb=2, scale=2, upsample_mode="pixelshuffle")),
+        ("sr x3 upconv", SRResNet(3, 3, 64, 2, upscale=3, norm_type=None, mode="CNA"), False,
+         lambda sd, x: oracle.srresnet_forward(sd, x, nb=2, scale=3, upsample_mode="upconv")),
+        ("rrdb bn nac", RRDBNet(3, 3, 64, 1, upscale=2, norm_type="batch", mode="NAC"), True,
+         lambda sd, x: oracle.rrdbnet_forward(sd, x, nb=1, scale=2)),
+        ("rrdb ps3", RRDBNet(3, 3, 64, 1, upscale=3, upsample_mode="pixelshuffle"), False,
+         lambda sd, x: oracle.rrdbnet_forward(sd, x, nb=1, scale=3, upsample_mode="pixelshuffle")),
+    ]
+    for j, (tag, net, bn, fwd) in enumerate(cases):
+        sd = np_sd({k: tuple(v.shape) for k, v in net.state_dict().items()}, 600 + j, bn)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).eval()
+        for _ in range(3):
+            n, h, w = int(rng.randint(1, 4)), int(rng.randint(5, 75)), int(rng.randint(5, 75))
+            x = torch.from_numpy(synth.uniform((n, 3, h, w), int(rng.randint(1 << 20))))
+            with torch.no_grad():
+                ref = fwd(sd, x)
+            y = net(x.to(dev).half()).float().cpu()
+            err = (y - ref).abs()
+            lim = max(1.0, ref.abs().max().item())
+            assert y.shape == ref.shape and err.max().item() < 5e-3 * lim, (tag, n, h, w, err.max().item())
+            net._ws.fill_(0xFF)
+            assert torch.equal(net(x.to(dev).half()).float().cpu(), y), (tag, n, h, w, "reads unwritten workspace")
+
+
 # ---------------------------------------------------------- tiles / blend / io
 def test_extract_and_blend_bit_exact(dev, golden):
     import oracle
