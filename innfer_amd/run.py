@@ -341,33 +341,53 @@ def main(argv=None):
     models = [Model(mc, args.arch, sc, device=device, meval=meval, strict=strict, chop=chop) for mc, sc in zip(model_chain, scale_chain)]
     images = U.get_images_paths(args.input)
     os.makedirs(args.output, exist_ok=True)
-    for image_path in images:
-        img_name = osp.splitext(osp.basename(image_path))[0]
-        img = U.read_img(image_path)
-        if img is None:
-            print(f'Error reading image {image_path}, skipping.')
-            continue
-        if resize:
-            img = U.linear_resize(img, resize)
-        if use_modcrop:
-            img = U.modcrop(img, 4)
-        if len(models) == 1 and not use_guided_filter and img.dtype == np.uint8 and img.ndim == 3:
-            img_out = models[0].run_u8(img, normalize=normalize, fp16=fp16)          # conversions fused into the tile gather / blend / first and last conv
-        else:
-            t_img = U.np2tensor(img, normalize=normalize, device=device, dtype=torch.float16 if fp16 else torch.float32)
-            t_out = t_img
-            for mod in models:
-                t_out = mod(t_out)
-                if use_guided_filter:
-                    t_out = U.guided_filter(t_img, t_out, r=1, eps=5e-3)
-            img_out = U.tensor2np(t_out.detach(), denormalize=normalize)
-        if args.cf:
-            img_out = U.color_fix(img, img_out)
-        save_img_path = osp.join(args.output, f'{img_name:s}.png')
+    # The loop is pipelined over the images: one thread decodes the next image file while the GPU works on this one, up to sixteen threads
+    # encode and write finished images (PNG coding releases the GIL and is the slowest stage by far: profiles/r2/cli_pipeline.txt).  Everything that touches the GPU stays on this thread; outputs and messages are those
+    # of the serial loop, in its order.
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+
+    def save(img, img_out, path):
         if args.comp:
-            U.save_img_comp([img, img_out], save_img_path)
+            U.save_img_comp([img, img_out], path)
         else:
-            U.save_img(img_out, save_img_path)
+            U.save_img(img_out, path)
+
+    n_writers = max(2, min(16, os.cpu_count() or 2))
+    reader, writer, pending = ThreadPoolExecutor(1), ThreadPoolExecutor(n_writers), deque()
+    nxt = reader.submit(U.read_img, images[0]) if images else None
+    try:
+        for idx, image_path in enumerate(images):
+            img_name = osp.splitext(osp.basename(image_path))[0]
+            img = nxt.result()
+            nxt = reader.submit(U.read_img, images[idx + 1]) if idx + 1 < len(images) else None
+            if img is None:
+                print(f'Error reading image {image_path}, skipping.')
+                continue
+            if resize:
+                img = U.linear_resize(img, resize)
+            if use_modcrop:
+                img = U.modcrop(img, 4)
+            if len(models) == 1 and not use_guided_filter and img.dtype == np.uint8 and img.ndim == 3:
+                img_out = models[0].run_u8(img, normalize=normalize, fp16=fp16)          # conversions fused into the tile gather / blend / first and last conv
+            else:
+                t_img = U.np2tensor(img, normalize=normalize, device=device, dtype=torch.float16 if fp16 else torch.float32)
+                t_out = t_img
+                for mod in models:
+                    t_out = mod(t_out)
+                    if use_guided_filter:
+                        t_out = U.guided_filter(t_img, t_out, r=1, eps=5e-3)
+                img_out = U.tensor2np(t_out.detach(), denormalize=normalize)
+            if args.cf:
+                img_out = U.color_fix(img, img_out)
+            pending.append(writer.submit(save, img, img_out, osp.join(args.output, f'{img_name:s}.png')))
+            while len(pending) > n_writers:           # a bounded number of finished images wait for their files (an 8K RGB output is 100 MB)
+                pending.popleft().result()
+        while pending:
+            pending.popleft().result()
+    finally:
+        reader.shutdown(wait=True)
+        writer.shutdown(wait=True)
     return 0
 
 

@@ -7,6 +7,7 @@ Tolerances:
   tiles, blend (fp32), uint8 pre/post, geometry .. bit-exact
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1003,9 +1004,10 @@ def test_color_fix_vs_oracle(dev):
         U.color_fix(synth.image_u8(20, 20, 3, 1), synth.image_u8(10, 10, 3, 2), device=dev)      # LR larger than SR
 
 
-def test_command_line_image_loop(dev, tmp_path, monkeypatch):
-    """`run.py -m <chain> -i in -o out [-cf] [-comp]` (run.py:318-445) end to end on the HIP engine: files in, files out.  Two images (one
-    larger than a chop tile), a 1x + 2x model chain found by partial name in ./models; the PNGs must hold exactly what the library calls
+def test_command_line_image_loop(dev, tmp_path, monkeypatch, capsys):
+    """`run.py -m <chain> -i in -o out [-cf] [-comp]` (run.py:318-445) end to end on the HIP engine: files in, files out.  Five images (one
+    larger than a chop tile; more than the pipelined loop keeps in flight) and one file that is no image (reported and skipped, run.py:407-409),
+    a 1x + 2x model chain found by partial name in ./models; the PNGs must hold exactly what the library calls
     return and lie within one uint8 code of the oracle's fp32 forward on >= 99 % of the values."""
     import oracle
     from innfer_amd import run as R, synth
@@ -1015,11 +1017,15 @@ def test_command_line_image_loop(dev, tmp_path, monkeypatch):
     for name, scale, seed in (("1x_clean.pth", 1, 31), ("2x_up.pth", 2, 32)):
         sds[name] = _sd(synth.rrdbnet_shapes(nb=1, scale=scale), seed)
         torch.save(sds[name], str(tmp_path / "models" / name))
-    imgs = {"small": synth.image_u8(37, 52, 3, 41), "large": synth.image_u8(210, 230, 3, 42)}
+    imgs = {"small": synth.image_u8(37, 52, 3, 41), "large": synth.image_u8(210, 230, 3, 42), "a": synth.image_u8(20, 31, 3, 43),
+            "b": synth.image_u8(64, 17, 3, 44), "c": synth.image_u8(9, 9, 3, 45)}
     for k, im in imgs.items():
         U.save_img(im, str(tmp_path / "in" / f"{k}.png"))
+    (tmp_path / "in" / "broken.png").write_bytes(b"this is not a PNG file")
     monkeypatch.chdir(tmp_path)
     assert R.main(["-m", "clean+2x_up", "-i", "in", "-o", "out"]) == 0
+    assert "Error reading image" in capsys.readouterr().out and "broken.png" not in os.listdir(tmp_path / "out")
+    assert sorted(os.listdir(tmp_path / "out")) == sorted(f"{k}.png" for k in imgs)
     assert R.main(["-m", "clean+2x_up", "-i", "in", "-o", "out_cf", "-cf", "-comp"]) == 0
     m1 = R.Model(str(tmp_path / "models" / "1x_clean.pth"), "infer", 1)
     m2 = R.Model(str(tmp_path / "models" / "2x_up.pth"), "infer", 2)
