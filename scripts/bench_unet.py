@@ -31,4 +31,4 @@ for N in ([int(os.environ['UNET_N'])] if os.environ.get('UNET_N') else (1, 8, 64
                           "config": {"workload": "UnetGenerator(3,3,8,ngf 64, batch norm on the statistics of each image), 64x3x256x256 -> 64x3x256x256"},
                           "roofline": {"bound": "mfma", "achieved": round(fl / ms / 1e9, 2), "peak": 2516.6, "unit": "TFLOP/s",
                                        "frac": round(fl / ms / 1e9 / 2516.6, 4), "flops_per_forward": fl, "weight_bytes": wbytes,
-                                       "note": "whole forward (69 launches), not one kernel: the network is a chain of small GEMM-shaped layers"}}), flush=True)
+                                       "note": "whole forward (63 launches), not one kernel: the network is a chain of small GEMM-shaped layers"}}), flush=True)
