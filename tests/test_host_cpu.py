@@ -408,3 +408,41 @@ def test_small_helpers_golden():
     assert list(new.keys()) == tab["new_keys"]
     assert list(U.mod2normal(dict(new)).keys()) != [] and set(U.mod2normal(dict(new)).keys()) == set(old.keys())      # and back
     assert U.normal2mod({"a": 1}) == {"a": 1}
+
+
+def test_image_loop_is_pipelined_and_keeps_the_serial_semantics(tmp_path, monkeypatch, capsys):
+    """run.py main (reference run.py:404-442) over a folder with the model replaced by a stand-in (no GPU here): the reader / writer threads must
+    produce one PNG per readable image, holding that image's result, report and skip a file that is no image, and surface a writer's exception."""
+    from innfer_amd import run as R, synth
+    from innfer_amd.utils import utils as U
+
+    class Doubler:                                     # stands in for Model: nearest 2x of the uint8 image
+        def __init__(self, *a, **k):
+            pass
+
+        def run_u8(self, img, normalize=False, fp16=True):
+            return np.repeat(np.repeat(img, 2, 0), 2, 1)
+
+    monkeypatch.setattr(R, "Model", Doubler)
+    (tmp_path / "models").mkdir(); (tmp_path / "in").mkdir()
+    torch.save({}, str(tmp_path / "models" / "2x_standin.pth"))
+    imgs = {f"img{i:02d}": synth.image_u8(8 + i, 11 + 2 * i, 3, 700 + i) for i in range(21)}          # more images than writer threads + queue
+    for k, im in imgs.items():
+        U.save_img(im, str(tmp_path / "in" / f"{k}.png"))
+    (tmp_path / "in" / "img05b.png").write_bytes(b"no image")
+    monkeypatch.chdir(tmp_path)
+    assert R.main(["-m", "2x_standin", "-i", "in", "-o", "out"]) == 0
+    out = capsys.readouterr().out
+    assert out.count("Error reading image") == 1 and "img05b" in out
+    assert sorted(os.listdir(tmp_path / "out")) == sorted(f"{k}.png" for k in imgs)
+    for k, im in imgs.items():
+        assert np.array_equal(U.read_img(str(tmp_path / "out" / f"{k}.png")), np.repeat(np.repeat(im, 2, 0), 2, 1)), k
+    assert R.main(["-m", "2x_standin", "-i", "in", "-o", "out_comp", "-comp"]) == 0                  # LR | SR side by side (save_img_comp)
+    assert U.read_img(str(tmp_path / "out_comp" / "img00.png")).shape == (16, 44, 3)
+
+    def failing_save(*a, **k):
+        raise OSError("disk full")
+    monkeypatch.setattr(U, "save_img", failing_save)
+    with pytest.raises(OSError, match="disk full"):
+        R.main(["-m", "2x_standin", "-i", "in", "-o", "out2"])
+
