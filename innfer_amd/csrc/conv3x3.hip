@@ -1666,7 +1666,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
             if (nt != 4) return set_error(INNFER_ERR_UNSUPPORTED, "conv1x1: the running-sum operand is built for 64-channel tiles");
             return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x810>(k, L.N, s);
         }
-        return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s) : launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x10>(k, L.N, s);
+        // three input slots (a 1x1 stage has no halo): the loaders never pause between chunks -- about 1 % on PAN / PPON (kernel_experiments.txt 32)
+        return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x10, false, 3>(k, L.N, s) : launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x10, false, 3>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 2) {
         // 32-output layers: 24-row tiles, two LDS stages.  pc 5 (diagnostic builds): 16-row tiles on the three-slot input ring (continuous LDS-DMA
