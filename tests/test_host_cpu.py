@@ -236,6 +236,17 @@ def test_entry_points_report_errors_without_a_gpu():
     assert L.lib.innfer_net_flops(h, 1, 1080, 1920) == pytest.approx(35853696.0 * 1080 * 1920, rel=1e-12)
     assert L.lib.innfer_net_workspace_bytes(h, 1, 1080, 1920) > 0
     assert L.lib.innfer_net_forward(h, None, 0, None, 0, 1, 8, 8, None, 0, None) == L.ERR_INVALID
+    # input maps ('NAC' conv blocks): argument checks come before any device call
+    assert L.lib.innfer_net_set_conv_input_map(h, 999, None, None, 1) == L.ERR_INVALID
+    assert L.lib.innfer_net_set_conv_input_map(h, 1, None, None, 3) == L.ERR_INVALID                 # act: 0, 1, 2
+    assert L.lib.innfer_net_set_conv_input_map(h, 1, None, None, 1) == L.ERR_UNSUPPORTED             # a dense-block conv: no map in front of it
+    assert "model.1.sub.0.RDB1.conv1.0" in L.last_error()
+    L.check(L.lib.innfer_net_set_conv_input_map(h, 1, None, None, 0))                                # removing an absent map is fine
+    L.lib.innfer_net_destroy(h)
+    assert L.lib.innfer_srresnet_create_ex(C.byref(h), 3, 3, 32, 2, 3, 2, 1.0, 0) == L.ERR_UNSUPPORTED   # PixelShuffle(3) on 32 features
+    L.check(L.lib.innfer_srresnet_create_ex(C.byref(h), 3, 3, 64, 2, 3, 2, 1.0, 0))                      # ... on 64: conv 64 -> 576
+    L.check(L.lib.innfer_net_conv_info(h, 1 + 2 * 2 + 1, key, 128, C.byref(K), C.byref(Cc)))
+    assert (key.value.decode(), K.value, Cc.value) == ("model.2", 576, 64) and L.lib.innfer_net_scale(h) == 3
     L.lib.innfer_net_destroy(h)
 
 
