@@ -45,8 +45,8 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 105
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 106
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -80,6 +80,14 @@ int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_nc, int nf, 
  * act (0 none, 1 LeakyReLU(0.2), 2 ReLU), one elementwise launch in front of the conv.  Built for the first conv of an SRResNet block and LR_conv
  * (the norm in front of a block's second conv follows the first conv and is folded into its weights by the host).  All of NULL, NULL, 0 removes the map.  (105) */
 int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const float* h_alpha, const float* h_shift, int act);
+
+/* Arithmetic precision of innfer_net_forward, the reference's fp16 switch (`fp16 = not args.no_fp16 and gpu`, then `model.half()` / `t_img.half()`:
+ * run.py:345,383,421-422).  fp32 = 0 (default): fp16 activations and weights, fp32 accumulation.  fp32 = 1: the fp32-accurate forward -- every activation
+ * is kept as a PAIR of fp16 slabs (hi = fp16(x), lo = fp16((x - hi) * 2^11): 22 significant bits), every weight as a pair of panels, and a product is
+ * xh wh + 2^-11 (xh wl + xl wh) on the fp16 matrix cores with fp32 accumulation; input fp32 or uint8, twice the workspace (ask innfer_net_workspace_bytes
+ * after this call), three times the MFMA work.  Against the fp32 reference: <= 1e-4 on [0,1]-scaled outputs (measured ~1e-6).  Built for
+ * RRDBNet / SRResNet (every constructor variant of innfer_*_create_ex); the other generators have no fp32 mode (their Python shells raise).  (106) */
+int innfer_net_set_precision(innfer_net_t net, int fp32);
 
 void innfer_net_destroy(innfer_net_t net);
 
@@ -319,6 +327,10 @@ typedef struct {
                                            the 7x7 first convs of ResnetGenerator / UnetGeneratorWBC (ResNet_arch.py:57-60, WBCNet_arch.py:31) over their row-patch slab
                                            (channel kx * in_nc + c holds the horizontally displaced input); d_packed from innfer_pack_conv7x1(); K % 32 == 0, K <= 64,
                                            act 0 / 1 / 2, no residuals / row range / out_ch_off (104) */
+    int split;                          /* != 0: the fp32-accurate form (innfer_net_set_precision): d_in / d_out / d_res1 / d_res2 are the HI slabs of (hi, lo) pairs whose
+                                           lo slab = fp16((x - hi) * 2^11) lies in_lo / out_lo / res1_lo / res2_lo ELEMENTS behind; d_packed from innfer_pack_conv3x3_split();
+                                           K in {32, 64} for slab outputs; act 0 / 1 / 2, residuals, upsample2x, row range and batches as for the fp16 form (106) */
+    int64_t in_lo, out_lo, res1_lo, res2_lo;
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);
@@ -331,12 +343,18 @@ int innfer_pack_conv4x4s2(const float* h_weight_oihw, int K, int C, void* h_pack
 size_t innfer_convt2x_packed_bytes(int K, int C);
 int innfer_pack_convt2x(const float* h_weight_iohw, int K, int C, int k, void* h_packed);
 int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream);
+/* Panels of the split form: 3 * innfer_conv3x3_packed_bytes(K, C) bytes ((w - wh) * 2^11 | wh | wh, in the order the kernel's virtual chunks meet them).  (106) */
+int innfer_pack_conv3x3_split(const float* h_weight_oihw, int K, int C, void* h_packed);
 
 /* NCHW (f16/f32) <-> blocked-NHWC f16 slab helpers used by tests of the single conv. */
 int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int64_t group_stride, int ch_off,
                         int N, int C, int H, int W, void* stream);
 int innfer_slab_to_nchw(const void* d_slab, int64_t group_stride, int ch_off, void* d_dst, int dst_dtype,
                         int N, int C, int H, int W, void* stream);
+/* The same for the (hi, lo) slab pairs of the fp32-accurate mode: fp32 NCHW -> hi slab at d_slab, lo slab `lo` elements behind it, and back
+ * (hi + lo * 2^-11, exact in fp32).  (106) */
+int innfer_nchw_to_slab_split(const float* d_src, void* d_slab, int64_t group_stride, int64_t lo, int ch_off, int N, int C, int H, int W, void* stream);
+int innfer_slab_split_to_nchw(const void* d_slab, int64_t group_stride, int64_t lo, int ch_off, float* d_dst, int N, int C, int H, int W, void* stream);
 
 /* ------------------------------------------------------------ chop / blend
  * Replaces extract_patches_2d / recompose_tensor (utils/utils.py:318-369,

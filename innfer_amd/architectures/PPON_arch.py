@@ -23,8 +23,7 @@ class PPON(ParamEngineModule):
             raise ValueError('expected a 4D [N,C,H,W] tensor')
         if not x.is_cuda:
             raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
-        if x.dtype not in (torch.float16, torch.float32):
-            raise TypeError(f'unsupported dtype {x.dtype}')
+        self._check_dtype(x)
         self._upload()
         x = x.contiguous()
         N, _, H, W = x.shape

@@ -51,13 +51,29 @@ class EngineModule(nn.Module):
 
     # ---- weight upload (load time, not forward time) -------------------------
     def _weights_version(self):
-        # (data pointer, in-place version) of every tensor the engine was loaded from.  The tensor OBJECTS never change (load_state_dict and
-        # .to() work in place on them), so the walk over the module tree -- ~700 parameters for RRDBNet-23 -- is done once, not per forward.
+        # (data pointer, in-place version) of every tensor the engine was loaded from.  The walk over the module tree -- ~700 parameters for
+        # RRDBNet-23 -- is cached; everything that REBINDS tensor objects drops the cache: nn.Module._apply (.to / .cuda / .half replace buffers,
+        # and parameters under torch.__future__.set_overwrite_module_params_on_conversion) and load_state_dict (assign=True).
         ts = self.__dict__.get('_version_tensors')
         if ts is None:
             ts = list(self.parameters()) + list(self.buffers())
             self.__dict__['_version_tensors'] = ts
         return tuple([(t.data_ptr(), t._version) for t in ts])
+
+    def invalidate_weights(self):
+        """Forget which tensors the engine was loaded from: the next forward walks the module tree again and re-uploads if anything differs.
+        Call it after replacing a parameter / buffer OBJECT of a sub-module by hand (setattr, register_buffer)."""
+        self.__dict__.pop('_version_tensors', None)
+
+    def _apply(self, fn, *args, **kwargs):
+        r = super()._apply(fn, *args, **kwargs)
+        self.invalidate_weights()
+        return r
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weights()
+        return r
 
     def _ensure_engine(self):
         ver = self._weights_version()
@@ -108,7 +124,9 @@ class EngineModule(nn.Module):
     _OUTM = {None: 0, 'scaltanh': 1, 'tanh': 2, 'sigmoid': 3, 'clamp': 4}
 
     def forward(self, x, outm=None):
-        """outm: the range limiter of RRDBNet.forward / SRResNet.forward (RRDBNet_arch.py:50-62); any other value means none, as there."""
+        """outm: the range limiter of RRDBNet.forward / SRResNet.forward (RRDBNet_arch.py:50-62); any other value means none, as there.
+        The input's dtype selects the arithmetic, as `model.half()` / `t_img.half()` do in the reference (run.py:345,383,421-422): a float16 tensor
+        runs the fp16 engine, a float32 tensor the fp32-accurate one (innfer_net_set_precision: <= 1e-4 against the fp32 reference, 3x the MFMA work)."""
         self._outm = self._OUTM.get(outm, 0)
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise ValueError('expected a 4D [N,C,H,W] tensor')
@@ -131,6 +149,7 @@ class EngineModule(nn.Module):
         L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
         L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
         L.check(L.lib.innfer_net_set_outm(self._handle, int(getattr(self, '_outm', 0))))
+        L.check(L.lib.innfer_net_set_precision(self._handle, int(x.dtype == torch.float32)))
         x = x.contiguous()
         N, _, H, W = x.shape
         s = L.lib.innfer_net_scale(self._handle)
@@ -161,6 +180,7 @@ class EngineModule(nn.Module):
             L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
             L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
             L.check(L.lib.innfer_net_set_u8_io(self._handle, int(bool(normalize)), int(bool(fp16))))
+            L.check(L.lib.innfer_net_set_precision(self._handle, int(not fp16)))
             L.check(L.lib.innfer_net_set_outm(self._handle, 0))
             x = img.contiguous()
             batched = x.dim() == 4

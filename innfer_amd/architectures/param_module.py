@@ -53,9 +53,22 @@ class ParamEngineModule(nn.Module):
             except Exception:
                 pass
 
+    def invalidate_weights(self):
+        self.__dict__.pop('_version_tensors', None)
+
+    def _apply(self, fn, *args, **kwargs):          # .to / .cuda / .half rebind buffers: drop the cached walk of the module tree
+        r = super()._apply(fn, *args, **kwargs)
+        self.invalidate_weights()
+        return r
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weights()
+        return r
+
     def _upload(self):
         # parameters AND buffers: the running statistics of a BatchNorm are part of an eval()-mode forward
-        ts = self.__dict__.get('_version_tensors')      # the tensor objects never change: walk the module tree once
+        ts = self.__dict__.get('_version_tensors')      # walked once; _apply / load_state_dict drop the cache
         if ts is None:
             ts = list(self.parameters()) + list(self.buffers())
             self.__dict__['_version_tensors'] = ts
@@ -73,13 +86,22 @@ class ParamEngineModule(nn.Module):
     def _out_shape(self, N, H, W):
         raise NotImplementedError
 
+    def _check_dtype(self, x):
+        """The input's dtype is the arithmetic the caller asks for (the reference: model.half() / t_img.half(), run.py:345,383,421-422).  These
+        engines compute in fp16 with fp32 accumulation and nothing else: a float32 tensor is refused rather than served at fp16 accuracy."""
+        if x.dtype == torch.float32:
+            raise NotImplementedError(
+                f"{type(self).__name__}: no fp32-accurate engine is built for this generator -- its kernels compute in fp16 (fp32 accumulation).  Pass "
+                "x.half() (the reference's default mode, run.py:345,421-422) and call .float() on the result; RRDBNet / SRResNet take float32 tensors.")
+        if x.dtype != torch.float16:
+            raise TypeError(f'unsupported dtype {x.dtype}')
+
     def forward(self, x):
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise ValueError('expected a 4D [N,C,H,W] tensor')
         if not x.is_cuda:
             raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
-        if x.dtype not in (torch.float16, torch.float32):
-            raise TypeError(f'unsupported dtype {x.dtype}')
+        self._check_dtype(x)
         with torch.cuda.device(x.device):        # the library allocates and launches on the process's current HIP device
             return self._forward_on_device(x)
 

@@ -76,6 +76,9 @@ struct ConvLaunch {
     int outm;                                     // OUT_NCHW: `outm` of RRDBNet / SRResNet.forward applied after `act`: 1 (tanh + 1) / 2, 2 tanh, 3 sigmoid, 4 clamp(0, 1)
     int out_u8, out_denorm, out_round16;          // OUT_NCHW with <= 4 channels: write a uint8 HWC BGR(A) image instead -- tensor2np as the conv's epilogue
                                                   // (utils.py:197-248): [round to fp16,] optional denormalisation, clip(255 x).round() half to even, channel flip
+    int split;                                    // fp32-accurate mode: every tensor is a (hi, lo) pair of fp16 slabs, lo = fp16((x - hi) * 2^11) (conv3x3.hip, SPLIT); panels from
+    long in_lo, out_lo, res1_lo, res2_lo;         // conv_pack_split / conv_pack_1x1_split; *_lo: distance (elements) from a hi slab to its lo twin.  Plain 3x3 / 1x1 slab convs
+                                                  // (act 0..2, residuals, upsampled input, batches) and the planar last conv
     const f16* pair_wpk; const float* pair_bias;  // net.hip only: non-null = this 32-output LeakyReLU conv AND the next one of the dense block (inputs: the same
                                                   // C channels + this conv's output, output: the following channel group) as one conv_pair_launch
 };
@@ -96,6 +99,8 @@ int conv_pair_launch(const ConvPairLaunch& L, hipStream_t s);
 int conv_nt_for(int K);                           // 16-channel tiles per group: 1, 2 or 4
 size_t conv_packed_bytes(int K, int C);
 void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
+void conv_pack_split(const float* w_oihw, int K, int C, void* packed);     // host; 3 * conv_packed_bytes(K, C): the (wl | wh | wh) panels of ConvLaunch.split
+void conv_pack_1x1_split(const float* w_oi, int K, int C, void* packed);   // host; 3 * conv_packed_bytes_taps(K, C, 0x10)
 int conv_launch(const ConvLaunch& L, hipStream_t s);
 size_t conv_packed_bytes_taps(int K, int C, int mask);
 void conv_pack_1x1(const float* w_oi, int K, int C, void* packed);    // host; w [K][C]
@@ -119,6 +124,7 @@ struct FirstConvLaunch {
     const float* bias;
     f16* out; long out_gstride; f16* out2; long out2_gstride;
     int K; int N, H, W; int act;
+    long out_lo, out2_lo;                         // != 0: split output (ConvLaunch.split): the lo part of every value goes this many elements behind its hi part
 };
 int first_conv_launch(const FirstConvLaunch& L, hipStream_t s);
 

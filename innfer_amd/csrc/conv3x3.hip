@@ -105,6 +105,8 @@ struct KP {
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
     int total;               // tiles x channel groups of this launch
     int cv_gx, cv_gy, cv_h1, cv_w1;   // CV kernels (image canvas): the N images are the cells of a cv_gx x cv_gy grid, cell pitch (H + 1) x (W + 1)
+    long in_lo_bytes;        // SPLIT kernels (TMF | 0x2000): the low-part twin of the input slab lies this many bytes behind it,
+    long out_lo, res1_lo, res2_lo;   //   those of the output / residual slabs this many ELEMENTS behind them
 #ifdef INNFER_ABLATE
     int abl;                 // diagnostic build only: 1 no stores, 2 no weight DMA, 4 no input DMA, 8 no MFMA phase
 #endif
@@ -266,6 +268,69 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
                 h[j] = (f16)f;
             }
             *(f16x4*)(op + 4 * t) = h;
+        }
+    }
+}
+
+// SPLIT (fp32-accurate mode, conv3x3_pc<.., TMF | 0x2000>): a tensor is a PAIR of fp16 slabs -- hi = fp16(x) and lo = fp16((x - hi) * 2^11), the lo slab a
+// fixed distance behind the hi slab -- i.e. 22 significant bits per value with the fp16 kernels' data path.  The epilogue works on the fp32
+// accumulators exactly like the fp16 one (activation, *s1 + res1, *s2 + res2 with explicit fmaf) but reads its residuals as hi + lo * 2^-11 (exact
+// in fp32) and stores both parts.  CV: image-canvas addressing (see epilogue_slab_cv).
+constexpr float SPLIT_UP = 2048.0f, SPLIT_DOWN = 1.0f / 2048.0f;
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool CV>
+__device__ __forceinline__ void epilogue_slab_split(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0, int wave, int li, int cbase) {
+    constexpr int MT = 2 * RPW;
+    const int oc0 = cbase + p.out_coff;
+    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + (oc0 & 31);
+    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + (cbase & 31) : nullptr;
+    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + (cbase & 31) : nullptr;
+    int cyB = 0, yB = 0, cxB = 0, xB = 0;
+    if constexpr (CV) {
+        cyB = ty0 / p.cv_h1; yB = ty0 - cyB * p.cv_h1 + wave * RPW;
+        cxB = tx0 / p.cv_w1; xB = tx0 - cxB * p.cv_w1 + li;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        bool ok;
+        long off;                                  // element offset of the pixel inside a channel group
+        if constexpr (CV) {
+            int y = yB + (m >> 1), cy = cyB;
+            if (y >= p.cv_h1) { y -= p.cv_h1; ++cy; }
+            int x = xB + (m & 1) * 16, cx = cxB;
+            if (x >= p.cv_w1) { x -= p.cv_w1; ++cx; }
+            const int nn = cy * p.cv_gx + cx;
+            ok = y < p.H && x < p.W && cy < p.cv_gy && cx < p.cv_gx && nn < p.N;
+            off = (((long)nn * p.H + y) * p.W + x) * 32;
+        } else {
+            const int y = ty0 + wave * RPW + (m >> 1), x = tx0 + li + (m & 1) * 16;
+            ok = y < p.y1 && x < p.W;
+            off = (((long)n * p.H + y) * p.W + x) * 32;
+        }
+        if (!ok) continue;
+        f16x4 r1h[NT], r1l[NT], r2h[NT], r2l[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (R1) { r1h[t] = *(const f16x4*)(r1b + off + 4 * t); r1l[t] = *(const f16x4*)(r1b + p.res1_lo + off + 4 * t); }
+            if (R2) { r2h[t] = *(const f16x4*)(r2b + off + 4 * t); r2l[t] = *(const f16x4*)(r2b + p.res2_lo + off + 4 * t); }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = acc[t][m][j];
+                if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                if (R1) f = __builtin_fmaf(f, p.s1, __builtin_fmaf((float)r1l[t][j], SPLIT_DOWN, (float)r1h[t][j]));
+                if (R2) f = __builtin_fmaf(f, p.s2, __builtin_fmaf((float)r2l[t][j], SPLIT_DOWN, (float)r2h[t][j]));
+                FP32_VALUE(f);
+                h[j] = (f16)f;
+                float d = f - (float)h[j];
+                FP32_VALUE(d);
+                l[j] = (f16)(d * SPLIT_UP);
+            }
+            *(f16x4*)(ob + off + 4 * t) = h;
+            *(f16x4*)(ob + p.out_lo + off + 4 * t) = l;
         }
     }
 }
@@ -719,6 +784,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // fp32 running sums of its own pixels in registers (same additions in the same order as that pass made: same bits)
     constexpr bool PFX = (TMF & 0x800) != 0;
     constexpr bool STATS = (TMF & 0x1000) != 0;          // + 0x1000: partial norm statistics out of the epilogue (epilogue_stats)
+    // + 0x2000: fp32-accurate mode on split operands.  A tensor is a pair of fp16 slabs (hi, lo = (x - hi) * 2^11; see epilogue_slab_split), a weight
+    // likewise a pair of panels, and x * w = xh * wh + 2^-11 (xh * wl + xl * wh) (the 2^-22 term is dropped): the launch runs 3 * ncg virtual chunks --
+    // [0, ncg) stage (xh, wl), [ncg, 2 ncg) (xl, wh), [2 ncg, 3 ncg) (xh, wh) (panels packed in that order by conv_pack_split); the accumulators start
+    // at zero, are scaled by 2^-11 (exact) and receive the bias when the third part begins: ONE accumulator set, the fp16 kernel's MFMA stream.
+    constexpr bool SPLIT = (TMF & 0x2000) != 0;
+    static_assert(!SPLIT || (!S9 && !POLY && !S2 && !PFX && !STATS && (TM == 0x1FF || TM == 0x10)), "split operands: plain 3x3 and 1x1 convs");
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -909,6 +980,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         auto issue_to = [&](int c, char* st_i, char* st_w, const char* wsrc, int what) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const char* src = in_tile + c * p.in_gbytes;
+            if constexpr (SPLIT) {               // virtual chunk -> (part, channel group): parts 0 and 2 read the hi slab, part 1 the lo slab
+                const int part = c >= 2 * p.ncg ? 2 : (c >= p.ncg ? 1 : 0);
+                src = in_tile + (c - part * p.ncg) * p.in_gbytes + (part == 1 ? p.in_lo_bytes : 0);
+            }
             if constexpr (S9) {
                 const int sub = c / p.ncg, cg = c - sub * p.ncg;
                 const int sy = p.s9v ? 3 * (sub - 1) : 3 * (sub / 3 - 1), sx = p.s9v ? 0 : 3 * (sub % 3 - 1);
@@ -1082,7 +1157,17 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[t][m] = bias_r[t];
+                for (int m = 0; m < MT; ++m) acc[t][m] = SPLIT ? f32x4{0.f, 0.f, 0.f, 0.f} : bias_r[t];
+        }
+        if constexpr (SPLIT) {
+            if (c == 2 * p.ncg) {                    // the two cross terms are complete: scale them down (exact) and go on with xh * wh on top of the bias
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[t][m][j] = __builtin_fmaf(acc[t][m][j], SPLIT_DOWN, bias_r[t][j]);
+            }
         }
         const char* st = NSI == 3 ? smem + islot * IN_BYTES : smem + (g & 1) * STAGE;                       // halo tile
         const char* sw = NSI == 3 ? smem + 3 * IN_BYTES + (g & 1) * W_BYTES : st + IN_BYTES;              // weight panel
@@ -1190,7 +1275,17 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pfx[m][e] = 0.f;
             }
-            if constexpr (OUTMODE == OUT_SLAB && CV) {
+            if constexpr (OUTMODE == OUT_SLAB && SPLIT) {
+#define EPI(A, B, C) epilogue_slab_split<RPW, NT, A, B, C, CV>(p, acc, n, ty0, tx0, cw, li, cbase)
+            if (!p.res1) {
+                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
+            } else if (!p.res2) {
+                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
+            } else {
+                if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
+            }
+#undef EPI
+            } else if constexpr (OUTMODE == OUT_SLAB && CV) {
 #define EPI(A, B, C) epilogue_slab_cv<RPW, NT, A, B, C>(p, acc, ty0, tx0, cw, li, cbase)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
@@ -1354,13 +1449,13 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (__builtin_popcount(TM & 0x1FF) * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
-    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && TM == 0x1FF && !CV) {      // a batch of images whose size is not a whole number of tiles
+    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x2000) == 0x1FF && !CV) {      // a batch of images whose size is not a whole number of tiles
         int gy = 0; long t = 0;
         const int gx = INNFER_KNOB("INNFER_CANVAS", 1) ? canvas_grid<TH>(kp, N, &gy, &t) : 0;
         if (gx > 0) {
             KP kc = kp;
             kc.cv_gx = gx; kc.cv_gy = gy; kc.cv_h1 = kp.H + 1; kc.cv_w1 = kp.W + 1;
-            return launch_pc<RPW, NT, NLW, OUTMODE, false, false, 0x1FF, true, NSI, NCW>(kc, N, s);
+            return launch_pc<RPW, NT, NLW, OUTMODE, false, false, TM, true, NSI, NCW>(kc, N, s);
         }
     }
     static unsigned long long attr_done = 0;
@@ -1479,6 +1574,25 @@ void conv_pack_taps(const float* w, int K, int C, int mask, void* packed) {
                 }
             }
 }
+// fp32-accurate mode (ConvLaunch.split): the panels of the equivalent conv over 3 C virtual input channels -- (w - wh) * 2^11 for the chunks that meet
+// the hi slab first, then wh twice (lo slab, hi slab); every value is exactly representable, so conv_pack's fp16 conversion is the split itself
+static std::vector<float> split_weights(const float* w, int K, int C, int taps) {
+    std::vector<float> v((size_t)K * 3 * C * taps);
+    for (int k = 0; k < K; ++k)
+        for (int c = 0; c < C; ++c)
+            for (int t = 0; t < taps; ++t) {
+                const float x = w[((size_t)k * C + c) * taps + t];
+                const float h = (float)(f16)x;
+                const float l = (float)(f16)((x - h) * 2048.0f);
+                v[((size_t)k * 3 * C + c) * taps + t] = l;
+                v[((size_t)k * 3 * C + C + c) * taps + t] = h;
+                v[((size_t)k * 3 * C + 2 * C + c) * taps + t] = h;
+            }
+    return v;
+}
+void conv_pack_split(const float* w, int K, int C, void* packed) { conv_pack(split_weights(w, K, C, 9).data(), K, 3 * C, packed); }
+void conv_pack_1x1_split(const float* w, int K, int C, void* packed) { conv_pack_1x1(split_weights(w, K, C, 1).data(), K, 3 * C, packed); }
+
 void conv_pack_1x1(const float* w, int K, int C, void* packed) {
     const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
     f16* dst = (f16*)packed;
@@ -1615,6 +1729,20 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     const int pc = INNFER_KNOB("INNFER_PC", 1);     // producer / consumer kernel for slab outputs
     if (L.outm && (L.out_mode != OUT_NCHW || !pc || nt != 1 || L.res1 || L.res2 || L.outm < 0 || L.outm > 4))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: outm belongs to the planar last conv (<= 16 channels)");
+    if (L.split) {           // fp32-accurate mode on (hi, lo) slab pairs: 3 * C / 32 virtual chunks (conv3x3_pc<.., TMF | 0x2000>)
+        if (!pc || (L.act > 2 && !((L.act == 3 || L.act == 6) && L.out_mode == OUT_NCHW)) || L.reflect || L.dilation > 1 || L.dilation_groups || L.deconv_phases || L.stride2 || L.conv7v || L.conv7 || L.stats_part ||
+            L.prefix_lrelu || L.phase_c || L.pair_wpk || (long)3 * L.C / 32 > 0x7fff)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (fp32 mode): plain 3x3 / 1x1 convs with act 0..2, residuals, upsampled input");
+        k.nchunks = 3 * k.ncg;
+        k.in_lo_bytes = L.in_lo * 2; k.out_lo = L.out_lo; k.res1_lo = L.res1_lo; k.res2_lo = L.res2_lo;
+        if (L.out_mode == OUT_SLAB && L.conv1x1 && (nt == 2 || nt == 4))
+            return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x2010, false, 3>(k, L.N, s) : launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x2010, false, 3>(k, L.N, s);
+        if (L.conv1x1) return set_error(INNFER_ERR_UNSUPPORTED, "conv1x1 (fp32 mode): slab outputs of 32- / 64-channel tiles");
+        if (L.out_mode == OUT_SLAB && nt == 2) return launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x21FF>(k, L.N, s);
+        if (L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x21FF>(k, L.N, s);
+        if (L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2) return launch_pc<3, 1, 4, OUT_NCHW, false, false, 0x21FF>(k, L.N, s);
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (fp32 mode): slab outputs of 32- / 64-channel tiles or a planar output of <= 16 channels (K=%d)", L.K);
+    }
     if (L.dilation_groups > 0) {   // K = 32 * groups: output channel group g (its own 32-output panel) is the conv of dilation g + 1
         if (!pc || L.out_mode != OUT_SLAB || L.K != 32 * L.dilation_groups || L.dilation_groups > 8 || L.res1 || L.res2 || L.up || L.reflect ||
             L.y0 != 0 || k.y1 != L.H || (long)L.H * L.W * 64 >= 0x7fffffffL)

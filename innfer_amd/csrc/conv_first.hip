@@ -20,6 +20,7 @@ struct FP {
     const float* w; const float* bias;
     f16* out; long out_gstride; f16* out2; long out2_gstride;
     int K; long npix; int H, W; int act;
+    long out_lo, out2_lo;          // != 0: fp32-accurate mode -- the lo part fp16((f - hi) * 2^11) of every value goes this many elements behind its hi part
 };
 
 // One input value of the first conv: planar fp16 / fp32, or np2tensor of a uint8 HWC image (float32(u8) / 255, BGR -> RGB flip as in
@@ -70,16 +71,19 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
             }
         }
     }
-    f16x8 h;
+    f16x8 h, l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float f = acc[e];
         if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
         else if (p.act == 2) f = f > 0.f ? f : 0.f;
         h[e] = (f16)f;
+        l[e] = (f16)((f - (float)h[e]) * 2048.0f);
     }
     *(f16x8*)(p.out + (cg >> 5) * p.out_gstride + pix * 32 + (cg & 31)) = h;
     if (p.out2) *(f16x8*)(p.out2 + (cg >> 5) * p.out2_gstride + pix * 32 + (cg & 31)) = h;
+    if (p.out_lo) *(f16x8*)(p.out + p.out_lo + (cg >> 5) * p.out_gstride + pix * 32 + (cg & 31)) = l;
+    if (p.out2 && p.out2_lo) *(f16x8*)(p.out2 + p.out2_lo + (cg >> 5) * p.out2_gstride + pix * 32 + (cg & 31)) = l;
 }
 
 // The same conv on the matrix cores (K = 32 or 64 outputs): the 9 * Cin taps of a pixel are the k dimension of a 16 x 16 x 32 MFMA
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
             }
         }
         if (!live) continue;
-        f16 h[4 * NT];
+        f16 h[4 * NT], l[4 * NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
                 if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
                 else if (p.act == 2) f = f > 0.f ? f : 0.f;
                 h[4 * t + j] = (f16)f;
+                l[4 * t + j] = (f16)((f - (float)h[4 * t + j]) * 2048.0f);
             }
         const long o1 = (cb >> 5) * p.out_gstride + pix * 32 + (cb & 31);
         const long o2 = (cb >> 5) * p.out2_gstride + pix * 32 + (cb & 31);
@@ -168,6 +173,12 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
             for (int e = 0; e < 8; ++e) v[e] = h[8 * q + e];
             *(f16x8*)(p.out + o1 + 8 * q) = v;
             if (p.out2) *(f16x8*)(p.out2 + o2 + 8 * q) = v;
+            if (p.out_lo) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = l[8 * q + e];
+                *(f16x8*)(p.out + p.out_lo + o1 + 8 * q) = v;
+                if (p.out2) *(f16x8*)(p.out2 + p.out2_lo + o2 + 8 * q) = v;
+            }
         }
     }
 }
@@ -179,7 +190,7 @@ int first_conv_launch(const FirstConvLaunch& L, hipStream_t s) {
         return set_error(INNFER_ERR_UNSUPPORTED, "first conv: nf=%d must be a multiple of 8, <= 256", L.K);
     if (L.Cin < 1 || L.Cin > 8) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: in_nc=%d unsupported", L.Cin);
     FP p{L.in, L.in_f32, L.Cin, L.in_u8, L.in_norm, L.in_round16, L.w, L.bias, L.out, L.out_gstride, L.out2, L.out2_gstride,
-         L.K, (long)L.N * L.H * L.W, L.H, L.W, L.act};
+         L.K, (long)L.N * L.H * L.W, L.H, L.W, L.act, L.out_lo, L.out2_lo};
     if ((L.K == 32 || L.K == 64) && INNFER_KNOB("INNFER_FIRST_MFMA", 1)) {
         const long groups = (p.npix + 15) / 16, want = (groups + 3) / 4;
         const long grid = want < 8192 ? want : 8192;                 // 32 waves' worth of pixel groups per CU in flight, the rest by striding

@@ -37,6 +37,8 @@ struct ConvSlot {
     bool first = false;          // small-Cin VALU conv (fp32 [C*9][K] weights)
     int ksize = 3;               // 1: a 1x1 conv (one-tap panel, ConvLaunch.conv1x1)
     void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
+    std::vector<float> h_w;      // MFMA convs: the fp32 weights as they were set, kept for the fp32-accurate mode's panels
+    void* d_w32 = nullptr;       //   (hi | lo | hi) panels of conv_pack_split, built on the first forward in that mode
     float* d_b = nullptr;        // bias padded to the panel width
     bool loaded = false;
     // mode 'NAC' conv blocks (block.py:246-254: norm -> act -> conv): the conv reads act(alpha[c] * x + shift[c]); an elementwise pass in front of it
@@ -58,6 +60,7 @@ struct innfer_net {
     int u8_normalize = 0, u8_round16 = 1;   // innfer_net_forward with INNFER_U8 images: normalize / denormalize flags of np2tensor / tensor2np, fp16 mode
     int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
+    int fp32 = 0;                // innfer_net_set_precision: 1 = fp32-accurate forward on split operands (conv3x3.hip SPLIT), the reference's -no_fp16 mode (run.py:345,421-422)
     std::vector<ConvSlot> convs;
 };
 
@@ -172,6 +175,7 @@ extern "C" void innfer_net_destroy(innfer_net_t net) {
     for (auto& c : net->convs) {
         if (c.d_w) (void)hipFree(c.d_w);
         if (c.d_b) (void)hipFree(c.d_b);
+        if (c.d_w32) (void)hipFree(c.d_w32);
         if (c.d_map) (void)hipFree(c.d_map);
     }
     delete net;
@@ -211,6 +215,8 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
         }
         const int per = 16 * conv_nt_for(c.K);
         bias_n = (size_t)((c.K + per - 1) / per) * per;
+        c.h_w.assign(w, w + (size_t)c.K * c.C * c.ksize * c.ksize);
+        if (c.d_w32) { (void)hipFree(c.d_w32); c.d_w32 = nullptr; }
     }
     std::vector<float> bias(bias_n, 0.f);
     if (b) for (int k = 0; k < c.K; ++k) bias[k] = b[k];
@@ -237,6 +243,15 @@ extern "C" int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const fl
     if (!c.d_map) INNFER_HIP(hipMalloc((void**)&c.d_map, h.size() * sizeof(float)));
     INNFER_HIP(hipMemcpy(c.d_map, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     c.map_act = act;
+    return INNFER_OK;
+}
+
+// fp32 = 1: the forward keeps fp32 accuracy -- every activation is a pair of fp16 slabs (hi, lo = (x - hi) * 2^11: 22 significant bits), every weight a
+// pair of panels, products are xh wh + 2^-11 (xh wl + xl wh) on the fp16 MFMA path with fp32 accumulation (conv3x3.hip, SPLIT): three times the MFMA
+// work and twice the bytes of the fp16 forward.  The reference's fp32 mode on the GPU (`-no_fp16`: run.py:345,421-422).
+extern "C" int innfer_net_set_precision(innfer_net_t net, int fp32) {
+    if (!net || (fp32 != 0 && fp32 != 1)) return set_error(INNFER_ERR_INVALID, "set_precision: 0 (fp16 arithmetic) or 1 (fp32-accurate)");
+    net->fp32 = fp32;
     return INNFER_OK;
 }
 
@@ -295,6 +310,7 @@ extern "C" double innfer_net_flops(innfer_net_t net, int N, int H, int W) {
 //   hr         [N,sH,sW,nf]             HR_conv0 output
 struct Carve {
     size_t fea, slab[3], trunk, up[5], hr, tmp, total;
+    size_t lo;                   // fp32-accurate mode: every buffer's lo twin lies `lo` bytes behind it (the second half of the workspace)
     int slab_w;
 };
 
@@ -311,7 +327,8 @@ static Carve carve(const innfer_net* net, int N, int H, int W) {
     size_t m = 1;
     for (int u = 0; u < net->n_up; ++u) { m *= net->scale == 3 ? 9 : 4; c.up[u] = off; off += al(px * m * net->nf * 2); }
     c.hr = off; off += al(px * m * net->nf * 2);
-    c.total = off;
+    c.lo = net->fp32 ? off : 0;
+    c.total = net->fp32 ? 2 * off : off;
     return c;
 }
 
@@ -402,7 +419,8 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
     const double obytes = L.out_mode == OUT_NCHW ? (L.out_u8 ? 1.0 : L.out_f32 ? 4.0 : 2.0) : 2.0;
     const double bytes = px * (L.C * 2.0 / (L.up ? 4.0 : 1.0) + L.K * obytes + (L.res1 ? L.K * 2.0 : 0.0) + (L.res2 ? L.K * 2.0 : 0.0))
                          + (double)taps * L.K * L.C * 2.0;
-    return timed_end(s, 2.0 * taps * L.K * L.C * px, bytes, 16 * conv_nt_for(L.K) + L.out_mode);
+    // (fp32-accurate mode: the same algorithmic FLOPs -- executed: 3x --, two slabs per tensor, three panels per weight)
+    return timed_end(s, 2.0 * taps * L.K * L.C * px, L.split ? 2.0 * bytes + (double)taps * L.K * L.C * 2.0 : bytes, 16 * conv_nt_for(L.K) + L.out_mode + (L.split ? 1000 : 0));
 }
 
 // nearest-neighbour upsampling of a slab by an integer factor (src = dst / f, block.py:321-322).  The 2x case is folded into the conv's input
@@ -443,6 +461,29 @@ __global__ void slab_input_map(const f16* src, f16* dst, long g_elems, int group
     *(f16x8*)(dst + g * g_elems + r * 8) = y;
 }
 
+// The same on the (hi, lo) slab pairs of the fp32-accurate mode: x = hi + lo * 2^-11, mapped in fp32, split again
+__global__ void slab_input_map_split(const f16* src, f16* dst, long lo, long g_elems, int groups, const float* map, int C, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = g_elems / 8;
+    if (i >= per * groups) return;
+    const int g = (int)(i / per);
+    const long r = i % per;
+    const int c = g * 32 + (int)(r & 3) * 8;
+    const f16x8 xh = *(const f16x8*)(src + g * g_elems + r * 8), xl = *(const f16x8*)(src + lo + g * g_elems + r * 8);
+    f16x8 yh, yl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = __builtin_fmaf((float)xl[e], 1.0f / 2048.0f, (float)xh[e]);
+        float v = c + e < C ? x * map[c + e] + map[C + c + e] : 0.f;
+        if (act == 1) v = fmaxf(v, 0.2f * v);
+        else if (act == 2) v = fmaxf(v, 0.f);
+        yh[e] = (f16)v;
+        yl[e] = (f16)((v - (float)yh[e]) * 2048.0f);
+    }
+    *(f16x8*)(dst + g * g_elems + r * 8) = yh;
+    *(f16x8*)(dst + lo + g * g_elems + r * 8) = yl;
+}
+
 // PixelShuffle(r) between slabs: out[n, y r + i, x r + j, c] = in[n, y, x, c r^2 + i r + j] (torch.nn.PixelShuffle); 8 output channels per thread
 __global__ void slab_pixel_shuffle(const f16* src, long src_g, f16* dst, long dst_g, int nf, int N, int H, int W, int r) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -463,10 +504,11 @@ __global__ void slab_pixel_shuffle(const f16* src, long src_g, f16* dst, long ds
     *(f16x8*)(dst + (long)(c >> 5) * dst_g + m * 32 + (c & 31)) = v;
 }
 
-int do_input_map(const ConvSlot& cs, const f16* src, f16* dst, long G, hipStream_t s) {
+int do_input_map(const ConvSlot& cs, const f16* src, f16* dst, long G, hipStream_t s, long lo = 0) {
     const int groups = (cs.C + 31) / 32;
     const long n = G / 8 * groups;
-    hipLaunchKernelGGL(slab_input_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, G, groups, (const float*)cs.d_map, cs.C, cs.map_act);
+    if (lo) hipLaunchKernelGGL(slab_input_map_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, lo, G, groups, (const float*)cs.d_map, cs.C, cs.map_act);
+    else hipLaunchKernelGGL(slab_input_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, G, groups, (const float*)cs.d_map, cs.C, cs.map_act);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -487,11 +529,13 @@ struct Plan {                    // one MFMA conv in the launch list
 };
 
 // in/out point at channel 0 of the tensors; *_g are their group strides (elements).
-ConvLaunch mk(const ConvSlot& cs, const f16* in, long in_g, void* out, long out_g,
-              int N, int H, int W, int act) {
+// lo > 0: fp32-accurate mode, every slab's lo twin `lo` elements behind it
+ConvLaunch mk_launch(const ConvSlot& cs, const f16* in, long in_g, void* out, long out_g,
+                     int N, int H, int W, int act, long lo) {
     ConvLaunch L{};
     L.in = in; L.in_gstride = in_g; L.C = cs.C;
-    L.wpk = (const f16*)cs.d_w; L.bias = cs.d_b;
+    L.wpk = (const f16*)(lo ? cs.d_w32 : cs.d_w); L.bias = cs.d_b;
+    if (lo) { L.split = 1; L.in_lo = L.out_lo = L.res1_lo = L.res2_lo = lo; }
     L.out = out; L.out_gstride = out_g; L.out_coff = 0; L.K = cs.K;
     L.N = N; L.H = H; L.W = W; L.act = act;
     L.s1 = 1.f; L.s2 = 1.f;
@@ -547,6 +591,21 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     char* ws = (char*)d_ws;
     const int nf = net->nf, gc = net->gc;
     const long G = (long)N * H * W * 32;          // group stride of every LR-resolution slab
+    const long LO = (long)(cv.lo / 2);            // fp32-accurate mode: elements from a slab to its lo twin (0: fp16 mode)
+    if (net->fp32) {
+        if (in_dtype == INNFER_F16) return set_error(INNFER_ERR_INVALID, "forward: the fp32-accurate mode takes fp32 or uint8 input (an fp16 tensor is the fp16 mode's)");
+        for (auto& c : net->convs) {
+            if (c.first || c.d_w32) continue;
+            std::vector<char> host(3 * (c.ksize == 1 ? conv_packed_bytes_taps(c.K, c.C, 0x10) : conv_packed_bytes(c.K, c.C)));
+            if (c.ksize == 1) conv_pack_1x1_split(c.h_w.data(), c.K, c.C, host.data());
+            else conv_pack_split(c.h_w.data(), c.K, c.C, host.data());
+            INNFER_HIP(hipMalloc(&c.d_w32, host.size()));
+            INNFER_HIP(hipMemcpy(c.d_w32, host.data(), host.size(), hipMemcpyHostToDevice));
+        }
+    }
+    auto mk = [&](const ConvSlot& cs, const f16* in, long in_g, void* out, long out_g, int N_, int H_, int W_, int act) {
+        return mk_launch(cs, in, in_g, out, out_g, N_, H_, W_, act, LO);
+    };
     f16* fea = (f16*)(ws + cv.fea);
     f16* slab[3] = {(f16*)(ws + cv.slab[0]), (f16*)(ws + cv.slab[1]), (f16*)(ws + cv.slab[2])};
     f16* trunk = (f16*)(ws + cv.trunk);
@@ -559,6 +618,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         F.in_u8 = in_dtype == INNFER_U8; F.in_norm = net->u8_normalize; F.in_round16 = net->u8_round16;     // np2tensor as the conv's prologue
         F.out = fea; F.out_gstride = G; F.out2 = slab[0]; F.out2_gstride = G;
         F.K = nf; F.N = N; F.H = H; F.W = W; F.act = 0;
+        F.out_lo = LO; F.out2_lo = LO;
         int rc = do_first(F, s);
         if (rc) return rc;
     }
@@ -582,7 +642,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
                     chain.push_back(mk(cs, S, G, t1x1, G, N, H, W, 0));
                 }
                 // (conv1, conv2) and (conv3, conv4) as fused pairs (conv_pair.hip) on whole-frame launches of the plain dense block
-                const bool pairs = (net->pair_convs == 2 || (net->pair_convs == 1 && N == 1)) && !net->plus && net->trunk_act == 1 && gc == 32 && nf % 32 == 0 && nf >= 64 && net->band_rows == 0 &&
+                const bool pairs = !net->fp32 && (net->pair_convs == 2 || (net->pair_convs == 1 && N == 1)) && !net->plus && net->trunk_act == 1 && gc == 32 && nf % 32 == 0 && nf >= 64 && net->band_rows == 0 &&
                                    (long)N * H * W * 64 < 0x7fffffffL;
                 for (int i = 0; i < 4; ++i) {
                     const ConvSlot& cs = net->convs[ci++];
@@ -613,7 +673,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
                 int rc = run_chain(chain, 0, s);
                 if (rc) return rc;
                 chain.clear();
-                rc = do_input_map(c0, slab[a], trunk, G, s);
+                rc = do_input_map(c0, slab[a], trunk, G, s, LO);
                 if (rc) return rc;
                 in0 = trunk;
             }
@@ -632,7 +692,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             int rc = run_chain(chain, 0, s);
             if (rc) return rc;
             chain.clear();
-            rc = do_input_map(cs, slab[cur], slab[(cur + 1) % 3], G, s);
+            rc = do_input_map(cs, slab[cur], slab[(cur + 1) % 3], G, s, LO);
             if (rc) return rc;
             in = slab[(cur + 1) % 3];
         }
@@ -642,7 +702,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     }
     bool any_map = false;
     for (auto& c : net->convs) any_map |= c.d_map != nullptr;
-    int rc = run_chain(chain, any_map ? 0 : net->band_rows, s);
+    int rc = run_chain(chain, (any_map || net->fp32) ? 0 : net->band_rows, s);
     if (rc) return rc;
 
     const f16* t = trunk;
@@ -651,7 +711,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         const ConvSlot& cs = net->convs[ci++];
         f16* dst = (f16*)(ws + cv.up[u]);
         const long gi = (long)N * h * w * 32, go = gi * 4;
-        if (net->ps_up && (net->scale == 3 || net->nf != 64)) {
+        if (net->ps_up && (net->scale == 3 || net->nf != 64 || net->fp32)) {
             // PixelShuffle(3), or factor 2 on 32 features: the conv (nf -> r^2 nf, act in its epilogue -- it commutes with the permutation) writes a
             // slab in the (still unused) HR region, one gather pass rearranges it (block.py:333-346).  The 64-feature factor-2 stages shuffle in the
             // conv's own store (OUT_SHUFFLE2) below.
@@ -661,6 +721,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             if (rc) return rc;
             const long gr = gi * r * r, nthr = (long)N * h * w * r * r * (net->nf / 8);
             hipLaunchKernelGGL(slab_pixel_shuffle, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const f16*)Y, gi, dst, gr, net->nf, N, h, w, r);
+            if (LO) hipLaunchKernelGGL(slab_pixel_shuffle, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const f16*)Y + LO, gi, dst + LO, gr, net->nf, N, h, w, r);
             INNFER_HIP(hipGetLastError());
             t = dst; h *= r; w *= r;
             continue;
@@ -669,6 +730,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             f16* U = (f16*)(ws + cv.hr);
             const long g3 = gi * 9, nthr = (long)N * 9 * h * w * 4 * (net->nf / 32);
             hipLaunchKernelGGL(slab_upsample_nearest, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, t, gi, U, g3, net->nf / 32, N, h, w, 3);
+            if (LO) hipLaunchKernelGGL(slab_upsample_nearest, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, t + LO, gi, U + LO, g3, net->nf / 32, N, h, w, 3);
             INNFER_HIP(hipGetLastError());
             rc = do_conv(mk(cs, U, g3, dst, g3, N, 3 * h, 3 * w, net->trunk_act), s);
             if (rc) return rc;
@@ -744,6 +806,13 @@ extern "C" int innfer_pack_conv3x3(const float* w, int K, int C, void* h_packed)
     return INNFER_OK;
 }
 
+extern "C" int innfer_pack_conv3x3_split(const float* w, int K, int C, void* h_packed) {
+    if (!w || !h_packed || K <= 0 || C <= 0 || C % 32)
+        return set_error(INNFER_ERR_INVALID, "pack_conv3x3_split: K=%d C=%d (C must be a multiple of 32)", K, C);
+    conv_pack_split(w, K, C, h_packed);
+    return INNFER_OK;
+}
+
 extern "C" size_t innfer_conv7x1_packed_bytes(int K, int C) { return (K > 0 && C > 0 && C % 32 == 0) ? conv_packed_bytes7v(K, C) : 0; }
 extern "C" int innfer_pack_conv7x1(const float* w, int K, int C, void* packed) {
     if (!w || !packed || K <= 0 || K % 32 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv7x1: K=%d (%% 32) C=%d (%% 32)", K, C);
@@ -808,6 +877,11 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.res2 = (const f16*)a->d_res2; L.res2_gstride = a->res2_group_stride; L.s2 = a->res2_scale;
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
     L.out_mode = a->pixel_shuffle2 ? OUT_SHUFFLE2 : OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
+    if (a->split) {
+        if (a->pixel_shuffle2 || a->K % 32 || a->in_lo <= 0 || a->out_lo <= 0 || (a->d_res1 && a->res1_lo <= 0) || (a->d_res2 && a->res2_lo <= 0))
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (split): K in {32, 64} (K=%d), slab output, the lo distances of every tensor given", a->K);
+        L.split = 1; L.in_lo = a->in_lo; L.out_lo = a->out_lo; L.res1_lo = a->res1_lo; L.res2_lo = a->res2_lo;
+    }
     return conv_launch(L, (hipStream_t)stream);
 }
 

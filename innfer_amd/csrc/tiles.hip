@@ -39,6 +39,32 @@ __global__ void k_slab_to_nchw(const f16* slab, long gstride, int ch_off, void* 
     if (f32) ((float*)dst)[i] = (float)v; else ((f16*)dst)[i] = v;
 }
 
+// (hi, lo) slab pairs of the fp32-accurate mode (conv3x3.hip SPLIT): hi = fp16(x), lo = fp16((x - hi) * 2^11)
+__global__ void k_nchw_to_slab_split(const float* src, f16* slab, long gstride, long lo, int ch_off, int C, long hw, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long px = i % hw;
+    const int c = (int)((i / hw) % C);
+    const long n = i / (hw * C);
+    const float v = src[i];
+    const int ch = ch_off + c;
+    const long o = (ch >> 5) * gstride + (n * hw + px) * 32 + (ch & 31);
+    const f16 h = (f16)v;
+    slab[o] = h;
+    slab[o + lo] = (f16)((v - (float)h) * 2048.0f);
+}
+
+__global__ void k_slab_split_to_nchw(const f16* slab, long gstride, long lo, int ch_off, float* dst, int C, long hw, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long px = i % hw;
+    const int c = (int)((i / hw) % C);
+    const long n = i / (hw * C);
+    const int ch = ch_off + c;
+    const long o = (ch >> 5) * gstride + (n * hw + px) * 32 + (ch & 31);
+    dst[i] = __builtin_fmaf((float)slab[o + lo], 1.0f / 2048.0f, (float)slab[o]);
+}
+
 // Four consecutive pixels per thread: when P, the tile step and the output width are multiples of 4 every tile origin is, so the four pixels lie
 // under the same tiles and every tile row is read with one 8- / 16-byte load and written with one store.  The ramp step of torch.linspace (one
 // IEEE division) is computed once per thread, not per weight.  Same products, sums and division per pixel in the same order as k_recompose
@@ -306,6 +332,24 @@ int slab_to_nchw(const f16* slab, long gstride, int ch_off, void* dst, int f32, 
 }  // namespace innfer
 
 using namespace innfer;
+
+extern "C" int innfer_nchw_to_slab_split(const float* d_src, void* d_slab, int64_t group_stride, int64_t lo, int ch_off, int N, int C, int H, int W, void* stream) {
+    if (!d_src || !d_slab || lo <= 0) return set_error(INNFER_ERR_INVALID, "nchw_to_slab_split: null argument / lo <= 0");
+    const long hw = (long)H * W, total = hw * C * N;
+    if (total == 0) return INNFER_OK;
+    hipLaunchKernelGGL(k_nchw_to_slab_split, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, d_src, (f16*)d_slab, (long)group_stride, (long)lo, ch_off, C, hw, total);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+extern "C" int innfer_slab_split_to_nchw(const void* d_slab, int64_t group_stride, int64_t lo, int ch_off, float* d_dst, int N, int C, int H, int W, void* stream) {
+    if (!d_dst || !d_slab || lo <= 0) return set_error(INNFER_ERR_INVALID, "slab_split_to_nchw: null argument / lo <= 0");
+    const long hw = (long)H * W, total = hw * C * N;
+    if (total == 0) return INNFER_OK;
+    hipLaunchKernelGGL(k_slab_split_to_nchw, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)d_slab, (long)group_stride, (long)lo, ch_off, d_dst, C, hw, total);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
 
 // ------------------------------------------------------------------ C ABI part
 static int axis_plan(int size, int ps, int step_int, int* org) {

@@ -46,6 +46,7 @@ class ConvArgs(C.Structure):
         ("row_begin", C.c_int), ("row_end", C.c_int),
         ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int), ("pixel_shuffle2", C.c_int),
         ("stride2_k4", C.c_int), ("transposed2x", C.c_int), ("column7", C.c_int),
+        ("split", C.c_int), ("in_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64), ("res2_lo", C.c_int64),
     ]
 
 
@@ -72,6 +73,10 @@ SIGNATURES = {
     "innfer_srresnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 6 + [C.c_float, C.c_int]),
     "innfer_net_set_conv_input_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "innfer_net_set_outm": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_net_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_pack_conv3x3_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "innfer_nchw_to_slab_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_int] * 5 + [C.c_void_p]),
+    "innfer_slab_split_to_nchw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
@@ -179,7 +184,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 105          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 106          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

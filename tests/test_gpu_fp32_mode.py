@@ -1,0 +1,238 @@
+"""The fp32-accurate forward (innfer_net_set_precision(1); `-no_fp16` of the reference's command line, run.py:345,421-422) against the fp32
+golden vectors generated from the reference.  Needs an MI355X: `pytest -m gpu`.
+
+Tolerance: fp32 path vs G3 / G4 max-abs <= 1e-4 on [0,1]-scaled outputs.  The engine keeps every value as a pair of fp16
+slabs (22 significant bits) and multiplies on the fp16 matrix cores with fp32 accumulation, so the expected error is ~1e-6; the single-conv
+tests below hold the kernel to 3e-6 of the output range against float64 convolutions of the same fp32 operands.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _sd(shapes, seed=0):
+    from innfer_amd import synth
+    return {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed).items()}
+
+
+def _split_slab(dev, x, groups, Hs, Ws):
+    """fp32 NCHW (cpu) -> (tensor holding the hi slab [groups,N,H,W,32] followed by its lo twin, group stride, lo distance) on the GPU."""
+    import innfer_amd.lib as L
+    N, Cc = x.shape[:2]
+    g = N * Hs * Ws * 32
+    lo = groups * g
+    buf = torch.full((2, groups, N, Hs, Ws, 32), 7.0, dtype=torch.float16, device=dev)       # junk in unused groups
+    L.check(L.lib.innfer_nchw_to_slab_split(x.to(dev).contiguous().data_ptr(), buf.data_ptr(), g, lo, 0, N, Cc, Hs, Ws, None))
+    return buf, g, lo
+
+
+def _run_split_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0, in_extra=0, rows=None, out_off=0, out_channels=None):
+    """x [N,C,Hs,Ws] fp32 (cpu), w [K,C,3,3] fp32: the split conv through the C ABI, result NCHW fp32 on the cpu."""
+    import innfer_amd.lib as L
+    N, Cc, Hs, Ws = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up else (Hs, Ws)
+    xin, g_in, lo_in = _split_slab(dev, x, (Cc + in_extra) // 32, Hs, Ws)
+    packed = np.zeros(3 * L.lib.innfer_conv3x3_packed_bytes(K, Cc), dtype=np.uint8)
+    wc = np.ascontiguousarray(w.numpy())
+    L.check(L.lib.innfer_pack_conv3x3_split(wc.ctypes.data, K, Cc, packed.ctypes.data))
+    d_packed, d_bias = torch.from_numpy(packed).to(dev), b.float().to(dev)
+    og = (out_channels or max(K, 32)) // 32
+    g_out = N * H * W * 32
+    out = torch.full((2, og, N, H, W, 32), -3.0, dtype=torch.float16, device=dev)
+    a = L.ConvArgs()
+    a.d_in, a.in_group_stride, a.C = xin.data_ptr(), g_in, Cc
+    a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
+    a.d_out, a.out_group_stride, a.out_ch_off, a.K = out.data_ptr(), g_out, out_off, K
+    a.N, a.H, a.W, a.act, a.upsample2x = N, H, W, act, int(up)
+    a.split, a.in_lo, a.out_lo = 1, lo_in, og * g_out
+    keep = [xin, d_packed, d_bias]
+    for name, r, sc in (("1", res1, s1), ("2", res2, s2)):
+        if r is not None:
+            rs, g_r, lo_r = _split_slab(dev, r, max(K, 32) // 32, H, W)
+            setattr(a, f"d_res{name}", rs.data_ptr()); setattr(a, f"res{name}_group_stride", g_r); setattr(a, f"res{name}_scale", sc)
+            setattr(a, f"res{name}_lo", lo_r)
+            keep.append(rs)
+    if rows:
+        a.row_begin, a.row_end = rows
+    L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
+    torch.cuda.synchronize()
+    res = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
+    L.check(L.lib.innfer_slab_split_to_nchw(out.data_ptr(), g_out, og * g_out, out_off, res.data_ptr(), N, K, H, W, None))
+    torch.cuda.synchronize()
+    return res.cpu()
+
+
+def _ref64(x, w, b, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0):
+    xx = x.double()
+    if up:
+        xx = F.interpolate(xx, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xx, w.double(), b.double(), padding=1)
+    if act == 1:
+        y = F.leaky_relu(y, 0.2)
+    elif act == 2:
+        y = F.relu(y)
+    if res1 is not None:
+        y = y * s1 + res1.double()
+    if res2 is not None:
+        y = y * s2 + res2.double()
+    return y
+
+
+def test_split_slab_round_trip_keeps_22_bits(dev):
+    """fp32 -> (hi, lo) slabs -> fp32: relative error <= 2^-22 (values in fp16's normal range), exact zeros, fp16-representable values exact."""
+    import innfer_amd.lib as L
+    from innfer_amd import synth
+    x = torch.from_numpy(synth.uniform((2, 40, 9, 11), 7, -4, 4))
+    x[0, 0, 0, :4] = torch.tensor([0.0, 1.0, -0.5, 1.0009765625])
+    buf, g, lo = _split_slab(dev, x, 2, 9, 11)
+    back = torch.empty_like(x, device=dev)
+    L.check(L.lib.innfer_slab_split_to_nchw(buf.data_ptr(), g, lo, 0, back.data_ptr(), 2, 40, 9, 11, None))
+    torch.cuda.synchronize()
+    back = back.cpu()
+    assert torch.equal(back[0, 0, 0, :4], x[0, 0, 0, :4])
+    rel = ((back - x).abs() / x.abs().clamp_min(1e-3)).max().item()
+    assert rel <= 2.0 ** -22, rel
+
+
+@pytest.mark.parametrize("Cc,K,H,W,N,act", [
+    (64, 32, 16, 32, 1, 1), (96, 32, 37, 45, 2, 1), (160, 32, 33, 33, 1, 2), (192, 64, 21, 50, 2, 0), (64, 64, 24, 40, 3, 1),
+    (32, 32, 5, 3, 1, 0), (64, 64, 1, 1, 1, 1), (128, 32, 50, 70, 5, 1),
+])
+def test_split_conv_vs_float64_conv2d(dev, Cc, K, H, W, N, act):
+    """The split conv (hi/lo operands, three virtual chunk passes, one accumulator set) against F.conv2d in float64 on the same fp32 operands.
+    N > 1 takes the image-canvas form where that saves tiles."""
+    from innfer_amd import synth
+    x = torch.from_numpy(synth.uniform((N, Cc, H, W), 1, -1, 1))
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 2, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.from_numpy(synth.uniform((K,), 3, -1, 1))
+    got = _run_split_conv(dev, x, w, b, K, act=act, in_extra=32)
+    ref = _ref64(x, w, b, act=act)
+    err = (got.double() - ref).abs().max().item()
+    print(f"split conv {Cc}->{K} {N}x{H}x{W}: max|err| {err:.2e}")
+    assert err < 3e-6, err
+
+
+def test_split_conv_epilogues_upsample_rows(dev):
+    """Residual epilogues (x5 * 0.2 + x, then * 0.2 + x: RRDBNet_arch.py:98,165), the nearest-2x read (block.py:358), a row range and an output
+    channel offset in split mode."""
+    from innfer_amd import synth
+    x = torch.from_numpy(synth.uniform((2, 192, 30, 41), 11, -1, 1))
+    w = torch.from_numpy(synth.uniform((64, 192, 3, 3), 12, -1, 1)) / np.sqrt(9 * 192)
+    b = torch.from_numpy(synth.uniform((64,), 13, -1, 1))
+    r1 = torch.from_numpy(synth.uniform((2, 64, 30, 41), 14, -2, 2))
+    r2 = torch.from_numpy(synth.uniform((2, 64, 30, 41), 15, -2, 2))
+    got = _run_split_conv(dev, x, w, b, 64, res1=r1, s1=0.2, res2=r2, s2=0.2)
+    assert (got.double() - _ref64(x, w, b, res1=r1, s1=0.2, res2=r2, s2=0.2)).abs().max().item() < 3e-6
+    got = _run_split_conv(dev, x, w, b, 64, act=1, res1=r1, s1=1.0)
+    assert (got.double() - _ref64(x, w, b, act=1, res1=r1, s1=1.0)).abs().max().item() < 3e-6
+    xs = torch.from_numpy(synth.uniform((1, 64, 17, 23), 16, -1, 1))
+    ws = torch.from_numpy(synth.uniform((64, 64, 3, 3), 17, -1, 1)) / np.sqrt(9 * 64)
+    got = _run_split_conv(dev, xs, ws, b, 64, act=1, up=True)
+    assert (got.double() - _ref64(xs, ws, b, act=1, up=True)).abs().max().item() < 3e-6
+    w32 = torch.from_numpy(synth.uniform((32, 64, 3, 3), 18, -1, 1)) / np.sqrt(9 * 64)
+    full = _ref64(xs, w32, b[:32], act=1)
+    got = _run_split_conv(dev, xs, w32, b[:32], 32, act=1, rows=(5, 12), out_off=32, out_channels=64)
+    assert (got[:, :, 5:12].double() - full[:, :, 5:12]).abs().max().item() < 3e-6
+
+
+def _rrdb(dev, nb, scale, seed=0, **kw):
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    net = RRDBNet(3, 3, 64, nb, upscale=scale, **kw)
+    net.load_state_dict(_sd(synth.rrdbnet_shapes(nb=nb, scale=scale, **({"plus": True} if kw.get("plus") else {})), seed), strict=True)
+    return net.to(dev).eval()
+
+
+def test_rrdbnet_fp32_mode_vs_golden_g3(dev, golden):
+    """RRDBNet-23 4x on a float32 tensor = the fp32-accurate engine: vs golden G3 (the reference's fp32 forward) <= 1e-4; the same
+    module on x.half() still runs the fp16 engine (error of the fp16 size, <= 1e-2); the fp32 result does not depend on which mode ran before; a
+    batch equals its batch-1 forwards bit for bit."""
+    from innfer_amd import synth
+    g3 = golden("g3_rrdbnet23_x4")
+    net = _rrdb(dev, 23, 4)
+    for tag, shape, seed in (("out_32", (1, 3, 32, 32), 3), ("out_16", (1, 3, 16, 16), 4)):
+        x = torch.from_numpy(synth.uniform(shape, seed)).to(dev)
+        y32 = net(x)
+        assert y32.dtype == torch.float32
+        err = np.abs(y32.cpu().numpy() - g3[tag])
+        print(f"RRDBNet-23 fp32 mode vs G3 {tag}: max {err.max():.2e} mean {err.mean():.2e}")
+        assert err.max() < FP32_TOL, (tag, err.max())
+        y16 = net(x.half())
+        e16 = np.abs(y16.float().cpu().numpy() - g3[tag]).max()
+        assert y16.dtype == torch.float16 and 10 * err.max() < e16 < 1e-2, (e16, err.max())
+        assert torch.equal(net(x), y32)
+    xb = torch.from_numpy(synth.uniform((1, 3, 16, 16), 77)).to(dev)
+    y2 = net(torch.cat([x, xb], 0))
+    assert torch.equal(y2[0:1], y32) and torch.equal(y2[1:2], net(xb))
+
+
+def test_fp32_mode_scales_plus_srresnet(dev, golden):
+    """fp32-accurate forwards of the other net.hip graphs against their fp32 goldens: RRDBNet 1x / 2x / 3x / 8x, finalact and ESRGAN+ (G5), SRResNet
+    4x with PixelShuffle (G6: the shuffle runs as a gather over both slabs of a pair), <= 1e-4."""
+    from innfer_amd import synth
+    from innfer_amd.architectures.SRResNet_arch import SRResNet
+    g = golden("g5_scales")
+    x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 5)).to(dev)
+    for scale in (1, 2, 3, 8):
+        y = _rrdb(dev, 1, scale)(x).cpu().numpy()
+        err = np.abs(y - g[f"out_x{scale}"]).max()
+        print(f"RRDBNet {scale}x fp32 mode: max err {err:.2e}")
+        assert y.shape == g[f"out_x{scale}"].shape and err < FP32_TOL, (scale, err)
+    for fa in ("tanh", "sigmoid"):
+        assert np.abs(_rrdb(dev, 1, 4, finalact=fa)(x).cpu().numpy() - g[f"out_x4_{fa}"]).max() < FP32_TOL, fa
+    err = np.abs(_rrdb(dev, 1, 4, plus=True)(x).cpu().numpy() - g["out_x4_plus"]).max()
+    print(f"ESRGAN+ fp32 mode: max err {err:.2e}")
+    assert err < FP32_TOL, err
+    g6 = golden("g6_srgan")
+    net = SRResNet(3, 3, 64, 16, upscale=4, norm_type=None, act_type='relu', mode='CNA', upsample_mode='pixelshuffle')
+    net.load_state_dict(_sd(synth.srresnet_shapes(nb=16, scale=4)), strict=True)
+    y = net.to(dev).eval()(torch.from_numpy(synth.uniform((1, 3, 24, 24), 6)).to(dev)).cpu().numpy()
+    err = np.abs(y - g6["out_24"]).max()
+    print(f"SRResNet 4x fp32 mode: max err {err:.2e}")
+    assert err < FP32_TOL, err
+
+
+def test_model_chop_fp32_mode_vs_golden_g4(dev, golden, tmp_path):
+    """Model.__call__ (chop and un-tiled) on float32 tensors vs golden G4 (the reference's Model in fp32): <= 1e-4 -- tile gather, canvas batches
+    through the fp32-accurate engine, fp32 blend (bit-exact by itself)."""
+    from innfer_amd import synth
+    from innfer_amd.run import Model
+    g = golden("g4_chop")
+    for (nb, scale, h, w, tag) in [(2, 4, 250, 330, "x4_250x330"), (1, 2, 201, 640, "x2_201x640"), (1, 1, 150, 250, "x1_150x250")]:
+        path = str(tmp_path / f"{scale}x_{tag}.pth")
+        torch.save(_sd(synth.rrdbnet_shapes(nb=nb, scale=scale)), path)
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), 40 + scale)).to(dev)
+        y = Model(path, arch="infer", scale=None, device="cuda", chop=True, tile_batch=4)(x)
+        assert y.dtype == torch.float32 and tuple(y.shape) == (1, 3, h * scale, w * scale)
+        y = y.cpu()
+        e1 = np.abs(y[0, :, ::8, ::8].numpy() - g[f"chop_{tag}_sub"]).max()
+        e2 = np.abs(y[0, :, -32:, -32:].numpy() - g[f"chop_{tag}_crop_b"]).max()
+        y2 = Model(path, arch="infer", device="cuda", chop=False)(x).cpu()
+        e3 = np.abs(y2[0, :, ::8, ::8].numpy() - g[f"nochop_{tag}_sub"]).max()
+        print(f"Model fp32 mode {tag}: chop {e1:.2e} / {e2:.2e}, un-tiled {e3:.2e}")
+        assert max(e1, e2, e3) < FP32_TOL, (tag, e1, e2, e3)
+
+
+def test_generators_without_an_fp32_engine_refuse_float32(dev):
+    """PAN / UNet / PPON / CycleGAN ResNet / WBC UNet compute in fp16 only: a float32 tensor must raise, not run at fp16 accuracy behind fp32 I/O."""
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    for arch, scale, shape in (("pan", 4, (1, 3, 16, 16)), ("unet_256", 1, (1, 3, 256, 256)), ("ppon", 4, (1, 3, 16, 16)), ("resnet_9blocks", 1, (1, 3, 32, 32)),
+                               ("wbcunet", 1, (1, 3, 32, 32))):
+        net = get_network(get_network_G_config(arch, scale)).to(dev)
+        with pytest.raises(NotImplementedError, match="fp32"):
+            net(torch.zeros(shape, device=dev))

@@ -680,8 +680,8 @@ def test_unet256_golden(dev, golden):
     yab = net(torch.cat([xa, xb], 0).half()).float().cpu().numpy()
     assert np.array_equal(yab[0:1], ya)
     assert np.array_equal(yab[1:2], net(xb.half()).float().cpu().numpy())
-    y32 = net(xa).float().cpu().numpy()                             # fp32 I/O
-    assert np.abs(y32 - ref).max() < 1e-2
+    with pytest.raises(NotImplementedError, match="fp32"):          # no fp32-accurate engine for this generator: refused, not served at fp16 accuracy
+        net(xa)
     # What fp16 costs on THIS network: the reference's own fp16 mode (net.half(), run.py:383, on the CPU: golden G17) is 6.9e-3 max /
     # 6.7e-4 mean away from its fp32 output.  The HIP path (fp16 activations, fp32 accumulate and statistics; measured 4.3e-3 / 4.1e-4)
     # must be no further from the fp32 truth than that, and within twice that of the reference's fp16 output (two roundings apart).
@@ -747,7 +747,7 @@ def test_unet_instance_norm_and_dropout_variants_golden(dev, golden):
         net = net.to(dev)
         net = net.eval() if ev else net.train()
         x = torch.from_numpy(synth.uniform((1, 3, 64, 96), 240 + i, -1.0, 1.0)).to(dev)
-        for xin in (x, x.half()):
+        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
             err = np.abs(net(xin).float().cpu().numpy() - g[tag])
             assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
         if kw.get("use_dropout"):
@@ -1157,7 +1157,7 @@ def test_ppon_scales_golden(dev, golden):
         net.load_state_dict(_sd(shapes, 340 + j), strict=True)
         net = net.to(dev).eval()
         x = torch.from_numpy(synth.uniform((1, 3, 10, 12), 350 + j)).to(dev)
-        for xin in (x, x.half()):
+        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
             outs = net(xin)
             for name, y in zip("csp", outs):
                 ref = g[f"x{sc}_{name}"].astype(np.float32)
@@ -1182,7 +1182,7 @@ def test_ppon_golden(dev, golden):
     net = net.to(dev).eval()
     for (h, w, seed) in [(24, 24, 13), (20, 28, 14)]:
         x = torch.from_numpy(synth.uniform((1, 3, h, w), seed)).to(dev)
-        for xin in (x, x.half()):
+        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
             outs = net(xin)
             assert len(outs) == 3
             for name, y in zip("csp", outs):
@@ -1191,6 +1191,7 @@ def test_ppon_golden(dev, golden):
                 assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 2e-3 * max(1.0, np.abs(ref).max()), (name, h, w, err.max(), err.mean())
     xb = torch.from_numpy(synth.uniform((2, 3, 24, 24), 13)).to(dev)
     xb[1] = torch.from_numpy(synth.uniform((1, 3, 24, 24), 77)).to(dev)[0]
+    xb = xb.half()
     yb = net(xb)[2]
     assert torch.equal(yb[0:1], net(xb[0:1])[2]) and torch.equal(yb[1:2], net(xb[1:2])[2])
     # Model keeps the perceptual output (run.py:191-192)
@@ -1217,7 +1218,7 @@ def test_cyclegan_resnet9_golden(dev, golden):
     for (h, w, seed) in [(32, 40, 15), (64, 64, 16)]:
         x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0)).to(dev)
         ref = g[f"out_{h}x{w}"].astype(np.float32)
-        for xin in (x, x.half()):
+        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
             y = net(xin).float().cpu().numpy()
             err = np.abs(y - ref)
             assert np.isfinite(y).all() and np.abs(y).max() <= 1.0
@@ -1236,7 +1237,7 @@ def test_cyclegan_resnet9_golden(dev, golden):
     yab = net(torch.cat([xa, xb], 0))
     assert torch.equal(yab[0:1], net(xa)) and torch.equal(yab[1:2], net(xb))
     with pytest.raises(ValueError):
-        net(torch.zeros(1, 3, 30, 40, device=dev))                      # not a multiple of 4
+        net(torch.zeros(1, 3, 30, 40, device=dev, dtype=torch.float16))                      # not a multiple of 4
 
 
 def test_cyclegan_resnet_padding_and_dropout_variants_golden(dev, golden):
@@ -1257,7 +1258,7 @@ def test_cyclegan_resnet_padding_and_dropout_variants_golden(dev, golden):
         net = net.to(dev)
         net = net.train() if train else net.eval()
         x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0)).to(dev)
-        for xin in (x, x.half()):
+        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
             err = np.abs(net(xin).float().cpu().numpy() - g[tag])
             assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
     with pytest.raises(NotImplementedError):
@@ -1309,7 +1310,7 @@ def test_wbcunet_and_guided_filter_golden(dev, golden):
     for (h, w, seed) in [(32, 40, 17), (64, 64, 18)]:
         x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0)).to(dev)
         ref, ref_gf = g[f"out_{h}x{w}"].astype(np.float32), g[f"gf_{h}x{w}"].astype(np.float32)
-        for xin in (x, x.half()):
+        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
             y = net(xin)
             err = np.abs(y.float().cpu().numpy() - ref)
             assert err.max() < 5e-3 and err.mean() < 5e-4, (h, w, err.max(), err.mean())
@@ -1328,7 +1329,7 @@ def test_wbcunet_and_guided_filter_golden(dev, golden):
     net_tf.load_state_dict(_sd(shapes), strict=True)
     net_tf = net_tf.to(dev).eval()
     x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 17, -1.0, 1.0)).to(dev)
-    err = np.abs(net_tf(x).float().cpu().numpy() - g["out_tf_32x40"])
+    err = np.abs(net_tf(x.half()).float().cpu().numpy() - g["out_tf_32x40"])
     assert err.max() < 5e-3 and err.mean() < 5e-4, (err.max(), err.mean())
 
 
@@ -1350,15 +1351,15 @@ def test_pan_golden(dev, golden):
     for (h, w, seed) in [(48, 48, 8), (50, 70, 9)]:
         x = torch.from_numpy(synth.uniform((1, 3, h, w), seed)).to(dev)
         ref = g[f"out_{h}x{w}"].astype(np.float32)
-        for xin in (x, x.half()):
+        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
             y = net(xin).float().cpu().numpy()
             err = np.abs(y - ref)
             assert y.shape == ref.shape and np.isfinite(y).all()
             assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (h, w, err.max(), err.mean())
-        outs[(h, w)] = net(x).float().cpu().numpy()
+        outs[(h, w)] = net(x.half()).float().cpu().numpy()
     # a batch is independent images (attention and pooling are per image)
-    xa = torch.from_numpy(synth.uniform((1, 3, 48, 48), 8)).to(dev)
-    xb = torch.from_numpy(synth.uniform((1, 3, 48, 48), 21)).to(dev)
+    xa = torch.from_numpy(synth.uniform((1, 3, 48, 48), 8)).to(dev).half()
+    xb = torch.from_numpy(synth.uniform((1, 3, 48, 48), 21)).to(dev).half()
     yab = net(torch.cat([xa, xb], 0)).float().cpu().numpy()
     assert np.array_equal(yab[0:1], outs[(48, 48)])
     assert np.array_equal(yab[1:2], net(xb).float().cpu().numpy())
@@ -1380,7 +1381,7 @@ def test_pan_constructor_variants_golden(dev, golden):
         net = net.to(dev).eval()
         x = torch.from_numpy(synth.uniform((1, 3, 20, 28), 195 + i)).to(dev)
         ref = g[tag].astype(np.float32)
-        for xin in (x, x.half()):
+        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
             y = net(xin).float().cpu().numpy()
             err = np.abs(y - ref)
             assert y.shape == ref.shape and err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (tag, err.max(), err.mean())
@@ -1403,14 +1404,14 @@ def test_pan_scales_vs_oracle(dev):
         x = torch.from_numpy(synth.uniform((2, in_nc, h, w), 30 + scale))
         with torch.no_grad():
             ref = oracle.pan_forward(sd, x, nb=3, scale=scale).numpy()
-        y = net(x.to(dev)).float().cpu().numpy()
+        y = net(x.to(dev).half()).float().cpu().numpy()
         err = np.abs(y - ref)
         assert y.shape == ref.shape
         assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (scale, err.max(), err.mean())
         net._ws.fill_(0xFF)                                             # every byte read was written by this forward: NaN-poisoned workspace
-        assert torch.equal(net(x.to(dev)).float().cpu(), torch.from_numpy(y))
+        assert torch.equal(net(x.to(dev).half()).float().cpu(), torch.from_numpy(y))
     with pytest.raises(ValueError):
-        net(torch.zeros(1, 1, 3, 8, device=dev))                        # MaxPool2d(4) needs >= 4x4
+        net(torch.zeros(1, 1, 3, 8, device=dev, dtype=torch.float16))                        # MaxPool2d(4) needs >= 4x4
 
 
 def test_small_generators_shape_fuzz_and_poisoned_workspace(dev):
@@ -1663,8 +1664,7 @@ def test_first_conv_on_the_matrix_cores_all_widths(dev):
                 y16 = net(x.to(dev)).float().cpu()
                 y32 = net(x.float().to(dev)).float().cpu()
                 assert (y16 - ref).abs().max().item() < 5e-3, (in_nc, nf, shape)
-                assert (y32 - ref).abs().max().item() < 5e-3, (in_nc, nf, shape)
-                assert torch.equal(net(x.float().to(dev)).half(), net(x.to(dev))), (in_nc, nf, shape)
+                assert (y32 - ref).abs().max().item() < 1e-4, (in_nc, nf, shape)      # a float32 tensor runs the fp32-accurate engine (test_gpu_fp32_mode.py)
 
 
 # ---------------------------------------------------------------- Model / chop
