@@ -25,7 +25,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     : dominant kernel (by summed time) -- algorithmic FLOPs and bytes per launch / its average launch
                  duration, from HIP events around every launch of one forward; BOTH roofs per kernel, `bound` = the larger floor
   cpu_baseline : the oracle (torch fp32 restatement of the reference) timed on the host cores on a
-                 bounded sample (rank 0, N == 1 only).
+                 bounded sample (rank 0, in a child process that never touches a GPU; at every N).
+  chop8k       : BASELINE config 3 (8K input through chop_forward, 3268 tiles) -- 1 warm-up + 1 timed pass on the same ranks
+  unet64       : BASELINE config 5 (pix2pix UNet_256 on 64x3x256x256), N == 1 only
 """
 import argparse
 import ctypes as C
@@ -57,7 +59,7 @@ def kernel_key(k):
 
 
 def kind_name(k):
-    return "first_conv_kernel" if k == 0 else kernel_key(k)
+    return "first_conv_mfma<4,1>" if k == 0 else kernel_key(k)          # (3 -> 64 on the matrix cores, csrc/conv_first.hip)
 
 
 def build_net(dev, nb=23, scale=4):
@@ -264,16 +266,91 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def unet64_object(dev, reps=20):
+    """BASELINE config 5: UnetGenerator(3, 3, 8 downs, ngf 64, BatchNorm on the statistics of each image -- run.py runs pix2pix with meval=False, one
+    image at a time) on 64 x 3 x 256 x 256, fp16, synthetic weights; HIP events around `reps` forwards on the launch stream."""
+    import torch
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config("p2p_256", 1))
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()
+    x = torch.from_numpy(synth.uniform((64, 3, 256, 256), 3, -1, 1)).to(dev).half()
+    for _ in range(3):
+        net(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        net(x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = net.flops(64, 256, 256)                    # 12.1 GFLOP per image (SURVEY 8d)
+    out = {"workload": "pix2pix UnetGenerator(3, 3, 8, ngf 64), train-mode BatchNorm per image, 64x3x256x256 -> 64x3x256x256 fp16 (BASELINE config 5)",
+           "steps": reps, "warmup": 3, "ms_per_step": round(ms, 4), "value": round(64 / ms * 1e3, 1), "unit": "img/s",
+           "model_tflops": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4)}
+    per = unet_per_kernel(net, x)
+    if per:
+        out["per_kernel"] = per
+    net.release_workspace()
+    return out
+
+
+def unet_per_kernel(net, x):
+    """Per-kernel two-roof entries of one UNet forward from the library's launch timer (innfer_timer_*), or None when the library has none."""
+    import innfer_amd.lib as L
+    if not hasattr(L, "timed_launches"):
+        return None
+    launches = L.timed_launches(lambda: net(x))
+    agg = {}
+    for name, ms, fl, by in launches:
+        a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+        a[0] += ms; a[1] += fl; a[2] += by; a[3] += 1
+    per = {}
+    for name, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        e = {"launches": v[3], "ms_total": round(v[0], 4)}
+        if v[1] > 0 and v[2] > 0:
+            e.update(two_roofs(v[1], v[2], v[0]))
+        elif v[2] > 0:
+            e.update({"gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1), "frac_hbm": round(v[2] / (PEAK_HBM_GBS * 1e9) / (v[0] * 1e-3), 4), "bound": "hbm"})
+        per[name] = e
+    return per
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: the parent starts one fresh process per rank BEFORE anything touches the GPU
 # (never re-exec a process that has initialised HIP), relays rank 0's JSON line and fails if a rank fails.
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT any HIP / torch.cuda call in the parent that spawns the ranks: GPU nodes of the KFD topology in
+    sysfs (simd_count > 0), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  Falls back to
+    torch.cuda.device_count() (which does not create a context on this image) when sysfs has no topology."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split() for l in open(f).read().splitlines() if len(l.split()) == 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except Exception:
+            pass
+    if n == 0:
+        import torch
+        return torch.cuda.device_count()
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args, argv):
     import socket
     n = args.gpus
     dry = os.environ.get("INNFER_BENCH_DRYRUN") == "1" or os.environ.get("INNFER_BENCH_SELFTEST") == "1"
     if not dry:
-        import torch                                    # device_count() does not initialise the GPU on this image
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < n:
             log(f"--gpus {n} but only {have} GPU(s) visible (INNFER_BENCH_DRYRUN=1 rehearses the N > 1 control flow on one GPU)")
             return 2
@@ -345,7 +422,9 @@ def main():
                     help="innfer_net_set_pair_convs: 0 one launch per layer (default), 1 fused conv pairs on single-image forwards, 2 always")
     ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch (0 = innfer_amd.parallel.tile_batches: evenly sized launches of <= 272 tiles)")
     ap.add_argument("--sharded-steps", type=int, default=2, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip")
+    ap.add_argument("--fp32", action="store_true", help="frame workloads: a float32 frame = the fp32-accurate engine (the reference's -no_fp16 mode); no roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the chop8k (BASELINE config 3) and unet64 (config 5) objects of the line")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-power-probe", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -442,12 +521,13 @@ def main():
     frame = args.workload.startswith("frame")
     if frame:
         H, W = (1080, 1920) if args.workload == "frame1080" else (540, 960)
-        x = torch.from_numpy(synth.uniform((1, 3, H, W), 2 + rank)).to(dev).half()
+        x = torch.from_numpy(synth.uniform((1, 3, H, W), 2 + rank)).to(dev)
+        x = x.float() if args.fp32 else x.half()
         out_pix = 16 * H * W * world                # every rank produces its own frame
 
         def step():
             return net(x)
-        cfg = {"workload": f"ESRGAN RRDBNet-23 4x fp16, 1x3x{H}x{W} -> 1x3x{4 * H}x{4 * W}, un-tiled "
+        cfg = {"workload": f"ESRGAN RRDBNet-23 4x {'fp32-accurate (fp16 hi/lo pairs, -no_fp16)' if args.fp32 else 'fp16'}, 1x3x{H}x{W} -> 1x3x{4 * H}x{4 * W}, un-tiled "
                            f"(Model(chop=False)), one frame per rank", "band_rows": args.band_rows,
                "parallelism": (f"frame replicas x{world}" if world > 1 else "single GPU") + tag}
         scaling = "weak"
@@ -484,7 +564,7 @@ def main():
         line = {"metric": metric, "value": round(out_pix * args.steps / wall / 1e6, 2),
                 "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling,
-                "vs_baseline": None, "dtype": "f16", "data": "synthetic", "config": cfg,
+                "vs_baseline": None, "dtype": "f32 as fp16 (hi, lo) pairs" if (frame and args.fp32) else "f16", "data": "synthetic", "config": cfg,
                 "hip_event_ms_per_step": round(ev_ms / args.steps, 3)}
         if not frame:
             flops, _ = chop_flops(main_runners, H, W)
@@ -494,7 +574,7 @@ def main():
             flops = net.flops(1, H, W)
             line["model_tflops"] = round(flops * world * args.steps / wall / 1e12, 2)
             line["frac_of_mfma_peak"] = round(flops * args.steps / wall / 1e12 / PEAK_F16_TFLOPS, 4)
-            if not args.no_roofline:
+            if not args.no_roofline and not args.fp32:
                 log('per-launch timing')
                 timed_forward(net, x)
                 launches = timed_forward(net, x)
@@ -540,8 +620,31 @@ def main():
         del cstep, runners
         torch.cuda.empty_cache()
 
+    # ---- BASELINE config 3 on the same ranks: 8K input through chop_forward (3268 tiles), one warm-up + one timed pass ----
+    if not args.no_extras and args.workload != "chop8k":
+        log('chop8k')
+        kstep, kH, kW, kwhat, krunners = chop_setup("chop8k")
+        kwall = timed_steps(kstep, 1, 1, world, sync, barrier, max_over_ranks)
+        if rank == 0:
+            kfl, ntile = chop_flops(krunners, kH, kW)           # 4686.8 TFLOP (the redundant tile FLOPs of the reference's tiling count)
+            line["chop8k"] = {
+                "workload": f"{kwhat} fp16, {kH}x{kW} input through chop_forward, {ntile} tiles of 200^2 (BASELINE config 3), tile list sharded over "
+                            f"{world} rank(s), blend on rank 0" + tag,
+                "steps": 1, "warmup": 1, "s_per_frame": round(kwall, 3), "value": round(16 * kH * kW / kwall / 1e6, 2), "unit": "unique-output MPix/s",
+                "model_tflops": round(kfl / kwall / 1e12, 1), "frac_of_mfma_peak_all_gpus": round(kfl / kwall / 1e12 / (PEAK_F16_TFLOPS * world), 4),
+                "tile_batches": parallel.tile_batches(parallel.shard_tiles(ntile, world, 0)[1], args.tile_batch or None,
+                                                      parallel.engine_tile_cap(net, 200, torch.float16, dev))}
+        del kstep, krunners
+        net.release_workspace()
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE config 5: pix2pix UNet_256, 64 x 3 x 256 x 256 (one GPU) ----
+    if not args.no_extras and world == 1:
+        log('unet64')
+        line["unet64"] = unet64_object(dev)
+
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             log('cpu baseline')
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -331,6 +331,9 @@ typedef struct {
                                            lo slab = fp16((x - hi) * 2^11) lies in_lo / out_lo / res1_lo / res2_lo ELEMENTS behind; d_packed from innfer_pack_conv3x3_split();
                                            K in {32, 64} for slab outputs; act 0 / 1 / 2, residuals, upsample2x, row range and batches as for the fp16 form (106) */
     int64_t in_lo, out_lo, res1_lo, res2_lo;
+    int winograd;                       /* experiment (profiles/r3/winograd.txt; not used by the networks): 1 = Winograd F(2,3) along the image rows on 16 x 32 tiles -- two
+                                           thirds of the MFMA work, fp16 transforms (parity vs the direct form: test_winograd_rows_vs_direct); d_packed from
+                                           innfer_pack_conv3x3_wino(); K % 32 == 0, act 0 / 1 / 2, residuals, upsample2x, row range; 2 = the direct conv on the same tiles (K 32) (106) */
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);
@@ -345,6 +348,8 @@ int innfer_pack_convt2x(const float* h_weight_iohw, int K, int C, int k, void* h
 int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream);
 /* Panels of the split form: 3 * innfer_conv3x3_packed_bytes(K, C) bytes ((w - wh) * 2^11 | wh | wh, in the order the kernel's virtual chunks meet them).  (106) */
 int innfer_pack_conv3x3_split(const float* h_weight_oihw, int K, int C, void* h_packed);
+size_t innfer_conv3x3_wino_packed_bytes(int K, int C);
+int innfer_pack_conv3x3_wino(const float* h_weight_oihw, int K, int C, void* h_packed);
 
 /* NCHW (f16/f32) <-> blocked-NHWC f16 slab helpers used by tests of the single conv. */
 int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int64_t group_stride, int ch_off,

@@ -10,6 +10,10 @@ from .param_module import ParamEngineModule
 
 class PPON(ParamEngineModule):
     _api = 'ppon'
+    _n_outputs = 3
+
+    def _out_shape(self, N, H, W):
+        return (N, self.out_nc, H * self.scale, W * self.scale)
 
     def __init__(self, in_nc=3, nf=64, nb=24, out_nc=3, upscale=4, act_type='lrelu', alpha=1.0):
         super().__init__()

@@ -204,6 +204,16 @@ class EngineModule(nn.Module):
     def release_workspace(self):
         self._ws = None
 
+    def tile_batch_bytes(self, b, ps, dtype=torch.float16):
+        """Device bytes a forward of b tiles of ps x ps takes beyond the weights: the engine workspace (innfer_net_workspace_bytes in the precision
+        `dtype` selects -- twice as much in the fp32-accurate mode) + the input tiles + the HR tiles twice (the batch's result and its copy in the
+        tile buffer the blend reads).  parallel.engine_tile_cap sizes the chop batches with it."""
+        self._ensure_engine()
+        L.check(L.lib.innfer_net_set_precision(self._handle, int(dtype == torch.float32)))
+        elt = 4 if dtype == torch.float32 else 2
+        s = L.lib.innfer_net_scale(self._handle)
+        return L.lib.innfer_net_workspace_bytes(self._handle, b, ps, ps) + b * (self.in_nc * ps * ps + 2 * self.out_nc * (ps * s) ** 2) * elt
+
     def flops(self, N, H, W):
         self._ensure_engine()
         return L.lib.innfer_net_flops(self._handle, N, H, W)

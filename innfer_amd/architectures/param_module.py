@@ -86,6 +86,18 @@ class ParamEngineModule(nn.Module):
     def _out_shape(self, N, H, W):
         raise NotImplementedError
 
+    def release_workspace(self):
+        self._ws = None
+
+    def tile_batch_bytes(self, b, ps, dtype=torch.float16):
+        """Device bytes a forward of b tiles of ps x ps takes beyond the weights (workspace + input tiles + the output twice: the batch's result
+        and its copy in the tile buffer the blend reads); parallel.engine_tile_cap sizes the chop batches with it."""
+        import math
+        out = self._out_shape(1, ps, ps)
+        n_out = getattr(self, '_n_outputs', 1)
+        in_nc = getattr(self, 'in_nc', None) or getattr(self, 'input_nc', 3)
+        return self._fn('workspace_bytes')(self._handle, b, ps, ps) + b * (in_nc * ps * ps + (n_out + 1) * math.prod(out)) * 2
+
     def _check_dtype(self, x):
         """The input's dtype is the arithmetic the caller asks for (the reference: model.half() / t_img.half(), run.py:345,383,421-422).  These
         engines compute in fp16 with fp32 accumulation and nothing else: a float32 tensor is refused rather than served at fp16 accuracy."""

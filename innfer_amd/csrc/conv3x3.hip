@@ -335,6 +335,45 @@ __device__ __forceinline__ void epilogue_slab_split(const KP& p, f32x4 (&acc)[NT
     }
 }
 
+// WINO (conv3x3_pc<.., TMF | 0x4000>): output transform of the row Winograd form -- lane li holds M_0..3 of pixel pair li of each of the wave's rows:
+// Y(2 li) = M0 + M1 + M2 + bias, Y(2 li + 1) = M1 - M2 - M3 + bias, then the fp16 epilogue (activation, *s1 + res1, *s2 + res2, one rounding).
+template <int RPW, int NT, int ACT, bool R1, bool R2>
+__device__ __forceinline__ void epilogue_slab_wino(const KP& p, f32x4 (&m)[4][NT][RPW], const f32x4 (&bias)[NT], int n, int ty0, int tx0, int wave, int li, int cbase) {
+    const int oc0 = cbase + p.out_coff;
+    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + (oc0 & 31);
+    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + (cbase & 31) : nullptr;
+    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + (cbase & 31) : nullptr;
+#pragma unroll
+    for (int rw = 0; rw < RPW; ++rw) {
+        const int y = ty0 + wave * RPW + rw;
+        if (y >= p.y1) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int x = tx0 + 2 * li + q;
+            if (x >= p.W) continue;
+            const long off = (((long)n * p.H + y) * p.W + x) * 32;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f16x4 r1, r2, h;
+                if (R1) r1 = *(const f16x4*)(r1b + off + 4 * t);
+                if (R2) r2 = *(const f16x4*)(r2b + off + 4 * t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = q == 0 ? (m[0][t][rw][j] + m[1][t][rw][j]) + m[2][t][rw][j] : (m[1][t][rw][j] - m[2][t][rw][j]) - m[3][t][rw][j];
+                    f += bias[t][j];
+                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[j]);
+                    if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[j]);
+                    FP32_VALUE(f);
+                    h[j] = (f16)f;
+                }
+                *(f16x4*)(ob + off + 4 * t) = h;
+            }
+        }
+    }
+}
+
 template <int RPW, int NT, int OUTMODE>
 __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mfma(const KP p) {
     constexpr int TH = 4 * RPW;
@@ -790,6 +829,15 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // at zero, are scaled by 2^-11 (exact) and receive the bias when the third part begins: ONE accumulator set, the fp16 kernel's MFMA stream.
     constexpr bool SPLIT = (TMF & 0x2000) != 0;
     static_assert(!SPLIT || (!S9 && !POLY && !S2 && !PFX && !STATS && (TM == 0x1FF || TM == 0x10)), "split operands: plain 3x3 and 1x1 convs");
+    // + 0x4000: Winograd F(2,3) along the image rows (experiment, profiles/r3/winograd.txt).  An output pixel pair (2j, 2j+1) of a row is
+    //   Y = A^T [(G g) . (B^T d)],  d = the four input columns 2j-1 .. 2j+2:   V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3;  Y0 = M0 + M1 + M2, Y1 = M1 - M2 - M3
+    // with M_xi = sum over the three kernel rows and the input channels of U_xi,r * V_xi: 12 MFMAs (4 xi x 3 rows) per 32 output pixels of a row and
+    // 16-channel output tile instead of 18 (2 segments x 9 taps) -- two thirds of the matrix work; the weight panel holds U = G g per kernel row (12
+    // "taps", conv_pack_wino), the MFMA's 16 columns are the row's 16 pixel pairs.  The input transform is 16 v_pk_add_f16 per input row and chunk on the
+    // fragments as they come out of LDS.  LDS image: a halo row holds its even columns (0, 2, .. 32) then its odd ones (18-pixel halves of the 36-pixel
+    // pitch), so that the stride-2 reads d0 / d2 (even[j], even[j+1]) and d1 / d3 (odd[j], odd[j+1]) are 16 consecutive pixels each: conflict free.
+    constexpr bool WINO = (TMF & 0x4000) != 0;
+    static_assert(!WINO || (!S9 && !POLY && !S2 && !PFX && !STATS && !SPLIT && !CV && TM == 0x1FF && NSI == 2 && NCW == 8 && OUTMODE == OUT_SLAB), "Winograd rows: plain 3x3 slab convs");
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -797,7 +845,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int KQ = (NQ + NLW - 1) / NLW;
     constexpr int IN_BYTES = NQ * 1024;
     constexpr int WROWS = NT * 16;
-    constexpr int NTAP = __builtin_popcount(TM);                    // taps in the panel, in (r, s) order
+    constexpr int NTAP = WINO ? 12 : __builtin_popcount(TM);        // taps in the panel, in (r, s) order (WINO: (r, xi))
     constexpr int W_BYTES = NTAP * WROWS * 64;
     constexpr int WQ = W_BYTES / 1024;
     constexpr int KW = (WQ + NLW - 1) / NLW;
@@ -870,7 +918,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
             for (int k = 0; k < KQ; ++k) {
                 const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                const int ly = px / LWP, lx = px - ly * LWP;
+                const int ly = px / LWP;
+                int lx = px - ly * LWP;
+                if constexpr (WINO) lx = lx >= 18 ? (lx == 35 ? LVALID : 2 * (lx - 18) + 1) : (lx == 17 ? LVALID : 2 * lx);      // even columns, then odd ones (17 valid of 18 each)
                 const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
                 const int ry = S2 ? 2 * ly : p.up ? (ly + ypar) >> 1 : ly;
                 const int rx = S2 ? 2 * lx : p.up ? (lx + 1) >> 1 : lx;
@@ -959,7 +1009,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
                     const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                    const int ly = px / LWP, lx = px - ly * LWP;
+                    const int ly = px / LWP;
+                    int lx = px - ly * LWP;
+                    if constexpr (WINO) lx = lx >= 18 ? 2 * (lx - 18) + 1 : 2 * lx;
                     const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
                     if (Y < 0 || Y >= p.H || X < 0 || X >= p.W) {
                         // reflection padding: the ring of pixels one step outside the image mirrors the pixel one step inside; farther
@@ -1129,10 +1181,25 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             boffs[s][par] = pb * 64 + ((lg ^ (((((li + s) >> 2) & 1) ^ rowpar) << 1)) << 4);
         }
     const int aoffs = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    // WINO: byte offsets of d(half h, pixel pair li + dl) in the wave's rows 0 and 1: LDS pixel P = row * 36 + 18 h + li + dl, slot lg ^ 2 bit2(P); rows of one
+    // parity differ by whole multiples of two pitches (36 = 4 x 9: bit2(P) depends on the row's parity only), i.e. by immediates
+    int woffs[WINO ? 2 : 1][2][2];
+    if constexpr (WINO) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int dl = 0; dl < 2; ++dl) {
+                    const int P = (cw * RPW + q) * LWP + 18 * h + li + dl;
+                    woffs[q][h][dl] = P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4);
+                }
+    }
     int islot = 0;                                                // NSI == 3: g % 3
     f32x4 bias_r[NT];
     int bias_kg = -1;
     f32x4 acc[NT][MT];
+    f32x4 wacc[WINO ? 4 : 1][NT][WINO ? RPW : 1];          // WINO: M_xi of the wave's RPW rows (16 pixel pairs each) per 16-channel tile
     float pfx[PFX ? MT : 1][8];          // (cleared after a tile's last chunk, in front of its epilogue: live sums there would cost the epilogue's registers)
 #pragma unroll
     for (int m = 0; m < (PFX ? MT : 1); ++m)
@@ -1158,6 +1225,14 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[t][m] = SPLIT ? f32x4{0.f, 0.f, 0.f, 0.f} : bias_r[t];
+            if constexpr (WINO) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int m = 0; m < RPW; ++m) wacc[x][t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         if constexpr (SPLIT) {
             if (c == 2 * p.ncg) {                    // the two cross terms are complete: scale them down (exact) and go on with xh * wh on top of the bias
@@ -1179,6 +1254,33 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         constexpr bool abl_no_mfma = false;
 #endif
         if (abl_no_mfma) {
+        } else if constexpr (WINO) {
+            f16x8 a[4][3][NT];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a[x][r][t] = *(const f16x8*)(sw + aoffs + ((r * 4 + x) * WROWS + t * 16) * 64);
+#pragma unroll
+            for (int rr = 0; rr < RPW + 2; ++rr) {
+                const char* rowp = st + (rr - (rr & 1)) * LWP * 64;
+                const f16x8 d0 = *(const f16x8*)(rowp + woffs[rr & 1][0][0]), d1 = *(const f16x8*)(rowp + woffs[rr & 1][1][0]);
+                const f16x8 d2 = *(const f16x8*)(rowp + woffs[rr & 1][0][1]), d3 = *(const f16x8*)(rowp + woffs[rr & 1][1][1]);
+                f16x8 v[4];
+                v[0] = d0 - d2; v[1] = d1 + d2; v[2] = d2 - d1; v[3] = d1 - d3;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int rw = rr - r;
+                    if (rw >= 0 && rw < RPW) {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                wacc[x][t][rw] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[x][r][t], v[x], wacc[x][t][rw], 0, 0, 0);
+                    }
+                }
+            }
         } else if constexpr (TM == 0x1FF && PIPE) {
             // Software-pipelined fragment reads (the nine-tap kernels).  The B fragments of a chunk are walked in (s, rr, seg) order through
             // a three-register ring, each read issued two MFMA groups (>= 8 MFMAs = 128 pipe cycles) ahead of its use; the weight fragments
@@ -1275,7 +1377,17 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pfx[m][e] = 0.f;
             }
-            if constexpr (OUTMODE == OUT_SLAB && SPLIT) {
+            if constexpr (WINO) {
+#define EPI(A, B, C) epilogue_slab_wino<RPW, NT, A, B, C>(p, wacc, bias_r, n, ty0, tx0, cw, li, cbase)
+            if (!p.res1) {
+                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
+            } else if (!p.res2) {
+                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
+            } else {
+                if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
+            }
+#undef EPI
+            } else if constexpr (OUTMODE == OUT_SLAB && SPLIT) {
 #define EPI(A, B, C) epilogue_slab_split<RPW, NT, A, B, C, CV>(p, acc, n, ty0, tx0, cw, li, cbase)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
@@ -1446,10 +1558,10 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI, int NCW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = NCW * RPW;
-    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (__builtin_popcount(TM & 0x1FF) * NT * 16 * 64);
+    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
-    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x2000) == 0x1FF && !CV) {      // a batch of images whose size is not a whole number of tiles
+    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
         int gy = 0; long t = 0;
         const int gx = INNFER_KNOB("INNFER_CANVAS", 1) ? canvas_grid<TH>(kp, N, &gy, &t) : 0;
         if (gx > 0) {
@@ -1593,6 +1705,35 @@ static std::vector<float> split_weights(const float* w, int K, int C, int taps) 
 void conv_pack_split(const float* w, int K, int C, void* packed) { conv_pack(split_weights(w, K, C, 9).data(), K, 3 * C, packed); }
 void conv_pack_1x1_split(const float* w, int K, int C, void* packed) { conv_pack_1x1(split_weights(w, K, C, 1).data(), K, 3 * C, packed); }
 
+// Row-Winograd panels (conv3x3_pc<.., TMF | 0x4000>): 32-channel output groups (NT = 2) whatever K is, 12 "taps" per chunk in (kernel row r, xi) order,
+// U_xi = G g over the kernel row's three columns (fp32, ONE rounding to fp16): [group][chunk][r * 4 + xi][row R][slot][8 ch]
+size_t conv_packed_bytes_wino(int K, int C) { return (size_t)((K + 31) / 32) * (C / 32) * 12 * 32 * 64; }
+void conv_pack_wino(const float* w, int K, int C, void* packed) {
+    const int nt = 2, rows = 32, groups = (K + 31) / 32, nch = C / 32;
+    f16* dst = (f16*)packed;
+    for (int g = 0; g < groups; ++g)
+        for (int c = 0; c < nch; ++c)
+            for (int tap = 0; tap < 12; ++tap) {
+                const int r = tap >> 2, xi = tap & 3;
+                for (int R = 0; R < rows; ++R) {
+                    const int t = R >> 4, rho = R & 15;
+                    const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
+                    for (int sg = 0; sg < 4; ++sg) {
+                        const int cg = sg ^ (((R >> 2) & 1) << 1);
+                        for (int e = 0; e < 8; ++e) {
+                            const int ic = c * 32 + cg * 8 + e;
+                            float u = 0.f;
+                            if (oc < K) {
+                                const float* gk = w + ((size_t)oc * C + ic) * 9 + r * 3;
+                                u = xi == 0 ? gk[0] : xi == 3 ? gk[2] : xi == 1 ? 0.5f * (gk[0] + gk[1] + gk[2]) : 0.5f * (gk[0] - gk[1] + gk[2]);
+                            }
+                            *dst++ = (f16)u;
+                        }
+                    }
+                }
+            }
+}
+
 void conv_pack_1x1(const float* w, int K, int C, void* packed) {
     const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
     f16* dst = (f16*)packed;
@@ -1729,6 +1870,15 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     const int pc = INNFER_KNOB("INNFER_PC", 1);     // producer / consumer kernel for slab outputs
     if (L.outm && (L.out_mode != OUT_NCHW || !pc || nt != 1 || L.res1 || L.res2 || L.outm < 0 || L.outm > 4))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: outm belongs to the planar last conv (<= 16 channels)");
+    if (L.wino) {            // experiment (profiles/r3/winograd.txt): 1 = Winograd F(2,3) along the rows, 2 = the direct conv on the same tiles (16 rows x 32 px, 32-channel
+                             // output groups) for the A/B; panels from conv_pack_wino / conv_pack(K = 32) per group
+        if (!pc || L.out_mode != OUT_SLAB || L.K % 32 || L.act > 2 || L.reflect || L.dilation > 1 || L.dilation_groups || L.deconv_phases || L.stride2 || L.conv7v || L.conv7 ||
+            L.stats_part || L.conv1x1 || L.pair_wpk || L.split)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (Winograd rows): plain 3x3 slab convs, K %% 32 == 0, act 0..2, residuals, upsampled input");
+        k.KG = L.K / 32;
+        if (L.wino == 2 && L.K != 32) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (A/B tile shape): K == 32");
+        return L.wino == 1 ? launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x41FF>(k, L.N, s) : launch_pc<2, 2, 4>(k, L.N, s);
+    }
     if (L.split) {           // fp32-accurate mode on (hi, lo) slab pairs: 3 * C / 32 virtual chunks (conv3x3_pc<.., TMF | 0x2000>)
         if (!pc || (L.act > 2 && !((L.act == 3 || L.act == 6) && L.out_mode == OUT_NCHW)) || L.reflect || L.dilation > 1 || L.dilation_groups || L.deconv_phases || L.stride2 || L.conv7v || L.conv7 || L.stats_part ||
             L.prefix_lrelu || L.phase_c || L.pair_wpk || (long)3 * L.C / 32 > 0x7fff)

@@ -47,6 +47,7 @@ class ConvArgs(C.Structure):
         ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int), ("pixel_shuffle2", C.c_int),
         ("stride2_k4", C.c_int), ("transposed2x", C.c_int), ("column7", C.c_int),
         ("split", C.c_int), ("in_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64), ("res2_lo", C.c_int64),
+        ("winograd", C.c_int),
     ]
 
 
@@ -75,6 +76,8 @@ SIGNATURES = {
     "innfer_net_set_outm": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_pack_conv3x3_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "innfer_conv3x3_wino_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "innfer_pack_conv3x3_wino": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_nchw_to_slab_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_int] * 5 + [C.c_void_p]),
     "innfer_slab_split_to_nchw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),

@@ -50,18 +50,84 @@ def shard_tiles(n_tiles, world, rank):
 MAX_TILE_BATCH = 272
 
 
-def tile_batches(count, tile_batch=None):
-    """Sizes of the network launches for `count` tiles.  tile_batch=None: as few launches as fit `MAX_TILE_BATCH` tiles each, evenly sized
-    (798 tiles -> 3 x 266).  A launch tiles its whole batch as ONE canvas (csrc/conv3x3.hip, conv3x3_pc<.., CV>) whose tile count is then
-    rounded up to whole rounds of 256 workgroups: 64 tiles of 200^2 are 13.35 rounds (93 % useful), 266 are 54.8 (98 %); the workspace
-    of 272 tiles of 200^2 is 64 GB of the 288 GB.  A number: fixed-size launches (the last one takes the remainder)."""
+def tile_batches(count, tile_batch=None, cap=None):
+    """Sizes of the network launches for `count` tiles.  tile_batch=None: as few launches as fit `cap` tiles each (default MAX_TILE_BATCH), evenly
+    sized (798 tiles -> 3 x 266).  A launch tiles its whole batch as ONE canvas (csrc/conv3x3.hip, conv3x3_pc<.., CV>) whose tile count is then
+    rounded up to whole rounds of 256 workgroups: 64 tiles of 200^2 are 13.35 rounds (93 % useful), 266 are 54.8 (98 %).  The workspace of 272
+    tiles of 200^2 is 64 GB of the 288 GB for a 4x RRDBNet in fp16 -- but 202 GiB at 8x and 770 GiB at 16x: callers that know their engine pass
+    cap=engine_tile_cap(...), which sizes the launch from innfer_*_workspace_bytes and the free memory.  A number: fixed-size launches (the
+    last one takes the remainder)."""
     if count <= 0:
         return []
     if tile_batch:
         return [min(tile_batch, count - i) for i in range(0, count, tile_batch)]
-    nb = -(-count // MAX_TILE_BATCH)
+    cap = max(1, min(int(cap), MAX_TILE_BATCH)) if cap else MAX_TILE_BATCH
+    nb = -(-count // cap)
     base, rem = divmod(count, nb)
     return [base + (1 if i < rem else 0) for i in range(nb)]
+
+
+def free_device_bytes(device):
+    """Bytes a new allocation can draw on: what the driver reports free plus the blocks torch's caching allocator holds without using them."""
+    free, _ = torch.cuda.mem_get_info(device)
+    return free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+
+
+def engine_tile_cap(model_fn, ps, dtype, device, fraction=0.8, budget=None):
+    """Largest tile batch (<= MAX_TILE_BATCH) whose engine workspace plus tile tensors fit `fraction` of the device's free memory (or `budget`
+    bytes): model_fn.tile_batch_bytes(b, ps, dtype) when the callable has one (the nn.Module shells of innfer_amd do), MAX_TILE_BATCH otherwise.
+    The engine's own workspace counts as free (it is re-used or replaced)."""
+    cost = getattr(model_fn, 'tile_batch_bytes', None)
+    if cost is None:
+        return MAX_TILE_BATCH
+    if budget is None:
+        ws = getattr(model_fn, '_ws', None)
+        budget = fraction * (free_device_bytes(device) + (ws.numel() if ws is not None else 0))
+    if cost(MAX_TILE_BATCH, ps, dtype) <= budget:
+        return MAX_TILE_BATCH
+    lo, hi = 1, MAX_TILE_BATCH                      # cost is monotonic in the batch: largest b with cost(b) <= budget (at least 1)
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if cost(mid, ps, dtype) <= budget:
+            lo = mid
+        else:
+            hi = mid - 1
+    return lo
+
+
+def run_tile_batches(model_fn, tiles, tile_batch=None, sink=None, pick=None):
+    """tiles [n,C,ps,ps] through model_fn in batches (tile_batches with the engine's cap); an allocator out-of-memory halves the batch and goes
+    on (workspace released first) instead of ending the image.  sink(i, y): consume the result of tiles [i, i + len(y)); without one the results
+    are returned concatenated.  pick: applied to model_fn's return value (PPON returns a tuple)."""
+    n = tiles.shape[0]
+    outs = []
+    cap = None if tile_batch else engine_tile_cap(model_fn, tiles.shape[-1], tiles.dtype, tiles.device)
+    i = 0
+    while i < n:
+        sizes = tile_batches(n - i, tile_batch, cap)
+        b = sizes[0]
+        try:
+            y = model_fn(tiles[i:i + b])
+        except torch.OutOfMemoryError:
+            if b == 1:
+                raise
+            rel = getattr(model_fn, 'release_workspace', None)
+            if rel is not None:
+                rel()
+            torch.cuda.empty_cache()
+            tile_batch, cap = None, max(1, b // 2)
+            continue
+        if pick is not None:
+            y = pick(y)
+        if sink is not None:
+            sink(i, y)
+        else:
+            outs.append(y)
+        i += b
+        del y
+    if sink is not None:
+        return None
+    return torch.cat(outs, 0) if len(outs) != 1 else outs[0]
 
 
 def _sync(t):
@@ -185,16 +251,13 @@ class ChopRunner:
             tiles = self.extract_fn(data, (ps, ps), [self.step, self.step], batch_first=True,
                                     tile_range=(first, count)).squeeze(0)
             base = first if rank == 0 else 0
+            def land(i, y):
+                if y.shape[1:] != hr.shape[1:] or y.dtype != hr.dtype:
+                    raise RuntimeError(f'ChopRunner: model_fn returned {tuple(y.shape[1:])} {y.dtype}, every rank was told '
+                                       f'{tuple(hr.shape[1:])} {hr.dtype} (set out_channels / out_dtype)')
+                hr[base + i:base + i + y.shape[0]].copy_(y)
             with torch.no_grad():
-                i = 0
-                for b in tile_batches(count, self.tile_batch):
-                    y = self.model_fn(tiles[i:i + b])
-                    if y.shape[1:] != hr.shape[1:] or y.dtype != hr.dtype:
-                        raise RuntimeError(f'ChopRunner: model_fn returned {tuple(y.shape[1:])} {y.dtype}, every rank was told '
-                                           f'{tuple(hr.shape[1:])} {hr.dtype} (set out_channels / out_dtype)')
-                    hr[base + i:base + i + b].copy_(y)
-                    i += b
-                    del y
+                run_tile_batches(self.model_fn, tiles, self.tile_batch, sink=land)
             del tiles
         if prof:
             _sync(data)

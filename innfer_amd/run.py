@@ -6,7 +6,8 @@ Differences that are the point of this build:
   * chop tiles are pushed through the network in BATCHES (the reference loops
     batch-1 and calls empty_cache() per tile, run.py:186-197); per-tile results
     are identical because tiles are independent.  tile_batch=None sizes the
-    batches for 288 GB of HBM (parallel.tile_batches: <= 272 tiles per launch);
+    batches from the engine's workspace and the free memory (parallel.engine_tile_cap:
+    <= 272 tiles per launch; an allocator OOM halves the batch and goes on);
   * with torch.distributed initialised, tiles can be sharded over ranks and
     gathered on rank 0 (parallel.py).
 There is no CPU execution path: device must be a GPU.
@@ -161,21 +162,19 @@ class Model:
         patch_size = min(H, W, patch_size)
         tiles = extract_patches_2d(data, (patch_size, patch_size), [step, step], batch_first=True,
                                    tile_range=tile_range).squeeze(0)
-        from .parallel import tile_batches
-        outs, i = [], 0
+        from .parallel import run_tile_batches
         with torch.no_grad():
-            for b in tile_batches(tiles.shape[0], self.tile_batch):
-                outs.append(self._predict(tiles[i:i + b]))
-                i += b
-        hr = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
+            hr = run_tile_batches(self.model, tiles, self.tile_batch, pick=self._pick)
         if tile_range is not None:
             return hr
         return recompose_tensor(hr, H, W, step=step, scale=self.scale)
 
-    def _predict(self, x):
-        """self.model(x); PPON returns (content, structure, perceptual) and run.py keeps the last (run.py:191-192,220-221)."""
-        y = self.model(x)
+    def _pick(self, y):
+        """PPON returns (content, structure, perceptual) and run.py keeps the last (run.py:191-192,220-221)."""
         return y[2] if self.arch == 'ppon' else y
+
+    def _predict(self, x):
+        return self._pick(self.model(x))
 
     def __call__(self, data):
         if self.chop:
@@ -191,7 +190,7 @@ class Model:
         import numpy as np
         from . import lib as L
         from .architectures.engine_module import EngineModule
-        from .parallel import tile_batches
+        from .parallel import run_tile_batches
         from .utils import utils as U
         host = isinstance(img, np.ndarray)
         d = torch.from_numpy(np.ascontiguousarray(img)).to(self.device) if host else img.contiguous()
@@ -210,11 +209,7 @@ class Model:
                 n = len(ys) * len(xs)
                 tiles = torch.empty((n, Cc, ps, ps), dtype=dt, device=d.device)
                 L.check(L.lib.innfer_extract_tiles_u8(d.data_ptr(), Cc, H, W, int(bool(normalize)), ps, 0.5, 0, n, tiles.data_ptr(), code, stream))
-                outs, i = [], 0
-                for b in tile_batches(n, self.tile_batch):
-                    outs.append(self._predict(tiles[i:i + b]))
-                    i += b
-                hr = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
+                hr = run_tile_batches(self.model, tiles, self.tile_batch, pick=self._pick)
                 Co, P = hr.shape[1], hr.shape[2]
                 if out is None:
                     out = torch.empty((H * s, W * s, Co), dtype=torch.uint8, device=d.device)

@@ -78,3 +78,50 @@ def test_tile_batches():
         b = tile_batches(n)
         assert sum(b) == n and max(b) <= MAX_TILE_BATCH and max(b) - min(b) <= 1 and len(b) == -(-n // MAX_TILE_BATCH)
     assert tile_batches(10, 4) == [4, 4, 2] and tile_batches(8, 64) == [8]
+
+
+def test_tile_batches_are_sized_from_the_engine_and_survive_oom():
+    """the chop batch follows the engine's workspace, not a constant.  engine_tile_cap takes the largest batch whose cost fits the
+    budget (a 16x network: 2.9 GB per tile -> far fewer than 272 per launch); run_tile_batches halves the batch when the allocator runs out and
+    still returns every tile's result in order."""
+    import torch
+    from innfer_amd.parallel import MAX_TILE_BATCH, engine_tile_cap, run_tile_batches, tile_batches
+
+    class Fake:
+        def __init__(self, per_tile, limit=None):
+            self.per_tile, self.limit, self.calls, self.released = per_tile, limit, [], 0
+
+        def tile_batch_bytes(self, b, ps, dtype):
+            return 1000 + b * self.per_tile
+
+        def release_workspace(self):
+            self.released += 1
+
+        def __call__(self, x):
+            self.calls.append(x.shape[0])
+            if self.limit and x.shape[0] > self.limit:
+                raise torch.OutOfMemoryError("fake")
+            return x * 2.0
+
+    assert engine_tile_cap(Fake(10), 200, torch.float16, "cpu", budget=1e9) == MAX_TILE_BATCH
+    assert engine_tile_cap(Fake(100), 200, torch.float16, "cpu", budget=1000 + 100 * 57 + 50) == 57
+    assert engine_tile_cap(Fake(100), 200, torch.float16, "cpu", budget=5) == 1            # never zero: a single tile is tried (and may raise)
+    assert engine_tile_cap(lambda t: t, 200, torch.float16, "cpu", budget=5) == MAX_TILE_BATCH      # a bare callable: nothing known about it
+    assert tile_batches(100, None, 57) == [50, 50] and tile_batches(100, None, 1000) == [100] and tile_batches(7, 3, 2) == [3, 3, 1]
+    tiles = torch.arange(23 * 2, dtype=torch.float32).reshape(23, 2, 1, 1)
+    # (cap from the engine is MAX_TILE_BATCH here: budget unknown on the CPU -> patch the probe)
+    import innfer_amd.parallel as P
+    real = P.free_device_bytes
+    P.free_device_bytes = lambda device: 1 << 40
+    try:
+        m = Fake(10, limit=5)
+        y = run_tile_batches(m, tiles)
+        assert torch.equal(y, tiles * 2.0) and m.released >= 1
+        assert m.calls[0] == 23 and max(c for c in m.calls[-4:]) <= 5 and sum(c for c in m.calls if c <= 5) == 23
+        got = {}
+        run_tile_batches(Fake(10), tiles, tile_batch=4, sink=lambda i, t: got.__setitem__(i, t.clone()))
+        assert sorted(got) == [0, 4, 8, 12, 16, 20] and torch.equal(torch.cat([got[i] for i in sorted(got)]), tiles * 2.0)
+        with __import__("pytest").raises(torch.OutOfMemoryError):
+            run_tile_batches(Fake(10, limit=0.5), tiles)          # even one tile does not fit: the error surfaces
+    finally:
+        P.free_device_bytes = real

@@ -1041,6 +1041,24 @@ def test_command_line_image_loop(dev, tmp_path, monkeypatch, capsys):
             with torch.no_grad():
                 ref = oracle.tensor2np(oracle.rrdbnet_forward(sds["2x_up.pth"], oracle.rrdbnet_forward(sds["1x_clean.pth"], x, nb=1, scale=1), nb=1, scale=2))
             assert (np.abs(got.astype(np.int16) - ref.astype(np.int16)) <= 1).mean() >= 0.99
+    # -no_fp16 (run.py:345,421-422): the same chain on the fp32-accurate engine -- exactly the float32 library calls, and the oracle's fp32
+    # chop_forward chain to the uint8 code (<= 1e-4 before the rounding: a code can only differ where 255 x lies that close to a half)
+    assert R.main(["-m", "clean+2x_up", "-i", "in", "-o", "out32", "-no_fp16"]) == 0
+    f1 = lambda t: oracle.rrdbnet_forward(sds["1x_clean.pth"], t, nb=1, scale=1)
+    f2 = lambda t: oracle.rrdbnet_forward(sds["2x_up.pth"], t, nb=1, scale=2)
+    for k, im in imgs.items():
+        got = U.read_img(str(tmp_path / "out32" / f"{k}.png"))
+        assert np.array_equal(got, U.tensor2np(m2(m1(U.np2tensor(im, dtype=torch.float32))))), k
+        with torch.no_grad():
+            ref = oracle.tensor2np(oracle.chop_forward(f2, oracle.chop_forward(f1, oracle.np2tensor(im), 1), 2))
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        assert d.max() <= 1 and (d == 0).mean() >= 0.999, (k, d.max(), (d == 0).mean())
+    # a generator without an fp32 engine refuses the flag instead of running fp16 behind it
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    torch.save(get_network(get_network_G_config("pan", 4)).state_dict(), str(tmp_path / "models" / "4x_pan.pth"))
+    with pytest.raises(NotImplementedError, match="no_fp16"):
+        R.main(["-m", "4x_pan", "-i", "in", "-o", "out_pan", "-no_fp16"])
 
 
 @pytest.mark.parametrize("chop", [True, False])
@@ -1691,6 +1709,55 @@ def test_model_chop_golden(dev, golden, tmp_path):
         assert np.abs(y2[0, :, ::8, ::8].numpy() - g[f"nochop_{tag}_sub"]).max() < 1e-2
 
 
+def test_model_chop_16x_batches_follow_the_workspace(dev):
+    """a 16x RRDBNet needs 2.9 GB of workspace per 200 x 200 tile (innfer_net_workspace_bytes: 770 GiB for 266 tiles), so the chop
+    batches must follow the engine's workspace and the free memory instead of the 272-tile ceiling sized for 4x.  A 1000 x 1100 image (90 tiles)
+    through Model(chop=True): the automatic batches fit, and the blend equals the one of batch-1 launches bit for bit."""
+    from innfer_amd import synth
+    from innfer_amd.parallel import MAX_TILE_BATCH, engine_tile_cap, free_device_bytes
+    from innfer_amd.run import Model
+    sd = _sd(synth.rrdbnet_shapes(nb=1, scale=16), 161)
+    m = Model(None, arch="infer", device="cuda", chop=True, state_dict=dict(sd))
+    assert (m.arch, m.scale) == ("esrgan", 16)
+    cap = engine_tile_cap(m.model, 200, torch.float16, dev)
+    need = m.model.tile_batch_bytes(cap, 200, torch.float16)
+    assert 1 <= cap < MAX_TILE_BATCH and need <= 0.8 * free_device_bytes(dev) + 1, (cap, need)
+    assert m.model.tile_batch_bytes(MAX_TILE_BATCH, 200, torch.float16) > 700 * 2 ** 30
+    x = torch.from_numpy(synth.uniform((1, 3, 300, 500), 162)).to(dev).half()          # 2 x 4 tiles: 4800 x 8000 output
+    y = m(x)
+    assert tuple(y.shape) == (1, 3, 4800, 8000) and torch.isfinite(y).all()
+    m1 = Model(None, arch="infer", device="cuda", chop=True, tile_batch=1, state_dict=dict(sd))
+    assert torch.equal(m1(x), y)
+    del y
+    m.model.release_workspace(); m1.model.release_workspace()
+    torch.cuda.empty_cache()
+    # an allocator out-of-memory inside a launch halves the batch instead of ending the image: a budget-blind fixed batch of 90 tiles (260 GiB of
+    # workspace) with only ~100 GiB left free by a ballast tensor -> 90 fails, 45 fails (130 GiB), 22 runs
+    big = torch.from_numpy(synth.uniform((1, 3, 1000, 1100), 163)).to(dev).half()      # 9 x 10 = 90 tiles
+    from innfer_amd.parallel import run_tile_batches
+    from innfer_amd.utils import utils as U
+    tiles = U.extract_patches_2d(big, (200, 200), [0.5, 0.5], batch_first=True).squeeze(0)
+    seen, hr, ballast = [], None, None
+    orig = m.model.forward
+    def spy(t, *a, **k):
+        seen.append(t.shape[0])
+        return orig(t, *a, **k)
+    m.model.forward = spy
+    try:
+        ballast = torch.empty(max(0, free_device_bytes(dev) - 100 * 2 ** 30), dtype=torch.uint8, device=dev)
+        with torch.no_grad():
+            hr = run_tile_batches(m.model, tiles, tile_batch=MAX_TILE_BATCH)
+        assert seen[:2] == [90, 45] and sum(seen[2:]) == 90 and max(seen[2:]) <= 22, seen          # (the remaining tiles go in evenly sized launches)
+        assert tuple(hr.shape) == (90, 3, 3200, 3200)
+        m.model.forward = orig
+        assert torch.equal(hr[89:90], m.model(tiles[89:90]))
+    finally:
+        m.model.forward = orig
+        del hr, tiles, ballast
+        m.model.release_workspace()
+        torch.cuda.empty_cache()
+
+
 def test_model_chop_pan_vs_oracle(dev, tmp_path):
     """A PAN checkpoint through Model.__call__(chop=True): loader inference (arch / scale from the keys), tile batches through the
     halo-tile convs, blend -- against the oracle's chop_forward of the oracle's PAN on a 210x250 image (4 tiles)."""
@@ -1720,7 +1787,7 @@ def test_full_frame_1080p_translation_property(dev):
     contains the window plus the network's receptive radius (stride-1 convs are
     translation equivariant).  Also: banded schedule == plain schedule at full size."""
     from innfer_amd import synth
-    net, _ = _rrdb(dev, 23, 4)
+    net, sd = _rrdb(dev, 23, 4)
     x = torch.from_numpy(synth.uniform((1, 3, 1080, 1920), 31)).to(dev).half()
     y = net(x)
     assert tuple(y.shape) == (1, 3, 4320, 7680)
@@ -1735,6 +1802,79 @@ def test_full_frame_1080p_translation_property(dev):
     net.band_rows = 128
     assert torch.equal(net(x), y)
     net.band_rows = 0
+    # ... and the VALUES of that window against the oracle (fp32, host CPU) run on the same 734 x 734 crop -- the crop holds the window's whole
+    # receptive field, so the oracle's window IS the reference's value for the full frame (run.py:217-219, RRDBNet_arch.py:50-51).  SURVEY 8c:
+    # fp16 engine <= 1e-2 and >= 99 % of the uint8 codes within +-1; fp32-accurate engine (a float32 frame: 24 GB of slab pairs) <= 1e-4.
+    import oracle
+    crop = x[:, :, y0:y1, x0:x1].float().cpu()
+    with torch.no_grad():
+        ref = oracle.rrdbnet_forward(sd, crop, nb=23, scale=4)[:, :, 4 * (cy - hw - y0):4 * (cy + hw - y0), 4 * (cx - hw - x0):4 * (cx + hw - x0)]
+    e16 = (a.float().cpu() - ref).abs()
+    print(f"1080p frame, 128x128 HR window vs oracle: fp16 engine max {e16.max().item():.2e} mean {e16.mean().item():.2e}")
+    assert e16.max().item() < 1e-2, e16.max().item()
+    assert _codes_within_one(dev, a.float().cpu().numpy(), ref.numpy()) >= 0.99
+    del y, yc
+    y32 = net(x.float())
+    e32 = (y32[:, :, 4 * (cy - hw):4 * (cy + hw), 4 * (cx - hw):4 * (cx + hw)].cpu() - ref).abs()
+    print(f"1080p frame, same window: fp32-accurate engine max {e32.max().item():.2e} mean {e32.mean().item():.2e}")
+    assert e32.max().item() < 1e-4, e32.max().item()
+    del y32
+    net.release_workspace()
+    torch.cuda.empty_cache()
+
+
+def test_bench_shape_tile_batch_vs_oracle(dev):
+    """The chop path at the bench's shape: ONE launch sequence over a canvas of 266 tiles of 200 x 200 (parallel.tile_batches: 798 = 3 x 266) through
+    RRDBNet-23 4x.  Tiles at the canvas's first, an inner and its last cell against the oracle's fp32 forward of that tile alone (<= 1e-2, >= 99 %
+    of the uint8 codes within +-1) and against the batch-1 forward of the engine (bit for bit: tiles are independent, run.py:186-197)."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.parallel import tile_batches
+    assert tile_batches(798, None)[0] == 266
+    net, sd = _rrdb(dev, 23, 4)
+    n = 266
+    tiles = torch.from_numpy(synth.uniform((n, 3, 200, 200), 93)).half()
+    y = net(tiles.to(dev))
+    assert tuple(y.shape) == (n, 3, 800, 800)
+    for i in (0, 137, 265):
+        assert torch.equal(y[i:i + 1], net(tiles[i:i + 1].to(dev))), i
+    for i in (137, 265):
+        with torch.no_grad():
+            ref = oracle.rrdbnet_forward(sd, tiles[i:i + 1].float(), nb=23, scale=4)
+        err = (y[i:i + 1].float().cpu() - ref).abs()
+        print(f"tile {i} of a 266-tile canvas vs oracle: max {err.max().item():.2e} mean {err.mean().item():.2e}")
+        assert err.max().item() < 1e-2, (i, err.max().item())
+        assert _codes_within_one(dev, y[i:i + 1].float().cpu().numpy(), ref.numpy()) >= 0.99
+    del y
+    net.release_workspace()
+    torch.cuda.empty_cache()
+
+
+def test_unet256_batch64_vs_oracle(dev, golden):
+    """BASELINE config 5 at its stated size: pix2pix UNet_256 on 64 x 3 x 256 x 256 (train-mode BatchNorm per image, run.py:299-303,349-357).  Images
+    0 and 63 of the batch against the engine's batch-1 forwards (bit for bit) and against the oracle's fp32 forward of that image (<= 1e-2
+    on the tanh output... the network amplifies fp16 rounding through eight BatchNorms: bounded like golden G7 / G17)."""
+    import ast
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    g = golden("g7_unet256")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = _sd(shapes)
+    net = get_network(get_network_G_config("unet_256", 1))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()                              # run.py runs pix2pix with meval=False
+    x = torch.from_numpy(synth.uniform((64, 3, 256, 256), 640, -1.0, 1.0)).half()
+    y = net(x.to(dev))
+    assert tuple(y.shape) == (64, 3, 256, 256) and torch.isfinite(y).all()
+    for i in (0, 63):
+        assert torch.equal(y[i:i + 1], net(x[i:i + 1].to(dev))), i
+        with torch.no_grad():
+            ref = oracle.unet_forward(sd, x[i:i + 1].float())
+        err = (y[i:i + 1].float().cpu() - ref).abs()
+        print(f"UNet_256 x64, image {i} vs oracle: max {err.max().item():.2e} mean {err.mean().item():.2e}")
+        assert err.max().item() < 1e-2 and err.mean().item() < 1e-3, (i, err.max().item(), err.mean().item())
 
 
 def test_4k_input_untiled_addresses_beyond_2gib(dev):
@@ -1801,3 +1941,69 @@ def test_7x7_last_conv_interior_and_edge_tiles_vs_oracle(dev, kind):
         ref = oracle.wbcunet_forward(sd, x) if kind == "wbcunet" else oracle.resnet_forward(sd, x, n_blocks=9)
     err = (y - ref).abs()
     assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (kind, err.max().item(), err.mean().item())
+
+
+def _run_wino_conv(dev, x, w, b, K, mode, act=0, up=False, res1=None, s1=1.0, rows=None):
+    """The row-Winograd experiment (innfer_conv_args.winograd = 1) or the direct conv on the same tiles (2) through the C ABI."""
+    import innfer_amd.lib as L
+    N, Cc, Hs, Ws = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up else (Hs, Ws)
+    g_in = N * Hs * Ws * 32
+    slab = torch.full((Cc // 32, N, Hs, Ws, 32), 7.0, dtype=torch.float16, device=dev)
+    L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), g_in, 0, N, Cc, Hs, Ws, None))
+    wc = np.ascontiguousarray(w.numpy())
+    if mode == 1:
+        packed = np.zeros(L.lib.innfer_conv3x3_wino_packed_bytes(K, Cc), dtype=np.uint8)
+        L.check(L.lib.innfer_pack_conv3x3_wino(wc.ctypes.data, K, Cc, packed.ctypes.data))
+    else:
+        packed = np.zeros(L.lib.innfer_conv3x3_packed_bytes(K, Cc), dtype=np.uint8)
+        L.check(L.lib.innfer_pack_conv3x3(wc.ctypes.data, K, Cc, packed.ctypes.data))
+    d_packed, d_bias = torch.from_numpy(packed).to(dev), b.float().to(dev)
+    g_out = N * H * W * 32
+    out = torch.full((K // 32, N, H, W, 32), -3.0, dtype=torch.float16, device=dev)
+    a = L.ConvArgs()
+    a.d_in, a.in_group_stride, a.C = slab.data_ptr(), g_in, Cc
+    a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
+    a.d_out, a.out_group_stride, a.out_ch_off, a.K = out.data_ptr(), g_out, 0, K
+    a.N, a.H, a.W, a.act, a.upsample2x, a.winograd = N, H, W, act, int(up), mode
+    keep = [slab, d_packed, d_bias]
+    if res1 is not None:
+        rs = torch.empty((K // 32, N, H, W, 32), dtype=torch.float16, device=dev)
+        L.check(L.lib.innfer_nchw_to_slab(res1.to(dev).contiguous().data_ptr(), L.F16, rs.data_ptr(), g_out, 0, N, K, H, W, None))
+        a.d_res1, a.res1_group_stride, a.res1_scale = rs.data_ptr(), g_out, s1
+        keep.append(rs)
+    if rows:
+        a.row_begin, a.row_end = rows
+    L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
+    torch.cuda.synchronize()
+    res = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
+    L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), g_out, 0, res.data_ptr(), L.F32, N, K, H, W, None))
+    torch.cuda.synchronize()
+    return res.cpu(), out.cpu()
+
+
+def test_winograd_rows_vs_direct(dev):
+    """The row-Winograd experiment (F(2,3) along the image rows -- 12 MFMAs per 32 output pixels and channel tile instead of
+    18; fp16 input transform on the LDS fragments, U = G g rounded once) against F.conv2d on the same fp16 operands: within the single-conv
+    bound of the direct kernels (4e-3; its own transform rounding adds ~2^-11 of the operand size), ragged sizes, batches, borders, residual,
+    nearest-2x input, row range, K = 64 as two 32-channel groups; the direct conv on the same 16 x 32 tiles (the A/B partner) to the same bound."""
+    from innfer_amd import synth
+    rng = np.random.RandomState(7)
+    for case, (Cc, K, N, H, W, act, up, res, rows) in enumerate([
+            (64, 32, 1, 16, 32, 1, False, False, None), (160, 32, 1, 37, 45, 1, False, False, None), (96, 32, 2, 33, 70, 0, False, True, None),
+            (192, 64, 1, 21, 50, 0, False, True, None), (64, 64, 1, 17, 23, 1, True, False, None), (32, 32, 3, 5, 3, 2, False, False, None),
+            (128, 32, 1, 50, 64, 1, False, False, (7, 30)), (64, 32, 1, 1, 1, 0, False, False, None), (64, 32, 1, 40, 33, 1, False, False, None)]):
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        x = torch.from_numpy(synth.uniform((N, Cc, H, W), 5000 + case, -1, 1)).half()
+        w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 5100 + case, -1, 1)) / np.sqrt(9 * Cc)
+        b = torch.from_numpy(synth.uniform((K,), 5200 + case, -1, 1))
+        r1 = torch.from_numpy(synth.uniform((N, K, Ho, Wo), 5300 + case, -1, 1)).half() if res else None
+        ref = _ref_conv(x, w, b, act=act, up=up, res1=r1, s1=0.2)
+        for mode in ((1, 2) if K == 32 else (1,)):
+            got, raw = _run_wino_conv(dev, x, w, b, K, mode, act=act, up=up, res1=r1, s1=0.2, rows=rows)
+            if rows:
+                err = (got[:, :, rows[0]:rows[1]] - ref[:, :, rows[0]:rows[1]]).abs().max().item()
+                assert torch.all(raw[:, :, :rows[0]] == -3.0) and torch.all(raw[:, :, rows[1]:] == -3.0)
+            else:
+                err = (got - ref).abs().max().item()
+            assert err < 4e-3, (case, mode, err)
