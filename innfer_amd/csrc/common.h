@@ -79,7 +79,8 @@ struct ConvLaunch {
     int split;                                    // fp32-accurate mode: every tensor is a (hi, lo) pair of fp16 slabs, lo = fp16((x - hi) * 2^11) (conv3x3.hip, SPLIT); panels from
     long in_lo, out_lo, res1_lo, res2_lo;         // conv_pack_split / conv_pack_1x1_split; *_lo: distance (elements) from a hi slab to its lo twin.  Plain 3x3 / 1x1 slab convs
                                                   // (act 0..2, residuals, upsampled input, batches) and the planar last conv
-    int wino;                                     // experiment: 1 = Winograd F(2,3) along the rows (panels from conv_pack_wino), 2 = the direct conv on the same 16 x 32 tiles
+    int wino;                                     // experiment: 1 = Winograd F(2,3) along the rows (panels from conv_pack_wino), 2 = the direct conv on the same 16 x 32 tiles,
+                                                  // 3 = Winograd rows on 64-channel tiles with the weight transform made by the consumers (panels from conv_pack_wino9)
     const f16* pair_wpk; const float* pair_bias;  // net.hip only: non-null = this 32-output LeakyReLU conv AND the next one of the dense block (inputs: the same
                                                   // C channels + this conv's output, output: the following channel group) as one conv_pair_launch
 };
@@ -102,6 +103,7 @@ size_t conv_packed_bytes(int K, int C);
 void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
 size_t conv_packed_bytes_wino(int K, int C);
 void conv_pack_wino(const float* w_oihw, int K, int C, void* packed);      // host; ConvLaunch.wino == 1
+void conv_pack_wino9(const float* w_oihw, int K, int C, void* packed);     // host; ConvLaunch.wino == 3 (conv_packed_bytes(K, C) bytes)
 void conv_pack_split(const float* w_oihw, int K, int C, void* packed);     // host; 3 * conv_packed_bytes(K, C): the (wl | wh | wh) panels of ConvLaunch.split
 void conv_pack_1x1_split(const float* w_oi, int K, int C, void* packed);   // host; 3 * conv_packed_bytes_taps(K, C, 0x10)
 int conv_launch(const ConvLaunch& L, hipStream_t s);

@@ -820,6 +820,12 @@ extern "C" int innfer_pack_conv3x3_wino(const float* w, int K, int C, void* h_pa
     return INNFER_OK;
 }
 
+extern "C" int innfer_pack_conv3x3_wino9(const float* w, int K, int C, void* h_packed) {
+    if (!w || !h_packed || K <= 0 || K % 64 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv3x3_wino9: K=%d (%% 64) C=%d (%% 32)", K, C);
+    conv_pack_wino9(w, K, C, h_packed);
+    return INNFER_OK;
+}
+
 extern "C" size_t innfer_conv7x1_packed_bytes(int K, int C) { return (K > 0 && C > 0 && C % 32 == 0) ? conv_packed_bytes7v(K, C) : 0; }
 extern "C" int innfer_pack_conv7x1(const float* w, int K, int C, void* packed) {
     if (!w || !packed || K <= 0 || K % 32 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv7x1: K=%d (%% 32) C=%d (%% 32)", K, C);
@@ -885,7 +891,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
     L.out_mode = a->pixel_shuffle2 ? OUT_SHUFFLE2 : OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
     if (a->winograd) {
-        if (a->pixel_shuffle2 || a->split || a->K % 32 || a->out_ch_off % 32 || (a->winograd != 1 && a->winograd != 2))
+        if (a->pixel_shuffle2 || a->split || a->K % 32 || a->out_ch_off % 32 || a->winograd < 1 || a->winograd > 3)
             return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (winograd): 1 | 2, K %% 32 == 0 (K=%d), whole output groups", a->K);
         L.wino = a->winograd;
     }
