@@ -65,31 +65,44 @@ class FramePipeline:
     def __call__(self, frames):
         pending = []                                   # slots in flight, oldest first
         k = 0
-        for img in frames:
-            if not isinstance(img, np.ndarray) or img.dtype != np.uint8 or img.ndim != 3:
-                raise TypeError('FramePipeline: uint8 HWC numpy frames expected')
-            if self._slots is None:
-                self._alloc(img.shape)
-            sl = self._slots[k % self.depth]
-            if sl['busy']:                             # the ring is full: hand out its oldest frame first
+        try:
+            for img in frames:
+                if not isinstance(img, np.ndarray) or img.dtype != np.uint8 or img.ndim != 3:
+                    raise TypeError('FramePipeline: uint8 HWC numpy frames expected')
+                if self._slots is None:
+                    self._alloc(img.shape)
+                sl = self._slots[k % self.depth]
+                if sl['busy']:                             # the ring is full: hand out its oldest frame first
+                    yield self._finish(pending.pop(0))
+                if tuple(sl['h_in'].shape) != img.shape:
+                    raise ValueError('FramePipeline: all frames must have the shape of the first one')
+                sl['h_in'].numpy()[...] = img              # pageable -> pinned (host memcpy)
+                with torch.cuda.stream(self.s_in):
+                    sl['d_in'].copy_(sl['h_in'], non_blocking=True)
+                    sl['up'].record(self.s_in)
+                self._compute(sl, img.shape)
+                sl['h_out'] = self._free_out.pop()         # never the buffer lent to the consumer: that one returns in _finish
+                with torch.cuda.stream(self.s_out):
+                    self.s_out.wait_event(sl['done'])
+                    sl['h_out'].copy_(sl['d_out'], non_blocking=True)
+                    sl['down'].record(self.s_out)
+                sl['busy'] = True
+                pending.append(sl)
+                k += 1
+            while pending:
                 yield self._finish(pending.pop(0))
-            if tuple(sl['h_in'].shape) != img.shape:
-                raise ValueError('FramePipeline: all frames must have the shape of the first one')
-            sl['h_in'].numpy()[...] = img              # pageable -> pinned (host memcpy)
-            with torch.cuda.stream(self.s_in):
-                sl['d_in'].copy_(sl['h_in'], non_blocking=True)
-                sl['up'].record(self.s_in)
-            self._compute(sl, img.shape)
-            sl['h_out'] = self._free_out.pop()         # never the buffer lent to the consumer: that one returns in _finish
-            with torch.cuda.stream(self.s_out):
-                self.s_out.wait_event(sl['done'])
-                sl['h_out'].copy_(sl['d_out'], non_blocking=True)
-                sl['down'].record(self.s_out)
-            sl['busy'] = True
-            pending.append(sl)
-            k += 1
-        while pending:
-            yield self._finish(pending.pop(0))
+        finally:
+            # the consumer may abandon the generator mid-stream (break, exception): wait for what is in flight and return every buffer to the
+            # pool, so that the next call starts from a clean ring instead of failing on a drained one
+            for sl in pending:
+                sl['down'].synchronize()
+                sl['busy'] = False
+                if sl['h_out'] is not None:
+                    self._free_out.append(sl['h_out'])
+                    sl['h_out'] = None
+            if self._lent is not None:
+                self._free_out.append(self._lent)
+                self._lent = None
 
     def _finish(self, sl):
         sl['down'].synchronize()

@@ -263,20 +263,18 @@ def check_model_path(model_path, all_models=None):
 
 
 def get_scale_name(model_path, scale=None):
-    """`4x_name.pth` -> 4 (run.py:277-293)."""
+    """The scale a model file announces in the first two characters of its name -- `4x_name.pth` -> 4, `x2net.pth` -> 2 -- or None; an explicit
+    `scale` wins, with the reference's warning when the name disagrees (run.py:277-293)."""
     import os.path as osp
-    rlt_scale = None
-    scale_name = str(osp.basename(model_path)[0:2]).lower()
-    if 'x' in scale_name:
-        try:
-            rlt_scale = int(scale_name.replace('x', ''))
-        except ValueError:
-            rlt_scale = None
-    if scale:
-        if rlt_scale and (scale != rlt_scale):
-            print(f"Warning: possible model scale mismatch on {model_path}")
-        return scale
-    return rlt_scale
+    import re
+    head = osp.basename(model_path)[:2].lower()
+    digits = head.replace('x', '')
+    from_name = int(digits) if 'x' in head and re.fullmatch(r'[+-]?\d+', digits.strip()) else None
+    if not scale:
+        return from_name
+    if from_name and from_name != scale:
+        print(f"Warning: possible model scale mismatch on {model_path}")
+    return scale
 
 
 pix2pix_extras = {'meval': False, 'strict': True, 'normalize': True}       # run.py:299-303
@@ -357,6 +355,13 @@ def main(argv=None):
 
     n_writers = max(2, min(16, os.cpu_count() or 2))
     reader, writer, pending = ThreadPoolExecutor(1), ThreadPoolExecutor(n_writers), deque()
+    last_write = {}                 # output path -> future of the last write submitted for it
+
+    def save_after(prev, img, img_out, path):
+        # a/x.png and b/x.png (or x.png and x.jpg) share output/x.png: the reference's serial loop keeps the LAST one, so writes to one path are chained
+        if prev is not None:
+            prev.result()
+        save(img, img_out, path)
     nxt = reader.submit(U.read_img, images[0]) if images else None
     try:
         for idx, image_path in enumerate(images):
@@ -382,7 +387,10 @@ def main(argv=None):
                 img_out = U.tensor2np(t_out.detach(), denormalize=normalize)
             if args.cf:
                 img_out = U.color_fix(img, img_out)
-            pending.append(writer.submit(save, img, img_out, osp.join(args.output, f'{img_name:s}.png')))
+            out_path = osp.join(args.output, f'{img_name:s}.png')
+            fut = writer.submit(save_after, last_write.get(out_path), img, img_out, out_path)
+            last_write[out_path] = fut
+            pending.append(fut)
             while len(pending) > n_writers:           # a bounded number of finished images wait for their files (an 8K RGB output is 100 MB)
                 pending.popleft().result()
         while pending:

@@ -1160,6 +1160,13 @@ def test_frame_pipeline_equals_serial_loop(dev):
     fixed = [o.copy() for o in FramePipeline(net, scale=2, device=dev, depth=2, color_fix=True)(frames[:3])]
     for f, sr, fx in zip(frames, serial, fixed):
         assert np.array_equal(fx, U.color_fix(f, sr, device=dev))
+    # a consumer that abandons the stream mid-way (break) leaves a clean ring behind: the same pipeline object serves the next stream in full
+    pipe = FramePipeline(net, scale=2, device=dev, depth=3)
+    for i, o in enumerate(pipe(frames)):
+        if i == 1:
+            break
+    again = [o.copy() for o in pipe(frames)]
+    assert len(again) == len(serial) and all(np.array_equal(a, b) for a, b in zip(again, serial))
 
 
 def test_ppon_scales_golden(dev, golden):

@@ -451,6 +451,24 @@ def test_image_loop_is_pipelined_and_keeps_the_serial_semantics(tmp_path, monkey
     assert R.main(["-m", "2x_standin", "-i", "in", "-o", "out_comp", "-comp"]) == 0                  # LR | SR side by side (save_img_comp)
     assert U.read_img(str(tmp_path / "out_comp" / "img00.png")).shape == (16, 44, 3)
 
+    # inputs in sub-folders that share a stem are written to ONE output path; the reference's serial loop keeps the last one, and so must the
+    # writer pool (writes to one path are chained, never concurrent).  A slow first write would otherwise win the race.
+    import time
+    (tmp_path / "in2" / "a").mkdir(parents=True); (tmp_path / "in2" / "b").mkdir()
+    first, last = synth.image_u8(64, 64, 3, 801), synth.image_u8(9, 9, 3, 802)
+    U.save_img(first, str(tmp_path / "in2" / "a" / "same.png")); U.save_img(last, str(tmp_path / "in2" / "b" / "same.png"))
+    order = [p for p in U.get_images_paths(str(tmp_path / "in2"))]
+    real_save = U.save_img
+
+    def slow_first(img, path, *a, **k):
+        if img.shape[0] == 128:
+            time.sleep(0.5)                              # the 64 x 64 input's (earlier) write is slow
+        return real_save(img, path, *a, **k)
+    monkeypatch.setattr(U, "save_img", slow_first)
+    assert R.main(["-m", "2x_standin", "-i", "in2", "-o", "out_same"]) == 0
+    want = last if order[-1].endswith(os.path.join("b", "same.png")) else first
+    assert np.array_equal(U.read_img(str(tmp_path / "out_same" / "same.png")), np.repeat(np.repeat(want, 2, 0), 2, 1))
+
     def failing_save(*a, **k):
         raise OSError("disk full")
     monkeypatch.setattr(U, "save_img", failing_save)
