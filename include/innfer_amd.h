@@ -333,8 +333,7 @@ typedef struct {
     int64_t in_lo, out_lo, res1_lo, res2_lo;
     int winograd;                       /* experiment (profiles/r3/winograd.txt; not used by the networks): 1 = Winograd F(2,3) along the image rows on 16 x 32 tiles -- two
                                            thirds of the MFMA work, fp16 transforms (parity vs the direct form: test_winograd_rows_vs_direct); d_packed from
-                                           innfer_pack_conv3x3_wino(); K % 32 == 0, act 0 / 1 / 2, residuals, upsample2x, row range; 2 = the direct conv on the same tiles (K 32); 3 = the Winograd form on 64-channel tiles with
-                                           the weight transform made by the consumer waves (K % 64 == 0, d_packed from innfer_pack_conv3x3_wino9()) (106) */
+                                           innfer_pack_conv3x3_wino(); K % 32 == 0, act 0 / 1 / 2, residuals, upsample2x, row range; 2 = the direct conv on the same tiles (K 32) (106) */
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);
@@ -351,7 +350,6 @@ int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream);
 int innfer_pack_conv3x3_split(const float* h_weight_oihw, int K, int C, void* h_packed);
 size_t innfer_conv3x3_wino_packed_bytes(int K, int C);
 int innfer_pack_conv3x3_wino(const float* h_weight_oihw, int K, int C, void* h_packed);
-int innfer_pack_conv3x3_wino9(const float* h_weight_oihw, int K, int C, void* h_packed);     /* winograd = 3 (K % 64 == 0): innfer_conv3x3_packed_bytes(K, C) bytes */
 
 /* NCHW (f16/f32) <-> blocked-NHWC f16 slab helpers used by tests of the single conv. */
 int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int64_t group_stride, int ch_off,
@@ -362,6 +360,15 @@ int innfer_slab_to_nchw(const void* d_slab, int64_t group_stride, int ch_off, vo
  * (hi + lo * 2^-11, exact in fp32).  (106) */
 int innfer_nchw_to_slab_split(const float* d_src, void* d_slab, int64_t group_stride, int64_t lo, int ch_off, int N, int C, int H, int W, void* stream);
 int innfer_slab_split_to_nchw(const void* d_slab, int64_t group_stride, int64_t lo, int ch_off, float* d_dst, int N, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------ launch timer (measurement only)
+ * Between innfer_timer_start() and innfer_timer_stop() every kernel launch the calling thread makes through the library's conv / gather-GEMM / UNet
+ * entry points is bracketed by a HIP-event pair on its stream.  innfer_timer_stop synchronises `stream` and returns, per launch in issue order, a
+ * kernel-family name (names[i * name_cap ..], NUL-terminated), the elapsed ms, and the launch's ALGORITHMIC flops and HBM bytes (operands read once,
+ * results written once; 0 where a family has none).  n receives the number of launches recorded (entries beyond cap are dropped).  bench.py builds
+ * the per-kernel two-roof entries of its `unet64` object from it.  (106) */
+int innfer_timer_start(void);
+int innfer_timer_stop(void* stream, int cap, char* names, int name_cap, float* h_ms, double* h_flops, double* h_bytes, int* n);
 
 /* ------------------------------------------------------------ chop / blend
  * Replaces extract_patches_2d / recompose_tensor (utils/utils.py:318-369,

@@ -20,6 +20,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 int set_error(int code, const char* fmt, ...);
 
+// Generic launch timer (innfer_timer_start / innfer_timer_stop, net.hip): while a collection is open on the calling thread every instrumented launch is
+// bracketed by a HIP-event pair on its stream and recorded with a kernel-family name and its ALGORITHMIC flops / bytes.  Off: two thread-local loads.
+bool gt_on();
+void gt_begin(hipStream_t s);
+void gt_end(hipStream_t s, const char* name, double flops, double bytes);
+struct GtScope {                                   // brackets the enclosing block
+    hipStream_t s; const char* name; double flops, bytes; bool on;
+    GtScope(hipStream_t s_, const char* n, double f, double b) : s(s_), name(n), flops(f), bytes(b), on(gt_on()) { if (on) gt_begin(s); }
+    ~GtScope() { if (on) gt_end(s, name, flops, bytes); }
+};
+
 // A/B knobs of the kernel experiments kept under profiles/: an environment variable only in the diagnostic builds (`make ablate`,
 // `make stamps`); the shipped library compiles the measured-best value in as a constant, so the untaken branches (and the kernel
 // instantiations only they reach) are not even in the binary.  INNFER_DEBUG (net.hip) is the one run-time switch of the shipped library.
@@ -79,8 +90,7 @@ struct ConvLaunch {
     int split;                                    // fp32-accurate mode: every tensor is a (hi, lo) pair of fp16 slabs, lo = fp16((x - hi) * 2^11) (conv3x3.hip, SPLIT); panels from
     long in_lo, out_lo, res1_lo, res2_lo;         // conv_pack_split / conv_pack_1x1_split; *_lo: distance (elements) from a hi slab to its lo twin.  Plain 3x3 / 1x1 slab convs
                                                   // (act 0..2, residuals, upsampled input, batches) and the planar last conv
-    int wino;                                     // experiment: 1 = Winograd F(2,3) along the rows (panels from conv_pack_wino), 2 = the direct conv on the same 16 x 32 tiles,
-                                                  // 3 = Winograd rows on 64-channel tiles with the weight transform made by the consumers (panels from conv_pack_wino9)
+    int wino;                                     // experiment: 1 = Winograd F(2,3) along the rows (panels from conv_pack_wino), 2 = the direct conv on the same 16 x 32 tiles
     const f16* pair_wpk; const float* pair_bias;  // net.hip only: non-null = this 32-output LeakyReLU conv AND the next one of the dense block (inputs: the same
                                                   // C channels + this conv's output, output: the following channel group) as one conv_pair_launch
 };
@@ -103,7 +113,6 @@ size_t conv_packed_bytes(int K, int C);
 void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
 size_t conv_packed_bytes_wino(int K, int C);
 void conv_pack_wino(const float* w_oihw, int K, int C, void* packed);      // host; ConvLaunch.wino == 1
-void conv_pack_wino9(const float* w_oihw, int K, int C, void* packed);     // host; ConvLaunch.wino == 3 (conv_packed_bytes(K, C) bytes)
 void conv_pack_split(const float* w_oihw, int K, int C, void* packed);     // host; 3 * conv_packed_bytes(K, C): the (wl | wh | wh) panels of ConvLaunch.split
 void conv_pack_1x1_split(const float* w_oi, int K, int C, void* packed);   // host; 3 * conv_packed_bytes_taps(K, C, 0x10)
 int conv_launch(const ConvLaunch& L, hipStream_t s);

@@ -837,12 +837,6 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // fragments as they come out of LDS.  LDS image: a halo row holds its even columns (0, 2, .. 32) then its odd ones (18-pixel halves of the 36-pixel
     // pitch), so that the stride-2 reads d0 / d2 (even[j], even[j+1]) and d1 / d3 (odd[j], odd[j+1]) are 16 consecutive pixels each: conflict free.
     constexpr bool WINO = (TMF & 0x4000) != 0;
-    // + 0x8000 (with 0x4000): the weight transform U = G g is made by the consumers on the fragments of a NINE-tap panel (conv_pack_wino9: g0, g1 / 2, g2 per
-    // kernel row; U1 = (g0 + g2) / 2 + g1 / 2, U2 = (g0 + g2) / 2 - g1 / 2: 12 VALU per kernel row and channel tile) -- the 64-output tiles, whose 12-tap
-    // panels (49 KB per stage) do not fit the LDS beside the 16-row input stages
-    constexpr bool WINO_U = (TMF & 0x8000) != 0;
-    static_assert(!WINO_U || WINO, "0x8000 belongs to the Winograd form");
-    static_assert(!WINO || (!S9 && !POLY && !S2 && !PFX && !STATS && !SPLIT && !CV && TM == 0x1FF && NSI == 2 && NCW == 8 && OUTMODE == OUT_SLAB), "Winograd rows: plain 3x3 slab convs");
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -850,7 +844,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int KQ = (NQ + NLW - 1) / NLW;
     constexpr int IN_BYTES = NQ * 1024;
     constexpr int WROWS = NT * 16;
-    constexpr int NTAP = WINO ? (WINO_U ? 9 : 12) : __builtin_popcount(TM);        // taps in the panel, in (r, s) order (WINO: (r, xi))
+    constexpr int NTAP = WINO ? 12 : __builtin_popcount(TM);        // taps in the panel, in (r, s) order (WINO: (r, xi))
     constexpr int W_BYTES = NTAP * WROWS * 64;
     constexpr int WQ = W_BYTES / 1024;
     constexpr int KW = (WQ + NLW - 1) / NLW;
@@ -1259,36 +1253,6 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         constexpr bool abl_no_mfma = false;
 #endif
         if (abl_no_mfma) {
-        } else if constexpr (WINO && WINO_U) {
-            const f16x8 half8 = {(f16)0.5f, (f16)0.5f, (f16)0.5f, (f16)0.5f, (f16)0.5f, (f16)0.5f, (f16)0.5f, (f16)0.5f};
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                f16x8 u[4][NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f16x8 g0 = *(const f16x8*)(sw + aoffs + ((r * 3 + 0) * WROWS + t * 16) * 64);
-                    const f16x8 gh = *(const f16x8*)(sw + aoffs + ((r * 3 + 1) * WROWS + t * 16) * 64);          // g1 / 2
-                    const f16x8 g2 = *(const f16x8*)(sw + aoffs + ((r * 3 + 2) * WROWS + t * 16) * 64);
-                    const f16x8 tt = g0 + g2;
-                    u[0][t] = g0; u[3][t] = g2;
-                    u[1][t] = __builtin_elementwise_fma(tt, half8, gh);
-                    u[2][t] = __builtin_elementwise_fma(tt, half8, -gh);
-                }
-#pragma unroll
-                for (int rw = 0; rw < RPW; ++rw) {
-                    const int rr = rw + r;
-                    const char* rowp = st + (rr - (rr & 1)) * LWP * 64;
-                    const f16x8 d0 = *(const f16x8*)(rowp + woffs[rr & 1][0][0]), d1 = *(const f16x8*)(rowp + woffs[rr & 1][1][0]);
-                    const f16x8 d2 = *(const f16x8*)(rowp + woffs[rr & 1][0][1]), d3 = *(const f16x8*)(rowp + woffs[rr & 1][1][1]);
-                    f16x8 v[4];
-                    v[0] = d0 - d2; v[1] = d1 + d2; v[2] = d2 - d1; v[3] = d1 - d3;
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            wacc[x][t][rw] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u[x][t], v[x], wacc[x][t][rw], 0, 0, 0);
-                }
-            }
         } else if constexpr (WINO) {
             f16x8 a[4][3][NT];
 #pragma unroll
@@ -1615,7 +1579,7 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI, int NCW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = NCW * RPW;
-    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? ((TM & 0x8000) ? 9 : 12) : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64);
+    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
     if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
@@ -1791,14 +1755,6 @@ void conv_pack_wino(const float* w, int K, int C, void* packed) {
             }
 }
 
-// ... and the nine-tap panels of its on-the-fly form (TMF | 0xC000): conv_pack's layout with the middle column of every kernel row halved (g0, g1 / 2, g2)
-void conv_pack_wino9(const float* w, int K, int C, void* packed) {
-    std::vector<float> v(w, w + (size_t)K * C * 9);
-    for (size_t i = 0; i < (size_t)K * C; ++i)
-        for (int r = 0; r < 3; ++r) v[i * 9 + r * 3 + 1] *= 0.5f;
-    conv_pack(v.data(), K, C, packed);
-}
-
 void conv_pack_1x1(const float* w, int K, int C, void* packed) {
     const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
     f16* dst = (f16*)packed;
@@ -1888,7 +1844,31 @@ void conv_pack7x7(const float* w, int K, int C, void* packed) {
     conv_pack(v.data(), K, 9 * C, packed);
 }
 
+// Kernel-family name and algorithmic work of a launch, for the generic launch timer (common.h GtScope): every operand read once, every result written once
+static const char* conv_family(const ConvLaunch& L, double* flops, double* bytes) {
+    const int y1 = L.y1 > 0 ? L.y1 : L.H;
+    const double px = (double)L.N * (y1 - L.y0) * L.W;                       // pixels of the kernel's grid (ConvTranspose: the input grid, 4 phases each)
+    double taps = 9, in_px = px, obytes = L.out_mode == OUT_NCHW ? (L.out_u8 ? 1.0 : L.out_f32 ? 4.0 : 2.0) : 2.0;
+    const char* name = L.out_mode == OUT_NCHW ? "conv3x3_pc 3x3, planar output" : (conv_nt_for(L.K) == 4 ? "conv3x3_pc 3x3, 64-channel tiles" : "conv3x3_pc 3x3, 32-channel tiles");
+    if (L.conv1x1) { taps = 1; name = "conv3x3_pc 1x1"; }
+    if (L.up) in_px = px / 4;
+    if (L.stride2) { taps = 16; in_px = 4 * px; name = "conv3x3_pc Conv2d(4,2,1), stride-2 loader"; }
+    if (L.deconv_phases) { taps = 4; name = "conv3x3_pc ConvTranspose2d(k,2,1), phase lattice"; }
+    if (L.conv7v) { taps = 7; name = "conv3x3_pc 7x1 column conv"; }
+    if (L.conv7) { taps = 49; name = "conv3x3_pc 7x7 (nine displaced 3x3)"; }
+    if (L.dilation > 1 || L.dilation_groups) name = "conv3x3_pc dilated 3x3 (polyphase)";
+    if (L.out_mode == OUT_NCHW && L.phase_c > 0) { taps = 4; name = "conv3x3_pc outermost ConvTranspose2d(4,2,1): 4 phases, tanh, planar"; }      // (structural zeros not counted)
+    if (L.split) name = "conv3x3_pc 3x3, fp32 mode (hi/lo pairs)";
+    *flops = 2.0 * taps * L.K * L.C * px;
+    *bytes = in_px * L.C * 2.0 + px * L.K * obytes + (L.res1 ? px * L.K * 2.0 : 0.0) + (L.res2 ? px * L.K * 2.0 : 0.0) + taps * L.K * L.C * 2.0;
+    if (L.split) *bytes = 2.0 * *bytes + taps * L.K * L.C * 2.0;
+    return name;
+}
+
 int conv_launch(const ConvLaunch& L, hipStream_t s) {
+    double gt_flops = 0, gt_bytes = 0;
+    const char* gt_name = gt_on() ? conv_family(L, &gt_flops, &gt_bytes) : "";
+    GtScope gt(s, gt_name, gt_flops, gt_bytes);
     if (L.C <= 0 || L.C % 32) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: C=%d must be a multiple of 32", L.C);
     if (L.up && ((L.H | L.W) & 1)) return set_error(INNFER_ERR_INVALID, "conv3x3: upsampled size must be even");
     KP k{};
@@ -1940,10 +1920,6 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         if (!pc || L.out_mode != OUT_SLAB || L.K % 32 || L.act > 2 || L.reflect || L.dilation > 1 || L.dilation_groups || L.deconv_phases || L.stride2 || L.conv7v || L.conv7 ||
             L.stats_part || L.conv1x1 || L.pair_wpk || L.split)
             return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (Winograd rows): plain 3x3 slab convs, K %% 32 == 0, act 0..2, residuals, upsampled input");
-        if (L.wino == 3) {     // 64-channel tiles, weight transform by the consumers (panels from conv_pack_wino9)
-            if (L.K % 64) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (Winograd rows, 64-channel tiles): K %% 64 == 0");
-            return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0xC1FF>(k, L.N, s);
-        }
         k.KG = L.K / 32;
         if (L.wino == 2 && L.K != 32) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (A/B tile shape): K == 32");
         return L.wino == 1 ? launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x41FF>(k, L.N, s) : launch_pc<2, 2, 4>(k, L.N, s);

@@ -240,6 +240,9 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     if (ntaps < 1 || ntaps > 49) return set_error(INNFER_ERR_INVALID, "gather GEMM: %d taps", ntaps);
     const long M = (long)N * Ho * Wo;
     if (M <= 0) return INNFER_OK;
+    // (launch timer: the GEMM and, where it is split over K inside this call, its reduction as one entry)
+    GtScope gt(s, "gemm_gather (+ split-K reduce)", 2.0 * M * ngroup * (double)cout_pad * ntaps * cin_pad,
+               (double)N * Hin * Win * cin_pad * 2.0 + (double)M * ngroup * cout_pad * 4.0 + (double)ngroup * ntaps * cin_pad * cout_pad * 2.0);
     if ((long)N * Hin * Win * 64 >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "gather GEMM: input of %d x %d x %d pixels exceeds the 2 GiB buffer window", N, Hin, Win);
     const int nsteps = ntaps * g.nchunks;
     const size_t full = (size_t)N * Hfull * Wfull * g.raw_stride * sizeof(float);

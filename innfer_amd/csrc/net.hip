@@ -27,9 +27,57 @@ int set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace {
+struct GtRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
+thread_local std::vector<GtRec>* g_gt = nullptr;
+thread_local hipEvent_t g_gt_e0 = nullptr;
+}  // namespace
+bool gt_on() { return g_gt != nullptr; }
+void gt_begin(hipStream_t s) {
+    if (!g_gt) return;
+    g_gt_e0 = nullptr;
+    if (hipEventCreate(&g_gt_e0) != hipSuccess || hipEventRecord(g_gt_e0, s) != hipSuccess) g_gt_e0 = nullptr;
+}
+void gt_end(hipStream_t s, const char* name, double flops, double bytes) {
+    if (!g_gt || !g_gt_e0) return;
+    hipEvent_t e1 = nullptr;
+    if (hipEventCreate(&e1) != hipSuccess || hipEventRecord(e1, s) != hipSuccess) return;
+    g_gt->push_back(GtRec{name, g_gt_e0, e1, flops, bytes});
+    g_gt_e0 = nullptr;
+}
+
 }  // namespace innfer
 
 using namespace innfer;
+
+extern "C" int innfer_timer_start(void) {
+    if (g_gt) return set_error(INNFER_ERR_INVALID, "timer_start: a collection is already open on this thread");
+    g_gt = new std::vector<GtRec>();
+    return INNFER_OK;
+}
+
+extern "C" int innfer_timer_stop(void* stream, int cap, char* names, int name_cap, float* ms, double* flops, double* bytes, int* n) {
+    if (!g_gt) return set_error(INNFER_ERR_INVALID, "timer_stop: no collection is open on this thread");
+    std::vector<GtRec>* recs = g_gt;
+    g_gt = nullptr;
+    int rc = INNFER_OK;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = set_error(INNFER_ERR_HIP, "timer_stop: stream synchronize failed");
+    if (n) *n = (int)recs->size();
+    for (int i = 0; i < (int)recs->size(); ++i) {
+        GtRec& r = (*recs)[i];
+        if (rc == INNFER_OK && i < cap) {
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, r.e0, r.e1);
+            if (ms) ms[i] = t;
+            if (flops) flops[i] = r.flops;
+            if (bytes) bytes[i] = r.bytes;
+            if (names && name_cap > 0) { strncpy(names + (size_t)i * name_cap, r.name.c_str(), name_cap - 1); names[(size_t)i * name_cap + name_cap - 1] = 0; }
+        }
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    delete recs;
+    return rc;
+}
 
 struct ConvSlot {
     std::string key;
@@ -820,12 +868,6 @@ extern "C" int innfer_pack_conv3x3_wino(const float* w, int K, int C, void* h_pa
     return INNFER_OK;
 }
 
-extern "C" int innfer_pack_conv3x3_wino9(const float* w, int K, int C, void* h_packed) {
-    if (!w || !h_packed || K <= 0 || K % 64 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv3x3_wino9: K=%d (%% 64) C=%d (%% 32)", K, C);
-    conv_pack_wino9(w, K, C, h_packed);
-    return INNFER_OK;
-}
-
 extern "C" size_t innfer_conv7x1_packed_bytes(int K, int C) { return (K > 0 && C > 0 && C % 32 == 0) ? conv_packed_bytes7v(K, C) : 0; }
 extern "C" int innfer_pack_conv7x1(const float* w, int K, int C, void* packed) {
     if (!w || !packed || K <= 0 || K % 32 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv7x1: K=%d (%% 32) C=%d (%% 32)", K, C);
@@ -891,7 +933,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
     L.out_mode = a->pixel_shuffle2 ? OUT_SHUFFLE2 : OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
     if (a->winograd) {
-        if (a->pixel_shuffle2 || a->split || a->K % 32 || a->out_ch_off % 32 || a->winograd < 1 || a->winograd > 3)
+        if (a->pixel_shuffle2 || a->split || a->K % 32 || a->out_ch_off % 32 || (a->winograd != 1 && a->winograd != 2))
             return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (winograd): 1 | 2, K %% 32 == 0 (K=%d), whole output groups", a->K);
         L.wino = a->winograd;
     }

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void unet_post_slab_parts(const f16* src, long
 static int launch_post_slab_parts(const f16* src, long sg, int C, long HW, int N, const float* part, int nper, const float* gamma, const float* beta,
                                   PostDst d, PostDst d1, hipStream_t s) {
     const int pxb = ((HW + 1023) / 1024) * (C / 32) * N >= 256 ? 1024 : 256;
+    GtScope gt(s, "unet_post_slab_parts (BatchNorm + views from the fp16 slab)", 0.0, (double)N * HW * C * 2.0 * (1 + (d.p ? 1 : 0) + (d1.p ? 1 : 0)));
     hipLaunchKernelGGL(unet_post_slab_parts, dim3((unsigned)((HW + pxb - 1) / pxb), C / 32, N), dim3(256), 0, s, src, sg, C, HW, part, nper, 1e-5f,
                        gamma, beta, d, d1, pxb);
     INNFER_HIP(hipGetLastError());
@@ -800,6 +801,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         // a conv that no norm layer follows but that has a bias (instance-norm nets: outermost / innermost down conv): y = 1 * x + bias
         const bool nb = !bn && !l.transposed && l.d_bias && l.d_ones;
         if (HW <= DEEP_PX) {          // deep level: reduce + statistics + post in one launch
+            GtScope gt(s, "unet_deep_post (split-K reduce + BatchNorm + views)", 0.0, (double)N * HW * l.cout_pad * 4.0 * ks_last + (double)N * HW * l.cout * 2.0 * ((d0.p ? 1 : 0) + (d1.p ? 1 : 0)));
             hipLaunchKernelGGL(unet_deep_post, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw,
                                (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn && !ev ? l.d_gamma : nullptr, bn && !ev ? l.d_beta : nullptr,
                                bn && ev ? l.d_ev_alpha : (nb ? l.d_ones : nullptr), bn && ev ? l.d_ev_shift : (nb ? l.d_bias : nullptr), d0, d1);
@@ -807,10 +809,12 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             return INNFER_OK;
         }
         if (bn && !ev) {
+            GtScope gt(s, "norm statistics (fp32 rows)", 0.0, (double)N * HW * l.cout_pad * 4.0);
             int rc = norm::launch_stats(raw, l.cout_pad, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
             if (rc) return rc;
         }
         const long total = (long)N * HW * (l.cout / 8);
+        GtScope gt(s, "unet_post (BatchNorm + views from fp32 rows)", 0.0, (double)N * HW * l.cout_pad * 4.0 + (double)N * HW * l.cout * 2.0 * ((d0.p ? 1 : 0) + (d1.p ? 1 : 0)));
         hipLaunchKernelGGL(unet_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, l.cout_pad, l.cout, HW, N,
                            bn ? (ev ? l.d_ev_alpha : mean) : (nb ? l.d_ones : nullptr), bn ? (ev ? l.d_ev_shift : rstd) : (nb ? l.d_bias : nullptr),
                            (bn && !ev) ? l.cout : 0, d0, d1);
@@ -843,6 +847,8 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             if ((long)u->in_nc * H * W >= 0x7fffffffL || (long)N * ho >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "unet_forward: image too large");
             const unsigned grid = (unsigned)std::min<long>(((long)N * ho + 3) / 4, 256L * 8);
             const int abl = INNFER_KNOB("INNFER_FIRST_ABL", 0);
+            GtScope gt(s, "unet_first_mfma (3 -> 64, 4x4 s2, two views)", 2.0 * 16 * u->in_nc * l.cout * (double)N * HWo,
+                       (double)N * H * W * u->in_nc * (in_dtype == INNFER_F32 ? 4.0 : 2.0) + 2.0 * N * HWo * l.cout * 2.0);
             if (in_dtype == INNFER_F32)
                 hipLaunchKernelGGL(unet_first_mfma<float>, dim3(grid), dim3(256), 0, s, (const float*)d_in, u->in_nc, H, W, N, (const f16*)l.d_wf,
                                    (const float*)(l.bias >= 0 ? l.d_bias : nullptr), (f16*)(ws + cv.D[0]), (f16*)(ws + cv.CAT[0]), Go, abl);
@@ -890,6 +896,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
                 rc = launch_post_slab_parts((const f16*)Y, Go, l.cout, HWo, N, bnpart, conv_stats_nper(ho, wo, 1), l.d_gamma, l.d_beta, dl, dr, s);
                 if (rc) return rc;
             } else {
+                GtScope gt(s, "unet_post_slab (eval-mode BatchNorm + views)", 0.0, (double)N * HWo * l.cout * 2.0 * 3);
                 hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, Go, l.cout, HWo, N,
                                    (const float*)l.d_ev_alpha, (const float*)l.d_ev_shift, 0, dl, dr);
                 INNFER_HIP(hipGetLastError());
@@ -954,10 +961,12 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
                     if (rc) return rc;
                 } else {
                     if (!ev) {
+                        GtScope gt(s, "norm statistics (fp16 slab)", 0.0, (double)N * HW * l.cout * 2.0);
                         rc = norm::launch_stats_slab(Y, G, HW, 1e-5f, l.d_gamma, l.d_beta, mean, rstd, l.cout, N, bnpart, s);
                         if (rc) return rc;
                     }
                     const long total = (long)N * HW * (l.cout / 8);
+                    GtScope gt(s, "unet_post_slab (BatchNorm + views)", 0.0, (double)N * HW * l.cout * 2.0 * 2);
                     hipLaunchKernelGGL(unet_post_slab, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)Y, G, l.cout, HW, N,
                                        (const float*)(ev ? l.d_ev_alpha : mean), (const float*)(ev ? l.d_ev_shift : rstd), ev ? 0 : l.cout, dr, PostDst{nullptr, 0, 0, 0});
                     INNFER_HIP(hipGetLastError());
@@ -997,6 +1006,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             int rc = post(l, HW, true, dr, PostDst{nullptr, 0, 0, 0});
             if (rc) return rc;
         } else {
+            GtScope gt(s, "unet_final (bias + tanh -> NCHW)", 0.0, (double)N * HW * ((l.cout + 3) / 4 * 4) * 4.0 + (double)N * HW * l.cout * (out_dtype == INNFER_F32 ? 4.0 : 2.0));
             hipLaunchKernelGGL(unet_final, dim3((unsigned)((N * HW + 255) / 256)), dim3(256), 0, s, raw, (l.cout + 3) / 4 * 4, l.cout, HW, N,
                                l.d_bias, d_out, out_dtype == INNFER_F32);
             INNFER_HIP(hipGetLastError());

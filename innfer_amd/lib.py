@@ -74,11 +74,12 @@ SIGNATURES = {
     "innfer_srresnet_create_ex": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 6 + [C.c_float, C.c_int]),
     "innfer_net_set_conv_input_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "innfer_net_set_outm": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_timer_start": (C.c_int, []),
+    "innfer_timer_stop": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "innfer_net_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_pack_conv3x3_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv3x3_wino_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv3x3_wino": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "innfer_pack_conv3x3_wino9": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_nchw_to_slab_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_int] * 5 + [C.c_void_p]),
     "innfer_slab_split_to_nchw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
@@ -232,3 +233,21 @@ def blend_profile(P, step=0.5, scale=1):
     buf = (C.c_float * P)()
     check(_lib.innfer_blend_profile(P, step, scale, buf))
     return np.frombuffer(buf, dtype=np.float32).copy()
+
+
+def timed_launches(fn, stream=None, cap=4096, name_cap=64):
+    """fn() under the library's launch timer (innfer_timer_start / innfer_timer_stop): [(kernel family, ms, algorithmic flops, algorithmic bytes)] of
+    every instrumented launch fn made on this thread, in issue order.  Measurement only."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    names = C.create_string_buffer(cap * name_cap)
+    ms, fl, by, n = (C.c_float * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), C.c_int()
+    check(_lib.innfer_timer_start())
+    try:
+        fn()
+    finally:
+        rc = _lib.innfer_timer_stop(stream, cap, names, name_cap, ms, fl, by, C.byref(n))
+    check(rc)
+    raw = names.raw
+    return [(raw[i * name_cap:(i + 1) * name_cap].split(b"\0", 1)[0].decode(), ms[i], fl[i], by[i]) for i in range(min(n.value, cap))]

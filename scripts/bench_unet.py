@@ -16,7 +16,7 @@ for N in ([int(os.environ['UNET_N'])] if os.environ.get('UNET_N') else (1, 8, 64
     for _ in range(2): y = net(x)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = int(os.environ.get("UNET_REPS", "5"))
     e0.record()
     for _ in range(reps): y = net(x)
     e1.record(); torch.cuda.synchronize()

@@ -33,13 +33,9 @@ def run(Cc, K, H=1080, W=1920, reps=30):
     w = ((np.random.RandomState(1).rand(K, Cc, 3, 3).astype(np.float32) - 0.5) / np.sqrt(9 * Cc))
     d_bias = torch.zeros(64, device=dev)
     res = {}
-    for name, mode in (("shipped", 0), ("direct16", 2), ("wino16", 1), ("wino64u", 3)):
+    for name, mode in (("shipped", 0), ("direct16", 2), ("wino16", 1)):
         if mode == 2 and K != 32: continue
-        if mode == 3 and K % 64: continue
-        if mode == 3:
-            packed = np.zeros(L.lib.innfer_conv3x3_packed_bytes(K, Cc), dtype=np.uint8)
-            L.check(L.lib.innfer_pack_conv3x3_wino9(w.ctypes.data, K, Cc, packed.ctypes.data))
-        elif mode == 1:
+        if mode == 1:
             packed = np.zeros(L.lib.innfer_conv3x3_wino_packed_bytes(K, Cc), dtype=np.uint8)
             L.check(L.lib.innfer_pack_conv3x3_wino(w.ctypes.data, K, Cc, packed.ctypes.data))
         else:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ONE conv configuration in one mode, a few launches: the program behind `rocprofv3 --pmc ... -- python3 scripts/r3/wino_one.py C K mode`
-(mode 0 shipped kernel, 1 Winograd rows on 16 x 32 tiles / 32-channel groups, 2 direct conv on the same tiles, 3 Winograd rows on 64-channel tiles)."""
+(mode 0 shipped kernel, 1 Winograd rows on 16 x 32 tiles / 32-channel groups, 2 direct conv on the same tiles)."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -17,7 +17,7 @@ if mode == 1:
     L.check(L.lib.innfer_pack_conv3x3_wino(w.ctypes.data, K, Cc, packed.ctypes.data))
 else:
     packed = np.zeros(L.lib.innfer_conv3x3_packed_bytes(K, Cc), dtype=np.uint8)
-    L.check((L.lib.innfer_pack_conv3x3_wino9 if mode == 3 else L.lib.innfer_pack_conv3x3)(w.ctypes.data, K, Cc, packed.ctypes.data))
+    L.check(L.lib.innfer_pack_conv3x3(w.ctypes.data, K, Cc, packed.ctypes.data))
 d_packed, d_bias = torch.from_numpy(packed).to(dev), torch.zeros(64, device=dev)
 a = L.ConvArgs()
 a.d_in, a.in_group_stride, a.C = slab.data_ptr(), g, Cc
