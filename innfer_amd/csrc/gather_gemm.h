@@ -248,7 +248,10 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     const size_t full = (size_t)N * Hfull * Wfull * g.raw_stride * sizeof(float);
     // Split-K (deep UNet layers: a few pixels per image, a K loop of up to 256 steps): the decision depends on
     // the layer only, never on the batch size, so a batch stays bit-identical to the batch-1 forwards.
-    g.seg = (nsteps + 7) / 8;
+    // segments of >= 32 k-steps, at most 8: every segment costs a full-resolution fp32 partial result (written here, read back by the reduction), and
+    // a ConvTranspose level of 128 k-steps split eight ways moved 2 x 268 MB of partials for a 69 GFLOP layer (UNet_256 x 64, 8x8 -> 16x16)
+    const int want = nsteps >= 256 ? 8 : nsteps >= 128 ? 4 : nsteps >= 64 ? 2 : 1;
+    g.seg = (nsteps + want - 1) / want;
     const int segs = (nsteps + g.seg - 1) / g.seg;
     int ks = 1;
     if (scratch && nsteps >= 32 && (long)Ho * Wo <= split_max_px() && (size_t)segs * full <= scratch_bytes) ks = segs;
