@@ -1425,10 +1425,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #undef EPI
             } else {
                 // planar NCHW output (the network's last conv): activation only, K valid channels
-                // Fast path -- no activation / outm / phase scatter / uint8 image, K <= 4 (the SR networks' last conv in fp16 or fp32): only the lanes holding
-                // channels 0..3 (lg == 0) have anything to store, and the flag tests of the generic loop below (evaluated per value: ~1 k instructions per wave
-                // and tile, for 96 x 3 values) are gone.  Same values, same stores.
-                if (NT == 1 && p.act == 0 && p.outm == 0 && p.phase_c == 0 && !p.out_u8 && p.K <= 4) {
+                // Fast path -- K <= 4 planar channels, no phase scatter / uint8 image (the last conv of the SR networks, CycleGAN, WBC, PPON's heads): only the
+                // lanes holding channels 0..3 (lg == 0) have anything to store, and the per-VALUE work of the generic loop below (channel test, three 64-bit
+                // multiplies for the address, phase / uint8 tests: ~1 k instructions per wave and tile for 96 x 3 values) is hoisted.  Same values, same stores.
+                if (NT == 1 && p.phase_c == 0 && !p.out_u8 && p.K <= 4) {
                     if (lg == 0) {
                         const long plane = (long)p.H * p.W;
 #pragma unroll
@@ -1440,9 +1440,45 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 if (j >= p.K) break;
-                                const float f = acc[0][m][j];
+                                float f = acc[0][m][j];
+                                if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                                else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                                else if (p.act == 3) f = tanhf(f);
+                                else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
+                                if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
+                                else if (p.outm == 2) f = tanhf(f);
+                                else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
+                                else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
                                 if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
                                 else ((f16*)p.out)[o + j * plane] = (f16)f;
+                            }
+                        }
+                    }
+                } else if (NT == 1 && p.phase_c > 0 && p.outm == 0 && !p.out_u8 && (p.act == 3 || p.act == 0)) {
+                    // The four output phases of a stride-2 transposed conv as 4 * phase_c channels (the UNet's outermost layer: bias + tanh + phase scatter):
+                    // the channel -> (phase, channel) split is an integer division the generic loop below made per VALUE (24 per wave and tile); here once
+                    // per lane and tile.  Same values, same stores.
+                    if (cbase < p.K) {
+                        long obase[4]; bool live[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int ch = cbase + j, ph = ch / p.phase_c, c = ch - ph * p.phase_c;
+                            live[j] = ch < p.K;
+                            obase[j] = (((long)n * p.phase_c + c) * (2 * p.H) + (ph >> 1)) * (2 * p.W) + (ph & 1);
+                        }
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const int y = ty0 + cw * RPW + (m >> 1);
+                            const int x = tx0 + (m & 1) * 16 + li;
+                            if (y >= p.y1 || x >= p.W) continue;
+                            const long opix = (long)(2 * y) * (2 * p.W) + 2 * x;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (!live[j]) continue;
+                                float f = acc[0][m][j];
+                                if (p.act == 3) f = tanhf(f);
+                                if (p.out_f32) ((float*)p.out)[obase[j] + opix] = f;
+                                else ((f16*)p.out)[obase[j] + opix] = (f16)f;
                             }
                         }
                     }
