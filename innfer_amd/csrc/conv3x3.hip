@@ -1464,6 +1464,28 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                             }
                         }
                     }
+                } else if (NT == 1 && p.phase_c == 0 && p.out_u8 && p.K <= 4 && p.act == 0 && p.outm == 0) {
+                    // ... and the uint8 image form of the same conv (tensor2np as the epilogue, utils.py:197-248; EngineModule.forward_u8 / FramePipeline): the
+                    // conversion of the generic loop below, value for value, on the lanes that hold channels 0..3
+                    if (lg == 0) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const int y = ty0 + cw * RPW + (m >> 1);
+                            const int x = tx0 + (m & 1) * 16 + li;
+                            if (y >= p.y1 || x >= p.W) continue;
+                            uint8_t* o = (uint8_t*)p.out + (((long)n * p.H + y) * p.W + x) * p.K;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (j >= p.K) break;
+                                const float f = acc[0][m][j];
+                                float v = p.out_round16 ? (float)(f16)f : f;
+                                if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
+                                v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
+                                const int sc = (p.K == 3 || (p.K == 4 && j < 3)) ? 2 - j : j;
+                                o[sc] = (uint8_t)__float2int_rn(v);
+                            }
+                        }
+                    }
                 } else if (NT == 1 && p.phase_c > 0 && p.outm == 0 && !p.out_u8 && (p.act == 3 || p.act == 0)) {
                     // The four output phases of a stride-2 transposed conv as 4 * phase_c channels (the UNet's outermost layer: bias + tanh + phase scatter):
                     // the channel -> (phase, channel) split is an integer division the generic loop below made per VALUE (24 per wave and tile); here once
