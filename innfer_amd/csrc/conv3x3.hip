@@ -42,6 +42,10 @@
 // Pins a value as a rounded fp32 number in a VGPR: the backend cannot fold the fp16 conversion that
 // follows into the fma that produced it (v_fma_mixlo_f16 rounds ONCE, fma + convert rounds twice).
 #define FP32_VALUE(x) asm("" : "+v"(x))
+// cache-policy bits of the halo-tile LDS-DMA pieces (A/B builds only: -DINNFER_IN_AUX=2 = nt, 1 = sc0, 17 = sc0 sc1 ...); measured: profiles/r3/in_aux_ab.txt
+#ifndef INNFER_IN_AUX
+#define INNFER_IN_AUX 0
+#endif
 
 // No implicit floating-point contraction in this file.  With contraction allowed the backend may fold
 // "round to fp16 of (a*b + c)" into v_fma_mixlo_f16 (ONE rounding) for some unrolled copies of the
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 for (int k = 0; k < KQ; ++k) {
                     const int q = lw + NLW * k;
                     if (q < NQ)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void*)(st_i + q * 1024), 16, voff[k], 0, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void*)(st_i + q * 1024), 16, voff[k], 0, 0, INNFER_IN_AUX);
                 }
             }
 #else
