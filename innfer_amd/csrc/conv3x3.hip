@@ -912,6 +912,16 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 
     if (wave >= NCW) {
         // ================================ loaders ================================
+        // The loaders of the 16- / 32-output kernels issue at raised priority: their layers wait for the LDS-DMA stream, and a piece issued between the
+        // consumers' MFMAs costs 100-185 cycles of queueing (MI355X_MICROARCH.md).  32-output layers 0.1344 -> 0.1320 ms, last conv -3 %; the 64-output
+        // kernels, which wait for the matrix pipe, lose 0.5 % with it and keep the default (profiles/r3/prio_ab.txt; INNFER_PRIO: A/B builds).
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef INNFER_PRIO
+        __builtin_amdgcn_s_setprio(INNFER_PRIO);
+#else
+        if constexpr (NT <= 2) __builtin_amdgcn_s_setprio(3);
+#endif
+#endif
         const int lw = wave - NCW;
         int loff[KQ];
         int lpix[POLY ? KQ : 1];
@@ -1173,6 +1183,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     }
 
     // ================================ consumers ================================
+#if defined(INNFER_CPRIO) && defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_setprio(INNFER_CPRIO);
+#endif
     const int cw = wave;
     int boffs[3][2];
 #pragma unroll
