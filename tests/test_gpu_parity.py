@@ -2014,3 +2014,41 @@ def test_winograd_rows_vs_direct(dev):
             else:
                 err = (got - ref).abs().max().item()
             assert err < 4e-3, (case, mode, err)
+
+
+def test_weight_upload_follows_rebound_buffers_and_parameters(dev):
+    """nn.Module._apply (.to / .cuda / .half) REBINDS buffers, load_state_dict(assign=True) rebinds parameters; the engine's cached walk of the
+    module tree must not keep comparing the old tensor objects -- an edit of a BatchNorm running mean, or new weights, after such a rebinding has to reach
+    the next forward."""
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    shapes = synth.rrdbnet_shapes(nb=1, scale=2, norm=True)
+    net = RRDBNet(3, 3, 64, 1, upscale=2, norm_type="batch")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_running_stats(synth.fill_state_dict(shapes, 7), 7).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 16, 16), 8)).to(dev).half()
+    y0 = net(x).clone()
+    net._apply(lambda t: t.clone())                                   # what .to() does to buffers: new tensor objects behind the same names
+    bn = [k for k in net.state_dict() if k.endswith("running_mean")][0]
+    dict(net.named_buffers())[bn].add_(0.25)                          # in-place edit of the NEW object
+    y1 = net(x).clone()
+    assert not torch.equal(y1, y0), "the forward still used the statistics uploaded before the buffers were rebound"
+    sd2 = {k: v.clone() for k, v in net.state_dict().items()}
+    wkey = [k for k in sd2 if k.endswith("conv1.0.weight")][0]
+    sd2[wkey] = sd2[wkey] * 0.5
+    net.load_state_dict(sd2, strict=True, assign=True)                # parameters replaced by new objects
+    y2 = net(x)
+    assert not torch.equal(y2, y1), "the forward still used the weights uploaded before load_state_dict(assign=True)"
+    # the same for the engines addressed by parameter key (UNet: BatchNorm buffers are part of its eval-mode forward)
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    un = get_network(get_network_G_config("unet_128", 1))
+    un.load_state_dict(_sd({k: tuple(v.shape) for k, v in un.state_dict().items()}, 9), strict=True)
+    un = un.to(dev).eval()
+    xu = torch.from_numpy(synth.uniform((1, 3, 128, 128), 10, -1, 1)).to(dev).half()
+    u0 = un(xu).clone()
+    un._apply(lambda t: t.clone())
+    rv = [k for k in dict(un.named_buffers()) if k.endswith("running_var")][0]
+    dict(un.named_buffers())[rv].mul_(4.0)
+    assert not torch.equal(un(xu), u0)
