@@ -624,6 +624,7 @@ def main():
     if not args.no_extras and args.workload != "chop8k":
         log('chop8k')
         kstep, kH, kW, kwhat, krunners = chop_setup("chop8k")
+        # (every rank runs the same collective sequence: an exception here is fatal for the job on purpose -- swallowing it on one rank would hang the others)
         kwall = timed_steps(kstep, 1, 1, world, sync, barrier, max_over_ranks)
         if rank == 0:
             kfl, ntile = chop_flops(krunners, kH, kW)           # 4686.8 TFLOP (the redundant tile FLOPs of the reference's tiling count)
@@ -641,7 +642,10 @@ def main():
     # ---- BASELINE config 5: pix2pix UNet_256, 64 x 3 x 256 x 256 (one GPU) ----
     if not args.no_extras and world == 1:
         log('unet64')
-        line["unet64"] = unet64_object(dev)
+        try:
+            line["unet64"] = unet64_object(dev)
+        except Exception as e:                      # a side object must never cost the headline line
+            line["unet64"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         if not args.no_cpu_baseline:
