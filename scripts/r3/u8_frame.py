@@ -2,7 +2,7 @@
 """Device-resident uint8 frame in, uint8 frame out (EngineModule.forward_u8: np2tensor in the first conv, tensor2np in the last conv's epilogue) on the
 1080p bench frame, beside the fp16 tensor forward: what the uint8 epilogue of the planar last conv costs."""
 import os, sys
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from innfer_amd import synth

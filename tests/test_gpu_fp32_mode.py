@@ -6,7 +6,6 @@ slabs (22 significant bits) and multiplies on the fp16 matrix cores with fp32 ac
 tests below hold the kernel to 3e-6 of the output range against float64 convolutions of the same fp32 operands.
 """
 import ctypes as C
-import os
 
 import numpy as np
 import pytest
@@ -14,7 +13,6 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FP32_TOL = 1e-4
 
 
