@@ -46,28 +46,34 @@ inline long split_max_px() {
     return v < SPLIT_MAX_PX ? v : SPLIT_MAX_PX;
 }
 
-// Tile shapes: <BP, Q, STAGES> = 16*BP pixels per wave x 64*Q output channels, 4 waves:
-//   <2,1,4>  128 px x  64 co, 12 KiB per stage   small / narrow layers and every split-K launch
-//   <4,2,3>  256 px x 128 co, 24 KiB per stage   big layers (twice the MFMAs per staged byte)
-template <int BP, int Q, int STAGES>
-static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
+// Tile shapes: <BP, Q, STAGES, NCO> = 16*BP pixels per wave x 64*Q output channels per workgroup; 4*NCO waves, wave w multiplies pixel block w & 3
+// with the Q / NCO panels of channel block w >> 2:
+//   <2,1,4>    128 px x  64 co, 12 KiB per stage   small / narrow layers and every split-K launch
+//   <4,2,3>    256 px x 128 co, 24 KiB per stage   big layers (twice the MFMAs per staged byte)
+//   <4,4,3,2>  256 px x 256 co, 32 KiB per stage, 8 waves: the same MFMAs per wave as <4,2,3> with two thirds of the LDS-DMA bytes per MFMA -- the
+//              launches sit on the CU's LDS-DMA fill rate (experiments 38 / 42), so bytes per MFMA is what counts (round 3)
+template <int BP, int Q, int STAGES, int NCO = 1>
+static __global__ __launch_bounds__(256 * NCO) void gemm_gather(const GP p) {
     constexpr int PXT = 64 * BP;                                      // pixels per workgroup
+    constexpr int NW = 4 * NCO, QW = Q / NCO, BPW = BP / NCO;         // waves; panels a wave multiplies; pixel pieces a wave stages
+    static_assert(Q % NCO == 0 && BP % NCO == 0, "panels and pixel pieces split evenly over the channel blocks");
     constexpr int B_BYTES = PXT * 64, A_BYTES = Q * 4096, STAGE_BYTES = B_BYTES + A_BYTES;
-    constexpr int NPIECE = BP + Q;                                    // LDS-DMA pieces per wave and step
+    constexpr int NPIECE = BPW + QW;                                  // LDS-DMA pieces per wave and step
     __shared__ __attribute__((aligned(16))) char lds[STAGES * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
+    const int pw = wave & 3, cwv = wave >> 2;                         // this wave's pixel block and channel block
     const long M = (long)p.N * p.Ho * p.Wo;
     const long m0 = (long)blockIdx.x * PXT;
     const int cot = blockIdx.y * Q;                                   // first 64-channel panel of this workgroup
 
-    // staging role: pixel rows (tid>>2) + 64*h, 16-byte slot (tid&3); weight row (tid>>2) of panel cot + j
+    // staging role: pixel rows (tid>>2) + 16*NW*h, 16-byte slot (tid&3); weight quarter (wave & 3) of panels cot + (wave >> 2) + NCO*j
     const int sslot = tid & 3;
-    int spix[BP], soy[BP], sox[BP], cso[BP]; bool sok[BP];
+    int spix[BPW], soy[BPW], sox[BPW], cso[BPW]; bool sok[BPW];
 #pragma unroll
-    for (int h = 0; h < BP; ++h) {
-        const int srow = (tid >> 2) + 64 * h;
+    for (int h = 0; h < BPW; ++h) {
+        const int srow = (tid >> 2) + 16 * NW * h;
         const long sm = m0 + srow;
         sok[h] = sm < M;
         int n = 0;
@@ -97,7 +103,7 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
         char* st = lds + (rel % STAGES) * STAGE_BYTES;
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)c * p.in_g), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int h = 0; h < BP; ++h) {
+        for (int h = 0; h < BPW; ++h) {
             int iy = soy[h] * p.stride + p.dy[tap0 + t] * tapmul, ix = sox[h] * p.stride + p.dx[tap0 + t] * tapmul;
             if (p.reflect) {                                          // pad < size: one reflection is enough
                 iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
@@ -107,30 +113,31 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             if (p.up) { ok = ok && iy < 2 * p.Hin && ix < 2 * p.Win; iy >>= 1; ix >>= 1; }
             else ok = ok && iy < p.Hin && ix < p.Win;
             const int voff = ok ? (spix[h] + iy * p.Win + ix) * 64 + cso[h] : (int)0x80000000;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(st + (wave + 4 * h) * 1024), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(st + (wave + NW * h) * 1024), 16, voff, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < Q; ++j) {
+        for (int jj = 0; jj < QW; ++jj) {
+            const int j = cwv + NCO * jj;
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + j * panel_bytes + (long)step * 4096), 0, 4096, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + B_BYTES + j * 4096 + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + B_BYTES + j * 4096 + pw * 1024), 16, lane * 16, pw * 1024, 0, 0);
         }
 #else
         (void)step; (void)rel; (void)wtile; (void)spix; (void)cso; (void)panel_bytes; (void)tapmul; (void)tap0;
 #endif
     };
 
-    f32x4 acc[BP][4 * Q];
+    f32x4 acc[BP][4 * QW];
 #pragma unroll
     for (int h = 0; h < BP; ++h)
 #pragma unroll
-        for (int q = 0; q < 4 * Q; ++q) acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4 * QW; ++q) acc[h][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     int boff[BP];
 #pragma unroll
     for (int h = 0; h < BP; ++h) {
-        const int brow = wave * 16 * BP + 16 * h + li;
+        const int brow = pw * 16 * BP + 16 * h + li;
         boff[h] = brow * 64 + ((lg ^ (((brow >> 2) & 1) << 1)) << 4);
     }
-    const int aoff = B_BYTES + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    const int aoff = B_BYTES + cwv * QW * 4096 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);      // (panels cwv*QW .. of the stage: see the note on the order below)
 
     for (int s0 = 0; s0 < STAGES - 1 && s0 < nsteps; ++s0) issue(s0);
     for (int step = 0; step < nsteps; ++step) {
@@ -146,7 +153,7 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
 #pragma unroll
         for (int h = 0; h < BP; ++h) bf[h] = *(const f16x8*)(b + boff[h]);
 #pragma unroll
-        for (int q = 0; q < 4 * Q; ++q) {
+        for (int q = 0; q < 4 * QW; ++q) {
             const f16x8 a = *(const f16x8*)(b + q * 1024 + aoff);
 #pragma unroll
             for (int h = 0; h < BP; ++h) acc[h][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[h], acc[h][q], 0, 0, 0);
@@ -155,7 +162,7 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
     // D rows = out channels (16*lg + 4*q + j after the panel permutation), cols = pixels
 #pragma unroll
     for (int h = 0; h < BP; ++h) {
-        const long m = m0 + wave * 16 * BP + 16 * h + li;
+        const long m = m0 + pw * 16 * BP + 16 * h + li;
         if (m < M) {
             const int ox = (int)(m % p.Wo);
             const int oy = (int)((m / p.Wo) % p.Ho);
@@ -164,8 +171,8 @@ static __global__ __launch_bounds__(256) void gemm_gather(const GP p) {
             const long opix = (n * p.Hfull + (long)oy * p.os + ooy) * p.Wfull + (long)ox * p.os + oox;
             float* op = p.out + (long)zs * p.split_elems + zg * p.g_outoff + opix * p.raw_stride;
 #pragma unroll
-            for (int q = 0; q < 4 * Q; ++q) {
-                const int ch = (cot + (q >> 2)) * 64 + 16 * lg + 4 * (q & 3);
+            for (int q = 0; q < 4 * QW; ++q) {
+                const int ch = (cot + cwv * QW + (q >> 2)) * 64 + 16 * lg + 4 * (q & 3);
                 if (ch < p.cout_store) *(f32x4*)(op + ch) = acc[h][q];
             }
         }
@@ -266,7 +273,13 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     //  workgroup is latency-bound, 108 -> 181 us on a 256-tile layer, and no gain beside the wide split tiles: not built)
     const bool big = (ngroup == 1 || g_phase) && cout_pad % 128 == 0 &&
                      ((M + 255) / 256) * (cout_pad / 128) * ngroup * ks >= 256;
-    if (big) {
+    // (256 x 256 tiles where they still give every CU a workgroup: two thirds of the LDS-DMA bytes per MFMA of the 256 x 128 form)
+    const bool big2 = big && cout_pad % 256 == 0 && INNFER_KNOB("INNFER_GG_BIG2", 1) &&
+                      ((M + 255) / 256) * (cout_pad / 256) * ngroup * ks >= 256;
+    if (big2) {
+        dim3 grid((unsigned)((M + 255) / 256), (unsigned)(cout_pad / 256), (unsigned)(ks * ngroup));
+        hipLaunchKernelGGL((gemm_gather<4, 4, 3, 2>), grid, dim3(512), 0, s, g);
+    } else if (big) {
         dim3 grid((unsigned)((M + 255) / 256), (unsigned)(cout_pad / 128), (unsigned)(ks * ngroup));
         hipLaunchKernelGGL((gemm_gather<4, 2, 3>), grid, dim3(256), 0, s, g);
     } else {
