@@ -154,8 +154,11 @@ static int launch_post_slab_parts(const f16* src, long sg, int C, long HW, int N
 // launch.  A workgroup owns 32 channels of one image: 32 channel lanes x 32 pixel lanes, every thread keeps its <= DEEP_PX/32 pixels in
 // registers; the partial results are added in segment order, the statistics are the two-pass form on registers (as norm_stats.h), the
 // result goes to up to two fp16 destinations like unet_post.  part: ks segments of split_elems floats (ks == 1: the GEMM result itself).
-constexpr int DEEP_PX = 64;
+// (round 3: up to 256 pixels -- eight per thread -- so that the 8x8 -> 16x16 ConvTranspose level of a 256 x 256 input no longer takes a reduce, a statistics
+//  and a post launch over its fp32 rows: unet_deep_post<8>; the <= 64-pixel levels keep the two-pixel form)
+constexpr int DEEP_PX = 256;
 // ev_alpha / ev_shift != nullptr: eval-mode BatchNorm (the per-channel transform of the running statistics) instead of this image's.
+template <int NPX>
 __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long split_elems, int ks, int cpad, int C, int HW, float eps,
                                                        const float* gamma, const float* beta, const float* ev_alpha, const float* ev_shift,
                                                        PostDst d0, PostDst d1) {
@@ -171,10 +174,10 @@ __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long s
         __syncthreads();
         return t;
     };
-    float v[DEEP_PX / 32];
+    float v[NPX];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < DEEP_PX / 32; ++i) {
+    for (int i = 0; i < NPX; ++i) {
         const int px = pl + 32 * i;
         float a = 0.f;
         if (px < HW && c < C) {
@@ -192,14 +195,14 @@ __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long s
         const float mu = reduce32(sum) / (float)HW;
         float m2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < DEEP_PX / 32; ++i) { const float d = pl + 32 * i < HW ? v[i] - mu : 0.f; m2 += d * d; }
+        for (int i = 0; i < NPX; ++i) { const float d = pl + 32 * i < HW ? v[i] - mu : 0.f; m2 += d * d; }
         const float var = reduce32(m2) / (float)HW;
         if (c < C) { al = (1.0f / sqrtf(var + eps)) * gamma[c]; sh = beta[c] - mu * al; }
     }
     if (c >= C) return;
     const PostDst ds[2] = {d0, d1};
 #pragma unroll
-    for (int i = 0; i < DEEP_PX / 32; ++i) {
+    for (int i = 0; i < NPX; ++i) {
         const int px = pl + 32 * i;
         if (px >= HW) continue;
         const float y = (gamma || ev_alpha) ? v[i] * al + sh : v[i];
@@ -802,9 +805,14 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const bool nb = !bn && !l.transposed && l.d_bias && l.d_ones;
         if (HW <= DEEP_PX) {          // deep level: reduce + statistics + post in one launch
             GtScope gt(s, "unet_deep_post (split-K reduce + BatchNorm + views)", 0.0, (double)N * HW * l.cout_pad * 4.0 * ks_last + (double)N * HW * l.cout * 2.0 * ((d0.p ? 1 : 0) + (d1.p ? 1 : 0)));
-            hipLaunchKernelGGL(unet_deep_post, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw,
-                               (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn && !ev ? l.d_gamma : nullptr, bn && !ev ? l.d_beta : nullptr,
-                               bn && ev ? l.d_ev_alpha : (nb ? l.d_ones : nullptr), bn && ev ? l.d_ev_shift : (nb ? l.d_bias : nullptr), d0, d1);
+            if (HW <= 64)
+                hipLaunchKernelGGL(unet_deep_post<2>, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw,
+                                   (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn && !ev ? l.d_gamma : nullptr, bn && !ev ? l.d_beta : nullptr,
+                                   bn && ev ? l.d_ev_alpha : (nb ? l.d_ones : nullptr), bn && ev ? l.d_ev_shift : (nb ? l.d_bias : nullptr), d0, d1);
+            else
+                hipLaunchKernelGGL(unet_deep_post<8>, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw,
+                                   (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn && !ev ? l.d_gamma : nullptr, bn && !ev ? l.d_beta : nullptr,
+                                   bn && ev ? l.d_ev_alpha : (nb ? l.d_ones : nullptr), bn && ev ? l.d_ev_shift : (nb ? l.d_bias : nullptr), d0, d1);
             INNFER_HIP(hipGetLastError());
             return INNFER_OK;
         }
