@@ -234,3 +234,35 @@ def test_generators_without_an_fp32_engine_refuse_float32(dev):
         net = get_network(get_network_G_config(arch, scale)).to(dev)
         with pytest.raises(NotImplementedError, match="fp32"):
             net(torch.zeros(shape, device=dev))
+
+
+def test_split_conv_random_shapes_fuzz(dev):
+    """Seeded sweep over what the split kernels are parameterised on -- channel counts, image sizes around the tile sizes (24 x 32, 16 x 32), batches
+    (N > 1 takes the image-canvas form when that saves tiles: cells, gutters, tiles straddling images), activation, one or two residuals, nearest-2x
+    input -- against float64 F.conv2d on the same fp32 operands; bound 3e-6 of O(1) outputs (measured <= 1.8e-6)."""
+    from innfer_amd import synth
+    rng = np.random.RandomState(20260303)
+    worst = 0.0
+    for case in range(40):
+        K = int(rng.choice([32, 64]))
+        Cc = int(rng.choice([32, 64, 96, 128, 160, 192]))
+        N = int(rng.choice([1, 1, 2, 3, 5]))
+        H, W = int(rng.randint(1, 70)), int(rng.randint(1, 90))
+        if case % 6 == 0:
+            H, W = int(rng.choice([24, 48, 16, 32, 25, 47])), int(rng.choice([32, 64, 33, 63, 31]))      # whole tiles and one off
+        act = int(rng.choice([0, 1, 2]))
+        up = bool(rng.rand() < 0.15) and N == 1
+        use_r1 = rng.rand() < 0.4
+        use_r2 = use_r1 and rng.rand() < 0.5
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        x = torch.from_numpy(synth.uniform((N, Cc, H, W), 7000 + case, -1, 1))
+        w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 7100 + case, -1, 1)) / np.sqrt(9 * Cc)
+        b = torch.from_numpy(synth.uniform((K,), 7200 + case, -1, 1))
+        r1 = torch.from_numpy(synth.uniform((N, K, Ho, Wo), 7300 + case, -1, 1)) if use_r1 else None
+        r2 = torch.from_numpy(synth.uniform((N, K, Ho, Wo), 7400 + case, -1, 1)) if use_r2 else None
+        got = _run_split_conv(dev, x, w, b, K, act=act, up=up, res1=r1, s1=0.2, res2=r2, s2=0.2)
+        ref = _ref64(x, w, b, act=act, up=up, res1=r1, s1=0.2, res2=r2, s2=0.2)
+        err = (got.double() - ref).abs().max().item()
+        worst = max(worst, err)
+        assert err < 3e-6, (case, Cc, K, N, H, W, act, up, use_r1, use_r2, err)
+    print(f"split conv fuzz: worst max|err| {worst:.2e}")
