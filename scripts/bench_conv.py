@@ -19,7 +19,7 @@ def run(Cc, K, H, W, reps=20, res=False):
     g = N * H * W * 32 + pad
     slab = (torch.rand((Cc // 32) * g, device=dev) - 0.5).half()
     out = torch.empty((max(K, 32) // 32) * g, dtype=torch.float16, device=dev)
-    w = ((np.random.rand(K, Cc, 3, 3).astype(np.float32) - 0.5) / np.sqrt(9 * Cc))
+    w = ((np.random.rand(K, Cc, 3, 3) - 0.5) / np.sqrt(9 * Cc)).astype(np.float32)
     packed = np.zeros(L.lib.innfer_conv3x3_packed_bytes(K, Cc), dtype=np.uint8)
     L.check(L.lib.innfer_pack_conv3x3(w.ctypes.data, K, Cc, packed.ctypes.data))
     d_packed = torch.from_numpy(packed).to(dev)

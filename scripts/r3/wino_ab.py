@@ -30,7 +30,7 @@ def run(Cc, K, H=1080, W=1920, reps=30):
     g = H * W * 32
     slab = (torch.rand((Cc // 32) * g, device=dev) - 0.5).half()
     out = torch.empty((K // 32) * g, dtype=torch.float16, device=dev)
-    w = ((np.random.RandomState(1).rand(K, Cc, 3, 3).astype(np.float32) - 0.5) / np.sqrt(9 * Cc))
+    w = ((np.random.RandomState(1).rand(K, Cc, 3, 3) - 0.5) / np.sqrt(9 * Cc)).astype(np.float32)
     d_bias = torch.zeros(64, device=dev)
     res = {}
     for name, mode in (("shipped", 0), ("direct16", 2), ("wino16", 1)):

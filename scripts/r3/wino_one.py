@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 g = H * W * 32
 slab = (torch.rand((Cc // 32) * g, device=dev) - 0.5).half()
 out = torch.empty((K // 32) * g, dtype=torch.float16, device=dev)
-w = ((np.random.RandomState(1).rand(K, Cc, 3, 3).astype(np.float32) - 0.5) / np.sqrt(9 * Cc))
+w = ((np.random.RandomState(1).rand(K, Cc, 3, 3) - 0.5) / np.sqrt(9 * Cc)).astype(np.float32)
 if mode == 1:
     packed = np.zeros(L.lib.innfer_conv3x3_wino_packed_bytes(K, Cc), dtype=np.uint8)
     L.check(L.lib.innfer_pack_conv3x3_wino(w.ctypes.data, K, Cc, packed.ctypes.data))
