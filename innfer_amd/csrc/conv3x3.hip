@@ -81,6 +81,23 @@ constexpr int TW = 32;        // tile width (pixels)
 constexpr int LWP = 36;       // LDS row pitch (pixels): 36 px = 2304 B = 9 x 256 B, so every row starts on bank 0
 constexpr int LVALID = TW + 2;
 
+// The B (pixel) fragments a chunk of a tap-mask kernel multiplies, in (tap column, halo row, segment) order, with the kernel rows that use each:
+// the walk of the software-pipelined four-tap loop (conv3x3_pc, TM 0x1B / 0x1B0).
+struct TapWalk { int n; int s[3 * 8 * 2], rr[3 * 8 * 2], seg[3 * 8 * 2]; };
+constexpr TapWalk make_tap_walk(int tm, int rpw, int nseg) {
+    TapWalk w{};
+    for (int sc = 0; sc < 3; ++sc) {
+        if (!((tm >> sc) & 0x49)) continue;
+        for (int rr = 0; rr < rpw + 2; ++rr) {
+            bool need = false;
+            for (int r = 0; r < 3; ++r) need = need || (((tm >> (r * 3 + sc)) & 1) && rr - r >= 0 && rr - r < rpw);
+            if (!need) continue;
+            for (int sg = 0; sg < nseg; ++sg) { w.s[w.n] = sc; w.rr[w.n] = rr; w.seg[w.n] = sg; ++w.n; }
+        }
+    }
+    return w;
+}
+
 struct KP {
     const f16* in; long in_img_stride; long in_gbytes; int nchunks;   // gbytes: bytes between channel groups
     const f16* wpk; const float* bias;
@@ -860,6 +877,11 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #else
     constexpr bool PIPE = true;
 #endif
+#ifdef INNFER_NO_PIPE4
+    constexpr bool PIPE4 = false;                // A/B build: the four-tap kernels with the compiler's placement of the fragment reads
+#else
+    constexpr bool PIPE4 = true;
+#endif
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1336,6 +1358,43 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                     if (rr == RPW - 1) lda(sc + 1, 0);
                     if (rr == RPW) lda(sc + 1, 1);
                     if (rr == RPW + 1) lda(sc + 1, 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (NTAP == 4 && !PFX && PIPE4 && RPW <= 6) {
+            // The four-tap kernels (the stride-2 convs and the transposed-conv phases of the UNet / ResNet generators) with the fragment reads
+            // software-pipelined like the nine-tap loop above: all sixteen weight fragments of the chunk first, then the pixel fragments through a
+            // three-register ring, each read two MFMA groups ahead of its use.  Left to the scheduler, every read sat in front of its first use:
+            // a chunk-step took the LDS phase PLUS the MFMA phase (1.8 us for 1.0 us of matrix work).  Same MFMAs in the same order: same bits.
+            constexpr TapWalk WK = make_tap_walk(TM, RPW, NSEG);
+            constexpr int R0 = (TM & 0x007) ? 0 : 1, S0 = (TM & 0x049) ? 0 : 1;          // the mask is the 2 x 2 block of taps (R0 .. R0 + 1) x (S0 .. S0 + 1)
+            static_assert(TM == (0x1B << (3 * R0 + S0)), "four taps: a 2 x 2 block of the 3 x 3 lattice");
+            f16x8 a[2][NT];                                                              // the weight fragments of the current tap column, by tap row - R0
+            auto lda = [&](int sc, int q) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a[q][t] = *(const f16x8*)(sw + aoffs + ((q * 2 + sc - S0) * WROWS + t * 16) * 64);
+            };
+            f16x8 bq[3];
+            auto ldb = [&](int i) { return *(const f16x8*)(st + boffs[WK.s[i]][WK.rr[i] & 1] + (WK.rr[i] * LWP + WK.seg[i] * 16) * 64); };
+            lda(S0, 0); lda(S0, 1);
+            bq[0] = ldb(0);
+            if (WK.n > 1) bq[1] = ldb(1);
+#pragma unroll
+            for (int i = 0; i < WK.n; ++i) {
+                if (i + 2 < WK.n) bq[(i + 2) % 3] = ldb(i + 2);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int rw = WK.rr[i] - R0 - q;
+                    if (rw >= 0 && rw < RPW) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t][rw * 2 + WK.seg[i]] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q][t], bq[i % 3], acc[t][rw * 2 + WK.seg[i]], 0, 0, 0);
+                    }
+                }
+                // the next column's fragments overwrite this column's as soon as their last MFMA has been issued
+                if (WK.s[i] == S0 && WK.seg[i] == NSEG - 1) {
+                    if (WK.rr[i] == R0 + RPW - 1) lda(S0 + 1, 0);
+                    if (WK.rr[i] == R0 + RPW) lda(S0 + 1, 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1950,6 +2009,9 @@ static const char* conv_family(const ConvLaunch& L, double* flops, double* bytes
     return name;
 }
 
+#ifndef UNET_NSI
+#define UNET_NSI 3
+#endif
 int conv_launch(const ConvLaunch& L, hipStream_t s) {
     double gt_flops = 0, gt_bytes = 0;
     const char* gt_name = gt_on() ? conv_family(L, &gt_flops, &gt_bytes) : "";
@@ -2045,8 +2107,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         if (!pc || L.out_mode != OUT_SLAB || nt != 4 || L.phase_c <= 0 || L.phase_c % 64 || L.K != 4 * L.phase_c || L.res1 || L.res2 || L.up || L.reflect ||
             L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.dilation > 1 || L.dilation_groups)
             return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: slab output, 64-channel phase groups, no residual / upsampling / padding modes");
-        if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x141B>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x101B>(k, L.N, s);
-        return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x41B>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B>(k, L.N, s);
+        if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x141B, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x101B, false, UNET_NSI>(k, L.N, s);
+        return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x41B, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B, false, UNET_NSI>(k, L.N, s);
     }
     if (L.stride2) {         // Conv2d(k 4, s 2, p 1): H x W = the OUTPUT grid, source image 2H x 2W; panels from conv_pack_taps(K, 4C, 0x1B0), virtual channel
                              // (2 pa + pb) * C + ci, tap (1 + dy, 1 + dx) = w[co][ci][2 dy + pa][2 dx + pb]
@@ -2056,8 +2118,8 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         k.Hs = 2 * L.H; k.Ws = 2 * L.W; k.in_img_stride = (long)k.Hs * k.Ws * 32;
         k.nchunks = 4 * k.ncg;
         if (nt == 2) return launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
-        if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x17B0>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x13B0>(k, L.N, s);
-        return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x7B0>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x3B0>(k, L.N, s);
+        if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x17B0, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x13B0, false, UNET_NSI>(k, L.N, s);
+        return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x7B0, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x3B0, false, UNET_NSI>(k, L.N, s);
     }
     if (L.conv7v) {        // 7 x 1 column conv (padding 3 rows, zero or reflected) as three vertically displaced 3-tap blocks: panels from conv_pack7v, slab output
         if (!pc || L.out_mode != OUT_SLAB || (nt != 2 && nt != 4) || L.res1 || L.res2 || L.up || L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.reflect == 2 ||

@@ -21,6 +21,8 @@ struct GP {
                                           // larger than cout_pad lets several GEMMs fill one row (out points at the first channel)
     int Ho, Wo, stride;                   // this launch's output grid; in = out*stride + d
     int ntaps; int dy[49], dx[49];        // up to 7x7 taps
+    int ntaps_w; int wtap[49];            // taps of the weight panel, and the panel tap behind entry t of dy / dx: the launcher drops taps that lie in the
+                                          // padding for EVERY output pixel of the grid (2x2 -> 1x1 under a 4x4 stride-2 kernel: 12 of 16), a zero product
     int reflect;                          // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d) instead of zero
     int Hfull, Wfull, os, ooy, oox;       // out pixel = (oy*os + ooy, ox*os + oox)
     int up;                               // input is read through nearest-2x upsampling (Hin, Win = source size)
@@ -86,7 +88,7 @@ static __global__ __launch_bounds__(256 * NCO) void gemm_gather(const GP p) {
         spix[h] = n * p.Hin * p.Win;                                  // first pixel of the image (launch checks 32-bit range)
         cso[h] = (sslot ^ (((srow >> 2) & 1) << 1)) * 16;             // byte offset of the channel slot stored at LDS slot sslot
     }
-    const long panel_bytes = (long)p.ntaps * p.nchunks * 4096;
+    const long panel_bytes = (long)p.ntaps_w * p.nchunks * 4096;
     const int zg = p.ngroup > 1 ? (int)blockIdx.z / p.ksplit : 0, zs = (int)blockIdx.z - zg * p.ksplit;
     const int tapmul = 1 + zg * p.g_tapmul;
     const int tap0 = p.g_phase ? zg * p.ntaps : 0;
@@ -118,7 +120,7 @@ static __global__ __launch_bounds__(256 * NCO) void gemm_gather(const GP p) {
 #pragma unroll
         for (int jj = 0; jj < QW; ++jj) {
             const int j = cwv + NCO * jj;
-            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + j * panel_bytes + (long)step * 4096), 0, 4096, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wtile + j * panel_bytes + ((long)p.wtap[tap0 + t] * p.nchunks + c) * 4096), 0, 4096, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + B_BYTES + j * 4096 + pw * 1024), 16, lane * 16, pw * 1024, 0, 0);
         }
 #else
@@ -242,9 +244,35 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     if (g.raw_stride <= 0 || (g.raw_stride & 3)) return set_error(INNFER_ERR_INVALID, "gather GEMM: bad raw stride %d", g.raw_stride);
     g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps;
     if (g_phase && (ngroup != 4 || ntaps * 4 > 49)) return set_error(INNFER_ERR_INVALID, "gather GEMM: phase groups need 4 groups of <= 12 taps");
-    for (int t = 0; t < ntaps * (g_phase ? 4 : 1); ++t) { g.dy[t] = dy[t]; g.dx[t] = dx[t]; }
-    g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up; g.reflect = reflect;
     if (ntaps < 1 || ntaps > 49) return set_error(INNFER_ERR_INVALID, "gather GEMM: %d taps", ntaps);
+    g.ntaps_w = ntaps;
+    {   // Taps whose input pixel lies outside the image for every output pixel of the grid multiply zeros: drop them (the decision depends on the layer's
+        // geometry only, never on the batch).  Phase groups keep equal tap counts (they share the k loop); otherwise nothing is dropped.
+        const int ng = g_phase ? 4 : 1;
+        int keep[49], cnt[4] = {0, 0, 0, 0};
+        auto live = [&](int d, int no, int nin) {
+            if (reflect) return true;
+            for (int o = 0; o < no; ++o) { const int i = o * stride + d; if (i >= 0 && i < (up ? 2 * nin : nin)) return true; }
+            return false;
+        };
+        for (int gph = 0; gph < ng; ++gph)
+            for (int t = 0; t < ntaps; ++t) {
+                const bool lv = (ngroup > 1 && !g_phase) || (live(dy[gph * ntaps + t], Ho, Hin) && live(dx[gph * ntaps + t], Wo, Win));   // (dilated groups scale the taps: kept)
+                keep[gph * ntaps + t] = lv;
+                cnt[gph] += lv;
+            }
+        bool same = cnt[0] > 0;
+        for (int gph = 1; gph < ng; ++gph) same = same && cnt[gph] == cnt[0];
+        int n_act = same ? cnt[0] : ntaps;
+        for (int gph = 0; gph < ng; ++gph) {
+            int o = 0;
+            for (int t = 0; t < ntaps; ++t)
+                if (!same || keep[gph * ntaps + t]) { g.dy[gph * n_act + o] = dy[gph * ntaps + t]; g.dx[gph * n_act + o] = dx[gph * ntaps + t]; g.wtap[gph * n_act + o] = t; ++o; }
+        }
+        ntaps = n_act;
+        g.ntaps = ntaps;
+    }
+    g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up; g.reflect = reflect;
     const long M = (long)N * Ho * Wo;
     if (M <= 0) return INNFER_OK;
     // (launch timer: the GEMM and, where it is split over K inside this call, its reduction as one entry)
@@ -257,11 +285,14 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     // the layer only, never on the batch size, so a batch stays bit-identical to the batch-1 forwards.
     // segments of >= 32 k-steps, at most 8: every segment costs a full-resolution fp32 partial result (written here, read back by the reduction), and
     // a ConvTranspose level of 128 k-steps split eight ways moved 2 x 268 MB of partials for a 69 GFLOP layer (UNet_256 x 64, 8x8 -> 16x16)
-    const int want = nsteps >= 256 ? 8 : nsteps >= 128 ? 4 : nsteps >= 64 ? 2 : 1;
+    // (grids of at most 4 pixels per image -- the 2x2 and 1x1 levels: their partial results are a few hundred KB, their launches a handful of workgroups
+    //  walking a latency-bound k loop: segments of 8 k-steps, up to 32 of them)
+    const bool tiny = (long)Ho * Wo <= 4;      // (measured: at 16 pixels per image the 32-way split loses to the 8-way one, 36 -> 45 us, and its reduction too)
+    const int want = tiny ? std::min(32, std::max(1, nsteps / 8)) : nsteps >= 256 ? 8 : nsteps >= 128 ? 4 : nsteps >= 64 ? 2 : 1;
     g.seg = (nsteps + want - 1) / want;
     const int segs = (nsteps + g.seg - 1) / g.seg;
     int ks = 1;
-    if (scratch && nsteps >= 32 && (long)Ho * Wo <= split_max_px() && (size_t)segs * full <= scratch_bytes) ks = segs;
+    if (scratch && (nsteps >= 32 || (tiny && segs > 1)) && (long)Ho * Wo <= split_max_px() && (size_t)segs * full <= scratch_bytes) ks = segs;
     if (ngroup > 1 && !g_phase) ks = 1;        // phase groups may be split over K: every segment buffer then holds the whole full-resolution grid
     g.ksplit = ks;
     g.cout_store = cout_store > 0 ? cout_store : (g.raw_stride < cout_pad ? g.raw_stride : cout_pad);
@@ -271,7 +302,7 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     // (the tile shape never changes an element's accumulation order, so it may follow the batch size -- split launches included: 64 x 256^2
     //  1.76 -> 1.72 ms.  Folding the segments inside one workgroup instead of splitting -- same bits -- was measured too: the k loop of a
     //  workgroup is latency-bound, 108 -> 181 us on a 256-tile layer, and no gain beside the wide split tiles: not built)
-    const bool big = (ngroup == 1 || g_phase) && cout_pad % 128 == 0 &&
+    const bool big = !tiny && (ngroup == 1 || g_phase) && cout_pad % 128 == 0 &&
                      ((M + 255) / 256) * (cout_pad / 128) * ngroup * ks >= 256;
     // (256 x 256 tiles where they still give every CU a workgroup: two thirds of the LDS-DMA bytes per MFMA of the 256 x 128 form)
     const bool big2 = big && cout_pad % 256 == 0 && INNFER_KNOB("INNFER_GG_BIG2", 1) &&

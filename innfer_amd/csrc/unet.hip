@@ -183,7 +183,15 @@ __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long s
         if (px < HW && c < C) {
             const float* q = part + ((long)n * HW + px) * cpad + c;
             a = q[0];
-            for (int z = 1; z < ks; ++z) a += q[z * split_elems];
+            int z = 1;
+            for (; z + 8 <= ks; z += 8) {           // eight loads in flight, added in segment order (the order never depends on how they were fetched)
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = q[(long)(z + j) * split_elems];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a += t[j];
+            }
+            for (; z < ks; ++z) a += q[z * split_elems];
         }
         v[i] = a;
         sum += a;

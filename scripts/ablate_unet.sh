@@ -2,7 +2,7 @@
 # UNet_256 x64 with phases of the halo-tile conv kernel removed one at a time (diagnostic build: `make ablate`), kernel statistics per setting.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-for A in 0 1 2 4 8; do
+for A in ${ABLS:-0 1 2 4 8 16}; do
   UNET_N=64 INNFER_ABL=$A INNFER_LIB=$ROOT/innfer_amd/lib/libinnfer_amd_ablate.so rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/abl_unet_$A -- python3 $ROOT/scripts/bench_unet.py > /dev/null 2> $ROOT/gpurun_out/abl_unet_$A.err
   echo "ABL=$A"; python3 - $ROOT/gpurun_out/abl_unet_$A <<'PY'
 import csv, glob, sys

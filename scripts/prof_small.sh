@@ -8,6 +8,6 @@ cd $ROOT
 python3 - <<PY
 import csv, glob
 f = sorted(glob.glob("gpurun_out/prof_$TAG/*/*_kernel_stats.csv"))[-1]
-for r in list(csv.DictReader(open(f)))[:10]:
-    print(r["Name"][:70].ljust(70), r["Calls"].rjust(6), r["TotalDurationNs"].rjust(12), r["AverageNs"][:10].rjust(12), r["Percentage"])
+for r in list(csv.DictReader(open(f)))[:16]:
+    print(r["Name"][:95].ljust(95), r["Calls"].rjust(6), r["TotalDurationNs"].rjust(12), r["AverageNs"][:10].rjust(12), r["Percentage"])
 PY
