@@ -948,6 +948,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         int loff[KQ];
         int lpix[POLY ? KQ : 1];
         int s9_ty0 = 0, s9_tx0 = 0, s9_n = 0; bool s9_edge = false;          // S9: the current tile (edge tiles re-derive their offsets per chunk)
+        int s2_off[S2 ? KQ : 1]; unsigned s2_m0 = 0, s2_m1 = 0, s2_m2 = 0, s2_m3 = 0;   // S2 edge tiles: per-piece offsets of phase (0, 0), validity bits per phase
+        static_assert(!S2 || KQ <= 32, "one validity bit per piece");
         {
             const int ypar = p.up ? ((p.y0 - 1) & 1) : 0;
 #pragma unroll
@@ -1038,6 +1040,23 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 s9_ty0 = ty0; s9_tx0 = tx0; s9_n = n;
                 s9_edge = 2 * ty0 < 3 || 2 * (ty0 + TH) >= p.Hs || 2 * tx0 < 3 || 2 * (tx0 + TW) >= p.Ws;
                 in_tile = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)(2 * ty0 - 3) * p.Ws + (2 * tx0 - 3)) * 64;
+                if (s9_edge) {
+                    // a tile that touches the image border: the offsets of phase (0, 0) from the image origin and one validity bit per (phase, piece),
+                    // derived once per tile -- issue_to then selects; (deriving them per chunk cost the loaders ~0.7 us per step, and in the UNet's
+                    // 16 x 16 .. 64 x 64 grids every tile is such a tile: profiles/r3/ablate_unet.txt)
+                    s2_m0 = s2_m1 = s2_m2 = s2_m3 = 0;
+#pragma unroll
+                    for (int k = 0; k < KQ; ++k) {
+                        const int px = (lw + NLW * k) * 16 + (lane >> 2);
+                        const int ly = px / LWP, lx = px - ly * LWP;
+                        const int Yb = 2 * (ty0 - 1 + ly) - 1, Xb = 2 * (tx0 - 1 + lx) - 1;
+                        s2_off[S2 ? k : 0] = (Yb * p.Ws + Xb) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64);
+                        const bool y0 = Yb >= 0 && Yb < p.Hs, y1 = Yb + 1 >= 0 && Yb + 1 < p.Hs, x0 = Xb >= 0 && Xb < p.Ws, x1 = Xb + 1 >= 0 && Xb + 1 < p.Ws;
+                        const bool lv = loff[k] != OOB;
+                        s2_m0 |= (unsigned)(lv && y0 && x0) << k; s2_m1 |= (unsigned)(lv && y0 && x1) << k;
+                        s2_m2 |= (unsigned)(lv && y1 && x0) << k; s2_m3 |= (unsigned)(lv && y1 && x1) << k;
+                    }
+                }
                 return;
             }
             if (ty0 == 0 || ty0 + TH + 1 > p.H || tx0 == 0 || tx0 + TW + 1 > p.W) {
@@ -1100,16 +1119,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                     src = in_tile + cg * p.in_gbytes + ((long)pa * p.Ws + pb) * 64;
 #pragma unroll
                     for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
-                } else {                                                                  // offsets from the image origin, per lane
+                } else {                                                                  // offsets from the image origin, per lane (setup)
                     src = (const char*)(p.in + (long)s9_n * p.in_img_stride) + cg * p.in_gbytes;
+                    const int shift = (pa * p.Ws + pb) * 64;
+                    const unsigned m = ph == 0 ? s2_m0 : ph == 1 ? s2_m1 : ph == 2 ? s2_m2 : s2_m3;
 #pragma unroll
-                    for (int k = 0; k < KQ; ++k) {
-                        const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                        const int ly = px / LWP, lx = px - ly * LWP;
-                        const int Y = 2 * (s9_ty0 - 1 + ly) + pa - 1, X = 2 * (s9_tx0 - 1 + lx) + pb - 1;
-                        const bool ok = loff[k] != OOB && Y >= 0 && Y < p.Hs && X >= 0 && X < p.Ws;
-                        voff[k] = ok ? (Y * p.Ws + X) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64) : OOB;
-                    }
+                    for (int k = 0; k < KQ; ++k) voff[k] = ((m >> k) & 1u) ? s2_off[S2 ? k : 0] + shift : OOB;
                 }
             }
             const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
@@ -1135,7 +1150,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 }
             }
 #else
-            (void)c; (void)st_i; (void)st_w; (void)wsrc; (void)what; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile; (void)s9_ty0; (void)s9_tx0; (void)s9_n; (void)s9_edge;
+            (void)c; (void)st_i; (void)st_w; (void)wsrc; (void)what; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile; (void)s9_ty0; (void)s9_tx0; (void)s9_n; (void)s9_edge; (void)s2_off; (void)s2_m0; (void)s2_m1; (void)s2_m2; (void)s2_m3;
 #endif
         };
         auto issue = [&](int c, int stage) __attribute__((always_inline)) {

@@ -7,8 +7,11 @@ for A in ${ABLS:-0 1 2 4 8 16}; do
   echo "ABL=$A"; python3 - $ROOT/gpurun_out/abl_unet_$A <<'PY'
 import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv"))[-1]
-for r in list(csv.DictReader(open(f)))[:30]:
-    if "conv3x3_pc" in r["Name"] or "first" in r["Name"]:
-        print("  ", r["Name"][:70].ljust(70), r["Calls"].rjust(4), r["AverageNs"][:9].rjust(10))
+import re
+for r in sorted(csv.DictReader(open(f)), key=lambda r: r["Name"]):
+    if "conv3x3_pc" in r["Name"]:
+        m = re.search(r"conv3x3_pc<([^>]*)>", r["Name"])
+        # (the first launch of an instantiation carries the code-object load: the minimum is the steady state)
+        print("   conv3x3_pc<%s>" % m.group(1).replace(" ", ""), r["Calls"].rjust(4), "avg", r["AverageNs"][:9].rjust(10), "min", r["MinNs"].rjust(8))
 PY
 done
