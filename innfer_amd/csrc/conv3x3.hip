@@ -203,7 +203,7 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
 
 // DCV (conv3x3_pc<.., TM = 0x1B>: one output phase of ConvTranspose2d(4, 2, 1) per 16*NT-channel group): (ty0, tx0) are coordinates of the phase's
 // shifted lattice (see decode); virtual pixel (y', x') of phase (a, b) is output pixel (2y' - a, 2x' - b) of the 2H x 2W slab, channel ch % phase_c.
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, int NSEG = 2>
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, bool PAIR = false>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase, int dil = 1) {
     constexpr int MT = 2 * RPW;
@@ -234,6 +234,11 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
         rowstep = (long)p.W * 32 * 4;
         colstep = 16 * 32 * 2;
         ylim = p.H;
+        if constexpr (PAIR) { pix0 = ((long)(2 * n) * 2 * p.H + 2 * yw + a) * (2 * p.W) + 2 * xl + b; colstep = 4L * p.H * p.W * 32; }
+    } else if constexpr (PAIR) {
+        // PAIR (images at most 16 pixels wide): the tile's two 16-pixel segments are images 2n and 2n + 1 -- a segment step is an image step
+        pix0 = ((long)(2 * n) * p.H + yw) * p.W + xl;
+        colstep = (long)p.H * p.W * 32;
     }
     f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix0 * 32 + (oc0 & 31);
     const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + pix0 * 32 + (cbase & 31) : nullptr;
@@ -242,7 +247,7 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
     f16x4 r1[R1 ? MT : 1][NT], r2[R2 ? MT : 1][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        ok[m] = (NSEG == 2 || !(m & 1)) && (yw + (m >> 1) < ylim) && (xl + (m & 1) * 16 < xlim);
+        ok[m] = PAIR ? (2 * n + (m & 1) < p.N && yw + (m >> 1) < ylim && xl < xlim) : ((yw + (m >> 1) < ylim) && (xl + (m & 1) * 16 < xlim));
         const long o = (m >> 1) * rowstep + (m & 1) * colstep;
         if (HOIST && R1 && ok[m]) {
 #pragma unroll
@@ -746,22 +751,32 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 //   part[((slot * NCW + wave) * cn + channel) * 3],  slot = tile index over the batch (x 4 + phase behind the phase lattice).
 // norm::combine_parts merges an image's partials in index order (Chan's update): deterministic, no atomics, and the pass that re-read the conv
 // output for its statistics is gone.
-template <int RPW, int NT, bool DCV, int NSEG, int NCW>
+template <int RPW, int NT, bool DCV, bool PAIR, int NCW>
 __device__ __forceinline__ void epilogue_stats(const KP& p, const f32x4 (&acc)[NT][2 * RPW], const f32x4 (&bias)[NT], int ty0, int tx0, int wave, int li,
                                                int cbase, int tile) {
     static_assert(NT == 4, "sixteen channels per lane: one per pixel lane after the transposing reduction");
     constexpr int MT = 2 * RPW;
-    int yw = ty0 + wave * RPW, x0 = tx0, ylim = p.y1, c0 = cbase, slot = tile;
+    int yw = ty0 + wave * RPW, x0 = tx0, ylim = p.y1, c0 = cbase, slot = tile, ph = 0;
     if constexpr (DCV) {
-        const int ph = cbase / p.phase_c;
+        ph = cbase / p.phase_c;
         yw -= ph >> 1; x0 -= ph & 1; ylim = p.H;
         c0 -= ph * p.phase_c;
         slot = tile * 4 + ph;
     }
+    // PAIR: the two segments are two images (2q, 2q + 1; q = tile / tiles_y): one record set per image, at that image's slot
+#pragma unroll
+    for (int sg = 0; sg < (PAIR ? 2 : 1); ++sg) {
+    if constexpr (PAIR) {
+        const int q = tile / p.tiles_y, ty = tile - q * p.tiles_y;
+        if (2 * q + sg >= p.N) continue;
+        slot = (2 * q + sg) * p.tiles_y + ty;
+        if constexpr (DCV) slot = slot * 4 + ph;
+    }
     bool ok[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) ok[m] = (NSEG == 2 || !(m & 1)) && (yw + (m >> 1) < ylim) && (x0 + li + (m & 1) * 16 < p.W);
-    const int rows = min(max(ylim - yw, 0), RPW), cols = min(max(p.W - x0, 0), 16 * NSEG);
+    for (int m = 0; m < MT; ++m)
+        ok[m] = PAIR ? ((m & 1) == sg && yw + (m >> 1) < ylim && x0 + li < p.W) : ((yw + (m >> 1) < ylim) && (x0 + li + (m & 1) * 16 < p.W));
+    const int rows = min(max(ylim - yw, 0), RPW), cols = min(max(p.W - x0, 0), PAIR ? 16 : 32);
     const float cnt = (float)(rows * cols);                        // valid pixels of this wave (uniform)
     // sums of (x - bias) and of its square per channel: the conv response without its bias has a small mean, so M2 = s2 - s1^2 / n loses nothing
     float s1[16], s2[16];
@@ -799,6 +814,7 @@ __device__ __forceinline__ void epilogue_stats(const KP& p, const f32x4 (&acc)[N
     const float mean = s1[0] * inv;
     float* o = p.stats_part + ((long)(slot * NCW + wave) * p.stats_cn + c0 + li) * 3;
     o[0] = cnt; o[1] = bl + mean; o[2] = fmaxf(s2[0] - s1[0] * mean, 0.f);
+    }
 }
 
 // S9: a 7x7 convolution as nine 3x3 convolutions over displaced copies of the input -- virtual chunk c = (sub, group): the loader reads
@@ -826,7 +842,7 @@ __device__ __forceinline__ void epilogue_stats(const KP& p, const f32x4 (&acc)[N
 //   0x1FF  3x3 conv (software-pipelined fragment reads)          0x010  1x1 conv                      0x092  column taps (S9: 7 x 1 conv as three blocks)
 //   0x01B  ConvTranspose2d(k, 2, 1): one output phase per channel group on a lattice shifted by the phase, scatter into the 2x slab
 //   0x1B0 | 0x200  Conv2d(4, 2, 1): the loader gathers the space-to-depth source (chunk = (phase, channel group))
-//   | 0x400  grids <= 16 wide: one 16-pixel segment per tile row      | 0x800  (1x1) operand = LeakyReLU(running sum over the chunks) (PPON's c2)
+//   | 0x400  grids <= 16 wide: two images per tile row (PAIR)           | 0x800  (1x1) operand = LeakyReLU(running sum over the chunks) (PPON's c2)
 //   | 0x1000 partial norm statistics out of the epilogue (epilogue_stats)
 // Every flag is compile-time: the instantiations of the SR path (0x1FF without flags) contain none of the other modes' code.
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9 = false, bool POLY = false, int TMF = 0x1FF, bool CV = false, int NSI = 2, int NCW = 8>
@@ -835,10 +851,15 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // chunk c is (phase (pa, pb) = c / ncg, channel group c % ncg); cell (cy, cx) of phase (pa, pb) is source pixel (2cy + pa - 1, 2cx + pb - 1)
     // (the lattice of the image padded by one pixel), so output (y, x) reads cells y, y + 1 (taps r, s in {1, 2}: mask 0x1B0) and the padding
     // is the loader's range check.  H, W: the OUTPUT grid; the source image is Hs x Ws = 2H x 2W.
-    // + 0x400: images at most 16 pixels wide -- only the first 16-pixel segment of the tile row is multiplied and stored (the deep UNet levels)
+    // + 0x400 (PAIR): images at most 16 pixels wide -- a tile row is TWO images side by side: LDS columns 0..17 the halo row of image 2q, 18..35 that of
+    // image 2q + 1 (the 36-pixel pitch is exactly two 18-pixel halo rows), segment 0 / 1 of the MFMA walk = image 2q / 2q + 1 (the deep UNet levels;
+    // until round 3 the second segment was idle).  Every output pixel sees the same operands in the same order as in a tile of its own.
     constexpr int TM = TMF & 0x1FF;
     constexpr bool S2 = (TMF & 0x200) != 0;
-    constexpr int NSEG = (TMF & 0x400) ? 1 : 2;
+    constexpr bool PAIR = (TMF & 0x400) != 0;
+    constexpr int NSEG = 2;
+    constexpr int TWI = PAIR ? 16 : TW;                 // image columns a tile row segment set covers per image
+    static_assert(!PAIR || (__builtin_popcount(TMF & 0x1FF) == 4 && !S9 && !POLY && !CV), "image pairs: the four-tap kernels");
     // + 0x800 (one-tap kernels): the B operand of chunk k is LeakyReLU(0.2) of the running sum of chunks 0 .. k of the pixel -- PPON's
     // cat(d1, d1 + d2, .., d1 + .. + d8) -> act -> c2 (PPON_arch.py:104-114) without the pass that materialises it: the consumer keeps the
     // fp32 running sums of its own pixels in registers (same additions in the same order as that pass made: same bits)
@@ -958,6 +979,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 const int ly = px / LWP;
                 int lx = px - ly * LWP;
                 if constexpr (WINO) lx = lx >= 18 ? (lx == 35 ? LVALID : 2 * (lx - 18) + 1) : (lx == 17 ? LVALID : 2 * lx);      // even columns, then odd ones (17 valid of 18 each)
+                const bool imgb = PAIR && lx >= 18;                                       // PAIR: LDS columns 18 .. 35 are the halo row of the pair's second image
+                if (imgb) lx -= 18;
                 const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
                 const int ry = S2 ? 2 * ly : p.up ? (ly + ypar) >> 1 : ly;
                 const int rx = S2 ? 2 * lx : p.up ? (lx + 1) >> 1 : lx;
@@ -965,8 +988,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 // without memory traffic)
                 constexpr int R0 = (TM & 0x007) ? 0 : (TM & 0x038) ? 1 : 2, R1 = (TM & 0x1C0) ? 2 : (TM & 0x038) ? 1 : 0;
                 constexpr int S0 = (TM & 0x049) ? 0 : (TM & 0x092) ? 1 : 2, S1 = (TM & 0x124) ? 2 : (TM & 0x092) ? 1 : 0;
-                const bool used = ly >= R0 && ly <= TH - 1 + R1 && lx >= S0 && lx <= TW - 1 + S1;
-                loff[k] = (px < NPX && lx < LVALID && used) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 : OOB;
+                const bool used = ly >= R0 && ly <= TH - 1 + R1 && lx >= S0 && lx <= TWI - 1 + S1;
+                loff[k] = (px < NPX && lx < LVALID && used) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 + (imgb ? (int)p.in_img_stride * 2 : 0) : OOB;
                 if constexpr (POLY) {          // the tile's dilation scales the pixel part: voff = lpix * d + slot (setup)
                     lpix[k] = (px < NPX && lx < LVALID) ? (ly * p.fullW + lx) * 64 : -1;
                     loff[k] = slot * 16;
@@ -983,7 +1006,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             int kg, n, ty0, tx0, dl = 1;
             if constexpr (POLY) decode_poly(jj, kg, n, ty0, tx0, dl);
             else decode(jj, kg, n, ty0, tx0);
-            in_tile = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)((ty0 - 1) >> p.up) * p.Ws + ((tx0 >> p.up) - 1)) * 64;
+            const long n0 = PAIR ? 2L * n : n;                 // PAIR: n is the pair; image 2n + 1 lies one image stride behind (loff)
+            const bool no_b = PAIR && 2 * n + 1 >= p.N;        // an odd batch's last pair has no second image: its pieces stay zero
+            in_tile = (const char*)(p.in + n0 * p.in_img_stride) + ((long)((ty0 - 1) >> p.up) * p.Ws + ((tx0 >> p.up) - 1)) * 64;
             w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
 #pragma unroll
             for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
@@ -1037,9 +1062,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 return;
             }
             if constexpr (S2) {          // cells (ty0 - 1 .. ty0 + TH) x (tx0 - 1 .. tx0 + TW) of both phases: source rows 2 ty0 - 3 .. 2 (ty0 + TH)
-                s9_ty0 = ty0; s9_tx0 = tx0; s9_n = n;
-                s9_edge = 2 * ty0 < 3 || 2 * (ty0 + TH) >= p.Hs || 2 * tx0 < 3 || 2 * (tx0 + TW) >= p.Ws;
-                in_tile = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)(2 * ty0 - 3) * p.Ws + (2 * tx0 - 3)) * 64;
+                s9_ty0 = ty0; s9_tx0 = tx0; s9_n = (int)n0;
+                s9_edge = PAIR || 2 * ty0 < 3 || 2 * (ty0 + TH) >= p.Hs || 2 * tx0 < 3 || 2 * (tx0 + TW) >= p.Ws;
+                in_tile = (const char*)(p.in + n0 * p.in_img_stride) + ((long)(2 * ty0 - 3) * p.Ws + (2 * tx0 - 3)) * 64;
                 if (s9_edge) {
                     // a tile that touches the image border: the offsets of phase (0, 0) from the image origin and one validity bit per (phase, piece),
                     // derived once per tile -- issue_to then selects; (deriving them per chunk cost the loaders ~0.7 us per step, and in the UNet's
@@ -1048,26 +1073,31 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                     for (int k = 0; k < KQ; ++k) {
                         const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                        const int ly = px / LWP, lx = px - ly * LWP;
+                        const int ly = px / LWP;
+                        int lx = px - ly * LWP;
+                        const bool imgb = PAIR && lx >= 18;
+                        if (imgb) lx -= 18;
                         const int Yb = 2 * (ty0 - 1 + ly) - 1, Xb = 2 * (tx0 - 1 + lx) - 1;
-                        s2_off[S2 ? k : 0] = (Yb * p.Ws + Xb) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64);
+                        s2_off[S2 ? k : 0] = (Yb * p.Ws + Xb) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64);        // (loff carries the second image's stride)
                         const bool y0 = Yb >= 0 && Yb < p.Hs, y1 = Yb + 1 >= 0 && Yb + 1 < p.Hs, x0 = Xb >= 0 && Xb < p.Ws, x1 = Xb + 1 >= 0 && Xb + 1 < p.Ws;
-                        const bool lv = loff[k] != OOB;
+                        const bool lv = loff[k] != OOB && !(imgb && no_b);
                         s2_m0 |= (unsigned)(lv && y0 && x0) << k; s2_m1 |= (unsigned)(lv && y0 && x1) << k;
                         s2_m2 |= (unsigned)(lv && y1 && x0) << k; s2_m3 |= (unsigned)(lv && y1 && x1) << k;
                     }
                 }
                 return;
             }
-            if (ty0 == 0 || ty0 + TH + 1 > p.H || tx0 == 0 || tx0 + TW + 1 > p.W) {
+            if (PAIR || ty0 == 0 || ty0 + TH + 1 > p.H || tx0 == 0 || tx0 + TW + 1 > p.W) {
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
                     const int px = (lw + NLW * k) * 16 + (lane >> 2);
                     const int ly = px / LWP;
                     int lx = px - ly * LWP;
                     if constexpr (WINO) lx = lx >= 18 ? 2 * (lx - 18) + 1 : 2 * lx;
+                    const bool imgb = PAIR && lx >= 18;
+                    if (imgb) lx -= 18;
                     const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
-                    if (Y < 0 || Y >= p.H || X < 0 || X >= p.W) {
+                    if (Y < 0 || Y >= p.H || X < 0 || X >= p.W || (imgb && no_b)) {
                         // reflection padding: the ring of pixels one step outside the image mirrors the pixel one step inside; farther
                         // out (tile padding of a ragged frame) only feeds outputs that are never stored
                         // (reflect 2 = nn.ReplicationPad2d(1): the ring repeats the border pixel)
@@ -1233,6 +1263,18 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             const int rowpar = ((cw * RPW) & 1) ^ par;
             boffs[s][par] = pb * 64 + ((lg ^ (((((li + s) >> 2) & 1) ^ rowpar) << 1)) << 4);
         }
+    // PAIR: segment 1 starts at LDS column 18 (the second image's halo row), not 16: its own swizzle term
+    int boffp[PAIR ? 3 : 1][2];
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int pb = cw * RPW * LWP + 18 + li + s;
+                const int rowpar = ((cw * RPW) & 1) ^ par;
+                boffp[s][par] = pb * 64 + ((lg ^ (((((18 + li + s) >> 2) & 1) ^ rowpar) << 1)) << 4);
+            }
+    }
     const int aoffs = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
     // WINO: byte offsets of d(half h, pixel pair li + dl) in the wave's rows 0 and 1: LDS pixel P = row * 36 + 18 h + li + dl, slot lg ^ 2 bit2(P); rows of one
     // parity differ by whole multiples of two pitches (36 = 4 x 9: bit2(P) depends on the row's parity only), i.e. by immediates
@@ -1390,7 +1432,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 for (int t = 0; t < NT; ++t) a[q][t] = *(const f16x8*)(sw + aoffs + ((q * 2 + sc - S0) * WROWS + t * 16) * 64);
             };
             f16x8 bq[3];
-            auto ldb = [&](int i) { return *(const f16x8*)(st + boffs[WK.s[i]][WK.rr[i] & 1] + (WK.rr[i] * LWP + WK.seg[i] * 16) * 64); };
+            auto ldb = [&](int i) {
+                if constexpr (PAIR) { if (WK.seg[i]) return *(const f16x8*)(st + boffp[WK.s[i]][WK.rr[i] & 1] + WK.rr[i] * LWP * 64); }
+                return *(const f16x8*)(st + boffs[WK.s[i]][WK.rr[i] & 1] + (WK.rr[i] * LWP + WK.seg[i] * 16) * 64);
+            };
             lda(S0, 0); lda(S0, 1);
             bq[0] = ldb(0);
             if (WK.n > 1) bq[1] = ldb(1);
@@ -1432,7 +1477,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 if (!need) continue;
 #pragma unroll
                 for (int seg = 0; seg < NSEG; ++seg) {
-                    f16x8 b = *(const f16x8*)(st + boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64);
+                    f16x8 b = *(const f16x8*)(st + ((PAIR && seg) ? boffp[PAIR ? s : 0][rr & 1] + rr * LWP * 64 : boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64));
                     if constexpr (PFX) {           // (one tap: row rr feeds output row rr - 1 only)
                         static_assert(!PFX || TM == 0x10, "the running-sum operand belongs to the one-tap kernels");
 #pragma unroll
@@ -1501,9 +1546,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             } else if constexpr (OUTMODE == OUT_SLAB) {
             if constexpr (STATS) {
                 const int lid = run_start + (p.rev ? run_len - 1 - (jt - slots) : (jt - slots));         // (jt was advanced above)
-                epilogue_stats<RPW, NT, TM == 0x1B, NSEG, NCW>(p, acc, bias_r, ty0, tx0, cw, li, cbase, lid / p.KG);
+                epilogue_stats<RPW, NT, TM == 0x1B, PAIR, NCW>(p, acc, bias_r, ty0, tx0, cw, li, cbase, lid / p.KG);
             }
-#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, NSEG>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, PAIR>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
                 else if (NT == 4 && TM == 0x1FF && !POLY && p.act == 7) EPI((NT == 4 && TM == 0x1FF && !POLY) ? 7 : 0, false, false); else EPI(0, false, false);
@@ -1759,7 +1804,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
 #ifdef INNFER_ABLATE
     k.abl = getenv("INNFER_ABL") ? atoi(getenv("INNFER_ABL")) : 0;     // read per launch: scripts/ablate.py changes it between runs
 #endif
-    long total = (long)N * k.tiles_x * k.tiles_y * k.KG;
+    long total = (long)((TM & 0x400) ? (N + 1) / 2 : N) * k.tiles_x * k.tiles_y * k.KG;      // (0x400: two images per tile row)
     if constexpr (CV) {                       // one canvas instead of N images
         k.tiles_x = (k.cv_gx * k.cv_w1 + TW - 1) / TW;
         k.tiles_y = (k.cv_gy * k.cv_h1 + TH - 1) / TH;
