@@ -848,6 +848,27 @@ def test_stride2_conv_and_transposed_conv_vs_torch(dev):
             assert got.shape == ref.shape and (got - ref).abs().max().item() < 4e-3, ("up", k, N, Cc, K, H, W, (got - ref).abs().max().item())
 
 
+def test_small_grid_image_pairs_are_bit_identical_to_single_images(dev):
+    """Grids at most 16 pixels wide: conv3x3_pc<.., TMF | 0x400> puts two images of the batch side by side in one tile row (LDS columns 0..17 / 18..35).
+    Every output pixel must see the operands it saw in a tile of its own, in the same order: image i of an odd and of an even batch == the batch-1 run of
+    image i, bit for bit, for both stride-2 forms; grids narrower than 16 and taller than one tile included."""
+    rng = np.random.RandomState(23)
+    for (N, Cc, K, H, W) in [(3, 64, 64, 16, 16), (4, 32, 128, 8, 8), (5, 32, 64, 40, 12), (2, 96, 64, 3, 16)]:
+        b = torch.from_numpy(rng.uniform(-0.5, 0.5, K).astype(np.float32))
+        x = torch.from_numpy(rng.uniform(-1, 1, (N, Cc, 2 * H, 2 * W)).astype(np.float32)).half()
+        w = torch.from_numpy((rng.uniform(-1, 1, (K, Cc, 4, 4)) / np.sqrt(16 * Cc)).astype(np.float32)).half().float()
+        got = _run_stride2(dev, x, w, b, K, "down", act=1)
+        for i in range(N):
+            one = _run_stride2(dev, x[i:i + 1], w, b, K, "down", act=1)
+            assert torch.equal(got[i:i + 1], one), ("down", N, Cc, K, H, W, i)
+        x = torch.from_numpy(rng.uniform(-1, 1, (N, Cc, H, W)).astype(np.float32)).half()
+        w = torch.from_numpy((rng.uniform(-1, 1, (Cc, K, 4, 4)) / np.sqrt(4 * Cc)).astype(np.float32)).half().float()
+        got = _run_stride2(dev, x, w, b, K, "up", k=4, act=2)
+        for i in range(N):
+            one = _run_stride2(dev, x[i:i + 1], w, b, K, "up", k=4, act=2)
+            assert torch.equal(got[i:i + 1], one), ("up", N, Cc, K, H, W, i)
+
+
 def test_pair_gate_epilogue_vs_torch(dev):
     """act 7 of the single-conv ABI: 64 rows -> 32 channels, out[8 q + r] = conv[16 q + r] * sigmoid(conv[16 q + 8 + r]) -- two independent 3x3 convs
     (value, gate) interleaved that way against torch; a batch of ragged images (the canvas form) and one image."""
@@ -979,6 +1000,10 @@ def test_unet256_big_batch_uses_wide_tiles_and_stays_identical(dev):
     assert torch.isfinite(y).all()
     for i in (0, 7, 15):
         assert torch.equal(y[i:i + 1], net(x[i:i + 1])), i
+    # an odd batch: the last image of the 16-pixel-wide levels has no partner in its tile row (conv3x3_pc's image pairs), statistics per image
+    y5 = net(x[:5])
+    for i in range(5):
+        assert torch.equal(y5[i:i + 1], y[i:i + 1]), i
 
 
 def test_color_fix_vs_oracle(dev):
