@@ -97,6 +97,7 @@ constexpr TapWalk make_tap_walk(int tm, int rpw, int nseg) {
     }
     return w;
 }
+template <int TM_, int RPW_, int NSEG_> struct TapWalkOf { static constexpr TapWalk value = make_tap_walk(TM_, RPW_, NSEG_); };
 
 struct KP {
     const f16* in; long in_img_stride; long in_gbytes; int nchunks;   // gbytes: bytes between channel groups
@@ -921,7 +922,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     const int ntiles = (run_len - j0 + slots - 1) / slots;
     const int G = ntiles * p.nchunks;                            // chunks this workgroup goes through
 
-    auto decode = [&](int jj, int& kg_, int& n_, int& ty0_, int& tx0_) {
+    // (always_inline, like the loaders' lambdas: left as a call it takes the address of the kernel-argument struct, which then lives in scratch memory)
+    auto decode = [&](int jj, int& kg_, int& n_, int& ty0_, int& tx0_) __attribute__((always_inline)) {
         const int lid = run_start + (p.rev ? run_len - 1 - jj : jj);
         kg_ = lid % p.KG;
         int tile = lid / p.KG;
@@ -969,7 +971,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         int loff[KQ];
         int lpix[POLY ? KQ : 1];
         int s9_ty0 = 0, s9_tx0 = 0, s9_n = 0; bool s9_edge = false;          // S9: the current tile (edge tiles re-derive their offsets per chunk)
-        int s2_off[S2 ? KQ : 1]; unsigned s2_m0 = 0, s2_m1 = 0, s2_m2 = 0, s2_m3 = 0;   // S2 edge tiles: per-piece offsets of phase (0, 0), validity bits per phase
+        constexpr bool S2PRE = S2 && RPW == 2;      // (the 24-row, 32-channel form keeps the per-chunk derivation: with the per-tile one hipcc leaves its argument struct in scratch memory)
+        int s2_off[S2PRE ? KQ : 1]; unsigned s2_m0 = 0, s2_m1 = 0, s2_m2 = 0, s2_m3 = 0;   // S2 edge tiles: per-piece offsets of phase (0, 0), validity bits per phase
         static_assert(!S2 || KQ <= 32, "one validity bit per piece");
         {
             const int ypar = p.up ? ((p.y0 - 1) & 1) : 0;
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 s9_ty0 = ty0; s9_tx0 = tx0; s9_n = (int)n0;
                 s9_edge = PAIR || 2 * ty0 < 3 || 2 * (ty0 + TH) >= p.Hs || 2 * tx0 < 3 || 2 * (tx0 + TW) >= p.Ws;
                 in_tile = (const char*)(p.in + n0 * p.in_img_stride) + ((long)(2 * ty0 - 3) * p.Ws + (2 * tx0 - 3)) * 64;
-                if (s9_edge) {
+                if (S2PRE && s9_edge) {
                     // a tile that touches the image border: the offsets of phase (0, 0) from the image origin and one validity bit per (phase, piece),
                     // derived once per tile -- issue_to then selects; (deriving them per chunk cost the loaders ~0.7 us per step, and in the UNet's
                     // 16 x 16 .. 64 x 64 grids every tile is such a tile: profiles/r3/ablate_unet.txt)
@@ -1078,7 +1081,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                         const bool imgb = PAIR && lx >= 18;
                         if (imgb) lx -= 18;
                         const int Yb = 2 * (ty0 - 1 + ly) - 1, Xb = 2 * (tx0 - 1 + lx) - 1;
-                        s2_off[S2 ? k : 0] = (Yb * p.Ws + Xb) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64);        // (loff carries the second image's stride)
+                        s2_off[S2PRE ? k : 0] = (Yb * p.Ws + Xb) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64);        // (loff carries the second image's stride)
                         const bool y0 = Yb >= 0 && Yb < p.Hs, y1 = Yb + 1 >= 0 && Yb + 1 < p.Hs, x0 = Xb >= 0 && Xb < p.Ws, x1 = Xb + 1 >= 0 && Xb + 1 < p.Ws;
                         const bool lv = loff[k] != OOB && !(imgb && no_b);
                         s2_m0 |= (unsigned)(lv && y0 && x0) << k; s2_m1 |= (unsigned)(lv && y0 && x1) << k;
@@ -1149,12 +1152,22 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                     src = in_tile + cg * p.in_gbytes + ((long)pa * p.Ws + pb) * 64;
 #pragma unroll
                     for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
-                } else {                                                                  // offsets from the image origin, per lane (setup)
+                } else if constexpr (S2PRE) {                                             // offsets from the image origin, per lane (setup)
                     src = (const char*)(p.in + (long)s9_n * p.in_img_stride) + cg * p.in_gbytes;
                     const int shift = (pa * p.Ws + pb) * 64;
                     const unsigned m = ph == 0 ? s2_m0 : ph == 1 ? s2_m1 : ph == 2 ? s2_m2 : s2_m3;
 #pragma unroll
-                    for (int k = 0; k < KQ; ++k) voff[k] = ((m >> k) & 1u) ? s2_off[S2 ? k : 0] + shift : OOB;
+                    for (int k = 0; k < KQ; ++k) voff[k] = ((m >> k) & 1u) ? s2_off[S2PRE ? k : 0] + shift : OOB;
+                } else {                                                                  // (24-row tiles: per chunk, as before round 3)
+                    src = (const char*)(p.in + (long)s9_n * p.in_img_stride) + cg * p.in_gbytes;
+#pragma unroll
+                    for (int k = 0; k < KQ; ++k) {
+                        const int px = (lw + NLW * k) * 16 + (lane >> 2);
+                        const int ly = px / LWP, lx = px - ly * LWP;
+                        const int Y = 2 * (s9_ty0 - 1 + ly) + pa - 1, X = 2 * (s9_tx0 - 1 + lx) + pb - 1;
+                        const bool ok = loff[k] != OOB && Y >= 0 && Y < p.Hs && X >= 0 && X < p.Ws;
+                        voff[k] = ok ? (Y * p.Ws + X) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64) : OOB;
+                    }
                 }
             }
             const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
@@ -1423,7 +1436,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             // software-pipelined like the nine-tap loop above: all sixteen weight fragments of the chunk first, then the pixel fragments through a
             // three-register ring, each read two MFMA groups ahead of its use.  Left to the scheduler, every read sat in front of its first use:
             // a chunk-step took the LDS phase PLUS the MFMA phase (1.8 us for 1.0 us of matrix work).  Same MFMAs in the same order: same bits.
-            constexpr TapWalk WK = make_tap_walk(TM, RPW, NSEG);
+            constexpr const TapWalk& WK = TapWalkOf<TM, RPW, NSEG>::value;      // (a class-scope constant: a local copy indexed by a loop variable may land in scratch)
+            constexpr int NBW = TapWalkOf<TM, RPW, NSEG>::value.n;
             constexpr int R0 = (TM & 0x007) ? 0 : 1, S0 = (TM & 0x049) ? 0 : 1;          // the mask is the 2 x 2 block of taps (R0 .. R0 + 1) x (S0 .. S0 + 1)
             static_assert(TM == (0x1B << (3 * R0 + S0)), "four taps: a 2 x 2 block of the 3 x 3 lattice");
             f16x8 a[2][NT];                                                              // the weight fragments of the current tap column, by tap row - R0
@@ -1438,10 +1452,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             };
             lda(S0, 0); lda(S0, 1);
             bq[0] = ldb(0);
-            if (WK.n > 1) bq[1] = ldb(1);
+            if (NBW > 1) bq[1] = ldb(1);
 #pragma unroll
-            for (int i = 0; i < WK.n; ++i) {
-                if (i + 2 < WK.n) bq[(i + 2) % 3] = ldb(i + 2);
+            for (int i = 0; i < NBW; ++i) {
+                if (i + 2 < NBW) bq[(i + 2) % 3] = ldb(i + 2);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int rw = WK.rr[i] - R0 - q;
