@@ -763,7 +763,7 @@ int run_gemm(const Layer& l, const f16* wpk, const f16* in, long in_g, int N, in
 }
 }  // namespace
 
-// >= 70 % of the halo-tile kernel's pixels are real ones: 16-row tiles of 32 columns, or of 16 for grids at most 16 wide (conv3x3_pc's half-width form)
+// >= 70 % of the halo-tile kernel's pixels are real ones: 16-row tiles of 32 columns; grids at most 16 wide share a tile row between two images (conv3x3_pc's image pairs)
 static bool fills_tiles(int h, int w) {
     const long tw = w <= 16 ? 16 : (w + 31) / 32 * 32;
     return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * tw * 7;

@@ -821,7 +821,7 @@ def _run_stride2(dev, x, w, b, K, kind, k=4, act=0):
 
 def test_stride2_conv_and_transposed_conv_vs_torch(dev):
     """Conv2d(4, 2, 1) on the stride-2 gather loader and ConvTranspose2d(4, 2, 1) / (3, 2, 1, output_padding 1) on the phase lattice (conv3x3_pc
-    TMF 0x3B0 / 0x1B and their half-width forms) against torch in fp32 on the fp16-rounded operands, over seeded shapes: ragged tile rows and
+    TMF 0x3B0 / 0x1B and their image-pair forms for grids at most 16 wide) against torch in fp32 on the fp16-rounded operands, over seeded shapes: ragged tile rows and
     columns, one- and two-tile-wide images, grids at most 16 wide (one 16-pixel segment), batches, 64 .. 192 output channels, activations.
     Tolerance: fp16 rounding of the stored result plus fp32 accumulation order (<= 4e-3 for unit-scale outputs, as for the 3x3 conv)."""
     import torch.nn.functional as F
@@ -1466,7 +1466,7 @@ def test_pan_scales_vs_oracle(dev):
 
 def test_small_generators_shape_fuzz_and_poisoned_workspace(dev):
     """Seeded shapes for the pix2pix UNet, the CycleGAN ResNet and the WBC UNet against the oracle: every size decides anew which levels run on the
-    halo-tile kernel's stride-2 / phase-lattice / column / sub-block forms (ragged tile rows and columns, half-width grids, batches) and which on the
+    halo-tile kernel's stride-2 / phase-lattice / column / sub-block forms (ragged tile rows and columns, grids at most 16 wide, batches) and which on the
     gather GEMM.  Each forward is repeated on a workspace filled with 0xFF bytes (NaN as fp16 / fp32): the result must not change, i.e. every byte a
     kernel reads -- padded rings, statistics partials, split-K segments -- was written by this forward."""
     import oracle
