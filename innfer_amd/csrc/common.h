@@ -83,6 +83,9 @@ struct ConvLaunch {
     int conv7;                                    // 7x7 conv, padding 3 (zero or `reflect`), panels from conv_pack7x7: OUT_NCHW, K <= 16 only
     int reflect;                                  // 1: ReflectionPad2d(1) instead of zero padding (slab / planar outputs of the producer-consumer kernel);
                                                   // 2: ReplicationPad2d(1) (3x3 slab convs)
+    // HR_conv0 -> conv_last fused (conv3x3_pc<.., TMF | 0x20000>): this conv (64 -> 64, slab semantics, `out` unused) carries the network's last conv in its epilogue
+    const f16* fuse_w;                            //   conv_pack_fuse_last() panel of the last conv (4 KB, device), nullptr = not fused
+    const float* fuse_bias; float* fuse_side; void* fuse_out; int fuse_oc, fuse_out_f32;   // its bias, the rim buffer (conv_fuse_side_bytes), the planar result
     int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)
     int outm;                                     // OUT_NCHW: `outm` of RRDBNet / SRResNet.forward applied after `act`: 1 (tanh + 1) / 2, 2 tanh, 3 sigmoid, 4 clamp(0, 1)
     int out_u8, out_denorm, out_round16;          // OUT_NCHW with <= 4 channels: write a uint8 HWC BGR(A) image instead -- tensor2np as the conv's epilogue
@@ -124,6 +127,9 @@ void conv_pack7v(const float* w_oc7, int K, int C, void* packed);             //
 size_t conv_packed_bytes_s2k4(int K, int C);
 void conv_pack_s2k4(const float* w_oi44, int K, int C, void* packed);         // host; Conv2d(4, 2, 1) panels for ConvLaunch.stride2
 size_t conv_packed_bytes_deconv2x(int K, int C);
+bool conv_fuse_last_ok(const ConvLaunch& L);
+size_t conv_fuse_side_bytes(int N, int H, int W);
+void conv_pack_fuse_last(const float* w_last_oihw, int oc, void* packed_4k);   // host
 void conv_pack_deconv2x(const float* w_io, int K, int C, int k, void* packed); // host; ConvTranspose2d(k = 3 | 4, 2, 1) panels for ConvLaunch.deconv_phases, w [C][K][k][k]
 void conv_pack_taps(const float* w, int K, int C, int mask, void* packed);   // host; w [K][C][9], only the taps of `mask` are packed (conv_packed_bytes_taps)
 size_t conv_packed_bytes7x7(int K, int C);

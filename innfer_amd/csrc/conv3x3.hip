@@ -35,6 +35,7 @@
 // only: all ds_read_b128 are base+immediate and bank-conflict free.  A pixel fragment B(row, seg, s) is
 // read once and used by the up to three (row-in-wave, r) pairs that need it.
 #include "common.h"
+#include <type_traits>
 
 #include <cstdlib>
 #include <vector>
@@ -127,6 +128,12 @@ struct KP {
     int phase_c;             // OUT_NCHW: > 0 = channel ch is phase (ch / phase_c) of a 2x transposed conv: channel ch % phase_c at (2y + ph/2, 2x + ph%2)
     int total;               // tiles x channel groups of this launch
     int cv_gx, cv_gy, cv_h1, cv_w1;   // CV kernels (image canvas): the N images are the cells of a cv_gx x cv_gy grid, cell pitch (H + 1) x (W + 1)
+    // FUSE kernels (TMF | 0x20000): the network's LAST conv (64 -> fl_oc <= 3 planar channels, no activation) inside this conv's epilogue -- see fused_last_epilogue
+    const f16* fl_w;         //   its weights as four MFMA A fragments [row tile 2][k-step 2][lane 64][8] (conv_pack_fuse_last)
+    const float* fl_bias;    //   fl_oc biases
+    float* fl_side;          //   per tile 192 x 3 partial sums of the pixels within one pixel of a tile edge (conv_fuse_combine finishes them)
+    void* fl_out;            //   the planar [N, fl_oc, H, W] result
+    int fl_oc, fl_out_f32;
     long in_lo_bytes;        // SPLIT kernels (TMF | 0x2000): the low-part twin of the input slab lies this many bytes behind it,
     long out_lo, res1_lo, res2_lo;   //   those of the output / residual slabs this many ELEMENTS behind them
 #ifdef INNFER_ABLATE
@@ -746,6 +753,125 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 #define PCT(var) do { } while (0)
 #define PCACC(slot, t1, t0) do { } while (0)
 #endif
+// FUSE (conv3x3_pc<.., TMF | 0x20000>): index of a pixel of a tile's 18 x 34 neighbourhood (Y in [-1, 16], X in [-1, 32]) that is NOT at least one pixel inside
+// the tile, among the 192 such pixels: rows -1, 0 (34 each), rows 15, 16 (34 each), then columns -1, 0, 31, 32 of rows 1 .. 14
+__host__ __device__ inline int fuse_ring_index(int Y, int X) {
+    if (Y <= 0) return (Y + 1) * 34 + X + 1;
+    if (Y >= 15) return 68 + (Y - 15) * 34 + X + 1;
+    return 136 + (Y - 1) * 4 + (X <= 0 ? X + 1 : X - 29);
+}
+constexpr int FUSE_RING = 192;
+constexpr int FUSE_PITCH = 516;          // floats between the product planes in LDS (512 pixels + 4: see fused_last_epilogue)
+
+// The fused last conv (see the FUSE flag of conv3x3_pc).  acc: this wave's 2 rows x 32 pixels x 64 channels (bias included); pl: the LDS stage the tile has
+// finished with (>= 64 KB); aw: the last conv's four A fragments in LDS; tile: the tile's index over the batch (n, ty, tx).
+template <int RPW, int NT>
+__device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT][2 * RPW], char* pl, const char* aw, int n, int ty0, int tx0, int cw, int lane, int tile) {
+    constexpr int MT = 2 * RPW;
+    const int li = lane & 15, lg = lane >> 4;
+    asm volatile("s_barrier" ::: "memory");                   // every consumer has read its last fragments of this stage: it may be overwritten
+    // (three phases with short live ranges -- the kernel's main loop already sits at the 168-register budget: the fp16 fragments of all four pixel tiles first
+    //  (the 64 accumulator registers die there), then one A fragment at a time against all of them, then the stores)
+    f16x8 hb[MT][2];                                        // channels 16 lg + 8 ks + e of pixel li: the values the unfused epilogue would have stored
+    // (the activation chosen ONCE: a uniform test per value is a branch per value in this unrolled code -- 128 of them cost more than the rest of the epilogue)
+    auto to_f16 = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = acc[2 * ks + (e >> 2)][m][e & 3];
+                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    FP32_VALUE(f);
+                    hb[m][ks][e] = (f16)f;
+                }
+    };
+    if (p.act == 1) to_f16(std::integral_constant<int, 1>{}); else if (p.act == 2) to_f16(std::integral_constant<int, 2>{}); else to_f16(std::integral_constant<int, 0>{});
+    f32x4 pa[2][MT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) pa[rt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 af = *(const f16x8*)(aw + ((rt * 2 + ks) * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) pa[rt][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, hb[m][ks], pa[rt][m], 0, 0, 0);
+        }
+    }
+    // 27 planes of 512 pixels, plane pitch 516 floats: a store instruction's 64 lanes (16 pixels x the 4 rows 4 lg + j) and a gather's 64 consecutive
+    // pixels of one plane fall into 64 different banks (pixel-major rows of 32 floats were a 32-way conflict)
+    char* const plw = pl + ((4 * lg) * FUSE_PITCH + cw * RPW * 32 + li) * 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (16 * rt + 4 * lg + j < 27) *(float*)(plw + ((16 * rt + j) * FUSE_PITCH + (m >> 1) * 32 + (m & 1) * 16) * 4) = pa[rt][m][j];
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");                   // the tile's products are in LDS
+    const long plane = (long)p.H * p.W;
+    for (int o = cw * 64 + lane; o < 18 * 34; o += 512) {
+        const int Y = o / 34 - 1, X = o - (Y + 1) * 34 - 1;
+        float S0 = 0.f, S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int y = Y + dy - 1, x = X + dx - 1;          // out(Y, X) += W[dy][dx] . hr(Y + dy - 1, X + dx - 1)
+                if (y >= 0 && y < 16 && x >= 0 && x < 32) {
+                    const float* q = (const float*)pl + (dy * 3 + dx) * 3 * FUSE_PITCH + y * 32 + x;
+                    S0 += q[0]; S1 += q[FUSE_PITCH]; S2 += q[2 * FUSE_PITCH];
+                }
+            }
+        if (Y >= 1 && Y <= 14 && X >= 1 && X <= 30) {            // complete: every hr pixel it reads lies in this tile
+            const long ob = (long)n * p.fl_oc * plane + (long)(ty0 + Y) * p.W + tx0 + X;
+            const float v[3] = {S0 + p.fl_bias[0], p.fl_oc > 1 ? S1 + p.fl_bias[1] : 0.f, p.fl_oc > 2 ? S2 + p.fl_bias[2] : 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < p.fl_oc) {
+                    if (p.fl_out_f32) ((float*)p.fl_out)[ob + c * plane] = v[c];
+                    else ((f16*)p.fl_out)[ob + c * plane] = (f16)v[c];
+                }
+        } else {
+            float* sd = p.fl_side + ((long)tile * FUSE_RING + fuse_ring_index(Y, X)) * 3;
+            sd[0] = S0; sd[1] = S1; sd[2] = S2;
+        }
+    }
+}
+
+// Finishes the rim pixels of the fused last conv: every pixel on the rim of a tile sums, in a fixed order, the partial sums of the tiles whose 18 x 34
+// neighbourhood contains it (its own and one to three neighbours), adds the bias and stores.  One thread per (tile, rim pixel): 92 per tile.
+__global__ void fuse_combine_kernel(const float* side, const float* bias, void* out, int out_f32, int oc, int N, int H, int W) {
+    const int tiles_x = W / 32, tiles_y = H / 16, per_img = tiles_x * tiles_y;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * per_img * 92) return;
+    const int tile = (int)(idx / 92), r = (int)(idx - (long)tile * 92);
+    int Y, X;
+    if (r < 32) { Y = 0; X = r; } else if (r < 64) { Y = 15; X = r - 32; } else { const int k = r - 64; Y = 1 + (k >> 1); X = (k & 1) ? 31 : 0; }
+    const int n = tile / per_img, t = tile - n * per_img, ty = t / tiles_x, tx = t - ty * tiles_x;
+    float S[3] = {bias[0], oc > 1 ? bias[1] : 0.f, oc > 2 ? bias[2] : 0.f};
+    for (int a = -1; a <= 1; ++a)
+        for (int b = -1; b <= 1; ++b) {
+            const int nty = ty + a, ntx = tx + b;
+            if (nty < 0 || nty >= tiles_y || ntx < 0 || ntx >= tiles_x) continue;
+            const int Yr = Y - 16 * a, Xr = X - 32 * b;
+            if (Yr < -1 || Yr > 16 || Xr < -1 || Xr > 32) continue;
+            const float* sd = side + ((long)(n * per_img + nty * tiles_x + ntx) * FUSE_RING + fuse_ring_index(Yr, Xr)) * 3;
+            S[0] += sd[0]; S[1] += sd[1]; S[2] += sd[2];
+        }
+    const long plane = (long)H * W, ob = (long)n * oc * plane + (long)(ty * 16 + Y) * W + tx * 32 + X;
+    for (int c = 0; c < oc; ++c) {
+        if (out_f32) ((float*)out)[ob + c * plane] = S[c];
+        else ((f16*)out)[ob + c * plane] = (f16)S[c];
+    }
+}
+
 // Partial statistics of a norm layer that follows the conv, out of the accumulators (fp32, bias included, before the fp16 rounding): every consumer
 // wave reduces its RPW x 32 pixels per channel to (count, mean, M2 = sum of squared deviations from that mean) -- in-lane over its pixel tiles,
 // a fixed xor butterfly over the 16 pixel lanes -- and writes them to
@@ -880,6 +1006,15 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // fragments as they come out of LDS.  LDS image: a halo row holds its even columns (0, 2, .. 32) then its odd ones (18-pixel halves of the 36-pixel
     // pitch), so that the stride-2 reads d0 / d2 (even[j], even[j+1]) and d1 / d3 (odd[j], odd[j+1]) are 16 consecutive pixels each: conflict free.
     constexpr bool WINO = (TMF & 0x4000) != 0;
+    // + 0x20000 (FUSE): HR_conv0 -> conv_last in one kernel (RRDBNet_arch.py:36-42: HR_conv0 = conv + LeakyReLU, conv_last = conv, both 3x3) without recomputing a
+    // halo.  The epilogue turns the tile's LeakyReLU'd result into the MFMA's B operand in registers (the k order of the last conv's panel is chosen so that a
+    // lane's sixteen accumulator channels ARE its two k-step fragments), multiplies it by the 27 x 64 matrix W_last[(c, dy, dx)][k] (16 MFMAs per wave), parks
+    // the 27 products per pixel in the LDS stage the tile has finished with (fp32, 64 KB), and every output pixel of the tile's 18 x 34 neighbourhood sums the
+    // nine that lie inside the tile.  Pixels at least one pixel inside the tile are complete (+ bias -> planar output); the 92 pixels on the tile's rim and the
+    // 100 just outside it get partial sums (fl_side), finished by conv_fuse_combine from the two to four tiles that meet there, in a fixed order.  The 4.25 GB
+    // HR slab of a 1080p -> 4K frame is neither written nor read.  Two more workgroup barriers on a tile's last chunk (loaders included).
+    constexpr bool FUSE = (TMF & 0x20000) != 0;
+    static_assert(!FUSE || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation");
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -1242,8 +1377,15 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         int jt = j0, c = 0;
         setup(jt);
         issue(0, 0);
+        if constexpr (FUSE) {                 // the last conv's four A fragments (4 KB) behind the two stages, once per workgroup
+#if defined(__HIP_DEVICE_COMPILE__)
+            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)p.fl_w, 0, 4096, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(smem + 2 * STAGE + lw * 1024), 16, lane * 16, lw * 1024, 0, 0);
+#endif
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
+        int cc = 0;                            // FUSE: the chunk the consumers work on in step g
         for (int g = 0; g < G; ++g) {
             PCT(l0);
             if (g + 1 < G) {
@@ -1255,6 +1397,13 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 if (lw == 0) { PCACC(3, l1, l0); PCACC(4, l2, l1); }
             }
             PCT(l3);
+            if constexpr (FUSE) {             // a tile's last chunk: the consumers' fused epilogue meets at two more barriers
+                if (++cc == p.nchunks) {
+                    cc = 0;
+                    asm volatile("s_barrier" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                }
+            }
             asm volatile("s_barrier" ::: "memory");
             PCT(l4);
             if (lw == 0) PCACC(5, l4, l3);
@@ -1557,6 +1706,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
             }
 #undef EPI
+            } else if constexpr (FUSE) {
+                const int lidf = run_start + (p.rev ? run_len - 1 - (jt - slots) : (jt - slots));         // (jt was advanced above; KG == 1: the tile index)
+                fused_last_epilogue<RPW, NT>(p, acc, smem + ((g & 1) * STAGE), smem + 2 * STAGE, n, ty0, tx0, cw, lane, lidf);
             } else if constexpr (OUTMODE == OUT_SLAB) {
             if constexpr (STATS) {
                 const int lid = run_start + (p.rev ? run_len - 1 - (jt - slots) : (jt - slots));         // (jt was advanced above)
@@ -1797,7 +1949,7 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI, int NCW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = NCW * RPW;
-    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64);
+    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
     if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
@@ -2046,6 +2198,29 @@ void conv_pack7v(const float* w, int K, int C, void* packed) {
 
 // partial-statistics records (3 floats each per channel) an image contributes with ConvLaunch.stats_part: tiles of 16 x 32 pixels over the kernel's
 // H x W grid (the INPUT grid behind the phase lattice, which has four phases per tile), 8 consumer waves per tile
+// The fused last conv (ConvLaunch.fuse_w): what the launch must look like, the panel of the last conv and the bytes of the rim buffer.
+bool conv_fuse_last_ok(const ConvLaunch& L) {
+    return L.K == 64 && L.C % 32 == 0 && L.out_mode == OUT_SLAB && !L.res1 && !L.res2 && !L.up && !L.reflect && L.dilation <= 1 && !L.dilation_groups && !L.split && !L.wino &&
+           !L.stats_part && !L.conv1x1 && !L.stride2 && !L.deconv_phases && !L.conv7 && !L.conv7v && !L.prefix_lrelu && !L.pair_wpk && L.act >= 0 && L.act <= 2 && L.y0 == 0 && L.y1 == L.H &&
+           L.H % 16 == 0 && L.W % 32 == 0 && L.fuse_oc >= 1 && L.fuse_oc <= 3 && L.fuse_bias && L.fuse_side && L.fuse_out &&
+           (long)L.N * (L.H / 16) * (L.W / 32) * 92 < 0x7fffffffL;
+}
+size_t conv_fuse_side_bytes(int N, int H, int W) { return (size_t)N * (H / 16) * (W / 32) * FUSE_RING * 3 * sizeof(float); }
+// w_last [oc][64][3][3] -> four MFMA A fragments [row tile rt][k-step ks][lane][8]: row 16 rt + (lane & 15) = tap * 3 + c (27 of 32 rows), k-slot 8 (lane >> 4) + e of
+// step ks = input channel 16 (lane >> 4) + 8 ks + e -- the order in which a consumer lane of conv3x3_pc<2,4,..> holds its sixteen accumulator channels
+void conv_pack_fuse_last(const float* w, int oc, void* packed) {
+    f16* o = (f16*)packed;
+    for (int rt = 0; rt < 2; ++rt)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = 16 * rt + (lane & 15), tap = row / 3, c = row - 3 * tap, ch = 16 * (lane >> 4) + 8 * ks + e;
+                    float v = 0.f;
+                    if (tap < 9 && c < oc) v = w[((size_t)c * 64 + ch) * 9 + tap];
+                    o[((rt * 2 + ks) * 64 + lane) * 8 + e] = (f16)v;
+                }
+}
+
 int conv_stats_nper(int H, int W, int phases) { return ((H + 15) / 16) * ((W + TW - 1) / TW) * phases * 8; }
 
 size_t conv_packed_bytes7x7(int K, int C) { return conv_packed_bytes(K, 9 * C); }
@@ -2219,6 +2394,16 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         if (pc == 5) return launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 3>(k, L.N, s);
         if (INNFER_KNOB("INNFER_FAT", 0) & 1) return launch_pc<6, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);
         return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
+    }
+    if (L.fuse_w) {          // HR_conv0 with the network's last conv in its epilogue (conv3x3_pc<.., TMF | 0x20000>) + the rim pass
+        if (!conv_fuse_last_ok(L)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the fused last conv needs 64 -> 64 channels, whole 16 x 32 tiles, act 0..2, no residual / upsampling / row range");
+        k.fl_w = L.fuse_w; k.fl_bias = L.fuse_bias; k.fl_side = L.fuse_side; k.fl_out = L.fuse_out; k.fl_oc = L.fuse_oc; k.fl_out_f32 = L.fuse_out_f32;
+        if (int rc = launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x201FF>(k, L.N, s)) return rc;
+        const long nthr = (long)L.N * (L.H / 16) * (L.W / 32) * 92;
+        hipLaunchKernelGGL(fuse_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)L.fuse_side, L.fuse_bias, L.fuse_out, L.fuse_out_f32, L.fuse_oc,
+                           L.N, L.H, L.W);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 4 && L.stats_part) return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x11FF>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4) {

@@ -87,6 +87,7 @@ struct ConvSlot {
     void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
     std::vector<float> h_w;      // MFMA convs: the fp32 weights as they were set, kept for the fp32-accurate mode's panels
     void* d_w32 = nullptr;       //   (hi | lo | hi) panels of conv_pack_split, built on the first forward in that mode
+    void* d_fuse = nullptr;      // a last conv of 64 -> <= 3 channels: its panel for the epilogue of HR_conv0 (conv_pack_fuse_last), built with d_w
     float* d_b = nullptr;        // bias padded to the panel width
     bool loaded = false;
     // mode 'NAC' conv blocks (block.py:246-254: norm -> act -> conv): the conv reads act(alpha[c] * x + shift[c]); an elementwise pass in front of it
@@ -106,6 +107,7 @@ struct innfer_net {
     float res_scale = 1.f;       // SRResNet: x + res * res_scale (SRResNet_arch.py:88-91)
     int outm = 0;                // `outm` of RRDBNet / SRResNet.forward (RRDBNet_arch.py:50-62): 0 none, 1 scaltanh, 2 tanh, 3 sigmoid, 4 clamp
     int u8_normalize = 0, u8_round16 = 1;   // innfer_net_forward with INNFER_U8 images: normalize / denormalize flags of np2tensor / tensor2np, fp16 mode
+    int fused_tail = 1;          // HR_conv0 -> conv_last as one kernel where the shapes allow it (innfer_net_set_fused_tail)
     int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
     int fp32 = 0;                // innfer_net_set_precision: 1 = fp32-accurate forward on split operands (conv3x3.hip SPLIT), the reference's -no_fp16 mode (run.py:345,421-422)
@@ -224,6 +226,7 @@ extern "C" void innfer_net_destroy(innfer_net_t net) {
         if (c.d_w) (void)hipFree(c.d_w);
         if (c.d_b) (void)hipFree(c.d_b);
         if (c.d_w32) (void)hipFree(c.d_w32);
+        if (c.d_fuse) (void)hipFree(c.d_fuse);
         if (c.d_map) (void)hipFree(c.d_map);
     }
     delete net;
@@ -265,6 +268,12 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
         bias_n = (size_t)((c.K + per - 1) / per) * per;
         c.h_w.assign(w, w + (size_t)c.K * c.C * c.ksize * c.ksize);
         if (c.d_w32) { (void)hipFree(c.d_w32); c.d_w32 = nullptr; }
+        if (c.ksize == 3 && c.C == 64 && c.K <= 3) {          // (only the network's last conv has this shape)
+            std::vector<char> fp(4096);
+            conv_pack_fuse_last(w, c.K, fp.data());
+            if (!c.d_fuse) INNFER_HIP(hipMalloc(&c.d_fuse, fp.size()));
+            INNFER_HIP(hipMemcpy(c.d_fuse, fp.data(), fp.size(), hipMemcpyHostToDevice));
+        }
     }
     std::vector<float> bias(bias_n, 0.f);
     if (b) for (int k = 0; k < c.K; ++k) bias[k] = b[k];
@@ -306,6 +315,12 @@ extern "C" int innfer_net_set_precision(innfer_net_t net, int fp32) {
 extern "C" int innfer_net_set_band_rows(innfer_net_t net, int rows) {
     if (!net || rows < 0) return set_error(INNFER_ERR_INVALID, "set_band_rows: bad arguments");
     net->band_rows = rows;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_set_fused_tail(innfer_net_t net, int on) {
+    if (!net) return set_error(INNFER_ERR_INVALID, "set_fused_tail: null network");
+    net->fused_tail = on ? 1 : 0;
     return INNFER_OK;
 }
 
@@ -467,6 +482,10 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
     const double obytes = L.out_mode == OUT_NCHW ? (L.out_u8 ? 1.0 : L.out_f32 ? 4.0 : 2.0) : 2.0;
     const double bytes = px * (L.C * 2.0 / (L.up ? 4.0 : 1.0) + L.K * obytes + (L.res1 ? L.K * 2.0 : 0.0) + (L.res2 ? L.K * 2.0 : 0.0))
                          + (double)taps * L.K * L.C * 2.0;
+    if (L.fuse_w) {      // HR_conv0 + conv_last as one launch (+ the rim pass): both convs' FLOPs; bytes: C channels in, the planar result out, both weight sets
+        const double ob = L.fuse_out_f32 ? 4.0 : 2.0;
+        return timed_end(s, 2.0 * 9.0 * (L.K * (double)L.C + 64.0 * L.fuse_oc) * px, px * (L.C * 2.0 + L.fuse_oc * ob) + 9.0 * (L.K * L.C + 64.0 * L.fuse_oc) * 2.0, 16 * conv_nt_for(L.K) + L.out_mode);
+    }
     // (fp32-accurate mode: the same algorithmic FLOPs -- executed: 3x --, two slabs per tensor, three panels per weight)
     return timed_end(s, 2.0 * taps * L.K * L.C * px, L.split ? 2.0 * bytes + (double)taps * L.K * L.C * 2.0 : bytes, 16 * conv_nt_for(L.K) + L.out_mode + (L.split ? 1000 : 0));
 }
@@ -797,10 +816,27 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         if (rc) return rc;
         t = dst; h *= 2; w *= 2;
     }
+#ifndef INNFER_FUSE_LAST
+#define INNFER_FUSE_LAST 1
+#endif
     {
         const ConvSlot& cs = net->convs[ci++];
         const long gh = (long)N * h * w * 32;
         ConvLaunch L = mk(cs, t, gh, ws + cv.hr, gh, N, h, w, net->trunk_act);
+        // HR_conv0 -> conv_last in one kernel (conv3x3.hip, FUSE) where the shapes allow it: fp16 engine, 64 features, <= 3 planar float outputs without final
+        // activation / outm, whole 16 x 32 tiles.  The rim buffer lives where the HR slab would have been.
+        const ConvSlot& cl = net->convs[ci];
+        if (INNFER_FUSE_LAST && net->fused_tail && !net->fp32 && !any_map && net->band_rows == 0 && cl.d_fuse && cl.loaded && net->final_act == 0 && net->outm == 0 &&
+            (out_dtype == INNFER_F16 || out_dtype == INNFER_F32) && conv_fuse_side_bytes(N, h, w) <= (size_t)gh * 2 * (net->nf / 32)) {
+            L.fuse_w = (const f16*)cl.d_fuse; L.fuse_bias = cl.d_b; L.fuse_side = (float*)(ws + cv.hr); L.fuse_out = d_out; L.fuse_oc = cl.K;
+            L.fuse_out_f32 = out_dtype == INNFER_F32;
+            if (conv_fuse_last_ok(L)) {
+                rc = do_conv(L, s);
+                if (rc) return rc;
+                return INNFER_OK;
+            }
+            L.fuse_w = nullptr;
+        }
         rc = do_conv(L, s);
         if (rc) return rc;
     }

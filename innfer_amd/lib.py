@@ -84,6 +84,7 @@ SIGNATURES = {
     "innfer_slab_split_to_nchw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_net_set_fused_tail": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -189,7 +190,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 106          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 107          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

@@ -1813,6 +1813,54 @@ def test_model_chop_pan_vs_oracle(dev, tmp_path):
     assert err.max().item() < 1e-2 and err.mean().item() < 1.5e-3, (err.max().item(), err.mean().item())
 
 
+def _assert_same_to_the_last_rounding(a, b, what=""):
+    """Two fp16 results whose fp32 values were summed in a different order: equal up to one unit in the last place of the larger magnitude -- or, where
+    the sum cancels to almost nothing, up to the fp32 noise of adding 576 products in another order (4e-6) -- and on all but a few per cent of the values
+    bit for bit."""
+    af, bf = a.float(), b.float()
+    d = (af - bf).abs()
+    mag = torch.maximum(af.abs(), bf.abs()).clamp_min(2.0 ** -14)
+    ulp = torch.exp2(torch.floor(torch.log2(mag)) - 10).clamp_min(4e-6)
+    assert bool((d <= ulp * 1.001).all()), (what, (d / ulp).max().item())
+    assert (d > 0).float().mean().item() < 0.05, (what, (d > 0).float().mean().item())
+
+
+def test_fused_tail_vs_two_launches_and_oracle(dev):
+    """HR_conv0 -> conv_last as one kernel (conv3x3_pc<.., TMF | 0x20000>, innfer_net_set_fused_tail, the default) against the two-launch schedule and the
+    oracle: HR frames of 1 x 1 ... 4 x 3 tiles of 16 x 32 pixels (tiles with neighbours on every side, rims on the frame border), batches, a scale-2
+    net, ReLU features, one grey output channel, fp32 output tensors; frames that are NOT whole tiles take the two launches and must be bit-identical
+    with the knob on or off."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    cases = [(4, 3, "leakyrelu", (1, 3, 4, 8)), (4, 3, "leakyrelu", (1, 3, 12, 24)), (4, 3, "leakyrelu", (3, 3, 16, 24)), (2, 3, "leakyrelu", (2, 3, 24, 32)),
+             (4, 3, "relu", (1, 3, 8, 16)), (4, 1, "leakyrelu", (2, 1, 12, 16)), (4, 3, "leakyrelu", (1, 3, 200, 200))]
+    for i, (scale, nc, act, shape) in enumerate(cases):
+        shapes = synth.rrdbnet_shapes(nb=1, scale=scale, in_nc=nc, out_nc=nc) if nc != 3 else synth.rrdbnet_shapes(nb=1, scale=scale)
+        sd = _sd(shapes, 70 + i)
+        net = RRDBNet(nc, nc, 64, 1, upscale=scale, act_type=act)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform(shape, 700 + i)).to(dev).half()
+        yf = net(x)
+        net.fused_tail = False
+        y2 = net(x)
+        _assert_same_to_the_last_rounding(yf, y2, ("fused vs two launches", scale, nc, act, shape))
+        net.fused_tail = True
+        if i in (1, 2, 5):
+            with torch.no_grad():
+                ref = oracle.rrdbnet_forward(sd, x.float().cpu(), nb=1, scale=scale) if act == "leakyrelu" and nc == 3 else None
+            if ref is not None:
+                e = (yf.float().cpu() - ref).abs()
+                assert e.max().item() < 1e-2 and e.mean().item() < 1e-3, (shape, e.max().item(), e.mean().item())
+    # not whole tiles (HR 40 x 72): the knob changes nothing
+    net, _ = _rrdb(dev, 1, 4)
+    x = torch.from_numpy(synth.uniform((2, 3, 10, 18), 9)).to(dev).half()
+    ya = net(x)
+    net.fused_tail = False
+    assert torch.equal(ya, net(x))
+
+
 def test_full_frame_1080p_translation_property(dev):
     """BASELINE config 2 size (1x3x1080x1920 -> 1x3x4320x7680, RRDBNet-23 4x fp16): an
     interior window of the full-frame result equals the forward of a crop that
@@ -1821,7 +1869,11 @@ def test_full_frame_1080p_translation_property(dev):
     from innfer_amd import synth
     net, sd = _rrdb(dev, 23, 4)
     x = torch.from_numpy(synth.uniform((1, 3, 1080, 1920), 31)).to(dev).half()
+    yf = net(x)                       # HR_conv0 -> conv_last fused (the default; 4320 x 7680 is whole 16 x 32 tiles)
+    net.fused_tail = False            # the bit-for-bit properties below belong to the two-launch schedule: the fused tail sums a rim pixel in another order
     y = net(x)
+    _assert_same_to_the_last_rounding(yf, y, "fused tail vs two launches, 1080p frame")
+    del yf
     assert tuple(y.shape) == (1, 3, 4320, 7680)
     assert torch.isfinite(y).all()
     R = 23 * 15 + 6                                   # 3x3 convs on the LR grid: 1 + 345 + 1 (+2 HR-side, <1 LR px each)
@@ -1834,6 +1886,7 @@ def test_full_frame_1080p_translation_property(dev):
     net.band_rows = 128
     assert torch.equal(net(x), y)
     net.band_rows = 0
+    net.fused_tail = True
     # ... and the VALUES of that window against the oracle (fp32, host CPU) run on the same 734 x 734 crop -- the crop holds the window's whole
     # receptive field, so the oracle's window IS the reference's value for the full frame (run.py:217-219, RRDBNet_arch.py:50-51).  SURVEY 8c:
     # fp16 engine <= 1e-2 and >= 99 % of the uint8 codes within +-1; fp32-accurate engine (a float32 frame: 24 GB of slab pairs) <= 1e-4.
@@ -1918,7 +1971,12 @@ def test_4k_input_untiled_addresses_beyond_2gib(dev):
     net, _ = _rrdb(dev, 1, 4)
     H, W = 2160, 3840
     x = torch.from_numpy(synth.uniform((1, 3, H, W), 77)).to(dev).half()
+    yf = net(x)                       # fused tail: 64 800 x 4 tiles, rim buffer and planar stores beyond 2 GiB as well
+    net.fused_tail = False
     y = net(x)
+    _assert_same_to_the_last_rounding(yf[:, :, -512:, -512:], y[:, :, -512:, -512:], "fused tail vs two launches, corner of the 4K frame")
+    _assert_same_to_the_last_rounding(yf[:, :, :512, :512], y[:, :, :512, :512], "fused tail vs two launches, origin of the 4K frame")
+    del yf
     assert tuple(y.shape) == (1, 3, 4 * H, 4 * W) and torch.isfinite(y[:, :, -64:, -64:]).all()
     R, hw = 1 * 15 + 6, 24
     y0, x0 = H - hw - R, W - hw - R
