@@ -145,7 +145,7 @@ int innfer_net_set_pair_convs(innfer_net_t net, int mode);
 /* Scheduling knob: the last two convs of RRDBNet / SRResNet (HR_conv0 -> LeakyReLU -> conv_last, RRDBNet_arch.py:36-42) as ONE kernel -- the last conv
  * runs in the epilogue of HR_conv0 on the tile that kernel has just produced (csrc/conv3x3.hip, FUSE: no halo recompute; the pixels within one pixel
  * of a tile edge are finished by a small second pass), and the HR feature slab (4.25 GB for a 1080p -> 4K frame) is neither written nor read.
- * 1 (default) = fused wherever the shapes allow it: fp16 engine, 64 features, <= 3 planar fp16 / fp32 outputs, no final activation / outm, HR frame of whole
+ * 1 (default) = fused wherever the shapes allow it: fp16 engine, 64 features, <= 3 output channels (planar fp16 / fp32 or the uint8 image), no final activation / outm, HR frame of whole
  * 16 x 32 tiles, no row bands; every other case runs the two launches.  0 = always two launches.  The fused form adds the last conv's 576 products of
  * an output in a different order (fp32 either way): results agree to the last rounding of the fp16 output, not bit for bit.  (107) */
 int innfer_net_set_fused_tail(innfer_net_t net, int on);

@@ -181,6 +181,7 @@ class EngineModule(nn.Module):
             self._weights_device = img.device
             L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
             L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
+            L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
             L.check(L.lib.innfer_net_set_u8_io(self._handle, int(bool(normalize)), int(bool(fp16))))
             L.check(L.lib.innfer_net_set_precision(self._handle, int(not fp16)))
             L.check(L.lib.innfer_net_set_outm(self._handle, 0))

@@ -85,7 +85,7 @@ struct ConvLaunch {
                                                   // 2: ReplicationPad2d(1) (3x3 slab convs)
     // HR_conv0 -> conv_last fused (conv3x3_pc<.., TMF | 0x20000>): this conv (64 -> 64, slab semantics, `out` unused) carries the network's last conv in its epilogue
     const f16* fuse_w;                            //   conv_pack_fuse_last() panel of the last conv (4 KB, device), nullptr = not fused
-    const float* fuse_bias; float* fuse_side; void* fuse_out; int fuse_oc, fuse_out_f32;   // its bias, the rim buffer (conv_fuse_side_bytes), the planar result
+    const float* fuse_bias; float* fuse_side; void* fuse_out; int fuse_oc, fuse_out_mode;  // its bias, the rim buffer (conv_fuse_side_bytes), the result: 0 fp16 / 1 fp32 planar, 2 the uint8 HWC image (out_denorm, out_round16)
     int phase_c;                                  // OUT_NCHW: K = 4*phase_c channels are the 4 output phases of a stride-2 transposed conv (unet.hip)
     int outm;                                     // OUT_NCHW: `outm` of RRDBNet / SRResNet.forward applied after `act`: 1 (tanh + 1) / 2, 2 tanh, 3 sigmoid, 4 clamp(0, 1)
     int out_u8, out_denorm, out_round16;          // OUT_NCHW with <= 4 channels: write a uint8 HWC BGR(A) image instead -- tensor2np as the conv's epilogue

@@ -133,7 +133,7 @@ struct KP {
     const float* fl_bias;    //   fl_oc biases
     float* fl_side;          //   per tile 192 x 3 partial sums of the pixels within one pixel of a tile edge (conv_fuse_combine finishes them)
     void* fl_out;            //   the planar [N, fl_oc, H, W] result
-    int fl_oc, fl_out_f32;
+    int fl_oc, fl_out_mode;  //   0 fp16, 1 fp32 planar; 2 the uint8 HWC image (out_denorm / out_round16 as for the planar kernels)
     long in_lo_bytes;        // SPLIT kernels (TMF | 0x2000): the low-part twin of the input slab lies this many bytes behind it,
     long out_lo, res1_lo, res2_lo;   //   those of the output / residual slabs this many ELEMENTS behind them
 #ifdef INNFER_ABLATE
@@ -763,6 +763,30 @@ __host__ __device__ inline int fuse_ring_index(int Y, int X) {
 constexpr int FUSE_RING = 192;
 constexpr int FUSE_PITCH = 516;          // floats between the product planes in LDS (512 pixels + 4: see fused_last_epilogue)
 
+// One finished pixel of the fused last conv: planar fp16 / fp32 [N, oc, H, W] (mode 0 / 1), or the uint8 HWC BGR image of tensor2np (mode 2: the conversion of
+// the planar kernel's uint8 epilogue, value for value -- utils.py:197-248)
+__device__ __forceinline__ void fuse_store_pixel(void* out, int mode, int denorm, int round16, int oc, long n, int H, int W, int y, int x, const float (&v)[3]) {
+    if (mode == 2) {
+        uint8_t* o = (uint8_t*)out + ((n * H + y) * W + x) * oc;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c < oc) {
+                float t = round16 ? (float)(f16)v[c] : v[c];
+                if (denorm) t = fminf(fmaxf(__fdiv_rn(__fsub_rn(t, -1.0f), 2.0f), 0.0f), 1.0f);
+                t = fminf(fmaxf(__fmul_rn(255.0f, t), 0.0f), 255.0f);
+                o[oc == 3 ? 2 - c : c] = (uint8_t)__float2int_rn(t);
+            }
+        return;
+    }
+    const long plane = (long)H * W, ob = n * oc * plane + (long)y * W + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (c < oc) {
+            if (mode == 1) ((float*)out)[ob + c * plane] = v[c];
+            else ((f16*)out)[ob + c * plane] = (f16)v[c];
+        }
+}
+
 // The fused last conv (see the FUSE flag of conv3x3_pc).  acc: this wave's 2 rows x 32 pixels x 64 channels (bias included); pl: the LDS stage the tile has
 // finished with (>= 64 KB); aw: the last conv's four A fragments in LDS; tile: the tile's index over the batch (n, ty, tx).
 template <int RPW, int NT>
@@ -815,7 +839,6 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");                   // the tile's products are in LDS
-    const long plane = (long)p.H * p.W;
     for (int o = cw * 64 + lane; o < 18 * 34; o += 512) {
         const int Y = o / 34 - 1, X = o - (Y + 1) * 34 - 1;
         float S0 = 0.f, S1 = 0.f, S2 = 0.f;
@@ -830,14 +853,8 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
                 }
             }
         if (Y >= 1 && Y <= 14 && X >= 1 && X <= 30) {            // complete: every hr pixel it reads lies in this tile
-            const long ob = (long)n * p.fl_oc * plane + (long)(ty0 + Y) * p.W + tx0 + X;
             const float v[3] = {S0 + p.fl_bias[0], p.fl_oc > 1 ? S1 + p.fl_bias[1] : 0.f, p.fl_oc > 2 ? S2 + p.fl_bias[2] : 0.f};
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (c < p.fl_oc) {
-                    if (p.fl_out_f32) ((float*)p.fl_out)[ob + c * plane] = v[c];
-                    else ((f16*)p.fl_out)[ob + c * plane] = (f16)v[c];
-                }
+            fuse_store_pixel(p.fl_out, p.fl_out_mode, p.out_denorm, p.out_round16, p.fl_oc, n, p.H, p.W, ty0 + Y, tx0 + X, v);
         } else {
             float* sd = p.fl_side + ((long)tile * FUSE_RING + fuse_ring_index(Y, X)) * 3;
             sd[0] = S0; sd[1] = S1; sd[2] = S2;
@@ -847,7 +864,7 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
 
 // Finishes the rim pixels of the fused last conv: every pixel on the rim of a tile sums, in a fixed order, the partial sums of the tiles whose 18 x 34
 // neighbourhood contains it (its own and one to three neighbours), adds the bias and stores.  One thread per (tile, rim pixel): 92 per tile.
-__global__ void fuse_combine_kernel(const float* side, const float* bias, void* out, int out_f32, int oc, int N, int H, int W) {
+__global__ void fuse_combine_kernel(const float* side, const float* bias, void* out, int mode, int denorm, int round16, int oc, int N, int H, int W) {
     const int tiles_x = W / 32, tiles_y = H / 16, per_img = tiles_x * tiles_y;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)N * per_img * 92) return;
@@ -865,11 +882,7 @@ __global__ void fuse_combine_kernel(const float* side, const float* bias, void* 
             const float* sd = side + ((long)(n * per_img + nty * tiles_x + ntx) * FUSE_RING + fuse_ring_index(Yr, Xr)) * 3;
             S[0] += sd[0]; S[1] += sd[1]; S[2] += sd[2];
         }
-    const long plane = (long)H * W, ob = (long)n * oc * plane + (long)(ty * 16 + Y) * W + tx * 32 + X;
-    for (int c = 0; c < oc; ++c) {
-        if (out_f32) ((float*)out)[ob + c * plane] = S[c];
-        else ((f16*)out)[ob + c * plane] = (f16)S[c];
-    }
+    fuse_store_pixel(out, mode, denorm, round16, oc, n, H, W, ty * 16 + Y, tx * 32 + X, S);
 }
 
 // Partial statistics of a norm layer that follows the conv, out of the accumulators (fp32, bias included, before the fp16 rounding): every consumer
@@ -2397,10 +2410,10 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     }
     if (L.fuse_w) {          // HR_conv0 with the network's last conv in its epilogue (conv3x3_pc<.., TMF | 0x20000>) + the rim pass
         if (!conv_fuse_last_ok(L)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the fused last conv needs 64 -> 64 channels, whole 16 x 32 tiles, act 0..2, no residual / upsampling / row range");
-        k.fl_w = L.fuse_w; k.fl_bias = L.fuse_bias; k.fl_side = L.fuse_side; k.fl_out = L.fuse_out; k.fl_oc = L.fuse_oc; k.fl_out_f32 = L.fuse_out_f32;
+        k.fl_w = L.fuse_w; k.fl_bias = L.fuse_bias; k.fl_side = L.fuse_side; k.fl_out = L.fuse_out; k.fl_oc = L.fuse_oc; k.fl_out_mode = L.fuse_out_mode;
         if (int rc = launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x201FF>(k, L.N, s)) return rc;
         const long nthr = (long)L.N * (L.H / 16) * (L.W / 32) * 92;
-        hipLaunchKernelGGL(fuse_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)L.fuse_side, L.fuse_bias, L.fuse_out, L.fuse_out_f32, L.fuse_oc,
+        hipLaunchKernelGGL(fuse_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)L.fuse_side, L.fuse_bias, L.fuse_out, L.fuse_out_mode, L.out_denorm, L.out_round16, L.fuse_oc,
                            L.N, L.H, L.W);
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;

@@ -483,7 +483,7 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
     const double bytes = px * (L.C * 2.0 / (L.up ? 4.0 : 1.0) + L.K * obytes + (L.res1 ? L.K * 2.0 : 0.0) + (L.res2 ? L.K * 2.0 : 0.0))
                          + (double)taps * L.K * L.C * 2.0;
     if (L.fuse_w) {      // HR_conv0 + conv_last as one launch (+ the rim pass): both convs' FLOPs; bytes: C channels in, the planar result out, both weight sets
-        const double ob = L.fuse_out_f32 ? 4.0 : 2.0;
+        const double ob = L.fuse_out_mode == 2 ? 1.0 : L.fuse_out_mode == 1 ? 4.0 : 2.0;
         return timed_end(s, 2.0 * 9.0 * (L.K * (double)L.C + 64.0 * L.fuse_oc) * px, px * (L.C * 2.0 + L.fuse_oc * ob) + 9.0 * (L.K * L.C + 64.0 * L.fuse_oc) * 2.0, 16 * conv_nt_for(L.K) + L.out_mode);
     }
     // (fp32-accurate mode: the same algorithmic FLOPs -- executed: 3x --, two slabs per tensor, three panels per weight)
@@ -827,9 +827,10 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         // activation / outm, whole 16 x 32 tiles.  The rim buffer lives where the HR slab would have been.
         const ConvSlot& cl = net->convs[ci];
         if (INNFER_FUSE_LAST && net->fused_tail && !net->fp32 && !any_map && net->band_rows == 0 && cl.d_fuse && cl.loaded && net->final_act == 0 && net->outm == 0 &&
-            (out_dtype == INNFER_F16 || out_dtype == INNFER_F32) && conv_fuse_side_bytes(N, h, w) <= (size_t)gh * 2 * (net->nf / 32)) {
+            (out_dtype == INNFER_F16 || out_dtype == INNFER_F32 || out_dtype == INNFER_U8) && conv_fuse_side_bytes(N, h, w) <= (size_t)gh * 2 * (net->nf / 32)) {
             L.fuse_w = (const f16*)cl.d_fuse; L.fuse_bias = cl.d_b; L.fuse_side = (float*)(ws + cv.hr); L.fuse_out = d_out; L.fuse_oc = cl.K;
-            L.fuse_out_f32 = out_dtype == INNFER_F32;
+            L.fuse_out_mode = out_dtype == INNFER_U8 ? 2 : out_dtype == INNFER_F32 ? 1 : 0;
+            L.out_denorm = net->u8_normalize; L.out_round16 = net->u8_round16;     // (uint8: tensor2np as the store, as in the two-launch form)
             if (conv_fuse_last_ok(L)) {
                 rc = do_conv(L, s);
                 if (rc) return rc;

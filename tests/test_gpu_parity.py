@@ -1853,6 +1853,20 @@ def test_fused_tail_vs_two_launches_and_oracle(dev):
             if ref is not None:
                 e = (yf.float().cpu() - ref).abs()
                 assert e.max().item() < 1e-2 and e.mean().item() < 1e-3, (shape, e.max().item(), e.mean().item())
+    # the uint8 image form (forward_u8: np2tensor in the first conv, tensor2np as the fused tail's store): exactly tensor2np of the tensor forward with the
+    # fused tail on both sides (same sums, the fp16 rounding emulated in front of the uint8 conversion), and within one code of the two-launch form
+    from innfer_amd.utils import utils as U
+    net, _ = _rrdb(dev, 1, 4)
+    for normalize in (False, True):
+        img = torch.from_numpy(synth.image_u8(16, 24, 3, 5)).to(dev)
+        got = net.forward_u8(img, normalize=normalize)
+        want = U.tensor2np(net(U.np2tensor(img.cpu().numpy(), normalize=normalize, dtype=torch.float16).to(dev)), denormalize=normalize)
+        assert np.array_equal(got.cpu().numpy(), want), normalize
+        net.fused_tail = False
+        two = net.forward_u8(img, normalize=normalize)
+        net.fused_tail = True
+        dd = (got.int() - two.int()).abs()
+        assert dd.max().item() <= 1 and (dd > 0).float().mean().item() < 0.005, (normalize, dd.max().item(), (dd > 0).float().mean().item())
     # not whole tiles (HR 40 x 72): the knob changes nothing
     net, _ = _rrdb(dev, 1, 4)
     x = torch.from_numpy(synth.uniform((2, 3, 10, 18), 9)).to(dev).half()
