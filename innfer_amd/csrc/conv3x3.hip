@@ -839,19 +839,23 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");                   // the tile's products are in LDS
-    for (int o = cw * 64 + lane; o < 18 * 34; o += 512) {
-        const int Y = o / 34 - 1, X = o - (Y + 1) * 34 - 1;
+    // Every lane sums its OWN pixel of the tile (512 lanes, 512 pixels: no division, the row tests are uniform but for the first / last wave) ...
+    {
+        const int Y = cw * RPW + (lane >> 5), X = lane & 31;
+        const float* q0 = (const float*)pl + Y * 32 + X;
         float S0 = 0.f, S1 = 0.f, S2 = 0.f;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy) {
+            const bool ry = dy == 0 ? Y > 0 : (dy == 2 ? Y < 15 : true);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int y = Y + dy - 1, x = X + dx - 1;          // out(Y, X) += W[dy][dx] . hr(Y + dy - 1, X + dx - 1)
-                if (y >= 0 && y < 16 && x >= 0 && x < 32) {
-                    const float* q = (const float*)pl + (dy * 3 + dx) * 3 * FUSE_PITCH + y * 32 + x;
+                const bool cx = dx == 0 ? X > 0 : (dx == 2 ? X < 31 : true);
+                if (ry && cx) {                                   // out(Y, X) += W[dy][dx] . hr(Y + dy - 1, X + dx - 1)
+                    const float* q = q0 + (dy * 3 + dx) * 3 * FUSE_PITCH + (dy - 1) * 32 + (dx - 1);
                     S0 += q[0]; S1 += q[FUSE_PITCH]; S2 += q[2 * FUSE_PITCH];
                 }
             }
+        }
         if (Y >= 1 && Y <= 14 && X >= 1 && X <= 30) {            // complete: every hr pixel it reads lies in this tile
             const float v[3] = {S0 + p.fl_bias[0], p.fl_oc > 1 ? S1 + p.fl_bias[1] : 0.f, p.fl_oc > 2 ? S2 + p.fl_bias[2] : 0.f};
             fuse_store_pixel(p.fl_out, p.fl_out_mode, p.out_denorm, p.out_round16, p.fl_oc, n, p.H, p.W, ty0 + Y, tx0 + X, v);
@@ -859,6 +863,25 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
             float* sd = p.fl_side + ((long)tile * FUSE_RING + fuse_ring_index(Y, X)) * 3;
             sd[0] = S0; sd[1] = S1; sd[2] = S2;
         }
+    }
+    // ... and the first hundred lanes one of the 100 pixels just outside it (rows -1 and 16, columns -1 and 32), which only the tile's edge pixels reach
+    const int o = cw * 64 + lane;
+    if (o < 100) {
+        int Y, X;
+        if (o < 34) { Y = -1; X = o - 1; } else if (o < 68) { Y = 16; X = o - 35; } else { Y = (o - 68) >> 1; X = ((o - 68) & 1) ? 32 : -1; }
+        float S0 = 0.f, S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int y = Y + dy - 1, x = X + dx - 1;
+                if (y >= 0 && y < 16 && x >= 0 && x < 32) {
+                    const float* q = (const float*)pl + (dy * 3 + dx) * 3 * FUSE_PITCH + y * 32 + x;
+                    S0 += q[0]; S1 += q[FUSE_PITCH]; S2 += q[2 * FUSE_PITCH];
+                }
+            }
+        float* sd = p.fl_side + ((long)tile * FUSE_RING + fuse_ring_index(Y, X)) * 3;
+        sd[0] = S0; sd[1] = S1; sd[2] = S2;
     }
 }
 
