@@ -423,6 +423,8 @@ def main():
     ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch (0 = innfer_amd.parallel.tile_batches: evenly sized launches of <= 272 tiles)")
     ap.add_argument("--sharded-steps", type=int, default=2, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip")
     ap.add_argument("--fp32", action="store_true", help="frame workloads: a float32 frame = the fp32-accurate engine (the reference's -no_fp16 mode); no roofline object")
+    ap.add_argument("--no-fused-tail", action="store_true", help="A/B: HR_conv0 and conv_last as two launches (innfer_net_set_fused_tail 0)")
+    ap.add_argument("--no-upconv-phases", action="store_true", help="A/B: the up-convs as nine taps on the HR grid (innfer_net_set_upconv_phases 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the chop8k (BASELINE config 3) and unet64 (config 5) objects of the line")
     ap.add_argument("--no-roofline", action="store_true")
@@ -498,6 +500,8 @@ def main():
     from innfer_amd import parallel, synth
     net, _ = build_net(dev)
     net.band_rows = args.band_rows
+    net.fused_tail = not args.no_fused_tail
+    net.upconv_phases = not args.no_upconv_phases
     net.pair_convs = args.pair_convs
     tag = " (DRY RUN: all ranks on one GPU, gloo)" if dryrun else ""
 

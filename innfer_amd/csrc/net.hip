@@ -87,6 +87,9 @@ struct ConvSlot {
     void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
     std::vector<float> h_w;      // MFMA convs: the fp32 weights as they were set, kept for the fp32-accurate mode's panels
     void* d_w32 = nullptr;       //   (hi | lo | hi) panels of conv_pack_split, built on the first forward in that mode
+    bool up2x = false;           // the conv of an upconv_block (nearest 2x in front of it): also packed as the four 2x2-tap phases of the equivalent transposed conv
+    void* d_up4 = nullptr;       //   conv_pack_deconv2x panels of the summed weights + d_b4 (the bias once per phase), built with d_w
+    float* d_b4 = nullptr;
     void* d_fuse = nullptr;      // a last conv of 64 -> <= 3 channels: its panel for the epilogue of HR_conv0 (conv_pack_fuse_last), built with d_w
     float* d_b = nullptr;        // bias padded to the panel width
     bool loaded = false;
@@ -107,6 +110,10 @@ struct innfer_net {
     float res_scale = 1.f;       // SRResNet: x + res * res_scale (SRResNet_arch.py:88-91)
     int outm = 0;                // `outm` of RRDBNet / SRResNet.forward (RRDBNet_arch.py:50-62): 0 none, 1 scaltanh, 2 tanh, 3 sigmoid, 4 clamp
     int u8_normalize = 0, u8_round16 = 1;   // innfer_net_forward with INNFER_U8 images: normalize / denormalize flags of np2tensor / tensor2np, fp16 mode
+#ifndef INNFER_UP_PHASES_DEFAULT
+#define INNFER_UP_PHASES_DEFAULT 1
+#endif
+    int up_phases = INNFER_UP_PHASES_DEFAULT;   // upconv_block convs as four 2x2-tap phases on the LR grid (innfer_net_set_upconv_phases; the macro: A/B builds)
     int fused_tail = 1;          // HR_conv0 -> conv_last as one kernel where the shapes allow it (innfer_net_set_fused_tail)
     int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
@@ -168,7 +175,7 @@ extern "C" int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) {        // upconv_block: Upsample, conv, act -- pixelshuffle_block: conv, PixelShuffle, act (block.py:333-361)
         if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * (scale == 3 ? 9 : 4), nf);
-        else add_conv(net, "model." + std::to_string(idx + 1), nf, nf);
+        else { add_conv(net, "model." + std::to_string(idx + 1), nf, nf); net->convs.back().up2x = scale != 3; }
         idx += 3;
     }
     add_conv(net, "model." + std::to_string(idx), nf, nf);
@@ -205,7 +212,7 @@ extern "C" int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_n
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) {        // pixelshuffle_block: conv, PixelShuffle, act -- upconv_block: Upsample, conv, act (block.py:333-361)
         if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * (scale == 3 ? 9 : 4), nf);
-        else add_conv(net, "model." + std::to_string(idx + 1), nf, nf);
+        else { add_conv(net, "model." + std::to_string(idx + 1), nf, nf); net->convs.back().up2x = scale != 3; }
         idx += 3;
     }
     add_conv(net, "model." + std::to_string(idx), nf, nf);
@@ -227,6 +234,8 @@ extern "C" void innfer_net_destroy(innfer_net_t net) {
         if (c.d_b) (void)hipFree(c.d_b);
         if (c.d_w32) (void)hipFree(c.d_w32);
         if (c.d_fuse) (void)hipFree(c.d_fuse);
+        if (c.d_up4) (void)hipFree(c.d_up4);
+        if (c.d_b4) (void)hipFree(c.d_b4);
         if (c.d_map) (void)hipFree(c.d_map);
     }
     delete net;
@@ -268,6 +277,31 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
         bias_n = (size_t)((c.K + per - 1) / per) * per;
         c.h_w.assign(w, w + (size_t)c.K * c.C * c.ksize * c.ksize);
         if (c.d_w32) { (void)hipFree(c.d_w32); c.d_w32 = nullptr; }
+        if (c.up2x && c.ksize == 3 && c.K % 64 == 0 && c.C % 32 == 0) {
+            // nearest-2x + conv3x3 (block.py:358) == ConvTranspose2d(4, 2, 1) with the taps that meet the same LR pixel summed (fp32, ONE rounding to fp16):
+            // HR row 2y reads LR rows y - 1 (w row 0) and y (w rows 1 + 2), HR row 2y + 1 reads y (rows 0 + 1) and y + 1 (row 2); columns alike.
+            // Transposed-conv kernel index ky <-> summed rows: 3 -> {0}, 1 -> {1, 2}, 2 -> {0, 1}, 0 -> {2}.
+            static const int R[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};
+            std::vector<float> wt((size_t)c.C * c.K * 16, 0.f);
+            for (int ci = 0; ci < c.C; ++ci)
+                for (int co = 0; co < c.K; ++co)
+                    for (int ky = 0; ky < 4; ++ky)
+                        for (int kx = 0; kx < 4; ++kx) {
+                            float a = 0.f;
+                            for (int i = 0; i < 2; ++i)
+                                for (int j = 0; j < 2; ++j)
+                                    if (R[ky][i] >= 0 && R[kx][j] >= 0) a += w[(((size_t)co * c.C + ci) * 3 + R[ky][i]) * 3 + R[kx][j]];
+                            wt[(((size_t)ci * c.K + co) * 4 + ky) * 4 + kx] = a;
+                        }
+            std::vector<char> pk(conv_packed_bytes_deconv2x(c.K, c.C));
+            conv_pack_deconv2x(wt.data(), c.K, c.C, 4, pk.data());
+            std::vector<float> b4((size_t)4 * c.K, 0.f);
+            if (b) for (int ph = 0; ph < 4; ++ph) for (int k = 0; k < c.K; ++k) b4[(size_t)ph * c.K + k] = b[k];
+            if (!c.d_up4) INNFER_HIP(hipMalloc(&c.d_up4, pk.size()));
+            if (!c.d_b4) INNFER_HIP(hipMalloc((void**)&c.d_b4, b4.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(c.d_up4, pk.data(), pk.size(), hipMemcpyHostToDevice));
+            INNFER_HIP(hipMemcpy(c.d_b4, b4.data(), b4.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (c.ksize == 3 && c.C == 64 && c.K <= 3) {          // (only the network's last conv has this shape)
             std::vector<char> fp(4096);
             conv_pack_fuse_last(w, c.K, fp.data());
@@ -315,6 +349,12 @@ extern "C" int innfer_net_set_precision(innfer_net_t net, int fp32) {
 extern "C" int innfer_net_set_band_rows(innfer_net_t net, int rows) {
     if (!net || rows < 0) return set_error(INNFER_ERR_INVALID, "set_band_rows: bad arguments");
     net->band_rows = rows;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_set_upconv_phases(innfer_net_t net, int on) {
+    if (!net) return set_error(INNFER_ERR_INVALID, "set_upconv_phases: null network");
+    net->up_phases = on ? 1 : 0;
     return INNFER_OK;
 }
 
@@ -804,7 +844,14 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             t = dst; h *= 3; w *= 3;
             continue;
         }
-        if (!net->ps_up) {           // Upsample(nearest 2x) -> conv -> act
+        if (!net->ps_up && net->up_phases && !net->fp32 && cs.d_up4 && !cs.d_map && net->trunk_act <= 2) {
+            // Upsample(nearest 2x) -> conv -> act as the four output phases of the equivalent transposed conv: 2x2 taps on the LR grid instead of 3x3 on the
+            // HR grid (2.25 x fewer MACs), on the phase-lattice instantiation (conv3x3_pc<.., TM = 0x1B>)
+            ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, net->trunk_act);
+            L.wpk = (const f16*)cs.d_up4; L.bias = cs.d_b4;
+            L.K = 4 * cs.K; L.phase_c = cs.K; L.deconv_phases = 1;
+            rc = do_conv(L, s);
+        } else if (!net->ps_up) {    // Upsample(nearest 2x) -> conv -> act
             ConvLaunch L = mk(cs, t, gi, dst, go, N, 2 * h, 2 * w, net->trunk_act);
             L.up = 1;
             rc = do_conv(L, s);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_fused_tail": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_net_set_upconv_phases": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),

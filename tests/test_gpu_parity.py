@@ -1875,6 +1875,33 @@ def test_fused_tail_vs_two_launches_and_oracle(dev):
     assert torch.equal(ya, net(x))
 
 
+def test_upconv_phases_vs_nine_taps_and_oracle(dev):
+    """upconv_block (nearest 2x -> conv 3x3 -> act, block.py:348-361) as the four 2x2-tap phases of the equivalent transposed conv (innfer_net_set_upconv_phases,
+    the default) against the nine-tap form through the upsampling loader and against the oracle: the same linear map, the summed taps rounded to fp16 once
+    instead of tap by tap -- both within the fp16 bound of the oracle, and within 4e-3 of each other; scale 4 (two stages) and 2, batches, ragged sizes,
+    grids at most 16 pixels wide (image pairs), ReLU features."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    for i, (scale, act, shape) in enumerate([(4, "leakyrelu", (1, 3, 24, 40)), (4, "leakyrelu", (3, 3, 7, 13)), (2, "leakyrelu", (2, 3, 33, 65)), (4, "relu", (1, 3, 16, 16))]):
+        sd = _sd(synth.rrdbnet_shapes(nb=1, scale=scale), 90 + i)
+        net = RRDBNet(3, 3, 64, 1, upscale=scale, act_type=act)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform(shape, 950 + i)).to(dev).half()
+        yp = net(x)
+        net.upconv_phases = False
+        y9 = net(x)
+        net.upconv_phases = True
+        assert yp.shape == y9.shape and (yp.float() - y9.float()).abs().max().item() < 4e-3, (scale, act, shape, (yp.float() - y9.float()).abs().max().item())
+        if act == "leakyrelu":
+            with torch.no_grad():
+                ref = oracle.rrdbnet_forward(sd, x.float().cpu(), nb=1, scale=scale)
+            for tag, y in (("phases", yp), ("nine taps", y9)):
+                e = (y.float().cpu() - ref).abs()
+                assert e.max().item() < 1e-2 and e.mean().item() < 1e-3, (tag, scale, shape, e.max().item(), e.mean().item())
+
+
 def test_full_frame_1080p_translation_property(dev):
     """BASELINE config 2 size (1x3x1080x1920 -> 1x3x4320x7680, RRDBNet-23 4x fp16): an
     interior window of the full-frame result equals the forward of a crop that
