@@ -835,7 +835,7 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (16 * rt + 4 * lg + j < 27) *(float*)(plw + ((16 * rt + j) * FUSE_PITCH + (m >> 1) * 32 + (m & 1) * 16) * 4) = pa[rt][m][j];
+                *(float*)(plw + ((16 * rt + j) * FUSE_PITCH + (m >> 1) * 32 + (m & 1) * 16) * 4) = pa[rt][m][j];       // (all 32 rows: the five padding rows fit the stage, a lane-dependent test per store costs more)
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");                   // the tile's products are in LDS
