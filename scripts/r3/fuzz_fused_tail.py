@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HR_conv0 -> conv_last fused against the two-launch form on random frames of whole 16 x 32 HR tiles: 1..6 x 1..5 tiles, batches of 1..3,
-scale 4 and 2, LeakyReLU / ReLU features, fp16 and fp32 output tensors, uint8 images.  Agreement to the last rounding (tests/_assert_same_to_the_last_rounding)."""
+scale 4 and 2, LeakyReLU / ReLU features, fp16 output tensors and uint8 images.  Agreement to the last rounding (tests/_assert_same_to_the_last_rounding)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))

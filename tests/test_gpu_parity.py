@@ -1828,7 +1828,7 @@ def _assert_same_to_the_last_rounding(a, b, what=""):
 def test_fused_tail_vs_two_launches_and_oracle(dev):
     """HR_conv0 -> conv_last as one kernel (conv3x3_pc<.., TMF | 0x20000>, innfer_net_set_fused_tail, the default) against the two-launch schedule and the
     oracle: HR frames of 1 x 1 ... 4 x 3 tiles of 16 x 32 pixels (tiles with neighbours on every side, rims on the frame border), batches, a scale-2
-    net, ReLU features, one grey output channel, fp32 output tensors; frames that are NOT whole tiles take the two launches and must be bit-identical
+    net, ReLU features, one grey output channel, the uint8 image form; frames that are NOT whole tiles take the two launches and must be bit-identical
     with the knob on or off."""
     import oracle
     from innfer_amd import synth
