@@ -1867,6 +1867,16 @@ def test_fused_tail_vs_two_launches_and_oracle(dev):
         net.fused_tail = True
         dd = (got.int() - two.int()).abs()
         assert dd.max().item() <= 1 and (dd > 0).float().mean().item() < 0.005, (normalize, dd.max().item(), (dd > 0).float().mean().item())
+    # through the C ABI: fp16 engine, fp16 input, FLOAT32 output tensor (the fused tail's planar fp32 store): the fp16 result is its rounding
+    import innfer_amd.lib as L
+    x = torch.from_numpy(synth.uniform((2, 3, 8, 16), 11)).to(dev).half()
+    y16 = net(x)
+    y32 = torch.empty(y16.shape, dtype=torch.float32, device=dev)
+    L.check(L.lib.innfer_net_set_precision(net._handle, 0))
+    L.check(L.lib.innfer_net_forward(net._handle, x.data_ptr(), L.F16, y32.data_ptr(), L.F32, 2, 8, 16, net._ws.data_ptr(), net._ws.numel(),
+                                     torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(y32.half(), y16)
     # not whole tiles (HR 40 x 72): the knob changes nothing
     net, _ = _rrdb(dev, 1, 4)
     x = torch.from_numpy(synth.uniform((2, 3, 10, 18), 9)).to(dev).half()
