@@ -130,6 +130,7 @@ size_t conv_packed_bytes_deconv2x(int K, int C);
 bool conv_fuse_last_ok(const ConvLaunch& L);
 size_t conv_fuse_side_bytes(int N, int H, int W);
 void conv_pack_fuse_last(const float* w_last_oihw, int oc, void* packed_4k);   // host
+void conv_pack_up2x_phases(const float* w_oihw, int K, int C, void* packed);       // host; conv_packed_bytes_deconv2x(K, C) bytes: upconv_block as four 2x2-tap phases
 void conv_pack_deconv2x(const float* w_io, int K, int C, int k, void* packed); // host; ConvTranspose2d(k = 3 | 4, 2, 1) panels for ConvLaunch.deconv_phases, w [C][K][k][k]
 void conv_pack_taps(const float* w, int K, int C, int mask, void* packed);   // host; w [K][C][9], only the taps of `mask` are packed (conv_packed_bytes_taps)
 size_t conv_packed_bytes7x7(int K, int C);

@@ -2216,6 +2216,25 @@ void conv_pack_deconv2x(const float* w, int K, int C, int k, void* packed) {
     conv_pack_taps(w3.data(), K4, C, 0x1B, packed);
 }
 
+// nearest-2x + conv3x3 (upconv_block, block.py:348-361) as ConvTranspose2d(4, 2, 1): w [K][C][3][3] -> the phase panels of conv_pack_deconv2x with the taps that meet the same
+// LR pixel summed in fp32 (ONE rounding to fp16 in the packer): HR row 2y reads LR rows y - 1 (kernel row 0) and y (rows 1 + 2), HR row 2y + 1 reads y (rows 0 + 1) and
+// y + 1 (row 2), columns alike -- transposed-conv kernel index ky <-> summed rows 3: {0}, 1: {1, 2}, 2: {0, 1}, 0: {2}.  K % 64 == 0, C % 32 == 0.
+void conv_pack_up2x_phases(const float* w, int K, int C, void* packed) {
+    static const int R[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};
+    std::vector<float> wt((size_t)C * K * 16, 0.f);
+    for (int ci = 0; ci < C; ++ci)
+        for (int co = 0; co < K; ++co)
+            for (int ky = 0; ky < 4; ++ky)
+                for (int kx = 0; kx < 4; ++kx) {
+                    float a = 0.f;
+                    for (int i = 0; i < 2; ++i)
+                        for (int j = 0; j < 2; ++j)
+                            if (R[ky][i] >= 0 && R[kx][j] >= 0) a += w[(((size_t)co * C + ci) * 3 + R[ky][i]) * 3 + R[kx][j]];
+                    wt[(((size_t)ci * K + co) * 4 + ky) * 4 + kx] = a;
+                }
+    conv_pack_deconv2x(wt.data(), K, C, 4, packed);
+}
+
 // 7 x 1 column conv (ConvLaunch.conv7v): w [K][C][7] -> three 3-tap blocks (the 7 taps zero-padded to 9: tap k9 = k7 + 1), virtual channel
 // block * C + ci, centre-column taps only (mask 0x92)
 size_t conv_packed_bytes7v(int K, int C) { return conv_packed_bytes_taps(K, 3 * C, 0x92); }

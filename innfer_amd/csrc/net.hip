@@ -278,23 +278,9 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
         c.h_w.assign(w, w + (size_t)c.K * c.C * c.ksize * c.ksize);
         if (c.d_w32) { (void)hipFree(c.d_w32); c.d_w32 = nullptr; }
         if (c.up2x && c.ksize == 3 && c.K % 64 == 0 && c.C % 32 == 0) {
-            // nearest-2x + conv3x3 (block.py:358) == ConvTranspose2d(4, 2, 1) with the taps that meet the same LR pixel summed (fp32, ONE rounding to fp16):
-            // HR row 2y reads LR rows y - 1 (w row 0) and y (w rows 1 + 2), HR row 2y + 1 reads y (rows 0 + 1) and y + 1 (row 2); columns alike.
-            // Transposed-conv kernel index ky <-> summed rows: 3 -> {0}, 1 -> {1, 2}, 2 -> {0, 1}, 0 -> {2}.
-            static const int R[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};
-            std::vector<float> wt((size_t)c.C * c.K * 16, 0.f);
-            for (int ci = 0; ci < c.C; ++ci)
-                for (int co = 0; co < c.K; ++co)
-                    for (int ky = 0; ky < 4; ++ky)
-                        for (int kx = 0; kx < 4; ++kx) {
-                            float a = 0.f;
-                            for (int i = 0; i < 2; ++i)
-                                for (int j = 0; j < 2; ++j)
-                                    if (R[ky][i] >= 0 && R[kx][j] >= 0) a += w[(((size_t)co * c.C + ci) * 3 + R[ky][i]) * 3 + R[kx][j]];
-                            wt[(((size_t)ci * c.K + co) * 4 + ky) * 4 + kx] = a;
-                        }
+            // nearest-2x + conv3x3 (block.py:358) == ConvTranspose2d(4, 2, 1) with the taps that meet the same LR pixel summed (conv_pack_up2x_phases)
             std::vector<char> pk(conv_packed_bytes_deconv2x(c.K, c.C));
-            conv_pack_deconv2x(wt.data(), c.K, c.C, 4, pk.data());
+            conv_pack_up2x_phases(w, c.K, c.C, pk.data());
             std::vector<float> b4((size_t)4 * c.K, 0.f);
             if (b) for (int ph = 0; ph < 4; ++ph) for (int k = 0; k < c.K; ++k) b4[(size_t)ph * c.K + k] = b[k];
             if (!c.d_up4) INNFER_HIP(hipMalloc(&c.d_up4, pk.size()));

@@ -107,7 +107,9 @@ __global__ void ppon_axpy(const void* x, const void* y, void* dst, float a, long
 
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 
-struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr; };      // conv3x3.hip panels
+struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr;      // conv3x3.hip panels
+               void* d_up4 = nullptr; float* d_b4 = nullptr;     // the conv of an upconv_block also as four 2x2-tap phases (conv_pack_up2x_phases, bias once per phase)
+               void* d_fuse = nullptr; };                        // a head's last conv (64 -> <= 3): its panel for the epilogue of HR_conv0 (conv_pack_fuse_last)
 struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; void* d_dw3[8] = {};   // [0]: halo-tile panels of the eight dilated convs, back to back
               f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr;
               void* d_c2t = nullptr; };        // c2 as a centre-tap panel for the halo-tile kernel
@@ -181,7 +183,14 @@ extern "C" int innfer_ppon_create(innfer_ppon** out, int in_nc, int out_nc, int 
     return INNFER_OK;
 }
 
-static void free_conv3(Conv3& c) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); c.d_w = nullptr; c.d_b = nullptr; }
+static void free_conv3(Conv3& c) {
+    if (c.d_w) (void)hipFree(c.d_w);
+    if (c.d_b) (void)hipFree(c.d_b);
+    if (c.d_up4) (void)hipFree(c.d_up4);
+    if (c.d_b4) (void)hipFree(c.d_b4);
+    if (c.d_fuse) (void)hipFree(c.d_fuse);
+    c.d_w = nullptr; c.d_b = nullptr; c.d_up4 = nullptr; c.d_b4 = nullptr; c.d_fuse = nullptr;
+}
 
 static void free_device(innfer_ppon* p) {
     if (p->d_fea_w) (void)hipFree(p->d_fea_w);
@@ -233,7 +242,7 @@ extern "C" int innfer_ppon_set_param(innfer_ppon* p, int idx, const float* h_dat
 
 namespace {
 
-int upload_conv3(innfer_ppon* p, Conv3& c) {
+int upload_conv3(innfer_ppon* p, Conv3& c, int role = 0) {       // role 1: the conv of an upconv_block (factor 2), 2: a head's last conv
     const std::vector<float>& w = p->params[c.w].host;
     const std::vector<float>& b = p->params[c.b].host;
     std::vector<char> host(conv_packed_bytes(c.K, c.C));
@@ -246,6 +255,22 @@ int upload_conv3(innfer_ppon* p, Conv3& c) {
     INNFER_HIP(hipMalloc((void**)&c.d_b, bias_n * sizeof(float)));
     INNFER_HIP(hipMemcpy(c.d_w, host.data(), host.size(), hipMemcpyHostToDevice));
     INNFER_HIP(hipMemcpy(c.d_b, bias.data(), bias_n * sizeof(float), hipMemcpyHostToDevice));
+    if (role == 1 && c.K % 64 == 0 && c.C % 32 == 0) {
+        std::vector<char> pk(conv_packed_bytes_deconv2x(c.K, c.C));
+        conv_pack_up2x_phases(w.data(), c.K, c.C, pk.data());
+        std::vector<float> b4((size_t)4 * c.K);
+        for (int ph = 0; ph < 4; ++ph) for (int k = 0; k < c.K; ++k) b4[(size_t)ph * c.K + k] = b[k];
+        INNFER_HIP(hipMalloc(&c.d_up4, pk.size()));
+        INNFER_HIP(hipMalloc((void**)&c.d_b4, b4.size() * sizeof(float)));
+        INNFER_HIP(hipMemcpy(c.d_up4, pk.data(), pk.size(), hipMemcpyHostToDevice));
+        INNFER_HIP(hipMemcpy(c.d_b4, b4.data(), b4.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (role == 2 && c.C == 64 && c.K <= 3) {
+        std::vector<char> fp(4096);
+        conv_pack_fuse_last(w.data(), c.K, fp.data());
+        INNFER_HIP(hipMalloc(&c.d_fuse, fp.size()));
+        INNFER_HIP(hipMemcpy(c.d_fuse, fp.data(), fp.size(), hipMemcpyHostToDevice));
+    }
     return INNFER_OK;
 }
 
@@ -306,9 +331,9 @@ int upload(innfer_ppon* p) {
     int rc = upload_conv3(p, p->lr);
     if (rc) return rc;
     for (auto& H : p->heads) {
-        for (int u = 0; u < p->n_up; ++u) { rc = upload_conv3(p, H.up[u]); if (rc) return rc; }
+        for (int u = 0; u < p->n_up; ++u) { rc = upload_conv3(p, H.up[u], p->scale == 3 ? 0 : 1); if (rc) return rc; }
         rc = upload_conv3(p, H.hr0); if (rc) return rc;
-        rc = upload_conv3(p, H.hr1); if (rc) return rc;
+        rc = upload_conv3(p, H.hr1, 2); if (rc) return rc;
     }
     p->uploaded = true;
     return INNFER_OK;
@@ -477,8 +502,28 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
                 continue;
             }
             const long go = tg * 4;
-            CK(conv(Hd.up[u], t, tg, dst, go, 2 * h, 2 * w, 1, 1, nullptr, 0, OUT_SLAB));
+            if (Hd.up[u].d_up4) {       // upconv_block as the four 2x2-tap phases of the equivalent transposed conv on the LR grid
+                ConvLaunch L{};
+                L.in = t; L.in_gstride = tg; L.C = Hd.up[u].C;
+                L.wpk = (const f16*)Hd.up[u].d_up4; L.bias = Hd.up[u].d_b4;
+                L.out = dst; L.out_gstride = go; L.K = 4 * Hd.up[u].K; L.phase_c = Hd.up[u].K; L.deconv_phases = 1;
+                L.N = N; L.H = h; L.W = w; L.act = 1; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = h; L.out_mode = OUT_SLAB;
+                CK(conv_launch(L, s));
+            } else {
+                CK(conv(Hd.up[u], t, tg, dst, go, 2 * h, 2 * w, 1, 1, nullptr, 0, OUT_SLAB));
+            }
             t = dst; tg = go; h *= 2; w *= 2;
+        }
+        if (Hd.hr1.d_fuse && conv_fuse_side_bytes(N, h, w) <= (size_t)tg * 2 * (p->nf / 32)) {
+            // HR_conv0 -> conv_last of the head as one kernel; the rim buffer lives where the HR slab would have been
+            ConvLaunch L{};
+            L.in = t; L.in_gstride = tg; L.C = Hd.hr0.C;
+            L.wpk = (const f16*)Hd.hr0.d_w; L.bias = Hd.hr0.d_b;
+            L.out = ws + cv.hr; L.out_gstride = tg; L.K = Hd.hr0.K;
+            L.N = N; L.H = h; L.W = w; L.act = 1; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = h; L.out_mode = OUT_SLAB;
+            L.fuse_w = (const f16*)Hd.hr1.d_fuse; L.fuse_bias = Hd.hr1.d_b; L.fuse_side = (float*)(ws + cv.hr); L.fuse_out = out; L.fuse_oc = Hd.hr1.K;
+            L.fuse_out_mode = f32o ? 1 : 0;
+            if (conv_fuse_last_ok(L)) { CK(conv_launch(L, s)); return INNFER_OK; }
         }
         CK(conv(Hd.hr0, t, tg, ws + cv.hr, tg, h, w, 1, 0, nullptr, 0, OUT_SLAB));
         CK(conv(Hd.hr1, (const f16*)(ws + cv.hr), tg, out, 0, h, w, 0, 0, nullptr, 0, OUT_NCHW));
