@@ -49,17 +49,27 @@ WORKLOADS = ["frame1080", "frame540", "chop8k", "chop4k", "chain4k"]
 
 
 def kernel_key(k):
-    """rocprof-style name of the instantiation conv_launch picks for launch kind k = 16*NT + out_mode."""
+    """rocprof-style name of the instantiation conv_launch picks for launch kind k (csrc/net.hip do_conv): 16*NT + out_mode, + 1000 the
+    fp32-accurate form, + 2000 HR_conv0 + conv_last fused (TMF 0x201FF = 131583), + 3000 an up-conv as four 2x2-tap phases (TM 0x1B = 27) --
+    the suffixes are the ones scripts/summarize_prof.py gives the same instantiations in profiles/traffic.json."""
     if k == 1000:
         return "conv3x3_pair"
+    variant, k = k // 1000, k % 1000
     nt, mode = k // 16, k % 16
     if (nt, mode) in PC_SHAPE:
-        return "conv3x3_pc<%d,%d,%d,%d>" % PC_SHAPE[(nt, mode)]
-    return f"conv3x3_mfma<{MFMA_SHAPE[nt]},{nt},{mode}>"
+        name = "conv3x3_pc<%d,%d,%d,%d>" % PC_SHAPE[(nt, mode)]
+    else:
+        name = f"conv3x3_mfma<{MFMA_SHAPE[nt]},{nt},{mode}>"
+    return name + {0: "", 1: "+split", 2: "+tm131583", 3: "+tm27"}[variant]
 
 
 def kind_name(k):
     return "first_conv_mfma<4,1>" if k == 0 else kernel_key(k)          # (3 -> 64 on the matrix cores, csrc/conv_first.hip)
+
+
+KIND_NOTES = {"+tm131583": "HR_conv0 + conv_last in one launch (+ the rim pass): both convs' FLOPs, the 64-channel HR tensor neither written nor read",
+              "+tm27": "up-conv as four 2x2-tap phases on the LR grid: FLOPs are the ALGORITHMIC ones of the nine-tap layer it replaces "
+                       "(reference block.py:348-361); executed FLOPs = 4/9 of them, so `frac_mfma` here is not the matrix pipe's utilisation"}
 
 
 def build_net(dev, nb=23, scale=4):
@@ -76,7 +86,7 @@ def timed_forward(net, x):
     """Per-launch HIP-event timing of one forward (plain schedule) through the C ABI: [(kind, ms, flops, bytes)]."""
     import torch
     import innfer_amd.lib as L
-    net._ensure_engine()
+    net._engine_on(x.device)
     N, _, H, W = x.shape
     s = L.lib.innfer_net_scale(net._handle)
     out = torch.empty((N, net.out_nc, H * s, W * s), dtype=x.dtype, device=x.device)
@@ -125,15 +135,17 @@ def roofline_from_launches(launches):
     for k, v in agg.items():
         e = {"launches": v[3], "ms_total": round(v[0], 4), "avg_ms": round(v[0] / v[3], 5)}
         e.update(two_roofs(v[1], v[2], v[0]))
+        for suffix, note in KIND_NOTES.items():
+            if kind_name(k).endswith(suffix):
+                e["note"] = note
         per_kernel[kind_name(k)] = e
     total_ms = sum(v[0] for v in agg.values())
     total_fl = sum(v[1] for v in agg.values())
-    out = {"bound": r["bound"], "kernel": kind_name(dom), "launches": cnt, "avg_launch_ms": round(t_ms / cnt, 5),
-           "flops_per_launch": flops / cnt, "bytes_per_launch": nbytes / cnt}
-    if r["bound"] == "hbm":
-        out.update({"achieved": r["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": r["frac_hbm"]})
-    else:
-        out.update({"achieved": r["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": r["frac_mfma"]})
+    # the contract's roof for this path is the MFMA one (north_star ">= 0.5x MFMA roofline"): `bound` / `achieved` / `peak` / `frac`
+    # are quoted against it for the dominant kernel; `binding_roof` is the two-roof rule's answer for the same launches (the larger floor)
+    out = {"bound": "mfma", "kernel": kind_name(dom), "launches": cnt, "avg_launch_ms": round(t_ms / cnt, 5),
+           "flops_per_launch": flops / cnt, "bytes_per_launch": nbytes / cnt,
+           "achieved": r["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": r["frac_mfma"], "binding_roof": r["bound"]}
     out.update({"frac_mfma": r["frac_mfma"], "frac_hbm": r["frac_hbm"], "tflops": r["tflops"], "gbs": r["gbs"],
                 "flop_per_byte": r["flop_per_byte"], "ridge_flop_per_byte": round(PEAK_F16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
                 "traffic": pmc_traffic(dom),
@@ -266,9 +278,12 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def unet64_object(dev, reps=20):
+def unet64_object(dev, reps=50, windows=7, warm_s=0.6):
     """BASELINE config 5: UnetGenerator(3, 3, 8 downs, ngf 64, BatchNorm on the statistics of each image -- run.py runs pix2pix with meval=False, one
-    image at a time) on 64 x 3 x 256 x 256, fp16, synthetic weights; HIP events around `reps` forwards on the launch stream."""
+    image at a time) on 64 x 3 x 256 x 256, fp16, synthetic weights.  Warm-up by TIME (>= `warm_s` seconds and >= 50 forwards: the first forwards
+    after an engine is created / after the GPU idled have shown one-off dispatch stalls of 17-25 ms, profiles/r4/unet_stall.txt), then `windows`
+    windows of `reps` forwards, each between HIP events on the launch stream; `ms_per_step` is the MEDIAN window, min / max beside it, and
+    `hip_event_sum_ms` the sum of the per-launch HIP-event durations of one forward (what the kernels alone take)."""
     import torch
     from innfer_amd import synth
     from innfer_amd.architectures import get_network
@@ -278,22 +293,31 @@ def unet64_object(dev, reps=20):
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).train()
     x = torch.from_numpy(synth.uniform((64, 3, 256, 256), 3, -1, 1)).to(dev).half()
-    for _ in range(3):
-        net(x)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        net(x)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    n_warm, t0 = 0, time.perf_counter()
+    while n_warm < 50 or time.perf_counter() - t0 < warm_s:
+        for _ in range(10):
+            net(x)
+        torch.cuda.synchronize()
+        n_warm += 10
+    win = []
+    for _ in range(windows):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            net(x)
+        e1.record()
+        torch.cuda.synchronize()
+        win.append(e0.elapsed_time(e1) / reps)
+    ms = sorted(win)[len(win) // 2]
     fl = net.flops(64, 256, 256)                    # 12.1 GFLOP per image
     out = {"workload": "pix2pix UnetGenerator(3, 3, 8, ngf 64), train-mode BatchNorm per image, 64x3x256x256 -> 64x3x256x256 fp16 (BASELINE config 5)",
-           "steps": reps, "warmup": 3, "ms_per_step": round(ms, 4), "value": round(64 / ms * 1e3, 1), "unit": "img/s",
+           "steps": reps, "windows": windows, "warmup": n_warm, "ms_per_step": round(ms, 4), "ms_per_step_min": round(min(win), 4),
+           "ms_per_step_max": round(max(win), 4), "ms_per_step_windows": [round(w, 4) for w in win],
+           "value": round(64 / ms * 1e3, 1), "unit": "img/s",
            "model_tflops": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4)}
     per = unet_per_kernel(net, x)
     if per:
+        out["hip_event_sum_ms"] = round(sum(e["ms_total"] for e in per.values()), 4)
         out["per_kernel"] = per
     net.release_workspace()
     return out
@@ -338,6 +362,12 @@ def visible_gpu_count():
     if n == 0:
         import torch
         return torch.cuda.device_count()
+    # a container / lease that exposes a subset of the node's GPUs still shows the whole topology in sysfs: a GPU is usable only through its
+    # DRM render node, so the count is cut down to the render nodes this process may open
+    nodes = glob.glob("/dev/dri/renderD*")
+    usable = sum(os.access(d, os.R_OK | os.W_OK) for d in nodes)
+    if usable:                                      # (none accessible at all: not a statement about GPUs -- leave the topology count alone)
+        n = min(n, usable)
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:

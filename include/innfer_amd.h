@@ -86,7 +86,9 @@ int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const float* h_alph
  * is kept as a PAIR of fp16 slabs (hi = fp16(x), lo = fp16((x - hi) * 2^11): 22 significant bits), every weight as a pair of panels, and a product is
  * xh wh + 2^-11 (xh wl + xl wh) on the fp16 matrix cores with fp32 accumulation; input fp32 or uint8, twice the workspace (ask innfer_net_workspace_bytes
  * after this call), three times the MFMA work.  Against the fp32 reference: <= 1e-4 on [0,1]-scaled outputs (measured ~1e-6).  Built for
- * RRDBNet / SRResNet (every constructor variant of innfer_*_create_ex); the other generators have no fp32 mode (their Python shells raise).  (106) */
+ * RRDBNet / SRResNet (every constructor variant of innfer_*_create_ex); the other generators have no fp32 mode (their Python shells raise).  (106)
+ * A LOAD-TIME call: with fp32 = 1 it builds the split weight panels of every conv set so far (hipMalloc + synchronous copies; INNFER_ERR_NOMEM when they
+ * do not fit) -- call it after the last innfer_net_set_conv and outside stream capture; innfer_net_forward itself never allocates. */
 int innfer_net_set_precision(innfer_net_t net, int fp32);
 
 void innfer_net_destroy(innfer_net_t net);
@@ -113,9 +115,11 @@ int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dtype, void* d
 /* Same forward with a HIP-event pair around every kernel launch (on `stream`), then a
  * stream synchronise.  Fills up to `cap` entries: elapsed ms, algorithmic FLOPs, algorithmic HBM
  * bytes (every operand read once, every result written once: (C + K) * 2 B per output pixel,
- * + K * 2 B per residual, + the weight panel) and kernel kind (0 = first conv on VALU; 16*NT +
- * out_mode = the conv instantiation with NT 16-channel output tiles).  Used by bench.py for the
- * roofline object (both roofs per kernel). */
+ * + K * 2 B per residual, + the weight panel) and kernel kind (0 = first conv; 16*NT +
+ * out_mode = the conv instantiation with NT 16-channel output tiles; + 1000 its fp32-accurate form,
+ * + 2000 the fused HR_conv0 + conv_last launch, + 3000 an up-conv as four 2x2-tap phases, whose FLOPs
+ * are the algorithmic ones of the nine-tap layer it replaces: it executes 4/9 of them).  Used by
+ * bench.py for the roofline object (both roofs per kernel). */
 int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                              int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream,
                              int cap, float* h_ms, double* h_flops, double* h_bytes, int* h_kind, int* n_launches);

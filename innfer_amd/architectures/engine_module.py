@@ -143,11 +143,35 @@ class EngineModule(nn.Module):
         with torch.cuda.device(x.device):
             return self._forward_on_device(x)
 
-    def _forward_on_device(self, x):
-        if self._weights_device is not None and self._weights_device != x.device:
+    def _engine_on(self, device):
+        """The engine with its packed weights on `device`.  Call with `device` as the process's current HIP device (torch.cuda.device): the
+        library allocates on the current device, so an engine whose weights live on another GPU is destroyed and rebuilt here.  EVERY path that
+        may create the handle goes through this (forward, forward_u8, tile_batch_bytes, flops) -- a handle created outside it would put the
+        weights on whatever device happened to be current and the first forward elsewhere would launch with foreign pointers."""
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self._weights_device is not None and self._weights_device != device:
             self._destroy_handle()
         self._ensure_engine()
-        self._weights_device = x.device
+        self._weights_device = device
+
+    def _home_device(self, device=None):
+        """Device for the calls that carry no tensor: the one asked for, else where the weights already are, else where the parameters are,
+        else the current device."""
+        if device is not None:
+            device = torch.device(device)
+            return device if device.index is not None else torch.device('cuda', torch.cuda.current_device())
+        if self._weights_device is not None:
+            return self._weights_device
+        for p in self.parameters():
+            if p.is_cuda:
+                return p.device
+            break
+        return torch.device('cuda', torch.cuda.current_device())
+
+    def _forward_on_device(self, x):
+        self._engine_on(x.device)
         L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
         L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
         L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
@@ -177,10 +201,7 @@ class EngineModule(nn.Module):
         if not img.is_cuda:
             raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
         with torch.cuda.device(img.device):
-            if self._weights_device is not None and self._weights_device != img.device:
-                self._destroy_handle()
-            self._ensure_engine()
-            self._weights_device = img.device
+            self._engine_on(img.device)
             L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
             L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
             L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
@@ -210,16 +231,21 @@ class EngineModule(nn.Module):
     def release_workspace(self):
         self._ws = None
 
-    def tile_batch_bytes(self, b, ps, dtype=torch.float16):
+    def tile_batch_bytes(self, b, ps, dtype=torch.float16, device=None):
         """Device bytes a forward of b tiles of ps x ps takes beyond the weights: the engine workspace (innfer_net_workspace_bytes in the precision
         `dtype` selects -- twice as much in the fp32-accurate mode) + the input tiles + the HR tiles twice (the batch's result and its copy in the
-        tile buffer the blend reads).  parallel.engine_tile_cap sizes the chop batches with it."""
-        self._ensure_engine()
-        L.check(L.lib.innfer_net_set_precision(self._handle, int(dtype == torch.float32)))
-        elt = 4 if dtype == torch.float32 else 2
-        s = L.lib.innfer_net_scale(self._handle)
-        return L.lib.innfer_net_workspace_bytes(self._handle, b, ps, ps) + b * (self.in_nc * ps * ps + 2 * self.out_nc * (ps * s) ** 2) * elt
+        tile buffer the blend reads).  parallel.engine_tile_cap sizes the chop batches with it and names the GPU the tiles are on: the engine
+        (packed weights included) is built THERE, as the forward that follows would."""
+        device = self._home_device(device)
+        with torch.cuda.device(device):
+            self._engine_on(device)
+            L.check(L.lib.innfer_net_set_precision(self._handle, int(dtype == torch.float32)))
+            elt = 4 if dtype == torch.float32 else 2
+            s = L.lib.innfer_net_scale(self._handle)
+            return L.lib.innfer_net_workspace_bytes(self._handle, b, ps, ps) + b * (self.in_nc * ps * ps + 2 * self.out_nc * (ps * s) ** 2) * elt
 
-    def flops(self, N, H, W):
-        self._ensure_engine()
-        return L.lib.innfer_net_flops(self._handle, N, H, W)
+    def flops(self, N, H, W, device=None):
+        device = self._home_device(device)
+        with torch.cuda.device(device):
+            self._engine_on(device)
+            return L.lib.innfer_net_flops(self._handle, N, H, W)

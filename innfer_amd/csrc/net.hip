@@ -86,7 +86,7 @@ struct ConvSlot {
     int ksize = 3;               // 1: a 1x1 conv (one-tap panel, ConvLaunch.conv1x1)
     void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
     std::vector<float> h_w;      // MFMA convs: the fp32 weights as they were set, kept for the fp32-accurate mode's panels
-    void* d_w32 = nullptr;       //   (hi | lo | hi) panels of conv_pack_split, built on the first forward in that mode
+    void* d_w32 = nullptr;       //   (hi | lo | hi) panels of conv_pack_split, built by innfer_net_set_precision(1)
     bool up2x = false;           // the conv of an upconv_block (nearest 2x in front of it): also packed as the four 2x2-tap phases of the equivalent transposed conv
     void* d_up4 = nullptr;       //   conv_pack_deconv2x panels of the summed weights + d_b4 (the bias once per phase), built with d_w
     float* d_b4 = nullptr;
@@ -328,6 +328,19 @@ extern "C" int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const fl
 // work and twice the bytes of the fp16 forward.  The reference's fp32 mode on the GPU (`-no_fp16`: run.py:345,421-422).
 extern "C" int innfer_net_set_precision(innfer_net_t net, int fp32) {
     if (!net || (fp32 != 0 && fp32 != 1)) return set_error(INNFER_ERR_INVALID, "set_precision: 0 (fp16 arithmetic) or 1 (fp32-accurate)");
+    if (fp32) {
+        // The (wl | wh | wh) panels of every loaded conv are built HERE -- a load-time call, with its hipMalloc and synchronous copies -- never inside
+        // innfer_net_forward (stream capture, concurrent callers).  Idempotent: a conv that already has its panels is skipped; innfer_net_set_conv
+        // drops a conv's panels, so the call after a weight change rebuilds exactly those.
+        for (auto& c : net->convs) {
+            if (c.first || c.d_w32 || !c.loaded) continue;
+            std::vector<char> host(3 * (c.ksize == 1 ? conv_packed_bytes_taps(c.K, c.C, 0x10) : conv_packed_bytes(c.K, c.C)));
+            if (c.ksize == 1) conv_pack_1x1_split(c.h_w.data(), c.K, c.C, host.data());
+            else conv_pack_split(c.h_w.data(), c.K, c.C, host.data());
+            if (hipMalloc(&c.d_w32, host.size()) != hipSuccess) { c.d_w32 = nullptr; (void)hipGetLastError(); return set_error(INNFER_ERR_NOMEM, "set_precision: out of device memory for the fp32-accurate panels of '%s' (%zu bytes)", c.key.c_str(), host.size()); }
+            INNFER_HIP(hipMemcpy(c.d_w32, host.data(), host.size(), hipMemcpyHostToDevice));
+        }
+    }
     net->fp32 = fp32;
     return INNFER_OK;
 }
@@ -434,7 +447,7 @@ struct LaunchTimer {
     std::vector<hipEvent_t> ev;      // 2 per launch
     std::vector<double> flops;
     std::vector<double> bytes;       // algorithmic HBM bytes of the launch: every operand read once, every result written once
-    std::vector<int> kind;           // 0 first conv (VALU); 16*NT + out_mode for conv3x3_mfma
+    std::vector<int> kind;           // 0 first conv; 16*NT + out_mode (+ 1000 / 2000 / 3000: see do_conv) for the MFMA convs
 };
 thread_local LaunchTimer* g_timer = nullptr;
 
@@ -510,10 +523,14 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
                          + (double)taps * L.K * L.C * 2.0;
     if (L.fuse_w) {      // HR_conv0 + conv_last as one launch (+ the rim pass): both convs' FLOPs; bytes: C channels in, the planar result out, both weight sets
         const double ob = L.fuse_out_mode == 2 ? 1.0 : L.fuse_out_mode == 1 ? 4.0 : 2.0;
-        return timed_end(s, 2.0 * 9.0 * (L.K * (double)L.C + 64.0 * L.fuse_oc) * px, px * (L.C * 2.0 + L.fuse_oc * ob) + 9.0 * (L.K * L.C + 64.0 * L.fuse_oc) * 2.0, 16 * conv_nt_for(L.K) + L.out_mode);
+        return timed_end(s, 2.0 * 9.0 * (L.K * (double)L.C + 64.0 * L.fuse_oc) * px, px * (L.C * 2.0 + L.fuse_oc * ob) + 9.0 * (L.K * L.C + 64.0 * L.fuse_oc) * 2.0, 2000 + 16 * conv_nt_for(L.K) + L.out_mode);
     }
+    // launch kinds: 16 * NT + out_mode, + 1000 fp32-accurate (split) form, + 2000 fused HR_conv0 + conv_last (TMF 0x201FF), + 3000 the four 2x2-tap phases
+    // of an upconv_block (TM 0x1B, K = 4 * phase_c on the LR grid): their own instantiations, their own rows in the bench's per-kernel table.
+    // The phase form's FLOPs are the ALGORITHMIC ones of the layer it replaces (nine taps on the 2H x 2W grid = 2 * 9 * 4K * C per LR pixel); it executes 4/9 of them.
     // (fp32-accurate mode: the same algorithmic FLOPs -- executed: 3x --, two slabs per tensor, three panels per weight)
-    return timed_end(s, 2.0 * taps * L.K * L.C * px, L.split ? 2.0 * bytes + (double)taps * L.K * L.C * 2.0 : bytes, 16 * conv_nt_for(L.K) + L.out_mode + (L.split ? 1000 : 0));
+    return timed_end(s, 2.0 * taps * L.K * L.C * px, L.split ? 2.0 * bytes + (double)taps * L.K * L.C * 2.0 : bytes,
+                     16 * conv_nt_for(L.K) + L.out_mode + (L.split ? 1000 : 0) + (L.deconv_phases ? 3000 : 0));
 }
 
 // nearest-neighbour upsampling of a slab by an integer factor (src = dst / f, block.py:321-322).  The 2x case is folded into the conv's input
@@ -687,14 +704,8 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
     const long LO = (long)(cv.lo / 2);            // fp32-accurate mode: elements from a slab to its lo twin (0: fp16 mode)
     if (net->fp32) {
         if (in_dtype == INNFER_F16) return set_error(INNFER_ERR_INVALID, "forward: the fp32-accurate mode takes fp32 or uint8 input (an fp16 tensor is the fp16 mode's)");
-        for (auto& c : net->convs) {
-            if (c.first || c.d_w32) continue;
-            std::vector<char> host(3 * (c.ksize == 1 ? conv_packed_bytes_taps(c.K, c.C, 0x10) : conv_packed_bytes(c.K, c.C)));
-            if (c.ksize == 1) conv_pack_1x1_split(c.h_w.data(), c.K, c.C, host.data());
-            else conv_pack_split(c.h_w.data(), c.K, c.C, host.data());
-            INNFER_HIP(hipMalloc(&c.d_w32, host.size()));
-            INNFER_HIP(hipMemcpy(c.d_w32, host.data(), host.size(), hipMemcpyHostToDevice));
-        }
+        for (auto& c : net->convs)                // built by innfer_net_set_precision(1) (load time); a conv re-set since then rebuilds there too
+            if (!c.first && !c.d_w32) return set_error(INNFER_ERR_INVALID, "forward: the fp32-accurate panels of '%s' are missing: call innfer_net_set_precision(net, 1) after the last innfer_net_set_conv", c.key.c_str());
     }
     auto mk = [&](const ConvSlot& cs, const f16* in, long in_g, void* out, long out_g, int N_, int H_, int W_, int act) {
         return mk_launch(cs, in, in_g, out, out_g, N_, H_, W_, act, LO);

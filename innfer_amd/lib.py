@@ -209,6 +209,9 @@ def check(rc):
         raise ValueError(msg)
     if rc == ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
+    if rc == ERR_NOMEM:                 # the class torch's allocator raises: parallel.run_tile_batches halves the tile batch on it
+        import torch
+        raise torch.OutOfMemoryError(msg)
     raise InnferError(f"innfer_amd status {rc}: {msg}")
 
 

@@ -80,6 +80,13 @@ def engine_tile_cap(model_fn, ps, dtype, device, fraction=0.8, budget=None):
     cost = getattr(model_fn, 'tile_batch_bytes', None)
     if cost is None:
         return MAX_TILE_BATCH
+    try:                                            # the nn.Module shells build their engine on the GPU the tiles are on (not on the current device)
+        import inspect
+        if 'device' in inspect.signature(cost).parameters and torch.device(device).type == 'cuda':
+            import functools
+            cost = functools.partial(cost, device=device)
+    except (TypeError, ValueError):
+        pass
     if budget is None:
         ws = getattr(model_fn, '_ws', None)
         budget = fraction * (free_device_bytes(device) + (ws.numel() if ws is not None else 0))

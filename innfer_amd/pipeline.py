@@ -82,13 +82,13 @@ class FramePipeline:
                     sl['up'].record(self.s_in)
                 self._compute(sl, img.shape)
                 sl['h_out'] = self._free_out.pop()         # never the buffer lent to the consumer: that one returns in _finish
+                sl['busy'] = True
+                pending.append(sl)                         # from here on the `finally` below owns the buffer: a raise in the copy cannot leak it
+                k += 1
                 with torch.cuda.stream(self.s_out):
                     self.s_out.wait_event(sl['done'])
                     sl['h_out'].copy_(sl['d_out'], non_blocking=True)
                     sl['down'].record(self.s_out)
-                sl['busy'] = True
-                pending.append(sl)
-                k += 1
             while pending:
                 yield self._finish(pending.pop(0))
         finally:
