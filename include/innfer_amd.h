@@ -45,8 +45,8 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 107
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input.  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 108
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -145,6 +145,12 @@ int innfer_net_set_band_rows(innfer_net_t net, int rows);
  * package is power-bound, not HBM-bound, on this network and the pairs measure 3 % slower per frame
  * (profiles/r2/kernel_experiments.txt), hence the default. */
 int innfer_net_set_pair_convs(innfer_net_t net, int mode);
+
+/* The residual of a dense block's last conv (`x5 * 0.2 + x`, RRDBNet_arch.py:161-165) is that conv's own input channels 0..63.  on = 1 (default): the
+ * kernel stages those two channel groups LAST and adds x / 0.2 to the fp32 accumulators from the staged LDS tile; the epilogue scales by 0.2 -- x is not
+ * read a second time (265 MB of a 1327 MB launch at 1080p).  The sum is formed in another order than fma(acc, 0.2, x) (fp32 either way): results agree
+ * with on = 0 to the last rounding of the fp16 output, not bit for bit.  fp16 engine, nf = 64; everything else ignores the switch.  (108) */
+int innfer_net_set_residual_lds(innfer_net_t net, int on);
 
 /* Scheduling knob: the last two convs of RRDBNet / SRResNet (HR_conv0 -> LeakyReLU -> conv_last, RRDBNet_arch.py:36-42) as ONE kernel -- the last conv
  * runs in the epilogue of HR_conv0 on the tile that kernel has just produced (csrc/conv3x3.hip, FUSE: no halo recompute; the pixels within one pixel
@@ -352,6 +358,8 @@ typedef struct {
     int winograd;                       /* experiment (profiles/r3/winograd.txt; not used by the networks): 1 = Winograd F(2,3) along the image rows on 16 x 32 tiles -- two
                                            thirds of the MFMA work, fp16 transforms (parity vs the direct form: test_winograd_rows_vs_direct); d_packed from
                                            innfer_pack_conv3x3_wino(); K % 32 == 0, act 0 / 1 / 2, residuals, upsample2x, row range; 2 = the direct conv on the same tiles (K 32) (106) */
+    int res1_from_input;                /* != 0: d_res1 == d_in (same group stride), act 0, K = 64, C >= 96 -- the dense block's `x5 * 0.2 + x`: the residual is taken from the
+                                           conv's own staged input tiles (see innfer_net_set_residual_lds); ignored when the shape does not qualify (108) */
 } innfer_conv_args;
 
 size_t innfer_conv3x3_packed_bytes(int K, int C);

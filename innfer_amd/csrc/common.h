@@ -93,6 +93,8 @@ struct ConvLaunch {
     int split;                                    // fp32-accurate mode: every tensor is a (hi, lo) pair of fp16 slabs, lo = fp16((x - hi) * 2^11) (conv3x3.hip, SPLIT); panels from
     long in_lo, out_lo, res1_lo, res2_lo;         // conv_pack_split / conv_pack_1x1_split; *_lo: distance (elements) from a hi slab to its lo twin.  Plain 3x3 / 1x1 slab convs
                                                   // (act 0..2, residuals, upsampled input, batches) and the planar last conv
+    int res1_lds;                                 // 1: when res1 is the conv's own input (groups 0, 1: the dense block's x5 * 0.2 + x), act 0 and K = 64, take it from the staged LDS tiles
+                                                  // (conv3x3_pc RLDS: chunk order 2, 3, .., 0, 1; the residual enters the fp32 accumulators as x / s1) instead of re-reading it in the epilogue
     int wino;                                     // experiment: 1 = Winograd F(2,3) along the rows (panels from conv_pack_wino), 2 = the direct conv on the same 16 x 32 tiles
     const f16* pair_wpk; const float* pair_bias;  // net.hip only: non-null = this 32-output LeakyReLU conv AND the next one of the dense block (inputs: the same
                                                   // C channels + this conv's output, output: the following channel group) as one conv_pair_launch

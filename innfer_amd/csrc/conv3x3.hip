@@ -134,6 +134,7 @@ struct KP {
     float* fl_side;          //   per tile 192 x 3 partial sums of the pixels within one pixel of a tile edge (conv_fuse_combine finishes them)
     void* fl_out;            //   the planar [N, fl_oc, H, W] result
     int fl_oc, fl_out_mode;  //   0 fp16, 1 fp32 planar; 2 the uint8 HWC image (out_denorm / out_round16 as for the planar kernels)
+    float rs1;               // RLDS kernels (TMF | 0x40000): 1 / s1 -- the residual res1 (= the conv's own input groups 0, 1) is added to the accumulators as x / s1 from the live LDS stage
     long in_lo_bytes;        // SPLIT kernels (TMF | 0x2000): the low-part twin of the input slab lies this many bytes behind it,
     long out_lo, res1_lo, res2_lo;   //   those of the output / residual slabs this many ELEMENTS behind them
 #ifdef INNFER_ABLATE
@@ -150,7 +151,8 @@ struct KP {
 // pixel (y*d + py, x*d + px); the sub-image ends where the full image does.  No residuals in that mode.
 // CV (image canvas, see conv3x3_pc): (ty0, tx0) are canvas coordinates; a pixel tile may lie in the cell below / right of the tile's first
 // cell, or on the one-pixel gutter between cells (not stored).  Same arithmetic, per-pixel-tile addresses.
-template <int RPW, int NT, int ACT, bool R1, bool R2>
+// SC1 (RLDS kernels): res1 is already inside the accumulators as x / s1 (consumer loop); the epilogue only scales by s1 (then R2 as usual).
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool SC1 = false>
 __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2 * RPW], int ty0, int tx0, int wave, int li, int cbase) {
     constexpr int MT = 2 * RPW;
     // ACT 7 (pair gate, PAN's PAConv): the lane's upper NT / 2 channel tiles are the gates of its lower ones -- out = conv_lo * sigmoid(conv_hi),
@@ -178,12 +180,16 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
 #pragma unroll
             for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + 4 * t);
         }
+        if (!R1 && R2 && ok[m]) {       // one residual from memory: its loads for all pixel tiles first, like the R1-only form
+#pragma unroll
+            for (int t = 0; t < NT; ++t) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + off[m] + 4 * t);
+        }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (!ok[m]) continue;
         f16* op = ob + off[m];
-        if (R2) {
+        if (R1 && R2) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + 4 * t);
@@ -199,6 +205,7 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
                 if (ACT == 7) f = f * (1.0f / (1.0f + expf(-acc[t + NT / 2][m][j])));
                 else if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
                 else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                if (SC1) { f = f * p.s1; FP32_VALUE(f); }
                 if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
                 if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
                 FP32_VALUE(f);
@@ -211,7 +218,7 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
 
 // DCV (conv3x3_pc<.., TM = 0x1B>: one output phase of ConvTranspose2d(4, 2, 1) per 16*NT-channel group): (ty0, tx0) are coordinates of the phase's
 // shifted lattice (see decode); virtual pixel (y', x') of phase (a, b) is output pixel (2y' - a, 2x' - b) of the 2H x 2W slab, channel ch % phase_c.
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, bool PAIR = false>
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, bool PAIR = false, bool SC1 = false>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase, int dil = 1) {
     constexpr int MT = 2 * RPW;
@@ -295,6 +302,7 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
                 } else {
                     if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
                     else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    if (SC1) { f = f * p.s1; FP32_VALUE(f); }          // RLDS: res1 is inside the accumulator as x / s1
                     if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
                     if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
                 }
@@ -1049,6 +1057,14 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // nine that lie inside the tile.  Pixels at least one pixel inside the tile are complete (+ bias -> planar output); the 92 pixels on the tile's rim and the
     // 100 just outside it get partial sums (fl_side), finished by conv_fuse_combine from the two to four tiles that meet there, in a fixed order.  The 4.25 GB
     // HR slab of a 1080p -> 4K frame is neither written nor read.  Two more workgroup barriers on a tile's last chunk (loaders included).
+    // + 0x40000 (RLDS): the dense block's last conv (RRDBNet_arch.py:161-165: x5 = conv5(cat(x, x1 .. x4)); x5 * 0.2 + x) takes its residual x from LDS instead
+    // of re-reading it from memory in the epilogue: x IS the conv's input channel groups 0 and 1, so the chunks are walked in the order 2, 3, .., 0, 1 (loader:
+    // chunk c stages group (c + 2) mod nchunks and its panel) and at the end of the last two steps the live stage holds exactly the 32 residual channels half of
+    // the lanes need, at the centre tap's position of their own pixels: those lanes add x / s1 to their accumulators (s1 = 0.2: x * 5, exact product, one fp32
+    // rounding of the sum), the epilogue scales by s1.  265 MB of every 1327 MB launch (1080p) are no longer read twice; the RRDB-end launches, whose two
+    // residuals' loads did not fit the registers as one batch, keep ONE memory residual and hoist its loads like the others.
+    constexpr bool RLDS = (TMF & 0x40000) != 0;
+    static_assert(!RLDS || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x3FFFF) == 0x1FF && !S9 && !POLY), "residual from LDS: the plain 64-channel instantiation (and its canvas form)");
     constexpr bool FUSE = (TMF & 0x20000) != 0;
     static_assert(!FUSE || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation");
     constexpr int TH = NCW * RPW;
@@ -1368,7 +1384,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #endif
         };
         auto issue = [&](int c, int stage) __attribute__((always_inline)) {
-            issue_to(c, smem + stage * STAGE, smem + stage * STAGE + IN_BYTES, w_tile + (long)c * W_BYTES, 3);
+            const int cg = RLDS ? (c + 2 >= p.nchunks ? c + 2 - p.nchunks : c + 2) : c;      // RLDS: groups 2, 3, .., 0, 1 -- the residual's two groups last
+            issue_to(cg, smem + stage * STAGE, smem + stage * STAGE + IN_BYTES, w_tile + (long)cg * W_BYTES, 3);
         };
         if constexpr (NSI == 3) {
             // ---- ring of three input slots + two weight slots: the input cursor runs two chunks ahead of the consumers, the weight cursor one ----
@@ -1487,6 +1504,16 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                     const int P = (cw * RPW + q) * LWP + 18 * h + li + dl;
                     woffs[q][h][dl] = P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4);
                 }
+    }
+    // RLDS: byte offset of the lane's 16 residual channels (two 16-byte slots; the swizzle swaps slot PAIRS, so they stay adjacent) of its pixel tile m inside a
+    // stage: LDS pixel P = the centre tap's operand of output pixel (cw * RPW + m / 2, li + 16 (m % 2))
+    int roffs[RLDS ? MT : 1];
+    if constexpr (RLDS) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int P = (cw * RPW + (m >> 1) + 1) * LWP + li + (m & 1) * 16 + 1;
+            roffs[m] = P * 64 + (((lg & 1) ^ ((P >> 2) & 1)) << 5);
+        }
     }
     int islot = 0;                                                // NSI == 3: g % 3
     f32x4 bias_r[NT];
@@ -1700,6 +1727,20 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
         }
         }
+        if constexpr (RLDS) {
+            // chunk nchunks - 2 is input group 0 = residual channels 0..31 (lanes lg 0, 1), chunk nchunks - 1 group 1 = channels 32..63 (lanes lg 2, 3)
+            if (c >= p.nchunks - 2 && (lg >> 1) == c - (p.nchunks - 2)) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const f16x8 x0 = *(const f16x8*)(st + roffs[m]), x1 = *(const f16x8*)(st + roffs[m] + 16);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[t][m][j] = __builtin_fmaf((float)(t < 2 ? x0 : x1)[(t & 1) * 4 + j], p.rs1, acc[t][m][j]);
+                }
+            }
+        }
         PCT(c1);
         if (cw == 0) PCACC(0, c1, c0);
         if (++c == p.nchunks) {
@@ -1731,6 +1772,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
             }
 #undef EPI
+            } else if constexpr (OUTMODE == OUT_SLAB && CV && RLDS) {
+                if (p.res2) epilogue_slab_cv<RPW, NT, 0, false, true, true>(p, acc, ty0, tx0, cw, li, cbase);
+                else epilogue_slab_cv<RPW, NT, 0, false, false, true>(p, acc, ty0, tx0, cw, li, cbase);
+            } else if constexpr (OUTMODE == OUT_SLAB && RLDS) {
+                if (p.res2) epilogue_slab<RPW, NT, 0, false, true, true, false, false, false, true>(p, acc, n, ty0, tx0, cw, li, cbase, dcur);
+                else epilogue_slab<RPW, NT, 0, false, false, true, false, false, false, true>(p, acc, n, ty0, tx0, cw, li, cbase, dcur);
             } else if constexpr (OUTMODE == OUT_SLAB && CV) {
 #define EPI(A, B, C) epilogue_slab_cv<RPW, NT, A, B, C>(p, acc, ty0, tx0, cw, li, cbase)
             if (!p.res1) {
@@ -1988,7 +2035,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
-    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
+    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x42000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
         int gy = 0; long t = 0;
         const int gx = INNFER_KNOB("INNFER_CANVAS", 1) ? canvas_grid<TH>(kp, N, &gy, &t) : 0;
         if (gx > 0) {
@@ -2461,6 +2508,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         return INNFER_OK;
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 4 && L.stats_part) return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x11FF>(k, L.N, s);
+    if (pc && L.out_mode == OUT_SLAB && nt == 4 && L.res1_lds && L.res1 && L.res1 == L.in && L.res1_gstride == L.in_gstride && L.act == 0 && L.K == 64 && L.C >= 96 &&
+        !L.up && !L.reflect && L.s1 != 0.f) {
+        // the dense block's last conv: the residual is the conv's own input groups 0 and 1 -- taken from the live LDS stages (conv3x3_pc<.., TMF | 0x40000>)
+        k.rs1 = 1.0f / L.s1;
+        return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x401FF>(k, L.N, s);
+    }
     if (pc && L.out_mode == OUT_SLAB && nt == 4) {
         // diagnostic builds: four consumer waves of twice the rows (measured within +-1 %: profiles/r2/kernel_experiments.txt 10)
         if (INNFER_KNOB("INNFER_FAT", 0) & 2) return launch_pc<4, 4, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
         ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int), ("pixel_shuffle2", C.c_int),
         ("stride2_k4", C.c_int), ("transposed2x", C.c_int), ("column7", C.c_int),
         ("split", C.c_int), ("in_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64), ("res2_lo", C.c_int64),
-        ("winograd", C.c_int),
+        ("winograd", C.c_int), ("res1_from_input", C.c_int),
     ]
 
 
@@ -85,6 +85,7 @@ SIGNATURES = {
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_fused_tail": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_net_set_residual_lds": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_upconv_phases": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
@@ -191,7 +192,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 107          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 108          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

@@ -30,7 +30,7 @@ def _sd(shapes, seed=0):
 
 # ------------------------------------------------------------------ single conv
 def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0,
-              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False, dilation=0, res1_is_input=False):
+              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False, dilation=0, res1_is_input=False, res1_from_lds=False):
     """x [N,C,Hs,Ws] fp16 (cpu), w [K,C,3,3] fp32.  Runs the HIP conv on blocked-NHWC slabs
     ([C/32][N*H*W][32]) and returns (NCHW fp32 result, raw output slab [groups,N,H,W,32]) on the cpu."""
     import innfer_amd.lib as L
@@ -58,6 +58,7 @@ def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2
     keep = [slab, d_packed, d_bias]
     if res1_is_input:       # residual 1 = the first K channels of the conv's own input slab (x5 * 0.2 + x of an RDB)
         a.d_res1, a.res1_group_stride, a.res1_scale = slab.data_ptr(), g_in, s1
+        a.res1_from_input = int(res1_from_lds)      # innfer_conv_args.res1_from_input: x from the conv's own staged LDS tiles (conv3x3_pc RLDS)
         res1 = None
     for name, r, sc in (("1", res1, s1), ("2", res2, s2)):
         if r is not None:
@@ -183,6 +184,29 @@ def test_conv_rdb_residual_aliasing_the_input_slab(dev, N, H, W, with_res2):
     assert (got - ref).abs().max().item() < 4e-3
     got2, _ = _run_conv(dev, x, w, b, K, act=0, res1=x[:, :K].contiguous(), s1=0.2, res2=r2, s2=0.2)
     assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("N,Cc,H,W,with_res2,rows", [(1, 192, 37, 70, False, None), (1, 192, 16, 32, True, None), (4, 192, 40, 40, True, None), (3, 192, 200, 200, False, None),
+                                                     (1, 192, 1, 1, True, None), (1, 96, 33, 65, False, None), (2, 128, 17, 31, True, None), (1, 192, 64, 40, True, (16, 48))])
+def test_conv_rdb_residual_from_lds(dev, N, Cc, H, W, with_res2, rows):
+    """The same launch with the residual taken from the conv's own staged LDS tiles (innfer_conv_args.res1_from_input, conv3x3_pc<.., TMF | 0x40000>;
+    innfer_net_set_residual_lds, the networks' default): chunk order 2, 3, .., 0, 1 and x / s1 added to the fp32 accumulators instead of fma(acc, s1, x) in
+    the epilogue -- against F.conv2d (<= 4e-3) and against the epilogue-load form to the last fp16 rounding; plain lattice, image canvas, one and two residuals,
+    a row range, 96 .. 192 input channels."""
+    from innfer_amd import synth
+    K = 64
+    x = torch.from_numpy(synth.uniform((N, Cc, H, W), 14, -1, 1)).half()
+    w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 15, -1, 1)) / np.sqrt(9 * Cc)
+    b = torch.from_numpy(synth.uniform((K,), 16, -1, 1))
+    r2 = torch.from_numpy(synth.uniform((N, K, H, W), 17, -1, 1)).half() if with_res2 else None
+    got, raw = _run_conv(dev, x, w, b, K, act=0, s1=0.2, res2=r2, s2=0.2, res1_is_input=True, res1_from_lds=True, rows=rows)
+    base, raw0 = _run_conv(dev, x, w, b, K, act=0, s1=0.2, res2=r2, s2=0.2, res1_is_input=True, rows=rows)
+    ref = _ref_conv(x, w, b, act=0, res1=x[:, :K], s1=0.2, res2=r2, s2=0.2)
+    sl = slice(*rows) if rows else slice(None)
+    assert (got[:, :, sl] - ref[:, :, sl]).abs().max().item() < 4e-3
+    _assert_same_to_the_last_rounding(got[:, :, sl], base[:, :, sl], "residual from LDS vs epilogue load")
+    if rows:                                    # rows outside the range keep the buffer's fill value in both forms
+        assert torch.equal(raw[:, :, :rows[0]], raw0[:, :, :rows[0]]) and torch.equal(raw[:, :, rows[1]:], raw0[:, :, rows[1]:])
 
 
 def test_conv_pixel_attention_gate_epilogue(dev):
@@ -1825,6 +1849,31 @@ def _assert_same_to_the_last_rounding(a, b, what=""):
     assert (d > 0).float().mean().item() < 0.05, (what, (d > 0).float().mean().item())
 
 
+def test_residual_from_lds_network_level(dev):
+    """innfer_net_set_residual_lds (default on): the whole RRDBNet with the dense blocks' residual taken from LDS against the epilogue-load schedule and the
+    oracle -- a single image, a batch on the image canvas, a ragged frame; both schedules inside the oracle bound (<= 1e-2), within 2e-3 of each other (the two
+    sums differ in the last fp32 bit per block; 2 x 3 dense blocks and the up-convs carry that to a few fp16 ulps), and each schedule deterministic."""
+    import oracle
+    from innfer_amd import synth
+    net, sd = _rrdb(dev, 2, 4, seed=5)
+    for i, shape in enumerate([(1, 3, 40, 56), (3, 3, 33, 47), (1, 3, 16, 32)]):
+        x = torch.from_numpy(synth.uniform(shape, 60 + i))
+        with torch.no_grad():
+            ref = oracle.rrdbnet_forward(sd, x, nb=2, scale=4)
+        net.residual_lds = True
+        y1 = net(x.to(dev).half())
+        assert torch.equal(y1, net(x.to(dev).half()))
+        net.residual_lds = False
+        y0 = net(x.to(dev).half())
+        net.residual_lds = True
+        e1, e0 = (y1.float().cpu() - ref).abs().max().item(), (y0.float().cpu() - ref).abs().max().item()
+        d = (y1.float() - y0.float()).abs().max().item()
+        print(f"residual from LDS {shape}: vs oracle {e1:.2e} (epilogue loads: {e0:.2e}), between the schedules {d:.2e}")
+        assert e1 < 1e-2 and e0 < 1e-2 and d < 2e-3, (shape, e1, e0, d)
+        if shape[0] > 1:                        # a batch equals its images' own forwards bit for bit (canvas form of the same kernel)
+            assert torch.equal(y1[1:2], net(x[1:2].to(dev).half()))
+
+
 def test_fused_tail_vs_two_launches_and_oracle(dev):
     """HR_conv0 -> conv_last as one kernel (conv3x3_pc<.., TMF | 0x20000>, innfer_net_set_fused_tail, the default) against the two-launch schedule and the
     oracle: HR frames of 1 x 1 ... 4 x 3 tiles of 16 x 32 pixels (tiles with neighbours on every side, rims on the frame border), batches, a scale-2
@@ -1924,6 +1973,7 @@ def test_full_frame_1080p_translation_property(dev):
     net.fused_tail = False            # the bit-for-bit properties below belong to the two-launch schedule: the fused tail sums a rim pixel in another order
     y = net(x)
     _assert_same_to_the_last_rounding(yf, y, "fused tail vs two launches, 1080p frame")
+    corners16 = {"top-left": yf[:, :, :128, :128].float().cpu(), "bottom-right": yf[:, :, -128:, -128:].float().cpu()}   # the DEFAULT path's values
     del yf
     assert tuple(y.shape) == (1, 3, 4320, 7680)
     assert torch.isfinite(y).all()
@@ -1954,6 +2004,20 @@ def test_full_frame_1080p_translation_property(dev):
     e32 = (y32[:, :, 4 * (cy - hw):4 * (cy + hw), 4 * (cx - hw):4 * (cx + hw)].cpu() - ref).abs()
     print(f"1080p frame, same window: fp32-accurate engine max {e32.max().item():.2e} mean {e32.mean().item():.2e}")
     assert e32.max().item() < 1e-4, e32.max().item()
+    # ... and the frame's BORDERS against the oracle: the 128 x 128 HR windows in the top-left and bottom-right corners, where the
+    # zero padding of every conv (block.py:163-166, 213-254) meets the tile lattice's first and last (partly filled) tiles.  The oracle runs on the
+    # (32 + R)^2 LR crop anchored AT the corner: it shares the frame's two borders there, its other two sides lie beyond the window's receptive radius.
+    for name, (rows, cols, win) in {"top-left": (slice(0, 32 + R), slice(0, 32 + R), (slice(0, 128), slice(0, 128))),
+                                    "bottom-right": (slice(1080 - 32 - R, 1080), slice(1920 - 32 - R, 1920), (slice(-128, None), slice(-128, None)))}.items():
+        with torch.no_grad():
+            cref = oracle.rrdbnet_forward(sd, x[:, :, rows, cols].float().cpu(), nb=23, scale=4)[:, :, win[0], win[1]]
+        c16 = (corners16[name] - cref).abs()
+        c32 = (y32[:, :, win[0], win[1]].cpu() - cref).abs()
+        print(f"1080p frame, {name} 128x128 HR corner vs oracle: fp16 engine max {c16.max().item():.2e} mean {c16.mean().item():.2e}; "
+              f"fp32-accurate engine max {c32.max().item():.2e}")
+        assert c16.max().item() < 1e-2, (name, c16.max().item())
+        assert _codes_within_one(dev, corners16[name].numpy(), cref.numpy()) >= 0.99, name
+        assert c32.max().item() < 1e-4, (name, c32.max().item())
     del y32
     net.release_workspace()
     torch.cuda.empty_cache()
