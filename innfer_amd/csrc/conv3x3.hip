@@ -1445,10 +1445,20 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 if (++c == p.nchunks) { c = 0; jt += slots; setup(jt); }
                 issue(c, (g + 1) & 1);
                 PCT(l1);
+#ifdef INNFER_ABLATE
+                // abl 32 (with 8: no MFMA phase): FREE-RUNNING loaders -- the ceiling of this kernel's own access pattern (piece shapes, halo tiles, slab
+                // stores) without the per-chunk coupling to the consumers: a loader waits only for the chunk issued BEFORE the one it has just issued (one
+                // chunk always in flight) and meets the consumers once per tile (profiles/r4/access_pattern_ceiling.txt)
+                if (p.abl & 32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KQ + KW - 2) : "memory");
+                else
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PCT(l2);
                 if (lw == 0) { PCACC(3, l1, l0); PCACC(4, l2, l1); }
             }
+#ifdef INNFER_ABLATE
+            if ((p.abl & 32) && (g + 1) % p.nchunks != 0) continue;          // free-running: one barrier per tile
+#endif
             PCT(l3);
             if constexpr (FUSE) {             // a tile's last chunk: the consumers' fused epilogue meets at two more barriers
                 if (++cc == p.nchunks) {
@@ -1942,6 +1952,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
         }
         PCT(c2);
+#ifdef INNFER_ABLATE
+        if ((p.abl & 32) && c != 0) continue;                              // free-running loaders: the consumers meet them once per tile (c was advanced above)
+#endif
         asm volatile("s_barrier" ::: "memory");
         PCT(c3);
         if (cw == 0) { PCACC(1, c2, c1); PCACC(2, c3, c2); PCACC(6, 1, 0); }

@@ -156,33 +156,38 @@ def tensor2np(img, rgb2bgr=True, remove_batch=True, data_range=255, denormalize=
 
 
 # ---------------------------------------------------------------- files (utils.py:36-133): the image loop's codec hand-off
+def _suffixes(extensions):
+    return tuple(extensions) if not isinstance(extensions, str) else (extensions,)
+
+
 def is_ext_file(filename, extensions=IMG_EXTENSIONS):
-    return any(filename.endswith(extension) for extension in extensions)
+    """True when the name ends in one of `extensions` (case-sensitive, as the reference's lists spell both cases: utils.py:36-37)."""
+    return os.fspath(filename).endswith(_suffixes(extensions))
 
 
 def scan_dir(path, extensions=IMG_EXTENSIONS):
+    """Every file below `path` whose name ends in one of `extensions`, ordered by (directory, name) -- the order of the reference's sorted walk
+    (utils.py:40-49), which is the order the image loop processes and numbers its outputs in."""
     if not osp.isdir(path):
         raise AssertionError(f'{path:s} is not a valid directory')
-    files_list = []
-    for dirpath, _, fnames in sorted(os.walk(path)):
-        for fname in sorted(fnames):
-            if is_ext_file(fname, extensions):
-                files_list.append(osp.join(dirpath, fname))
-    return files_list
+    suffixes = _suffixes(extensions)
+    hits = [(folder, name) for folder, _, names in os.walk(path) for name in names if name.endswith(suffixes)]
+    return [osp.join(folder, name) for folder, name in sorted(hits)]
+
+
+def _non_empty_scan(path, extensions, what):
+    found = scan_dir(path, extensions)
+    if not found:
+        raise AssertionError(f'{path:s} has no valid {what} file')
+    return found
 
 
 def get_models_paths(path):
-    models = scan_dir(path, MODEL_EXTENSIONS)
-    if not models:
-        raise AssertionError(f'{path:s} has no valid model file')
-    return models
+    return _non_empty_scan(path, MODEL_EXTENSIONS, 'model')
 
 
 def get_images_paths(path):
-    images = scan_dir(path, IMG_EXTENSIONS)
-    if not images:
-        raise AssertionError(f'{path:s} has no valid image file')
-    return images
+    return _non_empty_scan(path, IMG_EXTENSIONS, 'image')
 
 
 def read_img(path=None):
