@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 108
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -146,10 +146,12 @@ int innfer_net_set_band_rows(innfer_net_t net, int rows);
  * (profiles/r2/kernel_experiments.txt), hence the default. */
 int innfer_net_set_pair_convs(innfer_net_t net, int mode);
 
-/* The residual of a dense block's last conv (`x5 * 0.2 + x`, RRDBNet_arch.py:161-165) is that conv's own input channels 0..63.  on = 1 (default): the
+/* The residual of a dense block's last conv (`x5 * 0.2 + x`, RRDBNet_arch.py:161-165) is that conv's own input channels 0..63.  With the LDS form the
  * kernel stages those two channel groups LAST and adds x / 0.2 to the fp32 accumulators from the staged LDS tile; the epilogue scales by 0.2 -- x is not
- * read a second time (265 MB of a 1327 MB launch at 1080p).  The sum is formed in another order than fma(acc, 0.2, x) (fp32 either way): results agree
- * with on = 0 to the last rounding of the fp16 output, not bit for bit.  fp16 engine, nf = 64; everything else ignores the switch.  (108) */
+ * read a second time (265 MB of a 1327 MB launch at 1080p).  on = 1 (default): the last dense block of every RRDB, whose epilogue also adds the RRDB's own
+ * residual (RRDBNet_arch.py:98) -- the measured gain (-3.7 % on those launches; the one-residual launches lose 0.9 % with it); on = 2: every dense block;
+ * on = 0: epilogue loads everywhere.  The sum is formed in another order than fma(acc, 0.2, x) (fp32 either way): results agree across the settings to the
+ * last rounding of the fp16 output, not bit for bit.  fp16 engine, nf = 64; everything else ignores the switch.  (108) */
 int innfer_net_set_residual_lds(innfer_net_t net, int on);
 
 /* Scheduling knob: the last two convs of RRDBNet / SRResNet (HR_conv0 -> LeakyReLU -> conv_last, RRDBNet_arch.py:36-42) as ONE kernel -- the last conv
@@ -227,6 +229,11 @@ int innfer_pan_num_params(innfer_pan_t p);
 int innfer_pan_param_info(innfer_pan_t p, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
 int innfer_pan_set_param(innfer_pan_t p, int idx, const float* h_data);
 size_t innfer_pan_workspace_bytes(innfer_pan_t p, int N, int H, int W);
+/* Schedule of the SCPA trunk (PAN_arch.py:58-105).  on = 1 (default): a block is ONE launch -- conv1_a | conv1_b, k1, k3 * sigmoid(k2), k4, conv3 and the
+ * residual on a 16 x 32 pixel tile with a 2-pixel halo, intermediates in LDS / registers, the block's weights resident in LDS (csrc/pan_scpa.hip); on = 0:
+ * five launches of the halo-tile conv kernel per block (rounds 1-3).  Same fp16 roundings of every intermediate tensor; the fp32 sums of conv1 and conv3 are
+ * formed per 32-channel k-step in both, so results agree to the last rounding of the fp16 tensors.  (108) */
+int innfer_pan_set_fused_scpa(innfer_pan_t p, int on);
 /* d_in [N,in_nc,H,W] -> d_out [N,out_nc,scale*H,scale*W], NCHW f16/f32; H, W >= 4. */
 int innfer_pan_forward(innfer_pan_t p, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                        int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);

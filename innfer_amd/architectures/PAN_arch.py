@@ -22,5 +22,12 @@ class PAN(ParamEngineModule):
     def _fn(self, name):
         return super()._fn('create_ex' if name == 'create' else name)
 
+    fused_scpa = True        # innfer_pan_set_fused_scpa: an SCPA block as one launch (csrc/pan_scpa.hip); False: the five-launch schedule (A/B, parity tests)
+
+    def _forward_on_device(self, x):
+        from .. import lib as L
+        L.check(L.lib.innfer_pan_set_fused_scpa(self._handle, int(bool(self.fused_scpa))))
+        return super()._forward_on_device(x)
+
     def _out_shape(self, N, H, W):
         return (N, self.out_nc, H * self.scale, W * self.scale)

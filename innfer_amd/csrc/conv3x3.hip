@@ -2522,8 +2522,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 4 && L.stats_part) return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x11FF>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4 && L.res1_lds && L.res1 && L.res1 == L.in && L.res1_gstride == L.in_gstride && L.act == 0 && L.K == 64 && L.C >= 96 &&
-        !L.up && !L.reflect && L.s1 != 0.f) {
-        // the dense block's last conv: the residual is the conv's own input groups 0 and 1 -- taken from the live LDS stages (conv3x3_pc<.., TMF | 0x40000>)
+        !L.up && !L.reflect && L.s1 != 0.f && (L.res1_lds == 2 || L.res2)) {
+        // the dense block's last conv: the residual is the conv's own input groups 0 and 1 -- taken from the live LDS stages (conv3x3_pc<.., TMF | 0x40000>).
+        // res1_lds 1 (the networks' default): only where a SECOND residual follows (the last dense block of an RRDB) -- there the epilogue could not batch two
+        // residuals' loads beside the accumulators and ran 15 % behind the one-residual layers; with x from LDS it keeps ONE memory residual and batches it
+        // (0.4096 -> 0.3945 ms per launch at 1080p).  The one-residual layers' batched loads were L2 hits already hidden behind the tile's last MFMAs: the LDS
+        // form costs them +0.9 % (0.3574 -> 0.3607 ms), so they keep the epilogue load; res1_lds 2 forces the LDS form everywhere (profiles/r4/rlds_ab.txt).
         k.rs1 = 1.0f / L.s1;
         return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x401FF>(k, L.N, s);
     }

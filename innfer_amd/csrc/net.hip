@@ -115,7 +115,7 @@ struct innfer_net {
 #endif
     int up_phases = INNFER_UP_PHASES_DEFAULT;   // upconv_block convs as four 2x2-tap phases on the LR grid (innfer_net_set_upconv_phases; the macro: A/B builds)
     int fused_tail = 1;          // HR_conv0 -> conv_last as one kernel where the shapes allow it (innfer_net_set_fused_tail)
-    int res_lds = 1;             // the dense block's x5 * 0.2 + x with x taken from the conv's own staged LDS tiles (innfer_net_set_residual_lds; conv3x3_pc RLDS)
+    int res_lds = 1;             // the dense block's x5 * 0.2 + x with x taken from the conv's own staged LDS tiles (innfer_net_set_residual_lds; conv3x3_pc RLDS): 1 = where the RRDB's residual follows, 2 = every block
     int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
     int fp32 = 0;                // innfer_net_set_precision: 1 = fp32-accurate forward on split operands (conv3x3.hip SPLIT), the reference's -no_fp16 mode (run.py:345,421-422)
@@ -360,7 +360,8 @@ extern "C" int innfer_net_set_upconv_phases(innfer_net_t net, int on) {
 
 extern "C" int innfer_net_set_residual_lds(innfer_net_t net, int on) {
     if (!net) return set_error(INNFER_ERR_INVALID, "set_residual_lds: null network");
-    net->res_lds = on ? 1 : 0;
+    if (on < 0 || on > 2) return set_error(INNFER_ERR_INVALID, "set_residual_lds: 0 (epilogue loads), 1 (the RRDB-end layers: default) or 2 (every dense block)");
+    net->res_lds = on;
     return INNFER_OK;
 }
 
@@ -1021,7 +1022,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.res2 = (const f16*)a->d_res2; L.res2_gstride = a->res2_group_stride; L.s2 = a->res2_scale;
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
     L.out_mode = a->pixel_shuffle2 ? OUT_SHUFFLE2 : OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
-    L.res1_lds = a->res1_from_input ? 1 : 0;
+    L.res1_lds = a->res1_from_input ? 2 : 0;                 // (the single-conv call: wherever the shape qualifies, one residual or two)
     if (a->winograd) {
         if (a->pixel_shuffle2 || a->split || a->K % 32 || a->out_ch_off % 32 || (a->winograd != 1 && a->winograd != 2))
             return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (winograd): 1 | 2, K %% 32 == 0 (K=%d), whole output groups", a->K);

@@ -306,6 +306,8 @@ struct innfer_pan {
     std::vector<Param> params;
     std::vector<Gemm> gemms;
     std::vector<float*> d_vecs;      // device copies of bias vectors / gamma, by param index (nullptr if unused)
+    std::vector<void*> d_scpa;       // one weight blob per SCPA block (pan_scpa.hip), trunk by trunk
+    int fused_scpa = 1;              // an SCPA block as ONE launch (innfer_pan_set_fused_scpa); 0: the five halo-tile launches of rounds 1-3
     bool uploaded = false;
 };
 
@@ -364,7 +366,14 @@ extern "C" void innfer_pan_destroy(innfer_pan* p) {
     if (!p) return;
     for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
+    for (auto v : p->d_scpa) if (v) (void)hipFree(v);
     delete p;
+}
+
+extern "C" int innfer_pan_set_fused_scpa(innfer_pan* p, int on) {
+    if (!p) return set_error(INNFER_ERR_INVALID, "pan_set_fused_scpa: null network");
+    p->fused_scpa = on ? 1 : 0;
+    return INNFER_OK;
 }
 
 extern "C" int innfer_pan_num_params(innfer_pan* p) { return p ? (int)p->params.size() : INNFER_ERR_INVALID; }
@@ -512,6 +521,22 @@ int upload(innfer_pan* p) {
         INNFER_HIP(hipMalloc((void**)&g.d_w, panel.size() * sizeof(f16)));
         INNFER_HIP(hipMemcpy(g.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
     }
+    for (auto v : p->d_scpa) if (v) (void)hipFree(v);
+    p->d_scpa.clear();
+    {   // one blob per SCPA block for the fused launch (pan_scpa.hip): the block's eight tensors as MFMA fragments
+        std::vector<char> blob(pan_scpa_blob_bytes());
+        auto Wk = [p](const std::string& key) -> const float* { return p->params[find(p, key)].host.data(); };
+        for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k)
+            for (int b = 0; b < p->nb; ++b) {
+                const std::string s = "SCPA_trunk" + std::string(k ? "2" : "") + "." + std::to_string(b) + ".";
+                pan_scpa_pack(Wk(s + "conv1_a.weight"), Wk(s + "conv1_b.weight"), Wk(s + "k1.0.weight"), Wk(s + "PACnv.k2.weight"), Wk(s + "PACnv.k2.bias"),
+                              Wk(s + "PACnv.k3.weight"), Wk(s + "PACnv.k4.weight"), Wk(s + "conv3.weight"), blob.data());
+                void* d = nullptr;
+                INNFER_HIP(hipMalloc(&d, blob.size()));
+                p->d_scpa.push_back(d);
+                INNFER_HIP(hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice));
+            }
+    }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
     p->d_vecs.assign(p->params.size(), nullptr);
     for (size_t i = 0; i < p->params.size(); ++i) {
@@ -609,6 +634,13 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {
     for (int b = 0; b < p->nb; ++b) {
         f16* xn = (b & 1) ? XB : XA;
+        if (p->fused_scpa && (long)N * H * W * 64 + 2 * G < 0x7fffffffL) {          // the whole block in one launch (pan_scpa.hip)
+            GtScope gt(s, "pan_scpa_fused (one SCPA block)", 2.0 * (2 * 20 * 40 + 3 * 9 * 20 * 20 + 20 * 20 + 40 * 40) * (double)px, 4.0 * 40 * (double)px + 28800.0);
+            CK(pan_scpa_launch(x, xn, G, p->d_scpa[(size_t)k * p->nb + b], N, H, W, s));
+            gi += 5;
+            x = xn;
+            continue;
+        }
         CK(conv3(x, G, H, W, 0, 1, nullptr, 0, AB, G));                               // lrelu([conv1_a | . | conv1_b]): a -> group 0, b -> group 1
         CK(conv3(AB, G, H, W, 0, 1, nullptr, 0, AB2, G));                             // lrelu(k1(a)) -> cat group 0
         CK(conv3(AB + G, G, H, W, 0, 7, nullptr, 0, K3Y, G));                         // y = k3(b) * sigmoid(k2(b) + bias): one conv, pair-gate epilogue

@@ -1,0 +1,377 @@
+// One SCPA block of PAN (reference architectures/PAN_arch.py:58-105) as ONE launch: x -> x + conv3(cat[lrelu(k1(lrelu(conv1_a x))),
+// lrelu(k4(k3(b) * sigmoid(k2(b) + bias)))]), b = lrelu(conv1_b x), without leaving the CU.
+//
+// Until round 4 a block was five launches of the SR path's halo-tile kernel with four HBM round trips of 32-channel-padded slabs (16 slab
+// groups moved per block for 4 that carry the block's input and output); at 20 / 40 channels those launches are bound by their loads and
+// stores and by launch latency, never by the matrix pipe (DESIGN: PAN).  Here a persistent workgroup (8 waves, one per CU, the whole LDS)
+// owns a 16 x 32 pixel tile:
+//   X   (20 x 36 halo pixels x 40 channels, 80 B per pixel)  global -> LDS by LDS-DMA, out-of-image pixels zero-filled by the buffer range
+//       check (= the zero padding of every conv of the block: conv1_a/b have no bias, so A and B are zero wherever x is)
+//   P1  A | B = lrelu(conv1_a | conv1_b (x)) on the whole halo tile        -> LDS (20 real channels in 48 B per pixel)
+//   P2a a' = lrelu(k1(A)) on the tile's 512 pixels                         -> registers: the MFMA result of a 32-row panel whose rows are permuted
+//       like the SR kernel's (a lane ends with 8 consecutive channels of its pixel) IS the B operand of the 1x1 conv3
+//   P2b Y = k3(B) * sigmoid(k2(B) + bias) on the 18 x 36 middle region, zero outside the image (k4's zero padding)   -> LDS (over A)
+//   P3  b' = lrelu(k4(Y)); out = conv3(a' | b') + x  (x from the X tile, held in registers since P1)               -> global slab
+// The block's weights (28.8 KB of fp16 values, 34 KB as MFMA A fragments without their all-zero rows / k-octets) stay in LDS for the whole
+// launch; the next tile's X is fetched while P2 / P3 run.  Arithmetic per value as in the five-launch schedule: fp16 operands, fp32
+// accumulation, A / B / Y / a' / b' rounded to fp16 where that schedule stored them -- the same roundings, different summation order of the
+// MFMA k-steps only where a conv's taps are walked in another order (none: taps in (dy, dx) order, one k-step per tap).
+#include "common.h"
+
+namespace innfer {
+
+namespace {
+
+constexpr int TW = 32, HC = TW + 4;
+constexpr int r2(int t) { return t ? 8 : 12; }          // real rows of 16-row tile t of a 32-row (20-channel) panel: row rho <-> channel 8 (rho >> 2) + 4 t + (rho & 3)
+constexpr int r4(int t) { return t < 2 ? 12 : 8; }      // ... of a 64-row (40-channel) panel: row rho <-> channel 16 (rho >> 2) + 4 t + (rho & 3)
+// compact weight blob (bytes): only real rows, only k-octets that can be non-zero
+constexpr int C1_ROW = 5 * 16, K_ROW = 3 * 16, C3_ROW = 6 * 16;
+constexpr int OFF_C1A = 0, C1_T1 = 12 * C1_ROW, C1_SIZE = 20 * C1_ROW;            // conv1_a: [t][row][oct 0..3 = k-step 0, oct 4 = k 32..39]
+constexpr int OFF_C1B = OFF_C1A + C1_SIZE;
+constexpr int K_T1 = 12 * K_ROW, K_TAP = 20 * K_ROW;                              // a 20 -> 20 conv: [tap][t][row][oct 0..2]
+constexpr int OFF_K1 = OFF_C1B + C1_SIZE, OFF_K3 = OFF_K1 + 9 * K_TAP, OFF_K4 = OFF_K3 + 9 * K_TAP, OFF_K2 = OFF_K4 + 9 * K_TAP;
+constexpr int OFF_C3 = OFF_K2 + K_TAP;                                             // conv3: [t 0..3][row][oct 0..2 = a', 3..5 = b']
+constexpr int c3_t(int t) { return (t < 2 ? t * 12 : 24 + (t - 2) * 8) * C3_ROW; }
+constexpr int OFF_B2 = OFF_C3 + 40 * C3_ROW;                                       // k2's bias: 32 floats by channel (20 real)
+constexpr int W_BYTES = OFF_B2 + 128;
+static_assert(W_BYTES == 34048, "blob layout");
+
+struct ScpaKP {
+    const f16* in; f16* out; long G;        // slabs of two 32-channel groups (40 real channels), group stride G elements
+    const char* w;                          // the block's blob (W_BYTES)
+    int N, H, W, tiles_x, tiles_y, total;
+};
+
+__device__ __forceinline__ f16x8 ldz(const char* p, bool ok) {
+    f16x8 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    if (ok) z = *(const f16x8*)p;
+    return z;
+}
+
+__device__ __forceinline__ f16x8 lrelu8(const f32x4& a, const f32x4& b) {
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = (f16)(a[j] > 0.f ? a[j] : 0.2f * a[j]);
+        v[4 + j] = (f16)(b[j] > 0.f ? b[j] : 0.2f * b[j]);
+    }
+    return v;
+}
+
+template <int TH>
+__global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
+    constexpr int HR = TH + 4, NPX = HR * HC;
+    static_assert(NPX % 16 == 0 && TH % 4 == 0, "whole 16-pixel MFMA tiles");
+    constexpr int NP1 = NPX / 16;                           // conv1's pixel tiles: the whole halo region
+    constexpr int NMID = ((TH + 2) * HC + 15) / 16;         // Y's pixel tiles: rows 1 .. TH + 2, every column
+    constexpr int PW = TH / 4;                              // output pixel tiles (16 px) per wave: TH rows x 2 segments over 8 waves
+    constexpr int XQ = (NPX * 5 + 63) / 64;                 // 1-KiB LDS-DMA pieces of an X tile
+    constexpr int KQ = (XQ + 7) / 8;
+    constexpr int XOFF = (W_BYTES + 1023) / 1024 * 1024, AOFF = XOFF + XQ * 1024, BOFF = AOFF + NPX * 48;
+    static_assert(BOFF + NPX * 48 + 1024 <= 160 * 1024, "LDS");
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const WL = smem;
+    char* const X = smem + XOFF;
+    char* const A = smem + AOFF;                            // A, then Y
+    char* const B = smem + BOFF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+
+    // the XCD's workgroups (blocks b, b + 8, ..) walk that XCD's contiguous run of the tile list: halos meet in one L2
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int run_q = p.total >> 3, run_r = p.total & 7;
+    const int run_start = xcd < run_r ? xcd * (run_q + 1) : run_r * (run_q + 1) + (xcd - run_r) * run_q;
+    const int run_len = run_q + (xcd < run_r ? 1 : 0);
+    const int slots = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int j0 = bid >> 3;
+    if (j0 >= run_len) return;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const long gbytes = p.G * 2;
+
+    // per-lane source offsets of this wave's X pieces relative to the tile's first halo pixel (group 0): slot i = piece * 64 + lane -> pixel i / 5, 16-byte
+    // part i % 5 (0..3: channels 0..31 of group 0; 4: channels 32..39 = the first 16 bytes of group 1)
+    int loff[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int i = (wave + 8 * k) * 64 + lane, P = i / 5, s = i - 5 * P, r = P / HC, c = P - r * HC;
+        loff[k] = (wave + 8 * k < XQ && P < NPX) ? (r * p.W + c) * 64 + (s < 4 ? s * 16 : (int)gbytes) : OOB;
+    }
+    auto decode = [&](int j, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
+        int t = run_start + j;
+        n = t / per_img; t -= n * per_img;
+        const int ty = t / p.tiles_x;
+        ty0 = ty * TH; tx0 = (t - ty * p.tiles_x) * TW;
+    };
+    auto fetch = [&](int j) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        int n, ty0, tx0;
+        decode(j, n, ty0, tx0);
+        const char* src = (const char*)(p.in + (long)n * p.H * p.W * 32) + ((long)(ty0 - 2) * p.W + (tx0 - 2)) * 64;
+        const bool edge = ty0 < 2 || ty0 + TH + 2 > p.H || tx0 < 2 || tx0 + TW + 2 > p.W;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int q = wave + 8 * k;
+            int vo = loff[k];
+            if (edge) {
+                const int i = q * 64 + lane, P = i / 5, r = P / HC, c = P - r * HC;
+                const int y = ty0 - 2 + r, x = tx0 - 2 + c;
+                if (y < 0 || y >= p.H || x < 0 || x >= p.W) vo = OOB;
+            }
+            if (q < XQ) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(X + q * 1024), 16, vo, 0, 0, 0);
+        }
+#else
+        (void)j;
+#endif
+    };
+
+    fetch(j0);
+    for (int i = tid; i < W_BYTES / 16; i += 512) *(f16x8*)(WL + i * 16) = *(const f16x8*)(p.w + i * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int j = j0; j < run_len; j += slots) {
+        int n, ty0, tx0;
+        decode(j, n, ty0, tx0);
+        // ---------------- P1: A | B = lrelu(conv1_a | conv1_b (x)) over the halo tile ----------------
+        f16x8 res[PW][2];
+        {
+            f16x8 wa[2][2], wb[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const char* ba = WL + OFF_C1A + (t ? C1_T1 : 0) + li * C1_ROW;
+                const char* bb = WL + OFF_C1B + (t ? C1_T1 : 0) + li * C1_ROW;
+                wa[t][0] = ldz(ba + lg * 16, li < r2(t)); wa[t][1] = ldz(ba + 64, li < r2(t) && lg == 0);
+                wb[t][0] = ldz(bb + lg * 16, li < r2(t)); wb[t][1] = ldz(bb + 64, li < r2(t) && lg == 0);
+            }
+            for (int i = wave; i < NP1; i += 8) {
+                const int P = 16 * i + li;
+                const f16x8 b0 = *(const f16x8*)(X + P * 80 + lg * 16);
+                const f16x8 b1 = ldz(X + P * 80 + 64, lg == 0);
+                f32x4 ca[2], cb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], b0, z4, 0, 0, 0);
+                    ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], b1, ca[t], 0, 0, 0);
+                    cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][0], b0, z4, 0, 0, 0);
+                    cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][1], b1, cb[t], 0, 0, 0);
+                }
+                if (lg < 3) {
+                    *(f16x8*)(A + P * 48 + lg * 16) = lrelu8(ca[0], ca[1]);
+                    *(f16x8*)(B + P * 48 + lg * 16) = lrelu8(cb[0], cb[1]);
+                }
+            }
+            // the residual x of this wave's output pixels, in conv3's result layout (a lane: channels 16 lg .. 16 lg + 15 of pixel li), before X is re-used
+#pragma unroll
+            for (int u = 0; u < PW; ++u) {
+                const int q = PW * wave + u, P = ((q >> 1) + 2) * HC + 2 + (q & 1) * 16 + li;
+                res[u][0] = ldz(X + P * 80 + (lg < 2 ? 2 * lg : 4) * 16, lg < 3);
+                res[u][1] = ldz(X + P * 80 + (2 * lg + 1) * 16, lg < 2);
+            }
+        }
+        __syncthreads();
+        if (j + slots < run_len) fetch(j + slots);                 // the next tile's X lands while P2 / P3 run
+        // ---------------- P2a: a' = lrelu(k1(A)) on the tile's own pixels (registers) ----------------
+        f16x8 ap[PW];
+        {
+            f16x8 wk[9][2];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    wk[tap][t] = ldz(WL + OFF_K1 + tap * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+#pragma unroll
+            for (int u = 0; u < PW; ++u) {
+                const int q = PW * wave + u, P = ((q >> 1) + 2) * HC + 2 + (q & 1) * 16 + li;
+                f32x4 c0 = z4, c1 = z4;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const f16x8 b = ldz(A + (P + (tap / 3 - 1) * HC + (tap % 3 - 1)) * 48 + lg * 16, lg < 3);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][0], b, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][1], b, c1, 0, 0, 0);
+                }
+                ap[u] = lrelu8(c0, c1);
+            }
+        }
+        __syncthreads();                                            // every wave has read A: Y may take its place
+        // ---------------- P2b: Y = k3(B) * sigmoid(k2(B) + bias) on rows 1 .. TH + 2, zero outside the image ----------------
+        {
+            f16x8 wk[9][2], w2[2];
+            f32x4 bk[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    wk[tap][t] = ldz(WL + OFF_K3 + tap * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+                w2[t] = ldz(WL + OFF_K2 + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+                bk[t] = *(const f32x4*)(WL + OFF_B2 + (8 * lg + 4 * t) * 4);
+            }
+            for (int i = wave; i < NMID; i += 8) {
+                const int P = HC + 16 * i + li;
+                f32x4 c0 = z4, c1 = z4, g0 = bk[0], g1 = bk[1];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const f16x8 b = ldz(B + (P + (tap / 3 - 1) * HC + (tap % 3 - 1)) * 48 + lg * 16, lg < 3);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][0], b, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][1], b, c1, 0, 0, 0);
+                    if (tap == 4) {
+                        g0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[0], b, g0, 0, 0, 0);
+                        g1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[1], b, g1, 0, 0, 0);
+                    }
+                }
+                const int r = P / HC, c = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + c;
+                const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
+                f16x8 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (f16)(inside ? c0[e] * (1.0f / (1.0f + expf(-g0[e]))) : 0.f);
+                    v[4 + e] = (f16)(inside ? c1[e] * (1.0f / (1.0f + expf(-g1[e]))) : 0.f);
+                }
+                if (lg < 3 && P < NPX) *(f16x8*)(A + P * 48 + lg * 16) = v;
+            }
+        }
+        __syncthreads();
+        // ---------------- P3: b' = lrelu(k4(Y)); out = conv3(a' | b') + x ----------------
+        {
+            f16x8 wk[9][2], w3[4][2];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    wk[tap][t] = ldz(WL + OFF_K4 + tap * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    w3[t][ks] = ldz(WL + OFF_C3 + c3_t(t) + (li * 6 + ks * 3 + lg) * 16, li < r4(t) && lg < 3);
+#pragma unroll
+            for (int u = 0; u < PW; ++u) {
+                const int q = PW * wave + u, row = q >> 1, col = (q & 1) * 16 + li, P = (row + 2) * HC + 2 + col;
+                f32x4 c0 = z4, c1 = z4;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const f16x8 b = ldz(A + (P + (tap / 3 - 1) * HC + (tap % 3 - 1)) * 48 + lg * 16, lg < 3);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][0], b, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][1], b, c1, 0, 0, 0);
+                }
+                const f16x8 bp = lrelu8(c0, c1);
+                f32x4 d[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[t][0], ap[u], z4, 0, 0, 0);
+                    d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[t][1], bp, d[t], 0, 0, 0);
+                }
+                const int y = ty0 + row, x = tx0 + col;
+                if (y < p.H && x < p.W) {
+                    f16x8 o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o0[e] = (f16)(d[0][e] + (float)res[u][0][e]); o0[4 + e] = (f16)(d[1][e] + (float)res[u][0][4 + e]);
+                        o1[e] = (f16)(d[2][e] + (float)res[u][1][e]); o1[4 + e] = (f16)(d[3][e] + (float)res[u][1][4 + e]);
+                    }
+                    f16* o = p.out + (lg >> 1) * p.G + (((long)n * p.H + y) * p.W + x) * 32 + (lg & 1) * 16;
+                    *(f16x8*)o = o0;
+                    *(f16x8*)(o + 8) = o1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next X has landed (and this tile's stores have left)
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+size_t pan_scpa_blob_bytes() { return W_BYTES; }
+
+// conv1_a / conv1_b [20][40], k1 / k3 / k4 [20][20][3][3], k2 [20][20] + bias [20], conv3 [40][40] (torch layouts, fp32) -> the kernel's blob
+void pan_scpa_pack(const float* c1a, const float* c1b, const float* k1, const float* k2, const float* k2b, const float* k3, const float* k4, const float* c3, void* blob) {
+    char* w = (char*)blob;
+    for (int i = 0; i < W_BYTES; ++i) w[i] = 0;
+    auto put = [&](int off, int e, float v) { ((f16*)(w + off))[e] = (f16)v; };
+    for (int part = 0; part < 2; ++part) {
+        const float* src = part ? c1b : c1a;
+        for (int t = 0; t < 2; ++t)
+            for (int rho = 0; rho < r2(t); ++rho) {
+                const int co = 8 * (rho >> 2) + 4 * t + (rho & 3);
+                for (int oct = 0; oct < 5; ++oct)
+                    for (int e = 0; e < 8; ++e)
+                        put((part ? OFF_C1B : OFF_C1A) + (t ? C1_T1 : 0) + rho * C1_ROW + oct * 16, e, src[co * 40 + oct * 8 + e]);
+            }
+    }
+    const float* ks[3] = {k1, k3, k4};
+    const int offs[3] = {OFF_K1, OFF_K3, OFF_K4};
+    for (int c = 0; c < 3; ++c)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int t = 0; t < 2; ++t)
+                for (int rho = 0; rho < r2(t); ++rho) {
+                    const int co = 8 * (rho >> 2) + 4 * t + (rho & 3);
+                    for (int oct = 0; oct < 3; ++oct)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = oct * 8 + e;
+                            put(offs[c] + tap * K_TAP + (t ? K_T1 : 0) + rho * K_ROW + oct * 16, e, ci < 20 ? ks[c][(co * 20 + ci) * 9 + tap] : 0.f);
+                        }
+                }
+    for (int t = 0; t < 2; ++t)
+        for (int rho = 0; rho < r2(t); ++rho) {
+            const int co = 8 * (rho >> 2) + 4 * t + (rho & 3);
+            for (int oct = 0; oct < 3; ++oct)
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = oct * 8 + e;
+                    put(OFF_K2 + (t ? K_T1 : 0) + rho * K_ROW + oct * 16, e, ci < 20 ? k2[co * 20 + ci] : 0.f);
+                }
+        }
+    for (int t = 0; t < 4; ++t)
+        for (int rho = 0; rho < r4(t); ++rho) {
+            const int co = 16 * (rho >> 2) + 4 * t + (rho & 3);
+            for (int oct = 0; oct < 6; ++oct)
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = (oct % 3) * 8 + e;                           // a' (octets 0..2) | b' (octets 3..5): cat[a, b] = input channels 0..19 | 20..39
+                    put(OFF_C3 + c3_t(t) + rho * C3_ROW + oct * 16, e, ci < 20 ? c3[co * 40 + (oct / 3) * 20 + ci] : 0.f);
+                }
+        }
+    for (int c = 0; c < 20; ++c) ((float*)(w + OFF_B2))[c] = k2b[c];
+}
+
+static int scpa_num_cus() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    static int cached[64] = {};
+    if (!cached[dev & 63]) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev & 63] = v;
+    }
+    return cached[dev & 63];
+}
+
+int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s) {
+    const int num_cus = scpa_num_cus();
+    constexpr int TH = 16;
+    constexpr int LDS = 160 * 1024;
+    static unsigned long long attr_done = 0;                // function attributes belong to the device's copy of the code object
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_done & bit)) {
+            INNFER_HIP(hipFuncSetAttribute((const void*)pan_scpa_fused<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr_done |= bit;
+        }
+    }
+    if ((long)N * H * W * 64 + 2 * G >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "pan_scpa: slab too large for 32-bit buffer offsets");
+    ScpaKP k{};
+    k.in = in; k.out = out; k.G = G; k.w = (const char*)d_blob; k.N = N; k.H = H; k.W = W;
+    k.tiles_x = (W + TW - 1) / TW; k.tiles_y = (H + TH - 1) / TH;
+    const long total = (long)N * k.tiles_x * k.tiles_y;
+    if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "pan_scpa: grid too large");
+    k.total = (int)total;
+    const int grid = total < num_cus ? (int)total : num_cus;
+    hipLaunchKernelGGL(pan_scpa_fused<TH>, dim3(grid), dim3(512), LDS, s, k);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+}  // namespace innfer

@@ -1439,6 +1439,41 @@ def test_pan_golden(dev, golden):
     assert np.array_equal(yab[1:2], net(xb).float().cpu().numpy())
 
 
+def test_pan_fused_scpa_vs_five_launches_and_oracle(dev):
+    """An SCPA block as ONE launch (csrc/pan_scpa.hip, innfer_pan_set_fused_scpa, the default) against the five-launch schedule of rounds 1-3 and the oracle:
+    frames smaller than a 16 x 32 tile, ragged frames with tiles on every border, whole tiles, batches (images are independent: bit-equal to their own
+    forwards), a 200 x 200 chop tile.  Both schedules round the same intermediate tensors to fp16; the 3 x 3 convs add their taps in another order."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config({"type": "pan", "nb": 4}, 4))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = _sd(shapes, 41)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    for i, shape in enumerate([(1, 3, 5, 7), (1, 3, 16, 32), (1, 3, 33, 65), (3, 3, 21, 37), (1, 3, 50, 70), (2, 3, 64, 96), (1, 3, 200, 200)]):
+        x = torch.from_numpy(synth.uniform(shape, 300 + i))
+        with torch.no_grad():
+            ref = oracle.pan_forward(sd, x, nb=4, scale=4)
+        net.fused_scpa = True
+        y1 = net(x.to(dev).half())
+        assert torch.equal(y1, net(x.to(dev).half()))
+        if shape[0] > 1:
+            assert torch.equal(y1[-1:], net(x[-1:].to(dev).half()))
+        net._ws.fill_(0xFF)                                             # every byte read was written by this forward
+        assert torch.equal(y1, net(x.to(dev).half()))
+        net.fused_scpa = False
+        y0 = net(x.to(dev).half())
+        net.fused_scpa = True
+        e1, e0 = (y1.float().cpu() - ref).abs(), (y0.float().cpu() - ref).abs()
+        d = (y1.float() - y0.float()).abs().max().item()
+        print(f"PAN fused SCPA {shape}: vs oracle max {e1.max().item():.2e} mean {e1.mean().item():.2e} (five launches: {e0.max().item():.2e} / {e0.mean().item():.2e}); "
+              f"between the schedules {d:.2e}")
+        bound = 1e-2 * max(1.0, ref.abs().max().item())
+        assert e1.max().item() < bound and e1.mean().item() < 1.5e-3 and e0.max().item() < bound and d < 4e-3, (shape, e1.max().item(), e0.max().item(), d)
+
+
 def test_pan_constructor_variants_golden(dev, golden):
     """PAN(self_attention=False), PAN(double_scpa=True) and both at 2x (PAN_arch.py:115-141,193-203) against the reference (G18): same
     parameter names in the same order, outputs within the PAN tolerance."""
@@ -1860,18 +1895,18 @@ def test_residual_from_lds_network_level(dev):
         x = torch.from_numpy(synth.uniform(shape, 60 + i))
         with torch.no_grad():
             ref = oracle.rrdbnet_forward(sd, x, nb=2, scale=4)
-        net.residual_lds = True
-        y1 = net(x.to(dev).half())
-        assert torch.equal(y1, net(x.to(dev).half()))
-        net.residual_lds = False
-        y0 = net(x.to(dev).half())
-        net.residual_lds = True
-        e1, e0 = (y1.float().cpu() - ref).abs().max().item(), (y0.float().cpu() - ref).abs().max().item()
-        d = (y1.float() - y0.float()).abs().max().item()
-        print(f"residual from LDS {shape}: vs oracle {e1:.2e} (epilogue loads: {e0:.2e}), between the schedules {d:.2e}")
-        assert e1 < 1e-2 and e0 < 1e-2 and d < 2e-3, (shape, e1, e0, d)
-        if shape[0] > 1:                        # a batch equals its images' own forwards bit for bit (canvas form of the same kernel)
-            assert torch.equal(y1[1:2], net(x[1:2].to(dev).half()))
+        ys = {}
+        for mode in (2, 1, 0):                  # every dense block / the RRDB-end blocks (the default) / epilogue loads
+            net.residual_lds = mode
+            ys[mode] = net(x.to(dev).half())
+            assert torch.equal(ys[mode], net(x.to(dev).half()))
+            if shape[0] > 1:                    # a batch equals its images' own forwards bit for bit (canvas form of the same kernel)
+                assert torch.equal(ys[mode][1:2], net(x[1:2].to(dev).half()))
+        net.residual_lds = 1
+        e = {m: (y.float().cpu() - ref).abs().max().item() for m, y in ys.items()}
+        d = max((ys[2].float() - ys[0].float()).abs().max().item(), (ys[1].float() - ys[0].float()).abs().max().item())
+        print(f"residual from LDS {shape}: vs oracle {e[2]:.2e} / {e[1]:.2e} (epilogue loads: {e[0]:.2e}), between the schedules {d:.2e}")
+        assert max(e.values()) < 1e-2 and d < 2e-3, (shape, e, d)
 
 
 def test_fused_tail_vs_two_launches_and_oracle(dev):
