@@ -28,6 +28,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                  bounded sample (rank 0, in a child process that never touches a GPU; at every N).
   chop8k       : BASELINE config 3 (8K input through chop_forward, 3268 tiles) -- 1 warm-up + 1 timed pass on the same ranks
   unet64       : BASELINE config 5 (pix2pix UNet_256 on 64x3x256x256), N == 1 only
+  pan540       : PAN 4x on a 1x3x540x960 frame (north_star's third conv stack), N == 1 only
 """
 import argparse
 import ctypes as C
@@ -318,6 +319,51 @@ def unet64_object(dev, reps=50, windows=7, warm_s=0.6):
            "ms_per_step_max": round(max(win), 4), "ms_per_step_windows": [round(w, 4) for w in win],
            "value": round(64 / ms * 1e3, 1), "unit": "img/s",
            "model_tflops": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4)}
+    per = unet_per_kernel(net, x)
+    if per:
+        out["hip_event_sum_ms"] = round(sum(e["ms_total"] for e in per.values()), 4)
+        out["per_kernel"] = per
+    net.release_workspace()
+    return out
+
+
+def pan540_object(dev, reps=20, windows=7, warm_s=0.5):
+    """SURVEY 8a row a12 / north_star "RRDB/SRResNet/PAN stacks": PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA self-attention; utils/defaults.py:78-89) on one
+    1 x 3 x 540 x 960 frame, fp16, synthetic weights, un-tiled.  Timed like unet64 (warm-up by time, median of `windows` windows of `reps` forwards between HIP
+    events); per-kernel two-roof entries from the library's launch timer.  Algorithmic work 488 952 MAC per input pixel (probed)."""
+    import torch
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config("pan", 4))
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    H, W = 540, 960
+    x = torch.from_numpy(synth.uniform((1, 3, H, W), 3)).to(dev).half()
+    n_warm, t0 = 0, time.perf_counter()
+    while n_warm < 20 or time.perf_counter() - t0 < warm_s:
+        for _ in range(5):
+            net(x)
+        torch.cuda.synchronize()
+        n_warm += 5
+    win = []
+    for _ in range(windows):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            net(x)
+        e1.record()
+        torch.cuda.synchronize()
+        win.append(e0.elapsed_time(e1) / reps)
+    ms = sorted(win)[len(win) // 2]
+    fl = 2.0 * 488952 * H * W
+    out = {"workload": "PAN 4x (nf 40, unf 24, 16 SCPA blocks, FSA), 1x3x540x960 -> 1x3x2160x3840 fp16, un-tiled (SURVEY 8a row a12)",
+           "steps": reps, "windows": windows, "warmup": n_warm, "ms_per_step": round(ms, 4), "ms_per_step_min": round(min(win), 4), "ms_per_step_max": round(max(win), 4),
+           "value": round(16 * H * W / ms / 1e3, 1), "unit": "output MPix/s", "model_tflops": round(fl / ms / 1e9, 1),
+           "frac_of_mfma_peak": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
+           "compulsory_hbm_note": "3 x 2 B in + 3 x 2 B x 16 out per input pixel = 0.05 GB per frame: this network is bound by its 40- / 24-channel intermediates, "
+                                  "which the five-launch SCPA schedule moved 16 slab groups per block and the one-launch schedule moves 4 (DESIGN: PAN)"}
     per = unet_per_kernel(net, x)
     if per:
         out["hip_event_sum_ms"] = round(sum(e["ms_total"] for e in per.values()), 4)
@@ -697,6 +743,14 @@ def main():
             line["unet64"] = unet64_object(dev)
         except Exception as e:                      # a side object must never cost the headline line
             line["unet64"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # ---- north_star's third stack: PAN 4x on a 540 x 960 frame (one GPU) ----
+    if not args.no_extras and world == 1:
+        log('pan540')
+        try:
+            line["pan540"] = pan540_object(dev)
+        except Exception as e:                      # a side object must never cost the headline line
+            line["pan540"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         if not args.no_cpu_baseline:

@@ -232,7 +232,9 @@ size_t innfer_pan_workspace_bytes(innfer_pan_t p, int N, int H, int W);
 /* Schedule of the SCPA trunk (PAN_arch.py:58-105).  on = 1 (default): a block is ONE launch -- conv1_a | conv1_b, k1, k3 * sigmoid(k2), k4, conv3 and the
  * residual on a 16 x 32 pixel tile with a 2-pixel halo, intermediates in LDS / registers, the block's weights resident in LDS (csrc/pan_scpa.hip); on = 0:
  * five launches of the halo-tile conv kernel per block (rounds 1-3).  Same fp16 roundings of every intermediate tensor; the fp32 sums of conv1 and conv3 are
- * formed per 32-channel k-step in both, so results agree to the last rounding of the fp16 tensors.  (108) */
+ * formed per 32-channel k-step in both, so results agree to the last rounding of the fp16 tensors.  on != 0 also moves the FSA block's attention
+ * (softmax(f^T g) h over the pooled pixels, block.py:398-473) from the VALU kernel to the matrix cores: scores from fp16 (hi, lo) pairs -- fp32-accurate --,
+ * exact row maxima, exp and sums in fp32, p and h as fp16 operands of the P V product; on = 2 keeps the VALU attention behind the fused blocks.  (108) */
 int innfer_pan_set_fused_scpa(innfer_pan_t p, int on);
 /* d_in [N,in_nc,H,W] -> d_out [N,out_nc,scale*H,scale*W], NCHW f16/f32; H, W >= 4. */
 int innfer_pan_forward(innfer_pan_t p, const void* d_in, int in_dtype, void* d_out, int out_dtype,

@@ -22,11 +22,12 @@ class PAN(ParamEngineModule):
     def _fn(self, name):
         return super()._fn('create_ex' if name == 'create' else name)
 
-    fused_scpa = True        # innfer_pan_set_fused_scpa: an SCPA block as one launch (csrc/pan_scpa.hip); False: the five-launch schedule (A/B, parity tests)
+    fused_scpa = True        # innfer_pan_set_fused_scpa: 1 / True = an SCPA block as one launch (csrc/pan_scpa.hip) + the FSA attention on the matrix cores; 0 / False: the
+                             # five-launch blocks and the VALU attention of rounds 1-3; 2: the fused blocks with the VALU attention (A/B, parity tests)
 
     def _forward_on_device(self, x):
         from .. import lib as L
-        L.check(L.lib.innfer_pan_set_fused_scpa(self._handle, int(bool(self.fused_scpa))))
+        L.check(L.lib.innfer_pan_set_fused_scpa(self._handle, int(self.fused_scpa)))
         return super()._forward_on_device(x)
 
     def _out_shape(self, N, H, W):

@@ -93,6 +93,8 @@ struct ConvLaunch {
     int split;                                    // fp32-accurate mode: every tensor is a (hi, lo) pair of fp16 slabs, lo = fp16((x - hi) * 2^11) (conv3x3.hip, SPLIT); panels from
     long in_lo, out_lo, res1_lo, res2_lo;         // conv_pack_split / conv_pack_1x1_split; *_lo: distance (elements) from a hi slab to its lo twin.  Plain 3x3 / 1x1 slab convs
                                                   // (act 0..2, residuals, upsampled input, batches) and the planar last conv
+    const f16* gate_w; const float* gate_bias;    // != nullptr (32-output slab convs): out = act(v * sigmoid(W v + b)) with v = fp16(conv + bias) -- PAN's pixel attention behind an up-conv
+                                                  // as this conv's epilogue; panels from conv_pack_selfgate (2 KB), 32 biases; `act` is the activation AFTER the gate
     int res1_lds;                                 // 1: when res1 is the conv's own input (groups 0, 1: the dense block's x5 * 0.2 + x), act 0 and K = 64, take it from the staged LDS tiles
                                                   // (conv3x3_pc RLDS: chunk order 2, 3, .., 0, 1; the residual enters the fp32 accumulators as x / s1) instead of re-reading it in the epilogue
     int wino;                                     // experiment: 1 = Winograd F(2,3) along the rows (panels from conv_pack_wino), 2 = the direct conv on the same 16 x 32 tiles
@@ -122,6 +124,7 @@ void conv_pack_split(const float* w_oihw, int K, int C, void* packed);     // ho
 void conv_pack_1x1_split(const float* w_oi, int K, int C, void* packed);   // host; 3 * conv_packed_bytes_taps(K, C, 0x10)
 int conv_launch(const ConvLaunch& L, hipStream_t s);
 size_t conv_packed_bytes_taps(int K, int C, int mask);
+void conv_pack_selfgate(const float* w32x32, void* packed_2k);      // host; ConvLaunch.gate_w
 void conv_pack_1x1(const float* w_oi, int K, int C, void* packed);    // host; w [K][C]
 int conv_stats_nper(int H, int W, int phases);                              // host; see ConvLaunch.stats_part
 size_t conv_packed_bytes7v(int K, int C);

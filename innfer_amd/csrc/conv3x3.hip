@@ -134,6 +134,7 @@ struct KP {
     float* fl_side;          //   per tile 192 x 3 partial sums of the pixels within one pixel of a tile edge (conv_fuse_combine finishes them)
     void* fl_out;            //   the planar [N, fl_oc, H, W] result
     int fl_oc, fl_out_mode;  //   0 fp16, 1 fp32 planar; 2 the uint8 HWC image (out_denorm / out_round16 as for the planar kernels)
+    const f16* sg_w; const float* sg_bias;   // SGATE kernels (TMF | 0x80000): a 1x1 conv of this conv's own fp16 result gates it -- out = v * sigmoid(W v + b): two A fragments [t][lane][8] (conv_pack_selfgate), 32 biases
     float rs1;               // RLDS kernels (TMF | 0x40000): 1 / s1 -- the residual res1 (= the conv's own input groups 0, 1) is added to the accumulators as x / s1 from the live LDS stage
     long in_lo_bytes;        // SPLIT kernels (TMF | 0x2000): the low-part twin of the input slab lies this many bytes behind it,
     long out_lo, res1_lo, res2_lo;   //   those of the output / residual slabs this many ELEMENTS behind them
@@ -1065,6 +1066,13 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // residuals' loads did not fit the registers as one batch, keep ONE memory residual and hoist its loads like the others.
     constexpr bool RLDS = (TMF & 0x40000) != 0;
     static_assert(!RLDS || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x3FFFF) == 0x1FF && !S9 && !POLY), "residual from LDS: the plain 64-channel instantiation (and its canvas form)");
+    // + 0x80000 (SGATE): PAN's pixel attention behind an up-conv (PAN_arch.py:11-35: upconv -> PA: x * sigmoid(conv1x1(x)) -> LeakyReLU) inside the up-conv's
+    // epilogue: a lane's accumulators are 8 consecutive channels of its pixel (NT = 2 row order), i.e. after the fp16 conversion -- the value the two-launch
+    // schedule stored -- the B fragment of the 1x1 conv; two MFMAs per pixel tile against the 32 x 32 gate matrix held in registers, then v * sigmoid(g) goes
+    // through the ordinary epilogue (its LeakyReLU, the store).  Same fp16 operands, same MFMA, same expression: bit-identical to the two launches, without the
+    // round trip of the 32-channel HR tensor (531 MB written and read again at 2160 x 3840).
+    constexpr bool SGATE = (TMF & 0x80000) != 0;
+    static_assert(!SGATE || (RPW == 3 && NT == 2 && NCW == 8 && OUTMODE == OUT_SLAB && (TMF & 0x7FFFF) == 0x1FF && !S9 && !POLY), "self gate: the 32-output slab kernel (and its canvas form)");
     constexpr bool FUSE = (TMF & 0x20000) != 0;
     static_assert(!FUSE || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation");
     constexpr int TH = NCW * RPW;
@@ -1525,6 +1533,15 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             roffs[m] = P * 64 + (((lg & 1) ^ ((P >> 2) & 1)) << 5);
         }
     }
+    f16x8 sgw[SGATE ? 2 : 1];
+    f32x4 sgb[SGATE ? 2 : 1];
+    if constexpr (SGATE) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            sgw[t] = *(const f16x8*)(p.sg_w + (t * 64 + lane) * 8);
+            sgb[t] = *(const f32x4*)(p.sg_bias + 8 * lg + 4 * t);
+        }
+    }
     int islot = 0;                                                // NSI == 3: g % 3
     f32x4 bias_r[NT];
     int bias_kg = -1;
@@ -1756,6 +1773,22 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         if (++c == p.nchunks) {
             c = 0;
             jt += slots;
+            if constexpr (SGATE) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f16x8 vb;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vb[4 * t + j] = (f16)acc[t][m][j];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_f16(sgw[t], vb, sgb[t], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[t][m][j] = (float)vb[4 * t + j] * (1.0f / (1.0f + expf(-g[j])));
+                    }
+                }
+            }
             if constexpr (PFX) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -2048,7 +2081,7 @@ int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
-    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x42000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
+    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0xC2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
         int gy = 0; long t = 0;
         const int gx = INNFER_KNOB("INNFER_CANVAS", 1) ? canvas_grid<TH>(kp, N, &gy, &t) : 0;
         if (gx > 0) {
@@ -2151,6 +2184,17 @@ void conv_pack(const float* w, int K, int C, void* packed) {
 
 // Panels holding only the taps of `mask` (bit r*3+s), in (r, s) order: [group][chunk][tap rank][row R][slot][8 ch]; mask 0x10 = a 1x1 conv,
 // w then is [K][C] (one value per pair) -- the counterpart of conv3x3_pc<.., TM>
+// The gate matrix of ConvLaunch.gate_w: w [32][32] (out, in; zero rows / columns beyond the real channels) as the two MFMA A fragments [t][lane][8]:
+// lane (rho = lane & 15, octet = lane >> 4) of tile t holds w[8 (rho >> 2) + 4 t + (rho & 3)][8 octet .. + 7] (the NT = 2 row order of conv_pack)
+void conv_pack_selfgate(const float* w32x32, void* packed_2k) {
+    f16* dst = (f16*)packed_2k;
+    for (int t = 0; t < 2; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int rho = lane & 15, oct = lane >> 4, oc = 8 * (rho >> 2) + 4 * t + (rho & 3);
+            for (int e = 0; e < 8; ++e) *dst++ = (f16)w32x32[oc * 32 + oct * 8 + e];
+        }
+}
+
 size_t conv_packed_bytes_taps(int K, int C, int mask) { return conv_packed_bytes(K, C) / 9 * __builtin_popcount(mask & 0x1FF); }
 // any mask: w is [K][C][9] (taps outside the mask are not read)
 void conv_pack_taps(const float* w, int K, int C, int mask, void* packed) {
@@ -2502,6 +2546,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         }
         // three input slots (a 1x1 stage has no halo): the loaders never pause between chunks -- about 1 % on PAN / PPON (kernel_experiments.txt 32)
         return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x10, false, 3>(k, L.N, s) : launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x10, false, 3>(k, L.N, s);
+    }
+    if (L.gate_w) {          // out = act(v * sigmoid(W v + b)), v = this conv's fp16 result (PAN's PA block behind an up-conv): conv3x3_pc<.., TMF | 0x80000>
+        if (!pc || L.out_mode != OUT_SLAB || nt != 2 || L.K != 32 || L.res1 || L.res2 || L.act > 2 || L.reflect || L.stats_part)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the self gate belongs to 32-output slab convs without residuals (act = the activation AFTER the gate)");
+        k.sg_w = L.gate_w; k.sg_bias = L.gate_bias;
+        return launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x801FF>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 2) {
         // 32-output layers: 24-row tiles, two LDS stages.  pc 5 (diagnostic builds): 16-row tiles on the three-slot input ring (continuous LDS-DMA

@@ -167,6 +167,171 @@ __global__ __launch_bounds__(256) void pan_attention(const float* fgh, const flo
     }
 }
 
+// ---- the same attention on the matrix cores (round 4) -----------------------------------------------------------------------------------------
+// pan_attention above is a VALU kernel: 33 TFLOP/s, 3.2 ms of a 6.0 ms forward at 540 x 960 (32 400 pooled pixels: 1.05 G query-key pairs) once the SCPA
+// trunk had shrunk.  Here, per workgroup of 8 waves and 128 queries (16 per wave: one MFMA column set):
+//   scores   s[key][query] = g_key . f_query as v_mfma_f32_16x16x32_f16 with keys as rows: both operands are fp16 (hi, lo * 2^11) pairs packed into the
+//            32-deep k dimension -- one MFMA for gh . fh, one for (gh . fl + gl . fh), s = s_hh + 2^-11 s_x: fp32-accurate scores (the 2^-22 term is dropped)
+//   softmax  two passes over the keys like the VALU kernel: the exact row maximum first, then p = exp(s - m) <= 1 and the sum in fp32 on the lanes
+//   out      o[c][query] += h[key][c] p[key][query]: the score MFMAs' rows are assigned to keys so that a lane ends with 8 CONSECUTIVE keys of its query
+//            (key of row rho of score tile t: 8 (rho >> 2) + 4 t + (rho & 3)) -- its fp16 p values ARE the B fragment of the P V product; h as fp16 A
+//            fragments [channel][key] prepared once per forward (pan_attn_prep)
+// Keys go through a double-buffered LDS stage of two 32-key blocks (per block 1 KB of g pairs + 3 KB of h fragments: one 16-byte load per thread), one
+// barrier per 64 keys; 8 waves x 16 queries per workgroup.  Never materialises the Np x Np matrix either.  att rows as before: fp32 [N * Np][C].
+constexpr int ATT_C = 40, ATT_CQ = 5, ATT_KB = 32;
+
+// per pooled pixel: QK[point] = {fh, fl', gh, gl'} (four 16-byte octets: 5 values + 3 zeros each; x = xh + xl' * 2^-11, bias added);
+// per image and 32-key block: Vt[blk][t 0..2][lane][8] = h[key blk * 32 + 8 lg + e][channel 16 t + li] + bias as fp16 (0 beyond Np / C)
+__global__ void pan_attn_prep(const float* fgh, const float* bf, const float* bg, const float* bh, int Np, int nblk, f16* QK, f16* Vt) {
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float* base = fgh + (long)n * Np * 64;
+    if (i < Np) {
+        f16x8 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[q][e] = (f16)0.f;
+#pragma unroll
+        for (int c = 0; c < ATT_CQ; ++c) {
+            const float f = base[i * 64 + c] + bf[c], g = base[i * 64 + ATT_CQ + c] + bg[c];
+            const f16 fh = (f16)f, gh = (f16)g;
+            o[0][c] = fh; o[1][c] = (f16)((f - (float)fh) * 2048.0f);
+            o[2][c] = gh; o[3][c] = (f16)((g - (float)gh) * 2048.0f);
+        }
+        f16* dst = QK + ((long)n * nblk * ATT_KB + i) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f16x8*)(dst + 8 * q) = o[q];
+    } else if (i < (long)nblk * ATT_KB) {                       // padding keys of the last block: zeros (masked to -inf in the kernel)
+        f16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (f16)0.f;
+        f16* dst = QK + ((long)n * nblk * ATT_KB + i) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f16x8*)(dst + 8 * q) = z;
+    }
+    if (i < (long)nblk * 3 * 64) {                              // one h fragment (8 keys of one channel) per thread
+        const int blk = (int)(i / 192), r = (int)(i - (long)blk * 192), t = r >> 6, lane = r & 63, li = lane & 15, lg = lane >> 4, c = 16 * t + li;
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long key = (long)blk * ATT_KB + 8 * lg + e;
+            v[e] = (f16)((key < Np && c < ATT_C) ? base[key * 64 + 2 * ATT_CQ + c] + bh[c] : 0.f);
+        }
+        *(f16x8*)(Vt + ((long)n * nblk * 192 + i) * 8) = v;
+    }
+}
+
+__global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f16* Vt, int Np, int nblk, float* out) {
+    // 8 waves x 16 queries (two waves per SIMD: one wave's exps and LDS reads run under the other's MFMAs); a stage holds TWO 32-key blocks (8 KB: one
+    // 16-byte piece per thread), so a barrier is paid once per 64 keys
+    __shared__ __attribute__((aligned(16))) char st[2][8192];  // per stage and block: g pairs of 32 keys (32 x 32 B) | three h fragments (3 x 1 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4, n = blockIdx.y;
+    const f16* qk = QK + (long)n * nblk * ATT_KB * 32;
+    const f16* vt = Vt + (long)n * nblk * 192 * 8;
+    const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // B operands of the score MFMAs for this wave's 16 queries (a query beyond Np reads a padding key's zero row: its results are never stored)
+    const int q = blockIdx.x * 128 + wave * 16 + li;
+    f16x8 bhh, bx;
+    {
+        const int qq = q < nblk * ATT_KB ? q : 0;
+        const f16x8 fh = *(const f16x8*)(qk + (long)qq * 32), fl = *(const f16x8*)(qk + (long)qq * 32 + 8);
+        bhh = lg == 0 ? fh : z8;
+        bx = lg == 0 ? fl : (lg == 1 ? fh : z8);
+    }
+    // staging: thread tid moves one 16-byte piece of block pair bp (blocks 2 bp, 2 bp + 1) into stage bp & 1
+    const int half = tid >> 8, t8 = tid & 255;
+    auto stage_src = [&](int bp) -> const f16* {
+        const int b = 2 * bp + half < nblk ? 2 * bp + half : nblk - 1;                            // (an odd tail: the last block twice, its second copy masked)
+        if (t8 < 64) return qk + ((long)b * ATT_KB + (t8 >> 1)) * 32 + 16 + (t8 & 1) * 8;        // {gh, gl'} of key t8 / 2
+        return vt + ((long)b * 192 + (t8 - 64)) * 8;
+    };
+    const int dst_off = half * 4096 + (t8 < 64 ? t8 * 16 : 1024 + (t8 - 64) * 16);
+    // the key of row rho (= li) of score tile t, and this lane's A-operand octet: gh for k-octet 0, gl' for k-octet 1
+    const int koff0 = (8 * (li >> 2) + (li & 3)) * 32 + (lg == 1 ? 16 : 0), koff1 = koff0 + 4 * 32;
+    auto scores = [&](const char* sp, f32x4 (&sc)[2]) __attribute__((always_inline)) {      // sc[t][j]: key 8 lg + 4 t + j of the block, query li
+        const f16x8 g0 = *(const f16x8*)(sp + koff0), g1 = *(const f16x8*)(sp + koff1);
+        const f16x8 a0h = lg == 0 ? g0 : z8, a0x = lg < 2 ? g0 : z8, a1h = lg == 0 ? g1 : z8, a1x = lg < 2 ? g1 : z8;
+        const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bhh, z4, 0, 0, 0), x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0x, bx, z4, 0, 0, 0);
+        const f32x4 h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bhh, z4, 0, 0, 0), x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1x, bx, z4, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[0][j] = __builtin_fmaf(x0[j], 1.0f / 2048.0f, h0[j]);
+            sc[1][j] = __builtin_fmaf(x1[j], 1.0f / 2048.0f, h1[j]);
+        }
+    };
+    const int npair = (nblk + 1) / 2;
+    float m = -INFINITY;
+    // ---- pass 1: the row maxima (g pairs only) ----
+    if (t8 < 64) *(f16x8*)(st[0] + dst_off) = *(const f16x8*)stage_src(0);
+    __syncthreads();
+    for (int bp = 0; bp < npair; ++bp) {
+        f16x8 nxt = z8;
+        if (t8 < 64 && bp + 1 < npair) nxt = *(const f16x8*)stage_src(bp + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = 2 * bp + h;
+            f32x4 sc[2];
+            scores(st[bp & 1] + h * 4096, sc);
+            const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (kb + 4 * t + j < Np) m = fmaxf(m, sc[t][j]);
+        }
+        if (t8 < 64 && bp + 1 < npair) *(f16x8*)(st[(bp + 1) & 1] + dst_off) = nxt;
+        __syncthreads();
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    // ---- pass 2: p = exp(s - m), sums, P V ----
+    f32x4 acc[3] = {z4, z4, z4};
+    float sum = 0.f;
+    *(f16x8*)(st[0] + dst_off) = *(const f16x8*)stage_src(0);
+    __syncthreads();
+    for (int bp = 0; bp < npair; ++bp) {
+        f16x8 nxt = z8;
+        if (bp + 1 < npair) nxt = *(const f16x8*)stage_src(bp + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = 2 * bp + h;
+            const char* sp = st[bp & 1] + h * 4096;
+            f32x4 sc[2];
+            scores(sp, sc);
+            f16x8 v[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) v[t] = *(const f16x8*)(sp + 1024 + t * 1024 + lane * 16);
+            const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
+            f16x8 pk;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = kb + 4 * t + j < Np ? __expf(sc[t][j] - m) : 0.f;
+                    sum += e;
+                    pk[4 * t + j] = (f16)e;
+                }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[t], pk, acc[t], 0, 0, 0);
+        }
+        if (bp + 1 < npair) *(f16x8*)(st[(bp + 1) & 1] + dst_off) = nxt;
+        __syncthreads();
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (q < Np) {
+        const float inv = 1.0f / sum;
+        float* o = out + ((long)n * Np + q) * ATT_C;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int c = 16 * t + 4 * lg;
+            if (c < ATT_C) *(f32x4*)(o + c) = acc[t] * inv;
+        }
+    }
+}
+
 __device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
 
@@ -294,6 +459,7 @@ struct Gemm {                       // one packed GEMM
     void* d_w3 = nullptr; float* d_b3 = nullptr; int K3 = 0;
     std::function<int(int)> bias_row;                   // optional: output row -> index into the bias parameter (-1: none); default: row == index
     bool one_tap = false;                               // a 1x1 conv: single-tap panel (conv_pack_1x1), the kernel's one-tap instantiation
+    bool pa_gate = false; void* d_gate = nullptr;       // the PA block's 1x1 conv (upsample.<i>.conv): also packed as the self-gate fragments of the conv in front of it (conv_pack_selfgate)
 };
 
 }  // namespace
@@ -307,6 +473,7 @@ struct innfer_pan {
     std::vector<Gemm> gemms;
     std::vector<float*> d_vecs;      // device copies of bias vectors / gamma, by param index (nullptr if unused)
     std::vector<void*> d_scpa;       // one weight blob per SCPA block (pan_scpa.hip), trunk by trunk
+    int mfma_attention = 1;          // the FSA block's attention on the matrix cores (pan_attention_mfma); 0: the VALU kernel of rounds 1-3 (set with fused_scpa: one A/B switch)
     int fused_scpa = 1;              // an SCPA block as ONE launch (innfer_pan_set_fused_scpa); 0: the five halo-tile launches of rounds 1-3
     bool uploaded = false;
 };
@@ -364,7 +531,7 @@ extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int
 
 extern "C" void innfer_pan_destroy(innfer_pan* p) {
     if (!p) return;
-    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); }
+    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
     for (auto v : p->d_scpa) if (v) (void)hipFree(v);
     delete p;
@@ -373,6 +540,8 @@ extern "C" void innfer_pan_destroy(innfer_pan* p) {
 extern "C" int innfer_pan_set_fused_scpa(innfer_pan* p, int on) {
     if (!p) return set_error(INNFER_ERR_INVALID, "pan_set_fused_scpa: null network");
     p->fused_scpa = on ? 1 : 0;
+    p->mfma_attention = on == 2 ? 0 : 1;          // (2: the fused trunk with the VALU attention -- A/B of the attention alone)
+    if (!on) p->mfma_attention = 0;
     return INNFER_OK;
 }
 
@@ -469,6 +638,7 @@ int build_gemms(innfer_pan* p) {
         add(u == 0 ? 64 : 32, UF, 9, [&w1, cin](int co, int ci, int t) { return ci < cin ? w1[((size_t)co * cin + ci) * 9 + t] : 0.f; }, b1.c_str());
         const std::string bp = "upsample." + std::to_string(i + 2) + ".conv.bias";
         add(32, UF, 9, [&wp, UF](int co, int ci, int t) { return ci < UF && t == 4 ? wp[(size_t)co * UF + ci] : 0.f; }, bp.c_str());
+        p->gemms.back().pa_gate = true;
         add(32, UF, 9, [&w4, UF](int co, int ci, int t) { return ci < UF ? w4[((size_t)co * UF + ci) * 9 + t] : 0.f; }, b4.c_str());
     }
     {   const auto& w = W("conv_last.weight");
@@ -482,6 +652,7 @@ int upload(innfer_pan* p) {
         if (g.d_w) { (void)hipFree(g.d_w); g.d_w = nullptr; }
         if (g.d_w3) { (void)hipFree(g.d_w3); g.d_w3 = nullptr; }
         if (g.d_b3) { (void)hipFree(g.d_b3); g.d_b3 = nullptr; }
+        if (g.d_gate) { (void)hipFree(g.d_gate); g.d_gate = nullptr; }
     }
     build_gemms(p);
     std::vector<f16> panel;
@@ -508,6 +679,12 @@ int upload(innfer_pan* p) {
                 std::vector<float> w1((size_t)g.K3 * g.cin_pad);
                 for (size_t i = 0; i < w1.size(); ++i) w1[i] = w3[i * 9 + 4];
                 conv_pack_1x1(w1.data(), g.K3, g.cin_pad, packed.data());
+                if (g.pa_gate && g.K3 == 32 && g.cin_pad == 32) {
+                    std::vector<char> gp(2048);
+                    conv_pack_selfgate(w1.data(), gp.data());
+                    INNFER_HIP(hipMalloc(&g.d_gate, gp.size()));
+                    INNFER_HIP(hipMemcpy(g.d_gate, gp.data(), gp.size(), hipMemcpyHostToDevice));
+                }
             } else {
                 conv_pack(w3.data(), g.K3, g.cin_pad, packed.data());
             }
@@ -549,7 +726,7 @@ int upload(innfer_pan* p) {
     return INNFER_OK;
 }
 
-struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, inp, t, pool, fgh, att, raw, hr[2][3], ups, total, slab_end; };
+struct PCarve { size_t x0, fea, xa, xb, ab, ab2, k3y, inp, t, pool, fgh, att, aqk, avt, raw, hr[2][3], ups, total, slab_end; };
 
 PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     PCarve c{};
@@ -567,6 +744,11 @@ PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
     c.slab_end = off;
     c.fgh = off; off += al((np ? np : 1) * 64 * 4);
     c.att = off; off += al((np ? np : 1) * p->nf * 4);
+    {   // MFMA attention: per image nblk 32-key blocks of {fh, fl', gh, gl'} rows (64 B per key) and of h fragments (3 KB per block)
+        const size_t nblk = ((size_t)hp * wp + 31) / 32;
+        c.aqk = off; off += al((size_t)N * nblk * 32 * 64 + 256);
+        c.avt = off; off += al((size_t)N * nblk * 3072 + 256);
+    }
     c.raw = off; off += al(px * m * (size_t)p->out_nc * 4);          // planar fp32 output of conv_last (every other conv writes fp16 slabs)
     c.total = off;
     return c;
@@ -608,7 +790,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     };
     // plain 3x3 conv on conv3x3.hip: dst = act(conv(in) + bias) [+ res]; planar != nullptr: fp32 NCHW output instead of a slab
     auto conv3 = [&](const f16* in, long in_g, int Ho, int Wo, int up, int act, const f16* res, long res_g, f16* dst, long dst_g,
-                     float* planar = nullptr) -> int {
+                     float* planar = nullptr, const Gemm* gate = nullptr) -> int {
         const Gemm& g = p->gemms[gi++];
         if (!g.tile3) return set_error(INNFER_ERR_INVALID, "pan: conv %d is not a halo-tile conv", gi - 1);
         ConvLaunch L{};
@@ -620,6 +802,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         L.y0 = 0; L.y1 = Ho;
         L.out_mode = planar ? OUT_NCHW : OUT_SLAB; L.out_f32 = planar ? 1 : 0;
         L.conv1x1 = g.one_tap ? 1 : 0;
+        if (gate) { L.gate_w = (const f16*)gate->d_gate; L.gate_bias = gate->d_b3; }      // out = act(v * sigmoid(W v + b)): the PA block as this conv's epilogue
         return conv_launch(L, s);
     };
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
@@ -627,8 +810,9 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         *AB = (f16*)(ws + cv.ab), *AB2 = (f16*)(ws + cv.ab2), *K3Y = (f16*)(ws + cv.k3y), *INP = (f16*)(ws + cv.inp),
         *T = (f16*)(ws + cv.t), *POOL = (f16*)(ws + cv.pool);
 
-    hipLaunchKernelGGL(pan_pre, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, p->in_nc, (long)H * W, N, X0);
-    INNFER_HIP(hipGetLastError());
+    {   GtScope gt(s, "pan_pre (NCHW -> slab)", 0.0, (double)px * (p->in_nc * (in_dtype == INNFER_F32 ? 4.0 : 2.0) + 64.0));
+        hipLaunchKernelGGL(pan_pre, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, d_in, in_dtype == INNFER_F32, p->in_nc, (long)H * W, N, X0);
+        INNFER_HIP(hipGetLastError()); }
     CK(conv3(X0, G, H, W, 0, 0, nullptr, 0, FEA, G));                                  // conv_first
     const f16* x = FEA;
     for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {
@@ -659,18 +843,31 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     if (p->self_attention) {   // FSA
         const int hp = H / 4, wp = W / 4;
         const long np = (long)N * hp * wp, Gp = np * 32;
-        hipLaunchKernelGGL(pan_maxpool, dim3((unsigned)((np * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, INP, G, nf, N, H, W, hp, wp, POOL, Gp);
-        INNFER_HIP(hipGetLastError());
+        {   GtScope gt(s, "pan_maxpool", 0.0, (double)px * nf * 2.0 + (double)np * 128.0);
+            hipLaunchKernelGGL(pan_maxpool, dim3((unsigned)((np * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, INP, G, nf, N, H, W, hp, wp, POOL, Gp);
+            INNFER_HIP(hipGetLastError()); }
         float* save = raw;
         raw = (float*)(ws + cv.fgh);
         CK(gemm(POOL, Gp, hp, wp, hp, wp, 0, true));                                  // [f | g | h], 64-float rows for pan_attention
         raw = save;
-        hipLaunchKernelGGL(pan_attention, dim3((hp * wp + 63) / 64, N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
-                           vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, (float*)(ws + cv.att));
-        INNFER_HIP(hipGetLastError());
-        hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
-                           INP, G, N, H, W, vec("FSA.gamma"), T);
-        INNFER_HIP(hipGetLastError());
+        if (p->mfma_attention && nf == ATT_C) {   // softmax(f^T g) h on the matrix cores: Np^2 (5 + 40) multiply-adds per image (the scores twice: max pass, accumulate pass)
+            const int Np = hp * wp, nblk = (Np + ATT_KB - 1) / ATT_KB;
+            GtScope gt(s, "pan_attention_mfma (+ prep)", 2.0 * N * (double)Np * Np * (2 * 5 + 40), (double)np * (64.0 + nf) * 4.0);
+            const long work = (long)nblk * 192 > (long)nblk * ATT_KB ? (long)nblk * 192 : (long)nblk * ATT_KB;
+            hipLaunchKernelGGL(pan_attn_prep, dim3((unsigned)((work + 255) / 256), N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
+                               vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), Np, nblk, (f16*)(ws + cv.aqk), (f16*)(ws + cv.avt));
+            hipLaunchKernelGGL(pan_attention_mfma, dim3((Np + 127) / 128, N), dim3(512), 0, s, (const f16*)(ws + cv.aqk), (const f16*)(ws + cv.avt), Np, nblk,
+                               (float*)(ws + cv.att));
+            INNFER_HIP(hipGetLastError());
+        } else {
+            GtScope gt(s, "pan_attention", 2.0 * N * (double)(hp * wp) * (hp * wp) * (2 * 5 + 40), (double)np * (64.0 + nf) * 4.0);
+            hipLaunchKernelGGL(pan_attention, dim3((hp * wp + 63) / 64, N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
+                               vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, (float*)(ws + cv.att));
+            INNFER_HIP(hipGetLastError()); }
+        {   GtScope gt(s, "pan_fsa_combine (bicubic + gamma * out + in)", 0.0, (double)px * nf * 4.0 + (double)np * nf * 4.0);
+            hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
+                               INP, G, N, H, W, vec("FSA.gamma"), T);
+            INNFER_HIP(hipGetLastError()); }
     }
     const f16* cur = p->self_attention ? T : INP;
     long cur_g = G;
@@ -680,16 +877,21 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         const int hh = uf * h, ww = uf * w;
         const long hpx = (long)N * hh * ww, HG = hpx * 32;
         f16 *V = (f16*)(ws + cv.hr[u][0]), *PA = (f16*)(ws + cv.hr[u][1]), *HRC = (f16*)(ws + cv.hr[u][2]);
+        // PA (x * sigmoid(conv1x1(x)) -> LeakyReLU) as the epilogue of the conv in front of it: V is never written (fused_scpa != 0; bit-identical)
+        const Gemm* gate = (p->fused_scpa && p->gemms[gi + 1].d_gate) ? &p->gemms[gi + 1] : nullptr;
+        f16* Vd = gate ? PA : V;
+        const int va = gate ? 1 : 0;
         if (p->bilinear_up || uf == 3) {                                               // conv(upsampled(t)): the upsampling as its own pass
             f16* UPS = (f16*)(ws + cv.ups);
             const int groups = u == 0 ? 2 : 1;                                         // nf = 40 / unf = 24 channels (pad channels stay zero: 0 interpolates to 0)
             const long tot = hpx * groups * 4;
             hipLaunchKernelGGL(pan_upsample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, cur, cur_g, UPS, HG, groups, N, h, w, uf, p->bilinear_up ? 1 : 0);
             INNFER_HIP(hipGetLastError());
-            CK(conv3(UPS, HG, hh, ww, 0, 0, nullptr, 0, V, HG));
+            CK(conv3(UPS, HG, hh, ww, 0, va, nullptr, 0, Vd, HG, nullptr, gate));
         } else
-        CK(conv3(cur, cur_g, hh, ww, 1, 0, nullptr, 0, V, HG));                        // conv(nearest2x(t))
-        CK(conv3(V, HG, hh, ww, 0, 4, V, HG, PA, HG));                                 // PA: lrelu(v * sigmoid(conv1x1(v)))
+        CK(conv3(cur, cur_g, hh, ww, 1, va, nullptr, 0, Vd, HG, nullptr, gate));       // conv(nearest2x(t)) [+ PA]
+        if (gate) ++gi;                                                                // (the 1x1 conv ran inside that launch)
+        else CK(conv3(V, HG, hh, ww, 0, 4, V, HG, PA, HG));                            // PA: lrelu(v * sigmoid(conv1x1(v)))
         // HRconv.  Two stages (4x): PAN's outer B.sequential flattens the stages with children(), which yields the shared LeakyReLU once per
         // stage -- nothing follows HRconv.  One stage (2x): the stage's own nn.Sequential is used as it is and holds the LeakyReLU in two slots,
         // so HRconv IS followed by it (PAN_arch.py:11-19, block.py:197-210; golden G18)
@@ -699,6 +901,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     CK(conv3(cur, cur_g, h, w, 0, 0, nullptr, 0, nullptr, 0, raw));                    // conv_last -> planar fp32 (+ bias)
     {
         const long fpx = (long)N * h * w;
+        GtScope gt(s, "pan_final (+ bilinear skip, NCHW)", 0.0, (double)fpx * p->out_nc * (4.0 + (out_dtype == INNFER_F32 ? 4.0 : 2.0)));
         hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, raw, 0, vec("conv_last.bias"), p->out_nc,
                            d_in, in_dtype == INNFER_F32, N, H, W, p->scale, d_out, out_dtype == INNFER_F32);
         INNFER_HIP(hipGetLastError());

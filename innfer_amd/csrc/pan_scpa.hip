@@ -34,20 +34,16 @@ constexpr int OFF_K1 = OFF_C1B + C1_SIZE, OFF_K3 = OFF_K1 + 9 * K_TAP, OFF_K4 = 
 constexpr int OFF_C3 = OFF_K2 + K_TAP;                                             // conv3: [t 0..3][row][oct 0..2 = a', 3..5 = b']
 constexpr int c3_t(int t) { return (t < 2 ? t * 12 : 24 + (t - 2) * 8) * C3_ROW; }
 constexpr int OFF_B2 = OFF_C3 + 40 * C3_ROW;                                       // k2's bias: 32 floats by channel (20 real)
-constexpr int W_BYTES = OFF_B2 + 128;
-static_assert(W_BYTES == 34048, "blob layout");
+constexpr int OFF_ZERO = OFF_B2 + 128;                                            // 16 zero bytes: what a lane reads for a structurally-zero fragment
+constexpr int W_BYTES = OFF_ZERO + 16;
+static_assert(W_BYTES == 34064, "blob layout");
 
 struct ScpaKP {
     const f16* in; f16* out; long G;        // slabs of two 32-channel groups (40 real channels), group stride G elements
     const char* w;                          // the block's blob (W_BYTES)
     int N, H, W, tiles_x, tiles_y, total;
+    int abl;                                // diagnostic build only (make ablate, INNFER_SCPA_ABL): skip 1 P1, 2 P2a, 4 P2b, 8 P3's MFMAs, 16 the X fetch, 32 the stores
 };
-
-__device__ __forceinline__ f16x8 ldz(const char* p, bool ok) {
-    f16x8 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-    if (ok) z = *(const f16x8*)p;
-    return z;
-}
 
 __device__ __forceinline__ f16x8 lrelu8(const f32x4& a, const f32x4& b) {
     f16x8 v;
@@ -59,25 +55,64 @@ __device__ __forceinline__ f16x8 lrelu8(const f32x4& a, const f32x4& b) {
     return v;
 }
 
+// Every LDS operand read is UNCONDITIONAL: a lane whose fragment is structurally zero (k-octet 3 of a 20-channel operand, a panel row beyond the real
+// ones) reads the 16 zero bytes at OFF_ZERO instead (a broadcast).  A predicated read is a branch around a ds_read + s_waitcnt per fragment -- the first
+// version of this kernel waited out the LDS latency once per tap (21 us per tile against 4 us of MFMA work).
+__device__ __forceinline__ f16x8 lds16(const char* smem, int off, bool real) { return *(const f16x8*)(smem + (real ? off : OFF_ZERO)); }
+
+// A 20 -> 20 channel 3x3 conv over this wave's RW output rows x 32 pixels (PW = 2 RW pixel tiles: tile u = row * 2 + segment) of the LDS image at
+// `src` (48 B per pixel, 36-pixel rows, the output tile at halo offset (2, 2)).  Column by column (dx outer, dy inner: the tap order of conv3x3_pc's
+// fragment walk): the column's six weight fragments and the RW + 2 input rows' pixel fragments are read up front -- every pixel fragment once, used by
+// up to three output rows -- then the MFMAs.
+template <int RW>
+__device__ __forceinline__ void conv33_rows(const char* smem, int src, int woff, int row0, int li, int lg, f32x4 (&acc)[2 * RW][2]) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        f16x8 w[3][2], b[RW + 2][2];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                w[dy][t] = lds16(smem, woff + (dy * 3 + dx) * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+#pragma unroll
+        for (int rr = 0; rr < RW + 2; ++rr)
+#pragma unroll
+            for (int seg = 0; seg < 2; ++seg)
+                b[rr][seg] = lds16(smem, src + ((row0 + rr + 1) * HC + 1 + seg * 16 + li + dx) * 48 + lg * 16, lg < 3);
+#pragma unroll
+        for (int rr = 0; rr < RW + 2; ++rr)
+#pragma unroll
+            for (int seg = 0; seg < 2; ++seg)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int lo = rr - dy;
+                    if (lo >= 0 && lo < RW) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[lo * 2 + seg][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[dy][t], b[rr][seg], acc[lo * 2 + seg][t], 0, 0, 0);
+                    }
+                }
+        __builtin_amdgcn_sched_barrier(0);          // one column's fragments in registers at a time (hoisting all three spills; the SIMD's other wave fills the gap)
+    }
+}
+
 template <int TH>
 __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
     constexpr int HR = TH + 4, NPX = HR * HC;
-    static_assert(NPX % 16 == 0 && TH % 4 == 0, "whole 16-pixel MFMA tiles");
+    static_assert(NPX % 16 == 0 && TH % 8 == 0, "whole 16-pixel MFMA tiles, whole rows per wave");
     constexpr int NP1 = NPX / 16;                           // conv1's pixel tiles: the whole halo region
     constexpr int NMID = ((TH + 2) * HC + 15) / 16;         // Y's pixel tiles: rows 1 .. TH + 2, every column
-    constexpr int PW = TH / 4;                              // output pixel tiles (16 px) per wave: TH rows x 2 segments over 8 waves
+    constexpr int PW = TH / 4, RW = PW / 2;                 // output pixel tiles (16 px) / rows per wave: TH rows x 2 segments over 8 waves
     constexpr int XQ = (NPX * 5 + 63) / 64;                 // 1-KiB LDS-DMA pieces of an X tile
     constexpr int KQ = (XQ + 7) / 8;
     constexpr int XOFF = (W_BYTES + 1023) / 1024 * 1024, AOFF = XOFF + XQ * 1024, BOFF = AOFF + NPX * 48;
     static_assert(BOFF + NPX * 48 + 1024 <= 160 * 1024, "LDS");
     constexpr int OOB = (int)0x80000000;
+    constexpr int TB = 3;                                   // pixel tiles of P1 / P2b in flight per wave (their fragment reads are issued together)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const WL = smem;
     char* const X = smem + XOFF;
-    char* const A = smem + AOFF;                            // A, then Y
-    char* const B = smem + BOFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
+    const int li_w = lane & 15, lg_w = lane >> 4;
 
     // the XCD's workgroups (blocks b, b + 8, ..) walk that XCD's contiguous run of the tile list: halos meet in one L2
     const int bid = blockIdx.x, xcd = bid & 7;
@@ -128,136 +163,161 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
     };
 
     fetch(j0);
-    for (int i = tid; i < W_BYTES / 16; i += 512) *(f16x8*)(WL + i * 16) = *(const f16x8*)(p.w + i * 16);
+    for (int i = tid; i < W_BYTES / 16; i += 512) *(f16x8*)(smem + i * 16) = *(const f16x8*)(p.w + i * 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int row0 = RW * wave;                             // this wave's first output row of the tile (P2a / P3)
     for (int j = j0; j < run_len; j += slots) {
         int n, ty0, tx0;
         decode(j, n, ty0, tx0);
+        // (opaque copies of the lane coordinates, renewed per tile: every LDS address below is then recomputed where it is used -- an add on a shared
+        //  per-lane base and a select -- instead of being hoisted out of the tile loop as ~150 loop-invariant address registers, which spilled)
+        int li = li_w, lg = lg_w;
+        asm volatile("" : "+v"(li), "+v"(lg));
         // ---------------- P1: A | B = lrelu(conv1_a | conv1_b (x)) over the halo tile ----------------
-        f16x8 res[PW][2];
+#ifdef INNFER_ABLATE
+        if (!(p.abl & 1))
+#endif
         {
             f16x8 wa[2][2], wb[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const char* ba = WL + OFF_C1A + (t ? C1_T1 : 0) + li * C1_ROW;
-                const char* bb = WL + OFF_C1B + (t ? C1_T1 : 0) + li * C1_ROW;
-                wa[t][0] = ldz(ba + lg * 16, li < r2(t)); wa[t][1] = ldz(ba + 64, li < r2(t) && lg == 0);
-                wb[t][0] = ldz(bb + lg * 16, li < r2(t)); wb[t][1] = ldz(bb + 64, li < r2(t) && lg == 0);
+                const int ba = OFF_C1A + (t ? C1_T1 : 0) + li * C1_ROW, bb = OFF_C1B + (t ? C1_T1 : 0) + li * C1_ROW;
+                wa[t][0] = lds16(smem, ba + lg * 16, li < r2(t)); wa[t][1] = lds16(smem, ba + 64, li < r2(t) && lg == 0);
+                wb[t][0] = lds16(smem, bb + lg * 16, li < r2(t)); wb[t][1] = lds16(smem, bb + 64, li < r2(t) && lg == 0);
             }
-            for (int i = wave; i < NP1; i += 8) {
-                const int P = 16 * i + li;
-                const f16x8 b0 = *(const f16x8*)(X + P * 80 + lg * 16);
-                const f16x8 b1 = ldz(X + P * 80 + 64, lg == 0);
-                f32x4 ca[2], cb[2];
+            for (int i0 = wave; i0 < NP1; i0 += 8 * TB) {
+                f16x8 b0[TB], b1[TB];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], b0, z4, 0, 0, 0);
-                    ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], b1, ca[t], 0, 0, 0);
-                    cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][0], b0, z4, 0, 0, 0);
-                    cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][1], b1, cb[t], 0, 0, 0);
+                for (int k = 0; k < TB; ++k) {
+                    const int i = i0 + 8 * k < NP1 ? i0 + 8 * k : i0, P = 16 * i + li;        // (a tile past the end repeats the first one: same values stored twice)
+                    b0[k] = *(const f16x8*)(X + P * 80 + lg * 16);
+                    b1[k] = lds16(smem, XOFF + P * 80 + 64, lg == 0);
                 }
-                if (lg < 3) {
-                    *(f16x8*)(A + P * 48 + lg * 16) = lrelu8(ca[0], ca[1]);
-                    *(f16x8*)(B + P * 48 + lg * 16) = lrelu8(cb[0], cb[1]);
-                }
-            }
-            // the residual x of this wave's output pixels, in conv3's result layout (a lane: channels 16 lg .. 16 lg + 15 of pixel li), before X is re-used
 #pragma unroll
-            for (int u = 0; u < PW; ++u) {
-                const int q = PW * wave + u, P = ((q >> 1) + 2) * HC + 2 + (q & 1) * 16 + li;
-                res[u][0] = ldz(X + P * 80 + (lg < 2 ? 2 * lg : 4) * 16, lg < 3);
-                res[u][1] = ldz(X + P * 80 + (2 * lg + 1) * 16, lg < 2);
+                for (int k = 0; k < TB; ++k) {
+                    const int i = i0 + 8 * k < NP1 ? i0 + 8 * k : i0, P = 16 * i + li;
+                    f32x4 ca[2], cb[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], b0[k], z4, 0, 0, 0);
+                        ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], b1[k], ca[t], 0, 0, 0);
+                        cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][0], b0[k], z4, 0, 0, 0);
+                        cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][1], b1[k], cb[t], 0, 0, 0);
+                    }
+                    if (lg < 3) {
+                        *(f16x8*)(smem + AOFF + P * 48 + lg * 16) = lrelu8(ca[0], ca[1]);
+                        *(f16x8*)(smem + BOFF + P * 48 + lg * 16) = lrelu8(cb[0], cb[1]);
+                    }
+                }
             }
         }
         __syncthreads();
-        if (j + slots < run_len) fetch(j + slots);                 // the next tile's X lands while P2 / P3 run
         // ---------------- P2a: a' = lrelu(k1(A)) on the tile's own pixels (registers) ----------------
-        f16x8 ap[PW];
+        f16x8 ap[PW], res[PW][2];
         {
-            f16x8 wk[9][2];
+            f32x4 acc[PW][2];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
+            for (int u = 0; u < PW; ++u) acc[u][0] = acc[u][1] = z4;
+#ifdef INNFER_ABLATE
+            if (!(p.abl & 2))
+#endif
+            conv33_rows<RW>(smem, AOFF, OFF_K1, row0, li, lg, acc);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    wk[tap][t] = ldz(WL + OFF_K1 + tap * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+            for (int u = 0; u < PW; ++u) ap[u] = lrelu8(acc[u][0], acc[u][1]);
+            // the residual x of this wave's output pixels, in conv3's result layout (a lane: channels 16 lg .. 16 lg + 15 of pixel li), before X is re-used
 #pragma unroll
             for (int u = 0; u < PW; ++u) {
-                const int q = PW * wave + u, P = ((q >> 1) + 2) * HC + 2 + (q & 1) * 16 + li;
-                f32x4 c0 = z4, c1 = z4;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const f16x8 b = ldz(A + (P + (tap / 3 - 1) * HC + (tap % 3 - 1)) * 48 + lg * 16, lg < 3);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][0], b, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][1], b, c1, 0, 0, 0);
-                }
-                ap[u] = lrelu8(c0, c1);
+                const int P = (row0 + (u >> 1) + 2) * HC + 2 + (u & 1) * 16 + li;
+                res[u][0] = lds16(smem, XOFF + P * 80 + (lg < 2 ? 2 * lg : 4) * 16, lg < 3);
+                res[u][1] = lds16(smem, XOFF + P * 80 + (2 * lg + 1) * 16, lg < 2);
             }
         }
-        __syncthreads();                                            // every wave has read A: Y may take its place
+        __syncthreads();                                            // every wave has read A (Y may take its place) and X (the next tile's may)
+#ifdef INNFER_ABLATE
+        if (!(p.abl & 16))
+#endif
+        if (j + slots < run_len) fetch(j + slots);                 // the next tile's X lands while P2b / P3 run
         // ---------------- P2b: Y = k3(B) * sigmoid(k2(B) + bias) on rows 1 .. TH + 2, zero outside the image ----------------
+#ifdef INNFER_ABLATE
+        if (!(p.abl & 4))
+#endif
         {
-            f16x8 wk[9][2], w2[2];
-            f32x4 bk[2];
+            const f32x4 bk0 = *(const f32x4*)(smem + OFF_B2 + (8 * lg) * 4), bk1 = *(const f32x4*)(smem + OFF_B2 + (8 * lg + 4) * 4);
+            for (int i0 = wave; i0 < NMID; i0 += 8 * TB) {
+                f32x4 c[TB][2], g[TB][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+                for (int k = 0; k < TB; ++k) { c[k][0] = c[k][1] = z4; g[k][0] = bk0; g[k][1] = bk1; }
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-                    wk[tap][t] = ldz(WL + OFF_K3 + tap * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
-                w2[t] = ldz(WL + OFF_K2 + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
-                bk[t] = *(const f32x4*)(WL + OFF_B2 + (8 * lg + 4 * t) * 4);
-            }
-            for (int i = wave; i < NMID; i += 8) {
-                const int P = HC + 16 * i + li;
-                f32x4 c0 = z4, c1 = z4, g0 = bk[0], g1 = bk[1];
+                for (int dx = 0; dx < 3; ++dx) {
+                    f16x8 w[3][2], b[TB][3];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const f16x8 b = ldz(B + (P + (tap / 3 - 1) * HC + (tap % 3 - 1)) * 48 + lg * 16, lg < 3);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][0], b, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][1], b, c1, 0, 0, 0);
-                    if (tap == 4) {
-                        g0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[0], b, g0, 0, 0, 0);
-                        g1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[1], b, g1, 0, 0, 0);
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            w[dy][t] = lds16(smem, OFF_K3 + (dy * 3 + dx) * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+#pragma unroll
+                    for (int k = 0; k < TB; ++k) {
+                        const int i = i0 + 8 * k < NMID ? i0 + 8 * k : i0, P = HC + 16 * i + li;
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) b[k][dy] = lds16(smem, BOFF + (P + (dy - 1) * HC + dx - 1) * 48 + lg * 16, lg < 3);
                     }
-                }
-                const int r = P / HC, c = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + c;
-                const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
-                f16x8 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = (f16)(inside ? c0[e] * (1.0f / (1.0f + expf(-g0[e]))) : 0.f);
-                    v[4 + e] = (f16)(inside ? c1[e] * (1.0f / (1.0f + expf(-g1[e]))) : 0.f);
+                    for (int k = 0; k < TB; ++k)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+                                c[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[dy][t], b[k][dy], c[k][t], 0, 0, 0);
+                    if (dx == 1) {                                  // k2: the 1x1 conv of the gate reads the centre pixel's fragment
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const f16x8 w2 = lds16(smem, OFF_K2 + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+#pragma unroll
+                            for (int k = 0; k < TB; ++k) g[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, b[k][1], g[k][t], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (lg < 3 && P < NPX) *(f16x8*)(A + P * 48 + lg * 16) = v;
+#pragma unroll
+                for (int k = 0; k < TB; ++k) {
+                    const int i = i0 + 8 * k < NMID ? i0 + 8 * k : i0, P = HC + 16 * i + li;
+                    const int r = P / HC, cc = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + cc;
+                    const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
+                    f16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // sigmoid on the hardware exponential and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each): the libm forms are ~50 VALU instructions per
+                        // value, 21 k values per tile -- a third of the first version's tile time; the result is rounded to fp16 two lines below
+                        v[e] = (f16)(inside ? c[k][0][e] * __frcp_rn(1.0f + __expf(-g[k][0][e])) : 0.f);
+                        v[4 + e] = (f16)(inside ? c[k][1][e] * __frcp_rn(1.0f + __expf(-g[k][1][e])) : 0.f);
+                    }
+                    if (lg < 3 && P < NPX) *(f16x8*)(smem + AOFF + P * 48 + lg * 16) = v;
+                }
             }
         }
         __syncthreads();
         // ---------------- P3: b' = lrelu(k4(Y)); out = conv3(a' | b') + x ----------------
         {
-            f16x8 wk[9][2], w3[4][2];
+            f32x4 acc[PW][2];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    wk[tap][t] = ldz(WL + OFF_K4 + tap * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+            for (int u = 0; u < PW; ++u) acc[u][0] = acc[u][1] = z4;
+#ifdef INNFER_ABLATE
+            if (!(p.abl & 8))
+#endif
+            conv33_rows<RW>(smem, AOFF, OFF_K4, row0, li, lg, acc);
+            f16x8 w3[4][2];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    w3[t][ks] = ldz(WL + OFF_C3 + c3_t(t) + (li * 6 + ks * 3 + lg) * 16, li < r4(t) && lg < 3);
+                    w3[t][ks] = lds16(smem, OFF_C3 + c3_t(t) + (li * 6 + ks * 3 + lg) * 16, li < r4(t) && lg < 3);
 #pragma unroll
             for (int u = 0; u < PW; ++u) {
-                const int q = PW * wave + u, row = q >> 1, col = (q & 1) * 16 + li, P = (row + 2) * HC + 2 + col;
-                f32x4 c0 = z4, c1 = z4;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const f16x8 b = ldz(A + (P + (tap / 3 - 1) * HC + (tap % 3 - 1)) * 48 + lg * 16, lg < 3);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][0], b, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[tap][1], b, c1, 0, 0, 0);
-                }
-                const f16x8 bp = lrelu8(c0, c1);
+                const int row = row0 + (u >> 1), col = (u & 1) * 16 + li;
+                const f16x8 bp = lrelu8(acc[u][0], acc[u][1]);
                 f32x4 d[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -265,6 +325,12 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                     d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[t][1], bp, d[t], 0, 0, 0);
                 }
                 const int y = ty0 + row, x = tx0 + col;
+                // the next tile's X pieces (issued before P2b) must have landed before the barrier below; waiting HERE, in front of this tile's stores,
+                // keeps the stores out of the wait (a vmcnt(0) behind them adds their round trip to every tile)
+                if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef INNFER_ABLATE
+                if (p.abl & 32) continue;
+#endif
                 if (y < p.H && x < p.W) {
                     f16x8 o0, o1;
 #pragma unroll
@@ -278,8 +344,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next X has landed (and this tile's stores have left)
-        __syncthreads();
+        __syncthreads();                                            // Y is dead, the next X is in LDS (every wave waited for its own pieces above)
     }
 }
 
@@ -368,6 +433,9 @@ int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, 
     const long total = (long)N * k.tiles_x * k.tiles_y;
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "pan_scpa: grid too large");
     k.total = (int)total;
+#ifdef INNFER_ABLATE
+    k.abl = getenv("INNFER_SCPA_ABL") ? atoi(getenv("INNFER_SCPA_ABL")) : 0;
+#endif
     const int grid = total < num_cus ? (int)total : num_cus;
     hipLaunchKernelGGL(pan_scpa_fused<TH>, dim3(grid), dim3(512), LDS, s, k);
     INNFER_HIP(hipGetLastError());
