@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 108
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -203,6 +203,11 @@ int innfer_unet_set_param(innfer_unet_t u, int idx, const float* h_data);
  * set like any other parameter; unset = a fresh BatchNorm's 0 / 1) as ATen's eval-mode batch_norm does: alpha = weight / sqrt(running_var + eps),
  * y = x * alpha + (bias - running_mean * alpha).  Default 0: statistics of the current image (how run.py runs pix2pix, meval=False). */
 int innfer_unet_set_eval(innfer_unet_t u, int eval_mode);
+/* The reference's fp16 switch for this generator (`fp16 = not args.no_fp16 and gpu`, run.py:345,421-422).  fp32 = 0 (default): the fp16 engine.  fp32 = 1: every
+ * conv, norm and activation in fp32 on NCHW fp32 tensors (csrc/f32ops.hip: v_mfma_f32_16x16x4_f32, fp32 statistics) -- <= 1e-4 of the fp32 reference;
+ * innfer_unet_forward then takes and returns INNFER_F32 only, and innfer_unet_workspace_bytes answers for this mode.  A load-time call (packs fp32 panels:
+ * hipMalloc + synchronous copies); call it after the last innfer_unet_set_param.  (108) */
+int innfer_unet_set_precision(innfer_unet_t u, int fp32);
 size_t innfer_unet_workspace_bytes(innfer_unet_t u, int N, int H, int W);
 double innfer_unet_flops(innfer_unet_t u, int N, int H, int W);
 /* d_in [N,in_nc,H,W] -> d_out [N,out_nc,H,W] (tanh range), NCHW f16/f32; H, W multiples of 2^num_downs. */
@@ -236,6 +241,9 @@ size_t innfer_pan_workspace_bytes(innfer_pan_t p, int N, int H, int W);
  * (softmax(f^T g) h over the pooled pixels, block.py:398-473) from the VALU kernel to the matrix cores: scores from fp16 (hi, lo) pairs -- fp32-accurate --,
  * exact row maxima, exp and sums in fp32, p and h as fp16 operands of the P V product; on = 2 keeps the VALU attention behind the fused blocks.  (108) */
 int innfer_pan_set_fused_scpa(innfer_pan_t p, int on);
+/* The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs PAN.forward in fp32 on NCHW fp32 tensors
+ * (csrc/f32ops.hip; the FSA attention on the fp32 VALU kernel) -- <= 1e-4 of the fp32 reference; fp32 tensors in and out; a load-time call.  (108) */
+int innfer_pan_set_precision(innfer_pan_t p, int fp32);
 /* d_in [N,in_nc,H,W] -> d_out [N,out_nc,scale*H,scale*W], NCHW f16/f32; H, W >= 4. */
 int innfer_pan_forward(innfer_pan_t p, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                        int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);

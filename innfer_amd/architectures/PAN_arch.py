@@ -8,6 +8,7 @@ from .param_module import ParamEngineModule
 
 class PAN(ParamEngineModule):
     _api = 'pan'
+    _has_fp32 = True         # float32 tensors: innfer_pan_set_precision(1), the fp32 forward (csrc/f32ops.hip)
 
     def __init__(self, in_nc=3, out_nc=3, nf=40, unf=24, nb=16, scale=4, self_attention=True,
                  double_scpa=False, ups_inter_mode='nearest'):

@@ -9,6 +9,7 @@ from .param_module import ParamEngineModule
 
 class UnetGenerator(ParamEngineModule):
     _api = 'unet'
+    _has_fp32 = True         # float32 tensors: innfer_unet_set_precision(1), the fp32 forward (csrc/f32ops.hip)
 
     def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm_type="batch", use_dropout=False,
                  upsample_mode="deconv"):

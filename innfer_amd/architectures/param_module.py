@@ -96,11 +96,19 @@ class ParamEngineModule(nn.Module):
         out = self._out_shape(1, ps, ps)
         n_out = getattr(self, '_n_outputs', 1)
         in_nc = getattr(self, 'in_nc', None) or getattr(self, 'input_nc', 3)
-        return self._fn('workspace_bytes')(self._handle, b, ps, ps) + b * (in_nc * ps * ps + (n_out + 1) * math.prod(out)) * 2
+        elt = 4 if dtype == torch.float32 else 2
+        if self._has_fp32:
+            self._upload()
+            L.check(self._fn('set_precision')(self._handle, int(dtype == torch.float32)))
+        return self._fn('workspace_bytes')(self._handle, b, ps, ps) + b * (in_nc * ps * ps + (n_out + 1) * math.prod(out)) * elt
+
+    _has_fp32 = False                # subclasses whose engine has an fp32 mode (innfer_<api>_set_precision): UNet, PAN
 
     def _check_dtype(self, x):
         """The input's dtype is the arithmetic the caller asks for (the reference: model.half() / t_img.half(), run.py:345,383,421-422).  These
         engines compute in fp16 with fp32 accumulation and nothing else: a float32 tensor is refused rather than served at fp16 accuracy."""
+        if x.dtype == torch.float32 and self._has_fp32:
+            return                       # float32 tensors run the engine's fp32 mode (the reference's -no_fp16: run.py:345,421-422)
         if x.dtype == torch.float32:
             raise NotImplementedError(
                 f"{type(self).__name__}: no fp32-accurate engine is built for this generator -- its kernels compute in fp16 (fp32 accumulation).  Pass "
@@ -122,6 +130,8 @@ class ParamEngineModule(nn.Module):
             raise NotImplementedError('this engine was first used on %s; build a second module for %s' % (self._weights_device, x.device))
         self._upload()
         self._weights_device = x.device
+        if self._has_fp32:               # the input's dtype IS the arithmetic, as model.half() / t_img.half() are in the reference
+            L.check(self._fn('set_precision')(self._handle, int(x.dtype == torch.float32)))
         x = x.contiguous()
         N, _, H, W = x.shape
         out = torch.empty(self._out_shape(N, H, W), dtype=x.dtype, device=x.device)

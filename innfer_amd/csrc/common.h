@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -164,5 +165,31 @@ size_t pan_scpa_blob_bytes();
 void pan_scpa_pack(const float* c1a, const float* c1b, const float* k1, const float* k2, const float* k2b, const float* k3, const float* k4, const float* c3, void* blob);
 // in / out: slabs of two 32-channel groups (40 real channels, pad channels zero), group stride G elements; x -> x + conv3(cat[..]) (PAN_arch.py:58-105)
 int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s);
+
+// ---- fp32 NCHW building blocks of the -no_fp16 mode of PAN / UNet (f32ops.hip) --------
+struct F32Conv {
+    const float* in; long in_nstride, in_cstride; int C, Hin, Win;       // input view: (n, c, y, x) at in + n * in_nstride + c * in_cstride + y * Win + x
+    const float* wp; const float* bias; int K;                          // f32conv_pack panels; bias may be null
+    float* out; long out_nstride, out_cstride, out_pstride; int Wout;    // output view: (n, k, Y, X) at out + n * ns + k * cs + (Y * Wout + X) * ps (ps 0 = 1)
+    int Ho, Wo;                                                         // the grid this launch walks (the phase grid of a transposed conv)
+    int osy, osx, ooy, oox;                                             // output pixel (Y, X) = (oy * osy + ooy, ox * osx + oox)
+    int isy, isx;                                                       // tap source = (oy * isy + dy[tap], ox * isx + dx[tap]); outside the image: zero
+    int ntap, dy[16], dx[16];
+    int up;                                                             // taps walk the nearest-2x upsampled image (source pixel = coordinate >> 1)
+    int in_act;                                                         // 0 / 1 LeakyReLU(0.2) / 2 ReLU applied to the input as it is read
+    int act;                                                            // epilogue activation: 0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 4 sigmoid
+    const float* res; long res_nstride, res_cstride;                    // + residual after the activation (same pixel indexing as `out` with ps 1)
+    const float* mul; long mul_nstride, mul_cstride;                    // v = mul * sigmoid(conv + bias) before the activation (pixel attention)
+    int N;
+};
+size_t f32conv_packed_floats(int K, int C, int ntap);
+void f32conv_pack(int K, int C, int ntap, const std::function<float(int, int, int)>& w, float* packed);     // host; w(k, c, tap)
+int f32conv_launch(const F32Conv& L, hipStream_t s);
+int f32_norm_launch(const float* in, long in_ns, long in_cs, float* out, long out_ns, long out_cs, int N, int C, long HW, int mode, float eps,
+                    const float* weight, const float* bias, const float* rmean, const float* rvar, int act, hipStream_t s);
+int f32_act_copy_launch(const float* in, long in_ns, float* out, long out_ns, long per_image, int N, int act, hipStream_t s);
+int f32_maxpool4_launch(const float* in, float* out, long planes, int H, int W, hipStream_t s);
+int f32_fsa_combine_launch(const float* att, int hp, int wp, int C, const float* inp, float* out, int N, int H, int W, const float* gamma, hipStream_t s);
+int f32_upsample_launch(const float* in, float* out, long planes, int h, int w, int f, int bilinear, hipStream_t s);
 
 }  // namespace innfer

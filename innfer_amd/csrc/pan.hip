@@ -472,6 +472,8 @@ struct innfer_pan {
     std::vector<Param> params;
     std::vector<Gemm> gemms;
     std::vector<float*> d_vecs;      // device copies of bias vectors / gamma, by param index (nullptr if unused)
+    bool fp32 = false;               // innfer_pan_set_precision(1): the fp32 forward on NCHW fp32 tensors (f32ops.hip), the reference's -no_fp16 mode
+    std::vector<float*> f32_w;       //   f32conv panels in forward order (pan_forward_f32 walks them)
     std::vector<void*> d_scpa;       // one weight blob per SCPA block (pan_scpa.hip), trunk by trunk
     int mfma_attention = 1;          // the FSA block's attention on the matrix cores (pan_attention_mfma); 0: the VALU kernel of rounds 1-3 (set with fused_scpa: one A/B switch)
     int fused_scpa = 1;              // an SCPA block as ONE launch (innfer_pan_set_fused_scpa); 0: the five halo-tile launches of rounds 1-3
@@ -534,6 +536,7 @@ extern "C" void innfer_pan_destroy(innfer_pan* p) {
     for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
     for (auto v : p->d_scpa) if (v) (void)hipFree(v);
+    for (auto v : p->f32_w) if (v) (void)hipFree(v);
     delete p;
 }
 
@@ -698,6 +701,8 @@ int upload(innfer_pan* p) {
         INNFER_HIP(hipMalloc((void**)&g.d_w, panel.size() * sizeof(f16)));
         INNFER_HIP(hipMemcpy(g.d_w, panel.data(), panel.size() * sizeof(f16), hipMemcpyHostToDevice));
     }
+    for (auto v : p->f32_w) if (v) (void)hipFree(v);                 // the fp32 panels follow the parameters: rebuilt by innfer_pan_set_precision
+    p->f32_w.clear();
     for (auto v : p->d_scpa) if (v) (void)hipFree(v);
     p->d_scpa.clear();
     {   // one blob per SCPA block for the fused launch (pan_scpa.hip): the block's eight tensors as MFMA fragments
@@ -756,9 +761,182 @@ PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
 
 }  // namespace
 
+namespace {
+// ---- the fp32 mode: PAN.forward on NCHW fp32 tensors with the generic fp32 ops (f32ops.hip); graph = oracle/nets.py pan_forward = PAN_arch.py:178-222 ----
+struct PCarve32 { size_t fea, xa, xb, ab, cat, k3y, yv, inp, t, pool, fgh, att, hr[2][3], ups, raw, total; };
+PCarve32 pcarve32(const innfer_pan* p, int N, int H, int W) {
+    PCarve32 c{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t px = (size_t)N * H * W, hp = H / 4, wp = W / 4, np = (size_t)N * hp * wp, nf = p->nf, gw = nf / 2, UF = p->unf;
+    size_t off = 0;
+    auto buf = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
+    c.fea = buf(px * nf); c.xa = buf(px * nf); c.xb = buf(px * nf); c.ab = buf(px * nf); c.cat = buf(px * nf); c.k3y = buf(px * gw); c.yv = buf(px * gw);
+    c.inp = buf(px * nf); c.t = buf(px * nf); c.pool = buf((np ? np : 1) * nf); c.fgh = buf((np ? np : 1) * 64); c.att = buf((np ? np : 1) * nf);
+    size_t m = 1, ups = 0;
+    for (int u = 0; u < p->n_up; ++u) {
+        const size_t cin = u == 0 ? nf : UF;
+        m *= p->scale == 3 ? 9 : 4;
+        ups = std::max(ups, px * m * cin);
+        for (int k = 0; k < 3; ++k) c.hr[u][k] = buf(px * m * UF);
+    }
+    c.ups = (p->bilinear_up || p->scale == 3) ? buf(ups) : 0;
+    c.raw = buf(px * m * p->out_nc);
+    c.total = off;
+    return c;
+}
+
+int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W, char* ws, hipStream_t s) {
+    const PCarve32 cv = pcarve32(p, N, H, W);
+    const int nf = p->nf, gw = nf / 2, UF = p->unf;
+    const long hw = (long)H * W;
+    auto B = [&](size_t o) { return (float*)(ws + o); };
+    float *FEA = B(cv.fea), *XA = B(cv.xa), *XB = B(cv.xb), *AB = B(cv.ab), *CAT = B(cv.cat), *K3Y = B(cv.k3y), *YV = B(cv.yv), *INP = B(cv.inp), *T = B(cv.t);
+    auto vec = [&](const std::string& key) -> const float* { const int i = find(p, key); return i >= 0 ? p->d_vecs[i] : nullptr; };
+    int wi = 0;
+    // conv of `ksz` x `ksz` taps (zero padding ksz / 2) over C input channels of a tensor with `ctot` channels at h x w (read through nearest-2x when `up`) -> K channels of a
+    // tensor with `ktot` channels, starting at the pointer given
+    auto conv = [&](const float* in, int ctot, int C, int h, int w, int up, int ksz, const float* bias, int K, float* out, int ktot, int act,
+                    const float* res = nullptr, int rtot = 0, const float* mul = nullptr, int mtot = 0) -> int {
+        F32Conv c{};
+        const int ho = up ? 2 * h : h, wo = up ? 2 * w : w;
+        c.in = in; c.in_nstride = (long)ctot * h * w; c.in_cstride = (long)h * w; c.C = C; c.Hin = h; c.Win = w;
+        c.wp = p->f32_w[wi++]; c.bias = bias; c.K = K;
+        c.out = out; c.out_nstride = (long)ktot * ho * wo; c.out_cstride = (long)ho * wo; c.out_pstride = 1; c.Wout = wo;
+        c.Ho = ho; c.Wo = wo; c.osy = c.osx = 1; c.isy = c.isx = 1; c.up = up;
+        c.ntap = ksz * ksz;
+        for (int t = 0; t < c.ntap; ++t) { c.dy[t] = t / ksz - ksz / 2; c.dx[t] = t % ksz - ksz / 2; }
+        c.act = act; c.N = N;
+        c.res = res; c.res_nstride = (long)rtot * ho * wo; c.res_cstride = (long)ho * wo;
+        c.mul = mul; c.mul_nstride = (long)mtot * ho * wo; c.mul_cstride = (long)ho * wo;
+        return f32conv_launch(c, s);
+    };
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    CK(conv(x, p->in_nc, p->in_nc, H, W, 0, 3, vec("conv_first.bias"), nf, FEA, nf, 0));
+    const float* xc = FEA;
+    for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {
+        const std::string sfx = k ? "2" : "";
+        for (int b = 0; b < p->nb; ++b) {
+            const std::string sb = "SCPA_trunk" + sfx + "." + std::to_string(b) + ".";
+            float* xn = (b & 1) ? XB : XA;
+            CK(conv(xc, nf, nf, H, W, 0, 1, nullptr, nf, AB, nf, 1));                                    // lrelu(conv1_a | conv1_b)
+            CK(conv(AB, nf, gw, H, W, 0, 3, nullptr, gw, CAT, nf, 1));                                   // a = lrelu(k1(a))
+            CK(conv(AB + gw * hw, nf, gw, H, W, 0, 3, nullptr, gw, K3Y, gw, 0));                         // k3(b)
+            CK(conv(AB + gw * hw, nf, gw, H, W, 0, 1, vec(sb + "PACnv.k2.bias"), gw, YV, gw, 0, nullptr, 0, K3Y, gw));   // k3(b) * sigmoid(k2(b) + bias)
+            CK(conv(YV, gw, gw, H, W, 0, 3, nullptr, gw, CAT + gw * hw, nf, 1));                          // b = lrelu(k4(.))
+            CK(conv(CAT, nf, nf, H, W, 0, 1, nullptr, nf, xn, nf, 0, xc, nf));                           // conv3(cat[a, b]) + x
+            xc = xn;
+        }
+        const std::string bk = "trunk_conv" + sfx + ".bias";
+        if (p->double_scpa && k == 0) { CK(conv(xc, nf, nf, H, W, 0, 3, vec(bk), nf, INP, nf, 0)); xc = INP; }
+        else CK(conv(xc, nf, nf, H, W, 0, 3, vec(bk), nf, p->double_scpa ? T : INP, nf, 0, FEA, nf));       // + fea
+    }
+    if (p->double_scpa) std::swap(INP, T);
+    const float* cur = INP;
+    if (p->self_attention) {
+        const int hp = H / 4, wp = W / 4, Np = hp * wp;
+        float *POOL = B(cv.pool), *FGH = B(cv.fgh), *ATT = B(cv.att);
+        CK(f32_maxpool4_launch(INP, POOL, (long)N * nf, H, W, s));
+        {   // [f | g | h] = 1x1 convs of the pooled pixels, written as 64-float rows per pixel (biases are added by the attention kernel)
+            F32Conv c{};
+            c.in = POOL; c.in_nstride = (long)nf * Np; c.in_cstride = Np; c.C = nf; c.Hin = hp; c.Win = wp;
+            c.wp = p->f32_w[wi++]; c.K = 2 * (nf / 8) + nf;
+            c.out = FGH; c.out_nstride = (long)Np * 64; c.out_cstride = 1; c.out_pstride = 64; c.Wout = wp;
+            c.Ho = hp; c.Wo = wp; c.osy = c.osx = 1; c.isy = c.isx = 1; c.ntap = 1; c.N = N;
+            CK(f32conv_launch(c, s));
+        }
+        hipLaunchKernelGGL(pan_attention, dim3((Np + 63) / 64, N), dim3(256), 0, s, (const float*)FGH, vec("FSA.conv_f.bias"), vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), Np, ATT);
+        INNFER_HIP(hipGetLastError());
+        CK(f32_fsa_combine_launch(ATT, hp, wp, nf, INP, T, N, H, W, vec("FSA.gamma"), s));
+        cur = T;
+    }
+    int h = H, w = W, cc = nf;
+    for (int u = 0; u < p->n_up; ++u) {
+        const int uf = p->scale == 3 ? 3 : 2, hh = uf * h, ww = uf * w, i = 5 * u;
+        float *V = B(cv.hr[u][0]), *PAo = B(cv.hr[u][1]), *HRC = B(cv.hr[u][2]);
+        const std::string s1 = "upsample." + std::to_string(i + 1) + ".bias", s2 = "upsample." + std::to_string(i + 2) + ".conv.bias", s4 = "upsample." + std::to_string(i + 4) + ".bias";
+        if (p->bilinear_up || uf == 3) {
+            float* UPS = B(cv.ups);
+            CK(f32_upsample_launch(cur, UPS, (long)N * cc, h, w, uf, p->bilinear_up ? 1 : 0, s));
+            CK(conv(UPS, cc, cc, hh, ww, 0, 3, vec(s1), UF, V, UF, 0));
+        } else {
+            CK(conv(cur, cc, cc, h, w, 1, 3, vec(s1), UF, V, UF, 0));                                   // conv(nearest2x(t))
+        }
+        CK(conv(V, UF, UF, hh, ww, 0, 1, vec(s2), UF, PAo, UF, 1, nullptr, 0, V, UF));                   // lrelu(v * sigmoid(conv1x1(v)))
+        CK(conv(PAo, UF, UF, hh, ww, 0, 3, vec(s4), UF, HRC, UF, p->n_up == 1 ? 1 : 0));                 // HRconv (+ the LeakyReLU only in one-stage nets: see the fp16 path)
+        cur = HRC; h = hh; w = ww; cc = UF;
+    }
+    float* RAW = B(cv.raw);
+    CK(conv(cur, cc, cc, h, w, 0, 3, vec("conv_last.bias"), p->out_nc, RAW, p->out_nc, 0));
+    {
+        const long fpx = (long)N * h * w;
+        hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, (const float*)RAW, 0, (const float*)nullptr, p->out_nc, (const void*)x, 1, N, H, W, p->scale, (void*)y, 1);
+        INNFER_HIP(hipGetLastError());
+    }
+#undef CK
+    return INNFER_OK;
+}
+}  // namespace
+
+// The reference's fp16 switch for this generator (run.py:345,421-422): fp32 = 1 runs PAN.forward in fp32 on NCHW fp32 tensors (csrc/f32ops.hip; the attention on the fp32
+// VALU kernel) -- <= 1e-4 of the fp32 reference; input / output fp32.  A load-time call: it packs the fp32 panels of the parameters set so far.
+extern "C" int innfer_pan_set_precision(innfer_pan* p, int fp32) {
+    if (!p || (fp32 != 0 && fp32 != 1)) return set_error(INNFER_ERR_INVALID, "pan_set_precision: 0 (fp16 arithmetic) or 1 (fp32)");
+    p->fp32 = fp32 != 0;
+    if (!p->fp32) return INNFER_OK;
+    if (!p->uploaded) { int rc = upload(p); if (rc) return rc; }
+    if (!p->f32_w.empty()) return INNFER_OK;
+    const int nf = p->nf, gw = nf / 2, UF = p->unf, cq = nf / 8;
+    auto Wk = [p](const std::string& key) -> const std::vector<float>& { return p->params[find(p, key)].host; };
+    std::vector<float> host;
+    auto put = [&](int K, int C, int ntap, const std::function<float(int, int, int)>& w) -> int {
+        host.resize(f32conv_packed_floats(K, C, ntap));
+        f32conv_pack(K, C, ntap, w, host.data());
+        float* d = nullptr;
+        INNFER_HIP(hipMalloc((void**)&d, host.size() * sizeof(float)));
+        p->f32_w.push_back(d);
+        INNFER_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+        return INNFER_OK;
+    };
+    auto plain = [&](const std::string& key, int K, int C, int ksz) -> int {      // torch layout [K][C][ksz][ksz]
+        const std::vector<float>& w = Wk(key);
+        const int T = ksz * ksz;
+        return put(K, C, T, [&w, C, T](int k, int c, int t) { return w[((size_t)k * C + c) * T + t]; });
+    };
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    CK(plain("conv_first.weight", nf, p->in_nc, 3));
+    for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {
+        const std::string sfx = k ? "2" : "";
+        for (int b = 0; b < p->nb; ++b) {
+            const std::string sb = "SCPA_trunk" + sfx + "." + std::to_string(b) + ".";
+            const std::vector<float>&wa = Wk(sb + "conv1_a.weight"), &wb = Wk(sb + "conv1_b.weight");
+            CK(put(nf, nf, 1, [&wa, &wb, nf, gw](int k2, int c, int) { return k2 < gw ? wa[(size_t)k2 * nf + c] : wb[(size_t)(k2 - gw) * nf + c]; }));
+            CK(plain(sb + "k1.0.weight", gw, gw, 3));
+            CK(plain(sb + "PACnv.k3.weight", gw, gw, 3));
+            CK(plain(sb + "PACnv.k2.weight", gw, gw, 1));
+            CK(plain(sb + "PACnv.k4.weight", gw, gw, 3));
+            CK(plain(sb + "conv3.weight", nf, nf, 1));
+        }
+        CK(plain("trunk_conv" + sfx + ".weight", nf, nf, 3));
+    }
+    if (p->self_attention) {
+        const std::vector<float>&wf = Wk("FSA.conv_f.weight"), &wg = Wk("FSA.conv_g.weight"), &wh = Wk("FSA.conv_h.weight");
+        CK(put(2 * cq + nf, nf, 1, [&wf, &wg, &wh, nf, cq](int k2, int c, int) {
+            return k2 < cq ? wf[(size_t)k2 * nf + c] : (k2 < 2 * cq ? wg[(size_t)(k2 - cq) * nf + c] : wh[(size_t)(k2 - 2 * cq) * nf + c]); }));
+    }
+    for (int u = 0; u < p->n_up; ++u) {
+        const int i = 5 * u, cin = u == 0 ? nf : UF;
+        CK(plain("upsample." + std::to_string(i + 1) + ".weight", UF, cin, 3));
+        CK(plain("upsample." + std::to_string(i + 2) + ".conv.weight", UF, UF, 1));
+        CK(plain("upsample." + std::to_string(i + 4) + ".weight", UF, UF, 3));
+    }
+    CK(plain("conv_last.weight", p->out_nc, UF, 3));
+#undef CK
+    return INNFER_OK;
+}
+
 extern "C" size_t innfer_pan_workspace_bytes(innfer_pan* p, int N, int H, int W) {
     if (!p || N <= 0 || H <= 0 || W <= 0) return 0;
-    return pcarve(p, N, H, W).total;
+    return p->fp32 ? pcarve32(p, N, H, W).total : pcarve(p, N, H, W).total;
 }
 
 extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype, void* d_out, int out_dtype,
@@ -766,7 +944,14 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     if (!p || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "pan_forward: null argument");
     if (N <= 0 || H <= 0 || W <= 0 || (p->self_attention && (H < 4 || W < 4)))
         return set_error(INNFER_ERR_INVALID, "pan_forward: input must be at least 4x4 (MaxPool2d(4))");
-    if (!p->uploaded) { int rc = upload(p); if (rc) return rc; }
+    if (!p->uploaded) { int rc = upload(p); if (rc) return rc; if (p->fp32) { rc = innfer_pan_set_precision(p, 1); if (rc) return rc; } }
+    if (p->fp32) {
+        if (in_dtype != INNFER_F32 || out_dtype != INNFER_F32) return set_error(INNFER_ERR_INVALID, "pan_forward: the fp32 mode takes and returns fp32 tensors");
+        if (p->f32_w.empty()) return set_error(INNFER_ERR_INVALID, "pan_forward: call innfer_pan_set_precision(p, 1) after the last innfer_pan_set_param");
+        const PCarve32 c32 = pcarve32(p, N, H, W);
+        if (ws_bytes < c32.total) return set_error(INNFER_ERR_WORKSPACE, "pan_forward: workspace %zu < %zu bytes", ws_bytes, c32.total);
+        return pan_forward_f32(p, (const float*)d_in, (float*)d_out, N, H, W, (char*)d_ws, (hipStream_t)stream);
+    }
     const PCarve cv = pcarve(p, N, H, W);
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "pan_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
     hipStream_t s = (hipStream_t)stream;

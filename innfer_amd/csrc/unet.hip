@@ -421,6 +421,8 @@ struct innfer_unet {
     bool uploaded = false;
     bool eval_mode = false;            // BatchNorm on running statistics (nn.Module.eval()) instead of the current image's
     bool upconv = false;               // upsample_mode 'upconv' (UNet_arch.py:114-118,127-131,142-146; block.py:348-361)
+    bool fp32 = false;                 // innfer_unet_set_precision(1): the fp32 forward on NCHW fp32 tensors (f32ops.hip), the reference's -no_fp16 mode
+    std::vector<float*> f32_down, f32_up[4];      //   f32conv panels per level (up: one per output phase; upconv: [0] only)
     bool instance_norm = false;        // norm_type 'instance' (UNet_arch.py:38-41): nn.InstanceNorm2d -- no parameters, no running statistics, always the
                                        // statistics of the image; every conv then has a bias (use_bias, :101-104), which only matters where no norm follows
 };
@@ -527,6 +529,8 @@ extern "C" void innfer_unet_destroy(innfer_unet* u) {
             if (l.d_ev_shift) (void)hipFree(l.d_ev_shift);
             if (l.d_ones) (void)hipFree(l.d_ones);
         }
+    for (auto v : u->f32_down) if (v) (void)hipFree(v);
+    for (auto& vv : u->f32_up) for (auto v : vv) if (v) (void)hipFree(v);
     delete u;
 }
 
@@ -579,6 +583,9 @@ static void phase_taps(int a, int b, int ky[4], int kx[4], int dy[4], int dx[4])
 }
 
 static int upload_all(innfer_unet* u) {
+    for (auto v : u->f32_down) if (v) (void)hipFree(v);               // the fp32 panels follow the parameters: rebuilt by innfer_unet_set_precision
+    u->f32_down.clear();
+    for (auto& vv : u->f32_up) { for (auto v : vv) if (v) (void)hipFree(v); vv.clear(); }
     for (auto& p : u->params)
         if (!p.set && p.key.find("running_") == std::string::npos && p.key.find("num_batches") == std::string::npos)
             return set_error(INNFER_ERR_INVALID, "unet: parameter '%s' was never set", p.key.c_str());
@@ -769,10 +776,147 @@ static bool fills_tiles(int h, int w) {
     return (long)h * w * 10 >= (long)((h + 15) / 16 * 16) * tw * 7;
 }
 
+namespace {
+// fp32 mode: CAT[k] (k = 1 .. L-1) = [t_k | u_k], 2 dc[k-1] channels at H >> k; RAW: the largest conv output in front of a norm; INNER: the innermost conv's output
+struct UCarve32 { std::vector<size_t> CAT; size_t raw, inner, total; };
+UCarve32 ucarve32(const innfer_unet* u, int N, int H, int W) {
+    UCarve32 c;
+    const int L = u->num_downs;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0, rawmax = 0;
+    c.CAT.assign(L, 0);
+    for (int k = 1; k < L; ++k) {
+        c.CAT[k] = off; off += al((size_t)N * 2 * u->dc[k - 1] * (H >> k) * (W >> k) * 4);
+        rawmax = std::max(rawmax, (size_t)N * u->dc[k - 1] * (H >> k) * (W >> k) * 4);        // up[k]'s output (and down[k-1]'s) before its norm
+    }
+    c.raw = off; off += al(rawmax);
+    c.inner = off; off += al((size_t)N * u->dc[L - 1] * (H >> L) * (W >> L) * 4);
+    c.total = off;
+    return c;
+}
+}  // namespace
+
 extern "C" size_t innfer_unet_workspace_bytes(innfer_unet* u, int N, int H, int W) {
     if (!u || N <= 0 || H <= 0 || W <= 0) return 0;
-    return ucarve(u, N, H, W).total;
+    return u->fp32 ? ucarve32(u, N, H, W).total : ucarve(u, N, H, W).total;
 }
+
+// The reference's fp16 switch for this generator (run.py:345,421-422): fp32 = 1 runs every conv, norm and activation of UnetGenerator.forward in fp32 on NCHW fp32
+// tensors (csrc/f32ops.hip: the fp32 matrix instruction, fp32 statistics) -- <= 1e-4 of the fp32 reference; input / output fp32.  A load-time call: it
+// packs the fp32 panels of the parameters set so far (hipMalloc + synchronous copies); the workspace differs (ask innfer_unet_workspace_bytes after it).
+extern "C" int innfer_unet_set_precision(innfer_unet* u, int fp32) {
+    if (!u || (fp32 != 0 && fp32 != 1)) return set_error(INNFER_ERR_INVALID, "unet_set_precision: 0 (fp16 arithmetic) or 1 (fp32)");
+    u->fp32 = fp32 != 0;
+    if (!u->fp32) return INNFER_OK;
+    if (!u->uploaded) { int rc = upload_all(u); if (rc) return rc; }
+    if (!u->f32_down.empty()) return INNFER_OK;                    // (upload_all clears them when a parameter changes)
+    const int L = u->num_downs;
+    u->f32_down.assign(L, nullptr);
+    for (auto& v : u->f32_up) v.assign(L, nullptr);
+    std::vector<float> host;
+    auto put = [&](float** dst, int K, int C, int ntap, const std::function<float(int, int, int)>& w) -> int {
+        host.resize(f32conv_packed_floats(K, C, ntap));
+        f32conv_pack(K, C, ntap, w, host.data());
+        INNFER_HIP(hipMalloc((void**)dst, host.size() * sizeof(float)));
+        INNFER_HIP(hipMemcpy(*dst, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+        return INNFER_OK;
+    };
+    for (int k = 0; k < L; ++k) {
+        const Layer &d = u->down[k], &p = u->up[k];
+        const std::vector<float>& wd = u->params[d.w].host;           // Conv2d(4, 2, 1): [cout][cin][4][4]
+        int rc = put(&u->f32_down[k], d.cout, d.cin, 16, [&](int co, int ci, int t) { return wd[((size_t)co * d.cin + ci) * 16 + t]; });
+        if (rc) return rc;
+        const std::vector<float>& wu = u->params[p.w].host;
+        if (p.upconv) {                                               // Upsample(nearest 2x) + Conv2d(3x3): [cout][cin][3][3]
+            rc = put(&u->f32_up[0][k], p.cout, p.cin, 9, [&](int co, int ci, int t) { return wu[((size_t)co * p.cin + ci) * 9 + t]; });
+            if (rc) return rc;
+        } else {                                                      // ConvTranspose2d(4, 2, 1): [cin][cout][4][4], one panel per output phase
+            for (int ph = 0; ph < 4; ++ph) {
+                int ky[4], kx[4], dy[4], dx[4];
+                phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
+                rc = put(&u->f32_up[ph][k], p.cout, p.cin, 4, [&](int co, int ci, int t) { return wu[(((size_t)ci * p.cout + co) * 4 + ky[t]) * 4 + kx[t]]; });
+                if (rc) return rc;
+            }
+        }
+    }
+    return INNFER_OK;
+}
+
+namespace {
+// UnetGenerator.forward in fp32 (UNet_arch.py:70-161; the in-place LeakyReLU at the head of every block rewrites the tensor the skip connection carries, the parent's
+// in-place ReLU acts on the concatenation: oracle/nets.py unet_forward states the same graph)
+int unet_forward_f32(innfer_unet* u, const float* x, float* y, int N, int H, int W, char* ws, hipStream_t s) {
+    const int L = u->num_downs;
+    const UCarve32 cv = ucarve32(u, N, H, W);
+    const bool ev = u->eval_mode && !u->instance_norm;
+    auto CAT = [&](int k) { return (float*)(ws + cv.CAT[k]); };
+    float* RAW = (float*)(ws + cv.raw);
+    float* INNER = (float*)(ws + cv.inner);
+    auto norm = [&](const Layer& l, const float* in, int C, int h, int w, float* out, long out_ns, int act) -> int {
+        const long hw = (long)h * w;
+        if (u->instance_norm) return f32_norm_launch(in, C * hw, hw, out, out_ns, hw, N, C, hw, 2, 1e-5f, nullptr, nullptr, nullptr, nullptr, act, s);
+        if (ev) return f32_norm_launch(in, C * hw, hw, out, out_ns, hw, N, C, hw, 3, 1e-5f, l.d_ev_alpha, l.d_ev_shift, nullptr, nullptr, act, s);
+        return f32_norm_launch(in, C * hw, hw, out, out_ns, hw, N, C, hw, 0, 1e-5f, l.d_gamma, l.d_beta, nullptr, nullptr, act, s);
+    };
+    // Conv2d(4, 2, 1) of level k: input view (C channels of a tensor with `ctot` channels) at h x w -> h/2 x w/2
+    auto down = [&](int k, const float* in, int ctot, int h, int w, int in_act, float* out, long out_ns, int act) -> int {
+        const Layer& d = u->down[k];
+        F32Conv c{};
+        c.in = in; c.in_nstride = (long)ctot * h * w; c.in_cstride = (long)h * w; c.C = d.cin; c.Hin = h; c.Win = w;
+        c.wp = u->f32_down[k]; c.bias = d.d_bias; c.K = d.cout;
+        c.out = out; c.out_nstride = out_ns; c.out_cstride = (long)(h / 2) * (w / 2); c.out_pstride = 1; c.Wout = w / 2;
+        c.Ho = h / 2; c.Wo = w / 2; c.osy = c.osx = 1; c.isy = c.isx = 2;
+        c.ntap = 16;
+        for (int t = 0; t < 16; ++t) { c.dy[t] = t / 4 - 1; c.dx[t] = t % 4 - 1; }
+        c.in_act = in_act; c.act = act; c.N = N;
+        return f32conv_launch(c, s);
+    };
+    // the up conv of level k: relu(input of `cin` channels at h x w) -> cout channels at 2h x 2w
+    auto up = [&](int k, const float* in, int h, int w, float* out, long out_ns, int act) -> int {
+        const Layer& p = u->up[k];
+        F32Conv c{};
+        c.in = in; c.in_nstride = (long)p.cin * h * w; c.in_cstride = (long)h * w; c.C = p.cin; c.Hin = h; c.Win = w;
+        c.bias = p.d_bias; c.K = p.cout;
+        c.out = out; c.out_nstride = out_ns; c.out_cstride = (long)4 * h * w; c.out_pstride = 1; c.Wout = 2 * w;
+        c.in_act = 2; c.act = act; c.N = N;
+        if (p.upconv) {
+            c.wp = u->f32_up[0][k]; c.up = 1; c.Ho = 2 * h; c.Wo = 2 * w; c.osy = c.osx = 1; c.isy = c.isx = 1; c.ntap = 9;
+            for (int t = 0; t < 9; ++t) { c.dy[t] = t / 3 - 1; c.dx[t] = t % 3 - 1; }
+            return f32conv_launch(c, s);
+        }
+        for (int ph = 0; ph < 4; ++ph) {
+            int ky[4], kx[4];
+            phase_taps(ph >> 1, ph & 1, ky, kx, c.dy, c.dx);
+            c.wp = u->f32_up[ph][k]; c.Ho = h; c.Wo = w; c.osy = c.osx = 2; c.ooy = ph >> 1; c.oox = ph & 1; c.isy = c.isx = 1; c.ntap = 4;
+            int rc = f32conv_launch(c, s);
+            if (rc) return rc;
+        }
+        return INNFER_OK;
+    };
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    // level 0: no norm behind the outermost conv; the next block's in-place LeakyReLU is this conv's epilogue (t_1 = the first half of CAT[1])
+    CK(down(0, x, u->in_nc, H, W, 0, CAT(1), (long)2 * u->dc[0] * (H / 2) * (W / 2), 1));
+    for (int k = 1; k <= L - 2; ++k) {
+        const int h = H >> k, w = W >> k;
+        CK(down(k, CAT(k), 2 * u->dc[k - 1], h, w, 0, RAW, (long)u->dc[k] * (h / 2) * (w / 2), 0));
+        CK(norm(u->down[k], RAW, u->dc[k], h / 2, w / 2, CAT(k + 1), (long)2 * u->dc[k] * (h / 2) * (w / 2), 1));     // norm, then the next block's LeakyReLU
+    }
+    {   // innermost block: conv (no norm) -> relu -> up conv -> norm -> second half of CAT[L-1]
+        const int k = L - 1, h = H >> k, w = W >> k;
+        CK(down(k, CAT(k), 2 * u->dc[k - 1], h, w, 0, INNER, (long)u->dc[k] * (h / 2) * (w / 2), 0));
+        CK(up(k, INNER, h / 2, w / 2, RAW, (long)u->dc[k - 1] * h * w, 0));
+        CK(norm(u->up[k], RAW, u->dc[k - 1], h, w, CAT(k) + (long)u->dc[k - 1] * h * w, (long)2 * u->dc[k - 1] * h * w, 0));
+    }
+    for (int k = L - 2; k >= 1; --k) {
+        const int h = H >> k, w = W >> k;                          // up[k]: relu(CAT[k+1]) at h/2 -> dc[k-1] channels at h
+        CK(up(k, CAT(k + 1), h / 2, w / 2, RAW, (long)u->dc[k - 1] * h * w, 0));
+        CK(norm(u->up[k], RAW, u->dc[k - 1], h, w, CAT(k) + (long)u->dc[k - 1] * h * w, (long)2 * u->dc[k - 1] * h * w, 0));
+    }
+    CK(up(0, CAT(1), H / 2, W / 2, y, (long)u->out_nc * H * W, 3));               // outermost: bias + tanh
+#undef CK
+    return INNFER_OK;
+}
+}  // namespace
 
 extern "C" double innfer_unet_flops(innfer_unet* u, int N, int H, int W) {
     if (!u) return 0.0;
@@ -794,7 +938,14 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     const bool ev = u->eval_mode && !u->instance_norm;            // InstanceNorm2d keeps no running statistics: eval() changes nothing
     if (!ev && (H >> (L - 1)) * (W >> (L - 1)) < 2)
         return set_error(INNFER_ERR_INVALID, "unet_forward: the norm layers need more than one value per channel");
-    if (!u->uploaded) { int rc = upload_all(u); if (rc) return rc; }
+    if (!u->uploaded) { int rc = upload_all(u); if (rc) return rc; if (u->fp32) { rc = innfer_unet_set_precision(u, 1); if (rc) return rc; } }
+    if (u->fp32) {
+        if (in_dtype != INNFER_F32 || out_dtype != INNFER_F32) return set_error(INNFER_ERR_INVALID, "unet_forward: the fp32 mode takes and returns fp32 tensors");
+        if (u->f32_down.empty()) return set_error(INNFER_ERR_INVALID, "unet_forward: call innfer_unet_set_precision(u, 1) after the last innfer_unet_set_param");
+        const UCarve32 c32 = ucarve32(u, N, H, W);
+        if (ws_bytes < c32.total) return set_error(INNFER_ERR_WORKSPACE, "unet_forward: workspace %zu < %zu bytes", ws_bytes, c32.total);
+        return unet_forward_f32(u, (const float*)d_in, (float*)d_out, N, H, W, (char*)d_ws, (hipStream_t)stream);
+    }
     const UCarve cv = ucarve(u, N, H, W);
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "unet_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
     hipStream_t s = (hipStream_t)stream;

@@ -96,6 +96,7 @@ SIGNATURES = {
     "innfer_unet_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "innfer_unet_set_param": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "innfer_unet_set_eval": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_unet_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -107,6 +108,7 @@ SIGNATURES = {
     "innfer_pan_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "innfer_pan_set_param": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "innfer_pan_set_fused_scpa": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_pan_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_pan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_pan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

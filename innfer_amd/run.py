@@ -333,11 +333,11 @@ def main(argv=None):
     model_chain, scale_chain = parse_models(args.models)
     models = [Model(mc, args.arch, sc, device=device, meval=meval, strict=strict, chop=chop) for mc, sc in zip(model_chain, scale_chain)]
     if not fp16:
-        # -no_fp16 = fp32 arithmetic on the GPU (run.py:345,421-422).  RRDBNet / SRResNet have an fp32-accurate engine (float32 tensors select it);
-        # the other generators compute in fp16 only and refuse instead of handing out fp16 accuracy under the flag.
+        # -no_fp16 = fp32 arithmetic on the GPU (run.py:345,421-422).  RRDBNet / SRResNet have an fp32-accurate engine, PAN and the pix2pix UNet an fp32 mode
+        # (float32 tensors select them); the other generators compute in fp16 only and refuse instead of handing out fp16 accuracy under the flag.
         from .architectures.engine_module import EngineModule
         for m in models:
-            if not isinstance(m.model, EngineModule):
+            if not isinstance(m.model, EngineModule) and not getattr(m.model, '_has_fp32', False):
                 raise NotImplementedError(f"-no_fp16: no fp32-accurate engine is built for '{m.arch}' ({type(m.model).__name__}); drop the flag to run its fp16 engine")
     images = U.get_images_paths(args.input)
     os.makedirs(args.output, exist_ok=True)

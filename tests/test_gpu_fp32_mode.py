@@ -225,11 +225,110 @@ def test_model_chop_fp32_mode_vs_golden_g4(dev, golden, tmp_path):
         assert max(e1, e2, e3) < FP32_TOL, (tag, e1, e2, e3)
 
 
+def test_unet_fp32_mode_vs_goldens(dev, golden):
+    """pix2pix UnetGenerator on float32 tensors = the reference's -no_fp16 mode (run.py:345,421-422): innfer_unet_set_precision(1), every conv / norm / activation in
+    fp32 (csrc/f32ops.hip).  Golden G7 (train-mode BatchNorm, UNet_256), G17 (eval mode on running statistics), G23 (instance norm, dropout under eval, upconv):
+    <= 1e-4 on the tanh output; a batch equals its images' own forwards; the fp16 engine still answers float16 tensors from the same module."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.architectures.UNet_arch import UnetGenerator
+    from innfer_amd.utils.defaults import get_network_G_config
+    from test_oracle_golden import G23_CASES, _g23_state
+    g, g17 = golden("g7_unet256"), golden("g17_fp16_and_eval")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    net = get_network(get_network_G_config("p2p_256", 1))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}, strict=True)
+    net = net.to(dev).train()
+    xa = torch.from_numpy(synth.uniform((1, 3, 256, 256), 7, -1.0, 1.0)).to(dev)
+    xb = torch.from_numpy(synth.uniform((1, 3, 256, 256), 8, -1.0, 1.0)).to(dev)
+    ya = net(xa)
+    assert ya.dtype == torch.float32
+    e = ya.cpu().numpy()[0, :, ::4, ::4] - g["out_a_sub"]        # (the fixture's fp32 part: every fourth pixel; `out_a` is stored as fp16)
+    print(f"unet256 fp32 mode, train-mode BN vs G7: max {np.abs(e).max():.2e} mean {np.abs(e).mean():.2e}")
+    assert np.abs(e).max() < FP32_TOL, np.abs(e).max()
+    assert np.abs(ya.cpu().numpy() - g["out_a"].astype(np.float32)).max() < 2.0 ** -11           # ... and the whole image to the fp16 fixture's own rounding
+    yab = net(torch.cat([xa, xb], 0))
+    assert torch.equal(yab[0:1], ya) and torch.equal(yab[1:2], net(xb))
+    y16 = net(xa.half())                                   # the dtype selects the engine per call
+    assert y16.dtype == torch.float16 and (y16.float() - ya).abs().max().item() < 1e-2
+    assert torch.equal(net(xa), ya)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_running_stats(synth.fill_state_dict(shapes, 0), 17).items()}, strict=True)
+    net.eval()
+    e = net(xa).cpu().numpy()[0, :, ::4, ::4] - g17["unet_eval_out_a_sub"]
+    print(f"unet256 fp32 mode, eval-mode BN vs G17: max {np.abs(e).max():.2e}")
+    assert np.abs(e).max() < FP32_TOL, np.abs(e).max()
+    g23 = golden("g23_unet_variants")
+    for i, (tag, kw, ev) in enumerate(G23_CASES):
+        v = UnetGenerator(3, 3, 5, ngf=32, **kw)
+        v.load_state_dict(_g23_state(g23, tag, i), strict=True)
+        v = v.to(dev)
+        v = v.eval() if ev else v.train()
+        x = torch.from_numpy(synth.uniform((1, 3, 64, 96), 240 + i, -1.0, 1.0)).to(dev)
+        e = np.abs(v(x).cpu().numpy() - g23[tag]).max()
+        print(f"unet variant {tag} fp32 mode vs G23: max {e:.2e}")
+        assert e < FP32_TOL, (tag, e)
+
+
+def test_pan_fp32_mode_vs_goldens(dev, golden):
+    """PAN on float32 tensors = the reference's -no_fp16 mode: innfer_pan_set_precision(1), PAN.forward in fp32 (csrc/f32ops.hip; FSA attention on the fp32 kernel).
+    Golden G8 (PAN 4x, 16 SCPA blocks, self attention), G18 (self_attention=False, double_scpa=True, 2x) and the oracle at scales 1 / 2 / 3 with ragged sizes,
+    grey input, bilinear up-blocks: <= 1e-4; batches equal their images' own forwards."""
+    import ast
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.architectures.PAN_arch import PAN
+    from innfer_amd.utils.defaults import get_network_G_config
+    from test_oracle_golden import G18_PAN
+    g = golden("g8_pan")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    net = get_network(get_network_G_config("pan", 4))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}, strict=True)
+    net = net.to(dev).eval()
+    for (h, w, seed) in [(48, 48, 8), (50, 70, 9)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed)).to(dev)
+        y = net(x)
+        assert y.dtype == torch.float32
+        e = np.abs(y.cpu().numpy() - g[f"out_{h}x{w}"].astype(np.float32))
+        print(f"PAN fp32 mode {h}x{w} vs G8: max {e.max():.2e} mean {e.mean():.2e}")
+        assert e.max() < FP32_TOL * max(1.0, np.abs(g[f'out_{h}x{w}']).max()), e.max()
+        y16 = net(x.half())
+        assert y16.dtype == torch.float16 and (y16.float() - y).abs().max().item() < 1e-2
+    xa = torch.from_numpy(synth.uniform((1, 3, 48, 48), 8)).to(dev)
+    xb = torch.from_numpy(synth.uniform((1, 3, 48, 48), 21)).to(dev)
+    yab = net(torch.cat([xa, xb], 0))
+    assert torch.equal(yab[0:1], net(xa)) and torch.equal(yab[1:2], net(xb))
+    g18 = golden("g18_pan_variants")
+    for i, (tag, kw) in enumerate(G18_PAN.items()):
+        shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g18[tag + "_keys"], g18[tag + "_shapes"])}
+        v = PAN(3, 3, 40, 24, 3, **kw)
+        v.load_state_dict({k: torch.from_numpy(a) for k, a in synth.fill_state_dict(shapes, 185 + i).items()}, strict=True)
+        v = v.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((1, 3, 20, 28), 195 + i)).to(dev)
+        e = np.abs(v(x).cpu().numpy() - g18[tag].astype(np.float32)).max()
+        print(f"PAN variant {tag} fp32 mode vs G18: max {e:.2e}")
+        assert e < FP32_TOL * max(1.0, np.abs(g18[tag]).max()), (tag, e)
+    for scale, in_nc, h, w, mode in [(2, 3, 37, 21, "nearest"), (1, 1, 24, 33, "nearest"), (3, 3, 17, 23, "nearest"), (4, 3, 20, 28, "bilinear")]:
+        cfg = get_network_G_config({"type": "pan", "nb": 3, "in_nc": in_nc, "out_nc": in_nc}, scale)
+        v = PAN(in_nc, in_nc, 40, 24, 3, scale=scale, ups_inter_mode=mode) if mode != "nearest" else get_network(cfg)
+        sd = {k: torch.from_numpy(a) for k, a in synth.fill_state_dict({k: tuple(t.shape) for k, t in v.state_dict().items()}, 50 + scale).items()}
+        v.load_state_dict(sd, strict=True)
+        v = v.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((2, in_nc, h, w), 30 + scale))
+        with torch.no_grad():
+            ref = oracle.pan_forward(sd, x, nb=3, scale=scale, ups_inter_mode=mode)
+        e = (v(x.to(dev)).cpu() - ref).abs().max().item()
+        print(f"PAN x{scale} {mode} fp32 mode vs oracle: max {e:.2e}")
+        assert e < FP32_TOL * max(1.0, ref.abs().max().item()), (scale, mode, e)
+
+
 def test_generators_without_an_fp32_engine_refuse_float32(dev):
-    """PAN / UNet / PPON / CycleGAN ResNet / WBC UNet compute in fp16 only: a float32 tensor must raise, not run at fp16 accuracy behind fp32 I/O."""
+    """PPON / CycleGAN ResNet / WBC UNet compute in fp16 only: a float32 tensor must raise, not run at fp16 accuracy behind fp32 I/O.  (PAN and the pix2pix UNet
+    have an fp32 mode since round 4: test_unet_fp32_mode_vs_goldens, test_pan_fp32_mode_vs_goldens.)"""
     from innfer_amd.architectures import get_network
     from innfer_amd.utils.defaults import get_network_G_config
-    for arch, scale, shape in (("pan", 4, (1, 3, 16, 16)), ("unet_256", 1, (1, 3, 256, 256)), ("ppon", 4, (1, 3, 16, 16)), ("resnet_9blocks", 1, (1, 3, 32, 32)),
+    for arch, scale, shape in (("ppon", 4, (1, 3, 16, 16)), ("resnet_9blocks", 1, (1, 3, 32, 32)),
                                ("wbcunet", 1, (1, 3, 32, 32))):
         net = get_network(get_network_G_config(arch, scale)).to(dev)
         with pytest.raises(NotImplementedError, match="fp32"):

@@ -704,8 +704,6 @@ def test_unet256_golden(dev, golden):
     yab = net(torch.cat([xa, xb], 0).half()).float().cpu().numpy()
     assert np.array_equal(yab[0:1], ya)
     assert np.array_equal(yab[1:2], net(xb.half()).float().cpu().numpy())
-    with pytest.raises(NotImplementedError, match="fp32"):          # no fp32-accurate engine for this generator: refused, not served at fp16 accuracy
-        net(xa)
     # What fp16 costs on THIS network: the reference's own fp16 mode (net.half(), run.py:383, on the CPU: golden G17) is 6.9e-3 max /
     # 6.7e-4 mean away from its fp32 output.  The HIP path (fp16 activations, fp32 accumulate and statistics; measured 4.3e-3 / 4.1e-4)
     # must be no further from the fp32 truth than that, and within twice that of the reference's fp16 output (two roundings apart).
@@ -1102,12 +1100,16 @@ def test_command_line_image_loop(dev, tmp_path, monkeypatch, capsys):
             ref = oracle.tensor2np(oracle.chop_forward(f2, oracle.chop_forward(f1, oracle.np2tensor(im), 1), 2))
         d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
         assert d.max() <= 1 and (d == 0).mean() >= 0.999, (k, d.max(), (d == 0).mean())
-    # a generator without an fp32 engine refuses the flag instead of running fp16 behind it
+    # PAN has an fp32 mode since round 4: the flag runs it (float32 tensors through Model.__call__); a generator without one still refuses the flag instead of
+    # running fp16 behind it
     from innfer_amd.architectures import get_network
     from innfer_amd.utils.defaults import get_network_G_config
     torch.save(get_network(get_network_G_config("pan", 4)).state_dict(), str(tmp_path / "models" / "4x_pan.pth"))
+    assert R.main(["-m", "4x_pan", "-i", "in", "-o", "out_pan", "-no_fp16"]) == 0
+    assert sorted(os.listdir(tmp_path / "out_pan")) == sorted(f"{k}.png" for k in imgs)
+    torch.save(get_network(get_network_G_config("ppon", 4)).state_dict(), str(tmp_path / "models" / "4x_ppon.pth"))
     with pytest.raises(NotImplementedError, match="no_fp16"):
-        R.main(["-m", "4x_pan", "-i", "in", "-o", "out_pan", "-no_fp16"])
+        R.main(["-m", "4x_ppon", "-a", "ppon", "-i", "in", "-o", "out_ppon", "-no_fp16"])
 
 
 @pytest.mark.parametrize("chop", [True, False])
