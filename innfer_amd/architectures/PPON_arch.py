@@ -10,6 +10,7 @@ from .param_module import ParamEngineModule
 
 class PPON(ParamEngineModule):
     _api = 'ppon'
+    _has_fp32 = True         # float32 tensors: innfer_ppon_set_precision(1), the fp32 forward (csrc/f32ops.hip)
     _n_outputs = 3
 
     def _out_shape(self, N, H, W):
@@ -29,6 +30,7 @@ class PPON(ParamEngineModule):
             raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
         self._check_dtype(x)
         self._upload()
+        L.check(L.lib.innfer_ppon_set_precision(self._handle, int(x.dtype == torch.float32)))      # the dtype IS the arithmetic (run.py:345,421-422)
         x = x.contiguous()
         N, _, H, W = x.shape
         s = self.scale

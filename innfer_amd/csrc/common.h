@@ -178,6 +178,7 @@ struct F32Conv {
     int up;                                                             // taps walk the nearest-2x upsampled image (source pixel = coordinate >> 1)
     int in_act;                                                         // 0 / 1 LeakyReLU(0.2) / 2 ReLU applied to the input as it is read
     int act;                                                            // epilogue activation: 0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 4 sigmoid
+    float oscale;                                                       // != 0: the activated value is multiplied by it before the residual is added (`x + 0.2 * conv`)
     const float* res; long res_nstride, res_cstride;                    // + residual after the activation (same pixel indexing as `out` with ps 1)
     const float* mul; long mul_nstride, mul_cstride;                    // v = mul * sigmoid(conv + bias) before the activation (pixel attention)
     int N;
@@ -191,5 +192,7 @@ int f32_act_copy_launch(const float* in, long in_ns, float* out, long out_ns, lo
 int f32_maxpool4_launch(const float* in, float* out, long planes, int H, int W, hipStream_t s);
 int f32_fsa_combine_launch(const float* att, int hp, int wp, int C, const float* inp, float* out, int N, int H, int W, const float* gamma, hipStream_t s);
 int f32_upsample_launch(const float* in, float* out, long planes, int h, int w, int f, int bilinear, hipStream_t s);
+int f32_axpy_launch(const float* x, const float* y, float* out, float a, long n, hipStream_t s);                 // out = a * x + y
+int f32_prefix_lrelu_launch(float* t, int N, int groups, int gc, long hw, hipStream_t s);                           // channel group k <- LeakyReLU(0.2)(group 0 + .. + group k), in place (PPON_arch.py:104-114)
 
 }  // namespace innfer

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void f32conv_kernel(const F32Conv p, int kt_pe
                 float v = acc[t][pt][j] + (p.bias ? p.bias[k] : 0.f);
                 if (p.mul) v = p.mul[(long)n * p.mul_nstride + (long)k * p.mul_cstride + opix] * (1.0f / (1.0f + expf(-v)));
                 v = f32_act(v, p.act);
+                if (p.oscale != 0.f) v *= p.oscale;
                 if (p.res) v += p.res[(long)n * p.res_nstride + (long)k * p.res_cstride + opix];
                 p.out[(long)n * p.out_nstride + (long)k * p.out_cstride + opix * p.out_pstride] = v;
             }
@@ -218,6 +219,25 @@ __global__ void f32_nearest_up_kernel(const float* in, float* out, long planes, 
     out[i] = in[pl * (long)h * w + (long)(y / f) * w + x / f];
 }
 
+__global__ void f32_axpy_kernel(const float* x, const float* y, float* out, float a, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + y[i];
+}
+
+// t: [N][groups * gc][hw]; channel c of group k becomes LeakyReLU(0.2)(sum of channel c of groups 0 .. k), the sums formed in group order (PPON's
+// cat(d1, d1 + d2, .., d1 + .. + d8) -> act: PPON_arch.py:104-114)
+__global__ void f32_prefix_lrelu_kernel(float* t, int N, int groups, int gc, long hw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * gc * hw) return;
+    const long px = i % hw, c = (i / hw) % gc, n = i / (hw * gc);
+    float* b = t + (n * groups * gc + c) * hw + px;
+    float run = 0.f;
+    for (int k = 0; k < groups; ++k) {
+        run += b[(long)k * gc * hw];
+        b[(long)k * gc * hw] = run > 0.f ? run : 0.2f * run;
+    }
+}
+
 }  // namespace
 
 size_t f32conv_packed_floats(int K, int C, int ntap) { return (size_t)ntap * ((C + 3) / 4) * ((K + 31) / 32 * 32) * 4; }
@@ -281,6 +301,19 @@ int f32_upsample_launch(const float* in, float* out, long planes, int h, int w, 
     const long tot = planes * (long)h * w * f * f;
     if (bilinear) hipLaunchKernelGGL(f32_bilinear_up_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, in, out, planes, h, w, f);
     else hipLaunchKernelGGL(f32_nearest_up_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, in, out, planes, h, w, f);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+int f32_axpy_launch(const float* x, const float* y, float* out, float a, long n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, out, a, n);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+int f32_prefix_lrelu_launch(float* t, int N, int groups, int gc, long hw, hipStream_t s) {
+    const long tot = (long)N * gc * hw;
+    hipLaunchKernelGGL(f32_prefix_lrelu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, t, N, groups, gc, hw);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }

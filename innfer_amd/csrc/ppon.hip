@@ -126,6 +126,8 @@ struct innfer_ppon {
     std::vector<ResB> rbs;                   // (nb + 4) * 3 residual blocks: CFEM trunk, SFEM, PFEM
     Conv3 lr;                                // CFEM.1.sub.<nb>
     Head heads[3];                           // CRM, SRM, PRM
+    bool fp32 = false;                       // innfer_ppon_set_precision(1): PPON.forward in fp32 on NCHW fp32 tensors (f32ops.hip), the reference's -no_fp16 mode
+    std::vector<float*> f32_w;               //   f32conv panels in forward order
     bool uploaded = false;
 };
 
@@ -193,6 +195,8 @@ static void free_conv3(Conv3& c) {
 }
 
 static void free_device(innfer_ppon* p) {
+    for (auto v : p->f32_w) if (v) (void)hipFree(v);
+    p->f32_w.clear();
     if (p->d_fea_w) (void)hipFree(p->d_fea_w);
     if (p->d_fea_b) (void)hipFree(p->d_fea_b);
     p->d_fea_w = p->d_fea_b = nullptr;
@@ -382,16 +386,180 @@ QCarve qcarve(const innfer_ppon* p, int N, int H, int W, int out_elt) {
 
 }  // namespace
 
+namespace {
+// ---- the fp32 mode: PPON.forward (PPON_arch.py:65-129) on NCHW fp32 tensors with the generic fp32 ops of f32ops.hip; graph = oracle/nets.py ppon_forward ----
+struct QCarve32 { size_t fea, t[4], o1, d, cfem, sfem, pfem, up[3], hr, ups, tmp_c, tmp_s, total; };
+QCarve32 qcarve32(const innfer_ppon* p, int N, int H, int W) {
+    QCarve32 c{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t px = (size_t)N * H * W, nf = p->nf;
+    size_t off = 0;
+    auto buf = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
+    c.fea = buf(px * nf);
+    for (int i = 0; i < 4; ++i) c.t[i] = buf(px * nf);
+    c.o1 = buf(px * nf); c.d = buf(px * nf * 4); c.cfem = buf(px * nf); c.sfem = buf(px * nf); c.pfem = buf(px * nf);
+    size_t m = 1;
+    for (int u = 0; u < p->n_up; ++u) { m *= p->scale == 3 ? 9 : 4; c.up[u] = buf(px * m * nf); }
+    c.hr = buf(px * m * nf);
+    c.ups = p->scale == 3 ? buf(px * 9 * nf) : 0;
+    c.tmp_c = buf(px * m * p->out_nc); c.tmp_s = buf(px * m * p->out_nc);
+    c.total = off;
+    return c;
+}
+
+int ppon_forward_f32(innfer_ppon* p, const float* x, float* out_c, float* out_s, float* out_p, int N, int H, int W, char* ws, hipStream_t s) {
+    const QCarve32 cv = qcarve32(p, N, H, W);
+    const int nf = p->nf;
+    const long hw = (long)H * W;
+    auto B = [&](size_t o) { return (float*)(ws + o); };
+    if (!out_c) out_c = B(cv.tmp_c);
+    if (!out_s) out_s = B(cv.tmp_s);
+    int wi = 0;
+    // 3x3 conv with dilation `dil` (zero padding = dil; 1x1 when ksz == 1) over C channels at h x w (read through nearest-2x when `up`) -> K channels of a tensor with ktot channels
+    auto conv = [&](const float* in, int C, int h, int w, int up, int ksz, int dil, const float* bias, int K, float* out, int ktot, int act,
+                    float oscale = 0.f, const float* res = nullptr, int rtot = 0) -> int {
+        F32Conv c{};
+        const int ho = up ? 2 * h : h, wo = up ? 2 * w : w;
+        c.in = in; c.in_nstride = (long)C * h * w; c.in_cstride = (long)h * w; c.C = C; c.Hin = h; c.Win = w;
+        c.wp = p->f32_w[wi++]; c.bias = bias; c.K = K;
+        c.out = out; c.out_nstride = (long)ktot * ho * wo; c.out_cstride = (long)ho * wo; c.out_pstride = 1; c.Wout = wo;
+        c.Ho = ho; c.Wo = wo; c.osy = c.osx = 1; c.isy = c.isx = 1; c.up = up;
+        c.ntap = ksz * ksz;
+        for (int t = 0; t < c.ntap; ++t) { c.dy[t] = (t / ksz - ksz / 2) * dil; c.dx[t] = (t % ksz - ksz / 2) * dil; }
+        c.act = act; c.oscale = oscale; c.N = N;
+        c.res = res; c.res_nstride = (long)rtot * ho * wo; c.res_cstride = (long)ho * wo;
+        return f32conv_launch(c, s);
+    };
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    float *FEA = B(cv.fea), *O1 = B(cv.o1), *D = B(cv.d), *CFEM = B(cv.cfem), *SFEM = B(cv.sfem), *PFEM = B(cv.pfem);
+    float* T[4] = {B(cv.t[0]), B(cv.t[1]), B(cv.t[2]), B(cv.t[3])};
+    CK(conv(x, p->in_nc, H, W, 0, 3, 1, p->d_fea_b, nf, FEA, nf, 0));
+    size_t rbi = 0;
+    // RRBlock_32 (PPON_arch.py:116-129): x -> RB1 -> RB2 -> RB3 -> * 0.2 + x; _ResBlock_32 (:79-114): c1, LeakyReLU, d1..d8 (dilation 1..8), running sums, LeakyReLU, c2 (1x1), * 0.2 + input
+    auto rrblock = [&](const float* xin, float* dst, float* sa, float* sb) -> int {
+        const float* cur = xin;
+        for (int k = 0; k < 3; ++k) {
+            const ResB& r = p->rbs[rbi++];
+            float* o = k == 1 ? sb : sa;
+            CK(conv(cur, nf, H, W, 0, 3, 1, r.c1.d_b, nf, O1, nf, 1));
+            for (int d = 0; d < 8; ++d) CK(conv(O1, nf, H, W, 0, 3, d + 1, r.d_dbias + 32 * d, nf / 2, D + (long)(nf / 2) * d * hw, 4 * nf, 0));
+            CK(f32_prefix_lrelu_launch(D, N, 8, nf / 2, hw, s));
+            CK(conv(D, 4 * nf, H, W, 0, 1, 1, r.d_c2b, nf, o, nf, 0, 0.2f, cur, nf));
+            cur = o;
+        }
+        return f32_axpy_launch(cur, xin, dst, 0.2f, (long)N * nf * hw, s);
+    };
+    // nblk RRBlocks from `from` (a buffer outside T); the last one writes `last` (outside T too).  T[0..3] rotate: a block's output and its two scratch
+    // buffers are never the buffer it reads
+    auto chain = [&](const float* from, int nblk, float* last) -> int {
+        const float* c = from;
+        int curi = -1;
+        for (int b = 0; b < nblk; ++b) {
+            int pick[3], n = 0;
+            for (int i = 0; i < 4 && n < 3; ++i) if (i != curi) pick[n++] = i;
+            float* dst = b == nblk - 1 ? last : T[pick[0]];
+            CK(rrblock(c, dst, T[pick[1]], T[pick[2]]));
+            c = dst;
+            curi = b == nblk - 1 ? -1 : pick[0];
+        }
+        return INNFER_OK;
+    };
+    CK(chain(FEA, p->nb, PFEM));                                                  // (the trunk's output borrows the PFEM buffer: dead once CFEM is formed)
+    CK(conv(PFEM, nf, H, W, 0, 3, 1, p->lr.d_b, nf, CFEM, nf, 0, 0.f, FEA, nf));  // CFEM = fea + LR_conv(trunk)
+    auto recon = [&](const float* in, const Head& Hd, float* out, float oscale, const float* res) -> int {
+        const float* c = in;
+        int h = H, w = W;
+        for (int u = 0; u < p->n_up; ++u) {
+            float* dst = B(cv.up[u]);
+            if (p->scale == 3) {
+                CK(f32_upsample_launch(c, B(cv.ups), (long)N * nf, h, w, 3, 0, s));
+                CK(conv(B(cv.ups), nf, 3 * h, 3 * w, 0, 3, 1, Hd.up[u].d_b, nf, dst, nf, 1));
+                h *= 3; w *= 3;
+            } else {
+                CK(conv(c, nf, h, w, 1, 3, 1, Hd.up[u].d_b, nf, dst, nf, 1));
+                h *= 2; w *= 2;
+            }
+            c = dst;
+        }
+        CK(conv(c, nf, h, w, 0, 3, 1, Hd.hr0.d_b, nf, B(cv.hr), nf, 1));
+        return conv(B(cv.hr), nf, h, w, 0, 3, 1, Hd.hr1.d_b, p->out_nc, out, p->out_nc, 0, oscale, res, p->out_nc);
+    };
+    CK(recon(CFEM, p->heads[0], out_c, 0.f, nullptr));
+    CK(chain(CFEM, 2, SFEM));
+    CK(recon(SFEM, p->heads[1], out_s, 0.f, out_c));                              // out_s = SRM(sfem) + out_c
+    CK(chain(SFEM, 2, PFEM));
+    CK(recon(PFEM, p->heads[2], out_p, p->alpha, out_s));                         // out_p = alpha * PRM(pfem) + out_s
+#undef CK
+    return INNFER_OK;
+}
+}  // namespace
+
+// The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs PPON.forward in fp32 on NCHW fp32 tensors.
+extern "C" int innfer_ppon_set_precision(innfer_ppon* p, int fp32) {
+    if (!p || (fp32 != 0 && fp32 != 1)) return set_error(INNFER_ERR_INVALID, "ppon_set_precision: 0 (fp16 arithmetic) or 1 (fp32)");
+    p->fp32 = fp32 != 0;
+    if (!p->fp32) return INNFER_OK;
+    if (!p->uploaded) { int rc = upload(p); if (rc) return rc; }
+    if (!p->f32_w.empty()) return INNFER_OK;
+    std::vector<float> host;
+    auto plain = [&](int widx, int K, int C, int ksz) -> int {                    // torch layout [K][C][ksz][ksz]
+        const std::vector<float>& w = p->params[widx].host;
+        const int T = ksz * ksz;
+        host.resize(f32conv_packed_floats(K, C, T));
+        f32conv_pack(K, C, T, [&w, C, T](int k, int c, int t) { return w[((size_t)k * C + c) * T + t]; }, host.data());
+        float* d = nullptr;
+        INNFER_HIP(hipMalloc((void**)&d, host.size() * sizeof(float)));
+        p->f32_w.push_back(d);
+        INNFER_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+        return INNFER_OK;
+    };
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    const int nf = p->nf;
+    CK(plain(p->fea_w, nf, p->in_nc, 3));
+    auto blocks = [&](size_t first, size_t count) -> int {
+        for (size_t i = first; i < first + count; ++i) {
+            const ResB& r = p->rbs[i];
+            CK(plain(r.c1.w, nf, nf, 3));
+            for (int d = 0; d < 8; ++d) CK(plain(r.d_w[d], nf / 2, nf, 3));
+            CK(plain(r.c2_w, nf, 4 * nf, 1));
+        }
+        return INNFER_OK;
+    };
+    auto head = [&](const Head& Hd) -> int {
+        for (int u = 0; u < p->n_up; ++u) CK(plain(Hd.up[u].w, nf, nf, 3));
+        CK(plain(Hd.hr0.w, nf, nf, 3));
+        CK(plain(Hd.hr1.w, p->out_nc, nf, 3));
+        return INNFER_OK;
+    };
+    // forward order: CFEM trunk, LR conv, CRM head, SFEM, SRM head, PFEM, PRM head
+    CK(blocks(0, (size_t)p->nb * 3));
+    CK(plain(p->lr.w, nf, nf, 3));
+    CK(head(p->heads[0]));
+    CK(blocks((size_t)p->nb * 3, 6));
+    CK(head(p->heads[1]));
+    CK(blocks((size_t)p->nb * 3 + 6, 6));
+    CK(head(p->heads[2]));
+#undef CK
+    return INNFER_OK;
+}
+
 extern "C" size_t innfer_ppon_workspace_bytes(innfer_ppon* p, int N, int H, int W) {
     if (!p || N <= 0 || H <= 0 || W <= 0) return 0;
-    return qcarve(p, N, H, W, 4).total;
+    return p->fp32 ? qcarve32(p, N, H, W).total : qcarve(p, N, H, W, 4).total;
 }
 
 extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtype, void* d_out_c, void* d_out_s, void* d_out_p,
                                    int out_dtype, int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
     if (!p || !d_in || !d_out_p || !d_ws) return set_error(INNFER_ERR_INVALID, "ppon_forward: null argument");
     if (N <= 0 || H <= 0 || W <= 0) return set_error(INNFER_ERR_INVALID, "ppon_forward: bad shape");
-    if (!p->uploaded) { int rc = upload(p); if (rc) return rc; }
+    if (!p->uploaded) { int rc = upload(p); if (rc) return rc; if (p->fp32) { rc = innfer_ppon_set_precision(p, 1); if (rc) return rc; } }
+    if (p->fp32) {
+        if (in_dtype != INNFER_F32 || out_dtype != INNFER_F32) return set_error(INNFER_ERR_INVALID, "ppon_forward: the fp32 mode takes and returns fp32 tensors");
+        if (p->f32_w.empty()) return set_error(INNFER_ERR_INVALID, "ppon_forward: call innfer_ppon_set_precision(p, 1) after the last innfer_ppon_set_param");
+        const QCarve32 c32 = qcarve32(p, N, H, W);
+        if (ws_bytes < c32.total) return set_error(INNFER_ERR_WORKSPACE, "ppon_forward: workspace %zu < %zu bytes", ws_bytes, c32.total);
+        return ppon_forward_f32(p, (const float*)d_in, (float*)d_out_c, (float*)d_out_s, (float*)d_out_p, N, H, W, (char*)d_ws, (hipStream_t)stream);
+    }
     const QCarve cv = qcarve(p, N, H, W, 4);
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "ppon_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
     hipStream_t s = (hipStream_t)stream;

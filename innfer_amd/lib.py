@@ -116,6 +116,7 @@ SIGNATURES = {
     "innfer_ppon_destroy": (None, [C.c_void_p]),
     "innfer_ppon_num_params": (C.c_int, [C.c_void_p]),
     "innfer_ppon_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_ppon_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_ppon_set_param": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "innfer_ppon_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_ppon_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

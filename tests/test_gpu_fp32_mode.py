@@ -323,13 +323,51 @@ def test_pan_fp32_mode_vs_goldens(dev, golden):
         assert e < FP32_TOL * max(1.0, ref.abs().max().item()), (scale, mode, e)
 
 
+def test_ppon_fp32_mode_vs_golden(dev, golden):
+    """PPON on float32 tensors (innfer_ppon_set_precision(1): the eight dilated convs as tap tables of the generic fp32 conv, running sums in fp32) against golden
+    G13 (all three outputs) and the oracle at scales 2 / 3 / 8: <= 1e-4 of the output range."""
+    import ast
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.PPON_arch import PPON
+    g = golden("g13_ppon")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    nb = max(int(k.split(".")[3]) for k in shapes if k.startswith("CFEM.1.sub."))
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}
+    net = PPON(3, 64, nb, 3, upscale=4)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    for (h, w, seed) in [(24, 24, 13), (20, 28, 14)]:                 # the golden's own inputs
+        outs = net(torch.from_numpy(synth.uniform((1, 3, h, w), seed)).to(dev))
+        for name, y in zip("csp", outs):
+            ref = g[f"out_{name}_{h}x{w}"].astype(np.float32)
+            e = np.abs(y.cpu().numpy() - ref).max()
+            print(f"PPON fp32 mode out_{name} {h}x{w} vs G13: max {e:.2e} (range {np.abs(ref).max():.2f})")
+            assert e < FP32_TOL * max(1.0, np.abs(ref).max()), (name, h, w, e)
+    for scale in (4, 2, 3, 8):
+        net = PPON(3, 64, nb, 3, upscale=scale)
+        sdn = sd if scale == 4 else {k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(t.shape) for k, t in net.state_dict().items()}, 60 + scale).items()}
+        net.load_state_dict(sdn, strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((2, 3, 12, 10) if scale == 8 else (2, 3, 24, 20), 70 + scale))
+        with torch.no_grad():
+            ref = oracle.ppon_forward(sdn, x, nb=nb, scale=scale)
+        ys = net(x.to(dev))
+        for name, y, r in zip(("out_c", "out_s", "out_p"), ys, ref):
+            e = (y.cpu() - r).abs().max().item()
+            print(f"PPON x{scale} fp32 mode {name} vs oracle: max {e:.2e} (range {r.abs().max().item():.2f})")
+            assert y.dtype == torch.float32 and e < FP32_TOL * max(1.0, r.abs().max().item()), (scale, name, e)
+        assert torch.equal(net(x[1:2].to(dev))[2], ys[2][1:2])
+        y16 = net(x.to(dev).half())[2]
+        assert y16.dtype == torch.float16 and (y16.float() - ys[2]).abs().max().item() < 1e-2 * max(1.0, ref[2].abs().max().item())
+
+
 def test_generators_without_an_fp32_engine_refuse_float32(dev):
-    """PPON / CycleGAN ResNet / WBC UNet compute in fp16 only: a float32 tensor must raise, not run at fp16 accuracy behind fp32 I/O.  (PAN and the pix2pix UNet
-    have an fp32 mode since round 4: test_unet_fp32_mode_vs_goldens, test_pan_fp32_mode_vs_goldens.)"""
+    """CycleGAN ResNet / WBC UNet compute in fp16 only: a float32 tensor must raise, not run at fp16 accuracy behind fp32 I/O.  (PAN, the pix2pix UNet and PPON
+    have an fp32 mode since round 4: test_unet_fp32_mode_vs_goldens, test_pan_fp32_mode_vs_goldens, test_ppon_fp32_mode_vs_golden.)"""
     from innfer_amd.architectures import get_network
     from innfer_amd.utils.defaults import get_network_G_config
-    for arch, scale, shape in (("ppon", 4, (1, 3, 16, 16)), ("resnet_9blocks", 1, (1, 3, 32, 32)),
-                               ("wbcunet", 1, (1, 3, 32, 32))):
+    for arch, scale, shape in (("resnet_9blocks", 1, (1, 3, 32, 32)), ("wbcunet", 1, (1, 3, 32, 32))):
         net = get_network(get_network_G_config(arch, scale)).to(dev)
         with pytest.raises(NotImplementedError, match="fp32"):
             net(torch.zeros(shape, device=dev))

@@ -1107,9 +1107,9 @@ def test_command_line_image_loop(dev, tmp_path, monkeypatch, capsys):
     torch.save(get_network(get_network_G_config("pan", 4)).state_dict(), str(tmp_path / "models" / "4x_pan.pth"))
     assert R.main(["-m", "4x_pan", "-i", "in", "-o", "out_pan", "-no_fp16"]) == 0
     assert sorted(os.listdir(tmp_path / "out_pan")) == sorted(f"{k}.png" for k in imgs)
-    torch.save(get_network(get_network_G_config("ppon", 4)).state_dict(), str(tmp_path / "models" / "4x_ppon.pth"))
+    torch.save(get_network(get_network_G_config("wbcunet", 1)).state_dict(), str(tmp_path / "models" / "1x_wbc.pth"))
     with pytest.raises(NotImplementedError, match="no_fp16"):
-        R.main(["-m", "4x_ppon", "-a", "ppon", "-i", "in", "-o", "out_ppon", "-no_fp16"])
+        R.main(["-m", "1x_wbc", "-a", "wbcunet", "-i", "in", "-o", "out_wbc", "-no_fp16"])
 
 
 @pytest.mark.parametrize("chop", [True, False])
