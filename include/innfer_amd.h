@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision.  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 108
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -292,6 +292,9 @@ int innfer_resnet_num_params(innfer_resnet_t r);
 int innfer_resnet_param_info(innfer_resnet_t r, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
 int innfer_resnet_set_param(innfer_resnet_t r, int idx, const float* h_data);
 size_t innfer_resnet_workspace_bytes(innfer_resnet_t r, int N, int H, int W);
+/* The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs the forward in fp32 on NCHW fp32 tensors
+ * (csrc/f32ops.hip) -- <= 1e-4 of the fp32 reference; fp32 tensors in and out; a load-time call.  (108) */
+int innfer_resnet_set_precision(innfer_resnet_t r, int fp32);
 int innfer_resnet_forward(innfer_resnet_t r, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                           int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 
@@ -307,6 +310,9 @@ int innfer_wbc_num_params(innfer_wbc_t u);
 int innfer_wbc_param_info(innfer_wbc_t u, int idx, char* key, size_t key_cap, int* ndim, int* shape4);
 int innfer_wbc_set_param(innfer_wbc_t u, int idx, const float* h_data);
 size_t innfer_wbc_workspace_bytes(innfer_wbc_t u, int N, int H, int W);
+/* The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs the forward in fp32 on NCHW fp32 tensors
+ * (csrc/f32ops.hip) -- <= 1e-4 of the fp32 reference; fp32 tensors in and out; a load-time call.  (108) */
+int innfer_wbc_set_precision(innfer_wbc_t w, int fp32);
 int innfer_wbc_forward(innfer_wbc_t u, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                        int N, int H, int W, void* d_workspace, size_t workspace_bytes, void* stream);
 /* d_x (guidance), d_y (input), d_out: [N,C,H,W] tensors of one dtype (f16/f32); means over 3x3 windows, reflect padding. */

@@ -10,6 +10,7 @@ _PADDING = {'reflect': 0, 'replicate': 1, 'zero': 2}          # innfer_resnet_cr
 
 class ResnetGenerator(ParamEngineModule):
     _api = 'resnet'
+    _has_fp32 = True         # float32 tensors: innfer_resnet_set_precision(1), the fp32 forward (csrc/f32ops.hip)
 
     def __init__(self, input_nc, output_nc, ngf=64, norm_type="batch", use_dropout=False, n_blocks=6,
                  padding_type='reflect', upsample_mode="deconv"):

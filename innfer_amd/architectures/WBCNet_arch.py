@@ -7,6 +7,7 @@ from .param_module import ParamEngineModule
 
 class UnetGeneratorWBC(ParamEngineModule):
     _api = 'wbc'
+    _has_fp32 = True         # float32 tensors: innfer_wbc_set_precision(1), the fp32 forward (csrc/f32ops.hip)
 
     def __init__(self, nf=32, mode='pt', slope=0.2):
         super().__init__()

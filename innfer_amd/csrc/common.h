@@ -174,7 +174,8 @@ struct F32Conv {
     int Ho, Wo;                                                         // the grid this launch walks (the phase grid of a transposed conv)
     int osy, osx, ooy, oox;                                             // output pixel (Y, X) = (oy * osy + ooy, ox * osx + oox)
     int isy, isx;                                                       // tap source = (oy * isy + dy[tap], ox * isx + dx[tap]); outside the image: zero
-    int ntap, dy[16], dx[16];
+    int ntap, dy[49], dx[49];                                           // up to 7 x 7 taps
+    int pad_mode;                                                       // taps outside the image: 0 read zero, 1 the mirrored pixel (nn.ReflectionPad2d), 2 the border pixel (nn.ReplicationPad2d)
     int up;                                                             // taps walk the nearest-2x upsampled image (source pixel = coordinate >> 1)
     int in_act;                                                         // 0 / 1 LeakyReLU(0.2) / 2 ReLU applied to the input as it is read
     int act;                                                            // epilogue activation: 0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 4 sigmoid
@@ -187,11 +188,13 @@ size_t f32conv_packed_floats(int K, int C, int ntap);
 void f32conv_pack(int K, int C, int ntap, const std::function<float(int, int, int)>& w, float* packed);     // host; w(k, c, tap)
 int f32conv_launch(const F32Conv& L, hipStream_t s);
 int f32_norm_launch(const float* in, long in_ns, long in_cs, float* out, long out_ns, long out_cs, int N, int C, long HW, int mode, float eps,
-                    const float* weight, const float* bias, const float* rmean, const float* rvar, int act, hipStream_t s);
+                    const float* weight, const float* bias, const float* rmean, const float* rvar, int act, hipStream_t s,
+                    const float* res = nullptr, long res_ns = 0, long res_cs = 0);       // + res after the activation (a residual block's skip)
 int f32_act_copy_launch(const float* in, long in_ns, float* out, long out_ns, long per_image, int N, int act, hipStream_t s);
 int f32_maxpool4_launch(const float* in, float* out, long planes, int H, int W, hipStream_t s);
 int f32_fsa_combine_launch(const float* att, int hp, int wp, int C, const float* inp, float* out, int N, int H, int W, const float* gamma, hipStream_t s);
 int f32_upsample_launch(const float* in, float* out, long planes, int h, int w, int f, int bilinear, hipStream_t s);
+int f32_upadd_launch(const float* in, const float* skip, float* out, long planes, int h, int w, int tf_mode, hipStream_t s);   // out = bilinear2x(in) + skip (WBCNet_arch.py:60-75; tf_mode: tf_2xupsample_bilinear :126-137)
 int f32_axpy_launch(const float* x, const float* y, float* out, float a, long n, hipStream_t s);                 // out = a * x + y
 int f32_prefix_lrelu_launch(float* t, int N, int groups, int gc, long hw, hipStream_t s);                           // channel group k <- LeakyReLU(0.2)(group 0 + .. + group k), in place (PPON_arch.py:104-114)
 

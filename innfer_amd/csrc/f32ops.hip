@@ -58,7 +58,13 @@ __global__ __launch_bounds__(256) void f32conv_kernel(const F32Conv p, int kt_pe
         bool ok[4];
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            const int vy = oy[pt] * p.isy + p.dy[tap], vx = ox[pt] * p.isx + p.dx[tap];
+            int vy = oy[pt] * p.isy + p.dy[tap], vx = ox[pt] * p.isx + p.dx[tap];
+            if (p.pad_mode == 1) {                                   // reflection (pad < size: one fold is enough)
+                vy = vy < 0 ? -vy : (vy >= Hv ? 2 * Hv - 2 - vy : vy);
+                vx = vx < 0 ? -vx : (vx >= Wv ? 2 * Wv - 2 - vx : vx);
+            } else if (p.pad_mode == 2) {                            // replication
+                vy = min(max(vy, 0), Hv - 1); vx = min(max(vx, 0), Wv - 1);
+            }
             ok[pt] = pv[pt] && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
             const int iy = p.up ? vy >> 1 : vy, ix = p.up ? vx >> 1 : vx;
             off[pt] = ok[pt] ? (long)iy * p.Win + ix : 0;
@@ -108,7 +114,8 @@ __global__ __launch_bounds__(256) void f32conv_kernel(const F32Conv p, int kt_pe
 // transform y = x * weight[c] + bias[c] (eval mode with ATen's precomputed alpha / shift).  Then the activation, then
 // the store through the output view (a channel offset into a concatenation).  Two passes over the plane for the statistics (mean, then squared deviations).
 __global__ __launch_bounds__(256) void f32_norm_kernel(const float* in, long in_ns, long in_cs, float* out, long out_ns, long out_cs, int C, long HW, int mode, float eps,
-                                                       const float* weight, const float* bias, const float* rmean, const float* rvar, int act) {
+                                                       const float* weight, const float* bias, const float* rmean, const float* rvar, int act,
+                                                       const float* res, long res_ns, long res_cs) {
     __shared__ float red[256];
     const int c = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const float* x = in + (long)n * in_ns + (long)c * in_cs;
@@ -116,7 +123,8 @@ __global__ __launch_bounds__(256) void f32_norm_kernel(const float* in, long in_
     if (mode == 3) {
         float* y3 = out + (long)n * out_ns + (long)c * out_cs;
         const float a3 = weight[c], s3 = bias[c];
-        for (long i = tid; i < HW; i += 256) y3[i] = f32_act(x[i] * a3 + s3, act);
+        const float* r3 = res ? res + (long)n * res_ns + (long)c * res_cs : nullptr;
+        for (long i = tid; i < HW; i += 256) y3[i] = f32_act(x[i] * a3 + s3, act) + (r3 ? r3[i] : 0.f);
         return;
     }
     if (mode == 1) {
@@ -139,7 +147,8 @@ __global__ __launch_bounds__(256) void f32_norm_kernel(const float* in, long in_
     const float inv = 1.0f / sqrtf(var + eps);
     const float al = mode == 2 ? inv : inv * weight[c], sh = mode == 2 ? -mean * inv : bias[c] - mean * inv * weight[c];
     float* y = out + (long)n * out_ns + (long)c * out_cs;
-    for (long i = tid; i < HW; i += 256) y[i] = f32_act(x[i] * al + sh, act);
+    const float* rr = res ? res + (long)n * res_ns + (long)c * res_cs : nullptr;
+    for (long i = tid; i < HW; i += 256) y[i] = f32_act(x[i] * al + sh, act) + (rr ? rr[i] : 0.f);
 }
 
 __global__ void f32_act_copy_kernel(const float* in, long in_ns, float* out, long out_ns, long per_image, int N, int act) {
@@ -219,6 +228,33 @@ __global__ void f32_nearest_up_kernel(const float* in, float* out, long planes, 
     out[i] = in[pl * (long)h * w + (long)(y / f) * w + x / f];
 }
 
+// out = up2x(in) + skip on NCHW fp32 planes.  pt: F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (ATen: source index max(0, (dst + 0.5) / 2 - 0.5), second tap
+// clamped); tf: tf_2xupsample_bilinear (WBCNet_arch.py:126-137): even positions copy, odd ones the mean with the next pixel (replicated at the border)
+__global__ void f32_upadd_kernel(const float* in, const float* skip, float* out, long planes, int h, int w, int tf_mode) {
+    const int H2 = 2 * h, W2 = 2 * w;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H2 * W2) return;
+    const int x = (int)(i % W2), y = (int)((i / W2) % H2);
+    const long pl = i / ((long)W2 * H2);
+    const float* b = in + pl * (long)h * w;
+    float v;
+    if (tf_mode) {
+        const int y0 = y >> 1, x0 = x >> 1, y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float a = b[(long)y0 * w + x0];
+        if (!(y & 1) && !(x & 1)) v = a;
+        else if ((y & 1) && !(x & 1)) v = (a + b[(long)y1 * w + x0]) / 2.f;
+        else if (!(y & 1) && (x & 1)) v = (a + b[(long)y0 * w + x1]) / 2.f;
+        else v = (a + b[(long)y1 * w + x1]) / 2.f;
+    } else {
+        const float sy = fmaxf(0.5f * ((float)y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)x + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        v = hy * (hx * b[(long)y0 * w + x0] + lx * b[(long)y0 * w + x1]) + ly * (hx * b[(long)y1 * w + x0] + lx * b[(long)y1 * w + x1]);
+    }
+    out[i] = v + skip[i];
+}
+
 __global__ void f32_axpy_kernel(const float* x, const float* y, float* out, float a, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a * x[i] + y[i];
@@ -255,7 +291,7 @@ void f32conv_pack(int K, int C, int ntap, const std::function<float(int, int, in
 }
 
 int f32conv_launch(const F32Conv& L, hipStream_t s) {
-    if (L.ntap < 1 || L.ntap > 16 || L.C < 1 || L.K < 1 || L.N < 1 || L.Ho < 1 || L.Wo < 1) return set_error(INNFER_ERR_INVALID, "f32conv: bad arguments");
+    if (L.ntap < 1 || L.ntap > 49 || L.C < 1 || L.K < 1 || L.N < 1 || L.Ho < 1 || L.Wo < 1) return set_error(INNFER_ERR_INVALID, "f32conv: bad arguments");
     const int C4 = (L.C + 3) / 4, Kp = (L.K + 31) / 32 * 32, nkt = Kp / 32;
     const int ktb = nkt >= 4 ? 4 : (nkt >= 2 ? 2 : 1);
     const long npx = (long)L.Ho * L.Wo, ptiles = (npx + 63) / 64;
@@ -269,8 +305,9 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
 }
 
 int f32_norm_launch(const float* in, long in_ns, long in_cs, float* out, long out_ns, long out_cs, int N, int C, long HW, int mode, float eps,
-                    const float* weight, const float* bias, const float* rmean, const float* rvar, int act, hipStream_t s) {
-    hipLaunchKernelGGL(f32_norm_kernel, dim3(C, N), dim3(256), 0, s, in, in_ns, in_cs, out, out_ns, out_cs, C, HW, mode, eps, weight, bias, rmean, rvar, act);
+                    const float* weight, const float* bias, const float* rmean, const float* rvar, int act, hipStream_t s,
+                    const float* res, long res_ns, long res_cs) {
+    hipLaunchKernelGGL(f32_norm_kernel, dim3(C, N), dim3(256), 0, s, in, in_ns, in_cs, out, out_ns, out_cs, C, HW, mode, eps, weight, bias, rmean, rvar, act, res, res_ns, res_cs);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
@@ -301,6 +338,13 @@ int f32_upsample_launch(const float* in, float* out, long planes, int h, int w, 
     const long tot = planes * (long)h * w * f * f;
     if (bilinear) hipLaunchKernelGGL(f32_bilinear_up_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, in, out, planes, h, w, f);
     else hipLaunchKernelGGL(f32_nearest_up_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, in, out, planes, h, w, f);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+int f32_upadd_launch(const float* in, const float* skip, float* out, long planes, int h, int w, int tf_mode, hipStream_t s) {
+    const long tot = planes * 4 * h * w;
+    hipLaunchKernelGGL(f32_upadd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, in, skip, out, planes, h, w, tf_mode);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }

@@ -283,6 +283,8 @@ struct innfer_resnet {
     int block_pad = 1;               // padding of the residual blocks' convs as a ConvLaunch.reflect code: 1 reflect, 2 replicate, 0 zero
     std::vector<Param> params;
     std::vector<Layer> layers;       // first, down1, down2, 2*n_blocks block convs, up1, up2, last
+    bool fp32 = false;               // innfer_resnet_set_precision(1): the fp32 forward on NCHW fp32 tensors (f32ops.hip), the reference's -no_fp16 mode
+    std::vector<std::vector<float*>> f32_w;   //   f32conv panels per layer (a ConvTranspose2d: one per output phase)
     bool uploaded = false;
     bool batch_norm = false;         // norm_type 'batch' (the constructor's default, ResNet_arch.py:19,39-49): nn.BatchNorm2d behind every conv but the last, and
                                      // no bias on those convs (use_bias is True for InstanceNorm2d only)
@@ -354,6 +356,8 @@ extern "C" int innfer_resnet_create_ex(innfer_resnet** out, int in_nc, int out_n
 }
 
 static void rn_free(innfer_resnet* r) {
+    for (auto& vv : r->f32_w) for (auto v : vv) if (v) (void)hipFree(v);          // (the fp32 panels follow the parameters: rebuilt by innfer_resnet_set_precision)
+    r->f32_w.clear();
     for (auto& l : r->layers) {
         for (auto w : l.d_w) if (w) (void)hipFree(w);
         l.d_w.clear();
@@ -564,9 +568,125 @@ RCarve rcarve(const innfer_resnet* r, int N, int H, int W) {
 
 }  // namespace
 
+namespace {
+// ---- the fp32 mode: ResnetGenerator.forward (ResNet_arch.py:19-151) on NCHW fp32 tensors with the generic fp32 ops of f32ops.hip; graph = oracle/nets.py resnet_forward ----
+struct RCarve32 { size_t raw, a, b, t0, t1, r1, u1, u2, total; };
+RCarve32 rcarve32(const innfer_resnet* r, int N, int H, int W) {
+    RCarve32 c{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t px = (size_t)N * H * W, g = r->ngf;
+    size_t off = 0;
+    auto buf = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
+    c.raw = buf(px * g); c.a = buf(px * g); c.b = buf(px / 4 * 2 * g); c.t0 = buf(px / 16 * 4 * g); c.t1 = buf(px / 16 * 4 * g); c.r1 = buf(px / 16 * 4 * g);
+    c.u1 = buf(px / 4 * 2 * g); c.u2 = buf(px * g);
+    c.total = off;
+    return c;
+}
+
+int resnet_forward_f32(innfer_resnet* r, const float* x, float* y, int N, int H, int W, char* ws, hipStream_t s) {
+    const RCarve32 cv = rcarve32(r, N, H, W);
+    const int nb = r->n_blocks;
+    auto B = [&](size_t o) { return (float*)(ws + o); };
+    float *RAW = B(cv.raw), *A = B(cv.a), *Bf = B(cv.b), *T0 = B(cv.t0), *T1 = B(cv.t1), *R1 = B(cv.r1), *U1 = B(cv.u1), *U2 = B(cv.u2);
+    // layer li over an h x w input: Conv2d(k, stride, padding k / 2 in `pad_mode`) / ConvTranspose2d(3, 2, 1, output_padding 1) as four phase launches / upconv (nearest 2x + 3x3)
+    auto conv = [&](int li, const float* in, int h, int w, int stride, int pad_mode, int act, float* out) -> int {
+        const Layer& l = r->layers[li];
+        F32Conv c{};
+        c.in = in; c.in_nstride = (long)l.cin * h * w; c.in_cstride = (long)h * w; c.C = l.cin; c.Hin = h; c.Win = w;
+        c.bias = l.d_b; c.K = l.cout; c.act = act; c.N = N; c.out = out; c.out_pstride = 1;
+        if (l.transposed) {
+            const int ho = 2 * h, wo = 2 * w;
+            c.out_nstride = (long)l.cout * ho * wo; c.out_cstride = (long)ho * wo; c.Wout = wo;
+            c.Ho = h; c.Wo = w; c.osy = c.osx = 2; c.isy = c.isx = 1;
+            for (int ph = 0; ph < 4; ++ph) {
+                int kyv[2], dyv[2], kxv[2], dxv[2];
+                const int ny = phase_taps1d(ph >> 1, kyv, dyv), nx = phase_taps1d(ph & 1, kxv, dxv);
+                c.ntap = ny * nx;
+                for (int t = 0; t < c.ntap; ++t) { c.dy[t] = dyv[t / nx]; c.dx[t] = dxv[t % nx]; }
+                c.ooy = ph >> 1; c.oox = ph & 1; c.wp = r->f32_w[li][ph];
+                int rc = f32conv_launch(c, s);
+                if (rc) return rc;
+            }
+            return INNFER_OK;
+        }
+        const int up = l.up2 ? 1 : 0, ho = up ? 2 * h : h / stride, wo = up ? 2 * w : w / stride;
+        c.out_nstride = (long)l.cout * ho * wo; c.out_cstride = (long)ho * wo; c.Wout = wo;
+        c.Ho = ho; c.Wo = wo; c.osy = c.osx = 1; c.isy = c.isx = stride; c.up = up; c.pad_mode = pad_mode;
+        c.ntap = l.k * l.k;
+        for (int t = 0; t < c.ntap; ++t) { c.dy[t] = t / l.k - l.k / 2; c.dx[t] = t % l.k - l.k / 2; }
+        c.wp = r->f32_w[li][0];
+        return f32conv_launch(c, s);
+    };
+    // the norm layer behind layer li (instance norm, or BatchNorm2d on the image's / the running statistics), activation, optional skip
+    auto norm = [&](int li, const float* in, int h, int w, int act, float* out, const float* res = nullptr) -> int {
+        const Layer& l = r->layers[li];
+        const long hw = (long)h * w;
+        const int C = l.cout;
+        if (!r->batch_norm) return f32_norm_launch(in, C * hw, hw, out, C * hw, hw, N, C, hw, 2, 1e-5f, nullptr, nullptr, nullptr, nullptr, act, s, res, C * hw, hw);
+        if (r->eval_mode) return f32_norm_launch(in, C * hw, hw, out, C * hw, hw, N, C, hw, 3, 1e-5f, l.d_ev_alpha, l.d_ev_shift, nullptr, nullptr, act, s, res, C * hw, hw);
+        return f32_norm_launch(in, C * hw, hw, out, C * hw, hw, N, C, hw, 0, 1e-5f, l.d_gamma, l.d_beta, nullptr, nullptr, act, s, res, C * hw, hw);
+    };
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    const int bp = r->block_pad;                                     // 1 reflect, 2 replicate, 0 zero: the same codes as F32Conv.pad_mode
+    CK(conv(0, x, H, W, 1, 1, 0, RAW)); CK(norm(0, RAW, H, W, 2, A));                  // c7s1: ReflectionPad2d(3), conv, norm, ReLU
+    CK(conv(1, A, H, W, 2, 0, 0, RAW)); CK(norm(1, RAW, H2, W2, 2, Bf));               // stride-2 3x3, zero padding
+    CK(conv(2, Bf, H2, W2, 2, 0, 0, RAW)); CK(norm(2, RAW, H4, W4, 2, T0));
+    float *cur = T0, *alt = T1;
+    for (int b = 0; b < nb; ++b) {                                   // ResnetBlock: x + norm(conv(relu(norm(conv(x)))))  (dropout: identity under eval)
+        CK(conv(3 + 2 * b, cur, H4, W4, 1, bp, 0, RAW)); CK(norm(3 + 2 * b, RAW, H4, W4, 2, R1));
+        CK(conv(4 + 2 * b, R1, H4, W4, 1, bp, 0, RAW)); CK(norm(4 + 2 * b, RAW, H4, W4, 0, alt, cur));
+        std::swap(cur, alt);
+    }
+    const int lu = 3 + 2 * nb;
+    CK(conv(lu, cur, H4, W4, 1, 0, 0, RAW)); CK(norm(lu, RAW, H2, W2, 2, U1));
+    CK(conv(lu + 1, U1, H2, W2, 1, 0, 0, RAW)); CK(norm(lu + 1, RAW, H, W, 2, U2));
+    CK(conv(lu + 2, U2, H, W, 1, 1, 3, y));                          // c7s1-out: ReflectionPad2d(3), conv + bias, tanh
+#undef CK
+    return INNFER_OK;
+}
+}  // namespace
+
+// The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs ResnetGenerator.forward in fp32 on NCHW fp32 tensors.
+extern "C" int innfer_resnet_set_precision(innfer_resnet* r, int fp32) {
+    if (!r || (fp32 != 0 && fp32 != 1)) return set_error(INNFER_ERR_INVALID, "resnet_set_precision: 0 (fp16 arithmetic) or 1 (fp32)");
+    r->fp32 = fp32 != 0;
+    if (!r->fp32) return INNFER_OK;
+    if (!r->uploaded) { int rc = rn_upload(r); if (rc) return rc; r->uploaded = true; }
+    if (!r->f32_w.empty()) return INNFER_OK;
+    std::vector<float> host;
+    auto put = [&](std::vector<float*>& dst, int K, int C, int ntap, const std::function<float(int, int, int)>& w) -> int {
+        host.resize(f32conv_packed_floats(K, C, ntap));
+        f32conv_pack(K, C, ntap, w, host.data());
+        float* d = nullptr;
+        INNFER_HIP(hipMalloc((void**)&d, host.size() * sizeof(float)));
+        dst.push_back(d);
+        INNFER_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+        return INNFER_OK;
+    };
+    r->f32_w.assign(r->layers.size(), {});
+    for (size_t li = 0; li < r->layers.size(); ++li) {
+        const Layer& l = r->layers[li];
+        const std::vector<float>& w = r->params[l.w].host;
+        if (l.transposed) {                                           // [cin][cout][3][3], one panel per output phase
+            for (int ph = 0; ph < 4; ++ph) {
+                int kyv[2], dyv[2], kxv[2], dxv[2];
+                const int ny = phase_taps1d(ph >> 1, kyv, dyv), nx = phase_taps1d(ph & 1, kxv, dxv);
+                int rc = put(r->f32_w[li], l.cout, l.cin, ny * nx, [&](int co, int ci, int t) { return w[(((size_t)ci * l.cout + co) * 3 + kyv[t / nx]) * 3 + kxv[t % nx]]; });
+                if (rc) return rc;
+            }
+        } else {
+            const int T = l.k * l.k, C = l.cin;
+            int rc = put(r->f32_w[li], l.cout, C, T, [&w, C, T](int k, int c, int t) { return w[((size_t)k * C + c) * T + t]; });
+            if (rc) return rc;
+        }
+    }
+    return INNFER_OK;
+}
+
 extern "C" size_t innfer_resnet_workspace_bytes(innfer_resnet* r, int N, int H, int W) {
     if (!r || N <= 0 || H <= 0 || W <= 0) return 0;
-    return rcarve(r, N, H, W).total;
+    return r->fp32 ? rcarve32(r, N, H, W).total : rcarve(r, N, H, W).total;
 }
 
 extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_dtype, void* d_out, int out_dtype,
@@ -574,7 +694,14 @@ extern "C" int innfer_resnet_forward(innfer_resnet* r, const void* d_in, int in_
     if (!r || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "resnet_forward: null argument");
     if (N <= 0 || H < 16 || W < 16 || (H & 3) || (W & 3))
         return set_error(INNFER_ERR_INVALID, "resnet_forward: H and W must be multiples of 4 and at least 16 (two stride-2 stages, reflection pads)");
-    if (!r->uploaded) { int rc = rn_upload(r); if (rc) return rc; }
+    if (!r->uploaded) { int rc = rn_upload(r); if (rc) return rc; if (r->fp32) { rc = innfer_resnet_set_precision(r, 1); if (rc) return rc; } }
+    if (r->fp32) {
+        if (in_dtype != INNFER_F32 || out_dtype != INNFER_F32) return set_error(INNFER_ERR_INVALID, "resnet_forward: the fp32 mode takes and returns fp32 tensors");
+        if (r->f32_w.empty()) return set_error(INNFER_ERR_INVALID, "resnet_forward: call innfer_resnet_set_precision(r, 1) after the last innfer_resnet_set_param");
+        const RCarve32 c32 = rcarve32(r, N, H, W);
+        if (ws_bytes < c32.total) return set_error(INNFER_ERR_WORKSPACE, "resnet_forward: workspace %zu < %zu bytes", ws_bytes, c32.total);
+        return resnet_forward_f32(r, (const float*)d_in, (float*)d_out, N, H, W, (char*)d_ws, (hipStream_t)stream);
+    }
     const RCarve cv = rcarve(r, N, H, W);
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "resnet_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
     hipStream_t s = (hipStream_t)stream;

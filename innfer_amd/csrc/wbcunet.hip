@@ -228,6 +228,8 @@ struct innfer_wbc {
     int nf = 32; int tf = 0;
     std::vector<Param> params;
     std::vector<Layer> layers;   // conv, conv_1..conv_4, block_0..3 (conv1, conv2), conv_5..conv_9
+    bool fp32 = false;           // innfer_wbc_set_precision(1): the fp32 forward on NCHW fp32 tensors (f32ops.hip), the reference's -no_fp16 mode
+    std::vector<float*> f32_w;   //   one f32conv panel per layer
     bool uploaded = false;
 };
 
@@ -264,7 +266,7 @@ static void wb_free(innfer_wbc* u) {
     }
 }
 
-extern "C" void innfer_wbc_destroy(innfer_wbc* u) { if (u) { wb_free(u); delete u; } }
+extern "C" void innfer_wbc_destroy(innfer_wbc* u) { if (u) { wb_free(u); for (auto v : u->f32_w) if (v) (void)hipFree(v); delete u; } }
 extern "C" int innfer_wbc_num_params(innfer_wbc* u) { return u ? (int)u->params.size() : INNFER_ERR_INVALID; }
 
 extern "C" int innfer_wbc_param_info(innfer_wbc* u, int idx, char* key, size_t key_cap, int* ndim, int* shape4) {
@@ -292,6 +294,8 @@ namespace {
 int wb_upload(innfer_wbc* u) {
     for (auto& q : u->params) if (!q.set) return set_error(INNFER_ERR_INVALID, "wbc: parameter '%s' was never set", q.key.c_str());
     wb_free(u);
+    for (auto v : u->f32_w) if (v) (void)hipFree(v);               // the fp32 panels follow the parameters: rebuilt by innfer_wbc_set_precision
+    u->f32_w.clear();
     std::vector<f16> panel;
     for (auto& l : u->layers) {
         const std::vector<float>& w = u->params[l.w].host;
@@ -384,16 +388,105 @@ WCarve wcarve(int N, int H, int W) {
 
 }  // namespace
 
+namespace {
+// ---- the fp32 mode: UnetGeneratorWBC.forward (WBCNet_arch.py:22-99) on NCHW fp32 tensors with the generic fp32 ops of f32ops.hip; graph = oracle/nets.py wbcunet_forward ----
+struct WCarve32 { size_t x0, t0, x1, t1, x2, r, u1, t2, u0, t3, total; };
+WCarve32 wcarve32(const innfer_wbc* u, int N, int H, int W) {
+    WCarve32 c{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t px = (size_t)N * H * W, nf = u->nf;
+    size_t off = 0;
+    auto buf = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
+    c.x0 = buf(px * nf); c.t0 = buf(px / 4 * nf); c.x1 = buf(px / 4 * 2 * nf); c.t1 = buf(px / 16 * 2 * nf); c.x2 = buf(px / 16 * 4 * nf); c.r = buf(px / 16 * 4 * nf);
+    c.u1 = buf(px / 4 * 2 * nf); c.t2 = buf(px / 4 * 2 * nf); c.u0 = buf(px * nf); c.t3 = buf(px * nf);
+    c.total = off;
+    return c;
+}
+
+int wbc_forward_f32(innfer_wbc* u, const float* x, float* y, int N, int H, int W, char* ws, hipStream_t s) {
+    const WCarve32 cv = wcarve32(u, N, H, W);
+    const int nf = u->nf;
+    auto B = [&](size_t o) { return (float*)(ws + o); };
+    // layer li: k x k conv (zero padding k / 2; stride 2: `pt` pads 1 on every side, `tf` pads (0, 1) = tf_same_padding) over the whole input tensor
+    auto conv = [&](int li, const float* in, int h, int w, int stride, int act, float* out, const float* res = nullptr) -> int {
+        const Layer& l = u->layers[li];
+        F32Conv c{};
+        const int ho = h / stride, wo = w / stride;
+        c.in = in; c.in_nstride = (long)l.cin * h * w; c.in_cstride = (long)h * w; c.C = l.cin; c.Hin = h; c.Win = w;
+        c.wp = u->f32_w[li]; c.bias = l.d_b; c.K = l.cout;
+        c.out = out; c.out_nstride = (long)l.cout * ho * wo; c.out_cstride = (long)ho * wo; c.out_pstride = 1; c.Wout = wo;
+        c.Ho = ho; c.Wo = wo; c.osy = c.osx = 1; c.isy = c.isx = stride;
+        c.ntap = l.k * l.k;
+        const int p0 = stride == 2 && u->tf ? 0 : l.k / 2;
+        for (int t = 0; t < c.ntap; ++t) { c.dy[t] = t / l.k - p0; c.dx[t] = t % l.k - p0; }
+        c.act = act; c.N = N;
+        c.res = res; c.res_nstride = c.out_nstride; c.res_cstride = c.out_cstride;
+        return f32conv_launch(c, s);
+    };
+#define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+    float *X0 = B(cv.x0), *T0 = B(cv.t0), *X1 = B(cv.x1), *T1 = B(cv.t1), *X2 = B(cv.x2), *R = B(cv.r), *U1 = B(cv.u1), *T2 = B(cv.t2), *U0 = B(cv.u0), *T3 = B(cv.t3);
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    CK(conv(0, x, H, W, 1, 1, X0));                                  // x0 = lrelu(conv 7x7)
+    CK(conv(1, X0, H, W, 2, 1, T0));                                 // lrelu(conv_1, stride 2)
+    CK(conv(2, T0, H2, W2, 1, 1, X1));                               // x1 = lrelu(conv_2)
+    CK(conv(3, X1, H2, W2, 2, 1, T1));
+    CK(conv(4, T1, H4, W4, 1, 1, X2));                               // x2 = lrelu(conv_4)
+    float *cur = X2, *alt = B(cv.u1);                                // the blocks ping-pong between X2 and U1 (2 nf at H/2 >= 4 nf at H/4; free until the first up-add)
+    for (int b = 0; b < 4; ++b) {
+        CK(conv(5 + 2 * b, cur, H4, W4, 1, 1, R));                   // lrelu(conv1)
+        CK(conv(6 + 2 * b, R, H4, W4, 1, 0, alt, cur));              // conv2 + x
+        std::swap(cur, alt);
+    }
+    CK(conv(13, cur, H4, W4, 1, 1, T1));                             // lrelu(conv_5): 2 nf at H/4
+    CK(f32_upadd_launch(T1, X1, U1, (long)N * 2 * nf, H4, W4, u->tf, s));          // up(x2) + x1
+    CK(conv(14, U1, H2, W2, 1, 1, T2));                              // lrelu(conv_6)
+    CK(conv(15, T2, H2, W2, 1, 1, T0));                              // x3 = lrelu(conv_7): nf at H/2
+    CK(f32_upadd_launch(T0, X0, U0, (long)N * nf, H2, W2, u->tf, s));              // up(x3) + x0
+    CK(conv(16, U0, H, W, 1, 1, T3));                                // x4 = lrelu(conv_8)
+    CK(conv(17, T3, H, W, 1, 0, y));                                 // conv_9 (7x7)
+#undef CK
+    return INNFER_OK;
+}
+}  // namespace
+
+// The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs UnetGeneratorWBC.forward in fp32 on NCHW fp32 tensors.
+extern "C" int innfer_wbc_set_precision(innfer_wbc* u, int fp32) {
+    if (!u || (fp32 != 0 && fp32 != 1)) return set_error(INNFER_ERR_INVALID, "wbc_set_precision: 0 (fp16 arithmetic) or 1 (fp32)");
+    u->fp32 = fp32 != 0;
+    if (!u->fp32) return INNFER_OK;
+    if (!u->uploaded) { int rc = wb_upload(u); if (rc) return rc; u->uploaded = true; }
+    if (!u->f32_w.empty()) return INNFER_OK;
+    std::vector<float> host;
+    for (auto& l : u->layers) {
+        const std::vector<float>& w = u->params[l.w].host;
+        const int T = l.k * l.k, C = l.cin;
+        host.resize(f32conv_packed_floats(l.cout, C, T));
+        f32conv_pack(l.cout, C, T, [&w, C, T](int k, int c, int t) { return w[((size_t)k * C + c) * T + t]; }, host.data());
+        float* d = nullptr;
+        INNFER_HIP(hipMalloc((void**)&d, host.size() * sizeof(float)));
+        u->f32_w.push_back(d);
+        INNFER_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return INNFER_OK;
+}
+
 extern "C" size_t innfer_wbc_workspace_bytes(innfer_wbc* u, int N, int H, int W) {
     if (!u || N <= 0 || H <= 0 || W <= 0) return 0;
-    return wcarve(N, H, W).total;
+    return u->fp32 ? wcarve32(u, N, H, W).total : wcarve(N, H, W).total;
 }
 
 extern "C" int innfer_wbc_forward(innfer_wbc* u, const void* d_in, int in_dtype, void* d_out, int out_dtype,
                                   int N, int H, int W, void* d_ws, size_t ws_bytes, void* stream) {
     if (!u || !d_in || !d_out || !d_ws) return set_error(INNFER_ERR_INVALID, "wbc_forward: null argument");
     if (N <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3)) return set_error(INNFER_ERR_INVALID, "wbc_forward: H and W must be multiples of 4 (run.py applies modcrop(img, 4))");
-    if (!u->uploaded) { int rc = wb_upload(u); if (rc) return rc; }
+    if (!u->uploaded) { int rc = wb_upload(u); if (rc) return rc; if (u->fp32) { rc = innfer_wbc_set_precision(u, 1); if (rc) return rc; } }
+    if (u->fp32) {
+        if (in_dtype != INNFER_F32 || out_dtype != INNFER_F32) return set_error(INNFER_ERR_INVALID, "wbc_forward: the fp32 mode takes and returns fp32 tensors");
+        if (u->f32_w.empty()) return set_error(INNFER_ERR_INVALID, "wbc_forward: call innfer_wbc_set_precision(u, 1) after the last innfer_wbc_set_param");
+        const WCarve32 c32 = wcarve32(u, N, H, W);
+        if (ws_bytes < c32.total) return set_error(INNFER_ERR_WORKSPACE, "wbc_forward: workspace %zu < %zu bytes", ws_bytes, c32.total);
+        return wbc_forward_f32(u, (const float*)d_in, (float*)d_out, N, H, W, (char*)d_ws, (hipStream_t)stream);
+    }
     const WCarve cv = wcarve(N, H, W);
     if (ws_bytes < cv.total) return set_error(INNFER_ERR_WORKSPACE, "wbc_forward: workspace %zu < %zu bytes", ws_bytes, cv.total);
     hipStream_t s = (hipStream_t)stream;

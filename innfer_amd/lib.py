@@ -127,6 +127,7 @@ SIGNATURES = {
     "innfer_resnet_destroy": (None, [C.c_void_p]),
     "innfer_resnet_num_params": (C.c_int, [C.c_void_p]),
     "innfer_resnet_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_resnet_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_resnet_set_param": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "innfer_resnet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_resnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -135,6 +136,7 @@ SIGNATURES = {
     "innfer_wbc_destroy": (None, [C.c_void_p]),
     "innfer_wbc_num_params": (C.c_int, [C.c_void_p]),
     "innfer_wbc_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "innfer_wbc_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_wbc_set_param": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "innfer_wbc_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "innfer_wbc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

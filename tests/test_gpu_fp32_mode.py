@@ -362,15 +362,91 @@ def test_ppon_fp32_mode_vs_golden(dev, golden):
         assert y16.dtype == torch.float16 and (y16.float() - ys[2]).abs().max().item() < 1e-2 * max(1.0, ref[2].abs().max().item())
 
 
-def test_generators_without_an_fp32_engine_refuse_float32(dev):
-    """CycleGAN ResNet / WBC UNet compute in fp16 only: a float32 tensor must raise, not run at fp16 accuracy behind fp32 I/O.  (PAN, the pix2pix UNet and PPON
-    have an fp32 mode since round 4: test_unet_fp32_mode_vs_goldens, test_pan_fp32_mode_vs_goldens, test_ppon_fp32_mode_vs_golden.)"""
+def test_cyclegan_resnet_fp32_mode_vs_goldens(dev, golden):
+    """CycleGAN ResnetGenerator on float32 tensors (innfer_resnet_set_precision(1)): reflection / replication / zero padding as the generic fp32 conv's padding modes, 7x7
+    convs as 49-entry tap tables, ConvTranspose2d(3, 2, 1, 1) as four phase launches, instance / batch norm in fp32.  Goldens G14 (9 blocks) and G22 (paddings, dropout
+    under eval, upconv, norm_type 'batch' in both modes): <= 1e-4 on the tanh output."""
+    import ast
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.architectures.ResNet_arch import ResnetGenerator
+    from innfer_amd.utils.defaults import get_network_G_config
+    from test_oracle_golden import G22_CASES, _g22_state
+    g = golden("g14_resnet9")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    net = get_network(get_network_G_config("resnet_9blocks", 1))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}, strict=True)
+    net = net.to(dev).eval()
+    for (h, w, seed) in [(32, 40, 15), (64, 64, 16)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0)).to(dev)
+        y = net(x)
+        e = np.abs(y.cpu().numpy() - g[f"out_{h}x{w}"].astype(np.float32)).max()
+        print(f"resnet9 fp32 mode {h}x{w} vs G14: max {e:.2e}")
+        assert y.dtype == torch.float32 and e < FP32_TOL, (h, w, e)
+        assert (net(x.half()).float() - y).abs().max().item() < 1e-2
+    xa = torch.from_numpy(synth.uniform((2, 3, 32, 40), 15, -1.0, 1.0)).to(dev)
+    yab = net(xa)
+    assert torch.equal(yab[0:1], net(xa[0:1])) and torch.equal(yab[1:2], net(xa[1:2]))
+    g22 = golden("g22_resnet_variants")
+    for i, (tag, kw) in enumerate(G22_CASES.items()):
+        shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g22[tag + "_keys"], g22[tag + "_shapes"])}
+        kw = dict(kw)
+        train = kw.pop("train", False)
+        v = ResnetGenerator(3, 3, 64, n_blocks=2, **{"norm_type": "instance", **kw})
+        v.load_state_dict(_g22_state(shapes, kw, i), strict=True)
+        v = v.to(dev)
+        v = v.train() if train else v.eval()
+        x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0)).to(dev)
+        e = np.abs(v(x).cpu().numpy() - g22[tag]).max()
+        print(f"resnet variant {tag} fp32 mode vs G22: max {e:.2e}")
+        assert e < FP32_TOL, (tag, e)
+
+
+def test_wbcunet_fp32_mode_vs_golden(dev, golden):
+    """White-box-Cartoonization UNet on float32 tensors (innfer_wbc_set_precision(1)), 'pt' and 'tf' variants, and the run.py sequence network -> guided filter in fp32
+    against golden G15: <= 1e-4."""
+    import ast
+    from innfer_amd import synth
     from innfer_amd.architectures import get_network
     from innfer_amd.utils.defaults import get_network_G_config
-    for arch, scale, shape in (("resnet_9blocks", 1, (1, 3, 32, 32)), ("wbcunet", 1, (1, 3, 32, 32))):
+    from innfer_amd.utils import utils as U
+    g = golden("g15_wbcunet")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, 0).items()}
+    net = get_network(get_network_G_config("wbcunet", 1))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    for (h, w, seed) in [(32, 40, 17), (64, 64, 18)]:
+        x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0)).to(dev)
+        y = net(x)
+        e = np.abs(y.cpu().numpy() - g[f"out_{h}x{w}"].astype(np.float32)).max()
+        gf = U.guided_filter(x, y, r=1, eps=5e-3).cpu().numpy()
+        eg = np.abs(gf - g[f"gf_{h}x{w}"].astype(np.float32)).max()
+        print(f"wbcunet fp32 mode {h}x{w} vs G15: network max {e:.2e}, + guided filter {eg:.2e}")
+        assert y.dtype == torch.float32 and e < FP32_TOL and eg < FP32_TOL, (h, w, e, eg)
+    xa = torch.from_numpy(synth.uniform((2, 3, 32, 40), 17, -1.0, 1.0)).to(dev)
+    yab = net(xa)
+    assert torch.equal(yab[0:1], net(xa[0:1])) and torch.equal(yab[1:2], net(xa[1:2]))
+    net_tf = get_network(get_network_G_config("wbcunet_tf", 1))
+    net_tf.load_state_dict(sd, strict=True)
+    net_tf = net_tf.to(dev).eval()
+    x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 17, -1.0, 1.0)).to(dev)
+    e = np.abs(net_tf(x).cpu().numpy() - g["out_tf_32x40"]).max()
+    print(f"wbcunet_tf fp32 mode vs G15: max {e:.2e}")
+    assert e < FP32_TOL, e
+
+
+def test_every_generator_answers_float32_tensors(dev):
+    """Since round 4 every generator has an fp32 mode (RRDBNet / SRResNet: the fp32-accurate engine on (hi, lo) fp16 pairs; PAN, UNet, PPON, CycleGAN ResNet, WBC UNet: fp32
+    tensors on the fp32 matrix instruction): a float32 tensor returns float32 -- never fp16 accuracy behind fp32 I/O, never a refusal (the reference's -no_fp16 runs all)."""
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    for arch, scale, shape in (("esrgan", 4, (1, 3, 16, 16)), ("srgan", 4, (1, 3, 16, 16)), ("pan", 4, (1, 3, 16, 16)), ("unet_256", 1, (1, 3, 256, 256)),
+                               ("ppon", 4, (1, 3, 16, 16)), ("resnet_9blocks", 1, (1, 3, 32, 32)), ("wbcunet", 1, (1, 3, 32, 32))):
         net = get_network(get_network_G_config(arch, scale)).to(dev)
-        with pytest.raises(NotImplementedError, match="fp32"):
-            net(torch.zeros(shape, device=dev))
+        y = net(torch.zeros(shape, device=dev))
+        y = y[-1] if isinstance(y, tuple) else y
+        assert y.dtype == torch.float32 and torch.isfinite(y).all(), arch
 
 
 def test_split_conv_random_shapes_fuzz(dev):

@@ -1100,16 +1100,13 @@ def test_command_line_image_loop(dev, tmp_path, monkeypatch, capsys):
             ref = oracle.tensor2np(oracle.chop_forward(f2, oracle.chop_forward(f1, oracle.np2tensor(im), 1), 2))
         d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
         assert d.max() <= 1 and (d == 0).mean() >= 0.999, (k, d.max(), (d == 0).mean())
-    # PAN has an fp32 mode since round 4: the flag runs it (float32 tensors through Model.__call__); a generator without one still refuses the flag instead of
-    # running fp16 behind it
+    # PAN has an fp32 mode since round 4: the flag runs it (float32 tensors through Model.__call__)
     from innfer_amd.architectures import get_network
     from innfer_amd.utils.defaults import get_network_G_config
     torch.save(get_network(get_network_G_config("pan", 4)).state_dict(), str(tmp_path / "models" / "4x_pan.pth"))
     assert R.main(["-m", "4x_pan", "-i", "in", "-o", "out_pan", "-no_fp16"]) == 0
     assert sorted(os.listdir(tmp_path / "out_pan")) == sorted(f"{k}.png" for k in imgs)
-    torch.save(get_network(get_network_G_config("wbcunet", 1)).state_dict(), str(tmp_path / "models" / "1x_wbc.pth"))
-    with pytest.raises(NotImplementedError, match="no_fp16"):
-        R.main(["-m", "1x_wbc", "-a", "wbcunet", "-i", "in", "-o", "out_wbc", "-no_fp16"])
+    # (every generator has an fp32 mode since round 4: test_gpu_fp32_mode.py::test_every_generator_answers_float32_tensors)
 
 
 @pytest.mark.parametrize("chop", [True, False])
