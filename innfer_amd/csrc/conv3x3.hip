@@ -1069,8 +1069,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // + 0x80000 (SGATE): PAN's pixel attention behind an up-conv (PAN_arch.py:11-35: upconv -> PA: x * sigmoid(conv1x1(x)) -> LeakyReLU) inside the up-conv's
     // epilogue: a lane's accumulators are 8 consecutive channels of its pixel (NT = 2 row order), i.e. after the fp16 conversion -- the value the two-launch
     // schedule stored -- the B fragment of the 1x1 conv; two MFMAs per pixel tile against the 32 x 32 gate matrix held in registers, then v * sigmoid(g) goes
-    // through the ordinary epilogue (its LeakyReLU, the store).  Same fp16 operands, same MFMA, same expression: bit-identical to the two launches, without the
-    // round trip of the 32-channel HR tensor (531 MB written and read again at 2160 x 3840).
+    // through the ordinary epilogue (its LeakyReLU, the store).  Same fp16 operands and the same MFMA as the two launches; the sigmoid is the fast form, so results
+    // agree to the last fp16 rounding -- without the round trip of the 32-channel HR tensor (531 MB written and read again at 2160 x 3840).
     constexpr bool SGATE = (TMF & 0x80000) != 0;
     static_assert(!SGATE || (RPW == 3 && NT == 2 && NCW == 8 && OUTMODE == OUT_SLAB && (TMF & 0x7FFFF) == 0x1FF && !S9 && !POLY), "self gate: the 32-output slab kernel (and its canvas form)");
     constexpr bool FUSE = (TMF & 0x20000) != 0;
@@ -1785,7 +1785,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                     for (int t = 0; t < 2; ++t) {
                         const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_f16(sgw[t], vb, sgb[t], 0, 0, 0);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[t][m][j] = (float)vb[4 * t + j] * (1.0f / (1.0f + expf(-g[j])));
+                        // (sigmoid on the hardware exponential / reciprocal: at 2160 x 3840 this epilogue evaluates 265 M of them -- the libm forms were 0.3 of the launch)
+                        for (int j = 0; j < 4; ++j) acc[t][m][j] = (float)vb[4 * t + j] * __frcp_rn(1.0f + __expf(-g[j]));
                     }
                 }
             }

@@ -447,6 +447,43 @@ __global__ void pan_final(const float* raw, int rs, const float* bias, int C, co
     }
 }
 
+// The same for the planar raw buffer (rs == 0) when FW % 4 == 0: four consecutive pixels of one channel per thread -- one 16-byte read of the conv's result, the
+// four bilinear samples of the input in pan_final's own arithmetic, one 8- / 16-byte store (the one-pixel-per-thread form moved 1.3 TB/s)
+__global__ void pan_final_x4(const float* raw, int C, const void* x, int x_f32, int N, int H, int W, int scale, void* out, int out_f32) {
+    const int FH = H * scale, FW = W * scale, FW4 = FW >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * C * FH * FW4) return;
+    const int X0 = (int)(i % FW4) * 4, Y = (int)((i / FW4) % FH);
+    const long nc = i / ((long)FW4 * FH);
+    const float sy = FH > 1 ? (float)(H - 1) / (float)(FH - 1) : 0.f, sx = FW > 1 ? (float)(W - 1) / (float)(FW - 1) : 0.f;
+    const float fy = sy * (float)Y;
+    const int y0 = (int)fy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    const float ly = fy - (float)y0;
+    const long pl = nc * (long)H * W;
+    auto at = [&](int yy, int xx) {
+        const long o = pl + (long)yy * W + xx;
+        return x_f32 ? ((const float*)x)[o] : (float)((const f16*)x)[o];
+    };
+    const long o = (nc * FH + Y) * (long)FW + X0;
+    const f32x4 r = *(const f32x4*)(raw + o);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float il;
+        if (scale > 1) {
+            const float fx = sx * (float)(X0 + e);
+            const int x0 = (int)fx, x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float lx = fx - (float)x0;
+            il = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
+        } else {
+            il = at(Y, X0 + e);
+        }
+        v[e] = r[e] + il;
+    }
+    if (out_f32) *(f32x4*)((float*)out + o) = f32x4{v[0], v[1], v[2], v[3]};
+    else *(f16x4*)((f16*)out + o) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+}
+
 struct Param { std::string key; std::vector<int> shape; std::vector<float> host; bool set = false; };
 
 struct Gemm {                       // one packed GEMM
@@ -1062,7 +1099,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         const int hh = uf * h, ww = uf * w;
         const long hpx = (long)N * hh * ww, HG = hpx * 32;
         f16 *V = (f16*)(ws + cv.hr[u][0]), *PA = (f16*)(ws + cv.hr[u][1]), *HRC = (f16*)(ws + cv.hr[u][2]);
-        // PA (x * sigmoid(conv1x1(x)) -> LeakyReLU) as the epilogue of the conv in front of it: V is never written (fused_scpa != 0; bit-identical)
+        // PA (x * sigmoid(conv1x1(x)) -> LeakyReLU) as the epilogue of the conv in front of it: V is never written (fused_scpa != 0; same values to the last fp16 rounding)
         const Gemm* gate = (p->fused_scpa && p->gemms[gi + 1].d_gate) ? &p->gemms[gi + 1] : nullptr;
         f16* Vd = gate ? PA : V;
         const int va = gate ? 1 : 0;
@@ -1087,6 +1124,11 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     {
         const long fpx = (long)N * h * w;
         GtScope gt(s, "pan_final (+ bilinear skip, NCHW)", 0.0, (double)fpx * p->out_nc * (4.0 + (out_dtype == INNFER_F32 ? 4.0 : 2.0)));
+        if (w % 4 == 0) {
+            const long nthr = fpx * p->out_nc / 4;
+            hipLaunchKernelGGL(pan_final_x4, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)raw, p->out_nc, d_in, in_dtype == INNFER_F32, N, H, W, p->scale,
+                               d_out, out_dtype == INNFER_F32);
+        } else
         hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, raw, 0, vec("conv_last.bias"), p->out_nc,
                            d_in, in_dtype == INNFER_F32, N, H, W, p->scale, d_out, out_dtype == INNFER_F32);
         INNFER_HIP(hipGetLastError());
