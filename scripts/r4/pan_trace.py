@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""40 forwards of PAN 4x on 1x3x540x960 (for rocprofv3 --kernel-trace; scripts/evidence_r4.sh)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from innfer_amd import synth
+from innfer_amd.architectures import get_network
+from innfer_amd.utils.defaults import get_network_G_config
+dev = torch.device("cuda:0")
+net = get_network(get_network_G_config("pan", 4))
+net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()}, strict=True)
+net = net.to(dev).eval()
+x = torch.from_numpy(synth.uniform((1, 3, 540, 960), 3)).to(dev).half()
+for _ in range(40):
+    net(x)
+torch.cuda.synchronize()
