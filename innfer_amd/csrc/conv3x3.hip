@@ -989,6 +989,178 @@ __device__ __forceinline__ void epilogue_stats(const KP& p, const f32x4 (&acc)[N
     }
 }
 
+// SGATE (conv3x3_pc<.., TMF | 0x80000>): v = fp16(acc) is the B fragment of the 32 x 32 gate matrix (a lane's 8 accumulators are 8 consecutive channels of its pixel);
+// acc <- v * sigmoid(W v + b).  Sigmoid on the hardware exponential / reciprocal: at 2160 x 3840 this epilogue evaluates 265 M of them (the libm forms were 0.3 of the launch).
+template <int MT>
+__device__ __forceinline__ void self_gate(f32x4 (&acc)[2][MT], const f16x8* sgw, const f32x4* sgb) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        f16x8 vb;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vb[4 * t + j] = (f16)acc[t][m][j];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_f16(sgw[t], vb, sgb[t], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][m][j] = (float)vb[4 * t + j] * __frcp_rn(1.0f + __expf(-g[j]));
+        }
+    }
+}
+
+// RLDS (conv3x3_pc<.., TMF | 0x40000>): the lane's 16 residual channels of each of its MT pixel tiles from the live LDS stage `st` (byte offsets roffs), added to the fp32
+// accumulators as x / s1 (rs1 = 1 / s1)
+template <int MT>
+__device__ __forceinline__ void residual_from_lds(f32x4 (&acc)[4][MT], const char* st, const int* roffs, float rs1) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const f16x8 x0 = *(const f16x8*)(st + roffs[m]), x1 = *(const f16x8*)(st + roffs[m] + 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[t][m][j] = __builtin_fmaf((float)(t < 2 ? x0 : x1)[(t & 1) * 4 + j], rs1, acc[t][m][j]);
+    }
+}
+
+// Planar (NCHW) epilogue of conv3x3_pc -- the networks' last convs: activation, `outm`, the phase scatter of a transposed conv, or tensor2np as the store
+// (uint8 HWC image).  Moved out of the kernel body in round 4; force-inlined, the code is the one that was measured.
+template <int RPW, int NT>
+__device__ __forceinline__ void epilogue_planar(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0, int cw, int li, int lg, int cbase) {
+    constexpr int MT = 2 * RPW;
+    // planar NCHW output (the network's last conv): activation only, K valid channels
+    // Fast path -- K <= 4 planar channels, no phase scatter / uint8 image (the last conv of the SR networks, CycleGAN, WBC, PPON's heads): only the
+    // lanes holding channels 0..3 (lg == 0) have anything to store, and the per-VALUE work of the generic loop below (channel test, three 64-bit
+    // multiplies for the address, phase / uint8 tests: ~1 k instructions per wave and tile for 96 x 3 values) is hoisted.  Same values, same stores.
+    if (NT == 1 && p.phase_c == 0 && !p.out_u8 && p.K <= 4) {
+        if (lg == 0) {
+            const long plane = (long)p.H * p.W;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = ty0 + cw * RPW + (m >> 1);
+                const int x = tx0 + (m & 1) * 16 + li;
+                if (y >= p.y1 || x >= p.W) continue;
+                const long o = (long)n * p.K * plane + (long)y * p.W + x;
+                if (p.act == 0 && p.outm == 0) {              // (the SR networks' last conv: not even a uniform test per value -- 1.39 ms with them, 1.08 without)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j >= p.K) break;
+                        const float f = acc[0][m][j];
+                        if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
+                        else ((f16*)p.out)[o + j * plane] = (f16)f;
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= p.K) break;
+                    float f = acc[0][m][j];
+                    if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                    else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                    else if (p.act == 3) f = tanhf(f);
+                    else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
+                    if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
+                    else if (p.outm == 2) f = tanhf(f);
+                    else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
+                    else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
+                    if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
+                    else ((f16*)p.out)[o + j * plane] = (f16)f;
+                }
+            }
+        }
+    } else if (NT == 1 && p.phase_c == 0 && p.out_u8 && p.K <= 4 && p.act == 0 && p.outm == 0) {
+        // ... and the uint8 image form of the same conv (tensor2np as the epilogue, utils.py:197-248; EngineModule.forward_u8 / FramePipeline): the
+        // conversion of the generic loop below, value for value, on the lanes that hold channels 0..3
+        if (lg == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = ty0 + cw * RPW + (m >> 1);
+                const int x = tx0 + (m & 1) * 16 + li;
+                if (y >= p.y1 || x >= p.W) continue;
+                uint8_t* o = (uint8_t*)p.out + (((long)n * p.H + y) * p.W + x) * p.K;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= p.K) break;
+                    const float f = acc[0][m][j];
+                    float v = p.out_round16 ? (float)(f16)f : f;
+                    if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
+                    v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
+                    const int sc = (p.K == 3 || (p.K == 4 && j < 3)) ? 2 - j : j;
+                    o[sc] = (uint8_t)__float2int_rn(v);
+                }
+            }
+        }
+    } else if (NT == 1 && p.phase_c > 0 && p.outm == 0 && !p.out_u8 && (p.act == 3 || p.act == 0)) {
+        // The four output phases of a stride-2 transposed conv as 4 * phase_c channels (the UNet's outermost layer: bias + tanh + phase scatter):
+        // the channel -> (phase, channel) split is an integer division the generic loop below made per VALUE (24 per wave and tile); here once
+        // per lane and tile.  Same values, same stores.
+        if (cbase < p.K) {
+            long obase[4]; bool live[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = cbase + j, ph = ch / p.phase_c, c = ch - ph * p.phase_c;
+                live[j] = ch < p.K;
+                obase[j] = (((long)n * p.phase_c + c) * (2 * p.H) + (ph >> 1)) * (2 * p.W) + (ph & 1);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = ty0 + cw * RPW + (m >> 1);
+                const int x = tx0 + (m & 1) * 16 + li;
+                if (y >= p.y1 || x >= p.W) continue;
+                const long opix = (long)(2 * y) * (2 * p.W) + 2 * x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!live[j]) continue;
+                    float f = acc[0][m][j];
+                    if (p.act == 3) f = tanhf(f);
+                    if (p.out_f32) ((float*)p.out)[obase[j] + opix] = f;
+                    else ((f16*)p.out)[obase[j] + opix] = (f16)f;
+                }
+            }
+        }
+    } else
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = ty0 + cw * RPW + (m >> 1);
+        const int x = tx0 + (m & 1) * 16 + li;
+        if (y >= p.y1 || x >= p.W) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = cbase + 4 * t + j;
+                if (ch >= p.K) continue;
+                float f = acc[t][m][j];
+                if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                else if (p.act == 3) f = tanhf(f);
+                else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
+                if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
+                else if (p.outm == 2) f = tanhf(f);
+                else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
+                else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
+                long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
+                if (p.phase_c > 0) {
+                    const int ph = ch / p.phase_c, c = ch - ph * p.phase_c;
+                    o = (((long)n * p.phase_c + c) * (2 * p.H) + 2 * y + (ph >> 1)) * (2 * p.W) + 2 * x + (ph & 1);
+                }
+                if (p.out_u8) {
+                    // tensor2np (utils.py:197-248) on the value the planar store would have held: [fp16 rounding,] denorm ((x + 1) / 2
+                    // clipped), clip(255 x, 0, 255).round() half to even, RGB -> BGR flip for 3 / 4 channels; HWC bytes
+                    float v = p.out_round16 ? (float)(f16)f : f;
+                    if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
+                    v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
+                    const int sc = (p.K == 3 || (p.K == 4 && ch < 3)) ? 2 - ch : ch;
+                    ((uint8_t*)p.out)[(((long)n * p.H + y) * p.W + x) * p.K + sc] = (uint8_t)__float2int_rn(v);
+                    continue;
+                }
+                if (p.out_f32) ((float*)p.out)[o] = f;
+                else ((f16*)p.out)[o] = (f16)f;
+            }
+    }
+}
+
 // S9: a 7x7 convolution as nine 3x3 convolutions over displaced copies of the input -- virtual chunk c = (sub, group): the loader reads
 // channel group `group` displaced by (3*(sub/3 - 1), 3*(sub%3 - 1)) pixels and the weight panel of that chunk holds the 3x3 block
 // (sub/3, sub%3) of the 7x7 kernel zero-padded to 9x9; the consumers see 9x as many chunks of an ordinary 3x3 conv.  Each input pixel
@@ -1756,40 +1928,14 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         }
         if constexpr (RLDS) {
             // chunk nchunks - 2 is input group 0 = residual channels 0..31 (lanes lg 0, 1), chunk nchunks - 1 group 1 = channels 32..63 (lanes lg 2, 3)
-            if (c >= p.nchunks - 2 && (lg >> 1) == c - (p.nchunks - 2)) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const f16x8 x0 = *(const f16x8*)(st + roffs[m]), x1 = *(const f16x8*)(st + roffs[m] + 16);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[t][m][j] = __builtin_fmaf((float)(t < 2 ? x0 : x1)[(t & 1) * 4 + j], p.rs1, acc[t][m][j]);
-                }
-            }
+            if (c >= p.nchunks - 2 && (lg >> 1) == c - (p.nchunks - 2)) residual_from_lds<MT>(acc, st, roffs, p.rs1);
         }
         PCT(c1);
         if (cw == 0) PCACC(0, c1, c0);
         if (++c == p.nchunks) {
             c = 0;
             jt += slots;
-            if constexpr (SGATE) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    f16x8 vb;
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) vb[4 * t + j] = (f16)acc[t][m][j];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_f16(sgw[t], vb, sgb[t], 0, 0, 0);
-#pragma unroll
-                        // (sigmoid on the hardware exponential / reciprocal: at 2160 x 3840 this epilogue evaluates 265 M of them -- the libm forms were 0.3 of the launch)
-                        for (int j = 0; j < 4; ++j) acc[t][m][j] = (float)vb[4 * t + j] * __frcp_rn(1.0f + __expf(-g[j]));
-                    }
-                }
-            }
+            if constexpr (SGATE) self_gate<MT>(acc, sgw, sgb);
             if constexpr (PFX) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -1853,136 +1999,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
 #undef EPI
             } else {
-                // planar NCHW output (the network's last conv): activation only, K valid channels
-                // Fast path -- K <= 4 planar channels, no phase scatter / uint8 image (the last conv of the SR networks, CycleGAN, WBC, PPON's heads): only the
-                // lanes holding channels 0..3 (lg == 0) have anything to store, and the per-VALUE work of the generic loop below (channel test, three 64-bit
-                // multiplies for the address, phase / uint8 tests: ~1 k instructions per wave and tile for 96 x 3 values) is hoisted.  Same values, same stores.
-                if (NT == 1 && p.phase_c == 0 && !p.out_u8 && p.K <= 4) {
-                    if (lg == 0) {
-                        const long plane = (long)p.H * p.W;
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const int y = ty0 + cw * RPW + (m >> 1);
-                            const int x = tx0 + (m & 1) * 16 + li;
-                            if (y >= p.y1 || x >= p.W) continue;
-                            const long o = (long)n * p.K * plane + (long)y * p.W + x;
-                            if (p.act == 0 && p.outm == 0) {              // (the SR networks' last conv: not even a uniform test per value -- 1.39 ms with them, 1.08 without)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    if (j >= p.K) break;
-                                    const float f = acc[0][m][j];
-                                    if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
-                                    else ((f16*)p.out)[o + j * plane] = (f16)f;
-                                }
-                                continue;
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (j >= p.K) break;
-                                float f = acc[0][m][j];
-                                if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
-                                else if (p.act == 2) f = f > 0.f ? f : 0.f;
-                                else if (p.act == 3) f = tanhf(f);
-                                else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
-                                if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
-                                else if (p.outm == 2) f = tanhf(f);
-                                else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
-                                else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
-                                if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
-                                else ((f16*)p.out)[o + j * plane] = (f16)f;
-                            }
-                        }
-                    }
-                } else if (NT == 1 && p.phase_c == 0 && p.out_u8 && p.K <= 4 && p.act == 0 && p.outm == 0) {
-                    // ... and the uint8 image form of the same conv (tensor2np as the epilogue, utils.py:197-248; EngineModule.forward_u8 / FramePipeline): the
-                    // conversion of the generic loop below, value for value, on the lanes that hold channels 0..3
-                    if (lg == 0) {
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const int y = ty0 + cw * RPW + (m >> 1);
-                            const int x = tx0 + (m & 1) * 16 + li;
-                            if (y >= p.y1 || x >= p.W) continue;
-                            uint8_t* o = (uint8_t*)p.out + (((long)n * p.H + y) * p.W + x) * p.K;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (j >= p.K) break;
-                                const float f = acc[0][m][j];
-                                float v = p.out_round16 ? (float)(f16)f : f;
-                                if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
-                                v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
-                                const int sc = (p.K == 3 || (p.K == 4 && j < 3)) ? 2 - j : j;
-                                o[sc] = (uint8_t)__float2int_rn(v);
-                            }
-                        }
-                    }
-                } else if (NT == 1 && p.phase_c > 0 && p.outm == 0 && !p.out_u8 && (p.act == 3 || p.act == 0)) {
-                    // The four output phases of a stride-2 transposed conv as 4 * phase_c channels (the UNet's outermost layer: bias + tanh + phase scatter):
-                    // the channel -> (phase, channel) split is an integer division the generic loop below made per VALUE (24 per wave and tile); here once
-                    // per lane and tile.  Same values, same stores.
-                    if (cbase < p.K) {
-                        long obase[4]; bool live[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int ch = cbase + j, ph = ch / p.phase_c, c = ch - ph * p.phase_c;
-                            live[j] = ch < p.K;
-                            obase[j] = (((long)n * p.phase_c + c) * (2 * p.H) + (ph >> 1)) * (2 * p.W) + (ph & 1);
-                        }
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const int y = ty0 + cw * RPW + (m >> 1);
-                            const int x = tx0 + (m & 1) * 16 + li;
-                            if (y >= p.y1 || x >= p.W) continue;
-                            const long opix = (long)(2 * y) * (2 * p.W) + 2 * x;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (!live[j]) continue;
-                                float f = acc[0][m][j];
-                                if (p.act == 3) f = tanhf(f);
-                                if (p.out_f32) ((float*)p.out)[obase[j] + opix] = f;
-                                else ((f16*)p.out)[obase[j] + opix] = (f16)f;
-                            }
-                        }
-                    }
-                } else
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int y = ty0 + cw * RPW + (m >> 1);
-                    const int x = tx0 + (m & 1) * 16 + li;
-                    if (y >= p.y1 || x >= p.W) continue;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int ch = cbase + 4 * t + j;
-                            if (ch >= p.K) continue;
-                            float f = acc[t][m][j];
-                            if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
-                            else if (p.act == 2) f = f > 0.f ? f : 0.f;
-                            else if (p.act == 3) f = tanhf(f);
-                            else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
-                            if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
-                            else if (p.outm == 2) f = tanhf(f);
-                            else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
-                            else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
-                            long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
-                            if (p.phase_c > 0) {
-                                const int ph = ch / p.phase_c, c = ch - ph * p.phase_c;
-                                o = (((long)n * p.phase_c + c) * (2 * p.H) + 2 * y + (ph >> 1)) * (2 * p.W) + 2 * x + (ph & 1);
-                            }
-                            if (p.out_u8) {
-                                // tensor2np (utils.py:197-248) on the value the planar store would have held: [fp16 rounding,] denorm ((x + 1) / 2
-                                // clipped), clip(255 x, 0, 255).round() half to even, RGB -> BGR flip for 3 / 4 channels; HWC bytes
-                                float v = p.out_round16 ? (float)(f16)f : f;
-                                if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
-                                v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
-                                const int sc = (p.K == 3 || (p.K == 4 && ch < 3)) ? 2 - ch : ch;
-                                ((uint8_t*)p.out)[(((long)n * p.H + y) * p.W + x) * p.K + sc] = (uint8_t)__float2int_rn(v);
-                                continue;
-                            }
-                            if (p.out_f32) ((float*)p.out)[o] = f;
-                            else ((f16*)p.out)[o] = (f16)f;
-                        }
-                }
+                epilogue_planar<RPW, NT>(p, acc, n, ty0, tx0, cw, li, lg, cbase);
             }
         }
         PCT(c2);
