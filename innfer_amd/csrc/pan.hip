@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void pan_attention(const float* fgh, const flo
 // trunk had shrunk.  Here, per workgroup of 8 waves and 128 queries (16 per wave: one MFMA column set):
 //   scores   s[key][query] = g_key . f_query as v_mfma_f32_16x16x32_f16 with keys as rows: both operands are fp16 (hi, lo * 2^11) pairs packed into the
 //            32-deep k dimension -- one MFMA for gh . fh, one for (gh . fl + gl . fh), s = s_hh + 2^-11 s_x: fp32-accurate scores (the 2^-22 term is dropped)
-//   softmax  two passes over the keys like the VALU kernel: the exact row maximum first, then p = exp(s - m) <= 1 and the sum in fp32 on the lanes
+//   softmax  one pass with a running row maximum (accumulators and sums rescaled when it moves): p = exp(s - m) <= 1 and the sum in fp32 on the lanes
 //   out      o[c][query] += h[key][c] p[key][query]: the score MFMAs' rows are assigned to keys so that a lane ends with 8 CONSECUTIVE keys of its query
 //            (key of row rho of score tile t: 8 (rho >> 2) + 4 t + (rho & 3)) -- its fp16 p values ARE the B fragment of the P V product; h as fp16 A
 //            fragments [channel][key] prepared once per forward (pan_attn_prep)
@@ -262,31 +262,11 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
         }
     };
     const int npair = (nblk + 1) / 2;
+    // ONE pass over the keys with a running row maximum (round 4, second version: the separate maximum pass recomputed every score -- 35 % of the kernel):
+    // per pair of blocks the lane's 16 scores -> their maximum -> the maximum over the four lanes that share the query (two cross-lane exchanges) ->
+    // m' = max(m, that); the accumulators and the sum are rescaled by exp(m - m') (1 when the maximum did not move), then p = exp(s - m') <= 1 as before.
+    // Masked keys (>= Np, the padding of the last block) score -inf: p = 0.
     float m = -INFINITY;
-    // ---- pass 1: the row maxima (g pairs only) ----
-    if (t8 < 64) *(f16x8*)(st[0] + dst_off) = *(const f16x8*)stage_src(0);
-    __syncthreads();
-    for (int bp = 0; bp < npair; ++bp) {
-        f16x8 nxt = z8;
-        if (t8 < 64 && bp + 1 < npair) nxt = *(const f16x8*)stage_src(bp + 1);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int b = 2 * bp + h;
-            f32x4 sc[2];
-            scores(st[bp & 1] + h * 4096, sc);
-            const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (kb + 4 * t + j < Np) m = fmaxf(m, sc[t][j]);
-        }
-        if (t8 < 64 && bp + 1 < npair) *(f16x8*)(st[(bp + 1) & 1] + dst_off) = nxt;
-        __syncthreads();
-    }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    // ---- pass 2: p = exp(s - m), sums, P V ----
     f32x4 acc[3] = {z4, z4, z4};
     float sum = 0.f;
     *(f16x8*)(st[0] + dst_off) = *(const f16x8*)stage_src(0);
@@ -294,22 +274,45 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
     for (int bp = 0; bp < npair; ++bp) {
         f16x8 nxt = z8;
         if (bp + 1 < npair) nxt = *(const f16x8*)stage_src(bp + 1);
+        f32x4 sc[2][2];
+        float bm = -INFINITY;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int b = 2 * bp + h;
+            scores(st[bp & 1] + h * 4096, sc[h]);
+            const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
+            if (kb + 8 > Np) {                                       // (only the last block of an image is ragged)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (kb + 4 * t + j >= Np) sc[h][t][j] = -INFINITY;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bm = fmaxf(bm, sc[h][t][j]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16));
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float mn = fmaxf(m, bm);                               // finite from the first pair on (every image has a key in its first block)
+        const float rescale = __expf(m - mn);                        // exp(-inf) = 0 on the first pair: acc and sum are zero there anyway
+        m = mn;
+        sum *= rescale;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = acc[t] * rescale;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
             const char* sp = st[bp & 1] + h * 4096;
-            f32x4 sc[2];
-            scores(sp, sc);
             f16x8 v[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) v[t] = *(const f16x8*)(sp + 1024 + t * 1024 + lane * 16);
-            const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
             f16x8 pk;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float e = kb + 4 * t + j < Np ? __expf(sc[t][j] - m) : 0.f;
+                    const float e = __expf(sc[h][t][j] - m);
                     sum += e;
                     pk[4 * t + j] = (f16)e;
                 }
