@@ -94,6 +94,8 @@ struct ConvLaunch {
     int split;                                    // fp32-accurate mode: every tensor is a (hi, lo) pair of fp16 slabs, lo = fp16((x - hi) * 2^11) (conv3x3.hip, SPLIT); panels from
     long in_lo, out_lo, res1_lo, res2_lo;         // conv_pack_split / conv_pack_1x1_split; *_lo: distance (elements) from a hi slab to its lo twin.  Plain 3x3 / 1x1 slab convs
                                                   // (act 0..2, residuals, upsampled input, batches) and the planar last conv
+    int in_relu;                                  // 1: the operand is max(stored input, 0) (applied as fragments leave LDS) -- transposed-conv phase launches and the planar
+                                                  // <= 16-output kernel: the UNet stores a skip tensor once (LeakyReLU form) and its up conv reads relu(cat) from it
     const f16* gate_w; const float* gate_bias;    // != nullptr (32-output slab convs): out = act(v * sigmoid(W v + b)) with v = fp16(conv + bias) -- PAN's pixel attention behind an up-conv
                                                   // as this conv's epilogue; panels from conv_pack_selfgate (2 KB), 32 biases; `act` is the activation AFTER the gate
     int res1_lds;                                 // 1: when res1 is the conv's own input (groups 0, 1: the dense block's x5 * 0.2 + x), act 0 and K = 64, take it from the staged LDS tiles

@@ -1161,6 +1161,16 @@ __device__ __forceinline__ void epilogue_planar(const KP& p, f32x4 (&acc)[NT][2 
     }
 }
 
+// max(x, 0) of a pixel fragment (BRELU kernels): four v_pk_max_f16.  Inline asm: the builtin max is the IEEE maxnum -- the compiler canonicalises its operand first
+// (a second v_pk_max_f16 x, x per register plus the hazard nops between the two) and the eight-instruction form cost the phase kernels 14 %.
+__device__ __forceinline__ f16x8 relu_frag(f16x8 b) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t v = __builtin_bit_cast(u32x4_t, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { unsigned o; asm("v_pk_max_f16 %0, %1, 0" : "=v"(o) : "v"(v[e])); v[e] = o; }
+    return __builtin_bit_cast(f16x8, v);
+}
+
 // S9: a 7x7 convolution as nine 3x3 convolutions over displaced copies of the input -- virtual chunk c = (sub, group): the loader reads
 // channel group `group` displaced by (3*(sub/3 - 1), 3*(sub%3 - 1)) pixels and the weight panel of that chunk holds the 3x3 block
 // (sub/3, sub%3) of the 7x7 kernel zero-padded to 9x9; the consumers see 9x as many chunks of an ordinary 3x3 conv.  Each input pixel
@@ -1245,6 +1255,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // agree to the last fp16 rounding -- without the round trip of the 32-channel HR tensor (531 MB written and read again at 2160 x 3840).
     constexpr bool SGATE = (TMF & 0x80000) != 0;
     static_assert(!SGATE || (RPW == 3 && NT == 2 && NCW == 8 && OUTMODE == OUT_SLAB && (TMF & 0x7FFFF) == 0x1FF && !S9 && !POLY), "self gate: the 32-output slab kernel (and its canvas form)");
+    // + 0x100000 (BRELU): the pixel operand is max(x, 0) of the stored slab -- the UNet keeps ONE stored form of a skip tensor (LeakyReLU, the down conv's operand);
+    // the up conv that reads the concatenation applies the ReLU as it takes a fragment from LDS (4 v_pk_max_f16 per fragment, i.e. per 2 .. 8 MFMAs).
+    // max(lrelu(v), 0) == relu(v) bit for bit in fp16, so the results are those of the two-view form.
+    constexpr bool BRELU = (TMF & 0x100000) != 0;
     constexpr bool FUSE = (TMF & 0x20000) != 0;
     static_assert(!FUSE || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation");
     constexpr int TH = NCW * RPW;
@@ -1822,6 +1836,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             };
             lda(0, 0); lda(0, 1); lda(0, 2);
             bq[0] = ldb(0); bq[1] = ldb(1);
+            if constexpr (BRELU) bq[0] = relu_frag(bq[0]);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int sc = i / GPS, j = i - sc * GPS, rr = j >> 1, seg = j & 1;
@@ -1835,6 +1850,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                             acc[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[r][t], bq[i % 3], acc[t][rw * 2 + seg], 0, 0, 0);
                     }
                 }
+                if constexpr (BRELU) { if (i + 1 < NB) bq[(i + 1) % 3] = relu_frag(bq[(i + 1) % 3]); }      // the NEXT group's fragment, in the shadow of this group's MFMAs
                 if (sc < 2 && seg == 1) {
                     if (rr == RPW - 1) lda(sc + 1, 0);
                     if (rr == RPW) lda(sc + 1, 1);
@@ -1864,6 +1880,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             lda(S0, 0); lda(S0, 1);
             bq[0] = ldb(0);
             if (NBW > 1) bq[1] = ldb(1);
+            if constexpr (BRELU) bq[0] = relu_frag(bq[0]);
 #pragma unroll
             for (int i = 0; i < NBW; ++i) {
                 if (i + 2 < NBW) bq[(i + 2) % 3] = ldb(i + 2);
@@ -1876,6 +1893,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                             acc[t][rw * 2 + WK.seg[i]] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q][t], bq[i % 3], acc[t][rw * 2 + WK.seg[i]], 0, 0, 0);
                     }
                 }
+                if constexpr (BRELU) { if (i + 1 < NBW) bq[(i + 1) % 3] = relu_frag(bq[(i + 1) % 3]); }      // the NEXT group's fragment, in the shadow of this group's MFMAs
                 // the next column's fragments overwrite this column's as soon as their last MFMA has been issued
                 if (WK.s[i] == S0 && WK.seg[i] == NSEG - 1) {
                     if (WK.rr[i] == R0 + RPW - 1) lda(S0 + 1, 0);
@@ -1903,6 +1921,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                 for (int seg = 0; seg < NSEG; ++seg) {
                     f16x8 b = *(const f16x8*)(st + ((PAIR && seg) ? boffp[PAIR ? s : 0][rr & 1] + rr * LWP * 64 : boffs[s][rr & 1] + (rr * LWP + seg * 16) * 64));
+                    if constexpr (BRELU) b = relu_frag(b);
                     if constexpr (PFX) {           // (one tap: row rr feeds output row rr - 1 only)
                         static_assert(!PFX || TM == 0x10, "the running-sum operand belongs to the one-tap kernels");
 #pragma unroll
@@ -2533,8 +2552,16 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         if (!pc || L.out_mode != OUT_SLAB || nt != 4 || L.phase_c <= 0 || L.phase_c % 64 || L.K != 4 * L.phase_c || L.res1 || L.res2 || L.up || L.reflect ||
             L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.dilation > 1 || L.dilation_groups)
             return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: slab output, 64-channel phase groups, no residual / upsampling / padding modes");
+        // (in_relu on the phase lattice was built and measured -- scripts/r4/unet_one_view.sh: the four v_pk_max_f16 per fragment share the issue port with the MFMAs of
+        //  these matrix-bound launches, +7.7 % on a 130-us launch against a 6 .. 12 us shorter post pass; only the HBM-bound outermost layer keeps the operand ReLU)
+        if (L.in_relu) return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: in_relu is built for the planar <= 16-output kernel only");
         if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x141B, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x101B, false, UNET_NSI>(k, L.N, s);
         return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x41B, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B, false, UNET_NSI>(k, L.N, s);
+    }
+    if (L.in_relu) {         // operand = max(stored, 0) (conv3x3_pc<.., TMF | 0x100000>): the planar 16-output kernel -- the UNet's outermost transposed conv
+        if (!(pc && L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2 && !L.conv7 && !L.stride2 && !L.conv7v && !L.conv1x1 && !L.gate_w && !L.fuse_w && !L.up && !L.reflect))
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: in_relu is built for the planar <= 16-output kernel");
+        return launch_pc<3, 1, 4, OUT_NCHW, false, false, 0x1001FF>(k, L.N, s);
     }
     if (L.stride2) {         // Conv2d(k 4, s 2, p 1): H x W = the OUTPUT grid, source image 2H x 2W; panels from conv_pack_taps(K, 4C, 0x1B0), virtual channel
                              // (2 pa + pb) * C + ci, tap (1 + dy, 1 + dx) = w[co][ci][2 dy + pa][2 dx + pb]

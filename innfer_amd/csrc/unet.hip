@@ -123,12 +123,10 @@ __global__ __launch_bounds__(256) void unet_post_slab_parts(const f16* src, long
 #pragma unroll
     for (int e = 0; e < 8; ++e) { al[e] = sal[q8 + e]; sh[e] = ssh[q8 + e]; }
     const int c0 = d.coff + cb + q8, c1 = d1.coff + cb + q8;
-#pragma unroll 4
-    for (int i = 0; i < pxb / 64; ++i) {
-        const long px = (long)blockIdx.x * pxb + pl + 64 * i;
-        if (px >= HW) break;
-        const long pix = (long)n * HW + px;
-        const f16x8 x = *(const f16x8*)(src + (cb >> 5) * sg + pix * 32 + q8);
+    const f16* sp = src + (cb >> 5) * sg + q8;
+    f16* o0 = d.p + (c0 >> 5) * d.g + (c0 & 31);
+    f16* o1 = d1.p ? d1.p + (c1 >> 5) * d1.g + (c1 & 31) : nullptr;
+    auto apply = [&](const f16x8 x, long pix) __attribute__((always_inline)) {
         f16x8 h, h1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -136,8 +134,25 @@ __global__ __launch_bounds__(256) void unet_post_slab_parts(const f16* src, long
             h[e] = (f16)(d.act == 1 ? fmaxf(v, 0.2f * v) : fmaxf(v, 0.f));
             h1[e] = (f16)(d1.act == 1 ? fmaxf(v, 0.2f * v) : fmaxf(v, 0.f));
         }
-        *(f16x8*)(d.p + (c0 >> 5) * d.g + pix * 32 + (c0 & 31)) = h;
-        if (d1.p) *(f16x8*)(d1.p + (c1 >> 5) * d1.g + pix * 32 + (c1 & 31)) = h1;
+        *(f16x8*)(o0 + pix * 32) = h;
+        if (o1) *(f16x8*)(o1 + pix * 32) = h1;
+    };
+    const long px0 = (long)blockIdx.x * pxb + pl, pixb = (long)n * HW + px0;
+    if ((long)(blockIdx.x + 1) * pxb <= HW) {
+        // whole block: four loads in flight per lane before the first is touched (a loop with a bounds exit keeps ONE in flight -- the compiler cannot hoist a load
+        // above the exit test -- and the pass then ran at 2.5 TB/s on the 64^2 level)
+        for (int i = 0; i < pxb / 64; i += 4) {
+            f16x8 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = *(const f16x8*)(sp + (pixb + 64 * (i + j)) * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) apply(x[j], pixb + 64 * (i + j));
+        }
+    } else {
+        for (int i = 0; i < pxb / 64; ++i) {
+            if (px0 + 64 * i >= HW) break;
+            apply(*(const f16x8*)(sp + (pixb + 64 * i) * 32), pixb + 64 * i);
+        }
     }
 }
 static int launch_post_slab_parts(const f16* src, long sg, int C, long HW, int N, const float* part, int nper, const float* gamma, const float* beta,
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(256) void unet_first_mfma(const TI* in, int C, int 
             if ((abl & 2) && h0[0][0] != (f16)12345.f) return;       // diagnostic build: no stores
 #endif
             *(f16x8*)(d0 + o) = h0[0]; *(f16x8*)(d0 + o + 8) = h0[1];
-            *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + o + 8) = h1[1];
+            if (d1) { *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + o + 8) = h1[1]; }      // (wave-uniform; nullptr: one stored form, the up conv applies the ReLU as it reads)
         };
         request(0, rawA);
         int sx = 0;
@@ -990,6 +1005,13 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
     };
 
     const bool first_mfma = u->down[0].patch && u->down[0].d_wf && L > 1;
+    // One stored form of the outermost skip tensor.  The first conv's result t feeds the next down conv as LeakyReLU(t) and the outermost up conv's concatenation as
+    // ReLU(t).  That up conv (HBM-bound: 128 -> 3 channels) takes max(stored, 0) as it reads its fragments from LDS (ConvLaunch.in_relu; relu(fp16(lrelu(t))) ==
+    // fp16(relu(t)) bit for bit), so only lrelu(t) is stored -- in the concatenation buffer, where the next down conv reads it too: 134 MB of the 64 x 256^2
+    // forward's writes less (first conv 94 -> 63 us, the up conv +2 us).  The inner levels keep two stored views: their up convs are matrix-bound and the operand
+    // ReLU shares the MFMAs' issue port (measured: +7.7 % on those launches against 6 .. 12 us less in the post pass; scripts/r4/unet_one_view.sh).
+    const int two_views = INNFER_KNOB("INNFER_UNET_TWO_VIEWS", 0);
+    auto one_view = [&](int k) { return !two_views && k == 0 && L > 1 && !u->up[0].upconv && u->up[0].phases; };
     if (first_mfma) {          // the outermost down conv reads the NCHW input itself
     } else if (u->down[0].patch) {   // NCHW input -> 64-channel patch slab at half resolution
         const long M = (long)N * (H / 2) * (W / 2);
@@ -1014,16 +1036,19 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             if ((long)u->in_nc * H * W >= 0x7fffffffL || (long)N * ho >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "unet_forward: image too large");
             const unsigned grid = (unsigned)std::min<long>(((long)N * ho + 3) / 4, 256L * 8);
             const int abl = INNFER_KNOB("INNFER_FIRST_ABL", 0);
-            GtScope gt(s, "unet_first_mfma (3 -> 64, 4x4 s2, two views)", 2.0 * 16 * u->in_nc * l.cout * (double)N * HWo,
-                       (double)N * H * W * u->in_nc * (in_dtype == INNFER_F32 ? 4.0 : 2.0) + 2.0 * N * HWo * l.cout * 2.0);
+            const bool ov = one_view(0);
+            GtScope gt(s, "unet_first_mfma (3 -> 64, 4x4 s2)", 2.0 * 16 * u->in_nc * l.cout * (double)N * HWo,
+                       (double)N * H * W * u->in_nc * (in_dtype == INNFER_F32 ? 4.0 : 2.0) + (ov ? 1.0 : 2.0) * N * HWo * l.cout * 2.0);
+            f16* dl = (f16*)(ws + (ov ? cv.CAT[0] : cv.D[0]));
+            f16* dr = ov ? nullptr : (f16*)(ws + cv.CAT[0]);
             if (in_dtype == INNFER_F32)
                 hipLaunchKernelGGL(unet_first_mfma<float>, dim3(grid), dim3(256), 0, s, (const float*)d_in, u->in_nc, H, W, N, (const f16*)l.d_wf,
-                                   (const float*)(l.bias >= 0 ? l.d_bias : nullptr), (f16*)(ws + cv.D[0]), (f16*)(ws + cv.CAT[0]), Go, abl);
+                                   (const float*)(l.bias >= 0 ? l.d_bias : nullptr), dl, dr, Go, abl);
             else
                 hipLaunchKernelGGL(unet_first_mfma<f16>, dim3(grid), dim3(256), 0, s, (const f16*)d_in, u->in_nc, H, W, N, (const f16*)l.d_wf,
-                                   (const float*)(l.bias >= 0 ? l.d_bias : nullptr), (f16*)(ws + cv.D[0]), (f16*)(ws + cv.CAT[0]), Go, abl);
+                                   (const float*)(l.bias >= 0 ? l.d_bias : nullptr), dl, dr, Go, abl);
             INNFER_HIP(hipGetLastError());
-            cur = (f16*)(ws + cv.D[0]); cur_g = Go;
+            cur = dl; cur_g = Go;
             h = ho; w = wo;
             continue;
         }
@@ -1031,8 +1056,9 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             // no BatchNorm behind the outermost conv: the two views of its output (lrelu for the next conv, relu for the concatenation) come
             // straight out of the conv epilogue, one launch each (HBM-bound launches; the GEMM + post pair makes three passes)
             const long HWo = (long)ho * wo, Go = (long)N * HWo * 32;
-            f16* dsts[2] = {(f16*)(ws + cv.D[k]), (f16*)(ws + cv.CAT[k])};
-            for (int v = 0; v < 2; ++v) {
+            const bool ov = one_view(k);
+            f16* dsts[2] = {(f16*)(ws + (ov ? cv.CAT[k] : cv.D[k])), (f16*)(ws + cv.CAT[k])};
+            for (int v = 0; v < (ov ? 1 : 2); ++v) {
                 ConvLaunch Lc{};
                 Lc.in = cur; Lc.in_gstride = Go; Lc.C = 64;
                 Lc.wpk = (const f16*)l.d_w3; Lc.bias = l.d_b3;
@@ -1059,6 +1085,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             if (rc) return rc;
             const long total = (long)N * HWo * (l.cout / 8);
             PostDst dl{(f16*)(ws + cv.D[k]), Go, 0, 1}, dr{(f16*)(ws + cv.CAT[k]), Go, 0, 2};
+            if (one_view(k)) { dl.p = dr.p; dr = PostDst{nullptr, 0, 0, 0}; }
             if (!ev) {           // the records are merged inside the post pass
                 rc = launch_post_slab_parts((const f16*)Y, Go, l.cout, HWo, N, bnpart, conv_stats_nper(ho, wo, 1), l.d_gamma, l.d_beta, dl, dr, s);
                 if (rc) return rc;
@@ -1085,6 +1112,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         if (k < L - 1) {
             PostDst dl{(f16*)(ws + cv.D[k]), G, 0, 1};              // lrelu(t): next down conv (and the skip's stored form)
             PostDst dr{(f16*)(ws + cv.CAT[k]), G, 0, 2};            // relu(t): first half of the up conv's concatenation
+            if (one_view(k)) { dl.p = dr.p; dr = PostDst{nullptr, 0, 0, 0}; }
             rc = post(l, HW, k > 0, dl, dr);
             cur = dl.p; cur_g = G;
         } else {
@@ -1149,6 +1177,7 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
             Lc.out = d_out; Lc.K = 4 * l.cout; Lc.N = N; Lc.H = h; Lc.W = w;
             Lc.act = 3; Lc.s1 = Lc.s2 = 1.f; Lc.y0 = 0; Lc.y1 = h;
             Lc.out_mode = OUT_NCHW; Lc.out_f32 = out_dtype == INNFER_F32; Lc.phase_c = l.cout;
+            Lc.in_relu = k < L - 1 && one_view(k);
             int rc = conv_launch(Lc, s);
             if (rc) return rc;
             h = hf; w = wf;
