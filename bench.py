@@ -100,7 +100,7 @@ def timed_forward(net, x):
     L.check(L.lib.innfer_net_set_band_rows(net._handle, int(net.band_rows)))
     L.check(L.lib.innfer_net_set_pair_convs(net._handle, int(net.pair_convs)))
     L.check(L.lib.innfer_net_set_fused_tail(net._handle, int(bool(net.fused_tail))))
-    L.check(L.lib.innfer_net_set_upconv_phases(net._handle, int(bool(net.upconv_phases))))
+    L.check(L.lib.innfer_net_set_upconv_phases(net._handle, int(net.upconv_phases)))
     L.check(L.lib.innfer_net_set_residual_lds(net._handle, int(net.residual_lds)))
     L.check(L.lib.innfer_net_forward_timed(net._handle, x.data_ptr(), L.F16, out.data_ptr(), L.F16, N, H, W,
                                            net._ws.data_ptr(), net._ws.numel(), stream, cap, ms, fl, by, kd, C.byref(n)))
@@ -504,6 +504,7 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="frame workloads: a float32 frame = the fp32-accurate engine (the reference's -no_fp16 mode); no roofline object")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: HR_conv0 and conv_last as two launches (innfer_net_set_fused_tail 0)")
     ap.add_argument("--no-upconv-phases", action="store_true", help="A/B: the up-convs as nine taps on the HR grid (innfer_net_set_upconv_phases 0)")
+    ap.add_argument("--upconv-phase-visits", action="store_true", help="A/B: the phase up-convs with one phase per visit of a tile (innfer_net_set_upconv_phases 2; default: all four phases in one visit)")
     ap.add_argument("--residual-lds", type=int, default=1, choices=[0, 1, 2], help="A/B: innfer_net_set_residual_lds -- the dense block's residual from the conv's own LDS stages: 0 never, 1 the RRDB-end blocks (default), 2 every block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the chop8k (BASELINE config 3) and unet64 (config 5) objects of the line")
@@ -581,7 +582,7 @@ def main():
     net, _ = build_net(dev)
     net.band_rows = args.band_rows
     net.fused_tail = not args.no_fused_tail
-    net.upconv_phases = not args.no_upconv_phases
+    net.upconv_phases = 0 if args.no_upconv_phases else (2 if args.upconv_phase_visits else 1)
     net.residual_lds = args.residual_lds
     net.pair_convs = args.pair_convs
     tag = " (DRY RUN: all ranks on one GPU, gloo)" if dryrun else ""

@@ -39,7 +39,8 @@ class EngineModule(nn.Module):
         self._weights_device = None          # GPU the engine's packed weights live on
         self._ws = None
         self.band_rows = 0
-        self.upconv_phases = True    # innfer_net_set_upconv_phases: upconv_block convs as four 2x2-tap phases on the LR grid (summed weights, one rounding)
+        self.upconv_phases = True    # innfer_net_set_upconv_phases: upconv_block convs as four 2x2-tap phases on the LR grid (summed weights, one rounding); True / 1: all four
+                                     # phases in one visit of a tile, 2: one phase per visit (rounds 3's form; same bits), False / 0: nine taps on the HR grid
         self.fused_tail = True       # innfer_net_set_fused_tail: HR_conv0 -> conv_last as one kernel where the shapes allow it (results agree to the last fp16 rounding with the two-launch form)
         self.residual_lds = 1        # innfer_net_set_residual_lds: the dense block's `x5 * 0.2 + x` takes x from the conv's own staged LDS tiles -- 1 the RRDB-end blocks (measured gain), 2 every block, 0 never (all agree to the last fp16 rounding)
         self.pair_convs = 0          # innfer_net_set_pair_convs: 0 one launch per layer (default), 1 fused conv pairs on single-image forwards, 2 always
@@ -177,7 +178,7 @@ class EngineModule(nn.Module):
         L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
         L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
         L.check(L.lib.innfer_net_set_residual_lds(self._handle, int(self.residual_lds)))
-        L.check(L.lib.innfer_net_set_upconv_phases(self._handle, int(bool(self.upconv_phases))))
+        L.check(L.lib.innfer_net_set_upconv_phases(self._handle, int(self.upconv_phases)))
         L.check(L.lib.innfer_net_set_outm(self._handle, int(getattr(self, '_outm', 0))))
         L.check(L.lib.innfer_net_set_precision(self._handle, int(x.dtype == torch.float32)))
         x = x.contiguous()
@@ -208,7 +209,7 @@ class EngineModule(nn.Module):
             L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
             L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
             L.check(L.lib.innfer_net_set_residual_lds(self._handle, int(self.residual_lds)))
-            L.check(L.lib.innfer_net_set_upconv_phases(self._handle, int(bool(self.upconv_phases))))
+            L.check(L.lib.innfer_net_set_upconv_phases(self._handle, int(self.upconv_phases)))
             L.check(L.lib.innfer_net_set_u8_io(self._handle, int(bool(normalize)), int(bool(fp16))))
             L.check(L.lib.innfer_net_set_precision(self._handle, int(not fp16)))
             L.check(L.lib.innfer_net_set_outm(self._handle, 0))

@@ -251,6 +251,11 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
         colstep = 16 * 32 * 2;
         ylim = p.H;
         if constexpr (PAIR) { pix0 = ((long)(2 * n) * 2 * p.H + 2 * yw + a) * (2 * p.W) + 2 * xl + b; colstep = 4L * p.H * p.W * 32; }
+#ifdef INNFER_ABLATE
+        // abl 64 (wrong results by construction): phase b of a row goes to the left / right HALF of the HR row as 16 consecutive pixels -- the same bytes as
+        // whole 128-byte lines instead of every other 64-byte pixel (what the half-line stores of the phase scatter cost: profiles/r4/upconv_bound.txt)
+        if (!PAIR && (p.abl & 64)) { pix0 = ((long)n * 2 * p.H + 2 * yw + a) * (2 * p.W) + xl + b * p.W; colstep = 16 * 32; }
+#endif
     } else if constexpr (PAIR) {
         // PAIR (images at most 16 pixels wide): the tile's two 16-pixel segments are images 2n and 2n + 1 -- a segment step is an image step
         pix0 = ((long)(2 * n) * p.H + yw) * p.W + xl;
@@ -281,6 +286,19 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
         if (p.abl & 1) continue;
 #endif
         f16* op = ob + (m >> 1) * rowstep + (m & 1) * colstep;
+#ifdef INNFER_ABLATE
+        // abl 128 (wrong results by construction): every lane's 32 bytes of pixel tile m at consecutive addresses -- a store instruction writes 1 KB of whole
+        // lines instead of 16-byte pieces of 32 (what the piece-wise stores of the MFMA result layout cost)
+        if (DCV && !PAIR && (p.abl & 128)) op = (f16*)p.out + (pix0 - 2 * li) * 32 + (m * 64 + (int)(threadIdx.x & 63)) * 16;
+        // abl 256 (values land permuted inside the wave's own 1 KB runs; same bytes, same lines, no overlap between waves): lane L writes piece L of the run --
+        // consecutive lanes -> consecutive addresses -- instead of lane (li, lg) -> pixel li, piece lg: what the LANE ORDER of the MFMA result layout costs
+        if (!DCV && !PAIR && !POLY && (p.abl & 256)) {
+            const int lgq = (int)(threadIdx.x & 63) >> 4;
+            if (NT == 2) op = op - li * 32 - 8 * lgq + (int)(threadIdx.x & 63) * 8;
+            else if (NT == 4) op = op - li * 32 - 16 * (lgq & 1) + ((lgq & 1) * 16 + li) * 16;
+        }
+        if (!DCV && !PAIR && !POLY && (p.abl & 128)) op = (f16*)p.out + (pix0 - li) * 32 + (m * 64 + (int)(threadIdx.x & 63)) * (4 * NT);      // (the plain layers: 16 / 32 bytes per lane)
+#endif
         if (!HOIST) {
             const long o = (m >> 1) * rowstep + (m & 1) * colstep;
 #pragma unroll
@@ -1259,6 +1277,16 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // the up conv that reads the concatenation applies the ReLU as it takes a fragment from LDS (4 v_pk_max_f16 per fragment, i.e. per 2 .. 8 MFMAs).
     // max(lrelu(v), 0) == relu(v) bit for bit in fp16, so the results are those of the two-view form.
     constexpr bool BRELU = (TMF & 0x100000) != 0;
+    // + 0x200000 (UP4): all four output phases of a 2x transposed conv (the SR networks' up-convs as phase convs, net.hip) in ONE visit of a tile.  The
+    // phase-lattice form (TM 0x1B) visits a tile once per phase and stages its input tile each time: the launch moves 4 x 128 B of input per LR pixel beside
+    // 512 B of output, and the ablation (profiles/r4/upconv_bound.txt) shows the input stream is 0.9 of the 2.35 ms the frame's two up-convs take.  Here the
+    // tile's two input groups (C = 64) stay in two of three LDS slots while the eight weight panels (phase, group) stream through the two weight slots:
+    // step g of a workgroup is (tile g / 8, phase (g % 8) / 2, group g % 2); phase (a, b) multiplies the 2 x 2 tap block (a .. a + 1) x (b .. b + 1) of
+    // the UNSHIFTED 3 x 3 halo tile (= the shifted lattice's taps {-1, 0}^2 at virtual pixel (y + a, x + b)) and stores through the phase-lattice
+    // epilogue after its second group.  The loaders fetch the next tile's group 0 into the free slot at step 0 and its group 1 into the slot the
+    // current tile's group 0 leaves after step 6.  Same MFMAs, same operands, same order per output value as the four-visit form: same bits.
+    constexpr bool UP4 = (TMF & 0x200000) != 0;
+    static_assert(!UP4 || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 3 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFFF) == 0x1FF && !S9 && !POLY && !CV), "one-pass phases: the 64-channel slab kernel on three input slots");
     constexpr bool FUSE = (TMF & 0x20000) != 0;
     static_assert(!FUSE || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation");
     constexpr int TH = NCW * RPW;
@@ -1268,7 +1296,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int KQ = (NQ + NLW - 1) / NLW;
     constexpr int IN_BYTES = NQ * 1024;
     constexpr int WROWS = NT * 16;
-    constexpr int NTAP = WINO ? 12 : __builtin_popcount(TM);        // taps in the panel, in (r, s) order (WINO: (r, xi))
+    constexpr int NTAP = WINO ? 12 : UP4 ? 4 : __builtin_popcount(TM);        // taps in the panel, in (r, s) order (WINO: (r, xi); UP4: a phase's 2 x 2 block)
     constexpr int W_BYTES = NTAP * WROWS * 64;
     constexpr int WQ = W_BYTES / 1024;
     constexpr int KW = (WQ + NLW - 1) / NLW;
@@ -1590,6 +1618,34 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 else if (my_in == KQ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KQ) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KQ - 1) : "memory");
             };
+            if constexpr (UP4) {
+                // tile T's groups 0 / 1 live in slots (2T) % 3 and (2T + 1) % 3 for its eight steps; weights: panel (g + 1) % 8 one step ahead
+                int jt_i = j0, base = 0;                                  // base: slot of the current tile's group 0
+                setup(jt_i);
+                issue_to(0, smem, wring, (const char*)p.wpk, 3);
+                issue_to(1, smem + IN_BYTES, nullptr, nullptr, 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                for (int g = 0; g < G; ++g) {
+                    const int st8 = g & 7;
+                    bool pending = false;
+                    if (g + 1 < G) issue_to(0, nullptr, wring + ((g + 1) & 1) * W_BYTES, (const char*)p.wpk + (long)((g + 1) & 7) * W_BYTES, 2);
+                    if (st8 == 0 && g + 8 < G) {                          // next tile's group 0 -> the slot the previous tile's group 1 has left
+                        jt_i += slots; setup(jt_i);
+                        const int fs = base == 0 ? 2 : base - 1;          // (base + 2) % 3
+                        issue_to(0, smem + fs * IN_BYTES, nullptr, nullptr, 1);
+                        pending = true;
+                    }
+                    if (st8 == 7 && g + 1 < G) {                          // next tile's group 1 -> this tile's group-0 slot (last read in step 6)
+                        issue_to(1, smem + base * IN_BYTES, nullptr, nullptr, 1);
+                        pending = true;
+                        base = base == 0 ? 2 : base - 1;
+                    }
+                    wait_all_but_in(pending);
+                    asm volatile("s_barrier" ::: "memory");
+                }
+                return;
+            }
             int jt_i = j0, c_i = 0;                                       // input cursor (setup() keeps its tile's offsets in voff / in_tile)
             int jt_w = j0, c_w = 0, kg_w;                                 // weight cursor
             { int n_, ty_, tx_; decode(jt_w, kg_w, n_, ty_, tx_); }
@@ -1728,6 +1784,103 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             sgb[t] = *(const f32x4*)(p.sg_bias + 8 * lg + 4 * t);
         }
     }
+    // The four-tap chunk as a generic lambda over the tap mask (the one-pass up-conv, UP4, walks a different 2 x 2 block per phase): acc += panel at sw x halo tile at st
+    auto four_tap = [&](auto tmc, f32x4 (&acc)[NT][2 * RPW], const char* st, const char* sw) __attribute__((always_inline)) {
+        constexpr int TMX = decltype(tmc)::value;
+        // The four-tap kernels (the stride-2 convs and the transposed-conv phases of the UNet / ResNet generators) with the fragment reads
+        // software-pipelined like the nine-tap loop above: all sixteen weight fragments of the chunk first, then the pixel fragments through a
+        // three-register ring, each read two MFMA groups ahead of its use.  Left to the scheduler, every read sat in front of its first use:
+        // a chunk-step took the LDS phase PLUS the MFMA phase (1.8 us for 1.0 us of matrix work).  Same MFMAs in the same order: same bits.
+        constexpr const TapWalk& WK = TapWalkOf<TMX, RPW, NSEG>::value;      // (a class-scope constant: a local copy indexed by a loop variable may land in scratch)
+        constexpr int NBW = TapWalkOf<TMX, RPW, NSEG>::value.n;
+        constexpr int R0 = (TMX & 0x007) ? 0 : 1, S0 = (TMX & 0x049) ? 0 : 1;          // the mask is the 2 x 2 block of taps (R0 .. R0 + 1) x (S0 .. S0 + 1)
+        static_assert(TMX == (0x1B << (3 * R0 + S0)), "four taps: a 2 x 2 block of the 3 x 3 lattice");
+        f16x8 a[2][NT];                                                              // the weight fragments of the current tap column, by tap row - R0
+        auto lda = [&](int sc, int q) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[q][t] = *(const f16x8*)(sw + aoffs + ((q * 2 + sc - S0) * WROWS + t * 16) * 64);
+        };
+        f16x8 bq[3];
+        auto ldb = [&](int i) {
+            if constexpr (PAIR) { if (WK.seg[i]) return *(const f16x8*)(st + boffp[WK.s[i]][WK.rr[i] & 1] + WK.rr[i] * LWP * 64); }
+            return *(const f16x8*)(st + boffs[WK.s[i]][WK.rr[i] & 1] + (WK.rr[i] * LWP + WK.seg[i] * 16) * 64);
+        };
+        lda(S0, 0); lda(S0, 1);
+        bq[0] = ldb(0);
+        if (NBW > 1) bq[1] = ldb(1);
+        if constexpr (BRELU) bq[0] = relu_frag(bq[0]);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            if (i + 2 < NBW) bq[(i + 2) % 3] = ldb(i + 2);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int rw = WK.rr[i] - R0 - q;
+                if (rw >= 0 && rw < RPW) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t][rw * 2 + WK.seg[i]] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q][t], bq[i % 3], acc[t][rw * 2 + WK.seg[i]], 0, 0, 0);
+                }
+            }
+            if constexpr (BRELU) { if (i + 1 < NBW) bq[(i + 1) % 3] = relu_frag(bq[(i + 1) % 3]); }      // the NEXT group's fragment, in the shadow of this group's MFMAs
+            // the next column's fragments overwrite this column's as soon as their last MFMA has been issued
+            if (WK.s[i] == S0 && WK.seg[i] == NSEG - 1) {
+                if (WK.rr[i] == R0 + RPW - 1) lda(S0 + 1, 0);
+                if (WK.rr[i] == R0 + RPW) lda(S0 + 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (UP4) {
+        // ---- the one-pass up-conv's own walk: per tile, the four phases as straight-line code (a phase's accumulators live from its bias to its epilogue only;
+        // a `switch` over the phase inside the generic step loop made the allocator carry them across all four unrolled bodies: 344 bytes of scratch per lane) ----
+        f32x4 bias_n[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bias_n[t] = *(const f32x4*)(p.bias + 4 * NT * lg + 4 * t);      // phase 0
+        asm volatile("s_barrier" ::: "memory");                   // both groups of the first tile and the first panel have landed
+        int slot0 = 0;                                            // LDS slot of the tile's group 0: (2 T) % 3
+#ifdef INNFER_ABLATE
+        const bool no_mfma = (p.abl & 8) != 0;
+#else
+        constexpr bool no_mfma = false;
+#endif
+        for (int jt = j0; jt < run_len; jt += slots) {
+            int kg, n, ty0, tx0;
+            decode(jt, kg, n, ty0, tx0);
+            auto phase = [&](auto phc) __attribute__((always_inline)) {
+                constexpr int PH = decltype(phc)::value, A = PH >> 1, B = PH & 1;
+                const int cbase = PH * WROWS + 4 * NT * lg;
+                f32x4 acc[NT][MT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[t][m] = bias_n[t];
+                {                        // the next phase's bias, requested two steps before it is needed
+                    const int nb = ((PH + 1) & 3) * WROWS + 4 * NT * lg;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bias_n[t] = *(const f32x4*)(p.bias + nb + 4 * t);
+                }
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    const int sl = slot0 + cg;
+                    const char* st = smem + (sl >= 3 ? sl - 3 : sl) * IN_BYTES;
+                    const char* sw = smem + 3 * IN_BYTES + cg * W_BYTES;              // (eight steps per tile: the step's parity is the group)
+                    if (!no_mfma) four_tap(std::integral_constant<int, (0x1B << (3 * A + B))>{}, acc, st, sw);
+                    if (cg == 1) {       // the phase's 16 x 32 virtual pixels go out through the phase-lattice epilogue (tile origin shifted by (a, b))
+                        if (p.act == 1) epilogue_slab<RPW, NT, 1, false, false, true, false, true>(p, acc, n, ty0 + A, tx0 + B, cw, li, cbase);
+                        else if (p.act == 2) epilogue_slab<RPW, NT, 2, false, false, true, false, true>(p, acc, n, ty0 + A, tx0 + B, cw, li, cbase);
+                        else epilogue_slab<RPW, NT, 0, false, false, true, false, true>(p, acc, n, ty0 + A, tx0 + B, cw, li, cbase);
+                    }
+                    asm volatile("s_barrier" ::: "memory");
+                }
+            };
+            phase(std::integral_constant<int, 0>{});
+            phase(std::integral_constant<int, 1>{});
+            phase(std::integral_constant<int, 2>{});
+            phase(std::integral_constant<int, 3>{});
+            slot0 = slot0 == 0 ? 2 : slot0 - 1;
+        }
+        return;
+    }
     int islot = 0;                                                // NSI == 3: g % 3
     f32x4 bias_r[NT];
     int bias_kg = -1;
@@ -1814,7 +1967,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                     }
                 }
             }
-        } else if constexpr (TM == 0x1FF && PIPE) {
+        } else if constexpr (TM == 0x1FF && PIPE && !UP4) {
             // Software-pipelined fragment reads (the nine-tap kernels).  The B fragments of a chunk are walked in (s, rr, seg) order through
             // a three-register ring, each read issued two MFMA groups (>= 8 MFMAs = 128 pipe cycles) ahead of its use; the weight fragments
             // of tap column s + 1 overwrite those of column s as soon as their last MFMA has been issued (A(s,0,*) after row RPW - 1,
@@ -1858,49 +2011,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else if constexpr (NTAP == 4 && !PFX && PIPE4 && RPW <= 6) {
-            // The four-tap kernels (the stride-2 convs and the transposed-conv phases of the UNet / ResNet generators) with the fragment reads
-            // software-pipelined like the nine-tap loop above: all sixteen weight fragments of the chunk first, then the pixel fragments through a
-            // three-register ring, each read two MFMA groups ahead of its use.  Left to the scheduler, every read sat in front of its first use:
-            // a chunk-step took the LDS phase PLUS the MFMA phase (1.8 us for 1.0 us of matrix work).  Same MFMAs in the same order: same bits.
-            constexpr const TapWalk& WK = TapWalkOf<TM, RPW, NSEG>::value;      // (a class-scope constant: a local copy indexed by a loop variable may land in scratch)
-            constexpr int NBW = TapWalkOf<TM, RPW, NSEG>::value.n;
-            constexpr int R0 = (TM & 0x007) ? 0 : 1, S0 = (TM & 0x049) ? 0 : 1;          // the mask is the 2 x 2 block of taps (R0 .. R0 + 1) x (S0 .. S0 + 1)
-            static_assert(TM == (0x1B << (3 * R0 + S0)), "four taps: a 2 x 2 block of the 3 x 3 lattice");
-            f16x8 a[2][NT];                                                              // the weight fragments of the current tap column, by tap row - R0
-            auto lda = [&](int sc, int q) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) a[q][t] = *(const f16x8*)(sw + aoffs + ((q * 2 + sc - S0) * WROWS + t * 16) * 64);
-            };
-            f16x8 bq[3];
-            auto ldb = [&](int i) {
-                if constexpr (PAIR) { if (WK.seg[i]) return *(const f16x8*)(st + boffp[WK.s[i]][WK.rr[i] & 1] + WK.rr[i] * LWP * 64); }
-                return *(const f16x8*)(st + boffs[WK.s[i]][WK.rr[i] & 1] + (WK.rr[i] * LWP + WK.seg[i] * 16) * 64);
-            };
-            lda(S0, 0); lda(S0, 1);
-            bq[0] = ldb(0);
-            if (NBW > 1) bq[1] = ldb(1);
-            if constexpr (BRELU) bq[0] = relu_frag(bq[0]);
-#pragma unroll
-            for (int i = 0; i < NBW; ++i) {
-                if (i + 2 < NBW) bq[(i + 2) % 3] = ldb(i + 2);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int rw = WK.rr[i] - R0 - q;
-                    if (rw >= 0 && rw < RPW) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            acc[t][rw * 2 + WK.seg[i]] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q][t], bq[i % 3], acc[t][rw * 2 + WK.seg[i]], 0, 0, 0);
-                    }
-                }
-                if constexpr (BRELU) { if (i + 1 < NBW) bq[(i + 1) % 3] = relu_frag(bq[(i + 1) % 3]); }      // the NEXT group's fragment, in the shadow of this group's MFMAs
-                // the next column's fragments overwrite this column's as soon as their last MFMA has been issued
-                if (WK.s[i] == S0 && WK.seg[i] == NSEG - 1) {
-                    if (WK.rr[i] == R0 + RPW - 1) lda(S0 + 1, 0);
-                    if (WK.rr[i] == R0 + RPW) lda(S0 + 1, 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        } else if constexpr (NTAP == 4 && !PFX && PIPE4 && RPW <= 6 && !UP4) {
+            four_tap(std::integral_constant<int, TM>{}, acc, st, sw);
         } else {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -2115,7 +2227,7 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI, int NCW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = NCW * RPW;
-    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0);
+    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : (TM & 0x200000) ? 4 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0);
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
     if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0xC2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
@@ -2555,6 +2667,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         // (in_relu on the phase lattice was built and measured -- scripts/r4/unet_one_view.sh: the four v_pk_max_f16 per fragment share the issue port with the MFMAs of
         //  these matrix-bound launches, +7.7 % on a 130-us launch against a 6 .. 12 us shorter post pass; only the HBM-bound outermost layer keeps the operand ReLU)
         if (L.in_relu) return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: in_relu is built for the planar <= 16-output kernel only");
+        if (L.C == 64 && L.phase_c == 64 && !L.stats_part && L.W > 16 && L.deconv_phases != 2) {
+            // the SR networks' up-convs (64 -> 64): all four phases in one visit of a tile, the input tile staged once (conv3x3_pc<.., TMF | 0x200000>);
+            // deconv_phases 2 keeps the one-phase-per-visit form (A/B, parity tests)
+            k.KG = 1; k.nchunks = 8;
+            return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x2001FF, false, 3>(k, L.N, s);
+        }
         if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x141B, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x101B, false, UNET_NSI>(k, L.N, s);
         return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x41B, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B, false, UNET_NSI>(k, L.N, s);
     }

@@ -354,7 +354,8 @@ extern "C" int innfer_net_set_band_rows(innfer_net_t net, int rows) {
 
 extern "C" int innfer_net_set_upconv_phases(innfer_net_t net, int on) {
     if (!net) return set_error(INNFER_ERR_INVALID, "set_upconv_phases: null network");
-    net->up_phases = on ? 1 : 0;
+    if (on < 0 || on > 2) return set_error(INNFER_ERR_INVALID, "set_upconv_phases: 0 (nine taps on the HR grid), 1 (four phases, one visit of a tile: default) or 2 (one phase per visit)");
+    net->up_phases = on;
     return INNFER_OK;
 }
 
@@ -855,7 +856,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             // HR grid (2.25 x fewer MACs), on the phase-lattice instantiation (conv3x3_pc<.., TM = 0x1B>)
             ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, net->trunk_act);
             L.wpk = (const f16*)cs.d_up4; L.bias = cs.d_b4;
-            L.K = 4 * cs.K; L.phase_c = cs.K; L.deconv_phases = 1;
+            L.K = 4 * cs.K; L.phase_c = cs.K; L.deconv_phases = net->up_phases;       // 1: all four phases in one visit of a tile (C = 64), 2: one phase per visit
             rc = do_conv(L, s);
         } else if (!net->ps_up) {    // Upsample(nearest 2x) -> conv -> act
             ConvLaunch L = mk(cs, t, gi, dst, go, N, 2 * h, 2 * w, net->trunk_act);

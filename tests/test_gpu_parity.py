@@ -1979,13 +1979,16 @@ def test_upconv_phases_vs_nine_taps_and_oracle(dev):
     import oracle
     from innfer_amd import synth
     from innfer_amd.architectures.RRDBNet_arch import RRDBNet
-    for i, (scale, act, shape) in enumerate([(4, "leakyrelu", (1, 3, 24, 40)), (4, "leakyrelu", (3, 3, 7, 13)), (2, "leakyrelu", (2, 3, 33, 65)), (4, "relu", (1, 3, 16, 16))]):
+    for i, (scale, act, shape) in enumerate([(4, "leakyrelu", (1, 3, 24, 40)), (4, "leakyrelu", (3, 3, 7, 13)), (2, "leakyrelu", (2, 3, 33, 65)), (4, "relu", (1, 3, 16, 16)), (4, "leakyrelu", (2, 3, 70, 100)),
+                                              (4, "relu", (1, 3, 256, 384))]):       # (the last: 768 tiles in the second stage -- three per workgroup, every state of the slot rotation)
         sd = _sd(synth.rrdbnet_shapes(nb=1, scale=scale), 90 + i)
         net = RRDBNet(3, 3, 64, 1, upscale=scale, act_type=act)
         net.load_state_dict(sd, strict=True)
         net = net.to(dev).eval()
         x = torch.from_numpy(synth.uniform(shape, 950 + i)).to(dev).half()
         yp = net(x)
+        net.upconv_phases = 2            # one phase per visit of a tile (round 3's form): the same MFMAs on the same operands in the same order
+        assert torch.equal(net(x), yp), (scale, act, shape, "four phases in one visit != one phase per visit")
         net.upconv_phases = False
         y9 = net(x)
         net.upconv_phases = True
