@@ -29,4 +29,10 @@ ablate:
 clean:
 	rm -f $(OBJ) $(LIB)
 
-.PHONY: all clean stamps ablate
+.PHONY: all clean stamps ablate ab_rowp0
+
+# A/B library: the 64-output layers of the SR networks in the lane-contiguous row order (INNFER_ROWP_DEFAULT 0; scripts/r4/rowp_ab.sh; never shipped)
+ab_rowp0: $(OBJ)
+	$(HIPCC) $(FLAGS) -DINNFER_ROWP_DEFAULT=0 -c innfer_amd/csrc/net.hip -o innfer_amd/csrc/net_rowp0.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o innfer_amd/lib/libinnfer_amd_rowp0.so $(filter-out innfer_amd/csrc/net.o,$(OBJ)) innfer_amd/csrc/net_rowp0.o -ldl
+	rm -f innfer_amd/csrc/net_rowp0.o

@@ -94,6 +94,9 @@ struct ConvLaunch {
     int split;                                    // fp32-accurate mode: every tensor is a (hi, lo) pair of fp16 slabs, lo = fp16((x - hi) * 2^11) (conv3x3.hip, SPLIT); panels from
     long in_lo, out_lo, res1_lo, res2_lo;         // conv_pack_split / conv_pack_1x1_split; *_lo: distance (elements) from a hi slab to its lo twin.  Plain 3x3 / 1x1 slab convs
                                                   // (act 0..2, residuals, upsampled input, batches) and the planar last conv
+    int rowp;                                     // 1 (64-channel output groups, slab output): the panels have the PLANE row order (conv_pack*(.., rowp = 1)) -- a lane's sixteen channels
+                                                  // are 16 bytes in each of the group's two slab planes, a store instruction touches one plane.  Plain 3x3 slab convs (residuals, canvas,
+                                                  // RLDS, fused last conv) and the transposed-conv phases; not the split / statistics / gate / stride-2 / 1x1 / planar forms
     int in_relu;                                  // 1: the operand is max(stored input, 0) (applied as fragments leave LDS) -- transposed-conv phase launches and the planar
                                                   // <= 16-output kernel: the UNet stores a skip tensor once (LeakyReLU form) and its up conv reads relu(cat) from it
     const f16* gate_w; const float* gate_bias;    // != nullptr (32-output slab convs): out = act(v * sigmoid(W v + b)) with v = fp16(conv + bias) -- PAN's pixel attention behind an up-conv
@@ -120,7 +123,7 @@ int conv_pair_launch(const ConvPairLaunch& L, hipStream_t s);
 // Panel geometry of packed weights.
 int conv_nt_for(int K);                           // 16-channel tiles per group: 1, 2 or 4
 size_t conv_packed_bytes(int K, int C);
-void conv_pack(const float* w_oihw, int K, int C, void* packed);   // host
+void conv_pack(const float* w_oihw, int K, int C, void* packed, int rowp = 0);   // host; rowp: the plane row order of 64-channel groups (ConvLaunch.rowp)
 size_t conv_packed_bytes_wino(int K, int C);
 void conv_pack_wino(const float* w_oihw, int K, int C, void* packed);      // host; ConvLaunch.wino == 1
 void conv_pack_split(const float* w_oihw, int K, int C, void* packed);     // host; 3 * conv_packed_bytes(K, C): the (wl | wh | wh) panels of ConvLaunch.split
@@ -137,10 +140,10 @@ void conv_pack_s2k4(const float* w_oi44, int K, int C, void* packed);         //
 size_t conv_packed_bytes_deconv2x(int K, int C);
 bool conv_fuse_last_ok(const ConvLaunch& L);
 size_t conv_fuse_side_bytes(int N, int H, int W);
-void conv_pack_fuse_last(const float* w_last_oihw, int oc, void* packed_4k);   // host
-void conv_pack_up2x_phases(const float* w_oihw, int K, int C, void* packed);       // host; conv_packed_bytes_deconv2x(K, C) bytes: upconv_block as four 2x2-tap phases
-void conv_pack_deconv2x(const float* w_io, int K, int C, int k, void* packed); // host; ConvTranspose2d(k = 3 | 4, 2, 1) panels for ConvLaunch.deconv_phases, w [C][K][k][k]
-void conv_pack_taps(const float* w, int K, int C, int mask, void* packed);   // host; w [K][C][9], only the taps of `mask` are packed (conv_packed_bytes_taps)
+void conv_pack_fuse_last(const float* w_last_oihw, int oc, void* packed_4k, int rowp = 0);   // host; rowp = the row order of the HR_conv0 panel it is fused behind
+void conv_pack_up2x_phases(const float* w_oihw, int K, int C, void* packed, int rowp = 0);       // host; conv_packed_bytes_deconv2x(K, C) bytes: upconv_block as four 2x2-tap phases
+void conv_pack_deconv2x(const float* w_io, int K, int C, int k, void* packed, int rowp = 0); // host; ConvTranspose2d(k = 3 | 4, 2, 1) panels for ConvLaunch.deconv_phases, w [C][K][k][k]
+void conv_pack_taps(const float* w, int K, int C, int mask, void* packed, int rowp = 0);   // host; w [K][C][9], only the taps of `mask` are packed (conv_packed_bytes_taps)
 size_t conv_packed_bytes7x7(int K, int C);
 void conv_pack7x7(const float* w_oihw, int K, int C, void* packed);   // host; C % 32 == 0
 

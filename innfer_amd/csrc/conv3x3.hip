@@ -143,6 +143,18 @@ struct KP {
 #endif
 };
 
+// Offsets of accumulator tile t of a lane from the lane's first channel, in a slab of group stride g (f16 elements) and in a linear channel array (bias), and the lane's
+// first channel inside its 16 NT-channel group.  ROWP (conv3x3_pc<.., TMF | 0x400000>, 64-channel groups): the PLANE row order -- accumulator (tile t, row 4 lg + j) is
+// channel 32 (t >> 1) + 8 lg + 4 (t & 1) + j instead of 16 lg + 4 t + j: a lane's sixteen channels are 16 bytes in EACH of the group's two 32-channel slab planes, lanes
+// lg = 0..3 cover a pixel's whole 64 bytes of one plane, and a store / residual-load instruction touches ONE plane -- half the lines per instruction (measured as an
+// ablation first: frame -1.4 %, profiles/r4/upconv_bound.txt).  Panels from conv_pack*(.., rowp = 1).
+template <int NT, bool ROWP>
+__device__ __forceinline__ long toff_slab(int t, long g) { return (NT == 4 && ROWP) ? (long)(t >> 1) * g + 4 * (t & 1) : 4 * t; }
+template <int NT, bool ROWP>
+__device__ __forceinline__ int toff_lin(int t) { return (NT == 4 && ROWP) ? 32 * (t >> 1) + 4 * (t & 1) : 4 * t; }
+template <int NT, bool ROWP>
+__device__ __forceinline__ int lane_cbase(int lg) { return ((NT == 4 && ROWP) ? 8 : 4 * NT) * lg; }
+
 // Slab epilogue, specialised on (activation, residual 1, residual 2) so that the unrolled loop over the
 // wave's pixel tiles is straight-line code: residual loads for all tiles first (their latencies
 // overlap), then act -> *s1 + res1 -> *s2 + res2 -> fp16 -> one 8*NT-byte store per pixel tile.
@@ -153,7 +165,7 @@ struct KP {
 // CV (image canvas, see conv3x3_pc): (ty0, tx0) are canvas coordinates; a pixel tile may lie in the cell below / right of the tile's first
 // cell, or on the one-pixel gutter between cells (not stored).  Same arithmetic, per-pixel-tile addresses.
 // SC1 (RLDS kernels): res1 is already inside the accumulators as x / s1 (consumer loop); the epilogue only scales by s1 (then R2 as usual).
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool SC1 = false>
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool SC1 = false, bool ROWP = false>
 __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2 * RPW], int ty0, int tx0, int wave, int li, int cbase) {
     constexpr int MT = 2 * RPW;
     // ACT 7 (pair gate, PAN's PAConv): the lane's upper NT / 2 channel tiles are the gates of its lower ones -- out = conv_lo * sigmoid(conv_hi),
@@ -179,11 +191,11 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
         off[m] = ((n * p.H + y) * p.W + x) * 32;
         if (R1 && !R2 && ok[m]) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + 4 * t);
+            for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + toff_slab<NT, ROWP>(t, p.res1_gstride));
         }
         if (!R1 && R2 && ok[m]) {       // one residual from memory: its loads for all pixel tiles first, like the R1-only form
 #pragma unroll
-            for (int t = 0; t < NT; ++t) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + off[m] + 4 * t);
+            for (int t = 0; t < NT; ++t) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + off[m] + toff_slab<NT, ROWP>(t, p.res2_gstride));
         }
     }
 #pragma unroll
@@ -193,8 +205,8 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
         if (R1 && R2) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + 4 * t);
-                r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + off[m] + 4 * t);
+                r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + toff_slab<NT, ROWP>(t, p.res1_gstride));
+                r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + off[m] + toff_slab<NT, ROWP>(t, p.res2_gstride));
             }
         }
 #pragma unroll
@@ -212,14 +224,14 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
                 FP32_VALUE(f);
                 h[j] = (f16)f;
             }
-            *(f16x4*)(op + 4 * t) = h;
+            *(f16x4*)(op + toff_slab<NT, ROWP>(t, p.out_gstride)) = h;
         }
     }
 }
 
 // DCV (conv3x3_pc<.., TM = 0x1B>: one output phase of ConvTranspose2d(4, 2, 1) per 16*NT-channel group): (ty0, tx0) are coordinates of the phase's
 // shifted lattice (see decode); virtual pixel (y', x') of phase (a, b) is output pixel (2y' - a, 2x' - b) of the 2H x 2W slab, channel ch % phase_c.
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, bool PAIR = false, bool SC1 = false>
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, bool PAIR = false, bool SC1 = false, bool ROWP = false>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase, int dil = 1) {
     constexpr int MT = 2 * RPW;
@@ -272,11 +284,11 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
         const long o = (m >> 1) * rowstep + (m & 1) * colstep;
         if (HOIST && R1 && ok[m]) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + 4 * t);
+            for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + toff_slab<NT, ROWP>(t, p.res1_gstride));
         }
         if (HOIST && R2 && ok[m]) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + o + 4 * t);
+            for (int t = 0; t < NT; ++t) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + o + toff_slab<NT, ROWP>(t, p.res2_gstride));
         }
     }
 #pragma unroll
@@ -303,8 +315,8 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
             const long o = (m >> 1) * rowstep + (m & 1) * colstep;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (R1) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + 4 * t);
-                if (R2) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + o + 4 * t);
+                if (R1) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + toff_slab<NT, ROWP>(t, p.res1_gstride));
+                if (R2) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + o + toff_slab<NT, ROWP>(t, p.res2_gstride));
             }
         }
 #pragma unroll
@@ -328,7 +340,7 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
                 FP32_VALUE(f);
                 h[j] = (f16)f;
             }
-            *(f16x4*)(op + 4 * t) = h;
+            *(f16x4*)(op + toff_slab<NT, ROWP>(t, p.out_gstride)) = h;
         }
     }
 }
@@ -1042,6 +1054,19 @@ __device__ __forceinline__ void residual_from_lds(f32x4 (&acc)[4][MT], const cha
     }
 }
 
+// The same for the plane row order (ROWP): the staged group HALF (0 / 1) holds the residual channels of the lane's tiles 2 half, 2 half + 1 -- 8 channels, one 16-byte slot
+template <int MT, int HALF>
+__device__ __forceinline__ void residual_from_lds_plane(f32x4 (&acc)[4][MT], const char* st, const int* roffs, float rs1) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const f16x8 x = *(const f16x8*)(st + roffs[m]);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[2 * HALF + tt][m][j] = __builtin_fmaf((float)x[tt * 4 + j], rs1, acc[2 * HALF + tt][m][j]);
+    }
+}
+
 // Planar (NCHW) epilogue of conv3x3_pc -- the networks' last convs: activation, `outm`, the phase scatter of a transposed conv, or tensor2np as the store
 // (uint8 HWC image).  Moved out of the kernel body in round 4; force-inlined, the code is the one that was measured.
 template <int RPW, int NT>
@@ -1286,6 +1311,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // epilogue after its second group.  The loaders fetch the next tile's group 0 into the free slot at step 0 and its group 1 into the slot the
     // current tile's group 0 leaves after step 6.  Same MFMAs, same operands, same order per output value as the four-visit form: same bits.
     constexpr bool UP4 = (TMF & 0x200000) != 0;
+    // + 0x400000 (ROWP): the plane row order of the 64-channel groups (see toff_slab): plain 3x3 slab convs (canvas, RLDS, FUSE forms included) and the one-pass up-conv
+    constexpr bool ROWP = (TMF & 0x400000) != 0;
+    static_assert(!ROWP || (RPW == 2 && NT == 4 && NCW == 8 && OUTMODE == OUT_SLAB && (TMF & 0x1FF) == 0x1FF && (TMF & ~0x6601FF) == 0 && !S9 && !POLY), "plane row order: the 64-channel slab kernels");
     static_assert(!UP4 || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 3 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFFF) == 0x1FF && !S9 && !POLY && !CV), "one-pass phases: the 64-channel slab kernel on three input slots");
     constexpr bool FUSE = (TMF & 0x20000) != 0;
     static_assert(!FUSE || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation");
@@ -1773,6 +1801,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         for (int m = 0; m < MT; ++m) {
             const int P = (cw * RPW + (m >> 1) + 1) * LWP + li + (m & 1) * 16 + 1;
             roffs[m] = P * 64 + (((lg & 1) ^ ((P >> 2) & 1)) << 5);
+            if constexpr (ROWP) roffs[m] = P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4);      // plane order: the ONE 16-byte slot with channels 8 lg .. 8 lg + 7 of the staged group
         }
     }
     f16x8 sgw[SGATE ? 2 : 1];
@@ -1833,9 +1862,11 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     if constexpr (UP4) {
         // ---- the one-pass up-conv's own walk: per tile, the four phases as straight-line code (a phase's accumulators live from its bias to its epilogue only;
         // a `switch` over the phase inside the generic step loop made the allocator carry them across all four unrolled bodies: 344 bytes of scratch per lane) ----
-        f32x4 bias_n[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bias_n[t] = *(const f32x4*)(p.bias + 4 * NT * lg + 4 * t);      // phase 0
+        // the four phases' biases (256 floats) in the 1 KB behind the weight ring: a phase starts from four ds_read_b128 instead of holding sixteen bias registers
+        // across the phase before it (the kernel sits at the 168-register budget of a 12-wave workgroup)
+        float* const bias_lds = (float*)(smem + 3 * IN_BYTES + 2 * W_BYTES);
+        if (cw == 0) *(f32x4*)(bias_lds + 4 * lane) = *(const f32x4*)(p.bias + 4 * lane);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");                   // both groups of the first tile and the first panel have landed
         int slot0 = 0;                                            // LDS slot of the tile's group 0: (2 T) % 3
 #ifdef INNFER_ABLATE
@@ -1846,18 +1877,19 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         for (int jt = j0; jt < run_len; jt += slots) {
             int kg, n, ty0, tx0;
             decode(jt, kg, n, ty0, tx0);
+            // (opaque per-tile copies of the lane coordinates: otherwise the four epilogues' per-lane address parts -- a dozen 64-bit values -- are hoisted out of
+            //  the tile loop and live across all of it: scratch spills at the 168-register budget of a 12-wave workgroup)
+            int li_t = li, lg_t = lg;
+            asm volatile("" : "+v"(li_t), "+v"(lg_t));
             auto phase = [&](auto phc) __attribute__((always_inline)) {
                 constexpr int PH = decltype(phc)::value, A = PH >> 1, B = PH & 1;
-                const int cbase = PH * WROWS + 4 * NT * lg;
+                const int cbase = PH * WROWS + lane_cbase<NT, ROWP>(lg_t);
                 f32x4 acc[NT][MT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 bt = *(const f32x4*)(bias_lds + cbase + toff_lin<NT, ROWP>(t));
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[t][m] = bias_n[t];
-                {                        // the next phase's bias, requested two steps before it is needed
-                    const int nb = ((PH + 1) & 3) * WROWS + 4 * NT * lg;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) bias_n[t] = *(const f32x4*)(p.bias + nb + 4 * t);
+                    for (int m = 0; m < MT; ++m) acc[t][m] = bt;
                 }
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg) {
@@ -1866,9 +1898,9 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                     const char* sw = smem + 3 * IN_BYTES + cg * W_BYTES;              // (eight steps per tile: the step's parity is the group)
                     if (!no_mfma) four_tap(std::integral_constant<int, (0x1B << (3 * A + B))>{}, acc, st, sw);
                     if (cg == 1) {       // the phase's 16 x 32 virtual pixels go out through the phase-lattice epilogue (tile origin shifted by (a, b))
-                        if (p.act == 1) epilogue_slab<RPW, NT, 1, false, false, true, false, true>(p, acc, n, ty0 + A, tx0 + B, cw, li, cbase);
-                        else if (p.act == 2) epilogue_slab<RPW, NT, 2, false, false, true, false, true>(p, acc, n, ty0 + A, tx0 + B, cw, li, cbase);
-                        else epilogue_slab<RPW, NT, 0, false, false, true, false, true>(p, acc, n, ty0 + A, tx0 + B, cw, li, cbase);
+                        if (p.act == 1) epilogue_slab<RPW, NT, 1, false, false, true, false, true, false, false, ROWP>(p, acc, n, ty0 + A, tx0 + B, cw, li_t, cbase);
+                        else if (p.act == 2) epilogue_slab<RPW, NT, 2, false, false, true, false, true, false, false, ROWP>(p, acc, n, ty0 + A, tx0 + B, cw, li_t, cbase);
+                        else epilogue_slab<RPW, NT, 0, false, false, true, false, true, false, false, ROWP>(p, acc, n, ty0 + A, tx0 + B, cw, li_t, cbase);
                     }
                     asm volatile("s_barrier" ::: "memory");
                 }
@@ -1901,10 +1933,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         if (c == 0) {
             if constexpr (POLY) decode_poly(jt, kg, n, ty0, tx0, dcur);
             else decode(jt, kg, n, ty0, tx0);
-            cbase = kg * WROWS + 4 * NT * lg;
+            cbase = kg * WROWS + lane_cbase<NT, ROWP>(lg);
             if (kg != bias_kg) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) bias_r[t] = *(const f32x4*)(p.bias + cbase + 4 * t);
+                for (int t = 0; t < NT; ++t) bias_r[t] = *(const f32x4*)(p.bias + cbase + toff_lin<NT, ROWP>(t));
                 bias_kg = kg;
             }
 #pragma unroll
@@ -2059,7 +2091,12 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         }
         if constexpr (RLDS) {
             // chunk nchunks - 2 is input group 0 = residual channels 0..31 (lanes lg 0, 1), chunk nchunks - 1 group 1 = channels 32..63 (lanes lg 2, 3)
-            if (c >= p.nchunks - 2 && (lg >> 1) == c - (p.nchunks - 2)) residual_from_lds<MT>(acc, st, roffs, p.rs1);
+            if constexpr (ROWP) {        // plane order: every lane takes 8 channels from each of the two groups -- tiles 0, 1 from group 0, tiles 2, 3 from group 1
+                if (c == p.nchunks - 2) residual_from_lds_plane<MT, 0>(acc, st, roffs, p.rs1);
+                else if (c == p.nchunks - 1) residual_from_lds_plane<MT, 1>(acc, st, roffs, p.rs1);
+            } else {
+                if (c >= p.nchunks - 2 && (lg >> 1) == c - (p.nchunks - 2)) residual_from_lds<MT>(acc, st, roffs, p.rs1);
+            }
         }
         PCT(c1);
         if (cw == 0) PCACC(0, c1, c0);
@@ -2094,16 +2131,16 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
 #undef EPI
             } else if constexpr (OUTMODE == OUT_SLAB && CV && RLDS) {
-                if (p.res2) epilogue_slab_cv<RPW, NT, 0, false, true, true>(p, acc, ty0, tx0, cw, li, cbase);
-                else epilogue_slab_cv<RPW, NT, 0, false, false, true>(p, acc, ty0, tx0, cw, li, cbase);
+                if (p.res2) epilogue_slab_cv<RPW, NT, 0, false, true, true, ROWP>(p, acc, ty0, tx0, cw, li, cbase);
+                else epilogue_slab_cv<RPW, NT, 0, false, false, true, ROWP>(p, acc, ty0, tx0, cw, li, cbase);
             } else if constexpr (OUTMODE == OUT_SLAB && RLDS) {
-                if (p.res2) epilogue_slab<RPW, NT, 0, false, true, true, false, false, false, true>(p, acc, n, ty0, tx0, cw, li, cbase, dcur);
-                else epilogue_slab<RPW, NT, 0, false, false, true, false, false, false, true>(p, acc, n, ty0, tx0, cw, li, cbase, dcur);
+                if (p.res2) epilogue_slab<RPW, NT, 0, false, true, true, false, false, false, true, ROWP>(p, acc, n, ty0, tx0, cw, li, cbase, dcur);
+                else epilogue_slab<RPW, NT, 0, false, false, true, false, false, false, true, ROWP>(p, acc, n, ty0, tx0, cw, li, cbase, dcur);
             } else if constexpr (OUTMODE == OUT_SLAB && CV) {
-#define EPI(A, B, C) epilogue_slab_cv<RPW, NT, A, B, C>(p, acc, ty0, tx0, cw, li, cbase)
+#define EPI(A, B, C) epilogue_slab_cv<RPW, NT, A, B, C, false, ROWP>(p, acc, ty0, tx0, cw, li, cbase)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
-                else if (NT == 4 && p.act == 7) EPI(NT == 4 ? 7 : 0, false, false); else EPI(0, false, false);
+                else if (NT == 4 && !ROWP && p.act == 7) EPI((NT == 4 && !ROWP) ? 7 : 0, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
                 if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
             } else {
@@ -2118,10 +2155,10 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 const int lid = run_start + (p.rev ? run_len - 1 - (jt - slots) : (jt - slots));         // (jt was advanced above)
                 epilogue_stats<RPW, NT, TM == 0x1B, PAIR, NCW>(p, acc, bias_r, ty0, tx0, cw, li, cbase, lid / p.KG);
             }
-#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, PAIR>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, PAIR, false, ROWP>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
-                else if (NT == 4 && TM == 0x1FF && !POLY && p.act == 7) EPI((NT == 4 && TM == 0x1FF && !POLY) ? 7 : 0, false, false); else EPI(0, false, false);
+                else if (NT == 4 && TM == 0x1FF && !POLY && !ROWP && p.act == 7) EPI((NT == 4 && TM == 0x1FF && !POLY && !ROWP) ? 7 : 0, false, false); else EPI(0, false, false);
             } else if (!p.res2) {
                 if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else if (p.act == 4) EPI(4, true, false);
                 else if (p.act == 5) EPI(5, true, false); else EPI(0, true, false);
@@ -2227,10 +2264,10 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI, int NCW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = NCW * RPW;
-    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : (TM & 0x200000) ? 4 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0);
+    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : (TM & 0x200000) ? 4 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0) + ((TM & 0x200000) ? 1024 : 0);      // (UP4: + the four phases' biases)
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
-    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0xC2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
+    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x4C2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
         int gy = 0; long t = 0;
         const int gx = INNFER_KNOB("INNFER_CANVAS", 1) ? canvas_grid<TH>(kp, N, &gy, &t) : 0;
         if (gx > 0) {
@@ -2311,15 +2348,20 @@ size_t conv_packed_bytes(int K, int C) {
 // Host: OIHW fp32 -> [group][chunk][tap][row R][slot][8 ch] fp16, the exact LDS image.
 // Row R = t*16 + rho of a group holds out channel  group*16*NT + (4*NT)*(rho>>2) + 4*t + (rho&3);
 // slot sigma holds input channels chunk*32 + 8*(sigma ^ 2*bit2(R)) .. +7.
-void conv_pack(const float* w, int K, int C, void* packed) {
+// out channel of row R = t * 16 + rho of output group g: NT rows of 16; rowp (NT = 4 only): the plane order of KP.rowp
+static inline int pack_row_oc(int g, int nt, int R, int rowp) {
+    const int t = R >> 4, rho = R & 15;
+    if (nt == 4 && rowp) return g * 64 + 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
+    return g * nt * 16 + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
+}
+void conv_pack(const float* w, int K, int C, void* packed, int rowp) {
     const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
     f16* dst = (f16*)packed;
     for (int g = 0; g < groups; ++g)
         for (int c = 0; c < nch; ++c)
             for (int tap = 0; tap < 9; ++tap)
                 for (int R = 0; R < rows; ++R) {
-                    const int t = R >> 4, rho = R & 15;
-                    const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
+                    const int oc = pack_row_oc(g, nt, R, rowp);
                     for (int sg = 0; sg < 4; ++sg) {
                         const int cg = sg ^ (((R >> 2) & 1) << 1);
                         for (int e = 0; e < 8; ++e) {
@@ -2346,7 +2388,7 @@ void conv_pack_selfgate(const float* w32x32, void* packed_2k) {
 
 size_t conv_packed_bytes_taps(int K, int C, int mask) { return conv_packed_bytes(K, C) / 9 * __builtin_popcount(mask & 0x1FF); }
 // any mask: w is [K][C][9] (taps outside the mask are not read)
-void conv_pack_taps(const float* w, int K, int C, int mask, void* packed) {
+void conv_pack_taps(const float* w, int K, int C, int mask, void* packed, int rowp) {
     const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
     f16* dst = (f16*)packed;
     for (int g = 0; g < groups; ++g)
@@ -2354,8 +2396,7 @@ void conv_pack_taps(const float* w, int K, int C, int mask, void* packed) {
             for (int tap = 0; tap < 9; ++tap) {
                 if (!((mask >> tap) & 1)) continue;
                 for (int R = 0; R < rows; ++R) {
-                    const int t = R >> 4, rho = R & 15;
-                    const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
+                    const int oc = pack_row_oc(g, nt, R, rowp);
                     for (int sg = 0; sg < 4; ++sg) {
                         const int cg = sg ^ (((R >> 2) & 1) << 1);
                         for (int e = 0; e < 8; ++e) {
@@ -2454,7 +2495,7 @@ void conv_pack_s2k4(const float* w, int K, int C, void* packed) {
 // tap (r, s) of the 3x3 lattice (r, s in {0, 1}) carries w[ci][c][3 - 2r - a][3 - 2s - b] (oy = 2 iy - 1 + ky); a kernel index of 3 does not
 // exist for k == 3: a structural zero (9 of the 16 phase taps are real there)
 size_t conv_packed_bytes_deconv2x(int K, int C) { return conv_packed_bytes_taps(4 * K, C, 0x1B); }
-void conv_pack_deconv2x(const float* w, int K, int C, int k, void* packed) {
+void conv_pack_deconv2x(const float* w, int K, int C, int k, void* packed, int rowp) {
     const int K4 = 4 * K;
     std::vector<float> w3((size_t)K4 * C * 9, 0.f);
     for (int co = 0; co < K4; ++co) {
@@ -2466,13 +2507,13 @@ void conv_pack_deconv2x(const float* w, int K, int C, int k, void* packed) {
                 for (int ci = 0; ci < C; ++ci) w3[((size_t)co * C + ci) * 9 + r * 3 + sx] = w[(((size_t)ci * K + c) * k + ky) * k + kx];
             }
     }
-    conv_pack_taps(w3.data(), K4, C, 0x1B, packed);
+    conv_pack_taps(w3.data(), K4, C, 0x1B, packed, rowp);
 }
 
 // nearest-2x + conv3x3 (upconv_block, block.py:348-361) as ConvTranspose2d(4, 2, 1): w [K][C][3][3] -> the phase panels of conv_pack_deconv2x with the taps that meet the same
 // LR pixel summed in fp32 (ONE rounding to fp16 in the packer): HR row 2y reads LR rows y - 1 (kernel row 0) and y (rows 1 + 2), HR row 2y + 1 reads y (rows 0 + 1) and
 // y + 1 (row 2), columns alike -- transposed-conv kernel index ky <-> summed rows 3: {0}, 1: {1, 2}, 2: {0, 1}, 0: {2}.  K % 64 == 0, C % 32 == 0.
-void conv_pack_up2x_phases(const float* w, int K, int C, void* packed) {
+void conv_pack_up2x_phases(const float* w, int K, int C, void* packed, int rowp) {
     static const int R[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};
     std::vector<float> wt((size_t)C * K * 16, 0.f);
     for (int ci = 0; ci < C; ++ci)
@@ -2485,7 +2526,7 @@ void conv_pack_up2x_phases(const float* w, int K, int C, void* packed) {
                             if (R[ky][i] >= 0 && R[kx][j] >= 0) a += w[(((size_t)co * C + ci) * 3 + R[ky][i]) * 3 + R[kx][j]];
                     wt[(((size_t)ci * K + co) * 4 + ky) * 4 + kx] = a;
                 }
-    conv_pack_deconv2x(wt.data(), K, C, 4, packed);
+    conv_pack_deconv2x(wt.data(), K, C, 4, packed, rowp);
 }
 
 // 7 x 1 column conv (ConvLaunch.conv7v): w [K][C][7] -> three 3-tap blocks (the 7 taps zero-padded to 9: tap k9 = k7 + 1), virtual channel
@@ -2516,13 +2557,13 @@ bool conv_fuse_last_ok(const ConvLaunch& L) {
 size_t conv_fuse_side_bytes(int N, int H, int W) { return (size_t)N * (H / 16) * (W / 32) * FUSE_RING * 3 * sizeof(float); }
 // w_last [oc][64][3][3] -> four MFMA A fragments [row tile rt][k-step ks][lane][8]: row 16 rt + (lane & 15) = tap * 3 + c (27 of 32 rows), k-slot 8 (lane >> 4) + e of
 // step ks = input channel 16 (lane >> 4) + 8 ks + e -- the order in which a consumer lane of conv3x3_pc<2,4,..> holds its sixteen accumulator channels
-void conv_pack_fuse_last(const float* w, int oc, void* packed) {
+void conv_pack_fuse_last(const float* w, int oc, void* packed, int rowp) {      // rowp: HR_conv0's panel has the plane row order -- a lane's k-step ks then holds channels 32 ks + 8 (lane >> 4) + e
     f16* o = (f16*)packed;
     for (int rt = 0; rt < 2; ++rt)
         for (int ks = 0; ks < 2; ++ks)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int row = 16 * rt + (lane & 15), tap = row / 3, c = row - 3 * tap, ch = 16 * (lane >> 4) + 8 * ks + e;
+                    const int row = 16 * rt + (lane & 15), tap = row / 3, c = row - 3 * tap, ch = rowp ? 32 * ks + 8 * (lane >> 4) + e : 16 * (lane >> 4) + 8 * ks + e;
                     float v = 0.f;
                     if (tap < 9 && c < oc) v = w[((size_t)c * 64 + ch) * 9 + tap];
                     o[((rt * 2 + ks) * 64 + lane) * 8 + e] = (f16)v;
@@ -2617,6 +2658,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     const int rpw64 = INNFER_KNOB("INNFER_RPW64", 3);
     const int rpw32 = INNFER_KNOB("INNFER_RPW32", 5);
     const int pc = INNFER_KNOB("INNFER_PC", 1);     // producer / consumer kernel for slab outputs
+    if (L.rowp && (nt != 4 || !pc || L.out_mode != OUT_SLAB || L.split || L.wino || L.stats_part || L.stride2 || L.conv1x1 || L.conv7 || L.conv7v || L.prefix_lrelu || L.pair_wpk ||
+                   L.gate_w || L.act > 2 || L.dilation > 1 || L.dilation_groups || (L.out_coff & 31)))
+        return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the plane row order (rowp) belongs to plain 3x3 slab convs and transposed-conv phases with 64-channel output groups");
     if (L.outm && (L.out_mode != OUT_NCHW || !pc || nt != 1 || L.res1 || L.res2 || L.outm < 0 || L.outm > 4))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: outm belongs to the planar last conv (<= 16 channels)");
     if (L.wino) {            // experiment (profiles/r3/winograd.txt): 1 = Winograd F(2,3) along the rows, 2 = the direct conv on the same tiles (16 rows x 32 px, 32-channel
@@ -2667,11 +2711,13 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         // (in_relu on the phase lattice was built and measured -- scripts/r4/unet_one_view.sh: the four v_pk_max_f16 per fragment share the issue port with the MFMAs of
         //  these matrix-bound launches, +7.7 % on a 130-us launch against a 6 .. 12 us shorter post pass; only the HBM-bound outermost layer keeps the operand ReLU)
         if (L.in_relu) return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: in_relu is built for the planar <= 16-output kernel only");
-        if (L.C == 64 && L.phase_c == 64 && !L.stats_part && L.W > 16 && L.deconv_phases != 2) {
-            // the SR networks' up-convs (64 -> 64): all four phases in one visit of a tile, the input tile staged once (conv3x3_pc<.., TMF | 0x200000>);
-            // deconv_phases 2 keeps the one-phase-per-visit form (A/B, parity tests)
+        if (L.rowp && (L.C != 64 || L.phase_c != 64 || L.stats_part || L.W <= 16 || L.deconv_phases == 2))
+            return set_error(INNFER_ERR_UNSUPPORTED, "deconv phases: plane-order panels belong to the one-visit form (C = 64, 64-channel phases, grids wider than 16, no statistics)");
+        if (L.rowp) {
+            // the SR networks' up-convs (64 -> 64): all four phases in one visit of a tile, the input tile staged once (conv3x3_pc<.., TMF | 0x200000>), panels in the
+            // plane row order; lane-contiguous panels (rowp 0) run the one-phase-per-visit form below
             k.KG = 1; k.nchunks = 8;
-            return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x2001FF, false, 3>(k, L.N, s);
+            return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x6001FF, false, 3>(k, L.N, s);
         }
         if (L.stats_part) return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x141B, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x101B, false, UNET_NSI>(k, L.N, s);
         return L.W <= 16 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x41B, false, UNET_NSI>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x1B, false, UNET_NSI>(k, L.N, s);
@@ -2726,7 +2772,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (L.fuse_w) {          // HR_conv0 with the network's last conv in its epilogue (conv3x3_pc<.., TMF | 0x20000>) + the rim pass
         if (!conv_fuse_last_ok(L)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the fused last conv needs 64 -> 64 channels, whole 16 x 32 tiles, act 0..2, no residual / upsampling / row range");
         k.fl_w = L.fuse_w; k.fl_bias = L.fuse_bias; k.fl_side = L.fuse_side; k.fl_out = L.fuse_out; k.fl_oc = L.fuse_oc; k.fl_out_mode = L.fuse_out_mode;
-        if (int rc = launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x201FF>(k, L.N, s)) return rc;
+        if (int rc = L.rowp ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x4201FF>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x201FF>(k, L.N, s)) return rc;
         const long nthr = (long)L.N * (L.H / 16) * (L.W / 32) * 92;
         hipLaunchKernelGGL(fuse_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)L.fuse_side, L.fuse_bias, L.fuse_out, L.fuse_out_mode, L.out_denorm, L.out_round16, L.fuse_oc,
                            L.N, L.H, L.W);
@@ -2742,12 +2788,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         // (0.4096 -> 0.3945 ms per launch at 1080p).  The one-residual layers' batched loads were L2 hits already hidden behind the tile's last MFMAs: the LDS
         // form costs them +0.9 % (0.3574 -> 0.3607 ms), so they keep the epilogue load; res1_lds 2 forces the LDS form everywhere (profiles/r4/rlds_ab.txt).
         k.rs1 = 1.0f / L.s1;
-        return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x401FF>(k, L.N, s);
+        return L.rowp ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x4401FF>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x401FF>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 4) {
         // diagnostic builds: four consumer waves of twice the rows (measured within +-1 %: profiles/r2/kernel_experiments.txt 10)
         if (INNFER_KNOB("INNFER_FAT", 0) & 2) return launch_pc<4, 4, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);
-        return launch_pc<2, 4, 4>(k, L.N, s);
+        return L.rowp ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x4001FF>(k, L.N, s) : launch_pc<2, 4, 4>(k, L.N, s);
     }
     if (L.conv7) {         // 7x7 (padding 3) as nine displaced 3x3 convs: planar output, <= 16 output channels, panels from conv_pack7x7
         if (!pc || L.out_mode != OUT_NCHW || nt != 1 || L.res1 || L.res2 || L.up || (long)L.H * L.W * 64 >= 0x7fffffffL)

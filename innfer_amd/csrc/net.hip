@@ -79,6 +79,9 @@ extern "C" int innfer_timer_stop(void* stream, int cap, char* names, int name_ca
     return rc;
 }
 
+#ifndef INNFER_ROWP_DEFAULT
+#define INNFER_ROWP_DEFAULT 1      // (A/B builds: 0 = the lane-contiguous row order everywhere)
+#endif
 struct ConvSlot {
     std::string key;
     int K = 0, C = 0;
@@ -87,8 +90,11 @@ struct ConvSlot {
     void* d_w = nullptr;         // packed panels (MFMA) or fp32 k-major (first)
     std::vector<float> h_w;      // MFMA convs: the fp32 weights as they were set, kept for the fp32-accurate mode's panels
     void* d_w32 = nullptr;       //   (hi | lo | hi) panels of conv_pack_split, built by innfer_net_set_precision(1)
+    bool rowp = false;           // 3x3 convs of exactly 64 outputs: d_w (and d_up4, d_fuse behind it) in the plane row order (ConvLaunch.rowp) -- a store instruction of the 64-channel
+                                 // kernels then touches one slab plane; set when the weights are packed.  The split panels (d_w32) keep the lane-contiguous order.
     bool up2x = false;           // the conv of an upconv_block (nearest 2x in front of it): also packed as the four 2x2-tap phases of the equivalent transposed conv
     void* d_up4 = nullptr;       //   conv_pack_deconv2x panels of the summed weights + d_b4 (the bias once per phase), built with d_w
+    void* d_up4p = nullptr;      //   the same in the plane row order (rowp slots: the one-visit form, conv3x3_pc UP4); d_up4 stays lane-contiguous (grids <= 16 wide, A/B)
     float* d_b4 = nullptr;
     void* d_fuse = nullptr;      // a last conv of 64 -> <= 3 channels: its panel for the epilogue of HR_conv0 (conv_pack_fuse_last), built with d_w
     float* d_b = nullptr;        // bias padded to the panel width
@@ -236,6 +242,7 @@ extern "C" void innfer_net_destroy(innfer_net_t net) {
         if (c.d_w32) (void)hipFree(c.d_w32);
         if (c.d_fuse) (void)hipFree(c.d_fuse);
         if (c.d_up4) (void)hipFree(c.d_up4);
+        if (c.d_up4p) (void)hipFree(c.d_up4p);
         if (c.d_b4) (void)hipFree(c.d_b4);
         if (c.d_map) (void)hipFree(c.d_map);
     }
@@ -272,7 +279,8 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
             conv_pack_1x1(w, c.K, c.C, host.data());
         } else {
             host.resize(conv_packed_bytes(c.K, c.C));
-            conv_pack(w, c.K, c.C, host.data());
+            c.rowp = INNFER_ROWP_DEFAULT && c.K == 64;
+            conv_pack(w, c.K, c.C, host.data(), c.rowp);
         }
         const int per = 16 * conv_nt_for(c.K);
         bias_n = (size_t)((c.K + per - 1) / per) * per;
@@ -287,11 +295,16 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
             if (!c.d_up4) INNFER_HIP(hipMalloc(&c.d_up4, pk.size()));
             if (!c.d_b4) INNFER_HIP(hipMalloc((void**)&c.d_b4, b4.size() * sizeof(float)));
             INNFER_HIP(hipMemcpy(c.d_up4, pk.data(), pk.size(), hipMemcpyHostToDevice));
+            if (c.rowp && c.C == 64) {
+                conv_pack_up2x_phases(w, c.K, c.C, pk.data(), 1);
+                if (!c.d_up4p) INNFER_HIP(hipMalloc(&c.d_up4p, pk.size()));
+                INNFER_HIP(hipMemcpy(c.d_up4p, pk.data(), pk.size(), hipMemcpyHostToDevice));
+            }
             INNFER_HIP(hipMemcpy(c.d_b4, b4.data(), b4.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         if (c.ksize == 3 && c.C == 64 && c.K <= 3) {          // (only the network's last conv has this shape)
             std::vector<char> fp(4096);
-            conv_pack_fuse_last(w, c.K, fp.data());
+            conv_pack_fuse_last(w, c.K, fp.data(), INNFER_ROWP_DEFAULT);          // (fused behind HR_conv0, a 64-output conv: its row order)
             if (!c.d_fuse) INNFER_HIP(hipMalloc(&c.d_fuse, fp.size()));
             INNFER_HIP(hipMemcpy(c.d_fuse, fp.data(), fp.size(), hipMemcpyHostToDevice));
         }
@@ -661,6 +674,7 @@ ConvLaunch mk_launch(const ConvSlot& cs, const f16* in, long in_g, void* out, lo
     L.y0 = 0; L.y1 = H;
     L.out_mode = OUT_SLAB;
     L.conv1x1 = cs.ksize == 1;
+    L.rowp = (!lo && cs.rowp) ? 1 : 0;          // (the split panels keep the lane-contiguous order)
     return L;
 }
 
@@ -855,8 +869,9 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             // Upsample(nearest 2x) -> conv -> act as the four output phases of the equivalent transposed conv: 2x2 taps on the LR grid instead of 3x3 on the
             // HR grid (2.25 x fewer MACs), on the phase-lattice instantiation (conv3x3_pc<.., TM = 0x1B>)
             ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, net->trunk_act);
-            L.wpk = (const f16*)cs.d_up4; L.bias = cs.d_b4;
-            L.K = 4 * cs.K; L.phase_c = cs.K; L.deconv_phases = net->up_phases;       // 1: all four phases in one visit of a tile (C = 64), 2: one phase per visit
+            const bool one_visit = net->up_phases == 1 && cs.d_up4p && w > 16;       // all four phases in one visit of a tile (C = 64, plane-order panels); else one phase per visit
+            L.wpk = (const f16*)(one_visit ? cs.d_up4p : cs.d_up4); L.bias = cs.d_b4;
+            L.K = 4 * cs.K; L.phase_c = cs.K; L.deconv_phases = one_visit ? 1 : 2; L.rowp = one_visit ? 1 : 0;
             rc = do_conv(L, s);
         } else if (!net->ps_up) {    // Upsample(nearest 2x) -> conv -> act
             ConvLaunch L = mk(cs, t, gi, dst, go, N, 2 * h, 2 * w, net->trunk_act);
@@ -945,6 +960,19 @@ extern "C" int innfer_pack_conv3x3(const float* w, int K, int C, void* h_packed)
     return INNFER_OK;
 }
 
+extern "C" int innfer_pack_conv3x3_rows(const float* w, int K, int C, int plane_rows, void* h_packed) {
+    if (!w || !h_packed || K <= 0 || C <= 0 || C % 32 || (plane_rows && K % 64))
+        return set_error(INNFER_ERR_INVALID, "pack_conv3x3_rows: K=%d C=%d (C must be a multiple of 32; the plane row order needs K %% 64 == 0)", K, C);
+    conv_pack(w, K, C, h_packed, plane_rows ? 1 : 0);
+    return INNFER_OK;
+}
+
+extern "C" int innfer_pack_convt2x_rows(const float* w, int K, int C, int k, int plane_rows, void* packed) {
+    if (!w || !packed || K <= 0 || K % 64 || C <= 0 || C % 32 || (k != 3 && k != 4)) return set_error(INNFER_ERR_INVALID, "pack_convT2x_rows: K=%d (%% 64) C=%d (%% 32) k=%d (3 | 4)", K, C, k);
+    conv_pack_deconv2x(w, K, C, k, packed, plane_rows ? 1 : 0);
+    return INNFER_OK;
+}
+
 extern "C" int innfer_pack_conv3x3_split(const float* w, int K, int C, void* h_packed) {
     if (!w || !h_packed || K <= 0 || C <= 0 || C % 32)
         return set_error(INNFER_ERR_INVALID, "pack_conv3x3_split: K=%d C=%d (C must be a multiple of 32)", K, C);
@@ -1003,7 +1031,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
         L.out = a->d_out; L.out_gstride = a->out_group_stride; L.K = a->K;
         L.N = a->N; L.H = a->H; L.W = a->W; L.act = a->act; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = a->H; L.out_mode = OUT_SLAB;
         if (a->stride2_k4) L.stride2 = 1;
-        else { L.K = 4 * a->K; L.phase_c = a->K; L.deconv_phases = 1; }
+        else { L.K = 4 * a->K; L.phase_c = a->K; L.deconv_phases = 1; L.rowp = a->plane_rows ? 1 : 0; }
         return conv_launch(L, (hipStream_t)stream);
     }
     if (a->pixel_shuffle2) {
@@ -1024,6 +1052,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.y0 = a->row_begin; L.y1 = a->row_end > 0 ? a->row_end : a->H;
     L.out_mode = a->pixel_shuffle2 ? OUT_SHUFFLE2 : OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
     L.res1_lds = a->res1_from_input ? 2 : 0;                 // (the single-conv call: wherever the shape qualifies, one residual or two)
+    L.rowp = a->plane_rows ? 1 : 0;
     if (a->winograd) {
         if (a->pixel_shuffle2 || a->split || a->K % 32 || a->out_ch_off % 32 || (a->winograd != 1 && a->winograd != 2))
             return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (winograd): 1 | 2, K %% 32 == 0 (K=%d), whole output groups", a->K);

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
         ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int), ("pixel_shuffle2", C.c_int),
         ("stride2_k4", C.c_int), ("transposed2x", C.c_int), ("column7", C.c_int),
         ("split", C.c_int), ("in_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64), ("res2_lo", C.c_int64),
-        ("winograd", C.c_int), ("res1_from_input", C.c_int),
+        ("winograd", C.c_int), ("res1_from_input", C.c_int), ("plane_rows", C.c_int),
     ]
 
 
@@ -146,6 +146,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "innfer_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "innfer_pack_conv3x3_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "innfer_pack_convt2x_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv3x3_f16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "innfer_filter2d": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "innfer_conv7x1_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -198,7 +200,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 108          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 109          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

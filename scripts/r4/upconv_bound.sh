@@ -4,7 +4,7 @@
 export INNFER_LIB=innfer_amd/lib/libinnfer_amd_ablate.so
 for form in "" "--upconv-phase-visits"; do
 echo "== ${form:-four phases in one visit of a tile (default)}"
-for abl in 0 1 64 128 192; do
+for abl in 0 512 0 512; do
   INNFER_ABL=$abl python3 bench.py --steps 6 --warmup 3 --no-extras --no-cpu-baseline --sharded-steps 0 --no-power-probe $form 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1])

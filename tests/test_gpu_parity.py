@@ -30,10 +30,19 @@ def _sd(shapes, seed=0):
 
 # ------------------------------------------------------------------ single conv
 def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2=1.0,
-              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False, dilation=0, res1_is_input=False, res1_from_lds=False):
+              in_extra=0, out_channels=None, out_off=0, rows=None, reflect=False, dilation=0, res1_is_input=False, res1_from_lds=False, plane_rows=None):
     """x [N,C,Hs,Ws] fp16 (cpu), w [K,C,3,3] fp32.  Runs the HIP conv on blocked-NHWC slabs
-    ([C/32][N*H*W][32]) and returns (NCHW fp32 result, raw output slab [groups,N,H,W,32]) on the cpu."""
+    ([C/32][N*H*W][32]) and returns (NCHW fp32 result, raw output slab [groups,N,H,W,32]) on the cpu.
+    64-channel output groups exist in two row orders (innfer_conv_args.plane_rows): unless one is asked for, both run and must agree bit for bit."""
     import innfer_amd.lib as L
+    if plane_rows is None and K % 64 == 0 and not dilation and out_off % 32 == 0:
+        kw = dict(act=act, up=up, res1=res1, s1=s1, res2=res2, s2=s2, in_extra=in_extra, out_channels=out_channels, out_off=out_off, rows=rows, reflect=reflect,
+                  dilation=dilation, res1_is_input=res1_is_input, res1_from_lds=res1_from_lds)
+        r0, o0 = _run_conv(dev, x, w, b, K, plane_rows=0, **kw)
+        r1, o1 = _run_conv(dev, x, w, b, K, plane_rows=1, **kw)
+        assert torch.equal(r0, r1) and torch.equal(o0, o1), "plane row order != lane-contiguous row order"
+        return r1, o1
+    plane_rows = int(bool(plane_rows))
     N, Cc, Hs, Ws = x.shape
     H, W = (2 * Hs, 2 * Ws) if up else (Hs, Ws)
     in_groups = (Cc + in_extra) // 32
@@ -44,7 +53,7 @@ def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2
     nbytes = L.lib.innfer_conv3x3_packed_bytes(K, Cc)
     packed = np.zeros(nbytes, dtype=np.uint8)
     wc = np.ascontiguousarray(w.numpy())
-    L.check(L.lib.innfer_pack_conv3x3(wc.ctypes.data, K, Cc, packed.ctypes.data))
+    L.check(L.lib.innfer_pack_conv3x3_rows(wc.ctypes.data, K, Cc, plane_rows, packed.ctypes.data))
     d_packed = torch.from_numpy(packed).to(dev)
     d_bias = b.float().to(dev)
     out_channels = out_channels or max(K, 32)
@@ -55,6 +64,7 @@ def _run_conv(dev, x, w, b, K, act=0, up=False, res1=None, s1=1.0, res2=None, s2
     a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
     a.d_out, a.out_group_stride, a.out_ch_off, a.K = out.data_ptr(), g_out, out_off, K
     a.N, a.H, a.W, a.act, a.upsample2x = N, H, W, act, int(up)
+    a.plane_rows = plane_rows
     keep = [slab, d_packed, d_bias]
     if res1_is_input:       # residual 1 = the first K channels of the conv's own input slab (x5 * 0.2 + x of an RDB)
         a.d_res1, a.res1_group_stride, a.res1_scale = slab.data_ptr(), g_in, s1
@@ -805,7 +815,7 @@ def test_unet_variants_vs_oracle(dev):
         assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (in_nc, out_nc, num_downs, err.max().item(), err.mean().item())
 
 
-def _run_stride2(dev, x, w, b, K, kind, k=4, act=0):
+def _run_stride2(dev, x, w, b, K, kind, k=4, act=0, plane_rows=0):
     """The stride-2 forms of the single-conv ABI: kind 'down' = Conv2d(4, 2, 1) (x [N,C,2H,2W] -> [N,K,H,W]), kind 'up' = ConvTranspose2d(k, 2, 1[, 1])
     (x [N,C,H,W] -> [N,K,2H,2W]).  Returns the NCHW fp32 result on the cpu."""
     import innfer_amd.lib as L
@@ -821,7 +831,7 @@ def _run_stride2(dev, x, w, b, K, kind, k=4, act=0):
         d_bias = b.float().to(dev)
     else:
         packed = np.zeros(L.lib.innfer_convt2x_packed_bytes(K, Cc), dtype=np.uint8)
-        L.check(L.lib.innfer_pack_convt2x(wc.ctypes.data, K, Cc, k, packed.ctypes.data))
+        L.check(L.lib.innfer_pack_convt2x_rows(wc.ctypes.data, K, Cc, k, plane_rows, packed.ctypes.data))
         d_bias = b.float().repeat(4).to(dev)
     d_packed = torch.from_numpy(packed).to(dev)
     out = torch.full((K // 32, N, Ho, Wo, 32), -3.0, dtype=torch.float16, device=dev)
@@ -834,6 +844,7 @@ def _run_stride2(dev, x, w, b, K, kind, k=4, act=0):
         a.H, a.W, a.stride2_k4 = Ho, Wo, 1
     else:
         a.H, a.W, a.transposed2x = Hi, Wi, k
+        a.plane_rows = plane_rows
     L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
     res = torch.empty((N, K, Ho, Wo), dtype=torch.float32, device=dev)
     L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), g_out, 0, res.data_ptr(), L.F32, N, K, Ho, Wo, None))
@@ -848,7 +859,7 @@ def test_stride2_conv_and_transposed_conv_vs_torch(dev):
     Tolerance: fp16 rounding of the stored result plus fp32 accumulation order (<= 4e-3 for unit-scale outputs, as for the 3x3 conv)."""
     import torch.nn.functional as F
     rng = np.random.RandomState(11)
-    cases = [(1, 32, 64, 16, 32), (2, 64, 128, 24, 40), (1, 96, 64, 7, 9), (3, 32, 192, 16, 16), (1, 64, 64, 33, 65), (2, 32, 64, 5, 16), (1, 128, 128, 48, 17)]
+    cases = [(1, 32, 64, 16, 32), (2, 64, 128, 24, 40), (1, 96, 64, 7, 9), (3, 32, 192, 16, 16), (1, 64, 64, 33, 65), (2, 32, 64, 5, 16), (1, 128, 128, 48, 17), (2, 64, 64, 50, 100)]
     for _ in range(6):
         cases.append((int(rng.randint(1, 4)), 32 * int(rng.randint(1, 5)), 64 * int(rng.randint(1, 4)), int(rng.randint(1, 50)), int(rng.randint(1, 70))))
     for i, (N, Cc, K, H, W) in enumerate(cases):
@@ -868,6 +879,8 @@ def test_stride2_conv_and_transposed_conv_vs_torch(dev):
             ref = post(F.conv_transpose2d(x.float(), w, b, stride=2, padding=1, output_padding=1 if k == 3 else 0))
             got = _run_stride2(dev, x, w, b, K, "up", k=k, act=act)
             assert got.shape == ref.shape and (got - ref).abs().max().item() < 4e-3, ("up", k, N, Cc, K, H, W, (got - ref).abs().max().item())
+            if Cc == 64 and K == 64 and W > 16:      # plane-order panels: all four phases in one visit of a tile (conv3x3_pc UP4) -- the same MFMAs in the same order
+                assert torch.equal(_run_stride2(dev, x, w, b, K, "up", k=k, act=act, plane_rows=1), got), ("up, one visit", k, N, H, W)
 
 
 def test_small_grid_image_pairs_are_bit_identical_to_single_images(dev):
