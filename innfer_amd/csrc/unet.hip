@@ -299,8 +299,9 @@ __global__ void unet_pre_patch(const void* in, int in_f32, int C, int H, int W, 
 // (the input is 1/5 of the bytes this kernel writes and every value is re-read from L1 / L2), multiplies by the 64 x 64 weight panel it keeps in
 // registers and writes BOTH views of the result (no norm layer follows this conv): LeakyReLU(0.2) for the next down conv, ReLU for the
 // concatenation.  Replaces unet_pre_patch + two one-tap conv launches (178 -> 98 us at 64 x 256^2): one pass.
-// wpk: [k-step][16-channel tile t][row rho][k-block lg][8], row rho of tile t = output channel 16 * (rho >> 2) + 4 * t + (rho & 3), so that lane
-// group lg ends up with channels 16 lg .. 16 lg + 15 of its pixel (32 contiguous bytes per view).
+// wpk: [k-step][16-channel tile t][row rho][k-block lg][8], row rho of tile t = output channel 32 (t >> 1) + 8 (rho >> 2) + 4 (t & 1) + (rho & 3) (the plane
+// row order of conv3x3.hip's 64-channel kernels): lane group lg ends up with channels 8 lg .. 8 lg + 7 of EACH 32-channel slab plane of its pixel, the four
+// groups cover the pixel's whole 64 bytes of a plane, and a store instruction touches one plane (round 4; 16 lg .. 16 lg + 15 before: two planes per store).
 template <typename TI>
 __global__ __launch_bounds__(256) void unet_first_mfma(const TI* in, int C, int H, int W, int N, const f16* wpk, const float* bias,
                                                        f16* d0, f16* d1, long g, int abl) {
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void unet_first_mfma(const TI* in, int C, int 
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b4[t][j] = bias ? bias[16 * lg + 4 * t + j] : 0.f;
+        for (int j = 0; j < 4; ++j) b4[t][j] = bias ? bias[32 * (t >> 1) + 8 * lg + 4 * (t & 1) + j] : 0.f;
     const int ky0 = (lg & 1) * 2;
     // element offsets of this lane's 16 window values from the first value of its row pair in channel 0 (loop constants; one image < 2^31 elements)
     int off[2][8];
@@ -389,12 +390,12 @@ __global__ __launch_bounds__(256) void unet_first_mfma(const TI* in, int C, int 
                     h0[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.2f * v);
                     h1[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.f);
                 }
-            const long o = (lg >> 1) * g + (m0 + sx * 16) * 32 + (lg & 1) * 16;
+            const long o = (m0 + sx * 16) * 32 + lg * 8;              // h[0]: plane 0 (tiles 0, 1), h[1]: plane 1 (tiles 2, 3)
 #ifdef INNFER_ABLATE
             if ((abl & 2) && h0[0][0] != (f16)12345.f) return;       // diagnostic build: no stores
 #endif
-            *(f16x8*)(d0 + o) = h0[0]; *(f16x8*)(d0 + o + 8) = h0[1];
-            if (d1) { *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + o + 8) = h1[1]; }      // (wave-uniform; nullptr: one stored form, the up conv applies the ReLU as it reads)
+            *(f16x8*)(d0 + o) = h0[0]; *(f16x8*)(d0 + g + o) = h0[1];
+            if (d1) { *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + g + o) = h1[1]; }      // (wave-uniform; nullptr: one stored form, the up conv applies the ReLU as it reads)
         };
         request(0, rawA);
         int sx = 0;
@@ -633,7 +634,7 @@ static int upload_all(innfer_unet* u) {
                         for (int t = 0; t < 4; ++t)
                             for (int rho = 0; rho < 16; ++rho)
                                 for (int q = 0; q < 32; ++q) {
-                                    const int co = 16 * (rho >> 2) + 4 * t + (rho & 3), kk = ks * 32 + q, c = kk >> 4, tap = kk & 15;
+                                    const int co = 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3), kk = ks * 32 + q, c = kk >> 4, tap = kk & 15;      // (plane row order: see unet_first_mfma)
                                     wf[((ks * 4 + t) * 16 + rho) * 32 + q] = (f16)(c < l.cin ? w[(((size_t)co * l.cin + c) * 4 + (tap >> 2)) * 4 + (tap & 3)] : 0.f);
                                 }
                     rc = upload_f16(&l.d_wf, wf); if (rc) return rc;
