@@ -50,9 +50,10 @@ WORKLOADS = ["frame1080", "frame540", "chop8k", "chop4k", "chain4k"]
 
 
 def kernel_key(k):
-    """rocprof-style name of the instantiation conv_launch picks for launch kind k (csrc/net.hip do_conv): 16*NT + out_mode, + 1000 the
-    fp32-accurate form, + 2000 HR_conv0 + conv_last fused (TMF 0x201FF = 131583), + 3000 an up-conv as four 2x2-tap phases (TM 0x1B = 27) --
-    the suffixes are the ones scripts/summarize_prof.py gives the same instantiations in profiles/traffic.json."""
+    """Name of the instantiation family conv_launch picks for launch kind k (csrc/net.hip do_conv): 16*NT + out_mode, + 1000 the fp32-accurate form,
+    + 2000 HR_conv0 + conv_last fused (rocprof: conv3x3_pc<2,4,4,0,..,TMF 4325887 = 0x4201FF>), + 3000 an up-conv as four 2x2-tap phases (TMF 6291967 =
+    0x6001FF).  The plain 64-output row holds both the plain (TMF 4194815) and the residual-from-LDS (4456959) launches; profiles/traffic.json lists the
+    instantiations by their TMF."""
     if k == 1000:
         return "conv3x3_pair"
     variant, k = k // 1000, k % 1000
@@ -61,15 +62,15 @@ def kernel_key(k):
         name = "conv3x3_pc<%d,%d,%d,%d>" % PC_SHAPE[(nt, mode)]
     else:
         name = f"conv3x3_mfma<{MFMA_SHAPE[nt]},{nt},{mode}>"
-    return name + {0: "", 1: "+split", 2: "+tm131583", 3: "+tm27"}[variant]
+    return name + {0: "", 1: "+split", 2: "+fused_tail", 3: "+upconv_phases"}[variant]
 
 
 def kind_name(k):
     return "first_conv_mfma<4,1>" if k == 0 else kernel_key(k)          # (3 -> 64 on the matrix cores, csrc/conv_first.hip)
 
 
-KIND_NOTES = {"+tm131583": "HR_conv0 + conv_last in one launch (+ the rim pass): both convs' FLOPs, the 64-channel HR tensor neither written nor read",
-              "+tm27": "up-conv as four 2x2-tap phases on the LR grid: FLOPs are the ALGORITHMIC ones of the nine-tap layer it replaces "
+KIND_NOTES = {"+fused_tail": "HR_conv0 + conv_last in one launch (+ the rim pass): both convs' FLOPs, the 64-channel HR tensor neither written nor read",
+              "+upconv_phases": "up-conv as four 2x2-tap phases on the LR grid (all four in one visit of a tile): FLOPs are the ALGORITHMIC ones of the nine-tap layer it replaces "
                        "(reference block.py:348-361); executed FLOPs = 4/9 of them, so `frac_mfma` here is not the matrix pipe's utilisation"}
 
 

@@ -9,7 +9,7 @@ for abl in 0 512 0 512; do
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1])
 pk=d.get('per_kernel') or d['roofline'].get('per_kernel')
-r=pk['conv3x3_pc<2,4,4,0>+tm27']
+r=pk['conv3x3_pc<2,4,4,0>+upconv_phases']
 print('abl=%-3s up-conv launches: %.4f ms total (%d launches)   frame %.2f ms' % ('$abl', r['ms_total'], r['launches'], d['ms_per_step']))
 "
 done

@@ -6,7 +6,7 @@ for i in 1 2 3; do
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1])
 pk=d.get('per_kernel') or d['roofline'].get('per_kernel')
-r=pk['conv3x3_pc<2,4,4,0>+tm27']
+r=pk['conv3x3_pc<2,4,4,0>+upconv_phases']
 print('%-24s frame %.3f ms  frac %.4f   up-conv launches %.4f ms' % ('$f' or 'one visit (default)', d['ms_per_step'], d['roofline']['frac'] if 'frac' in d['roofline'] else 0, r['ms_total']))
 "
   done
