@@ -301,7 +301,8 @@ __global__ void unet_pre_patch(const void* in, int in_f32, int C, int H, int W, 
 // concatenation.  Replaces unet_pre_patch + two one-tap conv launches (178 -> 98 us at 64 x 256^2): one pass.
 // wpk: [k-step][16-channel tile t][row rho][k-block lg][8], row rho of tile t = output channel 32 (t >> 1) + 8 (rho >> 2) + 4 (t & 1) + (rho & 3) (the plane
 // row order of conv3x3.hip's 64-channel kernels): lane group lg ends up with channels 8 lg .. 8 lg + 7 of EACH 32-channel slab plane of its pixel, the four
-// groups cover the pixel's whole 64 bytes of a plane, and a store instruction touches one plane (round 4; 16 lg .. 16 lg + 15 before: two planes per store).
+// groups cover the pixel's whole 64 bytes of a plane, and a store instruction touches one plane (round 4; 16 lg .. 16 lg + 15 before: two planes per store; neutral
+// for this kernel in a same-box A/B, profiles/r4/unet_first_rowp_ab.txt).
 template <typename TI>
 __global__ __launch_bounds__(256) void unet_first_mfma(const TI* in, int C, int H, int W, int N, const f16* wpk, const float* bias,
                                                        f16* d0, f16* d1, long g, int abl) {
