@@ -165,8 +165,10 @@ int innfer_net_set_fused_tail(innfer_net_t net, int on);
 /* Scheduling knob: the conv of an upconv_block (nn.Upsample(nearest 2x) -> conv 3x3 -> act, block.py:348-361) as the four 2x2-tap output phases of the
  * equivalent ConvTranspose2d(4, 2, 1) on the LR grid -- 2.25 x fewer multiply-adds than nine taps on the HR grid.  The taps that meet the same LR pixel are
  * summed in fp32 and rounded to fp16 ONCE (the nine-tap form rounds each of them): the same linear map with a rounding of the same size, not the same bits.
- * 1 (default) = phases for the fp16 engine where the conv has 64 n output channels; 0 = the nine-tap form through the upsampling loader.  (107) */
-int innfer_net_set_upconv_phases(innfer_net_t net, int on);
+ * 1 (default) = phases for the fp16 engine where the conv has 64 n output channels -- 64 -> 64 convs on grids wider than 16 pixels compute all four phases in ONE visit of
+ * a tile (the input tile staged once); 2 = one phase per visit of a tile everywhere (the same bits as 1: A/B and parity tests) (109); 0 = the nine-tap form through
+ * the upsampling loader.  (107) */
+int innfer_net_set_upconv_phases(innfer_net_t net, int mode);
 
 /* `finalact` of the reference constructors (RRDBNet_arch.py:45-48: an activation module after the last conv):
  * 0 none (default), 1 LeakyReLU(0.2), 2 ReLU, 3 tanh, 6 sigmoid. */
