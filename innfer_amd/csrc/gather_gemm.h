@@ -33,6 +33,9 @@ struct GP {
                                           // input: weights wpk + g*g_wbytes, taps * (1 + g*g_tapmul), output out + g*g_outoff
     int g_phase;                          // ngroup == 4 output phases of a stride-2 transposed conv: group g uses taps [g*ntaps, (g+1)*ntaps)
                                           // of dy/dx and writes output pixel (oy*os + (g>>1), ox*os + (g&1))
+#ifdef INNFER_ABLATE
+    int abl;                              // diagnostic build only (INNFER_GG_ABL): 1 = the pixel operand staged for a chunk's first tap only
+#endif
 };
 
 // 128 pixels x 64 output channels per workgroup (4 waves x (32 px x 64 co) = 8 MFMAs per wave and 32-channel
@@ -104,6 +107,11 @@ static __global__ __launch_bounds__(256 * NCO) void gemm_gather(const GP p) {
         const int t = step / p.nchunks, c = step - t * p.nchunks;
         char* st = lds + (rel % STAGES) * STAGE_BYTES;
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)c * p.in_g), 0, 0x7fffffff, 0x00020000);
+#ifdef INNFER_ABLATE
+        // INNFER_GG_ABL 1 (wrong results by construction): the pixel operand is staged for the FIRST tap of a chunk only -- what a form that keeps the input tile in
+        // LDS across the taps could gain at most (profiles/r4/gg_resident_bound.txt)
+        if (!(p.abl & 1) || t == 0)
+#endif
 #pragma unroll
         for (int h = 0; h < BPW; ++h) {
             int iy = soy[h] * p.stride + p.dy[tap0 + t] * tapmul, ix = sox[h] * p.stride + p.dx[tap0 + t] * tapmul;
@@ -273,6 +281,9 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
         g.ntaps = ntaps;
     }
     g.Hfull = Hfull; g.Wfull = Wfull; g.os = os; g.ooy = ooy; g.oox = oox; g.up = up; g.reflect = reflect;
+#ifdef INNFER_ABLATE
+    g.abl = getenv("INNFER_GG_ABL") ? atoi(getenv("INNFER_GG_ABL")) : 0;
+#endif
     const long M = (long)N * Ho * Wo;
     if (M <= 0) return INNFER_OK;
     // (launch timer: the GEMM and, where it is split over K inside this call, its reduction as one entry)
