@@ -34,7 +34,7 @@ struct GP {
     int g_phase;                          // ngroup == 4 output phases of a stride-2 transposed conv: group g uses taps [g*ntaps, (g+1)*ntaps)
                                           // of dy/dx and writes output pixel (oy*os + (g>>1), ox*os + (g&1))
 #ifdef INNFER_ABLATE
-    int abl;                              // diagnostic build only (INNFER_GG_ABL): 1 = the pixel operand staged for a chunk's first tap only
+    int abl;                              // diagnostic build only (INNFER_GG_ABL): 1 = the pixel operand staged for a chunk's first tap only, 2 = the weight panels for the first steps only
 #endif
 };
 
@@ -125,6 +125,9 @@ static __global__ __launch_bounds__(256 * NCO) void gemm_gather(const GP p) {
             const int voff = ok ? (spix[h] + iy * p.Win + ix) * 64 + cso[h] : (int)0x80000000;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(st + (wave + NW * h) * 1024), 16, voff, 0, 0, 0);
         }
+#ifdef INNFER_ABLATE
+        if (!(p.abl & 2) || rel < STAGES)           // INNFER_GG_ABL 2: the weight panels staged for the first STAGES steps only (what the weight stream costs)
+#endif
 #pragma unroll
         for (int jj = 0; jj < QW; ++jj) {
             const int j = cwv + NCO * jj;
@@ -169,7 +172,7 @@ static __global__ __launch_bounds__(256 * NCO) void gemm_gather(const GP p) {
             for (int h = 0; h < BP; ++h) acc[h][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[h], acc[h][q], 0, 0, 0);
         }
     }
-    // D rows = out channels (16*lg + 4*q + j after the panel permutation), cols = pixels
+    // D rows = out channels (16 (q & 3) + 4 lg + j of the 64-channel panel q >> 2), cols = pixels
 #pragma unroll
     for (int h = 0; h < BP; ++h) {
         const long m = m0 + pw * 16 * BP + 16 * h + li;
@@ -182,7 +185,7 @@ static __global__ __launch_bounds__(256 * NCO) void gemm_gather(const GP p) {
             float* op = p.out + (long)zs * p.split_elems + zg * p.g_outoff + opix * p.raw_stride;
 #pragma unroll
             for (int q = 0; q < 4 * QW; ++q) {
-                const int ch = (cot + cwv * QW + (q >> 2)) * 64 + 16 * lg + 4 * (q & 3);
+                const int ch = (cot + cwv * QW + (q >> 2)) * 64 + 16 * (q & 3) + 4 * lg;      // (natural row order: see pack_panels)
                 if (ch < p.cout_store) *(f32x4*)(op + ch) = acc[h][q];
             }
         }
@@ -191,7 +194,10 @@ static __global__ __launch_bounds__(256 * NCO) void gemm_gather(const GP p) {
 
 
 // ---- host: weight panels -----------------------------------------------------------------------
-// row R = q*16 + rho of a 64-channel tile holds out channel cot*64 + 16*(rho>>2) + 4*q + (rho&3);
+// row R = q*16 + rho of a 64-channel tile holds out channel cot*64 + R (the natural order: a lane group lg ends up with channels 16 q + 4 lg .. + 3 of MFMA tile q, so ONE
+// store instruction -- 16 bytes per lane -- writes a pixel's 16 consecutive channels as 64 contiguous bytes.  Until round 4 the rows were permuted so that a lane
+// held 16 consecutive channels over its four tiles: every instruction then wrote four 16-byte pieces 64 bytes apart per pixel, and the split-K partials -- 134 MB
+// on the UNet's 8x8 -> 16x16 level -- paid for it: profiles/r4/gg_resident_bound.txt);
 // LDS slot s of that row holds input channels chunk*32 + 8*(s ^ 2*bit2(R)) .. +7
 template <typename W>
 inline void pack_panels(std::vector<f16>& dst, int cout, int cin, int cin_pad, int ntaps, W weight_of) {
@@ -203,7 +209,7 @@ inline void pack_panels(std::vector<f16>& dst, int cout, int cin, int cin_pad, i
             for (int c = 0; c < nch; ++c)
                 for (int R = 0; R < 64; ++R) {
                     const int q = R >> 4, rho = R & 15;
-                    const int co = cot * 64 + 16 * (rho >> 2) + 4 * q + (rho & 3);
+                    const int co = cot * 64 + 16 * q + rho;
                     for (int s = 0; s < 4; ++s) {
                         const int cg = s ^ (((R >> 2) & 1) << 1);
                         for (int e = 0; e < 8; ++e, ++o) {
