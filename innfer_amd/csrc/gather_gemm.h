@@ -305,7 +305,7 @@ inline int launch(const f16* wpk, int cin_pad, int cout_pad, const f16* in, long
     // (grids of at most 4 pixels per image -- the 2x2 and 1x1 levels: their partial results are a few hundred KB, their launches a handful of workgroups
     //  walking a latency-bound k loop: segments of 8 k-steps, up to 32 of them)
     const bool tiny = (long)Ho * Wo <= 4;      // (measured: at 16 pixels per image the 32-way split loses to the 8-way one, 36 -> 45 us, and its reduction too)
-    const int want = tiny ? std::min(32, std::max(1, nsteps / 8)) : nsteps >= 256 ? 8 : nsteps >= 128 ? INNFER_KNOB("INNFER_GG_WANT128", 4) : nsteps >= 64 ? INNFER_KNOB("INNFER_GG_WANT64", 2) : 1;
+    const int want = tiny ? std::min(32, std::max(1, nsteps / 8)) : nsteps >= 256 ? INNFER_KNOB("INNFER_GG_WANT256", 8) : nsteps >= 128 ? INNFER_KNOB("INNFER_GG_WANT128", 4) : nsteps >= 64 ? INNFER_KNOB("INNFER_GG_WANT64", 2) : 1;
     g.seg = (nsteps + want - 1) / want;
     const int segs = (nsteps + g.seg - 1) / g.seg;
     int ks = 1;
