@@ -2792,7 +2792,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 4) {
         // diagnostic builds: four consumer waves of twice the rows (measured within +-1 %: profiles/r2/kernel_experiments.txt 10)
-        if (INNFER_KNOB("INNFER_FAT", 0) & 2) return launch_pc<4, 4, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);
+        if (!L.rowp && (INNFER_KNOB("INNFER_FAT", 0) & 2)) return launch_pc<4, 4, 4, OUT_SLAB, false, false, 0x1FF, false, 2, 4>(k, L.N, s);
         return L.rowp ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x4001FF>(k, L.N, s) : launch_pc<2, 4, 4>(k, L.N, s);
     }
     if (L.conv7) {         // 7x7 (padding 3) as nine displaced 3x3 convs: planar output, <= 16 output channels, panels from conv_pack7x7
