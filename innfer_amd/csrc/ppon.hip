@@ -109,6 +109,7 @@ struct Param { std::string key; std::vector<int> shape; std::vector<float> host;
 
 struct Conv3 { int w = -1, b = -1, K = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr;      // conv3x3.hip panels
                void* d_up4 = nullptr; float* d_b4 = nullptr;     // the conv of an upconv_block also as four 2x2-tap phases (conv_pack_up2x_phases, bias once per phase)
+               void* d_up4p = nullptr;                           //   64 -> 64: the same panels in the plane row order, for the one-visit form (conv3x3_pc UP4 | ROWP, as net.hip)
                void* d_fuse = nullptr; };                        // a head's last conv (64 -> <= 3): its panel for the epilogue of HR_conv0 (conv_pack_fuse_last)
 struct ResB { Conv3 c1; int d_w[8], d_b[8], c2_w, c2_b; void* d_dw3[8] = {};   // [0]: halo-tile panels of the eight dilated convs, back to back
               f16* d_dw = nullptr; long dw_bytes = 0; f16* d_c2 = nullptr; float* d_dbias = nullptr; float* d_c2b = nullptr;
@@ -189,9 +190,10 @@ static void free_conv3(Conv3& c) {
     if (c.d_w) (void)hipFree(c.d_w);
     if (c.d_b) (void)hipFree(c.d_b);
     if (c.d_up4) (void)hipFree(c.d_up4);
+    if (c.d_up4p) (void)hipFree(c.d_up4p);
     if (c.d_b4) (void)hipFree(c.d_b4);
     if (c.d_fuse) (void)hipFree(c.d_fuse);
-    c.d_w = nullptr; c.d_b = nullptr; c.d_up4 = nullptr; c.d_b4 = nullptr; c.d_fuse = nullptr;
+    c.d_w = nullptr; c.d_b = nullptr; c.d_up4 = nullptr; c.d_up4p = nullptr; c.d_b4 = nullptr; c.d_fuse = nullptr;
 }
 
 static void free_device(innfer_ppon* p) {
@@ -268,6 +270,11 @@ int upload_conv3(innfer_ppon* p, Conv3& c, int role = 0) {       // role 1: the 
         INNFER_HIP(hipMalloc((void**)&c.d_b4, b4.size() * sizeof(float)));
         INNFER_HIP(hipMemcpy(c.d_up4, pk.data(), pk.size(), hipMemcpyHostToDevice));
         INNFER_HIP(hipMemcpy(c.d_b4, b4.data(), b4.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (c.K == 64 && c.C == 64) {
+            conv_pack_up2x_phases(w.data(), c.K, c.C, pk.data(), 1);
+            INNFER_HIP(hipMalloc(&c.d_up4p, pk.size()));
+            INNFER_HIP(hipMemcpy(c.d_up4p, pk.data(), pk.size(), hipMemcpyHostToDevice));
+        }
     }
     if (role == 2 && c.C == 64 && c.K <= 3) {
         std::vector<char> fp(4096);
@@ -673,8 +680,9 @@ extern "C" int innfer_ppon_forward(innfer_ppon* p, const void* d_in, int in_dtyp
             if (Hd.up[u].d_up4) {       // upconv_block as the four 2x2-tap phases of the equivalent transposed conv on the LR grid
                 ConvLaunch L{};
                 L.in = t; L.in_gstride = tg; L.C = Hd.up[u].C;
-                L.wpk = (const f16*)Hd.up[u].d_up4; L.bias = Hd.up[u].d_b4;
-                L.out = dst; L.out_gstride = go; L.K = 4 * Hd.up[u].K; L.phase_c = Hd.up[u].K; L.deconv_phases = 1;
+                const bool one_visit = Hd.up[u].d_up4p && w > 16;          // all four phases in one visit of a tile, plane-order panels (grids <= 16 wide: image pairs, one phase per visit)
+                L.wpk = (const f16*)(one_visit ? Hd.up[u].d_up4p : Hd.up[u].d_up4); L.bias = Hd.up[u].d_b4;
+                L.out = dst; L.out_gstride = go; L.K = 4 * Hd.up[u].K; L.phase_c = Hd.up[u].K; L.deconv_phases = one_visit ? 1 : 2; L.rowp = one_visit ? 1 : 0;
                 L.N = N; L.H = h; L.W = w; L.act = 1; L.s1 = L.s2 = 1.f; L.y0 = 0; L.y1 = h; L.out_mode = OUT_SLAB;
                 CK(conv_launch(L, s));
             } else {
