@@ -86,7 +86,7 @@ int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const float* h_alph
  * is kept as a PAIR of fp16 slabs (hi = fp16(x), lo = fp16((x - hi) * 2^11): 22 significant bits), every weight as a pair of panels, and a product is
  * xh wh + 2^-11 (xh wl + xl wh) on the fp16 matrix cores with fp32 accumulation; input fp32 or uint8, twice the workspace (ask innfer_net_workspace_bytes
  * after this call), three times the MFMA work.  Against the fp32 reference: <= 1e-4 on [0,1]-scaled outputs (measured ~1e-6).  Built for
- * RRDBNet / SRResNet (every constructor variant of innfer_*_create_ex); the other generators have no fp32 mode (their Python shells raise).  (106)
+ * RRDBNet / SRResNet (every constructor variant of innfer_*_create_ex); the other generators have their own fp32 mode (innfer_<api>_set_precision, 108).  (106)
  * A LOAD-TIME call: with fp32 = 1 it builds the split weight panels of every conv set so far (hipMalloc + synchronous copies; INNFER_ERR_NOMEM when they
  * do not fit) -- call it after the last innfer_net_set_conv and outside stream capture; innfer_net_forward itself never allocates. */
 int innfer_net_set_precision(innfer_net_t net, int fp32);

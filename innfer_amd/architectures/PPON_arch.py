@@ -29,6 +29,11 @@ class PPON(ParamEngineModule):
         if not x.is_cuda:
             raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
         self._check_dtype(x)
+        with torch.cuda.device(x.device):        # the library allocates and launches on the process's current HIP device
+            return self._forward_on_device(x)
+
+    def _forward_on_device(self, x):
+        self._claim_device(x.device)
         self._upload()
         L.check(L.lib.innfer_ppon_set_precision(self._handle, int(x.dtype == torch.float32)))      # the dtype IS the arithmetic (run.py:345,421-422)
         x = x.contiguous()

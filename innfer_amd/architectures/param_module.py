@@ -89,30 +89,55 @@ class ParamEngineModule(nn.Module):
     def release_workspace(self):
         self._ws = None
 
-    def tile_batch_bytes(self, b, ps, dtype=torch.float16):
+    def _home_device(self, device=None):
+        """Device for the calls that carry no tensor: the one asked for, else where the weights already are, else where the parameters are,
+        else the current device (EngineModule._home_device's rule)."""
+        if device is not None:
+            device = torch.device(device)
+            return device if device.index is not None else torch.device('cuda', torch.cuda.current_device())
+        if self._weights_device is not None:
+            return self._weights_device
+        for p in self.parameters():
+            if p.is_cuda:
+                return p.device
+            break
+        return torch.device('cuda', torch.cuda.current_device())
+
+    def _claim_device(self, device):
+        """The engine's device allocations (packed weights, fp32 panels) are made on the process's current HIP device by the first call that needs
+        them and stay there: record where, refuse another GPU (a size query used to upload on whatever device was current)."""
+        if self._weights_device is not None and self._weights_device != device:
+            raise NotImplementedError('this engine was first used on %s; build a second module for %s' % (self._weights_device, device))
+        self._weights_device = device
+
+    def tile_batch_bytes(self, b, ps, dtype=torch.float16, device=None):
         """Device bytes a forward of b tiles of ps x ps takes beyond the weights (workspace + input tiles + the output twice: the batch's result
-        and its copy in the tile buffer the blend reads); parallel.engine_tile_cap sizes the chop batches with it."""
+        and its copy in the tile buffer the blend reads); parallel.engine_tile_cap sizes the chop batches with it and names the GPU the tiles are
+        on.  Side effect: the engine is put into the precision `dtype` selects (innfer_<api>_set_precision -- its workspace differs per mode), which
+        in the fp32 mode uploads the weights and builds their fp32 panels; that happens under torch.cuda.device(device), like the forward that follows."""
         import math
         out = self._out_shape(1, ps, ps)
         n_out = getattr(self, '_n_outputs', 1)
         in_nc = getattr(self, 'in_nc', None) or getattr(self, 'input_nc', 3)
         elt = 4 if dtype == torch.float32 else 2
-        if self._has_fp32:
-            self._upload()
-            L.check(self._fn('set_precision')(self._handle, int(dtype == torch.float32)))
-        return self._fn('workspace_bytes')(self._handle, b, ps, ps) + b * (in_nc * ps * ps + (n_out + 1) * math.prod(out)) * elt
+        device = self._home_device(device)
+        with torch.cuda.device(device):
+            if self._has_fp32:
+                self._claim_device(device)
+                self._upload()
+                L.check(self._fn('set_precision')(self._handle, int(dtype == torch.float32)))
+            return self._fn('workspace_bytes')(self._handle, b, ps, ps) + b * (in_nc * ps * ps + (n_out + 1) * math.prod(out)) * elt
 
-    _has_fp32 = False                # subclasses whose engine has an fp32 mode (innfer_<api>_set_precision): UNet, PAN
+    _has_fp32 = False                # engines with an fp32 mode (innfer_<api>_set_precision): every shipped one (UNet, PAN, PPON, CycleGAN ResNet, WBC UNet)
 
     def _check_dtype(self, x):
-        """The input's dtype is the arithmetic the caller asks for (the reference: model.half() / t_img.half(), run.py:345,383,421-422).  These
-        engines compute in fp16 with fp32 accumulation and nothing else: a float32 tensor is refused rather than served at fp16 accuracy."""
+        """The input's dtype is the arithmetic the caller asks for (the reference: model.half() / t_img.half(), run.py:345,383,421-422): float16
+        tensors run the fp16 engine, float32 tensors the engine's fp32 mode (csrc/f32ops.hip).  Every shipped generator has both; the refusal below
+        is for a future engine that is built fp16-only -- it must not serve fp16 accuracy under -no_fp16."""
         if x.dtype == torch.float32 and self._has_fp32:
             return                       # float32 tensors run the engine's fp32 mode (the reference's -no_fp16: run.py:345,421-422)
         if x.dtype == torch.float32:
-            raise NotImplementedError(
-                f"{type(self).__name__}: no fp32-accurate engine is built for this generator -- its kernels compute in fp16 (fp32 accumulation).  Pass "
-                "x.half() (the reference's default mode, run.py:345,421-422) and call .float() on the result; RRDBNet / SRResNet take float32 tensors.")
+            raise NotImplementedError(f"{type(self).__name__}: this engine has no fp32 mode; pass x.half() (the reference's default mode, run.py:345,421-422)")
         if x.dtype != torch.float16:
             raise TypeError(f'unsupported dtype {x.dtype}')
 
@@ -126,10 +151,8 @@ class ParamEngineModule(nn.Module):
             return self._forward_on_device(x)
 
     def _forward_on_device(self, x):
-        if self._weights_device is not None and self._weights_device != x.device:
-            raise NotImplementedError('this engine was first used on %s; build a second module for %s' % (self._weights_device, x.device))
+        self._claim_device(x.device)
         self._upload()
-        self._weights_device = x.device
         if self._has_fp32:               # the input's dtype IS the arithmetic, as model.half() / t_img.half() are in the reference
             L.check(self._fn('set_precision')(self._handle, int(x.dtype == torch.float32)))
         x = x.contiguous()

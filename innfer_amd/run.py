@@ -333,8 +333,8 @@ def main(argv=None):
     model_chain, scale_chain = parse_models(args.models)
     models = [Model(mc, args.arch, sc, device=device, meval=meval, strict=strict, chop=chop) for mc, sc in zip(model_chain, scale_chain)]
     if not fp16:
-        # -no_fp16 = fp32 arithmetic on the GPU (run.py:345,421-422).  RRDBNet / SRResNet have an fp32-accurate engine, PAN and the pix2pix UNet an fp32 mode
-        # (float32 tensors select them); the other generators compute in fp16 only and refuse instead of handing out fp16 accuracy under the flag.
+        # -no_fp16 = fp32 arithmetic on the GPU (run.py:345,421-422).  RRDBNet / SRResNet have an fp32-accurate engine, every other shipped generator an fp32
+        # mode (float32 tensors select them).  The check stays for an engine built fp16-only: it must refuse, not hand out fp16 accuracy under the flag.
         from .architectures.engine_module import EngineModule
         for m in models:
             if not isinstance(m.model, EngineModule) and not getattr(m.model, '_has_fp32', False):

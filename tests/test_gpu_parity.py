@@ -779,7 +779,7 @@ def test_unet_instance_norm_and_dropout_variants_golden(dev, golden):
         net = net.to(dev)
         net = net.eval() if ev else net.train()
         x = torch.from_numpy(synth.uniform((1, 3, 64, 96), 240 + i, -1.0, 1.0)).to(dev)
-        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
+        for xin in (x.half(),):          # (float32 tensors run the engine's fp32 mode: test_gpu_fp32_mode.py)
             err = np.abs(net(xin).float().cpu().numpy() - g[tag])
             assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
         if kw.get("use_dropout"):
@@ -1243,7 +1243,7 @@ def test_ppon_scales_golden(dev, golden):
         net.load_state_dict(_sd(shapes, 340 + j), strict=True)
         net = net.to(dev).eval()
         x = torch.from_numpy(synth.uniform((1, 3, 10, 12), 350 + j)).to(dev)
-        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
+        for xin in (x.half(),):          # (float32 tensors run the engine's fp32 mode: test_gpu_fp32_mode.py)
             outs = net(xin)
             for name, y in zip("csp", outs):
                 ref = g[f"x{sc}_{name}"].astype(np.float32)
@@ -1268,7 +1268,7 @@ def test_ppon_golden(dev, golden):
     net = net.to(dev).eval()
     for (h, w, seed) in [(24, 24, 13), (20, 28, 14)]:
         x = torch.from_numpy(synth.uniform((1, 3, h, w), seed)).to(dev)
-        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
+        for xin in (x.half(),):          # (float32 tensors run the engine's fp32 mode: test_gpu_fp32_mode.py)
             outs = net(xin)
             assert len(outs) == 3
             for name, y in zip("csp", outs):
@@ -1304,7 +1304,7 @@ def test_cyclegan_resnet9_golden(dev, golden):
     for (h, w, seed) in [(32, 40, 15), (64, 64, 16)]:
         x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0)).to(dev)
         ref = g[f"out_{h}x{w}"].astype(np.float32)
-        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
+        for xin in (x.half(),):          # (float32 tensors run the engine's fp32 mode: test_gpu_fp32_mode.py)
             y = net(xin).float().cpu().numpy()
             err = np.abs(y - ref)
             assert np.isfinite(y).all() and np.abs(y).max() <= 1.0
@@ -1344,7 +1344,7 @@ def test_cyclegan_resnet_padding_and_dropout_variants_golden(dev, golden):
         net = net.to(dev)
         net = net.train() if train else net.eval()
         x = torch.from_numpy(synth.uniform((1, 3, 32, 40), 225 + i, -1.0, 1.0)).to(dev)
-        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
+        for xin in (x.half(),):          # (float32 tensors run the engine's fp32 mode: test_gpu_fp32_mode.py)
             err = np.abs(net(xin).float().cpu().numpy() - g[tag])
             assert err.max() < 1e-2 and err.mean() < 2e-3, (tag, err.max(), err.mean())
     with pytest.raises(NotImplementedError):
@@ -1396,7 +1396,7 @@ def test_wbcunet_and_guided_filter_golden(dev, golden):
     for (h, w, seed) in [(32, 40, 17), (64, 64, 18)]:
         x = torch.from_numpy(synth.uniform((1, 3, h, w), seed, -1.0, 1.0)).to(dev)
         ref, ref_gf = g[f"out_{h}x{w}"].astype(np.float32), g[f"gf_{h}x{w}"].astype(np.float32)
-        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
+        for xin in (x.half(),):          # (float32 tensors run the engine's fp32 mode: test_gpu_fp32_mode.py)
             y = net(xin)
             err = np.abs(y.float().cpu().numpy() - ref)
             assert err.max() < 5e-3 and err.mean() < 5e-4, (h, w, err.max(), err.mean())
@@ -1437,7 +1437,7 @@ def test_pan_golden(dev, golden):
     for (h, w, seed) in [(48, 48, 8), (50, 70, 9)]:
         x = torch.from_numpy(synth.uniform((1, 3, h, w), seed)).to(dev)
         ref = g[f"out_{h}x{w}"].astype(np.float32)
-        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
+        for xin in (x.half(),):          # (float32 tensors run the engine's fp32 mode: test_gpu_fp32_mode.py)
             y = net(xin).float().cpu().numpy()
             err = np.abs(y - ref)
             assert y.shape == ref.shape and np.isfinite(y).all()
@@ -1505,7 +1505,7 @@ def test_pan_constructor_variants_golden(dev, golden):
         net = net.to(dev).eval()
         x = torch.from_numpy(synth.uniform((1, 3, 20, 28), 195 + i)).to(dev)
         ref = g[tag].astype(np.float32)
-        for xin in (x.half(),):          # (float32 tensors are refused: no fp32-accurate engine for this generator, test_gpu_fp32_mode.py)
+        for xin in (x.half(),):          # (float32 tensors run the engine's fp32 mode: test_gpu_fp32_mode.py)
             y = net(xin).float().cpu().numpy()
             err = np.abs(y - ref)
             assert y.shape == ref.shape and err.max() < 1e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 1.5e-3, (tag, err.max(), err.mean())
