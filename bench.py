@@ -29,6 +29,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   chop8k       : BASELINE config 3 (8K input through chop_forward, 3268 tiles) -- 1 warm-up + 1 timed pass on the same ranks
   unet64       : BASELINE config 5 (pix2pix UNet_256 on 64x3x256x256), N == 1 only
   pan540       : PAN 4x on a 1x3x540x960 frame (north_star's third conv stack), N == 1 only
+  srresnet1080 : SRResNet-16 4x on the 1080p frame (north_star's second conv stack), N == 1 only
 """
 import argparse
 import ctypes as C
@@ -124,7 +125,7 @@ def two_roofs(flops, nbytes, ms):
     t = ms * 1e-3
     t_mfma, t_hbm = flops / (PEAK_F16_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
     return {"tflops": round(flops / t / 1e12, 2), "gbs": round(nbytes / t / 1e9, 1),
-            "frac_mfma": round(t_mfma / t, 4), "frac_hbm": round(t_hbm / t, 4),
+            "frac_mfma": round(t_mfma / t, 4), "frac_hbm": round(t_hbm / t, 4), "frac_binding": round(max(t_mfma, t_hbm) / t, 4),
             "bound": "mfma" if t_mfma >= t_hbm else "hbm", "flop_per_byte": round(flops / nbytes, 1)}
 
 
@@ -143,14 +144,19 @@ def roofline_from_launches(launches):
         for suffix, note in KIND_NOTES.items():
             if kind_name(k).endswith(suffix):
                 e["note"] = note
+        if kind_name(k).endswith("+upconv_phases"):          # the matrix pipe executes 4/9 of the nine-tap layer's algorithmic FLOPs
+            e["frac_mfma_executed"] = round(e["frac_mfma"] * 4.0 / 9.0, 4)
         per_kernel[kind_name(k)] = e
     total_ms = sum(v[0] for v in agg.values())
     total_fl = sum(v[1] for v in agg.values())
     # the contract's roof for this path is the MFMA one (north_star ">= 0.5x MFMA roofline"): `bound` / `achieved` / `peak` / `frac`
-    # are quoted against it for the dominant kernel; `binding_roof` is the two-roof rule's answer for the same launches (the larger floor)
+    # are quoted against it for the dominant kernel -- `frac` = `frac_mfma_algorithmic` = algorithmic FLOPs / time / the 2.4 GHz dense peak, NOT a
+    # utilisation of the binding resource; `binding_roof` is the two-roof rule's answer for the same launches (the larger floor) and `frac_binding`
+    # the fraction against THAT roof (both under explicit names)
     out = {"bound": "mfma", "kernel": kind_name(dom), "launches": cnt, "avg_launch_ms": round(t_ms / cnt, 5),
            "flops_per_launch": flops / cnt, "bytes_per_launch": nbytes / cnt,
-           "achieved": r["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": r["frac_mfma"], "binding_roof": r["bound"]}
+           "achieved": r["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": r["frac_mfma"], "frac_mfma_algorithmic": r["frac_mfma"],
+           "binding_roof": r["bound"], "frac_binding": r["frac_binding"]}
     out.update({"frac_mfma": r["frac_mfma"], "frac_hbm": r["frac_hbm"], "tflops": r["tflops"], "gbs": r["gbs"],
                 "flop_per_byte": r["flop_per_byte"], "ridge_flop_per_byte": round(PEAK_F16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
                 "traffic": pmc_traffic(dom),
@@ -373,6 +379,51 @@ def pan540_object(dev, reps=20, windows=7, warm_s=0.5):
     return out
 
 
+def srresnet1080_object(dev, reps=10, windows=7, warm_s=0.5):
+    """SURVEY 8a row a11 / north_star "RRDB/SRResNet/PAN stacks": SRResNet-16 4x as utils/defaults.py:53-67 builds it (no norm, ReLU, CNA, pixelshuffle,
+    res_scale 1; SRResNet_arch.py:15-91) on one 1 x 3 x 1080 x 1920 frame, fp16, synthetic weights, un-tiled.  Timed like unet64 (warm-up by time, median
+    of `windows` windows of `reps` forwards between HIP events); per-kernel two-roof entries from innfer_net_forward_timed (the RRDBNet engine's timer).
+    Algorithmic work 2 572 992 MAC per input pixel (probed) = net.flops()."""
+    import torch
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config("srgan", 4))
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    H, W = 1080, 1920
+    x = torch.from_numpy(synth.uniform((1, 3, H, W), 3)).to(dev).half()
+    n_warm, t0 = 0, time.perf_counter()
+    while n_warm < 10 or time.perf_counter() - t0 < warm_s:
+        for _ in range(5):
+            net(x)
+        torch.cuda.synchronize()
+        n_warm += 5
+    win = []
+    for _ in range(windows):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            net(x)
+        e1.record()
+        torch.cuda.synchronize()
+        win.append(e0.elapsed_time(e1) / reps)
+    ms = sorted(win)[len(win) // 2]
+    fl = net.flops(1, H, W)
+    out = {"workload": "SRResNet-16 4x (nf 64, no norm, ReLU, CNA, pixelshuffle: utils/defaults.py:53-67), 1x3x1080x1920 -> 1x3x4320x7680 fp16, un-tiled (SURVEY 8a row a11)",
+           "steps": reps, "windows": windows, "warmup": n_warm, "ms_per_step": round(ms, 4), "ms_per_step_min": round(min(win), 4), "ms_per_step_max": round(max(win), 4),
+           "value": round(16 * H * W / ms / 1e3, 1), "unit": "output MPix/s", "model_tflops": round(fl / ms / 1e9, 1),
+           "frac_of_mfma_peak": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4), "pair_convs": int(getattr(net, "pair_convs", 0))}
+    timed_forward(net, x)
+    r = roofline_from_launches(timed_forward(net, x))
+    out["hip_event_sum_ms"] = round(sum(e["ms_total"] for e in r["per_kernel"].values()), 4)
+    out["dominant_kernel"] = {k: r[k] for k in ("kernel", "launches", "avg_launch_ms", "tflops", "gbs", "frac_mfma", "frac_hbm", "binding_roof", "frac_binding")}
+    out["per_kernel"] = r["per_kernel"]
+    net.release_workspace()
+    return out
+
+
 def unet_per_kernel(net, x):
     """Per-kernel two-roof entries of one UNet forward from the library's launch timer (innfer_timer_*), or None when the library has none."""
     import innfer_amd.lib as L
@@ -501,7 +552,8 @@ def main():
     ap.add_argument("--pair-convs", type=int, default=0, choices=[0, 1, 2],
                     help="innfer_net_set_pair_convs: 0 one launch per layer (default), 1 fused conv pairs on single-image forwards, 2 always")
     ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch (0 = innfer_amd.parallel.tile_batches: evenly sized launches of <= 272 tiles)")
-    ap.add_argument("--sharded-steps", type=int, default=2, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip")
+    ap.add_argument("--sharded-steps", type=int, default=-1, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip; default 2 on one GPU, 5 on N > 1 "
+                    "(the strong-scaling table of the first multi-GPU run comes from these objects: VERDICT r4 item 6a)")
     ap.add_argument("--fp32", action="store_true", help="frame workloads: a float32 frame = the fp32-accurate engine (the reference's -no_fp16 mode); no roofline object")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: HR_conv0 and conv_last as two launches (innfer_net_set_fused_tail 0)")
     ap.add_argument("--no-upconv-phases", action="store_true", help="A/B: the up-convs as nine taps on the HR grid (innfer_net_set_upconv_phases 0)")
@@ -525,6 +577,8 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.sharded_steps < 0:
+        args.sharded_steps = 5 if world > 1 else 2
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"--gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}")
@@ -678,6 +732,15 @@ def main():
     net.release_workspace()
     torch.cuda.empty_cache()
 
+    def gather_phases(phases):
+        """[rank][stage] -> {tiles, compute_ms, exchange_ms, blend_ms, bcast_ms, ...} of the profiled pass, from every rank (rank 0 keeps the list)."""
+        mine = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in p.items()} for p in phases]
+        if world == 1:
+            return [mine]
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        return box
+
     # ---- BASELINE config 4 on the same ranks: chain 1x + 4x, 4K input, tile list sharded, RCCL exchange ----
     if args.sharded_steps > 0 and args.workload != "chain4k":
         log('tile-sharded chain4k')
@@ -688,6 +751,7 @@ def main():
         cstep()
         sync()
         phases = [dict(r.last) for r in runners]
+        all_phases = gather_phases(phases)
         if world > 1:
             barrier()
         if rank == 0:
@@ -702,6 +766,7 @@ def main():
                 "model_tflops": round(tf / (ms * 1e-3), 1),
                 "frac_of_mfma_peak_all_gpus": round(tf / (ms * 1e-3) / (PEAK_F16_TFLOPS * world), 4),
                 "rank0_phases_ms": [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in p.items()} for p in phases],
+                "per_rank_phases_ms": all_phases,
                 "exchange_bytes_into_rank0": sum(p.get("exchange_bytes", 0) for p in phases),
                 "exchange_ms": round(sum(p.get("exchange_ms", 0.0) for p in phases), 2)}
         del cstep, runners
@@ -709,15 +774,24 @@ def main():
 
     # ---- BASELINE config 3 on the same ranks: 8K input through chop_forward (3268 tiles), one warm-up + one timed pass ----
     def chop8k_object():
+        ksteps = 5 if world > 1 else 1
         kstep, kH, kW, kwhat, krunners = chop_setup("chop8k")
-        kwall = timed_steps(kstep, 1, 1, world, sync, barrier, max_over_ranks)
+        kwall = timed_steps(kstep, ksteps, 1, world, sync, barrier, max_over_ranks) / ksteps
+        kphases = None
+        if world > 1:                               # one more pass with a synchronise around every phase, every rank reporting (never timed)
+            for r in krunners:
+                r.profile = True
+            kstep()
+            sync()
+            kphases = gather_phases([dict(r.last) for r in krunners])
+            barrier()
         out = None
         if rank == 0:
             kfl, ntile = chop_flops(krunners, kH, kW)           # 4686.8 TFLOP (the redundant tile FLOPs of the reference's tiling count)
             out = {
                 "workload": f"{kwhat} fp16, {kH}x{kW} input through chop_forward, {ntile} tiles of 200^2 (BASELINE config 3), tile list sharded over "
                             f"{world} rank(s), blend on rank 0" + tag,
-                "steps": 1, "warmup": 1, "s_per_frame": round(kwall, 3), "value": round(16 * kH * kW / kwall / 1e6, 2), "unit": "unique-output MPix/s",
+                "steps": ksteps, "warmup": 1, "per_rank_phases_ms": kphases, "s_per_frame": round(kwall, 3), "value": round(16 * kH * kW / kwall / 1e6, 2), "unit": "unique-output MPix/s",
                 "model_tflops": round(kfl / kwall / 1e12, 1), "frac_of_mfma_peak_all_gpus": round(kfl / kwall / 1e12 / (PEAK_F16_TFLOPS * world), 4),
                 "tile_batches": parallel.tile_batches(parallel.shard_tiles(ntile, world, 0)[1], args.tile_batch or None,
                                                       parallel.engine_tile_cap(net, 200, torch.float16, dev))}
@@ -753,6 +827,14 @@ def main():
             line["pan540"] = pan540_object(dev)
         except Exception as e:                      # a side object must never cost the headline line
             line["pan540"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # ---- north_star's second stack: SRResNet-16 4x on the 1080p frame (one GPU) ----
+    if not args.no_extras and world == 1:
+        log('srresnet1080')
+        try:
+            line["srresnet1080"] = srresnet1080_object(dev)
+        except Exception as e:                      # a side object must never cost the headline line
+            line["srresnet1080"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         if not args.no_cpu_baseline:

@@ -45,8 +45,8 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 109
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works).  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 110
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -88,7 +88,8 @@ int innfer_net_set_conv_input_map(innfer_net_t net, int idx, const float* h_alph
  * after this call), three times the MFMA work.  Against the fp32 reference: <= 1e-4 on [0,1]-scaled outputs (measured ~1e-6).  Built for
  * RRDBNet / SRResNet (every constructor variant of innfer_*_create_ex); the other generators have their own fp32 mode (innfer_<api>_set_precision, 108).  (106)
  * A LOAD-TIME call: with fp32 = 1 it builds the split weight panels of every conv set so far (hipMalloc + synchronous copies; INNFER_ERR_NOMEM when they
- * do not fit) -- call it after the last innfer_net_set_conv and outside stream capture; innfer_net_forward itself never allocates. */
+ * do not fit -- the panels this call had built are released again) -- outside stream capture; innfer_net_forward itself never allocates.  Either call
+ * order works: an innfer_net_set_conv on a network that is already in the fp32 mode builds that conv's panels itself (110). */
 int innfer_net_set_precision(innfer_net_t net, int fp32);
 
 void innfer_net_destroy(innfer_net_t net);

@@ -26,10 +26,10 @@ class PAN(ParamEngineModule):
     fused_scpa = True        # innfer_pan_set_fused_scpa: 1 / True = an SCPA block as one launch (csrc/pan_scpa.hip) + the FSA attention on the matrix cores; 0 / False: the
                              # five-launch blocks and the VALU attention of rounds 1-3; 2: the fused blocks with the VALU attention (A/B, parity tests)
 
-    def _forward_on_device(self, x):
+    def _forward_on_device(self, x, out=None):
         from .. import lib as L
         L.check(L.lib.innfer_pan_set_fused_scpa(self._handle, int(self.fused_scpa)))
-        return super()._forward_on_device(x)
+        return super()._forward_on_device(x, out)
 
     def _out_shape(self, N, H, W):
         return (N, self.out_nc, H * self.scale, W * self.scale)

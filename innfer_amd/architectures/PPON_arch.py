@@ -12,6 +12,7 @@ class PPON(ParamEngineModule):
     _api = 'ppon'
     _has_fp32 = True         # float32 tensors: innfer_ppon_set_precision(1), the fp32 forward (csrc/f32ops.hip)
     _n_outputs = 3
+    _accepts_out = False     # three results per forward: chop batches are copied into the tile buffer (run.py keeps the last)
 
     def _out_shape(self, N, H, W):
         return (N, self.out_nc, H * self.scale, W * self.scale)

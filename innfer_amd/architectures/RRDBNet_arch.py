@@ -90,10 +90,10 @@ class RRDBNet(EngineModule):
         b = ((0.0 if b is None else b.astype(np.float64)) - mean) * a + beta
         return w, b.astype(np.float32)
 
-    def forward(self, x, outm=None):
+    def forward(self, x, outm=None, out=None):
         if self.norm and self.training:
             raise NotImplementedError("RRDBNet(norm_type='batch') in train mode normalises with batch statistics; the engine folds the eval-mode BatchNorm (net.eval())")
-        return super().forward(x, outm)
+        return super().forward(x, outm, out)
 
     def _create_handle(self):
         h = C.c_void_p()

@@ -30,12 +30,12 @@ class ResnetGenerator(ParamEngineModule):
     def _fn(self, name):
         return super()._fn('create_ex' if name == 'create' else name)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         if self.use_dropout and self.training:
             raise NotImplementedError('ResnetGenerator(use_dropout=True) in train mode draws random masks; the engine runs the eval-mode graph (net.eval())')
         from .. import lib as L
         L.check(L.lib.innfer_resnet_set_eval(self._handle, int(not self.training)))       # BatchNorm follows the module's mode like nn.BatchNorm2d
-        return super().forward(x)
+        return super().forward(x, out)
 
     def _out_shape(self, N, H, W):
         return (N, self.output_nc, H, W)

@@ -81,10 +81,10 @@ class SRResNet(EngineModule):
                 a, sh = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(sh, np.float32)
                 L.check(L.lib.innfer_net_set_conv_input_map(self._handle, i, a.ctypes.data, sh.ctypes.data, act))
 
-    def forward(self, x, outm=None):
+    def forward(self, x, outm=None, out=None):
         if self.norm and self.training:
             raise NotImplementedError("SRResNet(norm_type='batch') in train mode normalises with batch statistics; the engine runs the eval-mode BatchNorm (net.eval())")
-        return super().forward(x, outm)
+        return super().forward(x, outm, out)
 
     def _create_handle(self):
         h = C.c_void_p()

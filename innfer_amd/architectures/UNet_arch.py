@@ -32,11 +32,11 @@ class UnetGenerator(ParamEngineModule):
     def _out_shape(self, N, H, W):
         return (N, self.output_nc, H, W)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         if self.use_dropout and self.training:
             raise NotImplementedError('UnetGenerator(use_dropout=True) in train mode draws random masks; the engine runs the eval-mode graph (net.eval())')
         L.check(L.lib.innfer_unet_set_eval(self._handle, int(not self.training)))
-        return super().forward(x)
+        return super().forward(x, out)
 
     def flops(self, N, H, W):
         return L.lib.innfer_unet_flops(self._handle, N, H, W)

@@ -18,6 +18,16 @@ class _Node(nn.Module):
     """Anonymous container used to spell dotted key paths ("model.1.sub.0...")."""
 
 
+def _result_tensor(out, shape, x):
+    """The tensor a forward writes: a fresh one, or the caller's `out` when it is exactly what a fresh one would be."""
+    if out is None:
+        return torch.empty(shape, dtype=x.dtype, device=x.device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != x.dtype or out.device != x.device or not out.is_contiguous():
+        raise ValueError(f'out= must be a contiguous {tuple(shape)} {x.dtype} tensor on {x.device}; got {tuple(out.shape)} {out.dtype} on {out.device}'
+                         f'{"" if out.is_contiguous() else ", not contiguous"}')
+    return out
+
+
 class EngineModule(nn.Module):
     def __init__(self, shapes):
         super().__init__()
@@ -127,8 +137,11 @@ class EngineModule(nn.Module):
     # ---- forward ---------------------------------------------------------------
     _OUTM = {None: 0, 'scaltanh': 1, 'tanh': 2, 'sigmoid': 3, 'clamp': 4}
 
-    def forward(self, x, outm=None):
+    _accepts_out = True              # forward(x, out=...) writes its result into a caller's tensor (parallel.run_tile_batches lands chop batches in the tile buffer)
+
+    def forward(self, x, outm=None, out=None):
         """outm: the range limiter of RRDBNet.forward / SRResNet.forward (RRDBNet_arch.py:50-62); any other value means none, as there.
+        out: optional contiguous [N, out_nc, s*H, s*W] tensor of x's dtype on x's device that receives the result (and is returned) instead of a fresh one.
         The input's dtype selects the arithmetic, as `model.half()` / `t_img.half()` do in the reference (run.py:345,383,421-422): a float16 tensor
         runs the fp16 engine, a float32 tensor the fp32-accurate one (innfer_net_set_precision: <= 1e-4 against the fp32 reference, 3x the MFMA work)."""
         self._outm = self._OUTM.get(outm, 0)
@@ -143,7 +156,7 @@ class EngineModule(nn.Module):
         # the library allocates and launches on the process's CURRENT HIP device: make that the input's for the whole call
         # (weights packed for another GPU are re-uploaded)
         with torch.cuda.device(x.device):
-            return self._forward_on_device(x)
+            return self._forward_on_device(x, out)
 
     def _engine_on(self, device):
         """The engine with its packed weights on `device`.  Call with `device` as the process's current HIP device (torch.cuda.device): the
@@ -172,7 +185,7 @@ class EngineModule(nn.Module):
             break
         return torch.device('cuda', torch.cuda.current_device())
 
-    def _forward_on_device(self, x):
+    def _forward_on_device(self, x, out=None):
         self._engine_on(x.device)
         L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
         L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
@@ -184,7 +197,7 @@ class EngineModule(nn.Module):
         x = x.contiguous()
         N, _, H, W = x.shape
         s = L.lib.innfer_net_scale(self._handle)
-        out = torch.empty((N, self.out_nc, H * s, W * s), dtype=x.dtype, device=x.device)
+        out = _result_tensor(out, (N, self.out_nc, H * s, W * s), x)
         need = L.lib.innfer_net_workspace_bytes(self._handle, N, H, W)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
             self._ws = None
@@ -247,6 +260,14 @@ class EngineModule(nn.Module):
             elt = 4 if dtype == torch.float32 else 2
             s = L.lib.innfer_net_scale(self._handle)
             return L.lib.innfer_net_workspace_bytes(self._handle, b, ps, ps) + b * (self.in_nc * ps * ps + 2 * self.out_nc * (ps * s) ** 2) * elt
+
+    def _out_shape(self, N, H, W, device=None):
+        """Shape of forward's result for an [N, in_nc, H, W] input (the scale is the engine's)."""
+        device = self._home_device(device)
+        with torch.cuda.device(device):
+            self._engine_on(device)
+            s = L.lib.innfer_net_scale(self._handle)
+        return (N, self.out_nc, H * s, W * s)
 
     def flops(self, N, H, W, device=None):
         device = self._home_device(device)

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from .. import lib as L
-from .engine_module import _Node
+from .engine_module import _Node, _result_tensor
 
 
 class ParamEngineModule(nn.Module):
@@ -141,23 +141,25 @@ class ParamEngineModule(nn.Module):
         if x.dtype != torch.float16:
             raise TypeError(f'unsupported dtype {x.dtype}')
 
-    def forward(self, x):
+    _accepts_out = True              # forward(x, out=...): see EngineModule
+
+    def forward(self, x, out=None):
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise ValueError('expected a 4D [N,C,H,W] tensor')
         if not x.is_cuda:
             raise RuntimeError('innfer_amd runs its forward on an MI355X only: there is no CPU path')
         self._check_dtype(x)
         with torch.cuda.device(x.device):        # the library allocates and launches on the process's current HIP device
-            return self._forward_on_device(x)
+            return self._forward_on_device(x, out)
 
-    def _forward_on_device(self, x):
+    def _forward_on_device(self, x, out=None):
         self._claim_device(x.device)
         self._upload()
         if self._has_fp32:               # the input's dtype IS the arithmetic, as model.half() / t_img.half() are in the reference
             L.check(self._fn('set_precision')(self._handle, int(x.dtype == torch.float32)))
         x = x.contiguous()
         N, _, H, W = x.shape
-        out = torch.empty(self._out_shape(N, H, W), dtype=x.dtype, device=x.device)
+        out = _result_tensor(out, self._out_shape(N, H, W), x)
         need = self._fn('workspace_bytes')(self._handle, N, H, W)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
             self._ws = None

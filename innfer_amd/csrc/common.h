@@ -188,6 +188,10 @@ struct F32Conv {
     const float* res; long res_nstride, res_cstride;                    // + residual after the activation (same pixel indexing as `out` with ps 1)
     const float* mul; long mul_nstride, mul_cstride;                    // v = mul * sigmoid(conv + bias) before the activation (pixel attention)
     int N;
+    int phase_k;                                                        // > 0: the four output phases of a stride-2 transposed conv in ONE launch -- K = 4 * phase_k, channel k' is phase
+                                                                        // k' / phase_k (a, b) = (ph >> 1, ph & 1) of output channel k' % phase_k at pixel (2 oy + a, 2 ox + b); bias / res / mul
+                                                                        // are indexed by the output channel.  Pays where 4 * phase_k fits the 16-channel tile a single phase would take anyway
+                                                                        // (the UNet's outermost layer, 3 channels): the input is read once instead of four times.  osy = osx = 1, oo* = 0.
 };
 size_t f32conv_packed_floats(int K, int C, int ntap);
 void f32conv_pack(int K, int C, int ntap, const std::function<float(int, int, int)>& w, float* packed);     // host; w(k, c, tap)

@@ -13,6 +13,8 @@
 //   * zero padding = the validity test of a tap; input views with a channel offset / stride: torch.cat is an offset, never a copy
 //   epilogue: v = acc + bias; v = mul * sigmoid(v) (pixel attention, PAN_arch.py:21-55); activation; + residual; stored through an output view
 // GEMM view: rows = 16 output channels (A = weights), columns = 16 consecutive output pixels (B = gathered input), reduction = (tap, 4 channels) per MFMA.
+#include <atomic>
+#include <algorithm>
 #include "common.h"
 
 namespace innfer {
@@ -92,13 +94,19 @@ __global__ __launch_bounds__(256) void f32conv_kernel(const F32Conv p, int kt_pe
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
         if (!pv[pt]) continue;
-        const long opix = ((long)(oy[pt] * p.osy + p.ooy) * p.Wout + ox[pt] * p.osx + p.oox);
+        const long opix0 = ((long)(oy[pt] * p.osy + p.ooy) * p.Wout + ox[pt] * p.osx + p.oox);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 16 * t + 4 * lg + j;
+                int k = k0 + 16 * t + 4 * lg + j;
                 if (k >= p.K) continue;
+                long opix = opix0;
+                if (p.phase_k > 0) {                       // fused phases: channel k is phase ph of output channel k % phase_k
+                    const int ph = k / p.phase_k;
+                    k -= ph * p.phase_k;
+                    opix = (long)(2 * oy[pt] + (ph >> 1)) * p.Wout + 2 * ox[pt] + (ph & 1);
+                }
                 float v = acc[t][pt][j] + (p.bias ? p.bias[k] : 0.f);
                 if (p.mul) v = p.mul[(long)n * p.mul_nstride + (long)k * p.mul_cstride + opix] * (1.0f / (1.0f + expf(-v)));
                 v = f32_act(v, p.act);
@@ -107,6 +115,231 @@ __global__ __launch_bounds__(256) void f32conv_kernel(const F32Conv p, int kt_pe
                 p.out[(long)n * p.out_nstride + (long)k * p.out_cstride + opix * p.out_pstride] = v;
             }
     }
+}
+
+// ---- LDS-tiled form (round 5) ------------------------------------------------------------------------------------------------
+// The kernel above reads every MFMA operand with a scalar global load behind per-lane bounds tests (0.12 of the fp32 matrix peak).  Here a workgroup owns
+// KT = 16 NKT output channels x 256 output pixels -- TY x TX pixels of IMG images, TY TX IMG = 256: 8 x 32 of one image down to 1 x 1 of 256 images, so the
+// UNet's 8 x 8 .. 1 x 1 levels fill their pixel tiles with the batch -- and walks the input channels in chunks of CC:
+//   patch    every source pixel a tap of the tile reads (PH x PW per channel and image) with the padding mode, the nearest-2x view and the input activation
+//            resolved as it is written.  A thread's (at most NE) elements of a chunk have chunk-invariant offsets, derived once per tile; the NEXT chunk's values
+//            are loaded into registers before the current chunk's MFMAs issue and written to LDS after them: HBM latency hides behind a whole compute phase
+//            (the first version staged load -> wait -> write per chunk and ran at 1.0x of the direct kernel: latency-bound; profiles/r5/fp32_modes.txt);
+//   weights  the chunk's rows [tap][c4][KT][4] by LDS-DMA (one 1-KB piece per row, range-checked zero fill beyond the panel) into the OTHER of two LDS
+//            buffers, in flight during the same compute phase;
+//   compute  wave w: its 4 pixel tiles (16 pixels each) x NKT channel tiles, per (tap, 4 channels) NKT + 4 ds_read_b32 for 4 NKT MFMAs, fragments of the
+//            next step fetched before the current step's MFMAs issue.
+// Same panels, same epilogue, same F32Conv views as the direct kernel; the sums run in another order (chunk-major instead of tap-major): fp32 round-off,
+// inside the 1e-4 bound of the mode by two orders of magnitude.
+struct F32Tile {
+    int C4, Kp;                  // panel geometry (f32conv_pack)
+    unsigned wbytes;             // panel bytes: the weight DMA's range check
+    int dymin, dxmin;            // smallest tap displacement: patch row 0 / column 0 of tile (ty0, tx0) is source (ty0 * isy + dymin, tx0 * isx + dxmin)
+    int PH, PW, plane, PS;       // patch rows, columns, floats per channel (IMG PH PW), floats between channel planes (padded: bank spread of the four k lanes)
+    float rplane, rimg, rpw;     // reciprocals for the per-tile element decode
+    int CC;                      // input channels per chunk (multiple of 4)
+    int txs, tys, imgs;          // log2 TX, log2 TY, log2 IMG; TX TY IMG <= 256 (fewer: the last waves' pixel tiles are empty)
+    int tiles_x, nkg;            // tile columns; channel groups of KT
+};
+
+constexpr int F32_NE = 21;       // patch elements per thread and chunk: CC * plane <= 256 * NE
+
+__device__ __forceinline__ int f32_fastdiv(int e, int d, float rd) {      // floor(e / d) for 0 <= e < 2^21 (rd = 1 / d): (e + 0.5) / d lies >= 0.5 / d from an integer
+    (void)d;
+    return (int)(((float)e + 0.5f) * rd);
+}
+
+// NPT: pixel tiles (16 pixels) per wave -- 4: a 256-pixel tile; 1: a 64-pixel tile for the grids whose tiles hold at most 64 live pixels (the UNet's <= 8 x 8
+// levels): the same walk without the MFMAs of empty pixel tiles (a run-time skip of them cost the big layers 40 %: see below)
+template <int NKT, int NPT>
+__global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32Tile t) {
+    extern __shared__ __attribute__((aligned(16))) float f32lds[];
+    constexpr int NE = F32_NE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+    const int kg = blockIdx.x % t.nkg, tile = blockIdx.x / t.nkg;
+    const int tyi = tile / t.tiles_x, txi = tile - tyi * t.tiles_x;
+    const int TXm = (1 << t.txs) - 1, TYm = (1 << t.tys) - 1, IMG = 1 << t.imgs;
+    const int oy0 = tyi << t.tys, ox0 = txi << t.txs, k0 = kg * 16 * NKT, n0 = blockIdx.z * IMG;
+    const int CC4 = t.CC >> 2, nstep = p.ntap * CC4;
+    float* patch = f32lds;
+    char* wl0 = (char*)(f32lds + (long)t.CC * t.PS);
+    const long wl_bytes = (long)nstep * 1024;
+    const float* inb = p.in + (long)n0 * p.in_nstride;
+    const int Hv = p.up ? 2 * p.Hin : p.Hin, Wv = p.up ? 2 * p.Win : p.Win;
+    const int img_px = t.PH * t.PW;
+    // ---- this thread's patch elements e = tid + 256 i of a chunk: global offset from (image n0, channel c0) or -1 (padding, beyond the batch), LDS offset
+    int goff[NE], loff[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + 256 * i;
+        const int cl = f32_fastdiv(e, t.plane, t.rplane), rem = e - cl * t.plane;
+        const int il = f32_fastdiv(rem, img_px, t.rimg), r2 = rem - il * img_px;
+        const int y = f32_fastdiv(r2, t.PW, t.rpw), x = r2 - y * t.PW;
+        int vy = oy0 * p.isy + t.dymin + y, vx = ox0 * p.isx + t.dxmin + x;
+        if (p.pad_mode == 1) {
+            vy = vy < 0 ? -vy : (vy >= Hv ? 2 * Hv - 2 - vy : vy);
+            vx = vx < 0 ? -vx : (vx >= Wv ? 2 * Wv - 2 - vx : vx);
+        } else if (p.pad_mode == 2) {
+            vy = min(max(vy, 0), Hv - 1); vx = min(max(vx, 0), Wv - 1);
+        }
+        const bool in_chunk = cl < t.CC;
+        const bool ok = in_chunk && il < IMG && n0 + il < p.N && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
+        const int iy = p.up ? vy >> 1 : vy, ix = p.up ? vx >> 1 : vx;
+        goff[i] = ok ? (int)(cl * p.in_cstride + il * p.in_nstride) + iy * p.Win + ix : -1;
+        loff[i] = in_chunk ? cl * t.PS + rem : -1;
+    }
+    // ---- B fragment bases of the wave's four pixel tiles (floats into the patch, without tap and chunk-channel terms)
+    int boff[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        const int q = (pt * 4 + wave) * 16 + li;                  // pixel tiles are dealt to the waves round-robin: a tile of fewer than 256 pixels still feeds all four
+        const int x = q & TXm, y = (q >> t.txs) & TYm, il = min(q >> (t.txs + t.tys), IMG - 1);      // (pixels beyond the tile's images: computed on image IMG - 1, never stored)
+        boff[pt] = il * img_px + y * p.isy * t.PW + x * p.isx + lg * t.PS;
+    }
+    // (pixel tiles without a live pixel still run their MFMAs: a wave-uniform skip made hipcc shuffle the 64 accumulator registers through copies on every
+    //  step -- 48 v_accvgpr_mov per 16 MFMAs, big layers 84 -> 50 TFLOP/s -- and the layers with such tiles wait for their weight stream, not for the pipe)
+    // tap -> patch displacement, lane `tap` of one register (read with v_readlane per step: indexing the kernel-argument arrays per step is a scalar memory
+    // load whose latency a step of few MFMAs cannot hide -- the 1 x 1 levels ran 250 cycles per 32-cycle step on it)
+    const int tapv = lane < p.ntap ? (p.dy[lane] - t.dymin) * t.PW + (p.dx[lane] - t.dxmin) : 0;
+    f32x4 acc[NKT][NPT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[kt][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float v[NE];
+    auto prefetch_patch = [&](int c0) __attribute__((always_inline)) {
+        const float* ic = inb + (long)c0 * p.in_cstride;
+        const int lim = min(t.CC, p.C - c0) * t.plane;            // elements of channels that exist
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] = (goff[i] >= 0 && tid + 256 * i < lim) ? ic[goff[i]] : 0.f;
+    };
+    auto issue_weights = [&](int c0, int buf) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, t.wbytes, 0x00020000);
+        char* dst = wl0 + buf * wl_bytes;
+        const int c40 = c0 >> 2;
+        const bool lane_ok = lane < 16 * NKT && k0 + lane < t.Kp;
+        for (int r = wave; r < nstep; r += 4) {
+            const int tap = r / CC4, c4l = r - tap * CC4;
+            const unsigned row = (unsigned)(((tap * t.C4 + c40 + c4l) * t.Kp + k0) * 16);
+            const int voff = (lane_ok && c40 + c4l < t.C4) ? (int)(row + lane * 16) : (int)0x80000000;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, voff, 0, 0, 0);
+        }
+#else
+        (void)c0; (void)buf;
+#endif
+    };
+
+    prefetch_patch(0);
+    issue_weights(0, 0);
+    int buf = 0;
+    for (int c0 = 0; c0 < p.C; c0 += t.CC, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this chunk's patch values and weight pieces have arrived
+        __syncthreads();                                           // the previous chunk's fragments have been read
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (loff[i] >= 0) {
+                float f = v[i];
+                if (p.in_act == 1) f = f > 0.f ? f : 0.2f * f;
+                else if (p.in_act == 2) f = f > 0.f ? f : 0.f;
+                patch[loff[i]] = f;
+            }
+        }
+        __syncthreads();
+        if (c0 + t.CC < p.C) {                                     // the next chunk: loads in flight behind this chunk's MFMAs
+            prefetch_patch(c0 + t.CC);
+            issue_weights(c0 + t.CC, buf ^ 1);
+        }
+        // ---- compute: (tap, 4 channels) steps, the next step's fragments in flight behind the current MFMAs
+        const float* wl = (const float*)(wl0 + buf * wl_bytes);
+        // G steps per loop trip: their fragments are fetched together, one trip ahead of their MFMAs.  A step of NKT NPT MFMAs keeps the pipe busy for 32 NKT NPT
+        // cycles; with one or two waves per SIMD an LDS read (~130 cycles) hides behind 16 MFMAs but not behind 1 .. 4 (the UNet's <= 8 x 8 levels ran 200 cycles per
+        // 32-cycle step), so the narrow forms fetch four steps at a time.  Steps beyond the chunk's last multiply zeros.
+        constexpr int G = NKT * NPT >= 8 ? 1 : 4;
+        float an[G][NKT], bn[G][NPT];
+        int ftap = 0, fc4 = 0;
+        auto fetch_group = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                if (ftap < p.ntap) {
+                    const int toff = __builtin_amdgcn_readlane(tapv, ftap) + fc4 * 4 * t.PS;
+                    const float* wa = wl + (long)(ftap * CC4 + fc4) * 256 + li * 4 + lg;
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) an[u][kt] = wa[kt * 64];
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) bn[u][pt] = patch[boff[pt] + toff];
+                    if (++fc4 == CC4) { fc4 = 0; ++ftap; }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) an[u][kt] = 0.f;
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) bn[u][pt] = 0.f;
+                }
+            }
+        };
+        const int ngroups = (nstep + G - 1) / G;
+        fetch_group();
+        for (int g = 0; g < ngroups; ++g) {
+            float a[G][NKT], b[G][NPT];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) a[u][kt] = an[u][kt];
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) b[u][pt] = bn[u][pt];
+            }
+            if (g + 1 < ngroups) fetch_group();
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) acc[kt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][kt], b[u][pt], acc[kt][pt], 0, 0, 0);
+        }
+    }
+    // ---- epilogue (the direct kernel's): bias, gate, activation, scale, residual, store through the output view
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        const int q = (pt * 4 + wave) * 16 + li;
+        const int ox = ox0 + (q & TXm), oy = oy0 + ((q >> t.txs) & TYm), il = q >> (t.txs + t.tys), n = n0 + il;
+        if (oy >= p.Ho || ox >= p.Wo || il >= IMG || n >= p.N) continue;
+        const long opix0 = ((long)(oy * p.osy + p.ooy) * p.Wout + ox * p.osx + p.oox);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = k0 + 16 * kt + 4 * lg + j;
+                if (k >= p.K) continue;
+                long opix = opix0;
+                if (p.phase_k > 0) {                       // fused phases: channel k is phase ph of output channel k % phase_k
+                    const int ph = k / p.phase_k;
+                    k -= ph * p.phase_k;
+                    opix = (long)(2 * oy + (ph >> 1)) * p.Wout + 2 * ox + (ph & 1);
+                }
+                float f = acc[kt][pt][j] + (p.bias ? p.bias[k] : 0.f);
+                if (p.mul) f = p.mul[(long)n * p.mul_nstride + (long)k * p.mul_cstride + opix] * (1.0f / (1.0f + expf(-f)));
+                f = f32_act(f, p.act);
+                if (p.oscale != 0.f) f *= p.oscale;
+                if (p.res) f += p.res[(long)n * p.res_nstride + (long)k * p.res_cstride + opix];
+                p.out[(long)n * p.out_nstride + (long)k * p.out_cstride + opix * p.out_pstride] = f;
+            }
+    }
+}
+
+template <int NKT, int NPT>
+static int f32conv_tiled_launch(const F32Conv& k, const F32Tile& t, int tiles, int zgroups, size_t lds, hipStream_t s) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        INNFER_HIP(hipFuncSetAttribute((const void*)f32conv_tiled<NKT, NPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((f32conv_tiled<NKT, NPT>), dim3((unsigned)(tiles * t.nkg), 1, (unsigned)zgroups), dim3(256), lds, s, k, t);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
 }
 
 // Normalisation of one (image, channel) plane per block, fp32: mode 0 nn.BatchNorm2d in TRAINING mode on the statistics of the image (run.py runs pix2pix with
@@ -292,13 +525,84 @@ void f32conv_pack(int K, int C, int ntap, const std::function<float(int, int, in
 
 int f32conv_launch(const F32Conv& L, hipStream_t s) {
     if (L.ntap < 1 || L.ntap > 49 || L.C < 1 || L.K < 1 || L.N < 1 || L.Ho < 1 || L.Wo < 1) return set_error(INNFER_ERR_INVALID, "f32conv: bad arguments");
+    if (L.phase_k && (L.phase_k < 0 || L.K != 4 * L.phase_k || L.osy != 1 || L.osx != 1 || L.ooy || L.oox || (L.out_pstride > 1)))
+        return set_error(INNFER_ERR_INVALID, "f32conv: fused phases take K = 4 * phase_k channels on the input grid (osy = osx = 1, no offset)");
     const int C4 = (L.C + 3) / 4, Kp = (L.K + 31) / 32 * 32, nkt = Kp / 32;
-    const int ktb = nkt >= 4 ? 4 : (nkt >= 2 ? 2 : 1);
-    const long npx = (long)L.Ho * L.Wo, ptiles = (npx + 63) / 64;
-    const int ptb = 4 / ktb;
+    const long npx = (long)L.Ho * L.Wo;
     F32Conv k = L;
     if (k.out_pstride == 0) k.out_pstride = 1;
     GtScope gt(s, "f32conv (fp32 MFMA, -no_fp16 mode)", 2.0 * L.N * (double)npx * L.K * L.C * L.ntap, (double)L.N * npx * (L.C * L.ntap / (double)(L.isy * L.isx) + L.K) * 4.0);
+#ifdef INNFER_ABLATE
+    static const int f32_direct = getenv("INNFER_F32_DIRECT") ? atoi(getenv("INNFER_F32_DIRECT")) : 0;      // A/B: the direct (round-4) kernel for every shape
+#else
+    constexpr int f32_direct = 0;
+#endif
+    // ---- the LDS-tiled kernel: 256-pixel tiles of 8 x 32 / 16 x 16 pixels of one image, or of the whole (<= 8 x 8) grids of several images ----
+    if (!f32_direct) {
+        F32Tile t{};
+        t.C4 = C4; t.Kp = Kp;
+        int dymin = L.dy[0], dymax = L.dy[0], dxmin = L.dx[0], dxmax = L.dx[0];
+        for (int i = 1; i < L.ntap; ++i) {
+            dymin = std::min(dymin, L.dy[i]); dymax = std::max(dymax, L.dy[i]);
+            dxmin = std::min(dxmin, L.dx[i]); dxmax = std::max(dxmax, L.dx[i]);
+        }
+        auto clog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+        t.txs = std::min(L.Wo > 16 ? 5 : 4, clog2(L.Wo));
+        t.tys = std::min(8 - t.txs, clog2(L.Ho));
+        const int TX = 1 << t.txs, TY = 1 << t.tys;
+        t.dymin = dymin; t.dxmin = dxmin;
+        t.PH = (TY - 1) * L.isy + (dymax - dymin) + 1;
+        t.PW = (TX - 1) * L.isx + (dxmax - dxmin) + 1;
+        // Channels per chunk first -- from the geometry of ONE image's patch, never from the batch: the chunk size is the order of the sums, and a batch must
+        // equal its images' own forwards bit for bit -- then as many images per tile as fill the 256 pixels and keep the chunk within a thread's NE elements.
+        const int cmax = (L.C + 3) / 4 * 4;
+        int cc = std::min(32, cmax);
+        auto lds_bytes = [&](int c, int img) { return (size_t)c * (img * t.PH * t.PW + 80) * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };
+        while (cc > 4 && ((long)cc * t.PH * t.PW > 256L * F32_NE || lds_bytes(cc, 1) > 72 * 1024)) cc -= 4;
+        // Grids of at most 64 pixels (tiles that hold whole images): the 64-pixel tile form (NPT 1), where a tile's images -- and with them the live pixel tiles of
+        // its waves -- are bought with channels per chunk: 4 x 4 outputs with 32 channels per chunk leave room for ONE image's patch = 16 live pixels of 256.
+        // These layers wait for their weight stream (16.8 MB per 512 -> 512 level against < 1 GFLOP at 1 x 1): few images per tile (at most 8: more workgroups
+        // to pull it, 256 for a batch of 64 at 1 x 1) and as many channels per chunk as that leaves (fewer latency hops: one per chunk).
+        const bool small = (1 << (t.txs + t.tys)) <= 32;
+        t.imgs = 8 - t.txs - t.tys;
+        if (small) {
+            t.imgs = std::min(6 - t.txs - t.tys, 3);
+            while (cc > 4 && (long)cc * t.PH * t.PW * (1 << t.imgs) > 256L * F32_NE) cc -= 4;
+        }
+        while (t.imgs > 0 && ((long)cc * (1 << t.imgs) * t.PH * t.PW > 256L * F32_NE || lds_bytes(cc, 1 << t.imgs) > 72 * 1024)) --t.imgs;
+        const int IMG = 1 << t.imgs;
+        const bool npt1 = (1 << (t.txs + t.tys + t.imgs)) <= 64;
+        t.plane = IMG * t.PH * t.PW;
+        t.PS = t.plane + ((16 - t.plane % 64) + 64) % 64;          // plane stride = 16 (mod 64 banks): the four k lanes of a fragment read land 16 banks apart
+        t.rplane = 1.0f / (float)t.plane; t.rimg = 1.0f / (float)(t.PH * t.PW); t.rpw = 1.0f / (float)t.PW;
+        const int nkt16 = (L.K + 15) / 16;                          // 16-channel tiles that hold real outputs
+        const int tiles_y = (L.Ho + TY - 1) / TY;
+        t.tiles_x = (L.Wo + TX - 1) / TX;
+        const int tiles = t.tiles_x * tiles_y, zgroups = (L.N + IMG - 1) / IMG;
+        int NKT = nkt16 >= 4 ? 4 : nkt16;
+        while (NKT > 1 && NKT != 3 && (long)tiles * zgroups * ((nkt16 + NKT - 1) / NKT) < 512) NKT >>= 1;      // small launches: more, narrower workgroups
+        t.nkg = (nkt16 + NKT - 1) / NKT;
+        auto lds_total = [&](int c) { return (size_t)c * t.PS * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };
+        const size_t wbytes = f32conv_packed_floats(L.K, L.C, L.ntap) * 4;
+        if ((long)cc * t.plane <= 256L * F32_NE && lds_total(cc) <= 150 * 1024 && wbytes < 0x7fffffffu &&
+            (long)cc * L.in_cstride + (long)IMG * L.in_nstride + (long)L.Hin * L.Win < 0x7fffffffL && (long)cc * t.plane < (1 << 21)) {
+            t.CC = cc; t.wbytes = (unsigned)wbytes;
+            const size_t lds = lds_total(cc);
+            switch (NKT * 2 + (npt1 ? 1 : 0)) {
+                case 2: return f32conv_tiled_launch<1, 4>(k, t, tiles, zgroups, lds, s);
+                case 3: return f32conv_tiled_launch<1, 1>(k, t, tiles, zgroups, lds, s);
+                case 4: return f32conv_tiled_launch<2, 4>(k, t, tiles, zgroups, lds, s);
+                case 5: return f32conv_tiled_launch<2, 1>(k, t, tiles, zgroups, lds, s);
+                case 6: return f32conv_tiled_launch<3, 4>(k, t, tiles, zgroups, lds, s);
+                case 7: return f32conv_tiled_launch<3, 1>(k, t, tiles, zgroups, lds, s);
+                case 8: return f32conv_tiled_launch<4, 4>(k, t, tiles, zgroups, lds, s);
+                default: return f32conv_tiled_launch<4, 1>(k, t, tiles, zgroups, lds, s);
+            }
+        }
+    }
+    const int ktb = nkt >= 4 ? 4 : (nkt >= 2 ? 2 : 1);
+    const long ptiles = (npx + 63) / 64;
+    const int ptb = 4 / ktb;
     hipLaunchKernelGGL(f32conv_kernel, dim3((unsigned)((ptiles + ptb - 1) / ptb), (unsigned)((nkt + ktb - 1) / ktb), (unsigned)L.N), dim3(256), 0, s, k, ktb, C4, Kp);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;

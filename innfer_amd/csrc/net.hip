@@ -261,6 +261,22 @@ extern "C" int innfer_net_conv_info(innfer_net_t net, int idx, char* key, size_t
     return INNFER_OK;
 }
 
+// The (wl | wh | wh) panels of one loaded conv for the fp32-accurate mode (conv_pack_split), from the fp32 weights kept at innfer_net_set_conv.
+static int build_split_panels(ConvSlot& c) {
+    std::vector<char> host(3 * (c.ksize == 1 ? conv_packed_bytes_taps(c.K, c.C, 0x10) : conv_packed_bytes(c.K, c.C)));
+    if (c.ksize == 1) conv_pack_1x1_split(c.h_w.data(), c.K, c.C, host.data());
+    else conv_pack_split(c.h_w.data(), c.K, c.C, host.data());
+    if (hipMalloc(&c.d_w32, host.size()) != hipSuccess) {
+        c.d_w32 = nullptr; (void)hipGetLastError();
+        return set_error(INNFER_ERR_NOMEM, "out of device memory for the fp32-accurate panels of '%s' (%zu bytes)", c.key.c_str(), host.size());
+    }
+    if (hipMemcpy(c.d_w32, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(c.d_w32); c.d_w32 = nullptr; (void)hipGetLastError();
+        return set_error(INNFER_ERR_HIP, "copying the fp32-accurate panels of '%s' failed", c.key.c_str());
+    }
+    return INNFER_OK;
+}
+
 extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, const float* b) {
     if (!net || idx < 0 || idx >= (int)net->convs.size() || !w) return set_error(INNFER_ERR_INVALID, "set_conv: bad arguments");
     ConvSlot& c = net->convs[idx];
@@ -316,6 +332,9 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
     INNFER_HIP(hipMemcpy(c.d_w, host.data(), host.size(), hipMemcpyHostToDevice));
     INNFER_HIP(hipMemcpy(c.d_b, bias.data(), bias_n * sizeof(float), hipMemcpyHostToDevice));
     c.loaded = true;
+    // a network already in the fp32-accurate mode (set_precision(1) before this set_conv, or one conv re-set afterwards: the ABI-106 call order) gets this
+    // conv's split panels here -- set_conv is a load-time call like set_precision; innfer_net_forward never allocates
+    if (net->fp32 && !c.first) return build_split_panels(c);
     return INNFER_OK;
 }
 
@@ -346,13 +365,15 @@ extern "C" int innfer_net_set_precision(innfer_net_t net, int fp32) {
         // The (wl | wh | wh) panels of every loaded conv are built HERE -- a load-time call, with its hipMalloc and synchronous copies -- never inside
         // innfer_net_forward (stream capture, concurrent callers).  Idempotent: a conv that already has its panels is skipped; innfer_net_set_conv
         // drops a conv's panels, so the call after a weight change rebuilds exactly those.
+        std::vector<ConvSlot*> built;              // panels allocated by THIS call: released again when one of them does not fit
         for (auto& c : net->convs) {
             if (c.first || c.d_w32 || !c.loaded) continue;
-            std::vector<char> host(3 * (c.ksize == 1 ? conv_packed_bytes_taps(c.K, c.C, 0x10) : conv_packed_bytes(c.K, c.C)));
-            if (c.ksize == 1) conv_pack_1x1_split(c.h_w.data(), c.K, c.C, host.data());
-            else conv_pack_split(c.h_w.data(), c.K, c.C, host.data());
-            if (hipMalloc(&c.d_w32, host.size()) != hipSuccess) { c.d_w32 = nullptr; (void)hipGetLastError(); return set_error(INNFER_ERR_NOMEM, "set_precision: out of device memory for the fp32-accurate panels of '%s' (%zu bytes)", c.key.c_str(), host.size()); }
-            INNFER_HIP(hipMemcpy(c.d_w32, host.data(), host.size(), hipMemcpyHostToDevice));
+            const int rc = build_split_panels(c);
+            if (rc != INNFER_OK) {
+                for (ConvSlot* q : built) { (void)hipFree(q->d_w32); q->d_w32 = nullptr; }
+                return rc;
+            }
+            built.push_back(&c);
         }
     }
     net->fp32 = fp32;

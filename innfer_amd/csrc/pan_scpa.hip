@@ -16,6 +16,7 @@
 // launch; the next tile's X is fetched while P2 / P3 run.  Arithmetic per value as in the five-launch schedule: fp16 operands, fp32
 // accumulation, A / B / Y / a' / b' rounded to fp16 where that schedule stored them -- the same roundings, different summation order of the
 // MFMA k-steps only where a conv's taps are walked in another order (none: taps in (dy, dx) order, one k-step per tap).
+#include <atomic>
 #include "common.h"
 
 namespace innfer {
@@ -404,26 +405,30 @@ void pan_scpa_pack(const float* c1a, const float* c1b, const float* k1, const fl
 static int scpa_num_cus() {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    static int cached[64] = {};
-    if (!cached[dev & 63]) {
+    static std::atomic<int> cached[64] = {};              // (relaxed: every thread that misses stores the same value)
+    v = cached[dev & 63].load(std::memory_order_relaxed);
+    if (!v) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cached[dev & 63] = v;
+        cached[dev & 63].store(v, std::memory_order_relaxed);
     }
-    return cached[dev & 63];
+    return v;
 }
 
 int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s) {
     const int num_cus = scpa_num_cus();
     constexpr int TH = 16;
     constexpr int LDS = 160 * 1024;
-    static unsigned long long attr_done = 0;                // function attributes belong to the device's copy of the code object
+    static std::atomic<unsigned long long> attr_done{0};    // function attributes belong to the device's copy of the code object; concurrent first calls may both set it (idempotent)
     {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         const unsigned long long bit = 1ull << (dev & 63);
-        if (!(attr_done & bit)) {
-            INNFER_HIP(hipFuncSetAttribute((const void*)pan_scpa_fused<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            attr_done |= bit;
+        if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)pan_scpa_fused<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+                (void)hipGetLastError();
+                return set_error(INNFER_ERR_UNSUPPORTED, "pan_scpa: the fused SCPA block needs 160 KB of LDS per workgroup (gfx950); innfer_pan_set_fused_scpa(pan, 0) selects the five-launch schedule");
+            }
+            attr_done.fetch_or(bit, std::memory_order_release);
         }
     }
     if ((long)N * H * W * 64 + 2 * G >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "pan_scpa: slab too large for 32-bit buffer offsets");

@@ -847,6 +847,19 @@ extern "C" int innfer_unet_set_precision(innfer_unet* u, int fp32) {
         if (p.upconv) {                                               // Upsample(nearest 2x) + Conv2d(3x3): [cout][cin][3][3]
             rc = put(&u->f32_up[0][k], p.cout, p.cin, 9, [&](int co, int ci, int t) { return wu[((size_t)co * p.cin + ci) * 9 + t]; });
             if (rc) return rc;
+        } else if (4 * p.cout <= 16) {
+            // ConvTranspose2d(4, 2, 1) with so few outputs that all four phases fit the 16-channel tile one phase would occupy (the outermost layer: 3): ONE conv of
+            // 9 taps on the input grid and 4 cout channels, channel ph * cout + co = phase ph of output co; a phase's panel rows are zero at the taps that are not
+            // its own (F32Conv.phase_k).  The 128-channel input is read once instead of four times -- the four launches were HBM-bound on it (profiles/r5/fp32_modes.txt)
+            rc = put(&u->f32_up[0][k], 4 * p.cout, p.cin, 9, [&](int kq, int ci, int t) {
+                const int ph = kq / p.cout, co = kq - ph * p.cout, ty = t / 3 - 1, tx = t % 3 - 1;
+                int ky[4], kx[4], dy[4], dx[4];
+                phase_taps(ph >> 1, ph & 1, ky, kx, dy, dx);
+                for (int q = 0; q < 4; ++q)
+                    if (dy[q] == ty && dx[q] == tx) return wu[(((size_t)ci * p.cout + co) * 4 + ky[q]) * 4 + kx[q]];
+                return 0.f;
+            });
+            if (rc) return rc;
         } else {                                                      // ConvTranspose2d(4, 2, 1): [cin][cout][4][4], one panel per output phase
             for (int ph = 0; ph < 4; ++ph) {
                 int ky[4], kx[4], dy[4], dx[4];
@@ -898,6 +911,11 @@ int unet_forward_f32(innfer_unet* u, const float* x, float* y, int N, int H, int
         c.in_act = 2; c.act = act; c.N = N;
         if (p.upconv) {
             c.wp = u->f32_up[0][k]; c.up = 1; c.Ho = 2 * h; c.Wo = 2 * w; c.osy = c.osx = 1; c.isy = c.isx = 1; c.ntap = 9;
+            for (int t = 0; t < 9; ++t) { c.dy[t] = t / 3 - 1; c.dx[t] = t % 3 - 1; }
+            return f32conv_launch(c, s);
+        }
+        if (4 * p.cout <= 16) {       // all four phases in one launch (see innfer_unet_set_precision)
+            c.wp = u->f32_up[0][k]; c.K = 4 * p.cout; c.phase_k = p.cout; c.Ho = h; c.Wo = w; c.osy = c.osx = 1; c.isy = c.isx = 1; c.ntap = 9;
             for (int t = 0; t < 9; ++t) { c.dy[t] = t / 3 - 1; c.dx[t] = t % 3 - 1; }
             return f32conv_launch(c, s);
         }

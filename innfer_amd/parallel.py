@@ -102,19 +102,23 @@ def engine_tile_cap(model_fn, ps, dtype, device, fraction=0.8, budget=None):
     return lo
 
 
-def run_tile_batches(model_fn, tiles, tile_batch=None, sink=None, pick=None):
+def run_tile_batches(model_fn, tiles, tile_batch=None, sink=None, pick=None, out=None):
     """tiles [n,C,ps,ps] through model_fn in batches (tile_batches with the engine's cap); an allocator out-of-memory halves the batch and goes
-    on (workspace released first) instead of ending the image.  sink(i, y): consume the result of tiles [i, i + len(y)); without one the results
-    are returned concatenated.  pick: applied to model_fn's return value (PPON returns a tuple)."""
+    on (the ladder VERDICT r2 asked for instead of a constant).  sink(i, y) receives batch i's result and nothing is returned; otherwise the results
+    are returned concatenated.  pick: applied to model_fn's return value (PPON returns a tuple).
+    out: a preallocated contiguous [n, C', P, P] tensor the results belong in (and the return value).  A model_fn that takes `out=` (the nn.Module
+    shells: `_accepts_out`) writes every batch straight into its rows -- no per-batch result tensor, no copy, no concatenation (VERDICT r4 item 6b);
+    any other callable's results are copied there."""
     n = tiles.shape[0]
     outs = []
+    lands = out is not None and pick is None and bool(getattr(model_fn, '_accepts_out', False))
     cap = None if tile_batch else engine_tile_cap(model_fn, tiles.shape[-1], tiles.dtype, tiles.device)
     i = 0
     while i < n:
         sizes = tile_batches(n - i, tile_batch, cap)
         b = sizes[0]
         try:
-            y = model_fn(tiles[i:i + b])
+            y = model_fn(tiles[i:i + b], out=out[i:i + b]) if lands else model_fn(tiles[i:i + b])
         except torch.OutOfMemoryError:
             if b == 1:
                 raise
@@ -126,12 +130,19 @@ def run_tile_batches(model_fn, tiles, tile_batch=None, sink=None, pick=None):
             continue
         if pick is not None:
             y = pick(y)
-        if sink is not None:
+        if out is not None:
+            if not lands:
+                if y.shape[1:] != out.shape[1:] or y.dtype != out.dtype:
+                    raise RuntimeError(f'run_tile_batches: model_fn returned {tuple(y.shape[1:])} {y.dtype}, the tile buffer is {tuple(out.shape[1:])} {out.dtype}')
+                out[i:i + b].copy_(y)
+        elif sink is not None:
             sink(i, y)
         else:
             outs.append(y)
         i += b
         del y
+    if out is not None:
+        return out
     if sink is not None:
         return None
     return torch.cat(outs, 0) if len(outs) != 1 else outs[0]
@@ -258,13 +269,13 @@ class ChopRunner:
             tiles = self.extract_fn(data, (ps, ps), [self.step, self.step], batch_first=True,
                                     tile_range=(first, count)).squeeze(0)
             base = first if rank == 0 else 0
-            def land(i, y):
-                if y.shape[1:] != hr.shape[1:] or y.dtype != hr.dtype:
-                    raise RuntimeError(f'ChopRunner: model_fn returned {tuple(y.shape[1:])} {y.dtype}, every rank was told '
-                                       f'{tuple(hr.shape[1:])} {hr.dtype} (set out_channels / out_dtype)')
-                hr[base + i:base + i + y.shape[0]].copy_(y)
-            with torch.no_grad():
-                run_tile_batches(self.model_fn, tiles, self.tile_batch, sink=land)
+            with torch.no_grad():               # batches land in their rows of the tile buffer (engines: written there by the last conv, no copy)
+                try:
+                    run_tile_batches(self.model_fn, tiles, self.tile_batch, out=hr[base:base + count])
+                except (RuntimeError, ValueError) as e:
+                    if 'tile buffer' in str(e) or 'out= must be' in str(e):
+                        raise RuntimeError(f'ChopRunner: every rank was told model_fn returns {tuple(hr.shape[1:])} {hr.dtype} (set out_channels / out_dtype): {e}') from None
+                    raise
             del tiles
         if prof:
             _sync(data)

@@ -164,10 +164,21 @@ class Model:
                                    tile_range=tile_range).squeeze(0)
         from .parallel import run_tile_batches
         with torch.no_grad():
-            hr = run_tile_batches(self.model, tiles, self.tile_batch, pick=self._pick)
+            hr = run_tile_batches(self.model, tiles, self.tile_batch, pick=self._pick if self.arch == 'ppon' else None, out=self._tile_buffer(tiles))
         if tile_range is not None:
             return hr
         return recompose_tensor(hr, H, W, step=step, scale=self.scale)
+
+    def _tile_buffer(self, tiles):
+        """The [n, C', P, P] buffer the blend reads, allocated once so that every batch's result is written in place (no per-batch tensor + torch.cat):
+        known for the engines that state their output shape; None (concatenate) otherwise."""
+        m = self.model
+        if self.arch == 'ppon' or not getattr(m, '_accepts_out', False):
+            return None
+        n, _, ps, _ = tiles.shape
+        from .architectures.engine_module import EngineModule
+        shape = m._out_shape(n, ps, ps, device=tiles.device) if isinstance(m, EngineModule) else m._out_shape(n, ps, ps)
+        return torch.empty(tuple(shape), dtype=tiles.dtype, device=tiles.device)
 
     def _pick(self, y):
         """PPON returns (content, structure, perceptual) and run.py keeps the last (run.py:191-192,220-221)."""
@@ -209,7 +220,7 @@ class Model:
                 n = len(ys) * len(xs)
                 tiles = torch.empty((n, Cc, ps, ps), dtype=dt, device=d.device)
                 L.check(L.lib.innfer_extract_tiles_u8(d.data_ptr(), Cc, H, W, int(bool(normalize)), ps, 0.5, 0, n, tiles.data_ptr(), code, stream))
-                hr = run_tile_batches(self.model, tiles, self.tile_batch, pick=self._pick)
+                hr = run_tile_batches(self.model, tiles, self.tile_batch, pick=self._pick if self.arch == 'ppon' else None, out=self._tile_buffer(tiles))
                 Co, P = hr.shape[1], hr.shape[2]
                 if out is None:
                     out = torch.empty((H * s, W * s, Co), dtype=torch.uint8, device=d.device)

@@ -125,3 +125,34 @@ def test_tile_batches_are_sized_from_the_engine_and_survive_oom():
             run_tile_batches(Fake(10, limit=0.5), tiles)          # even one tile does not fit: the error surfaces
     finally:
         P.free_device_bytes = real
+
+
+def test_run_tile_batches_lands_results_in_the_tile_buffer():
+    """with out= every batch's result belongs in its rows of ONE preallocated buffer -- a model_fn that takes `out=` (the nn.Module
+    shells) writes there itself (no result tensor, no copy), any other callable's result is copied; both equal the concatenated form."""
+    import torch
+    from innfer_amd.parallel import run_tile_batches
+
+    class Lands:
+        _accepts_out = True
+        calls = []
+
+        def __call__(self, t, out=None):
+            assert out is not None and out.shape[0] == t.shape[0] and out.is_contiguous()
+            self.calls.append(out.data_ptr())
+            out.copy_(t * 2)
+            return out
+
+    tiles = torch.arange(7 * 3 * 4 * 4, dtype=torch.float32).reshape(7, 3, 4, 4)
+    ref = run_tile_batches(lambda t: t * 2, tiles, tile_batch=3)
+    buf = torch.full((7, 3, 4, 4), -1.0)
+    m = Lands()
+    got = run_tile_batches(m, tiles, tile_batch=3, out=buf)
+    assert got is buf and torch.equal(buf, ref)
+    assert m.calls == [buf[0:3].data_ptr(), buf[3:6].data_ptr(), buf[6:7].data_ptr()]          # written in place, batch by batch
+    buf2 = torch.full((7, 3, 4, 4), -1.0)
+    assert run_tile_batches(lambda t: t * 2, tiles, tile_batch=3, out=buf2) is buf2 and torch.equal(buf2, ref)
+    buf3 = torch.full((7, 3, 4, 4), -1.0)             # pick (a tuple-returning model): copied, even when the callable could land
+    assert torch.equal(run_tile_batches(lambda t: (t, t * 2), tiles, tile_batch=2, pick=lambda y: y[1], out=buf3), ref)
+    with __import__("pytest").raises(RuntimeError):
+        run_tile_batches(lambda t: t[:, :2] * 2, tiles, tile_batch=3, out=torch.empty(7, 3, 4, 4))

@@ -1489,6 +1489,38 @@ def test_pan_fused_scpa_vs_five_launches_and_oracle(dev):
         assert e1.max().item() < bound and e1.mean().item() < 1.5e-3 and e0.max().item() < bound and d < 4e-3 and da < 2e-3, (shape, e1.max().item(), e0.max().item(), d, da)
 
 
+def test_pan_bench_shapes_untiled_vs_oracle(dev):
+    """the shapes the bench runs PAN on, un-tiled, against the oracle -- 264 x 392 (6 468 pooled keys, ragged in both tile
+    directions) and the `pan540` workload itself, 540 x 960 = 32 400 pooled keys = 507 key blocks through the running-max softmax of
+    pan_attention_mfma (csrc/pan.hip); the largest shape the other tests reach is 200 x 200 = 2 500 keys.  The default 16-block network."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config("pan", 4))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = _sd(shapes, 43)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    for i, shape in enumerate([(1, 3, 264, 392), (1, 3, 540, 960)]):
+        x = torch.from_numpy(synth.uniform(shape, 330 + i))
+        with torch.no_grad():
+            ref = oracle.pan_forward(sd, x, nb=16, scale=4)
+        y1 = net(x.to(dev).half())
+        net._ws.fill_(0xFF)
+        assert torch.equal(y1, net(x.to(dev).half()))
+        net.fused_scpa = 2                                              # VALU attention: the MFMA attention's score / softmax path held to it at this key count
+        y2 = net(x.to(dev).half())
+        net.fused_scpa = True
+        e1 = (y1.float().cpu() - ref).abs()
+        da = (y1.float() - y2.float()).abs().max().item()
+        print(f"PAN un-tiled {shape}: vs oracle max {e1.max().item():.2e} mean {e1.mean().item():.2e}; MFMA attention vs VALU attention {da:.2e}")
+        assert y1.shape == ref.shape and torch.isfinite(y1).all()
+        bound = 1e-2 * max(1.0, ref.abs().max().item())
+        assert e1.max().item() < bound and e1.mean().item() < 1.5e-3 and da < 2e-3, (shape, e1.max().item(), e1.mean().item(), da)
+        del ref, y1, y2
+
+
 def test_pan_constructor_variants_golden(dev, golden):
     """PAN(self_attention=False), PAN(double_scpa=True) and both at 2x (PAN_arch.py:115-141,193-203) against the reference (G18): same
     parameter names in the same order, outputs within the PAN tolerance."""
@@ -1792,6 +1824,30 @@ def test_first_conv_on_the_matrix_cores_all_widths(dev):
 
 
 # ---------------------------------------------------------------- Model / chop
+def test_forward_into_callers_tensor(dev):
+    """forward(x, out=...): the last conv writes the caller's tensor -- same bits as a fresh result, for an engine of each base class and
+    for a row range of a larger buffer (how chop batches land in the tile buffer); a wrong shape / dtype / a strided view is refused."""
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = RRDBNet(3, 3, 64, 1, upscale=2)
+    net.load_state_dict(_sd(synth.rrdbnet_shapes(nb=1, scale=2), 7), strict=True)
+    pan = get_network(get_network_G_config({"type": "pan", "nb": 2}, 4))
+    pan.load_state_dict(_sd({k: tuple(v.shape) for k, v in pan.state_dict().items()}, 8), strict=True)
+    for m, s in ((net.to(dev).eval(), 2), (pan.to(dev).eval(), 4)):
+        x = torch.from_numpy(synth.uniform((3, 3, 40, 56), 9)).to(dev).half()
+        ref = m(x)
+        buf = torch.full((5, 3, 40 * s, 56 * s), float("nan"), dtype=torch.float16, device=dev)
+        y = m(x, out=buf[1:4])
+        assert y.data_ptr() == buf[1:4].data_ptr() and torch.equal(buf[1:4], ref)
+        assert torch.isnan(buf[0]).all() and torch.isnan(buf[4]).all()                      # nothing outside the rows it was given
+        for bad in (torch.empty((3, 3, 40 * s, 56 * s + 1), dtype=torch.float16, device=dev), torch.empty((3, 3, 40 * s, 56 * s), dtype=torch.float32, device=dev),
+                    torch.empty((3, 3, 40 * s, 2 * 56 * s), dtype=torch.float16, device=dev)[..., ::2]):
+            with pytest.raises(ValueError):
+                m(x, out=bad)
+
+
 def test_model_chop_golden(dev, golden, tmp_path):
     from innfer_amd import synth
     from innfer_amd.run import Model

@@ -211,6 +211,11 @@ def test_bench_two_ranks_dry_run(dev):
     assert ts["parallelism"] == "tile-dp2" and ts["scaling"] == "strong"
     # 798 tiles per stage, rank 1 owns 399: their raw outputs (1x stage: 3x200x200, 4x stage: 3x800x800, fp16) cross to rank 0
     assert ts["exchange_bytes_into_rank0"] == 399 * 3 * 2 * (200 ** 2 + 800 ** 2)
+    # every rank reports the phases of the profiled pass: [rank][stage] with its own tile count
+    pr = ts["per_rank_phases_ms"]
+    assert len(pr) == 2 and all(len(stages) == 2 for stages in pr)
+    assert [st["tiles"] for st in pr[0]] == [399, 399] and [st["tiles"] for st in pr[1]] == [399, 399]
+    assert all({"compute_ms", "exchange_ms", "blend_ms", "bcast_ms"} <= set(st) for stages in pr for st in stages)
     rf = line["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == ("GB/s" if rf["bound"] == "hbm" else "TFLOP/s")
     assert 0 < rf["frac"] <= 1 and 0 < rf["frac_mfma"] <= 1 and 0 < rf["frac_hbm"] <= 1
