@@ -59,6 +59,8 @@ def kernel_key(k):
         return "conv3x3_pair"
     variant, k = k // 1000, k % 1000
     nt, mode = k // 16, k % 16
+    if variant == 4:          # conv nf -> 4 nf with nn.PixelShuffle(2) as the store of conv3x3_pc<2,4,4,0,..,TMF 0xC001FF> (phase-major plane-order panels)
+        return "conv3x3_pc<2,4,4,0>+pixelshuffle"
     if (nt, mode) in PC_SHAPE:
         name = "conv3x3_pc<%d,%d,%d,%d>" % PC_SHAPE[(nt, mode)]
     else:

@@ -45,7 +45,7 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works).  innfer_version() returns the library's; a binding should compare. */
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works); innfer_pack_conv3x3_shuffle2 + innfer_conv_args.plane_rows = 2.  innfer_version() returns the library's; a binding should compare. */
 #define INNFER_ABI_VERSION 110
 int innfer_version(void);
 const char* innfer_last_error(void);
@@ -389,7 +389,8 @@ typedef struct {
                                            innfer_pack_conv3x3_wino(); K % 32 == 0, act 0 / 1 / 2, residuals, upsample2x, row range; 2 = the direct conv on the same tiles (K 32) (106) */
     int res1_from_input;                /* != 0: d_res1 == d_in (same group stride), act 0, K = 64, C >= 96 -- the dense block's `x5 * 0.2 + x`: the residual is taken from the
                                            conv's own staged input tiles (see innfer_net_set_residual_lds); ignored when the shape does not qualify (108) */
-    int plane_rows;                     /* != 0 (plain 3x3 slab convs and transposed2x with K % 64 == 0): d_packed comes from innfer_pack_conv3x3_rows(.., 1) /
+    int plane_rows;                     /* 2 with pixel_shuffle2 (K % 256 == 0): d_packed / d_bias from innfer_pack_conv3x3_shuffle2() (110).
+                                           != 0 (plain 3x3 slab convs and transposed2x with K % 64 == 0): d_packed comes from innfer_pack_conv3x3_rows(.., 1) /
                                            innfer_pack_convt2x_rows(.., 1) -- the row order in which a lane's sixteen output channels are 16 bytes in each of the group's two
                                            32-channel slab planes (what the networks use for their 64-output layers: one plane per store instruction); results are the same (109) */
 } innfer_conv_args;
@@ -398,6 +399,10 @@ size_t innfer_conv3x3_packed_bytes(int K, int C);
 int innfer_pack_conv3x3(const float* h_weight_oihw, int K, int C, void* h_packed);
 int innfer_pack_conv3x3_rows(const float* h_weight_oihw, int K, int C, int plane_rows, void* h_packed);      /* (109) same size; plane_rows: see innfer_conv_args */
 int innfer_pack_convt2x_rows(const float* h_weight_iohw, int K, int C, int k, int plane_rows, void* h_packed); /* (109) */
+/* (110) Panels for pixel_shuffle2 with plane_rows = 2: the conv channels PHASE-MAJOR (packed channel ph * K / 4 + oc = reference channel 4 oc + ph, ph = 2a + b the position
+ * in nn.PixelShuffle's 2 x 2 block) in the plane row order, so that the shuffle is the store of the producer / consumer kernel (what the networks use for their PixelShuffle(2)
+ * stages on 64 features).  K % 256 == 0; same size as innfer_pack_conv3x3; h_bias_out receives the K biases in the same order (zeros when h_bias is NULL): pass it as d_bias. */
+int innfer_pack_conv3x3_shuffle2(const float* h_weight_oihw, const float* h_bias, int K, int C, void* h_packed, float* h_bias_out);
 /* Panels of the two stride-2 forms above: h_weight is torch's layout, [K][C][4][4] for the conv and [C][K][k][k] for the transposed conv (k = 3 | 4). (104) */
 size_t innfer_conv7x1_packed_bytes(int K, int C);
 int innfer_pack_conv7x1(const float* h_weight_oc7, int K, int C, void* h_packed);     /* h_weight [K][C][7] */

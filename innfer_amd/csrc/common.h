@@ -94,7 +94,8 @@ struct ConvLaunch {
     int split;                                    // fp32-accurate mode: every tensor is a (hi, lo) pair of fp16 slabs, lo = fp16((x - hi) * 2^11) (conv3x3.hip, SPLIT); panels from
     long in_lo, out_lo, res1_lo, res2_lo;         // conv_pack_split / conv_pack_1x1_split; *_lo: distance (elements) from a hi slab to its lo twin.  Plain 3x3 / 1x1 slab convs
                                                   // (act 0..2, residuals, upsampled input, batches) and the planar last conv
-    int rowp;                                     // 1 (64-channel output groups, slab output): the panels have the PLANE row order (conv_pack*(.., rowp = 1)) -- a lane's sixteen channels
+    int rowp;                                     // 2 (OUT_SHUFFLE2, K % 256 == 0): phase-major plane-order panels + bias from conv_pack_shuffle2 -- the PixelShuffle(2) store on the producer / consumer kernel.
+                                                  // 1 (64-channel output groups, slab output): the panels have the PLANE row order (conv_pack*(.., rowp = 1)) -- a lane's sixteen channels
                                                   // are 16 bytes in each of the group's two slab planes, a store instruction touches one plane.  Plain 3x3 slab convs (residuals, canvas,
                                                   // RLDS, fused last conv) and the transposed-conv phases; not the split / statistics / gate / stride-2 / 1x1 / planar forms
     int in_relu;                                  // 1: the operand is max(stored input, 0) (applied as fragments leave LDS) -- transposed-conv phase launches and the planar
@@ -123,6 +124,7 @@ int conv_pair_launch(const ConvPairLaunch& L, hipStream_t s);
 // Panel geometry of packed weights.
 int conv_nt_for(int K);                           // 16-channel tiles per group: 1, 2 or 4
 size_t conv_packed_bytes(int K, int C);
+void conv_pack_shuffle2(const float* w_oihw, const float* bias, int K, int C, void* packed, float* bias_out);   // host; phase-major plane-order panels of the PixelShuffle(2) store (ConvLaunch.rowp = 2, OUT_SHUFFLE2): K % 256 == 0
 void conv_pack(const float* w_oihw, int K, int C, void* packed, int rowp = 0);   // host; rowp: the plane row order of 64-channel groups (ConvLaunch.rowp)
 size_t conv_packed_bytes_wino(int K, int C);
 void conv_pack_wino(const float* w_oihw, int K, int C, void* packed);      // host; ConvLaunch.wino == 1

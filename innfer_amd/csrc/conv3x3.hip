@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 // Pins a value as a rounded fp32 number in a VGPR: the backend cannot fold the fp16 conversion that
@@ -231,7 +232,10 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
 
 // DCV (conv3x3_pc<.., TM = 0x1B>: one output phase of ConvTranspose2d(4, 2, 1) per 16*NT-channel group): (ty0, tx0) are coordinates of the phase's
 // shifted lattice (see decode); virtual pixel (y', x') of phase (a, b) is output pixel (2y' - a, 2x' - b) of the 2H x 2W slab, channel ch % phase_c.
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, bool PAIR = false, bool SC1 = false, bool ROWP = false>
+// PSH (conv3x3_pc<.., TMF | 0x800000>: nn.PixelShuffle(2) as the store, block.py:333-346): the K = 4 * phase_c conv channels arrive PHASE-MAJOR (panels from
+// conv_pack_shuffle2: channel ph * phase_c + oc is reference channel 4 oc + ph), so a 64-channel group is one output phase (a, b) = (ph >> 1, ph & 1) of
+// 64 consecutive output channels: the DCV store without the lattice shift -- pixel (y, x) of the conv grid goes to (2y + a, 2x + b).
+template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, bool PAIR = false, bool SC1 = false, bool ROWP = false, bool PSH = false>
 __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
                                               int wave, int li, int cbase, int dil = 1) {
     constexpr int MT = 2 * RPW;
@@ -254,10 +258,10 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
         ylim = (p.fullH - py + d - 1) / d;
         xlim = (p.fullW - px + d - 1) / d;
     }
-    if constexpr (DCV) {
+    if constexpr (DCV || PSH) {
         const int ph = cbase / p.phase_c, a = ph >> 1, b = ph & 1;
         oc0 -= ph * p.phase_c;
-        yw -= a; xl -= b;                               // source pixel of the virtual one (>= 0: the lattice starts at (a, b))
+        if constexpr (!PSH) { yw -= a; xl -= b; }       // source pixel of the virtual one (>= 0: the lattice starts at (a, b))
         pix0 = ((long)n * 2 * p.H + 2 * yw + a) * (2 * p.W) + 2 * xl + b;
         rowstep = (long)p.W * 32 * 4;
         colstep = 16 * 32 * 2;
@@ -1313,7 +1317,13 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr bool UP4 = (TMF & 0x200000) != 0;
     // + 0x400000 (ROWP): the plane row order of the 64-channel groups (see toff_slab): plain 3x3 slab convs (canvas, RLDS, FUSE forms included) and the one-pass up-conv
     constexpr bool ROWP = (TMF & 0x400000) != 0;
-    static_assert(!ROWP || (RPW == 2 && NT == 4 && NCW == 8 && OUTMODE == OUT_SLAB && (TMF & 0x1FF) == 0x1FF && (TMF & ~0x6601FF) == 0 && !S9 && !POLY), "plane row order: the 64-channel slab kernels");
+    static_assert(!ROWP || (RPW == 2 && NT == 4 && NCW == 8 && OUTMODE == OUT_SLAB && (TMF & 0x1FF) == 0x1FF && (TMF & ~0xE601FF) == 0 && !S9 && !POLY), "plane row order: the 64-channel slab kernels");
+    // + 0x800000 (PSH): nn.PixelShuffle(2) as the store of a conv nf -> 4 nf (pixelshuffle_block, block.py:333-346; SRResNet's up stages, RRDBNet(upsample_mode=
+    // 'pixelshuffle')) on THIS kernel -- until round 4 those launches ran on the two-workgroup kernel of round 1 (0.30 of the MFMA peak, a third of an SRResNet frame).
+    // The panels are phase-major (conv_pack_shuffle2) in the plane row order, so a channel group is one output phase of 64 channels and the epilogue is the
+    // transposed-conv phase store without the lattice shift (epilogue_slab PSH).  Same MFMAs in the same order per value as the old form: same bits.
+    constexpr bool PSH = (TMF & 0x800000) != 0;
+    static_assert(!PSH || (ROWP && (TMF & ~0xC001FF) == 0 && NSI == 2 && !CV), "pixel-shuffle store: the plain 64-channel plane-order instantiation");
     static_assert(!UP4 || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 3 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFFF) == 0x1FF && !S9 && !POLY && !CV), "one-pass phases: the 64-channel slab kernel on three input slots");
     constexpr bool FUSE = (TMF & 0x20000) != 0;
     static_assert(!FUSE || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation");
@@ -2155,7 +2165,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
                 const int lid = run_start + (p.rev ? run_len - 1 - (jt - slots) : (jt - slots));         // (jt was advanced above)
                 epilogue_stats<RPW, NT, TM == 0x1B, PAIR, NCW>(p, acc, bias_r, ty0, tx0, cw, li, cbase, lid / p.KG);
             }
-#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, PAIR, false, ROWP>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
+#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, PAIR, false, ROWP, PSH>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
             if (!p.res1) {
                 if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
                 else if (NT == 4 && TM == 0x1FF && !POLY && !ROWP && p.act == 7) EPI((NT == 4 && TM == 0x1FF && !POLY && !ROWP) ? 7 : 0, false, false); else EPI(0, false, false);
@@ -2371,6 +2381,20 @@ void conv_pack(const float* w, int K, int C, void* packed, int rowp) {
                         }
                     }
                 }
+}
+
+// PixelShuffle(2) behind a conv (block.py:333-346): the K conv channels in PHASE-MAJOR order -- packed channel ph * (K / 4) + oc is reference channel 4 oc + ph,
+// ph = 2 a + b the position (a, b) inside the 2 x 2 output block (nn.PixelShuffle: out[oc][2y + a][2x + b] = in[4 oc + 2a + b][y][x]) -- in the plane row order:
+// the panels of conv3x3_pc<.., TMF | 0x800000> (ConvLaunch.rowp = 2 with OUT_SHUFFLE2).  bias_out (K floats, may be null with bias null) in the same order.
+void conv_pack_shuffle2(const float* w, const float* bias, int K, int C, void* packed, float* bias_out) {
+    const int pc = K / 4;
+    std::vector<float> wp((size_t)K * C * 9);
+    for (int ph = 0; ph < 4; ++ph)
+        for (int oc = 0; oc < pc; ++oc) {
+            memcpy(&wp[((size_t)ph * pc + oc) * C * 9], &w[((size_t)4 * oc + ph) * C * 9], sizeof(float) * (size_t)C * 9);
+            if (bias_out) bias_out[ph * pc + oc] = bias ? bias[4 * oc + ph] : 0.f;
+        }
+    conv_pack(wp.data(), K, C, packed, 1);
 }
 
 // Panels holding only the taps of `mask` (bit r*3+s), in (r, s) order: [group][chunk][tap rank][row R][slot][8 ch]; mask 0x10 = a 1x1 conv,
@@ -2658,7 +2682,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     const int rpw64 = INNFER_KNOB("INNFER_RPW64", 3);
     const int rpw32 = INNFER_KNOB("INNFER_RPW32", 5);
     const int pc = INNFER_KNOB("INNFER_PC", 1);     // producer / consumer kernel for slab outputs
-    if (L.rowp && (nt != 4 || !pc || L.out_mode != OUT_SLAB || L.split || L.wino || L.stats_part || L.stride2 || L.conv1x1 || L.conv7 || L.conv7v || L.prefix_lrelu || L.pair_wpk ||
+    if (L.rowp && !(L.rowp == 2 && L.out_mode == OUT_SHUFFLE2) && (nt != 4 || !pc || L.out_mode != OUT_SLAB || L.split || L.wino || L.stats_part || L.stride2 || L.conv1x1 || L.conv7 || L.conv7v || L.prefix_lrelu || L.pair_wpk ||
                    L.gate_w || L.act > 2 || L.dilation > 1 || L.dilation_groups || (L.out_coff & 31)))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the plane row order (rowp) belongs to plain 3x3 slab convs and transposed-conv phases with 64-channel output groups");
     if (L.outm && (L.out_mode != OUT_NCHW || !pc || nt != 1 || L.res1 || L.res2 || L.outm < 0 || L.outm > 4))
@@ -2778,6 +2802,13 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
                            L.N, L.H, L.W);
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
+    }
+    if (L.out_mode == OUT_SHUFFLE2 && L.rowp == 2) {          // PixelShuffle(2) store on the producer / consumer kernel: phase-major plane-order panels (conv_pack_shuffle2)
+        if (!pc || nt != 4 || L.K % 256 || L.res1 || L.res2 || L.up || L.reflect || L.act > 2 || L.y0 != 0 || k.y1 != L.H || L.stats_part ||
+            (long)L.N * L.H * L.W * 64 * 4 >= 0x7fffffffL)
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the phase-major PixelShuffle(2) store needs K %% 256 == 0 (64-channel phases), act 0..2, no residual / upsampling / row range, < 2 GiB per output group");
+        k.phase_c = L.K / 4;
+        return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0xC001FF>(k, L.N, s);
     }
     if (pc && L.out_mode == OUT_SLAB && nt == 4 && L.stats_part) return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x11FF>(k, L.N, s);
     if (pc && L.out_mode == OUT_SLAB && nt == 4 && L.res1_lds && L.res1 && L.res1 == L.in && L.res1_gstride == L.in_gstride && L.act == 0 && L.K == 64 && L.C >= 96 &&

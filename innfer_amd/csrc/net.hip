@@ -96,6 +96,9 @@ struct ConvSlot {
     void* d_up4 = nullptr;       //   conv_pack_deconv2x panels of the summed weights + d_b4 (the bias once per phase), built with d_w
     void* d_up4p = nullptr;      //   the same in the plane row order (rowp slots: the one-visit form, conv3x3_pc UP4); d_up4 stays lane-contiguous (grids <= 16 wide, A/B)
     float* d_b4 = nullptr;
+    bool ps2 = false;            // the conv in front of a PixelShuffle(2) stage (nf -> 4 nf, nf 64): also packed phase-major in the plane row order (conv_pack_shuffle2)
+    void* d_ps = nullptr;        //   those panels + d_bps (the bias in the same order): the shuffle is the producer / consumer kernel's store (ConvLaunch.rowp = 2)
+    float* d_bps = nullptr;
     void* d_fuse = nullptr;      // a last conv of 64 -> <= 3 channels: its panel for the epilogue of HR_conv0 (conv_pack_fuse_last), built with d_w
     float* d_b = nullptr;        // bias padded to the panel width
     bool loaded = false;
@@ -121,6 +124,10 @@ struct innfer_net {
 #endif
     int up_phases = INNFER_UP_PHASES_DEFAULT;   // upconv_block convs as four 2x2-tap phases on the LR grid (innfer_net_set_upconv_phases; the macro: A/B builds)
     int fused_tail = 1;          // HR_conv0 -> conv_last as one kernel where the shapes allow it (innfer_net_set_fused_tail)
+#ifndef INNFER_PS_PC_DEFAULT
+#define INNFER_PS_PC_DEFAULT 1
+#endif
+    int ps_pc = INNFER_PS_PC_DEFAULT;   // PixelShuffle(2) stages on the producer / consumer kernel (phase-major panels); 0 (A/B builds): the two-workgroup kernel of rounds 1-4
     int res_lds = 1;             // the dense block's x5 * 0.2 + x with x taken from the conv's own staged LDS tiles (innfer_net_set_residual_lds; conv3x3_pc RLDS): 1 = where the RRDB's residual follows, 2 = every block
     int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
@@ -181,7 +188,7 @@ extern "C" int innfer_rrdbnet_create_ex(innfer_net_t* out, int in_nc, int out_nc
     net->convs.back().map_ok = true;             // LR_conv under mode 'NAC' with a norm layer (RRDBNet_arch.py:29; block.py:246-254)
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) {        // upconv_block: Upsample, conv, act -- pixelshuffle_block: conv, PixelShuffle, act (block.py:333-361)
-        if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * (scale == 3 ? 9 : 4), nf);
+        if (net->ps_up) { add_conv(net, "model." + std::to_string(idx), nf * (scale == 3 ? 9 : 4), nf); net->convs.back().ps2 = scale != 3 && nf == 64; }
         else { add_conv(net, "model." + std::to_string(idx + 1), nf, nf); net->convs.back().up2x = scale != 3; }
         idx += 3;
     }
@@ -218,7 +225,7 @@ extern "C" int innfer_srresnet_create_ex(innfer_net_t* out, int in_nc, int out_n
     net->convs.back().map_ok = true;
     int idx = 2;
     for (int u = 0; u < net->n_up; ++u) {        // pixelshuffle_block: conv, PixelShuffle, act -- upconv_block: Upsample, conv, act (block.py:333-361)
-        if (net->ps_up) add_conv(net, "model." + std::to_string(idx), nf * (scale == 3 ? 9 : 4), nf);
+        if (net->ps_up) { add_conv(net, "model." + std::to_string(idx), nf * (scale == 3 ? 9 : 4), nf); net->convs.back().ps2 = scale != 3 && nf == 64; }
         else { add_conv(net, "model." + std::to_string(idx + 1), nf, nf); net->convs.back().up2x = scale != 3; }
         idx += 3;
     }
@@ -243,6 +250,8 @@ extern "C" void innfer_net_destroy(innfer_net_t net) {
         if (c.d_fuse) (void)hipFree(c.d_fuse);
         if (c.d_up4) (void)hipFree(c.d_up4);
         if (c.d_up4p) (void)hipFree(c.d_up4p);
+        if (c.d_ps) (void)hipFree(c.d_ps);
+        if (c.d_bps) (void)hipFree(c.d_bps);
         if (c.d_b4) (void)hipFree(c.d_b4);
         if (c.d_map) (void)hipFree(c.d_map);
     }
@@ -317,6 +326,15 @@ extern "C" int innfer_net_set_conv(innfer_net_t net, int idx, const float* w, co
                 INNFER_HIP(hipMemcpy(c.d_up4p, pk.data(), pk.size(), hipMemcpyHostToDevice));
             }
             INNFER_HIP(hipMemcpy(c.d_b4, b4.data(), b4.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (c.ps2 && c.ksize == 3 && c.K % 256 == 0 && c.C % 32 == 0) {
+            std::vector<char> pk(conv_packed_bytes(c.K, c.C));
+            std::vector<float> bp(c.K, 0.f);
+            conv_pack_shuffle2(w, b, c.K, c.C, pk.data(), bp.data());
+            if (!c.d_ps) INNFER_HIP(hipMalloc(&c.d_ps, pk.size()));
+            if (!c.d_bps) INNFER_HIP(hipMalloc((void**)&c.d_bps, bp.size() * sizeof(float)));
+            INNFER_HIP(hipMemcpy(c.d_ps, pk.data(), pk.size(), hipMemcpyHostToDevice));
+            INNFER_HIP(hipMemcpy(c.d_bps, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         if (c.ksize == 3 && c.C == 64 && c.K <= 3) {          // (only the network's last conv has this shape)
             std::vector<char> fp(4096);
@@ -569,11 +587,12 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
         return timed_end(s, 2.0 * 9.0 * (L.K * (double)L.C + 64.0 * L.fuse_oc) * px, px * (L.C * 2.0 + L.fuse_oc * ob) + 9.0 * (L.K * L.C + 64.0 * L.fuse_oc) * 2.0, 2000 + 16 * conv_nt_for(L.K) + L.out_mode);
     }
     // launch kinds: 16 * NT + out_mode, + 1000 fp32-accurate (split) form, + 2000 fused HR_conv0 + conv_last (TMF 0x201FF), + 3000 the four 2x2-tap phases
-    // of an upconv_block (TM 0x1B, K = 4 * phase_c on the LR grid): their own instantiations, their own rows in the bench's per-kernel table.
+    // of an upconv_block (TM 0x1B, K = 4 * phase_c on the LR grid), + 4000 the PixelShuffle(2) store on the producer / consumer kernel (TMF 0xC001FF): their own
+    // instantiations, their own rows in the bench's per-kernel table.
     // The phase form's FLOPs are the ALGORITHMIC ones of the layer it replaces (nine taps on the 2H x 2W grid = 2 * 9 * 4K * C per LR pixel); it executes 4/9 of them.
     // (fp32-accurate mode: the same algorithmic FLOPs -- executed: 3x --, two slabs per tensor, three panels per weight)
     return timed_end(s, 2.0 * taps * L.K * L.C * px, L.split ? 2.0 * bytes + (double)taps * L.K * L.C * 2.0 : bytes,
-                     16 * conv_nt_for(L.K) + L.out_mode + (L.split ? 1000 : 0) + (L.deconv_phases ? 3000 : 0));
+                     16 * conv_nt_for(L.K) + L.out_mode + (L.split ? 1000 : 0) + (L.deconv_phases ? 3000 : 0) + ((L.out_mode == OUT_SHUFFLE2 && L.rowp == 2) ? 4000 : 0));
 }
 
 // nearest-neighbour upsampling of a slab by an integer factor (src = dst / f, block.py:321-322).  The 2x case is folded into the conv's input
@@ -901,6 +920,7 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         } else {                     // conv nf->4nf -> PixelShuffle(2) -> act (SRGAN: ReLU; RRDBNet(upsample_mode='pixelshuffle'): its act_type)
             ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, net->trunk_act);
             L.out_mode = OUT_SHUFFLE2;
+            if (cs.d_ps && net->ps_pc && !cs.d_map) { L.wpk = (const f16*)cs.d_ps; L.bias = cs.d_bps; L.rowp = 2; }      // the store of the producer / consumer kernel (conv3x3_pc PSH)
             rc = do_conv(L, s);
         }
         if (rc) return rc;
@@ -985,6 +1005,13 @@ extern "C" int innfer_pack_conv3x3_rows(const float* w, int K, int C, int plane_
     if (!w || !h_packed || K <= 0 || C <= 0 || C % 32 || (plane_rows && K % 64))
         return set_error(INNFER_ERR_INVALID, "pack_conv3x3_rows: K=%d C=%d (C must be a multiple of 32; the plane row order needs K %% 64 == 0)", K, C);
     conv_pack(w, K, C, h_packed, plane_rows ? 1 : 0);
+    return INNFER_OK;
+}
+
+extern "C" int innfer_pack_conv3x3_shuffle2(const float* w, const float* bias, int K, int C, void* h_packed, float* h_bias_out) {
+    if (!w || !h_packed || !h_bias_out || K <= 0 || K % 256 || C <= 0 || C % 32)
+        return set_error(INNFER_ERR_INVALID, "pack_conv3x3_shuffle2: K=%d C=%d (K must be a multiple of 256: four phases of 64-channel groups; C of 32)", K, C);
+    conv_pack_shuffle2(w, bias, K, C, h_packed, h_bias_out);
     return INNFER_OK;
 }
 
@@ -1074,6 +1101,8 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.out_mode = a->pixel_shuffle2 ? OUT_SHUFFLE2 : OUT_SLAB; L.reflect = a->reflect_pad; L.dilation = a->dilation; L.dilation_groups = a->dilation_groups;
     L.res1_lds = a->res1_from_input ? 2 : 0;                 // (the single-conv call: wherever the shape qualifies, one residual or two)
     L.rowp = a->plane_rows ? 1 : 0;
+    if (a->pixel_shuffle2 && a->plane_rows == 2) L.rowp = 2;          // phase-major panels + bias from innfer_pack_conv3x3_shuffle2: the producer / consumer kernel's store
+    else if (a->pixel_shuffle2 && a->plane_rows) return set_error(INNFER_ERR_INVALID, "conv3x3: pixel_shuffle2 takes plane_rows 0 (innfer_pack_conv3x3 panels) or 2 (innfer_pack_conv3x3_shuffle2 panels)");
     if (a->winograd) {
         if (a->pixel_shuffle2 || a->split || a->K % 32 || a->out_ch_off % 32 || (a->winograd != 1 && a->winograd != 2))
             return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (winograd): 1 | 2, K %% 32 == 0 (K=%d), whole output groups", a->K);

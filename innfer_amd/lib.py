@@ -147,6 +147,7 @@ SIGNATURES = {
     "innfer_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "innfer_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_pack_conv3x3_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "innfer_pack_conv3x3_shuffle2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "innfer_pack_convt2x_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "innfer_conv3x3_f16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "innfer_filter2d": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
