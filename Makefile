@@ -10,7 +10,7 @@ all: $(LIB)
 
 innfer_amd/csrc/tiles.o innfer_amd/csrc/colorfix.o: FLAGS += -ffp-contract=off
 
-%.o: %.hip innfer_amd/csrc/common.h innfer_amd/csrc/gather_gemm.h innfer_amd/csrc/norm_stats.h include/innfer_amd.h
+%.o: %.hip $(wildcard innfer_amd/csrc/*.h) $(wildcard innfer_amd/csrc/*.inc) include/innfer_amd.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJ)

@@ -144,312 +144,7 @@ struct KP {
 #endif
 };
 
-// Offsets of accumulator tile t of a lane from the lane's first channel, in a slab of group stride g (f16 elements) and in a linear channel array (bias), and the lane's
-// first channel inside its 16 NT-channel group.  ROWP (conv3x3_pc<.., TMF | 0x400000>, 64-channel groups): the PLANE row order -- accumulator (tile t, row 4 lg + j) is
-// channel 32 (t >> 1) + 8 lg + 4 (t & 1) + j instead of 16 lg + 4 t + j: a lane's sixteen channels are 16 bytes in EACH of the group's two 32-channel slab planes, lanes
-// lg = 0..3 cover a pixel's whole 64 bytes of one plane, and a store / residual-load instruction touches ONE plane -- half the lines per instruction (measured as an
-// ablation first: frame -1.4 %, profiles/r4/upconv_bound.txt).  Panels from conv_pack*(.., rowp = 1).
-template <int NT, bool ROWP>
-__device__ __forceinline__ long toff_slab(int t, long g) { return (NT == 4 && ROWP) ? (long)(t >> 1) * g + 4 * (t & 1) : 4 * t; }
-template <int NT, bool ROWP>
-__device__ __forceinline__ int toff_lin(int t) { return (NT == 4 && ROWP) ? 32 * (t >> 1) + 4 * (t & 1) : 4 * t; }
-template <int NT, bool ROWP>
-__device__ __forceinline__ int lane_cbase(int lg) { return ((NT == 4 && ROWP) ? 8 : 4 * NT) * lg; }
-
-// Slab epilogue, specialised on (activation, residual 1, residual 2) so that the unrolled loop over the
-// wave's pixel tiles is straight-line code: residual loads for all tiles first (their latencies
-// overlap), then act -> *s1 + res1 -> *s2 + res2 -> fp16 -> one 8*NT-byte store per pixel tile.
-// (The generic runtime-flag version of this loop took ~15 k cycles per workgroup, a third of the
-// lifetime of a 64->32 workgroup: profiles/r1/wg_timeline_r1c.txt.)
-// POLY: (n, y, x) address a polyphase sub-image of a dilation-d conv: image n / d^2, phase (py, px) = (n % d^2) / d, % d, full-resolution
-// pixel (y*d + py, x*d + px); the sub-image ends where the full image does.  No residuals in that mode.
-// CV (image canvas, see conv3x3_pc): (ty0, tx0) are canvas coordinates; a pixel tile may lie in the cell below / right of the tile's first
-// cell, or on the one-pixel gutter between cells (not stored).  Same arithmetic, per-pixel-tile addresses.
-// SC1 (RLDS kernels): res1 is already inside the accumulators as x / s1 (consumer loop); the epilogue only scales by s1 (then R2 as usual).
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool SC1 = false, bool ROWP = false>
-__device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2 * RPW], int ty0, int tx0, int wave, int li, int cbase) {
-    constexpr int MT = 2 * RPW;
-    // ACT 7 (pair gate, PAN's PAConv): the lane's upper NT / 2 channel tiles are the gates of its lower ones -- out = conv_lo * sigmoid(conv_hi),
-    // half as many output channels (the launch's rows are ordered so that a value and its gate share a lane)
-    constexpr int NTS = ACT == 7 ? NT / 2 : NT;
-    const int oc0 = (ACT == 7 ? cbase >> 1 : cbase) + p.out_coff;
-    const int cyB = ty0 / p.cv_h1, yB = ty0 - cyB * p.cv_h1 + wave * RPW;        // wave-uniform
-    const int cxB = tx0 / p.cv_w1, xB = tx0 - cxB * p.cv_w1 + li;
-    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + (oc0 & 31);
-    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + (cbase & 31) : nullptr;
-    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + (cbase & 31) : nullptr;
-    bool ok[MT];
-    int off[MT];                                   // element offset of the pixel inside a channel group (< 2^31: checked by the host)
-    f16x4 r1[R1 ? MT : 1][NT], r2[R2 ? MT : 1][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        int y = yB + (m >> 1), cy = cyB;
-        if (y >= p.cv_h1) { y -= p.cv_h1; ++cy; }
-        int x = xB + (m & 1) * 16, cx = cxB;
-        if (x >= p.cv_w1) { x -= p.cv_w1; ++cx; }
-        const int n = cy * p.cv_gx + cx;
-        ok[m] = y < p.H && x < p.W && cy < p.cv_gy && cx < p.cv_gx && n < p.N;
-        off[m] = ((n * p.H + y) * p.W + x) * 32;
-        if (R1 && !R2 && ok[m]) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + toff_slab<NT, ROWP>(t, p.res1_gstride));
-        }
-        if (!R1 && R2 && ok[m]) {       // one residual from memory: its loads for all pixel tiles first, like the R1-only form
-#pragma unroll
-            for (int t = 0; t < NT; ++t) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + off[m] + toff_slab<NT, ROWP>(t, p.res2_gstride));
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (!ok[m]) continue;
-        f16* op = ob + off[m];
-        if (R1 && R2) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + off[m] + toff_slab<NT, ROWP>(t, p.res1_gstride));
-                r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + off[m] + toff_slab<NT, ROWP>(t, p.res2_gstride));
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NTS; ++t) {
-            f16x4 h;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float f = acc[t][m][j];
-                if (ACT == 7) f = f * (1.0f / (1.0f + expf(-acc[t + NT / 2][m][j])));
-                else if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                if (SC1) { f = f * p.s1; FP32_VALUE(f); }
-                if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
-                if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
-                FP32_VALUE(f);
-                h[j] = (f16)f;
-            }
-            *(f16x4*)(op + toff_slab<NT, ROWP>(t, p.out_gstride)) = h;
-        }
-    }
-}
-
-// DCV (conv3x3_pc<.., TM = 0x1B>: one output phase of ConvTranspose2d(4, 2, 1) per 16*NT-channel group): (ty0, tx0) are coordinates of the phase's
-// shifted lattice (see decode); virtual pixel (y', x') of phase (a, b) is output pixel (2y' - a, 2x' - b) of the 2H x 2W slab, channel ch % phase_c.
-// PSH (conv3x3_pc<.., TMF | 0x800000>: nn.PixelShuffle(2) as the store, block.py:333-346): the K = 4 * phase_c conv channels arrive PHASE-MAJOR (panels from
-// conv_pack_shuffle2: channel ph * phase_c + oc is reference channel 4 oc + ph), so a 64-channel group is one output phase (a, b) = (ph >> 1, ph & 1) of
-// 64 consecutive output channels: the DCV store without the lattice shift -- pixel (y, x) of the conv grid goes to (2y + a, 2x + b).
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool HOIST, bool POLY = false, bool DCV = false, bool PAIR = false, bool SC1 = false, bool ROWP = false, bool PSH = false>
-__device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0,
-                                              int wave, int li, int cbase, int dil = 1) {
-    constexpr int MT = 2 * RPW;
-    constexpr int NTS = ACT == 7 ? NT / 2 : NT;              // ACT 7: pair gate (see epilogue_slab_cv)
-    int oc0 = (ACT == 7 ? cbase >> 1 : cbase) + p.out_coff;
-    int yw = ty0 + wave * RPW, xl = tx0 + li;
-    long pix0 = ((long)n * p.H + yw) * p.W + xl;
-#ifdef INNFER_ABLATE
-    if (p.abl & 16) pix0 = (long)blockIdx.x * 64 + wave * RPW * p.W + li;      // every tile of a workgroup stores to the same (cache-resident) lines
-#endif
-    long rowstep = (long)p.W * 32;
-    long colstep = 16 * 32;
-    int ylim = p.y1, xlim = p.W;
-    if constexpr (POLY) {
-        const int d = dil, dd = d * d;
-        const int nn = n / dd, ph = n - nn * dd, py = ph / d, px = ph - py * d;
-        pix0 = ((long)nn * p.fullH + (long)yw * d + py) * p.fullW + (long)xl * d + px;
-        rowstep = (long)p.fullW * 32 * d;
-        colstep = 16L * 32 * d;
-        ylim = (p.fullH - py + d - 1) / d;
-        xlim = (p.fullW - px + d - 1) / d;
-    }
-    if constexpr (DCV || PSH) {
-        const int ph = cbase / p.phase_c, a = ph >> 1, b = ph & 1;
-        oc0 -= ph * p.phase_c;
-        if constexpr (!PSH) { yw -= a; xl -= b; }       // source pixel of the virtual one (>= 0: the lattice starts at (a, b))
-        pix0 = ((long)n * 2 * p.H + 2 * yw + a) * (2 * p.W) + 2 * xl + b;
-        rowstep = (long)p.W * 32 * 4;
-        colstep = 16 * 32 * 2;
-        ylim = p.H;
-        if constexpr (PAIR) { pix0 = ((long)(2 * n) * 2 * p.H + 2 * yw + a) * (2 * p.W) + 2 * xl + b; colstep = 4L * p.H * p.W * 32; }
-#ifdef INNFER_ABLATE
-        // abl 64 (wrong results by construction): phase b of a row goes to the left / right HALF of the HR row as 16 consecutive pixels -- the same bytes as
-        // whole 128-byte lines instead of every other 64-byte pixel (what the half-line stores of the phase scatter cost: profiles/r4/upconv_bound.txt)
-        if (!PAIR && (p.abl & 64)) { pix0 = ((long)n * 2 * p.H + 2 * yw + a) * (2 * p.W) + xl + b * p.W; colstep = 16 * 32; }
-#endif
-    } else if constexpr (PAIR) {
-        // PAIR (images at most 16 pixels wide): the tile's two 16-pixel segments are images 2n and 2n + 1 -- a segment step is an image step
-        pix0 = ((long)(2 * n) * p.H + yw) * p.W + xl;
-        colstep = (long)p.H * p.W * 32;
-    }
-    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + pix0 * 32 + (oc0 & 31);
-    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + pix0 * 32 + (cbase & 31) : nullptr;
-    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + pix0 * 32 + (cbase & 31) : nullptr;
-    bool ok[MT];
-    f16x4 r1[R1 ? MT : 1][NT], r2[R2 ? MT : 1][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        ok[m] = PAIR ? (2 * n + (m & 1) < p.N && yw + (m >> 1) < ylim && xl < xlim) : ((yw + (m >> 1) < ylim) && (xl + (m & 1) * 16 < xlim));
-        const long o = (m >> 1) * rowstep + (m & 1) * colstep;
-        if (HOIST && R1 && ok[m]) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + toff_slab<NT, ROWP>(t, p.res1_gstride));
-        }
-        if (HOIST && R2 && ok[m]) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + o + toff_slab<NT, ROWP>(t, p.res2_gstride));
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (!ok[m]) continue;
-#ifdef INNFER_ABLATE
-        if (p.abl & 1) continue;
-#endif
-        f16* op = ob + (m >> 1) * rowstep + (m & 1) * colstep;
-#ifdef INNFER_ABLATE
-        // abl 128 (wrong results by construction): every lane's 32 bytes of pixel tile m at consecutive addresses -- a store instruction writes 1 KB of whole
-        // lines instead of 16-byte pieces of 32 (what the piece-wise stores of the MFMA result layout cost)
-        if (DCV && !PAIR && (p.abl & 128)) op = (f16*)p.out + (pix0 - 2 * li) * 32 + (m * 64 + (int)(threadIdx.x & 63)) * 16;
-        // abl 256 (values land permuted inside the wave's own 1 KB runs; same bytes, same lines, no overlap between waves): lane L writes piece L of the run --
-        // consecutive lanes -> consecutive addresses -- instead of lane (li, lg) -> pixel li, piece lg: what the LANE ORDER of the MFMA result layout costs
-        if (!DCV && !PAIR && !POLY && (p.abl & 256)) {
-            const int lgq = (int)(threadIdx.x & 63) >> 4;
-            if (NT == 2) op = op - li * 32 - 8 * lgq + (int)(threadIdx.x & 63) * 8;
-            else if (NT == 4) op = op - li * 32 - 16 * (lgq & 1) + ((lgq & 1) * 16 + li) * 16;
-        }
-        if (!DCV && !PAIR && !POLY && (p.abl & 128)) op = (f16*)p.out + (pix0 - li) * 32 + (m * 64 + (int)(threadIdx.x & 63)) * (4 * NT);      // (the plain layers: 16 / 32 bytes per lane)
-#endif
-        if (!HOIST) {
-            const long o = (m >> 1) * rowstep + (m & 1) * colstep;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (R1) r1[R1 ? m : 0][t] = *(const f16x4*)(r1b + o + toff_slab<NT, ROWP>(t, p.res1_gstride));
-                if (R2) r2[R2 ? m : 0][t] = *(const f16x4*)(r2b + o + toff_slab<NT, ROWP>(t, p.res2_gstride));
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NTS; ++t) {
-            f16x4 h;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float f = acc[t][m][j];
-                if (ACT == 7) {
-                    f = f * (1.0f / (1.0f + expf(-acc[t + NT / 2][m][j])));
-                } else if (ACT >= 4) {           // pixel-attention gate (PAN): res1 * sigmoid(conv), ACT 4: LeakyReLU(0.2) after it
-                    f = (float)r1[R1 ? m : 0][t][j] * (1.0f / (1.0f + expf(-f)));
-                    if (ACT == 4) f = fmaxf(f, 0.2f * f);
-                } else {
-                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                    if (SC1) { f = f * p.s1; FP32_VALUE(f); }          // RLDS: res1 is inside the accumulator as x / s1
-                    if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
-                    if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
-                }
-                FP32_VALUE(f);
-                h[j] = (f16)f;
-            }
-            *(f16x4*)(op + toff_slab<NT, ROWP>(t, p.out_gstride)) = h;
-        }
-    }
-}
-
-// SPLIT (fp32-accurate mode, conv3x3_pc<.., TMF | 0x2000>): a tensor is a PAIR of fp16 slabs -- hi = fp16(x) and lo = fp16((x - hi) * 2^11), the lo slab a
-// fixed distance behind the hi slab -- i.e. 22 significant bits per value with the fp16 kernels' data path.  The epilogue works on the fp32
-// accumulators exactly like the fp16 one (activation, *s1 + res1, *s2 + res2 with explicit fmaf) but reads its residuals as hi + lo * 2^-11 (exact
-// in fp32) and stores both parts.  CV: image-canvas addressing (see epilogue_slab_cv).
-constexpr float SPLIT_UP = 2048.0f, SPLIT_DOWN = 1.0f / 2048.0f;
-template <int RPW, int NT, int ACT, bool R1, bool R2, bool CV>
-__device__ __forceinline__ void epilogue_slab_split(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0, int wave, int li, int cbase) {
-    constexpr int MT = 2 * RPW;
-    const int oc0 = cbase + p.out_coff;
-    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + (oc0 & 31);
-    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + (cbase & 31) : nullptr;
-    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + (cbase & 31) : nullptr;
-    int cyB = 0, yB = 0, cxB = 0, xB = 0;
-    if constexpr (CV) {
-        cyB = ty0 / p.cv_h1; yB = ty0 - cyB * p.cv_h1 + wave * RPW;
-        cxB = tx0 / p.cv_w1; xB = tx0 - cxB * p.cv_w1 + li;
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        bool ok;
-        long off;                                  // element offset of the pixel inside a channel group
-        if constexpr (CV) {
-            int y = yB + (m >> 1), cy = cyB;
-            if (y >= p.cv_h1) { y -= p.cv_h1; ++cy; }
-            int x = xB + (m & 1) * 16, cx = cxB;
-            if (x >= p.cv_w1) { x -= p.cv_w1; ++cx; }
-            const int nn = cy * p.cv_gx + cx;
-            ok = y < p.H && x < p.W && cy < p.cv_gy && cx < p.cv_gx && nn < p.N;
-            off = (((long)nn * p.H + y) * p.W + x) * 32;
-        } else {
-            const int y = ty0 + wave * RPW + (m >> 1), x = tx0 + li + (m & 1) * 16;
-            ok = y < p.y1 && x < p.W;
-            off = (((long)n * p.H + y) * p.W + x) * 32;
-        }
-        if (!ok) continue;
-        f16x4 r1h[NT], r1l[NT], r2h[NT], r2l[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (R1) { r1h[t] = *(const f16x4*)(r1b + off + 4 * t); r1l[t] = *(const f16x4*)(r1b + p.res1_lo + off + 4 * t); }
-            if (R2) { r2h[t] = *(const f16x4*)(r2b + off + 4 * t); r2l[t] = *(const f16x4*)(r2b + p.res2_lo + off + 4 * t); }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f16x4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float f = acc[t][m][j];
-                if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                if (R1) f = __builtin_fmaf(f, p.s1, __builtin_fmaf((float)r1l[t][j], SPLIT_DOWN, (float)r1h[t][j]));
-                if (R2) f = __builtin_fmaf(f, p.s2, __builtin_fmaf((float)r2l[t][j], SPLIT_DOWN, (float)r2h[t][j]));
-                FP32_VALUE(f);
-                h[j] = (f16)f;
-                float d = f - (float)h[j];
-                FP32_VALUE(d);
-                l[j] = (f16)(d * SPLIT_UP);
-            }
-            *(f16x4*)(ob + off + 4 * t) = h;
-            *(f16x4*)(ob + p.out_lo + off + 4 * t) = l;
-        }
-    }
-}
-
-// WINO (conv3x3_pc<.., TMF | 0x4000>): output transform of the row Winograd form -- lane li holds M_0..3 of pixel pair li of each of the wave's rows:
-// Y(2 li) = M0 + M1 + M2 + bias, Y(2 li + 1) = M1 - M2 - M3 + bias, then the fp16 epilogue (activation, *s1 + res1, *s2 + res2, one rounding).
-template <int RPW, int NT, int ACT, bool R1, bool R2>
-__device__ __forceinline__ void epilogue_slab_wino(const KP& p, f32x4 (&m)[4][NT][RPW], const f32x4 (&bias)[NT], int n, int ty0, int tx0, int wave, int li, int cbase) {
-    const int oc0 = cbase + p.out_coff;
-    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + (oc0 & 31);
-    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + (cbase & 31) : nullptr;
-    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + (cbase & 31) : nullptr;
-#pragma unroll
-    for (int rw = 0; rw < RPW; ++rw) {
-        const int y = ty0 + wave * RPW + rw;
-        if (y >= p.y1) continue;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int x = tx0 + 2 * li + q;
-            if (x >= p.W) continue;
-            const long off = (((long)n * p.H + y) * p.W + x) * 32;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                f16x4 r1, r2, h;
-                if (R1) r1 = *(const f16x4*)(r1b + off + 4 * t);
-                if (R2) r2 = *(const f16x4*)(r2b + off + 4 * t);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float f = q == 0 ? (m[0][t][rw][j] + m[1][t][rw][j]) + m[2][t][rw][j] : (m[1][t][rw][j] - m[2][t][rw][j]) - m[3][t][rw][j];
-                    f += bias[t][j];
-                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                    if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[j]);
-                    if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[j]);
-                    FP32_VALUE(f);
-                    h[j] = (f16)f;
-                }
-                *(f16x4*)(ob + off + 4 * t) = h;
-            }
-        }
-    }
-}
+#include "conv3x3_epilogue_slab.h"
 
 template <int RPW, int NT, int OUTMODE>
 __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mfma(const KP p) {
@@ -796,417 +491,11 @@ __global__ __launch_bounds__(256, (RPW == 3 && NT == 2) ? 3 : 2) void conv3x3_mf
 #define PCT(var) do { } while (0)
 #define PCACC(slot, t1, t0) do { } while (0)
 #endif
-// FUSE (conv3x3_pc<.., TMF | 0x20000>): index of a pixel of a tile's 18 x 34 neighbourhood (Y in [-1, 16], X in [-1, 32]) that is NOT at least one pixel inside
-// the tile, among the 192 such pixels: rows -1, 0 (34 each), rows 15, 16 (34 each), then columns -1, 0, 31, 32 of rows 1 .. 14
-__host__ __device__ inline int fuse_ring_index(int Y, int X) {
-    if (Y <= 0) return (Y + 1) * 34 + X + 1;
-    if (Y >= 15) return 68 + (Y - 15) * 34 + X + 1;
-    return 136 + (Y - 1) * 4 + (X <= 0 ? X + 1 : X - 29);
-}
-constexpr int FUSE_RING = 192;
-constexpr int FUSE_PITCH = 516;          // floats between the product planes in LDS (512 pixels + 4: see fused_last_epilogue)
+#include "conv3x3_fuse.h"
 
-// One finished pixel of the fused last conv: planar fp16 / fp32 [N, oc, H, W] (mode 0 / 1), or the uint8 HWC BGR image of tensor2np (mode 2: the conversion of
-// the planar kernel's uint8 epilogue, value for value -- utils.py:197-248)
-__device__ __forceinline__ void fuse_store_pixel(void* out, int mode, int denorm, int round16, int oc, long n, int H, int W, int y, int x, const float (&v)[3]) {
-    if (mode == 2) {
-        uint8_t* o = (uint8_t*)out + ((n * H + y) * W + x) * oc;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            if (c < oc) {
-                float t = round16 ? (float)(f16)v[c] : v[c];
-                if (denorm) t = fminf(fmaxf(__fdiv_rn(__fsub_rn(t, -1.0f), 2.0f), 0.0f), 1.0f);
-                t = fminf(fmaxf(__fmul_rn(255.0f, t), 0.0f), 255.0f);
-                o[oc == 3 ? 2 - c : c] = (uint8_t)__float2int_rn(t);
-            }
-        return;
-    }
-    const long plane = (long)H * W, ob = n * oc * plane + (long)y * W + x;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        if (c < oc) {
-            if (mode == 1) ((float*)out)[ob + c * plane] = v[c];
-            else ((f16*)out)[ob + c * plane] = (f16)v[c];
-        }
-}
+#include "conv3x3_stats_gate_rlds.h"
 
-// The fused last conv (see the FUSE flag of conv3x3_pc).  acc: this wave's 2 rows x 32 pixels x 64 channels (bias included); pl: the LDS stage the tile has
-// finished with (>= 64 KB); aw: the last conv's four A fragments in LDS; tile: the tile's index over the batch (n, ty, tx).
-template <int RPW, int NT>
-__device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT][2 * RPW], char* pl, const char* aw, int n, int ty0, int tx0, int cw, int lane, int tile) {
-    constexpr int MT = 2 * RPW;
-    const int li = lane & 15, lg = lane >> 4;
-    asm volatile("s_barrier" ::: "memory");                   // every consumer has read its last fragments of this stage: it may be overwritten
-    // (three phases with short live ranges -- the kernel's main loop already sits at the 168-register budget: the fp16 fragments of all four pixel tiles first
-    //  (the 64 accumulator registers die there), then one A fragment at a time against all of them, then the stores)
-    f16x8 hb[MT][2];                                        // channels 16 lg + 8 ks + e of pixel li: the values the unfused epilogue would have stored
-    // (the activation chosen ONCE: a uniform test per value is a branch per value in this unrolled code -- 128 of them cost more than the rest of the epilogue)
-    auto to_f16 = [&](auto act_tag) __attribute__((always_inline)) {
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float f = acc[2 * ks + (e >> 2)][m][e & 3];
-                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                    FP32_VALUE(f);
-                    hb[m][ks][e] = (f16)f;
-                }
-    };
-    if (p.act == 1) to_f16(std::integral_constant<int, 1>{}); else if (p.act == 2) to_f16(std::integral_constant<int, 2>{}); else to_f16(std::integral_constant<int, 0>{});
-    f32x4 pa[2][MT];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) pa[rt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const f16x8 af = *(const f16x8*)(aw + ((rt * 2 + ks) * 64 + lane) * 16);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) pa[rt][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, hb[m][ks], pa[rt][m], 0, 0, 0);
-        }
-    }
-    // 27 planes of 512 pixels, plane pitch 516 floats: a store instruction's 64 lanes (16 pixels x the 4 rows 4 lg + j) and a gather's 64 consecutive
-    // pixels of one plane fall into 64 different banks (pixel-major rows of 32 floats were a 32-way conflict)
-    char* const plw = pl + ((4 * lg) * FUSE_PITCH + cw * RPW * 32 + li) * 4;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *(float*)(plw + ((16 * rt + j) * FUSE_PITCH + (m >> 1) * 32 + (m & 1) * 16) * 4) = pa[rt][m][j];       // (all 32 rows: the five padding rows fit the stage, a lane-dependent test per store costs more)
-            }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");                   // the tile's products are in LDS
-    // Every lane sums its OWN pixel of the tile (512 lanes, 512 pixels: no division, the row tests are uniform but for the first / last wave) ...
-    {
-        const int Y = cw * RPW + (lane >> 5), X = lane & 31;
-        const float* q0 = (const float*)pl + Y * 32 + X;
-        float S0 = 0.f, S1 = 0.f, S2 = 0.f;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const bool ry = dy == 0 ? Y > 0 : (dy == 2 ? Y < 15 : true);
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const bool cx = dx == 0 ? X > 0 : (dx == 2 ? X < 31 : true);
-                if (ry && cx) {                                   // out(Y, X) += W[dy][dx] . hr(Y + dy - 1, X + dx - 1)
-                    const float* q = q0 + (dy * 3 + dx) * 3 * FUSE_PITCH + (dy - 1) * 32 + (dx - 1);
-                    S0 += q[0]; S1 += q[FUSE_PITCH]; S2 += q[2 * FUSE_PITCH];
-                }
-            }
-        }
-        if (Y >= 1 && Y <= 14 && X >= 1 && X <= 30) {            // complete: every hr pixel it reads lies in this tile
-            const float v[3] = {S0 + p.fl_bias[0], p.fl_oc > 1 ? S1 + p.fl_bias[1] : 0.f, p.fl_oc > 2 ? S2 + p.fl_bias[2] : 0.f};
-            fuse_store_pixel(p.fl_out, p.fl_out_mode, p.out_denorm, p.out_round16, p.fl_oc, n, p.H, p.W, ty0 + Y, tx0 + X, v);
-        } else {
-            float* sd = p.fl_side + ((long)tile * FUSE_RING + fuse_ring_index(Y, X)) * 3;
-            sd[0] = S0; sd[1] = S1; sd[2] = S2;
-        }
-    }
-    // ... and the first hundred lanes one of the 100 pixels just outside it (rows -1 and 16, columns -1 and 32), which only the tile's edge pixels reach
-    const int o = cw * 64 + lane;
-    if (o < 100) {
-        int Y, X;
-        if (o < 34) { Y = -1; X = o - 1; } else if (o < 68) { Y = 16; X = o - 35; } else { Y = (o - 68) >> 1; X = ((o - 68) & 1) ? 32 : -1; }
-        float S0 = 0.f, S1 = 0.f, S2 = 0.f;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int y = Y + dy - 1, x = X + dx - 1;
-                if (y >= 0 && y < 16 && x >= 0 && x < 32) {
-                    const float* q = (const float*)pl + (dy * 3 + dx) * 3 * FUSE_PITCH + y * 32 + x;
-                    S0 += q[0]; S1 += q[FUSE_PITCH]; S2 += q[2 * FUSE_PITCH];
-                }
-            }
-        float* sd = p.fl_side + ((long)tile * FUSE_RING + fuse_ring_index(Y, X)) * 3;
-        sd[0] = S0; sd[1] = S1; sd[2] = S2;
-    }
-}
-
-// Finishes the rim pixels of the fused last conv: every pixel on the rim of a tile sums, in a fixed order, the partial sums of the tiles whose 18 x 34
-// neighbourhood contains it (its own and one to three neighbours), adds the bias and stores.  One thread per (tile, rim pixel): 92 per tile.
-__global__ void fuse_combine_kernel(const float* side, const float* bias, void* out, int mode, int denorm, int round16, int oc, int N, int H, int W) {
-    const int tiles_x = W / 32, tiles_y = H / 16, per_img = tiles_x * tiles_y;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)N * per_img * 92) return;
-    const int tile = (int)(idx / 92), r = (int)(idx - (long)tile * 92);
-    int Y, X;
-    if (r < 32) { Y = 0; X = r; } else if (r < 64) { Y = 15; X = r - 32; } else { const int k = r - 64; Y = 1 + (k >> 1); X = (k & 1) ? 31 : 0; }
-    const int n = tile / per_img, t = tile - n * per_img, ty = t / tiles_x, tx = t - ty * tiles_x;
-    float S[3] = {bias[0], oc > 1 ? bias[1] : 0.f, oc > 2 ? bias[2] : 0.f};
-    for (int a = -1; a <= 1; ++a)
-        for (int b = -1; b <= 1; ++b) {
-            const int nty = ty + a, ntx = tx + b;
-            if (nty < 0 || nty >= tiles_y || ntx < 0 || ntx >= tiles_x) continue;
-            const int Yr = Y - 16 * a, Xr = X - 32 * b;
-            if (Yr < -1 || Yr > 16 || Xr < -1 || Xr > 32) continue;
-            const float* sd = side + ((long)(n * per_img + nty * tiles_x + ntx) * FUSE_RING + fuse_ring_index(Yr, Xr)) * 3;
-            S[0] += sd[0]; S[1] += sd[1]; S[2] += sd[2];
-        }
-    fuse_store_pixel(out, mode, denorm, round16, oc, n, H, W, ty * 16 + Y, tx * 32 + X, S);
-}
-
-// Partial statistics of a norm layer that follows the conv, out of the accumulators (fp32, bias included, before the fp16 rounding): every consumer
-// wave reduces its RPW x 32 pixels per channel to (count, mean, M2 = sum of squared deviations from that mean) -- in-lane over its pixel tiles,
-// a fixed xor butterfly over the 16 pixel lanes -- and writes them to
-//   part[((slot * NCW + wave) * cn + channel) * 3],  slot = tile index over the batch (x 4 + phase behind the phase lattice).
-// norm::combine_parts merges an image's partials in index order (Chan's update): deterministic, no atomics, and the pass that re-read the conv
-// output for its statistics is gone.
-template <int RPW, int NT, bool DCV, bool PAIR, int NCW>
-__device__ __forceinline__ void epilogue_stats(const KP& p, const f32x4 (&acc)[NT][2 * RPW], const f32x4 (&bias)[NT], int ty0, int tx0, int wave, int li,
-                                               int cbase, int tile) {
-    static_assert(NT == 4, "sixteen channels per lane: one per pixel lane after the transposing reduction");
-    constexpr int MT = 2 * RPW;
-    int yw = ty0 + wave * RPW, x0 = tx0, ylim = p.y1, c0 = cbase, slot = tile, ph = 0;
-    if constexpr (DCV) {
-        ph = cbase / p.phase_c;
-        yw -= ph >> 1; x0 -= ph & 1; ylim = p.H;
-        c0 -= ph * p.phase_c;
-        slot = tile * 4 + ph;
-    }
-    // PAIR: the two segments are two images (2q, 2q + 1; q = tile / tiles_y): one record set per image, at that image's slot
-#pragma unroll
-    for (int sg = 0; sg < (PAIR ? 2 : 1); ++sg) {
-    if constexpr (PAIR) {
-        const int q = tile / p.tiles_y, ty = tile - q * p.tiles_y;
-        if (2 * q + sg >= p.N) continue;
-        slot = (2 * q + sg) * p.tiles_y + ty;
-        if constexpr (DCV) slot = slot * 4 + ph;
-    }
-    bool ok[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-        ok[m] = PAIR ? ((m & 1) == sg && yw + (m >> 1) < ylim && x0 + li < p.W) : ((yw + (m >> 1) < ylim) && (x0 + li + (m & 1) * 16 < p.W));
-    const int rows = min(max(ylim - yw, 0), RPW), cols = min(max(p.W - x0, 0), PAIR ? 16 : 32);
-    const float cnt = (float)(rows * cols);                        // valid pixels of this wave (uniform)
-    // sums of (x - bias) and of its square per channel: the conv response without its bias has a small mean, so M2 = s2 - s1^2 / n loses nothing
-    float s1[16], s2[16];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a = 0.f, b = 0.f;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) { const float d = ok[m] ? acc[t][m][j] - bias[t][j] : 0.f; a += d; b += d * d; }
-            s1[4 * t + j] = a; s2[4 * t + j] = b;
-        }
-    // transposing reduction over the 16 pixel lanes: at the step of lane bit `bit` a lane keeps the half of its values whose channel index has
-    // that bit equal to its own and adds the partner's half -- 8 + 4 + 2 + 1 exchanges instead of 16 x 4; lane li ends with channel li's totals
-#define INNFER_TR_STEP(BIT, CNT)                                                                      \
-    _Pragma("unroll") for (int i = 0; i < CNT; ++i) {                                                 \
-        const bool up = (li & BIT) != 0;                                                              \
-        const float k1 = up ? s1[i + CNT] : s1[i], g1 = up ? s1[i] : s1[i + CNT];                     \
-        const float k2 = up ? s2[i + CNT] : s2[i], g2 = up ? s2[i] : s2[i + CNT];                     \
-        s1[i] = k1 + __shfl_xor(g1, BIT);                                                             \
-        s2[i] = k2 + __shfl_xor(g2, BIT);                                                             \
-    }
-    INNFER_TR_STEP(8, 8)
-    INNFER_TR_STEP(4, 4)
-    INNFER_TR_STEP(2, 2)
-    INNFER_TR_STEP(1, 1)
-#undef INNFER_TR_STEP
-    // channel of lane li: bit 3 chose between values [0, 8) / [8, 16), bit 2 between the halves of that, ... = value index li = 4 t + j
-    float bl = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bl = (li == 4 * t + j) ? bias[t][j] : bl;
-    const float inv = cnt > 0.f ? 1.0f / cnt : 0.f;
-    const float mean = s1[0] * inv;
-    float* o = p.stats_part + ((long)(slot * NCW + wave) * p.stats_cn + c0 + li) * 3;
-    o[0] = cnt; o[1] = bl + mean; o[2] = fmaxf(s2[0] - s1[0] * mean, 0.f);
-    }
-}
-
-// SGATE (conv3x3_pc<.., TMF | 0x80000>): v = fp16(acc) is the B fragment of the 32 x 32 gate matrix (a lane's 8 accumulators are 8 consecutive channels of its pixel);
-// acc <- v * sigmoid(W v + b).  Sigmoid on the hardware exponential / reciprocal: at 2160 x 3840 this epilogue evaluates 265 M of them (the libm forms were 0.3 of the launch).
-template <int MT>
-__device__ __forceinline__ void self_gate(f32x4 (&acc)[2][MT], const f16x8* sgw, const f32x4* sgb) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        f16x8 vb;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) vb[4 * t + j] = (f16)acc[t][m][j];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_f16(sgw[t], vb, sgb[t], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][m][j] = (float)vb[4 * t + j] * __frcp_rn(1.0f + __expf(-g[j]));
-        }
-    }
-}
-
-// RLDS (conv3x3_pc<.., TMF | 0x40000>): the lane's 16 residual channels of each of its MT pixel tiles from the live LDS stage `st` (byte offsets roffs), added to the fp32
-// accumulators as x / s1 (rs1 = 1 / s1)
-template <int MT>
-__device__ __forceinline__ void residual_from_lds(f32x4 (&acc)[4][MT], const char* st, const int* roffs, float rs1) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const f16x8 x0 = *(const f16x8*)(st + roffs[m]), x1 = *(const f16x8*)(st + roffs[m] + 16);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[t][m][j] = __builtin_fmaf((float)(t < 2 ? x0 : x1)[(t & 1) * 4 + j], rs1, acc[t][m][j]);
-    }
-}
-
-// The same for the plane row order (ROWP): the staged group HALF (0 / 1) holds the residual channels of the lane's tiles 2 half, 2 half + 1 -- 8 channels, one 16-byte slot
-template <int MT, int HALF>
-__device__ __forceinline__ void residual_from_lds_plane(f32x4 (&acc)[4][MT], const char* st, const int* roffs, float rs1) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const f16x8 x = *(const f16x8*)(st + roffs[m]);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[2 * HALF + tt][m][j] = __builtin_fmaf((float)x[tt * 4 + j], rs1, acc[2 * HALF + tt][m][j]);
-    }
-}
-
-// Planar (NCHW) epilogue of conv3x3_pc -- the networks' last convs: activation, `outm`, the phase scatter of a transposed conv, or tensor2np as the store
-// (uint8 HWC image).  Moved out of the kernel body in round 4; force-inlined, the code is the one that was measured.
-template <int RPW, int NT>
-__device__ __forceinline__ void epilogue_planar(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0, int cw, int li, int lg, int cbase) {
-    constexpr int MT = 2 * RPW;
-    // planar NCHW output (the network's last conv): activation only, K valid channels
-    // Fast path -- K <= 4 planar channels, no phase scatter / uint8 image (the last conv of the SR networks, CycleGAN, WBC, PPON's heads): only the
-    // lanes holding channels 0..3 (lg == 0) have anything to store, and the per-VALUE work of the generic loop below (channel test, three 64-bit
-    // multiplies for the address, phase / uint8 tests: ~1 k instructions per wave and tile for 96 x 3 values) is hoisted.  Same values, same stores.
-    if (NT == 1 && p.phase_c == 0 && !p.out_u8 && p.K <= 4) {
-        if (lg == 0) {
-            const long plane = (long)p.H * p.W;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int y = ty0 + cw * RPW + (m >> 1);
-                const int x = tx0 + (m & 1) * 16 + li;
-                if (y >= p.y1 || x >= p.W) continue;
-                const long o = (long)n * p.K * plane + (long)y * p.W + x;
-                if (p.act == 0 && p.outm == 0) {              // (the SR networks' last conv: not even a uniform test per value -- 1.39 ms with them, 1.08 without)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (j >= p.K) break;
-                        const float f = acc[0][m][j];
-                        if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
-                        else ((f16*)p.out)[o + j * plane] = (f16)f;
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j >= p.K) break;
-                    float f = acc[0][m][j];
-                    if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (p.act == 2) f = f > 0.f ? f : 0.f;
-                    else if (p.act == 3) f = tanhf(f);
-                    else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
-                    if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
-                    else if (p.outm == 2) f = tanhf(f);
-                    else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
-                    else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
-                    if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
-                    else ((f16*)p.out)[o + j * plane] = (f16)f;
-                }
-            }
-        }
-    } else if (NT == 1 && p.phase_c == 0 && p.out_u8 && p.K <= 4 && p.act == 0 && p.outm == 0) {
-        // ... and the uint8 image form of the same conv (tensor2np as the epilogue, utils.py:197-248; EngineModule.forward_u8 / FramePipeline): the
-        // conversion of the generic loop below, value for value, on the lanes that hold channels 0..3
-        if (lg == 0) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int y = ty0 + cw * RPW + (m >> 1);
-                const int x = tx0 + (m & 1) * 16 + li;
-                if (y >= p.y1 || x >= p.W) continue;
-                uint8_t* o = (uint8_t*)p.out + (((long)n * p.H + y) * p.W + x) * p.K;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j >= p.K) break;
-                    const float f = acc[0][m][j];
-                    float v = p.out_round16 ? (float)(f16)f : f;
-                    if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
-                    v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
-                    const int sc = (p.K == 3 || (p.K == 4 && j < 3)) ? 2 - j : j;
-                    o[sc] = (uint8_t)__float2int_rn(v);
-                }
-            }
-        }
-    } else if (NT == 1 && p.phase_c > 0 && p.outm == 0 && !p.out_u8 && (p.act == 3 || p.act == 0)) {
-        // The four output phases of a stride-2 transposed conv as 4 * phase_c channels (the UNet's outermost layer: bias + tanh + phase scatter):
-        // the channel -> (phase, channel) split is an integer division the generic loop below made per VALUE (24 per wave and tile); here once
-        // per lane and tile.  Same values, same stores.
-        if (cbase < p.K) {
-            long obase[4]; bool live[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ch = cbase + j, ph = ch / p.phase_c, c = ch - ph * p.phase_c;
-                live[j] = ch < p.K;
-                obase[j] = (((long)n * p.phase_c + c) * (2 * p.H) + (ph >> 1)) * (2 * p.W) + (ph & 1);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int y = ty0 + cw * RPW + (m >> 1);
-                const int x = tx0 + (m & 1) * 16 + li;
-                if (y >= p.y1 || x >= p.W) continue;
-                const long opix = (long)(2 * y) * (2 * p.W) + 2 * x;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!live[j]) continue;
-                    float f = acc[0][m][j];
-                    if (p.act == 3) f = tanhf(f);
-                    if (p.out_f32) ((float*)p.out)[obase[j] + opix] = f;
-                    else ((f16*)p.out)[obase[j] + opix] = (f16)f;
-                }
-            }
-        }
-    } else
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int y = ty0 + cw * RPW + (m >> 1);
-        const int x = tx0 + (m & 1) * 16 + li;
-        if (y >= p.y1 || x >= p.W) continue;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ch = cbase + 4 * t + j;
-                if (ch >= p.K) continue;
-                float f = acc[t][m][j];
-                if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
-                else if (p.act == 2) f = f > 0.f ? f : 0.f;
-                else if (p.act == 3) f = tanhf(f);
-                else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
-                if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
-                else if (p.outm == 2) f = tanhf(f);
-                else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
-                else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
-                long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
-                if (p.phase_c > 0) {
-                    const int ph = ch / p.phase_c, c = ch - ph * p.phase_c;
-                    o = (((long)n * p.phase_c + c) * (2 * p.H) + 2 * y + (ph >> 1)) * (2 * p.W) + 2 * x + (ph & 1);
-                }
-                if (p.out_u8) {
-                    // tensor2np (utils.py:197-248) on the value the planar store would have held: [fp16 rounding,] denorm ((x + 1) / 2
-                    // clipped), clip(255 x, 0, 255).round() half to even, RGB -> BGR flip for 3 / 4 channels; HWC bytes
-                    float v = p.out_round16 ? (float)(f16)f : f;
-                    if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
-                    v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
-                    const int sc = (p.K == 3 || (p.K == 4 && ch < 3)) ? 2 - ch : ch;
-                    ((uint8_t*)p.out)[(((long)n * p.H + y) * p.W + x) * p.K + sc] = (uint8_t)__float2int_rn(v);
-                    continue;
-                }
-                if (p.out_f32) ((float*)p.out)[o] = f;
-                else ((f16*)p.out)[o] = (f16)f;
-            }
-    }
-}
+#include "conv3x3_planar.h"
 
 // max(x, 0) of a pixel fragment (BRELU kernels): four v_pk_max_f16.  Inline asm: the builtin max is the IEEE maxnum -- the compiler canonicalises its operand first
 // (a second v_pk_max_f16 x, x per register plus the hazard nops between the two) and the eight-instruction form cost the phase kernels 14 %.
@@ -1402,365 +691,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         tx0_ = (tile - row * tx) * TW;
     };
 
-    if (wave >= NCW) {
-        // ================================ loaders ================================
-        // The loaders of the 16- / 32-output kernels issue at raised priority: their layers wait for the LDS-DMA stream, and a piece issued between the
-        // consumers' MFMAs costs 100-185 cycles of queueing (MI355X_MICROARCH.md).  32-output layers 0.1344 -> 0.1320 ms, last conv -3 %; the 64-output
-        // kernels, which wait for the matrix pipe, lose 0.5 % with it and keep the default (profiles/r3/prio_ab.txt; INNFER_PRIO: A/B builds).
-#if defined(__HIP_DEVICE_COMPILE__)
-#ifdef INNFER_PRIO
-        __builtin_amdgcn_s_setprio(INNFER_PRIO);
-#else
-        if constexpr (NT <= 2) __builtin_amdgcn_s_setprio(3);
-#endif
-#endif
-        const int lw = wave - NCW;
-        int loff[KQ];
-        int lpix[POLY ? KQ : 1];
-        int s9_ty0 = 0, s9_tx0 = 0, s9_n = 0; bool s9_edge = false;          // S9: the current tile (edge tiles re-derive their offsets per chunk)
-        constexpr bool S2PRE = S2 && RPW == 2;      // (the 24-row, 32-channel form keeps the per-chunk derivation: with the per-tile one hipcc leaves its argument struct in scratch memory)
-        int s2_off[S2PRE ? KQ : 1]; unsigned s2_m0 = 0, s2_m1 = 0, s2_m2 = 0, s2_m3 = 0;   // S2 edge tiles: per-piece offsets of phase (0, 0), validity bits per phase
-        static_assert(!S2 || KQ <= 32, "one validity bit per piece");
-        {
-            const int ypar = p.up ? ((p.y0 - 1) & 1) : 0;
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) {
-                const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                const int ly = px / LWP;
-                int lx = px - ly * LWP;
-                if constexpr (WINO) lx = lx >= 18 ? (lx == 35 ? LVALID : 2 * (lx - 18) + 1) : (lx == 17 ? LVALID : 2 * lx);      // even columns, then odd ones (17 valid of 18 each)
-                const bool imgb = PAIR && lx >= 18;                                       // PAIR: LDS columns 18 .. 35 are the halo row of the pair's second image
-                if (imgb) lx -= 18;
-                const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
-                const int ry = S2 ? 2 * ly : p.up ? (ly + ypar) >> 1 : ly;
-                const int rx = S2 ? 2 * lx : p.up ? (lx + 1) >> 1 : lx;
-                // only the halo rows / columns a tap of the mask reads are fetched (a 1x1 conv: none; the other lanes' pieces arrive as zeros
-                // without memory traffic)
-                constexpr int R0 = (TM & 0x007) ? 0 : (TM & 0x038) ? 1 : 2, R1 = (TM & 0x1C0) ? 2 : (TM & 0x038) ? 1 : 0;
-                constexpr int S0 = (TM & 0x049) ? 0 : (TM & 0x092) ? 1 : 2, S1 = (TM & 0x124) ? 2 : (TM & 0x092) ? 1 : 0;
-                const bool used = ly >= R0 && ly <= TH - 1 + R1 && lx >= S0 && lx <= TWI - 1 + S1;
-                loff[k] = (px < NPX && lx < LVALID && used) ? ((ry * p.Ws + rx) * 32 + slot * 8) * 2 + (imgb ? (int)p.in_img_stride * 2 : 0) : OOB;
-                if constexpr (POLY) {          // the tile's dilation scales the pixel part: voff = lpix * d + slot (setup)
-                    lpix[k] = (px < NPX && lx < LVALID) ? (ly * p.fullW + lx) * 64 : -1;
-                    loff[k] = slot * 16;
-                }
-            }
-        }
-        const int wvoff = lane * 16;
-        int voff[KQ];
-        const char* in_tile = nullptr;
-        const char* w_tile = nullptr;
-        // (always_inline: a lambda left as a call keeps the per-lane offset arrays it captures in scratch memory -- the S9 instantiation, whose
-        //  issue path is the longest, ran 11 x slower that way: profiles/r2/kernel_experiments.txt 13)
-        auto setup = [&](int jj) __attribute__((always_inline)) {
-            int kg, n, ty0, tx0, dl = 1;
-            if constexpr (POLY) decode_poly(jj, kg, n, ty0, tx0, dl);
-            else decode(jj, kg, n, ty0, tx0);
-            const long n0 = PAIR ? 2L * n : n;                 // PAIR: n is the pair; image 2n + 1 lies one image stride behind (loff)
-            const bool no_b = PAIR && 2 * n + 1 >= p.N;        // an odd batch's last pair has no second image: its pieces stay zero
-            in_tile = (const char*)(p.in + n0 * p.in_img_stride) + ((long)((ty0 - 1) >> p.up) * p.Ws + ((tx0 >> p.up) - 1)) * 64;
-            w_tile = (const char*)p.wpk + (long)kg * p.nchunks * W_BYTES;
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
-            if constexpr (POLY) {
-                const int d = dl, dd = d * d;
-                const int nn = n / dd, ph = n - nn * dd, py = ph / d, px = ph - py * d;
-                const int Hp = (p.fullH - py + d - 1) / d, Wp = (p.fullW - px + d - 1) / d;      // this component's extent
-                in_tile = (const char*)(p.in + (long)nn * p.in_img_stride) + (((long)(ty0 - 1) * d + py) * p.fullW + (long)(tx0 - 1) * d + px) * 64;
-                const bool edge = ty0 == 0 || ty0 + TH + 1 > Hp || tx0 == 0 || tx0 + TW + 1 > Wp;
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) {
-                    bool ok = lpix[POLY ? k : 0] >= 0;
-                    if (edge) {
-                        const int pxi = (lw + NLW * k) * 16 + (lane >> 2);
-                        const int ly = pxi / LWP, lx = pxi - ly * LWP;
-                        const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
-                        ok = ok && Y >= 0 && Y < Hp && X >= 0 && X < Wp;
-                    }
-                    voff[k] = ok ? lpix[POLY ? k : 0] * d + loff[k] : OOB;
-                }
-                return;
-            }
-            if constexpr (CV) {
-                const int uy = ty0 - 1 + p.cv_h1, ux = tx0 - 1 + p.cv_w1;                 // first halo pixel, shifted by one cell so that it is >= 0
-                const int qy = uy / p.cv_h1, qx = ux / p.cv_w1;
-                const int cyA = qy - 1, yA = uy - qy * p.cv_h1, cxA = qx - 1, xA = ux - qx * p.cv_w1;
-                const int nA = cyA * p.cv_gx + cxA;
-                if (cyA >= 0 && cxA >= 0 && cxA < p.cv_gx && nA < p.N && yA + LH <= p.H && xA + LVALID <= p.W) {
-                    in_tile = (const char*)(p.in + (long)nA * p.in_img_stride) + ((long)yA * p.Ws + xA) * 64;       // inside one image: plain path
-                    return;
-                }
-                in_tile = (const char*)p.in;                                              // offsets from the first image's origin, per lane
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) {
-                    const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                    const int ly = px / LWP, lx = px - ly * LWP;
-                    int y = yA + ly, cy = cyA;
-                    if (y >= p.cv_h1) { y -= p.cv_h1; ++cy; }
-                    int x = xA + lx, cx = cxA;
-                    if (x >= p.cv_w1) { x -= p.cv_w1; ++cx; }
-                    const int nn = cy * p.cv_gx + cx;
-                    const bool ok = loff[k] != OOB && y < p.H && x < p.W && cy >= 0 && cx >= 0 && cy < p.cv_gy && cx < p.cv_gx && nn < p.N;
-                    const int slot = (lane & 3) ^ (((px >> 2) & 1) << 1);
-                    voff[k] = ok ? (((nn * p.H + y) * p.W + x) * 32 + slot * 8) * 2 : OOB;
-                }
-                return;
-            }
-            if constexpr (S9) {          // displaced reads reach 4 pixels beyond the tile: such tiles derive their offsets per chunk (issue)
-                s9_ty0 = ty0; s9_tx0 = tx0; s9_n = n;
-                s9_edge = ty0 < 4 || ty0 + TH + 4 > p.H || tx0 < 4 || tx0 + TW + 4 > p.W;
-                return;
-            }
-            if constexpr (S2) {          // cells (ty0 - 1 .. ty0 + TH) x (tx0 - 1 .. tx0 + TW) of both phases: source rows 2 ty0 - 3 .. 2 (ty0 + TH)
-                s9_ty0 = ty0; s9_tx0 = tx0; s9_n = (int)n0;
-                s9_edge = PAIR || 2 * ty0 < 3 || 2 * (ty0 + TH) >= p.Hs || 2 * tx0 < 3 || 2 * (tx0 + TW) >= p.Ws;
-                in_tile = (const char*)(p.in + n0 * p.in_img_stride) + ((long)(2 * ty0 - 3) * p.Ws + (2 * tx0 - 3)) * 64;
-                if (S2PRE && s9_edge) {
-                    // a tile that touches the image border: the offsets of phase (0, 0) from the image origin and one validity bit per (phase, piece),
-                    // derived once per tile -- issue_to then selects; (deriving them per chunk cost the loaders ~0.7 us per step, and in the UNet's
-                    // 16 x 16 .. 64 x 64 grids every tile is such a tile: profiles/r3/ablate_unet.txt)
-                    s2_m0 = s2_m1 = s2_m2 = s2_m3 = 0;
-#pragma unroll
-                    for (int k = 0; k < KQ; ++k) {
-                        const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                        const int ly = px / LWP;
-                        int lx = px - ly * LWP;
-                        const bool imgb = PAIR && lx >= 18;
-                        if (imgb) lx -= 18;
-                        const int Yb = 2 * (ty0 - 1 + ly) - 1, Xb = 2 * (tx0 - 1 + lx) - 1;
-                        s2_off[S2PRE ? k : 0] = (Yb * p.Ws + Xb) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64);        // (loff carries the second image's stride)
-                        const bool y0 = Yb >= 0 && Yb < p.Hs, y1 = Yb + 1 >= 0 && Yb + 1 < p.Hs, x0 = Xb >= 0 && Xb < p.Ws, x1 = Xb + 1 >= 0 && Xb + 1 < p.Ws;
-                        const bool lv = loff[k] != OOB && !(imgb && no_b);
-                        s2_m0 |= (unsigned)(lv && y0 && x0) << k; s2_m1 |= (unsigned)(lv && y0 && x1) << k;
-                        s2_m2 |= (unsigned)(lv && y1 && x0) << k; s2_m3 |= (unsigned)(lv && y1 && x1) << k;
-                    }
-                }
-                return;
-            }
-            if (PAIR || ty0 == 0 || ty0 + TH + 1 > p.H || tx0 == 0 || tx0 + TW + 1 > p.W) {
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) {
-                    const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                    const int ly = px / LWP;
-                    int lx = px - ly * LWP;
-                    if constexpr (WINO) lx = lx >= 18 ? 2 * (lx - 18) + 1 : 2 * lx;
-                    const bool imgb = PAIR && lx >= 18;
-                    if (imgb) lx -= 18;
-                    const int Y = ty0 - 1 + ly, X = tx0 - 1 + lx;
-                    if (Y < 0 || Y >= p.H || X < 0 || X >= p.W || (imgb && no_b)) {
-                        // reflection padding: the ring of pixels one step outside the image mirrors the pixel one step inside; farther
-                        // out (tile padding of a ragged frame) only feeds outputs that are never stored
-                        // (reflect 2 = nn.ReplicationPad2d(1): the ring repeats the border pixel)
-                        if (p.reflect && loff[k] != OOB && Y >= -1 && Y <= p.H && X >= -1 && X <= p.W) {
-                            const int in1 = p.reflect == 2 ? 0 : 1, in2 = p.reflect == 2 ? 1 : 2;
-                            const int Yr = Y < 0 ? in1 : (Y >= p.H ? p.H - in2 : Y), Xr = X < 0 ? in1 : (X >= p.W ? p.W - in2 : X);
-                            voff[k] = loff[k] + ((Yr - Y) * p.Ws + (Xr - X)) * 64;
-                        } else {
-                            voff[k] = OOB;
-                        }
-                    }
-                }
-            }
-        };
-        // what: 1 input pieces, 2 weight pieces, 3 both; st_i / st_w: LDS destinations; wsrc: the chunk's weight panel
-        auto issue_to = [&](int c, char* st_i, char* st_w, const char* wsrc, int what) __attribute__((always_inline)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            const char* src = in_tile + c * p.in_gbytes;
-            if constexpr (SPLIT) {               // virtual chunk -> (part, channel group): parts 0 and 2 read the hi slab, part 1 the lo slab
-                const int part = c >= 2 * p.ncg ? 2 : (c >= p.ncg ? 1 : 0);
-                src = in_tile + (c - part * p.ncg) * p.in_gbytes + (part == 1 ? p.in_lo_bytes : 0);
-            }
-            if constexpr (S9) {
-                const int sub = c / p.ncg, cg = c - sub * p.ncg;
-                const int sy = p.s9v ? 3 * (sub - 1) : 3 * (sub / 3 - 1), sx = p.s9v ? 0 : 3 * (sub % 3 - 1);
-                if (!s9_edge) {
-                    src = in_tile + cg * p.in_gbytes + ((long)sy * p.Ws + sx) * 64;        // every displaced pixel is inside the image
-#pragma unroll
-                    for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
-                } else {                                                                  // offsets from the image origin, per lane
-                    src = (const char*)(p.in + (long)s9_n * p.in_img_stride) + cg * p.in_gbytes;
-#pragma unroll
-                    for (int k = 0; k < KQ; ++k) {
-                        const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                        const int ly = px / LWP, lx = px - ly * LWP;
-                        int Y = s9_ty0 - 1 + ly + sy, X = s9_tx0 - 1 + lx + sx;
-                        if (p.reflect) {                                                  // ReflectionPad2d(3)
-                            Y = Y < 0 ? -Y : (Y >= p.H ? 2 * p.H - 2 - Y : Y);
-                            X = X < 0 ? -X : (X >= p.W ? 2 * p.W - 2 - X : X);
-                        }
-                        const bool ok = loff[k] != OOB && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
-                        voff[k] = ok ? (Y * p.Ws + X) * 64 + (loff[k] - (ly * p.Ws + lx) * 64) : OOB;
-                    }
-                }
-            }
-            if constexpr (S2) {
-                const int ph = c / p.ncg, cg = c - ph * p.ncg, pa = ph >> 1, pb = ph & 1;
-                if (!s9_edge) {
-                    src = in_tile + cg * p.in_gbytes + ((long)pa * p.Ws + pb) * 64;
-#pragma unroll
-                    for (int k = 0; k < KQ; ++k) voff[k] = loff[k];
-                } else if constexpr (S2PRE) {                                             // offsets from the image origin, per lane (setup)
-                    src = (const char*)(p.in + (long)s9_n * p.in_img_stride) + cg * p.in_gbytes;
-                    const int shift = (pa * p.Ws + pb) * 64;
-                    const unsigned m = ph == 0 ? s2_m0 : ph == 1 ? s2_m1 : ph == 2 ? s2_m2 : s2_m3;
-#pragma unroll
-                    for (int k = 0; k < KQ; ++k) voff[k] = ((m >> k) & 1u) ? s2_off[S2PRE ? k : 0] + shift : OOB;
-                } else {                                                                  // (24-row tiles: per chunk, as before round 3)
-                    src = (const char*)(p.in + (long)s9_n * p.in_img_stride) + cg * p.in_gbytes;
-#pragma unroll
-                    for (int k = 0; k < KQ; ++k) {
-                        const int px = (lw + NLW * k) * 16 + (lane >> 2);
-                        const int ly = px / LWP, lx = px - ly * LWP;
-                        const int Y = 2 * (s9_ty0 - 1 + ly) + pa - 1, X = 2 * (s9_tx0 - 1 + lx) + pb - 1;
-                        const bool ok = loff[k] != OOB && Y >= 0 && Y < p.Hs && X >= 0 && X < p.Ws;
-                        voff[k] = ok ? (Y * p.Ws + X) * 64 + (loff[k] - (2 * ly * p.Ws + 2 * lx) * 64) : OOB;
-                    }
-                }
-            }
-            const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, W_BYTES, 0x00020000);
-#ifdef INNFER_ABLATE
-            if (p.abl & 2) what &= ~2;                                   // abl 2: no weight pieces, abl 4: no input pieces
-            if (p.abl & 4) what &= ~1;
-#endif
-            if (what & 2) {
-#pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    const int jq = lw + NLW * k;
-                    if (jq < WQ)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st_w + jq * 1024), 16, wvoff, jq * 1024, 0, 0);
-                }
-            }
-            if (what & 1) {
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) {
-                    const int q = lw + NLW * k;
-                    if (q < NQ)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void*)(st_i + q * 1024), 16, voff[k], 0, 0, INNFER_IN_AUX);
-                }
-            }
-#else
-            (void)c; (void)st_i; (void)st_w; (void)wsrc; (void)what; (void)wvoff; (void)KW; (void)in_tile; (void)w_tile; (void)s9_ty0; (void)s9_tx0; (void)s9_n; (void)s9_edge; (void)s2_off; (void)s2_m0; (void)s2_m1; (void)s2_m2; (void)s2_m3;
-#endif
-        };
-        auto issue = [&](int c, int stage) __attribute__((always_inline)) {
-            const int cg = RLDS ? (c + 2 >= p.nchunks ? c + 2 - p.nchunks : c + 2) : c;      // RLDS: groups 2, 3, .., 0, 1 -- the residual's two groups last
-            issue_to(cg, smem + stage * STAGE, smem + stage * STAGE + IN_BYTES, w_tile + (long)cg * W_BYTES, 3);
-        };
-        if constexpr (NSI == 3) {
-            // ---- ring of three input slots + two weight slots: the input cursor runs two chunks ahead of the consumers, the weight cursor one ----
-            char* const wring = smem + 3 * IN_BYTES;
-            const int my_in = (NQ - lw + NLW - 1) / NLW;                 // input pieces THIS wave issues per chunk (KQ or KQ - 1)
-            auto wait_all_but_in = [&](bool pending) {                    // everything older than the youngest chunk's input pieces has landed
-                if (!pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (my_in == KQ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KQ) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KQ - 1) : "memory");
-            };
-            if constexpr (UP4) {
-                // tile T's groups 0 / 1 live in slots (2T) % 3 and (2T + 1) % 3 for its eight steps; weights: panel (g + 1) % 8 one step ahead
-                int jt_i = j0, base = 0;                                  // base: slot of the current tile's group 0
-                setup(jt_i);
-                issue_to(0, smem, wring, (const char*)p.wpk, 3);
-                issue_to(1, smem + IN_BYTES, nullptr, nullptr, 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_barrier" ::: "memory");
-                for (int g = 0; g < G; ++g) {
-                    const int st8 = g & 7;
-                    bool pending = false;
-                    if (g + 1 < G) issue_to(0, nullptr, wring + ((g + 1) & 1) * W_BYTES, (const char*)p.wpk + (long)((g + 1) & 7) * W_BYTES, 2);
-                    if (st8 == 0 && g + 8 < G) {                          // next tile's group 0 -> the slot the previous tile's group 1 has left
-                        jt_i += slots; setup(jt_i);
-                        const int fs = base == 0 ? 2 : base - 1;          // (base + 2) % 3
-                        issue_to(0, smem + fs * IN_BYTES, nullptr, nullptr, 1);
-                        pending = true;
-                    }
-                    if (st8 == 7 && g + 1 < G) {                          // next tile's group 1 -> this tile's group-0 slot (last read in step 6)
-                        issue_to(1, smem + base * IN_BYTES, nullptr, nullptr, 1);
-                        pending = true;
-                        base = base == 0 ? 2 : base - 1;
-                    }
-                    wait_all_but_in(pending);
-                    asm volatile("s_barrier" ::: "memory");
-                }
-                return;
-            }
-            int jt_i = j0, c_i = 0;                                       // input cursor (setup() keeps its tile's offsets in voff / in_tile)
-            int jt_w = j0, c_w = 0, kg_w;                                 // weight cursor
-            { int n_, ty_, tx_; decode(jt_w, kg_w, n_, ty_, tx_); }
-            setup(jt_i);
-            issue_to(0, smem, wring, (const char*)p.wpk + (long)kg_w * p.nchunks * W_BYTES, 3);
-            bool pending = false;
-            if (G > 1) {
-                if (++c_i == p.nchunks) { c_i = 0; jt_i += slots; setup(jt_i); }
-                issue_to(c_i, smem + IN_BYTES, nullptr, nullptr, 1);
-                pending = true;
-            }
-            wait_all_but_in(pending);
-            asm volatile("s_barrier" ::: "memory");
-            int slot = 2;                                                 // (g + 2) % 3
-            for (int g = 0; g < G; ++g) {
-                pending = false;
-                if (g + 1 < G) {
-                    if (++c_w == p.nchunks) { c_w = 0; jt_w += slots; int n_, ty_, tx_; decode(jt_w, kg_w, n_, ty_, tx_); }
-                    issue_to(0, nullptr, wring + ((g + 1) & 1) * W_BYTES, (const char*)p.wpk + ((long)kg_w * p.nchunks + c_w) * W_BYTES, 2);
-                }
-                if (g + 2 < G) {
-                    if (++c_i == p.nchunks) { c_i = 0; jt_i += slots; setup(jt_i); }
-                    issue_to(c_i, smem + slot * IN_BYTES, nullptr, nullptr, 1);
-                    pending = true;
-                }
-                slot = slot == 2 ? 0 : slot + 1;
-                wait_all_but_in(pending);
-                asm volatile("s_barrier" ::: "memory");
-            }
-            return;
-        }
-        int jt = j0, c = 0;
-        setup(jt);
-        issue(0, 0);
-        if constexpr (FUSE) {                 // the last conv's four A fragments (4 KB) behind the two stages, once per workgroup
-#if defined(__HIP_DEVICE_COMPILE__)
-            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)p.fl_w, 0, 4096, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(smem + 2 * STAGE + lw * 1024), 16, lane * 16, lw * 1024, 0, 0);
-#endif
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        int cc = 0;                            // FUSE: the chunk the consumers work on in step g
-        for (int g = 0; g < G; ++g) {
-            PCT(l0);
-            if (g + 1 < G) {
-                if (++c == p.nchunks) { c = 0; jt += slots; setup(jt); }
-                issue(c, (g + 1) & 1);
-                PCT(l1);
-#ifdef INNFER_ABLATE
-                // abl 32 (with 8: no MFMA phase): FREE-RUNNING loaders -- the ceiling of this kernel's own access pattern (piece shapes, halo tiles, slab
-                // stores) without the per-chunk coupling to the consumers: a loader waits only for the chunk issued BEFORE the one it has just issued (one
-                // chunk always in flight) and meets the consumers once per tile (profiles/r4/access_pattern_ceiling.txt)
-                if (p.abl & 32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KQ + KW - 2) : "memory");
-                else
-#endif
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                PCT(l2);
-                if (lw == 0) { PCACC(3, l1, l0); PCACC(4, l2, l1); }
-            }
-#ifdef INNFER_ABLATE
-            if ((p.abl & 32) && (g + 1) % p.nchunks != 0) continue;          // free-running: one barrier per tile
-#endif
-            PCT(l3);
-            if constexpr (FUSE) {             // a tile's last chunk: the consumers' fused epilogue meets at two more barriers
-                if (++cc == p.nchunks) {
-                    cc = 0;
-                    asm volatile("s_barrier" ::: "memory");
-                    asm volatile("s_barrier" ::: "memory");
-                }
-            }
-            asm volatile("s_barrier" ::: "memory");
-            PCT(l4);
-            if (lw == 0) PCACC(5, l4, l3);
-        }
-        return;
-    }
+#include "conv3x3_pc_loaders.inc"
 
     // ================================ consumers ================================
 #if defined(INNFER_CPRIO) && defined(__HIP_DEVICE_COMPILE__)
@@ -1869,60 +800,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    if constexpr (UP4) {
-        // ---- the one-pass up-conv's own walk: per tile, the four phases as straight-line code (a phase's accumulators live from its bias to its epilogue only;
-        // a `switch` over the phase inside the generic step loop made the allocator carry them across all four unrolled bodies: 344 bytes of scratch per lane) ----
-        // the four phases' biases (256 floats) in the 1 KB behind the weight ring: a phase starts from four ds_read_b128 instead of holding sixteen bias registers
-        // across the phase before it (the kernel sits at the 168-register budget of a 12-wave workgroup)
-        float* const bias_lds = (float*)(smem + 3 * IN_BYTES + 2 * W_BYTES);
-        if (cw == 0) *(f32x4*)(bias_lds + 4 * lane) = *(const f32x4*)(p.bias + 4 * lane);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");                   // both groups of the first tile and the first panel have landed
-        int slot0 = 0;                                            // LDS slot of the tile's group 0: (2 T) % 3
-#ifdef INNFER_ABLATE
-        const bool no_mfma = (p.abl & 8) != 0;
-#else
-        constexpr bool no_mfma = false;
-#endif
-        for (int jt = j0; jt < run_len; jt += slots) {
-            int kg, n, ty0, tx0;
-            decode(jt, kg, n, ty0, tx0);
-            // (opaque per-tile copies of the lane coordinates: otherwise the four epilogues' per-lane address parts -- a dozen 64-bit values -- are hoisted out of
-            //  the tile loop and live across all of it: scratch spills at the 168-register budget of a 12-wave workgroup)
-            int li_t = li, lg_t = lg;
-            asm volatile("" : "+v"(li_t), "+v"(lg_t));
-            auto phase = [&](auto phc) __attribute__((always_inline)) {
-                constexpr int PH = decltype(phc)::value, A = PH >> 1, B = PH & 1;
-                const int cbase = PH * WROWS + lane_cbase<NT, ROWP>(lg_t);
-                f32x4 acc[NT][MT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 bt = *(const f32x4*)(bias_lds + cbase + toff_lin<NT, ROWP>(t));
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[t][m] = bt;
-                }
-#pragma unroll
-                for (int cg = 0; cg < 2; ++cg) {
-                    const int sl = slot0 + cg;
-                    const char* st = smem + (sl >= 3 ? sl - 3 : sl) * IN_BYTES;
-                    const char* sw = smem + 3 * IN_BYTES + cg * W_BYTES;              // (eight steps per tile: the step's parity is the group)
-                    if (!no_mfma) four_tap(std::integral_constant<int, (0x1B << (3 * A + B))>{}, acc, st, sw);
-                    if (cg == 1) {       // the phase's 16 x 32 virtual pixels go out through the phase-lattice epilogue (tile origin shifted by (a, b))
-                        if (p.act == 1) epilogue_slab<RPW, NT, 1, false, false, true, false, true, false, false, ROWP>(p, acc, n, ty0 + A, tx0 + B, cw, li_t, cbase);
-                        else if (p.act == 2) epilogue_slab<RPW, NT, 2, false, false, true, false, true, false, false, ROWP>(p, acc, n, ty0 + A, tx0 + B, cw, li_t, cbase);
-                        else epilogue_slab<RPW, NT, 0, false, false, true, false, true, false, false, ROWP>(p, acc, n, ty0 + A, tx0 + B, cw, li_t, cbase);
-                    }
-                    asm volatile("s_barrier" ::: "memory");
-                }
-            };
-            phase(std::integral_constant<int, 0>{});
-            phase(std::integral_constant<int, 1>{});
-            phase(std::integral_constant<int, 2>{});
-            phase(std::integral_constant<int, 3>{});
-            slot0 = slot0 == 0 ? 2 : slot0 - 1;
-        }
-        return;
-    }
+#include "conv3x3_pc_up4.inc"
     int islot = 0;                                                // NSI == 3: g % 3
     f32x4 bias_r[NT];
     int bias_kg = -1;
@@ -2120,65 +998,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pfx[m][e] = 0.f;
             }
-            if constexpr (WINO) {
-#define EPI(A, B, C) epilogue_slab_wino<RPW, NT, A, B, C>(p, wacc, bias_r, n, ty0, tx0, cw, li, cbase)
-            if (!p.res1) {
-                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
-            } else if (!p.res2) {
-                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
-            } else {
-                if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
-            }
-#undef EPI
-            } else if constexpr (OUTMODE == OUT_SLAB && SPLIT) {
-#define EPI(A, B, C) epilogue_slab_split<RPW, NT, A, B, C, CV>(p, acc, n, ty0, tx0, cw, li, cbase)
-            if (!p.res1) {
-                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false); else EPI(0, false, false);
-            } else if (!p.res2) {
-                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
-            } else {
-                if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
-            }
-#undef EPI
-            } else if constexpr (OUTMODE == OUT_SLAB && CV && RLDS) {
-                if (p.res2) epilogue_slab_cv<RPW, NT, 0, false, true, true, ROWP>(p, acc, ty0, tx0, cw, li, cbase);
-                else epilogue_slab_cv<RPW, NT, 0, false, false, true, ROWP>(p, acc, ty0, tx0, cw, li, cbase);
-            } else if constexpr (OUTMODE == OUT_SLAB && RLDS) {
-                if (p.res2) epilogue_slab<RPW, NT, 0, false, true, true, false, false, false, true, ROWP>(p, acc, n, ty0, tx0, cw, li, cbase, dcur);
-                else epilogue_slab<RPW, NT, 0, false, false, true, false, false, false, true, ROWP>(p, acc, n, ty0, tx0, cw, li, cbase, dcur);
-            } else if constexpr (OUTMODE == OUT_SLAB && CV) {
-#define EPI(A, B, C) epilogue_slab_cv<RPW, NT, A, B, C, false, ROWP>(p, acc, ty0, tx0, cw, li, cbase)
-            if (!p.res1) {
-                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
-                else if (NT == 4 && !ROWP && p.act == 7) EPI((NT == 4 && !ROWP) ? 7 : 0, false, false); else EPI(0, false, false);
-            } else if (!p.res2) {
-                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else EPI(0, true, false);
-            } else {
-                if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
-            }
-#undef EPI
-            } else if constexpr (FUSE) {
-                const int lidf = run_start + (p.rev ? run_len - 1 - (jt - slots) : (jt - slots));         // (jt was advanced above; KG == 1: the tile index)
-                fused_last_epilogue<RPW, NT>(p, acc, smem + ((g & 1) * STAGE), smem + 2 * STAGE, n, ty0, tx0, cw, lane, lidf);
-            } else if constexpr (OUTMODE == OUT_SLAB) {
-            if constexpr (STATS) {
-                const int lid = run_start + (p.rev ? run_len - 1 - (jt - slots) : (jt - slots));         // (jt was advanced above)
-                epilogue_stats<RPW, NT, TM == 0x1B, PAIR, NCW>(p, acc, bias_r, ty0, tx0, cw, li, cbase, lid / p.KG);
-            }
-#define EPI(A, B, C) epilogue_slab<RPW, NT, A, B, C, !(C), POLY, TM == 0x1B, PAIR, false, ROWP, PSH>(p, acc, n, ty0, tx0, cw, li, cbase, dcur)
-            if (!p.res1) {
-                if (p.act == 1) EPI(1, false, false); else if (p.act == 2) EPI(2, false, false);
-                else if (NT == 4 && TM == 0x1FF && !POLY && !ROWP && p.act == 7) EPI((NT == 4 && TM == 0x1FF && !POLY && !ROWP) ? 7 : 0, false, false); else EPI(0, false, false);
-            } else if (!p.res2) {
-                if (p.act == 1) EPI(1, true, false); else if (p.act == 2) EPI(2, true, false); else if (p.act == 4) EPI(4, true, false);
-                else if (p.act == 5) EPI(5, true, false); else EPI(0, true, false);
-            } else {
-                if (p.act == 1) EPI(1, true, true); else if (p.act == 2) EPI(2, true, true); else EPI(0, true, true);
-            }
-#undef EPI
-            } else {
-                epilogue_planar<RPW, NT>(p, acc, n, ty0, tx0, cw, li, lg, cbase);
-            }
+#include "conv3x3_pc_tile_end.inc"
         }
         PCT(c2);
 #ifdef INNFER_ABLATE
@@ -2343,274 +1163,8 @@ extern "C" int innfer_debug_read_stamps(unsigned long long* h, int n_words) {
 }
 namespace innfer {
 
-int conv_nt_for(int K) { return (K >= 64 && K % 64 == 0) ? 4 : (K >= 32 ? 2 : 1); }          // (96, 160 .. output channels: 32-channel groups)
+#include "conv3x3_pack.h"
 
-static int conv_groups(int K) {
-    const int per = 16 * conv_nt_for(K);
-    return (K + per - 1) / per;
-}
-
-size_t conv_packed_bytes(int K, int C) {
-    const int nt = conv_nt_for(K);
-    return (size_t)conv_groups(K) * (C / 32) * 9 * nt * 16 * 64;
-}
-
-// Host: OIHW fp32 -> [group][chunk][tap][row R][slot][8 ch] fp16, the exact LDS image.
-// Row R = t*16 + rho of a group holds out channel  group*16*NT + (4*NT)*(rho>>2) + 4*t + (rho&3);
-// slot sigma holds input channels chunk*32 + 8*(sigma ^ 2*bit2(R)) .. +7.
-// out channel of row R = t * 16 + rho of output group g: NT rows of 16; rowp (NT = 4 only): the plane order of KP.rowp
-static inline int pack_row_oc(int g, int nt, int R, int rowp) {
-    const int t = R >> 4, rho = R & 15;
-    if (nt == 4 && rowp) return g * 64 + 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
-    return g * nt * 16 + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
-}
-void conv_pack(const float* w, int K, int C, void* packed, int rowp) {
-    const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
-    f16* dst = (f16*)packed;
-    for (int g = 0; g < groups; ++g)
-        for (int c = 0; c < nch; ++c)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int R = 0; R < rows; ++R) {
-                    const int oc = pack_row_oc(g, nt, R, rowp);
-                    for (int sg = 0; sg < 4; ++sg) {
-                        const int cg = sg ^ (((R >> 2) & 1) << 1);
-                        for (int e = 0; e < 8; ++e) {
-                            const int ic = c * 32 + cg * 8 + e;
-                            const float v = oc < K ? w[((size_t)oc * C + ic) * 9 + tap] : 0.f;
-                            *dst++ = (f16)v;
-                        }
-                    }
-                }
-}
-
-// PixelShuffle(2) behind a conv (block.py:333-346): the K conv channels in PHASE-MAJOR order -- packed channel ph * (K / 4) + oc is reference channel 4 oc + ph,
-// ph = 2 a + b the position (a, b) inside the 2 x 2 output block (nn.PixelShuffle: out[oc][2y + a][2x + b] = in[4 oc + 2a + b][y][x]) -- in the plane row order:
-// the panels of conv3x3_pc<.., TMF | 0x800000> (ConvLaunch.rowp = 2 with OUT_SHUFFLE2).  bias_out (K floats, may be null with bias null) in the same order.
-void conv_pack_shuffle2(const float* w, const float* bias, int K, int C, void* packed, float* bias_out) {
-    const int pc = K / 4;
-    std::vector<float> wp((size_t)K * C * 9);
-    for (int ph = 0; ph < 4; ++ph)
-        for (int oc = 0; oc < pc; ++oc) {
-            memcpy(&wp[((size_t)ph * pc + oc) * C * 9], &w[((size_t)4 * oc + ph) * C * 9], sizeof(float) * (size_t)C * 9);
-            if (bias_out) bias_out[ph * pc + oc] = bias ? bias[4 * oc + ph] : 0.f;
-        }
-    conv_pack(wp.data(), K, C, packed, 1);
-}
-
-// Panels holding only the taps of `mask` (bit r*3+s), in (r, s) order: [group][chunk][tap rank][row R][slot][8 ch]; mask 0x10 = a 1x1 conv,
-// w then is [K][C] (one value per pair) -- the counterpart of conv3x3_pc<.., TM>
-// The gate matrix of ConvLaunch.gate_w: w [32][32] (out, in; zero rows / columns beyond the real channels) as the two MFMA A fragments [t][lane][8]:
-// lane (rho = lane & 15, octet = lane >> 4) of tile t holds w[8 (rho >> 2) + 4 t + (rho & 3)][8 octet .. + 7] (the NT = 2 row order of conv_pack)
-void conv_pack_selfgate(const float* w32x32, void* packed_2k) {
-    f16* dst = (f16*)packed_2k;
-    for (int t = 0; t < 2; ++t)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int rho = lane & 15, oct = lane >> 4, oc = 8 * (rho >> 2) + 4 * t + (rho & 3);
-            for (int e = 0; e < 8; ++e) *dst++ = (f16)w32x32[oc * 32 + oct * 8 + e];
-        }
-}
-
-size_t conv_packed_bytes_taps(int K, int C, int mask) { return conv_packed_bytes(K, C) / 9 * __builtin_popcount(mask & 0x1FF); }
-// any mask: w is [K][C][9] (taps outside the mask are not read)
-void conv_pack_taps(const float* w, int K, int C, int mask, void* packed, int rowp) {
-    const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
-    f16* dst = (f16*)packed;
-    for (int g = 0; g < groups; ++g)
-        for (int c = 0; c < nch; ++c)
-            for (int tap = 0; tap < 9; ++tap) {
-                if (!((mask >> tap) & 1)) continue;
-                for (int R = 0; R < rows; ++R) {
-                    const int oc = pack_row_oc(g, nt, R, rowp);
-                    for (int sg = 0; sg < 4; ++sg) {
-                        const int cg = sg ^ (((R >> 2) & 1) << 1);
-                        for (int e = 0; e < 8; ++e) {
-                            const int ic = c * 32 + cg * 8 + e;
-                            *dst++ = (f16)(oc < K ? w[((size_t)oc * C + ic) * 9 + tap] : 0.f);
-                        }
-                    }
-                }
-            }
-}
-// fp32-accurate mode (ConvLaunch.split): the panels of the equivalent conv over 3 C virtual input channels -- (w - wh) * 2^11 for the chunks that meet
-// the hi slab first, then wh twice (lo slab, hi slab); every value is exactly representable, so conv_pack's fp16 conversion is the split itself
-static std::vector<float> split_weights(const float* w, int K, int C, int taps) {
-    std::vector<float> v((size_t)K * 3 * C * taps);
-    for (int k = 0; k < K; ++k)
-        for (int c = 0; c < C; ++c)
-            for (int t = 0; t < taps; ++t) {
-                const float x = w[((size_t)k * C + c) * taps + t];
-                const float h = (float)(f16)x;
-                const float l = (float)(f16)((x - h) * 2048.0f);
-                v[((size_t)k * 3 * C + c) * taps + t] = l;
-                v[((size_t)k * 3 * C + C + c) * taps + t] = h;
-                v[((size_t)k * 3 * C + 2 * C + c) * taps + t] = h;
-            }
-    return v;
-}
-void conv_pack_split(const float* w, int K, int C, void* packed) { conv_pack(split_weights(w, K, C, 9).data(), K, 3 * C, packed); }
-void conv_pack_1x1_split(const float* w, int K, int C, void* packed) { conv_pack_1x1(split_weights(w, K, C, 1).data(), K, 3 * C, packed); }
-
-// Row-Winograd panels (conv3x3_pc<.., TMF | 0x4000>): 32-channel output groups (NT = 2) whatever K is, 12 "taps" per chunk in (kernel row r, xi) order,
-// U_xi = G g over the kernel row's three columns (fp32, ONE rounding to fp16): [group][chunk][r * 4 + xi][row R][slot][8 ch]
-size_t conv_packed_bytes_wino(int K, int C) { return (size_t)((K + 31) / 32) * (C / 32) * 12 * 32 * 64; }
-void conv_pack_wino(const float* w, int K, int C, void* packed) {
-    const int nt = 2, rows = 32, groups = (K + 31) / 32, nch = C / 32;
-    f16* dst = (f16*)packed;
-    for (int g = 0; g < groups; ++g)
-        for (int c = 0; c < nch; ++c)
-            for (int tap = 0; tap < 12; ++tap) {
-                const int r = tap >> 2, xi = tap & 3;
-                for (int R = 0; R < rows; ++R) {
-                    const int t = R >> 4, rho = R & 15;
-                    const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
-                    for (int sg = 0; sg < 4; ++sg) {
-                        const int cg = sg ^ (((R >> 2) & 1) << 1);
-                        for (int e = 0; e < 8; ++e) {
-                            const int ic = c * 32 + cg * 8 + e;
-                            float u = 0.f;
-                            if (oc < K) {
-                                const float* gk = w + ((size_t)oc * C + ic) * 9 + r * 3;
-                                u = xi == 0 ? gk[0] : xi == 3 ? gk[2] : xi == 1 ? 0.5f * (gk[0] + gk[1] + gk[2]) : 0.5f * (gk[0] - gk[1] + gk[2]);
-                            }
-                            *dst++ = (f16)u;
-                        }
-                    }
-                }
-            }
-}
-
-void conv_pack_1x1(const float* w, int K, int C, void* packed) {
-    const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
-    f16* dst = (f16*)packed;
-    for (int g = 0; g < groups; ++g)
-        for (int c = 0; c < nch; ++c)
-            for (int R = 0; R < rows; ++R) {
-                const int t = R >> 4, rho = R & 15;
-                const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
-                for (int sg = 0; sg < 4; ++sg) {
-                    const int cg = sg ^ (((R >> 2) & 1) << 1);
-                    for (int e = 0; e < 8; ++e) {
-                        const int ic = c * 32 + cg * 8 + e;
-                        *dst++ = (f16)(oc < K ? w[(size_t)oc * C + ic] : 0.f);
-                    }
-                }
-            }
-}
-
-// 7x7 weights [K][C][7][7] -> panels of the equivalent conv over 9*C virtual channels (conv3x3_pc<.., S9>): virtual channel sub*C + ci,
-// tap (r, s) holds w[k][ci][3*(sub/3) + r - 1][3*(sub%3) + s - 1] (zero outside the 7x7 kernel: the 9x9 padding ring)
-// Conv2d(k 4, s 2, p 1) for the stride-2 gather loader (ConvLaunch.stride2): w [K][C][4][4] -> panels over 4 * C virtual channels, mask 0x1B0;
-// virtual channel (2 pa + pb) * C + ci, tap (1 + dy, 1 + dx) = w[co][ci][2 dy + pa][2 dx + pb]
-size_t conv_packed_bytes_s2k4(int K, int C) { return conv_packed_bytes_taps(K, 4 * C, 0x1B0); }
-void conv_pack_s2k4(const float* w, int K, int C, void* packed) {
-    const int C4 = 4 * C;
-    std::vector<float> w3((size_t)K * C4 * 9, 0.f);
-    for (int co = 0; co < K; ++co)
-        for (int ph = 0; ph < 4; ++ph)
-            for (int ci = 0; ci < C; ++ci)
-                for (int dy = 0; dy < 2; ++dy)
-                    for (int dx = 0; dx < 2; ++dx)
-                        w3[((size_t)co * C4 + ph * C + ci) * 9 + (1 + dy) * 3 + 1 + dx] = w[(((size_t)co * C + ci) * 4 + 2 * dy + (ph >> 1)) * 4 + 2 * dx + (ph & 1)];
-    conv_pack_taps(w3.data(), K, C4, 0x1B0, packed);
-}
-
-// ConvTranspose2d(k, stride 2, padding 1[, output_padding 1 for k == 3]) for ConvLaunch.deconv_phases: w [C][K][k][k] (torch's layout) -> panels of
-// 4 * K phase-major output channels, mask 0x1B.  Output phase (a, b) taken at the virtual pixel (y + a, x + b) reads taps (dy, dx) in {-1, 0}^2;
-// tap (r, s) of the 3x3 lattice (r, s in {0, 1}) carries w[ci][c][3 - 2r - a][3 - 2s - b] (oy = 2 iy - 1 + ky); a kernel index of 3 does not
-// exist for k == 3: a structural zero (9 of the 16 phase taps are real there)
-size_t conv_packed_bytes_deconv2x(int K, int C) { return conv_packed_bytes_taps(4 * K, C, 0x1B); }
-void conv_pack_deconv2x(const float* w, int K, int C, int k, void* packed, int rowp) {
-    const int K4 = 4 * K;
-    std::vector<float> w3((size_t)K4 * C * 9, 0.f);
-    for (int co = 0; co < K4; ++co) {
-        const int ph = co / K, c = co - ph * K, a = ph >> 1, b = ph & 1;
-        for (int r = 0; r < 2; ++r)
-            for (int sx = 0; sx < 2; ++sx) {
-                const int ky = 3 - 2 * r - a, kx = 3 - 2 * sx - b;
-                if (ky >= k || kx >= k) continue;
-                for (int ci = 0; ci < C; ++ci) w3[((size_t)co * C + ci) * 9 + r * 3 + sx] = w[(((size_t)ci * K + c) * k + ky) * k + kx];
-            }
-    }
-    conv_pack_taps(w3.data(), K4, C, 0x1B, packed, rowp);
-}
-
-// nearest-2x + conv3x3 (upconv_block, block.py:348-361) as ConvTranspose2d(4, 2, 1): w [K][C][3][3] -> the phase panels of conv_pack_deconv2x with the taps that meet the same
-// LR pixel summed in fp32 (ONE rounding to fp16 in the packer): HR row 2y reads LR rows y - 1 (kernel row 0) and y (rows 1 + 2), HR row 2y + 1 reads y (rows 0 + 1) and
-// y + 1 (row 2), columns alike -- transposed-conv kernel index ky <-> summed rows 3: {0}, 1: {1, 2}, 2: {0, 1}, 0: {2}.  K % 64 == 0, C % 32 == 0.
-void conv_pack_up2x_phases(const float* w, int K, int C, void* packed, int rowp) {
-    static const int R[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};
-    std::vector<float> wt((size_t)C * K * 16, 0.f);
-    for (int ci = 0; ci < C; ++ci)
-        for (int co = 0; co < K; ++co)
-            for (int ky = 0; ky < 4; ++ky)
-                for (int kx = 0; kx < 4; ++kx) {
-                    float a = 0.f;
-                    for (int i = 0; i < 2; ++i)
-                        for (int j = 0; j < 2; ++j)
-                            if (R[ky][i] >= 0 && R[kx][j] >= 0) a += w[(((size_t)co * C + ci) * 3 + R[ky][i]) * 3 + R[kx][j]];
-                    wt[(((size_t)ci * K + co) * 4 + ky) * 4 + kx] = a;
-                }
-    conv_pack_deconv2x(wt.data(), K, C, 4, packed, rowp);
-}
-
-// 7 x 1 column conv (ConvLaunch.conv7v): w [K][C][7] -> three 3-tap blocks (the 7 taps zero-padded to 9: tap k9 = k7 + 1), virtual channel
-// block * C + ci, centre-column taps only (mask 0x92)
-size_t conv_packed_bytes7v(int K, int C) { return conv_packed_bytes_taps(K, 3 * C, 0x92); }
-void conv_pack7v(const float* w, int K, int C, void* packed) {
-    const int C3 = 3 * C;
-    std::vector<float> w3((size_t)K * C3 * 9, 0.f);
-    for (int co = 0; co < K; ++co)
-        for (int sb = 0; sb < 3; ++sb)
-            for (int r = 0; r < 3; ++r) {
-                const int ky = 3 * sb + r - 1;
-                if (ky < 0 || ky > 6) continue;
-                for (int ci = 0; ci < C; ++ci) w3[((size_t)co * C3 + sb * C + ci) * 9 + r * 3 + 1] = w[((size_t)co * C + ci) * 7 + ky];
-            }
-    conv_pack_taps(w3.data(), K, C3, 0x92, packed);
-}
-
-// partial-statistics records (3 floats each per channel) an image contributes with ConvLaunch.stats_part: tiles of 16 x 32 pixels over the kernel's
-// H x W grid (the INPUT grid behind the phase lattice, which has four phases per tile), 8 consumer waves per tile
-// The fused last conv (ConvLaunch.fuse_w): what the launch must look like, the panel of the last conv and the bytes of the rim buffer.
-bool conv_fuse_last_ok(const ConvLaunch& L) {
-    return L.K == 64 && L.C % 32 == 0 && L.out_mode == OUT_SLAB && !L.res1 && !L.res2 && !L.up && !L.reflect && L.dilation <= 1 && !L.dilation_groups && !L.split && !L.wino &&
-           !L.stats_part && !L.conv1x1 && !L.stride2 && !L.deconv_phases && !L.conv7 && !L.conv7v && !L.prefix_lrelu && !L.pair_wpk && L.act >= 0 && L.act <= 2 && L.y0 == 0 && L.y1 == L.H &&
-           L.H % 16 == 0 && L.W % 32 == 0 && L.fuse_oc >= 1 && L.fuse_oc <= 3 && L.fuse_bias && L.fuse_side && L.fuse_out &&
-           (long)L.N * (L.H / 16) * (L.W / 32) * 92 < 0x7fffffffL;
-}
-size_t conv_fuse_side_bytes(int N, int H, int W) { return (size_t)N * (H / 16) * (W / 32) * FUSE_RING * 3 * sizeof(float); }
-// w_last [oc][64][3][3] -> four MFMA A fragments [row tile rt][k-step ks][lane][8]: row 16 rt + (lane & 15) = tap * 3 + c (27 of 32 rows), k-slot 8 (lane >> 4) + e of
-// step ks = input channel 16 (lane >> 4) + 8 ks + e -- the order in which a consumer lane of conv3x3_pc<2,4,..> holds its sixteen accumulator channels
-void conv_pack_fuse_last(const float* w, int oc, void* packed, int rowp) {      // rowp: HR_conv0's panel has the plane row order -- a lane's k-step ks then holds channels 32 ks + 8 (lane >> 4) + e
-    f16* o = (f16*)packed;
-    for (int rt = 0; rt < 2; ++rt)
-        for (int ks = 0; ks < 2; ++ks)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 8; ++e) {
-                    const int row = 16 * rt + (lane & 15), tap = row / 3, c = row - 3 * tap, ch = rowp ? 32 * ks + 8 * (lane >> 4) + e : 16 * (lane >> 4) + 8 * ks + e;
-                    float v = 0.f;
-                    if (tap < 9 && c < oc) v = w[((size_t)c * 64 + ch) * 9 + tap];
-                    o[((rt * 2 + ks) * 64 + lane) * 8 + e] = (f16)v;
-                }
-}
-
-int conv_stats_nper(int H, int W, int phases) { return ((H + 15) / 16) * ((W + TW - 1) / TW) * phases * 8; }
-
-size_t conv_packed_bytes7x7(int K, int C) { return conv_packed_bytes(K, 9 * C); }
-void conv_pack7x7(const float* w, int K, int C, void* packed) {
-    std::vector<float> v((size_t)K * 9 * C * 9, 0.f);
-    for (int k = 0; k < K; ++k)
-        for (int sub = 0; sub < 9; ++sub)
-            for (int ci = 0; ci < C; ++ci)
-                for (int t = 0; t < 9; ++t) {
-                    const int ky = 3 * (sub / 3) + t / 3 - 1, kx = 3 * (sub % 3) + t % 3 - 1;
-                    if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7)
-                        v[((size_t)k * 9 * C + sub * C + ci) * 9 + t] = w[(((size_t)k * C + ci) * 7 + ky) * 7 + kx];
-                }
-    conv_pack(v.data(), K, 9 * C, packed);
-}
-
-// Kernel-family name and algorithmic work of a launch, for the generic launch timer (common.h GtScope): every operand read once, every result written once
 static const char* conv_family(const ConvLaunch& L, double* flops, double* bytes) {
     const int y1 = L.y1 > 0 ? L.y1 : L.H;
     const double px = (double)L.N * (y1 - L.y0) * L.W;                       // pixels of the kernel's grid (ConvTranspose: the input grid, 4 phases each)

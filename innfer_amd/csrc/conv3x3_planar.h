@@ -1,0 +1,140 @@
+// Planar (NCHW / uint8 image) epilogue of conv3x3_pc: the networks' last convs.
+// Part of csrc/conv3x3.hip (split out in round 5, VERDICT r4 item 7: no functional change -- the device assembly of the translation unit is identical);
+// included there, inside namespace innfer { namespace { .. } }, after KP / the tile constants.  Not a stand-alone header.
+
+// Planar (NCHW) epilogue of conv3x3_pc -- the networks' last convs: activation, `outm`, the phase scatter of a transposed conv, or tensor2np as the store
+// (uint8 HWC image).  Moved out of the kernel body in round 4; force-inlined, the code is the one that was measured.
+template <int RPW, int NT>
+__device__ __forceinline__ void epilogue_planar(const KP& p, f32x4 (&acc)[NT][2 * RPW], int n, int ty0, int tx0, int cw, int li, int lg, int cbase) {
+    constexpr int MT = 2 * RPW;
+    // planar NCHW output (the network's last conv): activation only, K valid channels
+    // Fast path -- K <= 4 planar channels, no phase scatter / uint8 image (the last conv of the SR networks, CycleGAN, WBC, PPON's heads): only the
+    // lanes holding channels 0..3 (lg == 0) have anything to store, and the per-VALUE work of the generic loop below (channel test, three 64-bit
+    // multiplies for the address, phase / uint8 tests: ~1 k instructions per wave and tile for 96 x 3 values) is hoisted.  Same values, same stores.
+    if (NT == 1 && p.phase_c == 0 && !p.out_u8 && p.K <= 4) {
+        if (lg == 0) {
+            const long plane = (long)p.H * p.W;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = ty0 + cw * RPW + (m >> 1);
+                const int x = tx0 + (m & 1) * 16 + li;
+                if (y >= p.y1 || x >= p.W) continue;
+                const long o = (long)n * p.K * plane + (long)y * p.W + x;
+                if (p.act == 0 && p.outm == 0) {              // (the SR networks' last conv: not even a uniform test per value -- 1.39 ms with them, 1.08 without)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j >= p.K) break;
+                        const float f = acc[0][m][j];
+                        if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
+                        else ((f16*)p.out)[o + j * plane] = (f16)f;
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= p.K) break;
+                    float f = acc[0][m][j];
+                    if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                    else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                    else if (p.act == 3) f = tanhf(f);
+                    else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
+                    if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
+                    else if (p.outm == 2) f = tanhf(f);
+                    else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
+                    else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
+                    if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
+                    else ((f16*)p.out)[o + j * plane] = (f16)f;
+                }
+            }
+        }
+    } else if (NT == 1 && p.phase_c == 0 && p.out_u8 && p.K <= 4 && p.act == 0 && p.outm == 0) {
+        // ... and the uint8 image form of the same conv (tensor2np as the epilogue, utils.py:197-248; EngineModule.forward_u8 / FramePipeline): the
+        // conversion of the generic loop below, value for value, on the lanes that hold channels 0..3
+        if (lg == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = ty0 + cw * RPW + (m >> 1);
+                const int x = tx0 + (m & 1) * 16 + li;
+                if (y >= p.y1 || x >= p.W) continue;
+                uint8_t* o = (uint8_t*)p.out + (((long)n * p.H + y) * p.W + x) * p.K;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= p.K) break;
+                    const float f = acc[0][m][j];
+                    float v = p.out_round16 ? (float)(f16)f : f;
+                    if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
+                    v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
+                    const int sc = (p.K == 3 || (p.K == 4 && j < 3)) ? 2 - j : j;
+                    o[sc] = (uint8_t)__float2int_rn(v);
+                }
+            }
+        }
+    } else if (NT == 1 && p.phase_c > 0 && p.outm == 0 && !p.out_u8 && (p.act == 3 || p.act == 0)) {
+        // The four output phases of a stride-2 transposed conv as 4 * phase_c channels (the UNet's outermost layer: bias + tanh + phase scatter):
+        // the channel -> (phase, channel) split is an integer division the generic loop below made per VALUE (24 per wave and tile); here once
+        // per lane and tile.  Same values, same stores.
+        if (cbase < p.K) {
+            long obase[4]; bool live[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = cbase + j, ph = ch / p.phase_c, c = ch - ph * p.phase_c;
+                live[j] = ch < p.K;
+                obase[j] = (((long)n * p.phase_c + c) * (2 * p.H) + (ph >> 1)) * (2 * p.W) + (ph & 1);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = ty0 + cw * RPW + (m >> 1);
+                const int x = tx0 + (m & 1) * 16 + li;
+                if (y >= p.y1 || x >= p.W) continue;
+                const long opix = (long)(2 * y) * (2 * p.W) + 2 * x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!live[j]) continue;
+                    float f = acc[0][m][j];
+                    if (p.act == 3) f = tanhf(f);
+                    if (p.out_f32) ((float*)p.out)[obase[j] + opix] = f;
+                    else ((f16*)p.out)[obase[j] + opix] = (f16)f;
+                }
+            }
+        }
+    } else
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = ty0 + cw * RPW + (m >> 1);
+        const int x = tx0 + (m & 1) * 16 + li;
+        if (y >= p.y1 || x >= p.W) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = cbase + 4 * t + j;
+                if (ch >= p.K) continue;
+                float f = acc[t][m][j];
+                if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
+                else if (p.act == 2) f = f > 0.f ? f : 0.f;
+                else if (p.act == 3) f = tanhf(f);
+                else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
+                if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
+                else if (p.outm == 2) f = tanhf(f);
+                else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
+                else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
+                long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
+                if (p.phase_c > 0) {
+                    const int ph = ch / p.phase_c, c = ch - ph * p.phase_c;
+                    o = (((long)n * p.phase_c + c) * (2 * p.H) + 2 * y + (ph >> 1)) * (2 * p.W) + 2 * x + (ph & 1);
+                }
+                if (p.out_u8) {
+                    // tensor2np (utils.py:197-248) on the value the planar store would have held: [fp16 rounding,] denorm ((x + 1) / 2
+                    // clipped), clip(255 x, 0, 255).round() half to even, RGB -> BGR flip for 3 / 4 channels; HWC bytes
+                    float v = p.out_round16 ? (float)(f16)f : f;
+                    if (p.out_denorm) v = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, -1.0f), 2.0f), 0.0f), 1.0f);
+                    v = fminf(fmaxf(__fmul_rn(255.0f, v), 0.0f), 255.0f);
+                    const int sc = (p.K == 3 || (p.K == 4 && ch < 3)) ? 2 - ch : ch;
+                    ((uint8_t*)p.out)[(((long)n * p.H + y) * p.W + x) * p.K + sc] = (uint8_t)__float2int_rn(v);
+                    continue;
+                }
+                if (p.out_f32) ((float*)p.out)[o] = f;
+                else ((f16*)p.out)[o] = (f16)f;
+            }
+    }
+}

@@ -140,6 +140,7 @@ struct F32Tile {
     int CC;                      // input channels per chunk (multiple of 4)
     int txs, tys, imgs;          // log2 TX, log2 TY, log2 IMG; TX TY IMG <= 256 (fewer: the last waves' pixel tiles are empty)
     int tiles_x, nkg;            // tile columns; channel groups of KT
+    int abl;                     // diagnostic build only (make ablate, INNFER_F32_ABL): skip 1 the MFMA steps, 2 the epilogue, 4 the patch loads, 8 the weight DMA
 };
 
 constexpr int F32_NE = 21;       // patch elements per thread and chunk: CC * plane <= 256 * NE
@@ -211,11 +212,21 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
     auto prefetch_patch = [&](int c0) __attribute__((always_inline)) {
         const float* ic = inb + (long)c0 * p.in_cstride;
         const int lim = min(t.CC, p.C - c0) * t.plane;            // elements of channels that exist
+#ifdef INNFER_ABLATE
+        if (t.abl & 4) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) v[i] = 0.f;
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NE; ++i) v[i] = (goff[i] >= 0 && tid + 256 * i < lim) ? ic[goff[i]] : 0.f;
     };
     auto issue_weights = [&](int c0, int buf) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef INNFER_ABLATE
+        if (t.abl & 8) return;
+#endif
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, t.wbytes, 0x00020000);
         char* dst = wl0 + buf * wl_bytes;
         const int c40 = c0 >> 2;
@@ -278,7 +289,11 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
                 }
             }
         };
+#ifdef INNFER_ABLATE
+        const int ngroups = (t.abl & 1) ? 0 : (nstep + G - 1) / G;
+#else
         const int ngroups = (nstep + G - 1) / G;
+#endif
         fetch_group();
         for (int g = 0; g < ngroups; ++g) {
             float a[G][NKT], b[G][NPT];
@@ -299,6 +314,9 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
         }
     }
     // ---- epilogue (the direct kernel's): bias, gate, activation, scale, residual, store through the output view
+#ifdef INNFER_ABLATE
+    if (t.abl & 2) return;
+#endif
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt) {
         const int q = (pt * 4 + wave) * 16 + li;
@@ -587,6 +605,9 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
         if ((long)cc * t.plane <= 256L * F32_NE && lds_total(cc) <= 150 * 1024 && wbytes < 0x7fffffffu &&
             (long)cc * L.in_cstride + (long)IMG * L.in_nstride + (long)L.Hin * L.Win < 0x7fffffffL && (long)cc * t.plane < (1 << 21)) {
             t.CC = cc; t.wbytes = (unsigned)wbytes;
+#ifdef INNFER_ABLATE
+            t.abl = getenv("INNFER_F32_ABL") ? atoi(getenv("INNFER_F32_ABL")) : 0;
+#endif
             const size_t lds = lds_total(cc);
             switch (NKT * 2 + (npt1 ? 1 : 0)) {
                 case 2: return f32conv_tiled_launch<1, 4>(k, t, tiles, zgroups, lds, s);
