@@ -140,6 +140,7 @@ struct F32Tile {
     int CC;                      // input channels per chunk (multiple of 4)
     int txs, tys, imgs;          // log2 TX, log2 TY, log2 IMG; TX TY IMG <= 256 (fewer: the last waves' pixel tiles are empty)
     int tiles_x, nkg;            // tile columns; channel groups of KT
+    int vec4;                    // the epilogue moves four consecutive pixels per lane (aligned, unit-stride output rows: see the kernel's epilogue)
     int abl;                     // diagnostic build only (make ablate, INNFER_F32_ABL): skip 1 the MFMA steps, 2 the epilogue, 4 the patch loads, 8 the weight DMA
 };
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
     const int oy0 = tyi << t.tys, ox0 = txi << t.txs, k0 = kg * 16 * NKT, n0 = blockIdx.z * IMG;
     const int CC4 = t.CC >> 2, nstep = p.ntap * CC4;
     float* patch = f32lds;
-    char* wl0 = (char*)(f32lds + (long)t.CC * t.PS);
+    char* wl0 = (char*)(f32lds + 2L * t.CC * t.PS);          // (two patch buffers in front)
     const long wl_bytes = (long)nstep * 1024;
     const float* inb = p.in + (long)n0 * p.in_nstride;
     const int Hv = p.up ? 2 * p.Hin : p.Hin, Wv = p.up ? 2 * p.Win : p.Win;
@@ -242,106 +243,158 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
 #endif
     };
 
-    prefetch_patch(0);
-    issue_weights(0, 0);
-    int buf = 0;
-    for (int c0 = 0; c0 < p.C; c0 += t.CC, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this chunk's patch values and weight pieces have arrived
-        __syncthreads();                                           // the previous chunk's fragments have been read
+    // The patch is double-buffered in LDS and its values run TWO chunks ahead in registers: chunk i's steps read patch buffer i & 1 while the writes of chunk i + 1
+    // (into the other buffer) and the loads of chunk i + 2 (into registers) are in flight behind them -- one barrier per chunk, at its end.  (With one patch buffer
+    // a chunk was wait -> barrier -> 21 LDS writes -> barrier -> steps: the writes and both barriers stood between the MFMA phases, and the two workgroups of a CU did
+    // not fill each other's gaps: matrix pipe 0.55 busy, profiles/r5/pmc_unet_fp32.txt.)
+    auto write_patch = [&](int pb) __attribute__((always_inline)) {
+        float* pw = patch + (long)pb * t.CC * t.PS;
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             if (loff[i] >= 0) {
                 float f = v[i];
                 if (p.in_act == 1) f = f > 0.f ? f : 0.2f * f;
                 else if (p.in_act == 2) f = f > 0.f ? f : 0.f;
-                patch[loff[i]] = f;
+                pw[loff[i]] = f;
             }
         }
-        __syncthreads();
-        if (c0 + t.CC < p.C) {                                     // the next chunk: loads in flight behind this chunk's MFMAs
-            prefetch_patch(c0 + t.CC);
+    };
+    prefetch_patch(0);
+    issue_weights(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    write_patch(0);
+    if (t.CC < p.C) prefetch_patch(t.CC);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = 0; c0 < p.C; c0 += t.CC, buf ^= 1) {
+        if (c0 + t.CC < p.C) {
+            write_patch(buf ^ 1);                                  // chunk i + 1's values: in registers since the wait in front of the last barrier
             issue_weights(c0 + t.CC, buf ^ 1);
+            if (c0 + 2 * t.CC < p.C) prefetch_patch(c0 + 2 * t.CC);
         }
+        const float* pcur = patch + (long)buf * t.CC * t.PS;
         // ---- compute: (tap, 4 channels) steps, the next step's fragments in flight behind the current MFMAs
         const float* wl = (const float*)(wl0 + buf * wl_bytes);
-        // G steps per loop trip: their fragments are fetched together, one trip ahead of their MFMAs.  A step of NKT NPT MFMAs keeps the pipe busy for 32 NKT NPT
-        // cycles; with one or two waves per SIMD an LDS read (~130 cycles) hides behind 16 MFMAs but not behind 1 .. 4 (the UNet's <= 8 x 8 levels ran 200 cycles per
-        // 32-cycle step), so the narrow forms fetch four steps at a time.  Steps beyond the chunk's last multiply zeros.
+        // G steps per group: a step of NKT NPT MFMAs keeps the pipe busy for 32 NKT NPT cycles; the narrow forms fetch several steps' fragments at a time.  Two groups
+        // per trip on alternating register sets.  (Hand-counted waits around inline-asm reads were tried -- hipcc waits for part of the NEXT group's reads in front of
+        // the CURRENT group's MFMAs -- and changed nothing: the matrix pipe of these kernels is 0.55 busy for other reasons, profiles/r5/fp32_modes.txt.)
         constexpr int G = NKT * NPT >= 8 ? 1 : 4;
-        float an[G][NKT], bn[G][NPT];
+        float fa0[G][NKT], fb0[G][NPT], fa1[G][NKT], fb1[G][NPT];
         int ftap = 0, fc4 = 0;
-        auto fetch_group = [&]() __attribute__((always_inline)) {
+        auto fetch_group = [&](float (&fa)[G][NKT], float (&fb)[G][NPT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 if (ftap < p.ntap) {
                     const int toff = __builtin_amdgcn_readlane(tapv, ftap) + fc4 * 4 * t.PS;
                     const float* wa = wl + (long)(ftap * CC4 + fc4) * 256 + li * 4 + lg;
 #pragma unroll
-                    for (int kt = 0; kt < NKT; ++kt) an[u][kt] = wa[kt * 64];
+                    for (int kt = 0; kt < NKT; ++kt) fa[u][kt] = wa[kt * 64];
 #pragma unroll
-                    for (int pt = 0; pt < NPT; ++pt) bn[u][pt] = patch[boff[pt] + toff];
+                    for (int pt = 0; pt < NPT; ++pt) fb[u][pt] = pcur[boff[pt] + toff];
                     if (++fc4 == CC4) { fc4 = 0; ++ftap; }
                 } else {
 #pragma unroll
-                    for (int kt = 0; kt < NKT; ++kt) an[u][kt] = 0.f;
+                    for (int kt = 0; kt < NKT; ++kt) fa[u][kt] = 0.f;
 #pragma unroll
-                    for (int pt = 0; pt < NPT; ++pt) bn[u][pt] = 0.f;
+                    for (int pt = 0; pt < NPT; ++pt) fb[u][pt] = 0.f;
                 }
             }
+        };
+        auto mfma_group = [&](const float (&fa)[G][NKT], const float (&fb)[G][NPT]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) acc[kt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][kt], fb[u][pt], acc[kt][pt], 0, 0, 0);
         };
 #ifdef INNFER_ABLATE
         const int ngroups = (t.abl & 1) ? 0 : (nstep + G - 1) / G;
 #else
         const int ngroups = (nstep + G - 1) / G;
 #endif
-        fetch_group();
-        for (int g = 0; g < ngroups; ++g) {
-            float a[G][NKT], b[G][NPT];
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) a[u][kt] = an[u][kt];
-#pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) b[u][pt] = bn[u][pt];
-            }
-            if (g + 1 < ngroups) fetch_group();
-#pragma unroll
-            for (int u = 0; u < G; ++u)
-#pragma unroll
-                for (int pt = 0; pt < NPT; ++pt)
-#pragma unroll
-                    for (int kt = 0; kt < NKT; ++kt) acc[kt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][kt], b[u][pt], acc[kt][pt], 0, 0, 0);
+        fetch_group(fa0, fb0);
+        for (int g = 0; g < ngroups; g += 2) {
+            fetch_group(fa1, fb1);                                 // group g + 1 (zeros beyond the last step: its MFMAs add nothing)
+            mfma_group(fa0, fb0);
+            if (g + 2 < ngroups) fetch_group(fa0, fb0);
+            mfma_group(fa1, fb1);
         }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the next chunk's patch writes and weight pieces (issued in front of this chunk's steps) are in LDS
+        __syncthreads();                                           // ... every wave's, and every wave has read this chunk's fragments
     }
-    // ---- epilogue (the direct kernel's): bias, gate, activation, scale, residual, store through the output view
+    // ---- epilogue: bias, gate, activation, scale, residual, store through the output view -- the direct kernel's arithmetic per value, ROW-WISE: the MFMA
+    // result layout gives a lane 4 channels of ONE pixel, so a store instruction of the value-by-value form wrote four 64-byte pieces of four channel planes (and
+    // its gate / residual loads read such pieces); at 20 .. 40 channels that epilogue was 21 % (3 x 3) to 61 % (1 x 1) of a PAN conv (profiles/r5/f32_ablate_pan.txt).
+    // The tile goes through LDS once ([channel][pixel], pitch TP + 4: conflict-free both ways), then wave w takes channels w, w + 4, ..: with the output rows
+    // 16-byte aligned a lane moves FOUR consecutive pixels -- one b128 LDS read, one 16-byte store per channel and 256 pixels -- else one pixel per lane, still whole
+    // 256-byte runs of a plane; the bias is a scalar per row.
 #ifdef INNFER_ABLATE
     if (t.abl & 2) return;
 #endif
+    constexpr int TP = 64 * NPT, QP = TP + 4;
+    __syncthreads();                                               // the last chunk's fragments have been read: the LDS is free
+    float* ot = f32lds;
 #pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) {
-        const int q = (pt * 4 + wave) * 16 + li;
-        const int ox = ox0 + (q & TXm), oy = oy0 + ((q >> t.txs) & TYm), il = q >> (t.txs + t.tys), n = n0 + il;
-        if (oy >= p.Ho || ox >= p.Wo || il >= IMG || n >= p.N) continue;
-        const long opix0 = ((long)(oy * p.osy + p.ooy) * p.Wout + ox * p.osx + p.oox);
+    for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int k = k0 + 16 * kt + 4 * lg + j;
-                if (k >= p.K) continue;
-                long opix = opix0;
-                if (p.phase_k > 0) {                       // fused phases: channel k is phase ph of output channel k % phase_k
-                    const int ph = k / p.phase_k;
-                    k -= ph * p.phase_k;
-                    opix = (long)(2 * oy + (ph >> 1)) * p.Wout + 2 * ox + (ph & 1);
+            for (int j = 0; j < 4; ++j) ot[(16 * kt + 4 * lg + j) * QP + (pt * 4 + wave) * 16 + li] = acc[kt][pt][j];
+    __syncthreads();
+    auto finish = [&](float f, int k, long nbase_mul, long nbase_res, long opix) __attribute__((always_inline)) {
+        if (p.mul) f = p.mul[nbase_mul + (long)k * p.mul_cstride + opix] * (1.0f / (1.0f + expf(-f)));
+        f = f32_act(f, p.act);
+        if (p.oscale != 0.f) f *= p.oscale;
+        if (p.res) f += p.res[nbase_res + (long)k * p.res_cstride + opix];
+        return f;
+    };
+    if (t.vec4) {
+        // four consecutive pixels of a row per lane (host: osx = 1, pixel stride 1, no fused phases, Wo / Wout / the view strides multiples of 4, 16-byte aligned bases)
+        const int q = 4 * lane;
+        if (q < TP) {
+            const int ox = ox0 + (q & TXm), oy = oy0 + ((q >> t.txs) & TYm), il = q >> (t.txs + t.tys), n = n0 + il;
+            if (oy < p.Ho && ox < p.Wo && il < IMG && n < p.N) {
+                const long opix = (long)(oy * p.osy + p.ooy) * p.Wout + ox + p.oox;
+                for (int kl = wave; kl < 16 * NKT; kl += 4) {
+                    const int k = k0 + kl;
+                    if (k >= p.K) break;
+                    f32x4 v = *(const f32x4*)(ot + kl * QP + q);
+                    const float bk = p.bias ? p.bias[k] : 0.f;
+                    f32x4 m4 = f32x4{0.f, 0.f, 0.f, 0.f}, r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.mul) m4 = *(const f32x4*)(p.mul + (long)n * p.mul_nstride + (long)k * p.mul_cstride + opix);
+                    if (p.res) r4 = *(const f32x4*)(p.res + (long)n * p.res_nstride + (long)k * p.res_cstride + opix);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float f = v[e] + bk;
+                        if (p.mul) f = m4[e] * (1.0f / (1.0f + expf(-f)));
+                        f = f32_act(f, p.act);
+                        if (p.oscale != 0.f) f *= p.oscale;
+                        if (p.res) f += r4[e];
+                        v[e] = f;
+                    }
+                    *(f32x4*)(p.out + (long)n * p.out_nstride + (long)k * p.out_cstride + opix) = v;
                 }
-                float f = acc[kt][pt][j] + (p.bias ? p.bias[k] : 0.f);
-                if (p.mul) f = p.mul[(long)n * p.mul_nstride + (long)k * p.mul_cstride + opix] * (1.0f / (1.0f + expf(-f)));
-                f = f32_act(f, p.act);
-                if (p.oscale != 0.f) f *= p.oscale;
-                if (p.res) f += p.res[(long)n * p.res_nstride + (long)k * p.res_cstride + opix];
-                p.out[(long)n * p.out_nstride + (long)k * p.out_cstride + opix * p.out_pstride] = f;
             }
+        }
+        return;
+    }
+    for (int kl = wave; kl < 16 * NKT; kl += 4) {
+        int k = k0 + kl;
+        if (k >= p.K) break;
+        int ph = 0;
+        if (p.phase_k > 0) { ph = k / p.phase_k; k -= ph * p.phase_k; }          // fused phases: channel k0 + kl is phase ph of output channel k
+        const float bk = p.bias ? p.bias[k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int q = lane + 64 * i;
+            const int ox = ox0 + (q & TXm), oy = oy0 + ((q >> t.txs) & TYm), il = q >> (t.txs + t.tys), n = n0 + il;
+            if (oy >= p.Ho || ox >= p.Wo || il >= IMG || n >= p.N) continue;
+            const long opix = p.phase_k > 0 ? (long)(2 * oy + (ph >> 1)) * p.Wout + 2 * ox + (ph & 1) : (long)(oy * p.osy + p.ooy) * p.Wout + ox * p.osx + p.oox;
+            const float f = finish(ot[kl * QP + q] + bk, k, (long)n * p.mul_nstride, (long)n * p.res_nstride, opix);
+            p.out[(long)n * p.out_nstride + (long)k * p.out_cstride + opix * p.out_pstride] = f;
+        }
     }
 }
 
@@ -355,6 +408,13 @@ static int f32conv_tiled_launch(const F32Conv& k, const F32Tile& t, int tiles, i
         INNFER_HIP(hipFuncSetAttribute((const void*)f32conv_tiled<NKT, NPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(bit, std::memory_order_release);
     }
+#ifdef INNFER_ABLATE
+    if (getenv("INNFER_F32_OCC")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)f32conv_tiled<NKT, NPT>, 256, lds);
+        fprintf(stderr, "[f32conv_tiled<%d,%d>] grid %d x %d lds %zu CC %d IMG %d -> %d workgroups / CU\n", NKT, NPT, tiles * t.nkg, zgroups, lds, t.CC, 1 << t.imgs, nb);
+    }
+#endif
     hipLaunchKernelGGL((f32conv_tiled<NKT, NPT>), dim3((unsigned)(tiles * t.nkg), 1, (unsigned)zgroups), dim3(256), lds, s, k, t);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
@@ -575,7 +635,7 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
         // equal its images' own forwards bit for bit -- then as many images per tile as fill the 256 pixels and keep the chunk within a thread's NE elements.
         const int cmax = (L.C + 3) / 4 * 4;
         int cc = std::min(32, cmax);
-        auto lds_bytes = [&](int c, int img) { return (size_t)c * (img * t.PH * t.PW + 80) * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };
+        auto lds_bytes = [&](int c, int img) { return 2 * (size_t)c * (img * t.PH * t.PW + 80) * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };
         while (cc > 4 && ((long)cc * t.PH * t.PW > 256L * F32_NE || lds_bytes(cc, 1) > 72 * 1024)) cc -= 4;
         // Grids of at most 64 pixels (tiles that hold whole images): the 64-pixel tile form (NPT 1), where a tile's images -- and with them the live pixel tiles of
         // its waves -- are bought with channels per chunk: 4 x 4 outputs with 32 channels per chunk leave room for ONE image's patch = 16 live pixels of 256.
@@ -600,15 +660,19 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
         int NKT = nkt16 >= 4 ? 4 : nkt16;
         while (NKT > 1 && NKT != 3 && (long)tiles * zgroups * ((nkt16 + NKT - 1) / NKT) < 512) NKT >>= 1;      // small launches: more, narrower workgroups
         t.nkg = (nkt16 + NKT - 1) / NKT;
-        auto lds_total = [&](int c) { return (size_t)c * t.PS * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };
+        auto lds_total = [&](int c) { return 2 * (size_t)c * t.PS * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };          // two patch buffers, two weight buffers
         const size_t wbytes = f32conv_packed_floats(L.K, L.C, L.ntap) * 4;
         if ((long)cc * t.plane <= 256L * F32_NE && lds_total(cc) <= 150 * 1024 && wbytes < 0x7fffffffu &&
             (long)cc * L.in_cstride + (long)IMG * L.in_nstride + (long)L.Hin * L.Win < 0x7fffffffL && (long)cc * t.plane < (1 << 21)) {
             t.CC = cc; t.wbytes = (unsigned)wbytes;
+            auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+            t.vec4 = TX >= 4 && L.osx == 1 && k.out_pstride == 1 && !L.phase_k && L.Wo % 4 == 0 && L.Wout % 4 == 0 && L.oox % 4 == 0 &&
+                     L.out_nstride % 4 == 0 && L.out_cstride % 4 == 0 && al16(L.out) &&
+                     (!L.res || (L.res_nstride % 4 == 0 && L.res_cstride % 4 == 0 && al16(L.res))) && (!L.mul || (L.mul_nstride % 4 == 0 && L.mul_cstride % 4 == 0 && al16(L.mul)));
 #ifdef INNFER_ABLATE
             t.abl = getenv("INNFER_F32_ABL") ? atoi(getenv("INNFER_F32_ABL")) : 0;
 #endif
-            const size_t lds = lds_total(cc);
+            const size_t lds = std::max(lds_total(cc), (size_t)16 * NKT * ((npt1 ? 64 : 256) + 4) * 4);      // (>= the epilogue's [channel][pixel] tile)
             switch (NKT * 2 + (npt1 ? 1 : 0)) {
                 case 2: return f32conv_tiled_launch<1, 4>(k, t, tiles, zgroups, lds, s);
                 case 3: return f32conv_tiled_launch<1, 1>(k, t, tiles, zgroups, lds, s);
