@@ -194,7 +194,7 @@ __global__ void pan_attn_prep(const float* fgh, const float* bf, const float* bg
             for (int e = 0; e < 8; ++e) o[q][e] = (f16)0.f;
 #pragma unroll
         for (int c = 0; c < ATT_CQ; ++c) {
-            const float f = base[i * 64 + c] + bf[c], g = base[i * 64 + ATT_CQ + c] + bg[c];
+            const float f = (base[i * 64 + c] + bf[c]) * 1.44269504088896340736f, g = base[i * 64 + ATT_CQ + c] + bg[c];      // f in log2 units: the kernel's exponential is 2^x
             const f16 fh = (f16)f, gh = (f16)g;
             o[0][c] = fh; o[1][c] = (f16)((f - (float)fh) * 2048.0f);
             o[2][c] = gh; o[3][c] = (f16)((g - (float)gh) * 2048.0f);
@@ -216,7 +216,7 @@ __global__ void pan_attn_prep(const float* fgh, const float* bf, const float* bg
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const long key = (long)blk * ATT_KB + 8 * lg + e;
-            v[e] = (f16)((key < Np && c < ATT_C) ? base[key * 64 + 2 * ATT_CQ + c] + bh[c] : 0.f);
+            v[e] = (f16)((key < Np && c < ATT_C) ? base[key * 64 + 2 * ATT_CQ + c] + bh[c] : ((key < Np && c == 47) ? 1.0f : 0.f));      // channel 47: ones -- its row of P V is the row sum
         }
         *(f16x8*)(Vt + ((long)n * nblk * 192 + i) * 8) = v;
     }
@@ -250,11 +250,11 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
     const int dst_off = half * 4096 + (t8 < 64 ? t8 * 16 : 1024 + (t8 - 64) * 16);
     // the key of row rho (= li) of score tile t, and this lane's A-operand octet: gh for k-octet 0, gl' for k-octet 1
     const int koff0 = (8 * (li >> 2) + (li & 3)) * 32 + (lg == 1 ? 16 : 0), koff1 = koff0 + 4 * 32;
-    auto scores = [&](const char* sp, f32x4 (&sc)[2]) __attribute__((always_inline)) {      // sc[t][j]: key 8 lg + 4 t + j of the block, query li
+    auto scores = [&](const char* sp, const f32x4& c0, f32x4 (&sc)[2]) __attribute__((always_inline)) {      // sc[t][j]: key 8 lg + 4 t + j of the block, query li, MINUS the offset in c0
         const f16x8 g0 = *(const f16x8*)(sp + koff0), g1 = *(const f16x8*)(sp + koff1);
         const f16x8 a0h = lg == 0 ? g0 : z8, a0x = lg < 2 ? g0 : z8, a1h = lg == 0 ? g1 : z8, a1x = lg < 2 ? g1 : z8;
-        const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bhh, z4, 0, 0, 0), x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0x, bx, z4, 0, 0, 0);
-        const f32x4 h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bhh, z4, 0, 0, 0), x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1x, bx, z4, 0, 0, 0);
+        const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bhh, c0, 0, 0, 0), x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0x, bx, z4, 0, 0, 0);
+        const f32x4 h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bhh, c0, 0, 0, 0), x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1x, bx, z4, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             sc[0][j] = __builtin_fmaf(x0[j], 1.0f / 2048.0f, h0[j]);
@@ -262,24 +262,27 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
         }
     };
     const int npair = (nblk + 1) / 2;
-    // ONE pass over the keys with a running row maximum (round 4, second version: the separate maximum pass recomputed every score -- 35 % of the kernel):
-    // per pair of blocks the lane's 16 scores -> their maximum -> the maximum over the four lanes that share the query (two cross-lane exchanges) ->
-    // m' = max(m, that); the accumulators and the sum are rescaled by exp(m - m') (1 when the maximum did not move), then p = exp(s - m') <= 1 as before.
-    // Masked keys (>= Np, the padding of the last block) score -inf: p = 0.
-    float m = -INFINITY;
+    // ONE pass over the keys with a running row maximum m.  Round 5 (<= 0.3 ms at 32 400 keys; the kernel is bound by the VALU work per score, 1.05 G scores):
+    //  * the scores arrive in log2 units (pan_attn_prep scales f by log2 e) and ALREADY MINUS m: -m is the score MFMAs' C operand, so p = 2^(s - m) is one v_exp_f32 per score
+    //    with no subtraction and no multiplication in front of it; when the maximum moves (wave-uniform test; after the first blocks it rarely does) the pair takes the
+    //    slow path: m += delta, accumulators rescaled by 2^-delta, p = 2^(s - m_old - delta);
+    //  * the row sum is a row of P V: channel 47 of the h fragments is 1 (pan_attn_prep), so lane (li, lg = 3) carries sum(p) in acc[2][3] -- the fp16 p the numerator uses --
+    //    and the sixteen additions per lane and pair are gone;
+    //  * p -> fp16 two at a time (v_cvt_pkrtz); the maximum over a lane's sixteen scores as a tree (v_max3).
+    // Masked keys (>= Np, the padding of the last block) score -inf: p = 0.  The first pair starts from m = 0 and takes its own maximum as delta.
+    float m = 0.f;
     f32x4 acc[3] = {z4, z4, z4};
-    float sum = 0.f;
     *(f16x8*)(st[0] + dst_off) = *(const f16x8*)stage_src(0);
     __syncthreads();
     for (int bp = 0; bp < npair; ++bp) {
         f16x8 nxt = z8;
         if (bp + 1 < npair) nxt = *(const f16x8*)stage_src(bp + 1);
         f32x4 sc[2][2];
-        float bm = -INFINITY;
+        const f32x4 c0 = {-m, -m, -m, -m};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int b = 2 * bp + h;
-            scores(st[bp & 1] + h * 4096, sc[h]);
+            scores(st[bp & 1] + h * 4096, c0, sc[h]);
             const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
             if (kb + 8 > Np) {                                       // (only the last block of an image is ragged)
 #pragma unroll
@@ -288,42 +291,49 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
                     for (int j = 0; j < 4; ++j)
                         if (kb + 4 * t + j >= Np) sc[h][t][j] = -INFINITY;
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bm = fmaxf(bm, sc[h][t][j]);
+        }
+        float bm;
+        {
+            const float m0 = fmaxf(fmaxf(sc[0][0][0], sc[0][0][1]), sc[0][0][2]), m1 = fmaxf(fmaxf(sc[0][0][3], sc[0][1][0]), sc[0][1][1]);
+            const float m2 = fmaxf(fmaxf(sc[0][1][2], sc[0][1][3]), sc[1][0][0]), m3 = fmaxf(fmaxf(sc[1][0][1], sc[1][0][2]), sc[1][0][3]);
+            const float m4 = fmaxf(fmaxf(sc[1][1][0], sc[1][1][1]), sc[1][1][2]);
+            bm = fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, sc[1][1][3]));
         }
         bm = fmaxf(bm, __shfl_xor(bm, 16));
         bm = fmaxf(bm, __shfl_xor(bm, 32));
-        const float mn = fmaxf(m, bm);                               // finite from the first pair on (every image has a key in its first block)
-        const float rescale = __expf(m - mn);                        // exp(-inf) = 0 on the first pair: acc and sum are zero there anyway
-        m = mn;
-        sum *= rescale;
+        const float delta = bp == 0 ? bm : fmaxf(bm, 0.f);          // (finite on the first pair: every image has a key in its first block)
+        if (__any(delta != 0.f)) {                                   // the maximum moved for some query of this wave
+            const float rescale = __builtin_amdgcn_exp2f(-delta);    // (acc is zero on the first pair)
+            m += delta;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = acc[t] * rescale;
+            for (int t = 0; t < 3; ++t) acc[t] = acc[t] * rescale;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sc[h][t][j] -= delta;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const char* sp = st[bp & 1] + h * 4096;
             f16x8 v[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) v[t] = *(const f16x8*)(sp + 1024 + t * 1024 + lane * 16);
-            f16x8 pk;
+            typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+            union { f16x8 v8; f16x2_t v2[4]; } pk;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float e = __expf(sc[h][t][j] - m);
-                    sum += e;
-                    pk[4 * t + j] = (f16)e;
-                }
+                for (int jj = 0; jj < 2; ++jj)
+                    pk.v2[2 * t + jj] = __builtin_bit_cast(f16x2_t, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(sc[h][t][2 * jj]), __builtin_amdgcn_exp2f(sc[h][t][2 * jj + 1])));
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[t], pk, acc[t], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[t], pk.v8, acc[t], 0, 0, 0);
         }
         if (bp + 1 < npair) *(f16x8*)(st[(bp + 1) & 1] + dst_off) = nxt;
         __syncthreads();
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    const float sum = __shfl(acc[2][3], 48 + li);                    // channel 47 = row 15 of tile 2: lane (li, lg = 3), element 3
     if (q < Np) {
         const float inv = 1.0f / sum;
         float* o = out + ((long)n * Np + q) * ATT_C;

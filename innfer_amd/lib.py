@@ -194,7 +194,12 @@ SIGNATURES = {
     "innfer_nchw_to_inthwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
+# INNFER_ABI_ANY=1 (measurement only: scripts/evidence_r5.sh A/Bs an OLDER build of the library against the current one on one box): bind the entry points that
+# library has and skip the revision check -- calls into entry points it lacks fail with AttributeError.  Never set for product use.
+_ABI_ANY = os.environ.get("INNFER_ABI_ANY") == "1"
 for _name, (_res, _args) in SIGNATURES.items():
+    if _ABI_ANY and not hasattr(_lib, _name):
+        continue
     _fn = getattr(_lib, _name)          # AttributeError here = header/library mismatch
     _fn.restype = _res
     _fn.argtypes = _args
@@ -202,7 +207,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 lib = _lib
 
 ABI_VERSION = 110          # the header revision this binding was written against (INNFER_ABI_VERSION)
-if _lib.innfer_version() != ABI_VERSION:
+if _lib.innfer_version() != ABI_VERSION and not _ABI_ANY:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 
 
