@@ -631,34 +631,70 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
         t.dymin = dymin; t.dxmin = dxmin;
         t.PH = (TY - 1) * L.isy + (dymax - dymin) + 1;
         t.PW = (TX - 1) * L.isx + (dxmax - dxmin) + 1;
-        // Channels per chunk first -- from the geometry of ONE image's patch, never from the batch: the chunk size is the order of the sums, and a batch must
-        // equal its images' own forwards bit for bit -- then as many images per tile as fill the 256 pixels and keep the chunk within a thread's NE elements.
-        const int cmax = (L.C + 3) / 4 * 4;
-        int cc = std::min(32, cmax);
-        auto lds_bytes = [&](int c, int img) { return 2 * (size_t)c * (img * t.PH * t.PW + 80) * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };
-        while (cc > 4 && ((long)cc * t.PH * t.PW > 256L * F32_NE || lds_bytes(cc, 1) > 72 * 1024)) cc -= 4;
-        // Grids of at most 64 pixels (tiles that hold whole images): the 64-pixel tile form (NPT 1), where a tile's images -- and with them the live pixel tiles of
-        // its waves -- are bought with channels per chunk: 4 x 4 outputs with 32 channels per chunk leave room for ONE image's patch = 16 live pixels of 256.
-        // These layers wait for their weight stream (16.8 MB per 512 -> 512 level against < 1 GFLOP at 1 x 1): few images per tile (at most 8: more workgroups
-        // to pull it, 256 for a batch of 64 at 1 x 1) and as many channels per chunk as that leaves (fewer latency hops: one per chunk).
-        const bool small = (1 << (t.txs + t.tys)) <= 32;
-        t.imgs = 8 - t.txs - t.tys;
-        if (small) {
-            t.imgs = std::min(6 - t.txs - t.tys, 3);
-            while (cc > 4 && (long)cc * t.PH * t.PW * (1 << t.imgs) > 256L * F32_NE) cc -= 4;
-        }
-        while (t.imgs > 0 && ((long)cc * (1 << t.imgs) * t.PH * t.PW > 256L * F32_NE || lds_bytes(cc, 1 << t.imgs) > 72 * 1024)) --t.imgs;
-        const int IMG = 1 << t.imgs;
-        const bool npt1 = (1 << (t.txs + t.tys + t.imgs)) <= 64;
-        t.plane = IMG * t.PH * t.PW;
-        t.PS = t.plane + ((16 - t.plane % 64) + 64) % 64;          // plane stride = 16 (mod 64 banks): the four k lanes of a fragment read land 16 banks apart
-        t.rplane = 1.0f / (float)t.plane; t.rimg = 1.0f / (float)(t.PH * t.PW); t.rpw = 1.0f / (float)t.PW;
-        const int nkt16 = (L.K + 15) / 16;                          // 16-channel tiles that hold real outputs
+        // Tile shape by a small cost model instead of rules (round 5: the rules left the UNet's 8 x 8 levels on half-empty 256-pixel tiles and its 4 x 4 .. 1 x 1
+        // levels with 4-channel chunks -- 6.0 of 15.4 ms for 18 % of the FLOPs).  Candidates: pixel tiles per wave NPT in {1, 4} (64- / 256-pixel tiles), images per
+        // tile IMG (powers of two that fit the tile), channels per chunk CC (multiples of 4 whose patch fits a thread's NE elements and the LDS), channel tiles NKT.
+        // Estimated cycles of a launch = rounds x max(one workgroup's life, the matrix-pipe time of the workgroups that share a CU):
+        //   life = setup + chunks x (steps x NKT x NPT x 32 + per-chunk overhead),  rounds = ceil(workgroups / (256 CUs x co-resident workgroups)).
+        // (IMG, NPT, CC) are chosen for a NOMINAL batch of 64 -- never from the real one: CC is the order of the sums, and a batch must equal its images' own
+        // forwards bit for bit; NKT (which does not touch the sums) is then chosen for the real batch.
+        const int cmax = (L.C + 3) / 4 * 4, nkt16 = (L.K + 15) / 16;          // nkt16: 16-channel tiles that hold real outputs
+        const int px1 = t.PH * t.PW, tile1 = 1 << (t.txs + t.tys);
         const int tiles_y = (L.Ho + TY - 1) / TY;
         t.tiles_x = (L.Wo + TX - 1) / TX;
-        const int tiles = t.tiles_x * tiles_y, zgroups = (L.N + IMG - 1) / IMG;
-        int NKT = nkt16 >= 4 ? 4 : nkt16;
-        while (NKT > 1 && NKT != 3 && (long)tiles * zgroups * ((nkt16 + NKT - 1) / NKT) < 512) NKT >>= 1;      // small launches: more, narrower workgroups
+        const int tiles = t.tiles_x * tiles_y;
+        auto lds_need = [&](int c, int img, int nktc, int npt) {
+            const size_t plane = (size_t)img * px1, ps = plane + 80;
+            return std::max(2 * (size_t)c * ps * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024, (size_t)16 * nktc * (64 * npt + 4) * 4);
+        };
+        auto est = [&](int npt, int img, int c, int nktc, int batch) -> double {
+            const size_t lds = lds_need(c, img, nktc, npt);
+            const int co_max = (int)std::min<size_t>(2, (160 * 1024) / lds);                    // (two waves per SIMD by registers)
+            if (co_max < 1) return 1e30;
+            const long wgs = (long)tiles * ((batch + img - 1) / img) * ((nkt16 + nktc - 1) / nktc);
+            const int chunks = (cmax + c - 1) / c;
+            const double mfma = (double)L.ntap * (c / 4) * nktc * npt * 32.0;      // (a floor of ~220 issue cycles per step, which the SQ counters of the <1,1> form suggest, chose worse shapes: 16.0 vs 14.9 ms)
+            const double life = 6000.0 + chunks * (mfma + 2500.0);
+            const long slots = 256L * co_max;
+            const long rounds = (wgs + slots - 1) / slots;
+            const int co = (int)std::min<long>(co_max, (wgs + 255) / 256);
+            return (double)rounds * std::max(life, (double)co * chunks * mfma);
+        };
+        int b_npt = 4, b_imgs = 0, cc = 4;
+        {
+            double best = 1e30;
+            for (int npt = 1; npt <= 4; npt += 3) {
+                if (tile1 > 64 * npt) continue;
+                for (int imgs = 0; (tile1 << imgs) <= 64 * npt; ++imgs) {
+                    for (int c = std::min(32, cmax); c >= 4; c -= 4) {
+                        if ((long)c * (px1 << imgs) > 256L * F32_NE) continue;
+                        double e = 1e30;
+                        for (int nktc = std::min(4, nkt16); nktc >= 1; nktc = nktc == 3 ? 2 : nktc >> 1) {
+                            if (lds_need(c, 1 << imgs, nktc, npt) > 76 * 1024 && !(c == 4 && imgs == 0)) continue;
+                            e = std::min(e, est(npt, 1 << imgs, c, nktc, 64));
+                        }
+                        if (e > 1e29) continue;                      // (no NKT fits the LDS with this CC: a smaller one may)
+                        if (e < best * 0.999) { best = e; b_npt = npt; b_imgs = imgs; cc = c; }
+                        break;                                       // (the largest CC that fits this (NPT, IMG): fewer chunks never cost more)
+                    }
+                }
+            }
+        }
+        t.imgs = b_imgs;
+        const int IMG = 1 << t.imgs;
+        const bool npt1 = b_npt == 1;
+        t.plane = IMG * px1;
+        t.PS = t.plane + ((16 - t.plane % 64) + 64) % 64;          // plane stride = 16 (mod 64 banks): the four k lanes of a fragment read land 16 banks apart
+        t.rplane = 1.0f / (float)t.plane; t.rimg = 1.0f / (float)px1; t.rpw = 1.0f / (float)t.PW;
+        const int zgroups = (L.N + IMG - 1) / IMG;
+        int NKT = std::min(4, nkt16);
+        {
+            double best = 1e30;
+            for (int nktc = std::min(4, nkt16); nktc >= 1; nktc = nktc == 3 ? 2 : nktc >> 1) {
+                const double e = est(b_npt, IMG, cc, nktc, L.N);
+                if (e < best * 0.999) { best = e; NKT = nktc; }
+            }
+        }
         t.nkg = (nkt16 + NKT - 1) / NKT;
         auto lds_total = [&](int c) { return 2 * (size_t)c * t.PS * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };          // two patch buffers, two weight buffers
         const size_t wbytes = f32conv_packed_floats(L.K, L.C, L.ntap) * 4;

@@ -784,6 +784,9 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         F.in = d_in; F.in_f32 = in_dtype == INNFER_F32; F.Cin = c0.C; F.w = (const float*)c0.d_w; F.bias = c0.d_b;
         F.in_u8 = in_dtype == INNFER_U8; F.in_norm = net->u8_normalize; F.in_round16 = net->u8_round16;     // np2tensor as the conv's prologue
         F.out = fea; F.out_gstride = G; F.out2 = slab[0]; F.out2_gstride = G;
+        // (SRResNet: the first block reads fea itself -- a second copy in slab[0] only serves the dense blocks' concatenation; one 128 B / pixel store less in a
+        //  launch that is bound by its stores)
+        if (net->kind == 1 && net->nb > 0) F.out2 = nullptr;
         F.K = nf; F.N = N; F.H = H; F.W = W; F.act = 0;
         F.out_lo = LO; F.out2_lo = LO;
         int rc = do_first(F, s);
@@ -836,19 +839,20 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         for (int b = 0; b < net->nb; ++b) {
             const int a = cur, m = (cur + 1) % 3, o = (cur + 2) % 3;
             const ConvSlot& c0 = net->convs[ci++];
-            const f16* in0 = slab[a];
+            const f16* xa = b == 0 ? fea : slab[a];                  // the block's input (block 0: conv_first's output, never rewritten: the last shortcut reads it too)
+            const f16* in0 = xa;
             if (c0.d_map) {          // mode 'NAC': norm -> act in front of the conv, into the (still unused) trunk slab; launches in order, whole frame
                 int rc = run_chain(chain, 0, s);
                 if (rc) return rc;
                 chain.clear();
-                rc = do_input_map(c0, slab[a], trunk, G, s, LO);
+                rc = do_input_map(c0, xa, trunk, G, s, LO);
                 if (rc) return rc;
                 in0 = trunk;
             }
             chain.push_back(mk(c0, in0, G, slab[m], G, N, H, W, net->trunk_act));
             const ConvSlot& c1 = net->convs[ci++];
             ConvLaunch L = mk(c1, slab[m], G, slab[o], G, N, H, W, 0);
-            L.res1 = slab[a]; L.res1_gstride = G; L.s1 = net->res_scale;          // x + res * res_scale
+            L.res1 = xa; L.res1_gstride = G; L.s1 = net->res_scale;               // x + res * res_scale
             chain.push_back(L);
             cur = o;
         }

@@ -1755,14 +1755,16 @@ def test_extract_and_blend_bit_exact(dev, golden):
 
 def test_blend_identity_at_full_size(dev):
     """Size-independent property at the 8K-input tile count (3268 tiles of 200x200, scale 1):
-    recompose(extract(x)) == x up to fp32 rounding."""
+    recompose(extract(x)) == x up to fp32 rounding: out = (sum_k w_k x) / (sum_k w_k) over the <= 4 tiles that cover a pixel -- one rounding per product, per
+    addition of either sum and for the quotient: <= 8 half-ulps of a value below 1 = 8 * 2^-24 = 4.8e-7 (seeded input: with fresh random data the maximum over
+    100 M values moved between 3.0e-7 and 3.6e-7 from run to run, around the old 3e-7 bound)."""
     from innfer_amd.utils import utils as U
     h, w = 4320, 7680
-    x = torch.rand((1, 3, h, w), device=dev)
+    x = torch.rand((1, 3, h, w), device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
     tiles = U.extract_patches_2d(x, (200, 200), [0.5, 0.5], batch_first=True).squeeze(0)
     assert tiles.shape[0] == 3268
     r = U.recompose_tensor(tiles, h, w, step=0.5, scale=1)
-    assert (r - x).abs().max().item() <= 3e-7
+    assert (r - x).abs().max().item() <= 4.8e-7
 
 
 def test_pre_post_bit_exact(dev, golden):
