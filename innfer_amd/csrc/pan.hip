@@ -525,6 +525,7 @@ struct innfer_pan {
     bool fp32 = false;               // innfer_pan_set_precision(1): the fp32 forward on NCHW fp32 tensors (f32ops.hip), the reference's -no_fp16 mode
     std::vector<float*> f32_w;       //   f32conv panels in forward order (pan_forward_f32 walks them)
     std::vector<void*> d_scpa;       // one weight blob per SCPA block (pan_scpa.hip), trunk by trunk
+    int scpa_c8 = 1;                 // compact channel plane between the fused SCPA blocks (pan_scpa_launch in_c8 / out_c8); 0: A/B (fused_scpa 3)
     int mfma_attention = 1;          // the FSA block's attention on the matrix cores (pan_attention_mfma); 0: the VALU kernel of rounds 1-3 (set with fused_scpa: one A/B switch)
     int fused_scpa = 1;              // an SCPA block as ONE launch (innfer_pan_set_fused_scpa); 0: the five halo-tile launches of rounds 1-3
     bool uploaded = false;
@@ -594,6 +595,7 @@ extern "C" int innfer_pan_set_fused_scpa(innfer_pan* p, int on) {
     if (!p) return set_error(INNFER_ERR_INVALID, "pan_set_fused_scpa: null network");
     p->fused_scpa = on ? 1 : 0;
     p->mfma_attention = on == 2 ? 0 : 1;          // (2: the fused trunk with the VALU attention -- A/B of the attention alone)
+    p->scpa_c8 = on == 3 ? 0 : 1;                 // (3: the fused blocks on two-group slabs throughout -- A/B of the compact channel plane alone, same bits)
     if (!on) p->mfma_attention = 0;
     return INNFER_OK;
 }
@@ -1055,7 +1057,9 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         f16* xn = (b & 1) ? XB : XA;
         if (p->fused_scpa && (long)N * H * W * 64 + 2 * G < 0x7fffffffL) {          // the whole block in one launch (pan_scpa.hip)
             GtScope gt(s, "pan_scpa_fused (one SCPA block)", 2.0 * (2 * 20 * 40 + 3 * 9 * 20 * 20 + 20 * 20 + 40 * 40) * (double)px, 4.0 * 40 * (double)px + 28800.0);
-            CK(pan_scpa_launch(x, xn, G, p->d_scpa[(size_t)k * p->nb + b], N, H, W, s));
+            // between two blocks of a trunk the tensor's channels 32..39 travel as a compact 16-byte plane (80 instead of 128 bytes per pixel each way; the counters
+            // showed 138 MB per launch against 83 MB algorithmic: profiles/r5/traffic_other.txt); the trunk's first block reads and its last writes the two-group slab
+            CK(pan_scpa_launch(x, xn, G, p->d_scpa[(size_t)k * p->nb + b], N, H, W, s, p->scpa_c8 && b > 0, p->scpa_c8 && b + 1 < p->nb));
             gi += 5;
             x = xn;
             continue;

@@ -43,6 +43,8 @@ struct ScpaKP {
     const f16* in; f16* out; long G;        // slabs of two 32-channel groups (40 real channels), group stride G elements
     const char* w;                          // the block's blob (W_BYTES)
     int N, H, W, tiles_x, tiles_y, total;
+    int in_c8, out_c8;                      // != 0: channels 32..39 of the input / output slab travel COMPACT -- 16 bytes per pixel at (G elements + pixel * 8) instead of the first 16 bytes
+                                            // of a 64-byte group-1 pixel (whose other 48 bytes are zeros no SCPA block reads): between two SCPA blocks of the trunk (round 5)
     int abl;                                // diagnostic build only (make ablate, INNFER_SCPA_ABL): skip 1 P1, 2 P2a, 4 P2b, 8 P3's MFMAs, 16 the X fetch, 32 the stores
 };
 
@@ -128,11 +130,16 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 
     // per-lane source offsets of this wave's X pieces relative to the tile's first halo pixel (group 0): slot i = piece * 64 + lane -> pixel i / 5, 16-byte
     // part i % 5 (0..3: channels 0..31 of group 0; 4: channels 32..39 = the first 16 bytes of group 1)
+    // (compact input, p.in_c8: part 4 lies at gbytes + pixel * 16 from the slab's origin = gbytes + (r W + c) * 16 - 48 * (the tile's first halo pixel index) from the tile's
+    //  group-0 address: the per-lane part here, the per-tile part in fetch)
     int loff[KQ];
+    [[maybe_unused]] unsigned part4 = 0;                    // bit k: piece k of this lane is part 4
 #pragma unroll
     for (int k = 0; k < KQ; ++k) {
         const int i = (wave + 8 * k) * 64 + lane, P = i / 5, s = i - 5 * P, r = P / HC, c = P - r * HC;
-        loff[k] = (wave + 8 * k < XQ && P < NPX) ? (r * p.W + c) * 64 + (s < 4 ? s * 16 : (int)gbytes) : OOB;
+        const bool ok = wave + 8 * k < XQ && P < NPX;
+        loff[k] = ok ? (s < 4 ? (r * p.W + c) * 64 + s * 16 : (r * p.W + c) * (p.in_c8 ? 16 : 64) + (int)gbytes) : OOB;
+        part4 |= (unsigned)(ok && s == 4) << k;
     }
     auto decode = [&](int j, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
         int t = run_start + j;
@@ -147,10 +154,12 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
         const char* src = (const char*)(p.in + (long)n * p.H * p.W * 32) + ((long)(ty0 - 2) * p.W + (tx0 - 2)) * 64;
         const bool edge = ty0 < 2 || ty0 + TH + 2 > p.H || tx0 < 2 || tx0 + TW + 2 > p.W;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
+        const int c8_shift = p.in_c8 ? 48 * (int)((long)n * p.H * p.W + (long)(ty0 - 2) * p.W + (tx0 - 2)) : 0;
 #pragma unroll
         for (int k = 0; k < KQ; ++k) {
             const int q = wave + 8 * k;
             int vo = loff[k];
+            if ((part4 >> k) & 1) vo -= c8_shift;
             if (edge) {
                 const int i = q * 64 + lane, P = i / 5, r = P / HC, c = P - r * HC;
                 const int y = ty0 - 2 + r, x = tx0 - 2 + c;
@@ -339,9 +348,14 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                         o0[e] = (f16)(d[0][e] + (float)res[u][0][e]); o0[4 + e] = (f16)(d[1][e] + (float)res[u][0][4 + e]);
                         o1[e] = (f16)(d[2][e] + (float)res[u][1][e]); o1[4 + e] = (f16)(d[3][e] + (float)res[u][1][4 + e]);
                     }
-                    f16* o = p.out + (lg >> 1) * p.G + (((long)n * p.H + y) * p.W + x) * 32 + (lg & 1) * 16;
-                    *(f16x8*)o = o0;
-                    *(f16x8*)(o + 8) = o1;
+                    const long pix = ((long)n * p.H + y) * p.W + x;
+                    if (p.out_c8 && lg >= 2) {                       // channels 32..39 compact; 40..63 (zeros) not stored
+                        if (lg == 2) *(f16x8*)(p.out + p.G + pix * 8) = o0;
+                    } else {
+                        f16* o = p.out + (lg >> 1) * p.G + pix * 32 + (lg & 1) * 16;
+                        *(f16x8*)o = o0;
+                        *(f16x8*)(o + 8) = o1;
+                    }
                 }
             }
         }
@@ -414,7 +428,7 @@ static int scpa_num_cus() {
     return v;
 }
 
-int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s) {
+int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s, int in_c8, int out_c8) {
     const int num_cus = scpa_num_cus();
     constexpr int TH = 16;
     constexpr int LDS = 160 * 1024;
@@ -434,6 +448,7 @@ int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, 
     if ((long)N * H * W * 64 + 2 * G >= 0x7fffffffL) return set_error(INNFER_ERR_UNSUPPORTED, "pan_scpa: slab too large for 32-bit buffer offsets");
     ScpaKP k{};
     k.in = in; k.out = out; k.G = G; k.w = (const char*)d_blob; k.N = N; k.H = H; k.W = W;
+    k.in_c8 = in_c8; k.out_c8 = out_c8;
     k.tiles_x = (W + TW - 1) / TW; k.tiles_y = (H + TH - 1) / TH;
     const long total = (long)N * k.tiles_x * k.tiles_y;
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "pan_scpa: grid too large");

@@ -1509,6 +1509,8 @@ def test_pan_fused_scpa_vs_five_launches_and_oracle(dev):
         y0 = net(x.to(dev).half())
         net.fused_scpa = 2                                              # the fused blocks with the VALU attention: the two changes apart
         y2 = net(x.to(dev).half())
+        net.fused_scpa = 3                                              # two-group slabs between the blocks instead of the compact channel plane (round 5): same bits
+        assert torch.equal(net(x.to(dev).half()), y1), shape
         net.fused_scpa = True
         e1, e0 = (y1.float().cpu() - ref).abs(), (y0.float().cpu() - ref).abs()
         d = (y1.float() - y0.float()).abs().max().item()
