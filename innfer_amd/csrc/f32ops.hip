@@ -165,11 +165,14 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
     const int CC4 = t.CC >> 2, nstep = p.ntap * CC4;
     float* patch = f32lds;
     char* wl0 = (char*)(f32lds + 2L * t.CC * t.PS);          // (two patch buffers in front)
-    const long wl_bytes = (long)nstep * 1024;
-    const float* inb = p.in + (long)n0 * p.in_nstride;
+    constexpr int RPI = NKT == 3 ? 1 : 4 / NKT;                  // weight rows per 1-KB LDS-DMA piece: a row is 16 NKT channels x 16 bytes (NKT 3: 768 of a 1-KB pitch)
+    constexpr int ROWB = 1024 / RPI;                            // bytes between rows in LDS
+    const long wl_bytes = (long)((nstep + RPI - 1) / RPI) * 1024;
+    [[maybe_unused]] const float* inb = p.in + (long)n0 * p.in_nstride;
     const int Hv = p.up ? 2 * p.Hin : p.Hin, Wv = p.up ? 2 * p.Win : p.Win;
     const int img_px = t.PH * t.PW;
     // ---- this thread's patch elements e = tid + 256 i of a chunk: global offset from (image n0, channel c0) or -1 (padding, beyond the batch), LDS offset
+    const int nfull = (t.CC * t.plane) >> 8, nrem = (t.CC * t.plane) & 255;      // whole 256-thread slots of a chunk's elements, threads of the partial one
     int goff[NE], loff[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
         const bool in_chunk = cl < t.CC;
         const bool ok = in_chunk && il < IMG && n0 + il < p.N && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
         const int iy = p.up ? vy >> 1 : vy, ix = p.up ? vx >> 1 : vx;
-        goff[i] = ok ? (int)(cl * p.in_cstride + il * p.in_nstride) + iy * p.Win + ix : -1;
-        loff[i] = in_chunk ? cl * t.PS + rem : -1;
+        goff[i] = ok ? ((int)(cl * p.in_cstride + il * p.in_nstride) + iy * p.Win + ix) * 4 : (int)0x80000000;
+        loff[i] = in_chunk ? cl * t.PS + rem : 0;                  // (slots past the chunk's elements are never loaded / written: nfull, nrem below)
     }
     // ---- B fragment bases of the wave's four pixel tiles (floats into the patch, without tap and chunk-channel terms)
     int boff[NPT];
@@ -210,9 +213,11 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
         for (int pt = 0; pt < NPT; ++pt) acc[kt][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float v[NE];
+    // (buffer loads: one instruction per element -- the per-element 64-bit address arithmetic of plain loads was a third of a chunk's ~600 fixed instructions, and the
+    //  chunk's fixed cost is what the UNet's <= 8 x 8 levels pay 30 .. 40 times per workgroup: profiles/r5/f32_ablate_deep.txt.  goff holds BYTE offsets; an element
+    //  outside the image / batch carries the out-of-range offset and loads zero; the descriptor is rebuilt per chunk on the chunk's first channel)
     auto prefetch_patch = [&](int c0) __attribute__((always_inline)) {
-        const float* ic = inb + (long)c0 * p.in_cstride;
-        const int lim = min(t.CC, p.C - c0) * t.plane;            // elements of channels that exist
+#if defined(__HIP_DEVICE_COMPILE__)
 #ifdef INNFER_ABLATE
         if (t.abl & 4) {
 #pragma unroll
@@ -220,8 +225,20 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
             return;
         }
 #endif
+        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + (long)c0 * p.in_cstride), 0, 0x7fffffff, 0x00020000);
+        if (c0 + t.CC <= p.C) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) v[i] = (goff[i] >= 0 && tid + 256 * i < lim) ? ic[goff[i]] : 0.f;
+            for (int i = 0; i < NE; ++i)
+                if (i <= nfull) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, goff[i], 0, 0));          // (slot nfull: its tail threads carry the out-of-range offset)
+        } else {                                                  // the last chunk of a channel count that is no multiple of CC: channels beyond C read zero
+            const int lim = (p.C - c0) * t.plane;
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+                if (i <= nfull) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, tid + 256 * i < lim ? goff[i] : (int)0x80000000, 0, 0));
+        }
+#else
+        (void)c0;
+#endif
     };
     auto issue_weights = [&](int c0, int buf) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -231,12 +248,19 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, t.wbytes, 0x00020000);
         char* dst = wl0 + buf * wl_bytes;
         const int c40 = c0 >> 2;
-        const bool lane_ok = lane < 16 * NKT && k0 + lane < t.Kp;
-        for (int r = wave; r < nstep; r += 4) {
-            const int tap = r / CC4, c4l = r - tap * CC4;
+        // piece j (1 KB) holds rows j RPI .. j RPI + RPI - 1: lane -> (its row of the piece, channel of the row); wave w takes pieces w, w + 4, ..
+        constexpr int LPR = 64 / RPI;                            // lanes per row
+        const int sub = lane / LPR, kk = lane - sub * LPR;
+        const bool lane_ok = kk < 16 * NKT && k0 + kk < t.Kp;
+        const int npieces = (nstep + RPI - 1) / RPI;
+        int r = wave * RPI + sub;                                // this lane's row, stepped by 4 RPI rows per piece without divisions
+        int tap = r / CC4, c4l = r - tap * CC4;
+        const int dtap = (4 * RPI) / CC4, dc4 = 4 * RPI - dtap * CC4;
+        for (int j = wave; j < npieces; j += 4, r += 4 * RPI, tap += dtap, c4l += dc4) {
+            if (c4l >= CC4) { c4l -= CC4; ++tap; }
             const unsigned row = (unsigned)(((tap * t.C4 + c40 + c4l) * t.Kp + k0) * 16);
-            const int voff = (lane_ok && c40 + c4l < t.C4) ? (int)(row + lane * 16) : (int)0x80000000;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, voff, 0, 0, 0);
+            const int voff = (lane_ok && r < nstep && c40 + c4l < t.C4) ? (int)(row + kk * 16) : (int)0x80000000;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, voff, 0, 0, 0);
         }
 #else
         (void)c0; (void)buf;
@@ -249,15 +273,15 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
     // not fill each other's gaps: matrix pipe 0.55 busy, profiles/r5/pmc_unet_fp32.txt.)
     auto write_patch = [&](int pb) __attribute__((always_inline)) {
         float* pw = patch + (long)pb * t.CC * t.PS;
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            if (loff[i] >= 0) {
-                float f = v[i];
-                if (p.in_act == 1) f = f > 0.f ? f : 0.2f * f;
-                else if (p.in_act == 2) f = f > 0.f ? f : 0.f;
-                pw[loff[i]] = f;
-            }
+        // (slots 0 .. nfull - 1 hold an element for every thread, slot nfull for the first nrem threads, later slots none: uniform tests, no per-element predicate)
+#define INNFER_F32_WRITE(EXPR)                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NE; ++i) {                                              \
+            if (i < nfull || (i == nfull && tid < nrem)) pw[loff[i]] = (EXPR);                        \
         }
+        if (p.in_act == 1) { INNFER_F32_WRITE(v[i] > 0.f ? v[i] : 0.2f * v[i]) }
+        else if (p.in_act == 2) { INNFER_F32_WRITE(fmaxf(v[i], 0.f)) }
+        else { INNFER_F32_WRITE(v[i]) }
+#undef INNFER_F32_WRITE
     };
     prefetch_patch(0);
     issue_weights(0, 0);
@@ -287,7 +311,7 @@ __global__ __launch_bounds__(256) void f32conv_tiled(const F32Conv p, const F32T
             for (int u = 0; u < G; ++u) {
                 if (ftap < p.ntap) {
                     const int toff = __builtin_amdgcn_readlane(tapv, ftap) + fc4 * 4 * t.PS;
-                    const float* wa = wl + (long)(ftap * CC4 + fc4) * 256 + li * 4 + lg;
+                    const float* wa = wl + (long)(ftap * CC4 + fc4) * (ROWB / 4) + li * 4 + lg;
 #pragma unroll
                     for (int kt = 0; kt < NKT; ++kt) fa[u][kt] = wa[kt * 64];
 #pragma unroll
@@ -635,7 +659,7 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
         // levels with 4-channel chunks -- 6.0 of 15.4 ms for 18 % of the FLOPs).  Candidates: pixel tiles per wave NPT in {1, 4} (64- / 256-pixel tiles), images per
         // tile IMG (powers of two that fit the tile), channels per chunk CC (multiples of 4 whose patch fits a thread's NE elements and the LDS), channel tiles NKT.
         // Estimated cycles of a launch = rounds x max(one workgroup's life, the matrix-pipe time of the workgroups that share a CU):
-        //   life = setup + chunks x (steps x NKT x NPT x 32 + per-chunk overhead),  rounds = ceil(workgroups / (256 CUs x co-resident workgroups)).
+        //   life = setup + chunks x (steps x (NKT x NPT x 32 + (NKT + NPT) x 16) + per-chunk overhead),  rounds = ceil(workgroups / (256 CUs x co-resident workgroups)).
         // (IMG, NPT, CC) are chosen for a NOMINAL batch of 64 -- never from the real one: CC is the order of the sums, and a batch must equal its images' own
         // forwards bit for bit; NKT (which does not touch the sums) is then chosen for the real batch.
         const int cmax = (L.C + 3) / 4 * 4, nkt16 = (L.K + 15) / 16;          // nkt16: 16-channel tiles that hold real outputs
@@ -645,7 +669,8 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
         const int tiles = t.tiles_x * tiles_y;
         auto lds_need = [&](int c, int img, int nktc, int npt) {
             const size_t plane = (size_t)img * px1, ps = plane + 80;
-            return std::max(2 * (size_t)c * ps * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024, (size_t)16 * nktc * (64 * npt + 4) * 4);
+            const size_t rpi = nktc == 3 ? 1 : 4 / nktc, wb = ((size_t)L.ntap * (c / 4) + rpi - 1) / rpi * 1024;      // weight rows are 256 NKT bytes apart (four / two per DMA piece)
+            return std::max(2 * (size_t)c * ps * 4 + 2 * wb, (size_t)16 * nktc * (64 * npt + 4) * 4);
         };
         auto est = [&](int npt, int img, int c, int nktc, int batch) -> double {
             const size_t lds = lds_need(c, img, nktc, npt);
@@ -653,7 +678,7 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
             if (co_max < 1) return 1e30;
             const long wgs = (long)tiles * ((batch + img - 1) / img) * ((nkt16 + nktc - 1) / nktc);
             const int chunks = (cmax + c - 1) / c;
-            const double mfma = (double)L.ntap * (c / 4) * nktc * npt * 32.0;      // (a floor of ~220 issue cycles per step, which the SQ counters of the <1,1> form suggest, chose worse shapes: 16.0 vs 14.9 ms)
+            const double mfma = (double)L.ntap * (c / 4) * (nktc * npt * 32.0 + (nktc + npt) * 16.0);      // (+ ~16 cycles per fragment read that the MFMAs do not cover: favours wide steps -- the b32-fed loop tops out at 0.76 of the pipe, profiles/r5/mfma_f32_micro.txt)
             const double life = 6000.0 + chunks * (mfma + 2500.0);
             const long slots = 256L * co_max;
             const long rounds = (wgs + slots - 1) / slots;
@@ -666,16 +691,14 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
             for (int npt = 1; npt <= 4; npt += 3) {
                 if (tile1 > 64 * npt) continue;
                 for (int imgs = 0; (tile1 << imgs) <= 64 * npt; ++imgs) {
-                    for (int c = std::min(32, cmax); c >= 4; c -= 4) {
+                    for (int c = std::min(128, cmax); c >= 4; c -= 4) {
                         if ((long)c * (px1 << imgs) > 256L * F32_NE) continue;
                         double e = 1e30;
                         for (int nktc = std::min(4, nkt16); nktc >= 1; nktc = nktc == 3 ? 2 : nktc >> 1) {
                             if (lds_need(c, 1 << imgs, nktc, npt) > 76 * 1024 && !(c == 4 && imgs == 0)) continue;
                             e = std::min(e, est(npt, 1 << imgs, c, nktc, 64));
                         }
-                        if (e > 1e29) continue;                      // (no NKT fits the LDS with this CC: a smaller one may)
-                        if (e < best * 0.999) { best = e; b_npt = npt; b_imgs = imgs; cc = c; }
-                        break;                                       // (the largest CC that fits this (NPT, IMG): fewer chunks never cost more)
+                        if (e < best * 0.999) { best = e; b_npt = npt; b_imgs = imgs; cc = c; }      // (every CC: a smaller one may admit a wider NKT within the LDS)
                     }
                 }
             }
@@ -696,10 +719,13 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
             }
         }
         t.nkg = (nkt16 + NKT - 1) / NKT;
-        auto lds_total = [&](int c) { return 2 * (size_t)c * t.PS * 4 + 2 * (size_t)L.ntap * (c / 4) * 1024; };          // two patch buffers, two weight buffers
+        auto lds_total = [&](int c) {                                 // two patch buffers, two weight buffers
+            const size_t rpi = NKT == 3 ? 1 : 4 / NKT;
+            return 2 * (size_t)c * t.PS * 4 + 2 * (((size_t)L.ntap * (c / 4) + rpi - 1) / rpi * 1024);
+        };
         const size_t wbytes = f32conv_packed_floats(L.K, L.C, L.ntap) * 4;
         if ((long)cc * t.plane <= 256L * F32_NE && lds_total(cc) <= 150 * 1024 && wbytes < 0x7fffffffu &&
-            (long)cc * L.in_cstride + (long)IMG * L.in_nstride + (long)L.Hin * L.Win < 0x7fffffffL && (long)cc * t.plane < (1 << 21)) {
+            ((long)cc * L.in_cstride + (long)IMG * L.in_nstride + (long)L.Hin * L.Win) * 4 < 0x7fffffffL && (long)cc * t.plane < (1 << 21)) {
             t.CC = cc; t.wbytes = (unsigned)wbytes;
             auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
             t.vec4 = TX >= 4 && L.osx == 1 && k.out_pstride == 1 && !L.phase_k && L.Wo % 4 == 0 && L.Wout % 4 == 0 && L.oox % 4 == 0 &&

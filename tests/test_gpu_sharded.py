@@ -325,3 +325,34 @@ def test_bench_counts_gpus_without_touching_hip():
     import bench
     n = bench.visible_gpu_count()
     assert n >= 1 and n == torch.cuda.device_count()
+
+
+def test_key_addressed_engine_fp32_tiles_on_a_non_current_gpu(dev):
+    """ParamEngineModule.tile_batch_bytes uploads the weights and builds the fp32 panels -- on the device the caller names, not on whatever GPU happens
+    to be current; the forward that follows launches there with those pointers.  PAN in -no_fp16 mode sized and run on cuda:1 while cuda:0 is current, and a PPON forward on
+    cuda:1 (its own forward override).  Skips on a one-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.parallel import engine_tile_cap, run_tile_batches
+    from innfer_amd.utils.defaults import get_network_G_config
+    d1 = torch.device("cuda", 1)
+    torch.cuda.set_device(0)
+    for arch, kw in (("pan", {"nb": 2}), ("ppon", {"nb": 2})):
+        net = get_network(get_network_G_config({"type": arch, **kw}, 4))
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 3).items()}, strict=True)
+        net = net.to(d1).eval()
+        tiles = torch.from_numpy(synth.uniform((3, 3, 24, 24), 4)).to(d1)            # float32: the fp32 mode
+        cap = engine_tile_cap(net, 24, torch.float32, d1)
+        assert cap >= 1 and net._weights_device == d1 and torch.cuda.current_device() == 0
+        pick = (lambda y: y[2]) if arch == "ppon" else None
+        y = run_tile_batches(net, tiles, 2, pick=pick)
+        assert y.device == d1 and torch.isfinite(y).all()
+        ref = get_network(get_network_G_config({"type": arch, **kw}, 4))
+        ref.load_state_dict(net.state_dict(), strict=True)
+        with torch.cuda.device(d1):
+            r = ref.to(d1).eval()(tiles)
+        assert torch.equal(y, r[2] if arch == "ppon" else r)
+        with pytest.raises(NotImplementedError):                                      # one engine, one GPU: a second device is refused, not served with foreign pointers
+            net.tile_batch_bytes(1, 24, torch.float32, device=torch.device("cuda", 0))
