@@ -683,7 +683,7 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
             const long slots = 256L * co_max;
             const long rounds = (wgs + slots - 1) / slots;
             const int co = (int)std::min<long>(co_max, (wgs + 255) / 256);
-            return (double)rounds * std::max(life, (double)co * chunks * mfma);
+            return (double)rounds * std::max(life, (double)co * chunks * (mfma + 1200.0));      // (about half of a chunk's fixed cost is not hidden by the co-resident workgroup)
         };
         int b_npt = 4, b_imgs = 0, cc = 4;
         {
@@ -695,7 +695,7 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
                         if ((long)c * (px1 << imgs) > 256L * F32_NE) continue;
                         double e = 1e30;
                         for (int nktc = std::min(4, nkt16); nktc >= 1; nktc = nktc == 3 ? 2 : nktc >> 1) {
-                            if (lds_need(c, 1 << imgs, nktc, npt) > 76 * 1024 && !(c == 4 && imgs == 0)) continue;
+                            if (lds_need(c, 1 << imgs, nktc, npt) > 80 * 1024 && !(c == 4 && imgs == 0)) continue;
                             e = std::min(e, est(npt, 1 << imgs, c, nktc, 64));
                         }
                         if (e < best * 0.999) { best = e; b_npt = npt; b_imgs = imgs; cc = c; }      // (every CC: a smaller one may admit a wider NKT within the LDS)
