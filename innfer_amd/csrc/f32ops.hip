@@ -486,6 +486,68 @@ __global__ __launch_bounds__(256) void f32_norm_kernel(const float* in, long in_
     for (long i = tid; i < HW; i += 256) y[i] = f32_act(x[i] * al + sh, act) + (rr ? rr[i] : 0.f);
 }
 
+// The same with the plane held in registers (HW <= 256 VPT: every plane of the networks up to 128 x 128): ONE read of the plane instead of three.  Thread tid holds
+// elements tid, tid + 256, .. exactly as the loops above walk them, and the block reductions are the same trees: the results are the same bits as f32_norm_kernel's.
+template <int VPT>
+__global__ __launch_bounds__(256) void f32_norm_reg_kernel(const float* in, long in_ns, long in_cs, float* out, long out_ns, long out_cs, int C, int HW, int mode, float eps,
+                                                           const float* weight, const float* bias, int act, const float* res, long res_ns, long res_cs) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const float* x = in + (long)n * in_ns + (long)c * in_cs;
+    float v[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) v[j] = tid + 256 * j < HW ? x[tid + 256 * j] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) if (tid + 256 * j < HW) s += v[j];
+    red[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
+    const float mean = red[0] / (float)HW;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) if (tid + 256 * j < HW) { const float d = v[j] - mean; q += d * d; }
+    red[tid] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
+    const float var = red[0] / (float)HW;
+    const float inv = 1.0f / sqrtf(var + eps);
+    const float al = mode == 2 ? inv : inv * weight[c], sh = mode == 2 ? -mean * inv : bias[c] - mean * inv * weight[c];
+    float* y = out + (long)n * out_ns + (long)c * out_cs;
+    const float* rr = res ? res + (long)n * res_ns + (long)c * res_cs : nullptr;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+        if (tid + 256 * j < HW) y[tid + 256 * j] = f32_act(v[j] * al + sh, act) + (rr ? rr[tid + 256 * j] : 0.f);
+}
+
+// Planes of at most 64 values (the <= 8 x 8 levels): one WAVE per plane, four planes per block -- a 256-thread block with two block reductions per 1 .. 64 values was
+// 46 us per launch whatever the size (eight such launches per UNet forward).  Sums over the lanes by xor butterflies (a fixed order; not the block tree's: results
+// differ from f32_norm_kernel's in the last bits, not between a batch and its images).
+__global__ __launch_bounds__(256) void f32_norm_small_kernel(const float* in, long in_ns, long in_cs, float* out, long out_ns, long out_cs, int C, int HW, int N, int mode, float eps,
+                                                             const float* weight, const float* bias, int act, const float* res, long res_ns, long res_cs) {
+    const int lane = threadIdx.x & 63, plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= C * N) return;
+    const int n = plane / C, c = plane - n * C;
+    const float* x = in + (long)n * in_ns + (long)c * in_cs;
+    const float v = lane < HW ? x[lane] : 0.f;
+    float s = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)HW;
+    const float d = lane < HW ? v - mean : 0.f;
+    float q = d * d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float var = q / (float)HW;
+    const float inv = 1.0f / sqrtf(var + eps);
+    const float al = mode == 2 ? inv : inv * weight[c], sh = mode == 2 ? -mean * inv : bias[c] - mean * inv * weight[c];
+    if (lane < HW) {
+        const float r = res ? res[(long)n * res_ns + (long)c * res_cs + lane] : 0.f;
+        out[(long)n * out_ns + (long)c * out_cs + lane] = f32_act(v * al + sh, act) + r;
+    }
+}
+
 __global__ void f32_act_copy_kernel(const float* in, long in_ns, float* out, long out_ns, long per_image, int N, int act) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per_image * N) return;
@@ -672,6 +734,13 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
             const size_t rpi = nktc == 3 ? 1 : 4 / nktc, wb = ((size_t)L.ntap * (c / 4) + rpi - 1) / rpi * 1024;      // weight rows are 256 NKT bytes apart (four / two per DMA piece)
             return std::max(2 * (size_t)c * ps * 4 + 2 * wb, (size_t)16 * nktc * (64 * npt + 4) * 4);
         };
+#ifdef INNFER_ABLATE
+        static const double unhidden = getenv("INNFER_F32_UNHIDDEN") ? atof(getenv("INNFER_F32_UNHIDDEN")) : 0.0;      // A/B of the model's constants (diagnostic build)
+        static const size_t lds_cap = (getenv("INNFER_F32_LDSCAP") ? atoi(getenv("INNFER_F32_LDSCAP")) : 80) * 1024;
+#else
+        constexpr double unhidden = 0.0;           // (a term for the part of a chunk's fixed cost the co-resident workgroup does not hide: 1200 cycles bought the UNet 1 % and cost PAN 7.5 %, scripts/r5/f32_model_ab.sh)
+        constexpr size_t lds_cap = 80 * 1024;
+#endif
         auto est = [&](int npt, int img, int c, int nktc, int batch) -> double {
             const size_t lds = lds_need(c, img, nktc, npt);
             const int co_max = (int)std::min<size_t>(2, (160 * 1024) / lds);                    // (two waves per SIMD by registers)
@@ -683,7 +752,7 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
             const long slots = 256L * co_max;
             const long rounds = (wgs + slots - 1) / slots;
             const int co = (int)std::min<long>(co_max, (wgs + 255) / 256);
-            return (double)rounds * std::max(life, (double)co * chunks * (mfma + 1200.0));      // (about half of a chunk's fixed cost is not hidden by the co-resident workgroup)
+            return (double)rounds * std::max(life, (double)co * chunks * (mfma + unhidden));
         };
         int b_npt = 4, b_imgs = 0, cc = 4;
         {
@@ -695,7 +764,7 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
                         if ((long)c * (px1 << imgs) > 256L * F32_NE) continue;
                         double e = 1e30;
                         for (int nktc = std::min(4, nkt16); nktc >= 1; nktc = nktc == 3 ? 2 : nktc >> 1) {
-                            if (lds_need(c, 1 << imgs, nktc, npt) > 80 * 1024 && !(c == 4 && imgs == 0)) continue;
+                            if (lds_need(c, 1 << imgs, nktc, npt) > lds_cap && !(c == 4 && imgs == 0)) continue;
                             e = std::min(e, est(npt, 1 << imgs, c, nktc, 64));
                         }
                         if (e < best * 0.999) { best = e; b_npt = npt; b_imgs = imgs; cc = c; }      // (every CC: a smaller one may admit a wider NKT within the LDS)
@@ -758,7 +827,15 @@ int f32conv_launch(const F32Conv& L, hipStream_t s) {
 int f32_norm_launch(const float* in, long in_ns, long in_cs, float* out, long out_ns, long out_cs, int N, int C, long HW, int mode, float eps,
                     const float* weight, const float* bias, const float* rmean, const float* rvar, int act, hipStream_t s,
                     const float* res, long res_ns, long res_cs) {
-    hipLaunchKernelGGL(f32_norm_kernel, dim3(C, N), dim3(256), 0, s, in, in_ns, in_cs, out, out_ns, out_cs, C, HW, mode, eps, weight, bias, rmean, rvar, act, res, res_ns, res_cs);
+    if ((mode == 0 || mode == 2) && HW <= 64) {                       // statistics of tiny planes: a wave per plane
+        hipLaunchKernelGGL(f32_norm_small_kernel, dim3((unsigned)(((long)C * N + 3) / 4)), dim3(256), 0, s, in, in_ns, in_cs, out, out_ns, out_cs, C, (int)HW, N, mode, eps, weight, bias, act, res, res_ns, res_cs);
+    } else if ((mode == 0 || mode == 2) && HW <= 256 * 16) {          // the plane in registers: one read instead of three (same bits as the three-pass kernel)
+        hipLaunchKernelGGL(f32_norm_reg_kernel<16>, dim3(C, N), dim3(256), 0, s, in, in_ns, in_cs, out, out_ns, out_cs, C, (int)HW, mode, eps, weight, bias, act, res, res_ns, res_cs);
+    } else if ((mode == 0 || mode == 2) && HW <= 256 * 64) {
+        hipLaunchKernelGGL(f32_norm_reg_kernel<64>, dim3(C, N), dim3(256), 0, s, in, in_ns, in_cs, out, out_ns, out_cs, C, (int)HW, mode, eps, weight, bias, act, res, res_ns, res_cs);
+    } else {
+        hipLaunchKernelGGL(f32_norm_kernel, dim3(C, N), dim3(256), 0, s, in, in_ns, in_cs, out, out_ns, out_cs, C, HW, mode, eps, weight, bias, rmean, rvar, act, res, res_ns, res_cs);
+    }
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;
 }
