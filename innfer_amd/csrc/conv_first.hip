@@ -93,10 +93,19 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
 // conv_pack): one or two 16-byte stores per output slab.  fp32 weights and fp32 input are split into an fp16 head and an fp16 remainder
 // (w = wh + wl, x = xh + xl; wh*xh + wl*xh + wh*xl with fp32 accumulation), so the result keeps the fp32 VALU kernel's accuracy (product
 // terms below 2^-22 relative dropped) although the MFMA operands are fp16.  Bound by its two 128 B/pixel stores, as it should be.
-template <int NT, int STEPS>                                        // STEPS = ceil(9 Cin / 32): 1 for gray / RGB, 2 for 4..7 channels, 3 for 8
+// (round 5: the walk.  The first form strode over 16-pixel groups of the flattened pixel index: two 64-bit divisions and eight bounds-tested, index-rebuilt
+//  loads per lane and group -- ~500 VALU instructions for 8 MFMAs: 0.26 ms for a 1080p frame whose stores need 0.07-0.14.  Now a workgroup owns 64 columns x
+//  FIRST_ROWS rows of one image, wave w its 16-column strip: a lane's eight patch offsets and column validity are fixed for the strip, a row costs eight loads
+//  at base + offset, and the weight fragments are built once per FIRST_ROWS groups.  Same operands, same MFMA order: the same bits.)
+constexpr int FIRST_ROWS = 8;
+template <int NT, int STEPS, bool FAST16>                           // STEPS = ceil(9 Cin / 32): 1 for gray / RGB, 2 for 4..7 channels, 3 for 8; FAST16: planar fp16 input
 __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const int nk = p.Cin * 9;
+    const int x = blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + li;    // this lane's column
+    const int y0 = blockIdx.y * FIRST_ROWS, y1 = min(y0 + FIRST_ROWS, p.H);
+    const long n = blockIdx.z;
+    if (blockIdx.x * 64 + (int)(threadIdx.x >> 6) * 16 >= p.W) return;      // (a strip beyond the image: whole waves)
     // weight fragments, once per wave: row li of sub-tile t is output channel 4 NT (li >> 2) + 4 t + (li & 3); k octet lg of every step
     f16x8 wh[STEPS][NT], wl[STEPS][NT];
 #pragma unroll
@@ -118,33 +127,53 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias[t] = *(const f32x4*)(p.bias + cb + 4 * t);
     const long hw = (long)p.H * p.W;
-    const long ngroups = (p.npix + 15) >> 4;
-    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
-    for (long g = wave_id; g < ngroups; g += nwaves) {
-        const long pix = g * 16 + li;
-        const bool live = pix < p.npix;
-        const long n = live ? pix / hw : 0;
-        const long rem = live ? pix - n * hw : 0;
-        const int y = (int)(rem / p.W), x = (int)(rem - (long)y * p.W);
+    const bool live = x < p.W;
+    // the lane's patch elements: (channel, row offset, column) of k = 32 st + 8 lg + e; column validity never changes along the strip, row validity only on the
+    // image's first and last row (bit masks, wave-uniform tests)
+    int eoff[STEPS][8];                                              // FAST16: element offset from (row y, channel 0, column 0); else (channel << 20 | column + 1) -- W < 2^20 (launch)
+    unsigned xok = 0, top = 0, bot = 0;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = st * 32 + lg * 8 + e;
+            const int ci = kk / 9, tap = kk - ci * 9, r = tap / 3, sx = tap - r * 3, X = x + sx - 1;
+            eoff[st][e] = FAST16 ? (int)(ci * hw) + (r - 1) * p.W + X : (ci << 20) | (X + 1);
+            if (live && kk < nk && X >= 0 && X < p.W) xok |= 1u << (st * 8 + e);
+            if (r == 0) top |= 1u << (st * 8 + e);
+            if (r == 2) bot |= 1u << (st * 8 + e);
+        }
+    const bool any_lo = !FAST16 && (p.in_f32 != 0 || (p.in_u8 && !p.in_round16));
+    [[maybe_unused]] const f16* in16 = (const f16*)p.in + n * p.Cin * hw;
+    for (int y = y0; y < y1; ++y) {
+        const unsigned ok = xok & (y == 0 ? ~top : ~0u) & (y == p.H - 1 ? ~bot : ~0u);
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = bias[t];
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {             // compile-time index into the fragment arrays (a runtime one would send them to scratch)
             f16x8 xh, xl;
-            bool any_lo = false;
+            if constexpr (FAST16) {                      // the values are the hi operands as they lie in memory, no lo part
+                const f16* row = in16 + (long)y * p.W;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int kk = st * 32 + lg * 8 + e;
-                const int ci = kk / 9, tap = kk - ci * 9, r = tap / 3, s = tap - r * 3;
-                const int Y = y + r - 1, X = x + s - 1;
-                float v = 0.f;
-                if (live && kk < nk && Y >= 0 && Y < p.H && X >= 0 && X < p.W) v = first_conv_input(p, n, ci, Y, X, hw);
-                const f16 h = (f16)v;
-                xh[e] = h;
-                xl[e] = (f16)(v - (float)h);
+                for (int e = 0; e < 8; ++e) {
+                    const bool o = (ok >> (st * 8 + e)) & 1;
+                    const f16 v = row[o ? eoff[st][e] : 0];           // (an element outside the image reads the row's own first value, then zero)
+                    xh[e] = o ? v : (f16)0.f;
+                    xl[e] = (f16)0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = st * 32 + lg * 8 + e;
+                    const int r = (kk - (kk / 9) * 9) / 3;
+                    float v = 0.f;
+                    if ((ok >> (st * 8 + e)) & 1) v = first_conv_input(p, n, eoff[st][e] >> 20, y + r - 1, (eoff[st][e] & 0xfffff) - 1, hw);
+                    const f16 h = (f16)v;
+                    xh[e] = h;
+                    xl[e] = (f16)(v - (float)h);
+                }
             }
-            any_lo = p.in_f32 != 0 || (p.in_u8 && !p.in_round16);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st][t], xh, acc[t], 0, 0, 0);
@@ -153,6 +182,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
             }
         }
         if (!live) continue;
+        const long pix = n * hw + (long)y * p.W + x;
         f16 h[4 * NT], l[4 * NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -192,10 +222,13 @@ int first_conv_launch(const FirstConvLaunch& L, hipStream_t s) {
     FP p{L.in, L.in_f32, L.Cin, L.in_u8, L.in_norm, L.in_round16, L.w, L.bias, L.out, L.out_gstride, L.out2, L.out2_gstride,
          L.K, (long)L.N * L.H * L.W, L.H, L.W, L.act, L.out_lo, L.out2_lo};
     if ((L.K == 32 || L.K == 64) && INNFER_KNOB("INNFER_FIRST_MFMA", 1)) {
-        const long groups = (p.npix + 15) / 16, want = (groups + 3) / 4;
-        const long grid = want < 8192 ? want : 8192;                 // 32 waves' worth of pixel groups per CU in flight, the rest by striding
+        if (L.N > 65535 || (L.H + FIRST_ROWS - 1) / FIRST_ROWS > 65535) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: %d images of %d rows exceed the launch grid", L.N, L.H);
+        const dim3 grid((unsigned)((L.W + 63) / 64), (unsigned)((L.H + FIRST_ROWS - 1) / FIRST_ROWS), (unsigned)L.N);
         const int steps = (L.Cin * 9 + 31) / 32;
-#define FC(NT_, ST_) hipLaunchKernelGGL((first_conv_mfma<NT_, ST_>), dim3((unsigned)grid), dim3(256), 0, s, p)
+        const bool fast16 = !L.in_u8 && !L.in_f32 && (long)L.Cin * L.H * L.W < 0x7fffffffL;
+        if (L.W >= (1 << 20) - 1) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: %d columns", L.W);
+#define FC(NT_, ST_) do { if (fast16) hipLaunchKernelGGL((first_conv_mfma<NT_, ST_, true>), grid, dim3(256), 0, s, p); \
+                          else hipLaunchKernelGGL((first_conv_mfma<NT_, ST_, false>), grid, dim3(256), 0, s, p); } while (0)
         if (L.K == 64) { if (steps == 1) FC(4, 1); else if (steps == 2) FC(4, 2); else FC(4, 3); }
         else { if (steps == 1) FC(2, 1); else if (steps == 2) FC(2, 2); else FC(2, 3); }
 #undef FC
