@@ -173,19 +173,22 @@ static int launch_post_slab_parts(const f16* src, long sg, int C, long HW, int N
 //  and a post launch over its fp32 rows: unet_deep_post<8>; the <= 64-pixel levels keep the two-pixel form)
 constexpr int DEEP_PX = 256;
 // ev_alpha / ev_shift != nullptr: eval-mode BatchNorm (the per-channel transform of the running statistics) instead of this image's.
-template <int NPX>
-__global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long split_elems, int ks, int cpad, int C, int HW, float eps,
+// (round 5: PL pixel lanes -- 32, or 16 / 4 / 1 for the levels of at most 16 / 4 / 1 pixels: a 1024-thread workgroup per 32 channels of a 1 x 1 level kept 31 of its 32
+//  pixel lanes idle and still paid its two 32-way reductions: 12.7 us a launch whatever the level.  One pixel per lane in the same lane order: the same sums, the same bits)
+template <int NPX, int PL = 32>
+__global__ __launch_bounds__(32 * PL) void unet_deep_post(const float* part, long split_elems, int ks, int cpad, int C, int HW, float eps,
                                                        const float* gamma, const float* beta, const float* ev_alpha, const float* ev_shift,
                                                        PostDst d0, PostDst d1) {
-    __shared__ float red[1024];
+    __shared__ float red[32 * PL];
     const int n = blockIdx.y, cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     auto reduce32 = [&](float v) {
+        if constexpr (PL == 1) return 0.f + v;                      // (t = 0 + red[cl], as the loop below would)
         red[threadIdx.x] = v;
         __syncthreads();
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) t += red[cl + 32 * i];
+        for (int i = 0; i < PL; ++i) t += red[cl + 32 * i];        // (lanes beyond PL held pixels >= HW: zeros)
         __syncthreads();
         return t;
     };
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long s
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
-        const int px = pl + 32 * i;
+        const int px = pl + PL * i;
         float a = 0.f;
         if (px < HW && c < C) {
             const float* q = part + ((long)n * HW + px) * cpad + c;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long s
         const float mu = reduce32(sum) / (float)HW;
         float m2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NPX; ++i) { const float d = pl + 32 * i < HW ? v[i] - mu : 0.f; m2 += d * d; }
+        for (int i = 0; i < NPX; ++i) { const float d = pl + PL * i < HW ? v[i] - mu : 0.f; m2 += d * d; }
         const float var = reduce32(m2) / (float)HW;
         if (c < C) { al = (1.0f / sqrtf(var + eps)) * gamma[c]; sh = beta[c] - mu * al; }
     }
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(1024) void unet_deep_post(const float* part, long s
     const PostDst ds[2] = {d0, d1};
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
-        const int px = pl + 32 * i;
+        const int px = pl + PL * i;
         if (px >= HW) continue;
         const float y = (gamma || ev_alpha) ? v[i] * al + sh : v[i];
 #pragma unroll
@@ -999,7 +1002,13 @@ extern "C" int innfer_unet_forward(innfer_unet* u, const void* d_in, int in_dtyp
         const bool nb = !bn && !l.transposed && l.d_bias && l.d_ones;
         if (HW <= DEEP_PX) {          // deep level: reduce + statistics + post in one launch
             GtScope gt(s, "unet_deep_post (split-K reduce + BatchNorm + views)", 0.0, (double)N * HW * l.cout_pad * 4.0 * ks_last + (double)N * HW * l.cout * 2.0 * ((d0.p ? 1 : 0) + (d1.p ? 1 : 0)));
-            if (HW <= 64)
+#define INNFER_DEEP_POST(NPX_, PL_) hipLaunchKernelGGL((unet_deep_post<NPX_, PL_>), dim3((l.cout + 31) / 32, N), dim3(32 * PL_), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw, \
+                                   (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn && !ev ? l.d_gamma : nullptr, bn && !ev ? l.d_beta : nullptr, \
+                                   bn && ev ? l.d_ev_alpha : (nb ? l.d_ones : nullptr), bn && ev ? l.d_ev_shift : (nb ? l.d_bias : nullptr), d0, d1)
+            if (HW == 1) INNFER_DEEP_POST(1, 1);
+            else if (HW <= 4) INNFER_DEEP_POST(1, 4);
+            else if (HW <= 16) INNFER_DEEP_POST(1, 16);
+            else if (HW <= 64)
                 hipLaunchKernelGGL(unet_deep_post<2>, dim3((l.cout + 31) / 32, N), dim3(1024), 0, s, ks_last > 1 ? (const float*)splitk : (const float*)raw,
                                    (long)N * HW * l.cout_pad, ks_last, l.cout_pad, l.cout, (int)HW, 1e-5f, bn && !ev ? l.d_gamma : nullptr, bn && !ev ? l.d_beta : nullptr,
                                    bn && ev ? l.d_ev_alpha : (nb ? l.d_ones : nullptr), bn && ev ? l.d_ev_shift : (nb ? l.d_bias : nullptr), d0, d1);
