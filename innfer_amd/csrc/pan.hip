@@ -397,6 +397,80 @@ __global__ void pan_fsa_combine(const float* att, int hp, int wp, int C, const f
     *(f16x8*)(dst + so) = h;
 }
 
+// The same for W == 4 wp (the 4 x 4 max-pool of a width that is a multiple of 4): the four pixels X = 4 k + 2 .. 4 k + 5 read the SAME four att columns k - 1 .. k + 2
+// (rx = X / 4 - 0.375: floor k for all four), so one thread takes the strip -- 32 cached 16-byte loads per four pixels instead of per pixel (the one-pixel form
+// moved 2 GB through L1 / L2 for a 540 x 960 map: 77 us).  Per value the same products and sums in the same order as pan_fsa_combine.
+__global__ __launch_bounds__(256) void pan_fsa_combine_x4(const float* att, int hp, int wp, int C, const f16* inp, long g, int N, int H, int W, const float* gamma, f16* dst) {
+    const int c8 = ((C + 31) / 32 * 32) >> 3, ns = wp + 1;          // strips k = -1 .. wp - 1 of a row
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * H * ns * c8) return;
+    const long r = t / c8;
+    const int c0 = (int)(t - r * c8) * 8;
+    const int k = (int)(r % ns) - 1, Y = (int)((r / ns) % H);
+    const long n = r / ((long)ns * H);
+    const int X0 = 4 * k + 2;
+    const long row_i = (n * H + Y) * (long)W;
+    if (c0 >= C) {                                   // pad channels of the last group: zeros (the up conv reads whole groups)
+        f16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (f16)0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (X0 + j >= 0 && X0 + j < W) *(f16x8*)(dst + (c0 >> 5) * g + (row_i + X0 + j) * 32 + (c0 & 31)) = z;
+        return;
+    }
+    const float A = -0.75f;
+    const float sy = (float)hp / (float)H, sx = (float)wp / (float)W;
+    const float ry = sy * ((float)Y + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry);
+    const float ty = ry - (float)iy;
+    const float wy[4] = {cc2(ty + 1.f, A), cc1(ty, A), cc1(1.f - ty, A), cc2(2.f - ty, A)};
+    float wx[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float rx = sx * ((float)(X0 + j) + 0.5f) - 0.5f;
+        const float tx = rx - (float)k;              // floor(rx) == k for the strip's four pixels
+        wx[j][0] = cc2(tx + 1.f, A); wx[j][1] = cc1(tx, A); wx[j][2] = cc1(1.f - tx, A); wx[j][3] = cc2(2.f - tx, A);
+    }
+    const float gm = gamma[0];
+    const float* an = att + n * (long)hp * wp * C + c0;
+    float v[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), hp - 1);
+        f32x4 q0[4], q1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xx = min(max(k - 1 + b, 0), wp - 1);
+            const float* q = an + ((long)yy * wp + xx) * C;
+            q0[b] = *(const f32x4*)q; q1[b] = *(const f32x4*)(q + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { row[e] += q0[b][e] * wx[j][b]; row[4 + e] += q1[b][e] * wx[j][b]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] += row[e] * wy[a];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (X0 + j < 0 || X0 + j >= W) continue;
+        const long so = (c0 >> 5) * g + (row_i + X0 + j) * 32 + (c0 & 31);
+        const f16x8 in8 = *(const f16x8*)(inp + so);
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (f16)(gm * v[j][e] + (float)in8[e]);
+        *(f16x8*)(dst + so) = h;
+    }
+}
+
 // F.interpolate(t, scale_factor=f, mode) on a blocked slab, f = 2 | 3.  bilinear (align_corners=False, ATen upsample_bilinear2d): source index
 // max(0, (dst + 0.5) / f - 0.5), the second tap clamped to the last pixel, fp32 arithmetic in ATen's association; nearest: source dst / f.
 // One thread per (output pixel, 8 channels) of `groups` 32-channel groups.
@@ -1104,6 +1178,10 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
                                vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), hp * wp, (float*)(ws + cv.att));
             INNFER_HIP(hipGetLastError()); }
         {   GtScope gt(s, "pan_fsa_combine (bicubic + gamma * out + in)", 0.0, (double)px * nf * 4.0 + (double)np * nf * 4.0);
+            if (W == 4 * wp)
+                hipLaunchKernelGGL(pan_fsa_combine_x4, dim3((unsigned)(((long)N * H * (wp + 1) * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
+                                   INP, G, N, H, W, vec("FSA.gamma"), T);
+            else
             hipLaunchKernelGGL(pan_fsa_combine, dim3((unsigned)((px * ((nf + 31) / 32 * 4) + 255) / 256)), dim3(256), 0, s, (const float*)(ws + cv.att), hp, wp, nf,
                                INP, G, N, H, W, vec("FSA.gamma"), T);
             INNFER_HIP(hipGetLastError()); }
@@ -1137,6 +1215,8 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         CK(conv3(PA, HG, hh, ww, 0, p->n_up == 1 ? 1 : 0, nullptr, 0, HRC, HG));
         cur = HRC; cur_g = HG; h = hh; w = ww;
     }
+    // (round 5: the bilinear skip as conv_last's own store was built and measured -- 168 + 72 us -> 585 us at 540 x 960: the 16 lanes that hold the three planar channels
+    //  gather 72 values per tile on the consumer waves' critical path; reverted, profiles/r5/pan_tail.txt)
     CK(conv3(cur, cur_g, h, w, 0, 0, nullptr, 0, nullptr, 0, raw));                    // conv_last -> planar fp32 (+ bias)
     {
         const long fpx = (long)N * h * w;
