@@ -7,6 +7,7 @@
 // 8 consecutive output channels and writes one 16-byte piece, so a wave writes
 // whole contiguous pixels.  Weights live in LDS as fp32 [Cin*9][K].
 #include "common.h"
+#include <type_traits>
 
 namespace innfer {
 namespace {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
 //  loads per lane and group -- ~500 VALU instructions for 8 MFMAs: 0.26 ms for a 1080p frame whose stores need 0.07-0.14.  Now a workgroup owns 64 columns x
 //  FIRST_ROWS rows of one image, wave w its 16-column strip: a lane's eight patch offsets and column validity are fixed for the strip, a row costs eight loads
 //  at base + offset, and the weight fragments are built once per FIRST_ROWS groups.  Same operands, same MFMA order: the same bits.)
-constexpr int FIRST_ROWS = 8;
+constexpr int FIRST_ROWS = 16;
 template <int NT, int STEPS, bool FAST16>                           // STEPS = ceil(9 Cin / 32): 1 for gray / RGB, 2 for 4..7 channels, 3 for 8; FAST16: planar fp16 input
 __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
@@ -106,26 +107,28 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
     const int y0 = blockIdx.y * FIRST_ROWS, y1 = min(y0 + FIRST_ROWS, p.H);
     const long n = blockIdx.z;
     if (blockIdx.x * 64 + (int)(threadIdx.x >> 6) * 16 >= p.W) return;      // (a strip beyond the image: whole waves)
-    // weight fragments, once per wave: row li of sub-tile t is output channel 4 NT (li >> 2) + 4 t + (li & 3); k octet lg of every step
+    // weight fragments, once per wave: row li of sub-tile t is output channel 32 (t >> 1) + 8 (li >> 2) + 4 (t & 1) + (li & 3) (the plane row order of conv3x3.hip's
+    // 64-channel kernels): lane group lg ends with channels 8 lg .. 8 lg + 7 of EACH 32-channel slab plane of its pixel, so the four groups of a pixel column write its whole
+    // 64-byte line of a plane and a store instruction covers 16 pixels x 64 bytes of ONE plane (round 5, with the row walk: the stores are what is left of this kernel)
     f16x8 wh[STEPS][NT], wl[STEPS][NT];
 #pragma unroll
     for (int st = 0; st < STEPS; ++st)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int oc = 4 * NT * (li >> 2) + 4 * t + (li & 3);
+            const int oc = 32 * (t >> 1) + 8 * (li >> 2) + 4 * (t & 1) + (li & 3);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int kk = st * 32 + lg * 8 + e;
-                const float w = kk < nk ? p.w[(long)kk * p.K + oc] : 0.f;
+                const float wv = p.w[(long)min(kk, nk - 1) * p.K + oc];          // (unconditional load, then the select: a predicated load is a branch each -- 64 of them per wave)
+                const float w = kk < nk ? wv : 0.f;
                 const f16 h = (f16)w;
                 wh[st][t][e] = h;
                 wl[st][t][e] = (f16)(w - (float)h);
             }
         }
-    const int cb = 4 * NT * lg;                                      // this lane's first output channel
     f32x4 bias[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bias[t] = *(const f32x4*)(p.bias + cb + 4 * t);
+    for (int t = 0; t < NT; ++t) bias[t] = *(const f32x4*)(p.bias + 32 * (t >> 1) + 8 * lg + 4 * (t & 1));
     const long hw = (long)p.H * p.W;
     const bool live = x < p.W;
     // the lane's patch elements: (channel, row offset, column) of k = 32 st + 8 lg + e; column validity never changes along the strip, row validity only on the
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
         }
     const bool any_lo = !FAST16 && (p.in_f32 != 0 || (p.in_u8 && !p.in_round16));
     [[maybe_unused]] const f16* in16 = (const f16*)p.in + n * p.Cin * hw;
-    for (int y = y0; y < y1; ++y) {
+    // One row of the strip: (FAST16) `raw` holds the row's 8 STEPS patch values as loaded -- requested one row ahead, first touched here.
+    auto process = [&](int y, const unsigned (&raw)[STEPS][8]) __attribute__((always_inline)) {
         const unsigned ok = xok & (y == 0 ? ~top : ~0u) & (y == p.H - 1 ? ~bot : ~0u);
         f32x4 acc[NT];
 #pragma unroll
@@ -154,12 +158,10 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
         for (int st = 0; st < STEPS; ++st) {             // compile-time index into the fragment arrays (a runtime one would send them to scratch)
             f16x8 xh, xl;
             if constexpr (FAST16) {                      // the values are the hi operands as they lie in memory, no lo part
-                const f16* row = in16 + (long)y * p.W;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const bool o = (ok >> (st * 8 + e)) & 1;
-                    const f16 v = row[o ? eoff[st][e] : 0];           // (an element outside the image reads the row's own first value, then zero)
-                    xh[e] = o ? v : (f16)0.f;
+                    xh[e] = o ? __builtin_bit_cast(f16, (unsigned short)raw[st][e]) : (f16)0.f;
                     xl[e] = (f16)0.f;
                 }
             } else {
@@ -181,35 +183,64 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
                 if (any_lo) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st][t], xl, acc[t], 0, 0, 0);
             }
         }
-        if (!live) continue;
+        if (!live) return;
         const long pix = n * hw + (long)y * p.W + x;
         f16 h[4 * NT], l[4 * NT];
+        // (the activation chosen ONCE per row: a uniform test per value is a branch per value in this unrolled code -- 16 of them, with the accumulators copied around each)
+        auto finish = [&](auto act_tag) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float f = acc[t][j];
-                if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
-                else if (p.act == 2) f = f > 0.f ? f : 0.f;
-                h[4 * t + j] = (f16)f;
-                l[4 * t + j] = (f16)((f - (float)h[4 * t + j]) * 2048.0f);
-            }
-        const long o1 = (cb >> 5) * p.out_gstride + pix * 32 + (cb & 31);
-        const long o2 = (cb >> 5) * p.out2_gstride + pix * 32 + (cb & 31);
+                for (int j = 0; j < 4; ++j) {
+                    float f = acc[t][j];
+                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    h[4 * t + j] = (f16)f;
+                    l[4 * t + j] = (f16)((f - (float)h[4 * t + j]) * 2048.0f);
+                }
+        };
+        if (p.act == 1) finish(std::integral_constant<int, 1>{}); else if (p.act == 2) finish(std::integral_constant<int, 2>{}); else finish(std::integral_constant<int, 0>{});
+        const long o = pix * 32 + 8 * lg;
 #pragma unroll
-        for (int q = 0; q < NT / 2; ++q) {
+        for (int q = 0; q < NT / 2; ++q) {                            // plane q: tiles 2 q, 2 q + 1
             f16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = h[8 * q + e];
-            *(f16x8*)(p.out + o1 + 8 * q) = v;
-            if (p.out2) *(f16x8*)(p.out2 + o2 + 8 * q) = v;
+            *(f16x8*)(p.out + q * p.out_gstride + o) = v;
+            if (p.out2) *(f16x8*)(p.out2 + q * p.out2_gstride + o) = v;
             if (p.out_lo) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = l[8 * q + e];
-                *(f16x8*)(p.out + p.out_lo + o1 + 8 * q) = v;
-                if (p.out2) *(f16x8*)(p.out2 + p.out2_lo + o2 + 8 * q) = v;
+                *(f16x8*)(p.out + p.out_lo + q * p.out_gstride + o) = v;
+                if (p.out2) *(f16x8*)(p.out2 + p.out2_lo + q * p.out2_gstride + o) = v;
             }
         }
+    };
+    if constexpr (FAST16) {
+        // unconditional loads from a clamped offset (an element outside the image reads the row's own first value, zeroed when it is used): independent, all in flight
+        // together, and the NEXT row's are requested before this row is multiplied and stored (two register sets used alternately, as in unet_first_mfma)
+        auto request = [&](int y, unsigned (&raw)[STEPS][8]) __attribute__((always_inline)) {
+            const unsigned ok = xok & (y == 0 ? ~top : ~0u) & (y == p.H - 1 ? ~bot : ~0u);
+            const unsigned short* row = (const unsigned short*)in16 + (long)y * p.W;
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) raw[st][e] = row[((ok >> (st * 8 + e)) & 1) ? eoff[st][e] : 0];
+        };
+        unsigned rawA[STEPS][8], rawB[STEPS][8];
+        request(y0, rawA);
+        int y = y0;
+        for (; y + 1 < y1; y += 2) {
+            request(y + 1, rawB);
+            process(y, rawA);
+            if (y + 2 < y1) request(y + 2, rawA);
+            process(y + 1, rawB);
+        }
+        if (y < y1) process(y, rawA);
+    } else {
+        unsigned none[STEPS][8] = {};
+        for (int y = y0; y < y1; ++y) process(y, none);
     }
 }
 

@@ -7,7 +7,7 @@ from innfer_amd import synth
 from innfer_amd.architectures import get_network
 from innfer_amd.utils.defaults import get_network_G_config
 CASES = {"pan": (4, (1, 3, 540, 960), (0, 1), False), "p2p_256": (1, (64, 3, 256, 256), (-1, 1), True), "ppon": (4, (8, 3, 200, 200), (0, 1), False),
-         "resnet_9blocks": (1, (16, 3, 256, 256), (-1, 1), False), "wbcunet": (1, (1, 3, 1080, 1920), (-1, 1), False), "srgan": (4, (1, 3, 1080, 1920), (0, 1), False)}
+         "resnet_9blocks": (1, (16, 3, 256, 256), (-1, 1), False), "wbcunet": (1, (1, 3, 1080, 1920), (-1, 1), False), "srgan": (4, (1, 3, 1080, 1920), (0, 1), False), "esrgan": (4, (1, 3, 1080, 1920), (0, 1), False)}
 arch = sys.argv[1] if len(sys.argv) > 1 else "p2p_256"
 half = len(sys.argv) > 2 and sys.argv[2] == "fp16"
 scale, shape, rng, train = CASES[arch]
