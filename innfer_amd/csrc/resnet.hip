@@ -186,9 +186,16 @@ __global__ __launch_bounds__(256) void rn_post_slab_parts(const f16* src, int C,
         const int cl = t & 31, lg = t >> 5, c = cb + cl;
         float cnt = 0.f, mu = 0.f, m2 = 0.f;
         if (c < C)
-            for (int r = lg; r < nper; r += 8) {
-                const float* q = part + (((long)n * nper + r) * C + c) * 3;
-                norm::chan_merge(cnt, mu, m2, q[0], q[1], q[2]);
+            for (int r = lg; r < nper; r += 32) {          // four records per trip, their loads issued together (as unet_post_slab_parts, round 5): same merge order, same bits
+                float rec[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = r + 8 * j;
+                    const float* q = part + (((long)n * nper + min(rr, nper - 1)) * C + c) * 3;
+                    rec[j][0] = rr < nper ? q[0] : 0.f; rec[j][1] = q[1]; rec[j][2] = q[2];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) norm::chan_merge(cnt, mu, m2, rec[j][0], rec[j][1], rec[j][2]);      // (count 0: no-op)
             }
         sn[lg][cl] = cnt; sm[lg][cl] = mu; sq[lg][cl] = m2;
         __syncthreads();

@@ -104,9 +104,18 @@ __global__ __launch_bounds__(256) void unet_post_slab_parts(const f16* src, long
     {
         const int cl = t & 31, lg = t >> 5, c = cb + cl;
         float cnt = 0.f, mu = 0.f, m2 = 0.f;
-        for (int r = lg; r < nper; r += 8) {
-            const float* q = part + (((long)n * nper + r) * C + c) * 3;
-            norm::chan_merge(cnt, mu, m2, q[0], q[1], q[2]);
+        // (four records per trip, their loads issued together: one record per trip was one exposed load latency per record -- 32 trips for the 256 records of the
+        //  128 x 128 level, repeated by each of its 16 pixel blocks: that launch ran at 3.2 TB/s against 4.6 for its siblings.  Same merge order: same bits.)
+        for (int r = lg; r < nper; r += 32) {
+            float rec[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = r + 8 * j;
+                const float* q = part + (((long)n * nper + min(rr, nper - 1)) * C + c) * 3;
+                rec[j][0] = rr < nper ? q[0] : 0.f; rec[j][1] = q[1]; rec[j][2] = q[2];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) norm::chan_merge(cnt, mu, m2, rec[j][0], rec[j][1], rec[j][2]);      // (count 0: no-op)
         }
         sn[lg][cl] = cnt; sm[lg][cl] = mu; sq[lg][cl] = m2;
         __syncthreads();
@@ -157,7 +166,8 @@ __global__ __launch_bounds__(256) void unet_post_slab_parts(const f16* src, long
 }
 static int launch_post_slab_parts(const f16* src, long sg, int C, long HW, int N, const float* part, int nper, const float* gamma, const float* beta,
                                   PostDst d, PostDst d1, hipStream_t s) {
-    const int pxb = ((HW + 1023) / 1024) * (C / 32) * N >= 256 ? 1024 : 256;
+    // (4096 pixels per workgroup where that still leaves >= 4 workgroups per CU: the statistics merge in front is repeated by every pixel block of an image)
+    const int pxb = ((HW + 4095) / 4096) * (C / 32) * N >= 1024 ? 4096 : ((HW + 1023) / 1024) * (C / 32) * N >= 256 ? 1024 : 256;
     GtScope gt(s, "unet_post_slab_parts (BatchNorm + views from the fp16 slab)", 0.0, (double)N * HW * C * 2.0 * (1 + (d.p ? 1 : 0) + (d1.p ? 1 : 0)));
     hipLaunchKernelGGL(unet_post_slab_parts, dim3((unsigned)((HW + pxb - 1) / pxb), C / 32, N), dim3(256), 0, s, src, sg, C, HW, part, nper, 1e-5f,
                        gamma, beta, d, d1, pxb);
