@@ -89,7 +89,7 @@ __device__ __forceinline__ void self_gate(f32x4 (&acc)[2][MT], const f16x8* sgw,
         for (int t = 0; t < 2; ++t) {
             const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_f16(sgw[t], vb, sgb[t], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][m][j] = (float)vb[4 * t + j] * __frcp_rn(1.0f + __expf(-g[j]));
+            for (int j = 0; j < 4; ++j) acc[t][m][j] = (float)vb[4 * t + j] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[j]));
         }
     }
 }

@@ -301,8 +301,8 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                     for (int e = 0; e < 4; ++e) {
                         // sigmoid on the hardware exponential and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each): the libm forms are ~50 VALU instructions per
                         // value, 21 k values per tile -- a third of the first version's tile time; the result is rounded to fp16 two lines below
-                        v[e] = (f16)(inside ? c[k][0][e] * __frcp_rn(1.0f + __expf(-g[k][0][e])) : 0.f);
-                        v[4 + e] = (f16)(inside ? c[k][1][e] * __frcp_rn(1.0f + __expf(-g[k][1][e])) : 0.f);
+                        v[e] = (f16)(inside ? c[k][0][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][0][e])) : 0.f);
+                        v[4 + e] = (f16)(inside ? c[k][1][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][1][e])) : 0.f);
                     }
                     if (lg < 3 && P < NPX) *(f16x8*)(smem + AOFF + P * 48 + lg * 16) = v;
                 }
