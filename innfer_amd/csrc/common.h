@@ -21,6 +21,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 int set_error(int code, const char* fmt, ...);
 
+// Activations of the fp16 engines' epilogues on the hardware exponential / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): tanhf / expf / the IEEE division are 30 .. 50
+// instructions per value, these 4 .. 6 -- the results are rounded to fp16 (or are a final fp32 image within the engines' 1e-2 bounds).  The fp32 mode (f32ops.hip) keeps libm.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }      // (+-inf -> +-1; absolute error ~1e-7)
+
 // Generic launch timer (innfer_timer_start / innfer_timer_stop, net.hip): while a collection is open on the calling thread every instrumented launch is
 // bracketed by a HIP-event pair on its stream and recorded with a kernel-family name and its ALGORITHMIC flops / bytes.  Off: two thread-local loads.
 bool gt_on();

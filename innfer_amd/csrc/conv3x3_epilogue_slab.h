@@ -74,7 +74,7 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float f = acc[t][m][j];
-                if (ACT == 7) f = f * (1.0f / (1.0f + expf(-acc[t + NT / 2][m][j])));
+                if (ACT == 7) f = f * fast_sigmoid(acc[t + NT / 2][m][j]);
                 else if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
                 else if (ACT == 2) f = f > 0.f ? f : 0.f;
                 if (SC1) { f = f * p.s1; FP32_VALUE(f); }
@@ -188,9 +188,9 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
             for (int j = 0; j < 4; ++j) {
                 float f = acc[t][m][j];
                 if (ACT == 7) {
-                    f = f * (1.0f / (1.0f + expf(-acc[t + NT / 2][m][j])));
+                    f = f * fast_sigmoid(acc[t + NT / 2][m][j]);
                 } else if (ACT >= 4) {           // pixel-attention gate (PAN): res1 * sigmoid(conv), ACT 4: LeakyReLU(0.2) after it
-                    f = (float)r1[R1 ? m : 0][t][j] * (1.0f / (1.0f + expf(-f)));
+                    f = (float)r1[R1 ? m : 0][t][j] * (fast_sigmoid(f));
                     if (ACT == 4) f = fmaxf(f, 0.2f * f);
                 } else {
                     if (ACT == 1) f = f > 0.f ? f : 0.2f * f;

@@ -36,11 +36,11 @@ __device__ __forceinline__ void epilogue_planar(const KP& p, f32x4 (&acc)[NT][2 
                     float f = acc[0][m][j];
                     if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
                     else if (p.act == 2) f = f > 0.f ? f : 0.f;
-                    else if (p.act == 3) f = tanhf(f);
-                    else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
-                    if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
-                    else if (p.outm == 2) f = tanhf(f);
-                    else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
+                    else if (p.act == 3) f = fast_tanh(f);
+                    else if (p.act == 6) f = fast_sigmoid(f);
+                    if (p.outm == 1) f = (fast_tanh(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
+                    else if (p.outm == 2) f = fast_tanh(f);
+                    else if (p.outm == 3) f = fast_sigmoid(f);
                     else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
                     if (p.out_f32) ((float*)p.out)[o + j * plane] = f;
                     else ((f16*)p.out)[o + j * plane] = (f16)f;
@@ -91,7 +91,7 @@ __device__ __forceinline__ void epilogue_planar(const KP& p, f32x4 (&acc)[NT][2 
                 for (int j = 0; j < 4; ++j) {
                     if (!live[j]) continue;
                     float f = acc[0][m][j];
-                    if (p.act == 3) f = tanhf(f);
+                    if (p.act == 3) f = fast_tanh(f);
                     if (p.out_f32) ((float*)p.out)[obase[j] + opix] = f;
                     else ((f16*)p.out)[obase[j] + opix] = (f16)f;
                 }
@@ -112,11 +112,11 @@ __device__ __forceinline__ void epilogue_planar(const KP& p, f32x4 (&acc)[NT][2 
                 float f = acc[t][m][j];
                 if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
                 else if (p.act == 2) f = f > 0.f ? f : 0.f;
-                else if (p.act == 3) f = tanhf(f);
-                else if (p.act == 6) f = 1.0f / (1.0f + expf(-f));
-                if (p.outm == 1) f = (tanhf(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
-                else if (p.outm == 2) f = tanhf(f);
-                else if (p.outm == 3) f = 1.0f / (1.0f + expf(-f));
+                else if (p.act == 3) f = fast_tanh(f);
+                else if (p.act == 6) f = fast_sigmoid(f);
+                if (p.outm == 1) f = (fast_tanh(f) + 1.0f) / 2.0f;                     // RRDBNet_arch.py:53-60
+                else if (p.outm == 2) f = fast_tanh(f);
+                else if (p.outm == 3) f = fast_sigmoid(f);
                 else if (p.outm == 4) f = fminf(fmaxf(f, 0.0f), 1.0f);
                 long o = (((long)n * p.K + ch) * p.H + y) * p.W + x;
                 if (p.phase_c > 0) {

@@ -163,7 +163,7 @@ __global__ void rn_sum9_tanh(const float* Q, const float* bias, void* out, int o
     for (int sr = 0; sr < 3; ++sr)
 #pragma unroll
         for (int sc = 0; sc < 3; ++sc) a += q[((long)(sr * 3 + sc) * Hp + 3 * sr) * Wp + 3 * sc];
-    a = tanhf(a);
+    a = fast_tanh(a);
     if (out_f32) ((float*)out)[i] = a; else ((f16*)out)[i] = (f16)a;
 }
 
@@ -268,7 +268,7 @@ __global__ void rn_final(const float* raw, int rs, int C, long HW, int N, const 
     if (i >= (long)N * HW) return;
     const long n = i / HW, px = i % HW;
     for (int c = 0; c < C; ++c) {
-        const float y = tanhf(raw[i * rs + c] + bias[c]);
+        const float y = fast_tanh(raw[i * rs + c] + bias[c]);
         const long o = (n * C + c) * HW + px;
         if (out_f32) ((float*)out)[o] = y; else ((f16*)out)[o] = (f16)y;
     }

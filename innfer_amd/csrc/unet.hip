@@ -257,7 +257,7 @@ __global__ void unet_final(const float* raw, int cpad, int C, long HW, int N, co
     if (i >= (long)N * HW) return;
     const long n = i / HW, px = i % HW;
     for (int c = 0; c < C; ++c) {
-        const float y = tanhf(raw[i * cpad + c] + bias[c]);
+        const float y = fast_tanh(raw[i * cpad + c] + bias[c]);
         const long o = (n * C + c) * HW + px;
         if (out_f32) ((float*)out)[o] = y; else ((f16*)out)[o] = (f16)y;
     }
