@@ -243,7 +243,9 @@ size_t innfer_pan_workspace_bytes(innfer_pan_t p, int N, int H, int W);
  * formed per 32-channel k-step in both, so results agree to the last rounding of the fp16 tensors.  on != 0 also moves the FSA block's attention
  * (softmax(f^T g) h over the pooled pixels, block.py:398-473) from the VALU kernel to the matrix cores: scores from fp16 (hi, lo) pairs -- fp32-accurate --,
  * exact row maxima, exp and sums in fp32, p and h as fp16 operands of the P V product; on = 2 keeps the VALU attention behind the fused blocks; on = 3 (110) keeps the
- * trunk tensors on two-group slabs between the fused blocks (default since 110: channels 32..39 travel as a compact 16-byte plane there; same bits).  (108) */
+ * trunk tensors on two-group slabs between the fused blocks (default since 110: channels 32..39 travel as a compact 16-byte plane there; same bits); on = 4 (110) runs the
+ * last stage's HRconv and conv_last as two launches (default since 110 where the full-resolution grid is whole 16 x 32 tiles: conv_last in HRconv's epilogue, the 24-channel
+ * full-resolution tensor neither written nor read; same values to the summation order of conv_last).  (108) */
 int innfer_pan_set_fused_scpa(innfer_pan_t p, int on);
 /* The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs PAN.forward in fp32 on NCHW fp32 tensors
  * (csrc/f32ops.hip; the FSA attention on the fp32 VALU kernel) -- <= 1e-4 of the fp32 reference; fp32 tensors in and out; a load-time call.  (108) */

@@ -24,7 +24,8 @@ class PAN(ParamEngineModule):
         return super()._fn('create_ex' if name == 'create' else name)
 
     fused_scpa = True        # innfer_pan_set_fused_scpa: 1 / True = an SCPA block as one launch (csrc/pan_scpa.hip) + the FSA attention on the matrix cores; 0 / False: the
-                             # five-launch blocks and the VALU attention of rounds 1-3; 2: the fused blocks with the VALU attention (A/B, parity tests)
+                             # five-launch blocks and the VALU attention of rounds 1-3; 2: the fused blocks with the VALU attention (A/B, parity tests); 3: no compact
+                             # channel plane; 4: HRconv and conv_last as two launches (A/B of the fused tail)
 
     def _forward_on_device(self, x, out=None):
         from .. import lib as L

@@ -147,7 +147,7 @@ void conv_pack_s2k4(const float* w_oi44, int K, int C, void* packed);         //
 size_t conv_packed_bytes_deconv2x(int K, int C);
 bool conv_fuse_last_ok(const ConvLaunch& L);
 size_t conv_fuse_side_bytes(int N, int H, int W);
-void conv_pack_fuse_last(const float* w_last_oihw, int oc, void* packed_4k, int rowp = 0);   // host; rowp = the row order of the HR_conv0 panel it is fused behind
+void conv_pack_fuse_last(const float* w_last_oihw, int oc, void* packed_4k, int rowp = 0, int cin = 64);   // host; rowp = the row order of the HR_conv0 panel it is fused behind; cin = 32: behind a 32-channel conv (w [oc][32][3][3])
 void conv_pack_up2x_phases(const float* w_oihw, int K, int C, void* packed, int rowp = 0);       // host; conv_packed_bytes_deconv2x(K, C) bytes: upconv_block as four 2x2-tap phases
 void conv_pack_deconv2x(const float* w_io, int K, int C, int k, void* packed, int rowp = 0); // host; ConvTranspose2d(k = 3 | 4, 2, 1) panels for ConvLaunch.deconv_phases, w [C][K][k][k]
 void conv_pack_taps(const float* w, int K, int C, int mask, void* packed, int rowp = 0);   // host; w [K][C][9], only the taps of `mask` are packed (conv_packed_bytes_taps)

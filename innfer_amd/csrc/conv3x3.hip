@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     static_assert(!PSH || (ROWP && (TMF & ~0xC001FF) == 0 && NSI == 2 && !CV), "pixel-shuffle store: the plain 64-channel plane-order instantiation");
     static_assert(!UP4 || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 3 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFFF) == 0x1FF && !S9 && !POLY && !CV), "one-pass phases: the 64-channel slab kernel on three input slots");
     constexpr bool FUSE = (TMF & 0x20000) != 0;
-    static_assert(!FUSE || (RPW == 2 && NT == 4 && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation");
+    static_assert(!FUSE || (RPW == 2 && (NT == 4 || (NT == 2 && !ROWP)) && NCW == 8 && NSI == 2 && OUTMODE == OUT_SLAB && (TMF & 0x1FFFF) == 0x1FF && !S9 && !POLY && !CV), "the fused last conv: the plain 64-channel instantiation (and the 32-channel one on 16-row tiles)");
     constexpr int TH = NCW * RPW;
     constexpr int LH = TH + 2;
     constexpr int NPX = LH * LWP;
@@ -1340,7 +1340,7 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         k.sg_w = L.gate_w; k.sg_bias = L.gate_bias;
         return launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x801FF>(k, L.N, s);
     }
-    if (pc && L.out_mode == OUT_SLAB && nt == 2) {
+    if (pc && L.out_mode == OUT_SLAB && nt == 2 && !L.fuse_w) {
         // 32-output layers: 24-row tiles, two LDS stages.  pc 5 (diagnostic builds): 16-row tiles on the three-slot input ring (continuous LDS-DMA
         // issue) -- measured within +-1 % of the default on the frame and on the chop path (profiles/r2/kernel_experiments.txt), so the simpler form ships
         if (pc == 5) return launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x1FF, false, 3>(k, L.N, s);
@@ -1348,9 +1348,11 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         return pc == 2 ? launch_pc<3, 2, 8>(k, L.N, s) : pc == 3 ? launch_pc<2, 2, 4>(k, L.N, s) : launch_pc<3, 2, 4>(k, L.N, s);
     }
     if (L.fuse_w) {          // HR_conv0 with the network's last conv in its epilogue (conv3x3_pc<.., TMF | 0x20000>) + the rim pass
-        if (!conv_fuse_last_ok(L)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the fused last conv needs 64 -> 64 channels, whole 16 x 32 tiles, act 0..2, no residual / upsampling / row range");
+        if (!conv_fuse_last_ok(L)) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the fused last conv needs 64 or 32 output channels, whole 16 x 32 tiles, act 0..2, no residual / upsampling / row range");
         k.fl_w = L.fuse_w; k.fl_bias = L.fuse_bias; k.fl_side = L.fuse_side; k.fl_out = L.fuse_out; k.fl_oc = L.fuse_oc; k.fl_out_mode = L.fuse_out_mode;
-        if (int rc = L.rowp ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x4201FF>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x201FF>(k, L.N, s)) return rc;
+        if (nt == 2 && L.rowp) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the fused last conv behind a 32-channel conv takes lane-contiguous panels");
+        if (int rc = nt == 2 ? launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x201FF>(k, L.N, s)
+                             : L.rowp ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x4201FF>(k, L.N, s) : launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x201FF>(k, L.N, s)) return rc;
         const long nthr = (long)L.N * (L.H / 16) * (L.W / 32) * 92;
         hipLaunchKernelGGL(fuse_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)L.fuse_side, L.fuse_bias, L.fuse_out, L.fuse_out_mode, L.out_denorm, L.out_round16, L.fuse_oc,
                            L.N, L.H, L.W);

@@ -45,14 +45,15 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
     asm volatile("s_barrier" ::: "memory");                   // every consumer has read its last fragments of this stage: it may be overwritten
     // (three phases with short live ranges -- the kernel's main loop already sits at the 168-register budget: the fp16 fragments of all four pixel tiles first
     //  (the 64 accumulator registers die there), then one A fragment at a time against all of them, then the stores)
-    f16x8 hb[MT][2];                                        // channels 16 lg + 8 ks + e of pixel li: the values the unfused epilogue would have stored
+    constexpr int KS = NT / 2;                              // 32-channel k-steps: 2 for the 64-channel kernel; 1 for the 32-channel one (round 5: PAN's HRconv + conv_last)
+    f16x8 hb[MT][KS];                                       // channels 4 NT lg + 8 ks + e of pixel li: the values the unfused epilogue would have stored
     // (the activation chosen ONCE: a uniform test per value is a branch per value in this unrolled code -- 128 of them cost more than the rest of the epilogue)
     auto to_f16 = [&](auto act_tag) __attribute__((always_inline)) {
         constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float f = acc[2 * ks + (e >> 2)][m][e & 3];
@@ -69,8 +70,8 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
 #pragma unroll
         for (int m = 0; m < MT; ++m) pa[rt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const f16x8 af = *(const f16x8*)(aw + ((rt * 2 + ks) * 64 + lane) * 16);
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 af = *(const f16x8*)(aw + ((rt * KS + ks) * 64 + lane) * 16);
 #pragma unroll
             for (int m = 0; m < MT; ++m) pa[rt][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, hb[m][ks], pa[rt][m], 0, 0, 0);
         }
@@ -84,7 +85,10 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                *(float*)(plw + ((16 * rt + j) * FUSE_PITCH + (m >> 1) * 32 + (m & 1) * 16) * 4) = pa[rt][m][j];       // (all 32 rows: the five padding rows fit the stage, a lane-dependent test per store costs more)
+                // (64-channel kernel: all 32 rows -- the five padding rows fit its 77-KB stage, a lane-dependent test per store costs more; 32-channel kernel: a 59-KB stage
+                //  holds 28 planes, rows 28 .. 31 -- lane group 3 of row tile 1 -- are padding and stay unwritten)
+                if (NT == 4 || rt == 0 || lg < 3)
+                    *(float*)(plw + ((16 * rt + j) * FUSE_PITCH + (m >> 1) * 32 + (m & 1) * 16) * 4) = pa[rt][m][j];
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");                   // the tile's products are in LDS

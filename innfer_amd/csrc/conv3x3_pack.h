@@ -232,7 +232,7 @@ void conv_pack7v(const float* w, int K, int C, void* packed) {
 // H x W grid (the INPUT grid behind the phase lattice, which has four phases per tile), 8 consumer waves per tile
 // The fused last conv (ConvLaunch.fuse_w): what the launch must look like, the panel of the last conv and the bytes of the rim buffer.
 bool conv_fuse_last_ok(const ConvLaunch& L) {
-    return L.K == 64 && L.C % 32 == 0 && L.out_mode == OUT_SLAB && !L.res1 && !L.res2 && !L.up && !L.reflect && L.dilation <= 1 && !L.dilation_groups && !L.split && !L.wino &&
+    return (L.K == 64 || L.K == 32) && L.C % 32 == 0 && L.out_mode == OUT_SLAB && !L.res1 && !L.res2 && !L.up && !L.reflect && L.dilation <= 1 && !L.dilation_groups && !L.split && !L.wino &&
            !L.stats_part && !L.conv1x1 && !L.stride2 && !L.deconv_phases && !L.conv7 && !L.conv7v && !L.prefix_lrelu && !L.pair_wpk && L.act >= 0 && L.act <= 2 && L.y0 == 0 && L.y1 == L.H &&
            L.H % 16 == 0 && L.W % 32 == 0 && L.fuse_oc >= 1 && L.fuse_oc <= 3 && L.fuse_bias && L.fuse_side && L.fuse_out &&
            (long)L.N * (L.H / 16) * (L.W / 32) * 92 < 0x7fffffffL;
@@ -240,16 +240,20 @@ bool conv_fuse_last_ok(const ConvLaunch& L) {
 size_t conv_fuse_side_bytes(int N, int H, int W) { return (size_t)N * (H / 16) * (W / 32) * FUSE_RING * 3 * sizeof(float); }
 // w_last [oc][64][3][3] -> four MFMA A fragments [row tile rt][k-step ks][lane][8]: row 16 rt + (lane & 15) = tap * 3 + c (27 of 32 rows), k-slot 8 (lane >> 4) + e of
 // step ks = input channel 16 (lane >> 4) + 8 ks + e -- the order in which a consumer lane of conv3x3_pc<2,4,..> holds its sixteen accumulator channels
-void conv_pack_fuse_last(const float* w, int oc, void* packed, int rowp) {      // rowp: HR_conv0's panel has the plane row order -- a lane's k-step ks then holds channels 32 ks + 8 (lane >> 4) + e
+// (cin = 32: behind a 32-channel conv -- conv3x3_pc<2, 2, ..>, one k-step, a lane holds channels 8 (lane >> 4) + e; the 4-KB buffer's second half stays zero)
+void conv_pack_fuse_last(const float* w, int oc, void* packed, int rowp, int cin) {      // rowp: HR_conv0's panel has the plane row order -- a lane's k-step ks then holds channels 32 ks + 8 (lane >> 4) + e
     f16* o = (f16*)packed;
+    const int KS = cin / 32;
+    for (int i = 0; i < 2048; ++i) o[i] = (f16)0.f;
     for (int rt = 0; rt < 2; ++rt)
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int row = 16 * rt + (lane & 15), tap = row / 3, c = row - 3 * tap, ch = rowp ? 32 * ks + 8 * (lane >> 4) + e : 16 * (lane >> 4) + 8 * ks + e;
+                    const int row = 16 * rt + (lane & 15), tap = row / 3, c = row - 3 * tap;
+                    const int ch = KS == 1 ? 8 * (lane >> 4) + e : rowp ? 32 * ks + 8 * (lane >> 4) + e : 16 * (lane >> 4) + 8 * ks + e;
                     float v = 0.f;
-                    if (tap < 9 && c < oc) v = w[((size_t)c * 64 + ch) * 9 + tap];
-                    o[((rt * 2 + ks) * 64 + lane) * 8 + e] = (f16)v;
+                    if (tap < 9 && c < oc) v = w[((size_t)c * cin + ch) * 9 + tap];
+                    o[((rt * KS + ks) * 64 + lane) * 8 + e] = (f16)v;
                 }
 }
 

@@ -583,6 +583,7 @@ struct Gemm {                       // one packed GEMM
     void* d_w3 = nullptr; float* d_b3 = nullptr; int K3 = 0;
     std::function<int(int)> bias_row;                   // optional: output row -> index into the bias parameter (-1: none); default: row == index
     bool one_tap = false;                               // a 1x1 conv: single-tap panel (conv_pack_1x1), the kernel's one-tap instantiation
+    void* d_fuse = nullptr;                             // conv_last behind a 32-channel HRconv: its panel for that conv's fused epilogue (conv_pack_fuse_last(.., cin = 32)); round 5
     bool pa_gate = false; void* d_gate = nullptr;       // the PA block's 1x1 conv (upsample.<i>.conv): also packed as the self-gate fragments of the conv in front of it (conv_pack_selfgate)
 };
 
@@ -601,6 +602,7 @@ struct innfer_pan {
     std::vector<void*> d_scpa;       // one weight blob per SCPA block (pan_scpa.hip), trunk by trunk
     int scpa_c8 = 1;                 // compact channel plane between the fused SCPA blocks (pan_scpa_launch in_c8 / out_c8); 0: A/B (fused_scpa 3)
     int mfma_attention = 1;          // the FSA block's attention on the matrix cores (pan_attention_mfma); 0: the VALU kernel of rounds 1-3 (set with fused_scpa: one A/B switch)
+    int fused_last = 1;              // the last stage's HRconv with conv_last in its epilogue (conv3x3_pc FUSE on 32 channels, round 5); 0: two launches (fused_scpa 4)
     int fused_scpa = 1;              // an SCPA block as ONE launch (innfer_pan_set_fused_scpa); 0: the five halo-tile launches of rounds 1-3
     bool uploaded = false;
 };
@@ -658,7 +660,7 @@ extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int
 
 extern "C" void innfer_pan_destroy(innfer_pan* p) {
     if (!p) return;
-    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); }
+    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); if (g.d_fuse) (void)hipFree(g.d_fuse); }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
     for (auto v : p->d_scpa) if (v) (void)hipFree(v);
     for (auto v : p->f32_w) if (v) (void)hipFree(v);
@@ -670,6 +672,7 @@ extern "C" int innfer_pan_set_fused_scpa(innfer_pan* p, int on) {
     p->fused_scpa = on ? 1 : 0;
     p->mfma_attention = on == 2 ? 0 : 1;          // (2: the fused trunk with the VALU attention -- A/B of the attention alone)
     p->scpa_c8 = on == 3 ? 0 : 1;                 // (3: the fused blocks on two-group slabs throughout -- A/B of the compact channel plane alone, same bits)
+    p->fused_last = on == 4 ? 0 : 1;              // (4: HRconv and conv_last of the last stage as two launches -- A/B of the fused tail alone)
     if (!on) p->mfma_attention = 0;
     return INNFER_OK;
 }
@@ -782,6 +785,7 @@ int upload(innfer_pan* p) {
         if (g.d_w3) { (void)hipFree(g.d_w3); g.d_w3 = nullptr; }
         if (g.d_b3) { (void)hipFree(g.d_b3); g.d_b3 = nullptr; }
         if (g.d_gate) { (void)hipFree(g.d_gate); g.d_gate = nullptr; }
+        if (g.d_fuse) { (void)hipFree(g.d_fuse); g.d_fuse = nullptr; }
     }
     build_gemms(p);
     std::vector<f16> panel;
@@ -816,6 +820,12 @@ int upload(innfer_pan* p) {
                 }
             } else {
                 conv_pack(w3.data(), g.K3, g.cin_pad, packed.data());
+                if (g.K3 <= 3 && g.cin_pad == 32 && &g == &p->gemms.back()) {      // conv_last behind the last stage's HRconv (unf <= 32 channels): also as that conv's fused epilogue
+                    std::vector<char> fp(4096);
+                    conv_pack_fuse_last(w3.data(), g.K3, fp.data(), 0, 32);
+                    INNFER_HIP(hipMalloc(&g.d_fuse, fp.size()));
+                    INNFER_HIP(hipMemcpy(g.d_fuse, fp.data(), fp.size(), hipMemcpyHostToDevice));
+                }
             }
             INNFER_HIP(hipMalloc(&g.d_w3, packed.size()));
             INNFER_HIP(hipMemcpy(g.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
@@ -1101,7 +1111,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     };
     // plain 3x3 conv on conv3x3.hip: dst = act(conv(in) + bias) [+ res]; planar != nullptr: fp32 NCHW output instead of a slab
     auto conv3 = [&](const f16* in, long in_g, int Ho, int Wo, int up, int act, const f16* res, long res_g, f16* dst, long dst_g,
-                     float* planar = nullptr, const Gemm* gate = nullptr) -> int {
+                     float* planar = nullptr, const Gemm* gate = nullptr, const Gemm* last = nullptr, float* last_out = nullptr) -> int {
         const Gemm& g = p->gemms[gi++];
         if (!g.tile3) return set_error(INNFER_ERR_INVALID, "pan: conv %d is not a halo-tile conv", gi - 1);
         ConvLaunch L{};
@@ -1114,6 +1124,9 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         L.out_mode = planar ? OUT_NCHW : OUT_SLAB; L.out_f32 = planar ? 1 : 0;
         L.conv1x1 = g.one_tap ? 1 : 0;
         if (gate) { L.gate_w = (const f16*)gate->d_gate; L.gate_bias = gate->d_b3; }      // out = act(v * sigmoid(W v + b)): the PA block as this conv's epilogue
+        if (last) {          // HRconv -> conv_last in one launch (conv3x3_pc FUSE on 32 channels): `dst` is never written -- its slab holds the rim buffer instead
+            L.fuse_w = (const f16*)last->d_fuse; L.fuse_bias = last->d_b3; L.fuse_side = (float*)dst; L.fuse_out = last_out; L.fuse_oc = last->K3; L.fuse_out_mode = 1;
+        }
         return conv_launch(L, s);
     };
 #define CK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
@@ -1189,6 +1202,7 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
     const f16* cur = p->self_attention ? T : INP;
     long cur_g = G;
     int h = H, w = W;
+    bool fused_last = false;
     for (int u = 0; u < p->n_up; ++u) {
         const int uf = p->scale == 3 ? 3 : 2;
         const int hh = uf * h, ww = uf * w;
@@ -1212,11 +1226,19 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
         // HRconv.  Two stages (4x): PAN's outer B.sequential flattens the stages with children(), which yields the shared LeakyReLU once per
         // stage -- nothing follows HRconv.  One stage (2x): the stage's own nn.Sequential is used as it is and holds the LeakyReLU in two slots,
         // so HRconv IS followed by it (PAN_arch.py:11-19, block.py:197-210; golden G18)
-        CK(conv3(PA, HG, hh, ww, 0, p->n_up == 1 ? 1 : 0, nullptr, 0, HRC, HG));
+        // (round 5) the last stage's HRconv carries conv_last in its epilogue where the grid is whole 16 x 32 tiles: the 24-channel tensor at full resolution (531 MB of slab
+        // at 2160 x 3840) is neither written nor read back; the rim sums live in its place
+        const Gemm& gl = p->gemms.back();
+        fused_last = u == p->n_up - 1 && gl.d_fuse && p->fused_scpa && p->fused_last && hh % 16 == 0 && ww % 32 == 0 && conv_fuse_side_bytes(N, hh, ww) <= (size_t)HG * 2 &&
+                     (long)N * (hh / 16) * (ww / 32) * 92 < 0x7fffffffL;
+        if (fused_last) CK(conv3(PA, HG, hh, ww, 0, p->n_up == 1 ? 1 : 0, nullptr, 0, HRC, HG, nullptr, nullptr, &gl, raw));
+        else CK(conv3(PA, HG, hh, ww, 0, p->n_up == 1 ? 1 : 0, nullptr, 0, HRC, HG));
         cur = HRC; cur_g = HG; h = hh; w = ww;
     }
     // (round 5: the bilinear skip as conv_last's own store was built and measured -- 168 + 72 us -> 585 us at 540 x 960: the 16 lanes that hold the three planar channels
     //  gather 72 values per tile on the consumer waves' critical path; reverted, profiles/r5/pan_tail.txt)
+    if (fused_last) ++gi;                                                              // (conv_last ran inside the HRconv launch)
+    else
     CK(conv3(cur, cur_g, h, w, 0, 0, nullptr, 0, nullptr, 0, raw));                    // conv_last -> planar fp32 (+ bias)
     {
         const long fpx = (long)N * h * w;

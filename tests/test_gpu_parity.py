@@ -1682,6 +1682,34 @@ def test_small_generators_shape_fuzz_and_poisoned_workspace(dev):
             check(wb, x, ref, 8e-3, 1e-3, mode)
 
 
+def test_pan_fused_tail_vs_two_launches(dev):
+    """Round 5: the last stage's HRconv carries conv_last in its epilogue (conv3x3_pc FUSE on the 32-channel kernel, 16-row tiles) wherever the full-resolution grid is whole
+    16 x 32 tiles; `fused_scpa = 4` runs the two launches.  Same fp16 HR values, conv_last summed in another order: agreement to the last rounding of the fp16 output, batches
+    and 2x / 4x; a ragged grid takes the two-launch form in both settings (bit-equal); the fused form is poison-proof (its rim buffer lives in the unwritten HR slab)."""
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    for scale, shapes in ((4, [(1, 3, 48, 48), (2, 3, 24, 40), (3, 3, 200, 200), (1, 3, 50, 70)]), (2, [(2, 3, 32, 48), (1, 3, 33, 48)])):
+        net = get_network(get_network_G_config({"type": "pan", "nb": 2}, scale))
+        net.load_state_dict(_sd({k: tuple(v.shape) for k, v in net.state_dict().items()}, 700 + scale), strict=True)
+        net = net.to(dev).eval()
+        for shape in shapes:
+            x = torch.from_numpy(synth.uniform(shape, 710 + shape[2])).to(dev).half()
+            net.fused_scpa = True
+            yf = net(x)
+            net._ws.fill_(0xFF)
+            assert torch.equal(net(x), yf), (scale, shape, "the fused tail reads unwritten workspace")
+            net.fused_scpa = 4
+            y2 = net(x)
+            net.fused_scpa = True
+            whole = (shape[2] * scale) % 16 == 0 and (shape[3] * scale) % 32 == 0
+            if whole:
+                _assert_same_to_the_last_rounding(yf, y2, (scale, shape))
+            else:
+                assert torch.equal(yf, y2), (scale, shape)
+            assert torch.isfinite(yf.float()).all()
+
+
 def test_sr_network_options_shape_fuzz_and_poisoned_workspace(dev):
     """Seeded ragged shapes and batches for the SR shells' graph-changing options against the oracle: SRResNet's own defaults (BatchNorm, 'NAC': the
     input map in front of every block and of LR_conv), RRDBNet(norm_type='batch', mode='NAC'), the PixelShuffle(3) stage and PixelShuffle(2) on 32
