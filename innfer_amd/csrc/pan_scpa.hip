@@ -17,6 +17,7 @@
 // accumulation, A / B / Y / a' / b' rounded to fp16 where that schedule stored them -- the same roundings, different summation order of the
 // MFMA k-steps only where a conv's taps are walked in another order (none: taps in (dy, dx) order, one k-step per tap).
 #include <atomic>
+#include <type_traits>
 #include "common.h"
 
 namespace innfer {
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
     constexpr int HR = TH + 4, NPX = HR * HC;
     static_assert(NPX % 16 == 0 && TH % 8 == 0, "whole 16-pixel MFMA tiles, whole rows per wave");
     constexpr int NP1 = NPX / 16;                           // conv1's pixel tiles: the whole halo region
-    constexpr int NMID = ((TH + 2) * HC + 15) / 16;         // Y's pixel tiles: rows 1 .. TH + 2, every column
+    constexpr int YW = TW + 2, NY = (TH + 2) * YW;          // Y: rows 1 .. TH + 2, columns 1 .. TW + 2 of the halo tile -- what k4 reads (round 5: every column before, 41 tiles
+    constexpr int NMID = (NY + 15) / 16;                    //    of 16 pixels for TH = 16; 39 now: five per wave instead of six)
     constexpr int PW = TH / 4, RW = PW / 2;                 // output pixel tiles (16 px) / rows per wave: TH rows x 2 segments over 8 waves
     constexpr int XQ = (NPX * 5 + 63) / 64;                 // 1-KiB LDS-DMA pieces of an X tile
     constexpr int KQ = (XQ + 7) / 8;
@@ -256,26 +258,31 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 #endif
         {
             const f32x4 bk0 = *(const f32x4*)(smem + OFF_B2 + (8 * lg) * 4), bk1 = *(const f32x4*)(smem + OFF_B2 + (8 * lg + 4) * 4);
-            for (int i0 = wave; i0 < NMID; i0 += 8 * TB) {
-                f32x4 c[TB][2], g[TB][2];
+            // pixel tile i of the flattened (TH + 2) x (TW + 2) region: pixel Q = 16 i + lane -> halo-tile pixel P = (Q / YW + 1) HC + Q % YW + 1
+            auto halo_px = [&](int i) __attribute__((always_inline)) {
+                const int Q = min(16 * i + li, NY - 1), r = Q / YW;
+                return (r + 1) * HC + (Q - r * YW) + 1;
+            };
+            auto pass = [&](auto nkc, int i0) __attribute__((always_inline)) {      // NK pixel tiles i0, i0 + 8, .. of this wave, their fragment reads issued together
+                constexpr int NK = decltype(nkc)::value;
+                f32x4 c[NK][2], g[NK][2];
+                int Pk[NK];
 #pragma unroll
-                for (int k = 0; k < TB; ++k) { c[k][0] = c[k][1] = z4; g[k][0] = bk0; g[k][1] = bk1; }
+                for (int k = 0; k < NK; ++k) { c[k][0] = c[k][1] = z4; g[k][0] = bk0; g[k][1] = bk1; Pk[k] = halo_px(i0 + 8 * k < NMID ? i0 + 8 * k : i0); }
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    f16x8 w[3][2], b[TB][3];
+                    f16x8 w[3][2], b[NK][3];
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
                             w[dy][t] = lds16(smem, OFF_K3 + (dy * 3 + dx) * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
 #pragma unroll
-                    for (int k = 0; k < TB; ++k) {
-                        const int i = i0 + 8 * k < NMID ? i0 + 8 * k : i0, P = HC + 16 * i + li;
+                    for (int k = 0; k < NK; ++k)
 #pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) b[k][dy] = lds16(smem, BOFF + (P + (dy - 1) * HC + dx - 1) * 48 + lg * 16, lg < 3);
-                    }
+                        for (int dy = 0; dy < 3; ++dy) b[k][dy] = lds16(smem, BOFF + (Pk[k] + (dy - 1) * HC + dx - 1) * 48 + lg * 16, lg < 3);
 #pragma unroll
-                    for (int k = 0; k < TB; ++k)
+                    for (int k = 0; k < NK; ++k)
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -286,14 +293,14 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                         for (int t = 0; t < 2; ++t) {
                             const f16x8 w2 = lds16(smem, OFF_K2 + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
 #pragma unroll
-                            for (int k = 0; k < TB; ++k) g[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, b[k][1], g[k][t], 0, 0, 0);
+                            for (int k = 0; k < NK; ++k) g[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, b[k][1], g[k][t], 0, 0, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int k = 0; k < TB; ++k) {
-                    const int i = i0 + 8 * k < NMID ? i0 + 8 * k : i0, P = HC + 16 * i + li;
+                for (int k = 0; k < NK; ++k) {
+                    const int i = i0 + 8 * k < NMID ? i0 + 8 * k : i0, P = Pk[k];
                     const int r = P / HC, cc = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + cc;
                     const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
                     f16x8 v;
@@ -304,9 +311,14 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                         v[e] = (f16)(inside ? c[k][0][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][0][e])) : 0.f);
                         v[4 + e] = (f16)(inside ? c[k][1][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][1][e])) : 0.f);
                     }
-                    if (lg < 3 && P < NPX) *(f16x8*)(smem + AOFF + P * 48 + lg * 16) = v;
+                    if (lg < 3 && 16 * i + li < NY) *(f16x8*)(smem + AOFF + P * 48 + lg * 16) = v;
                 }
-            }
+            };
+            // wave w takes tiles w, w + 8, ..: TB at a time; the last pass holds only the tiles that are left (two of 39 for TH = 16: six tile slots per wave were 41 tiles' worth)
+            constexpr int NK0 = (NMID + 7) / 8 < TB ? (NMID + 7) / 8 : TB, NK1 = NMID > 8 * TB ? ((NMID - 8 * TB + 7) / 8 < TB ? (NMID - 8 * TB + 7) / 8 : TB) : 0;
+            static_assert(NMID <= 16 * TB, "two passes cover the region");
+            pass(std::integral_constant<int, NK0>{}, wave);
+            if constexpr (NK1 > 0) pass(std::integral_constant<int, NK1>{}, wave + 8 * TB);
         }
         __syncthreads();
         // ---------------- P3: b' = lrelu(k4(Y)); out = conv3(a' | b') + x ----------------
