@@ -149,13 +149,14 @@ __global__ void fuse_combine_kernel(const float* side, const float* bias, void* 
     if (r < 32) { Y = 0; X = r; } else if (r < 64) { Y = 15; X = r - 32; } else { const int k = r - 64; Y = 1 + (k >> 1); X = (k & 1) ? 31 : 0; }
     const int n = tile / per_img, t = tile - n * per_img, ty = t / tiles_x, tx = t - ty * tiles_x;
     float S[3] = {bias[0], oc > 1 ? bias[1] : 0.f, oc > 2 ? bias[2] : 0.f};
-    for (int a = -1; a <= 1; ++a)
-        for (int b = -1; b <= 1; ++b) {
+    // the tiles whose 18 x 34 neighbourhood holds this pixel: its own and, for a pixel of the first / last row (column), the tile above / below (left / right) -- in the
+    // order of the nine-neighbour scan this replaces (rows of tiles ascending, then columns: the same sums), without its five to eight empty trips per pixel
+    const int a0 = Y == 0 ? -1 : 0, a1 = Y == 15 ? 1 : 0, b0 = X == 0 ? -1 : 0, b1 = X == 31 ? 1 : 0;
+    for (int a = a0; a <= a1; ++a)
+        for (int b = b0; b <= b1; ++b) {
             const int nty = ty + a, ntx = tx + b;
             if (nty < 0 || nty >= tiles_y || ntx < 0 || ntx >= tiles_x) continue;
-            const int Yr = Y - 16 * a, Xr = X - 32 * b;
-            if (Yr < -1 || Yr > 16 || Xr < -1 || Xr > 32) continue;
-            const float* sd = side + ((long)(n * per_img + nty * tiles_x + ntx) * FUSE_RING + fuse_ring_index(Yr, Xr)) * 3;
+            const float* sd = side + ((long)(n * per_img + nty * tiles_x + ntx) * FUSE_RING + fuse_ring_index(Y - 16 * a, X - 32 * b)) * 3;
             S[0] += sd[0]; S[1] += sd[1]; S[2] += sd[2];
         }
     fuse_store_pixel(out, mode, denorm, round16, oc, n, H, W, ty * 16 + Y, tx * 32 + X, S);
