@@ -395,21 +395,27 @@ __global__ __launch_bounds__(256) void unet_first_mfma(const TI* in, int C, int 
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][t], bf[ks], acc[t], 0, 0, 0);
-            f16x8 h0[2], h1[2];
+            f16x8 h0[2];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = acc[t][j];
                     h0[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.2f * v);
-                    h1[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(v, 0.f);
                 }
             const long o = (m0 + sx * 16) * 32 + lg * 8;              // h[0]: plane 0 (tiles 0, 1), h[1]: plane 1 (tiles 2, 3)
 #ifdef INNFER_ABLATE
             if ((abl & 2) && h0[0][0] != (f16)12345.f) return;       // diagnostic build: no stores
 #endif
             *(f16x8*)(d0 + o) = h0[0]; *(f16x8*)(d0 + g + o) = h0[1];
-            if (d1) { *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + g + o) = h1[1]; }      // (wave-uniform; nullptr: one stored form, the up conv applies the ReLU as it reads)
+            if (d1) {                                                 // (wave-uniform; nullptr: one stored form, the up conv applies the ReLU as it reads -- and the ReLU view is not even computed)
+                f16x8 h1[2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h1[t >> 1][(t & 1) * 4 + j] = (f16)fmaxf(acc[t][j], 0.f);
+                *(f16x8*)(d1 + o) = h1[0]; *(f16x8*)(d1 + g + o) = h1[1];
+            }
         };
         request(0, rawA);
         int sx = 0;
