@@ -108,6 +108,14 @@ class ParamEngineModule(nn.Module):
         them and stay there: record where, refuse another GPU (a size query used to upload on whatever device was current)."""
         if self._weights_device is not None and self._weights_device != device:
             raise NotImplementedError('this engine was first used on %s; build a second module for %s' % (self._weights_device, device))
+
+    def _upload_on(self, device, fp32=None):
+        """Upload (and, with fp32 given, select the precision) on `device`; the module is pinned to that GPU only once both succeeded (a failed
+        upload -- out of memory inside a size query -- used to leave the module bound to a device that holds nothing)."""
+        self._claim_device(device)
+        self._upload()
+        if fp32 is not None:
+            L.check(self._fn('set_precision')(self._handle, int(fp32)))
         self._weights_device = device
 
     def tile_batch_bytes(self, b, ps, dtype=torch.float16, device=None):
@@ -123,9 +131,7 @@ class ParamEngineModule(nn.Module):
         device = self._home_device(device)
         with torch.cuda.device(device):
             if self._has_fp32:
-                self._claim_device(device)
-                self._upload()
-                L.check(self._fn('set_precision')(self._handle, int(dtype == torch.float32)))
+                self._upload_on(device, dtype == torch.float32)
             return self._fn('workspace_bytes')(self._handle, b, ps, ps) + b * (in_nc * ps * ps + (n_out + 1) * math.prod(out)) * elt
 
     _has_fp32 = False                # engines with an fp32 mode (innfer_<api>_set_precision): every shipped one (UNet, PAN, PPON, CycleGAN ResNet, WBC UNet)
@@ -153,10 +159,8 @@ class ParamEngineModule(nn.Module):
             return self._forward_on_device(x, out)
 
     def _forward_on_device(self, x, out=None):
-        self._claim_device(x.device)
-        self._upload()
-        if self._has_fp32:               # the input's dtype IS the arithmetic, as model.half() / t_img.half() are in the reference
-            L.check(self._fn('set_precision')(self._handle, int(x.dtype == torch.float32)))
+        # (the input's dtype IS the arithmetic, as model.half() / t_img.half() are in the reference)
+        self._upload_on(x.device, (x.dtype == torch.float32) if self._has_fp32 else None)
         x = x.contiguous()
         N, _, H, W = x.shape
         out = _result_tensor(out, self._out_shape(N, H, W), x)

@@ -924,7 +924,9 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         } else {                     // conv nf->4nf -> PixelShuffle(2) -> act (SRGAN: ReLU; RRDBNet(upsample_mode='pixelshuffle'): its act_type)
             ConvLaunch L = mk(cs, t, gi, dst, go, N, h, w, net->trunk_act);
             L.out_mode = OUT_SHUFFLE2;
-            if (cs.d_ps && net->ps_pc && !cs.d_map) { L.wpk = (const f16*)cs.d_ps; L.bias = cs.d_bps; L.rowp = 2; }      // the store of the producer / consumer kernel (conv3x3_pc PSH)
+            // the store of the producer / consumer kernel (conv3x3_pc PSH) while an output group stays below 2 GiB (conv_launch's bound for that form: chop batches of
+            // more than 209 tiles of 200 x 200 at the first stage and 4x frames beyond 8.39 M LR pixels at the second take the two-workgroup kernel, whose indices are 64-bit)
+            if (cs.d_ps && net->ps_pc && !cs.d_map && (long)N * h * w * 256 < 0x7fffffffL) { L.wpk = (const f16*)cs.d_ps; L.bias = cs.d_bps; L.rowp = 2; }
             rc = do_conv(L, s);
         }
         if (rc) return rc;

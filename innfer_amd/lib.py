@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("INNFER_LIB") or os.path.join(_HERE, "lib", "libinnfer_amd.so")
+_DEFAULT_LIB = os.path.join(_HERE, "lib", "libinnfer_amd.so")
+LIB_PATH = os.environ.get("INNFER_LIB") or _DEFAULT_LIB
 
 F16, F32, U8 = 0, 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM, ERR_WORKSPACE = 0, -1, -2, -3, -4, -5
@@ -196,7 +197,12 @@ SIGNATURES = {
 
 # INNFER_ABI_ANY=1 (measurement only: scripts/evidence_r5.sh A/Bs an OLDER build of the library against the current one on one box): bind the entry points that
 # library has and skip the revision check -- calls into entry points it lacks fail with AttributeError.  Never set for product use.
-_ABI_ANY = os.environ.get("INNFER_ABI_ANY") == "1"
+#  Only honoured together with INNFER_LIB pointing at a NON-default library, and loudly: struct layouts are not checked in this mode.
+_ABI_ANY = os.environ.get("INNFER_ABI_ANY") == "1" and bool(os.environ.get("INNFER_LIB")) and os.path.realpath(os.environ["INNFER_LIB"]) != os.path.realpath(_DEFAULT_LIB)
+if os.environ.get("INNFER_ABI_ANY") == "1":
+    import warnings
+    warnings.warn("INNFER_ABI_ANY=1: " + ("binding %s without the ABI revision / symbol check (measurement only; struct layouts are unchecked)" % LIB_PATH if _ABI_ANY
+                  else "ignored -- it needs INNFER_LIB to name a library other than the in-tree default"), RuntimeWarning, stacklevel=2)
 for _name, (_res, _args) in SIGNATURES.items():
     if _ABI_ANY and not hasattr(_lib, _name):
         continue

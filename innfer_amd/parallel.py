@@ -109,6 +109,8 @@ def run_tile_batches(model_fn, tiles, tile_batch=None, sink=None, pick=None, out
     out: a preallocated contiguous [n, C', P, P] tensor the results belong in (and the return value).  A model_fn that takes `out=` (the nn.Module
     shells: `_accepts_out`) writes every batch straight into its rows -- no per-batch result tensor, no copy, no concatenation (VERDICT r4 item 6b);
     any other callable's results are copied there."""
+    if out is not None and sink is not None:
+        raise ValueError('run_tile_batches: give sink= or out=, not both (out= lands the results in the tile buffer; no sink calls are made)')
     n = tiles.shape[0]
     outs = []
     lands = out is not None and pick is None and bool(getattr(model_fn, '_accepts_out', False))

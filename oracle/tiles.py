@@ -103,6 +103,43 @@ def chop_forward(model_fn, data, scale, patch_size=200, step=0.5):
     return recompose_tensor(torch.cat(outs, 0), H, W, step=step, scale=scale)
 
 
+def chop_forward_window(model_fn, data_fn, height, width, scale, window, patch_size=200, step=0.5, cache=None):
+    """chop_forward (run.py:167-202 + utils.py:372-445) evaluated on ONE output window only: window = (y0, y1, x0, x1) in output pixels.  The tile origins,
+    the blend profile and the (h, w) order of the `+=` are those of recompose_tensor above, but only the tiles whose output extent meets the window are run
+    (model_fn on data_fn(y, y + ps, x, x + ps), the tile's input crop [1,C,ps,ps]) and only the window's part of num / den is kept: the result equals
+    chop_forward(...)[:, :, y0:y1, x0:x1] bit for bit at a cost of <= a handful of forwards (tests at BASELINE's full sizes, where the whole frame would be
+    3268 forwards).  cache: optional dict tile index -> model output, shared between calls."""
+    ps, ys_in, xs_in = chop_geometry(height, width, patch_size, step)
+    P = ps * scale
+    full_h, full_w = scale * height, scale * width
+    y0, y1, x0, x1 = window
+    assert 0 <= y0 < y1 <= full_h and 0 <= x0 < x1 <= full_w
+    ys, xs = recompose_origins(full_h, full_w, P, step)
+    assert len(ys) == len(ys_in) and len(xs) == len(xs_in)
+    prof = blend_profile(P, step, scale)
+    wpatch = prof[None].repeat(P, 1) * prof[:, None].repeat(1, P)
+    num = den = None
+    for iy, y in enumerate(ys):
+        for ix, x in enumerate(xs):
+            a0, a1, b0, b1 = max(y, y0), min(y + P, y1), max(x, x0), min(x + P, x1)
+            if a0 >= a1 or b0 >= b1:
+                continue
+            k = iy * len(xs) + ix
+            if cache is not None and k in cache:
+                out = cache[k]
+            else:
+                out = model_fn(data_fn(ys_in[iy], ys_in[iy] + ps, xs_in[ix], xs_in[ix] + ps))
+                if cache is not None:
+                    cache[k] = out
+            if num is None:
+                num = torch.zeros(1, out.shape[1], y1 - y0, x1 - x0, dtype=out.dtype)
+                den = torch.zeros_like(num)
+            wv = wpatch[a0 - y:a1 - y, b0 - x:b1 - x]
+            num[0, :, a0 - y0:a1 - y0, b0 - x0:b1 - x0] += out[0, :, a0 - y:a1 - y, b0 - x:b1 - x] * wv
+            den[0, :, a0 - y0:a1 - y0, b0 - x0:b1 - x0] += wv[None]
+    return num / den
+
+
 def geometry_table(shapes):
     """Golden G1 helper: {(H,W): dict(n, nh, nw, ys, xs)}."""
     out = {}

@@ -708,6 +708,33 @@ def test_srresnet_golden(dev, golden):
     assert np.abs(yt - np.tanh(g["out_24"])).max() < 1e-2
 
 
+def test_srresnet_chop_batch_beyond_the_pixelshuffle_store_bound(dev):
+    """the phase-major PixelShuffle(2) store of the producer / consumer kernel is bounded at 2 GiB per output group (N * H * W * 256 bytes); the
+    engine's own default chop batches (parallel.engine_tile_cap: up to 272 tiles of 200 x 200 for SRResNet = 10.9 M pixels, 2.8 GB at the first stage) exceed it and
+    the forward raised.  Such launches take the two-workgroup kernel (64-bit indices).  220 tiles (2.25 GB at stage 1, 9 GB at stage 2): the first / a middle / the
+    last tile == the engine's batch-1 forward of that tile bit for bit (tiles are independent; both PixelShuffle stores compute the same bits), last tile vs oracle."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.SRResNet_arch import SRResNet
+    sd = _sd(synth.srresnet_shapes(nb=16, scale=4))
+    net = SRResNet(3, 3, 64, 16, upscale=4, norm_type=None, act_type='relu', mode='CNA', upsample_mode='pixelshuffle')
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    n = 220
+    assert n * 200 * 200 * 256 >= 2 ** 31 - 1
+    tiles = torch.from_numpy(synth.uniform((n, 3, 200, 200), 94)).half()
+    y = net(tiles.to(dev))
+    assert tuple(y.shape) == (n, 3, 800, 800)
+    for i in (0, 111, n - 1):
+        assert torch.equal(y[i:i + 1], net(tiles[i:i + 1].to(dev))), i
+    with torch.no_grad():
+        ref = oracle.srresnet_forward(sd, tiles[n - 1:n].float(), nb=16, scale=4)
+    assert (y[n - 1:n].float().cpu() - ref).abs().max().item() < 1e-2
+    del y
+    net.release_workspace()
+    torch.cuda.empty_cache()
+
+
 def test_missing_weights_and_cpu_are_loud(dev):
     from innfer_amd.architectures.RRDBNet_arch import RRDBNet
     net = RRDBNet(3, 3, 64, 1, upscale=2)

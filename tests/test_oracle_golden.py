@@ -444,3 +444,24 @@ def test_g16_mrrdbnet(golden):
     with torch.no_grad():
         y = oracle.mrrdbnet_forward(sd, x, nb=2)
     np.testing.assert_allclose(y.numpy(), g["out"], atol=2e-6, rtol=0)
+
+
+def test_chop_forward_window_is_the_full_chop_on_its_window():
+    """oracle.chop_forward_window (the restricted chop_forward the full-size GPU tests check BASELINE configs 3 / 4 with) == oracle.chop_forward -- itself pinned to the
+    reference's by G2 / G4 -- on the window, bit for bit: corners, a four-tile seam, a ragged last row / column, a window across many tiles; one and two stages."""
+    import torch.nn.functional as F
+    x = torch.from_numpy(synth.uniform((1, 3, 431, 615), 71))
+    w = torch.from_numpy(synth.uniform((3, 3, 3, 3), 72, -0.3, 0.3))
+    fn = lambda t: F.interpolate(F.conv2d(t, w, padding=1), scale_factor=2.0, mode="bilinear")
+    crop = lambda a, b, c, d: x[:, :, a:b, c:d]
+    full = oracle.chop_forward(fn, x, 2)
+    for win in [(0, 64, 0, 64), (862 - 50, 862, 1230 - 70, 1230), (390, 470, 380, 460), (100, 700, 50, 60)]:
+        r = oracle.chop_forward_window(fn, crop, 431, 615, 2, win)
+        assert torch.equal(r, full[:, :, win[0]:win[1], win[2]:win[3]]), win
+    f1 = lambda t: F.conv2d(t, w, padding=1)
+    mid_full = oracle.chop_forward(f1, x, 1)
+    two = oracle.chop_forward(fn, mid_full, 2)
+    cache = {}
+    mid = lambda a, b, c, d: oracle.chop_forward_window(f1, crop, 431, 615, 1, (a, b, c, d), cache=cache)
+    win = (862 - 40, 862, 1230 - 40, 1230)
+    assert torch.equal(oracle.chop_forward_window(fn, mid, 431, 615, 2, win), two[:, :, win[0]:win[1], win[2]:win[3]])
