@@ -59,6 +59,8 @@ def kernel_key(k):
         return "conv3x3_pair"
     variant, k = k // 1000, k % 1000
     nt, mode = k // 16, k % 16
+    if variant == 5:          # the last upconv_block -> HR_conv0 -> conv_last chained through LDS (csrc/hr_chain.hip)
+        return "hr_chain_kernel<upconv+HR_conv0+conv_last>"
     if variant == 4:          # conv nf -> 4 nf with nn.PixelShuffle(2) as the store of conv3x3_pc<2,4,4,0,..,TMF 0xC001FF> (phase-major plane-order panels)
         return "conv3x3_pc<2,4,4,0>+pixelshuffle"
     if (nt, mode) in PC_SHAPE:
@@ -72,7 +74,9 @@ def kind_name(k):
     return "first_conv_mfma<4,1>" if k == 0 else kernel_key(k)          # (3 -> 64 on the matrix cores, csrc/conv_first.hip)
 
 
-KIND_NOTES = {"+fused_tail": "HR_conv0 + conv_last in one launch (+ the rim pass): both convs' FLOPs, the 64-channel HR tensor neither written nor read",
+KIND_NOTES = {"hr_chain_kernel<upconv+HR_conv0+conv_last>": "the last upconv_block -> HR_conv0 -> conv_last as one kernel chained through LDS: the three layers' ALGORITHMIC FLOPs (nine taps each on the "
+                                                            "HR grid; executed: 4/9 of the up-conv's x 1.2 for the recomputed halo), the 64-channel HR tensor never written",
+              "+fused_tail": "HR_conv0 + conv_last in one launch (+ the rim pass): both convs' FLOPs, the 64-channel HR tensor neither written nor read",
               "+upconv_phases": "up-conv as four 2x2-tap phases on the LR grid (all four in one visit of a tile): FLOPs are the ALGORITHMIC ones of the nine-tap layer it replaces "
                        "(reference block.py:348-361); executed FLOPs = 4/9 of them, so `frac_mfma` here is not the matrix pipe's utilisation"}
 
@@ -104,6 +108,7 @@ def timed_forward(net, x):
     L.check(L.lib.innfer_net_set_band_rows(net._handle, int(net.band_rows)))
     L.check(L.lib.innfer_net_set_pair_convs(net._handle, int(net.pair_convs)))
     L.check(L.lib.innfer_net_set_fused_tail(net._handle, int(bool(net.fused_tail))))
+    L.check(L.lib.innfer_net_set_hr_chain(net._handle, int(bool(net.hr_chain))))
     L.check(L.lib.innfer_net_set_upconv_phases(net._handle, int(net.upconv_phases)))
     L.check(L.lib.innfer_net_set_residual_lds(net._handle, int(net.residual_lds)))
     L.check(L.lib.innfer_net_forward_timed(net._handle, x.data_ptr(), L.F16, out.data_ptr(), L.F16, N, H, W,
@@ -557,6 +562,7 @@ def main():
     ap.add_argument("--sharded-steps", type=int, default=-1, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip; default 2 on one GPU, 5 on N > 1 "
                     "(the strong-scaling table of the first multi-GPU run comes from these objects: VERDICT r4 item 6a)")
     ap.add_argument("--fp32", action="store_true", help="frame workloads: a float32 frame = the fp32-accurate engine (the reference's -no_fp16 mode); no roofline object")
+    ap.add_argument("--no-hr-chain", action="store_true", help="A/B: the last up-conv and HR_conv0 + conv_last as two launches (innfer_net_set_hr_chain 0)")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: HR_conv0 and conv_last as two launches (innfer_net_set_fused_tail 0)")
     ap.add_argument("--no-upconv-phases", action="store_true", help="A/B: the up-convs as nine taps on the HR grid (innfer_net_set_upconv_phases 0)")
     ap.add_argument("--upconv-phase-visits", action="store_true", help="A/B: the phase up-convs with one phase per visit of a tile (innfer_net_set_upconv_phases 2; default: all four phases in one visit)")
@@ -639,6 +645,7 @@ def main():
     net, _ = build_net(dev)
     net.band_rows = args.band_rows
     net.fused_tail = not args.no_fused_tail
+    net.hr_chain = not args.no_hr_chain
     net.upconv_phases = 0 if args.no_upconv_phases else (2 if args.upconv_phase_visits else 1)
     net.residual_lds = args.residual_lds
     net.pair_convs = args.pair_convs

@@ -45,8 +45,8 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works); innfer_pack_conv3x3_shuffle2 + innfer_conv_args.plane_rows = 2.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 110
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works); innfer_pack_conv3x3_shuffle2 + innfer_conv_args.plane_rows = 2.  111: innfer_net_set_hr_chain.  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 111
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -162,6 +162,10 @@ int innfer_net_set_residual_lds(innfer_net_t net, int on);
  * 16 x 32 tiles, no row bands; every other case runs the two launches.  0 = always two launches.  The fused form adds the last conv's 576 products of
  * an output in a different order (fp32 either way): results agree to the last rounding of the fp16 output, not bit for bit.  (107) */
 int innfer_net_set_fused_tail(innfer_net_t net, int on);
+/* on (default): the LAST upconv_block -> HR_conv0 -> conv_last (RRDBNet_arch.py:31-42, block.py:348-361) run as ONE kernel chained through LDS where the fused tail and the
+ * one-visit up-conv both apply (fp16 engine, 64 features, whole 16 x 32 output tiles): the 64-channel HR tensor between them is neither written nor read.  Bit-identical to
+ * the two launches it replaces (off).  ABI 111. */
+int innfer_net_set_hr_chain(innfer_net_t net, int on);
 
 /* Scheduling knob: the conv of an upconv_block (nn.Upsample(nearest 2x) -> conv 3x3 -> act, block.py:348-361) as the four 2x2-tap output phases of the
  * equivalent ConvTranspose2d(4, 2, 1) on the LR grid -- 2.25 x fewer multiply-adds than nine taps on the HR grid.  The taps that meet the same LR pixel are

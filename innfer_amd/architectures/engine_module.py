@@ -51,6 +51,7 @@ class EngineModule(nn.Module):
         self.band_rows = 0
         self.upconv_phases = True    # innfer_net_set_upconv_phases: upconv_block convs as four 2x2-tap phases on the LR grid (summed weights, one rounding); True / 1: all four
                                      # phases in one visit of a tile, 2: one phase per visit (rounds 3's form; same bits), False / 0: nine taps on the HR grid
+        self.hr_chain = True         # innfer_net_set_hr_chain: the last upconv_block -> HR_conv0 -> conv_last as ONE kernel chained through LDS (bit-identical to the launches it replaces)
         self.fused_tail = True       # innfer_net_set_fused_tail: HR_conv0 -> conv_last as one kernel where the shapes allow it (results agree to the last fp16 rounding with the two-launch form)
         self.residual_lds = 1        # innfer_net_set_residual_lds: the dense block's `x5 * 0.2 + x` takes x from the conv's own staged LDS tiles -- 1 the RRDB-end blocks (measured gain), 2 every block, 0 never (all agree to the last fp16 rounding)
         self.pair_convs = 0          # innfer_net_set_pair_convs: 0 one launch per layer (default), 1 fused conv pairs on single-image forwards, 2 always
@@ -190,6 +191,7 @@ class EngineModule(nn.Module):
         L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
         L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
         L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
+        L.check(L.lib.innfer_net_set_hr_chain(self._handle, int(bool(self.hr_chain))))
         L.check(L.lib.innfer_net_set_residual_lds(self._handle, int(self.residual_lds)))
         L.check(L.lib.innfer_net_set_upconv_phases(self._handle, int(self.upconv_phases)))
         L.check(L.lib.innfer_net_set_outm(self._handle, int(getattr(self, '_outm', 0))))
@@ -221,6 +223,7 @@ class EngineModule(nn.Module):
             L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
             L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
             L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
+            L.check(L.lib.innfer_net_set_hr_chain(self._handle, int(bool(self.hr_chain))))
             L.check(L.lib.innfer_net_set_residual_lds(self._handle, int(self.residual_lds)))
             L.check(L.lib.innfer_net_set_upconv_phases(self._handle, int(self.upconv_phases)))
             L.check(L.lib.innfer_net_set_u8_io(self._handle, int(bool(normalize)), int(bool(fp16))))

@@ -154,6 +154,12 @@ void conv_pack_taps(const float* w, int K, int C, int mask, void* packed, int ro
 size_t conv_packed_bytes7x7(int K, int C);
 void conv_pack7x7(const float* w_oihw, int K, int C, void* packed);   // host; C % 32 == 0
 
+// ---- the HR tail as one kernel (hr_chain.hip): the last upconv_block -> HR_conv0 -> conv_last chained through LDS ----
+// L: the HR_conv0 launch carrying the fused last conv exactly as conv_launch would take it (fuse_* set; H x W = the HR grid; rowp 1); beside it the up-conv's input slab
+// (two 32-channel groups on the H/2 x W/2 grid), its one-visit phase panels (conv_pack_up2x_phases(.., rowp 1)), the bias once per phase (256 floats) and its activation.
+bool hr_chain_ok(const ConvLaunch& L);
+int hr_chain_launch(const ConvLaunch& L, const f16* up_in, long up_in_gstride, const f16* up_wpk, const float* up_bias, int up_act, hipStream_t s);
+
 // ---- first conv: few input channels, NCHW input (conv_first.hip) -------------
 struct FirstConvLaunch {
     const void* in; int in_f32; int Cin;          // NCHW planar input

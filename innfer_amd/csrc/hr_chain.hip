@@ -1,0 +1,415 @@
+// The HR tail of the SR networks as ONE kernel: the last upconv_block -> HR_conv0 (+ act) -> conv_last, chained through LDS (round 6).
+//
+// Replaces, for RRDBNet (RRDBNet_arch.py:31-42, block.py:348-361):  Upsample(nearest 2x) -> conv3x3(64 -> 64) -> LeakyReLU   (the second upconv_block)
+//                                                                     -> HR_conv0 = conv3x3(64 -> 64) -> LeakyReLU -> conv_last = conv3x3(64 -> out_nc)
+// The layer-by-layer engine wrote the up-conv's [64 ch, 4H x 4W] result (4.25 GB at 1080p: the launch is bound by that store) and read it back in the fused
+// HR_conv0 + conv_last launch.  Here an output tile of 16 x 32 HR pixels never leaves the CU:
+//   stage A  the up-conv as the four 2 x 2-tap phases of the equivalent transposed conv (the panels of the one-visit form: conv_pack_up2x_phases, plane row order) on the
+//            tile's 18 x 34 neighbourhood (HR_conv0's halo, recomputed: 612 pixels for 512 = +20 % of the up-conv's MFMAs), its activation, fp16 rounding -- the values
+//            the unchained engine stored -- written into LDS in the halo-tile image of conv3x3_pc, zeros outside the frame (HR_conv0's zero padding);
+//   stage B  HR_conv0 on that LDS-resident tile: the consumer loop of conv3x3_pc<2,4,..> (same fragments, same MFMA order per value), weights through a ring in LDS;
+//   fuse     conv_last in HR_conv0's epilogue: conv3x3_fuse.h as it is (rim pixels by fuse_combine_kernel).
+// Every value sees the same operands in the same order as in the two unchained launches: results are BIT-IDENTICAL to them (tests/test_gpu_parity.py).
+//
+// Workgroup: 8 waves (two per SIMD, 256 registers each), one persistent workgroup per CU, XCD-aware tile walk as in conv3x3_pc.  No loader waves:
+//   * stage A's weights never touch LDS.  Wave w owns phase w / 2 and one 32-channel half of its outputs for all of the phase's 153 virtual pixels (9 x 17 LR-grid
+//     positions, linearised into 10 MFMA column groups -- no 17-wide rows padded to 32); its eight A fragments of one input group (4 taps x 2 channel tiles, 32 registers) come straight from L2
+//     (each fragment is one contiguous 1 KB of the panel) and are reloaded tap by tap as soon as their last MFMA is issued -- the next group's weights are in flight under
+//     the current group's MFMAs, and no barrier is needed inside stage A at all (the 128 KB of phase panels through a 16-KB LDS ring would be a barrier every 640 cycles);
+//   * the LR input tile (10 x 18 pixels x 64 channels, rows padded to 25 pixels so that the linearised pixel walk stays bank-conflict free), stage B's weight pieces
+//     (one tap COLUMN of one input group = 12 KB, three ring slots) and conv_last's fragments arrive by LDS-DMA issued by the consumer waves themselves.
+// LDS: HR tile 2 x 41 KB | LR tile 2 x 16 KB | weight ring 3 x 12 KB | conv_last fragments 4 KB | biases = 155 KB.
+#include "common.h"
+
+#include <type_traits>
+
+#define FP32_VALUE(x) asm("" : "+v"(x))
+#ifndef INNFER_IN_AUX
+#define INNFER_IN_AUX 0
+#endif
+#pragma clang fp contract(off)
+
+namespace innfer {
+
+namespace {
+
+#define STAMP(i) do { } while (0)
+#include "conv3x3_kp.h"
+#include "conv3x3_fuse.h"
+
+struct ChainP {
+    KP kp;                        // what fused_last_epilogue reads: H, W (the HR grid), act (HR_conv0's), fl_*, out_denorm, out_round16
+    const f16* in; long in_img_stride, in_gbytes;      // the up-conv's input slab: two 32-channel groups of [N, h, w] pixels
+    int h, w;                     // its grid; the HR grid is 2h x 2w
+    const f16* wup; const float* bup;      // conv_pack_up2x_phases(.., rowp 1) panels [phase][group][tap][64][64 B] and the bias once per phase (256 floats)
+    const f16* whr; const float* bhr;                  // HR_conv0: conv_pack(64, 64, rowp 1) [group][tap][64][64 B], 64 biases
+    int N, tiles_x, tiles_y, total, rev;
+};
+
+constexpr int CH_IN_BYTES = (((16 + 2) * LWP + 15) / 16) * 1024;       // one 32-channel group of the 18 x 36-pixel HR tile, as conv3x3_pc stages it (41 984)
+constexpr int CH_LRP = 25;                                               // LR tile row pitch (pixels): 17 + 8 -- see lr_off
+constexpr int CH_LR_CG = 16 * 1024;                                      // 10 rows x 25 px x 64 B = 16 000 -> 16 DMA pieces
+constexpr int CH_LRT = 0;                                                // (first: its addresses stay below 64 KB, the input group is an immediate of the read)
+constexpr int CH_HRT = CH_LRT + 2 * CH_LR_CG;
+constexpr int CH_WB = CH_HRT + 2 * CH_IN_BYTES;
+constexpr int CH_WB_SLOT = 3 * 64 * 64;                                  // one tap column (3 taps) x 64 rows x 64 B
+constexpr int CH_FLW = CH_WB + 3 * CH_WB_SLOT;
+constexpr int CH_BUP = CH_FLW + 4096;
+constexpr int CH_BHR = CH_BUP + 1024;
+constexpr int CH_LDS = CH_BHR + 256;
+static_assert(CH_LDS <= 160 * 1024, "the chain's stages must fit the CU's LDS");
+static_assert(2 * CH_IN_BYTES >= 27 * FUSE_PITCH * 4, "the fused last conv parks its 27 product planes in the HR tile");
+
+// ACT_UP: the up-conv's activation (1 LeakyReLU(0.2), 2 ReLU) -- compile-time: a run-time choice triples the unrolled epilogue of stage A
+template <int ACT_UP>
+__global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
+    constexpr int RPW = 2, NT = 4, MT = 2 * RPW;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+
+    // ---- workgroup -> tiles: as conv3x3_pc (blocks b, b + 8, .. share an XCD and walk a contiguous run of the tile list) ----
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int run_q = p.total >> 3, run_r = p.total & 7;
+    const int run_start = xcd < run_r ? xcd * (run_q + 1) : run_r * (run_q + 1) + (xcd - run_r) * run_q;
+    const int run_len = run_q + (xcd < run_r ? 1 : 0);
+    const int slots = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int j0 = bid >> 3;
+    if (j0 >= run_len) return;
+    auto decode = [&](int jj, int& lid_, int& n_, int& ty0_, int& tx0_) __attribute__((always_inline)) {
+        lid_ = run_start + (p.rev ? run_len - 1 - jj : jj);
+        n_ = lid_ / per_img;
+        const int tile = lid_ - n_ * per_img;
+        const int ty = tile / p.tiles_x;
+        ty0_ = ty * 16;
+        tx0_ = (tile - ty * p.tiles_x) * TW;
+    };
+
+    // ---- stage A, per-lane constants ----
+    // Wave w computes phase ph = w / 2 = 2a + b of the transposed conv (output pixel (2y + a, 2x + b) reads LR rows y + a - 1, y + a and columns x + b - 1, x + b)
+    // for half of the phase's pixels inside the tile's 18 x 34 neighbourhood (local HR rows r = 0 .. 17 <-> frame row ty0 - 1 + r, ty0 even: r even is a = 1).
+    // Local HR pixel (r, c) = (2k + (1 - a), 2m + (1 - b)), k = 0 .. 8, m = 0 .. 16, reads LR-tile pixels (k + dr, m + dc), dr, dc in {0, 1} (LR-tile origin = LR pixel
+    // (ty0 / 2 - 1, tx0 / 2 - 1)) with the phase panel's tap 2 dr + dc -- the SAME for all four phases.  Virtual pixel v = 17 k + m = 0 .. 152; group g of the wave holds
+    // v = 16 (5 hf + g) + li.  LR tile rows are 25 pixels apart, so pixel index P = 25 k + m = v + 8 k: the 16 lanes of a fragment read walk consecutive pixels with
+    // at most one jump of 8 -- P mod 8 stays a permutation inside each half of a ds_read_b128 lane group, i.e. the 16-byte-slot XOR swizzle of conv3x3_pc (slot ^=
+    // 2 bit2(P)) keeps every read bank-conflict free (a pitch of 18 would conflict two ways on every row change).
+    const int ph = wave >> 1, th = wave & 1;          // th: the wave's half of the 64 output channels = slab plane th (channel tiles 2 th, 2 th + 1 of the plane row order)
+    const int ra = 1 - (ph >> 1), cb = 1 - (ph & 1);
+    int lrP[10], hrP[10];         // LR-tile pixel index of group g's pixel at tap (0, 0); HR-tile pixel index (row * 36 + column) it produces, -1: no pixel (v >= 153)
+#pragma unroll
+    for (int g = 0; g < 10; ++g) {
+        const int v = 16 * g + li;
+        const int vv = v < 153 ? v : 152;
+        const int k = (vv * 241) >> 12, m = vv - 17 * k;          // (v / 17 for v < 4096 / 17)
+        lrP[g] = k * CH_LRP + m;
+        hrP[g] = v < 153 ? (2 * k + ra) * LWP + 2 * m + cb : -1;
+    }
+    // the phase's A fragments straight from the panel: fragment (group cg, tap rank, tile t) = 1 KB at cg * 16 KB + (rank * 64 + 16 t) * 64, lane (li, lg) reads row li, octet lg
+    // (buffer loads: ONE per-lane offset register and a scalar offset per fragment -- global loads off 64-bit per-lane pointers cost two address registers each)
+    const int wa_voff = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    f16x8 wa[4][2];
+    auto load_wa = [&](int cg, int rank) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __amdgpu_buffer_rsrc_t rwa = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wup + (long)ph * 2 * 16384 + th * 2048), 0, 2 * 16384, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            wa[rank][t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rwa, wa_voff, cg * 16384 + (rank * 64 + t * 16) * 64, 0));
+#else
+        (void)cg; (void)rank; (void)wa_voff;
+#endif
+    };
+
+    // ---- stage B, per-lane constants (conv3x3_pc's consumers: wave cw owns tile rows 2 cw, 2 cw + 1) ----
+    const int cw = wave;
+    int boffs[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int pb = cw * RPW * LWP + li + s;
+            const int rowpar = ((cw * RPW) & 1) ^ par;
+            boffs[s][par] = CH_HRT + pb * 64 + ((lg ^ (((((li + s) >> 2) & 1) ^ rowpar) << 1)) << 4);
+        }
+    const int aoffs = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+
+    // ---- LDS-DMA issue (every wave its share) ----
+    // LR tile: 32 pieces (group cg = q / 16, pixels 16 (q % 16) .. + 15); wave w issues q = w, w + 8, w + 16, w + 24: two offsets
+    int lroff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int P = 16 * (wave + 8 * i) + (lane >> 2);
+        const int row = P / CH_LRP, col = P - row * CH_LRP;
+        const int slot = (lane & 3) ^ (((P >> 2) & 1) << 1);
+        lroff[i] = (row < 10 && col < 18) ? ((row * p.w + col) * 32 + slot * 8) * 2 : OOB;
+    }
+    auto issue_lr = [&](int n, int ty0, int tx0) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int Y = (ty0 >> 1) - 1, X = (tx0 >> 1) - 1;
+        const char* base = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)Y * p.w + X) * 64;
+        int vo[2] = {lroff[0], lroff[1]};
+        if (Y < 0 || Y + 10 > p.h || X < 0 || X + 18 > p.w) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int P = 16 * (wave + 8 * i) + (lane >> 2);
+                const int row = P / CH_LRP, col = P - row * CH_LRP;
+                if (Y + row < 0 || Y + row >= p.h || X + col < 0 || X + col >= p.w) vo[i] = OOB;
+            }
+        }
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)(base + cg * p.in_gbytes), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void*)(smem + CH_LRT + cg * CH_LR_CG + (wave + 8 * i) * 1024), 16, vo[i], 0, 0, INNFER_IN_AUX);
+        }
+#else
+        (void)n; (void)ty0; (void)tx0; (void)lroff;
+#endif
+    };
+    // stage B weights, step n = (group n / 3, tap column n % 3): 12 pieces of 1 KB -- piece j: tap row j / 4, quarter j % 4 of its 4 KB; waves 0 .. 7 issue j = w, waves 0 .. 3 also j = w + 8
+    auto issue_wb = [&](int n) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int cg = n / 3, sc = n - 3 * cg;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.whr, 0, 2 * 9 * 4096, 0x00020000);
+        char* slot = smem + CH_WB + (n % 3) * CH_WB_SLOT;
+        {
+            const int j = wave;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(slot + j * 1024), 16, lane * 16, ((cg * 9 + (j >> 2) * 3 + sc) * 4 + (j & 3)) * 1024, 0, 0);
+        }
+        if (wave < 4) {
+            const int j = wave + 8;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(slot + j * 1024), 16, lane * 16, ((cg * 9 + (j >> 2) * 3 + sc) * 4 + (j & 3)) * 1024, 0, 0);
+        }
+#else
+        (void)n;
+#endif
+    };
+    auto wait_vm_all = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    // ---- prologue: conv_last's fragments, the biases, the first tile's LR tile and stage B pieces 0, 1, the first weights of stage A ----
+    int lid, n, ty0, tx0;
+    decode(j0, lid, n, ty0, tx0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (wave < 4) {
+        const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)p.kp.fl_w, 0, 4096, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(smem + CH_FLW + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+    }
+#endif
+    if (wave == 4) *(f32x4*)(smem + CH_BUP + lane * 16) = *(const f32x4*)(p.bup + 4 * lane);
+    if (wave == 5 && lane < 16) *(f32x4*)(smem + CH_BHR + lane * 16) = *(const f32x4*)(p.bhr + 4 * lane);
+    issue_lr(n, ty0, tx0);
+    issue_wb(0);
+    issue_wb(1);
+    load_wa(0, 0); load_wa(0, 1); load_wa(0, 2); load_wa(0, 3);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+
+    for (int j = j0; j < run_len; j += slots) {
+        const bool has_next = j + slots < run_len;
+        // ================================ stage A: the up-conv's four phases on the 18 x 34 neighbourhood ================================
+        f32x4 acc[10][2];
+        {
+            const float* bl = (const float*)(smem + CH_BUP) + ph * 64 + 32 * th + 8 * lg;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 bt = *(const f32x4*)(bl + 4 * t);
+#pragma unroll
+                for (int g = 0; g < 10; ++g) acc[g][t] = bt;
+            }
+        }
+        {
+            // 80 pixel fragments in (group cg, tap, pixel group) order through a five-register ring, each read four MFMA pairs ahead of its use.  Taps in the order of the
+            // one-visit kernel's walk (tap column first: ranks 0, 2, 1, 3), input group 0 before 1: the order in which the unchained launch accumulated every value.
+            // The read address is derived from the group's pixel index as the read is issued (4 VALU instructions beside 2 MFMAs): hoisted out of the tile loop the
+            // eighty of them would be eighty registers.
+            constexpr int NRD = 80, RING = 5, AHEAD = 4;
+            f16x8 bq[RING];
+            auto ldb = [&](int i) __attribute__((always_inline)) {
+                const int cg = i / 40, rem = i - 40 * cg, ti = rem / 10, g = rem - 10 * ti, rank = ((ti & 1) << 1) | (ti >> 1);
+                int P = lrP[g];
+                asm volatile("" : "+v"(P));
+                P += (rank >> 1) * CH_LRP + (rank & 1);
+                return *(const f16x8*)(smem + CH_LRT + cg * CH_LR_CG + P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4));
+            };
+#pragma unroll
+            for (int i = 0; i < AHEAD; ++i) bq[i] = ldb(i);
+#pragma unroll
+            for (int i = 0; i < NRD; ++i) {
+                const int cg = i / 40, rem = i - 40 * cg, ti = rem / 10, g = rem - 10 * ti, rank = ((ti & 1) << 1) | (ti >> 1);
+                if (i + AHEAD < NRD) bq[(i + AHEAD) % RING] = ldb(i + AHEAD);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[rank][t], bq[i % RING], acc[g][t], 0, 0, 0);
+                // the tap's fragments have issued their last MFMA of input group 0: fetch group 1's into the same registers (in flight under the other taps' MFMAs)
+                if (g == 9 && cg == 0) load_wa(1, rank);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");          // B1: every wave has left the previous tile's fused epilogue (its products lie in the HR tile)
+        {
+            // epilogue A: activation, fp16 (the values the unchained up-conv stored), zeros outside the frame, into the HR tile: a lane's 8 channels are octet lg of
+            // its pixel in the wave's 32-channel group (plane row order).  The activation is chosen ONCE: a uniform test per value is a branch per value in unrolled code.
+            const bool edge = ty0 == 0 || ty0 + 16 >= p.kp.H || tx0 == 0 || tx0 + TW >= p.kp.W;
+            auto store_tile = [&](auto act_tag, auto edge_tag) __attribute__((always_inline)) {
+                constexpr int ACT = decltype(act_tag)::value;
+                constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+                for (int g = 0; g < 10; ++g) {
+                    f16x8 h;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) {
+                            float f = acc[g][t][jx];
+                            if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                            else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                            FP32_VALUE(f);
+                            h[4 * t + jx] = (f16)f;
+                        }
+                    const int P = hrP[g];
+                    if constexpr (EDGE) {          // a tile on the frame's border: the neighbourhood's pixels outside the frame are HR_conv0's zero padding (selects, no branch)
+                        int Pq = P;
+                        asm volatile("" : "+v"(Pq));          // (row / column re-derived here: hoisted, the twenty of them would be twenty registers)
+                        const int r = (Pq * 1821) >> 16, c = Pq - r * LWP;          // (P / 36 for P < 648)
+                        const int y = ty0 - 1 + r, x = tx0 - 1 + c;
+                        const bool zero = y < 0 || y >= p.kp.H || x < 0 || x >= p.kp.W;
+                        u32x4 hv = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = zero ? 0u : hv[e];
+                        h = __builtin_bit_cast(f16x8, hv);
+                    }
+                    if (g < 9 || P >= 0)          // (only the last group has lanes without a pixel)
+                        *(f16x8*)(smem + CH_HRT + th * CH_IN_BYTES + P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4)) = h;
+                }
+            };
+            if (edge) store_tile(std::integral_constant<int, ACT_UP>{}, std::true_type{});
+            else store_tile(std::integral_constant<int, ACT_UP>{}, std::false_type{});
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");          // B2: the HR tile is complete; the LR tile is free
+        issue_wb(2);
+        int lid2 = 0, n2 = 0, ty2 = 0, tx2 = 0;
+        if (has_next) { decode(j + slots, lid2, n2, ty2, tx2); issue_lr(n2, ty2, tx2); }
+
+        // ================================ stage B: HR_conv0 on the LDS-resident tile ================================
+        f16x8 a[3][NT];
+        auto lda = [&](int slot, int r) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[r][t] = *(const f16x8*)(smem + CH_WB + slot * CH_WB_SLOT + aoffs + (r * 64 + t * 16) * 64);
+        };
+        lda(0, 0); lda(0, 1); lda(0, 2);
+        f32x4 acc2[NT][MT];
+        {
+            const float* bl = (const float*)(smem + CH_BHR) + 8 * lg;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 bt = *(const f32x4*)(bl + 32 * (t >> 1) + 4 * (t & 1));
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc2[t][m] = bt;
+            }
+        }
+        {
+            // conv3x3_pc's software-pipelined nine-tap walk, one tap column per step: 8 pixel fragments (halo rows 0 .. 3 x 2 segments) through the ring, the next
+            // column's weight fragments overwrite this column's as soon as their last MFMA is issued -- from the NEXT ring slot, visible since the previous barrier.
+            f16x8 bq[3];
+            auto ldb = [&](int i) __attribute__((always_inline)) {          // i = step * 8 + halo row * 2 + segment
+                const int st = i >> 3, jj = i & 7, rr = jj >> 1, seg = jj & 1, cg = st / 3, sc = st - 3 * cg;
+                return *(const f16x8*)(smem + cg * CH_IN_BYTES + boffs[sc][rr & 1] + (rr * LWP + seg * 16) * 64);
+            };
+            bq[0] = ldb(0); bq[1] = ldb(1);
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int i = st * 8 + jj, rr = jj >> 1, seg = jj & 1;
+                    if (i + 2 < 48) bq[(i + 2) % 3] = ldb(i + 2);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int rw = rr - r;
+                        if (rw >= 0 && rw < RPW) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                acc2[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[r][t], bq[i % 3], acc2[t][rw * 2 + seg], 0, 0, 0);
+                        }
+                    }
+                    if (st < 5 && seg == 1) {
+                        if (rr == RPW - 1) lda((st + 1) % 3, 0);
+                        if (rr == RPW) lda((st + 1) % 3, 1);
+                        if (rr == RPW + 1) lda((st + 1) % 3, 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (st < 4) {
+                    // end of step st: the piece(s) of step st + 2 this wave issued a step ago have landed (step 0: the next tile's LR pieces, issued after them, may stay in flight)
+                    if (st == 0 && has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else wait_vm_all();
+                    asm volatile("s_barrier" ::: "memory");          // steps st + 1, st + 2 are visible; the slots of steps <= st are free
+                    if (st + 3 < 6) issue_wb(st + 3);
+                    // after step 3 the ring's slots 0 and 1 (steps 3 and 4: their fragments are in registers by now) take the NEXT tile's steps 0 and 1 -- the panels do
+                    // not depend on the tile; steps 4 and 5 run without a barrier
+                    if (st == 3 && has_next) { issue_wb(0); issue_wb(1); }
+                }
+            }
+        }
+        wait_vm_all();                                   // (the next tile's LR tile, issued a whole stage ago, and its first two weight pieces: visible to every wave behind the epilogue's barriers)
+        // stage A's weights of the NEXT tile's first input group (the panels do not depend on the tile): in flight under the epilogue, not held across stage B
+        if (has_next) { load_wa(0, 0); load_wa(0, 1); load_wa(0, 2); load_wa(0, 3); }
+        // ================================ conv_last in the epilogue (conv3x3_fuse.h; three workgroup barriers) ================================
+        fused_last_epilogue<RPW, NT>(p.kp, acc2, smem + CH_HRT, smem + CH_FLW, n, ty0, tx0, cw, lane, lid);
+        lid = lid2; n = n2; ty0 = ty2; tx0 = tx2;
+    }
+}
+
+}  // namespace
+
+// L: the HR_conv0 launch with the fused last conv as net.hip builds it (fuse_* set, H x W the HR grid, in unused); the up-conv's operands beside it.
+int hr_chain_launch(const ConvLaunch& L, const f16* up_in, long up_in_gstride, const f16* up_wpk, const float* up_bias, int up_act, hipStream_t s) {
+    double gt_flops = 0, gt_bytes = 0;
+    if (gt_on()) {
+        const double px = (double)L.N * L.H * L.W;
+        gt_flops = 2.0 * 9.0 * (64.0 * 64 + 64.0 * 64 + 64.0 * L.fuse_oc) * px;
+        gt_bytes = px / 4 * 128.0 + px * L.fuse_oc * (L.fuse_out_mode == 2 ? 1.0 : L.fuse_out_mode == 1 ? 4.0 : 2.0) + 9.0 * (2 * 64.0 * 64 + 64.0 * L.fuse_oc) * 2.0;
+    }
+    GtScope gt(s, "hr_chain: upconv -> HR_conv0 -> conv_last", gt_flops, gt_bytes);
+    if (!hr_chain_ok(L) || (up_act != 1 && up_act != 2)) return set_error(INNFER_ERR_UNSUPPORTED, "hr_chain: 64 -> 64 -> 64 -> <= 3 channels on whole 16 x 32 HR tiles, act 1 / 2");
+    static int attr_dev_mask = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_dev_mask & (1 << (dev & 31)))) {
+        INNFER_HIP(hipFuncSetAttribute((const void*)hr_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+        INNFER_HIP(hipFuncSetAttribute((const void*)hr_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+        attr_dev_mask |= 1 << (dev & 31);
+    }
+    ChainP c{};
+    c.kp.H = L.H; c.kp.W = L.W; c.kp.act = L.act;
+    c.kp.fl_w = L.fuse_w; c.kp.fl_bias = L.fuse_bias; c.kp.fl_side = L.fuse_side; c.kp.fl_out = L.fuse_out; c.kp.fl_oc = L.fuse_oc; c.kp.fl_out_mode = L.fuse_out_mode;
+    c.kp.out_denorm = L.out_denorm; c.kp.out_round16 = L.out_round16;
+    c.h = L.H / 2; c.w = L.W / 2;
+    c.in = up_in; c.in_gbytes = up_in_gstride * 2; c.in_img_stride = (long)c.h * c.w * 32;
+    c.wup = up_wpk; c.bup = up_bias;
+    c.whr = L.wpk; c.bhr = L.bias;
+    c.N = L.N; c.tiles_x = L.W / TW; c.tiles_y = L.H / 16;
+    const long total = (long)L.N * c.tiles_x * c.tiles_y;
+    c.total = (int)total; c.rev = L.rev ? 1 : 0;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const long grid = total < cus ? total : cus;
+    if (up_act == 1) hipLaunchKernelGGL(hr_chain_kernel<1>, dim3((unsigned)grid), dim3(512), CH_LDS, s, c);
+    else hipLaunchKernelGGL(hr_chain_kernel<2>, dim3((unsigned)grid), dim3(512), CH_LDS, s, c);
+    INNFER_HIP(hipGetLastError());
+    const long nthr = (long)L.N * (L.H / 16) * (L.W / 32) * 92;
+    hipLaunchKernelGGL(fuse_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)L.fuse_side, L.fuse_bias, L.fuse_out, L.fuse_out_mode, L.out_denorm, L.out_round16, L.fuse_oc,
+                       L.N, L.H, L.W);
+    INNFER_HIP(hipGetLastError());
+    return INNFER_OK;
+}
+
+bool hr_chain_ok(const ConvLaunch& L) {
+    return conv_fuse_last_ok(L) && L.K == 64 && L.C == 64 && L.rowp == 1 && (L.act == 1 || L.act == 2 || L.act == 0) && L.H % 16 == 0 && L.W % 32 == 0 && L.W / 2 > 16 &&
+           (long)(L.H / 2) * (L.W / 2) * 64 < 0x7fffffffL && (long)L.N * (L.H / 16) * (L.W / 32) < 0x7fffffffL;
+}
+
+}  // namespace innfer

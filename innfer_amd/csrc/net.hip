@@ -82,6 +82,9 @@ extern "C" int innfer_timer_stop(void* stream, int cap, char* names, int name_ca
 #ifndef INNFER_ROWP_DEFAULT
 #define INNFER_ROWP_DEFAULT 1      // (A/B builds: 0 = the lane-contiguous row order everywhere)
 #endif
+#ifndef INNFER_FUSE_LAST
+#define INNFER_FUSE_LAST 1
+#endif
 struct ConvSlot {
     std::string key;
     int K = 0, C = 0;
@@ -124,6 +127,10 @@ struct innfer_net {
 #endif
     int up_phases = INNFER_UP_PHASES_DEFAULT;   // upconv_block convs as four 2x2-tap phases on the LR grid (innfer_net_set_upconv_phases; the macro: A/B builds)
     int fused_tail = 1;          // HR_conv0 -> conv_last as one kernel where the shapes allow it (innfer_net_set_fused_tail)
+#ifndef INNFER_HR_CHAIN_DEFAULT
+#define INNFER_HR_CHAIN_DEFAULT 1
+#endif
+    int hr_chain = INNFER_HR_CHAIN_DEFAULT;   // the LAST upconv_block -> HR_conv0 -> conv_last as one kernel chained through LDS (hr_chain.hip; innfer_net_set_hr_chain): the 64-channel HR tensor is never written
 #ifndef INNFER_PS_PC_DEFAULT
 #define INNFER_PS_PC_DEFAULT 1
 #endif
@@ -421,6 +428,12 @@ extern "C" int innfer_net_set_residual_lds(innfer_net_t net, int on) {
 extern "C" int innfer_net_set_fused_tail(innfer_net_t net, int on) {
     if (!net) return set_error(INNFER_ERR_INVALID, "set_fused_tail: null network");
     net->fused_tail = on ? 1 : 0;
+    return INNFER_OK;
+}
+
+extern "C" int innfer_net_set_hr_chain(innfer_net_t net, int on) {
+    if (!net) return set_error(INNFER_ERR_INVALID, "set_hr_chain: null network");
+    net->hr_chain = on ? 1 : 0;
     return INNFER_OK;
 }
 
@@ -909,6 +922,37 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
             t = dst; h *= 3; w *= 3;
             continue;
         }
+        if (u == net->n_up - 1 && !net->ps_up && net->up_phases == 1 && net->hr_chain && !net->fp32 && cs.d_up4p && !cs.d_map && (net->trunk_act == 1 || net->trunk_act == 2) && w > 16 &&
+            INNFER_FUSE_LAST && net->fused_tail && !any_map && net->band_rows == 0 && net->final_act == 0 && net->outm == 0) {
+            // The last upconv_block -> HR_conv0 -> conv_last as ONE kernel (hr_chain.hip): the [64 ch, 2h x 2w] tensor between them (4.25 GB of a 1080p -> 4K frame, written
+            // by a store-bound launch and read back by the next) stays in LDS tile by tile.  Same operands in the same order per value as the two launches below: same bits.
+            const ConvSlot& ch = net->convs[ci];           // HR_conv0
+            const ConvSlot& cl = net->convs[ci + 1];       // conv_last
+            const int hh = 2 * h, wh = 2 * w;
+            const long gh = (long)N * hh * wh * 32;
+            if (ch.K == 64 && ch.C == 64 && ch.rowp && cl.d_fuse && cl.loaded && conv_fuse_side_bytes(N, hh, wh) <= (size_t)gh * 2 * (net->nf / 32)) {
+                ConvLaunch L = mk(ch, nullptr, gh, ws + cv.hr, gh, N, hh, wh, net->trunk_act);
+                L.fuse_w = (const f16*)cl.d_fuse; L.fuse_bias = cl.d_b; L.fuse_side = (float*)(ws + cv.hr); L.fuse_out = d_out; L.fuse_oc = cl.K;
+                L.fuse_out_mode = out_dtype == INNFER_U8 ? 2 : out_dtype == INNFER_F32 ? 1 : 0;
+                L.out_denorm = net->u8_normalize; L.out_round16 = net->u8_round16;
+                if (hr_chain_ok(L)) {
+                    rc = timed_begin(s);
+                    if (rc) return rc;
+                    {
+                        thread_local unsigned parity = 0;
+                        L.rev = INNFER_KNOB("INNFER_TILE_REV", 1) ? (int)(parity++ & 1) : 0;
+                    }
+                    rc = hr_chain_launch(L, t, gi, (const f16*)cs.d_up4p, cs.d_b4, net->trunk_act, s);
+                    if (rc) return rc;
+                    rc = debug_after("hr_chain", s);
+                    if (rc) return rc;
+                    // the three layers' ALGORITHMIC FLOPs (nine taps each on the HR grid); bytes: the LR tensor in, the planar result out, the weights
+                    const double pxh = (double)N * hh * wh;
+                    const double ob = L.fuse_out_mode == 2 ? 1.0 : L.fuse_out_mode == 1 ? 4.0 : 2.0;
+                    return timed_end(s, 2.0 * 9.0 * (64.0 * 64 + 64.0 * 64 + 64.0 * cl.K) * pxh, pxh / 4 * 128.0 + pxh * cl.K * ob + 9.0 * (2 * 64.0 * 64 + 64.0 * cl.K) * 2.0, 5000 + 16 * 4);
+                }
+            }
+        }
         if (!net->ps_up && net->up_phases && !net->fp32 && cs.d_up4 && !cs.d_map && net->trunk_act <= 2) {
             // Upsample(nearest 2x) -> conv -> act as the four output phases of the equivalent transposed conv: 2x2 taps on the LR grid instead of 3x3 on the
             // HR grid (2.25 x fewer MACs), on the phase-lattice instantiation (conv3x3_pc<.., TM = 0x1B>)
@@ -932,9 +976,6 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
         if (rc) return rc;
         t = dst; h *= 2; w *= 2;
     }
-#ifndef INNFER_FUSE_LAST
-#define INNFER_FUSE_LAST 1
-#endif
     {
         const ConvSlot& cs = net->convs[ci++];
         const long gh = (long)N * h * w * 32;

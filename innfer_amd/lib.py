@@ -86,6 +86,7 @@ SIGNATURES = {
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_fused_tail": (C.c_int, [C.c_void_p, C.c_int]),
+    "innfer_net_set_hr_chain": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_residual_lds": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_upconv_phases": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_final_act": (C.c_int, [C.c_void_p, C.c_int]),
@@ -212,7 +213,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 110          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 111          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION and not _ABI_ANY:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

@@ -2159,6 +2159,42 @@ def test_upconv_phases_vs_nine_taps_and_oracle(dev):
                 assert e.max().item() < 1e-2 and e.mean().item() < 1e-3, (tag, scale, shape, e.max().item(), e.mean().item())
 
 
+def test_hr_chain_equals_the_launches_it_replaces(dev):
+    """The last upconv_block -> HR_conv0 -> conv_last as ONE kernel chained through LDS (csrc/hr_chain.hip, innfer_net_set_hr_chain; RRDBNet_arch.py:31-42,
+    block.py:348-361) against the two launches it replaces (one-visit up-conv + fused HR_conv0 / conv_last): every value sees the same fp16 operands in the same MFMA
+    order, so the results must be EQUAL bit for bit -- frames of whole 16 x 32 HR tiles: all-border tiles, interior tiles, batches, a 200 x 200 chop tile, 2x and 4x
+    networks, ReLU trunks, fp16 and uint8 boundaries; and against the oracle."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures.RRDBNet_arch import RRDBNet
+    cases = [(4, 1, 8, 16, "leakyrelu"), (4, 1, 24, 40, "leakyrelu"), (4, 2, 28, 56, "leakyrelu"), (2, 1, 48, 80, "leakyrelu"), (2, 3, 24, 32, "relu"),
+             (4, 1, 200, 200, "leakyrelu"), (4, 1, 36, 104, "relu"), (8, 1, 12, 24, "leakyrelu")]
+    for i, (scale, n, h, w, act) in enumerate(cases):
+        sd = _sd(synth.rrdbnet_shapes(nb=1, scale=scale), 300 + i)
+        net = RRDBNet(3, 3, 64, 1, upscale=scale, act_type=act)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).eval()
+        x = torch.from_numpy(synth.uniform((n, 3, h, w), 310 + i)).to(dev).half()
+        net.hr_chain = True
+        y1 = net(x)
+        net._ws.fill_(0xFF)                        # (poisoned workspace: the chained kernel must not read the HR slab it no longer writes)
+        y1b = net(x)
+        net.hr_chain = False
+        y0 = net(x)
+        assert torch.equal(y1, y0), (scale, n, h, w, act, (y1.float() - y0.float()).abs().max().item())
+        assert torch.equal(y1, y1b), (scale, n, h, w, act, "poisoned workspace")
+        if i in (1, 4):
+            with torch.no_grad():
+                ref = oracle.rrdbnet_forward(sd, x.float().cpu(), nb=1, scale=scale, act_type=act)
+            assert (y1.float().cpu() - ref).abs().max().item() < 1e-2, (scale, n, h, w)
+        if i in (1, 5):                            # uint8 in, uint8 out (np2tensor / tensor2np fused at both ends)
+            img = torch.from_numpy((synth.uniform((h, w, 3), 320 + i) * 255).astype(np.uint8)).to(dev)
+            net.hr_chain = True
+            u1 = net.forward_u8(img)
+            net.hr_chain = False
+            assert torch.equal(u1, net.forward_u8(img)), (scale, n, h, w, "u8")
+
+
 def test_full_frame_1080p_translation_property(dev):
     """BASELINE config 2 size (1x3x1080x1920 -> 1x3x4320x7680, RRDBNet-23 4x fp16): an
     interior window of the full-frame result equals the forward of a crop that
