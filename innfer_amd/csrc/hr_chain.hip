@@ -36,6 +36,11 @@ namespace {
 #define STAMP(i) do { } while (0)
 #include "conv3x3_kp.h"
 #include "conv3x3_fuse.h"
+#ifdef INNFER_ABLATE
+#define CH_ABL(bit) (p.abl & (bit))
+#else
+#define CH_ABL(bit) false
+#endif
 
 struct ChainP {
     KP kp;                        // what fused_last_epilogue reads: H, W (the HR grid), act (HR_conv0's), fl_*, out_denorm, out_round16
@@ -44,6 +49,9 @@ struct ChainP {
     const f16* wup; const float* bup;      // conv_pack_up2x_phases(.., rowp 1) panels [phase][group][tap][64][64 B] and the bias once per phase (256 floats)
     const f16* whr; const float* bhr;                  // HR_conv0: conv_pack(64, 64, rowp 1) [group][tap][64][64 B], 64 biases
     int N, tiles_x, tiles_y, total, rev;
+#ifdef INNFER_ABLATE
+    int abl;                      // diagnostic build only (scripts/r6/hr_chain_micro.cpp): 1 no stage A reads / MFMAs, 2 no HR-tile stores, 4 no stage B reads / MFMAs, 8 no fused epilogue, 16 no LR-tile DMA, 32 no stage B weight DMA, 64 no stage A weight loads
+#endif
 };
 
 constexpr int CH_IN_BYTES = (((16 + 2) * LWP + 15) / 16) * 1024;       // one 32-channel group of the 18 x 36-pixel HR tile, as conv3x3_pc stages it (41 984)
@@ -59,6 +67,13 @@ constexpr int CH_BHR = CH_BUP + 1024;
 constexpr int CH_LDS = CH_BHR + 256;
 static_assert(CH_LDS <= 160 * 1024, "the chain's stages must fit the CU's LDS");
 static_assert(2 * CH_IN_BYTES >= 27 * FUSE_PITCH * 4, "the fused last conv parks its 27 product planes in the HR tile");
+
+// HR tile image in LDS: rows of 36 pixels x 64 B per 32-channel group as in conv3x3_pc, but inside a row the EVEN columns come first and the odd ones 72 slots behind,
+// and the four 16-byte octets of pixel pair j rotate by j: slot(col, octet) = 4 (col / 2) + ((octet + col / 2) & 3) + 72 (col & 1).  Stage B's fragment reads (16 consecutive
+// columns from any start, one octet per 16-lane half) stay bank-conflict free, and stage A's stores -- 8 lanes holding every other column (one phase) -- conflict two ways
+// instead of four as in conv3x3_pc's pixel-major image, where a phase's columns all fall into the same 64-byte half of every 128-byte bank window (ablation: the stores
+// were 0.7 of the first version's 4.1 ms).
+__host__ __device__ constexpr int hr_slot(int col, int oct) { return 4 * (col >> 1) + ((oct + (col >> 1)) & 3) + 72 * (col & 1); }
 
 // ACT_UP: the up-conv's activation (1 LeakyReLU(0.2), 2 ReLU) -- compile-time: a run-time choice triples the unrolled epilogue of stage A
 template <int ACT_UP>
@@ -99,41 +114,40 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
     // 2 bit2(P)) keeps every read bank-conflict free (a pitch of 18 would conflict two ways on every row change).
     const int ph = wave >> 1, th = wave & 1;          // th: the wave's half of the 64 output channels = slab plane th (channel tiles 2 th, 2 th + 1 of the plane row order)
     const int ra = 1 - (ph >> 1), cb = 1 - (ph & 1);
-    int lrP[10], hrP[10];         // LR-tile pixel index of group g's pixel at tap (0, 0); HR-tile pixel index (row * 36 + column) it produces, -1: no pixel (v >= 153)
+    int lrP[10], hrO[10];         // LR-tile pixel index of group g's pixel at tap (0, 0); byte offset of the HR-tile pixel it produces (octet lg), -1: no pixel (v >= 153)
 #pragma unroll
     for (int g = 0; g < 10; ++g) {
         const int v = 16 * g + li;
         const int vv = v < 153 ? v : 152;
         const int k = (vv * 241) >> 12, m = vv - 17 * k;          // (v / 17 for v < 4096 / 17)
         lrP[g] = k * CH_LRP + m;
-        hrP[g] = v < 153 ? (2 * k + ra) * LWP + 2 * m + cb : -1;
+        hrO[g] = v < 153 ? (2 * k + ra) * (LWP * 64) + hr_slot(2 * m + cb, lg) * 16 : -1;
     }
-    // the phase's A fragments straight from the panel: fragment (group cg, tap rank, tile t) = 1 KB at cg * 16 KB + (rank * 64 + 16 t) * 64, lane (li, lg) reads row li, octet lg
-    // (buffer loads: ONE per-lane offset register and a scalar offset per fragment -- global loads off 64-bit per-lane pointers cost two address registers each)
+    // The phase's A fragments straight from the panel, ONCE per kernel: the wave's phase and channel half never change, so its sixteen fragments (2 input groups x 4 taps x
+    // 2 channel tiles, 64 registers) serve every tile -- no weight traffic at all in stage A.  Fragment (group cg, tap rank, tile t) = 1 KB at cg * 16 KB + (rank * 64 + 16 t) * 64,
+    // lane (li, lg) reads row li, octet lg (buffer loads: one per-lane offset register and a scalar offset per fragment).
     const int wa_voff = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
-    f16x8 wa[4][2];
-    auto load_wa = [&](int cg, int rank) __attribute__((always_inline)) {
+    f16x8 wa[8][2];
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (!CH_ABL(64)) {
         const __amdgpu_buffer_rsrc_t rwa = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wup + (long)ph * 2 * 16384 + th * 2048), 0, 2 * 16384, 0x00020000);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            wa[rank][t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rwa, wa_voff, cg * 16384 + (rank * 64 + t * 16) * 64, 0));
+        for (int sr = 0; sr < 8; ++sr)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                wa[sr][t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rwa, wa_voff, (sr >> 2) * 16384 + ((sr & 3) * 64 + t * 16) * 64, 0));
+    }
 #else
-        (void)cg; (void)rank; (void)wa_voff;
+    (void)wa_voff;
 #endif
-    };
 
     // ---- stage B, per-lane constants (conv3x3_pc's consumers: wave cw owns tile rows 2 cw, 2 cw + 1) ----
     const int cw = wave;
-    int boffs[3][2];
+    int boffs[3][2];              // byte offset of the wave's first halo row, column 16 seg + li + s, octet lg: [tap column s][segment]
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int sc = 0; sc < 3; ++sc)
 #pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int pb = cw * RPW * LWP + li + s;
-            const int rowpar = ((cw * RPW) & 1) ^ par;
-            boffs[s][par] = CH_HRT + pb * 64 + ((lg ^ (((((li + s) >> 2) & 1) ^ rowpar) << 1)) << 4);
-        }
+        for (int seg = 0; seg < 2; ++seg) boffs[sc][seg] = CH_HRT + cw * RPW * (LWP * 64) + hr_slot(16 * seg + li + sc, lg) * 16;
     const int aoffs = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
 
     // ---- LDS-DMA issue (every wave its share) ----
@@ -148,6 +162,7 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
     }
     auto issue_lr = [&](int n, int ty0, int tx0) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
+        if (CH_ABL(16)) return;
         const int Y = (ty0 >> 1) - 1, X = (tx0 >> 1) - 1;
         const char* base = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)Y * p.w + X) * 64;
         int vo[2] = {lroff[0], lroff[1]};
@@ -173,6 +188,7 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
     // stage B weights, step n = (group n / 3, tap column n % 3): 12 pieces of 1 KB -- piece j: tap row j / 4, quarter j % 4 of its 4 KB; waves 0 .. 7 issue j = w, waves 0 .. 3 also j = w + 8
     auto issue_wb = [&](int n) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
+        if (CH_ABL(32)) return;
         const int cg = n / 3, sc = n - 3 * cg;
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.whr, 0, 2 * 9 * 4096, 0x00020000);
         char* slot = smem + CH_WB + (n % 3) * CH_WB_SLOT;
@@ -204,89 +220,76 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
     issue_lr(n, ty0, tx0);
     issue_wb(0);
     issue_wb(1);
-    load_wa(0, 0); load_wa(0, 1); load_wa(0, 2); load_wa(0, 3);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
     for (int j = j0; j < run_len; j += slots) {
         const bool has_next = j + slots < run_len;
         // ================================ stage A: the up-conv's four phases on the 18 x 34 neighbourhood ================================
-        f32x4 acc[10][2];
+        asm volatile("s_barrier" ::: "memory");          // B1: every wave has left the previous tile's fused epilogue (its products lie in the HR tile)
         {
-            const float* bl = (const float*)(smem + CH_BUP) + ph * 64 + 32 * th + 8 * lg;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const f32x4 bt = *(const f32x4*)(bl + 4 * t);
-#pragma unroll
-                for (int g = 0; g < 10; ++g) acc[g][t] = bt;
-            }
-        }
-        {
-            // 80 pixel fragments in (group cg, tap, pixel group) order through a five-register ring, each read four MFMA pairs ahead of its use.  Taps in the order of the
-            // one-visit kernel's walk (tap column first: ranks 0, 2, 1, 3), input group 0 before 1: the order in which the unchained launch accumulated every value.
-            // The read address is derived from the group's pixel index as the read is issued (4 VALU instructions beside 2 MFMAs): hoisted out of the tile loop the
-            // eighty of them would be eighty registers.
+            // Pixel group by pixel group: 8 fragment reads (input group x tap) feed 16 MFMAs on the group's two accumulators, then its activation, fp16 rounding -- the
+            // values the unchained up-conv stored --, zeros outside the frame, and ONE 16-byte store into the HR tile (a lane's 8 channels are octet lg of its pixel in the
+            // wave's 32-channel group: plane row order); the epilogue of group g is placed inside the MFMAs of group g + 1.  Taps in the order of the one-visit kernel's walk
+            // (tap column first: ranks 0, 2, 1, 3), input group 0 before 1: the order in which the unchained launch accumulated every value.  The read address is derived
+            // from the group's pixel index as the read is issued (4 VALU instructions beside 2 MFMAs): hoisted out of the tile loop they would be forty registers.
             constexpr int NRD = 80, RING = 5, AHEAD = 4;
+            const bool edge = ty0 == 0 || ty0 + 16 >= p.kp.H || tx0 == 0 || tx0 + TW >= p.kp.W;
+            const float* bl = (const float*)(smem + CH_BUP) + ph * 64 + 32 * th + 8 * lg;
+            const f32x4 bias0 = *(const f32x4*)bl, bias1 = *(const f32x4*)(bl + 4);
             f16x8 bq[RING];
+            f32x4 acc[2][2];          // [group parity][channel tile]
             auto ldb = [&](int i) __attribute__((always_inline)) {
-                const int cg = i / 40, rem = i - 40 * cg, ti = rem / 10, g = rem - 10 * ti, rank = ((ti & 1) << 1) | (ti >> 1);
+                const int g = i >> 3, sr = i & 7, cg = sr >> 2, ti = sr & 3, rank = ((ti & 1) << 1) | (ti >> 1);
                 int P = lrP[g];
                 asm volatile("" : "+v"(P));
                 P += (rank >> 1) * CH_LRP + (rank & 1);
                 return *(const f16x8*)(smem + CH_LRT + cg * CH_LR_CG + P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4));
             };
+            auto store_group = [&](int g) __attribute__((always_inline)) {
+                f16x8 h;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        float f = acc[g & 1][t][jx];
+                        if (ACT_UP == 1) f = f > 0.f ? f : 0.2f * f;
+                        else if (ACT_UP == 2) f = f > 0.f ? f : 0.f;
+                        FP32_VALUE(f);
+                        h[4 * t + jx] = (f16)f;
+                    }
+                int O = hrO[g];
+                if (edge) {               // a tile on the frame's border: the neighbourhood's pixels outside the frame are HR_conv0's zero padding (selects, one uniform branch)
+                    int v = 16 * g + li;
+                    asm volatile("" : "+v"(v));          // (row / column re-derived here: hoisted, the twenty of them would be twenty registers)
+                    const int k = (v * 241) >> 12, m = v - 17 * k;
+                    const int y = ty0 - 1 + 2 * k + ra, x = tx0 - 1 + 2 * m + cb;
+                    const bool zero = y < 0 || y >= p.kp.H || x < 0 || x >= p.kp.W;
+                    u32x4 hv = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = zero ? 0u : hv[e];
+                    h = __builtin_bit_cast(f16x8, hv);
+                }
+                if (CH_ABL(2)) return;
+                if (g < 9 || O >= 0)          // (only the last group has lanes without a pixel)
+                    *(f16x8*)(smem + CH_HRT + th * CH_IN_BYTES + O) = h;
+            };
+            if (!CH_ABL(1)) {
 #pragma unroll
             for (int i = 0; i < AHEAD; ++i) bq[i] = ldb(i);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NRD; ++i) {
-                const int cg = i / 40, rem = i - 40 * cg, ti = rem / 10, g = rem - 10 * ti, rank = ((ti & 1) << 1) | (ti >> 1);
+                const int g = i >> 3, sr = i & 7, ti = sr & 3, wr = (sr & 4) | ((ti & 1) << 1) | (ti >> 1);          // wr: (input group, tap rank) of step sr
                 if (i + AHEAD < NRD) bq[(i + AHEAD) % RING] = ldb(i + AHEAD);
+                if (sr == 0) { acc[g & 1][0] = bias0; acc[g & 1][1] = bias1; }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[rank][t], bq[i % RING], acc[g][t], 0, 0, 0);
-                // the tap's fragments have issued their last MFMA of input group 0: fetch group 1's into the same registers (in flight under the other taps' MFMAs)
-                if (g == 9 && cg == 0) load_wa(1, rank);
+                for (int t = 0; t < 2; ++t) acc[g & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[wr][t], bq[i % RING], acc[g & 1][t], 0, 0, 0);
+                if (sr == 3 && g > 0) store_group(g - 1);          // (in the shadow of this group's MFMAs)
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        asm volatile("s_barrier" ::: "memory");          // B1: every wave has left the previous tile's fused epilogue (its products lie in the HR tile)
-        {
-            // epilogue A: activation, fp16 (the values the unchained up-conv stored), zeros outside the frame, into the HR tile: a lane's 8 channels are octet lg of
-            // its pixel in the wave's 32-channel group (plane row order).  The activation is chosen ONCE: a uniform test per value is a branch per value in unrolled code.
-            const bool edge = ty0 == 0 || ty0 + 16 >= p.kp.H || tx0 == 0 || tx0 + TW >= p.kp.W;
-            auto store_tile = [&](auto act_tag, auto edge_tag) __attribute__((always_inline)) {
-                constexpr int ACT = decltype(act_tag)::value;
-                constexpr bool EDGE = decltype(edge_tag)::value;
-#pragma unroll
-                for (int g = 0; g < 10; ++g) {
-                    f16x8 h;
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int jx = 0; jx < 4; ++jx) {
-                            float f = acc[g][t][jx];
-                            if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                            else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                            FP32_VALUE(f);
-                            h[4 * t + jx] = (f16)f;
-                        }
-                    const int P = hrP[g];
-                    if constexpr (EDGE) {          // a tile on the frame's border: the neighbourhood's pixels outside the frame are HR_conv0's zero padding (selects, no branch)
-                        int Pq = P;
-                        asm volatile("" : "+v"(Pq));          // (row / column re-derived here: hoisted, the twenty of them would be twenty registers)
-                        const int r = (Pq * 1821) >> 16, c = Pq - r * LWP;          // (P / 36 for P < 648)
-                        const int y = ty0 - 1 + r, x = tx0 - 1 + c;
-                        const bool zero = y < 0 || y >= p.kp.H || x < 0 || x >= p.kp.W;
-                        u32x4 hv = __builtin_bit_cast(u32x4, h);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hv[e] = zero ? 0u : hv[e];
-                        h = __builtin_bit_cast(f16x8, hv);
-                    }
-                    if (g < 9 || P >= 0)          // (only the last group has lanes without a pixel)
-                        *(f16x8*)(smem + CH_HRT + th * CH_IN_BYTES + P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4)) = h;
-                }
-            };
-            if (edge) store_tile(std::integral_constant<int, ACT_UP>{}, std::true_type{});
-            else store_tile(std::integral_constant<int, ACT_UP>{}, std::false_type{});
+            store_group(9);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");          // B2: the HR tile is complete; the LR tile is free
@@ -317,11 +320,12 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             f16x8 bq[3];
             auto ldb = [&](int i) __attribute__((always_inline)) {          // i = step * 8 + halo row * 2 + segment
                 const int st = i >> 3, jj = i & 7, rr = jj >> 1, seg = jj & 1, cg = st / 3, sc = st - 3 * cg;
-                return *(const f16x8*)(smem + cg * CH_IN_BYTES + boffs[sc][rr & 1] + (rr * LWP + seg * 16) * 64);
+                return *(const f16x8*)(smem + cg * CH_IN_BYTES + boffs[sc][seg] + rr * (LWP * 64));
             };
-            bq[0] = ldb(0); bq[1] = ldb(1);
+            if (!CH_ABL(4)) { bq[0] = ldb(0); bq[1] = ldb(1); }
 #pragma unroll
             for (int st = 0; st < 6; ++st) {
+                if (!CH_ABL(4))
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     const int i = st * 8 + jj, rr = jj >> 1, seg = jj & 1;
@@ -355,10 +359,8 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             }
         }
         wait_vm_all();                                   // (the next tile's LR tile, issued a whole stage ago, and its first two weight pieces: visible to every wave behind the epilogue's barriers)
-        // stage A's weights of the NEXT tile's first input group (the panels do not depend on the tile): in flight under the epilogue, not held across stage B
-        if (has_next) { load_wa(0, 0); load_wa(0, 1); load_wa(0, 2); load_wa(0, 3); }
         // ================================ conv_last in the epilogue (conv3x3_fuse.h; three workgroup barriers) ================================
-        fused_last_epilogue<RPW, NT>(p.kp, acc2, smem + CH_HRT, smem + CH_FLW, n, ty0, tx0, cw, lane, lid);
+        if (!CH_ABL(8)) fused_last_epilogue<RPW, NT>(p.kp, acc2, smem + CH_HRT, smem + CH_FLW, n, ty0, tx0, cw, lane, lid);
         lid = lid2; n = n2; ty0 = ty2; tx0 = tx2;
     }
 }
@@ -394,6 +396,9 @@ int hr_chain_launch(const ConvLaunch& L, const f16* up_in, long up_in_gstride, c
     c.N = L.N; c.tiles_x = L.W / TW; c.tiles_y = L.H / 16;
     const long total = (long)L.N * c.tiles_x * c.tiles_y;
     c.total = (int)total; c.rev = L.rev ? 1 : 0;
+#ifdef INNFER_ABLATE
+    c.abl = getenv("INNFER_ABL") ? atoi(getenv("INNFER_ABL")) : 0;
+#endif
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const long grid = total < cus ? total : cus;
