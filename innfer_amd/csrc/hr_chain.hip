@@ -114,13 +114,13 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
     // 2 bit2(P)) keeps every read bank-conflict free (a pitch of 18 would conflict two ways on every row change).
     const int ph = wave >> 1, th = wave & 1;          // th: the wave's half of the 64 output channels = slab plane th (channel tiles 2 th, 2 th + 1 of the plane row order)
     const int ra = 1 - (ph >> 1), cb = 1 - (ph & 1);
-    int lrP[10], hrO[10];         // LR-tile pixel index of group g's pixel at tap (0, 0); byte offset of the HR-tile pixel it produces (octet lg), -1: no pixel (v >= 153)
+    int lrQ[10], hrO[10];         // byte offset of the LR-tile pixel of group g at tap (0, 0), octet lg, BEFORE the slot swizzle (pixel * 64 + 16 lg); byte offset of the HR-tile pixel it produces (octet lg), -1: no pixel (v >= 153)
 #pragma unroll
     for (int g = 0; g < 10; ++g) {
         const int v = 16 * g + li;
         const int vv = v < 153 ? v : 152;
         const int k = (vv * 241) >> 12, m = vv - 17 * k;          // (v / 17 for v < 4096 / 17)
-        lrP[g] = k * CH_LRP + m;
+        lrQ[g] = (k * CH_LRP + m) * 64 + lg * 16;
         hrO[g] = v < 153 ? (2 * k + ra) * (LWP * 64) + hr_slot(2 * m + cb, lg) * 16 : -1;
     }
     // The phase's A fragments straight from the panel, ONCE per kernel: the wave's phase and channel half never change, so its sixteen fragments (2 input groups x 4 taps x
@@ -239,12 +239,20 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             const f32x4 bias0 = *(const f32x4*)bl, bias1 = *(const f32x4*)(bl + 4);
             f16x8 bq[RING];
             f32x4 acc[2][2];          // [group parity][channel tile]
+            // Read addresses: pixel P + tap, octet lg at byte (P + tap) * 64 + 16 (lg ^ 2 bit2(P + tap)) -- with w = the unswizzled offset (bit 8 of w = bit2 of the pixel,
+            // bits 4, 5 = lg) that is w ^ ((w >> 3) & 32): three VALU instructions per address, four addresses per pixel group (input group 1 = + 16 KB, an immediate).
+            // The tap terms pass through an opaque register once per tile so that the forty sums are not hoisted out of the tile loop (forty registers).
+            int tap64[4];
+#pragma unroll
+            for (int rk = 0; rk < 4; ++rk) { tap64[rk] = ((rk >> 1) * CH_LRP + (rk & 1)) * 64; asm volatile("" : "+v"(tap64[rk])); }
+            int ad[4];
             auto ldb = [&](int i) __attribute__((always_inline)) {
                 const int g = i >> 3, sr = i & 7, cg = sr >> 2, ti = sr & 3, rank = ((ti & 1) << 1) | (ti >> 1);
-                int P = lrP[g];
-                asm volatile("" : "+v"(P));
-                P += (rank >> 1) * CH_LRP + (rank & 1);
-                return *(const f16x8*)(smem + CH_LRT + cg * CH_LR_CG + P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4));
+                if (cg == 0) {
+                    const int w = lrQ[g] + tap64[rank];
+                    ad[ti] = w ^ ((w >> 3) & 32);
+                }
+                return *(const f16x8*)(smem + CH_LRT + cg * CH_LR_CG + ad[ti]);
             };
             auto store_group = [&](int g) __attribute__((always_inline)) {
                 f16x8 h;
@@ -253,8 +261,11 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx) {
                         float f = acc[g & 1][t][jx];
-                        if (ACT_UP == 1) f = f > 0.f ? f : 0.2f * f;
-                        else if (ACT_UP == 2) f = f > 0.f ? f : 0.f;
+                        // (LeakyReLU as max(f, 0.2 f) == f > 0 ? f : 0.2 f for every finite f.  As v_med3_f32(f, 0.2 f, +inf): the builtin max is the IEEE maxnum, which
+                        //  canonicalises its operand first -- three instructions per value like compare + select, and this stage is bound by vector issue; an inline-asm
+                        //  v_max_f32 is invisible to the hazard recogniser -- as the first reader of an MFMA result it read stale registers)
+                        if (ACT_UP == 1) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, __builtin_inff());
+                        else if (ACT_UP == 2) f = __builtin_amdgcn_fmed3f(f, 0.f, __builtin_inff());
                         FP32_VALUE(f);
                         h[4 * t + jx] = (f16)f;
                     }
@@ -279,14 +290,17 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             for (int i = 0; i < AHEAD; ++i) bq[i] = ldb(i);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < NRD; ++i) {
-                const int g = i >> 3, sr = i & 7, ti = sr & 3, wr = (sr & 4) | ((ti & 1) << 1) | (ti >> 1);          // wr: (input group, tap rank) of step sr
-                if (i + AHEAD < NRD) bq[(i + AHEAD) % RING] = ldb(i + AHEAD);
-                if (sr == 0) { acc[g & 1][0] = bias0; acc[g & 1][1] = bias1; }
+            for (int g = 0; g < 10; ++g) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[g & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[wr][t], bq[i % RING], acc[g & 1][t], 0, 0, 0);
-                if (sr == 3 && g > 0) store_group(g - 1);          // (in the shadow of this group's MFMAs)
-                __builtin_amdgcn_sched_barrier(0);
+                for (int sr = 0; sr < 8; ++sr) {
+                    const int i = 8 * g + sr, ti = sr & 3, wr = (sr & 4) | ((ti & 1) << 1) | (ti >> 1);          // wr: (input group, tap rank) of step sr
+                    if (i + AHEAD < NRD) bq[(i + AHEAD) % RING] = ldb(i + AHEAD);
+                    // (a group's first MFMAs take the bias as their C operand: no moves)
+                    acc[g & 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[wr][0], bq[i % RING], sr == 0 ? bias0 : acc[g & 1][0], 0, 0, 0);
+                    acc[g & 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[wr][1], bq[i % RING], sr == 0 ? bias1 : acc[g & 1][1], 0, 0, 0);
+                    if (sr == 3 && g > 0) store_group(g - 1);          // (in the shadow of this group's MFMAs)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             store_group(9);
             }
