@@ -114,14 +114,15 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
     // 2 bit2(P)) keeps every read bank-conflict free (a pitch of 18 would conflict two ways on every row change).
     const int ph = wave >> 1, th = wave & 1;          // th: the wave's half of the 64 output channels = slab plane th (channel tiles 2 th, 2 th + 1 of the plane row order)
     const int ra = 1 - (ph >> 1), cb = 1 - (ph & 1);
-    int lrQ[10], hrO[10];         // byte offset of the LR-tile pixel of group g at tap (0, 0), octet lg, BEFORE the slot swizzle (pixel * 64 + 16 lg); byte offset of the HR-tile pixel it produces (octet lg), -1: no pixel (v >= 153)
+    int lrhr[10];                 // per pixel group, packed (the kernel lives at its register budget): low 16 bits = byte offset of the LR-tile pixel at tap (0, 0), octet lg, BEFORE the
+                                  // slot swizzle (pixel * 64 + 16 lg); high 16 bits = byte offset of the HR-tile pixel it produces (octet lg), 0xFFFF: no pixel (v >= 153)
 #pragma unroll
     for (int g = 0; g < 10; ++g) {
         const int v = 16 * g + li;
         const int vv = v < 153 ? v : 152;
         const int k = (vv * 241) >> 12, m = vv - 17 * k;          // (v / 17 for v < 4096 / 17)
-        lrQ[g] = (k * CH_LRP + m) * 64 + lg * 16;
-        hrO[g] = v < 153 ? (2 * k + ra) * (LWP * 64) + hr_slot(2 * m + cb, lg) * 16 : -1;
+        static_assert(18 * LWP * 64 < 0xFFFF && 10 * CH_LRP * 64 < 0x10000, "both offsets fit 16 bits");
+        lrhr[g] = ((k * CH_LRP + m) * 64 + lg * 16) | ((v < 153 ? (2 * k + ra) * (LWP * 64) + hr_slot(2 * m + cb, lg) * 16 : 0xFFFF) << 16);
     }
     // The phase's A fragments straight from the panel, ONCE per kernel: the wave's phase and channel half never change, so its sixteen fragments (2 input groups x 4 taps x
     // 2 channel tiles, 64 registers) serve every tile -- no weight traffic at all in stage A.  Fragment (group cg, tap rank, tile t) = 1 KB at cg * 16 KB + (rank * 64 + 16 t) * 64,
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             auto ldb = [&](int i) __attribute__((always_inline)) {
                 const int g = i >> 3, sr = i & 7, cg = sr >> 2, ti = sr & 3, rank = ((ti & 1) << 1) | (ti >> 1);
                 if (cg == 0) {
-                    const int w = lrQ[g] + tap64[rank];
+                    const int w = (lrhr[g] & 0xFFFF) + tap64[rank];
                     ad[ti] = w ^ ((w >> 3) & 32);
                 }
                 return *(const f16x8*)(smem + CH_LRT + cg * CH_LR_CG + ad[ti]);
@@ -269,10 +270,13 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
                         FP32_VALUE(f);
                         h[4 * t + jx] = (f16)f;
                     }
-                int O = hrO[g];
+                int pk = lrhr[g];
+                asm volatile("" : "+v"(pk));          // (opaque: the ten store addresses derived from it would be hoisted out of the tile loop and spilled)
+                const int O = (int)((unsigned)pk >> 16);
                 if (edge) {               // a tile on the frame's border: the neighbourhood's pixels outside the frame are HR_conv0's zero padding (selects, one uniform branch)
-                    int v = 16 * g + li;
+                    int v = li;
                     asm volatile("" : "+v"(v));          // (row / column re-derived here: hoisted, the twenty of them would be twenty registers)
+                    v += 16 * g;
                     const int k = (v * 241) >> 12, m = v - 17 * k;
                     const int y = ty0 - 1 + 2 * k + ra, x = tx0 - 1 + 2 * m + cb;
                     const bool zero = y < 0 || y >= p.kp.H || x < 0 || x >= p.kp.W;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
                     h = __builtin_bit_cast(f16x8, hv);
                 }
                 if (CH_ABL(2)) return;
-                if (g < 9 || O >= 0)          // (only the last group has lanes without a pixel)
+                if (g < 9 || O != 0xFFFF)          // (only the last group has lanes without a pixel)
                     *(f16x8*)(smem + CH_HRT + th * CH_IN_BYTES + O) = h;
             };
             if (!CH_ABL(1)) {
@@ -305,19 +309,24 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             store_group(9);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // (vmcnt: this wave's piece(s) of stage B's step 1, issued behind the previous tile's epilogue)
         asm volatile("s_barrier" ::: "memory");          // B2: the HR tile is complete; the LR tile is free
         issue_wb(2);
         int lid2 = 0, n2 = 0, ty2 = 0, tx2 = 0;
         if (has_next) { decode(j + slots, lid2, n2, ty2, tx2); issue_lr(n2, ty2, tx2); }
 
         // ================================ stage B: HR_conv0 on the LDS-resident tile ================================
-        f16x8 a[3][NT];
-        auto lda = [&](int slot, int r) __attribute__((always_inline)) {
+        // conv3x3_pc's nine-tap walk, one TAP per sub-step u = 3 * step + kernel row r (step = (input group, tap column): one 12-KB ring slot): the tap's four weight fragments
+        // against the 2 x 2 pixel fragments (output rows 0, 1 of the wave = halo rows r, r + 1; two segments) it meets -- 16 MFMAs.  Per output value the taps arrive in
+        // conv3x3_pc's order (column by column, kernel rows ascending).  Two fragment sets of four (the next tap's load under this tap's MFMAs) instead of conv3x3_pc's
+        // twelve live fragments: 16 registers that stage A's resident weights need (20 % more pixel-fragment reads; LDS has the room).
+        f16x8 a[2][NT];
+        auto lda = [&](int u) __attribute__((always_inline)) {          // tap u -> set u & 1; ring slot (u / 3) % 3
+            const int st = u / 3, r = u - 3 * st;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a[r][t] = *(const f16x8*)(smem + CH_WB + slot * CH_WB_SLOT + aoffs + (r * 64 + t * 16) * 64);
+            for (int t = 0; t < NT; ++t) a[u & 1][t] = *(const f16x8*)(smem + CH_WB + (st % 3) * CH_WB_SLOT + aoffs + (r * 64 + t * 16) * 64);
         };
-        lda(0, 0); lda(0, 1); lda(0, 2);
+        lda(0);
         f32x4 acc2[NT][MT];
         {
             const float* bl = (const float*)(smem + CH_BHR) + 8 * lg;
@@ -329,11 +338,9 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             }
         }
         {
-            // conv3x3_pc's software-pipelined nine-tap walk, one tap column per step: 8 pixel fragments (halo rows 0 .. 3 x 2 segments) through the ring, the next
-            // column's weight fragments overwrite this column's as soon as their last MFMA is issued -- from the NEXT ring slot, visible since the previous barrier.
             f16x8 bq[3];
-            auto ldb = [&](int i) __attribute__((always_inline)) {          // i = step * 8 + halo row * 2 + segment
-                const int st = i >> 3, jj = i & 7, rr = jj >> 1, seg = jj & 1, cg = st / 3, sc = st - 3 * cg;
+            auto ldb = [&](int i) __attribute__((always_inline)) {          // i = 4 u + 2 (output row) + segment
+                const int u = i >> 2, st = u / 3, r = u - 3 * st, cg = st / 3, sc = st - 3 * cg, rr = r + ((i >> 1) & 1), seg = i & 1;
                 return *(const f16x8*)(smem + cg * CH_IN_BYTES + boffs[sc][seg] + rr * (LWP * 64));
             };
             if (!CH_ABL(4)) { bq[0] = ldb(0); bq[1] = ldb(1); }
@@ -341,24 +348,18 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             for (int st = 0; st < 6; ++st) {
                 if (!CH_ABL(4))
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int i = st * 8 + jj, rr = jj >> 1, seg = jj & 1;
-                    if (i + 2 < 48) bq[(i + 2) % 3] = ldb(i + 2);
+                for (int r = 0; r < 3; ++r) {
+                    const int u = 3 * st + r;
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const int rw = rr - r;
-                        if (rw >= 0 && rw < RPW) {
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 4 * u + q, m = q;                       // m = 2 (output row) + segment
+                        if (i + 2 < 72) bq[(i + 2) % 3] = ldb(i + 2);
+                        if (q == 0 && u + 1 < 18) lda(u + 1);                 // (step st + 1's slot is visible since the barrier before step st)
 #pragma unroll
-                            for (int t = 0; t < NT; ++t)
-                                acc2[t][rw * 2 + seg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[r][t], bq[i % 3], acc2[t][rw * 2 + seg], 0, 0, 0);
-                        }
+                        for (int t = 0; t < NT; ++t)
+                            acc2[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1][t], bq[i % 3], acc2[t][m], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (st < 5 && seg == 1) {
-                        if (rr == RPW - 1) lda((st + 1) % 3, 0);
-                        if (rr == RPW) lda((st + 1) % 3, 1);
-                        if (rr == RPW + 1) lda((st + 1) % 3, 2);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (st < 4) {
                     // end of step st: the piece(s) of step st + 2 this wave issued a step ago have landed (step 0: the next tile's LR pieces, issued after them, may stay in flight)
@@ -366,15 +367,22 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
                     else wait_vm_all();
                     asm volatile("s_barrier" ::: "memory");          // steps st + 1, st + 2 are visible; the slots of steps <= st are free
                     if (st + 3 < 6) issue_wb(st + 3);
-                    // after step 3 the ring's slots 0 and 1 (steps 3 and 4: their fragments are in registers by now) take the NEXT tile's steps 0 and 1 -- the panels do
-                    // not depend on the tile; steps 4 and 5 run without a barrier
-                    if (st == 3 && has_next) { issue_wb(0); issue_wb(1); }
+                    // after step 3 the ring's slot 0 (step 3's: its fragments are in registers by now) takes the NEXT tile's step 0 -- the panels do not depend on the
+                    // tile; steps 4 and 5 run without a barrier (slot 1 = step 4's is refilled behind the epilogue's barriers, slot 2 = step 5's behind B2)
+                    if (st == 3 && has_next) issue_wb(0);
                 }
             }
         }
-        wait_vm_all();                                   // (the next tile's LR tile, issued a whole stage ago, and its first two weight pieces: visible to every wave behind the epilogue's barriers)
+        wait_vm_all();                                   // (the next tile's LR tile, issued a whole stage ago, and its first weight piece: visible to every wave behind the epilogue's barriers)
         // ================================ conv_last in the epilogue (conv3x3_fuse.h; three workgroup barriers) ================================
-        if (!CH_ABL(8)) fused_last_epilogue<RPW, NT>(p.kp, acc2, smem + CH_HRT, smem + CH_FLW, n, ty0, tx0, cw, lane, lid);
+        {
+            // (an opaque per-tile copy of the lane index: otherwise the epilogue's per-lane addresses, ring indices and predicates -- all tile-invariant -- are hoisted
+            //  out of the tile loop and held across stages A and B, which then spill: ~100 registers)
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            if (!CH_ABL(8)) fused_last_epilogue<RPW, NT>(p.kp, acc2, smem + CH_HRT, smem + CH_FLW, n, ty0, tx0, cw, lane_t, lid);
+        }
+        if (has_next) issue_wb(1);                       // (every wave is past step 4: the epilogue's barriers; it lands under the next tile's stage A and is waited for before B2)
         lid = lid2; n = n2; ty0 = ty2; tx0 = tx2;
     }
 }
