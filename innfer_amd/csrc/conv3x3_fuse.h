@@ -36,13 +36,14 @@ __device__ __forceinline__ void fuse_store_pixel(void* out, int mode, int denorm
         }
 }
 
-// The fused last conv (see the FUSE flag of conv3x3_pc).  acc: this wave's 2 rows x 32 pixels x 64 channels (bias included); pl: the LDS stage the tile has
-// finished with (>= 64 KB); aw: the last conv's four A fragments in LDS; tile: the tile's index over the batch (n, ty, tx).
+// The fused last conv (see the FUSE flag of conv3x3_pc) in two halves -- fused_last_epilogue below runs them back to back; csrc/hr_chain.hip puts other work between them.
+// fused_last_products: acc = this wave's 2 rows x 32 pixels x 64 channels (bias included) -> activation, fp16, the 27 x 64 last-conv matrix on the matrix cores, the 27 products per
+// pixel parked in `pl` (the LDS stage the tile has finished with, >= 64 KB; every wave must be past its last read of it: the caller's barrier); aw: the last conv's four A fragments
+// in LDS.  The caller makes the products visible (s_waitcnt lgkmcnt(0) + barrier) before fused_last_sums.
 template <int RPW, int NT>
-__device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT][2 * RPW], char* pl, const char* aw, int n, int ty0, int tx0, int cw, int lane, int tile) {
+__device__ __forceinline__ void fused_last_products(const KP& p, f32x4 (&acc)[NT][2 * RPW], char* pl, const char* aw, int cw, int lane) {
     constexpr int MT = 2 * RPW;
     const int li = lane & 15, lg = lane >> 4;
-    asm volatile("s_barrier" ::: "memory");                   // every consumer has read its last fragments of this stage: it may be overwritten
     // (three phases with short live ranges -- the kernel's main loop already sits at the 168-register budget: the fp16 fragments of all four pixel tiles first
     //  (the 64 accumulator registers die there), then one A fragment at a time against all of them, then the stores)
     constexpr int KS = NT / 2;                              // 32-channel k-steps: 2 for the 64-channel kernel; 1 for the 32-channel one (round 5: PAN's HRconv + conv_last)
@@ -90,8 +91,12 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
                 if (NT == 4 || rt == 0 || lg < 3)
                     *(float*)(plw + ((16 * rt + j) * FUSE_PITCH + (m >> 1) * 32 + (m & 1) * 16) * 4) = pa[rt][m][j];
             }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");                   // the tile's products are in LDS
+}
+
+// fused_last_sums: every output pixel of the tile's 18 x 34 neighbourhood sums the nine products that lie inside the tile (see the FUSE flag of conv3x3_pc); tile: the tile's index
+// over the batch (n, ty, tx).
+template <int RPW>
+__device__ __forceinline__ void fused_last_sums(const KP& p, const char* pl, int n, int ty0, int tx0, int cw, int lane, int tile) {
     // Every lane sums its OWN pixel of the tile (512 lanes, 512 pixels: no division, the row tests are uniform but for the first / last wave) ...
     {
         const int Y = cw * RPW + (lane >> 5), X = lane & 31;
@@ -136,6 +141,17 @@ __device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT
         float* sd = p.fl_side + ((long)tile * FUSE_RING + fuse_ring_index(Y, X)) * 3;
         sd[0] = S0; sd[1] = S1; sd[2] = S2;
     }
+}
+
+// acc: this wave's 2 rows x 32 pixels x 64 channels (bias included); pl: the LDS stage the tile has finished with (>= 64 KB); aw: the last conv's four A fragments in LDS; tile: the
+// tile's index over the batch (n, ty, tx).
+template <int RPW, int NT>
+__device__ __forceinline__ void fused_last_epilogue(const KP& p, f32x4 (&acc)[NT][2 * RPW], char* pl, const char* aw, int n, int ty0, int tx0, int cw, int lane, int tile) {
+    asm volatile("s_barrier" ::: "memory");                   // every consumer has read its last fragments of this stage: it may be overwritten
+    fused_last_products<RPW, NT>(p, acc, pl, aw, cw, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");                   // the tile's products are in LDS
+    fused_last_sums<RPW>(p, pl, n, ty0, tx0, cw, lane, tile);
 }
 
 // Finishes the rim pixels of the fused last conv: every pixel on the rim of a tile sums, in a fixed order, the partial sums of the tiles whose 18 x 34

@@ -75,6 +75,15 @@ static_assert(2 * CH_IN_BYTES >= 27 * FUSE_PITCH * 4, "the fused last conv parks
 // were 0.7 of the first version's 4.1 ms).
 __host__ __device__ constexpr int hr_slot(int col, int oct) { return 4 * (col >> 1) + ((oct + (col >> 1)) & 3) + 72 * (col & 1); }
 
+struct ChGrp { int w, lr1, lr2, hrA1, hrA2, c1, c2; };
+// pixel group g of stage A: lanes li < w are in lattice row k_g, column m0 + li; the others in row k_g + 1, column m0 + li - 17.
+//   LR-tile pixel (tap 0, 0), unswizzled byte offset  = li * 64 + lg * 16 + (li < w ? lr1 : lr2)
+//   HR-tile pixel, byte offset (hr_slot image)        = (ra * 36 * 64 + cb * 72 * 16) + li * 64 + 16 ((lg + li + (li < w ? c1 : c2)) & 3) + (li < w ? hrA1 : hrA2)
+constexpr ChGrp ch_grp(int g) {
+    const int v0 = 16 * g, k = v0 / 17, m0 = v0 - 17 * k;
+    return ChGrp{17 - m0, (k * 25 + m0) * 64, ((k + 1) * 25 + m0 - 17) * 64, 2 * k * 36 * 64 + 64 * m0, 2 * (k + 1) * 36 * 64 + 64 * (m0 - 17), m0 & 3, (m0 - 17) & 3};
+}
+
 // ACT_UP: the up-conv's activation (1 LeakyReLU(0.2), 2 ReLU) -- compile-time: a run-time choice triples the unrolled epilogue of stage A
 template <int ACT_UP>
 __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
@@ -114,16 +123,10 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
     // 2 bit2(P)) keeps every read bank-conflict free (a pitch of 18 would conflict two ways on every row change).
     const int ph = wave >> 1, th = wave & 1;          // th: the wave's half of the 64 output channels = slab plane th (channel tiles 2 th, 2 th + 1 of the plane row order)
     const int ra = 1 - (ph >> 1), cb = 1 - (ph & 1);
-    int lrhr[10];                 // per pixel group, packed (the kernel lives at its register budget): low 16 bits = byte offset of the LR-tile pixel at tap (0, 0), octet lg, BEFORE the
-                                  // slot swizzle (pixel * 64 + 16 lg); high 16 bits = byte offset of the HR-tile pixel it produces (octet lg), 0xFFFF: no pixel (v >= 153)
-#pragma unroll
-    for (int g = 0; g < 10; ++g) {
-        const int v = 16 * g + li;
-        const int vv = v < 153 ? v : 152;
-        const int k = (vv * 241) >> 12, m = vv - 17 * k;          // (v / 17 for v < 4096 / 17)
-        static_assert(18 * LWP * 64 < 0xFFFF && 10 * CH_LRP * 64 < 0x10000, "both offsets fit 16 bits");
-        lrhr[g] = ((k * CH_LRP + m) * 64 + lg * 16) | ((v < 153 ? (2 * k + ra) * (LWP * 64) + hr_slot(2 * m + cb, lg) * 16 : 0xFFFF) << 16);
-    }
+    // Group g holds virtual pixels v = 16 g + li: rows k_g (lanes li < w_g) and k_g + 1 (the others) of the 9 x 17 lattice -- the per-lane offsets of its LR-tile pixel and
+    // of the HR-tile pixel it produces are a lane term plus one of two COMPILE-TIME constants per group (ch_grp below): a compare and a select where ten tile-invariant
+    // registers were held (and spilled: the kernel lives at its register budget).  Lanes li >= 9 of group 9 (v >= 153) have no pixel: they read inside the LDS
+    // allocation, compute into their own MFMA columns and store nothing.
     // The phase's A fragments straight from the panel, ONCE per kernel: the wave's phase and channel half never change, so its sixteen fragments (2 input groups x 4 taps x
     // 2 channel tiles, 64 registers) serve every tile -- no weight traffic at all in stage A.  Fragment (group cg, tap rank, tile t) = 1 KB at cg * 16 KB + (rank * 64 + 16 t) * 64,
     // lane (li, lg) reads row li, octet lg (buffer loads: one per-lane offset register and a scalar offset per fragment).
@@ -243,6 +246,9 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             // Read addresses: pixel P + tap, octet lg at byte (P + tap) * 64 + 16 (lg ^ 2 bit2(P + tap)) -- with w = the unswizzled offset (bit 8 of w = bit2 of the pixel,
             // bits 4, 5 = lg) that is w ^ ((w >> 3) & 32): three VALU instructions per address, four addresses per pixel group (input group 1 = + 16 KB, an immediate).
             // The tap terms pass through an opaque register once per tile so that the forty sums are not hoisted out of the tile loop (forty registers).
+            int li_t = li, lane64 = li * 64 + lg * 16, sum_t = li + lg;          // (opaque per tile, like the tap terms)
+            asm volatile("" : "+v"(li_t), "+v"(lane64), "+v"(sum_t));
+            const int hr0 = CH_HRT + th * CH_IN_BYTES + ra * (LWP * 64) + cb * (72 * 16) + li_t * 64;
             int tap64[4];
 #pragma unroll
             for (int rk = 0; rk < 4; ++rk) { tap64[rk] = ((rk >> 1) * CH_LRP + (rk & 1)) * 64; asm volatile("" : "+v"(tap64[rk])); }
@@ -250,7 +256,8 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
             auto ldb = [&](int i) __attribute__((always_inline)) {
                 const int g = i >> 3, sr = i & 7, cg = sr >> 2, ti = sr & 3, rank = ((ti & 1) << 1) | (ti >> 1);
                 if (cg == 0) {
-                    const int w = (lrhr[g] & 0xFFFF) + tap64[rank];
+                    const ChGrp G = ch_grp(g);          // (g is a constant of the unrolled loop)
+                    const int w = lane64 + (li_t < G.w ? G.lr1 : G.lr2) + tap64[rank];
                     ad[ti] = w ^ ((w >> 3) & 32);
                 }
                 return *(const f16x8*)(smem + CH_LRT + cg * CH_LR_CG + ad[ti]);
@@ -270,9 +277,6 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
                         FP32_VALUE(f);
                         h[4 * t + jx] = (f16)f;
                     }
-                int pk = lrhr[g];
-                asm volatile("" : "+v"(pk));          // (opaque: the ten store addresses derived from it would be hoisted out of the tile loop and spilled)
-                const int O = (int)((unsigned)pk >> 16);
                 if (edge) {               // a tile on the frame's border: the neighbourhood's pixels outside the frame are HR_conv0's zero padding (selects, one uniform branch)
                     int v = li;
                     asm volatile("" : "+v"(v));          // (row / column re-derived here: hoisted, the twenty of them would be twenty registers)
@@ -286,8 +290,11 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
                     h = __builtin_bit_cast(f16x8, hv);
                 }
                 if (CH_ABL(2)) return;
-                if (g < 9 || O != 0xFFFF)          // (only the last group has lanes without a pixel)
-                    *(f16x8*)(smem + CH_HRT + th * CH_IN_BYTES + O) = h;
+                const ChGrp G = ch_grp(g);
+                const bool first = li_t < G.w;
+                const int O = hr0 + (first ? G.hrA1 : G.hrA2) + (((sum_t + (first ? G.c1 : G.c2)) & 3) << 4);
+                if (g < 9 || first)          // (only the last group has lanes without a pixel: its second row, v >= 153)
+                    *(f16x8*)(smem + O) = h;
             };
             if (!CH_ABL(1)) {
 #pragma unroll
