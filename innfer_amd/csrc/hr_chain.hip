@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
         asm volatile("s_barrier" ::: "memory");          // B2: the HR tile is complete; the LR tile is free
         issue_wb(2);
         int lid2 = 0, n2 = 0, ty2 = 0, tx2 = 0;
-        if (has_next) { decode(j + slots, lid2, n2, ty2, tx2); issue_lr(n2, ty2, tx2); }
+        if (has_next) decode(j + slots, lid2, n2, ty2, tx2);
 
         // ================================ stage B: HR_conv0 on the LDS-resident tile ================================
         // conv3x3_pc's nine-tap walk, one TAP per sub-step u = 3 * step + kernel row r (step = (input group, tap column): one 12-KB ring slot): the tap's four weight fragments
@@ -369,25 +369,32 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
                     }
                 }
                 if (st < 4) {
-                    // end of step st: the piece(s) of step st + 2 this wave issued a step ago have landed (step 0: the next tile's LR pieces, issued after them, may stay in flight)
-                    if (st == 0 && has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    // end of step st: the piece(s) of step st + 2 this wave issued a step ago have landed (step 3: the next tile's LR pieces, issued after them, stay in flight)
+                    if (st == 3 && has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else wait_vm_all();
                     asm volatile("s_barrier" ::: "memory");          // steps st + 1, st + 2 are visible; the slots of steps <= st are free
                     if (st + 3 < 6) issue_wb(st + 3);
+                    // the next tile's LR tile behind the last weight piece: the only traffic here that may come from HBM gets steps 3 .. 5 and the epilogue's first half to land,
+                    // and no weight wait ever waits for it (issued behind B2 it was waited for with step 3's piece: 0.2 of 3.9 ms in the ablation)
+                    if (st == 2 && has_next) issue_lr(n2, ty2, tx2);
                     // after step 3 the ring's slot 0 (step 3's: its fragments are in registers by now) takes the NEXT tile's step 0 -- the panels do not depend on the
                     // tile; steps 4 and 5 run without a barrier (slot 1 = step 4's is refilled behind the epilogue's barriers, slot 2 = step 5's behind B2)
                     if (st == 3 && has_next) issue_wb(0);
                 }
             }
         }
-        wait_vm_all();                                   // (the next tile's LR tile, issued a whole stage ago, and its first weight piece: visible to every wave behind the epilogue's barriers)
-        // ================================ conv_last in the epilogue (conv3x3_fuse.h; three workgroup barriers) ================================
+        // ================================ conv_last in the epilogue (conv3x3_fuse.h) ================================
         {
             // (an opaque per-tile copy of the lane index: otherwise the epilogue's per-lane addresses, ring indices and predicates -- all tile-invariant -- are hoisted
             //  out of the tile loop and held across stages A and B, which then spill: ~100 registers)
             int lane_t = lane;
             asm volatile("" : "+v"(lane_t));
-            if (!CH_ABL(8)) fused_last_epilogue<RPW, NT>(p.kp, acc2, smem + CH_HRT, smem + CH_FLW, n, ty0, tx0, cw, lane_t, lid);
+            asm volatile("s_barrier" ::: "memory");          // every wave has read its last fragments of the HR tile: it may be overwritten
+            if (!CH_ABL(8)) fused_last_products<RPW, NT>(p.kp, acc2, smem + CH_HRT, smem + CH_FLW, cw, lane_t);
+            // the next tile's LR tile and first weight piece have landed (before the sums' global stores join the queue): visible to every wave behind the barrier
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");          // the tile's products are in LDS
+            if (!CH_ABL(8)) fused_last_sums<RPW>(p.kp, smem + CH_HRT, n, ty0, tx0, cw, lane_t, lid);
         }
         if (has_next) issue_wb(1);                       // (every wave is past step 4: the epilogue's barriers; it lands under the next tile's stage A and is waited for before B2)
         lid = lid2; n = n2; ty0 = ty2; tx0 = tx2;

@@ -2168,7 +2168,8 @@ def test_hr_chain_equals_the_launches_it_replaces(dev):
     from innfer_amd import synth
     from innfer_amd.architectures.RRDBNet_arch import RRDBNet
     cases = [(4, 1, 8, 16, "leakyrelu"), (4, 1, 24, 40, "leakyrelu"), (4, 2, 28, 56, "leakyrelu"), (2, 1, 48, 80, "leakyrelu"), (2, 3, 24, 32, "relu"),
-             (4, 1, 200, 200, "leakyrelu"), (4, 1, 36, 104, "relu"), (8, 1, 12, 24, "leakyrelu")]
+             (4, 1, 200, 200, "leakyrelu"), (4, 1, 36, 104, "relu"), (8, 1, 12, 24, "leakyrelu"), (4, 1, 272, 480, "leakyrelu"), (4, 5, 200, 200, "leakyrelu")]
+    # (the last two: 4080 / 6250 tiles = 16 / 25 per persistent workgroup, both traversal directions: the LR-tile / weight-ring hand-over between tiles)
     for i, (scale, n, h, w, act) in enumerate(cases):
         sd = _sd(synth.rrdbnet_shapes(nb=1, scale=scale), 300 + i)
         net = RRDBNet(3, 3, 64, 1, upscale=scale, act_type=act)
