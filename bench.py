@@ -55,8 +55,6 @@ def kernel_key(k):
     + 2000 HR_conv0 + conv_last fused (rocprof: conv3x3_pc<2,4,4,0,..,TMF 4325887 = 0x4201FF>), + 3000 an up-conv as four 2x2-tap phases (TMF 6291967 =
     0x6001FF).  The plain 64-output row holds both the plain (TMF 4194815) and the residual-from-LDS (4456959) launches; profiles/traffic.json lists the
     instantiations by their TMF."""
-    if k == 1000:
-        return "conv3x3_pair"
     variant, k = k // 1000, k % 1000
     nt, mode = k // 16, k % 16
     if variant == 5:          # the last upconv_block -> HR_conv0 -> conv_last chained through LDS (csrc/hr_chain.hip)
@@ -79,6 +77,46 @@ KIND_NOTES = {"hr_chain_kernel<upconv+HR_conv0+conv_last>": "the last upconv_blo
               "+fused_tail": "HR_conv0 + conv_last in one launch (+ the rim pass): both convs' FLOPs, the 64-channel HR tensor neither written nor read",
               "+upconv_phases": "up-conv as four 2x2-tap phases on the LR grid (all four in one visit of a tile): FLOPs are the ALGORITHMIC ones of the nine-tap layer it replaces "
                        "(reference block.py:348-361); executed FLOPs = 4/9 of them, so `frac_mfma` here is not the matrix pipe's utilisation"}
+
+
+XGMI_LINK_GBS = 153.0          # per link and direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
+XGMI_PAYLOAD_EFF = 0.8         # payload share of a large point-to-point transfer the model assumes (unmeasured on this pool: no multi-GPU box has run it)
+
+
+def predict_tile_scaling(stages, out_channels=3, worlds=(1, 2, 4, 8)):
+    """The strong-scaling table the first multi-GPU run is judged against, from ONE rank's measured phases.
+    stages: per chained model {tiles_total, ms_per_tile (this rank's compute ms / its tiles), blend_ms, tile_bytes (one raw HR tile), bcast_bytes (the blended
+    intermediate handed to the next model, 0 for the last)}.  Model (innfer_amd/parallel.py): the row-major tile list is split evenly, so the slowest rank computes
+    ceil(tiles / N) tiles at the measured per-tile cost (tiles are independent: run.py:186-197); every other rank then sends its raw HR tiles to rank 0 point to point --
+    its own xGMI link each (N <= 8: 7 links per GPU), all in one grouped send/recv, so the exchange lasts one peer's share / (link rate x payload efficiency);
+    rank 0 blends alone (measured, does not shrink); between chained models the intermediate is broadcast: one link time."""
+    import math
+    link = XGMI_LINK_GBS * 1e9 * XGMI_PAYLOAD_EFF
+    rows, t1 = [], None
+    for n in worlds:
+        comp = exch = blend = bcast = 0.0
+        for st in stages:
+            share = math.ceil(st["tiles_total"] / n)
+            comp += share * st["ms_per_tile"]
+            if n > 1:
+                exch += (st["tiles_total"] // n) * st["tile_bytes"] / link * 1e3          # (a peer's share; rank 0 keeps its own)
+                bcast += st["bcast_bytes"] / link * 1e3
+            blend += st["blend_ms"]
+        total = comp + exch + blend + bcast
+        t1 = total if n == 1 else t1
+        rows.append({"n_gpus": n, "ms_per_frame": round(total, 2), "compute_ms": round(comp, 2), "exchange_ms": round(exch, 2), "blend_ms": round(blend, 2),
+                     "bcast_ms": round(bcast, 2), "speedup": round(t1 / total, 3), "efficiency": round(t1 / total / n, 3)})
+    return rows
+
+
+def stage_model(phases, ps, scales, last_bcast=False):
+    """predict_tile_scaling's input from the profiled pass of one rank (ChopRunner.last per chained model)."""
+    out = []
+    for i, (p, sc) in enumerate(zip(phases, scales)):
+        P = ps * sc
+        out.append({"tiles_total": p["tiles_total"], "ms_per_tile": p["compute_ms"] / max(1, p["tiles"]), "blend_ms": p["blend_ms"],
+                    "tile_bytes": 3 * P * P * 2, "bcast_bytes": 0 if (i == len(phases) - 1 and not last_bcast) else 3 * p.get("out_h", 0) * p.get("out_w", 0) * 2})
+    return out
 
 
 def build_net(dev, nb=23, scale=4):
@@ -106,7 +144,6 @@ def timed_forward(net, x):
     ms, fl, by, kd, n = (C.c_float * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), (C.c_int * cap)(), C.c_int()
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(L.lib.innfer_net_set_band_rows(net._handle, int(net.band_rows)))
-    L.check(L.lib.innfer_net_set_pair_convs(net._handle, int(net.pair_convs)))
     L.check(L.lib.innfer_net_set_fused_tail(net._handle, int(bool(net.fused_tail))))
     L.check(L.lib.innfer_net_set_hr_chain(net._handle, int(bool(net.hr_chain))))
     L.check(L.lib.innfer_net_set_upconv_phases(net._handle, int(net.upconv_phases)))
@@ -421,7 +458,7 @@ def srresnet1080_object(dev, reps=10, windows=7, warm_s=0.5):
     out = {"workload": "SRResNet-16 4x (nf 64, no norm, ReLU, CNA, pixelshuffle: utils/defaults.py:53-67), 1x3x1080x1920 -> 1x3x4320x7680 fp16, un-tiled (SURVEY 8a row a11)",
            "steps": reps, "windows": windows, "warmup": n_warm, "ms_per_step": round(ms, 4), "ms_per_step_min": round(min(win), 4), "ms_per_step_max": round(max(win), 4),
            "value": round(16 * H * W / ms / 1e3, 1), "unit": "output MPix/s", "model_tflops": round(fl / ms / 1e9, 1),
-           "frac_of_mfma_peak": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4), "pair_convs": int(getattr(net, "pair_convs", 0))}
+           "frac_of_mfma_peak": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4)}
     timed_forward(net, x)
     r = roofline_from_launches(timed_forward(net, x))
     out["hip_event_sum_ms"] = round(sum(e["ms_total"] for e in r["per_kernel"].values()), 4)
@@ -556,8 +593,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="frame1080", choices=WORKLOADS)
     ap.add_argument("--band-rows", type=int, default=0)
-    ap.add_argument("--pair-convs", type=int, default=0, choices=[0, 1, 2],
-                    help="innfer_net_set_pair_convs: 0 one launch per layer (default), 1 fused conv pairs on single-image forwards, 2 always")
     ap.add_argument("--tile-batch", type=int, default=0, help="chop workloads: tiles per network launch (0 = innfer_amd.parallel.tile_batches: evenly sized launches of <= 272 tiles)")
     ap.add_argument("--sharded-steps", type=int, default=-1, help="timed passes of the tile_sharded (chain4k) measurement; 0 = skip; default 2 on one GPU, 5 on N > 1 "
                     "(the strong-scaling table of the first multi-GPU run comes from these objects: VERDICT r4 item 6a)")
@@ -648,7 +683,6 @@ def main():
     net.hr_chain = not args.no_hr_chain
     net.upconv_phases = 0 if args.no_upconv_phases else (2 if args.upconv_phase_visits else 1)
     net.residual_lds = args.residual_lds
-    net.pair_convs = args.pair_convs
     tag = " (DRY RUN: all ranks on one GPU, gloo)" if dryrun else ""
 
     def chop_setup(workload, profile=False):
@@ -778,6 +812,14 @@ def main():
                 "per_rank_phases_ms": all_phases,
                 "exchange_bytes_into_rank0": sum(p.get("exchange_bytes", 0) for p in phases),
                 "exchange_ms": round(sum(p.get("exchange_ms", 0.0) for p in phases), 2)}
+            # the prediction this (or the first multi-GPU) run is checked against: from THIS rank's per-tile cost and blend time (predict_tile_scaling)
+            for p_, sc_ in zip(phases, (1, 4)):
+                p_["out_h"], p_["out_w"] = cH * sc_, cW * sc_
+            pred = predict_tile_scaling(stage_model(phases, 200, (1, 4)))
+            line["tile_sharded"]["predicted"] = pred
+            line["tile_sharded"]["predicted_ms"] = next((r["ms_per_frame"] for r in pred if r["n_gpus"] == world), None)
+            line["tile_sharded"]["prediction_model"] = (f"ceil(tiles/N) x this rank's ms per tile + one peer's raw HR tiles over one xGMI link ({XGMI_LINK_GBS:.0f} GB/s x "
+                                                        f"{XGMI_PAYLOAD_EFF}) + rank 0's blend + the intermediate's broadcast (one link time); DESIGN.md section 8")
         del cstep, runners
         torch.cuda.empty_cache()
 
@@ -786,13 +828,14 @@ def main():
         ksteps = 5 if world > 1 else 1
         kstep, kH, kW, kwhat, krunners = chop_setup("chop8k")
         kwall = timed_steps(kstep, ksteps, 1, world, sync, barrier, max_over_ranks) / ksteps
-        kphases = None
-        if world > 1:                               # one more pass with a synchronise around every phase, every rank reporting (never timed)
-            for r in krunners:
-                r.profile = True
-            kstep()
-            sync()
-            kphases = gather_phases([dict(r.last) for r in krunners])
+        # one more pass with a synchronise around every phase, every rank reporting (never timed)
+        for r in krunners:
+            r.profile = True
+        kstep()
+        sync()
+        kmine = [dict(r.last) for r in krunners]
+        kphases = gather_phases(kmine)
+        if world > 1:
             barrier()
         out = None
         if rank == 0:
@@ -804,6 +847,9 @@ def main():
                 "model_tflops": round(kfl / kwall / 1e12, 1), "frac_of_mfma_peak_all_gpus": round(kfl / kwall / 1e12 / (PEAK_F16_TFLOPS * world), 4),
                 "tile_batches": parallel.tile_batches(parallel.shard_tiles(ntile, world, 0)[1], args.tile_batch or None,
                                                       parallel.engine_tile_cap(net, 200, torch.float16, dev))}
+            kpred = predict_tile_scaling(stage_model(kmine, 200, (4,)))
+            out["predicted"] = kpred
+            out["predicted_ms"] = next((r["ms_per_frame"] for r in kpred if r["n_gpus"] == world), None)
         del kstep, krunners
         return out
 

@@ -45,8 +45,8 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works); innfer_pack_conv3x3_shuffle2 + innfer_conv_args.plane_rows = 2.  111: innfer_net_set_hr_chain.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 111
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works); innfer_pack_conv3x3_shuffle2 + innfer_conv_args.plane_rows = 2.  111: innfer_net_set_hr_chain.  112: REMOVED -- innfer_net_set_pair_convs (csrc/conv_pair.hip: the fused conv pairs of a dense block, measured 3 % slower per frame in round 2 and off ever since), innfer_pack_conv3x3_wino / innfer_conv3x3_wino_packed_bytes and the meaning of innfer_conv_args.winograd (now reserved0, must be 0): the row-Winograd experiment of round 3.  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 112
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -137,15 +137,6 @@ int innfer_net_forward_timed(innfer_net_t net, const void* d_in, int in_dtype, v
 int innfer_net_set_u8_io(innfer_net_t net, int normalize, int fp16_mode);
 
 int innfer_net_set_band_rows(innfer_net_t net, int rows);
-
-/* Scheduling knob: how the 32-output convs of a residual dense block (RRDBNet_arch.py:152-160) are launched.
- * 0 (default) = one launch per layer.  1 = (conv1, conv2) and (conv3, conv4) as fused pairs on single-image forwards
- * (csrc/conv_pair.hip: conv_b runs on the tile conv_a has just produced, its other inputs come from L2 / Infinity Cache instead
- * of HBM; 0.43 x the HBM bytes of the two layers for 1.16 x their MFMA work); batches keep one launch per layer.  2 = pairs for
- * batches too.  Results are bit-identical either way (every output sees the same operands in the same order); on MI355X the
- * package is power-bound, not HBM-bound, on this network and the pairs measure 3 % slower per frame
- * (profiles/r2/kernel_experiments.txt), hence the default. */
-int innfer_net_set_pair_convs(innfer_net_t net, int mode);
 
 /* The residual of a dense block's last conv (`x5 * 0.2 + x`, RRDBNet_arch.py:161-165) is that conv's own input channels 0..63.  With the LDS form the
  * kernel stages those two channel groups LAST and adds x / 0.2 to the fp32 accumulators from the staged LDS tile; the epilogue scales by 0.2 -- x is not
@@ -391,9 +382,8 @@ typedef struct {
                                            lo slab = fp16((x - hi) * 2^11) lies in_lo / out_lo / res1_lo / res2_lo ELEMENTS behind; d_packed from innfer_pack_conv3x3_split();
                                            K in {32, 64} for slab outputs; act 0 / 1 / 2, residuals, upsample2x, row range and batches as for the fp16 form (106) */
     int64_t in_lo, out_lo, res1_lo, res2_lo;
-    int winograd;                       /* experiment (profiles/r3/winograd.txt; not used by the networks): 1 = Winograd F(2,3) along the image rows on 16 x 32 tiles -- two
-                                           thirds of the MFMA work, fp16 transforms (parity vs the direct form: test_winograd_rows_vs_direct); d_packed from
-                                           innfer_pack_conv3x3_wino(); K % 32 == 0, act 0 / 1 / 2, residuals, upsample2x, row range; 2 = the direct conv on the same tiles (K 32) (106) */
+    int reserved0;                      /* must be 0 (until ABI 111: `winograd`, the row-Winograd experiment of profiles/r3/winograd.txt -- measured slower, removed in 112; the
+                                           field keeps the struct layout) */
     int res1_from_input;                /* != 0: d_res1 == d_in (same group stride), act 0, K = 64, C >= 96 -- the dense block's `x5 * 0.2 + x`: the residual is taken from the
                                            conv's own staged input tiles (see innfer_net_set_residual_lds); ignored when the shape does not qualify (108) */
     int plane_rows;                     /* 2 with pixel_shuffle2 (K % 256 == 0): d_packed / d_bias from innfer_pack_conv3x3_shuffle2() (110).
@@ -420,8 +410,6 @@ int innfer_pack_convt2x(const float* h_weight_iohw, int K, int C, int k, void* h
 int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream);
 /* Panels of the split form: 3 * innfer_conv3x3_packed_bytes(K, C) bytes ((w - wh) * 2^11 | wh | wh, in the order the kernel's virtual chunks meet them).  (106) */
 int innfer_pack_conv3x3_split(const float* h_weight_oihw, int K, int C, void* h_packed);
-size_t innfer_conv3x3_wino_packed_bytes(int K, int C);
-int innfer_pack_conv3x3_wino(const float* h_weight_oihw, int K, int C, void* h_packed);
 
 /* NCHW (f16/f32) <-> blocked-NHWC f16 slab helpers used by tests of the single conv. */
 int innfer_nchw_to_slab(const void* d_src, int src_dtype, void* d_slab, int64_t group_stride, int ch_off,

@@ -54,7 +54,6 @@ class EngineModule(nn.Module):
         self.hr_chain = True         # innfer_net_set_hr_chain: the last upconv_block -> HR_conv0 -> conv_last as ONE kernel chained through LDS (bit-identical to the launches it replaces)
         self.fused_tail = True       # innfer_net_set_fused_tail: HR_conv0 -> conv_last as one kernel where the shapes allow it (results agree to the last fp16 rounding with the two-launch form)
         self.residual_lds = 1        # innfer_net_set_residual_lds: the dense block's `x5 * 0.2 + x` takes x from the conv's own staged LDS tiles -- 1 the RRDB-end blocks (measured gain), 2 every block, 0 never (all agree to the last fp16 rounding)
-        self.pair_convs = 0          # innfer_net_set_pair_convs: 0 one launch per layer (default), 1 fused conv pairs on single-image forwards, 2 always
 
     # ---- subclasses provide the C handle ------------------------------------
     def _create_handle(self):
@@ -189,7 +188,6 @@ class EngineModule(nn.Module):
     def _forward_on_device(self, x, out=None):
         self._engine_on(x.device)
         L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
-        L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
         L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
         L.check(L.lib.innfer_net_set_hr_chain(self._handle, int(bool(self.hr_chain))))
         L.check(L.lib.innfer_net_set_residual_lds(self._handle, int(self.residual_lds)))
@@ -221,7 +219,6 @@ class EngineModule(nn.Module):
         with torch.cuda.device(img.device):
             self._engine_on(img.device)
             L.check(L.lib.innfer_net_set_band_rows(self._handle, int(self.band_rows)))
-            L.check(L.lib.innfer_net_set_pair_convs(self._handle, int(self.pair_convs)))
             L.check(L.lib.innfer_net_set_fused_tail(self._handle, int(bool(self.fused_tail))))
             L.check(L.lib.innfer_net_set_hr_chain(self._handle, int(bool(self.hr_chain))))
             L.check(L.lib.innfer_net_set_residual_lds(self._handle, int(self.residual_lds)))

@@ -109,30 +109,13 @@ struct ConvLaunch {
                                                   // as this conv's epilogue; panels from conv_pack_selfgate (2 KB), 32 biases; `act` is the activation AFTER the gate
     int res1_lds;                                 // 1: when res1 is the conv's own input (groups 0, 1: the dense block's x5 * 0.2 + x), act 0 and K = 64, take it from the staged LDS tiles
                                                   // (conv3x3_pc RLDS: chunk order 2, 3, .., 0, 1; the residual enters the fp32 accumulators as x / s1) instead of re-reading it in the epilogue
-    int wino;                                     // experiment: 1 = Winograd F(2,3) along the rows (panels from conv_pack_wino), 2 = the direct conv on the same 16 x 32 tiles
-    const f16* pair_wpk; const float* pair_bias;  // net.hip only: non-null = this 32-output LeakyReLU conv AND the next one of the dense block (inputs: the same
-                                                  // C channels + this conv's output, output: the following channel group) as one conv_pair_launch
 };
-
-// conv_a (C -> 32) and conv_b (C + 32 -> 32) of a residual dense block in one tile visit (conv_pair.hip): LeakyReLU(0.2) after both, bias, no
-// residuals; x_a goes to the channel group `out` = in + (C / 32) * in_gstride (the dense concat), x_b to the group after it.
-struct ConvPairLaunch {
-    const f16* in; long in_gstride; int C;        // C % 32 == 0, C >= 64
-    const f16* wpk_a; const float* bias_a;        // conv_pack(K = 32, C)
-    const f16* wpk_b; const float* bias_b;        // conv_pack(K = 32, C + 32)
-    f16* out;
-    int N, H, W;
-    int rev;
-};
-int conv_pair_launch(const ConvPairLaunch& L, hipStream_t s);
 
 // Panel geometry of packed weights.
 int conv_nt_for(int K);                           // 16-channel tiles per group: 1, 2 or 4
 size_t conv_packed_bytes(int K, int C);
 void conv_pack_shuffle2(const float* w_oihw, const float* bias, int K, int C, void* packed, float* bias_out);   // host; phase-major plane-order panels of the PixelShuffle(2) store (ConvLaunch.rowp = 2, OUT_SHUFFLE2): K % 256 == 0
 void conv_pack(const float* w_oihw, int K, int C, void* packed, int rowp = 0);   // host; rowp: the plane row order of 64-channel groups (ConvLaunch.rowp)
-size_t conv_packed_bytes_wino(int K, int C);
-void conv_pack_wino(const float* w_oihw, int K, int C, void* packed);      // host; ConvLaunch.wino == 1
 void conv_pack_split(const float* w_oihw, int K, int C, void* packed);     // host; 3 * conv_packed_bytes(K, C): the (wl | wh | wh) panels of ConvLaunch.split
 void conv_pack_1x1_split(const float* w_oi, int K, int C, void* packed);   // host; 3 * conv_packed_bytes_taps(K, C, 0x10)
 int conv_launch(const ConvLaunch& L, hipStream_t s);

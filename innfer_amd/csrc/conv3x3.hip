@@ -516,14 +516,6 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // at zero, are scaled by 2^-11 (exact) and receive the bias when the third part begins: ONE accumulator set, the fp16 kernel's MFMA stream.
     constexpr bool SPLIT = (TMF & 0x2000) != 0;
     static_assert(!SPLIT || (!S9 && !POLY && !S2 && !PFX && !STATS && (TM == 0x1FF || TM == 0x10)), "split operands: plain 3x3 and 1x1 convs");
-    // + 0x4000: Winograd F(2,3) along the image rows (experiment, profiles/r3/winograd.txt).  An output pixel pair (2j, 2j+1) of a row is
-    //   Y = A^T [(G g) . (B^T d)],  d = the four input columns 2j-1 .. 2j+2:   V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3;  Y0 = M0 + M1 + M2, Y1 = M1 - M2 - M3
-    // with M_xi = sum over the three kernel rows and the input channels of U_xi,r * V_xi: 12 MFMAs (4 xi x 3 rows) per 32 output pixels of a row and
-    // 16-channel output tile instead of 18 (2 segments x 9 taps) -- two thirds of the matrix work; the weight panel holds U = G g per kernel row (12
-    // "taps", conv_pack_wino), the MFMA's 16 columns are the row's 16 pixel pairs.  The input transform is 16 v_pk_add_f16 per input row and chunk on the
-    // fragments as they come out of LDS.  LDS image: a halo row holds its even columns (0, 2, .. 32) then its odd ones (18-pixel halves of the 36-pixel
-    // pitch), so that the stride-2 reads d0 / d2 (even[j], even[j+1]) and d1 / d3 (odd[j], odd[j+1]) are 16 consecutive pixels each: conflict free.
-    constexpr bool WINO = (TMF & 0x4000) != 0;
     // + 0x20000 (FUSE): HR_conv0 -> conv_last in one kernel (RRDBNet_arch.py:36-42: HR_conv0 = conv + LeakyReLU, conv_last = conv, both 3x3) without recomputing a
     // halo.  The epilogue turns the tile's LeakyReLU'd result into the MFMA's B operand in registers (the k order of the last conv's panel is chosen so that a
     // lane's sixteen accumulator channels ARE its two k-step fragments), multiplies it by the 27 x 64 matrix W_last[(c, dy, dx)][k] (16 MFMAs per wave), parks
@@ -578,7 +570,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     constexpr int KQ = (NQ + NLW - 1) / NLW;
     constexpr int IN_BYTES = NQ * 1024;
     constexpr int WROWS = NT * 16;
-    constexpr int NTAP = WINO ? 12 : UP4 ? 4 : __builtin_popcount(TM);        // taps in the panel, in (r, s) order (WINO: (r, xi); UP4: a phase's 2 x 2 block)
+    constexpr int NTAP = UP4 ? 4 : __builtin_popcount(TM);        // taps in the panel, in (r, s) order (UP4: a phase's 2 x 2 block)
     constexpr int W_BYTES = NTAP * WROWS * 64;
     constexpr int WQ = W_BYTES / 1024;
     constexpr int KW = (WQ + NLW - 1) / NLW;
@@ -675,20 +667,6 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             }
     }
     const int aoffs = li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
-    // WINO: byte offsets of d(half h, pixel pair li + dl) in the wave's rows 0 and 1: LDS pixel P = row * 36 + 18 h + li + dl, slot lg ^ 2 bit2(P); rows of one
-    // parity differ by whole multiples of two pitches (36 = 4 x 9: bit2(P) depends on the row's parity only), i.e. by immediates
-    int woffs[WINO ? 2 : 1][2][2];
-    if constexpr (WINO) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int dl = 0; dl < 2; ++dl) {
-                    const int P = (cw * RPW + q) * LWP + 18 * h + li + dl;
-                    woffs[q][h][dl] = P * 64 + ((lg ^ (((P >> 2) & 1) << 1)) << 4);
-                }
-    }
     // RLDS: byte offset of the lane's 16 residual channels (two 16-byte slots; the swizzle swaps slot PAIRS, so they stay adjacent) of its pixel tile m inside a
     // stage: LDS pixel P = the centre tap's operand of output pixel (cw * RPW + m / 2, li + 16 (m % 2))
     int roffs[RLDS ? MT : 1];
@@ -760,7 +738,6 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     f32x4 bias_r[NT];
     int bias_kg = -1;
     f32x4 acc[NT][MT];
-    f32x4 wacc[WINO ? 4 : 1][NT][WINO ? RPW : 1];          // WINO: M_xi of the wave's RPW rows (16 pixel pairs each) per 16-channel tile
     float pfx[PFX ? MT : 1][8];          // (cleared after a tile's last chunk, in front of its epilogue: live sums there would cost the epilogue's registers)
 #pragma unroll
     for (int m = 0; m < (PFX ? MT : 1); ++m)
@@ -786,14 +763,6 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[t][m] = SPLIT ? f32x4{0.f, 0.f, 0.f, 0.f} : bias_r[t];
-            if constexpr (WINO) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int m = 0; m < RPW; ++m) wacc[x][t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
         }
         if constexpr (SPLIT) {
             if (c == 2 * p.ncg) {                    // the two cross terms are complete: scale them down (exact) and go on with xh * wh on top of the bias
@@ -815,33 +784,6 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         constexpr bool abl_no_mfma = false;
 #endif
         if (abl_no_mfma) {
-        } else if constexpr (WINO) {
-            f16x8 a[4][3][NT];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) a[x][r][t] = *(const f16x8*)(sw + aoffs + ((r * 4 + x) * WROWS + t * 16) * 64);
-#pragma unroll
-            for (int rr = 0; rr < RPW + 2; ++rr) {
-                const char* rowp = st + (rr - (rr & 1)) * LWP * 64;
-                const f16x8 d0 = *(const f16x8*)(rowp + woffs[rr & 1][0][0]), d1 = *(const f16x8*)(rowp + woffs[rr & 1][1][0]);
-                const f16x8 d2 = *(const f16x8*)(rowp + woffs[rr & 1][0][1]), d3 = *(const f16x8*)(rowp + woffs[rr & 1][1][1]);
-                f16x8 v[4];
-                v[0] = d0 - d2; v[1] = d1 + d2; v[2] = d2 - d1; v[3] = d1 - d3;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int rw = rr - r;
-                    if (rw >= 0 && rw < RPW) {
-#pragma unroll
-                        for (int x = 0; x < 4; ++x)
-#pragma unroll
-                            for (int t = 0; t < NT; ++t)
-                                wacc[x][t][rw] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[x][r][t], v[x], wacc[x][t][rw], 0, 0, 0);
-                    }
-                }
-            }
         } else if constexpr (TM == 0x1FF && PIPE && !UP4) {
             // Software-pipelined fragment reads (the nine-tap kernels).  The B fragments of a chunk are walked in (s, rr, seg) order through
             // a three-register ring, each read issued two MFMA groups (>= 8 MFMAs = 128 pipe cycles) ahead of its use; the weight fragments
@@ -1049,10 +991,10 @@ int canvas_grid(const KP& k, int N, int* gy, long* tiles) {
 template <int RPW, int NT, int NLW, int OUTMODE, bool S9, bool POLY, int TM, bool CV, int NSI, int NCW>
 int launch_pc(const KP& kp, int N, hipStream_t s) {
     constexpr int TH = NCW * RPW;
-    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x4000) ? 12 : (TM & 0x200000) ? 4 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0) + ((TM & 0x200000) ? 1024 : 0);      // (UP4: + the four phases' biases)
+    constexpr int LDS = NSI * ((((TH + 2) * LWP + 15) / 16) * 1024) + 2 * (((TM & 0x200000) ? 4 : __builtin_popcount(TM & 0x1FF)) * NT * 16 * 64) + ((TM & 0x20000) ? 4096 : 0) + ((TM & 0x200000) ? 1024 : 0);      // (UP4: + the four phases' biases)
     static_assert(LDS <= 160 * 1024, "the stages must fit the CU's LDS");
     static_assert(NSI == 2 || (NSI == 3 && !S9 && !POLY), "the three-slot input ring exists for the plain and the canvas loader");
-    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x4C2000) == 0x1FF && !CV) {      // (not the Winograd experiment: no canvas form)      // a batch of images whose size is not a whole number of tiles
+    if constexpr (OUTMODE == OUT_SLAB && !S9 && !POLY && (TM & ~0x4C2000) == 0x1FF && !CV) {      // a batch of images whose size is not a whole number of tiles
         int gy = 0; long t = 0;
         const int gx = INNFER_KNOB("INNFER_CANVAS", 1) ? canvas_grid<TH>(kp, N, &gy, &t) : 0;
         if (gx > 0) {
@@ -1191,23 +1133,14 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     const int rpw64 = INNFER_KNOB("INNFER_RPW64", 3);
     const int rpw32 = INNFER_KNOB("INNFER_RPW32", 5);
     const int pc = INNFER_KNOB("INNFER_PC", 1);     // producer / consumer kernel for slab outputs
-    if (L.rowp && !(L.rowp == 2 && L.out_mode == OUT_SHUFFLE2) && (nt != 4 || !pc || L.out_mode != OUT_SLAB || L.split || L.wino || L.stats_part || L.stride2 || L.conv1x1 || L.conv7 || L.conv7v || L.prefix_lrelu || L.pair_wpk ||
+    if (L.rowp && !(L.rowp == 2 && L.out_mode == OUT_SHUFFLE2) && (nt != 4 || !pc || L.out_mode != OUT_SLAB || L.split || L.stats_part || L.stride2 || L.conv1x1 || L.conv7 || L.conv7v || L.prefix_lrelu ||
                    L.gate_w || L.act > 2 || L.dilation > 1 || L.dilation_groups || (L.out_coff & 31)))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: the plane row order (rowp) belongs to plain 3x3 slab convs and transposed-conv phases with 64-channel output groups");
     if (L.outm && (L.out_mode != OUT_NCHW || !pc || nt != 1 || L.res1 || L.res2 || L.outm < 0 || L.outm > 4))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: outm belongs to the planar last conv (<= 16 channels)");
-    if (L.wino) {            // experiment (profiles/r3/winograd.txt): 1 = Winograd F(2,3) along the rows, 2 = the direct conv on the same tiles (16 rows x 32 px, 32-channel
-                             // output groups) for the A/B; panels from conv_pack_wino / conv_pack(K = 32) per group
-        if (!pc || L.out_mode != OUT_SLAB || L.K % 32 || L.act > 2 || L.reflect || L.dilation > 1 || L.dilation_groups || L.deconv_phases || L.stride2 || L.conv7v || L.conv7 ||
-            L.stats_part || L.conv1x1 || L.pair_wpk || L.split)
-            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (Winograd rows): plain 3x3 slab convs, K %% 32 == 0, act 0..2, residuals, upsampled input");
-        k.KG = L.K / 32;
-        if (L.wino == 2 && L.K != 32) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (A/B tile shape): K == 32");
-        return L.wino == 1 ? launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x41FF>(k, L.N, s) : launch_pc<2, 2, 4>(k, L.N, s);
-    }
     if (L.split) {           // fp32-accurate mode on (hi, lo) slab pairs: 3 * C / 32 virtual chunks (conv3x3_pc<.., TMF | 0x2000>)
         if (!pc || (L.act > 2 && !((L.act == 3 || L.act == 6) && L.out_mode == OUT_NCHW)) || L.reflect || L.dilation > 1 || L.dilation_groups || L.deconv_phases || L.stride2 || L.conv7v || L.conv7 || L.stats_part ||
-            L.prefix_lrelu || L.phase_c || L.pair_wpk || (long)3 * L.C / 32 > 0x7fff)
+            L.prefix_lrelu || L.phase_c || (long)3 * L.C / 32 > 0x7fff)
             return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (fp32 mode): plain 3x3 / 1x1 convs with act 0..2, residuals, upsampled input");
         k.nchunks = 3 * k.ncg;
         k.in_lo_bytes = L.in_lo * 2; k.out_lo = L.out_lo; k.res1_lo = L.res1_lo; k.res2_lo = L.res2_lo;

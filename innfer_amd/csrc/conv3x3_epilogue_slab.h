@@ -1,4 +1,4 @@
-// Slab epilogues of the conv kernels: plain / canvas / split (fp32-accurate) / Winograd, with the row-order helpers (toff_slab, lane_cbase).
+// Slab epilogues of the conv kernels: plain / canvas / split (fp32-accurate), with the row-order helpers (toff_slab, lane_cbase).
 // Part of csrc/conv3x3.hip (split out in round 5, VERDICT r4 item 7: no functional change -- the device assembly of the translation unit is identical);
 // included there, inside namespace innfer { namespace { .. } }, after KP / the tile constants.  Not a stand-alone header.
 
@@ -266,45 +266,6 @@ __device__ __forceinline__ void epilogue_slab_split(const KP& p, f32x4 (&acc)[NT
             }
             *(f16x4*)(ob + off + 4 * t) = h;
             *(f16x4*)(ob + p.out_lo + off + 4 * t) = l;
-        }
-    }
-}
-
-// WINO (conv3x3_pc<.., TMF | 0x4000>): output transform of the row Winograd form -- lane li holds M_0..3 of pixel pair li of each of the wave's rows:
-// Y(2 li) = M0 + M1 + M2 + bias, Y(2 li + 1) = M1 - M2 - M3 + bias, then the fp16 epilogue (activation, *s1 + res1, *s2 + res2, one rounding).
-template <int RPW, int NT, int ACT, bool R1, bool R2>
-__device__ __forceinline__ void epilogue_slab_wino(const KP& p, f32x4 (&m)[4][NT][RPW], const f32x4 (&bias)[NT], int n, int ty0, int tx0, int wave, int li, int cbase) {
-    const int oc0 = cbase + p.out_coff;
-    f16* ob = (f16*)p.out + (oc0 >> 5) * p.out_gstride + (oc0 & 31);
-    const f16* r1b = R1 ? p.res1 + (cbase >> 5) * p.res1_gstride + (cbase & 31) : nullptr;
-    const f16* r2b = R2 ? p.res2 + (cbase >> 5) * p.res2_gstride + (cbase & 31) : nullptr;
-#pragma unroll
-    for (int rw = 0; rw < RPW; ++rw) {
-        const int y = ty0 + wave * RPW + rw;
-        if (y >= p.y1) continue;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int x = tx0 + 2 * li + q;
-            if (x >= p.W) continue;
-            const long off = (((long)n * p.H + y) * p.W + x) * 32;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                f16x4 r1, r2, h;
-                if (R1) r1 = *(const f16x4*)(r1b + off + 4 * t);
-                if (R2) r2 = *(const f16x4*)(r2b + off + 4 * t);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float f = q == 0 ? (m[0][t][rw][j] + m[1][t][rw][j]) + m[2][t][rw][j] : (m[1][t][rw][j] - m[2][t][rw][j]) - m[3][t][rw][j];
-                    f += bias[t][j];
-                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                    if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[j]);
-                    if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[j]);
-                    FP32_VALUE(f);
-                    h[j] = (f16)f;
-                }
-                *(f16x4*)(ob + off + 4 * t) = h;
-            }
         }
     }
 }

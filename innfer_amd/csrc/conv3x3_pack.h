@@ -109,35 +109,6 @@ static std::vector<float> split_weights(const float* w, int K, int C, int taps) 
 void conv_pack_split(const float* w, int K, int C, void* packed) { conv_pack(split_weights(w, K, C, 9).data(), K, 3 * C, packed); }
 void conv_pack_1x1_split(const float* w, int K, int C, void* packed) { conv_pack_1x1(split_weights(w, K, C, 1).data(), K, 3 * C, packed); }
 
-// Row-Winograd panels (conv3x3_pc<.., TMF | 0x4000>): 32-channel output groups (NT = 2) whatever K is, 12 "taps" per chunk in (kernel row r, xi) order,
-// U_xi = G g over the kernel row's three columns (fp32, ONE rounding to fp16): [group][chunk][r * 4 + xi][row R][slot][8 ch]
-size_t conv_packed_bytes_wino(int K, int C) { return (size_t)((K + 31) / 32) * (C / 32) * 12 * 32 * 64; }
-void conv_pack_wino(const float* w, int K, int C, void* packed) {
-    const int nt = 2, rows = 32, groups = (K + 31) / 32, nch = C / 32;
-    f16* dst = (f16*)packed;
-    for (int g = 0; g < groups; ++g)
-        for (int c = 0; c < nch; ++c)
-            for (int tap = 0; tap < 12; ++tap) {
-                const int r = tap >> 2, xi = tap & 3;
-                for (int R = 0; R < rows; ++R) {
-                    const int t = R >> 4, rho = R & 15;
-                    const int oc = g * rows + 4 * nt * (rho >> 2) + 4 * t + (rho & 3);
-                    for (int sg = 0; sg < 4; ++sg) {
-                        const int cg = sg ^ (((R >> 2) & 1) << 1);
-                        for (int e = 0; e < 8; ++e) {
-                            const int ic = c * 32 + cg * 8 + e;
-                            float u = 0.f;
-                            if (oc < K) {
-                                const float* gk = w + ((size_t)oc * C + ic) * 9 + r * 3;
-                                u = xi == 0 ? gk[0] : xi == 3 ? gk[2] : xi == 1 ? 0.5f * (gk[0] + gk[1] + gk[2]) : 0.5f * (gk[0] - gk[1] + gk[2]);
-                            }
-                            *dst++ = (f16)u;
-                        }
-                    }
-                }
-            }
-}
-
 void conv_pack_1x1(const float* w, int K, int C, void* packed) {
     const int nt = conv_nt_for(K), rows = nt * 16, groups = conv_groups(K), nch = C / 32;
     f16* dst = (f16*)packed;
@@ -232,8 +203,8 @@ void conv_pack7v(const float* w, int K, int C, void* packed) {
 // H x W grid (the INPUT grid behind the phase lattice, which has four phases per tile), 8 consumer waves per tile
 // The fused last conv (ConvLaunch.fuse_w): what the launch must look like, the panel of the last conv and the bytes of the rim buffer.
 bool conv_fuse_last_ok(const ConvLaunch& L) {
-    return (L.K == 64 || L.K == 32) && L.C % 32 == 0 && L.out_mode == OUT_SLAB && !L.res1 && !L.res2 && !L.up && !L.reflect && L.dilation <= 1 && !L.dilation_groups && !L.split && !L.wino &&
-           !L.stats_part && !L.conv1x1 && !L.stride2 && !L.deconv_phases && !L.conv7 && !L.conv7v && !L.prefix_lrelu && !L.pair_wpk && L.act >= 0 && L.act <= 2 && L.y0 == 0 && L.y1 == L.H &&
+    return (L.K == 64 || L.K == 32) && L.C % 32 == 0 && L.out_mode == OUT_SLAB && !L.res1 && !L.res2 && !L.up && !L.reflect && L.dilation <= 1 && !L.dilation_groups && !L.split &&
+           !L.stats_part && !L.conv1x1 && !L.stride2 && !L.deconv_phases && !L.conv7 && !L.conv7v && !L.prefix_lrelu && L.act >= 0 && L.act <= 2 && L.y0 == 0 && L.y1 == L.H &&
            L.H % 16 == 0 && L.W % 32 == 0 && L.fuse_oc >= 1 && L.fuse_oc <= 3 && L.fuse_bias && L.fuse_side && L.fuse_out &&
            (long)L.N * (L.H / 16) * (L.W / 32) * 92 < 0x7fffffffL;
 }

@@ -2,10 +2,8 @@
 // straight from the caller's tensor, fp16 blocked-NHWC slab output.
 // Replaces `fea_conv = conv_block(in_nc, nf, 3)` (RRDBNet_arch.py:25, SRResNet_arch.py:24).
 //
-// 1728 MAC per pixel for 3->64: 0.01 % of an RRDBNet-23 forward, so this is a plain
-// VALU kernel bound by its 128 B/pixel store: K/8 lanes per pixel, each lane owns
-// 8 consecutive output channels and writes one 16-byte piece, so a wave writes
-// whole contiguous pixels.  Weights live in LDS as fp32 [Cin*9][K].
+// 1728 MAC per pixel for 3->64: 0.01 % of an RRDBNet-23 forward, bound by its 128 B/pixel store.  On the matrix cores with split fp32 operands (first_conv_mfma
+// below); the VALU kernel of round 1 it replaced (K/8 lanes per pixel) was removed in round 6: every engine's first conv has 32 or 64 outputs.
 #include "common.h"
 #include <type_traits>
 
@@ -37,54 +35,6 @@ __device__ __forceinline__ float first_conv_input(const FP& p, long n, int ci, i
     }
     const long o = (n * p.Cin + ci) * hw + (long)Y * p.W + X;
     return p.in_f32 ? ((const float*)p.in)[o] : (float)((const f16*)p.in)[o];
-}
-
-__global__ __launch_bounds__(256) void first_conv_kernel(const FP p) {
-    extern __shared__ __attribute__((aligned(16))) float sw[];
-    const int nw = p.Cin * 9 * p.K;
-    for (int i = threadIdx.x; i < nw + p.K; i += 256) sw[i] = i < nw ? p.w[i] : p.bias[i - nw];
-    __syncthreads();
-    const int tpp = p.K >> 3;                         // lanes per pixel
-    const int ppb = 256 / tpp;
-    const int sub = threadIdx.x / tpp;
-    if (sub >= ppb) return;
-    const long pix = (long)blockIdx.x * ppb + sub;
-    if (pix >= p.npix) return;
-    const int cg = (threadIdx.x % tpp) * 8;
-    const int x = (int)(pix % p.W);
-    const int y = (int)((pix / p.W) % p.H);
-    const long n = pix / ((long)p.W * p.H);
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = sw[nw + cg + e];
-    for (int ci = 0; ci < p.Cin; ++ci) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int Y = y + r - 1;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int X = x + s - 1;
-                float v = 0.f;
-                if (Y >= 0 && Y < p.H && X >= 0 && X < p.W) v = first_conv_input(p, n, ci, Y, X, (long)p.H * p.W);
-                const float* wk = sw + (ci * 9 + r * 3 + s) * p.K + cg;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, wk[e], acc[e]);
-            }
-        }
-    }
-    f16x8 h, l;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float f = acc[e];
-        if (p.act == 1) f = f > 0.f ? f : 0.2f * f;
-        else if (p.act == 2) f = f > 0.f ? f : 0.f;
-        h[e] = (f16)f;
-        l[e] = (f16)((f - (float)h[e]) * 2048.0f);
-    }
-    *(f16x8*)(p.out + (cg >> 5) * p.out_gstride + pix * 32 + (cg & 31)) = h;
-    if (p.out2) *(f16x8*)(p.out2 + (cg >> 5) * p.out2_gstride + pix * 32 + (cg & 31)) = h;
-    if (p.out_lo) *(f16x8*)(p.out + p.out_lo + (cg >> 5) * p.out_gstride + pix * 32 + (cg & 31)) = l;
-    if (p.out2 && p.out2_lo) *(f16x8*)(p.out2 + p.out2_lo + (cg >> 5) * p.out2_gstride + pix * 32 + (cg & 31)) = l;
 }
 
 // The same conv on the matrix cores (K = 32 or 64 outputs): the 9 * Cin taps of a pixel are the k dimension of a 16 x 16 x 32 MFMA
@@ -252,7 +202,7 @@ int first_conv_launch(const FirstConvLaunch& L, hipStream_t s) {
     if (L.Cin < 1 || L.Cin > 8) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: in_nc=%d unsupported", L.Cin);
     FP p{L.in, L.in_f32, L.Cin, L.in_u8, L.in_norm, L.in_round16, L.w, L.bias, L.out, L.out_gstride, L.out2, L.out2_gstride,
          L.K, (long)L.N * L.H * L.W, L.H, L.W, L.act, L.out_lo, L.out2_lo};
-    if ((L.K == 32 || L.K == 64) && INNFER_KNOB("INNFER_FIRST_MFMA", 1)) {
+    if (L.K == 32 || L.K == 64) {
         if (L.N > 65535 || (L.H + FIRST_ROWS - 1) / FIRST_ROWS > 65535) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: %d images of %d rows exceed the launch grid", L.N, L.H);
         const dim3 grid((unsigned)((L.W + 63) / 64), (unsigned)((L.H + FIRST_ROWS - 1) / FIRST_ROWS), (unsigned)L.N);
         const int steps = (L.Cin * 9 + 31) / 32;
@@ -266,13 +216,7 @@ int first_conv_launch(const FirstConvLaunch& L, hipStream_t s) {
         INNFER_HIP(hipGetLastError());
         return INNFER_OK;
     }
-    const int ppb = 256 / (L.K / 8);
-    const long grid = (p.npix + ppb - 1) / ppb;
-    const size_t lds = (size_t)(L.Cin * 9 * L.K + L.K) * sizeof(float);
-    if (lds > 64 * 1024) return set_error(INNFER_ERR_UNSUPPORTED, "first conv: %d x %d weights exceed LDS", L.Cin, L.K);
-    hipLaunchKernelGGL(first_conv_kernel, dim3((unsigned)grid), dim3(256), lds, s, p);
-    INNFER_HIP(hipGetLastError());
-    return INNFER_OK;
+    return set_error(INNFER_ERR_UNSUPPORTED, "first conv: K = %d (built: 32 or 64 outputs on the matrix cores)", L.K);
 }
 
 }  // namespace innfer

@@ -171,9 +171,11 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
         const char* base = (const char*)(p.in + (long)n * p.in_img_stride) + ((long)Y * p.w + X) * 64;
         int vo[2] = {lroff[0], lroff[1]};
         if (Y < 0 || Y + 10 > p.h || X < 0 || X + 18 > p.w) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));          // (border tiles only: re-derived from an opaque copy -- shared with lroff's set-up the rows / columns are held, i.e. spilled, across the kernel)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int P = 16 * (wave + 8 * i) + (lane >> 2);
+                const int P = 16 * (wave + 8 * i) + (ln >> 2);
                 const int row = P / CH_LRP, col = P - row * CH_LRP;
                 if (Y + row < 0 || Y + row >= p.h || X + col < 0 || X + col >= p.w) vo[i] = OOB;
             }

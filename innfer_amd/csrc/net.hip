@@ -136,7 +136,6 @@ struct innfer_net {
 #endif
     int ps_pc = INNFER_PS_PC_DEFAULT;   // PixelShuffle(2) stages on the producer / consumer kernel (phase-major panels); 0 (A/B builds): the two-workgroup kernel of rounds 1-4
     int res_lds = 1;             // the dense block's x5 * 0.2 + x with x taken from the conv's own staged LDS tiles (innfer_net_set_residual_lds; conv3x3_pc RLDS): 1 = where the RRDB's residual follows, 2 = every block
-    int pair_convs = 0;          // 0 never (default: measured slower, profiles/r2/kernel_experiments.txt 7), 1 single-image forwards, 2 always
     bool plus = false;           // ESRGAN+ residual paths (RRDBNet_arch.py:155-160)
     int fp32 = 0;                // innfer_net_set_precision: 1 = fp32-accurate forward on split operands (conv3x3.hip SPLIT), the reference's -no_fp16 mode (run.py:345,421-422)
     std::vector<ConvSlot> convs;
@@ -437,12 +436,6 @@ extern "C" int innfer_net_set_hr_chain(innfer_net_t net, int on) {
     return INNFER_OK;
 }
 
-extern "C" int innfer_net_set_pair_convs(innfer_net_t net, int mode) {
-    if (!net || mode < 0 || mode > 2) return set_error(INNFER_ERR_INVALID, "set_pair_convs: mode 0, 1 or 2");
-    net->pair_convs = mode;
-    return INNFER_OK;
-}
-
 extern "C" int innfer_net_set_u8_io(innfer_net_t net, int normalize, int fp16_mode) {
     if (!net) return set_error(INNFER_ERR_INVALID, "set_u8_io: null net");
     net->u8_normalize = normalize != 0;
@@ -573,23 +566,13 @@ int do_conv(const ConvLaunch& L, hipStream_t s) {
         ConvLaunch R = L;
         const int y1 = L.y1 > 0 ? L.y1 : L.H;
         R.rev = (alt && L.y0 == 0 && y1 == L.H) ? (int)(parity++ & 1) : 0;
-        if (L.pair_wpk) {
-            ConvPairLaunch P{};
-            P.in = L.in; P.in_gstride = L.in_gstride; P.C = L.C;
-            P.wpk_a = L.wpk; P.bias_a = L.bias; P.wpk_b = L.pair_wpk; P.bias_b = L.pair_bias;
-            P.out = (f16*)L.out; P.N = L.N; P.H = L.H; P.W = L.W; P.rev = R.rev;
-            rc = conv_pair_launch(P, s);
-        } else {
-            rc = conv_launch(R, s);
-        }
+        rc = conv_launch(R, s);
     }
     if (rc) return rc;
     rc = debug_after("conv3x3", s);
     if (rc) return rc;
     const int y1 = L.y1 > 0 ? L.y1 : L.H;
     const double px = (double)L.N * (y1 - L.y0) * L.W;
-    if (L.pair_wpk)      // both layers' FLOPs; bytes of the FUSED schedule: C channels in, 64 out, both panels
-        return timed_end(s, 2.0 * 9.0 * 32.0 * (2.0 * L.C + 32.0) * px, px * (L.C * 2.0 + 64.0 * 2.0) + 9.0 * 32.0 * (2.0 * L.C + 32.0) * 2.0, 1000);
     const int taps = L.conv1x1 ? 1 : 9;
     // algorithmic bytes per output pixel: C input channels (a quarter of them per pixel behind the folded nearest-2x), K outputs, K per residual
     const double obytes = L.out_mode == OUT_NCHW ? (L.out_u8 ? 1.0 : L.out_f32 ? 4.0 : 2.0) : 2.0;
@@ -824,14 +807,9 @@ extern "C" int innfer_net_forward(innfer_net_t net, const void* d_in, int in_dty
                     const ConvSlot& cs = net->convs[ci++];
                     chain.push_back(mk(cs, S, G, t1x1, G, N, H, W, 0));
                 }
-                // (conv1, conv2) and (conv3, conv4) as fused pairs (conv_pair.hip) on whole-frame launches of the plain dense block
-                const bool pairs = !net->fp32 && (net->pair_convs == 2 || (net->pair_convs == 1 && N == 1)) && !net->plus && net->trunk_act == 1 && gc == 32 && nf % 32 == 0 && nf >= 64 && net->band_rows == 0 &&
-                                   (long)N * H * W * 64 < 0x7fffffffL;
                 for (int i = 0; i < 4; ++i) {
                     const ConvSlot& cs = net->convs[ci++];
-                    if (pairs && (i & 1)) continue;               // launched with its predecessor
                     ConvLaunch L = mk(cs, S, G, S + (long)((nf + i * gc) / 32) * G, G, N, H, W, net->trunk_act);
-                    if (pairs) { L.pair_wpk = (const f16*)net->convs[ci].d_w; L.pair_bias = net->convs[ci].d_b; }
                     if (net->plus && i == 1) { L.res1 = t1x1; L.res1_gstride = G; L.s1 = 1.f; }          // x2 += conv1x1(x)
                     if (net->plus && i == 3) {                                                             // x4 += x2
                         L.res1 = S + (long)((nf + gc) / 32) * G; L.res1_gstride = G; L.s1 = 1.f;
@@ -1075,13 +1053,6 @@ extern "C" int innfer_pack_conv3x3_split(const float* w, int K, int C, void* h_p
     return INNFER_OK;
 }
 
-extern "C" size_t innfer_conv3x3_wino_packed_bytes(int K, int C) { return (K > 0 && C > 0 && C % 32 == 0) ? conv_packed_bytes_wino(K, C) : 0; }
-extern "C" int innfer_pack_conv3x3_wino(const float* w, int K, int C, void* h_packed) {
-    if (!w || !h_packed || K <= 0 || K % 32 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv3x3_wino: K=%d (%% 32) C=%d (%% 32)", K, C);
-    conv_pack_wino(w, K, C, h_packed);
-    return INNFER_OK;
-}
-
 extern "C" size_t innfer_conv7x1_packed_bytes(int K, int C) { return (K > 0 && C > 0 && C % 32 == 0) ? conv_packed_bytes7v(K, C) : 0; }
 extern "C" int innfer_pack_conv7x1(const float* w, int K, int C, void* packed) {
     if (!w || !packed || K <= 0 || K % 32 || C <= 0 || C % 32) return set_error(INNFER_ERR_INVALID, "pack_conv7x1: K=%d (%% 32) C=%d (%% 32)", K, C);
@@ -1150,11 +1121,7 @@ extern "C" int innfer_conv3x3_f16(const innfer_conv_args* a, void* stream) {
     L.rowp = a->plane_rows ? 1 : 0;
     if (a->pixel_shuffle2 && a->plane_rows == 2) L.rowp = 2;          // phase-major panels + bias from innfer_pack_conv3x3_shuffle2: the producer / consumer kernel's store
     else if (a->pixel_shuffle2 && a->plane_rows) return set_error(INNFER_ERR_INVALID, "conv3x3: pixel_shuffle2 takes plane_rows 0 (innfer_pack_conv3x3 panels) or 2 (innfer_pack_conv3x3_shuffle2 panels)");
-    if (a->winograd) {
-        if (a->pixel_shuffle2 || a->split || a->K % 32 || a->out_ch_off % 32 || (a->winograd != 1 && a->winograd != 2))
-            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (winograd): 1 | 2, K %% 32 == 0 (K=%d), whole output groups", a->K);
-        L.wino = a->winograd;
-    }
+    if (a->reserved0) return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: innfer_conv_args.reserved0 (the row-Winograd experiment until ABI 111) must be 0");
     if (a->split) {
         if (a->pixel_shuffle2 || a->K % 32 || a->in_lo <= 0 || a->out_lo <= 0 || (a->d_res1 && a->res1_lo <= 0) || (a->d_res2 && a->res2_lo <= 0))
             return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (split): K in {32, 64} (K=%d), slab output, the lo distances of every tensor given", a->K);

@@ -48,7 +48,7 @@ class ConvArgs(C.Structure):
         ("reflect_pad", C.c_int), ("dilation", C.c_int), ("dilation_groups", C.c_int), ("pixel_shuffle2", C.c_int),
         ("stride2_k4", C.c_int), ("transposed2x", C.c_int), ("column7", C.c_int),
         ("split", C.c_int), ("in_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64), ("res2_lo", C.c_int64),
-        ("winograd", C.c_int), ("res1_from_input", C.c_int), ("plane_rows", C.c_int),
+        ("reserved0", C.c_int), ("res1_from_input", C.c_int), ("plane_rows", C.c_int),
     ]
 
 
@@ -79,12 +79,9 @@ SIGNATURES = {
     "innfer_timer_stop": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "innfer_net_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_pack_conv3x3_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "innfer_conv3x3_wino_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "innfer_pack_conv3x3_wino": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "innfer_nchw_to_slab_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_int] * 5 + [C.c_void_p]),
     "innfer_slab_split_to_nchw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "innfer_net_set_band_rows": (C.c_int, [C.c_void_p, C.c_int]),
-    "innfer_net_set_pair_convs": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_fused_tail": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_hr_chain": (C.c_int, [C.c_void_p, C.c_int]),
     "innfer_net_set_residual_lds": (C.c_int, [C.c_void_p, C.c_int]),
@@ -213,7 +210,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 lib = _lib
 
-ABI_VERSION = 111          # the header revision this binding was written against (INNFER_ABI_VERSION)
+ABI_VERSION = 112          # the header revision this binding was written against (INNFER_ABI_VERSION)
 if _lib.innfer_version() != ABI_VERSION and not _ABI_ANY:
     raise ImportError(f"{LIB_PATH} speaks ABI {_lib.innfer_version()}, this binding {ABI_VERSION}: rebuild with `make`")
 

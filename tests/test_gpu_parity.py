@@ -672,23 +672,6 @@ def test_rrdbnet_banded_schedule_is_identical(dev):
     net.band_rows = 0
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 150, 70), (1, 3, 23, 31), (1, 3, 44, 60), (1, 3, 45, 61), (1, 3, 1, 1), (2, 3, 50, 33)])
-def test_rrdbnet_fused_conv_pairs_are_bit_identical(dev, shape):
-    """conv_pair.hip: (conv1, conv2) / (conv3, conv4) of every dense block in one tile visit (22 x 30 owned pixels of a 24 x 32 region,
-    x_a read back from L2) against one launch per layer -- ragged sizes, sizes that are whole tiles, one pixel, a batch (mode 2)."""
-    from innfer_amd import synth
-    net, _ = _rrdb(dev, 2, 2)
-    x = torch.from_numpy(synth.uniform(shape, 23)).to(dev).half()
-    net.pair_convs = 0
-    y = net(x)
-    net.pair_convs = 2
-    if net._ws is not None:
-        net._ws.fill_(0x7B)                       # stale x_a from the run before must not leak into the result
-    assert torch.equal(net(x), y)
-    net.pair_convs = 1
-    assert torch.equal(net(x), y)
-
-
 def test_srresnet_golden(dev, golden):
     from innfer_amd import synth
     from innfer_amd.architectures.SRResNet_arch import SRResNet
@@ -2381,72 +2364,6 @@ def test_7x7_last_conv_interior_and_edge_tiles_vs_oracle(dev, kind):
         ref = oracle.wbcunet_forward(sd, x) if kind == "wbcunet" else oracle.resnet_forward(sd, x, n_blocks=9)
     err = (y - ref).abs()
     assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (kind, err.max().item(), err.mean().item())
-
-
-def _run_wino_conv(dev, x, w, b, K, mode, act=0, up=False, res1=None, s1=1.0, rows=None):
-    """The row-Winograd experiment (innfer_conv_args.winograd = 1) or the direct conv on the same tiles (2) through the C ABI."""
-    import innfer_amd.lib as L
-    N, Cc, Hs, Ws = x.shape
-    H, W = (2 * Hs, 2 * Ws) if up else (Hs, Ws)
-    g_in = N * Hs * Ws * 32
-    slab = torch.full((Cc // 32, N, Hs, Ws, 32), 7.0, dtype=torch.float16, device=dev)
-    L.check(L.lib.innfer_nchw_to_slab(x.to(dev).contiguous().data_ptr(), L.F16, slab.data_ptr(), g_in, 0, N, Cc, Hs, Ws, None))
-    wc = np.ascontiguousarray(w.numpy())
-    if mode == 1:
-        packed = np.zeros(L.lib.innfer_conv3x3_wino_packed_bytes(K, Cc), dtype=np.uint8)
-        L.check(L.lib.innfer_pack_conv3x3_wino(wc.ctypes.data, K, Cc, packed.ctypes.data))
-    else:
-        packed = np.zeros(L.lib.innfer_conv3x3_packed_bytes(K, Cc), dtype=np.uint8)
-        L.check(L.lib.innfer_pack_conv3x3(wc.ctypes.data, K, Cc, packed.ctypes.data))
-    d_packed, d_bias = torch.from_numpy(packed).to(dev), b.float().to(dev)
-    g_out = N * H * W * 32
-    out = torch.full((K // 32, N, H, W, 32), -3.0, dtype=torch.float16, device=dev)
-    a = L.ConvArgs()
-    a.d_in, a.in_group_stride, a.C = slab.data_ptr(), g_in, Cc
-    a.d_packed, a.d_bias = d_packed.data_ptr(), d_bias.data_ptr()
-    a.d_out, a.out_group_stride, a.out_ch_off, a.K = out.data_ptr(), g_out, 0, K
-    a.N, a.H, a.W, a.act, a.upsample2x, a.winograd = N, H, W, act, int(up), mode
-    keep = [slab, d_packed, d_bias]
-    if res1 is not None:
-        rs = torch.empty((K // 32, N, H, W, 32), dtype=torch.float16, device=dev)
-        L.check(L.lib.innfer_nchw_to_slab(res1.to(dev).contiguous().data_ptr(), L.F16, rs.data_ptr(), g_out, 0, N, K, H, W, None))
-        a.d_res1, a.res1_group_stride, a.res1_scale = rs.data_ptr(), g_out, s1
-        keep.append(rs)
-    if rows:
-        a.row_begin, a.row_end = rows
-    L.check(L.lib.innfer_conv3x3_f16(C.byref(a), None))
-    torch.cuda.synchronize()
-    res = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
-    L.check(L.lib.innfer_slab_to_nchw(out.data_ptr(), g_out, 0, res.data_ptr(), L.F32, N, K, H, W, None))
-    torch.cuda.synchronize()
-    return res.cpu(), out.cpu()
-
-
-def test_winograd_rows_vs_direct(dev):
-    """The row-Winograd experiment (F(2,3) along the image rows -- 12 MFMAs per 32 output pixels and channel tile instead of
-    18; fp16 input transform on the LDS fragments, U = G g rounded once) against F.conv2d on the same fp16 operands: within the single-conv
-    bound of the direct kernels (4e-3; its own transform rounding adds ~2^-11 of the operand size), ragged sizes, batches, borders, residual,
-    nearest-2x input, row range, K = 64 as two 32-channel groups; the direct conv on the same 16 x 32 tiles (the A/B partner) to the same bound."""
-    from innfer_amd import synth
-    rng = np.random.RandomState(7)
-    for case, (Cc, K, N, H, W, act, up, res, rows) in enumerate([
-            (64, 32, 1, 16, 32, 1, False, False, None), (160, 32, 1, 37, 45, 1, False, False, None), (96, 32, 2, 33, 70, 0, False, True, None),
-            (192, 64, 1, 21, 50, 0, False, True, None), (64, 64, 1, 17, 23, 1, True, False, None), (32, 32, 3, 5, 3, 2, False, False, None),
-            (128, 32, 1, 50, 64, 1, False, False, (7, 30)), (64, 32, 1, 1, 1, 0, False, False, None), (64, 32, 1, 40, 33, 1, False, False, None)]):
-        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
-        x = torch.from_numpy(synth.uniform((N, Cc, H, W), 5000 + case, -1, 1)).half()
-        w = torch.from_numpy(synth.uniform((K, Cc, 3, 3), 5100 + case, -1, 1)) / np.sqrt(9 * Cc)
-        b = torch.from_numpy(synth.uniform((K,), 5200 + case, -1, 1))
-        r1 = torch.from_numpy(synth.uniform((N, K, Ho, Wo), 5300 + case, -1, 1)).half() if res else None
-        ref = _ref_conv(x, w, b, act=act, up=up, res1=r1, s1=0.2)
-        for mode in ((1, 2) if K == 32 else (1,)):
-            got, raw = _run_wino_conv(dev, x, w, b, K, mode, act=act, up=up, res1=r1, s1=0.2, rows=rows)
-            if rows:
-                err = (got[:, :, rows[0]:rows[1]] - ref[:, :, rows[0]:rows[1]]).abs().max().item()
-                assert torch.all(raw[:, :, :rows[0]] == -3.0) and torch.all(raw[:, :, rows[1]:] == -3.0)
-            else:
-                err = (got - ref).abs().max().item()
-            assert err < 4e-3, (case, mode, err)
 
 
 def test_weight_upload_follows_rebound_buffers_and_parameters(dev):

@@ -478,9 +478,9 @@ def test_image_loop_is_pipelined_and_keeps_the_serial_semantics(tmp_path, monkey
 
 
 @pytest.mark.parametrize("K,Cc", [(32, 64), (64, 96)])
-def test_split_and_winograd_panels(K, Cc):
+def test_split_panels(K, Cc):
     """Host packers of round 3 (no GPU needed).  innfer_pack_conv3x3_split: the panels of the conv over 3 C virtual input channels -- (w - wh) * 2^11, wh, wh
-    -- so that wh + wl * 2^-11 carries w to 2^-22; innfer_pack_conv3x3_wino: twelve "taps" per kernel row r and xi, U = G g (fp32 transform, one rounding)."""
+    -- so that wh + wl * 2^-11 carries w to 2^-22."""
     w = np.ascontiguousarray((synth.uniform((K, Cc, 3, 3), 11, -1, 1) / np.sqrt(9 * Cc)).astype(np.float32))
     n = L.lib.innfer_conv3x3_packed_bytes(K, Cc)
     buf = np.zeros(3 * n, dtype=np.uint8)
@@ -490,22 +490,3 @@ def test_split_and_winograd_panels(K, Cc):
     virt = np.concatenate([wl, wh, wh], axis=1)                       # [K, 3C, 3, 3]: exactly representable, so the reference packer's cast is the identity
     assert np.array_equal(buf.view(np.float16), _pack_reference(virt, K, 3 * Cc).reshape(-1))
     assert np.abs(wh + wl / 2048.0 - w).max() <= 2.0 ** -22 * np.abs(w).max()
-    # Winograd rows: decode the panel with the layout of _pack_reference (tap index r * 4 + xi instead of r * 3 + s; 32-channel output groups)
-    nb = L.lib.innfer_conv3x3_wino_packed_bytes(K, Cc)
-    assert nb == (K // 32) * (Cc // 32) * 12 * 32 * 64
-    pw = np.zeros(nb, dtype=np.uint8)
-    L.check(L.lib.innfer_pack_conv3x3_wino(w.ctypes.data, K, Cc, pw.ctypes.data))
-    pw = pw.view(np.float16).reshape(K // 32, Cc // 32, 12, 32, 4, 8).astype(np.float32)
-    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float32)
-    U = np.einsum("xs,kcrs->kcrx", G, w.astype(np.float32))          # [K, C, 3, 4]
-    for g in range(K // 32):
-        for R in range(32):
-            t, rho = R >> 4, R & 15
-            oc = g * 32 + 8 * (rho >> 2) + 4 * t + (rho & 3)
-            for sg in range(4):
-                cg = sg ^ (((R >> 2) & 1) << 1)
-                for c in range(Cc // 32):
-                    got = pw[g, c, :, R, sg, :]                       # [12, 8]
-                    want = U[oc, c * 32 + cg * 8:c * 32 + cg * 8 + 8].transpose(1, 2, 0).reshape(12, 8)          # [r * 4 + xi, e]
-                    assert np.array_equal(got, want.astype(np.float16).astype(np.float32)), (g, R, sg, c)
-    assert L.lib.innfer_pack_conv3x3_wino(w.ctypes.data, 48, Cc, pw.ctypes.data) == L.ERR_INVALID
