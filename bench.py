@@ -420,6 +420,37 @@ def pan540_object(dev, reps=20, windows=7, warm_s=0.5):
         out["hip_event_sum_ms"] = round(sum(e["ms_total"] for e in per.values()), 4)
         out["per_kernel"] = per
     net.release_workspace()
+    # ... and PAN where the command line runs it: run.py:373-375 hard-codes chop=True, patch 200 for every SR architecture, so a 1080p frame
+    # reaches PAN as 190 tiles of 200 x 200 (10 x 19, step 0.5) -> extract, batches through the network, overlap blend (Model.chop_forward, run.py:167-202)
+    try:
+        from innfer_amd import parallel
+        Hc, Wc = 1080, 1920
+        xc = torch.from_numpy(synth.uniform((1, 3, Hc, Wc), 4)).to(dev).half()
+        runner = parallel.ChopRunner(net, scale=4)
+        for _ in range(3):
+            runner(xc)
+        torch.cuda.synchronize()
+        cw = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                runner(xc)
+            e1.record()
+            torch.cuda.synchronize()
+            cw.append(e0.elapsed_time(e1) / 4)
+        cms = sorted(cw)[len(cw) // 2]
+        import innfer_amd.lib as L
+        ps, ys, xs = L.chop_plan(Hc, Wc, 200, 0.5)
+        ntile = len(ys) * len(xs)
+        out["chop1080"] = {"workload": f"PAN 4x fp16, 1x3x{Hc}x{Wc} through chop_forward: {ntile} tiles of {ps}^2 (patch 200, step 0.5), extract + network + overlap blend -- the "
+                                       "shape the reference's command line gives PAN (run.py:373-375)",
+                           "tiles": ntile, "tile_batches": parallel.tile_batches(ntile, None, parallel.engine_tile_cap(net, ps, torch.float16, dev)),
+                           "ms_per_frame": round(cms, 3), "ms_min": round(min(cw), 3), "ms_max": round(max(cw), 3), "value": round(16 * Hc * Wc / cms / 1e3, 1),
+                           "unit": "unique-output MPix/s", "model_tflops": round(2.0 * 488952 * ntile * ps * ps / cms / 1e9, 1)}
+        net.release_workspace()
+    except Exception as e:                              # a side object must never cost the rest of the line
+        out["chop1080"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 
@@ -769,6 +800,11 @@ def main():
                     if pw:
                         pw["frac_of_peak_at_sclk"] = round(line["roofline"]["tflops"] / pw["peak_at_sclk_tflops"], 4)
                         line["roofline"]["power"] = pw
+                        # a box-normalised companion of `value`: the boxes of the pool hold different shader clocks under the same 1400 W cap (1.62 ..
+                        # 1.76 GHz seen; +-3 % of frame time), more than most kernel changes move -- the same step rescaled to a 1700 MHz box.  A comparison aid, never `value`.
+                        line["box_normalised"] = {"sclk_mhz": pw["sclk_mhz"], "ms_per_step_at_1700mhz": round(line["ms_per_step"] * pw["sclk_mhz"] / 1700.0, 3),
+                                                  "value_at_1700mhz": round(line["value"] * 1700.0 / pw["sclk_mhz"], 2),
+                                                  "note": "ms_per_step x sclk / 1700 MHz (the frame is matrix-pipe / power bound: time scales with 1 / sclk); sclk = mean of the rocm-smi samples of the power probe"}
                 log("per-layer classes:\n" + per_layer_table(launches))
     if frame:
         del x
@@ -880,6 +916,7 @@ def main():
         log('pan540')
         try:
             line["pan540"] = pan540_object(dev)
+            line["pan_chop1080"] = line["pan540"].pop("chop1080", None)
         except Exception as e:                      # a side object must never cost the headline line
             line["pan540"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 

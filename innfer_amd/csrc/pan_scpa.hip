@@ -63,6 +63,10 @@ __device__ __forceinline__ f16x8 lrelu8(const f32x4& a, const f32x4& b) {
 // ones) reads the 16 zero bytes at OFF_ZERO instead (a broadcast).  A predicated read is a branch around a ds_read + s_waitcnt per fragment -- the first
 // version of this kernel waited out the LDS latency once per tap (21 us per tile against 4 us of MFMA work).
 __device__ __forceinline__ f16x8 lds16(const char* smem, int off, bool real) { return *(const f16x8*)(smem + (real ? off : OFF_ZERO)); }
+// A PIXEL fragment whose k-octet is structural padding (octet 3 of a 24-channel A / B / Y pixel, octets 1 .. 3 of x's second k-step) needs no select (round 6, VERDICT r5
+// item 3b: 250 compares + 275 selects per 260 MFMAs): the weight fragment it meets holds zeros there (lds16 above), so the lane may read whatever FINITE fp16 data follows its
+// pixel -- the next pixel's first octet(s), the zero-filled slack behind the X tile, the first bytes of the region behind A, or the zeroed tail behind B (see the kernel's start).
+__device__ __forceinline__ f16x8 px16(const char* smem, int off) { return *(const f16x8*)(smem + off); }
 
 // A 20 -> 20 channel 3x3 conv over this wave's RW output rows x 32 pixels (PW = 2 RW pixel tiles: tile u = row * 2 + segment) of the LDS image at
 // `src` (48 B per pixel, 36-pixel rows, the output tile at halo offset (2, 2)).  Column by column (dx outer, dy inner: the tap order of conv3x3_pc's
@@ -82,7 +86,7 @@ __device__ __forceinline__ void conv33_rows(const char* smem, int src, int woff,
         for (int rr = 0; rr < RW + 2; ++rr)
 #pragma unroll
             for (int seg = 0; seg < 2; ++seg)
-                b[rr][seg] = lds16(smem, src + ((row0 + rr + 1) * HC + 1 + seg * 16 + li + dx) * 48 + lg * 16, lg < 3);
+                b[rr][seg] = px16(smem, src + ((row0 + rr + 1) * HC + 1 + seg * 16 + li + dx) * 48 + lg * 16);
 #pragma unroll
         for (int rr = 0; rr < RW + 2; ++rr)
 #pragma unroll
@@ -176,6 +180,9 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 
     fetch(j0);
     for (int i = tid; i < W_BYTES / 16; i += 512) *(f16x8*)(smem + i * 16) = *(const f16x8*)(p.w + i * 16);
+    // (finite data wherever a padding k-octet may be read: the 1 KB behind B -- px16 -- and, for the first tile's P1, the head of A behind the X tile's own zero-filled slack)
+    if (tid < 64) *(f16x8*)(smem + BOFF + NPX * 48 + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < 4) *(f16x8*)(smem + AOFF + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                 for (int k = 0; k < TB; ++k) {
                     const int i = i0 + 8 * k < NP1 ? i0 + 8 * k : i0, P = 16 * i + li;        // (a tile past the end repeats the first one: same values stored twice)
                     b0[k] = *(const f16x8*)(X + P * 80 + lg * 16);
-                    b1[k] = lds16(smem, XOFF + P * 80 + 64, lg == 0);
+                    b1[k] = px16(smem, XOFF + P * 80 + 64 + lg * 16);
                 }
 #pragma unroll
                 for (int k = 0; k < TB; ++k) {
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 #pragma unroll
                     for (int k = 0; k < NK; ++k)
 #pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) b[k][dy] = lds16(smem, BOFF + (Pk[k] + (dy - 1) * HC + dx - 1) * 48 + lg * 16, lg < 3);
+                        for (int dy = 0; dy < 3; ++dy) b[k][dy] = px16(smem, BOFF + (Pk[k] + (dy - 1) * HC + dx - 1) * 48 + lg * 16);
 #pragma unroll
                     for (int k = 0; k < NK; ++k)
 #pragma unroll
