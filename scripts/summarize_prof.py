@@ -56,6 +56,10 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
                 continue
             # conv3x3_pc<RPW, NT, NLW, OUT, S9, POLY, TM, CV, NSI>: the key keeps the first four numbers (bench.py's kernel names); the 7x7 / polyphase /
             # canvas variants get a suffix
+            if "hr_chain_kernel" in r["Kernel_Name"]:          # csrc/hr_chain.hip (round 6): bench.py's kernel_key of launch kind 5000 + ..
+                t = traffic.setdefault("hr_chain_kernel<upconv+HR_conv0+conv_last>", {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+                t[counter][0] += float(r["Counter_Value"]); t[counter][1] += 1
+                continue
             m = re.search(r"(conv3x3_mfma|conv3x3_pc)<([^>]*)>", r["Kernel_Name"])
             if not m:
                 continue
