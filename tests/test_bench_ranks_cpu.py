@@ -156,3 +156,5 @@ def test_run_tile_batches_lands_results_in_the_tile_buffer():
     assert torch.equal(run_tile_batches(lambda t: (t, t * 2), tiles, tile_batch=2, pick=lambda y: y[1], out=buf3), ref)
     with __import__("pytest").raises(RuntimeError):
         run_tile_batches(lambda t: t[:, :2] * 2, tiles, tile_batch=3, out=torch.empty(7, 3, 4, 4))
+    with pytest.raises(ValueError):          # sink= and out= are alternatives (out= used to win silently)
+        run_tile_batches(lambda t: t * 2, tiles, tile_batch=3, sink=lambda i, y: None, out=torch.empty_like(ref))
