@@ -6,19 +6,21 @@
 // HR_conv0 + conv_last launch.  Here an output tile of 16 x 32 HR pixels never leaves the CU:
 //   stage A  the up-conv as the four 2 x 2-tap phases of the equivalent transposed conv (the panels of the one-visit form: conv_pack_up2x_phases, plane row order) on the
 //            tile's 18 x 34 neighbourhood (HR_conv0's halo, recomputed: 612 pixels for 512 = +20 % of the up-conv's MFMAs), its activation, fp16 rounding -- the values
-//            the unchained engine stored -- written into LDS in the halo-tile image of conv3x3_pc, zeros outside the frame (HR_conv0's zero padding);
-//   stage B  HR_conv0 on that LDS-resident tile: the consumer loop of conv3x3_pc<2,4,..> (same fragments, same MFMA order per value), weights through a ring in LDS;
+//            the unchained engine stored -- written into an LDS image of the tile (hr_slot below), zeros outside the frame (HR_conv0's zero padding);
+//   stage B  HR_conv0 on that LDS-resident tile: the walk of conv3x3_pc<2,4,..> (same fragments, same MFMA order per value), weights through a ring in LDS;
 //   fuse     conv_last in HR_conv0's epilogue: conv3x3_fuse.h as it is (rim pixels by fuse_combine_kernel).
-// Every value sees the same operands in the same order as in the two unchained launches: results are BIT-IDENTICAL to them (tests/test_gpu_parity.py).
+// Every value sees the same operands in the same order as in the two unchained launches: results are BIT-IDENTICAL to them (tests/test_gpu_parity.py
+// test_hr_chain_equals_the_launches_it_replaces, scripts/r6/fuzz_chain.py).
 //
-// Workgroup: 8 waves (two per SIMD, 256 registers each), one persistent workgroup per CU, XCD-aware tile walk as in conv3x3_pc.  No loader waves:
+// Workgroup: 8 waves (two per SIMD, 256 registers each, no scratch), one persistent workgroup per CU, XCD-aware tile walk as in conv3x3_pc.  No loader waves:
 //   * stage A's weights never touch LDS.  Wave w owns phase w / 2 and one 32-channel half of its outputs for all of the phase's 153 virtual pixels (9 x 17 LR-grid
-//     positions, linearised into 10 MFMA column groups -- no 17-wide rows padded to 32); its eight A fragments of one input group (4 taps x 2 channel tiles, 32 registers) come straight from L2
-//     (each fragment is one contiguous 1 KB of the panel) and are reloaded tap by tap as soon as their last MFMA is issued -- the next group's weights are in flight under
-//     the current group's MFMAs, and no barrier is needed inside stage A at all (the 128 KB of phase panels through a 16-KB LDS ring would be a barrier every 640 cycles);
+//     positions, linearised into 10 MFMA column groups -- no 17-wide rows padded to 32); its sixteen A fragments (2 input groups x 4 taps x 2 channel tiles, 64 registers:
+//     each one contiguous 1 KB of the panel) are loaded ONCE per kernel, so stage A has no weight traffic and needs no barrier (the 128 KB of phase panels through a
+//     16-KB LDS ring would be a barrier every 640 cycles; reloading them per tile from L2 cost 0.38 of the first version's 4.1 ms);
 //   * the LR input tile (10 x 18 pixels x 64 channels, rows padded to 25 pixels so that the linearised pixel walk stays bank-conflict free), stage B's weight pieces
 //     (one tap COLUMN of one input group = 12 KB, three ring slots) and conv_last's fragments arrive by LDS-DMA issued by the consumer waves themselves.
-// LDS: HR tile 2 x 41 KB | LR tile 2 x 16 KB | weight ring 3 x 12 KB | conv_last fragments 4 KB | biases = 155 KB.
+// LDS: LR tile 2 x 16 KB | HR tile 2 x 41 KB | weight ring 3 x 12 KB | conv_last fragments 4 KB | biases = 155 KB.
+// Measured, ablated and bounded in DESIGN.md 3.2b / docs/EXPERIMENTS.md 103-111; diagnostic driver scripts/r6/hr_chain_micro.cpp (-DINNFER_ABLATE).
 #include "common.h"
 
 #include <type_traits>
@@ -55,7 +57,7 @@ struct ChainP {
 };
 
 constexpr int CH_IN_BYTES = (((16 + 2) * LWP + 15) / 16) * 1024;       // one 32-channel group of the 18 x 36-pixel HR tile, as conv3x3_pc stages it (41 984)
-constexpr int CH_LRP = 25;                                               // LR tile row pitch (pixels): 17 + 8 -- see lr_off
+constexpr int CH_LRP = 25;                                               // LR tile row pitch (pixels): 17 + 8 -- see stage A's per-lane constants
 constexpr int CH_LR_CG = 16 * 1024;                                      // 10 rows x 25 px x 64 B = 16 000 -> 16 DMA pieces
 constexpr int CH_LRT = 0;                                                // (first: its addresses stay below 64 KB, the input group is an immediate of the read)
 constexpr int CH_HRT = CH_LRT + 2 * CH_LR_CG;
@@ -115,16 +117,16 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
 
     // ---- stage A, per-lane constants ----
     // Wave w computes phase ph = w / 2 = 2a + b of the transposed conv (output pixel (2y + a, 2x + b) reads LR rows y + a - 1, y + a and columns x + b - 1, x + b)
-    // for half of the phase's pixels inside the tile's 18 x 34 neighbourhood (local HR rows r = 0 .. 17 <-> frame row ty0 - 1 + r, ty0 even: r even is a = 1).
+    // for one 32-channel half of the outputs, on the tile's 18 x 34 neighbourhood (local HR rows r = 0 .. 17 <-> frame row ty0 - 1 + r, ty0 even: r even is a = 1).
     // Local HR pixel (r, c) = (2k + (1 - a), 2m + (1 - b)), k = 0 .. 8, m = 0 .. 16, reads LR-tile pixels (k + dr, m + dc), dr, dc in {0, 1} (LR-tile origin = LR pixel
-    // (ty0 / 2 - 1, tx0 / 2 - 1)) with the phase panel's tap 2 dr + dc -- the SAME for all four phases.  Virtual pixel v = 17 k + m = 0 .. 152; group g of the wave holds
-    // v = 16 (5 hf + g) + li.  LR tile rows are 25 pixels apart, so pixel index P = 25 k + m = v + 8 k: the 16 lanes of a fragment read walk consecutive pixels with
+    // (ty0 / 2 - 1, tx0 / 2 - 1)) with the phase panel's tap 2 dr + dc -- the SAME for all four phases.  Virtual pixel v = 17 k + m = 0 .. 152; group g (0 .. 9) holds
+    // v = 16 g + li.  LR tile rows are 25 pixels apart, so pixel index P = 25 k + m = v + 8 k: the 16 lanes of a fragment read walk consecutive pixels with
     // at most one jump of 8 -- P mod 8 stays a permutation inside each half of a ds_read_b128 lane group, i.e. the 16-byte-slot XOR swizzle of conv3x3_pc (slot ^=
     // 2 bit2(P)) keeps every read bank-conflict free (a pitch of 18 would conflict two ways on every row change).
     const int ph = wave >> 1, th = wave & 1;          // th: the wave's half of the 64 output channels = slab plane th (channel tiles 2 th, 2 th + 1 of the plane row order)
     const int ra = 1 - (ph >> 1), cb = 1 - (ph & 1);
     // Group g holds virtual pixels v = 16 g + li: rows k_g (lanes li < w_g) and k_g + 1 (the others) of the 9 x 17 lattice -- the per-lane offsets of its LR-tile pixel and
-    // of the HR-tile pixel it produces are a lane term plus one of two COMPILE-TIME constants per group (ch_grp below): a compare and a select where ten tile-invariant
+    // of the HR-tile pixel it produces are a lane term plus one of two COMPILE-TIME constants per group (ch_grp above): a compare and a select where ten tile-invariant
     // registers were held (and spilled: the kernel lives at its register budget).  Lanes li >= 9 of group 9 (v >= 153) have no pixel: they read inside the LDS
     // allocation, compute into their own MFMA columns and store nothing.
     // The phase's A fragments straight from the panel, ONCE per kernel: the wave's phase and channel half never change, so its sixteen fragments (2 input groups x 4 taps x
