@@ -5,7 +5,9 @@ first conv (widths around 16 / 64 boundaries, 1..8 input channels), the PixelShu
 (UNets of 5..8 levels), pan_fsa_combine's strips (widths that are / are not multiples of 4).  Usage: fuzz_r5.py [seconds] [seed]; prints BAD lines, exit code 1 if any.
 FUZZ_CROSS=1: no oracle (30 s a case on the box's host cores) -- the fp16 engine is held to the fp32 engine of the same module instead (two independent kernel sets)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.abspath(__file__))
+while not os.path.isdir(os.path.join(ROOT, "innfer_amd")):          # (the script moved under scripts/archive/ in round 6)
+    ROOT = os.path.dirname(ROOT)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.chdir(ROOT)
 import numpy as np, torch
