@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void pan_attention(const float* fgh, const flo
 // Keys go through a double-buffered LDS stage of two 32-key blocks (per block 1 KB of g pairs + 3 KB of h fragments: one 16-byte load per thread), one
 // barrier per 64 keys; 8 waves x 16 queries per workgroup.  Never materialises the Np x Np matrix either.  att rows as before: fp32 [N * Np][C].
 constexpr int ATT_C = 40, ATT_CQ = 5, ATT_KB = 32;
+constexpr int ATT_SP = 4;          // block pairs (64 keys each) per LDS stage of pan_attention_mfma
 
 // per pooled pixel: QK[point] = {fh, fl', gh, gl'} (four 16-byte octets: 5 values + 3 zeros each; x = xh + xl' * 2^-11, bias added);
 // per image and 32-key block: Vt[blk][t 0..2][lane][8] = h[key blk * 32 + 8 lg + e][channel 16 t + li] + bias as fp16 (0 beyond Np / C)
@@ -225,7 +226,9 @@ __global__ void pan_attn_prep(const float* fgh, const float* bf, const float* bg
 __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f16* Vt, int Np, int nblk, float* out) {
     // 8 waves x 16 queries (two waves per SIMD: one wave's exps and LDS reads run under the other's MFMAs); a stage holds TWO 32-key blocks (8 KB: one
     // 16-byte piece per thread), so a barrier is paid once per 64 keys
-    __shared__ __attribute__((aligned(16))) char st[2][8192];  // per stage and block: g pairs of 32 keys (32 x 32 B) | three h fragments (3 x 1 KB)
+    // (round 6: a stage holds ATT_SP block pairs = 256 keys -- the barrier per 64 keys was a quarter of the kernel: 506 of them per workgroup at 32 400 keys)
+    constexpr int SP = ATT_SP;
+    __shared__ __attribute__((aligned(16))) char st[2][SP * 8192];  // per stage, pair and block: g pairs of 32 keys (32 x 32 B) | three h fragments (3 x 1 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4, n = blockIdx.y;
     const f16* qk = QK + (long)n * nblk * ATT_KB * 32;
     const f16* vt = Vt + (long)n * nblk * 192 * 8;
@@ -272,17 +275,23 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
     // Masked keys (>= Np, the padding of the last block) score -inf: p = 0.  The first pair starts from m = 0 and takes its own maximum as delta.
     float m = 0.f;
     f32x4 acc[3] = {z4, z4, z4};
-    *(f16x8*)(st[0] + dst_off) = *(const f16x8*)stage_src(0);
+#pragma unroll
+    for (int u = 0; u < SP; ++u)
+        if (u < npair) *(f16x8*)(st[0] + u * 8192 + dst_off) = *(const f16x8*)stage_src(u);
     __syncthreads();
-    for (int bp = 0; bp < npair; ++bp) {
-        f16x8 nxt = z8;
-        if (bp + 1 < npair) nxt = *(const f16x8*)stage_src(bp + 1);
+    for (int bp0 = 0; bp0 < npair; bp0 += SP) {
+        f16x8 nxt[SP];
+#pragma unroll
+        for (int u = 0; u < SP; ++u) nxt[u] = bp0 + SP + u < npair ? *(const f16x8*)stage_src(bp0 + SP + u) : z8;
+        const char* const stg = st[(bp0 / SP) & 1];
+        for (int bp = bp0; bp < bp0 + SP && bp < npair; ++bp) {
+        const char* const sb = stg + (bp - bp0) * 8192;
         f32x4 sc[2][2];
         const f32x4 c0 = {-m, -m, -m, -m};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int b = 2 * bp + h;
-            scores(st[bp & 1] + h * 4096, c0, sc[h]);
+            scores(sb + h * 4096, c0, sc[h]);
             const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
             if (kb + 8 > Np) {                                       // (only the last block of an image is ragged)
 #pragma unroll
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const char* sp = st[bp & 1] + h * 4096;
+            const char* sp = sb + h * 4096;
             f16x8 v[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) v[t] = *(const f16x8*)(sp + 1024 + t * 1024 + lane * 16);
@@ -330,7 +339,13 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[t], pk.v8, acc[t], 0, 0, 0);
         }
-        if (bp + 1 < npair) *(f16x8*)(st[(bp + 1) & 1] + dst_off) = nxt;
+        }
+        if (bp0 + SP < npair) {
+            char* const nst = st[((bp0 / SP) + 1) & 1];
+#pragma unroll
+            for (int u = 0; u < SP; ++u)
+                if (bp0 + SP + u < npair) *(f16x8*)(nst + u * 8192 + dst_off) = nxt[u];
+        }
         __syncthreads();
     }
     const float sum = __shfl(acc[2][3], 48 + li);                    // channel 47 = row 15 of tile 2: lane (li, lg = 3), element 3
