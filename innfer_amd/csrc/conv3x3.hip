@@ -27,7 +27,9 @@
 //                                epilogue: S9 (a 7x7 conv as nine displaced 3x3 convs) and POLY (a dilated conv as
 //                                ordinary convs on the polyphase components of the image);
 //   conv3x3_mfma<RPW,NT,OUT>     two independent 4-wave workgroups per CU, tile = 4*RPW rows x 32 px, one LDS
-//                                stage each: PixelShuffle outputs, planar outputs with residuals, fallback.
+//                                stage each (round 1's kernel; kept as the FALLBACK some launches still reach): PixelShuffle(2) stores whose output group is
+//                                2 GiB or more (64-bit indices: SRResNet chop batches beyond 209 tiles, net.hip), PixelShuffle on plain panels (ABI plane_rows 0), planar
+//                                outputs with residuals or 32 / 64 planar channels, and every slab conv of the diagnostic builds' INNFER_PC=0.
 // Per 32-channel chunk the halo tile ((rows+2) x 34 px x 64 B) and the weight panel (9 x 16*NT x 64 B) are
 // staged with LDS-DMA (buffer_load_dwordx4 ... lds; out-of-image lanes are zero-filled by the buffer range
 // check = the conv's zero padding).  LDS rows are 36 px (2304 B = 9 x 256 B: every row starts on bank 0);

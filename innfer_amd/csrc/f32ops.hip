@@ -29,6 +29,9 @@ __device__ __forceinline__ float f32_act(float v, int act) {
     return v;
 }
 
+// The LARGE-SHAPE FALLBACK of f32conv_launch (round 4's first form of the conv; kept on purpose): f32conv_tiled below addresses its patch with 32-bit byte offsets
+// and bounded LDS tiles -- a launch whose input view spans 2 GiB or more (fp32 NCHW frames beyond ~8 M pixels x 64 channels), whose weight panel exceeds 2 GiB or whose best tile does not
+// fit comes here: 64-bit addressing, operands straight from L1 / L2, ~0.12 of the fp32 matrix peak.  Every golden and bench shape takes the tiled kernel.
 // One wave: 32 output channels x 64 output pixels (2 x 4 MFMA tiles of 16 x 16); a block of 4 waves covers `kt_per_block` 32-channel tiles x (4 / kt_per_block)
 // 64-pixel tiles.  Weights wp: [tap][C4][Kp][4] fp32 (Kp = K rounded up to 32, C4 = ceil(C / 4); zeros beyond K / C).
 __global__ __launch_bounds__(256) void f32conv_kernel(const F32Conv p, int kt_per_block, int C4, int Kp) {
