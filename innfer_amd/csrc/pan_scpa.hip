@@ -49,12 +49,14 @@ struct ScpaKP {
     int abl;                                // diagnostic build only (make ablate, INNFER_SCPA_ABL): skip 1 P1, 2 P2a, 4 P2b, 8 P3's MFMAs, 16 the X fetch, 32 the stores
 };
 
+// (LeakyReLU as v_med3_f32(x, 0.2 x, +inf) == x > 0 ? x : 0.2 x for every finite x: two instructions per value instead of multiply + compare + select -- round 6: the block is
+//  bound by vector issue, 5.5 VALU instructions per MFMA by the counters, profiles/r6/pmc_pan.txt)
 __device__ __forceinline__ f16x8 lrelu8(const f32x4& a, const f32x4& b) {
     f16x8 v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        v[j] = (f16)(a[j] > 0.f ? a[j] : 0.2f * a[j]);
-        v[4 + j] = (f16)(b[j] > 0.f ? b[j] : 0.2f * b[j]);
+        v[j] = (f16)__builtin_amdgcn_fmed3f(a[j], 0.2f * a[j], __builtin_inff());
+        v[4 + j] = (f16)__builtin_amdgcn_fmed3f(b[j], 0.2f * b[j], __builtin_inff());
     }
     return v;
 }
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 #endif
         {
             const f32x4 bk0 = *(const f32x4*)(smem + OFF_B2 + (8 * lg) * 4), bk1 = *(const f32x4*)(smem + OFF_B2 + (8 * lg + 4) * 4);
+            const bool edge_t = ty0 < 2 || ty0 + TH + 2 > p.H || tx0 < 2 || tx0 + TW + 2 > p.W;
             // pixel tile i of the flattened (TH + 2) x (TW + 2) region: pixel Q = 16 i + lane -> halo-tile pixel P = (Q / YW + 1) HC + Q % YW + 1
             auto halo_px = [&](int i) __attribute__((always_inline)) {
                 const int Q = min(16 * i + li, NY - 1), r = Q / YW;
@@ -308,15 +311,17 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
                     const int i = i0 + 8 * k < NMID ? i0 + 8 * k : i0, P = Pk[k];
-                    const int r = P / HC, cc = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + cc;
-                    const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
                     f16x8 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         // sigmoid on the hardware exponential and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each): the libm forms are ~50 VALU instructions per
                         // value, 21 k values per tile -- a third of the first version's tile time; the result is rounded to fp16 two lines below
-                        v[e] = (f16)(inside ? c[k][0][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][0][e])) : 0.f);
-                        v[4 + e] = (f16)(inside ? c[k][1][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][1][e])) : 0.f);
+                        v[e] = (f16)(c[k][0][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][0][e])));
+                        v[4 + e] = (f16)(c[k][1][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][1][e])));
+                    }
+                    if (edge_t) {          // (a tile on the frame's border only -- wave-uniform: Y is zero outside the image = k4's zero padding; interior tiles pay no compare / select per value)
+                        const int r = P / HC, cc = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + cc;
+                        if (!(y >= 0 && y < p.H && x >= 0 && x < p.W)) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     }
                     if (lg < 3 && 16 * i + li < NY) *(f16x8*)(smem + AOFF + P * 48 + lg * 16) = v;
                 }
