@@ -1,7 +1,7 @@
 # Build the gfx950 HIP library in-tree (the .so travels to the GPU box with the snapshot).
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
-SRC   := innfer_amd/csrc/conv3x3.hip innfer_amd/csrc/hr_chain.hip innfer_amd/csrc/conv_first.hip innfer_amd/csrc/tiles.hip innfer_amd/csrc/net.hip innfer_amd/csrc/unet.hip innfer_amd/csrc/pan.hip innfer_amd/csrc/pan_scpa.hip innfer_amd/csrc/f32ops.hip innfer_amd/csrc/colorfix.hip innfer_amd/csrc/ppon.hip innfer_amd/csrc/resnet.hip innfer_amd/csrc/wbcunet.hip innfer_amd/csrc/comm.hip
+SRC   := innfer_amd/csrc/conv3x3.hip innfer_amd/csrc/hr_chain.hip innfer_amd/csrc/conv_first.hip innfer_amd/csrc/tiles.hip innfer_amd/csrc/net.hip innfer_amd/csrc/unet.hip innfer_amd/csrc/pan.hip innfer_amd/csrc/pan_scpa.hip innfer_amd/csrc/pan_scpa_split.hip innfer_amd/csrc/f32ops.hip innfer_amd/csrc/colorfix.hip innfer_amd/csrc/ppon.hip innfer_amd/csrc/resnet.hip innfer_amd/csrc/wbcunet.hip innfer_amd/csrc/comm.hip
 OBJ   := $(SRC:.hip=.o)
 LIB   := innfer_amd/lib/libinnfer_amd.so
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function

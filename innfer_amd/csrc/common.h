@@ -167,6 +167,15 @@ void pan_scpa_pack(const float* c1a, const float* c1b, const float* k1, const fl
 // in / out: slabs of two 32-channel groups (40 real channels, pad channels zero), group stride G elements; x -> x + conv3(cat[..]) (PAN_arch.py:58-105)
 int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s, int in_c8 = 0, int out_c8 = 0);      // *_c8: channels 32..39 as a compact 16-byte plane (between two SCPA blocks)
 
+// ---- the same block in the fp32-accurate mode on (hi, lo) fp16 operand pairs (pan_scpa_split.hip) ----
+// tensors as "split planes" of npx = N * H * W pixels: [hi ch 0..31: 64 B / pixel][hi 32..39: 16 B][lo 0..31: 64 B][lo 32..39: 16 B], 160 B per pixel in all
+size_t pan_scpa_split_blob_bytes();
+void pan_scpa_split_pack(const float* c1a, const float* c1b, const float* k1, const float* k2, const float* k2b, const float* k3, const float* k4, const float* c3, void* blob);
+bool pan_scpa_split_ok(int N, int H, int W);                                         // 32-bit buffer offsets
+int pan_scpa_split_launch(const void* in, void* out, const void* d_blob, int N, int H, int W, hipStream_t s);
+int pan_split_from_nchw(const float* x, void* planes, int N, int H, int W, hipStream_t s);      // NCHW fp32, 40 channels
+int pan_split_to_nchw(const void* planes, float* x, int N, int H, int W, hipStream_t s);
+
 // ---- fp32 NCHW building blocks of the -no_fp16 mode of PAN / UNet (f32ops.hip) --------
 struct F32Conv {
     const float* in; long in_nstride, in_cstride; int C, Hin, Win;       // input view: (n, c, y, x) at in + n * in_nstride + c * in_cstride + y * Win + x

@@ -615,6 +615,7 @@ struct innfer_pan {
     bool fp32 = false;               // innfer_pan_set_precision(1): the fp32 forward on NCHW fp32 tensors (f32ops.hip), the reference's -no_fp16 mode
     std::vector<float*> f32_w;       //   f32conv panels in forward order (pan_forward_f32 walks them)
     std::vector<void*> d_scpa;       // one weight blob per SCPA block (pan_scpa.hip), trunk by trunk
+    std::vector<void*> d_scpa32;     // ... as (hi, lo) blob pairs for the fp32 mode's fused block (pan_scpa_split.hip): packed by innfer_pan_set_precision(1)
     int scpa_c8 = 1;                 // compact channel plane between the fused SCPA blocks (pan_scpa_launch in_c8 / out_c8); 0: A/B (fused_scpa 3)
     int mfma_attention = 1;          // the FSA block's attention on the matrix cores (pan_attention_mfma); 0: the VALU kernel of rounds 1-3 (set with fused_scpa: one A/B switch)
     int fused_last = 1;              // the last stage's HRconv with conv_last in its epilogue (conv3x3_pc FUSE on 32 channels, round 5); 0: two launches (fused_scpa 4)
@@ -678,6 +679,7 @@ extern "C" void innfer_pan_destroy(innfer_pan* p) {
     for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); if (g.d_fuse) (void)hipFree(g.d_fuse); }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
     for (auto v : p->d_scpa) if (v) (void)hipFree(v);
+    for (auto v : p->d_scpa32) if (v) (void)hipFree(v);
     for (auto v : p->f32_w) if (v) (void)hipFree(v);
     delete p;
 }
@@ -856,6 +858,8 @@ int upload(innfer_pan* p) {
     p->f32_w.clear();
     for (auto v : p->d_scpa) if (v) (void)hipFree(v);
     p->d_scpa.clear();
+    for (auto v : p->d_scpa32) if (v) (void)hipFree(v);
+    p->d_scpa32.clear();
     {   // one blob per SCPA block for the fused launch (pan_scpa.hip): the block's eight tensors as MFMA fragments
         std::vector<char> blob(pan_scpa_blob_bytes());
         auto Wk = [p](const std::string& key) -> const float* { return p->params[find(p, key)].host.data(); };
@@ -966,6 +970,20 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
     const float* xc = FEA;
     for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k) {
         const std::string sfx = k ? "2" : "";
+        // the trunk's blocks as one launch each on (hi, lo) fp16 operand pairs (pan_scpa_split.hip; innfer_pan_set_fused_scpa(pan, 0): the six generic fp32 launches per block)
+        if (p->fused_scpa && (int)p->d_scpa32.size() == (p->double_scpa ? 2 : 1) * p->nb && pan_scpa_split_ok(N, H, W)) {
+            void *sa = XA, *sb = XB;
+            const double px = (double)N * H * W;
+            { GtScope gt(s, "pan split planes <-> NCHW fp32", 0.0, 320.0 * px); CK(pan_split_from_nchw(xc, sa, N, H, W, s)); }
+            for (int b = 0; b < p->nb; ++b) {
+                GtScope gt(s, "pan_scpa_split (one SCPA block, fp32 mode)", 2.0 * (2 * 20 * 40 + 3 * 9 * 20 * 20 + 20 * 20 + 40 * 40) * px, 320.0 * px + 57600.0);
+                CK(pan_scpa_split_launch(sa, sb, p->d_scpa32[(size_t)k * p->nb + b], N, H, W, s));
+                std::swap(sa, sb);
+            }
+            { GtScope gt(s, "pan split planes <-> NCHW fp32", 0.0, 320.0 * px); CK(pan_split_to_nchw(sa, AB, N, H, W, s)); }
+            xc = AB;
+            wi += 6 * p->nb;
+        } else
         for (int b = 0; b < p->nb; ++b) {
             const std::string sb = "SCPA_trunk" + sfx + "." + std::to_string(b) + ".";
             float* xn = (b & 1) ? XB : XA;
@@ -1082,6 +1100,20 @@ extern "C" int innfer_pan_set_precision(innfer_pan* p, int fp32) {
     }
     CK(plain("conv_last.weight", p->out_nc, UF, 3));
 #undef CK
+    {   // the SCPA blocks as (hi, lo) blob pairs for the fused split-operand launch (pan_scpa_split.hip)
+        std::vector<char> blob(pan_scpa_split_blob_bytes());
+        auto Wp = [p](const std::string& key) -> const float* { return p->params[find(p, key)].host.data(); };
+        for (int k = 0; k < (p->double_scpa ? 2 : 1); ++k)
+            for (int b = 0; b < p->nb; ++b) {
+                const std::string s = "SCPA_trunk" + std::string(k ? "2" : "") + "." + std::to_string(b) + ".";
+                pan_scpa_split_pack(Wp(s + "conv1_a.weight"), Wp(s + "conv1_b.weight"), Wp(s + "k1.0.weight"), Wp(s + "PACnv.k2.weight"), Wp(s + "PACnv.k2.bias"),
+                                    Wp(s + "PACnv.k3.weight"), Wp(s + "PACnv.k4.weight"), Wp(s + "conv3.weight"), blob.data());
+                void* d = nullptr;
+                INNFER_HIP(hipMalloc(&d, blob.size()));
+                p->d_scpa32.push_back(d);
+                INNFER_HIP(hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice));
+            }
+    }
     return INNFER_OK;
 }
 
