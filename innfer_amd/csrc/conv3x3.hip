@@ -1141,9 +1141,9 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
     if (L.outm && (L.out_mode != OUT_NCHW || !pc || nt != 1 || L.res1 || L.res2 || L.outm < 0 || L.outm > 4))
         return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3: outm belongs to the planar last conv (<= 16 channels)");
     if (L.split) {           // fp32-accurate mode on (hi, lo) slab pairs: 3 * C / 32 virtual chunks (conv3x3_pc<.., TMF | 0x2000>)
-        if (!pc || (L.act > 2 && !((L.act == 3 || L.act == 6) && L.out_mode == OUT_NCHW)) || L.reflect || L.dilation > 1 || L.dilation_groups || L.deconv_phases || L.stride2 || L.conv7v || L.conv7 || L.stats_part ||
+        if (!pc || (L.act > 2 && !((L.act == 3 || L.act == 6) && L.out_mode == OUT_NCHW) && !((L.act == 4 || L.act == 5) && L.conv1x1 && nt == 2)) || L.reflect || L.dilation > 1 || L.dilation_groups || L.deconv_phases || L.stride2 || L.conv7v || L.conv7 || L.stats_part ||
             L.prefix_lrelu || L.phase_c || (long)3 * L.C / 32 > 0x7fff)
-            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (fp32 mode): plain 3x3 / 1x1 convs with act 0..2, residuals, upsampled input");
+            return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (fp32 mode): plain 3x3 / 1x1 convs with act 0..2 (the 32-channel 1x1 conv also the PA gate), residuals, upsampled input");
         k.nchunks = 3 * k.ncg;
         k.in_lo_bytes = L.in_lo * 2; k.out_lo = L.out_lo; k.res1_lo = L.res1_lo; k.res2_lo = L.res2_lo;
         if (L.out_mode == OUT_SLAB && L.conv1x1 && (nt == 2 || nt == 4))

@@ -254,10 +254,15 @@ __device__ __forceinline__ void epilogue_slab_split(const KP& p, f32x4 (&acc)[NT
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float f = acc[t][m][j];
-                if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                else if (ACT == 2) f = f > 0.f ? f : 0.f;
-                if (R1) f = __builtin_fmaf(f, p.s1, __builtin_fmaf((float)r1l[t][j], SPLIT_DOWN, (float)r1h[t][j]));
-                if (R2) f = __builtin_fmaf(f, p.s2, __builtin_fmaf((float)r2l[t][j], SPLIT_DOWN, (float)r2h[t][j]));
+                if (ACT >= 4) {                  // pixel-attention gate (PAN, fp32 mode): res1 * sigmoid(conv), ACT 4: LeakyReLU(0.2) after it
+                    f = __builtin_fmaf((float)r1l[t][j], SPLIT_DOWN, (float)r1h[t][j]) * fast_sigmoid(f);
+                    if (ACT == 4) f = fmaxf(f, 0.2f * f);
+                } else {
+                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
+                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    if (R1) f = __builtin_fmaf(f, p.s1, __builtin_fmaf((float)r1l[t][j], SPLIT_DOWN, (float)r1h[t][j]));
+                    if (R2) f = __builtin_fmaf(f, p.s2, __builtin_fmaf((float)r2l[t][j], SPLIT_DOWN, (float)r2h[t][j]));
+                }
                 FP32_VALUE(f);
                 h[j] = (f16)f;
                 float d = f - (float)h[j];

@@ -53,6 +53,27 @@ __global__ void pan_pre(const void* in, int in_f32, int C, long HW, int N, f16* 
 
 // MaxPool2d(4): one thread per (pooled pixel, 8 channels), 16-byte loads (C % 8 == 0); the pad channels up to the next multiple of 32 are
 // written as zeros (the projections behind it read whole 32-channel groups)
+// fp32 mode: NCHW fp32 -> a (hi, lo) pair of fp16 slabs (lo = fp16((x - hi) * 2^11), `lo` elements behind hi; conv3x3_pc's split operands), pad channels zero.
+// A thread: 8 channels of one pixel.
+__global__ void pan_nchw_to_slab_pair(const float* x, int C, long HW, int N, int groups, f16* slab, long lo) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x, npx = (long)N * HW;
+    if (i >= npx * groups * 4) return;
+    const long pix = i / (groups * 4);
+    const int o = (int)(i - pix * groups * 4), g = o >> 2, oct = o & 3;
+    const long n = pix / HW, q = pix - n * HW;
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 32 + oct * 8 + e;
+        const float f = c < C ? x[(n * C + c) * HW + q] : 0.f;
+        const f16 hh = (f16)f;
+        h[e] = hh; l[e] = (f16)((f - (float)hh) * 2048.0f);
+    }
+    f16* d = slab + (long)g * npx * 32 + pix * 32 + oct * 8;
+    *(f16x8*)d = h;
+    *(f16x8*)(d + lo) = l;
+}
+
 __global__ void pan_maxpool(const f16* in, long in_g, int C, int N, int H, int W, int hp, int wp, f16* out, long out_g) {
     const int c8 = ((C + 31) / 32 * 32) >> 3;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,7 +204,8 @@ constexpr int ATT_SP = 4;          // block pairs (64 keys each) per LDS stage o
 
 // per pooled pixel: QK[point] = {fh, fl', gh, gl'} (four 16-byte octets: 5 values + 3 zeros each; x = xh + xl' * 2^-11, bias added);
 // per image and 32-key block: Vt[blk][t 0..2][lane][8] = h[key blk * 32 + 8 lg + e][channel 16 t + li] + bias as fp16 (0 beyond Np / C)
-__global__ void pan_attn_prep(const float* fgh, const float* bf, const float* bg, const float* bh, int Np, int nblk, f16* QK, f16* Vt) {
+// Vl != nullptr (fp32 mode): the h fragments as (hi, lo) pairs, lo = fp16((h - hi) * 2^11) in a second array of Vt's layout (the row of ones: hi 1, lo 0)
+__global__ void pan_attn_prep(const float* fgh, const float* bf, const float* bg, const float* bh, int Np, int nblk, f16* QK, f16* Vt, f16* Vl) {
     const int n = blockIdx.y;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const float* base = fgh + (long)n * Np * 64;
@@ -213,25 +235,33 @@ __global__ void pan_attn_prep(const float* fgh, const float* bf, const float* bg
     }
     if (i < (long)nblk * 3 * 64) {                              // one h fragment (8 keys of one channel) per thread
         const int blk = (int)(i / 192), r = (int)(i - (long)blk * 192), t = r >> 6, lane = r & 63, li = lane & 15, lg = lane >> 4, c = 16 * t + li;
-        f16x8 v;
+        f16x8 v, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const long key = (long)blk * ATT_KB + 8 * lg + e;
-            v[e] = (f16)((key < Np && c < ATT_C) ? base[key * 64 + 2 * ATT_CQ + c] + bh[c] : ((key < Np && c == 47) ? 1.0f : 0.f));      // channel 47: ones -- its row of P V is the row sum
+            const float f = (key < Np && c < ATT_C) ? base[key * 64 + 2 * ATT_CQ + c] + bh[c] : ((key < Np && c == 47) ? 1.0f : 0.f);      // channel 47: ones -- its row of P V is the row sum
+            v[e] = (f16)f;
+            vl[e] = (f16)((f - (float)v[e]) * 2048.0f);
         }
         *(f16x8*)(Vt + ((long)n * nblk * 192 + i) * 8) = v;
+        if (Vl) *(f16x8*)(Vl + ((long)n * nblk * 192 + i) * 8) = vl;
     }
 }
 
-__global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f16* Vt, int Np, int nblk, float* out) {
+// SPLIT (the fp32 mode's attention, round 6): p and h as (hi, lo * 2^11) fp16 pairs as well -- p V = ph vh + 2^-11 (ph vl + pl vh), three MFMAs per fragment into two accumulator
+// sets (the row of ones gives sum(ph) and sum(pl): numerator and denominator use the same 22-bit p); a stage block grows by the 3 KB of lo fragments.
+template <bool SPLIT>
+__global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f16* Vt, const f16* Vl, int Np, int nblk, float* out) {
     // 8 waves x 16 queries (two waves per SIMD: one wave's exps and LDS reads run under the other's MFMAs); a stage holds TWO 32-key blocks (8 KB: one
     // 16-byte piece per thread), so a barrier is paid once per 64 keys
     // (round 6: a stage holds ATT_SP block pairs = 256 keys -- the barrier per 64 keys was a quarter of the kernel: 506 of them per workgroup at 32 400 keys)
-    constexpr int SP = ATT_SP;
-    __shared__ __attribute__((aligned(16))) char st[2][SP * 8192];  // per stage, pair and block: g pairs of 32 keys (32 x 32 B) | three h fragments (3 x 1 KB)
+    constexpr int SP = SPLIT ? 2 : ATT_SP;
+    constexpr int BLK = SPLIT ? 7168 : 4096, PER = BLK / 16, NPC = (2 * PER + 511) / 512;      // bytes / 16-byte pieces of a block in a stage; pieces per thread and pair
+    __shared__ __attribute__((aligned(16))) char st[2][SP * 2 * BLK];  // per stage, pair and block: g pairs of 32 keys (32 x 32 B) | three h fragments (3 x 1 KB) [| their lo parts]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4, n = blockIdx.y;
     const f16* qk = QK + (long)n * nblk * ATT_KB * 32;
     const f16* vt = Vt + (long)n * nblk * 192 * 8;
+    [[maybe_unused]] const f16* vl = SPLIT ? Vl + (long)n * nblk * 192 * 8 : nullptr;
     const f16x8 z8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     // B operands of the score MFMAs for this wave's 16 queries (a query beyond Np reads a padding key's zero row: its results are never stored)
@@ -243,14 +273,16 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
         bhh = lg == 0 ? fh : z8;
         bx = lg == 0 ? fl : (lg == 1 ? fh : z8);
     }
-    // staging: thread tid moves one 16-byte piece of block pair bp (blocks 2 bp, 2 bp + 1) into stage bp & 1
-    const int half = tid >> 8, t8 = tid & 255;
-    auto stage_src = [&](int bp) -> const f16* {
+    // staging: thread tid moves the 16-byte pieces tid, tid + 512, .. (< 2 PER) of block pair bp (blocks 2 bp, 2 bp + 1)
+    auto stage_src = [&](int bp, int c) -> const f16* {
+        const int pc = tid + 512 * c, half = pc >= PER ? 1 : 0, t8 = pc - half * PER;
         const int b = 2 * bp + half < nblk ? 2 * bp + half : nblk - 1;                            // (an odd tail: the last block twice, its second copy masked)
         if (t8 < 64) return qk + ((long)b * ATT_KB + (t8 >> 1)) * 32 + 16 + (t8 & 1) * 8;        // {gh, gl'} of key t8 / 2
-        return vt + ((long)b * 192 + (t8 - 64)) * 8;
+        if (!SPLIT || t8 < 256) return vt + ((long)b * 192 + (t8 - 64)) * 8;
+        return vl + ((long)b * 192 + (t8 - 256)) * 8;
     };
-    const int dst_off = half * 4096 + (t8 < 64 ? t8 * 16 : 1024 + (t8 - 64) * 16);
+    auto piece_ok = [&](int c) { return tid + 512 * c < 2 * PER; };
+    auto dst_off = [&](int c) { const int pc = tid + 512 * c, half = pc >= PER ? 1 : 0, t8 = pc - half * PER; return half * BLK + t8 * 16; };
     // the key of row rho (= li) of score tile t, and this lane's A-operand octet: gh for k-octet 0, gl' for k-octet 1
     const int koff0 = (8 * (li >> 2) + (li & 3)) * 32 + (lg == 1 ? 16 : 0), koff1 = koff0 + 4 * 32;
     auto scores = [&](const char* sp, const f32x4& c0, f32x4 (&sc)[2]) __attribute__((always_inline)) {      // sc[t][j]: key 8 lg + 4 t + j of the block, query li, MINUS the offset in c0
@@ -275,23 +307,28 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
     // Masked keys (>= Np, the padding of the last block) score -inf: p = 0.  The first pair starts from m = 0 and takes its own maximum as delta.
     float m = 0.f;
     f32x4 acc[3] = {z4, z4, z4};
+    [[maybe_unused]] f32x4 accx[3] = {z4, z4, z4};
 #pragma unroll
     for (int u = 0; u < SP; ++u)
-        if (u < npair) *(f16x8*)(st[0] + u * 8192 + dst_off) = *(const f16x8*)stage_src(u);
+#pragma unroll
+        for (int c = 0; c < NPC; ++c)
+            if (u < npair && piece_ok(c)) *(f16x8*)(st[0] + u * 2 * BLK + dst_off(c)) = *(const f16x8*)stage_src(u, c);
     __syncthreads();
     for (int bp0 = 0; bp0 < npair; bp0 += SP) {
-        f16x8 nxt[SP];
+        f16x8 nxt[SP][NPC];
 #pragma unroll
-        for (int u = 0; u < SP; ++u) nxt[u] = bp0 + SP + u < npair ? *(const f16x8*)stage_src(bp0 + SP + u) : z8;
+        for (int u = 0; u < SP; ++u)
+#pragma unroll
+            for (int c = 0; c < NPC; ++c) nxt[u][c] = (bp0 + SP + u < npair && piece_ok(c)) ? *(const f16x8*)stage_src(bp0 + SP + u, c) : z8;
         const char* const stg = st[(bp0 / SP) & 1];
         for (int bp = bp0; bp < bp0 + SP && bp < npair; ++bp) {
-        const char* const sb = stg + (bp - bp0) * 8192;
+        const char* const sb = stg + (bp - bp0) * 2 * BLK;
         f32x4 sc[2][2];
         const f32x4 c0 = {-m, -m, -m, -m};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int b = 2 * bp + h;
-            scores(sb + h * 4096, c0, sc[h]);
+            scores(sb + h * BLK, c0, sc[h]);
             const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
             if (kb + 8 > Np) {                                       // (only the last block of an image is ragged)
 #pragma unroll
@@ -315,7 +352,7 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
             const float rescale = __builtin_amdgcn_exp2f(-delta);    // (acc is zero on the first pair)
             m += delta;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = acc[t] * rescale;
+            for (int t = 0; t < 3; ++t) { acc[t] = acc[t] * rescale; if (SPLIT) accx[t] = accx[t] * rescale; }
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -325,12 +362,33 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const char* sp = sb + h * 4096;
+            const char* sp = sb + h * BLK;
             f16x8 v[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) v[t] = *(const f16x8*)(sp + 1024 + t * 1024 + lane * 16);
             typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
             union { f16x8 v8; f16x2_t v2[4]; } pk;
+            if constexpr (SPLIT) {
+                f16x8 w[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) w[t] = *(const f16x8*)(sp + 4096 + t * 1024 + lane * 16);
+                union { f16x8 v8; f16x2_t v2[4]; } pl;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const float e0 = __builtin_amdgcn_exp2f(sc[h][t][2 * jj]), e1 = __builtin_amdgcn_exp2f(sc[h][t][2 * jj + 1]);
+                        const f16x2_t ph = __builtin_bit_cast(f16x2_t, __builtin_amdgcn_cvt_pkrtz(e0, e1));
+                        pk.v2[2 * t + jj] = ph;
+                        pl.v2[2 * t + jj] = __builtin_bit_cast(f16x2_t, __builtin_amdgcn_cvt_pkrtz((e0 - (float)ph[0]) * 2048.0f, (e1 - (float)ph[1]) * 2048.0f));
+                    }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[t], pk.v8, acc[t], 0, 0, 0);
+                    accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], pk.v8, accx[t], 0, 0, 0);
+                    accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[t], pl.v8, accx[t], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -338,15 +396,24 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
                     pk.v2[2 * t + jj] = __builtin_bit_cast(f16x2_t, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(sc[h][t][2 * jj]), __builtin_amdgcn_exp2f(sc[h][t][2 * jj + 1])));
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[t], pk.v8, acc[t], 0, 0, 0);
+            }
         }
         }
         if (bp0 + SP < npair) {
             char* const nst = st[((bp0 / SP) + 1) & 1];
 #pragma unroll
             for (int u = 0; u < SP; ++u)
-                if (bp0 + SP + u < npair) *(f16x8*)(nst + u * 8192 + dst_off) = nxt[u];
+#pragma unroll
+                for (int c = 0; c < NPC; ++c)
+                    if (bp0 + SP + u < npair && piece_ok(c)) *(f16x8*)(nst + u * 2 * BLK + dst_off(c)) = nxt[u][c];
         }
         __syncthreads();
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_fmaf(accx[t][j], 1.0f / 2048.0f, acc[t][j]);
     }
     const float sum = __shfl(acc[2][3], 48 + li);                    // channel 47 = row 15 of tile 2: lane (li, lg = 3), element 3
     if (q < Np) {
@@ -599,6 +666,7 @@ struct Gemm {                       // one packed GEMM
     std::function<int(int)> bias_row;                   // optional: output row -> index into the bias parameter (-1: none); default: row == index
     bool one_tap = false;                               // a 1x1 conv: single-tap panel (conv_pack_1x1), the kernel's one-tap instantiation
     void* d_fuse = nullptr;                             // conv_last behind a 32-channel HRconv: its panel for that conv's fused epilogue (conv_pack_fuse_last(.., cin = 32)); round 5
+    void* d_w3s = nullptr;                              // fp32 mode: the (wl | wh | wh) panels of conv3x3_pc's split-operand form (conv_pack_split / conv_pack_1x1_split), the HR side's convs
     bool pa_gate = false; void* d_gate = nullptr;       // the PA block's 1x1 conv (upsample.<i>.conv): also packed as the self-gate fragments of the conv in front of it (conv_pack_selfgate)
 };
 
@@ -676,7 +744,7 @@ extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int
 
 extern "C" void innfer_pan_destroy(innfer_pan* p) {
     if (!p) return;
-    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); if (g.d_fuse) (void)hipFree(g.d_fuse); }
+    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); if (g.d_fuse) (void)hipFree(g.d_fuse); if (g.d_w3s) (void)hipFree(g.d_w3s); }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
     for (auto v : p->d_scpa) if (v) (void)hipFree(v);
     for (auto v : p->d_scpa32) if (v) (void)hipFree(v);
@@ -803,6 +871,7 @@ int upload(innfer_pan* p) {
         if (g.d_b3) { (void)hipFree(g.d_b3); g.d_b3 = nullptr; }
         if (g.d_gate) { (void)hipFree(g.d_gate); g.d_gate = nullptr; }
         if (g.d_fuse) { (void)hipFree(g.d_fuse); g.d_fuse = nullptr; }
+        if (g.d_w3s) { (void)hipFree(g.d_w3s); g.d_w3s = nullptr; }
     }
     build_gemms(p);
     std::vector<f16> panel;
@@ -918,7 +987,7 @@ PCarve pcarve(const innfer_pan* p, int N, int H, int W) {
 
 namespace {
 // ---- the fp32 mode: PAN.forward on NCHW fp32 tensors with the generic fp32 ops (f32ops.hip); graph = oracle/nets.py pan_forward = PAN_arch.py:178-222 ----
-struct PCarve32 { size_t fea, xa, xb, ab, cat, k3y, yv, inp, t, pool, fgh, att, hr[2][3], ups, raw, total; };
+struct PCarve32 { size_t fea, xa, xb, ab, cat, k3y, yv, inp, t, pool, fgh, att, aqk, avt, avl, hr[2][3], ups, raw, total; };
 PCarve32 pcarve32(const innfer_pan* p, int N, int H, int W) {
     PCarve32 c{};
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -927,12 +996,16 @@ PCarve32 pcarve32(const innfer_pan* p, int N, int H, int W) {
     auto buf = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
     c.fea = buf(px * nf); c.xa = buf(px * nf); c.xb = buf(px * nf); c.ab = buf(px * nf); c.cat = buf(px * nf); c.k3y = buf(px * gw); c.yv = buf(px * gw);
     c.inp = buf(px * nf); c.t = buf(px * nf); c.pool = buf((np ? np : 1) * nf); c.fgh = buf((np ? np : 1) * 64); c.att = buf((np ? np : 1) * nf);
+    {   // the attention on the matrix cores (pan_attention_mfma<true>): per image nblk 32-key blocks of {fh, fl', gh, gl'} rows (64 B per key) and of h fragments (3 KB hi + 3 KB lo)
+        const size_t nblk = (hp * wp + 31) / 32;
+        c.aqk = buf((size_t)N * nblk * 32 * 16 + 64); c.avt = buf((size_t)N * nblk * 768 + 64); c.avl = buf((size_t)N * nblk * 768 + 64);
+    }
     size_t m = 1, ups = 0;
     for (int u = 0; u < p->n_up; ++u) {
         const size_t cin = u == 0 ? nf : UF;
         m *= p->scale == 3 ? 9 : 4;
         ups = std::max(ups, px * m * cin);
-        for (int k = 0; k < 3; ++k) c.hr[u][k] = buf(px * m * UF);
+        for (int k = 0; k < 3; ++k) c.hr[u][k] = buf(px * m * 32);          // (32 floats = 128 B per pixel: a one-group (hi, lo) slab pair of the split-operand HR side; the generic path uses UF floats of it)
     }
     c.ups = (p->bilinear_up || p->scale == 3) ? buf(ups) : 0;
     c.raw = buf(px * m * p->out_nc);
@@ -1013,12 +1086,65 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
             c.Ho = hp; c.Wo = wp; c.osy = c.osx = 1; c.isy = c.isx = 1; c.ntap = 1; c.N = N;
             CK(f32conv_launch(c, s));
         }
-        hipLaunchKernelGGL(pan_attention, dim3((Np + 63) / 64, N), dim3(256), 0, s, (const float*)FGH, vec("FSA.conv_f.bias"), vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), Np, ATT);
+        if (p->mfma_attention && nf == ATT_C) {      // softmax(f^T g) h on the matrix cores with (hi, lo) fp16 pairs of f, g, p and h (pan_attention_mfma<true>)
+            const int nblk = (Np + ATT_KB - 1) / ATT_KB;
+            GtScope gt(s, "pan_attention_mfma, fp32 mode (+ prep)", 2.0 * N * (double)Np * Np * (2 * 5 + 40), (double)N * Np * (64.0 + nf) * 4.0);
+            const long work = (long)nblk * 192 > (long)nblk * ATT_KB ? (long)nblk * 192 : (long)nblk * ATT_KB;
+            hipLaunchKernelGGL(pan_attn_prep, dim3((unsigned)((work + 255) / 256), N), dim3(256), 0, s, (const float*)FGH, vec("FSA.conv_f.bias"), vec("FSA.conv_g.bias"),
+                               vec("FSA.conv_h.bias"), Np, nblk, (f16*)(ws + cv.aqk), (f16*)(ws + cv.avt), (f16*)(ws + cv.avl));
+            hipLaunchKernelGGL(pan_attention_mfma<true>, dim3((Np + 127) / 128, N), dim3(512), 0, s, (const f16*)(ws + cv.aqk), (const f16*)(ws + cv.avt), (const f16*)(ws + cv.avl),
+                               Np, nblk, ATT);
+        } else {
+            GtScope gt(s, "pan_attention (fp32 VALU)", 2.0 * N * (double)Np * Np * (2 * 5 + 40), (double)N * Np * (64.0 + nf) * 4.0);
+            hipLaunchKernelGGL(pan_attention, dim3((Np + 63) / 64, N), dim3(256), 0, s, (const float*)FGH, vec("FSA.conv_f.bias"), vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), Np, ATT);
+        }
         INNFER_HIP(hipGetLastError());
         CK(f32_fsa_combine_launch(ATT, hp, wp, nf, INP, T, N, H, W, vec("FSA.gamma"), s));
         cur = T;
     }
     int h = H, w = W, cc = nf;
+    float* RAW = B(cv.raw);
+    // The HR side on the halo-tile kernel's split-operand form (conv3x3_pc SPLIT: (hi, lo) fp16 slab pairs, three MFMAs per product, fp32 accumulators): per stage
+    // conv(nearest2x(.)) -> 1x1 conv with the PA gate as its epilogue -> HRconv, then conv_last -> planar fp32.  innfer_pan_set_fused_scpa(pan, 0), bilinear / 3x stages:
+    // the generic fp32 convs below.
+    const size_t g_first = p->gemms.size() - 1 - 3 * (size_t)p->n_up;
+    bool split_hr = p->fused_scpa && p->n_up > 0 && !p->bilinear_up && p->scale != 3 && (long)N * H * W * (p->scale * p->scale) * 64 < 0x7fffffffL;
+    for (size_t i = g_first; i < p->gemms.size() && split_hr; ++i) if (!p->gemms[i].d_w3s) split_hr = false;
+    if (split_hr) {
+        const long px = (long)N * H * W;
+        f16* TS = (f16*)XA;                                     // (XA | XB are contiguous and free here: 320 B per pixel for the 256 of a two-group pair)
+        {   GtScope gt(s, "pan NCHW fp32 -> (hi, lo) slab pair", 0.0, (double)px * (nf * 4.0 + 256.0));
+            hipLaunchKernelGGL(pan_nchw_to_slab_pair, dim3((unsigned)((px * 8 + 255) / 256)), dim3(256), 0, s, cur, nf, hw, N, 2, TS, 2 * px * 32);
+            INNFER_HIP(hipGetLastError()); }
+        auto convs = [&](const Gemm& g, const f16* in, long in_g, long in_lo, int Ho, int Wo, int up, int act, const f16* res, f16* dst, float* planar) -> int {
+            ConvLaunch L{};
+            const long og = (long)N * Ho * Wo * 32;
+            L.in = in; L.in_gstride = in_g; L.C = g.cin_pad;
+            L.wpk = (const f16*)g.d_w3s; L.bias = g.d_b3;
+            L.out = planar ? (void*)planar : (void*)dst; L.out_gstride = og; L.K = g.K3;
+            L.N = N; L.H = Ho; L.W = Wo; L.act = act; L.up = up;
+            L.res1 = res; L.res1_gstride = og; L.s1 = 1.f; L.s2 = 1.f;
+            L.y0 = 0; L.y1 = Ho;
+            L.out_mode = planar ? OUT_NCHW : OUT_SLAB; L.out_f32 = planar ? 1 : 0;
+            L.conv1x1 = g.one_tap ? 1 : 0;
+            L.split = 1; L.in_lo = in_lo; L.out_lo = og; L.res1_lo = og;
+            return conv_launch(L, s);
+        };
+        const f16* c16 = TS;
+        long c_g = px * 32, c_lo = 2 * px * 32;
+        size_t gi = g_first;
+        for (int u = 0; u < p->n_up; ++u) {
+            const int hh = 2 * h, ww = 2 * w;
+            const long HG = (long)N * hh * ww * 32;
+            f16 *V = (f16*)B(cv.hr[u][0]), *PAo = (f16*)B(cv.hr[u][1]), *HRC = (f16*)B(cv.hr[u][2]);
+            CK(convs(p->gemms[gi], c16, c_g, c_lo, hh, ww, 1, 0, nullptr, V, nullptr));                          // conv(nearest2x(t))
+            CK(convs(p->gemms[gi + 1], V, HG, HG, hh, ww, 0, 4, V, PAo, nullptr));                              // lrelu(v * sigmoid(conv1x1(v)))
+            CK(convs(p->gemms[gi + 2], PAo, HG, HG, hh, ww, 0, p->n_up == 1 ? 1 : 0, nullptr, HRC, nullptr));  // HRconv
+            gi += 3;
+            c16 = HRC; c_g = HG; c_lo = HG; h = hh; w = ww;
+        }
+        CK(convs(p->gemms[gi], c16, c_g, c_lo, h, w, 0, 0, nullptr, nullptr, RAW));                               // conv_last -> planar fp32 (+ bias)
+    } else {
     for (int u = 0; u < p->n_up; ++u) {
         const int uf = p->scale == 3 ? 3 : 2, hh = uf * h, ww = uf * w, i = 5 * u;
         float *V = B(cv.hr[u][0]), *PAo = B(cv.hr[u][1]), *HRC = B(cv.hr[u][2]);
@@ -1034,8 +1160,8 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
         CK(conv(PAo, UF, UF, hh, ww, 0, 3, vec(s4), UF, HRC, UF, p->n_up == 1 ? 1 : 0));                 // HRconv (+ the LeakyReLU only in one-stage nets: see the fp16 path)
         cur = HRC; h = hh; w = ww; cc = UF;
     }
-    float* RAW = B(cv.raw);
     CK(conv(cur, cc, cc, h, w, 0, 3, vec("conv_last.bias"), p->out_nc, RAW, p->out_nc, 0));
+    }
     {
         const long fpx = (long)N * h * w;
         hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, (const float*)RAW, 0, (const float*)nullptr, p->out_nc, (const void*)x, 1, N, H, W, p->scale, (void*)y, 1);
@@ -1100,6 +1226,25 @@ extern "C" int innfer_pan_set_precision(innfer_pan* p, int fp32) {
     }
     CK(plain("conv_last.weight", p->out_nc, UF, 3));
 #undef CK
+    {   // the HR side's convs (per stage: up-conv, the PA block's 1x1 conv, HRconv; conv_last) as split panels of the halo-tile kernel (conv3x3_pc SPLIT)
+        const size_t first = p->gemms.size() - 1 - 3 * (size_t)p->n_up;
+        for (size_t i = first; i < p->gemms.size(); ++i) {
+            Gemm& g = p->gemms[i];
+            if (!g.tile3 || g.d_w3s) continue;
+            std::vector<float> w3((size_t)g.K3 * g.cin_pad * 9, 0.f);
+            for (int co = 0; co < g.cout; ++co)
+                for (int ci = 0; ci < g.cin_pad; ++ci)
+                    for (int t = 0; t < 9; ++t) w3[((size_t)co * g.cin_pad + ci) * 9 + t] = g.weight(co, ci, t);
+            std::vector<char> packed(3 * (g.one_tap ? conv_packed_bytes_taps(g.K3, g.cin_pad, 0x10) : conv_packed_bytes(g.K3, g.cin_pad)));
+            if (g.one_tap) {
+                std::vector<float> w1((size_t)g.K3 * g.cin_pad);
+                for (size_t j = 0; j < w1.size(); ++j) w1[j] = w3[j * 9 + 4];
+                conv_pack_1x1_split(w1.data(), g.K3, g.cin_pad, packed.data());
+            } else conv_pack_split(w3.data(), g.K3, g.cin_pad, packed.data());
+            INNFER_HIP(hipMalloc(&g.d_w3s, packed.size()));
+            INNFER_HIP(hipMemcpy(g.d_w3s, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        }
+    }
     {   // the SCPA blocks as (hi, lo) blob pairs for the fused split-operand launch (pan_scpa_split.hip)
         std::vector<char> blob(pan_scpa_split_blob_bytes());
         auto Wp = [p](const std::string& key) -> const float* { return p->params[find(p, key)].host.data(); };
@@ -1228,8 +1373,8 @@ extern "C" int innfer_pan_forward(innfer_pan* p, const void* d_in, int in_dtype,
             GtScope gt(s, "pan_attention_mfma (+ prep)", 2.0 * N * (double)Np * Np * (2 * 5 + 40), (double)np * (64.0 + nf) * 4.0);
             const long work = (long)nblk * 192 > (long)nblk * ATT_KB ? (long)nblk * 192 : (long)nblk * ATT_KB;
             hipLaunchKernelGGL(pan_attn_prep, dim3((unsigned)((work + 255) / 256), N), dim3(256), 0, s, (const float*)(ws + cv.fgh), vec("FSA.conv_f.bias"),
-                               vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), Np, nblk, (f16*)(ws + cv.aqk), (f16*)(ws + cv.avt));
-            hipLaunchKernelGGL(pan_attention_mfma, dim3((Np + 127) / 128, N), dim3(512), 0, s, (const f16*)(ws + cv.aqk), (const f16*)(ws + cv.avt), Np, nblk,
+                               vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), Np, nblk, (f16*)(ws + cv.aqk), (f16*)(ws + cv.avt), (f16*)nullptr);
+            hipLaunchKernelGGL(pan_attention_mfma<false>, dim3((Np + 127) / 128, N), dim3(512), 0, s, (const f16*)(ws + cv.aqk), (const f16*)(ws + cv.avt), (const f16*)nullptr, Np, nblk,
                                (float*)(ws + cv.att));
             INNFER_HIP(hipGetLastError());
         } else {
