@@ -28,7 +28,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                  bounded sample (rank 0, in a child process that never touches a GPU; at every N).
   chop8k       : BASELINE config 3 (8K input through chop_forward, 3268 tiles) -- 1 warm-up + 1 timed pass on the same ranks
   unet64       : BASELINE config 5 (pix2pix UNet_256 on 64x3x256x256), N == 1 only
-  pan540       : PAN 4x on a 1x3x540x960 frame (north_star's third conv stack), N == 1 only
+  pan540       : PAN 4x on a 1x3x540x960 frame (north_star's third conv stack), N == 1 only (+ pan_chop1080: the CLI's tiled shape; pan540_fp32: the -no_fp16 mode)
   srresnet1080 : SRResNet-16 4x on the 1080p frame (north_star's second conv stack), N == 1 only
 """
 import argparse
@@ -451,6 +451,32 @@ def pan540_object(dev, reps=20, windows=7, warm_s=0.5):
         net.release_workspace()
     except Exception as e:                              # a side object must never cost the rest of the line
         out["chop1080"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # ... and the same frame as a float32 tensor = the reference's -no_fp16 mode (run.py:345,421-422; SURVEY 8c "fp32 path <= 1e-4"): since round 6 the SCPA blocks, the
+    # HR side and the attention run on (hi, lo) fp16 operand pairs of the matrix cores (csrc/pan_scpa_split.hip, conv3x3_pc SPLIT, pan_attention_mfma<true>)
+    try:
+        xf = x.float()
+        for _ in range(5):
+            net(xf)
+        torch.cuda.synchronize()
+        fw = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                net(xf)
+            e1.record()
+            torch.cuda.synchronize()
+            fw.append(e0.elapsed_time(e1) / 10)
+        fms = sorted(fw)[len(fw) // 2]
+        out["fp32"] = {"workload": "PAN 4x, 1x3x540x960 float32 -> 1x3x2160x3840 float32, un-tiled: the -no_fp16 mode, <= 1e-4 of the fp32 reference (tests/test_gpu_fp32_mode.py)",
+                       "ms_per_step": round(fms, 4), "ms_per_step_min": round(min(fw), 4), "ms_per_step_max": round(max(fw), 4), "value": round(16 * H * W / fms / 1e3, 1),
+                       "unit": "output MPix/s", "dtype": "f32 as fp16 (hi, lo) pairs", "x_fp16_engine": round(fms / ms, 2)}
+        per32 = unet_per_kernel(net, xf)
+        if per32:
+            out["fp32"]["per_kernel"] = per32
+        net.release_workspace()
+    except Exception as e:
+        out["fp32"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 
@@ -917,6 +943,7 @@ def main():
         try:
             line["pan540"] = pan540_object(dev)
             line["pan_chop1080"] = line["pan540"].pop("chop1080", None)
+            line["pan540_fp32"] = line["pan540"].pop("fp32", None)
         except Exception as e:                      # a side object must never cost the headline line
             line["pan540"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 

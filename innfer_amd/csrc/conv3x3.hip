@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
     // through the ordinary epilogue (its LeakyReLU, the store).  Same fp16 operands and the same MFMA as the two launches; the sigmoid is the fast form, so results
     // agree to the last fp16 rounding -- without the round trip of the 32-channel HR tensor (531 MB written and read again at 2160 x 3840).
     constexpr bool SGATE = (TMF & 0x80000) != 0;
-    static_assert(!SGATE || (RPW == 3 && NT == 2 && NCW == 8 && OUTMODE == OUT_SLAB && (TMF & 0x7FFFF) == 0x1FF && !S9 && !POLY), "self gate: the 32-output slab kernel (and its canvas form)");
+    static_assert(!SGATE || (RPW == 3 && NT == 2 && NCW == 8 && OUTMODE == OUT_SLAB && ((TMF & 0x7FFFF) == 0x1FF || (TMF & 0x7FFFF) == 0x21FF) && !S9 && !POLY), "self gate: the 32-output slab kernel (its canvas form, its split-operand form)");
     // + 0x100000 (BRELU): the pixel operand is max(x, 0) of the stored slab -- the UNet keeps ONE stored form of a skip tensor (LeakyReLU, the down conv's operand);
     // the up conv that reads the concatenation applies the ReLU as it takes a fragment from LDS (4 v_pk_max_f16 per fragment, i.e. per 2 .. 8 MFMAs).
     // max(lrelu(v), 0) == relu(v) bit for bit in fp16, so the results are those of the two-view form.
@@ -681,11 +681,13 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         }
     }
     f16x8 sgw[SGATE ? 2 : 1];
+    [[maybe_unused]] f16x8 sgwl[(SGATE && SPLIT) ? 2 : 1];           // (fp32 mode: the lo fragments, 2 KB behind the hi ones)
     f32x4 sgb[SGATE ? 2 : 1];
     if constexpr (SGATE) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             sgw[t] = *(const f16x8*)(p.sg_w + (t * 64 + lane) * 8);
+            if constexpr (SPLIT) sgwl[t] = *(const f16x8*)(p.sg_w + 1024 + (t * 64 + lane) * 8);
             sgb[t] = *(const f32x4*)(p.sg_bias + 8 * lg + 4 * t);
         }
     }
@@ -890,7 +892,8 @@ __global__ __launch_bounds__(64 * (NCW + NLW), 1) void conv3x3_pc(const KP p) {
         if (++c == p.nchunks) {
             c = 0;
             jt += slots;
-            if constexpr (SGATE) self_gate<MT>(acc, sgw, sgb);
+            if constexpr (SGATE && SPLIT) self_gate_split<MT>(acc, sgw, sgwl, sgb);
+            else if constexpr (SGATE) self_gate<MT>(acc, sgw, sgb);
             if constexpr (PFX) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -1149,6 +1152,12 @@ int conv_launch(const ConvLaunch& L, hipStream_t s) {
         if (L.out_mode == OUT_SLAB && L.conv1x1 && (nt == 2 || nt == 4))
             return nt == 4 ? launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x2010, false, 3>(k, L.N, s) : launch_pc<2, 2, 4, OUT_SLAB, false, false, 0x2010, false, 3>(k, L.N, s);
         if (L.conv1x1) return set_error(INNFER_ERR_UNSUPPORTED, "conv1x1 (fp32 mode): slab outputs of 32- / 64-channel tiles");
+        if (L.gate_w) {      // out = act(v * sigmoid(W v + b)) on the conv's fp32 result: gate_w = the hi | lo fragments of conv_pack_selfgate (4 KB)
+            if (L.out_mode != OUT_SLAB || nt != 2 || L.K != 32 || L.res1 || L.res2 || L.act > 2)
+                return set_error(INNFER_ERR_UNSUPPORTED, "conv3x3 (fp32 mode): the self gate belongs to 32-output slab convs without residuals");
+            k.sg_w = L.gate_w; k.sg_bias = L.gate_bias;
+            return launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x821FF>(k, L.N, s);
+        }
         if (L.out_mode == OUT_SLAB && nt == 2) return launch_pc<3, 2, 4, OUT_SLAB, false, false, 0x21FF>(k, L.N, s);
         if (L.out_mode == OUT_SLAB && nt == 4) return launch_pc<2, 4, 4, OUT_SLAB, false, false, 0x21FF>(k, L.N, s);
         if (L.out_mode == OUT_NCHW && nt == 1 && !L.res1 && !L.res2) return launch_pc<3, 1, 4, OUT_NCHW, false, false, 0x21FF>(k, L.N, s);

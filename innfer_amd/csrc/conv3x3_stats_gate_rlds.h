@@ -94,6 +94,34 @@ __device__ __forceinline__ void self_gate(f32x4 (&acc)[2][MT], const f16x8* sgw,
     }
 }
 
+// The same gate in the fp32-accurate mode (SPLIT + SGATE): the accumulators hold the conv's fp32 result; v is split into (hi, lo * 2^11) in registers and
+// g = Wh vh + 2^-11 (Wl vh + Wh vl) + b (three MFMAs per 16-row tile), acc <- v * sigmoid(g) with v in fp32.
+template <int MT>
+__device__ __forceinline__ void self_gate_split(f32x4 (&acc)[2][MT], const f16x8* wh, const f16x8* wl, const f32x4* sgb) {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        f16x8 vh, vl;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float f = acc[t][m][j];
+                const f16 h = (f16)f;
+                vh[4 * t + j] = h;
+                vl[4 * t + j] = (f16)((f - (float)h) * 2048.0f);
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 gm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], vh, sgb[t], 0, 0, 0);
+            f32x4 gx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], vh, z4, 0, 0, 0);
+            gx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], vl, gx, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][m][j] = acc[t][m][j] * __builtin_amdgcn_rcpf(1.0f + __expf(-__builtin_fmaf(gx[j], 1.0f / 2048.0f, gm[j])));
+        }
+    }
+}
+
 // RLDS (conv3x3_pc<.., TMF | 0x40000>): the lane's 16 residual channels of each of its MT pixel tiles from the live LDS stage `st` (byte offsets roffs), added to the fp32
 // accumulators as x / s1 (rs1 = 1 / s1)
 template <int MT>

@@ -666,6 +666,7 @@ struct Gemm {                       // one packed GEMM
     std::function<int(int)> bias_row;                   // optional: output row -> index into the bias parameter (-1: none); default: row == index
     bool one_tap = false;                               // a 1x1 conv: single-tap panel (conv_pack_1x1), the kernel's one-tap instantiation
     void* d_fuse = nullptr;                             // conv_last behind a 32-channel HRconv: its panel for that conv's fused epilogue (conv_pack_fuse_last(.., cin = 32)); round 5
+    void* d_gate_s = nullptr;                           // fp32 mode: the PA block's 1x1 conv as hi | lo self-gate fragments (4 KB) for the split up-conv's epilogue
     void* d_w3s = nullptr;                              // fp32 mode: the (wl | wh | wh) panels of conv3x3_pc's split-operand form (conv_pack_split / conv_pack_1x1_split), the HR side's convs
     bool pa_gate = false; void* d_gate = nullptr;       // the PA block's 1x1 conv (upsample.<i>.conv): also packed as the self-gate fragments of the conv in front of it (conv_pack_selfgate)
 };
@@ -687,6 +688,7 @@ struct innfer_pan {
     int scpa_c8 = 1;                 // compact channel plane between the fused SCPA blocks (pan_scpa_launch in_c8 / out_c8); 0: A/B (fused_scpa 3)
     int mfma_attention = 1;          // the FSA block's attention on the matrix cores (pan_attention_mfma); 0: the VALU kernel of rounds 1-3 (set with fused_scpa: one A/B switch)
     int fused_last = 1;              // the last stage's HRconv with conv_last in its epilogue (conv3x3_pc FUSE on 32 channels, round 5); 0: two launches (fused_scpa 4)
+    bool pa_two_launches = false;    // fp32 mode A/B (innfer_pan_set_fused_scpa(pan, 5)): the PA block as its own split 1x1 launch instead of the up-conv's epilogue
     int fused_scpa = 1;              // an SCPA block as ONE launch (innfer_pan_set_fused_scpa); 0: the five halo-tile launches of rounds 1-3
     bool uploaded = false;
 };
@@ -744,7 +746,7 @@ extern "C" int innfer_pan_create_ex(innfer_pan** out, int in_nc, int out_nc, int
 
 extern "C" void innfer_pan_destroy(innfer_pan* p) {
     if (!p) return;
-    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); if (g.d_fuse) (void)hipFree(g.d_fuse); if (g.d_w3s) (void)hipFree(g.d_w3s); }
+    for (auto& g : p->gemms) { if (g.d_w) (void)hipFree(g.d_w); if (g.d_w3) (void)hipFree(g.d_w3); if (g.d_b3) (void)hipFree(g.d_b3); if (g.d_gate) (void)hipFree(g.d_gate); if (g.d_fuse) (void)hipFree(g.d_fuse); if (g.d_w3s) (void)hipFree(g.d_w3s); if (g.d_gate_s) (void)hipFree(g.d_gate_s); }
     for (auto v : p->d_vecs) if (v) (void)hipFree(v);
     for (auto v : p->d_scpa) if (v) (void)hipFree(v);
     for (auto v : p->d_scpa32) if (v) (void)hipFree(v);
@@ -759,6 +761,7 @@ extern "C" int innfer_pan_set_fused_scpa(innfer_pan* p, int on) {
     p->scpa_c8 = on == 3 ? 0 : 1;                 // (3: the fused blocks on two-group slabs throughout -- A/B of the compact channel plane alone, same bits)
     p->fused_last = on == 4 ? 0 : 1;              // (4: HRconv and conv_last of the last stage as two launches -- A/B of the fused tail alone)
     if (!on) p->mfma_attention = 0;
+    p->pa_two_launches = on == 5;                 // (5, fp32 mode: the PA block of the HR side as its own launch -- A/B of the split self gate alone)
     return INNFER_OK;
 }
 
@@ -872,6 +875,7 @@ int upload(innfer_pan* p) {
         if (g.d_gate) { (void)hipFree(g.d_gate); g.d_gate = nullptr; }
         if (g.d_fuse) { (void)hipFree(g.d_fuse); g.d_fuse = nullptr; }
         if (g.d_w3s) { (void)hipFree(g.d_w3s); g.d_w3s = nullptr; }
+        if (g.d_gate_s) { (void)hipFree(g.d_gate_s); g.d_gate_s = nullptr; }
     }
     build_gemms(p);
     std::vector<f16> panel;
@@ -1077,7 +1081,7 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
     if (p->self_attention) {
         const int hp = H / 4, wp = W / 4, Np = hp * wp;
         float *POOL = B(cv.pool), *FGH = B(cv.fgh), *ATT = B(cv.att);
-        CK(f32_maxpool4_launch(INP, POOL, (long)N * nf, H, W, s));
+        { GtScope gt(s, "f32 maxpool 4x4", 0.0, (double)N * nf * hw * 4.0 * (1.0 + 1.0 / 16)); CK(f32_maxpool4_launch(INP, POOL, (long)N * nf, H, W, s)); }
         {   // [f | g | h] = 1x1 convs of the pooled pixels, written as 64-float rows per pixel (biases are added by the attention kernel)
             F32Conv c{};
             c.in = POOL; c.in_nstride = (long)nf * Np; c.in_cstride = Np; c.C = nf; c.Hin = hp; c.Win = wp;
@@ -1099,7 +1103,7 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
             hipLaunchKernelGGL(pan_attention, dim3((Np + 63) / 64, N), dim3(256), 0, s, (const float*)FGH, vec("FSA.conv_f.bias"), vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), Np, ATT);
         }
         INNFER_HIP(hipGetLastError());
-        CK(f32_fsa_combine_launch(ATT, hp, wp, nf, INP, T, N, H, W, vec("FSA.gamma"), s));
+        { GtScope gt(s, "f32 fsa_combine (bicubic + gamma * out + in)", 0.0, (double)N * nf * hw * 8.0); CK(f32_fsa_combine_launch(ATT, hp, wp, nf, INP, T, N, H, W, vec("FSA.gamma"), s)); }
         cur = T;
     }
     int h = H, w = W, cc = nf;
@@ -1116,7 +1120,7 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
         {   GtScope gt(s, "pan NCHW fp32 -> (hi, lo) slab pair", 0.0, (double)px * (nf * 4.0 + 256.0));
             hipLaunchKernelGGL(pan_nchw_to_slab_pair, dim3((unsigned)((px * 8 + 255) / 256)), dim3(256), 0, s, cur, nf, hw, N, 2, TS, 2 * px * 32);
             INNFER_HIP(hipGetLastError()); }
-        auto convs = [&](const Gemm& g, const f16* in, long in_g, long in_lo, int Ho, int Wo, int up, int act, const f16* res, f16* dst, float* planar) -> int {
+        auto convs = [&](const Gemm& g, const f16* in, long in_g, long in_lo, int Ho, int Wo, int up, int act, const f16* res, f16* dst, float* planar, const Gemm* gate = nullptr) -> int {
             ConvLaunch L{};
             const long og = (long)N * Ho * Wo * 32;
             L.in = in; L.in_gstride = in_g; L.C = g.cin_pad;
@@ -1128,6 +1132,7 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
             L.out_mode = planar ? OUT_NCHW : OUT_SLAB; L.out_f32 = planar ? 1 : 0;
             L.conv1x1 = g.one_tap ? 1 : 0;
             L.split = 1; L.in_lo = in_lo; L.out_lo = og; L.res1_lo = og;
+            if (gate) { L.gate_w = (const f16*)gate->d_gate_s; L.gate_bias = gate->d_b3; }      // out = act(v * sigmoid(W v + b)): the PA block as this conv's epilogue
             return conv_launch(L, s);
         };
         const f16* c16 = TS;
@@ -1137,8 +1142,12 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
             const int hh = 2 * h, ww = 2 * w;
             const long HG = (long)N * hh * ww * 32;
             f16 *V = (f16*)B(cv.hr[u][0]), *PAo = (f16*)B(cv.hr[u][1]), *HRC = (f16*)B(cv.hr[u][2]);
+            if (p->gemms[gi + 1].d_gate_s && p->fused_scpa != 0 && !p->pa_two_launches)
+                CK(convs(p->gemms[gi], c16, c_g, c_lo, hh, ww, 1, 1, nullptr, PAo, nullptr, &p->gemms[gi + 1]));  // conv(nearest2x(t)) with the PA block as its epilogue: V is never written
+            else {
             CK(convs(p->gemms[gi], c16, c_g, c_lo, hh, ww, 1, 0, nullptr, V, nullptr));                          // conv(nearest2x(t))
             CK(convs(p->gemms[gi + 1], V, HG, HG, hh, ww, 0, 4, V, PAo, nullptr));                              // lrelu(v * sigmoid(conv1x1(v)))
+            }
             CK(convs(p->gemms[gi + 2], PAo, HG, HG, hh, ww, 0, p->n_up == 1 ? 1 : 0, nullptr, HRC, nullptr));  // HRconv
             gi += 3;
             c16 = HRC; c_g = HG; c_lo = HG; h = hh; w = ww;
@@ -1164,6 +1173,7 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
     }
     {
         const long fpx = (long)N * h * w;
+        GtScope gt(s, "pan_final (+ bilinear skip, NCHW)", 0.0, (double)fpx * p->out_nc * 8.0);
         hipLaunchKernelGGL(pan_final, dim3((unsigned)((fpx + 255) / 256)), dim3(256), 0, s, (const float*)RAW, 0, (const float*)nullptr, p->out_nc, (const void*)x, 1, N, H, W, p->scale, (void*)y, 1);
         INNFER_HIP(hipGetLastError());
     }
@@ -1240,6 +1250,15 @@ extern "C" int innfer_pan_set_precision(innfer_pan* p, int fp32) {
                 std::vector<float> w1((size_t)g.K3 * g.cin_pad);
                 for (size_t j = 0; j < w1.size(); ++j) w1[j] = w3[j * 9 + 4];
                 conv_pack_1x1_split(w1.data(), g.K3, g.cin_pad, packed.data());
+                if (g.pa_gate && g.K3 == 32 && g.cin_pad == 32) {
+                    std::vector<float> wh(w1.size()), wl(w1.size());
+                    for (size_t j = 0; j < w1.size(); ++j) { const f16 h = (f16)w1[j]; wh[j] = (float)h; wl[j] = (float)(f16)((w1[j] - (float)h) * 2048.0f); }
+                    std::vector<char> gp(4096);
+                    conv_pack_selfgate(wh.data(), gp.data());
+                    conv_pack_selfgate(wl.data(), gp.data() + 2048);
+                    INNFER_HIP(hipMalloc(&g.d_gate_s, gp.size()));
+                    INNFER_HIP(hipMemcpy(g.d_gate_s, gp.data(), gp.size(), hipMemcpyHostToDevice));
+                }
             } else conv_pack_split(w3.data(), g.K3, g.cin_pad, packed.data());
             INNFER_HIP(hipMalloc(&g.d_w3s, packed.size()));
             INNFER_HIP(hipMemcpy(g.d_w3s, packed.data(), packed.size(), hipMemcpyHostToDevice));

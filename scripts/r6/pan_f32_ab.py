@@ -46,6 +46,8 @@ for shape in [(1, 3, 540, 960), (16, 3, 200, 200)]:
         t.setdefault(f, []).append(ms(x))
         y[f] = net(x)
     print(f"== {shape} fp32 mode: split-fused {t[1][0]:.3f} / {t[1][1]:.3f} ms   generic {t[0][0]:.3f} / {t[0][1]:.3f} ms   max |diff| {(y[1] - y[0]).abs().max().item():.2e}", flush=True)
+    net.fused_scpa = 5
+    print(f"   (the PA blocks as their own split 1x1 launches: {ms(x):.3f} ms; max |diff| to the fused form {(net(x) - y[1]).abs().max().item():.2e})", flush=True)
     net.fused_scpa = 1
     launches = L.timed_launches(lambda: net(x))
     agg = {}
