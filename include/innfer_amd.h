@@ -45,8 +45,8 @@ typedef struct innfer_net* innfer_net_t;
 
 /* ABI revision of this header (major*100 + minor).  101/102: innfer_conv_args grew reflect_pad / dilation / dilation_groups (zero-initialise the struct),
  * innfer_wbc_create takes tf_mode, innfer_net_set_final_act.  103: innfer_net_forward_timed reports algorithmic bytes, innfer_conv_args.pixel_shuffle2, innfer_unet_set_eval,
- * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works); innfer_pack_conv3x3_shuffle2 + innfer_conv_args.plane_rows = 2.  111: innfer_net_set_hr_chain.  112: REMOVED -- innfer_net_set_pair_convs (csrc/conv_pair.hip: the fused conv pairs of a dense block, measured 3 % slower per frame in round 2 and off ever since), innfer_pack_conv3x3_wino / innfer_conv3x3_wino_packed_bytes and the meaning of innfer_conv_args.winograd (now reserved0, must be 0): the row-Winograd experiment of round 3.  innfer_version() returns the library's; a binding should compare. */
-#define INNFER_ABI_VERSION 112
+ * innfer_comm_* / innfer_gather_tiles / innfer_shard_tiles.  104: innfer_rrdbnet_create_ex, innfer_pan_create_ex, innfer_srresnet_create_ex, innfer_resnet_create_ex, innfer_unet_create_ex, innfer_net_set_outm, innfer_guided_filter_ex, innfer_filter2d, innfer_net_set_pair_convs, innfer_inthwc_to_nchw / innfer_nchw_to_inthwc, innfer_linear_resize, INNFER_U8 at the network boundary (innfer_net_set_u8_io), innfer_extract_tiles_u8 / innfer_recompose_u8, innfer_conv_args.stride2_k4 / transposed2x / column7 with innfer_pack_conv4x4s2 / innfer_pack_convt2x / innfer_pack_conv7x1.  105: innfer_net_set_conv_input_map, SRResNet scale 3, PixelShuffle(3) stages (nf 64) and PixelShuffle(2) on nf 32.  106: the fp32-accurate mode -- innfer_net_set_precision, innfer_conv_args.split / *_lo, innfer_pack_conv3x3_split, innfer_nchw_to_slab_split / innfer_slab_split_to_nchw.  107: innfer_net_set_fused_tail, innfer_net_set_upconv_phases.  108: innfer_net_set_residual_lds, innfer_conv_args.res1_from_input, innfer_pan_set_fused_scpa, innfer_unet_set_precision, innfer_pan_set_precision, innfer_ppon_set_precision, innfer_resnet_set_precision, innfer_wbc_set_precision.  109: innfer_conv_args.plane_rows, innfer_pack_conv3x3_rows, innfer_pack_convt2x_rows; innfer_net_set_upconv_phases takes 0 / 1 / 2.  110: innfer_net_set_conv on a network in the fp32 mode builds that conv's split panels (either call order of set_precision / set_conv works); innfer_pack_conv3x3_shuffle2 + innfer_conv_args.plane_rows = 2.  111: innfer_net_set_hr_chain.  112: REMOVED -- innfer_net_set_pair_convs (csrc/conv_pair.hip: the fused conv pairs of a dense block, measured 3 % slower per frame in round 2 and off ever since), innfer_pack_conv3x3_wino / innfer_conv3x3_wino_packed_bytes and the meaning of innfer_conv_args.winograd (now reserved0, must be 0): the row-Winograd experiment of round 3.  113: no new symbol -- innfer_pan_set_precision(p, 1) now selects the split-operand forms for PAN's SCPA trunk / up-stages / attention (innfer_pan_set_fused_scpa(p, 0) keeps the 112 form; 5: A/B of the PA epilogue).  innfer_version() returns the library's; a binding should compare. */
+#define INNFER_ABI_VERSION 113
 int innfer_version(void);
 const char* innfer_last_error(void);
 
@@ -240,10 +240,15 @@ size_t innfer_pan_workspace_bytes(innfer_pan_t p, int N, int H, int W);
  * exact row maxima, exp and sums in fp32, p and h as fp16 operands of the P V product; on = 2 keeps the VALU attention behind the fused blocks; on = 3 (110) keeps the
  * trunk tensors on two-group slabs between the fused blocks (default since 110: channels 32..39 travel as a compact 16-byte plane there; same bits); on = 4 (110) runs the
  * last stage's HRconv and conv_last as two launches (default since 110 where the full-resolution grid is whole 16 x 32 tiles: conv_last in HRconv's epilogue, the 24-channel
- * full-resolution tensor neither written nor read; same values to the summation order of conv_last).  (108) */
+ * full-resolution tensor neither written nor read; same values to the summation order of conv_last).  (108)
+ * In the fp32 mode (innfer_pan_set_precision(p, 1); since 113): on != 0 runs the SCPA blocks (csrc/pan_scpa_split.hip), the up-stages and the attention on
+ * (hi, lo) fp16 operand pairs of the matrix cores, on = 0 every conv on the generic fp32 kernel and the attention on the VALU kernel (the form of 108 - 112);
+ * on = 5 keeps the PA block of an up-stage as its own 1x1 launch instead of the up-conv's epilogue (A/B). */
 int innfer_pan_set_fused_scpa(innfer_pan_t p, int on);
-/* The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs PAN.forward in fp32 on NCHW fp32 tensors
- * (csrc/f32ops.hip; the FSA attention on the fp32 VALU kernel) -- <= 1e-4 of the fp32 reference; fp32 tensors in and out; a load-time call.  (108) */
+/* The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs PAN.forward with fp32-accurate arithmetic
+ * -- <= 1e-4 of the fp32 reference; fp32 tensors in and out; a load-time call.  (108: every conv on the generic fp32 kernel of csrc/f32ops.hip, the FSA
+ * attention on the fp32 VALU kernel.  113: the SCPA trunk, nearest-2x up-stages and the attention as three-MFMA products of (hi, lo = (x - hi) * 2^11) fp16
+ * pairs with fp32 accumulation -- the SR engine's SPLIT convention; conv_first, the trunk conv, the f | g | h projections, bilinear / 3x stages stay on f32ops.) */
 int innfer_pan_set_precision(innfer_pan_t p, int fp32);
 /* d_in [N,in_nc,H,W] -> d_out [N,out_nc,scale*H,scale*W], NCHW f16/f32; H, W >= 4. */
 int innfer_pan_forward(innfer_pan_t p, const void* d_in, int in_dtype, void* d_out, int out_dtype,

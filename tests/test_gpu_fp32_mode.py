@@ -325,6 +325,53 @@ def test_pan_fp32_mode_vs_goldens(dev, golden):
         assert e < FP32_TOL * max(1.0, ref.abs().max().item()), (scale, mode, e)
 
 
+def test_pan_fp32_split_forms_vs_generic_and_oracle(dev):
+    """The split-operand forms of PAN's fp32 mode (round 6: csrc/pan_scpa_split.hip -- an SCPA block as one launch on (hi, lo) fp16 pairs, 8 x 32 tiles --, the HR side on
+    conv3x3_pc SPLIT with the PA block as the up-conv's epilogue, the attention on pan_attention_mfma<true>) against the generic fp32 kernels they replace
+    (innfer_pan_set_fused_scpa(pan, 0)) and against the oracle: frames of exactly one tile, one pixel more than a tile in both directions, several tile rows / XCD runs,
+    border-only frames, batches (an image of a batch == its own forward, bit for bit).  <= 1e-4 of the oracle, <= 1e-5 between the two engines."""
+    import oracle
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config("pan", 4))
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    try:
+        for shape in [(1, 3, 8, 32), (1, 3, 9, 33), (2, 3, 37, 45), (1, 3, 4, 5), (3, 3, 16, 64), (1, 3, 70, 130)]:
+            x = torch.from_numpy(synth.uniform(shape, 60 + shape[2], 0, 1))
+            with torch.no_grad():
+                ref = oracle.pan_forward(sd, x, nb=16, scale=4)
+            y = {}
+            for mode in (1, 0, 5):
+                net.fused_scpa = mode
+                y[mode] = net(x.to(dev))
+                assert y[mode].dtype == torch.float32
+            lim = max(1.0, ref.abs().max().item())
+            e1, e0 = (y[1].cpu() - ref).abs().max().item(), (y[0].cpu() - ref).abs().max().item()
+            d10, d15 = (y[1] - y[0]).abs().max().item(), (y[1] - y[5]).abs().max().item()
+            print(f"PAN fp32 {shape}: split forms vs oracle {e1:.2e}, generic vs oracle {e0:.2e}, split vs generic {d10:.2e}, PA epilogue vs PA launch {d15:.2e}")
+            assert e1 < FP32_TOL * lim and e0 < FP32_TOL * lim, (shape, e1, e0)
+            assert d10 < 1e-5 * lim and d15 < 1e-5 * lim, (shape, d10, d15)
+            net.fused_scpa = 1
+            if shape[0] > 1:
+                xs = x.to(dev)
+                for i in range(shape[0]):
+                    assert torch.equal(y[1][i:i + 1], net(xs[i:i + 1])), (shape, i)
+        # a frame of many tiles per workgroup (270 x 480: 34 x 15 tiles of 8 x 32 on 256 workgroups), engines against each other
+        x = torch.from_numpy(synth.uniform((1, 3, 270, 480), 77, 0, 1)).to(dev)
+        net.fused_scpa = 1
+        a = net(x)
+        net.fused_scpa = 0
+        b = net(x)
+        d = (a - b).abs().max().item()
+        print(f"PAN fp32 270x480: split forms vs generic {d:.2e}")
+        assert d < 1e-5 * max(1.0, b.abs().max().item()), d
+    finally:
+        net.fused_scpa = 1
+
+
 def test_ppon_fp32_mode_vs_golden(dev, golden):
     """PPON on float32 tensors (innfer_ppon_set_precision(1): the eight dilated convs as tap tables of the generic fp32 conv, running sums in fp32) against golden
     G13 (all three outputs) and the oracle at scales 2 / 3 / 8: <= 1e-4 of the output range."""
