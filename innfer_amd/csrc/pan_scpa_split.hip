@@ -35,7 +35,8 @@ using namespace scpa;
 
 constexpr int TH = 8, HR = TH + 4, NPX = HR * HC, NP1 = NPX / 16;          // 12 x 36 halo pixels = 27 pixel tiles of 16
 constexpr int YW = TW + 2, NY = (TH + 2) * YW, NMID = (NY + 15) / 16;        // Y: the 10 x 34 region k4 reads = 22 pixel tiles
-constexpr int KT = (NP1 + 7) / 8;                                           // P1 pixel tiles per wave (4)
+constexpr int KT = 4;                                                       // P1 tile slots per wave (p1_tile)
+static_assert(NP1 == 27, "p1_tile's work list");
 // this kernel's own blob (one per hi / lo): conv1_a | conv1_b and conv3 in the fp16 kernel's compact row-major form, the 20 -> 20 convs in the permuted form above
 constexpr int KS_T1 = 36 * 16, KS_Z0 = 60 * 16, KS_Z1 = 61 * 16, KS_TAP = 62 * 16;
 constexpr int S_K1 = 0, S_K3 = S_K1 + 9 * KS_TAP, S_K4 = S_K3 + 9 * KS_TAP, S_K2 = S_K4 + 9 * KS_TAP;     // (first: their lo twins stay within a 16-bit offset of the lane constants)
@@ -62,6 +63,9 @@ struct SplitKP {
 };
 
 __device__ __forceinline__ f16x8 lds16(const char* smem, int off, bool real) { return *(const f16x8*)(smem + (real ? off : S_ZERO)); }
+// P1's work list: 27 pixel tiles of the halo region, each an A unit and a B unit.  Slot k < 3 of wave w: tile w + 8 k (both units); slot 3: tiles 24 .. 26, the A unit by
+// waves 0 .. 2 and the B unit by waves 3 .. 5 (3.5 tile slots on the longest wave instead of 4: the phase ends at the barrier behind its slowest wave)
+__device__ __forceinline__ int p1_tile(int wave, int k) { return k < 3 ? wave + 8 * k : (wave < 6 ? 24 + (wave < 3 ? wave : wave - 3) : -1); }
 __device__ __forceinline__ f16x8 px16(const char* smem, int off) { return *(const f16x8*)(smem + off); }
 __device__ __forceinline__ f16x8 gload(const __amdgpu_buffer_rsrc_t rs, int off) { return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0)); }
 
@@ -163,13 +167,13 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
         asm volatile("" : "+v"(li), "+v"(lg));
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            const int P = 16 * (wave + 8 * k) + li, r = P / HC, c = P - r * HC;
+            const int P = 16 * p1_tile(wave, k) + li, r = P / HC, c = P - r * HC;
             int o32 = (base + r * p.W + c) * 64 + lg * 16, o8 = (base + r * p.W + c) * 16;
             if (edge) {
                 const int y = ty0 - 2 + r, x = tx0 - 2 + c;
                 if (y < 0 || y >= p.H || x < 0 || x >= p.W) o32 = o8 = OOB;
             }
-            if (wave + 8 * k >= NP1) o32 = o8 = OOB;          // (a slot past the halo tile's 27 pixel tiles: the range check answers without a memory access)
+            if (p1_tile(wave, k) < 0) o32 = o8 = OOB;         // (an empty slot: the range check answers without a memory access)
             xh0[k] = gload(rs, o32);
             xh1[k] = gload(rs, o8 + o_hi8);
             xl0[k] = gload(rs, o32 + o_lo32);
@@ -209,10 +213,11 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
                 }
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                if (wave + 8 * k >= NP1) continue;
-                const int P = 16 * (wave + 8 * k) + li;
+                if (p1_tile(wave, k) < 0) continue;
+                const int P = 16 * p1_tile(wave, k) + li;
 #pragma unroll
                 for (int ab = 0; ab < 2; ++ab) {
+                    if (k == KT - 1 && ab != (wave >= 3 ? 1 : 0)) continue;      // (the last three pixel tiles: A by waves 0..2, B by waves 3..5)
                     f32x4 cm[2], cx[2];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
