@@ -12,7 +12,7 @@
 //       like the SR kernel's (a lane ends with 8 consecutive channels of its pixel) IS the B operand of the 1x1 conv3
 //   P2b Y = k3(B) * sigmoid(k2(B) + bias) on the 18 x 36 middle region, zero outside the image (k4's zero padding)   -> LDS (over A)
 //   P3  b' = lrelu(k4(Y)); out = conv3(a' | b') + x  (x from the X tile, held in registers since P1)               -> global slab
-// The block's weights (28.8 KB of fp16 values, 34 KB as MFMA A fragments without their all-zero rows / k-octets) stay in LDS for the whole
+// The block's weights (28.8 KB of fp16 values, 35 KB as MFMA A fragments without their all-zero rows / k-octets, pan_scpa_layout.h) stay in LDS for the whole
 // launch; the next tile's X is fetched while P2 / P3 run.  Arithmetic per value as in the five-launch schedule: fp16 operands, fp32
 // accumulation, A / B / Y / a' / b' rounded to fp16 where that schedule stored them -- the same roundings, different summation order of the
 // MFMA k-steps only where a conv's taps are walked in another order (none: taps in (dy, dx) order, one k-step per tap).
@@ -57,25 +57,24 @@ __device__ __forceinline__ f16x8 lds16(const char* smem, int off, bool real) { r
 // pixel -- the next pixel's first octet(s), the zero-filled slack behind the X tile, the first bytes of the region behind A, or the zeroed tail behind B (see the kernel's start).
 __device__ __forceinline__ f16x8 px16(const char* smem, int off) { return *(const f16x8*)(smem + off); }
 
-// A 20 -> 20 channel 3x3 conv over this wave's RW output rows x 32 pixels (PW = 2 RW pixel tiles: tile u = row * 2 + segment) of the LDS image at
-// `src` (48 B per pixel, 36-pixel rows, the output tile at halo offset (2, 2)).  Column by column (dx outer, dy inner: the tap order of conv3x3_pc's
-// fragment walk): the column's six weight fragments and the RW + 2 input rows' pixel fragments are read up front -- every pixel fragment once, used by
-// up to three output rows -- then the MFMAs.
+// A 20 -> 20 channel 3x3 conv over this wave's RW output rows x 32 pixels (PW = 2 RW pixel tiles: tile u = row * 2 + segment) of an LDS image (octet planes of
+// `plane` bytes, 36-pixel rows, the output tile at halo offset (2, 2)): pb = the lane's pixel-fragment base (the plane of its octet + the first tap's pixel of the wave's
+// first row, segment 0), w0 / w1 = its fragment offsets inside a tap block (pan_scpa_layout.h), woff = the conv's panels.  Column by column (dx outer, dy inner: the tap
+// order of conv3x3_pc's fragment walk): the column's six weight fragments and the RW + 2 input rows' pixel fragments are read up front -- every pixel fragment once, used
+// by up to three output rows -- then the MFMAs.  Every address is a lane constant + an immediate.
 template <int RW>
-__device__ __forceinline__ void conv33_rows(const char* smem, int src, int woff, int row0, int li, int lg, f32x4 (&acc)[2 * RW][2]) {
+__device__ __forceinline__ void conv33_rows(const char* smem, int pb, int w0, int w1, int woff, f32x4 (&acc)[2 * RW][2]) {
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
         f16x8 w[3][2], b[RW + 2][2];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                w[dy][t] = lds16(smem, woff + (dy * 3 + dx) * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+            for (int t = 0; t < 2; ++t) w[dy][t] = px16(smem, (t ? w1 : w0) + woff + (dy * 3 + dx) * K_TAP);
 #pragma unroll
         for (int rr = 0; rr < RW + 2; ++rr)
 #pragma unroll
-            for (int seg = 0; seg < 2; ++seg)
-                b[rr][seg] = px16(smem, src + ((row0 + rr + 1) * HC + 1 + seg * 16 + li + dx) * 48 + lg * 16);
+            for (int seg = 0; seg < 2; ++seg) b[rr][seg] = px16(smem, pb + (rr * HC + seg * 16 + dx) * 16);
 #pragma unroll
         for (int rr = 0; rr < RW + 2; ++rr)
 #pragma unroll
@@ -103,8 +102,9 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
     constexpr int PW = TH / 4, RW = PW / 2;                 // output pixel tiles (16 px) / rows per wave: TH rows x 2 segments over 8 waves
     constexpr int XQ = (NPX * 5 + 63) / 64;                 // 1-KiB LDS-DMA pieces of an X tile
     constexpr int KQ = (XQ + 7) / 8;
-    constexpr int XOFF = (W_BYTES + 1023) / 1024 * 1024, AOFF = XOFF + XQ * 1024, BOFF = AOFF + NPX * 48;
-    static_assert(BOFF + NPX * 48 + 1024 <= 160 * 1024, "LDS");
+    constexpr int PL = NPX * 16;                            // an octet plane of the A / B / Y images (pan_scpa_layout.h)
+    constexpr int XOFF = (W_BYTES + 255) / 256 * 256, AOFF = XOFF + XQ * 1024, BOFF = AOFF + 3 * PL;
+    static_assert(PL % 256 == 0 && BOFF + 3 * PL + 1024 <= 160 * 1024, "LDS");
     constexpr int OOB = (int)0x80000000;
     constexpr int TB = 3;                                   // pixel tiles of P1 / P2b in flight per wave (their fragment reads are issued together)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -170,13 +170,16 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
     fetch(j0);
     for (int i = tid; i < W_BYTES / 16; i += 512) *(f16x8*)(smem + i * 16) = *(const f16x8*)(p.w + i * 16);
     // (finite data wherever a padding k-octet may be read: the 1 KB behind B -- px16 -- and, for the first tile's P1, the head of A behind the X tile's own zero-filled slack)
-    if (tid < 64) *(f16x8*)(smem + BOFF + NPX * 48 + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < 64) *(f16x8*)(smem + BOFF + 3 * PL + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (tid < 4) *(f16x8*)(smem + AOFF + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int row0 = RW * wave;                             // this wave's first output row of the tile (P2a / P3)
+    // lane constants of the fragment reads (pan_scpa_layout.h): the octet plane a lane reads (k-octet 3: octet 2 again), its offsets inside a tap block, its pixel base
+    const int lo_w = lg_w < 3 ? lg_w : 2, w0_w = kfrag_t0(li_w, lg_w), w1_w = kfrag_t1(li_w, lg_w);
+    const int pconv_w = lo_w * PL + ((row0 + 1) * HC + 1 + li_w) * 16;
     for (int j = j0; j < run_len; j += slots) {
         int n, ty0, tx0;
         decode(j, n, ty0, tx0);
@@ -216,8 +219,8 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                         cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][1], b1[k], cb[t], 0, 0, 0);
                     }
                     if (lg < 3) {
-                        *(f16x8*)(smem + AOFF + P * 48 + lg * 16) = lrelu8(ca[0], ca[1]);
-                        *(f16x8*)(smem + BOFF + P * 48 + lg * 16) = lrelu8(cb[0], cb[1]);
+                        *(f16x8*)(smem + AOFF + lg * PL + P * 16) = lrelu8(ca[0], ca[1]);
+                        *(f16x8*)(smem + BOFF + lg * PL + P * 16) = lrelu8(cb[0], cb[1]);
                     }
                 }
             }
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 #ifdef INNFER_ABLATE
             if (!(p.abl & 2))
 #endif
-            conv33_rows<RW>(smem, AOFF, OFF_K1, row0, li, lg, acc);
+            conv33_rows<RW>(smem, AOFF + pconv_w, w0_w, w1_w, OFF_K1, acc);
 #pragma unroll
             for (int u = 0; u < PW; ++u) ap[u] = lrelu8(acc[u][0], acc[u][1]);
             // the residual x of this wave's output pixels, in conv3's result layout (a lane: channels 16 lg .. 16 lg + 15 of pixel li), before X is re-used
@@ -273,11 +276,11 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
-                            w[dy][t] = lds16(smem, OFF_K3 + (dy * 3 + dx) * K_TAP + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+                            w[dy][t] = px16(smem, (t ? w1_w : w0_w) + OFF_K3 + (dy * 3 + dx) * K_TAP);
 #pragma unroll
                     for (int k = 0; k < NK; ++k)
 #pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) b[k][dy] = px16(smem, BOFF + (Pk[k] + (dy - 1) * HC + dx - 1) * 48 + lg * 16);
+                        for (int dy = 0; dy < 3; ++dy) b[k][dy] = px16(smem, BOFF + lo_w * PL + (Pk[k] - HC - 1) * 16 + (dy * HC + dx) * 16);
 #pragma unroll
                     for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                     if (dx == 1) {                                  // k2: the 1x1 conv of the gate reads the centre pixel's fragment
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            const f16x8 w2 = lds16(smem, OFF_K2 + (t ? K_T1 : 0) + (li * 3 + lg) * 16, li < r2(t) && lg < 3);
+                            const f16x8 w2 = px16(smem, (t ? w1_w : w0_w) + OFF_K2);
 #pragma unroll
                             for (int k = 0; k < NK; ++k) g[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, b[k][1], g[k][t], 0, 0, 0);
                         }
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
                         const int r = P / HC, cc = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + cc;
                         if (!(y >= 0 && y < p.H && x >= 0 && x < p.W)) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     }
-                    if (lg < 3 && 16 * i + li < NY) *(f16x8*)(smem + AOFF + P * 48 + lg * 16) = v;
+                    if (lg < 3 && 16 * i + li < NY) *(f16x8*)(smem + AOFF + lg * PL + P * 16) = v;
                 }
             };
             // wave w takes tiles w, w + 8, ..: TB at a time; the last pass holds only the tiles that are left (two of 39 for TH = 16: six tile slots per wave were 41 tiles' worth)
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 #ifdef INNFER_ABLATE
             if (!(p.abl & 8))
 #endif
-            conv33_rows<RW>(smem, AOFF, OFF_K4, row0, li, lg, acc);
+            conv33_rows<RW>(smem, AOFF + pconv_w, w0_w, w1_w, OFF_K4, acc);
             f16x8 w3[4][2];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -393,28 +396,24 @@ void pan_scpa_pack(const float* c1a, const float* c1b, const float* k1, const fl
                         put((part ? OFF_C1B : OFF_C1A) + (t ? C1_T1 : 0) + rho * C1_ROW + oct * 16, e, src[co * 40 + oct * 8 + e]);
             }
     }
+    // a tap block of a 20 -> 20 conv: tile 0's 12 rows at slots 3 sigma0(row) + octet, tile 1's 8 rows at 36 + 3 sigma1(row) + octet, two zero slots (pan_scpa_layout.h)
+    auto tap_block = [&](int base, const float* wsrc, int ntap, int tap) {
+        for (int t = 0; t < 2; ++t)
+            for (int rho = 0; rho < r2(t); ++rho) {
+                const int co = 8 * (rho >> 2) + 4 * t + (rho & 3);
+                const int slot = t ? 36 + 3 * SIG1[rho] : 3 * SIG0[rho];
+                for (int oct = 0; oct < 3; ++oct)
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = oct * 8 + e;
+                        put(base + (slot + oct) * 16, e, ci < 20 ? wsrc[(co * 20 + ci) * ntap + tap] : 0.f);
+                    }
+            }
+    };
     const float* ks[3] = {k1, k3, k4};
     const int offs[3] = {OFF_K1, OFF_K3, OFF_K4};
     for (int c = 0; c < 3; ++c)
-        for (int tap = 0; tap < 9; ++tap)
-            for (int t = 0; t < 2; ++t)
-                for (int rho = 0; rho < r2(t); ++rho) {
-                    const int co = 8 * (rho >> 2) + 4 * t + (rho & 3);
-                    for (int oct = 0; oct < 3; ++oct)
-                        for (int e = 0; e < 8; ++e) {
-                            const int ci = oct * 8 + e;
-                            put(offs[c] + tap * K_TAP + (t ? K_T1 : 0) + rho * K_ROW + oct * 16, e, ci < 20 ? ks[c][(co * 20 + ci) * 9 + tap] : 0.f);
-                        }
-                }
-    for (int t = 0; t < 2; ++t)
-        for (int rho = 0; rho < r2(t); ++rho) {
-            const int co = 8 * (rho >> 2) + 4 * t + (rho & 3);
-            for (int oct = 0; oct < 3; ++oct)
-                for (int e = 0; e < 8; ++e) {
-                    const int ci = oct * 8 + e;
-                    put(OFF_K2 + (t ? K_T1 : 0) + rho * K_ROW + oct * 16, e, ci < 20 ? k2[co * 20 + ci] : 0.f);
-                }
-        }
+        for (int tap = 0; tap < 9; ++tap) tap_block(offs[c] + tap * K_TAP, ks[c], 9, tap);
+    tap_block(OFF_K2, k2, 1, 0);
     for (int t = 0; t < 4; ++t)
         for (int rho = 0; rho < r4(t); ++rho) {
             const int co = 16 * (rho >> 2) + 4 * t + (rho & 3);

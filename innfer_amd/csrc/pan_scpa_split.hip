@@ -37,21 +37,12 @@ constexpr int TH = 8, HR = TH + 4, NPX = HR * HC, NP1 = NPX / 16;          // 12
 constexpr int YW = TW + 2, NY = (TH + 2) * YW, NMID = (NY + 15) / 16;        // Y: the 10 x 34 region k4 reads = 22 pixel tiles
 constexpr int KT = 4;                                                       // P1 tile slots per wave (p1_tile)
 static_assert(NP1 == 27, "p1_tile's work list");
-// this kernel's own blob (one per hi / lo): conv1_a | conv1_b and conv3 in the fp16 kernel's compact row-major form, the 20 -> 20 convs in the permuted form above
-constexpr int KS_T1 = 36 * 16, KS_Z0 = 60 * 16, KS_Z1 = 61 * 16, KS_TAP = 62 * 16;
-constexpr int S_K1 = 0, S_K3 = S_K1 + 9 * KS_TAP, S_K4 = S_K3 + 9 * KS_TAP, S_K2 = S_K4 + 9 * KS_TAP;     // (first: their lo twins stay within a 16-bit offset of the lane constants)
-constexpr int S_C1A = S_K2 + KS_TAP, S_C1B = S_C1A + C1_SIZE, S_C3 = S_C1B + C1_SIZE, S_B2 = S_C3 + 40 * C3_ROW, S_ZERO = S_B2 + 128, S_BYTES = S_ZERO + 16;
-constexpr int SIG0[12] = {7, 2, 8, 3, 9, 4, 10, 5, 0, 11, 6, 1};           // position of row rho of tile 0 (12 real rows) / tile 1 (8) inside its part of a tap block
-constexpr int SIG1[8] = {6, 1, 7, 2, 5, 0, 3, 4};
-constexpr unsigned long long SIG1_NIB = 0x43052716ull;
-constexpr unsigned long long sig_nib(const int* t, int n) { unsigned long long v = 0; for (int i = n - 1; i >= 0; --i) v = (v << 4) | (unsigned)t[i]; return v; }
-static_assert(sig_nib(SIG1, 8) == SIG1_NIB, "nibble table");
-constexpr int WLO = (S_BYTES + 255) / 256 * 256;                            // the lo blob behind the hi blob
+constexpr int WLO = (W_BYTES + 255) / 256 * 256;                            // the lo blob behind the hi blob
 constexpr int PL = NPX * 16;                                                // an octet plane of the LDS images
 constexpr int AH = 2 * WLO, AL = AH + 3 * PL, BH = AL + 3 * PL, BL = BH + 3 * PL, TAIL = BL + 3 * PL;
 constexpr int LDS_BYTES = TAIL + 1024;
 static_assert(NPX % 16 == 0 && PL % 256 == 0 && LDS_BYTES <= 160 * 1024, "LDS");
-static_assert(WLO + S_K2 + KS_TAP < 65536 && 3 * PL + (3 * HC + 2) * 16 < 65536, "fragment offsets fit the 16-bit immediate of ds_read_b128");
+static_assert(WLO + OFF_K2 + K_TAP < 65536 && 3 * PL + (3 * HC + 2) * 16 < 65536, "fragment offsets fit the 16-bit immediate of ds_read_b128");
 constexpr int OOB = (int)0x80000000;
 constexpr float UP = 2048.0f, DOWN = 1.0f / 2048.0f;
 
@@ -62,7 +53,7 @@ struct SplitKP {
     int N, H, W, tiles_x, tiles_y, total;
 };
 
-__device__ __forceinline__ f16x8 lds16(const char* smem, int off, bool real) { return *(const f16x8*)(smem + (real ? off : S_ZERO)); }
+__device__ __forceinline__ f16x8 lds16(const char* smem, int off, bool real) { return *(const f16x8*)(smem + (real ? off : OFF_ZERO)); }
 // P1's work list: 27 pixel tiles of the halo region, each an A unit and a B unit.  Slot k < 3 of wave w: tile w + 8 k (both units); slot 3: tiles 24 .. 26, the A unit by
 // waves 0 .. 2 and the B unit by waves 3 .. 5 (3.5 tile slots on the longest wave instead of 4: the phase ends at the barrier behind its slowest wave)
 __device__ __forceinline__ int p1_tile(int wave, int k) { return k < 3 ? wave + 8 * k : (wave < 6 ? 24 + (wave < 3 ? wave : wave - 3) : -1); }
@@ -105,7 +96,7 @@ __device__ __forceinline__ void conv33_split(const char* smem, int pb, int w0, i
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int o = (t ? w1 : w0) + woff + (dy * 3 + dx) * KS_TAP;
+                const int o = (t ? w1 : w0) + woff + (dy * 3 + dx) * K_TAP;
                 wh[dy][t] = px16(smem, o);
                 wl[dy][t] = px16(smem, o + WLO);
             }
@@ -191,9 +182,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
     const int row0 = 2 * (wave >> 1), seg = wave & 1;        // this wave's two output rows / its segment (P2a, P3)
     // lane constants of the fragment reads (see the head of the file)
     const int lo_w = lg_w < 3 ? lg_w : 2;                                                    // the octet plane a lane reads (k-octet 3: octet 2 again)
-    const int r0_w = li_w < 12 ? li_w : li_w - 12, r1_w = li_w < 8 ? li_w : (li_w < 12 ? li_w - 4 : li_w - 12);
-    const int w0_w = lg_w < 3 ? (3 * (int)((sig_nib(SIG0, 12) >> (4 * r0_w)) & 15) + lg_w) * 16 : KS_Z0;
-    const int w1_w = lg_w < 3 ? KS_T1 + (3 * (int)((SIG1_NIB >> (4 * r1_w)) & 15) + lg_w) * 16 : KS_Z1;
+    const int w0_w = kfrag_t0(li_w, lg_w), w1_w = kfrag_t1(li_w, lg_w);
     const int pconv_w = lo_w * PL + ((row0 + 1) * HC + 1 + seg * 16 + li_w) * 16;              // + AH / AL ..: the first tap's pixel of the wave's first row
     for (int j = j0; j < run_len; j += slots) {
         int n, ty0, tx0;
@@ -207,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
             for (int ab = 0; ab < 2; ++ab)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int b = (ab ? S_C1B : S_C1A) + (t ? C1_T1 : 0) + li * C1_ROW;
+                    const int b = (ab ? OFF_C1B : OFF_C1A) + (t ? C1_T1 : 0) + li * C1_ROW;
                     wh[ab][t][0] = lds16(smem, b + lg * 16, li < r2(t)); wh[ab][t][1] = lds16(smem, b + 64, li < r2(t) && lg == 0);
                     wl[ab][t][0] = lds16(smem, WLO + b + lg * 16, li < r2(t)); wl[ab][t][1] = lds16(smem, WLO + b + 64, li < r2(t) && lg == 0);
                 }
@@ -244,14 +233,14 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
             f32x4 cm[2][2], cx[2][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) cm[u][0] = cm[u][1] = cx[u][0] = cx[u][1] = z4;
-            conv33_split(smem, AH + pconv_w, w0_w, w1_w, S_K1, cm, cx);
+            conv33_split(smem, AH + pconv_w, w0_w, w1_w, OFF_K1, cm, cx);
 #pragma unroll
             for (int u = 0; u < 2; ++u) join_split8<true>(cm[u], cx[u], aph[u], apl[u]);
         }
         __syncthreads();                                            // every wave has read A: Y may take its place
         // ---------------- P2b: Y = k3(B) * sigmoid(k2(B) + bias) on rows 1 .. TH + 2, zero outside the image ----------------
         {
-            const f32x4 bk0 = *(const f32x4*)(smem + S_B2 + (8 * lg) * 4), bk1 = *(const f32x4*)(smem + S_B2 + (8 * lg + 4) * 4);
+            const f32x4 bk0 = *(const f32x4*)(smem + OFF_B2 + (8 * lg) * 4), bk1 = *(const f32x4*)(smem + OFF_B2 + (8 * lg + 4) * 4);
             const bool edge_t = ty0 < 2 || ty0 + TH + 2 > p.H || tx0 < 2 || tx0 + TW + 2 > p.W;
             auto halo_px = [&](int i) __attribute__((always_inline)) {
                 const int Q = min(16 * i + li, NY - 1), r = Q / YW;
@@ -274,7 +263,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
                     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            const int o = (t ? w1_w : w0_w) + S_K3 + (dy * 3 + dx) * KS_TAP;
+                            const int o = (t ? w1_w : w0_w) + OFF_K3 + (dy * 3 + dx) * K_TAP;
                             wh[dy][t] = px16(smem, o);
                             wl[dy][t] = px16(smem, o + WLO);
                         }
@@ -299,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
                     if (dx == 1) {                                  // k2: the 1x1 conv of the gate reads the centre pixel's fragments
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            const int o = (t ? w1_w : w0_w) + S_K2;
+                            const int o = (t ? w1_w : w0_w) + OFF_K2;
                             const f16x8 w2h = px16(smem, o), w2l = px16(smem, o + WLO);
 #pragma unroll
                             for (int k = 0; k < NK; ++k) {
@@ -345,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
             f32x4 cm[2][2], cx[2][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) cm[u][0] = cm[u][1] = cx[u][0] = cx[u][1] = z4;
-            conv33_split(smem, AH + pconv_w, w0_w, w1_w, S_K4, cm, cx);
+            conv33_split(smem, AH + pconv_w, w0_w, w1_w, OFF_K4, cm, cx);
             f16x8 bph[2], bpl[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) join_split8<true>(cm[u], cx[u], bph[u], bpl[u]);
@@ -372,7 +361,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
                     f16x8 w3h[2], w3l[2];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const int o = S_C3 + c3_t(t) + (li * 6 + ks * 3 + lg) * 16;
+                        const int o = OFF_C3 + c3_t(t) + (li * 6 + ks * 3 + lg) * 16;
                         w3h[ks] = lds16(smem, o, li < r4(t) && lg < 3);
                         w3l[ks] = lds16(smem, WLO + o, li < r4(t) && lg < 3);
                     }
@@ -442,51 +431,7 @@ __global__ void split_to_nchw(const char* planes, float* x, int npx, int hw) {
 
 size_t pan_scpa_split_blob_bytes() { return 2 * WLO; }
 
-namespace {
-// one blob (hi or lo values, already fp16-representable floats) in this kernel's layout
-void pack_blob(const float* c1a, const float* c1b, const float* k1, const float* k2, const float* k2b, const float* k3, const float* k4, const float* c3, char* w) {
-    auto put = [&](int off, int e, float v) { ((f16*)(w + off))[e] = (f16)v; };
-    for (int part = 0; part < 2; ++part) {
-        const float* src = part ? c1b : c1a;
-        for (int t = 0; t < 2; ++t)
-            for (int rho = 0; rho < r2(t); ++rho) {
-                const int co = 8 * (rho >> 2) + 4 * t + (rho & 3);
-                for (int oct = 0; oct < 5; ++oct)
-                    for (int e = 0; e < 8; ++e) put((part ? S_C1B : S_C1A) + (t ? C1_T1 : 0) + rho * C1_ROW + oct * 16, e, src[co * 40 + oct * 8 + e]);
-            }
-    }
-    // a tap block of a 20 -> 20 conv: tile 0's 12 rows at slots 3 sigma0(row) + octet, tile 1's 8 rows at 36 + 3 sigma1(row) + octet, two zero slots
-    auto tap_block = [&](int base, const float* wsrc, int ntap, int tap) {
-        for (int t = 0; t < 2; ++t)
-            for (int rho = 0; rho < r2(t); ++rho) {
-                const int co = 8 * (rho >> 2) + 4 * t + (rho & 3);
-                const int slot = t ? 36 + 3 * SIG1[rho] : 3 * SIG0[rho];
-                for (int oct = 0; oct < 3; ++oct)
-                    for (int e = 0; e < 8; ++e) {
-                        const int ci = oct * 8 + e;
-                        put(base + (slot + oct) * 16, e, ci < 20 ? wsrc[(co * 20 + ci) * ntap + tap] : 0.f);
-                    }
-            }
-    };
-    const float* ks[3] = {k1, k3, k4};
-    const int offs[3] = {S_K1, S_K3, S_K4};
-    for (int c = 0; c < 3; ++c)
-        for (int tap = 0; tap < 9; ++tap) tap_block(offs[c] + tap * KS_TAP, ks[c], 9, tap);
-    tap_block(S_K2, k2, 1, 0);
-    for (int t = 0; t < 4; ++t)
-        for (int rho = 0; rho < r4(t); ++rho) {
-            const int co = 16 * (rho >> 2) + 4 * t + (rho & 3);
-            for (int oct = 0; oct < 6; ++oct)
-                for (int e = 0; e < 8; ++e) {
-                    const int ci = (oct % 3) * 8 + e;                           // a' (octets 0..2) | b' (octets 3..5): cat[a, b] = input channels 0..19 | 20..39
-                    put(S_C3 + c3_t(t) + rho * C3_ROW + oct * 16, e, ci < 20 ? c3[co * 40 + (oct / 3) * 20 + ci] : 0.f);
-                }
-        }
-    for (int c = 0; c < 20; ++c) ((float*)(w + S_B2))[c] = k2b[c];
-}
-}  // namespace
-
-// the blob twice: fp16(w) and fp16((w - fp16(w)) * 2^11) (k2's bias, fp32, in the first)
+// the fp16 kernel's blob (pan_scpa_pack) twice: fp16(w) and fp16((w - fp16(w)) * 2^11) (k2's bias, fp32, in the first)
 void pan_scpa_split_pack(const float* c1a, const float* c1b, const float* k1, const float* k2, const float* k2b, const float* k3, const float* k4, const float* c3, void* blob) {
     char* w = (char*)blob;
     for (int i = 0; i < 2 * WLO; ++i) w[i] = 0;
@@ -502,8 +447,8 @@ void pan_scpa_split_pack(const float* c1a, const float* c1b, const float* k1, co
         }
     }
     const std::vector<float> zb(20, 0.f);
-    pack_blob(hi[0].data(), hi[1].data(), hi[2].data(), hi[3].data(), k2b, hi[4].data(), hi[5].data(), hi[6].data(), w);
-    pack_blob(lo[0].data(), lo[1].data(), lo[2].data(), lo[3].data(), zb.data(), lo[4].data(), lo[5].data(), lo[6].data(), w + WLO);
+    pan_scpa_pack(hi[0].data(), hi[1].data(), hi[2].data(), hi[3].data(), k2b, hi[4].data(), hi[5].data(), hi[6].data(), w);
+    pan_scpa_pack(lo[0].data(), lo[1].data(), lo[2].data(), lo[3].data(), zb.data(), lo[4].data(), lo[5].data(), lo[6].data(), w + WLO);
 }
 
 bool pan_scpa_split_ok(int N, int H, int W) { return (long)N * H * W * 160 < 0x7fffffffL; }
