@@ -272,6 +272,11 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
         const f16x8 fh = *(const f16x8*)(qk + (long)qq * 32), fl = *(const f16x8*)(qk + (long)qq * 32 + 8);
         bhh = lg == 0 ? fh : z8;
         bx = lg == 0 ? fl : (lg == 1 ? fh : z8);
+        // (round 6) the cross operand carries the 2^-11 of s = s_hh + 2^-11 s_x itself, so the cross MFMA accumulates ON TOP of the main one and the sixteen joining
+        // multiply-adds per key pair are gone (the kernel is bound by its vector instructions): fl' 2^-11 and fh 2^-11 are fp16 values below ~5e-4 |f| -- where they
+        // fall under the normal range their rounding is <= 3e-8 absolute per term, against scores that carry 1e-6
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bx[e] = bx[e] * (f16)(1.0f / 2048.0f);
     }
     // staging: thread tid moves the 16-byte pieces tid, tid + 512, .. (< 2 PER) of block pair bp (blocks 2 bp, 2 bp + 1)
     auto stage_src = [&](int bp, int c) -> const f16* {
@@ -288,13 +293,9 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
     auto scores = [&](const char* sp, const f32x4& c0, f32x4 (&sc)[2]) __attribute__((always_inline)) {      // sc[t][j]: key 8 lg + 4 t + j of the block, query li, MINUS the offset in c0
         const f16x8 g0 = *(const f16x8*)(sp + koff0), g1 = *(const f16x8*)(sp + koff1);
         const f16x8 a0h = lg == 0 ? g0 : z8, a0x = lg < 2 ? g0 : z8, a1h = lg == 0 ? g1 : z8, a1x = lg < 2 ? g1 : z8;
-        const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bhh, c0, 0, 0, 0), x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0x, bx, z4, 0, 0, 0);
-        const f32x4 h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bhh, c0, 0, 0, 0), x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1x, bx, z4, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sc[0][j] = __builtin_fmaf(x0[j], 1.0f / 2048.0f, h0[j]);
-            sc[1][j] = __builtin_fmaf(x1[j], 1.0f / 2048.0f, h1[j]);
-        }
+        const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bhh, c0, 0, 0, 0), h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bhh, c0, 0, 0, 0);
+        sc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0x, bx, h0, 0, 0, 0);
+        sc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1x, bx, h1, 0, 0, 0);
     };
     const int npair = (nblk + 1) / 2;
     // ONE pass over the keys with a running row maximum m.  Round 5 (<= 0.3 ms at 32 400 keys; the kernel is bound by the VALU work per score, 1.05 G scores):
