@@ -292,10 +292,11 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
     const int koff0 = (8 * (li >> 2) + (li & 3)) * 32 + (lg == 1 ? 16 : 0), koff1 = koff0 + 4 * 32;
     auto scores = [&](const char* sp, const f32x4& c0, f32x4 (&sc)[2]) __attribute__((always_inline)) {      // sc[t][j]: key 8 lg + 4 t + j of the block, query li, MINUS the offset in c0
         const f16x8 g0 = *(const f16x8*)(sp + koff0), g1 = *(const f16x8*)(sp + koff1);
-        const f16x8 a0h = lg == 0 ? g0 : z8, a0x = lg < 2 ? g0 : z8, a1h = lg == 0 ? g1 : z8, a1x = lg < 2 ? g1 : z8;
-        const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bhh, c0, 0, 0, 0), h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bhh, c0, 0, 0, 0);
-        sc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0x, bx, h0, 0, 0, 0);
-        sc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1x, bx, h1, 0, 0, 0);
+        // (no masking of the A operand: the B operands are zero in every k-octet that must not contribute -- bhh beyond octet 0, bx beyond octet 1 -- so whatever finite
+        //  g data a lane of those octets holds is multiplied by zero; round 6: the four selects per key block were 16 of ~35 vector instructions)
+        const f32x4 h0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(g0, bhh, c0, 0, 0, 0), h1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, bhh, c0, 0, 0, 0);
+        sc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g0, bx, h0, 0, 0, 0);
+        sc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, bx, h1, 0, 0, 0);
     };
     const int npair = (nblk + 1) / 2;
     // ONE pass over the keys with a running row maximum m.  Round 5 (<= 0.3 ms at 32 400 keys; the kernel is bound by the VALU work per score, 1.05 G scores):
