@@ -308,6 +308,7 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
     //  * p -> fp16 two at a time (v_cvt_pkrtz); the maximum over a lane's sixteen scores as a tree (v_max3).
     // Masked keys (>= Np, the padding of the last block) score -inf: p = 0.  The first pair starts from m = 0 and takes its own maximum as delta.
     float m = 0.f;
+    f32x4 c0 = z4;                                                   // -m: the C operand of the score MFMAs
     f32x4 acc[3] = {z4, z4, z4};
     [[maybe_unused]] f32x4 accx[3] = {z4, z4, z4};
 #pragma unroll
@@ -326,13 +327,12 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
         for (int bp = bp0; bp < bp0 + SP && bp < npair; ++bp) {
         const char* const sb = stg + (bp - bp0) * 2 * BLK;
         f32x4 sc[2][2];
-        const f32x4 c0 = {-m, -m, -m, -m};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int b = 2 * bp + h;
             scores(sb + h * BLK, c0, sc[h]);
-            const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
-            if (kb + 8 > Np) {                                       // (only the last block of an image is ragged)
+            if ((b + 1) * ATT_KB > Np) {                             // (wave-uniform: only the last block of an image is ragged, an odd tail's second copy wholly masked)
+                const int kb = b < nblk ? b * ATT_KB + 8 * lg : Np;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -340,6 +340,8 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
                         if (kb + 4 * t + j >= Np) sc[h][t][j] = -INFINITY;
             }
         }
+        // the lane's own maximum decides whether the pair takes the slow path (some score of some query of the wave above the running maximum, or the first pair); only
+        // there do the four lanes of a query need their common maximum (two cross-lane exchanges, off the fast path since round 6)
         float bm;
         {
             const float m0 = fmaxf(fmaxf(sc[0][0][0], sc[0][0][1]), sc[0][0][2]), m1 = fmaxf(fmaxf(sc[0][0][3], sc[0][1][0]), sc[0][1][1]);
@@ -347,12 +349,13 @@ __global__ __launch_bounds__(512) void pan_attention_mfma(const f16* QK, const f
             const float m4 = fmaxf(fmaxf(sc[1][1][0], sc[1][1][1]), sc[1][1][2]);
             bm = fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, sc[1][1][3]));
         }
-        bm = fmaxf(bm, __shfl_xor(bm, 16));
-        bm = fmaxf(bm, __shfl_xor(bm, 32));
-        const float delta = bp == 0 ? bm : fmaxf(bm, 0.f);          // (finite on the first pair: every image has a key in its first block)
-        if (__any(delta != 0.f)) {                                   // the maximum moved for some query of this wave
+        if (bp == 0 || __any(bm > 0.f)) {                            // the maximum moved for some query of this wave
+            bm = fmaxf(bm, __shfl_xor(bm, 16));
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float delta = bp == 0 ? bm : fmaxf(bm, 0.f);      // (finite on the first pair: every image has a key in its first block)
             const float rescale = __builtin_amdgcn_exp2f(-delta);    // (acc is zero on the first pair)
             m += delta;
+            c0 = f32x4{-m, -m, -m, -m};
 #pragma unroll
             for (int t = 0; t < 3; ++t) { acc[t] = acc[t] * rescale; if (SPLIT) accx[t] = accx[t] * rescale; }
 #pragma unroll
