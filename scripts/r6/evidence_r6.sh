@@ -34,6 +34,23 @@ fi
 # 5. the other generators at their bench sizes
 step bench_pan python3 scripts/bench_pan.py
 step bench_srresnet python3 scripts/bench_srresnet.py
+# 6. PAN per launch (fp16 engine and the fp32 mode on split operands), the fp32 mode's engines against each other and the oracle
+step pan_breakdown python3 scripts/r6/pan_breakdown.py
+step pan_f32_ab python3 scripts/r6/pan_f32_ab.py
+# 7. rocprofv3 kernel statistics of PAN 540 x 960 in both modes (the program directly behind `--`)
+for m in pan540_once pan540_f32_once; do
+    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$m" -- python3 "$ROOT/scripts/r6/$m.py" > "$OUT/prof_$m.log" 2>&1 )
+    f=$(find "$OUT/prof_$m" -name "*kernel_stats.csv" | head -1)
+    if [ -n "$f" ]; then python3 - "$f" > "$OUT/kernel_stats_$m.txt" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:14]:
+    print(f"{r['Name'][:86]:88s} calls={int(r['Calls']):4d} total_us={float(r['TotalDurationNs']) / 1e3:10.1f} avg_us={float(r['AverageNs']) / 1e3:9.2f} pct={float(r['Percentage']):6.2f}")
+PY
+        echo OK > "$OUT/kernel_stats_$m.status"
+    else echo "FAILED no kernel_stats.csv" > "$OUT/kernel_stats_$m.status"; FAILS=$((FAILS + 1)); fi
+    rm -rf "$OUT/prof_$m"
+done
 ls -la "$OUT"
 echo "[evidence_r6] failed steps: $FAILS"
 exit $FAILS
