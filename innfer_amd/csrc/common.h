@@ -206,7 +206,8 @@ int f32_norm_launch(const float* in, long in_ns, long in_cs, float* out, long ou
                     const float* res = nullptr, long res_ns = 0, long res_cs = 0);       // + res after the activation (a residual block's skip)
 int f32_act_copy_launch(const float* in, long in_ns, float* out, long out_ns, long per_image, int N, int act, hipStream_t s);
 int f32_maxpool4_launch(const float* in, float* out, long planes, int H, int W, hipStream_t s);
-int f32_fsa_combine_launch(const float* att, int hp, int wp, int C, const float* inp, float* out, int N, int H, int W, const float* gamma, hipStream_t s);
+int f32_fsa_combine_launch(const float* att, int hp, int wp, int C, const float* inp, float* out, int N, int H, int W, const float* gamma, hipStream_t s,
+                            float* att_t = nullptr);      // att_t: N * C * hp * wp floats of scratch -- the 4-pixel-strip form on channel-major rows (W == 4 wp)
 int f32_upsample_launch(const float* in, float* out, long planes, int h, int w, int f, int bilinear, hipStream_t s);
 int f32_upadd_launch(const float* in, const float* skip, float* out, long planes, int h, int w, int tf_mode, hipStream_t s);   // out = bilinear2x(in) + skip (WBCNet_arch.py:60-75; tf_mode: tf_2xupsample_bilinear :126-137)
 int f32_axpy_launch(const float* x, const float* y, float* out, float a, long n, hipStream_t s);                 // out = a * x + y

@@ -603,6 +603,64 @@ __global__ void f32_fsa_combine_kernel(const float* att, int hp, int wp, int C, 
     out[i] = gamma[0] * v + inp[i];
 }
 
+// The same for W == 4 wp (H / 4 x W / 4 pooling: every PAN frame whose width is a multiple of 4): a thread owns the strip X0 = 4 k + 2 .. 4 k + 5 of one row and channel,
+// whose four pixels share floor(rx) == k, i.e. the same 4 x 4 taps -- 16 gathered reads for four outputs instead of 64 (the one-pixel kernel was 0.27 ms of PAN's 5.1 ms
+// fp32 forward at 540 x 960, TA-bound).  The same products in the same order per output: identical bits.
+// att here is CHANNEL-major ([N][C][hp * wp], f32_att_transpose_kernel below): the strips of a wave are consecutive k, so a tap's 64 reads are consecutive floats; with the
+// attention kernel's pixel-major rows they were 64 cache lines (160-byte stride) and the kernel sat at 0.76 TB/s.
+__global__ __launch_bounds__(256) void f32_fsa_combine_x4_kernel(const float* att, int hp, int wp, int C, const float* inp, float* out, int N, int H, int W, const float* gamma) {
+    const int ns = wp + 1;                                   // strips k = -1 .. wp - 1 of a row
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * C * H * ns) return;
+    const int k = (int)(t % ns) - 1, Y = (int)((t / ns) % H), c = (int)((t / ((long)ns * H)) % C);
+    const long n = t / ((long)ns * H * C);
+    const int X0 = 4 * k + 2;
+    const float A = -0.75f;
+    const float sy = (float)hp / (float)H, sx = (float)wp / (float)W;
+    const float ry = sy * ((float)Y + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry);
+    const float ty = ry - (float)iy;
+    const float wy[4] = {cub2(ty + 1.f, A), cub1(ty, A), cub1(1.f - ty, A), cub2(2.f - ty, A)};
+    float wx[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float rx = sx * ((float)(X0 + j) + 0.5f) - 0.5f;
+        const float tx = rx - (float)k;                      // floor(rx) == k for the strip's four pixels
+        wx[j][0] = cub2(tx + 1.f, A); wx[j][1] = cub1(tx, A); wx[j][2] = cub1(1.f - tx, A); wx[j][3] = cub2(2.f - tx, A);
+    }
+    const float* an = att + (n * C + c) * (long)hp * wp;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), hp - 1);
+        float q[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[b] = an[(long)yy * wp + min(max(k - 1 + b, 0), wp - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) row += q[b] * wx[j][b];
+            v[j] += row * wy[a];
+        }
+    }
+    const float gm = gamma[0];
+    const long o = ((n * C + c) * H + Y) * (long)W + X0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (X0 + j >= 0 && X0 + j < W) out[o + j] = gm * v[j] + inp[o + j];
+}
+
+// [N][Np][C] -> [N][C][Np] (the attention's rows, 5 MB at 540 x 960) through a 32 x 33 LDS tile
+__global__ __launch_bounds__(256) void f32_att_transpose_kernel(const float* att, float* att_t, int Np, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (p0 + r < Np && c0 + tx < C) tile[r][tx] = att[((long)n * Np + p0 + r) * C + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (c0 + r < C && p0 + tx < Np) att_t[((long)n * C + c0 + r) * Np + p0 + tx] = tile[tx][r];
+}
+
 // F.interpolate(scale_factor = f, mode = 'bilinear', align_corners = False) on NCHW fp32 planes (PAN ups_inter_mode 'bilinear', block.py:286-323)
 __global__ void f32_bilinear_up_kernel(const float* in, float* out, long planes, int h, int w, int f) {
     const int H2 = f * h, W2 = f * w;
@@ -858,8 +916,12 @@ int f32_maxpool4_launch(const float* in, float* out, long planes, int H, int W, 
     return INNFER_OK;
 }
 
-int f32_fsa_combine_launch(const float* att, int hp, int wp, int C, const float* inp, float* out, int N, int H, int W, const float* gamma, hipStream_t s) {
+int f32_fsa_combine_launch(const float* att, int hp, int wp, int C, const float* inp, float* out, int N, int H, int W, const float* gamma, hipStream_t s, float* att_t) {
     const long tot = (long)N * C * H * W;
+    if (W == 4 * wp && att_t && N <= 65535) {
+        hipLaunchKernelGGL(f32_att_transpose_kernel, dim3((hp * wp + 31) / 32, (C + 31) / 32, N), dim3(256), 0, s, att, att_t, hp * wp, C);
+        hipLaunchKernelGGL(f32_fsa_combine_x4_kernel, dim3((unsigned)(((long)N * C * H * (wp + 1) + 255) / 256)), dim3(256), 0, s, (const float*)att_t, hp, wp, C, inp, out, N, H, W, gamma);
+    } else
     hipLaunchKernelGGL(f32_fsa_combine_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, att, hp, wp, C, inp, out, N, H, W, gamma);
     INNFER_HIP(hipGetLastError());
     return INNFER_OK;

@@ -1108,7 +1108,7 @@ int pan_forward_f32(innfer_pan* p, const float* x, float* y, int N, int H, int W
             hipLaunchKernelGGL(pan_attention, dim3((Np + 63) / 64, N), dim3(256), 0, s, (const float*)FGH, vec("FSA.conv_f.bias"), vec("FSA.conv_g.bias"), vec("FSA.conv_h.bias"), Np, ATT);
         }
         INNFER_HIP(hipGetLastError());
-        { GtScope gt(s, "f32 fsa_combine (bicubic + gamma * out + in)", 0.0, (double)N * nf * hw * 8.0); CK(f32_fsa_combine_launch(ATT, hp, wp, nf, INP, T, N, H, W, vec("FSA.gamma"), s)); }
+        { GtScope gt(s, "f32 fsa_combine (bicubic + gamma * out + in)", 0.0, (double)N * nf * hw * 8.0); CK(f32_fsa_combine_launch(ATT, hp, wp, nf, INP, T, N, H, W, vec("FSA.gamma"), s, FGH)); }      // (FGH: dead behind the attention, 64 >= nf floats per pooled pixel)
         cur = T;
     }
     int h = H, w = W, cc = nf;
