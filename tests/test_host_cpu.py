@@ -490,3 +490,47 @@ def test_split_panels(K, Cc):
     virt = np.concatenate([wl, wh, wh], axis=1)                       # [K, 3C, 3, 3]: exactly representable, so the reference packer's cast is the identity
     assert np.array_equal(buf.view(np.float16), _pack_reference(virt, K, 3 * Cc).reshape(-1))
     assert np.abs(wh + wl / 2048.0 - w).max() <= 2.0 ** -22 * np.abs(w).max()
+
+
+def test_scpa_panel_layout_is_bank_conflict_free():
+    """csrc/pan_scpa_layout.h: the permuted tap blocks of the SCPA kernels' 20 -> 20 convs.  Re-derives the lane constants (kfrag_t0 / kfrag_t1) from the header's sigma tables and
+    checks what its comment claims: every real (row, octet) fragment has a slot of its own inside the 62-slot block, lanes of rows beyond the real ones read a real row of
+    their own ds_read_b128 lane group, lanes of k-octet 3 read the block's zero slots, and in each of the four lane groups ({0-3, 12-15, 20-27}, ...) the distinct addresses
+    of a read fall on distinct 16-byte slots mod 256 B -- for every tap (block base parity) -- so a fragment read is free of bank conflicts."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "innfer_amd", "csrc", "pan_scpa_layout.h")).read()
+    sig0 = [int(v) for v in re.search(r"SIG0\[12\] = \{([^}]*)\}", src).group(1).split(",")]
+    sig1 = [int(v) for v in re.search(r"SIG1\[8\] = \{([^}]*)\}", src).group(1).split(",")]
+    assert sorted(sig0) == list(range(12)) and sorted(sig1) == list(range(8))
+    K_T1, K_Z0, K_Z1, K_TAP = 36, 60, 61, 62                                  # slots (16 B)
+    assert all(f"{name} = {v} * 16" in src for name, v in (("K_T1", K_T1), ("K_Z0", K_Z0), ("K_Z1", K_Z1), ("K_TAP", K_TAP)))
+
+    def t0(li, lg):
+        r = li if li < 12 else li - 12
+        return 3 * sig0[r] + lg if lg < 3 else K_Z0
+
+    def t1(li, lg):
+        r = li if li < 8 else (li - 4 if li < 12 else li - 12)
+        return K_T1 + 3 * sig1[r] + lg if lg < 3 else K_Z1
+
+    # real fragments: one slot each, inside the block, clear of the zero slots
+    real = [t0(li, lg) for li in range(12) for lg in range(3)] + [t1(li, lg) for li in range(8) for lg in range(3)]
+    assert len(set(real)) == 60 and max(real) < K_Z0 and min(real) >= 0
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for f, nreal in ((t0, 12), (t1, 8)):
+        for g in groups:
+            addr = {}
+            for lane in g:
+                li, lg = lane & 15, lane >> 4
+                a = f(li, lg)
+                if lg < 3 and li >= nreal:                                      # a row beyond the real ones: the fragment of a real row whose lane sits in the same group
+                    src_lanes = [l for l in g if (l >> 4) == lg and (l & 15) < nreal and f(l & 15, lg) == a]
+                    assert src_lanes, (f.__name__, lane)
+                addr[lane] = a
+            for tap in range(9):                                                # the block's base moves by 62 slots per tap: every parity mod 16
+                slots = {}
+                for a in set(addr.values()):
+                    s = (tap * K_TAP + a) % 16
+                    assert s not in slots, (f.__name__, g, tap, a, slots[s])
+                    slots[s] = a
