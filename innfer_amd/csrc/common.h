@@ -165,7 +165,7 @@ size_t pan_scpa_blob_bytes();
 // torch layouts, fp32: conv1_a / conv1_b [20][40], k1 / k3 / k4 [20][20][3][3], k2 [20][20] + bias [20], conv3 [40][40] -> the kernel's weight blob (host)
 void pan_scpa_pack(const float* c1a, const float* c1b, const float* k1, const float* k2, const float* k2b, const float* k3, const float* k4, const float* c3, void* blob);
 // in / out: slabs of two 32-channel groups (40 real channels, pad channels zero), group stride G elements; x -> x + conv3(cat[..]) (PAN_arch.py:58-105)
-int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s, int in_c8 = 0, int out_c8 = 0);      // *_c8: channels 32..39 as a compact 16-byte plane (between two SCPA blocks)
+int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s, int in_c8 = 0, int out_c8 = 0, int duo = -1);      // duo: 1 two 4-wave workgroups per CU on 8 x 32 tiles, 0 one 8-wave workgroup on 16 x 32, < 0 by the frame      // *_c8: channels 32..39 as a compact 16-byte plane (between two SCPA blocks)
 
 // ---- the same block in the fp32-accurate mode on (hi, lo) fp16 operand pairs (pan_scpa_split.hip) ----
 // tensors as "split planes" of npx = N * H * W pixels: [hi ch 0..31: 64 B / pixel][hi 32..39: 16 B][lo 0..31: 64 B][lo 32..39: 16 B], 160 B per pixel in all

@@ -377,6 +377,237 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
     }
 }
 
+// ---- the same block with TWO workgroups per CU (round 6, VERDICT r5 item 3b: "two tiles in flight per workgroup, or 2 x 4-wave workgroups per CU") ----------------
+// What made room: x need not be staged in LDS (csrc/pan_scpa_split.hip showed it) -- conv1_a / conv1_b are 1x1, so a wave loads the B operand of its pixel tiles straight
+// from memory in fragment layout, the next tile's while this tile's P3 runs -- which leaves the weights (35 KB) and the A | B planes.  A workgroup of FOUR waves owns an
+// 8 x 32 tile (12 x 36 halo pixels: planes 41.5 KB): 77.6 KB of LDS, two workgroups per CU, each SIMD holding one wave of either.  The two run their barrier-separated
+// phases independently, so one's vector-heavy P1 / P2b overlaps the other's MFMA-heavy P2a / P3 instead of both waves of a SIMD doing the same thing at the same time.
+// Same arithmetic in the same order per value as pan_scpa_fused (k-steps, taps dx-major): bit-identical outputs.
+constexpr int D_TH = 8, D_NPX = (D_TH + 4) * HC, D_NP1 = D_NPX / 16, D_PL = D_NPX * 16;           // 12 x 36 halo pixels = 27 pixel tiles; an octet plane
+constexpr int D_YW = TW + 2, D_NY = (D_TH + 2) * D_YW, D_NMID = (D_NY + 15) / 16;                    // Y: the 10 x 34 region k4 reads = 22 pixel tiles
+constexpr int D_KT = (D_NP1 + 3) / 4;                                                               // P1 tile slots per wave (7)
+constexpr int D_W = (W_BYTES + 255) / 256 * 256, D_A = D_W, D_B = D_A + 3 * D_PL, D_LDS = D_B + 3 * D_PL + 1024;
+static_assert(D_PL % 256 == 0 && 2 * D_LDS <= 160 * 1024, "two workgroups per CU");
+
+__global__ __launch_bounds__(256, 2) void pan_scpa_duo(const ScpaKP p) {
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li_w = lane & 15, lg_w = lane >> 4;
+    const int bid = blockIdx.x, xcd = bid & 7;
+    const int run_q = p.total >> 3, run_r = p.total & 7;
+    const int run_start = xcd < run_r ? xcd * (run_q + 1) : run_r * (run_q + 1) + (xcd - run_r) * run_q;
+    const int run_len = run_q + (xcd < run_r ? 1 : 0);
+    const int slots = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int j0 = bid >> 3;
+    if (j0 >= run_len) return;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int gbytes = (int)(p.G * 2), c8s = p.in_c8 ? 16 : 64;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0x7fffffff, 0x00020000);
+
+    auto decode = [&](int j, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
+        int t = run_start + j;
+        n = t / per_img; t -= n * per_img;
+        const int ty = t / p.tiles_x;
+        ty0 = ty * D_TH; tx0 = (t - ty * p.tiles_x) * TW;
+    };
+    // the B operand of this wave's P1 pixel tiles (halo pixels 16 (wave + 4 k) + li of tile j): channels 0..31 (octet lg) and 32..39 (every lane group the same octet:
+    // only k-octet 0 of the second k-step meets non-zero weights); pixels outside the image read zero (the buffer's range check) = the zero padding of the block's convs
+    f16x8 x0[D_KT], x1[D_KT];
+    auto load_x = [&](int j) __attribute__((always_inline)) {
+        int n, ty0, tx0;
+        decode(j, n, ty0, tx0);
+        const int base = (n * p.H + ty0 - 2) * p.W + tx0 - 2;
+        const bool edge = ty0 < 2 || ty0 + D_TH + 2 > p.H || tx0 < 2 || tx0 + TW + 2 > p.W;
+        int li = li_w, lg = lg_w;
+        asm volatile("" : "+v"(li), "+v"(lg));
+#pragma unroll
+        for (int k = 0; k < D_KT; ++k) {
+            const int P = 16 * (wave + 4 * k) + li, r = P / HC, c = P - r * HC;
+            int o0 = (base + r * p.W + c) * 64 + lg * 16, o1 = gbytes + (base + r * p.W + c) * c8s;
+            if (edge) {
+                const int y = ty0 - 2 + r, x = tx0 - 2 + c;
+                if (y < 0 || y >= p.H || x < 0 || x >= p.W) o0 = o1 = OOB;
+            }
+            if (wave + 4 * k >= D_NP1) o0 = o1 = OOB;        // (an empty slot: the range check answers without a memory access)
+            x0[k] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, o0, 0, 0));
+            x1[k] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, o1, 0, 0));
+        }
+    };
+
+    load_x(j0);
+    for (int i = tid; i < W_BYTES / 16; i += 256) *(f16x8*)(smem + i * 16) = *(const f16x8*)(p.w + i * 16);
+    for (int i = tid; i < (D_LDS - D_A) / 16; i += 256) *(f16x8*)(smem + D_A + i * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};      // finite data wherever a padding k-octet may be read
+    __syncthreads();
+
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int row0 = 2 * wave;                               // this wave's two output rows (P2a / P3), both segments: pixel tile u = row * 2 + segment
+    const int lo_w = lg_w < 3 ? lg_w : 2, w0_w = kfrag_t0(li_w, lg_w), w1_w = kfrag_t1(li_w, lg_w);
+    const int pconv_w = lo_w * D_PL + ((row0 + 1) * HC + 1 + li_w) * 16;
+    for (int j = j0; j < run_len; j += slots) {
+        int n, ty0, tx0;
+        decode(j, n, ty0, tx0);
+        int li = li_w, lg = lg_w;
+        asm volatile("" : "+v"(li), "+v"(lg));
+        // ---------------- P1: A | B = lrelu(conv1_a | conv1_b (x)) over the halo tile ----------------
+        {
+            f16x8 wa[2][2], wb[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ba = OFF_C1A + (t ? C1_T1 : 0) + li * C1_ROW, bb = OFF_C1B + (t ? C1_T1 : 0) + li * C1_ROW;
+                wa[t][0] = lds16(smem, ba + lg * 16, li < r2(t)); wa[t][1] = lds16(smem, ba + 64, li < r2(t) && lg == 0);
+                wb[t][0] = lds16(smem, bb + lg * 16, li < r2(t)); wb[t][1] = lds16(smem, bb + 64, li < r2(t) && lg == 0);
+            }
+#pragma unroll
+            for (int k = 0; k < D_KT; ++k) {
+                if (wave + 4 * k >= D_NP1) continue;
+                const int P = 16 * (wave + 4 * k) + li;
+                f32x4 ca[2], cb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][0], x0[k], z4, 0, 0, 0);
+                    ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][1], x1[k], ca[t], 0, 0, 0);
+                    cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][0], x0[k], z4, 0, 0, 0);
+                    cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][1], x1[k], cb[t], 0, 0, 0);
+                }
+                if (lg < 3) {
+                    *(f16x8*)(smem + D_A + lg * D_PL + P * 16) = lrelu8(ca[0], ca[1]);
+                    *(f16x8*)(smem + D_B + lg * D_PL + P * 16) = lrelu8(cb[0], cb[1]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- P2a: a' = lrelu(k1(A)) on the wave's own pixels (registers) ----------------
+        f16x8 ap[4];
+        {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u][0] = acc[u][1] = z4;
+            conv33_rows<2>(smem, D_A + pconv_w, w0_w, w1_w, OFF_K1, acc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ap[u] = lrelu8(acc[u][0], acc[u][1]);
+        }
+        __syncthreads();                                            // every wave has read A: Y may take its place
+        // ---------------- P2b: Y = k3(B) * sigmoid(k2(B) + bias) on rows 1 .. TH + 2, zero outside the image ----------------
+        {
+            const f32x4 bk0 = *(const f32x4*)(smem + OFF_B2 + (8 * lg) * 4), bk1 = *(const f32x4*)(smem + OFF_B2 + (8 * lg + 4) * 4);
+            const bool edge_t = ty0 < 2 || ty0 + D_TH + 2 > p.H || tx0 < 2 || tx0 + TW + 2 > p.W;
+            auto halo_px = [&](int i) __attribute__((always_inline)) {
+                const int Q = min(16 * i + li, D_NY - 1), r = Q / D_YW;
+                return (r + 1) * HC + (Q - r * D_YW) + 1;
+            };
+            auto pass = [&](int i0) __attribute__((always_inline)) {               // three pixel tiles i0, i0 + 4, i0 + 8 of this wave, their fragment reads issued together
+                constexpr int NK = 3;
+                f32x4 c[NK][2], g[NK][2];
+                int Pk[NK];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) { c[k][0] = c[k][1] = z4; g[k][0] = bk0; g[k][1] = bk1; Pk[k] = halo_px(i0 + 4 * k < D_NMID ? i0 + 4 * k : i0); }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    f16x8 w[3][2], b[NK][3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) w[dy][t] = px16(smem, (t ? w1_w : w0_w) + OFF_K3 + (dy * 3 + dx) * K_TAP);
+#pragma unroll
+                    for (int k = 0; k < NK; ++k)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) b[k][dy] = px16(smem, D_B + lo_w * D_PL + (Pk[k] - HC - 1) * 16 + (dy * HC + dx) * 16);
+#pragma unroll
+                    for (int k = 0; k < NK; ++k)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+                                c[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[dy][t], b[k][dy], c[k][t], 0, 0, 0);
+                    if (dx == 1) {                                  // k2: the 1x1 conv of the gate reads the centre pixel's fragment
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const f16x8 w2 = px16(smem, (t ? w1_w : w0_w) + OFF_K2);
+#pragma unroll
+                            for (int k = 0; k < NK; ++k) g[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, b[k][1], g[k][t], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int i = i0 + 4 * k < D_NMID ? i0 + 4 * k : i0, P = Pk[k];
+                    f16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (f16)(c[k][0][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][0][e])));
+                        v[4 + e] = (f16)(c[k][1][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][1][e])));
+                    }
+                    if (edge_t) {          // (a tile on the frame's border only: Y is zero outside the image = k4's zero padding)
+                        const int r = P / HC, cc = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + cc;
+                        if (!(y >= 0 && y < p.H && x >= 0 && x < p.W)) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                    if (lg < 3 && 16 * i + li < D_NY) *(f16x8*)(smem + D_A + lg * D_PL + P * 16) = v;
+                }
+            };
+            static_assert(D_NMID <= 24, "two passes of three tile slots per wave cover the region");
+            pass(wave);
+            pass(wave + 12);
+        }
+        __syncthreads();
+        // ---------------- P3: b' = lrelu(k4(Y)); out = conv3(a' | b') + x ----------------
+        {
+            // the residual x of the wave's pixels in conv3's result layout (a lane: channels 16 lg .. 16 lg + 15 of pixel li), re-read from memory (L2)
+            f16x8 res[4][2];
+            long opix[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int y = ty0 + row0 + (u >> 1), x = tx0 + (u & 1) * 16 + li;
+                const bool ok = y < p.H && x < p.W;
+                const int pix = (n * p.H + y) * p.W + x;
+                opix[u] = ok ? pix : -1;
+                const int o0 = !ok || lg == 3 ? OOB : (lg < 2 ? pix * 64 + lg * 32 : gbytes + pix * c8s), o1 = ok && lg < 2 ? o0 + 16 : OOB;
+                res[u][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, o0, 0, 0));
+                res[u][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, o1, 0, 0));
+            }
+            load_x(j + slots < run_len ? j + slots : j);           // the next tile's x, in flight while this tile finishes (unconditional: a conditional load keeps the OLD x alive through P2)
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u][0] = acc[u][1] = z4;
+            conv33_rows<2>(smem, D_A + pconv_w, w0_w, w1_w, OFF_K4, acc);
+            f16x8 w3[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    w3[t][ks] = lds16(smem, OFF_C3 + c3_t(t) + (li * 6 + ks * 3 + lg) * 16, li < r4(t) && lg < 3);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f16x8 bp = lrelu8(acc[u][0], acc[u][1]);
+                f32x4 d[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[t][0], ap[u], z4, 0, 0, 0);
+                    d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[t][1], bp, d[t], 0, 0, 0);
+                }
+                if (opix[u] >= 0) {
+                    f16x8 o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o0[e] = (f16)(d[0][e] + (float)res[u][0][e]); o0[4 + e] = (f16)(d[1][e] + (float)res[u][0][4 + e]);
+                        o1[e] = (f16)(d[2][e] + (float)res[u][1][e]); o1[4 + e] = (f16)(d[3][e] + (float)res[u][1][4 + e]);
+                    }
+                    const long pix = opix[u];
+                    if (p.out_c8 && lg >= 2) {                       // channels 32..39 compact; 40..63 (zeros) not stored
+                        if (lg == 2) *(f16x8*)(p.out + p.G + pix * 8) = o0;
+                    } else {
+                        f16* o = p.out + (lg >> 1) * p.G + pix * 32 + (lg & 1) * 16;
+                        *(f16x8*)o = o0;
+                        *(f16x8*)(o + 8) = o1;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                            // Y is dead
+    }
+}
+
 }  // namespace
 
 size_t pan_scpa_blob_bytes() { return W_BYTES; }
@@ -438,7 +669,7 @@ static int scpa_num_cus() {
     return v;
 }
 
-int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s, int in_c8, int out_c8) {
+int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, int H, int W, hipStream_t s, int in_c8, int out_c8, int duo) {
     const int num_cus = scpa_num_cus();
     constexpr int TH = 16;
     constexpr int LDS = 160 * 1024;
@@ -466,6 +697,30 @@ int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, 
 #ifdef INNFER_ABLATE
     k.abl = getenv("INNFER_SCPA_ABL") ? atoi(getenv("INNFER_SCPA_ABL")) : 0;
 #endif
+    // duo < 0: the form by the frame -- two workgroups per CU where 16-row tiles would waste half of their last row of tiles or more (H mod 16 in 1 .. 8: the command line's
+    // 200 x 200 chop tiles are 12.5 tiles high) or leave CUs without a tile; one 8-wave workgroup otherwise (540 x 960: the two forms measure the same, docs/EXPERIMENTS.md 127)
+    if (duo < 0) duo = ((H % TH) >= 1 && (H % TH) <= TH / 2) || total < num_cus;
+    if (duo) {           // two 4-wave workgroups per CU on 8 x 32 tiles (pan_scpa_duo)
+        static std::atomic<unsigned long long> duo_done{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(duo_done.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)pan_scpa_duo, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS) != hipSuccess) {
+                (void)hipGetLastError();
+                return set_error(INNFER_ERR_UNSUPPORTED, "pan_scpa: the two-workgroup form needs 78 KB of LDS per workgroup");
+            }
+            duo_done.fetch_or(bit, std::memory_order_release);
+        }
+        k.tiles_y = (H + D_TH - 1) / D_TH;
+        const long tot8 = (long)N * k.tiles_x * k.tiles_y;
+        if (tot8 > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "pan_scpa: grid too large");
+        k.total = (int)tot8;
+        const int g2 = tot8 < 2L * num_cus ? (int)tot8 : 2 * num_cus;
+        hipLaunchKernelGGL(pan_scpa_duo, dim3(g2), dim3(256), D_LDS, s, k);
+        INNFER_HIP(hipGetLastError());
+        return INNFER_OK;
+    }
     const int grid = total < num_cus ? (int)total : num_cus;
     hipLaunchKernelGGL(pan_scpa_fused<TH>, dim3(grid), dim3(512), LDS, s, k);
     INNFER_HIP(hipGetLastError());

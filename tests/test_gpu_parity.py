@@ -1531,6 +1531,29 @@ def test_pan_fused_scpa_vs_five_launches_and_oracle(dev):
         assert e1.max().item() < bound and e1.mean().item() < 1.5e-3 and e0.max().item() < bound and d < 4e-3 and da < 2e-3, (shape, e1.max().item(), e0.max().item(), d, da)
 
 
+def test_pan_scpa_two_workgroup_form_is_bit_identical(dev):
+    """The SCPA block kernel's two forms (round 6): one 8-wave workgroup per CU on 16 x 32 tiles (pan_scpa_fused; innfer_pan_set_fused_scpa(pan, 7))
+    and two 4-wave workgroups per CU on 8 x 32 tiles with x loaded straight into MFMA fragments (pan_scpa_duo; 6) run the same MFMAs in the same order per value: the
+    whole network's outputs are bit-identical -- one-tile, tile-plus-one-pixel, border-only and multi-tile frames, batches, 200 x 200 chop tiles -- and so is the
+    default, which picks the form by the frame."""
+    from innfer_amd import synth
+    from innfer_amd.architectures import get_network
+    from innfer_amd.utils.defaults import get_network_G_config
+    net = get_network(get_network_G_config("pan", 4))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 3).items()}, strict=True)
+    net = net.to(dev).eval()
+    try:
+        for shape in [(1, 3, 8, 32), (1, 3, 9, 33), (2, 3, 37, 45), (1, 3, 6, 40), (3, 3, 16, 64), (1, 3, 70, 130), (2, 3, 200, 200), (1, 3, 136, 260)]:
+            x = torch.from_numpy(synth.uniform(shape, 90 + shape[3], 0, 1)).to(dev).half()
+            y = {}
+            for mode in (7, 6, 1):
+                net.fused_scpa = mode
+                y[mode] = net(x)
+            assert torch.equal(y[7], y[6]) and torch.equal(y[7], y[1]), shape
+    finally:
+        net.fused_scpa = 1
+
+
 def test_pan_bench_shapes_untiled_vs_oracle(dev):
     """the shapes the bench runs PAN on, un-tiled, against the oracle -- 264 x 392 (6 468 pooled keys, ragged in both tile
     directions) and the `pan540` workload itself, 540 x 960 = 32 400 pooled keys = 507 key blocks through the running-max softmax of
