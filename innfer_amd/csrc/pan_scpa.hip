@@ -39,12 +39,37 @@ struct ScpaKP {
 // (LeakyReLU as v_med3_f32(x, 0.2 x, +inf) == x > 0 ? x : 0.2 x for every finite x: two instructions per value instead of multiply + compare + select -- round 6: the block is
 //  bound by vector issue, 5.5 VALU instructions per MFMA by the counters, profiles/r6/pmc_pan.txt)
 __device__ __forceinline__ f16x8 lrelu8(const f32x4& a, const f32x4& b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     f16x8 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        v[j] = (f16)__builtin_amdgcn_fmed3f(a[j], 0.2f * a[j], __builtin_inff());
-        v[4 + j] = (f16)__builtin_amdgcn_fmed3f(b[j], 0.2f * b[j], __builtin_inff());
-    }
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4& x = h ? b : a;
+            const f2 s = f2{x[2 * q], x[2 * q + 1]} * f2{0.2f, 0.2f};               // (two values per v_pk_mul_f32)
+            v[4 * h + 2 * q] = (f16)__builtin_amdgcn_fmed3f(x[2 * q], s[0], __builtin_inff());
+            v[4 * h + 2 * q + 1] = (f16)__builtin_amdgcn_fmed3f(x[2 * q + 1], s[1], __builtin_inff());
+        }
+    return v;
+}
+
+// The PA gate of a lane's eight channels: c * sigmoid(g) = c / (1 + 2^(-g log2 e)) on the hardware exponential and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each: the libm forms
+// are ~50 VALU instructions per value, 21 k values per tile -- a third of the first version's tile time), the multiplications and the addition as PACKED fp32 operations (two values
+// per v_pk_mul_f32 / v_pk_add_f32: the block is bound by its vector instructions); the result is rounded to fp16.  Same operations per value as the scalar form: same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x8 gate8(const f32x4& c0, const f32x4& c1, const f32x4& g0, const f32x4& g1) {
+    f16x8 v;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4& c = h ? c1 : c0;
+            const f32x4& g = h ? g1 : g0;
+            const f32x2 x = f32x2{g[2 * q], g[2 * q + 1]} * f32x2{-1.44269504088896340736f, -1.44269504088896340736f};
+            const f32x2 d = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} + f32x2{1.0f, 1.0f};
+            const f32x2 r = f32x2{c[2 * q], c[2 * q + 1]} * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            v[4 * h + 2 * q] = (f16)r[0]; v[4 * h + 2 * q + 1] = (f16)r[1];
+        }
     return v;
 }
 
@@ -301,14 +326,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
                     const int i = i0 + 8 * k < NMID ? i0 + 8 * k : i0, P = Pk[k];
-                    f16x8 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // sigmoid on the hardware exponential and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each): the libm forms are ~50 VALU instructions per
-                        // value, 21 k values per tile -- a third of the first version's tile time; the result is rounded to fp16 two lines below
-                        v[e] = (f16)(c[k][0][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][0][e])));
-                        v[4 + e] = (f16)(c[k][1][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][1][e])));
-                    }
+                    f16x8 v = gate8(c[k][0], c[k][1], g[k][0], g[k][1]);
                     if (edge_t) {          // (a tile on the frame's border only -- wave-uniform: Y is zero outside the image = k4's zero padding; interior tiles pay no compare / select per value)
                         const int r = P / HC, cc = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + cc;
                         if (!(y >= 0 && y < p.H && x >= 0 && x < p.W)) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -533,12 +551,7 @@ __global__ __launch_bounds__(256, 2) void pan_scpa_duo(const ScpaKP p) {
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
                     const int i = i0 + 4 * k < D_NMID ? i0 + 4 * k : i0, P = Pk[k];
-                    f16x8 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (f16)(c[k][0][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][0][e])));
-                        v[4 + e] = (f16)(c[k][1][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[k][1][e])));
-                    }
+                    f16x8 v = gate8(c[k][0], c[k][1], g[k][0], g[k][1]);
                     if (edge_t) {          // (a tile on the frame's border only: Y is zero outside the image = k4's zero padding)
                         const int r = P / HC, cc = P - r * HC, y = ty0 - 2 + r, x = tx0 - 2 + cc;
                         if (!(y >= 0 && y < p.H && x >= 0 && x < p.W)) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
