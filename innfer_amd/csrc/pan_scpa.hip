@@ -34,7 +34,23 @@ struct ScpaKP {
     int in_c8, out_c8;                      // != 0: channels 32..39 of the input / output slab travel COMPACT -- 16 bytes per pixel at (G elements + pixel * 8) instead of the first 16 bytes
                                             // of a 64-byte group-1 pixel (whose other 48 bytes are zeros no SCPA block reads): between two SCPA blocks of the trunk (round 5)
     int abl;                                // diagnostic build only (make ablate, INNFER_SCPA_ABL): skip 1 P1, 2 P2a, 4 P2b, 8 P3's MFMAs, 16 the X fetch, 32 the stores
+#ifdef INNFER_STAMPS
+    unsigned long long* stamps;             // diagnostic build only (scripts/r6/scpa_micro.cpp): per workgroup, wave 0's shader-clock cycles in P1 / P2a / P2b / P3 (barriers included), its tile count, and the shader-clock / 100-MHz cycles of its tile loop (their quotient x 100 MHz = the clock the chip held)
+#endif
 };
+// in-kernel phase stamps of the diagnostic build (s_memtime = shader-clock cycles); nothing in the shipped library
+#ifdef INNFER_STAMPS
+unsigned long long* g_scpa_stamps = nullptr;
+#define ST_DECL unsigned long long st_t = 0, st_acc[5] = {0, 0, 0, 0, 0}; const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#define ST_BEGIN st_t = __builtin_amdgcn_s_memtime(); st_acc[4] += 1;
+#define ST_MARK(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; }
+#define ST_END if (p.stamps && threadIdx.x == 0) { for (int i_ = 0; i_ < 5; ++i_) p.stamps[blockIdx.x * 7 + i_] = st_acc[i_]; p.stamps[blockIdx.x * 7 + 5] = __builtin_amdgcn_s_memtime() - st_c0; p.stamps[blockIdx.x * 7 + 6] = __builtin_amdgcn_s_memrealtime() - st_r0; }
+#else
+#define ST_DECL
+#define ST_BEGIN
+#define ST_MARK(i)
+#define ST_END
+#endif
 
 // (LeakyReLU as v_med3_f32(x, 0.2 x, +inf) == x > 0 ? x : 0.2 x for every finite x: two instructions per value instead of multiply + compare + select -- round 6: the block is
 //  bound by vector issue, 5.5 VALU instructions per MFMA by the counters, profiles/r6/pmc_pan.txt)
@@ -71,6 +87,18 @@ __device__ __forceinline__ f16x8 gate8(const f32x4& c0, const f32x4& c1, const f
             v[4 * h + 2 * q] = (f16)r[0]; v[4 * h + 2 * q + 1] = (f16)r[1];
         }
     return v;
+}
+
+// The block's weights global -> LDS by LDS-DMA: every wave issues its 1-KB pieces back to back (one round trip for the whole blob instead of a load -> store loop's several;
+// the blob is L2-resident after the first workgroups) -- the caller waits (s_waitcnt vmcnt(0)) and meets the barrier.
+template <int NWAVES>
+__device__ __forceinline__ void weights_to_lds(char* smem, const char* w, int bytes, int wave, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, bytes, 0x00020000);
+    for (int q = wave; q * 1024 < bytes; q += NWAVES)
+        if (q * 1024 + lane * 16 < bytes)                    // (the last piece: only the lanes inside the blob -- what follows it in LDS belongs to somebody else)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem + q * 1024), 16, q * 1024 + lane * 16, 0, 0, 0);
+#endif
 }
 
 // Every LDS operand read is UNCONDITIONAL: a lane whose fragment is structurally zero (k-octet 3 of a 20-channel operand, a panel row beyond the real
@@ -193,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
     };
 
     fetch(j0);
-    for (int i = tid; i < W_BYTES / 16; i += 512) *(f16x8*)(smem + i * 16) = *(const f16x8*)(p.w + i * 16);
+    weights_to_lds<8>(smem, p.w, W_BYTES, wave, lane);
     // (finite data wherever a padding k-octet may be read: the 1 KB behind B -- px16 -- and, for the first tile's P1, the head of A behind the X tile's own zero-filled slack)
     if (tid < 64) *(f16x8*)(smem + BOFF + 3 * PL + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (tid < 4) *(f16x8*)(smem + AOFF + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -205,7 +233,9 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
     // lane constants of the fragment reads (pan_scpa_layout.h): the octet plane a lane reads (k-octet 3: octet 2 again), its offsets inside a tap block, its pixel base
     const int lo_w = lg_w < 3 ? lg_w : 2, w0_w = kfrag_t0(li_w, lg_w), w1_w = kfrag_t1(li_w, lg_w);
     const int pconv_w = lo_w * PL + ((row0 + 1) * HC + 1 + li_w) * 16;
+    ST_DECL
     for (int j = j0; j < run_len; j += slots) {
+        ST_BEGIN
         int n, ty0, tx0;
         decode(j, n, ty0, tx0);
         // (opaque copies of the lane coordinates, renewed per tile: every LDS address below is then recomputed where it is used -- an add on a shared
@@ -251,6 +281,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
             }
         }
         __syncthreads();
+        ST_MARK(0)
         // ---------------- P2a: a' = lrelu(k1(A)) on the tile's own pixels (registers) ----------------
         f16x8 ap[PW], res[PW][2];
         {
@@ -272,6 +303,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
             }
         }
         __syncthreads();                                            // every wave has read A (Y may take its place) and X (the next tile's may)
+        ST_MARK(1)
 #ifdef INNFER_ABLATE
         if (!(p.abl & 16))
 #endif
@@ -341,6 +373,7 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
             if constexpr (NK1 > 0) pass(std::integral_constant<int, NK1>{}, wave + 8 * TB);
         }
         __syncthreads();
+        ST_MARK(2)
         // ---------------- P3: b' = lrelu(k4(Y)); out = conv3(a' | b') + x ----------------
         {
             f32x4 acc[PW][2];
@@ -392,7 +425,9 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_fused(const ScpaKP p) {
             }
         }
         __syncthreads();                                            // Y is dead, the next X is in LDS (every wave waited for its own pieces above)
+        ST_MARK(3)
     }
+    ST_END
 }
 
 // ---- the same block with TWO workgroups per CU (round 6, VERDICT r5 item 3b: "two tiles in flight per workgroup, or 2 x 4-wave workgroups per CU") ----------------
@@ -454,15 +489,20 @@ __global__ __launch_bounds__(256, 2) void pan_scpa_duo(const ScpaKP p) {
     };
 
     load_x(j0);
-    for (int i = tid; i < W_BYTES / 16; i += 256) *(f16x8*)(smem + i * 16) = *(const f16x8*)(p.w + i * 16);
-    for (int i = tid; i < (D_LDS - D_A) / 16; i += 256) *(f16x8*)(smem + D_A + i * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};      // finite data wherever a padding k-octet may be read
+    weights_to_lds<4>(smem, p.w, W_BYTES, wave, lane);
+    // (finite data wherever a fragment read may land: P1 writes every pixel of all six planes before the first read, so only the 1 KB behind them -- where the reads of the
+    //  last pixels' right-hand taps end -- needs initialising)
+    if (tid < 64) *(f16x8*)(smem + D_B + 3 * D_PL + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int row0 = 2 * wave;                               // this wave's two output rows (P2a / P3), both segments: pixel tile u = row * 2 + segment
     const int lo_w = lg_w < 3 ? lg_w : 2, w0_w = kfrag_t0(li_w, lg_w), w1_w = kfrag_t1(li_w, lg_w);
     const int pconv_w = lo_w * D_PL + ((row0 + 1) * HC + 1 + li_w) * 16;
+    ST_DECL
     for (int j = j0; j < run_len; j += slots) {
+        ST_BEGIN
         int n, ty0, tx0;
         decode(j, n, ty0, tx0);
         int li = li_w, lg = lg_w;
@@ -495,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void pan_scpa_duo(const ScpaKP p) {
             }
         }
         __syncthreads();
+        ST_MARK(0)
         // ---------------- P2a: a' = lrelu(k1(A)) on the wave's own pixels (registers) ----------------
         f16x8 ap[4];
         {
@@ -506,6 +547,7 @@ __global__ __launch_bounds__(256, 2) void pan_scpa_duo(const ScpaKP p) {
             for (int u = 0; u < 4; ++u) ap[u] = lrelu8(acc[u][0], acc[u][1]);
         }
         __syncthreads();                                            // every wave has read A: Y may take its place
+        ST_MARK(1)
         // ---------------- P2b: Y = k3(B) * sigmoid(k2(B) + bias) on rows 1 .. TH + 2, zero outside the image ----------------
         {
             const f32x4 bk0 = *(const f32x4*)(smem + OFF_B2 + (8 * lg) * 4), bk1 = *(const f32x4*)(smem + OFF_B2 + (8 * lg + 4) * 4);
@@ -564,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void pan_scpa_duo(const ScpaKP p) {
             pass(wave + 12);
         }
         __syncthreads();
+        ST_MARK(2)
         // ---------------- P3: b' = lrelu(k4(Y)); out = conv3(a' | b') + x ----------------
         {
             // the residual x of the wave's pixels in conv3's result layout (a lane: channels 16 lg .. 16 lg + 15 of pixel li), re-read from memory (L2)
@@ -618,7 +661,9 @@ __global__ __launch_bounds__(256, 2) void pan_scpa_duo(const ScpaKP p) {
             }
         }
         __syncthreads();                                            // Y is dead
+        ST_MARK(3)
     }
+    ST_END
 }
 
 }  // namespace
@@ -703,6 +748,9 @@ int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, 
     ScpaKP k{};
     k.in = in; k.out = out; k.G = G; k.w = (const char*)d_blob; k.N = N; k.H = H; k.W = W;
     k.in_c8 = in_c8; k.out_c8 = out_c8;
+#ifdef INNFER_STAMPS
+    k.stamps = g_scpa_stamps;
+#endif
     k.tiles_x = (W + TW - 1) / TW; k.tiles_y = (H + TH - 1) / TH;
     const long total = (long)N * k.tiles_x * k.tiles_y;
     if (total > 0x7fffffffL) return set_error(INNFER_ERR_INVALID, "pan_scpa: grid too large");

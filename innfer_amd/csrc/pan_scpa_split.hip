@@ -173,9 +173,18 @@ __global__ __launch_bounds__(512, 1) void pan_scpa_split(const SplitKP p) {
     };
 
     load_x(j0);
-    for (int i = tid; i < 2 * WLO / 16; i += 512) *(f16x8*)(smem + i * 16) = *(const f16x8*)(p.w + i * 16);
-    // (finite data wherever a padding k-octet may be read: the planes start as zeros, and so does the 1 KB behind them)
-    for (int i = tid; i < (LDS_BYTES - AH) / 16; i += 512) *(f16x8*)(smem + AH + i * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+    {   // the two blobs global -> LDS by LDS-DMA: every wave issues its 1-KB pieces back to back (one round trip instead of a load -> store loop's several)
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 2 * WLO, 0x00020000);
+        for (int q = wave; q * 1024 < 2 * WLO; q += 8)
+            if (q * 1024 + lane * 16 < 2 * WLO)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem + q * 1024), 16, q * 1024 + lane * 16, 0, 0, 0);
+    }
+#endif
+    // (finite data wherever a fragment read may land: P1 writes every pixel of all twelve planes before the first read, so only the 1 KB behind them -- where the reads of
+    //  the last pixels' right-hand taps end -- needs initialising)
+    if (tid < 64) *(f16x8*)(smem + TAIL + tid * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
