@@ -245,8 +245,7 @@ size_t innfer_pan_workspace_bytes(innfer_pan_t p, int N, int H, int W);
  * (hi, lo) fp16 operand pairs of the matrix cores, on = 0 every conv on the generic fp32 kernel and the attention on the VALU kernel (the form of 108 - 112);
  * on = 5 keeps the PA block of an up-stage as its own 1x1 launch instead of the up-conv's epilogue (A/B).
  * fp16 (113): the block kernel has two forms with the same bits -- one 8-wave workgroup per CU on 16 x 32 tiles, two 4-wave workgroups per CU on 8 x 32 tiles (x loaded straight into
- * MFMA fragments) -- chosen by the frame (the second where 16-row tiles would leave their last tile row at most half used, e.g. 200 x 200 chop tiles, or CUs without a tile);
- * on = 6 / 7 force the second / the first (A/B). */
+ * MFMA fragments; the default) -- on = 6 / 7 force the second / the first (A/B). */
 int innfer_pan_set_fused_scpa(innfer_pan_t p, int on);
 /* The reference's fp16 switch for this generator (run.py:345,421-422), as innfer_unet_set_precision: fp32 = 1 runs PAN.forward with fp32-accurate arithmetic
  * -- <= 1e-4 of the fp32 reference; fp32 tensors in and out; a load-time call.  (108: every conv on the generic fp32 kernel of csrc/f32ops.hip, the FSA

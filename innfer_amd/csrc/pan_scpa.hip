@@ -52,8 +52,10 @@ unsigned long long* g_scpa_stamps = nullptr;
 #define ST_END
 #endif
 
-// (LeakyReLU as v_med3_f32(x, 0.2 x, +inf) == x > 0 ? x : 0.2 x for every finite x: two instructions per value instead of multiply + compare + select -- round 6: the block is
-//  bound by vector issue, 5.5 VALU instructions per MFMA by the counters, profiles/r6/pmc_pan.txt)
+// (LeakyReLU as v_med3_f32(x, 0.2 x, top) == x > 0 ? x : 0.2 x for every |x| <= top: a packed multiply and ONE instruction per value instead of multiply + compare + select -- round 6:
+//  the block is bound by vector issue, 5.5 VALU instructions per MFMA by the counters, profiles/r6/pmc_pan.txt.  `top` is a finite constant on purpose: with +inf LLVM rewrites the median
+//  as max(x, 0.2 x) and, in IEEE mode, puts a canonicalising v_max x, x in front of it -- two instructions per value, 224 of the tile's 1467)
+constexpr float LRELU_TOP = 3.0e38f;
 __device__ __forceinline__ f16x8 lrelu8(const f32x4& a, const f32x4& b) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     f16x8 v;
@@ -63,8 +65,8 @@ __device__ __forceinline__ f16x8 lrelu8(const f32x4& a, const f32x4& b) {
         for (int q = 0; q < 2; ++q) {
             const f32x4& x = h ? b : a;
             const f2 s = f2{x[2 * q], x[2 * q + 1]} * f2{0.2f, 0.2f};               // (two values per v_pk_mul_f32)
-            v[4 * h + 2 * q] = (f16)__builtin_amdgcn_fmed3f(x[2 * q], s[0], __builtin_inff());
-            v[4 * h + 2 * q + 1] = (f16)__builtin_amdgcn_fmed3f(x[2 * q + 1], s[1], __builtin_inff());
+            v[4 * h + 2 * q] = (f16)__builtin_amdgcn_fmed3f(x[2 * q], s[0], LRELU_TOP);
+            v[4 * h + 2 * q + 1] = (f16)__builtin_amdgcn_fmed3f(x[2 * q + 1], s[1], LRELU_TOP);
         }
     return v;
 }
@@ -758,9 +760,9 @@ int pan_scpa_launch(const f16* in, f16* out, long G, const void* d_blob, int N, 
 #ifdef INNFER_ABLATE
     k.abl = getenv("INNFER_SCPA_ABL") ? atoi(getenv("INNFER_SCPA_ABL")) : 0;
 #endif
-    // duo < 0: the form by the frame -- two workgroups per CU where 16-row tiles would waste half of their last row of tiles or more (H mod 16 in 1 .. 8: the command line's
-    // 200 x 200 chop tiles are 12.5 tiles high) or leave CUs without a tile; one 8-wave workgroup otherwise (540 x 960: the two forms measure the same, docs/EXPERIMENTS.md 127)
-    if (duo < 0) duo = ((H % TH) >= 1 && (H % TH) <= TH / 2) || total < num_cus;
+    // duo < 0: the default form -- two workgroups per CU.  It wins most where 16-row tiles would waste half of their last row of tiles or more (the command line's 200 x 200 chop
+    // tiles are 12.5 tiles high: -10 % per launch) or leave CUs without a tile, and since its vector work shrank (docs/EXPERIMENTS.md 127-131) also at 540 x 960 (-3.6 %)
+    if (duo < 0) duo = 1;
     if (duo) {           // two 4-wave workgroups per CU on 8 x 32 tiles (pan_scpa_duo)
         static std::atomic<unsigned long long> duo_done{0};
         int dev = 0;

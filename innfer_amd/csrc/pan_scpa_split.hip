@@ -68,7 +68,7 @@ __device__ __forceinline__ void join_split8(const f32x4 (&m)[2], const f32x4 (&x
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float f = __builtin_fmaf(x[t][j], DOWN, m[t][j]);
-            if (ACT) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, __builtin_inff());
+            if (ACT) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, 3.0e38f);       // (LeakyReLU; a finite top: with +inf LLVM emits max(x, 0.2 x) behind a canonicalising v_max x, x)
             const f16 hh = (f16)f;
             h[4 * t + j] = hh;
             l[4 * t + j] = (f16)__builtin_fmaf((float)hh, -UP, f * UP);          // = (f - hh) * 2^11 exactly: one v_fma_mixlo_f16 behind the multiply
