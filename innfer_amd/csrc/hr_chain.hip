@@ -273,11 +273,12 @@ __global__ __launch_bounds__(512, 1) void hr_chain_kernel(const ChainP p) {
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx) {
                         float f = acc[g & 1][t][jx];
-                        // (LeakyReLU as max(f, 0.2 f) == f > 0 ? f : 0.2 f for every finite f.  As v_med3_f32(f, 0.2 f, +inf): the builtin max is the IEEE maxnum, which
-                        //  canonicalises its operand first -- three instructions per value like compare + select, and this stage is bound by vector issue; an inline-asm
-                        //  v_max_f32 is invisible to the hazard recogniser -- as the first reader of an MFMA result it read stale registers)
-                        if (ACT_UP == 1) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, __builtin_inff());
-                        else if (ACT_UP == 2) f = __builtin_amdgcn_fmed3f(f, 0.f, __builtin_inff());
+                        // (LeakyReLU as max(f, 0.2 f) == f > 0 ? f : 0.2 f for every finite f.  As v_med3_f32(f, 0.2 f, top) with a FINITE top: the builtin max is the IEEE
+                        //  maxnum, which canonicalises its operand first -- three instructions per value like compare + select, and this stage is bound by vector issue --
+                        //  and so is what LLVM makes of a median whose third operand is +inf (the form this kernel shipped with until the end of round 6: 576 v_max for 288
+                        //  values); an inline-asm v_max_f32 is invisible to the hazard recogniser -- as the first reader of an MFMA result it read stale registers)
+                        if (ACT_UP == 1) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, 3.0e38f);
+                        else if (ACT_UP == 2) f = __builtin_amdgcn_fmed3f(f, 0.f, 3.0e38f);
                         FP32_VALUE(f);
                         h[4 * t + jx] = (f16)f;
                     }
