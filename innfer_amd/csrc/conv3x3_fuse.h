@@ -58,8 +58,8 @@ __device__ __forceinline__ void fused_last_products(const KP& p, f32x4 (&acc)[NT
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float f = acc[2 * ks + (e >> 2)][m][e & 3];
-                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    if (ACT == 1) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, 3.0e38f);      // (max(f, 0.2 f) as ONE instruction: a finite top keeps LLVM from rewriting it as maxnum + canonicalise)
+                    else if (ACT == 2) f = __builtin_amdgcn_fmed3f(f, 0.f, 3.0e38f);
                     FP32_VALUE(f);
                     hb[m][ks][e] = (f16)f;
                 }
