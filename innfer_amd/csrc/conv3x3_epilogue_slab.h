@@ -7,6 +7,10 @@
 // channel 32 (t >> 1) + 8 lg + 4 (t & 1) + j instead of 16 lg + 4 t + j: a lane's sixteen channels are 16 bytes in EACH of the group's two 32-channel slab planes, lanes
 // lg = 0..3 cover a pixel's whole 64 bytes of one plane, and a store / residual-load instruction touches ONE plane -- half the lines per instruction (measured as an
 // ablation first: frame -1.4 %, profiles/r4/upconv_bound.txt).  Panels from conv_pack*(.., rowp = 1).
+// LeakyReLU / ReLU as v_med3_f32(f, 0.2 f | 0, top): == f > 0 ? f : 0.2 f | 0 for every |f| <= top, one instruction behind the multiply instead of compare + select.  The top is a FINITE
+// constant on purpose: with +inf LLVM rewrites the median as maxnum and, in IEEE mode, puts a canonicalising v_max x, x in front of it (round 6, docs/EXPERIMENTS.md 131).
+constexpr float ACT_TOP = 3.0e38f;
+
 template <int NT, bool ROWP>
 __device__ __forceinline__ long toff_slab(int t, long g) { return (NT == 4 && ROWP) ? (long)(t >> 1) * g + 4 * (t & 1) : 4 * t; }
 template <int NT, bool ROWP>
@@ -75,8 +79,8 @@ __device__ __forceinline__ void epilogue_slab_cv(const KP& p, f32x4 (&acc)[NT][2
             for (int j = 0; j < 4; ++j) {
                 float f = acc[t][m][j];
                 if (ACT == 7) f = f * fast_sigmoid(acc[t + NT / 2][m][j]);
-                else if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                else if (ACT == 1) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, ACT_TOP);       // (max(f, 0.2 f) as ONE instruction; see ACT_TOP)
+                else if (ACT == 2) f = __builtin_amdgcn_fmed3f(f, 0.f, ACT_TOP);
                 if (SC1) { f = f * p.s1; FP32_VALUE(f); }
                 if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
                 if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
@@ -193,8 +197,8 @@ __device__ __forceinline__ void epilogue_slab(const KP& p, f32x4 (&acc)[NT][2 * 
                     f = (float)r1[R1 ? m : 0][t][j] * (fast_sigmoid(f));
                     if (ACT == 4) f = fmaxf(f, 0.2f * f);
                 } else {
-                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    if (ACT == 1) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, ACT_TOP);
+                    else if (ACT == 2) f = __builtin_amdgcn_fmed3f(f, 0.f, ACT_TOP);
                     if (SC1) { f = f * p.s1; FP32_VALUE(f); }          // RLDS: res1 is inside the accumulator as x / s1
                     if (R1) f = __builtin_fmaf(f, p.s1, (float)r1[R1 ? m : 0][t][j]);
                     if (R2) f = __builtin_fmaf(f, p.s2, (float)r2[R2 ? m : 0][t][j]);
@@ -258,8 +262,8 @@ __device__ __forceinline__ void epilogue_slab_split(const KP& p, f32x4 (&acc)[NT
                     f = __builtin_fmaf((float)r1l[t][j], SPLIT_DOWN, (float)r1h[t][j]) * fast_sigmoid(f);
                     if (ACT == 4) f = fmaxf(f, 0.2f * f);
                 } else {
-                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    if (ACT == 1) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, ACT_TOP);
+                    else if (ACT == 2) f = __builtin_amdgcn_fmed3f(f, 0.f, ACT_TOP);
                     if (R1) f = __builtin_fmaf(f, p.s1, __builtin_fmaf((float)r1l[t][j], SPLIT_DOWN, (float)r1h[t][j]));
                     if (R2) f = __builtin_fmaf(f, p.s2, __builtin_fmaf((float)r2l[t][j], SPLIT_DOWN, (float)r2h[t][j]));
                 }

@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FP p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float f = acc[t][j];
-                    if (ACT == 1) f = f > 0.f ? f : 0.2f * f;
-                    else if (ACT == 2) f = f > 0.f ? f : 0.f;
+                    if (ACT == 1) f = __builtin_amdgcn_fmed3f(f, 0.2f * f, 3.0e38f);      // (one instruction behind the multiply; a finite top: conv3x3_epilogue_slab.h ACT_TOP)
+                    else if (ACT == 2) f = __builtin_amdgcn_fmed3f(f, 0.f, 3.0e38f);
                     h[4 * t + j] = (f16)f;
                     l[4 * t + j] = (f16)((f - (float)h[4 * t + j]) * 2048.0f);
                 }
