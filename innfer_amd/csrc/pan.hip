@@ -693,7 +693,7 @@ struct innfer_pan {
     int scpa_c8 = 1;                 // compact channel plane between the fused SCPA blocks (pan_scpa_launch in_c8 / out_c8); 0: A/B (fused_scpa 3)
     int mfma_attention = 1;          // the FSA block's attention on the matrix cores (pan_attention_mfma); 0: the VALU kernel of rounds 1-3 (set with fused_scpa: one A/B switch)
     int fused_last = 1;              // the last stage's HRconv with conv_last in its epilogue (conv3x3_pc FUSE on 32 channels, round 5); 0: two launches (fused_scpa 4)
-    int scpa_duo = -1;               // fp16: an SCPA block on two 4-wave workgroups per CU, 8 x 32 tiles (pan_scpa_duo; innfer_pan_set_fused_scpa(pan, 6)); 0: one 8-wave workgroup, 16 x 32 (7); -1: the default form (the first)
+    int scpa_duo = -1;               // fp16: an SCPA block on two 4-wave workgroups per CU, 8 x 32 tiles (pan_scpa_duo; innfer_pan_set_fused_scpa(pan, 6)); 0: one 8-wave workgroup, 16 x 32 (7); -1: the default = the two-workgroup form
     bool pa_two_launches = false;    // fp32 mode A/B (innfer_pan_set_fused_scpa(pan, 5)): the PA block as its own split 1x1 launch instead of the up-conv's epilogue
     int fused_scpa = 1;              // an SCPA block as ONE launch (innfer_pan_set_fused_scpa); 0: the five halo-tile launches of rounds 1-3
     bool uploaded = false;
@@ -767,7 +767,7 @@ extern "C" int innfer_pan_set_fused_scpa(innfer_pan* p, int on) {
     p->scpa_c8 = on == 3 ? 0 : 1;                 // (3: the fused blocks on two-group slabs throughout -- A/B of the compact channel plane alone, same bits)
     p->fused_last = on == 4 ? 0 : 1;              // (4: HRconv and conv_last of the last stage as two launches -- A/B of the fused tail alone)
     if (!on) p->mfma_attention = 0;
-    p->scpa_duo = on == 6 ? 1 : (on == 7 ? 0 : -1);      // (6 / 7: A/B of the block kernel's two forms -- two 4-wave workgroups per CU / one 8-wave workgroup; default: the first)
+    p->scpa_duo = on == 6 ? 1 : (on == 7 ? 0 : -1);      // (6 / 7: A/B of the block kernel's two forms -- two 4-wave workgroups per CU / one 8-wave workgroup; default: the two-workgroup form)
     p->pa_two_launches = on == 5;                 // (5, fp32 mode: the PA block of the HR side as its own launch -- A/B of the split self gate alone)
     return INNFER_OK;
 }
